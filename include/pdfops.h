@@ -1,0 +1,112 @@
+/*
+ * pdfops.h -- C ABI of libpdfops.so, the MI355X (gfx950) replacement for the reference's
+ * libs/pointops CUDA extension (`pointops._C`).
+ *
+ * Each entry point replaces one `extern "C"` launcher of the reference (file:line cited per
+ * function, paths relative to the reference root).  Signatures keep the reference's parameter
+ * lists and add
+ *   - `b`      : the scene count, where the reference inferred it by scanning `offset`,
+ *   - `stream` : a hipStream_t passed as void* (the reference launched on the legacy stream),
+ * and return an int status: 0 = ok, PDF_ERR_* (<0) = argument error, >0 = hipError_t.
+ *
+ * Contract (same as the reference unless noted):
+ *   - all pointers are DEVICE pointers owned by the caller; the library never allocates,
+ *     never synchronises and keeps no global state (re-entrant, any thread, any stream);
+ *   - float data is fp32, indices/offsets are int32, `offset` arrays hold CUMULATIVE scene ends;
+ *   - kNN placeholder for scenes with fewer than `nsample` points: idx = -1, dist2 = 1e10;
+ *   - outputs written by plain stores need no initialisation (grouping/subtraction/
+ *     interpolation/aggregation forward, knn, fps, aggregation grad_position);
+ *     outputs that are ACCUMULATED into must be pre-zeroed by the caller exactly as the
+ *     reference's Python wrappers do: every grad_* scatter target and the attention_* forward outputs;
+ *   - gather kernels treat idx < 0 as a zero row (the reference dereferences it: undefined).
+ */
+#ifndef PDFOPS_H
+#define PDFOPS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDF_OK 0
+#define PDF_ERR_BAD_ARG (-1)      /* null pointer / negative size */
+#define PDF_ERR_NSAMPLE (-2)      /* nsample outside 1..128 (reference: best_dist[128], knn_query_cuda_kernel.cu:82) */
+#define PDF_ERR_UNSUPPORTED (-3)  /* shape outside what the kernels are built for */
+
+/* version / build probe (no GPU needed) */
+int pdf_abi_version(void);
+const char *pdf_build_info(void);
+
+/* replaces knn_query_cuda_launcher, libs/pointops/src/knn_query/knn_query_cuda_kernel.h:13
+ * (kernel knn_query_cuda_kernel.cu:60-104).  idx (m,nsample), dist2 (m,nsample) = SQUARED distances. */
+int pdf_knn_query(int m, int nsample, const float *xyz, const float *new_xyz,
+                  const int *offset, const int *new_offset, int b,
+                  int *idx, float *dist2, void *stream);
+
+/* replaces farthest_point_sampling_cuda_launcher, libs/pointops/src/sampling/sampling_cuda_kernel.h:13
+ * (kernel sampling_cuda_kernel.cu:14-129).  `n` = size of the largest scene (fixes the reference's
+ * block size opt_n_threads(n), cuda_utils.h:11-14, which fixes its arg-max tie rule).
+ * `tmp` (N floats) is scratch and need NOT be pre-filled (the reference wants 1e10). */
+int pdf_farthest_point_sampling(int b, int n, const float *xyz, const int *offset,
+                                const int *new_offset, float *tmp, int *idx, void *stream);
+
+/* log2 of the block size the reference would launch for a largest-scene size n (cuda_utils.h:11-14) */
+int pdf_fps_reference_block_log2(int n);
+
+/* Bucketed exact FPS (same results as pdf_farthest_point_sampling, far fewer point updates).
+ * Host-side sizes: n_total = offset[b-1].  Workspace from pdf_fps_workspace_bytes(). */
+long pdf_fps_workspace_bytes(int b, int n_total);
+int pdf_farthest_point_sampling_bucketed(int b, int n, int n_total, const float *xyz, const int *offset,
+                                         const int *new_offset, void *workspace, long workspace_bytes,
+                                         int *idx, void *stream);
+
+/* replaces grouping_{forward,backward}_cuda_launcher, libs/pointops/src/grouping/grouping_cuda_kernel.h:14-15 */
+int pdf_grouping_forward(int m, int nsample, int c, const float *input, const int *idx, float *output, void *stream);
+int pdf_grouping_backward(int m, int nsample, int c, const float *grad_output, const int *idx, float *grad_input, void *stream);
+
+/* replaces interpolation_{forward,backward}_cuda_launcher, libs/pointops/src/interpolation/interpolation_cuda_kernel.h:14-15 */
+int pdf_interpolation_forward(int n, int c, int k, const float *input, const int *idx, const float *weight, float *output, void *stream);
+int pdf_interpolation_backward(int n, int c, int k, const float *grad_output, const int *idx, const float *weight, float *grad_input, void *stream);
+
+/* replaces subtraction_{forward,backward}_cuda_launcher, libs/pointops/src/subtraction/subtraction_cuda_kernel.h:14-15 */
+int pdf_subtraction_forward(int n, int nsample, int c, const float *input1, const float *input2, const int *idx, float *output, void *stream);
+int pdf_subtraction_backward(int n, int nsample, int c, const int *idx, const float *grad_output, float *grad_input1, float *grad_input2, void *stream);
+
+/* replaces aggregation_{forward,backward}_cuda_launcher, libs/pointops/src/aggregation/aggregation_cuda_kernel.h:14-15 */
+int pdf_aggregation_forward(int n, int nsample, int c, int w_c, const float *input, const float *position,
+                            const float *weight, const int *idx, float *output, void *stream);
+int pdf_aggregation_backward(int n, int nsample, int c, int w_c, const float *input, const float *position,
+                             const float *weight, const int *idx, const float *grad_output,
+                             float *grad_input, float *grad_position, float *grad_weight, void *stream);
+
+/* replace attention_{relation,fusion}_step_{forward,backward}_cuda_launcher,
+ * libs/pointops/src/attention/attention_cuda_kernel.h:31-53 */
+int pdf_attention_relation_step_forward(int m, int g, int c, const float *query, const float *key, const float *weight,
+                                        const int *index_target, const int *index_refer, float *output, void *stream);
+int pdf_attention_relation_step_backward(int m, int g, int c, const float *query, float *grad_query,
+                                         const float *key, float *grad_key, const float *weight, float *grad_weight,
+                                         const int *index_target, const int *index_refer, const float *grad_output, void *stream);
+int pdf_attention_fusion_step_forward(int m, int g, int c, const float *weight, const float *value,
+                                      const int *index_target, const int *index_refer, float *output, void *stream);
+int pdf_attention_fusion_step_backward(int m, int g, int c, const float *weight, float *grad_weight,
+                                       const float *value, float *grad_value,
+                                       const int *index_target, const int *index_refer, const float *grad_output, void *stream);
+
+/* ---- fused entry points of our own (no reference launcher; they fuse the reference's Python-side
+ *      compositions so the (m,nsample,c) temporaries never reach HBM) ---- */
+
+/* pointops.grouping(idx, feat, xyz, new_xyz, with_xyz) -- libs/pointops/functions/grouping.py:36-60.
+ * output (m, nsample, 3*with_xyz + c): [ (xyz[idx]-new_xyz) masked by idx>=0 | feat[idx] ], idx<0 -> zeros. */
+int pdf_group_forward(int m, int nsample, int c, int with_xyz, const float *feat, const float *xyz,
+                      const float *new_xyz, const int *idx, float *output, void *stream);
+/* gradient w.r.t. feat only (xyz carries no gradient on this path); grad_feat (n,c) pre-zeroed. */
+int pdf_group_backward(int m, int nsample, int c, int with_xyz, const float *grad_output, const int *idx,
+                       float *grad_feat, void *stream);
+
+/* inverse-distance weights of pointops.interpolation -- libs/pointops/functions/interpolation.py:14-17:
+ * weight[n,j] = (1/(sqrt(dist2[n,j])+1e-8)) / sum_j(...) */
+int pdf_interpolation_weights(int n, int k, const float *dist2, float *weight, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDFOPS_H */

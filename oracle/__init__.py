@@ -1,0 +1,56 @@
+"""CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+Loads oracle/liboracle.so (C restatement of the reference's libs/pointops kernels, see pdfops_oracle.c)
+and exposes it through the same backend interface as the HIP library so that tests, ``smoke()`` and
+bench.py's ``cpu_baseline`` leg can compare / time it.  Nothing under pointcloudpdf_amd/ imports this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+from pointcloudpdf_amd._native import CBackend
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "pdfops_oracle.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-B", "liboracle.so"], check=True, capture_output=True)
+    return LIB_PATH
+
+
+class OracleBackend(CBackend):
+    """The reference algorithms on CPU tensors."""
+
+    def __init__(self):
+        build()
+        lib = ctypes.CDLL(LIB_PATH)
+        # the reference launcher has no scene-count argument (knn_query_cuda_kernel.h:13)
+        super().__init__(lib, "oracle_", "cpu", False, proto_overrides={"knn_query": "iipppppp"})
+        lib.oracle_opt_n_threads.restype = ctypes.c_int
+        lib.oracle_opt_n_threads.argtypes = [ctypes.c_int]
+        lib.oracle_num_threads.restype = ctypes.c_int
+        lib.oracle_set_num_threads.argtypes = [ctypes.c_int]
+
+    def opt_n_threads(self, n):
+        return int(self.lib.oracle_opt_n_threads(int(n)))
+
+    def num_threads(self):
+        return int(self.lib.oracle_num_threads())
+
+    def set_num_threads(self, n):
+        self.lib.oracle_set_num_threads(int(n))
+
+
+_backend = None
+
+
+def backend():
+    global _backend
+    if _backend is None:
+        _backend = OracleBackend()
+    return _backend

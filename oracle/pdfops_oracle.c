@@ -1,0 +1,398 @@
+/*
+ * pdfops_oracle.c -- CPU restatement of the reference's libs/pointops CUDA kernels.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product path (pointcloudpdf_amd/)
+ * never imports, links or executes anything under oracle/.
+ *
+ * Parity status (see DESIGN.md "Oracle"):
+ *   - The reference CUDA extension cannot be built in this image (its kernel headers pull
+ *     <ATen/cuda/CUDAContext.h> -> <cuda_runtime_api.h>, absent on ROCm) and libs/pointops
+ *     has no tests, golden vectors or known-answer files.  The KERNEL restatements below
+ *     (knn_query, farthest_point_sampling, grouping2, interpolation2, subtraction,
+ *     aggregation, attention_*) are therefore "parity unpinned": they follow the .cu
+ *     bodies statement by statement, nothing stronger is available.
+ *   - The PYTHON-level reference ops (pointops.grouping, pointops.interpolation,
+ *     knn_query_and_group) and the PointTransformer / PTRecognizer modules ARE pinned:
+ *     tests/golden/make_golden.py imports the reference's own Python files on top of this
+ *     library and commits the outputs as fixtures.
+ *
+ * Arithmetic: IEEE fp32, as written, no FMA contraction (compile with -ffp-contract=off).
+ * Every function cites the reference file:line (paths relative to /root/reference/) it follows.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* libs/pointops/src/cuda_utils.h:11-14 */
+int oracle_opt_n_threads(int work_size)
+{
+    const int pow_2 = (int)(log((double)work_size) / log(2.0));
+    int v = 1 << pow_2;
+    if (v > 1024) v = 1024;
+    if (v < 1) v = 1;
+    return v;
+}
+
+int oracle_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+void oracle_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+/* ------------------------------------------------------------------ kNN */
+/* libs/pointops/src/knn_query/knn_query_cuda_kernel.cu:15-30 */
+static void reheap(float *dist, int *idx, int k)
+{
+    int root = 0;
+    int child = root * 2 + 1;
+    while (child < k) {
+        if (child + 1 < k && dist[child + 1] > dist[child]) child++;
+        if (dist[root] > dist[child]) return;
+        float td = dist[root]; dist[root] = dist[child]; dist[child] = td;
+        int ti = idx[root]; idx[root] = idx[child]; idx[child] = ti;
+        root = child;
+        child = root * 2 + 1;
+    }
+}
+
+/* knn_query_cuda_kernel.cu:33-42 */
+static void heap_sort(float *dist, int *idx, int k)
+{
+    for (int i = k - 1; i > 0; i--) {
+        float td = dist[0]; dist[0] = dist[i]; dist[i] = td;
+        int ti = idx[0]; idx[0] = idx[i]; idx[i] = ti;
+        reheap(dist, idx, i);
+    }
+}
+
+/* knn_query_cuda_kernel.cu:45-56 */
+static int get_bt_idx(int idx, const int *offset)
+{
+    int i = 0;
+    while (1) {
+        if (idx < offset[i]) break;
+        else i++;
+    }
+    return i;
+}
+
+/* knn_query_cuda_kernel.cu:60-104 (one loop iteration == one CUDA thread) */
+int oracle_knn_query(int m, int nsample, const float *xyz, const float *new_xyz,
+                     const int *offset, const int *new_offset, int *idx, float *dist2)
+{
+    if (nsample > 128 || nsample < 1) return 1; /* best_dist[128] in the reference */
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int pt_idx = 0; pt_idx < m; pt_idx++) {
+        const float *q = new_xyz + (size_t)pt_idx * 3;
+        int *oi = idx + (size_t)pt_idx * nsample;
+        float *od = dist2 + (size_t)pt_idx * nsample;
+        int bt_idx = get_bt_idx(pt_idx, new_offset);
+        int start = bt_idx == 0 ? 0 : offset[bt_idx - 1];
+        int end = offset[bt_idx];
+        float new_x = q[0], new_y = q[1], new_z = q[2];
+        float best_dist[128];
+        int best_idx[128];
+        for (int i = 0; i < nsample; i++) { best_dist[i] = 1e10f; best_idx[i] = -1; }
+        for (int i = start; i < end; i++) {
+            float x = xyz[(size_t)i * 3 + 0];
+            float y = xyz[(size_t)i * 3 + 1];
+            float z = xyz[(size_t)i * 3 + 2];
+            float d2 = (new_x - x) * (new_x - x) + (new_y - y) * (new_y - y) + (new_z - z) * (new_z - z);
+            if (d2 < best_dist[0]) {
+                best_dist[0] = d2;
+                best_idx[0] = i;
+                reheap(best_dist, best_idx, nsample);
+            }
+        }
+        heap_sort(best_dist, best_idx, nsample);
+        for (int i = 0; i < nsample; i++) { oi[i] = best_idx[i]; od[i] = best_dist[i]; }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ FPS */
+/* libs/pointops/src/sampling/sampling_cuda_kernel.cu:14-129, launcher :131-171.
+ * Lock-step emulation of one thread block per scene: `dists`/`dists_i` are the
+ * __shared__ arrays, the `for s` loop is the unrolled stride-halving tree of
+ * __update() calls (:5-10, :64-123).  block size = opt_n_threads(n) (:133). */
+int oracle_farthest_point_sampling(int b, int n, const float *xyz, const int *offset,
+                                   const int *new_offset, float *tmp, int *idx)
+{
+    const int block_size = oracle_opt_n_threads(n);
+    int status = 0;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int bid = 0; bid < b; bid++) {
+        float *dists = (float *)malloc(sizeof(float) * block_size);
+        int *dists_i = (int *)malloc(sizeof(int) * block_size);
+        if (!dists || !dists_i) { status = 2; free(dists); free(dists_i); continue; }
+        int start_n, end_n, start_m, end_m, old;
+        if (bid == 0) {
+            start_n = 0; end_n = offset[0]; start_m = 0; end_m = new_offset[0]; old = 0;
+        } else {
+            start_n = offset[bid - 1]; end_n = offset[bid];
+            start_m = new_offset[bid - 1]; end_m = new_offset[bid];
+            old = offset[bid - 1];
+        }
+        if (end_m > start_m) idx[start_m] = start_n; /* :39 (guarded: m_b == 0 writes OOB upstream) */
+        for (int j = start_m + 1; j < end_m; j++) {
+            float x1 = xyz[(size_t)old * 3 + 0];
+            float y1 = xyz[(size_t)old * 3 + 1];
+            float z1 = xyz[(size_t)old * 3 + 2];
+            for (int t = 0; t < block_size; t++) { dists[t] = -1.f; dists_i[t] = start_n; } /* :44-45 */
+            /* every thread's strided scan, visited in increasing k (== per-thread order) :49-59 */
+            int tid = 0;
+            for (int k = start_n; k < end_n; k++) {
+                float x2 = xyz[(size_t)k * 3 + 0];
+                float y2 = xyz[(size_t)k * 3 + 1];
+                float z2 = xyz[(size_t)k * 3 + 2];
+                float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+                float d2 = d < tmp[k] ? d : tmp[k]; /* min(d, tmp[k]) */
+                tmp[k] = d2;
+                if (d2 > dists[tid]) { dists_i[tid] = k; dists[tid] = d2; }
+                if (++tid == block_size) tid = 0;
+            }
+            for (int s = block_size / 2; s >= 1; s /= 2) { /* :64-123 */
+                for (int t = 0; t < s; t++) {
+                    float v1 = dists[t], v2 = dists[t + s];
+                    int i1 = dists_i[t], i2 = dists_i[t + s];
+                    dists[t] = v1 > v2 ? v1 : v2;
+                    dists_i[t] = v2 > v1 ? i2 : i1;
+                }
+            }
+            old = dists_i[0]; /* :125 */
+            idx[j] = old;
+        }
+        free(dists);
+        free(dists_i);
+    }
+    return status;
+}
+
+/* ------------------------------------------------------------------ grouping2 */
+/* libs/pointops/src/grouping/grouping_cuda_kernel.cu:5-14 */
+int oracle_grouping_forward(int m, int nsample, int c, const float *input, const int *idx, float *output)
+{
+    const long total = (long)m * nsample * c;
+#pragma omp parallel for
+    for (long index = 0; index < total; index++) {
+        const int c_idx = (int)(index % c);
+        const int nsample_idx = (int)((index / c) % nsample);
+        const int m_idx = (int)(index / nsample / c);
+        const long input_idx = (long)idx[(long)m_idx * nsample + nsample_idx] * c + c_idx;
+        output[index] = input[input_idx];
+    }
+    return 0;
+}
+
+/* grouping_cuda_kernel.cu:16-25 (atomicAdd -> serial +=, thread order = index order) */
+int oracle_grouping_backward(int m, int nsample, int c, const float *grad_output, const int *idx, float *grad_input)
+{
+    const long total = (long)m * nsample * c;
+    for (long index = 0; index < total; index++) {
+        const int c_idx = (int)(index % c);
+        const int nsample_idx = (int)((index / c) % nsample);
+        const int m_idx = (int)(index / nsample / c);
+        const long input_idx = (long)idx[(long)m_idx * nsample + nsample_idx] * c + c_idx;
+        grad_input[input_idx] += grad_output[index];
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ interpolation2 */
+/* libs/pointops/src/interpolation/interpolation_cuda_kernel.cu:5-18 (output pre-zeroed by caller) */
+int oracle_interpolation_forward(int n, int c, int k, const float *input, const int *idx, const float *weight, float *output)
+{
+    const long total = (long)n * c;
+#pragma omp parallel for
+    for (long index = 0; index < total; index++) {
+        int c_idx = (int)(index % c);
+        int n_idx = (int)(index / c);
+        for (int i = 0; i < k; i++) {
+            long idx_idx = (long)n_idx * k + i;
+            long input_idx = (long)idx[idx_idx] * c + c_idx;
+            output[index] += input[input_idx] * weight[idx_idx];
+        }
+    }
+    return 0;
+}
+
+/* interpolation_cuda_kernel.cu:20-33 */
+int oracle_interpolation_backward(int n, int c, int k, const float *grad_output, const int *idx, const float *weight, float *grad_input)
+{
+    const long total = (long)n * c;
+    for (long index = 0; index < total; index++) {
+        int c_idx = (int)(index % c);
+        int n_idx = (int)(index / c);
+        for (int i = 0; i < k; i++) {
+            long idx_idx = (long)n_idx * k + i;
+            long input_idx = (long)idx[idx_idx] * c + c_idx;
+            grad_input[input_idx] += grad_output[index] * weight[idx_idx];
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ subtraction */
+/* libs/pointops/src/subtraction/subtraction_cuda_kernel.cu:5-16 */
+int oracle_subtraction_forward(int n, int nsample, int c, const float *input1, const float *input2, const int *idx, float *output)
+{
+    const long total = (long)n * nsample * c;
+#pragma omp parallel for
+    for (long index = 0; index < total; index++) {
+        const int c_idx = (int)(index % c);
+        const int nsample_idx = (int)((index / c) % nsample);
+        const int n_idx = (int)(index / nsample / c);
+        const long idx_idx = (long)n_idx * nsample + nsample_idx;
+        const long input1_idx = (long)n_idx * c + c_idx;
+        const long input2_idx = (long)idx[idx_idx] * c + c_idx;
+        output[index] = input1[input1_idx] - input2[input2_idx];
+    }
+    return 0;
+}
+
+/* subtraction_cuda_kernel.cu:18-30 */
+int oracle_subtraction_backward(int n, int nsample, int c, const int *idx, const float *grad_output, float *grad_input1, float *grad_input2)
+{
+    const long total = (long)n * nsample * c;
+    for (long index = 0; index < total; index++) {
+        const int c_idx = (int)(index % c);
+        const int nsample_idx = (int)((index / c) % nsample);
+        const int n_idx = (int)(index / nsample / c);
+        const long idx_idx = (long)n_idx * nsample + nsample_idx;
+        const long input1_idx = (long)n_idx * c + c_idx;
+        const long input2_idx = (long)idx[idx_idx] * c + c_idx;
+        grad_input1[input1_idx] += grad_output[index];
+        grad_input2[input2_idx] += -grad_output[index];
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ aggregation */
+/* libs/pointops/src/aggregation/aggregation_cuda_kernel.cu:5-20 (output pre-zeroed) */
+int oracle_aggregation_forward(int n, int nsample, int c, int w_c, const float *input, const float *position,
+                               const float *weight, const int *idx, float *output)
+{
+    const long total = (long)n * c;
+#pragma omp parallel for
+    for (long index = 0; index < total; index++) {
+        const int c_idx = (int)(index % c);
+        const int n_idx = (int)(index / c);
+        const int w_c_idx = c_idx % w_c;
+        for (int nsample_idx = 0; nsample_idx < nsample; nsample_idx++) {
+            long idx_idx = (long)n_idx * nsample + nsample_idx;
+            long input_idx = (long)idx[idx_idx] * c + c_idx;
+            long position_idx = (long)n_idx * nsample * c + (long)nsample_idx * c + c_idx;
+            long weight_idx = (long)n_idx * nsample * w_c + (long)nsample_idx * w_c + w_c_idx;
+            output[index] += (input[input_idx] + position[position_idx]) * weight[weight_idx];
+        }
+    }
+    return 0;
+}
+
+/* aggregation_cuda_kernel.cu:22-39 */
+int oracle_aggregation_backward(int n, int nsample, int c, int w_c, const float *input, const float *position,
+                                const float *weight, const int *idx, const float *grad_output,
+                                float *grad_input, float *grad_position, float *grad_weight)
+{
+    const long total = (long)n * c;
+    for (long index = 0; index < total; index++) {
+        const int c_idx = (int)(index % c);
+        const int n_idx = (int)(index / c);
+        const int w_c_idx = c_idx % w_c;
+        for (int nsample_idx = 0; nsample_idx < nsample; nsample_idx++) {
+            long idx_idx = (long)n_idx * nsample + nsample_idx;
+            long input_idx = (long)idx[idx_idx] * c + c_idx;
+            long position_idx = (long)n_idx * nsample * c + (long)nsample_idx * c + c_idx;
+            long weight_idx = (long)n_idx * nsample * w_c + (long)nsample_idx * w_c + w_c_idx;
+            grad_input[input_idx] += grad_output[index] * weight[weight_idx];
+            grad_position[position_idx] = grad_output[index] * weight[weight_idx];
+            grad_weight[weight_idx] += grad_output[index] * (input[input_idx] + position[position_idx]);
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ attention steps */
+/* libs/pointops/src/attention/attention_cuda_kernel.cu:9-24; grid (ceil(m/512), g, c):
+ * serial order here is r fastest inside (g, c) blocks -- the sum over c per (r, g) is what matters */
+int oracle_attention_relation_step_forward(int m, int g, int c, const float *query, const float *key, const float *weight,
+                                           const int *index_target, const int *index_refer, float *output)
+{
+    for (int c_idx = 0; c_idx < c; c_idx++)
+        for (int g_idx = 0; g_idx < g; g_idx++)
+            for (int r_idx = 0; r_idx < m; r_idx++) {
+                long q_idx = (long)index_target[r_idx] * g * c + (long)g_idx * c + c_idx;
+                long k_idx = (long)index_refer[r_idx] * g * c + (long)g_idx * c + c_idx;
+                float r = query[q_idx] * key[k_idx] * weight[c_idx];
+                output[(long)r_idx * g + g_idx] += r;
+            }
+    return 0;
+}
+
+/* attention_cuda_kernel.cu:26-47 */
+int oracle_attention_relation_step_backward(int m, int g, int c, const float *query, float *grad_query,
+                                            const float *key, float *grad_key, const float *weight, float *grad_weight,
+                                            const int *index_target, const int *index_refer, const float *grad_output)
+{
+    for (int c_idx = 0; c_idx < c; c_idx++)
+        for (int g_idx = 0; g_idx < g; g_idx++)
+            for (int r_idx = 0; r_idx < m; r_idx++) {
+                long q_idx = (long)index_target[r_idx] * g * c + (long)g_idx * c + c_idx;
+                long k_idx = (long)index_refer[r_idx] * g * c + (long)g_idx * c + c_idx;
+                long o_idx = (long)r_idx * g + g_idx;
+                float grad_r = grad_output[o_idx];
+                grad_query[q_idx] += grad_r * key[k_idx] * weight[c_idx];
+                grad_key[k_idx] += grad_r * query[q_idx] * weight[c_idx];
+                grad_weight[c_idx] += grad_r * key[k_idx] * query[q_idx];
+            }
+    return 0;
+}
+
+/* attention_cuda_kernel.cu:50-66 */
+int oracle_attention_fusion_step_forward(int m, int g, int c, const float *weight, const float *value,
+                                         const int *index_target, const int *index_refer, float *output)
+{
+    for (int c_idx = 0; c_idx < c; c_idx++)
+        for (int g_idx = 0; g_idx < g; g_idx++)
+            for (int r_idx = 0; r_idx < m; r_idx++) {
+                long o_idx = (long)index_target[r_idx] * g * c + (long)g_idx * c + c_idx;
+                long v_idx = (long)index_refer[r_idx] * g * c + (long)g_idx * c + c_idx;
+                float f = weight[(long)r_idx * g + g_idx] * value[v_idx];
+                output[o_idx] += f;
+            }
+    return 0;
+}
+
+/* attention_cuda_kernel.cu:69-86 */
+int oracle_attention_fusion_step_backward(int m, int g, int c, const float *weight, float *grad_weight,
+                                          const float *value, float *grad_value,
+                                          const int *index_target, const int *index_refer, const float *grad_output)
+{
+    for (int c_idx = 0; c_idx < c; c_idx++)
+        for (int g_idx = 0; g_idx < g; g_idx++)
+            for (int r_idx = 0; r_idx < m; r_idx++) {
+                long o_idx = (long)index_target[r_idx] * g * c + (long)g_idx * c + c_idx;
+                long v_idx = (long)index_refer[r_idx] * g * c + (long)g_idx * c + c_idx;
+                long w_idx = (long)r_idx * g + g_idx;
+                float grad = grad_output[o_idx];
+                grad_weight[w_idx] += grad * value[v_idx];
+                grad_value[v_idx] += grad * weight[w_idx];
+            }
+    return 0;
+}

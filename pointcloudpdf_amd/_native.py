@@ -1,0 +1,322 @@
+"""ctypes binding of the C ABI declared in include/pdfops.h.
+
+``CBackend`` turns torch tensors into raw pointers + sizes and calls the C entry points.  The
+product instance (``hip_backend()``) binds ``libpdfops.so`` (prefix ``pdf_``, device pointers, a
+trailing hipStream_t).  There is NO CPU fallback in this package: if the library is missing or a
+tensor is not on a ROCm device the call raises.  (The test-only oracle binds its own library
+through the same class from ``oracle/``; nothing here imports it.)
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpdfops.so")
+
+c_int = ctypes.c_int
+c_long = ctypes.c_long
+c_void_p = ctypes.c_void_p
+
+# name -> argument kinds ("i" int, "l" long, "p" pointer); the stream pointer is appended for HIP.
+_PROTOS = {
+    "knn_query": "iippppipp",
+    "farthest_point_sampling": "iippppp",
+    "grouping_forward": "iiippp",
+    "grouping_backward": "iiippp",
+    "interpolation_forward": "iiipppp",
+    "interpolation_backward": "iiipppp",
+    "subtraction_forward": "iiipppp",
+    "subtraction_backward": "iiipppp",
+    "aggregation_forward": "iiiippppp",
+    "aggregation_backward": "iiiipppppppp",
+    "attention_relation_step_forward": "iiipppppp",
+    "attention_relation_step_backward": "iiippppppppp",
+    "attention_fusion_step_forward": "iiippppp",
+    "attention_fusion_step_backward": "iiippppppp",
+}
+_HIP_ONLY_PROTOS = {
+    "group_forward": "iiiippppp",
+    "group_backward": "iiiippp",
+    "interpolation_weights": "iipp",
+    "farthest_point_sampling_bucketed": "iiipppplp",
+}
+_KIND = {"i": c_int, "l": c_long, "p": c_void_p}
+
+
+class PdfOpsError(RuntimeError):
+    pass
+
+
+def _check(t, dtype, name):
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t
+
+
+class CBackend:
+    """Calls a C library that implements the pdfops ABI on tensors of one device kind."""
+
+    def __init__(self, lib, prefix, device_type, use_stream, extra_protos=(), proto_overrides=None):
+        self.lib = lib
+        self.prefix = prefix
+        self.device_type = device_type
+        self.use_stream = use_stream
+        self._fn = {}
+        protos = dict(_PROTOS)
+        for k in extra_protos:
+            protos[k] = _HIP_ONLY_PROTOS[k]
+        protos.update(proto_overrides or {})
+        for name, kinds in protos.items():
+            f = getattr(lib, prefix + name)
+            f.restype = c_int
+            f.argtypes = [_KIND[k] for k in kinds] + ([c_void_p] if use_stream else [])
+            self._fn[name] = f
+
+    # -- plumbing -------------------------------------------------------------------------------
+    def _ptr(self, t):
+        if t.device.type != self.device_type:
+            raise PdfOpsError(
+                f"pointcloudpdf_amd: tensor on '{t.device}' but this backend runs on '{self.device_type}' "
+                "(the HIP path has no CPU fallback)"
+            )
+        return c_void_p(t.data_ptr())
+
+    def _call(self, name, *args):
+        conv = []
+        for a in args:
+            conv.append(self._ptr(a) if isinstance(a, torch.Tensor) else a)
+        if self.use_stream:
+            conv.append(c_void_p(torch.cuda.current_stream().cuda_stream))
+        rc = self._fn[name](*conv)
+        if rc != 0:
+            raise PdfOpsError(f"{self.prefix}{name} failed with status {rc}")
+
+    def _new(self, like, shape, dtype, zero=False):
+        return (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=like.device)
+
+    # -- reference ops ----------------------------------------------------------------------------
+    def knn_query(self, nsample, xyz, new_xyz, offset, new_offset):
+        """-> idx (m, nsample) int32, dist2 (m, nsample) f32 (squared).  knn_query_cuda, query.py:19-23."""
+        _check(xyz, torch.float32, "xyz"); _check(new_xyz, torch.float32, "new_xyz")
+        _check(offset, torch.int32, "offset"); _check(new_offset, torch.int32, "new_offset")
+        if not 1 <= nsample <= 128:
+            raise ValueError("nsample must be in 1..128")
+        m = new_xyz.shape[0]
+        idx = self._new(xyz, (m, nsample), torch.int32)
+        dist2 = self._new(xyz, (m, nsample), torch.float32)
+        if self.use_stream:
+            self._call("knn_query", m, nsample, xyz, new_xyz, offset, new_offset, offset.shape[0], idx, dist2)
+        else:
+            self._call("knn_query", m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2)
+        return idx, dist2
+
+    def farthest_point_sampling(self, xyz, offset, new_offset, n_max, m_total):
+        """-> idx (m_total,) int32.  farthest_point_sampling_cuda, sampling.py:18-22."""
+        _check(xyz, torch.float32, "xyz")
+        _check(offset, torch.int32, "offset"); _check(new_offset, torch.int32, "new_offset")
+        idx = self._new(xyz, (m_total,), torch.int32, zero=True)
+        tmp = torch.full((xyz.shape[0],), 1e10, dtype=torch.float32, device=xyz.device)
+        self._call("farthest_point_sampling", offset.shape[0], int(n_max), xyz, offset, new_offset, tmp, idx)
+        return idx
+
+    def grouping_forward(self, input, idx):
+        _check(input, torch.float32, "input"); _check(idx, torch.int32, "idx")
+        m, ns = idx.shape
+        c = input.shape[1]
+        out = self._new(input, (m, ns, c), torch.float32)
+        self._call("grouping_forward", m, ns, c, input, idx, out)
+        return out
+
+    def grouping_backward(self, grad_output, idx, n):
+        _check(grad_output, torch.float32, "grad_output"); _check(idx, torch.int32, "idx")
+        m, ns, c = grad_output.shape
+        gi = self._new(grad_output, (n, c), torch.float32, zero=True)
+        self._call("grouping_backward", m, ns, c, grad_output, idx, gi)
+        return gi
+
+    def interpolation_forward(self, input, idx, weight):
+        _check(input, torch.float32, "input"); _check(idx, torch.int32, "idx"); _check(weight, torch.float32, "weight")
+        n, k = idx.shape
+        c = input.shape[1]
+        out = self._new(input, (n, c), torch.float32, zero=True)
+        self._call("interpolation_forward", n, c, k, input, idx, weight, out)
+        return out
+
+    def interpolation_backward(self, grad_output, idx, weight, m):
+        _check(grad_output, torch.float32, "grad_output"); _check(idx, torch.int32, "idx"); _check(weight, torch.float32, "weight")
+        n, c = grad_output.shape
+        k = idx.shape[1]
+        gi = self._new(grad_output, (m, c), torch.float32, zero=True)
+        self._call("interpolation_backward", n, c, k, grad_output, idx, weight, gi)
+        return gi
+
+    def subtraction_forward(self, input1, input2, idx):
+        _check(input1, torch.float32, "input1"); _check(input2, torch.float32, "input2"); _check(idx, torch.int32, "idx")
+        n, c = input1.shape
+        ns = idx.shape[-1]
+        out = self._new(input1, (n, ns, c), torch.float32, zero=True)
+        self._call("subtraction_forward", n, ns, c, input1, input2, idx, out)
+        return out
+
+    def subtraction_backward(self, idx, grad_output, n2=None):
+        _check(grad_output, torch.float32, "grad_output"); _check(idx, torch.int32, "idx")
+        n, ns, c = grad_output.shape
+        g1 = self._new(grad_output, (n, c), torch.float32, zero=True)
+        g2 = self._new(grad_output, (n if n2 is None else n2, c), torch.float32, zero=True)
+        self._call("subtraction_backward", n, ns, c, idx, grad_output, g1, g2)
+        return g1, g2
+
+    def aggregation_forward(self, input, position, weight, idx):
+        for t, nm in ((input, "input"), (position, "position"), (weight, "weight")):
+            _check(t, torch.float32, nm)
+        _check(idx, torch.int32, "idx")
+        n, ns, c = position.shape
+        w_c = weight.shape[-1]
+        out = self._new(input, (n, c), torch.float32, zero=True)
+        self._call("aggregation_forward", n, ns, c, w_c, input, position, weight, idx, out)
+        return out
+
+    def aggregation_backward(self, input, position, weight, idx, grad_output):
+        _check(grad_output, torch.float32, "grad_output")
+        n, ns, c = position.shape
+        w_c = weight.shape[-1]
+        gi = self._new(input, tuple(input.shape), torch.float32, zero=True)
+        gp = self._new(input, (n, ns, c), torch.float32, zero=True)
+        gw = self._new(input, (n, ns, w_c), torch.float32, zero=True)
+        self._call("aggregation_backward", n, ns, c, w_c, input, position, weight, idx, grad_output, gi, gp, gw)
+        return gi, gp, gw
+
+    def attention_relation_step_forward(self, query, key, weight, index_target, index_refer):
+        for t, nm in ((query, "query"), (key, "key"), (weight, "weight")):
+            _check(t, torch.float32, nm)
+        _check(index_target, torch.int32, "index_target"); _check(index_refer, torch.int32, "index_refer")
+        _, g, c = query.shape
+        m = index_target.shape[0]
+        out = self._new(query, (m, g), torch.float32, zero=True)
+        self._call("attention_relation_step_forward", m, g, c, query, key, weight, index_target, index_refer, out)
+        return out
+
+    def attention_relation_step_backward(self, query, key, weight, index_target, index_refer, grad_output):
+        _check(grad_output, torch.float32, "grad_output")
+        n, g, c = query.shape
+        m = index_target.shape[0]
+        gq = self._new(query, (n, g, c), torch.float32, zero=True)
+        gk = self._new(query, tuple(key.shape), torch.float32, zero=True)
+        gw = self._new(query, (c,), torch.float32, zero=True)
+        self._call("attention_relation_step_backward", m, g, c, query, gq, key, gk, weight, gw,
+                   index_target, index_refer, grad_output)
+        return gq, gk, gw
+
+    def attention_fusion_step_forward(self, weight, value, index_target, index_refer):
+        _check(weight, torch.float32, "weight"); _check(value, torch.float32, "value")
+        _check(index_target, torch.int32, "index_target"); _check(index_refer, torch.int32, "index_refer")
+        n, g, c = value.shape
+        m = index_refer.shape[0]
+        out = self._new(value, (n, g, c), torch.float32, zero=True)
+        self._call("attention_fusion_step_forward", m, g, c, weight, value, index_target, index_refer, out)
+        return out
+
+    def attention_fusion_step_backward(self, weight, value, index_target, index_refer, grad_output):
+        _check(grad_output, torch.float32, "grad_output")
+        n, g, c = value.shape
+        m = index_target.shape[0]
+        gw = self._new(value, (m, g), torch.float32, zero=True)
+        gv = self._new(value, (n, g, c), torch.float32, zero=True)
+        self._call("attention_fusion_step_backward", m, g, c, weight, gw, value, gv, index_target, index_refer, grad_output)
+        return gw, gv
+
+
+class HipBackend(CBackend):
+    """libpdfops.so on the current ROCm device; adds the fused entry points."""
+
+    def __init__(self, lib):
+        super().__init__(lib, "pdf_", "cuda", True, extra_protos=tuple(_HIP_ONLY_PROTOS))
+        lib.pdf_fps_workspace_bytes.restype = c_long
+        lib.pdf_fps_workspace_bytes.argtypes = [c_int, c_int]
+        lib.pdf_abi_version.restype = c_int
+        lib.pdf_build_info.restype = ctypes.c_char_p
+        self.fps_mode = os.environ.get("PDFOPS_FPS", "bucketed")  # "bucketed" | "plain"
+
+    def farthest_point_sampling(self, xyz, offset, new_offset, n_max, m_total):
+        if self.fps_mode == "plain":
+            return super().farthest_point_sampling(xyz, offset, new_offset, n_max, m_total)
+        _check(xyz, torch.float32, "xyz")
+        _check(offset, torch.int32, "offset"); _check(new_offset, torch.int32, "new_offset")
+        b, n_total = offset.shape[0], xyz.shape[0]
+        idx = self._new(xyz, (m_total,), torch.int32, zero=True)
+        nbytes = int(self.lib.pdf_fps_workspace_bytes(b, n_total))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=xyz.device)
+        self._call("farthest_point_sampling_bucketed", b, int(n_max), n_total, xyz, offset, new_offset, ws, nbytes, idx)
+        return idx
+
+    def group_forward(self, feat, xyz, new_xyz, idx, with_xyz):
+        _check(feat, torch.float32, "feat"); _check(idx, torch.int32, "idx")
+        m, ns = idx.shape
+        c = feat.shape[1]
+        out = self._new(feat, (m, ns, c + (3 if with_xyz else 0)), torch.float32)
+        if with_xyz:
+            _check(xyz, torch.float32, "xyz"); _check(new_xyz, torch.float32, "new_xyz")
+            self._call("group_forward", m, ns, c, 1, feat, xyz, new_xyz, idx, out)
+        else:
+            self._call("group_forward", m, ns, c, 0, feat, feat, feat, idx, out)
+        return out
+
+    def group_backward(self, grad_output, idx, n, c, with_xyz):
+        _check(grad_output, torch.float32, "grad_output")
+        m, ns = idx.shape
+        gf = self._new(grad_output, (n, c), torch.float32, zero=True)
+        self._call("group_backward", m, ns, c, 1 if with_xyz else 0, grad_output, idx, gf)
+        return gf
+
+    def interpolation_weights(self, dist2):
+        _check(dist2, torch.float32, "dist2")
+        n, k = dist2.shape
+        w = self._new(dist2, (n, k), torch.float32)
+        self._call("interpolation_weights", n, k, dist2, w)
+        return w
+
+
+_lock = threading.Lock()
+_hip = None
+_override = None  # set only by tests / the CPU-baseline leg (oracle injection)
+
+
+def load_library(path=LIB_PATH):
+    if not os.path.exists(path):
+        raise PdfOpsError(
+            f"pointcloudpdf_amd: {path} is missing. Build it with `python -m pointcloudpdf_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no fallback implementation."
+        )
+    return ctypes.CDLL(path)
+
+
+def hip_backend():
+    global _hip
+    if _hip is None:
+        with _lock:
+            if _hip is None:
+                _hip = HipBackend(load_library())
+    return _hip
+
+
+def backend_for(t):
+    """The backend that must serve tensor ``t``.  CPU tensors raise unless a test injected a backend."""
+    if _override is not None:
+        return _override
+    if t.device.type == "cuda":
+        return hip_backend()
+    raise PdfOpsError(
+        f"pointcloudpdf_amd: got a tensor on '{t.device}'. The product path is HIP-only (MI355X); "
+        "move inputs to a ROCm device."
+    )
+
+
+def _set_backend_for_testing(backend):
+    """TEST / CPU-BASELINE ONLY: route every op through ``backend`` (e.g. the CPU oracle). Returns the previous one."""
+    global _override
+    prev, _override = _override, backend
+    return prev

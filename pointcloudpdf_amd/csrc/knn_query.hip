@@ -1,0 +1,146 @@
+// kNN query for gfx950 -- replaces libs/pointops/src/knn_query/knn_query_cuda_kernel.cu:60-112.
+//
+// Semantics are the reference's, bit for bit: every query scans the points of its own scene in
+// index order, keeps an nsample-slot max-heap, replaces the root iff d2 < root (strict), and ends
+// with the reference's heap sort -- so ties resolve exactly as upstream (heap-history dependent).
+// d2 is evaluated as written in IEEE fp32 (this TU is compiled with -ffp-contract=off).
+//
+// MI355X mapping (not the reference's one-thread-per-query-over-global-memory layout):
+//   * one lane = one query, 128-lane workgroups; the candidate index is wave-uniform, so candidate
+//     coordinates arrive through the scalar cache (s_load) and sit in SGPRs: zero LDS/VMEM
+//     traffic in the inner loop, 8 VALU ops per pair;
+//   * candidates are consumed 8 at a time; a v_min3 tree + one wave-wide compare skips the
+//     whole chunk when no lane improves its heap root (the common case after warm-up);
+//   * the heap lives in LDS, column per lane ([slot][lane] -> conflict-free), not in scratch.
+// Roofline: FP32 VALU (8 flop/pair as written); algorithmic HBM bytes are 12N+12M+8Mk.
+#include "pdfops_common.h"
+
+namespace {
+
+template <int BLOCK>
+__device__ __forceinline__ void heap_sift_root(float *hd, int *hi, int tid, int size, float v, int vi) {
+    // == "dist[0]=v; reheap(dist, idx, size)" of knn_query_cuda_kernel.cu:15-30
+    int pos = 0;
+    while (true) {
+        int child = 2 * pos + 1;
+        if (child >= size) break;
+        float cd = hd[child * BLOCK + tid];
+        if (child + 1 < size) {
+            float cd2 = hd[(child + 1) * BLOCK + tid];
+            if (cd2 > cd) { cd = cd2; ++child; }
+        }
+        if (v > cd) break;
+        hd[pos * BLOCK + tid] = cd;
+        hi[pos * BLOCK + tid] = hi[child * BLOCK + tid];
+        pos = child;
+    }
+    hd[pos * BLOCK + tid] = v;
+    hi[pos * BLOCK + tid] = vi;
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void knn_scan_kernel(int m, int k, const float *__restrict__ xyz,
+                                                         const float *__restrict__ new_xyz,
+                                                         const int *__restrict__ offset,
+                                                         const int *__restrict__ new_offset, int b,
+                                                         int *__restrict__ idx, float *__restrict__ dist2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char knn_smem[];
+    float *hd = reinterpret_cast<float *>(knn_smem);  // [k][BLOCK]
+    int *hi = reinterpret_cast<int *>(hd + k * BLOCK);  // [k][BLOCK]
+    const int tid = threadIdx.x;
+    const int q = blockIdx.x * BLOCK + tid;
+    const bool active = q < m;
+
+    int bt = 0;  // get_bt_idx, knn_query_cuda_kernel.cu:45-56 (bounded by b)
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (active) {
+        while (bt < b - 1 && q >= new_offset[bt]) ++bt;
+        qx = new_xyz[3 * (size_t)q + 0];
+        qy = new_xyz[3 * (size_t)q + 1];
+        qz = new_xyz[3 * (size_t)q + 2];
+    }
+    for (int s = 0; s < k; ++s) {
+        hd[s * BLOCK + tid] = 1e10f;
+        hi[s * BLOCK + tid] = -1;
+    }
+    float root = 1e10f;
+
+    const int bt_lo = __builtin_amdgcn_readfirstlane(pdf_wave_min_i32(active ? bt : 0x7fffffff));
+    const int bt_hi = __builtin_amdgcn_readfirstlane(pdf_wave_max_i32(active ? bt : -1));
+    for (int sb = bt_lo; sb <= bt_hi; ++sb) {  // scenes touched by this wave (normally one)
+        const int start = sb == 0 ? 0 : offset[sb - 1];
+        const int end = offset[sb];
+        const bool mine = active && bt == sb;
+        float thr = mine ? root : -1.0f;  // d2 >= 0 never beats -1: foreign lanes stay idle
+        int i = start;
+        for (; i + 8 <= end; i += 8) {
+            const float *__restrict__ p = xyz + 3 * (size_t)i;  // wave-uniform -> s_load
+            float d[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float x = p[3 * u + 0], y = p[3 * u + 1], z = p[3 * u + 2];
+                d[u] = (qx - x) * (qx - x) + (qy - y) * (qy - y) + (qz - z) * (qz - z);
+            }
+            const float m0 = fminf(fminf(d[0], d[1]), d[2]);
+            const float m1 = fminf(fminf(d[3], d[4]), d[5]);
+            const float m2 = fminf(fminf(d[6], d[7]), m0);
+            const float dmin = fminf(m1, m2);
+            if (__builtin_amdgcn_ballot_w64(dmin < thr) != 0ull) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (d[u] < thr) {
+                        heap_sift_root<BLOCK>(hd, hi, tid, k, d[u], i + u);
+                        thr = hd[tid];
+                    }
+                }
+            }
+        }
+        for (; i < end; ++i) {
+            const float *__restrict__ p = xyz + 3 * (size_t)i;
+            const float x = p[0], y = p[1], z = p[2];
+            const float d = (qx - x) * (qx - x) + (qy - y) * (qy - y) + (qz - z) * (qz - z);
+            if (d < thr) {
+                heap_sift_root<BLOCK>(hd, hi, tid, k, d, i);
+                thr = hd[tid];
+            }
+        }
+        if (mine) root = thr;
+    }
+
+    // heap_sort, knn_query_cuda_kernel.cu:33-42
+    for (int i = k - 1; i > 0; --i) {
+        const float v = hd[i * BLOCK + tid];
+        const int vi = hi[i * BLOCK + tid];
+        hd[i * BLOCK + tid] = hd[tid];
+        hi[i * BLOCK + tid] = hi[tid];
+        heap_sift_root<BLOCK>(hd, hi, tid, i, v, vi);
+    }
+    if (active) {
+        int *oi = idx + (size_t)q * k;
+        float *od = dist2 + (size_t)q * k;
+        for (int s = 0; s < k; ++s) {
+            oi[s] = hi[s * BLOCK + tid];
+            od[s] = hd[s * BLOCK + tid];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int pdf_knn_query(int m, int nsample, const float *xyz, const float *new_xyz, const int *offset,
+                             const int *new_offset, int b, int *idx, float *dist2, void *stream) {
+    if (m < 0 || b < 1 || !xyz || !new_xyz || !offset || !new_offset || !idx || !dist2) return PDF_ERR_BAD_ARG;
+    if (nsample < 1 || nsample > 128) return PDF_ERR_NSAMPLE;
+    if (m == 0) return PDF_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (nsample <= 32) {
+        constexpr int BLOCK = 128;
+        const size_t lds = (size_t)nsample * BLOCK * 8;
+        knn_scan_kernel<BLOCK><<<pdf_divup(m, BLOCK), BLOCK, lds, s>>>(m, nsample, xyz, new_xyz, offset, new_offset, b, idx, dist2);
+    } else {
+        constexpr int BLOCK = 64;
+        const size_t lds = (size_t)nsample * BLOCK * 8;
+        knn_scan_kernel<BLOCK><<<pdf_divup(m, BLOCK), BLOCK, lds, s>>>(m, nsample, xyz, new_xyz, offset, new_offset, b, idx, dist2);
+    }
+    return pdf_launch_status();
+}

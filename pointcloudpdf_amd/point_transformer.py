@@ -1,0 +1,254 @@
+"""PointTransformer-V1 segmentation backbone for MI355X.
+
+Plugin-compatible with pointcept/models/point_transformer/point_transformer_seg.py:19-327: the classes are
+registered as ``PointTransformer-Seg26/38/50`` with the same constructor kwargs, the same submodule tree
+(``enc1..enc5`` / ``dec1..dec5`` as ``nn.Sequential``; ``linear1, bn1, transformer.{linear_q, linear_k, linear_v,
+linear_p, linear_w}, bn2, linear3, bn3``; ``TransitionDown.{linear, bn}``; ``TransitionUp.{linear1, linear2}``;
+``cls``) and therefore the same ``state_dict`` keys, and every stage returns ``[p, x, o]`` so that
+``ModelHook`` names such as ``backbone.enc3`` / ``backbone.dec2.1`` resolve.
+
+What differs is the execution plan:
+  * all coordinate-only work (FPS, kNN, interpolation tables) comes from one ``Geometry`` per batch
+    (identical results, computed once instead of 4 + 31 times) -- geometry.py;
+  * no ``.item()`` / host syncs inside the layers, no (n, ns, c) transpose copies for the BatchNorm-as-LayerNorm;
+  * gathers, relative coordinates, masks and concatenations run in the fused HIP gather kernels.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import pointops
+from .geometry import Geometry, tag_of
+from .registry import MODELS
+
+
+class LayerNorm1d(nn.BatchNorm1d):
+    """BatchNorm1d over the channel (last) dim of an (n, ns, c) tensor -- pointcept/models/point_transformer/utils.py:7-14.
+    The reference transposes to (n, c, ns) and back (two full copies); statistics over all n*ns rows per channel
+    are the same as BatchNorm over the (n*ns, c) view, which needs no copy."""
+
+    def forward(self, input):
+        shape = input.shape
+        return super().forward(input.reshape(-1, shape[-1])).view(shape)
+
+
+class PointTransformerLayer(nn.Module):
+    """Vector attention with shared planes -- point_transformer_seg.py:19-78."""
+
+    def __init__(self, in_planes, out_planes, share_planes=8, nsample=16):
+        super().__init__()
+        self.mid_planes = mid_planes = out_planes // 1
+        self.out_planes = out_planes
+        self.share_planes = share_planes
+        self.nsample = nsample
+        self.linear_q = nn.Linear(in_planes, mid_planes)
+        self.linear_k = nn.Linear(in_planes, mid_planes)
+        self.linear_v = nn.Linear(in_planes, out_planes)
+        self.linear_p = nn.Sequential(
+            nn.Linear(3, 3), LayerNorm1d(3), nn.ReLU(inplace=True), nn.Linear(3, out_planes)
+        )
+        self.linear_w = nn.Sequential(
+            LayerNorm1d(mid_planes),
+            nn.ReLU(inplace=True),
+            nn.Linear(mid_planes, out_planes // share_planes),
+            LayerNorm1d(out_planes // share_planes),
+            nn.ReLU(inplace=True),
+            nn.Linear(out_planes // share_planes, out_planes // share_planes),
+        )
+        self.softmax = nn.Softmax(dim=1)
+
+    def forward(self, pxo):
+        p, x, o = pxo  # (n, 3), (n, c), (b)
+        x_q, x_k, x_v = self.linear_q(x), self.linear_k(x), self.linear_v(x)
+        x_k, idx = pointops.knn_query_and_group(x_k, p, o, new_xyz=p, new_offset=o, nsample=self.nsample, with_xyz=True)
+        x_v, _ = pointops.knn_query_and_group(x_v, p, o, new_xyz=p, new_offset=o, idx=idx, nsample=self.nsample, with_xyz=False)
+        p_r, x_k = x_k[:, :, 0:3], x_k[:, :, 3:]
+        p_r = self.linear_p(p_r)  # (n, ns, c); out_planes == mid_planes so the (i j) reduction upstream is the identity
+        r_qk = x_k - x_q.unsqueeze(1) + p_r
+        w = self.softmax(self.linear_w(r_qk))  # (n, ns, c/s), softmax over the neighbour dim
+        n, ns, c = x_v.shape
+        s = self.share_planes
+        x = ((x_v + p_r).view(n, ns, s, c // s) * w.unsqueeze(2)).sum(1)  # einsum "n t s i, n t i -> n s i"
+        return x.reshape(n, c)
+
+
+class TransitionDown(nn.Module):
+    """point_transformer_seg.py:81-119"""
+
+    def __init__(self, in_planes, out_planes, stride=1, nsample=16):
+        super().__init__()
+        self.stride, self.nsample = stride, nsample
+        if stride != 1:
+            self.linear = nn.Linear(3 + in_planes, out_planes, bias=False)
+            self.pool = nn.MaxPool1d(nsample)
+        else:
+            self.linear = nn.Linear(in_planes, out_planes, bias=False)
+        self.bn = nn.BatchNorm1d(out_planes)
+        self.relu = nn.ReLU(inplace=True)
+
+    def _downsample(self, p, o):
+        tag = tag_of(p)
+        if tag is not None:
+            geom, level = tag
+            new_level, _ = geom.down(level, self.stride)
+            return geom.coord(new_level), geom.offset(new_level)
+        # untagged coordinates: the reference's own host-side offset arithmetic (:96-100)
+        ends = [int(v) for v in o.detach().cpu().tolist()]
+        n_o, count, prev = [], 0, 0
+        for e in ends:
+            count += (e - prev) // self.stride
+            prev = e
+            n_o.append(count)
+        n_o = torch.tensor(n_o, dtype=torch.int32, device=p.device)
+        idx = pointops.farthest_point_sampling(p, o, n_o)
+        return p[idx.long(), :].contiguous(), n_o
+
+    def forward(self, pxo):
+        p, x, o = pxo  # (n, 3), (n, c), (b)
+        if self.stride != 1:
+            n_p, n_o = self._downsample(p, o)
+            x, _ = pointops.knn_query_and_group(x, p, offset=o, new_xyz=n_p, new_offset=n_o, nsample=self.nsample, with_xyz=True)
+            m, ns = x.shape[0], x.shape[1]
+            y = self.relu(self.bn(self.linear(x).view(m * ns, -1)))  # BN over all m*ns rows == BN1d on (m, c, ns)
+            x = self.pool(y.view(m, ns, -1).transpose(1, 2)).squeeze(-1)  # (m, c)
+            p, o = n_p, n_o
+        else:
+            x = self.relu(self.bn(self.linear(x)))  # (n, c)
+        return [p, x, o]
+
+
+class TransitionUp(nn.Module):
+    """point_transformer_seg.py:122-168"""
+
+    def __init__(self, in_planes, out_planes=None):
+        super().__init__()
+        if out_planes is None:
+            self.linear1 = nn.Sequential(nn.Linear(2 * in_planes, in_planes), nn.BatchNorm1d(in_planes), nn.ReLU(inplace=True))
+            self.linear2 = nn.Sequential(nn.Linear(in_planes, in_planes), nn.ReLU(inplace=True))
+        else:
+            self.linear1 = nn.Sequential(nn.Linear(out_planes, out_planes), nn.BatchNorm1d(out_planes), nn.ReLU(inplace=True))
+            self.linear2 = nn.Sequential(nn.Linear(in_planes, out_planes), nn.BatchNorm1d(out_planes), nn.ReLU(inplace=True))
+
+    @staticmethod
+    def _scene_sizes(p, o):
+        tag = tag_of(p)
+        ends = tag[0].offset_host(tag[1]) if tag is not None else [int(v) for v in o.detach().cpu().tolist()]
+        return [ends[0]] + [ends[i] - ends[i - 1] for i in range(1, len(ends))]
+
+    def forward(self, pxo1, pxo2=None):
+        if pxo2 is None:
+            p, x, o = pxo1  # head: append the scene-mean context to every point (:148-161)
+            sizes = self._scene_sizes(p, o)
+            chunks = x.split(sizes, dim=0)
+            means = torch.cat([ch.sum(0, True) / ch.shape[0] for ch in chunks], 0)  # (b, c)
+            ctx = self.linear2(means)
+            rep = torch.repeat_interleave(ctx, torch.tensor(sizes, device=x.device), dim=0, output_size=x.shape[0])
+            x = self.linear1(torch.cat((x, rep), 1))
+        else:
+            p1, x1, o1 = pxo1
+            p2, x2, o2 = pxo2
+            x = self.linear1(x1) + pointops.interpolation(p2, p1, self.linear2(x2), o2, o1)
+        return x
+
+
+class Bottleneck(nn.Module):
+    """point_transformer_seg.py:171-192"""
+
+    expansion = 1
+
+    def __init__(self, in_planes, planes, share_planes=8, nsample=16):
+        super().__init__()
+        self.linear1 = nn.Linear(in_planes, planes, bias=False)
+        self.bn1 = nn.BatchNorm1d(planes)
+        self.transformer = PointTransformerLayer(planes, planes, share_planes, nsample)
+        self.bn2 = nn.BatchNorm1d(planes)
+        self.linear3 = nn.Linear(planes, planes * self.expansion, bias=False)
+        self.bn3 = nn.BatchNorm1d(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, pxo):
+        p, x, o = pxo
+        identity = x
+        x = self.relu(self.bn1(self.linear1(x)))
+        x = self.relu(self.bn2(self.transformer([p, x, o])))
+        x = self.bn3(self.linear3(x))
+        x = self.relu(x + identity)
+        return [p, x, o]
+
+
+class PointTransformerSeg(nn.Module):
+    """point_transformer_seg.py:195-303"""
+
+    def __init__(self, block, blocks, in_channels=6, num_classes=13):
+        super().__init__()
+        self.in_channels = in_channels
+        self.in_planes, planes = in_channels, [32, 64, 128, 256, 512]
+        share_planes = 8
+        stride, nsample = [1, 4, 4, 4, 4], [8, 16, 16, 16, 16]
+        self.strides, self.nsamples = stride, nsample
+        for i in range(5):  # enc1..enc5: N/1, N/4, N/16, N/64, N/256
+            setattr(self, f"enc{i + 1}", self._make_enc(block, planes[i], blocks[i], share_planes, stride[i], nsample[i]))
+        for i in range(4, -1, -1):  # dec5 (head: transform p5) .. dec1 (fusion p2 and p1)
+            setattr(self, f"dec{i + 1}", self._make_dec(block, planes[i], 1, share_planes, nsample[i], is_head=(i == 4)))
+        self.cls = nn.Sequential(
+            nn.Linear(planes[0], planes[0]), nn.BatchNorm1d(planes[0]), nn.ReLU(inplace=True), nn.Linear(planes[0], num_classes)
+        )
+        self._last_geometry = None
+
+    def _make_enc(self, block, planes, blocks, share_planes=8, stride=1, nsample=16):
+        layers = [TransitionDown(self.in_planes, planes * block.expansion, stride, nsample)]
+        self.in_planes = planes * block.expansion
+        layers += [block(self.in_planes, self.in_planes, share_planes, nsample=nsample) for _ in range(blocks)]
+        return nn.Sequential(*layers)
+
+    def _make_dec(self, block, planes, blocks, share_planes=8, nsample=16, is_head=False):
+        layers = [TransitionUp(self.in_planes, None if is_head else planes * block.expansion)]
+        self.in_planes = planes * block.expansion
+        layers += [block(self.in_planes, self.in_planes, share_planes, nsample=nsample) for _ in range(blocks)]
+        return nn.Sequential(*layers)
+
+    def geometry_for(self, data_dict):
+        """The batch's Geometry: reuse a prefetched one (``data_dict['pdf_geometry']``) or build it here."""
+        geom = data_dict.get("pdf_geometry") if isinstance(data_dict, dict) else None
+        if geom is None:
+            geom = Geometry(data_dict["coord"], data_dict["offset"], data_dict.get("offset_host"))
+            try:
+                data_dict["pdf_geometry"] = geom  # keeps the memo table alive for the recognizer pass
+            except TypeError:
+                pass
+        self._last_geometry = geom
+        return geom
+
+    def forward(self, data_dict):
+        geom = self.geometry_for(data_dict)
+        p0, o0 = geom.coord(0), geom.offset(0)
+        x0 = data_dict["feat"]
+        p1, x1, o1 = self.enc1([p0, x0, o0])
+        p2, x2, o2 = self.enc2([p1, x1, o1])
+        p3, x3, o3 = self.enc3([p2, x2, o2])
+        p4, x4, o4 = self.enc4([p3, x3, o3])
+        p5, x5, o5 = self.enc5([p4, x4, o4])
+        x5 = self.dec5[1:]([p5, self.dec5[0]([p5, x5, o5]), o5])[1]
+        x4 = self.dec4[1:]([p4, self.dec4[0]([p4, x4, o4], [p5, x5, o5]), o4])[1]
+        x3 = self.dec3[1:]([p3, self.dec3[0]([p3, x3, o3], [p4, x4, o4]), o3])[1]
+        x2 = self.dec2[1:]([p2, self.dec2[0]([p2, x2, o2], [p3, x3, o3]), o2])[1]
+        x1 = self.dec1[1:]([p1, self.dec1[0]([p1, x1, o1], [p2, x2, o2]), o1])[1]
+        return self.cls(x1)
+
+
+@MODELS.register_module("PointTransformer-Seg26")
+class PointTransformerSeg26(PointTransformerSeg):
+    def __init__(self, **kwargs):
+        super().__init__(Bottleneck, [1, 1, 1, 1, 1], **kwargs)
+
+
+@MODELS.register_module("PointTransformer-Seg38")
+class PointTransformerSeg38(PointTransformerSeg):
+    def __init__(self, **kwargs):
+        super().__init__(Bottleneck, [1, 2, 2, 2, 2], **kwargs)
+
+
+@MODELS.register_module("PointTransformer-Seg50")
+class PointTransformerSeg50(PointTransformerSeg):
+    def __init__(self, **kwargs):
+        super().__init__(Bottleneck, [1, 2, 3, 5, 2], **kwargs)

@@ -1,0 +1,378 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures by running the REFERENCE's own Python code.
+
+Run in the build container only (needs /root/reference):   python tests/golden/make_golden.py
+
+What is executed from /root/reference (imported in place, never copied; bytecode writing disabled):
+  * libs/pointops/functions/*.py            -- the reference's autograd wrappers and python helpers
+                                               (grouping(), interpolation(), knn_query_and_group(), ...)
+  * pointcept/models/point_transformer/{utils,point_transformer_seg}.py   -- PointTransformerSeg50
+  * pointcept/recognizers/recognizer_model/pt_v1.py                       -- PTRecognizer (PDF U-decoder)
+  * pointcept/models/utils/model_hook.py                                  -- BaseModelHook (forward-hook tap)
+  * pointcept/models/losses/{builder,misc}.py                             -- CrossEntropyLoss
+Three shims make that possible on a CUDA-less box:
+  1. ``pointops._C`` (the CUDA extension, unbuildable here) is a stub that calls oracle/liboracle.so, our C
+     restatement of the .cu kernels;
+  2. ``torch.cuda.IntTensor/FloatTensor`` are replaced by CPU constructors;
+  3. ``pointcept.models`` / ``pointcept.recognizers`` are pre-seeded as bare packages so their __init__ files
+     (which import spconv / torch_scatter / timm model families) are skipped.
+So the fixtures pin OUR host code (ops composition, modules, hooks, losses) against the reference's Python, with the
+kernel layer supplied by the oracle.  Inputs are regenerated from seeds by pointcloudpdf_amd.synthetic; weights by
+synthetic.fill_parameters_deterministic (name-keyed closed form) -- only expected outputs are stored.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+import oracle  # noqa: E402
+from pointcloudpdf_amd import synthetic  # noqa: E402
+
+# configuration shared with tests/test_model_parity.py
+MODEL_CASES = {
+    # name: (scene sizes, grid size used by the generator)
+    "b2_2048_1600": ([2048, 1600], 0.25),
+    "b1_3000": ([3000], 0.2),
+}
+ROW_STRIDE = 4      # big per-point tensors are stored every ROW_STRIDE-th row (tests slice the same way)
+GRAD_ROWS = 16      # big gradient matrices: first GRAD_ROWS rows + the full-tensor sum / L2 norm
+
+
+def thin(a):
+    """Row-subsample tensors with more than 1000 rows."""
+    return a[::ROW_STRIDE] if a.ndim >= 2 and a.shape[0] > 1000 else a
+
+
+def pack_grad(out, key, g):
+    g = np.asarray(g)
+    out[key] = g[:GRAD_ROWS] if g.ndim >= 2 else g
+    out[key + "#sum"] = np.array([g.astype(np.float64).sum(), np.sqrt((g.astype(np.float64) ** 2).sum())])
+
+
+GRAD_PARAMS = [
+    "enc1.0.linear.weight", "enc1.1.transformer.linear_q.weight", "enc1.1.transformer.linear_p.0.weight",
+    "enc1.1.transformer.linear_p.1.weight", "enc1.1.transformer.linear_w.2.weight", "enc1.1.transformer.linear_w.3.bias",
+    "enc2.0.linear.weight", "enc2.1.transformer.linear_k.weight", "enc2.2.transformer.linear_v.bias",
+    "enc3.0.bn.weight", "enc3.2.linear3.weight", "enc4.3.transformer.linear_w.5.weight", "enc5.0.linear.weight",
+    "enc5.2.bn3.bias", "dec5.0.linear2.0.weight", "dec5.0.linear1.0.weight", "dec4.0.linear2.0.weight",
+    "dec3.1.transformer.linear_p.3.weight", "dec2.0.linear1.1.weight", "dec1.1.linear1.weight", "cls.0.weight", "cls.3.bias",
+]
+REC_GRAD_PARAMS = ["dec5.linear1.0.weight", "dec4.linear2.0.weight", "dec3.linear2.1.weight", "dec2.linear1.0.bias",
+                   "dec1.linear2.0.weight", "confidence.0.weight", "confidence.3.weight"]
+
+
+# ------------------------------------------------------------------------------------------------ shims
+def install_reference():
+    be = oracle.backend()
+
+    C = types.ModuleType("pointops._C")  # signatures: libs/pointops/src/pointops_api.cpp:16-31
+
+    def knn_query_cuda(m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2):
+        i, d = be.knn_query(nsample, xyz.contiguous(), new_xyz.contiguous(), offset.contiguous(), new_offset.contiguous())
+        idx.copy_(i); dist2.copy_(d)
+
+    def farthest_point_sampling_cuda(b, n, xyz, offset, new_offset, tmp, idx):
+        be._call("farthest_point_sampling", int(b), int(n), xyz, offset.contiguous(), new_offset.contiguous(), tmp, idx)
+
+    def grouping_forward_cuda(m, nsample, c, input, idx, output):
+        be._call("grouping_forward", m, nsample, c, input, idx, output)
+
+    def grouping_backward_cuda(m, nsample, c, grad_output, idx, grad_input):
+        be._call("grouping_backward", m, nsample, c, grad_output.contiguous(), idx, grad_input)
+
+    def interpolation_forward_cuda(n, c, k, input, idx, weight, output):
+        be._call("interpolation_forward", n, c, k, input, idx, weight, output)
+
+    def interpolation_backward_cuda(n, c, k, grad_output, idx, weight, grad_input):
+        be._call("interpolation_backward", n, c, k, grad_output.contiguous(), idx, weight, grad_input)
+
+    def subtraction_forward_cuda(n, nsample, c, input1, input2, idx, output):
+        be._call("subtraction_forward", n, nsample, c, input1, input2, idx, output)
+
+    def subtraction_backward_cuda(n, nsample, c, idx, grad_output, grad_input1, grad_input2):
+        be._call("subtraction_backward", n, nsample, c, idx, grad_output.contiguous(), grad_input1, grad_input2)
+
+    def aggregation_forward_cuda(n, nsample, c, w_c, input, position, weight, idx, output):
+        be._call("aggregation_forward", n, nsample, c, w_c, input, position, weight, idx, output)
+
+    def aggregation_backward_cuda(n, nsample, c, w_c, input, position, weight, idx, grad_output, gi, gp, gw):
+        be._call("aggregation_backward", n, nsample, c, w_c, input, position, weight, idx, grad_output.contiguous(), gi, gp, gw)
+
+    def attention_relation_step_forward_cuda(m, g, c, query, key, weight, it, ir, output):
+        be._call("attention_relation_step_forward", m, g, c, query, key, weight, it, ir, output)
+
+    def attention_relation_step_backward_cuda(m, g, c, query, gq, key, gk, weight, gw, it, ir, grad_output):
+        be._call("attention_relation_step_backward", m, g, c, query, gq, key, gk, weight, gw, it, ir, grad_output.contiguous())
+
+    def attention_fusion_step_forward_cuda(m, g, c, weight, value, it, ir, output):
+        be._call("attention_fusion_step_forward", m, g, c, weight, value, it, ir, output)
+
+    def attention_fusion_step_backward_cuda(m, g, c, weight, gw, value, gv, it, ir, grad_output):
+        be._call("attention_fusion_step_backward", m, g, c, weight, gw, value, gv, it, ir, grad_output.contiguous())
+
+    def _absent(*a, **k):
+        raise NotImplementedError("ball queries are off the hot path")
+
+    for name, fn in list(locals().items()):
+        if name.endswith("_cuda"):
+            setattr(C, name, fn)
+    C.ball_query_cuda = _absent
+    C.random_ball_query_cuda = _absent
+
+    # shim 2: CPU constructors for torch.cuda.{Int,Float}Tensor
+    torch.cuda.IntTensor = lambda *a: torch.IntTensor(*a)
+    torch.cuda.FloatTensor = lambda *a: torch.FloatTensor(*a)
+
+    # shim 1: reference python wrappers on top of the stub
+    # (libs/pointops/setup.py:22-23 installs the ``functions`` directory AS the package ``pointops``)
+    sys.modules["pointops._C"] = C
+    fdir = os.path.join(REF, "libs", "pointops", "functions")
+    spec = importlib.util.spec_from_file_location("pointops", os.path.join(fdir, "__init__.py"),
+                                                  submodule_search_locations=[fdir])
+    ref_pointops = importlib.util.module_from_spec(spec)
+    sys.modules["pointops"] = ref_pointops
+    spec.loader.exec_module(ref_pointops)
+
+    # shim 3: bare packages, then load the few reference files we need by path
+    sys.path.insert(0, REF)
+    for pkg in ["pointcept.models", "pointcept.models.point_transformer", "pointcept.models.utils",
+                "pointcept.models.losses", "pointcept.recognizers", "pointcept.recognizers.recognizer_model"]:
+        m = types.ModuleType(pkg)
+        m.__path__ = [os.path.join(REF, *pkg.split("."))]
+        sys.modules[pkg] = m
+
+    def load(modname):
+        path = os.path.join(REF, *modname.split(".")) + ".py"
+        spec = importlib.util.spec_from_file_location(modname, path)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[modname] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    load("pointcept.models.builder")
+    load("pointcept.models.point_transformer.utils")
+    seg = load("pointcept.models.point_transformer.point_transformer_seg")
+    pt = sys.modules["pointcept.models.point_transformer"]
+    pt.TransitionUp, pt.Bottleneck = seg.TransitionUp, seg.Bottleneck
+    rec = load("pointcept.recognizers.recognizer_model.pt_v1")
+    hook = load("pointcept.models.utils.model_hook")
+    load("pointcept.models.losses.builder")
+    losses = load("pointcept.models.losses.misc")
+    return ref_pointops, seg, rec, hook, losses
+
+
+HOOK_CONFIG = {  # configs/s3dis/openseg-pt-v1-0-pointpdf-v1m1-base.py:11-27
+    **{f"backbone.enc{i}": ["forward_output"] for i in range(1, 6)},
+    **{f"backbone.dec{i}.1": ["forward_output"] for i in range(1, 6)},
+    "backbone": ["forward_output"],
+}
+
+
+class _Wrap(torch.nn.Module):  # gives the hooks the "backbone." prefix DefaultSegmentor would
+    def __init__(self, backbone):
+        super().__init__()
+        self.backbone = backbone
+
+    def forward(self, d):
+        return self.backbone(d)
+
+
+def run_model_case(seg, rec, hook, losses, sizes, grid_size, train):
+    batch = synthetic.make_batch(sizes, first_scene_id=100, grid_size=grid_size)
+    torch.manual_seed(0)
+    model = _Wrap(seg.PointTransformerSeg50(in_channels=6, num_classes=13))
+    recog = rec.PTRecognizer()
+    synthetic.fill_parameters_deterministic(model.backbone, seed=1)
+    synthetic.fill_parameters_deterministic(recog, seed=2)
+    model.train(train); recog.train(train)
+    calls = []
+    C = sys.modules["pointops._C"]
+    orig_knn, orig_fps = C.knn_query_cuda, C.farthest_point_sampling_cuda
+
+    # the wrappers bound the functions at import time -> patch the names inside functions.query / sampling
+    qmod, smod = sys.modules["pointops.query"], sys.modules["pointops.sampling"]
+
+    def spy_knn(m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2):
+        orig_knn(m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2)
+        calls.append(("knn", nsample, xyz.shape[0], new_xyz.shape[0], idx.clone()))
+
+    def spy_fps(b, n, xyz, offset, new_offset, tmp, idx):
+        orig_fps(b, n, xyz, offset, new_offset, tmp, idx)
+        calls.append(("fps", int(n), xyz.shape[0], idx.shape[0], idx.clone()))
+
+    qmod.knn_query_cuda, smod.farthest_point_sampling_cuda = spy_knn, spy_fps
+    mh = hook.BaseModelHook(HOOK_CONFIG, clone_tensor=True, exclude_clone={"backbone": ["forward_output"]},
+                            logger=hook.BaseModelHook._DummyLogger())
+    mh.model = model
+    out = {}
+    data = dict(coord=batch["coord"], feat=batch["feat"], offset=batch["offset"])
+    with mh:
+        logits = model(data)
+        conf = recog(mh)
+    qmod.knn_query_cuda, smod.farthest_point_sampling_cuda = orig_knn, orig_fps
+    out["logits"] = logits.detach().numpy()
+    out["conf"] = conf.detach().numpy()
+    for i in range(1, 6):
+        p, x, o = mh[f"backbone.enc{i}"]["forward_output"]
+        out[f"enc{i}_p"], out[f"enc{i}_x"], out[f"enc{i}_o"] = thin(p.detach().numpy()), thin(x.detach().numpy()), o.numpy()
+        out[f"dec{i}_x"] = thin(mh[f"backbone.dec{i}.1"]["forward_output"][1].detach().numpy())
+    # geometry census: FPS per level and the distinct kNN tables (first occurrence of each (k, n, m))
+    seen = {}
+    for kind, a, n, m, idx in calls:
+        seen.setdefault((kind, a, n, m), idx.numpy())
+    for (kind, a, n, m), idx in seen.items():
+        out[f"{kind}_{a}_{n}_{m}"] = idx
+    out["n_pointops_calls"] = np.array([sum(c[0] == "fps" for c in calls), sum(c[0] == "knn" for c in calls)])
+    # losses (DefaultSegmentor CE on known labels; PointPdfV1 CE on cat[logits, conf] with a fixed pseudo mask)
+    ce = losses.CrossEntropyLoss(loss_weight=1.0, ignore_index=-1)
+    seg_loss = ce(logits, batch["segment"])
+    pseudo_mask = (torch.arange(logits.shape[0]) % 7) == 3
+    segment_pseudo = batch["segment"].clone()
+    segment_pseudo[pseudo_mask] = 13
+    full = torch.cat([logits, conf], -1)
+    rec_loss = ce(full, segment_pseudo) * 0.1
+    out["seg_loss"], out["rec_loss"] = seg_loss.detach().numpy(), rec_loss.detach().numpy()
+    out["score"] = full.softmax(-1)[:, -1].detach().numpy()
+    out["msp_score"] = (-logits.log_softmax(-1).max(-1)[0]).detach().numpy()
+    if train:
+        (seg_loss + rec_loss).backward()
+        named = dict(model.backbone.named_parameters())
+        for k in GRAD_PARAMS:
+            pack_grad(out, "grad_" + k, named[k].grad.numpy())
+        rnamed = dict(recog.named_parameters())
+        for k in REC_GRAD_PARAMS:
+            pack_grad(out, "rgrad_" + k, rnamed[k].grad.numpy())
+        # BatchNorm running statistics after one training step (momentum update)
+        sd = model.backbone.state_dict()
+        for k in ["enc1.0.bn.running_mean", "enc2.1.transformer.linear_w.0.running_var", "dec1.1.bn2.running_var"]:
+            out["buf_" + k] = sd[k].numpy()
+    return out
+
+
+def run_op_cases(ref_pointops):
+    """Python-level reference ops (pure torch given idx) + every autograd wrapper, on seeded inputs."""
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    n, m, c, ns = 500, 200, 8, 8
+    xyz = torch.rand(n, 3, generator=g)
+    offset = torch.tensor([200, 500], dtype=torch.int32)
+    new_xyz = xyz[torch.cat([torch.arange(0, 200, 4), torch.arange(200, 500, 2)])].contiguous()
+    new_offset = torch.tensor([50, 200], dtype=torch.int32)
+    feat = torch.randn(n, c, generator=g)
+    idx, dist = ref_pointops.knn_query(ns, xyz, offset, new_xyz, new_offset)
+    out["knn_idx"], out["knn_dist"] = idx.numpy(), dist.numpy()
+    idx_pad = idx.clone(); idx_pad[::5, -2:] = -1  # placeholder rows
+    out["idx_pad"] = idx_pad.numpy()
+    out["grouping_xyz"] = ref_pointops.grouping(idx_pad, feat, xyz, new_xyz, with_xyz=True).numpy()
+    out["grouping_noxyz"] = ref_pointops.grouping(idx_pad, feat, xyz, new_xyz, with_xyz=False).numpy()
+    f = feat.clone().requires_grad_(True)
+    y = ref_pointops.grouping(idx_pad, f, xyz, new_xyz, with_xyz=True)
+    go = torch.randn(y.shape, generator=g)
+    y.backward(go)
+    out["grouping_go"], out["grouping_gfeat"] = go.numpy(), f.grad.numpy()
+    # interpolation: coarse (new_xyz) -> fine (xyz)
+    cf = torch.randn(m, c, generator=g).requires_grad_(True)
+    yi = ref_pointops.interpolation(new_xyz, xyz, cf, new_offset, offset)
+    gi = torch.randn(yi.shape, generator=g)
+    yi.backward(gi)
+    out["interp_feat"], out["interp_out"], out["interp_go"], out["interp_gfeat"] = cf.detach().numpy(), yi.detach().numpy(), gi.numpy(), cf.grad.numpy()
+    cf2 = cf.detach().clone().requires_grad_(True)
+    yi2 = ref_pointops.interpolation2(new_xyz, xyz, cf2, new_offset, offset)
+    yi2.backward(gi)
+    out["interp2_out"], out["interp2_gfeat"] = yi2.detach().numpy(), cf2.grad.numpy()
+    # grouping2 / subtraction / aggregation with a self-kNN table
+    sidx, _ = ref_pointops.knn_query(ns, xyz, offset)
+    out["self_idx"] = sidx.numpy()
+    f2 = feat.clone().requires_grad_(True)
+    y2 = ref_pointops.grouping2(f2, sidx)
+    g2 = torch.randn(y2.shape, generator=g)
+    y2.backward(g2)
+    out["grouping2_out"], out["grouping2_go"], out["grouping2_gin"] = y2.detach().numpy(), g2.numpy(), f2.grad.numpy()
+    a = torch.randn(n, c, generator=g).requires_grad_(True)
+    b = torch.randn(n, c, generator=g).requires_grad_(True)
+    ys = ref_pointops.subtraction(a, b, sidx)
+    gs = torch.randn(ys.shape, generator=g)
+    ys.backward(gs)
+    out["sub_a"], out["sub_b"], out["sub_out"], out["sub_go"] = a.detach().numpy(), b.detach().numpy(), ys.detach().numpy(), gs.numpy()
+    out["sub_ga"], out["sub_gb"] = a.grad.numpy(), b.grad.numpy()
+    inp = torch.randn(n, c, generator=g).requires_grad_(True)
+    pos = torch.randn(n, ns, c, generator=g).requires_grad_(True)
+    w = torch.randn(n, ns, c // 4, generator=g).requires_grad_(True)
+    ya = ref_pointops.aggregation(inp, pos, w, sidx)
+    ga = torch.randn(ya.shape, generator=g)
+    ya.backward(ga)
+    for k_, v in dict(agg_in=inp, agg_pos=pos, agg_w=w, agg_out=ya).items():
+        out[k_] = v.detach().numpy()
+    out["agg_go"], out["agg_gin"], out["agg_gpos"], out["agg_gw"] = ga.numpy(), inp.grad.numpy(), pos.grad.numpy(), w.grad.numpy()
+    # attention steps on a random edge list
+    E, G, CC = 900, 4, 6
+    q = torch.randn(n, G, CC, generator=g).requires_grad_(True)
+    k = torch.randn(n, G, CC, generator=g).requires_grad_(True)
+    aw = torch.randn(CC, generator=g)
+    it = torch.randint(0, n, (E,), generator=g, dtype=torch.int32)
+    ir = torch.randint(0, n, (E,), generator=g, dtype=torch.int32)
+    yr = ref_pointops.attention_relation_step(q, k, aw, it, ir)
+    gr = torch.randn(yr.shape, generator=g)
+    yr.backward(gr)
+    for k_, v in dict(att_q=q, att_k=k, att_w=aw, att_it=it, att_ir=ir, rel_out=yr, rel_go=gr, rel_gq=q.grad, rel_gk=k.grad).items():
+        out[k_] = v.detach().numpy()
+    ew = torch.randn(E, G, generator=g).requires_grad_(True)
+    v = torch.randn(n, G, CC, generator=g).requires_grad_(True)
+    yf = ref_pointops.attention_fusion_step(ew, v, it, ir)
+    gf = torch.randn(yf.shape, generator=g)
+    yf.backward(gf)
+    for k_, vv in dict(fus_w=ew, fus_v=v, fus_out=yf, fus_go=gf, fus_gw=ew.grad, fus_gv=v.grad).items():
+        out[k_] = vv.detach().numpy()
+    # inputs that are cheap to store rather than re-derive
+    out["xyz"], out["new_xyz"], out["feat"] = xyz.numpy(), new_xyz.numpy(), feat.numpy()
+    out["offset"], out["new_offset"] = offset.numpy(), new_offset.numpy()
+    # query_and_group with dilation, batch/offset converters
+    qg, qidx = ref_pointops.query_and_group(4, xyz, new_xyz, feat, None, offset, new_offset, dilation=1)
+    out["qg_out"], out["qg_idx"] = qg.numpy(), qidx.numpy()
+    out["offset2batch"] = ref_pointops.offset2batch(offset).numpy()
+    out["batch2offset"] = ref_pointops.batch2offset(ref_pointops.offset2batch(offset)).numpy()
+    return out
+
+
+def run_hook_case(hook):
+    """BaseModelHook on a toy module: forward/backward capture + clone semantics."""
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 5), torch.nn.ReLU(), torch.nn.Linear(5, 2))
+    synthetic.fill_parameters_deterministic(net, seed=5)
+    mh = hook.BaseModelHook({"0": ["forward_output", "backward_outputGrad"], "2": ["forward_input"]},
+                            logger=hook.BaseModelHook._DummyLogger())
+    mh.model = net
+    x = torch.arange(12, dtype=torch.float32).view(3, 4) / 10
+    with mh:
+        y = net(x)
+        y.sum().backward()
+    return dict(x=x.numpy(), fo0=mh["0"]["forward_output"].detach().numpy(),
+                bo0=mh["0"]["backward_outputGrad"].detach().numpy(), fi2=mh["2"]["forward_input"].detach().numpy())
+
+
+def main():
+    ref_pointops, seg, rec, hook, losses = install_reference()
+    np.savez_compressed(os.path.join(OUT, "ops_python_ref.npz"), **run_op_cases(ref_pointops))
+    np.savez_compressed(os.path.join(OUT, "model_hook_ref.npz"), **run_hook_case(hook))
+    for name, (sizes, gs) in MODEL_CASES.items():
+        for train in (True, False):
+            res = run_model_case(seg, rec, hook, losses, sizes, gs, train)
+            np.savez_compressed(os.path.join(OUT, f"model_{name}_{'train' if train else 'eval'}.npz"), **res)
+            print(name, "train" if train else "eval", "calls fps/knn:", res["n_pointops_calls"],
+                  "loss", float(res["seg_loss"]), float(res["rec_loss"]))
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()
