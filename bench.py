@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Headline benchmark: PointTransformer-V1 Seg50 + PDF U-decoder, one training step (fwd + bwd + SGD update) on
+S3DIS-shaped synthetic scenes of 100k points, bs = 2 scenes per GPU (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one pass of the hot path over one batch that is already resident in HBM: geometry pre-pass (4 FPS + the
+13 distinct kNN tables + interpolation tables), Seg50 forward, U-decoder forward, CE + PDF loss, backward (DDP gradient
+all-reduce over RCCL when N > 1), SGD update.  Every step gets a different batch from a small rotating pool and builds
+a fresh Geometry -- nothing is cached across steps.  K steps are timed between barrier + synchronize pairs; the MAX over
+ranks is reported; value = (points processed by all ranks) / time.
+
+The JSON line also carries
+  * "roofline": the dominant kernel's achieved algorithmic HBM GB/s (SURVEY.md 8d byte counts / HIP-event time of that
+    kernel measured live on the stream it runs on) against the 8 TB/s HBM3E peak;
+  * "cpu_baseline": the CPU oracle (reference algorithms: brute-force kNN, iterative FPS, torch-CPU layers) timed on
+    this host's cores on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=100000, help="points per scene")
+    ap.add_argument("--scenes", type=int, default=2, help="scenes per GPU (batch size per rank)")
+    ap.add_argument("--pool", type=int, default=3, help="distinct batches per rank to rotate through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-points", type=int, default=16000, help="scene size of the bounded CPU-baseline sample")
+    ap.add_argument("--amp", action="store_true", help="fp16 autocast around the step (reference enable_amp=True)")
+    return ap.parse_args()
+
+
+class KernelTimer:
+    """HIP-event timing of individual backend calls on torch's current stream (the stream the kernels are launched on)."""
+
+    def __init__(self, backend, names):
+        self.backend, self.names = backend, names
+        self.records = {n: [] for n in names}
+        self.enabled = False
+        self._orig = {}
+
+    def install(self):
+        for n in self.names:
+            orig = getattr(self.backend, n)
+            self._orig[n] = orig
+
+            def wrapped(*a, _orig=orig, _n=n, **k):
+                if not self.enabled:
+                    return _orig(*a, **k)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = _orig(*a, **k)
+                e1.record()
+                self.records[_n].append((e0, e1, self._bytes(_n, a, out)))
+                return out
+
+            setattr(self.backend, n, wrapped)
+
+    @staticmethod
+    def _bytes(name, args, out):
+        """Algorithmic HBM bytes of one call."""
+        if name == "knn_query":  # 12N + 12M + 8B + 8Mk
+            k, xyz, new_xyz, offset = args[0], args[1], args[2], args[3]
+            return 12 * xyz.shape[0] + 12 * new_xyz.shape[0] + 8 * offset.shape[0] + 8 * new_xyz.shape[0] * k
+        if name == "farthest_point_sampling":  # 12N + 4M'
+            return 12 * args[0].shape[0] + 4 * out.shape[0]
+        if name == "group_forward":  # table once + idx + output (+ xyz / new_xyz / rel-xyz when with_xyz)
+            feat, xyz, new_xyz, idx, with_xyz = args
+            m, ns = idx.shape
+            b = 4 * feat.numel() + 4 * idx.numel() + 4 * m * ns * feat.shape[1]
+            if with_xyz:
+                b += 12 * xyz.shape[0] + 12 * m + 12 * m * ns
+            return b
+        if name == "group_backward":
+            go, idx, n, c, with_xyz = args
+            return 4 * go.numel() + 4 * idx.numel() + 4 * n * c
+        return 0
+
+    def summary(self):
+        out = {}
+        for n, recs in self.records.items():
+            if not recs:
+                continue
+            ms = [e0.elapsed_time(e1) for e0, e1, _ in recs]
+            out[n] = dict(calls=len(recs), total_ms=sum(ms), avg_ms=sum(ms) / len(ms),
+                          avg_bytes=sum(b for _, _, b in recs) / len(recs))
+        return out
+
+
+def cpu_baseline(points):
+    """The oracle (a port of the reference algorithms) on this host's cores: one training step on a bounded sample."""
+    import oracle
+    from pointcloudpdf_amd import _native, engine, synthetic
+
+    be = oracle.backend()
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    be.set_num_threads(cores)
+    prev = _native._set_backend_for_testing(be)
+    try:
+        step = engine.OpenSegStep()
+        synthetic.fill_parameters_deterministic(step, seed=1)
+        step.train()
+        batch = synthetic.make_batch([points], first_scene_id=900)
+        t0 = time.perf_counter()
+        out = step(batch)
+        out["loss"].backward()
+        dt = time.perf_counter() - t0
+    finally:
+        _native._set_backend_for_testing(prev)
+    return dict(value=points / dt, unit="points/s", cores=cores, kind="port",
+                sample=f"1 step (fwd+bwd) on 1 synthetic scene of {points} points, CPU oracle ops (brute-force kNN, "
+                       f"iterative FPS; quadratic in scene size) + torch-CPU layers, {dt:.1f} s wall")
+
+
+def main():
+    args = parse()
+    from pointcloudpdf_amd import _native, engine, synthetic
+
+    rank, local_rank, world = engine.init_distributed()
+    assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (the HIP path has no CPU fallback)"
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    torch.backends.cuda.matmul.allow_tf32 = False
+    be = _native.hip_backend()
+
+    step = engine.OpenSegStep().to(dev)
+    synthetic.fill_parameters_deterministic(step, seed=1)  # identical "random-init" weights on every rank
+    step.train()
+    module = engine.wrap_ddp(step, dev) if world > 1 else step
+    opt = torch.optim.SGD(step.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+
+    sizes = [args.points] * args.scenes
+    pool = [synthetic.make_batch(sizes, first_scene_id=1000 * rank + 10 * i, device=dev) for i in range(args.pool)]
+    timer = KernelTimer(be, ["knn_query", "farthest_point_sampling", "group_forward", "group_backward"])
+    timer.install()
+
+    def one_step(i):
+        batch = pool[i % len(pool)]
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16, enabled=args.amp):
+            out = module(dict(coord=batch["coord"], feat=batch["feat"], offset=batch["offset"],
+                              offset_host=batch["offset_host"], segment=batch["segment"]))
+        out["loss"].backward()
+        opt.step()
+        return out
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    fence()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = one_step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(out["loss"].item())
+
+    if rank == 0:
+        pts_per_step = args.points * args.scenes * world
+        ks = timer.summary()
+        dom = max(ks, key=lambda n: ks[n]["total_ms"]) if ks else None
+        roof = None
+        if dom:
+            achieved = ks[dom]["avg_bytes"] / (ks[dom]["avg_ms"] * 1e-3) / 1e9
+            roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=achieved / HBM_PEAK_GBS, traffic=None, avg_launch_ms=ks[dom]["avg_ms"],
+                        launches_per_step=ks[dom]["calls"] / args.steps,
+                        share_of_step=ks[dom]["total_ms"] / (dt * 1e3))
+        line = {
+            "metric": "points/sec fwd+bwd (PT-v1 Seg50 + PDF U-decoder, 100k-pt scenes)",
+            "value": pts_per_step * args.steps / dt,
+            "unit": "points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16-autocast" if args.amp else "f32",
+            "data": "synthetic",
+            "config": {"workload": f"S3DIS-shaped synthetic voxelised scenes, {args.scenes} x {args.points} points per GPU, "
+                                   "PointTransformer-Seg50 + PointPdf-v1m1 U-decoder, fwd+bwd+SGD, geometry recomputed every step",
+                       "scenes_per_gpu": args.scenes, "points_per_scene": args.points, "parallelism": f"dp{world}"},
+            "per_gpu_points_per_s": pts_per_step * args.steps / dt / world,
+            "loss": loss,
+            "kernels": ks,
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_points)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,91 @@
+"""One open-world training step of the hot path, as a single module (so ONE DistributedDataParallel reducer covers
+segmentor + U-decoder; the reference wraps them separately: pointcept/engines/train.py:218-222 and :419-423).
+
+``OpenSegStep.forward(batch)`` == ``OpenSegTrainer.model_forward`` (engines/train.py:373-380): label_rename
+(segment := segment_known, :387-391), segmentor forward + CE, recognizer forward (+ PDF loss), summed loss.
+Whole scenes are the sharding unit: each rank runs its own scenes, gradients are the only thing exchanged
+(DDP all-reduce over RCCL/xGMI), BatchNorm statistics stay per rank (sync_bn=False, broadcast_buffers=False upstream).
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from . import point_transformer, recognizer, segmentor  # noqa: F401  (registers the classes)
+from .model_hook import BaseModelHook
+from .registry import MODELS, RECOGNIZER
+
+PT_V1_HOOKS = {  # configs/s3dis/openseg-pt-v1-0-pointpdf-v1m1-base.py:11-27
+    **{f"backbone.enc{i}": ["forward_output"] for i in range(1, 6)},
+    **{f"backbone.dec{i}.1": ["forward_output"] for i in range(1, 6)},
+    "backbone": ["forward_output"],
+}
+
+
+def default_pseudo_mask(coord, seg_logits, offset):
+    """Stand-in for the PDF pseudo-label pass (scope row f-2): a fixed 1-in-7 pattern."""
+    return (torch.arange(coord.shape[0], device=coord.device) % 7) == 3
+
+
+class OpenSegStep(nn.Module):
+    def __init__(self, backbone="PointTransformer-Seg50", in_channels=6, num_classes=13, loss_weight=0.1,
+                 start_epoch=0, pseudo_mask_fn=default_pseudo_mask):
+        super().__init__()
+        ce = [dict(type="CrossEntropyLoss", loss_weight=1.0, ignore_index=-1)]
+        self.model = MODELS.build(dict(type="DefaultSegmentor",
+                                       backbone=dict(type=backbone, in_channels=in_channels, num_classes=num_classes),
+                                       criteria=ce))
+        self.recognizer = RECOGNIZER.build(dict(type="PointPdf-v1m1", recognizer=dict(type="PointTransformer-Recognizer"),
+                                                criteria=ce, loss_weight=loss_weight, step_loss_weight=False,
+                                                num_classes=num_classes, start_epoch=start_epoch,
+                                                pseudo_mask_fn=pseudo_mask_fn))
+        self.hooks = BaseModelHook(PT_V1_HOOKS, clone_tensor=True, exclude_clone={"backbone": ["forward_output"]})
+        self.hooks.set_model(self.model)
+        self.recognizer.model_hooks = self.hooks
+        self.recognizer.set_epoch(start_epoch)
+        self.recognizer.trigger_operation()  # release the U-decoder parameters before DDP sees them
+
+    def forward(self, batch):
+        input_dict = dict(batch)
+        if "segment_known" in input_dict:
+            input_dict["segment"] = input_dict["segment_known"]
+        with self.hooks:
+            out = self.model(input_dict)
+            rec = self.recognizer(input_dict)
+        loss = out["loss"]
+        if "loss" in rec:
+            loss = loss + rec["loss"]
+        return dict(loss=loss, model_loss=out["loss"].detach(), recognizer_loss=rec.get("loss", loss.new_zeros(())).detach(),
+                    score=rec["score"].detach())
+
+
+def wrap_ddp(module, device):
+    """DDP over RCCL: one flat bucket (34 MB of fp32 gradients), bucket views, per-rank BN buffers."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    if device.type == "cuda":
+        return DDP(module, device_ids=[device.index], broadcast_buffers=False, bucket_cap_mb=64,
+                   gradient_as_bucket_view=True)
+    return DDP(module, broadcast_buffers=False, bucket_cap_mb=64, gradient_as_bucket_view=True)
+
+
+def shard_scene_ids(num_scenes, rank, world_size):
+    """Whole scenes are the sharding unit (engines/defaults.py:139 + DistributedSampler, engines/train.py:437-438)."""
+    return list(range(rank, num_scenes, world_size))
+
+
+def init_distributed():
+    """Read the torchrun environment; returns (rank, local_rank, world_size). Backend 'nccl' is RCCL on ROCm."""
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world_size)
+    return rank, local_rank, world_size

@@ -1,0 +1,305 @@
+"""GPU suite: the HIP kernels behind the C ABI (include/pdfops.h) against the CPU oracle on identical seeded inputs.
+kNN / FPS indices: bit-exact.  Gathers/subtractions: bit-exact.  FMA-reordered sums and atomic scatters: 1e-5/1e-6."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from pointcloudpdf_amd import _native
+
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    be = _native.hip_backend()  # raises if libpdfops.so is missing: no fallback
+    assert be.lib.pdf_abi_version() >= 1
+    return be
+
+
+def cloud(n, seed, snap=0):
+    rng = np.random.default_rng(seed)
+    xyz = rng.random((n, 3)).astype(np.float32) * np.array([8, 6, 3], dtype=np.float32)
+    if snap:
+        xyz = (np.floor(xyz * snap) / snap).astype(np.float32)
+    return torch.from_numpy(xyz)
+
+
+def offs(sizes):
+    return torch.tensor(np.cumsum(sizes), dtype=torch.int32)
+
+
+def both_knn(hip, oracle_backend, k, xyz, new_xyz, off, noff):
+    i_o, d_o = oracle_backend.knn_query(k, xyz, new_xyz, off, noff)
+    i_h, d_h = hip.knn_query(k, xyz.to(DEV), new_xyz.to(DEV), off.to(DEV), noff.to(DEV))
+    torch.cuda.synchronize()
+    return i_o, d_o, i_h.cpu(), d_h.cpu()
+
+
+@pytest.mark.parametrize("k", [1, 3, 8, 16, 33, 128])
+@pytest.mark.parametrize("snap", [0, 5])
+def test_knn_bit_exact(hip, oracle_backend, k, snap):
+    sizes = [1500, 37, 2900, 600]
+    xyz = cloud(sum(sizes), 11 + k, snap)
+    off = offs(sizes)
+    i_o, d_o, i_h, d_h = both_knn(hip, oracle_backend, k, xyz, xyz, off, off)
+    assert torch.equal(i_o, i_h), f"kNN idx mismatch rows: {(i_o != i_h).any(1).sum().item()}"
+    assert torch.equal(d_o, d_h)
+
+
+def test_knn_cross_queries_and_placeholders(hip, oracle_backend):
+    sizes, qsizes = [900, 5, 2000], [200, 5, 333]
+    xyz = cloud(sum(sizes), 3)
+    sel = torch.cat([torch.arange(0, 200), torch.arange(900, 905), 905 + torch.arange(0, 333) * 5])
+    new_xyz = xyz[sel].contiguous()
+    i_o, d_o, i_h, d_h = both_knn(hip, oracle_backend, 16, xyz, new_xyz, offs(sizes), offs(qsizes))
+    assert torch.equal(i_o, i_h) and torch.equal(d_o, d_h)
+    assert (i_h[200:205, 5:] == -1).all() and (d_h[200:205, 5:] == 1e10).all()
+
+
+def test_knn_many_tiny_scenes_in_one_wave(hip, oracle_backend):
+    sizes = [7, 1, 12, 3, 30, 2, 9, 64, 5, 11] * 6
+    xyz = cloud(sum(sizes), 21, snap=3)
+    off = offs(sizes)
+    i_o, d_o, i_h, d_h = both_knn(hip, oracle_backend, 8, xyz, xyz, off, off)
+    assert torch.equal(i_o, i_h) and torch.equal(d_o, d_h)
+
+
+def test_knn_rejects_bad_arguments(hip):
+    from pointcloudpdf_amd._native import PdfOpsError
+
+    xyz = torch.rand(10, 3, device=DEV)
+    off = torch.tensor([10], dtype=torch.int32, device=DEV)
+    with pytest.raises(ValueError):
+        hip.knn_query(129, xyz, xyz, off, off)
+    with pytest.raises(PdfOpsError):
+        hip.knn_query(3, xyz.cpu(), xyz.cpu(), off.cpu(), off.cpu())  # CPU tensors: loud failure, no fallback
+
+
+def test_knn_full_size_properties(hip, oracle_backend):
+    """BASELINE config-2 size (2 x 100k, k=8): structure everywhere + oracle equality on a query sample."""
+    from pointcloudpdf_amd import synthetic
+
+    batch = synthetic.make_batch([100000, 100000], first_scene_id=0)
+    xyz, off = batch["coord"], batch["offset"]
+    idx, d2 = hip.knn_query(8, xyz.to(DEV), xyz.to(DEV), off.to(DEV), off.to(DEV))
+    idx, d2 = idx.cpu(), d2.cpu()
+    assert (d2[:, 1:] >= d2[:, :-1]).all()  # ascending
+    assert (idx[:100000] < 100000).all() and (idx[100000:] >= 100000).all() and (idx >= 0).all()
+    assert (idx[:, 0] == torch.arange(200000)).float().mean() > 0.999  # self is the nearest (d=0) unless duplicates
+    assert (d2[:, 0] == 0).all()
+    q = torch.cat([torch.arange(0, 100000, 997), torch.arange(100000, 200000, 991)])
+    noff = torch.tensor([(q < 100000).sum().item(), q.numel()], dtype=torch.int32)
+    i_o, d_o = oracle_backend.knn_query(8, xyz, xyz[q].contiguous(), off, noff)
+    assert torch.equal(i_o, idx[q]) and torch.equal(d_o, d2[q])
+
+
+# ----------------------------------------------------------------------------------------------- FPS
+def both_fps(hip, oracle_backend, xyz, sizes, msizes):
+    off, noff = offs(sizes), offs(msizes)
+    n_max, m_total = max(sizes), sum(msizes)
+    f_o = oracle_backend.farthest_point_sampling(xyz, off, noff, n_max, m_total)
+    res = {}
+    for mode in ("plain", "bucketed"):
+        hip.fps_mode = mode
+        res[mode] = hip.farthest_point_sampling(xyz.to(DEV), off.to(DEV), noff.to(DEV), n_max, m_total).cpu()
+    hip.fps_mode = "bucketed"
+    return f_o, res
+
+
+@pytest.mark.parametrize("sizes", [[1000], [4096 + 7], [37], [300, 1500, 64], [2048, 1600], [25000], [6250, 6100]])
+@pytest.mark.parametrize("snap", [0, 6])
+def test_fps_bit_exact(hip, oracle_backend, sizes, snap):
+    xyz = cloud(sum(sizes), 5 + len(sizes), snap)
+    msizes = [max(s // 4, 1) for s in sizes]
+    f_o, res = both_fps(hip, oracle_backend, xyz, sizes, msizes)
+    for mode, f_h in res.items():
+        bad = (f_o != f_h).nonzero()
+        assert torch.equal(f_o, f_h), f"{mode}: first mismatch at sample {bad[0].item() if len(bad) else -1} of {f_o.numel()}"
+
+
+def test_fps_single_sample_and_duplicates(hip, oracle_backend):
+    xyz = torch.cat([cloud(50, 1), cloud(50, 1)])  # every point duplicated: zero distances, ties everywhere
+    f_o, res = both_fps(hip, oracle_backend, xyz, [100], [100])
+    for f_h in res.values():
+        assert torch.equal(f_o, f_h)
+    f_o, res = both_fps(hip, oracle_backend, cloud(10, 2), [10], [1])
+    for f_h in res.values():
+        assert torch.equal(f_o, f_h) and f_h.tolist() == [0]
+
+
+def test_fps_full_size_100k(hip, oracle_backend):
+    """Level-1 FPS of the headline config (100k -> 25k) against the oracle's lock-step emulation."""
+    from pointcloudpdf_amd import synthetic
+
+    xyz = torch.from_numpy(synthetic.make_scene(100000, 7)["coord"])
+    f_o, res = both_fps(hip, oracle_backend, xyz, [100000], [25000])
+    for mode, f_h in res.items():
+        assert torch.equal(f_o, f_h), mode
+    # size-independent properties: unique samples, first sample is point 0, min pairwise distance decreases
+    f = res["bucketed"].long()
+    assert f[0] == 0 and f.unique().numel() == f.numel()
+
+
+# ----------------------------------------------------------------------------------------------- gather family
+@pytest.fixture(scope="module")
+def table(hip, oracle_backend):
+    sizes = [700, 1300]
+    xyz = cloud(sum(sizes), 9)
+    off = offs(sizes)
+    idx, _ = oracle_backend.knn_query(16, xyz, xyz, off, off)
+    idx_pad = idx.clone()
+    idx_pad[::7, -3:] = -1
+    return xyz, off, idx, idx_pad
+
+
+@pytest.mark.parametrize("c", [32, 6, 3, 1, 64])
+def test_grouping2_fwd_bwd(hip, oracle_backend, table, c):
+    xyz, off, idx, _ = table
+    g = torch.Generator().manual_seed(c)
+    x = torch.randn(xyz.shape[0], c, generator=g)
+    y_o = oracle_backend.grouping_forward(x, idx)
+    y_h = hip.grouping_forward(x.to(DEV), idx.to(DEV)).cpu()
+    assert torch.equal(y_o, y_h)
+    go = torch.randn(y_o.shape, generator=g)
+    g_o = oracle_backend.grouping_backward(go, idx, x.shape[0])
+    g_h = hip.grouping_backward(go.to(DEV), idx.to(DEV), x.shape[0]).cpu()
+    assert_close(g_h, g_o, 1e-5, "grouping bwd")
+
+
+@pytest.mark.parametrize("c,with_xyz", [(32, True), (32, False), (6, True), (5, False)])
+def test_group_fused_twin(hip, oracle_backend, table, c, with_xyz):
+    """pdf_group_forward/backward == the reference's python grouping() (composition, run on the CPU through torch)."""
+    from pointcloudpdf_amd import pointops, _native
+
+    xyz, off, _, idx_pad = table
+    g = torch.Generator().manual_seed(c)
+    feat = torch.randn(xyz.shape[0], c, generator=g)
+    new_xyz = xyz + 0.01
+    prev = _native._set_backend_for_testing(oracle_backend)
+    try:
+        f_c = feat.clone().requires_grad_(True)
+        y_c = pointops.grouping(idx_pad, f_c, xyz, new_xyz, with_xyz=with_xyz)
+        go = torch.randn(y_c.shape, generator=g)
+        y_c.backward(go)
+    finally:
+        _native._set_backend_for_testing(prev)
+    f_d = feat.to(DEV).requires_grad_(True)
+    y_d = pointops.grouping(idx_pad.to(DEV), f_d, xyz.to(DEV), new_xyz.to(DEV), with_xyz=with_xyz)
+    assert torch.equal(y_d.detach().cpu(), y_c.detach())
+    y_d.backward(go.to(DEV))
+    assert_close(f_d.grad.cpu(), f_c.grad, 1e-5, "group bwd")
+
+
+@pytest.mark.parametrize("c,k", [(32, 3), (64, 3), (7, 5), (512, 3)])
+def test_interpolation2_fwd_bwd(hip, oracle_backend, c, k):
+    xyz = cloud(3000, 4)
+    off = offs([1000, 2000])
+    coarse = xyz[::4].contiguous()
+    coff = offs([250, 500])
+    idx, d2 = oracle_backend.knn_query(k, coarse, xyz, coff, off)
+    w = 1.0 / (torch.sqrt(d2) + 1e-8)
+    w = w / w.sum(1, keepdim=True)
+    w_h = hip.interpolation_weights(d2.to(DEV)).cpu()
+    assert_close(w_h, w, 1e-6, "interp weights")
+    g = torch.Generator().manual_seed(c)
+    x = torch.randn(coarse.shape[0], c, generator=g)
+    y_o = oracle_backend.interpolation_forward(x, idx, w)
+    y_h = hip.interpolation_forward(x.to(DEV), idx.to(DEV), w.to(DEV)).cpu()
+    assert_close(y_h, y_o, 1e-6, "interp fwd")
+    go = torch.randn(y_o.shape, generator=g)
+    g_o = oracle_backend.interpolation_backward(go, idx, w, x.shape[0])
+    g_h = hip.interpolation_backward(go.to(DEV), idx.to(DEV), w.to(DEV), x.shape[0]).cpu()
+    assert_close(g_h, g_o, 1e-5, "interp bwd")
+
+
+@pytest.mark.parametrize("c", [32, 10])
+def test_subtraction_fwd_bwd(hip, oracle_backend, table, c):
+    xyz, off, idx, _ = table
+    g = torch.Generator().manual_seed(c)
+    a, b = torch.randn(xyz.shape[0], c, generator=g), torch.randn(xyz.shape[0], c, generator=g)
+    y_o = oracle_backend.subtraction_forward(a, b, idx)
+    y_h = hip.subtraction_forward(a.to(DEV), b.to(DEV), idx.to(DEV)).cpu()
+    assert torch.equal(y_o, y_h)
+    go = torch.randn(y_o.shape, generator=g)
+    g1_o, g2_o = oracle_backend.subtraction_backward(idx, go)
+    g1_h, g2_h = hip.subtraction_backward(idx.to(DEV), go.to(DEV))
+    assert_close(g1_h.cpu(), g1_o, 1e-5, "sub g1")
+    assert_close(g2_h.cpu(), g2_o, 1e-5, "sub g2")
+
+
+@pytest.mark.parametrize("c,w_c", [(32, 4), (64, 8), (24, 24)])
+def test_aggregation_fwd_bwd(hip, oracle_backend, table, c, w_c):
+    xyz, off, idx, _ = table
+    n, ns = idx.shape
+    g = torch.Generator().manual_seed(c)
+    x, pos, w = torch.randn(n, c, generator=g), torch.randn(n, ns, c, generator=g), torch.randn(n, ns, w_c, generator=g)
+    y_o = oracle_backend.aggregation_forward(x, pos, w, idx)
+    y_h = hip.aggregation_forward(x.to(DEV), pos.to(DEV), w.to(DEV), idx.to(DEV)).cpu()
+    assert_close(y_h, y_o, 1e-6, "agg fwd")
+    go = torch.randn(n, c, generator=g)
+    o = oracle_backend.aggregation_backward(x, pos, w, idx, go)
+    h = hip.aggregation_backward(x.to(DEV), pos.to(DEV), w.to(DEV), idx.to(DEV), go.to(DEV))
+    for a, b, nm in zip(h, o, ["gi", "gp", "gw"]):
+        assert_close(a.cpu(), b, 1e-5, "agg " + nm)
+
+
+def test_attention_steps_fwd_bwd(hip, oracle_backend):
+    g = torch.Generator().manual_seed(1)
+    n, E, G, C = 600, 5000, 4, 8
+    q, k, v = (torch.randn(n, G, C, generator=g) for _ in range(3))
+    aw = torch.randn(C, generator=g)
+    it = torch.randint(0, n, (E,), generator=g, dtype=torch.int32)
+    ir = torch.randint(0, n, (E,), generator=g, dtype=torch.int32)
+    d = lambda t: t.to(DEV)
+    y_o = oracle_backend.attention_relation_step_forward(q, k, aw, it, ir)
+    y_h = hip.attention_relation_step_forward(d(q), d(k), d(aw), d(it), d(ir)).cpu()
+    assert_close(y_h, y_o, 1e-6, "rel fwd")
+    go = torch.randn(E, G, generator=g)
+    o = oracle_backend.attention_relation_step_backward(q, k, aw, it, ir, go)
+    h = hip.attention_relation_step_backward(d(q), d(k), d(aw), d(it), d(ir), d(go))
+    for a, b, nm in zip(h, o, ["gq", "gk", "gw"]):
+        assert_close(a.cpu(), b, 2e-5, "rel " + nm)
+    ew = torch.randn(E, G, generator=g)
+    y_o = oracle_backend.attention_fusion_step_forward(ew, v, it, ir)
+    y_h = hip.attention_fusion_step_forward(d(ew), d(v), d(it), d(ir)).cpu()
+    assert_close(y_h, y_o, 1e-5, "fus fwd")
+    go = torch.randn(n, G, C, generator=g)
+    o = oracle_backend.attention_fusion_step_backward(ew, v, it, ir, go)
+    h = hip.attention_fusion_step_backward(d(ew), d(v), d(it), d(ir), d(go))
+    for a, b, nm in zip(h, o, ["gw", "gv"]):
+        assert_close(a.cpu(), b, 1e-5, "fus " + nm)
+
+
+def test_python_level_goldens_on_gpu(hip, golden_dir):
+    """The fixtures produced by the reference's Python wrappers, replayed through the HIP path."""
+    from pointcloudpdf_amd import pointops
+
+    g = np.load(os.path.join(golden_dir, "ops_python_ref.npz"))
+    T = lambda a, grad=False: torch.from_numpy(np.array(a)).to(DEV).requires_grad_(grad)
+    idx, dist = pointops.knn_query(8, T(g["xyz"]), T(g["offset"]), T(g["new_xyz"]), T(g["new_offset"]))
+    assert np.array_equal(idx.cpu().numpy(), g["knn_idx"]) and np.array_equal(dist.cpu().numpy(), g["knn_dist"])
+    feat = T(g["feat"], True)
+    y = pointops.grouping(T(g["idx_pad"]), feat, T(g["xyz"]), T(g["new_xyz"]), with_xyz=True)
+    assert np.array_equal(y.detach().cpu().numpy(), g["grouping_xyz"])
+    y.backward(T(g["grouping_go"]))
+    assert_close(feat.grad.cpu(), g["grouping_gfeat"], 1e-5)
+    cf = T(g["interp_feat"], True)
+    yi = pointops.interpolation(T(g["new_xyz"]), T(g["xyz"]), cf, T(g["new_offset"]), T(g["offset"]))
+    assert_close(yi.cpu(), g["interp_out"], 1e-6)
+    yi.backward(T(g["interp_go"]))
+    assert_close(cf.grad.cpu(), g["interp_gfeat"], 1e-5)
+    inp, pos, w = T(g["agg_in"], True), T(g["agg_pos"], True), T(g["agg_w"], True)
+    ya = pointops.aggregation(inp, pos, w, T(g["self_idx"]))
+    assert_close(ya.cpu(), g["agg_out"], 1e-6)
+    ya.backward(T(g["agg_go"]))
+    assert_close(inp.grad.cpu(), g["agg_gin"], 1e-5)
+    assert_close(w.grad.cpu(), g["agg_gw"], 1e-5)
+    a, b = T(g["sub_a"], True), T(g["sub_b"], True)
+    ys = pointops.subtraction(a, b, T(g["self_idx"]))
+    assert np.array_equal(ys.detach().cpu().numpy(), g["sub_out"])

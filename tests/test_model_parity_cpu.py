@@ -1,0 +1,125 @@
+"""CPU suite (BASELINE config 1 plumbing): our PointTransformer-Seg50 + PDF U-decoder host code, driven by the CPU
+oracle, reproduces the tensors captured from the reference's own modules (tests/golden/model_*.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from pointcloudpdf_amd import synthetic
+from pointcloudpdf_amd.registry import MODELS, RECOGNIZER, LOSSES
+
+
+@pytest.mark.parametrize("name", list(helpers.MODEL_CASES))
+@pytest.mark.parametrize("train", [True, False])
+def test_model_matches_reference_python(use_oracle, golden_dir, name, train):
+    g = np.load(os.path.join(golden_dir, f"model_{name}_{'train' if train else 'eval'}.npz"))
+    torch.manual_seed(0)
+    out = helpers.run_case(name, train)
+    helpers.check_case_against_golden(out, g, train)
+    assert tuple(g["n_pointops_calls"]) == (4, 31)  # the reference's census; ours is memoised:
+    assert out["geometry"].memo_size() <= 4 + 13 + 9
+
+
+def test_state_dict_keys_match_reference_layout():
+    """Checkpoint compatibility surface: parameter names of the reference modules."""
+    m = MODELS.build(dict(type="PointTransformer-Seg50", in_channels=6, num_classes=13))
+    keys = set(m.state_dict().keys())
+    for k in ["enc1.0.linear.weight", "enc1.0.bn.running_mean", "enc1.1.linear1.weight", "enc1.1.transformer.linear_q.bias",
+              "enc1.1.transformer.linear_p.0.weight", "enc1.1.transformer.linear_p.1.running_var",
+              "enc1.1.transformer.linear_p.3.bias", "enc1.1.transformer.linear_w.0.weight",
+              "enc1.1.transformer.linear_w.2.weight", "enc1.1.transformer.linear_w.3.num_batches_tracked",
+              "enc1.1.transformer.linear_w.5.bias", "enc4.5.bn3.weight", "enc5.2.linear3.weight",
+              "dec5.0.linear1.0.weight", "dec5.0.linear2.0.bias", "dec4.0.linear2.1.running_mean", "dec1.1.bn2.bias",
+              "cls.0.weight", "cls.1.running_var", "cls.3.bias"]:
+        assert k in keys, k
+    assert sum(p.numel() for p in m.parameters()) == 7767729  # SURVEY.md 2.3 [probe]
+    r = MODELS.build(dict(type="PointTransformer-Recognizer"))
+    assert sum(p.numel() for p in r.parameters()) == 792513
+    assert {"dec5.linear1.0.weight", "dec1.linear2.1.bias", "confidence.3.weight"} <= set(r.state_dict().keys())
+
+
+def test_registered_names():
+    for n in ["PointTransformer-Seg26", "PointTransformer-Seg38", "PointTransformer-Seg50", "PointTransformer-Recognizer",
+              "DefaultSegmentor"]:
+        assert n in MODELS, n
+    assert "PointPdf-v1m1" in RECOGNIZER and "MaxProbability" in RECOGNIZER
+    assert "CrossEntropyLoss" in LOSSES
+
+
+def test_segmentor_and_recognizer_contract(use_oracle):
+    """configs/s3dis/openseg-pt-v1-0-msp.py model/recognizer dicts build and obey the dict-in/dict-out contract."""
+    from pointcloudpdf_amd.model_hook import BaseModelHook
+
+    seg = MODELS.build(dict(type="DefaultSegmentor", backbone=dict(type="PointTransformer-Seg26", in_channels=6, num_classes=13),
+                            criteria=[dict(type="CrossEntropyLoss", loss_weight=1.0, ignore_index=-1)]))
+    synthetic.fill_parameters_deterministic(seg, seed=3)
+    batch = synthetic.make_batch([1100, 900], grid_size=0.3)
+    msp = RECOGNIZER.build(dict(type="MaxProbability", method="msp"))
+    pdf = RECOGNIZER.build(dict(type="PointPdf-v1m1", recognizer=dict(type="PointTransformer-Recognizer"),
+                                criteria=[dict(type="CrossEntropyLoss", loss_weight=1.0, ignore_index=-1)], loss_weight=0.1,
+                                step_loss_weight=True, num_classes=13, start_epoch=1,
+                                pseudo_mask_fn=lambda c, l, o: (torch.arange(c.shape[0]) % 5) == 0))
+    hook = BaseModelHook(helpers.HOOK_CONFIG, exclude_clone={"backbone": ["forward_output"]}).set_model(seg)
+    msp.model_hooks = hook
+    pdf.model_hooks = hook
+    seg.train(); pdf.train()
+    with hook:
+        d = dict(coord=batch["coord"], feat=batch["feat"], offset=batch["offset"], segment=batch["segment"])
+        out = seg(d)
+        assert set(out) == {"loss"}
+        s = msp(d)["score"]
+        assert s.shape == (2000,) and (s >= 0).all()
+        pdf.set_epoch(0)
+        r0 = pdf(d)
+        assert set(r0) == {"score"} and r0["score"].shape == (2000, 1)
+        assert not any(p.requires_grad for p in pdf.recognizer.parameters())  # frozen before start_epoch
+        pdf.set_epoch(1)
+        r1 = pdf(d)
+        assert set(r1) == {"score", "loss"} and r1["score"].shape == (2000,)
+        assert all(p.requires_grad for p in pdf.recognizer.parameters())
+        (out["loss"] + r1["loss"]).backward()
+        pdf.set_epoch(3)
+        pdf(d)
+        assert abs(pdf.alpha - 0.01) < 1e-12  # stepped once (pointpdf_v1m1_base.py:395-398)
+    seg.eval(); pdf.eval()
+    with hook:
+        out = seg(dict(coord=batch["coord"], feat=batch["feat"], offset=batch["offset"], segment=batch["segment"]))
+        assert set(out) == {"loss", "seg_logits"}
+        assert pdf(dict(segment=batch["segment"]))["score"].shape == (2000,)
+        out = seg(dict(coord=batch["coord"], feat=batch["feat"], offset=batch["offset"]))
+        assert set(out) == {"seg_logits"}
+
+
+def test_model_hook_matches_reference_hook(golden_dir):
+    from pointcloudpdf_amd.model_hook import BaseModelHook
+
+    g = np.load(os.path.join(golden_dir, "model_hook_ref.npz"))
+    net = torch.nn.Sequential(torch.nn.Linear(4, 5), torch.nn.ReLU(), torch.nn.Linear(5, 2))
+    synthetic.fill_parameters_deterministic(net, seed=5)
+    mh = BaseModelHook({"0": ["forward_output", "backward_outputGrad"], "2": ["forward_input"]}).set_model(net)
+    with mh:
+        net(torch.from_numpy(g["x"])).sum().backward()
+    helpers.assert_close(mh["0"]["forward_output"], g["fo0"], 1e-6)
+    helpers.assert_close(mh["0"]["backward_outputGrad"], g["bo0"], 1e-6)
+    helpers.assert_close(mh["2"]["forward_input"], g["fi2"], 1e-6)
+    with pytest.raises(AssertionError):
+        BaseModelHook({"0": ["forward_outputGrad"]})
+
+
+def test_untagged_coordinates_take_the_uncached_path(use_oracle):
+    """TransitionDown / interpolation on tensors that no Geometry handed out behave as upstream (host-side offsets)."""
+    from pointcloudpdf_amd.point_transformer import TransitionDown, TransitionUp
+    from pointcloudpdf_amd.geometry import Geometry
+
+    batch = synthetic.make_batch([600, 400], grid_size=0.3)
+    td = TransitionDown(6, 16, stride=4, nsample=8)
+    synthetic.fill_parameters_deterministic(td, seed=9)
+    p, x, o = batch["coord"].clone(), batch["feat"], batch["offset"].int()
+    p1, x1, o1 = td([p, x, o])
+    geom = Geometry(batch["coord"], batch["offset"])
+    p2, x2, o2 = td([geom.coord(0), x, geom.offset(0)])
+    assert torch.equal(p1, p2) and torch.equal(o1, o2)
+    helpers.assert_close(x1, x2, 1e-6)
+    assert o1.tolist() == [150, 250]

@@ -1,0 +1,125 @@
+"""CPU suite: the oracle-backed host ops reproduce the fixtures produced by the REFERENCE's Python wrappers
+(tests/golden/ops_python_ref.npz, made by tests/golden/make_golden.py from libs/pointops/functions/*.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close
+from pointcloudpdf_amd import pointops
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, "ops_python_ref.npz"))
+
+
+def T(a, grad=False):
+    t = torch.from_numpy(np.array(a))
+    return t.requires_grad_(True) if grad else t
+
+
+def test_knn_query_matches_reference_wrapper(use_oracle, g):
+    idx, dist = pointops.knn_query(8, T(g["xyz"]), T(g["offset"]), T(g["new_xyz"]), T(g["new_offset"]))
+    assert idx.dtype == torch.int32 and np.array_equal(idx.numpy(), g["knn_idx"])
+    assert np.array_equal(dist.numpy(), g["knn_dist"])  # sqrt(dist2), bit-exact
+    sidx, _ = pointops.knn_query(8, T(g["xyz"]), T(g["offset"]))
+    assert np.array_equal(sidx.numpy(), g["self_idx"])
+
+
+def test_grouping_python_twin(use_oracle, g):
+    idx, feat, xyz, new_xyz = T(g["idx_pad"]), T(g["feat"], True), T(g["xyz"]), T(g["new_xyz"])
+    y = pointops.grouping(idx, feat, xyz, new_xyz, with_xyz=True)
+    assert np.array_equal(y.detach().numpy(), g["grouping_xyz"])  # pure gathers/subtractions: exact
+    assert np.array_equal(pointops.grouping(idx, feat, xyz, new_xyz, with_xyz=False).detach().numpy(), g["grouping_noxyz"])
+    y.backward(T(g["grouping_go"]))
+    assert_close(feat.grad, g["grouping_gfeat"], 1e-6, "grouping grad")
+    # -1 rows gather zeros
+    assert (y.detach().numpy()[g["idx_pad"] < 0] == 0).all()
+
+
+def test_interpolation(use_oracle, g):
+    xyz, new_xyz, off, noff = T(g["xyz"]), T(g["new_xyz"]), T(g["offset"]), T(g["new_offset"])
+    cf = T(g["interp_feat"], True)
+    y = pointops.interpolation(new_xyz, xyz, cf, noff, off)
+    assert_close(y, g["interp_out"], 1e-6, "interpolation")
+    y.backward(T(g["interp_go"]))
+    assert_close(cf.grad, g["interp_gfeat"], 1e-5, "interpolation grad")
+    cf2 = T(g["interp_feat"], True)
+    y2 = pointops.interpolation2(new_xyz, xyz, cf2, noff, off)
+    assert_close(y2, g["interp2_out"], 1e-6, "interpolation2")
+    y2.backward(T(g["interp_go"]))
+    assert_close(cf2.grad, g["interp2_gfeat"], 1e-5, "interpolation2 grad")
+
+
+def test_grouping2_subtraction_aggregation(use_oracle, g):
+    sidx = T(g["self_idx"])
+    f = T(g["feat"], True)
+    y = pointops.grouping2(f, sidx)
+    assert np.array_equal(y.detach().numpy(), g["grouping2_out"])
+    y.backward(T(g["grouping2_go"]))
+    assert_close(f.grad, g["grouping2_gin"], 1e-5, "grouping2 grad")
+
+    a, b = T(g["sub_a"], True), T(g["sub_b"], True)
+    ys = pointops.subtraction(a, b, sidx)
+    assert np.array_equal(ys.detach().numpy(), g["sub_out"])
+    ys.backward(T(g["sub_go"]))
+    assert_close(a.grad, g["sub_ga"], 1e-5, "sub ga")
+    assert_close(b.grad, g["sub_gb"], 1e-5, "sub gb")
+
+    inp, pos, w = T(g["agg_in"], True), T(g["agg_pos"], True), T(g["agg_w"], True)
+    ya = pointops.aggregation(inp, pos, w, sidx)
+    assert_close(ya, g["agg_out"], 1e-6, "aggregation")
+    ya.backward(T(g["agg_go"]))
+    assert_close(inp.grad, g["agg_gin"], 1e-5, "agg gin")
+    assert_close(pos.grad, g["agg_gpos"], 1e-6, "agg gpos")
+    assert_close(w.grad, g["agg_gw"], 1e-5, "agg gw")
+
+
+def test_attention_steps(use_oracle, g):
+    q, k, aw = T(g["att_q"], True), T(g["att_k"], True), T(g["att_w"], True)
+    it, ir = T(g["att_it"]), T(g["att_ir"])
+    y = pointops.attention_relation_step(q, k, aw, it, ir)
+    assert_close(y, g["rel_out"], 1e-6, "relation")
+    y.backward(T(g["rel_go"]))
+    assert_close(q.grad, g["rel_gq"], 1e-5, "rel gq")
+    assert_close(k.grad, g["rel_gk"], 1e-5, "rel gk")
+    assert aw.grad is None  # upstream returns None for weight (attention.py:62)
+    ew, v = T(g["fus_w"], True), T(g["fus_v"], True)
+    yf = pointops.attention_fusion_step(ew, v, it, ir)
+    assert_close(yf, g["fus_out"], 1e-6, "fusion")
+    yf.backward(T(g["fus_go"]))
+    assert_close(ew.grad, g["fus_gw"], 1e-5, "fus gw")
+    assert_close(v.grad, g["fus_gv"], 1e-5, "fus gv")
+
+
+def test_query_and_group_and_converters(use_oracle, g):
+    qg, qidx = pointops.query_and_group(4, T(g["xyz"]), T(g["new_xyz"]), T(g["feat"]), None, T(g["offset"]), T(g["new_offset"]), dilation=1)
+    assert np.array_equal(qidx.numpy(), g["qg_idx"])
+    assert np.array_equal(qg.numpy(), g["qg_out"])
+    assert np.array_equal(pointops.offset2batch(T(g["offset"])).numpy(), g["offset2batch"])
+    assert np.array_equal(pointops.batch2offset(T(g["offset2batch"])).numpy(), g["batch2offset"])
+
+
+def test_off_path_queries_raise(use_oracle):
+    with pytest.raises(NotImplementedError):
+        pointops.ball_query(4, 1.0, 0.0, torch.zeros(4, 3), torch.tensor([4]))
+
+
+def test_public_names_match_reference():
+    # libs/pointops/functions/__init__.py:1-14
+    names = ["knn_query", "ball_query", "random_ball_query", "farthest_point_sampling", "grouping", "grouping2",
+             "interpolation", "interpolation2", "subtraction", "aggregation", "attention_relation_step",
+             "attention_fusion_step", "query_and_group", "knn_query_and_group", "ball_query_and_group",
+             "batch2offset", "offset2batch"]
+    for n in names:
+        assert callable(getattr(pointops, n)), n
+
+
+def test_cpu_tensors_fail_loudly_without_injection():
+    """The product path has no CPU fallback: it must raise, not silently compute."""
+    from pointcloudpdf_amd._native import PdfOpsError
+
+    with pytest.raises(PdfOpsError):
+        pointops.knn_query(3, torch.rand(10, 3), torch.tensor([10], dtype=torch.int32))
