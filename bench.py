@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-points", type=int, default=16000, help="scene size of the bounded CPU-baseline sample")
     ap.add_argument("--amp", action="store_true", help="fp16 autocast around the step (reference enable_amp=True)")
+    ap.add_argument("--prefetch", type=int, default=3, help="geometry pre-pass depth in steps (0 = inline, serial)")
     return ap.parse_args()
 
 
@@ -152,15 +153,32 @@ def main():
     timer = KernelTimer(be, ["knn_query", "farthest_point_sampling", "group_forward", "group_backward"])
     timer.install()
 
+    from pointcloudpdf_amd.geometry import GeometryPrefetcher
+
+    prefetcher = GeometryPrefetcher(depth=args.prefetch) if args.prefetch > 0 else None
+    tickets = {}
+
+    def submit(i):
+        b = pool[i % len(pool)]
+        tickets[i] = prefetcher.submit(b["coord"], b["offset"], b["offset_host"])
+
     def one_step(i):
         batch = pool[i % len(pool)]
+        data = dict(coord=batch["coord"], feat=batch["feat"], offset=batch["offset"],
+                    offset_host=batch["offset_host"], segment=batch["segment"])
+        if prefetcher is not None:
+            data["pdf_geometry"] = prefetcher.get(tickets.pop(i))  # pre-pass of THIS batch, launched `depth` steps ago
+            submit(i + args.prefetch)                             # every step launches exactly one pre-pass
         opt.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=torch.float16, enabled=args.amp):
-            out = module(dict(coord=batch["coord"], feat=batch["feat"], offset=batch["offset"],
-                              offset_host=batch["offset_host"], segment=batch["segment"]))
+            out = module(data)
         out["loss"].backward()
         opt.step()
         return out
+
+    if prefetcher is not None:
+        for i in range(args.prefetch):
+            submit(i)
 
     def fence():
         if world > 1:
@@ -212,6 +230,7 @@ def main():
                        "scenes_per_gpu": args.scenes, "points_per_scene": args.points, "parallelism": f"dp{world}"},
             "per_gpu_points_per_s": pts_per_step * args.steps / dt / world,
             "loss": loss,
+            "geometry_prefetch_depth": args.prefetch,
             "kernels": ks,
             "roofline": roof,
         }

@@ -55,6 +55,7 @@ int pdf_fps_reference_block_log2(int n);
 /* Bucketed exact FPS (same results as pdf_farthest_point_sampling, far fewer point updates).
  * Host-side sizes: n_total = offset[b-1].  Workspace from pdf_fps_workspace_bytes(). */
 long pdf_fps_workspace_bytes(int b, int n_total);
+long pdf_fps_stats_offset(int b, int n_total); /* 4 x u32 per scene: bucket updates, super visits, samples, buckets */
 int pdf_farthest_point_sampling_bucketed(int b, int n, int n_total, const float *xyz, const int *offset,
                                          const int *new_offset, void *workspace, long workspace_bytes,
                                          int *idx, void *stream);

@@ -237,6 +237,10 @@ class HipBackend(CBackend):
         super().__init__(lib, "pdf_", "cuda", True, extra_protos=tuple(_HIP_ONLY_PROTOS))
         lib.pdf_fps_workspace_bytes.restype = c_long
         lib.pdf_fps_workspace_bytes.argtypes = [c_int, c_int]
+        lib.pdf_fps_stats_offset.restype = c_long
+        lib.pdf_fps_stats_offset.argtypes = [c_int, c_int]
+        self.collect_fps_stats = False  # debug: keep the work counters of the last bucketed FPS call (forces a sync)
+        self.last_fps_stats = None
         lib.pdf_abi_version.restype = c_int
         lib.pdf_build_info.restype = ctypes.c_char_p
         self.fps_mode = os.environ.get("PDFOPS_FPS", "bucketed")  # "bucketed" | "plain"
@@ -251,6 +255,9 @@ class HipBackend(CBackend):
         nbytes = int(self.lib.pdf_fps_workspace_bytes(b, n_total))
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=xyz.device)
         self._call("farthest_point_sampling_bucketed", b, int(n_max), n_total, xyz, offset, new_offset, ws, nbytes, idx)
+        if self.collect_fps_stats:
+            o = int(self.lib.pdf_fps_stats_offset(b, n_total))
+            self.last_fps_stats = ws[o:o + 16 * b].view(torch.int32).view(b, 4).cpu()
         return idx
 
     def group_forward(self, feat, xyz, new_xyz, idx, with_xyz):

@@ -1,15 +1,545 @@
-// Bucketed exact farthest point sampling (placeholder wiring: forwards to the plain kernel until the
-// bucket-pruned kernel lands; the entry points and workspace contract are final).
+// Bucketed exact farthest point sampling for gfx950.
+//
+// Same results, bit for bit, as the plain kernel / the reference (sampling_cuda_kernel.cu:14-129): sample j is the
+// arg-max of tmp[k] = min_i d(k, sample_i) with the reference's tie rule, encoded as the packed key of sampling.hip.
+// What changes is the work per iteration.  The reference touches every point of the scene for every sample
+// (25,000 x 100,000 point updates at level 1).  Here the points of a scene are grouped into spatial buckets of 64
+// (counting sort by a 15-bit Morton cell of the scene's bounding box), each bucket keeps
+//      bounding box | best packed key (max tmp + tie key) | coordinates of that best point
+// in LDS, and a new sample s only visits buckets with  d_bb(s, bucket) < max tmp(bucket)  where d_bb is the
+// box distance evaluated with the same fp32 operation sequence as d.  Because IEEE rounding is monotonic,
+// d_fp32(k, s) >= d_bb_fp32 for every point k of the bucket, so a skipped bucket provably has min(d, tmp) == tmp for
+// all its points: pruning is EXACT, no epsilon.  16 buckets form a super-bucket with the same record, checked first.
+//
+// Execution: one single-wave workgroup per scene (a sample depends on the previous one; extra waves only add
+// barriers).  Per iteration: super check (<= 3 per lane) -> bucket check (lanes 0..15) -> 64-lane update of each
+// surviving bucket (one point per lane, coalesced 1 KiB loads from the L2-resident sorted copy) -> u64 wave
+// max-reductions.  Typical iteration touches 1-4 buckets instead of 1,563.  Roofline: latency-bound by design;
+// algorithmic HBM bytes 12N + 4M' (SURVEY.md 8d).
 #include "pdfops_common.h"
+#include <stdlib.h>
+
+extern "C" int pdf_fps_reference_block_log2(int n);
+
+namespace {
+
+constexpr int BSZ = 64;            // points per bucket (= one wave, one point per lane)
+constexpr int SUP = 16;            // buckets per super-bucket
+constexpr int NB_MAX = 3072;       // buckets per scene held in LDS (=> scenes up to 196,608 points)
+constexpr int NS_MAX = NB_MAX / SUP;
+constexpr int CELLS = 32768;       // 15-bit Morton cells per scene
+constexpr int REL_BITS = 22;
+constexpr unsigned REL_MASK = (1u << REL_BITS) - 1u;
+constexpr int PB = 256;            // block size of the preparation kernels
+
+struct Layout {  // byte offsets into the caller's workspace
+    size_t stats, bbox, hist, cursor, cell, pts, kb, meta, total;
+    int npad, nbk;
+};
+
+__host__ __device__ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+__host__ __device__ inline Layout make_layout(int b, int n_total) {
+    Layout L;
+    L.npad = n_total + BSZ * b;
+    L.nbk = L.npad / BSZ + b;
+    size_t o = 0;
+    L.stats = o;  o = align256(o + (size_t)b * 4 * 4);  // per scene: bucket updates, super visits, samples, -
+    L.bbox = o;   o = align256(o + (size_t)b * 8 * 4);
+    L.hist = o;   o = align256(o + (size_t)b * CELLS * 4);
+    L.cursor = o; o = align256(o + (size_t)b * CELLS * 4);
+    L.cell = o;   o = align256(o + (size_t)n_total * 4);
+    L.pts = o;    o = align256(o + (size_t)L.npad * 16);
+    L.kb = o;     o = align256(o + (size_t)L.npad * 4);
+    L.meta = o;   o = align256(o + (size_t)L.nbk * 12 * 4);
+    L.total = o;
+    return L;
+}
+
+struct Scene {
+    int start_n, n, start_m, m, pbase, bbase, nb;
+};
+
+// Scene table entry from the cumulative offsets (b is small: linear scan).
+__device__ inline Scene scene_of(int s, const int *__restrict__ offset, const int *__restrict__ new_offset) {
+    Scene sc;
+    int pbase = 0, bbase = 0, prev = 0;
+    for (int i = 0; i < s; ++i) {
+        const int e = offset[i];
+        const int nb = (e - prev + BSZ - 1) / BSZ;
+        pbase += nb * BSZ;
+        bbase += nb;
+        prev = e;
+    }
+    sc.start_n = prev;
+    sc.n = offset[s] - prev;
+    sc.start_m = s == 0 ? 0 : new_offset[s - 1];
+    sc.m = new_offset[s] - sc.start_m;
+    sc.pbase = pbase;
+    sc.bbase = bbase;
+    sc.nb = (sc.n + BSZ - 1) / BSZ;
+    return sc;
+}
+
+__device__ inline unsigned keybits(int rel, int bs_ref_log2) {
+    const unsigned slot = (unsigned)rel & ((1u << bs_ref_log2) - 1u);
+    const unsigned rev = bs_ref_log2 ? (__brev(slot) >> (32 - bs_ref_log2)) : 0u;
+    return ((~rev & 0x3ffu) << REL_BITS) | (~(unsigned)rel & REL_MASK);
+}
+
+__device__ inline float dist_as_written(float x2, float y2, float z2, float x1, float y1, float z1) {
+    return (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+}
+
+// ---------------------------------------------------------------- preparation kernels
+__global__ __launch_bounds__(PB) void k_bbox(const float *__restrict__ xyz, const int *__restrict__ offset, float *__restrict__ bbox) {
+    __shared__ float red[6][PB / 64];
+    const int s = blockIdx.x;
+    const int start = s == 0 ? 0 : offset[s - 1], end = offset[s];
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int i = start + threadIdx.x; i < end; i += PB)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = xyz[3 * (size_t)i + a];
+            lo[a] = fminf(lo[a], v);
+            hi[a] = fmaxf(hi[a], v);
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            red[a][threadIdx.x >> 6] = lo[a];
+            red[3 + a][threadIdx.x >> 6] = hi[a];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float l = red[threadIdx.x][0], h = red[3 + threadIdx.x][0];
+        for (int w = 1; w < PB / 64; ++w) {
+            l = fminf(l, red[threadIdx.x][w]);
+            h = fmaxf(h, red[3 + threadIdx.x][w]);
+        }
+        bbox[s * 8 + threadIdx.x] = l;
+        const float ext = h - l;
+        bbox[s * 8 + 3 + threadIdx.x] = ext > 0.f ? 32.0f / (ext * 1.0001f) : 0.f;  // cells per unit length
+    }
+}
+
+__device__ inline unsigned spread5(unsigned v) {  // 5 bits -> every third bit
+    v &= 31u;
+    v = (v | (v << 8)) & 0x100fu;
+    v = (v | (v << 4)) & 0x10c3u;
+    v = (v | (v << 2)) & 0x1249u;
+    return v;
+}
+
+__device__ inline int scene_of_point(int i, const int *__restrict__ offset, int b) {
+    int s = 0;
+    while (s < b - 1 && i >= offset[s]) ++s;
+    return s;
+}
+
+__global__ __launch_bounds__(PB) void k_hist(int n_total, int b, const float *__restrict__ xyz, const int *__restrict__ offset,
+                                             const float *__restrict__ bbox, unsigned *__restrict__ hist, unsigned *__restrict__ cell) {
+    const int i = blockIdx.x * PB + threadIdx.x;
+    if (i >= n_total) return;
+    const int s = scene_of_point(i, offset, b);
+    unsigned q[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float t = (xyz[3 * (size_t)i + a] - bbox[s * 8 + a]) * bbox[s * 8 + 3 + a];
+        int v = (int)t;
+        q[a] = (unsigned)(v < 0 ? 0 : v > 31 ? 31 : v);
+    }
+    const unsigned c = spread5(q[0]) | (spread5(q[1]) << 1) | (spread5(q[2]) << 2);
+    cell[i] = c;
+    atomicAdd(&hist[(size_t)s * CELLS + c], 1u);
+}
+
+// exclusive scan of the 32768 cell counts of one scene (1024 threads x 32 cells), in place
+__global__ __launch_bounds__(1024) void k_scan(unsigned *__restrict__ hist) {
+    __shared__ unsigned wsum[16];
+    unsigned *h = hist + (size_t)blockIdx.x * CELLS;
+    const int t = threadIdx.x;
+    unsigned v[32], sum = 0;
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+        v[u] = h[t * 32 + u];
+        sum += v[u];
+    }
+    unsigned inc = sum;  // inclusive scan of per-thread sums across the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned up = __shfl_up(inc, o, 64);
+        if ((t & 63) >= o) inc += up;
+    }
+    if ((t & 63) == 63) wsum[t >> 6] = inc;
+    __syncthreads();
+    unsigned base = 0;
+    for (int w = 0; w < (t >> 6); ++w) base += wsum[w];
+    unsigned run = base + inc - sum;
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+        h[t * 32 + u] = run;
+        run += v[u];
+    }
+}
+
+__global__ __launch_bounds__(PB) void k_scatter(int n_total, int b, const float *__restrict__ xyz, const int *__restrict__ offset,
+                                                const int *__restrict__ new_offset, const unsigned *__restrict__ start,
+                                                unsigned *__restrict__ cursor, const unsigned *__restrict__ cell,
+                                                float4 *__restrict__ pts, unsigned *__restrict__ kb, int bs_ref_log2) {
+    const int i = blockIdx.x * PB + threadIdx.x;
+    if (i >= n_total) return;
+    const int s = scene_of_point(i, offset, b);
+    const Scene sc = scene_of(s, offset, new_offset);
+    const unsigned c = cell[i];
+    const unsigned r = start[(size_t)s * CELLS + c] + atomicAdd(&cursor[(size_t)s * CELLS + c], 1u);
+    const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+    // tmp after the first sample (= first point of the scene); the reference starts from tmp = 1e10 (sampling.py:19)
+    const float x1 = xyz[3 * (size_t)sc.start_n], y1 = xyz[3 * (size_t)sc.start_n + 1], z1 = xyz[3 * (size_t)sc.start_n + 2];
+    const float t = fminf(dist_as_written(x, y, z, x1, y1, z1), 1e10f);
+    const size_t dst = (size_t)sc.pbase + r;
+    pts[dst] = make_float4(x, y, z, t);
+    kb[dst] = keybits(i - sc.start_n, bs_ref_log2);
+}
+
+// pad the tail of every scene's last bucket with never-winning points
+__global__ void k_pad(int b, const int *__restrict__ offset, const int *__restrict__ new_offset, float4 *__restrict__ pts,
+                      unsigned *__restrict__ kb) {
+    const int s = blockIdx.x;
+    const Scene sc = scene_of(s, offset, new_offset);
+    const int r = sc.n + threadIdx.x;
+    if (r < sc.nb * BSZ) {
+        pts[(size_t)sc.pbase + r] = make_float4(0.f, 0.f, 0.f, -1.f);
+        kb[(size_t)sc.pbase + r] = 0u;
+    }
+}
+
+// one wave per bucket: bounding box, best packed key, coordinates of the best point -> 12 dwords of metadata
+__global__ __launch_bounds__(64) void k_meta(const float4 *__restrict__ pts, const unsigned *__restrict__ kb, float *__restrict__ meta) {
+    const int bk = blockIdx.x;
+    const int lane = threadIdx.x;
+    const float4 p = pts[(size_t)bk * BSZ + lane];
+    const bool valid = p.w >= 0.f;
+    float lo[3] = {valid ? p.x : 3.0e38f, valid ? p.y : 3.0e38f, valid ? p.z : 3.0e38f};
+    float hi[3] = {valid ? p.x : -3.0e38f, valid ? p.y : -3.0e38f, valid ? p.z : -3.0e38f};
+    unsigned long long key = valid ? (((unsigned long long)pdf_f32_ordered(p.w) << 32) | kb[(size_t)bk * BSZ + lane]) : 0ull;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64));
+        }
+    }
+    const unsigned long long best = pdf_wave_max_u64(key);
+    const unsigned long long mask = __ballot(key == best && valid);
+    const int win = mask ? __ffsll((long long)mask) - 1 : 0;
+    const float bx = __shfl(p.x, win, 64), by = __shfl(p.y, win, 64), bz = __shfl(p.z, win, 64);
+    if (lane == 0) {
+        float *m = meta + (size_t)bk * 12;
+        m[0] = lo[0]; m[1] = lo[1]; m[2] = lo[2];
+        m[3] = hi[0]; m[4] = hi[1]; m[5] = hi[2];
+        m[6] = __uint_as_float((unsigned)(best >> 32));
+        m[7] = __uint_as_float((unsigned)best);
+        m[8] = bx; m[9] = by; m[10] = bz; m[11] = 0.f;
+    }
+}
+
+// ---------------------------------------------------------------- the sampling kernel (one wave per scene)
+struct Rec {  // SoA record arrays in LDS
+    float *lox, *loy, *loz, *hix, *hiy, *hiz, *bx, *by, *bz;
+    unsigned *khi, *klo;
+};
+
+__device__ inline Rec carve(float *base, int n) {
+    Rec r;
+    r.lox = base; r.loy = base + n; r.loz = base + 2 * n;
+    r.hix = base + 3 * n; r.hiy = base + 4 * n; r.hiz = base + 5 * n;
+    r.bx = base + 6 * n; r.by = base + 7 * n; r.bz = base + 8 * n;
+    r.khi = reinterpret_cast<unsigned *>(base + 9 * n);
+    r.klo = reinterpret_cast<unsigned *>(base + 10 * n);
+    return r;
+}
+
+// box distance with the operation sequence of dist_as_written (monotone rounding => lower bound of every point's d)
+__device__ inline float box_dist(const Rec &r, int i, float cx, float cy, float cz) {
+    const float gx = fmaxf(fmaxf(r.lox[i] - cx, cx - r.hix[i]), 0.f);
+    const float gy = fmaxf(fmaxf(r.loy[i] - cy, cy - r.hiy[i]), 0.f);
+    const float gz = fmaxf(fmaxf(r.loz[i] - cz, cz - r.hiz[i]), 0.f);
+    return gx * gx + gy * gy + gz * gz;
+}
+
+// wave64 unsigned max through DPP (no LDS round trips): row_shr 1/2/4/8 fold each 16-lane row into its last lane,
+// row_bcast:15 / row_bcast:31 carry the row results to lane 63, v_readlane broadcasts.  ~8 VALU ops.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_or0(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+    v = max(v, dpp_or0<0x111, 0xf>(v));
+    v = max(v, dpp_or0<0x112, 0xf>(v));
+    v = max(v, dpp_or0<0x114, 0xf>(v));
+    v = max(v, dpp_or0<0x118, 0xf>(v));
+    v = max(v, dpp_or0<0x142, 0xa>(v));
+    v = max(v, dpp_or0<0x143, 0xc>(v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// arg-max of the packed key (hi = ordered tmp, lo = tie key; lo unique among lanes with hi != 0). Returns the lane.
+__device__ __forceinline__ int wave_argmax_key(unsigned hi, unsigned lo, unsigned &mhi, unsigned &mlo) {
+    mhi = wave_umax(hi);
+    mlo = wave_umax(hi == mhi ? lo : 0u);
+    const unsigned long long m = __ballot(hi == mhi && lo == mlo);
+    return __ffsll((long long)m) - 1;
+}
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), lane));
+}
+// single-wave workgroup: LDS traffic only needs the wave's own DS queue drained, never the VMEM queue
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// Row-wise (16-lane) unsigned max: after the four row_shr folds, lanes 15/31/47/63 hold their row's maximum.
+__device__ __forceinline__ unsigned row_umax_bcast(unsigned v, int row) {
+    v = max(v, dpp_or0<0x111, 0xf>(v));
+    v = max(v, dpp_or0<0x112, 0xf>(v));
+    v = max(v, dpp_or0<0x114, 0xf>(v));
+    v = max(v, dpp_or0<0x118, 0xf>(v));
+    const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 15), r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 31);
+    const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 47), r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+    return row == 0 ? r0 : row == 1 ? r1 : row == 2 ? r2 : r3;
+}
+
+constexpr int FPS_UNROLL = 4;  // bucket loads in flight per wave
+
+// NW waves per scene.  Every wave derives the same sample / active-super / active-bucket lists from the shared LDS
+// records (redundantly, no communication); the surviving buckets are dealt round-robin to the waves; two barriers per
+// sample fence the bucket-record writes.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_fps(const int *__restrict__ offset, const int *__restrict__ new_offset,
+                                                 float4 *__restrict__ pts, const unsigned *__restrict__ kbs,
+                                                 const float *__restrict__ meta, int *__restrict__ idx, int nb_cap,
+                                                 unsigned *__restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) float fps_lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int row = lane >> 4, col = lane & 15;
+    const Scene sc = scene_of(blockIdx.x, offset, new_offset);
+    if (sc.m <= 0) return;
+    const int nb = sc.nb, ns = (nb + SUP - 1) / SUP;
+    const int ns_cap = (nb_cap + SUP - 1) / SUP;
+    Rec B = carve(fps_lds, nb_cap);
+    Rec S = carve(fps_lds + 11 * nb_cap, ns_cap);
+    // active-super list, double-buffered by sample parity (a fast wave may already build sample j+1's list while a slow
+    // one still refreshes the supers of sample j); active-bucket list (consumed between barriers A and B)
+    unsigned short *slist_base = reinterpret_cast<unsigned short *>(fps_lds + 11 * nb_cap + 11 * ns_cap);
+    const int slist_stride = ((ns_cap + 63) & ~63) + 64;
+    unsigned short *blist = slist_base + 2 * slist_stride;  // [nb_cap]
+    unsigned n_updates = 0, n_supers = 0;
+
+    // load bucket records, build super records
+    for (int i = tid; i < nb; i += 64 * NW) {
+        const float *m = meta + (size_t)(sc.bbase + i) * 12;
+        B.lox[i] = m[0]; B.loy[i] = m[1]; B.loz[i] = m[2];
+        B.hix[i] = m[3]; B.hiy[i] = m[4]; B.hiz[i] = m[5];
+        B.khi[i] = __float_as_uint(m[6]); B.klo[i] = __float_as_uint(m[7]);
+        B.bx[i] = m[8]; B.by[i] = m[9]; B.bz[i] = m[10];
+    }
+    __syncthreads();
+    for (int s = tid; s < ns; s += 64 * NW) {
+        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        unsigned long long best = 0ull;
+        int bi = s * SUP;
+        for (int i = s * SUP; i < min(nb, s * SUP + SUP); ++i) {
+            lo[0] = fminf(lo[0], B.lox[i]); lo[1] = fminf(lo[1], B.loy[i]); lo[2] = fminf(lo[2], B.loz[i]);
+            hi[0] = fmaxf(hi[0], B.hix[i]); hi[1] = fmaxf(hi[1], B.hiy[i]); hi[2] = fmaxf(hi[2], B.hiz[i]);
+            const unsigned long long k = ((unsigned long long)B.khi[i] << 32) | B.klo[i];
+            if (k > best) { best = k; bi = i; }
+        }
+        S.lox[s] = lo[0]; S.loy[s] = lo[1]; S.loz[s] = lo[2];
+        S.hix[s] = hi[0]; S.hiy[s] = hi[1]; S.hiz[s] = hi[2];
+        S.khi[s] = (unsigned)(best >> 32); S.klo[s] = (unsigned)best;
+        S.bx[s] = B.bx[bi]; S.by[s] = B.by[bi]; S.bz[s] = B.bz[bi];
+    }
+    __syncthreads();
+
+    if (tid == 0) idx[sc.start_m] = sc.start_n;
+    // sample 1 needs no update pass: tmp already holds the distances to sample 0 (k_scatter)
+    for (int j = 1; j < sc.m; ++j) {
+        // ---- 1. arg-max over super records (every wave, redundantly)
+        unsigned bhi = 0u, blo = 0u;
+        int bs = 0;
+        for (int s = lane; s < ns; s += 64) {
+            const unsigned h = S.khi[s], l = S.klo[s];
+            if (h > bhi || (h == bhi && l > blo)) { bhi = h; blo = l; bs = s; }
+        }
+        unsigned whi, wlo;
+        const int wl = wave_argmax_key(bhi, blo, whi, wlo);
+        const int wsup = __builtin_amdgcn_readlane(bs, wl);
+        const float cx = S.bx[wsup], cy = S.by[wsup], cz = S.bz[wsup];
+        if (tid == 0) idx[sc.start_m + j] = sc.start_n + (int)(~wlo & REL_MASK);
+        if (j == sc.m - 1) break;  // the last sample needs no distance update
+
+        // ---- 2. active supers -> slist
+        unsigned short *slist = slist_base + (j & 1) * slist_stride;
+        int n_sup = 0;
+        for (int s0 = 0; s0 < ns; s0 += 64) {
+            const int s = s0 + lane;
+            bool act = false;
+            if (s < ns) act = pdf_f32_ordered(box_dist(S, s, cx, cy, cz)) < S.khi[s];
+            const unsigned long long m = __ballot(act);
+            if (act) slist[n_sup + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)s;
+            n_sup += __popcll(m);
+        }
+        lds_fence();
+        // ---- 3. active buckets of those supers (4 supers x 16 buckets per pass) -> blist
+        int n_bk = 0;
+        for (int g = 0; g < n_sup; g += 4) {
+            bool bact = false;
+            int bk = 0;
+            if (g + row < n_sup) {
+                bk = (int)slist[g + row] * SUP + col;
+                if (bk < nb) bact = pdf_f32_ordered(box_dist(B, bk, cx, cy, cz)) < B.khi[bk];
+            }
+            const unsigned long long m = __ballot(bact);
+            if (bact) blist[n_bk + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)bk;
+            n_bk += __popcll(m);
+        }
+        n_supers += n_sup;
+        n_updates += n_bk;
+        if (NW > 1) __syncthreads(); else lds_fence();  // A: nobody still reads bucket records / every list is complete
+
+        // ---- 4. update the surviving buckets (dealt round-robin to the waves, FPS_UNROLL loads in flight)
+        for (int i0 = wave * FPS_UNROLL; i0 < n_bk; i0 += NW * FPS_UNROLL) {
+            float4 p[FPS_UNROLL];
+            unsigned kb[FPS_UNROLL];
+            int bkid[FPS_UNROLL];
+#pragma unroll
+            for (int u = 0; u < FPS_UNROLL; ++u) {
+                bkid[u] = i0 + u < n_bk ? (int)blist[i0 + u] : -1;
+                if (bkid[u] >= 0) {
+                    const size_t pos = (size_t)sc.pbase + (size_t)bkid[u] * BSZ + lane;
+                    p[u] = pts[pos];
+                    kb[u] = kbs[pos];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < FPS_UNROLL; ++u) {
+                if (bkid[u] < 0) break;
+                unsigned khi = 0u;
+                if (p[u].w >= 0.f) {
+                    const float d = dist_as_written(p[u].x, p[u].y, p[u].z, cx, cy, cz);
+                    if (d < p[u].w) {
+                        p[u].w = d;
+                        pts[(size_t)sc.pbase + (size_t)bkid[u] * BSZ + lane].w = d;
+                    }
+                    khi = pdf_f32_ordered(p[u].w);
+                }
+                unsigned mhi, mlo;
+                const int kl = wave_argmax_key(khi, kb[u], mhi, mlo);
+                const float nx = lane_bcast(p[u].x, kl), ny = lane_bcast(p[u].y, kl), nz = lane_bcast(p[u].z, kl);
+                if (lane == 0) {
+                    B.khi[bkid[u]] = mhi; B.klo[bkid[u]] = mlo;
+                    B.bx[bkid[u]] = nx; B.by[bkid[u]] = ny; B.bz[bkid[u]] = nz;
+                }
+            }
+        }
+        if (NW > 1) __syncthreads(); else lds_fence();  // B: bucket records + tmp stores of every wave are visible
+
+        // ---- 5. refresh the touched super records (every wave, redundantly; 4 supers per pass, one per 16-lane row)
+        for (int g = 0; g < n_sup; g += 4) {
+            unsigned h16 = 0u, l16 = 0u;
+            int sup = -1, bk = 0;
+            if (g + row < n_sup) {
+                sup = (int)slist[g + row];
+                bk = sup * SUP + col;
+                if (bk < nb) { h16 = B.khi[bk]; l16 = B.klo[bk]; }
+            }
+            const unsigned mh = row_umax_bcast(h16, row);
+            const unsigned ml = row_umax_bcast(h16 == mh ? l16 : 0u, row);
+            const unsigned long long m = __ballot(sup >= 0 && h16 == mh && l16 == ml);
+            if (col == 0 && sup >= 0) {
+                const int wcol = __ffs((unsigned)(m >> (16 * row)) & 0xffffu) - 1;
+                const int wb = sup * SUP + wcol;
+                S.khi[sup] = mh; S.klo[sup] = ml;
+                S.bx[sup] = B.bx[wb]; S.by[sup] = B.by[wb]; S.bz[sup] = B.bz[wb];
+            }
+        }
+        lds_fence();
+    }
+    if (tid == 0 && stats) {
+        stats[blockIdx.x * 4 + 0] = n_updates;
+        stats[blockIdx.x * 4 + 1] = n_supers;
+        stats[blockIdx.x * 4 + 2] = (unsigned)sc.m;
+        stats[blockIdx.x * 4 + 3] = (unsigned)nb;
+    }
+}
+
+}  // namespace
 
 extern "C" long pdf_fps_workspace_bytes(int b, int n_total) {
     if (b < 1 || n_total < 0) return -1;
-    return (long)n_total * 4 + 256;
+    return (long)make_layout(b, n_total).total;
+}
+
+// byte offset of the per-scene work counters (4 x u32: bucket updates, super visits, samples, buckets) in the workspace
+extern "C" long pdf_fps_stats_offset(int b, int n_total) {
+    if (b < 1 || n_total < 0) return -1;
+    return (long)make_layout(b, n_total).stats;
 }
 
 extern "C" int pdf_farthest_point_sampling_bucketed(int b, int n, int n_total, const float *xyz, const int *offset,
                                                     const int *new_offset, void *workspace, long workspace_bytes,
                                                     int *idx, void *stream) {
-    if (!workspace || workspace_bytes < pdf_fps_workspace_bytes(b, n_total)) return PDF_ERR_BAD_ARG;
-    return pdf_farthest_point_sampling(b, n, xyz, offset, new_offset, static_cast<float *>(workspace), idx, stream);
+    if (b < 1 || n < 1 || n_total < 1 || !xyz || !offset || !new_offset || !workspace || !idx) return PDF_ERR_BAD_ARG;
+    const Layout L = make_layout(b, n_total);
+    if (workspace_bytes < (long)L.total) return PDF_ERR_BAD_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char *ws = static_cast<char *>(workspace);
+    const int nb_cap = (n + BSZ - 1) / BSZ;
+    if (nb_cap > NB_MAX || n > (1 << REL_BITS)) {
+        // scene too large for the LDS-resident bucket table: exact plain kernel (tmp scratch carved from the workspace)
+        return pdf_farthest_point_sampling(b, n, xyz, offset, new_offset, reinterpret_cast<float *>(ws + L.pts), idx, stream);
+    }
+    float *bbox = reinterpret_cast<float *>(ws + L.bbox);
+    unsigned *hist = reinterpret_cast<unsigned *>(ws + L.hist);
+    unsigned *cursor = reinterpret_cast<unsigned *>(ws + L.cursor);
+    unsigned *cell = reinterpret_cast<unsigned *>(ws + L.cell);
+    float4 *pts = reinterpret_cast<float4 *>(ws + L.pts);
+    unsigned *kb = reinterpret_cast<unsigned *>(ws + L.kb);
+    float *meta = reinterpret_cast<float *>(ws + L.meta);
+    hipError_t e = hipMemsetAsync(ws + L.hist, 0, L.cell - L.hist, s);  // hist + cursor
+    if (e != hipSuccess) return (int)e;
+    const int lg = pdf_fps_reference_block_log2(n);
+    k_bbox<<<b, PB, 0, s>>>(xyz, offset, bbox);
+    k_hist<<<pdf_divup(n_total, PB), PB, 0, s>>>(n_total, b, xyz, offset, bbox, hist, cell);
+    k_scan<<<b, 1024, 0, s>>>(hist);
+    k_scatter<<<pdf_divup(n_total, PB), PB, 0, s>>>(n_total, b, xyz, offset, new_offset, hist, cursor, cell, pts, kb, lg);
+    k_pad<<<b, BSZ, 0, s>>>(b, offset, new_offset, pts, kb);
+    // the exact bucket count lives on the device (offsets): launch the upper bound sum_b ceil(n_b/64) <= npad/64;
+    // surplus waves summarise unused slots that no scene ever reads
+    k_meta<<<L.npad / BSZ, 64, 0, s>>>(pts, kb, meta);
+    const int ns_cap = (nb_cap + SUP - 1) / SUP;
+    const size_t lds = (size_t)(11 * nb_cap + 11 * ns_cap) * 4 + (size_t)(2 * (((ns_cap + 63) & ~63) + 64) + nb_cap + 64) * 2;
+    const char *env_nw = getenv("PDFOPS_FPS_NW");  // tuning knob (waves per scene): 1, 2 or 4
+    const int nw = env_nw ? atoi(env_nw) : 4;
+    unsigned *stats = reinterpret_cast<unsigned *>(ws + L.stats);
+#define PDF_LAUNCH_FPS(NW_)                                                                                              \
+    do {                                                                                                                 \
+        if (lds > 64 * 1024) {                                                                                           \
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fps<NW_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return (int)e;                                                                          \
+        }                                                                                                                \
+        k_fps<NW_><<<b, 64 * NW_, lds, s>>>(offset, new_offset, pts, kb, meta, idx, nb_cap, stats);                       \
+    } while (0)
+    if (nw == 1) PDF_LAUNCH_FPS(1);
+    else if (nw == 2) PDF_LAUNCH_FPS(2);
+    else PDF_LAUNCH_FPS(4);
+#undef PDF_LAUNCH_FPS
+    return pdf_launch_status();
 }

@@ -59,7 +59,9 @@ class Geometry:
         """coord (N,3) f32 contiguous; offset (B,) cumulative ends (any int dtype / device)."""
         if coord.dtype != torch.float32:
             coord = coord.float()
-        coord = coord.contiguous()
+        # a fresh tensor OBJECT over the caller's storage: the geometry tag lives on the Python object, and the same
+        # coordinate tensor may back several Geometry instances (e.g. pre-passes of later steps already in flight)
+        coord = coord.contiguous().view(-1, 3)
         if offset_host is None:
             offset_host = [int(v) for v in offset.detach().cpu().tolist()]  # the ONE host sync per batch
         o_dev = offset.to(device=coord.device, dtype=torch.int32).contiguous()
@@ -83,6 +85,14 @@ class Geometry:
     def offset_host(self, level):
         return self.levels[level].o_host
 
+    def sizes(self, level):
+        """Per-scene point counts of a level as a device int64 tensor (memoised)."""
+        key = ("sizes", level)
+        if key not in self._memo:
+            o = self.levels[level].o.long()
+            self._memo[key] = torch.diff(o, prepend=o.new_zeros(1))
+        return self._memo[key]
+
     @property
     def device(self):
         return self.levels[0].p.device
@@ -102,7 +112,9 @@ class Geometry:
             count += (e - prev) // stride
             prev = e
             n_o.append(count)
-        n_o_dev = torch.tensor(n_o, dtype=torch.int32).to(L.p.device, non_blocking=True)
+        # device copy derived ON the device from the level's offsets (stream-ordered; no host buffer whose lifetime a
+        # queued async H2D copy would depend on)
+        n_o_dev = torch.cumsum(torch.div(self.sizes(level), stride, rounding_mode="floor"), 0).to(torch.int32)
         be = _native.backend_for(L.p)
         fps_idx = be.farthest_point_sampling(L.p, L.o, n_o_dev, L.n_max, count)
         n_p = L.p.index_select(0, fps_idx.long()).contiguous()
@@ -128,7 +140,65 @@ class Geometry:
         return self._memo[key]
 
     def memo_size(self):
-        return len(self._memo)
+        """Number of memoised geometry ops (FPS + kNN + interpolation tables)."""
+        return sum(1 for k in self._memo if k[0] in ("down", "knn", "interp"))
+
+    # ------------------------------------------------------------------ pre-pass
+    def precompute(self, strides=(1, 4, 4, 4, 4), nsamples=(8, 16, 16, 16, 16), interp_k=3, recognizer=True):
+        """Run every coordinate-only op of one PointTransformer-Seg (+ PDF U-decoder) forward now, on the current
+        stream: 4 FPS, 5 self-kNN, 4 down-sampling kNN, 4 (+1 for the U-decoder's level-5 self query) interpolation
+        tables -- the 13 distinct kNN tables behind the reference's 31 calls."""
+        lvl = 0
+        self.knn(nsamples[0], 0, 0)
+        for i in range(1, len(strides)):
+            new_level, _ = self.down(lvl, strides[i])
+            self.knn(nsamples[i], lvl, new_level)        # TransitionDown grouping (point_transformer_seg.py:103-111)
+            self.knn(nsamples[i], new_level, new_level)  # PointTransformerLayer self query (:48-50)
+            self.interp(new_level, lvl, interp_k)        # TransitionUp fusion (:163-167)
+            lvl = new_level
+        if recognizer:
+            self.interp(lvl, lvl, interp_k)              # PTRecognizer.dec5 interpolates level 5 onto itself (pt_v1.py:37)
+        return self
+
+    def tensors(self):
+        out = [lv.p for lv in self.levels] + [lv.o for lv in self.levels]
+        for v in self._memo.values():
+            out += [t for t in (v if isinstance(v, tuple) else (v,)) if isinstance(t, torch.Tensor)]
+        return out
+
+
+class GeometryPrefetcher:
+    """Computes the Geometry of upcoming batches on side HIP streams while the current batch trains.
+
+    FPS is a chain of tens of thousands of dependent arg-max steps that occupies one workgroup per scene; the rest of
+    the chip would idle behind it.  Coordinates are known as soon as a batch is collated, so its pre-pass can run
+    ``depth`` steps ahead (the way a DataLoader prefetches): every step still pays for exactly one full pre-pass,
+    only its latency is taken off the critical path.  ``get()`` makes the consumer stream wait for the pre-pass and
+    registers the tables with it (caching-allocator stream safety)."""
+
+    def __init__(self, depth=3, **plan):
+        self.depth, self.plan = depth, plan
+        self.streams = [torch.cuda.Stream() for _ in range(max(depth, 1))]
+        self._n = 0
+
+    def submit(self, coord, offset, offset_host=None):
+        stream = self.streams[self._n % len(self.streams)]
+        self._n += 1
+        stream.wait_stream(torch.cuda.current_stream())  # inputs were produced on the caller's stream
+        with torch.cuda.stream(stream):
+            geom = Geometry(coord, offset, offset_host).precompute(**self.plan)
+            done = torch.cuda.Event()
+            done.record(stream)
+        return geom, done, stream
+
+    @staticmethod
+    def get(ticket):
+        geom, done, stream = ticket
+        cur = torch.cuda.current_stream()
+        cur.wait_event(done)
+        for t in geom.tensors():
+            t.record_stream(cur)
+        return geom
 
 
 def interpolation_weights(dist2):

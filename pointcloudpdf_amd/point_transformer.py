@@ -149,7 +149,9 @@ class TransitionUp(nn.Module):
             chunks = x.split(sizes, dim=0)
             means = torch.cat([ch.sum(0, True) / ch.shape[0] for ch in chunks], 0)  # (b, c)
             ctx = self.linear2(means)
-            rep = torch.repeat_interleave(ctx, torch.tensor(sizes, device=x.device), dim=0, output_size=x.shape[0])
+            tag = tag_of(p)
+            sizes_dev = tag[0].sizes(tag[1]) if tag is not None else torch.diff(o.long(), prepend=o.new_zeros(1).long())
+            rep = torch.repeat_interleave(ctx, sizes_dev, dim=0, output_size=x.shape[0])
             x = self.linear1(torch.cat((x, rep), 1))
         else:
             p1, x1, o1 = pxo1
