@@ -1,0 +1,85 @@
+"""CPU suite: the N > 1 path (whole scenes sharded over ranks, one gradient all-reduce, max-over-ranks timing) with
+world_size 2 over gloo.  The ops run on the CPU oracle here (test-only injection); the product path is HIP + RCCL."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, sizes_per_rank, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    import oracle
+    from pointcloudpdf_amd import _native, engine, synthetic
+
+    _native._set_backend_for_testing(oracle.backend())
+    r, lr, w = engine.init_distributed()
+    assert (r, w) == (rank, world) and dist.get_backend() == "gloo"
+    step = engine.OpenSegStep(backbone="PointTransformer-Seg26")
+    synthetic.fill_parameters_deterministic(step, seed=1)
+    step.train()
+    ddp = engine.wrap_ddp(step, torch.device("cpu"))
+    # whole scenes are the sharding unit: global scene list -> this rank's scenes
+    scene_ids = engine.shard_scene_ids(len(sizes_per_rank) * world, rank, world)
+    sizes = [sizes_per_rank[i // world] for i in scene_ids]
+    batch = synthetic.make_batch(sizes, first_scene_id=scene_ids[0], grid_size=0.3)
+    out = ddp(batch)
+    out["loss"].backward()
+    grads = {n: p.grad.clone() for n, p in step.named_parameters() if p.grad is not None}
+    # reference: average of per-rank local gradients, computed without DDP
+    torch.save(dict(loss=out["loss"].detach(), grads=grads, scene_ids=scene_ids, n=batch["coord"].shape[0]),
+               os.path.join(out_dir, f"ddp_{rank}.pt"))
+    local = engine.OpenSegStep(backbone="PointTransformer-Seg26")
+    synthetic.fill_parameters_deterministic(local, seed=1)
+    local.train()
+    lo = local(batch)
+    lo["loss"].backward()
+    torch.save({n: p.grad.clone() for n, p in local.named_parameters() if p.grad is not None}, os.path.join(out_dir, f"local_{rank}.pt"))
+    # bench.py's timing contract: MAX over ranks
+    t = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert t.item() == float(world)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, [1100, 900], str(tmp_path)), nprocs=world, join=True)
+    d = [torch.load(tmp_path / f"ddp_{r}.pt") for r in range(world)]
+    loc = [torch.load(tmp_path / f"local_{r}.pt") for r in range(world)]
+    assert d[0]["scene_ids"] == [0, 2] and d[1]["scene_ids"] == [1, 3]  # disjoint whole scenes
+    assert d[0]["n"] == d[1]["n"] == 2000
+    assert abs(d[0]["loss"].item() - d[1]["loss"].item()) > 0  # different scenes per rank
+    gscale = max(((loc[0][n] + loc[1][n]) / 2).abs().max().item() for n in d[0]["grads"])
+    for name, g0 in d[0]["grads"].items():
+        g1 = d[1]["grads"][name]
+        assert torch.equal(g0, g1), f"{name}: ranks disagree after all-reduce"
+        mean_local = (loc[0][name] + loc[1][name]) / 2
+        scale = mean_local.abs().max().item() + 1e-12
+        # analytically-zero gradients (biases in front of a train-mode BatchNorm) are rounding noise: floor at 1e-5 of the
+        # largest gradient in the model
+        assert (g0 - mean_local).abs().max().item() <= 1e-5 * scale + 1e-5 * gscale, name
+
+
+def test_shard_scene_ids_partition():
+    from pointcloudpdf_amd import engine
+
+    ids = [engine.shard_scene_ids(16, r, 8) for r in range(8)]
+    assert sorted(sum(ids, [])) == list(range(16)) and all(len(i) == 2 for i in ids)
