@@ -107,6 +107,31 @@ int pdf_group_backward(int m, int nsample, int c, int with_xyz, const float *gra
  * weight[n,j] = (1/(sqrt(dist2[n,j])+1e-8)) / sum_j(...) */
 int pdf_interpolation_weights(int n, int k, const float *dist2, float *weight, void *stream);
 
+/* Fused PointTransformerLayer (point_transformer_seg.py:45-78 incl. the three BatchNorm-as-LayerNorm norms,
+ * pointcept/models/point_transformer/utils.py:7-14), forward.  Supported: nsample in {8,16}, c in {32,64,128}
+ * (pdf_pt_layer_supported).  weights[8] = Wp1,bp1,Wp2,bp2,Ww1,bw1,Ww2,bw2 (host array of device pointers);
+ * bn_params[6] = gamma/beta of linear_p[1], linear_w[0], linear_w[3]; bn_buffers[6] = their running mean/var
+ * (updated in place when training).  bn (2*(3+c+c/8) floats) receives the scale/shift of the three norms,
+ * saved (same size) their batch mean / rstd (training), H (n*nsample*c/8) the pre-norm attention hidden,
+ * partial = pdf_pt_layer_partial_floats(...) floats of scratch, out (n,c). */
+int pdf_pt_layer_supported(int nsample, int c);
+long pdf_pt_layer_partial_floats(int n, int nsample, int c);
+int pdf_pt_layer_forward(int n, int nsample, int c, const float *xq, const float *xk, const float *xv,
+                         const float *p, const int *idx, const float *const *weights,
+                         const float *const *bn_params, float *const *bn_buffers, int training, float eps,
+                         float momentum, float *bn, float *saved, float *H, float *partial, float *out,
+                         void *stream);
+
+/* Backward of the fused PointTransformerLayer (train mode).  gxk / gxv are pre-zeroed scatter targets, gxq is
+ * overwritten.  sums needs pdf_pt_layer_bwd_sums_floats(c) + 2*(3+c+c/8) floats and returns the parameter-gradient
+ * sections documented in csrc/fused_layer.hip. */
+long pdf_pt_layer_bwd_partial_floats(int n, int nsample, int c);
+long pdf_pt_layer_bwd_sums_floats(int c);
+int pdf_pt_layer_backward(int n, int nsample, int c, const float *xq, const float *xk, const float *xv,
+                          const float *p, const int *idx, const float *const *weights, const float *bn,
+                          const float *saved, const float *H, const float *gout, float *gxq, float *gxk,
+                          float *gxv, float *G2, float *G3, float *partial, float *sums, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

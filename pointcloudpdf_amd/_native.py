@@ -243,6 +243,17 @@ class HipBackend(CBackend):
         self.last_fps_stats = None
         lib.pdf_abi_version.restype = c_int
         lib.pdf_build_info.restype = ctypes.c_char_p
+        lib.pdf_pt_layer_supported.restype = c_int
+        lib.pdf_pt_layer_supported.argtypes = [c_int, c_int]
+        for fn in (lib.pdf_pt_layer_partial_floats, lib.pdf_pt_layer_bwd_partial_floats):
+            fn.restype = c_long
+            fn.argtypes = [c_int, c_int, c_int]
+        lib.pdf_pt_layer_bwd_sums_floats.restype = c_long
+        lib.pdf_pt_layer_bwd_sums_floats.argtypes = [c_int]
+        lib.pdf_pt_layer_forward.restype = c_int
+        lib.pdf_pt_layer_forward.argtypes = [c_int, c_int, c_int] + [c_void_p] * 8 + [c_int, ctypes.c_float, ctypes.c_float] + [c_void_p] * 6
+        lib.pdf_pt_layer_backward.restype = c_int
+        lib.pdf_pt_layer_backward.argtypes = [c_int, c_int, c_int] + [c_void_p] * 18
         self.fps_mode = os.environ.get("PDFOPS_FPS", "bucketed")  # "bucketed" | "plain"
 
     def farthest_point_sampling(self, xyz, offset, new_offset, n_max, m_total):
@@ -259,6 +270,72 @@ class HipBackend(CBackend):
             o = int(self.lib.pdf_fps_stats_offset(b, n_total))
             self.last_fps_stats = ws[o:o + 16 * b].view(torch.int32).view(b, 4).cpu()
         return idx
+
+    # -- fused PointTransformerLayer -----------------------------------------------------------------
+    def pt_layer_supported(self, nsample, c):
+        return bool(self.lib.pdf_pt_layer_supported(int(nsample), int(c)))
+
+    @staticmethod
+    def _ptr_array(tensors):
+        return (c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+    def pt_layer_forward(self, xq, xk, xv, p, idx, weights, bn_params, bn_buffers, training, eps, momentum):
+        """-> out (N,C), ctx tensors (bn scale/shift, saved mean/rstd, H).  See include/pdfops.h."""
+        n, c = xq.shape
+        k = idx.shape[1]
+        cs = c // 8
+        for t in (xq, xk, xv, p, *weights, *bn_params):
+            _check(t, torch.float32, "pt_layer tensor")
+        _check(idx, torch.int32, "idx")
+        bn = self._new(xq, (2 * (3 + c + cs),), torch.float32)
+        saved = self._new(xq, (2 * (3 + c + cs),), torch.float32)
+        H = self._new(xq, (n, k, cs), torch.float32)
+        partial = self._new(xq, (int(self.lib.pdf_pt_layer_partial_floats(n, k, c)),), torch.float32)
+        out = self._new(xq, (n, c), torch.float32)
+        rc = self.lib.pdf_pt_layer_forward(
+            n, k, c, self._ptr(xq), self._ptr(xk), self._ptr(xv), self._ptr(p), self._ptr(idx),
+            self._ptr_array(weights), self._ptr_array(bn_params), self._ptr_array(bn_buffers), int(bool(training)),
+            ctypes.c_float(eps), ctypes.c_float(momentum), self._ptr(bn), self._ptr(saved), self._ptr(H),
+            self._ptr(partial), self._ptr(out), c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise PdfOpsError(f"pdf_pt_layer_forward failed with status {rc}")
+        return out, bn, saved, H
+
+    def pt_layer_backward(self, xq, xk, xv, p, idx, weights, bn, saved, H, gout):
+        n, c = xq.shape
+        k = idx.shape[1]
+        cs = c // 8
+        _check(gout, torch.float32, "gout")
+        gxq = self._new(xq, (n, c), torch.float32)
+        gxk = self._new(xq, (n, c), torch.float32, zero=True)
+        gxv = self._new(xq, (n, c), torch.float32, zero=True)
+        G2 = self._new(xq, (n * k * cs,), torch.float32)
+        G3 = self._new(xq, (n * k * 3,), torch.float32)
+        partial = self._new(xq, (int(self.lib.pdf_pt_layer_bwd_partial_floats(n, k, c)),), torch.float32)
+        nsum = int(self.lib.pdf_pt_layer_bwd_sums_floats(c))
+        sums = self._new(xq, (nsum + 2 * (3 + c + cs),), torch.float32)
+        rc = self.lib.pdf_pt_layer_backward(
+            n, k, c, self._ptr(xq), self._ptr(xk), self._ptr(xv), self._ptr(p), self._ptr(idx),
+            self._ptr_array(weights), self._ptr(bn), self._ptr(saved), self._ptr(H), self._ptr(gout),
+            self._ptr(gxq), self._ptr(gxk), self._ptr(gxv), self._ptr(G2), self._ptr(G3), self._ptr(partial),
+            self._ptr(sums), c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise PdfOpsError(f"pdf_pt_layer_backward failed with status {rc}")
+        # unpack the parameter-gradient sections (layout: csrc/fused_layer.hip, pdf_pt_layer_backward)
+        o1 = 0
+        o2 = o1 + 3 * cs + cs * cs
+        o3 = o2 + 2 * c + cs + cs * c
+        o4 = o3 + 8 + 4 * c
+        g = dict(
+            beta2=sums[o1:o1 + cs], gamma2=sums[o1 + cs:o1 + 2 * cs], bw2=sums[o1 + 2 * cs:o1 + 3 * cs],
+            Ww2=sums[o1 + 3 * cs:o2].view(cs, cs),
+            beta1=sums[o2:o2 + c], gamma1=sums[o2 + c:o2 + 2 * c], bw1=sums[o2 + 2 * c:o2 + 2 * c + cs],
+            Ww1=sums[o2 + 2 * c + cs:o3].view(cs, c),
+            betap=sums[o3:o3 + 3], gammap=sums[o3 + 3:o3 + 6], bp2=sums[o3 + 8:o3 + 8 + c],
+            Wp2=sums[o3 + 8 + c:o4].view(c, 3),
+            bp1=sums[o4:o4 + 3], Wp1=sums[o4 + 3:o4 + 12].view(3, 3),
+        )
+        return gxq, gxk, gxv, g
 
     def group_forward(self, feat, xyz, new_xyz, idx, with_xyz):
         _check(feat, torch.float32, "feat"); _check(idx, torch.int32, "idx")

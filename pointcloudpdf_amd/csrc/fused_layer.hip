@@ -1,0 +1,1035 @@
+// Fused PointTransformerLayer (vector attention with shared planes) for gfx950 -- forward passes.
+// Reference semantics: pointcept/models/point_transformer/point_transformer_seg.py:45-78 with
+// LayerNorm1d == BatchNorm1d over all n*nsample rows (utils.py:7-14), in train mode (batch statistics) or eval mode.
+//
+//   rel   = mask * (p[idx] - p[i])                         (grouping(), libs/pointops/functions/grouping.py:49-57)
+//   t1    = rel Wp1^T + bp1 ; t1n = relu(BNp(t1))          (linear_p[0..2])
+//   p_r   = t1n Wp2^T + bp2                                (linear_p[3])
+//   r     = x_k[idx] - x_q[i] + p_r                        (:63-69)
+//   h     = relu(BN1(r)) Ww1^T + bw1                       (linear_w[0..2])
+//   z     = relu(BN2(h)) Ww2^T + bw2 ; w = softmax_j z     (linear_w[3..5], softmax over the neighbour dim)
+//   out_i = sum_j (x_v[idx] + p_r) * w[.., ch mod C/8]     (:72-77)
+//
+// The reference materialises ~12 (n, ns, c) tensors per layer (205 MB each at levels 1/2).  Here nothing c-wide ever
+// reaches HBM: every pass re-gathers the neighbour rows (they sit in L2 / Infinity Cache) and recomputes the cheap
+// 3-channel branch; only h (n, ns, c/8) is stored.  Train-mode BatchNorm needs the statistics of t1, r and h over all
+// rows before they can be normalised, hence four passes:
+//   P1 stats(t1) -> P2 stats(r) -> P3 h + stats(h) -> P4 softmax + aggregation,   each followed by a tiny finalize.
+// Mapping: one lane = one (point, neighbour) row, 64 rows per wave tile; neighbour rows are gathered with coalesced
+// 16-byte loads (8 lanes per 128-byte row chunk) into a padded LDS tile and read back row-per-lane (conflict-free,
+// stride 33); weights are wave-uniform and arrive through the scalar cache; per-channel statistics are reduced through
+// the same LDS tile read column-wise.  HBM-bound by design (algorithmic bytes: q,k,v rows once + p + idx + out).
+#include "pdfops_common.h"
+
+namespace fl {
+
+constexpr int TS = 33;          // LDS tile row stride in floats (bank-conflict-free for row-per-lane and column reads)
+constexpr int WPB = 4;          // waves per block
+constexpr int MAX_BLOCKS = 1024;
+
+struct LayerArgs {
+    int N;                                   // points
+    const float *xq, *xk, *xv, *p;           // (N,C) x3, (N,3)
+    const int *idx;                          // (N,K)
+    const float *Wp1, *bp1, *Wp2, *bp2;      // (3,3) (3) (C,3) (C)
+    const float *Ww1, *bw1, *Ww2, *bw2;      // (CS,C) (CS) (CS,CS) (CS)
+    const float *sp, *tp, *s1, *t1, *s2, *t2;  // BatchNorm scale/shift: y = x*s + t  (3,3,C,C,CS,CS)
+    float *H;                                // (N,K,CS) pre-BN2 activations
+    float *out;                              // (N,C)
+    float *partial;                          // per-wave partial sums for the statistics of the current pass
+    // ---- backward only
+    const float *gout;                       // (N,C) gradient of the layer output
+    const float *mean, *rstd;                // saved batch statistics [p(3) | 1(C) | 2(CS)] (mean and rstd arrays)
+    const float *sums;                       // column sums of the previous backward pass (BatchNorm-backward terms)
+    float *G2, *G3;                          // (N,K,CS) grad wrt BN2 output (post-ReLU mask), (N,K,3) same for BNp
+    float *gxq, *gxk, *gxv;                  // (N,C) gradients (gxk / gxv pre-zeroed scatter targets)
+    float inv_rows;                          // 1 / (N*K)
+};
+
+struct WaveLds {
+    float *tile;   // [64][TS]
+    float *qtile;  // [8][TS]   rows of the tile's centre points
+    int *rowid;    // [64]      gathered row index per tile row (-1 = zero row)
+    float *aux;    // [64][AUX] second operand of the weight-gradient products (backward kernels only)
+};
+constexpr int AUX = 17;
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Gather 32 channels [c0, c0+32) of the 64 rows listed in L.rowid into L.tile (coalesced: 8 lanes x 16 B per row).
+__device__ __forceinline__ void stage_rows(const WaveLds &L, const float *__restrict__ table, int C, int c0, int lane) {
+    const int sub = lane >> 3, col = (lane & 7) * 4;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int row = t * 8 + sub;
+        const int src = L.rowid[row];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (src >= 0) v = *reinterpret_cast<const float4 *>(table + (size_t)src * C + c0 + col);
+        float *d = L.tile + row * TS + col;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+}
+
+// Rows of the tile's PPT centre points (first point i0) into L.qtile.
+template <int PPT>
+__device__ __forceinline__ void stage_points(const WaveLds &L, const float *__restrict__ table, int C, int c0, int i0, int N, int lane) {
+    if (lane < PPT * 8) {
+        const int pt = lane >> 3, col = (lane & 7) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i0 + pt < N) v = *reinterpret_cast<const float4 *>(table + (size_t)(i0 + pt) * C + c0 + col);
+        float *d = L.qtile + pt * TS + col;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+}
+
+struct Row {
+    int row, i, nb;
+    bool valid;
+    float rel[3];  // masked relative coordinates
+    float t1[3];   // Linear(3,3) output (pre-BN)
+};
+
+template <int K>
+__device__ __forceinline__ Row load_row(const LayerArgs &A, long tile, int lane) {
+    Row R;
+    const long row = tile * 64 + lane;
+    R.valid = row < (long)A.N * K;
+    R.row = (int)row;
+    R.i = (int)(row / K);
+    R.nb = R.valid ? A.idx[row] : -1;
+    R.rel[0] = R.rel[1] = R.rel[2] = 0.f;
+    if (R.nb >= 0) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) R.rel[b] = A.p[(size_t)R.nb * 3 + b] - A.p[(size_t)R.i * 3 + b];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        R.t1[a] = R.rel[0] * A.Wp1[a * 3 + 0] + R.rel[1] * A.Wp1[a * 3 + 1] + R.rel[2] * A.Wp1[a * 3 + 2] + A.bp1[a];
+    return R;
+}
+
+__device__ __forceinline__ void bn_relu3(const LayerArgs &A, const float *t1, float *t1n) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) t1n[a] = fmaxf(t1[a] * A.sp[a] + A.tp[a], 0.f);
+}
+
+// p_r chunk: 32 channels [c0, c0+32) of Linear(3, C)
+__device__ __forceinline__ void pos_chunk(const LayerArgs &A, const float *t1n, int c0, float *pr) {
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        const float *w = A.Wp2 + (size_t)(c0 + c) * 3;
+        pr[c] = t1n[0] * w[0] + t1n[1] * w[1] + t1n[2] * w[2] + A.bp2[c0 + c];
+    }
+}
+
+// Column sums of the 64x32 tile: lane (ch = lane & 31, half = lane >> 5) adds its 32 rows into s / ss.
+__device__ __forceinline__ void column_stats(const WaveLds &L, int lane, float &s, float &ss) {
+    const int ch = lane & 31, r0 = (lane >> 5) * 32;
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        const float v = L.tile[(r0 + r) * TS + ch];
+        a += v;
+        b += v * v;
+    }
+    s += a;
+    ss += b;
+}
+
+constexpr int LDS_FLOATS_PER_WAVE = 64 * TS + 8 * TS + 64;
+constexpr int LDS_FLOATS_PER_WAVE_BWD = LDS_FLOATS_PER_WAVE + 64 * AUX;
+template <bool BWD = false>
+__device__ __forceinline__ WaveLds carve_lds(float *base, int wave) {
+    WaveLds L;
+    float *w = base + wave * (BWD ? LDS_FLOATS_PER_WAVE_BWD : LDS_FLOATS_PER_WAVE);
+    L.tile = w;
+    L.qtile = w + 64 * TS;
+    L.rowid = reinterpret_cast<int *>(w + 64 * TS + 8 * TS);
+    L.aux = w + LDS_FLOATS_PER_WAVE;
+    return L;
+}
+
+// ------------------------------------------------------------------------------------------------ P1: stats of t1
+template <int K>
+__global__ __launch_bounds__(64 * WPB) void k_p1(LayerArgs A) {
+    const int lane = threadIdx.x & 63;
+    const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
+    const long ntiles = ((long)A.N * K + 63) / 64;
+    float s[3] = {0.f, 0.f, 0.f}, ss[3] = {0.f, 0.f, 0.f};
+    for (long tile = wave_g; tile < ntiles; tile += nwaves) {
+        const Row R = load_row<K>(A, tile, lane);
+        if (R.valid) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { s[a] += R.t1[a]; ss[a] += R.t1[a] * R.t1[a]; }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { s[a] = pdf_wave_sum_f32(s[a]); ss[a] = pdf_wave_sum_f32(ss[a]); }
+    if (lane == 0) {
+        float *o = A.partial + wave_g * 6;
+        o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = ss[0]; o[4] = ss[1]; o[5] = ss[2];
+    }
+}
+
+// r chunk of one row: needs the staged xk chunk (tile) and xq chunk (qtile)
+template <int K>
+__device__ __forceinline__ void rqk_chunk(const WaveLds &L, int lane, const float *pr, float *r) {
+    const float *xk = L.tile + lane * TS;
+    const float *xq = L.qtile + (lane / K) * TS;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) r[c] = (xk[c] - xq[c]) + pr[c];
+}
+
+// ------------------------------------------------------------------------------------------------ P2: stats of r
+template <int C, int K>
+__global__ __launch_bounds__(64 * WPB) void k_p2(LayerArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NCH = C / 32, PPT = 64 / K;
+    const int lane = threadIdx.x & 63;
+    const WaveLds L = carve_lds<false>(lds, threadIdx.x >> 6);
+    const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
+    const long ntiles = ((long)A.N * K + 63) / 64;
+    float s[NCH], ss[NCH];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) { s[q] = 0.f; ss[q] = 0.f; }
+    for (long tile = wave_g; tile < ntiles; tile += nwaves) {
+        const Row R = load_row<K>(A, tile, lane);
+        float t1n[3];
+        bn_relu3(A, R.t1, t1n);
+        L.rowid[lane] = R.nb;
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            stage_rows(L, A.xk, C, q * 32, lane);
+            stage_points<PPT>(L, A.xq, C, q * 32, (int)(tile * PPT), A.N, lane);
+            wave_sync();
+            float pr[32], r[32];
+            pos_chunk(A, t1n, q * 32, pr);
+            rqk_chunk<K>(L, lane, pr, r);
+            wave_sync();
+#pragma unroll
+            for (int c = 0; c < 32; ++c) L.tile[lane * TS + c] = R.valid ? r[c] : 0.f;
+            wave_sync();
+            column_stats(L, lane, s[q], ss[q]);
+            wave_sync();
+        }
+    }
+    // partial layout per wave: [sum(C) | sumsq(C)]
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        const float a = s[q] + __shfl_xor(s[q], 32, 64), b = ss[q] + __shfl_xor(ss[q], 32, 64);
+        if (lane < 32) {
+            A.partial[wave_g * 2 * C + q * 32 + lane] = a;
+            A.partial[wave_g * 2 * C + C + q * 32 + lane] = b;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ P3: h (+ stats)
+template <int C, int K, bool STATS>
+__global__ __launch_bounds__(64 * WPB) void k_p3(LayerArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NCH = C / 32, PPT = 64 / K, CS = C / 8;
+    const int lane = threadIdx.x & 63;
+    const WaveLds L = carve_lds<false>(lds, threadIdx.x >> 6);
+    const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
+    const long ntiles = ((long)A.N * K + 63) / 64;
+    float s = 0.f, ss = 0.f;  // lane (ch = lane & 31 < CS, half) accumulates channel ch of h   (CS <= 16 here)
+    for (long tile = wave_g; tile < ntiles; tile += nwaves) {
+        const Row R = load_row<K>(A, tile, lane);
+        float t1n[3];
+        bn_relu3(A, R.t1, t1n);
+        L.rowid[lane] = R.nb;
+        wave_sync();
+        float h[CS];
+#pragma unroll
+        for (int o = 0; o < CS; ++o) h[o] = A.bw1[o];
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            stage_rows(L, A.xk, C, q * 32, lane);
+            stage_points<PPT>(L, A.xq, C, q * 32, (int)(tile * PPT), A.N, lane);
+            wave_sync();
+            float pr[32], r[32];
+            pos_chunk(A, t1n, q * 32, pr);
+            rqk_chunk<K>(L, lane, pr, r);
+            wave_sync();
+#pragma unroll
+            for (int c = 0; c < 32; ++c) r[c] = fmaxf(r[c] * A.s1[q * 32 + c] + A.t1[q * 32 + c], 0.f);
+#pragma unroll
+            for (int o = 0; o < CS; ++o) {
+                const float *wrow = A.Ww1 + (size_t)o * C + q * 32;  // wave-uniform, contiguous -> batched s_load
+#pragma unroll
+                for (int c = 0; c < 32; ++c) h[o] += r[c] * wrow[c];
+            }
+        }
+        if (R.valid) {
+            float *dst = A.H + (size_t)R.row * CS;
+#pragma unroll
+            for (int o = 0; o < CS; o += 4) *reinterpret_cast<float4 *>(dst + o) = make_float4(h[o], h[o + 1], h[o + 2], h[o + 3]);
+        }
+        if (STATS) {
+#pragma unroll
+            for (int o = 0; o < CS; ++o) L.tile[lane * TS + o] = R.valid ? h[o] : 0.f;
+            wave_sync();
+            if ((lane & 31) < CS) column_stats(L, lane, s, ss);
+            wave_sync();
+        }
+    }
+    if (STATS) {
+        const float a = s + __shfl_xor(s, 32, 64), b = ss + __shfl_xor(ss, 32, 64);
+        if (lane < CS) {
+            A.partial[wave_g * 2 * CS + lane] = a;
+            A.partial[wave_g * 2 * CS + CS + lane] = b;
+        }
+    }
+}
+
+// butterfly reductions inside groups of K (8 or 16) consecutive lanes, every lane gets the result (DPP only)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+template <int K>
+__device__ __forceinline__ float group_max(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_f<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_f<0x141>(v));  // row_half_mirror
+    if (K == 16) v = fmaxf(v, dpp_f<0x140>(v));  // row_mirror
+    return v;
+}
+template <int K>
+__device__ __forceinline__ float group_sum(float v) {
+    v += dpp_f<0xB1>(v);
+    v += dpp_f<0x4E>(v);
+    v += dpp_f<0x141>(v);
+    if (K == 16) v += dpp_f<0x140>(v);
+    return v;
+}
+
+// attention weights of one row from its stored h: w = softmax_j( relu(BN2(h)) Ww2^T + bw2 )
+template <int CS>
+__device__ __forceinline__ void load_hidden(const LayerArgs &A, const Row &R, float *h) {
+    const float *src = A.H + (size_t)(R.valid ? R.row : 0) * CS;
+#pragma unroll
+    for (int o = 0; o < CS; o += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + o);
+        h[o] = v.x; h[o + 1] = v.y; h[o + 2] = v.z; h[o + 3] = v.w;
+    }
+}
+
+template <int CS, int K>
+__device__ __forceinline__ void attn_weights(const LayerArgs &A, const Row &R, float *w, float *h_out = nullptr, float *u_out = nullptr) {
+    float u[CS];
+    load_hidden<CS>(A, R, u);
+#pragma unroll
+    for (int o = 0; o < CS; ++o) {
+        if (h_out) h_out[o] = u[o];
+        u[o] = fmaxf(u[o] * A.s2[o] + A.t2[o], 0.f);
+        if (u_out) u_out[o] = u[o];
+    }
+#pragma unroll
+    for (int o = 0; o < CS; ++o) {
+        float z = A.bw2[o];
+#pragma unroll
+        for (int c = 0; c < CS; ++c) z += u[c] * A.Ww2[o * CS + c];
+        const float m = group_max<K>(z);
+        const float e = __expf(z - m);
+        w[o] = e / group_sum<K>(e);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ P4: aggregation
+template <int C, int K>
+__global__ __launch_bounds__(64 * WPB) void k_p4(LayerArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NCH = C / 32, PPT = 64 / K, CS = C / 8;
+    const int lane = threadIdx.x & 63;
+    const WaveLds L = carve_lds<false>(lds, threadIdx.x >> 6);
+    const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
+    const long ntiles = ((long)A.N * K + 63) / 64;
+    for (long tile = wave_g; tile < ntiles; tile += nwaves) {
+        const Row R = load_row<K>(A, tile, lane);
+        float t1n[3];
+        bn_relu3(A, R.t1, t1n);
+        float w[CS];
+        attn_weights<CS, K>(A, R, w);
+        L.rowid[lane] = R.nb;
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            stage_rows(L, A.xv, C, q * 32, lane);
+            wave_sync();
+            float pr[32], val[32];
+            pos_chunk(A, t1n, q * 32, pr);
+            const float *xv = L.tile + lane * TS;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) val[c] = (xv[c] + pr[c]) * w[(q * 32 + c) % CS];
+            wave_sync();
+#pragma unroll
+            for (int c = 0; c < 32; ++c) L.tile[lane * TS + c] = val[c];
+            wave_sync();
+            // out[(i0+pt), q*32+ch] = sum_j tile[pt*K + j][ch]
+#pragma unroll
+            for (int m = 0; m < PPT / 2; ++m) {
+                const int pt = m * 2 + (lane >> 5), ch = lane & 31;
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < K; ++j) acc += L.tile[(pt * K + j) * TS + ch];
+                const long i = tile * PPT + pt;
+                if (i < A.N) A.out[(size_t)i * C + q * 32 + ch] = acc;
+            }
+            wave_sync();
+        }
+    }
+}
+
+// ================================================================================================ backward passes
+// Given g_out (N,C) the chain is differentiated in four passes, mirroring the forward ones in reverse (each train-mode
+// BatchNorm needs sum(dy) and sum(dy * xhat) over ALL rows before dx can be formed):
+//   B1: d softmax / Ww2 / BN2-sums, scatter g_xv                  -> G2 = dL/d(BN2 out, masked by its ReLU)
+//   B2: BN2 backward -> g_h, d Ww1, BN1-sums
+//   B3: BN1 backward -> g_r: scatter g_xk, g_xq, g_pr -> d Wp2, G3 = dL/d(BNp out, masked), BNp-sums
+//   B4: BNp backward -> d Wp1
+// Parameter gradients and BatchNorm sums are accumulated per wave in registers (lanes <-> output elements, operands
+// exchanged through LDS tiles), written as one partial row per wave and column-summed by k_colsum (deterministic).
+constexpr int MAX_BLOCKS_BWD = 256;
+
+__device__ __forceinline__ void scatter_rows_atomic(const WaveLds &L, float *__restrict__ table, int C, int c0, int lane) {
+    const int sub = lane >> 3, col = (lane & 7) * 4;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int row = t * 8 + sub;
+        const int dst = L.rowid[row];
+        if (dst < 0) continue;
+        const float *sv = L.tile + row * TS + col;
+        float *d = table + (size_t)dst * C + c0 + col;
+        pdf_atomic_add(d + 0, sv[0]); pdf_atomic_add(d + 1, sv[1]); pdf_atomic_add(d + 2, sv[2]); pdf_atomic_add(d + 3, sv[3]);
+    }
+}
+
+__device__ __forceinline__ float column_sum(const WaveLds &L, int lane) {  // lane (ch = lane & 31, half): 32 rows
+    const int ch = lane & 31, r0 = (lane >> 5) * 32;
+    float a = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) a += L.tile[(r0 + r) * TS + ch];
+    return a;
+}
+
+// sum over the 64 tile rows of A[r][a] * B[r][b]; A in L.aux (stride AUX), B in L.tile (stride TS)
+__device__ __forceinline__ float dot_aux_tile(const WaveLds &L, int a, int b) {
+    float acc = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < 64; ++r) acc += L.aux[r * AUX + a] * L.tile[r * TS + b];
+    return acc;
+}
+
+// ---- B1 partial layout (floats): [sum g_y2 (CS) | sum g_y2*hhat (CS) | g_bw2 (CS) | g_Ww2 (CS*CS)]
+template <int C> constexpr int b1_width() { return 3 * (C / 8) + (C / 8) * (C / 8); }
+// ---- B2: [sum g_y1 (C) | sum g_y1*rhat (C) | g_bw1 (CS) | g_Ww1 (CS*C)]
+template <int C> constexpr int b2_width() { return 2 * C + C / 8 + (C / 8) * C; }
+// ---- B3: [sum g_yp (3) | sum g_yp*that (3) | pad 2 | g_bp2 (C) | g_Wp2 (C*3)]
+template <int C> constexpr int b3_width() { return 8 + C + 3 * C; }
+// ---- B4: [g_bp1 (3) | g_Wp1 (9) | pad 4]
+constexpr int b4_width() { return 16; }
+
+template <int C, int K>
+__global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NCH = C / 32, PPT = 64 / K, CS = C / 8, NW2 = (CS * CS + 63) / 64, W = b1_width<C>();
+    const int lane = threadIdx.x & 63;
+    const WaveLds L = carve_lds<true>(lds, threadIdx.x >> 6);
+    const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
+    const long ntiles = ((long)A.N * K + 63) / 64;
+    const float *m2 = A.mean + 3 + C, *r2 = A.rstd + 3 + C;
+    float sg[CS], sgh[CS], sgz[CS], aw2[NW2];
+#pragma unroll
+    for (int o = 0; o < CS; ++o) { sg[o] = 0.f; sgh[o] = 0.f; sgz[o] = 0.f; }
+#pragma unroll
+    for (int m = 0; m < NW2; ++m) aw2[m] = 0.f;
+    for (long tile = wave_g; tile < ntiles; tile += nwaves) {
+        const Row R = load_row<K>(A, tile, lane);
+        float t1n[3];
+        bn_relu3(A, R.t1, t1n);
+        float w[CS], h[CS], u[CS], gw[CS];
+        attn_weights<CS, K>(A, R, w, h, u);
+#pragma unroll
+        for (int o = 0; o < CS; ++o) gw[o] = 0.f;
+        L.rowid[lane] = R.nb;
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            stage_rows(L, A.xv, C, q * 32, lane);
+            stage_points<PPT>(L, A.gout, C, q * 32, (int)(tile * PPT), A.N, lane);
+            wave_sync();
+            float pr[32], ga[32];
+            pos_chunk(A, t1n, q * 32, pr);
+            const float *xv = L.tile + lane * TS;
+            const float *go = L.qtile + (lane / K) * TS;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                const float g = R.valid ? go[c] : 0.f;
+                gw[(q * 32 + c) % CS] += g * (xv[c] + pr[c]);
+                ga[c] = g * w[(q * 32 + c) % CS];
+            }
+            wave_sync();
+#pragma unroll
+            for (int c = 0; c < 32; ++c) L.tile[lane * TS + c] = ga[c];
+            wave_sync();
+            scatter_rows_atomic(L, A.gxv, C, q * 32, lane);
+            wave_sync();
+        }
+        // softmax backward over the K neighbours, then Linear(CS,CS) and the ReLU of BN2
+        float gz[CS], gy2[CS];
+#pragma unroll
+        for (int o = 0; o < CS; ++o) {
+            const float dot = group_sum<K>(w[o] * gw[o]);
+            gz[o] = R.valid ? w[o] * (gw[o] - dot) : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < CS; ++c) {
+            float gu = 0.f;
+#pragma unroll
+            for (int o = 0; o < CS; ++o) gu += gz[o] * A.Ww2[o * CS + c];
+            gy2[c] = u[c] > 0.f ? gu : 0.f;
+            const float hhat = (h[c] - m2[c]) * r2[c];
+            sg[c] += gy2[c];
+            sgh[c] += gy2[c] * hhat;
+            sgz[c] += gz[c];
+        }
+        if (R.valid) {
+            float *dst = A.G2 + (size_t)R.row * CS;
+#pragma unroll
+            for (int o = 0; o < CS; o += 4) *reinterpret_cast<float4 *>(dst + o) = make_float4(gy2[o], gy2[o + 1], gy2[o + 2], gy2[o + 3]);
+        }
+        // g_Ww2[o][c] += sum_rows gz[o] * u[c]
+#pragma unroll
+        for (int o = 0; o < CS; ++o) { L.aux[lane * AUX + o] = gz[o]; L.tile[lane * TS + o] = R.valid ? u[o] : 0.f; }
+        wave_sync();
+#pragma unroll
+        for (int m = 0; m < NW2; ++m) {
+            const int e = m * 64 + lane;
+            if (e < CS * CS) aw2[m] += dot_aux_tile(L, e / CS, e % CS);
+        }
+        wave_sync();
+    }
+    float *o = A.partial + wave_g * W;
+#pragma unroll
+    for (int c = 0; c < CS; ++c) {
+        const float a = pdf_wave_sum_f32(sg[c]), b = pdf_wave_sum_f32(sgh[c]), d = pdf_wave_sum_f32(sgz[c]);
+        if (lane == 0) { o[c] = a; o[CS + c] = b; o[2 * CS + c] = d; }
+    }
+#pragma unroll
+    for (int m = 0; m < NW2; ++m) {
+        const int e = m * 64 + lane;
+        if (e < CS * CS) o[3 * CS + e] = aw2[m];
+    }
+}
+
+// g_h of one row from the stored G2 / H rows and the BN2-backward sums
+template <int C>
+__device__ __forceinline__ void hidden_grad(const LayerArgs &A, const Row &R, float *gh) {
+    constexpr int CS = C / 8;
+    const float *m2 = A.mean + 3 + C, *r2 = A.rstd + 3 + C;
+    float h[CS];
+    load_hidden<CS>(A, R, h);
+    const float *src = A.G2 + (size_t)(R.valid ? R.row : 0) * CS;
+#pragma unroll
+    for (int o = 0; o < CS; o += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + o);
+        gh[o] = v.x; gh[o + 1] = v.y; gh[o + 2] = v.z; gh[o + 3] = v.w;
+    }
+#pragma unroll
+    for (int o = 0; o < CS; ++o) {
+        const float hhat = (h[o] - m2[o]) * r2[o];
+        const float g = A.s2[o] * (gh[o] - A.sums[o] * A.inv_rows - hhat * A.sums[CS + o] * A.inv_rows);
+        gh[o] = R.valid ? g : 0.f;
+    }
+}
+
+// r, y1 = BN1(r) and g_y1 = (Ww1^T g_h) masked by the ReLU, for one 32-channel chunk (xk / xq staged)
+template <int C, int K>
+__device__ __forceinline__ void chunk_r_gy1(const LayerArgs &A, const WaveLds &L, int lane, int q, const float *t1n,
+                                            const float *gh, float *r, float *gy1) {
+    constexpr int CS = C / 8;
+    float pr[32];
+    pos_chunk(A, t1n, q * 32, pr);
+    rqk_chunk<K>(L, lane, pr, r);
+#pragma unroll
+    for (int c = 0; c < 32; ++c) gy1[c] = 0.f;
+#pragma unroll
+    for (int o = 0; o < CS; ++o) {
+        const float *wrow = A.Ww1 + (size_t)o * C + q * 32;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) gy1[c] += gh[o] * wrow[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        const float y1 = r[c] * A.s1[q * 32 + c] + A.t1[q * 32 + c];
+        if (!(y1 > 0.f)) gy1[c] = 0.f;
+    }
+}
+
+template <int C, int K>
+__global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NCH = C / 32, PPT = 64 / K, CS = C / 8, W = b2_width<C>();
+    const int lane = threadIdx.x & 63;
+    const WaveLds L = carve_lds<true>(lds, threadIdx.x >> 6);
+    const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
+    const long ntiles = ((long)A.N * K + 63) / 64;
+    const float *m1 = A.mean + 3, *r1 = A.rstd + 3;
+    float sg[NCH], sgr[NCH], sgh = 0.f, aw1[NCH][CS / 2];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        sg[q] = 0.f; sgr[q] = 0.f;
+#pragma unroll
+        for (int m = 0; m < CS / 2; ++m) aw1[q][m] = 0.f;
+    }
+    for (long tile = wave_g; tile < ntiles; tile += nwaves) {
+        const Row R = load_row<K>(A, tile, lane);
+        float t1n[3];
+        bn_relu3(A, R.t1, t1n);
+        float gh[CS];
+        hidden_grad<C>(A, R, gh);
+        L.rowid[lane] = R.nb;
+#pragma unroll
+        for (int o = 0; o < CS; ++o) L.aux[lane * AUX + o] = gh[o];
+        wave_sync();
+        if ((lane & 31) < CS) {  // g_bw1: column sums of the g_h tile
+            const int ch = lane & 31, r0 = (lane >> 5) * 32;
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) a += L.aux[(r0 + r) * AUX + ch];
+            sgh += a;
+        }
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            stage_rows(L, A.xk, C, q * 32, lane);
+            stage_points<PPT>(L, A.xq, C, q * 32, (int)(tile * PPT), A.N, lane);
+            wave_sync();
+            float r[32], gy1[32];
+            chunk_r_gy1<C, K>(A, L, lane, q, t1n, gh, r, gy1);
+            wave_sync();
+            // v1 = relu(BN1(r)) -> tile, g_Ww1[o][q*32+c] += sum_rows g_h[o] * v1[c]
+#pragma unroll
+            for (int c = 0; c < 32; ++c) L.tile[lane * TS + c] = R.valid ? fmaxf(r[c] * A.s1[q * 32 + c] + A.t1[q * 32 + c], 0.f) : 0.f;
+            wave_sync();
+#pragma unroll
+            for (int m = 0; m < CS / 2; ++m) aw1[q][m] += dot_aux_tile(L, 2 * m + (lane >> 5), lane & 31);
+            wave_sync();
+#pragma unroll
+            for (int c = 0; c < 32; ++c) L.tile[lane * TS + c] = gy1[c];
+            wave_sync();
+            sg[q] += column_sum(L, lane);
+            wave_sync();
+#pragma unroll
+            for (int c = 0; c < 32; ++c) L.tile[lane * TS + c] = gy1[c] * ((r[c] - m1[q * 32 + c]) * r1[q * 32 + c]);
+            wave_sync();
+            sgr[q] += column_sum(L, lane);
+            wave_sync();
+        }
+    }
+    float *o = A.partial + wave_g * W;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        const float a = sg[q] + __shfl_xor(sg[q], 32, 64), b = sgr[q] + __shfl_xor(sgr[q], 32, 64);
+        if (lane < 32) { o[q * 32 + lane] = a; o[C + q * 32 + lane] = b; }
+#pragma unroll
+        for (int m = 0; m < CS / 2; ++m) o[2 * C + CS + (size_t)(2 * m + (lane >> 5)) * C + q * 32 + (lane & 31)] = aw1[q][m];
+    }
+    const float hsum = sgh + __shfl_xor(sgh, 32, 64);
+    if (lane < CS) o[2 * C + lane] = hsum;
+}
+
+template <int C, int K>
+__global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NCH = C / 32, PPT = 64 / K, CS = C / 8, W = b3_width<C>();
+    const int lane = threadIdx.x & 63;
+    const WaveLds L = carve_lds<true>(lds, threadIdx.x >> 6);
+    const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
+    const long ntiles = ((long)A.N * K + 63) / 64;
+    const float *m1 = A.mean + 3, *r1 = A.rstd + 3, *mp = A.mean, *rp = A.rstd;
+    const float *sum_gy1 = A.sums, *sum_gy1r = A.sums + C;  // column sums of B2 (A.sums points at B2's result here)
+    float sgp[3] = {0.f, 0.f, 0.f}, sgpt[3] = {0.f, 0.f, 0.f}, sbp2[NCH], awp2[NCH][2];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) { sbp2[q] = 0.f; awp2[q][0] = 0.f; awp2[q][1] = 0.f; }
+    for (long tile = wave_g; tile < ntiles; tile += nwaves) {
+        const Row R = load_row<K>(A, tile, lane);
+        float t1n[3];
+        bn_relu3(A, R.t1, t1n);
+        float gh[CS], w[CS];
+        {   // hidden_grad needs B1's sums: they are passed through A.G3-adjacent pointer `sums2` (see launcher)
+            LayerArgs A2 = A;
+            A2.sums = A.sums + 2 * C;  // launcher packs [B2 sums (2C) | B1 sums (2CS)] for this pass
+            hidden_grad<C>(A2, R, gh);
+        }
+        attn_weights<CS, K>(A, R, w);
+        L.rowid[lane] = R.nb;
+        // t1n tile for the Wp2 gradient
+        L.aux[lane * AUX + 0] = R.valid ? t1n[0] : 0.f;
+        L.aux[lane * AUX + 1] = R.valid ? t1n[1] : 0.f;
+        L.aux[lane * AUX + 2] = R.valid ? t1n[2] : 0.f;
+        float gt1n[3] = {0.f, 0.f, 0.f};
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            stage_rows(L, A.xk, C, q * 32, lane);
+            stage_points<PPT>(L, A.xq, C, q * 32, (int)(tile * PPT), A.N, lane);
+            wave_sync();
+            float r[32], g[32];
+            chunk_r_gy1<C, K>(A, L, lane, q, t1n, gh, r, g);
+            // BN1 backward: g_r = s1 * (g_y1 - mean(g_y1) - rhat * mean(g_y1 * rhat))
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                const int ch = q * 32 + c;
+                const float rhat = (r[c] - m1[ch]) * r1[ch];
+                const float gr = A.s1[ch] * (g[c] - sum_gy1[ch] * A.inv_rows - rhat * sum_gy1r[ch] * A.inv_rows);
+                g[c] = R.valid ? gr : 0.f;
+            }
+            wave_sync();
+            stage_points<PPT>(L, A.gout, C, q * 32, (int)(tile * PPT), A.N, lane);  // qtile: xq no longer needed
+#pragma unroll
+            for (int c = 0; c < 32; ++c) L.tile[lane * TS + c] = g[c];
+            wave_sync();
+            scatter_rows_atomic(L, A.gxk, C, q * 32, lane);
+            // g_xq[i] = - sum_j g_r
+#pragma unroll
+            for (int m = 0; m < PPT / 2; ++m) {
+                const int pt = m * 2 + (lane >> 5), ch = lane & 31;
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < K; ++j) acc += L.tile[(pt * K + j) * TS + ch];
+                const long i = tile * PPT + pt;
+                if (i < A.N) A.gxq[(size_t)i * C + q * 32 + ch] = -acc;
+            }
+            // g_pr = g_r + g_out * w   (the aggregation's share of p_r)
+            const float *go = L.qtile + (lane / K) * TS;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) g[c] += R.valid ? go[c] * w[(q * 32 + c) % CS] : 0.f;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                const float *wp = A.Wp2 + (size_t)(q * 32 + c) * 3;
+                gt1n[0] += g[c] * wp[0]; gt1n[1] += g[c] * wp[1]; gt1n[2] += g[c] * wp[2];
+            }
+            wave_sync();
+#pragma unroll
+            for (int c = 0; c < 32; ++c) L.tile[lane * TS + c] = g[c];
+            wave_sync();
+            sbp2[q] += column_sum(L, lane);
+            // g_Wp2[q*32+c][a] += sum_rows g_pr[c] * t1n[a]    (96 outputs per chunk: e = c*3 + a)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int e = m * 64 + lane;
+                if (e < 96) {
+                    const int c = e / 3, a = e % 3;
+                    float acc = 0.f;
+#pragma unroll 8
+                    for (int rr = 0; rr < 64; ++rr) acc += L.tile[rr * TS + c] * L.aux[rr * AUX + a];
+                    awp2[q][m] += acc;
+                }
+            }
+            wave_sync();
+        }
+        float gyp[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            gyp[a] = (R.valid && t1n[a] > 0.f) ? gt1n[a] : 0.f;
+            sgp[a] += gyp[a];
+            sgpt[a] += gyp[a] * ((R.t1[a] - mp[a]) * rp[a]);
+        }
+        if (R.valid) {
+            float *dst = A.G3 + (size_t)R.row * 3;
+            dst[0] = gyp[0]; dst[1] = gyp[1]; dst[2] = gyp[2];
+        }
+    }
+    float *o = A.partial + wave_g * W;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float x = pdf_wave_sum_f32(sgp[a]), y = pdf_wave_sum_f32(sgpt[a]);
+        if (lane == 0) { o[a] = x; o[3 + a] = y; }
+    }
+    if (lane == 0) { o[6] = 0.f; o[7] = 0.f; }
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        const float a = sbp2[q] + __shfl_xor(sbp2[q], 32, 64);
+        if (lane < 32) o[8 + q * 32 + lane] = a;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int e = m * 64 + lane;
+            if (e < 96) o[8 + C + (size_t)q * 96 + e] = awp2[q][m];  // == [(q*32 + c)*3 + a]
+        }
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(64 * WPB) void k_b4(LayerArgs A) {
+    const int lane = threadIdx.x & 63;
+    const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
+    const long ntiles = ((long)A.N * K + 63) / 64;
+    float acc[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) acc[e] = 0.f;
+    for (long tile = wave_g; tile < ntiles; tile += nwaves) {
+        const Row R = load_row<K>(A, tile, lane);
+        if (!R.valid) continue;
+        const float *g3 = A.G3 + (size_t)R.row * 3;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float that = (R.t1[a] - A.mean[a]) * A.rstd[a];
+            const float gt1 = A.sp[a] * (g3[a] - A.sums[a] * A.inv_rows - that * A.sums[3 + a] * A.inv_rows);
+            acc[a] += gt1;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) acc[3 + a * 3 + b] += gt1 * R.rel[b];
+        }
+    }
+    float *o = A.partial + wave_g * b4_width();
+#pragma unroll
+    for (int e = 0; e < 12; ++e) {
+        const float v = pdf_wave_sum_f32(acc[e]);
+        if (lane == 0) o[e] = v;
+    }
+    if (lane == 0) { o[12] = 0.f; o[13] = 0.f; o[14] = 0.f; o[15] = 0.f; }
+}
+
+// out[col] = sum_rows partial[row][col]   (double accumulation, deterministic)
+__global__ void k_colsum(const float *__restrict__ partial, int rows, int width, float *__restrict__ out) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= width) return;
+    double s = 0.0;
+    for (int r = 0; r < rows; ++r) s += (double)partial[(size_t)r * width + col];
+    out[col] = (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------ BN finalize
+// partial: [rows][2*nch] (sum | sumsq).  Train: batch mean/var -> scale/shift (+ running-stat update, saved mean/rstd).
+__global__ void k_bn_finalize(const float *__restrict__ partial, int rows, int nch, double count,
+                              const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float momentum,
+                              float *__restrict__ running_mean, float *__restrict__ running_var,
+                              float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean_out,
+                              float *__restrict__ rstd_out) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= nch) return;
+    double s = 0.0, ss = 0.0;
+    for (int r = 0; r < rows; ++r) {
+        s += (double)partial[(size_t)r * 2 * nch + ch];
+        ss += (double)partial[(size_t)r * 2 * nch + nch + ch];
+    }
+    const double mean = s / count;
+    double var = ss / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[ch] * rstd;
+    scale[ch] = sc;
+    shift[ch] = beta[ch] - (float)mean * sc;
+    mean_out[ch] = (float)mean;
+    rstd_out[ch] = rstd;
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)mean;
+        running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
+    }
+}
+
+// Eval: scale/shift from running statistics.
+__global__ void k_bn_eval(int nch, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                          const float *__restrict__ running_mean, const float *__restrict__ running_var,
+                          float *__restrict__ scale, float *__restrict__ shift) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= nch) return;
+    const float sc = gamma[ch] / sqrtf(running_var[ch] + eps);
+    scale[ch] = sc;
+    shift[ch] = beta[ch] - running_mean[ch] * sc;
+}
+
+static inline int grid_for_tiles(long ntiles) {
+    long g = (ntiles + WPB - 1) / WPB;
+    if (g > MAX_BLOCKS) g = MAX_BLOCKS;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace fl
+
+// ================================================================================================ C ABI
+// Workspace contract (caller-owned floats): `bn` = 2*(3 + C + C/8) scale/shift values laid out
+// [sp(3) tp(3) s1(C) t1(C) s2(CS) t2(CS)], `saved` = mean/rstd in the same order (train mode, for backward),
+// `partial` = pdf_pt_layer_partial_floats(N, K, C) floats of scratch.
+extern "C" long pdf_pt_layer_partial_floats(int n, int nsample, int c) {
+    const long ntiles = ((long)n * nsample + 63) / 64;
+    return (long)fl::grid_for_tiles(ntiles) * fl::WPB * 2 * (c > 3 ? c : 3);
+}
+
+extern "C" int pdf_pt_layer_supported(int nsample, int c) {
+    return (nsample == 8 || nsample == 16) && (c == 32 || c == 64 || c == 128);
+}
+
+namespace fl {
+
+template <int C, int K>
+int forward_impl(LayerArgs A, int training, float eps, float momentum, const float *const *bn_params, float *const *bn_buffers,
+                 float *bn, float *saved, hipStream_t s) {
+    constexpr int CS = C / 8;
+    const long rows = (long)A.N * K;
+    const long ntiles = (rows + 63) / 64;
+    const int grid = grid_for_tiles(ntiles);
+    const int nw = grid * WPB;
+    const size_t lds = (size_t)WPB * LDS_FLOATS_PER_WAVE * sizeof(float);
+    float *sp = bn, *tp = bn + 3, *s1 = bn + 6, *t1 = bn + 6 + C, *s2 = bn + 6 + 2 * C, *t2 = bn + 6 + 2 * C + CS;
+    A.sp = sp; A.tp = tp; A.s1 = s1; A.t1 = t1; A.s2 = s2; A.t2 = t2;
+    // bn_params: gamma_p, beta_p, gamma_1, beta_1, gamma_2, beta_2 ; bn_buffers: rm_p, rv_p, rm_1, rv_1, rm_2, rv_2
+    if (!training) {
+        k_bn_eval<<<1, 64, 0, s>>>(3, bn_params[0], bn_params[1], eps, bn_buffers[0], bn_buffers[1], sp, tp);
+        k_bn_eval<<<pdf_divup(C, 64), 64, 0, s>>>(C, bn_params[2], bn_params[3], eps, bn_buffers[2], bn_buffers[3], s1, t1);
+        k_bn_eval<<<1, 64, 0, s>>>(CS, bn_params[4], bn_params[5], eps, bn_buffers[4], bn_buffers[5], s2, t2);
+        k_p3<C, K, false><<<grid, 64 * WPB, lds, s>>>(A);
+        k_p4<C, K><<<grid, 64 * WPB, lds, s>>>(A);
+        return pdf_launch_status();
+    }
+    float *mp = saved, *rp = saved + 3, *m1 = saved + 6, *r1 = saved + 6 + C, *m2 = saved + 6 + 2 * C, *r2 = saved + 6 + 2 * C + CS;
+    k_p1<K><<<grid, 64 * WPB, 0, s>>>(A);
+    k_bn_finalize<<<1, 64, 0, s>>>(A.partial, nw, 3, (double)rows, bn_params[0], bn_params[1], eps, momentum, bn_buffers[0], bn_buffers[1], sp, tp, mp, rp);
+    k_p2<C, K><<<grid, 64 * WPB, lds, s>>>(A);
+    k_bn_finalize<<<pdf_divup(C, 64), 64, 0, s>>>(A.partial, nw, C, (double)rows, bn_params[2], bn_params[3], eps, momentum, bn_buffers[2], bn_buffers[3], s1, t1, m1, r1);
+    k_p3<C, K, true><<<grid, 64 * WPB, lds, s>>>(A);
+    k_bn_finalize<<<1, 64, 0, s>>>(A.partial, nw, CS, (double)rows, bn_params[4], bn_params[5], eps, momentum, bn_buffers[4], bn_buffers[5], s2, t2, m2, r2);
+    k_p4<C, K><<<grid, 64 * WPB, lds, s>>>(A);
+    return pdf_launch_status();
+}
+
+}  // namespace fl
+
+namespace fl {
+
+static inline int grid_for_tiles_bwd(long ntiles) {
+    long g = (ntiles + WPB - 1) / WPB;
+    if (g > MAX_BLOCKS_BWD) g = MAX_BLOCKS_BWD;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+template <int C, int K>
+int backward_impl(LayerArgs A, float *sums, hipStream_t s) {
+    constexpr int CS = C / 8;
+    const long rows = (long)A.N * K;
+    const long ntiles = (rows + 63) / 64;
+    const int grid = grid_for_tiles_bwd(ntiles), nw = grid * WPB;
+    const size_t lds = (size_t)WPB * LDS_FLOATS_PER_WAVE_BWD * sizeof(float);
+    A.inv_rows = (float)(1.0 / (double)rows);
+    // sums layout (floats): [S1: b1_width | S2: b2_width | S3: b3_width | S4: 16 | X: 2C + 2CS scratch for B3]
+    float *S1 = sums, *S2 = S1 + b1_width<C>(), *S3 = S2 + b2_width<C>(), *S4 = S3 + b3_width<C>(), *X = S4 + b4_width();
+    k_b1<C, K><<<grid, 64 * WPB, lds, s>>>(A);
+    k_colsum<<<pdf_divup(b1_width<C>(), 64), 64, 0, s>>>(A.partial, nw, b1_width<C>(), S1);
+    A.sums = S1;
+    k_b2<C, K><<<grid, 64 * WPB, lds, s>>>(A);
+    k_colsum<<<pdf_divup(b2_width<C>(), 64), 64, 0, s>>>(A.partial, nw, b2_width<C>(), S2);
+    // B3 wants [B2 sums (2C) | B1 sums (2CS)] contiguous
+    hipError_t e = hipMemcpyAsync(X, S2, sizeof(float) * 2 * C, hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyAsync(X + 2 * C, S1, sizeof(float) * 2 * CS, hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return (int)e;
+    A.sums = X;
+    k_b3<C, K><<<grid, 64 * WPB, lds, s>>>(A);
+    k_colsum<<<pdf_divup(b3_width<C>(), 64), 64, 0, s>>>(A.partial, nw, b3_width<C>(), S3);
+    A.sums = S3;
+    k_b4<K><<<grid, 64 * WPB, 0, s>>>(A);
+    k_colsum<<<1, 64, 0, s>>>(A.partial, nw, b4_width(), S4);
+    return pdf_launch_status();
+}
+
+}  // namespace fl
+
+extern "C" long pdf_pt_layer_bwd_partial_floats(int n, int nsample, int c) {
+    const long ntiles = ((long)n * nsample + 63) / 64;
+    const long w = 2L * c + c / 8 + (long)(c / 8) * c;  // widest pass (B2)
+    return (long)fl::grid_for_tiles_bwd(ntiles) * fl::WPB * w;
+}
+
+// floats in the `sums` result buffer and the offsets of its four sections [S1 | S2 | S3 | S4 | scratch]
+extern "C" long pdf_pt_layer_bwd_sums_floats(int c) {
+    const int cs = c / 8;
+    return (long)(3 * cs + cs * cs) + (2L * c + cs + (long)cs * c) + (8 + 4L * c) + 16 + (2L * c + 2 * cs);
+}
+
+// Backward of one PointTransformerLayer (training mode).  Inputs as the forward plus g_out, the forward's bn / saved /
+// H buffers; outputs: gxq (N,C) written, gxk / gxv (N,C) PRE-ZEROED scatter targets, G2 (N*K*C/8) and G3 (N*K*3)
+// scratch, partial scratch (pdf_pt_layer_bwd_partial_floats), sums (pdf_pt_layer_bwd_sums_floats) which receives
+//   S1 = [sum g_y2 | sum g_y2*hhat | g_bw2 | g_Ww2]          -> d beta2, d gamma2, d bw2, d Ww2
+//   S2 = [sum g_y1 | sum g_y1*rhat | g_bw1 | g_Ww1]          -> d beta1, d gamma1, d bw1, d Ww1
+//   S3 = [sum g_yp(3) | sum g_yp*that(3) | 0 0 | g_bp2 | g_Wp2] -> d betap, d gammap, d bp2, d Wp2
+//   S4 = [g_bp1(3) | g_Wp1(9) | 0 x4]
+extern "C" int pdf_pt_layer_backward(int n, int nsample, int c, const float *xq, const float *xk, const float *xv,
+                                     const float *p, const int *idx, const float *const *weights, const float *bn,
+                                     const float *saved, const float *H, const float *gout, float *gxq, float *gxk,
+                                     float *gxv, float *G2, float *G3, float *partial, float *sums, void *stream) {
+    if (n < 1 || !xq || !xk || !xv || !p || !idx || !weights || !bn || !saved || !H || !gout || !gxq || !gxk || !gxv ||
+        !G2 || !G3 || !partial || !sums)
+        return PDF_ERR_BAD_ARG;
+    if (!pdf_pt_layer_supported(nsample, c)) return PDF_ERR_UNSUPPORTED;
+    const int cs = c / 8;
+    fl::LayerArgs A;
+    A.N = n; A.xq = xq; A.xk = xk; A.xv = xv; A.p = p; A.idx = idx;
+    A.Wp1 = weights[0]; A.bp1 = weights[1]; A.Wp2 = weights[2]; A.bp2 = weights[3];
+    A.Ww1 = weights[4]; A.bw1 = weights[5]; A.Ww2 = weights[6]; A.bw2 = weights[7];
+    A.sp = bn; A.tp = bn + 3; A.s1 = bn + 6; A.t1 = bn + 6 + c; A.s2 = bn + 6 + 2 * c; A.t2 = bn + 6 + 2 * c + cs;
+    // saved = [mp(3) rp(3) m1(C) r1(C) m2(CS) r2(CS)] -> mean / rstd views indexed [p(3) | 1(C) | 2(CS)]
+    // (the kernels index A.mean / A.rstd as [0..3) p, [3..3+C) 1, [3+C..) 2: build those views in `sums` scratch)
+    A.H = const_cast<float *>(H); A.out = nullptr; A.partial = partial;
+    A.gout = gout; A.G2 = G2; A.G3 = G3; A.gxq = gxq; A.gxk = gxk; A.gxv = gxv; A.sums = nullptr;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // re-pack saved statistics into contiguous mean[] and rstd[] arrays at the tail of `sums`
+    const long tail = pdf_pt_layer_bwd_sums_floats(c);
+    float *mean = sums + tail, *rstd = mean + (3 + c + cs);
+    hipError_t e;
+#define PDF_CP(dst_, src_, cnt_) do { e = hipMemcpyAsync(dst_, src_, sizeof(float) * (cnt_), hipMemcpyDeviceToDevice, s); if (e != hipSuccess) return (int)e; } while (0)
+    PDF_CP(mean, saved, 3); PDF_CP(rstd, saved + 3, 3);
+    PDF_CP(mean + 3, saved + 6, c); PDF_CP(rstd + 3, saved + 6 + c, c);
+    PDF_CP(mean + 3 + c, saved + 6 + 2 * c, cs); PDF_CP(rstd + 3 + c, saved + 6 + 2 * c + cs, cs);
+#undef PDF_CP
+    A.mean = mean; A.rstd = rstd;
+#define PDF_BWD(C_, K_) return fl::backward_impl<C_, K_>(A, sums, s)
+    if (nsample == 8) {
+        if (c == 32) PDF_BWD(32, 8);
+        if (c == 64) PDF_BWD(64, 8);
+        PDF_BWD(128, 8);
+    } else {
+        if (c == 32) PDF_BWD(32, 16);
+        if (c == 64) PDF_BWD(64, 16);
+        PDF_BWD(128, 16);
+    }
+#undef PDF_BWD
+}
+
+// Forward of one PointTransformerLayer.  weights: Wp1,bp1,Wp2,bp2,Ww1,bw1,Ww2,bw2 ; bn_params: gamma/beta of the three
+// norms ; bn_buffers: running mean/var of the three norms (updated in train mode; may hold nulls to skip the update).
+extern "C" int pdf_pt_layer_forward(int n, int nsample, int c, const float *xq, const float *xk, const float *xv,
+                                    const float *p, const int *idx, const float *const *weights,
+                                    const float *const *bn_params, float *const *bn_buffers, int training, float eps,
+                                    float momentum, float *bn, float *saved, float *H, float *partial, float *out,
+                                    void *stream) {
+    if (n < 1 || !xq || !xk || !xv || !p || !idx || !weights || !bn_params || !bn_buffers || !bn || !H || !partial || !out)
+        return PDF_ERR_BAD_ARG;
+    if (!pdf_pt_layer_supported(nsample, c)) return PDF_ERR_UNSUPPORTED;
+    if (training && !saved) return PDF_ERR_BAD_ARG;
+    fl::LayerArgs A;
+    A.N = n; A.xq = xq; A.xk = xk; A.xv = xv; A.p = p; A.idx = idx;
+    A.Wp1 = weights[0]; A.bp1 = weights[1]; A.Wp2 = weights[2]; A.bp2 = weights[3];
+    A.Ww1 = weights[4]; A.bw1 = weights[5]; A.Ww2 = weights[6]; A.bw2 = weights[7];
+    A.H = H; A.out = out; A.partial = partial;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define PDF_FWD(C_, K_) return fl::forward_impl<C_, K_>(A, training, eps, momentum, bn_params, bn_buffers, bn, saved, s)
+    if (nsample == 8) {
+        if (c == 32) PDF_FWD(32, 8);
+        if (c == 64) PDF_FWD(64, 8);
+        PDF_FWD(128, 8);
+    } else {
+        if (c == 32) PDF_FWD(32, 16);
+        if (c == 64) PDF_FWD(64, 16);
+        PDF_FWD(128, 16);
+    }
+#undef PDF_FWD
+}

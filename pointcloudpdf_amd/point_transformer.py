@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import pointops
+from . import _native, pointops
 from .geometry import Geometry, tag_of
 from .registry import MODELS
 
@@ -34,6 +34,44 @@ class LayerNorm1d(nn.BatchNorm1d):
             return super().forward(input.transpose(1, 2).contiguous()).transpose(1, 2).contiguous()
         shape = input.shape
         return super().forward(input.reshape(-1, shape[-1])).view(shape)
+
+
+class _FusedPTLayer(torch.autograd.Function):
+    """The whole PointTransformerLayer after the q/k/v projections as one autograd node over the fused HIP passes
+    (csrc/fused_layer.hip): no (n, ns, c) tensor is materialised in either direction."""
+
+    @staticmethod
+    def forward(ctx, layer, idx, p, xq, xk, xv, *params):
+        be = _native.hip_backend()
+        lp, lw = layer.linear_p, layer.linear_w
+        weights = [lp[0].weight, lp[0].bias, lp[3].weight, lp[3].bias, lw[2].weight, lw[2].bias, lw[5].weight, lw[5].bias]
+        norms = [lp[1], lw[0], lw[3]]
+        bn_params = [t for n in norms for t in (n.weight, n.bias)]
+        training = layer.training
+        bn_buffers = [t for n in norms for t in (n.running_mean, n.running_var)]
+        weights = [w.detach().contiguous() for w in weights]
+        bn_params = [w.detach().contiguous() for w in bn_params]
+        out, bn, saved, H = be.pt_layer_forward(xq.contiguous(), xk.contiguous(), xv.contiguous(), p, idx, weights,
+                                                bn_params, bn_buffers, training, norms[0].eps, norms[0].momentum)
+        if training:
+            for n in norms:
+                n.num_batches_tracked += 1
+        ctx.save_for_backward(xq, xk, xv, p, idx, bn, saved, H, *weights)
+        ctx.training = training
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        if not ctx.training:
+            raise RuntimeError("fused PointTransformerLayer: backward is implemented for training mode (batch statistics)")
+        xq, xk, xv, p, idx, bn, saved, H, *weights = ctx.saved_tensors
+        be = _native.hip_backend()
+        gxq, gxk, gxv, g = be.pt_layer_backward(xq.contiguous(), xk.contiguous(), xv.contiguous(), p, idx, list(weights),
+                                                bn, saved, H, gout.contiguous())
+        # order of *params in forward(): Wp1 bp1 gamma_p beta_p Wp2 bp2 gamma_1 beta_1 Ww1 bw1 gamma_2 beta_2 Ww2 bw2
+        grads = (g["Wp1"], g["bp1"], g["gammap"], g["betap"], g["Wp2"], g["bp2"], g["gamma1"], g["beta1"], g["Ww1"],
+                 g["bw1"], g["gamma2"], g["beta2"], g["Ww2"], g["bw2"])
+        return (None, None, None, gxq, gxk, gxv) + grads
 
 
 class PointTransformerLayer(nn.Module):
@@ -61,9 +99,27 @@ class PointTransformerLayer(nn.Module):
         )
         self.softmax = nn.Softmax(dim=1)
 
+    fused = True  # class-wide switch: use the fused HIP passes where they apply
+
+    def _fused_ok(self, x):
+        if not (self.fused and x.is_cuda and x.dtype == torch.float32 and self.mid_planes == self.out_planes
+                and self.share_planes == 8):
+            return False
+        if torch.is_grad_enabled() and not self.training and any(p.requires_grad for p in self.parameters()):
+            return False  # eval-mode backward is not implemented in the fused path
+        return _native.hip_backend().pt_layer_supported(self.nsample, self.out_planes)
+
+    def _param_list(self):
+        lp, lw = self.linear_p, self.linear_w
+        return [lp[0].weight, lp[0].bias, lp[1].weight, lp[1].bias, lp[3].weight, lp[3].bias, lw[0].weight, lw[0].bias,
+                lw[2].weight, lw[2].bias, lw[3].weight, lw[3].bias, lw[5].weight, lw[5].bias]
+
     def forward(self, pxo):
         p, x, o = pxo  # (n, 3), (n, c), (b)
         x_q, x_k, x_v = self.linear_q(x), self.linear_k(x), self.linear_v(x)
+        if self._fused_ok(x):
+            idx, _ = pointops.knn_query(self.nsample, p, o, p, o)
+            return _FusedPTLayer.apply(self, idx, p, x_q, x_k, x_v, *self._param_list())
         x_k, idx = pointops.knn_query_and_group(x_k, p, o, new_xyz=p, new_offset=o, nsample=self.nsample, with_xyz=True)
         x_v, _ = pointops.knn_query_and_group(x_v, p, o, new_xyz=p, new_offset=o, idx=idx, nsample=self.nsample, with_xyz=False)
         p_r, x_k = x_k[:, :, 0:3], x_k[:, :, 3:]

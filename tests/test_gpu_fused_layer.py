@@ -1,0 +1,91 @@
+"""GPU suite: the fused PointTransformerLayer passes (csrc/fused_layer.hip) against the op-by-op composition of the same
+module (which is itself pinned to the reference by the model fixtures): outputs, input gradients, all 14 parameter
+gradients and the BatchNorm running statistics."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import max_rel
+
+pytestmark = pytest.mark.gpu
+
+
+def run_layer(fused, C, K, N, train, seed=0):
+    from pointcloudpdf_amd import synthetic
+    from pointcloudpdf_amd.geometry import Geometry
+    from pointcloudpdf_amd.point_transformer import PointTransformerLayer
+
+    torch.manual_seed(seed)
+    sizes = [N // 2 + 17, N - N // 2 - 17]
+    batch = synthetic.make_batch(sizes, first_scene_id=50, grid_size=0.25, device="cuda")
+    geom = Geometry(batch["coord"], batch["offset"], batch["offset_host"])
+    layer = PointTransformerLayer(C, C, 8, K).cuda()
+    synthetic.fill_parameters_deterministic(layer, seed=3)
+    layer.train(train)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.randn(sum(sizes), C, device="cuda", generator=g).requires_grad_(True)
+    PointTransformerLayer.fused = fused
+    try:
+        with torch.set_grad_enabled(train):
+            y = layer([geom.coord(0), x, geom.offset(0)])
+        res = {"y": y.detach().cpu().numpy()}
+        if train:
+            go = torch.randn(y.shape, device="cuda", generator=g)
+            y.backward(go)
+            res["gx"] = x.grad.cpu().numpy()
+            for n, p in layer.named_parameters():
+                res["g_" + n] = p.grad.cpu().numpy()
+            for n, b in layer.named_buffers():
+                res["b_" + n] = b.detach().cpu().numpy()
+    finally:
+        PointTransformerLayer.fused = True
+    return res
+
+
+@pytest.mark.parametrize("C,K", [(32, 8), (64, 16), (128, 16), (32, 16), (64, 8)])
+def test_fused_layer_train(C, K):
+    a = run_layer(True, C, K, 3000, True)
+    b = run_layer(False, C, K, 3000, True)
+    assert max_rel(a["y"], b["y"]) < 2e-5, max_rel(a["y"], b["y"])
+    report = {k: (max_rel(a[k], b[k]), float(np.abs(b[k]).max())) for k in a if k != "y"}
+    print({k: (f"{v[0]:.1e}", f"{v[1]:.1e}") for k, v in report.items()})
+    gscale = max(v[1] for k, v in report.items() if k.startswith("g_"))
+    # biases in front of a train-mode BatchNorm (and q/k biases, which cancel in r - mean(r)) have analytically zero
+    # gradients: both paths return rounding noise there -> compare only tensors above 1e-4 of the largest gradient
+    bad = {k: v for k, v in report.items()
+           if v[0] > (2e-5 if k.startswith("b_") else 1e-3) and (k.startswith("b_") or v[1] > 1e-4 * gscale)}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("C,K", [(32, 8), (64, 16), (128, 16)])
+def test_fused_layer_eval(C, K):
+    a = run_layer(True, C, K, 2500, False)
+    b = run_layer(False, C, K, 2500, False)
+    assert max_rel(a["y"], b["y"]) < 2e-5
+
+
+def test_fused_layer_short_scene_placeholders():
+    """Scenes with fewer than nsample points: idx = -1 rows gather zeros in both paths."""
+    from pointcloudpdf_amd import synthetic
+    from pointcloudpdf_amd.geometry import Geometry
+    from pointcloudpdf_amd.point_transformer import PointTransformerLayer
+
+    torch.manual_seed(1)
+    coord = torch.rand(600 + 9, 3, device="cuda")
+    offset = torch.tensor([600, 609], dtype=torch.int32, device="cuda")
+    layer = PointTransformerLayer(32, 32, 8, 16).cuda()
+    synthetic.fill_parameters_deterministic(layer, seed=4)
+    layer.train()
+    x = torch.randn(609, 32, device="cuda")
+    outs = []
+    for fused in (True, False):
+        PointTransformerLayer.fused = fused
+        geom = Geometry(coord, offset)
+        xx = x.clone().requires_grad_(True)
+        y = layer([geom.coord(0), xx, geom.offset(0)])
+        y.square().sum().backward()
+        outs.append((y.detach().cpu().numpy(), xx.grad.cpu().numpy()))
+    PointTransformerLayer.fused = True
+    assert (geom.knn(16, 0, 0)[0][600:] == -1).any()
+    assert max_rel(outs[0][0], outs[1][0]) < 2e-5
+    assert max_rel(outs[0][1], outs[1][1]) < 1e-3
