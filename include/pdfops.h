@@ -42,6 +42,18 @@ int pdf_knn_query(int m, int nsample, const float *xyz, const float *new_xyz,
                   const int *offset, const int *new_offset, int b,
                   int *idx, float *dist2, void *stream);
 
+/* Same results through a uniform grid (exact: queries whose answer could depend on the reference's tie-breaking
+ * are re-run by the scan kernel).  n = number of source points, workspace from pdf_knn_workspace_bytes(b, n, m). */
+long pdf_knn_workspace_bytes(int b, int n, int m);
+int pdf_knn_grid_supported(int nsample);
+int pdf_knn_query_ws(int m, int nsample, int n, const float *xyz, const float *new_xyz, const int *offset,
+                     const int *new_offset, int b, int *idx, float *dist2, void *workspace, long workspace_bytes,
+                     void *stream);
+/* the exact scan restricted to qlist[0 .. *qcount) (device pointers); qlist == NULL: all m queries */
+int pdf_knn_query_list(int m, int nsample, const float *xyz, const float *new_xyz, const int *offset,
+                       const int *new_offset, int b, int *idx, float *dist2, const int *qlist, const int *qcount,
+                       void *stream);
+
 /* replaces farthest_point_sampling_cuda_launcher, libs/pointops/src/sampling/sampling_cuda_kernel.h:13
  * (kernel sampling_cuda_kernel.cu:14-129).  `n` = size of the largest scene (fixes the reference's
  * block size opt_n_threads(n), cuda_utils.h:11-14, which fixes its arg-max tie rule).

@@ -255,6 +255,30 @@ class HipBackend(CBackend):
         lib.pdf_pt_layer_backward.restype = c_int
         lib.pdf_pt_layer_backward.argtypes = [c_int, c_int, c_int] + [c_void_p] * 18
         self.fps_mode = os.environ.get("PDFOPS_FPS", "bucketed")  # "bucketed" | "plain"
+        self.knn_mode = os.environ.get("PDFOPS_KNN", "grid")      # "grid" | "scan"
+        lib.pdf_knn_workspace_bytes.restype = c_long
+        lib.pdf_knn_workspace_bytes.argtypes = [c_int, c_int, c_int]
+        lib.pdf_knn_grid_supported.restype = c_int
+        lib.pdf_knn_grid_supported.argtypes = [c_int]
+        lib.pdf_knn_query_ws.restype = c_int
+        lib.pdf_knn_query_ws.argtypes = [c_int, c_int, c_int] + [c_void_p] * 4 + [c_int] + [c_void_p] * 3 + [c_long, c_void_p]
+
+    def knn_query(self, nsample, xyz, new_xyz, offset, new_offset):
+        if self.knn_mode == "scan" or not self.lib.pdf_knn_grid_supported(int(nsample)):
+            return super().knn_query(nsample, xyz, new_xyz, offset, new_offset)
+        _check(xyz, torch.float32, "xyz"); _check(new_xyz, torch.float32, "new_xyz")
+        _check(offset, torch.int32, "offset"); _check(new_offset, torch.int32, "new_offset")
+        n, m, b = xyz.shape[0], new_xyz.shape[0], offset.shape[0]
+        idx = self._new(xyz, (m, nsample), torch.int32)
+        dist2 = self._new(xyz, (m, nsample), torch.float32)
+        nbytes = int(self.lib.pdf_knn_workspace_bytes(b, n, m))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=xyz.device)
+        rc = self.lib.pdf_knn_query_ws(m, int(nsample), n, self._ptr(xyz), self._ptr(new_xyz), self._ptr(offset),
+                                       self._ptr(new_offset), b, self._ptr(idx), self._ptr(dist2), self._ptr(ws), nbytes,
+                                       c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise PdfOpsError(f"pdf_knn_query_ws failed with status {rc}")
+        return idx, dist2
 
     def farthest_point_sampling(self, xyz, offset, new_offset, n_max, m_total):
         if self.fps_mode == "plain":

@@ -23,6 +23,7 @@ EXTRA = {
     "knn_query.hip": ["-ffp-contract=off"],
     "sampling.hip": ["-ffp-contract=off"],
     "sampling_bucketed.hip": ["-ffp-contract=off"],
+    "knn_grid.hip": ["-ffp-contract=off"],
 }
 
 

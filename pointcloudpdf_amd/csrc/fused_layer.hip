@@ -25,22 +25,28 @@ namespace fl {
 
 constexpr int TS = 33;          // LDS tile row stride in floats (bank-conflict-free for row-per-lane and column reads)
 constexpr int WPB = 4;          // waves per block
-constexpr int MAX_BLOCKS = 1024;
+constexpr int MAX_BLOCKS = 512;
+
+// Wave-uniform read-only operands (weights, BatchNorm coefficients, reduction results) are addressed through the
+// constant address space: the compiler then fetches them with s_load into SGPRs instead of keeping one VGPR per value
+// and lane (which spilled thousands of registers in the first version of these kernels).
+typedef const float __attribute__((address_space(4))) *cfloat_p;
+__host__ __device__ inline cfloat_p as_const(const float *p) { return (cfloat_p)(uintptr_t)p; }
 
 struct LayerArgs {
     int N;                                   // points
     const float *xq, *xk, *xv, *p;           // (N,C) x3, (N,3)
     const int *idx;                          // (N,K)
-    const float *Wp1, *bp1, *Wp2, *bp2;      // (3,3) (3) (C,3) (C)
-    const float *Ww1, *bw1, *Ww2, *bw2;      // (CS,C) (CS) (CS,CS) (CS)
-    const float *sp, *tp, *s1, *t1, *s2, *t2;  // BatchNorm scale/shift: y = x*s + t  (3,3,C,C,CS,CS)
+    cfloat_p Wp1, bp1, Wp2, bp2;             // (3,3) (3) (C,3) (C)
+    cfloat_p Ww1, bw1, Ww2, bw2;             // (CS,C) (CS) (CS,CS) (CS)
+    cfloat_p sp, tp, s1, t1, s2, t2;         // BatchNorm scale/shift: y = x*s + t  (3,3,C,C,CS,CS)
     float *H;                                // (N,K,CS) pre-BN2 activations
     float *out;                              // (N,C)
     float *partial;                          // per-wave partial sums for the statistics of the current pass
     // ---- backward only
     const float *gout;                       // (N,C) gradient of the layer output
-    const float *mean, *rstd;                // saved batch statistics [p(3) | 1(C) | 2(CS)] (mean and rstd arrays)
-    const float *sums;                       // column sums of the previous backward pass (BatchNorm-backward terms)
+    cfloat_p mean, rstd;                     // saved batch statistics [p(3) | 1(C) | 2(CS)] (mean and rstd arrays)
+    cfloat_p sums;                           // column sums of the previous backward pass (BatchNorm-backward terms)
     float *G2, *G3;                          // (N,K,CS) grad wrt BN2 output (post-ReLU mask), (N,K,3) same for BNp
     float *gxq, *gxk, *gxv;                  // (N,C) gradients (gxk / gxv pre-zeroed scatter targets)
     float inv_rows;                          // 1 / (N*K)
@@ -121,7 +127,7 @@ __device__ __forceinline__ void bn_relu3(const LayerArgs &A, const float *t1, fl
 __device__ __forceinline__ void pos_chunk(const LayerArgs &A, const float *t1n, int c0, float *pr) {
 #pragma unroll
     for (int c = 0; c < 32; ++c) {
-        const float *w = A.Wp2 + (size_t)(c0 + c) * 3;
+        cfloat_p w = A.Wp2 + (size_t)(c0 + c) * 3;
         pr[c] = t1n[0] * w[0] + t1n[1] * w[1] + t1n[2] * w[2] + A.bp2[c0 + c];
     }
 }
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(64 * WPB) void k_p3(LayerArgs A) {
             for (int c = 0; c < 32; ++c) r[c] = fmaxf(r[c] * A.s1[q * 32 + c] + A.t1[q * 32 + c], 0.f);
 #pragma unroll
             for (int o = 0; o < CS; ++o) {
-                const float *wrow = A.Ww1 + (size_t)o * C + q * 32;  // wave-uniform, contiguous -> batched s_load
+                cfloat_p wrow = A.Ww1 + (size_t)o * C + q * 32;  // wave-uniform, contiguous -> batched s_load
 #pragma unroll
                 for (int c = 0; c < 32; ++c) h[o] += r[c] * wrow[c];
             }
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
     const WaveLds L = carve_lds<true>(lds, threadIdx.x >> 6);
     const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
     const long ntiles = ((long)A.N * K + 63) / 64;
-    const float *m2 = A.mean + 3 + C, *r2 = A.rstd + 3 + C;
+    cfloat_p m2 = A.mean + 3 + C, r2 = A.rstd + 3 + C;
     float sg[CS], sgh[CS], sgz[CS], aw2[NW2];
 #pragma unroll
     for (int o = 0; o < CS; ++o) { sg[o] = 0.f; sgh[o] = 0.f; sgz[o] = 0.f; }
@@ -533,7 +539,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
 template <int C>
 __device__ __forceinline__ void hidden_grad(const LayerArgs &A, const Row &R, float *gh) {
     constexpr int CS = C / 8;
-    const float *m2 = A.mean + 3 + C, *r2 = A.rstd + 3 + C;
+    cfloat_p m2 = A.mean + 3 + C, r2 = A.rstd + 3 + C;
     float h[CS];
     load_hidden<CS>(A, R, h);
     const float *src = A.G2 + (size_t)(R.valid ? R.row : 0) * CS;
@@ -562,7 +568,7 @@ __device__ __forceinline__ void chunk_r_gy1(const LayerArgs &A, const WaveLds &L
     for (int c = 0; c < 32; ++c) gy1[c] = 0.f;
 #pragma unroll
     for (int o = 0; o < CS; ++o) {
-        const float *wrow = A.Ww1 + (size_t)o * C + q * 32;
+        cfloat_p wrow = A.Ww1 + (size_t)o * C + q * 32;
 #pragma unroll
         for (int c = 0; c < 32; ++c) gy1[c] += gh[o] * wrow[c];
     }
@@ -581,7 +587,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
     const WaveLds L = carve_lds<true>(lds, threadIdx.x >> 6);
     const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
     const long ntiles = ((long)A.N * K + 63) / 64;
-    const float *m1 = A.mean + 3, *r1 = A.rstd + 3;
+    cfloat_p m1 = A.mean + 3, r1 = A.rstd + 3;
     float sg[NCH], sgr[NCH], sgh = 0.f, aw1[NCH][CS / 2];
 #pragma unroll
     for (int q = 0; q < NCH; ++q) {
@@ -653,8 +659,8 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
     const WaveLds L = carve_lds<true>(lds, threadIdx.x >> 6);
     const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
     const long ntiles = ((long)A.N * K + 63) / 64;
-    const float *m1 = A.mean + 3, *r1 = A.rstd + 3, *mp = A.mean, *rp = A.rstd;
-    const float *sum_gy1 = A.sums, *sum_gy1r = A.sums + C;  // column sums of B2 (A.sums points at B2's result here)
+    cfloat_p m1 = A.mean + 3, r1 = A.rstd + 3, mp = A.mean, rp = A.rstd;
+    cfloat_p sum_gy1 = A.sums, sum_gy1r = A.sums + C;  // column sums of B2 (A.sums points at B2's result here)
     float sgp[3] = {0.f, 0.f, 0.f}, sgpt[3] = {0.f, 0.f, 0.f}, sbp2[NCH], awp2[NCH][2];
 #pragma unroll
     for (int q = 0; q < NCH; ++q) { sbp2[q] = 0.f; awp2[q][0] = 0.f; awp2[q][1] = 0.f; }
@@ -713,7 +719,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
             for (int c = 0; c < 32; ++c) g[c] += R.valid ? go[c] * w[(q * 32 + c) % CS] : 0.f;
 #pragma unroll
             for (int c = 0; c < 32; ++c) {
-                const float *wp = A.Wp2 + (size_t)(q * 32 + c) * 3;
+                cfloat_p wp = A.Wp2 + (size_t)(q * 32 + c) * 3;
                 gt1n[0] += g[c] * wp[0]; gt1n[1] += g[c] * wp[1]; gt1n[2] += g[c] * wp[2];
             }
             wave_sync();
@@ -797,28 +803,43 @@ __global__ __launch_bounds__(64 * WPB) void k_b4(LayerArgs A) {
 }
 
 // out[col] = sum_rows partial[row][col]   (double accumulation, deterministic)
-__global__ void k_colsum(const float *__restrict__ partial, int rows, int width, float *__restrict__ out) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= width) return;
+__global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ partial, int rows, int width, float *__restrict__ out) {
+    __shared__ double red[16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + cl;
     double s = 0.0;
-    for (int r = 0; r < rows; ++r) s += (double)partial[(size_t)r * width + col];
+    if (col < width)
+        for (int r = rl; r < rows; r += 16) s += (double)partial[(size_t)r * width + col];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl != 0 || col >= width) return;
+    for (int k = 1; k < 16; ++k) s += red[k][cl];
     out[col] = (float)s;
 }
 
 // ------------------------------------------------------------------------------------------------ BN finalize
 // partial: [rows][2*nch] (sum | sumsq).  Train: batch mean/var -> scale/shift (+ running-stat update, saved mean/rstd).
-__global__ void k_bn_finalize(const float *__restrict__ partial, int rows, int nch, double count,
+// block = 16 channels x 16 row-lanes: every row-lane sums a strided subset of the partial rows in double, LDS combine.
+__global__ __launch_bounds__(256) void k_bn_finalize(const float *__restrict__ partial, int rows, int nch, double count,
                               const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float momentum,
                               float *__restrict__ running_mean, float *__restrict__ running_var,
                               float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean_out,
                               float *__restrict__ rstd_out) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= nch) return;
+    __shared__ double red[2][16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int ch = blockIdx.x * 16 + cl;
     double s = 0.0, ss = 0.0;
-    for (int r = 0; r < rows; ++r) {
-        s += (double)partial[(size_t)r * 2 * nch + ch];
-        ss += (double)partial[(size_t)r * 2 * nch + nch + ch];
+    if (ch < nch) {
+        for (int r = rl; r < rows; r += 16) {
+            s += (double)partial[(size_t)r * 2 * nch + ch];
+            ss += (double)partial[(size_t)r * 2 * nch + nch + ch];
+        }
     }
+    red[0][rl][cl] = s;
+    red[1][rl][cl] = ss;
+    __syncthreads();
+    if (rl != 0 || ch >= nch) return;
+    for (int k = 1; k < 16; ++k) { s += red[0][k][cl]; ss += red[1][k][cl]; }
     const double mean = s / count;
     double var = ss / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -880,7 +901,7 @@ int forward_impl(LayerArgs A, int training, float eps, float momentum, const flo
     const int nw = grid * WPB;
     const size_t lds = (size_t)WPB * LDS_FLOATS_PER_WAVE * sizeof(float);
     float *sp = bn, *tp = bn + 3, *s1 = bn + 6, *t1 = bn + 6 + C, *s2 = bn + 6 + 2 * C, *t2 = bn + 6 + 2 * C + CS;
-    A.sp = sp; A.tp = tp; A.s1 = s1; A.t1 = t1; A.s2 = s2; A.t2 = t2;
+    A.sp = as_const(sp); A.tp = as_const(tp); A.s1 = as_const(s1); A.t1 = as_const(t1); A.s2 = as_const(s2); A.t2 = as_const(t2);
     // bn_params: gamma_p, beta_p, gamma_1, beta_1, gamma_2, beta_2 ; bn_buffers: rm_p, rv_p, rm_1, rv_1, rm_2, rv_2
     if (!training) {
         k_bn_eval<<<1, 64, 0, s>>>(3, bn_params[0], bn_params[1], eps, bn_buffers[0], bn_buffers[1], sp, tp);
@@ -892,11 +913,11 @@ int forward_impl(LayerArgs A, int training, float eps, float momentum, const flo
     }
     float *mp = saved, *rp = saved + 3, *m1 = saved + 6, *r1 = saved + 6 + C, *m2 = saved + 6 + 2 * C, *r2 = saved + 6 + 2 * C + CS;
     k_p1<K><<<grid, 64 * WPB, 0, s>>>(A);
-    k_bn_finalize<<<1, 64, 0, s>>>(A.partial, nw, 3, (double)rows, bn_params[0], bn_params[1], eps, momentum, bn_buffers[0], bn_buffers[1], sp, tp, mp, rp);
+    k_bn_finalize<<<1, 256, 0, s>>>(A.partial, nw, 3, (double)rows, bn_params[0], bn_params[1], eps, momentum, bn_buffers[0], bn_buffers[1], sp, tp, mp, rp);
     k_p2<C, K><<<grid, 64 * WPB, lds, s>>>(A);
-    k_bn_finalize<<<pdf_divup(C, 64), 64, 0, s>>>(A.partial, nw, C, (double)rows, bn_params[2], bn_params[3], eps, momentum, bn_buffers[2], bn_buffers[3], s1, t1, m1, r1);
+    k_bn_finalize<<<pdf_divup(C, 16), 256, 0, s>>>(A.partial, nw, C, (double)rows, bn_params[2], bn_params[3], eps, momentum, bn_buffers[2], bn_buffers[3], s1, t1, m1, r1);
     k_p3<C, K, true><<<grid, 64 * WPB, lds, s>>>(A);
-    k_bn_finalize<<<1, 64, 0, s>>>(A.partial, nw, CS, (double)rows, bn_params[4], bn_params[5], eps, momentum, bn_buffers[4], bn_buffers[5], s2, t2, m2, r2);
+    k_bn_finalize<<<pdf_divup(CS, 16), 256, 0, s>>>(A.partial, nw, CS, (double)rows, bn_params[4], bn_params[5], eps, momentum, bn_buffers[4], bn_buffers[5], s2, t2, m2, r2);
     k_p4<C, K><<<grid, 64 * WPB, lds, s>>>(A);
     return pdf_launch_status();
 }
@@ -923,21 +944,21 @@ int backward_impl(LayerArgs A, float *sums, hipStream_t s) {
     // sums layout (floats): [S1: b1_width | S2: b2_width | S3: b3_width | S4: 16 | X: 2C + 2CS scratch for B3]
     float *S1 = sums, *S2 = S1 + b1_width<C>(), *S3 = S2 + b2_width<C>(), *S4 = S3 + b3_width<C>(), *X = S4 + b4_width();
     k_b1<C, K><<<grid, 64 * WPB, lds, s>>>(A);
-    k_colsum<<<pdf_divup(b1_width<C>(), 64), 64, 0, s>>>(A.partial, nw, b1_width<C>(), S1);
-    A.sums = S1;
+    k_colsum<<<pdf_divup(b1_width<C>(), 16), 256, 0, s>>>(A.partial, nw, b1_width<C>(), S1);
+    A.sums = as_const(S1);
     k_b2<C, K><<<grid, 64 * WPB, lds, s>>>(A);
-    k_colsum<<<pdf_divup(b2_width<C>(), 64), 64, 0, s>>>(A.partial, nw, b2_width<C>(), S2);
+    k_colsum<<<pdf_divup(b2_width<C>(), 16), 256, 0, s>>>(A.partial, nw, b2_width<C>(), S2);
     // B3 wants [B2 sums (2C) | B1 sums (2CS)] contiguous
     hipError_t e = hipMemcpyAsync(X, S2, sizeof(float) * 2 * C, hipMemcpyDeviceToDevice, s);
     if (e != hipSuccess) return (int)e;
     e = hipMemcpyAsync(X + 2 * C, S1, sizeof(float) * 2 * CS, hipMemcpyDeviceToDevice, s);
     if (e != hipSuccess) return (int)e;
-    A.sums = X;
+    A.sums = as_const(X);
     k_b3<C, K><<<grid, 64 * WPB, lds, s>>>(A);
-    k_colsum<<<pdf_divup(b3_width<C>(), 64), 64, 0, s>>>(A.partial, nw, b3_width<C>(), S3);
-    A.sums = S3;
+    k_colsum<<<pdf_divup(b3_width<C>(), 16), 256, 0, s>>>(A.partial, nw, b3_width<C>(), S3);
+    A.sums = as_const(S3);
     k_b4<K><<<grid, 64 * WPB, 0, s>>>(A);
-    k_colsum<<<1, 64, 0, s>>>(A.partial, nw, b4_width(), S4);
+    k_colsum<<<1, 256, 0, s>>>(A.partial, nw, b4_width(), S4);
     return pdf_launch_status();
 }
 
@@ -973,13 +994,15 @@ extern "C" int pdf_pt_layer_backward(int n, int nsample, int c, const float *xq,
     const int cs = c / 8;
     fl::LayerArgs A;
     A.N = n; A.xq = xq; A.xk = xk; A.xv = xv; A.p = p; A.idx = idx;
-    A.Wp1 = weights[0]; A.bp1 = weights[1]; A.Wp2 = weights[2]; A.bp2 = weights[3];
-    A.Ww1 = weights[4]; A.bw1 = weights[5]; A.Ww2 = weights[6]; A.bw2 = weights[7];
-    A.sp = bn; A.tp = bn + 3; A.s1 = bn + 6; A.t1 = bn + 6 + c; A.s2 = bn + 6 + 2 * c; A.t2 = bn + 6 + 2 * c + cs;
+    using fl::as_const;
+    A.Wp1 = as_const(weights[0]); A.bp1 = as_const(weights[1]); A.Wp2 = as_const(weights[2]); A.bp2 = as_const(weights[3]);
+    A.Ww1 = as_const(weights[4]); A.bw1 = as_const(weights[5]); A.Ww2 = as_const(weights[6]); A.bw2 = as_const(weights[7]);
+    A.sp = as_const(bn); A.tp = as_const(bn + 3); A.s1 = as_const(bn + 6); A.t1 = as_const(bn + 6 + c);
+    A.s2 = as_const(bn + 6 + 2 * c); A.t2 = as_const(bn + 6 + 2 * c + cs);
     // saved = [mp(3) rp(3) m1(C) r1(C) m2(CS) r2(CS)] -> mean / rstd views indexed [p(3) | 1(C) | 2(CS)]
     // (the kernels index A.mean / A.rstd as [0..3) p, [3..3+C) 1, [3+C..) 2: build those views in `sums` scratch)
     A.H = const_cast<float *>(H); A.out = nullptr; A.partial = partial;
-    A.gout = gout; A.G2 = G2; A.G3 = G3; A.gxq = gxq; A.gxk = gxk; A.gxv = gxv; A.sums = nullptr;
+    A.gout = gout; A.G2 = G2; A.G3 = G3; A.gxq = gxq; A.gxk = gxk; A.gxv = gxv; A.sums = as_const(nullptr);
     hipStream_t s = static_cast<hipStream_t>(stream);
     // re-pack saved statistics into contiguous mean[] and rstd[] arrays at the tail of `sums`
     const long tail = pdf_pt_layer_bwd_sums_floats(c);
@@ -990,7 +1013,7 @@ extern "C" int pdf_pt_layer_backward(int n, int nsample, int c, const float *xq,
     PDF_CP(mean + 3, saved + 6, c); PDF_CP(rstd + 3, saved + 6 + c, c);
     PDF_CP(mean + 3 + c, saved + 6 + 2 * c, cs); PDF_CP(rstd + 3 + c, saved + 6 + 2 * c + cs, cs);
 #undef PDF_CP
-    A.mean = mean; A.rstd = rstd;
+    A.mean = as_const(mean); A.rstd = as_const(rstd);
 #define PDF_BWD(C_, K_) return fl::backward_impl<C_, K_>(A, sums, s)
     if (nsample == 8) {
         if (c == 32) PDF_BWD(32, 8);
@@ -1017,8 +1040,9 @@ extern "C" int pdf_pt_layer_forward(int n, int nsample, int c, const float *xq, 
     if (training && !saved) return PDF_ERR_BAD_ARG;
     fl::LayerArgs A;
     A.N = n; A.xq = xq; A.xk = xk; A.xv = xv; A.p = p; A.idx = idx;
-    A.Wp1 = weights[0]; A.bp1 = weights[1]; A.Wp2 = weights[2]; A.bp2 = weights[3];
-    A.Ww1 = weights[4]; A.bw1 = weights[5]; A.Ww2 = weights[6]; A.bw2 = weights[7];
+    using fl::as_const;
+    A.Wp1 = as_const(weights[0]); A.bp1 = as_const(weights[1]); A.Wp2 = as_const(weights[2]); A.bp2 = as_const(weights[3]);
+    A.Ww1 = as_const(weights[4]); A.bw1 = as_const(weights[5]); A.Ww2 = as_const(weights[6]); A.bw2 = as_const(weights[7]);
     A.H = H; A.out = out; A.partial = partial;
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define PDF_FWD(C_, K_) return fl::forward_impl<C_, K_>(A, training, eps, momentum, bn_params, bn_buffers, bn, saved, s)

@@ -1,0 +1,305 @@
+// Grid-accelerated exact kNN for gfx950.
+//
+// Result contract: bit-identical to pdf_knn_query / the reference scan (knn_query_cuda_kernel.cu:60-104).
+// The reference's brute force is O(M * N_scene); its result is "the nsample smallest as-written fp32 distances in
+// ascending order", with ties resolved by heap history.  This path finds the same nsample (+1) smallest distances
+// through a uniform grid over the scene and hands every query whose answer could depend on tie-breaking (two equal
+// distances among the best nsample+1) -- or whose scene holds fewer than nsample+1 points -- to the exact scan kernel.
+// With real-valued coordinates that is ~never; with grid-snapped coordinates it is every query (still exact).
+//
+//   k_grid_setup : per scene bounding box -> cell size from volume / count (target 4 points per cell), dims <= 2^20 cells
+//   k_grid_hist / k_grid_scan / k_grid_scatter : counting sort of the source points by cell -> float4 {x,y,z,idx}
+//   k_grid_query : one lane per query, rings of cells around the query's cell until the (nsample+1)-th best distance
+//                  is certified by the distance to the searched cube's faces; top list in registers (static insertion)
+//   knn_scan_kernel (knn_query.hip) on the redo list
+// Work per query ~ a few hundred candidate distances instead of N_scene.  Bound: latency / VALU; HBM bytes 12N+12M+8Mk.
+#include "pdfops_common.h"
+
+extern "C" int pdf_knn_query_list(int m, int nsample, const float *xyz, const float *new_xyz, const int *offset,
+                                  const int *new_offset, int b, int *idx, float *dist2, const int *qlist,
+                                  const int *qcount, void *stream);
+
+namespace kg {
+
+constexpr int CAP_CELLS = 1 << 20;  // cells per scene
+constexpr int PB = 256;
+
+struct SceneGrid {      // 16 floats / ints per scene in the workspace
+    float minx, miny, minz, inv_h;
+    float h;
+    int nx, ny, nz;
+    int start, n;       // source point range
+    int cell_base;      // offset of this scene's cells in the cell arrays
+    int pad[5];
+};
+
+struct Layout {
+    size_t grid, cell_start, cursor, cell_of, sorted, redo, total;
+};
+__host__ __device__ inline size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
+__host__ __device__ inline Layout make_layout(int b, int n, int m) {
+    Layout L;
+    size_t o = 0;
+    L.grid = o;       o = al(o + (size_t)b * sizeof(SceneGrid));
+    L.cell_start = o; o = al(o + ((size_t)b * CAP_CELLS + 1) * 4);
+    L.cursor = o;     o = al(o + (size_t)b * CAP_CELLS * 4);
+    L.cell_of = o;    o = al(o + (size_t)n * 4);
+    L.sorted = o;     o = al(o + (size_t)n * 16);
+    L.redo = o;       o = al(o + ((size_t)m + 4) * 4);
+    L.total = o;
+    return L;
+}
+
+__global__ __launch_bounds__(PB) void k_grid_setup(const float *__restrict__ xyz, const int *__restrict__ offset, SceneGrid *__restrict__ grids) {
+    __shared__ float red[6][PB / 64];
+    const int s = blockIdx.x;
+    const int start = s == 0 ? 0 : offset[s - 1], end = offset[s];
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int i = start + threadIdx.x; i < end; i += PB)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = xyz[3 * (size_t)i + a];
+            lo[a] = fminf(lo[a], v);
+            hi[a] = fmaxf(hi[a], v);
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64));
+        }
+        if ((threadIdx.x & 63) == 0) { red[a][threadIdx.x >> 6] = lo[a]; red[3 + a][threadIdx.x >> 6] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float l[3], h[3];
+        for (int a = 0; a < 3; ++a) {
+            l[a] = red[a][0]; h[a] = red[3 + a][0];
+            for (int w = 1; w < PB / 64; ++w) { l[a] = fminf(l[a], red[a][w]); h[a] = fmaxf(h[a], red[3 + a][w]); }
+        }
+        const int n = end - start;
+        float ext[3];
+        for (int a = 0; a < 3; ++a) ext[a] = n > 0 ? fmaxf(h[a] - l[a], 1e-6f) : 1.f;
+        // target ~4 points per cell if the points filled the box; never more than CAP_CELLS cells
+        float cell = cbrtf(ext[0] * ext[1] * ext[2] * 4.0f / (float)(n > 0 ? n : 1));
+        const float longest = fmaxf(ext[0], fmaxf(ext[1], ext[2]));
+        cell = fmaxf(cell, longest / 1000.f);
+        int nx, ny, nz;
+        while (true) {
+            nx = (int)(ext[0] / cell) + 1; ny = (int)(ext[1] / cell) + 1; nz = (int)(ext[2] / cell) + 1;
+            if ((long)nx * ny * nz < CAP_CELLS) break;  // strict: slot [ncell] holds the end sentinel
+            cell *= 1.26f;
+        }
+        SceneGrid g;
+        g.minx = l[0]; g.miny = l[1]; g.minz = l[2];
+        g.h = cell; g.inv_h = 1.0f / cell;
+        g.nx = nx; g.ny = ny; g.nz = nz;
+        g.start = start; g.n = n;
+        g.cell_base = s * CAP_CELLS;
+        grids[s] = g;
+    }
+}
+
+__device__ __forceinline__ int cell_coord(float v, float lo, float inv_h, int n) {
+    int c = (int)floorf((v - lo) * inv_h);
+    return c < 0 ? 0 : (c >= n ? n - 1 : c);
+}
+
+__device__ __forceinline__ int scene_of(int i, const int *__restrict__ offset, int b) {
+    int s = 0;
+    while (s < b - 1 && i >= offset[s]) ++s;
+    return s;
+}
+
+__global__ __launch_bounds__(PB) void k_grid_hist(int n, int b, const float *__restrict__ xyz, const int *__restrict__ offset,
+                                                  const SceneGrid *__restrict__ grids, unsigned *__restrict__ count, int *__restrict__ cell_of) {
+    const int i = blockIdx.x * PB + threadIdx.x;
+    if (i >= n) return;
+    const int s = scene_of(i, offset, b);
+    const SceneGrid g = grids[s];
+    const int cx = cell_coord(xyz[3 * (size_t)i], g.minx, g.inv_h, g.nx);
+    const int cy = cell_coord(xyz[3 * (size_t)i + 1], g.miny, g.inv_h, g.ny);
+    const int cz = cell_coord(xyz[3 * (size_t)i + 2], g.minz, g.inv_h, g.nz);
+    const int c = g.cell_base + (cz * g.ny + cy) * g.nx + cx;
+    cell_of[i] = c;
+    atomicAdd(&count[c], 1u);
+}
+
+// exclusive scan of one scene's cell counts (in place) + the scene's point base; one 1024-thread block per scene
+__global__ __launch_bounds__(1024) void k_grid_scan(const SceneGrid *__restrict__ grids, unsigned *__restrict__ cells) {
+    __shared__ unsigned wsum[16];
+    __shared__ unsigned carry;
+    const SceneGrid g = grids[blockIdx.x];
+    const int ncell = g.nx * g.ny * g.nz;
+    unsigned *h = cells + g.cell_base;
+    const int t = threadIdx.x;
+    if (t == 0) carry = (unsigned)g.start;
+    __syncthreads();
+    for (int base = 0; base < ncell; base += 1024 * 8) {
+        unsigned v[8], sum = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = base + t * 8 + u;
+            v[u] = c < ncell ? h[c] : 0u;
+            sum += v[u];
+        }
+        unsigned inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned up = __shfl_up(inc, o, 64);
+            if ((t & 63) >= o) inc += up;
+        }
+        if ((t & 63) == 63) wsum[t >> 6] = inc;
+        __syncthreads();
+        unsigned wbase = 0;
+        for (int w = 0; w < (t >> 6); ++w) wbase += wsum[w];
+        unsigned run = carry + wbase + inc - sum;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = base + t * 8 + u;
+            if (c < ncell) h[c] = run;
+            run += v[u];
+        }
+        __syncthreads();
+        if (t == 1023) carry = run;
+        __syncthreads();
+    }
+    if (t == 0) h[ncell] = carry;  // end sentinel (next scene's base or the slack slot)
+}
+
+__global__ __launch_bounds__(PB) void k_grid_scatter(int n, const float *__restrict__ xyz, const int *__restrict__ cell_of,
+                                                     const unsigned *__restrict__ cell_start, unsigned *__restrict__ cursor,
+                                                     float4 *__restrict__ sorted) {
+    const int i = blockIdx.x * PB + threadIdx.x;
+    if (i >= n) return;
+    const int c = cell_of[i];
+    const unsigned pos = cell_start[c] + atomicAdd(&cursor[c], 1u);
+    sorted[pos] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], __int_as_float(i));
+}
+
+// sorted insertion into a (d, i) list of KP1 entries kept in registers (static indices only)
+template <int KP1>
+__device__ __forceinline__ void insert(float (&bd)[KP1], int (&bi)[KP1], float d, int i) {
+    if (!(d < bd[KP1 - 1] || (d == bd[KP1 - 1] && i < bi[KP1 - 1]))) return;
+#pragma unroll
+    for (int s = KP1 - 1; s >= 0; --s) {
+        const bool up = s > 0 && (d < bd[s - 1] || (d == bd[s - 1] && i < bi[s - 1]));
+        if (up) { bd[s] = bd[s - 1]; bi[s] = bi[s - 1]; }
+        else { bd[s] = d; bi[s] = i; break; }
+    }
+}
+
+template <int KP1>
+__global__ __launch_bounds__(PB) void k_grid_query(int m, int b, const float *__restrict__ new_xyz, const int *__restrict__ new_offset,
+                                                   const SceneGrid *__restrict__ grids, const unsigned *__restrict__ cell_start,
+                                                   const float4 *__restrict__ sorted, int *__restrict__ idx,
+                                                   float *__restrict__ dist2, int *__restrict__ redo) {
+    constexpr int K = KP1 - 1;
+    const int q = blockIdx.x * PB + threadIdx.x;
+    if (q >= m) return;
+    const int s = scene_of(q, new_offset, b);
+    const SceneGrid g = grids[s];
+    const float qx = new_xyz[3 * (size_t)q], qy = new_xyz[3 * (size_t)q + 1], qz = new_xyz[3 * (size_t)q + 2];
+    bool need_redo = g.n < KP1;  // placeholders / not enough points for the tie test: exact scan
+    float bd[KP1];
+    int bi[KP1];
+#pragma unroll
+    for (int t = 0; t < KP1; ++t) { bd[t] = 3.0e38f; bi[t] = 0x7fffffff; }
+    if (!need_redo) {
+        const int cx = cell_coord(qx, g.minx, g.inv_h, g.nx), cy = cell_coord(qy, g.miny, g.inv_h, g.ny), cz = cell_coord(qz, g.minz, g.inv_h, g.nz);
+        const unsigned *cs = cell_start + g.cell_base;
+        const int rmax = max(g.nx, max(g.ny, g.nz));
+        for (int R = 0; R <= rmax; ++R) {
+            const int x0 = max(cx - R, 0), x1 = min(cx + R, g.nx - 1);
+            const int y0 = max(cy - R, 0), y1 = min(cy + R, g.ny - 1);
+            const int z0 = max(cz - R, 0), z1 = min(cz + R, g.nz - 1);
+            for (int z = z0; z <= z1; ++z)
+                for (int y = y0; y <= y1; ++y) {
+                    // shell of the cube of radius R: on a z- or y-face every x, otherwise only the two x-faces
+                    const bool face = (z - cz == R) || (cz - z == R) || (y - cy == R) || (cy - y == R);
+                    const int xa = face ? x0 : cx - R, xb = face ? x1 : cx + R;
+                    const int xstep = face ? 1 : max(2 * R, 1);
+                    for (int x = xa; x <= xb; x += xstep) {
+                        if (x < 0 || x >= g.nx) continue;
+                        const int c = (z * g.ny + y) * g.nx + x;
+                        const unsigned p0 = cs[c], p1 = cs[c + 1];
+                        for (unsigned p = p0; p < p1; ++p) {
+                            const float4 v = sorted[p];
+                            const float d = (qx - v.x) * (qx - v.x) + (qy - v.y) * (qy - v.y) + (qz - v.z) * (qz - v.z);
+                            insert<KP1>(bd, bi, d, __float_as_int(v.w));
+                        }
+                    }
+                }
+            // certified radius: distance from the query to the nearest face of the searched cube that is not a grid wall
+            float rc = 3.0e38f;
+            if (cx - R > 0) rc = fminf(rc, qx - (g.minx + (float)(cx - R) * g.h));
+            if (cx + R < g.nx - 1) rc = fminf(rc, (g.minx + (float)(cx + R + 1) * g.h) - qx);
+            if (cy - R > 0) rc = fminf(rc, qy - (g.miny + (float)(cy - R) * g.h));
+            if (cy + R < g.ny - 1) rc = fminf(rc, (g.miny + (float)(cy + R + 1) * g.h) - qy);
+            if (cz - R > 0) rc = fminf(rc, qz - (g.minz + (float)(cz - R) * g.h));
+            if (cz + R < g.nz - 1) rc = fminf(rc, (g.minz + (float)(cz + R + 1) * g.h) - qz);
+            if (rc >= 3.0e38f) break;                       // the cube is the whole grid
+            // slack for the rounding of cell edges and distances (relative + a few ulps of the coordinate magnitude)
+            rc = fmaxf(rc * 0.999f - 2e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz) + g.h), 0.f);
+            if (bd[KP1 - 1] < rc * rc) break;               // the K+1 best are all inside the certified ball
+        }
+        // ties among the K+1 best distances make the reference's answer depend on its heap history: exact scan instead
+#pragma unroll
+        for (int t = 0; t < K; ++t) need_redo |= (bd[t] == bd[t + 1]);
+    }
+    if (need_redo) {
+        const int slot = atomicAdd(&redo[0], 1);
+        redo[4 + slot] = q;
+        return;
+    }
+    int *oi = idx + (size_t)q * K;
+    float *od = dist2 + (size_t)q * K;
+#pragma unroll
+    for (int t = 0; t < K; ++t) { oi[t] = bi[t]; od[t] = bd[t]; }
+}
+
+}  // namespace kg
+
+extern "C" long pdf_knn_workspace_bytes(int b, int n, int m) {
+    if (b < 1 || n < 0 || m < 0) return -1;
+    return (long)kg::make_layout(b, n, m).total;
+}
+
+// nsample values served by the grid path (others fall back to the scan inside pdf_knn_query_ws)
+extern "C" int pdf_knn_grid_supported(int nsample) { return nsample == 3 || nsample == 8 || nsample == 16; }
+
+extern "C" int pdf_knn_query_ws(int m, int nsample, int n, const float *xyz, const float *new_xyz, const int *offset,
+                                const int *new_offset, int b, int *idx, float *dist2, void *workspace,
+                                long workspace_bytes, void *stream) {
+    if (m < 0 || n < 0 || b < 1 || !xyz || !new_xyz || !offset || !new_offset || !idx || !dist2) return PDF_ERR_BAD_ARG;
+    if (nsample < 1 || nsample > 128) return PDF_ERR_NSAMPLE;
+    if (m == 0) return PDF_OK;
+    if (!pdf_knn_grid_supported(nsample) || b > 64)
+        return pdf_knn_query(m, nsample, xyz, new_xyz, offset, new_offset, b, idx, dist2, stream);
+    const kg::Layout L = kg::make_layout(b, n, m);
+    if (!workspace || workspace_bytes < (long)L.total) return PDF_ERR_BAD_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char *ws = static_cast<char *>(workspace);
+    kg::SceneGrid *grids = reinterpret_cast<kg::SceneGrid *>(ws + L.grid);
+    unsigned *cell_start = reinterpret_cast<unsigned *>(ws + L.cell_start);
+    unsigned *cursor = reinterpret_cast<unsigned *>(ws + L.cursor);
+    int *cell_of = reinterpret_cast<int *>(ws + L.cell_of);
+    float4 *sorted = reinterpret_cast<float4 *>(ws + L.sorted);
+    int *redo = reinterpret_cast<int *>(ws + L.redo);
+    hipError_t e = hipMemsetAsync(ws + L.cell_start, 0, L.cell_of - L.cell_start, s);  // counts + cursors
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(redo, 0, 16, s);
+    if (e != hipSuccess) return (int)e;
+    kg::k_grid_setup<<<b, kg::PB, 0, s>>>(xyz, offset, grids);
+    kg::k_grid_hist<<<pdf_divup(n, kg::PB), kg::PB, 0, s>>>(n, b, xyz, offset, grids, cell_start, cell_of);
+    kg::k_grid_scan<<<b, 1024, 0, s>>>(grids, cell_start);
+    kg::k_grid_scatter<<<pdf_divup(n, kg::PB), kg::PB, 0, s>>>(n, xyz, cell_of, cell_start, cursor, sorted);
+    const int grid = pdf_divup(m, kg::PB);
+    if (nsample == 3) kg::k_grid_query<4><<<grid, kg::PB, 0, s>>>(m, b, new_xyz, new_offset, grids, cell_start, sorted, idx, dist2, redo);
+    else if (nsample == 8) kg::k_grid_query<9><<<grid, kg::PB, 0, s>>>(m, b, new_xyz, new_offset, grids, cell_start, sorted, idx, dist2, redo);
+    else kg::k_grid_query<17><<<grid, kg::PB, 0, s>>>(m, b, new_xyz, new_offset, grids, cell_start, sorted, idx, dist2, redo);
+    int rc = pdf_launch_status();
+    if (rc != PDF_OK) return rc;
+    return pdf_knn_query_list(m, nsample, xyz, new_xyz, offset, new_offset, b, idx, dist2, redo + 4, redo, stream);
+}

@@ -43,13 +43,21 @@ __global__ __launch_bounds__(BLOCK) void knn_scan_kernel(int m, int k, const flo
                                                          const float *__restrict__ new_xyz,
                                                          const int *__restrict__ offset,
                                                          const int *__restrict__ new_offset, int b,
-                                                         int *__restrict__ idx, float *__restrict__ dist2) {
+                                                         int *__restrict__ idx, float *__restrict__ dist2,
+                                                         const int *__restrict__ qlist, const int *__restrict__ qcount) {
     extern __shared__ __attribute__((aligned(16))) unsigned char knn_smem[];
     float *hd = reinterpret_cast<float *>(knn_smem);  // [k][BLOCK]
     int *hi = reinterpret_cast<int *>(hd + k * BLOCK);  // [k][BLOCK]
     const int tid = threadIdx.x;
-    const int q = blockIdx.x * BLOCK + tid;
-    const bool active = q < m;
+    // optional indirection: only the queries listed in qlist[0 .. *qcount) (the grid path's exact-scan "redo" list)
+    int q = blockIdx.x * BLOCK + tid;
+    bool active = q < m;
+    if (qlist) {
+        const int cnt = *qcount;
+        if (blockIdx.x * BLOCK >= cnt) return;
+        active = q < cnt;
+        q = active ? qlist[q] : 0;
+    }
 
     int bt = 0;  // get_bt_idx, knn_query_cuda_kernel.cu:45-56 (bounded by b)
     float qx = 0.f, qy = 0.f, qz = 0.f;
@@ -127,8 +135,10 @@ __global__ __launch_bounds__(BLOCK) void knn_scan_kernel(int m, int k, const flo
 
 }  // namespace
 
-extern "C" int pdf_knn_query(int m, int nsample, const float *xyz, const float *new_xyz, const int *offset,
-                             const int *new_offset, int b, int *idx, float *dist2, void *stream) {
+// Exact scan restricted to the queries qlist[0 .. *qcount) (both on the device); qlist == nullptr: all m queries.
+extern "C" int pdf_knn_query_list(int m, int nsample, const float *xyz, const float *new_xyz, const int *offset,
+                                  const int *new_offset, int b, int *idx, float *dist2, const int *qlist,
+                                  const int *qcount, void *stream) {
     if (m < 0 || b < 1 || !xyz || !new_xyz || !offset || !new_offset || !idx || !dist2) return PDF_ERR_BAD_ARG;
     if (nsample < 1 || nsample > 128) return PDF_ERR_NSAMPLE;
     if (m == 0) return PDF_OK;
@@ -136,11 +146,16 @@ extern "C" int pdf_knn_query(int m, int nsample, const float *xyz, const float *
     if (nsample <= 32) {
         constexpr int BLOCK = 128;
         const size_t lds = (size_t)nsample * BLOCK * 8;
-        knn_scan_kernel<BLOCK><<<pdf_divup(m, BLOCK), BLOCK, lds, s>>>(m, nsample, xyz, new_xyz, offset, new_offset, b, idx, dist2);
+        knn_scan_kernel<BLOCK><<<pdf_divup(m, BLOCK), BLOCK, lds, s>>>(m, nsample, xyz, new_xyz, offset, new_offset, b, idx, dist2, qlist, qcount);
     } else {
         constexpr int BLOCK = 64;
         const size_t lds = (size_t)nsample * BLOCK * 8;
-        knn_scan_kernel<BLOCK><<<pdf_divup(m, BLOCK), BLOCK, lds, s>>>(m, nsample, xyz, new_xyz, offset, new_offset, b, idx, dist2);
+        knn_scan_kernel<BLOCK><<<pdf_divup(m, BLOCK), BLOCK, lds, s>>>(m, nsample, xyz, new_xyz, offset, new_offset, b, idx, dist2, qlist, qcount);
     }
     return pdf_launch_status();
+}
+
+extern "C" int pdf_knn_query(int m, int nsample, const float *xyz, const float *new_xyz, const int *offset,
+                             const int *new_offset, int b, int *idx, float *dist2, void *stream) {
+    return pdf_knn_query_list(m, nsample, xyz, new_xyz, offset, new_offset, b, idx, dist2, nullptr, nullptr, stream);
 }

@@ -77,11 +77,12 @@ def install_reference():
     C = types.ModuleType("pointops._C")  # signatures: libs/pointops/src/pointops_api.cpp:16-31
 
     def knn_query_cuda(m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2):
-        i, d = be.knn_query(nsample, xyz.contiguous(), new_xyz.contiguous(), offset.contiguous(), new_offset.contiguous())
+        i, d = be.knn_query(nsample, xyz.float().contiguous(), new_xyz.float().contiguous(), offset.contiguous(), new_offset.contiguous())
         idx.copy_(i); dist2.copy_(d)
 
     def farthest_point_sampling_cuda(b, n, xyz, offset, new_offset, tmp, idx):
-        be._call("farthest_point_sampling", int(b), int(n), xyz, offset.contiguous(), new_offset.contiguous(), tmp, idx)
+        tmp32 = torch.full((xyz.shape[0],), 1e10, dtype=torch.float32)  # (the fp64 run hands in a double scratch)
+        be._call("farthest_point_sampling", int(b), int(n), xyz.float().contiguous(), offset.contiguous(), new_offset.contiguous(), tmp32, idx)
 
     def grouping_forward_cuda(m, nsample, c, input, idx, output):
         be._call("grouping_forward", m, nsample, c, input, idx, output)
@@ -258,6 +259,43 @@ def run_model_case(seg, rec, hook, losses, sizes, grid_size, train):
     return out
 
 
+def run_model_case_fp64(seg, rec, hook, losses, sizes, grid_size):
+    """The reference modules evaluated in float64 (coordinates / kNN / FPS stay fp32): the yard-stick that shows how
+    much of a gradient difference is fp32 rounding of the reference itself."""
+    batch = synthetic.make_batch(sizes, first_scene_id=100, grid_size=grid_size)
+    model = _Wrap(seg.PointTransformerSeg50(in_channels=6, num_classes=13))
+    recog = rec.PTRecognizer()
+    synthetic.fill_parameters_deterministic(model.backbone, seed=1)
+    synthetic.fill_parameters_deterministic(recog, seed=2)
+    model.double().train(); recog.double().train()
+    f32 = torch.cuda.FloatTensor
+    torch.cuda.FloatTensor = lambda *a: torch.DoubleTensor(*a)
+    try:
+        mh = hook.BaseModelHook(HOOK_CONFIG, clone_tensor=True, exclude_clone={"backbone": ["forward_output"]},
+                                logger=hook.BaseModelHook._DummyLogger())
+        mh.model = model
+        with mh:
+            logits = model(dict(coord=batch["coord"], feat=batch["feat"].double(), offset=batch["offset"]))
+            conf = recog(mh)
+        ce = losses.CrossEntropyLoss(loss_weight=1.0, ignore_index=-1)
+        seg_loss = ce(logits, batch["segment"])
+        pseudo_mask = (torch.arange(logits.shape[0]) % 7) == 3
+        segment_pseudo = batch["segment"].clone()
+        segment_pseudo[pseudo_mask] = 13
+        rec_loss = ce(torch.cat([logits, conf], -1), segment_pseudo) * 0.1
+        (seg_loss + rec_loss).backward()
+    finally:
+        torch.cuda.FloatTensor = f32
+    out = {"logits64": logits.detach().numpy(), "conf64": conf.detach().numpy()}
+    named = dict(model.backbone.named_parameters())
+    for k in GRAD_PARAMS:
+        pack_grad(out, "g64_" + k, named[k].grad.numpy())
+    rnamed = dict(recog.named_parameters())
+    for k in REC_GRAD_PARAMS:
+        pack_grad(out, "rg64_" + k, rnamed[k].grad.numpy())
+    return out
+
+
 def run_op_cases(ref_pointops):
     """Python-level reference ops (pure torch given idx) + every autograd wrapper, on seeded inputs."""
     out = {}
@@ -366,6 +404,11 @@ def main():
     for name, (sizes, gs) in MODEL_CASES.items():
         for train in (True, False):
             res = run_model_case(seg, rec, hook, losses, sizes, gs, train)
+            if train:
+                res.update(run_model_case_fp64(seg, rec, hook, losses, sizes, gs))
+                print("  fp32 reference vs its own fp64 evaluation: logits", float(np.abs(res["logits"] - res["logits64"]).max()),
+                      {k[5:]: float(np.abs(res[k] - res["g64_" + k[5:]]).max() / (np.abs(res["g64_" + k[5:]]).max() + 1e-30))
+                       for k in ("grad_enc1.0.linear.weight", "grad_cls.0.weight", "grad_enc3.2.linear3.weight")})
             np.savez_compressed(os.path.join(OUT, f"model_{name}_{'train' if train else 'eval'}.npz"), **res)
             print(name, "train" if train else "eval", "calls fps/knn:", res["n_pointops_calls"],
                   "loss", float(res["seg_loss"]), float(res["rec_loss"]))

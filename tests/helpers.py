@@ -126,22 +126,29 @@ def check_case_against_golden(out, g, train, tol=REL_TOL):
     for k in ["logits", "conf", "score", "msp_score", "seg_loss", "rec_loss"]:
         assert_close(out[k], g[k], tol, k)
     if train:
+        report = {}
         for key in g.files:
             if key.endswith("#sum"):
                 continue
             if key.startswith("grad_") or key.startswith("rgrad_"):
                 named = out["named"] if key.startswith("grad_") else out["rnamed"]
-                grad = named[key.split("_", 1)[1]].grad.detach().cpu().numpy()
+                name = key.split("_", 1)[1]
+                grad = named[name].grad.detach().cpu().numpy()
                 part = grad[:GRAD_ROWS] if grad.ndim >= 2 else grad
-                # gradients: error relative to the full tensor's scale
-                scale = np.abs(grad).max() + 1e-30
-                err = np.abs(part - g[key]).max() / scale
+                k64 = ("g64_" if key.startswith("grad_") else "rg64_") + name
+                truth = g[k64]                      # the reference network evaluated in fp64
+                scale = np.abs(truth).max() + 1e-30
                 if scale < 1e-6:
                     continue  # analytically-zero gradients (biases in front of a train-mode BatchNorm): pure rounding noise
-                assert err <= GRAD_TOL, f"{key}: rel err {err:.3e}"
-                s = g[key + "#sum"]
+                ours = np.abs(part - truth).max() / scale
+                ref32 = np.abs(g[key] - truth).max() / scale  # how far the reference's own fp32 run is from fp64
+                report[name] = (ours, ref32)
+                # as close to the fp64 evaluation as the reference's fp32 run is (x4 + 5e-3 slack), never worse than GRAD_TOL
+                assert ours <= min(GRAD_TOL, 4 * ref32 + 5e-3), f"{key}: ours-vs-fp64 {ours:.3e}, reference-fp32-vs-fp64 {ref32:.3e}"
                 l2 = np.sqrt((grad.astype(np.float64) ** 2).sum())
-                assert abs(l2 - s[1]) <= GRAD_TOL * s[1] + 1e-12, f"{key}: L2 norm {l2} vs {s[1]}"
+                s64 = g[k64 + "#sum"]
+                assert abs(l2 - s64[1]) <= GRAD_TOL * s64[1] + 1e-12, f"{key}: L2 norm {l2} vs {s64[1]}"
             elif key.startswith("buf_"):
                 assert_close(out["state"][key[4:]], g[key], tol, key)
+        out["grad_report"] = report
     return n
