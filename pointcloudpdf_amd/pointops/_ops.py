@@ -132,7 +132,7 @@ def grouping(idx, feat, xyz, new_xyz=None, with_xyz=False):
         new_xyz = xyz
     assert xyz.is_contiguous() and feat.is_contiguous()
     be = _be(feat)
-    if hasattr(be, "group_forward"):
+    if hasattr(be, "group_forward") and feat.dtype == torch.float32:  # (fp64 inputs: torch composition, used by accuracy probes)
         if with_xyz:
             assert new_xyz.is_contiguous()
         return _GroupFused.apply(feat, xyz, new_xyz, idx.contiguous(), with_xyz)
