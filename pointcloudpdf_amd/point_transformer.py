@@ -18,8 +18,16 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _native, pointops
+from .dense import linear as _lin
 from .geometry import Geometry, tag_of
 from .registry import MODELS
+
+
+def _seq(seq, x):
+    """Run an nn.Sequential, routing its nn.Linear members through the split-K weight-gradient path."""
+    for m in seq:
+        x = _lin(m, x) if isinstance(m, nn.Linear) else m(x)
+    return x
 
 
 class LayerNorm1d(nn.BatchNorm1d):
@@ -116,7 +124,7 @@ class PointTransformerLayer(nn.Module):
 
     def forward(self, pxo):
         p, x, o = pxo  # (n, 3), (n, c), (b)
-        x_q, x_k, x_v = self.linear_q(x), self.linear_k(x), self.linear_v(x)
+        x_q, x_k, x_v = _lin(self.linear_q, x), _lin(self.linear_k, x), _lin(self.linear_v, x)
         if self._fused_ok(x):
             idx, _ = pointops.knn_query(self.nsample, p, o, p, o)
             return _FusedPTLayer.apply(self, idx, p, x_q, x_k, x_v, *self._param_list())
@@ -176,7 +184,7 @@ class TransitionDown(nn.Module):
                 x = self.pool(self.relu(self.bn(self.linear(x).transpose(1, 2).contiguous()))).squeeze(-1)
             p, o = n_p, n_o
         else:
-            x = self.relu(self.bn(self.linear(x)))  # (n, c)
+            x = self.relu(self.bn(_lin(self.linear, x)))  # (n, c)
         return [p, x, o]
 
 
@@ -204,15 +212,15 @@ class TransitionUp(nn.Module):
             sizes = self._scene_sizes(p, o)
             chunks = x.split(sizes, dim=0)
             means = torch.cat([ch.sum(0, True) / ch.shape[0] for ch in chunks], 0)  # (b, c)
-            ctx = self.linear2(means)
+            ctx = _seq(self.linear2, means)
             tag = tag_of(p)
             sizes_dev = tag[0].sizes(tag[1]) if tag is not None else torch.diff(o.long(), prepend=o.new_zeros(1).long())
             rep = torch.repeat_interleave(ctx, sizes_dev, dim=0, output_size=x.shape[0])
-            x = self.linear1(torch.cat((x, rep), 1))
+            x = _seq(self.linear1, torch.cat((x, rep), 1))
         else:
             p1, x1, o1 = pxo1
             p2, x2, o2 = pxo2
-            x = self.linear1(x1) + pointops.interpolation(p2, p1, self.linear2(x2), o2, o1)
+            x = _seq(self.linear1, x1) + pointops.interpolation(p2, p1, _seq(self.linear2, x2), o2, o1)
         return x
 
 
@@ -234,9 +242,9 @@ class Bottleneck(nn.Module):
     def forward(self, pxo):
         p, x, o = pxo
         identity = x
-        x = self.relu(self.bn1(self.linear1(x)))
+        x = self.relu(self.bn1(_lin(self.linear1, x)))
         x = self.relu(self.bn2(self.transformer([p, x, o])))
-        x = self.bn3(self.linear3(x))
+        x = self.bn3(_lin(self.linear3, x))
         x = self.relu(x + identity)
         return [p, x, o]
 
@@ -298,7 +306,7 @@ class PointTransformerSeg(nn.Module):
         x3 = self.dec3[1:]([p3, self.dec3[0]([p3, x3, o3], [p4, x4, o4]), o3])[1]
         x2 = self.dec2[1:]([p2, self.dec2[0]([p2, x2, o2], [p3, x3, o3]), o2])[1]
         x1 = self.dec1[1:]([p1, self.dec1[0]([p1, x1, o1], [p2, x2, o2]), o1])[1]
-        return self.cls(x1)
+        return _seq(self.cls, x1)
 
 
 @MODELS.register_module("PointTransformer-Seg26")

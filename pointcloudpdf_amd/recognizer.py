@@ -10,7 +10,7 @@
 import torch
 import torch.nn as nn
 
-from .point_transformer import TransitionUp
+from .point_transformer import TransitionUp, _seq
 from .registry import MODELS, RECOGNIZER, build_model
 from .segmentor import build_criteria
 
@@ -39,7 +39,7 @@ class PTRecognizer(nn.Module):
         r3 = self.dec3([p3, x3, o3], [p4, r4, o4])
         r2 = self.dec2([p2, x2, o2], [p3, r3, o3])
         r1 = self.dec1([p1, x1, o1], [p2, r2, o2])
-        return self.confidence(r1)  # (n, 1)
+        return _seq(self.confidence, r1)  # (n, 1)
 
 
 @RECOGNIZER.register_module("PointPdf-v1m1")
