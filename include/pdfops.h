@@ -144,6 +144,17 @@ int pdf_pt_layer_backward(int n, int nsample, int c, const float *xq, const floa
                           const float *saved, const float *H, const float *gout, float *gxq, float *gxk,
                           float *gxv, float *G2, float *G3, float *partial, float *sums, void *stream);
 
+/* BatchNorm1d over (n, c) rows fused with the residual add and ReLU that follow it in the Bottleneck
+ * (point_transformer_seg.py:184-192).  c must be a power of two in 4..1024.  coef (4c floats) = scale|shift|mean|rstd,
+ * partial = pdf_bn_partial_floats(n, c) floats of scratch; backward: sums (2c) receives [d beta | d gamma]. */
+int pdf_bn_supported(int c);
+long pdf_bn_partial_floats(long n, int c);
+int pdf_bn_act_forward(long n, int c, const float *x, const float *res, const float *gamma, const float *beta,
+                       float *running_mean, float *running_var, int training, float eps, float momentum, int relu,
+                       float *coef, float *partial, float *y, void *stream);
+int pdf_bn_act_backward(long n, int c, const float *gy, const float *x, const float *res, const float *coef,
+                        int training, int relu, float *partial, float *sums, float *gx, float *gres, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

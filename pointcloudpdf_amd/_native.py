@@ -243,6 +243,14 @@ class HipBackend(CBackend):
         self.last_fps_stats = None
         lib.pdf_abi_version.restype = c_int
         lib.pdf_build_info.restype = ctypes.c_char_p
+        lib.pdf_bn_supported.restype = c_int
+        lib.pdf_bn_supported.argtypes = [c_int]
+        lib.pdf_bn_partial_floats.restype = c_long
+        lib.pdf_bn_partial_floats.argtypes = [c_long, c_int]
+        lib.pdf_bn_act_forward.restype = c_int
+        lib.pdf_bn_act_forward.argtypes = [c_long, c_int] + [c_void_p] * 6 + [c_int, ctypes.c_float, ctypes.c_float, c_int] + [c_void_p] * 4
+        lib.pdf_bn_act_backward.restype = c_int
+        lib.pdf_bn_act_backward.argtypes = [c_long, c_int] + [c_void_p] * 4 + [c_int, c_int] + [c_void_p] * 5
         lib.pdf_pt_layer_supported.restype = c_int
         lib.pdf_pt_layer_supported.argtypes = [c_int, c_int]
         for fn in (lib.pdf_pt_layer_partial_floats, lib.pdf_pt_layer_bwd_partial_floats):
@@ -360,6 +368,36 @@ class HipBackend(CBackend):
             bp1=sums[o4:o4 + 3], Wp1=sums[o4 + 3:o4 + 12].view(3, 3),
         )
         return gxq, gxk, gxv, g
+
+    # -- BatchNorm + residual + ReLU over (n, c) rows ------------------------------------------------------
+    def bn_supported(self, c):
+        return bool(self.lib.pdf_bn_supported(int(c)))
+
+    def bn_act_forward(self, x, res, gamma, beta, running_mean, running_var, training, eps, momentum, relu):
+        n, c = x.shape
+        coef = self._new(x, (4 * c,), torch.float32)
+        partial = self._new(x, (int(self.lib.pdf_bn_partial_floats(n, c)),), torch.float32)
+        y = self._new(x, (n, c), torch.float32)
+        P = lambda t: None if t is None else self._ptr(t)
+        rc = self.lib.pdf_bn_act_forward(n, c, P(x), P(res), P(gamma), P(beta), P(running_mean), P(running_var),
+                                         int(bool(training)), ctypes.c_float(eps), ctypes.c_float(momentum), int(bool(relu)),
+                                         P(coef), P(partial), P(y), c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise PdfOpsError(f"pdf_bn_act_forward failed with status {rc}")
+        return y, coef
+
+    def bn_act_backward(self, gy, x, res, coef, training, relu, need_res):
+        n, c = x.shape
+        partial = self._new(x, (int(self.lib.pdf_bn_partial_floats(n, c)),), torch.float32)
+        sums = self._new(x, (2 * c,), torch.float32)
+        gx = self._new(x, (n, c), torch.float32)
+        gres = self._new(x, (n, c), torch.float32) if need_res else None
+        P = lambda t: None if t is None else self._ptr(t)
+        rc = self.lib.pdf_bn_act_backward(n, c, P(gy), P(x), P(res), P(coef), int(bool(training)), int(bool(relu)), P(partial),
+                                          P(sums), P(gx), P(gres), c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise PdfOpsError(f"pdf_bn_act_backward failed with status {rc}")
+        return gx, gres, sums[c:], sums[:c]  # gx, gres, d gamma, d beta
 
     def group_forward(self, feat, xyz, new_xyz, idx, with_xyz):
         _check(feat, torch.float32, "feat"); _check(idx, torch.int32, "idx")

@@ -859,12 +859,30 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float *__restrict__ p
 // Eval: scale/shift from running statistics.
 __global__ void k_bn_eval(int nch, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                           const float *__restrict__ running_mean, const float *__restrict__ running_var,
-                          float *__restrict__ scale, float *__restrict__ shift) {
+                          float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean_out,
+                          float *__restrict__ rstd_out) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= nch) return;
-    const float sc = gamma[ch] / sqrtf(running_var[ch] + eps);
+    const float rstd = 1.0f / sqrtf(running_var[ch] + eps);
+    const float sc = gamma[ch] * rstd;
     scale[ch] = sc;
     shift[ch] = beta[ch] - running_mean[ch] * sc;
+    if (mean_out) { mean_out[ch] = running_mean[ch]; rstd_out[ch] = rstd; }
+}
+
+// host-side launchers shared with pointwise.hip (kernels stay private to this translation unit)
+void launch_bn_finalize(const float *partial, int rows, int nch, double count, const float *gamma, const float *beta, float eps,
+                        float momentum, float *running_mean, float *running_var, float *scale, float *shift, float *mean_out,
+                        float *rstd_out, hipStream_t s) {
+    k_bn_finalize<<<pdf_divup(nch, 16), 256, 0, s>>>(partial, rows, nch, count, gamma, beta, eps, momentum, running_mean, running_var,
+                                                     scale, shift, mean_out, rstd_out);
+}
+void launch_bn_eval(int nch, const float *gamma, const float *beta, float eps, const float *running_mean, const float *running_var,
+                    float *scale, float *shift, float *mean_out, float *rstd_out, hipStream_t s) {
+    k_bn_eval<<<pdf_divup(nch, 64), 64, 0, s>>>(nch, gamma, beta, eps, running_mean, running_var, scale, shift, mean_out, rstd_out);
+}
+void launch_colsum(const float *partial, int rows, int width, float *out, hipStream_t s) {
+    k_colsum<<<pdf_divup(width, 16), 256, 0, s>>>(partial, rows, width, out);
 }
 
 static inline int grid_for_tiles(long ntiles) {
@@ -904,9 +922,9 @@ int forward_impl(LayerArgs A, int training, float eps, float momentum, const flo
     A.sp = as_const(sp); A.tp = as_const(tp); A.s1 = as_const(s1); A.t1 = as_const(t1); A.s2 = as_const(s2); A.t2 = as_const(t2);
     // bn_params: gamma_p, beta_p, gamma_1, beta_1, gamma_2, beta_2 ; bn_buffers: rm_p, rv_p, rm_1, rv_1, rm_2, rv_2
     if (!training) {
-        k_bn_eval<<<1, 64, 0, s>>>(3, bn_params[0], bn_params[1], eps, bn_buffers[0], bn_buffers[1], sp, tp);
-        k_bn_eval<<<pdf_divup(C, 64), 64, 0, s>>>(C, bn_params[2], bn_params[3], eps, bn_buffers[2], bn_buffers[3], s1, t1);
-        k_bn_eval<<<1, 64, 0, s>>>(CS, bn_params[4], bn_params[5], eps, bn_buffers[4], bn_buffers[5], s2, t2);
+        k_bn_eval<<<1, 64, 0, s>>>(3, bn_params[0], bn_params[1], eps, bn_buffers[0], bn_buffers[1], sp, tp, nullptr, nullptr);
+        k_bn_eval<<<pdf_divup(C, 64), 64, 0, s>>>(C, bn_params[2], bn_params[3], eps, bn_buffers[2], bn_buffers[3], s1, t1, nullptr, nullptr);
+        k_bn_eval<<<1, 64, 0, s>>>(CS, bn_params[4], bn_params[5], eps, bn_buffers[4], bn_buffers[5], s2, t2, nullptr, nullptr);
         k_p3<C, K, false><<<grid, 64 * WPB, lds, s>>>(A);
         k_p4<C, K><<<grid, 64 * WPB, lds, s>>>(A);
         return pdf_launch_status();

@@ -43,3 +43,46 @@ def linear(module, x):
     if x.dim() == 2 and x.is_cuda and x.shape[0] >= _MIN_ROWS and torch.is_grad_enabled() and x.is_contiguous():
         return _LinearSplitK.apply(x, module.weight, module.bias)
     return module(x)
+
+
+class _BnAct(torch.autograd.Function):
+    """relu?( BatchNorm1d(x) [+ residual] ) as one autograd node over the HIP kernels of csrc/pointwise.hip."""
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, bn, relu):
+        from . import _native
+
+        be = _native.hip_backend()
+        training = bn.training or bn.running_mean is None
+        y, coef = be.bn_act_forward(x, residual, weight.detach(), bias.detach(), bn.running_mean, bn.running_var, training,
+                                    bn.eps, bn.momentum if bn.momentum is not None else 0.1, relu)
+        if training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+        ctx.save_for_backward(x, residual if residual is not None else x.new_empty(0), coef)
+        ctx.cfg = (training, relu, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import _native
+
+        x, residual, coef = ctx.saved_tensors
+        training, relu, has_res = ctx.cfg
+        be = _native.hip_backend()
+        gx, gres, ggamma, gbeta = be.bn_act_backward(gy.contiguous(), x, residual if has_res else None, coef, training, relu,
+                                                     has_res and ctx.needs_input_grad[1])
+        return gx, gres, ggamma, gbeta, None, None
+
+
+def bn_act(bn, x, residual=None, relu=True):
+    """``relu(bn(x) + residual)`` for an nn.BatchNorm1d on (N, C) rows; falls back to torch off-device / odd widths."""
+    from . import _native
+
+    if (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous() and bn.affine
+            and bn.track_running_stats and _native.hip_backend().bn_supported(x.shape[1])
+            and (residual is None or residual.is_contiguous())):
+        return _BnAct.apply(x, residual, bn.weight, bn.bias, bn, relu)
+    y = bn(x)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y

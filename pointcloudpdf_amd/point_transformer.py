@@ -18,15 +18,27 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _native, pointops
-from .dense import linear as _lin
+from .dense import bn_act as _bn_act, linear as _lin
 from .geometry import Geometry, tag_of
 from .registry import MODELS
 
 
 def _seq(seq, x):
-    """Run an nn.Sequential, routing its nn.Linear members through the split-K weight-gradient path."""
-    for m in seq:
-        x = _lin(m, x) if isinstance(m, nn.Linear) else m(x)
+    """Run an nn.Sequential of Linear / BatchNorm1d / ReLU members: Linear through the split-K weight-gradient path,
+    BatchNorm1d (+ a directly following ReLU) through the fused normalisation kernels."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Linear):
+            x = _lin(m, x)
+        elif isinstance(m, nn.BatchNorm1d) and type(m) is nn.BatchNorm1d and x.dim() == 2:
+            relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            x = _bn_act(m, x, None, relu)
+            i += 1 if relu else 0
+        else:
+            x = m(x)
+        i += 1
     return x
 
 
@@ -184,7 +196,7 @@ class TransitionDown(nn.Module):
                 x = self.pool(self.relu(self.bn(self.linear(x).transpose(1, 2).contiguous()))).squeeze(-1)
             p, o = n_p, n_o
         else:
-            x = self.relu(self.bn(_lin(self.linear, x)))  # (n, c)
+            x = _bn_act(self.bn, _lin(self.linear, x), None, True)  # (n, c)
         return [p, x, o]
 
 
@@ -242,10 +254,9 @@ class Bottleneck(nn.Module):
     def forward(self, pxo):
         p, x, o = pxo
         identity = x
-        x = self.relu(self.bn1(_lin(self.linear1, x)))
-        x = self.relu(self.bn2(self.transformer([p, x, o])))
-        x = self.bn3(_lin(self.linear3, x))
-        x = self.relu(x + identity)
+        x = _bn_act(self.bn1, _lin(self.linear1, x), None, True)
+        x = _bn_act(self.bn2, self.transformer([p, x, o]), None, True)
+        x = _bn_act(self.bn3, _lin(self.linear3, x), identity, True)  # relu(bn3(.) + identity)
         return [p, x, o]
 
 
