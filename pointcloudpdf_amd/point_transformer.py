@@ -53,7 +53,10 @@ class LayerNorm1d(nn.BatchNorm1d):
             # upstream layout there; the device path below is the product
             return super().forward(input.transpose(1, 2).contiguous()).transpose(1, 2).contiguous()
         shape = input.shape
-        return super().forward(input.reshape(-1, shape[-1])).view(shape)
+        x2d = input.reshape(-1, shape[-1])
+        if input.dtype == torch.float32 and _native.hip_backend().bn_supported(shape[-1]):
+            return _bn_act(self, x2d.contiguous(), None, False).view(shape)
+        return nn.BatchNorm1d.forward(self, x2d).view(shape)  # 3-channel norm of linear_p / odd widths
 
 
 class _FusedPTLayer(torch.autograd.Function):
@@ -190,7 +193,7 @@ class TransitionDown(nn.Module):
             x, _ = pointops.knn_query_and_group(x, p, offset=o, new_xyz=n_p, new_offset=n_o, nsample=self.nsample, with_xyz=True)
             m, ns = x.shape[0], x.shape[1]
             if x.is_cuda:
-                y = self.relu(self.bn(self.linear(x).view(m * ns, -1)))  # BN over all m*ns rows == BN1d on (m, c, ns)
+                y = _bn_act(self.bn, _lin(self.linear, x.view(m * ns, -1)), None, True)  # BN over all m*ns rows == BN1d on (m, c, ns)
                 x = self.pool(y.view(m, ns, -1).transpose(1, 2)).squeeze(-1)  # (m, c)
             else:  # host-logic tests only (see LayerNorm1d.forward)
                 x = self.pool(self.relu(self.bn(self.linear(x).transpose(1, 2).contiguous()))).squeeze(-1)
