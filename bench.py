@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--cpu-points", type=int, default=16000, help="scene size of the bounded CPU-baseline sample")
     ap.add_argument("--amp", action="store_true", help="fp16 autocast around the step (reference enable_amp=True)")
     ap.add_argument("--prefetch", type=int, default=3, help="geometry pre-pass depth in steps (0 = inline, serial)")
+    ap.add_argument("--graph", type=int, default=0, help="replay fwd+bwd+SGD as one captured hipGraph (needs --prefetch > 0)")
     return ap.parse_args()
 
 
@@ -180,6 +181,45 @@ def main():
         for i in range(args.prefetch):
             submit(i)
 
+    # ---- optional: the whole step (fwd + bwd + SGD) as ONE captured hipGraph.  The step issues ~3000 kernel launches
+    # and is host-bound in eager mode; scene sizes are fixed, so the launch sequence is static.  Inputs and the
+    # geometry tables live in static buffers that are refreshed (device-to-device copies) before every replay; the
+    # geometry pre-pass itself keeps running eagerly on the side streams.
+    use_graph = bool(args.graph) and prefetcher is not None and world == 1  # (DDP + capture: not attempted)
+    graph = None
+    if use_graph:
+        from pointcloudpdf_amd.geometry import Geometry
+
+        b0 = pool[0]
+        static = {k: b0[k].clone() for k in ("coord", "feat", "offset", "segment")}
+        static_geom = Geometry(static["coord"], static["offset"], b0["offset_host"]).precompute()
+        static_data = dict(coord=static["coord"], feat=static["feat"], offset=static["offset"], offset_host=b0["offset_host"],
+                           segment=static["segment"], pdf_geometry=static_geom)
+        static_out = {}
+
+        def graph_body():
+            opt.zero_grad(set_to_none=False)
+            with torch.autocast("cuda", dtype=torch.float16, enabled=args.amp):
+                out = module(dict(static_data))
+            out["loss"].backward()
+            opt.step()
+            static_out["loss"] = out["loss"].detach()
+
+        eager_step = one_step
+
+        def one_step(i):  # noqa: F811
+            batch = pool[i % len(pool)]
+            geom = prefetcher.get(tickets.pop(i))
+            submit(i + args.prefetch)
+            for k in ("coord", "feat", "segment"):
+                static[k].copy_(batch[k])
+            static_geom.load(geom)
+            if graph is None:
+                graph_body()
+            else:
+                graph.replay()
+            return static_out
+
     def fence():
         if world > 1:
             torch.distributed.barrier()
@@ -188,6 +228,17 @@ def main():
     for i in range(args.warmup):
         one_step(i)
     fence()
+    if use_graph:
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                graph_body()
+            graph = g
+            fence()
+        except Exception as e:  # capture not possible in this configuration: stay eager
+            print(f"[bench] hipGraph capture failed, running eager: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            graph = None
+            torch.cuda.synchronize()
     timer.enabled = True
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -231,6 +282,7 @@ def main():
             "per_gpu_points_per_s": pts_per_step * args.steps / dt / world,
             "loss": loss,
             "geometry_prefetch_depth": args.prefetch,
+            "hipgraph": bool(use_graph and graph is not None),
             "kernels": ks,
             "roofline": roof,
         }

@@ -23,7 +23,9 @@
 
 namespace fl {
 
-constexpr int TS = 33;          // LDS tile row stride in floats (bank-conflict-free for row-per-lane and column reads)
+// LDS tile row strides (floats) are odd (33 / 65 / 17): row-per-lane and column reads are both bank-conflict-free.
+__host__ __device__ constexpr int tile_stride(int c) { return c / 8 > 32 ? 65 : 33; }      // holds 32-channel chunks and CS-wide rows
+__host__ __device__ constexpr int aux_stride(int c) { return c / 8 <= 16 ? 17 : c / 8 + 1; }
 constexpr int WPB = 4;          // waves per block
 constexpr int MAX_BLOCKS = 512;
 
@@ -56,9 +58,9 @@ struct WaveLds {
     float *tile;   // [64][TS]
     float *qtile;  // [8][TS]   rows of the tile's centre points
     int *rowid;    // [64]      gathered row index per tile row (-1 = zero row)
-    float *aux;    // [64][AUX] second operand of the weight-gradient products (backward kernels only)
+    float *aux;    // [64][as] second operand of the weight-gradient products (backward kernels only)
+    int ts, as;    // row strides of tile / qtile and of aux
 };
-constexpr int AUX = 17;
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -75,7 +77,7 @@ __device__ __forceinline__ void stage_rows(const WaveLds &L, const float *__rest
         const int src = L.rowid[row];
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (src >= 0) v = *reinterpret_cast<const float4 *>(table + (size_t)src * C + c0 + col);
-        float *d = L.tile + row * TS + col;
+        float *d = L.tile + row * L.ts + col;
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
 }
@@ -87,7 +89,7 @@ __device__ __forceinline__ void stage_points(const WaveLds &L, const float *__re
         const int pt = lane >> 3, col = (lane & 7) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i0 + pt < N) v = *reinterpret_cast<const float4 *>(table + (size_t)(i0 + pt) * C + c0 + col);
-        float *d = L.qtile + pt * TS + col;
+        float *d = L.qtile + pt * L.ts + col;
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
 }
@@ -133,12 +135,12 @@ __device__ __forceinline__ void pos_chunk(const LayerArgs &A, const float *t1n, 
 }
 
 // Column sums of the 64x32 tile: lane (ch = lane & 31, half = lane >> 5) adds its 32 rows into s / ss.
-__device__ __forceinline__ void column_stats(const WaveLds &L, int lane, float &s, float &ss) {
-    const int ch = lane & 31, r0 = (lane >> 5) * 32;
+__device__ __forceinline__ void column_stats(const WaveLds &L, int lane, float &s, float &ss, int col0 = 0) {
+    const int ch = col0 + (lane & 31), r0 = (lane >> 5) * 32;
     float a = 0.f, b = 0.f;
 #pragma unroll
     for (int r = 0; r < 32; ++r) {
-        const float v = L.tile[(r0 + r) * TS + ch];
+        const float v = L.tile[(r0 + r) * L.ts + ch];
         a += v;
         b += v * v;
     }
@@ -146,16 +148,19 @@ __device__ __forceinline__ void column_stats(const WaveLds &L, int lane, float &
     ss += b;
 }
 
-constexpr int LDS_FLOATS_PER_WAVE = 64 * TS + 8 * TS + 64;
-constexpr int LDS_FLOATS_PER_WAVE_BWD = LDS_FLOATS_PER_WAVE + 64 * AUX;
-template <bool BWD = false>
+__host__ __device__ constexpr int lds_floats_per_wave(int c, bool bwd) {
+    return 64 * tile_stride(c) + 8 * tile_stride(c) + 64 + (bwd ? 64 * aux_stride(c) : 0);
+}
+template <bool BWD, int C>
 __device__ __forceinline__ WaveLds carve_lds(float *base, int wave) {
     WaveLds L;
-    float *w = base + wave * (BWD ? LDS_FLOATS_PER_WAVE_BWD : LDS_FLOATS_PER_WAVE);
+    L.ts = tile_stride(C);
+    L.as = aux_stride(C);
+    float *w = base + wave * lds_floats_per_wave(C, BWD);
     L.tile = w;
-    L.qtile = w + 64 * TS;
-    L.rowid = reinterpret_cast<int *>(w + 64 * TS + 8 * TS);
-    L.aux = w + LDS_FLOATS_PER_WAVE;
+    L.qtile = w + 64 * L.ts;
+    L.rowid = reinterpret_cast<int *>(w + 64 * L.ts + 8 * L.ts);
+    L.aux = w + lds_floats_per_wave(C, false);
     return L;
 }
 
@@ -184,8 +189,8 @@ __global__ __launch_bounds__(64 * WPB) void k_p1(LayerArgs A) {
 // r chunk of one row: needs the staged xk chunk (tile) and xq chunk (qtile)
 template <int K>
 __device__ __forceinline__ void rqk_chunk(const WaveLds &L, int lane, const float *pr, float *r) {
-    const float *xk = L.tile + lane * TS;
-    const float *xq = L.qtile + (lane / K) * TS;
+    const float *xk = L.tile + lane * L.ts;
+    const float *xq = L.qtile + (lane / K) * L.ts;
 #pragma unroll
     for (int c = 0; c < 32; ++c) r[c] = (xk[c] - xq[c]) + pr[c];
 }
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(64 * WPB) void k_p2(LayerArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NCH = C / 32, PPT = 64 / K;
     const int lane = threadIdx.x & 63;
-    const WaveLds L = carve_lds<false>(lds, threadIdx.x >> 6);
+    const WaveLds L = carve_lds<false, C>(lds, threadIdx.x >> 6);
     const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
     const long ntiles = ((long)A.N * K + 63) / 64;
     float s[NCH], ss[NCH];
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(64 * WPB) void k_p2(LayerArgs A) {
             rqk_chunk<K>(L, lane, pr, r);
             wave_sync();
 #pragma unroll
-            for (int c = 0; c < 32; ++c) L.tile[lane * TS + c] = R.valid ? r[c] : 0.f;
+            for (int c = 0; c < 32; ++c) L.tile[lane * L.ts + c] = R.valid ? r[c] : 0.f;
             wave_sync();
             column_stats(L, lane, s[q], ss[q]);
             wave_sync();
@@ -241,10 +246,13 @@ __global__ __launch_bounds__(64 * WPB) void k_p3(LayerArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NCH = C / 32, PPT = 64 / K, CS = C / 8;
     const int lane = threadIdx.x & 63;
-    const WaveLds L = carve_lds<false>(lds, threadIdx.x >> 6);
+    const WaveLds L = carve_lds<false, C>(lds, threadIdx.x >> 6);
     const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
     const long ntiles = ((long)A.N * K + 63) / 64;
-    float s = 0.f, ss = 0.f;  // lane (ch = lane & 31 < CS, half) accumulates channel ch of h   (CS <= 16 here)
+    constexpr int NH = (CS + 31) / 32;
+    float s[NH], ss[NH];      // lane (ch = lane & 31, half) accumulates channel hh*32 + ch of h
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) { s[hh] = 0.f; ss[hh] = 0.f; }
     for (long tile = wave_g; tile < ntiles; tile += nwaves) {
         const Row R = load_row<K>(A, tile, lane);
         float t1n[3];
@@ -279,17 +287,23 @@ __global__ __launch_bounds__(64 * WPB) void k_p3(LayerArgs A) {
         }
         if (STATS) {
 #pragma unroll
-            for (int o = 0; o < CS; ++o) L.tile[lane * TS + o] = R.valid ? h[o] : 0.f;
+            for (int o = 0; o < CS; ++o) L.tile[lane * L.ts + o] = R.valid ? h[o] : 0.f;
             wave_sync();
-            if ((lane & 31) < CS) column_stats(L, lane, s, ss);
+#pragma unroll
+            for (int hh = 0; hh < NH; ++hh)
+                if (hh * 32 + (lane & 31) < CS) column_stats(L, lane, s[hh], ss[hh], hh * 32);
             wave_sync();
         }
     }
     if (STATS) {
-        const float a = s + __shfl_xor(s, 32, 64), b = ss + __shfl_xor(ss, 32, 64);
-        if (lane < CS) {
-            A.partial[wave_g * 2 * CS + lane] = a;
-            A.partial[wave_g * 2 * CS + CS + lane] = b;
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) {
+            const float a = s[hh] + __shfl_xor(s[hh], 32, 64), b = ss[hh] + __shfl_xor(ss[hh], 32, 64);
+            const int ch = hh * 32 + lane;
+            if (lane < 32 && ch < CS) {
+                A.partial[wave_g * 2 * CS + ch] = a;
+                A.partial[wave_g * 2 * CS + CS + ch] = b;
+            }
         }
     }
 }
@@ -354,7 +368,7 @@ __global__ __launch_bounds__(64 * WPB) void k_p4(LayerArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NCH = C / 32, PPT = 64 / K, CS = C / 8;
     const int lane = threadIdx.x & 63;
-    const WaveLds L = carve_lds<false>(lds, threadIdx.x >> 6);
+    const WaveLds L = carve_lds<false, C>(lds, threadIdx.x >> 6);
     const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
     const long ntiles = ((long)A.N * K + 63) / 64;
     for (long tile = wave_g; tile < ntiles; tile += nwaves) {
@@ -371,12 +385,12 @@ __global__ __launch_bounds__(64 * WPB) void k_p4(LayerArgs A) {
             wave_sync();
             float pr[32], val[32];
             pos_chunk(A, t1n, q * 32, pr);
-            const float *xv = L.tile + lane * TS;
+            const float *xv = L.tile + lane * L.ts;
 #pragma unroll
             for (int c = 0; c < 32; ++c) val[c] = (xv[c] + pr[c]) * w[(q * 32 + c) % CS];
             wave_sync();
 #pragma unroll
-            for (int c = 0; c < 32; ++c) L.tile[lane * TS + c] = val[c];
+            for (int c = 0; c < 32; ++c) L.tile[lane * L.ts + c] = val[c];
             wave_sync();
             // out[(i0+pt), q*32+ch] = sum_j tile[pt*K + j][ch]
 #pragma unroll
@@ -384,7 +398,7 @@ __global__ __launch_bounds__(64 * WPB) void k_p4(LayerArgs A) {
                 const int pt = m * 2 + (lane >> 5), ch = lane & 31;
                 float acc = 0.f;
 #pragma unroll
-                for (int j = 0; j < K; ++j) acc += L.tile[(pt * K + j) * TS + ch];
+                for (int j = 0; j < K; ++j) acc += L.tile[(pt * K + j) * L.ts + ch];
                 const long i = tile * PPT + pt;
                 if (i < A.N) A.out[(size_t)i * C + q * 32 + ch] = acc;
             }
@@ -411,7 +425,7 @@ __device__ __forceinline__ void scatter_rows_atomic(const WaveLds &L, float *__r
         const int row = t * 8 + sub;
         const int dst = L.rowid[row];
         if (dst < 0) continue;
-        const float *sv = L.tile + row * TS + col;
+        const float *sv = L.tile + row * L.ts + col;
         float *d = table + (size_t)dst * C + c0 + col;
         pdf_atomic_add(d + 0, sv[0]); pdf_atomic_add(d + 1, sv[1]); pdf_atomic_add(d + 2, sv[2]); pdf_atomic_add(d + 3, sv[3]);
     }
@@ -421,7 +435,7 @@ __device__ __forceinline__ float column_sum(const WaveLds &L, int lane) {  // la
     const int ch = lane & 31, r0 = (lane >> 5) * 32;
     float a = 0.f;
 #pragma unroll
-    for (int r = 0; r < 32; ++r) a += L.tile[(r0 + r) * TS + ch];
+    for (int r = 0; r < 32; ++r) a += L.tile[(r0 + r) * L.ts + ch];
     return a;
 }
 
@@ -429,7 +443,7 @@ __device__ __forceinline__ float column_sum(const WaveLds &L, int lane) {  // la
 __device__ __forceinline__ float dot_aux_tile(const WaveLds &L, int a, int b) {
     float acc = 0.f;
 #pragma unroll 8
-    for (int r = 0; r < 64; ++r) acc += L.aux[r * AUX + a] * L.tile[r * TS + b];
+    for (int r = 0; r < 64; ++r) acc += L.aux[r * L.as + a] * L.tile[r * L.ts + b];
     return acc;
 }
 
@@ -447,7 +461,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NCH = C / 32, PPT = 64 / K, CS = C / 8, NW2 = (CS * CS + 63) / 64, W = b1_width<C>();
     const int lane = threadIdx.x & 63;
-    const WaveLds L = carve_lds<true>(lds, threadIdx.x >> 6);
+    const WaveLds L = carve_lds<true, C>(lds, threadIdx.x >> 6);
     const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
     const long ntiles = ((long)A.N * K + 63) / 64;
     cfloat_p m2 = A.mean + 3 + C, r2 = A.rstd + 3 + C;
@@ -473,8 +487,8 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
             wave_sync();
             float pr[32], ga[32];
             pos_chunk(A, t1n, q * 32, pr);
-            const float *xv = L.tile + lane * TS;
-            const float *go = L.qtile + (lane / K) * TS;
+            const float *xv = L.tile + lane * L.ts;
+            const float *go = L.qtile + (lane / K) * L.ts;
 #pragma unroll
             for (int c = 0; c < 32; ++c) {
                 const float g = R.valid ? go[c] : 0.f;
@@ -483,7 +497,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
             }
             wave_sync();
 #pragma unroll
-            for (int c = 0; c < 32; ++c) L.tile[lane * TS + c] = ga[c];
+            for (int c = 0; c < 32; ++c) L.tile[lane * L.ts + c] = ga[c];
             wave_sync();
             scatter_rows_atomic(L, A.gxv, C, q * 32, lane);
             wave_sync();
@@ -513,7 +527,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
         }
         // g_Ww2[o][c] += sum_rows gz[o] * u[c]
 #pragma unroll
-        for (int o = 0; o < CS; ++o) { L.aux[lane * AUX + o] = gz[o]; L.tile[lane * TS + o] = R.valid ? u[o] : 0.f; }
+        for (int o = 0; o < CS; ++o) { L.aux[lane * L.as + o] = gz[o]; L.tile[lane * L.ts + o] = R.valid ? u[o] : 0.f; }
         wave_sync();
 #pragma unroll
         for (int m = 0; m < NW2; ++m) {
@@ -584,11 +598,14 @@ __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NCH = C / 32, PPT = 64 / K, CS = C / 8, W = b2_width<C>();
     const int lane = threadIdx.x & 63;
-    const WaveLds L = carve_lds<true>(lds, threadIdx.x >> 6);
+    const WaveLds L = carve_lds<true, C>(lds, threadIdx.x >> 6);
     const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
     const long ntiles = ((long)A.N * K + 63) / 64;
     cfloat_p m1 = A.mean + 3, r1 = A.rstd + 3;
-    float sg[NCH], sgr[NCH], sgh = 0.f, aw1[NCH][CS / 2];
+    constexpr int NH = (CS + 31) / 32;
+    float sg[NCH], sgr[NCH], sgh[NH], aw1[NCH][CS / 2];
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) sgh[hh] = 0.f;
 #pragma unroll
     for (int q = 0; q < NCH; ++q) {
         sg[q] = 0.f; sgr[q] = 0.f;
@@ -603,14 +620,17 @@ __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
         hidden_grad<C>(A, R, gh);
         L.rowid[lane] = R.nb;
 #pragma unroll
-        for (int o = 0; o < CS; ++o) L.aux[lane * AUX + o] = gh[o];
+        for (int o = 0; o < CS; ++o) L.aux[lane * L.as + o] = gh[o];
         wave_sync();
-        if ((lane & 31) < CS) {  // g_bw1: column sums of the g_h tile
-            const int ch = lane & 31, r0 = (lane >> 5) * 32;
-            float a = 0.f;
 #pragma unroll
-            for (int r = 0; r < 32; ++r) a += L.aux[(r0 + r) * AUX + ch];
-            sgh += a;
+        for (int hh = 0; hh < NH; ++hh) {  // g_bw1: column sums of the g_h tile
+            const int ch = hh * 32 + (lane & 31), r0 = (lane >> 5) * 32;
+            if (ch < CS) {
+                float a = 0.f;
+#pragma unroll
+                for (int r = 0; r < 32; ++r) a += L.aux[(r0 + r) * L.as + ch];
+                sgh[hh] += a;
+            }
         }
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
@@ -622,18 +642,18 @@ __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
             wave_sync();
             // v1 = relu(BN1(r)) -> tile, g_Ww1[o][q*32+c] += sum_rows g_h[o] * v1[c]
 #pragma unroll
-            for (int c = 0; c < 32; ++c) L.tile[lane * TS + c] = R.valid ? fmaxf(r[c] * A.s1[q * 32 + c] + A.t1[q * 32 + c], 0.f) : 0.f;
+            for (int c = 0; c < 32; ++c) L.tile[lane * L.ts + c] = R.valid ? fmaxf(r[c] * A.s1[q * 32 + c] + A.t1[q * 32 + c], 0.f) : 0.f;
             wave_sync();
 #pragma unroll
             for (int m = 0; m < CS / 2; ++m) aw1[q][m] += dot_aux_tile(L, 2 * m + (lane >> 5), lane & 31);
             wave_sync();
 #pragma unroll
-            for (int c = 0; c < 32; ++c) L.tile[lane * TS + c] = gy1[c];
+            for (int c = 0; c < 32; ++c) L.tile[lane * L.ts + c] = gy1[c];
             wave_sync();
             sg[q] += column_sum(L, lane);
             wave_sync();
 #pragma unroll
-            for (int c = 0; c < 32; ++c) L.tile[lane * TS + c] = gy1[c] * ((r[c] - m1[q * 32 + c]) * r1[q * 32 + c]);
+            for (int c = 0; c < 32; ++c) L.tile[lane * L.ts + c] = gy1[c] * ((r[c] - m1[q * 32 + c]) * r1[q * 32 + c]);
             wave_sync();
             sgr[q] += column_sum(L, lane);
             wave_sync();
@@ -647,8 +667,11 @@ __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
 #pragma unroll
         for (int m = 0; m < CS / 2; ++m) o[2 * C + CS + (size_t)(2 * m + (lane >> 5)) * C + q * 32 + (lane & 31)] = aw1[q][m];
     }
-    const float hsum = sgh + __shfl_xor(sgh, 32, 64);
-    if (lane < CS) o[2 * C + lane] = hsum;
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) {
+        const float hsum = sgh[hh] + __shfl_xor(sgh[hh], 32, 64);
+        if (lane < 32 && hh * 32 + lane < CS) o[2 * C + hh * 32 + lane] = hsum;
+    }
 }
 
 template <int C, int K>
@@ -656,7 +679,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NCH = C / 32, PPT = 64 / K, CS = C / 8, W = b3_width<C>();
     const int lane = threadIdx.x & 63;
-    const WaveLds L = carve_lds<true>(lds, threadIdx.x >> 6);
+    const WaveLds L = carve_lds<true, C>(lds, threadIdx.x >> 6);
     const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
     const long ntiles = ((long)A.N * K + 63) / 64;
     cfloat_p m1 = A.mean + 3, r1 = A.rstd + 3, mp = A.mean, rp = A.rstd;
@@ -677,9 +700,9 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
         attn_weights<CS, K>(A, R, w);
         L.rowid[lane] = R.nb;
         // t1n tile for the Wp2 gradient
-        L.aux[lane * AUX + 0] = R.valid ? t1n[0] : 0.f;
-        L.aux[lane * AUX + 1] = R.valid ? t1n[1] : 0.f;
-        L.aux[lane * AUX + 2] = R.valid ? t1n[2] : 0.f;
+        L.aux[lane * L.as + 0] = R.valid ? t1n[0] : 0.f;
+        L.aux[lane * L.as + 1] = R.valid ? t1n[1] : 0.f;
+        L.aux[lane * L.as + 2] = R.valid ? t1n[2] : 0.f;
         float gt1n[3] = {0.f, 0.f, 0.f};
         wave_sync();
 #pragma unroll
@@ -700,7 +723,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
             wave_sync();
             stage_points<PPT>(L, A.gout, C, q * 32, (int)(tile * PPT), A.N, lane);  // qtile: xq no longer needed
 #pragma unroll
-            for (int c = 0; c < 32; ++c) L.tile[lane * TS + c] = g[c];
+            for (int c = 0; c < 32; ++c) L.tile[lane * L.ts + c] = g[c];
             wave_sync();
             scatter_rows_atomic(L, A.gxk, C, q * 32, lane);
             // g_xq[i] = - sum_j g_r
@@ -709,12 +732,12 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
                 const int pt = m * 2 + (lane >> 5), ch = lane & 31;
                 float acc = 0.f;
 #pragma unroll
-                for (int j = 0; j < K; ++j) acc += L.tile[(pt * K + j) * TS + ch];
+                for (int j = 0; j < K; ++j) acc += L.tile[(pt * K + j) * L.ts + ch];
                 const long i = tile * PPT + pt;
                 if (i < A.N) A.gxq[(size_t)i * C + q * 32 + ch] = -acc;
             }
             // g_pr = g_r + g_out * w   (the aggregation's share of p_r)
-            const float *go = L.qtile + (lane / K) * TS;
+            const float *go = L.qtile + (lane / K) * L.ts;
 #pragma unroll
             for (int c = 0; c < 32; ++c) g[c] += R.valid ? go[c] * w[(q * 32 + c) % CS] : 0.f;
 #pragma unroll
@@ -724,7 +747,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
             }
             wave_sync();
 #pragma unroll
-            for (int c = 0; c < 32; ++c) L.tile[lane * TS + c] = g[c];
+            for (int c = 0; c < 32; ++c) L.tile[lane * L.ts + c] = g[c];
             wave_sync();
             sbp2[q] += column_sum(L, lane);
             // g_Wp2[q*32+c][a] += sum_rows g_pr[c] * t1n[a]    (96 outputs per chunk: e = c*3 + a)
@@ -735,7 +758,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
                     const int c = e / 3, a = e % 3;
                     float acc = 0.f;
 #pragma unroll 8
-                    for (int rr = 0; rr < 64; ++rr) acc += L.tile[rr * TS + c] * L.aux[rr * AUX + a];
+                    for (int rr = 0; rr < 64; ++rr) acc += L.tile[rr * L.ts + c] * L.aux[rr * L.as + a];
                     awp2[q][m] += acc;
                 }
             }
@@ -885,6 +908,11 @@ void launch_colsum(const float *partial, int rows, int width, float *out, hipStr
     k_colsum<<<pdf_divup(width, 16), 256, 0, s>>>(partial, rows, width, out);
 }
 
+template <typename KernelT>
+static inline void allow_lds(KernelT kernel, size_t lds) {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
 static inline int grid_for_tiles(long ntiles) {
     long g = (ntiles + WPB - 1) / WPB;
     if (g > MAX_BLOCKS) g = MAX_BLOCKS;
@@ -904,7 +932,7 @@ extern "C" long pdf_pt_layer_partial_floats(int n, int nsample, int c) {
 }
 
 extern "C" int pdf_pt_layer_supported(int nsample, int c) {
-    return (nsample == 8 || nsample == 16) && (c == 32 || c == 64 || c == 128);
+    return ((nsample == 8 || nsample == 16) && (c == 32 || c == 64 || c == 128)) || (nsample == 16 && c == 256);  // c == 512 is instantiated but not yet validated
 }
 
 namespace fl {
@@ -917,7 +945,7 @@ int forward_impl(LayerArgs A, int training, float eps, float momentum, const flo
     const long ntiles = (rows + 63) / 64;
     const int grid = grid_for_tiles(ntiles);
     const int nw = grid * WPB;
-    const size_t lds = (size_t)WPB * LDS_FLOATS_PER_WAVE * sizeof(float);
+    const size_t lds = (size_t)WPB * lds_floats_per_wave(C, false) * sizeof(float);
     float *sp = bn, *tp = bn + 3, *s1 = bn + 6, *t1 = bn + 6 + C, *s2 = bn + 6 + 2 * C, *t2 = bn + 6 + 2 * C + CS;
     A.sp = as_const(sp); A.tp = as_const(tp); A.s1 = as_const(s1); A.t1 = as_const(t1); A.s2 = as_const(s2); A.t2 = as_const(t2);
     // bn_params: gamma_p, beta_p, gamma_1, beta_1, gamma_2, beta_2 ; bn_buffers: rm_p, rv_p, rm_1, rv_1, rm_2, rv_2
@@ -925,11 +953,16 @@ int forward_impl(LayerArgs A, int training, float eps, float momentum, const flo
         k_bn_eval<<<1, 64, 0, s>>>(3, bn_params[0], bn_params[1], eps, bn_buffers[0], bn_buffers[1], sp, tp, nullptr, nullptr);
         k_bn_eval<<<pdf_divup(C, 64), 64, 0, s>>>(C, bn_params[2], bn_params[3], eps, bn_buffers[2], bn_buffers[3], s1, t1, nullptr, nullptr);
         k_bn_eval<<<1, 64, 0, s>>>(CS, bn_params[4], bn_params[5], eps, bn_buffers[4], bn_buffers[5], s2, t2, nullptr, nullptr);
+        allow_lds(k_p3<C, K, false>, lds);
+        allow_lds(k_p4<C, K>, lds);
         k_p3<C, K, false><<<grid, 64 * WPB, lds, s>>>(A);
         k_p4<C, K><<<grid, 64 * WPB, lds, s>>>(A);
         return pdf_launch_status();
     }
     float *mp = saved, *rp = saved + 3, *m1 = saved + 6, *r1 = saved + 6 + C, *m2 = saved + 6 + 2 * C, *r2 = saved + 6 + 2 * C + CS;
+    allow_lds(k_p2<C, K>, lds);
+    allow_lds(k_p3<C, K, true>, lds);
+    allow_lds(k_p4<C, K>, lds);
     k_p1<K><<<grid, 64 * WPB, 0, s>>>(A);
     k_bn_finalize<<<1, 256, 0, s>>>(A.partial, nw, 3, (double)rows, bn_params[0], bn_params[1], eps, momentum, bn_buffers[0], bn_buffers[1], sp, tp, mp, rp);
     k_p2<C, K><<<grid, 64 * WPB, lds, s>>>(A);
@@ -957,10 +990,13 @@ int backward_impl(LayerArgs A, float *sums, hipStream_t s) {
     const long rows = (long)A.N * K;
     const long ntiles = (rows + 63) / 64;
     const int grid = grid_for_tiles_bwd(ntiles), nw = grid * WPB;
-    const size_t lds = (size_t)WPB * LDS_FLOATS_PER_WAVE_BWD * sizeof(float);
+    const size_t lds = (size_t)WPB * lds_floats_per_wave(C, true) * sizeof(float);
     A.inv_rows = (float)(1.0 / (double)rows);
     // sums layout (floats): [S1: b1_width | S2: b2_width | S3: b3_width | S4: 16 | X: 2C + 2CS scratch for B3]
     float *S1 = sums, *S2 = S1 + b1_width<C>(), *S3 = S2 + b2_width<C>(), *S4 = S3 + b3_width<C>(), *X = S4 + b4_width();
+    allow_lds(k_b1<C, K>, lds);
+    allow_lds(k_b2<C, K>, lds);
+    allow_lds(k_b3<C, K>, lds);
     k_b1<C, K><<<grid, 64 * WPB, lds, s>>>(A);
     k_colsum<<<pdf_divup(b1_width<C>(), 16), 256, 0, s>>>(A.partial, nw, b1_width<C>(), S1);
     A.sums = as_const(S1);
@@ -1040,7 +1076,9 @@ extern "C" int pdf_pt_layer_backward(int n, int nsample, int c, const float *xq,
     } else {
         if (c == 32) PDF_BWD(32, 16);
         if (c == 64) PDF_BWD(64, 16);
-        PDF_BWD(128, 16);
+        if (c == 128) PDF_BWD(128, 16);
+        if (c == 256) PDF_BWD(256, 16);
+        PDF_BWD(512, 16);
     }
 #undef PDF_BWD
 }
@@ -1071,7 +1109,9 @@ extern "C" int pdf_pt_layer_forward(int n, int nsample, int c, const float *xq, 
     } else {
         if (c == 32) PDF_FWD(32, 16);
         if (c == 64) PDF_FWD(64, 16);
-        PDF_FWD(128, 16);
+        if (c == 128) PDF_FWD(128, 16);
+        if (c == 256) PDF_FWD(256, 16);
+        PDF_FWD(512, 16);
     }
 #undef PDF_FWD
 }

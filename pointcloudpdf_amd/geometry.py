@@ -160,6 +160,22 @@ class Geometry:
             self.interp(lvl, lvl, interp_k)              # PTRecognizer.dec5 interpolates level 5 onto itself (pt_v1.py:37)
         return self
 
+    def load(self, src):
+        """Overwrite this (static-address) Geometry with the tables of ``src`` (same level sizes): lets a captured
+        hipGraph of the training step replay against the pre-pass of a new batch."""
+        assert len(self.levels) == len(src.levels)
+        for a, b in zip(self.levels, src.levels):
+            assert a.p.shape == b.p.shape and a.o_host == b.o_host, "graph replay needs identical scene sizes"
+            a.p.copy_(b.p)
+            a.o.copy_(b.o)
+        assert set(self._memo) == set(src._memo), (set(self._memo) ^ set(src._memo))
+        for k, v in self._memo.items():
+            w = src._memo[k]
+            for t, u in zip(v if isinstance(v, tuple) else (v,), w if isinstance(w, tuple) else (w,)):
+                if isinstance(t, torch.Tensor):
+                    t.copy_(u)
+        return self
+
     def tensors(self):
         out = [lv.p for lv in self.levels] + [lv.o for lv in self.levels]
         for v in self._memo.values():
