@@ -30,6 +30,9 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+# HBM traffic per launch from rocprofv3 PMC passes (profiles/r01_b_pmc_{fetch,write}_size.txt; FETCH_SIZE doubled as the
+# guide prescribes for gfx950, KB -> bytes, averaged over the launches of the profiled run like `achieved`).
+PMC_TRAFFIC_BYTES = {"farthest_point_sampling": (2 * 1357.0 + 2284.3) * 1024}
 
 
 def parse():
@@ -92,6 +95,14 @@ class KernelTimer:
         if name == "group_backward":
             go, idx, n, c, with_xyz = args
             return 4 * go.numel() + 4 * idx.numel() + 4 * n * c
+        if name == "pt_layer_forward":  # q,k,v rows once + p + idx + out (SURVEY 8d "fused PT layer fwd")
+            xq, idx = args[0], args[4]
+            n, c = xq.shape
+            return 4 * n * c * 3 + 12 * n + 4 * idx.numel() + 4 * n * c
+        if name == "pt_layer_backward":  # the forward's inputs + g_out + the three input gradients
+            xq, idx = args[0], args[4]
+            n, c = xq.shape
+            return 4 * n * c * 3 + 12 * n + 4 * idx.numel() + 4 * n * c + 4 * n * c * 3
         return 0
 
     def summary(self):
@@ -111,7 +122,9 @@ def cpu_baseline(points):
     from pointcloudpdf_amd import _native, engine, synthetic
 
     be = oracle.backend()
-    cores = os.cpu_count() or 1
+    # threads actually used: capped -- on a 256-core host, 256-way OpenMP/ATen threading of these small per-op loops
+    # is slower than 16 threads by two orders of magnitude (measured: 410 s vs seconds for the same sample)
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     be.set_num_threads(cores)
     prev = _native._set_backend_for_testing(be)
@@ -151,7 +164,8 @@ def main():
 
     sizes = [args.points] * args.scenes
     pool = [synthetic.make_batch(sizes, first_scene_id=1000 * rank + 10 * i, device=dev) for i in range(args.pool)]
-    timer = KernelTimer(be, ["knn_query", "farthest_point_sampling", "group_forward", "group_backward"])
+    timer = KernelTimer(be, ["knn_query", "farthest_point_sampling", "group_forward", "group_backward",
+                             "pt_layer_forward", "pt_layer_backward"])
     timer.install()
 
     from pointcloudpdf_amd.geometry import GeometryPrefetcher
@@ -256,13 +270,18 @@ def main():
         pts_per_step = args.points * args.scenes * world
         ks = timer.summary()
         dom = max(ks, key=lambda n: ks[n]["total_ms"]) if ks else None
-        roof = None
-        if dom:
-            achieved = ks[dom]["avg_bytes"] / (ks[dom]["avg_ms"] * 1e-3) / 1e9
-            roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=None, avg_launch_ms=ks[dom]["avg_ms"],
-                        launches_per_step=ks[dom]["calls"] / args.steps,
-                        share_of_step=ks[dom]["total_ms"] / (dt * 1e3))
+        def roofline_of(name):
+            achieved = ks[name]["avg_bytes"] / (ks[name]["avg_ms"] * 1e-3) / 1e9
+            return dict(bound="hbm", kernel=name, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=achieved / HBM_PEAK_GBS, traffic=PMC_TRAFFIC_BYTES.get(name),
+                        algorithmic_bytes_per_launch=ks[name]["avg_bytes"], avg_launch_ms=ks[name]["avg_ms"],
+                        launches_per_step=ks[name]["calls"] / args.steps,
+                        gpu_time_share_of_step=ks[name]["total_ms"] / (dt * 1e3))
+
+        roof = roofline_of(dom) if dom else None
+        # the gather family is what the HBM roofline is meaningful for (FPS / kNN are latency / VALU bound by design)
+        second = [n for n in ("pt_layer_backward", "pt_layer_forward", "group_backward", "group_forward") if n in ks]
+        roof2 = roofline_of(max(second, key=lambda n: ks[n]["total_ms"])) if second else None
         line = {
             "metric": "points/sec fwd+bwd (PT-v1 Seg50 + PDF U-decoder, 100k-pt scenes)",
             "value": pts_per_step * args.steps / dt,
@@ -285,6 +304,7 @@ def main():
             "hipgraph": bool(use_graph and graph is not None),
             "kernels": ks,
             "roofline": roof,
+            "roofline_gather_family": roof2,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_points)
