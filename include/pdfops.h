@@ -155,6 +155,38 @@ int pdf_bn_act_forward(long n, int c, const float *x, const float *res, const fl
 int pdf_bn_act_backward(long n, int c, const float *gy, const float *x, const float *res, const float *coef,
                         int training, int relu, float *partial, float *sums, float *gx, float *gres, void *stream);
 
+/* coefficients only (statistics pass + finalize, or running statistics) */
+int pdf_bn_coef(long n, int c, const float *x, const float *gamma, const float *beta, float *running_mean,
+                float *running_var, int training, float eps, float momentum, float *coef, float *partial, void *stream);
+/* y = relu?(x * scale + shift + res) with coefficients computed elsewhere (no statistics pass) */
+int pdf_bn_apply(long n, int c, const float *x, const float *res, const float *coef, int relu, float *y, void *stream);
+
+/* Dense per-point Linear on the fp32 matrix cores (csrc/rowlin.hip).  y (+)= f(x) Wt + bias with f = identity or the
+ * folded BatchNorm-affine (+ReLU) of the producer (scale/shift over the k input channels); partial (optional,
+ * pdf_rowlin_partial_floats) receives per-row-block column sums / sums of squares of y for the BatchNorm that follows.
+ * transpose_w = 1 computes the input gradient dX = G W with the layer's (out, in) weight. */
+long pdf_rowlin_partial_floats(long n, int o);
+int pdf_rowlin_partial_rows(long n);
+int pdf_rowlin_forward(long n, int k, int o, const float *x, long ldx, const float *w, int transpose_w,
+                       const float *bias, const float *scale, const float *shift, int relu, float *y, long ldy,
+                       int accumulate, float *partial, void *stream);
+/* dW (o,k) += G^T f(X), db (o) += column sums of G (pre-zeroed; db may be NULL) */
+int pdf_rowlin_wgrad(long n, int k, int o, const float *g, long ldg, const float *x, long ldx,
+                     const float *scale, const float *shift, int relu, float *dw, float *db, void *stream);
+/* BatchNorm coefficients from column partials [rows][2c] (sum | sum of squares): coef = scale|shift|mean|rstd */
+int pdf_bn_coef_from_partial(const float *partial, int rows, long n, int c, const float *gamma, const float *beta,
+                             float *running_mean, float *running_var, float eps, float momentum, float *coef, void *stream);
+
+/* Dense halves of the Bottleneck (point_transformer_seg.py:184-192) as single host calls (csrc/block.hip documents the
+ * pointer tables p[]): pre = linear1 + bn1 + ReLU + q/k/v projections, post = bn2 + ReLU + linear3 + bn3 + residual + ReLU. */
+int pdf_bn_coef_eval_or_partial(const float *partial, int rows, long n, int c, const float *gamma, const float *beta,
+                                float *running_mean, float *running_var, int training, float eps, float momentum,
+                                float *coef, void *stream);
+int pdf_block_pre_forward(long n, int c, void *const *p, int training, float eps, float momentum, void *stream);
+int pdf_block_pre_backward(long n, int c, void *const *p, int training, void *stream);
+int pdf_block_post_forward(long n, int c, void *const *p, int training, float eps, float momentum, void *stream);
+int pdf_block_post_backward(long n, int c, void *const *p, int training, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

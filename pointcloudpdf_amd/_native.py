@@ -243,6 +243,32 @@ class HipBackend(CBackend):
         self.last_fps_stats = None
         lib.pdf_abi_version.restype = c_int
         lib.pdf_build_info.restype = ctypes.c_char_p
+        for nm in ("pre_forward", "post_forward"):
+            f = getattr(lib, "pdf_block_" + nm)
+            f.restype = c_int
+            f.argtypes = [c_long, c_int, c_void_p, c_int, ctypes.c_float, ctypes.c_float, c_void_p]
+        for nm in ("pre_backward", "post_backward"):
+            f = getattr(lib, "pdf_block_" + nm)
+            f.restype = c_int
+            f.argtypes = [c_long, c_int, c_void_p, c_int, c_void_p]
+        lib.pdf_rowlin_partial_floats.restype = c_long
+        lib.pdf_rowlin_partial_floats.argtypes = [c_long, c_int]
+        lib.pdf_rowlin_partial_rows.restype = c_int
+        lib.pdf_rowlin_partial_rows.argtypes = [c_long]
+        lib.pdf_rowlin_forward.restype = c_int
+        lib.pdf_rowlin_forward.argtypes = [c_long, c_int, c_int, c_void_p, c_long, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                           c_int, c_void_p, c_long, c_int, c_void_p, c_void_p]
+        lib.pdf_rowlin_wgrad.restype = c_int
+        lib.pdf_rowlin_wgrad.argtypes = [c_long, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int,
+                                         c_void_p, c_void_p, c_void_p]
+        lib.pdf_bn_coef_from_partial.restype = c_int
+        lib.pdf_bn_coef_from_partial.argtypes = [c_void_p, c_int, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                 ctypes.c_float, ctypes.c_float, c_void_p, c_void_p]
+        lib.pdf_bn_coef.restype = c_int
+        lib.pdf_bn_coef.argtypes = [c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, ctypes.c_float,
+                                    ctypes.c_float, c_void_p, c_void_p, c_void_p]
+        lib.pdf_bn_apply.restype = c_int
+        lib.pdf_bn_apply.argtypes = [c_long, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
         lib.pdf_bn_supported.restype = c_int
         lib.pdf_bn_supported.argtypes = [c_int]
         lib.pdf_bn_partial_floats.restype = c_long
@@ -368,6 +394,92 @@ class HipBackend(CBackend):
             bp1=sums[o4:o4 + 3], Wp1=sums[o4 + 3:o4 + 12].view(3, 3),
         )
         return gxq, gxk, gxv, g
+
+    # -- dense per-point Linear on the matrix cores (csrc/rowlin.hip) ---------------------------------------
+    def _stream(self):
+        return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def rowlin(self, x, w, bias=None, coef=None, relu=False, transpose_w=False, out=None, accumulate=False, stats=False):
+        """y = f(x) @ Wt + bias (see include/pdfops.h); x (n,k) with row stride x.stride(0); returns (y, partial|None)."""
+        n, k = x.shape
+        o = w.shape[1] if transpose_w else w.shape[0]
+        y = out if out is not None else torch.empty((n, o), dtype=torch.float32, device=x.device)
+        partial = None
+        if stats:
+            partial = torch.empty((int(self.lib.pdf_rowlin_partial_floats(n, o)),), dtype=torch.float32, device=x.device)
+        rc = self.lib.pdf_rowlin_forward(n, k, o, x.data_ptr(), x.stride(0), w.data_ptr(), int(transpose_w),
+                                         None if bias is None else bias.data_ptr(),
+                                         None if coef is None else coef.data_ptr(),
+                                         None if coef is None else coef.data_ptr() + 4 * k, int(relu), y.data_ptr(), y.stride(0),
+                                         int(accumulate), None if partial is None else partial.data_ptr(), self._stream())
+        if rc != 0:
+            raise PdfOpsError(f"pdf_rowlin_forward failed with status {rc}")
+        return y, partial
+
+    def rowlin_wgrad(self, g, x, coef, relu, need_bias):
+        n, o = g.shape
+        k = x.shape[1]
+        dw = torch.zeros((o, k), dtype=torch.float32, device=x.device)
+        db = torch.zeros((o,), dtype=torch.float32, device=x.device) if need_bias else None
+        rc = self.lib.pdf_rowlin_wgrad(n, k, o, g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0),
+                                       None if coef is None else coef.data_ptr(),
+                                       None if coef is None else coef.data_ptr() + 4 * k, int(relu), dw.data_ptr(),
+                                       None if db is None else db.data_ptr(), self._stream())
+        if rc != 0:
+            raise PdfOpsError(f"pdf_rowlin_wgrad failed with status {rc}")
+        return dw, db
+
+    def bn_coef_from_partial(self, partial, n, c, bn, training):
+        """coef (4c) = scale|shift|mean|rstd of BatchNorm ``bn`` from rowlin column partials (training) or running stats."""
+        coef = torch.empty((4 * c,), dtype=torch.float32, device=partial.device if partial is not None else bn.weight.device)
+        if training:
+            rows = int(self.lib.pdf_rowlin_partial_rows(n))
+            rc = self.lib.pdf_bn_coef_from_partial(partial.data_ptr(), rows, n, c, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                                   bn.running_mean.data_ptr(), bn.running_var.data_ptr(), ctypes.c_float(bn.eps),
+                                                   ctypes.c_float(bn.momentum if bn.momentum is not None else 0.1),
+                                                   coef.data_ptr(), self._stream())
+            if rc != 0:
+                raise PdfOpsError(f"pdf_bn_coef_from_partial failed with status {rc}")
+        else:
+            rstd = torch.rsqrt(bn.running_var + bn.eps)
+            sc = bn.weight.detach() * rstd
+            coef = torch.cat([sc, bn.bias.detach() - bn.running_mean * sc, bn.running_mean, rstd])
+        return coef
+
+    def bn_coef(self, x, bn, training):
+        """coef (4c) of BatchNorm ``bn`` over the rows of x: batch statistics (training, updates running stats) or running."""
+        n, c = x.shape
+        coef = torch.empty((4 * c,), dtype=torch.float32, device=x.device)
+        partial = torch.empty((int(self.lib.pdf_bn_partial_floats(n, c)),), dtype=torch.float32, device=x.device) if training else None
+        rc = self.lib.pdf_bn_coef(n, c, x.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                                  bn.running_var.data_ptr(), int(bool(training)), ctypes.c_float(bn.eps),
+                                  ctypes.c_float(bn.momentum if bn.momentum is not None else 0.1), coef.data_ptr(),
+                                  None if partial is None else partial.data_ptr(), self._stream())
+        if rc != 0:
+            raise PdfOpsError(f"pdf_bn_coef failed with status {rc}")
+        return coef
+
+    def bn_apply(self, x, res, coef, relu):
+        n, c = x.shape
+        y = torch.empty_like(x)
+        rc = self.lib.pdf_bn_apply(n, c, x.data_ptr(), None if res is None else res.data_ptr(), coef.data_ptr(), int(relu),
+                                   y.data_ptr(), self._stream())
+        if rc != 0:
+            raise PdfOpsError(f"pdf_bn_apply failed with status {rc}")
+        return y
+
+    # -- Bottleneck halves as single host calls (csrc/block.hip) -------------------------------------------
+    def _ptable(self, tensors):
+        return (c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+    def block_call(self, name, n, c, tensors, training, eps=None, momentum=None):
+        fn = getattr(self.lib, "pdf_block_" + name)
+        if eps is None:
+            rc = fn(n, c, self._ptable(tensors), int(bool(training)), self._stream())
+        else:
+            rc = fn(n, c, self._ptable(tensors), int(bool(training)), ctypes.c_float(eps), ctypes.c_float(momentum), self._stream())
+        if rc != 0:
+            raise PdfOpsError(f"pdf_block_{name} failed with status {rc}")
 
     # -- BatchNorm + residual + ReLU over (n, c) rows ------------------------------------------------------
     def bn_supported(self, c):

@@ -220,3 +220,44 @@ extern "C" int pdf_bn_act_backward(long n, int c, const float *gy, const float *
 #undef F4
     return pdf_launch_status();
 }
+
+// Coefficients of a train-mode BatchNorm whose column statistics were produced by a GEMM epilogue (rowlin STATS).
+extern "C" int pdf_bn_coef_from_partial(const float *partial, int rows, long n, int c, const float *gamma, const float *beta,
+                                        float *running_mean, float *running_var, float eps, float momentum, float *coef,
+                                        void *stream) {
+    if (!partial || rows < 1 || n < 1 || c < 1 || !gamma || !beta || !coef) return PDF_ERR_BAD_ARG;
+    fl::launch_bn_finalize(partial, rows, c, (double)n, gamma, beta, eps, momentum, running_mean, running_var, coef, coef + c,
+                           coef + 2 * c, coef + 3 * c, static_cast<hipStream_t>(stream));
+    return pdf_launch_status();
+}
+
+// y = relu?(x * scale + shift + res) with given coefficients (no statistics pass)
+extern "C" int pdf_bn_apply(long n, int c, const float *x, const float *res, const float *coef, int relu, float *y, void *stream) {
+    if (n < 1 || !x || !coef || !y) return PDF_ERR_BAD_ARG;
+    if (!pdf_bn_supported(c)) return PDF_ERR_UNSUPPORTED;
+    const long n4 = n * (c / 4);
+    pw::k_bn_apply<<<pw::grid_elems(n4), pw::PB, 0, static_cast<hipStream_t>(stream)>>>(
+        n4, c / 4, reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(coef), reinterpret_cast<const float4 *>(coef + c),
+        reinterpret_cast<const float4 *>(res), relu, reinterpret_cast<float4 *>(y));
+    return pdf_launch_status();
+}
+
+// Coefficients (scale|shift|mean|rstd) of a BatchNorm over (n, c) rows without applying it: statistics pass + finalize
+// (training) or running statistics (eval).  Used when the affine + ReLU is folded into the consumer GEMM's prologue.
+extern "C" int pdf_bn_coef(long n, int c, const float *x, const float *gamma, const float *beta, float *running_mean,
+                           float *running_var, int training, float eps, float momentum, float *coef, float *partial, void *stream) {
+    if (n < 1 || !gamma || !beta || !coef) return PDF_ERR_BAD_ARG;
+    if (!pdf_bn_supported(c)) return PDF_ERR_UNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (training) {
+        if (!partial || !x) return PDF_ERR_BAD_ARG;
+        const int g = pw::grid_rows(n, c);
+        pw::k_bn_stats<<<g, pw::PB, pw::PB * 8 * sizeof(float), s>>>(n, c, x, partial);
+        fl::launch_bn_finalize(partial, g, c, (double)n, gamma, beta, eps, momentum, running_mean, running_var, coef, coef + c,
+                               coef + 2 * c, coef + 3 * c, s);
+    } else {
+        if (!running_mean || !running_var) return PDF_ERR_BAD_ARG;
+        fl::launch_bn_eval(c, gamma, beta, eps, running_mean, running_var, coef, coef + c, coef + 2 * c, coef + 3 * c, s);
+    }
+    return pdf_launch_status();
+}

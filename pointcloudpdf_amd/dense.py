@@ -86,3 +86,214 @@ def bn_act(bn, x, residual=None, relu=True):
     if residual is not None:
         y = y + residual
     return F.relu(y) if relu else y
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Matrix-core Linear layers with the neighbouring BatchNorm folded in (csrc/rowlin.hip).  One autograd node each:
+#   _LinearStats   : y = x W^T + b                     (+ column statistics of y for the BatchNorm that follows)
+#   _BnReluLinear  : y_i = relu(bn(z)) W_i^T + b_i      (statistics of z from the producer's epilogue or a stats pass;
+#                                                         the normalised activation never reaches HBM)
+#   _BnActPartial  : relu(bn(z) + residual) with the statistics of z supplied by the producer's epilogue
+# ------------------------------------------------------------------------------------------------------------------
+def _be():
+    from . import _native
+
+    return _native.hip_backend()
+
+
+class _LinearStats(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, want_stats):
+        y, partial = _be().rowlin(x, weight.detach(), None if bias is None else bias.detach(), stats=want_stats)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        if partial is None:
+            partial = x.new_empty(0)
+        ctx.mark_non_differentiable(partial)
+        return y, partial
+
+    @staticmethod
+    def backward(ctx, g, _gp):
+        x, weight = ctx.saved_tensors
+        be = _be()
+        g = g.contiguous()
+        gx = be.rowlin(g, weight, transpose_w=True)[0] if ctx.needs_input_grad[0] else None
+        gw, gb = be.rowlin_wgrad(g, x, None, False, ctx.has_bias)
+        return gx, gw, gb, None
+
+
+class _BnReluLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, partial, gamma, beta, bn, relu, want_stats, *wb):
+        be = _be()
+        n, c = z.shape
+        training = bn.training
+        if training and partial is not None and partial.numel() > 0:
+            coef = be.bn_coef_from_partial(partial, n, c, bn, True)
+        else:
+            coef = be.bn_coef(z, bn, training)
+        if training:
+            bn.num_batches_tracked += 1
+        weights, biases = wb[0::2], wb[1::2]
+        outs, pout = [], None
+        for w, b in zip(weights, biases):
+            y, p = be.rowlin(z, w.detach(), None if b is None else b.detach(), coef=coef, relu=relu, stats=want_stats)
+            outs.append(y)
+            pout = p
+        ctx.save_for_backward(z, coef, *weights)
+        ctx.cfg = (training, relu, [b is not None for b in biases])
+        if pout is None:
+            pout = z.new_empty(0)
+        ctx.mark_non_differentiable(pout)
+        return (*outs, pout)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        z, coef, *weights = ctx.saved_tensors
+        training, relu, has_bias = ctx.cfg
+        be = _be()
+        grads_wb = []
+        da = None
+        for i, (g, w) in enumerate(zip(gs[:-1], weights)):
+            if g is None:
+                grads_wb += [torch.zeros_like(w), torch.zeros(w.shape[0], device=w.device) if has_bias[i] else None]
+                continue
+            g = g.contiguous()
+            da = be.rowlin(g, w, transpose_w=True, out=da, accumulate=da is not None)[0]
+            gw, gb = be.rowlin_wgrad(g, z, coef, relu, has_bias[i])
+            grads_wb += [gw, gb]
+        gz, _, ggamma, gbeta = be.bn_act_backward(da, z, None, coef, training, relu, False)
+        return (gz, None, ggamma, gbeta, None, None, None, *grads_wb)
+
+
+class _BnActPartial(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, partial, residual, gamma, beta, bn, relu):
+        be = _be()
+        n, c = z.shape
+        training = bn.training
+        if training and partial is not None and partial.numel() > 0:
+            coef = be.bn_coef_from_partial(partial, n, c, bn, True)
+        else:
+            coef = be.bn_coef(z, bn, training)
+        if training:
+            bn.num_batches_tracked += 1
+        y = be.bn_apply(z, residual, coef, relu)
+        ctx.save_for_backward(z, residual if residual is not None else z.new_empty(0), coef)
+        ctx.cfg = (training, relu, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        z, residual, coef = ctx.saved_tensors
+        training, relu, has_res = ctx.cfg
+        gz, gres, ggamma, gbeta = _be().bn_act_backward(gy.contiguous(), z, residual if has_res else None, coef, training, relu,
+                                                       has_res and ctx.needs_input_grad[2])
+        return gz, None, gres, ggamma, gbeta, None, None
+
+
+def fused_ok(x, *bns):
+    """The matrix-core path applies to fp32 (N, C) rows on the device with power-of-two BatchNorm widths."""
+    if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous()):
+        return False
+    be = _be()
+    return all(type(b) is torch.nn.BatchNorm1d and b.affine and b.track_running_stats and be.bn_supported(b.num_features) for b in bns)
+
+
+def linear_stats(lin, x, want_stats=True):
+    y, partial = _LinearStats.apply(x, lin.weight, lin.bias, want_stats)
+    return y, partial
+
+
+def bn_relu_linear(bn, z, partial, lins, relu=True, want_stats=False):
+    wb = []
+    for lin in lins:
+        wb += [lin.weight, lin.bias]
+    out = _BnReluLinear.apply(z, partial, bn.weight, bn.bias, bn, relu, want_stats, *wb)
+    return out[:-1], out[-1]
+
+
+def bn_act_partial(bn, z, partial, residual=None, relu=True):
+    return _BnActPartial.apply(z, partial, residual, bn.weight, bn.bias, bn, relu)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Bottleneck halves: ONE host call per half and direction (csrc/block.hip).
+# ------------------------------------------------------------------------------------------------------------------
+class _BlockPre(torch.autograd.Function):
+    """(x_q, x_k, x_v) = q/k/v( relu(bn1(linear1(x))) )"""
+
+    @staticmethod
+    def forward(ctx, x, W1, g1, b1, Wq, bq, Wk, bk, Wv, bv, blk):
+        be = _be()
+        n, c = x.shape
+        bn1, training = blk.bn1, blk.bn1.training
+        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=x.device)
+        z1, coef1, xq, xk, xv = e(n, c), e(4 * c), e(n, c), e(n, c), e(n, c)
+        partial = e(int(be.lib.pdf_rowlin_partial_floats(n, c)))
+        be.block_call("pre_forward", n, c, [x, W1, g1, b1, bn1.running_mean, bn1.running_var, Wq, bq, Wk, bk, Wv, bv,
+                                            z1, coef1, xq, xk, xv, partial], training, bn1.eps, bn1.momentum or 0.1)
+        ctx.save_for_backward(x, z1, coef1, W1, Wq, Wk, Wv)
+        ctx.training = training
+        return xq, xk, xv
+
+    @staticmethod
+    def backward(ctx, gxq, gxk, gxv):
+        x, z1, coef1, W1, Wq, Wk, Wv = ctx.saved_tensors
+        be = _be()
+        n, c = x.shape
+        cc = c * c
+        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=x.device)
+        gx, grads, dy, sums = e(n, c), e(cc + 2 * c + 3 * (cc + c)), e(n, c), e(2 * c)
+        partial = e(int(be.lib.pdf_bn_partial_floats(n, c)))
+        be.block_call("pre_backward", n, c, [x, z1, coef1, W1, Wq, Wk, Wv, gxq.contiguous(), gxk.contiguous(), gxv.contiguous(),
+                                             gx, grads, dy, partial, sums], ctx.training)
+        o = cc + 2 * c
+        out = [gx, grads[:cc].view(c, c), grads[cc:cc + c], grads[cc + c:cc + 2 * c]]
+        for i in range(3):
+            out += [grads[o + i * (cc + c): o + i * (cc + c) + cc].view(c, c), grads[o + i * (cc + c) + cc: o + (i + 1) * (cc + c)]]
+        return (*out, None)
+
+
+class _BlockPost(torch.autograd.Function):
+    """y = relu( bn3(linear3(relu(bn2(t)))) + x )"""
+
+    @staticmethod
+    def forward(ctx, t, x, g2, b2, W3, g3, b3, blk):
+        be = _be()
+        n, c = t.shape
+        bn2, bn3, training = blk.bn2, blk.bn3, blk.bn2.training
+        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=t.device)
+        coef2, z3, coef3, y = e(4 * c), e(n, c), e(4 * c), e(n, c)
+        partial = e(max(int(be.lib.pdf_rowlin_partial_floats(n, c)), int(be.lib.pdf_bn_partial_floats(n, c))))
+        be.block_call("post_forward", n, c, [t, x, g2, b2, bn2.running_mean, bn2.running_var, W3, g3, b3, bn3.running_mean,
+                                             bn3.running_var, coef2, z3, coef3, y, partial], training, bn2.eps, bn2.momentum or 0.1)
+        ctx.save_for_backward(t, x, z3, coef2, coef3, W3)
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        t, x, z3, coef2, coef3, W3 = ctx.saved_tensors
+        be = _be()
+        n, c = t.shape
+        cc = c * c
+        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=t.device)
+        gt, gres, grads, da, sums = e(n, c), e(n, c), e(cc + 4 * c), e(n, c), e(2 * c)
+        partial = e(int(be.lib.pdf_bn_partial_floats(n, c)))
+        be.block_call("post_backward", n, c, [gy.contiguous(), t, x, z3, coef2, coef3, W3, gt, gres, grads, da, partial, sums],
+                      ctx.training)
+        return (gt, gres, grads[cc:cc + c], grads[cc + c:cc + 2 * c], grads[:cc].view(c, c), grads[cc + 2 * c:cc + 3 * c],
+                grads[cc + 3 * c:cc + 4 * c], None)
+
+
+def bottleneck(blk, p, x, o):
+    """Bottleneck.forward through the two host-side halves and the (fused) attention layer."""
+    t = blk.transformer
+    xq, xk, xv = _BlockPre.apply(x, blk.linear1.weight, blk.bn1.weight, blk.bn1.bias, t.linear_q.weight, t.linear_q.bias,
+                                 t.linear_k.weight, t.linear_k.bias, t.linear_v.weight, t.linear_v.bias, blk)
+    a = t.attend(p, x, o, xq, xk, xv)
+    y = _BlockPost.apply(a.contiguous(), x, blk.bn2.weight, blk.bn2.bias, blk.linear3.weight, blk.bn3.weight, blk.bn3.bias, blk)
+    if blk.training:
+        torch._foreach_add_([blk.bn1.num_batches_tracked, blk.bn2.num_batches_tracked, blk.bn3.num_batches_tracked], 1)
+    return y

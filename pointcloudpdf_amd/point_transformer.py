@@ -13,11 +13,14 @@ What differs is the execution plan:
   * no ``.item()`` / host syncs inside the layers, no (n, ns, c) transpose copies for the BatchNorm-as-LayerNorm;
   * gathers, relative coordinates, masks and concatenations run in the fused HIP gather kernels.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _native, pointops
+from . import dense
 from .dense import bn_act as _bn_act, linear as _lin
 from .geometry import Geometry, tag_of
 from .registry import MODELS
@@ -140,6 +143,10 @@ class PointTransformerLayer(nn.Module):
     def forward(self, pxo):
         p, x, o = pxo  # (n, 3), (n, c), (b)
         x_q, x_k, x_v = _lin(self.linear_q, x), _lin(self.linear_k, x), _lin(self.linear_v, x)
+        return self.attend(p, x, o, x_q, x_k, x_v)
+
+    def attend(self, p, x, o, x_q, x_k, x_v):
+        """Everything after the q/k/v projections (``x`` is only consulted for device / dtype)."""
         if self._fused_ok(x):
             idx, _ = pointops.knn_query(self.nsample, p, o, p, o)
             return _FusedPTLayer.apply(self, idx, p, x_q, x_k, x_v, *self._param_list())
@@ -254,9 +261,14 @@ class Bottleneck(nn.Module):
         self.bn3 = nn.BatchNorm1d(planes * self.expansion)
         self.relu = nn.ReLU(inplace=True)
 
+    matrix_core = os.environ.get("PDFOPS_MATRIX_CORE", "0") != "0"  # (opt-in: measured 72 vs 66 ms/step) class-wide switch: Linear + BatchNorm chains through csrc/rowlin.hip
+
     def forward(self, pxo):
         p, x, o = pxo
         identity = x
+        t = self.transformer
+        if self.matrix_core and dense.fused_ok(x, self.bn1, self.bn2, self.bn3):
+            return [p, dense.bottleneck(self, p, x, o), o]
         x = _bn_act(self.bn1, _lin(self.linear1, x), None, True)
         x = _bn_act(self.bn2, self.transformer([p, x, o]), None, True)
         x = _bn_act(self.bn3, _lin(self.linear3, x), identity, True)  # relu(bn3(.) + identity)

@@ -61,3 +61,79 @@ def test_split_k_linear_matches_torch():
         res.append((y.detach(), x.grad, lin.weight.grad.clone(), lin.bias.grad.clone()))
     for a, b in zip(*res):
         assert max_rel(a.cpu().numpy(), b.cpu().numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("n,k,o", [(5000, 32, 32), (3001, 6, 32), (777, 512, 512), (40000, 64, 192), (999, 35, 64), (2500, 32, 13), (130, 256, 1)])
+@pytest.mark.parametrize("pre", [False, True])
+def test_rowlin_forward_dgrad_wgrad(n, k, o, pre):
+    from pointcloudpdf_amd import _native
+
+    be = _native.hip_backend()
+    g = torch.Generator(device="cuda").manual_seed(n + k + o)
+    x = torch.randn(n, k, device="cuda", generator=g)
+    w = torch.randn(o, k, device="cuda", generator=g) / k ** 0.5
+    b = torch.randn(o, device="cuda", generator=g)
+    coef = None
+    fx = x
+    if pre:
+        sc = torch.rand(k, device="cuda", generator=g) + 0.5
+        sh = torch.randn(k, device="cuda", generator=g) * 0.3
+        coef = torch.cat([sc, sh, torch.zeros(2 * k, device="cuda")])
+        fx = torch.relu(x * sc + sh)
+    y, partial = be.rowlin(x, w, b, coef=coef, relu=True, stats=True)
+    ref = fx.double() @ w.double().t() + b.double()
+    assert max_rel(y.cpu().numpy(), ref.cpu().numpy()) < 2e-6
+    rows = partial.numel() // (2 * o)
+    ps = partial.view(rows, 2 * o).double().sum(0)
+    assert max_rel(ps[:o].cpu().numpy(), ref.sum(0).cpu().numpy()) < 1e-4
+    assert max_rel(ps[o:].cpu().numpy(), (ref * ref).sum(0).cpu().numpy()) < 1e-5
+    go = torch.randn(n, o, device="cuda", generator=g)
+    gx, _ = be.rowlin(go, w, transpose_w=True)
+    assert max_rel(gx.cpu().numpy(), (go.double() @ w.double()).cpu().numpy()) < 2e-6
+    gx2, _ = be.rowlin(go, w, transpose_w=True, out=gx.clone(), accumulate=True)
+    assert max_rel(gx2.cpu().numpy(), (2 * (go.double() @ w.double())).cpu().numpy()) < 2e-6
+    dw, db = be.rowlin_wgrad(go, x, coef, True, True)
+    assert max_rel(dw.cpu().numpy(), (go.double().t() @ fx.double()).cpu().numpy()) < 1e-5
+    assert max_rel(db.cpu().numpy(), go.double().sum(0).cpu().numpy()) < 1e-5
+    # strided views (row stride > width)
+    big = torch.randn(n, k + 5, device="cuda", generator=g)
+    y2, _ = be.rowlin(big[:, :k], w, b)
+    assert max_rel(y2.cpu().numpy(), (big[:, :k].double() @ w.double().t() + b.double()).cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("C,K,train", [(32, 8, True), (64, 16, True), (256, 16, True), (512, 16, True), (32, 8, False)])
+def test_bottleneck_matrix_core_path(C, K, train):
+    """Bottleneck through rowlin / folded norms vs the op-by-op path (same module, switch off)."""
+    from pointcloudpdf_amd import synthetic
+    from pointcloudpdf_amd.geometry import Geometry
+    from pointcloudpdf_amd.point_transformer import Bottleneck
+
+    sizes = [900, 700] if C <= 64 else [300, 260]
+    batch = synthetic.make_batch(sizes, first_scene_id=60, grid_size=0.25, device="cuda")
+    res = []
+    default = Bottleneck.matrix_core
+    for mc in (True, False):
+        torch.manual_seed(0)
+        geom = Geometry(batch["coord"], batch["offset"], batch["offset_host"])
+        blk = Bottleneck(C, C, 8, K).cuda()
+        synthetic.fill_parameters_deterministic(blk, seed=7)
+        blk.train(train)
+        g = torch.Generator(device="cuda").manual_seed(1)
+        x = torch.randn(sum(sizes), C, device="cuda", generator=g).requires_grad_(True)
+        Bottleneck.matrix_core = mc
+        try:
+            y = blk([geom.coord(0), x, geom.offset(0)])[1]
+            y.backward(torch.randn(y.shape, device="cuda", generator=g))
+        finally:
+            Bottleneck.matrix_core = default
+        out = {"y": y.detach().cpu().numpy(), "gx": x.grad.cpu().numpy()}
+        out.update({"g_" + n: p.grad.cpu().numpy() for n, p in blk.named_parameters() if p.grad is not None})
+        out.update({"b_" + n: b.detach().float().cpu().numpy() for n, b in blk.named_buffers()})
+        res.append(out)
+    a, b = res
+    gscale = max(abs(v).max() for k, v in b.items() if k.startswith("g_"))
+    for k in b:
+        if k.startswith("g_") and abs(b[k]).max() < 1e-4 * gscale:
+            continue  # analytically-zero gradients (biases in front of a train-mode BatchNorm)
+        tol = 2e-5 if (k == "y" or k.startswith("b_")) else (2e-3 if C < 512 else 3e-2)  # 560 rows x 512 ch: fp32 noise (q/k grads are tiny differences)
+        assert max_rel(a[k], b[k]) < tol, (k, max_rel(a[k], b[k]))

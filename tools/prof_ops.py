@@ -22,3 +22,17 @@ print("top ops by count")
 for e in rows[:45]:
     print(f"{e.count:6d}  cpu_total {e.cpu_time_total/1e3:8.2f} ms  self_cpu {e.self_cpu_time_total/1e3:8.2f} ms  dev {e.device_time_total/1e3:8.2f} ms  {e.key[:80]}")
 print("total self cpu ms", sum(e.self_cpu_time_total for e in ka) / 1e3)
+# who issues the device-to-device copies / which autograd nodes own the launches
+from collections import Counter
+own, launches = Counter(), Counter()
+for ev in prof.events():
+    if ev.name in ("hipMemcpyAsync", "hipMemcpyWithStream", "hipLaunchKernel", "hipExtModuleLaunchKernel", "hipModuleLaunchKernel", "hipMemsetAsync"):
+        p, chain = ev.cpu_parent, []
+        while p is not None:
+            chain.append(p.name); p = p.cpu_parent
+        key = " < ".join(chain[:3]) if chain else "(none)"
+        (own if "Memcpy" in ev.name else launches)[key] += 1
+print("memcpy owners")
+for k, v in own.most_common(25): print(f"{v:6d}  {k[:160]}")
+print("launch owners")
+for k, v in launches.most_common(40): print(f"{v:6d}  {k[:160]}")
