@@ -166,7 +166,7 @@ int pdf_bn_apply(long n, int c, const float *x, const float *res, const float *c
  * pdf_rowlin_partial_floats) receives per-row-block column sums / sums of squares of y for the BatchNorm that follows.
  * transpose_w = 1 computes the input gradient dX = G W with the layer's (out, in) weight. */
 long pdf_rowlin_partial_floats(long n, int o);
-int pdf_rowlin_partial_rows(long n);
+int pdf_rowlin_partial_rows(long n, int k, int o);
 int pdf_rowlin_forward(long n, int k, int o, const float *x, long ldx, const float *w, int transpose_w,
                        const float *bias, const float *scale, const float *shift, int relu, float *y, long ldy,
                        int accumulate, float *partial, void *stream);
@@ -176,6 +176,15 @@ int pdf_rowlin_wgrad(long n, int k, int o, const float *g, long ldg, const float
 /* BatchNorm coefficients from column partials [rows][2c] (sum | sum of squares): coef = scale|shift|mean|rstd */
 int pdf_bn_coef_from_partial(const float *partial, int rows, long n, int c, const float *gamma, const float *beta,
                              float *running_mean, float *running_var, float eps, float momentum, float *coef, void *stream);
+
+/* Several Linear layers over the same rows in one launch: nin = 1, nout <= 3 (y[i] = f(x[0]) Wt[i] + bias[i]: the q/k/v
+ * projections, point_transformer_seg.py:47-49) or nin <= 3, nout = 1 (y[0] (+)= sum_i x[i] Wt[i]: their input gradient);
+ * pdf_rowlin_wgrad_multi: weight / bias gradients of up to three layers sharing the input x. */
+int pdf_rowlin_multi(long n, int k, int o, int nin, int nout, const float *const *x, long ldx, const float *const *w,
+                     int transpose_w, const float *const *bias, const float *scale, const float *shift, int relu,
+                     float *const *y, long ldy, int accumulate, void *stream);
+int pdf_rowlin_wgrad_multi(long n, int k, int o, int ng, const float *const *g, long ldg, const float *x, long ldx,
+                           const float *scale, const float *shift, int relu, float *const *dw, float *const *db, void *stream);
 
 /* Dense halves of the Bottleneck (point_transformer_seg.py:184-192) as single host calls (csrc/block.hip documents the
  * pointer tables p[]): pre = linear1 + bn1 + ReLU + q/k/v projections, post = bn2 + ReLU + linear3 + bn3 + residual + ReLU. */

@@ -251,10 +251,16 @@ class HipBackend(CBackend):
             f = getattr(lib, "pdf_block_" + nm)
             f.restype = c_int
             f.argtypes = [c_long, c_int, c_void_p, c_int, c_void_p]
+        lib.pdf_rowlin_multi.restype = c_int
+        lib.pdf_rowlin_multi.argtypes = [c_long, c_int, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                         c_int, c_void_p, c_long, c_int, c_void_p]
+        lib.pdf_rowlin_wgrad_multi.restype = c_int
+        lib.pdf_rowlin_wgrad_multi.argtypes = [c_long, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int,
+                                               c_void_p, c_void_p, c_void_p]
         lib.pdf_rowlin_partial_floats.restype = c_long
         lib.pdf_rowlin_partial_floats.argtypes = [c_long, c_int]
         lib.pdf_rowlin_partial_rows.restype = c_int
-        lib.pdf_rowlin_partial_rows.argtypes = [c_long]
+        lib.pdf_rowlin_partial_rows.argtypes = [c_long, c_int, c_int]
         lib.pdf_rowlin_forward.restype = c_int
         lib.pdf_rowlin_forward.argtypes = [c_long, c_int, c_int, c_void_p, c_long, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                            c_int, c_void_p, c_long, c_int, c_void_p, c_void_p]
@@ -407,6 +413,7 @@ class HipBackend(CBackend):
         partial = None
         if stats:
             partial = torch.empty((int(self.lib.pdf_rowlin_partial_floats(n, o)),), dtype=torch.float32, device=x.device)
+            partial._pdf_rows = int(self.lib.pdf_rowlin_partial_rows(n, k, o))
         rc = self.lib.pdf_rowlin_forward(n, k, o, x.data_ptr(), x.stride(0), w.data_ptr(), int(transpose_w),
                                          None if bias is None else bias.data_ptr(),
                                          None if coef is None else coef.data_ptr(),
@@ -415,6 +422,35 @@ class HipBackend(CBackend):
         if rc != 0:
             raise PdfOpsError(f"pdf_rowlin_forward failed with status {rc}")
         return y, partial
+
+    @staticmethod
+    def _ptrs(tensors, n=3):
+        return (c_void_p * n)(*[t.data_ptr() if t is not None else None for t in list(tensors) + [None] * (n - len(tensors))])
+
+    def rowlin_multi(self, xs, ws, biases=None, coef=None, relu=False, transpose_w=False, nout=1):
+        """nout = 3: [f(xs[0]) @ Wt_i + b_i]; nout = 1: [sum_i xs[i] @ Wt_i (+ b_0)]   (pdf_rowlin_multi)"""
+        n, k = xs[0].shape
+        o = ws[0].shape[1] if transpose_w else ws[0].shape[0]
+        ys = [torch.empty((n, o), dtype=torch.float32, device=xs[0].device) for _ in range(nout)]
+        rc = self.lib.pdf_rowlin_multi(n, k, o, len(xs), nout, self._ptrs(xs), xs[0].stride(0), self._ptrs(ws), int(transpose_w),
+                                       None if biases is None else self._ptrs(biases),
+                                       None if coef is None else coef.data_ptr(), None if coef is None else coef.data_ptr() + 4 * k,
+                                       int(relu), self._ptrs(ys), o, 0, self._stream())
+        if rc != 0:
+            raise PdfOpsError(f"pdf_rowlin_multi failed with status {rc}")
+        return ys
+
+    def rowlin_wgrad_multi(self, gs, x, coef, relu):
+        n, o = gs[0].shape
+        k = x.shape[1]
+        dws = [torch.zeros((o, k), dtype=torch.float32, device=x.device) for _ in gs]
+        dbs = [torch.zeros((o,), dtype=torch.float32, device=x.device) for _ in gs]
+        rc = self.lib.pdf_rowlin_wgrad_multi(n, k, o, len(gs), self._ptrs(gs), gs[0].stride(0), x.data_ptr(), x.stride(0),
+                                             None if coef is None else coef.data_ptr(), None if coef is None else coef.data_ptr() + 4 * k,
+                                             int(relu), self._ptrs(dws), self._ptrs(dbs), self._stream())
+        if rc != 0:
+            raise PdfOpsError(f"pdf_rowlin_wgrad_multi failed with status {rc}")
+        return dws, dbs
 
     def rowlin_wgrad(self, g, x, coef, relu, need_bias):
         n, o = g.shape
@@ -433,7 +469,7 @@ class HipBackend(CBackend):
         """coef (4c) = scale|shift|mean|rstd of BatchNorm ``bn`` from rowlin column partials (training) or running stats."""
         coef = torch.empty((4 * c,), dtype=torch.float32, device=partial.device if partial is not None else bn.weight.device)
         if training:
-            rows = int(self.lib.pdf_rowlin_partial_rows(n))
+            rows = partial._pdf_rows
             rc = self.lib.pdf_bn_coef_from_partial(partial.data_ptr(), rows, n, c, bn.weight.data_ptr(), bn.bias.data_ptr(),
                                                    bn.running_mean.data_ptr(), bn.running_var.data_ptr(), ctypes.c_float(bn.eps),
                                                    ctypes.c_float(bn.momentum if bn.momentum is not None else 0.1),

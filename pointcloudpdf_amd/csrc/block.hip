@@ -35,10 +35,11 @@ extern "C" int pdf_block_pre_forward(long n, int c, void *const *p, int training
     float *z1 = (float *)p[12], *coef1 = (float *)p[13], *partial = (float *)p[17];
     Err e;
     e << pdf_rowlin_forward(n, c, c, x, c, W1, 0, nullptr, nullptr, nullptr, 0, z1, c, 0, training ? partial : nullptr, stream);
-    e << pdf_bn_coef_eval_or_partial(partial, pdf_rowlin_partial_rows(n), n, c, g1, b1, rm1, rv1, training, eps, momentum, coef1, stream);
-    for (int i = 0; i < 3; ++i)
-        e << pdf_rowlin_forward(n, c, c, z1, c, (const float *)p[6 + 2 * i], 0, (const float *)p[7 + 2 * i], coef1, coef1 + c, 1,
-                                (float *)p[14 + i], c, 0, nullptr, stream);
+    e << pdf_bn_coef_eval_or_partial(partial, pdf_rowlin_partial_rows(n, c, c), n, c, g1, b1, rm1, rv1, training, eps, momentum, coef1, stream);
+    const float *xs[1] = {z1}, *ws[3] = {(const float *)p[6], (const float *)p[8], (const float *)p[10]};
+    const float *bs[3] = {(const float *)p[7], (const float *)p[9], (const float *)p[11]};
+    float *ys[3] = {(float *)p[14], (float *)p[15], (float *)p[16]};
+    e << pdf_rowlin_multi(n, c, c, 1, 3, xs, c, ws, 0, bs, coef1, coef1 + c, 1, ys, c, 0, stream);
     return e.rc;
 }
 
@@ -55,11 +56,12 @@ extern "C" int pdf_block_pre_backward(long n, int c, void *const *p, int trainin
     hipError_t he = hipMemsetAsync(grads, 0, sizeof(float) * (size_t)(cc + 2 * c + 3 * (cc + c)), s);
     if (he != hipSuccess) return (int)he;
     Err e;
-    for (int i = 0; i < 3; ++i) {
-        const float *g = (const float *)p[7 + i], *W = (const float *)p[4 + i];
-        e << pdf_rowlin_forward(n, c, c, g, c, W, 1, nullptr, nullptr, nullptr, 0, dy, c, i > 0, nullptr, stream);
-        e << pdf_rowlin_wgrad(n, c, c, g, c, z1, c, coef1, coef1 + c, 1, dqkv + i * (cc + c), dqkv + i * (cc + c) + cc, stream);
-    }
+    const float *gs[3] = {(const float *)p[7], (const float *)p[8], (const float *)p[9]};
+    const float *ws[3] = {(const float *)p[4], (const float *)p[5], (const float *)p[6]};
+    float *dws[3] = {dqkv, dqkv + (cc + c), dqkv + 2 * (cc + c)}, *dbs[3] = {dqkv + cc, dqkv + (cc + c) + cc, dqkv + 2 * (cc + c) + cc};
+    float *ys[1] = {dy};
+    e << pdf_rowlin_multi(n, c, c, 3, 1, gs, c, ws, 1, nullptr, nullptr, nullptr, 0, ys, c, 0, stream);
+    e << pdf_rowlin_wgrad_multi(n, c, c, 3, gs, c, z1, c, coef1, coef1 + c, 1, dws, dbs, stream);
     // bn1 backward in place on dy (elementwise: same index read and written)
     e << pdf_bn_act_backward(n, c, dy, z1, nullptr, coef1, training, 1, partial, sums, dy, nullptr, stream);
     he = hipMemcpyAsync(db1, sums, sizeof(float) * c, hipMemcpyDeviceToDevice, s);          // d beta
@@ -81,7 +83,7 @@ extern "C" int pdf_block_post_forward(long n, int c, void *const *p, int trainin
     Err e;
     e << pdf_bn_coef(n, c, t, (const float *)p[2], (const float *)p[3], (float *)p[4], (float *)p[5], training, eps, momentum, coef2, partial, stream);
     e << pdf_rowlin_forward(n, c, c, t, c, (const float *)p[6], 0, nullptr, coef2, coef2 + c, 1, z3, c, 0, training ? partial : nullptr, stream);
-    e << pdf_bn_coef_eval_or_partial(partial, pdf_rowlin_partial_rows(n), n, c, (const float *)p[7], (const float *)p[8], (float *)p[9],
+    e << pdf_bn_coef_eval_or_partial(partial, pdf_rowlin_partial_rows(n, c, c), n, c, (const float *)p[7], (const float *)p[8], (float *)p[9],
                                      (float *)p[10], training, eps, momentum, coef3, stream);
     e << pdf_bn_apply(n, c, z3, x, coef3, 1, y, stream);
     return e.rc;

@@ -20,6 +20,7 @@
 // stride 33); weights are wave-uniform and arrive through the scalar cache; per-channel statistics are reduced through
 // the same LDS tile read column-wise.  HBM-bound by design (algorithmic bytes: q,k,v rows once + p + idx + out).
 #include "pdfops_common.h"
+#include <cstdlib>
 
 namespace fl {
 
@@ -27,7 +28,12 @@ namespace fl {
 __host__ __device__ constexpr int tile_stride(int c) { return c / 8 > 32 ? 65 : 33; }      // holds 32-channel chunks and CS-wide rows
 __host__ __device__ constexpr int aux_stride(int c) { return c / 8 <= 16 ? 17 : c / 8 + 1; }
 constexpr int WPB = 4;          // waves per block
-constexpr int MAX_BLOCKS = 512;
+constexpr int MAX_BLOCKS = 512;   // default persistent grid of the forward passes (PDFOPS_PT_BLOCKS_FWD overrides)
+static inline int env_blocks(const char *name, int dflt) {
+    const char *v = getenv(name);
+    const int x = v ? atoi(v) : 0;
+    return x > 0 ? x : dflt;
+}
 
 // Wave-uniform read-only operands (weights, BatchNorm coefficients, reduction results) are addressed through the
 // constant address space: the compiler then fetches them with s_load into SGPRs instead of keeping one VGPR per value
@@ -418,16 +424,16 @@ __global__ __launch_bounds__(64 * WPB) void k_p4(LayerArgs A) {
 // exchanged through LDS tiles), written as one partial row per wave and column-summed by k_colsum (deterministic).
 constexpr int MAX_BLOCKS_BWD = 256;
 
+// Scatter-add the 64x32 tile into rows L.rowid[] of `table`.  One instruction = 2 rows x 32 consecutive channels, i.e. two
+// whole 128-byte lines: the L2 / memory-side atomic units are billed per request, and the former 8-rows-x-8-lanes shape
+// (16-byte pieces of 8 different rows) cost 16 requests per instruction instead of 4 (TCC request count = kernel time here).
 __device__ __forceinline__ void scatter_rows_atomic(const WaveLds &L, float *__restrict__ table, int C, int c0, int lane) {
-    const int sub = lane >> 3, col = (lane & 7) * 4;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const int row = t * 8 + sub;
+    const int half = lane >> 5, col = lane & 31;
+#pragma unroll 8
+    for (int t = 0; t < 32; ++t) {
+        const int row = 2 * t + half;
         const int dst = L.rowid[row];
-        if (dst < 0) continue;
-        const float *sv = L.tile + row * L.ts + col;
-        float *d = table + (size_t)dst * C + c0 + col;
-        pdf_atomic_add(d + 0, sv[0]); pdf_atomic_add(d + 1, sv[1]); pdf_atomic_add(d + 2, sv[2]); pdf_atomic_add(d + 3, sv[3]);
+        if (dst >= 0) pdf_atomic_add(table + (size_t)dst * C + c0 + col, L.tile[row * L.ts + col]);
     }
 }
 
@@ -914,8 +920,9 @@ static inline void allow_lds(KernelT kernel, size_t lds) {
 }
 
 static inline int grid_for_tiles(long ntiles) {
+    static const int cap = env_blocks("PDFOPS_PT_BLOCKS_FWD", MAX_BLOCKS);
     long g = (ntiles + WPB - 1) / WPB;
-    if (g > MAX_BLOCKS) g = MAX_BLOCKS;
+    if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (int)g;
 }
@@ -978,8 +985,9 @@ int forward_impl(LayerArgs A, int training, float eps, float momentum, const flo
 namespace fl {
 
 static inline int grid_for_tiles_bwd(long ntiles) {
+    static const int cap = env_blocks("PDFOPS_PT_BLOCKS_BWD", MAX_BLOCKS_BWD);
     long g = (ntiles + WPB - 1) / WPB;
-    if (g > MAX_BLOCKS_BWD) g = MAX_BLOCKS_BWD;
+    if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (int)g;
 }

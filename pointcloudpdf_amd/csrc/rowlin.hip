@@ -10,6 +10,7 @@
 // N ~ 10^5 rows with 3..512 channels: HBM-bound (read X once per 64 output columns, write Y once); MFMA keeps the ~0.4 MFLOP/pt
 // off the VALU.  Shapes are arbitrary (edges are zero-padded in LDS), X / Y / G carry a row stride.
 #include "pdfops_common.h"
+#include <cstdlib>
 
 namespace rl {
 
@@ -173,8 +174,27 @@ __global__ __launch_bounds__(256) void k_wgrad(WArgs a) {
 
 }  // namespace rl
 
-extern "C" long pdf_rowlin_partial_floats(long n, int o) { return ((n + rl::BM - 1) / rl::BM) * 2 * (long)o; }
-extern "C" int pdf_rowlin_partial_rows(long n) { return (int)((n + rl::BM - 1) / rl::BM); }
+// streaming kernels (rowlin2.hip): cover the channel widths of the Bottleneck; the tiled kernels above take every other shape
+namespace rl2 {
+int try_forward(long n, int k, int o, int nin, int nout, const float *const *x, long ldx, const float *const *w, int transpose_w,
+                const float *const *bias, const float *scale, const float *shift, int relu, float *const *y, long ldy,
+                int accumulate, float *partial, hipStream_t s);
+int try_wgrad(long n, int k, int o, int ng, const float *const *g, long ldg, const float *x, long ldx, const float *scale,
+              const float *shift, int relu, float *const *dw, float *const *db, hipStream_t s);
+int stats_rows(long n);
+}  // namespace rl2
+
+static inline bool rowlin_streams(int k, int o) {
+    return (k == 32 || k == 64 || k == 128 || k == 256 || k == 512) && o % 16 == 0 && getenv("PDFOPS_ROWLIN_TILED") == nullptr;
+}
+
+extern "C" int pdf_rowlin_partial_rows(long n, int k, int o) {
+    return rowlin_streams(k, o) ? rl2::stats_rows(n) : (int)((n + rl::BM - 1) / rl::BM);
+}
+extern "C" long pdf_rowlin_partial_floats(long n, int o) {
+    const long a = (n + rl::BM - 1) / rl::BM, b = rl2::stats_rows(n);
+    return (a > b ? a : b) * 2 * (long)o;
+}
 
 // Y (n, o; row stride ldy) (+)= f(X (n, k; row stride ldx)) * Wt + bias.  transpose_w = 0: W is (o, k) row-major (forward);
 // 1: W is (k, o) row-major, i.e. the layer's own (out, in) weight used for the input gradient dX = G W.
@@ -182,6 +202,12 @@ extern "C" int pdf_rowlin_forward(long n, int k, int o, const float *x, long ldx
                                   const float *bias, const float *scale, const float *shift, int relu, float *y, long ldy,
                                   int accumulate, float *partial, void *stream) {
     if (n < 1 || k < 1 || o < 1 || !x || !w || !y || ldx < k || ldy < o) return PDF_ERR_BAD_ARG;
+    if (rowlin_streams(k, o)) {
+        if (rl2::try_forward(n, k, o, 1, 1, &x, ldx, &w, transpose_w, &bias, scale, shift, relu, &y, ldy, accumulate, partial,
+                             static_cast<hipStream_t>(stream)))
+            return pdf_launch_status();
+        if (partial) return PDF_ERR_BAD_ARG;  // statistics layout is tied to the streaming kernel for these shapes (needs 16-byte alignment)
+    }
     rl::FwdArgs a;
     a.N = n; a.K = k; a.O = o; a.X = x; a.ldx = ldx; a.W = w;
     a.wso = transpose_w ? 1 : k; a.wsk = transpose_w ? o : 1;
@@ -201,6 +227,8 @@ extern "C" int pdf_rowlin_forward(long n, int k, int o, const float *x, long ldx
 extern "C" int pdf_rowlin_wgrad(long n, int k, int o, const float *g, long ldg, const float *x, long ldx,
                                 const float *scale, const float *shift, int relu, float *dw, float *db, void *stream) {
     if (n < 1 || k < 1 || o < 1 || !g || !x || !dw || ldg < o || ldx < k) return PDF_ERR_BAD_ARG;
+    if (rowlin_streams(k, o) && rl2::try_wgrad(n, k, o, 1, &g, ldg, x, ldx, scale, shift, relu, &dw, &db, static_cast<hipStream_t>(stream)))
+        return pdf_launch_status();
     rl::WArgs a;
     a.N = n; a.K = k; a.O = o; a.G = g; a.ldg = ldg; a.X = x; a.ldx = ldx; a.scale = scale; a.shift = shift; a.relu = relu;
     a.dW = dw; a.db = db;
@@ -215,4 +243,39 @@ extern "C" int pdf_rowlin_wgrad(long n, int k, int o, const float *g, long ldg, 
     if (scale) rl::k_wgrad<true><<<grid, 256, 0, s>>>(a);
     else rl::k_wgrad<false><<<grid, 256, 0, s>>>(a);
     return pdf_launch_status();
+}
+
+// Several Linear layers over the same rows in one launch (channel widths 32..256, see rowlin2.hip):
+//   nin = 1, nout = 1..3 :  y[i] = f(x[0]) Wt[i] + bias[i]              (q, k, v projections from one read of x)
+//   nin = 1..3, nout = 1 :  y[0] (+)= sum_i x[i] Wt[i] (+ bias[0])      (input gradient of the three projections)
+// Shapes the streaming kernels do not cover are issued as single-layer launches.
+extern "C" int pdf_rowlin_multi(long n, int k, int o, int nin, int nout, const float *const *x, long ldx, const float *const *w,
+                                int transpose_w, const float *const *bias, const float *scale, const float *shift, int relu,
+                                float *const *y, long ldy, int accumulate, void *stream) {
+    if (n < 1 || k < 1 || o < 1 || !x || !w || !y || nin < 1 || nout < 1 || nin > 3 || nout > 3 || (nin > 1 && nout > 1)) return PDF_ERR_BAD_ARG;
+    if (rowlin_streams(k, o) && rl2::try_forward(n, k, o, nin, nout, x, ldx, w, transpose_w, bias, scale, shift, relu, y, ldy, accumulate,
+                                                 nullptr, static_cast<hipStream_t>(stream)))
+        return pdf_launch_status();
+    int rc = 0;
+    if (nin == 1) {
+        for (int i = 0; i < nout && rc == 0; ++i)
+            rc = pdf_rowlin_forward(n, k, o, x[0], ldx, w[i], transpose_w, bias ? bias[i] : nullptr, scale, shift, relu, y[i], ldy, accumulate, nullptr, stream);
+    } else {
+        for (int i = 0; i < nin && rc == 0; ++i)
+            rc = pdf_rowlin_forward(n, k, o, x[i], ldx, w[i], transpose_w, (i == 0 && bias) ? bias[0] : nullptr, scale, shift, relu, y[0], ldy,
+                                    accumulate || i > 0, nullptr, stream);
+    }
+    return rc;
+}
+
+// dW[i] += G[i]^T f(X), db[i] += column sums of G[i] for up to three gradients sharing the layer input X.
+extern "C" int pdf_rowlin_wgrad_multi(long n, int k, int o, int ng, const float *const *g, long ldg, const float *x, long ldx,
+                                      const float *scale, const float *shift, int relu, float *const *dw, float *const *db,
+                                      void *stream) {
+    if (n < 1 || k < 1 || o < 1 || ng < 1 || ng > 3 || !g || !x || !dw) return PDF_ERR_BAD_ARG;
+    if (rowlin_streams(k, o) && rl2::try_wgrad(n, k, o, ng, g, ldg, x, ldx, scale, shift, relu, dw, db, static_cast<hipStream_t>(stream)))
+        return pdf_launch_status();
+    int rc = 0;
+    for (int i = 0; i < ng && rc == 0; ++i) rc = pdf_rowlin_wgrad(n, k, o, g[i], ldg, x, ldx, scale, shift, relu, dw[i], db ? db[i] : nullptr, stream);
+    return rc;
 }

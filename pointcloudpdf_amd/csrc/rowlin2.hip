@@ -1,0 +1,335 @@
+// Streaming per-point Linear layers for channel widths 32..512 (second-generation kernels behind pdf_rowlin_*).
+//
+// The Bottleneck's Linear layers (point_transformer_seg.py:184-192, 45-78: linear1, linear_q/k/v, linear3) are skinny GEMMs:
+// N = 10^5..10^3 rows, 32..512 channels, i.e. 16..256 FLOP per byte of activations -- HBM / latency bound, never
+// MFMA bound.  The kernels therefore stream the activation rows exactly once and keep the whole weight slab in registers:
+//
+//   forward / input gradient (k_fwd):  Y_out[n, o] = sum_in sum_k f(X_in[n, k]) Wt_in/out(k, o) + bias[o]
+//     one wave = 16 rows per trip; v_mfma_f32_16x16x4_f32 with A = W (rows = output channels) and B = X^T (cols = rows n):
+//     lane (n = l & 15, kq = l >> 4) loads float4 X[n][16 j + 4 kq ..+4] (64 contiguous bytes per row and instruction) and
+//     ends up with float4 Y[n][o0 + 4 (l >> 4) ..+4]: both sides are 16-byte accesses, no LDS, no barrier.
+//     The reduction index is permuted (k = 16 j + 4 kq + c at MFMA step (j, c)), which a dot product does not mind.
+//     f = identity or relu(x * scale[k] + shift[k]) (the BatchNorm + ReLU in front of the layer), optional epilogue =
+//     per-column sum / sum of squares of Y for the BatchNorm behind it.  Up to three inputs (dX = sum G_i W_i) or three
+//     outputs (q, k, v from one read of the activations).
+//   weight gradient (k_wg):  dW[o, k] += sum_n G[n, o] f(X[n, k]),  db[o] += sum_n G[n, o]
+//     reduction index = rows: lane (i = l & 15, nq = l >> 4) loads VW consecutive channels of row n0 + nq of G and of X;
+//     MFMA (c, c') accumulates the 16x16 sub-block {o = VW i + c} x {k = VW j + c'}: VW^2 MFMAs per 4 rows cover a
+//     (16 VW)^2 block of dW.  Waves reduce through LDS atomics, blocks through global atomics (dW pre-zeroed).
+//
+// fp32 in / fp32 accumulate (bit-equal to an fmaf chain): the reference computes these layers in fp32.
+#include "pdfops_common.h"
+
+namespace rl2 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct FwdArgs {
+    long N;
+    int O;                   // width of ONE output tensor
+    const float *X[3]; long ldx;
+    const float *W[3]; long wso, wsk;   // Wt(k, o) = W[o * wso + k * wsk]; indexed by input (NIN > 1) or by output
+    const float *bias[3];    // per output (nullable)
+    const float *scale, *shift; int relu;
+    float *Y[3]; long ldy;
+    int accumulate;
+    float *partial;          // [gridDim.x][2 * O] (STATS; single output)
+};
+
+constexpr int FWD_CAP = 1024;   // row-blocks (4 waves each) of the persistent grid
+static inline int fwd_row_blocks(long n) {
+    const long tiles = (n + 15) / 16, b = (tiles + 3) / 4;
+    return (int)(b < 1 ? 1 : (b > FWD_CAP ? FWD_CAP : b));
+}
+
+template <int K, int NOB, int NIN, bool PRE, bool STATS>
+__global__ __launch_bounds__(256) void k_fwd(FwdArgs a) {
+    constexpr int NJ = K / 16;
+    constexpr bool COEF_REGS = K <= 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int gcol0 = blockIdx.y * NOB * 16;   // column over the concatenated outputs; a 16-column block never straddles two
+    int outi[NOB], colb[NOB];
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) { outi[ob] = (gcol0 + ob * 16) / a.O; colb[ob] = gcol0 + ob * 16 - outi[ob] * a.O; }
+    f32x4 Wr[NIN][NOB][NJ];
+#pragma unroll
+    for (int in = 0; in < NIN; ++in) {
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) {
+            const float *W = a.W[NIN > 1 ? in : outi[ob]];
+            const long o = colb[ob] + li;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if (a.wsk == 1) {   // (out, in) row-major: four consecutive reduction indices in one 16-byte load
+                    Wr[in][ob][j] = *reinterpret_cast<const f32x4 *>(W + o * a.wso + 16 * j + 4 * kq);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) Wr[in][ob][j][c] = W[o * a.wso + (long)(16 * j + 4 * kq + c) * a.wsk];
+                }
+            }
+        }
+    }
+    f32x4 bias4[NOB];
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+        const float *b = a.bias[NIN > 1 ? 0 : outi[ob]];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias4[ob][r] = b ? b[colb[ob] + 4 * kq + r] : 0.f;
+    }
+    f32x4 sc4[COEF_REGS && PRE ? NJ : 1], sh4[COEF_REGS && PRE ? NJ : 1];
+    if (PRE && COEF_REGS) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            sc4[j] = *reinterpret_cast<const f32x4 *>(a.scale + 16 * j + 4 * kq);
+            sh4[j] = *reinterpret_cast<const f32x4 *>(a.shift + 16 * j + 4 * kq);
+        }
+    }
+    f32x4 s4[STATS ? NOB : 1], ss4[STATS ? NOB : 1];
+    if (STATS) {
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) { s4[ob] = f32x4{0.f, 0.f, 0.f, 0.f}; ss4[ob] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+    const long ntiles = (a.N + 15) / 16;
+    for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
+        const long n = tile * 16 + li;
+        const bool valid = n < a.N;
+        f32x4 acc[NOB];
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int in = 0; in < NIN; ++in) {
+            const float *xr = a.X[in] + (valid ? n : 0) * a.ldx + 4 * kq;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                f32x4 x4 = *reinterpret_cast<const f32x4 *>(xr + 16 * j);
+                if (PRE) {
+                    const f32x4 sc = COEF_REGS ? sc4[COEF_REGS ? j : 0] : *reinterpret_cast<const f32x4 *>(a.scale + 16 * j + 4 * kq);
+                    const f32x4 sh = COEF_REGS ? sh4[COEF_REGS ? j : 0] : *reinterpret_cast<const f32x4 *>(a.shift + 16 * j + 4 * kq);
+                    x4 = x4 * sc + sh;
+                    if (a.relu) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) x4[c] = fmaxf(x4[c], 0.f);
+                    }
+                }
+                if (!valid) x4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob)
+                        acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wr[in][ob][j][c], x4[c], acc[ob], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) {
+            f32x4 v = acc[ob] + bias4[ob];
+            float *dst = a.Y[outi[ob]] + (valid ? n : 0) * a.ldy + colb[ob] + 4 * kq;
+            if (a.accumulate && valid) v += *reinterpret_cast<const f32x4 *>(dst);
+            if (valid) *reinterpret_cast<f32x4 *>(dst) = v;
+            if (STATS && valid) { s4[ob] += v; ss4[ob] += v * v; }
+        }
+    }
+    if (STATS) {
+        __shared__ float red[4][2][NOB * 16];
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = s4[ob][r], ss = ss4[ob][r];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) { s += __shfl_xor(s, m, 64); ss += __shfl_xor(ss, m, 64); }
+                if (li == 0) { red[wave][0][ob * 16 + 4 * kq + r] = s; red[wave][1][ob * 16 + 4 * kq + r] = ss; }
+            }
+        __syncthreads();
+        const int t = threadIdx.x;
+        if (t < NOB * 16) {
+            float *row = a.partial + (size_t)blockIdx.x * 2 * a.O;
+            row[gcol0 + t] = red[0][0][t] + red[1][0][t] + red[2][0][t] + red[3][0][t];      // STATS: single output, gcol0 == column
+            row[a.O + gcol0 + t] = red[0][1][t] + red[1][1][t] + red[2][1][t] + red[3][1][t];
+        }
+    }
+}
+
+struct WArgs {
+    long N;
+    int K, O;
+    const float *G[3]; long ldg;
+    const float *X; long ldx;
+    const float *scale, *shift; int relu;
+    float *dW[3], *db[3];
+    long rows_per_block;     // multiple of 64
+};
+
+template <int VW> struct Vec;
+template <> struct Vec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct Vec<4> { typedef float type __attribute__((ext_vector_type(4))); };
+
+template <int VW, bool PRE>
+__global__ __launch_bounds__(256) void k_wg(WArgs a) {
+    typedef typename Vec<VW>::type vec;
+    constexpr int B = 16 * VW;   // block edge of dW
+    __shared__ float red[B * B];
+    __shared__ float redb[B];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, nq = lane >> 4;
+    const int nkb = a.K / B;
+    const int ob = (blockIdx.y / nkb) * B, kb = (blockIdx.y % nkb) * B;
+    const float *G = a.G[blockIdx.z];
+    for (int e = threadIdx.x; e < B * B; e += 256) red[e] = 0.f;
+    if (threadIdx.x < B) redb[threadIdx.x] = 0.f;
+    vec sc, sh;
+    if (PRE) {
+        sc = *reinterpret_cast<const vec *>(a.scale + kb + VW * li);
+        sh = *reinterpret_cast<const vec *>(a.shift + kb + VW * li);
+    }
+    f32x4 acc[VW][VW];
+    float gsum[VW];
+#pragma unroll
+    for (int c = 0; c < VW; ++c) {
+        gsum[c] = 0.f;
+#pragma unroll
+        for (int c2 = 0; c2 < VW; ++c2) acc[c][c2] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const long rb = (long)blockIdx.x * a.rows_per_block;
+    const long re = rb + a.rows_per_block < a.N ? rb + a.rows_per_block : a.N;
+    for (long r0 = rb + 16 * wave; r0 < re; r0 += 64) {
+        vec gv[4], xv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const long n = r0 + 4 * t + nq;
+            const bool ok = n < re;
+            const long nn = ok ? n : rb;
+            gv[t] = *reinterpret_cast<const vec *>(G + nn * a.ldg + ob + VW * li);
+            xv[t] = *reinterpret_cast<const vec *>(a.X + nn * a.ldx + kb + VW * li);
+            if (PRE) {
+                xv[t] = xv[t] * sc + sh;
+                if (a.relu) {
+#pragma unroll
+                    for (int c = 0; c < VW; ++c) xv[t][c] = fmaxf(xv[t][c], 0.f);
+                }
+            }
+            if (!ok) {
+#pragma unroll
+                for (int c = 0; c < VW; ++c) { gv[t][c] = 0.f; xv[t][c] = 0.f; }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int c = 0; c < VW; ++c) {
+                gsum[c] += gv[t][c];
+#pragma unroll
+                for (int c2 = 0; c2 < VW; ++c2)
+                    acc[c][c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[t][c], xv[t][c2], acc[c][c2], 0, 0, 0);
+            }
+    }
+    __syncthreads();
+    // D layout: acc[c][c2][r] = dW[ob + VW (4 nq + r) + c][kb + VW li + c2]
+#pragma unroll
+    for (int c = 0; c < VW; ++c)
+#pragma unroll
+        for (int c2 = 0; c2 < VW; ++c2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(&red[(VW * (4 * nq + r) + c) * B + VW * li + c2], acc[c][c2][r]);
+    float *db = a.db[blockIdx.z];
+    if (db && kb == 0) {
+#pragma unroll
+        for (int c = 0; c < VW; ++c) {
+            float g = gsum[c];
+            g += __shfl_xor(g, 16, 64);
+            g += __shfl_xor(g, 32, 64);
+            if (nq == 0) atomicAdd(&redb[VW * li + c], g);
+        }
+    }
+    __syncthreads();
+    float *dW = a.dW[blockIdx.z];
+    for (int e = threadIdx.x; e < B * B; e += 256) pdf_atomic_add(dW + (long)(ob + e / B) * a.K + kb + e % B, red[e]);
+    if (db && kb == 0 && threadIdx.x < B) pdf_atomic_add(db + ob + threadIdx.x, redb[threadIdx.x]);
+}
+
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int K, int NOB, int NIN>
+static void launch_fwd(const FwdArgs &a, int nslabs, hipStream_t s) {
+    const dim3 grid((unsigned)fwd_row_blocks(a.N), (unsigned)nslabs);
+    const bool pre = a.scale != nullptr, stats = a.partial != nullptr;
+    if (NIN == 1 && stats) {
+        if (pre) k_fwd<K, NOB, 1, true, true><<<grid, 256, 0, s>>>(a);
+        else k_fwd<K, NOB, 1, false, true><<<grid, 256, 0, s>>>(a);
+    } else {
+        if (pre) k_fwd<K, NOB, NIN, true, false><<<grid, 256, 0, s>>>(a);
+        else k_fwd<K, NOB, NIN, false, false><<<grid, 256, 0, s>>>(a);
+    }
+}
+
+// returns 1 when a streaming kernel took the job, 0 when the shape is not covered (caller falls back to the tiled kernel)
+int try_forward(long n, int k, int o, int nin, int nout, const float *const *x, long ldx, const float *const *w, int transpose_w,
+                const float *const *bias, const float *scale, const float *shift, int relu, float *const *y, long ldy,
+                int accumulate, float *partial, hipStream_t s) {
+    if (nin < 1 || nout < 1 || (nin > 1 && nout > 1) || nin > 3 || nout > 3) return 0;
+    if (partial && (nin != 1 || nout != 1)) return 0;
+    if ((ldx & 3) || (ldy & 3) || (o & 15)) return 0;
+    for (int i = 0; i < (nin > 1 ? nin : nout); ++i) if (!aligned16(w[i])) return 0;
+    if (scale && (!aligned16(scale) || !aligned16(shift))) return 0;
+    for (int i = 0; i < nin; ++i) if (!aligned16(x[i])) return 0;
+    for (int i = 0; i < nout; ++i) if (!aligned16(y[i])) return 0;
+    FwdArgs a;
+    a.N = n; a.O = o; a.ldx = ldx; a.ldy = ldy; a.scale = scale; a.shift = shift; a.relu = relu; a.accumulate = accumulate;
+    a.partial = partial;
+    a.wso = transpose_w ? 1 : k; a.wsk = transpose_w ? o : 1;
+    for (int i = 0; i < 3; ++i) {
+        a.X[i] = i < nin ? x[i] : nullptr;
+        a.W[i] = i < (nin > 1 ? nin : nout) ? w[i] : nullptr;
+        a.bias[i] = (bias && i < nout) ? bias[i] : nullptr;
+        a.Y[i] = i < nout ? y[i] : nullptr;
+    }
+    const int cols = o * nout;
+#define PDF_RL2(K_, NOB_, NIN_) do { if (cols % (NOB_ * 16) == 0) { launch_fwd<K_, NOB_, NIN_>(a, cols / (NOB_ * 16), s); return 1; } } while (0)
+    if (nin == 1) {
+        switch (k) {
+        case 32: if (!partial) PDF_RL2(32, 6, 1); PDF_RL2(32, 2, 1); PDF_RL2(32, 1, 1); break;
+        case 64: PDF_RL2(64, 4, 1); PDF_RL2(64, 1, 1); break;
+        case 128: PDF_RL2(128, 4, 1); PDF_RL2(128, 1, 1); break;
+        case 256: PDF_RL2(256, 2, 1); PDF_RL2(256, 1, 1); break;
+        case 512: PDF_RL2(512, 1, 1); break;
+        default: break;
+        }
+    } else if (nin == 3) {
+        switch (k) {
+        case 32: PDF_RL2(32, 2, 3); break;
+        case 64: PDF_RL2(64, 2, 3); break;
+        case 128: PDF_RL2(128, 1, 3); break;
+        case 256: PDF_RL2(256, 1, 3); break;
+        default: break;
+        }
+    }
+#undef PDF_RL2
+    return 0;
+}
+
+int try_wgrad(long n, int k, int o, int ng, const float *const *g, long ldg, const float *x, long ldx, const float *scale,
+              const float *shift, int relu, float *const *dw, float *const *db, hipStream_t s) {
+    if (ng < 1 || ng > 3) return 0;
+    const int vw = (k % 64 == 0 && o % 64 == 0) ? 4 : ((k % 32 == 0 && o % 32 == 0) ? 2 : 0);
+    if (!vw) return 0;
+    if ((ldg % vw) || (ldx % vw) || !aligned16(x)) return 0;
+    if (scale && (!aligned16(scale) || !aligned16(shift))) return 0;
+    for (int i = 0; i < ng; ++i) if (!aligned16(g[i])) return 0;
+    WArgs a;
+    a.N = n; a.K = k; a.O = o; a.ldg = ldg; a.X = x; a.ldx = ldx; a.scale = scale; a.shift = shift; a.relu = relu;
+    for (int i = 0; i < 3; ++i) { a.G[i] = i < ng ? g[i] : nullptr; a.dW[i] = i < ng ? dw[i] : nullptr; a.db[i] = (db && i < ng) ? db[i] : nullptr; }
+    const int b = 16 * vw, nblk = (o / b) * (k / b) * ng;
+    long split = (768 + nblk - 1) / nblk;              // ~768 workgroups in flight
+    const long max_split = (n + 255) / 256;            // at least 256 rows (4 trips per wave) per workgroup
+    if (split > max_split) split = max_split;
+    if (split < 1) split = 1;
+    a.rows_per_block = ((n + split - 1) / split + 63) / 64 * 64;
+    const dim3 grid((unsigned)((n + a.rows_per_block - 1) / a.rows_per_block), (unsigned)((o / b) * (k / b)), (unsigned)ng);
+    if (vw == 4) { if (scale) k_wg<4, true><<<grid, 256, 0, s>>>(a); else k_wg<4, false><<<grid, 256, 0, s>>>(a); }
+    else         { if (scale) k_wg<2, true><<<grid, 256, 0, s>>>(a); else k_wg<2, false><<<grid, 256, 0, s>>>(a); }
+    return 1;
+}
+
+int stats_rows(long n) { return fwd_row_blocks(n); }
+
+}  // namespace rl2

@@ -63,7 +63,8 @@ def test_split_k_linear_matches_torch():
         assert max_rel(a.cpu().numpy(), b.cpu().numpy()) < 2e-5
 
 
-@pytest.mark.parametrize("n,k,o", [(5000, 32, 32), (3001, 6, 32), (777, 512, 512), (40000, 64, 192), (999, 35, 64), (2500, 32, 13), (130, 256, 1)])
+@pytest.mark.parametrize("n,k,o", [(5000, 32, 32), (3001, 6, 32), (777, 512, 512), (40000, 64, 192), (999, 35, 64), (2500, 32, 13), (130, 256, 1),
+                                   (100003, 32, 32), (50001, 64, 64), (12517, 128, 128), (3125, 256, 256), (5, 32, 96), (1000, 128, 48)])
 @pytest.mark.parametrize("pre", [False, True])
 def test_rowlin_forward_dgrad_wgrad(n, k, o, pre):
     from pointcloudpdf_amd import _native
@@ -83,8 +84,8 @@ def test_rowlin_forward_dgrad_wgrad(n, k, o, pre):
     y, partial = be.rowlin(x, w, b, coef=coef, relu=True, stats=True)
     ref = fx.double() @ w.double().t() + b.double()
     assert max_rel(y.cpu().numpy(), ref.cpu().numpy()) < 2e-6
-    rows = partial.numel() // (2 * o)
-    ps = partial.view(rows, 2 * o).double().sum(0)
+    rows = partial._pdf_rows
+    ps = partial[: rows * 2 * o].view(rows, 2 * o).double().sum(0)
     assert max_rel(ps[:o].cpu().numpy(), ref.sum(0).cpu().numpy()) < 1e-4
     assert max_rel(ps[o:].cpu().numpy(), (ref * ref).sum(0).cpu().numpy()) < 1e-5
     go = torch.randn(n, o, device="cuda", generator=g)
@@ -99,6 +100,36 @@ def test_rowlin_forward_dgrad_wgrad(n, k, o, pre):
     big = torch.randn(n, k + 5, device="cuda", generator=g)
     y2, _ = be.rowlin(big[:, :k], w, b)
     assert max_rel(y2.cpu().numpy(), (big[:, :k].double() @ w.double().t() + b.double()).cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("n,c", [(30011, 32), (9000, 64), (4097, 128), (1500, 256), (300, 512), (200, 48)])
+@pytest.mark.parametrize("pre", [False, True])
+def test_rowlin_multi(n, c, pre):
+    """q/k/v projections in one launch, their joint input gradient and the three weight gradients."""
+    from pointcloudpdf_amd import _native
+
+    be = _native.hip_backend()
+    g = torch.Generator(device="cuda").manual_seed(n + c)
+    x = torch.randn(n, c, device="cuda", generator=g)
+    ws = [torch.randn(c, c, device="cuda", generator=g) / c ** 0.5 for _ in range(3)]
+    bs = [torch.randn(c, device="cuda", generator=g) for _ in range(3)]
+    coef, fx = None, x
+    if pre:
+        sc = torch.rand(c, device="cuda", generator=g) + 0.5
+        sh = torch.randn(c, device="cuda", generator=g) * 0.3
+        coef = torch.cat([sc, sh, torch.zeros(2 * c, device="cuda")])
+        fx = torch.relu(x * sc + sh)
+    ys = be.rowlin_multi([x], ws, bs, coef=coef, relu=True, nout=3)
+    for y, w, b in zip(ys, ws, bs):
+        assert max_rel(y.cpu().numpy(), (fx.double() @ w.double().t() + b.double()).cpu().numpy()) < 2e-6
+    gs = [torch.randn(n, c, device="cuda", generator=g) for _ in range(3)]
+    (gx,) = be.rowlin_multi(gs, ws, None, transpose_w=True, nout=1)
+    ref = sum(gi.double() @ w.double() for gi, w in zip(gs, ws))
+    assert max_rel(gx.cpu().numpy(), ref.cpu().numpy()) < 2e-6
+    dws, dbs = be.rowlin_wgrad_multi(gs, x, coef, True)
+    for gi, dw, db in zip(gs, dws, dbs):
+        assert max_rel(dw.cpu().numpy(), (gi.double().t() @ fx.double()).cpu().numpy()) < 1e-5
+        assert max_rel(db.cpu().numpy(), gi.double().sum(0).cpu().numpy()) < 1e-5
 
 
 @pytest.mark.parametrize("C,K,train", [(32, 8, True), (64, 16, True), (256, 16, True), (512, 16, True), (32, 8, False)])
