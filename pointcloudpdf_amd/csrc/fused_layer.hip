@@ -55,6 +55,7 @@ struct LayerArgs {
     const float *gout;                       // (N,C) gradient of the layer output
     cfloat_p mean, rstd;                     // saved batch statistics [p(3) | 1(C) | 2(CS)] (mean and rstd arrays)
     cfloat_p sums;                           // column sums of the previous backward pass (BatchNorm-backward terms)
+    cfloat_p sums2;                          // B3 only: column sums of B1 (BN2-backward terms), `sums` then holds B2's
     float *G2, *G3;                          // (N,K,CS) grad wrt BN2 output (post-ReLU mask), (N,K,3) same for BNp
     float *gxq, *gxk, *gxv;                  // (N,C) gradients (gxk / gxv pre-zeroed scatter targets)
     float inv_rows;                          // 1 / (N*K)
@@ -698,9 +699,9 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
         float t1n[3];
         bn_relu3(A, R.t1, t1n);
         float gh[CS], w[CS];
-        {   // hidden_grad needs B1's sums: they are passed through A.G3-adjacent pointer `sums2` (see launcher)
+        {   // hidden_grad needs B1's sums (A.sums2); A.sums holds B2's in this pass
             LayerArgs A2 = A;
-            A2.sums = A.sums + 2 * C;  // launcher packs [B2 sums (2C) | B1 sums (2CS)] for this pass
+            A2.sums = A.sums2;
             hidden_grad<C>(A2, R, gh);
         }
         attn_weights<CS, K>(A, R, w);
@@ -832,43 +833,60 @@ __global__ __launch_bounds__(64 * WPB) void k_b4(LayerArgs A) {
 }
 
 // out[col] = sum_rows partial[row][col]   (double accumulation, deterministic)
-__global__ __launch_bounds__(256) void k_colsum(const float *__restrict__ partial, int rows, int width, float *__restrict__ out) {
-    __shared__ double red[16][17];
+// block = 16 columns x RED_RL row-lanes; every row-lane sums a strided subset of the rows with four independent chains
+// (the loads are what costs: ~2000 partial rows, so the row dimension gets 64 lanes and 4-deep load pipelining).
+constexpr int RED_RL = 64, RED_THREADS = 16 * RED_RL;
+__global__ __launch_bounds__(RED_THREADS) void k_colsum(const float *__restrict__ partial, int rows, int width, float *__restrict__ out) {
+    __shared__ double red[RED_RL][17];
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int col = blockIdx.x * 16 + cl;
-    double s = 0.0;
-    if (col < width)
-        for (int r = rl; r < rows; r += 16) s += (double)partial[(size_t)r * width + col];
-    red[rl][cl] = s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (col < width) {
+        const float *src = partial + col;
+        int r = rl;
+        for (; r + 3 * RED_RL < rows; r += 4 * RED_RL) {
+            const float a = src[(size_t)r * width], b = src[(size_t)(r + RED_RL) * width];
+            const float c = src[(size_t)(r + 2 * RED_RL) * width], d = src[(size_t)(r + 3 * RED_RL) * width];
+            s0 += (double)a; s1 += (double)b; s2 += (double)c; s3 += (double)d;
+        }
+        for (; r < rows; r += RED_RL) s0 += (double)src[(size_t)r * width];
+    }
+    red[rl][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (rl != 0 || col >= width) return;
-    for (int k = 1; k < 16; ++k) s += red[k][cl];
+    double s = 0.0;
+    for (int k = 0; k < RED_RL; ++k) s += red[k][cl];
     out[col] = (float)s;
 }
 
 // ------------------------------------------------------------------------------------------------ BN finalize
 // partial: [rows][2*nch] (sum | sumsq).  Train: batch mean/var -> scale/shift (+ running-stat update, saved mean/rstd).
-// block = 16 channels x 16 row-lanes: every row-lane sums a strided subset of the partial rows in double, LDS combine.
-__global__ __launch_bounds__(256) void k_bn_finalize(const float *__restrict__ partial, int rows, int nch, double count,
+// block = 16 channels x RED_RL row-lanes: every row-lane sums a strided subset of the partial rows in double, LDS combine.
+__global__ __launch_bounds__(RED_THREADS) void k_bn_finalize(const float *__restrict__ partial, int rows, int nch, double count,
                               const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float momentum,
                               float *__restrict__ running_mean, float *__restrict__ running_var,
                               float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean_out,
                               float *__restrict__ rstd_out) {
-    __shared__ double red[2][16][17];
+    __shared__ double red[2][RED_RL][17];
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int ch = blockIdx.x * 16 + cl;
-    double s = 0.0, ss = 0.0;
+    double s0 = 0.0, s1 = 0.0, q0 = 0.0, q1 = 0.0;
     if (ch < nch) {
-        for (int r = rl; r < rows; r += 16) {
-            s += (double)partial[(size_t)r * 2 * nch + ch];
-            ss += (double)partial[(size_t)r * 2 * nch + nch + ch];
+        const float *src = partial + ch;
+        const size_t w = 2 * (size_t)nch;
+        int r = rl;
+        for (; r + RED_RL < rows; r += 2 * RED_RL) {
+            const float a = src[r * w], b = src[(r + RED_RL) * w], c = src[r * w + nch], d = src[(r + RED_RL) * w + nch];
+            s0 += (double)a; s1 += (double)b; q0 += (double)c; q1 += (double)d;
         }
+        for (; r < rows; r += RED_RL) { s0 += (double)src[r * w]; q0 += (double)src[r * w + nch]; }
     }
-    red[0][rl][cl] = s;
-    red[1][rl][cl] = ss;
+    red[0][rl][cl] = s0 + s1;
+    red[1][rl][cl] = q0 + q1;
     __syncthreads();
     if (rl != 0 || ch >= nch) return;
-    for (int k = 1; k < 16; ++k) { s += red[0][k][cl]; ss += red[1][k][cl]; }
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < RED_RL; ++k) { s += red[0][k][cl]; ss += red[1][k][cl]; }
     const double mean = s / count;
     double var = ss / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -903,7 +921,7 @@ __global__ void k_bn_eval(int nch, const float *__restrict__ gamma, const float 
 void launch_bn_finalize(const float *partial, int rows, int nch, double count, const float *gamma, const float *beta, float eps,
                         float momentum, float *running_mean, float *running_var, float *scale, float *shift, float *mean_out,
                         float *rstd_out, hipStream_t s) {
-    k_bn_finalize<<<pdf_divup(nch, 16), 256, 0, s>>>(partial, rows, nch, count, gamma, beta, eps, momentum, running_mean, running_var,
+    k_bn_finalize<<<pdf_divup(nch, 16), RED_THREADS, 0, s>>>(partial, rows, nch, count, gamma, beta, eps, momentum, running_mean, running_var,
                                                      scale, shift, mean_out, rstd_out);
 }
 void launch_bn_eval(int nch, const float *gamma, const float *beta, float eps, const float *running_mean, const float *running_var,
@@ -911,7 +929,7 @@ void launch_bn_eval(int nch, const float *gamma, const float *beta, float eps, c
     k_bn_eval<<<pdf_divup(nch, 64), 64, 0, s>>>(nch, gamma, beta, eps, running_mean, running_var, scale, shift, mean_out, rstd_out);
 }
 void launch_colsum(const float *partial, int rows, int width, float *out, hipStream_t s) {
-    k_colsum<<<pdf_divup(width, 16), 256, 0, s>>>(partial, rows, width, out);
+    k_colsum<<<pdf_divup(width, 16), RED_THREADS, 0, s>>>(partial, rows, width, out);
 }
 
 template <typename KernelT>
@@ -931,7 +949,7 @@ static inline int grid_for_tiles(long ntiles) {
 
 // ================================================================================================ C ABI
 // Workspace contract (caller-owned floats): `bn` = 2*(3 + C + C/8) scale/shift values laid out
-// [sp(3) tp(3) s1(C) t1(C) s2(CS) t2(CS)], `saved` = mean/rstd in the same order (train mode, for backward),
+// [sp(3) tp(3) s1(C) t1(C) s2(CS) t2(CS)], `saved` = [mean: p(3) 1(C) 2(CS)][rstd: same] (train mode, for backward),
 // `partial` = pdf_pt_layer_partial_floats(N, K, C) floats of scratch.
 extern "C" long pdf_pt_layer_partial_floats(int n, int nsample, int c) {
     const long ntiles = ((long)n * nsample + 63) / 64;
@@ -966,16 +984,17 @@ int forward_impl(LayerArgs A, int training, float eps, float momentum, const flo
         k_p4<C, K><<<grid, 64 * WPB, lds, s>>>(A);
         return pdf_launch_status();
     }
-    float *mp = saved, *rp = saved + 3, *m1 = saved + 6, *r1 = saved + 6 + C, *m2 = saved + 6 + 2 * C, *r2 = saved + 6 + 2 * C + CS;
+    constexpr int T = 3 + C + CS;   // saved = [mean: p(3) | 1(C) | 2(CS)] [rstd: same order]  (the layout the backward kernels index)
+    float *mp = saved, *m1 = saved + 3, *m2 = saved + 3 + C, *rp = saved + T, *r1 = saved + T + 3, *r2 = saved + T + 3 + C;
     allow_lds(k_p2<C, K>, lds);
     allow_lds(k_p3<C, K, true>, lds);
     allow_lds(k_p4<C, K>, lds);
     k_p1<K><<<grid, 64 * WPB, 0, s>>>(A);
-    k_bn_finalize<<<1, 256, 0, s>>>(A.partial, nw, 3, (double)rows, bn_params[0], bn_params[1], eps, momentum, bn_buffers[0], bn_buffers[1], sp, tp, mp, rp);
+    k_bn_finalize<<<1, RED_THREADS, 0, s>>>(A.partial, nw, 3, (double)rows, bn_params[0], bn_params[1], eps, momentum, bn_buffers[0], bn_buffers[1], sp, tp, mp, rp);
     k_p2<C, K><<<grid, 64 * WPB, lds, s>>>(A);
-    k_bn_finalize<<<pdf_divup(C, 16), 256, 0, s>>>(A.partial, nw, C, (double)rows, bn_params[2], bn_params[3], eps, momentum, bn_buffers[2], bn_buffers[3], s1, t1, m1, r1);
+    k_bn_finalize<<<pdf_divup(C, 16), RED_THREADS, 0, s>>>(A.partial, nw, C, (double)rows, bn_params[2], bn_params[3], eps, momentum, bn_buffers[2], bn_buffers[3], s1, t1, m1, r1);
     k_p3<C, K, true><<<grid, 64 * WPB, lds, s>>>(A);
-    k_bn_finalize<<<pdf_divup(CS, 16), 256, 0, s>>>(A.partial, nw, CS, (double)rows, bn_params[4], bn_params[5], eps, momentum, bn_buffers[4], bn_buffers[5], s2, t2, m2, r2);
+    k_bn_finalize<<<pdf_divup(CS, 16), RED_THREADS, 0, s>>>(A.partial, nw, CS, (double)rows, bn_params[4], bn_params[5], eps, momentum, bn_buffers[4], bn_buffers[5], s2, t2, m2, r2);
     k_p4<C, K><<<grid, 64 * WPB, lds, s>>>(A);
     return pdf_launch_status();
 }
@@ -984,8 +1003,11 @@ int forward_impl(LayerArgs A, int training, float eps, float momentum, const flo
 
 namespace fl {
 
-static inline int grid_for_tiles_bwd(long ntiles) {
-    static const int cap = env_blocks("PDFOPS_PT_BLOCKS_BWD", MAX_BLOCKS_BWD);
+// two blocks per CU pay off where the passes are latency-bound on many small tiles (C <= 64: 1.0 -> 0.78 ms at level 1);
+// at C >= 128 the per-wave partial rows (weight-gradient blocks) cost more than the extra waves bring
+static inline int grid_for_tiles_bwd(long ntiles, int c) {
+    static const int env_cap = env_blocks("PDFOPS_PT_BLOCKS_BWD", 0);
+    const int cap = env_cap > 0 ? env_cap : (c <= 64 ? 2 * MAX_BLOCKS_BWD : MAX_BLOCKS_BWD);
     long g = (ntiles + WPB - 1) / WPB;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
@@ -997,30 +1019,26 @@ int backward_impl(LayerArgs A, float *sums, hipStream_t s) {
     constexpr int CS = C / 8;
     const long rows = (long)A.N * K;
     const long ntiles = (rows + 63) / 64;
-    const int grid = grid_for_tiles_bwd(ntiles), nw = grid * WPB;
+    const int grid = grid_for_tiles_bwd(ntiles, C), nw = grid * WPB;
     const size_t lds = (size_t)WPB * lds_floats_per_wave(C, true) * sizeof(float);
     A.inv_rows = (float)(1.0 / (double)rows);
     // sums layout (floats): [S1: b1_width | S2: b2_width | S3: b3_width | S4: 16 | X: 2C + 2CS scratch for B3]
-    float *S1 = sums, *S2 = S1 + b1_width<C>(), *S3 = S2 + b2_width<C>(), *S4 = S3 + b3_width<C>(), *X = S4 + b4_width();
+    float *S1 = sums, *S2 = S1 + b1_width<C>(), *S3 = S2 + b2_width<C>(), *S4 = S3 + b3_width<C>();
     allow_lds(k_b1<C, K>, lds);
     allow_lds(k_b2<C, K>, lds);
     allow_lds(k_b3<C, K>, lds);
     k_b1<C, K><<<grid, 64 * WPB, lds, s>>>(A);
-    k_colsum<<<pdf_divup(b1_width<C>(), 16), 256, 0, s>>>(A.partial, nw, b1_width<C>(), S1);
+    k_colsum<<<pdf_divup(b1_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, nw, b1_width<C>(), S1);
     A.sums = as_const(S1);
     k_b2<C, K><<<grid, 64 * WPB, lds, s>>>(A);
-    k_colsum<<<pdf_divup(b2_width<C>(), 16), 256, 0, s>>>(A.partial, nw, b2_width<C>(), S2);
-    // B3 wants [B2 sums (2C) | B1 sums (2CS)] contiguous
-    hipError_t e = hipMemcpyAsync(X, S2, sizeof(float) * 2 * C, hipMemcpyDeviceToDevice, s);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemcpyAsync(X + 2 * C, S1, sizeof(float) * 2 * CS, hipMemcpyDeviceToDevice, s);
-    if (e != hipSuccess) return (int)e;
-    A.sums = as_const(X);
+    k_colsum<<<pdf_divup(b2_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, nw, b2_width<C>(), S2);
+    A.sums = as_const(S2);   // B3: BN1-backward terms from B2, BN2-backward terms from B1
+    A.sums2 = as_const(S1);
     k_b3<C, K><<<grid, 64 * WPB, lds, s>>>(A);
-    k_colsum<<<pdf_divup(b3_width<C>(), 16), 256, 0, s>>>(A.partial, nw, b3_width<C>(), S3);
+    k_colsum<<<pdf_divup(b3_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, nw, b3_width<C>(), S3);
     A.sums = as_const(S3);
     k_b4<K><<<grid, 64 * WPB, 0, s>>>(A);
-    k_colsum<<<1, 256, 0, s>>>(A.partial, nw, b4_width(), S4);
+    k_colsum<<<1, RED_THREADS, 0, s>>>(A.partial, nw, b4_width(), S4);
     return pdf_launch_status();
 }
 
@@ -1029,7 +1047,7 @@ int backward_impl(LayerArgs A, float *sums, hipStream_t s) {
 extern "C" long pdf_pt_layer_bwd_partial_floats(int n, int nsample, int c) {
     const long ntiles = ((long)n * nsample + 63) / 64;
     const long w = 2L * c + c / 8 + (long)(c / 8) * c;  // widest pass (B2)
-    return (long)fl::grid_for_tiles_bwd(ntiles) * fl::WPB * w;
+    return (long)fl::grid_for_tiles_bwd(ntiles, c) * fl::WPB * w;
 }
 
 // floats in the `sums` result buffer and the offsets of its four sections [S1 | S2 | S3 | S4 | scratch]
@@ -1061,21 +1079,10 @@ extern "C" int pdf_pt_layer_backward(int n, int nsample, int c, const float *xq,
     A.Ww1 = as_const(weights[4]); A.bw1 = as_const(weights[5]); A.Ww2 = as_const(weights[6]); A.bw2 = as_const(weights[7]);
     A.sp = as_const(bn); A.tp = as_const(bn + 3); A.s1 = as_const(bn + 6); A.t1 = as_const(bn + 6 + c);
     A.s2 = as_const(bn + 6 + 2 * c); A.t2 = as_const(bn + 6 + 2 * c + cs);
-    // saved = [mp(3) rp(3) m1(C) r1(C) m2(CS) r2(CS)] -> mean / rstd views indexed [p(3) | 1(C) | 2(CS)]
-    // (the kernels index A.mean / A.rstd as [0..3) p, [3..3+C) 1, [3+C..) 2: build those views in `sums` scratch)
     A.H = const_cast<float *>(H); A.out = nullptr; A.partial = partial;
-    A.gout = gout; A.G2 = G2; A.G3 = G3; A.gxq = gxq; A.gxk = gxk; A.gxv = gxv; A.sums = as_const(nullptr);
+    A.gout = gout; A.G2 = G2; A.G3 = G3; A.gxq = gxq; A.gxk = gxk; A.gxv = gxv; A.sums = as_const(nullptr); A.sums2 = as_const(nullptr);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // re-pack saved statistics into contiguous mean[] and rstd[] arrays at the tail of `sums`
-    const long tail = pdf_pt_layer_bwd_sums_floats(c);
-    float *mean = sums + tail, *rstd = mean + (3 + c + cs);
-    hipError_t e;
-#define PDF_CP(dst_, src_, cnt_) do { e = hipMemcpyAsync(dst_, src_, sizeof(float) * (cnt_), hipMemcpyDeviceToDevice, s); if (e != hipSuccess) return (int)e; } while (0)
-    PDF_CP(mean, saved, 3); PDF_CP(rstd, saved + 3, 3);
-    PDF_CP(mean + 3, saved + 6, c); PDF_CP(rstd + 3, saved + 6 + c, c);
-    PDF_CP(mean + 3 + c, saved + 6 + 2 * c, cs); PDF_CP(rstd + 3 + c, saved + 6 + 2 * c + cs, cs);
-#undef PDF_CP
-    A.mean = as_const(mean); A.rstd = as_const(rstd);
+    A.mean = as_const(saved); A.rstd = as_const(saved + (3 + c + cs));   // forward's layout: [mean p|1|2][rstd p|1|2]
 #define PDF_BWD(C_, K_) return fl::backward_impl<C_, K_>(A, sums, s)
     if (nsample == 8) {
         if (c == 32) PDF_BWD(32, 8);

@@ -19,6 +19,7 @@
 //
 // fp32 in / fp32 accumulate (bit-equal to an fmaf chain): the reference computes these layers in fp32.
 #include "pdfops_common.h"
+#include <cstdlib>
 
 namespace rl2 {
 
@@ -168,15 +169,13 @@ template <int VW, bool PRE>
 __global__ __launch_bounds__(256) void k_wg(WArgs a) {
     typedef typename Vec<VW>::type vec;
     constexpr int B = 16 * VW;   // block edge of dW
-    __shared__ float red[B * B];
-    __shared__ float redb[B];
+    __shared__ float red[4][B * B];   // one (16 VW)^2 block per wave: plain stores, then a 4-way sum (LDS atomics cost 20 us here)
+    __shared__ float redb[4][B];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, nq = lane >> 4;
     const int nkb = a.K / B;
     const int ob = (blockIdx.y / nkb) * B, kb = (blockIdx.y % nkb) * B;
     const float *G = a.G[blockIdx.z];
-    for (int e = threadIdx.x; e < B * B; e += 256) red[e] = 0.f;
-    if (threadIdx.x < B) redb[threadIdx.x] = 0.f;
     vec sc, sh;
     if (PRE) {
         sc = *reinterpret_cast<const vec *>(a.scale + kb + VW * li);
@@ -223,28 +222,30 @@ __global__ __launch_bounds__(256) void k_wg(WArgs a) {
                     acc[c][c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(gv[t][c], xv[t][c2], acc[c][c2], 0, 0, 0);
             }
     }
-    __syncthreads();
     // D layout: acc[c][c2][r] = dW[ob + VW (4 nq + r) + c][kb + VW li + c2]
 #pragma unroll
     for (int c = 0; c < VW; ++c)
 #pragma unroll
         for (int c2 = 0; c2 < VW; ++c2)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(&red[(VW * (4 * nq + r) + c) * B + VW * li + c2], acc[c][c2][r]);
+            for (int r = 0; r < 4; ++r) red[wave][(VW * (4 * nq + r) + c) * B + VW * li + c2] = acc[c][c2][r];
     float *db = a.db[blockIdx.z];
-    if (db && kb == 0) {
+    const bool want_db = db && kb == 0;
+    if (want_db) {
 #pragma unroll
         for (int c = 0; c < VW; ++c) {
             float g = gsum[c];
             g += __shfl_xor(g, 16, 64);
             g += __shfl_xor(g, 32, 64);
-            if (nq == 0) atomicAdd(&redb[VW * li + c], g);
+            if (nq == 0) redb[wave][VW * li + c] = g;
         }
     }
     __syncthreads();
     float *dW = a.dW[blockIdx.z];
-    for (int e = threadIdx.x; e < B * B; e += 256) pdf_atomic_add(dW + (long)(ob + e / B) * a.K + kb + e % B, red[e]);
-    if (db && kb == 0 && threadIdx.x < B) pdf_atomic_add(db + ob + threadIdx.x, redb[threadIdx.x]);
+    for (int e = threadIdx.x; e < B * B; e += 256)
+        pdf_atomic_add(dW + (long)(ob + e / B) * a.K + kb + e % B, (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]));
+    if (want_db && threadIdx.x < B)
+        pdf_atomic_add(db + ob + threadIdx.x, (redb[0][threadIdx.x] + redb[1][threadIdx.x]) + (redb[2][threadIdx.x] + redb[3][threadIdx.x]));
 }
 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -319,7 +320,8 @@ int try_wgrad(long n, int k, int o, int ng, const float *const *g, long ldg, con
     a.N = n; a.K = k; a.O = o; a.ldg = ldg; a.X = x; a.ldx = ldx; a.scale = scale; a.shift = shift; a.relu = relu;
     for (int i = 0; i < 3; ++i) { a.G[i] = i < ng ? g[i] : nullptr; a.dW[i] = i < ng ? dw[i] : nullptr; a.db[i] = (db && i < ng) ? db[i] : nullptr; }
     const int b = 16 * vw, nblk = (o / b) * (k / b) * ng;
-    long split = (768 + nblk - 1) / nblk;              // ~768 workgroups in flight
+    static const int target = [] { const char *v = getenv("PDFOPS_WG_BLOCKS"); const int x = v ? atoi(v) : 0; return x > 0 ? x : 512; }();
+    long split = (target + nblk - 1) / nblk;           // workgroups in flight (every one ends with (16 VW)^2 global atomics)
     const long max_split = (n + 255) / 256;            // at least 256 rows (4 trips per wave) per workgroup
     if (split > max_split) split = max_split;
     if (split < 1) split = 1;

@@ -261,7 +261,7 @@ class Bottleneck(nn.Module):
         self.bn3 = nn.BatchNorm1d(planes * self.expansion)
         self.relu = nn.ReLU(inplace=True)
 
-    matrix_core = os.environ.get("PDFOPS_MATRIX_CORE", "0") != "0"  # (opt-in: measured 72 vs 66 ms/step) class-wide switch: Linear + BatchNorm chains through csrc/rowlin.hip
+    matrix_core = os.environ.get("PDFOPS_MATRIX_CORE", "1") != "0"  # class-wide switch: Linear + BatchNorm chains through csrc/rowlin.hip
 
     def forward(self, pxo):
         p, x, o = pxo

@@ -17,6 +17,13 @@ for lv in levels:
     layer = PointTransformerLayer(c, c, 8, k).cuda().train()
     p, o = geom.coord(lv), geom.offset(lv)
     n = p.shape[0]
+    if os.environ.get("MORTON"):   # experiment: spatially coherent point order inside every scene
+        q = ((p - p.min(0).values) / 0.05).long().clamp_(0, 1023)
+        def spread(v):
+            v = (v | (v << 16)) & 0x030000FF; v = (v | (v << 8)) & 0x0300F00F; v = (v | (v << 4)) & 0x030C30C3; return (v | (v << 2)) & 0x09249249
+        key = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+        scene = torch.bucketize(torch.arange(n, device="cuda"), o.long(), right=True)
+        p = p[torch.argsort(key + (scene << 32))].contiguous()
     x = torch.randn(n, c, device="cuda")
     xq, xk, xv = [torch.randn(n, c, device="cuda", requires_grad=True) for _ in range(3)]
     go = torch.randn(n, c, device="cuda")
