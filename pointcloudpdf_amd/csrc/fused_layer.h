@@ -1,0 +1,42 @@
+// Shared declarations of the fused PointTransformerLayer kernels (fused_layer.hip: row-per-lane passes for every supported
+// shape; fused_layer_mfma.hip: matrix-core passes for nsample == 16, C >= 128).
+#pragma once
+#include "pdfops_common.h"
+
+namespace fl {
+
+constexpr int WPB = 4;          // waves per block
+
+// Wave-uniform read-only operands (weights, BatchNorm coefficients, reduction results) are addressed through the
+// constant address space: the compiler then fetches them with s_load into SGPRs instead of keeping one VGPR per value
+// and lane (which spilled thousands of registers in the first version of these kernels).
+typedef const float __attribute__((address_space(4))) *cfloat_p;
+__host__ __device__ inline cfloat_p as_const(const float *p) { return (cfloat_p)(uintptr_t)p; }
+
+struct LayerArgs {
+    int N;                                   // points
+    const float *xq, *xk, *xv, *p;           // (N,C) x3, (N,3)
+    const int *idx;                          // (N,K)
+    cfloat_p Wp1, bp1, Wp2, bp2;             // (3,3) (3) (C,3) (C)
+    cfloat_p Ww1, bw1, Ww2, bw2;             // (CS,C) (CS) (CS,CS) (CS)
+    cfloat_p sp, tp, s1, t1, s2, t2;         // BatchNorm scale/shift: y = x*s + t  (3,3,C,C,CS,CS)
+    float *H;                                // (N,K,CS) pre-BN2 activations
+    float *out;                              // (N,C)
+    float *partial;                          // per-wave partial sums for the statistics of the current pass
+    // ---- backward only
+    const float *gout;                       // (N,C) gradient of the layer output
+    cfloat_p mean, rstd;                     // saved batch statistics [p(3) | 1(C) | 2(CS)] (mean and rstd arrays)
+    cfloat_p sums;                           // column sums of the previous backward pass (BatchNorm-backward terms)
+    cfloat_p sums2;                          // B3 only: column sums of B1 (BN2-backward terms), `sums` then holds B2's
+    float *G2, *G3;                          // (N,K,CS) grad wrt BN2 output (post-ReLU mask), (N,K,3) same for BNp
+    float *gxq, *gxk, *gxv;                  // (N,C) gradients (gxk / gxv pre-zeroed scatter targets)
+    float inv_rows;                          // 1 / (N*K)
+};
+
+}  // namespace fl
+
+namespace flm {
+// matrix-core variants (fused_layer_mfma.hip); `grid` blocks of 64 * WPB threads, partial rows = grid * WPB
+bool supported(int nsample, int c);
+void launch_p3(const fl::LayerArgs &A, int c, bool stats, int grid, hipStream_t s);
+}  // namespace flm

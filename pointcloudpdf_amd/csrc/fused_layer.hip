@@ -19,7 +19,7 @@
 // 16-byte loads (8 lanes per 128-byte row chunk) into a padded LDS tile and read back row-per-lane (conflict-free,
 // stride 33); weights are wave-uniform and arrive through the scalar cache; per-channel statistics are reduced through
 // the same LDS tile read column-wise.  HBM-bound by design (algorithmic bytes: q,k,v rows once + p + idx + out).
-#include "pdfops_common.h"
+#include "fused_layer.h"
 #include <cstdlib>
 
 namespace fl {
@@ -27,39 +27,12 @@ namespace fl {
 // LDS tile row strides (floats) are odd (33 / 65 / 17): row-per-lane and column reads are both bank-conflict-free.
 __host__ __device__ constexpr int tile_stride(int c) { return c / 8 > 32 ? 65 : 33; }      // holds 32-channel chunks and CS-wide rows
 __host__ __device__ constexpr int aux_stride(int c) { return c / 8 <= 16 ? 17 : c / 8 + 1; }
-constexpr int WPB = 4;          // waves per block
 constexpr int MAX_BLOCKS = 512;   // default persistent grid of the forward passes (PDFOPS_PT_BLOCKS_FWD overrides)
 static inline int env_blocks(const char *name, int dflt) {
     const char *v = getenv(name);
     const int x = v ? atoi(v) : 0;
     return x > 0 ? x : dflt;
 }
-
-// Wave-uniform read-only operands (weights, BatchNorm coefficients, reduction results) are addressed through the
-// constant address space: the compiler then fetches them with s_load into SGPRs instead of keeping one VGPR per value
-// and lane (which spilled thousands of registers in the first version of these kernels).
-typedef const float __attribute__((address_space(4))) *cfloat_p;
-__host__ __device__ inline cfloat_p as_const(const float *p) { return (cfloat_p)(uintptr_t)p; }
-
-struct LayerArgs {
-    int N;                                   // points
-    const float *xq, *xk, *xv, *p;           // (N,C) x3, (N,3)
-    const int *idx;                          // (N,K)
-    cfloat_p Wp1, bp1, Wp2, bp2;             // (3,3) (3) (C,3) (C)
-    cfloat_p Ww1, bw1, Ww2, bw2;             // (CS,C) (CS) (CS,CS) (CS)
-    cfloat_p sp, tp, s1, t1, s2, t2;         // BatchNorm scale/shift: y = x*s + t  (3,3,C,C,CS,CS)
-    float *H;                                // (N,K,CS) pre-BN2 activations
-    float *out;                              // (N,C)
-    float *partial;                          // per-wave partial sums for the statistics of the current pass
-    // ---- backward only
-    const float *gout;                       // (N,C) gradient of the layer output
-    cfloat_p mean, rstd;                     // saved batch statistics [p(3) | 1(C) | 2(CS)] (mean and rstd arrays)
-    cfloat_p sums;                           // column sums of the previous backward pass (BatchNorm-backward terms)
-    cfloat_p sums2;                          // B3 only: column sums of B1 (BN2-backward terms), `sums` then holds B2's
-    float *G2, *G3;                          // (N,K,CS) grad wrt BN2 output (post-ReLU mask), (N,K,3) same for BNp
-    float *gxq, *gxk, *gxv;                  // (N,C) gradients (gxk / gxv pre-zeroed scatter targets)
-    float inv_rows;                          // 1 / (N*K)
-};
 
 struct WaveLds {
     float *tile;   // [64][TS]
@@ -980,7 +953,8 @@ int forward_impl(LayerArgs A, int training, float eps, float momentum, const flo
         k_bn_eval<<<1, 64, 0, s>>>(CS, bn_params[4], bn_params[5], eps, bn_buffers[4], bn_buffers[5], s2, t2, nullptr, nullptr);
         allow_lds(k_p3<C, K, false>, lds);
         allow_lds(k_p4<C, K>, lds);
-        k_p3<C, K, false><<<grid, 64 * WPB, lds, s>>>(A);
+        if (flm::supported(K, C)) flm::launch_p3(A, C, false, grid, s);
+        else k_p3<C, K, false><<<grid, 64 * WPB, lds, s>>>(A);
         k_p4<C, K><<<grid, 64 * WPB, lds, s>>>(A);
         return pdf_launch_status();
     }
@@ -993,7 +967,8 @@ int forward_impl(LayerArgs A, int training, float eps, float momentum, const flo
     k_bn_finalize<<<1, RED_THREADS, 0, s>>>(A.partial, nw, 3, (double)rows, bn_params[0], bn_params[1], eps, momentum, bn_buffers[0], bn_buffers[1], sp, tp, mp, rp);
     k_p2<C, K><<<grid, 64 * WPB, lds, s>>>(A);
     k_bn_finalize<<<pdf_divup(C, 16), RED_THREADS, 0, s>>>(A.partial, nw, C, (double)rows, bn_params[2], bn_params[3], eps, momentum, bn_buffers[2], bn_buffers[3], s1, t1, m1, r1);
-    k_p3<C, K, true><<<grid, 64 * WPB, lds, s>>>(A);
+    if (flm::supported(K, C)) flm::launch_p3(A, C, true, grid, s);
+    else k_p3<C, K, true><<<grid, 64 * WPB, lds, s>>>(A);
     k_bn_finalize<<<pdf_divup(CS, 16), RED_THREADS, 0, s>>>(A.partial, nw, CS, (double)rows, bn_params[4], bn_params[5], eps, momentum, bn_buffers[4], bn_buffers[5], s2, t2, m2, r2);
     k_p4<C, K><<<grid, 64 * WPB, lds, s>>>(A);
     return pdf_launch_status();
