@@ -1002,14 +1002,15 @@ int backward_impl(LayerArgs A, float *sums, hipStream_t s) {
     allow_lds(k_b1<C, K>, lds);
     allow_lds(k_b2<C, K>, lds);
     allow_lds(k_b3<C, K>, lds);
-    k_b1<C, K><<<grid, 64 * WPB, lds, s>>>(A);
+    const bool mfma = flm::supported(K, C);
+    if (mfma) flm::launch_b1(A, C, grid, s); else k_b1<C, K><<<grid, 64 * WPB, lds, s>>>(A);
     k_colsum<<<pdf_divup(b1_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, nw, b1_width<C>(), S1);
     A.sums = as_const(S1);
-    k_b2<C, K><<<grid, 64 * WPB, lds, s>>>(A);
+    if (mfma) flm::launch_b2(A, C, grid, s); else k_b2<C, K><<<grid, 64 * WPB, lds, s>>>(A);
     k_colsum<<<pdf_divup(b2_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, nw, b2_width<C>(), S2);
     A.sums = as_const(S2);   // B3: BN1-backward terms from B2, BN2-backward terms from B1
     A.sums2 = as_const(S1);
-    k_b3<C, K><<<grid, 64 * WPB, lds, s>>>(A);
+    if (mfma) flm::launch_b3(A, C, grid, s); else k_b3<C, K><<<grid, 64 * WPB, lds, s>>>(A);
     k_colsum<<<pdf_divup(b3_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, nw, b3_width<C>(), S3);
     A.sums = as_const(S3);
     k_b4<K><<<grid, 64 * WPB, 0, s>>>(A);

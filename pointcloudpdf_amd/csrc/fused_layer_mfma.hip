@@ -140,9 +140,428 @@ __global__ __launch_bounds__(64 * WPB) void k_p3(LayerArgs A) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ shared pieces (backward)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+// all-reduce over the 16 row-lanes of a DPP row (the 16 neighbours of the point)
+__device__ __forceinline__ float max16(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v)); v = fmaxf(v, dpp_f<0x141>(v)); v = fmaxf(v, dpp_f<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ float sum16(float v) {
+    v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v); v += dpp_f<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ const float *gp(cfloat_p p) { return (const float *)(uintptr_t)p; }
+
+// Attention branch of one point (16 rows): h, u = relu(BN2(h)), w = softmax over the rows of (u Ww2^T + bw2).
+// Lane (row, kq) holds hidden units {16 ob + 4 kq + e}; the MFMA D fragment of z^T = Ww2 u^T has the same index set.
+template <int NOB>
+struct AttnW {
+    f32x4 W2a[NOB][NOB];   // A operand of z^T: Ww2[16 ob + (l & 15)][16 jo + 4 kq + e]
+    f32x4 bw2[NOB], s2[NOB], t2[NOB];
+    __device__ __forceinline__ void load(const LayerArgs &A, int row, int kq) {
+        constexpr int CS = NOB * 16;
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) {
+#pragma unroll
+            for (int jo = 0; jo < NOB; ++jo) W2a[ob][jo] = ld4(gp(A.Ww2) + (ob * 16 + row) * CS + 16 * jo + 4 * kq);
+            bw2[ob] = ld4(gp(A.bw2) + 16 * ob + 4 * kq);
+            s2[ob] = ld4(gp(A.s2) + 16 * ob + 4 * kq);
+            t2[ob] = ld4(gp(A.t2) + 16 * ob + 4 * kq);
+        }
+    }
+    __device__ __forceinline__ void weights(const f32x4 *h, f32x4 *u, f32x4 *w) const {
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) u[ob] = relu4(h[ob] * s2[ob] + t2[ob]);
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) {
+            f32x4 z = zero4();
+#pragma unroll
+            for (int jo = 0; jo < NOB; ++jo)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z = __builtin_amdgcn_mfma_f32_16x16x4f32(W2a[ob][jo][e], u[jo][e], z, 0, 0, 0);
+            z += bw2[ob];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float m = max16(z[r]);
+                const float ex = __expf(z[r] - m);
+                w[ob][r] = ex / sum16(ex);
+            }
+        }
+    }
+};
+
+constexpr int TS = 68;   // row stride (floats) of the 16 x 64 transposition tiles
+
+// scatter-add the wave's 16 x 64 tile into rows rowid[] of `table`, lanes along channels (4 whole lines per instruction)
+__device__ __forceinline__ void scatter_tile(const float *tile, const int *rowid, float *table, int C, int c0, int lane) {
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr) {
+        const int dst = rowid[rr];
+        if (dst >= 0) pdf_atomic_add(table + (size_t)dst * C + c0 + lane, tile[rr * TS + lane]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ B1
+// partial row per wave: [sum g_y2 (CS) | sum g_y2*hhat (CS) | g_bw2 (CS) | g_Ww2 (CS*CS)]   (as fl::k_b1)
+template <int C>
+__global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
+    constexpr int CS = C / 8, NOB = CS / 16, NCHK = C / 64, GS = CS + 4, W = 3 * CS + CS * CS;
+    __shared__ __attribute__((aligned(16))) float cst[4 * C];            // Wp2 (3C) | bp2 (C)
+    __shared__ __attribute__((aligned(16))) float tiles[WPB][16 * TS];
+    __shared__ __attribute__((aligned(16))) float gzt[WPB][16 * GS], ut[WPB][16 * GS];
+    __shared__ int rowids[WPB][16];
+    for (int e = threadIdx.x; e < 3 * C; e += 64 * WPB) cst[e] = gp(A.Wp2)[e];
+    for (int e = threadIdx.x; e < C; e += 64 * WPB) cst[3 * C + e] = gp(A.bp2)[e];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4, wv = threadIdx.x >> 6;
+    const long wave_g = (long)blockIdx.x * WPB + wv, nwaves = (long)gridDim.x * WPB;
+    float *tile = tiles[wv], *gz_t = gzt[wv], *u_t = ut[wv];
+    int *rowid = rowids[wv];
+    AttnW<NOB> att;
+    att.load(A, row, kq);
+    f32x4 W2t[NOB][NOB], m2[NOB], r2[NOB];   // A operand of g_u^T = Ww2^T g_z^T: Ww2[16 jo + 4 kq + e][16 ub + (l & 15)]
+#pragma unroll
+    for (int ub = 0; ub < NOB; ++ub) {
+#pragma unroll
+        for (int jo = 0; jo < NOB; ++jo)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) W2t[ub][jo][e] = gp(A.Ww2)[(16 * jo + 4 * kq + e) * CS + 16 * ub + row];
+        m2[ub] = ld4(gp(A.mean) + 3 + C + 16 * ub + 4 * kq);
+        r2[ub] = ld4(gp(A.rstd) + 3 + C + 16 * ub + 4 * kq);
+    }
+    f32x4 sg[NOB], sgh[NOB], sgz[NOB], accw[NOB][NOB];
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+        sg[ob] = zero4(); sgh[ob] = zero4(); sgz[ob] = zero4();
+#pragma unroll
+        for (int ub = 0; ub < NOB; ++ub) accw[ob][ub] = zero4();
+    }
+    for (long i = wave_g; i < A.N; i += nwaves) {
+        const PRow R = load_prow(A, i, row);
+        if (kq == 0) rowid[row] = R.nb;
+        f32x4 h[NOB], u[NOB], w[NOB], gw[NOB];
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) { h[ob] = ld4(A.H + ((size_t)i * 16 + row) * CS + 16 * ob + 4 * kq); gw[ob] = zero4(); }
+        att.weights(h, u, w);
+#pragma unroll 1
+        for (int q = 0; q < NCHK; ++q) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int g = 4 * (4 * q + jj) + kq;   // channel 16 j + 4 kq + e  ->  hidden unit (c mod CS): block jj % NOB, same (kq, e)
+                const f32x4 go = ld4(A.gout + (size_t)i * C + 4 * g);
+                const f32x4 xv = R.nb >= 0 ? ld4(A.xv + (size_t)R.nb * C + 4 * g) : zero4();
+                const f32x4 pr = pos4(cst, C, g, R.t1n);
+                gw[jj % NOB] += go * (xv + pr);
+                *reinterpret_cast<f32x4 *>(tile + row * TS + 16 * jj + 4 * kq) = go * w[jj % NOB];
+            }
+            wave_sync();
+            scatter_tile(tile, rowid, A.gxv, C, 64 * q, lane);
+            wave_sync();
+        }
+        // softmax backward over the 16 rows, Linear(CS, CS) backward, ReLU / BN2 bookkeeping
+        f32x4 gz[NOB], gy2[NOB];
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dot = sum16(w[ob][r] * gw[ob][r]);
+                gz[ob][r] = w[ob][r] * (gw[ob][r] - dot);
+            }
+#pragma unroll
+        for (int ub = 0; ub < NOB; ++ub) {
+            f32x4 gu = zero4();
+#pragma unroll
+            for (int jo = 0; jo < NOB; ++jo)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gu = __builtin_amdgcn_mfma_f32_16x16x4f32(W2t[ub][jo][e], gz[jo][e], gu, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gy2[ub][r] = u[ub][r] > 0.f ? gu[r] : 0.f;
+            *reinterpret_cast<f32x4 *>(A.G2 + ((size_t)i * 16 + row) * CS + 16 * ub + 4 * kq) = gy2[ub];
+            sg[ub] += gy2[ub];
+            sgh[ub] += gy2[ub] * ((h[ub] - m2[ub]) * r2[ub]);
+            sgz[ub] += gz[ub];
+            *reinterpret_cast<f32x4 *>(gz_t + row * GS + 16 * ub + 4 * kq) = gz[ub];
+            *reinterpret_cast<f32x4 *>(u_t + row * GS + 16 * ub + 4 * kq) = u[ub];
+        }
+        wave_sync();
+        // g_Ww2[o][u'] += sum_rows g_z[row][o] u[row][u']  (reduction index = rows: operands re-read lanes-along-units)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float a_[NOB], b_[NOB];
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) { a_[ob] = gz_t[(4 * t + kq) * GS + 16 * ob + row]; b_[ob] = u_t[(4 * t + kq) * GS + 16 * ob + row]; }
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+                for (int ub = 0; ub < NOB; ++ub) accw[ob][ub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[ob], b_[ub], accw[ob][ub], 0, 0, 0);
+        }
+        wave_sync();
+    }
+    float *o = A.partial + wave_g * W;
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a = sg[ob][r], b = sgh[ob][r], d = sgz[ob][r];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); d += __shfl_xor(d, m, 64); }
+            if (row == 0) { o[16 * ob + 4 * kq + r] = a; o[CS + 16 * ob + 4 * kq + r] = b; o[2 * CS + 16 * ob + 4 * kq + r] = d; }
+        }
+#pragma unroll
+        for (int ub = 0; ub < NOB; ++ub)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[3 * CS + (16 * ob + 4 * kq + r) * CS + 16 * ub + row] = accw[ob][ub][r];
+    }
+}
+
+// g_h of the lane's hidden units from the stored G2 / H rows and the BN2-backward sums (`sums` = [sum g_y2 | sum g_y2*hhat])
+template <int C, int NOB>
+__device__ __forceinline__ void hidden_grad(const LayerArgs &A, const float *sums, long i, int row, int kq, f32x4 *gh, f32x4 *h_out = nullptr) {
+    constexpr int CS = C / 8;
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+        const int o = 16 * ob + 4 * kq;
+        const f32x4 h = ld4(A.H + ((size_t)i * 16 + row) * CS + o), g2 = ld4(A.G2 + ((size_t)i * 16 + row) * CS + o);
+        const f32x4 hhat = (h - ld4(gp(A.mean) + 3 + C + o)) * ld4(gp(A.rstd) + 3 + C + o);
+        gh[ob] = ld4(gp(A.s2) + o) * (g2 - ld4(sums + o) * A.inv_rows - hhat * (ld4(sums + CS + o) * A.inv_rows));
+        if (h_out) h_out[ob] = h;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ B2 (64-channel slabs)
+// partial row per wave-row (all slabs of one blockIdx.x write disjoint columns of the same rows):
+//   [sum g_y1 (C) | sum g_y1*rhat (C) | g_bw1 (CS) | g_Ww1 (CS*C)]   (as fl::k_b2)
+template <int C>
+__global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
+    constexpr int CS = C / 8, NOB = CS / 16, GS = CS + 4, WS = 68, W = 2 * C + CS + CS * C;
+    __shared__ __attribute__((aligned(16))) float cst[6 * C];
+    __shared__ __attribute__((aligned(16))) float wl[CS * WS];            // Ww1[:, slab]
+    __shared__ __attribute__((aligned(16))) float ght[WPB][16 * GS], v1t[WPB][16 * TS];
+    const int slab = blockIdx.y, c0 = 64 * slab;
+    for (int e = threadIdx.x; e < CS * 64; e += 64 * WPB) wl[(e / 64) * WS + e % 64] = gp(A.Ww1)[(size_t)(e / 64) * C + c0 + e % 64];
+    stage_consts<C>(cst, A);
+    const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4, wv = threadIdx.x >> 6;
+    const long wave_g = (long)blockIdx.x * WPB + wv, nwaves = (long)gridDim.x * WPB;
+    float *gh_t = ght[wv], *v1_t = v1t[wv];
+    f32x4 sg[4], sgr[4], sgh[NOB], accw[NOB][4], m1[4], r1[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        sg[jj] = zero4(); sgr[jj] = zero4();
+        m1[jj] = ld4(gp(A.mean) + 3 + c0 + 16 * jj + 4 * kq);
+        r1[jj] = ld4(gp(A.rstd) + 3 + c0 + 16 * jj + 4 * kq);
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) accw[ob][jj] = zero4();
+    }
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) sgh[ob] = zero4();
+    for (long i = wave_g; i < A.N; i += nwaves) {
+        const PRow R = load_prow(A, i, row);
+        f32x4 gh[NOB];
+        hidden_grad<C, NOB>(A, gp(A.sums), i, row, kq, gh);
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) {
+            sgh[ob] += gh[ob];
+            *reinterpret_cast<f32x4 *>(gh_t + row * GS + 16 * ob + 4 * kq) = gh[ob];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int g = 4 * (4 * slab + jj) + kq;
+            f32x4 acc = zero4();   // (Ww1^T g_h)[channel 16 j + 4 kq + reg][row]
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(16 * ob + 4 * kq + e) * WS + 16 * jj + row], gh[ob][e], acc, 0, 0, 0);
+            const f32x4 r = r4_of(A, cst, C, i, R, g);
+            const f32x4 y1 = r * ld4(cst + 4 * C + 4 * g) + ld4(cst + 5 * C + 4 * g);
+            f32x4 gy1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gy1[e] = y1[e] > 0.f ? acc[e] : 0.f;
+            sg[jj] += gy1;
+            sgr[jj] += gy1 * ((r - m1[jj]) * r1[jj]);
+            *reinterpret_cast<f32x4 *>(v1_t + row * TS + 16 * jj + 4 * kq) = relu4(y1);
+        }
+        wave_sync();
+        // g_Ww1[o][c] += sum_rows g_h[row][o] v1[row][c]
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float a_[NOB], b_[4];
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) a_[ob] = gh_t[(4 * t + kq) * GS + 16 * ob + row];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) b_[jj] = v1_t[(4 * t + kq) * TS + 16 * jj + row];
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) accw[ob][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_[ob], b_[jj], accw[ob][jj], 0, 0, 0);
+        }
+        wave_sync();
+    }
+    float *o = A.partial + wave_g * W;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a = sg[jj][r], b = sgr[jj][r];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+            if (row == 0) { o[c0 + 16 * jj + 4 * kq + r] = a; o[C + c0 + 16 * jj + 4 * kq + r] = b; }
+        }
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+        if (slab == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = sgh[ob][r];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) a += __shfl_xor(a, m, 64);
+                if (row == 0) o[2 * C + 16 * ob + 4 * kq + r] = a;
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[2 * C + CS + (size_t)(16 * ob + 4 * kq + r) * C + c0 + 16 * jj + row] = accw[ob][jj][r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ B3
+// partial row per wave: [sum g_yp (3) | sum g_yp*that (3) | pad 2 | g_bp2 (C) | g_Wp2 (C*3)]   (as fl::k_b3)
+template <int C>
+__global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
+    constexpr int CS = C / 8, NOB = CS / 16, NCHK = C / 64, WS = C + 4, W = 8 + 4 * C;
+    __shared__ __attribute__((aligned(16))) float cst[6 * C];
+    __shared__ __attribute__((aligned(16))) float wl[CS * WS];
+    __shared__ __attribute__((aligned(16))) float tiles[WPB][16 * TS];
+    __shared__ float t1ns[WPB][16 * 4];
+    __shared__ int rowids[WPB][16];
+    for (int e = threadIdx.x; e < CS * C; e += 64 * WPB) wl[(e / C) * WS + e % C] = gp(A.Ww1)[e];
+    stage_consts<C>(cst, A);
+    const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4, wv = threadIdx.x >> 6;
+    const long wave_g = (long)blockIdx.x * WPB + wv, nwaves = (long)gridDim.x * WPB;
+    float *tile = tiles[wv], *t1nt = t1ns[wv];
+    int *rowid = rowids[wv];
+    AttnW<NOB> att;
+    att.load(A, row, kq);
+    const float *S2 = gp(A.sums), *S1 = gp(A.sums2);   // [sum g_y1 (C) | sum g_y1*rhat (C)], [sum g_y2 | sum g_y2*hhat]
+    float sgp[3] = {0.f, 0.f, 0.f}, sgpt[3] = {0.f, 0.f, 0.f};
+    float *o = A.partial + wave_g * W;
+    // The 64-channel chunks are the OUTER loop (every chunk re-derives the cheap per-point quantities): the per-channel
+    // accumulators then are four scalars, and g_t1n (a sum over all channels) is accumulated in G3 by the owning lane.
+#pragma unroll 1
+    for (int q = 0; q < NCHK; ++q) {
+        float sbp2 = 0.f, awp2[3] = {0.f, 0.f, 0.f};
+        for (long i = wave_g; i < A.N; i += nwaves) {
+            const PRow R = load_prow(A, i, row);
+            if (kq == 0) { rowid[row] = R.nb; t1nt[row * 4 + 0] = R.t1n[0]; t1nt[row * 4 + 1] = R.t1n[1]; t1nt[row * 4 + 2] = R.t1n[2]; }
+            f32x4 gh[NOB], h[NOB], u[NOB], w[NOB];
+            hidden_grad<C, NOB>(A, S1, i, row, kq, gh, h);
+            att.weights(h, u, w);
+            float gt1n[3] = {0.f, 0.f, 0.f};
+            f32x4 gpr[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = 4 * q + jj, g = 4 * j + kq;
+                f32x4 acc = zero4();
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(16 * ob + 4 * kq + e) * WS + 16 * j + row], gh[ob][e], acc, 0, 0, 0);
+                const f32x4 r = r4_of(A, cst, C, i, R, g);
+                const f32x4 s1 = ld4(cst + 4 * C + 4 * g);
+                const f32x4 y1 = r * s1 + ld4(cst + 5 * C + 4 * g);
+                f32x4 gy1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gy1[e] = y1[e] > 0.f ? acc[e] : 0.f;
+                // BN1 backward: g_r = s1 * (g_y1 - mean(g_y1) - rhat * mean(g_y1 * rhat))
+                const f32x4 rhat = (r - ld4(gp(A.mean) + 3 + 4 * g)) * ld4(gp(A.rstd) + 3 + 4 * g);
+                const f32x4 gr = s1 * (gy1 - ld4(S2 + 4 * g) * A.inv_rows - rhat * (ld4(S2 + C + 4 * g) * A.inv_rows));
+                *reinterpret_cast<f32x4 *>(tile + row * TS + 16 * jj + 4 * kq) = gr;
+                gpr[jj] = gr + ld4(A.gout + (size_t)i * C + 4 * g) * w[jj % NOB];   // + the aggregation's share of p_r
+                const f32x4 w0 = ld4(cst + 12 * g), w1 = ld4(cst + 12 * g + 4), w2 = ld4(cst + 12 * g + 8);
+                const float wp[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0], w2[1], w2[2], w2[3]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    gt1n[0] += gpr[jj][e] * wp[3 * e]; gt1n[1] += gpr[jj][e] * wp[3 * e + 1]; gt1n[2] += gpr[jj][e] * wp[3 * e + 2];
+                }
+            }
+            wave_sync();
+            {   // lanes along channels: scatter g_xk, g_xq[i] = - sum_rows g_r
+                float acc = 0.f;
+#pragma unroll 4
+                for (int rr = 0; rr < 16; ++rr) {
+                    const float v = tile[rr * TS + lane];
+                    acc += v;
+                    const int dst = rowid[rr];
+                    if (dst >= 0) pdf_atomic_add(A.gxk + (size_t)dst * C + 64 * q + lane, v);
+                }
+                A.gxq[(size_t)i * C + 64 * q + lane] = -acc;
+            }
+            wave_sync();
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<f32x4 *>(tile + row * TS + 16 * jj + 4 * kq) = gpr[jj];
+            wave_sync();
+#pragma unroll 4
+            for (int rr = 0; rr < 16; ++rr) {   // g_bp2 / g_Wp2 of channel 64 q + lane
+                const float v = tile[rr * TS + lane];
+                sbp2 += v;
+                awp2[0] += v * t1nt[rr * 4 + 0]; awp2[1] += v * t1nt[rr * 4 + 1]; awp2[2] += v * t1nt[rr * 4 + 2];
+            }
+            wave_sync();
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                float v = gt1n[a];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (kq == 0) {
+                    float *g3 = A.G3 + ((size_t)i * 16 + row) * 3 + a;
+                    if (q > 0) v += *g3;
+                    if (q == NCHK - 1) {   // all channels seen: ReLU mask of BNp, BNp-backward sums
+                        v = R.t1n[a] > 0.f ? v : 0.f;
+                        sgp[a] += v;
+                        sgpt[a] += v * ((R.t1[a] - A.mean[a]) * A.rstd[a]);
+                    }
+                    *g3 = v;
+                }
+            }
+        }
+        o[8 + 64 * q + lane] = sbp2;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) o[8 + C + (size_t)(64 * q + lane) * 3 + a] = awp2[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float x = pdf_wave_sum_f32(sgp[a]), y = pdf_wave_sum_f32(sgpt[a]);
+        if (lane == 0) { o[a] = x; o[3 + a] = y; }
+    }
+    if (lane == 0) { o[6] = 0.f; o[7] = 0.f; }
+}
+
 void launch_p3(const LayerArgs &A, int c, bool stats, int grid, hipStream_t s) {
     if (c == 128) { if (stats) k_p3<128, true><<<grid, 64 * WPB, 0, s>>>(A); else k_p3<128, false><<<grid, 64 * WPB, 0, s>>>(A); }
     else          { if (stats) k_p3<256, true><<<grid, 64 * WPB, 0, s>>>(A); else k_p3<256, false><<<grid, 64 * WPB, 0, s>>>(A); }
+}
+
+
+void launch_b1(const LayerArgs &A, int c, int grid, hipStream_t s) {
+    if (c == 128) k_b1<128><<<grid, 64 * WPB, 0, s>>>(A); else k_b1<256><<<grid, 64 * WPB, 0, s>>>(A);
+}
+void launch_b2(const LayerArgs &A, int c, int grid, hipStream_t s) {
+    if (c == 128) k_b2<128><<<dim3(grid, 2), 64 * WPB, 0, s>>>(A); else k_b2<256><<<dim3(grid, 4), 64 * WPB, 0, s>>>(A);
+}
+void launch_b3(const LayerArgs &A, int c, int grid, hipStream_t s) {
+    if (c == 128) k_b3<128><<<grid, 64 * WPB, 0, s>>>(A); else k_b3<256><<<grid, 64 * WPB, 0, s>>>(A);
 }
 
 }  // namespace flm
