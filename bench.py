@@ -38,15 +38,17 @@ PMC_TRAFFIC_BYTES = {"farthest_point_sampling": (2 * 1357.0 + 2284.3) * 1024}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--points", type=int, default=100000, help="points per scene")
     ap.add_argument("--scenes", type=int, default=2, help="scenes per GPU (batch size per rank)")
     ap.add_argument("--pool", type=int, default=3, help="distinct batches per rank to rotate through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-points", type=int, default=16000, help="scene size of the bounded CPU-baseline sample")
     ap.add_argument("--amp", action="store_true", help="fp16 autocast around the step (reference enable_amp=True)")
-    ap.add_argument("--prefetch", type=int, default=3, help="geometry pre-pass depth in steps (0 = inline, serial)")
+    ap.add_argument("--prefetch", type=int, default=6,
+                    help="geometry pre-pass group: the pre-pass of the NEXT `prefetch` batches runs as one launch sequence on a side "
+                         "stream while the current group trains (0 = inline, serial)")
     ap.add_argument("--graph", type=int, default=0, help="replay fwd+bwd+SGD as one captured hipGraph (needs --prefetch > 0)")
     return ap.parse_args()
 
@@ -170,20 +172,37 @@ def main():
 
     from pointcloudpdf_amd.geometry import GeometryPrefetcher
 
-    prefetcher = GeometryPrefetcher(depth=args.prefetch) if args.prefetch > 0 else None
+    prefetcher = GeometryPrefetcher(depth=2) if args.prefetch > 0 else None   # two side streams, alternating groups
     tickets = {}
 
+    # Group boundaries sit at warmup + k * D, so the timed region queues exactly steps / D group pre-passes (one pre-pass
+    # per trained batch; the final fence drains the last one).  D = largest divisor of --steps <= --prefetch when there
+    # is one >= 4, else --prefetch itself (then the window holds ceil(steps / D) groups: more pre-pass work, never less).
+    D = args.prefetch
+    if D > 0:
+        divs = [d for d in range(4, D + 1) if args.steps % d == 0]
+        D = max(divs) if divs else D
+    phase = args.warmup % D if D > 0 else 0
+
+    def submit_range(lo, hi):
+        """One FPS / kNN launch sequence over the scenes of steps lo .. hi-1 (FPS is a chain of dependent arg-max steps,
+        one workgroup per scene: its latency is amortised over the group instead of being paid per step)."""
+        group = [pool[j % len(pool)] for j in range(lo, hi)]
+        for j, t in enumerate(prefetcher.submit_group(group)):
+            tickets[lo + j] = t
+
     def submit(i):
-        b = pool[i % len(pool)]
-        tickets[i] = prefetcher.submit(b["coord"], b["offset"], b["offset_host"])
+        """Called with i = step + D right after step's tables were fetched: queues the NEXT group at a boundary."""
+        if (i - phase) % D == 0:
+            submit_range(i, i + D)
 
     def one_step(i):
         batch = pool[i % len(pool)]
         data = dict(coord=batch["coord"], feat=batch["feat"], offset=batch["offset"],
                     offset_host=batch["offset_host"], segment=batch["segment"])
         if prefetcher is not None:
-            data["pdf_geometry"] = prefetcher.get(tickets.pop(i))  # pre-pass of THIS batch, launched `depth` steps ago
-            submit(i + args.prefetch)                             # every step launches exactly one pre-pass
+            data["pdf_geometry"] = prefetcher.get(tickets.pop(i))  # pre-pass of THIS batch, queued with its group
+            submit(i + D)                             # (acts once per group) every batch gets exactly one pre-pass
         opt.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=torch.float16, enabled=args.amp):
             out = module(data)
@@ -192,8 +211,10 @@ def main():
         return out
 
     if prefetcher is not None:
-        for i in range(args.prefetch):
-            submit(i)
+        b0 = phase if phase > 0 else D
+        submit_range(0, b0)
+        if phase > 0:
+            submit_range(b0, b0 + D)
 
     # ---- optional: the whole step (fwd + bwd + SGD) as ONE captured hipGraph.  The step issues ~3000 kernel launches
     # and is host-bound in eager mode; scene sizes are fixed, so the launch sequence is static.  Inputs and the
@@ -224,7 +245,7 @@ def main():
         def one_step(i):  # noqa: F811
             batch = pool[i % len(pool)]
             geom = prefetcher.get(tickets.pop(i))
-            submit(i + args.prefetch)
+            submit(i + D)
             for k in ("coord", "feat", "segment"):
                 static[k].copy_(batch[k])
             static_geom.load(geom)
@@ -300,7 +321,7 @@ def main():
                        "scenes_per_gpu": args.scenes, "points_per_scene": args.points, "parallelism": f"dp{world}"},
             "per_gpu_points_per_s": pts_per_step * args.steps / dt / world,
             "loss": loss,
-            "geometry_prefetch_depth": args.prefetch,
+            "geometry_prefetch_group": D,
             "hipgraph": bool(use_graph and graph is not None),
             "kernels": ks,
             "roofline": roof,

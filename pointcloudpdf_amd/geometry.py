@@ -176,6 +176,49 @@ class Geometry:
                     t.copy_(u)
         return self
 
+    def split(self, scene_counts):
+        """Per-batch Geometry objects of a pre-pass that was run over several batches at once (scenes of batch 0, then
+        batch 1, ...; ``scene_counts[b]`` scenes each).  Every op on this path works scene by scene, so the tables of a
+        batch are row slices of the group's tables with the index base of the batch subtracted -- bit-identical to a
+        pre-pass of the batch alone.  This is how FPS latency (a chain of ~25k dependent arg-max steps per scene, one
+        workgroup per scene) is amortised: one launch carries the scenes of ``len(scene_counts)`` upcoming steps."""
+        assert sum(scene_counts) == len(self.levels[0].o_host), "scene_counts must cover the group's scenes"
+        out, s0 = [], 0
+        for nsc in scene_counts:
+            s1 = s0 + nsc
+            g = Geometry.__new__(Geometry)
+            g.levels, g._memo = [], {}
+            rows = []  # (first row, end row) of this batch at every level
+            for lv in self.levels:
+                r0 = lv.o_host[s0 - 1] if s0 > 0 else 0
+                r1 = lv.o_host[s1 - 1]
+                rows.append((r0, r1))
+                o = lv.o[s0:s1]
+                g._add_level(lv.p[r0:r1], (o - r0) if r0 else o, [e - r0 for e in lv.o_host[s0:s1]])
+
+            def rebase(idx, base):
+                return idx if base == 0 else torch.where(idx >= 0, idx - base, idx)
+
+            for key, val in self._memo.items():
+                kind = key[0]
+                if kind == "sizes":
+                    g._memo[key] = val[s0:s1]
+                elif kind == "down":
+                    new_level, fps_idx = val
+                    q0, q1 = rows[new_level]
+                    g._memo[key] = (new_level, rebase(fps_idx[q0:q1], rows[key[1]][0]))
+                elif kind == "knn":
+                    (idx, dist2), (q0, q1) = val, rows[key[3]]
+                    g._memo[key] = (rebase(idx[q0:q1], rows[key[2]][0]), dist2[q0:q1])
+                elif kind == "interp":
+                    (idx, weight), (q0, q1) = val, rows[key[3]]
+                    g._memo[key] = (rebase(idx[q0:q1], rows[key[2]][0]), weight[q0:q1])
+                else:
+                    raise RuntimeError(f"Geometry.split: unknown memo entry {key}")
+            out.append(g)
+            s0 = s1
+        return out
+
     def tensors(self):
         out = [lv.p for lv in self.levels] + [lv.o for lv in self.levels]
         for v in self._memo.values():
@@ -206,6 +249,27 @@ class GeometryPrefetcher:
             done = torch.cuda.Event()
             done.record(stream)
         return geom, done, stream
+
+    def submit_group(self, batches):
+        """One pre-pass over the scenes of several upcoming batches (dicts with coord / offset / offset_host) -> one
+        ticket per batch.  See Geometry.split."""
+        stream = self.streams[self._n % len(self.streams)]
+        self._n += 1
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            coord = torch.cat([b["coord"] for b in batches])
+            counts, o_host, base = [], [], 0
+            for b in batches:
+                counts.append(len(b["offset_host"]))
+                o_host += [base + int(e) for e in b["offset_host"]]
+                base = o_host[-1]
+            bases = [0] + [o_host[sum(counts[:i + 1]) - 1] for i in range(len(batches) - 1)]
+            offset = torch.cat([b["offset"].to(torch.int32) + int(bs) for b, bs in zip(batches, bases)])
+            group = Geometry(coord, offset, o_host).precompute(**self.plan)
+            geoms = group.split(counts)
+            done = torch.cuda.Event()
+            done.record(stream)
+        return [(g, done, stream) for g in geoms]
 
     @staticmethod
     def get(ticket):

@@ -123,3 +123,35 @@ def test_untagged_coordinates_take_the_uncached_path(use_oracle):
     assert torch.equal(p1, p2) and torch.equal(o1, o2)
     helpers.assert_close(x1, x2, 1e-6)
     assert o1.tolist() == [150, 250]
+
+
+def test_geometry_split_matches_per_batch_prepass(use_oracle):
+    """A pre-pass over the scenes of several batches, split per batch, equals the pre-pass of each batch alone."""
+    from pointcloudpdf_amd.geometry import Geometry
+
+    batches = [synthetic.make_batch(sz, first_scene_id=10 * i, grid_size=0.3) for i, sz in enumerate([[700, 500], [640], [300, 900, 420]])]
+    plan = dict(strides=(1, 4, 4), nsamples=(8, 8, 8), interp_k=3, recognizer=True)
+    coord = torch.cat([b["coord"] for b in batches])
+    ends, base = [], 0
+    for b in batches:
+        ends += [base + e for e in b["offset_host"]]
+        base = ends[-1]
+    group = Geometry(coord, torch.tensor(ends, dtype=torch.int32), ends).precompute(**plan)
+    parts = group.split([len(b["offset_host"]) for b in batches])
+    assert len(parts) == len(batches)
+    for b, part in zip(batches, parts):
+        alone = Geometry(b["coord"], b["offset"], b["offset_host"]).precompute(**plan)
+        assert len(part.levels) == len(alone.levels) and set(part._memo) == set(alone._memo)
+        for la, lb in zip(part.levels, alone.levels):
+            assert torch.equal(la.p, lb.p) and torch.equal(la.o.int(), lb.o.int()) and la.o_host == lb.o_host and la.n_max == lb.n_max
+        for key, va in part._memo.items():
+            vb = alone._memo[key]
+            for ta, tb in zip(va if isinstance(va, tuple) else (va,), vb if isinstance(vb, tuple) else (vb,)):
+                if isinstance(ta, torch.Tensor):
+                    assert torch.equal(ta, tb), key
+                else:
+                    assert ta == tb, key
+        # the split geometry serves the memoised pointops calls of its own coordinate tensors
+        from pointcloudpdf_amd import pointops
+        idx, _ = pointops.knn_query(8, part.coord(1), part.offset(1), part.coord(1), part.offset(1))
+        assert torch.equal(idx, alone._memo[("knn", 8, 1, 1)][0])
