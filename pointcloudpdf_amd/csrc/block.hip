@@ -44,14 +44,14 @@ extern "C" int pdf_block_pre_forward(long n, int c, void *const *p, int training
 }
 
 // p[]: x, z1, coef1, W1, Wq, Wk, Wv, gxq, gxk, gxv                                  (inputs)
-//      gx, grads [dW1 (c*c) | dgamma1 (c) | dbeta1 (c) | {dW (c*c), db (c)} x q,k,v]   (outputs; grads zeroed here)
-//      dy (n*c), partial (pdf_bn_partial_floats(n, c)), sums (2c)                         (scratch)
+//      gx, grads [dW1 (c*c) | dbeta1 (c) | dgamma1 (c) | {dW (c*c), db (c)} x q,k,v]   (outputs; grads zeroed here)
+//      dy (n*c), partial (pdf_bn_partial_floats(n, c))                                    (scratch; p[14] unused)
 extern "C" int pdf_block_pre_backward(long n, int c, void *const *p, int training, void *stream) {
     if (n < 1 || !p) return PDF_ERR_BAD_ARG;
     const float *x = (const float *)p[0], *z1 = (const float *)p[1], *coef1 = (const float *)p[2], *W1 = (const float *)p[3];
-    float *gx = (float *)p[10], *grads = (float *)p[11], *dy = (float *)p[12], *partial = (float *)p[13], *sums = (float *)p[14];
+    float *gx = (float *)p[10], *grads = (float *)p[11], *dy = (float *)p[12], *partial = (float *)p[13];
     const long cc = (long)c * c;
-    float *dW1 = grads, *dg1 = grads + cc, *db1 = dg1 + c, *dqkv = db1 + c;
+    float *dW1 = grads, *db1 = grads + cc, *dqkv = db1 + 2 * c;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t he = hipMemsetAsync(grads, 0, sizeof(float) * (size_t)(cc + 2 * c + 3 * (cc + c)), s);
     if (he != hipSuccess) return (int)he;
@@ -62,12 +62,8 @@ extern "C" int pdf_block_pre_backward(long n, int c, void *const *p, int trainin
     float *ys[1] = {dy};
     e << pdf_rowlin_multi(n, c, c, 3, 1, gs, c, ws, 1, nullptr, nullptr, nullptr, 0, ys, c, 0, stream);
     e << pdf_rowlin_wgrad_multi(n, c, c, 3, gs, c, z1, c, coef1, coef1 + c, 1, dws, dbs, stream);
-    // bn1 backward in place on dy (elementwise: same index read and written)
-    e << pdf_bn_act_backward(n, c, dy, z1, nullptr, coef1, training, 1, partial, sums, dy, nullptr, stream);
-    he = hipMemcpyAsync(db1, sums, sizeof(float) * c, hipMemcpyDeviceToDevice, s);          // d beta
-    if (he != hipSuccess) return (int)he;
-    he = hipMemcpyAsync(dg1, sums + c, sizeof(float) * c, hipMemcpyDeviceToDevice, s);      // d gamma
-    if (he != hipSuccess) return (int)he;
+    // bn1 backward in place on dy (elementwise: same index read and written); its column sums ARE [d beta1 | d gamma1]
+    e << pdf_bn_act_backward(n, c, dy, z1, nullptr, coef1, training, 1, partial, db1, dy, nullptr, stream);
     e << pdf_rowlin_forward(n, c, c, dy, c, W1, 1, nullptr, nullptr, nullptr, 0, gx, c, 0, nullptr, stream);
     e << pdf_rowlin_wgrad(n, c, c, dy, c, x, c, nullptr, nullptr, 0, dW1, nullptr, stream);
     return e.rc;
@@ -90,32 +86,24 @@ extern "C" int pdf_block_post_forward(long n, int c, void *const *p, int trainin
 }
 
 // p[]: gy, t, x, z3, coef2, coef3, W3                                               (inputs)
-//      gt, gres, grads [dW3 (c*c) | dgamma2 | dbeta2 | dgamma3 | dbeta3]             (outputs; grads zeroed here)
-//      da (n*c), partial, sums (2c)                                                   (scratch)
+//      gt, gres, grads [dW3 (c*c) | dbeta2 | dgamma2 | dbeta3 | dgamma3]             (outputs; grads zeroed here)
+//      da (n*c), partial                                                              (scratch; p[12] unused)
 extern "C" int pdf_block_post_backward(long n, int c, void *const *p, int training, void *stream) {
     if (n < 1 || !p) return PDF_ERR_BAD_ARG;
     const float *gy = (const float *)p[0], *t = (const float *)p[1], *x = (const float *)p[2], *z3 = (const float *)p[3];
     const float *coef2 = (const float *)p[4], *coef3 = (const float *)p[5], *W3 = (const float *)p[6];
-    float *gt = (float *)p[7], *gres = (float *)p[8], *grads = (float *)p[9], *da = (float *)p[10], *partial = (float *)p[11], *sums = (float *)p[12];
+    float *gt = (float *)p[7], *gres = (float *)p[8], *grads = (float *)p[9], *da = (float *)p[10], *partial = (float *)p[11];
     const long cc = (long)c * c;
-    float *dW3 = grads, *dg2 = grads + cc, *db2 = dg2 + c, *dg3 = db2 + c, *db3 = dg3 + c;
+    float *dW3 = grads, *db2 = grads + cc, *db3 = db2 + 2 * c;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t he = hipMemsetAsync(grads, 0, sizeof(float) * (size_t)(cc + 4 * c), s);
     if (he != hipSuccess) return (int)he;
     Err e;
-    // bn3 backward: gz3 -> da (scratch), gres
-    e << pdf_bn_act_backward(n, c, gy, z3, x, coef3, training, 1, partial, sums, da, gres, stream);
-    he = hipMemcpyAsync(db3, sums, sizeof(float) * c, hipMemcpyDeviceToDevice, s);
-    if (he != hipSuccess) return (int)he;
-    he = hipMemcpyAsync(dg3, sums + c, sizeof(float) * c, hipMemcpyDeviceToDevice, s);
-    if (he != hipSuccess) return (int)he;
+    // bn3 backward: gz3 -> da (scratch), gres; column sums land in the gradient slots [d beta | d gamma]
+    e << pdf_bn_act_backward(n, c, gy, z3, x, coef3, training, 1, partial, db3, da, gres, stream);
     e << pdf_rowlin_wgrad(n, c, c, da, c, t, c, coef2, coef2 + c, 1, dW3, nullptr, stream);
     e << pdf_rowlin_forward(n, c, c, da, c, W3, 1, nullptr, nullptr, nullptr, 0, gt, c, 0, nullptr, stream);
     // bn2 backward in place on gt
-    e << pdf_bn_act_backward(n, c, gt, t, nullptr, coef2, training, 1, partial, sums, gt, nullptr, stream);
-    he = hipMemcpyAsync(db2, sums, sizeof(float) * c, hipMemcpyDeviceToDevice, s);
-    if (he != hipSuccess) return (int)he;
-    he = hipMemcpyAsync(dg2, sums + c, sizeof(float) * c, hipMemcpyDeviceToDevice, s);
-    if (he != hipSuccess) return (int)he;
+    e << pdf_bn_act_backward(n, c, gt, t, nullptr, coef2, training, 1, partial, db2, gt, nullptr, stream);
     return e.rc;
 }

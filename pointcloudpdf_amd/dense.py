@@ -13,6 +13,48 @@ _CHUNK = 2048
 _MIN_ROWS = 16384
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# BatchNorm step counters.  nn.BatchNorm increments ``num_batches_tracked`` once per training forward: one tiny kernel per
+# norm, ~80 launches per step on this model.  Inside ``deferred_counters()`` (the training step wraps its forward in it) the
+# increments are collected and applied with ONE multi-tensor add on exit; outside, every norm bumps its counter at once.
+# ------------------------------------------------------------------------------------------------------------------
+_pending_counters = None
+
+
+def bump_counters(counters):
+    counters = [c for c in counters if c is not None]
+    if not counters:
+        return
+    if _pending_counters is not None:
+        _pending_counters.extend(counters)
+    elif len(counters) == 1:
+        counters[0].add_(1)
+    else:
+        torch._foreach_add_(counters, 1)
+
+
+class deferred_counters:
+    def __enter__(self):
+        global _pending_counters
+        self._outer = _pending_counters
+        _pending_counters = []
+        return self
+
+    def __exit__(self, *exc):
+        global _pending_counters
+        mine, _pending_counters = _pending_counters, self._outer
+        if mine:
+            if self._outer is not None:
+                self._outer.extend(mine)
+            else:
+                by_dev = {}
+                for c in mine:
+                    by_dev.setdefault(c.device, []).append(c)
+                for cs in by_dev.values():
+                    torch._foreach_add_(cs, 1)
+        return False
+
+
 class _LinearSplitK(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -56,8 +98,8 @@ class _BnAct(torch.autograd.Function):
         training = bn.training or bn.running_mean is None
         y, coef = be.bn_act_forward(x, residual, weight.detach(), bias.detach(), bn.running_mean, bn.running_var, training,
                                     bn.eps, bn.momentum if bn.momentum is not None else 0.1, relu)
-        if training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
+        if training:
+            bump_counters([bn.num_batches_tracked])
         ctx.save_for_backward(x, residual if residual is not None else x.new_empty(0), coef)
         ctx.cfg = (training, relu, residual is not None)
         return y
@@ -133,7 +175,7 @@ class _BnReluLinear(torch.autograd.Function):
         else:
             coef = be.bn_coef(z, bn, training)
         if training:
-            bn.num_batches_tracked += 1
+            bump_counters([bn.num_batches_tracked])
         weights, biases = wb[0::2], wb[1::2]
         outs, pout = [], None
         for w, b in zip(weights, biases):
@@ -177,7 +219,7 @@ class _BnActPartial(torch.autograd.Function):
         else:
             coef = be.bn_coef(z, bn, training)
         if training:
-            bn.num_batches_tracked += 1
+            bump_counters([bn.num_batches_tracked])
         y = be.bn_apply(z, residual, coef, relu)
         ctx.save_for_backward(z, residual if residual is not None else z.new_empty(0), coef)
         ctx.cfg = (training, relu, residual is not None)
@@ -249,7 +291,7 @@ class _BlockPre(torch.autograd.Function):
         be.block_call("pre_backward", n, c, [x, z1, coef1, W1, Wq, Wk, Wv, gxq.contiguous(), gxk.contiguous(), gxv.contiguous(),
                                              gx, grads, dy, partial, sums], ctx.training)
         o = cc + 2 * c
-        out = [gx, grads[:cc].view(c, c), grads[cc:cc + c], grads[cc + c:cc + 2 * c]]
+        out = [gx, grads[:cc].view(c, c), grads[cc + c:cc + 2 * c], grads[cc:cc + c]]   # dW1, dgamma1, dbeta1 (buffer: dW1 | dbeta1 | dgamma1)
         for i in range(3):
             out += [grads[o + i * (cc + c): o + i * (cc + c) + cc].view(c, c), grads[o + i * (cc + c) + cc: o + (i + 1) * (cc + c)]]
         return (*out, None)
@@ -283,8 +325,9 @@ class _BlockPost(torch.autograd.Function):
         partial = e(int(be.lib.pdf_bn_partial_floats(n, c)))
         be.block_call("post_backward", n, c, [gy.contiguous(), t, x, z3, coef2, coef3, W3, gt, gres, grads, da, partial, sums],
                       ctx.training)
-        return (gt, gres, grads[cc:cc + c], grads[cc + c:cc + 2 * c], grads[:cc].view(c, c), grads[cc + 2 * c:cc + 3 * c],
-                grads[cc + 3 * c:cc + 4 * c], None)
+        # buffer: dW3 | dbeta2 | dgamma2 | dbeta3 | dgamma3 ; forward args: t, x, g2, b2, W3, g3, b3
+        return (gt, gres, grads[cc + c:cc + 2 * c], grads[cc:cc + c], grads[:cc].view(c, c), grads[cc + 3 * c:cc + 4 * c],
+                grads[cc + 2 * c:cc + 3 * c], None)
 
 
 def bottleneck(blk, p, x, o):
@@ -295,5 +338,5 @@ def bottleneck(blk, p, x, o):
     a = t.attend(p, x, o, xq, xk, xv)
     y = _BlockPost.apply(a.contiguous(), x, blk.bn2.weight, blk.bn2.bias, blk.linear3.weight, blk.bn3.weight, blk.bn3.bias, blk)
     if blk.training:
-        torch._foreach_add_([blk.bn1.num_batches_tracked, blk.bn2.num_batches_tracked, blk.bn3.num_batches_tracked], 1)
+        bump_counters([blk.bn1.num_batches_tracked, blk.bn2.num_batches_tracked, blk.bn3.num_batches_tracked])
     return y

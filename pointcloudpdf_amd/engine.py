@@ -9,6 +9,8 @@ Whole scenes are the sharding unit: each rank runs its own scenes, gradients are
 import os
 
 import torch
+
+from . import dense
 import torch.nn as nn
 
 from . import point_transformer, recognizer, segmentor  # noqa: F401  (registers the classes)
@@ -49,7 +51,7 @@ class OpenSegStep(nn.Module):
         input_dict = dict(batch)
         if "segment_known" in input_dict:
             input_dict["segment"] = input_dict["segment_known"]
-        with self.hooks:
+        with self.hooks, dense.deferred_counters():   # BatchNorm step counters: one multi-tensor add per step
             out = self.model(input_dict)
             rec = self.recognizer(input_dict)
         loss = out["loss"]

@@ -80,8 +80,7 @@ class _FusedPTLayer(torch.autograd.Function):
         out, bn, saved, H = be.pt_layer_forward(xq.contiguous(), xk.contiguous(), xv.contiguous(), p, idx, weights,
                                                 bn_params, bn_buffers, training, norms[0].eps, norms[0].momentum)
         if training:
-            for n in norms:
-                n.num_batches_tracked += 1
+            dense.bump_counters([n.num_batches_tracked for n in norms])
         ctx.save_for_backward(xq, xk, xv, p, idx, bn, saved, H, *weights)
         ctx.training = training
         return out
