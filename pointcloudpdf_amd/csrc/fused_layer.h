@@ -38,7 +38,9 @@ struct LayerArgs {
 namespace flm {
 // matrix-core variants (fused_layer_mfma.hip); `grid` blocks of 64 * WPB threads, partial rows = grid * WPB
 bool supported(int nsample, int c);
+void launch_p2(const fl::LayerArgs &A, int c, int grid, hipStream_t s);
 void launch_p3(const fl::LayerArgs &A, int c, bool stats, int grid, hipStream_t s);
+void launch_p4(const fl::LayerArgs &A, int c, int grid, hipStream_t s);
 void launch_b1(const fl::LayerArgs &A, int c, int grid, hipStream_t s);
 void launch_b2(const fl::LayerArgs &A, int c, int grid, hipStream_t s);
 void launch_b3(const fl::LayerArgs &A, int c, int grid, hipStream_t s);

@@ -930,7 +930,8 @@ extern "C" long pdf_pt_layer_partial_floats(int n, int nsample, int c) {
 }
 
 extern "C" int pdf_pt_layer_supported(int nsample, int c) {
-    return ((nsample == 8 || nsample == 16) && (c == 32 || c == 64 || c == 128)) || (nsample == 16 && c == 256);  // c == 512 is instantiated but not yet validated
+    return ((nsample == 8 || nsample == 16) && (c == 32 || c == 64 || c == 128)) || (nsample == 16 && c == 256) ||
+           (c == 512 && flm::supported(nsample, c));   // C = 512: matrix-core passes only (fused_layer_mfma.hip)
 }
 
 namespace fl {
@@ -955,7 +956,7 @@ int forward_impl(LayerArgs A, int training, float eps, float momentum, const flo
         allow_lds(k_p4<C, K>, lds);
         if (flm::supported(K, C)) flm::launch_p3(A, C, false, grid, s);
         else k_p3<C, K, false><<<grid, 64 * WPB, lds, s>>>(A);
-        k_p4<C, K><<<grid, 64 * WPB, lds, s>>>(A);
+        if (flm::supported(K, C)) flm::launch_p4(A, C, grid, s); else k_p4<C, K><<<grid, 64 * WPB, lds, s>>>(A);
         return pdf_launch_status();
     }
     constexpr int T = 3 + C + CS;   // saved = [mean: p(3) | 1(C) | 2(CS)] [rstd: same order]  (the layout the backward kernels index)
@@ -965,12 +966,12 @@ int forward_impl(LayerArgs A, int training, float eps, float momentum, const flo
     allow_lds(k_p4<C, K>, lds);
     k_p1<K><<<grid, 64 * WPB, 0, s>>>(A);
     k_bn_finalize<<<1, RED_THREADS, 0, s>>>(A.partial, nw, 3, (double)rows, bn_params[0], bn_params[1], eps, momentum, bn_buffers[0], bn_buffers[1], sp, tp, mp, rp);
-    k_p2<C, K><<<grid, 64 * WPB, lds, s>>>(A);
+    if (flm::supported(K, C)) flm::launch_p2(A, C, grid, s); else k_p2<C, K><<<grid, 64 * WPB, lds, s>>>(A);
     k_bn_finalize<<<pdf_divup(C, 16), RED_THREADS, 0, s>>>(A.partial, nw, C, (double)rows, bn_params[2], bn_params[3], eps, momentum, bn_buffers[2], bn_buffers[3], s1, t1, m1, r1);
     if (flm::supported(K, C)) flm::launch_p3(A, C, true, grid, s);
     else k_p3<C, K, true><<<grid, 64 * WPB, lds, s>>>(A);
     k_bn_finalize<<<pdf_divup(CS, 16), RED_THREADS, 0, s>>>(A.partial, nw, CS, (double)rows, bn_params[4], bn_params[5], eps, momentum, bn_buffers[4], bn_buffers[5], s2, t2, m2, r2);
-    k_p4<C, K><<<grid, 64 * WPB, lds, s>>>(A);
+    if (flm::supported(K, C)) flm::launch_p4(A, C, grid, s); else k_p4<C, K><<<grid, 64 * WPB, lds, s>>>(A);
     return pdf_launch_status();
 }
 

@@ -23,20 +23,52 @@ using fl::LayerArgs;
 using fl::WPB;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-bool supported(int nsample, int c) { return nsample == 16 && (c == 128 || c == 256) && getenv("PDFOPS_PT_NO_MFMA") == nullptr; }
+bool supported(int nsample, int c) {
+    return nsample == 16 && (c == 128 || c == 256 || c == 512) && getenv("PDFOPS_PT_NO_MFMA") == nullptr;
+}
 
 __device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ void st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 __device__ __forceinline__ f32x4 relu4(f32x4 v) { return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)}; }
+__device__ __forceinline__ const float *gp(cfloat_p p) { return (const float *)(uintptr_t)p; }
 
-// Block-wide LDS copy of the per-channel constants: [Wp2 (3C: channel-major, 3 per channel) | bp2 (C) | s1 (C) | t1 (C)]
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+// all-reduce over the 16 row-lanes of a DPP row (the 16 neighbours of the point)
+__device__ __forceinline__ float max16(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v)); v = fmaxf(v, dpp_f<0x141>(v)); v = fmaxf(v, dpp_f<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ float sum16(float v) {
+    v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v); v += dpp_f<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- dynamic LDS layout (floats).  cst = per-channel constants [Wp2 (3C, channel-major) | bp2 (C) | s1 (C) | t1 (C)];
+// W2 = padded copy of Ww2 (row stride CS + 4); TS = row stride of the 16 x 64 transposition tiles.
+constexpr int TS = 68;
+__host__ __device__ constexpr int w2_floats(int c) { return (c / 8) * (c / 8 + 4); }
+
 template <int C>
-__device__ __forceinline__ void stage_consts(float *cst, const LayerArgs &A) {
-    const float *wp2 = (const float *)(uintptr_t)A.Wp2, *bp2 = (const float *)(uintptr_t)A.bp2;
-    const float *s1 = (const float *)(uintptr_t)A.s1, *t1 = (const float *)(uintptr_t)A.t1;
-    for (int e = threadIdx.x; e < 3 * C; e += 64 * WPB) cst[e] = wp2[e];
-    for (int e = threadIdx.x; e < C; e += 64 * WPB) { cst[3 * C + e] = bp2[e]; cst[4 * C + e] = s1[e]; cst[5 * C + e] = t1[e]; }
-    __syncthreads();
+__device__ __forceinline__ void stage_consts(float *cst, const LayerArgs &A, bool with_bn1) {
+    for (int e = threadIdx.x; e < 3 * C; e += 64 * WPB) cst[e] = gp(A.Wp2)[e];
+    for (int e = threadIdx.x; e < C; e += 64 * WPB) {
+        cst[3 * C + e] = gp(A.bp2)[e];
+        if (with_bn1) { cst[4 * C + e] = gp(A.s1)[e]; cst[5 * C + e] = gp(A.t1)[e]; }
+    }
+}
+template <int C>
+__device__ __forceinline__ void stage_w2(float *w2, const LayerArgs &A) {
+    constexpr int CS = C / 8;
+    for (int e = threadIdx.x; e < CS * CS; e += 64 * WPB) w2[(e / CS) * (CS + 4) + e % CS] = gp(A.Ww2)[e];
 }
 
 // One point's 16 neighbour rows: geometry branch of the lane's row (3-channel, cheap, replicated over the 4 kq lanes)
@@ -78,27 +110,82 @@ __device__ __forceinline__ f32x4 r4_of(const LayerArgs &A, const float *cst, int
     return (xk - xq) + pos4(cst, C, g, R.t1n);
 }
 
+// Attention branch of one point (16 rows): u = relu(BN2(h)), w = softmax over the rows of (u Ww2^T + bw2).
+// Lane (row, kq) holds hidden units {16 ob + 4 kq + e}; the MFMA D fragment of z^T = Ww2 u^T has the same index set.
+template <int NOB>
+__device__ __forceinline__ void attn_weights(const LayerArgs &A, const float *w2, int row, int kq, const f32x4 *h, f32x4 *u, f32x4 *w) {
+    constexpr int CS = NOB * 16, WS2 = CS + 4;
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) u[ob] = relu4(h[ob] * ld4(gp(A.s2) + 16 * ob + 4 * kq) + ld4(gp(A.t2) + 16 * ob + 4 * kq));
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+        f32x4 z = zero4();
+#pragma unroll
+        for (int jo = 0; jo < NOB; ++jo) {
+            const f32x4 a = ld4(w2 + (ob * 16 + row) * WS2 + 16 * jo + 4 * kq);   // A operand: Ww2[16 ob + (l & 15)][16 jo + 4 kq + e]
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], u[jo][e], z, 0, 0, 0);
+        }
+        z += ld4(gp(A.bw2) + 16 * ob + 4 * kq);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float m = max16(z[r]);
+            const float ex = __expf(z[r] - m);
+            w[ob][r] = ex / sum16(ex);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ P2: stats of r (slabs)
+// partial row per wave-row: [sum r (C) | sum r^2 (C)]; slab y writes channels [64 y, 64 y + 64)
+template <int C>
+__global__ __launch_bounds__(64 * WPB) void k_p2(LayerArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *cst = lds;
+    stage_consts<C>(cst, A, false);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
+    const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
+    const int c0 = 64 * blockIdx.y;
+    f32x4 s[4], ss[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) { s[jj] = zero4(); ss[jj] = zero4(); }
+    for (long i = wave_g; i < A.N; i += nwaves) {
+        const PRow R = load_prow(A, i, row);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const f32x4 r = r4_of(A, cst, C, i, R, 4 * (4 * (int)blockIdx.y + jj) + kq);
+            s[jj] += r;
+            ss[jj] += r * r;
+        }
+    }
+    float *o = A.partial + wave_g * 2 * C;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = s[jj][e], b = ss[jj][e];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+            if (row == 0) { o[c0 + 16 * jj + 4 * kq + e] = a; o[C + c0 + 16 * jj + 4 * kq + e] = b; }
+        }
+}
+
 // ------------------------------------------------------------------------------------------------ P3: h (+ stats of h)
 template <int C, bool STATS>
 __global__ __launch_bounds__(64 * WPB) void k_p3(LayerArgs A) {
     constexpr int CS = C / 8, NJ = C / 16, NOB = CS / 16, WS = C + 4;   // WS: padded row stride of the Ww1 copy
-    __shared__ __attribute__((aligned(16))) float cst[6 * C];
-    __shared__ __attribute__((aligned(16))) float wl[CS * WS];
-    {
-        const float *ww1 = (const float *)(uintptr_t)A.Ww1;
-        for (int e = threadIdx.x; e < CS * C; e += 64 * WPB) wl[(e / C) * WS + e % C] = ww1[e];
-    }
-    stage_consts<C>(cst, A);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *cst = lds, *wl = lds + 6 * C;
+    for (int e = threadIdx.x; e < CS * C; e += 64 * WPB) wl[(e / C) * WS + e % C] = gp(A.Ww1)[e];
+    stage_consts<C>(cst, A, true);
+    __syncthreads();
     const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
     const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
-    const float *bw1 = (const float *)(uintptr_t)A.bw1;
     const float *wa = wl + row * WS + 4 * kq;   // A operand (hidden unit ob*16 + (l & 15), k = kq): wa[ob * 16 * WS + 16 j ..+4]
-    f32x4 b4[NOB];
+    f32x4 b4[NOB], s4[NOB], ss4[NOB];
 #pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) b4[ob] = ld4(bw1 + ob * 16 + 4 * kq);
-    f32x4 s4[NOB], ss4[NOB];
-#pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) { s4[ob] = zero4(); ss4[ob] = zero4(); }
+    for (int ob = 0; ob < NOB; ++ob) { b4[ob] = ld4(gp(A.bw1) + ob * 16 + 4 * kq); s4[ob] = zero4(); ss4[ob] = zero4(); }
     for (long i = wave_g; i < A.N; i += nwaves) {
         const PRow R = load_prow(A, i, row);
         f32x4 acc[NOB];
@@ -120,7 +207,7 @@ __global__ __launch_bounds__(64 * WPB) void k_p3(LayerArgs A) {
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) {
             const f32x4 h = acc[ob] + b4[ob];   // h[row][ob*16 + 4 kq + reg]
-            *reinterpret_cast<f32x4 *>(A.H + ((size_t)i * 16 + row) * CS + ob * 16 + 4 * kq) = h;
+            st4(A.H + ((size_t)i * 16 + row) * CS + ob * 16 + 4 * kq, h);
             if (STATS) { s4[ob] += h; ss4[ob] += h * h; }
         }
     }
@@ -140,67 +227,39 @@ __global__ __launch_bounds__(64 * WPB) void k_p3(LayerArgs A) {
     }
 }
 
-
-// ------------------------------------------------------------------------------------------------ shared pieces (backward)
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xf, 0xf, false));
-}
-// all-reduce over the 16 row-lanes of a DPP row (the 16 neighbours of the point)
-__device__ __forceinline__ float max16(float v) {
-    v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v)); v = fmaxf(v, dpp_f<0x141>(v)); v = fmaxf(v, dpp_f<0x140>(v));
-    return v;
-}
-__device__ __forceinline__ float sum16(float v) {
-    v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v); v += dpp_f<0x140>(v);
-    return v;
-}
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-__device__ __forceinline__ const float *gp(cfloat_p p) { return (const float *)(uintptr_t)p; }
-
-// Attention branch of one point (16 rows): h, u = relu(BN2(h)), w = softmax over the rows of (u Ww2^T + bw2).
-// Lane (row, kq) holds hidden units {16 ob + 4 kq + e}; the MFMA D fragment of z^T = Ww2 u^T has the same index set.
-template <int NOB>
-struct AttnW {
-    f32x4 W2a[NOB][NOB];   // A operand of z^T: Ww2[16 ob + (l & 15)][16 jo + 4 kq + e]
-    f32x4 bw2[NOB], s2[NOB], t2[NOB];
-    __device__ __forceinline__ void load(const LayerArgs &A, int row, int kq) {
-        constexpr int CS = NOB * 16;
+// ------------------------------------------------------------------------------------------------ P4: aggregation
+// out[i][c] = sum_rows (x_v[nb][c] + p_r[c]) * w[row][c mod CS]
+template <int C>
+__global__ __launch_bounds__(64 * WPB) void k_p4(LayerArgs A) {
+    constexpr int CS = C / 8, NJ = C / 16, NOB = CS / 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *cst = lds, *w2 = lds + 4 * C;
+    stage_consts<C>(cst, A, false);
+    stage_w2<C>(w2, A);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
+    const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
+    for (long i = wave_g; i < A.N; i += nwaves) {
+        const PRow R = load_prow(A, i, row);
+        f32x4 h[NOB], u[NOB], w[NOB];
 #pragma unroll
-        for (int ob = 0; ob < NOB; ++ob) {
+        for (int ob = 0; ob < NOB; ++ob) h[ob] = ld4(A.H + ((size_t)i * 16 + row) * CS + 16 * ob + 4 * kq);
+        attn_weights<NOB>(A, w2, row, kq, h, u, w);
+#pragma unroll 1
+        for (int j0 = 0; j0 < NJ; j0 += NOB) {
 #pragma unroll
-            for (int jo = 0; jo < NOB; ++jo) W2a[ob][jo] = ld4(gp(A.Ww2) + (ob * 16 + row) * CS + 16 * jo + 4 * kq);
-            bw2[ob] = ld4(gp(A.bw2) + 16 * ob + 4 * kq);
-            s2[ob] = ld4(gp(A.s2) + 16 * ob + 4 * kq);
-            t2[ob] = ld4(gp(A.t2) + 16 * ob + 4 * kq);
-        }
-    }
-    __device__ __forceinline__ void weights(const f32x4 *h, f32x4 *u, f32x4 *w) const {
+            for (int jo = 0; jo < NOB; ++jo) {   // channel 16 j + 4 kq + e -> hidden unit block j % NOB == jo
+                const int g = 4 * (j0 + jo) + kq;
+                const f32x4 xv = R.nb >= 0 ? ld4(A.xv + (size_t)R.nb * C + 4 * g) : zero4();
+                const f32x4 v = (xv + pos4(cst, C, g, R.t1n)) * w[jo];
+                f32x4 t;
 #pragma unroll
-        for (int ob = 0; ob < NOB; ++ob) u[ob] = relu4(h[ob] * s2[ob] + t2[ob]);
-#pragma unroll
-        for (int ob = 0; ob < NOB; ++ob) {
-            f32x4 z = zero4();
-#pragma unroll
-            for (int jo = 0; jo < NOB; ++jo)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) z = __builtin_amdgcn_mfma_f32_16x16x4f32(W2a[ob][jo][e], u[jo][e], z, 0, 0, 0);
-            z += bw2[ob];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float m = max16(z[r]);
-                const float ex = __expf(z[r] - m);
-                w[ob][r] = ex / sum16(ex);
+                for (int e = 0; e < 4; ++e) t[e] = sum16(v[e]);
+                if (row == 0) st4(A.out + (size_t)i * C + 4 * g, t);
             }
         }
     }
-};
-
-constexpr int TS = 68;   // row stride (floats) of the 16 x 64 transposition tiles
+}
 
 // scatter-add the wave's 16 x 64 tile into rows rowid[] of `table`, lanes along channels (4 whole lines per instruction)
 __device__ __forceinline__ void scatter_tile(const float *tile, const int *rowid, float *table, int C, int c0, int lane) {
@@ -215,30 +274,18 @@ __device__ __forceinline__ void scatter_tile(const float *tile, const int *rowid
 // partial row per wave: [sum g_y2 (CS) | sum g_y2*hhat (CS) | g_bw2 (CS) | g_Ww2 (CS*CS)]   (as fl::k_b1)
 template <int C>
 __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
-    constexpr int CS = C / 8, NOB = CS / 16, NCHK = C / 64, GS = CS + 4, W = 3 * CS + CS * CS;
-    __shared__ __attribute__((aligned(16))) float cst[4 * C];            // Wp2 (3C) | bp2 (C)
-    __shared__ __attribute__((aligned(16))) float tiles[WPB][16 * TS];
-    __shared__ __attribute__((aligned(16))) float gzt[WPB][16 * GS], ut[WPB][16 * GS];
-    __shared__ int rowids[WPB][16];
-    for (int e = threadIdx.x; e < 3 * C; e += 64 * WPB) cst[e] = gp(A.Wp2)[e];
-    for (int e = threadIdx.x; e < C; e += 64 * WPB) cst[3 * C + e] = gp(A.bp2)[e];
+    constexpr int CS = C / 8, NOB = CS / 16, NCHK = C / 64, GS = CS + 4, WS2 = CS + 4, W = 3 * CS + CS * CS;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *cst = lds, *w2 = cst + 4 * C;                                  // Wp2 (3C) | bp2 (C); padded Ww2
+    const int wv = threadIdx.x >> 6;
+    float *tile = w2 + w2_floats(C) + wv * 16 * TS;
+    float *gz_t = w2 + w2_floats(C) + WPB * 16 * TS + wv * 16 * GS, *u_t = gz_t + WPB * 16 * GS;
+    int *rowid = reinterpret_cast<int *>(w2 + w2_floats(C) + WPB * 16 * TS + 2 * WPB * 16 * GS) + wv * 16;
+    stage_consts<C>(cst, A, false);
+    stage_w2<C>(w2, A);
     __syncthreads();
-    const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
     const long wave_g = (long)blockIdx.x * WPB + wv, nwaves = (long)gridDim.x * WPB;
-    float *tile = tiles[wv], *gz_t = gzt[wv], *u_t = ut[wv];
-    int *rowid = rowids[wv];
-    AttnW<NOB> att;
-    att.load(A, row, kq);
-    f32x4 W2t[NOB][NOB], m2[NOB], r2[NOB];   // A operand of g_u^T = Ww2^T g_z^T: Ww2[16 jo + 4 kq + e][16 ub + (l & 15)]
-#pragma unroll
-    for (int ub = 0; ub < NOB; ++ub) {
-#pragma unroll
-        for (int jo = 0; jo < NOB; ++jo)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) W2t[ub][jo][e] = gp(A.Ww2)[(16 * jo + 4 * kq + e) * CS + 16 * ub + row];
-        m2[ub] = ld4(gp(A.mean) + 3 + C + 16 * ub + 4 * kq);
-        r2[ub] = ld4(gp(A.rstd) + 3 + C + 16 * ub + 4 * kq);
-    }
     f32x4 sg[NOB], sgh[NOB], sgz[NOB], accw[NOB][NOB];
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) {
@@ -252,7 +299,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
         f32x4 h[NOB], u[NOB], w[NOB], gw[NOB];
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) { h[ob] = ld4(A.H + ((size_t)i * 16 + row) * CS + 16 * ob + 4 * kq); gw[ob] = zero4(); }
-        att.weights(h, u, w);
+        attn_weights<NOB>(A, w2, row, kq, h, u, w);
 #pragma unroll 1
         for (int q = 0; q < NCHK; ++q) {
 #pragma unroll
@@ -262,36 +309,39 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
                 const f32x4 xv = R.nb >= 0 ? ld4(A.xv + (size_t)R.nb * C + 4 * g) : zero4();
                 const f32x4 pr = pos4(cst, C, g, R.t1n);
                 gw[jj % NOB] += go * (xv + pr);
-                *reinterpret_cast<f32x4 *>(tile + row * TS + 16 * jj + 4 * kq) = go * w[jj % NOB];
+                st4(tile + row * TS + 16 * jj + 4 * kq, go * w[jj % NOB]);
             }
             wave_sync();
             scatter_tile(tile, rowid, A.gxv, C, 64 * q, lane);
             wave_sync();
         }
         // softmax backward over the 16 rows, Linear(CS, CS) backward, ReLU / BN2 bookkeeping
-        f32x4 gz[NOB], gy2[NOB];
+        f32x4 gz[NOB];
 #pragma unroll
-        for (int ob = 0; ob < NOB; ++ob)
+        for (int ob = 0; ob < NOB; ++ob) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float dot = sum16(w[ob][r] * gw[ob][r]);
                 gz[ob][r] = w[ob][r] * (gw[ob][r] - dot);
             }
+            sgz[ob] += gz[ob];
+            st4(gz_t + row * GS + 16 * ob + 4 * kq, gz[ob]);
+            st4(u_t + row * GS + 16 * ob + 4 * kq, u[ob]);
+        }
 #pragma unroll
         for (int ub = 0; ub < NOB; ++ub) {
-            f32x4 gu = zero4();
+            f32x4 gu = zero4();   // g_u^T = Ww2^T g_z^T: A operand Ww2[16 jo + 4 kq + e][16 ub + (l & 15)]
 #pragma unroll
             for (int jo = 0; jo < NOB; ++jo)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) gu = __builtin_amdgcn_mfma_f32_16x16x4f32(W2t[ub][jo][e], gz[jo][e], gu, 0, 0, 0);
+                for (int e = 0; e < 4; ++e)
+                    gu = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[(16 * jo + 4 * kq + e) * WS2 + 16 * ub + row], gz[jo][e], gu, 0, 0, 0);
+            f32x4 gy2;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gy2[ub][r] = u[ub][r] > 0.f ? gu[r] : 0.f;
-            *reinterpret_cast<f32x4 *>(A.G2 + ((size_t)i * 16 + row) * CS + 16 * ub + 4 * kq) = gy2[ub];
-            sg[ub] += gy2[ub];
-            sgh[ub] += gy2[ub] * ((h[ub] - m2[ub]) * r2[ub]);
-            sgz[ub] += gz[ub];
-            *reinterpret_cast<f32x4 *>(gz_t + row * GS + 16 * ub + 4 * kq) = gz[ub];
-            *reinterpret_cast<f32x4 *>(u_t + row * GS + 16 * ub + 4 * kq) = u[ub];
+            for (int r = 0; r < 4; ++r) gy2[r] = u[ub][r] > 0.f ? gu[r] : 0.f;
+            st4(A.G2 + ((size_t)i * 16 + row) * CS + 16 * ub + 4 * kq, gy2);
+            sg[ub] += gy2;
+            sgh[ub] += gy2 * ((h[ub] - ld4(gp(A.mean) + 3 + C + 16 * ub + 4 * kq)) * ld4(gp(A.rstd) + 3 + C + 16 * ub + 4 * kq));
         }
         wave_sync();
         // g_Ww2[o][u'] += sum_rows g_z[row][o] u[row][u']  (reduction index = rows: operands re-read lanes-along-units)
@@ -344,15 +394,16 @@ __device__ __forceinline__ void hidden_grad(const LayerArgs &A, const float *sum
 template <int C>
 __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
     constexpr int CS = C / 8, NOB = CS / 16, GS = CS + 4, WS = 68, W = 2 * C + CS + CS * C;
-    __shared__ __attribute__((aligned(16))) float cst[6 * C];
-    __shared__ __attribute__((aligned(16))) float wl[CS * WS];            // Ww1[:, slab]
-    __shared__ __attribute__((aligned(16))) float ght[WPB][16 * GS], v1t[WPB][16 * TS];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wv = threadIdx.x >> 6;
+    float *cst = lds, *wl = cst + 6 * C;                                   // Ww1[:, slab], row stride 68
+    float *gh_t = wl + CS * WS + wv * 16 * GS, *v1_t = wl + CS * WS + WPB * 16 * GS + wv * 16 * TS;
     const int slab = blockIdx.y, c0 = 64 * slab;
     for (int e = threadIdx.x; e < CS * 64; e += 64 * WPB) wl[(e / 64) * WS + e % 64] = gp(A.Ww1)[(size_t)(e / 64) * C + c0 + e % 64];
-    stage_consts<C>(cst, A);
-    const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4, wv = threadIdx.x >> 6;
+    stage_consts<C>(cst, A, true);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
     const long wave_g = (long)blockIdx.x * WPB + wv, nwaves = (long)gridDim.x * WPB;
-    float *gh_t = ght[wv], *v1_t = v1t[wv];
     f32x4 sg[4], sgr[4], sgh[NOB], accw[NOB][4], m1[4], r1[4];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
@@ -371,7 +422,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) {
             sgh[ob] += gh[ob];
-            *reinterpret_cast<f32x4 *>(gh_t + row * GS + 16 * ob + 4 * kq) = gh[ob];
+            st4(gh_t + row * GS + 16 * ob + 4 * kq, gh[ob]);
         }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
@@ -389,7 +440,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
             for (int e = 0; e < 4; ++e) gy1[e] = y1[e] > 0.f ? acc[e] : 0.f;
             sg[jj] += gy1;
             sgr[jj] += gy1 * ((r - m1[jj]) * r1[jj]);
-            *reinterpret_cast<f32x4 *>(v1_t + row * TS + 16 * jj + 4 * kq) = relu4(y1);
+            st4(v1_t + row * TS + 16 * jj + 4 * kq, relu4(y1));
         }
         wave_sync();
         // g_Ww1[o][c] += sum_rows g_h[row][o] v1[row][c]
@@ -439,45 +490,46 @@ __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
 // partial row per wave: [sum g_yp (3) | sum g_yp*that (3) | pad 2 | g_bp2 (C) | g_Wp2 (C*3)]   (as fl::k_b3)
 template <int C>
 __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
-    constexpr int CS = C / 8, NOB = CS / 16, NCHK = C / 64, WS = C + 4, W = 8 + 4 * C;
-    __shared__ __attribute__((aligned(16))) float cst[6 * C];
-    __shared__ __attribute__((aligned(16))) float wl[CS * WS];
-    __shared__ __attribute__((aligned(16))) float tiles[WPB][16 * TS];
-    __shared__ float t1ns[WPB][16 * 4];
-    __shared__ int rowids[WPB][16];
-    for (int e = threadIdx.x; e < CS * C; e += 64 * WPB) wl[(e / C) * WS + e % C] = gp(A.Ww1)[e];
-    stage_consts<C>(cst, A);
-    const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4, wv = threadIdx.x >> 6;
+    constexpr int CS = C / 8, NOB = CS / 16, NCHK = C / 64, WS = 68, W = 8 + 4 * C;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wv = threadIdx.x >> 6;
+    float *cst = lds, *w2 = cst + 6 * C, *wl = w2 + w2_floats(C);        // wl: Ww1[:, 64 q ..+64] of the current chunk
+    float *tile = wl + CS * WS + wv * 16 * TS;
+    float *t1nt = wl + CS * WS + WPB * 16 * TS + wv * 64;
+    int *rowid = reinterpret_cast<int *>(wl + CS * WS + WPB * 16 * TS + WPB * 64) + wv * 16;
+    stage_consts<C>(cst, A, true);
+    stage_w2<C>(w2, A);
+    const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
     const long wave_g = (long)blockIdx.x * WPB + wv, nwaves = (long)gridDim.x * WPB;
-    float *tile = tiles[wv], *t1nt = t1ns[wv];
-    int *rowid = rowids[wv];
-    AttnW<NOB> att;
-    att.load(A, row, kq);
     const float *S2 = gp(A.sums), *S1 = gp(A.sums2);   // [sum g_y1 (C) | sum g_y1*rhat (C)], [sum g_y2 | sum g_y2*hhat]
     float sgp[3] = {0.f, 0.f, 0.f}, sgpt[3] = {0.f, 0.f, 0.f};
     float *o = A.partial + wave_g * W;
     // The 64-channel chunks are the OUTER loop (every chunk re-derives the cheap per-point quantities): the per-channel
-    // accumulators then are four scalars, and g_t1n (a sum over all channels) is accumulated in G3 by the owning lane.
+    // accumulators then are four scalars, the Ww1 copy in LDS is one 64-column slab, and g_t1n (a sum over all channels)
+    // is accumulated in G3 by the owning lane.
 #pragma unroll 1
     for (int q = 0; q < NCHK; ++q) {
+        __syncthreads();   // previous slab fully consumed (and, first trip, constants staged)
+        for (int e = threadIdx.x; e < CS * 64; e += 64 * WPB) wl[(e / 64) * WS + e % 64] = gp(A.Ww1)[(size_t)(e / 64) * C + 64 * q + e % 64];
+        __syncthreads();
         float sbp2 = 0.f, awp2[3] = {0.f, 0.f, 0.f};
         for (long i = wave_g; i < A.N; i += nwaves) {
             const PRow R = load_prow(A, i, row);
             if (kq == 0) { rowid[row] = R.nb; t1nt[row * 4 + 0] = R.t1n[0]; t1nt[row * 4 + 1] = R.t1n[1]; t1nt[row * 4 + 2] = R.t1n[2]; }
             f32x4 gh[NOB], h[NOB], u[NOB], w[NOB];
             hidden_grad<C, NOB>(A, S1, i, row, kq, gh, h);
-            att.weights(h, u, w);
+            attn_weights<NOB>(A, w2, row, kq, h, u, w);
             float gt1n[3] = {0.f, 0.f, 0.f};
             f32x4 gpr[4];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                const int j = 4 * q + jj, g = 4 * j + kq;
+                const int g = 4 * (4 * q + jj) + kq;
                 f32x4 acc = zero4();
 #pragma unroll
                 for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(16 * ob + 4 * kq + e) * WS + 16 * j + row], gh[ob][e], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(16 * ob + 4 * kq + e) * WS + 16 * jj + row], gh[ob][e], acc, 0, 0, 0);
                 const f32x4 r = r4_of(A, cst, C, i, R, g);
                 const f32x4 s1 = ld4(cst + 4 * C + 4 * g);
                 const f32x4 y1 = r * s1 + ld4(cst + 5 * C + 4 * g);
@@ -487,10 +539,10 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
                 // BN1 backward: g_r = s1 * (g_y1 - mean(g_y1) - rhat * mean(g_y1 * rhat))
                 const f32x4 rhat = (r - ld4(gp(A.mean) + 3 + 4 * g)) * ld4(gp(A.rstd) + 3 + 4 * g);
                 const f32x4 gr = s1 * (gy1 - ld4(S2 + 4 * g) * A.inv_rows - rhat * (ld4(S2 + C + 4 * g) * A.inv_rows));
-                *reinterpret_cast<f32x4 *>(tile + row * TS + 16 * jj + 4 * kq) = gr;
+                st4(tile + row * TS + 16 * jj + 4 * kq, gr);
                 gpr[jj] = gr + ld4(A.gout + (size_t)i * C + 4 * g) * w[jj % NOB];   // + the aggregation's share of p_r
-                const f32x4 w0 = ld4(cst + 12 * g), w1 = ld4(cst + 12 * g + 4), w2 = ld4(cst + 12 * g + 8);
-                const float wp[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0], w2[1], w2[2], w2[3]};
+                const f32x4 w0 = ld4(cst + 12 * g), w1 = ld4(cst + 12 * g + 4), w2v = ld4(cst + 12 * g + 8);
+                const float wp[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2v[0], w2v[1], w2v[2], w2v[3]};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     gt1n[0] += gpr[jj][e] * wp[3 * e]; gt1n[1] += gpr[jj][e] * wp[3 * e + 1]; gt1n[2] += gpr[jj][e] * wp[3 * e + 2];
@@ -510,7 +562,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
             }
             wave_sync();
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<f32x4 *>(tile + row * TS + 16 * jj + 4 * kq) = gpr[jj];
+            for (int jj = 0; jj < 4; ++jj) st4(tile + row * TS + 16 * jj + 4 * kq, gpr[jj]);
             wave_sync();
 #pragma unroll 4
             for (int rr = 0; rr < 16; ++rr) {   // g_bp2 / g_Wp2 of channel 64 q + lane
@@ -548,20 +600,39 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
     if (lane == 0) { o[6] = 0.f; o[7] = 0.f; }
 }
 
-void launch_p3(const LayerArgs &A, int c, bool stats, int grid, hipStream_t s) {
-    if (c == 128) { if (stats) k_p3<128, true><<<grid, 64 * WPB, 0, s>>>(A); else k_p3<128, false><<<grid, 64 * WPB, 0, s>>>(A); }
-    else          { if (stats) k_p3<256, true><<<grid, 64 * WPB, 0, s>>>(A); else k_p3<256, false><<<grid, 64 * WPB, 0, s>>>(A); }
+// ------------------------------------------------------------------------------------------------ launchers
+template <typename KernelT>
+static void launch(KernelT kernel, dim3 grid, size_t lds_floats, const LayerArgs &A, hipStream_t s) {
+    const size_t lds = lds_floats * sizeof(float);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    kernel<<<grid, 64 * WPB, lds, s>>>(A);
 }
+#define PDF_FLM(KERNEL, GRID, LDS)                                                   \
+    do {                                                                              \
+        if (c == 128) launch(KERNEL<128>, GRID, LDS, A, s);                           \
+        else if (c == 256) launch(KERNEL<256>, GRID, LDS, A, s);                      \
+        else launch(KERNEL<512>, GRID, LDS, A, s);                                    \
+    } while (0)
 
-
+void launch_p2(const LayerArgs &A, int c, int grid, hipStream_t s) { PDF_FLM(k_p2, dim3(grid, c / 64), (size_t)4 * c); }
+void launch_p3(const LayerArgs &A, int c, bool stats, int grid, hipStream_t s) {
+    const size_t lds = (size_t)6 * c + (size_t)(c / 8) * (c + 4);
+    if (stats) {
+        if (c == 128) launch(k_p3<128, true>, dim3(grid), lds, A, s); else if (c == 256) launch(k_p3<256, true>, dim3(grid), lds, A, s); else launch(k_p3<512, true>, dim3(grid), lds, A, s);
+    } else {
+        if (c == 128) launch(k_p3<128, false>, dim3(grid), lds, A, s); else if (c == 256) launch(k_p3<256, false>, dim3(grid), lds, A, s); else launch(k_p3<512, false>, dim3(grid), lds, A, s);
+    }
+}
+void launch_p4(const LayerArgs &A, int c, int grid, hipStream_t s) { PDF_FLM(k_p4, dim3(grid), (size_t)4 * c + w2_floats(c)); }
 void launch_b1(const LayerArgs &A, int c, int grid, hipStream_t s) {
-    if (c == 128) k_b1<128><<<grid, 64 * WPB, 0, s>>>(A); else k_b1<256><<<grid, 64 * WPB, 0, s>>>(A);
+    PDF_FLM(k_b1, dim3(grid), (size_t)4 * c + w2_floats(c) + WPB * 16 * TS + 2 * WPB * 16 * (c / 8 + 4) + WPB * 16);
 }
 void launch_b2(const LayerArgs &A, int c, int grid, hipStream_t s) {
-    if (c == 128) k_b2<128><<<dim3(grid, 2), 64 * WPB, 0, s>>>(A); else k_b2<256><<<dim3(grid, 4), 64 * WPB, 0, s>>>(A);
+    PDF_FLM(k_b2, dim3(grid, c / 64), (size_t)6 * c + (size_t)(c / 8) * 68 + WPB * 16 * (c / 8 + 4) + WPB * 16 * TS);
 }
 void launch_b3(const LayerArgs &A, int c, int grid, hipStream_t s) {
-    if (c == 128) k_b3<128><<<grid, 64 * WPB, 0, s>>>(A); else k_b3<256><<<grid, 64 * WPB, 0, s>>>(A);
+    PDF_FLM(k_b3, dim3(grid), (size_t)6 * c + w2_floats(c) + (size_t)(c / 8) * 68 + WPB * 16 * TS + WPB * 64 + WPB * 16);
 }
+#undef PDF_FLM
 
 }  // namespace flm

@@ -42,7 +42,7 @@ def run_layer(fused, C, K, N, train, seed=0):
     return res
 
 
-@pytest.mark.parametrize("C,K", [(32, 8), (64, 16), (128, 16), (32, 16), (64, 8), (256, 16)])
+@pytest.mark.parametrize("C,K", [(32, 8), (64, 16), (128, 16), (32, 16), (64, 8), (256, 16), (512, 16)])
 def test_fused_layer_train(C, K):
     n = 3000 if C <= 128 else 900
     a = run_layer(True, C, K, n, True)
@@ -58,7 +58,7 @@ def test_fused_layer_train(C, K):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("C,K", [(32, 8), (64, 16), (128, 16), (256, 16)])
+@pytest.mark.parametrize("C,K", [(32, 8), (64, 16), (128, 16), (256, 16), (512, 16)])
 def test_fused_layer_eval(C, K):
     a = run_layer(True, C, K, 2500, False)
     b = run_layer(False, C, K, 2500, False)

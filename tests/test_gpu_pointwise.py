@@ -166,5 +166,5 @@ def test_bottleneck_matrix_core_path(C, K, train):
     for k in b:
         if k.startswith("g_") and abs(b[k]).max() < 1e-4 * gscale:
             continue  # analytically-zero gradients (biases in front of a train-mode BatchNorm)
-        tol = 2e-5 if (k == "y" or k.startswith("b_")) else (2e-3 if C < 512 else 3e-2)  # 560 rows x 512 ch: fp32 noise (q/k grads are tiny differences)
+        tol = 2e-5 if (k == "y" or k.startswith("b_")) else (2e-3 if C < 256 else (5e-3 if C == 256 else 3e-2))  # 560 rows through three train-mode norms: fp32 summation-order noise grows with C (q/k grads are tiny differences)
         assert max_rel(a[k], b[k]) < tol, (k, max_rel(a[k], b[k]))
