@@ -24,8 +24,14 @@ using fl::WPB;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 bool supported(int nsample, int c) {
-    return nsample == 16 && (c == 128 || c == 256 || c == 512) && getenv("PDFOPS_PT_NO_MFMA") == nullptr;
+    return nsample == 16 && (c == 64 || c == 128 || c == 256 || c == 512) && getenv("PDFOPS_PT_NO_MFMA") == nullptr;
 }
+
+// C/8 hidden units, padded to whole 16-row MFMA blocks (C = 64: 8 units, the upper half of the block is zero padding).
+// Lane (row, kq) owns hidden units {16 ob + 4 kq + e}; `hv` = those exist.  With 8 units the channel -> unit map
+// (c mod 8) sends the channels of lanes kq = 2, 3 to the units of lanes kq - 2: one xor-32 exchange where that matters.
+__host__ __device__ constexpr int nob_of(int c) { return c / 8 >= 16 ? c / 128 : 1; }
+__host__ __device__ constexpr int csp_of(int c) { return 16 * nob_of(c); }
 
 __device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ __forceinline__ void st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
@@ -55,7 +61,7 @@ __device__ __forceinline__ void wave_sync() {
 // ---- dynamic LDS layout (floats).  cst = per-channel constants [Wp2 (3C, channel-major) | bp2 (C) | s1 (C) | t1 (C)];
 // W2 = padded copy of Ww2 (row stride CS + 4); TS = row stride of the 16 x 64 transposition tiles.
 constexpr int TS = 68;
-__host__ __device__ constexpr int w2_floats(int c) { return (c / 8) * (c / 8 + 4); }
+__host__ __device__ constexpr int w2_floats(int c) { return csp_of(c) * (csp_of(c) + 4); }
 
 template <int C>
 __device__ __forceinline__ void stage_consts(float *cst, const LayerArgs &A, bool with_bn1) {
@@ -67,8 +73,16 @@ __device__ __forceinline__ void stage_consts(float *cst, const LayerArgs &A, boo
 }
 template <int C>
 __device__ __forceinline__ void stage_w2(float *w2, const LayerArgs &A) {
-    constexpr int CS = C / 8;
-    for (int e = threadIdx.x; e < CS * CS; e += 64 * WPB) w2[(e / CS) * (CS + 4) + e % CS] = gp(A.Ww2)[e];
+    constexpr int CS = C / 8, CSP = csp_of(C);
+    for (int e = threadIdx.x; e < CSP * (CSP + 4); e += 64 * WPB) {
+        const int o = e / (CSP + 4), u = e % (CSP + 4);
+        w2[e] = (o < CS && u < CS) ? gp(A.Ww2)[o * CS + u] : 0.f;
+    }
+}
+// guarded float4 of a CS-long per-unit array (zero where the lane's units do not exist)
+__device__ __forceinline__ f32x4 ldu(const float *p, int o, bool hv) { return hv ? ld4(p + o) : zero4(); }
+__device__ __forceinline__ f32x4 xchg32(f32x4 v) {
+    return f32x4{__shfl_xor(v[0], 32, 64), __shfl_xor(v[1], 32, 64), __shfl_xor(v[2], 32, 64), __shfl_xor(v[3], 32, 64)};
 }
 
 // One point's 16 neighbour rows: geometry branch of the lane's row (3-channel, cheap, replicated over the 4 kq lanes)
@@ -112,11 +126,14 @@ __device__ __forceinline__ f32x4 r4_of(const LayerArgs &A, const float *cst, int
 
 // Attention branch of one point (16 rows): u = relu(BN2(h)), w = softmax over the rows of (u Ww2^T + bw2).
 // Lane (row, kq) holds hidden units {16 ob + 4 kq + e}; the MFMA D fragment of z^T = Ww2 u^T has the same index set.
-template <int NOB>
+template <int C>
 __device__ __forceinline__ void attn_weights(const LayerArgs &A, const float *w2, int row, int kq, const f32x4 *h, f32x4 *u, f32x4 *w) {
-    constexpr int CS = NOB * 16, WS2 = CS + 4;
+    constexpr int CS = C / 8, NOB = nob_of(C), WS2 = csp_of(C) + 4;
 #pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) u[ob] = relu4(h[ob] * ld4(gp(A.s2) + 16 * ob + 4 * kq) + ld4(gp(A.t2) + 16 * ob + 4 * kq));
+    for (int ob = 0; ob < NOB; ++ob) {
+        const bool hv = 16 * ob + 4 * kq < CS;
+        u[ob] = relu4(h[ob] * ldu(gp(A.s2), 16 * ob + 4 * kq, hv) + ldu(gp(A.t2), 16 * ob + 4 * kq, hv));   // padding lanes: 0
+    }
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) {
         f32x4 z = zero4();
@@ -126,7 +143,7 @@ __device__ __forceinline__ void attn_weights(const LayerArgs &A, const float *w2
 #pragma unroll
             for (int e = 0; e < 4; ++e) z = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], u[jo][e], z, 0, 0, 0);
         }
-        z += ld4(gp(A.bw2) + 16 * ob + 4 * kq);
+        z += ldu(gp(A.bw2), 16 * ob + 4 * kq, 16 * ob + 4 * kq < CS);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float m = max16(z[r]);
@@ -134,6 +151,17 @@ __device__ __forceinline__ void attn_weights(const LayerArgs &A, const float *w2
             w[ob][r] = ex / sum16(ex);
         }
     }
+    if (CS < 16) {   // channels of lanes kq = 2, 3 use the units of lanes kq - 2
+        const f32x4 x = xchg32(w[0]);
+        if (kq >= 2) w[0] = x;
+    }
+}
+
+// h (or G2) row fragment of the lane: units {16 ob + 4 kq + e}
+template <int C>
+__device__ __forceinline__ f32x4 ld_units(const float *base, long rowidx, int ob, int kq) {
+    constexpr int CS = C / 8;
+    return 16 * ob + 4 * kq < CS ? ld4(base + (size_t)rowidx * CS + 16 * ob + 4 * kq) : zero4();
 }
 
 // ------------------------------------------------------------------------------------------------ P2: stats of r (slabs)
@@ -174,10 +202,10 @@ __global__ __launch_bounds__(64 * WPB) void k_p2(LayerArgs A) {
 // ------------------------------------------------------------------------------------------------ P3: h (+ stats of h)
 template <int C, bool STATS>
 __global__ __launch_bounds__(64 * WPB) void k_p3(LayerArgs A) {
-    constexpr int CS = C / 8, NJ = C / 16, NOB = CS / 16, WS = C + 4;   // WS: padded row stride of the Ww1 copy
+    constexpr int CS = C / 8, NJ = C / 16, NOB = nob_of(C), CSP = csp_of(C), WS = C + 4;   // WS: padded row stride of the Ww1 copy
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *cst = lds, *wl = lds + 6 * C;
-    for (int e = threadIdx.x; e < CS * C; e += 64 * WPB) wl[(e / C) * WS + e % C] = gp(A.Ww1)[e];
+    for (int e = threadIdx.x; e < CSP * C; e += 64 * WPB) wl[(e / C) * WS + e % C] = e / C < CS ? gp(A.Ww1)[e] : 0.f;
     stage_consts<C>(cst, A, true);
     __syncthreads();
     const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
@@ -185,7 +213,7 @@ __global__ __launch_bounds__(64 * WPB) void k_p3(LayerArgs A) {
     const float *wa = wl + row * WS + 4 * kq;   // A operand (hidden unit ob*16 + (l & 15), k = kq): wa[ob * 16 * WS + 16 j ..+4]
     f32x4 b4[NOB], s4[NOB], ss4[NOB];
 #pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) { b4[ob] = ld4(gp(A.bw1) + ob * 16 + 4 * kq); s4[ob] = zero4(); ss4[ob] = zero4(); }
+    for (int ob = 0; ob < NOB; ++ob) { b4[ob] = ldu(gp(A.bw1), ob * 16 + 4 * kq, ob * 16 + 4 * kq < CS); s4[ob] = zero4(); ss4[ob] = zero4(); }
     for (long i = wave_g; i < A.N; i += nwaves) {
         const PRow R = load_prow(A, i, row);
         f32x4 acc[NOB];
@@ -207,7 +235,7 @@ __global__ __launch_bounds__(64 * WPB) void k_p3(LayerArgs A) {
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) {
             const f32x4 h = acc[ob] + b4[ob];   // h[row][ob*16 + 4 kq + reg]
-            st4(A.H + ((size_t)i * 16 + row) * CS + ob * 16 + 4 * kq, h);
+            if (ob * 16 + 4 * kq < CS) st4(A.H + ((size_t)i * 16 + row) * CS + ob * 16 + 4 * kq, h);
             if (STATS) { s4[ob] += h; ss4[ob] += h * h; }
         }
     }
@@ -219,7 +247,7 @@ __global__ __launch_bounds__(64 * WPB) void k_p3(LayerArgs A) {
                 float s = s4[ob][r], ss = ss4[ob][r];
 #pragma unroll
                 for (int m = 1; m < 16; m <<= 1) { s += __shfl_xor(s, m, 64); ss += __shfl_xor(ss, m, 64); }
-                if (row == 0) {
+                if (row == 0 && ob * 16 + 4 * kq < CS) {
                     A.partial[wave_g * 2 * CS + ob * 16 + 4 * kq + r] = s;
                     A.partial[wave_g * 2 * CS + CS + ob * 16 + 4 * kq + r] = ss;
                 }
@@ -231,7 +259,7 @@ __global__ __launch_bounds__(64 * WPB) void k_p3(LayerArgs A) {
 // out[i][c] = sum_rows (x_v[nb][c] + p_r[c]) * w[row][c mod CS]
 template <int C>
 __global__ __launch_bounds__(64 * WPB) void k_p4(LayerArgs A) {
-    constexpr int CS = C / 8, NJ = C / 16, NOB = CS / 16;
+    constexpr int NJ = C / 16, NOB = nob_of(C);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *cst = lds, *w2 = lds + 4 * C;
     stage_consts<C>(cst, A, false);
@@ -243,8 +271,8 @@ __global__ __launch_bounds__(64 * WPB) void k_p4(LayerArgs A) {
         const PRow R = load_prow(A, i, row);
         f32x4 h[NOB], u[NOB], w[NOB];
 #pragma unroll
-        for (int ob = 0; ob < NOB; ++ob) h[ob] = ld4(A.H + ((size_t)i * 16 + row) * CS + 16 * ob + 4 * kq);
-        attn_weights<NOB>(A, w2, row, kq, h, u, w);
+        for (int ob = 0; ob < NOB; ++ob) h[ob] = ld_units<C>(A.H, i * 16 + row, ob, kq);
+        attn_weights<C>(A, w2, row, kq, h, u, w);
 #pragma unroll 1
         for (int j0 = 0; j0 < NJ; j0 += NOB) {
 #pragma unroll
@@ -274,7 +302,7 @@ __device__ __forceinline__ void scatter_tile(const float *tile, const int *rowid
 // partial row per wave: [sum g_y2 (CS) | sum g_y2*hhat (CS) | g_bw2 (CS) | g_Ww2 (CS*CS)]   (as fl::k_b1)
 template <int C>
 __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
-    constexpr int CS = C / 8, NOB = CS / 16, NCHK = C / 64, GS = CS + 4, WS2 = CS + 4, W = 3 * CS + CS * CS;
+    constexpr int CS = C / 8, NOB = nob_of(C), CSP = csp_of(C), NCHK = C / 64, GS = CSP + 4, WS2 = CSP + 4, W = 3 * CS + CS * CS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *cst = lds, *w2 = cst + 4 * C;                                  // Wp2 (3C) | bp2 (C); padded Ww2
     const int wv = threadIdx.x >> 6;
@@ -283,6 +311,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
     int *rowid = reinterpret_cast<int *>(w2 + w2_floats(C) + WPB * 16 * TS + 2 * WPB * 16 * GS) + wv * 16;
     stage_consts<C>(cst, A, false);
     stage_w2<C>(w2, A);
+    for (int e = threadIdx.x; e < 2 * WPB * 16 * GS; e += 64 * WPB) (w2 + w2_floats(C) + WPB * 16 * TS)[e] = 0.f;   // unit tiles incl. padding columns
     __syncthreads();
     const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
     const long wave_g = (long)blockIdx.x * WPB + wv, nwaves = (long)gridDim.x * WPB;
@@ -298,8 +327,8 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
         if (kq == 0) rowid[row] = R.nb;
         f32x4 h[NOB], u[NOB], w[NOB], gw[NOB];
 #pragma unroll
-        for (int ob = 0; ob < NOB; ++ob) { h[ob] = ld4(A.H + ((size_t)i * 16 + row) * CS + 16 * ob + 4 * kq); gw[ob] = zero4(); }
-        attn_weights<NOB>(A, w2, row, kq, h, u, w);
+        for (int ob = 0; ob < NOB; ++ob) { h[ob] = ld_units<C>(A.H, i * 16 + row, ob, kq); gw[ob] = zero4(); }
+        attn_weights<C>(A, w2, row, kq, h, u, w);
 #pragma unroll 1
         for (int q = 0; q < NCHK; ++q) {
 #pragma unroll
@@ -317,16 +346,20 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
         }
         // softmax backward over the 16 rows, Linear(CS, CS) backward, ReLU / BN2 bookkeeping
         f32x4 gz[NOB];
+        if (CS < 16) gw[0] += xchg32(gw[0]);   // 8 units: lanes kq and kq ^ 2 hold partial sums of the same units
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) {
+            const bool hv = 16 * ob + 4 * kq < CS;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float dot = sum16(w[ob][r] * gw[ob][r]);
-                gz[ob][r] = w[ob][r] * (gw[ob][r] - dot);
+                gz[ob][r] = hv ? w[ob][r] * (gw[ob][r] - dot) : 0.f;
             }
             sgz[ob] += gz[ob];
-            st4(gz_t + row * GS + 16 * ob + 4 * kq, gz[ob]);
-            st4(u_t + row * GS + 16 * ob + 4 * kq, u[ob]);
+            if (hv) {
+                st4(gz_t + row * GS + 16 * ob + 4 * kq, gz[ob]);
+                st4(u_t + row * GS + 16 * ob + 4 * kq, u[ob]);
+            }
         }
 #pragma unroll
         for (int ub = 0; ub < NOB; ++ub) {
@@ -339,9 +372,10 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
             f32x4 gy2;
 #pragma unroll
             for (int r = 0; r < 4; ++r) gy2[r] = u[ub][r] > 0.f ? gu[r] : 0.f;
-            st4(A.G2 + ((size_t)i * 16 + row) * CS + 16 * ub + 4 * kq, gy2);
+            const bool hv = 16 * ub + 4 * kq < CS;
+            if (hv) st4(A.G2 + ((size_t)i * 16 + row) * CS + 16 * ub + 4 * kq, gy2);
             sg[ub] += gy2;
-            sgh[ub] += gy2 * ((h[ub] - ld4(gp(A.mean) + 3 + C + 16 * ub + 4 * kq)) * ld4(gp(A.rstd) + 3 + C + 16 * ub + 4 * kq));
+            sgh[ub] += gy2 * ((h[ub] - ldu(gp(A.mean) + 3 + C, 16 * ub + 4 * kq, hv)) * ldu(gp(A.rstd) + 3 + C, 16 * ub + 4 * kq, hv));
         }
         wave_sync();
         // g_Ww2[o][u'] += sum_rows g_z[row][o] u[row][u']  (reduction index = rows: operands re-read lanes-along-units)
@@ -365,25 +399,27 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
             float a = sg[ob][r], b = sgh[ob][r], d = sgz[ob][r];
 #pragma unroll
             for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); d += __shfl_xor(d, m, 64); }
-            if (row == 0) { o[16 * ob + 4 * kq + r] = a; o[CS + 16 * ob + 4 * kq + r] = b; o[2 * CS + 16 * ob + 4 * kq + r] = d; }
+            if (row == 0 && 16 * ob + 4 * kq < CS) { o[16 * ob + 4 * kq + r] = a; o[CS + 16 * ob + 4 * kq + r] = b; o[2 * CS + 16 * ob + 4 * kq + r] = d; }
         }
 #pragma unroll
         for (int ub = 0; ub < NOB; ++ub)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[3 * CS + (16 * ob + 4 * kq + r) * CS + 16 * ub + row] = accw[ob][ub][r];
+            for (int r = 0; r < 4; ++r)
+                if (16 * ob + 4 * kq < CS && 16 * ub + row < CS) o[3 * CS + (16 * ob + 4 * kq + r) * CS + 16 * ub + row] = accw[ob][ub][r];
     }
 }
 
 // g_h of the lane's hidden units from the stored G2 / H rows and the BN2-backward sums (`sums` = [sum g_y2 | sum g_y2*hhat])
-template <int C, int NOB>
+template <int C>
 __device__ __forceinline__ void hidden_grad(const LayerArgs &A, const float *sums, long i, int row, int kq, f32x4 *gh, f32x4 *h_out = nullptr) {
-    constexpr int CS = C / 8;
+    constexpr int CS = C / 8, NOB = nob_of(C);
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) {
         const int o = 16 * ob + 4 * kq;
-        const f32x4 h = ld4(A.H + ((size_t)i * 16 + row) * CS + o), g2 = ld4(A.G2 + ((size_t)i * 16 + row) * CS + o);
-        const f32x4 hhat = (h - ld4(gp(A.mean) + 3 + C + o)) * ld4(gp(A.rstd) + 3 + C + o);
-        gh[ob] = ld4(gp(A.s2) + o) * (g2 - ld4(sums + o) * A.inv_rows - hhat * (ld4(sums + CS + o) * A.inv_rows));
+        const bool hv = o < CS;
+        const f32x4 h = ld_units<C>(A.H, i * 16 + row, ob, kq), g2 = ld_units<C>(A.G2, i * 16 + row, ob, kq);
+        const f32x4 hhat = (h - ldu(gp(A.mean) + 3 + C, o, hv)) * ldu(gp(A.rstd) + 3 + C, o, hv);
+        gh[ob] = ldu(gp(A.s2), o, hv) * (g2 - ldu(sums, o, hv) * A.inv_rows - hhat * (ldu(sums + CS, o, hv) * A.inv_rows));   // padding lanes: 0
         if (h_out) h_out[ob] = h;
     }
 }
@@ -393,13 +429,14 @@ __device__ __forceinline__ void hidden_grad(const LayerArgs &A, const float *sum
 //   [sum g_y1 (C) | sum g_y1*rhat (C) | g_bw1 (CS) | g_Ww1 (CS*C)]   (as fl::k_b2)
 template <int C>
 __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
-    constexpr int CS = C / 8, NOB = CS / 16, GS = CS + 4, WS = 68, W = 2 * C + CS + CS * C;
+    constexpr int CS = C / 8, NOB = nob_of(C), CSP = csp_of(C), GS = CSP + 4, WS = 68, W = 2 * C + CS + CS * C;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wv = threadIdx.x >> 6;
     float *cst = lds, *wl = cst + 6 * C;                                   // Ww1[:, slab], row stride 68
-    float *gh_t = wl + CS * WS + wv * 16 * GS, *v1_t = wl + CS * WS + WPB * 16 * GS + wv * 16 * TS;
+    float *gh_t = wl + CSP * WS + wv * 16 * GS, *v1_t = wl + CSP * WS + WPB * 16 * GS + wv * 16 * TS;
     const int slab = blockIdx.y, c0 = 64 * slab;
-    for (int e = threadIdx.x; e < CS * 64; e += 64 * WPB) wl[(e / 64) * WS + e % 64] = gp(A.Ww1)[(size_t)(e / 64) * C + c0 + e % 64];
+    for (int e = threadIdx.x; e < CSP * 64; e += 64 * WPB) wl[(e / 64) * WS + e % 64] = e / 64 < CS ? gp(A.Ww1)[(size_t)(e / 64) * C + c0 + e % 64] : 0.f;
+    for (int e = threadIdx.x; e < WPB * 16 * GS; e += 64 * WPB) (wl + CSP * WS)[e] = 0.f;   // g_h tiles incl. padding columns
     stage_consts<C>(cst, A, true);
     __syncthreads();
     const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
@@ -418,11 +455,11 @@ __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
     for (long i = wave_g; i < A.N; i += nwaves) {
         const PRow R = load_prow(A, i, row);
         f32x4 gh[NOB];
-        hidden_grad<C, NOB>(A, gp(A.sums), i, row, kq, gh);
+        hidden_grad<C>(A, gp(A.sums), i, row, kq, gh);
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) {
             sgh[ob] += gh[ob];
-            st4(gh_t + row * GS + 16 * ob + 4 * kq, gh[ob]);
+            if (16 * ob + 4 * kq < CS) st4(gh_t + row * GS + 16 * ob + 4 * kq, gh[ob]);
         }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
@@ -476,13 +513,14 @@ __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
                 float a = sgh[ob][r];
 #pragma unroll
                 for (int m = 1; m < 16; m <<= 1) a += __shfl_xor(a, m, 64);
-                if (row == 0) o[2 * C + 16 * ob + 4 * kq + r] = a;
+                if (row == 0 && 16 * ob + 4 * kq < CS) o[2 * C + 16 * ob + 4 * kq + r] = a;
             }
         }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[2 * C + CS + (size_t)(16 * ob + 4 * kq + r) * C + c0 + 16 * jj + row] = accw[ob][jj][r];
+            for (int r = 0; r < 4; ++r)
+                if (16 * ob + 4 * kq < CS) o[2 * C + CS + (size_t)(16 * ob + 4 * kq + r) * C + c0 + 16 * jj + row] = accw[ob][jj][r];
     }
 }
 
@@ -490,13 +528,13 @@ __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
 // partial row per wave: [sum g_yp (3) | sum g_yp*that (3) | pad 2 | g_bp2 (C) | g_Wp2 (C*3)]   (as fl::k_b3)
 template <int C>
 __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
-    constexpr int CS = C / 8, NOB = CS / 16, NCHK = C / 64, WS = 68, W = 8 + 4 * C;
+    constexpr int CS = C / 8, NOB = nob_of(C), CSP = csp_of(C), NCHK = C / 64, WS = 68, W = 8 + 4 * C;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wv = threadIdx.x >> 6;
     float *cst = lds, *w2 = cst + 6 * C, *wl = w2 + w2_floats(C);        // wl: Ww1[:, 64 q ..+64] of the current chunk
-    float *tile = wl + CS * WS + wv * 16 * TS;
-    float *t1nt = wl + CS * WS + WPB * 16 * TS + wv * 64;
-    int *rowid = reinterpret_cast<int *>(wl + CS * WS + WPB * 16 * TS + WPB * 64) + wv * 16;
+    float *tile = wl + CSP * WS + wv * 16 * TS;
+    float *t1nt = wl + CSP * WS + WPB * 16 * TS + wv * 64;
+    int *rowid = reinterpret_cast<int *>(wl + CSP * WS + WPB * 16 * TS + WPB * 64) + wv * 16;
     stage_consts<C>(cst, A, true);
     stage_w2<C>(w2, A);
     const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
@@ -510,15 +548,15 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
 #pragma unroll 1
     for (int q = 0; q < NCHK; ++q) {
         __syncthreads();   // previous slab fully consumed (and, first trip, constants staged)
-        for (int e = threadIdx.x; e < CS * 64; e += 64 * WPB) wl[(e / 64) * WS + e % 64] = gp(A.Ww1)[(size_t)(e / 64) * C + 64 * q + e % 64];
+        for (int e = threadIdx.x; e < CSP * 64; e += 64 * WPB) wl[(e / 64) * WS + e % 64] = e / 64 < CS ? gp(A.Ww1)[(size_t)(e / 64) * C + 64 * q + e % 64] : 0.f;
         __syncthreads();
         float sbp2 = 0.f, awp2[3] = {0.f, 0.f, 0.f};
         for (long i = wave_g; i < A.N; i += nwaves) {
             const PRow R = load_prow(A, i, row);
             if (kq == 0) { rowid[row] = R.nb; t1nt[row * 4 + 0] = R.t1n[0]; t1nt[row * 4 + 1] = R.t1n[1]; t1nt[row * 4 + 2] = R.t1n[2]; }
             f32x4 gh[NOB], h[NOB], u[NOB], w[NOB];
-            hidden_grad<C, NOB>(A, S1, i, row, kq, gh, h);
-            attn_weights<NOB>(A, w2, row, kq, h, u, w);
+            hidden_grad<C>(A, S1, i, row, kq, gh, h);
+            attn_weights<C>(A, w2, row, kq, h, u, w);
             float gt1n[3] = {0.f, 0.f, 0.f};
             f32x4 gpr[4];
 #pragma unroll
@@ -609,29 +647,35 @@ static void launch(KernelT kernel, dim3 grid, size_t lds_floats, const LayerArgs
 }
 #define PDF_FLM(KERNEL, GRID, LDS)                                                   \
     do {                                                                              \
-        if (c == 128) launch(KERNEL<128>, GRID, LDS, A, s);                           \
+        if (c == 64) launch(KERNEL<64>, GRID, LDS, A, s);                             \
+        else if (c == 128) launch(KERNEL<128>, GRID, LDS, A, s);                      \
         else if (c == 256) launch(KERNEL<256>, GRID, LDS, A, s);                      \
         else launch(KERNEL<512>, GRID, LDS, A, s);                                    \
     } while (0)
 
 void launch_p2(const LayerArgs &A, int c, int grid, hipStream_t s) { PDF_FLM(k_p2, dim3(grid, c / 64), (size_t)4 * c); }
 void launch_p3(const LayerArgs &A, int c, bool stats, int grid, hipStream_t s) {
-    const size_t lds = (size_t)6 * c + (size_t)(c / 8) * (c + 4);
+    const size_t lds = (size_t)6 * c + (size_t)csp_of(c) * (c + 4);
     if (stats) {
-        if (c == 128) launch(k_p3<128, true>, dim3(grid), lds, A, s); else if (c == 256) launch(k_p3<256, true>, dim3(grid), lds, A, s); else launch(k_p3<512, true>, dim3(grid), lds, A, s);
+        if (c == 64) launch(k_p3<64, true>, dim3(grid), lds, A, s); else if (c == 128) launch(k_p3<128, true>, dim3(grid), lds, A, s); else if (c == 256) launch(k_p3<256, true>, dim3(grid), lds, A, s); else launch(k_p3<512, true>, dim3(grid), lds, A, s);
     } else {
-        if (c == 128) launch(k_p3<128, false>, dim3(grid), lds, A, s); else if (c == 256) launch(k_p3<256, false>, dim3(grid), lds, A, s); else launch(k_p3<512, false>, dim3(grid), lds, A, s);
+        if (c == 64) launch(k_p3<64, false>, dim3(grid), lds, A, s); else if (c == 128) launch(k_p3<128, false>, dim3(grid), lds, A, s); else if (c == 256) launch(k_p3<256, false>, dim3(grid), lds, A, s); else launch(k_p3<512, false>, dim3(grid), lds, A, s);
     }
 }
-void launch_p4(const LayerArgs &A, int c, int grid, hipStream_t s) { PDF_FLM(k_p4, dim3(grid), (size_t)4 * c + w2_floats(c)); }
+void launch_p4(const LayerArgs &A, int c, int grid, hipStream_t s) {
+    // no per-wave partial rows in this pass: size the grid for occupancy (one point per wave and trip, latency-bound)
+    long g = ((long)A.N + WPB - 1) / WPB;
+    g = g > 2048 ? 2048 : (g < grid ? grid : g);
+    PDF_FLM(k_p4, dim3((unsigned)g), (size_t)4 * c + w2_floats(c));
+}
 void launch_b1(const LayerArgs &A, int c, int grid, hipStream_t s) {
-    PDF_FLM(k_b1, dim3(grid), (size_t)4 * c + w2_floats(c) + WPB * 16 * TS + 2 * WPB * 16 * (c / 8 + 4) + WPB * 16);
+    PDF_FLM(k_b1, dim3(grid), (size_t)4 * c + w2_floats(c) + WPB * 16 * TS + 2 * WPB * 16 * (csp_of(c) + 4) + WPB * 16);
 }
 void launch_b2(const LayerArgs &A, int c, int grid, hipStream_t s) {
-    PDF_FLM(k_b2, dim3(grid, c / 64), (size_t)6 * c + (size_t)(c / 8) * 68 + WPB * 16 * (c / 8 + 4) + WPB * 16 * TS);
+    PDF_FLM(k_b2, dim3(grid, c / 64), (size_t)6 * c + (size_t)csp_of(c) * 68 + WPB * 16 * (csp_of(c) + 4) + WPB * 16 * TS);
 }
 void launch_b3(const LayerArgs &A, int c, int grid, hipStream_t s) {
-    PDF_FLM(k_b3, dim3(grid), (size_t)6 * c + w2_floats(c) + (size_t)(c / 8) * 68 + WPB * 16 * TS + WPB * 64 + WPB * 16);
+    PDF_FLM(k_b3, dim3(grid), (size_t)6 * c + w2_floats(c) + (size_t)csp_of(c) * 68 + WPB * 16 * TS + WPB * 64 + WPB * 16);
 }
 #undef PDF_FLM
 

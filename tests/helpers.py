@@ -43,6 +43,18 @@ def max_rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
+def l2_rel(a, b):
+    """||a-b||_2 / ||b||_2.  For GRADIENTS of two fp32 implementations of the same layer: a ReLU whose pre-activation sits
+    within rounding distance of zero (|bn(x)| ~ 1e-6 happens for ~1 in 10^5 elements) may open in one implementation and
+    close in the other; that moves ONE channel's gradients by ~1e-2 of the tensor maximum in whichever implementation --
+    fp64 sides with either (tools/pt_vs_unfused.py).  The Frobenius norm keeps such isolated kink flips at ~1e-3 while a
+    systematically wrong kernel still shows up at 1e-2 and above; forward values and buffers stay on max_rel."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
 def assert_close(a, b, tol=REL_TOL, what=""):
     if isinstance(a, torch.Tensor):
         a = a.detach().cpu().numpy()

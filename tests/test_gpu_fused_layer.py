@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import max_rel
+from helpers import l2_rel, max_rel
 
 pytestmark = pytest.mark.gpu
 
@@ -48,7 +48,8 @@ def test_fused_layer_train(C, K):
     a = run_layer(True, C, K, n, True)
     b = run_layer(False, C, K, n, True)
     assert max_rel(a["y"], b["y"]) < 2e-5, max_rel(a["y"], b["y"])
-    report = {k: (max_rel(a[k], b[k]), float(np.abs(b[k]).max())) for k in a if k != "y"}
+    # gradients in the Frobenius norm (isolated ReLU-kink flips between two fp32 implementations: helpers.l2_rel), buffers in max-rel
+    report = {k: ((max_rel if k.startswith("b_") else l2_rel)(a[k], b[k]), float(np.abs(b[k]).max())) for k in a if k != "y"}
     print({k: (f"{v[0]:.1e}", f"{v[1]:.1e}") for k, v in report.items()})
     gscale = max(v[1] for k, v in report.items() if k.startswith("g_"))
     # biases in front of a train-mode BatchNorm (and q/k biases, which cancel in r - mean(r)) have analytically zero
