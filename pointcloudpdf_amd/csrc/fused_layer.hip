@@ -910,6 +910,15 @@ static inline void allow_lds(KernelT kernel, size_t lds) {
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
+// matrix-core passes work on one point (16 rows) per wave and trip: size their grids by points, not by 64-row tiles
+// (level 5 has 780 points: 49 workgroups by tiles, 195 by points)
+static inline int grid_for_points(long n, int cap) {
+    long g = (n + WPB - 1) / WPB;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
 static inline int grid_for_tiles(long ntiles) {
     static const int cap = env_blocks("PDFOPS_PT_BLOCKS_FWD", MAX_BLOCKS);
     long g = (ntiles + WPB - 1) / WPB;
@@ -926,7 +935,8 @@ static inline int grid_for_tiles(long ntiles) {
 // `partial` = pdf_pt_layer_partial_floats(N, K, C) floats of scratch.
 extern "C" long pdf_pt_layer_partial_floats(int n, int nsample, int c) {
     const long ntiles = ((long)n * nsample + 63) / 64;
-    return (long)fl::grid_for_tiles(ntiles) * fl::WPB * 2 * (c > 3 ? c : 3);
+    const int g = flm::supported(nsample, c) ? fl::grid_for_points(n, fl::MAX_BLOCKS) : fl::grid_for_tiles(ntiles);
+    return (long)g * fl::WPB * 2 * (c > 3 ? c : 3);
 }
 
 extern "C" int pdf_pt_layer_supported(int nsample, int c) {
@@ -942,7 +952,7 @@ int forward_impl(LayerArgs A, int training, float eps, float momentum, const flo
     constexpr int CS = C / 8;
     const long rows = (long)A.N * K;
     const long ntiles = (rows + 63) / 64;
-    const int grid = grid_for_tiles(ntiles);
+    const int grid = flm::supported(K, C) ? grid_for_points(A.N, MAX_BLOCKS) : grid_for_tiles(ntiles);
     const int nw = grid * WPB;
     const size_t lds = (size_t)WPB * lds_floats_per_wave(C, false) * sizeof(float);
     float *sp = bn, *tp = bn + 3, *s1 = bn + 6, *t1 = bn + 6 + C, *s2 = bn + 6 + 2 * C, *t2 = bn + 6 + 2 * C + CS;
@@ -995,7 +1005,7 @@ int backward_impl(LayerArgs A, float *sums, hipStream_t s) {
     constexpr int CS = C / 8;
     const long rows = (long)A.N * K;
     const long ntiles = (rows + 63) / 64;
-    const int grid = grid_for_tiles_bwd(ntiles, C), nw = grid * WPB;
+    const int grid = flm::supported(K, C) ? grid_for_points(A.N, C <= 64 ? 2 * MAX_BLOCKS_BWD : MAX_BLOCKS_BWD) : grid_for_tiles_bwd(ntiles, C), nw = grid * WPB;
     const size_t lds = (size_t)WPB * lds_floats_per_wave(C, true) * sizeof(float);
     A.inv_rows = (float)(1.0 / (double)rows);
     // sums layout (floats): [S1: b1_width | S2: b2_width | S3: b3_width | S4: 16 | X: 2C + 2CS scratch for B3]
@@ -1024,7 +1034,8 @@ int backward_impl(LayerArgs A, float *sums, hipStream_t s) {
 extern "C" long pdf_pt_layer_bwd_partial_floats(int n, int nsample, int c) {
     const long ntiles = ((long)n * nsample + 63) / 64;
     const long w = 2L * c + c / 8 + (long)(c / 8) * c;  // widest pass (B2)
-    return (long)fl::grid_for_tiles_bwd(ntiles, c) * fl::WPB * w;
+    const int g = flm::supported(nsample, c) ? fl::grid_for_points(n, c <= 64 ? 2 * fl::MAX_BLOCKS_BWD : fl::MAX_BLOCKS_BWD) : fl::grid_for_tiles_bwd(ntiles, c);
+    return (long)g * fl::WPB * w;
 }
 
 // floats in the `sums` result buffer and the offsets of its four sections [S1 | S2 | S3 | S4 | scratch]

@@ -292,7 +292,9 @@ extern "C" int pdf_grouping_backward(int m, int nsample, int c, const float *gra
     if (m < 0 || nsample < 1 || c < 1 || !grad_output || !idx || !grad_input) return PDF_ERR_BAD_ARG;
     if (m == 0) return PDF_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int v = pick_vec(c);
+    // scatter-adds run one float per lane (64 consecutive floats = whole 128-byte lines per instruction): the atomic units
+    // bill per request, and the 16-byte-per-lane shape splits every line into four requests (see fused_layer.hip)
+    const int v = 1;
     const long rows = (long)m * nsample;
     DISPATCH_VEC(v, (grouping_bwd_kernel<V><<<grid_for(rows * (c / V)), GB, 0, s>>>(rows, c / V, grad_output, idx, grad_input)));
     return pdf_launch_status();
@@ -332,7 +334,9 @@ extern "C" int pdf_interpolation_backward(int n, int c, int k, const float *grad
     if (n < 0 || c < 1 || k < 1 || !grad_output || !idx || !weight || !grad_input) return PDF_ERR_BAD_ARG;
     if (n == 0) return PDF_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int v = pick_vec(c);
+    // scatter-adds run one float per lane (64 consecutive floats = whole 128-byte lines per instruction): the atomic units
+    // bill per request, and the 16-byte-per-lane shape splits every line into four requests (see fused_layer.hip)
+    const int v = 1;
     DISPATCH_VEC(v, (interp_bwd_kernel<V><<<grid_for((long)n * (c / V)), GB, 0, s>>>(n, c / V, k, grad_output, idx, weight, grad_input)));
     return pdf_launch_status();
 }
@@ -359,7 +363,9 @@ extern "C" int pdf_subtraction_backward(int n, int nsample, int c, const int *id
     if (n < 0 || nsample < 1 || c < 1 || !idx || !grad_output || !grad_input1 || !grad_input2) return PDF_ERR_BAD_ARG;
     if (n == 0) return PDF_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int v = pick_vec(c);
+    // scatter-adds run one float per lane (64 consecutive floats = whole 128-byte lines per instruction): the atomic units
+    // bill per request, and the 16-byte-per-lane shape splits every line into four requests (see fused_layer.hip)
+    const int v = 1;
     DISPATCH_VEC(v, (sub_bwd_kernel<V><<<grid_for((long)n * (c / V)), GB, 0, s>>>(n, nsample, c / V, idx, grad_output, grad_input1, grad_input2)));
     return pdf_launch_status();
 }
