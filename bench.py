@@ -162,7 +162,7 @@ def main():
     synthetic.fill_parameters_deterministic(step, seed=1)  # identical "random-init" weights on every rank
     step.train()
     module = engine.wrap_ddp(step, dev) if world > 1 else step
-    opt = torch.optim.SGD(step.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    opt = torch.optim.SGD(step.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4, fused=True)
 
     sizes = [args.points] * args.scenes
     pool = [synthetic.make_batch(sizes, first_scene_id=1000 * rank + 10 * i, device=dev) for i in range(args.pool)]

@@ -913,6 +913,8 @@ static inline void allow_lds(KernelT kernel, size_t lds) {
 // matrix-core passes work on one point (16 rows) per wave and trip: size their grids by points, not by 64-row tiles
 // (level 5 has 780 points: 49 workgroups by tiles, 195 by points)
 static inline int grid_for_points(long n, int cap) {
+    static const int env_cap = env_blocks("PDFOPS_PT_BLOCKS_MFMA", 0);
+    if (env_cap > 0) cap = env_cap;
     long g = (n + WPB - 1) / WPB;
     if (g > cap) g = cap;
     if (g < 1) g = 1;
@@ -1005,7 +1007,7 @@ int backward_impl(LayerArgs A, float *sums, hipStream_t s) {
     constexpr int CS = C / 8;
     const long rows = (long)A.N * K;
     const long ntiles = (rows + 63) / 64;
-    const int grid = flm::supported(K, C) ? grid_for_points(A.N, C <= 64 ? 2 * MAX_BLOCKS_BWD : MAX_BLOCKS_BWD) : grid_for_tiles_bwd(ntiles, C), nw = grid * WPB;
+    const int grid = flm::supported(K, C) ? grid_for_points(A.N, C <= 128 ? 2 * MAX_BLOCKS_BWD : MAX_BLOCKS_BWD) : grid_for_tiles_bwd(ntiles, C), nw = grid * WPB;
     const size_t lds = (size_t)WPB * lds_floats_per_wave(C, true) * sizeof(float);
     A.inv_rows = (float)(1.0 / (double)rows);
     // sums layout (floats): [S1: b1_width | S2: b2_width | S3: b3_width | S4: 16 | X: 2C + 2CS scratch for B3]
@@ -1034,7 +1036,7 @@ int backward_impl(LayerArgs A, float *sums, hipStream_t s) {
 extern "C" long pdf_pt_layer_bwd_partial_floats(int n, int nsample, int c) {
     const long ntiles = ((long)n * nsample + 63) / 64;
     const long w = 2L * c + c / 8 + (long)(c / 8) * c;  // widest pass (B2)
-    const int g = flm::supported(nsample, c) ? fl::grid_for_points(n, c <= 64 ? 2 * fl::MAX_BLOCKS_BWD : fl::MAX_BLOCKS_BWD) : fl::grid_for_tiles_bwd(ntiles, c);
+    const int g = flm::supported(nsample, c) ? fl::grid_for_points(n, c <= 128 ? 2 * fl::MAX_BLOCKS_BWD : fl::MAX_BLOCKS_BWD) : fl::grid_for_tiles_bwd(ntiles, c);
     return (long)g * fl::WPB * w;
 }
 

@@ -532,9 +532,9 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wv = threadIdx.x >> 6;
     float *cst = lds, *w2 = cst + 6 * C, *wl = w2 + w2_floats(C);        // wl: Ww1[:, 64 q ..+64] of the current chunk
-    float *tile = wl + CSP * WS + wv * 16 * TS;
-    float *t1nt = wl + CSP * WS + WPB * 16 * TS + wv * 64;
-    int *rowid = reinterpret_cast<int *>(wl + CSP * WS + WPB * 16 * TS + WPB * 64) + wv * 16;
+    float *tile = wl + CSP * WS + wv * 32 * TS, *tile2 = tile + 16 * TS;   // g_r tile, g_pr tile
+    float *t1nt = wl + CSP * WS + WPB * 32 * TS + wv * 64;
+    int *rowid = reinterpret_cast<int *>(wl + CSP * WS + WPB * 32 * TS + WPB * 64) + wv * 16;
     stage_consts<C>(cst, A, true);
     stage_w2<C>(w2, A);
     const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
@@ -558,9 +558,8 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
             hidden_grad<C>(A, S1, i, row, kq, gh, h);
             attn_weights<C>(A, w2, row, kq, h, u, w);
             float gt1n[3] = {0.f, 0.f, 0.f};
-            f32x4 gpr[4];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll 1
+            for (int jj = 0; jj < 4; ++jj) {   // rolled: the unrolled form kept ~240 VGPRs of loads in flight (1 wave / SIMD)
                 const int g = 4 * (4 * q + jj) + kq;
                 f32x4 acc = zero4();
 #pragma unroll
@@ -578,12 +577,16 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
                 const f32x4 rhat = (r - ld4(gp(A.mean) + 3 + 4 * g)) * ld4(gp(A.rstd) + 3 + 4 * g);
                 const f32x4 gr = s1 * (gy1 - ld4(S2 + 4 * g) * A.inv_rows - rhat * (ld4(S2 + C + 4 * g) * A.inv_rows));
                 st4(tile + row * TS + 16 * jj + 4 * kq, gr);
-                gpr[jj] = gr + ld4(A.gout + (size_t)i * C + 4 * g) * w[jj % NOB];   // + the aggregation's share of p_r
+                f32x4 wsel = w[0];   // w[jj % NOB] with a rolled jj
+#pragma unroll
+                for (int t = 1; t < NOB; ++t) if (jj % NOB == t) wsel = w[t];
+                const f32x4 gpr = gr + ld4(A.gout + (size_t)i * C + 4 * g) * wsel;   // + the aggregation's share of p_r
+                st4(tile2 + row * TS + 16 * jj + 4 * kq, gpr);
                 const f32x4 w0 = ld4(cst + 12 * g), w1 = ld4(cst + 12 * g + 4), w2v = ld4(cst + 12 * g + 8);
                 const float wp[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2v[0], w2v[1], w2v[2], w2v[3]};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    gt1n[0] += gpr[jj][e] * wp[3 * e]; gt1n[1] += gpr[jj][e] * wp[3 * e + 1]; gt1n[2] += gpr[jj][e] * wp[3 * e + 2];
+                    gt1n[0] += gpr[e] * wp[3 * e]; gt1n[1] += gpr[e] * wp[3 * e + 1]; gt1n[2] += gpr[e] * wp[3 * e + 2];
                 }
             }
             wave_sync();
@@ -598,13 +601,9 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
                 }
                 A.gxq[(size_t)i * C + 64 * q + lane] = -acc;
             }
-            wave_sync();
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) st4(tile + row * TS + 16 * jj + 4 * kq, gpr[jj]);
-            wave_sync();
 #pragma unroll 4
             for (int rr = 0; rr < 16; ++rr) {   // g_bp2 / g_Wp2 of channel 64 q + lane
-                const float v = tile[rr * TS + lane];
+                const float v = tile2[rr * TS + lane];
                 sbp2 += v;
                 awp2[0] += v * t1nt[rr * 4 + 0]; awp2[1] += v * t1nt[rr * 4 + 1]; awp2[2] += v * t1nt[rr * 4 + 2];
             }
@@ -675,7 +674,7 @@ void launch_b2(const LayerArgs &A, int c, int grid, hipStream_t s) {
     PDF_FLM(k_b2, dim3(grid, c / 64), (size_t)6 * c + (size_t)csp_of(c) * 68 + WPB * 16 * (csp_of(c) + 4) + WPB * 16 * TS);
 }
 void launch_b3(const LayerArgs &A, int c, int grid, hipStream_t s) {
-    PDF_FLM(k_b3, dim3(grid), (size_t)6 * c + w2_floats(c) + (size_t)csp_of(c) * 68 + WPB * 16 * TS + WPB * 64 + WPB * 16);
+    PDF_FLM(k_b3, dim3(grid), (size_t)6 * c + w2_floats(c) + (size_t)csp_of(c) * 68 + WPB * 32 * TS + WPB * 64 + WPB * 16);
 }
 #undef PDF_FLM
 

@@ -6,7 +6,7 @@ from pointcloudpdf_amd import engine, synthetic
 from pointcloudpdf_amd.geometry import Geometry
 dev = torch.device("cuda")
 step = engine.OpenSegStep().to(dev); synthetic.fill_parameters_deterministic(step, seed=1); step.train()
-opt = torch.optim.SGD(step.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+opt = torch.optim.SGD(step.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4, fused=True)
 b = synthetic.make_batch([100000, 100000], device=dev)
 geom = Geometry(b["coord"], b["offset"], b["offset_host"]).precompute()
 torch.cuda.synchronize()
