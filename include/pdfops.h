@@ -195,6 +195,9 @@ int pdf_block_pre_forward(long n, int c, void *const *p, int training, float eps
 int pdf_block_pre_backward(long n, int c, void *const *p, int training, void *stream);
 int pdf_block_post_forward(long n, int c, void *const *p, int training, float eps, float momentum, void *stream);
 int pdf_block_post_backward(long n, int c, void *const *p, int training, void *stream);
+/* The whole Bottleneck (both halves + the fused attention layer) as one call per direction; tables in csrc/block.hip. */
+int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p, int training, float eps, float momentum, void *stream);
+int pdf_bottleneck_backward(long n, int nsample, int c, void *const *p, int training, void *stream);
 
 #ifdef __cplusplus
 }

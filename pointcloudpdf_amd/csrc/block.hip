@@ -46,7 +46,7 @@ extern "C" int pdf_block_pre_forward(long n, int c, void *const *p, int training
 // p[]: x, z1, coef1, W1, Wq, Wk, Wv, gxq, gxk, gxv                                  (inputs)
 //      gx, grads [dW1 (c*c) | dbeta1 (c) | dgamma1 (c) | {dW (c*c), db (c)} x q,k,v]   (outputs; grads zeroed here)
 //      dy (n*c), partial (pdf_bn_partial_floats(n, c))                                    (scratch; p[14] unused)
-extern "C" int pdf_block_pre_backward(long n, int c, void *const *p, int training, void *stream) {
+static int block_pre_backward(long n, int c, void *const *p, int training, int accumulate_gx, void *stream) {
     if (n < 1 || !p) return PDF_ERR_BAD_ARG;
     const float *x = (const float *)p[0], *z1 = (const float *)p[1], *coef1 = (const float *)p[2], *W1 = (const float *)p[3];
     float *gx = (float *)p[10], *grads = (float *)p[11], *dy = (float *)p[12], *partial = (float *)p[13];
@@ -64,9 +64,13 @@ extern "C" int pdf_block_pre_backward(long n, int c, void *const *p, int trainin
     e << pdf_rowlin_wgrad_multi(n, c, c, 3, gs, c, z1, c, coef1, coef1 + c, 1, dws, dbs, stream);
     // bn1 backward in place on dy (elementwise: same index read and written); its column sums ARE [d beta1 | d gamma1]
     e << pdf_bn_act_backward(n, c, dy, z1, nullptr, coef1, training, 1, partial, db1, dy, nullptr, stream);
-    e << pdf_rowlin_forward(n, c, c, dy, c, W1, 1, nullptr, nullptr, nullptr, 0, gx, c, 0, nullptr, stream);
+    e << pdf_rowlin_forward(n, c, c, dy, c, W1, 1, nullptr, nullptr, nullptr, 0, gx, c, accumulate_gx, nullptr, stream);
     e << pdf_rowlin_wgrad(n, c, c, dy, c, x, c, nullptr, nullptr, 0, dW1, nullptr, stream);
     return e.rc;
+}
+
+extern "C" int pdf_block_pre_backward(long n, int c, void *const *p, int training, void *stream) {
+    return block_pre_backward(n, c, p, training, 0, stream);
 }
 
 // p[]: t, x (identity), gamma2, beta2, rm2, rv2, W3, gamma3, beta3, rm3, rv3        (inputs)
@@ -105,5 +109,59 @@ extern "C" int pdf_block_post_backward(long n, int c, void *const *p, int traini
     e << pdf_rowlin_forward(n, c, c, da, c, W3, 1, nullptr, nullptr, nullptr, 0, gt, c, 0, nullptr, stream);
     // bn2 backward in place on gt
     e << pdf_bn_act_backward(n, c, gt, t, nullptr, coef2, training, 1, partial, db2, gt, nullptr, stream);
+    return e.rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The whole Bottleneck (point_transformer_seg.py:184-192: linear1-bn1-relu, PointTransformerLayer, bn2-relu, linear3-bn3,
+// + identity, relu) as ONE host call per direction: pre half, fused attention layer (fused_layer*.hip), post half.
+// Forward table p[]:
+//    0 x | 1 W1 2 gamma1 3 beta1 4 rm1 5 rv1 | 6 Wq 7 bq 8 Wk 9 bk 10 Wv 11 bv | 12 coord 13 knn idx
+//   14-21 layer weights (Wp1 bp1 Wp2 bp2 Ww1 bw1 Ww2 bw2) | 22-27 layer norm params (g_p b_p g_1 b_1 g_2 b_2)
+//   28-33 layer norm buffers (rm/rv x3) | 34 gamma2 35 beta2 36 rm2 37 rv2 | 38 W3 | 39 gamma3 40 beta3 41 rm3 42 rv3
+//   saved / outputs: 43 z1 44 coef1 45 xq 46 xk 47 xv 48 layer bn (2T) 49 layer saved (2T) 50 H 51 t 52 coef2 53 z3 54 coef3 55 y
+//   56 scratch (max of pdf_rowlin_partial_floats, pdf_bn_partial_floats, pdf_pt_layer_partial_floats)
+extern "C" int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p, int training, float eps, float momentum, void *stream) {
+    if (n < 1 || !p) return PDF_ERR_BAD_ARG;
+    Err e;
+    void *pre[18] = {p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], p[10], p[11], p[43], p[44], p[45], p[46], p[47], p[56]};
+    e << pdf_block_pre_forward(n, c, pre, training, eps, momentum, stream);
+    const float *weights[8], *bn_params[6];
+    float *bn_buffers[6];
+    for (int i = 0; i < 8; ++i) weights[i] = (const float *)p[14 + i];
+    for (int i = 0; i < 6; ++i) { bn_params[i] = (const float *)p[22 + i]; bn_buffers[i] = (float *)p[28 + i]; }
+    e << pdf_pt_layer_forward((int)n, nsample, c, (const float *)p[45], (const float *)p[46], (const float *)p[47], (const float *)p[12],
+                              (const int *)p[13], weights, bn_params, bn_buffers, training, eps, momentum, (float *)p[48], (float *)p[49],
+                              (float *)p[50], (float *)p[56], (float *)p[51], stream);
+    void *post[16] = {p[51], p[0], p[34], p[35], p[36], p[37], p[38], p[39], p[40], p[41], p[42], p[52], p[53], p[54], p[55], p[56]};
+    e << pdf_block_post_forward(n, c, post, training, eps, momentum, stream);
+    return e.rc;
+}
+
+// Backward table p[]:
+//    0 gy | 1 x 2 z1 3 coef1 4 W1 5 Wq 6 Wk 7 Wv | 8 coord 9 knn idx 10-17 layer weights 18 layer bn 19 layer saved 20 H
+//   21 xq 22 xk 23 xv | 24 t 25 z3 26 coef2 27 coef3 28 W3
+//   outputs: 29 gx (n*c; = identity branch + linear1 branch) 30 grads of the pre half (block_pre_backward layout)
+//            31 grads of the post half (pdf_block_post_backward layout) 32 layer sums (pdf_pt_layer_bwd_sums_floats(c))
+//   scratch: 33 gt 34 da / dy 35 gxq 36 gxk 37 gxv (n*c each) 38 G2 (n*nsample*c/8) 39 G3 (n*nsample*3)
+//            40 partial (max of pdf_bn_partial_floats, pdf_pt_layer_bwd_partial_floats)
+extern "C" int pdf_bottleneck_backward(long n, int nsample, int c, void *const *p, int training, void *stream) {
+    if (n < 1 || !p) return PDF_ERR_BAD_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Err e;
+    void *post[13] = {p[0], p[24], p[1], p[25], p[26], p[27], p[28], p[33], p[29], p[31], p[34], p[40], nullptr};
+    e << pdf_block_post_backward(n, c, post, training, stream);
+    hipError_t he = hipMemsetAsync(p[36], 0, sizeof(float) * (size_t)n * c, s);   // scatter targets of the layer backward
+    if (he != hipSuccess) return (int)he;
+    he = hipMemsetAsync(p[37], 0, sizeof(float) * (size_t)n * c, s);
+    if (he != hipSuccess) return (int)he;
+    const float *weights[8];
+    for (int i = 0; i < 8; ++i) weights[i] = (const float *)p[10 + i];
+    e << pdf_pt_layer_backward((int)n, nsample, c, (const float *)p[21], (const float *)p[22], (const float *)p[23], (const float *)p[8],
+                               (const int *)p[9], weights, (const float *)p[18], (const float *)p[19], (const float *)p[20],
+                               (const float *)p[33], (float *)p[35], (float *)p[36], (float *)p[37], (float *)p[38], (float *)p[39],
+                               (float *)p[40], (float *)p[32], stream);
+    void *pre[15] = {p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[35], p[36], p[37], p[29], p[30], p[34], p[40], nullptr};
+    e << block_pre_backward(n, c, pre, training, 1, stream);   // gx += dy W1 on top of the identity branch
     return e.rc;
 }

@@ -6,6 +6,9 @@ single 32x32 macro-tile with K = N on ONE workgroup (measured 270 us per call, 4
 keeps nn.Linear's parameters but routes that one product through a batched GEMM over row chunks (split-K expressed
 as a batch: S = N / 2048 independent products, summed afterwards), which fills the chip.
 """
+import ctypes
+from ctypes import c_void_p
+
 import torch
 import torch.nn.functional as F
 
@@ -330,9 +333,132 @@ class _BlockPost(torch.autograd.Function):
                 grads[cc + 2 * c:cc + 3 * c], None)
 
 
-def bottleneck(blk, p, x, o):
-    """Bottleneck.forward through the two host-side halves and the (fused) attention layer."""
+# ------------------------------------------------------------------------------------------------------------------
+# The whole Bottleneck as ONE autograd node and ONE host call per direction (csrc/block.hip: pdf_bottleneck_*): the forward
+# of the step is host-bound, and three Function.apply + ~25 allocations + three ctypes calls per block were most of it.
+# ------------------------------------------------------------------------------------------------------------------
+def _al(v):
+    return (v + 63) & ~63   # 256-byte aligned sub-buffers
+
+
+class _BottleneckFn(torch.autograd.Function):
+    """params: W1 g1 b1 | Wq bq Wk bk Wv bv | layer: Wp1 bp1 gp bp Wp2 bp2 g1' b1' Ww1 bw1 g2' b2' Ww2 bw2 | g2 b2 W3 g3 b3"""
+
+    @staticmethod
+    def forward(ctx, blk, idx, p, x, *params):
+        be = _be()
+        lib = be.lib
+        n, c = x.shape
+        k = idx.shape[1]
+        cs, T = c // 8, 3 + c + c // 8
+        t = blk.transformer
+        lp, lw = t.linear_p, t.linear_w
+        training = blk.training
+        (W1, g1, b1, Wq, bq, Wk, bk, Wv, bv, Wp1, bp1, gp, bp, Wp2, bp2, g1p, b1p, Ww1, bw1, g2p, b2p, Ww2, bw2, g2, b2, W3, g3, b3) = params
+        nc = n * c
+        sizes = [nc, 4 * c, nc, nc, nc, 2 * T, 2 * T, n * k * cs, nc, 4 * c, nc, 4 * c]   # z1 coef1 xq xk xv bn saved H t coef2 z3 coef3
+        offs, tot = [], 0
+        for sz in sizes:
+            offs.append(tot)
+            tot += _al(sz)
+        act = torch.empty((tot,), dtype=torch.float32, device=x.device)
+        y = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        scratch = torch.empty((max(int(lib.pdf_rowlin_partial_floats(n, c)), int(lib.pdf_bn_partial_floats(n, c)),
+                                   int(lib.pdf_pt_layer_partial_floats(n, k, c))),), dtype=torch.float32, device=x.device)
+        base = act.data_ptr()
+        ap = [base + 4 * o for o in offs]
+        bn1, bn2, bn3 = blk.bn1, blk.bn2, blk.bn3
+        ptrs = [x.data_ptr(), W1.data_ptr(), g1.data_ptr(), b1.data_ptr(), bn1.running_mean.data_ptr(), bn1.running_var.data_ptr(),
+                Wq.data_ptr(), bq.data_ptr(), Wk.data_ptr(), bk.data_ptr(), Wv.data_ptr(), bv.data_ptr(), p.data_ptr(), idx.data_ptr(),
+                Wp1.data_ptr(), bp1.data_ptr(), Wp2.data_ptr(), bp2.data_ptr(), Ww1.data_ptr(), bw1.data_ptr(), Ww2.data_ptr(), bw2.data_ptr(),
+                gp.data_ptr(), bp.data_ptr(), g1p.data_ptr(), b1p.data_ptr(), g2p.data_ptr(), b2p.data_ptr(),
+                lp[1].running_mean.data_ptr(), lp[1].running_var.data_ptr(), lw[0].running_mean.data_ptr(), lw[0].running_var.data_ptr(),
+                lw[3].running_mean.data_ptr(), lw[3].running_var.data_ptr(),
+                g2.data_ptr(), b2.data_ptr(), bn2.running_mean.data_ptr(), bn2.running_var.data_ptr(), W3.data_ptr(),
+                g3.data_ptr(), b3.data_ptr(), bn3.running_mean.data_ptr(), bn3.running_var.data_ptr(),
+                *ap, y.data_ptr(), scratch.data_ptr()]
+        rc = lib.pdf_bottleneck_forward(n, k, c, (c_void_p * len(ptrs))(*ptrs), int(training), ctypes.c_float(bn1.eps),
+                                        ctypes.c_float(bn1.momentum or 0.1), be._stream())
+        if rc != 0:
+            raise RuntimeError(f"pdf_bottleneck_forward failed with status {rc}")
+        ctx.save_for_backward(x, p, idx, act, W1, Wq, Wk, Wv, W3, Wp1, bp1, Wp2, bp2, Ww1, bw1, Ww2, bw2)
+        ctx.cfg = (training, offs, k)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        training, offs, k = ctx.cfg
+        if not training:
+            raise RuntimeError("fused Bottleneck: backward is implemented for training mode (batch statistics)")
+        x, p, idx, act, W1, Wq, Wk, Wv, W3, Wp1, bp1, Wp2, bp2, Ww1, bw1, Ww2, bw2 = ctx.saved_tensors
+        be = _be()
+        lib = be.lib
+        n, c = x.shape
+        cs, cc, nc = c // 8, c * c, n * c
+        gy = gy.contiguous()
+        npre, npost, nsum = cc + 2 * c + 3 * (cc + c), cc + 4 * c, int(lib.pdf_pt_layer_bwd_sums_floats(c))
+        o_pre, o_post, o_sum = 0, _al(npre), _al(npre) + _al(npost)
+        grads = torch.empty((o_sum + _al(nsum),), dtype=torch.float32, device=x.device)
+        gx = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        ssz = [nc, nc, nc, nc, nc, n * k * cs, n * k * 3,
+               max(int(lib.pdf_bn_partial_floats(n, c)), int(lib.pdf_pt_layer_bwd_partial_floats(n, k, c)))]   # gt da gxq gxk gxv G2 G3 partial
+        soff, tot = [], 0
+        for sz in ssz:
+            soff.append(tot)
+            tot += _al(sz)
+        scratch = torch.empty((tot,), dtype=torch.float32, device=x.device)
+        a, sb, gb = act.data_ptr(), scratch.data_ptr(), grads.data_ptr()
+        A = lambda i: a + 4 * offs[i]   # z1 coef1 xq xk xv bn saved H t coef2 z3 coef3
+        S = lambda i: sb + 4 * soff[i]
+        ptrs = [gy.data_ptr(), x.data_ptr(), A(0), A(1), W1.data_ptr(), Wq.data_ptr(), Wk.data_ptr(), Wv.data_ptr(), p.data_ptr(), idx.data_ptr(),
+                Wp1.data_ptr(), bp1.data_ptr(), Wp2.data_ptr(), bp2.data_ptr(), Ww1.data_ptr(), bw1.data_ptr(), Ww2.data_ptr(), bw2.data_ptr(),
+                A(5), A(6), A(7), A(2), A(3), A(4), A(8), A(10), A(9), A(11), W3.data_ptr(),
+                gx.data_ptr(), gb + 4 * o_pre, gb + 4 * o_post, gb + 4 * o_sum,
+                S(0), S(1), S(2), S(3), S(4), S(5), S(6), S(7)]
+        rc = lib.pdf_bottleneck_backward(n, k, c, (c_void_p * len(ptrs))(*ptrs), int(training), be._stream())
+        if rc != 0:
+            raise RuntimeError(f"pdf_bottleneck_backward failed with status {rc}")
+        G = lambda o, sz, *shape: grads[o:o + sz].view(*shape) if shape else grads[o:o + sz]
+        # pre half: dW1 | dbeta1 | dgamma1 | {dW, db} x q, k, v
+        dW1, db1, dg1 = G(o_pre, cc, c, c), G(o_pre + cc, c), G(o_pre + cc + c, c)
+        q0 = o_pre + cc + 2 * c
+        qkv = []
+        for i in range(3):
+            qkv += [G(q0 + i * (cc + c), cc, c, c), G(q0 + i * (cc + c) + cc, c)]
+        # post half: dW3 | dbeta2 | dgamma2 | dbeta3 | dgamma3
+        dW3, db2, dg2, db3, dg3 = G(o_post, cc, c, c), G(o_post + cc, c), G(o_post + cc + c, c), G(o_post + cc + 2 * c, c), G(o_post + cc + 3 * c, c)
+        # layer sums (csrc/fused_layer.hip, pdf_pt_layer_backward): S1 | S2 | S3 | S4
+        o1 = o_sum
+        o2 = o1 + 3 * cs + cs * cs
+        o3 = o2 + 2 * c + cs + cs * c
+        o4 = o3 + 8 + 4 * c
+        beta2p, gamma2p, dbw2, dWw2 = G(o1, cs), G(o1 + cs, cs), G(o1 + 2 * cs, cs), G(o1 + 3 * cs, cs * cs, cs, cs)
+        beta1p, gamma1p, dbw1, dWw1 = G(o2, c), G(o2 + c, c), G(o2 + 2 * c, cs), G(o2 + 2 * c + cs, cs * c, cs, c)
+        betap, gammap, dbp2, dWp2 = G(o3, 3), G(o3 + 3, 3), G(o3 + 8, c), G(o3 + 8 + c, 3 * c, c, 3)
+        dbp1, dWp1 = G(o4, 3), G(o4 + 3, 9, 3, 3)
+        layer = [dWp1, dbp1, gammap, betap, dWp2, dbp2, gamma1p, beta1p, dWw1, dbw1, gamma2p, beta2p, dWw2, dbw2]
+        return (None, None, None, gx, dW1, dg1, db1, *qkv, *layer, dg2, db2, dW3, dg3, db3)
+
+
+def _bottleneck_params(blk):
     t = blk.transformer
+    return [blk.linear1.weight, blk.bn1.weight, blk.bn1.bias, t.linear_q.weight, t.linear_q.bias, t.linear_k.weight, t.linear_k.bias,
+            t.linear_v.weight, t.linear_v.bias, *t._param_list(), blk.bn2.weight, blk.bn2.bias, blk.linear3.weight, blk.bn3.weight, blk.bn3.bias]
+
+
+def bottleneck(blk, p, x, o):
+    """Bottleneck.forward through the fused kernels: one autograd node when the attention layer is fused too, else the two
+    host-side halves around PointTransformerLayer.attend."""
+    t = blk.transformer
+    if t._fused_ok(x):
+        from . import pointops
+        idx, _ = pointops.knn_query(t.nsample, p, o, p, o)
+        y = _BottleneckFn.apply(blk, idx, p, x, *_bottleneck_params(blk))
+        if blk.training:
+            lp, lw = t.linear_p, t.linear_w
+            bump_counters([blk.bn1.num_batches_tracked, blk.bn2.num_batches_tracked, blk.bn3.num_batches_tracked,
+                           lp[1].num_batches_tracked, lw[0].num_batches_tracked, lw[3].num_batches_tracked])
+        return y
     xq, xk, xv = _BlockPre.apply(x, blk.linear1.weight, blk.bn1.weight, blk.bn1.bias, t.linear_q.weight, t.linear_q.bias,
                                  t.linear_k.weight, t.linear_k.bias, t.linear_v.weight, t.linear_v.bias, blk)
     a = t.attend(p, x, o, xq, xk, xv)
