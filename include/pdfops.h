@@ -154,6 +154,9 @@ int pdf_bn_act_forward(long n, int c, const float *x, const float *res, const fl
                        float *coef, float *partial, float *y, void *stream);
 int pdf_bn_act_backward(long n, int c, const float *gy, const float *x, const float *res, const float *coef,
                         int training, int relu, float *partial, float *sums, float *gx, float *gres, void *stream);
+/* as pdf_bn_act_backward with sums zeroed by the caller (block sums added atomically, no column-sum pass) */
+int pdf_bn_act_backward_acc(long n, int c, const float *gy, const float *x, const float *res, const float *coef,
+                            int training, int relu, float *sums, float *gx, float *gres, void *stream);
 
 /* coefficients only (statistics pass + finalize, or running statistics) */
 int pdf_bn_coef(long n, int c, const float *x, const float *gamma, const float *beta, float *running_mean,

@@ -46,15 +46,17 @@ extern "C" int pdf_block_pre_forward(long n, int c, void *const *p, int training
 // p[]: x, z1, coef1, W1, Wq, Wk, Wv, gxq, gxk, gxv                                  (inputs)
 //      gx, grads [dW1 (c*c) | dbeta1 (c) | dgamma1 (c) | {dW (c*c), db (c)} x q,k,v]   (outputs; grads zeroed here)
 //      dy (n*c), partial (pdf_bn_partial_floats(n, c))                                    (scratch; p[14] unused)
-static int block_pre_backward(long n, int c, void *const *p, int training, int accumulate_gx, void *stream) {
+static int block_pre_backward(long n, int c, void *const *p, int training, int accumulate_gx, int grads_zeroed, void *stream) {
     if (n < 1 || !p) return PDF_ERR_BAD_ARG;
     const float *x = (const float *)p[0], *z1 = (const float *)p[1], *coef1 = (const float *)p[2], *W1 = (const float *)p[3];
-    float *gx = (float *)p[10], *grads = (float *)p[11], *dy = (float *)p[12], *partial = (float *)p[13];
+    float *gx = (float *)p[10], *grads = (float *)p[11], *dy = (float *)p[12];
     const long cc = (long)c * c;
     float *dW1 = grads, *db1 = grads + cc, *dqkv = db1 + 2 * c;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t he = hipMemsetAsync(grads, 0, sizeof(float) * (size_t)(cc + 2 * c + 3 * (cc + c)), s);
-    if (he != hipSuccess) return (int)he;
+    if (!grads_zeroed) {
+        hipError_t he = hipMemsetAsync(grads, 0, sizeof(float) * (size_t)(cc + 2 * c + 3 * (cc + c)), s);
+        if (he != hipSuccess) return (int)he;
+    }
     Err e;
     const float *gs[3] = {(const float *)p[7], (const float *)p[8], (const float *)p[9]};
     const float *ws[3] = {(const float *)p[4], (const float *)p[5], (const float *)p[6]};
@@ -63,14 +65,14 @@ static int block_pre_backward(long n, int c, void *const *p, int training, int a
     e << pdf_rowlin_multi(n, c, c, 3, 1, gs, c, ws, 1, nullptr, nullptr, nullptr, 0, ys, c, 0, stream);
     e << pdf_rowlin_wgrad_multi(n, c, c, 3, gs, c, z1, c, coef1, coef1 + c, 1, dws, dbs, stream);
     // bn1 backward in place on dy (elementwise: same index read and written); its column sums ARE [d beta1 | d gamma1]
-    e << pdf_bn_act_backward(n, c, dy, z1, nullptr, coef1, training, 1, partial, db1, dy, nullptr, stream);
+    e << pdf_bn_act_backward_acc(n, c, dy, z1, nullptr, coef1, training, 1, db1, dy, nullptr, stream);   // db1 zeroed with grads
     e << pdf_rowlin_forward(n, c, c, dy, c, W1, 1, nullptr, nullptr, nullptr, 0, gx, c, accumulate_gx, nullptr, stream);
     e << pdf_rowlin_wgrad(n, c, c, dy, c, x, c, nullptr, nullptr, 0, dW1, nullptr, stream);
     return e.rc;
 }
 
 extern "C" int pdf_block_pre_backward(long n, int c, void *const *p, int training, void *stream) {
-    return block_pre_backward(n, c, p, training, 0, stream);
+    return block_pre_backward(n, c, p, training, 0, 0, stream);
 }
 
 // p[]: t, x (identity), gamma2, beta2, rm2, rv2, W3, gamma3, beta3, rm3, rv3        (inputs)
@@ -92,24 +94,30 @@ extern "C" int pdf_block_post_forward(long n, int c, void *const *p, int trainin
 // p[]: gy, t, x, z3, coef2, coef3, W3                                               (inputs)
 //      gt, gres, grads [dW3 (c*c) | dbeta2 | dgamma2 | dbeta3 | dgamma3]             (outputs; grads zeroed here)
 //      da (n*c), partial                                                              (scratch; p[12] unused)
-extern "C" int pdf_block_post_backward(long n, int c, void *const *p, int training, void *stream) {
+static int block_post_backward(long n, int c, void *const *p, int training, int grads_zeroed, void *stream) {
     if (n < 1 || !p) return PDF_ERR_BAD_ARG;
     const float *gy = (const float *)p[0], *t = (const float *)p[1], *x = (const float *)p[2], *z3 = (const float *)p[3];
     const float *coef2 = (const float *)p[4], *coef3 = (const float *)p[5], *W3 = (const float *)p[6];
-    float *gt = (float *)p[7], *gres = (float *)p[8], *grads = (float *)p[9], *da = (float *)p[10], *partial = (float *)p[11];
+    float *gt = (float *)p[7], *gres = (float *)p[8], *grads = (float *)p[9], *da = (float *)p[10];
     const long cc = (long)c * c;
     float *dW3 = grads, *db2 = grads + cc, *db3 = db2 + 2 * c;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t he = hipMemsetAsync(grads, 0, sizeof(float) * (size_t)(cc + 4 * c), s);
-    if (he != hipSuccess) return (int)he;
+    if (!grads_zeroed) {
+        hipError_t he = hipMemsetAsync(grads, 0, sizeof(float) * (size_t)(cc + 4 * c), s);
+        if (he != hipSuccess) return (int)he;
+    }
     Err e;
     // bn3 backward: gz3 -> da (scratch), gres; column sums land in the gradient slots [d beta | d gamma]
-    e << pdf_bn_act_backward(n, c, gy, z3, x, coef3, training, 1, partial, db3, da, gres, stream);
+    e << pdf_bn_act_backward_acc(n, c, gy, z3, x, coef3, training, 1, db3, da, gres, stream);
     e << pdf_rowlin_wgrad(n, c, c, da, c, t, c, coef2, coef2 + c, 1, dW3, nullptr, stream);
     e << pdf_rowlin_forward(n, c, c, da, c, W3, 1, nullptr, nullptr, nullptr, 0, gt, c, 0, nullptr, stream);
     // bn2 backward in place on gt
-    e << pdf_bn_act_backward(n, c, gt, t, nullptr, coef2, training, 1, partial, db2, gt, nullptr, stream);
+    e << pdf_bn_act_backward_acc(n, c, gt, t, nullptr, coef2, training, 1, db2, gt, nullptr, stream);
     return e.rc;
+}
+
+extern "C" int pdf_block_post_backward(long n, int c, void *const *p, int training, void *stream) {
+    return block_post_backward(n, c, p, training, 0, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -142,6 +150,7 @@ extern "C" int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p
 //    0 gy | 1 x 2 z1 3 coef1 4 W1 5 Wq 6 Wk 7 Wv | 8 coord 9 knn idx 10-17 layer weights 18 layer bn 19 layer saved 20 H
 //   21 xq 22 xk 23 xv | 24 t 25 z3 26 coef2 27 coef3 28 W3
 //   outputs: 29 gx (n*c; = identity branch + linear1 branch) 30 grads of the pre half (block_pre_backward layout)
+//            [30 | 31 | 36 | 37 must be laid out contiguously in this order: they are zeroed with one memset]
 //            31 grads of the post half (pdf_block_post_backward layout) 32 layer sums (pdf_pt_layer_bwd_sums_floats(c))
 //   scratch: 33 gt 34 da / dy 35 gxq 36 gxk 37 gxv (n*c each) 38 G2 (n*nsample*c/8) 39 G3 (n*nsample*3)
 //            40 partial (max of pdf_bn_partial_floats, pdf_pt_layer_bwd_partial_floats)
@@ -150,11 +159,10 @@ extern "C" int pdf_bottleneck_backward(long n, int nsample, int c, void *const *
     hipStream_t s = static_cast<hipStream_t>(stream);
     Err e;
     void *post[13] = {p[0], p[24], p[1], p[25], p[26], p[27], p[28], p[33], p[29], p[31], p[34], p[40], nullptr};
-    e << pdf_block_post_backward(n, c, post, training, stream);
-    hipError_t he = hipMemsetAsync(p[36], 0, sizeof(float) * (size_t)n * c, s);   // scatter targets of the layer backward
+    // ONE memset: the caller lays out [grads of the pre half | grads of the post half | gxk | gxv] contiguously (p[30] .. end of p[37])
+    hipError_t he = hipMemsetAsync(p[30], 0, (size_t)((char *)p[37] - (char *)p[30]) + sizeof(float) * (size_t)n * c, s);
     if (he != hipSuccess) return (int)he;
-    he = hipMemsetAsync(p[37], 0, sizeof(float) * (size_t)n * c, s);
-    if (he != hipSuccess) return (int)he;
+    e << block_post_backward(n, c, post, training, 1, stream);
     const float *weights[8];
     for (int i = 0; i < 8; ++i) weights[i] = (const float *)p[10 + i];
     e << pdf_pt_layer_backward((int)n, nsample, c, (const float *)p[21], (const float *)p[22], (const float *)p[23], (const float *)p[8],
@@ -162,6 +170,6 @@ extern "C" int pdf_bottleneck_backward(long n, int nsample, int c, void *const *
                                (const float *)p[33], (float *)p[35], (float *)p[36], (float *)p[37], (float *)p[38], (float *)p[39],
                                (float *)p[40], (float *)p[32], stream);
     void *pre[15] = {p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[35], p[36], p[37], p[29], p[30], p[34], p[40], nullptr};
-    e << block_pre_backward(n, c, pre, training, 1, stream);   // gx += dy W1 on top of the identity branch
+    e << block_pre_backward(n, c, pre, training, 1, 1, stream);   // gx += dy W1 on top of the identity branch
     return e.rc;
 }

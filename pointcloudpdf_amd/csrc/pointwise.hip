@@ -67,7 +67,8 @@ __global__ __launch_bounds__(PB) void k_bn_apply(long n4, int c4, const float4 *
 __global__ __launch_bounds__(PB) void k_bn_bwd_reduce(long n, int c, const float *__restrict__ gy, const float *__restrict__ x,
                                                       const float *__restrict__ res, const float *__restrict__ scale,
                                                       const float *__restrict__ shift, const float *__restrict__ mean,
-                                                      const float *__restrict__ rstd, int relu, float *__restrict__ partial) {
+                                                      const float *__restrict__ rstd, int relu, float *__restrict__ partial,
+                                                      float *__restrict__ sums_acc) {
     extern __shared__ float red[];
     const int tpr = c / 4, rpb = PB / tpr;
     const int tr = threadIdx.x / tpr, tc = threadIdx.x % tpr;
@@ -100,7 +101,8 @@ __global__ __launch_bounds__(PB) void k_bn_bwd_reduce(long n, int c, const float
             float a = 0.f;
             for (int rr = 0; rr < rpb; ++rr) a += red[(rr * tpr + threadIdx.x) * 8 + k];
             const int ch = threadIdx.x * 4 + (k & 3);
-            partial[(size_t)blockIdx.x * 2 * c + (k < 4 ? ch : c + ch)] = a;
+            if (sums_acc) pdf_atomic_add(sums_acc + (k < 4 ? ch : c + ch), a);   // pre-zeroed sums: no column-sum launch
+            else partial[(size_t)blockIdx.x * 2 * c + (k < 4 ? ch : c + ch)] = a;
         }
     }
 }
@@ -199,16 +201,17 @@ extern "C" int pdf_bn_act_forward(long n, int c, const float *x, const float *re
 }
 
 // Backward.  sums (2c floats) receives [d beta | d gamma] = [sum g' | sum g' * xhat]; gres may be null.
-extern "C" int pdf_bn_act_backward(long n, int c, const float *gy, const float *x, const float *res, const float *coef,
-                                   int training, int relu, float *partial, float *sums, float *gx, float *gres, void *stream) {
-    if (n < 1 || !gy || !x || !coef || !partial || !sums || !gx) return PDF_ERR_BAD_ARG;
+static int bn_act_backward(long n, int c, const float *gy, const float *x, const float *res, const float *coef,
+                           int training, int relu, float *partial, float *sums, int sums_zeroed, float *gx, float *gres, void *stream) {
+    if (n < 1 || !gy || !x || !coef || (!partial && !sums_zeroed) || !sums || !gx) return PDF_ERR_BAD_ARG;
     if (!pdf_bn_supported(c)) return PDF_ERR_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const float *scale = coef, *shift = coef + c, *mean = coef + 2 * c, *rstd = coef + 3 * c;
     const int g = pw::grid_rows(n, c);
     const long n4 = n * (c / 4);
-    pw::k_bn_bwd_reduce<<<g, pw::PB, pw::PB * 8 * sizeof(float), s>>>(n, c, gy, x, res, scale, shift, mean, rstd, relu, partial);
-    fl::launch_colsum(partial, g, 2 * c, sums, s);
+    pw::k_bn_bwd_reduce<<<g, pw::PB, pw::PB * 8 * sizeof(float), s>>>(n, c, gy, x, res, scale, shift, mean, rstd, relu, partial,
+                                                                      sums_zeroed ? sums : nullptr);
+    if (!sums_zeroed) fl::launch_colsum(partial, g, 2 * c, sums, s);
 #define F4(p) reinterpret_cast<const float4 *>(p)
     if (training)
         pw::k_bn_bwd_apply<<<pw::grid_elems(n4), pw::PB, 0, s>>>(n4, c / 4, F4(gy), F4(x), F4(res), F4(scale), F4(shift), F4(mean), F4(rstd),
@@ -219,6 +222,16 @@ extern "C" int pdf_bn_act_backward(long n, int c, const float *gy, const float *
                                                                reinterpret_cast<float4 *>(gx), reinterpret_cast<float4 *>(gres));
 #undef F4
     return pdf_launch_status();
+}
+
+extern "C" int pdf_bn_act_backward(long n, int c, const float *gy, const float *x, const float *res, const float *coef,
+                                   int training, int relu, float *partial, float *sums, float *gx, float *gres, void *stream) {
+    return bn_act_backward(n, c, gy, x, res, coef, training, relu, partial, sums, 0, gx, gres, stream);
+}
+// same, `sums` (2c) zeroed by the caller: the block sums are added atomically, the column-sum launch disappears
+extern "C" int pdf_bn_act_backward_acc(long n, int c, const float *gy, const float *x, const float *res, const float *coef,
+                                       int training, int relu, float *sums, float *gx, float *gres, void *stream) {
+    return bn_act_backward(n, c, gy, x, res, coef, training, relu, nullptr, sums, 1, gx, gres, stream);
 }
 
 // Coefficients of a train-mode BatchNorm whose column statistics were produced by a GEMM epilogue (rowlin STATS).

@@ -397,11 +397,15 @@ class _BottleneckFn(torch.autograd.Function):
         cs, cc, nc = c // 8, c * c, n * c
         gy = gy.contiguous()
         npre, npost, nsum = cc + 2 * c + 3 * (cc + c), cc + 4 * c, int(lib.pdf_pt_layer_bwd_sums_floats(c))
-        o_pre, o_post, o_sum = 0, _al(npre), _al(npre) + _al(npost)
+        # one buffer, zeroed by ONE memset in C: [grads pre | grads post | gxk | gxv] then the layer's sums (overwritten)
+        o_pre, o_post = 0, _al(npre)
+        o_gxk = o_post + _al(npost)
+        o_gxv = o_gxk + _al(nc)
+        o_sum = o_gxv + _al(nc)
         grads = torch.empty((o_sum + _al(nsum),), dtype=torch.float32, device=x.device)
         gx = torch.empty((n, c), dtype=torch.float32, device=x.device)
-        ssz = [nc, nc, nc, nc, nc, n * k * cs, n * k * 3,
-               max(int(lib.pdf_bn_partial_floats(n, c)), int(lib.pdf_pt_layer_bwd_partial_floats(n, k, c)))]   # gt da gxq gxk gxv G2 G3 partial
+        ssz = [nc, nc, nc, n * k * cs, n * k * 3,
+               max(int(lib.pdf_bn_partial_floats(n, c)), int(lib.pdf_pt_layer_bwd_partial_floats(n, k, c)))]   # gt da gxq G2 G3 partial
         soff, tot = [], 0
         for sz in ssz:
             soff.append(tot)
@@ -414,7 +418,7 @@ class _BottleneckFn(torch.autograd.Function):
                 Wp1.data_ptr(), bp1.data_ptr(), Wp2.data_ptr(), bp2.data_ptr(), Ww1.data_ptr(), bw1.data_ptr(), Ww2.data_ptr(), bw2.data_ptr(),
                 A(5), A(6), A(7), A(2), A(3), A(4), A(8), A(10), A(9), A(11), W3.data_ptr(),
                 gx.data_ptr(), gb + 4 * o_pre, gb + 4 * o_post, gb + 4 * o_sum,
-                S(0), S(1), S(2), S(3), S(4), S(5), S(6), S(7)]
+                S(0), S(1), S(2), gb + 4 * o_gxk, gb + 4 * o_gxv, S(3), S(4), S(5)]
         rc = lib.pdf_bottleneck_backward(n, k, c, (c_void_p * len(ptrs))(*ptrs), int(training), be._stream())
         if rc != 0:
             raise RuntimeError(f"pdf_bottleneck_backward failed with status {rc}")
