@@ -237,7 +237,7 @@ class GeometryPrefetcher:
 
     def __init__(self, depth=3, **plan):
         self.depth, self.plan = depth, plan
-        self.streams = [torch.cuda.Stream() for _ in range(max(depth, 1))]
+        self.streams = [torch.cuda.Stream() for _ in range(max(depth, 1))]   # (stream priorities: measured, no effect on this stack)
         self._n = 0
 
     def submit(self, coord, offset, offset_host=None):
