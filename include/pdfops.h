@@ -202,6 +202,13 @@ int pdf_block_post_backward(long n, int c, void *const *p, int training, void *s
 int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p, int training, float eps, float momentum, void *stream);
 int pdf_bottleneck_backward(long n, int nsample, int c, void *const *p, int training, void *stream);
 
+/* Cross-entropy with an ignore label, mean over the counted rows (pointcept/models/losses/misc.py:14-39 as configured on
+ * this path).  Forward: loss[0], acc = [sum, count], grad (n*c) = softmax - onehot (0 on ignored rows); backward scales grad in
+ * place by gy[0] / count. */
+int pdf_ce_forward(long n, int c, const float *logits, const long *target, long ignore, float *grad, float *acc, float *loss,
+                   void *stream);
+int pdf_ce_backward(long n, int c, float *grad, const float *acc, const float *gy, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,76 @@
+// Cross-entropy over (N, C) logits with an ignore label, mean over the counted rows -- nn.CrossEntropyLoss as configured on
+// this path (losses/misc.py:14-39: weight=None, label_smoothing=0, reduction="mean", ignore_index=-1).
+// torch runs log_softmax + an nll reduction that is a single-block kernel (173 us forward + 147 us backward for 200k x 13);
+// here one lane owns one row (C <= 64 logits in registers): max / log-sum-exp / picked logit, a block reduction and two
+// atomics (sum of losses, number of counted rows).  The forward also leaves softmax - onehot (zero on ignored rows) in
+// `grad`, so the backward is one scaled copy.  Bound: HBM (8NC bytes forward).
+#include "pdfops_common.h"
+
+namespace {
+
+constexpr int LB = 256;
+
+__global__ __launch_bounds__(LB) void k_ce_fwd(long n, int c, const float *__restrict__ logits, const long *__restrict__ target,
+                                               long ignore, float *__restrict__ grad, float *__restrict__ acc) {
+    __shared__ float red[2][LB / 64];
+    float loss = 0.f, cnt = 0.f;
+    for (long r = (long)blockIdx.x * LB + threadIdx.x; r < n; r += (long)gridDim.x * LB) {
+        const float *x = logits + r * c;
+        const long t = target[r];
+        float m = x[0];
+        for (int j = 1; j < c; ++j) m = fmaxf(m, x[j]);
+        float s = 0.f;
+        for (int j = 0; j < c; ++j) s += __expf(x[j] - m);
+        const float lse = m + __logf(s);
+        const bool counted = t != ignore && t >= 0 && t < c;
+        if (counted) { loss += lse - x[t]; cnt += 1.f; }
+        float *g = grad + r * c;
+        const float inv = 1.f / s;
+        for (int j = 0; j < c; ++j) g[j] = counted ? __expf(x[j] - m) * inv - (j == t ? 1.f : 0.f) : 0.f;
+    }
+    loss = pdf_wave_sum_f32(loss);
+    cnt = pdf_wave_sum_f32(cnt);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = loss; red[1][threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, b = 0.f;
+        for (int w = 0; w < LB / 64; ++w) { a += red[0][w]; b += red[1][w]; }
+        pdf_atomic_add(acc, a);
+        pdf_atomic_add(acc + 1, b);
+    }
+}
+
+// acc = [sum of losses, counted rows] -> out = mean loss (NaN when nothing is counted, as torch)
+__global__ void k_ce_mean(const float *__restrict__ acc, float *__restrict__ out) { out[0] = acc[0] / acc[1]; }
+
+// grad_logits = (softmax - onehot) * gy / count   (in place on the forward's buffer)
+__global__ __launch_bounds__(LB) void k_ce_bwd(long total, float *__restrict__ grad, const float *__restrict__ acc,
+                                               const float *__restrict__ gy) {
+    const float scale = gy[0] / acc[1];
+    for (long e = (long)blockIdx.x * LB + threadIdx.x; e < total; e += (long)gridDim.x * LB) grad[e] *= scale;
+}
+
+}  // namespace
+
+// loss (1 float) = mean over rows with target != ignore of -log softmax(logits)[target]; grad (n*c) receives softmax - onehot;
+// acc (2 floats) receives [sum, count] (zeroed here).
+extern "C" int pdf_ce_forward(long n, int c, const float *logits, const long *target, long ignore, float *grad, float *acc,
+                              float *loss, void *stream) {
+    if (n < 1 || c < 1 || !logits || !target || !grad || !acc || !loss) return PDF_ERR_BAD_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(acc, 0, 2 * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    long g = (n + LB - 1) / LB;
+    if (g > 1024) g = 1024;
+    k_ce_fwd<<<(unsigned)g, LB, 0, s>>>(n, c, logits, target, ignore, grad, acc);
+    k_ce_mean<<<1, 1, 0, s>>>(acc, loss);
+    return pdf_launch_status();
+}
+
+extern "C" int pdf_ce_backward(long n, int c, float *grad, const float *acc, const float *gy, void *stream) {
+    if (n < 1 || c < 1 || !grad || !acc || !gy) return PDF_ERR_BAD_ARG;
+    long g = (n * c + LB - 1) / LB;
+    if (g > 2048) g = 2048;
+    k_ce_bwd<<<(unsigned)g, LB, 0, static_cast<hipStream_t>(stream)>>>(n * c, grad, acc, gy);
+    return pdf_launch_status();
+}

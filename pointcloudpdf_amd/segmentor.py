@@ -19,7 +19,45 @@ class CrossEntropyLoss(nn.Module):
                                         reduction=reduction, label_smoothing=label_smoothing)
 
     def forward(self, pred, target):
-        return self.loss(pred, target) * self.loss_weight
+        l = self.loss
+        if (pred.is_cuda and pred.dim() == 2 and pred.dtype == torch.float32 and pred.shape[1] <= 64 and target.dtype == torch.int64
+                and l.weight is None and l.label_smoothing == 0.0 and l.reduction == "mean"):
+            return _FusedCE.apply(pred.contiguous(), target.contiguous(), int(l.ignore_index)) * self.loss_weight
+        return l(pred, target) * self.loss_weight
+
+
+class _FusedCE(torch.autograd.Function):
+    """nn.CrossEntropyLoss(mean, ignore_index) over (N, C <= 64) fp32 logits as one HIP kernel per direction (csrc/loss.hip)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, ignore):
+        import ctypes
+        from . import _native
+
+        be = _native.hip_backend()
+        n, c = pred.shape
+        grad = torch.empty_like(pred)
+        acc = torch.empty((3,), dtype=torch.float32, device=pred.device)   # [sum, count, mean]
+        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = be.lib.pdf_ce_forward(n, c, pred.data_ptr(), target.data_ptr(), ignore, grad.data_ptr(), acc.data_ptr(), acc.data_ptr() + 8, s)
+        if rc != 0:
+            raise RuntimeError(f"pdf_ce_forward failed with status {rc}")
+        ctx.save_for_backward(grad, acc)
+        return acc[2]
+
+    @staticmethod
+    def backward(ctx, gy):
+        import ctypes
+        from . import _native
+
+        grad, acc = ctx.saved_tensors
+        n, c = grad.shape
+        gy = gy.contiguous().float()
+        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = _native.hip_backend().lib.pdf_ce_backward(n, c, grad.data_ptr(), acc.data_ptr(), gy.data_ptr(), s)
+        if rc != 0:
+            raise RuntimeError(f"pdf_ce_backward failed with status {rc}")
+        return grad, None, None
 
 
 class Criteria:

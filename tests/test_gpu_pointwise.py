@@ -170,3 +170,21 @@ def test_bottleneck_matrix_core_path(C, K, train):
             assert max_rel(a[k], b[k]) < 2e-5, (k, max_rel(a[k], b[k]))
         else:  # gradients: Frobenius norm (isolated ReLU-kink flips, see helpers.l2_rel)
             assert l2_rel(a[k], b[k]) < 5e-3, (k, l2_rel(a[k], b[k]), max_rel(a[k], b[k]))  # 3-element tensors (BNp) get no averaging
+
+
+@pytest.mark.parametrize("n,c", [(200003, 13), (5000, 14), (77, 64), (3, 2)])
+def test_fused_cross_entropy(n, c):
+    """csrc/loss.hip vs nn.CrossEntropyLoss (mean, ignore_index=-1), value and gradient."""
+    from pointcloudpdf_amd.segmentor import CrossEntropyLoss
+
+    g = torch.Generator(device="cuda").manual_seed(n + c)
+    logits = (torch.randn(n, c, device="cuda", generator=g) * 3).requires_grad_(True)
+    target = torch.randint(-1, c, (n,), device="cuda", generator=g)
+    crit = CrossEntropyLoss(loss_weight=0.7, ignore_index=-1)
+    loss = crit(logits, target)
+    (loss * 1.3).backward()
+    ref_in = logits.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(ref_in, target, ignore_index=-1) * 0.7
+    (ref * 1.3).backward()
+    assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+    assert max_rel(logits.grad.cpu().numpy(), ref_in.grad.cpu().numpy()) < 1e-5
