@@ -161,7 +161,7 @@ def main():
     step = engine.OpenSegStep().to(dev)
     synthetic.fill_parameters_deterministic(step, seed=1)  # identical "random-init" weights on every rank
     step.train()
-    module = engine.wrap_ddp(step, dev) if world > 1 else step
+    module = engine.wrap_ddp(step, dev) if (world > 1 or os.environ.get("PDFOPS_FORCE_DDP")) else step   # (knob: DDP hooks at world size 1)
     opt = torch.optim.SGD(step.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4, fused=True)
 
     sizes = [args.points] * args.scenes

@@ -83,7 +83,7 @@ def init_distributed():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    if world_size > 1 and not dist.is_initialized():
+    if (world_size > 1 or os.environ.get("PDFOPS_FORCE_DDP")) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = "nccl" if torch.cuda.is_available() else "gloo"
