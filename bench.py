@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--scenes", type=int, default=2, help="scenes per GPU (batch size per rank)")
     ap.add_argument("--pool", type=int, default=3, help="distinct batches per rank to rotate through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-points", type=int, default=16000, help="scene size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-points", type=int, default=100000, help="scene size of the bounded CPU-baseline sample")
     ap.add_argument("--amp", action="store_true", help="fp16 autocast around the step (reference enable_amp=True)")
     ap.add_argument("--prefetch", type=int, default=6,
                     help="geometry pre-pass group: the pre-pass of the NEXT `prefetch` batches runs as one launch sequence on a side "

@@ -10,6 +10,10 @@ import ctypes
 from ctypes import c_void_p
 
 import torch
+
+# custom autograd nodes run in fp32 under autocast (the kernels are fp32; upstream's python ops promote to fp32 the same way)
+_amp_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_amp_bwd = torch.amp.custom_bwd(device_type="cuda")
 import torch.nn.functional as F
 
 _CHUNK = 2048
@@ -60,12 +64,14 @@ class deferred_counters:
 
 class _LinearSplitK(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         return F.linear(x, weight, bias)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         g = g.contiguous()
@@ -94,6 +100,7 @@ class _BnAct(torch.autograd.Function):
     """relu?( BatchNorm1d(x) [+ residual] ) as one autograd node over the HIP kernels of csrc/pointwise.hip."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, residual, weight, bias, bn, relu):
         from . import _native
 
@@ -108,6 +115,7 @@ class _BnAct(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, gy):
         from . import _native
 
@@ -148,6 +156,7 @@ def _be():
 
 class _LinearStats(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, weight, bias, want_stats):
         y, partial = _be().rowlin(x, weight.detach(), None if bias is None else bias.detach(), stats=want_stats)
         ctx.save_for_backward(x, weight)
@@ -158,6 +167,7 @@ class _LinearStats(torch.autograd.Function):
         return y, partial
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g, _gp):
         x, weight = ctx.saved_tensors
         be = _be()
@@ -169,6 +179,7 @@ class _LinearStats(torch.autograd.Function):
 
 class _BnReluLinear(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, z, partial, gamma, beta, bn, relu, want_stats, *wb):
         be = _be()
         n, c = z.shape
@@ -193,6 +204,7 @@ class _BnReluLinear(torch.autograd.Function):
         return (*outs, pout)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, *gs):
         z, coef, *weights = ctx.saved_tensors
         training, relu, has_bias = ctx.cfg
@@ -213,6 +225,7 @@ class _BnReluLinear(torch.autograd.Function):
 
 class _BnActPartial(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, z, partial, residual, gamma, beta, bn, relu):
         be = _be()
         n, c = z.shape
@@ -229,6 +242,7 @@ class _BnActPartial(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, gy):
         z, residual, coef = ctx.saved_tensors
         training, relu, has_res = ctx.cfg
@@ -269,6 +283,7 @@ class _BlockPre(torch.autograd.Function):
     """(x_q, x_k, x_v) = q/k/v( relu(bn1(linear1(x))) )"""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, W1, g1, b1, Wq, bq, Wk, bk, Wv, bv, blk):
         be = _be()
         n, c = x.shape
@@ -283,6 +298,7 @@ class _BlockPre(torch.autograd.Function):
         return xq, xk, xv
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, gxq, gxk, gxv):
         x, z1, coef1, W1, Wq, Wk, Wv = ctx.saved_tensors
         be = _be()
@@ -304,6 +320,7 @@ class _BlockPost(torch.autograd.Function):
     """y = relu( bn3(linear3(relu(bn2(t)))) + x )"""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, t, x, g2, b2, W3, g3, b3, blk):
         be = _be()
         n, c = t.shape
@@ -318,6 +335,7 @@ class _BlockPost(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, gy):
         t, x, z3, coef2, coef3, W3 = ctx.saved_tensors
         be = _be()
@@ -345,6 +363,7 @@ class _BottleneckFn(torch.autograd.Function):
     """params: W1 g1 b1 | Wq bq Wk bk Wv bv | layer: Wp1 bp1 gp bp Wp2 bp2 g1' b1' Ww1 bw1 g2' b2' Ww2 bw2 | g2 b2 W3 g3 b3"""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, blk, idx, p, x, *params):
         be = _be()
         lib = be.lib
@@ -386,6 +405,7 @@ class _BottleneckFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, gy):
         training, offs, k = ctx.cfg
         if not training:

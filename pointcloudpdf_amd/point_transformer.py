@@ -16,6 +16,10 @@ What differs is the execution plan:
 import os
 
 import torch
+
+# custom autograd nodes run in fp32 under autocast (the kernels are fp32; upstream's python ops promote to fp32 the same way)
+_amp_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_amp_bwd = torch.amp.custom_bwd(device_type="cuda")
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -67,6 +71,7 @@ class _FusedPTLayer(torch.autograd.Function):
     (csrc/fused_layer.hip): no (n, ns, c) tensor is materialised in either direction."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, layer, idx, p, xq, xk, xv, *params):
         be = _native.hip_backend()
         lp, lw = layer.linear_p, layer.linear_w
@@ -86,6 +91,7 @@ class _FusedPTLayer(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, gout):
         if not ctx.training:
             raise RuntimeError("fused PointTransformerLayer: backward is implemented for training mode (batch statistics)")

@@ -12,6 +12,10 @@ on torch's current stream, errors are raised (the reference has none), and coord
 ``Geometry`` are served from its memo table instead of re-running kNN.
 """
 import torch
+
+# custom autograd nodes run in fp32 under autocast (the kernels are fp32; upstream's python ops promote to fp32 the same way)
+_amp_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_amp_bwd = torch.amp.custom_bwd(device_type="cuda")
 from torch.autograd import Function
 
 from .. import _native
@@ -31,6 +35,7 @@ class KNNQuery(Function):
     """libs/pointops/functions/query.py:7-24"""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, nsample, xyz, offset, new_xyz=None, new_offset=None):
         if new_xyz is None or new_offset is None:
             new_xyz, new_offset = xyz, offset
@@ -70,6 +75,7 @@ class FarthestPointSampling(Function):
     """libs/pointops/functions/sampling.py:7-24"""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, xyz, offset, new_offset, offset_host=None, new_offset_host=None):
         assert xyz.is_contiguous()
         if offset_host is None:  # reference behaviour: host syncs (sampling.py:15-18)
@@ -95,6 +101,7 @@ class Grouping(Function):
     """libs/pointops/functions/grouping.py:7-33"""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, input, idx):
         assert input.is_contiguous() and idx.is_contiguous()
         ctx.n = input.shape[0]
@@ -102,6 +109,7 @@ class Grouping(Function):
         return _be(input).grouping_forward(input, idx)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, grad_output):
         (idx,) = ctx.saved_tensors
         return _be(grad_output).grouping_backward(grad_output.contiguous(), idx, ctx.n), None
@@ -114,12 +122,14 @@ class _GroupFused(Function):
     """Fused twin of the python grouping() (grouping.py:36-60): gather + relative xyz + mask + cat in one pass."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, feat, xyz, new_xyz, idx, with_xyz):
         ctx.shape = (feat.shape[0], feat.shape[1], bool(with_xyz))
         ctx.save_for_backward(idx)
         return _be(feat).group_forward(feat, xyz, new_xyz, idx, bool(with_xyz))
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, grad_output):
         (idx,) = ctx.saved_tensors
         n, c, with_xyz = ctx.shape
@@ -155,12 +165,14 @@ class _InterpolateIdx(Function):
     """out = sum_k feat[idx[:,k]] * weight[:,k] with a scatter backward (interpolation.py:20-21 / :25-59)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, input, idx, weight):
         ctx.m = input.shape[0]
         ctx.save_for_backward(idx, weight)
         return _be(input).interpolation_forward(input, idx, weight)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, grad_output):
         idx, weight = ctx.saved_tensors
         return _be(grad_output).interpolation_backward(grad_output.contiguous(), idx, weight, ctx.m), None, None
@@ -178,6 +190,8 @@ def interpolation(xyz, new_xyz, feat, offset, new_offset, k=3):
     """libs/pointops/functions/interpolation.py:8-22: coords (m,3) -> new_xyz (n,3), feat (m,c) -> (n,c)."""
     assert xyz.is_contiguous() and new_xyz.is_contiguous() and feat.is_contiguous()
     idx, weight = _interp_tables(xyz, new_xyz, offset, new_offset, k)
+    if feat.dtype != torch.float32:  # autocast: upstream accumulates feat[idx] * weight (fp32) into an fp32 tensor
+        feat = feat.float()
     return _InterpolateIdx.apply(feat, idx, weight)
 
 
@@ -185,6 +199,7 @@ class Interpolation(Function):
     """libs/pointops/functions/interpolation.py:25-59"""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, xyz, new_xyz, input, offset, new_offset, k=3):
         assert xyz.is_contiguous() and new_xyz.is_contiguous() and input.is_contiguous()
         idx, weight = _interp_tables(xyz, new_xyz, offset, new_offset, k)
@@ -193,6 +208,7 @@ class Interpolation(Function):
         return _be(input).interpolation_forward(input, idx, weight)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, grad_output):
         idx, weight = ctx.saved_tensors
         gi = _be(grad_output).interpolation_backward(grad_output.contiguous(), idx, weight, ctx.m)
@@ -207,6 +223,7 @@ class Subtraction(Function):
     """libs/pointops/functions/subtraction.py:7-38"""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, input1, input2, idx):
         assert input1.is_contiguous() and input2.is_contiguous()
         ctx.n2 = input2.shape[0]
@@ -214,6 +231,7 @@ class Subtraction(Function):
         return _be(input1).subtraction_forward(input1, input2, idx.contiguous())
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, grad_output):
         (idx,) = ctx.saved_tensors
         g1, g2 = _be(grad_output).subtraction_backward(idx, grad_output.contiguous(), ctx.n2)
@@ -227,12 +245,14 @@ class Aggregation(Function):
     """libs/pointops/functions/aggregation.py:7-57"""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, input, position, weight, idx):
         assert input.is_contiguous() and position.is_contiguous() and weight.is_contiguous()
         ctx.save_for_backward(input, position, weight, idx)
         return _be(input).aggregation_forward(input, position, weight, idx.contiguous())
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, grad_output):
         input, position, weight, idx = ctx.saved_tensors
         gi, gp, gw = _be(grad_output).aggregation_backward(input, position, weight, idx, grad_output.contiguous())
@@ -247,6 +267,7 @@ class AttentionRelationStep(Function):
     """libs/pointops/functions/attention.py:12-62"""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, query, key, weight, index_target, index_refer):
         assert query.is_contiguous() and key.is_contiguous() and weight.is_contiguous()
         assert index_target.is_contiguous() and index_refer.is_contiguous()
@@ -256,6 +277,7 @@ class AttentionRelationStep(Function):
         return _be(query).attention_relation_step_forward(query, key, weight, it, ir)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, grad_output):
         query, key, weight, it, ir = ctx.saved_tensors
         gq, gk, _ = _be(query).attention_relation_step_backward(query, key, weight, it, ir, grad_output.contiguous())
@@ -266,6 +288,7 @@ class AttentionFusionStep(Function):
     """libs/pointops/functions/attention.py:65-116"""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, weight, value, index_target, index_refer):
         assert weight.is_contiguous() and value.is_contiguous()
         assert index_target.is_contiguous() and index_refer.is_contiguous()
@@ -275,6 +298,7 @@ class AttentionFusionStep(Function):
         return _be(value).attention_fusion_step_forward(weight, value, it, ir)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, grad_output):
         weight, value, it, ir = ctx.saved_tensors
         gw, gv = _be(value).attention_fusion_step_backward(weight, value, it, ir, grad_output.contiguous())

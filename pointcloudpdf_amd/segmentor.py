@@ -1,6 +1,10 @@
 """Segmentor wrapper and losses of the hot path -- pointcept/models/default.py:39-62,
 pointcept/models/losses/builder.py:13-27, pointcept/models/losses/misc.py:14-39 (contract only: dict in, dict out)."""
 import torch
+
+# custom autograd nodes run in fp32 under autocast (the kernels are fp32; upstream's python ops promote to fp32 the same way)
+_amp_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_amp_bwd = torch.amp.custom_bwd(device_type="cuda")
 import torch.nn as nn
 
 from .registry import LOSSES, MODELS, build_model
@@ -30,6 +34,7 @@ class _FusedCE(torch.autograd.Function):
     """nn.CrossEntropyLoss(mean, ignore_index) over (N, C <= 64) fp32 logits as one HIP kernel per direction (csrc/loss.hip)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, pred, target, ignore):
         import ctypes
         from . import _native
@@ -46,6 +51,7 @@ class _FusedCE(torch.autograd.Function):
         return acc[2]
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, gy):
         import ctypes
         from . import _native
