@@ -14,6 +14,8 @@
 //   knn_scan_kernel (knn_query.hip) on the redo list
 // Work per query ~ a few hundred candidate distances instead of N_scene.  Bound: latency / VALU; HBM bytes 12N+12M+8Mk.
 #include "pdfops_common.h"
+#include <cstdio>
+#include <cstdlib>
 
 extern "C" int pdf_knn_query_list(int m, int nsample, const float *xyz, const float *new_xyz, const int *offset,
                                   const int *new_offset, int b, int *idx, float *dist2, const int *qlist,
@@ -50,7 +52,7 @@ __host__ __device__ inline Layout make_layout(int b, int n, int m) {
     return L;
 }
 
-__global__ __launch_bounds__(PB) void k_grid_setup(const float *__restrict__ xyz, const int *__restrict__ offset, SceneGrid *__restrict__ grids) {
+__global__ __launch_bounds__(PB) void k_grid_setup(const float *__restrict__ xyz, const int *__restrict__ offset, SceneGrid *__restrict__ grids, float ppc) {
     __shared__ float red[6][PB / 64];
     const int s = blockIdx.x;
     const int start = s == 0 ? 0 : offset[s - 1], end = offset[s];
@@ -81,8 +83,8 @@ __global__ __launch_bounds__(PB) void k_grid_setup(const float *__restrict__ xyz
         const int n = end - start;
         float ext[3];
         for (int a = 0; a < 3; ++a) ext[a] = n > 0 ? fmaxf(h[a] - l[a], 1e-6f) : 1.f;
-        // target ~4 points per cell if the points filled the box; never more than CAP_CELLS cells
-        float cell = cbrtf(ext[0] * ext[1] * ext[2] * 4.0f / (float)(n > 0 ? n : 1));
+        // target ~ppc points per cell if the points filled the box; never more than CAP_CELLS cells
+        float cell = cbrtf(ext[0] * ext[1] * ext[2] * ppc / (float)(n > 0 ? n : 1));
         const float longest = fmaxf(ext[0], fmaxf(ext[1], ext[2]));
         cell = fmaxf(cell, longest / 1000.f);
         int nx, ny, nz;
@@ -190,17 +192,28 @@ __device__ __forceinline__ void insert(float (&bd)[KP1], int (&bi)[KP1], float d
     }
 }
 
-template <int KP1>
+// SELF: the queries ARE the source points (self kNN of a level: 5 of the 13 tables, most of the query work).  Thread t then
+// takes the t-th point of the cell-sorted copy instead of the t-th point in memory order: the 64 lanes of a wave sit in the
+// same or adjacent cells, walk the same rings and read the same cell lists (coherent loads, little divergence).
+template <int KP1, bool SELF>
 __global__ __launch_bounds__(PB) void k_grid_query(int m, int b, const float *__restrict__ new_xyz, const int *__restrict__ new_offset,
                                                    const SceneGrid *__restrict__ grids, const unsigned *__restrict__ cell_start,
                                                    const float4 *__restrict__ sorted, int *__restrict__ idx,
                                                    float *__restrict__ dist2, int *__restrict__ redo) {
     constexpr int K = KP1 - 1;
-    const int q = blockIdx.x * PB + threadIdx.x;
-    if (q >= m) return;
+    const int t_ = blockIdx.x * PB + threadIdx.x;
+    if (t_ >= m) return;
+    int q = t_;
+    float qx, qy, qz;
+    if (SELF) {
+        const float4 me = sorted[t_];   // the sorted copy keeps the scenes in order: position t_ belongs to scene_of(t_)
+        q = __float_as_int(me.w);
+        qx = me.x; qy = me.y; qz = me.z;
+    } else {
+        qx = new_xyz[3 * (size_t)q]; qy = new_xyz[3 * (size_t)q + 1]; qz = new_xyz[3 * (size_t)q + 2];
+    }
     const int s = scene_of(q, new_offset, b);
     const SceneGrid g = grids[s];
-    const float qx = new_xyz[3 * (size_t)q], qy = new_xyz[3 * (size_t)q + 1], qz = new_xyz[3 * (size_t)q + 2];
     bool need_redo = g.n < KP1;  // placeholders / not enough points for the tie test: exact scan
     float bd[KP1];
     int bi[KP1];
@@ -291,15 +304,28 @@ extern "C" int pdf_knn_query_ws(int m, int nsample, int n, const float *xyz, con
     if (e != hipSuccess) return (int)e;
     e = hipMemsetAsync(redo, 0, 16, s);
     if (e != hipSuccess) return (int)e;
-    kg::k_grid_setup<<<b, kg::PB, 0, s>>>(xyz, offset, grids);
+    // cell size: `ppc` points per cell if the points filled the bounding box (they lie on surfaces, so occupied cells hold more)
+    static const float ppc_env = [] { const char *v = getenv("PDFOPS_KNN_PPC"); return v ? (float)atof(v) : 0.f; }();
+    const float ppc = ppc_env > 0.f ? ppc_env : 1.0f;   // measured on 12 x 100k-point scenes: 1 beats 4 by 25 % at level 1, equal below
+    kg::k_grid_setup<<<b, kg::PB, 0, s>>>(xyz, offset, grids, ppc);
     kg::k_grid_hist<<<pdf_divup(n, kg::PB), kg::PB, 0, s>>>(n, b, xyz, offset, grids, cell_start, cell_of);
     kg::k_grid_scan<<<b, 1024, 0, s>>>(grids, cell_start);
     kg::k_grid_scatter<<<pdf_divup(n, kg::PB), kg::PB, 0, s>>>(n, xyz, cell_of, cell_start, cursor, sorted);
     const int grid = pdf_divup(m, kg::PB);
-    if (nsample == 3) kg::k_grid_query<4><<<grid, kg::PB, 0, s>>>(m, b, new_xyz, new_offset, grids, cell_start, sorted, idx, dist2, redo);
-    else if (nsample == 8) kg::k_grid_query<9><<<grid, kg::PB, 0, s>>>(m, b, new_xyz, new_offset, grids, cell_start, sorted, idx, dist2, redo);
-    else kg::k_grid_query<17><<<grid, kg::PB, 0, s>>>(m, b, new_xyz, new_offset, grids, cell_start, sorted, idx, dist2, redo);
+    const bool self = new_xyz == xyz && new_offset == offset && m == n && getenv("PDFOPS_KNN_NO_SELF") == nullptr;
+#define PDF_KQ(KP1_) do { if (self) kg::k_grid_query<KP1_, true><<<grid, kg::PB, 0, s>>>(m, b, new_xyz, new_offset, grids, cell_start, sorted, idx, dist2, redo); \
+                          else kg::k_grid_query<KP1_, false><<<grid, kg::PB, 0, s>>>(m, b, new_xyz, new_offset, grids, cell_start, sorted, idx, dist2, redo); } while (0)
+    if (nsample == 3) PDF_KQ(4);
+    else if (nsample == 8) PDF_KQ(9);
+    else PDF_KQ(17);
+#undef PDF_KQ
     int rc = pdf_launch_status();
     if (rc != PDF_OK) return rc;
+    if (getenv("PDFOPS_KNN_DEBUG")) {   // diagnostics: size of the exact-scan redo list (synchronises)
+        int cnt = -1;
+        (void)hipMemcpyAsync(&cnt, redo, sizeof(int), hipMemcpyDeviceToHost, s);
+        (void)hipStreamSynchronize(s);
+        fprintf(stderr, "[pdfops] knn grid: m=%d nsample=%d b=%d redo=%d\n", m, nsample, b, cnt);
+    }
     return pdf_knn_query_list(m, nsample, xyz, new_xyz, offset, new_offset, b, idx, dist2, redo + 4, redo, stream);
 }

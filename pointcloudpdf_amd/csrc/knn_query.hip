@@ -14,6 +14,7 @@
 //   * the heap lives in LDS, column per lane ([slot][lane] -> conflict-free), not in scratch.
 // Roofline: FP32 VALU (8 flop/pair as written); algorithmic HBM bytes are 12N+12M+8Mk.
 #include "pdfops_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(BLOCK) void knn_scan_kernel(int m, int k, const flo
                                                          const int *__restrict__ offset,
                                                          const int *__restrict__ new_offset, int b,
                                                          int *__restrict__ idx, float *__restrict__ dist2,
-                                                         const int *__restrict__ qlist, const int *__restrict__ qcount) {
+                                                         const int *__restrict__ qlist, const int *__restrict__ qcount, int min_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char knn_smem[];
     float *hd = reinterpret_cast<float *>(knn_smem);  // [k][BLOCK]
     int *hi = reinterpret_cast<int *>(hd + k * BLOCK);  // [k][BLOCK]
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(BLOCK) void knn_scan_kernel(int m, int k, const flo
     bool active = q < m;
     if (qlist) {
         const int cnt = *qcount;
-        if (blockIdx.x * BLOCK >= cnt) return;
+        if (cnt <= min_count || blockIdx.x * BLOCK >= cnt) return;
         active = q < cnt;
         q = active ? qlist[q] : 0;
     }
@@ -133,6 +134,70 @@ __global__ __launch_bounds__(BLOCK) void knn_scan_kernel(int m, int k, const flo
     }
 }
 
+constexpr int REDO_WAVE_MAX = 8192;
+
+// The same exact process for a SHORT list of queries (the grid path's redo list: typically 0-10 of 10^5..10^6 queries),
+// one WAVE per query: 64 candidates are evaluated at a time in index order, a ballot marks the ones below the current heap
+// root and they are sifted in ascending index order with a re-test against the updated root -- exactly the insertions the
+// serial scan performs, in the same order (heap history and hence the tie order are unchanged).  One lane scanning a
+// 25k-point scene alone took 1.5 ms (the whole kNN call: 2.4 ms); this takes ~20 us.
+__global__ __launch_bounds__(64) void knn_redo_wave_kernel(int m, int k, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                           const int *__restrict__ offset, const int *__restrict__ new_offset, int b,
+                                                           int *__restrict__ idx, float *__restrict__ dist2,
+                                                           const int *__restrict__ qlist, const int *__restrict__ qcount) {
+    __shared__ float hd[128];
+    __shared__ int hi[128];
+    const int lane = threadIdx.x;
+    const int cnt = *qcount;
+    if (cnt > REDO_WAVE_MAX) return;   // long lists: the lane-per-query kernel (launched next) takes them
+    for (int e = blockIdx.x; e < cnt; e += gridDim.x) {
+        const int q = qlist[e];
+        int bt = 0;
+        while (bt < b - 1 && q >= new_offset[bt]) ++bt;
+        const float qx = new_xyz[3 * (size_t)q + 0], qy = new_xyz[3 * (size_t)q + 1], qz = new_xyz[3 * (size_t)q + 2];
+        for (int s = lane; s < k; s += 64) { hd[s] = 1e10f; hi[s] = -1; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_barrier();
+        float thr = 1e10f;
+        const int start = bt == 0 ? 0 : offset[bt - 1], end = offset[bt];
+        for (int i0 = start; i0 < end; i0 += 64) {
+            const int i = i0 + lane;
+            float d = 3.0e38f;
+            if (i < end) {
+                const float x = xyz[3 * (size_t)i + 0], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+                d = (qx - x) * (qx - x) + (qy - y) * (qy - y) + (qz - z) * (qz - z);
+            }
+            unsigned long long mask = __builtin_amdgcn_ballot_w64(i < end && d < thr);
+            while (mask) {
+                const int j = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const float dj = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(d), j));
+                if (dj < thr) {                       // wave-uniform: every lane performs the same sift on the shared heap
+                    heap_sift_root<1>(hd, hi, 0, k, dj, i0 + j);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_s_barrier();
+                    thr = hd[0];
+                }
+            }
+        }
+        // heap_sort, knn_query_cuda_kernel.cu:33-42
+        for (int i = k - 1; i > 0; --i) {
+            const float v = hd[i];
+            const int vi = hi[i];
+            __builtin_amdgcn_s_barrier();
+            hd[i] = hd[0];
+            hi[i] = hi[0];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_barrier();
+            heap_sift_root<1>(hd, hi, 0, i, v, vi);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_barrier();
+        }
+        for (int s = lane; s < k; s += 64) { idx[(size_t)q * k + s] = hi[s]; dist2[(size_t)q * k + s] = hd[s]; }
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
 }  // namespace
 
 // Exact scan restricted to the queries qlist[0 .. *qcount) (both on the device); qlist == nullptr: all m queries.
@@ -143,14 +208,21 @@ extern "C" int pdf_knn_query_list(int m, int nsample, const float *xyz, const fl
     if (nsample < 1 || nsample > 128) return PDF_ERR_NSAMPLE;
     if (m == 0) return PDF_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    int min_count = -1;
+    if (qlist && getenv("PDFOPS_KNN_SERIAL_REDO") == nullptr) {
+        // short redo lists (the normal case: 0-10 queries): one wave per listed query; lists longer than REDO_WAVE_MAX
+        // (grid-snapped scenes where every query ties) fall through to the lane-per-query kernel below
+        knn_redo_wave_kernel<<<1024, 64, 0, s>>>(m, nsample, xyz, new_xyz, offset, new_offset, b, idx, dist2, qlist, qcount);
+        min_count = REDO_WAVE_MAX;
+    }
     if (nsample <= 32) {
         constexpr int BLOCK = 128;
         const size_t lds = (size_t)nsample * BLOCK * 8;
-        knn_scan_kernel<BLOCK><<<pdf_divup(m, BLOCK), BLOCK, lds, s>>>(m, nsample, xyz, new_xyz, offset, new_offset, b, idx, dist2, qlist, qcount);
+        knn_scan_kernel<BLOCK><<<pdf_divup(m, BLOCK), BLOCK, lds, s>>>(m, nsample, xyz, new_xyz, offset, new_offset, b, idx, dist2, qlist, qcount, min_count);
     } else {
         constexpr int BLOCK = 64;
         const size_t lds = (size_t)nsample * BLOCK * 8;
-        knn_scan_kernel<BLOCK><<<pdf_divup(m, BLOCK), BLOCK, lds, s>>>(m, nsample, xyz, new_xyz, offset, new_offset, b, idx, dist2, qlist, qcount);
+        knn_scan_kernel<BLOCK><<<pdf_divup(m, BLOCK), BLOCK, lds, s>>>(m, nsample, xyz, new_xyz, offset, new_offset, b, idx, dist2, qlist, qcount, min_count);
     }
     return pdf_launch_status();
 }

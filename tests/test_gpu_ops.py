@@ -70,6 +70,22 @@ def test_knn_many_tiny_scenes_in_one_wave(hip, oracle_backend):
     assert torch.equal(i_o, i_h) and torch.equal(d_o, d_h)
 
 
+def test_knn_long_and_short_redo_lists(hip, oracle_backend):
+    """Grid path with ties: a snapped cloud of 11,000 points sends every query to the exact re-scan (list longer than the
+    wave-per-query limit -> lane-per-query kernel); 3 duplicated points in a real-valued cloud give a short list (wave-per-
+    query kernel).  Both must reproduce the reference's tie order bit for bit."""
+    sizes = [11000]
+    xyz = cloud(sum(sizes), 5, snap=2)
+    off = offs(sizes)
+    i_o, d_o, i_h, d_h = both_knn(hip, oracle_backend, 16, xyz, xyz, off, off)
+    assert torch.equal(i_o, i_h) and torch.equal(d_o, d_h)
+    xyz = cloud(6000, 9)
+    xyz[100], xyz[2500], xyz[5999] = xyz[7], xyz[7], xyz[4000]   # duplicates -> equal distances for a handful of queries
+    off = offs([6000])
+    i_o, d_o, i_h, d_h = both_knn(hip, oracle_backend, 8, xyz, xyz, off, off)
+    assert torch.equal(i_o, i_h) and torch.equal(d_o, d_h)
+
+
 def test_knn_rejects_bad_arguments(hip):
     from pointcloudpdf_amd._native import PdfOpsError
 
