@@ -85,3 +85,28 @@ def test_ddp_rccl_step_matches_plain_step():
         assert all(np.isfinite(v).all() for v in gb.values())
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_grouped_prepass_split_is_bit_identical_on_gpu():
+    """GeometryPrefetcher.submit_group: one FPS / kNN launch sequence over the scenes of three batches, split per batch,
+    equals the pre-pass of every batch alone (HIP kernels, bit-exact tables)."""
+    from pointcloudpdf_amd import synthetic
+    from pointcloudpdf_amd.geometry import Geometry, GeometryPrefetcher
+
+    dev = torch.device("cuda", 0)
+    batches = [synthetic.make_batch(sz, first_scene_id=20 * i, device=dev) for i, sz in enumerate([[9000, 7000], [12000], [5000, 6500, 4000]])]
+    pf = GeometryPrefetcher(depth=2)
+    tickets = pf.submit_group(batches)
+    for b, t in zip(batches, tickets):
+        part = pf.get(t)
+        alone = Geometry(b["coord"], b["offset"], b["offset_host"]).precompute()
+        torch.cuda.synchronize()
+        assert set(part._memo) == set(alone._memo) and len(part.levels) == len(alone.levels)
+        for la, lb in zip(part.levels, alone.levels):
+            assert torch.equal(la.p, lb.p) and torch.equal(la.o.int(), lb.o.int()) and la.o_host == lb.o_host
+        for key, va in part._memo.items():
+            vb = alone._memo[key]
+            for ta, tb in zip(va if isinstance(va, tuple) else (va,), vb if isinstance(vb, tuple) else (vb,)):
+                if isinstance(ta, torch.Tensor):
+                    assert torch.equal(ta, tb), key
