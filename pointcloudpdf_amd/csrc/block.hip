@@ -49,7 +49,7 @@ extern "C" int pdf_block_pre_forward(long n, int c, void *const *p, int training
 static int block_pre_backward(long n, int c, void *const *p, int training, int accumulate_gx, int grads_zeroed, void *stream) {
     if (n < 1 || !p) return PDF_ERR_BAD_ARG;
     const float *x = (const float *)p[0], *z1 = (const float *)p[1], *coef1 = (const float *)p[2], *W1 = (const float *)p[3];
-    float *gx = (float *)p[10], *grads = (float *)p[11], *dy = (float *)p[12];
+    float *gx = (float *)p[10], *grads = (float *)p[11], *dy = (float *)p[12], *partial = (float *)p[13];
     const long cc = (long)c * c;
     float *dW1 = grads, *db1 = grads + cc, *dqkv = db1 + 2 * c;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -65,7 +65,7 @@ static int block_pre_backward(long n, int c, void *const *p, int training, int a
     e << pdf_rowlin_multi(n, c, c, 3, 1, gs, c, ws, 1, nullptr, nullptr, nullptr, 0, ys, c, 0, stream);
     e << pdf_rowlin_wgrad_multi(n, c, c, 3, gs, c, z1, c, coef1, coef1 + c, 1, dws, dbs, stream);
     // bn1 backward in place on dy (elementwise: same index read and written); its column sums ARE [d beta1 | d gamma1]
-    e << pdf_bn_act_backward_acc(n, c, dy, z1, nullptr, coef1, training, 1, db1, dy, nullptr, stream);   // db1 zeroed with grads
+    e << pdf_bn_act_backward(n, c, dy, z1, nullptr, coef1, training, 1, partial, db1, dy, nullptr, stream);   // (the atomic variant: 782 blocks on 64 addresses, +13 us)
     e << pdf_rowlin_forward(n, c, c, dy, c, W1, 1, nullptr, nullptr, nullptr, 0, gx, c, accumulate_gx, nullptr, stream);
     e << pdf_rowlin_wgrad(n, c, c, dy, c, x, c, nullptr, nullptr, 0, dW1, nullptr, stream);
     return e.rc;
@@ -98,7 +98,7 @@ static int block_post_backward(long n, int c, void *const *p, int training, int 
     if (n < 1 || !p) return PDF_ERR_BAD_ARG;
     const float *gy = (const float *)p[0], *t = (const float *)p[1], *x = (const float *)p[2], *z3 = (const float *)p[3];
     const float *coef2 = (const float *)p[4], *coef3 = (const float *)p[5], *W3 = (const float *)p[6];
-    float *gt = (float *)p[7], *gres = (float *)p[8], *grads = (float *)p[9], *da = (float *)p[10];
+    float *gt = (float *)p[7], *gres = (float *)p[8], *grads = (float *)p[9], *da = (float *)p[10], *partial = (float *)p[11];
     const long cc = (long)c * c;
     float *dW3 = grads, *db2 = grads + cc, *db3 = db2 + 2 * c;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -108,11 +108,11 @@ static int block_post_backward(long n, int c, void *const *p, int training, int 
     }
     Err e;
     // bn3 backward: gz3 -> da (scratch), gres; column sums land in the gradient slots [d beta | d gamma]
-    e << pdf_bn_act_backward_acc(n, c, gy, z3, x, coef3, training, 1, db3, da, gres, stream);
+    e << pdf_bn_act_backward(n, c, gy, z3, x, coef3, training, 1, partial, db3, da, gres, stream);
     e << pdf_rowlin_wgrad(n, c, c, da, c, t, c, coef2, coef2 + c, 1, dW3, nullptr, stream);
     e << pdf_rowlin_forward(n, c, c, da, c, W3, 1, nullptr, nullptr, nullptr, 0, gt, c, 0, nullptr, stream);
     // bn2 backward in place on gt
-    e << pdf_bn_act_backward_acc(n, c, gt, t, nullptr, coef2, training, 1, db2, gt, nullptr, stream);
+    e << pdf_bn_act_backward(n, c, gt, t, nullptr, coef2, training, 1, partial, db2, gt, nullptr, stream);
     return e.rc;
 }
 
