@@ -30,9 +30,10 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-# HBM traffic per launch from rocprofv3 PMC passes (profiles/r01_b_pmc_{fetch,write}_size.txt; FETCH_SIZE doubled as the
-# guide prescribes for gfx950, KB -> bytes, averaged over the launches of the profiled run like `achieved`).
-PMC_TRAFFIC_BYTES = {"farthest_point_sampling": (2 * 1357.0 + 2284.3) * 1024}
+# HBM traffic per launch from rocprofv3 PMC passes (profiles/r01_e_pmc_{fetch,write}_size.txt: one launch = the 12 scenes of a
+# 6-batch group; FETCH_SIZE doubled as the guide prescribes for gfx950, KB -> bytes, averaged over the launches of the profiled
+# run like `achieved`).  FPS: 11,068 KB fetch (x2) + 46,864 KB write -- the tmp-distance stores of the touched buckets.
+PMC_TRAFFIC_BYTES = {"farthest_point_sampling": (2 * 11068.0 + 46863.9) * 1024}
 
 
 def parse():
@@ -97,6 +98,11 @@ class KernelTimer:
         if name == "group_backward":
             go, idx, n, c, with_xyz = args
             return 4 * go.numel() + 4 * idx.numel() + 4 * n * c
+        if name in ("bottleneck_forward", "bottleneck_backward"):
+            # the Bottleneck as a function: x in, y out, coordinates + kNN table (forward); backward: g_y in, g_x out, x, tables.
+            # Weights are negligible; the activations saved for the backward are NOT counted (strict I/O figure).
+            n, k, c = args[0], args[1], args[2]
+            return 8 * n * c + 12 * n + 4 * n * k + (4 * n * c if name == "bottleneck_backward" else 0)
         if name == "pt_layer_forward":  # q,k,v rows once + p + idx + out (SURVEY 8d "fused PT layer fwd")
             xq, idx = args[0], args[4]
             n, c = xq.shape
@@ -167,7 +173,7 @@ def main():
     sizes = [args.points] * args.scenes
     pool = [synthetic.make_batch(sizes, first_scene_id=1000 * rank + 10 * i, device=dev) for i in range(args.pool)]
     timer = KernelTimer(be, ["knn_query", "farthest_point_sampling", "group_forward", "group_backward",
-                             "pt_layer_forward", "pt_layer_backward"])
+                             "pt_layer_forward", "pt_layer_backward", "bottleneck_forward", "bottleneck_backward"])
     timer.install()
 
     from pointcloudpdf_amd.geometry import GeometryPrefetcher
@@ -301,7 +307,7 @@ def main():
 
         roof = roofline_of(dom) if dom else None
         # the gather family is what the HBM roofline is meaningful for (FPS / kNN are latency / VALU bound by design)
-        second = [n for n in ("pt_layer_backward", "pt_layer_forward", "group_backward", "group_forward") if n in ks]
+        second = [n for n in ("bottleneck_backward", "bottleneck_forward", "pt_layer_backward", "pt_layer_forward", "group_backward", "group_forward") if n in ks]
         roof2 = roofline_of(max(second, key=lambda n: ks[n]["total_ms"])) if second else None
         line = {
             "metric": "points/sec fwd+bwd (PT-v1 Seg50 + PDF U-decoder, 100k-pt scenes)",

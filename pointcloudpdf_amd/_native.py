@@ -512,6 +512,18 @@ class HipBackend(CBackend):
             raise PdfOpsError(f"pdf_bn_apply failed with status {rc}")
         return y
 
+    # -- whole Bottleneck as one host call per direction (csrc/block.hip); thin methods so that bench.py can time them
+    def bottleneck_forward(self, n, k, c, ptrs, training, eps, momentum):
+        rc = self.lib.pdf_bottleneck_forward(n, k, c, (c_void_p * len(ptrs))(*ptrs), int(training), ctypes.c_float(eps),
+                                             ctypes.c_float(momentum), self._stream())
+        if rc != 0:
+            raise PdfOpsError(f"pdf_bottleneck_forward failed with status {rc}")
+
+    def bottleneck_backward(self, n, k, c, ptrs, training):
+        rc = self.lib.pdf_bottleneck_backward(n, k, c, (c_void_p * len(ptrs))(*ptrs), int(training), self._stream())
+        if rc != 0:
+            raise PdfOpsError(f"pdf_bottleneck_backward failed with status {rc}")
+
     # -- Bottleneck halves as single host calls (csrc/block.hip) -------------------------------------------
     def _ptable(self, tensors):
         return (c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])

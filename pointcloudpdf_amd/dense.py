@@ -396,10 +396,7 @@ class _BottleneckFn(torch.autograd.Function):
                 g2.data_ptr(), b2.data_ptr(), bn2.running_mean.data_ptr(), bn2.running_var.data_ptr(), W3.data_ptr(),
                 g3.data_ptr(), b3.data_ptr(), bn3.running_mean.data_ptr(), bn3.running_var.data_ptr(),
                 *ap, y.data_ptr(), scratch.data_ptr()]
-        rc = lib.pdf_bottleneck_forward(n, k, c, (c_void_p * len(ptrs))(*ptrs), int(training), ctypes.c_float(bn1.eps),
-                                        ctypes.c_float(bn1.momentum or 0.1), be._stream())
-        if rc != 0:
-            raise RuntimeError(f"pdf_bottleneck_forward failed with status {rc}")
+        be.bottleneck_forward(n, k, c, ptrs, training, bn1.eps, bn1.momentum or 0.1)
         ctx.save_for_backward(x, p, idx, act, W1, Wq, Wk, Wv, W3, Wp1, bp1, Wp2, bp2, Ww1, bw1, Ww2, bw2)
         ctx.cfg = (training, offs, k)
         return y
@@ -439,9 +436,7 @@ class _BottleneckFn(torch.autograd.Function):
                 A(5), A(6), A(7), A(2), A(3), A(4), A(8), A(10), A(9), A(11), W3.data_ptr(),
                 gx.data_ptr(), gb + 4 * o_pre, gb + 4 * o_post, gb + 4 * o_sum,
                 S(0), S(1), S(2), gb + 4 * o_gxk, gb + 4 * o_gxv, S(3), S(4), S(5)]
-        rc = lib.pdf_bottleneck_backward(n, k, c, (c_void_p * len(ptrs))(*ptrs), int(training), be._stream())
-        if rc != 0:
-            raise RuntimeError(f"pdf_bottleneck_backward failed with status {rc}")
+        be.bottleneck_backward(n, k, c, ptrs, training)
         G = lambda o, sz, *shape: grads[o:o + sz].view(*shape) if shape else grads[o:o + sz]
         # pre half: dW1 | dbeta1 | dgamma1 | {dW, db} x q, k, v
         dW1, db1, dg1 = G(o_pre, cc, c, c), G(o_pre + cc, c), G(o_pre + cc + c, c)
