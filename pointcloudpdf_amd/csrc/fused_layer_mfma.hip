@@ -91,9 +91,9 @@ struct PRow {
     float t1[3];     // Linear(3,3) output (pre-BN)
     float t1n[3];    // relu(BNp(t1))
 };
-__device__ __forceinline__ PRow load_prow(const LayerArgs &A, long i, int row) {
+__device__ __forceinline__ PRow load_prow(const LayerArgs &A, long i, int nb) {
     PRow R;
-    R.nb = A.idx[i * 16 + row];
+    R.nb = nb;
     float rel[3] = {0.f, 0.f, 0.f};
     if (R.nb >= 0) {
 #pragma unroll
@@ -178,8 +178,11 @@ __global__ __launch_bounds__(64 * WPB) void k_p2(LayerArgs A) {
     f32x4 s[4], ss[4];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) { s[jj] = zero4(); ss[jj] = zero4(); }
+    int nb_next = wave_g < A.N ? A.idx[wave_g * 16 + row] : -1;
     for (long i = wave_g; i < A.N; i += nwaves) {
-        const PRow R = load_prow(A, i, row);
+        const int nb_cur = nb_next;
+        nb_next = i + nwaves < A.N ? A.idx[(i + nwaves) * 16 + row] : -1;   // next trip's index: in flight during this trip
+        const PRow R = load_prow(A, i, nb_cur);
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const f32x4 r = r4_of(A, cst, C, i, R, 4 * (4 * (int)blockIdx.y + jj) + kq);
@@ -214,8 +217,11 @@ __global__ __launch_bounds__(64 * WPB) void k_p3(LayerArgs A) {
     f32x4 b4[NOB], s4[NOB], ss4[NOB];
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) { b4[ob] = ldu(gp(A.bw1), ob * 16 + 4 * kq, ob * 16 + 4 * kq < CS); s4[ob] = zero4(); ss4[ob] = zero4(); }
+    int nb_next = wave_g < A.N ? A.idx[wave_g * 16 + row] : -1;
     for (long i = wave_g; i < A.N; i += nwaves) {
-        const PRow R = load_prow(A, i, row);
+        const int nb_cur = nb_next;
+        nb_next = i + nwaves < A.N ? A.idx[(i + nwaves) * 16 + row] : -1;   // next trip's index: in flight during this trip
+        const PRow R = load_prow(A, i, nb_cur);
         f32x4 acc[NOB];
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) acc[ob] = zero4();
@@ -267,8 +273,11 @@ __global__ __launch_bounds__(64 * WPB) void k_p4(LayerArgs A) {
     __syncthreads();
     const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
     const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
+    int nb_next = wave_g < A.N ? A.idx[wave_g * 16 + row] : -1;
     for (long i = wave_g; i < A.N; i += nwaves) {
-        const PRow R = load_prow(A, i, row);
+        const int nb_cur = nb_next;
+        nb_next = i + nwaves < A.N ? A.idx[(i + nwaves) * 16 + row] : -1;   // next trip's index: in flight during this trip
+        const PRow R = load_prow(A, i, nb_cur);
         f32x4 h[NOB], u[NOB], w[NOB];
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) h[ob] = ld_units<C>(A.H, i * 16 + row, ob, kq);
@@ -322,8 +331,11 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
 #pragma unroll
         for (int ub = 0; ub < NOB; ++ub) accw[ob][ub] = zero4();
     }
+    int nb_next = wave_g < A.N ? A.idx[wave_g * 16 + row] : -1;
     for (long i = wave_g; i < A.N; i += nwaves) {
-        const PRow R = load_prow(A, i, row);
+        const int nb_cur = nb_next;
+        nb_next = i + nwaves < A.N ? A.idx[(i + nwaves) * 16 + row] : -1;   // next trip's index: in flight during this trip
+        const PRow R = load_prow(A, i, nb_cur);
         if (kq == 0) rowid[row] = R.nb;
         f32x4 h[NOB], u[NOB], w[NOB], gw[NOB];
 #pragma unroll
@@ -452,8 +464,11 @@ __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
     }
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) sgh[ob] = zero4();
+    int nb_next = wave_g < A.N ? A.idx[wave_g * 16 + row] : -1;
     for (long i = wave_g; i < A.N; i += nwaves) {
-        const PRow R = load_prow(A, i, row);
+        const int nb_cur = nb_next;
+        nb_next = i + nwaves < A.N ? A.idx[(i + nwaves) * 16 + row] : -1;   // next trip's index: in flight during this trip
+        const PRow R = load_prow(A, i, nb_cur);
         f32x4 gh[NOB];
         hidden_grad<C>(A, gp(A.sums), i, row, kq, gh);
 #pragma unroll
@@ -555,7 +570,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
         __syncthreads();
         float sbp2 = 0.f, awp2[3] = {0.f, 0.f, 0.f};
         for (long i = wave_g; i < A.N; i += nwaves) {
-            const PRow R = load_prow(A, i, row);
+            const PRow R = load_prow(A, i, A.idx[i * 16 + row]);   // (index prefetch one trip ahead: slower here at C = 256, measured)
             if (kq == 0) { rowid[row] = R.nb; t1nt[row * 4 + 0] = R.t1n[0]; t1nt[row * 4 + 1] = R.t1n[1]; t1nt[row * 4 + 2] = R.t1n[2]; }
             f32x4 gh[NOB], h[NOB], u[NOB], w[NOB];
             hidden_grad<C>(A, S1, i, row, kq, gh, h);
