@@ -180,6 +180,7 @@ def main():
 
     prefetcher = GeometryPrefetcher(depth=2) if args.prefetch > 0 else None   # two side streams, alternating groups
     tickets = {}
+    submit_host_s = []   # host time of every grouped pre-pass submission
 
     # Group boundaries sit at warmup + k * D, so the timed region queues exactly steps / D group pre-passes (one pre-pass
     # per trained batch; the final fence drains the last one).  D = largest divisor of --steps <= --prefetch when there
@@ -194,8 +195,17 @@ def main():
         """One FPS / kNN launch sequence over the scenes of steps lo .. hi-1 (FPS is a chain of dependent arg-max steps,
         one workgroup per scene: its latency is amortised over the group instead of being paid per step)."""
         group = [pool[j % len(pool)] for j in range(lo, hi)]
+        t_sub = time.perf_counter()
+        prof = None
+        if os.environ.get("PDFOPS_PROFILE_SUBMIT") and len(submit_host_s) == 3:
+            import cProfile
+            prof = cProfile.Profile(); prof.enable()
         for j, t in enumerate(prefetcher.submit_group(group)):
             tickets[lo + j] = t
+        if prof is not None:
+            import pstats
+            prof.disable(); pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(14)
+        submit_host_s.append(time.perf_counter() - t_sub)
 
     def submit(i):
         """Called with i = step + D right after step's tables were fetched: queues the NEXT group at a boundary."""
@@ -328,6 +338,7 @@ def main():
             "per_gpu_points_per_s": pts_per_step * args.steps / dt / world,
             "loss": loss,
             "geometry_prefetch_group": D,
+            "prepass_submit_host_ms": (1e3 * min(submit_host_s)) if submit_host_s else None,   # host time of one group submission (warm)
             "hipgraph": bool(use_graph and graph is not None),
             "kernels": ks,
             "roofline": roof,

@@ -202,6 +202,27 @@ int pdf_block_post_backward(long n, int c, void *const *p, int training, void *s
 int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p, int training, float eps, float momentum, void *stream);
 int pdf_bottleneck_backward(long n, int nsample, int c, void *const *p, int training, void *stream);
 
+/* Row-weighted variants of the streaming Linear kernels and the bare BatchNorm-backward sums (building blocks of pdf_td_*). */
+int pdf_rowlin_forward_roww(long n, int k, int o, const float *x, long ldx, const float *w, int transpose_w, float *y, long ldy,
+                            int accumulate, const float *roww, long rws, void *stream);
+int pdf_rowlin_wgrad_roww(long n, int k, int o, const float *g, long ldg, const float *x, long ldx, float *dw, const float *roww,
+                          long rws, void *stream);
+int pdf_bn_bwd_sums(long n, int c, const float *gy, const float *x, const float *coef, int relu, float *partial, float *sums,
+                    void *stream);
+
+/* Fused TransitionDown with stride (point_transformer_seg.py:96-119): grouping with relative coordinates + Linear(3+cin, cout) +
+ * train/eval BatchNorm + ReLU + max over the 16 neighbours, forward and backward, without the (m, 16, .) intermediates.
+ * Geometry-only inputs (memoised per Geometry): idx (m,16), rel4 (m,16,4) masked relative coordinates, Z (n,32) = [sum of the
+ * relative coordinates of the rows gathering point j (3) | their count | 0...], consts (16) = [sum rel^T rel (9) | sum rel (3)].
+ * Pointer tables: csrc/transition_down.hip. */
+int pdf_td_supported(int nsample, int cin, int cout);
+int pdf_td_tables(long m, int b, const float *p_src, const float *p_new, const int *idx, const int *new_offset, float *rel4, float *Z,
+                  float *scene_sums, void *stream);   /* Z (n,32) and scene_sums (b,16) zeroed by the caller */
+long pdf_td_gram_floats(int cin);
+long pdf_td_bwd_scratch_floats(long m, int cin, int cout);
+int pdf_td_forward(long n, long m, int cin, int cout, void *const *p, int training, float eps, float momentum, void *stream);
+int pdf_td_backward(long n, long m, int cin, int cout, void *const *p, void *stream);
+
 /* Cross-entropy with an ignore label, mean over the counted rows (pointcept/models/losses/misc.py:14-39 as configured on
  * this path).  Forward: loss[0], acc = [sum, count], grad (n*c) = softmax - onehot (0 on ignored rows); backward scales grad in
  * place by gy[0] / count. */

@@ -247,6 +247,18 @@ class HipBackend(CBackend):
             f = getattr(lib, "pdf_block_" + nm)
             f.restype = c_int
             f.argtypes = [c_long, c_int, c_void_p, c_int, ctypes.c_float, ctypes.c_float, c_void_p]
+        lib.pdf_td_tables.restype = c_int
+        lib.pdf_td_tables.argtypes = [c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        lib.pdf_td_supported.restype = c_int
+        lib.pdf_td_supported.argtypes = [c_int, c_int, c_int]
+        lib.pdf_td_gram_floats.restype = c_long
+        lib.pdf_td_gram_floats.argtypes = [c_int]
+        lib.pdf_td_bwd_scratch_floats.restype = c_long
+        lib.pdf_td_bwd_scratch_floats.argtypes = [c_long, c_int, c_int]
+        lib.pdf_td_forward.restype = c_int
+        lib.pdf_td_forward.argtypes = [c_long, c_long, c_int, c_int, c_void_p, c_int, ctypes.c_float, ctypes.c_float, c_void_p]
+        lib.pdf_td_backward.restype = c_int
+        lib.pdf_td_backward.argtypes = [c_long, c_long, c_int, c_int, c_void_p, c_void_p]
         lib.pdf_ce_forward.restype = c_int
         lib.pdf_ce_forward.argtypes = [c_long, c_int, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p]
         lib.pdf_ce_backward.restype = c_int
@@ -511,6 +523,18 @@ class HipBackend(CBackend):
         if rc != 0:
             raise PdfOpsError(f"pdf_bn_apply failed with status {rc}")
         return y
+
+    def td_tables(self, p_src, p_new, idx, new_offset):
+        """Geometry-only tables of the fused TransitionDown: rel4 (m,16,4), Z (n,32), scene_sums (b,16) (csrc/transition_down.hip)."""
+        m, n, b = p_new.shape[0], p_src.shape[0], new_offset.shape[0]
+        rel4 = torch.empty((m, 16, 4), dtype=torch.float32, device=p_src.device)
+        Z = torch.zeros((n, 32), dtype=torch.float32, device=p_src.device)
+        sums = torch.zeros((b, 16), dtype=torch.float32, device=p_src.device)
+        rc = self.lib.pdf_td_tables(m, b, p_src.data_ptr(), p_new.data_ptr(), idx.data_ptr(), new_offset.data_ptr(), rel4.data_ptr(), Z.data_ptr(),
+                                    sums.data_ptr(), self._stream())
+        if rc != 0:
+            raise PdfOpsError(f"pdf_td_tables failed with status {rc}")
+        return rel4, Z, sums
 
     # -- whole Bottleneck as one host call per direction (csrc/block.hip); thin methods so that bench.py can time them
     def bottleneck_forward(self, n, k, c, ptrs, training, eps, momentum):

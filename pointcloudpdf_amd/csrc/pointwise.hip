@@ -274,3 +274,17 @@ extern "C" int pdf_bn_coef(long n, int c, const float *x, const float *gamma, co
     }
     return pdf_launch_status();
 }
+
+// Only the two BatchNorm-backward column sums [sum g' | sum g' * xhat] (g' = gy masked by the ReLU of x * scale + shift), no input
+// gradient: used by csrc/transition_down.hip with coefficients that express the max-pooled output.
+extern "C" int pdf_bn_bwd_sums(long n, int c, const float *gy, const float *x, const float *coef, int relu, float *partial, float *sums,
+                               void *stream) {
+    if (n < 1 || !gy || !x || !coef || !partial || !sums) return PDF_ERR_BAD_ARG;
+    if (!pdf_bn_supported(c)) return PDF_ERR_UNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int g = pw::grid_rows(n, c);
+    pw::k_bn_bwd_reduce<<<g, pw::PB, pw::PB * 8 * sizeof(float), s>>>(n, c, gy, x, nullptr, coef, coef + c, coef + 2 * c, coef + 3 * c, relu, partial,
+                                                                      nullptr);
+    fl::launch_colsum(partial, g, 2 * c, sums, s);
+    return pdf_launch_status();
+}

@@ -178,9 +178,9 @@ __global__ __launch_bounds__(256) void k_wgrad(WArgs a) {
 namespace rl2 {
 int try_forward(long n, int k, int o, int nin, int nout, const float *const *x, long ldx, const float *const *w, int transpose_w,
                 const float *const *bias, const float *scale, const float *shift, int relu, float *const *y, long ldy,
-                int accumulate, float *partial, hipStream_t s);
+                int accumulate, float *partial, hipStream_t s, const float *roww = nullptr, long rws = 0);
 int try_wgrad(long n, int k, int o, int ng, const float *const *g, long ldg, const float *x, long ldx, const float *scale,
-              const float *shift, int relu, float *const *dw, float *const *db, hipStream_t s);
+              const float *shift, int relu, float *const *dw, float *const *db, hipStream_t s, const float *roww = nullptr, long rws = 0);
 int stats_rows(long n);
 }  // namespace rl2
 
@@ -278,4 +278,24 @@ extern "C" int pdf_rowlin_wgrad_multi(long n, int k, int o, int ng, const float 
     int rc = 0;
     for (int i = 0; i < ng && rc == 0; ++i) rc = pdf_rowlin_wgrad(n, k, o, g[i], ldg, x, ldx, scale, shift, relu, dw[i], db ? db[i] : nullptr, stream);
     return rc;
+}
+
+// Row-weighted variants for the streaming shapes (csrc/transition_down.hip: Gram matrices x^T diag(cnt) x and the dense part of
+// the input gradient cnt .* (x Q)): y = roww[n] * (x Wt) (+)= ..., dW += sum_n roww[n] g[n]^T x[n].  roww has element stride rws.
+extern "C" int pdf_rowlin_forward_roww(long n, int k, int o, const float *x, long ldx, const float *w, int transpose_w, float *y, long ldy,
+                                       int accumulate, const float *roww, long rws, void *stream) {
+    if (n < 1 || !x || !w || !y || !rowlin_streams(k, o)) return PDF_ERR_UNSUPPORTED;
+    const float *bias = nullptr;
+    if (!rl2::try_forward(n, k, o, 1, 1, &x, ldx, &w, transpose_w, &bias, nullptr, nullptr, 0, &y, ldy, accumulate, nullptr,
+                          static_cast<hipStream_t>(stream), roww, rws))
+        return PDF_ERR_UNSUPPORTED;
+    return pdf_launch_status();
+}
+extern "C" int pdf_rowlin_wgrad_roww(long n, int k, int o, const float *g, long ldg, const float *x, long ldx, float *dw, const float *roww,
+                                     long rws, void *stream) {
+    if (n < 1 || !g || !x || !dw || !rowlin_streams(k, o)) return PDF_ERR_UNSUPPORTED;
+    float *db = nullptr;
+    if (!rl2::try_wgrad(n, k, o, 1, &g, ldg, x, ldx, nullptr, nullptr, 0, &dw, &db, static_cast<hipStream_t>(stream), roww, rws))
+        return PDF_ERR_UNSUPPORTED;
+    return pdf_launch_status();
 }

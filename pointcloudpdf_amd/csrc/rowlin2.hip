@@ -35,6 +35,7 @@ struct FwdArgs {
     float *Y[3]; long ldy;
     int accumulate;
     float *partial;          // [gridDim.x][2 * O] (STATS; single output)
+    const float *roww; long rws;   // optional per-row factor of the product (y = roww[n] * (f(x) Wt) + bias), element stride rws
 };
 
 constexpr int FWD_CAP = 1024;   // row-blocks (4 waves each) of the persistent grid
@@ -123,7 +124,9 @@ __global__ __launch_bounds__(256) void k_fwd(FwdArgs a) {
         }
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) {
-            f32x4 v = acc[ob] + bias4[ob];
+            f32x4 v = acc[ob];
+            if (a.roww) v *= a.roww[(valid ? n : 0) * a.rws];
+            v += bias4[ob];
             float *dst = a.Y[outi[ob]] + (valid ? n : 0) * a.ldy + colb[ob] + 4 * kq;
             if (a.accumulate && valid) v += *reinterpret_cast<const f32x4 *>(dst);
             if (valid) *reinterpret_cast<f32x4 *>(dst) = v;
@@ -159,6 +162,7 @@ struct WArgs {
     const float *scale, *shift; int relu;
     float *dW[3], *db[3];
     long rows_per_block;     // multiple of 64
+    const float *roww; long rws;   // optional per-row weight of G (dW = sum_n roww[n] G[n]^T f(X[n]))
 };
 
 template <int VW> struct Vec;
@@ -199,6 +203,7 @@ __global__ __launch_bounds__(256) void k_wg(WArgs a) {
             const bool ok = n < re;
             const long nn = ok ? n : rb;
             gv[t] = *reinterpret_cast<const vec *>(G + nn * a.ldg + ob + VW * li);
+            if (a.roww) gv[t] *= a.roww[nn * a.rws];
             xv[t] = *reinterpret_cast<const vec *>(a.X + nn * a.ldx + kb + VW * li);
             if (PRE) {
                 xv[t] = xv[t] * sc + sh;
@@ -266,7 +271,7 @@ static void launch_fwd(const FwdArgs &a, int nslabs, hipStream_t s) {
 // returns 1 when a streaming kernel took the job, 0 when the shape is not covered (caller falls back to the tiled kernel)
 int try_forward(long n, int k, int o, int nin, int nout, const float *const *x, long ldx, const float *const *w, int transpose_w,
                 const float *const *bias, const float *scale, const float *shift, int relu, float *const *y, long ldy,
-                int accumulate, float *partial, hipStream_t s) {
+                int accumulate, float *partial, hipStream_t s, const float *roww, long rws) {
     if (nin < 1 || nout < 1 || (nin > 1 && nout > 1) || nin > 3 || nout > 3) return 0;
     if (partial && (nin != 1 || nout != 1)) return 0;
     if ((ldx & 3) || (ldy & 3) || (o & 15)) return 0;
@@ -276,7 +281,7 @@ int try_forward(long n, int k, int o, int nin, int nout, const float *const *x, 
     for (int i = 0; i < nout; ++i) if (!aligned16(y[i])) return 0;
     FwdArgs a;
     a.N = n; a.O = o; a.ldx = ldx; a.ldy = ldy; a.scale = scale; a.shift = shift; a.relu = relu; a.accumulate = accumulate;
-    a.partial = partial;
+    a.partial = partial; a.roww = roww; a.rws = rws;
     a.wso = transpose_w ? 1 : k; a.wsk = transpose_w ? o : 1;
     for (int i = 0; i < 3; ++i) {
         a.X[i] = i < nin ? x[i] : nullptr;
@@ -309,7 +314,7 @@ int try_forward(long n, int k, int o, int nin, int nout, const float *const *x, 
 }
 
 int try_wgrad(long n, int k, int o, int ng, const float *const *g, long ldg, const float *x, long ldx, const float *scale,
-              const float *shift, int relu, float *const *dw, float *const *db, hipStream_t s) {
+              const float *shift, int relu, float *const *dw, float *const *db, hipStream_t s, const float *roww, long rws) {
     if (ng < 1 || ng > 3) return 0;
     const int vw = (k % 64 == 0 && o % 64 == 0) ? 4 : ((k % 32 == 0 && o % 32 == 0) ? 2 : 0);
     if (!vw) return 0;
@@ -317,7 +322,7 @@ int try_wgrad(long n, int k, int o, int ng, const float *const *g, long ldg, con
     if (scale && (!aligned16(scale) || !aligned16(shift))) return 0;
     for (int i = 0; i < ng; ++i) if (!aligned16(g[i])) return 0;
     WArgs a;
-    a.N = n; a.K = k; a.O = o; a.ldg = ldg; a.X = x; a.ldx = ldx; a.scale = scale; a.shift = shift; a.relu = relu;
+    a.N = n; a.K = k; a.O = o; a.ldg = ldg; a.X = x; a.ldx = ldx; a.scale = scale; a.shift = shift; a.relu = relu; a.roww = roww; a.rws = rws;
     for (int i = 0; i < 3; ++i) { a.G[i] = i < ng ? g[i] : nullptr; a.dW[i] = i < ng ? dw[i] : nullptr; a.db[i] = (db && i < ng) ? db[i] : nullptr; }
     const int b = 16 * vw, nblk = (o / b) * (k / b) * ng;
     static const int target = [] { const char *v = getenv("PDFOPS_WG_BLOCKS"); const int x = v ? atoi(v) : 0; return x > 0 ? x : 512; }();

@@ -485,3 +485,70 @@ def bottleneck(blk, p, x, o):
     if blk.training:
         bump_counters([blk.bn1.num_batches_tracked, blk.bn2.num_batches_tracked, blk.bn3.num_batches_tracked])
     return y
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Fused TransitionDown with stride (csrc/transition_down.hip): one autograd node, one host call per direction.
+# ------------------------------------------------------------------------------------------------------------------
+class _TransitionDownFn(torch.autograd.Function):
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, mod, idx, rel4, Z, consts, x, W, gamma, beta):
+        be = _be()
+        lib = be.lib
+        n, cin = x.shape
+        m, cout = idx.shape[0], W.shape[0]
+        bn, training = mod.bn, mod.training
+        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=x.device)
+        coef, out, gram = e(4 * cout), e(m, cout), e(int(lib.pdf_td_gram_floats(cin)))
+        arg = torch.empty((m, cout), dtype=torch.uint8, device=x.device)
+        ptrs = [x.data_ptr(), idx.data_ptr(), rel4.data_ptr(), Z.data_ptr(), consts.data_ptr(), W.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                bn.running_mean.data_ptr(), bn.running_var.data_ptr(), coef.data_ptr(), out.data_ptr(), arg.data_ptr(), gram.data_ptr()]
+        rc = lib.pdf_td_forward(n, m, cin, cout, (c_void_p * len(ptrs))(*ptrs), int(training), ctypes.c_float(bn.eps),
+                                ctypes.c_float(bn.momentum or 0.1), be._stream())
+        if rc != 0:
+            raise RuntimeError(f"pdf_td_forward failed with status {rc}")
+        ctx.save_for_backward(x, idx, rel4, Z, consts, W, gamma, beta, coef, out, arg, gram)
+        ctx.training = training
+        return out
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, gout):
+        if not ctx.training:
+            raise RuntimeError("fused TransitionDown: backward is implemented for training mode (batch statistics)")
+        x, idx, rel4, Z, consts, W, gamma, beta, coef, out, arg, gram = ctx.saved_tensors
+        be = _be()
+        lib = be.lib
+        n, cin = x.shape
+        m, cout = out.shape
+        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=x.device)
+        gx, dW, dgb = e(n, cin), e(cout, 3 + cin), e(2 * cout)
+        scratch = e(int(lib.pdf_td_bwd_scratch_floats(m, cin, cout)))
+        gout = gout.contiguous()
+        ptrs = [gout.data_ptr(), out.data_ptr(), arg.data_ptr(), x.data_ptr(), idx.data_ptr(), rel4.data_ptr(), Z.data_ptr(), consts.data_ptr(),
+                W.data_ptr(), gamma.data_ptr(), beta.data_ptr(), coef.data_ptr(), gram.data_ptr(), gx.data_ptr(), dW.data_ptr(), dgb.data_ptr(),
+                scratch.data_ptr()]
+        rc = lib.pdf_td_backward(n, m, cin, cout, (c_void_p * len(ptrs))(*ptrs), be._stream())
+        if rc != 0:
+            raise RuntimeError(f"pdf_td_backward failed with status {rc}")
+        return None, None, None, None, None, gx, dW, dgb[cout:], dgb[:cout]
+
+
+def transition_down(mod, geom, level, new_level, x):
+    """TransitionDown (stride > 1) through the fused kernels; the caller checked ``transition_down_ok``."""
+    idx, _ = geom.knn(mod.nsample, level, new_level)
+    rel4, Z, _, consts = geom.td(mod.nsample, level, new_level)
+    out = _TransitionDownFn.apply(mod, idx, rel4, Z, consts, x, mod.linear.weight, mod.bn.weight, mod.bn.bias)
+    if mod.training:
+        bump_counters([mod.bn.num_batches_tracked])
+    return out
+
+
+def transition_down_ok(mod, x):
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous() and type(mod.bn) is torch.nn.BatchNorm1d
+            and mod.bn.affine and mod.bn.track_running_stats and mod.linear.bias is None):
+        return False
+    if torch.is_grad_enabled() and not mod.training and any(p.requires_grad for p in mod.parameters()):
+        return False
+    return bool(_be().lib.pdf_td_supported(mod.nsample, x.shape[1], mod.linear.weight.shape[0]))

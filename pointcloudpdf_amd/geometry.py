@@ -139,9 +139,34 @@ class Geometry:
             self._memo[key] = (idx, interpolation_weights(dist2))
         return self._memo[key]
 
+    def td(self, nsample, src_level, query_level):
+        """Geometry-only tables of the fused TransitionDown (csrc/transition_down.hip) for the grouping of level ``src_level``
+        points around the level ``query_level`` points: (rel4 (M,k,4) masked relative coordinates, Z (N,32) = per SOURCE point
+        [sum of the relative coordinates of the rows that gather it (3) | number of such rows | 0...], per-scene moment sums
+        (b,16), consts (16) = the batch's [sum rel^T rel (9) | sum rel (3) | 0...])."""
+        key = ("td", nsample, src_level, query_level)
+        if key not in self._memo:
+            idx, _ = self.knn(nsample, src_level, query_level)
+            S, Q = self.levels[src_level], self.levels[query_level]
+            assert nsample == 16, "fused TransitionDown tables: nsample 16"
+            rel4, Z, _ = _native.backend_for(S.p).td_tables(S.p, Q.p, idx, Q.o)
+            # per-scene [xx xy xz yy yz zz | sx sy sz] of the relative coordinates: per-point sums over the 16 rows, then one
+            # fp64 reduction per scene (scenes are contiguous point ranges known on the host; a column-wise cumsum took 57 ms)
+            r0, r1, r2 = rel4[..., 0], rel4[..., 1], rel4[..., 2]
+            mom = torch.stack([(r0 * r0).sum(1), (r0 * r1).sum(1), (r0 * r2).sum(1), (r1 * r1).sum(1), (r1 * r2).sum(1), (r2 * r2).sum(1),
+                               r0.sum(1), r1.sum(1), r2.sum(1)], -1).double()
+            scene_sums = Z.new_zeros(len(Q.o_host), 16)
+            prev = 0
+            for si, e in enumerate(Q.o_host):
+                if e > prev:
+                    scene_sums[si, :9] = mom[prev:e].sum(0).float()
+                prev = e
+            self._memo[key] = (rel4, Z, scene_sums, _td_consts(scene_sums))
+        return self._memo[key]
+
     def memo_size(self):
         """Number of memoised geometry ops (FPS + kNN + interpolation tables)."""
-        return sum(1 for k in self._memo if k[0] in ("down", "knn", "interp"))
+        return sum(1 for k in self._memo if k[0] in ("down", "knn", "interp"))  # ("td" tables are derived data)
 
     # ------------------------------------------------------------------ pre-pass
     def precompute(self, strides=(1, 4, 4, 4, 4), nsamples=(8, 16, 16, 16, 16), interp_k=3, recognizer=True):
@@ -158,6 +183,9 @@ class Geometry:
             lvl = new_level
         if recognizer:
             self.interp(lvl, lvl, interp_k)              # PTRecognizer.dec5 interpolates level 5 onto itself (pt_v1.py:37)
+        if self.levels[0].p.is_cuda:                     # tables of the fused TransitionDown (device path only)
+            for i in range(1, len(strides)):
+                self.td(nsamples[i], i - 1, i)
         return self
 
     def load(self, src):
@@ -213,6 +241,9 @@ class Geometry:
                 elif kind == "interp":
                     (idx, weight), (q0, q1) = val, rows[key[3]]
                     g._memo[key] = (rebase(idx[q0:q1], rows[key[2]][0]), weight[q0:q1])
+                elif kind == "td":   # rel4 by query rows, Z by source rows; the 12 sums are per batch
+                    (rel4, Z, scene_sums, _), (q0, q1), (r0, r1) = val, rows[key[3]], rows[key[2]]
+                    g._memo[key] = (rel4[q0:q1], Z[r0:r1], scene_sums[s0:s1], _td_consts(scene_sums[s0:s1]))
                 else:
                     raise RuntimeError(f"Geometry.split: unknown memo entry {key}")
             out.append(g)
@@ -224,6 +255,16 @@ class Geometry:
         for v in self._memo.values():
             out += [t for t in (v if isinstance(v, tuple) else (v,)) if isinstance(t, torch.Tensor)]
         return out
+
+
+def _td_consts(scene_sums):
+    """(b,16) per-scene [xx xy xz yy yz zz | sx sy sz] -> the batch's [sum rel^T rel (9) | sum rel (3) | 0 x4]."""
+    t = scene_sums.double().sum(0)
+    out = scene_sums.new_zeros(16)
+    out[:9] = torch.stack([t[0], t[1], t[2], t[1], t[3], t[4], t[2], t[4], t[5]]).float()   # (no index tensors: an H2D copy here would block the
+    #                                                                                         host behind the whole pre-pass stream)
+    out[9:12] = t[6:9].float()
+    return out
 
 
 class GeometryPrefetcher:

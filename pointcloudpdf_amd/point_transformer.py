@@ -170,6 +170,8 @@ class PointTransformerLayer(nn.Module):
 class TransitionDown(nn.Module):
     """point_transformer_seg.py:81-119"""
 
+    fused = os.environ.get("PDFOPS_FUSED_TD", "1") != "0"   # class-wide switch: csrc/transition_down.hip where it applies
+
     def __init__(self, in_planes, out_planes, stride=1, nsample=16):
         super().__init__()
         self.stride, self.nsample = stride, nsample
@@ -202,6 +204,9 @@ class TransitionDown(nn.Module):
         p, x, o = pxo  # (n, 3), (n, c), (b)
         if self.stride != 1:
             n_p, n_o = self._downsample(p, o)
+            tag, ntag = tag_of(p), tag_of(n_p)
+            if self.fused and tag is not None and ntag is not None and tag[0] is ntag[0] and dense.transition_down_ok(self, x):
+                return [n_p, dense.transition_down(self, tag[0], tag[1], ntag[1], x), n_o]
             x, _ = pointops.knn_query_and_group(x, p, offset=o, new_xyz=n_p, new_offset=n_o, nsample=self.nsample, with_xyz=True)
             m, ns = x.shape[0], x.shape[1]
             if x.is_cuda:

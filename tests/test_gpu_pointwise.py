@@ -1,4 +1,5 @@
 """GPU suite: fused BatchNorm(+residual)(+ReLU) kernels (csrc/pointwise.hip) and the split-K Linear against torch."""
+import numpy as np
 import pytest
 import torch
 
@@ -188,3 +189,45 @@ def test_fused_cross_entropy(n, c):
     (ref * 1.3).backward()
     assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
     assert max_rel(logits.grad.cpu().numpy(), ref_in.grad.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("cin,sizes,train", [(32, [3000, 2600], True), (64, [900, 40], True), (128, [700], True), (256, [300, 260], True),
+                                              (32, [2000, 1500], False), (64, [10, 1200], True)])
+def test_fused_transition_down(cin, sizes, train):
+    """csrc/transition_down.hip (Gram-matrix BatchNorm statistics, sparse arg-max backward) vs the composed path
+    (grouping kernel + Linear + BatchNorm + ReLU + MaxPool1d), incl. scenes shorter than nsample (-1 placeholder rows)."""
+    from pointcloudpdf_amd import synthetic
+    from pointcloudpdf_amd.geometry import Geometry
+    from pointcloudpdf_amd.point_transformer import TransitionDown
+
+    batch = synthetic.make_batch(sizes, first_scene_id=70, grid_size=0.25, device="cuda")
+    res = []
+    for fused in (True, False):
+        geom = Geometry(batch["coord"], batch["offset"], batch["offset_host"])
+        td = TransitionDown(cin, 2 * cin, 4, 16).cuda()
+        synthetic.fill_parameters_deterministic(td, seed=11)
+        td.train(train)
+        g = torch.Generator(device="cuda").manual_seed(2)
+        x = torch.randn(sum(sizes), cin, device="cuda", generator=g).requires_grad_(train)
+        TransitionDown.fused = fused
+        try:
+            with torch.set_grad_enabled(train):
+                p2, y, o2 = td([geom.coord(0), x, geom.offset(0)])
+            out = {"y": y.detach().cpu().numpy(), "p": p2.cpu().numpy(), "o": o2.cpu().numpy()}
+            if train:
+                y.backward(torch.randn(y.shape, device="cuda", generator=g))
+                out["gx"] = x.grad.cpu().numpy()
+                out.update({"g_" + n: p.grad.cpu().numpy() for n, p in td.named_parameters()})
+            out.update({"b_" + n: b.detach().float().cpu().numpy() for n, b in td.named_buffers()})
+        finally:
+            TransitionDown.fused = True
+        res.append(out)
+    a, b = res
+    assert np.array_equal(a["p"], b["p"]) and np.array_equal(a["o"], b["o"])
+    for k in b:
+        if k in ("p", "o"):
+            continue
+        if k == "y" or k.startswith("b_"):
+            assert max_rel(a[k], b[k]) < 2e-5, (k, max_rel(a[k], b[k]))
+        else:
+            assert l2_rel(a[k], b[k]) < 2e-3, (k, l2_rel(a[k], b[k]), max_rel(a[k], b[k]))
