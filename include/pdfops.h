@@ -201,6 +201,9 @@ int pdf_block_post_backward(long n, int c, void *const *p, int training, void *s
 /* The whole Bottleneck (both halves + the fused attention layer) as one call per direction; tables in csrc/block.hip. */
 int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p, int training, float eps, float momentum, void *stream);
 int pdf_bottleneck_backward(long n, int nsample, int c, void *const *p, int training, void *stream);
+/* Linear (+ bias) -> BatchNorm1d -> (ReLU) as one call per direction (TransitionUp, heads); tables in csrc/block.hip. */
+int pdf_linbn_forward(long n, int k, int o, void *const *p, int training, int relu, float eps, float momentum, void *stream);
+int pdf_linbn_backward(long n, int k, int o, void *const *p, int training, int relu, void *stream);
 
 /* Row-weighted variants of the streaming Linear kernels and the bare BatchNorm-backward sums (building blocks of pdf_td_*). */
 int pdf_rowlin_forward_roww(long n, int k, int o, const float *x, long ldx, const float *w, int transpose_w, float *y, long ldy,

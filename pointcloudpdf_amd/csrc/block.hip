@@ -173,3 +173,38 @@ extern "C" int pdf_bottleneck_backward(long n, int nsample, int c, void *const *
     e << block_pre_backward(n, c, pre, training, 1, 1, stream);   // gx += dy W1 on top of the identity branch
     return e.rc;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Linear (+ bias) -> BatchNorm1d -> ReLU on (n, k) rows as one host call per direction (TransitionUp.linear1/linear2, the cls
+// and confidence heads: point_transformer_seg.py:131-147, 229-234; pt_v1.py:17-24).  Streaming shapes only (k in 32..512,
+// o % 16 == 0): the GEMM's epilogue emits the column statistics, so the norm costs one extra pass (apply) instead of three.
+// Forward p[]: 0 x 1 W (o,k) 2 bias 3 gamma 4 beta 5 rm 6 rv | 7 z (n,o) 8 coef (4o) 9 y (n,o) 10 partial (pdf_rowlin_partial_floats(n,o))
+extern "C" int pdf_linbn_forward(long n, int k, int o, void *const *p, int training, int relu, float eps, float momentum, void *stream) {
+    if (n < 1 || !p) return PDF_ERR_BAD_ARG;
+    if (!pdf_bn_supported(o)) return PDF_ERR_UNSUPPORTED;
+    Err e;
+    float *z = (float *)p[7], *coef = (float *)p[8], *partial = (float *)p[10];
+    e << pdf_rowlin_forward(n, k, o, (const float *)p[0], k, (const float *)p[1], 0, (const float *)p[2], nullptr, nullptr, 0, z, o, 0,
+                            training ? partial : nullptr, stream);
+    e << pdf_bn_coef_eval_or_partial(partial, pdf_rowlin_partial_rows(n, k, o), n, o, (const float *)p[3], (const float *)p[4], (float *)p[5],
+                                     (float *)p[6], training, eps, momentum, coef, stream);
+    e << pdf_bn_apply(n, o, z, nullptr, coef, relu, (float *)p[9], stream);
+    return e.rc;
+}
+
+// Backward p[]: 0 gy 1 x 2 z 3 coef 4 W | 5 gx (n,k) or null 6 grads [dW (o*k) | db (o) | dbeta (o) | dgamma (o)] (zeroed here)
+//               7 gz (n,o) scratch 8 partial (pdf_bn_partial_floats(n,o))
+extern "C" int pdf_linbn_backward(long n, int k, int o, void *const *p, int training, int relu, void *stream) {
+    if (n < 1 || !p) return PDF_ERR_BAD_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float *grads = (float *)p[6], *gz = (float *)p[7];
+    const long ok = (long)o * k;
+    hipError_t he = hipMemsetAsync(grads, 0, sizeof(float) * (size_t)(ok + 3 * o), s);
+    if (he != hipSuccess) return (int)he;
+    Err e;
+    e << pdf_bn_act_backward(n, o, (const float *)p[0], (const float *)p[2], nullptr, (const float *)p[3], training, relu, (float *)p[8],
+                             grads + ok + o, gz, nullptr, stream);                                                    // [dbeta | dgamma]
+    if (p[5]) e << pdf_rowlin_forward(n, o, k, gz, o, (const float *)p[4], 1, nullptr, nullptr, nullptr, 0, (float *)p[5], k, 0, nullptr, stream);
+    e << pdf_rowlin_wgrad(n, k, o, gz, o, (const float *)p[1], k, nullptr, nullptr, 0, grads, grads + ok, stream);    // dW, db
+    return e.rc;
+}

@@ -552,3 +552,76 @@ def transition_down_ok(mod, x):
     if torch.is_grad_enabled() and not mod.training and any(p.requires_grad for p in mod.parameters()):
         return False
     return bool(_be().lib.pdf_td_supported(mod.nsample, x.shape[1], mod.linear.weight.shape[0]))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Linear (+ bias) -> BatchNorm1d -> (ReLU) as one autograd node (csrc/block.hip: pdf_linbn_*): TransitionUp, heads.
+# ------------------------------------------------------------------------------------------------------------------
+class _LinBnFn(torch.autograd.Function):
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, lin, bn, relu, x, W, b, gamma, beta):
+        be = _be()
+        lib = be.lib
+        n, k = x.shape
+        o = W.shape[0]
+        training = bn.training
+        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=x.device)
+        z, coef, y = e(n, o), e(4 * o), e(n, o)
+        partial = e(int(lib.pdf_rowlin_partial_floats(n, o)))
+        ptrs = [x.data_ptr(), W.data_ptr(), b.data_ptr() if b is not None else None, gamma.data_ptr(), beta.data_ptr(),
+                bn.running_mean.data_ptr(), bn.running_var.data_ptr(), z.data_ptr(), coef.data_ptr(), y.data_ptr(), partial.data_ptr()]
+        rc = lib.pdf_linbn_forward(n, k, o, (c_void_p * len(ptrs))(*ptrs), int(training), int(relu), ctypes.c_float(bn.eps),
+                                   ctypes.c_float(bn.momentum or 0.1), be._stream())
+        if rc != 0:
+            raise RuntimeError(f"pdf_linbn_forward failed with status {rc}")
+        ctx.save_for_backward(x, z, coef, W)
+        ctx.cfg = (training, relu, b is not None)
+        return y
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, gy):
+        x, z, coef, W = ctx.saved_tensors
+        training, relu, has_bias = ctx.cfg
+        be = _be()
+        lib = be.lib
+        n, k = x.shape
+        o = W.shape[0]
+        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=x.device)
+        need_gx = ctx.needs_input_grad[3]
+        gx = e(n, k) if need_gx else None
+        grads, gz = e(o * k + 3 * o), e(n, o)
+        partial = e(int(lib.pdf_bn_partial_floats(n, o)))
+        gy = gy.contiguous()
+        ptrs = [gy.data_ptr(), x.data_ptr(), z.data_ptr(), coef.data_ptr(), W.data_ptr(), gx.data_ptr() if need_gx else None, grads.data_ptr(),
+                gz.data_ptr(), partial.data_ptr()]
+        rc = lib.pdf_linbn_backward(n, k, o, (c_void_p * len(ptrs))(*ptrs), int(training), int(relu), be._stream())
+        if rc != 0:
+            raise RuntimeError(f"pdf_linbn_backward failed with status {rc}")
+        ok = o * k
+        return (None, None, None, gx, grads[:ok].view(o, k), grads[ok:ok + o] if has_bias else None, grads[ok + 2 * o:ok + 3 * o], grads[ok + o:ok + 2 * o])
+
+
+LINBN = True   # module-wide switch of the Linear -> BatchNorm1d -> ReLU node (tests compare both paths)
+
+
+def linbn_ok(lin, bn, x):
+    if not LINBN:
+        return False
+    if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous() and type(bn) is torch.nn.BatchNorm1d and bn.affine
+            and bn.track_running_stats):
+        return False
+    k, o = lin.in_features, lin.out_features
+    if k not in (32, 64, 128, 256, 512) or o % 16 or not _be().bn_supported(o):
+        return False
+    if torch.is_grad_enabled() and not bn.training and any(p.requires_grad for p in list(lin.parameters()) + list(bn.parameters())):
+        return False  # (eval-mode backward goes through the composed ops)
+    return True
+
+
+def linear_bn_act(lin, bn, x, relu):
+    y = _LinBnFn.apply(lin, bn, relu, x, lin.weight, lin.bias, bn.weight, bn.bias)
+    if bn.training:
+        bump_counters([bn.num_batches_tracked])
+    return y

@@ -37,6 +37,12 @@ def _seq(seq, x):
     i = 0
     while i < len(mods):
         m = mods[i]
+        if (isinstance(m, nn.Linear) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d) and x.dim() == 2
+                and dense.linbn_ok(m, mods[i + 1], x)):   # Linear -> BatchNorm1d (-> ReLU) as one node (csrc/block.hip)
+            relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+            x = dense.linear_bn_act(m, mods[i + 1], x, relu)
+            i += 3 if relu else 2
+            continue
         if isinstance(m, nn.Linear):
             x = _lin(m, x)
         elif isinstance(m, nn.BatchNorm1d) and type(m) is nn.BatchNorm1d and x.dim() == 2:

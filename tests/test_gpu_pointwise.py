@@ -231,3 +231,41 @@ def test_fused_transition_down(cin, sizes, train):
             assert max_rel(a[k], b[k]) < 2e-5, (k, max_rel(a[k], b[k]))
         else:
             assert l2_rel(a[k], b[k]) < 2e-3, (k, l2_rel(a[k], b[k]), max_rel(a[k], b[k]))
+
+
+@pytest.mark.parametrize("n,k,o,train", [(5000, 64, 32, True), (3000, 512, 256, True), (777, 32, 32, True), (20000, 32, 32, False), (1500, 256, 512, True)])
+def test_linear_bn_relu_node(n, k, o, train):
+    """Linear -> BatchNorm1d -> ReLU as one node (csrc/block.hip: pdf_linbn_*) vs the composed ops, through point_transformer._seq."""
+    import torch.nn as nn
+    from pointcloudpdf_amd import dense, synthetic
+    from pointcloudpdf_amd.point_transformer import _seq
+
+    res = []
+    for fused in (True, False):
+        seq = nn.Sequential(nn.Linear(k, o), nn.BatchNorm1d(o), nn.ReLU(inplace=True)).cuda()
+        synthetic.fill_parameters_deterministic(seq, seed=4)
+        seq.train(train)
+        g = torch.Generator(device="cuda").manual_seed(n + k)
+        x = torch.randn(n, k, device="cuda", generator=g).requires_grad_(train)
+        dense.LINBN = fused
+        try:
+            with torch.set_grad_enabled(train):
+                y = _seq(seq, x)
+            out = {"y": y.detach().cpu().numpy()}
+            if train:
+                y.backward(torch.randn(y.shape, device="cuda", generator=g))
+                out["gx"] = x.grad.cpu().numpy()
+                out.update({"g_" + nm: p.grad.cpu().numpy() for nm, p in seq.named_parameters()})
+            out.update({"b_" + nm: b.detach().float().cpu().numpy() for nm, b in seq.named_buffers()})
+        finally:
+            dense.LINBN = True
+        res.append(out)
+    a, b = res
+    gscale = max([abs(v).max() for kk, v in b.items() if kk.startswith("g_")] + [1e-30])
+    for kk in b:
+        if kk.startswith("g_") and abs(b[kk]).max() < 1e-4 * gscale:
+            continue  # the Linear bias in front of a train-mode BatchNorm: analytically zero gradient
+        if kk == "y" or kk.startswith("b_"):
+            assert max_rel(a[kk], b[kk]) < 2e-5, (kk, max_rel(a[kk], b[kk]))
+        else:
+            assert l2_rel(a[kk], b[kk]) < 2e-3, (kk, l2_rel(a[kk], b[kk]))
