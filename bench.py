@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-points", type=int, default=100000, help="scene size of the bounded CPU-baseline sample")
     ap.add_argument("--amp", action="store_true", help="fp16 autocast around the step (reference enable_amp=True)")
-    ap.add_argument("--prefetch", type=int, default=6,
+    ap.add_argument("--prefetch", type=int, default=16,
                     help="geometry pre-pass group: the pre-pass of the NEXT `prefetch` batches runs as one launch sequence on a side "
                          "stream while the current group trains (0 = inline, serial)")
     ap.add_argument("--graph", type=int, default=0, help="replay fwd+bwd+SGD as one captured hipGraph (needs --prefetch > 0)")
@@ -182,13 +182,18 @@ def main():
     tickets = {}
     submit_host_s = []   # host time of every grouped pre-pass submission
 
-    # Group boundaries sit at warmup + k * D, so the timed region queues exactly steps / D group pre-passes (one pre-pass
-    # per trained batch; the final fence drains the last one).  D = largest divisor of --steps <= --prefetch when there
-    # is one >= 4, else --prefetch itself (then the window holds ceil(steps / D) groups: more pre-pass work, never less).
+    # Group boundaries sit at warmup + k * D, so the timed region queues exactly steps / D group pre-passes (one pre-pass per
+    # trained batch) and, D steps being a whole group's lead time, drains them before the closing fence.  Only ONE group
+    # pre-pass is in flight at a time and its latency is the FPS chain (~160 ms however many scenes it carries), so the step
+    # time is bounded below by latency / D: D = --steps when that is <= --prefetch, else the largest divisor of --steps in
+    # [8, --prefetch], else --prefetch itself (then the window holds ceil(steps / D) groups: more pre-pass work, never less).
     D = args.prefetch
     if D > 0:
-        divs = [d for d in range(4, D + 1) if args.steps % d == 0]
-        D = max(divs) if divs else D
+        if args.steps <= D:
+            D = max(args.steps, 1)
+        else:
+            divs = [d for d in range(8, D + 1) if args.steps % d == 0]
+            D = max(divs) if divs else D
     phase = args.warmup % D if D > 0 else 0
 
     def submit_range(lo, hi):
