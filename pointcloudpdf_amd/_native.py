@@ -60,6 +60,10 @@ def _check(t, dtype, name):
 class CBackend:
     """Calls a C library that implements the pdfops ABI on tensors of one device kind."""
 
+    # the reference kernels ACCUMULATE into interpolation / aggregation / subtraction outputs, so its wrappers pre-zero them
+    # (interpolation.py:39, aggregation.py:21); a backend whose kernels overwrite those outputs skips the fill
+    overwrites_outputs = False
+
     def __init__(self, lib, prefix, device_type, use_stream, extra_protos=(), proto_overrides=None):
         self.lib = lib
         self.prefix = prefix
@@ -142,7 +146,7 @@ class CBackend:
         _check(input, torch.float32, "input"); _check(idx, torch.int32, "idx"); _check(weight, torch.float32, "weight")
         n, k = idx.shape
         c = input.shape[1]
-        out = self._new(input, (n, c), torch.float32, zero=True)
+        out = self._new(input, (n, c), torch.float32, zero=not self.overwrites_outputs)
         self._call("interpolation_forward", n, c, k, input, idx, weight, out)
         return out
 
@@ -158,7 +162,7 @@ class CBackend:
         _check(input1, torch.float32, "input1"); _check(input2, torch.float32, "input2"); _check(idx, torch.int32, "idx")
         n, c = input1.shape
         ns = idx.shape[-1]
-        out = self._new(input1, (n, ns, c), torch.float32, zero=True)
+        out = self._new(input1, (n, ns, c), torch.float32, zero=not self.overwrites_outputs)
         self._call("subtraction_forward", n, ns, c, input1, input2, idx, out)
         return out
 
@@ -176,7 +180,7 @@ class CBackend:
         _check(idx, torch.int32, "idx")
         n, ns, c = position.shape
         w_c = weight.shape[-1]
-        out = self._new(input, (n, c), torch.float32, zero=True)
+        out = self._new(input, (n, c), torch.float32, zero=not self.overwrites_outputs)
         self._call("aggregation_forward", n, ns, c, w_c, input, position, weight, idx, out)
         return out
 
@@ -185,7 +189,7 @@ class CBackend:
         n, ns, c = position.shape
         w_c = weight.shape[-1]
         gi = self._new(input, tuple(input.shape), torch.float32, zero=True)
-        gp = self._new(input, (n, ns, c), torch.float32, zero=True)
+        gp = self._new(input, (n, ns, c), torch.float32, zero=not self.overwrites_outputs)
         gw = self._new(input, (n, ns, w_c), torch.float32, zero=True)
         self._call("aggregation_backward", n, ns, c, w_c, input, position, weight, idx, grad_output, gi, gp, gw)
         return gi, gp, gw
@@ -232,6 +236,8 @@ class CBackend:
 
 class HipBackend(CBackend):
     """libpdfops.so on the current ROCm device; adds the fused entry points."""
+
+    overwrites_outputs = True
 
     def __init__(self, lib):
         super().__init__(lib, "pdf_", "cuda", True, extra_protos=tuple(_HIP_ONLY_PROTOS))

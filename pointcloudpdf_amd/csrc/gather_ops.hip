@@ -269,6 +269,190 @@ __global__ __launch_bounds__(GB) void agg_bwd_kernel(long n, int nsample, int c,
     }
 }
 
+
+// ================================================================ 32-bit fast paths (total elements < 2^31)
+// The generic kernels above divide 64-bit element ids by a runtime row length per element (an emulated 64-bit division:
+// ~100 instructions) and keep one 16-B access in flight per lane.  These twins use a 32-bit multiply-high division,
+// issue U independent gathers before the first store, and store the streamed (m, nsample, c) output non-temporally so
+// that it does not evict the gathered table from the XCD's L2.
+struct FastDiv { unsigned d, m, s; };   // q = n / d for n < 2^31:  (mulhi(n, m) + n) >> s,  m = ceil(2^(32+s) / d) - 2^32
+static inline FastDiv mk_fastdiv(unsigned d) {
+    FastDiv f; f.d = d; unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    f.s = s;
+    f.m = (unsigned)(((((unsigned __int128)1) << (32 + s)) + d - 1) / d - (((unsigned __int128)1) << 32));
+    return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv f) { return (__umulhi(n, f.m) + n) >> f.s; }
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_stream(v4f *p, v4f v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void st_stream(float *p, float v) { __builtin_nontemporal_store(v, p); }
+
+// grouping_cuda_kernel.cu:5-14, float4 per lane
+template <int U>
+__global__ __launch_bounds__(GB) void grouping_fwd32(unsigned total, FastDiv cvd, const v4f *__restrict__ input,
+                                                     const int *__restrict__ idx, v4f *__restrict__ output) {
+    const unsigned stride = gridDim.x * GB, cv = cvd.d;
+    unsigned e = blockIdx.x * GB + threadIdx.x;
+    for (; e < total && total - e > (U - 1) * stride; e += U * stride) {
+        v4f v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned ee = e + u * stride, r = fdiv(ee, cvd), col = ee - r * cv;
+            const int j = idx[r];
+            v[u] = j >= 0 ? input[(unsigned long)j * cv + col] : (v4f)(0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) st_stream(output + e + u * stride, v[u]);
+    }
+    for (; e < total; e += stride) {
+        const unsigned r = fdiv(e, cvd), col = e - r * cv;
+        const int j = idx[r];
+        st_stream(output + e, j >= 0 ? input[(unsigned long)j * cv + col] : (v4f)(0.f));
+    }
+}
+
+// subtraction_cuda_kernel.cu:5-16, float4 per lane (rowd = nsample * cv: element -> query point)
+template <int U>
+__global__ __launch_bounds__(GB) void sub_fwd32(unsigned total, FastDiv cvd, FastDiv rowd, const v4f *__restrict__ input1,
+                                                const v4f *__restrict__ input2, const int *__restrict__ idx,
+                                                v4f *__restrict__ output) {
+    const unsigned stride = gridDim.x * GB, cv = cvd.d;
+    unsigned e = blockIdx.x * GB + threadIdx.x;
+    for (; e < total && total - e > (U - 1) * stride; e += U * stride) {
+        v4f a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned ee = e + u * stride, r = fdiv(ee, cvd), col = ee - r * cv, n = fdiv(ee, rowd);
+            const int j = idx[r];
+            a[u] = input1[(unsigned long)n * cv + col];
+            b[u] = j >= 0 ? input2[(unsigned long)j * cv + col] : (v4f)(0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) st_stream(output + e + u * stride, a[u] - b[u]);
+    }
+    for (; e < total; e += stride) {
+        const unsigned r = fdiv(e, cvd), col = e - r * cv, n = fdiv(e, rowd);
+        const int j = idx[r];
+        const v4f b = j >= 0 ? input2[(unsigned long)j * cv + col] : (v4f)(0.f);
+        st_stream(output + e, input1[(unsigned long)n * cv + col] - b);
+    }
+}
+
+// interpolation_cuda_kernel.cu:5-18, float4 per lane, K neighbours gathered before the first multiply-add
+template <int K>
+__global__ __launch_bounds__(GB) void interp_fwd32(unsigned total, FastDiv cvd, int k_rt, const v4f *__restrict__ input,
+                                                   const int *__restrict__ idx, const float *__restrict__ weight,
+                                                   v4f *__restrict__ output) {
+    const unsigned stride = gridDim.x * GB, cv = cvd.d;
+    for (unsigned e = blockIdx.x * GB + threadIdx.x; e < total; e += stride) {
+        const unsigned r = fdiv(e, cvd), col = e - r * cv;
+        v4f acc = (v4f)(0.f);
+        if (K > 0) {
+            int j[K > 0 ? K : 1]; float w[K > 0 ? K : 1]; v4f v[K > 0 ? K : 1];
+#pragma unroll
+            for (int i = 0; i < K; ++i) { j[i] = idx[(unsigned long)r * K + i]; w[i] = weight[(unsigned long)r * K + i]; }
+#pragma unroll
+            for (int i = 0; i < K; ++i) v[i] = j[i] >= 0 ? input[(unsigned long)j[i] * cv + col] : (v4f)(0.f);
+#pragma unroll
+            for (int i = 0; i < K; ++i) acc += v[i] * w[i];   // same summation order as the reference (i ascending)
+        } else {
+            for (int i = 0; i < k_rt; ++i) {
+                const int j = idx[(unsigned long)r * k_rt + i];
+                const float w = weight[(unsigned long)r * k_rt + i];
+                if (j >= 0) acc += input[(unsigned long)j * cv + col] * w;
+            }
+        }
+        st_stream(output + e, acc);
+    }
+}
+
+// aggregation_cuda_kernel.cu:5-20 with 4 consecutive channels per lane (needs c % 4 == 0 and w_c % 4 == 0: the four
+// channels then use four consecutive weights)
+__global__ __launch_bounds__(GB) void agg_fwd32(unsigned total, FastDiv cvd, int nsample, unsigned wv,
+                                                const v4f *__restrict__ input, const v4f *__restrict__ position,
+                                                const v4f *__restrict__ weight, const int *__restrict__ idx,
+                                                v4f *__restrict__ output) {
+    const unsigned stride = gridDim.x * GB, cv = cvd.d;
+    for (unsigned e = blockIdx.x * GB + threadIdx.x; e < total; e += stride) {
+        const unsigned r = fdiv(e, cvd), col = e - r * cv, wcol = col % wv;
+        v4f acc = (v4f)(0.f);
+        const unsigned long base = (unsigned long)r * nsample;
+#pragma unroll 4
+        for (int s = 0; s < nsample; ++s) {
+            const int j = idx[base + s];
+            const v4f in = j >= 0 ? input[(unsigned long)j * cv + col] : (v4f)(0.f);
+            acc += (in + __builtin_nontemporal_load(position + (base + s) * cv + col)) * weight[(base + s) * wv + wcol];
+        }
+        output[e] = acc;
+    }
+}
+
+// pointops.grouping() twin, with_xyz or not: each lane builds 4 consecutive floats of the flat (rows, oc) output (they may
+// straddle the xyz | feat boundary or two rows) and stores them as one 16-B line piece
+__global__ __launch_bounds__(GB) void group_fwd32(unsigned total4, unsigned total, FastDiv ocd, FastDiv nsd, int c, int with_xyz,
+                                                  const float *__restrict__ feat, const float *__restrict__ xyz,
+                                                  const float *__restrict__ new_xyz, const int *__restrict__ idx,
+                                                  float *__restrict__ output) {
+    const unsigned stride = gridDim.x * GB, oc = ocd.d, sh = with_xyz ? 3u : 0u;
+    for (unsigned q = blockIdx.x * GB + threadIdx.x; q < total4; q += stride) {
+        const unsigned e0 = q * 4;
+        unsigned r = fdiv(e0, ocd), col = e0 - r * oc;
+        int j = idx[r];
+        float o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float v = 0.f;
+            if (e0 + u < total) {
+                if (col < sh) { if (j >= 0) v = xyz[(unsigned long)j * 3 + col] - new_xyz[(unsigned long)fdiv(r, nsd) * 3 + col]; }
+                else if (j >= 0) v = feat[(unsigned long)j * c + (col - sh)];
+            }
+            o[u] = v;
+            if (++col == oc) { col = 0; ++r; j = (e0 + u + 1 < total) ? idx[r] : -1; }
+        }
+        if (e0 + 3 < total) st_stream(reinterpret_cast<v4f *>(output) + q, (v4f){o[0], o[1], o[2], o[3]});
+        else for (int u = 0; u < 4 && e0 + u < total; ++u) output[e0 + u] = o[u];
+    }
+}
+
+
+// aggregation_cuda_kernel.cu:22-39 with the grad_weight sums of one row reduced across the wave before they leave it: the
+// c / w_c channels that share a weight sit w_c lanes apart in the SAME wave (needs 64 % w_c == 0 and c | 64 or 64 | c), so
+// xor-shuffles over w_c, 2 w_c, ... replace c / w_c atomics per element by a plain store (c <= 64) or c / 64 atomics.
+__global__ __launch_bounds__(GB) void agg_bwd32(unsigned total, FastDiv cd, int nsample, int w_c, int span,
+                                                const float *__restrict__ input, const float *__restrict__ position,
+                                                const float *__restrict__ weight, const int *__restrict__ idx,
+                                                const float *__restrict__ grad_output, float *__restrict__ grad_input,
+                                                float *__restrict__ grad_position, float *__restrict__ grad_weight) {
+    const unsigned stride = gridDim.x * GB, c = cd.d;
+    const unsigned padded = (total + 63u) & ~63u;   // whole waves iterate together (shuffles need every lane)
+    for (unsigned e = blockIdx.x * GB + threadIdx.x; e < padded; e += stride) {
+        const bool live = e < total;
+        const unsigned r = live ? fdiv(e, cd) : 0, col = live ? e - r * c : 0, wcol = col % w_c;
+        const float go = live ? grad_output[e] : 0.f;
+        const unsigned long base = (unsigned long)r * nsample;
+        for (int s = 0; s < nsample; ++s) {
+            float gw = 0.f;
+            if (live) {
+                const int j = idx[base + s];
+                const unsigned long pi = (base + s) * c + col;
+                const float w = weight[(base + s) * w_c + wcol];
+                const float in = j >= 0 ? input[(unsigned long)j * c + col] : 0.f;
+                if (j >= 0) pdf_atomic_add(grad_input + (unsigned long)j * c + col, go * w);
+                st_stream(grad_position + pi, go * w);
+                gw = go * (in + __builtin_nontemporal_load(position + pi));
+            }
+            for (int o = w_c; o < span; o <<= 1) gw += __shfl_xor(gw, o, 64);
+            if (live && (col & (span - 1)) < (unsigned)w_c) {
+                float *dst = grad_weight + (base + s) * w_c + wcol;
+                if (span == (int)c) *dst += gw;   // the whole row was in this wave (pre-zeroed accumulate target)
+                else pdf_atomic_add(dst, gw);
+            }
+        }
+    }
+}
+
 #define DISPATCH_VEC(V_, ...)                 \
     switch (V_) {                             \
         case 4: { constexpr int V = 4; __VA_ARGS__; } break; \
@@ -284,6 +468,11 @@ extern "C" int pdf_grouping_forward(int m, int nsample, int c, const float *inpu
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int v = pick_vec(c);
     const long rows = (long)m * nsample;
+    if (v == 4 && rows * (c / 4) < (1L << 31)) {
+        const unsigned total = (unsigned)(rows * (c / 4));
+        grouping_fwd32<4><<<grid_for(((long)total + 3) / 4), GB, 0, s>>>(total, mk_fastdiv(c / 4), (const v4f *)input, idx, (v4f *)output);
+        return pdf_launch_status();
+    }
     DISPATCH_VEC(v, (grouping_fwd_kernel<V><<<grid_for(rows * (c / V)), GB, 0, s>>>(rows, c / V, input, idx, output)));
     return pdf_launch_status();
 }
@@ -307,7 +496,13 @@ extern "C" int pdf_group_forward(int m, int nsample, int c, int with_xyz, const 
     if (m == 0) return PDF_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long rows = (long)m * nsample;
-    group_fwd_kernel<<<grid_for(rows * (c + (with_xyz ? 3 : 0))), GB, 0, s>>>(rows, nsample, c, with_xyz, feat, xyz, new_xyz, idx, output);
+    const int oc = c + (with_xyz ? 3 : 0);
+    if (rows * oc < (1L << 31)) {
+        const unsigned total = (unsigned)(rows * oc), total4 = (total + 3) / 4;
+        group_fwd32<<<grid_for(total4), GB, 0, s>>>(total4, total, mk_fastdiv(oc), mk_fastdiv(nsample), c, with_xyz, feat, xyz, new_xyz, idx, output);
+        return pdf_launch_status();
+    }
+    group_fwd_kernel<<<grid_for(rows * oc), GB, 0, s>>>(rows, nsample, c, with_xyz, feat, xyz, new_xyz, idx, output);
     return pdf_launch_status();
 }
 
@@ -326,6 +521,13 @@ extern "C" int pdf_interpolation_forward(int n, int c, int k, const float *input
     if (n == 0) return PDF_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int v = pick_vec(c);
+    if (v == 4 && (long)n * (c / 4) < (1L << 31) && (long)n * k < (1L << 31)) {
+        const unsigned total = (unsigned)((long)n * (c / 4));
+        const FastDiv cvd = mk_fastdiv(c / 4);
+        if (k == 3) interp_fwd32<3><<<grid_for(total), GB, 0, s>>>(total, cvd, k, (const v4f *)input, idx, weight, (v4f *)output);
+        else interp_fwd32<0><<<grid_for(total), GB, 0, s>>>(total, cvd, k, (const v4f *)input, idx, weight, (v4f *)output);
+        return pdf_launch_status();
+    }
     DISPATCH_VEC(v, (interp_fwd_kernel<V><<<grid_for((long)n * (c / V)), GB, 0, s>>>(n, c / V, k, input, idx, weight, output)));
     return pdf_launch_status();
 }
@@ -355,6 +557,12 @@ extern "C" int pdf_subtraction_forward(int n, int nsample, int c, const float *i
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int v = pick_vec(c);
     const long rows = (long)n * nsample;
+    if (v == 4 && rows * (c / 4) < (1L << 31)) {
+        const unsigned total = (unsigned)(rows * (c / 4));
+        sub_fwd32<4><<<grid_for(((long)total + 3) / 4), GB, 0, s>>>(total, mk_fastdiv(c / 4), mk_fastdiv((unsigned)nsample * (c / 4)),
+                                                                 (const v4f *)input1, (const v4f *)input2, idx, (v4f *)output);
+        return pdf_launch_status();
+    }
     DISPATCH_VEC(v, (sub_fwd_kernel<V><<<grid_for(rows * (c / V)), GB, 0, s>>>(rows, nsample, c / V, input1, input2, idx, output)));
     return pdf_launch_status();
 }
@@ -375,6 +583,12 @@ extern "C" int pdf_aggregation_forward(int n, int nsample, int c, int w_c, const
     if (n < 0 || nsample < 1 || c < 1 || w_c < 1 || !input || !position || !weight || !idx || !output) return PDF_ERR_BAD_ARG;
     if (n == 0) return PDF_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (c % 4 == 0 && w_c % 4 == 0 && (long)n * nsample * (c / 4) < (1L << 31)) {
+        const unsigned total = (unsigned)((long)n * (c / 4));
+        agg_fwd32<<<grid_for(total), GB, 0, s>>>(total, mk_fastdiv(c / 4), nsample, (unsigned)(w_c / 4), (const v4f *)input,
+                                                 (const v4f *)position, (const v4f *)weight, idx, (v4f *)output);
+        return pdf_launch_status();
+    }
     agg_fwd_kernel<<<grid_for((long)n * c), GB, 0, s>>>(n, nsample, c, w_c, input, position, weight, idx, output);
     return pdf_launch_status();
 }
@@ -387,6 +601,12 @@ extern "C" int pdf_aggregation_backward(int n, int nsample, int c, int w_c, cons
         return PDF_ERR_BAD_ARG;
     if (n == 0) return PDF_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if ((long)n * nsample * c < (1L << 31) && 64 % w_c == 0 && c % w_c == 0 && (c % 64 == 0 || 64 % c == 0)) {
+        const unsigned total = (unsigned)((long)n * c);
+        agg_bwd32<<<grid_for(total), GB, 0, s>>>(total, mk_fastdiv(c), nsample, w_c, c < 64 ? c : 64, input, position, weight, idx,
+                                                 grad_output, grad_input, grad_position, grad_weight);
+        return pdf_launch_status();
+    }
     agg_bwd_kernel<<<grid_for((long)n * c), GB, 0, s>>>(n, nsample, c, w_c, input, position, weight, idx, grad_output,
                                                         grad_input, grad_position, grad_weight);
     return pdf_launch_status();
