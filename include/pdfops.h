@@ -54,6 +54,22 @@ int pdf_knn_query_list(int m, int nsample, const float *xyz, const float *new_xy
                        const int *new_offset, int b, int *idx, float *dist2, const int *qlist, const int *qcount,
                        void *stream);
 
+/* replaces ball_query_cuda_launcher, libs/pointops/src/ball_query/ball_query_cuda_kernel.h:9-17 (kernel
+ * ball_query_cuda_kernel.cu:58-123): points with d2 <= 1e-5 or min_radius^2 <= d2 < max_radius^2, collected in index
+ * order, permuted by the reference's heap_sort, then the first candidates (<= nsample, padded with idx -1 / dist2 1e10) or
+ * every (count / nsample)-th one (dist2 then holds the candidate INDEX as float, as upstream :120).  The reference's
+ * per-thread list holds 2048 candidates and overruns beyond; here the first 2048 accepted points are kept.
+ * nsample <= 2048, min_radius < max_radius. */
+int pdf_ball_query(int m, int nsample, float min_radius, float max_radius, const float *xyz, const float *new_xyz,
+                   const int *offset, const int *new_offset, int b, int *idx, float *dist2, void *stream);
+
+/* replaces random_ball_query_cuda_launcher, libs/pointops/src/random_ball_query/random_ball_query_cuda_kernel.h:9-17
+ * (kernel random_ball_query_cuda_kernel.cu:58-108): the first nsample accepted points along the caller's per-scene
+ * permutation `order` (n ints, global row ids), padded with idx -1 / dist2 1e10. */
+int pdf_random_ball_query(int m, int nsample, float min_radius, float max_radius, const int *order, const float *xyz,
+                          const float *new_xyz, const int *offset, const int *new_offset, int b, int *idx, float *dist2,
+                          void *stream);
+
 /* replaces farthest_point_sampling_cuda_launcher, libs/pointops/src/sampling/sampling_cuda_kernel.h:13
  * (kernel sampling_cuda_kernel.cu:14-129).  `n` = size of the largest scene (fixes the reference's
  * block size opt_n_threads(n), cuda_utils.h:11-14, which fixes its arg-max tie rule).

@@ -30,7 +30,7 @@ class OracleBackend(CBackend):
         build()
         lib = ctypes.CDLL(LIB_PATH)
         # the reference launcher has no scene-count argument (knn_query_cuda_kernel.h:13)
-        super().__init__(lib, "oracle_", "cpu", False, proto_overrides={"knn_query": "iipppppp"})
+        super().__init__(lib, "oracle_", "cpu", False, proto_overrides={"knn_query": "iipppppp", "ball_query": "iiffpppppp", "random_ball_query": "iiffppppppp"})
         lib.oracle_opt_n_threads.restype = ctypes.c_int
         lib.oracle_opt_n_threads.argtypes = [ctypes.c_int]
         lib.oracle_num_threads.restype = ctypes.c_int

@@ -126,6 +126,89 @@ int oracle_knn_query(int m, int nsample, const float *xyz, const float *new_xyz,
     return 0;
 }
 
+
+/* ------------------------------------------------------------------ ball queries */
+/* libs/pointops/src/ball_query/ball_query_cuda_kernel.cu:15-30 (same body as the kNN reheap) and :33-42: the reference
+ * calls heap_sort on the index-ordered candidate list WITHOUT building a heap first; restated as written. */
+#define ORACLE_BQ_CAP 2048 /* candi_dist[2048], ball_query_cuda_kernel.cu:85-86 (the reference overruns beyond; we stop) */
+
+/* ball_query_cuda_kernel.cu:58-123 (one loop iteration == one CUDA thread) */
+int oracle_ball_query(int m, int nsample, float min_radius, float max_radius, const float *xyz, const float *new_xyz,
+                      const int *offset, const int *new_offset, int *idx, float *dist2)
+{
+    if (nsample < 1 || nsample > ORACLE_BQ_CAP) return 1;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int pt_idx = 0; pt_idx < m; pt_idx++) {
+        const float *q = new_xyz + (size_t)pt_idx * 3;
+        int *oi = idx + (size_t)pt_idx * nsample;
+        float *od = dist2 + (size_t)pt_idx * nsample;
+        int bt_idx = get_bt_idx(pt_idx, new_offset);
+        int start = bt_idx == 0 ? 0 : offset[bt_idx - 1];
+        int end = offset[bt_idx];
+        float max_radius2 = max_radius * max_radius;
+        float min_radius2 = min_radius * min_radius;
+        float new_x = q[0], new_y = q[1], new_z = q[2];
+        float candi_dist[ORACLE_BQ_CAP];
+        int candi_idx[ORACLE_BQ_CAP];
+        int candi_num = 0;
+        for (int i = start; i < end && candi_num < ORACLE_BQ_CAP; i++) {
+            float x = xyz[i * 3 + 0], y = xyz[i * 3 + 1], z = xyz[i * 3 + 2];
+            float d2 = (new_x - x) * (new_x - x) + (new_y - y) * (new_y - y) + (new_z - z) * (new_z - z);
+            if (d2 <= 1e-5 || (d2 >= min_radius2 && d2 < max_radius2)) { /* 1e-5 is a double literal upstream too */
+                candi_dist[candi_num] = d2;
+                candi_idx[candi_num] = i;
+                candi_num += 1;
+            }
+        }
+        heap_sort(candi_dist, candi_idx, candi_num);
+        if (candi_num <= nsample) {
+            for (int i = 0; i < candi_num; i++) { oi[i] = candi_idx[i]; od[i] = candi_dist[i]; }
+            for (int i = candi_num; i < nsample; i++) { oi[i] = -1; od[i] = 1e10f; }
+        } else {
+            float sep = (float)candi_num / nsample;
+            for (int i = 0; i < nsample; i++) {
+                int index = (int)(sep * i);
+                if (index > candi_num - 1) index = candi_num - 1;
+                oi[i] = candi_idx[index];
+                od[i] = candi_idx[index]; /* sic, ball_query_cuda_kernel.cu:120 */
+            }
+        }
+    }
+    return 0;
+}
+
+/* libs/pointops/src/random_ball_query/random_ball_query_cuda_kernel.cu:58-108 */
+int oracle_random_ball_query(int m, int nsample, float min_radius, float max_radius, const int *order, const float *xyz,
+                             const float *new_xyz, const int *offset, const int *new_offset, int *idx, float *dist2)
+{
+    if (nsample < 1) return 1;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int pt_idx = 0; pt_idx < m; pt_idx++) {
+        const float *q = new_xyz + (size_t)pt_idx * 3;
+        int *oi = idx + (size_t)pt_idx * nsample;
+        float *od = dist2 + (size_t)pt_idx * nsample;
+        int bt_idx = get_bt_idx(pt_idx, new_offset);
+        int start = bt_idx == 0 ? 0 : offset[bt_idx - 1];
+        int end = offset[bt_idx];
+        float max_radius2 = max_radius * max_radius;
+        float min_radius2 = min_radius * min_radius;
+        float new_x = q[0], new_y = q[1], new_z = q[2];
+        int cnt = 0;
+        for (int i = start; i < end; i++) {
+            float x = xyz[order[i] * 3 + 0], y = xyz[order[i] * 3 + 1], z = xyz[order[i] * 3 + 2];
+            float d2 = (new_x - x) * (new_x - x) + (new_y - y) * (new_y - y) + (new_z - z) * (new_z - z);
+            if (d2 <= 1e-5 || (d2 >= min_radius2 && d2 < max_radius2)) {
+                od[cnt] = d2;
+                oi[cnt] = order[i];
+                cnt += 1;
+                if (cnt >= nsample) break;
+            }
+        }
+        for (int i = cnt; i < nsample; i++) { oi[i] = -1; od[i] = 1e10f; }
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------ FPS */
 /* libs/pointops/src/sampling/sampling_cuda_kernel.cu:14-129, launcher :131-171.
  * Lock-step emulation of one thread block per scene: `dists`/`dists_i` are the

@@ -18,10 +18,13 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpdfops.so")
 c_int = ctypes.c_int
 c_long = ctypes.c_long
 c_void_p = ctypes.c_void_p
+c_float = ctypes.c_float
 
-# name -> argument kinds ("i" int, "l" long, "p" pointer); the stream pointer is appended for HIP.
+# name -> argument kinds ("i" int, "l" long, "f" float, "p" pointer); the stream pointer is appended for HIP.
 _PROTOS = {
     "knn_query": "iippppipp",
+    "ball_query": "iiffppppipp",
+    "random_ball_query": "iiffpppppipp",
     "farthest_point_sampling": "iippppp",
     "grouping_forward": "iiippp",
     "grouping_backward": "iiippp",
@@ -42,7 +45,7 @@ _HIP_ONLY_PROTOS = {
     "interpolation_weights": "iipp",
     "farthest_point_sampling_bucketed": "iiipppplp",
 }
-_KIND = {"i": c_int, "l": c_long, "p": c_void_p}
+_KIND = {"i": c_int, "l": c_long, "f": c_float, "p": c_void_p}
 
 
 class PdfOpsError(RuntimeError):
@@ -116,6 +119,28 @@ class CBackend:
             self._call("knn_query", m, nsample, xyz, new_xyz, offset, new_offset, offset.shape[0], idx, dist2)
         else:
             self._call("knn_query", m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2)
+        return idx, dist2
+
+    def ball_query(self, nsample, max_radius, min_radius, xyz, new_xyz, offset, new_offset, order=None):
+        """-> idx (m, nsample) int32, dist2 (m, nsample) f32.  ball_query_cuda / random_ball_query_cuda (``order`` given),
+        query.py:48-64, 96-111."""
+        _check(xyz, torch.float32, "xyz"); _check(new_xyz, torch.float32, "new_xyz")
+        _check(offset, torch.int32, "offset"); _check(new_offset, torch.int32, "new_offset")
+        if not min_radius < max_radius:
+            raise ValueError("min_radius must be below max_radius")
+        if not 1 <= nsample <= 2048:
+            raise ValueError("nsample must be in 1..2048")
+        m = new_xyz.shape[0]
+        idx = self._new(xyz, (m, nsample), torch.int32)
+        dist2 = self._new(xyz, (m, nsample), torch.float32)
+        head = [m, nsample, float(min_radius), float(max_radius)]
+        name = "ball_query"
+        if order is not None:
+            _check(order, torch.int32, "order")
+            head.append(order)
+            name = "random_ball_query"
+        tail = [offset.shape[0], idx, dist2] if self.use_stream else [idx, dist2]
+        self._call(name, *head, xyz, new_xyz, offset, new_offset, *tail)
         return idx, dist2
 
     def farthest_point_sampling(self, xyz, offset, new_offset, n_max, m_total):

@@ -24,6 +24,7 @@ EXTRA = {
     "sampling.hip": ["-ffp-contract=off"],
     "sampling_bucketed.hip": ["-ffp-contract=off"],
     "knn_grid.hip": ["-ffp-contract=off"],
+    "ball_query.hip": ["-ffp-contract=off"],
 }
 
 

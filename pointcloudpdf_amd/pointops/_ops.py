@@ -53,21 +53,49 @@ class KNNQuery(Function):
 knn_query = KNNQuery.apply
 
 
-def _not_on_path(name, where):
-    def fn(*args, **kwargs):
-        raise NotImplementedError(
-            f"pointops.{name} is outside the PointTransformer-V1 / PDF hot path (no in-tree caller on it; "
-            f"upstream kernel: {where}). See DESIGN.md 'Out of scope'."
-        )
+class BallQuery(Function):
+    """libs/pointops/functions/query.py:78-115 (argument order: nsample, max_radius, min_radius, ...)"""
 
-    fn.__name__ = name
-    return fn
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, nsample, max_radius, min_radius, xyz, offset, new_xyz=None, new_offset=None):
+        if new_xyz is None or new_offset is None:
+            new_xyz, new_offset = xyz, offset
+        assert xyz.is_contiguous() and new_xyz.is_contiguous()
+        assert min_radius < max_radius
+        idx, dist2 = _be(xyz).ball_query(nsample, max_radius, min_radius, xyz, new_xyz,
+                                         _i32(offset).contiguous(), _i32(new_offset).contiguous())
+        dist = torch.sqrt(dist2)
+        ctx.mark_non_differentiable(idx, dist)
+        return idx, dist
 
 
-ball_query = _not_on_path("ball_query", "libs/pointops/src/ball_query/ball_query_cuda_kernel.cu:58-123")
-random_ball_query = _not_on_path(
-    "random_ball_query", "libs/pointops/src/random_ball_query/random_ball_query_cuda_kernel.cu:58-108"
-)
+class RandomBallQuery(Function):
+    """libs/pointops/functions/query.py:27-75: one ``torch.randperm`` per scene (drawn on ``offset``'s device from torch's
+    global generator, as upstream), then the first nsample in-shell points along that permutation."""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, nsample, max_radius, min_radius, xyz, offset, new_xyz=None, new_offset=None):
+        if new_xyz is None or new_offset is None:
+            new_xyz, new_offset = xyz, offset
+        assert xyz.is_contiguous() and new_xyz.is_contiguous()
+        assert min_radius < max_radius
+        ends = [int(v) for v in offset.tolist()]
+        order, start = [], 0
+        for e in ends:
+            order.append(torch.randperm(e - start, dtype=torch.int32, device=offset.device) + start)
+            start = e
+        order = torch.cat(order, dim=0).to(xyz.device)
+        idx, dist2 = _be(xyz).ball_query(nsample, max_radius, min_radius, xyz, new_xyz,
+                                         _i32(offset).contiguous(), _i32(new_offset).contiguous(), order=order.contiguous())
+        dist = torch.sqrt(dist2)
+        ctx.mark_non_differentiable(idx, dist)
+        return idx, dist
+
+
+ball_query = BallQuery.apply
+random_ball_query = RandomBallQuery.apply
 
 
 # ----------------------------------------------------------------------------- sampling

@@ -120,14 +120,18 @@ def install_reference():
     def attention_fusion_step_backward_cuda(m, g, c, weight, gw, value, gv, it, ir, grad_output):
         be._call("attention_fusion_step_backward", m, g, c, weight, gw, value, gv, it, ir, grad_output.contiguous())
 
-    def _absent(*a, **k):
-        raise NotImplementedError("ball queries are off the hot path")
+    def ball_query_cuda(m, nsample, min_radius, max_radius, xyz, new_xyz, offset, new_offset, idx, dist2):
+        i, d = be.ball_query(nsample, max_radius, min_radius, xyz.contiguous(), new_xyz.contiguous(), offset.contiguous(), new_offset.contiguous())
+        idx.copy_(i); dist2.copy_(d)
+
+    def random_ball_query_cuda(m, nsample, min_radius, max_radius, order, xyz, new_xyz, offset, new_offset, idx, dist2):
+        i, d = be.ball_query(nsample, max_radius, min_radius, xyz.contiguous(), new_xyz.contiguous(), offset.contiguous(),
+                             new_offset.contiguous(), order=order.contiguous())
+        idx.copy_(i); dist2.copy_(d)
 
     for name, fn in list(locals().items()):
         if name.endswith("_cuda"):
             setattr(C, name, fn)
-    C.ball_query_cuda = _absent
-    C.random_ball_query_cuda = _absent
 
     # shim 2: CPU constructors for torch.cuda.{Int,Float}Tensor
     torch.cuda.IntTensor = lambda *a: torch.IntTensor(*a)
@@ -381,6 +385,34 @@ def run_op_cases(ref_pointops):
     return out
 
 
+def run_ball_cases(ref_pointops):
+    """ball_query / random_ball_query / ball_query_and_group through the reference's wrappers (query.py:27-115,
+    utils.py:21-41); inputs are regenerated from the seed by the tests."""
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    n = 900
+    xyz = torch.rand(n, 3, generator=g) * torch.tensor([4.0, 3.0, 2.0])
+    xyz[700:720] = xyz[100:120]          # duplicated points (d2 == 0 <= 1e-5 branch)
+    offset = torch.tensor([300, 305, 900], dtype=torch.int32)
+    sel = torch.cat([torch.arange(0, 300, 3), torch.arange(300, 305), torch.arange(305, 900, 5)])
+    new_xyz = xyz[sel].contiguous()
+    new_offset = torch.tensor([100, 105, 224], dtype=torch.int32)
+    feat = torch.randn(n, 6, generator=g)
+    out["xyz"], out["offset"], out["new_xyz"], out["new_offset"], out["feat"] = (
+        xyz.numpy(), offset.numpy(), new_xyz.numpy(), new_offset.numpy(), feat.numpy())
+    for tag, (ns, rmax, rmin) in {"a": (16, 0.5, 0.0), "b": (8, 0.9, 0.3), "c": (32, 0.25, 0.0)}.items():
+        i, d = ref_pointops.ball_query(ns, rmax, rmin, xyz, offset, new_xyz, new_offset)
+        out[f"bq_{tag}_idx"], out[f"bq_{tag}_dist"] = i.numpy(), d.numpy()
+        i, d = ref_pointops.ball_query(ns, rmax, rmin, xyz, offset)
+        out[f"bqs_{tag}_idx"], out[f"bqs_{tag}_dist"] = i.numpy(), d.numpy()
+        torch.manual_seed(5)
+        i, d = ref_pointops.random_ball_query(ns, rmax, rmin, xyz, offset, new_xyz, new_offset)
+        out[f"rbq_{tag}_idx"], out[f"rbq_{tag}_dist"] = i.numpy(), d.numpy()
+    gr, gi = ref_pointops.ball_query_and_group(feat, xyz, offset, new_xyz, new_offset, max_radio=0.5, min_radio=0.0, nsample=16, with_xyz=True)
+    out["bqg_out"], out["bqg_idx"] = gr.numpy(), gi.numpy()
+    return out
+
+
 def run_hook_case(hook):
     """BaseModelHook on a toy module: forward/backward capture + clone semantics."""
     torch.manual_seed(3)
@@ -399,6 +431,9 @@ def run_hook_case(hook):
 
 def main():
     ref_pointops, seg, rec, hook, losses = install_reference()
+    np.savez_compressed(os.path.join(OUT, "ops_ball_ref.npz"), **run_ball_cases(ref_pointops))
+    if "--only-ball" in sys.argv:
+        return
     np.savez_compressed(os.path.join(OUT, "ops_python_ref.npz"), **run_op_cases(ref_pointops))
     np.savez_compressed(os.path.join(OUT, "model_hook_ref.npz"), **run_hook_case(hook))
     for name, (sizes, gs) in MODEL_CASES.items():

@@ -162,6 +162,74 @@ def test_fps_full_size_100k(hip, oracle_backend):
     assert f[0] == 0 and f.unique().numel() == f.numel()
 
 
+# ----------------------------------------------------------------------------------------------- ball queries
+def both_ball(hip, oracle_backend, ns, rmax, rmin, xyz, new_xyz, off, noff, order=None):
+    i_o, d_o = oracle_backend.ball_query(ns, rmax, rmin, xyz, new_xyz, off, noff, order=order)
+    i_h, d_h = hip.ball_query(ns, rmax, rmin, xyz.to(DEV), new_xyz.to(DEV), off.to(DEV), noff.to(DEV),
+                              order=None if order is None else order.to(DEV))
+    torch.cuda.synchronize()
+    return i_o, d_o, i_h.cpu(), d_h.cpu()
+
+
+@pytest.mark.parametrize("ns,rmax,rmin", [(16, 0.4, 0.0), (8, 1.2, 0.5), (64, 0.3, 0.0), (5, 2.5, 0.0), (100, 0.8, 0.1)])
+@pytest.mark.parametrize("snap", [0, 4])
+def test_ball_query_bit_exact(hip, oracle_backend, ns, rmax, rmin, snap):
+    """ball_query_cuda_kernel.cu:58-123: shell test, index-ordered candidates, the un-heapified heap_sort permutation,
+    padding / strided pick -- bit for bit, incl. a scene shorter than nsample, snapped clouds (duplicates: d2 == 0) and
+    rmax = 2.5 on 2900 points (more than 2048 candidates: the list stops at the first 2048 on both sides)."""
+    sizes = [1500, 3, 2900, 600]
+    xyz = cloud(sum(sizes), 31 + ns, snap)
+    off = offs(sizes)
+    i_o, d_o, i_h, d_h = both_ball(hip, oracle_backend, ns, rmax, rmin, xyz, xyz, off, off)
+    assert torch.equal(i_o, i_h), f"ball idx mismatch rows: {(i_o != i_h).any(1).sum().item()}"
+    assert torch.equal(d_o, d_h)
+    qsel = torch.cat([torch.arange(0, 1500, 7), torch.arange(1500, 1503), torch.arange(1503, 4403, 11), torch.arange(4403, 5003, 3)])
+    qoff = offs([215, 3, 264, 200])
+    i_o, d_o, i_h, d_h = both_ball(hip, oracle_backend, ns, rmax, rmin, xyz, xyz[qsel].contiguous(), off, qoff)
+    assert torch.equal(i_o, i_h) and torch.equal(d_o, d_h)
+
+
+@pytest.mark.parametrize("ns,rmax,rmin", [(16, 0.4, 0.0), (8, 1.2, 0.5), (70, 0.6, 0.0)])
+def test_random_ball_query_bit_exact(hip, oracle_backend, ns, rmax, rmin):
+    sizes = [1500, 3, 2900, 600]
+    xyz = cloud(sum(sizes), 77, snap=0)
+    off = offs(sizes)
+    g = torch.Generator().manual_seed(ns)
+    order, start = [], 0
+    for n in sizes:
+        order.append(torch.randperm(n, generator=g, dtype=torch.int32) + start); start += n
+    order = torch.cat(order)
+    i_o, d_o, i_h, d_h = both_ball(hip, oracle_backend, ns, rmax, rmin, xyz, xyz, off, off, order=order)
+    assert torch.equal(i_o, i_h) and torch.equal(d_o, d_h)
+
+
+def test_ball_query_python_goldens_on_gpu(hip, golden_dir):
+    """Fixtures produced by the reference's own BallQuery / ball_query_and_group wrappers, replayed through the HIP path."""
+    from pointcloudpdf_amd import pointops
+
+    g = np.load(os.path.join(golden_dir, "ops_ball_ref.npz"))
+    T = lambda a: torch.from_numpy(np.array(a)).to(DEV)
+    for tag, (ns, rmax, rmin) in {"a": (16, 0.5, 0.0), "b": (8, 0.9, 0.3), "c": (32, 0.25, 0.0)}.items():
+        i, d = pointops.ball_query(ns, rmax, rmin, T(g["xyz"]), T(g["offset"]), T(g["new_xyz"]), T(g["new_offset"]))
+        assert np.array_equal(i.cpu().numpy(), g[f"bq_{tag}_idx"])
+        assert_close(d.cpu(), g[f"bq_{tag}_dist"], 1e-6, "ball dist")   # device sqrt vs host sqrt: an ulp
+        i, _ = pointops.random_ball_query(ns, rmax, rmin, T(g["xyz"]), T(g["offset"]), T(g["new_xyz"]), T(g["new_offset"]))
+        ref = g[f"bq_{tag}_idx"]   # a different permutation picks different members of the same shell
+        assert ((i.cpu().numpy() >= 0).sum(1) == (ref >= 0).sum(1)).all()
+    out, idx = pointops.ball_query_and_group(T(g["feat"]), T(g["xyz"]), T(g["offset"]), T(g["new_xyz"]), T(g["new_offset"]),
+                                             max_radio=0.5, min_radio=0.0, nsample=16, with_xyz=True)
+    assert np.array_equal(idx.cpu().numpy(), g["bqg_idx"]) and np.array_equal(out.cpu().numpy(), g["bqg_out"])
+
+
+def test_ball_query_rejects_bad_arguments(hip):
+    xyz = cloud(100, 1).to(DEV)
+    off = offs([100]).to(DEV)
+    with pytest.raises(ValueError):
+        hip.ball_query(8, 0.5, 0.5, xyz, xyz, off, off)
+    with pytest.raises(ValueError):
+        hip.ball_query(4096, 0.5, 0.0, xyz, xyz, off, off)
+
+
 # ----------------------------------------------------------------------------------------------- gather family
 @pytest.fixture(scope="module")
 def table(hip, oracle_backend):
@@ -249,7 +317,7 @@ def test_subtraction_fwd_bwd(hip, oracle_backend, table, c):
     assert_close(g2_h.cpu(), g2_o, 1e-5, "sub g2")
 
 
-@pytest.mark.parametrize("c,w_c", [(32, 4), (64, 8), (24, 24)])
+@pytest.mark.parametrize("c,w_c", [(32, 4), (64, 8), (24, 24), (128, 16), (16, 2), (40, 5)])
 def test_aggregation_fwd_bwd(hip, oracle_backend, table, c, w_c):
     xyz, off, idx, _ = table
     n, ns = idx.shape

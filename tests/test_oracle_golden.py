@@ -102,9 +102,35 @@ def test_query_and_group_and_converters(use_oracle, g):
     assert np.array_equal(pointops.batch2offset(T(g["offset2batch"])).numpy(), g["batch2offset"])
 
 
-def test_off_path_queries_raise(use_oracle):
-    with pytest.raises(NotImplementedError):
-        pointops.ball_query(4, 1.0, 0.0, torch.zeros(4, 3), torch.tensor([4]))
+@pytest.fixture(scope="module")
+def gb(golden_dir):
+    return np.load(os.path.join(golden_dir, "ops_ball_ref.npz"))
+
+
+BALL_CASES = {"a": (16, 0.5, 0.0), "b": (8, 0.9, 0.3), "c": (32, 0.25, 0.0)}
+
+
+@pytest.mark.parametrize("tag", sorted(BALL_CASES))
+def test_ball_queries_match_reference_wrappers(use_oracle, gb, tag):
+    """query.py:27-115 run by make_golden.py on the reference's own wrappers (shell test incl. the d2 <= 1e-5 branch on
+    duplicated points, un-heapified heap_sort permutation, -1 / 1e10 padding, the every-(count/nsample)-th pick with the index
+    stored as distance, a 5-point scene)."""
+    ns, rmax, rmin = BALL_CASES[tag]
+    xyz, off, nxyz, noff = T(gb["xyz"]), T(gb["offset"]), T(gb["new_xyz"]), T(gb["new_offset"])
+    i, d = pointops.ball_query(ns, rmax, rmin, xyz, off, nxyz, noff)
+    assert i.dtype == torch.int32 and np.array_equal(i.numpy(), gb[f"bq_{tag}_idx"])
+    assert np.array_equal(d.numpy(), gb[f"bq_{tag}_dist"])
+    i, d = pointops.ball_query(ns, rmax, rmin, xyz, off)
+    assert np.array_equal(i.numpy(), gb[f"bqs_{tag}_idx"]) and np.array_equal(d.numpy(), gb[f"bqs_{tag}_dist"])
+    torch.manual_seed(5)  # the wrapper draws one torch.randperm per scene from the global generator, as upstream
+    i, d = pointops.random_ball_query(ns, rmax, rmin, xyz, off, nxyz, noff)
+    assert np.array_equal(i.numpy(), gb[f"rbq_{tag}_idx"]) and np.array_equal(d.numpy(), gb[f"rbq_{tag}_dist"])
+
+
+def test_ball_query_and_group(use_oracle, gb):
+    out, idx = pointops.ball_query_and_group(T(gb["feat"]), T(gb["xyz"]), T(gb["offset"]), T(gb["new_xyz"]), T(gb["new_offset"]),
+                                             max_radio=0.5, min_radio=0.0, nsample=16, with_xyz=True)
+    assert np.array_equal(idx.numpy(), gb["bqg_idx"]) and np.array_equal(out.numpy(), gb["bqg_out"])
 
 
 def test_public_names_match_reference():
