@@ -22,7 +22,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-a
 EXTRA = {
     "knn_query.hip": ["-ffp-contract=off"],
     "sampling.hip": ["-ffp-contract=off"],
-    "sampling_bucketed.hip": ["-ffp-contract=off"],
+    "sampling_bucketed.hip": ["-ffp-contract=off"] + (["-DFPS_PROFILE"] if os.environ.get("PDFOPS_FPS_PROFILE") else []) + ([f"-DPDF_FPS_MW_UNROLL={os.environ['PDFOPS_FPS_MW_UNROLL']}"] if os.environ.get("PDFOPS_FPS_MW_UNROLL") else []),
     "knn_grid.hip": ["-ffp-contract=off"],
     "ball_query.hip": ["-ffp-contract=off"],
 }

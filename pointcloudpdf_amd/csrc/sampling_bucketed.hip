@@ -31,6 +31,7 @@ constexpr int CELLS = 32768;       // 15-bit Morton cells per scene
 constexpr int REL_BITS = 22;
 constexpr unsigned REL_MASK = (1u << REL_BITS) - 1u;
 constexpr int PB = 256;            // block size of the preparation kernels
+constexpr int MSTRIDE = 16;        // dwords of metadata per bucket (box 6, best key 2, best xyz 3, second-best key 2)
 
 struct Layout {  // byte offsets into the caller's workspace
     size_t stats, bbox, hist, cursor, cell, pts, kb, meta, total;
@@ -51,7 +52,7 @@ __host__ __device__ inline Layout make_layout(int b, int n_total) {
     L.cell = o;   o = align256(o + (size_t)n_total * 4);
     L.pts = o;    o = align256(o + (size_t)L.npad * 16);
     L.kb = o;     o = align256(o + (size_t)L.npad * 4);
-    L.meta = o;   o = align256(o + (size_t)L.nbk * 12 * 4);
+    L.meta = o;   o = align256(o + (size_t)L.nbk * MSTRIDE * 4);
     L.total = o;
     return L;
 }
@@ -220,7 +221,7 @@ __global__ void k_pad(int b, const int *__restrict__ offset, const int *__restri
     }
 }
 
-// one wave per bucket: bounding box, best packed key, coordinates of the best point -> 12 dwords of metadata
+// one wave per bucket: bounding box, best packed key, coordinates of the best point, second-best key -> MSTRIDE dwords
 __global__ __launch_bounds__(64) void k_meta(const float4 *__restrict__ pts, const unsigned *__restrict__ kb, float *__restrict__ meta) {
     const int bk = blockIdx.x;
     const int lane = threadIdx.x;
@@ -241,13 +242,16 @@ __global__ __launch_bounds__(64) void k_meta(const float4 *__restrict__ pts, con
     const unsigned long long mask = __ballot(key == best && valid);
     const int win = mask ? __ffsll((long long)mask) - 1 : 0;
     const float bx = __shfl(p.x, win, 64), by = __shfl(p.y, win, 64), bz = __shfl(p.z, win, 64);
+    const unsigned long long second = pdf_wave_max_u64(lane == win ? 0ull : key);
     if (lane == 0) {
-        float *m = meta + (size_t)bk * 12;
+        float *m = meta + (size_t)bk * MSTRIDE;
+        m[11] = __uint_as_float((unsigned)(second >> 32));
+        m[12] = __uint_as_float((unsigned)second);
         m[0] = lo[0]; m[1] = lo[1]; m[2] = lo[2];
         m[3] = hi[0]; m[4] = hi[1]; m[5] = hi[2];
         m[6] = __uint_as_float((unsigned)(best >> 32));
         m[7] = __uint_as_float((unsigned)best);
-        m[8] = bx; m[9] = by; m[10] = bz; m[11] = 0.f;
+        m[8] = bx; m[9] = by; m[10] = bz;
     }
 }
 
@@ -315,6 +319,9 @@ __device__ __forceinline__ unsigned row_umax_bcast(unsigned v, int row) {
 }
 
 constexpr int FPS_UNROLL = 4;  // bucket loads in flight per wave
+#ifndef PDF_FPS_MW_UNROLL
+#define PDF_FPS_MW_UNROLL 8
+#endif
 
 // NW waves per scene.  Every wave derives the same sample / active-super / active-bucket lists from the shared LDS
 // records (redundantly, no communication); the surviving buckets are dealt round-robin to the waves; two barriers per
@@ -344,7 +351,7 @@ __global__ __launch_bounds__(64 * NW) void k_fps(const int *__restrict__ offset,
 
     // load bucket records, build super records
     for (int i = tid; i < nb; i += 64 * NW) {
-        const float *m = meta + (size_t)(sc.bbase + i) * 12;
+        const float *m = meta + (size_t)(sc.bbase + i) * MSTRIDE;
         B.lox[i] = m[0]; B.loy[i] = m[1]; B.loz[i] = m[2];
         B.hix[i] = m[3]; B.hiy[i] = m[4]; B.hiz[i] = m[5];
         B.khi[i] = __float_as_uint(m[6]); B.klo[i] = __float_as_uint(m[7]);
@@ -480,6 +487,555 @@ __global__ __launch_bounds__(64 * NW) void k_fps(const int *__restrict__ offset,
     }
 }
 
+// ---------------------------------------------------------------- several samples per round (exact)
+// The per-sample chain above is pure latency (arg-max -> lists -> one L2 round trip -> records -> two barriers: ~3.6 us).
+// k_fps_multi emits up to KMAX samples per round of the same chain.  Let c_1 be the arg-max and c_t (t >= 2) the best
+// point outside the super-buckets of c_1..c_{t-1}.  c_t is accepted -- it IS sample j+t-1 of the sequential algorithm -- if
+//   (a) key(c_t) > second-best key (before this round) of every super-bucket that holds an earlier candidate, and
+//   (b) d(c_u, c_t) >= tmp[c_t] for every earlier candidate c_u (as-written fp32 distance).
+// Proof: inserting c_1..c_{t-1} only lowers tmp values.  By (b) tmp[c_t] keeps its value; every other point outside the
+// earlier candidates' supers had a smaller key than c_t already; inside those supers every point other than the candidate
+// itself is bounded by the super's second-best key, which (a) puts below key(c_t); the candidates themselves drop to
+// tmp = 0.  Keys are unique (the low word carries the point's index), so c_t is the unique arg-max after t-1 insertions.
+// Both tests use values from before the round, the accepted prefix is known before any update, and the updates
+// tmp = min(tmp, d(., c_u)) commute -- one pass over the union of the touched buckets applies them all.
+// Records carry the second-best key per bucket and per super-bucket for (a).
+struct Rec2 {
+    float *lox, *loy, *loz, *hix, *hiy, *hiz, *bx, *by, *bz;
+    unsigned *khi, *klo, *k2hi, *k2lo;
+};
+constexpr int REC2 = 13;
+__device__ inline Rec2 carve2(float *base, int n) {
+    Rec2 r;
+    r.lox = base; r.loy = base + n; r.loz = base + 2 * n;
+    r.hix = base + 3 * n; r.hiy = base + 4 * n; r.hiz = base + 5 * n;
+    r.bx = base + 6 * n; r.by = base + 7 * n; r.bz = base + 8 * n;
+    r.khi = reinterpret_cast<unsigned *>(base + 9 * n);
+    r.klo = reinterpret_cast<unsigned *>(base + 10 * n);
+    r.k2hi = reinterpret_cast<unsigned *>(base + 11 * n);
+    r.k2lo = reinterpret_cast<unsigned *>(base + 12 * n);
+    return r;
+}
+__device__ __forceinline__ float box_dist_v(float lox, float loy, float loz, float hix, float hiy, float hiz, float cx, float cy, float cz) {
+    const float gx = fmaxf(fmaxf(lox - cx, cx - hix), 0.f);
+    const float gy = fmaxf(fmaxf(loy - cy, cy - hiy), 0.f);
+    const float gz = fmaxf(fmaxf(loz - cz, cz - hiz), 0.f);
+    return gx * gx + gy * gy + gz * gz;
+}
+__device__ __forceinline__ bool key_gt(unsigned ah, unsigned al, unsigned bh, unsigned bl) { return ah > bh || (ah == bh && al > bl); }
+
+template <int NW, int KMAX>
+__global__ __launch_bounds__(64 * NW) void k_fps_multi(const int *__restrict__ offset, const int *__restrict__ new_offset,
+                                                       float4 *__restrict__ pts, const unsigned *__restrict__ kbs,
+                                                       const float *__restrict__ meta, int *__restrict__ idx, int nb_cap,
+                                                       unsigned *__restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) float fps_lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int row = lane >> 4, col = lane & 15;
+    const Scene sc = scene_of(blockIdx.x, offset, new_offset);
+    if (sc.m <= 0) return;
+    const int nb = sc.nb, ns = (nb + SUP - 1) / SUP;
+    const int ns_cap = (nb_cap + SUP - 1) / SUP;
+    Rec2 B = carve2(fps_lds, nb_cap);
+    Rec2 S = carve2(fps_lds + REC2 * nb_cap, ns_cap);
+    unsigned short *slist_base = reinterpret_cast<unsigned short *>(fps_lds + REC2 * nb_cap + REC2 * ns_cap);
+    const int slist_stride = ((ns_cap + 63) & ~63) + 64;
+    unsigned short *blist = slist_base + 2 * slist_stride;  // [nb_cap]
+    unsigned n_updates = 0, n_supers = 0, n_rounds = 0;
+#ifdef FPS_PROFILE
+    unsigned long long tc[5] = {0, 0, 0, 0, 0}, t_prev = __builtin_readcyclecounter();
+#define FPS_TICK(i_) do { const unsigned long long t_now = __builtin_readcyclecounter(); tc[i_] += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define FPS_TICK(i_) do {} while (0)
+#endif
+
+    for (int i = tid; i < nb; i += 64 * NW) {
+        const float *m = meta + (size_t)(sc.bbase + i) * MSTRIDE;
+        B.lox[i] = m[0]; B.loy[i] = m[1]; B.loz[i] = m[2];
+        B.hix[i] = m[3]; B.hiy[i] = m[4]; B.hiz[i] = m[5];
+        B.khi[i] = __float_as_uint(m[6]); B.klo[i] = __float_as_uint(m[7]);
+        B.bx[i] = m[8]; B.by[i] = m[9]; B.bz[i] = m[10];
+        B.k2hi[i] = __float_as_uint(m[11]); B.k2lo[i] = __float_as_uint(m[12]);
+    }
+    __syncthreads();
+    for (int s = tid; s < ns; s += 64 * NW) {
+        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        unsigned long long best = 0ull, second = 0ull;
+        int bi = s * SUP;
+        for (int i = s * SUP; i < min(nb, s * SUP + SUP); ++i) {
+            lo[0] = fminf(lo[0], B.lox[i]); lo[1] = fminf(lo[1], B.loy[i]); lo[2] = fminf(lo[2], B.loz[i]);
+            hi[0] = fmaxf(hi[0], B.hix[i]); hi[1] = fmaxf(hi[1], B.hiy[i]); hi[2] = fmaxf(hi[2], B.hiz[i]);
+            const unsigned long long k = ((unsigned long long)B.khi[i] << 32) | B.klo[i];
+            const unsigned long long k2 = ((unsigned long long)B.k2hi[i] << 32) | B.k2lo[i];
+            if (k > best) { second = best > k2 ? best : k2; best = k; bi = i; }
+            else if (k > second) second = k;   // (k2 < k <= best: k2 cannot beat k)
+        }
+        S.lox[s] = lo[0]; S.loy[s] = lo[1]; S.loz[s] = lo[2];
+        S.hix[s] = hi[0]; S.hiy[s] = hi[1]; S.hiz[s] = hi[2];
+        S.khi[s] = (unsigned)(best >> 32); S.klo[s] = (unsigned)best;
+        S.k2hi[s] = (unsigned)(second >> 32); S.k2lo[s] = (unsigned)second;
+        S.bx[s] = B.bx[bi]; S.by[s] = B.by[bi]; S.bz[s] = B.bz[bi];
+    }
+    __syncthreads();
+
+    if (tid == 0) idx[sc.start_m] = sc.start_n;
+    int j = 1;
+    FPS_TICK(4);
+    while (j < sc.m) {
+        // ---- 1. candidates (every wave, redundantly): per-lane best over its supers, then up to KMAX wave arg-maxes
+        float cx[KMAX], cy[KMAX], cz[KMAX];
+        int csup[KMAX];
+        unsigned bhi = 0u, blo = 0u;
+        int bs = 0;
+        for (int s = lane; s < ns; s += 64) {
+            const unsigned h = S.khi[s], l = S.klo[s];
+            if (key_gt(h, l, bhi, blo)) { bhi = h; blo = l; bs = s; }
+        }
+        const int kmax = min(KMAX, sc.m - j);
+        int a = 0;
+        unsigned bound_hi = 0u, bound_lo = 0u;   // max second-best key over the accepted candidates' supers
+#pragma unroll
+        for (int t = 0; t < KMAX; ++t) {
+            if (t >= kmax) break;
+            unsigned whi, wlo;
+            const int wl = wave_argmax_key(bhi, blo, whi, wlo);
+            if (t > 0 && !key_gt(whi, wlo, bound_hi, bound_lo)) break;          // (a)  (also stops at key 0: no valid point left)
+            const int wsup = __builtin_amdgcn_readlane(bs, wl);
+            const float x = S.bx[wsup], y = S.by[wsup], z = S.bz[wsup];
+            bool far = true;                                                       // (b)
+#pragma unroll
+            for (int u = 0; u < KMAX; ++u)
+                if (u < t) far = far && !(pdf_f32_ordered(dist_as_written(x, y, z, cx[u], cy[u], cz[u])) < whi);
+            if (!far) break;
+            cx[t] = x; cy[t] = y; cz[t] = z; csup[t] = wsup;
+            a = t + 1;
+            if (tid == 0) idx[sc.start_m + j + t] = sc.start_n + (int)(~wlo & REL_MASK);
+            const unsigned s2h = S.k2hi[wsup], s2l = S.k2lo[wsup];
+            if (key_gt(s2h, s2l, bound_hi, bound_lo)) { bound_hi = s2h; bound_lo = s2l; }
+            if (t + 1 < kmax && lane == wl) {   // the owning lane re-scans its supers without the taken ones
+                bhi = 0u; blo = 0u; bs = 0;
+                for (int s = lane; s < ns; s += 64) {
+                    bool taken = false;
+#pragma unroll
+                    for (int u = 0; u < KMAX; ++u) if (u <= t) taken = taken || s == csup[u];
+                    const unsigned h = S.khi[s], l = S.klo[s];
+                    if (!taken && key_gt(h, l, bhi, blo)) { bhi = h; blo = l; bs = s; }
+                }
+            }
+        }
+        // a >= 1 here (t = 0 always accepts)
+        j += a;
+        ++n_rounds;
+        if (j >= sc.m) break;  // the last sample needs no distance update
+        FPS_TICK(0);
+
+        // ---- 2. active supers (touched by any accepted centre) -> slist
+        unsigned short *slist = slist_base + (n_rounds & 1) * slist_stride;
+        int n_sup = 0;
+        for (int s0 = 0; s0 < ns; s0 += 64) {
+            const int s = s0 + lane;
+            bool act = false;
+            if (s < ns) {
+                const float lx = S.lox[s], ly = S.loy[s], lz = S.loz[s], hx = S.hix[s], hy = S.hiy[s], hz = S.hiz[s];
+                const unsigned kh = S.khi[s];
+#pragma unroll
+                for (int u = 0; u < KMAX; ++u)
+                    if (u < a) act = act || pdf_f32_ordered(box_dist_v(lx, ly, lz, hx, hy, hz, cx[u], cy[u], cz[u])) < kh;
+            }
+            const unsigned long long m = __ballot(act);
+            if (act) slist[n_sup + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)s;
+            n_sup += __popcll(m);
+        }
+        lds_fence();
+        // ---- 3. active buckets of those supers -> blist
+        int n_bk = 0;
+        for (int g = 0; g < n_sup; g += 4) {
+            bool bact = false;
+            int bk = 0;
+            if (g + row < n_sup) {
+                bk = (int)slist[g + row] * SUP + col;
+                if (bk < nb) {
+                    const float lx = B.lox[bk], ly = B.loy[bk], lz = B.loz[bk], hx = B.hix[bk], hy = B.hiy[bk], hz = B.hiz[bk];
+                    const unsigned kh = B.khi[bk];
+#pragma unroll
+                    for (int u = 0; u < KMAX; ++u)
+                        if (u < a) bact = bact || pdf_f32_ordered(box_dist_v(lx, ly, lz, hx, hy, hz, cx[u], cy[u], cz[u])) < kh;
+                }
+            }
+            const unsigned long long m = __ballot(bact);
+            if (bact) blist[n_bk + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)bk;
+            n_bk += __popcll(m);
+        }
+        n_supers += n_sup;
+        n_updates += n_bk;
+        if (NW > 1) __syncthreads(); else lds_fence();  // A
+        FPS_TICK(1);
+
+        // ---- 4. update the surviving buckets with every accepted centre
+        for (int i0 = wave * FPS_UNROLL; i0 < n_bk; i0 += NW * FPS_UNROLL) {
+            float4 p[FPS_UNROLL];
+            unsigned kb[FPS_UNROLL];
+            int bkid[FPS_UNROLL];
+#pragma unroll
+            for (int u = 0; u < FPS_UNROLL; ++u) {
+                bkid[u] = i0 + u < n_bk ? (int)blist[i0 + u] : -1;
+                if (bkid[u] >= 0) {
+                    const size_t pos = (size_t)sc.pbase + (size_t)bkid[u] * BSZ + lane;
+                    p[u] = pts[pos];
+                    kb[u] = kbs[pos];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < FPS_UNROLL; ++u) {
+                if (bkid[u] < 0) break;
+                unsigned khi = 0u;
+                if (p[u].w >= 0.f) {
+                    float w = p[u].w;
+#pragma unroll
+                    for (int v = 0; v < KMAX; ++v)
+                        if (v < a) {
+                            const float d = dist_as_written(p[u].x, p[u].y, p[u].z, cx[v], cy[v], cz[v]);
+                            if (d < w) w = d;
+                        }
+                    if (w < p[u].w) pts[(size_t)sc.pbase + (size_t)bkid[u] * BSZ + lane].w = w;
+                    khi = pdf_f32_ordered(w);
+                }
+                unsigned mhi, mlo;
+                const int kl = wave_argmax_key(khi, kb[u], mhi, mlo);
+                const unsigned h2 = lane == kl ? 0u : khi, l2 = lane == kl ? 0u : kb[u];
+                const unsigned m2hi = wave_umax(h2);
+                const unsigned m2lo = wave_umax(h2 == m2hi ? l2 : 0u);
+                const float nx = lane_bcast(p[u].x, kl), ny = lane_bcast(p[u].y, kl), nz = lane_bcast(p[u].z, kl);
+                if (lane == 0) {
+                    B.khi[bkid[u]] = mhi; B.klo[bkid[u]] = mlo;
+                    B.k2hi[bkid[u]] = m2hi; B.k2lo[bkid[u]] = m2lo;
+                    B.bx[bkid[u]] = nx; B.by[bkid[u]] = ny; B.bz[bkid[u]] = nz;
+                }
+            }
+        }
+        if (NW > 1) __syncthreads(); else lds_fence();  // B
+        FPS_TICK(2);
+
+        // ---- 5. refresh the touched super records (best + second-best; 4 supers per pass, one per 16-lane row)
+        for (int g = 0; g < n_sup; g += 4) {
+            unsigned h16 = 0u, l16 = 0u, h2 = 0u, l2 = 0u;
+            int sup = -1, bk = 0;
+            if (g + row < n_sup) {
+                sup = (int)slist[g + row];
+                bk = sup * SUP + col;
+                if (bk < nb) { h16 = B.khi[bk]; l16 = B.klo[bk]; h2 = B.k2hi[bk]; l2 = B.k2lo[bk]; }
+            }
+            const unsigned mh = row_umax_bcast(h16, row);
+            const unsigned ml = row_umax_bcast(h16 == mh ? l16 : 0u, row);
+            const unsigned long long m = __ballot(sup >= 0 && h16 == mh && l16 == ml);
+            const int wcol = __ffs((unsigned)(m >> (16 * row)) & 0xffffu) - 1;
+            // second-best of the super: the winning bucket contributes its second-best key, the others their best
+            const unsigned sh = col == wcol ? h2 : h16, sl = col == wcol ? l2 : l16;
+            const unsigned m2h = row_umax_bcast(sh, row);
+            const unsigned m2l = row_umax_bcast(sh == m2h ? sl : 0u, row);
+            if (col == 0 && sup >= 0) {
+                const int wb = sup * SUP + wcol;
+                S.khi[sup] = mh; S.klo[sup] = ml;
+                S.k2hi[sup] = m2h; S.k2lo[sup] = m2l;
+                S.bx[sup] = B.bx[wb]; S.by[sup] = B.by[wb]; S.bz[sup] = B.bz[wb];
+            }
+        }
+        lds_fence();
+        FPS_TICK(3);
+    }
+    if (tid == 0 && stats) {
+        stats[blockIdx.x * 4 + 0] = n_updates;
+        stats[blockIdx.x * 4 + 1] = n_supers;
+        stats[blockIdx.x * 4 + 2] = (unsigned)sc.m;
+        stats[blockIdx.x * 4 + 3] = n_rounds;
+#ifdef FPS_PROFILE
+        for (int i = 0; i < 4; ++i) stats[blockIdx.x * 4 + i] = (unsigned)(tc[i] >> 10);   // kilo-cycles: candidates | lists | updates | refresh
+#endif
+    }
+#undef FPS_TICK
+}
+
+// ---------------------------------------------------------------- one centre per wave
+// k_fps_multi still derives every list redundantly in every wave; measured (s_memtime, 100k-point scene, K = 8): candidate
+// selection 11.6k cycles per round, lists 13.7k, updates 24.7k, super refresh 8.8k -- instruction latency of ONE wave,
+// not memory.  k_fps_mw keeps the acceptance rule (same proof) and spreads the rest over NW = KMAX waves:
+//   phase 1  every wave, redundantly: up to NW accepted centres (registers).
+//   phase 2  wave u owns centre u: its active supers (private list), then the active buckets of those supers.  A bucket or
+//            super touched by several centres is CLAIMED once (ds exchange of the round tag) and appended to the shared
+//            lists through a wave-aggregated LDS counter.
+//   barrier A
+//   phase 3  the shared bucket list is dealt round-robin to the waves; a bucket gets the centres whose bit is set in its
+//            claim word (the owner clears the word).
+//   barrier B
+//   phase 4  the shared super list is dealt to the waves (4 supers per pass); barrier C.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_fps_mw(const int *__restrict__ offset, const int *__restrict__ new_offset,
+                                                    float4 *__restrict__ pts, const unsigned *__restrict__ kbs,
+                                                    const float *__restrict__ meta, int *__restrict__ idx, int nb_cap,
+                                                    unsigned *__restrict__ stats) {
+    constexpr int KMAX = NW;
+    constexpr int UNR = PDF_FPS_MW_UNROLL;   // bucket loads in flight per wave
+    constexpr int NSL = (NS_MAX + 63) / 64;   // supers per lane
+    extern __shared__ __attribute__((aligned(16))) float fps_lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int row = lane >> 4, col = lane & 15;
+    const Scene sc = scene_of(blockIdx.x, offset, new_offset);
+    if (sc.m <= 0) return;
+    const int nb = sc.nb, ns = (nb + SUP - 1) / SUP;
+    const int ns_cap = (nb_cap + SUP - 1) / SUP;
+    Rec2 B = carve2(fps_lds, nb_cap);
+    Rec2 S = carve2(fps_lds + REC2 * nb_cap, ns_cap);
+    unsigned *claimB = reinterpret_cast<unsigned *>(fps_lds + REC2 * nb_cap + REC2 * ns_cap);   // [nb_cap] round tag of the claim
+    unsigned *claimS = claimB + nb_cap;                                                          // [ns_cap]
+    unsigned *cnt = claimS + ns_cap;                                                             // [4]: n_bk[2], n_sup[2] by round parity
+    float *cent = reinterpret_cast<float *>(cnt + 4);                                            // [3 * KMAX] the round's centres
+    int *cent_n = reinterpret_cast<int *>(cent + 3 * KMAX);                                      // [4]
+    unsigned short *blist = reinterpret_cast<unsigned short *>(cent_n + 4);                      // [nb_cap + 64] shared
+    unsigned short *slist = blist + nb_cap + 64;                                                 // [ns_cap + 64] shared
+    const int psl_stride = ((ns_cap + 63) & ~63) + 64;
+    unsigned short *pslist = slist + ns_cap + 64 + wave * psl_stride;                            // private per wave
+    unsigned n_updates = 0, n_supers = 0, n_rounds = 0;
+#ifdef FPS_PROFILE
+    unsigned long long tc[5] = {0, 0, 0, 0, 0}, t_prev = __builtin_readcyclecounter();
+#define FPS_TICK(i_) do { const unsigned long long t_now = __builtin_readcyclecounter(); tc[i_] += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define FPS_TICK(i_) do {} while (0)
+#endif
+
+    for (int i = tid; i < nb; i += 64 * NW) {
+        const float *m = meta + (size_t)(sc.bbase + i) * MSTRIDE;
+        B.lox[i] = m[0]; B.loy[i] = m[1]; B.loz[i] = m[2];
+        B.hix[i] = m[3]; B.hiy[i] = m[4]; B.hiz[i] = m[5];
+        B.khi[i] = __float_as_uint(m[6]); B.klo[i] = __float_as_uint(m[7]);
+        B.bx[i] = m[8]; B.by[i] = m[9]; B.bz[i] = m[10];
+        B.k2hi[i] = __float_as_uint(m[11]); B.k2lo[i] = __float_as_uint(m[12]);
+        claimB[i] = 0u;
+    }
+    if (tid < 4) cnt[tid] = 0u;
+    __syncthreads();
+    for (int s = tid; s < ns; s += 64 * NW) {
+        float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        unsigned long long best = 0ull, second = 0ull;
+        int bi = s * SUP;
+        for (int i = s * SUP; i < min(nb, s * SUP + SUP); ++i) {
+            lo[0] = fminf(lo[0], B.lox[i]); lo[1] = fminf(lo[1], B.loy[i]); lo[2] = fminf(lo[2], B.loz[i]);
+            hi[0] = fmaxf(hi[0], B.hix[i]); hi[1] = fmaxf(hi[1], B.hiy[i]); hi[2] = fmaxf(hi[2], B.hiz[i]);
+            const unsigned long long k = ((unsigned long long)B.khi[i] << 32) | B.klo[i];
+            const unsigned long long k2 = ((unsigned long long)B.k2hi[i] << 32) | B.k2lo[i];
+            if (k > best) { second = best > k2 ? best : k2; best = k; bi = i; }
+            else if (k > second) second = k;
+        }
+        S.lox[s] = lo[0]; S.loy[s] = lo[1]; S.loz[s] = lo[2];
+        S.hix[s] = hi[0]; S.hiy[s] = hi[1]; S.hiz[s] = hi[2];
+        S.khi[s] = (unsigned)(best >> 32); S.klo[s] = (unsigned)best;
+        S.k2hi[s] = (unsigned)(second >> 32); S.k2lo[s] = (unsigned)second;
+        S.bx[s] = B.bx[bi]; S.by[s] = B.by[bi]; S.bz[s] = B.bz[bi];
+        claimS[s] = 0u;
+    }
+    __syncthreads();
+
+    if (tid == 0) idx[sc.start_m] = sc.start_n;
+    int j = 1;
+    FPS_TICK(4);
+    while (j < sc.m) {
+        // ---- 1. candidates: WAVE 0 ONLY (the other waves sleep at barrier D instead of competing for the SIMDs' issue
+        // slots with redundant copies) -- acceptance rule of k_fps_multi.  Each lane keeps the records of ITS supers
+        // (s = lane + 64 i) in registers for the round; lane u holds accepted centre u, so test (b) is one distance per lane.
+        if (wave == 0) {
+            unsigned skh[NSL], skl[NSL], sk2h[NSL], sk2l[NSL];
+            float sbx[NSL], sby[NSL], sbz[NSL];
+#pragma unroll
+            for (int i = 0; i < NSL; ++i) {
+                const int s = lane + 64 * i;
+                const bool ok = s < ns;
+                skh[i] = ok ? S.khi[s] : 0u; skl[i] = ok ? S.klo[s] : 0u;
+                sk2h[i] = ok ? S.k2hi[s] : 0u; sk2l[i] = ok ? S.k2lo[s] : 0u;
+                sbx[i] = ok ? S.bx[s] : 0.f; sby[i] = ok ? S.by[s] : 0.f; sbz[i] = ok ? S.bz[s] : 0.f;
+            }
+            const int kmax = min(KMAX, sc.m - j);
+            int acc = 0, my_idx = 0;
+            float mcx = 0.f, mcy = 0.f, mcz = 0.f;   // lane u: centre u
+            unsigned bound_hi = 0u, bound_lo = 0u;
+            for (int t = 0; t < kmax; ++t) {
+                unsigned bhi = skh[0], blo = skl[0], b2h = sk2h[0], b2l = sk2l[0];
+                float bx = sbx[0], by = sby[0], bz = sbz[0];
+                int bi = 0;
+#pragma unroll
+                for (int i = 1; i < NSL; ++i)
+                    if (key_gt(skh[i], skl[i], bhi, blo)) { bhi = skh[i]; blo = skl[i]; b2h = sk2h[i]; b2l = sk2l[i]; bx = sbx[i]; by = sby[i]; bz = sbz[i]; bi = i; }
+                unsigned whi, wlo;
+                const int wl = wave_argmax_key(bhi, blo, whi, wlo);
+                if (t > 0 && !key_gt(whi, wlo, bound_hi, bound_lo)) break;          // (a)  (also stops at key 0: nothing left)
+                const float x = lane_bcast(bx, wl), y = lane_bcast(by, wl), z = lane_bcast(bz, wl);
+                const bool near = lane < t && pdf_f32_ordered(dist_as_written(x, y, z, mcx, mcy, mcz)) < whi;   // (b)
+                if (__ballot(near) != 0ull) break;
+                const unsigned s2h = (unsigned)__builtin_amdgcn_readlane((int)b2h, wl), s2l = (unsigned)__builtin_amdgcn_readlane((int)b2l, wl);
+                if (lane == t) { mcx = x; mcy = y; mcz = z; my_idx = sc.start_n + (int)(~wlo & REL_MASK); }
+                acc = t + 1;
+                if (key_gt(s2h, s2l, bound_hi, bound_lo)) { bound_hi = s2h; bound_lo = s2l; }
+                if (lane == wl) {   // retire the taken super from this lane's slots
+#pragma unroll
+                    for (int i = 0; i < NSL; ++i) if (i == bi) { skh[i] = 0u; skl[i] = 0u; }
+                }
+            }
+            if (lane < acc) {
+                idx[sc.start_m + j + lane] = my_idx;
+                cent[3 * lane + 0] = mcx; cent[3 * lane + 1] = mcy; cent[3 * lane + 2] = mcz;
+            }
+            if (lane == 0) cent_n[0] = acc;
+        }
+        __syncthreads();  // D: the round's centres are published
+        const int a = cent_n[0];
+        float cx[KMAX], cy[KMAX], cz[KMAX];
+#pragma unroll
+        for (int u = 0; u < KMAX; ++u) { cx[u] = cent[3 * u + 0]; cy[u] = cent[3 * u + 1]; cz[u] = cent[3 * u + 2]; }
+        j += a;
+        ++n_rounds;
+        if (j >= sc.m) break;
+        FPS_TICK(0);
+        const unsigned tag = n_rounds;          // > 0, unique per round
+        const int q = (int)(n_rounds & 1u);
+
+        // ---- 2. wave u owns centre u: active supers (private list), active buckets; claims feed the shared lists
+        if (wave < a) {
+            float mx = cx[0], my = cy[0], mz = cz[0];
+#pragma unroll
+            for (int u = 1; u < KMAX; ++u) if (u == wave) { mx = cx[u]; my = cy[u]; mz = cz[u]; }
+            int n_my = 0;
+            for (int s0 = 0; s0 < ns; s0 += 64) {
+                const int s = s0 + lane;
+                bool act = false;
+                if (s < ns) act = pdf_f32_ordered(box_dist_v(S.lox[s], S.loy[s], S.loz[s], S.hix[s], S.hiy[s], S.hiz[s], mx, my, mz)) < S.khi[s];
+                const unsigned long long m = __ballot(act);
+                if (act) pslist[n_my + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)s;
+                n_my += __popcll(m);
+                bool fresh = false;
+                if (act) fresh = atomicExch(&claimS[s], tag) != tag;
+                const unsigned long long mf = __ballot(fresh);
+                if (mf) {
+                    unsigned base = 0u;
+                    if (lane == 0) base = atomicAdd(&cnt[2 + q], (unsigned)__popcll(mf));
+                    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                    if (fresh) slist[base + __popcll(mf & ((1ull << lane) - 1ull))] = (unsigned short)s;
+                }
+            }
+            lds_fence();
+            for (int g = 0; g < n_my; g += 4) {
+                bool bact = false;
+                int bk = 0;
+                if (g + row < n_my) {
+                    bk = (int)pslist[g + row] * SUP + col;
+                    if (bk < nb)
+                        bact = pdf_f32_ordered(box_dist_v(B.lox[bk], B.loy[bk], B.loz[bk], B.hix[bk], B.hiy[bk], B.hiz[bk], mx, my, mz)) < B.khi[bk];
+                }
+                bool fresh = false;   // claimB[bk] = mask of the centres that reach the bucket; the first one lists it
+                if (bact) fresh = atomicOr(&claimB[bk], 1u << wave) == 0u;
+                const unsigned long long mf = __ballot(fresh);
+                if (mf) {
+                    unsigned base = 0u;
+                    if (lane == 0) base = atomicAdd(&cnt[q], (unsigned)__popcll(mf));
+                    base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                    if (fresh) blist[base + __popcll(mf & ((1ull << lane) - 1ull))] = (unsigned short)bk;
+                }
+            }
+        }
+        __syncthreads();  // A: shared lists complete
+        FPS_TICK(1);
+        const int n_bk = (int)cnt[q], n_sup = (int)cnt[2 + q];
+        if (tid == 0) { cnt[q ^ 1] = 0u; cnt[2 + (q ^ 1)] = 0u; }   // next round's counters (nobody touches them before barrier C)
+        n_supers += n_sup;
+        n_updates += n_bk;
+
+        // ---- 3. update the claimed buckets with every accepted centre
+        for (int i0 = wave * UNR; i0 < n_bk; i0 += NW * UNR) {
+            float4 p[UNR];
+            unsigned kb[UNR];
+            int bkid[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                bkid[u] = i0 + u < n_bk ? (int)blist[i0 + u] : -1;
+                if (bkid[u] >= 0) {
+                    const size_t pos = (size_t)sc.pbase + (size_t)bkid[u] * BSZ + lane;
+                    p[u] = pts[pos];
+                    kb[u] = kbs[pos];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {   // (no early exit: the UNR reduction chains are independent and interleave)
+                const bool live = bkid[u] >= 0;
+                const unsigned msk = live ? (unsigned)__builtin_amdgcn_readfirstlane((int)claimB[bkid[u]]) : 0u;   // centres that reach it
+                unsigned khi = 0u;
+                if (live && p[u].w >= 0.f) {
+                    float w = p[u].w;
+#pragma unroll
+                    for (int v = 0; v < KMAX; ++v)
+                        if ((msk >> v) & 1u) {
+                            const float d = dist_as_written(p[u].x, p[u].y, p[u].z, cx[v], cy[v], cz[v]);
+                            if (d < w) w = d;
+                        }
+                    if (w < p[u].w) pts[(size_t)sc.pbase + (size_t)bkid[u] * BSZ + lane].w = w;
+                    khi = pdf_f32_ordered(w);
+                }
+                const unsigned klo = live ? kb[u] : 0u;
+                unsigned mhi, mlo;
+                const int kl = wave_argmax_key(khi, klo, mhi, mlo);
+                const unsigned h2 = lane == kl ? 0u : khi, l2 = lane == kl ? 0u : klo;
+                const unsigned m2hi = wave_umax(h2);
+                const unsigned m2lo = wave_umax(h2 == m2hi ? l2 : 0u);
+                const float nx = lane_bcast(live ? p[u].x : 0.f, kl & 63), ny = lane_bcast(live ? p[u].y : 0.f, kl & 63), nz = lane_bcast(live ? p[u].z : 0.f, kl & 63);
+                if (lane == 0 && live) {
+                    claimB[bkid[u]] = 0u;
+                    B.khi[bkid[u]] = mhi; B.klo[bkid[u]] = mlo;
+                    B.k2hi[bkid[u]] = m2hi; B.k2lo[bkid[u]] = m2lo;
+                    B.bx[bkid[u]] = nx; B.by[bkid[u]] = ny; B.bz[bkid[u]] = nz;
+                }
+            }
+        }
+        __syncthreads();  // B: bucket records + tmp stores visible
+        FPS_TICK(2);
+
+        // ---- 4. refresh the claimed supers (dealt to the waves, 4 supers per pass)
+        for (int g = 4 * wave; g < n_sup; g += 4 * NW) {
+            unsigned h16 = 0u, l16 = 0u, h2 = 0u, l2 = 0u;
+            int sup = -1, bk = 0;
+            if (g + row < n_sup) {
+                sup = (int)slist[g + row];
+                bk = sup * SUP + col;
+                if (bk < nb) { h16 = B.khi[bk]; l16 = B.klo[bk]; h2 = B.k2hi[bk]; l2 = B.k2lo[bk]; }
+            }
+            const unsigned mh = row_umax_bcast(h16, row);
+            const unsigned ml = row_umax_bcast(h16 == mh ? l16 : 0u, row);
+            const unsigned long long m = __ballot(sup >= 0 && h16 == mh && l16 == ml);
+            const int wcol = __ffs((unsigned)(m >> (16 * row)) & 0xffffu) - 1;
+            const unsigned sh = col == wcol ? h2 : h16, sl = col == wcol ? l2 : l16;
+            const unsigned m2h = row_umax_bcast(sh, row);
+            const unsigned m2l = row_umax_bcast(sh == m2h ? sl : 0u, row);
+            if (col == 0 && sup >= 0) {
+                const int wb = sup * SUP + wcol;
+                S.khi[sup] = mh; S.klo[sup] = ml;
+                S.k2hi[sup] = m2h; S.k2lo[sup] = m2l;
+                S.bx[sup] = B.bx[wb]; S.by[sup] = B.by[wb]; S.bz[sup] = B.bz[wb];
+            }
+        }
+        __syncthreads();  // C: super records complete before the next round's candidates
+        FPS_TICK(3);
+    }
+    if (tid == 0 && stats) {
+        stats[blockIdx.x * 4 + 0] = n_updates;
+        stats[blockIdx.x * 4 + 1] = n_supers;
+        stats[blockIdx.x * 4 + 2] = (unsigned)sc.m;
+        stats[blockIdx.x * 4 + 3] = n_rounds;
+#ifdef FPS_PROFILE
+        for (int i = 0; i < 4; ++i) stats[blockIdx.x * 4 + i] = (unsigned)(tc[i] >> 10);   // kilo-cycles: candidates | lists | updates | refresh
+#endif
+    }
+#undef FPS_TICK
+}
+
 }  // namespace
 
 extern "C" long pdf_fps_workspace_bytes(int b, int n_total) {
@@ -529,6 +1085,36 @@ extern "C" int pdf_farthest_point_sampling_bucketed(int b, int n, int n_total, c
     const char *env_nw = getenv("PDFOPS_FPS_NW");  // tuning knob (waves per scene): 1, 2 or 4
     const int nw = env_nw ? atoi(env_nw) : 4;
     unsigned *stats = reinterpret_cast<unsigned *>(ws + L.stats);
+    // several samples per round (k_fps_multi) when its larger records fit the 160 KB of LDS (scenes up to ~180k points)
+    const size_t lds2 = (size_t)(REC2 * nb_cap + REC2 * ns_cap) * 4 + (size_t)(2 * (((ns_cap + 63) & ~63) + 64) + nb_cap + 64) * 2;
+    const char *env_k = getenv("PDFOPS_FPS_K");    // tuning knob (samples per round): 1 = the one-sample kernel, 4 or 8
+    const int kmulti = env_k ? atoi(env_k) : 8;
+    // one centre per wave (k_fps_mw<8>): records + claim tags + shared / private lists
+    const size_t lds3 = (size_t)(REC2 * nb_cap + REC2 * ns_cap + nb_cap + ns_cap + 4 + 3 * 8 + 4) * 4 +
+                        (size_t)(nb_cap + 64 + ns_cap + 64 + 8 * (((ns_cap + 63) & ~63) + 64)) * 2;
+    const char *env_mw = getenv("PDFOPS_FPS_MW");   // tuning knob: 0 = k_fps_multi
+    if (kmulti > 1 && (!env_mw || atoi(env_mw) != 0) && lds3 <= 160 * 1024) {
+        if (lds3 > 64 * 1024) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fps_mw<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+            if (e != hipSuccess) return (int)e;
+        }
+        k_fps_mw<8><<<b, 64 * 8, lds3, s>>>(offset, new_offset, pts, kb, meta, idx, nb_cap, stats);
+        return pdf_launch_status();
+    }
+    if (kmulti > 1 && lds2 <= 160 * 1024) {
+#define PDF_LAUNCH_FPS_MULTI(NW_, K_)                                                                                    \
+    do {                                                                                                                 \
+        if (lds2 > 64 * 1024) {                                                                                          \
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fps_multi<NW_, K_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
+            if (e != hipSuccess) return (int)e;                                                                          \
+        }                                                                                                                \
+        k_fps_multi<NW_, K_><<<b, 64 * NW_, lds2, s>>>(offset, new_offset, pts, kb, meta, idx, nb_cap, stats);            \
+    } while (0)
+        if (kmulti <= 4) { if (nw == 8) PDF_LAUNCH_FPS_MULTI(8, 4); else PDF_LAUNCH_FPS_MULTI(4, 4); }
+        else { if (nw == 8) PDF_LAUNCH_FPS_MULTI(8, 8); else PDF_LAUNCH_FPS_MULTI(4, 8); }
+#undef PDF_LAUNCH_FPS_MULTI
+        return pdf_launch_status();
+    }
 #define PDF_LAUNCH_FPS(NW_)                                                                                              \
     do {                                                                                                                 \
         if (lds > 64 * 1024) {                                                                                           \
