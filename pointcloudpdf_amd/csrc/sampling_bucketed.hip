@@ -320,7 +320,7 @@ __device__ __forceinline__ unsigned row_umax_bcast(unsigned v, int row) {
 
 constexpr int FPS_UNROLL = 4;  // bucket loads in flight per wave
 #ifndef PDF_FPS_MW_UNROLL
-#define PDF_FPS_MW_UNROLL 8
+#define PDF_FPS_MW_UNROLL 4
 #endif
 
 // NW waves per scene.  Every wave derives the same sample / active-super / active-bucket lists from the shared LDS
