@@ -30,10 +30,10 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-# HBM traffic per launch from rocprofv3 PMC passes (profiles/r01_e_pmc_{fetch,write}_size.txt: one launch = the 12 scenes of a
-# 6-batch group; FETCH_SIZE doubled as the guide prescribes for gfx950, KB -> bytes, averaged over the launches of the profiled
-# run like `achieved`).  FPS: 11,068 KB fetch (x2) + 46,864 KB write -- the tmp-distance stores of the touched buckets.
-PMC_TRAFFIC_BYTES = {"farthest_point_sampling": (2 * 11068.0 + 46863.9) * 1024}
+# HBM traffic per launch from rocprofv3 PMC passes (profiles/r01_g_pmc_{fetch,write}_size.txt: one launch = the 24 scenes of a
+# 12-batch group; FETCH_SIZE doubled as the guide prescribes for gfx950, KB -> bytes, averaged over the launches of the profiled
+# run like `achieved`).  FPS (k_fps_mw): 10,418 KB fetch (x2) + 48,576 KB write -- the tmp-distance stores of the touched buckets.
+PMC_TRAFFIC_BYTES = {"farthest_point_sampling": (2 * 10417.7 + 48575.9) * 1024}
 
 
 def parse():
@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--scenes", type=int, default=2, help="scenes per GPU (batch size per rank)")
     ap.add_argument("--pool", type=int, default=3, help="distinct batches per rank to rotate through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ops-roofline", action="store_true", help="skip the per-op HBM roofline micro-benchmark (rank 0, N = 1)")
     ap.add_argument("--cpu-points", type=int, default=100000, help="scene size of the bounded CPU-baseline sample")
     ap.add_argument("--amp", action="store_true", help="fp16 autocast around the step (reference enable_amp=True)")
     ap.add_argument("--prefetch", type=int, default=16,
@@ -349,6 +350,13 @@ def main():
             "roofline": roof,
             "roofline_gather_family": roof2,
         }
+        if world == 1 and not args.no_ops_roofline:
+            # the pointops drop-in ops on their own (level-1 shapes of this config: 200k points, c = 32, k = 8), HIP-event timed on
+            # the launching stream, against the 8 TB/s HBM peak with the SURVEY 8(d) byte counts (tools/ops_roofline.py)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import ops_roofline
+            line["roofline_ops"] = [dict(op=r["op"], us=round(r["us"], 1), GBps=round(r["GBps"], 1), frac=round(r["frac"], 4))
+                                    for r in ops_roofline.run(iters=10, level2=False, references=False)]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_points)
         print(json.dumps(line), flush=True)

@@ -286,8 +286,13 @@ static inline FastDiv mk_fastdiv(unsigned d) {
 __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv f) { return (__umulhi(n, f.m) + n) >> f.s; }
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+#ifndef PDF_GATHER_PLAIN_STORES   // measured: streamed stores 57.1 us vs plain 59.2 us (grouping2 fwd, 200k x 8 x 32)
 __device__ __forceinline__ void st_stream(v4f *p, v4f v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ void st_stream(float *p, float v) { __builtin_nontemporal_store(v, p); }
+#else
+__device__ __forceinline__ void st_stream(v4f *p, v4f v) { *p = v; }
+__device__ __forceinline__ void st_stream(float *p, float v) { *p = v; }
+#endif
 
 // grouping_cuda_kernel.cu:5-14, float4 per lane
 template <int U>

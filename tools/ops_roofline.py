@@ -33,6 +33,16 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--only", default="")
     a = ap.parse_args()
+    rows = run(a.iters, a.only, verbose=True)
+    if a.json:
+        os.makedirs(os.path.dirname(a.json) or ".", exist_ok=True)
+        json.dump(dict(peak_GBps=PEAK, iters=a.iters, rows=rows), open(a.json, "w"), indent=1)
+
+
+def run(iters=20, only="", verbose=False, level2=True, references=True):
+    """-> list of dicts (op, us, algorithmic_MB, GBps, frac).  Used by bench.py for its "roofline_ops" entry."""
+    class A: pass
+    a = A(); a.iters, a.only = iters, only
     be = _native.hip_backend()
     dev = "cuda"
     b = synthetic.make_batch([100000, 100000], first_scene_id=3, device=dev)
@@ -50,7 +60,8 @@ def main():
         s = timeit(fn, a.iters)
         gbs = nbytes / s / 1e9
         rows.append(dict(op=name, us=s * 1e6, algorithmic_MB=nbytes / 1e6, GBps=gbs, frac=gbs / PEAK))
-        print(f"{name:58s} {s * 1e6:9.1f} us  {nbytes / 1e6:8.1f} MB  {gbs:8.1f} GB/s  {100 * gbs / PEAK:5.1f} % of HBM peak", flush=True)
+        if verbose:
+            print(f"{name:58s} {s * 1e6:9.1f} us  {nbytes / 1e6:8.1f} MB  {gbs:8.1f} GB/s  {100 * gbs / PEAK:5.1f} % of HBM peak", flush=True)
 
     # ---- kNN (12N + 12M + 8B + 8Mk)
     def knn_bytes(n, m, k):
@@ -66,7 +77,7 @@ def main():
     idx3, d3 = be.knn_query(3, L2.p, L1.p, L2.o, L1.o)
     w3 = be.interpolation_weights(d3)
 
-    for (tag, L, idx, c, k) in (("L1 c=32 k=8", L1, idx1, 32, 8), ("L2 c=64 k=16", L2, idx2, 64, 16)):
+    for (tag, L, idx, c, k) in (("L1 c=32 k=8", L1, idx1, 32, 8), ("L2 c=64 k=16", L2, idx2, 64, 16))[:2 if level2 else 1]:
         n = L.p.shape[0]
         feat = torch.randn(n, c, device=dev, generator=g)
         # grouping fwd: 4Nc + 4Mk + 4Mkc  (+ 12N + 12M + 12Mk with xyz)
@@ -99,14 +110,13 @@ def main():
         gf = torch.randn(n1, c, device=dev, generator=g)
         add(f"interpolation2 bwd L2->L1 c={c} k=3", ib, lambda: be.interpolation_backward(gf, idx3, w3, n2))
 
-    # ---- reference point: device copy of 256 MB (read + write)
-    src = torch.empty(64 * 1024 * 1024, device=dev); dst = torch.empty_like(src)
-    add("copy 256 MB (d2d, read+write = 512 MB)", 2 * src.numel() * 4, lambda: dst.copy_(src))
-    add("fill 256 MB (write only)", src.numel() * 4, lambda: dst.zero_())
-    add("sum 256 MB (read only)", src.numel() * 4, lambda: src.sum())
-    if a.json:
-        os.makedirs(os.path.dirname(a.json) or ".", exist_ok=True)
-        json.dump(dict(peak_GBps=PEAK, iters=a.iters, rows=rows), open(a.json, "w"), indent=1)
+    # ---- reference points: device copy / fill / read of 256 MB
+    if references:
+        src = torch.empty(64 * 1024 * 1024, device=dev); dst = torch.empty_like(src)
+        add("copy 256 MB (d2d, read+write = 512 MB)", 2 * src.numel() * 4, lambda: dst.copy_(src))
+        add("fill 256 MB (write only)", src.numel() * 4, lambda: dst.zero_())
+        add("sum 256 MB (read only)", src.numel() * 4, lambda: src.sum())
+    return rows
 
 
 if __name__ == "__main__":
