@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--prefetch", type=int, default=16,
                     help="geometry pre-pass group: the pre-pass of the NEXT `prefetch` batches runs as one launch sequence on a side "
                          "stream while the current group trains (0 = inline, serial)")
+    ap.add_argument("--ddp", choices=["flat", "torch"], default="flat",
+                    help="gradient exchange for N > 1: one flat-buffer all-reduce after the backward (engine.FlatGradAllReduce) or "
+                         "torch DistributedDataParallel (per-parameter bucket copies: +3 ms per step, measured)")
     ap.add_argument("--graph", type=int, default=0, help="replay fwd+bwd+SGD as one captured hipGraph (needs --prefetch > 0)")
     return ap.parse_args()
 
@@ -157,6 +160,12 @@ def main():
     args = parse()
     from pointcloudpdf_amd import _native, engine, synthetic
 
+    # Native libraries print through C stdio on stdout (RCCL's version banner at communicator creation); block-buffered, that
+    # text would land AFTER the JSON line when the process exits.  File descriptor 1 points at stderr until the line is printed.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank, local_rank, world = engine.init_distributed()
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (the HIP path has no CPU fallback)"
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -168,7 +177,10 @@ def main():
     step = engine.OpenSegStep().to(dev)
     synthetic.fill_parameters_deterministic(step, seed=1)  # identical "random-init" weights on every rank
     step.train()
-    module = engine.wrap_ddp(step, dev) if (world > 1 or os.environ.get("PDFOPS_FORCE_DDP")) else step   # (knob: DDP hooks at world size 1)
+    force_dp = bool(os.environ.get("PDFOPS_FORCE_DDP"))   # knob: exercise the N > 1 gradient exchange at world size 1
+    use_dp = world > 1 or force_dp
+    module = engine.wrap_ddp(step, dev) if (use_dp and args.ddp == "torch") else step
+    grad_sync = engine.FlatGradAllReduce(step) if (use_dp and args.ddp == "flat") else None
     opt = torch.optim.SGD(step.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4, fused=True)
 
     sizes = [args.points] * args.scenes
@@ -229,6 +241,8 @@ def main():
         with torch.autocast("cuda", dtype=torch.float16, enabled=args.amp):
             out = module(data)
         out["loss"].backward()
+        if grad_sync is not None:
+            grad_sync.sync(force=force_dp)   # ONE all-reduce (RCCL) over the flat gradient buffer
         opt.step()
         return out
 
@@ -242,7 +256,7 @@ def main():
     # and is host-bound in eager mode; scene sizes are fixed, so the launch sequence is static.  Inputs and the
     # geometry tables live in static buffers that are refreshed (device-to-device copies) before every replay; the
     # geometry pre-pass itself keeps running eagerly on the side streams.
-    use_graph = bool(args.graph) and prefetcher is not None and world == 1  # (DDP + capture: not attempted)
+    use_graph = bool(args.graph) and prefetcher is not None and world == 1 and not use_dp  # (collectives + capture: not attempted)
     graph = None
     if use_graph:
         from pointcloudpdf_amd.geometry import Geometry
@@ -340,7 +354,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"S3DIS-shaped synthetic voxelised scenes, {args.scenes} x {args.points} points per GPU, "
                                    "PointTransformer-Seg50 + PointPdf-v1m1 U-decoder, fwd+bwd+SGD, geometry recomputed every step",
-                       "scenes_per_gpu": args.scenes, "points_per_scene": args.points, "parallelism": f"dp{world}"},
+                       "scenes_per_gpu": args.scenes, "points_per_scene": args.points, "parallelism": f"dp{world}",
+                       "gradient_exchange": (args.ddp if use_dp else "none")},
             "per_gpu_points_per_s": pts_per_step * args.steps / dt / world,
             "loss": loss,
             "geometry_prefetch_group": D,
@@ -359,9 +374,15 @@ def main():
                                     for r in ops_roofline.run(iters=10, level2=False, references=False)]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_points)
-        print(json.dumps(line), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+    import ctypes
+    ctypes.CDLL(None).fflush(None)   # drain C stdio into stderr, then give stdout back for the ONE JSON line
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

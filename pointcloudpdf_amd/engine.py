@@ -71,6 +71,52 @@ def wrap_ddp(module, device):
     return DDP(module, broadcast_buffers=False, bucket_cap_mb=64, gradient_as_bucket_view=True)
 
 
+class FlatGradAllReduce:
+    """The data-parallel gradient exchange as ONE all-reduce over ONE flat fp32 buffer (7,767,729 + 792,513 parameters =
+    34.3 MB), fired after the backward pass: gradients are packed with a multi-tensor copy, summed over the ranks (RCCL ring
+    over xGMI: ~0.5 ms at 8 GPUs), scaled by 1/world and unpacked with a second multi-tensor copy -- about ten launches per
+    step.  torch's DistributedDataParallel gives the same result (``wrap_ddp``; upstream wraps its models in it,
+    engines/defaults.py:22-43) but its reducer copies every one of the 609 per-parameter gradients into the bucket with its
+    own kernel: +3 ms on a 22 ms step, measured at world size 1.  Parameters are broadcast from rank 0 at construction, buffers
+    (BatchNorm statistics) stay per rank as upstream (``broadcast_buffers=False``, engines/train.py:220)."""
+
+    def __init__(self, module, broadcast_parameters=True):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        if broadcast_parameters and self.world > 1:
+            with torch.no_grad():
+                torch._foreach_copy_(self.views, [p.data for p in self.params])
+                dist.broadcast(self.flat, 0)
+                torch._foreach_copy_([p.data for p in self.params], self.views)
+
+    @torch.no_grad()
+    def sync(self, force=False):
+        """Call between ``loss.backward()`` and ``optimizer.step()``: every ``p.grad`` becomes the mean over the ranks.
+        ``force`` runs the pack / all-reduce / unpack sequence at world size 1 too (overhead measurements)."""
+        if self.world == 1 and not (force and self.dist.is_initialized()):
+            return
+        have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None]
+        if len(have) != len(self.params):
+            self.flat.zero_()   # a parameter without a local gradient contributes zeros
+        torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        self.dist.all_reduce(self.flat)
+        self.flat.mul_(1.0 / self.world)
+        for v, p in zip(self.views, self.params):
+            if p.grad is None:
+                p.grad = v.clone()
+        torch._foreach_copy_([g for _, g in have], [v for v, _ in have])
+
+
 def shard_scene_ids(num_scenes, rank, world_size):
     """Whole scenes are the sharding unit (engines/defaults.py:139 + DistributedSampler, engines/train.py:437-438)."""
     return list(range(rank, num_scenes, world_size))

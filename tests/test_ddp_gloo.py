@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, sizes_per_rank, out_dir):
+def _worker(rank, world, port, sizes_per_rank, out_dir, mode="ddp"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     torch.set_num_threads(2)
@@ -33,13 +33,23 @@ def _worker(rank, world, port, sizes_per_rank, out_dir):
     step = engine.OpenSegStep(backbone="PointTransformer-Seg26")
     synthetic.fill_parameters_deterministic(step, seed=1)
     step.train()
-    ddp = engine.wrap_ddp(step, torch.device("cpu"))
+    if mode == "flat":   # perturb the non-zero ranks: the constructor must broadcast rank 0's parameters
+        if rank > 0:
+            with torch.no_grad():
+                for p in step.parameters():
+                    p.add_(0.01)
+        sync = engine.FlatGradAllReduce(step)
+        ddp = step
+    else:
+        ddp = engine.wrap_ddp(step, torch.device("cpu"))
     # whole scenes are the sharding unit: global scene list -> this rank's scenes
     scene_ids = engine.shard_scene_ids(len(sizes_per_rank) * world, rank, world)
     sizes = [sizes_per_rank[i // world] for i in scene_ids]
     batch = synthetic.make_batch(sizes, first_scene_id=scene_ids[0], grid_size=0.3)
     out = ddp(batch)
     out["loss"].backward()
+    if mode == "flat":
+        sync.sync()
     grads = {n: p.grad.clone() for n, p in step.named_parameters() if p.grad is not None}
     # reference: average of per-rank local gradients, computed without DDP
     torch.save(dict(loss=out["loss"].detach(), grads=grads, scene_ids=scene_ids, n=batch["coord"].shape[0]),
@@ -58,10 +68,12 @@ def _worker(rank, world, port, sizes_per_rank, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_gradient_allreduce(tmp_path):
+@pytest.mark.parametrize("mode", ["ddp", "flat"])
+def test_two_rank_gradient_allreduce(tmp_path, mode):
+    """mode "ddp": torch DistributedDataParallel; mode "flat": engine.FlatGradAllReduce (bench.py's default for N > 1)."""
     world = 2
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, [1100, 900], str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, [1100, 900], str(tmp_path), mode), nprocs=world, join=True)
     d = [torch.load(tmp_path / f"ddp_{r}.pt") for r in range(world)]
     loc = [torch.load(tmp_path / f"local_{r}.pt") for r in range(world)]
     assert d[0]["scene_ids"] == [0, 2] and d[1]["scene_ids"] == [1, 3]  # disjoint whole scenes
