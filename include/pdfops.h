@@ -249,6 +249,45 @@ int pdf_ce_forward(long n, int c, const float *logits, const long *target, long 
                    void *stream);
 int pdf_ce_backward(long n, int c, float *grad, const float *acc, const float *gy, void *stream);
 
+/* ---- libs/pointops2 window attention: the CSR-by-query v2 / v3 launchers of
+ * libs/pointops2/src/attention_v2/attention_cuda_kernel_v2.h and libs/pointops2/src/rpe_v2/relative_pos_encoding_cuda_kernel_v2.h,
+ * same parameter lists + stream.  N = number of queries (index0_offsets has N + 1 entries), M = edges, C = h * d,
+ * tables are (L, h, d, 3), rel_idx is (M, 3).  n_max (longest edge list) is accepted for parity and not needed.
+ * Overwritten outputs: attn / output / grad_q / grad_attn.  Pre-zeroed by the caller: grad_k, grad_v, grad_table*. */
+int pdf_attention_step1_forward_v2(int N, int M, int h, int C, unsigned n_max, const float *q, const float *k,
+                                   const int *index0_offsets, const int *index1, float *attn, void *stream);
+int pdf_attention_step1_backward_v2(int N, int M, int h, int C, unsigned n_max, const float *grad_out, const int *index0_offsets,
+                                    const int *index1, const float *q, const float *k, float *grad_q, float *grad_k, void *stream);
+int pdf_dot_prod_with_idx_forward_v3(int N, int M, int h, int hdim, unsigned n_max, const float *q, const int *index_q_offsets,
+                                     const float *k, const int *index_k, const float *table_q, const float *table_k,
+                                     const int *rel_idx, float *output, void *stream);
+int pdf_dot_prod_with_idx_backward_v3(int N, int M, int h, int hdim, unsigned n_max, const float *grad_out, const float *q,
+                                      const int *index_q_offsets, const float *k, const int *index_k, const float *table_q,
+                                      const float *table_k, const int *rel_idx, float *grad_q, float *grad_k, float *grad_table_q,
+                                      float *grad_table_k, void *stream);
+int pdf_attention_step2_with_rel_pos_value_forward_v2(int N, int M, int h, int hdim, unsigned n_max, const float *attn, const float *v,
+                                                      const int *index0_offsets, const int *index1, const float *table,
+                                                      const int *rel_idx, float *output, void *stream);
+int pdf_attention_step2_with_rel_pos_value_backward_v2(int N, int M, int h, int hdim, unsigned n_max, const float *grad_out,
+                                                       const int *index0_offsets, const int *index1, const float *attn, const float *v,
+                                                       const float *table, const int *rel_idx, float *grad_attn, float *grad_v,
+                                                       float *grad_table, void *stream);
+
+/* the three table ops with the table length L (rows of the tables) passed explicitly: per-head kernels that keep the head's
+ * table slabs and the table gradients in LDS (fall back to the entry points above when d is not a power of two <= 64 or the
+ * slabs exceed 64 KB) */
+int pdf_dot_prod_with_idx_forward_v3_l(int N, int M, int h, int hdim, int L, const float *q, const int *index_q_offsets, const float *k,
+                                       const int *index_k, const float *table_q, const float *table_k, const int *rel_idx, float *output,
+                                       void *stream);
+int pdf_dot_prod_with_idx_backward_v3_l(int N, int M, int h, int hdim, int L, const float *grad_out, const float *q,
+                                        const int *index_q_offsets, const float *k, const int *index_k, const float *table_q,
+                                        const float *table_k, const int *rel_idx, float *grad_q, float *grad_k, float *grad_table_q,
+                                        float *grad_table_k, void *stream);
+int pdf_attention_step2_with_rel_pos_value_backward_v2_l(int N, int M, int h, int hdim, int L, const float *grad_out,
+                                                         const int *index0_offsets, const int *index1, const float *attn, const float *v,
+                                                         const float *table, const int *rel_idx, float *grad_attn, float *grad_v,
+                                                         float *grad_table, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

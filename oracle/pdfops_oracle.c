@@ -479,3 +479,182 @@ int oracle_attention_fusion_step_backward(int m, int g, int c, const float *weig
             }
     return 0;
 }
+
+/* ------------------------------------------------------------------ pointops2 window attention */
+/* libs/pointops2/src/attention_v2/attention_cuda_kernel_v2.cu:7-48: block (q_idx, h_idx), thread n_idx = edge start + n_idx.
+ * C = h * d; N = number of queries (= entries of index0_offsets - 1). */
+int oracle_attention_step1_forward_v2(int N, int M, int h, int C, unsigned n_max, const float *q, const float *k,
+                                      const int *index0_offsets, const int *index1, float *attn)
+{
+    (void)M; (void)n_max;
+    const int d = C / h;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int q_idx = 0; q_idx < N; q_idx++)
+        for (int h_idx = 0; h_idx < h; h_idx++) {
+            const int start = index0_offsets[q_idx], end = index0_offsets[q_idx + 1];
+            for (int m_idx = start; m_idx < end; m_idx++) {
+                float sum = 0;
+                for (int i = 0; i < d; i++) {
+                    int k_idx = index1[m_idx];
+                    float key = k[(size_t)k_idx * C + h_idx * d + i];
+                    sum += q[(size_t)q_idx * C + h_idx * d + i] * key;
+                }
+                attn[(size_t)m_idx * h + h_idx] = sum;
+            }
+        }
+    return 0;
+}
+
+/* attention_cuda_kernel_v2.cu:50-93 (shared-memory / global atomicAdd -> serial +=; grad_q overwritten, grad_k accumulated) */
+int oracle_attention_step1_backward_v2(int N, int M, int h, int C, unsigned n_max, const float *grad_out, const int *index0_offsets,
+                                       const int *index1, const float *q, const float *k, float *grad_q, float *grad_k)
+{
+    (void)M; (void)n_max;
+    const int d = C / h;
+    for (int q_idx = 0; q_idx < N; q_idx++)
+        for (int h_idx = 0; h_idx < h; h_idx++) {
+            const int start = index0_offsets[q_idx], end = index0_offsets[q_idx + 1];
+            float gradient_new[64];
+            for (int i = 0; i < d; i++) gradient_new[i] = 0;
+            for (int m_idx = start; m_idx < end; m_idx++) {
+                float gradient = grad_out[(size_t)m_idx * h + h_idx];
+                for (int i = 0; i < d; i++) {
+                    int k_idx = index1[m_idx];
+                    gradient_new[i] += gradient * k[(size_t)k_idx * C + h_idx * d + i];
+                    grad_k[(size_t)k_idx * C + h_idx * d + i] += gradient * q[(size_t)q_idx * C + h_idx * d + i];
+                }
+            }
+            for (int i = 0; i < d; i++) grad_q[(size_t)q_idx * C + h_idx * d + i] = gradient_new[i];
+        }
+    return 0;
+}
+
+/* libs/pointops2/src/rpe_v2/relative_pos_encoding_cuda_kernel_v2.cu:247-285 */
+int oracle_dot_prod_with_idx_forward_v3(int N, int M, int h, int d, unsigned n_max, const float *q, const int *index_q_offsets,
+                                        const float *k, const int *index_k, const float *table_q, const float *table_k,
+                                        const int *rel_idx, float *output)
+{
+    (void)M; (void)n_max;
+    const int C = h * d;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int q_idx = 0; q_idx < N; q_idx++)
+        for (int h_idx = 0; h_idx < h; h_idx++) {
+            const int start = index_q_offsets[q_idx], end = index_q_offsets[q_idx + 1];
+            for (int m_idx = start; m_idx < end; m_idx++) {
+                int k_idx = index_k[m_idx];
+                size_t r_idx1 = rel_idx[m_idx * 3], r_idx2 = rel_idx[m_idx * 3 + 1], r_idx3 = rel_idx[m_idx * 3 + 2];
+                float sum = 0;
+                for (int i = 0; i < d; i++) {
+                    float table_q_scalar_i = table_q[r_idx1 * C * 3 + h_idx * d * 3 + i * 3] + table_q[r_idx2 * C * 3 + h_idx * d * 3 + i * 3 + 1] +
+                                             table_q[r_idx3 * C * 3 + h_idx * d * 3 + i * 3 + 2];
+                    sum += q[(size_t)q_idx * C + h_idx * d + i] * table_q_scalar_i;
+                    float table_k_scalar_i = table_k[r_idx1 * C * 3 + h_idx * d * 3 + i * 3] + table_k[r_idx2 * C * 3 + h_idx * d * 3 + i * 3 + 1] +
+                                             table_k[r_idx3 * C * 3 + h_idx * d * 3 + i * 3 + 2];
+                    sum += k[(size_t)k_idx * C + h_idx * d + i] * table_k_scalar_i;
+                }
+                output[(size_t)m_idx * h + h_idx] = sum;
+            }
+        }
+    return 0;
+}
+
+/* relative_pos_encoding_cuda_kernel_v2.cu:287-340 */
+int oracle_dot_prod_with_idx_backward_v3(int N, int M, int h, int d, unsigned n_max, const float *grad_out, const float *q,
+                                         const int *index_q_offsets, const float *k, const int *index_k, const float *table_q,
+                                         const float *table_k, const int *rel_idx, float *grad_q, float *grad_k, float *grad_table_q,
+                                         float *grad_table_k)
+{
+    (void)M; (void)n_max;
+    const int C = h * d;
+    for (int q_idx = 0; q_idx < N; q_idx++)
+        for (int h_idx = 0; h_idx < h; h_idx++) {
+            const int start = index_q_offsets[q_idx], end = index_q_offsets[q_idx + 1];
+            float gradients_q[64];
+            for (int i = 0; i < d; i++) gradients_q[i] = 0;
+            for (int m_idx = start; m_idx < end; m_idx++) {
+                int k_idx = index_k[m_idx];
+                size_t r_idx1 = rel_idx[m_idx * 3], r_idx2 = rel_idx[m_idx * 3 + 1], r_idx3 = rel_idx[m_idx * 3 + 2];
+                float gradient = grad_out[(size_t)m_idx * h + h_idx];
+                for (int i = 0; i < d; i++) {
+                    float table_q_scalar_i = table_q[r_idx1 * C * 3 + h_idx * d * 3 + i * 3] + table_q[r_idx2 * C * 3 + h_idx * d * 3 + i * 3 + 1] +
+                                             table_q[r_idx3 * C * 3 + h_idx * d * 3 + i * 3 + 2];
+                    float table_k_scalar_i = table_k[r_idx1 * C * 3 + h_idx * d * 3 + i * 3] + table_k[r_idx2 * C * 3 + h_idx * d * 3 + i * 3 + 1] +
+                                             table_k[r_idx3 * C * 3 + h_idx * d * 3 + i * 3 + 2];
+                    float q_scalar_i = q[(size_t)q_idx * C + h_idx * d + i];
+                    float k_scalar_i = k[(size_t)k_idx * C + h_idx * d + i];
+                    gradients_q[i] += table_q_scalar_i * gradient;
+                    grad_k[(size_t)k_idx * C + h_idx * d + i] += table_k_scalar_i * gradient;
+                    grad_table_q[r_idx1 * C * 3 + h_idx * d * 3 + i * 3] += q_scalar_i * gradient;
+                    grad_table_q[r_idx2 * C * 3 + h_idx * d * 3 + i * 3 + 1] += q_scalar_i * gradient;
+                    grad_table_q[r_idx3 * C * 3 + h_idx * d * 3 + i * 3 + 2] += q_scalar_i * gradient;
+                    grad_table_k[r_idx1 * C * 3 + h_idx * d * 3 + i * 3] += k_scalar_i * gradient;
+                    grad_table_k[r_idx2 * C * 3 + h_idx * d * 3 + i * 3 + 1] += k_scalar_i * gradient;
+                    grad_table_k[r_idx3 * C * 3 + h_idx * d * 3 + i * 3 + 2] += k_scalar_i * gradient;
+                }
+            }
+            for (int i = 0; i < d; i++) grad_q[(size_t)q_idx * C + h_idx * d + i] = gradients_q[i];
+        }
+    return 0;
+}
+
+/* relative_pos_encoding_cuda_kernel_v2.cu:397-439 */
+int oracle_attention_step2_with_rel_pos_value_forward_v2(int N, int M, int h, int d, unsigned n_max, const float *attn, const float *v,
+                                                         const int *index0_offsets, const int *index1, const float *table,
+                                                         const int *rel_idx, float *output)
+{
+    (void)M; (void)n_max;
+    const int C = h * d;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int q_idx = 0; q_idx < N; q_idx++)
+        for (int h_idx = 0; h_idx < h; h_idx++) {
+            const int start = index0_offsets[q_idx], end = index0_offsets[q_idx + 1];
+            float result[64];
+            for (int i = 0; i < d; i++) result[i] = 0;
+            for (int m_idx = start; m_idx < end; m_idx++) {
+                float attn_scalar = attn[(size_t)m_idx * h + h_idx];
+                size_t r_idx1 = rel_idx[m_idx * 3], r_idx2 = rel_idx[m_idx * 3 + 1], r_idx3 = rel_idx[m_idx * 3 + 2];
+                for (int i = 0; i < d; i++) {
+                    int v_idx = index1[m_idx];
+                    float table_scaler_i = table[r_idx1 * C * 3 + h_idx * d * 3 + i * 3] + table[r_idx2 * C * 3 + h_idx * d * 3 + i * 3 + 1] +
+                                           table[r_idx3 * C * 3 + h_idx * d * 3 + i * 3 + 2];
+                    float value_scaler_i = v[(size_t)v_idx * C + h_idx * d + i];
+                    result[i] += (table_scaler_i + value_scaler_i) * attn_scalar;
+                }
+            }
+            for (int i = 0; i < d; i++) output[(size_t)q_idx * C + h_idx * d + i] = result[i];
+        }
+    return 0;
+}
+
+/* relative_pos_encoding_cuda_kernel_v2.cu:441-484 */
+int oracle_attention_step2_with_rel_pos_value_backward_v2(int N, int M, int h, int d, unsigned n_max, const float *grad_out,
+                                                          const int *index0_offsets, const int *index1, const float *attn, const float *v,
+                                                          const float *table, const int *rel_idx, float *grad_attn, float *grad_v,
+                                                          float *grad_table)
+{
+    (void)M; (void)n_max;
+    const int C = h * d;
+    for (int q_idx = 0; q_idx < N; q_idx++)
+        for (int h_idx = 0; h_idx < h; h_idx++) {
+            const int start = index0_offsets[q_idx], end = index0_offsets[q_idx + 1];
+            for (int m_idx = start; m_idx < end; m_idx++) {
+                int v_idx = index1[m_idx];
+                size_t r_idx1 = rel_idx[m_idx * 3], r_idx2 = rel_idx[m_idx * 3 + 1], r_idx3 = rel_idx[m_idx * 3 + 2];
+                float attn_scalar = attn[(size_t)m_idx * h + h_idx];
+                float grad_attn_sum = 0;
+                for (int i = 0; i < d; i++) {
+                    float grad_out_scaler_i = grad_out[(size_t)q_idx * C + h_idx * d + i];
+                    float table_scaler_i = table[r_idx1 * C * 3 + h_idx * d * 3 + i * 3] + table[r_idx2 * C * 3 + h_idx * d * 3 + i * 3 + 1] +
+                                           table[r_idx3 * C * 3 + h_idx * d * 3 + i * 3 + 2];
+                    float value_scaler_i = v[(size_t)v_idx * C + h_idx * d + i];
+                    grad_attn_sum += (table_scaler_i + value_scaler_i) * grad_out_scaler_i;
+                    grad_v[(size_t)v_idx * C + h_idx * d + i] += attn_scalar * grad_out_scaler_i;
+                    grad_table[r_idx1 * C * 3 + h_idx * d * 3 + i * 3] += attn_scalar * grad_out_scaler_i;
+                    grad_table[r_idx2 * C * 3 + h_idx * d * 3 + i * 3 + 1] += attn_scalar * grad_out_scaler_i;
+                    grad_table[r_idx3 * C * 3 + h_idx * d * 3 + i * 3 + 2] += attn_scalar * grad_out_scaler_i;
+                }
+                grad_attn[(size_t)m_idx * h + h_idx] = grad_attn_sum;
+            }
+        }
+    return 0;
+}

@@ -38,8 +38,18 @@ _PROTOS = {
     "attention_relation_step_backward": "iiippppppppp",
     "attention_fusion_step_forward": "iiippppp",
     "attention_fusion_step_backward": "iiippppppp",
+    # libs/pointops2 window attention (v2 / v3 launchers)
+    "attention_step1_forward_v2": "iiiiippppp",
+    "attention_step1_backward_v2": "iiiiippppppp",
+    "dot_prod_with_idx_forward_v3": "iiiiipppppppp",
+    "dot_prod_with_idx_backward_v3": "iiiiipppppppppppp",
+    "attention_step2_with_rel_pos_value_forward_v2": "iiiiippppppp",
+    "attention_step2_with_rel_pos_value_backward_v2": "iiiiipppppppppp",
 }
 _HIP_ONLY_PROTOS = {
+    "dot_prod_with_idx_forward_v3_l": "iiiiipppppppp",
+    "dot_prod_with_idx_backward_v3_l": "iiiiipppppppppppp",
+    "attention_step2_with_rel_pos_value_backward_v2_l": "iiiiipppppppppp",
     "group_forward": "iiiippppp",
     "group_backward": "iiiippp",
     "interpolation_weights": "iipp",
@@ -257,6 +267,84 @@ class CBackend:
         gv = self._new(value, (n, g, c), torch.float32, zero=True)
         self._call("attention_fusion_step_backward", m, g, c, weight, gw, value, gv, index_target, index_refer, grad_output)
         return gw, gv
+
+
+    # -- libs/pointops2 window attention ---------------------------------------------------------------
+    def attention_step1_v2(self, q, k, index1, offsets, n_max):
+        """-> attn (M, h).  AttentionStep1_v2.forward, libs/pointops2/functions/pointops.py:170-199."""
+        _check(q, torch.float32, "q"); _check(k, torch.float32, "k")
+        _check(index1, torch.int32, "index1"); _check(offsets, torch.int32, "index0_offsets")
+        n, h, d = q.shape
+        m = index1.shape[0]
+        if offsets.shape[0] != n + 1:
+            raise ValueError("index0_offsets must have N + 1 entries")
+        attn = self._new(q, (m, h), torch.float32)
+        self._call("attention_step1_forward_v2", n, m, h, h * d, int(n_max), q, k, offsets, index1, attn)
+        return attn
+
+    def attention_step1_v2_backward(self, grad_out, q, k, index1, offsets, n_max):
+        _check(grad_out, torch.float32, "grad_output")
+        n, h, d = q.shape
+        m = index1.shape[0]
+        gq = self._new(q, tuple(q.shape), torch.float32)
+        gk = self._new(q, tuple(k.shape), torch.float32, zero=True)
+        self._call("attention_step1_backward_v2", n, m, h, h * d, int(n_max), grad_out, offsets, index1, q, k, gq, gk)
+        return gq, gk
+
+    def dot_prod_with_idx_v3(self, q, offsets, n_max, k, index_k, table_q, table_k, rel_idx):
+        """-> out (M, h).  DotProdWithIdx_v3.forward, pointops.py:632-676."""
+        for t, nm in ((q, "q"), (k, "k"), (table_q, "table_q"), (table_k, "table_k")):
+            _check(t, torch.float32, nm)
+        for t, nm in ((offsets, "index_q_offsets"), (index_k, "index_k"), (rel_idx, "rel_idx")):
+            _check(t, torch.int32, nm)
+        n, h, d = q.shape
+        m = index_k.shape[0]
+        if offsets.shape[0] != n + 1 or table_q.shape != table_k.shape or tuple(table_q.shape[1:]) != (h, d, 3):
+            raise ValueError("dot_prod_with_idx_v3: inconsistent shapes")
+        out = self._new(q, (m, h), torch.float32)
+        if self.use_stream:   # HIP: per-head kernels with the table slabs in LDS (table length instead of n_max)
+            self._call("dot_prod_with_idx_forward_v3_l", n, m, h, d, int(table_q.shape[0]), q, offsets, k, index_k, table_q, table_k, rel_idx, out)
+        else:
+            self._call("dot_prod_with_idx_forward_v3", n, m, h, d, int(n_max), q, offsets, k, index_k, table_q, table_k, rel_idx, out)
+        return out
+
+    def dot_prod_with_idx_v3_backward(self, grad_out, q, offsets, n_max, k, index_k, table_q, table_k, rel_idx):
+        _check(grad_out, torch.float32, "grad_output")
+        n, h, d = q.shape
+        m = index_k.shape[0]
+        gq = self._new(q, tuple(q.shape), torch.float32)
+        gk = self._new(q, tuple(k.shape), torch.float32, zero=True)
+        gtq = self._new(q, tuple(table_q.shape), torch.float32, zero=True)
+        gtk = self._new(q, tuple(table_k.shape), torch.float32, zero=True)
+        name, x = ("dot_prod_with_idx_backward_v3_l", int(table_q.shape[0])) if self.use_stream else ("dot_prod_with_idx_backward_v3", int(n_max))
+        self._call(name, n, m, h, d, x, grad_out, q, offsets, k, index_k, table_q, table_k, rel_idx, gq, gk, gtq, gtk)
+        return gq, gk, gtq, gtk
+
+    def attention_step2_with_rel_pos_value_v2(self, attn, v, offsets, n_max, index1, table, rel_idx):
+        """-> out (N, h, d).  AttentionStep2WithRelPosValue_v2.forward, pointops.py:854-895."""
+        for t, nm in ((attn, "attn"), (v, "v"), (table, "table")):
+            _check(t, torch.float32, nm)
+        for t, nm in ((offsets, "index0_offsets"), (index1, "index1"), (rel_idx, "rel_idx")):
+            _check(t, torch.int32, nm)
+        m, h = attn.shape
+        n, _, d = v.shape
+        if offsets.shape[0] != n + 1 or tuple(table.shape[1:]) != (h, d, 3):
+            raise ValueError("attention_step2_with_rel_pos_value_v2: inconsistent shapes")
+        out = self._new(v, (n, h, d), torch.float32)
+        self._call("attention_step2_with_rel_pos_value_forward_v2", n, m, h, d, int(n_max), attn, v, offsets, index1, table, rel_idx, out)
+        return out
+
+    def attention_step2_with_rel_pos_value_v2_backward(self, grad_out, attn, v, offsets, n_max, index1, table, rel_idx):
+        _check(grad_out, torch.float32, "grad_output")
+        m, h = attn.shape
+        n, _, d = v.shape
+        ga = self._new(v, (m, h), torch.float32, zero=True)
+        gv = self._new(v, (n, h, d), torch.float32, zero=True)
+        gt = self._new(v, tuple(table.shape), torch.float32, zero=True)
+        name, x = (("attention_step2_with_rel_pos_value_backward_v2_l", int(table.shape[0])) if self.use_stream
+                   else ("attention_step2_with_rel_pos_value_backward_v2", int(n_max)))
+        self._call(name, n, m, h, d, x, grad_out, offsets, index1, attn, v, table, rel_idx, ga, gv, gt)
+        return ga, gv, gt
 
 
 class HipBackend(CBackend):

@@ -1,0 +1,482 @@
+// Window-attention ops of libs/pointops2 for gfx950 (the CSR-by-query "v2 / v3" kernels that
+// StratifiedTransformer's WindowAttention calls, stratified_transformer_v1m1_origin.py:277-341):
+//   attention_step1_v2                        attn[m,h]   = <q[q(m),h,:], k[index1[m],h,:]>
+//   dot_prod_with_idx_v3                      out[m,h]    = <q[q(m),h,:], Tq(m,h,:)> + <k[index_k[m],h,:], Tk(m,h,:)>
+//   attention_step2_with_rel_pos_value_v2     out[q,h,:]  = sum_{m in q} attn[m,h] * (v[index1[m],h,:] + T(m,h,:))
+// with T(m,h,i) = table[r1,h,i,0] + table[r2,h,i,1] + table[r3,h,i,2], (r1,r2,r3) = rel_idx[m,:], edges of query q =
+// [offsets[q], offsets[q+1]).  Replaces libs/pointops2/src/attention_v2/attention_cuda_kernel_v2.cu:7-93 and
+// libs/pointops2/src/rpe_v2/relative_pos_encoding_cuda_kernel_v2.cu:247-527.
+//
+// The reference launches a (query, head) block of n_max threads, one thread per edge, each walking its d = 16 / 32 channels
+// with stride-C gathers, and reduces through shared-memory atomics.  Here one 256-lane workgroup owns a QUERY (all heads):
+//   * edge-indexed results (attn, out[m,h], grad_attn): lane = (edge, head) with the head fastest, so a wave reads whole
+//     contiguous key rows (h*d = C floats per edge) and writes consecutive outputs;
+//   * query-indexed results (out[q,:], grad_q): lane = channel, loop over the query's edges -- coalesced row reads, no
+//     atomics, fixed summation order (the reference's shared atomics are unordered);
+//   * true scatters (grad_k, grad_v: rows shared between queries) are fp32 atomics, one float per lane over whole rows;
+//   * table gradients collide massively (L ~ 50 rows receive millions of edges); round 1 sends them as global atomics like
+//     the reference (next: per-workgroup LDS privatisation over edge chunks).
+// d is any positive size (the reference throws unless d is 16 or 32); n_max is accepted for signature parity and unused.
+// All kernels: HBM / atomic-rate bound; algorithmic bytes are listed at the entry points.
+#include "pdfops_common.h"
+
+namespace {
+
+constexpr int WB = 256;
+
+__device__ __forceinline__ float table_sum(const float *__restrict__ t, int r1, int r2, int r3, int C, int c) {
+    // table layout (L, h, d, 3); summation order as written upstream: (t[r1,.,0] + t[r2,.,1]) + t[r3,.,2]
+    return t[((size_t)r1 * C + c) * 3] + t[((size_t)r2 * C + c) * 3 + 1] + t[((size_t)r3 * C + c) * 3 + 2];
+}
+
+// ---------------------------------------------------------------- attention_step1_v2
+// attention_cuda_kernel_v2.cu:7-48
+__global__ __launch_bounds__(WB) void k_step1_fwd(int h, int d, const float *__restrict__ q, const float *__restrict__ k,
+                                                  const int *__restrict__ offsets, const int *__restrict__ index1,
+                                                  float *__restrict__ attn) {
+    extern __shared__ float qv[];
+    const int qi = blockIdx.x, C = h * d;
+    const int start = offsets[qi], end = offsets[qi + 1];
+    if (end <= start) return;
+    for (int c = threadIdx.x; c < C; c += WB) qv[c] = q[(size_t)qi * C + c];
+    __syncthreads();
+    const int total = (end - start) * h;
+    for (int e = threadIdx.x; e < total; e += WB) {
+        const int m = start + e / h, hh = e % h;
+        const float *kr = k + (size_t)index1[m] * C + hh * d;
+        const float *qr = qv + hh * d;
+        float sum = 0.f;
+        for (int i = 0; i < d; ++i) sum += qr[i] * kr[i];
+        attn[(size_t)m * h + hh] = sum;
+    }
+}
+
+// attention_cuda_kernel_v2.cu:50-93.  grad_q[q,:] = sum_m go[m,h] k[index1[m],:] (written, not accumulated);
+// grad_k[index1[m],:] += go[m,h] q[q,:] (pre-zeroed scatter target).
+__global__ __launch_bounds__(WB) void k_step1_bwd(int h, int d, const float *__restrict__ go, const int *__restrict__ offsets,
+                                                  const int *__restrict__ index1, const float *__restrict__ q,
+                                                  const float *__restrict__ k, float *__restrict__ grad_q,
+                                                  float *__restrict__ grad_k) {
+    extern __shared__ float qv[];
+    const int qi = blockIdx.x, C = h * d;
+    const int start = offsets[qi], end = offsets[qi + 1];
+    for (int c = threadIdx.x; c < C; c += WB) {
+        qv[c] = q[(size_t)qi * C + c];
+        const int hh = c / d;
+        float acc = 0.f;
+        for (int m = start; m < end; ++m) acc += go[(size_t)m * h + hh] * k[(size_t)index1[m] * C + c];
+        grad_q[(size_t)qi * C + c] = acc;
+    }
+    __syncthreads();
+    const long total = (long)(end - start) * C;
+    for (long e = threadIdx.x; e < total; e += WB) {
+        const int m = start + (int)(e / C), c = (int)(e % C);
+        pdf_atomic_add(grad_k + (size_t)index1[m] * C + c, go[(size_t)m * h + c / d] * qv[c]);
+    }
+}
+
+// ---------------------------------------------------------------- dot_prod_with_idx_v3
+// relative_pos_encoding_cuda_kernel_v2.cu:247-285
+__global__ __launch_bounds__(WB) void k_dot3_fwd(int h, int d, const float *__restrict__ q, const int *__restrict__ offsets,
+                                                 const float *__restrict__ k, const int *__restrict__ index_k,
+                                                 const float *__restrict__ table_q, const float *__restrict__ table_k,
+                                                 const int *__restrict__ rel_idx, float *__restrict__ output) {
+    extern __shared__ float qv[];
+    const int qi = blockIdx.x, C = h * d;
+    const int start = offsets[qi], end = offsets[qi + 1];
+    if (end <= start) return;
+    for (int c = threadIdx.x; c < C; c += WB) qv[c] = q[(size_t)qi * C + c];
+    __syncthreads();
+    const int total = (end - start) * h;
+    for (int e = threadIdx.x; e < total; e += WB) {
+        const int m = start + e / h, hh = e % h;
+        const int r1 = rel_idx[(size_t)m * 3], r2 = rel_idx[(size_t)m * 3 + 1], r3 = rel_idx[(size_t)m * 3 + 2];
+        const float *kr = k + (size_t)index_k[m] * C;
+        float sum = 0.f;
+        for (int i = 0; i < d; ++i) {
+            const int c = hh * d + i;
+            sum += qv[c] * table_sum(table_q, r1, r2, r3, C, c);
+            sum += kr[c] * table_sum(table_k, r1, r2, r3, C, c);
+        }
+        output[(size_t)m * h + hh] = sum;
+    }
+}
+
+// relative_pos_encoding_cuda_kernel_v2.cu:287-340.  grad_q written; grad_k, grad_table_q, grad_table_k pre-zeroed.
+__global__ __launch_bounds__(WB) void k_dot3_bwd(int h, int d, const float *__restrict__ go, const float *__restrict__ q,
+                                                 const int *__restrict__ offsets, const float *__restrict__ k,
+                                                 const int *__restrict__ index_k, const float *__restrict__ table_q,
+                                                 const float *__restrict__ table_k, const int *__restrict__ rel_idx,
+                                                 float *__restrict__ grad_q, float *__restrict__ grad_k,
+                                                 float *__restrict__ grad_table_q, float *__restrict__ grad_table_k) {
+    extern __shared__ float qv[];
+    const int qi = blockIdx.x, C = h * d;
+    const int start = offsets[qi], end = offsets[qi + 1];
+    for (int c = threadIdx.x; c < C; c += WB) {
+        qv[c] = q[(size_t)qi * C + c];
+        const int hh = c / d;
+        float acc = 0.f;
+        for (int m = start; m < end; ++m) {
+            const int r1 = rel_idx[(size_t)m * 3], r2 = rel_idx[(size_t)m * 3 + 1], r3 = rel_idx[(size_t)m * 3 + 2];
+            acc += table_sum(table_q, r1, r2, r3, C, c) * go[(size_t)m * h + hh];
+        }
+        grad_q[(size_t)qi * C + c] = acc;
+    }
+    __syncthreads();
+    const long total = (long)(end - start) * C;
+    for (long e = threadIdx.x; e < total; e += WB) {
+        const int m = start + (int)(e / C), c = (int)(e % C);
+        const int r1 = rel_idx[(size_t)m * 3], r2 = rel_idx[(size_t)m * 3 + 1], r3 = rel_idx[(size_t)m * 3 + 2];
+        const float g = go[(size_t)m * h + c / d];
+        const size_t kc = (size_t)index_k[m] * C + c;
+        pdf_atomic_add(grad_k + kc, table_sum(table_k, r1, r2, r3, C, c) * g);
+        const float gq = qv[c] * g, gk = k[kc] * g;
+        pdf_atomic_add(grad_table_q + ((size_t)r1 * C + c) * 3, gq);
+        pdf_atomic_add(grad_table_q + ((size_t)r2 * C + c) * 3 + 1, gq);
+        pdf_atomic_add(grad_table_q + ((size_t)r3 * C + c) * 3 + 2, gq);
+        pdf_atomic_add(grad_table_k + ((size_t)r1 * C + c) * 3, gk);
+        pdf_atomic_add(grad_table_k + ((size_t)r2 * C + c) * 3 + 1, gk);
+        pdf_atomic_add(grad_table_k + ((size_t)r3 * C + c) * 3 + 2, gk);
+    }
+}
+
+// ---------------------------------------------------------------- attention_step2_with_rel_pos_value_v2
+// relative_pos_encoding_cuda_kernel_v2.cu:397-439 (output written, one lane per channel; the reference reduces through
+// shared atomics in arbitrary order)
+__global__ __launch_bounds__(WB) void k_step2rv_fwd(int h, int d, const float *__restrict__ attn, const float *__restrict__ v,
+                                                    const int *__restrict__ offsets, const int *__restrict__ index1,
+                                                    const float *__restrict__ table, const int *__restrict__ rel_idx,
+                                                    float *__restrict__ output) {
+    const int qi = blockIdx.x, C = h * d;
+    const int start = offsets[qi], end = offsets[qi + 1];
+    for (int c = threadIdx.x; c < C; c += WB) {
+        const int hh = c / d;
+        float acc = 0.f;
+        for (int m = start; m < end; ++m) {
+            const int r1 = rel_idx[(size_t)m * 3], r2 = rel_idx[(size_t)m * 3 + 1], r3 = rel_idx[(size_t)m * 3 + 2];
+            acc += (table_sum(table, r1, r2, r3, C, c) + v[(size_t)index1[m] * C + c]) * attn[(size_t)m * h + hh];
+        }
+        output[(size_t)qi * C + c] = acc;
+    }
+}
+
+// relative_pos_encoding_cuda_kernel_v2.cu:441-484.  grad_attn written; grad_v, grad_table pre-zeroed.
+__global__ __launch_bounds__(WB) void k_step2rv_bwd(int h, int d, const float *__restrict__ go, const int *__restrict__ offsets,
+                                                    const int *__restrict__ index1, const float *__restrict__ attn,
+                                                    const float *__restrict__ v, const float *__restrict__ table,
+                                                    const int *__restrict__ rel_idx, float *__restrict__ grad_attn,
+                                                    float *__restrict__ grad_v, float *__restrict__ grad_table) {
+    extern __shared__ float gv[];
+    const int qi = blockIdx.x, C = h * d;
+    const int start = offsets[qi], end = offsets[qi + 1];
+    if (end <= start) return;
+    for (int c = threadIdx.x; c < C; c += WB) gv[c] = go[(size_t)qi * C + c];
+    __syncthreads();
+    const int total = (end - start) * h;
+    for (int e = threadIdx.x; e < total; e += WB) {
+        const int m = start + e / h, hh = e % h;
+        const int r1 = rel_idx[(size_t)m * 3], r2 = rel_idx[(size_t)m * 3 + 1], r3 = rel_idx[(size_t)m * 3 + 2];
+        const float *vr = v + (size_t)index1[m] * C;
+        float sum = 0.f;
+        for (int i = 0; i < d; ++i) {
+            const int c = hh * d + i;
+            sum += (table_sum(table, r1, r2, r3, C, c) + vr[c]) * gv[c];
+        }
+        grad_attn[(size_t)m * h + hh] = sum;
+    }
+    const long totc = (long)(end - start) * C;
+    for (long e = threadIdx.x; e < totc; e += WB) {
+        const int m = start + (int)(e / C), c = (int)(e % C);
+        const int r1 = rel_idx[(size_t)m * 3], r2 = rel_idx[(size_t)m * 3 + 1], r3 = rel_idx[(size_t)m * 3 + 2];
+        const float g = attn[(size_t)m * h + c / d] * gv[c];
+        pdf_atomic_add(grad_v + (size_t)index1[m] * C + c, g);
+        pdf_atomic_add(grad_table + ((size_t)r1 * C + c) * 3, g);
+        pdf_atomic_add(grad_table + ((size_t)r2 * C + c) * 3 + 1, g);
+        pdf_atomic_add(grad_table + ((size_t)r3 * C + c) * 3 + 2, g);
+    }
+}
+
+
+// ================================================================ per-head kernels with the tables in LDS
+// The kernels above read the relative-position tables from global memory: 3 strided dwords per (edge, channel) and table,
+// 4.6e8 table loads for the reference's own test shape (M = 800k, C = 96), and every table-gradient atomic lands on one of
+// ~L*3 hot rows.  A head's slab of a table is small (L * d * 3 floats: 9 KB at L = 48, d = 16), so these twins give a
+// workgroup ONE head and a chunk of QCH consecutive queries (a contiguous edge range in CSR order): the head's table slabs
+// are staged in LDS once per workgroup, table gradients accumulate in LDS (ds_add_f32) and leave as one global atomic per
+// table element and workgroup, grad_q of the chunk accumulates in LDS and is stored plainly.  lane = (edge, channel) with the
+// channel fastest: key / value rows are read and scattered 4 * d contiguous bytes per edge.  Needs d a power of two <= 64 and
+// the slabs to fit 64 KB; anything else takes the generic kernels.
+constexpr int QCH = 64;   // queries per workgroup
+
+__device__ __forceinline__ int find_query(const int *__restrict__ offs, int nq, int m) {
+    // largest j in [0, nq) with offs[j] <= m  (offs has nq + 1 entries, offs[nq] > m)
+    int lo = 0, hi = nq;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (offs[mid] <= m) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ void stage_table(float *__restrict__ dst, const float *__restrict__ table, int L, int C, int d, int hh) {
+    const int per = d * 3;   // floats of one (r, head) slab row
+    for (int e = threadIdx.x; e < L * per; e += WB) {
+        const int r = e / per, x = e - r * per;
+        dst[e] = table[((size_t)r * C + (size_t)hh * d) * 3 + x];
+    }
+}
+__device__ __forceinline__ float lds_table_sum(const float *t, int r1, int r2, int r3, int d, int i) {
+    return t[(r1 * d + i) * 3] + t[(r2 * d + i) * 3 + 1] + t[(r3 * d + i) * 3 + 2];
+}
+
+// dot_prod_with_idx_v3 forward, lane = edge (the d-loop keeps the reference's summation order)
+__global__ __launch_bounds__(WB) void k_dot3_fwd_h(int N, int h, int d, int L, const float *__restrict__ q, const int *__restrict__ offsets,
+                                                   const float *__restrict__ k, const int *__restrict__ index_k,
+                                                   const float *__restrict__ table_q, const float *__restrict__ table_k,
+                                                   const int *__restrict__ rel_idx, float *__restrict__ output) {
+    extern __shared__ float sm[];
+    float *tq = sm, *tk = tq + L * d * 3;
+    int *offs = reinterpret_cast<int *>(tk + L * d * 3);
+    const int hh = blockIdx.y, C = h * d;
+    const int q0 = blockIdx.x * QCH, nq = min(QCH, N - q0);
+    for (int j = threadIdx.x; j <= nq; j += WB) offs[j] = offsets[q0 + j];
+    stage_table(tq, table_q, L, C, d, hh);
+    stage_table(tk, table_k, L, C, d, hh);
+    __syncthreads();
+    const int e0 = offs[0], e1 = offs[nq];
+    for (int m = e0 + threadIdx.x; m < e1; m += WB) {
+        const int qi = q0 + find_query(offs, nq, m);
+        const int r1 = rel_idx[(size_t)m * 3], r2 = rel_idx[(size_t)m * 3 + 1], r3 = rel_idx[(size_t)m * 3 + 2];
+        const float *qr = q + (size_t)qi * C + hh * d, *kr = k + (size_t)index_k[m] * C + hh * d;
+        float sum = 0.f;
+        for (int i = 0; i < d; ++i) {
+            sum += qr[i] * lds_table_sum(tq, r1, r2, r3, d, i);
+            sum += kr[i] * lds_table_sum(tk, r1, r2, r3, d, i);
+        }
+        output[(size_t)m * h + hh] = sum;
+    }
+}
+
+// dot_prod_with_idx_v3 backward, lane = (edge, channel)
+__global__ __launch_bounds__(WB) void k_dot3_bwd_h(int N, int h, int d, int L, const float *__restrict__ go, const float *__restrict__ q,
+                                                   const int *__restrict__ offsets, const float *__restrict__ k,
+                                                   const int *__restrict__ index_k, const float *__restrict__ table_q,
+                                                   const float *__restrict__ table_k, const int *__restrict__ rel_idx,
+                                                   float *__restrict__ grad_q, float *__restrict__ grad_k,
+                                                   float *__restrict__ grad_table_q, float *__restrict__ grad_table_k) {
+    extern __shared__ float sm[];
+    const int T = L * d * 3;
+    float *tq = sm, *tk = tq + T, *gtq = tk + T, *gtk = gtq + T, *gqs = gtk + T;   // gqs: QCH * d
+    int *offs = reinterpret_cast<int *>(gqs + QCH * d);
+    const int hh = blockIdx.y, C = h * d;
+    const int q0 = blockIdx.x * QCH, nq = min(QCH, N - q0);
+    for (int j = threadIdx.x; j <= nq; j += WB) offs[j] = offsets[q0 + j];
+    stage_table(tq, table_q, L, C, d, hh);
+    stage_table(tk, table_k, L, C, d, hh);
+    for (int e = threadIdx.x; e < 2 * T + QCH * d; e += WB) gtq[e] = 0.f;   // gtq | gtk | gqs are contiguous
+    __syncthreads();
+    const int e0 = offs[0], e1 = offs[nq];
+    const int lg = 31 - __clz(d);
+    const long total = (long)(e1 - e0) << lg;
+    for (long e = threadIdx.x; e < total; e += WB) {
+        const int m = e0 + (int)(e >> lg), i = (int)e & (d - 1);
+        const int ql = find_query(offs, nq, m);
+        const int r1 = rel_idx[(size_t)m * 3], r2 = rel_idx[(size_t)m * 3 + 1], r3 = rel_idx[(size_t)m * 3 + 2];
+        const float g = go[(size_t)m * h + hh];
+        const size_t kc = (size_t)index_k[m] * C + hh * d + i;
+        const float qv = q[(size_t)(q0 + ql) * C + hh * d + i], kv = k[kc];
+        atomicAdd(&gqs[ql * d + i], lds_table_sum(tq, r1, r2, r3, d, i) * g);
+        pdf_atomic_add(grad_k + kc, lds_table_sum(tk, r1, r2, r3, d, i) * g);
+        const float gq = qv * g, gk = kv * g;
+        atomicAdd(&gtq[(r1 * d + i) * 3], gq); atomicAdd(&gtq[(r2 * d + i) * 3 + 1], gq); atomicAdd(&gtq[(r3 * d + i) * 3 + 2], gq);
+        atomicAdd(&gtk[(r1 * d + i) * 3], gk); atomicAdd(&gtk[(r2 * d + i) * 3 + 1], gk); atomicAdd(&gtk[(r3 * d + i) * 3 + 2], gk);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nq * d; e += WB) grad_q[(size_t)(q0 + e / d) * C + hh * d + e % d] = gqs[e];
+    const int per = d * 3;
+    for (int e = threadIdx.x; e < T; e += WB) {
+        const int r = e / per, x = e - r * per;
+        const size_t dst = ((size_t)r * C + (size_t)hh * d) * 3 + x;
+        if (gtq[e] != 0.f) pdf_atomic_add(grad_table_q + dst, gtq[e]);
+        if (gtk[e] != 0.f) pdf_atomic_add(grad_table_k + dst, gtk[e]);
+    }
+}
+
+// attention_step2_with_rel_pos_value_v2 backward, lane = (edge, channel); grad_attn = 16/32-lane shuffle reduction
+__global__ __launch_bounds__(WB) void k_step2rv_bwd_h(int N, int h, int d, int L, const float *__restrict__ go, const int *__restrict__ offsets,
+                                                      const int *__restrict__ index1, const float *__restrict__ attn,
+                                                      const float *__restrict__ v, const float *__restrict__ table,
+                                                      const int *__restrict__ rel_idx, float *__restrict__ grad_attn,
+                                                      float *__restrict__ grad_v, float *__restrict__ grad_table) {
+    extern __shared__ float sm[];
+    const int T = L * d * 3;
+    float *tb = sm, *gt = tb + T;
+    int *offs = reinterpret_cast<int *>(gt + T);
+    const int hh = blockIdx.y, C = h * d;
+    const int q0 = blockIdx.x * QCH, nq = min(QCH, N - q0);
+    for (int j = threadIdx.x; j <= nq; j += WB) offs[j] = offsets[q0 + j];
+    stage_table(tb, table, L, C, d, hh);
+    for (int e = threadIdx.x; e < T; e += WB) gt[e] = 0.f;
+    __syncthreads();
+    const int e0 = offs[0], e1 = offs[nq];
+    const int lg = 31 - __clz(d);
+    const long total = (long)(e1 - e0) << lg;
+    const long padded = (total + 63) & ~63L;   // whole waves iterate together (shuffles)
+    for (long e = threadIdx.x; e < padded; e += WB) {
+        const bool live = e < total;
+        float part = 0.f;
+        int m = 0;
+        const int i = (int)e & (d - 1);
+        if (live) {
+            m = e0 + (int)(e >> lg);
+            const int ql = find_query(offs, nq, m);
+            const int r1 = rel_idx[(size_t)m * 3], r2 = rel_idx[(size_t)m * 3 + 1], r3 = rel_idx[(size_t)m * 3 + 2];
+            const size_t vc = (size_t)index1[m] * C + hh * d + i;
+            const float gout = go[(size_t)(q0 + ql) * C + hh * d + i];
+            part = (lds_table_sum(tb, r1, r2, r3, d, i) + v[vc]) * gout;
+            const float g = attn[(size_t)m * h + hh] * gout;
+            pdf_atomic_add(grad_v + vc, g);
+            atomicAdd(&gt[(r1 * d + i) * 3], g); atomicAdd(&gt[(r2 * d + i) * 3 + 1], g); atomicAdd(&gt[(r3 * d + i) * 3 + 2], g);
+        }
+        for (int o = d >> 1; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        if (live && i == 0) grad_attn[(size_t)m * h + hh] = part;
+    }
+    __syncthreads();
+    const int per = d * 3;
+    for (int e = threadIdx.x; e < T; e += WB) {
+        const int r = e / per, x = e - r * per;
+        if (gt[e] != 0.f) pdf_atomic_add(grad_table + ((size_t)r * C + (size_t)hh * d) * 3 + x, gt[e]);
+    }
+}
+
+static inline bool pow2_le64(int d) { return d >= 1 && d <= 64 && (d & (d - 1)) == 0; }
+
+static inline int bad_shape(int N, int M, int h, int C) { return N < 0 || M < 0 || h < 1 || C < 1 || C % h != 0; }
+
+}  // namespace
+
+// replaces attention_step1_forward_cuda_launcher_v2, libs/pointops2/src/attention_v2/attention_cuda_kernel_v2.h
+// N = number of queries (rows of q, entries of index0_offsets minus one), M = edges.  Bytes: 4NC (q) + 4MC (gathered k rows)
+// + 4M + 4N (indices) + 4Mh (attn).
+extern "C" int pdf_attention_step1_forward_v2(int N, int M, int h, int C, unsigned n_max, const float *q, const float *k,
+                                              const int *index0_offsets, const int *index1, float *attn, void *stream) {
+    (void)n_max;
+    if (bad_shape(N, M, h, C)) return PDF_ERR_BAD_ARG;
+    if (N == 0 || M == 0) return PDF_OK;   // (0-size tensors carry null pointers)
+    if (!q || !k || !index0_offsets || !index1 || !attn) return PDF_ERR_BAD_ARG;
+    k_step1_fwd<<<N, WB, sizeof(float) * C, static_cast<hipStream_t>(stream)>>>(h, C / h, q, k, index0_offsets, index1, attn);
+    return pdf_launch_status();
+}
+
+// replaces attention_step1_backward_cuda_launcher_v2.  grad_q (N,h,d) is overwritten, grad_k must be zeroed by the caller.
+extern "C" int pdf_attention_step1_backward_v2(int N, int M, int h, int C, unsigned n_max, const float *grad_out,
+                                               const int *index0_offsets, const int *index1, const float *q, const float *k,
+                                               float *grad_q, float *grad_k, void *stream) {
+    (void)n_max;
+    if (bad_shape(N, M, h, C) || !grad_out || !q || !k || !index0_offsets || !index1 || !grad_q || !grad_k) return PDF_ERR_BAD_ARG;
+    if (N == 0) return PDF_OK;
+    k_step1_bwd<<<N, WB, sizeof(float) * C, static_cast<hipStream_t>(stream)>>>(h, C / h, grad_out, index0_offsets, index1, q, k, grad_q, grad_k);
+    return pdf_launch_status();
+}
+
+// replaces dot_prod_with_idx_forward_cuda_launcher_v3, libs/pointops2/src/rpe_v2/relative_pos_encoding_cuda_kernel_v2.h
+extern "C" int pdf_dot_prod_with_idx_forward_v3(int N, int M, int h, int hdim, unsigned n_max, const float *q,
+                                                const int *index_q_offsets, const float *k, const int *index_k,
+                                                const float *table_q, const float *table_k, const int *rel_idx, float *output,
+                                                void *stream) {
+    (void)n_max;
+    if (N < 0 || M < 0 || h < 1 || hdim < 1 || !q || !index_q_offsets || !k || !index_k || !table_q || !table_k || !rel_idx || !output)
+        return PDF_ERR_BAD_ARG;
+    if (N == 0 || M == 0) return PDF_OK;
+    k_dot3_fwd<<<N, WB, sizeof(float) * h * hdim, static_cast<hipStream_t>(stream)>>>(h, hdim, q, index_q_offsets, k, index_k, table_q, table_k,
+                                                                                  rel_idx, output);
+    return pdf_launch_status();
+}
+
+// The same op with the table length L (rows of table_q / table_k) known: per-head kernels with the tables in LDS.
+extern "C" int pdf_dot_prod_with_idx_forward_v3_l(int N, int M, int h, int hdim, int L, const float *q, const int *index_q_offsets,
+                                                  const float *k, const int *index_k, const float *table_q, const float *table_k,
+                                                  const int *rel_idx, float *output, void *stream) {
+    if (N < 0 || M < 0 || h < 1 || hdim < 1 || L < 1) return PDF_ERR_BAD_ARG;
+    if (N == 0 || M == 0) return PDF_OK;
+    if (!q || !index_q_offsets || !k || !index_k || !table_q || !table_k || !rel_idx || !output) return PDF_ERR_BAD_ARG;
+    const size_t lds = sizeof(float) * (size_t)(2 * L * hdim * 3) + sizeof(int) * (QCH + 1);
+    if (lds > 64 * 1024) return pdf_dot_prod_with_idx_forward_v3(N, M, h, hdim, 0, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, output, stream);
+    k_dot3_fwd_h<<<dim3(pdf_divup(N, QCH), h), WB, lds, static_cast<hipStream_t>(stream)>>>(N, h, hdim, L, q, index_q_offsets, k, index_k, table_q,
+                                                                                       table_k, rel_idx, output);
+    return pdf_launch_status();
+}
+
+// replaces dot_prod_with_idx_backward_cuda_launcher_v3.  grad_q overwritten; grad_k, grad_table_q, grad_table_k zeroed by the caller.
+extern "C" int pdf_dot_prod_with_idx_backward_v3(int N, int M, int h, int hdim, unsigned n_max, const float *grad_out, const float *q,
+                                                 const int *index_q_offsets, const float *k, const int *index_k, const float *table_q,
+                                                 const float *table_k, const int *rel_idx, float *grad_q, float *grad_k,
+                                                 float *grad_table_q, float *grad_table_k, void *stream) {
+    (void)n_max;
+    if (N < 0 || M < 0 || h < 1 || hdim < 1 || !grad_out || !q || !index_q_offsets || !k || !index_k || !table_q || !table_k || !rel_idx ||
+        !grad_q || !grad_k || !grad_table_q || !grad_table_k)
+        return PDF_ERR_BAD_ARG;
+    if (N == 0) return PDF_OK;
+    k_dot3_bwd<<<N, WB, sizeof(float) * h * hdim, static_cast<hipStream_t>(stream)>>>(h, hdim, grad_out, q, index_q_offsets, k, index_k, table_q,
+                                                                                  table_k, rel_idx, grad_q, grad_k, grad_table_q, grad_table_k);
+    return pdf_launch_status();
+}
+
+extern "C" int pdf_dot_prod_with_idx_backward_v3_l(int N, int M, int h, int hdim, int L, const float *grad_out, const float *q,
+                                                   const int *index_q_offsets, const float *k, const int *index_k, const float *table_q,
+                                                   const float *table_k, const int *rel_idx, float *grad_q, float *grad_k,
+                                                   float *grad_table_q, float *grad_table_k, void *stream) {
+    if (N < 0 || M < 0 || h < 1 || hdim < 1 || L < 1) return PDF_ERR_BAD_ARG;
+    if (N == 0) return PDF_OK;
+    if (!q || !index_q_offsets || !k || !table_q || !table_k || !grad_q || !grad_k || !grad_table_q || !grad_table_k) return PDF_ERR_BAD_ARG;
+    const size_t lds = sizeof(float) * (size_t)(4 * L * hdim * 3 + QCH * hdim) + sizeof(int) * (QCH + 1);
+    if (M == 0 || !pow2_le64(hdim) || lds > 64 * 1024)
+        return pdf_dot_prod_with_idx_backward_v3(N, M, h, hdim, 0, grad_out, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, grad_q,
+                                                 grad_k, grad_table_q, grad_table_k, stream);
+    k_dot3_bwd_h<<<dim3(pdf_divup(N, QCH), h), WB, lds, static_cast<hipStream_t>(stream)>>>(N, h, hdim, L, grad_out, q, index_q_offsets, k, index_k,
+                                                                                       table_q, table_k, rel_idx, grad_q, grad_k, grad_table_q,
+                                                                                       grad_table_k);
+    return pdf_launch_status();
+}
+
+// replaces attention_step2_with_rel_pos_value_forward_cuda_launcher_v2.  output (N,h,d) is overwritten.
+extern "C" int pdf_attention_step2_with_rel_pos_value_forward_v2(int N, int M, int h, int hdim, unsigned n_max, const float *attn,
+                                                                 const float *v, const int *index0_offsets, const int *index1,
+                                                                 const float *table, const int *rel_idx, float *output, void *stream) {
+    (void)n_max;
+    if (N < 0 || M < 0 || h < 1 || hdim < 1 || !attn || !v || !index0_offsets || !index1 || !table || !rel_idx || !output) return PDF_ERR_BAD_ARG;
+    if (N == 0) return PDF_OK;
+    k_step2rv_fwd<<<N, WB, 0, static_cast<hipStream_t>(stream)>>>(h, hdim, attn, v, index0_offsets, index1, table, rel_idx, output);
+    return pdf_launch_status();
+}
+
+// replaces attention_step2_with_rel_pos_value_backward_cuda_launcher_v2.  grad_attn overwritten; grad_v, grad_table zeroed by the caller.
+extern "C" int pdf_attention_step2_with_rel_pos_value_backward_v2(int N, int M, int h, int hdim, unsigned n_max, const float *grad_out,
+                                                                  const int *index0_offsets, const int *index1, const float *attn,
+                                                                  const float *v, const float *table, const int *rel_idx,
+                                                                  float *grad_attn, float *grad_v, float *grad_table, void *stream) {
+    (void)n_max;
+    if (N < 0 || M < 0 || h < 1 || hdim < 1 || !grad_out || !index0_offsets || !index1 || !attn || !v || !table || !rel_idx || !grad_attn ||
+        !grad_v || !grad_table)
+        return PDF_ERR_BAD_ARG;
+    if (N == 0 || M == 0) return PDF_OK;
+    k_step2rv_bwd<<<N, WB, sizeof(float) * h * hdim, static_cast<hipStream_t>(stream)>>>(h, hdim, grad_out, index0_offsets, index1, attn, v, table,
+                                                                                     rel_idx, grad_attn, grad_v, grad_table);
+    return pdf_launch_status();
+}
+
+extern "C" int pdf_attention_step2_with_rel_pos_value_backward_v2_l(int N, int M, int h, int hdim, int L, const float *grad_out,
+                                                                    const int *index0_offsets, const int *index1, const float *attn,
+                                                                    const float *v, const float *table, const int *rel_idx,
+                                                                    float *grad_attn, float *grad_v, float *grad_table, void *stream) {
+    if (N < 0 || M < 0 || h < 1 || hdim < 1 || L < 1) return PDF_ERR_BAD_ARG;
+    if (N == 0 || M == 0) return PDF_OK;
+    if (!grad_out || !index0_offsets || !index1 || !attn || !v || !table || !rel_idx || !grad_attn || !grad_v || !grad_table) return PDF_ERR_BAD_ARG;
+    const size_t lds = sizeof(float) * (size_t)(2 * L * hdim * 3) + sizeof(int) * (QCH + 1);
+    if (!pow2_le64(hdim) || lds > 64 * 1024)
+        return pdf_attention_step2_with_rel_pos_value_backward_v2(N, M, h, hdim, 0, grad_out, index0_offsets, index1, attn, v, table, rel_idx,
+                                                                  grad_attn, grad_v, grad_table, stream);
+    k_step2rv_bwd_h<<<dim3(pdf_divup(N, QCH), h), WB, lds, static_cast<hipStream_t>(stream)>>>(N, h, hdim, L, grad_out, index0_offsets, index1, attn, v,
+                                                                                          table, rel_idx, grad_attn, grad_v, grad_table);
+    return pdf_launch_status();
+}

@@ -1,0 +1,114 @@
+"""The CSR-by-query attention ops of the reference's ``pointops2`` (libs/pointops2/functions/pointops.py) that
+StratifiedTransformer's WindowAttention calls (stratified_transformer_v1m1_origin.py:277-341), on the C ABI of
+include/pdfops.h.  Same names, positional orders, dtypes and autograd behaviour:
+
+  attention_step1_v2(q, k, index1, index0_offsets, n_max) -> attn (M, h)                     pointops.py:170-258
+  dot_prod_with_idx_v3(q, index_q_offsets, n_max, k, index_k, table_q, table_k, rel_idx)      pointops.py:632-755
+  attention_step2_with_rel_pos_value_v2(attn, v, index0_offsets, n_max, index1, table, rel_idx) -> (N, h, d)   pointops.py:854-961
+
+q / k / v are (N, h, d) fp32, indices int32, ``index0_offsets`` has N + 1 entries (edges of query i are
+offsets[i] .. offsets[i+1]), tables are (L, h, d, 3), rel_idx is (M, 3).  Differences, all deliberate: any d (upstream throws
+unless d is 16 or 32), outputs live on the inputs' device, kernels run on torch's current stream, argument errors raise.
+The geometric ops under pointops2's own names (the model also calls these) are thin adapters over ``pointcloudpdf_amd.pointops``.
+"""
+import torch
+from torch.autograd import Function
+
+from .. import _native
+from .. import pointops as _p1
+
+_amp_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_amp_bwd = torch.amp.custom_bwd(device_type="cuda")
+
+
+def _be(t):
+    return _native.backend_for(t)
+
+
+class AttentionStep1_v2(Function):
+    """libs/pointops2/functions/pointops.py:170-255"""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, q, k, index1, index0_offsets, n_max):
+        assert q.is_contiguous() and k.is_contiguous() and index0_offsets.is_contiguous() and index1.is_contiguous()
+        assert n_max <= 1024
+        out = _be(q).attention_step1_v2(q, k, index1, index0_offsets, n_max)
+        ctx.n_max = int(n_max)
+        ctx.save_for_backward(q, k, index0_offsets, index1)
+        return out
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, grad_output):
+        q, k, index0_offsets, index1 = ctx.saved_tensors
+        gq, gk = _be(q).attention_step1_v2_backward(grad_output.contiguous(), q, k, index1, index0_offsets, ctx.n_max)
+        return gq, gk, None, None, None
+
+
+class DotProdWithIdx_v3(Function):
+    """libs/pointops2/functions/pointops.py:632-752"""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, q, index_q_offsets, n_max, k, index_k, table_q, table_k, rel_idx):
+        for t in (q, index_q_offsets, k, index_k, table_q, table_k, rel_idx):
+            assert t.is_contiguous()
+        assert table_k.shape[0] == table_q.shape[0]
+        out = _be(q).dot_prod_with_idx_v3(q, index_q_offsets, n_max, k, index_k, table_q, table_k, rel_idx)
+        ctx.n_max = int(n_max)
+        ctx.save_for_backward(q, index_q_offsets, k, index_k, table_q, table_k, rel_idx)
+        return out
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, grad_output):
+        q, index_q_offsets, k, index_k, table_q, table_k, rel_idx = ctx.saved_tensors
+        gq, gk, gtq, gtk = _be(q).dot_prod_with_idx_v3_backward(grad_output.contiguous(), q, index_q_offsets, ctx.n_max, k, index_k,
+                                                                 table_q, table_k, rel_idx)
+        return gq, None, None, gk, None, gtq, gtk, None
+
+
+class AttentionStep2WithRelPosValue_v2(Function):
+    """libs/pointops2/functions/pointops.py:854-958"""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, attn, v, index0_offsets, n_max, index1, table, rel_idx):
+        for t in (attn, v, index0_offsets, index1, table, rel_idx):
+            assert t.is_contiguous()
+        out = _be(v).attention_step2_with_rel_pos_value_v2(attn, v, index0_offsets, n_max, index1, table, rel_idx)
+        ctx.n_max = int(n_max)
+        ctx.save_for_backward(attn, v, index0_offsets, index1, table, rel_idx)
+        return out
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, grad_output):
+        attn, v, index0_offsets, index1, table, rel_idx = ctx.saved_tensors
+        ga, gv, gt = _be(v).attention_step2_with_rel_pos_value_v2_backward(grad_output.contiguous(), attn, v, index0_offsets, ctx.n_max,
+                                                                            index1, table, rel_idx)
+        return ga, gv, None, None, None, gt, None
+
+
+attention_step1_v2 = AttentionStep1_v2.apply
+dot_prod_with_idx_v3 = DotProdWithIdx_v3.apply
+attention_step2_with_rel_pos_value_v2 = AttentionStep2WithRelPosValue_v2.apply
+
+
+# ---- the geometric ops under pointops2's names / argument orders (libs/pointops2/functions/pointops.py:16-56, 964-1001, 1113-1127)
+def furthestsampling(xyz, offset, new_offset):
+    """pointops.py:16-34 -> idx (m) int32"""
+    return _p1.farthest_point_sampling(xyz, offset, new_offset)
+
+
+def knnquery(nsample, xyz, new_xyz, offset, new_offset):
+    """pointops.py:37-56: (nsample, xyz, new_xyz, offset, new_offset) -> (idx (m, nsample), dist (m, nsample) = sqrt(d2))"""
+    if new_xyz is None:
+        new_xyz, new_offset = xyz, offset
+    return _p1.knn_query(nsample, xyz, offset, new_xyz, new_offset)
+
+
+def interpolation(xyz, new_xyz, feat, offset, new_offset, k=3):
+    """pointops.py:1113-1127 (same arithmetic as libs/pointops interpolation)"""
+    return _p1.interpolation(xyz, new_xyz, feat, offset, new_offset, k)

@@ -413,6 +413,84 @@ def run_ball_cases(ref_pointops):
     return out
 
 
+def install_reference_pointops2():
+    """libs/pointops2/functions/pointops.py on top of a ``pointops2_cuda`` stub backed by the oracle (signatures:
+    libs/pointops2/src/pointops_api.cpp:35-44).  Needs install_reference() first (CPU torch.cuda.*Tensor constructors)."""
+    be = oracle.backend()
+    C2 = types.ModuleType("pointops2_cuda")
+
+    def attention_step1_forward_cuda_v2(N, M, h, C, n_max, q, k, index0_offsets, index1, attn):
+        be._call("attention_step1_forward_v2", N, M, h, C, int(n_max), q, k, index0_offsets, index1, attn)
+
+    def attention_step1_backward_cuda_v2(N, M, h, C, n_max, grad_out, index0_offsets, index1, q, k, grad_q, grad_k):
+        be._call("attention_step1_backward_v2", N, M, h, C, int(n_max), grad_out.contiguous(), index0_offsets, index1, q, k, grad_q, grad_k)
+
+    def dot_prod_with_idx_forward_cuda_v3(N, M, h, hdim, n_max, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, output):
+        be._call("dot_prod_with_idx_forward_v3", N, M, h, hdim, int(n_max), q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, output)
+
+    def dot_prod_with_idx_backward_cuda_v3(N, M, h, hdim, n_max, grad_out, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx,
+                                           grad_q, grad_k, grad_table_q, grad_table_k):
+        be._call("dot_prod_with_idx_backward_v3", N, M, h, hdim, int(n_max), grad_out.contiguous(), q, index_q_offsets, k, index_k, table_q,
+                 table_k, rel_idx, grad_q, grad_k, grad_table_q, grad_table_k)
+
+    def attention_step2_with_rel_pos_value_forward_cuda_v2(N, M, h, hdim, n_max, attn, v, index0_offsets, index1, table, rel_idx, output):
+        be._call("attention_step2_with_rel_pos_value_forward_v2", N, M, h, hdim, int(n_max), attn, v, index0_offsets, index1, table, rel_idx, output)
+
+    def attention_step2_with_rel_pos_value_backward_cuda_v2(N, M, h, hdim, n_max, grad_out, index0_offsets, index1, attn, v, table, rel_idx,
+                                                            grad_attn, grad_v, grad_table):
+        be._call("attention_step2_with_rel_pos_value_backward_v2", N, M, h, hdim, int(n_max), grad_out.contiguous(), index0_offsets, index1,
+                 attn, v, table, rel_idx, grad_attn, grad_v, grad_table)
+
+    for name, fn in list(locals().items()):
+        if name.endswith(("_v2", "_v3")):
+            setattr(C2, name, fn)
+    sys.modules["pointops2_cuda"] = C2
+    path = os.path.join(REF, "libs", "pointops2", "functions", "pointops.py")
+    spec = importlib.util.spec_from_file_location("ref_pointops2_functions", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def window_graph(seed, n, h, d, L, max_deg):
+    """Random CSR-by-query edge lists shaped like StratifiedTransformer's window attention (some queries without edges)."""
+    g = torch.Generator().manual_seed(seed)
+    deg = torch.randint(0, max_deg + 1, (n,), generator=g)
+    deg[::7] = 0
+    offsets = torch.cat([torch.zeros(1, dtype=torch.long), deg.cumsum(0)]).int()
+    m = int(offsets[-1])
+    index1 = torch.randint(0, n, (m,), generator=g).int()
+    rel_idx = torch.randint(0, L, (m, 3), generator=g).int()
+    q, k, v = (torch.randn(n, h, d, generator=g) for _ in range(3))
+    tq, tk, tv = (torch.randn(L, h, d, 3, generator=g) * 0.5 for _ in range(3))
+    return dict(offsets=offsets, index1=index1, rel_idx=rel_idx, q=q, k=k, v=v, tq=tq, tk=tk, tv=tv, n_max=int(deg.max()), m=m)
+
+
+WINDOW_CASES = {"h3d16": (11, 300, 3, 16, 24, 40), "h2d32": (12, 170, 2, 32, 10, 90)}
+
+
+def run_pointops2_cases(ref_p2):
+    """attention_step1_v2 / dot_prod_with_idx_v3 / attention_step2_with_rel_pos_value_v2 through the reference's autograd wrappers
+    (libs/pointops2/functions/pointops.py:170-258, 632-755, 854-961), chained as in WindowAttention.forward
+    (stratified_transformer_v1m1_origin.py:277-341): attn = softmax-free (step1 + bias), out = step2(attn, v)."""
+    out = {}
+    for tag, cfg in WINDOW_CASES.items():
+        G = window_graph(*cfg)
+        q, k, v = (G[n].clone().requires_grad_(True) for n in ("q", "k", "v"))
+        tq, tk, tv = (G[n].clone().requires_grad_(True) for n in ("tq", "tk", "tv"))
+        attn = ref_p2.attention_step1_v2(q, k, G["index1"], G["offsets"], G["n_max"])
+        bias = ref_p2.dot_prod_with_idx_v3(q, G["offsets"], G["n_max"], k, G["index1"], tq, tk, G["rel_idx"])
+        a = (attn + bias) * 0.1
+        x = ref_p2.attention_step2_with_rel_pos_value_v2(a, v, G["offsets"], G["n_max"], G["index1"], tv, G["rel_idx"])
+        gen = torch.Generator().manual_seed(99)
+        gx = torch.randn(x.shape, generator=gen)
+        x.backward(gx)
+        out[f"{tag}_attn"], out[f"{tag}_bias"], out[f"{tag}_x"], out[f"{tag}_gx"] = attn.detach().numpy(), bias.detach().numpy(), x.detach().numpy(), gx.numpy()
+        for nm, t in (("q", q), ("k", k), ("v", v), ("tq", tq), ("tk", tk), ("tv", tv)):
+            out[f"{tag}_g{nm}"] = t.grad.numpy()
+    return out
+
+
 def run_hook_case(hook):
     """BaseModelHook on a toy module: forward/backward capture + clone semantics."""
     torch.manual_seed(3)
@@ -431,8 +509,12 @@ def run_hook_case(hook):
 
 def main():
     ref_pointops, seg, rec, hook, losses = install_reference()
-    np.savez_compressed(os.path.join(OUT, "ops_ball_ref.npz"), **run_ball_cases(ref_pointops))
+    if "--only-pointops2" not in sys.argv:
+        np.savez_compressed(os.path.join(OUT, "ops_ball_ref.npz"), **run_ball_cases(ref_pointops))
     if "--only-ball" in sys.argv:
+        return
+    np.savez_compressed(os.path.join(OUT, "ops_pointops2_ref.npz"), **run_pointops2_cases(install_reference_pointops2()))
+    if "--only-pointops2" in sys.argv:
         return
     np.savez_compressed(os.path.join(OUT, "ops_python_ref.npz"), **run_op_cases(ref_pointops))
     np.savez_compressed(os.path.join(OUT, "model_hook_ref.npz"), **run_hook_case(hook))

@@ -1,0 +1,73 @@
+"""GPU suite for SURVEY 8 row f-1: the HIP window-attention kernels (csrc/window_attention.hip) through the C ABI against the
+oracle on identical seeded CSR graphs, and against the fixtures made by the reference's own autograd wrappers."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close
+from test_pointops2_cpu import WINDOW_CASES, DenseEdgeList, chain, window_graph
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def p2():
+    from pointcloudpdf_amd import _native
+    from pointcloudpdf_amd.pointops2 import pointops
+
+    assert torch.cuda.is_available()
+    _native.hip_backend()   # raises if libpdfops.so is missing: no fallback
+    return pointops
+
+
+@pytest.mark.parametrize("tag", sorted(WINDOW_CASES))
+def test_reference_wrapper_fixtures_on_gpu(p2, golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, "ops_pointops2_ref.npz"))
+    res = chain(p2, window_graph(*WINDOW_CASES[tag]), dev="cuda")
+    for key, val in res.items():
+        assert_close(val, g[f"{tag}_{key}"], 2e-5, f"{tag} {key}")   # dot products: FMA contraction + atomic order
+
+
+@pytest.mark.parametrize("cfg", [(21, 3000, 6, 16, 48, 300), (22, 800, 12, 16, 20, 60), (23, 500, 1, 8, 5, 30), (24, 64, 3, 20, 7, 1000)])
+def test_hip_vs_oracle_bigger_graphs(p2, oracle_backend, cfg):
+    """Edge lists longer than one workgroup pass (n_max 300 / 1000), 12 heads, a head size that is not a multiple of 4,
+    empty queries.  Oracle side = the same wrappers with the CPU backend injected."""
+    from pointcloudpdf_amd import _native
+
+    G = window_graph(*cfg)
+    hip = chain(p2, G, dev="cuda")
+    prev = _native._set_backend_for_testing(oracle_backend)
+    try:
+        ora = chain(p2, G, dev="cpu")
+    finally:
+        _native._set_backend_for_testing(prev)
+    for key in hip:
+        assert_close(hip[key], ora[key], 5e-5, f"{cfg} {key}")
+
+
+def test_reference_test_script_shape_properties(p2):
+    """The reference's own test scripts use N = 35000, M = 800000, C = 96, h = 6 (libs/pointops2/functions/
+    test_attention_op_step1_v2.py:13-18): v2 / v3 against the dense edge-list formulas at that size."""
+    g = torch.Generator().manual_seed(1)
+    n, h, d, L, m = 35000, 6, 16, 48, 800000
+    index0, _ = torch.sort(torch.randint(0, n, (m,), generator=g))
+    offsets = torch.cat([torch.zeros(1, dtype=torch.long), index0.bincount(minlength=n).cumsum(0)]).int()
+    G = dict(offsets=offsets, index1=torch.randint(0, n, (m,), generator=g).int(), rel_idx=torch.randint(0, L, (m, 3), generator=g).int(),
+             q=torch.rand(n, h, d, generator=g), k=torch.rand(n, h, d, generator=g), v=torch.rand(n, h, d, generator=g),
+             tq=torch.rand(L, h, d, 3, generator=g), tk=torch.rand(L, h, d, 3, generator=g), tv=torch.rand(L, h, d, 3, generator=g),
+             n_max=int((offsets[1:] - offsets[:-1]).max()), m=m)
+    ours, dense = chain(p2, G, dev="cuda"), chain(DenseEdgeList, G, dev="cuda")
+    for key in ours:
+        assert_close(ours[key], dense[key], 1e-4, key)
+
+
+def test_empty_and_bad_arguments(p2):
+    dev = "cuda"
+    q = torch.randn(5, 2, 16, device=dev)
+    off = torch.zeros(6, dtype=torch.int32, device=dev)
+    e = torch.zeros(0, dtype=torch.int32, device=dev)
+    assert p2.attention_step1_v2(q, q, e, off, 0).shape == (0, 2)
+    with pytest.raises(ValueError):
+        p2.attention_step1_v2(q, q, e, off[:-1].contiguous(), 0)
