@@ -3,10 +3,14 @@ import sys
 
 
 def install_pointops():
-    """Make ``import pointops`` resolve to this package's drop-in (libs/pointops/functions/__init__.py:1-14 names)."""
-    from . import pointops
+    """Make ``import pointops`` (libs/pointops/functions/__init__.py:1-14 names) and ``import pointops2.pointops``
+    (the window-attention part, libs/pointops2/functions/pointops.py) resolve to this package's drop-ins."""
+    from . import pointops, pointops2
 
     sys.modules["pointops"] = pointops
+    # libs/pointops2: ``import pointops2.pointops as pointops`` (stratified_transformer_v1m1_origin.py:21)
+    sys.modules["pointops2"] = pointops2
+    sys.modules["pointops2.pointops"] = pointops2.pointops
     return pointops
 
 
