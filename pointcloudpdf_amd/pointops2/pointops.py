@@ -112,3 +112,18 @@ def knnquery(nsample, xyz, new_xyz, offset, new_offset):
 def interpolation(xyz, new_xyz, feat, offset, new_offset, k=3):
     """pointops.py:1113-1127 (same arithmetic as libs/pointops interpolation)"""
     return _p1.interpolation(xyz, new_xyz, feat, offset, new_offset, k)
+
+
+def queryandgroup(nsample, xyz, new_xyz, feat, idx, offset, new_offset, use_xyz=True, return_indx=False):
+    """pointops.py:964-1001: kNN grouping, output (m, nsample, [3+]c) with the RELATIVE coordinates in front.  One fused
+    gather (``pointops.grouping``) instead of the reference's index / subtract / cat chain; the only difference is in scenes
+    with fewer than nsample points, where upstream's ``xyz[idx]`` wraps the -1 placeholder to the LAST row of the batch and
+    this op gathers a zero row."""
+    assert xyz.is_contiguous() and feat.is_contiguous()
+    if new_xyz is None:
+        new_xyz = xyz
+    assert new_xyz.is_contiguous()
+    if idx is None:
+        idx, _ = knnquery(nsample, xyz, new_xyz, offset, new_offset)
+    out = _p1.grouping(idx, feat, xyz, new_xyz, with_xyz=use_xyz)
+    return (out, idx) if return_indx else out

@@ -112,3 +112,21 @@ def test_pointops2_names_and_adapters(use_oracle):
     assert torch.equal(idx, ref_idx) and torch.equal(dist, ref_dist)
     noff = torch.tensor([30, 50], dtype=torch.int32)
     assert torch.equal(p2.furthestsampling(xyz, off, noff), p1.farthest_point_sampling(xyz, off, noff))
+
+
+def test_queryandgroup_matches_reference_composition(use_oracle):
+    """libs/pointops2/functions/pointops.py:964-1001 written out with plain indexing (scenes with at least nsample points)."""
+    g = torch.Generator().manual_seed(3)
+    xyz = torch.rand(260, 3, generator=g)
+    feat = torch.randn(260, 5, generator=g)
+    off = torch.tensor([100, 260], dtype=torch.int32)
+    new_xyz = xyz[::4].contiguous()
+    noff = torch.tensor([25, 65], dtype=torch.int32)
+    for use_xyz in (True, False):
+        out, idx = p2.queryandgroup(8, xyz, new_xyz, feat, None, off, noff, use_xyz=use_xyz, return_indx=True)
+        flat = idx.view(-1).long()
+        gx = xyz[flat].view(65, 8, 3) - new_xyz.unsqueeze(1)
+        gf = feat[flat].view(65, 8, 5)
+        want = torch.cat((gx, gf), -1) if use_xyz else gf
+        assert torch.equal(out, want)
+    assert p2.queryandgroup(8, xyz, new_xyz, feat, idx, off, noff, use_xyz=False).shape == (65, 8, 5)
