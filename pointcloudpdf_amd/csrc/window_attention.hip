@@ -218,15 +218,20 @@ __device__ __forceinline__ int find_query(const int *__restrict__ offs, int nq, 
     return lo;
 }
 
+// LDS slab of one head: row r at r * (3 d + 1) floats.  The odd stride spreads the rows over the banks: with the natural
+// stride 48 (d = 16) the lanes of a lane-per-edge loop -- same channel, different r -- would hit two banks (32-way conflict).
+__device__ __forceinline__ int slab_stride(int d) { return 3 * d + 1; }
+__device__ __forceinline__ int slab_floats(int L, int d) { return L * (3 * d + 1); }
 __device__ __forceinline__ void stage_table(float *__restrict__ dst, const float *__restrict__ table, int L, int C, int d, int hh) {
     const int per = d * 3;   // floats of one (r, head) slab row
     for (int e = threadIdx.x; e < L * per; e += WB) {
         const int r = e / per, x = e - r * per;
-        dst[e] = table[((size_t)r * C + (size_t)hh * d) * 3 + x];
+        dst[r * (per + 1) + x] = table[((size_t)r * C + (size_t)hh * d) * 3 + x];
     }
 }
 __device__ __forceinline__ float lds_table_sum(const float *t, int r1, int r2, int r3, int d, int i) {
-    return t[(r1 * d + i) * 3] + t[(r2 * d + i) * 3 + 1] + t[(r3 * d + i) * 3 + 2];
+    const int st = 3 * d + 1;
+    return t[r1 * st + 3 * i] + t[r2 * st + 3 * i + 1] + t[r3 * st + 3 * i + 2];
 }
 
 // dot_prod_with_idx_v3 forward, lane = edge (the d-loop keeps the reference's summation order)
@@ -235,8 +240,8 @@ __global__ __launch_bounds__(WB) void k_dot3_fwd_h(int N, int h, int d, int L, c
                                                    const float *__restrict__ table_q, const float *__restrict__ table_k,
                                                    const int *__restrict__ rel_idx, float *__restrict__ output) {
     extern __shared__ float sm[];
-    float *tq = sm, *tk = tq + L * d * 3;
-    int *offs = reinterpret_cast<int *>(tk + L * d * 3);
+    float *tq = sm, *tk = tq + slab_floats(L, d);
+    int *offs = reinterpret_cast<int *>(tk + slab_floats(L, d));
     const int hh = blockIdx.y, C = h * d;
     const int q0 = blockIdx.x * QCH, nq = min(QCH, N - q0);
     for (int j = threadIdx.x; j <= nq; j += WB) offs[j] = offsets[q0 + j];
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(WB) void k_dot3_bwd_h(int N, int h, int d, int L, c
                                                    float *__restrict__ grad_q, float *__restrict__ grad_k,
                                                    float *__restrict__ grad_table_q, float *__restrict__ grad_table_k) {
     extern __shared__ float sm[];
-    const int T = L * d * 3;
+    const int T = slab_floats(L, d);
     float *tq = sm, *tk = tq + T, *gtq = tk + T, *gtk = gtq + T, *gqs = gtk + T;   // gqs: QCH * d
     int *offs = reinterpret_cast<int *>(gqs + QCH * d);
     const int hh = blockIdx.y, C = h * d;
@@ -288,17 +293,18 @@ __global__ __launch_bounds__(WB) void k_dot3_bwd_h(int N, int h, int d, int L, c
         atomicAdd(&gqs[ql * d + i], lds_table_sum(tq, r1, r2, r3, d, i) * g);
         pdf_atomic_add(grad_k + kc, lds_table_sum(tk, r1, r2, r3, d, i) * g);
         const float gq = qv * g, gk = kv * g;
-        atomicAdd(&gtq[(r1 * d + i) * 3], gq); atomicAdd(&gtq[(r2 * d + i) * 3 + 1], gq); atomicAdd(&gtq[(r3 * d + i) * 3 + 2], gq);
-        atomicAdd(&gtk[(r1 * d + i) * 3], gk); atomicAdd(&gtk[(r2 * d + i) * 3 + 1], gk); atomicAdd(&gtk[(r3 * d + i) * 3 + 2], gk);
+        { const int st = slab_stride(d); atomicAdd(&gtq[r1 * st + 3 * i], gq); atomicAdd(&gtq[r2 * st + 3 * i + 1], gq); atomicAdd(&gtq[r3 * st + 3 * i + 2], gq);
+        atomicAdd(&gtk[r1 * st + 3 * i], gk); atomicAdd(&gtk[r2 * st + 3 * i + 1], gk); atomicAdd(&gtk[r3 * st + 3 * i + 2], gk); }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < nq * d; e += WB) grad_q[(size_t)(q0 + e / d) * C + hh * d + e % d] = gqs[e];
     const int per = d * 3;
-    for (int e = threadIdx.x; e < T; e += WB) {
+    for (int e = threadIdx.x; e < L * per; e += WB) {
         const int r = e / per, x = e - r * per;
         const size_t dst = ((size_t)r * C + (size_t)hh * d) * 3 + x;
-        if (gtq[e] != 0.f) pdf_atomic_add(grad_table_q + dst, gtq[e]);
-        if (gtk[e] != 0.f) pdf_atomic_add(grad_table_k + dst, gtk[e]);
+        const float a = gtq[r * (per + 1) + x], b = gtk[r * (per + 1) + x];
+        if (a != 0.f) pdf_atomic_add(grad_table_q + dst, a);
+        if (b != 0.f) pdf_atomic_add(grad_table_k + dst, b);
     }
 }
 
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(WB) void k_step2rv_bwd_h(int N, int h, int d, int L
                                                       const int *__restrict__ rel_idx, float *__restrict__ grad_attn,
                                                       float *__restrict__ grad_v, float *__restrict__ grad_table) {
     extern __shared__ float sm[];
-    const int T = L * d * 3;
+    const int T = slab_floats(L, d);
     float *tb = sm, *gt = tb + T;
     int *offs = reinterpret_cast<int *>(gt + T);
     const int hh = blockIdx.y, C = h * d;
@@ -336,16 +342,168 @@ __global__ __launch_bounds__(WB) void k_step2rv_bwd_h(int N, int h, int d, int L
             part = (lds_table_sum(tb, r1, r2, r3, d, i) + v[vc]) * gout;
             const float g = attn[(size_t)m * h + hh] * gout;
             pdf_atomic_add(grad_v + vc, g);
-            atomicAdd(&gt[(r1 * d + i) * 3], g); atomicAdd(&gt[(r2 * d + i) * 3 + 1], g); atomicAdd(&gt[(r3 * d + i) * 3 + 2], g);
+            { const int st = slab_stride(d); atomicAdd(&gt[r1 * st + 3 * i], g); atomicAdd(&gt[r2 * st + 3 * i + 1], g); atomicAdd(&gt[r3 * st + 3 * i + 2], g); }
         }
         for (int o = d >> 1; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
         if (live && i == 0) grad_attn[(size_t)m * h + hh] = part;
     }
     __syncthreads();
     const int per = d * 3;
-    for (int e = threadIdx.x; e < T; e += WB) {
+    for (int e = threadIdx.x; e < L * per; e += WB) {
         const int r = e / per, x = e - r * per;
-        if (gt[e] != 0.f) pdf_atomic_add(grad_table + ((size_t)r * C + (size_t)hh * d) * 3 + x, gt[e]);
+        const float a = gt[r * (per + 1) + x];
+        if (a != 0.f) pdf_atomic_add(grad_table + ((size_t)r * C + (size_t)hh * d) * 3 + x, a);
+    }
+}
+
+
+// ---------------------------------------------------------------- table gradients on the matrix cores (d = 16)
+// grad_table[r, h, :, axis] = sum_m [rel_idx[m, axis] == r] * x[m, :] is a product of a one-hot (L x edges) matrix with the
+// (edges x 16) matrix of per-edge channel rows.  The k_*_h kernels pay three ds_add_f32 per (edge, channel) and table for it
+// (measured: they ARE the kernel time).  In the lane = (edge, channel) mapping a wave already holds 4 edges x 16 channels --
+// exactly the B operand of v_mfma_f32_16x16x4_f32 (B[k = lane/16][n = lane%16]); the A operand A[m = lane%16][k = lane/16] is
+// the one-hot test of the lane's OWN edge against row 16*rb + lane%16.  So every wave-trip issues 3 axes x ceil(L/16) MFMAs per
+// table and keeps G in accumulators (D[m = 4*(lane/16) + j][n = lane%16]); LDS atomics are needed once per wave at the end.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int RB>
+__global__ __launch_bounds__(WB) void k_dot3_bwd_m16(int N, int h, int L, const float *__restrict__ go, const float *__restrict__ q,
+                                                     const int *__restrict__ offsets, const float *__restrict__ k,
+                                                     const int *__restrict__ index_k, const float *__restrict__ table_q,
+                                                     const float *__restrict__ table_k, const int *__restrict__ rel_idx,
+                                                     float *__restrict__ grad_q, float *__restrict__ grad_k,
+                                                     float *__restrict__ grad_table_q, float *__restrict__ grad_table_k) {
+    constexpr int d = 16;
+    extern __shared__ float sm[];
+    const int T = slab_floats(L, d);
+    float *tq = sm, *tk = tq + T, *gtq = tk + T, *gtk = gtq + T, *gqs = gtk + T;   // gqs: QCH * d
+    int *offs = reinterpret_cast<int *>(gqs + QCH * d);
+    const int hh = blockIdx.y, C = h * d;
+    const int q0 = blockIdx.x * QCH, nq = min(QCH, N - q0);
+    for (int j = threadIdx.x; j <= nq; j += WB) offs[j] = offsets[q0 + j];
+    stage_table(tq, table_q, L, C, d, hh);
+    stage_table(tk, table_k, L, C, d, hh);
+    for (int e = threadIdx.x; e < 2 * T + QCH * d; e += WB) gtq[e] = 0.f;
+    __syncthreads();
+    const int e0 = offs[0], e1 = offs[nq];
+    const long total = (long)(e1 - e0) * d;
+    const long padded = (total + 63) & ~63L;
+    const int lane = threadIdx.x & 63, i = lane & 15;
+    f32x4 aq[3][RB], ak[3][RB];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) { aq[a][rb] = (f32x4)(0.f); ak[a][rb] = (f32x4)(0.f); }
+    for (long e = threadIdx.x; e < padded; e += WB) {
+        float xq = 0.f, xk = 0.f;
+        int r[3] = {-1, -1, -1};
+        if (e < total) {
+            const int m = e0 + (int)(e >> 4);
+            const int ql = find_query(offs, nq, m);
+            r[0] = rel_idx[(size_t)m * 3]; r[1] = rel_idx[(size_t)m * 3 + 1]; r[2] = rel_idx[(size_t)m * 3 + 2];
+            const float g = go[(size_t)m * h + hh];
+            const size_t kc = (size_t)index_k[m] * C + hh * d + i;
+            atomicAdd(&gqs[ql * d + i], lds_table_sum(tq, r[0], r[1], r[2], d, i) * g);
+            pdf_atomic_add(grad_k + kc, lds_table_sum(tk, r[0], r[1], r[2], d, i) * g);
+            xq = q[(size_t)(q0 + ql) * C + hh * d + i] * g;
+            xk = k[kc] * g;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const float hot = r[a] == 16 * rb + i ? 1.f : 0.f;
+                aq[a][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(hot, xq, aq[a][rb], 0, 0, 0);
+                ak[a][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(hot, xk, ak[a][rb], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = 16 * rb + 4 * (lane >> 4) + j;
+                if (row < L) {
+                    atomicAdd(&gtq[row * slab_stride(d) + 3 * i + a], aq[a][rb][j]);
+                    atomicAdd(&gtk[row * slab_stride(d) + 3 * i + a], ak[a][rb][j]);
+                }
+            }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nq * d; e += WB) grad_q[(size_t)(q0 + e / d) * C + hh * d + e % d] = gqs[e];
+    const int per = d * 3;
+    for (int e = threadIdx.x; e < L * per; e += WB) {
+        const int rr = e / per, x = e - rr * per;
+        const size_t dst = ((size_t)rr * C + (size_t)hh * d) * 3 + x;
+        const float a = gtq[rr * (per + 1) + x], b = gtk[rr * (per + 1) + x];
+        if (a != 0.f) pdf_atomic_add(grad_table_q + dst, a);
+        if (b != 0.f) pdf_atomic_add(grad_table_k + dst, b);
+    }
+}
+
+template <int RB>
+__global__ __launch_bounds__(WB) void k_step2rv_bwd_m16(int N, int h, int L, const float *__restrict__ go, const int *__restrict__ offsets,
+                                                        const int *__restrict__ index1, const float *__restrict__ attn,
+                                                        const float *__restrict__ v, const float *__restrict__ table,
+                                                        const int *__restrict__ rel_idx, float *__restrict__ grad_attn,
+                                                        float *__restrict__ grad_v, float *__restrict__ grad_table) {
+    constexpr int d = 16;
+    extern __shared__ float sm[];
+    const int T = slab_floats(L, d);
+    float *tb = sm, *gt = tb + T;
+    int *offs = reinterpret_cast<int *>(gt + T);
+    const int hh = blockIdx.y, C = h * d;
+    const int q0 = blockIdx.x * QCH, nq = min(QCH, N - q0);
+    for (int j = threadIdx.x; j <= nq; j += WB) offs[j] = offsets[q0 + j];
+    stage_table(tb, table, L, C, d, hh);
+    for (int e = threadIdx.x; e < T; e += WB) gt[e] = 0.f;
+    __syncthreads();
+    const int e0 = offs[0], e1 = offs[nq];
+    const long total = (long)(e1 - e0) * d;
+    const long padded = (total + 63) & ~63L;
+    const int lane = threadIdx.x & 63, i = lane & 15;
+    f32x4 acc[3][RB];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[a][rb] = (f32x4)(0.f);
+    for (long e = threadIdx.x; e < padded; e += WB) {
+        const bool live = e < total;
+        float part = 0.f, x = 0.f;
+        int m = 0, r[3] = {-1, -1, -1};
+        if (live) {
+            m = e0 + (int)(e >> 4);
+            const int ql = find_query(offs, nq, m);
+            r[0] = rel_idx[(size_t)m * 3]; r[1] = rel_idx[(size_t)m * 3 + 1]; r[2] = rel_idx[(size_t)m * 3 + 2];
+            const size_t vc = (size_t)index1[m] * C + hh * d + i;
+            const float gout = go[(size_t)(q0 + ql) * C + hh * d + i];
+            part = (lds_table_sum(tb, r[0], r[1], r[2], d, i) + v[vc]) * gout;
+            x = attn[(size_t)m * h + hh] * gout;
+            pdf_atomic_add(grad_v + vc, x);
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                acc[a][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(r[a] == 16 * rb + i ? 1.f : 0.f, x, acc[a][rb], 0, 0, 0);
+        for (int o = 8; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        if (live && i == 0) grad_attn[(size_t)m * h + hh] = part;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = 16 * rb + 4 * (lane >> 4) + j;
+                if (row < L) atomicAdd(&gt[row * slab_stride(d) + 3 * i + a], acc[a][rb][j]);
+            }
+    __syncthreads();
+    const int per = d * 3;
+    for (int e = threadIdx.x; e < L * per; e += WB) {
+        const int rr = e / per, x = e - rr * per;
+        const float a = gt[rr * (per + 1) + x];
+        if (a != 0.f) pdf_atomic_add(grad_table + ((size_t)rr * C + (size_t)hh * d) * 3 + x, a);
     }
 }
 
@@ -400,7 +558,7 @@ extern "C" int pdf_dot_prod_with_idx_forward_v3_l(int N, int M, int h, int hdim,
     if (N < 0 || M < 0 || h < 1 || hdim < 1 || L < 1) return PDF_ERR_BAD_ARG;
     if (N == 0 || M == 0) return PDF_OK;
     if (!q || !index_q_offsets || !k || !index_k || !table_q || !table_k || !rel_idx || !output) return PDF_ERR_BAD_ARG;
-    const size_t lds = sizeof(float) * (size_t)(2 * L * hdim * 3) + sizeof(int) * (QCH + 1);
+    const size_t lds = sizeof(float) * (size_t)(2 * L * (hdim * 3 + 1)) + sizeof(int) * (QCH + 1);
     if (lds > 64 * 1024) return pdf_dot_prod_with_idx_forward_v3(N, M, h, hdim, 0, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, output, stream);
     k_dot3_fwd_h<<<dim3(pdf_divup(N, QCH), h), WB, lds, static_cast<hipStream_t>(stream)>>>(N, h, hdim, L, q, index_q_offsets, k, index_k, table_q,
                                                                                        table_k, rel_idx, output);
@@ -429,13 +587,26 @@ extern "C" int pdf_dot_prod_with_idx_backward_v3_l(int N, int M, int h, int hdim
     if (N < 0 || M < 0 || h < 1 || hdim < 1 || L < 1) return PDF_ERR_BAD_ARG;
     if (N == 0) return PDF_OK;
     if (!q || !index_q_offsets || !k || !table_q || !table_k || !grad_q || !grad_k || !grad_table_q || !grad_table_k) return PDF_ERR_BAD_ARG;
-    const size_t lds = sizeof(float) * (size_t)(4 * L * hdim * 3 + QCH * hdim) + sizeof(int) * (QCH + 1);
+    const size_t lds = sizeof(float) * (size_t)(4 * L * (hdim * 3 + 1) + QCH * hdim) + sizeof(int) * (QCH + 1);
     if (M == 0 || !pow2_le64(hdim) || lds > 64 * 1024)
         return pdf_dot_prod_with_idx_backward_v3(N, M, h, hdim, 0, grad_out, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, grad_q,
                                                  grad_k, grad_table_q, grad_table_k, stream);
-    k_dot3_bwd_h<<<dim3(pdf_divup(N, QCH), h), WB, lds, static_cast<hipStream_t>(stream)>>>(N, h, hdim, L, grad_out, q, index_q_offsets, k, index_k,
-                                                                                       table_q, table_k, rel_idx, grad_q, grad_k, grad_table_q,
-                                                                                       grad_table_k);
+    const dim3 grid(pdf_divup(N, QCH), h);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hdim == 16 && L <= 64) {   // table gradients as one-hot MFMA products
+#define PDF_DOT3_M16(RB_) k_dot3_bwd_m16<RB_><<<grid, WB, lds, st>>>(N, h, L, grad_out, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, \
+                                                                    grad_q, grad_k, grad_table_q, grad_table_k)
+        switch ((L + 15) / 16) {
+            case 1: PDF_DOT3_M16(1); break;
+            case 2: PDF_DOT3_M16(2); break;
+            case 3: PDF_DOT3_M16(3); break;
+            default: PDF_DOT3_M16(4); break;
+        }
+#undef PDF_DOT3_M16
+        return pdf_launch_status();
+    }
+    k_dot3_bwd_h<<<grid, WB, lds, st>>>(N, h, hdim, L, grad_out, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, grad_q, grad_k,
+                                        grad_table_q, grad_table_k);
     return pdf_launch_status();
 }
 
@@ -472,11 +643,24 @@ extern "C" int pdf_attention_step2_with_rel_pos_value_backward_v2_l(int N, int M
     if (N < 0 || M < 0 || h < 1 || hdim < 1 || L < 1) return PDF_ERR_BAD_ARG;
     if (N == 0 || M == 0) return PDF_OK;
     if (!grad_out || !index0_offsets || !index1 || !attn || !v || !table || !rel_idx || !grad_attn || !grad_v || !grad_table) return PDF_ERR_BAD_ARG;
-    const size_t lds = sizeof(float) * (size_t)(2 * L * hdim * 3) + sizeof(int) * (QCH + 1);
+    const size_t lds = sizeof(float) * (size_t)(2 * L * (hdim * 3 + 1)) + sizeof(int) * (QCH + 1);
     if (!pow2_le64(hdim) || lds > 64 * 1024)
         return pdf_attention_step2_with_rel_pos_value_backward_v2(N, M, h, hdim, 0, grad_out, index0_offsets, index1, attn, v, table, rel_idx,
                                                                   grad_attn, grad_v, grad_table, stream);
-    k_step2rv_bwd_h<<<dim3(pdf_divup(N, QCH), h), WB, lds, static_cast<hipStream_t>(stream)>>>(N, h, hdim, L, grad_out, index0_offsets, index1, attn, v,
-                                                                                          table, rel_idx, grad_attn, grad_v, grad_table);
+    const dim3 grid(pdf_divup(N, QCH), h);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hdim == 16 && L <= 64) {
+#define PDF_S2_M16(RB_) k_step2rv_bwd_m16<RB_><<<grid, WB, lds, st>>>(N, h, L, grad_out, index0_offsets, index1, attn, v, table, rel_idx, grad_attn, \
+                                                                     grad_v, grad_table)
+        switch ((L + 15) / 16) {
+            case 1: PDF_S2_M16(1); break;
+            case 2: PDF_S2_M16(2); break;
+            case 3: PDF_S2_M16(3); break;
+            default: PDF_S2_M16(4); break;
+        }
+#undef PDF_S2_M16
+        return pdf_launch_status();
+    }
+    k_step2rv_bwd_h<<<grid, WB, lds, st>>>(N, h, hdim, L, grad_out, index0_offsets, index1, attn, v, table, rel_idx, grad_attn, grad_v, grad_table);
     return pdf_launch_status();
 }

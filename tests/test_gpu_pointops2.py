@@ -30,10 +30,12 @@ def test_reference_wrapper_fixtures_on_gpu(p2, golden_dir, tag):
         assert_close(val, g[f"{tag}_{key}"], 2e-5, f"{tag} {key}")   # dot products: FMA contraction + atomic order
 
 
-@pytest.mark.parametrize("cfg", [(21, 3000, 6, 16, 48, 300), (22, 800, 12, 16, 20, 60), (23, 500, 1, 8, 5, 30), (24, 64, 3, 20, 7, 1000)])
+@pytest.mark.parametrize("cfg", [(21, 3000, 6, 16, 48, 300), (22, 800, 12, 16, 20, 60), (23, 500, 1, 8, 5, 30), (24, 64, 3, 20, 7, 1000),
+                                 (25, 700, 3, 16, 10, 50), (26, 900, 2, 16, 60, 80), (27, 400, 2, 32, 30, 70), (28, 300, 2, 16, 70, 40)])
 def test_hip_vs_oracle_bigger_graphs(p2, oracle_backend, cfg):
     """Edge lists longer than one workgroup pass (n_max 300 / 1000), 12 heads, a head size that is not a multiple of 4,
-    empty queries.  Oracle side = the same wrappers with the CPU backend injected."""
+    empty queries; d = 16 with L = 10 / 20 / 48 / 60 (1-4 one-hot MFMA row blocks), L = 70 and d = 32 (LDS-atomic kernels),
+    d = 8 / 20 (generic kernels).  Oracle side = the same wrappers with the CPU backend injected."""
     from pointcloudpdf_amd import _native
 
     G = window_graph(*cfg)
