@@ -14,8 +14,8 @@
 //   * query-indexed results (out[q,:], grad_q): lane = channel, loop over the query's edges -- coalesced row reads, no
 //     atomics, fixed summation order (the reference's shared atomics are unordered);
 //   * true scatters (grad_k, grad_v: rows shared between queries) are fp32 atomics, one float per lane over whole rows;
-//   * table gradients collide massively (L ~ 50 rows receive millions of edges); round 1 sends them as global atomics like
-//     the reference (next: per-workgroup LDS privatisation over edge chunks).
+//   * table gradients collide massively (L ~ 50 rows receive millions of edges): see the per-head kernels further down (table
+//     slabs in LDS, gradients as one-hot MFMA products); the query-owned kernels here are the fallback for other shapes.
 // d is any positive size (the reference throws unless d is 16 or 32); n_max is accepted for signature parity and unused.
 // All kernels: HBM / atomic-rate bound; algorithmic bytes are listed at the entry points.
 #include "pdfops_common.h"
