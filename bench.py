@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--points", type=int, default=100000, help="points per scene")
     ap.add_argument("--scenes", type=int, default=2, help="scenes per GPU (batch size per rank)")
     ap.add_argument("--pool", type=int, default=3, help="distinct batches per rank to rotate through")
+    ap.add_argument("--jitter", type=float, default=0.0,
+                    help="scene sizes drawn in points * (1 +- jitter), seeded per rank and scene (SURVEY 8d config 3, secondary "
+                         "number: straggler imbalance across ranks); 0 = every scene exactly --points")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ops-roofline", action="store_true", help="skip the per-op HBM roofline micro-benchmark (rank 0, N = 1)")
     ap.add_argument("--cpu-points", type=int, default=100000, help="scene size of the bounded CPU-baseline sample")
@@ -151,7 +154,29 @@ def cpu_baseline(points):
         dt = time.perf_counter() - t0
     finally:
         _native._set_backend_for_testing(prev)
-    return dict(value=points / dt, unit="points/s", cores=cores, kind="port",
+    # op level (SURVEY 8d "CPU baseline" i / iii): the oracle's kNN (OpenMP over queries) and torch.cdist + topk -- the stand-in for
+    # torch-cluster's knn, which is absent on both boxes -- on a bounded sample: the first 20,000 queries of the scene, k = 8
+    ops = {}
+    try:
+        coord, off = batch["coord"], batch["offset"]
+        nq = min(20000, points)
+        qry, qoff = coord[:nq].contiguous(), torch.tensor([nq], dtype=torch.int32)
+        t0 = time.perf_counter(); be.knn_query(8, coord, qry, off, qoff); t_or = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for lo in range(0, nq, 2000):
+            torch.cdist(qry[lo:lo + 2000], coord).topk(8, dim=1, largest=False)
+        t_cd = time.perf_counter() - t0
+        ops = {"knn_oracle_queries_per_s": nq / t_or, "knn_cdist_topk_queries_per_s": nq / t_cd,
+               "knn_sample": f"{nq} queries over {points} points, k = 8"}
+    except Exception as e:   # the baseline is a report, never a reason to lose the line
+        ops = {"error": f"{type(e).__name__}: {e}"}
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+    except OSError:
+        pass
+    return dict(value=points / dt, unit="points/s", cores=cores, kind="port", cpu_model=cpu_model, host_cores=os.cpu_count(), ops=ops,
                 sample=f"1 step (fwd+bwd) on 1 synthetic scene of {points} points, CPU oracle ops (brute-force kNN, "
                        f"iterative FPS; quadratic in scene size) + torch-CPU layers, {dt:.1f} s wall")
 
@@ -183,8 +208,15 @@ def main():
     grad_sync = engine.FlatGradAllReduce(step) if (use_dp and args.ddp == "flat") else None
     opt = torch.optim.SGD(step.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4, fused=True)
 
-    sizes = [args.points] * args.scenes
-    pool = [synthetic.make_batch(sizes, first_scene_id=1000 * rank + 10 * i, device=dev) for i in range(args.pool)]
+    def scene_sizes(i):
+        if args.jitter <= 0:
+            return [args.points] * args.scenes
+        import numpy as np
+        rng = np.random.default_rng(7919 * rank + i)
+        return [int(round(args.points * (1.0 + args.jitter * (2.0 * rng.random() - 1.0)))) for _ in range(args.scenes)]
+
+    pool = [synthetic.make_batch(scene_sizes(i), first_scene_id=1000 * rank + 10 * i, device=dev) for i in range(args.pool)]
+    pool_points = [int(b["coord"].shape[0]) for b in pool]
     timer = KernelTimer(be, ["knn_query", "farthest_point_sampling", "group_forward", "group_backward",
                              "pt_layer_forward", "pt_layer_backward", "bottleneck_forward", "bottleneck_backward"])
     timer.install()
@@ -324,7 +356,10 @@ def main():
     loss = float(out["loss"].item())
 
     if rank == 0:
-        pts_per_step = args.points * args.scenes * world
+        # points actually processed in the timed steps (sizes differ per batch when --jitter is set; other ranks draw from the
+        # same distribution, so the whole-job figure is this rank's count times the world size)
+        pts_total = sum(pool_points[(args.warmup + i) % len(pool)] for i in range(args.steps)) * world
+        pts_per_step = pts_total / args.steps
         ks = timer.summary()
         dom = max(ks, key=lambda n: ks[n]["total_ms"]) if ks else None
         def roofline_of(name):
@@ -354,7 +389,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"S3DIS-shaped synthetic voxelised scenes, {args.scenes} x {args.points} points per GPU, "
                                    "PointTransformer-Seg50 + PointPdf-v1m1 U-decoder, fwd+bwd+SGD, geometry recomputed every step",
-                       "scenes_per_gpu": args.scenes, "points_per_scene": args.points, "parallelism": f"dp{world}",
+                       "scenes_per_gpu": args.scenes, "points_per_scene": args.points, "size_jitter": args.jitter, "parallelism": f"dp{world}",
                        "gradient_exchange": (args.ddp if use_dp else "none")},
             "per_gpu_points_per_s": pts_per_step * args.steps / dt / world,
             "loss": loss,
