@@ -127,3 +127,63 @@ def queryandgroup(nsample, xyz, new_xyz, feat, idx, offset, new_offset, use_xyz=
         idx, _ = knnquery(nsample, xyz, new_xyz, offset, new_offset)
     out = _p1.grouping(idx, feat, xyz, new_xyz, with_xyz=use_xyz)
     return (out, idx) if return_indx else out
+
+
+# ---- the v1 edge-list forms (arbitrary edge order, explicit index0) -- libs/pointops2/functions/pointops.py:93-167, 261-404,
+# 407-629, 758-851.  Upstream runs them as edge-parallel kernels with one global atomic per (edge, channel); here the edge list is
+# brought into CSR-by-query order once (stable sort of index0) and the v2 / v3 kernels above do the work; results return in the
+# caller's edge order.  Autograd flows through the permutation gathers.
+def _csr_by_query(index0, n_queries):
+    i0 = index0.long()
+    order = torch.sort(i0, stable=True)[1]
+    counts = torch.bincount(i0, minlength=n_queries)
+    offsets = torch.cat([counts.new_zeros(1), counts.cumsum(0)]).int()
+    inverse = torch.empty_like(order)
+    inverse[order] = torch.arange(order.shape[0], device=order.device)
+    return order, inverse, offsets
+
+
+def _num_queries(index0, n_rows):
+    """upstream sizes the output as index0.max() + 1 (a host sync); the CSR kernels want one offset per row of q / v."""
+    nq = int(index0.max().item()) + 1 if index0.numel() else 0
+    if nq > n_rows:
+        raise ValueError(f"index0 refers to query {nq - 1} but there are only {n_rows} rows")
+    return nq
+
+
+def attention_step1(q, k, index0, index1):
+    """pointops.py:93-167 -> attn (M, h) = <q[index0[m]], k[index1[m]]> per head"""
+    order, inverse, offsets = _csr_by_query(index0, q.shape[0])
+    return attention_step1_v2(q, k, index1[order].contiguous(), offsets, 0)[inverse]
+
+
+def dot_prod_with_idx_v2(q, index_q, k, index_k, table_q, table_k, rel_idx):
+    """pointops.py:476-629 -> (M, h)"""
+    order, inverse, offsets = _csr_by_query(index_q, q.shape[0])
+    out = dot_prod_with_idx_v3(q, offsets, 0, k, index_k[order].contiguous(), table_q, table_k, rel_idx[order].contiguous())
+    return out[inverse]
+
+
+def dot_prod_with_idx(q, index, table, rel_idx):
+    """pointops.py:407-473 -> (M, h) = <q[index[m]], T(m)>: the two-sided op with a zero key table"""
+    return dot_prod_with_idx_v2(q, index, q.detach(), index, table, torch.zeros_like(table), rel_idx)
+
+
+def attention_step2_with_rel_pos_value(attn, v, index0, index1, table, rel_idx):
+    """pointops.py:758-851 -> (index0.max() + 1, h, d)"""
+    nq = _num_queries(index0, v.shape[0])
+    order, _, offsets = _csr_by_query(index0, v.shape[0])
+    out = attention_step2_with_rel_pos_value_v2(attn[order].contiguous(), v, offsets, 0, index1[order].contiguous(), table,
+                                                rel_idx[order].contiguous())
+    return out[:nq]
+
+
+def attention_step2(attn, v, index0, index1):
+    """pointops.py:261-335 -> (index0.max() + 1, h, d) = sum over the query's edges of attn * v[index1]"""
+    h, d = v.shape[1], v.shape[2]
+    table = v.new_zeros(1, h, d, 3)
+    rel_idx = torch.zeros(index0.shape[0], 3, dtype=torch.int32, device=v.device)
+    return attention_step2_with_rel_pos_value(attn, v, index0, index1, table, rel_idx)
+
+
+attention_step2_v2 = attention_step2   # pointops.py:338-404: same semantics, different upstream launch shape

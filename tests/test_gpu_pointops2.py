@@ -73,3 +73,12 @@ def test_empty_and_bad_arguments(p2):
     assert p2.attention_step1_v2(q, q, e, off, 0).shape == (0, 2)
     with pytest.raises(ValueError):
         p2.attention_step1_v2(q, q, e, off[:-1].contiguous(), 0)
+
+
+def test_v1_edge_list_forms_on_gpu(p2):
+    from test_pointops2_cpu import DenseEdgeListV1, edge_list_case, run_edge_list_ops
+
+    G = edge_list_case(seed=6, n=4000, h=6, d=16, L=48, m=90000)
+    ours, dense = run_edge_list_ops(p2, G, dev="cuda"), run_edge_list_ops(DenseEdgeListV1, G, dev="cuda")
+    for key in ours:
+        assert_close(ours[key], dense[key], 1e-4, key)

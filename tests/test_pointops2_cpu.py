@@ -130,3 +130,73 @@ def test_queryandgroup_matches_reference_composition(use_oracle):
         want = torch.cat((gx, gf), -1) if use_xyz else gf
         assert torch.equal(out, want)
     assert p2.queryandgroup(8, xyz, new_xyz, feat, idx, off, noff, use_xyz=False).shape == (65, 8, 5)
+
+
+def edge_list_case(seed=5, n=150, h=3, d=16, L=12, m=2000):
+    g = torch.Generator().manual_seed(seed)
+    G = dict(index0=torch.randint(0, n, (m,), generator=g).int(), index1=torch.randint(0, n, (m,), generator=g).int(),
+             rel_idx=torch.randint(0, L, (m, 3), generator=g).int(), attn=torch.randn(m, h, generator=g))
+    G["index0"][0] = n - 1   # index0.max() + 1 == n (upstream sizes outputs that way)
+    for nm in ("q", "k", "v"):
+        G[nm] = torch.randn(n, h, d, generator=g)
+    for nm in ("tq", "tk", "tv"):
+        G[nm] = torch.randn(L, h, d, 3, generator=g) * 0.5
+    return G
+
+
+def run_edge_list_ops(ops, G, dev="cpu"):
+    """The v1 edge-list forms on an UNSORTED edge list, forward values and gradients of every float input."""
+    T = lambda t: t.to(dev)
+    leaf = {nm: T(G[nm]).clone().requires_grad_(True) for nm in ("q", "k", "v", "tq", "tk", "tv", "attn")}
+    i0, i1, rel = T(G["index0"]), T(G["index1"]), T(G["rel_idx"])
+    outs = dict(
+        step1=ops.attention_step1(leaf["q"], leaf["k"], i0, i1),
+        dot=ops.dot_prod_with_idx(leaf["q"], i0, leaf["tq"], rel),
+        dot2=ops.dot_prod_with_idx_v2(leaf["q"], i0, leaf["k"], i1, leaf["tq"], leaf["tk"], rel),
+        step2=ops.attention_step2(leaf["attn"], leaf["v"], i0, i1),
+        step2rv=ops.attention_step2_with_rel_pos_value(leaf["attn"], leaf["v"], i0, i1, leaf["tv"], rel),
+    )
+    total = sum((o * torch.cos(torch.arange(o.numel(), device=o.device, dtype=torch.float32)).view_as(o)).sum() for o in outs.values())
+    total.backward()
+    res = {k_: v_.detach().cpu() for k_, v_ in outs.items()}
+    res.update({"g_" + nm: t.grad.detach().cpu() for nm, t in leaf.items()})
+    return res
+
+
+class DenseEdgeListV1:
+    @staticmethod
+    def _table(t, rel):
+        r = rel.long()
+        return t[r[:, 0], :, :, 0] + t[r[:, 1], :, :, 1] + t[r[:, 2], :, :, 2]
+
+    @staticmethod
+    def attention_step1(q, k, index0, index1):
+        return (q[index0.long()] * k[index1.long()]).sum(-1)
+
+    @classmethod
+    def dot_prod_with_idx(cls, q, index, table, rel):
+        return (q[index.long()] * cls._table(table, rel)).sum(-1)
+
+    @classmethod
+    def dot_prod_with_idx_v2(cls, q, index_q, k, index_k, tq, tk, rel):
+        return (q[index_q.long()] * cls._table(tq, rel)).sum(-1) + (k[index_k.long()] * cls._table(tk, rel)).sum(-1)
+
+    @staticmethod
+    def attention_step2(attn, v, index0, index1):
+        nq = int(index0.max()) + 1
+        return torch.zeros(nq, *v.shape[1:], dtype=v.dtype, device=v.device).index_add(0, index0.long(), v[index1.long()] * attn.unsqueeze(-1))
+
+    @classmethod
+    def attention_step2_with_rel_pos_value(cls, attn, v, index0, index1, table, rel):
+        nq = int(index0.max()) + 1
+        contrib = (v[index1.long()] + cls._table(table, rel)) * attn.unsqueeze(-1)
+        return torch.zeros(nq, *v.shape[1:], dtype=v.dtype, device=v.device).index_add(0, index0.long(), contrib)
+
+
+def test_v1_edge_list_forms_match_dense_formulas(use_oracle):
+    """libs/pointops2/functions/pointops.py:93-167, 261-335, 407-473, 476-629, 758-851 on an unsorted edge list."""
+    G = edge_list_case()
+    ours, dense = run_edge_list_ops(p2, G), run_edge_list_ops(DenseEdgeListV1, G)
+    assert set(ours) == set(dense)
+    for key in ours:
+        assert_close(ours[key], dense[key], 2e-5, key)
