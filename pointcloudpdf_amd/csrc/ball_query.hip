@@ -150,6 +150,7 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void random_ball_query_kernel(int m,
 
 extern "C" int pdf_ball_query(int m, int nsample, float min_radius, float max_radius, const float *xyz, const float *new_xyz,
                               const int *offset, const int *new_offset, int b, int *idx, float *dist2, void *stream) {
+    if (m == 0) return PDF_OK;   // (0-size tensors carry null pointers: not an argument error)
     if (m < 0 || b < 1 || !xyz || !new_xyz || !offset || !new_offset || !idx || !dist2) return PDF_ERR_BAD_ARG;
     if (nsample < 1 || nsample > BQ_CAP) return PDF_ERR_NSAMPLE;
     if (!(min_radius < max_radius)) return PDF_ERR_BAD_ARG;  // query.py:46 asserts the same
@@ -162,6 +163,7 @@ extern "C" int pdf_ball_query(int m, int nsample, float min_radius, float max_ra
 extern "C" int pdf_random_ball_query(int m, int nsample, float min_radius, float max_radius, const int *order, const float *xyz,
                                      const float *new_xyz, const int *offset, const int *new_offset, int b, int *idx, float *dist2,
                                      void *stream) {
+    if (m == 0) return PDF_OK;
     if (m < 0 || b < 1 || !order || !xyz || !new_xyz || !offset || !new_offset || !idx || !dist2) return PDF_ERR_BAD_ARG;
     if (nsample < 1) return PDF_ERR_NSAMPLE;
     if (!(min_radius < max_radius)) return PDF_ERR_BAD_ARG;

@@ -468,8 +468,8 @@ __global__ __launch_bounds__(GB) void agg_bwd32(unsigned total, FastDiv cd, int 
 }  // namespace
 
 extern "C" int pdf_grouping_forward(int m, int nsample, int c, const float *input, const int *idx, float *output, void *stream) {
-    if (m < 0 || nsample < 1 || c < 1 || !input || !idx || !output) return PDF_ERR_BAD_ARG;
     if (m == 0) return PDF_OK;
+    if (m < 0 || nsample < 1 || c < 1 || !input || !idx || !output) return PDF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int v = pick_vec(c);
     const long rows = (long)m * nsample;
@@ -483,8 +483,8 @@ extern "C" int pdf_grouping_forward(int m, int nsample, int c, const float *inpu
 }
 
 extern "C" int pdf_grouping_backward(int m, int nsample, int c, const float *grad_output, const int *idx, float *grad_input, void *stream) {
-    if (m < 0 || nsample < 1 || c < 1 || !grad_output || !idx || !grad_input) return PDF_ERR_BAD_ARG;
     if (m == 0) return PDF_OK;
+    if (m < 0 || nsample < 1 || c < 1 || !grad_output || !idx || !grad_input) return PDF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // scatter-adds run one float per lane (64 consecutive floats = whole 128-byte lines per instruction): the atomic units
     // bill per request, and the 16-byte-per-lane shape splits every line into four requests (see fused_layer.hip)
@@ -496,9 +496,9 @@ extern "C" int pdf_grouping_backward(int m, int nsample, int c, const float *gra
 
 extern "C" int pdf_group_forward(int m, int nsample, int c, int with_xyz, const float *feat, const float *xyz,
                                  const float *new_xyz, const int *idx, float *output, void *stream) {
+    if (m == 0) return PDF_OK;
     if (m < 0 || nsample < 1 || c < 1 || !feat || !idx || !output) return PDF_ERR_BAD_ARG;
     if (with_xyz && (!xyz || !new_xyz)) return PDF_ERR_BAD_ARG;
-    if (m == 0) return PDF_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long rows = (long)m * nsample;
     const int oc = c + (with_xyz ? 3 : 0);
@@ -513,8 +513,8 @@ extern "C" int pdf_group_forward(int m, int nsample, int c, int with_xyz, const 
 
 extern "C" int pdf_group_backward(int m, int nsample, int c, int with_xyz, const float *grad_output, const int *idx,
                                   float *grad_feat, void *stream) {
-    if (m < 0 || nsample < 1 || c < 1 || !grad_output || !idx || !grad_feat) return PDF_ERR_BAD_ARG;
     if (m == 0) return PDF_OK;
+    if (m < 0 || nsample < 1 || c < 1 || !grad_output || !idx || !grad_feat) return PDF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long rows = (long)m * nsample;
     group_bwd_kernel<<<grid_for(rows * c), GB, 0, s>>>(rows, c, with_xyz, grad_output, idx, grad_feat);
@@ -522,8 +522,8 @@ extern "C" int pdf_group_backward(int m, int nsample, int c, int with_xyz, const
 }
 
 extern "C" int pdf_interpolation_forward(int n, int c, int k, const float *input, const int *idx, const float *weight, float *output, void *stream) {
-    if (n < 0 || c < 1 || k < 1 || !input || !idx || !weight || !output) return PDF_ERR_BAD_ARG;
     if (n == 0) return PDF_OK;
+    if (n < 0 || c < 1 || k < 1 || !input || !idx || !weight || !output) return PDF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int v = pick_vec(c);
     if (v == 4 && (long)n * (c / 4) < (1L << 31) && (long)n * k < (1L << 31)) {
@@ -538,8 +538,8 @@ extern "C" int pdf_interpolation_forward(int n, int c, int k, const float *input
 }
 
 extern "C" int pdf_interpolation_backward(int n, int c, int k, const float *grad_output, const int *idx, const float *weight, float *grad_input, void *stream) {
-    if (n < 0 || c < 1 || k < 1 || !grad_output || !idx || !weight || !grad_input) return PDF_ERR_BAD_ARG;
     if (n == 0) return PDF_OK;
+    if (n < 0 || c < 1 || k < 1 || !grad_output || !idx || !weight || !grad_input) return PDF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // scatter-adds run one float per lane (64 consecutive floats = whole 128-byte lines per instruction): the atomic units
     // bill per request, and the 16-byte-per-lane shape splits every line into four requests (see fused_layer.hip)
@@ -549,16 +549,16 @@ extern "C" int pdf_interpolation_backward(int n, int c, int k, const float *grad
 }
 
 extern "C" int pdf_interpolation_weights(int n, int k, const float *dist2, float *weight, void *stream) {
-    if (n < 0 || k < 1 || !dist2 || !weight) return PDF_ERR_BAD_ARG;
     if (n == 0) return PDF_OK;
+    if (n < 0 || k < 1 || !dist2 || !weight) return PDF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     interp_weights_kernel<<<grid_for(n), GB, 0, s>>>(n, k, dist2, weight);
     return pdf_launch_status();
 }
 
 extern "C" int pdf_subtraction_forward(int n, int nsample, int c, const float *input1, const float *input2, const int *idx, float *output, void *stream) {
-    if (n < 0 || nsample < 1 || c < 1 || !input1 || !input2 || !idx || !output) return PDF_ERR_BAD_ARG;
     if (n == 0) return PDF_OK;
+    if (n < 0 || nsample < 1 || c < 1 || !input1 || !input2 || !idx || !output) return PDF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int v = pick_vec(c);
     const long rows = (long)n * nsample;
@@ -573,8 +573,8 @@ extern "C" int pdf_subtraction_forward(int n, int nsample, int c, const float *i
 }
 
 extern "C" int pdf_subtraction_backward(int n, int nsample, int c, const int *idx, const float *grad_output, float *grad_input1, float *grad_input2, void *stream) {
-    if (n < 0 || nsample < 1 || c < 1 || !idx || !grad_output || !grad_input1 || !grad_input2) return PDF_ERR_BAD_ARG;
     if (n == 0) return PDF_OK;
+    if (n < 0 || nsample < 1 || c < 1 || !idx || !grad_output || !grad_input1 || !grad_input2) return PDF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // scatter-adds run one float per lane (64 consecutive floats = whole 128-byte lines per instruction): the atomic units
     // bill per request, and the 16-byte-per-lane shape splits every line into four requests (see fused_layer.hip)
@@ -585,8 +585,8 @@ extern "C" int pdf_subtraction_backward(int n, int nsample, int c, const int *id
 
 extern "C" int pdf_aggregation_forward(int n, int nsample, int c, int w_c, const float *input, const float *position,
                                        const float *weight, const int *idx, float *output, void *stream) {
-    if (n < 0 || nsample < 1 || c < 1 || w_c < 1 || !input || !position || !weight || !idx || !output) return PDF_ERR_BAD_ARG;
     if (n == 0) return PDF_OK;
+    if (n < 0 || nsample < 1 || c < 1 || w_c < 1 || !input || !position || !weight || !idx || !output) return PDF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (c % 4 == 0 && w_c % 4 == 0 && (long)n * nsample * (c / 4) < (1L << 31)) {
         const unsigned total = (unsigned)((long)n * (c / 4));
@@ -601,10 +601,10 @@ extern "C" int pdf_aggregation_forward(int n, int nsample, int c, int w_c, const
 extern "C" int pdf_aggregation_backward(int n, int nsample, int c, int w_c, const float *input, const float *position,
                                         const float *weight, const int *idx, const float *grad_output,
                                         float *grad_input, float *grad_position, float *grad_weight, void *stream) {
+    if (n == 0) return PDF_OK;
     if (n < 0 || nsample < 1 || c < 1 || w_c < 1 || !input || !position || !weight || !idx || !grad_output ||
         !grad_input || !grad_position || !grad_weight)
         return PDF_ERR_BAD_ARG;
-    if (n == 0) return PDF_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if ((long)n * nsample * c < (1L << 31) && 64 % w_c == 0 && c % w_c == 0 && (c % 64 == 0 || 64 % c == 0)) {
         const unsigned total = (unsigned)((long)n * c);

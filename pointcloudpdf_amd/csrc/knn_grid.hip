@@ -285,6 +285,7 @@ extern "C" int pdf_knn_grid_supported(int nsample) { return nsample == 3 || nsam
 extern "C" int pdf_knn_query_ws(int m, int nsample, int n, const float *xyz, const float *new_xyz, const int *offset,
                                 const int *new_offset, int b, int *idx, float *dist2, void *workspace,
                                 long workspace_bytes, void *stream) {
+    if (m == 0) return PDF_OK;   // (0-size tensors carry null pointers: not an argument error)
     if (m < 0 || n < 0 || b < 1 || !xyz || !new_xyz || !offset || !new_offset || !idx || !dist2) return PDF_ERR_BAD_ARG;
     if (nsample < 1 || nsample > 128) return PDF_ERR_NSAMPLE;
     if (m == 0) return PDF_OK;

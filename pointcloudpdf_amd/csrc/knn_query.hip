@@ -204,6 +204,7 @@ __global__ __launch_bounds__(64) void knn_redo_wave_kernel(int m, int k, const f
 extern "C" int pdf_knn_query_list(int m, int nsample, const float *xyz, const float *new_xyz, const int *offset,
                                   const int *new_offset, int b, int *idx, float *dist2, const int *qlist,
                                   const int *qcount, void *stream) {
+    if (m == 0) return PDF_OK;   // (0-size tensors carry null pointers: not an argument error)
     if (m < 0 || b < 1 || !xyz || !new_xyz || !offset || !new_offset || !idx || !dist2) return PDF_ERR_BAD_ARG;
     if (nsample < 1 || nsample > 128) return PDF_ERR_NSAMPLE;
     if (m == 0) return PDF_OK;

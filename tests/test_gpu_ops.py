@@ -389,3 +389,26 @@ def test_python_level_goldens_on_gpu(hip, golden_dir):
     a, b = T(g["sub_a"], True), T(g["sub_b"], True)
     ys = pointops.subtraction(a, b, T(g["self_idx"]))
     assert np.array_equal(ys.detach().cpu().numpy(), g["sub_out"])
+
+
+def test_empty_inputs_are_no_ops(hip):
+    """Zero queries / zero rows: every entry point returns empty outputs instead of launching an empty grid (0-size tensors carry
+    null data pointers)."""
+    xyz = cloud(300, 2).to(DEV)
+    off = offs([300]).to(DEV)
+    q0 = torch.zeros(0, 3, device=DEV)
+    qoff = torch.zeros(1, dtype=torch.int32, device=DEV)
+    idx, d2 = hip.knn_query(8, xyz, q0, off, qoff)
+    assert idx.shape == (0, 8) and d2.shape == (0, 8)
+    bi, bd = hip.ball_query(8, 0.5, 0.0, xyz, q0, off, qoff)
+    assert bi.shape == (0, 8)
+    feat = torch.randn(300, 16, device=DEV)
+    e_idx = torch.zeros(0, 8, dtype=torch.int32, device=DEV)
+    assert hip.grouping_forward(feat, e_idx).shape == (0, 8, 16)
+    assert hip.group_forward(feat, xyz, q0, e_idx, True).shape == (0, 8, 19)
+    assert torch.count_nonzero(hip.grouping_backward(torch.zeros(0, 8, 16, device=DEV), e_idx, 300)) == 0
+    e3 = torch.zeros(0, 3, dtype=torch.int32, device=DEV)
+    assert hip.interpolation_forward(feat, e3, torch.zeros(0, 3, device=DEV)).shape == (0, 16)
+    assert hip.subtraction_forward(torch.zeros(0, 16, device=DEV), feat, e_idx).shape == (0, 8, 16)
+    assert hip.aggregation_forward(feat, torch.zeros(0, 8, 16, device=DEV), torch.zeros(0, 8, 2, device=DEV), e_idx).shape == (0, 16)
+    torch.cuda.synchronize()
