@@ -288,6 +288,13 @@ int pdf_attention_step2_with_rel_pos_value_backward_v2_l(int N, int M, int h, in
                                                          const float *table, const int *rel_idx, float *grad_attn, float *grad_v,
                                                          float *grad_table, void *stream);
 
+/* ---- GridSample voxel keys: replaces the numpy front half of pointcept/datasets/transform.py:813-823 and
+ * fnv_hash_vec (:911-925) for a batch of scenes.  coord (n,3) f32, offset (b) cumulative ends, min_grid (b,3) int64 = per-scene
+ * floor(min coord / grid) -> grid (n,3) int64 scene-relative voxel coordinates, key (n) uint64 FNV keys.  f32 = 0: float64
+ * division (NumPy >= 2 promotion), f32 = 1: float32 division (NumPy 1.x). */
+int pdf_grid_hash(long n, int b, const float *coord, const int *offset, double gx, double gy, double gz, int f32,
+                  const long long *min_grid, long long *grid, unsigned long long *key, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,7 @@ c_int = ctypes.c_int
 c_long = ctypes.c_long
 c_void_p = ctypes.c_void_p
 c_float = ctypes.c_float
+c_double = ctypes.c_double
 
 # name -> argument kinds ("i" int, "l" long, "f" float, "p" pointer); the stream pointer is appended for HIP.
 _PROTOS = {
@@ -47,6 +48,7 @@ _PROTOS = {
     "attention_step2_with_rel_pos_value_backward_v2": "iiiiipppppppppp",
 }
 _HIP_ONLY_PROTOS = {
+    "grid_hash": "lippdddippp",
     "dot_prod_with_idx_forward_v3_l": "iiiiipppppppp",
     "dot_prod_with_idx_backward_v3_l": "iiiiipppppppppppp",
     "attention_step2_with_rel_pos_value_backward_v2_l": "iiiiipppppppppp",
@@ -55,7 +57,7 @@ _HIP_ONLY_PROTOS = {
     "interpolation_weights": "iipp",
     "farthest_point_sampling_bucketed": "iiipppplp",
 }
-_KIND = {"i": c_int, "l": c_long, "f": c_float, "p": c_void_p}
+_KIND = {"i": c_int, "l": c_long, "f": c_float, "d": c_double, "p": c_void_p}
 
 
 class PdfOpsError(RuntimeError):
@@ -713,6 +715,17 @@ class HipBackend(CBackend):
         if rc != 0:
             raise PdfOpsError(f"pdf_bn_act_backward failed with status {rc}")
         return gx, gres, sums[c:], sums[:c]  # gx, gres, d gamma, d beta
+
+    def grid_hash(self, coord, offset, grid_size, min_grid, float32_division=False):
+        """-> grid (n,3) int64 scene-relative voxel coordinates, key (n) int64 holding the uint64 FNV key bits.
+        GridSample front half, pointcept/datasets/transform.py:813-823, 911-925."""
+        _check(coord, torch.float32, "coord"); _check(offset, torch.int32, "offset"); _check(min_grid, torch.int64, "min_grid")
+        n = coord.shape[0]
+        grid = self._new(coord, (n, 3), torch.int64)
+        key = self._new(coord, (n,), torch.int64)
+        gx, gy, gz = (float(g) for g in grid_size)
+        self._call("grid_hash", n, offset.shape[0], coord, offset, gx, gy, gz, 1 if float32_division else 0, min_grid, grid, key)
+        return grid, key
 
     def group_forward(self, feat, xyz, new_xyz, idx, with_xyz):
         _check(feat, torch.float32, "feat"); _check(idx, torch.int32, "idx")

@@ -491,6 +491,43 @@ def run_pointops2_cases(ref_p2):
     return out
 
 
+def dense_scene(seed, n, room=(6.0, 4.0, 2.5)):
+    """Raw (pre-voxelisation) points of one scene: dense samples of a box shell with negative coordinates included."""
+    rng = np.random.default_rng(seed)
+    c = rng.random((n, 3)) * np.array(room) - np.array([1.0, 0.5, 0.25])
+    face = rng.integers(0, 3, n)
+    c[np.arange(n), face] = np.where(rng.random(n) < 0.5, -np.array([1.0, 0.5, 0.25])[face], (np.array(room) - np.array([1.0, 0.5, 0.25]))[face])
+    return c.astype(np.float32)
+
+
+GRID_CASES = {"a": (31, 60000, 0.05), "b": (32, 25000, 0.02), "c": (33, 7, 0.5)}
+
+
+def run_gridsample_cases():
+    """The reference's own GridSample (pointcept/datasets/transform.py:786-925) on raw scenes: uint64 keys, grid coordinates,
+    voxel partition (inverse), counts.  The kept point per voxel is NOT stored (np.argsort is unstable and train mode draws from
+    np.random): tests check membership instead."""
+    spec = importlib.util.spec_from_file_location("ref_transform", os.path.join(REF, "pointcept", "datasets", "transform.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["ref_transform"] = mod
+    spec.loader.exec_module(mod)
+    out = {}
+    for tag, (seed, n, gs) in GRID_CASES.items():
+        coord = dense_scene(seed, n)
+        t = mod.GridSample(grid_size=gs, hash_type="fnv", mode="train", keys=("coord", "index"), return_inverse=True, return_grid_coord=True)
+        np.random.seed(seed)
+        d = t(dict(coord=coord.copy(), index=np.arange(n)))
+        scaled = coord / np.array(gs)
+        grid = np.floor(scaled).astype(int)
+        grid -= grid.min(0)
+        out[f"{tag}_key"] = mod.GridSample.fnv_hash_vec(grid)
+        out[f"{tag}_inverse"] = d["inverse"]
+        out[f"{tag}_kept_index"] = d["index"]
+        out[f"{tag}_kept_grid"] = d["grid_coord"]
+        out[f"{tag}_division_dtype"] = np.array(str(scaled.dtype))
+    return out
+
+
 def run_hook_case(hook):
     """BaseModelHook on a toy module: forward/backward capture + clone semantics."""
     torch.manual_seed(3)
@@ -509,12 +546,16 @@ def run_hook_case(hook):
 
 def main():
     ref_pointops, seg, rec, hook, losses = install_reference()
-    if "--only-pointops2" not in sys.argv:
+    if "--only-pointops2" not in sys.argv and "--only-gridsample" not in sys.argv:
         np.savez_compressed(os.path.join(OUT, "ops_ball_ref.npz"), **run_ball_cases(ref_pointops))
     if "--only-ball" in sys.argv:
         return
-    np.savez_compressed(os.path.join(OUT, "ops_pointops2_ref.npz"), **run_pointops2_cases(install_reference_pointops2()))
+    if "--only-gridsample" not in sys.argv:
+        np.savez_compressed(os.path.join(OUT, "ops_pointops2_ref.npz"), **run_pointops2_cases(install_reference_pointops2()))
     if "--only-pointops2" in sys.argv:
+        return
+    np.savez_compressed(os.path.join(OUT, "ops_gridsample_ref.npz"), **run_gridsample_cases())
+    if "--only-gridsample" in sys.argv:
         return
     np.savez_compressed(os.path.join(OUT, "ops_python_ref.npz"), **run_op_cases(ref_pointops))
     np.savez_compressed(os.path.join(OUT, "model_hook_ref.npz"), **run_hook_case(hook))
