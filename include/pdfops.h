@@ -295,6 +295,12 @@ int pdf_attention_step2_with_rel_pos_value_backward_v2_l(int N, int M, int h, in
 int pdf_grid_hash(long n, int b, const float *coord, const int *offset, double gx, double gy, double gz, int f32,
                   const long long *min_grid, long long *grid, unsigned long long *key, void *stream);
 
+/* ---- test-time fragment voting (pointcept/engines/test.py:218-229, 243-251): pred[index[r], :] +=
+ * softmax(logits[r, :]); score_sum[index[r]] += score[r]; score_cnt[index[r]] += 1.  index (n) int64, distinct within a call
+ * (one point per voxel of a GridSample test fragment); score may be NULL. */
+int pdf_vote_accumulate(long n, int c, const float *logits, const float *score, const long *index, float *pred,
+                        float *score_sum, float *score_cnt, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

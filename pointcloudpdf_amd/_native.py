@@ -49,6 +49,7 @@ _PROTOS = {
 }
 _HIP_ONLY_PROTOS = {
     "grid_hash": "lippdddippp",
+    "vote_accumulate": "lipppppp",
     "dot_prod_with_idx_forward_v3_l": "iiiiipppppppp",
     "dot_prod_with_idx_backward_v3_l": "iiiiipppppppppppp",
     "attention_step2_with_rel_pos_value_backward_v2_l": "iiiiipppppppppp",
@@ -726,6 +727,18 @@ class HipBackend(CBackend):
         gx, gy, gz = (float(g) for g in grid_size)
         self._call("grid_hash", n, offset.shape[0], coord, offset, gx, gy, gz, 1 if float32_division else 0, min_grid, grid, key)
         return grid, key
+
+    def vote_accumulate(self, logits, score, index, pred, score_sum, score_cnt):
+        """One test-time fragment into the running vote (engines/test.py:218-229, 243-251); index entries must be distinct."""
+        _check(logits, torch.float32, "logits"); _check(index, torch.int64, "index"); _check(pred, torch.float32, "pred")
+        if score is not None:
+            _check(score, torch.float32, "score"); _check(score_sum, torch.float32, "score_sum"); _check(score_cnt, torch.float32, "score_cnt")
+        n, c = logits.shape
+        if pred.shape[1] != c:
+            raise ValueError("pred and logits disagree on the number of classes")
+        nul = ctypes.c_void_p(None)
+        self._call("vote_accumulate", n, c, logits, nul if score is None else score, index, pred,
+                   nul if score is None else score_sum, nul if score is None else score_cnt)
 
     def group_forward(self, feat, xyz, new_xyz, idx, with_xyz):
         _check(feat, torch.float32, "feat"); _check(idx, torch.int32, "idx")

@@ -50,7 +50,39 @@ __global__ __launch_bounds__(LB) void k_ce_bwd(long total, float *__restrict__ g
     for (long e = (long)blockIdx.x * LB + threadIdx.x; e < total; e += (long)gridDim.x * LB) grad[e] *= scale;
 }
 
+// Test-time fragment voting (engines/test.py:218-229, 243-251): pred[index[r], :] += softmax(logits[r, :]) and the running
+// sum / count behind scatter_mean(score, index).  The points of ONE fragment are distinct (one per voxel), so a call needs no
+// atomics; fragments are accumulated by successive calls on the same stream.  lane = row, logits in registers.
+__global__ __launch_bounds__(LB) void k_vote(long n, int c, const float *__restrict__ logits, const float *__restrict__ score,
+                                             const long *__restrict__ index, float *__restrict__ pred, float *__restrict__ score_sum,
+                                             float *__restrict__ score_cnt) {
+    for (long r = (long)blockIdx.x * LB + threadIdx.x; r < n; r += (long)gridDim.x * LB) {
+        const float *x = logits + r * c;
+        float m = x[0];
+        for (int j = 1; j < c; ++j) m = fmaxf(m, x[j]);
+        float s = 0.f;
+        for (int j = 0; j < c; ++j) s += __expf(x[j] - m);
+        const float inv = 1.f / s;
+        const long dst = index[r];
+        float *p = pred + dst * c;
+        for (int j = 0; j < c; ++j) p[j] += __expf(x[j] - m) * inv;
+        if (score) { score_sum[dst] += score[r]; score_cnt[dst] += 1.f; }
+    }
+}
+
 }  // namespace
+
+// pred (N_full, c), score_sum / score_cnt (N_full) accumulate one fragment: logits (n, c), score (n) or NULL, index (n) int64 with
+// DISTINCT entries.  Replaces the python accumulation of engines/test.py:218-229 + the scatter_mean inputs of :243-251.
+extern "C" int pdf_vote_accumulate(long n, int c, const float *logits, const float *score, const long *index, float *pred,
+                                   float *score_sum, float *score_cnt, void *stream) {
+    if (n == 0) return PDF_OK;
+    if (n < 0 || c < 1 || !logits || !index || !pred || (score && (!score_sum || !score_cnt))) return PDF_ERR_BAD_ARG;
+    long g = (n + LB - 1) / LB;
+    if (g > 2048) g = 2048;
+    k_vote<<<(unsigned)g, LB, 0, static_cast<hipStream_t>(stream)>>>(n, c, logits, score, index, pred, score_sum, score_cnt);
+    return pdf_launch_status();
+}
 
 // loss (1 float) = mean over rows with target != ignore of -log softmax(logits)[target]; grad (n*c) receives softmax - onehot;
 // acc (2 floats) receives [sum, count] (zeroed here).
