@@ -528,6 +528,57 @@ def run_gridsample_cases():
     return out
 
 
+def pseudo_label_scene(seed, n):
+    """A scene with a smooth low-confidence blob: coordinates from the synthetic generator, 20-class logits that are confident
+    everywhere except around one furniture-sized region."""
+    sc = synthetic.make_scene(n, scene_id=seed, kind="scannet")
+    coord = torch.from_numpy(sc["coord"])
+    g = torch.Generator().manual_seed(seed)
+    centre = coord[torch.randint(0, n, (1,), generator=g)]
+    d = torch.norm(coord - centre, dim=-1)
+    conf = 6.0 * torch.sigmoid((d - 0.8) * 4.0) + 0.3 * torch.randn(n, generator=g)       # low near the centre
+    logits = 0.2 * torch.randn(n, 20, generator=g)
+    cls = (coord[:, 0] * 3).long() % 20
+    logits[torch.arange(n), cls] += conf
+    return coord, logits
+
+
+PSEUDO_CASES = {"s1": (5, 6000), "s2": (9, 9000)}
+PSEUDO_KW = dict(condition_from="msp", beta=1.5, seed_from="ml", seed_range=0.15, num_seed=100, slide_window=True)
+
+
+def run_pseudo_label_cases():
+    """The reference's OWN PointPdfV1.pseudo_labeling (pointpdf_v1m1_base.py:187-382) on CPU tensors, with the neighbour table
+    supplied by the oracle's radius query (first 64 points in index order within 0.1 m) and seeded torch / numpy generators."""
+    sys.modules.setdefault("torch_points_kernels", types.ModuleType("torch_points_kernels"))
+    viz = types.ModuleType("pointcept.utils.visualization")
+    viz.save_point_cloud = lambda *a, **k: None
+    sys.modules["pointcept.utils.visualization"] = viz
+    for pkg in ["pointcept.recognizers.ours"]:
+        m = types.ModuleType(pkg)
+        m.__path__ = [os.path.join(REF, *pkg.split("."))]
+        sys.modules[pkg] = m
+    name = "pointcept.recognizers.ours.pointpdf_v1m1_base"
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, *name.split(".")) + ".py")
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    be = oracle.backend()
+    out = {}
+    for tag, (seed, n) in PSEUDO_CASES.items():
+        coord, logits = pseudo_label_scene(seed, n)
+        off = torch.tensor([n], dtype=torch.int32)
+        nn, _ = be.ball_query(64, 0.1, 0.0, coord.contiguous(), coord.contiguous(), off, off, order=torch.arange(n, dtype=torch.int32))
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        mask = mod.PointPdfV1.pseudo_labeling(coord, logits, nn.long(), PSEUDO_KW["condition_from"], PSEUDO_KW["beta"], PSEUDO_KW["seed_from"],
+                                              PSEUDO_KW["seed_range"], PSEUDO_KW["num_seed"], PSEUDO_KW["slide_window"])
+        out[f"{tag}_mask"] = mask.numpy()
+        out[f"{tag}_nn_rows"] = nn[:50].numpy()
+        print("pseudo", tag, int(mask.sum()), "of", n)
+    return out
+
+
 def run_hook_case(hook):
     """BaseModelHook on a toy module: forward/backward capture + clone semantics."""
     torch.manual_seed(3)
@@ -546,16 +597,20 @@ def run_hook_case(hook):
 
 def main():
     ref_pointops, seg, rec, hook, losses = install_reference()
-    if "--only-pointops2" not in sys.argv and "--only-gridsample" not in sys.argv:
+    if "--only-pointops2" not in sys.argv and "--only-gridsample" not in sys.argv and "--only-pseudo" not in sys.argv:
         np.savez_compressed(os.path.join(OUT, "ops_ball_ref.npz"), **run_ball_cases(ref_pointops))
     if "--only-ball" in sys.argv:
         return
-    if "--only-gridsample" not in sys.argv:
+    if "--only-gridsample" not in sys.argv and "--only-pseudo" not in sys.argv:
         np.savez_compressed(os.path.join(OUT, "ops_pointops2_ref.npz"), **run_pointops2_cases(install_reference_pointops2()))
     if "--only-pointops2" in sys.argv:
         return
-    np.savez_compressed(os.path.join(OUT, "ops_gridsample_ref.npz"), **run_gridsample_cases())
+    if "--only-pseudo" not in sys.argv:
+        np.savez_compressed(os.path.join(OUT, "ops_gridsample_ref.npz"), **run_gridsample_cases())
     if "--only-gridsample" in sys.argv:
+        return
+    np.savez_compressed(os.path.join(OUT, "ops_pseudo_label_ref.npz"), **run_pseudo_label_cases())
+    if "--only-pseudo" in sys.argv:
         return
     np.savez_compressed(os.path.join(OUT, "ops_python_ref.npz"), **run_op_cases(ref_pointops))
     np.savez_compressed(os.path.join(OUT, "model_hook_ref.npz"), **run_hook_case(hook))

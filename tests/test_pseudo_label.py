@@ -1,0 +1,97 @@
+"""the PDF pseudo-label pass.  ``pseudo_label.pseudo_labeling`` against fixtures produced by the REFERENCE's own
+``PointPdfV1.pseudo_labeling`` (tests/golden/ops_pseudo_label_ref.npz: same neighbour table, same torch / numpy seeds) -- exact on
+CPU tensors; on the GPU the same algorithm runs on device tensors (float rounding may move a top-k boundary: IoU bound)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+
+PSEUDO_CASES = {"s1": (5, 6000), "s2": (9, 9000)}
+PSEUDO_KW = dict(condition_from="msp", beta=1.5, seed_from="ml", seed_range=0.15, num_seed=100, slide_window=True)
+
+
+def pseudo_label_scene(seed, n):
+    """Same generator as tests/golden/make_golden.py::pseudo_label_scene."""
+    from pointcloudpdf_amd import synthetic
+
+    sc = synthetic.make_scene(n, scene_id=seed, kind="scannet")
+    coord = torch.from_numpy(sc["coord"])
+    g = torch.Generator().manual_seed(seed)
+    centre = coord[torch.randint(0, n, (1,), generator=g)]
+    d = torch.norm(coord - centre, dim=-1)
+    conf = 6.0 * torch.sigmoid((d - 0.8) * 4.0) + 0.3 * torch.randn(n, generator=g)
+    logits = 0.2 * torch.randn(n, 20, generator=g)
+    cls = (coord[:, 0] * 3).long() % 20
+    logits[torch.arange(n), cls] += conf
+    return coord, logits
+
+
+@pytest.fixture(scope="module")
+def gp(golden_dir):
+    return np.load(os.path.join(golden_dir, "ops_pseudo_label_ref.npz"))
+
+
+@pytest.mark.parametrize("tag", sorted(PSEUDO_CASES))
+def test_pseudo_labeling_matches_reference_method(use_oracle, gp, tag):
+    from pointcloudpdf_amd import pseudo_label
+
+    seed, n = PSEUDO_CASES[tag]
+    coord, logits = pseudo_label_scene(seed, n)
+    off = torch.tensor([n], dtype=torch.int32)
+    nn = pseudo_label.radius_neighbors(coord, off, 0.1, 64)          # oracle-backed here: first 64 in index order within 0.1 m
+    assert np.array_equal(nn[:50].numpy(), gp[f"{tag}_nn_rows"])
+    assert (nn[:, 0] >= 0).all()                                      # every point has a neighbour within the radius (itself at least)
+    np.random.seed(seed)
+    mask = pseudo_label.pseudo_labeling(coord, logits, nn, generator=torch.Generator().manual_seed(seed), **PSEUDO_KW)
+    assert mask.dtype == torch.bool and np.array_equal(mask.numpy(), gp[f"{tag}_mask"])
+
+
+@pytest.mark.gpu
+def test_pseudo_mask_on_gpu_batch(gp):
+    """Two scenes as one batch on the device: HIP radius query + device region growing; per-scene masks against the fixtures."""
+    from pointcloudpdf_amd import pseudo_label
+
+    tags = sorted(PSEUDO_CASES)
+    scenes = [pseudo_label_scene(*PSEUDO_CASES[t]) for t in tags]
+    coord = torch.cat([s[0] for s in scenes]).cuda()
+    logits = torch.cat([s[1] for s in scenes]).cuda()
+    sizes = [s[0].shape[0] for s in scenes]
+    off = torch.tensor(np.cumsum(sizes), dtype=torch.int32, device="cuda")
+    nn = pseudo_label.radius_neighbors(coord, off, 0.1, 64)
+    assert np.array_equal(nn[:50].cpu().numpy(), gp[f"{tags[0]}_nn_rows"])
+    start = 0
+    for t, n in zip(tags, sizes):
+        seed = PSEUDO_CASES[t][0]
+        np.random.seed(seed)
+        local = nn[start:start + n].clone()
+        local[local != -1] -= start
+        mask = pseudo_label.pseudo_labeling(coord[start:start + n], logits[start:start + n], local,
+                                            generator=torch.Generator().manual_seed(seed), **PSEUDO_KW).numpy()
+        ref = gp[f"{t}_mask"]
+        inter, union = (mask & ref).sum(), (mask | ref).sum()
+        assert union > 0 and inter / union >= 0.9, (t, int(mask.sum()), int(ref.sum()), inter / union)
+        start += n
+    full = pseudo_label.get_pseudo_mask(coord, logits, off, radius=0.1, max_neighbor=64, generator=torch.Generator().manual_seed(1), **PSEUDO_KW)
+    assert full.shape == (sum(sizes),) and full.dtype == torch.bool and full.is_cuda and 0 < int(full.sum()) < sum(sizes) // 4
+
+
+@pytest.mark.gpu
+def test_training_step_with_the_pseudo_label_pass():
+    """BASELINE config 4: ScanNet-shaped scenes (9 channels, 20 classes), PT-v1 + PDF U-decoder WITH the pseudo-label pass
+    (recognizer settings of configs/scannet/openseg-pt-v1-0-pointpdf-v1m1-base.py:40-58) -- one training step."""
+    from pointcloudpdf_amd import engine, pseudo_label, synthetic
+
+    fn = pseudo_label.make_pseudo_mask_fn(radius=0.02 * 5, max_neighbor=64, **PSEUDO_KW)
+    step = engine.OpenSegStep(in_channels=9, num_classes=20, loss_weight=0.04, pseudo_mask_fn=fn).cuda()
+    synthetic.fill_parameters_deterministic(step, seed=4)
+    step.train()
+    batch = synthetic.make_batch([6000, 5000], first_scene_id=60, kind="scannet", device="cuda", unknown=(4, 7, 14, 16))
+    np.random.seed(0)
+    out = step(batch)
+    out["loss"].backward()
+    assert torch.isfinite(out["loss"]).item() and float(out["recognizer_loss"]) > 0
+    assert all(p.grad is None or torch.isfinite(p.grad).all() for p in step.parameters())
