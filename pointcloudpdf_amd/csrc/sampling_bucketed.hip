@@ -792,8 +792,8 @@ __global__ __launch_bounds__(64 * NW) void k_fps_mw(const int *__restrict__ offs
     unsigned *claimB = reinterpret_cast<unsigned *>(fps_lds + REC2 * nb_cap + REC2 * ns_cap);   // [nb_cap] round tag of the claim
     unsigned *claimS = claimB + nb_cap;                                                          // [ns_cap]
     unsigned *cnt = claimS + ns_cap;                                                             // [4]: n_bk[2], n_sup[2] by round parity
-    float *cent = reinterpret_cast<float *>(cnt + 4);                                            // [3 * KMAX] the round's centres
-    int *cent_n = reinterpret_cast<int *>(cent + 3 * KMAX);                                      // [4]
+    float *cent = reinterpret_cast<float *>(cnt + 4);                                            // [3 * 16] the round's centres
+    int *cent_n = reinterpret_cast<int *>(cent + 3 * 16);                                      // [4]
     unsigned short *blist = reinterpret_cast<unsigned short *>(cent_n + 4);                      // [nb_cap + 64] shared
     unsigned short *slist = blist + nb_cap + 64;                                                 // [ns_cap + 64] shared
     const int psl_stride = ((ns_cap + 63) & ~63) + 64;
@@ -1088,17 +1088,26 @@ extern "C" int pdf_farthest_point_sampling_bucketed(int b, int n, int n_total, c
     // several samples per round (k_fps_multi) when its larger records fit the 160 KB of LDS (scenes up to ~180k points)
     const size_t lds2 = (size_t)(REC2 * nb_cap + REC2 * ns_cap) * 4 + (size_t)(2 * (((ns_cap + 63) & ~63) + 64) + nb_cap + 64) * 2;
     const char *env_k = getenv("PDFOPS_FPS_K");    // tuning knob (samples per round): 1 = the one-sample kernel, 4 or 8
-    const int kmulti = env_k ? atoi(env_k) : 8;
-    // one centre per wave (k_fps_mw<8>): records + claim tags + shared / private lists
-    const size_t lds3 = (size_t)(REC2 * nb_cap + REC2 * ns_cap + nb_cap + ns_cap + 4 + 3 * 8 + 4) * 4 +
-                        (size_t)(nb_cap + 64 + ns_cap + 64 + 8 * (((ns_cap + 63) & ~63) + 64)) * 2;
-    const char *env_mw = getenv("PDFOPS_FPS_MW");   // tuning knob: 0 = k_fps_multi
-    if (kmulti > 1 && (!env_mw || atoi(env_mw) != 0) && lds3 <= 160 * 1024) {
-        if (lds3 > 64 * 1024) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fps_mw<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-            if (e != hipSuccess) return (int)e;
-        }
-        k_fps_mw<8><<<b, 64 * 8, lds3, s>>>(offset, new_offset, pts, kb, meta, idx, nb_cap, stats);
+    const int kmulti = env_k ? atoi(env_k) : (n >= 3072 ? 8 : 1);
+    // one centre per wave (k_fps_mw<NW>): records + claim tags + shared / private lists
+    const char *env_mw = getenv("PDFOPS_FPS_MW");   // tuning knob: 0 = k_fps_multi, 8 / 16 = waves (= centres per round) of k_fps_mw
+    // measured (2 scenes, levels 100k / 25k / 6250 / 1562 points): 16 waves 33.0 / 10.0 / 3.9 / 1.7 ms, 8 waves 41.3 / 10.8 / 3.6 / 1.5 ms,
+    // the one-sample kernel 91 / 20 / 4.9 / 1.2 ms -> by the size of the largest scene
+    const int mw = env_mw ? atoi(env_mw) : (n >= 16384 ? 16 : n >= 3072 ? 8 : 0);
+    const int mww = mw >= 16 ? 16 : 8;
+    const size_t lds3 = (size_t)(REC2 * nb_cap + REC2 * ns_cap + nb_cap + ns_cap + 4 + 3 * 16 + 4) * 4 +
+                        (size_t)(nb_cap + 64 + ns_cap + 64 + mww * (((ns_cap + 63) & ~63) + 64)) * 2;
+    if (kmulti > 1 && mw != 0 && lds3 <= 160 * 1024) {
+#define PDF_LAUNCH_FPS_MW(NW_)                                                                                            \
+    do {                                                                                                                 \
+        if (lds3 > 64 * 1024) {                                                                                          \
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fps_mw<NW_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3); \
+            if (e != hipSuccess) return (int)e;                                                                          \
+        }                                                                                                                \
+        k_fps_mw<NW_><<<b, 64 * NW_, lds3, s>>>(offset, new_offset, pts, kb, meta, idx, nb_cap, stats);                   \
+    } while (0)
+        if (mww == 16) PDF_LAUNCH_FPS_MW(16); else PDF_LAUNCH_FPS_MW(8);
+#undef PDF_LAUNCH_FPS_MW
         return pdf_launch_status();
     }
     if (kmulti > 1 && lds2 <= 160 * 1024) {

@@ -17,7 +17,7 @@ for lvl in range(4):
     noff = torch.tensor(msizes, device="cuda").cumsum(0).int()
     ref = None
     line = []
-    for k, nw, mw in (("1", "4", "0"), ("8", "8", "0"), ("8", "8", "1")):
+    for k, nw, mw in (("1", "4", "0"), ("8", "8", "8"), ("8", "8", "16")):
         os.environ["PDFOPS_FPS_K"] = k; os.environ["PDFOPS_FPS_NW"] = nw; os.environ["PDFOPS_FPS_MW"] = mw
         idx = be.farthest_point_sampling(xyz, off, noff, max(sizes), sum(msizes))
         torch.cuda.synchronize()
