@@ -43,7 +43,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--points", type=int, default=100000, help="points per scene")
+    ap.add_argument("--workload", choices=["s3dis", "scannet"], default="s3dis",
+                    help="s3dis = BASELINE config 2 / 3 (6 input channels, 13 classes, the headline); scannet = config 4 shape (coord + "
+                         "colour + normal = 9 channels, 20 classes, unknown classes {4, 7, 14, 16}, 150k points per scene unless --points)")
+    ap.add_argument("--pseudo-label", type=int, default=0,
+                    help="1 = run the PDF pseudo-label pass inside the step (config 4; recognizer settings of "
+                         "configs/scannet/openseg-pt-v1-0-pointpdf-v1m1-base.py:40-58) instead of the fixed 1-in-7 stand-in mask")
+    ap.add_argument("--points", type=int, default=None, help="points per scene (default 100000, scannet: 150000)")
     ap.add_argument("--scenes", type=int, default=2, help="scenes per GPU (batch size per rank)")
     ap.add_argument("--pool", type=int, default=3, help="distinct batches per rank to rotate through")
     ap.add_argument("--jitter", type=float, default=0.0,
@@ -201,7 +207,15 @@ def main():
     torch.backends.cuda.matmul.allow_tf32 = False
     be = _native.hip_backend()
 
-    step = engine.OpenSegStep().to(dev)
+    scannet = args.workload == "scannet"
+    if args.points is None:
+        args.points = 150000 if scannet else 100000
+    step_kw = dict(in_channels=9, num_classes=20, loss_weight=0.04) if scannet else {}
+    if args.pseudo_label:
+        from pointcloudpdf_amd import pseudo_label
+        step_kw["pseudo_mask_fn"] = pseudo_label.make_pseudo_mask_fn(radius=0.02 * 5, max_neighbor=64, condition_from="msp", beta=1.5,
+                                                                    seed_from="ml", seed_range=0.15, num_seed=100, slide_window=True)
+    step = engine.OpenSegStep(**step_kw).to(dev)
     synthetic.fill_parameters_deterministic(step, seed=1)  # identical "random-init" weights on every rank
     step.train()
     force_dp = bool(os.environ.get("PDFOPS_FORCE_DDP"))   # knob: exercise the N > 1 gradient exchange at world size 1
@@ -217,7 +231,8 @@ def main():
         rng = np.random.default_rng(7919 * rank + i)
         return [int(round(args.points * (1.0 + args.jitter * (2.0 * rng.random() - 1.0)))) for _ in range(args.scenes)]
 
-    pool = [synthetic.make_batch(scene_sizes(i), first_scene_id=1000 * rank + 10 * i, device=dev) for i in range(args.pool)]
+    batch_kw = dict(kind="scannet", unknown=(4, 7, 14, 16)) if scannet else {}
+    pool = [synthetic.make_batch(scene_sizes(i), first_scene_id=1000 * rank + 10 * i, device=dev, **batch_kw) for i in range(args.pool)]
     pool_points = [int(b["coord"].shape[0]) for b in pool]
     timer = KernelTimer(be, ["knn_query", "farthest_point_sampling", "group_forward", "group_backward",
                              "pt_layer_forward", "pt_layer_backward", "bottleneck_forward", "bottleneck_backward"])
@@ -389,8 +404,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f16-autocast" if args.amp else "f32",
             "data": "synthetic",
-            "config": {"workload": f"S3DIS-shaped synthetic voxelised scenes, {args.scenes} x {args.points} points per GPU, "
-                                   "PointTransformer-Seg50 + PointPdf-v1m1 U-decoder, fwd+bwd+SGD, geometry recomputed every step",
+            "config": {"workload": f"{'ScanNet' if scannet else 'S3DIS'}-shaped synthetic voxelised scenes, {args.scenes} x {args.points} points per GPU, "
+                                   "PointTransformer-Seg50 + PointPdf-v1m1 U-decoder, fwd+bwd+SGD, geometry recomputed every step"
+                                   + (", PDF pseudo-label pass inside the step" if args.pseudo_label else ""),
                        "scenes_per_gpu": args.scenes, "points_per_scene": args.points, "size_jitter": args.jitter, "parallelism": f"dp{world}",
                        "gradient_exchange": (args.ddp if use_dp else "none")},
             "per_gpu_points_per_s": pts_per_step * args.steps / dt / world,
@@ -402,14 +418,14 @@ def main():
             "roofline": roof,
             "roofline_gather_family": roof2,
         }
-        if world == 1 and not args.no_ops_roofline:
+        if world == 1 and not args.no_ops_roofline and not scannet:
             # the pointops drop-in ops on their own (level-1 shapes of this config: 200k points, c = 32, k = 8), HIP-event timed on
             # the launching stream, against the 8 TB/s HBM peak with the SURVEY 8(d) byte counts (tools/ops_roofline.py)
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import ops_roofline
             line["roofline_ops"] = [dict(op=r["op"], us=round(r["us"], 1), GBps=round(r["GBps"], 1), frac=round(r["frac"], 4))
                                     for r in ops_roofline.run(iters=10, level2=False, references=False)]
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not scannet:   # (the CPU baseline is quoted on the headline workload)
             line["cpu_baseline"] = cpu_baseline(args.cpu_points)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
