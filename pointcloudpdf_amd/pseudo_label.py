@@ -10,7 +10,7 @@ extra "unknown" label.
 
 What runs where: the neighbour table comes from the HIP radius query (``radius_neighbors``); region growing is torch indexing on the
 device; MST / GMM / connected components stay on scipy / sklearn on the host exactly as upstream (it moves the tensors with .cpu()
-there too) -- they see a few thousand edges.  Upstream spreads scenes over joblib workers; here scenes run one after the other.
+there too) -- they see a few thousand edges.  Upstream spreads scenes over joblib workers; here they run on worker threads.
 
 Parity: ``pseudo_labeling`` is pinned against the reference's OWN static method (tests/golden/ops_pseudo_label_ref.npz, same
 neighbour table, same torch / numpy seeds).  The neighbour table itself replaces ``torch_points_kernels.ball_query(radius,
@@ -121,17 +121,34 @@ def pseudo_labeling(coord, logits, neighbors, condition_from="msp", beta=1.5, se
 
 
 @torch.no_grad()
-def get_pseudo_mask(coord, seg_logits, offset, radius=0.1, max_neighbor=64, neighbors=None, offset_host=None, generator=None, **kw):
+def get_pseudo_mask(coord, seg_logits, offset, radius=0.1, max_neighbor=64, neighbors=None, offset_host=None, generator=None, workers=4, **kw):
     """pointpdf_v1m1_base.py:118-185 for a batch: neighbour table once, scenes one by one; -> bool (N,) on coord's device."""
     if neighbors is None:
         neighbors = radius_neighbors(coord, offset, radius, max_neighbor)
     ends = offset_host if offset_host is not None else [int(v) for v in offset.tolist()]
-    masks, start = [], 0
-    for e in ends:
-        nn = neighbors[start:e].clone()
-        nn[nn != -1] -= start
-        masks.append(pseudo_labeling(coord[start:e], seg_logits[start:e], nn, generator=generator, **kw))
-        start = e
+    starts = [0] + ends[:-1]
+    stream = torch.cuda.current_stream() if coord.is_cuda else None
+
+    def one(se):
+        s0, e = se
+        nn = neighbors[s0:e].clone()
+        nn[nn != -1] -= s0
+        return pseudo_labeling(coord[s0:e], seg_logits[s0:e], nn, generator=generator, **kw)
+
+    def one_on_stream(se):   # worker threads start on the default stream: keep them on the caller's
+        with torch.cuda.stream(stream):
+            return one(se)
+
+    scenes = list(zip(starts, ends))
+    if workers > 1 and len(scenes) > 1 and generator is None:
+        # upstream fans the scenes out over joblib workers (parallel_processing, n_jobs=4); threads here: the scipy / sklearn stage
+        # and the device syncs release the GIL.  Not used with an explicit generator (the draw order would depend on scheduling).
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(max_workers=min(workers, len(scenes))) as ex:
+            masks = list(ex.map(one_on_stream if stream is not None else one, scenes))
+    else:
+        masks = [one(se) for se in scenes]
     return torch.cat(masks).to(coord.device)
 
 
