@@ -162,6 +162,37 @@ def test_fps_full_size_100k(hip, oracle_backend):
     assert f[0] == 0 and f.unique().numel() == f.numel()
 
 
+def test_fps_config4_size_and_kernel_variants(hip):
+    """ScanNet-shaped 150k -> 37.5k (16-wave multi-sample kernel, LDS-resident records near the 160 KB limit) and a 3-scene batch whose
+    scenes fall into the three kernel classes (>= 16k points: 16 waves, >= 3k: 8 waves, below: the one-sample kernel -- chosen by
+    the LARGEST scene) against the plain reference-shaped kernel; every PDFOPS_FPS_MW / PDFOPS_FPS_K variant gives the same indices."""
+    from pointcloudpdf_amd import synthetic
+
+    xyz = torch.from_numpy(synthetic.make_scene(150000, 11, kind="scannet")["coord"]).to(DEV)
+    off, noff = offs([150000]).to(DEV), offs([37500]).to(DEV)
+    hip.fps_mode = "plain"
+    want = hip.farthest_point_sampling(xyz, off, noff, 150000, 37500)
+    hip.fps_mode = "bucketed"
+    try:
+        assert torch.equal(hip.farthest_point_sampling(xyz, off, noff, 150000, 37500), want)
+        sizes, msizes = [20000, 5000, 900], [5000, 1250, 225]
+        pts = torch.cat([torch.from_numpy(synthetic.make_scene(n, 20 + i)["coord"]) for i, n in enumerate(sizes)]).to(DEV)
+        o3, n3 = offs(sizes).to(DEV), offs(msizes).to(DEV)
+        hip.fps_mode = "plain"
+        want3 = hip.farthest_point_sampling(pts, o3, n3, max(sizes), sum(msizes))
+        hip.fps_mode = "bucketed"
+        for env in ({}, {"PDFOPS_FPS_MW": "8"}, {"PDFOPS_FPS_MW": "16"}, {"PDFOPS_FPS_MW": "0"}, {"PDFOPS_FPS_K": "1"}, {"PDFOPS_FPS_MW": "0", "PDFOPS_FPS_K": "4"}):
+            os.environ.update(env)
+            try:
+                got = hip.farthest_point_sampling(pts, o3, n3, max(sizes), sum(msizes))
+            finally:
+                for k_ in env:
+                    os.environ.pop(k_, None)
+            assert torch.equal(got, want3), env
+    finally:
+        hip.fps_mode = "bucketed"
+
+
 # ----------------------------------------------------------------------------------------------- ball queries
 def both_ball(hip, oracle_backend, ns, rmax, rmin, xyz, new_xyz, off, noff, order=None):
     i_o, d_o = oracle_backend.ball_query(ns, rmax, rmin, xyz, new_xyz, off, noff, order=order)
