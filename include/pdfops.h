@@ -301,6 +301,13 @@ int pdf_grid_hash(long n, int b, const float *coord, const int *offset, double g
 int pdf_vote_accumulate(long n, int c, const float *logits, const float *score, const long *index, float *pred,
                         float *score_sum, float *score_cnt, void *stream);
 
+/* Fixed-radius neighbour table of a batch with itself over the kNN grid (cells >= radius): idx (n, nsample) = the first nsample
+ * points of the query's scene in index order within `radius`, -1 / 1e10 padded -- the results of pdf_random_ball_query with the
+ * identity permutation and min_radius 0 (stands in for torch_points_kernels.ball_query(..., mode="partial_dense") in the PDF
+ * pseudo-label pass, pointpdf_v1m1_base.py:122-130).  Workspace: pdf_knn_workspace_bytes(b, n, 0); b <= 64. */
+int pdf_radius_neighbors_self(int n, int nsample, float radius, const float *xyz, const int *offset, int b, int *idx, float *dist2,
+                              void *workspace, long workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

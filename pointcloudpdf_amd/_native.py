@@ -49,6 +49,7 @@ _PROTOS = {
 }
 _HIP_ONLY_PROTOS = {
     "grid_hash": "lippdddippp",
+    "radius_neighbors_self": "iifppipppl",
     "vote_accumulate": "lipppppp",
     "dot_prod_with_idx_forward_v3_l": "iiiiipppppppp",
     "dot_prod_with_idx_backward_v3_l": "iiiiipppppppppppp",
@@ -716,6 +717,20 @@ class HipBackend(CBackend):
         if rc != 0:
             raise PdfOpsError(f"pdf_bn_act_backward failed with status {rc}")
         return gx, gres, sums[c:], sums[:c]  # gx, gres, d gamma, d beta
+
+    def radius_neighbors_self(self, nsample, radius, xyz, offset):
+        """-> idx (n, nsample) int32, dist2 (n, nsample): the first nsample points of the scene in index order within radius."""
+        _check(xyz, torch.float32, "xyz"); _check(offset, torch.int32, "offset")
+        n, b = xyz.shape[0], offset.shape[0]
+        idx = self._new(xyz, (n, nsample), torch.int32)
+        dist2 = self._new(xyz, (n, nsample), torch.float32)
+        if b > 64:   # the grid workspace is sized for <= 64 scenes: in-order scan
+            order = torch.arange(n, dtype=torch.int32, device=xyz.device)
+            return self.ball_query(nsample, radius, 0.0, xyz, xyz, offset, offset, order=order)
+        nbytes = int(self.lib.pdf_knn_workspace_bytes(b, n, 0))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=xyz.device)
+        self._call("radius_neighbors_self", n, int(nsample), float(radius), xyz, offset, b, idx, dist2, ws, nbytes)
+        return idx, dist2
 
     def grid_hash(self, coord, offset, grid_size, min_grid, float32_division=False):
         """-> grid (n,3) int64 scene-relative voxel coordinates, key (n) int64 holding the uint64 FNV key bits.

@@ -52,7 +52,8 @@ __host__ __device__ inline Layout make_layout(int b, int n, int m) {
     return L;
 }
 
-__global__ __launch_bounds__(PB) void k_grid_setup(const float *__restrict__ xyz, const int *__restrict__ offset, SceneGrid *__restrict__ grids, float ppc) {
+__global__ __launch_bounds__(PB) void k_grid_setup(const float *__restrict__ xyz, const int *__restrict__ offset, SceneGrid *__restrict__ grids, float ppc,
+                                                   float min_cell) {
     __shared__ float red[6][PB / 64];
     const int s = blockIdx.x;
     const int start = s == 0 ? 0 : offset[s - 1], end = offset[s];
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(PB) void k_grid_setup(const float *__restrict__ xyz
         // target ~ppc points per cell if the points filled the box; never more than CAP_CELLS cells
         float cell = cbrtf(ext[0] * ext[1] * ext[2] * ppc / (float)(n > 0 ? n : 1));
         const float longest = fmaxf(ext[0], fmaxf(ext[1], ext[2]));
-        cell = fmaxf(cell, longest / 1000.f);
+        cell = fmaxf(fmaxf(cell, longest / 1000.f), min_cell);   // (radius queries ask for cell >= radius: 27 cells cover the ball)
         int nx, ny, nz;
         while (true) {
             nx = (int)(ext[0] / cell) + 1; ny = (int)(ext[1] / cell) + 1; nz = (int)(ext[2] / cell) + 1;
@@ -272,6 +273,92 @@ __global__ __launch_bounds__(PB) void k_grid_query(int m, int b, const float *__
     for (int t = 0; t < K; ++t) { oi[t] = bi[t]; od[t] = bd[t]; }
 }
 
+// ---------------------------------------------------------------- fixed-radius neighbours over the same grid
+// "The first nsample points of the scene, in index order, with d2 < radius^2 (or d2 <= 1e-5), padded with -1" -- the contract of
+// pdf_random_ball_query walked along the identity permutation (the table behind the PDF pseudo-label pass, pseudo_label.py) --
+// for SELF queries, from the 27 cells around the query instead of the whole scene.  One wave per query: the cells' points are
+// read 64 at a time, accepted ones (as-written fp32 distance: same values as the scan) are appended to an LDS list, and the
+// nsample smallest INDICES are selected by rank counting (indices are unique), which also puts them in index order.  A query
+// whose ball holds more than RQ_CAP points falls back to the in-order scan of its scene inside the same wave.
+constexpr int RQ_WAVES = 4, RQ_CAP = 1024;
+
+__global__ __launch_bounds__(64 * RQ_WAVES) void k_grid_radius_self(int n, int b, int nsample, float radius, const float *__restrict__ xyz,
+                                                                    const int *__restrict__ offset, const SceneGrid *__restrict__ grids,
+                                                                    const unsigned *__restrict__ cell_start, const float4 *__restrict__ sorted,
+                                                                    int *__restrict__ idx, float *__restrict__ dist2) {
+    __shared__ int s_idx[RQ_WAVES][RQ_CAP];
+    __shared__ float s_d2[RQ_WAVES][RQ_CAP];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = blockIdx.x * RQ_WAVES + wave;
+    if (q >= n) return;   // wave-uniform, no block barrier below
+    int *ci = s_idx[wave];
+    float *cd = s_d2[wave];
+    const int sc = scene_of(q, offset, b);
+    const SceneGrid g = grids[sc];
+    const float qx = xyz[3 * (size_t)q], qy = xyz[3 * (size_t)q + 1], qz = xyz[3 * (size_t)q + 2];
+    const float r2 = radius * radius;
+    const int cx = cell_coord(qx, g.minx, g.inv_h, g.nx), cy = cell_coord(qy, g.miny, g.inv_h, g.ny), cz = cell_coord(qz, g.minz, g.inv_h, g.nz);
+    int cnt = 0;   // wave-uniform
+    bool overflow = false;
+    for (int dz = -1; dz <= 1 && !overflow; ++dz)
+        for (int dy = -1; dy <= 1 && !overflow; ++dy) {
+            const int y = cy + dy, z = cz + dz;
+            if (y < 0 || y >= g.ny || z < 0 || z >= g.nz) continue;
+            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);           // the three x-cells are contiguous in the sorted copy
+            const int c0 = g.cell_base + (z * g.ny + y) * g.nx + x0;
+            const unsigned beg = cell_start[c0], end = cell_start[c0 + (x1 - x0) + 1];
+            for (unsigned base = beg; base < end; base += 64) {
+                const unsigned p = base + lane;
+                bool ok = false;
+                float d2 = 0.f;
+                int id = -1;
+                if (p < end) {
+                    const float4 v = sorted[p];
+                    id = __float_as_int(v.w);
+                    d2 = (qx - v.x) * (qx - v.x) + (qy - v.y) * (qy - v.y) + (qz - v.z) * (qz - v.z);
+                    ok = d2 <= 1e-5f || d2 < r2;
+                }
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(ok);
+                const int pos = cnt + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                if (ok && pos < RQ_CAP) { ci[pos] = id; cd[pos] = d2; }
+                cnt += __builtin_popcountll(mask);
+                if (cnt > RQ_CAP) { overflow = true; break; }
+            }
+        }
+    int *oi = idx + (size_t)q * nsample;
+    float *od = dist2 + (size_t)q * nsample;
+    if (overflow) {   // in-order scan of the scene (random_ball_query_kernel with the identity permutation)
+        int c2 = 0;
+        for (int base = g.start; base < g.start + g.n && c2 < nsample; base += 64) {
+            const int i = base + lane;
+            bool ok = false;
+            float d2 = 0.f;
+            if (i < g.start + g.n) {
+                const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+                d2 = (qx - x) * (qx - x) + (qy - y) * (qy - y) + (qz - z) * (qz - z);
+                ok = d2 <= 1e-5f || d2 < r2;
+            }
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(ok);
+            const int pos = c2 + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            if (ok && pos < nsample) { oi[pos] = i; od[pos] = d2; }
+            c2 += __builtin_popcountll(mask);
+        }
+        if (c2 > nsample) c2 = nsample;
+        for (int s = c2 + lane; s < nsample; s += 64) { oi[s] = -1; od[s] = 1e10f; }
+        return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // rank of every candidate among the candidates' indices; ranks below nsample are the answer, already in index order
+    for (int c = lane; c < cnt; c += 64) {
+        const int mine = ci[c];
+        int rank = 0;
+        for (int o = 0; o < cnt; ++o) rank += ci[o] < mine ? 1 : 0;
+        if (rank < nsample) { oi[rank] = mine; od[rank] = cd[c]; }
+    }
+    for (int s = min(cnt, nsample) + lane; s < nsample; s += 64) { oi[s] = -1; od[s] = 1e10f; }
+}
+
 }  // namespace kg
 
 extern "C" long pdf_knn_workspace_bytes(int b, int n, int m) {
@@ -308,7 +395,7 @@ extern "C" int pdf_knn_query_ws(int m, int nsample, int n, const float *xyz, con
     // cell size: `ppc` points per cell if the points filled the bounding box (they lie on surfaces, so occupied cells hold more)
     static const float ppc_env = [] { const char *v = getenv("PDFOPS_KNN_PPC"); return v ? (float)atof(v) : 0.f; }();
     const float ppc = ppc_env > 0.f ? ppc_env : 1.0f;   // measured on 12 x 100k-point scenes: 1 beats 4 by 25 % at level 1, equal below
-    kg::k_grid_setup<<<b, kg::PB, 0, s>>>(xyz, offset, grids, ppc);
+    kg::k_grid_setup<<<b, kg::PB, 0, s>>>(xyz, offset, grids, ppc, 0.f);
     kg::k_grid_hist<<<pdf_divup(n, kg::PB), kg::PB, 0, s>>>(n, b, xyz, offset, grids, cell_start, cell_of);
     kg::k_grid_scan<<<b, 1024, 0, s>>>(grids, cell_start);
     kg::k_grid_scatter<<<pdf_divup(n, kg::PB), kg::PB, 0, s>>>(n, xyz, cell_of, cell_start, cursor, sorted);
@@ -329,4 +416,32 @@ extern "C" int pdf_knn_query_ws(int m, int nsample, int n, const float *xyz, con
         fprintf(stderr, "[pdfops] knn grid: m=%d nsample=%d b=%d redo=%d\n", m, nsample, b, cnt);
     }
     return pdf_knn_query_list(m, nsample, xyz, new_xyz, offset, new_offset, b, idx, dist2, redo + 4, redo, stream);
+}
+
+
+// Fixed-radius neighbour table of a batch with itself: idx (n, nsample) = the first nsample points of the query's scene, in index
+// order, within `radius` (the query included), -1 padded; dist2 = squared distances (1e10 padded).  Same results as
+// pdf_random_ball_query with order = identity and min_radius = 0.  Workspace: pdf_knn_workspace_bytes(b, n, 0).
+extern "C" int pdf_radius_neighbors_self(int n, int nsample, float radius, const float *xyz, const int *offset, int b, int *idx,
+                                         float *dist2, void *workspace, long workspace_bytes, void *stream) {
+    if (n == 0) return PDF_OK;
+    if (n < 0 || b < 1 || b > 64 || !xyz || !offset || !idx || !dist2 || !(radius > 0.f)) return PDF_ERR_BAD_ARG;
+    if (nsample < 1 || nsample > kg::RQ_CAP) return PDF_ERR_NSAMPLE;
+    const kg::Layout L = kg::make_layout(b, n, 0);
+    if (!workspace || workspace_bytes < (long)L.total) return PDF_ERR_BAD_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char *ws = static_cast<char *>(workspace);
+    kg::SceneGrid *grids = reinterpret_cast<kg::SceneGrid *>(ws + L.grid);
+    unsigned *cell_start = reinterpret_cast<unsigned *>(ws + L.cell_start);
+    unsigned *cursor = reinterpret_cast<unsigned *>(ws + L.cursor);
+    int *cell_of = reinterpret_cast<int *>(ws + L.cell_of);
+    float4 *sorted = reinterpret_cast<float4 *>(ws + L.sorted);
+    hipError_t e = hipMemsetAsync(ws + L.cell_start, 0, L.cell_of - L.cell_start, s);
+    if (e != hipSuccess) return (int)e;
+    kg::k_grid_setup<<<b, kg::PB, 0, s>>>(xyz, offset, grids, 1.0f, radius * 1.0001f);   // cell >= radius
+    kg::k_grid_hist<<<pdf_divup(n, kg::PB), kg::PB, 0, s>>>(n, b, xyz, offset, grids, cell_start, cell_of);
+    kg::k_grid_scan<<<b, 1024, 0, s>>>(grids, cell_start);
+    kg::k_grid_scatter<<<pdf_divup(n, kg::PB), kg::PB, 0, s>>>(n, xyz, cell_of, cell_start, cursor, sorted);
+    kg::k_grid_radius_self<<<pdf_divup(n, kg::RQ_WAVES), 64 * kg::RQ_WAVES, 0, s>>>(n, b, nsample, radius, xyz, offset, grids, cell_start, sorted, idx, dist2);
+    return pdf_launch_status();
 }

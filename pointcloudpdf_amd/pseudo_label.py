@@ -28,8 +28,11 @@ def radius_neighbors(coord, offset, radius, max_neighbor):
     """-> (N, max_neighbor) int64 neighbour ids (global rows, the point itself included), -1 padded."""
     be = _native.backend_for(coord)
     off = offset.int().contiguous()
-    order = torch.arange(coord.shape[0], dtype=torch.int32, device=coord.device)   # identity permutation: index order
-    idx, _ = be.ball_query(int(max_neighbor), float(radius), 0.0, coord.contiguous(), coord.contiguous(), off, off, order=order)
+    if hasattr(be, "radius_neighbors_self"):       # HIP: 27 grid cells around every point instead of the whole scene (same results)
+        idx, _ = be.radius_neighbors_self(int(max_neighbor), float(radius), coord.contiguous(), off)
+    else:
+        order = torch.arange(coord.shape[0], dtype=torch.int32, device=coord.device)   # identity permutation: index order
+        idx, _ = be.ball_query(int(max_neighbor), float(radius), 0.0, coord.contiguous(), coord.contiguous(), off, off, order=order)
     return idx.long()
 
 

@@ -443,3 +443,19 @@ def test_empty_inputs_are_no_ops(hip):
     assert hip.subtraction_forward(torch.zeros(0, 16, device=DEV), feat, e_idx).shape == (0, 8, 16)
     assert hip.aggregation_forward(feat, torch.zeros(0, 8, 16, device=DEV), torch.zeros(0, 8, 2, device=DEV), e_idx).shape == (0, 16)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("radius,ns,snap", [(0.1, 64, 0), (0.25, 16, 0), (0.3, 64, 4), (1.5, 32, 0), (0.05, 8, 0)])
+def test_radius_neighbors_grid_matches_in_order_scan(hip, radius, ns, snap):
+    """pdf_radius_neighbors_self (27 grid cells, rank selection; radius 1.5 overflows the candidate list -> in-wave scan) against
+    pdf_random_ball_query walked along the identity permutation: indices and squared distances bit for bit, incl. duplicated points
+    (snapped cloud), a 3-point scene and empty balls beyond the point itself."""
+    sizes = [6000, 3, 9000, 800]
+    xyz = cloud(sum(sizes), 51, snap).to(DEV)
+    off = offs(sizes).to(DEV)
+    order = torch.arange(sum(sizes), dtype=torch.int32, device=DEV)
+    i_s, d_s = hip.ball_query(ns, radius, 0.0, xyz, xyz, off, off, order=order)
+    i_g, d_g = hip.radius_neighbors_self(ns, radius, xyz, off)
+    torch.cuda.synchronize()
+    assert torch.equal(i_s, i_g), f"rows differing: {(i_s != i_g).any(1).sum().item()}"
+    assert torch.equal(d_s, d_g)
