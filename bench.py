@@ -30,12 +30,13 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-# HBM traffic per launch from rocprofv3 PMC passes (profiles/r01_g_pmc_{fetch,write}_size.txt: one launch = the 24 scenes of a
+# HBM traffic per launch from rocprofv3 PMC passes (profiles/r01_h_pmc_{fetch,write}_size.txt: one launch = the 24 scenes of a
 # 12-batch group; FETCH_SIZE doubled as the guide prescribes for gfx950, KB -> bytes, averaged over the launches of the profiled
-# run like `achieved`).  FPS (k_fps_mw): 10,418 KB fetch (x2) + 48,576 KB write -- the tmp-distance stores of the touched buckets.
+# run like `achieved`).  FPS (k_fps_mw<16> / <8> / k_fps<4> by level): 9,498 KB fetch (x2) + 49,096 KB write on average -- the
+# tmp-distance stores of the touched buckets.
 # Bottleneck backward: sum over the kernels that only run in backward passes (k_b*, k_wg, k_bn_bwd_*, k_colsum: 19.06 GB per step in
-# the same PMC passes; a few of their launches belong to the Linear-BN nodes outside the Bottlenecks) / 18 calls per step.
-PMC_TRAFFIC_BYTES = {"farthest_point_sampling": (2 * 10417.7 + 48575.9) * 1024, "bottleneck_backward": 19063.8e6 / 18}
+# the r01_g PMC passes; a few of their launches belong to the Linear-BN nodes outside the Bottlenecks) / 18 calls per step.
+PMC_TRAFFIC_BYTES = {"farthest_point_sampling": (2 * 9498.0 + 49096.0) * 1024, "bottleneck_backward": 19063.8e6 / 18}
 
 
 def parse():
