@@ -308,6 +308,13 @@ int pdf_vote_accumulate(long n, int c, const float *logits, const float *score, 
 int pdf_radius_neighbors_self(int n, int nsample, float radius, const float *xyz, const int *offset, int b, int *idx, float *dist2,
                               void *workspace, long workspace_bytes, void *stream);
 
+/* Softmax over the edges of every query, per head (x, y: (M, h); index0_offsets: N + 1 entries; h <= 64): stands in for
+ * torch_scatter.scatter_softmax(src, index_0, dim=0) in WindowAttention.forward (stratified_transformer_v1m1_origin.py:322-324;
+ * torch_scatter is an unvendored dependency).  backward: grad_x = y * (grad_y - sum over the query of y * grad_y). */
+int pdf_segment_softmax_forward(int N, int M, int h, const int *index0_offsets, const float *x, float *y, void *stream);
+int pdf_segment_softmax_backward(int N, int M, int h, const int *index0_offsets, const float *y, const float *grad_y, float *grad_x,
+                                 void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -658,3 +658,34 @@ int oracle_attention_step2_with_rel_pos_value_backward_v2(int N, int M, int h, i
         }
     return 0;
 }
+
+
+/* torch_scatter.scatter_softmax(src, index, dim=0) for a CSR-ordered index (third-party, unvendored and unversioned in the reference:
+ * README.md:105 installs it through torch-points3d's dependencies; published algorithm: per group, exp(x - max) / sum).  Used at
+ * pointcept/models/stratified_transformer/stratified_transformer_v1m1_origin.py:322-324.  "Parity unpinned" (no reference vectors). */
+int oracle_segment_softmax_forward(int N, int M, int h, const int *index0_offsets, const float *x, float *y)
+{
+    (void)M;
+    for (int q = 0; q < N; q++)
+        for (int hh = 0; hh < h; hh++) {
+            const int start = index0_offsets[q], end = index0_offsets[q + 1];
+            float mx = -3.0e38f, sum = 0;
+            for (int m = start; m < end; m++) mx = x[(size_t)m * h + hh] > mx ? x[(size_t)m * h + hh] : mx;
+            for (int m = start; m < end; m++) sum += expf(x[(size_t)m * h + hh] - mx);
+            for (int m = start; m < end; m++) y[(size_t)m * h + hh] = expf(x[(size_t)m * h + hh] - mx) / sum;
+        }
+    return 0;
+}
+
+int oracle_segment_softmax_backward(int N, int M, int h, const int *index0_offsets, const float *y, const float *grad_y, float *grad_x)
+{
+    (void)M;
+    for (int q = 0; q < N; q++)
+        for (int hh = 0; hh < h; hh++) {
+            const int start = index0_offsets[q], end = index0_offsets[q + 1];
+            float dot = 0;
+            for (int m = start; m < end; m++) dot += y[(size_t)m * h + hh] * grad_y[(size_t)m * h + hh];
+            for (int m = start; m < end; m++) grad_x[(size_t)m * h + hh] = y[(size_t)m * h + hh] * (grad_y[(size_t)m * h + hh] - dot);
+        }
+    return 0;
+}

@@ -46,6 +46,8 @@ _PROTOS = {
     "dot_prod_with_idx_backward_v3": "iiiiipppppppppppp",
     "attention_step2_with_rel_pos_value_forward_v2": "iiiiippppppp",
     "attention_step2_with_rel_pos_value_backward_v2": "iiiiipppppppppp",
+    "segment_softmax_forward": "iiippp",
+    "segment_softmax_backward": "iiipppp",
 }
 _HIP_ONLY_PROTOS = {
     "grid_hash": "lippdddippp",
@@ -349,6 +351,24 @@ class CBackend:
                    else ("attention_step2_with_rel_pos_value_backward_v2", int(n_max)))
         self._call(name, n, m, h, d, x, grad_out, offsets, index1, attn, v, table, rel_idx, ga, gv, gt)
         return ga, gv, gt
+
+
+    def segment_softmax(self, x, offsets):
+        """-> y (M, h): softmax over the edges of every query, per head (scatter_softmax for a CSR-ordered index)."""
+        _check(x, torch.float32, "src"); _check(offsets, torch.int32, "index0_offsets")
+        m, h = x.shape
+        if h > 64:
+            raise ValueError("segment_softmax: at most 64 heads")
+        y = self._new(x, (m, h), torch.float32)
+        self._call("segment_softmax_forward", offsets.shape[0] - 1, m, h, offsets, x, y)
+        return y
+
+    def segment_softmax_backward(self, y, grad_y, offsets):
+        _check(grad_y, torch.float32, "grad_output")
+        m, h = y.shape
+        gx = self._new(y, (m, h), torch.float32)
+        self._call("segment_softmax_backward", offsets.shape[0] - 1, m, h, offsets, y, grad_y, gx)
+        return gx
 
 
 class HipBackend(CBackend):

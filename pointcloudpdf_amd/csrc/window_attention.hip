@@ -507,6 +507,45 @@ __global__ __launch_bounds__(WB) void k_step2rv_bwd_m16(int N, int h, int L, con
     }
 }
 
+
+// ---------------------------------------------------------------- segment softmax over the edges of a query
+// StratifiedTransformer normalises the attention logits per query and head with torch_scatter.scatter_softmax(src, index_0, dim=0)
+// (stratified_transformer_v1m1_origin.py:322-324; torch_scatter is an unvendored dependency, absent here): y[m,h] =
+// exp(x[m,h] - max_q) / sum_q over the edges m of query q.  With the CSR offsets the op is one pass per query: lane = (query slot,
+// head) with HP = next power of two >= h heads per slot, so a wave carries 64 / HP queries and walks their edge lists in lockstep
+// (rows of h consecutive floats: coalesced); max, sum and the write are three sweeps over <= n_max edges.
+__global__ __launch_bounds__(WB) void k_seg_softmax_fwd(int N, int h, int HP, const int *__restrict__ offsets, const float *__restrict__ x,
+                                                        float *__restrict__ y) {
+    const int per_wave = 64 / HP;
+    const int lane = threadIdx.x & 63, slot = lane / HP, hh = lane - slot * HP;
+    const long wave = ((long)blockIdx.x * WB + threadIdx.x) >> 6;
+    const long q = wave * per_wave + slot;
+    if (q >= N || hh >= h) return;
+    const int start = offsets[q], end = offsets[q + 1];
+    float mx = -3.0e38f;
+    for (int m = start; m < end; ++m) mx = fmaxf(mx, x[(size_t)m * h + hh]);
+    float sum = 0.f;
+    for (int m = start; m < end; ++m) sum += __expf(x[(size_t)m * h + hh] - mx);
+    const float inv = 1.f / sum;
+    for (int m = start; m < end; ++m) y[(size_t)m * h + hh] = __expf(x[(size_t)m * h + hh] - mx) * inv;
+}
+
+// gx = y * (gy - sum_q y * gy)
+__global__ __launch_bounds__(WB) void k_seg_softmax_bwd(int N, int h, int HP, const int *__restrict__ offsets, const float *__restrict__ y,
+                                                        const float *__restrict__ gy, float *__restrict__ gx) {
+    const int per_wave = 64 / HP;
+    const int lane = threadIdx.x & 63, slot = lane / HP, hh = lane - slot * HP;
+    const long wave = ((long)blockIdx.x * WB + threadIdx.x) >> 6;
+    const long q = wave * per_wave + slot;
+    if (q >= N || hh >= h) return;
+    const int start = offsets[q], end = offsets[q + 1];
+    float dot = 0.f;
+    for (int m = start; m < end; ++m) dot += y[(size_t)m * h + hh] * gy[(size_t)m * h + hh];
+    for (int m = start; m < end; ++m) gx[(size_t)m * h + hh] = y[(size_t)m * h + hh] * (gy[(size_t)m * h + hh] - dot);
+}
+
+static inline int heads_pow2(int h) { int p = 1; while (p < h) p <<= 1; return p; }
+
 static inline bool pow2_le64(int d) { return d >= 1 && d <= 64 && (d & (d - 1)) == 0; }
 
 static inline int bad_shape(int N, int M, int h, int C) { return N < 0 || M < 0 || h < 1 || C < 1 || C % h != 0; }
@@ -662,5 +701,27 @@ extern "C" int pdf_attention_step2_with_rel_pos_value_backward_v2_l(int N, int M
         return pdf_launch_status();
     }
     k_step2rv_bwd_h<<<grid, WB, lds, st>>>(N, h, hdim, L, grad_out, index0_offsets, index1, attn, v, table, rel_idx, grad_attn, grad_v, grad_table);
+    return pdf_launch_status();
+}
+
+
+// Softmax over the edges of every query, per head: x, y (M, h); index0_offsets (N + 1).  Replaces torch_scatter.scatter_softmax
+// (src, index_0, dim=0) at stratified_transformer_v1m1_origin.py:322-324 for a CSR-ordered edge list.  h <= 64.
+extern "C" int pdf_segment_softmax_forward(int N, int M, int h, const int *index0_offsets, const float *x, float *y, void *stream) {
+    if (N == 0 || M == 0) return PDF_OK;
+    if (N < 0 || M < 0 || h < 1 || h > 64 || !index0_offsets || !x || !y) return PDF_ERR_BAD_ARG;
+    const int hp = heads_pow2(h), per_wave = 64 / hp;
+    const long waves = ((long)N + per_wave - 1) / per_wave;
+    k_seg_softmax_fwd<<<pdf_divup(waves * 64, WB), WB, 0, static_cast<hipStream_t>(stream)>>>(N, h, hp, index0_offsets, x, y);
+    return pdf_launch_status();
+}
+
+extern "C" int pdf_segment_softmax_backward(int N, int M, int h, const int *index0_offsets, const float *y, const float *grad_y, float *grad_x,
+                                            void *stream) {
+    if (N == 0 || M == 0) return PDF_OK;
+    if (N < 0 || M < 0 || h < 1 || h > 64 || !index0_offsets || !y || !grad_y || !grad_x) return PDF_ERR_BAD_ARG;
+    const int hp = heads_pow2(h), per_wave = 64 / hp;
+    const long waves = ((long)N + per_wave - 1) / per_wave;
+    k_seg_softmax_bwd<<<pdf_divup(waves * 64, WB), WB, 0, static_cast<hipStream_t>(stream)>>>(N, h, hp, index0_offsets, y, grad_y, grad_x);
     return pdf_launch_status();
 }

@@ -187,3 +187,24 @@ def attention_step2(attn, v, index0, index1):
 
 
 attention_step2_v2 = attention_step2   # pointops.py:338-404: same semantics, different upstream launch shape
+
+
+# ---- softmax over the edges of a query (torch_scatter.scatter_softmax(src, index_0, dim=0) for a CSR-ordered edge list) ----
+class SegmentSoftmax(Function):
+    """stratified_transformer_v1m1_origin.py:322-324; torch_scatter is an unvendored dependency of the reference, absent here."""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, src, index0_offsets):
+        y = _be(src).segment_softmax(src.contiguous(), index0_offsets.contiguous())
+        ctx.save_for_backward(y, index0_offsets)
+        return y
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, grad_output):
+        y, offsets = ctx.saved_tensors
+        return _be(y).segment_softmax_backward(y, grad_output.contiguous(), offsets), None
+
+
+segment_softmax = SegmentSoftmax.apply

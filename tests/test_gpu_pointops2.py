@@ -82,3 +82,14 @@ def test_v1_edge_list_forms_on_gpu(p2):
     ours, dense = run_edge_list_ops(p2, G, dev="cuda"), run_edge_list_ops(DenseEdgeListV1, G, dev="cuda")
     for key in ours:
         assert_close(ours[key], dense[key], 1e-4, key)
+
+
+def test_window_attention_module_on_gpu(p2):
+    """The reference's WindowAttention block (stage-1 shape of the S3DIS config: dim 48, 3 heads, window 0.4 m ... scaled down) on the HIP
+    kernels against the dense restatement with shared parameters: output, input gradient and all seven parameter gradients."""
+    from test_pointops2_cpu import DenseWindowAttention, run_window_attention, window_attention_case
+
+    mod, args = window_attention_case(dev="cuda", seed=4, n=6000, dim=96, heads=6, max_deg=60)
+    ours, dense = run_window_attention(mod, DenseWindowAttention(mod), args)
+    for key in ours:
+        assert_close(ours[key], dense[key], 2e-4, key)

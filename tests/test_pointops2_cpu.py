@@ -200,3 +200,87 @@ def test_v1_edge_list_forms_match_dense_formulas(use_oracle):
     assert set(ours) == set(dense)
     for key in ours:
         assert_close(ours[key], dense[key], 2e-5, key)
+
+
+def dense_segment_softmax(x, off):
+    idx0 = DenseEdgeList._index0(off)
+    n = off.shape[0] - 1
+    mx = torch.full((n, x.shape[1]), -3.0e38, dtype=x.dtype, device=x.device).scatter_reduce(0, idx0[:, None].expand_as(x), x, "amax")
+    e = torch.exp(x - mx[idx0])
+    return e / torch.zeros_like(mx).index_add(0, idx0, e)[idx0]
+
+
+def test_segment_softmax_matches_dense_formula(use_oracle):
+    G = window_graph(*WINDOW_CASES["h3d16"])
+    x = torch.randn(G["m"], 3, generator=torch.Generator().manual_seed(8)).requires_grad_(True)
+    y = p2.segment_softmax(x, G["offsets"])
+    gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(9))
+    y.backward(gy)
+    xr = x.detach().clone().requires_grad_(True)
+    yr = dense_segment_softmax(xr, G["offsets"])
+    yr.backward(gy)
+    assert_close(y, yr, 1e-6, "segment softmax")
+    assert_close(x.grad, xr.grad, 1e-5, "segment softmax grad")
+
+
+class DenseWindowAttention(torch.nn.Module):
+    """WindowAttention.forward (stratified_transformer_v1m1_origin.py:253-350) written with dense edge-list indexing, sharing the
+    parameters of the module under test."""
+
+    def __init__(self, mod):
+        super().__init__()
+        self.m = mod
+
+    def forward(self, feats, xyz, index_0, index_1, index_0_offsets, n_max):
+        m = self.m
+        n, c = feats.shape
+        qkv = m.qkv(feats).reshape(n, 3, m.num_heads, c // m.num_heads).permute(1, 0, 2, 3)
+        q, k, v = qkv[0] * m.scale, qkv[1], qkv[2]
+        i0, i1 = index_0.long(), index_1.long()
+        rel = m.relative_position_index(xyz, index_0, index_1).long()
+        tab = lambda t: t[rel[:, 0], :, :, 0] + t[rel[:, 1], :, :, 1] + t[rel[:, 2], :, :, 2]
+        attn = (q[i0] * k[i1]).sum(-1) + (q[i0] * tab(m.relative_pos_query_table)).sum(-1) + (k[i1] * tab(m.relative_pos_key_table)).sum(-1)
+        attn = dense_segment_softmax(attn, index_0_offsets)
+        x = torch.zeros_like(v).index_add(0, i0, (v[i1] + tab(m.relative_pos_value_table)) * attn.unsqueeze(-1))
+        return m.proj(x.reshape(n, c))
+
+
+def window_attention_case(dev="cpu", seed=3, n=400, dim=48, heads=3, max_deg=30):
+    from pointcloudpdf_amd.stratified import WindowAttention
+
+    g = torch.Generator().manual_seed(seed)
+    xyz = torch.rand(n, 3, generator=g) * 0.3          # inside one 0.4 m window: |offset| < window_size
+    deg = torch.randint(1, max_deg + 1, (n,), generator=g)
+    off = torch.cat([torch.zeros(1, dtype=torch.long), deg.cumsum(0)]).int()
+    m = int(off[-1])
+    index_0 = torch.repeat_interleave(torch.arange(n), deg)
+    index_1 = torch.randint(0, n, (m,), generator=g)
+    feats = torch.randn(n, dim, generator=g)
+    torch.manual_seed(seed)
+    mod = WindowAttention(dim, window_size=0.4, num_heads=heads, quant_size=0.05, rel_query=True, rel_key=True, rel_value=True)
+    with torch.no_grad():
+        for t in (mod.relative_pos_query_table, mod.relative_pos_key_table, mod.relative_pos_value_table):
+            t.mul_(10.0)                              # trunc_normal(std=0.02) tables would hide table errors behind the qk term
+    T = lambda t: t.to(dev)
+    return mod.to(dev), [T(feats), T(xyz), T(index_0), T(index_1), T(off), int(deg.max())]
+
+
+def run_window_attention(mod, dense, args):
+    outs = []
+    for net in (mod, dense):
+        for p in mod.parameters():
+            p.grad = None
+        f = args[0].clone().requires_grad_(True)
+        y = net(f, *args[1:])
+        y.backward(torch.cos(torch.arange(y.numel(), device=y.device, dtype=torch.float32)).view_as(y))
+        outs.append(dict(y=y.detach().cpu(), gf=f.grad.cpu(), **{n_: p.grad.detach().cpu().clone() for n_, p in mod.named_parameters()}))
+    return outs
+
+
+def test_window_attention_module_matches_dense_restatement(use_oracle):
+    mod, args = window_attention_case()
+    assert set(n_ for n_, _ in mod.named_parameters()) == {"relative_pos_query_table", "relative_pos_key_table", "relative_pos_value_table",
+                                                           "qkv.weight", "qkv.bias", "proj.weight", "proj.bias"}   # reference checkpoint keys
+    ours, dense = run_window_attention(mod, DenseWindowAttention(mod), args)
+    for key in ours:
+        assert_close(ours[key], dense[key], 5e-5, key)
