@@ -422,6 +422,31 @@ __global__ __launch_bounds__(GB) void group_fwd32(unsigned total4, unsigned tota
 }
 
 
+
+// pointops.grouping() twin for c % 4 == 0: lane = (row, piece) with c/4 float4 pieces of the feature row + one xyz piece per row.
+// Feature pieces are 16-B loads (aligned in the table) and 16-B stores at dword-aligned addresses (rows of 3 + c floats are not
+// 16-B aligned; gfx950 splits such stores in hardware), the xyz piece is 3 scalars.
+__global__ __launch_bounds__(GB) void group_fwd_rows(unsigned total, FastDiv pd, FastDiv nsd, int c, int with_xyz,
+                                                     const float *__restrict__ feat, const float *__restrict__ xyz,
+                                                     const float *__restrict__ new_xyz, const int *__restrict__ idx,
+                                                     float *__restrict__ output) {
+    typedef float u4f __attribute__((ext_vector_type(4), aligned(4)));   // 16 bytes, dword alignment
+    const unsigned stride = gridDim.x * GB, pieces = pd.d, cv = c >> 2, oc = c + (with_xyz ? 3 : 0), sh = with_xyz ? 3u : 0u;
+    for (unsigned e = blockIdx.x * GB + threadIdx.x; e < total; e += stride) {
+        const unsigned r = fdiv(e, pd), q = e - r * pieces;
+        const int j = idx[r];
+        float *o = output + (size_t)r * oc;
+        if (q < cv) {
+            const v4f v = j >= 0 ? reinterpret_cast<const v4f *>(feat)[(unsigned long)j * cv + q] : (v4f)(0.f);
+            *reinterpret_cast<u4f *>(o + sh + 4 * q) = (u4f)v;
+        } else {   // the xyz piece (only when with_xyz)
+            const unsigned m = fdiv(r, nsd);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) o[a] = j >= 0 ? xyz[(unsigned long)j * 3 + a] - new_xyz[(unsigned long)m * 3 + a] : 0.f;
+        }
+    }
+}
+
 // aggregation_cuda_kernel.cu:22-39 with the grad_weight sums of one row reduced across the wave before they leave it: the
 // c / w_c channels that share a weight sit w_c lanes apart in the SAME wave (needs 64 % w_c == 0 and c | 64 or 64 | c), so
 // xor-shuffles over w_c, 2 w_c, ... replace c / w_c atomics per element by a plain store (c <= 64) or c / 64 atomics.
@@ -502,6 +527,11 @@ extern "C" int pdf_group_forward(int m, int nsample, int c, int with_xyz, const 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long rows = (long)m * nsample;
     const int oc = c + (with_xyz ? 3 : 0);
+    if (c % 4 == 0 && rows * (c / 4 + 1) < (1L << 31)) {
+        const unsigned pieces = (unsigned)(c / 4 + (with_xyz ? 1 : 0)), total = (unsigned)(rows * pieces);
+        group_fwd_rows<<<grid_for(total), GB, 0, s>>>(total, mk_fastdiv(pieces), mk_fastdiv(nsample), c, with_xyz, feat, xyz, new_xyz, idx, output);
+        return pdf_launch_status();
+    }
     if (rows * oc < (1L << 31)) {
         const unsigned total = (unsigned)(rows * oc), total4 = (total + 3) / 4;
         group_fwd32<<<grid_for(total4), GB, 0, s>>>(total4, total, mk_fastdiv(oc), mk_fastdiv(nsample), c, with_xyz, feat, xyz, new_xyz, idx, output);
