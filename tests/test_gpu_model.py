@@ -162,3 +162,32 @@ def test_scannet_full_size_step_runs_and_is_finite():
     out, grads, _ = _scannet_step("cuda", [150000, 150000])
     assert torch.isfinite(out["loss"]).item() and out["score"].shape == (300000,)
     assert all(torch.isfinite(g).all() for g in grads.values())
+
+
+@pytest.mark.parametrize("name", ["PointTransformer-Seg26", "PointTransformer-Seg38"])
+def test_seg26_seg38_match_cpu_oracle_path(oracle_backend, name):
+    """The other two registered depths (point_transformer_seg.py:306-327): the HIP path against the same module on the oracle backend
+    (the module code itself is pinned to the reference through the Seg50 fixtures): logits 1e-4, loss, eval mode too."""
+    from pointcloudpdf_amd import _native, synthetic
+    from pointcloudpdf_amd.registry import MODELS
+
+    def run(dev, backend, train):
+        prev = _native._set_backend_for_testing(backend) if backend is not None else None
+        try:
+            seg = MODELS.build(dict(type="DefaultSegmentor", backbone=dict(type=name, in_channels=6, num_classes=13),
+                                    criteria=[dict(type="CrossEntropyLoss", loss_weight=1.0, ignore_index=-1)])).to(dev)
+            synthetic.fill_parameters_deterministic(seg, seed=6)
+            seg.train(train)
+            batch = synthetic.make_batch([1700, 1400], first_scene_id=30, device=dev)
+            logits = seg.backbone(dict(coord=batch["coord"], feat=batch["feat"], offset=batch["offset"]))
+            out = seg(batch)
+            return logits.detach().cpu(), out["loss"].detach().cpu()
+        finally:
+            if backend is not None:
+                _native._set_backend_for_testing(prev)
+
+    for train in (True, False):
+        lo, so = run("cpu", oracle_backend, train)
+        lh, sh = run("cuda", None, train)
+        helpers.assert_close(lh, lo, 1e-4, f"{name} logits train={train}")
+        helpers.assert_close(sh, so, 1e-4, f"{name} loss train={train}")
