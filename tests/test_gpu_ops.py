@@ -189,6 +189,14 @@ def test_fps_config4_size_and_kernel_variants(hip):
                 for k_ in env:
                     os.environ.pop(k_, None)
             assert torch.equal(got, want3), env
+        # 170k points: the one-centre-per-wave records no longer fit the LDS -> k_fps_multi; 200k: bucket records do not fit -> plain kernel
+        for n in (170000, 200000):
+            big = torch.from_numpy(synthetic.make_scene(n, 12, kind="scannet")["coord"]).to(DEV)
+            ob, nb = offs([n]).to(DEV), offs([n // 4]).to(DEV)
+            hip.fps_mode = "plain"
+            wb = hip.farthest_point_sampling(big, ob, nb, n, n // 4)
+            hip.fps_mode = "bucketed"
+            assert torch.equal(hip.farthest_point_sampling(big, ob, nb, n, n // 4), wb), n
     finally:
         hip.fps_mode = "bucketed"
 
