@@ -467,3 +467,16 @@ def test_radius_neighbors_grid_matches_in_order_scan(hip, radius, ns, snap):
     torch.cuda.synchronize()
     assert torch.equal(i_s, i_g), f"rows differing: {(i_s != i_g).any(1).sum().item()}"
     assert torch.equal(d_s, d_g)
+
+
+def test_more_than_64_scenes_take_the_scan_paths(hip, oracle_backend):
+    """The grid workspaces are sized for <= 64 scenes per call; beyond that kNN and the radius table fall back to the exact scans."""
+    sizes = [40 + (i % 7) * 13 for i in range(70)]
+    xyz = cloud(sum(sizes), 61)
+    off = offs(sizes)
+    i_o, d_o, i_h, d_h = both_knn(hip, oracle_backend, 8, xyz, xyz, off, off)
+    assert torch.equal(i_o, i_h) and torch.equal(d_o, d_h)
+    order = torch.arange(sum(sizes), dtype=torch.int32)
+    r_o, _ = oracle_backend.ball_query(16, 0.8, 0.0, xyz, xyz, off, off, order=order)
+    r_h, _ = hip.radius_neighbors_self(16, 0.8, xyz.to(DEV), off.to(DEV))
+    assert torch.equal(r_o, r_h.cpu())
