@@ -252,6 +252,7 @@ def main():
     # [8, --prefetch], else --prefetch itself (then the window holds ceil(steps / D) groups: more pre-pass work, never less).
     D = args.prefetch
     if D > 0:
+        D = max(1, min(D, 64 // max(args.scenes, 1)))   # the grid kNN / radius workspaces hold <= 64 scenes per call (beyond: exact scans)
         if args.steps <= D:
             D = max(args.steps, 1)
         else:
