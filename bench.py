@@ -30,13 +30,34 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-# HBM traffic per launch from rocprofv3 PMC passes (profiles/r01_h_pmc_{fetch,write}_size.txt: one launch = the 24 scenes of a
-# 12-batch group; FETCH_SIZE doubled as the guide prescribes for gfx950, KB -> bytes, averaged over the launches of the profiled
-# run like `achieved`).  FPS (k_fps_mw<16> / <8> / k_fps<4> by level): 9,498 KB fetch (x2) + 49,096 KB write on average -- the
-# tmp-distance stores of the touched buckets.
-# Bottleneck backward: sum over the kernels that only run in backward passes (k_b*, k_wg, k_bn_bwd_*, k_colsum: 19.06 GB per step in
-# the r01_g PMC passes; a few of their launches belong to the Linear-BN nodes outside the Bottlenecks) / 18 calls per step.
-PMC_TRAFFIC_BYTES = {"farthest_point_sampling": (2 * 9498.0 + 49096.0) * 1024, "bottleneck_backward": 19063.8e6 / 18}
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+
+
+def kernel_source_hash():
+    """Hash of the kernel sources the PMC numbers belong to (csrc/*.hip, csrc/*.h, include/pdfops.h)."""
+    import hashlib
+    h = hashlib.sha256()
+    cs = os.path.join(ROOT, "pointcloudpdf_amd", "csrc")
+    for f in sorted(os.listdir(cs)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(cs, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "pdfops.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_traffic():
+    """HBM traffic per launch from the rocprofv3 PMC passes of `bash tools/prof_round.sh <tag>` (separate FETCH_SIZE / WRITE_SIZE runs;
+    FETCH_SIZE doubled for gfx950 and KB -> bytes as /opt/skills/guides/MI355X_MICROARCH.md prescribes), written by
+    tools/traffic_json.py.  The file records the hash of the kernel sources it was measured on: numbers of other sources are not
+    reported (traffic = null, note says why) rather than silently going stale."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return {}, "no profiles/r02_traffic.json"
+    if t.get("kernel_source_hash") != kernel_source_hash():
+        return {}, f"profiles/r02_traffic.json was measured on other kernel sources ({t.get('kernel_source_hash')})"
+    return t, None
 
 
 def parse():
@@ -66,8 +87,56 @@ def parse():
     ap.add_argument("--ddp", choices=["flat", "torch"], default="flat",
                     help="gradient exchange for N > 1: one flat-buffer all-reduce after the backward (engine.FlatGradAllReduce) or "
                          "torch DistributedDataParallel (per-parameter bucket copies: +3 ms per step, measured)")
-    ap.add_argument("--graph", type=int, default=0, help="replay fwd+bwd+SGD as one captured hipGraph (needs --prefetch > 0)")
+    ap.add_argument("--no-latency-sweep", action="store_true",
+                    help="skip the look-ahead sweep (serial step time with --prefetch 0 and groups of 1 / 2 / 3 batches; rank 0, N = 1)")
+    ap.add_argument("--no-n1-reference", action="store_true",
+                    help="N > 1 started without torchrun: do not time the one-rank run that efficiency_vs_n1 is quoted against")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without torchrun: this process never touches the GPU; it starts N ranks (one per GPU, the
+    environment torchrun would give them, rendezvous on 127.0.0.1), relays rank 0's JSON line and adds the weak-scaling efficiency
+    against a one-rank run of the same command (timed first, same steps / warmup).  Mirrors pointcept/engines/launch.py:74-113
+    (one process per GPU) without re-executing anything that has initialised HIP."""
+    import socket
+    import subprocess
+
+    if torch.cuda.device_count() < args.gpus:   # (device_count does not initialise the GPU on this image)
+        print(f"[bench] --gpus {args.gpus} but only {torch.cuda.device_count()} visible", file=sys.stderr)
+        return 2
+    argv = [a for a in sys.argv[1:]]
+
+    def run(world, extra):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PDFOPS_BENCH_CHILD="1")
+            cmd = [sys.executable, os.path.abspath(__file__)] + argv + extra
+            procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+        out, _ = procs[0].communicate()
+        codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+        return max(abs(c) for c in codes), out
+
+    n1 = None
+    if not args.no_n1_reference:
+        rc, out = run(1, ["--gpus", "1", "--no-cpu-baseline", "--no-ops-roofline", "--no-latency-sweep"])
+        try:
+            n1 = json.loads(out.strip().splitlines()[-1])
+        except (ValueError, IndexError):
+            print(f"[bench] one-rank reference run failed (exit {rc})", file=sys.stderr)
+    rc, out = run(args.gpus, [])
+    try:
+        line = json.loads(out.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        print(f"[bench] the {args.gpus}-rank run printed no JSON line (exit {rc})", file=sys.stderr)
+        return rc or 1
+    if n1 is not None:
+        line["n1_reference"] = {"ms_per_step": n1["ms_per_step"], "value": n1["value"]}
+        line["efficiency_vs_n1"] = (line["value"] / line["n_gpus"]) / n1["value"]
+    print(json.dumps(line), flush=True)
+    return rc
 
 
 class KernelTimer:
@@ -192,6 +261,8 @@ def cpu_baseline(points):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
     from pointcloudpdf_amd import _native, engine, synthetic
 
     # Native libraries print through C stdio on stdout (RCCL's version banner at communicator creation); block-buffered, that
@@ -202,7 +273,8 @@ def main():
 
     rank, local_rank, world = engine.init_distributed()
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (the HIP path has no CPU fallback)"
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     torch.backends.cuda.matmul.allow_tf32 = False
@@ -241,53 +313,62 @@ def main():
 
     from pointcloudpdf_amd.geometry import GeometryPrefetcher
 
-    prefetcher = GeometryPrefetcher(depth=2) if args.prefetch > 0 else None   # two side streams, alternating groups
-    tickets = {}
-    submit_host_s = []   # host time of every grouped pre-pass submission
+    prefetcher = GeometryPrefetcher(depth=2)   # two side streams, alternating groups
 
-    # Group boundaries sit at warmup + k * D, so the timed region queues exactly steps / D group pre-passes (one pre-pass per
-    # trained batch) and, D steps being a whole group's lead time, drains them before the closing fence.  Only ONE group
-    # pre-pass is in flight at a time and its latency is the FPS chain (~160 ms however many scenes it carries), so the step
-    # time is bounded below by latency / D: D = --steps when that is <= --prefetch, else the largest divisor of --steps in
-    # [8, --prefetch], else --prefetch itself (then the window holds ceil(steps / D) groups: more pre-pass work, never less).
-    D = args.prefetch
-    if D > 0:
-        D = max(1, min(D, 64 // max(args.scenes, 1)))   # the grid kNN / radius workspaces hold <= 64 scenes per call (beyond: exact scans)
-        if args.steps <= D:
-            D = max(args.steps, 1)
-        else:
-            divs = [d for d in range(8, D + 1) if args.steps % d == 0]
-            D = max(divs) if divs else D
-    phase = args.warmup % D if D > 0 else 0
+    class Schedule:
+        """Grouped geometry pre-pass for `warmup + steps` steps: the pre-pass of the next D batches runs as ONE launch sequence on a
+        side stream (FPS is a chain of dependent arg-max steps, one workgroup per scene: its latency is amortised over the group
+        instead of being paid per step).  Group boundaries sit at warmup + k * D, so the timed region queues exactly steps / D group
+        pre-passes -- every trained batch gets exactly one full pre-pass, nothing is cached -- and, D steps being a whole group's
+        lead time, drains them before the closing fence.  D = 0: the pre-pass runs inline on the main stream (serial step)."""
 
-    def submit_range(lo, hi):
-        """One FPS / kNN launch sequence over the scenes of steps lo .. hi-1 (FPS is a chain of dependent arg-max steps,
-        one workgroup per scene: its latency is amortised over the group instead of being paid per step)."""
-        group = [pool[j % len(pool)] for j in range(lo, hi)]
-        t_sub = time.perf_counter()
-        prof = None
-        if os.environ.get("PDFOPS_PROFILE_SUBMIT") and len(submit_host_s) == 3:
-            import cProfile
-            prof = cProfile.Profile(); prof.enable()
-        for j, t in enumerate(prefetcher.submit_group(group)):
-            tickets[lo + j] = t
-        if prof is not None:
-            import pstats
-            prof.disable(); pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(14)
-        submit_host_s.append(time.perf_counter() - t_sub)
+        def __init__(self, D, warmup, steps):
+            if D > 0:
+                D = max(1, min(D, 64 // max(args.scenes, 1)))   # the grid kNN / radius workspaces hold <= 64 scenes per call
+                if steps <= D:
+                    D = max(steps, 1)
+                else:
+                    divs = [d for d in range(min(8, D), D + 1) if steps % d == 0]
+                    D = max(divs) if divs else D
+            self.D, self.phase = D, (warmup % D if D > 0 else 0)
+            self.tickets, self.submit_host_s = {}, []
 
-    def submit(i):
-        """Called with i = step + D right after step's tables were fetched: queues the NEXT group at a boundary."""
-        if (i - phase) % D == 0:
-            submit_range(i, i + D)
+        def _submit_range(self, lo, hi):
+            group = [pool[j % len(pool)] for j in range(lo, hi)]
+            t_sub = time.perf_counter()
+            for j, t in enumerate(prefetcher.submit_group(group)):
+                self.tickets[lo + j] = t
+            self.submit_host_s.append(time.perf_counter() - t_sub)
 
-    def one_step(i):
+        def start(self):
+            if self.D > 0:
+                b0 = self.phase if self.phase > 0 else self.D
+                self._submit_range(0, b0)
+                if self.phase > 0:
+                    self._submit_range(b0, b0 + self.D)
+
+        def geometry(self, i):
+            """Tables of step i's batch (queued with its group); queues the NEXT group when i crosses a boundary."""
+            if self.D == 0:
+                return None
+            geom = prefetcher.get(self.tickets.pop(i))
+            if (i + self.D - self.phase) % self.D == 0:
+                self._submit_range(i + self.D, i + 2 * self.D)
+            return geom
+
+        def drain(self):
+            """Pre-passes queued beyond the last step (none when steps is a multiple of D): wait for them, drop them."""
+            for t in self.tickets.values():
+                prefetcher.get(t)
+            self.tickets.clear()
+
+    def one_step(i, sched):
         batch = pool[i % len(pool)]
         data = dict(coord=batch["coord"], feat=batch["feat"], offset=batch["offset"],
                     offset_host=batch["offset_host"], segment=batch["segment"])
-        if prefetcher is not None:
-            data["pdf_geometry"] = prefetcher.get(tickets.pop(i))  # pre-pass of THIS batch, queued with its group
-            submit(i + D)                             # (acts once per group) every batch gets exactly one pre-pass
+        geom = sched.geometry(i)
+        if geom is not None:
+            data["pdf_geometry"] = geom
         opt.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=torch.float16, enabled=args.amp):
             out = module(data)
@@ -297,81 +378,37 @@ def main():
         opt.step()
         return out
 
-    if prefetcher is not None:
-        b0 = phase if phase > 0 else D
-        submit_range(0, b0)
-        if phase > 0:
-            submit_range(b0, b0 + D)
-
-    # ---- optional: the whole step (fwd + bwd + SGD) as ONE captured hipGraph.  The step issues ~3000 kernel launches
-    # and is host-bound in eager mode; scene sizes are fixed, so the launch sequence is static.  Inputs and the
-    # geometry tables live in static buffers that are refreshed (device-to-device copies) before every replay; the
-    # geometry pre-pass itself keeps running eagerly on the side streams.
-    use_graph = bool(args.graph) and prefetcher is not None and world == 1 and not use_dp  # (collectives + capture: not attempted)
-    graph = None
-    if use_graph:
-        from pointcloudpdf_amd.geometry import Geometry
-
-        b0 = pool[0]
-        static = {k: b0[k].clone() for k in ("coord", "feat", "offset", "segment")}
-        static_geom = Geometry(static["coord"], static["offset"], b0["offset_host"]).precompute()
-        static_data = dict(coord=static["coord"], feat=static["feat"], offset=static["offset"], offset_host=b0["offset_host"],
-                           segment=static["segment"], pdf_geometry=static_geom)
-        static_out = {}
-
-        def graph_body():
-            opt.zero_grad(set_to_none=False)
-            with torch.autocast("cuda", dtype=torch.float16, enabled=args.amp):
-                out = module(dict(static_data))
-            out["loss"].backward()
-            opt.step()
-            static_out["loss"] = out["loss"].detach()
-
-        eager_step = one_step
-
-        def one_step(i):  # noqa: F811
-            batch = pool[i % len(pool)]
-            geom = prefetcher.get(tickets.pop(i))
-            submit(i + D)
-            for k in ("coord", "feat", "segment"):
-                static[k].copy_(batch[k])
-            static_geom.load(geom)
-            if graph is None:
-                graph_body()
-            else:
-                graph.replay()
-            return static_out
-
     def fence():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        one_step(i)
-    fence()
-    if use_graph:
-        try:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                graph_body()
-            graph = g
-            fence()
-        except Exception as e:  # capture not possible in this configuration: stay eager
-            print(f"[bench] hipGraph capture failed, running eager: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
-            graph = None
-            torch.cuda.synchronize()
-    timer.enabled = True
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = one_step(args.warmup + i)
-    fence()
-    dt = time.perf_counter() - t0
-    timer.enabled = False
+    def timed(D, warmup, steps, with_timer=False):
+        """W untimed steps, then EXACTLY K steps between barrier + synchronize pairs -> (seconds, last output, schedule)."""
+        sched = Schedule(D, warmup, steps)
+        sched.start()
+        for i in range(warmup):
+            one_step(i, sched)
+        fence()
+        timer.enabled = with_timer
+        t0 = time.perf_counter()
+        for i in range(steps):
+            out = one_step(warmup + i, sched)
+        fence()
+        dt = time.perf_counter() - t0
+        timer.enabled = False
+        sched.drain()
+        return dt, out, sched
+
+    dt_local, out, sched = timed(args.prefetch, args.warmup, args.steps, with_timer=True)
+    D = sched.D
+    dt, rank_ms = dt_local, [dt_local / args.steps * 1e3]
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.tensor([dt_local], device=dev, dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        torch.distributed.all_gather(allt, t)
+        rank_ms = [float(x.item()) / args.steps * 1e3 for x in allt]
+        dt = max(float(x.item()) for x in allt)   # MAX over ranks
     loss = float(out["loss"].item())
 
     if rank == 0:
@@ -380,14 +417,19 @@ def main():
         pts_total = sum(pool_points[(args.warmup + i) % len(pool)] for i in range(args.steps)) * world
         pts_per_step = pts_total / args.steps
         ks = timer.summary()
+        traffic, traffic_note = load_traffic()
         dom = max(ks, key=lambda n: ks[n]["total_ms"]) if ks else None
+
         def roofline_of(name):
             achieved = ks[name]["avg_bytes"] / (ks[name]["avg_ms"] * 1e-3) / 1e9
-            return dict(bound="hbm", kernel=name, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=PMC_TRAFFIC_BYTES.get(name),
-                        algorithmic_bytes_per_launch=ks[name]["avg_bytes"], avg_launch_ms=ks[name]["avg_ms"],
-                        launches_per_step=ks[name]["calls"] / args.steps,
-                        gpu_time_share_of_step=ks[name]["total_ms"] / (dt * 1e3))
+            r = dict(bound="hbm", kernel=name, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                     frac=achieved / HBM_PEAK_GBS, traffic=(traffic.get("host_calls", {}).get(name) if traffic else None),
+                     algorithmic_bytes_per_launch=ks[name]["avg_bytes"], avg_launch_ms=ks[name]["avg_ms"],
+                     launches_per_step=ks[name]["calls"] / args.steps,
+                     gpu_time_share_of_step=ks[name]["total_ms"] / (dt * 1e3))
+            if traffic_note:
+                r["traffic_note"] = traffic_note
+            return r
 
         roof = roofline_of(dom) if dom else None
         # the gather family is what the HBM roofline is meaningful for (FPS / kNN are latency / VALU bound by design)
@@ -412,14 +454,29 @@ def main():
                        "scenes_per_gpu": args.scenes, "points_per_scene": args.points, "size_jitter": args.jitter, "parallelism": f"dp{world}",
                        "gradient_exchange": (args.ddp if use_dp else "none")},
             "per_gpu_points_per_s": pts_per_step * args.steps / dt / world,
+            "rccl_ranks": world if (world > 1 and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl") else 0,
+            "rank_ms_per_step": rank_ms,
             "loss": loss,
             "geometry_prefetch_group": D,
-            "prepass_submit_host_ms": (1e3 * min(submit_host_s)) if submit_host_s else None,   # host time of one group submission (warm)
-            "hipgraph": bool(use_graph and graph is not None),
+            "prepass_submit_host_ms": (1e3 * min(sched.submit_host_s)) if sched.submit_host_s else None,   # host time of one group submission (warm)
             "kernels": ks,
             "roofline": roof,
             "roofline_gather_family": roof2,
         }
+        if traffic and traffic.get("dominant_gpu_kernel"):
+            line["dominant_gpu_kernel"] = traffic["dominant_gpu_kernel"]   # the single hottest GPU kernel of the kernel trace (tools/traffic_json.py)
+
+    # ---- latency: how much look-ahead the number above depends on (FPS is a serial chain per scene).  serial = pre-pass inline on
+    # the main stream, every step pays the whole FPS chain; then groups of 1 / 2 / 3 batches.
+    if world == 1 and not args.no_latency_sweep and not args.pseudo_label:
+        sweep = {}
+        for Dl, st, wu in ((0, 4, 1), (1, 6, 2), (2, 6, 2), (3, 6, 3)):
+            dtl, _, _ = timed(Dl, wu, st)
+            sweep["serial" if Dl == 0 else f"group_{Dl}"] = dtl / st * 1e3
+        line["serial_ms_per_step"] = sweep["serial"]
+        line["lookahead_sweep_ms_per_step"] = sweep
+
+    if rank == 0:
         if world == 1 and not args.no_ops_roofline and not scannet:
             # the pointops drop-in ops on their own (level-1 shapes of this config: 200k points, c = 32, k = 8), HIP-event timed on
             # the launching stream, against the 8 TB/s HBM peak with the SURVEY 8(d) byte counts (tools/ops_roofline.py)

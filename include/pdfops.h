@@ -243,11 +243,12 @@ int pdf_td_forward(long n, long m, int cin, int cout, void *const *p, int traini
 int pdf_td_backward(long n, long m, int cin, int cout, void *const *p, void *stream);
 
 /* Cross-entropy with an ignore label, mean over the counted rows (pointcept/models/losses/misc.py:14-39 as configured on
- * this path).  Forward: loss[0], acc = [sum, count], grad (n*c) = softmax - onehot (0 on ignored rows); backward scales grad in
- * place by gy[0] / count. */
+ * this path).  Forward: loss[0], acc = [sum, count], grad (n*c) = softmax - onehot (0 on ignored rows); a target that is neither
+ * `ignore` nor in [0, c) makes the loss NaN (torch raises a device-side assert there).  Backward: grad_out = dlogits * gy[0] /
+ * count; dlogits (the forward's `grad`) is only read, so the node can be differentiated more than once; grad_out may alias it. */
 int pdf_ce_forward(long n, int c, const float *logits, const long *target, long ignore, float *grad, float *acc, float *loss,
                    void *stream);
-int pdf_ce_backward(long n, int c, float *grad, const float *acc, const float *gy, void *stream);
+int pdf_ce_backward(long n, int c, const float *dlogits, const float *acc, const float *gy, float *grad_out, void *stream);
 
 /* ---- libs/pointops2 window attention: the CSR-by-query v2 / v3 launchers of
  * libs/pointops2/src/attention_v2/attention_cuda_kernel_v2.h and libs/pointops2/src/rpe_v2/relative_pos_encoding_cuda_kernel_v2.h,

@@ -68,6 +68,22 @@ class PdfOpsError(RuntimeError):
     pass
 
 
+def require_current_device(*tensors):
+    """Every launch goes onto torch's current stream of the CURRENT device (the reference relies on
+    ``torch.cuda.set_device(local_rank)`` the same way, engines/launch.py:131).  A tensor that lives on another GPU would be
+    handed to a stream of the wrong device -- a fault, or a kernel unordered against the tensor's own stream -- so that is an
+    error here, raised before anything is enqueued.  The public ``pointops`` ops switch devices themselves (CBackend._call)."""
+    cur = None
+    for t in tensors:
+        if t is None or not t.is_cuda:
+            continue
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise PdfOpsError(f"pointcloudpdf_amd: tensor on {t.device} but the current device is cuda:{cur}; call "
+                              "torch.cuda.set_device(...) or wrap the call in torch.cuda.device(...)")
+
+
 def _check(t, dtype, name):
     if t.dtype != dtype:
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
@@ -109,12 +125,25 @@ class CBackend:
         return c_void_p(t.data_ptr())
 
     def _call(self, name, *args):
-        conv = []
+        conv, dev = [], None
         for a in args:
-            conv.append(self._ptr(a) if isinstance(a, torch.Tensor) else a)
+            if isinstance(a, torch.Tensor):
+                conv.append(self._ptr(a))
+                if dev is None:
+                    dev = a.device
+                elif a.device != dev:
+                    raise PdfOpsError(f"{self.prefix}{name}: tensors on different devices ({dev}, {a.device})")
+            else:
+                conv.append(a)
         if self.use_stream:
-            conv.append(c_void_p(torch.cuda.current_stream().cuda_stream))
-        rc = self._fn[name](*conv)
+            if dev is not None and dev.index != torch.cuda.current_device():
+                # the stream must belong to the tensors' device (and per-device kernel attributes are set for the current one)
+                with torch.cuda.device(dev):
+                    rc = self._fn[name](*conv, c_void_p(torch.cuda.current_stream().cuda_stream))
+            else:
+                rc = self._fn[name](*conv, c_void_p(torch.cuda.current_stream().cuda_stream))
+        else:
+            rc = self._fn[name](*conv)
         if rc != 0:
             raise PdfOpsError(f"{self.prefix}{name} failed with status {rc}")
 
@@ -405,7 +434,7 @@ class HipBackend(CBackend):
         lib.pdf_ce_forward.restype = c_int
         lib.pdf_ce_forward.argtypes = [c_long, c_int, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p]
         lib.pdf_ce_backward.restype = c_int
-        lib.pdf_ce_backward.argtypes = [c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
+        lib.pdf_ce_backward.argtypes = [c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         lib.pdf_linbn_forward.restype = c_int
         lib.pdf_linbn_forward.argtypes = [c_long, c_int, c_int, c_void_p, c_int, c_int, ctypes.c_float, ctypes.c_float, c_void_p]
         lib.pdf_linbn_backward.restype = c_int
@@ -470,12 +499,17 @@ class HipBackend(CBackend):
         lib.pdf_knn_query_ws.restype = c_int
         lib.pdf_knn_query_ws.argtypes = [c_int, c_int, c_int] + [c_void_p] * 4 + [c_int] + [c_void_p] * 3 + [c_long, c_void_p]
 
+    KNN_GRID_MAX_SCENES = 64
+
     def knn_query(self, nsample, xyz, new_xyz, offset, new_offset):
         if self.knn_mode == "scan" or not self.lib.pdf_knn_grid_supported(int(nsample)):
             return super().knn_query(nsample, xyz, new_xyz, offset, new_offset)
         _check(xyz, torch.float32, "xyz"); _check(new_xyz, torch.float32, "new_xyz")
         _check(offset, torch.int32, "offset"); _check(new_offset, torch.int32, "new_offset")
         n, m, b = xyz.shape[0], new_xyz.shape[0], offset.shape[0]
+        if b > self.KNN_GRID_MAX_SCENES:   # the grid workspace holds <= 64 scenes; beyond, the C side scans anyway (no workspace)
+            return super().knn_query(nsample, xyz, new_xyz, offset, new_offset)
+        require_current_device(xyz, new_xyz, offset, new_offset)
         idx = self._new(xyz, (m, nsample), torch.int32)
         dist2 = self._new(xyz, (m, nsample), torch.float32)
         nbytes = int(self.lib.pdf_knn_workspace_bytes(b, n, m))
@@ -518,6 +552,7 @@ class HipBackend(CBackend):
         for t in (xq, xk, xv, p, *weights, *bn_params):
             _check(t, torch.float32, "pt_layer tensor")
         _check(idx, torch.int32, "idx")
+        require_current_device(xq, xk, xv, p, idx)
         bn = self._new(xq, (2 * (3 + c + cs),), torch.float32)
         saved = self._new(xq, (2 * (3 + c + cs),), torch.float32)
         H = self._new(xq, (n, k, cs), torch.float32)
@@ -537,6 +572,7 @@ class HipBackend(CBackend):
         k = idx.shape[1]
         cs = c // 8
         _check(gout, torch.float32, "gout")
+        require_current_device(xq, gout)
         gxq = self._new(xq, (n, c), torch.float32)
         gxk = self._new(xq, (n, c), torch.float32, zero=True)
         gxv = self._new(xq, (n, c), torch.float32, zero=True)
@@ -639,7 +675,7 @@ class HipBackend(CBackend):
             rows = partial._pdf_rows
             rc = self.lib.pdf_bn_coef_from_partial(partial.data_ptr(), rows, n, c, bn.weight.data_ptr(), bn.bias.data_ptr(),
                                                    bn.running_mean.data_ptr(), bn.running_var.data_ptr(), ctypes.c_float(bn.eps),
-                                                   ctypes.c_float(bn.momentum if bn.momentum is not None else 0.1),
+                                                   ctypes.c_float(bn.momentum),
                                                    coef.data_ptr(), self._stream())
             if rc != 0:
                 raise PdfOpsError(f"pdf_bn_coef_from_partial failed with status {rc}")
@@ -656,7 +692,7 @@ class HipBackend(CBackend):
         partial = torch.empty((int(self.lib.pdf_bn_partial_floats(n, c)),), dtype=torch.float32, device=x.device) if training else None
         rc = self.lib.pdf_bn_coef(n, c, x.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
                                   bn.running_var.data_ptr(), int(bool(training)), ctypes.c_float(bn.eps),
-                                  ctypes.c_float(bn.momentum if bn.momentum is not None else 0.1), coef.data_ptr(),
+                                  ctypes.c_float(bn.momentum), coef.data_ptr(),
                                   None if partial is None else partial.data_ptr(), self._stream())
         if rc != 0:
             raise PdfOpsError(f"pdf_bn_coef failed with status {rc}")
@@ -714,6 +750,7 @@ class HipBackend(CBackend):
 
     def bn_act_forward(self, x, res, gamma, beta, running_mean, running_var, training, eps, momentum, relu):
         n, c = x.shape
+        require_current_device(x, res, gamma)
         coef = self._new(x, (4 * c,), torch.float32)
         partial = self._new(x, (int(self.lib.pdf_bn_partial_floats(n, c)),), torch.float32)
         y = self._new(x, (n, c), torch.float32)
@@ -727,6 +764,7 @@ class HipBackend(CBackend):
 
     def bn_act_backward(self, gy, x, res, coef, training, relu, need_res):
         n, c = x.shape
+        require_current_device(gy, x)
         partial = self._new(x, (int(self.lib.pdf_bn_partial_floats(n, c)),), torch.float32)
         sums = self._new(x, (2 * c,), torch.float32)
         gx = self._new(x, (n, c), torch.float32)

@@ -24,6 +24,9 @@ __global__ __launch_bounds__(LB) void k_ce_fwd(long n, int c, const float *__res
         const float lse = m + __logf(s);
         const bool counted = t != ignore && t >= 0 && t < c;
         if (counted) { loss += lse - x[t]; cnt += 1.f; }
+        // a label that is neither the ignore value nor a class id (torch: device-side assert) poisons the loss instead of being
+        // dropped silently: a mis-sized head / label map shows up as a NaN loss on the first step, without a host sync
+        else if (t != ignore) loss += __builtin_nanf("");
         float *g = grad + r * c;
         const float inv = 1.f / s;
         for (int j = 0; j < c; ++j) g[j] = counted ? __expf(x[j] - m) * inv - (j == t ? 1.f : 0.f) : 0.f;
@@ -43,11 +46,12 @@ __global__ __launch_bounds__(LB) void k_ce_fwd(long n, int c, const float *__res
 // acc = [sum of losses, counted rows] -> out = mean loss (NaN when nothing is counted, as torch)
 __global__ void k_ce_mean(const float *__restrict__ acc, float *__restrict__ out) { out[0] = acc[0] / acc[1]; }
 
-// grad_logits = (softmax - onehot) * gy / count   (in place on the forward's buffer)
-__global__ __launch_bounds__(LB) void k_ce_bwd(long total, float *__restrict__ grad, const float *__restrict__ acc,
-                                               const float *__restrict__ gy) {
+// grad_logits = (softmax - onehot) * gy / count.  The forward's buffer is only READ: a second backward over the same graph
+// (retain_graph, torch.autograd.grad followed by backward) must see the unscaled values again.
+__global__ __launch_bounds__(LB) void k_ce_bwd(long total, const float *__restrict__ dlogits, const float *__restrict__ acc,
+                                               const float *__restrict__ gy, float *__restrict__ out) {
     const float scale = gy[0] / acc[1];
-    for (long e = (long)blockIdx.x * LB + threadIdx.x; e < total; e += (long)gridDim.x * LB) grad[e] *= scale;
+    for (long e = (long)blockIdx.x * LB + threadIdx.x; e < total; e += (long)gridDim.x * LB) out[e] = dlogits[e] * scale;
 }
 
 // Test-time fragment voting (engines/test.py:218-229, 243-251): pred[index[r], :] += softmax(logits[r, :]) and the running
@@ -99,10 +103,10 @@ extern "C" int pdf_ce_forward(long n, int c, const float *logits, const long *ta
     return pdf_launch_status();
 }
 
-extern "C" int pdf_ce_backward(long n, int c, float *grad, const float *acc, const float *gy, void *stream) {
-    if (n < 1 || c < 1 || !grad || !acc || !gy) return PDF_ERR_BAD_ARG;
+extern "C" int pdf_ce_backward(long n, int c, const float *dlogits, const float *acc, const float *gy, float *grad_out, void *stream) {
+    if (n < 1 || c < 1 || !dlogits || !acc || !gy || !grad_out) return PDF_ERR_BAD_ARG;
     long g = (n * c + LB - 1) / LB;
     if (g > 2048) g = 2048;
-    k_ce_bwd<<<(unsigned)g, LB, 0, static_cast<hipStream_t>(stream)>>>(n * c, grad, acc, gy);
+    k_ce_bwd<<<(unsigned)g, LB, 0, static_cast<hipStream_t>(stream)>>>(n * c, dlogits, acc, gy, grad_out);
     return pdf_launch_status();
 }

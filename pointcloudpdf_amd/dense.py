@@ -107,7 +107,7 @@ class _BnAct(torch.autograd.Function):
         be = _native.hip_backend()
         training = bn.training or bn.running_mean is None
         y, coef = be.bn_act_forward(x, residual, weight.detach(), bias.detach(), bn.running_mean, bn.running_var, training,
-                                    bn.eps, bn.momentum if bn.momentum is not None else 0.1, relu)
+                                    bn.eps, bn.momentum, relu)
         if training:
             bump_counters([bn.num_batches_tracked])
         ctx.save_for_backward(x, residual if residual is not None else x.new_empty(0), coef)
@@ -132,7 +132,7 @@ def bn_act(bn, x, residual=None, relu=True):
     from . import _native
 
     if (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous() and bn.affine
-            and bn.track_running_stats and _native.hip_backend().bn_supported(x.shape[1])
+            and bn.track_running_stats and bn.momentum is not None and _native.hip_backend().bn_supported(x.shape[1])
             and (residual is None or residual.is_contiguous())):
         return _BnAct.apply(x, residual, bn.weight, bn.bias, bn, relu)
     y = torch.nn.BatchNorm1d.forward(bn, x)  # (not bn(x): subclasses such as LayerNorm1d route back here)
@@ -154,10 +154,18 @@ def _be():
     return _native.hip_backend()
 
 
+def _rcd(*tensors):
+    """All tensors of a fused node live on the current device (the launches go onto its current stream)."""
+    from . import _native
+
+    _native.require_current_device(*tensors)
+
+
 class _LinearStats(torch.autograd.Function):
     @staticmethod
     @_amp_fwd
     def forward(ctx, x, weight, bias, want_stats):
+        _rcd(x, weight)
         y, partial = _be().rowlin(x, weight.detach(), None if bias is None else bias.detach(), stats=want_stats)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
@@ -182,6 +190,7 @@ class _BnReluLinear(torch.autograd.Function):
     @_amp_fwd
     def forward(ctx, z, partial, gamma, beta, bn, relu, want_stats, *wb):
         be = _be()
+        _rcd(z, gamma, wb[0])
         n, c = z.shape
         training = bn.training
         if training and partial is not None and partial.numel() > 0:
@@ -228,6 +237,7 @@ class _BnActPartial(torch.autograd.Function):
     @_amp_fwd
     def forward(ctx, z, partial, residual, gamma, beta, bn, relu):
         be = _be()
+        _rcd(z, residual, gamma)
         n, c = z.shape
         training = bn.training
         if training and partial is not None and partial.numel() > 0:
@@ -256,7 +266,9 @@ def fused_ok(x, *bns):
     if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous()):
         return False
     be = _be()
-    return all(type(b) is torch.nn.BatchNorm1d and b.affine and b.track_running_stats and be.bn_supported(b.num_features) for b in bns)
+    # (momentum=None means a cumulative moving average in torch: the fused norms implement the exponential update only)
+    return all(type(b) is torch.nn.BatchNorm1d and b.affine and b.track_running_stats and b.momentum is not None
+               and be.bn_supported(b.num_features) for b in bns)
 
 
 def linear_stats(lin, x, want_stats=True):
@@ -286,13 +298,14 @@ class _BlockPre(torch.autograd.Function):
     @_amp_fwd
     def forward(ctx, x, W1, g1, b1, Wq, bq, Wk, bk, Wv, bv, blk):
         be = _be()
+        _rcd(x, W1)
         n, c = x.shape
         bn1, training = blk.bn1, blk.bn1.training
         e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=x.device)
         z1, coef1, xq, xk, xv = e(n, c), e(4 * c), e(n, c), e(n, c), e(n, c)
         partial = e(int(be.lib.pdf_rowlin_partial_floats(n, c)))
         be.block_call("pre_forward", n, c, [x, W1, g1, b1, bn1.running_mean, bn1.running_var, Wq, bq, Wk, bk, Wv, bv,
-                                            z1, coef1, xq, xk, xv, partial], training, bn1.eps, bn1.momentum or 0.1)
+                                            z1, coef1, xq, xk, xv, partial], training, bn1.eps, bn1.momentum)
         ctx.save_for_backward(x, z1, coef1, W1, Wq, Wk, Wv)
         ctx.training = training
         return xq, xk, xv
@@ -323,13 +336,14 @@ class _BlockPost(torch.autograd.Function):
     @_amp_fwd
     def forward(ctx, t, x, g2, b2, W3, g3, b3, blk):
         be = _be()
+        _rcd(t, x, W3)
         n, c = t.shape
         bn2, bn3, training = blk.bn2, blk.bn3, blk.bn2.training
         e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=t.device)
         coef2, z3, coef3, y = e(4 * c), e(n, c), e(4 * c), e(n, c)
         partial = e(max(int(be.lib.pdf_rowlin_partial_floats(n, c)), int(be.lib.pdf_bn_partial_floats(n, c))))
         be.block_call("post_forward", n, c, [t, x, g2, b2, bn2.running_mean, bn2.running_var, W3, g3, b3, bn3.running_mean,
-                                             bn3.running_var, coef2, z3, coef3, y, partial], training, bn2.eps, bn2.momentum or 0.1)
+                                             bn3.running_var, coef2, z3, coef3, y, partial], training, bn2.eps, bn2.momentum)
         ctx.save_for_backward(t, x, z3, coef2, coef3, W3)
         ctx.training = training
         return y
@@ -366,6 +380,7 @@ class _BottleneckFn(torch.autograd.Function):
     @_amp_fwd
     def forward(ctx, blk, idx, p, x, *params):
         be = _be()
+        _rcd(idx, p, x, params[0])
         lib = be.lib
         n, c = x.shape
         k = idx.shape[1]
@@ -396,7 +411,7 @@ class _BottleneckFn(torch.autograd.Function):
                 g2.data_ptr(), b2.data_ptr(), bn2.running_mean.data_ptr(), bn2.running_var.data_ptr(), W3.data_ptr(),
                 g3.data_ptr(), b3.data_ptr(), bn3.running_mean.data_ptr(), bn3.running_var.data_ptr(),
                 *ap, y.data_ptr(), scratch.data_ptr()]
-        be.bottleneck_forward(n, k, c, ptrs, training, bn1.eps, bn1.momentum or 0.1)
+        be.bottleneck_forward(n, k, c, ptrs, training, bn1.eps, bn1.momentum)
         ctx.save_for_backward(x, p, idx, act, W1, Wq, Wk, Wv, W3, Wp1, bp1, Wp2, bp2, Ww1, bw1, Ww2, bw2)
         ctx.cfg = (training, offs, k)
         return y
@@ -495,6 +510,7 @@ class _TransitionDownFn(torch.autograd.Function):
     @_amp_fwd
     def forward(ctx, mod, idx, rel4, Z, consts, x, W, gamma, beta):
         be = _be()
+        _rcd(idx, rel4, Z, x, W)
         lib = be.lib
         n, cin = x.shape
         m, cout = idx.shape[0], W.shape[0]
@@ -505,7 +521,7 @@ class _TransitionDownFn(torch.autograd.Function):
         ptrs = [x.data_ptr(), idx.data_ptr(), rel4.data_ptr(), Z.data_ptr(), consts.data_ptr(), W.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                 bn.running_mean.data_ptr(), bn.running_var.data_ptr(), coef.data_ptr(), out.data_ptr(), arg.data_ptr(), gram.data_ptr()]
         rc = lib.pdf_td_forward(n, m, cin, cout, (c_void_p * len(ptrs))(*ptrs), int(training), ctypes.c_float(bn.eps),
-                                ctypes.c_float(bn.momentum or 0.1), be._stream())
+                                ctypes.c_float(bn.momentum), be._stream())
         if rc != 0:
             raise RuntimeError(f"pdf_td_forward failed with status {rc}")
         ctx.save_for_backward(x, idx, rel4, Z, consts, W, gamma, beta, coef, out, arg, gram)
@@ -547,7 +563,7 @@ def transition_down(mod, geom, level, new_level, x):
 
 def transition_down_ok(mod, x):
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous() and type(mod.bn) is torch.nn.BatchNorm1d
-            and mod.bn.affine and mod.bn.track_running_stats and mod.linear.bias is None):
+            and mod.bn.affine and mod.bn.track_running_stats and mod.bn.momentum is not None and mod.linear.bias is None):
         return False
     if torch.is_grad_enabled() and not mod.training and any(p.requires_grad for p in mod.parameters()):
         return False
@@ -562,6 +578,7 @@ class _LinBnFn(torch.autograd.Function):
     @_amp_fwd
     def forward(ctx, lin, bn, relu, x, W, b, gamma, beta):
         be = _be()
+        _rcd(x, W, gamma)
         lib = be.lib
         n, k = x.shape
         o = W.shape[0]
@@ -572,7 +589,7 @@ class _LinBnFn(torch.autograd.Function):
         ptrs = [x.data_ptr(), W.data_ptr(), b.data_ptr() if b is not None else None, gamma.data_ptr(), beta.data_ptr(),
                 bn.running_mean.data_ptr(), bn.running_var.data_ptr(), z.data_ptr(), coef.data_ptr(), y.data_ptr(), partial.data_ptr()]
         rc = lib.pdf_linbn_forward(n, k, o, (c_void_p * len(ptrs))(*ptrs), int(training), int(relu), ctypes.c_float(bn.eps),
-                                   ctypes.c_float(bn.momentum or 0.1), be._stream())
+                                   ctypes.c_float(bn.momentum), be._stream())
         if rc != 0:
             raise RuntimeError(f"pdf_linbn_forward failed with status {rc}")
         ctx.save_for_backward(x, z, coef, W)
@@ -610,7 +627,7 @@ def linbn_ok(lin, bn, x):
     if not LINBN:
         return False
     if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous() and type(bn) is torch.nn.BatchNorm1d and bn.affine
-            and bn.track_running_stats):
+            and bn.track_running_stats and bn.momentum is not None):
         return False
     k, o = lin.in_features, lin.out_features
     if k not in (32, 64, 128, 256, 512) or o % 16 or not _be().bn_supported(o):

@@ -144,6 +144,8 @@ class PointTransformerLayer(nn.Module):
             return False
         if torch.is_grad_enabled() and not self.training and any(p.requires_grad for p in self.parameters()):
             return False  # eval-mode backward is not implemented in the fused path
+        if any(n.momentum is None for n in (self.linear_p[1], self.linear_w[0], self.linear_w[3])):
+            return False  # cumulative-average running statistics: torch's BatchNorm
         return _native.hip_backend().pt_layer_supported(self.nsample, self.out_planes)
 
     def _param_list(self):

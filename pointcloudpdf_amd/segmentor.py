@@ -43,6 +43,7 @@ class _FusedCE(torch.autograd.Function):
         n, c = pred.shape
         grad = torch.empty_like(pred)
         acc = torch.empty((3,), dtype=torch.float32, device=pred.device)   # [sum, count, mean]
+        _native.require_current_device(pred, target)
         s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         rc = be.lib.pdf_ce_forward(n, c, pred.data_ptr(), target.data_ptr(), ignore, grad.data_ptr(), acc.data_ptr(), acc.data_ptr() + 8, s)
         if rc != 0:
@@ -56,14 +57,16 @@ class _FusedCE(torch.autograd.Function):
         import ctypes
         from . import _native
 
-        grad, acc = ctx.saved_tensors
-        n, c = grad.shape
+        dlogits, acc = ctx.saved_tensors
+        n, c = dlogits.shape
         gy = gy.contiguous().float()
+        out = torch.empty_like(dlogits)   # the saved buffer stays untouched: the node may be differentiated again (retain_graph)
+        _native.require_current_device(dlogits, gy)
         s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        rc = _native.hip_backend().lib.pdf_ce_backward(n, c, grad.data_ptr(), acc.data_ptr(), gy.data_ptr(), s)
+        rc = _native.hip_backend().lib.pdf_ce_backward(n, c, dlogits.data_ptr(), acc.data_ptr(), gy.data_ptr(), out.data_ptr(), s)
         if rc != 0:
             raise RuntimeError(f"pdf_ce_backward failed with status {rc}")
-        return grad, None, None
+        return out, None, None
 
 
 class Criteria:

@@ -62,8 +62,7 @@ class WindowAttention(nn.Module):
         else:
             bias = 0.0
         attn = pointops.segment_softmax(attn + bias, off)                                  # scatter_softmax(src, index_0, dim=0), :322-324
-        if self.attn_drop.p > 0:
-            attn = self.attn_drop(attn)
+        # (upstream constructs ``attn_drop`` but never applies it -- :246 vs :322-341 -- so neither does this forward)
         if self.rel_value:
             x = pointops.attention_step2_with_rel_pos_value_v2(attn.float(), value.float(), off, n_max, i1,
                                                                self.relative_pos_value_table.float(), rel_idx)

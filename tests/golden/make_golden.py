@@ -42,6 +42,7 @@ MODEL_CASES = {
     # name: (scene sizes, grid size used by the generator)
     "b2_2048_1600": ([2048, 1600], 0.25),
     "b1_3000": ([3000], 0.2),
+    "b1_8192": ([8192], 0.12),      # BASELINE config 1: one 8,192-point scene
 }
 ROW_STRIDE = 4      # big per-point tensors are stored every ROW_STRIDE-th row (tests slice the same way)
 GRAD_ROWS = 16      # big gradient matrices: first GRAD_ROWS rows + the full-tensor sum / L2 norm
@@ -579,6 +580,102 @@ def run_pseudo_label_cases():
     return out
 
 
+PDF_CASE = ("b2_2048_1600", [2048, 1600], 0.25)
+PDF_MODES = {  # name: (train?, epoch, start_epoch, step_loss_weight, hand "segment" in?)
+    "train_pre": (True, 0, 2, False, True),      # epoch < start_epoch: U-decoder frozen, raw confidence returned, no PDF loss
+    "train_post": (True, 2, 2, False, True),     # epoch >= start_epoch: PDF loss * alpha, softmax score
+    "train_decay": (True, 4, 2, True, True),     # epoch > start_epoch + 1 with step_loss_weight: alpha * 0.1 (once)
+    "eval_seg": (False, 2, 2, False, True),      # eval with labels: softmax score
+    "eval_test": (False, 2, 2, False, False),    # test: seg_logits only
+}
+PDF_GRADS = ["model.backbone.cls.0.weight", "model.backbone.dec1.1.linear1.weight", "model.backbone.dec2.0.linear1.1.weight",
+             "recognizer.recognizer.confidence.0.weight", "recognizer.recognizer.dec1.linear2.0.weight", "recognizer.recognizer.dec3.linear2.1.weight"]
+
+
+def run_pointpdf_forward_cases(hook):
+    """One open-world step through the reference's OWN classes: DefaultSegmentor (pointcept/models/default.py:39-62) +
+    PointPdfV1.forward / trigger_operation (pointcept/recognizers/ours/pointpdf_v1m1_base.py:72-116, 384-398) wired as
+    OpenSegTrainer.model_forward does (engines/train.py:373-380, label_rename :387-391).  Extra shims, same kind as above:
+    ``pointcept.models.utils.structure`` (imports spconv; default.py only names ``Point``) is a bare module, the bare
+    ``pointcept.models.losses`` package gets ``build_criteria``, ``torch_points_kernels`` is an empty module.  The
+    pseudo-label pass itself (get_pseudo_mask: third-party ball query, row f-2, pinned separately) is replaced on the instance
+    by the fixed 1-in-7 mask that engine.default_pseudo_mask produces."""
+    sys.modules.setdefault("torch_points_kernels", types.ModuleType("torch_points_kernels"))
+    viz = types.ModuleType("pointcept.utils.visualization")
+    viz.save_point_cloud = lambda *a, **k: None
+    sys.modules["pointcept.utils.visualization"] = viz
+    st = types.ModuleType("pointcept.models.utils.structure")
+    st.Point = dict
+    sys.modules["pointcept.models.utils.structure"] = st
+    sys.modules["pointcept.models.losses"].build_criteria = sys.modules["pointcept.models.losses.builder"].build_criteria
+    if "pointcept.recognizers.ours" not in sys.modules:
+        m = types.ModuleType("pointcept.recognizers.ours")
+        m.__path__ = [os.path.join(REF, "pointcept", "recognizers", "ours")]
+        sys.modules["pointcept.recognizers.ours"] = m
+
+    def load(modname):
+        if modname in sys.modules and hasattr(sys.modules[modname], "__file__") and sys.modules[modname].__file__:
+            return sys.modules[modname]
+        path = os.path.join(REF, *modname.split(".")) + ".py"
+        spec = importlib.util.spec_from_file_location(modname, path)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[modname] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    default = load("pointcept.models.default")
+    pdf = load("pointcept.recognizers.ours.pointpdf_v1m1_base")
+    tag, sizes, gs = PDF_CASE
+    ce = [dict(type="CrossEntropyLoss", loss_weight=1.0, ignore_index=-1)]
+    out = {}
+    for mode, (train, epoch, start_epoch, step_lw, with_segment) in PDF_MODES.items():
+        batch = synthetic.make_batch(sizes, first_scene_id=100, grid_size=gs)
+
+        class RefStep(torch.nn.Module):   # same parameter names as engine.OpenSegStep: model.backbone.*, recognizer.recognizer.*
+            def __init__(self):
+                super().__init__()
+                self.model = default.DefaultSegmentor(backbone=dict(type="PointTransformer-Seg50", in_channels=6, num_classes=13), criteria=ce)
+                self.recognizer = pdf.PointPdfV1(recognizer=dict(type="PointTransformer-Recognizer"), criteria=ce, loss_weight=0.1,
+                                                 step_loss_weight=step_lw, num_classes=13, start_epoch=start_epoch, kp_ball_radius=0.1,
+                                                 kp_max_neighbor=34, condition_from="msp", beta=1.5, seed_from="ml", seed_range=0.01,
+                                                 num_seed=20, slide_window=True)
+
+        step = RefStep()
+        synthetic.fill_parameters_deterministic(step, seed=1)
+        step.train(train)
+        mh = hook.BaseModelHook(HOOK_CONFIG, clone_tensor=True, exclude_clone={"backbone": ["forward_output"]},
+                                logger=hook.BaseModelHook._DummyLogger())
+        mh.model = step.model
+        step.recognizer.model_hooks = mh
+        step.recognizer.epoch = epoch
+        step.recognizer.get_pseudo_mask = lambda coord, seg_logits, offset: (torch.arange(coord.shape[0]) % 7) == 3
+        input_dict = dict(coord=batch["coord"], feat=batch["feat"], offset=batch["offset"])
+        if with_segment:
+            input_dict["segment"] = batch["segment"]
+        with mh:
+            mo = step.model(input_dict)
+            ro = step.recognizer(input_dict)
+        out[f"{mode}_model_keys"] = np.array(sorted(mo.keys()))
+        out[f"{mode}_rec_keys"] = np.array(sorted(ro.keys()))
+        for k, v in mo.items():
+            out[f"{mode}_model_{k}"] = v.detach().numpy()
+        for k, v in ro.items():
+            out[f"{mode}_rec_{k}"] = v.detach().numpy()
+        out[f"{mode}_alpha"] = np.array(float(step.recognizer.alpha))
+        out[f"{mode}_rec_requires_grad"] = np.array([p.requires_grad for p in step.recognizer.recognizer.parameters()])
+        if train:
+            loss = mo["loss"] + ro["loss"] if "loss" in ro else mo["loss"]
+            loss.backward()
+            named = dict(step.named_parameters())
+            for k in PDF_GRADS:
+                g = named[k].grad
+                out[f"{mode}_hasgrad_{k}"] = np.array(g is not None)
+                if g is not None:
+                    pack_grad(out, f"{mode}_grad_{k}", g.numpy())
+        print("pointpdf", mode, {k: (float(v) if v.ndim == 0 else v.shape) for k, v in out.items() if k.startswith(mode) and "_rec_" in k and "keys" not in k and "requires" not in k})
+    return out
+
+
 def run_hook_case(hook):
     """BaseModelHook on a toy module: forward/backward capture + clone semantics."""
     torch.manual_seed(3)
@@ -596,25 +693,32 @@ def run_hook_case(hook):
 
 
 def main():
+    """No flag: regenerate every fixture.  --only-ball | --only-pointops2 | --only-gridsample | --only-pseudo | --only-pointpdf |
+    --only-case=<model case name>: just that one (the others are left as committed)."""
     ref_pointops, seg, rec, hook, losses = install_reference()
-    if "--only-pointops2" not in sys.argv and "--only-gridsample" not in sys.argv and "--only-pseudo" not in sys.argv:
-        np.savez_compressed(os.path.join(OUT, "ops_ball_ref.npz"), **run_ball_cases(ref_pointops))
-    if "--only-ball" in sys.argv:
-        return
-    if "--only-gridsample" not in sys.argv and "--only-pseudo" not in sys.argv:
-        np.savez_compressed(os.path.join(OUT, "ops_pointops2_ref.npz"), **run_pointops2_cases(install_reference_pointops2()))
-    if "--only-pointops2" in sys.argv:
-        return
-    if "--only-pseudo" not in sys.argv:
-        np.savez_compressed(os.path.join(OUT, "ops_gridsample_ref.npz"), **run_gridsample_cases())
-    if "--only-gridsample" in sys.argv:
-        return
-    np.savez_compressed(os.path.join(OUT, "ops_pseudo_label_ref.npz"), **run_pseudo_label_cases())
-    if "--only-pseudo" in sys.argv:
-        return
-    np.savez_compressed(os.path.join(OUT, "ops_python_ref.npz"), **run_op_cases(ref_pointops))
-    np.savez_compressed(os.path.join(OUT, "model_hook_ref.npz"), **run_hook_case(hook))
+    flags = [a for a in sys.argv[1:] if a.startswith("--only-")]
+    only_case = [a.split("=", 1)[1] for a in flags if a.startswith("--only-case=")]
+    want = lambda what: not flags or f"--only-{what}" in flags
+
+    def save(name, data):
+        np.savez_compressed(os.path.join(OUT, name), **data)
+
+    if want("ball"):
+        save("ops_ball_ref.npz", run_ball_cases(ref_pointops))
+    if want("pointops2"):
+        save("ops_pointops2_ref.npz", run_pointops2_cases(install_reference_pointops2()))
+    if want("gridsample"):
+        save("ops_gridsample_ref.npz", run_gridsample_cases())
+    if want("pseudo"):
+        save("ops_pseudo_label_ref.npz", run_pseudo_label_cases())
+    if want("pointpdf"):
+        save("model_pointpdf_forward.npz", run_pointpdf_forward_cases(hook))
+    if not flags:
+        save("ops_python_ref.npz", run_op_cases(ref_pointops))
+        save("model_hook_ref.npz", run_hook_case(hook))
     for name, (sizes, gs) in MODEL_CASES.items():
+        if flags and name not in only_case:
+            continue
         for train in (True, False):
             res = run_model_case(seg, rec, hook, losses, sizes, gs, train)
             if train:
@@ -622,7 +726,7 @@ def main():
                 print("  fp32 reference vs its own fp64 evaluation: logits", float(np.abs(res["logits"] - res["logits64"]).max()),
                       {k[5:]: float(np.abs(res[k] - res["g64_" + k[5:]]).max() / (np.abs(res["g64_" + k[5:]]).max() + 1e-30))
                        for k in ("grad_enc1.0.linear.weight", "grad_cls.0.weight", "grad_enc3.2.linear3.weight")})
-            np.savez_compressed(os.path.join(OUT, f"model_{name}_{'train' if train else 'eval'}.npz"), **res)
+            save(f"model_{name}_{'train' if train else 'eval'}.npz", res)
             print(name, "train" if train else "eval", "calls fps/knn:", res["n_pointops_calls"],
                   "loss", float(res["seg_loss"]), float(res["rec_loss"]))
     for f in sorted(os.listdir(OUT)):

@@ -8,7 +8,7 @@ from pointcloudpdf_amd.point_transformer import PointTransformerSeg50
 from pointcloudpdf_amd.recognizer import PTRecognizer
 
 # must match tests/golden/make_golden.py
-MODEL_CASES = {"b2_2048_1600": ([2048, 1600], 0.25), "b1_3000": ([3000], 0.2)}
+MODEL_CASES = {"b2_2048_1600": ([2048, 1600], 0.25), "b1_3000": ([3000], 0.2), "b1_8192": ([8192], 0.12)}
 ROW_STRIDE = 4
 GRAD_ROWS = 16
 HOOK_CONFIG = {
@@ -174,3 +174,82 @@ def check_case_against_golden(out, g, train, tol=REL_TOL):
                 assert_close(out["state"][key[4:]], g[key], tol, key)
         out["grad_report"] = report
     return n
+
+
+# ---- PointPdfV1.forward / trigger_operation fixture (tests/golden/make_golden.py: PDF_CASE / PDF_MODES / PDF_GRADS) ----
+PDF_CASE = ("b2_2048_1600", [2048, 1600], 0.25)
+PDF_MODES = {
+    "train_pre": (True, 0, 2, False, True),
+    "train_post": (True, 2, 2, False, True),
+    "train_decay": (True, 4, 2, True, True),
+    "eval_seg": (False, 2, 2, False, True),
+    "eval_test": (False, 2, 2, False, False),
+}
+PDF_GRADS = ["model.backbone.cls.0.weight", "model.backbone.dec1.1.linear1.weight", "model.backbone.dec2.0.linear1.1.weight",
+             "recognizer.recognizer.confidence.0.weight", "recognizer.recognizer.dec1.linear2.0.weight", "recognizer.recognizer.dec3.linear2.1.weight"]
+
+
+def run_pdf_case(mode, device="cpu"):
+    """DefaultSegmentor + PointPdf-v1m1 built through the registries and wired the way OpenSegTrainer.model_forward does
+    (engines/train.py:373-380); returns (model_output, recognizer_output, step module)."""
+    from pointcloudpdf_amd import engine
+    from pointcloudpdf_amd.registry import MODELS, RECOGNIZER
+
+    train, epoch, start_epoch, step_lw, with_segment = PDF_MODES[mode]
+    _, sizes, gs = PDF_CASE
+    batch = synthetic.make_batch(sizes, first_scene_id=100, grid_size=gs, device=device)
+    ce = [dict(type="CrossEntropyLoss", loss_weight=1.0, ignore_index=-1)]
+
+    class Step(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.model = MODELS.build(dict(type="DefaultSegmentor", backbone=dict(type="PointTransformer-Seg50", in_channels=6, num_classes=13), criteria=ce))
+            self.recognizer = RECOGNIZER.build(dict(type="PointPdf-v1m1", recognizer=dict(type="PointTransformer-Recognizer"), criteria=ce,
+                                                    loss_weight=0.1, step_loss_weight=step_lw, num_classes=13, start_epoch=start_epoch,
+                                                    kp_ball_radius=0.1, kp_max_neighbor=34, condition_from="msp", beta=1.5, seed_from="ml",
+                                                    seed_range=0.01, num_seed=20, slide_window=True,
+                                                    pseudo_mask_fn=engine.default_pseudo_mask))
+
+    step = Step()
+    synthetic.fill_parameters_deterministic(step, seed=1)
+    step = step.to(device)
+    step.train(train)
+    mh = BaseModelHook(HOOK_CONFIG, clone_tensor=True, exclude_clone={"backbone": ["forward_output"]}).set_model(step.model)
+    step.recognizer.model_hooks = mh
+    step.recognizer.set_epoch(epoch)
+    d = dict(coord=batch["coord"], feat=batch["feat"], offset=batch["offset"])
+    if with_segment:
+        d["segment"] = batch["segment"]
+    with mh:
+        mo = step.model(d)
+        ro = step.recognizer(d)
+    if train:
+        loss = mo["loss"] + ro["loss"] if "loss" in ro else mo["loss"]
+        loss.backward()
+    return mo, ro, step
+
+
+def check_pdf_case(mode, mo, ro, step, g, tol=REL_TOL):
+    """Against tests/golden/model_pointpdf_forward.npz (the reference's own DefaultSegmentor + PointPdfV1 classes)."""
+    assert sorted(mo.keys()) == list(g[f"{mode}_model_keys"]), (mode, sorted(mo.keys()))
+    assert sorted(ro.keys()) == list(g[f"{mode}_rec_keys"]), (mode, sorted(ro.keys()))
+    for k, v in mo.items():
+        assert tuple(v.shape) == g[f"{mode}_model_{k}"].shape
+        assert_close(v, g[f"{mode}_model_{k}"], tol, f"{mode} model {k}")
+    for k, v in ro.items():
+        assert tuple(v.shape) == g[f"{mode}_rec_{k}"].shape, (mode, k, v.shape)
+        assert_close(v, g[f"{mode}_rec_{k}"], tol, f"{mode} recognizer {k}")
+    assert abs(float(step.recognizer.alpha) - float(g[f"{mode}_alpha"])) < 1e-12
+    assert [p.requires_grad for p in step.recognizer.recognizer.parameters()] == list(g[f"{mode}_rec_requires_grad"])
+    if PDF_MODES[mode][0]:
+        named = dict(step.named_parameters())
+        for k in PDF_GRADS:
+            has = bool(g[f"{mode}_hasgrad_{k}"])
+            assert (named[k].grad is not None) == has, (mode, k)
+            if has:
+                grad = named[k].grad.detach().cpu().numpy()
+                ref = g[f"{mode}_grad_{k}"]
+                part = grad[:GRAD_ROWS] if grad.ndim >= 2 else grad
+                assert np.abs(part - ref).max() <= GRAD_TOL * (np.abs(ref).max() + 1e-30), (mode, k)
+                l2 = np.sqrt((grad.astype(np.float64) ** 2).sum())
+                assert abs(l2 - g[f"{mode}_grad_{k}#sum"][1]) <= GRAD_TOL * g[f"{mode}_grad_{k}#sum"][1] + 1e-12, (mode, k)

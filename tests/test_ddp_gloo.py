@@ -95,3 +95,16 @@ def test_shard_scene_ids_partition():
 
     ids = [engine.shard_scene_ids(16, r, 8) for r in range(8)]
     assert sorted(sum(ids, [])) == list(range(16)) and all(len(i) == 2 for i in ids)
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` starts its own ranks (no torchrun needed) and fails loudly, before any rank is started, when the
+    box has fewer GPUs -- it never falls back to timing one GPU under an n_gpus = N label."""
+    import subprocess
+    import sys
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has GPUs: the launch path itself is covered by tests/test_gpu_model.py")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "--gpus 2 but only" in r.stderr and r.stdout.strip() == ""

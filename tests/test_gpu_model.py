@@ -24,6 +24,16 @@ def test_model_matches_reference_on_gpu(golden_dir, name, train):
     helpers.check_case_against_golden(out, g, train)
 
 
+@pytest.mark.parametrize("mode", list(helpers.PDF_MODES))
+def test_pointpdf_forward_matches_reference_class_on_gpu(golden_dir, mode):
+    """DefaultSegmentor + PointPdfV1.forward / trigger_operation on the HIP path against the fixture produced by the reference's
+    own classes (tests/golden/model_pointpdf_forward.npz; pointpdf_v1m1_base.py:72-116, 384-398, default.py:39-62)."""
+    g = np.load(os.path.join(golden_dir, "model_pointpdf_forward.npz"))
+    torch.backends.cuda.matmul.allow_tf32 = False
+    mo, ro, step = helpers.run_pdf_case(mode, device="cuda")
+    helpers.check_pdf_case(mode, mo, ro, step, g)
+
+
 def test_full_size_step_runs_and_is_finite():
     """BASELINE config 2 shape (2 x 100k points): one fwd+bwd, finite outputs, every parameter receives a gradient."""
     from pointcloudpdf_amd import synthetic
@@ -191,3 +201,21 @@ def test_seg26_seg38_match_cpu_oracle_path(oracle_backend, name):
         lh, sh = run("cuda", None, train)
         helpers.assert_close(lh, lo, 1e-4, f"{name} logits train={train}")
         helpers.assert_close(sh, so, 1e-4, f"{name} loss train={train}")
+
+
+def test_bench_launches_its_own_rccl_ranks():
+    """`python bench.py --gpus 2` (no torchrun): the parent spawns one rank per GPU before touching HIP, ranks rendezvous over RCCL,
+    the JSON line carries n_gpus = rccl_ranks = 2, per-rank step times and the efficiency against a one-rank run."""
+    import json
+    import subprocess
+    import sys
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the round-end scaling run has them; the 1-GPU test box does not)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "4", "--points", "30000"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and len(line["rank_ms_per_step"]) == 2
+    assert line["config"]["gradient_exchange"] == "flat" and 0.2 < line["efficiency_vs_n1"] < 1.5
