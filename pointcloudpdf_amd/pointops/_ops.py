@@ -218,6 +218,12 @@ def interpolation(xyz, new_xyz, feat, offset, new_offset, k=3):
     """libs/pointops/functions/interpolation.py:8-22: coords (m,3) -> new_xyz (n,3), feat (m,c) -> (n,c)."""
     assert xyz.is_contiguous() and new_xyz.is_contiguous() and feat.is_contiguous()
     idx, weight = _interp_tables(xyz, new_xyz, offset, new_offset, k)
+    if feat.dtype == torch.float64:  # accuracy probes (fp64 yardstick runs): upstream's own formulation (:18-21), zero row for idx -1
+        feat_p = torch.cat([feat, feat.new_zeros(1, feat.shape[1])], dim=0)
+        out = feat.new_zeros(new_xyz.shape[0], feat.shape[1])
+        for i in range(k):
+            out = out + feat_p[idx[:, i].long(), :] * weight[:, i].double().unsqueeze(-1)
+        return out
     if feat.dtype != torch.float32:  # autocast: upstream accumulates feat[idx] * weight (fp32) into an fp32 tensor
         feat = feat.float()
     return _InterpolateIdx.apply(feat, idx, weight)
