@@ -150,15 +150,18 @@ int pdf_pt_layer_forward(int n, int nsample, int c, const float *xq, const float
                          float momentum, float *bn, float *saved, float *H, float *partial, float *out,
                          void *stream);
 
-/* Backward of the fused PointTransformerLayer (train mode).  gxk / gxv are pre-zeroed scatter targets, gxq is
- * overwritten.  sums needs pdf_pt_layer_bwd_sums_floats(c) + 2*(3+c+c/8) floats and returns the parameter-gradient
- * sections documented in csrc/fused_layer.hip. */
+/* Backward of the fused PointTransformerLayer (train mode).  gxq / gxk / gxv are overwritten: the scatters of g_xk and g_xv run as
+ * segmented gathers over the INVERSE of the kNN table (inv_off (n+1), inv_entry, entry_base -- see pdf_seg_sum_rows), so they are
+ * deterministic and atomics-free; Wsm (n*nsample*c/8) and GR (n*nsample*c) are scratch (softmax weights, g_r rows).  sums needs
+ * pdf_pt_layer_bwd_sums_floats(c) + 2*(3+c+c/8) floats and returns the parameter-gradient sections documented in
+ * csrc/fused_layer.hip. */
 long pdf_pt_layer_bwd_partial_floats(int n, int nsample, int c);
 long pdf_pt_layer_bwd_sums_floats(int c);
 int pdf_pt_layer_backward(int n, int nsample, int c, const float *xq, const float *xk, const float *xv,
                           const float *p, const int *idx, const float *const *weights, const float *bn,
                           const float *saved, const float *H, const float *gout, float *gxq, float *gxk,
-                          float *gxv, float *G2, float *G3, float *partial, float *sums, void *stream);
+                          float *gxv, float *G2, float *G3, float *Wsm, float *GR, const int *inv_off, const int *inv_entry,
+                          int entry_base, float *partial, float *sums, void *stream);
 
 /* BatchNorm1d over (n, c) rows fused with the residual add and ReLU that follow it in the Bottleneck
  * (point_transformer_seg.py:184-192).  c must be a power of two in 4..1024.  coef (4c floats) = scale|shift|mean|rstd,
@@ -216,7 +219,7 @@ int pdf_block_post_forward(long n, int c, void *const *p, int training, float ep
 int pdf_block_post_backward(long n, int c, void *const *p, int training, void *stream);
 /* The whole Bottleneck (both halves + the fused attention layer) as one call per direction; tables in csrc/block.hip. */
 int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p, int training, float eps, float momentum, void *stream);
-int pdf_bottleneck_backward(long n, int nsample, int c, void *const *p, int training, void *stream);
+int pdf_bottleneck_backward(long n, int nsample, int c, void *const *p, int training, int entry_base, void *stream);
 /* Linear (+ bias) -> BatchNorm1d -> (ReLU) as one call per direction (TransitionUp, heads); tables in csrc/block.hip. */
 int pdf_linbn_forward(long n, int k, int o, void *const *p, int training, int relu, float eps, float momentum, void *stream);
 int pdf_linbn_backward(long n, int k, int o, void *const *p, int training, int relu, void *stream);
@@ -241,6 +244,17 @@ long pdf_td_gram_floats(int cin);
 long pdf_td_bwd_scratch_floats(long m, int cin, int cout);
 int pdf_td_forward(long n, long m, int cin, int cout, void *const *p, int training, float eps, float momentum, void *stream);
 int pdf_td_backward(long n, long m, int cin, int cout, void *const *p, void *stream);
+
+/* ---- scatter-adds as segmented gathers over an inverse neighbour table (csrc/seg_gather.hip; no reference counterpart: the reference
+ * scatters with atomicAdd -- grouping_cuda_kernel.cu:20-25, interpolation_cuda_kernel.cu:27-33, subtraction_cuda_kernel.cu:24-30,
+ * aggregation_cuda_kernel.cu:30-39).  For a table idx (m, nsample) over n rows: inv_off (n + 1) ascending positions into inv_entry;
+ * inv_entry holds entry ids e + entry_base (e = i * nsample + j) grouped by destination idx[e], ascending inside a destination
+ * (fixed summation order); entries with idx < 0 lie outside every segment.  pdf_subtraction_backward / pdf_aggregation_backward
+ * accept a NULL scatter target (grad_input2 / grad_input) when the caller forms it with these. */
+int pdf_seg_sum_rows(long n, int c, const float *src, const int *inv_off, const int *inv_entry, int entry_base, float scale, float *out,
+                     void *stream);
+int pdf_seg_sum_weighted(long n, int c, int nsample, int w_c, const float *src, const float *w, const int *inv_off, const int *inv_entry,
+                         int entry_base, float *out, void *stream);
 
 /* Cross-entropy with an ignore label, mean over the counted rows (pointcept/models/losses/misc.py:14-39 as configured on
  * this path).  Forward: loss[0], acc = [sum, count], grad (n*c) = softmax - onehot (0 on ignored rows); a target that is neither

@@ -60,6 +60,8 @@ _HIP_ONLY_PROTOS = {
     "group_backward": "iiiippp",
     "interpolation_weights": "iipp",
     "farthest_point_sampling_bucketed": "iiipppplp",
+    "seg_sum_rows": "lipppifp",
+    "seg_sum_weighted": "liiippppip",
 }
 _KIND = {"i": c_int, "l": c_long, "f": c_float, "d": c_double, "p": c_void_p}
 
@@ -82,6 +84,30 @@ def require_current_device(*tensors):
         if t.device.index != cur:
             raise PdfOpsError(f"pointcloudpdf_amd: tensor on {t.device} but the current device is cuda:{cur}; call "
                               "torch.cuda.set_device(...) or wrap the call in torch.cuda.device(...)")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Inverse neighbour tables (csrc/seg_gather.hip): entry ids of a table idx (m, nsample) grouped by destination row.
+# Plumbing only (one stable device sort + one binary search per table); built once per table -- by the geometry pre-pass on
+# its side stream for the tables the model uses, lazily here for any other idx tensor -- and cached on the idx tensor object.
+# ------------------------------------------------------------------------------------------------------------------
+_INV = "_pdf_inverse"
+
+
+def attach_inverse(idx, n, table):
+    setattr(idx, _INV, (idx.data_ptr(), idx._version, int(n), table))
+    return table
+
+
+def inverse_table(idx, n):
+    """-> (inv_off (n + 1) int32, inv_entry int32, entry_base int) for idx (m, nsample) int32 with values in [-1, n)."""
+    cached = getattr(idx, _INV, None)
+    if cached is not None and cached[0] == idx.data_ptr() and cached[1] == idx._version and cached[2] == int(n):
+        return cached[3]
+    flat = idx.reshape(-1)
+    vals, perm = torch.sort(flat, stable=True)        # ascending destination, ascending entry id inside a destination; -1 first
+    off = torch.searchsorted(vals, torch.arange(int(n) + 1, device=idx.device, dtype=vals.dtype), out_int32=True)
+    return attach_inverse(idx, n, (off, perm.to(torch.int32), 0))
 
 
 def _check(t, dtype, name):
@@ -442,7 +468,7 @@ class HipBackend(CBackend):
         lib.pdf_bottleneck_forward.restype = c_int
         lib.pdf_bottleneck_forward.argtypes = [c_long, c_int, c_int, c_void_p, c_int, ctypes.c_float, ctypes.c_float, c_void_p]
         lib.pdf_bottleneck_backward.restype = c_int
-        lib.pdf_bottleneck_backward.argtypes = [c_long, c_int, c_int, c_void_p, c_int, c_void_p]
+        lib.pdf_bottleneck_backward.argtypes = [c_long, c_int, c_int, c_void_p, c_int, c_int, c_void_p]
         for nm in ("pre_backward", "post_backward"):
             f = getattr(lib, "pdf_block_" + nm)
             f.restype = c_int
@@ -489,7 +515,7 @@ class HipBackend(CBackend):
         lib.pdf_pt_layer_forward.restype = c_int
         lib.pdf_pt_layer_forward.argtypes = [c_int, c_int, c_int] + [c_void_p] * 8 + [c_int, ctypes.c_float, ctypes.c_float] + [c_void_p] * 6
         lib.pdf_pt_layer_backward.restype = c_int
-        lib.pdf_pt_layer_backward.argtypes = [c_int, c_int, c_int] + [c_void_p] * 18
+        lib.pdf_pt_layer_backward.argtypes = [c_int, c_int, c_int] + [c_void_p] * 19 + [c_int] + [c_void_p] * 3
         self.fps_mode = os.environ.get("PDFOPS_FPS", "bucketed")  # "bucketed" | "plain"
         self.knn_mode = os.environ.get("PDFOPS_KNN", "grid")      # "grid" | "scan"
         lib.pdf_knn_workspace_bytes.restype = c_long
@@ -500,6 +526,55 @@ class HipBackend(CBackend):
         lib.pdf_knn_query_ws.argtypes = [c_int, c_int, c_int] + [c_void_p] * 4 + [c_int] + [c_void_p] * 3 + [c_long, c_void_p]
 
     KNN_GRID_MAX_SCENES = 64
+    # scatter-adds of the gather family as segmented gathers over inverse tables (PDFOPS_INVERSE=0: the atomic kernels, for A/B runs)
+    use_inverse = os.environ.get("PDFOPS_INVERSE", "1") != "0"
+
+    def grouping_backward(self, grad_output, idx, n):
+        if not self.use_inverse:
+            return super().grouping_backward(grad_output, idx, n)
+        _check(grad_output, torch.float32, "grad_output"); _check(idx, torch.int32, "idx")
+        m, ns, c = grad_output.shape
+        off, ent, base = inverse_table(idx, n)
+        gi = self._new(grad_output, (n, c), torch.float32)
+        self._call("seg_sum_rows", n, c, grad_output, off, ent, base, 1.0, gi)
+        return gi
+
+    def interpolation_backward(self, grad_output, idx, weight, m):
+        if not self.use_inverse:
+            return super().interpolation_backward(grad_output, idx, weight, m)
+        _check(grad_output, torch.float32, "grad_output"); _check(idx, torch.int32, "idx"); _check(weight, torch.float32, "weight")
+        n, c = grad_output.shape
+        off, ent, base = inverse_table(idx, m)
+        gi = self._new(grad_output, (m, c), torch.float32)
+        self._call("seg_sum_weighted", m, c, idx.shape[1], 1, grad_output, weight, off, ent, base, gi)
+        return gi
+
+    def subtraction_backward(self, idx, grad_output, n2=None):
+        if not self.use_inverse:
+            return super().subtraction_backward(idx, grad_output, n2)
+        _check(grad_output, torch.float32, "grad_output"); _check(idx, torch.int32, "idx")
+        n, ns, c = grad_output.shape
+        n2 = n if n2 is None else n2
+        off, ent, base = inverse_table(idx, n2)
+        g1 = self._new(grad_output, (n, c), torch.float32, zero=True)
+        g2 = self._new(grad_output, (n2, c), torch.float32)
+        self._call("subtraction_backward", n, ns, c, idx, grad_output, g1, None)       # row sums only
+        self._call("seg_sum_rows", n2, c, grad_output, off, ent, base, -1.0, g2)
+        return g1, g2
+
+    def aggregation_backward(self, input, position, weight, idx, grad_output):
+        if not self.use_inverse:
+            return super().aggregation_backward(input, position, weight, idx, grad_output)
+        _check(grad_output, torch.float32, "grad_output")
+        n, ns, c = position.shape
+        w_c = weight.shape[-1]
+        off, ent, base = inverse_table(idx, input.shape[0])
+        gi = self._new(input, tuple(input.shape), torch.float32)
+        gp = self._new(input, (n, ns, c), torch.float32)
+        gw = self._new(input, (n, ns, w_c), torch.float32, zero=True)
+        self._call("aggregation_backward", n, ns, c, w_c, input, position, weight, idx, grad_output, None, gp, gw)
+        self._call("seg_sum_weighted", input.shape[0], c, ns, w_c, grad_output, weight, off, ent, base, gi)
+        return gi, gp, gw
 
     def knn_query(self, nsample, xyz, new_xyz, offset, new_offset):
         if self.knn_mode == "scan" or not self.lib.pdf_knn_grid_supported(int(nsample)):
@@ -574,17 +649,21 @@ class HipBackend(CBackend):
         _check(gout, torch.float32, "gout")
         require_current_device(xq, gout)
         gxq = self._new(xq, (n, c), torch.float32)
-        gxk = self._new(xq, (n, c), torch.float32, zero=True)
-        gxv = self._new(xq, (n, c), torch.float32, zero=True)
+        gxk = self._new(xq, (n, c), torch.float32)
+        gxv = self._new(xq, (n, c), torch.float32)
         G2 = self._new(xq, (n * k * cs,), torch.float32)
         G3 = self._new(xq, (n * k * 3,), torch.float32)
+        Wsm = self._new(xq, (n * k * cs,), torch.float32)
+        GR = self._new(xq, (n * k * c,), torch.float32)
+        inv_off, inv_entry, entry_base = inverse_table(idx, n)
         partial = self._new(xq, (int(self.lib.pdf_pt_layer_bwd_partial_floats(n, k, c)),), torch.float32)
         nsum = int(self.lib.pdf_pt_layer_bwd_sums_floats(c))
         sums = self._new(xq, (nsum + 2 * (3 + c + cs),), torch.float32)
         rc = self.lib.pdf_pt_layer_backward(
             n, k, c, self._ptr(xq), self._ptr(xk), self._ptr(xv), self._ptr(p), self._ptr(idx),
             self._ptr_array(weights), self._ptr(bn), self._ptr(saved), self._ptr(H), self._ptr(gout),
-            self._ptr(gxq), self._ptr(gxk), self._ptr(gxv), self._ptr(G2), self._ptr(G3), self._ptr(partial),
+            self._ptr(gxq), self._ptr(gxk), self._ptr(gxv), self._ptr(G2), self._ptr(G3), self._ptr(Wsm), self._ptr(GR),
+            self._ptr(inv_off), self._ptr(inv_entry), int(entry_base), self._ptr(partial),
             self._ptr(sums), c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
             raise PdfOpsError(f"pdf_pt_layer_backward failed with status {rc}")
@@ -726,8 +805,8 @@ class HipBackend(CBackend):
         if rc != 0:
             raise PdfOpsError(f"pdf_bottleneck_forward failed with status {rc}")
 
-    def bottleneck_backward(self, n, k, c, ptrs, training):
-        rc = self.lib.pdf_bottleneck_backward(n, k, c, (c_void_p * len(ptrs))(*ptrs), int(training), self._stream())
+    def bottleneck_backward(self, n, k, c, ptrs, training, entry_base=0):
+        rc = self.lib.pdf_bottleneck_backward(n, k, c, (c_void_p * len(ptrs))(*ptrs), int(training), int(entry_base), self._stream())
         if rc != 0:
             raise PdfOpsError(f"pdf_bottleneck_backward failed with status {rc}")
 
@@ -827,6 +906,8 @@ class HipBackend(CBackend):
 
     def group_backward(self, grad_output, idx, n, c, with_xyz):
         _check(grad_output, torch.float32, "grad_output")
+        if not with_xyz and self.use_inverse:
+            return self.grouping_backward(grad_output, idx, n)
         m, ns = idx.shape
         gf = self._new(grad_output, (n, c), torch.float32, zero=True)
         self._call("group_backward", m, ns, c, 1 if with_xyz else 0, grad_output, idx, gf)

@@ -150,17 +150,19 @@ extern "C" int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p
 //    0 gy | 1 x 2 z1 3 coef1 4 W1 5 Wq 6 Wk 7 Wv | 8 coord 9 knn idx 10-17 layer weights 18 layer bn 19 layer saved 20 H
 //   21 xq 22 xk 23 xv | 24 t 25 z3 26 coef2 27 coef3 28 W3
 //   outputs: 29 gx (n*c; = identity branch + linear1 branch) 30 grads of the pre half (block_pre_backward layout)
-//            [30 | 31 | 36 | 37 must be laid out contiguously in this order: they are zeroed with one memset]
+//            [30 | 31 | 32 must be laid out contiguously in this order: 30 and 31 are zeroed with one memset]
 //            31 grads of the post half (pdf_block_post_backward layout) 32 layer sums (pdf_pt_layer_bwd_sums_floats(c))
 //   scratch: 33 gt 34 da / dy 35 gxq 36 gxk 37 gxv (n*c each) 38 G2 (n*nsample*c/8) 39 G3 (n*nsample*3)
 //            40 partial (max of pdf_bn_partial_floats, pdf_pt_layer_bwd_partial_floats)
-extern "C" int pdf_bottleneck_backward(long n, int nsample, int c, void *const *p, int training, void *stream) {
+//            41 Wsm (n*nsample*c/8) 42 GR (n*nsample*c) | inverse kNN table: 43 inv_off (n+1) 44 inv_entry, entry_base
+extern "C" int pdf_bottleneck_backward(long n, int nsample, int c, void *const *p, int training, int entry_base, void *stream) {
     if (n < 1 || !p) return PDF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     Err e;
     void *post[13] = {p[0], p[24], p[1], p[25], p[26], p[27], p[28], p[33], p[29], p[31], p[34], p[40], nullptr};
-    // ONE memset: the caller lays out [grads of the pre half | grads of the post half | gxk | gxv] contiguously (p[30] .. end of p[37])
-    hipError_t he = hipMemsetAsync(p[30], 0, (size_t)((char *)p[37] - (char *)p[30]) + sizeof(float) * (size_t)n * c, s);
+    // ONE memset: the caller lays out [grads of the pre half | grads of the post half] contiguously (p[30] .. p[32]); g_xk / g_xv are
+    // written by the segmented gathers (no zeroing)
+    hipError_t he = hipMemsetAsync(p[30], 0, (size_t)((char *)p[32] - (char *)p[30]), s);
     if (he != hipSuccess) return (int)he;
     e << block_post_backward(n, c, post, training, 1, stream);
     const float *weights[8];
@@ -168,6 +170,7 @@ extern "C" int pdf_bottleneck_backward(long n, int nsample, int c, void *const *
     e << pdf_pt_layer_backward((int)n, nsample, c, (const float *)p[21], (const float *)p[22], (const float *)p[23], (const float *)p[8],
                                (const int *)p[9], weights, (const float *)p[18], (const float *)p[19], (const float *)p[20],
                                (const float *)p[33], (float *)p[35], (float *)p[36], (float *)p[37], (float *)p[38], (float *)p[39],
+                               (float *)p[41], (float *)p[42], (const int *)p[43], (const int *)p[44], entry_base,
                                (float *)p[40], (float *)p[32], stream);
     void *pre[15] = {p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[35], p[36], p[37], p[29], p[30], p[34], p[40], nullptr};
     e << block_pre_backward(n, c, pre, training, 1, 1, stream);   // gx += dy W1 on top of the identity branch

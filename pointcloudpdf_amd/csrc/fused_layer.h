@@ -29,7 +29,9 @@ struct LayerArgs {
     cfloat_p sums;                           // column sums of the previous backward pass (BatchNorm-backward terms)
     cfloat_p sums2;                          // B3 only: column sums of B1 (BN2-backward terms), `sums` then holds B2's
     float *G2, *G3;                          // (N,K,CS) grad wrt BN2 output (post-ReLU mask), (N,K,3) same for BNp
-    float *gxq, *gxk, *gxv;                  // (N,C) gradients (gxk / gxv pre-zeroed scatter targets)
+    float *gxq, *gxk, *gxv;                  // (N,C) gradients
+    float *Wsm, *GR;                         // (N,K,CS) softmax weights (B1 -> g_xv gather), (N,K,C) g_r rows (B3 -> g_xk gather):
+                                             // the scatters of g_xv / g_xk run as segmented gathers over the inverse kNN table
     float inv_rows;                          // 1 / (N*K)
 };
 

@@ -398,16 +398,14 @@ __global__ __launch_bounds__(64 * WPB) void k_p4(LayerArgs A) {
 // exchanged through LDS tiles), written as one partial row per wave and column-summed by k_colsum (deterministic).
 constexpr int MAX_BLOCKS_BWD = 256;
 
-// Scatter-add the 64x32 tile into rows L.rowid[] of `table`.  One instruction = 2 rows x 32 consecutive channels, i.e. two
-// whole 128-byte lines: the L2 / memory-side atomic units are billed per request, and the former 8-rows-x-8-lanes shape
-// (16-byte pieces of 8 different rows) cost 16 requests per instruction instead of 4 (TCC request count = kernel time here).
-__device__ __forceinline__ void scatter_rows_atomic(const WaveLds &L, float *__restrict__ table, int C, int c0, int lane) {
+// Store the 64x32 tile as channels [c0, c0+32) of rows row0 .. row0+63 of `table` (E x C): 2 rows x 32 consecutive channels per
+// instruction = whole 128-byte lines, streamed (read once by the segmented gather that follows).
+__device__ __forceinline__ void store_rows(const WaveLds &L, float *__restrict__ table, int C, int c0, long row0, long nrows, int lane) {
     const int half = lane >> 5, col = lane & 31;
 #pragma unroll 8
     for (int t = 0; t < 32; ++t) {
         const int row = 2 * t + half;
-        const int dst = L.rowid[row];
-        if (dst >= 0) pdf_atomic_add(table + (size_t)dst * C + c0 + col, L.tile[row * L.ts + col]);
+        if (row0 + row < nrows) __builtin_nontemporal_store(L.tile[row * L.ts + col], table + (size_t)(row0 + row) * C + c0 + col);
     }
 }
 
@@ -465,7 +463,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
             stage_rows(L, A.xv, C, q * 32, lane);
             stage_points<PPT>(L, A.gout, C, q * 32, (int)(tile * PPT), A.N, lane);
             wave_sync();
-            float pr[32], ga[32];
+            float pr[32];
             pos_chunk(A, t1n, q * 32, pr);
             const float *xv = L.tile + lane * L.ts;
             const float *go = L.qtile + (lane / K) * L.ts;
@@ -473,14 +471,13 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
             for (int c = 0; c < 32; ++c) {
                 const float g = R.valid ? go[c] : 0.f;
                 gw[(q * 32 + c) % CS] += g * (xv[c] + pr[c]);
-                ga[c] = g * w[(q * 32 + c) % CS];
             }
             wave_sync();
+        }
+        if (R.valid) {   // softmax weights of the row: g_xv[nb] = sum over the inverse table of g_out[i] * w  (pdf_seg_sum_weighted)
+            float *dst = A.Wsm + (size_t)R.row * CS;
 #pragma unroll
-            for (int c = 0; c < 32; ++c) L.tile[lane * L.ts + c] = ga[c];
-            wave_sync();
-            scatter_rows_atomic(L, A.gxv, C, q * 32, lane);
-            wave_sync();
+            for (int o = 0; o < CS; o += 4) *reinterpret_cast<float4 *>(dst + o) = make_float4(w[o], w[o + 1], w[o + 2], w[o + 3]);
         }
         // softmax backward over the K neighbours, then Linear(CS,CS) and the ReLU of BN2
         float gz[CS], gy2[CS];
@@ -705,7 +702,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
 #pragma unroll
             for (int c = 0; c < 32; ++c) L.tile[lane * L.ts + c] = g[c];
             wave_sync();
-            scatter_rows_atomic(L, A.gxk, C, q * 32, lane);
+            store_rows(L, A.GR, C, q * 32, tile * 64, (long)A.N * K, lane);   // g_xk[nb] = segmented sum of these rows (pdf_seg_sum_rows)
             // g_xq[i] = - sum_j g_r
 #pragma unroll
             for (int m = 0; m < PPT / 2; ++m) {
@@ -1003,7 +1000,7 @@ static inline int grid_for_tiles_bwd(long ntiles, int c) {
 }
 
 template <int C, int K>
-int backward_impl(LayerArgs A, float *sums, hipStream_t s) {
+int backward_impl(LayerArgs A, float *sums, const int *inv_off, const int *inv_entry, int entry_base, hipStream_t s) {
     constexpr int CS = C / 8;
     const long rows = (long)A.N * K;
     const long ntiles = (rows + 63) / 64;
@@ -1018,6 +1015,9 @@ int backward_impl(LayerArgs A, float *sums, hipStream_t s) {
     const bool mfma = flm::supported(K, C);
     if (mfma) flm::launch_b1(A, C, grid, s); else k_b1<C, K><<<grid, 64 * WPB, lds, s>>>(A);
     k_colsum<<<pdf_divup(b1_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, nw, b1_width<C>(), S1);
+    // g_xv[nb, c] = sum over the entries (i, j) with idx[i, j] == nb of g_out[i, c] * w[i, j, c mod C/8]   (no atomics, fixed order)
+    int rc = pdf_seg_sum_weighted(A.N, C, K, CS, A.gout, A.Wsm, inv_off, inv_entry, entry_base, A.gxv, s);
+    if (rc != PDF_OK) return rc;
     A.sums = as_const(S1);
     if (mfma) flm::launch_b2(A, C, grid, s); else k_b2<C, K><<<grid, 64 * WPB, lds, s>>>(A);
     k_colsum<<<pdf_divup(b2_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, nw, b2_width<C>(), S2);
@@ -1025,6 +1025,8 @@ int backward_impl(LayerArgs A, float *sums, hipStream_t s) {
     A.sums2 = as_const(S1);
     if (mfma) flm::launch_b3(A, C, grid, s); else k_b3<C, K><<<grid, 64 * WPB, lds, s>>>(A);
     k_colsum<<<pdf_divup(b3_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, nw, b3_width<C>(), S3);
+    rc = pdf_seg_sum_rows(A.N, C, A.GR, inv_off, inv_entry, entry_base, 1.0f, A.gxk, s);   // g_xk[nb] = sum of the g_r rows that gathered nb
+    if (rc != PDF_OK) return rc;
     A.sums = as_const(S3);
     k_b4<K><<<grid, 64 * WPB, 0, s>>>(A);
     k_colsum<<<1, RED_THREADS, 0, s>>>(A.partial, nw, b4_width(), S4);
@@ -1047,7 +1049,8 @@ extern "C" long pdf_pt_layer_bwd_sums_floats(int c) {
 }
 
 // Backward of one PointTransformerLayer (training mode).  Inputs as the forward plus g_out, the forward's bn / saved /
-// H buffers; outputs: gxq (N,C) written, gxk / gxv (N,C) PRE-ZEROED scatter targets, G2 (N*K*C/8) and G3 (N*K*3)
+// H buffers and the INVERSE of the kNN table (inv_off (N+1), inv_entry, entry_base: csrc/seg_gather.hip); outputs: gxq, gxk, gxv
+// (N,C) written (no pre-zeroing: the scatters run as segmented gathers), G2 (N*K*C/8), G3 (N*K*3), Wsm (N*K*C/8) and GR (N*K*C)
 // scratch, partial scratch (pdf_pt_layer_bwd_partial_floats), sums (pdf_pt_layer_bwd_sums_floats) which receives
 //   S1 = [sum g_y2 | sum g_y2*hhat | g_bw2 | g_Ww2]          -> d beta2, d gamma2, d bw2, d Ww2
 //   S2 = [sum g_y1 | sum g_y1*rhat | g_bw1 | g_Ww1]          -> d beta1, d gamma1, d bw1, d Ww1
@@ -1056,9 +1059,10 @@ extern "C" long pdf_pt_layer_bwd_sums_floats(int c) {
 extern "C" int pdf_pt_layer_backward(int n, int nsample, int c, const float *xq, const float *xk, const float *xv,
                                      const float *p, const int *idx, const float *const *weights, const float *bn,
                                      const float *saved, const float *H, const float *gout, float *gxq, float *gxk,
-                                     float *gxv, float *G2, float *G3, float *partial, float *sums, void *stream) {
+                                     float *gxv, float *G2, float *G3, float *Wsm, float *GR, const int *inv_off, const int *inv_entry,
+                                     int entry_base, float *partial, float *sums, void *stream) {
     if (n < 1 || !xq || !xk || !xv || !p || !idx || !weights || !bn || !saved || !H || !gout || !gxq || !gxk || !gxv ||
-        !G2 || !G3 || !partial || !sums)
+        !G2 || !G3 || !Wsm || !GR || !inv_off || !inv_entry || !partial || !sums)
         return PDF_ERR_BAD_ARG;
     if (!pdf_pt_layer_supported(nsample, c)) return PDF_ERR_UNSUPPORTED;
     const int cs = c / 8;
@@ -1070,10 +1074,10 @@ extern "C" int pdf_pt_layer_backward(int n, int nsample, int c, const float *xq,
     A.sp = as_const(bn); A.tp = as_const(bn + 3); A.s1 = as_const(bn + 6); A.t1 = as_const(bn + 6 + c);
     A.s2 = as_const(bn + 6 + 2 * c); A.t2 = as_const(bn + 6 + 2 * c + cs);
     A.H = const_cast<float *>(H); A.out = nullptr; A.partial = partial;
-    A.gout = gout; A.G2 = G2; A.G3 = G3; A.gxq = gxq; A.gxk = gxk; A.gxv = gxv; A.sums = as_const(nullptr); A.sums2 = as_const(nullptr);
+    A.gout = gout; A.G2 = G2; A.G3 = G3; A.gxq = gxq; A.gxk = gxk; A.gxv = gxv; A.Wsm = Wsm; A.GR = GR; A.sums = as_const(nullptr); A.sums2 = as_const(nullptr);
     hipStream_t s = static_cast<hipStream_t>(stream);
     A.mean = as_const(saved); A.rstd = as_const(saved + (3 + c + cs));   // forward's layout: [mean p|1|2][rstd p|1|2]
-#define PDF_BWD(C_, K_) return fl::backward_impl<C_, K_>(A, sums, s)
+#define PDF_BWD(C_, K_) return fl::backward_impl<C_, K_>(A, sums, inv_off, inv_entry, entry_base, s)
     if (nsample == 8) {
         if (c == 32) PDF_BWD(32, 8);
         if (c == 64) PDF_BWD(64, 8);

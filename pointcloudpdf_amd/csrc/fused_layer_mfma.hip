@@ -298,15 +298,6 @@ __global__ __launch_bounds__(64 * WPB) void k_p4(LayerArgs A) {
     }
 }
 
-// scatter-add the wave's 16 x 64 tile into rows rowid[] of `table`, lanes along channels (4 whole lines per instruction)
-__device__ __forceinline__ void scatter_tile(const float *tile, const int *rowid, float *table, int C, int c0, int lane) {
-#pragma unroll 4
-    for (int rr = 0; rr < 16; ++rr) {
-        const int dst = rowid[rr];
-        if (dst >= 0) pdf_atomic_add(table + (size_t)dst * C + c0 + lane, tile[rr * TS + lane]);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ B1
 // partial row per wave: [sum g_y2 (CS) | sum g_y2*hhat (CS) | g_bw2 (CS) | g_Ww2 (CS*CS)]   (as fl::k_b1)
 template <int C>
@@ -336,7 +327,6 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
         const int nb_cur = nb_next;
         nb_next = i + nwaves < A.N ? A.idx[(i + nwaves) * 16 + row] : -1;   // next trip's index: in flight during this trip
         const PRow R = load_prow(A, i, nb_cur);
-        if (kq == 0) rowid[row] = R.nb;
         f32x4 h[NOB], u[NOB], w[NOB], gw[NOB];
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) { h[ob] = ld_units<C>(A.H, i * 16 + row, ob, kq); gw[ob] = zero4(); }
@@ -350,12 +340,12 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
                 const f32x4 xv = R.nb >= 0 ? ld4(A.xv + (size_t)R.nb * C + 4 * g) : zero4();
                 const f32x4 pr = pos4(cst, C, g, R.t1n);
                 gw[jj % NOB] += go * (xv + pr);
-                st4(tile + row * TS + 16 * jj + 4 * kq, go * w[jj % NOB]);
             }
-            wave_sync();
-            scatter_tile(tile, rowid, A.gxv, C, 64 * q, lane);
-            wave_sync();
         }
+        // softmax weights of the 16 rows: g_xv[nb] = sum over the inverse kNN table of g_out[i] * w  (pdf_seg_sum_weighted)
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob)
+            if (16 * ob + 4 * kq < CS) st4(A.Wsm + ((size_t)i * 16 + row) * CS + 16 * ob + 4 * kq, w[ob]);
         // softmax backward over the 16 rows, Linear(CS, CS) backward, ReLU / BN2 bookkeeping
         f32x4 gz[NOB];
         if (CS < 16) gw[0] += xchg32(gw[0]);   // 8 units: lanes kq and kq ^ 2 hold partial sums of the same units
@@ -571,7 +561,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
         float sbp2 = 0.f, awp2[3] = {0.f, 0.f, 0.f};
         for (long i = wave_g; i < A.N; i += nwaves) {
             const PRow R = load_prow(A, i, A.idx[i * 16 + row]);   // (index prefetch one trip ahead: slower here at C = 256, measured)
-            if (kq == 0) { rowid[row] = R.nb; t1nt[row * 4 + 0] = R.t1n[0]; t1nt[row * 4 + 1] = R.t1n[1]; t1nt[row * 4 + 2] = R.t1n[2]; }
+            if (kq == 0) { t1nt[row * 4 + 0] = R.t1n[0]; t1nt[row * 4 + 1] = R.t1n[1]; t1nt[row * 4 + 2] = R.t1n[2]; }
             f32x4 gh[NOB], h[NOB], u[NOB], w[NOB];
             hidden_grad<C>(A, S1, i, row, kq, gh, h);
             attn_weights<C>(A, w2, row, kq, h, u, w);
@@ -612,14 +602,13 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
                 }
             }
             wave_sync();
-            {   // lanes along channels: scatter g_xk, g_xq[i] = - sum_rows g_r
+            {   // lanes along channels: g_r rows out (256 B per row and chunk), g_xq[i] = - sum_rows g_r
                 float acc = 0.f;
 #pragma unroll 4
                 for (int rr = 0; rr < 16; ++rr) {
                     const float v = tile[rr * TS + lane];
                     acc += v;
-                    const int dst = rowid[rr];
-                    if (dst >= 0) pdf_atomic_add(A.gxk + (size_t)dst * C + 64 * q + lane, v);
+                    __builtin_nontemporal_store(v, A.GR + ((size_t)i * 16 + rr) * C + 64 * q + lane);   // g_xk = segmented sum of these rows
                 }
                 A.gxq[(size_t)i * C + 64 * q + lane] = -acc;
             }

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(GB) void sub_bwd_kernel(long n, int nsample, int cv
             const int j = idx[r * nsample + s];
 #pragma unroll
             for (int u = 0; u < V; ++u) vset(acc, u, vget(acc, u) + vget(g, u));
-            if (j < 0) continue;
+            if (j < 0 || !grad_input2) continue;   // (null: the caller forms grad_input2 by the segmented gather, seg_gather.hip)
             float *dst = grad_input2 + ((long)j * cv + col) * V;
 #pragma unroll
             for (int u = 0; u < V; ++u) pdf_atomic_add(dst + u, -vget(g, u));
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(GB) void agg_bwd_kernel(long n, int nsample, int c,
             const long wi = (r * nsample + s) * w_c + wcol;
             const float w = weight[wi];
             const float in = j >= 0 ? input[(long)j * c + col] : 0.f;
-            if (j >= 0) pdf_atomic_add(grad_input + (long)j * c + col, go * w);
+            if (j >= 0 && grad_input) pdf_atomic_add(grad_input + (long)j * c + col, go * w);
             grad_position[pi] = go * w;
             pdf_atomic_add(grad_weight + wi, go * (in + position[pi]));
         }
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(GB) void agg_bwd32(unsigned total, FastDiv cd, int 
                 const unsigned long pi = (base + s) * c + col;
                 const float w = weight[(base + s) * w_c + wcol];
                 const float in = j >= 0 ? input[(unsigned long)j * c + col] : 0.f;
-                if (j >= 0) pdf_atomic_add(grad_input + (unsigned long)j * c + col, go * w);
+                if (j >= 0 && grad_input) pdf_atomic_add(grad_input + (unsigned long)j * c + col, go * w);
                 st_stream(grad_position + pi, go * w);
                 gw = go * (in + __builtin_nontemporal_load(position + pi));
             }
@@ -604,7 +604,7 @@ extern "C" int pdf_subtraction_forward(int n, int nsample, int c, const float *i
 
 extern "C" int pdf_subtraction_backward(int n, int nsample, int c, const int *idx, const float *grad_output, float *grad_input1, float *grad_input2, void *stream) {
     if (n == 0) return PDF_OK;
-    if (n < 0 || nsample < 1 || c < 1 || !idx || !grad_output || !grad_input1 || !grad_input2) return PDF_ERR_BAD_ARG;
+    if (n < 0 || nsample < 1 || c < 1 || !idx || !grad_output || !grad_input1) return PDF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // scatter-adds run one float per lane (64 consecutive floats = whole 128-byte lines per instruction): the atomic units
     // bill per request, and the 16-byte-per-lane shape splits every line into four requests (see fused_layer.hip)
@@ -632,9 +632,8 @@ extern "C" int pdf_aggregation_backward(int n, int nsample, int c, int w_c, cons
                                         const float *weight, const int *idx, const float *grad_output,
                                         float *grad_input, float *grad_position, float *grad_weight, void *stream) {
     if (n == 0) return PDF_OK;
-    if (n < 0 || nsample < 1 || c < 1 || w_c < 1 || !input || !position || !weight || !idx || !grad_output ||
-        !grad_input || !grad_position || !grad_weight)
-        return PDF_ERR_BAD_ARG;
+    if (n < 0 || nsample < 1 || c < 1 || w_c < 1 || !input || !position || !weight || !idx || !grad_output || !grad_position || !grad_weight)
+        return PDF_ERR_BAD_ARG;   // (grad_input may be null: the caller forms it by the segmented gather, pdf_seg_sum_weighted)
     hipStream_t s = static_cast<hipStream_t>(stream);
     if ((long)n * nsample * c < (1L << 31) && 64 % w_c == 0 && c % w_c == 0 && (c % 64 == 0 || 64 % c == 0)) {
         const unsigned total = (unsigned)((long)n * c);

@@ -429,15 +429,16 @@ class _BottleneckFn(torch.autograd.Function):
         cs, cc, nc = c // 8, c * c, n * c
         gy = gy.contiguous()
         npre, npost, nsum = cc + 2 * c + 3 * (cc + c), cc + 4 * c, int(lib.pdf_pt_layer_bwd_sums_floats(c))
-        # one buffer, zeroed by ONE memset in C: [grads pre | grads post | gxk | gxv] then the layer's sums (overwritten)
+        # one buffer: [grads pre | grads post] zeroed by ONE memset in C, then the layer's sums (overwritten)
         o_pre, o_post = 0, _al(npre)
-        o_gxk = o_post + _al(npost)
-        o_gxv = o_gxk + _al(nc)
-        o_sum = o_gxv + _al(nc)
+        o_sum = o_post + _al(npost)
         grads = torch.empty((o_sum + _al(nsum),), dtype=torch.float32, device=x.device)
         gx = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        from . import _native
+        inv_off, inv_entry, entry_base = _native.inverse_table(idx, n)   # cached on idx by the geometry pre-pass
         ssz = [nc, nc, nc, n * k * cs, n * k * 3,
-               max(int(lib.pdf_bn_partial_floats(n, c)), int(lib.pdf_pt_layer_bwd_partial_floats(n, k, c)))]   # gt da gxq G2 G3 partial
+               max(int(lib.pdf_bn_partial_floats(n, c)), int(lib.pdf_pt_layer_bwd_partial_floats(n, k, c))),
+               nc, nc, n * k * cs, n * k * c]   # gt da gxq G2 G3 partial | gxk gxv Wsm GR
         soff, tot = [], 0
         for sz in ssz:
             soff.append(tot)
@@ -450,8 +451,8 @@ class _BottleneckFn(torch.autograd.Function):
                 Wp1.data_ptr(), bp1.data_ptr(), Wp2.data_ptr(), bp2.data_ptr(), Ww1.data_ptr(), bw1.data_ptr(), Ww2.data_ptr(), bw2.data_ptr(),
                 A(5), A(6), A(7), A(2), A(3), A(4), A(8), A(10), A(9), A(11), W3.data_ptr(),
                 gx.data_ptr(), gb + 4 * o_pre, gb + 4 * o_post, gb + 4 * o_sum,
-                S(0), S(1), S(2), gb + 4 * o_gxk, gb + 4 * o_gxv, S(3), S(4), S(5)]
-        be.bottleneck_backward(n, k, c, ptrs, training)
+                S(0), S(1), S(2), S(6), S(7), S(3), S(4), S(5), S(8), S(9), inv_off.data_ptr(), inv_entry.data_ptr()]
+        be.bottleneck_backward(n, k, c, ptrs, training, entry_base)
         G = lambda o, sz, *shape: grads[o:o + sz].view(*shape) if shape else grads[o:o + sz]
         # pre half: dW1 | dbeta1 | dgamma1 | {dW, db} x q, k, v
         dW1, db1, dg1 = G(o_pre, cc, c, c), G(o_pre + cc, c), G(o_pre + cc + c, c)

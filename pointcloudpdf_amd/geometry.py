@@ -164,6 +164,15 @@ class Geometry:
             self._memo[key] = (rel4, Z, scene_sums, _td_consts(scene_sums))
         return self._memo[key]
 
+    def inverse(self, nsample, src_level, query_level):
+        """Inverse of the kNN table (nsample, src_level, query_level): (inv_off, inv_entry, entry_base), see csrc/seg_gather.hip.
+        Also cached on the idx tensor itself, which is where the backward passes look it up."""
+        key = ("inv", nsample, src_level, query_level)
+        if key not in self._memo:
+            idx, _ = self.knn(nsample, src_level, query_level)
+            self._memo[key] = _native.inverse_table(idx, self.levels[src_level].p.shape[0])
+        return self._memo[key]
+
     def memo_size(self):
         """Number of memoised geometry ops (FPS + kNN + interpolation tables)."""
         return sum(1 for k in self._memo if k[0] in ("down", "knn", "interp"))  # ("td" tables are derived data)
@@ -186,6 +195,13 @@ class Geometry:
         if self.levels[0].p.is_cuda:                     # tables of the fused TransitionDown (device path only)
             for i in range(1, len(strides)):
                 self.td(nsamples[i], i - 1, i)
+            if _native.hip_backend().use_inverse:        # inverse tables for the gather-form backward passes (device path only)
+                for i in range(len(strides)):
+                    self.inverse(nsamples[i], i, i)      # PointTransformerLayer g_xk / g_xv
+                for i in range(1, len(strides)):
+                    self.inverse(interp_k, i, i - 1)     # interpolation backward (TransitionUp, U-decoder)
+                if recognizer:
+                    self.inverse(interp_k, lvl, lvl)
         return self
 
     def load(self, src):
@@ -238,12 +254,17 @@ class Geometry:
                 elif kind == "knn":
                     (idx, dist2), (q0, q1) = val, rows[key[3]]
                     g._memo[key] = (rebase(idx[q0:q1], rows[key[2]][0]), dist2[q0:q1])
-                elif kind == "interp":
+                elif kind == "interp":   # (the index tensor OBJECT of the kNN entry: the inverse table is cached on it)
                     (idx, weight), (q0, q1) = val, rows[key[3]]
-                    g._memo[key] = (rebase(idx[q0:q1], rows[key[2]][0]), weight[q0:q1])
+                    g._memo[key] = (g._memo[("knn",) + key[1:]][0], weight[q0:q1])
                 elif kind == "td":   # rel4 by query rows, Z by source rows; the 12 sums are per batch
                     (rel4, Z, scene_sums, _), (q0, q1), (r0, r1) = val, rows[key[3]], rows[key[2]]
                     g._memo[key] = (rel4[q0:q1], Z[r0:r1], scene_sums[s0:s1], _td_consts(scene_sums[s0:s1]))
+                elif kind == "inv":   # absolute positions into the group's shared entry array; entry ids rebased by the batch's first entry
+                    (off, ent, base), (q0, _), (r0, r1) = val, rows[key[3]], rows[key[2]]
+                    tab = (off[r0:r1 + 1], ent, base + q0 * key[1])
+                    g._memo[key] = tab
+                    _native.attach_inverse(g._memo[("knn",) + key[1:]][0], r1 - r0, tab)
                 else:
                     raise RuntimeError(f"Geometry.split: unknown memo entry {key}")
             out.append(g)

@@ -118,11 +118,22 @@ def test_grouped_prepass_split_is_bit_identical_on_gpu():
         for key, va in part._memo.items():
             vb = alone._memo[key]
             for ta, tb in zip(va if isinstance(va, tuple) else (va,), vb if isinstance(vb, tuple) else (vb,)):
+                if key[0] == "inv":
+                    continue   # compared below (absolute positions into the group's shared entry array)
                 if isinstance(ta, torch.Tensor):
                     if key[0] == "td":   # float sums accumulated with atomics: equal up to the summation order
                         assert ta.shape == tb.shape and helpers.max_rel(ta.cpu().numpy(), tb.cpu().numpy()) < 1e-5, key
                     else:
                         assert torch.equal(ta, tb), key
+        for key, (off, ent, base) in part._memo.items():   # inverse kNN tables: same segments, same entry order
+            if key[0] != "inv":
+                continue
+            off_a, ent_a, base_a = alone._memo[key]
+            lo, hi = int(off[0]), int(off[-1])
+            assert base_a == 0 and torch.equal(off - lo, off_a - int(off_a[0])), key
+            assert torch.equal(ent[lo:hi] - base, ent_a[int(off_a[0]):int(off_a[-1])]), key
+            idx = part._memo[("knn",) + key[1:]][0]
+            assert getattr(idx, "_pdf_inverse")[3] is part._memo[key]   # cached where the backward passes look it up
 
 
 def _scannet_step(device, sizes, backend=None):
