@@ -534,6 +534,8 @@ class HipBackend(CBackend):
             return super().grouping_backward(grad_output, idx, n)
         _check(grad_output, torch.float32, "grad_output"); _check(idx, torch.int32, "idx")
         m, ns, c = grad_output.shape
+        if grad_output.numel() == 0 or n == 0:
+            return self._new(grad_output, (n, c), torch.float32, zero=True)
         off, ent, base = inverse_table(idx, n)
         gi = self._new(grad_output, (n, c), torch.float32)
         self._call("seg_sum_rows", n, c, grad_output, off, ent, base, 1.0, gi)
@@ -544,6 +546,8 @@ class HipBackend(CBackend):
             return super().interpolation_backward(grad_output, idx, weight, m)
         _check(grad_output, torch.float32, "grad_output"); _check(idx, torch.int32, "idx"); _check(weight, torch.float32, "weight")
         n, c = grad_output.shape
+        if grad_output.numel() == 0 or m == 0:
+            return self._new(grad_output, (m, c), torch.float32, zero=True)
         off, ent, base = inverse_table(idx, m)
         gi = self._new(grad_output, (m, c), torch.float32)
         self._call("seg_sum_weighted", m, c, idx.shape[1], 1, grad_output, weight, off, ent, base, gi)
@@ -555,6 +559,8 @@ class HipBackend(CBackend):
         _check(grad_output, torch.float32, "grad_output"); _check(idx, torch.int32, "idx")
         n, ns, c = grad_output.shape
         n2 = n if n2 is None else n2
+        if grad_output.numel() == 0 or n2 == 0:
+            return super().subtraction_backward(idx, grad_output, n2)
         off, ent, base = inverse_table(idx, n2)
         g1 = self._new(grad_output, (n, c), torch.float32, zero=True)
         g2 = self._new(grad_output, (n2, c), torch.float32)
@@ -568,6 +574,8 @@ class HipBackend(CBackend):
         _check(grad_output, torch.float32, "grad_output")
         n, ns, c = position.shape
         w_c = weight.shape[-1]
+        if position.numel() == 0 or input.shape[0] == 0:
+            return super().aggregation_backward(input, position, weight, idx, grad_output)
         off, ent, base = inverse_table(idx, input.shape[0])
         gi = self._new(input, tuple(input.shape), torch.float32)
         gp = self._new(input, (n, ns, c), torch.float32)

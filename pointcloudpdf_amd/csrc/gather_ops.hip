@@ -608,7 +608,7 @@ extern "C" int pdf_subtraction_backward(int n, int nsample, int c, const int *id
     hipStream_t s = static_cast<hipStream_t>(stream);
     // scatter-adds run one float per lane (64 consecutive floats = whole 128-byte lines per instruction): the atomic units
     // bill per request, and the 16-byte-per-lane shape splits every line into four requests (see fused_layer.hip)
-    const int v = 1;
+    const int v = grad_input2 ? 1 : pick_vec(c);   // (no scatter target: row sums only, 16 bytes per lane)
     DISPATCH_VEC(v, (sub_bwd_kernel<V><<<grid_for((long)n * (c / V)), GB, 0, s>>>(n, nsample, c / V, idx, grad_output, grad_input1, grad_input2)));
     return pdf_launch_status();
 }

@@ -125,10 +125,10 @@ def test_grouped_prepass_split_is_bit_identical_on_gpu():
                         assert ta.shape == tb.shape and helpers.max_rel(ta.cpu().numpy(), tb.cpu().numpy()) < 1e-5, key
                     else:
                         assert torch.equal(ta, tb), key
-        for key, (off, ent, base) in part._memo.items():   # inverse kNN tables: same segments, same entry order
+        for key, val in part._memo.items():   # inverse kNN tables: same segments, same entry order
             if key[0] != "inv":
                 continue
-            off_a, ent_a, base_a = alone._memo[key]
+            (off, ent, base), (off_a, ent_a, base_a) = val, alone._memo[key]
             lo, hi = int(off[0]), int(off[-1])
             assert base_a == 0 and torch.equal(off - lo, off_a - int(off_a[0])), key
             assert torch.equal(ent[lo:hi] - base, ent_a[int(off_a[0]):int(off_a[-1])]), key
