@@ -65,9 +65,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--workload", choices=["s3dis", "scannet"], default="s3dis",
+    ap.add_argument("--workload", choices=["s3dis", "scannet", "stratified"], default="s3dis",
                     help="s3dis = BASELINE config 2 / 3 (6 input channels, 13 classes, the headline); scannet = config 4 shape (coord + "
-                         "colour + normal = 9 channels, 20 classes, unknown classes {4, 7, 14, 16}, 150k points per scene unless --points)")
+                         "colour + normal = 9 channels, 20 classes, unknown classes {4, 7, 14, 16}, 150k points per scene unless --points); "
+                         "stratified = config 5: StratifiedTransformer ST-v1m1 + ST-v1m1-Recognizer (pointops2 window attention) on S3DIS-shaped "
+                         "scenes of 80k points (the reference's SphereCrop point_max) unless --points")
     ap.add_argument("--pseudo-label", type=int, default=0,
                     help="1 = run the PDF pseudo-label pass inside the step (config 4; recognizer settings of "
                          "configs/scannet/openseg-pt-v1-0-pointpdf-v1m1-base.py:40-58) instead of the fixed 1-in-7 stand-in mask")
@@ -280,10 +282,12 @@ def main():
     torch.backends.cuda.matmul.allow_tf32 = False
     be = _native.hip_backend()
 
-    scannet = args.workload == "scannet"
+    scannet, strat = args.workload == "scannet", args.workload == "stratified"
     if args.points is None:
-        args.points = 150000 if scannet else 100000
-    step_kw = dict(in_channels=9, num_classes=20, loss_weight=0.04) if scannet else {}
+        args.points = 150000 if scannet else (80000 if strat else 100000)
+    step_kw = dict(in_channels=9, num_classes=20, loss_weight=0.04) if scannet else (dict(backbone="ST-v1m1", loss_weight=0.008) if strat else {})
+    if strat:
+        args.prefetch = 0   # (the geometry pre-pass is PointTransformer-V1's; ST builds its window partition inside the forward)
     if args.pseudo_label:
         from pointcloudpdf_amd import pseudo_label
         step_kw["pseudo_mask_fn"] = pseudo_label.make_pseudo_mask_fn(radius=0.02 * 5, max_neighbor=64, condition_from="msp", beta=1.5,
@@ -436,7 +440,8 @@ def main():
         second = [n for n in ("bottleneck_backward", "bottleneck_forward", "pt_layer_backward", "pt_layer_forward", "group_backward", "group_forward") if n in ks]
         roof2 = roofline_of(max(second, key=lambda n: ks[n]["total_ms"])) if second else None
         line = {
-            "metric": "points/sec fwd+bwd (PT-v1 Seg50 + PDF U-decoder, 100k-pt scenes)",
+            "metric": ("points/sec fwd+bwd (StratifiedTransformer ST-v1m1 + PDF U-decoder)" if strat else
+                       "points/sec fwd+bwd (PT-v1 Seg50 + PDF U-decoder, 100k-pt scenes)"),
             "value": pts_per_step * args.steps / dt,
             "unit": "points/s",
             "n_gpus": world,
@@ -449,7 +454,8 @@ def main():
             "dtype": "f16-autocast" if args.amp else "f32",
             "data": "synthetic",
             "config": {"workload": f"{'ScanNet' if scannet else 'S3DIS'}-shaped synthetic voxelised scenes, {args.scenes} x {args.points} points per GPU, "
-                                   "PointTransformer-Seg50 + PointPdf-v1m1 U-decoder, fwd+bwd+SGD, geometry recomputed every step"
+                                   + ("StratifiedTransformer ST-v1m1 + PointPdf-v1m1 / ST-v1m1-Recognizer, fwd+bwd+SGD, window partition recomputed every step" if strat else
+                                      "PointTransformer-Seg50 + PointPdf-v1m1 U-decoder, fwd+bwd+SGD, geometry recomputed every step")
                                    + (", PDF pseudo-label pass inside the step" if args.pseudo_label else ""),
                        "scenes_per_gpu": args.scenes, "points_per_scene": args.points, "size_jitter": args.jitter, "parallelism": f"dp{world}",
                        "gradient_exchange": (args.ddp if use_dp else "none")},
@@ -468,7 +474,7 @@ def main():
 
     # ---- latency: how much look-ahead the number above depends on (FPS is a serial chain per scene).  serial = pre-pass inline on
     # the main stream, every step pays the whole FPS chain; then groups of 1 / 2 / 3 batches.
-    if world == 1 and not args.no_latency_sweep and not args.pseudo_label:
+    if world == 1 and not args.no_latency_sweep and not args.pseudo_label and not strat:
         sweep = {}
         for Dl, st, wu in ((0, 4, 1), (1, 6, 2), (2, 6, 2), (3, 6, 3)):
             dtl, _, _ = timed(Dl, wu, st)
@@ -477,14 +483,14 @@ def main():
         line["lookahead_sweep_ms_per_step"] = sweep
 
     if rank == 0:
-        if world == 1 and not args.no_ops_roofline and not scannet:
+        if world == 1 and not args.no_ops_roofline and not scannet and not strat:
             # the pointops drop-in ops on their own (level-1 shapes of this config: 200k points, c = 32, k = 8), HIP-event timed on
             # the launching stream, against the 8 TB/s HBM peak with the SURVEY 8(d) byte counts (tools/ops_roofline.py)
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import ops_roofline
             line["roofline_ops"] = [dict(op=r["op"], us=round(r["us"], 1), GBps=round(r["GBps"], 1), frac=round(r["frac"], 4))
                                     for r in ops_roofline.run(iters=10, level2=False, references=False)]
-        if world == 1 and not args.no_cpu_baseline and not scannet:   # (the CPU baseline is quoted on the headline workload)
+        if world == 1 and not args.no_cpu_baseline and not scannet and not strat:   # (the CPU baseline is quoted on the headline workload)
             line["cpu_baseline"] = cpu_baseline(args.cpu_points)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

@@ -253,6 +253,8 @@ int pdf_td_backward(long n, long m, int cin, int cout, void *const *p, void *str
  * accept a NULL scatter target (grad_input2 / grad_input) when the caller forms it with these. */
 int pdf_seg_sum_rows(long n, int c, const float *src, const int *inv_off, const int *inv_entry, int entry_base, float scale, float *out,
                      void *stream);
+int pdf_seg_sum_rows_strided(long n, int c, const float *src, long src_stride, const int *inv_off, const int *inv_entry, int entry_base,
+                             float scale, float *out, void *stream);
 int pdf_seg_sum_weighted(long n, int c, int nsample, int w_c, const float *src, const float *w, const int *inv_off, const int *inv_entry,
                          int entry_base, float *out, void *stream);
 

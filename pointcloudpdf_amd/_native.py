@@ -61,6 +61,7 @@ _HIP_ONLY_PROTOS = {
     "interpolation_weights": "iipp",
     "farthest_point_sampling_bucketed": "iiipppplp",
     "seg_sum_rows": "lipppifp",
+    "seg_sum_rows_strided": "liplppifp",
     "seg_sum_weighted": "liiippppip",
 }
 _KIND = {"i": c_int, "l": c_long, "f": c_float, "d": c_double, "p": c_void_p}
@@ -917,6 +918,12 @@ class HipBackend(CBackend):
         if not with_xyz and self.use_inverse:
             return self.grouping_backward(grad_output, idx, n)
         m, ns = idx.shape
+        if with_xyz and self.use_inverse and grad_output.numel() > 0 and n > 0:
+            # rows are [g_rel_xyz (3) | g_feat (c)]: the feature part is summed per source point over the inverse table
+            off, ent, base = inverse_table(idx, n)
+            gf = self._new(grad_output, (n, c), torch.float32)
+            self._call("seg_sum_rows_strided", n, c, grad_output.view(-1)[3:], 3 + c, off, ent, base, 1.0, gf)
+            return gf
         gf = self._new(grad_output, (n, c), torch.float32, zero=True)
         self._call("group_backward", m, ns, c, 1 if with_xyz else 0, grad_output, idx, gf)
         return gf

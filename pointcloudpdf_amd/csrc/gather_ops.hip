@@ -483,6 +483,40 @@ __global__ __launch_bounds__(GB) void agg_bwd32(unsigned total, FastDiv cd, int 
     }
 }
 
+// aggregation_cuda_kernel.cu:22-39 WITHOUT grad_input (the caller forms it with pdf_seg_sum_weighted), 4 consecutive channels per
+// lane: grad_position = g_out * w streamed out as 16-byte pieces; grad_weight[n, s, wc] = sum over the c / w_c channels that share
+// the weight of g_out * (input[idx] + position): those channels sit wv = w_c / 4 lanes apart in the SAME wave (needs cv = c / 4 <= 64,
+// cv and wv powers of two), so xor-shuffles over wv, 2 wv, ... replace the atomics and the first wv lanes of a row store the result.
+__global__ __launch_bounds__(GB) void agg_bwd_vec(unsigned total, FastDiv cvd, int nsample, unsigned wv,
+                                                  const v4f *__restrict__ input, const v4f *__restrict__ position,
+                                                  const v4f *__restrict__ weight, const int *__restrict__ idx,
+                                                  const v4f *__restrict__ grad_output, v4f *__restrict__ grad_position,
+                                                  v4f *__restrict__ grad_weight) {
+    const unsigned stride = gridDim.x * GB, cv = cvd.d;
+    const unsigned padded = (total + 63u) & ~63u;   // whole waves iterate together (the shuffles need every lane)
+    for (unsigned e = blockIdx.x * GB + threadIdx.x; e < padded; e += stride) {
+        const bool live = e < total;
+        const unsigned r = live ? fdiv(e, cvd) : 0, col = live ? e - r * cv : 0, wcol = col % wv;
+        const v4f go = live ? grad_output[e] : (v4f)(0.f);
+        const unsigned long base = (unsigned long)r * nsample;
+#pragma unroll 2
+        for (int s = 0; s < nsample; ++s) {
+            v4f gw = (v4f)(0.f);
+            if (live) {
+                const int j = idx[base + s];
+                const v4f in = j >= 0 ? input[(unsigned long)j * cv + col] : (v4f)(0.f);
+                const v4f w = weight[(base + s) * wv + wcol];
+                st_stream(grad_position + (base + s) * cv + col, go * w);
+                gw = go * (in + __builtin_nontemporal_load(position + (base + s) * cv + col));
+            }
+            for (unsigned o = wv; o < cv; o <<= 1) {
+                gw.x += __shfl_xor(gw.x, o, 64); gw.y += __shfl_xor(gw.y, o, 64); gw.z += __shfl_xor(gw.z, o, 64); gw.w += __shfl_xor(gw.w, o, 64);
+            }
+            if (live && col < wv) grad_weight[(base + s) * wv + col] = gw;
+        }
+    }
+}
+
 #define DISPATCH_VEC(V_, ...)                 \
     switch (V_) {                             \
         case 4: { constexpr int V = 4; __VA_ARGS__; } break; \
@@ -635,6 +669,14 @@ extern "C" int pdf_aggregation_backward(int n, int nsample, int c, int w_c, cons
     if (n < 0 || nsample < 1 || c < 1 || w_c < 1 || !input || !position || !weight || !idx || !grad_output || !grad_position || !grad_weight)
         return PDF_ERR_BAD_ARG;   // (grad_input may be null: the caller forms it by the segmented gather, pdf_seg_sum_weighted)
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const int cv = c / 4, wv = w_c / 4;
+    if (!grad_input && c % 4 == 0 && w_c % 4 == 0 && c % w_c == 0 && cv <= 64 && (cv & (cv - 1)) == 0 && (wv & (wv - 1)) == 0 &&
+        (long)n * nsample * cv < (1L << 31)) {
+        const unsigned total = (unsigned)((long)n * cv);
+        agg_bwd_vec<<<grid_for(total), GB, 0, s>>>(total, mk_fastdiv(cv), nsample, (unsigned)wv, (const v4f *)input, (const v4f *)position,
+                                                   (const v4f *)weight, idx, (const v4f *)grad_output, (v4f *)grad_position, (v4f *)grad_weight);
+        return pdf_launch_status();
+    }
     if ((long)n * nsample * c < (1L << 31) && 64 % w_c == 0 && c % w_c == 0 && (c % 64 == 0 || 64 % c == 0)) {
         const unsigned total = (unsigned)((long)n * c);
         agg_bwd32<<<grid_for(total), GB, 0, s>>>(total, mk_fastdiv(c), nsample, w_c, c < 64 ? c : 64, input, position, weight, idx,

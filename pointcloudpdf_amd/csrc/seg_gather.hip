@@ -55,8 +55,9 @@ template <> __device__ __forceinline__ float4 zero<4>() { return make_float4(0.f
 template <> __device__ __forceinline__ float zero<1>() { return 0.f; }
 
 // out[v, :] = scale * sum over the segment of src[e, :]          (src rows are indexed by the entry id itself)
+// (sv = source row stride in units of T: rows wider than the c channels that are summed, e.g. the (3 + c)-float rows of grouping(with_xyz))
 template <int V>
-__global__ __launch_bounds__(TB) void k_seg_rows(unsigned total, FastDiv cvd, const typename Vec<V>::T *__restrict__ src,
+__global__ __launch_bounds__(TB) void k_seg_rows(unsigned total, FastDiv cvd, unsigned sv, const typename Vec<V>::T *__restrict__ src,
                                                  const int *__restrict__ inv_off, const int *__restrict__ inv_entry, int entry_base,
                                                  float scale, typename Vec<V>::T *__restrict__ out) {
     using T = typename Vec<V>::T;
@@ -68,11 +69,11 @@ __global__ __launch_bounds__(TB) void k_seg_rows(unsigned total, FastDiv cvd, co
     T a0 = zero<V>(), a1 = zero<V>();
     for (; t + 4 <= end; t += 4) {
         const int e0 = inv_entry[t] - entry_base, e1 = inv_entry[t + 1] - entry_base, e2 = inv_entry[t + 2] - entry_base, e3 = inv_entry[t + 3] - entry_base;
-        const T x0 = vld(src + (size_t)e0 * cv + p), x1 = vld(src + (size_t)e1 * cv + p);
-        const T x2 = vld(src + (size_t)e2 * cv + p), x3 = vld(src + (size_t)e3 * cv + p);
+        const T x0 = vld(src + (size_t)e0 * sv + p), x1 = vld(src + (size_t)e1 * sv + p);
+        const T x2 = vld(src + (size_t)e2 * sv + p), x3 = vld(src + (size_t)e3 * sv + p);
         add_acc(a0, x0); add_acc(a1, x1); add_acc(a0, x2); add_acc(a1, x3);
     }
-    for (; t < end; ++t) add_acc(a0, vld(src + (size_t)(inv_entry[t] - entry_base) * cv + p));
+    for (; t < end; ++t) add_acc(a0, vld(src + (size_t)(inv_entry[t] - entry_base) * sv + p));
     add_acc(a0, a1);
     out[(size_t)v * cv + p] = scaled(a0, scale);
 }
@@ -103,13 +104,15 @@ __global__ __launch_bounds__(TB) void k_seg_weighted(unsigned total, FastDiv cvd
             return w[(size_t)e * w_c + wo];
         }
     };
-    for (; t + 2 <= end; t += 2) {
+    for (; t + 4 <= end; t += 4) {
         const unsigned e0 = (unsigned)(inv_entry[t] - entry_base), e1 = (unsigned)(inv_entry[t + 1] - entry_base);
+        const unsigned e2 = (unsigned)(inv_entry[t + 2] - entry_base), e3 = (unsigned)(inv_entry[t + 3] - entry_base);
         const T x0 = vld(src + (size_t)fdiv(e0, nsd) * cv + p), x1 = vld(src + (size_t)fdiv(e1, nsd) * cv + p);
-        const T w0 = wload(e0), w1 = wload(e1);
-        fma_acc(a0, x0, w0); fma_acc(a1, x1, w1);
+        const T x2 = vld(src + (size_t)fdiv(e2, nsd) * cv + p), x3 = vld(src + (size_t)fdiv(e3, nsd) * cv + p);
+        const T w0 = wload(e0), w1 = wload(e1), w2 = wload(e2), w3 = wload(e3);
+        fma_acc(a0, x0, w0); fma_acc(a1, x1, w1); fma_acc(a0, x2, w2); fma_acc(a1, x3, w3);
     }
-    if (t < end) {
+    for (; t < end; ++t) {
         const unsigned e0 = (unsigned)(inv_entry[t] - entry_base);
         fma_acc(a0, vld(src + (size_t)fdiv(e0, nsd) * cv + p), wload(e0));
     }
@@ -119,23 +122,29 @@ __global__ __launch_bounds__(TB) void k_seg_weighted(unsigned total, FastDiv cvd
 
 }  // namespace sg
 
-// out (n, c) = scale * segmented sum of the rows src[e, :] (E x c, indexed by entry id) -- grouping / subtraction backward, g_xk.
-extern "C" int pdf_seg_sum_rows(long n, int c, const float *src, const int *inv_off, const int *inv_entry, int entry_base, float scale,
-                                float *out, void *stream) {
+// out (n, c) = scale * segmented sum of the rows src[e * src_stride + 0 .. c) (src_stride >= c floats between consecutive entries;
+// src may point at a column offset inside wider rows) -- grouping / subtraction backward, grouping(with_xyz) backward, g_xk.
+extern "C" int pdf_seg_sum_rows_strided(long n, int c, const float *src, long src_stride, const int *inv_off, const int *inv_entry,
+                                        int entry_base, float scale, float *out, void *stream) {
     if (n == 0) return PDF_OK;
-    if (n < 0 || c < 1 || !src || !inv_off || !inv_entry || !out) return PDF_ERR_BAD_ARG;
+    if (n < 0 || c < 1 || src_stride < c || !src || !inv_off || !inv_entry || !out) return PDF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool v4 = c % 4 == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0);
+    const bool v4 = c % 4 == 0 && src_stride % 4 == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0);
     const int cv = v4 ? c / 4 : c;
     const long total = n * cv;
-    if (total >= (1L << 31)) return PDF_ERR_UNSUPPORTED;
+    if (total >= (1L << 31) || src_stride >= (1L << 31)) return PDF_ERR_UNSUPPORTED;
     const unsigned g = (unsigned)((total + sg::TB - 1) / sg::TB);
     if (v4)
-        sg::k_seg_rows<4><<<g, sg::TB, 0, s>>>((unsigned)total, sg::mk_fastdiv(cv), reinterpret_cast<const float4 *>(src), inv_off, inv_entry,
-                                               entry_base, scale, reinterpret_cast<float4 *>(out));
+        sg::k_seg_rows<4><<<g, sg::TB, 0, s>>>((unsigned)total, sg::mk_fastdiv(cv), (unsigned)(src_stride / 4), reinterpret_cast<const float4 *>(src),
+                                               inv_off, inv_entry, entry_base, scale, reinterpret_cast<float4 *>(out));
     else
-        sg::k_seg_rows<1><<<g, sg::TB, 0, s>>>((unsigned)total, sg::mk_fastdiv(cv), src, inv_off, inv_entry, entry_base, scale, out);
+        sg::k_seg_rows<1><<<g, sg::TB, 0, s>>>((unsigned)total, sg::mk_fastdiv(cv), (unsigned)src_stride, src, inv_off, inv_entry, entry_base, scale, out);
     return pdf_launch_status();
+}
+
+extern "C" int pdf_seg_sum_rows(long n, int c, const float *src, const int *inv_off, const int *inv_entry, int entry_base, float scale,
+                                float *out, void *stream) {
+    return pdf_seg_sum_rows_strided(n, c, src, c, inv_off, inv_entry, entry_base, scale, out, stream);
 }
 
 // out (n, c)[v, ch] = segmented sum of src[e / nsample, ch] * w[e, ch mod w_c]; src (m, c), w (m * nsample, w_c).

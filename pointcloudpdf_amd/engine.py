@@ -29,19 +29,38 @@ def default_pseudo_mask(coord, seg_logits, offset):
     return (torch.arange(coord.shape[0], device=coord.device) % 7) == 3
 
 
+ST_V1M1_HOOKS = {  # configs/s3dis/openseg-st-v1m1-0-origin-pointpdf-v1m1-base.py:41-51 (the non-existent "backbone.upsamples.3" left out)
+    **{f"backbone.upsamples.{i}": ["forward_input", "forward_output"] for i in range(3)},
+    "backbone": ["forward_output"],
+}
+ST_V1M1_BACKBONE = dict(  # configs/s3dis/openseg-st-v1m1-0-origin-pointpdf-v1m1-base.py:13-38
+    type="ST-v1m1", downsample_scale=8, depths=[2, 2, 6, 2], channels=[48, 96, 192, 384], num_heads=[3, 6, 12, 24],
+    window_size=[0.16, 0.32, 0.64, 1.28], up_k=3, grid_sizes=[0.04, 0.08, 0.16, 0.32], quant_sizes=[0.01, 0.02, 0.04, 0.08],
+    rel_query=True, rel_key=True, rel_value=True, drop_path_rate=0.3, num_layers=4, concat_xyz=True, ratio=0.25, k=16,
+    prev_grid_size=0.04, sigma=1.0, stem_transformer=True, kp_ball_radius=0.04 * 2.5, kp_max_neighbor=34)
+
+
 class OpenSegStep(nn.Module):
     def __init__(self, backbone="PointTransformer-Seg50", in_channels=6, num_classes=13, loss_weight=0.1,
                  start_epoch=0, pseudo_mask_fn=default_pseudo_mask):
+        """``backbone``: a registered PointTransformer-Seg* name (PT-v1 + PDF U-decoder, BASELINE configs 2-4) or "ST-v1m1"
+        (StratifiedTransformer + ST-v1m1-Recognizer with the reference's S3DIS settings, BASELINE config 5)."""
         super().__init__()
+        from . import stratified  # noqa: F401  (registers ST-v1m1 / ST-v1m1-Recognizer)
+
         ce = [dict(type="CrossEntropyLoss", loss_weight=1.0, ignore_index=-1)]
-        self.model = MODELS.build(dict(type="DefaultSegmentor",
-                                       backbone=dict(type=backbone, in_channels=in_channels, num_classes=num_classes),
-                                       criteria=ce))
-        self.recognizer = RECOGNIZER.build(dict(type="PointPdf-v1m1", recognizer=dict(type="PointTransformer-Recognizer"),
+        if backbone == "ST-v1m1":
+            bb = dict(ST_V1M1_BACKBONE, num_classes=num_classes)
+            rec, hooks = dict(type="ST-v1m1-Recognizer", up_k=3, channels=bb["channels"], num_layers=4), ST_V1M1_HOOKS
+        else:
+            bb = dict(type=backbone, in_channels=in_channels, num_classes=num_classes)
+            rec, hooks = dict(type="PointTransformer-Recognizer"), PT_V1_HOOKS
+        self.model = MODELS.build(dict(type="DefaultSegmentor", backbone=bb, criteria=ce))
+        self.recognizer = RECOGNIZER.build(dict(type="PointPdf-v1m1", recognizer=rec,
                                                 criteria=ce, loss_weight=loss_weight, step_loss_weight=False,
                                                 num_classes=num_classes, start_epoch=start_epoch,
                                                 pseudo_mask_fn=pseudo_mask_fn))
-        self.hooks = BaseModelHook(PT_V1_HOOKS, clone_tensor=True, exclude_clone={"backbone": ["forward_output"]})
+        self.hooks = BaseModelHook(hooks, clone_tensor=True, exclude_clone={"backbone": ["forward_output"]})
         self.hooks.set_model(self.model)
         self.recognizer.model_hooks = self.hooks
         self.recognizer.set_epoch(start_epoch)

@@ -129,6 +129,9 @@ def fill_parameters_deterministic(module, seed=0):
     state = module.state_dict()
     new = {}
     for name, t in state.items():
+        if name.endswith("K_points"):   # geometric constants (KPConv kernel-point layout), not weights
+            new[name] = t
+            continue
         rs = np.random.RandomState((zlib.crc32(name.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)
         u = rs.uniform(-1.0, 1.0, size=tuple(t.shape)) if t.numel() else np.zeros(tuple(t.shape))
         if name.endswith("num_batches_tracked"):

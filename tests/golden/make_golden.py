@@ -676,6 +676,120 @@ def run_pointpdf_forward_cases(hook):
     return out
 
 
+ST_CFG = dict(downsample_scale=8, depths=[2, 2, 6, 2], channels=[48, 96, 192, 384], num_heads=[3, 6, 12, 24],
+              window_size=[0.16, 0.32, 0.64, 1.28], up_k=3, grid_sizes=[0.04, 0.08, 0.16, 0.32], quant_sizes=[0.01, 0.02, 0.04, 0.08],
+              rel_query=True, rel_key=True, rel_value=True, num_layers=4, concat_xyz=True, num_classes=13, ratio=0.25, k=16,
+              prev_grid_size=0.04, sigma=1.0, stem_transformer=True, kp_ball_radius=0.04 * 2.5, kp_max_neighbor=34)   # configs/s3dis/openseg-st-v1m1-0-origin-pointpdf-v1m1-base.py:13-38
+ST_SIZES, ST_GRID = [3000, 2500], 0.04
+# (the reference config also names "backbone.upsamples.3", which does not exist at num_layers = 4: its hook slots stay None and
+# STRecognizer.forward reads but never uses them -- st_v1m1.py:48-55)
+ST_HOOKS = {**{f"backbone.upsamples.{i}": ["forward_input", "forward_output"] for i in range(4)}, "backbone": ["forward_output"]}
+ST_GRADS = ["stem_layer.0.kpconv.weight", "layers.0.blocks.0.attn.qkv.weight", "layers.0.blocks.1.attn.relative_pos_query_table",
+            "layers.1.blocks.0.attn.relative_pos_value_table", "layers.2.blocks.3.mlp.fc1.weight", "layers.0.downsample.linear.weight",
+            "layers.3.blocks.1.attn.proj.weight", "upsamples.0.linear2.1.weight", "upsamples.2.linear1.0.weight", "classifier.0.weight"]
+ST_REC_GRADS = ["upsamples.0.linear1.1.weight", "upsamples.2.linear2.1.weight", "confidence.3.weight"]
+
+
+def run_stratified_cases(hook):
+    """The reference's OWN StratifiedTransformer (pointcept/models/stratified_transformer/stratified_transformer_v1m1_origin.py) and
+    STRecognizer (pointcept/recognizers/recognizer_model/st_v1m1.py), imported in place and run on CPU.  Shims: the third-party
+    modules this image lacks are provided as modules that re-export OUR stand-ins (pointcloudpdf_amd.stratified: KPConvLayer,
+    FastBatchNorm1d, DropPath, voxel_grid; a plain-torch scatter_softmax written here; tp.ball_query = the oracle's in-order radius
+    query) -- so the fixture pins the reference's own window partition / block / model code, while those pieces stay "parity
+    unpinned"; ``pointops2.pointops`` is the reference's own libs/pointops2/functions/pointops.py over the oracle-backed
+    ``pointops2_cuda`` stub (+ furthestsampling_cuda / knnquery_cuda); ``Tensor.cuda()`` is the identity."""
+    from pointcloudpdf_amd import stratified as ours
+    from pointcloudpdf_amd import pseudo_label, _native
+
+    be = oracle.backend()
+    prev = _native._set_backend_for_testing(be)
+    try:
+        ref_p2 = install_reference_pointops2()
+        C2 = sys.modules["pointops2_cuda"]
+
+        def furthestsampling_cuda(b, n, xyz, offset, new_offset, tmp, idx):
+            be._call("farthest_point_sampling", int(b), int(n), xyz.float().contiguous(), offset.int().contiguous(), new_offset.int().contiguous(),
+                     torch.full((xyz.shape[0],), 1e10, dtype=torch.float32), idx)
+
+        def knnquery_cuda(m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2):
+            i, d = be.knn_query(nsample, xyz.float().contiguous(), new_xyz.float().contiguous(), offset.int().contiguous(), new_offset.int().contiguous())
+            idx.copy_(i); dist2.copy_(d)
+
+        C2.furthestsampling_cuda, C2.knnquery_cuda = furthestsampling_cuda, knnquery_cuda
+        pkg = types.ModuleType("pointops2"); pkg.__path__ = []; pkg.pointops = ref_p2
+        sys.modules["pointops2"], sys.modules["pointops2.pointops"] = pkg, ref_p2
+
+        def mod(name, **attrs):
+            parts = name.split(".")
+            for i in range(1, len(parts) + 1):
+                sys.modules.setdefault(".".join(parts[:i]), types.ModuleType(".".join(parts[:i])))
+                sys.modules[".".join(parts[:i])].__path__ = []
+            for k, v in attrs.items():
+                setattr(sys.modules[name], k, v)
+
+        def scatter_softmax(src, index, dim=0):   # torch_scatter.scatter_softmax along dim 0, plain torch (independent of our CSR kernel)
+            n = int(index.max()) + 1
+            idx = index.view(-1, *([1] * (src.dim() - 1))).expand_as(src)
+            mx = torch.full((n,) + src.shape[1:], -float("inf"), dtype=src.dtype).scatter_reduce(0, idx, src.detach(), "amax", include_self=True)
+            e = torch.exp(src - mx.gather(0, idx))
+            return e / torch.zeros((n,) + src.shape[1:], dtype=src.dtype).scatter_add(0, idx, e).gather(0, idx)
+
+        def ball_query(radius, max_neighbor, x, y, mode="partial_dense", batch_x=None, batch_y=None):
+            offset = torch.cumsum(torch.bincount(batch_x), 0).int()
+            return (pseudo_label.radius_neighbors(x.contiguous(), offset, radius, max_neighbor),)
+
+        tpk = sys.modules.setdefault("torch_points_kernels", types.ModuleType("torch_points_kernels"))
+        tpk.ball_query = ball_query
+        mod("torch_points3d.modules.KPConv.kernels", KPConvLayer=ours.KPConvLayer)
+        mod("torch_points3d.core.common_modules", FastBatchNorm1d=ours.FastBatchNorm1d)
+        mod("torch_scatter", scatter_softmax=scatter_softmax)
+        mod("timm.models.layers", DropPath=ours.DropPath, trunc_normal_=torch.nn.init.trunc_normal_)
+        mod("torch_geometric.nn.pool", voxel_grid=lambda pos, batch, size, start=None, end=None: ours._voxel_grid(pos, batch, size, start))
+        torch.Tensor.cuda = lambda self, *a, **k: self
+
+        def load(modname, path):
+            spec = importlib.util.spec_from_file_location(modname, path)
+            m = importlib.util.module_from_spec(spec)
+            sys.modules[modname] = m
+            spec.loader.exec_module(m)
+            return m
+
+        st = load("ref_stratified", os.path.join(REF, "pointcept", "models", "stratified_transformer", "stratified_transformer_v1m1_origin.py"))
+        strec = load("ref_st_recognizer", os.path.join(REF, "pointcept", "recognizers", "recognizer_model", "st_v1m1.py"))
+        out = {}
+        for mode, (train, dpr) in {"train": (True, 0.0), "eval": (False, 0.3)}.items():
+            batch = synthetic.make_batch(ST_SIZES, first_scene_id=300, grid_size=ST_GRID)
+            model = _Wrap(st.StratifiedTransformer(drop_path_rate=dpr, **ST_CFG))
+            recog = strec.STRecognizer(up_k=3, channels=ST_CFG["channels"], num_layers=4)
+            synthetic.fill_parameters_deterministic(model.backbone, seed=11)
+            synthetic.fill_parameters_deterministic(recog, seed=12)
+            model.train(train); recog.train(train)
+            mh = hook.BaseModelHook(ST_HOOKS, clone_tensor=True, exclude_clone={"backbone": ["forward_output"]}, logger=hook.BaseModelHook._DummyLogger())
+            mh.model = model
+            with mh:
+                logits = model(dict(coord=batch["coord"], feat=batch["feat"], offset=batch["offset"]))
+                conf = recog(mh)
+            out[f"{mode}_logits"], out[f"{mode}_conf"] = logits.detach().numpy(), conf.detach().numpy()
+            for i in range(3):
+                fi, fo = mh[f"backbone.upsamples.{i}"]["forward_input"], mh[f"backbone.upsamples.{i}"]["forward_output"]
+                out[f"{mode}_up{i}_in_shapes"] = np.array([tuple(t.shape) + (0,) * (2 - t.dim()) for t in fi])
+                out[f"{mode}_up{i}_out"] = thin(fo[0].detach().numpy())
+            if train:
+                ce = torch.nn.CrossEntropyLoss(ignore_index=-1)
+                loss = ce(logits, batch["segment"]) + 0.1 * ce(torch.cat([logits, conf], -1), batch["segment"].clamp(min=0))
+                loss.backward()
+                out["train_loss"] = loss.detach().numpy()
+                named, rnamed = dict(model.backbone.named_parameters()), dict(recog.named_parameters())
+                for k in ST_GRADS:
+                    pack_grad(out, "grad_" + k, named[k].grad.numpy())
+                for k in ST_REC_GRADS:
+                    pack_grad(out, "rgrad_" + k, rnamed[k].grad.numpy())
+            print("stratified", mode, logits.shape, float(logits.abs().max()), float(conf.abs().max()))
+        return out
+    finally:
+        _native._set_backend_for_testing(prev)
+
+
 def run_hook_case(hook):
     """BaseModelHook on a toy module: forward/backward capture + clone semantics."""
     torch.manual_seed(3)
@@ -693,7 +807,7 @@ def run_hook_case(hook):
 
 
 def main():
-    """No flag: regenerate every fixture.  --only-ball | --only-pointops2 | --only-gridsample | --only-pseudo | --only-pointpdf |
+    """No flag: regenerate every fixture.  --only-ball | --only-pointops2 | --only-gridsample | --only-pseudo | --only-pointpdf | --only-stratified |
     --only-case=<model case name>: just that one (the others are left as committed)."""
     ref_pointops, seg, rec, hook, losses = install_reference()
     flags = [a for a in sys.argv[1:] if a.startswith("--only-")]
@@ -713,6 +827,8 @@ def main():
         save("ops_pseudo_label_ref.npz", run_pseudo_label_cases())
     if want("pointpdf"):
         save("model_pointpdf_forward.npz", run_pointpdf_forward_cases(hook))
+    if want("stratified"):
+        save("model_stratified.npz", run_stratified_cases(hook))
     if not flags:
         save("ops_python_ref.npz", run_op_cases(ref_pointops))
         save("model_hook_ref.npz", run_hook_case(hook))

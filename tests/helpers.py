@@ -253,3 +253,61 @@ def check_pdf_case(mode, mo, ro, step, g, tol=REL_TOL):
                 assert np.abs(part - ref).max() <= GRAD_TOL * (np.abs(ref).max() + 1e-30), (mode, k)
                 l2 = np.sqrt((grad.astype(np.float64) ** 2).sum())
                 assert abs(l2 - g[f"{mode}_grad_{k}#sum"][1]) <= GRAD_TOL * g[f"{mode}_grad_{k}#sum"][1] + 1e-12, (mode, k)
+
+
+# ---- StratifiedTransformer (ST-v1m1) + ST-v1m1-Recognizer fixture (tests/golden/make_golden.py: ST_CFG / ST_SIZES / ST_GRADS) ----
+ST_CFG = dict(downsample_scale=8, depths=[2, 2, 6, 2], channels=[48, 96, 192, 384], num_heads=[3, 6, 12, 24],
+              window_size=[0.16, 0.32, 0.64, 1.28], up_k=3, grid_sizes=[0.04, 0.08, 0.16, 0.32], quant_sizes=[0.01, 0.02, 0.04, 0.08],
+              rel_query=True, rel_key=True, rel_value=True, num_layers=4, concat_xyz=True, num_classes=13, ratio=0.25, k=16,
+              prev_grid_size=0.04, sigma=1.0, stem_transformer=True, kp_ball_radius=0.04 * 2.5, kp_max_neighbor=34)
+ST_SIZES, ST_GRID = [3000, 2500], 0.04
+ST_HOOKS = {**{f"backbone.upsamples.{i}": ["forward_input", "forward_output"] for i in range(3)}, "backbone": ["forward_output"]}
+ST_GRADS = ["stem_layer.0.kpconv.weight", "layers.0.blocks.0.attn.qkv.weight", "layers.0.blocks.1.attn.relative_pos_query_table",
+            "layers.1.blocks.0.attn.relative_pos_value_table", "layers.2.blocks.3.mlp.fc1.weight", "layers.0.downsample.linear.weight",
+            "layers.3.blocks.1.attn.proj.weight", "upsamples.0.linear2.1.weight", "upsamples.2.linear1.0.weight", "classifier.0.weight"]
+ST_REC_GRADS = ["upsamples.0.linear1.1.weight", "upsamples.2.linear2.1.weight", "confidence.3.weight"]
+
+
+def run_stratified_case(mode, device="cpu"):
+    from pointcloudpdf_amd.registry import MODELS
+
+    train, dpr = {"train": (True, 0.0), "eval": (False, 0.3)}[mode]
+    batch = synthetic.make_batch(ST_SIZES, first_scene_id=300, grid_size=ST_GRID, device=device)
+    model = Wrap(MODELS.build(dict(type="ST-v1m1", drop_path_rate=dpr, **ST_CFG)))
+    recog = MODELS.build(dict(type="ST-v1m1-Recognizer", up_k=3, channels=ST_CFG["channels"], num_layers=4))
+    synthetic.fill_parameters_deterministic(model.backbone, seed=11)
+    synthetic.fill_parameters_deterministic(recog, seed=12)
+    model, recog = model.to(device), recog.to(device)
+    model.train(train); recog.train(train)
+    mh = BaseModelHook(ST_HOOKS, clone_tensor=True, exclude_clone={"backbone": ["forward_output"]}).set_model(model)
+    with mh:
+        logits = model(dict(coord=batch["coord"], feat=batch["feat"], offset=batch["offset"]))
+        conf = recog(mh)
+    out = dict(logits=logits, conf=conf, hooks=mh, model=model, recog=recog)
+    if train:
+        ce = torch.nn.CrossEntropyLoss(ignore_index=-1)
+        loss = ce(logits, batch["segment"]) + 0.1 * ce(torch.cat([logits, conf], -1), batch["segment"].clamp(min=0))
+        loss.backward()
+        out["loss"] = loss
+    return out
+
+
+def check_stratified_case(mode, out, g, tol=REL_TOL, grad_tol=GRAD_TOL):
+    assert_close(out["logits"], g[f"{mode}_logits"], tol, f"ST {mode} logits")
+    assert_close(out["conf"], g[f"{mode}_conf"], tol, f"ST {mode} conf")
+    for i in range(3):
+        fi, fo = out["hooks"][f"backbone.upsamples.{i}"]["forward_input"], out["hooks"][f"backbone.upsamples.{i}"]["forward_output"]
+        shapes = np.array([tuple(t.shape) + (0,) * (2 - t.dim()) for t in fi])
+        assert np.array_equal(shapes, g[f"{mode}_up{i}_in_shapes"]), (i, shapes)
+        assert_close(thin(fo[0].detach().cpu().numpy()), g[f"{mode}_up{i}_out"], tol, f"ST {mode} upsample {i}")
+    if mode == "train":
+        assert_close(out["loss"], g["train_loss"], tol, "ST loss")
+        named, rnamed = dict(out["model"].backbone.named_parameters()), dict(out["recog"].named_parameters())
+        for prefix, names, table in (("grad_", ST_GRADS, named), ("rgrad_", ST_REC_GRADS, rnamed)):
+            for k in names:
+                grad = table[k].grad.detach().cpu().numpy()
+                ref = g[prefix + k]
+                part = grad[:GRAD_ROWS] if grad.ndim >= 2 else grad
+                assert np.abs(part - ref).max() <= grad_tol * (np.abs(ref).max() + 1e-30), (k, np.abs(part - ref).max(), np.abs(ref).max())
+                l2 = np.sqrt((grad.astype(np.float64) ** 2).sum())
+                assert abs(l2 - g[prefix + k + "#sum"][1]) <= grad_tol * g[prefix + k + "#sum"][1] + 1e-12, k

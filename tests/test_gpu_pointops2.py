@@ -93,3 +93,32 @@ def test_window_attention_module_on_gpu(p2):
     ours, dense = run_window_attention(mod, DenseWindowAttention(mod), args)
     for key in ours:
         assert_close(ours[key], dense[key], 2e-4, key)
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_stratified_model_matches_reference_classes_on_gpu(golden_dir, mode):
+    """BASELINE config 5's model: ST-v1m1 + ST-v1m1-Recognizer on the HIP path (window attention, FPS / kNN / grouping / interpolation,
+    radius neighbours) against the fixture produced by the reference's own classes (tests/golden/model_stratified.npz)."""
+    import os
+    import numpy as np
+    import helpers
+
+    g = np.load(os.path.join(golden_dir, "model_stratified.npz"))
+    torch.backends.cuda.matmul.allow_tf32 = False
+    out = helpers.run_stratified_case(mode, device="cuda")
+    helpers.check_stratified_case(mode, out, g)
+
+
+def test_stratified_training_step_through_the_engine():
+    """OpenSegStep("ST-v1m1"): DefaultSegmentor + PointPdf-v1m1 over the ST hooks, one fwd + bwd at 2 x 20k points."""
+    from pointcloudpdf_amd import engine, synthetic
+
+    step = engine.OpenSegStep(backbone="ST-v1m1", loss_weight=0.008).cuda()
+    step.train()
+    batch = synthetic.make_batch([20000, 18000], first_scene_id=60, device="cuda")
+    out = step(batch)
+    out["loss"].backward()
+    assert torch.isfinite(out["loss"]).item() and out["score"].shape == (38000,)
+    missing = [n for n, p in step.named_parameters() if p.grad is None]
+    assert not missing, missing[:5]
+    assert all(torch.isfinite(p.grad).all() for p in step.parameters())

@@ -24,6 +24,9 @@ for lv in levels:
         key = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
         scene = torch.bucketize(torch.arange(n, device="cuda"), o.long(), right=True)
         p = p[torch.argsort(key + (scene << 32))].contiguous()
+        g2 = Geometry(p, o, geom.offset_host(lv))   # tagged coordinates again: the kNN table comes from the memo, as in the natural order
+        p, o = g2.coord(0), g2.offset(0)
+        g2.knn(k, 0, 0)
     x = torch.randn(n, c, device="cuda")
     xq, xk, xv = [torch.randn(n, c, device="cuda", requires_grad=True) for _ in range(3)]
     go = torch.randn(n, c, device="cuda")
