@@ -15,6 +15,27 @@ struct Err {
     int rc = 0;
     Err &operator<<(int r) { if (rc == 0 && r != 0) rc = r; return *this; }
 };
+
+// Optional second stream for the weight-gradient kernels of a Bottleneck backward.  They are leaves of the backward graph (nothing
+// in the block consumes dW), while the input-gradient chain is a sequence of dependent, latency-bound launches at the deep levels
+// (3,124 / 780 points): forked onto `aux` behind an event, the wgrad kernels fill the CUs the chain leaves idle.  Caller-owned
+// handles (no global state); aux == nullptr runs everything on the main stream.
+struct Fork {
+    hipStream_t main, aux;
+    hipEvent_t fork, join;
+    bool on() const { return aux != nullptr; }
+    hipStream_t begin(Err &e) const {   // work issued on the returned stream starts after everything queued on `main` so far
+        if (!on()) return main;
+        e << (int)hipEventRecord(fork, main);
+        e << (int)hipStreamWaitEvent(aux, fork, 0);
+        return aux;
+    }
+    void finish(Err &e) const {         // `main` continues after everything queued on `aux`
+        if (!on()) return;
+        e << (int)hipEventRecord(join, aux);
+        e << (int)hipStreamWaitEvent(main, join, 0);
+    }
+};
 }  // namespace
 
 // coef from GEMM-epilogue partials (training) or running statistics (eval)
@@ -46,7 +67,7 @@ extern "C" int pdf_block_pre_forward(long n, int c, void *const *p, int training
 // p[]: x, z1, coef1, W1, Wq, Wk, Wv, gxq, gxk, gxv                                  (inputs)
 //      gx, grads [dW1 (c*c) | dbeta1 (c) | dgamma1 (c) | {dW (c*c), db (c)} x q,k,v]   (outputs; grads zeroed here)
 //      dy (n*c), partial (pdf_bn_partial_floats(n, c))                                    (scratch; p[14] unused)
-static int block_pre_backward(long n, int c, void *const *p, int training, int accumulate_gx, int grads_zeroed, void *stream) {
+static int block_pre_backward(long n, int c, void *const *p, int training, int accumulate_gx, int grads_zeroed, void *stream, const Fork *fk = nullptr) {
     if (n < 1 || !p) return PDF_ERR_BAD_ARG;
     const float *x = (const float *)p[0], *z1 = (const float *)p[1], *coef1 = (const float *)p[2], *W1 = (const float *)p[3];
     float *gx = (float *)p[10], *grads = (float *)p[11], *dy = (float *)p[12], *partial = (float *)p[13];
@@ -62,17 +83,19 @@ static int block_pre_backward(long n, int c, void *const *p, int training, int a
     const float *ws[3] = {(const float *)p[4], (const float *)p[5], (const float *)p[6]};
     float *dws[3] = {dqkv, dqkv + (cc + c), dqkv + 2 * (cc + c)}, *dbs[3] = {dqkv + cc, dqkv + (cc + c) + cc, dqkv + 2 * (cc + c) + cc};
     float *ys[1] = {dy};
+    void *ws_stream = fk ? (void *)fk->begin(e) : stream;   // q/k/v weight gradients: g_xq / g_xk / g_xv are final here
+    e << pdf_rowlin_wgrad_multi(n, c, c, 3, gs, c, z1, c, coef1, coef1 + c, 1, dws, dbs, ws_stream);
     e << pdf_rowlin_multi(n, c, c, 3, 1, gs, c, ws, 1, nullptr, nullptr, nullptr, 0, ys, c, 0, stream);
-    e << pdf_rowlin_wgrad_multi(n, c, c, 3, gs, c, z1, c, coef1, coef1 + c, 1, dws, dbs, stream);
     // bn1 backward in place on dy (elementwise: same index read and written); its column sums ARE [d beta1 | d gamma1]
     e << pdf_bn_act_backward(n, c, dy, z1, nullptr, coef1, training, 1, partial, db1, dy, nullptr, stream);   // (the atomic variant: 782 blocks on 64 addresses, +13 us)
+    ws_stream = fk ? (void *)fk->begin(e) : stream;         // dW1 needs the finished dy
+    e << pdf_rowlin_wgrad(n, c, c, dy, c, x, c, nullptr, nullptr, 0, dW1, nullptr, ws_stream);
     e << pdf_rowlin_forward(n, c, c, dy, c, W1, 1, nullptr, nullptr, nullptr, 0, gx, c, accumulate_gx, nullptr, stream);
-    e << pdf_rowlin_wgrad(n, c, c, dy, c, x, c, nullptr, nullptr, 0, dW1, nullptr, stream);
     return e.rc;
 }
 
 extern "C" int pdf_block_pre_backward(long n, int c, void *const *p, int training, void *stream) {
-    return block_pre_backward(n, c, p, training, 0, 0, stream);
+    return block_pre_backward(n, c, p, training, 0, 0, stream, nullptr);
 }
 
 // p[]: t, x (identity), gamma2, beta2, rm2, rv2, W3, gamma3, beta3, rm3, rv3        (inputs)
@@ -94,7 +117,7 @@ extern "C" int pdf_block_post_forward(long n, int c, void *const *p, int trainin
 // p[]: gy, t, x, z3, coef2, coef3, W3                                               (inputs)
 //      gt, gres, grads [dW3 (c*c) | dbeta2 | dgamma2 | dbeta3 | dgamma3]             (outputs; grads zeroed here)
 //      da (n*c), partial                                                              (scratch; p[12] unused)
-static int block_post_backward(long n, int c, void *const *p, int training, int grads_zeroed, void *stream) {
+static int block_post_backward(long n, int c, void *const *p, int training, int grads_zeroed, void *stream, const Fork *fk = nullptr) {
     if (n < 1 || !p) return PDF_ERR_BAD_ARG;
     const float *gy = (const float *)p[0], *t = (const float *)p[1], *x = (const float *)p[2], *z3 = (const float *)p[3];
     const float *coef2 = (const float *)p[4], *coef3 = (const float *)p[5], *W3 = (const float *)p[6];
@@ -109,7 +132,8 @@ static int block_post_backward(long n, int c, void *const *p, int training, int 
     Err e;
     // bn3 backward: gz3 -> da (scratch), gres; column sums land in the gradient slots [d beta | d gamma]
     e << pdf_bn_act_backward(n, c, gy, z3, x, coef3, training, 1, partial, db3, da, gres, stream);
-    e << pdf_rowlin_wgrad(n, c, c, da, c, t, c, coef2, coef2 + c, 1, dW3, nullptr, stream);
+    void *ws_stream = fk ? (void *)fk->begin(e) : stream;
+    e << pdf_rowlin_wgrad(n, c, c, da, c, t, c, coef2, coef2 + c, 1, dW3, nullptr, ws_stream);
     e << pdf_rowlin_forward(n, c, c, da, c, W3, 1, nullptr, nullptr, nullptr, 0, gt, c, 0, nullptr, stream);
     // bn2 backward in place on gt
     e << pdf_bn_act_backward(n, c, gt, t, nullptr, coef2, training, 1, partial, db2, gt, nullptr, stream);
@@ -117,7 +141,7 @@ static int block_post_backward(long n, int c, void *const *p, int training, int 
 }
 
 extern "C" int pdf_block_post_backward(long n, int c, void *const *p, int training, void *stream) {
-    return block_post_backward(n, c, p, training, 0, stream);
+    return block_post_backward(n, c, p, training, 0, stream, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -155,16 +179,20 @@ extern "C" int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p
 //   scratch: 33 gt 34 da / dy 35 gxq 36 gxk 37 gxv (n*c each) 38 G2 (n*nsample*c/8) 39 G3 (n*nsample*3)
 //            40 partial (max of pdf_bn_partial_floats, pdf_pt_layer_bwd_partial_floats)
 //            41 Wsm (n*nsample*c/8) 42 GR (n*nsample*c) | inverse kNN table: 43 inv_off (n+1) 44 inv_entry, entry_base
+//            45 dy (n*c; separate from 34: the forked dW3 kernel may still be reading `da` when the pre half starts)
+//   optional: 46 aux stream, 47 fork event, 48 join event (all three or none: weight gradients on the second stream, see Fork)
 extern "C" int pdf_bottleneck_backward(long n, int nsample, int c, void *const *p, int training, int entry_base, void *stream) {
     if (n < 1 || !p) return PDF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     Err e;
+    Fork fk{s, static_cast<hipStream_t>(p[46]), static_cast<hipEvent_t>(p[47]), static_cast<hipEvent_t>(p[48])};
+    if (!p[46] || !p[47] || !p[48]) fk.aux = nullptr;
     void *post[13] = {p[0], p[24], p[1], p[25], p[26], p[27], p[28], p[33], p[29], p[31], p[34], p[40], nullptr};
     // ONE memset: the caller lays out [grads of the pre half | grads of the post half] contiguously (p[30] .. p[32]); g_xk / g_xv are
     // written by the segmented gathers (no zeroing)
     hipError_t he = hipMemsetAsync(p[30], 0, (size_t)((char *)p[32] - (char *)p[30]), s);
     if (he != hipSuccess) return (int)he;
-    e << block_post_backward(n, c, post, training, 1, stream);
+    e << block_post_backward(n, c, post, training, 1, stream, &fk);
     const float *weights[8];
     for (int i = 0; i < 8; ++i) weights[i] = (const float *)p[10 + i];
     e << pdf_pt_layer_backward((int)n, nsample, c, (const float *)p[21], (const float *)p[22], (const float *)p[23], (const float *)p[8],
@@ -172,8 +200,9 @@ extern "C" int pdf_bottleneck_backward(long n, int nsample, int c, void *const *
                                (const float *)p[33], (float *)p[35], (float *)p[36], (float *)p[37], (float *)p[38], (float *)p[39],
                                (float *)p[41], (float *)p[42], (const int *)p[43], (const int *)p[44], entry_base,
                                (float *)p[40], (float *)p[32], stream);
-    void *pre[15] = {p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[35], p[36], p[37], p[29], p[30], p[34], p[40], nullptr};
-    e << block_pre_backward(n, c, pre, training, 1, 1, stream);   // gx += dy W1 on top of the identity branch
+    void *pre[15] = {p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[35], p[36], p[37], p[29], p[30], p[45], p[40], nullptr};
+    e << block_pre_backward(n, c, pre, training, 1, 1, stream, &fk);   // gx += dy W1 on top of the identity branch
+    fk.finish(e);   // the gradients written on the second stream are complete before anything later on `stream`
     return e.rc;
 }
 

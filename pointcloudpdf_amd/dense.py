@@ -438,7 +438,7 @@ class _BottleneckFn(torch.autograd.Function):
         inv_off, inv_entry, entry_base = _native.inverse_table(idx, n)   # cached on idx by the geometry pre-pass
         ssz = [nc, nc, nc, n * k * cs, n * k * 3,
                max(int(lib.pdf_bn_partial_floats(n, c)), int(lib.pdf_pt_layer_bwd_partial_floats(n, k, c))),
-               nc, nc, n * k * cs, n * k * c]   # gt da gxq G2 G3 partial | gxk gxv Wsm GR
+               nc, nc, n * k * cs, n * k * c, nc]   # gt da gxq G2 G3 partial | gxk gxv Wsm GR | dy
         soff, tot = [], 0
         for sz in ssz:
             soff.append(tot)
@@ -451,7 +451,8 @@ class _BottleneckFn(torch.autograd.Function):
                 Wp1.data_ptr(), bp1.data_ptr(), Wp2.data_ptr(), bp2.data_ptr(), Ww1.data_ptr(), bw1.data_ptr(), Ww2.data_ptr(), bw2.data_ptr(),
                 A(5), A(6), A(7), A(2), A(3), A(4), A(8), A(10), A(9), A(11), W3.data_ptr(),
                 gx.data_ptr(), gb + 4 * o_pre, gb + 4 * o_post, gb + 4 * o_sum,
-                S(0), S(1), S(2), S(6), S(7), S(3), S(4), S(5), S(8), S(9), inv_off.data_ptr(), inv_entry.data_ptr()]
+                S(0), S(1), S(2), S(6), S(7), S(3), S(4), S(5), S(8), S(9), inv_off.data_ptr(), inv_entry.data_ptr(), S(10),
+                *be.aux_handles(x.device)]
         be.bottleneck_backward(n, k, c, ptrs, training, entry_base)
         G = lambda o, sz, *shape: grads[o:o + sz].view(*shape) if shape else grads[o:o + sz]
         # pre half: dW1 | dbeta1 | dgamma1 | {dW, db} x q, k, v
