@@ -790,6 +790,66 @@ def run_stratified_cases(hook):
         _native._set_backend_for_testing(prev)
 
 
+def run_datapath_cases():
+    """The reference's OWN SphereCrop (pointcept/datasets/transform.py:929-1025), collate_fn / point_collate_fn (datasets/utils.py:15-56)
+    and evaluation helpers (utils/misc.py:55-87: intersection_and_union_gpu, aupr_and_auroc incl. its sklearn calls) on seeded inputs."""
+    import random as pyrandom
+
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, *rel.split("/")))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[name] = m
+        spec.loader.exec_module(m)
+        return m
+
+    tr = sys.modules.get("ref_transform") or load("ref_transform", "pointcept/datasets/transform.py")
+    ut = load("ref_dataset_utils", "pointcept/datasets/utils.py")
+    misc = load("ref_misc", "pointcept/utils/misc.py")
+    out = {}
+    # ---- SphereCrop: three scenes (one below the limit), centre and random modes
+    for tag, (seed, n, pmax, mode) in {"a": (41, 9000, 4000, "center"), "b": (42, 6500, 6500, "center"), "c": (43, 12000, 5000, "random")}.items():
+        coord = dense_scene(seed, n)
+        rng = np.random.RandomState(seed)
+        color = rng.rand(n, 3).astype(np.float32)
+        segment = rng.randint(0, 13, n)
+        np.random.seed(seed)
+        d = tr.SphereCrop(point_max=pmax, mode=mode)(dict(coord=coord.copy(), color=color.copy(), segment=segment.copy(), index=np.arange(n)))
+        np.random.seed(seed)
+        out[f"crop_{tag}_center"] = np.array(np.random.randint(n) if mode == "random" else n // 2)
+        out[f"crop_{tag}_coord"], out[f"crop_{tag}_segment"] = d["coord"], d["segment"]
+    # ---- collate: dict samples with an "offset" key, list samples, Mix3D
+    samples = []
+    for i, n in enumerate([5, 3, 4, 6]):
+        g = torch.Generator().manual_seed(50 + i)
+        samples.append(dict(coord=torch.rand(n, 3, generator=g), segment=torch.randint(0, 13, (n,), generator=g), offset=torch.tensor([n]), name=f"scene{i}"))
+    c = ut.collate_fn([dict(s) for s in samples])
+    out["collate_coord"], out["collate_segment"], out["collate_offset"], out["collate_name"] = c["coord"].numpy(), c["segment"].numpy(), c["offset"].numpy(), np.array(c["name"])
+    lc = ut.collate_fn([[s["coord"], s["segment"]] for s in samples])
+    out["collate_list_offset"] = lc[-1].numpy()
+    pyrandom.seed(0)
+    m = ut.point_collate_fn([dict(s) for s in samples], mix_prob=1.0)
+    out["mix_offset"], out["mix_offset_ori"] = m["offset"].numpy(), m["offset_ori"].numpy()
+    # ---- evaluation metrics
+    g = torch.Generator().manual_seed(77)
+    n, k = 5000, 13
+    segment = torch.randint(0, k, (n,), generator=g)
+    segment[torch.rand(n, generator=g) < 0.1] = -1
+    pred = torch.where(torch.rand(n, generator=g) < 0.7, segment.clamp(min=0), torch.randint(0, k, (n,), generator=g))
+    score = torch.rand(n, generator=g) + 0.5 * torch.isin(segment, torch.tensor([5, 9])).float()
+    score = torch.round(score * 200) / 200          # ties between scores
+    i, u, t = misc.intersection_and_union_gpu(pred.float(), segment.float(), k, -1)   # (torch.histc has no int64 CPU kernel; the values are small integers)
+    out["iou_pred"], out["iou_segment"], out["iou_score"] = pred.numpy(), segment.numpy(), score.numpy()
+    out["iou_intersection"], out["iou_union"], out["iou_target"] = i.numpy(), u.numpy(), t.numpy()
+    aupr, auroc = misc.aupr_and_auroc(score.clone(), segment.clone(), [5, 9], -1)
+    out["aupr"], out["auroc"] = np.array(aupr), np.array(auroc)
+    none = misc.aupr_and_auroc(score.clone(), segment.clamp(max=4).clone(), [5, 9], -1)
+    out["aupr_none"] = np.array(none[0] is None and none[1] is None)
+    mask_known = ~misc.selected_mask([5, 9], k) if hasattr(misc, "selected_mask") else None
+    iou_class = i.numpy() / (u.numpy() + 1e-10)
+    out["miou_known"] = np.array(np.mean(iou_class[mask_known]))
+    return out
+
+
 def run_hook_case(hook):
     """BaseModelHook on a toy module: forward/backward capture + clone semantics."""
     torch.manual_seed(3)
@@ -807,7 +867,7 @@ def run_hook_case(hook):
 
 
 def main():
-    """No flag: regenerate every fixture.  --only-ball | --only-pointops2 | --only-gridsample | --only-pseudo | --only-pointpdf | --only-stratified |
+    """No flag: regenerate every fixture.  --only-ball | --only-pointops2 | --only-gridsample | --only-pseudo | --only-pointpdf | --only-stratified | --only-datapath |
     --only-case=<model case name>: just that one (the others are left as committed)."""
     ref_pointops, seg, rec, hook, losses = install_reference()
     flags = [a for a in sys.argv[1:] if a.startswith("--only-")]
@@ -827,6 +887,8 @@ def main():
         save("ops_pseudo_label_ref.npz", run_pseudo_label_cases())
     if want("pointpdf"):
         save("model_pointpdf_forward.npz", run_pointpdf_forward_cases(hook))
+    if want("datapath"):
+        save("ops_datapath_ref.npz", run_datapath_cases())
     if want("stratified"):
         save("model_stratified.npz", run_stratified_cases(hook))
     if not flags:

@@ -1,0 +1,105 @@
+"""SphereCrop / collate on the device and the open-world evaluation metrics against fixtures produced by the reference's OWN code
+(tests/golden/ops_datapath_ref.npz: datasets/transform.py:929-1025, datasets/utils.py:15-56, utils/misc.py:55-87).  Runs on CPU
+tensors here and on the GPU in the -m gpu suite (same torch code, device tensors)."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from pointcloudpdf_amd import data_path, evaluator
+
+DEVICES = ["cpu"]
+
+
+def _dense_scene(seed, n, room=(6.0, 4.0, 2.5)):   # == tests/golden/make_golden.py::dense_scene
+    rng = np.random.default_rng(seed)
+    c = rng.random((n, 3)) * np.array(room) - np.array([1.0, 0.5, 0.25])
+    face = rng.integers(0, 3, n)
+    c[np.arange(n), face] = np.where(rng.random(n) < 0.5, -np.array([1.0, 0.5, 0.25])[face], (np.array(room) - np.array([1.0, 0.5, 0.25]))[face])
+    return c.astype(np.float32)
+
+
+def _crop_inputs(seed, n):
+    coord = _dense_scene(seed, n)
+    rng = np.random.RandomState(seed)
+    color = rng.rand(n, 3).astype(np.float32)
+    segment = rng.randint(0, 13, n)
+    return coord, color, segment
+
+
+CROPS = {"a": (41, 9000, 4000, "center"), "b": (42, 6500, 6500, "center"), "c": (43, 12000, 5000, "random")}
+
+
+def check_sphere_crop(g, device):
+    # the three scenes as ONE batch (per-scene limits differ in the fixture, so each is also checked alone)
+    for tag, (seed, n, pmax, mode) in CROPS.items():
+        coord, color, segment = _crop_inputs(seed, n)
+        data = dict(coord=torch.from_numpy(coord).to(device), color=torch.from_numpy(color).to(device), segment=torch.from_numpy(segment).to(device))
+        out, off, kept = data_path.sphere_crop(data, [n], point_max=pmax, mode=mode, centers=[int(g[f"crop_{tag}_center"])])
+        ref_coord, ref_seg = g[f"crop_{tag}_coord"], g[f"crop_{tag}_segment"]
+        assert int(off[-1]) == ref_coord.shape[0] == min(n, pmax)
+        ours = out["coord"].cpu().numpy()
+        if n <= pmax:
+            assert np.array_equal(ours, ref_coord) and np.array_equal(out["segment"].cpu().numpy(), ref_seg)   # untouched
+        else:   # same kept SET and same ascending-distance order (upstream's argsort is unstable: equidistant points may swap)
+            c = coord[int(g[f"crop_{tag}_center"])]
+            d_ours, d_ref = ((ours - c) ** 2).sum(1), ((ref_coord - c) ** 2).sum(1)
+            assert np.all(np.diff(d_ours) >= 0) and np.array_equal(np.sort(d_ours), np.sort(d_ref))
+            assert set(map(tuple, ours.round(6))) == set(map(tuple, ref_coord.round(6)))
+    # batched: scenes a + c together give the same rows as each alone
+    (sa, na, pa, _), (sc, nc, pc, _) = CROPS["a"], CROPS["c"]
+    ca, cc = _crop_inputs(sa, na)[0], _crop_inputs(sc, nc)[0]
+    both = dict(coord=torch.from_numpy(np.concatenate([ca, cc])).to(device))
+    out, off, kept = data_path.sphere_crop(both, [na, na + nc], point_max=pa, mode="center")
+    alone_a = data_path.sphere_crop(dict(coord=torch.from_numpy(ca).to(device)), [na], point_max=pa, mode="center")[2]
+    alone_c = data_path.sphere_crop(dict(coord=torch.from_numpy(cc).to(device)), [nc], point_max=pa, mode="center")[2]
+    assert off.tolist() == [pa, 2 * pa] and torch.equal(kept[:pa], alone_a) and torch.equal(kept[pa:] - na, alone_c)
+
+
+def check_collate(g, device):
+    samples = []
+    for i, n in enumerate([5, 3, 4, 6]):
+        gen = torch.Generator().manual_seed(50 + i)
+        samples.append(dict(coord=torch.rand(n, 3, generator=gen).to(device), segment=torch.randint(0, 13, (n,), generator=gen).to(device),
+                            offset=torch.tensor([n]).to(device), name=f"scene{i}"))
+    c = data_path.collate_fn([dict(s) for s in samples])
+    assert np.array_equal(c["coord"].cpu().numpy(), g["collate_coord"]) and np.array_equal(c["segment"].cpu().numpy(), g["collate_segment"])
+    assert np.array_equal(c["offset"].cpu().numpy(), g["collate_offset"]) and list(c["name"]) == list(g["collate_name"])
+    lc = data_path.collate_fn([[s["coord"], s["segment"]] for s in samples])
+    assert np.array_equal(lc[-1].cpu().numpy(), g["collate_list_offset"]) and lc[-1].dtype == torch.int32
+    random.seed(0)
+    m = data_path.point_collate_fn([dict(s) for s in samples], mix_prob=1.0)
+    assert np.array_equal(m["offset"].cpu().numpy(), g["mix_offset"]) and np.array_equal(m["offset_ori"].cpu().numpy(), g["mix_offset_ori"])
+
+
+def check_metrics(g, device):
+    pred, segment, score = (torch.from_numpy(g[k]).to(device) for k in ("iou_pred", "iou_segment", "iou_score"))
+    i, u, t = evaluator.intersection_and_union(pred, segment, 13, -1)
+    assert np.array_equal(i.cpu().numpy(), g["iou_intersection"]) and np.array_equal(u.cpu().numpy(), g["iou_union"])
+    assert np.array_equal(t.cpu().numpy(), g["iou_target"])
+    aupr, auroc = evaluator.aupr_and_auroc(score, segment, [5, 9], -1)
+    assert abs(aupr - float(g["aupr"])) < 1e-9 and abs(auroc - float(g["auroc"])) < 1e-9      # sklearn's numbers
+    assert evaluator.aupr_and_auroc(score, segment.clamp(max=4), [5, 9], -1) == (None, None) and bool(g["aupr_none"])
+    ev = evaluator.OpenSegEvaluator(13, [5, 9], -1)
+    logits = torch.nn.functional.one_hot(pred, 13).float()
+    half = pred.shape[0] // 2
+    ev.update(logits[:half], score[:half], segment[:half], loss=1.0)
+    ev.update(logits[half:], score[half:], segment[half:], loss=3.0)
+    s = ev.summary()
+    assert abs(s["mIoU"] - float(g["miou_known"])) < 1e-6 and s["loss"] == 2.0 and 0.0 < s["aupr"] <= 1.0 and 0.0 < s["auroc"] <= 1.0
+    assert s["iou_class"].shape == (13,) and not ev.mask_known[5] and not ev.mask_known[9] and ev.mask_known.sum() == 11
+
+
+@pytest.mark.parametrize("what", ["crop", "collate", "metrics"])
+def test_datapath_matches_reference_code(golden_dir, what):
+    g = np.load(os.path.join(golden_dir, "ops_datapath_ref.npz"))
+    {"crop": check_sphere_crop, "collate": check_collate, "metrics": check_metrics}[what](g, "cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("what", ["crop", "collate", "metrics"])
+def test_datapath_on_the_device(golden_dir, what):
+    g = np.load(os.path.join(golden_dir, "ops_datapath_ref.npz"))
+    {"crop": check_sphere_crop, "collate": check_collate, "metrics": check_metrics}[what](g, "cuda")
