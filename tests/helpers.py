@@ -29,6 +29,10 @@ GRAD_TOL = 2e-2
 # (tests/test_gpu_fused_layer.py, tests/test_gpu_ops.py).
 WELL_CONDITIONED = ("cls", "dec1", "dec2", "dec3", "dec4", "confidence")
 LOOSE_GRAD_TOL = 0.2
+# With 8,192 points (BASELINE config 1) level 5 holds 32 points and the amplification is gone: every gradient of the HIP path sits
+# within 1.5e-2 of the fp64 evaluation (the reference's own fp32 run: 2e-3; measured on MI355X, tools/grad_report.py), so the
+# sanity bound shrinks to 5e-2 there; at 100k / 150k points the full distribution is checked (tests/test_gpu_fullsize.py).
+LOOSE_GRAD_TOL_BY_POINTS = {8192: 5e-2}
 
 
 def thin(a):
@@ -165,11 +169,12 @@ def check_case_against_golden(out, g, train, tol=REL_TOL):
                 report[name] = (ours, ref32)
                 # as close to the fp64 evaluation as the reference's fp32 run is (x4 + 5e-3 slack), never worse than GRAD_TOL
                 strict = name.startswith(WELL_CONDITIONED)
-                bound = min(GRAD_TOL, 4 * ref32 + 5e-3) if strict else LOOSE_GRAD_TOL
+                loose = LOOSE_GRAD_TOL_BY_POINTS.get(n, LOOSE_GRAD_TOL)
+                bound = min(GRAD_TOL, 4 * ref32 + 5e-3) if strict else loose
                 assert ours <= bound, f"{key}: ours-vs-fp64 {ours:.3e}, reference-fp32-vs-fp64 {ref32:.3e}"
                 l2 = np.sqrt((grad.astype(np.float64) ** 2).sum())
                 s64 = g[k64 + "#sum"]
-                assert abs(l2 - s64[1]) <= (GRAD_TOL if strict else LOOSE_GRAD_TOL) * s64[1] + 1e-12, f"{key}: L2 norm {l2} vs {s64[1]}"
+                assert abs(l2 - s64[1]) <= (GRAD_TOL if strict else loose) * s64[1] + 1e-12, f"{key}: L2 norm {l2} vs {s64[1]}"
             elif key.startswith("buf_"):
                 assert_close(out["state"][key[4:]], g[key], tol, key)
         out["grad_report"] = report
