@@ -83,6 +83,9 @@ def parse():
     ap.add_argument("--no-ops-roofline", action="store_true", help="skip the per-op HBM roofline micro-benchmark (rank 0, N = 1)")
     ap.add_argument("--cpu-points", type=int, default=100000, help="scene size of the bounded CPU-baseline sample")
     ap.add_argument("--amp", action="store_true", help="fp16 autocast around the step (reference enable_amp=True)")
+    ap.add_argument("--storage", choices=["f32", "bf16"], default="f32",
+                    help="bf16: the reduced-precision variant -- the fused PointTransformerLayer keeps its saved / scratch row arrays (H, G2, "
+                         "softmax weights, g_r rows) as bfloat16 with fp32 accumulation (the reference trains under AMP); the headline stays f32")
     ap.add_argument("--prefetch", type=int, default=16,
                     help="geometry pre-pass group: the pre-pass of the NEXT `prefetch` batches runs as one launch sequence on a side "
                          "stream while the current group trains (0 = inline, serial)")
@@ -281,6 +284,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.backends.cuda.matmul.allow_tf32 = False
     be = _native.hip_backend()
+    be.set_storage(args.storage)
 
     scannet, strat = args.workload == "scannet", args.workload == "stratified"
     if args.points is None:
@@ -451,7 +455,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16-autocast" if args.amp else "f32",
+            "dtype": "f16-autocast" if args.amp else ("bf16-storage/f32-acc" if args.storage == "bf16" else "f32"),
             "data": "synthetic",
             "config": {"workload": f"{'ScanNet' if scannet else 'S3DIS'}-shaped synthetic voxelised scenes, {args.scenes} x {args.points} points per GPU, "
                                    + ("StratifiedTransformer ST-v1m1 + PointPdf-v1m1 / ST-v1m1-Recognizer, fwd+bwd+SGD, window partition recomputed every step" if strat else

@@ -148,20 +148,22 @@ int pdf_pt_layer_forward(int n, int nsample, int c, const float *xq, const float
                          const float *p, const int *idx, const float *const *weights,
                          const float *const *bn_params, float *const *bn_buffers, int training, float eps,
                          float momentum, float *bn, float *saved, float *H, float *partial, float *out,
-                         void *stream);
+                         int storage_bf16, void *stream);
 
 /* Backward of the fused PointTransformerLayer (train mode).  gxq / gxk / gxv are overwritten: the scatters of g_xk and g_xv run as
  * segmented gathers over the INVERSE of the kNN table (inv_off (n+1), inv_entry, entry_base -- see pdf_seg_sum_rows), so they are
  * deterministic and atomics-free; Wsm (n*nsample*c/8) and GR (n*nsample*c) are scratch (softmax weights, g_r rows).  sums needs
  * pdf_pt_layer_bwd_sums_floats(c) + 2*(3+c+c/8) floats and returns the parameter-gradient sections documented in
- * csrc/fused_layer.hip. */
+ * csrc/fused_layer.hip.  storage_bf16 (forward AND backward of a layer must agree): the row arrays only the layer itself reads --
+ * H (saved), G2 / Wsm / GR (scratch) -- hold bfloat16 (round-to-nearest-even) in the first half of the same buffers; every sum and
+ * product stays fp32.  The reduced-precision variant behind `bench.py --storage bf16` (the reference trains under AMP). */
 long pdf_pt_layer_bwd_partial_floats(int n, int nsample, int c);
 long pdf_pt_layer_bwd_sums_floats(int c);
 int pdf_pt_layer_backward(int n, int nsample, int c, const float *xq, const float *xk, const float *xv,
                           const float *p, const int *idx, const float *const *weights, const float *bn,
                           const float *saved, const float *H, const float *gout, float *gxq, float *gxk,
                           float *gxv, float *G2, float *G3, float *Wsm, float *GR, const int *inv_off, const int *inv_entry,
-                          int entry_base, float *partial, float *sums, void *stream);
+                          int entry_base, float *partial, float *sums, int storage_bf16, void *stream);
 
 /* BatchNorm1d over (n, c) rows fused with the residual add and ReLU that follow it in the Bottleneck
  * (point_transformer_seg.py:184-192).  c must be a power of two in 4..1024.  coef (4c floats) = scale|shift|mean|rstd,
@@ -218,8 +220,8 @@ int pdf_block_pre_backward(long n, int c, void *const *p, int training, void *st
 int pdf_block_post_forward(long n, int c, void *const *p, int training, float eps, float momentum, void *stream);
 int pdf_block_post_backward(long n, int c, void *const *p, int training, void *stream);
 /* The whole Bottleneck (both halves + the fused attention layer) as one call per direction; tables in csrc/block.hip. */
-int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p, int training, float eps, float momentum, void *stream);
-int pdf_bottleneck_backward(long n, int nsample, int c, void *const *p, int training, int entry_base, void *stream);
+int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p, int training, float eps, float momentum, int storage_bf16, void *stream);
+int pdf_bottleneck_backward(long n, int nsample, int c, void *const *p, int training, int entry_base, int storage_bf16, void *stream);
 /* Linear (+ bias) -> BatchNorm1d -> (ReLU) as one call per direction (TransitionUp, heads); tables in csrc/block.hip. */
 int pdf_linbn_forward(long n, int k, int o, void *const *p, int training, int relu, float eps, float momentum, void *stream);
 int pdf_linbn_backward(long n, int k, int o, void *const *p, int training, int relu, void *stream);
@@ -255,6 +257,10 @@ int pdf_seg_sum_rows(long n, int c, const float *src, const int *inv_off, const 
                      void *stream);
 int pdf_seg_sum_rows_strided(long n, int c, const float *src, long src_stride, const int *inv_off, const int *inv_entry, int entry_base,
                              float scale, float *out, void *stream);
+int pdf_seg_sum_rows_x(long n, int c, const float *src, long src_stride, int src_bf16, const int *inv_off, const int *inv_entry, int entry_base,
+                       float scale, float *out, void *stream);     /* src rows fp32 or bfloat16 */
+int pdf_seg_sum_weighted_x(long n, int c, int nsample, int w_c, const float *src, const float *w, int w_bf16, const int *inv_off,
+                           const int *inv_entry, int entry_base, float *out, void *stream);   /* w fp32 or bfloat16 */
 int pdf_seg_sum_weighted(long n, int c, int nsample, int w_c, const float *src, const float *w, const int *inv_off, const int *inv_entry,
                          int entry_base, float *out, void *stream);
 

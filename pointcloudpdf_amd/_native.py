@@ -467,9 +467,9 @@ class HipBackend(CBackend):
         lib.pdf_linbn_backward.restype = c_int
         lib.pdf_linbn_backward.argtypes = [c_long, c_int, c_int, c_void_p, c_int, c_int, c_void_p]
         lib.pdf_bottleneck_forward.restype = c_int
-        lib.pdf_bottleneck_forward.argtypes = [c_long, c_int, c_int, c_void_p, c_int, ctypes.c_float, ctypes.c_float, c_void_p]
+        lib.pdf_bottleneck_forward.argtypes = [c_long, c_int, c_int, c_void_p, c_int, ctypes.c_float, ctypes.c_float, c_int, c_void_p]
         lib.pdf_bottleneck_backward.restype = c_int
-        lib.pdf_bottleneck_backward.argtypes = [c_long, c_int, c_int, c_void_p, c_int, c_int, c_void_p]
+        lib.pdf_bottleneck_backward.argtypes = [c_long, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]
         for nm in ("pre_backward", "post_backward"):
             f = getattr(lib, "pdf_block_" + nm)
             f.restype = c_int
@@ -514,9 +514,9 @@ class HipBackend(CBackend):
         lib.pdf_pt_layer_bwd_sums_floats.restype = c_long
         lib.pdf_pt_layer_bwd_sums_floats.argtypes = [c_int]
         lib.pdf_pt_layer_forward.restype = c_int
-        lib.pdf_pt_layer_forward.argtypes = [c_int, c_int, c_int] + [c_void_p] * 8 + [c_int, ctypes.c_float, ctypes.c_float] + [c_void_p] * 6
+        lib.pdf_pt_layer_forward.argtypes = [c_int, c_int, c_int] + [c_void_p] * 8 + [c_int, ctypes.c_float, ctypes.c_float] + [c_void_p] * 5 + [c_int, c_void_p]
         lib.pdf_pt_layer_backward.restype = c_int
-        lib.pdf_pt_layer_backward.argtypes = [c_int, c_int, c_int] + [c_void_p] * 19 + [c_int] + [c_void_p] * 3
+        lib.pdf_pt_layer_backward.argtypes = [c_int, c_int, c_int] + [c_void_p] * 19 + [c_int] + [c_void_p] * 2 + [c_int, c_void_p]
         self.fps_mode = os.environ.get("PDFOPS_FPS", "bucketed")  # "bucketed" | "plain"
         self.knn_mode = os.environ.get("PDFOPS_KNN", "grid")      # "grid" | "scan"
         lib.pdf_knn_workspace_bytes.restype = c_long
@@ -529,6 +529,15 @@ class HipBackend(CBackend):
     KNN_GRID_MAX_SCENES = 64
     # scatter-adds of the gather family as segmented gathers over inverse tables (PDFOPS_INVERSE=0: the atomic kernels, for A/B runs)
     use_inverse = os.environ.get("PDFOPS_INVERSE", "1") != "0"
+    # reduced-precision variant (the reference trains under AMP, engines/train.py:343-356): the fused PointTransformerLayer keeps the
+    # row arrays only it reads -- H (saved), G2 / Wsm / GR (backward scratch) -- as bfloat16; sums, products, statistics, parameters and
+    # every tensor that crosses the layer boundary stay fp32.  Set per process (PDFOPS_STORAGE=bf16) or with set_storage().
+    storage_bf16 = os.environ.get("PDFOPS_STORAGE", "f32") == "bf16"
+
+    def set_storage(self, kind):
+        if kind not in ("f32", "bf16"):
+            raise ValueError("storage: 'f32' or 'bf16'")
+        self.storage_bf16 = kind == "bf16"
 
     def grouping_backward(self, grad_output, idx, n):
         if not self.use_inverse:
@@ -646,12 +655,12 @@ class HipBackend(CBackend):
             n, k, c, self._ptr(xq), self._ptr(xk), self._ptr(xv), self._ptr(p), self._ptr(idx),
             self._ptr_array(weights), self._ptr_array(bn_params), self._ptr_array(bn_buffers), int(bool(training)),
             ctypes.c_float(eps), ctypes.c_float(momentum), self._ptr(bn), self._ptr(saved), self._ptr(H),
-            self._ptr(partial), self._ptr(out), c_void_p(torch.cuda.current_stream().cuda_stream))
+            self._ptr(partial), self._ptr(out), int(self.storage_bf16), c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
             raise PdfOpsError(f"pdf_pt_layer_forward failed with status {rc}")
         return out, bn, saved, H
 
-    def pt_layer_backward(self, xq, xk, xv, p, idx, weights, bn, saved, H, gout):
+    def pt_layer_backward(self, xq, xk, xv, p, idx, weights, bn, saved, H, gout, storage_bf16=None):
         n, c = xq.shape
         k = idx.shape[1]
         cs = c // 8
@@ -673,7 +682,7 @@ class HipBackend(CBackend):
             self._ptr_array(weights), self._ptr(bn), self._ptr(saved), self._ptr(H), self._ptr(gout),
             self._ptr(gxq), self._ptr(gxk), self._ptr(gxv), self._ptr(G2), self._ptr(G3), self._ptr(Wsm), self._ptr(GR),
             self._ptr(inv_off), self._ptr(inv_entry), int(entry_base), self._ptr(partial),
-            self._ptr(sums), c_void_p(torch.cuda.current_stream().cuda_stream))
+            self._ptr(sums), int(self.storage_bf16 if storage_bf16 is None else storage_bf16), c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
             raise PdfOpsError(f"pdf_pt_layer_backward failed with status {rc}")
         # unpack the parameter-gradient sections (layout: csrc/fused_layer.hip, pdf_pt_layer_backward)
@@ -808,9 +817,9 @@ class HipBackend(CBackend):
         return rel4, Z, sums
 
     # -- whole Bottleneck as one host call per direction (csrc/block.hip); thin methods so that bench.py can time them
-    def bottleneck_forward(self, n, k, c, ptrs, training, eps, momentum):
+    def bottleneck_forward(self, n, k, c, ptrs, training, eps, momentum, storage_bf16=0):
         rc = self.lib.pdf_bottleneck_forward(n, k, c, (c_void_p * len(ptrs))(*ptrs), int(training), ctypes.c_float(eps),
-                                             ctypes.c_float(momentum), self._stream())
+                                             ctypes.c_float(momentum), int(storage_bf16), self._stream())
         if rc != 0:
             raise PdfOpsError(f"pdf_bottleneck_forward failed with status {rc}")
 
@@ -833,8 +842,8 @@ class HipBackend(CBackend):
         st, evs = table[key]
         return [st.cuda_stream, evs[0].cuda_event, evs[1].cuda_event]
 
-    def bottleneck_backward(self, n, k, c, ptrs, training, entry_base=0):
-        rc = self.lib.pdf_bottleneck_backward(n, k, c, (c_void_p * len(ptrs))(*ptrs), int(training), int(entry_base), self._stream())
+    def bottleneck_backward(self, n, k, c, ptrs, training, entry_base=0, storage_bf16=0):
+        rc = self.lib.pdf_bottleneck_backward(n, k, c, (c_void_p * len(ptrs))(*ptrs), int(training), int(entry_base), int(storage_bf16), self._stream())
         if rc != 0:
             raise PdfOpsError(f"pdf_bottleneck_backward failed with status {rc}")
 

@@ -33,7 +33,35 @@ struct LayerArgs {
     float *Wsm, *GR;                         // (N,K,CS) softmax weights (B1 -> g_xv gather), (N,K,C) g_r rows (B3 -> g_xk gather):
                                              // the scatters of g_xv / g_xk run as segmented gathers over the inverse kNN table
     float inv_rows;                          // 1 / (N*K)
+    int bf16;                                // H / G2 / Wsm / GR hold bfloat16 (half the bytes of the same buffers) instead of fp32
 };
+
+// ---- row arrays that only this layer writes and reads (H saved by the forward; G2, Wsm, GR scratch of the backward): stored as
+// fp32 or, reduced-precision variant, as bfloat16 with round-to-nearest-even; all arithmetic stays fp32.  `idx` = element index.
+__device__ __forceinline__ unsigned f2bf(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float bf2f(unsigned h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ void st_u4(float *base, size_t idx, float a, float b, float c, float d, int bf16) {
+    if (bf16) {
+        uint2 v; v.x = f2bf(a) | (f2bf(b) << 16); v.y = f2bf(c) | (f2bf(d) << 16);
+        *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(base) + idx) = v;
+    } else {
+        *reinterpret_cast<float4 *>(base + idx) = make_float4(a, b, c, d);
+    }
+}
+__device__ __forceinline__ float4 ld_u4(const float *base, size_t idx, int bf16) {
+    if (bf16) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned short *>(base) + idx);
+        return make_float4(bf2f(v.x & 0xffffu), bf2f(v.x >> 16), bf2f(v.y & 0xffffu), bf2f(v.y >> 16));
+    }
+    return *reinterpret_cast<const float4 *>(base + idx);
+}
+__device__ __forceinline__ void st_u1_stream(float *base, size_t idx, float v, int bf16) {
+    if (bf16) __builtin_nontemporal_store((unsigned short)f2bf(v), reinterpret_cast<unsigned short *>(base) + idx);
+    else __builtin_nontemporal_store(v, base + idx);
+}
 
 }  // namespace fl
 

@@ -261,9 +261,8 @@ __global__ __launch_bounds__(64 * WPB) void k_p3(LayerArgs A) {
             }
         }
         if (R.valid) {
-            float *dst = A.H + (size_t)R.row * CS;
 #pragma unroll
-            for (int o = 0; o < CS; o += 4) *reinterpret_cast<float4 *>(dst + o) = make_float4(h[o], h[o + 1], h[o + 2], h[o + 3]);
+            for (int o = 0; o < CS; o += 4) st_u4(A.H, (size_t)R.row * CS + o, h[o], h[o + 1], h[o + 2], h[o + 3], A.bf16);
         }
         if (STATS) {
 #pragma unroll
@@ -313,10 +312,10 @@ __device__ __forceinline__ float group_sum(float v) {
 // attention weights of one row from its stored h: w = softmax_j( relu(BN2(h)) Ww2^T + bw2 )
 template <int CS>
 __device__ __forceinline__ void load_hidden(const LayerArgs &A, const Row &R, float *h) {
-    const float *src = A.H + (size_t)(R.valid ? R.row : 0) * CS;
+    const size_t src = (size_t)(R.valid ? R.row : 0) * CS;
 #pragma unroll
     for (int o = 0; o < CS; o += 4) {
-        const float4 v = *reinterpret_cast<const float4 *>(src + o);
+        const float4 v = ld_u4(A.H, src + o, A.bf16);
         h[o] = v.x; h[o + 1] = v.y; h[o + 2] = v.z; h[o + 3] = v.w;
     }
 }
@@ -400,12 +399,12 @@ constexpr int MAX_BLOCKS_BWD = 256;
 
 // Store the 64x32 tile as channels [c0, c0+32) of rows row0 .. row0+63 of `table` (E x C): 2 rows x 32 consecutive channels per
 // instruction = whole 128-byte lines, streamed (read once by the segmented gather that follows).
-__device__ __forceinline__ void store_rows(const WaveLds &L, float *__restrict__ table, int C, int c0, long row0, long nrows, int lane) {
+__device__ __forceinline__ void store_rows(const WaveLds &L, float *__restrict__ table, int C, int c0, long row0, long nrows, int lane, int bf16) {
     const int half = lane >> 5, col = lane & 31;
 #pragma unroll 8
     for (int t = 0; t < 32; ++t) {
         const int row = 2 * t + half;
-        if (row0 + row < nrows) __builtin_nontemporal_store(L.tile[row * L.ts + col], table + (size_t)(row0 + row) * C + c0 + col);
+        if (row0 + row < nrows) st_u1_stream(table, (size_t)(row0 + row) * C + c0 + col, L.tile[row * L.ts + col], bf16);
     }
 }
 
@@ -475,9 +474,8 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
             wave_sync();
         }
         if (R.valid) {   // softmax weights of the row: g_xv[nb] = sum over the inverse table of g_out[i] * w  (pdf_seg_sum_weighted)
-            float *dst = A.Wsm + (size_t)R.row * CS;
 #pragma unroll
-            for (int o = 0; o < CS; o += 4) *reinterpret_cast<float4 *>(dst + o) = make_float4(w[o], w[o + 1], w[o + 2], w[o + 3]);
+            for (int o = 0; o < CS; o += 4) st_u4(A.Wsm, (size_t)R.row * CS + o, w[o], w[o + 1], w[o + 2], w[o + 3], A.bf16);
         }
         // softmax backward over the K neighbours, then Linear(CS,CS) and the ReLU of BN2
         float gz[CS], gy2[CS];
@@ -498,9 +496,8 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
             sgz[c] += gz[c];
         }
         if (R.valid) {
-            float *dst = A.G2 + (size_t)R.row * CS;
 #pragma unroll
-            for (int o = 0; o < CS; o += 4) *reinterpret_cast<float4 *>(dst + o) = make_float4(gy2[o], gy2[o + 1], gy2[o + 2], gy2[o + 3]);
+            for (int o = 0; o < CS; o += 4) st_u4(A.G2, (size_t)R.row * CS + o, gy2[o], gy2[o + 1], gy2[o + 2], gy2[o + 3], A.bf16);
         }
         // g_Ww2[o][c] += sum_rows gz[o] * u[c]
 #pragma unroll
@@ -533,10 +530,10 @@ __device__ __forceinline__ void hidden_grad(const LayerArgs &A, const Row &R, fl
     cfloat_p m2 = A.mean + 3 + C, r2 = A.rstd + 3 + C;
     float h[CS];
     load_hidden<CS>(A, R, h);
-    const float *src = A.G2 + (size_t)(R.valid ? R.row : 0) * CS;
+    const size_t src = (size_t)(R.valid ? R.row : 0) * CS;
 #pragma unroll
     for (int o = 0; o < CS; o += 4) {
-        const float4 v = *reinterpret_cast<const float4 *>(src + o);
+        const float4 v = ld_u4(A.G2, src + o, A.bf16);
         gh[o] = v.x; gh[o + 1] = v.y; gh[o + 2] = v.z; gh[o + 3] = v.w;
     }
 #pragma unroll
@@ -702,7 +699,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
 #pragma unroll
             for (int c = 0; c < 32; ++c) L.tile[lane * L.ts + c] = g[c];
             wave_sync();
-            store_rows(L, A.GR, C, q * 32, tile * 64, (long)A.N * K, lane);   // g_xk[nb] = segmented sum of these rows (pdf_seg_sum_rows)
+            store_rows(L, A.GR, C, q * 32, tile * 64, (long)A.N * K, lane, A.bf16);   // g_xk[nb] = segmented sum of these rows (pdf_seg_sum_rows)
             // g_xq[i] = - sum_j g_r
 #pragma unroll
             for (int m = 0; m < PPT / 2; ++m) {
@@ -1016,7 +1013,7 @@ int backward_impl(LayerArgs A, float *sums, const int *inv_off, const int *inv_e
     if (mfma) flm::launch_b1(A, C, grid, s); else k_b1<C, K><<<grid, 64 * WPB, lds, s>>>(A);
     k_colsum<<<pdf_divup(b1_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, nw, b1_width<C>(), S1);
     // g_xv[nb, c] = sum over the entries (i, j) with idx[i, j] == nb of g_out[i, c] * w[i, j, c mod C/8]   (no atomics, fixed order)
-    int rc = pdf_seg_sum_weighted(A.N, C, K, CS, A.gout, A.Wsm, inv_off, inv_entry, entry_base, A.gxv, s);
+    int rc = pdf_seg_sum_weighted_x(A.N, C, K, CS, A.gout, A.Wsm, A.bf16, inv_off, inv_entry, entry_base, A.gxv, s);
     if (rc != PDF_OK) return rc;
     A.sums = as_const(S1);
     if (mfma) flm::launch_b2(A, C, grid, s); else k_b2<C, K><<<grid, 64 * WPB, lds, s>>>(A);
@@ -1025,7 +1022,7 @@ int backward_impl(LayerArgs A, float *sums, const int *inv_off, const int *inv_e
     A.sums2 = as_const(S1);
     if (mfma) flm::launch_b3(A, C, grid, s); else k_b3<C, K><<<grid, 64 * WPB, lds, s>>>(A);
     k_colsum<<<pdf_divup(b3_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, nw, b3_width<C>(), S3);
-    rc = pdf_seg_sum_rows(A.N, C, A.GR, inv_off, inv_entry, entry_base, 1.0f, A.gxk, s);   // g_xk[nb] = sum of the g_r rows that gathered nb
+    rc = pdf_seg_sum_rows_x(A.N, C, A.GR, C, A.bf16, inv_off, inv_entry, entry_base, 1.0f, A.gxk, s);   // g_xk[nb] = sum of the g_r rows that gathered nb
     if (rc != PDF_OK) return rc;
     A.sums = as_const(S3);
     k_b4<K><<<grid, 64 * WPB, 0, s>>>(A);
@@ -1060,7 +1057,7 @@ extern "C" int pdf_pt_layer_backward(int n, int nsample, int c, const float *xq,
                                      const float *p, const int *idx, const float *const *weights, const float *bn,
                                      const float *saved, const float *H, const float *gout, float *gxq, float *gxk,
                                      float *gxv, float *G2, float *G3, float *Wsm, float *GR, const int *inv_off, const int *inv_entry,
-                                     int entry_base, float *partial, float *sums, void *stream) {
+                                     int entry_base, float *partial, float *sums, int storage_bf16, void *stream) {
     if (n < 1 || !xq || !xk || !xv || !p || !idx || !weights || !bn || !saved || !H || !gout || !gxq || !gxk || !gxv ||
         !G2 || !G3 || !Wsm || !GR || !inv_off || !inv_entry || !partial || !sums)
         return PDF_ERR_BAD_ARG;
@@ -1074,7 +1071,7 @@ extern "C" int pdf_pt_layer_backward(int n, int nsample, int c, const float *xq,
     A.sp = as_const(bn); A.tp = as_const(bn + 3); A.s1 = as_const(bn + 6); A.t1 = as_const(bn + 6 + c);
     A.s2 = as_const(bn + 6 + 2 * c); A.t2 = as_const(bn + 6 + 2 * c + cs);
     A.H = const_cast<float *>(H); A.out = nullptr; A.partial = partial;
-    A.gout = gout; A.G2 = G2; A.G3 = G3; A.gxq = gxq; A.gxk = gxk; A.gxv = gxv; A.Wsm = Wsm; A.GR = GR; A.sums = as_const(nullptr); A.sums2 = as_const(nullptr);
+    A.gout = gout; A.G2 = G2; A.G3 = G3; A.gxq = gxq; A.gxk = gxk; A.gxv = gxv; A.Wsm = Wsm; A.GR = GR; A.bf16 = storage_bf16; A.sums = as_const(nullptr); A.sums2 = as_const(nullptr);
     hipStream_t s = static_cast<hipStream_t>(stream);
     A.mean = as_const(saved); A.rstd = as_const(saved + (3 + c + cs));   // forward's layout: [mean p|1|2][rstd p|1|2]
 #define PDF_BWD(C_, K_) return fl::backward_impl<C_, K_>(A, sums, inv_off, inv_entry, entry_base, s)
@@ -1098,7 +1095,7 @@ extern "C" int pdf_pt_layer_forward(int n, int nsample, int c, const float *xq, 
                                     const float *p, const int *idx, const float *const *weights,
                                     const float *const *bn_params, float *const *bn_buffers, int training, float eps,
                                     float momentum, float *bn, float *saved, float *H, float *partial, float *out,
-                                    void *stream) {
+                                    int storage_bf16, void *stream) {
     if (n < 1 || !xq || !xk || !xv || !p || !idx || !weights || !bn_params || !bn_buffers || !bn || !H || !partial || !out)
         return PDF_ERR_BAD_ARG;
     if (!pdf_pt_layer_supported(nsample, c)) return PDF_ERR_UNSUPPORTED;
@@ -1108,7 +1105,7 @@ extern "C" int pdf_pt_layer_forward(int n, int nsample, int c, const float *xq, 
     using fl::as_const;
     A.Wp1 = as_const(weights[0]); A.bp1 = as_const(weights[1]); A.Wp2 = as_const(weights[2]); A.bp2 = as_const(weights[3]);
     A.Ww1 = as_const(weights[4]); A.bw1 = as_const(weights[5]); A.Ww2 = as_const(weights[6]); A.bw2 = as_const(weights[7]);
-    A.H = H; A.out = out; A.partial = partial;
+    A.H = H; A.out = out; A.partial = partial; A.bf16 = storage_bf16;
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define PDF_FWD(C_, K_) return fl::forward_impl<C_, K_>(A, training, eps, momentum, bn_params, bn_buffers, bn, saved, s)
     if (nsample == 8) {

@@ -159,10 +159,13 @@ __device__ __forceinline__ void attn_weights(const LayerArgs &A, const float *w2
 
 // h (or G2) row fragment of the lane: units {16 ob + 4 kq + e}
 template <int C>
-__device__ __forceinline__ f32x4 ld_units(const float *base, long rowidx, int ob, int kq) {
+__device__ __forceinline__ f32x4 ld_units(const float *base, long rowidx, int ob, int kq, int bf16) {
     constexpr int CS = C / 8;
-    return 16 * ob + 4 * kq < CS ? ld4(base + (size_t)rowidx * CS + 16 * ob + 4 * kq) : zero4();
+    if (!(16 * ob + 4 * kq < CS)) return zero4();
+    const float4 v = fl::ld_u4(base, (size_t)rowidx * CS + 16 * ob + 4 * kq, bf16);
+    return f32x4{v.x, v.y, v.z, v.w};
 }
+__device__ __forceinline__ void st_units4(float *base, size_t idx, f32x4 v, int bf16) { fl::st_u4(base, idx, v[0], v[1], v[2], v[3], bf16); }
 
 // ------------------------------------------------------------------------------------------------ P2: stats of r (slabs)
 // partial row per wave-row: [sum r (C) | sum r^2 (C)]; slab y writes channels [64 y, 64 y + 64)
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(64 * WPB) void k_p3(LayerArgs A) {
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) {
             const f32x4 h = acc[ob] + b4[ob];   // h[row][ob*16 + 4 kq + reg]
-            if (ob * 16 + 4 * kq < CS) st4(A.H + ((size_t)i * 16 + row) * CS + ob * 16 + 4 * kq, h);
+            if (ob * 16 + 4 * kq < CS) st_units4(A.H, ((size_t)i * 16 + row) * CS + ob * 16 + 4 * kq, h, A.bf16);
             if (STATS) { s4[ob] += h; ss4[ob] += h * h; }
         }
     }
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(64 * WPB) void k_p4(LayerArgs A) {
         const PRow R = load_prow(A, i, nb_cur);
         f32x4 h[NOB], u[NOB], w[NOB];
 #pragma unroll
-        for (int ob = 0; ob < NOB; ++ob) h[ob] = ld_units<C>(A.H, i * 16 + row, ob, kq);
+        for (int ob = 0; ob < NOB; ++ob) h[ob] = ld_units<C>(A.H, i * 16 + row, ob, kq, A.bf16);
         attn_weights<C>(A, w2, row, kq, h, u, w);
 #pragma unroll 1
         for (int j0 = 0; j0 < NJ; j0 += NOB) {
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
         const PRow R = load_prow(A, i, nb_cur);
         f32x4 h[NOB], u[NOB], w[NOB], gw[NOB];
 #pragma unroll
-        for (int ob = 0; ob < NOB; ++ob) { h[ob] = ld_units<C>(A.H, i * 16 + row, ob, kq); gw[ob] = zero4(); }
+        for (int ob = 0; ob < NOB; ++ob) { h[ob] = ld_units<C>(A.H, i * 16 + row, ob, kq, A.bf16); gw[ob] = zero4(); }
         attn_weights<C>(A, w2, row, kq, h, u, w);
 #pragma unroll 1
         for (int q = 0; q < NCHK; ++q) {
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
         // softmax weights of the 16 rows: g_xv[nb] = sum over the inverse kNN table of g_out[i] * w  (pdf_seg_sum_weighted)
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob)
-            if (16 * ob + 4 * kq < CS) st4(A.Wsm + ((size_t)i * 16 + row) * CS + 16 * ob + 4 * kq, w[ob]);
+            if (16 * ob + 4 * kq < CS) st_units4(A.Wsm, ((size_t)i * 16 + row) * CS + 16 * ob + 4 * kq, w[ob], A.bf16);
         // softmax backward over the 16 rows, Linear(CS, CS) backward, ReLU / BN2 bookkeeping
         f32x4 gz[NOB];
         if (CS < 16) gw[0] += xchg32(gw[0]);   // 8 units: lanes kq and kq ^ 2 hold partial sums of the same units
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) gy2[r] = u[ub][r] > 0.f ? gu[r] : 0.f;
             const bool hv = 16 * ub + 4 * kq < CS;
-            if (hv) st4(A.G2 + ((size_t)i * 16 + row) * CS + 16 * ub + 4 * kq, gy2);
+            if (hv) st_units4(A.G2, ((size_t)i * 16 + row) * CS + 16 * ub + 4 * kq, gy2, A.bf16);
             sg[ub] += gy2;
             sgh[ub] += gy2 * ((h[ub] - ldu(gp(A.mean) + 3 + C, 16 * ub + 4 * kq, hv)) * ldu(gp(A.rstd) + 3 + C, 16 * ub + 4 * kq, hv));
         }
@@ -419,7 +422,7 @@ __device__ __forceinline__ void hidden_grad(const LayerArgs &A, const float *sum
     for (int ob = 0; ob < NOB; ++ob) {
         const int o = 16 * ob + 4 * kq;
         const bool hv = o < CS;
-        const f32x4 h = ld_units<C>(A.H, i * 16 + row, ob, kq), g2 = ld_units<C>(A.G2, i * 16 + row, ob, kq);
+        const f32x4 h = ld_units<C>(A.H, i * 16 + row, ob, kq, A.bf16), g2 = ld_units<C>(A.G2, i * 16 + row, ob, kq, A.bf16);
         const f32x4 hhat = (h - ldu(gp(A.mean) + 3 + C, o, hv)) * ldu(gp(A.rstd) + 3 + C, o, hv);
         gh[ob] = ldu(gp(A.s2), o, hv) * (g2 - ldu(sums, o, hv) * A.inv_rows - hhat * (ldu(sums + CS, o, hv) * A.inv_rows));   // padding lanes: 0
         if (h_out) h_out[ob] = h;
@@ -608,7 +611,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
                 for (int rr = 0; rr < 16; ++rr) {
                     const float v = tile[rr * TS + lane];
                     acc += v;
-                    __builtin_nontemporal_store(v, A.GR + ((size_t)i * 16 + rr) * C + 64 * q + lane);   // g_xk = segmented sum of these rows
+                    fl::st_u1_stream(A.GR, ((size_t)i * 16 + rr) * C + 64 * q + lane, v, A.bf16);   // g_xk = segmented sum of these rows
                 }
                 A.gxq[(size_t)i * C + 64 * q + lane] = -acc;
             }

@@ -43,6 +43,11 @@ template <int V> struct Vec;
 template <> struct Vec<4> { using T = float4; };
 template <> struct Vec<1> { using T = float; };
 __device__ __forceinline__ float4 vld(const float4 *p) { return *p; }
+__device__ __forceinline__ float bf2f(unsigned h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ float4 vld_bf(const unsigned short *p) {   // four consecutive bfloat16 -> fp32
+    const uint2 v = *reinterpret_cast<const uint2 *>(p);
+    return make_float4(bf2f(v.x & 0xffffu), bf2f(v.x >> 16), bf2f(v.y & 0xffffu), bf2f(v.y >> 16));
+}
 __device__ __forceinline__ float vld(const float *p) { return *p; }
 __device__ __forceinline__ void fma_acc(float4 &a, float4 x, float4 w) { a.x += x.x * w.x; a.y += x.y * w.y; a.z += x.z * w.z; a.w += x.w * w.w; }
 __device__ __forceinline__ void fma_acc(float &a, float x, float w) { a += x * w; }
@@ -120,6 +125,50 @@ __global__ __launch_bounds__(TB) void k_seg_weighted(unsigned total, FastDiv cvd
     out[(size_t)v * cv + p] = a0;
 }
 
+// The fused PointTransformerLayer's reduced-precision variant keeps its g_r rows / softmax weights as bfloat16 (fp32 sums here).
+__global__ __launch_bounds__(TB) void k_seg_rows_bf(unsigned total, FastDiv cvd, unsigned src_stride, const unsigned short *__restrict__ src,
+                                                    const int *__restrict__ inv_off, const int *__restrict__ inv_entry, int entry_base,
+                                                    float scale, float4 *__restrict__ out) {
+    const unsigned gid = blockIdx.x * TB + threadIdx.x;
+    if (gid >= total) return;
+    const unsigned v = fdiv(gid, cvd), p = gid - v * cvd.d, cv = cvd.d;
+    int t = inv_off[v];
+    const int end = inv_off[v + 1];
+    float4 a0 = zero<4>(), a1 = zero<4>();
+    for (; t + 4 <= end; t += 4) {
+        const int e0 = inv_entry[t] - entry_base, e1 = inv_entry[t + 1] - entry_base, e2 = inv_entry[t + 2] - entry_base, e3 = inv_entry[t + 3] - entry_base;
+        const float4 x0 = vld_bf(src + (size_t)e0 * src_stride + 4 * p), x1 = vld_bf(src + (size_t)e1 * src_stride + 4 * p);
+        const float4 x2 = vld_bf(src + (size_t)e2 * src_stride + 4 * p), x3 = vld_bf(src + (size_t)e3 * src_stride + 4 * p);
+        add_acc(a0, x0); add_acc(a1, x1); add_acc(a0, x2); add_acc(a1, x3);
+    }
+    for (; t < end; ++t) add_acc(a0, vld_bf(src + (size_t)(inv_entry[t] - entry_base) * src_stride + 4 * p));
+    add_acc(a0, a1);
+    out[(size_t)v * cv + p] = scaled(a0, scale);
+}
+
+__global__ __launch_bounds__(TB) void k_seg_weighted_bfw(unsigned total, FastDiv cvd, FastDiv nsd, int w_c, const float4 *__restrict__ src,
+                                                         const unsigned short *__restrict__ w, const int *__restrict__ inv_off,
+                                                         const int *__restrict__ inv_entry, int entry_base, float4 *__restrict__ out) {
+    const unsigned gid = blockIdx.x * TB + threadIdx.x;
+    if (gid >= total) return;
+    const unsigned v = fdiv(gid, cvd), p = gid - v * cvd.d, cv = cvd.d;
+    const unsigned wo = (p * 4) % (unsigned)w_c;
+    int t = inv_off[v];
+    const int end = inv_off[v + 1];
+    float4 a0 = zero<4>(), a1 = zero<4>();
+    for (; t + 2 <= end; t += 2) {
+        const unsigned e0 = (unsigned)(inv_entry[t] - entry_base), e1 = (unsigned)(inv_entry[t + 1] - entry_base);
+        const float4 x0 = vld(src + (size_t)fdiv(e0, nsd) * cv + p), x1 = vld(src + (size_t)fdiv(e1, nsd) * cv + p);
+        fma_acc(a0, x0, vld_bf(w + (size_t)e0 * w_c + wo)); fma_acc(a1, x1, vld_bf(w + (size_t)e1 * w_c + wo));
+    }
+    if (t < end) {
+        const unsigned e0 = (unsigned)(inv_entry[t] - entry_base);
+        fma_acc(a0, vld(src + (size_t)fdiv(e0, nsd) * cv + p), vld_bf(w + (size_t)e0 * w_c + wo));
+    }
+    add_acc(a0, a1);
+    out[(size_t)v * cv + p] = a0;
+}
+
 }  // namespace sg
 
 // out (n, c) = scale * segmented sum of the rows src[e * src_stride + 0 .. c) (src_stride >= c floats between consecutive entries;
@@ -167,5 +216,32 @@ extern "C" int pdf_seg_sum_weighted(long n, int c, int nsample, int w_c, const f
                                                           inv_entry, entry_base, reinterpret_cast<float4 *>(out));
     else
         sg::k_seg_weighted<1, false><<<g, sg::TB, 0, s>>>((unsigned)total, cvd, nsd, w_c, src, w, inv_off, inv_entry, entry_base, out);
+    return pdf_launch_status();
+}
+
+// Internal twins used by the fused layer: source rows / weights either fp32 or bfloat16 (`*_bf16` flag; needs c % 4 == 0, w_c % 4 == 0).
+extern "C" int pdf_seg_sum_rows_x(long n, int c, const float *src, long src_stride, int src_bf16, const int *inv_off, const int *inv_entry,
+                                  int entry_base, float scale, float *out, void *stream) {
+    if (!src_bf16) return pdf_seg_sum_rows_strided(n, c, src, src_stride, inv_off, inv_entry, entry_base, scale, out, stream);
+    if (n == 0) return PDF_OK;
+    if (n < 0 || c < 4 || c % 4 || src_stride % 4 || !src || !inv_off || !inv_entry || !out) return PDF_ERR_BAD_ARG;
+    const long total = n * (c / 4);
+    if (total >= (1L << 31)) return PDF_ERR_UNSUPPORTED;
+    sg::k_seg_rows_bf<<<(unsigned)((total + sg::TB - 1) / sg::TB), sg::TB, 0, static_cast<hipStream_t>(stream)>>>(
+        (unsigned)total, sg::mk_fastdiv(c / 4), (unsigned)src_stride, reinterpret_cast<const unsigned short *>(src), inv_off, inv_entry, entry_base,
+        scale, reinterpret_cast<float4 *>(out));
+    return pdf_launch_status();
+}
+
+extern "C" int pdf_seg_sum_weighted_x(long n, int c, int nsample, int w_c, const float *src, const float *w, int w_bf16, const int *inv_off,
+                                      const int *inv_entry, int entry_base, float *out, void *stream) {
+    if (!w_bf16) return pdf_seg_sum_weighted(n, c, nsample, w_c, src, w, inv_off, inv_entry, entry_base, out, stream);
+    if (n == 0) return PDF_OK;
+    if (n < 0 || c % 4 || w_c % 4 || c % w_c || nsample < 1 || !src || !w || !inv_off || !inv_entry || !out) return PDF_ERR_BAD_ARG;
+    const long total = n * (c / 4);
+    if (total >= (1L << 31)) return PDF_ERR_UNSUPPORTED;
+    sg::k_seg_weighted_bfw<<<(unsigned)((total + sg::TB - 1) / sg::TB), sg::TB, 0, static_cast<hipStream_t>(stream)>>>(
+        (unsigned)total, sg::mk_fastdiv(c / 4), sg::mk_fastdiv(nsample), w_c, reinterpret_cast<const float4 *>(src),
+        reinterpret_cast<const unsigned short *>(w), inv_off, inv_entry, entry_base, reinterpret_cast<float4 *>(out));
     return pdf_launch_status();
 }

@@ -94,6 +94,7 @@ class _FusedPTLayer(torch.autograd.Function):
             dense.bump_counters([n.num_batches_tracked for n in norms])
         ctx.save_for_backward(xq, xk, xv, p, idx, bn, saved, H, *weights)
         ctx.training = training
+        ctx.bf16 = int(be.storage_bf16)   # H was written in this format
         return out
 
     @staticmethod
@@ -104,7 +105,7 @@ class _FusedPTLayer(torch.autograd.Function):
         xq, xk, xv, p, idx, bn, saved, H, *weights = ctx.saved_tensors
         be = _native.hip_backend()
         gxq, gxk, gxv, g = be.pt_layer_backward(xq.contiguous(), xk.contiguous(), xv.contiguous(), p, idx, list(weights),
-                                                bn, saved, H, gout.contiguous())
+                                                bn, saved, H, gout.contiguous(), storage_bf16=ctx.bf16)
         # order of *params in forward(): Wp1 bp1 gamma_p beta_p Wp2 bp2 gamma_1 beta_1 Ww1 bw1 gamma_2 beta_2 Ww2 bw2
         grads = (g["Wp1"], g["bp1"], g["gammap"], g["betap"], g["Wp2"], g["bp2"], g["gamma1"], g["beta1"], g["Ww1"],
                  g["bw1"], g["gamma2"], g["beta2"], g["Ww2"], g["bw2"])

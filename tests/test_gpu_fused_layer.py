@@ -91,3 +91,47 @@ def test_fused_layer_short_scene_placeholders():
     assert (geom.knn(16, 0, 0)[0][600:] == -1).any()
     assert max_rel(outs[0][0], outs[1][0]) < 2e-5
     assert max_rel(outs[0][1], outs[1][1]) < 1e-3
+
+
+def test_bf16_storage_variant_tracks_the_fp32_layer():
+    """PDFOPS_STORAGE=bf16 / HipBackend.set_storage("bf16"): the layer's own row arrays (H saved by the forward; G2, softmax weights, g_r
+    rows in the backward) as bfloat16 with fp32 arithmetic.  Tolerances = bfloat16 rounding of those arrays (8 mantissa bits, 4e-3 per
+    element): outputs within 1e-2 (max-norm relative), input / parameter gradients within 5e-2 (Frobenius; measured 3.2e-2 at C = 32)."""
+    import torch
+    import helpers
+    from pointcloudpdf_amd import _native, synthetic
+    from pointcloudpdf_amd.geometry import Geometry
+    from pointcloudpdf_amd.point_transformer import PointTransformerLayer
+
+    be = _native.hip_backend()
+    batch = synthetic.make_batch([9000, 7000], first_scene_id=80, device="cuda")
+    geom = Geometry(batch["coord"], batch["offset"], batch["offset_host"])
+    for c, k in ((32, 8), (64, 16), (128, 16)):
+        torch.manual_seed(c)
+        layer = PointTransformerLayer(c, c, 8, k).cuda().train()
+        p, o = geom.coord(0), geom.offset(0)
+        n = p.shape[0]
+        x = torch.randn(n, c, device="cuda")
+        base = [torch.randn(n, c, device="cuda") for _ in range(3)]
+        go = torch.randn(n, c, device="cuda")
+        res = {}
+        for kind in ("f32", "bf16"):
+            be.set_storage(kind)
+            try:
+                xs = [t.clone().requires_grad_(True) for t in base]
+                layer.zero_grad(set_to_none=True)
+                y = layer.attend(p, x, o, *xs)
+                y.backward(go)
+                torch.cuda.synchronize()
+                res[kind] = (y.detach().cpu().numpy(), [t.grad.cpu().numpy() for t in xs],
+                             {nm: q.grad.cpu().numpy() for nm, q in layer.named_parameters() if q.grad is not None})
+            finally:
+                be.set_storage("f32")
+        yf, gf, pf = res["f32"]
+        yb, gb, pb = res["bf16"]
+        assert helpers.max_rel(yb, yf) < 1e-2 and helpers.max_rel(yb, yf) > 0.0, (c, helpers.max_rel(yb, yf))
+        for a, b in zip(gb, gf):
+            assert helpers.l2_rel(a, b) < 5e-2, (c, helpers.l2_rel(a, b))
+        for nm in pf:
+            if np.abs(pf[nm]).max() > 1e-6:
+                assert helpers.l2_rel(pb[nm], pf[nm]) < 5e-2, (c, nm, helpers.l2_rel(pb[nm], pf[nm]))
