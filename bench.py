@@ -151,6 +151,8 @@ class KernelTimer:
         self.backend, self.names = backend, names
         self.records = {n: [] for n in names}
         self.enabled = False
+        self.sample = True    # per-step switch: the timed loop samples every `every`-th step (a pair of timing events per call costs
+        self.every = int(os.environ.get("PDFOPS_BENCH_TIMER_EVERY", "4"))   # ~0.5 ms per step of marker packets when taken on all of them)
         self._orig = {}
 
     def install(self):
@@ -159,7 +161,7 @@ class KernelTimer:
             self._orig[n] = orig
 
             def wrapped(*a, _orig=orig, _n=n, **k):
-                if not self.enabled:
+                if not (self.enabled and self.sample):
                     return _orig(*a, **k)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -401,10 +403,13 @@ def main():
         timer.enabled = with_timer
         t0 = time.perf_counter()
         for i in range(steps):
+            timer.sample = timer.every > 0 and i % timer.every == 0
             out = one_step(warmup + i, sched)
         fence()
         dt = time.perf_counter() - t0
         timer.enabled = False
+        if with_timer:
+            timer.sampled_steps = len([i for i in range(steps) if timer.every > 0 and i % timer.every == 0])
         sched.drain()
         return dt, out, sched
 
@@ -433,8 +438,9 @@ def main():
             r = dict(bound="hbm", kernel=name, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                      frac=achieved / HBM_PEAK_GBS, traffic=(traffic.get("host_calls", {}).get(name) if traffic else None),
                      algorithmic_bytes_per_launch=ks[name]["avg_bytes"], avg_launch_ms=ks[name]["avg_ms"],
-                     launches_per_step=ks[name]["calls"] / args.steps,
-                     gpu_time_share_of_step=ks[name]["total_ms"] / (dt * 1e3))
+                     launches_per_step=ks[name]["calls"] / max(timer.sampled_steps, 1),
+                     gpu_time_share_of_step=ks[name]["total_ms"] / max(timer.sampled_steps, 1) / (dt / args.steps * 1e3),
+                     timed_steps=f"{timer.sampled_steps} of {args.steps} (every {timer.every}th step of the timed region carries the HIP events)")
             if traffic_note:
                 r["traffic_note"] = traffic_note
             return r

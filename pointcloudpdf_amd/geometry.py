@@ -131,6 +131,15 @@ class Geometry:
             self._memo[key] = be.knn_query(nsample, S.p, Q.p, S.o, Q.o)
         return self._memo[key]
 
+    def knn_dist(self, nsample, src_level, query_level):
+        """(idx, sqrt(dist2)) as ``pointops.knn_query`` returns them (query.py:24); the square root is taken once per table, not
+        once per call (18 calls per forward reuse 5 self tables)."""
+        key = ("knn_dist", nsample, src_level, query_level)
+        if key not in self._memo:
+            idx, dist2 = self.knn(nsample, src_level, query_level)
+            self._memo[key] = torch.sqrt(dist2)
+        return self.knn(nsample, src_level, query_level)[0], self._memo[key]
+
     def interp(self, coarse_level, fine_level, k=3):
         """(idx (N_fine,k) int32, weight (N_fine,k) f32) of pointops.interpolation (interpolation.py:13-17)."""
         key = ("interp", k, coarse_level, fine_level)
@@ -183,11 +192,11 @@ class Geometry:
         stream: 4 FPS, 5 self-kNN, 4 down-sampling kNN, 4 (+1 for the U-decoder's level-5 self query) interpolation
         tables -- the 13 distinct kNN tables behind the reference's 31 calls."""
         lvl = 0
-        self.knn(nsamples[0], 0, 0)
+        self.knn_dist(nsamples[0], 0, 0)
         for i in range(1, len(strides)):
             new_level, _ = self.down(lvl, strides[i])
             self.knn(nsamples[i], lvl, new_level)        # TransitionDown grouping (point_transformer_seg.py:103-111)
-            self.knn(nsamples[i], new_level, new_level)  # PointTransformerLayer self query (:48-50)
+            self.knn_dist(nsamples[i], new_level, new_level)  # PointTransformerLayer self query (:48-50), incl. the distances it returns
             self.interp(new_level, lvl, interp_k)        # TransitionUp fusion (:163-167)
             lvl = new_level
         if recognizer:
@@ -254,6 +263,9 @@ class Geometry:
                 elif kind == "knn":
                     (idx, dist2), (q0, q1) = val, rows[key[3]]
                     g._memo[key] = (rebase(idx[q0:q1], rows[key[2]][0]), dist2[q0:q1])
+                elif kind == "knn_dist":
+                    q0, q1 = rows[key[3]]
+                    g._memo[key] = val[q0:q1]
                 elif kind == "interp":   # (the index tensor OBJECT of the kNN entry: the inverse table is cached on it)
                     (idx, weight), (q0, q1) = val, rows[key[3]]
                     g._memo[key] = (g._memo[("knn",) + key[1:]][0], weight[q0:q1])

@@ -42,10 +42,10 @@ class KNNQuery(Function):
         assert xyz.is_contiguous() and new_xyz.is_contiguous()
         ts, tq = tag_of(xyz), tag_of(new_xyz)
         if ts is not None and tq is not None and ts[0] is tq[0]:
-            idx, dist2 = ts[0].knn(nsample, ts[1], tq[1])
+            idx, dist = ts[0].knn_dist(nsample, ts[1], tq[1])
         else:
             idx, dist2 = _be(xyz).knn_query(nsample, xyz, new_xyz, _i32(offset).contiguous(), _i32(new_offset).contiguous())
-        dist = torch.sqrt(dist2)
+            dist = torch.sqrt(dist2)
         ctx.mark_non_differentiable(idx, dist)
         return idx, dist
 
