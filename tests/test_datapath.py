@@ -46,7 +46,7 @@ def check_sphere_crop(g, device):
         else:   # same kept SET and same ascending-distance order (upstream's argsort is unstable: equidistant points may swap)
             c = coord[int(g[f"crop_{tag}_center"])]
             d_ours, d_ref = ((ours - c) ** 2).sum(1), ((ref_coord - c) ** 2).sum(1)
-            assert np.all(np.diff(d_ours) >= 0) and np.array_equal(np.sort(d_ours), np.sort(d_ref))
+            assert np.all(np.diff(d_ours) >= -1e-6 * d_ours.max()) and np.array_equal(np.sort(d_ours), np.sort(d_ref))   # (the device sums x^2 + y^2 + z^2 in its own order: ties / last-bit swaps)
             assert set(map(tuple, ours.round(6))) == set(map(tuple, ref_coord.round(6)))
     # batched: scenes a + c together give the same rows as each alone
     (sa, na, pa, _), (sc, nc, pc, _) = CROPS["a"], CROPS["c"]
