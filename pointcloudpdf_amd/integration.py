@@ -17,11 +17,11 @@ def install_pointops():
 def register_into_pointcept(force=True):
     """Register our classes under the reference's names in a live pointcept install's registries."""
     from pointcept.models.builder import MODELS as PC_MODELS  # noqa: import error = pointcept not importable
-    from . import point_transformer, recognizer, segmentor, model_hook
+    from . import point_transformer, recognizer, segmentor, model_hook, stratified  # noqa: F401  (fills the registries)
     from .registry import MODELS, RECOGNIZER, MODELHOOKS
 
     for name in ["PointTransformer-Seg26", "PointTransformer-Seg38", "PointTransformer-Seg50",
-                 "PointTransformer-Recognizer", "DefaultSegmentor"]:
+                 "PointTransformer-Recognizer", "ST-v1m1", "ST-v1m1-Recognizer", "DefaultSegmentor"]:
         PC_MODELS.register_module(name=name, force=force, module=MODELS.get(name))
     try:
         from pointcept.recognizers.builder import RECOGNIZER as PC_REC
