@@ -106,9 +106,142 @@ def _prune_by_spanning_tree(coord, msp, neighbors, node):
     return mask
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# The pruning stage on the device (round 2): spanning tree and connected components as torch device ops, the 2-component 1-D
+# mixture as a closed-form EM on the (few thousand) tree weights.  Upstream moves everything to the host here and calls
+# scipy.sparse.csgraph.minimum_spanning_tree / connected_components and sklearn.mixture.GaussianMixture (whose k-means
+# initialisation draws from numpy's GLOBAL random state, so upstream's own result is not reproducible run to run).
+# ------------------------------------------------------------------------------------------------------------------
+def _pointer_jump(parent):
+    while True:
+        nxt = parent[parent]
+        if torch.equal(nxt, parent):
+            return parent
+        parent = nxt
+
+
+def minimum_spanning_forest(n, eu, ev, ew):
+    """Boruvka on the undirected graph given by directed entries (eu[e], ev[e], ew[e]) -- a pair listed in both directions with two
+    weights counts with the smaller one, as scipy's Kruskal over the stored entries does.  Returns the indices (into eu / ev / ew) of the
+    chosen entries.  Ties are ordered by (weight, entry index), so equal weights cannot close a cycle; with distinct weights the tree
+    is THE minimum spanning forest, i.e. scipy.sparse.csgraph.minimum_spanning_tree's."""
+    dev = eu.device
+    E = eu.shape[0]
+    if E == 0:
+        return eu.new_zeros(0)
+    u2, v2 = torch.cat([eu, ev]), torch.cat([ev, eu])          # entry e and its mirror e + E
+    w2 = torch.cat([ew, ew]).double()
+    eid = torch.arange(2 * E, device=dev)
+    order_rank = torch.empty(2 * E, dtype=torch.long, device=dev)
+    canon = eid % E
+    # total order (weight, canonical entry): two stable sorts; rank of every directed copy
+    by_canon = torch.argsort(canon, stable=True)
+    srt = by_canon[torch.argsort(w2[by_canon], stable=True)]
+    order_rank[srt] = torch.arange(2 * E, device=dev)
+    # the mirror must share its entry's rank so that both endpoints agree on "the" lightest edge between two components
+    order_rank = torch.minimum(order_rank, torch.cat([order_rank[E:], order_rank[:E]]))
+    comp = torch.arange(n, device=dev)
+    chosen = torch.zeros(E, dtype=torch.bool, device=dev)
+    big = 4 * E + 4
+    while True:
+        cu, cv = comp[u2], comp[v2]
+        live = cu != cv
+        if not bool(live.any()):
+            break
+        key = torch.where(live, order_rank, torch.full_like(order_rank, big))
+        best = torch.full((n,), big, dtype=torch.long, device=dev).scatter_reduce(0, cu, key, "amin", include_self=True)
+        pick = live & (key == best[cu])                         # the lightest outgoing copy of every component (one per component)
+        chosen[canon[pick]] = True
+        # hook every component onto the component at the other end of its lightest edge; 2-cycles keep the smaller id as root
+        parent = torch.arange(n, device=dev)
+        parent[cu[pick]] = cv[pick]
+        back = parent[parent] == torch.arange(n, device=dev)    # c -> d -> c
+        root_fix = back & (torch.arange(n, device=dev) < parent)
+        parent = torch.where(root_fix, torch.arange(n, device=dev), parent)
+        comp = _pointer_jump(parent)[comp]
+    return torch.nonzero(chosen).flatten()
+
+
+def connected_labels(n, eu, ev):
+    """Connected components of an undirected edge list as min-label propagation with pointer jumping -> label (n,) = smallest node id."""
+    lab = torch.arange(n, device=eu.device)
+    if eu.numel() == 0:
+        return lab
+    while True:
+        lu, lv = lab[eu], lab[ev]
+        m = torch.minimum(lu, lv)
+        new = lab.scatter_reduce(0, lu, m, "amin", include_self=True).scatter_reduce(0, lv, m, "amin", include_self=True)
+        new = _pointer_jump(new)
+        if torch.equal(new, lab):
+            return lab
+        lab = new
+
+
+def gmm2_1d(x, iters=200, tol=1e-6, reg=1e-6):
+    """Two-component 1-D Gaussian mixture by EM (numpy, a few thousand tree weights): deterministic quartile start instead of
+    sklearn's randomly seeded k-means; same model, covariance floor and stopping rule family as sklearn.mixture.GaussianMixture
+    (n_components=2, reg_covar=1e-6).  -> (means (2,), variances (2,), weights (2,))"""
+    x = np.asarray(x, dtype=np.float64).reshape(-1)
+    if x.size < 2 or np.ptp(x) == 0.0:
+        return np.array([x.mean() if x.size else 0.0] * 2), np.array([reg, reg]), np.array([0.5, 0.5])
+    q1, q3 = np.quantile(x, [0.25, 0.75])
+    mu = np.array([q1, q3]) if q3 > q1 else np.array([x.min(), x.max()])
+    for _ in range(10):                                          # 2-means from the quartiles
+        a = np.abs(x[:, None] - mu[None, :]).argmin(1)
+        if a.min() == a.max():
+            break
+        mu = np.array([x[a == 0].mean(), x[a == 1].mean()])
+    a = np.abs(x[:, None] - mu[None, :]).argmin(1)
+    r = np.stack([a == 0, a == 1], 1).astype(np.float64)
+    prev = -np.inf
+    for _ in range(iters):
+        nk = r.sum(0) + 1e-300
+        pi, mu = nk / x.size, (r * x[:, None]).sum(0) / nk
+        var = (r * (x[:, None] - mu[None, :]) ** 2).sum(0) / nk + reg
+        logp = -0.5 * (np.log(2 * np.pi * var)[None, :] + (x[:, None] - mu[None, :]) ** 2 / var[None, :]) + np.log(pi)[None, :]
+        mx = logp.max(1, keepdims=True)
+        lse = mx[:, 0] + np.log(np.exp(logp - mx).sum(1))
+        r = np.exp(logp - lse[:, None])
+        ll = lse.mean()
+        if abs(ll - prev) < tol:
+            break
+        prev = ll
+    return mu, var, pi
+
+
+def _prune_by_spanning_tree_device(coord, msp, neighbors, node):
+    """``_prune_by_spanning_tree`` (pointpdf_v1m1_base.py:309-380) without leaving the device for the graph work: Boruvka spanning
+    forest over the neighbour similarities inside the region, the weak-edge threshold from the mixture of the tree weights (one
+    small device -> host copy), connected components by label propagation, component sizes by a device unique."""
+    n = coord.shape[0]
+    node_nn = neighbors[node]
+    sim = _pair_similarity(node, node_nn, coord, msp)
+    keep = (node_nn != -1) & torch.isin(node_nn, node) & (node_nn != node[:, None])
+    eu = node[:, None].expand_as(node_nn)[keep]
+    ev = node_nn[keep]
+    ew = sim[keep]
+    # upstream builds a scipy csr_matrix from these triplets, which SUMS repeated (row, col) entries -- and `node` does hold
+    # repeats when the region is still the seed list (seeds are drawn with replacement, :206): same arithmetic here
+    key, inv = torch.unique(eu * n + ev, return_inverse=True)
+    ew = torch.zeros(key.shape[0], dtype=ew.dtype, device=ew.device).scatter_add_(0, inv, ew)
+    eu, ev = torch.div(key, n, rounding_mode="floor"), key % n
+    tree = minimum_spanning_forest(n, eu, ev, ew)
+    w = ew[tree]
+    means, var, _ = gmm2_1d(w.cpu().numpy())
+    top = int(np.argmax(means))
+    lower = means[top] - 2.0 * var[top]                          # the "std" of upstream's z-score filter is the covariance, as there
+    weak = w.double() < lower                                    # upstream keeps exactly the left outliers of the tree
+    lab = connected_labels(n, eu[tree][weak], ev[tree][weak])
+    touched = torch.unique(torch.cat([node, node_nn.reshape(-1)]))[1:]   # ([1:]: upstream drops the first entry, the -1 padding)
+    labels, sizes = torch.unique(lab[touched], return_counts=True)
+    sz = sizes.double()
+    big = (sz - sz.mean()) / sz.std(unbiased=False) > 2.0        # z_score_mask_np(area="right", score=2.0); numpy's std is the population one
+    return torch.isin(lab, labels[big])
+
+
 @torch.no_grad()
 def pseudo_labeling(coord, logits, neighbors, condition_from="msp", beta=1.5, seed_from="ml", seed_range=0.15, num_seed=100,
-                    slide_window=True, generator=None):
+                    slide_window=True, generator=None, prune="auto"):
     """One scene (local neighbour ids) -> bool mask (n,) on the host, like upstream's static method (:187-382).  The seed draw uses
     a CPU generator (upstream: the global one), the GMM numpy's global state."""
     msp = torch.softmax(logits, dim=-1).max(dim=-1)[0]
@@ -120,6 +253,10 @@ def pseudo_labeling(coord, logits, neighbors, condition_from="msp", beta=1.5, se
     dice = torch.randint(0, int(seed_range * len(src)), [num_seed], generator=generator)
     seeds = torch.sort(src, dim=-1)[1][dice.to(src.device)]
     region = _grow_region(coord, score, neighbors, seeds, stop, slide_window)
+    # prune: "host" = scipy / sklearn exactly as upstream (CPU tensors: the reference-parity path); "device" = the same stage as
+    # device graph ops + a deterministic mixture fit; "auto" = device for device tensors
+    if prune == "device" or (prune == "auto" and coord.is_cuda):
+        return _prune_by_spanning_tree_device(coord, msp, neighbors, region).cpu()
     return _prune_by_spanning_tree(coord, msp, neighbors, region)
 
 

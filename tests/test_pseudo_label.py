@@ -95,3 +95,65 @@ def test_training_step_with_the_pseudo_label_pass():
     out["loss"].backward()
     assert torch.isfinite(out["loss"]).item() and float(out["recognizer_loss"]) > 0
     assert all(p.grad is None or torch.isfinite(p.grad).all() for p in step.parameters())
+
+
+# ---------------------------------------------------------------- the pruning stage as device graph ops (round 2)
+def test_device_spanning_forest_and_components_match_scipy():
+    """Boruvka (minimum_spanning_forest) picks a forest of the same size and total weight as scipy's minimum_spanning_tree on random
+    directed neighbour graphs (both directions stored with different weights, negative weights, ties), and connected_labels gives the
+    same partition as scipy's connected_components."""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import connected_components, minimum_spanning_tree
+    from pointcloudpdf_amd import pseudo_label as pl
+
+    g = torch.Generator().manual_seed(0)
+    for trial in range(6):
+        n, k = 500, 5
+        nn = torch.randint(0, n, (n, k), generator=g)
+        if trial >= 3:   # several components: neighbours only inside blocks of 100 nodes
+            nn = (torch.arange(n)[:, None] // 100) * 100 + nn % 100
+        w = torch.rand(n, k, generator=g) - 0.3
+        if trial % 3 == 2:
+            w = torch.round(w * 8) / 8          # ties
+        eu, ev, ew = torch.arange(n)[:, None].expand(n, k).reshape(-1), nn.reshape(-1), w.reshape(-1)
+        keep = eu != ev
+        eu, ev, ew = eu[keep], ev[keep], ew[keep]
+        _, first = np.unique((eu * n + ev).numpy(), return_index=True)      # (csr_matrix would SUM duplicate entries)
+        eu, ev, ew = eu[first], ev[first], ew[first]
+        ew = torch.where(ew == 0, torch.full_like(ew, 1e-3), ew)             # (an explicit zero is "no edge" for scipy)
+        ref = minimum_spanning_tree(csr_matrix((ew.numpy(), (eu.numpy(), ev.numpy())), shape=(n, n)))
+        tree = pl.minimum_spanning_forest(n, eu, ev, ew)
+        assert tree.numel() == ref.nnz and abs(float(ew[tree].double().sum()) - ref.data.sum()) < 1e-9
+        ncomp, lab_ref = connected_components(ref, directed=False)
+        lab = pl.connected_labels(n, eu[tree], ev[tree])
+        assert len(set(zip(lab_ref.tolist(), lab.tolist()))) == ncomp == len(torch.unique(lab))
+
+
+def test_gmm2_1d_matches_sklearn():
+    from sklearn.mixture import GaussianMixture
+    from pointcloudpdf_amd import pseudo_label as pl
+
+    for seed, (m0, s0, n0, m1, s1, n1) in enumerate([(0.2, 0.05, 3000, 0.7, 0.1, 1500), (-0.5, 0.2, 800, 0.6, 0.05, 4000)]):
+        rs = np.random.RandomState(seed)
+        x = np.concatenate([rs.normal(m0, s0, n0), rs.normal(m1, s1, n1)])
+        gm = GaussianMixture(2, random_state=0).fit(x.reshape(-1, 1))
+        mu, var, pi = pl.gmm2_1d(x)
+        o, o_ref = np.argsort(mu), np.argsort(gm.means_.flatten())
+        assert np.allclose(mu[o], gm.means_.flatten()[o_ref], atol=2e-3) and np.allclose(var[o], gm.covariances_.flatten()[o_ref], rtol=5e-2)
+
+
+def test_device_pruning_matches_host_pruning(use_oracle, gp):
+    """The whole pseudo_labeling with prune="device" (CPU tensors here; the GPU suite runs it on device tensors by default, see
+    test_pseudo_mask_on_gpu_batch) against the reference-parity host path on the fixture scenes: the region is the same, so the masks
+    can differ only through the mixture fit (deterministic EM vs sklearn's k-means-seeded one)."""
+    from pointcloudpdf_amd import pseudo_label as pl
+
+    for tag, (seed, n) in PSEUDO_CASES.items():
+        coord, logits = pseudo_label_scene(seed, n)
+        nn = pl.radius_neighbors(coord, torch.tensor([n], dtype=torch.int32), 0.1, 64)
+        np.random.seed(seed)
+        host = pl.pseudo_labeling(coord, logits, nn, generator=torch.Generator().manual_seed(seed), prune="host", **PSEUDO_KW)
+        assert np.array_equal(host.numpy(), gp[f"{tag}_mask"])     # (the host path IS the reference's result)
+        dev = pl.pseudo_labeling(coord, logits, nn, generator=torch.Generator().manual_seed(seed), prune="device", **PSEUDO_KW)
+        inter, union = int((host & dev).sum()), int((host | dev).sum())
+        assert union > 0 and inter / union >= 0.9, (tag, inter, union)
