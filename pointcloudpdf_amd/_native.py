@@ -60,6 +60,11 @@ _HIP_ONLY_PROTOS = {
     "group_backward": "iiiippp",
     "interpolation_weights": "iipp",
     "farthest_point_sampling_bucketed": "iiipppplp",
+    "grouping_forward_ordered": "iiipppp",
+    "group_forward_ordered": "iiiipppppp",
+    "interpolation_forward_ordered": "iiippppp",
+    "subtraction_forward_ordered": "iiippppp",
+    "aggregation_forward_ordered": "iiiipppppp",
     "seg_sum_rows": "lipppifp",
     "seg_sum_rows_strided": "liplppifp",
     "seg_sum_weighted": "liiippppip",
@@ -109,6 +114,23 @@ def inverse_table(idx, n):
     vals, perm = torch.sort(flat, stable=True)        # ascending destination, ascending entry id inside a destination; -1 first
     off = torch.searchsorted(vals, torch.arange(int(n) + 1, device=idx.device, dtype=vals.dtype), out_int32=True)
     return attach_inverse(idx, n, (off, perm.to(torch.int32), 0))
+
+
+_ORD = "_pdf_order"
+
+
+def attach_order(idx, order):
+    """Remember a visiting order of the QUERIES of a neighbour table (a permutation of its rows: the Morton order of the query points,
+    Geometry.order) on the idx tensor; the forward gathers then walk the queries in that order (csrc/gather_ops.hip, *_ord kernels)."""
+    setattr(idx, _ORD, (idx.data_ptr(), idx._version, order))
+    return idx
+
+
+def order_of(idx):
+    tag = getattr(idx, _ORD, None)
+    if tag is not None and tag[0] == idx.data_ptr() and tag[1] == idx._version and tag[2].shape[0] == idx.shape[0]:
+        return tag[2]
+    return None
 
 
 def _check(t, dtype, name):
@@ -539,6 +561,40 @@ class HipBackend(CBackend):
             raise ValueError("storage: 'f32' or 'bf16'")
         self.storage_bf16 = kind == "bf16"
 
+    # forward gathers: queries visited in the order attached to the idx tensor (Geometry: Morton order of the query level), if any
+    def grouping_forward(self, input, idx):
+        _check(input, torch.float32, "input"); _check(idx, torch.int32, "idx")
+        m, ns = idx.shape
+        c = input.shape[1]
+        out = self._new(input, (m, ns, c), torch.float32)
+        self._call("grouping_forward_ordered", m, ns, c, input, idx, order_of(idx), out)
+        return out
+
+    def interpolation_forward(self, input, idx, weight):
+        _check(input, torch.float32, "input"); _check(idx, torch.int32, "idx"); _check(weight, torch.float32, "weight")
+        n, k = idx.shape
+        c = input.shape[1]
+        out = self._new(input, (n, c), torch.float32)
+        self._call("interpolation_forward_ordered", n, c, k, input, idx, weight, order_of(idx), out)
+        return out
+
+    def subtraction_forward(self, input1, input2, idx):
+        _check(input1, torch.float32, "input1"); _check(input2, torch.float32, "input2"); _check(idx, torch.int32, "idx")
+        n, c = input1.shape
+        ns = idx.shape[-1]
+        out = self._new(input1, (n, ns, c), torch.float32)
+        self._call("subtraction_forward_ordered", n, ns, c, input1, input2, idx, order_of(idx), out)
+        return out
+
+    def aggregation_forward(self, input, position, weight, idx):
+        for t, nm in ((input, "input"), (position, "position"), (weight, "weight")):
+            _check(t, torch.float32, nm)
+        _check(idx, torch.int32, "idx")
+        n, ns, c = position.shape
+        out = self._new(input, (n, c), torch.float32)
+        self._call("aggregation_forward_ordered", n, ns, c, weight.shape[-1], input, position, weight, idx, order_of(idx), out)
+        return out
+
     def grouping_backward(self, grad_output, idx, n):
         if not self.use_inverse:
             return super().grouping_backward(grad_output, idx, n)
@@ -936,9 +992,9 @@ class HipBackend(CBackend):
         out = self._new(feat, (m, ns, c + (3 if with_xyz else 0)), torch.float32)
         if with_xyz:
             _check(xyz, torch.float32, "xyz"); _check(new_xyz, torch.float32, "new_xyz")
-            self._call("group_forward", m, ns, c, 1, feat, xyz, new_xyz, idx, out)
+            self._call("group_forward_ordered", m, ns, c, 1, feat, xyz, new_xyz, idx, order_of(idx), out)
         else:
-            self._call("group_forward", m, ns, c, 0, feat, feat, feat, idx, out)
+            self._call("group_forward_ordered", m, ns, c, 0, feat, feat, feat, idx, order_of(idx), out)
         return out
 
     def group_backward(self, grad_output, idx, n, c, with_xyz):

@@ -318,6 +318,148 @@ __global__ __launch_bounds__(GB) void grouping_fwd32(unsigned total, FastDiv cvd
     }
 }
 
+// grouping forward with the QUERIES visited in a caller-supplied order (a spatially coherent one: the geometry pre-pass sorts every
+// level's points by Morton cell) and the workgroups of one XCD walking ONE contiguous stretch of that order.  A gathered row is
+// a whole 128-byte line whatever the storage order, so what matters is WHEN rows are touched: consecutive sorted queries share
+// most of their neighbours, and with the dispatcher's round-robin placement (workgroup b -> XCD b mod 8) undone by the remap below
+// those repeats hit the 4 MB L2 of the XCD instead of crossing the fabric to the Infinity Cache.  Each query's nsample x c output
+// block is contiguous, so the permuted visiting order still stores whole lines.
+constexpr int XCDS = 8;
+__device__ __forceinline__ unsigned xcd_chunked_block(unsigned b, unsigned g) {   // bijective for any g (guide: "XCD swizzle must be bijective")
+    const unsigned q = g / XCDS, r = g % XCDS, x = b % XCDS;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / XCDS;
+}
+
+template <int U>
+__global__ __launch_bounds__(GB) void grouping_fwd_ord(unsigned total, FastDiv cvd, FastDiv rowd /* nsample * cv */, int nsample,
+                                                       const int *__restrict__ order, const v4f *__restrict__ input,
+                                                       const int *__restrict__ idx, v4f *__restrict__ output) {
+    const unsigned cv = cvd.d, blk = xcd_chunked_block(blockIdx.x, gridDim.x);
+    const unsigned w0 = blk * (GB * U) + threadIdx.x;
+    v4f v[U];
+    unsigned long dst[U];
+    bool live[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const unsigned w = w0 + u * GB;
+        live[u] = w < total;
+        const unsigned sq = live[u] ? fdiv(w, rowd) : 0;           // position in the visiting order
+        const unsigned rem = w - sq * rowd.d, j = fdiv(rem, cvd), col = rem - j * cv;
+        const unsigned long row = (unsigned long)(order ? (unsigned)order[sq] : sq) * nsample + j;
+        const int src = live[u] ? idx[row] : -1;
+        dst[u] = row * cv + col;
+        v[u] = src >= 0 ? input[(unsigned long)src * cv + col] : (v4f)(0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (live[u]) st_stream(output + dst[u], v[u]);
+}
+
+// the same visiting scheme for the other forward gathers (order == nullptr: queries in storage order, still one contiguous
+// stretch per XCD)
+template <int U>
+__global__ __launch_bounds__(GB) void sub_fwd_ord(unsigned total, FastDiv cvd, FastDiv rowd, int nsample, const int *__restrict__ order,
+                                                  const v4f *__restrict__ input1, const v4f *__restrict__ input2,
+                                                  const int *__restrict__ idx, v4f *__restrict__ output) {
+    const unsigned cv = cvd.d, blk = xcd_chunked_block(blockIdx.x, gridDim.x);
+    const unsigned w0 = blk * (GB * U) + threadIdx.x;
+    v4f a[U], b[U];
+    unsigned long dst[U];
+    bool live[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const unsigned w = w0 + u * GB;
+        live[u] = w < total;
+        const unsigned sq = live[u] ? fdiv(w, rowd) : 0;
+        const unsigned rem = w - sq * rowd.d, j = fdiv(rem, cvd), col = rem - j * cv;
+        const unsigned q = order ? (unsigned)order[sq] : sq;
+        const unsigned long row = (unsigned long)q * nsample + j;
+        const int src = live[u] ? idx[row] : -1;
+        dst[u] = row * cv + col;
+        a[u] = input1[(unsigned long)q * cv + col];
+        b[u] = src >= 0 ? input2[(unsigned long)src * cv + col] : (v4f)(0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (live[u]) st_stream(output + dst[u], a[u] - b[u]);
+}
+
+// interpolation / aggregation: one lane = (query, 16-byte piece), the neighbours are a loop
+template <int K>
+__global__ __launch_bounds__(GB) void interp_fwd_ord(unsigned total, FastDiv cvd, const int *__restrict__ order, const v4f *__restrict__ input,
+                                                     const int *__restrict__ idx, const float *__restrict__ weight, v4f *__restrict__ output) {
+    const unsigned cv = cvd.d, blk = xcd_chunked_block(blockIdx.x, gridDim.x);
+    const unsigned w = blk * GB + threadIdx.x;
+    if (w >= total) return;
+    const unsigned sq = fdiv(w, cvd), col = w - sq * cv, r = order ? (unsigned)order[sq] : sq;
+    int j[K]; float wt[K]; v4f v[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) { j[i] = idx[(unsigned long)r * K + i]; wt[i] = weight[(unsigned long)r * K + i]; }
+#pragma unroll
+    for (int i = 0; i < K; ++i) v[i] = j[i] >= 0 ? input[(unsigned long)j[i] * cv + col] : (v4f)(0.f);
+    v4f acc = (v4f)(0.f);
+#pragma unroll
+    for (int i = 0; i < K; ++i) acc += v[i] * wt[i];   // same summation order as the reference (i ascending)
+    st_stream(output + (unsigned long)r * cv + col, acc);
+}
+
+__global__ __launch_bounds__(GB) void agg_fwd_ord(unsigned total, FastDiv cvd, int nsample, unsigned wv, const int *__restrict__ order,
+                                                  const v4f *__restrict__ input, const v4f *__restrict__ position,
+                                                  const v4f *__restrict__ weight, const int *__restrict__ idx, v4f *__restrict__ output) {
+    const unsigned cv = cvd.d, blk = xcd_chunked_block(blockIdx.x, gridDim.x);
+    const unsigned w = blk * GB + threadIdx.x;
+    if (w >= total) return;
+    const unsigned sq = fdiv(w, cvd), col = w - sq * cv, wcol = col % wv, r = order ? (unsigned)order[sq] : sq;
+    v4f acc = (v4f)(0.f);
+    const unsigned long base = (unsigned long)r * nsample;
+#pragma unroll 4
+    for (int s = 0; s < nsample; ++s) {
+        const int j = idx[base + s];
+        const v4f in = j >= 0 ? input[(unsigned long)j * cv + col] : (v4f)(0.f);
+        acc += (in + __builtin_nontemporal_load(position + (base + s) * cv + col)) * weight[(base + s) * wv + wcol];
+    }
+    output[(unsigned long)r * cv + col] = acc;
+}
+
+// pointops.grouping(with_xyz) rows of 3 + c floats (see group_fwd_rows): lane = (row, piece), U items per lane
+template <int U>
+__global__ __launch_bounds__(GB) void group_fwd_rows_ord(unsigned total, FastDiv pd, FastDiv nsd, FastDiv qd /* nsample * pieces */, int c,
+                                                         int with_xyz, const int *__restrict__ order, const float *__restrict__ feat,
+                                                         const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                         const int *__restrict__ idx, float *__restrict__ output) {
+    typedef float u4f __attribute__((ext_vector_type(4), aligned(4)));
+    const unsigned pieces = pd.d, cv = c >> 2, oc = c + (with_xyz ? 3 : 0), sh = with_xyz ? 3u : 0u;
+    const unsigned blk = xcd_chunked_block(blockIdx.x, gridDim.x);
+    const unsigned w0 = blk * (GB * U) + threadIdx.x;
+    v4f v[U];
+    float *o[U];
+    unsigned q[U], m[U];
+    int j[U];
+    bool live[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const unsigned w = w0 + u * GB;
+        live[u] = w < total;
+        const unsigned sq = live[u] ? fdiv(w, qd) : 0, rem = w - sq * qd.d, jn = fdiv(rem, pd);
+        q[u] = rem - jn * pieces;
+        m[u] = order ? (unsigned)order[sq] : sq;
+        const unsigned long r = (unsigned long)m[u] * nsd.d + jn;
+        j[u] = live[u] ? idx[r] : -1;
+        o[u] = output + r * oc;
+        v[u] = (q[u] < cv && j[u] >= 0) ? reinterpret_cast<const v4f *>(feat)[(unsigned long)j[u] * cv + q[u]] : (v4f)(0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (!live[u]) continue;
+        if (q[u] < cv) {
+            *reinterpret_cast<u4f *>(o[u] + sh + 4 * q[u]) = (u4f)v[u];
+        } else {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) o[u][a] = j[u] >= 0 ? xyz[(unsigned long)j[u] * 3 + a] - new_xyz[(unsigned long)m[u] * 3 + a] : 0.f;
+        }
+    }
+}
+
 // subtraction_cuda_kernel.cu:5-16, float4 per lane (rowd = nsample * cv: element -> query point)
 template <int U>
 __global__ __launch_bounds__(GB) void sub_fwd32(unsigned total, FastDiv cvd, FastDiv rowd, const v4f *__restrict__ input1,
@@ -526,19 +668,28 @@ __global__ __launch_bounds__(GB) void agg_bwd_vec(unsigned total, FastDiv cvd, i
 
 }  // namespace
 
-extern "C" int pdf_grouping_forward(int m, int nsample, int c, const float *input, const int *idx, float *output, void *stream) {
+// The forward gathers with an optional visiting order of the queries (a permutation of 0 .. m-1, nullptr = storage order): same
+// output either way; see grouping_fwd_ord.  The reference-ABI entry points below are these with order = nullptr.
+extern "C" int pdf_grouping_forward_ordered(int m, int nsample, int c, const float *input, const int *idx, const int *order, float *output,
+                                            void *stream) {
     if (m == 0) return PDF_OK;
     if (m < 0 || nsample < 1 || c < 1 || !input || !idx || !output) return PDF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int v = pick_vec(c);
     const long rows = (long)m * nsample;
     if (v == 4 && rows * (c / 4) < (1L << 31)) {
+        constexpr int U = 4;
         const unsigned total = (unsigned)(rows * (c / 4));
-        grouping_fwd32<4><<<grid_for(((long)total + 3) / 4), GB, 0, s>>>(total, mk_fastdiv(c / 4), (const v4f *)input, idx, (v4f *)output);
+        grouping_fwd_ord<U><<<(total + GB * U - 1) / (GB * U), GB, 0, s>>>(total, mk_fastdiv(c / 4), mk_fastdiv(nsample * (c / 4)), nsample, order,
+                                                                          (const v4f *)input, idx, (v4f *)output);
         return pdf_launch_status();
     }
     DISPATCH_VEC(v, (grouping_fwd_kernel<V><<<grid_for(rows * (c / V)), GB, 0, s>>>(rows, c / V, input, idx, output)));
     return pdf_launch_status();
+}
+
+extern "C" int pdf_grouping_forward(int m, int nsample, int c, const float *input, const int *idx, float *output, void *stream) {
+    return pdf_grouping_forward_ordered(m, nsample, c, input, idx, nullptr, output, stream);
 }
 
 extern "C" int pdf_grouping_backward(int m, int nsample, int c, const float *grad_output, const int *idx, float *grad_input, void *stream) {
@@ -553,8 +704,8 @@ extern "C" int pdf_grouping_backward(int m, int nsample, int c, const float *gra
     return pdf_launch_status();
 }
 
-extern "C" int pdf_group_forward(int m, int nsample, int c, int with_xyz, const float *feat, const float *xyz,
-                                 const float *new_xyz, const int *idx, float *output, void *stream) {
+extern "C" int pdf_group_forward_ordered(int m, int nsample, int c, int with_xyz, const float *feat, const float *xyz, const float *new_xyz,
+                                         const int *idx, const int *order, float *output, void *stream) {
     if (m == 0) return PDF_OK;
     if (m < 0 || nsample < 1 || c < 1 || !feat || !idx || !output) return PDF_ERR_BAD_ARG;
     if (with_xyz && (!xyz || !new_xyz)) return PDF_ERR_BAD_ARG;
@@ -563,7 +714,9 @@ extern "C" int pdf_group_forward(int m, int nsample, int c, int with_xyz, const 
     const int oc = c + (with_xyz ? 3 : 0);
     if (c % 4 == 0 && rows * (c / 4 + 1) < (1L << 31)) {
         const unsigned pieces = (unsigned)(c / 4 + (with_xyz ? 1 : 0)), total = (unsigned)(rows * pieces);
-        group_fwd_rows<<<grid_for(total), GB, 0, s>>>(total, mk_fastdiv(pieces), mk_fastdiv(nsample), c, with_xyz, feat, xyz, new_xyz, idx, output);
+        constexpr int U = 4;
+        group_fwd_rows_ord<U><<<(total + GB * U - 1) / (GB * U), GB, 0, s>>>(total, mk_fastdiv(pieces), mk_fastdiv(nsample), mk_fastdiv(nsample * pieces),
+                                                                           c, with_xyz, order, feat, xyz, new_xyz, idx, output);
         return pdf_launch_status();
     }
     if (rows * oc < (1L << 31)) {
@@ -573,6 +726,11 @@ extern "C" int pdf_group_forward(int m, int nsample, int c, int with_xyz, const 
     }
     group_fwd_kernel<<<grid_for(rows * oc), GB, 0, s>>>(rows, nsample, c, with_xyz, feat, xyz, new_xyz, idx, output);
     return pdf_launch_status();
+}
+
+extern "C" int pdf_group_forward(int m, int nsample, int c, int with_xyz, const float *feat, const float *xyz,
+                                 const float *new_xyz, const int *idx, float *output, void *stream) {
+    return pdf_group_forward_ordered(m, nsample, c, with_xyz, feat, xyz, new_xyz, idx, nullptr, output, stream);
 }
 
 extern "C" int pdf_group_backward(int m, int nsample, int c, int with_xyz, const float *grad_output, const int *idx,
@@ -585,7 +743,8 @@ extern "C" int pdf_group_backward(int m, int nsample, int c, int with_xyz, const
     return pdf_launch_status();
 }
 
-extern "C" int pdf_interpolation_forward(int n, int c, int k, const float *input, const int *idx, const float *weight, float *output, void *stream) {
+extern "C" int pdf_interpolation_forward_ordered(int n, int c, int k, const float *input, const int *idx, const float *weight, const int *order,
+                                                 float *output, void *stream) {
     if (n == 0) return PDF_OK;
     if (n < 0 || c < 1 || k < 1 || !input || !idx || !weight || !output) return PDF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -593,12 +752,16 @@ extern "C" int pdf_interpolation_forward(int n, int c, int k, const float *input
     if (v == 4 && (long)n * (c / 4) < (1L << 31) && (long)n * k < (1L << 31)) {
         const unsigned total = (unsigned)((long)n * (c / 4));
         const FastDiv cvd = mk_fastdiv(c / 4);
-        if (k == 3) interp_fwd32<3><<<grid_for(total), GB, 0, s>>>(total, cvd, k, (const v4f *)input, idx, weight, (v4f *)output);
+        if (k == 3) interp_fwd_ord<3><<<(total + GB - 1) / GB, GB, 0, s>>>(total, cvd, order, (const v4f *)input, idx, weight, (v4f *)output);
         else interp_fwd32<0><<<grid_for(total), GB, 0, s>>>(total, cvd, k, (const v4f *)input, idx, weight, (v4f *)output);
         return pdf_launch_status();
     }
     DISPATCH_VEC(v, (interp_fwd_kernel<V><<<grid_for((long)n * (c / V)), GB, 0, s>>>(n, c / V, k, input, idx, weight, output)));
     return pdf_launch_status();
+}
+
+extern "C" int pdf_interpolation_forward(int n, int c, int k, const float *input, const int *idx, const float *weight, float *output, void *stream) {
+    return pdf_interpolation_forward_ordered(n, c, k, input, idx, weight, nullptr, output, stream);
 }
 
 extern "C" int pdf_interpolation_backward(int n, int c, int k, const float *grad_output, const int *idx, const float *weight, float *grad_input, void *stream) {
@@ -620,20 +783,26 @@ extern "C" int pdf_interpolation_weights(int n, int k, const float *dist2, float
     return pdf_launch_status();
 }
 
-extern "C" int pdf_subtraction_forward(int n, int nsample, int c, const float *input1, const float *input2, const int *idx, float *output, void *stream) {
+extern "C" int pdf_subtraction_forward_ordered(int n, int nsample, int c, const float *input1, const float *input2, const int *idx,
+                                               const int *order, float *output, void *stream) {
     if (n == 0) return PDF_OK;
     if (n < 0 || nsample < 1 || c < 1 || !input1 || !input2 || !idx || !output) return PDF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int v = pick_vec(c);
     const long rows = (long)n * nsample;
     if (v == 4 && rows * (c / 4) < (1L << 31)) {
+        constexpr int U = 4;
         const unsigned total = (unsigned)(rows * (c / 4));
-        sub_fwd32<4><<<grid_for(((long)total + 3) / 4), GB, 0, s>>>(total, mk_fastdiv(c / 4), mk_fastdiv((unsigned)nsample * (c / 4)),
-                                                                 (const v4f *)input1, (const v4f *)input2, idx, (v4f *)output);
+        sub_fwd_ord<U><<<(total + GB * U - 1) / (GB * U), GB, 0, s>>>(total, mk_fastdiv(c / 4), mk_fastdiv((unsigned)nsample * (c / 4)), nsample, order,
+                                                                     (const v4f *)input1, (const v4f *)input2, idx, (v4f *)output);
         return pdf_launch_status();
     }
     DISPATCH_VEC(v, (sub_fwd_kernel<V><<<grid_for(rows * (c / V)), GB, 0, s>>>(rows, nsample, c / V, input1, input2, idx, output)));
     return pdf_launch_status();
+}
+
+extern "C" int pdf_subtraction_forward(int n, int nsample, int c, const float *input1, const float *input2, const int *idx, float *output, void *stream) {
+    return pdf_subtraction_forward_ordered(n, nsample, c, input1, input2, idx, nullptr, output, stream);
 }
 
 extern "C" int pdf_subtraction_backward(int n, int nsample, int c, const int *idx, const float *grad_output, float *grad_input1, float *grad_input2, void *stream) {
@@ -647,19 +816,24 @@ extern "C" int pdf_subtraction_backward(int n, int nsample, int c, const int *id
     return pdf_launch_status();
 }
 
-extern "C" int pdf_aggregation_forward(int n, int nsample, int c, int w_c, const float *input, const float *position,
-                                       const float *weight, const int *idx, float *output, void *stream) {
+extern "C" int pdf_aggregation_forward_ordered(int n, int nsample, int c, int w_c, const float *input, const float *position,
+                                               const float *weight, const int *idx, const int *order, float *output, void *stream) {
     if (n == 0) return PDF_OK;
     if (n < 0 || nsample < 1 || c < 1 || w_c < 1 || !input || !position || !weight || !idx || !output) return PDF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (c % 4 == 0 && w_c % 4 == 0 && (long)n * nsample * (c / 4) < (1L << 31)) {
         const unsigned total = (unsigned)((long)n * (c / 4));
-        agg_fwd32<<<grid_for(total), GB, 0, s>>>(total, mk_fastdiv(c / 4), nsample, (unsigned)(w_c / 4), (const v4f *)input,
-                                                 (const v4f *)position, (const v4f *)weight, idx, (v4f *)output);
+        agg_fwd_ord<<<(total + GB - 1) / GB, GB, 0, s>>>(total, mk_fastdiv(c / 4), nsample, (unsigned)(w_c / 4), order, (const v4f *)input,
+                                                       (const v4f *)position, (const v4f *)weight, idx, (v4f *)output);
         return pdf_launch_status();
     }
     agg_fwd_kernel<<<grid_for((long)n * c), GB, 0, s>>>(n, nsample, c, w_c, input, position, weight, idx, output);
     return pdf_launch_status();
+}
+
+extern "C" int pdf_aggregation_forward(int n, int nsample, int c, int w_c, const float *input, const float *position,
+                                       const float *weight, const int *idx, float *output, void *stream) {
+    return pdf_aggregation_forward_ordered(n, nsample, c, w_c, input, position, weight, idx, nullptr, output, stream);
 }
 
 extern "C" int pdf_aggregation_backward(int n, int nsample, int c, int w_c, const float *input, const float *position,

@@ -129,6 +129,30 @@ class Geometry:
             S, Q = self.levels[src_level], self.levels[query_level]
             be = _native.backend_for(S.p)
             self._memo[key] = be.knn_query(nsample, S.p, Q.p, S.o, Q.o)
+            if S.p.is_cuda:   # the forward gathers visit the queries in Morton order (neighbouring queries share rows: L2 hits)
+                _native.attach_order(self._memo[key][0], self.order(query_level))
+        return self._memo[key]
+
+    def order(self, level):
+        """Morton order of a level's points, scene by scene: a permutation (N_l,) int32 of the level's rows.  Used as the VISITING order
+        of the queries in the forward gathers (csrc/gather_ops.hip); nothing is stored in this order."""
+        key = ("order", level)
+        if key not in self._memo:
+            p = self.levels[level].p
+            lo = p.min(0)[0]
+            cell = torch.clamp((p.max(0)[0] - lo).max() / 1023.0, min=1e-9)
+            q = ((p - lo) / cell).long().clamp_(0, 1023)
+
+            def spread(v):   # 10 bits -> every third bit
+                v = (v | (v << 16)) & 0x030000FF
+                v = (v | (v << 8)) & 0x0300F00F
+                v = (v | (v << 4)) & 0x030C30C3
+                return (v | (v << 2)) & 0x09249249
+
+            code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+            scene = torch.repeat_interleave(torch.arange(len(self.levels[level].o_host), device=p.device), self.sizes(level),
+                                            output_size=p.shape[0])
+            self._memo[key] = torch.argsort(code + (scene << 30), stable=True).to(torch.int32)
         return self._memo[key]
 
     def knn_dist(self, nsample, src_level, query_level):
@@ -263,6 +287,9 @@ class Geometry:
                 elif kind == "knn":
                     (idx, dist2), (q0, q1) = val, rows[key[3]]
                     g._memo[key] = (rebase(idx[q0:q1], rows[key[2]][0]), dist2[q0:q1])
+                elif kind == "order":   # scene-major: the batch's rows occupy the same positions of the sorted list
+                    r0, r1 = rows[key[1]]
+                    g._memo[key] = val[r0:r1] - r0 if r0 else val[r0:r1]
                 elif kind == "knn_dist":
                     q0, q1 = rows[key[3]]
                     g._memo[key] = val[q0:q1]
@@ -279,6 +306,9 @@ class Geometry:
                     _native.attach_inverse(g._memo[("knn",) + key[1:]][0], r1 - r0, tab)
                 else:
                     raise RuntimeError(f"Geometry.split: unknown memo entry {key}")
+            for key, val in g._memo.items():   # visiting orders travel with the batch's index tensors
+                if key[0] == "knn" and ("order", key[3]) in g._memo:
+                    _native.attach_order(val[0], g._memo[("order", key[3])])
             out.append(g)
             s0 = s1
         return out

@@ -120,6 +120,9 @@ def test_grouped_prepass_split_is_bit_identical_on_gpu():
             for ta, tb in zip(va if isinstance(va, tuple) else (va,), vb if isinstance(vb, tuple) else (vb,)):
                 if key[0] == "inv":
                     continue   # compared below (absolute positions into the group's shared entry array)
+                if key[0] == "order":   # a visiting order (Morton cells quantised over the GROUP's extent): any permutation of the rows is valid
+                    assert ta.shape == tb.shape and torch.equal(torch.sort(ta.long())[0], torch.arange(ta.shape[0], device=ta.device)), key
+                    continue
                 if isinstance(ta, torch.Tensor):
                     if key[0] == "td":   # float sums accumulated with atomics: equal up to the summation order
                         assert ta.shape == tb.shape and helpers.max_rel(ta.cpu().numpy(), tb.cpu().numpy()) < 1e-5, key

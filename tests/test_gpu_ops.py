@@ -545,3 +545,35 @@ def test_segmented_gather_backward_matches_atomic_kernels(oracle_backend, c, k, 
         if key in ref:
             assert_close(a[key], ref[key], 2e-6, f"{key} vs oracle")
         assert_close(a[key], atomic[key], 2e-6, f"{key} vs atomic kernels")
+
+
+def test_forward_gathers_with_a_visiting_order_are_bit_identical():
+    """grouping2 / grouping(with_xyz) / subtraction / aggregation / interpolation forward with the Morton visiting order a Geometry
+    attaches to its kNN tables (XCD-chunked *_ord kernels) against the same ops on an untagged copy of the table (storage order): the
+    outputs are bit-identical -- the order only changes WHEN a query is processed."""
+    from pointcloudpdf_amd import _native, synthetic
+    from pointcloudpdf_amd.geometry import Geometry
+
+    be = _native.hip_backend()
+    b = synthetic.make_batch([30000, 17000], first_scene_id=12, device="cuda")
+    geom = Geometry(b["coord"], b["offset"], b["offset_host"])
+    lvl2, _ = geom.down(0, 4)
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    for (k, src, qry, c) in ((8, 0, 0, 32), (16, lvl2, lvl2, 64), (16, 0, lvl2, 32), (3, lvl2, 0, 64)):
+        idx, d2 = geom.knn(k, src, qry)
+        order = _native.order_of(idx)
+        assert order is not None and sorted(order.tolist()) == list(range(idx.shape[0]))
+        plain = idx.clone()                                        # no order attached
+        assert _native.order_of(plain) is None
+        ns, nq = geom.coord(src).shape[0], idx.shape[0]
+        feat = torch.randn(ns, c, device="cuda", generator=g)
+        assert torch.equal(be.grouping_forward(feat, idx), be.grouping_forward(feat, plain))
+        assert torch.equal(be.group_forward(feat, geom.coord(src), geom.coord(qry), idx, True), be.group_forward(feat, geom.coord(src), geom.coord(qry), plain, True))
+        if k == 3:
+            w = be.interpolation_weights(d2)
+            assert torch.equal(be.interpolation_forward(feat, idx, w), be.interpolation_forward(feat, plain, w))
+        if src == qry:
+            f1 = torch.randn(nq, c, device="cuda", generator=g)
+            assert torch.equal(be.subtraction_forward(f1, feat, idx), be.subtraction_forward(f1, feat, plain))
+            pos = torch.randn(nq, k, c, device="cuda", generator=g); wt = torch.randn(nq, k, c // 8, device="cuda", generator=g)
+            assert torch.equal(be.aggregation_forward(feat, pos, wt, idx), be.aggregation_forward(feat, pos, wt, plain))

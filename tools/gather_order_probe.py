@@ -12,6 +12,24 @@ def morton_perm(p):
         v = (v | (v << 16)) & 0x030000FF; v = (v | (v << 8)) & 0x0300F00F; v = (v | (v << 4)) & 0x030C30C3; v = (v | (v << 2)) & 0x09249249
         return v
     return torch.argsort(spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2), stable=True)
+def morton_order_of(p, off_host):
+    parts, s = [], 0
+    for e in off_host:
+        parts.append(morton_perm(p[s:e]) + s); s = e
+    return torch.cat(parts).int().contiguous()
+# natural storage order, queries VISITED in Morton order + XCD-contiguous chunks (pdf_grouping_forward_ordered)
+p0 = b["coord"]; off0 = b["offset"].int(); n0 = p0.shape[0]
+idx0, _ = be.knn_query(8, p0, p0, off0, off0)
+order0 = morton_order_of(p0, b["offset_host"])
+ident = torch.arange(n0, dtype=torch.int32, device="cuda")
+feat0 = torch.randn(n0, 32, device="cuda")
+out_ref = be.grouping_forward(feat0, idx0)
+for name, o in (("identity order", ident), ("morton visiting order", order0)):
+    out = torch.empty(n0, 8, 32, device="cuda")
+    fn = lambda: be._call("grouping_forward_ordered", n0, 8, 32, feat0, idx0, o, out)
+    fn(); assert torch.equal(out, out_ref), name
+    s = timeit(fn, 20); gb = 4 * n0 * 32 + 4 * n0 * 8 + 4 * n0 * 8 * 32 + 4 * n0
+    print(f"ordered kernel, {name:24s} {s * 1e6:8.1f} us  {gb / s / 1e9:8.0f} GB/s  {gb / s / 8e12 * 100:5.1f} %")
 for mode in ("natural", "morton"):
     p = b["coord"].clone()
     off = b["offset"].int()

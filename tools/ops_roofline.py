@@ -71,10 +71,12 @@ def run(iters=20, only="", verbose=False, level2=True, references=True):
     add("knn_query L2 self k=16", knn_bytes(n2, n2, 16), lambda: be.knn_query(16, L2.p, L2.p, L2.o, L2.o))
     add("knn_query L1->L2 down k=16", knn_bytes(n1, n2, 16), lambda: be.knn_query(16, L1.p, L2.p, L1.o, L2.o))
     add("knn_query L2->L1 interp k=3", knn_bytes(n2, n1, 3), lambda: be.knn_query(3, L2.p, L1.p, L2.o, L1.o))
-    idx1, _ = be.knn_query(8, L1.p, L1.p, L1.o, L1.o)
-    idx2, _ = be.knn_query(16, L2.p, L2.p, L2.o, L2.o)
-    idxd, _ = be.knn_query(16, L1.p, L2.p, L1.o, L2.o)
-    idx3, d3 = be.knn_query(3, L2.p, L1.p, L2.o, L1.o)
+    # the tables as the model gets them: from the batch's Geometry (with the query level's Morton visiting order and, on first use
+    # in a backward, the inverse table attached to the idx tensor)
+    idx1, _ = geom.knn(8, 0, 0)
+    idx2, _ = geom.knn(16, l2, l2)
+    idxd, _ = geom.knn(16, 0, l2)
+    idx3, d3 = geom.knn(3, l2, 0)
     w3 = be.interpolation_weights(d3)
 
     for (tag, L, idx, c, k) in (("L1 c=32 k=8", L1, idx1, 32, 8), ("L2 c=64 k=16", L2, idx2, 64, 16))[:2 if level2 else 1]:
