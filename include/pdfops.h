@@ -162,7 +162,7 @@ int pdf_pt_layer_forward(int n, int nsample, int c, const float *xq, const float
                          const float *p, const int *idx, const float *const *weights,
                          const float *const *bn_params, float *const *bn_buffers, int training, float eps,
                          float momentum, float *bn, float *saved, float *H, float *partial, float *out,
-                         int storage_bf16, void *stream);
+                         int storage_bf16, const int *order, void *stream);
 
 /* Backward of the fused PointTransformerLayer (train mode).  gxq / gxk / gxv are overwritten: the scatters of g_xk and g_xv run as
  * segmented gathers over the INVERSE of the kNN table (inv_off (n+1), inv_entry, entry_base -- see pdf_seg_sum_rows), so they are
@@ -177,7 +177,7 @@ int pdf_pt_layer_backward(int n, int nsample, int c, const float *xq, const floa
                           const float *p, const int *idx, const float *const *weights, const float *bn,
                           const float *saved, const float *H, const float *gout, float *gxq, float *gxk,
                           float *gxv, float *G2, float *G3, float *Wsm, float *GR, const int *inv_off, const int *inv_entry,
-                          int entry_base, float *partial, float *sums, int storage_bf16, void *stream);
+                          int entry_base, float *partial, float *sums, int storage_bf16, const int *order, void *stream);
 
 /* BatchNorm1d over (n, c) rows fused with the residual add and ReLU that follow it in the Bottleneck
  * (point_transformer_seg.py:184-192).  c must be a power of two in 4..1024.  coef (4c floats) = scale|shift|mean|rstd,

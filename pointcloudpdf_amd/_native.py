@@ -536,9 +536,9 @@ class HipBackend(CBackend):
         lib.pdf_pt_layer_bwd_sums_floats.restype = c_long
         lib.pdf_pt_layer_bwd_sums_floats.argtypes = [c_int]
         lib.pdf_pt_layer_forward.restype = c_int
-        lib.pdf_pt_layer_forward.argtypes = [c_int, c_int, c_int] + [c_void_p] * 8 + [c_int, ctypes.c_float, ctypes.c_float] + [c_void_p] * 5 + [c_int, c_void_p]
+        lib.pdf_pt_layer_forward.argtypes = [c_int, c_int, c_int] + [c_void_p] * 8 + [c_int, ctypes.c_float, ctypes.c_float] + [c_void_p] * 5 + [c_int, c_void_p, c_void_p]
         lib.pdf_pt_layer_backward.restype = c_int
-        lib.pdf_pt_layer_backward.argtypes = [c_int, c_int, c_int] + [c_void_p] * 19 + [c_int] + [c_void_p] * 2 + [c_int, c_void_p]
+        lib.pdf_pt_layer_backward.argtypes = [c_int, c_int, c_int] + [c_void_p] * 19 + [c_int] + [c_void_p] * 2 + [c_int, c_void_p, c_void_p]
         self.fps_mode = os.environ.get("PDFOPS_FPS", "bucketed")  # "bucketed" | "plain"
         self.knn_mode = os.environ.get("PDFOPS_KNN", "grid")      # "grid" | "scan"
         lib.pdf_knn_workspace_bytes.restype = c_long
@@ -711,10 +711,22 @@ class HipBackend(CBackend):
             n, k, c, self._ptr(xq), self._ptr(xk), self._ptr(xv), self._ptr(p), self._ptr(idx),
             self._ptr_array(weights), self._ptr_array(bn_params), self._ptr_array(bn_buffers), int(bool(training)),
             ctypes.c_float(eps), ctypes.c_float(momentum), self._ptr(bn), self._ptr(saved), self._ptr(H),
-            self._ptr(partial), self._ptr(out), int(self.storage_bf16), c_void_p(torch.cuda.current_stream().cuda_stream))
+            self._ptr(partial), self._ptr(out), self.layer_flags(self.storage_bf16), self._order_ptr(idx), c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
             raise PdfOpsError(f"pdf_pt_layer_forward failed with status {rc}")
         return out, bn, saved, H
+
+    # visiting order of the points in the fused layer passes (PDFOPS_LAYER_ORDER=0: storage order, for A/B runs)
+    layer_order = os.environ.get("PDFOPS_LAYER_ORDER", "0") == "1"     # measured: no gain (22.3 vs 22.1 ms per step), the passes are not
+    layer_chunked = os.environ.get("PDFOPS_LAYER_CHUNKED", "0") == "1"  # bound by where their rows come from -- both off by default
+
+    def layer_flags(self, bf16):
+        """the `storage_bf16` argument of the layer entry points: bit 0 = bfloat16 row arrays, bit 1 = chunked point walk"""
+        return int(bool(bf16)) | (2 if self.layer_chunked else 0)
+
+    def _order_ptr(self, idx):
+        o = order_of(idx) if self.layer_order else None
+        return None if o is None else o.data_ptr()
 
     def pt_layer_backward(self, xq, xk, xv, p, idx, weights, bn, saved, H, gout, storage_bf16=None):
         n, c = xq.shape
@@ -738,7 +750,8 @@ class HipBackend(CBackend):
             self._ptr_array(weights), self._ptr(bn), self._ptr(saved), self._ptr(H), self._ptr(gout),
             self._ptr(gxq), self._ptr(gxk), self._ptr(gxv), self._ptr(G2), self._ptr(G3), self._ptr(Wsm), self._ptr(GR),
             self._ptr(inv_off), self._ptr(inv_entry), int(entry_base), self._ptr(partial),
-            self._ptr(sums), int(self.storage_bf16 if storage_bf16 is None else storage_bf16), c_void_p(torch.cuda.current_stream().cuda_stream))
+            self._ptr(sums), self.layer_flags(self.storage_bf16 if storage_bf16 is None else storage_bf16), self._order_ptr(idx),
+            c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
             raise PdfOpsError(f"pdf_pt_layer_backward failed with status {rc}")
         # unpack the parameter-gradient sections (layout: csrc/fused_layer.hip, pdf_pt_layer_backward)
@@ -875,7 +888,7 @@ class HipBackend(CBackend):
     # -- whole Bottleneck as one host call per direction (csrc/block.hip); thin methods so that bench.py can time them
     def bottleneck_forward(self, n, k, c, ptrs, training, eps, momentum, storage_bf16=0):
         rc = self.lib.pdf_bottleneck_forward(n, k, c, (c_void_p * len(ptrs))(*ptrs), int(training), ctypes.c_float(eps),
-                                             ctypes.c_float(momentum), int(storage_bf16), self._stream())
+                                             ctypes.c_float(momentum), self.layer_flags(storage_bf16), self._stream())
         if rc != 0:
             raise PdfOpsError(f"pdf_bottleneck_forward failed with status {rc}")
 
@@ -899,7 +912,7 @@ class HipBackend(CBackend):
         return [st.cuda_stream, evs[0].cuda_event, evs[1].cuda_event]
 
     def bottleneck_backward(self, n, k, c, ptrs, training, entry_base=0, storage_bf16=0):
-        rc = self.lib.pdf_bottleneck_backward(n, k, c, (c_void_p * len(ptrs))(*ptrs), int(training), int(entry_base), int(storage_bf16), self._stream())
+        rc = self.lib.pdf_bottleneck_backward(n, k, c, (c_void_p * len(ptrs))(*ptrs), int(training), int(entry_base), self.layer_flags(storage_bf16), self._stream())
         if rc != 0:
             raise PdfOpsError(f"pdf_bottleneck_backward failed with status {rc}")
 

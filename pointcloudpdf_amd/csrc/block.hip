@@ -152,7 +152,7 @@ extern "C" int pdf_block_post_backward(long n, int c, void *const *p, int traini
 //   14-21 layer weights (Wp1 bp1 Wp2 bp2 Ww1 bw1 Ww2 bw2) | 22-27 layer norm params (g_p b_p g_1 b_1 g_2 b_2)
 //   28-33 layer norm buffers (rm/rv x3) | 34 gamma2 35 beta2 36 rm2 37 rv2 | 38 W3 | 39 gamma3 40 beta3 41 rm3 42 rv3
 //   saved / outputs: 43 z1 44 coef1 45 xq 46 xk 47 xv 48 layer bn (2T) 49 layer saved (2T) 50 H 51 t 52 coef2 53 z3 54 coef3 55 y
-//   56 scratch (max of pdf_rowlin_partial_floats, pdf_bn_partial_floats, pdf_pt_layer_partial_floats)
+//   56 scratch (max of pdf_rowlin_partial_floats, pdf_bn_partial_floats, pdf_pt_layer_partial_floats) | 57 visiting order of the points (or null)
 extern "C" int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p, int training, float eps, float momentum, int storage_bf16, void *stream) {
     if (n < 1 || !p) return PDF_ERR_BAD_ARG;
     Err e;
@@ -164,7 +164,7 @@ extern "C" int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p
     for (int i = 0; i < 6; ++i) { bn_params[i] = (const float *)p[22 + i]; bn_buffers[i] = (float *)p[28 + i]; }
     e << pdf_pt_layer_forward((int)n, nsample, c, (const float *)p[45], (const float *)p[46], (const float *)p[47], (const float *)p[12],
                               (const int *)p[13], weights, bn_params, bn_buffers, training, eps, momentum, (float *)p[48], (float *)p[49],
-                              (float *)p[50], (float *)p[56], (float *)p[51], storage_bf16, stream);
+                              (float *)p[50], (float *)p[56], (float *)p[51], storage_bf16, (const int *)p[57], stream);
     void *post[16] = {p[51], p[0], p[34], p[35], p[36], p[37], p[38], p[39], p[40], p[41], p[42], p[52], p[53], p[54], p[55], p[56]};
     e << pdf_block_post_forward(n, c, post, training, eps, momentum, stream);
     return e.rc;
@@ -181,6 +181,7 @@ extern "C" int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p
 //            41 Wsm (n*nsample*c/8) 42 GR (n*nsample*c) | inverse kNN table: 43 inv_off (n+1) 44 inv_entry, entry_base
 //            45 dy (n*c; separate from 34: the forked dW3 kernel may still be reading `da` when the pre half starts)
 //   optional: 46 aux stream, 47 fork event, 48 join event (all three or none: weight gradients on the second stream, see Fork)
+//             49 visiting order of the points (or null)
 extern "C" int pdf_bottleneck_backward(long n, int nsample, int c, void *const *p, int training, int entry_base, int storage_bf16, void *stream) {
     if (n < 1 || !p) return PDF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -199,7 +200,7 @@ extern "C" int pdf_bottleneck_backward(long n, int nsample, int c, void *const *
                                (const int *)p[9], weights, (const float *)p[18], (const float *)p[19], (const float *)p[20],
                                (const float *)p[33], (float *)p[35], (float *)p[36], (float *)p[37], (float *)p[38], (float *)p[39],
                                (float *)p[41], (float *)p[42], (const int *)p[43], (const int *)p[44], entry_base,
-                               (float *)p[40], (float *)p[32], storage_bf16, stream);
+                               (float *)p[40], (float *)p[32], storage_bf16, (const int *)p[49], stream);
     void *pre[15] = {p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[35], p[36], p[37], p[29], p[30], p[45], p[40], nullptr};
     e << block_pre_backward(n, c, pre, training, 1, 1, stream, &fk);   // gx += dy W1 on top of the identity branch
     fk.finish(e);   // the gradients written on the second stream are complete before anything later on `stream`

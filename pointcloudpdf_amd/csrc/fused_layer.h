@@ -34,6 +34,37 @@ struct LayerArgs {
                                              // the scatters of g_xv / g_xk run as segmented gathers over the inverse kNN table
     float inv_rows;                          // 1 / (N*K)
     int bf16;                                // H / G2 / Wsm / GR hold bfloat16 (half the bytes of the same buffers) instead of fp32
+    int chunked;                             // point walk of the matrix-core passes: 1 = contiguous chunk per workgroup (XCD-major), 0 = grid-stride
+    const int *order;                        // visiting order of the points (a permutation of 0 .. N-1, Morton order from the geometry
+                                             // pre-pass) or nullptr: neighbouring points share neighbour rows -> per-XCD L2 hits
+};
+
+// The points one wave of the matrix-core passes visits: every workgroup owns one contiguous chunk of the visiting order (chunks dealt
+// XCD-major, pdf_xcd_chunked_block), its WPB waves interleave inside the chunk.
+struct PointWalk {
+    long t, end;
+    const int *order;
+    long stride;
+    __device__ __forceinline__ PointWalk(const LayerArgs &A, int wave_in_block) {
+        const unsigned g = gridDim.x;
+        order = A.order;
+        if (A.chunked) {   // one contiguous chunk of the visiting order per workgroup, chunks dealt XCD-major
+            const unsigned blk = pdf_xcd_chunked_block(blockIdx.x, g);
+            const long per = ((long)A.N + g - 1) / g;
+            t = (long)blk * per + wave_in_block;
+            end = (long)(blk + 1) * per < (long)A.N ? (long)(blk + 1) * per : (long)A.N;
+            stride = WPB;
+        } else {           // grid-stride over the points, one point per wave and trip
+            t = (long)blockIdx.x * WPB + wave_in_block;
+            end = A.N;
+            stride = (long)g * WPB;
+        }
+    }
+    __device__ __forceinline__ bool valid() const { return t < end; }
+    __device__ __forceinline__ bool has_next() const { return t + stride < end; }
+    __device__ __forceinline__ long point() const { return order ? (long)order[t] : t; }
+    __device__ __forceinline__ long next_point() const { return order ? (long)order[t + stride] : t + stride; }
+    __device__ __forceinline__ void step() { t += stride; }
 };
 
 // ---- row arrays that only this layer writes and reads (H saved by the forward; G2, Wsm, GR scratch of the backward): stored as

@@ -1057,7 +1057,7 @@ extern "C" int pdf_pt_layer_backward(int n, int nsample, int c, const float *xq,
                                      const float *p, const int *idx, const float *const *weights, const float *bn,
                                      const float *saved, const float *H, const float *gout, float *gxq, float *gxk,
                                      float *gxv, float *G2, float *G3, float *Wsm, float *GR, const int *inv_off, const int *inv_entry,
-                                     int entry_base, float *partial, float *sums, int storage_bf16, void *stream) {
+                                     int entry_base, float *partial, float *sums, int storage_bf16, const int *order, void *stream) {
     if (n < 1 || !xq || !xk || !xv || !p || !idx || !weights || !bn || !saved || !H || !gout || !gxq || !gxk || !gxv ||
         !G2 || !G3 || !Wsm || !GR || !inv_off || !inv_entry || !partial || !sums)
         return PDF_ERR_BAD_ARG;
@@ -1071,7 +1071,7 @@ extern "C" int pdf_pt_layer_backward(int n, int nsample, int c, const float *xq,
     A.sp = as_const(bn); A.tp = as_const(bn + 3); A.s1 = as_const(bn + 6); A.t1 = as_const(bn + 6 + c);
     A.s2 = as_const(bn + 6 + 2 * c); A.t2 = as_const(bn + 6 + 2 * c + cs);
     A.H = const_cast<float *>(H); A.out = nullptr; A.partial = partial;
-    A.gout = gout; A.G2 = G2; A.G3 = G3; A.gxq = gxq; A.gxk = gxk; A.gxv = gxv; A.Wsm = Wsm; A.GR = GR; A.bf16 = storage_bf16; A.sums = as_const(nullptr); A.sums2 = as_const(nullptr);
+    A.gout = gout; A.G2 = G2; A.G3 = G3; A.gxq = gxq; A.gxk = gxk; A.gxv = gxv; A.Wsm = Wsm; A.GR = GR; A.bf16 = storage_bf16 & 1; A.chunked = (storage_bf16 >> 1) & 1; A.order = order; A.sums = as_const(nullptr); A.sums2 = as_const(nullptr);
     hipStream_t s = static_cast<hipStream_t>(stream);
     A.mean = as_const(saved); A.rstd = as_const(saved + (3 + c + cs));   // forward's layout: [mean p|1|2][rstd p|1|2]
 #define PDF_BWD(C_, K_) return fl::backward_impl<C_, K_>(A, sums, inv_off, inv_entry, entry_base, s)
@@ -1095,7 +1095,7 @@ extern "C" int pdf_pt_layer_forward(int n, int nsample, int c, const float *xq, 
                                     const float *p, const int *idx, const float *const *weights,
                                     const float *const *bn_params, float *const *bn_buffers, int training, float eps,
                                     float momentum, float *bn, float *saved, float *H, float *partial, float *out,
-                                    int storage_bf16, void *stream) {
+                                    int storage_bf16, const int *order, void *stream) {
     if (n < 1 || !xq || !xk || !xv || !p || !idx || !weights || !bn_params || !bn_buffers || !bn || !H || !partial || !out)
         return PDF_ERR_BAD_ARG;
     if (!pdf_pt_layer_supported(nsample, c)) return PDF_ERR_UNSUPPORTED;
@@ -1105,7 +1105,7 @@ extern "C" int pdf_pt_layer_forward(int n, int nsample, int c, const float *xq, 
     using fl::as_const;
     A.Wp1 = as_const(weights[0]); A.bp1 = as_const(weights[1]); A.Wp2 = as_const(weights[2]); A.bp2 = as_const(weights[3]);
     A.Ww1 = as_const(weights[4]); A.bw1 = as_const(weights[5]); A.Ww2 = as_const(weights[6]); A.bw2 = as_const(weights[7]);
-    A.H = H; A.out = out; A.partial = partial; A.bf16 = storage_bf16;
+    A.H = H; A.out = out; A.partial = partial; A.bf16 = storage_bf16 & 1; A.chunked = (storage_bf16 >> 1) & 1; A.order = order;
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define PDF_FWD(C_, K_) return fl::forward_impl<C_, K_>(A, training, eps, momentum, bn_params, bn_buffers, bn, saved, s)
     if (nsample == 8) {

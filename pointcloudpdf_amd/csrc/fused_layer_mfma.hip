@@ -181,10 +181,12 @@ __global__ __launch_bounds__(64 * WPB) void k_p2(LayerArgs A) {
     f32x4 s[4], ss[4];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) { s[jj] = zero4(); ss[jj] = zero4(); }
-    int nb_next = wave_g < A.N ? A.idx[wave_g * 16 + row] : -1;
-    for (long i = wave_g; i < A.N; i += nwaves) {
+    fl::PointWalk pw(A, threadIdx.x >> 6);
+    int nb_next = pw.valid() ? A.idx[pw.point() * 16 + row] : -1;
+    for (; pw.valid(); pw.step()) {
+        const long i = pw.point();
         const int nb_cur = nb_next;
-        nb_next = i + nwaves < A.N ? A.idx[(i + nwaves) * 16 + row] : -1;   // next trip's index: in flight during this trip
+        nb_next = pw.has_next() ? A.idx[pw.next_point() * 16 + row] : -1;   // next trip's index: in flight during this trip
         const PRow R = load_prow(A, i, nb_cur);
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
@@ -220,10 +222,12 @@ __global__ __launch_bounds__(64 * WPB) void k_p3(LayerArgs A) {
     f32x4 b4[NOB], s4[NOB], ss4[NOB];
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) { b4[ob] = ldu(gp(A.bw1), ob * 16 + 4 * kq, ob * 16 + 4 * kq < CS); s4[ob] = zero4(); ss4[ob] = zero4(); }
-    int nb_next = wave_g < A.N ? A.idx[wave_g * 16 + row] : -1;
-    for (long i = wave_g; i < A.N; i += nwaves) {
+    fl::PointWalk pw(A, threadIdx.x >> 6);
+    int nb_next = pw.valid() ? A.idx[pw.point() * 16 + row] : -1;
+    for (; pw.valid(); pw.step()) {
+        const long i = pw.point();
         const int nb_cur = nb_next;
-        nb_next = i + nwaves < A.N ? A.idx[(i + nwaves) * 16 + row] : -1;   // next trip's index: in flight during this trip
+        nb_next = pw.has_next() ? A.idx[pw.next_point() * 16 + row] : -1;   // next trip's index: in flight during this trip
         const PRow R = load_prow(A, i, nb_cur);
         f32x4 acc[NOB];
 #pragma unroll
@@ -276,10 +280,12 @@ __global__ __launch_bounds__(64 * WPB) void k_p4(LayerArgs A) {
     __syncthreads();
     const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
     const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
-    int nb_next = wave_g < A.N ? A.idx[wave_g * 16 + row] : -1;
-    for (long i = wave_g; i < A.N; i += nwaves) {
+    fl::PointWalk pw(A, threadIdx.x >> 6);
+    int nb_next = pw.valid() ? A.idx[pw.point() * 16 + row] : -1;
+    for (; pw.valid(); pw.step()) {
+        const long i = pw.point();
         const int nb_cur = nb_next;
-        nb_next = i + nwaves < A.N ? A.idx[(i + nwaves) * 16 + row] : -1;   // next trip's index: in flight during this trip
+        nb_next = pw.has_next() ? A.idx[pw.next_point() * 16 + row] : -1;   // next trip's index: in flight during this trip
         const PRow R = load_prow(A, i, nb_cur);
         f32x4 h[NOB], u[NOB], w[NOB];
 #pragma unroll
@@ -325,10 +331,12 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
 #pragma unroll
         for (int ub = 0; ub < NOB; ++ub) accw[ob][ub] = zero4();
     }
-    int nb_next = wave_g < A.N ? A.idx[wave_g * 16 + row] : -1;
-    for (long i = wave_g; i < A.N; i += nwaves) {
+    fl::PointWalk pw(A, threadIdx.x >> 6);
+    int nb_next = pw.valid() ? A.idx[pw.point() * 16 + row] : -1;
+    for (; pw.valid(); pw.step()) {
+        const long i = pw.point();
         const int nb_cur = nb_next;
-        nb_next = i + nwaves < A.N ? A.idx[(i + nwaves) * 16 + row] : -1;   // next trip's index: in flight during this trip
+        nb_next = pw.has_next() ? A.idx[pw.next_point() * 16 + row] : -1;   // next trip's index: in flight during this trip
         const PRow R = load_prow(A, i, nb_cur);
         f32x4 h[NOB], u[NOB], w[NOB], gw[NOB];
 #pragma unroll
@@ -457,10 +465,12 @@ __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
     }
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) sgh[ob] = zero4();
-    int nb_next = wave_g < A.N ? A.idx[wave_g * 16 + row] : -1;
-    for (long i = wave_g; i < A.N; i += nwaves) {
+    fl::PointWalk pw(A, threadIdx.x >> 6);
+    int nb_next = pw.valid() ? A.idx[pw.point() * 16 + row] : -1;
+    for (; pw.valid(); pw.step()) {
+        const long i = pw.point();
         const int nb_cur = nb_next;
-        nb_next = i + nwaves < A.N ? A.idx[(i + nwaves) * 16 + row] : -1;   // next trip's index: in flight during this trip
+        nb_next = pw.has_next() ? A.idx[pw.next_point() * 16 + row] : -1;   // next trip's index: in flight during this trip
         const PRow R = load_prow(A, i, nb_cur);
         f32x4 gh[NOB];
         hidden_grad<C>(A, gp(A.sums), i, row, kq, gh);
@@ -562,7 +572,8 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
         for (int e = threadIdx.x; e < CSP * 64; e += 64 * WPB) wl[(e / 64) * WS + e % 64] = e / 64 < CS ? gp(A.Ww1)[(size_t)(e / 64) * C + 64 * q + e % 64] : 0.f;
         __syncthreads();
         float sbp2 = 0.f, awp2[3] = {0.f, 0.f, 0.f};
-        for (long i = wave_g; i < A.N; i += nwaves) {
+        for (fl::PointWalk pw(A, wv); pw.valid(); pw.step()) {
+            const long i = pw.point();
             const PRow R = load_prow(A, i, A.idx[i * 16 + row]);   // (index prefetch one trip ahead: slower here at C = 256, measured)
             if (kq == 0) { t1nt[row * 4 + 0] = R.t1n[0]; t1nt[row * 4 + 1] = R.t1n[1]; t1nt[row * 4 + 2] = R.t1n[2]; }
             f32x4 gh[NOB], h[NOB], u[NOB], w[NOB];

@@ -324,11 +324,7 @@ __global__ __launch_bounds__(GB) void grouping_fwd32(unsigned total, FastDiv cvd
 // most of their neighbours, and with the dispatcher's round-robin placement (workgroup b -> XCD b mod 8) undone by the remap below
 // those repeats hit the 4 MB L2 of the XCD instead of crossing the fabric to the Infinity Cache.  Each query's nsample x c output
 // block is contiguous, so the permuted visiting order still stores whole lines.
-constexpr int XCDS = 8;
-__device__ __forceinline__ unsigned xcd_chunked_block(unsigned b, unsigned g) {   // bijective for any g (guide: "XCD swizzle must be bijective")
-    const unsigned q = g / XCDS, r = g % XCDS, x = b % XCDS;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / XCDS;
-}
+__device__ __forceinline__ unsigned xcd_chunked_block(unsigned b, unsigned g) { return pdf_xcd_chunked_block(b, g); }   // pdfops_common.h
 
 template <int U>
 __global__ __launch_bounds__(GB) void grouping_fwd_ord(unsigned total, FastDiv cvd, FastDiv rowd /* nsample * cv */, int nsample,

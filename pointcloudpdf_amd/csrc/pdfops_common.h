@@ -54,3 +54,12 @@ __device__ __forceinline__ unsigned pdf_f32_ordered(float f) {
 __device__ __forceinline__ void pdf_atomic_add(float *p, float v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+// Workgroup -> work-chunk remap that gives every XCD ONE contiguous stretch of the chunk sequence: the dispatcher places workgroup b
+// on XCD b mod 8 (observed, /opt/skills/guides/MI355X_MICROARCH.md), so chunk ids are dealt XCD-major.  Bijective for any grid size g;
+// a pure speed choice (locality in the per-XCD L2), never a correctness assumption.
+#define PDF_XCDS 8
+__device__ __forceinline__ unsigned pdf_xcd_chunked_block(unsigned b, unsigned g) {
+    const unsigned q = g / PDF_XCDS, r = g % PDF_XCDS, x = b % PDF_XCDS;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / PDF_XCDS;
+}

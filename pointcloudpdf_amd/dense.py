@@ -410,7 +410,7 @@ class _BottleneckFn(torch.autograd.Function):
                 lw[3].running_mean.data_ptr(), lw[3].running_var.data_ptr(),
                 g2.data_ptr(), b2.data_ptr(), bn2.running_mean.data_ptr(), bn2.running_var.data_ptr(), W3.data_ptr(),
                 g3.data_ptr(), b3.data_ptr(), bn3.running_mean.data_ptr(), bn3.running_var.data_ptr(),
-                *ap, y.data_ptr(), scratch.data_ptr()]
+                *ap, y.data_ptr(), scratch.data_ptr(), be._order_ptr(idx)]
         bf16 = int(be.storage_bf16)
         be.bottleneck_forward(n, k, c, ptrs, training, bn1.eps, bn1.momentum, bf16)
         ctx.save_for_backward(x, p, idx, act, W1, Wq, Wk, Wv, W3, Wp1, bp1, Wp2, bp2, Ww1, bw1, Ww2, bw2)
@@ -453,7 +453,7 @@ class _BottleneckFn(torch.autograd.Function):
                 A(5), A(6), A(7), A(2), A(3), A(4), A(8), A(10), A(9), A(11), W3.data_ptr(),
                 gx.data_ptr(), gb + 4 * o_pre, gb + 4 * o_post, gb + 4 * o_sum,
                 S(0), S(1), S(2), S(6), S(7), S(3), S(4), S(5), S(8), S(9), inv_off.data_ptr(), inv_entry.data_ptr(), S(10),
-                *be.aux_handles(x.device)]
+                *be.aux_handles(x.device), be._order_ptr(idx)]
         be.bottleneck_backward(n, k, c, ptrs, training, entry_base, bf16)
         G = lambda o, sz, *shape: grads[o:o + sz].view(*shape) if shape else grads[o:o + sz]
         # pre half: dW1 | dbeta1 | dgamma1 | {dW, db} x q, k, v

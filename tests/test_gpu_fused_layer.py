@@ -133,5 +133,7 @@ def test_bf16_storage_variant_tracks_the_fp32_layer():
         for a, b in zip(gb, gf):
             assert helpers.l2_rel(a, b) < 5e-2, (c, helpers.l2_rel(a, b))
         for nm in pf:
+            if nm.endswith(("linear_p.0.bias", "linear_w.2.bias", "linear_w.5.bias")):
+                continue   # analytically zero (a bias in front of a train-mode BatchNorm / of the softmax over the neighbours): rounding noise
             if np.abs(pf[nm]).max() > 1e-6:
                 assert helpers.l2_rel(pb[nm], pf[nm]) < 5e-2, (c, nm, helpers.l2_rel(pb[nm], pf[nm]))
