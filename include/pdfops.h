@@ -274,7 +274,9 @@ int pdf_seg_sum_rows_strided(long n, int c, const float *src, long src_stride, c
 int pdf_seg_sum_rows_x(long n, int c, const float *src, long src_stride, int src_bf16, const int *inv_off, const int *inv_entry, int entry_base,
                        float scale, float *out, void *stream);     /* src rows fp32 or bfloat16 */
 int pdf_seg_sum_weighted_x(long n, int c, int nsample, int w_c, const float *src, const float *w, int w_bf16, const int *inv_off,
-                           const int *inv_entry, int entry_base, float *out, void *stream);   /* w fp32 or bfloat16 */
+                           const int *inv_entry, int entry_base, const int *order, float *out, void *stream);   /* w fp32 or bfloat16 */
+int pdf_seg_sum_weighted_ordered(long n, int c, int nsample, int w_c, const float *src, const float *w, const int *inv_off,
+                                 const int *inv_entry, int entry_base, const int *order, float *out, void *stream);   /* order: visiting order of the n destinations or NULL */
 int pdf_seg_sum_weighted(long n, int c, int nsample, int w_c, const float *src, const float *w, const int *inv_off, const int *inv_entry,
                          int entry_base, float *out, void *stream);
 

@@ -68,6 +68,7 @@ _HIP_ONLY_PROTOS = {
     "seg_sum_rows": "lipppifp",
     "seg_sum_rows_strided": "liplppifp",
     "seg_sum_weighted": "liiippppip",
+    "seg_sum_weighted_ordered": "liiippppipp",
 }
 _KIND = {"i": c_int, "l": c_long, "f": c_float, "d": c_double, "p": c_void_p}
 
@@ -119,11 +120,19 @@ def inverse_table(idx, n):
 _ORD = "_pdf_order"
 
 
-def attach_order(idx, order):
+def attach_order(idx, order, src_order=None):
     """Remember a visiting order of the QUERIES of a neighbour table (a permutation of its rows: the Morton order of the query points,
-    Geometry.order) on the idx tensor; the forward gathers then walk the queries in that order (csrc/gather_ops.hip, *_ord kernels)."""
-    setattr(idx, _ORD, (idx.data_ptr(), idx._version, order))
+    Geometry.order) on the idx tensor; the forward gathers then walk the queries in that order (csrc/gather_ops.hip, *_ord kernels).
+    ``src_order``: the same for the SOURCE rows (the destinations of the backward's segmented gathers)."""
+    setattr(idx, _ORD, (idx.data_ptr(), idx._version, order, src_order))
     return idx
+
+
+def src_order_of(idx, n):
+    tag = getattr(idx, _ORD, None)
+    if tag is not None and tag[0] == idx.data_ptr() and tag[1] == idx._version and tag[3] is not None and tag[3].shape[0] == n:
+        return tag[3]
+    return None
 
 
 def order_of(idx):
@@ -616,7 +625,7 @@ class HipBackend(CBackend):
             return self._new(grad_output, (m, c), torch.float32, zero=True)
         off, ent, base = inverse_table(idx, m)
         gi = self._new(grad_output, (m, c), torch.float32)
-        self._call("seg_sum_weighted", m, c, idx.shape[1], 1, grad_output, weight, off, ent, base, gi)
+        self._call("seg_sum_weighted_ordered", m, c, idx.shape[1], 1, grad_output, weight, off, ent, base, src_order_of(idx, m), gi)
         return gi
 
     def subtraction_backward(self, idx, grad_output, n2=None):
@@ -647,7 +656,7 @@ class HipBackend(CBackend):
         gp = self._new(input, (n, ns, c), torch.float32)
         gw = self._new(input, (n, ns, w_c), torch.float32, zero=True)
         self._call("aggregation_backward", n, ns, c, w_c, input, position, weight, idx, grad_output, None, gp, gw)
-        self._call("seg_sum_weighted", input.shape[0], c, ns, w_c, grad_output, weight, off, ent, base, gi)
+        self._call("seg_sum_weighted_ordered", input.shape[0], c, ns, w_c, grad_output, weight, off, ent, base, src_order_of(idx, input.shape[0]), gi)
         return gi, gp, gw
 
     def knn_query(self, nsample, xyz, new_xyz, offset, new_offset):
@@ -722,10 +731,10 @@ class HipBackend(CBackend):
 
     def layer_flags(self, bf16):
         """the `storage_bf16` argument of the layer entry points: bit 0 = bfloat16 row arrays, bit 1 = chunked point walk"""
-        return int(bool(bf16)) | (2 if self.layer_chunked else 0)
+        return int(bool(bf16)) | (2 if self.layer_chunked else 0) | (4 if self.layer_order else 0)
 
     def _order_ptr(self, idx):
-        o = order_of(idx) if self.layer_order else None
+        o = order_of(idx)   # (always handed over: the g_xv gather visits its destinations in this order; the passes only with bit 2)
         return None if o is None else o.data_ptr()
 
     def pt_layer_backward(self, xq, xk, xv, p, idx, weights, bn, saved, H, gout, storage_bf16=None):

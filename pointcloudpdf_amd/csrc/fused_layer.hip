@@ -997,7 +997,7 @@ static inline int grid_for_tiles_bwd(long ntiles, int c) {
 }
 
 template <int C, int K>
-int backward_impl(LayerArgs A, float *sums, const int *inv_off, const int *inv_entry, int entry_base, hipStream_t s) {
+int backward_impl(LayerArgs A, float *sums, const int *inv_off, const int *inv_entry, int entry_base, const int *gather_order, hipStream_t s) {
     constexpr int CS = C / 8;
     const long rows = (long)A.N * K;
     const long ntiles = (rows + 63) / 64;
@@ -1013,7 +1013,7 @@ int backward_impl(LayerArgs A, float *sums, const int *inv_off, const int *inv_e
     if (mfma) flm::launch_b1(A, C, grid, s); else k_b1<C, K><<<grid, 64 * WPB, lds, s>>>(A);
     k_colsum<<<pdf_divup(b1_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, nw, b1_width<C>(), S1);
     // g_xv[nb, c] = sum over the entries (i, j) with idx[i, j] == nb of g_out[i, c] * w[i, j, c mod C/8]   (no atomics, fixed order)
-    int rc = pdf_seg_sum_weighted_x(A.N, C, K, CS, A.gout, A.Wsm, A.bf16, inv_off, inv_entry, entry_base, A.gxv, s);
+    int rc = pdf_seg_sum_weighted_x(A.N, C, K, CS, A.gout, A.Wsm, A.bf16, inv_off, inv_entry, entry_base, gather_order, A.gxv, s);   // (destinations in Morton order: the g_out rows they share hit L2)
     if (rc != PDF_OK) return rc;
     A.sums = as_const(S1);
     if (mfma) flm::launch_b2(A, C, grid, s); else k_b2<C, K><<<grid, 64 * WPB, lds, s>>>(A);
@@ -1071,10 +1071,10 @@ extern "C" int pdf_pt_layer_backward(int n, int nsample, int c, const float *xq,
     A.sp = as_const(bn); A.tp = as_const(bn + 3); A.s1 = as_const(bn + 6); A.t1 = as_const(bn + 6 + c);
     A.s2 = as_const(bn + 6 + 2 * c); A.t2 = as_const(bn + 6 + 2 * c + cs);
     A.H = const_cast<float *>(H); A.out = nullptr; A.partial = partial;
-    A.gout = gout; A.G2 = G2; A.G3 = G3; A.gxq = gxq; A.gxk = gxk; A.gxv = gxv; A.Wsm = Wsm; A.GR = GR; A.bf16 = storage_bf16 & 1; A.chunked = (storage_bf16 >> 1) & 1; A.order = order; A.sums = as_const(nullptr); A.sums2 = as_const(nullptr);
+    A.gout = gout; A.G2 = G2; A.G3 = G3; A.gxq = gxq; A.gxk = gxk; A.gxv = gxv; A.Wsm = Wsm; A.GR = GR; A.bf16 = storage_bf16 & 1; A.chunked = (storage_bf16 >> 1) & 1; A.order = (storage_bf16 & 4) ? order : nullptr; A.sums = as_const(nullptr); A.sums2 = as_const(nullptr);
     hipStream_t s = static_cast<hipStream_t>(stream);
     A.mean = as_const(saved); A.rstd = as_const(saved + (3 + c + cs));   // forward's layout: [mean p|1|2][rstd p|1|2]
-#define PDF_BWD(C_, K_) return fl::backward_impl<C_, K_>(A, sums, inv_off, inv_entry, entry_base, s)
+#define PDF_BWD(C_, K_) return fl::backward_impl<C_, K_>(A, sums, inv_off, inv_entry, entry_base, order, s)
     if (nsample == 8) {
         if (c == 32) PDF_BWD(32, 8);
         if (c == 64) PDF_BWD(64, 8);
@@ -1105,7 +1105,7 @@ extern "C" int pdf_pt_layer_forward(int n, int nsample, int c, const float *xq, 
     using fl::as_const;
     A.Wp1 = as_const(weights[0]); A.bp1 = as_const(weights[1]); A.Wp2 = as_const(weights[2]); A.bp2 = as_const(weights[3]);
     A.Ww1 = as_const(weights[4]); A.bw1 = as_const(weights[5]); A.Ww2 = as_const(weights[6]); A.bw2 = as_const(weights[7]);
-    A.H = H; A.out = out; A.partial = partial; A.bf16 = storage_bf16 & 1; A.chunked = (storage_bf16 >> 1) & 1; A.order = order;
+    A.H = H; A.out = out; A.partial = partial; A.bf16 = storage_bf16 & 1; A.chunked = (storage_bf16 >> 1) & 1; A.order = (storage_bf16 & 4) ? order : nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define PDF_FWD(C_, K_) return fl::forward_impl<C_, K_>(A, training, eps, momentum, bn_params, bn_buffers, bn, saved, s)
     if (nsample == 8) {

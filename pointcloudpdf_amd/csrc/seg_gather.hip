@@ -85,14 +85,17 @@ __global__ __launch_bounds__(TB) void k_seg_rows(unsigned total, FastDiv cvd, un
 
 // out[v, ch] = sum over the segment of src[e / nsample, ch] * w[e, ch mod w_c]
 //   aggregation grad_input (w = attention weights), fused layer g_xv (src = g_out, w = softmax weights), interpolation (w_c = 1)
+// `order` (nullable): visiting order of the DESTINATION rows (their Morton order): neighbouring destinations are gathered by the same
+// source rows, which then hit the L2 of the XCD that owns this stretch of the order (pdf_xcd_chunked_block).
 template <int V, bool WVEC>
 __global__ __launch_bounds__(TB) void k_seg_weighted(unsigned total, FastDiv cvd, FastDiv nsd, int w_c, const typename Vec<V>::T *__restrict__ src,
                                                      const float *__restrict__ w, const int *__restrict__ inv_off,
-                                                     const int *__restrict__ inv_entry, int entry_base, typename Vec<V>::T *__restrict__ out) {
+                                                     const int *__restrict__ inv_entry, int entry_base, const int *__restrict__ order,
+                                                     typename Vec<V>::T *__restrict__ out) {
     using T = typename Vec<V>::T;
-    const unsigned gid = blockIdx.x * TB + threadIdx.x;
+    const unsigned gid = pdf_xcd_chunked_block(blockIdx.x, gridDim.x) * TB + threadIdx.x;
     if (gid >= total) return;
-    const unsigned v = fdiv(gid, cvd), p = gid - v * cvd.d, cv = cvd.d;
+    const unsigned sv = fdiv(gid, cvd), p = gid - sv * cvd.d, cv = cvd.d, v = order ? (unsigned)order[sv] : sv;
     const unsigned wo = (p * V) % (unsigned)w_c;   // first weight column of this piece (V consecutive channels; WVEC: w_c % 4 == 0)
     int t = inv_off[v];
     const int end = inv_off[v + 1];
@@ -197,8 +200,8 @@ extern "C" int pdf_seg_sum_rows(long n, int c, const float *src, const int *inv_
 }
 
 // out (n, c)[v, ch] = segmented sum of src[e / nsample, ch] * w[e, ch mod w_c]; src (m, c), w (m * nsample, w_c).
-extern "C" int pdf_seg_sum_weighted(long n, int c, int nsample, int w_c, const float *src, const float *w, const int *inv_off,
-                                    const int *inv_entry, int entry_base, float *out, void *stream) {
+extern "C" int pdf_seg_sum_weighted_ordered(long n, int c, int nsample, int w_c, const float *src, const float *w, const int *inv_off,
+                                            const int *inv_entry, int entry_base, const int *order, float *out, void *stream) {
     if (n == 0) return PDF_OK;
     if (n < 0 || c < 1 || nsample < 1 || w_c < 1 || c % w_c != 0 || !src || !w || !inv_off || !inv_entry || !out) return PDF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -210,13 +213,18 @@ extern "C" int pdf_seg_sum_weighted(long n, int c, int nsample, int w_c, const f
     const sg::FastDiv cvd = sg::mk_fastdiv(cv), nsd = sg::mk_fastdiv(nsample);
     if (v4 && w_c % 4 == 0 && ((uintptr_t)w % 16 == 0))
         sg::k_seg_weighted<4, true><<<g, sg::TB, 0, s>>>((unsigned)total, cvd, nsd, w_c, reinterpret_cast<const float4 *>(src), w, inv_off,
-                                                         inv_entry, entry_base, reinterpret_cast<float4 *>(out));
+                                                         inv_entry, entry_base, order, reinterpret_cast<float4 *>(out));
     else if (v4)
         sg::k_seg_weighted<4, false><<<g, sg::TB, 0, s>>>((unsigned)total, cvd, nsd, w_c, reinterpret_cast<const float4 *>(src), w, inv_off,
-                                                          inv_entry, entry_base, reinterpret_cast<float4 *>(out));
+                                                          inv_entry, entry_base, order, reinterpret_cast<float4 *>(out));
     else
-        sg::k_seg_weighted<1, false><<<g, sg::TB, 0, s>>>((unsigned)total, cvd, nsd, w_c, src, w, inv_off, inv_entry, entry_base, out);
+        sg::k_seg_weighted<1, false><<<g, sg::TB, 0, s>>>((unsigned)total, cvd, nsd, w_c, src, w, inv_off, inv_entry, entry_base, order, out);
     return pdf_launch_status();
+}
+
+extern "C" int pdf_seg_sum_weighted(long n, int c, int nsample, int w_c, const float *src, const float *w, const int *inv_off,
+                                    const int *inv_entry, int entry_base, float *out, void *stream) {
+    return pdf_seg_sum_weighted_ordered(n, c, nsample, w_c, src, w, inv_off, inv_entry, entry_base, nullptr, out, stream);
 }
 
 // Internal twins used by the fused layer: source rows / weights either fp32 or bfloat16 (`*_bf16` flag; needs c % 4 == 0, w_c % 4 == 0).
@@ -234,8 +242,8 @@ extern "C" int pdf_seg_sum_rows_x(long n, int c, const float *src, long src_stri
 }
 
 extern "C" int pdf_seg_sum_weighted_x(long n, int c, int nsample, int w_c, const float *src, const float *w, int w_bf16, const int *inv_off,
-                                      const int *inv_entry, int entry_base, float *out, void *stream) {
-    if (!w_bf16) return pdf_seg_sum_weighted(n, c, nsample, w_c, src, w, inv_off, inv_entry, entry_base, out, stream);
+                                      const int *inv_entry, int entry_base, const int *order, float *out, void *stream) {
+    if (!w_bf16) return pdf_seg_sum_weighted_ordered(n, c, nsample, w_c, src, w, inv_off, inv_entry, entry_base, order, out, stream);
     if (n == 0) return PDF_OK;
     if (n < 0 || c % 4 || w_c % 4 || c % w_c || nsample < 1 || !src || !w || !inv_off || !inv_entry || !out) return PDF_ERR_BAD_ARG;
     const long total = n * (c / 4);

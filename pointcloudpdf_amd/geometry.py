@@ -130,7 +130,7 @@ class Geometry:
             be = _native.backend_for(S.p)
             self._memo[key] = be.knn_query(nsample, S.p, Q.p, S.o, Q.o)
             if S.p.is_cuda:   # the forward gathers visit the queries in Morton order (neighbouring queries share rows: L2 hits)
-                _native.attach_order(self._memo[key][0], self.order(query_level))
+                _native.attach_order(self._memo[key][0], self.order(query_level), self.order(src_level))
         return self._memo[key]
 
     def order(self, level):
@@ -308,7 +308,7 @@ class Geometry:
                     raise RuntimeError(f"Geometry.split: unknown memo entry {key}")
             for key, val in g._memo.items():   # visiting orders travel with the batch's index tensors
                 if key[0] == "knn" and ("order", key[3]) in g._memo:
-                    _native.attach_order(val[0], g._memo[("order", key[3])])
+                    _native.attach_order(val[0], g._memo[("order", key[3])], g._memo.get(("order", key[2])))
             out.append(g)
             s0 = s1
         return out
