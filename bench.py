@@ -296,8 +296,11 @@ def main():
     if args.points is None:
         args.points = 150000 if scannet else (80000 if strat else 100000)
     step_kw = dict(in_channels=9, num_classes=20, loss_weight=0.04) if scannet else (dict(backbone="ST-v1m1", loss_weight=0.008) if strat else {})
+    st_ahead = 0
     if strat:
-        args.prefetch = 0   # (the geometry pre-pass is PointTransformer-V1's; ST builds its window partition inside the forward)
+        # ST's coordinate-only work (FPS chain + window edge tables) runs one batch ahead on a worker thread + side stream
+        # (stratified.StratifiedPrefetcher); --prefetch 0 keeps it inside the forward.  PointTransformer-V1's pre-pass does not apply.
+        st_ahead, args.prefetch = (1 if args.prefetch > 0 else 0), 0
     if args.pseudo_label:
         from pointcloudpdf_amd import pseudo_label
         step_kw["pseudo_mask_fn"] = pseudo_label.make_pseudo_mask_fn(radius=0.02 * 5, max_neighbor=64, condition_from="msp", beta=1.5,
@@ -376,6 +379,11 @@ def main():
                 prefetcher.get(t)
             self.tickets.clear()
 
+    st_prefetcher, st_tickets = None, {}
+    if st_ahead:
+        from pointcloudpdf_amd.stratified import StratifiedPrefetcher
+        st_prefetcher = StratifiedPrefetcher(step.model.backbone, windows=not os.environ.get("PDFOPS_ST_FPS_ONLY"))
+
     def one_step(i, sched):
         batch = pool[i % len(pool)]
         data = dict(coord=batch["coord"], feat=batch["feat"], offset=batch["offset"],
@@ -383,6 +391,11 @@ def main():
         geom = sched.geometry(i)
         if geom is not None:
             data["pdf_geometry"] = geom
+        if st_prefetcher is not None:
+            if i not in st_tickets:
+                st_tickets[i] = st_prefetcher.submit(batch)
+            st_tickets[i + 1] = st_prefetcher.submit(pool[(i + 1) % len(pool)])   # next batch's tables: during this step
+            data["st_geometry"] = st_prefetcher.get(st_tickets.pop(i))
         opt.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=torch.float16, enabled=args.amp):
             out = module(data)
@@ -415,6 +428,9 @@ def main():
         if with_timer:
             timer.sampled_steps = len([i for i in range(steps) if timer.every > 0 and i % timer.every == 0])
         sched.drain()
+        for t in st_tickets.values():
+            st_prefetcher.get(t)
+        st_tickets.clear()
         return dt, out, sched
 
     dt_local, out, sched = timed(args.prefetch, args.warmup, args.steps, with_timer=True)
@@ -478,7 +494,7 @@ def main():
             "rccl_ranks": world if (world > 1 and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl") else 0,
             "rank_ms_per_step": rank_ms,
             "loss": loss,
-            "geometry_prefetch_group": D,
+            "geometry_prefetch_group": (st_ahead if strat else D),
             "prepass_submit_host_ms": (1e3 * min(sched.submit_host_s)) if sched.submit_host_s else None,   # host time of one group submission (warm)
             "kernels": ks,
             "roofline": roof,

@@ -61,7 +61,14 @@ class WindowAttention(nn.Module):
         rel = torch.round(rel * 100000) / rel.new_tensor(100000.0)
         return torch.div(rel + 2 * self.window_size - 1e-4, rel.new_tensor(float(self.quant_size)), rounding_mode="trunc")
 
-    def forward(self, feats, xyz, index_0, index_1, index_0_offsets, n_max):
+    def checked_relative_position_index(self, xyz, index_0, index_1):
+        rel_idx = self.relative_position_index(xyz, index_0, index_1)
+        assert (rel_idx >= 0).all() and (rel_idx <= 2 * self.quant_grid_length - 1).all()
+        return rel_idx.int().contiguous()
+
+    def forward(self, feats, xyz, index_0, index_1, index_0_offsets, n_max, rel_idx=None):
+        """``rel_idx``: the (M, 3) int32 table rows of the edges when the caller already holds them (they depend on coordinates only:
+        BasicLayer computes them once per window partition instead of once per block)."""
         n, c = feats.shape
         assert index_0.shape[0] == index_1.shape[0]
         qkv = self.qkv(feats).reshape(n, 3, self.num_heads, c // self.num_heads).permute(1, 0, 2, 3).contiguous()
@@ -69,9 +76,8 @@ class WindowAttention(nn.Module):
         query = query * self.scale
         i1, off = index_1.int().contiguous(), index_0_offsets.int().contiguous()
         attn = pointops.attention_step1_v2(query.float(), key.float(), i1, off, n_max)
-        rel_idx = self.relative_position_index(xyz, index_0, index_1)
-        assert (rel_idx >= 0).all() and (rel_idx <= 2 * self.quant_grid_length - 1).all()
-        rel_idx = rel_idx.int().contiguous()
+        if rel_idx is None:
+            rel_idx = self.checked_relative_position_index(xyz, index_0, index_1)
         if self.rel_query and self.rel_key:
             bias = pointops.dot_prod_with_idx_v3(query.float(), off, n_max, key.float(), i1, self.relative_pos_query_table.float(),
                                                  self.relative_pos_key_table.float(), rel_idx)
@@ -250,18 +256,126 @@ class Mlp(nn.Module):
         return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
 
 
-def _strided_offsets(offset, fn):
-    ends = [int(v) for v in offset.detach().cpu().tolist()]
+def _strided_counts(ends, fn):
     out, count, prev = [], 0, 0
     for e in ends:
         count += fn(e - prev)
         prev = e
         out.append(count)
-    return torch.tensor(out, dtype=torch.int32, device=offset.device)
+    return out
+
+
+def _strided_offsets(offset, fn):
+    return torch.tensor(_strided_counts([int(v) for v in offset.detach().cpu().tolist()], fn), dtype=torch.int32, device=offset.device)
+
+
+class StratifiedGeometry:
+    """The coordinate-only chain of one StratifiedTransformer forward: per level the FPS subset that supplies the window keys
+    (n // downsample_scale + 1 points per scene, BasicLayer :479-489) and the TransitionDown sample (int(n * ratio) + 1 points, :165-174),
+    whose points are the next level's coordinates.  None of it depends on features, so -- as for PointTransformer-V1's Geometry --
+    it can run ahead of the step on a side stream (FPS is a serial chain per scene: 7 launches, ~60 ms of the 179 ms step at 2 x 80k
+    points when it runs inline).  Results are bit-identical to the inline calls (same kernel, same inputs).  With ``offset_host`` (the
+    scene ends as Python ints, as the collate function has them) no call of the chain waits for the device."""
+
+    def __init__(self, coord, offset, offset_host=None, downsample_scale=8, ratio=0.25, num_layers=4, stem_transformer=True):
+        self.coord, self.offset = coord.contiguous(), offset.int()
+        self.offset_host = [int(v) for v in (offset_host if offset_host is not None else offset.detach().cpu().tolist())]
+        self.cfg = (downsample_scale, ratio, num_layers, stem_transformer)
+        self.samples = {}        # ("keys" | "down", level) -> (int32 indices into that level's points, int32 scene ends of the subset)
+        self.windows = {}        # level -> BasicLayer.window_tables (filled by precompute(layers=...) only: data-dependent shapes)
+
+    def _sample(self, key, xyz, off, ends, fn):
+        n_ends = _strided_counts(ends, fn)
+        n_off = torch.tensor(n_ends, dtype=torch.int32).to(xyz.device, non_blocking=True)
+        self.samples[key] = (pointops.furthestsampling(xyz, off, n_off), n_off)
+        return self.samples[key] + (n_ends,)
+
+    def precompute(self, layers=None):
+        """``layers``: the model's BasicLayers by level (``StratifiedTransformer.layers_by_level()``) -> also their window edge tables.
+        Those have data-dependent shapes (host reads of counts), so that part belongs on a worker thread (StratifiedPrefetcher)."""
+        scale, ratio, num_layers, stem_transformer = self.cfg
+        xyz, off, ends = self.coord, self.offset, self.offset_host
+        level = 0
+        with torch.no_grad():
+            if not stem_transformer:   # a TransitionDown follows the KPConv stem (:737-741)
+                idx, off, ends = self._sample(("down", "stem"), xyz, off, ends, lambda n: int(n * ratio) + 1)
+                xyz, level = xyz[idx.long(), :].contiguous(), 1
+            for l in range(level, num_layers):
+                keys = self._sample(("keys", l), xyz, off, ends, lambda n: n // scale + 1)[0]
+                if l < num_layers - 1:
+                    idx, n_off, n_ends = self._sample(("down", l), xyz, off, ends, lambda n: int(n * ratio) + 1)
+                if layers is not None:
+                    self.windows[l] = layers[l].window_tables(xyz, off, keys)
+                if l < num_layers - 1:
+                    xyz, off, ends = xyz[idx.long(), :].contiguous(), n_off, n_ends
+        return self
+
+    def tensors(self):
+        out = [self.coord, self.offset] + [t for pair in self.samples.values() for t in pair]
+        for tables in self.windows.values():
+            out += [t for tab in tables.values() for t in tab if torch.is_tensor(t)]
+        return out
+
+
+class StratifiedPrefetcher:
+    """Builds the StratifiedGeometry of upcoming batches on a worker thread with its own HIP stream while the current batch trains
+    (the DataLoader-worker pattern, on the device): the FPS chain and the window partitions read coordinates only.  The worker's
+    host-side waits (partition sizes are data dependent) block that thread alone.  ``get()`` joins the worker, makes the consumer
+    stream wait for the side stream and registers the tables with it."""
+
+    def __init__(self, model, windows=True):
+        from concurrent.futures import ThreadPoolExecutor
+
+        self.model, self.windows = model, windows
+        self.stream = torch.cuda.Stream()
+        self.pool = ThreadPoolExecutor(max_workers=1)
+        self.device = torch.cuda.current_device()
+
+    def submit(self, batch):
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())   # the batch's tensors were produced on the caller's stream
+        geom = self.model.make_geometry(batch["coord"], batch["offset"], batch.get("offset_host"))
+
+        def work():
+            torch.cuda.set_device(self.device)
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ready)
+                geom.precompute(self.model.layers_by_level() if self.windows else None)
+                done = torch.cuda.Event()
+                done.record(self.stream)
+            return done
+
+        return geom, self.pool.submit(work)
+
+    @staticmethod
+    def get(ticket):
+        geom, future = ticket
+        cur = torch.cuda.current_stream()
+        cur.wait_event(future.result())
+        for t in geom.tensors():
+            t.record_stream(cur)
+        return geom
+
+    def close(self):
+        self.pool.shutdown(wait=True)
+
+
+_ACTIVE_GEOMETRY = None   # the StratifiedGeometry of the forward in progress (set by StratifiedTransformer.forward)
+
+
+def _fps(key, xyz, offset, fn):
+    """(sample indices, scene ends of the sample): from the forward's StratifiedGeometry when it holds them, else computed here."""
+    g = _ACTIVE_GEOMETRY
+    if g is not None and key in g.samples:
+        return g.samples[key]
+    new_offset = _strided_offsets(offset, fn)
+    return pointops.furthestsampling(xyz, offset.int(), new_offset), new_offset
 
 
 class TransitionDown(nn.Module):
     """:156-189 -- FPS (ratio * n + 1 points per scene), kNN grouping WITHOUT coordinates, LayerNorm, Linear, max over k."""
+
+    level = None   # set by StratifiedTransformer: key of this module's FPS call in a StratifiedGeometry
 
     def __init__(self, in_channels, out_channels, ratio, k, norm_layer=nn.LayerNorm):
         super().__init__()
@@ -271,8 +385,7 @@ class TransitionDown(nn.Module):
         self.pool = nn.MaxPool1d(k)
 
     def forward(self, feats, xyz, offset):
-        n_offset = _strided_offsets(offset, lambda n: int(n * self.ratio) + 1)
-        idx = pointops.furthestsampling(xyz, offset, n_offset)
+        idx, n_offset = _fps(("down", self.level), xyz, offset, lambda n: int(n * self.ratio) + 1)
         n_xyz = xyz[idx.long(), :].contiguous()
         feats = pointops.queryandgroup(self.k, xyz, n_xyz, feats.contiguous(), None, offset, n_offset, use_xyz=False)   # (m, k, c)
         m, k, c = feats.shape
@@ -294,9 +407,9 @@ class SwinTransformerBlock(nn.Module):
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer)
 
-    def forward(self, feats, xyz, index_0, index_1, index_0_offsets, n_max):
+    def forward(self, feats, xyz, index_0, index_1, index_0_offsets, n_max, rel_idx=None):
         short_cut = feats
-        feats = self.attn(self.norm1(feats), xyz, index_0, index_1, index_0_offsets, n_max)   # index_0 in ascending order
+        feats = self.attn(self.norm1(feats), xyz, index_0, index_1, index_0_offsets, n_max, rel_idx)   # index_0 in ascending order
         feats = short_cut + self.drop_path(feats)
         return feats + self.drop_path(self.mlp(self.norm2(feats)))
 
@@ -308,6 +421,7 @@ class BasicLayer(nn.Module):
                  rel_value=False, drop_path=0.0, mlp_ratio=4.0, qkv_bias=True, qk_scale=None, norm_layer=nn.LayerNorm, downsample=None,
                  ratio=0.25, k=16, out_channels=None):
         super().__init__()
+        self.level = None   # set by StratifiedTransformer (key of this layer's FPS calls in a StratifiedGeometry)
         self.depth, self.grid_size, self.max_window_counts = depth, grid_size, 64
         self.window_size, self.downsample_scale = window_size, downsample_scale
         self.blocks = nn.ModuleList([
@@ -317,27 +431,38 @@ class BasicLayer(nn.Module):
             for i in range(depth)])
         self.downsample = downsample(channel, out_channels, ratio, k) if downsample else None
 
-    def forward(self, feats, xyz, offset):
+    def window_tables(self, xyz, offset, downsample_idx):
+        """The edge tables of this layer's two window partitions (even blocks: plain, odd blocks: shifted by half a window) -- :468-536,
+        which rebuilds them for every block although they depend on the coordinates and the block's parity only.  Per parity:
+        (index_0 sorted, index_1, CSR offsets of index_0, longest row, relative-position table rows of the first block's attention)."""
         window_size = torch.tensor([self.window_size] * 3, dtype=xyz.dtype, device=xyz.device)
         batch = offset2batch(offset)
-        _, p2v_map, counts = grid_sample(xyz, batch, window_size, start=None)
-        _, shift_p2v_map, shift_counts = grid_sample(xyz + 1 / 2 * window_size, batch, window_size, start=xyz.min(0)[0])
-        new_offset = _strided_offsets(offset, lambda n: n // self.downsample_scale + 1)
-        downsample_idx = pointops.furthestsampling(xyz, offset.int(), new_offset.int())
+        xyz_min = xyz.min(0)[0]
         new_window_size = 2 * window_size
-        _, new_p2v_map, new_counts = grid_sample(xyz, batch, new_window_size, start=None)
-        _, shift_new_p2v_map, shift_new_counts = grid_sample(xyz + 1 / 2 * new_window_size, batch, new_window_size, start=xyz.min(0)[0])
-        for i, blk in enumerate(self.blocks):
-            even = i % 2 == 0
-            index_0, index_1 = get_indice_pairs(p2v_map if even else shift_p2v_map, counts if even else shift_counts,
-                                                new_p2v_map if even else shift_new_p2v_map, new_counts if even else shift_new_counts,
-                                                downsample_idx, batch, xyz, window_size, i)
+        parts = {0: grid_sample(xyz, batch, window_size, start=None)[1:] + grid_sample(xyz, batch, new_window_size, start=None)[1:]}
+        if self.depth > 1:
+            parts[1] = (grid_sample(xyz + 1 / 2 * window_size, batch, window_size, start=xyz_min)[1:]
+                        + grid_sample(xyz + 1 / 2 * new_window_size, batch, new_window_size, start=xyz_min)[1:])
+        tables = {}
+        for parity, (p2v, cnt, new_p2v, new_cnt) in parts.items():
+            index_0, index_1 = get_indice_pairs(p2v, cnt, new_p2v, new_cnt, downsample_idx, batch, xyz, window_size, parity)
             index_0, indices = torch.sort(index_0, stable=True)   # CSR by query
             index_1 = index_1[indices]
             index_0_counts = torch.bincount(index_0, minlength=xyz.shape[0])
-            n_max = index_0_counts.max()
+            n_max = int(index_0_counts.max())
             index_0_offsets = torch.cat([index_0_counts.new_zeros(1), index_0_counts.cumsum(dim=-1)], 0)
-            feats = blk(feats, xyz, index_0, index_1, index_0_offsets, n_max)
+            rel_idx = self.blocks[parity].attn.checked_relative_position_index(xyz, index_0, index_1)
+            tables[parity] = (index_0, index_1, index_0_offsets, n_max, rel_idx)
+        return tables
+
+    def forward(self, feats, xyz, offset):
+        g = _ACTIVE_GEOMETRY
+        tables = g.windows.get(self.level) if g is not None else None
+        if tables is None:
+            downsample_idx, _ = _fps(("keys", self.level), xyz, offset, lambda n: n // self.downsample_scale + 1)
+            tables = self.window_tables(xyz, offset, downsample_idx)
+        for i, blk in enumerate(self.blocks):
+            feats = blk(feats, xyz, *tables[i % 2])
         if self.downsample:
             feats_down, xyz_down, offset_down = self.downsample(feats, xyz, offset)
         else:
@@ -421,12 +546,35 @@ class StratifiedTransformer(nn.Module):
                        downsample=TransitionDown if i < num_layers - 1 else None, ratio=ratio, k=k,
                        out_channels=channels[i + 1] if i < num_layers - 1 else None)
             for i in range(self.layer_start, num_layers)])
+        for j, layer in enumerate(self.layers):
+            layer.level = self.layer_start + j
+            if layer.downsample is not None:
+                layer.downsample.level = self.layer_start + j
+        if not stem_transformer:
+            self.downsample.level = "stem"
+        self.geometry_cfg = dict(downsample_scale=downsample_scale, ratio=ratio, num_layers=num_layers, stem_transformer=stem_transformer)
         self.upsamples = nn.ModuleList([Upsample(up_k, channels[i], channels[i - 1]) for i in range(num_layers - 1, 0, -1)])
         self.classifier = nn.Sequential(nn.Linear(channels[0], channels[0]), nn.BatchNorm1d(channels[0]), nn.ReLU(inplace=True),
                                         nn.Linear(channels[0], num_classes))
         self.init_weights()
 
+    def layers_by_level(self):
+        return {layer.level: layer for layer in self.layers}
+
+    def make_geometry(self, coord, offset, offset_host=None):
+        """The batch's StratifiedGeometry (not yet computed): ``.precompute()`` it on any stream ahead of the step and pass it as
+        ``data_dict["st_geometry"]``."""
+        return StratifiedGeometry(coord, offset, offset_host, **self.geometry_cfg)
+
     def forward(self, data_dict):
+        global _ACTIVE_GEOMETRY
+        _ACTIVE_GEOMETRY = data_dict.get("st_geometry") if isinstance(data_dict, dict) else None
+        try:
+            return self._forward(data_dict)
+        finally:
+            _ACTIVE_GEOMETRY = None
+
+    def _forward(self, data_dict):
         from .pseudo_label import radius_neighbors
 
         feats, xyz, offset = data_dict["feat"], data_dict["coord"].contiguous(), data_dict["offset"].int()

@@ -273,7 +273,9 @@ ST_GRADS = ["stem_layer.0.kpconv.weight", "layers.0.blocks.0.attn.qkv.weight", "
 ST_REC_GRADS = ["upsamples.0.linear1.1.weight", "upsamples.2.linear2.1.weight", "confidence.3.weight"]
 
 
-def run_stratified_case(mode, device="cpu"):
+def run_stratified_case(mode, device="cpu", geometry=None):
+    """``geometry``: None = everything inside the forward; "fps" / "windows" = a StratifiedGeometry computed ahead of it."""
+    from pointcloudpdf_amd import stratified  # noqa: F401  (registers ST-v1m1 / ST-v1m1-Recognizer)
     from pointcloudpdf_amd.registry import MODELS
 
     train, dpr = {"train": (True, 0.0), "eval": (False, 0.3)}[mode]
@@ -285,8 +287,13 @@ def run_stratified_case(mode, device="cpu"):
     model, recog = model.to(device), recog.to(device)
     model.train(train); recog.train(train)
     mh = BaseModelHook(ST_HOOKS, clone_tensor=True, exclude_clone={"backbone": ["forward_output"]}).set_model(model)
+    data = dict(coord=batch["coord"], feat=batch["feat"], offset=batch["offset"])
+    if geometry is not None:
+        bb = model.backbone
+        data["st_geometry"] = bb.make_geometry(batch["coord"], batch["offset"], batch["offset_host"]).precompute(
+            bb.layers_by_level() if geometry == "windows" else None)
     with mh:
-        logits = model(dict(coord=batch["coord"], feat=batch["feat"], offset=batch["offset"]))
+        logits = model(data)
         conf = recog(mh)
     out = dict(logits=logits, conf=conf, hooks=mh, model=model, recog=recog)
     if train:

@@ -122,3 +122,37 @@ def test_stratified_training_step_through_the_engine():
     missing = [n for n, p in step.named_parameters() if p.grad is None]
     assert not missing, missing[:5]
     assert all(torch.isfinite(p.grad).all() for p in step.parameters())
+
+
+def test_stratified_prefetched_geometry_is_the_inline_geometry():
+    """StratifiedPrefetcher (worker thread + side stream, one batch ahead) hands the forward the same FPS subsets and window edge
+    tables it would compute itself: the tables are bit-identical to the inline ones, loss and scores of a training step agree to the
+    run-to-run noise of the forward (the fused cross-entropy adds its per-block partial sums with float atomics)."""
+    from pointcloudpdf_amd import engine, stratified, synthetic
+
+    step = engine.OpenSegStep(backbone="ST-v1m1", loss_weight=0.008).cuda()
+    synthetic.fill_parameters_deterministic(step, seed=3)
+    step.train()
+    batches = [synthetic.make_batch([20000, 18000], first_scene_id=60 + 10 * i, device="cuda") for i in range(2)]
+    bb = step.model.backbone
+    pf = stratified.StratifiedPrefetcher(bb)
+    tickets = [pf.submit(b) for b in batches]          # both queued before anything is consumed
+    for b, t in zip(batches, tickets):
+        with torch.random.fork_rng(devices=["cuda"]):
+            torch.manual_seed(5)
+            ref = step(dict(b))
+        geom = pf.get(t)
+        inline = bb.make_geometry(b["coord"], b["offset"]).precompute(bb.layers_by_level())
+        assert set(geom.samples) == set(inline.samples) and set(geom.windows) == set(inline.windows) == {0, 1, 2, 3}
+        for k in inline.samples:
+            assert torch.equal(geom.samples[k][0], inline.samples[k][0]) and torch.equal(geom.samples[k][1], inline.samples[k][1]), k
+        for lv in inline.windows:
+            for parity, tab in inline.windows[lv].items():
+                for x, y in zip(tab, geom.windows[lv][parity]):
+                    assert torch.equal(x, y) if torch.is_tensor(x) else x == y, (lv, parity)
+        with torch.random.fork_rng(devices=["cuda"]):
+            torch.manual_seed(5)
+            out = step(dict(b, st_geometry=geom))
+        assert abs(float(ref["loss"]) - float(out["loss"])) <= 1e-5 * abs(float(ref["loss"]))
+        assert (ref["score"] - out["score"]).abs().max() <= 1e-4 * ref["score"].abs().max()
+    pf.close()

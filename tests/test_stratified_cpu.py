@@ -19,6 +19,21 @@ def test_stratified_model_matches_reference_classes(use_oracle, golden_dir, mode
     helpers.check_stratified_case(mode, out, g)
 
 
+@pytest.mark.parametrize("geometry", ["fps", "windows"])
+def test_stratified_geometry_ahead_of_the_forward_changes_nothing(use_oracle, geometry):
+    """A StratifiedGeometry computed before the forward (FPS chain only, or with the window edge tables) feeds the same indices the
+    forward would compute itself: logits, confidence and loss are bit-identical; gradients to the run-to-run noise of the CPU
+    backward's threaded accumulation (1e-6 between two plain runs)."""
+    a = helpers.run_stratified_case("train")
+    b = helpers.run_stratified_case("train", geometry=geometry)
+    assert torch.equal(a["logits"], b["logits"]) and torch.equal(a["conf"], b["conf"]) and torch.equal(a["loss"], b["loss"])
+    ga, gb = dict(a["model"].named_parameters()), dict(b["model"].named_parameters())
+    for k in ga:
+        if ga[k].grad is not None:
+            assert (ga[k].grad - gb[k].grad).abs().max() <= 1e-5 * (ga[k].grad.abs().max() + 1e-30), k
+    assert len(b["model"].backbone.layers_by_level()) == 4
+
+
 def test_stratified_state_dict_layout_and_registry():
     """Parameter names of the reference classes (checkpoint compatibility) and the registry names of the reference config."""
     assert "ST-v1m1" in MODELS and "ST-v1m1-Recognizer" in MODELS
