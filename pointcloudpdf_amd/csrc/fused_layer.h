@@ -94,10 +94,52 @@ __device__ __forceinline__ void st_u1_stream(float *base, size_t idx, float v, i
     else __builtin_nontemporal_store(v, base + idx);
 }
 
+// ---- partial rows.  Every pass accumulates its BatchNorm sums / parameter gradients per wave in registers; the WPB waves of a block
+// then combine them in LDS (fixed order: deterministic) and the block stores ONE row.  The reducers (k_bn_finalize / k_colsum, ~280
+// launches per step, pure latency) read `grid` rows instead of `grid * WPB`, and the wide weight-gradient rows cost a quarter of the
+// traffic.  `o[col] = v` inside `emit` writes the wave's value of column `col`.
+struct RowRef {
+    float *p; bool add;
+    __device__ __forceinline__ void operator=(float v) const { *p = add ? *p + v : v; }
+};
+struct RowAcc {
+    float *row; bool add;
+    __device__ __forceinline__ RowRef operator[](size_t i) const { return RowRef{row + i, add}; }
+};
+// `stage`: WPB * width floats of LDS the pass no longer needs.  All waves write their rows at once, then every column is summed in wave
+// order into row 0.
+template <typename F>
+__device__ __forceinline__ void block_row(float *stage, int width, F &&emit) {
+    __syncthreads();
+    emit(RowAcc{stage + (threadIdx.x >> 6) * width, false});
+    __syncthreads();
+    for (int e = threadIdx.x; e < width; e += 64 * WPB) {
+        float v = stage[e];
+#pragma unroll
+        for (int w = 1; w < WPB; ++w) v += stage[w * width + e];
+        stage[e] = v;
+    }
+    __syncthreads();
+}
+// `stage`: width floats only (rows too wide for WPB copies): wave 0 stores, waves 1.. add, one after the other.
+template <typename F>
+__device__ __forceinline__ void block_row_seq(float *stage, F &&emit) {
+    const int wv = threadIdx.x >> 6;
+    __syncthreads();
+#pragma unroll 1
+    for (int w = 0; w < WPB; ++w) {
+        if (wv == w) emit(RowAcc{stage, w > 0});
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ void store_row(const float *stage, int width, float *dst) {
+    for (int e = threadIdx.x; e < width; e += 64 * WPB) dst[e] = stage[e];
+}
+
 }  // namespace fl
 
 namespace flm {
-// matrix-core variants (fused_layer_mfma.hip); `grid` blocks of 64 * WPB threads, partial rows = grid * WPB
+// matrix-core variants (fused_layer_mfma.hip); `grid` blocks of 64 * WPB threads, partial rows = grid
 bool supported(int nsample, int c);
 void launch_p2(const fl::LayerArgs &A, int c, int grid, hipStream_t s);
 void launch_p3(const fl::LayerArgs &A, int c, bool stats, int grid, hipStream_t s);

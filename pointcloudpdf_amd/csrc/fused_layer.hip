@@ -20,6 +20,7 @@
 // stride 33); weights are wave-uniform and arrive through the scalar cache; per-channel statistics are reduced through
 // the same LDS tile read column-wise.  HBM-bound by design (algorithmic bytes: q,k,v rows once + p + idx + out).
 #include "fused_layer.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace fl {
@@ -51,14 +52,19 @@ __device__ __forceinline__ void wave_sync() {
 // Gather 32 channels [c0, c0+32) of the 64 rows listed in L.rowid into L.tile (coalesced: 8 lanes x 16 B per row).
 __device__ __forceinline__ void stage_rows(const WaveLds &L, const float *__restrict__ table, int C, int c0, int lane) {
     const int sub = lane >> 3, col = (lane & 7) * 4;
+    // all eight gathers in flight at once: clamped address + select (a load under `if (src >= 0)` gets its own branch and wait,
+    // which serialised the eight round trips of every staged chunk)
+    int src[8];
+    float4 v[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) src[t] = L.rowid[t * 8 + sub];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t] = *reinterpret_cast<const float4 *>(table + (size_t)max(src[t], 0) * C + c0 + col);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        const int row = t * 8 + sub;
-        const int src = L.rowid[row];
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (src >= 0) v = *reinterpret_cast<const float4 *>(table + (size_t)src * C + c0 + col);
-        float *d = L.tile + row * L.ts + col;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        float *d = L.tile + (t * 8 + sub) * L.ts + col;
+        const bool ok = src[t] >= 0;
+        d[0] = ok ? v[t].x : 0.f; d[1] = ok ? v[t].y : 0.f; d[2] = ok ? v[t].z : 0.f; d[3] = ok ? v[t].w : 0.f;
     }
 }
 
@@ -67,10 +73,10 @@ template <int PPT>
 __device__ __forceinline__ void stage_points(const WaveLds &L, const float *__restrict__ table, int C, int c0, int i0, int N, int lane) {
     if (lane < PPT * 8) {
         const int pt = lane >> 3, col = (lane & 7) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i0 + pt < N) v = *reinterpret_cast<const float4 *>(table + (size_t)(i0 + pt) * C + c0 + col);
+        const bool ok = i0 + pt < N;
+        const float4 v = *reinterpret_cast<const float4 *>(table + (size_t)(ok ? i0 + pt : N - 1) * C + c0 + col);
         float *d = L.qtile + pt * L.ts + col;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        d[0] = ok ? v.x : 0.f; d[1] = ok ? v.y : 0.f; d[2] = ok ? v.z : 0.f; d[3] = ok ? v.w : 0.f;
     }
 }
 
@@ -88,12 +94,15 @@ __device__ __forceinline__ Row load_row(const LayerArgs &A, long tile, int lane)
     R.valid = row < (long)A.N * K;
     R.row = (int)row;
     R.i = (int)(row / K);
-    R.nb = R.valid ? A.idx[row] : -1;
-    R.rel[0] = R.rel[1] = R.rel[2] = 0.f;
-    if (R.nb >= 0) {
+    const long rowc = R.valid ? row : (long)A.N * K - 1;   // (clamped addresses + selects: no loads under a branch)
+    const int nb = A.idx[rowc];
+    R.nb = R.valid ? nb : -1;
+    const size_t nbc = (size_t)max(R.nb, 0), ic = (size_t)(rowc / K);
+    float pn[3], pi[3];
 #pragma unroll
-        for (int b = 0; b < 3; ++b) R.rel[b] = A.p[(size_t)R.nb * 3 + b] - A.p[(size_t)R.i * 3 + b];
-    }
+    for (int b = 0; b < 3; ++b) { pn[b] = A.p[nbc * 3 + b]; pi[b] = A.p[ic * 3 + b]; }
+#pragma unroll
+    for (int b = 0; b < 3; ++b) R.rel[b] = R.nb >= 0 ? pn[b] - pi[b] : 0.f;
 #pragma unroll
     for (int a = 0; a < 3; ++a)
         R.t1[a] = R.rel[0] * A.Wp1[a * 3 + 0] + R.rel[1] * A.Wp1[a * 3 + 1] + R.rel[2] * A.Wp1[a * 3 + 2] + A.bp1[a];
@@ -160,10 +169,11 @@ __global__ __launch_bounds__(64 * WPB) void k_p1(LayerArgs A) {
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) { s[a] = pdf_wave_sum_f32(s[a]); ss[a] = pdf_wave_sum_f32(ss[a]); }
-    if (lane == 0) {
-        float *o = A.partial + wave_g * 6;
-        o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = ss[0]; o[4] = ss[1]; o[5] = ss[2];
-    }
+    __shared__ float stage[WPB * 8];
+    block_row(stage, 8, [&](RowAcc o) {
+        if (lane == 0) { o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = ss[0]; o[4] = ss[1]; o[5] = ss[2]; }
+    });
+    store_row(stage, 6, A.partial + (size_t)blockIdx.x * 6);
 }
 
 // r chunk of one row: needs the staged xk chunk (tile) and xq chunk (qtile)
@@ -209,15 +219,15 @@ __global__ __launch_bounds__(64 * WPB) void k_p2(LayerArgs A) {
             wave_sync();
         }
     }
-    // partial layout per wave: [sum(C) | sumsq(C)]
+    // partial row layout: [sum(C) | sumsq(C)]
+    block_row(lds, 2 * C, [&](RowAcc o) {
 #pragma unroll
-    for (int q = 0; q < NCH; ++q) {
-        const float a = s[q] + __shfl_xor(s[q], 32, 64), b = ss[q] + __shfl_xor(ss[q], 32, 64);
-        if (lane < 32) {
-            A.partial[wave_g * 2 * C + q * 32 + lane] = a;
-            A.partial[wave_g * 2 * C + C + q * 32 + lane] = b;
+        for (int q = 0; q < NCH; ++q) {
+            const float a = s[q] + __shfl_xor(s[q], 32, 64), b = ss[q] + __shfl_xor(ss[q], 32, 64);
+            if (lane < 32) { o[q * 32 + lane] = a; o[C + q * 32 + lane] = b; }
         }
-    }
+    });
+    store_row(lds, 2 * C, A.partial + (size_t)blockIdx.x * 2 * C);
 }
 
 // ------------------------------------------------------------------------------------------------ P3: h (+ stats)
@@ -275,15 +285,15 @@ __global__ __launch_bounds__(64 * WPB) void k_p3(LayerArgs A) {
         }
     }
     if (STATS) {
+        block_row(lds, 2 * CS, [&](RowAcc o) {
 #pragma unroll
-        for (int hh = 0; hh < NH; ++hh) {
-            const float a = s[hh] + __shfl_xor(s[hh], 32, 64), b = ss[hh] + __shfl_xor(ss[hh], 32, 64);
-            const int ch = hh * 32 + lane;
-            if (lane < 32 && ch < CS) {
-                A.partial[wave_g * 2 * CS + ch] = a;
-                A.partial[wave_g * 2 * CS + CS + ch] = b;
+            for (int hh = 0; hh < NH; ++hh) {
+                const float a = s[hh] + __shfl_xor(s[hh], 32, 64), b = ss[hh] + __shfl_xor(ss[hh], 32, 64);
+                const int ch = hh * 32 + lane;
+                if (lane < 32 && ch < CS) { o[ch] = a; o[CS + ch] = b; }
             }
-        }
+        });
+        store_row(lds, 2 * CS, A.partial + (size_t)blockIdx.x * 2 * CS);
     }
 }
 
@@ -510,17 +520,20 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
         }
         wave_sync();
     }
-    float *o = A.partial + wave_g * W;
+    auto emit = [&](RowAcc o) {
 #pragma unroll
-    for (int c = 0; c < CS; ++c) {
-        const float a = pdf_wave_sum_f32(sg[c]), b = pdf_wave_sum_f32(sgh[c]), d = pdf_wave_sum_f32(sgz[c]);
-        if (lane == 0) { o[c] = a; o[CS + c] = b; o[2 * CS + c] = d; }
-    }
+        for (int c = 0; c < CS; ++c) {
+            const float a = pdf_wave_sum_f32(sg[c]), b = pdf_wave_sum_f32(sgh[c]), d = pdf_wave_sum_f32(sgz[c]);
+            if (lane == 0) { o[c] = a; o[CS + c] = b; o[2 * CS + c] = d; }
+        }
 #pragma unroll
-    for (int m = 0; m < NW2; ++m) {
-        const int e = m * 64 + lane;
-        if (e < CS * CS) o[3 * CS + e] = aw2[m];
-    }
+        for (int m = 0; m < NW2; ++m) {
+            const int e = m * 64 + lane;
+            if (e < CS * CS) o[3 * CS + e] = aw2[m];
+        }
+    };
+    if constexpr (W <= lds_floats_per_wave(C, true)) block_row(lds, W, emit); else block_row_seq(lds, emit);   // (WPB rows fit the tiles' LDS?)
+    store_row(lds, W, A.partial + (size_t)blockIdx.x * W);
 }
 
 // g_h of one row from the stored G2 / H rows and the BN2-backward sums
@@ -633,19 +646,22 @@ __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
             wave_sync();
         }
     }
-    float *o = A.partial + wave_g * W;
+    auto emit = [&](RowAcc o) {
 #pragma unroll
-    for (int q = 0; q < NCH; ++q) {
-        const float a = sg[q] + __shfl_xor(sg[q], 32, 64), b = sgr[q] + __shfl_xor(sgr[q], 32, 64);
-        if (lane < 32) { o[q * 32 + lane] = a; o[C + q * 32 + lane] = b; }
+        for (int q = 0; q < NCH; ++q) {
+            const float a = sg[q] + __shfl_xor(sg[q], 32, 64), b = sgr[q] + __shfl_xor(sgr[q], 32, 64);
+            if (lane < 32) { o[q * 32 + lane] = a; o[C + q * 32 + lane] = b; }
 #pragma unroll
-        for (int m = 0; m < CS / 2; ++m) o[2 * C + CS + (size_t)(2 * m + (lane >> 5)) * C + q * 32 + (lane & 31)] = aw1[q][m];
-    }
+            for (int m = 0; m < CS / 2; ++m) o[2 * C + CS + (size_t)(2 * m + (lane >> 5)) * C + q * 32 + (lane & 31)] = aw1[q][m];
+        }
 #pragma unroll
-    for (int hh = 0; hh < NH; ++hh) {
-        const float hsum = sgh[hh] + __shfl_xor(sgh[hh], 32, 64);
-        if (lane < 32 && hh * 32 + lane < CS) o[2 * C + hh * 32 + lane] = hsum;
-    }
+        for (int hh = 0; hh < NH; ++hh) {
+            const float hsum = sgh[hh] + __shfl_xor(sgh[hh], 32, 64);
+            if (lane < 32 && hh * 32 + lane < CS) o[2 * C + hh * 32 + lane] = hsum;
+        }
+    };
+    if constexpr (W <= lds_floats_per_wave(C, true)) block_row(lds, W, emit); else block_row_seq(lds, emit);   // (WPB rows fit the tiles' LDS?)
+    store_row(lds, W, A.partial + (size_t)blockIdx.x * W);
 }
 
 template <int C, int K>
@@ -671,7 +687,14 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
             A2.sums = A.sums2;
             hidden_grad<C>(A2, R, gh);
         }
-        attn_weights<CS, K>(A, R, w);
+        {   // softmax weights of the row: stored by B1 (Wsm) -- read back instead of redoing BN2, Linear(CS, CS) and the softmax
+            const size_t src = (size_t)(R.valid ? R.row : 0) * CS;
+#pragma unroll
+            for (int o = 0; o < CS; o += 4) {
+                const float4 v = ld_u4(A.Wsm, src + o, A.bf16);
+                w[o] = v.x; w[o + 1] = v.y; w[o + 2] = v.z; w[o + 3] = v.w;
+            }
+        }
         L.rowid[lane] = R.nb;
         // t1n tile for the Wp2 gradient
         L.aux[lane * L.as + 0] = R.valid ? t1n[0] : 0.f;
@@ -750,23 +773,26 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
             dst[0] = gyp[0]; dst[1] = gyp[1]; dst[2] = gyp[2];
         }
     }
-    float *o = A.partial + wave_g * W;
+    auto emit = [&](RowAcc o) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float x = pdf_wave_sum_f32(sgp[a]), y = pdf_wave_sum_f32(sgpt[a]);
-        if (lane == 0) { o[a] = x; o[3 + a] = y; }
-    }
-    if (lane == 0) { o[6] = 0.f; o[7] = 0.f; }
-#pragma unroll
-    for (int q = 0; q < NCH; ++q) {
-        const float a = sbp2[q] + __shfl_xor(sbp2[q], 32, 64);
-        if (lane < 32) o[8 + q * 32 + lane] = a;
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int e = m * 64 + lane;
-            if (e < 96) o[8 + C + (size_t)q * 96 + e] = awp2[q][m];  // == [(q*32 + c)*3 + a]
+        for (int a = 0; a < 3; ++a) {
+            const float x = pdf_wave_sum_f32(sgp[a]), y = pdf_wave_sum_f32(sgpt[a]);
+            if (lane == 0) { o[a] = x; o[3 + a] = y; }
         }
-    }
+        if (lane == 0) { o[6] = 0.f; o[7] = 0.f; }
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const float a = sbp2[q] + __shfl_xor(sbp2[q], 32, 64);
+            if (lane < 32) o[8 + q * 32 + lane] = a;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int e = m * 64 + lane;
+                if (e < 96) o[8 + C + (size_t)q * 96 + e] = awp2[q][m];  // == [(q*32 + c)*3 + a]
+            }
+        }
+    };
+    if constexpr (W <= lds_floats_per_wave(C, true)) block_row(lds, W, emit); else block_row_seq(lds, emit);   // (WPB rows fit the tiles' LDS?)
+    store_row(lds, W, A.partial + (size_t)blockIdx.x * W);
 }
 
 template <int K>
@@ -790,39 +816,57 @@ __global__ __launch_bounds__(64 * WPB) void k_b4(LayerArgs A) {
             for (int b = 0; b < 3; ++b) acc[3 + a * 3 + b] += gt1 * R.rel[b];
         }
     }
-    float *o = A.partial + wave_g * b4_width();
+    __shared__ float stage[WPB * 16];
+    block_row(stage, 16, [&](RowAcc o) {
 #pragma unroll
-    for (int e = 0; e < 12; ++e) {
-        const float v = pdf_wave_sum_f32(acc[e]);
-        if (lane == 0) o[e] = v;
-    }
-    if (lane == 0) { o[12] = 0.f; o[13] = 0.f; o[14] = 0.f; o[15] = 0.f; }
+        for (int e = 0; e < 12; ++e) {
+            const float v = pdf_wave_sum_f32(acc[e]);
+            if (lane == 0) o[e] = v;
+        }
+        if (lane == 0) { o[12] = 0.f; o[13] = 0.f; o[14] = 0.f; o[15] = 0.f; }
+    });
+    store_row(stage, b4_width(), A.partial + (size_t)blockIdx.x * b4_width());
 }
 
 // out[col] = sum_rows partial[row][col]   (double accumulation, deterministic)
-// block = 16 columns x RED_RL row-lanes; every row-lane sums a strided subset of the rows with four independent chains
-// (the loads are what costs: ~2000 partial rows, so the row dimension gets 64 lanes and 4-deep load pipelining).
-constexpr int RED_RL = 64, RED_THREADS = 16 * RED_RL;
+// block = 16 columns x RED_RL row-lanes; every row-lane sums a strided subset of the rows.  These kernels are pure latency (a few
+// hundred KB read by 4 .. 64 workgroups, ~280 launches per step): every lane keeps RED_B independent loads in flight, so ~2,000 partial
+// rows cost two memory round trips instead of eight.
+constexpr int RED_RL = 64, RED_THREADS = 16 * RED_RL, RED_B = 16;
+__device__ __forceinline__ double strided_sum(const float *__restrict__ src, size_t stride, int rl, int rows) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int r = rl; r < rows; r += RED_B * RED_RL) {
+        float v[RED_B];
+        // (clamped address + select afterwards: a load under a condition gets its own branch and wait, which serialises the batch)
+#pragma unroll
+        for (int t = 0; t < RED_B; ++t) v[t] = src[(size_t)min(r + t * RED_RL, rows - 1) * stride];
+#pragma unroll
+        for (int t = 0; t < RED_B; ++t) v[t] = (r + t * RED_RL < rows) ? v[t] : 0.f;
+#pragma unroll
+        for (int t = 0; t < RED_B; t += 4) { s0 += (double)v[t]; s1 += (double)v[t + 1]; s2 += (double)v[t + 2]; s3 += (double)v[t + 3]; }
+    }
+    return (s0 + s1) + (s2 + s3);
+}
+
+// sum over the 4 row-lanes of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48 share a column)
+__device__ __forceinline__ double wave_rows_sum(double v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+constexpr int RED_WAVES = RED_THREADS / 64;
+
 __global__ __launch_bounds__(RED_THREADS) void k_colsum(const float *__restrict__ partial, int rows, int width, float *__restrict__ out) {
-    __shared__ double red[RED_RL][17];
+    __shared__ double red[RED_WAVES][17];
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int col = blockIdx.x * 16 + cl;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    if (col < width) {
-        const float *src = partial + col;
-        int r = rl;
-        for (; r + 3 * RED_RL < rows; r += 4 * RED_RL) {
-            const float a = src[(size_t)r * width], b = src[(size_t)(r + RED_RL) * width];
-            const float c = src[(size_t)(r + 2 * RED_RL) * width], d = src[(size_t)(r + 3 * RED_RL) * width];
-            s0 += (double)a; s1 += (double)b; s2 += (double)c; s3 += (double)d;
-        }
-        for (; r < rows; r += RED_RL) s0 += (double)src[(size_t)r * width];
-    }
-    red[rl][cl] = (s0 + s1) + (s2 + s3);
+    const double v = wave_rows_sum(col < width ? strided_sum(partial + col, (size_t)width, rl, rows) : 0.0);
+    if ((threadIdx.x & 63) < 16) red[threadIdx.x >> 6][cl] = v;
     __syncthreads();
     if (rl != 0 || col >= width) return;
     double s = 0.0;
-    for (int k = 0; k < RED_RL; ++k) s += red[k][cl];
+#pragma unroll
+    for (int k = 0; k < RED_WAVES; ++k) s += red[k][cl];
     out[col] = (float)s;
 }
 
@@ -834,26 +878,17 @@ __global__ __launch_bounds__(RED_THREADS) void k_bn_finalize(const float *__rest
                               float *__restrict__ running_mean, float *__restrict__ running_var,
                               float *__restrict__ scale, float *__restrict__ shift, float *__restrict__ mean_out,
                               float *__restrict__ rstd_out) {
-    __shared__ double red[2][RED_RL][17];
+    __shared__ double red[2][RED_WAVES][17];
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int ch = blockIdx.x * 16 + cl;
-    double s0 = 0.0, s1 = 0.0, q0 = 0.0, q1 = 0.0;
-    if (ch < nch) {
-        const float *src = partial + ch;
-        const size_t w = 2 * (size_t)nch;
-        int r = rl;
-        for (; r + RED_RL < rows; r += 2 * RED_RL) {
-            const float a = src[r * w], b = src[(r + RED_RL) * w], c = src[r * w + nch], d = src[(r + RED_RL) * w + nch];
-            s0 += (double)a; s1 += (double)b; q0 += (double)c; q1 += (double)d;
-        }
-        for (; r < rows; r += RED_RL) { s0 += (double)src[r * w]; q0 += (double)src[r * w + nch]; }
-    }
-    red[0][rl][cl] = s0 + s1;
-    red[1][rl][cl] = q0 + q1;
+    const double a = wave_rows_sum(ch < nch ? strided_sum(partial + ch, 2 * (size_t)nch, rl, rows) : 0.0);
+    const double b = wave_rows_sum(ch < nch ? strided_sum(partial + nch + ch, 2 * (size_t)nch, rl, rows) : 0.0);
+    if ((threadIdx.x & 63) < 16) { red[0][threadIdx.x >> 6][cl] = a; red[1][threadIdx.x >> 6][cl] = b; }
     __syncthreads();
     if (rl != 0 || ch >= nch) return;
     double s = 0.0, ss = 0.0;
-    for (int k = 0; k < RED_RL; ++k) { s += red[0][k][cl]; ss += red[1][k][cl]; }
+#pragma unroll
+    for (int k = 0; k < RED_WAVES; ++k) { s += red[0][k][cl]; ss += red[1][k][cl]; }
     const double mean = s / count;
     double var = ss / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -915,6 +950,16 @@ static inline int grid_for_points(long n, int cap) {
     return (int)g;
 }
 
+// Per-pass grids of the matrix-core passes (one point per wave and trip).  The passes differ in what a resident block costs: P3 / B3 / B1
+// write short partial rows (2 C/8, 8 + 4 C, 3 C/8 + (C/8)^2 floats per wave) and gain from more waves per SIMD; B2's partial row holds a
+// (C/8) x C weight-gradient block per wave, so its grid stays small.  PDFOPS_PT_CAP_<pass> overrides the default cap.
+enum Pass { P3 = 0, B1 = 1, B2 = 2, B3 = 3 };
+static inline int pass_grid(Pass pass, long n, int dflt_cap) {
+    static const int env_cap[4] = {env_blocks("PDFOPS_PT_CAP_P3", 0), env_blocks("PDFOPS_PT_CAP_B1", 0), env_blocks("PDFOPS_PT_CAP_B2", 0),
+                                   env_blocks("PDFOPS_PT_CAP_B3", 0)};   // (read once per process, like the other PDFOPS_PT_* caps)
+    return grid_for_points(n, env_cap[pass] > 0 ? env_cap[pass] : dflt_cap);
+}
+
 static inline int grid_for_tiles(long ntiles) {
     static const int cap = env_blocks("PDFOPS_PT_BLOCKS_FWD", MAX_BLOCKS);
     long g = (ntiles + WPB - 1) / WPB;
@@ -949,7 +994,6 @@ int forward_impl(LayerArgs A, int training, float eps, float momentum, const flo
     const long rows = (long)A.N * K;
     const long ntiles = (rows + 63) / 64;
     const int grid = flm::supported(K, C) ? grid_for_points(A.N, MAX_BLOCKS) : grid_for_tiles(ntiles);
-    const int nw = grid * WPB;
     const size_t lds = (size_t)WPB * lds_floats_per_wave(C, false) * sizeof(float);
     float *sp = bn, *tp = bn + 3, *s1 = bn + 6, *t1 = bn + 6 + C, *s2 = bn + 6 + 2 * C, *t2 = bn + 6 + 2 * C + CS;
     A.sp = as_const(sp); A.tp = as_const(tp); A.s1 = as_const(s1); A.t1 = as_const(t1); A.s2 = as_const(s2); A.t2 = as_const(t2);
@@ -971,12 +1015,13 @@ int forward_impl(LayerArgs A, int training, float eps, float momentum, const flo
     allow_lds(k_p3<C, K, true>, lds);
     allow_lds(k_p4<C, K>, lds);
     k_p1<K><<<grid, 64 * WPB, 0, s>>>(A);
-    k_bn_finalize<<<1, RED_THREADS, 0, s>>>(A.partial, nw, 3, (double)rows, bn_params[0], bn_params[1], eps, momentum, bn_buffers[0], bn_buffers[1], sp, tp, mp, rp);
+    k_bn_finalize<<<1, RED_THREADS, 0, s>>>(A.partial, grid, 3, (double)rows, bn_params[0], bn_params[1], eps, momentum, bn_buffers[0], bn_buffers[1], sp, tp, mp, rp);
     if (flm::supported(K, C)) flm::launch_p2(A, C, grid, s); else k_p2<C, K><<<grid, 64 * WPB, lds, s>>>(A);
-    k_bn_finalize<<<pdf_divup(C, 16), RED_THREADS, 0, s>>>(A.partial, nw, C, (double)rows, bn_params[2], bn_params[3], eps, momentum, bn_buffers[2], bn_buffers[3], s1, t1, m1, r1);
-    if (flm::supported(K, C)) flm::launch_p3(A, C, true, grid, s);
+    k_bn_finalize<<<pdf_divup(C, 16), RED_THREADS, 0, s>>>(A.partial, grid, C, (double)rows, bn_params[2], bn_params[3], eps, momentum, bn_buffers[2], bn_buffers[3], s1, t1, m1, r1);
+    int nw3 = grid;   // (P3's partial rows are 2 C/8 floats: a larger grid than P2's fits the same scratch)
+    if (flm::supported(K, C)) { const int g3 = pass_grid(P3, A.N, C <= 256 ? 2 * MAX_BLOCKS : MAX_BLOCKS); nw3 = g3; flm::launch_p3(A, C, true, g3, s); }
     else k_p3<C, K, true><<<grid, 64 * WPB, lds, s>>>(A);
-    k_bn_finalize<<<pdf_divup(CS, 16), RED_THREADS, 0, s>>>(A.partial, nw, CS, (double)rows, bn_params[4], bn_params[5], eps, momentum, bn_buffers[4], bn_buffers[5], s2, t2, m2, r2);
+    k_bn_finalize<<<pdf_divup(CS, 16), RED_THREADS, 0, s>>>(A.partial, nw3, CS, (double)rows, bn_params[4], bn_params[5], eps, momentum, bn_buffers[4], bn_buffers[5], s2, t2, m2, r2);
     if (flm::supported(K, C)) flm::launch_p4(A, C, grid, s); else k_p4<C, K><<<grid, 64 * WPB, lds, s>>>(A);
     return pdf_launch_status();
 }
@@ -1001,7 +1046,7 @@ int backward_impl(LayerArgs A, float *sums, const int *inv_off, const int *inv_e
     constexpr int CS = C / 8;
     const long rows = (long)A.N * K;
     const long ntiles = (rows + 63) / 64;
-    const int grid = flm::supported(K, C) ? grid_for_points(A.N, C <= 128 ? 2 * MAX_BLOCKS_BWD : MAX_BLOCKS_BWD) : grid_for_tiles_bwd(ntiles, C), nw = grid * WPB;
+    const int grid = flm::supported(K, C) ? grid_for_points(A.N, C <= 128 ? 2 * MAX_BLOCKS_BWD : MAX_BLOCKS_BWD) : grid_for_tiles_bwd(ntiles, C);
     const size_t lds = (size_t)WPB * lds_floats_per_wave(C, true) * sizeof(float);
     A.inv_rows = (float)(1.0 / (double)rows);
     // sums layout (floats): [S1: b1_width | S2: b2_width | S3: b3_width | S4: 16 | X: 2C + 2CS scratch for B3]
@@ -1010,23 +1055,27 @@ int backward_impl(LayerArgs A, float *sums, const int *inv_off, const int *inv_e
     allow_lds(k_b2<C, K>, lds);
     allow_lds(k_b3<C, K>, lds);
     const bool mfma = flm::supported(K, C);
-    if (mfma) flm::launch_b1(A, C, grid, s); else k_b1<C, K><<<grid, 64 * WPB, lds, s>>>(A);
-    k_colsum<<<pdf_divup(b1_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, nw, b1_width<C>(), S1);
+    // (the scratch is sized for B2's rows at `grid`; B1 / B3 rows are shorter, so more waves fit)
+    int g1 = mfma ? pass_grid(B1, A.N, grid) : grid, g3 = mfma ? pass_grid(B3, A.N, C == 256 ? 2 * grid : (C == 64 ? 4 * grid : grid)) : grid;
+    g1 = (int)std::min<long>(g1, (long)grid * b2_width<C>() / b1_width<C>());
+    g3 = (int)std::min<long>(g3, (long)grid * b2_width<C>() / b3_width<C>());
+    if (mfma) flm::launch_b1(A, C, g1, s); else k_b1<C, K><<<grid, 64 * WPB, lds, s>>>(A);
+    k_colsum<<<pdf_divup(b1_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, g1, b1_width<C>(), S1);
     // g_xv[nb, c] = sum over the entries (i, j) with idx[i, j] == nb of g_out[i, c] * w[i, j, c mod C/8]   (no atomics, fixed order)
     int rc = pdf_seg_sum_weighted_x(A.N, C, K, CS, A.gout, A.Wsm, A.bf16, inv_off, inv_entry, entry_base, gather_order, A.gxv, s);   // (destinations in Morton order: the g_out rows they share hit L2)
     if (rc != PDF_OK) return rc;
     A.sums = as_const(S1);
     if (mfma) flm::launch_b2(A, C, grid, s); else k_b2<C, K><<<grid, 64 * WPB, lds, s>>>(A);
-    k_colsum<<<pdf_divup(b2_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, nw, b2_width<C>(), S2);
+    k_colsum<<<pdf_divup(b2_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, grid, b2_width<C>(), S2);
     A.sums = as_const(S2);   // B3: BN1-backward terms from B2, BN2-backward terms from B1
     A.sums2 = as_const(S1);
-    if (mfma) flm::launch_b3(A, C, grid, s); else k_b3<C, K><<<grid, 64 * WPB, lds, s>>>(A);
-    k_colsum<<<pdf_divup(b3_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, nw, b3_width<C>(), S3);
+    if (mfma) flm::launch_b3(A, C, g3, s); else k_b3<C, K><<<grid, 64 * WPB, lds, s>>>(A);
+    k_colsum<<<pdf_divup(b3_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, g3, b3_width<C>(), S3);
     rc = pdf_seg_sum_rows_x(A.N, C, A.GR, C, A.bf16, inv_off, inv_entry, entry_base, 1.0f, A.gxk, s);   // g_xk[nb] = sum of the g_r rows that gathered nb
     if (rc != PDF_OK) return rc;
     A.sums = as_const(S3);
     k_b4<K><<<grid, 64 * WPB, 0, s>>>(A);
-    k_colsum<<<1, RED_THREADS, 0, s>>>(A.partial, nw, b4_width(), S4);
+    k_colsum<<<1, RED_THREADS, 0, s>>>(A.partial, grid, b4_width(), S4);
     return pdf_launch_status();
 }
 
@@ -1062,6 +1111,7 @@ extern "C" int pdf_pt_layer_backward(int n, int nsample, int c, const float *xq,
         !G2 || !G3 || !Wsm || !GR || !inv_off || !inv_entry || !partial || !sums)
         return PDF_ERR_BAD_ARG;
     if (!pdf_pt_layer_supported(nsample, c)) return PDF_ERR_UNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(weights[4]) & 15) return PDF_ERR_BAD_ARG;   // Ww1 is staged in 16-byte pieces
     const int cs = c / 8;
     fl::LayerArgs A;
     A.N = n; A.xq = xq; A.xk = xk; A.xv = xv; A.p = p; A.idx = idx;
@@ -1100,6 +1150,7 @@ extern "C" int pdf_pt_layer_forward(int n, int nsample, int c, const float *xq, 
         return PDF_ERR_BAD_ARG;
     if (!pdf_pt_layer_supported(nsample, c)) return PDF_ERR_UNSUPPORTED;
     if (training && !saved) return PDF_ERR_BAD_ARG;
+    if (reinterpret_cast<uintptr_t>(weights[4]) & 15) return PDF_ERR_BAD_ARG;   // Ww1 is staged in 16-byte pieces
     fl::LayerArgs A;
     A.N = n; A.xq = xq; A.xk = xk; A.xv = xv; A.p = p; A.idx = idx;
     using fl::as_const;

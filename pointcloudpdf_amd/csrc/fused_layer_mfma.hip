@@ -14,6 +14,7 @@
 //      (hidden unit 4 (l >> 4) + reg, row l & 15) is again "4 consecutive values per lane": float4 stores of h.
 //   Column statistics (sums over rows) are per-lane accumulators reduced over the 16 row-lanes once per kernel.
 #include "fused_layer.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace flm {
@@ -21,6 +22,9 @@ namespace flm {
 using fl::cfloat_p;
 using fl::LayerArgs;
 using fl::WPB;
+using fl::RowAcc;
+using fl::block_row;
+using fl::store_row;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 bool supported(int nsample, int c) {
@@ -63,20 +67,74 @@ __device__ __forceinline__ void wave_sync() {
 constexpr int TS = 68;
 __host__ __device__ constexpr int w2_floats(int c) { return csp_of(c) * (csp_of(c) + 4); }
 
-template <int C>
-__device__ __forceinline__ void stage_consts(float *cst, const LayerArgs &A, bool with_bn1) {
-    for (int e = threadIdx.x; e < 3 * C; e += 64 * WPB) cst[e] = gp(A.Wp2)[e];
-    for (int e = threadIdx.x; e < C; e += 64 * WPB) {
-        cst[3 * C + e] = gp(A.bp2)[e];
-        if (with_bn1) { cst[4 * C + e] = gp(A.s1)[e]; cst[5 * C + e] = gp(A.t1)[e]; }
+// ---- staging (global -> LDS).  Every helper issues ALL of a thread's global loads before its first LDS store: written as the
+// obvious `for (e ...) lds[e] = global[e]` loop the compiler keeps load -> store pairs in order and a block pays one L2 round trip
+// per iteration -- 16 per 64-channel Ww1 slab, ~10 us per chunk at C >= 256, which was most of k_b3 / k_b2 at levels 4 and 5
+// (3,124 / 780 points: one to three points per wave, the staging is not amortised).
+constexpr int NT = 64 * WPB;
+// (loads use a clamped index and the select happens afterwards: a load under a condition gets its own branch and wait)
+template <int N>
+__device__ __forceinline__ void stage_copy(float *dst, const float *src) {   // dst[e] = src[e], e < N
+    constexpr int PER = (N + NT - 1) / NT;
+    float v[PER];
+#pragma unroll
+    for (int t = 0; t < PER; ++t) v[t] = src[min((int)threadIdx.x + NT * t, N - 1)];
+#pragma unroll
+    for (int t = 0; t < PER; ++t) { const int e = threadIdx.x + NT * t; if (e < N) dst[e] = v[t]; }
+}
+// dst[r * WS + c] = r < rows_valid ? src[r * src_stride + c] : 0 for r < ROWS, c < COLS (float4 pieces; COLS, WS, src_stride % 4 == 0,
+// 16-byte aligned src -- checked at the C entry points)
+template <int ROWS, int COLS, int WS>
+__device__ __forceinline__ void stage_rows(float *dst, const float *src, int src_stride, int rows_valid) {
+    constexpr int Q = COLS / 4, N4 = ROWS * Q, PER = (N4 + NT - 1) / NT, B = PER > 8 ? 8 : PER;
+#pragma unroll 1
+    for (int t0 = 0; t0 < PER; t0 += B) {
+        f32x4 v[B];
+#pragma unroll
+        for (int t = 0; t < B; ++t) {
+            const int e = threadIdx.x + NT * (t0 + t), r = min(e / Q, rows_valid - 1), c4 = e % Q;
+            v[t] = ld4(src + (size_t)r * src_stride + 4 * c4);
+        }
+#pragma unroll
+        for (int t = 0; t < B; ++t) {
+            const int e = threadIdx.x + NT * (t0 + t), r = e / Q, c4 = e % Q;
+            if (e < N4) st4(dst + r * WS + 4 * c4, r < rows_valid ? v[t] : zero4());
+        }
     }
 }
 template <int C>
-__device__ __forceinline__ void stage_w2(float *w2, const LayerArgs &A) {
-    constexpr int CS = C / 8, CSP = csp_of(C);
-    for (int e = threadIdx.x; e < CSP * (CSP + 4); e += 64 * WPB) {
-        const int o = e / (CSP + 4), u = e % (CSP + 4);
-        w2[e] = (o < CS && u < CS) ? gp(A.Ww2)[o * CS + u] : 0.f;
+__device__ __forceinline__ void stage_consts(float *cst, const LayerArgs &A, bool with_bn1) {
+    constexpr int P3 = (3 * C + NT - 1) / NT, P1 = (C + NT - 1) / NT;
+    float a[P3], b[P1], c[P1], d[P1];
+#pragma unroll
+    for (int t = 0; t < P3; ++t) a[t] = gp(A.Wp2)[min((int)threadIdx.x + NT * t, 3 * C - 1)];
+#pragma unroll
+    for (int t = 0; t < P1; ++t) {
+        const int e = min((int)threadIdx.x + NT * t, C - 1);
+        b[t] = gp(A.bp2)[e];
+        if (with_bn1) { c[t] = gp(A.s1)[e]; d[t] = gp(A.t1)[e]; }   // (block-uniform condition)
+    }
+#pragma unroll
+    for (int t = 0; t < P3; ++t) { const int e = threadIdx.x + NT * t; if (e < 3 * C) cst[e] = a[t]; }
+#pragma unroll
+    for (int t = 0; t < P1; ++t) {
+        const int e = threadIdx.x + NT * t;
+        if (e < C) { cst[3 * C + e] = b[t]; if (with_bn1) { cst[4 * C + e] = c[t]; cst[5 * C + e] = d[t]; } }
+    }
+}
+template <int C>
+__device__ __forceinline__ void stage_w2(float *w2, const LayerArgs &A) {   // zero-padded copy of Ww2, row stride CSP + 4
+    constexpr int CS = C / 8, CSP = csp_of(C), N = CSP * (CSP + 4), PER = (N + NT - 1) / NT;
+    float v[PER];
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int e = threadIdx.x + NT * t, o = min(e / (CSP + 4), CS - 1), u = min(e % (CSP + 4), CS - 1);
+        v[t] = gp(A.Ww2)[o * CS + u];
+    }
+#pragma unroll
+    for (int t = 0; t < PER; ++t) {
+        const int e = threadIdx.x + NT * t, o = e / (CSP + 4), u = e % (CSP + 4);
+        if (e < N) w2[e] = (o < CS && u < CS) ? v[t] : 0.f;
     }
 }
 // guarded float4 of a CS-long per-unit array (zero where the lane's units do not exist)
@@ -85,24 +143,56 @@ __device__ __forceinline__ f32x4 xchg32(f32x4 v) {
     return f32x4{__shfl_xor(v[0], 32, 64), __shfl_xor(v[1], 32, 64), __shfl_xor(v[2], 32, 64), __shfl_xor(v[3], 32, 64)};
 }
 
-// One point's 16 neighbour rows: geometry branch of the lane's row (3-channel, cheap, replicated over the 4 kq lanes)
-struct PRow {
-    int nb;          // neighbour index (-1: zero row)
-    float t1[3];     // Linear(3,3) output (pre-BN)
-    float t1n[3];    // relu(BNp(t1))
-};
-__device__ __forceinline__ PRow load_prow(const LayerArgs &A, long i, int nb) {
-    PRow R;
-    R.nb = nb;
-    float rel[3] = {0.f, 0.f, 0.f};
-    if (R.nb >= 0) {
-#pragma unroll
-        for (int b = 0; b < 3; ++b) rel[b] = A.p[(size_t)R.nb * 3 + b] - A.p[(size_t)i * 3 + b];
+// ================================================================================================ trip structure
+// Memory-level parallelism.  One wave works on one point (16 neighbour rows) per trip.  Written naively every global load sits next
+// to its use and the compiler waits for each in turn (`global_load; s_waitcnt vmcnt(0)`: ~25 serialised L2 round trips per trip --
+// that, not bandwidth or arithmetic, was what these passes cost).  So every kernel below
+//   * issues ALL global loads of a trip (neighbour index of the NEXT trip, coordinates, H / G2 / Wsm rows, the first group of channel
+//     loads) into registers behind a scheduling barrier, then computes; long channel loops run in groups of four 16-channel blocks with
+//     the next group's loads in flight during the current group's arithmetic (double-buffered registers);
+//   * keeps per-channel / per-unit constants (BatchNorm coefficients, statistics, backward sums) in LDS, staged once per block;
+//   * never loads under a condition (a load inside a branch is a wait): clamped address + select;
+//   * takes the storage type of the row arrays as a template parameter (a runtime `if (bf16)` around a load splits the basic block).
+template <bool BF>
+__device__ __forceinline__ f32x4 ld_row4(const float *base, size_t idx) {   // 4 consecutive elements of a row array (fp32 / bfloat16 storage)
+    if constexpr (BF) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned short *>(base) + idx);
+        return f32x4{fl::bf2f(v.x & 0xffffu), fl::bf2f(v.x >> 16), fl::bf2f(v.y & 0xffffu), fl::bf2f(v.y >> 16)};
+    } else {
+        return ld4(base + idx);
     }
+}
+template <bool BF>
+__device__ __forceinline__ void st_row4(float *base, size_t idx, f32x4 v) {
+    if constexpr (BF) {
+        uint2 o; o.x = fl::f2bf(v[0]) | (fl::f2bf(v[1]) << 16); o.y = fl::f2bf(v[2]) | (fl::f2bf(v[3]) << 16);
+        *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(base) + idx) = o;
+    } else {
+        st4(base + idx, v);
+    }
+}
+__device__ __forceinline__ f32x4 sel4(bool c, f32x4 v) { return c ? v : zero4(); }
+
+// geometry branch of the lane's row (3 channels, replicated over the 4 kq lanes): weights in SGPRs, coordinates preloaded
+struct GeoW { float wp1[9], bp1[3], sp[3], tp[3]; };
+struct Geo { float t1[3], t1n[3]; };   // Linear(3,3) output (pre-BN), relu(BNp(t1))
+__device__ __forceinline__ GeoW geo_weights(const LayerArgs &A) {
+    GeoW G;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) G.wp1[e] = A.Wp1[e];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { G.bp1[a] = A.bp1[a]; G.sp[a] = A.sp[a]; G.tp[a] = A.tp[a]; }
+    return G;
+}
+__device__ __forceinline__ Geo geo_of(const GeoW &G, int nb, const float *pn, const float *pi) {
+    Geo R;
+    float rel[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) rel[b] = nb >= 0 ? pn[b] - pi[b] : 0.f;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        R.t1[a] = rel[0] * A.Wp1[a * 3 + 0] + rel[1] * A.Wp1[a * 3 + 1] + rel[2] * A.Wp1[a * 3 + 2] + A.bp1[a];
-        R.t1n[a] = fmaxf(R.t1[a] * A.sp[a] + A.tp[a], 0.f);
+        R.t1[a] = rel[0] * G.wp1[a * 3 + 0] + rel[1] * G.wp1[a * 3 + 1] + rel[2] * G.wp1[a * 3 + 2] + G.bp1[a];
+        R.t1n[a] = fmaxf(R.t1[a] * G.sp[a] + G.tp[a], 0.f);
     }
     return R;
 }
@@ -117,23 +207,38 @@ __device__ __forceinline__ f32x4 pos4(const float *cst, int C, int g, const floa
     return pr;
 }
 
-// r = x_k[nb] - x_q[i] + p_r for channel group g of the lane's row
-__device__ __forceinline__ f32x4 r4_of(const LayerArgs &A, const float *cst, int C, long i, const PRow &R, int g) {
-    const f32x4 xk = R.nb >= 0 ? ld4(A.xk + (size_t)R.nb * C + 4 * g) : zero4();
-    const f32x4 xq = ld4(A.xq + (size_t)i * C + 4 * g);
-    return (xk - xq) + pos4(cst, C, g, R.t1n);
+// per-unit constants in LDS, CSP floats each (padding units = 0):
+//   [0] s2 | [1] t2 | [2] bw2 | backward only (S != nullptr): [3] mean2 | [4] rstd2 | [5] S[0..CS) / rows | [6] S[CS..2CS) / rows
+constexpr int U_S2 = 0, U_T2 = 1, U_BW2 = 2, U_MEAN = 3, U_RSTD = 4, U_SA = 5, U_SB = 6;
+template <int C, bool BWD>   // (two instantiations on purpose: one body called with S == nullptr here and S != nullptr there crashes clang 22's CGSCC pipeline)
+__device__ __forceinline__ void stage_units(float *ucst, const LayerArgs &A, const float *S) {
+    constexpr int CS = C / 8, CSP = csp_of(C), N = (BWD ? 7 : 3) * CSP;
+    for (int e = threadIdx.x; e < N; e += NT) {
+        const int arr = e / CSP, u = min(e % CSP, CS - 1);
+        float v;
+        if constexpr (BWD) {
+            const float *src = arr == U_S2 ? gp(A.s2) : arr == U_T2 ? gp(A.t2) : arr == U_BW2 ? gp(A.bw2)
+                             : arr == U_MEAN ? gp(A.mean) + 3 + C : arr == U_RSTD ? gp(A.rstd) + 3 + C : arr == U_SA ? S : S + CS;
+            v = src[u] * (arr >= U_SA ? A.inv_rows : 1.f);
+        } else {
+            const float *src = arr == U_S2 ? gp(A.s2) : arr == U_T2 ? gp(A.t2) : gp(A.bw2);
+            v = src[u];
+        }
+        ucst[e] = e % CSP < CS ? v : 0.f;
+    }
 }
+template <int C> __device__ __forceinline__ f32x4 unit4(const float *ucst, int arr, int ob, int kq) { return ld4(ucst + arr * csp_of(C) + 16 * ob + 4 * kq); }
+// element offset of the lane's units of block ob inside a CS-long row, clamped into the row (invalid lanes re-read valid units, masked later)
+template <int C> __device__ __forceinline__ int unit_off(int ob, int kq) { return min(16 * ob + 4 * kq, C / 8 - 4); }
 
 // Attention branch of one point (16 rows): u = relu(BN2(h)), w = softmax over the rows of (u Ww2^T + bw2).
 // Lane (row, kq) holds hidden units {16 ob + 4 kq + e}; the MFMA D fragment of z^T = Ww2 u^T has the same index set.
 template <int C>
-__device__ __forceinline__ void attn_weights(const LayerArgs &A, const float *w2, int row, int kq, const f32x4 *h, f32x4 *u, f32x4 *w) {
+__device__ __forceinline__ void attn_weights(const float *ucst, const float *w2, int row, int kq, const f32x4 *h, f32x4 *u, f32x4 *w) {
     constexpr int CS = C / 8, NOB = nob_of(C), WS2 = csp_of(C) + 4;
 #pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) {
-        const bool hv = 16 * ob + 4 * kq < CS;
-        u[ob] = relu4(h[ob] * ldu(gp(A.s2), 16 * ob + 4 * kq, hv) + ldu(gp(A.t2), 16 * ob + 4 * kq, hv));   // padding lanes: 0
-    }
+    for (int ob = 0; ob < NOB; ++ob)
+        u[ob] = sel4(16 * ob + 4 * kq < CS, relu4(h[ob] * unit4<C>(ucst, U_S2, ob, kq) + unit4<C>(ucst, U_T2, ob, kq)));   // padding lanes: 0
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) {
         f32x4 z = zero4();
@@ -143,7 +248,7 @@ __device__ __forceinline__ void attn_weights(const LayerArgs &A, const float *w2
 #pragma unroll
             for (int e = 0; e < 4; ++e) z = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], u[jo][e], z, 0, 0, 0);
         }
-        z += ldu(gp(A.bw2), 16 * ob + 4 * kq, 16 * ob + 4 * kq < CS);
+        z += unit4<C>(ucst, U_BW2, ob, kq);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float m = max16(z[r]);
@@ -156,19 +261,20 @@ __device__ __forceinline__ void attn_weights(const LayerArgs &A, const float *w2
         if (kq >= 2) w[0] = x;
     }
 }
-
-// h (or G2) row fragment of the lane: units {16 ob + 4 kq + e}
+// g_h of the lane's hidden units from the H / G2 fragments and the BN2-backward sums (BN2 backward)
 template <int C>
-__device__ __forceinline__ f32x4 ld_units(const float *base, long rowidx, int ob, int kq, int bf16) {
-    constexpr int CS = C / 8;
-    if (!(16 * ob + 4 * kq < CS)) return zero4();
-    const float4 v = fl::ld_u4(base, (size_t)rowidx * CS + 16 * ob + 4 * kq, bf16);
-    return f32x4{v.x, v.y, v.z, v.w};
+__device__ __forceinline__ void hidden_grad(const float *ucst, int kq, const f32x4 *h, const f32x4 *g2, f32x4 *gh) {
+    constexpr int CS = C / 8, NOB = nob_of(C);
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+        const f32x4 hhat = (h[ob] - unit4<C>(ucst, U_MEAN, ob, kq)) * unit4<C>(ucst, U_RSTD, ob, kq);
+        gh[ob] = sel4(16 * ob + 4 * kq < CS,
+                      unit4<C>(ucst, U_S2, ob, kq) * (g2[ob] - unit4<C>(ucst, U_SA, ob, kq) - hhat * unit4<C>(ucst, U_SB, ob, kq)));   // padding lanes: 0
+    }
 }
-__device__ __forceinline__ void st_units4(float *base, size_t idx, f32x4 v, int bf16) { fl::st_u4(base, idx, v[0], v[1], v[2], v[3], bf16); }
 
 // ------------------------------------------------------------------------------------------------ P2: stats of r (slabs)
-// partial row per wave-row: [sum r (C) | sum r^2 (C)]; slab y writes channels [64 y, 64 y + 64)
+// partial row per block: [sum r (C) | sum r^2 (C)]; slab y writes channels [64 y, 64 y + 64)
 template <int C>
 __global__ __launch_bounds__(64 * WPB) void k_p2(LayerArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -176,8 +282,8 @@ __global__ __launch_bounds__(64 * WPB) void k_p2(LayerArgs A) {
     stage_consts<C>(cst, A, false);
     __syncthreads();
     const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
-    const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
     const int c0 = 64 * blockIdx.y;
+    const GeoW G = geo_weights(A);
     f32x4 s[4], ss[4];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) { s[jj] = zero4(); ss[jj] = zero4(); }
@@ -185,40 +291,53 @@ __global__ __launch_bounds__(64 * WPB) void k_p2(LayerArgs A) {
     int nb_next = pw.valid() ? A.idx[pw.point() * 16 + row] : -1;
     for (; pw.valid(); pw.step()) {
         const long i = pw.point();
-        const int nb_cur = nb_next;
-        nb_next = pw.has_next() ? A.idx[pw.next_point() * 16 + row] : -1;   // next trip's index: in flight during this trip
-        const PRow R = load_prow(A, i, nb_cur);
+        const int nb = nb_next;
+        const size_t nbc = (size_t)max(nb, 0);
+        nb_next = A.idx[(pw.has_next() ? pw.next_point() : i) * 16 + row];   // next trip's index: in flight during this trip
+        float pn[3], pi[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) { pn[b] = A.p[nbc * 3 + b]; pi[b] = A.p[(size_t)i * 3 + b]; }
+        f32x4 xk[4], xq[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-            const f32x4 r = r4_of(A, cst, C, i, R, 4 * (4 * (int)blockIdx.y + jj) + kq);
+            const int c4 = c0 + 16 * jj + 4 * kq;
+            xk[jj] = ld4(A.xk + nbc * C + c4); xq[jj] = ld4(A.xq + (size_t)i * C + c4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const Geo R = geo_of(G, nb, pn, pi);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const f32x4 r = (sel4(nb >= 0, xk[jj]) - xq[jj]) + pos4(cst, C, 4 * (4 * (int)blockIdx.y + jj) + kq, R.t1n);
             s[jj] += r;
             ss[jj] += r * r;
         }
     }
-    float *o = A.partial + wave_g * 2 * C;
+    block_row(lds, 128, [&](RowAcc o) {   // this slab's 64 + 64 columns
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
+        for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float a = s[jj][e], b = ss[jj][e];
+            for (int e = 0; e < 4; ++e) {
+                float a = s[jj][e], b = ss[jj][e];
 #pragma unroll
-            for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
-            if (row == 0) { o[c0 + 16 * jj + 4 * kq + e] = a; o[C + c0 + 16 * jj + 4 * kq + e] = b; }
-        }
+                for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+                if (row == 0) { o[16 * jj + 4 * kq + e] = a; o[64 + 16 * jj + 4 * kq + e] = b; }
+            }
+    });
+    if (threadIdx.x < 128) (A.partial + (size_t)blockIdx.x * 2 * C)[(threadIdx.x >> 6) * C + c0 + (threadIdx.x & 63)] = lds[threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------ P3: h (+ stats of h)
-template <int C, bool STATS>
+template <int C, bool STATS, bool BF>
 __global__ __launch_bounds__(64 * WPB) void k_p3(LayerArgs A) {
-    constexpr int CS = C / 8, NJ = C / 16, NOB = nob_of(C), CSP = csp_of(C), WS = C + 4;   // WS: padded row stride of the Ww1 copy
+    constexpr int CS = C / 8, NG = C / 64, NOB = nob_of(C), CSP = csp_of(C), WS = C + 4;   // WS: padded row stride of the Ww1 copy
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *cst = lds, *wl = lds + 6 * C;
-    for (int e = threadIdx.x; e < CSP * C; e += 64 * WPB) wl[(e / C) * WS + e % C] = e / C < CS ? gp(A.Ww1)[e] : 0.f;
+    stage_rows<CSP, C, WS>(wl, gp(A.Ww1), C, CS);
     stage_consts<C>(cst, A, true);
     __syncthreads();
     const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
-    const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
     const float *wa = wl + row * WS + 4 * kq;   // A operand (hidden unit ob*16 + (l & 15), k = kq): wa[ob * 16 * WS + 16 j ..+4]
+    const GeoW G = geo_weights(A);
     f32x4 b4[NOB], s4[NOB], ss4[NOB];
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) { b4[ob] = ldu(gp(A.bw1), ob * 16 + 4 * kq, ob * 16 + 4 * kq < CS); s4[ob] = zero4(); ss4[ob] = zero4(); }
@@ -226,78 +345,127 @@ __global__ __launch_bounds__(64 * WPB) void k_p3(LayerArgs A) {
     int nb_next = pw.valid() ? A.idx[pw.point() * 16 + row] : -1;
     for (; pw.valid(); pw.step()) {
         const long i = pw.point();
-        const int nb_cur = nb_next;
-        nb_next = pw.has_next() ? A.idx[pw.next_point() * 16 + row] : -1;   // next trip's index: in flight during this trip
-        const PRow R = load_prow(A, i, nb_cur);
+        const int nb = nb_next;
+        const size_t nbc = (size_t)max(nb, 0);
+        nb_next = A.idx[(pw.has_next() ? pw.next_point() : i) * 16 + row];
+        float pn[3], pi[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) { pn[b] = A.p[nbc * 3 + b]; pi[b] = A.p[(size_t)i * 3 + b]; }
+        const float *xkr = A.xk + nbc * C + 4 * kq, *xqr = A.xq + (size_t)i * C + 4 * kq;
         f32x4 acc[NOB];
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) acc[ob] = zero4();
+        if constexpr (C == 128 || C == 256) {
+            // (measured: at these widths the double-buffered groups cost more in occupancy -- 142 / 162 VGPRs -- than they hide)
+            const Geo R = geo_of(G, nb, pn, pi);
 #pragma unroll 2
-        for (int j = 0; j < NJ; ++j) {
-            const int g = 4 * j + kq;
-            const f32x4 r = r4_of(A, cst, C, i, R, g);
-            const f32x4 y = relu4(r * ld4(cst + 4 * C + 4 * g) + ld4(cst + 5 * C + 4 * g));
-            f32x4 w[NOB];
+            for (int j = 0; j < C / 16; ++j) {
+                const int g = 4 * j + kq;
+                const f32x4 r = (sel4(nb >= 0, ld4(xkr + 16 * j)) - ld4(xqr + 16 * j)) + pos4(cst, C, g, R.t1n);
+                const f32x4 y = relu4(r * ld4(cst + 4 * C + 4 * g) + ld4(cst + 5 * C + 4 * g));
+                f32x4 w[NOB];
 #pragma unroll
-            for (int ob = 0; ob < NOB; ++ob) w[ob] = ld4(wa + ob * 16 * WS + 16 * j);
+                for (int ob = 0; ob < NOB; ++ob) w[ob] = ld4(wa + ob * 16 * WS + 16 * j);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int ob = 0; ob < NOB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ob][e], y[e], acc[ob], 0, 0, 0);
+                    for (int ob = 0; ob < NOB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ob][e], y[e], acc[ob], 0, 0, 0);
+            }
+        } else {
+        f32x4 xk[2][4], xq[2][4];   // double-buffered groups of four 16-channel blocks
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) { xk[0][jj] = ld4(xkr + 16 * jj); xq[0][jj] = ld4(xqr + 16 * jj); }
+        __builtin_amdgcn_sched_barrier(0);
+        const Geo R = geo_of(G, nb, pn, pi);
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            if (gi + 1 < NG) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) { xk[(gi + 1) & 1][jj] = ld4(xkr + 64 * (gi + 1) + 16 * jj); xq[(gi + 1) & 1][jj] = ld4(xqr + 64 * (gi + 1) + 16 * jj); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = 4 * gi + jj, g = 4 * j + kq;
+                const f32x4 r = (sel4(nb >= 0, xk[gi & 1][jj]) - xq[gi & 1][jj]) + pos4(cst, C, g, R.t1n);
+                const f32x4 y = relu4(r * ld4(cst + 4 * C + 4 * g) + ld4(cst + 5 * C + 4 * g));
+                f32x4 w[NOB];
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) w[ob] = ld4(wa + ob * 16 * WS + 16 * j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[ob][e], y[e], acc[ob], 0, 0, 0);
+            }
+        }
         }
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) {
             const f32x4 h = acc[ob] + b4[ob];   // h[row][ob*16 + 4 kq + reg]
-            if (ob * 16 + 4 * kq < CS) st_units4(A.H, ((size_t)i * 16 + row) * CS + ob * 16 + 4 * kq, h, A.bf16);
+            if (ob * 16 + 4 * kq < CS) st_row4<BF>(A.H, ((size_t)i * 16 + row) * CS + ob * 16 + 4 * kq, h);
             if (STATS) { s4[ob] += h; ss4[ob] += h * h; }
         }
     }
     if (STATS) {
+        block_row(lds, 2 * CS, [&](RowAcc o) {
 #pragma unroll
-        for (int ob = 0; ob < NOB; ++ob)
+            for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float s = s4[ob][r], ss = ss4[ob][r];
+                for (int r = 0; r < 4; ++r) {
+                    float s = s4[ob][r], ss = ss4[ob][r];
 #pragma unroll
-                for (int m = 1; m < 16; m <<= 1) { s += __shfl_xor(s, m, 64); ss += __shfl_xor(ss, m, 64); }
-                if (row == 0 && ob * 16 + 4 * kq < CS) {
-                    A.partial[wave_g * 2 * CS + ob * 16 + 4 * kq + r] = s;
-                    A.partial[wave_g * 2 * CS + CS + ob * 16 + 4 * kq + r] = ss;
+                    for (int m = 1; m < 16; m <<= 1) { s += __shfl_xor(s, m, 64); ss += __shfl_xor(ss, m, 64); }
+                    if (row == 0 && ob * 16 + 4 * kq < CS) { o[ob * 16 + 4 * kq + r] = s; o[CS + ob * 16 + 4 * kq + r] = ss; }
                 }
-            }
+        });
+        store_row(lds, 2 * CS, A.partial + (size_t)blockIdx.x * 2 * CS);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ P4: aggregation
 // out[i][c] = sum_rows (x_v[nb][c] + p_r[c]) * w[row][c mod CS]
-template <int C>
+template <int C, bool BF>
 __global__ __launch_bounds__(64 * WPB) void k_p4(LayerArgs A) {
-    constexpr int NJ = C / 16, NOB = nob_of(C);
+    constexpr int CS = C / 8, NG = C / 64, NOB = nob_of(C), CSP = csp_of(C);
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *cst = lds, *w2 = lds + 4 * C;
+    float *cst = lds, *ucst = lds + 4 * C, *w2 = ucst + 3 * CSP;
     stage_consts<C>(cst, A, false);
+    stage_units<C, false>(ucst, A, nullptr);
     stage_w2<C>(w2, A);
     __syncthreads();
     const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
-    const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
+    const GeoW G = geo_weights(A);
     fl::PointWalk pw(A, threadIdx.x >> 6);
     int nb_next = pw.valid() ? A.idx[pw.point() * 16 + row] : -1;
     for (; pw.valid(); pw.step()) {
         const long i = pw.point();
-        const int nb_cur = nb_next;
-        nb_next = pw.has_next() ? A.idx[pw.next_point() * 16 + row] : -1;   // next trip's index: in flight during this trip
-        const PRow R = load_prow(A, i, nb_cur);
+        const int nb = nb_next;
+        const size_t nbc = (size_t)max(nb, 0);
+        nb_next = A.idx[(pw.has_next() ? pw.next_point() : i) * 16 + row];
+        float pn[3], pi[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) { pn[b] = A.p[nbc * 3 + b]; pi[b] = A.p[(size_t)i * 3 + b]; }
         f32x4 h[NOB], u[NOB], w[NOB];
 #pragma unroll
-        for (int ob = 0; ob < NOB; ++ob) h[ob] = ld_units<C>(A.H, i * 16 + row, ob, kq, A.bf16);
-        attn_weights<C>(A, w2, row, kq, h, u, w);
-#pragma unroll 1
-        for (int j0 = 0; j0 < NJ; j0 += NOB) {
+        for (int ob = 0; ob < NOB; ++ob) h[ob] = ld_row4<BF>(A.H, ((size_t)i * 16 + row) * CS + unit_off<C>(ob, kq));
+        const float *xvr = A.xv + nbc * C + 4 * kq;
+        f32x4 xv[2][4];
 #pragma unroll
-            for (int jo = 0; jo < NOB; ++jo) {   // channel 16 j + 4 kq + e -> hidden unit block j % NOB == jo
-                const int g = 4 * (j0 + jo) + kq;
-                const f32x4 xv = R.nb >= 0 ? ld4(A.xv + (size_t)R.nb * C + 4 * g) : zero4();
-                const f32x4 v = (xv + pos4(cst, C, g, R.t1n)) * w[jo];
+        for (int jj = 0; jj < 4; ++jj) xv[0][jj] = ld4(xvr + 16 * jj);
+        __builtin_amdgcn_sched_barrier(0);
+        const Geo R = geo_of(G, nb, pn, pi);
+        attn_weights<C>(ucst, w2, row, kq, h, u, w);
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            if (gi + 1 < NG) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) xv[(gi + 1) & 1][jj] = ld4(xvr + 64 * (gi + 1) + 16 * jj);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {   // channel 16 j + 4 kq + e -> hidden unit block j % NOB
+                const int j = 4 * gi + jj, g = 4 * j + kq;
+                const f32x4 v = (sel4(nb >= 0, xv[gi & 1][jj]) + pos4(cst, C, g, R.t1n)) * w[j % NOB];
                 f32x4 t;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) t[e] = sum16(v[e]);
@@ -308,22 +476,25 @@ __global__ __launch_bounds__(64 * WPB) void k_p4(LayerArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------ B1
-// partial row per wave: [sum g_y2 (CS) | sum g_y2*hhat (CS) | g_bw2 (CS) | g_Ww2 (CS*CS)]   (as fl::k_b1)
-template <int C>
+// partial row per block: [sum g_y2 (CS) | sum g_y2*hhat (CS) | g_bw2 (CS) | g_Ww2 (CS*CS)]   (as fl::k_b1)
+template <int C, bool BF>
 __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
     constexpr int CS = C / 8, NOB = nob_of(C), CSP = csp_of(C), NCHK = C / 64, GS = CSP + 4, WS2 = CSP + 4, W = 3 * CS + CS * CS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *cst = lds, *w2 = cst + 4 * C;                                  // Wp2 (3C) | bp2 (C); padded Ww2
+    float *cst = lds, *ucst = cst + 4 * C, *w2 = ucst + 7 * CSP;           // Wp2 (3C) | bp2 (C); per-unit constants; padded Ww2
     const int wv = threadIdx.x >> 6;
-    float *tile = w2 + w2_floats(C) + wv * 16 * TS;
-    float *gz_t = w2 + w2_floats(C) + WPB * 16 * TS + wv * 16 * GS, *u_t = gz_t + WPB * 16 * GS;
-    int *rowid = reinterpret_cast<int *>(w2 + w2_floats(C) + WPB * 16 * TS + 2 * WPB * 16 * GS) + wv * 16;
+    float *gz_t = w2 + w2_floats(C) + wv * 16 * GS, *u_t = gz_t + WPB * 16 * GS;
     stage_consts<C>(cst, A, false);
+    stage_units<C, false>(ucst, A, nullptr);
+    for (int e = threadIdx.x; e < 2 * CSP; e += NT) {   // mean2 | rstd2 (this pass computes the BN2-backward sums: no S yet)
+        const int u = min(e % CSP, CS - 1);
+        ucst[U_MEAN * CSP + e] = e % CSP < CS ? (e < CSP ? gp(A.mean) : gp(A.rstd))[3 + C + u] : 0.f;
+    }
     stage_w2<C>(w2, A);
-    for (int e = threadIdx.x; e < 2 * WPB * 16 * GS; e += 64 * WPB) (w2 + w2_floats(C) + WPB * 16 * TS)[e] = 0.f;   // unit tiles incl. padding columns
+    for (int e = threadIdx.x; e < 2 * WPB * 16 * GS; e += NT) (w2 + w2_floats(C))[e] = 0.f;   // unit tiles incl. padding columns
     __syncthreads();
     const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
-    const long wave_g = (long)blockIdx.x * WPB + wv, nwaves = (long)gridDim.x * WPB;
+    const GeoW G = geo_weights(A);
     f32x4 sg[NOB], sgh[NOB], sgz[NOB], accw[NOB][NOB];
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) {
@@ -331,32 +502,44 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
 #pragma unroll
         for (int ub = 0; ub < NOB; ++ub) accw[ob][ub] = zero4();
     }
-    fl::PointWalk pw(A, threadIdx.x >> 6);
+    fl::PointWalk pw(A, wv);
     int nb_next = pw.valid() ? A.idx[pw.point() * 16 + row] : -1;
     for (; pw.valid(); pw.step()) {
         const long i = pw.point();
-        const int nb_cur = nb_next;
-        nb_next = pw.has_next() ? A.idx[pw.next_point() * 16 + row] : -1;   // next trip's index: in flight during this trip
-        const PRow R = load_prow(A, i, nb_cur);
+        const size_t ri = (size_t)i * 16 + row;
+        const int nb = nb_next;
+        const size_t nbc = (size_t)max(nb, 0);
+        nb_next = A.idx[(pw.has_next() ? pw.next_point() : i) * 16 + row];
+        float pn[3], pi[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) { pn[b] = A.p[nbc * 3 + b]; pi[b] = A.p[(size_t)i * 3 + b]; }
         f32x4 h[NOB], u[NOB], w[NOB], gw[NOB];
 #pragma unroll
-        for (int ob = 0; ob < NOB; ++ob) { h[ob] = ld_units<C>(A.H, i * 16 + row, ob, kq, A.bf16); gw[ob] = zero4(); }
-        attn_weights<C>(A, w2, row, kq, h, u, w);
-#pragma unroll 1
+        for (int ob = 0; ob < NOB; ++ob) { h[ob] = ld_row4<BF>(A.H, ri * CS + unit_off<C>(ob, kq)); gw[ob] = zero4(); }
+        const float *xvr = A.xv + nbc * C + 4 * kq, *gor = A.gout + (size_t)i * C + 4 * kq;
+        f32x4 xv[2][4], go[2][4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) { xv[0][jj] = ld4(xvr + 16 * jj); go[0][jj] = ld4(gor + 16 * jj); }
+        __builtin_amdgcn_sched_barrier(0);
+        const Geo R = geo_of(G, nb, pn, pi);
+        attn_weights<C>(ucst, w2, row, kq, h, u, w);
+#pragma unroll
         for (int q = 0; q < NCHK; ++q) {
+            if (q + 1 < NCHK) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) { xv[(q + 1) & 1][jj] = ld4(xvr + 64 * (q + 1) + 16 * jj); go[(q + 1) & 1][jj] = ld4(gor + 64 * (q + 1) + 16 * jj); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const int g = 4 * (4 * q + jj) + kq;   // channel 16 j + 4 kq + e  ->  hidden unit (c mod CS): block jj % NOB, same (kq, e)
-                const f32x4 go = ld4(A.gout + (size_t)i * C + 4 * g);
-                const f32x4 xv = R.nb >= 0 ? ld4(A.xv + (size_t)R.nb * C + 4 * g) : zero4();
-                const f32x4 pr = pos4(cst, C, g, R.t1n);
-                gw[jj % NOB] += go * (xv + pr);
+                gw[jj % NOB] += go[q & 1][jj] * (sel4(nb >= 0, xv[q & 1][jj]) + pos4(cst, C, g, R.t1n));
             }
         }
-        // softmax weights of the 16 rows: g_xv[nb] = sum over the inverse kNN table of g_out[i] * w  (pdf_seg_sum_weighted)
+        // softmax weights of the 16 rows: g_xv[nb] = sum over the inverse kNN table of g_out[i] * w  (pdf_seg_sum_weighted); B3 reads them too
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob)
-            if (16 * ob + 4 * kq < CS) st_units4(A.Wsm, ((size_t)i * 16 + row) * CS + 16 * ob + 4 * kq, w[ob], A.bf16);
+            if (16 * ob + 4 * kq < CS) st_row4<BF>(A.Wsm, ri * CS + 16 * ob + 4 * kq, w[ob]);
         // softmax backward over the 16 rows, Linear(CS, CS) backward, ReLU / BN2 bookkeeping
         f32x4 gz[NOB];
         if (CS < 16) gw[0] += xchg32(gw[0]);   // 8 units: lanes kq and kq ^ 2 hold partial sums of the same units
@@ -386,9 +569,9 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) gy2[r] = u[ub][r] > 0.f ? gu[r] : 0.f;
             const bool hv = 16 * ub + 4 * kq < CS;
-            if (hv) st_units4(A.G2, ((size_t)i * 16 + row) * CS + 16 * ub + 4 * kq, gy2, A.bf16);
+            if (hv) st_row4<BF>(A.G2, ri * CS + 16 * ub + 4 * kq, gy2);
             sg[ub] += gy2;
-            sgh[ub] += gy2 * ((h[ub] - ldu(gp(A.mean) + 3 + C, 16 * ub + 4 * kq, hv)) * ldu(gp(A.rstd) + 3 + C, 16 * ub + 4 * kq, hv));
+            sgh[ub] += sel4(hv, gy2 * ((h[ub] - unit4<C>(ucst, U_MEAN, ub, kq)) * unit4<C>(ucst, U_RSTD, ub, kq)));
         }
         wave_sync();
         // g_Ww2[o][u'] += sum_rows g_z[row][o] u[row][u']  (reduction index = rows: operands re-read lanes-along-units)
@@ -404,56 +587,44 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
         }
         wave_sync();
     }
-    float *o = A.partial + wave_g * W;
+    block_row(lds, W, [&](RowAcc o) {
 #pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) {
+        for (int ob = 0; ob < NOB; ++ob) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float a = sg[ob][r], b = sgh[ob][r], d = sgz[ob][r];
+            for (int r = 0; r < 4; ++r) {
+                float a = sg[ob][r], b = sgh[ob][r], d = sgz[ob][r];
 #pragma unroll
-            for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); d += __shfl_xor(d, m, 64); }
-            if (row == 0 && 16 * ob + 4 * kq < CS) { o[16 * ob + 4 * kq + r] = a; o[CS + 16 * ob + 4 * kq + r] = b; o[2 * CS + 16 * ob + 4 * kq + r] = d; }
+                for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); d += __shfl_xor(d, m, 64); }
+                if (row == 0 && 16 * ob + 4 * kq < CS) { o[16 * ob + 4 * kq + r] = a; o[CS + 16 * ob + 4 * kq + r] = b; o[2 * CS + 16 * ob + 4 * kq + r] = d; }
+            }
+#pragma unroll
+            for (int ub = 0; ub < NOB; ++ub)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (16 * ob + 4 * kq < CS && 16 * ub + row < CS) o[3 * CS + (16 * ob + 4 * kq + r) * CS + 16 * ub + row] = accw[ob][ub][r];
         }
-#pragma unroll
-        for (int ub = 0; ub < NOB; ++ub)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (16 * ob + 4 * kq < CS && 16 * ub + row < CS) o[3 * CS + (16 * ob + 4 * kq + r) * CS + 16 * ub + row] = accw[ob][ub][r];
-    }
-}
-
-// g_h of the lane's hidden units from the stored G2 / H rows and the BN2-backward sums (`sums` = [sum g_y2 | sum g_y2*hhat])
-template <int C>
-__device__ __forceinline__ void hidden_grad(const LayerArgs &A, const float *sums, long i, int row, int kq, f32x4 *gh, f32x4 *h_out = nullptr) {
-    constexpr int CS = C / 8, NOB = nob_of(C);
-#pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) {
-        const int o = 16 * ob + 4 * kq;
-        const bool hv = o < CS;
-        const f32x4 h = ld_units<C>(A.H, i * 16 + row, ob, kq, A.bf16), g2 = ld_units<C>(A.G2, i * 16 + row, ob, kq, A.bf16);
-        const f32x4 hhat = (h - ldu(gp(A.mean) + 3 + C, o, hv)) * ldu(gp(A.rstd) + 3 + C, o, hv);
-        gh[ob] = ldu(gp(A.s2), o, hv) * (g2 - ldu(sums, o, hv) * A.inv_rows - hhat * (ldu(sums + CS, o, hv) * A.inv_rows));   // padding lanes: 0
-        if (h_out) h_out[ob] = h;
-    }
+    });
+    store_row(lds, W, A.partial + (size_t)blockIdx.x * W);
 }
 
 // ------------------------------------------------------------------------------------------------ B2 (64-channel slabs)
-// partial row per wave-row (all slabs of one blockIdx.x write disjoint columns of the same rows):
+// partial row per block (all slabs of one blockIdx.x write disjoint columns of the same row):
 //   [sum g_y1 (C) | sum g_y1*rhat (C) | g_bw1 (CS) | g_Ww1 (CS*C)]   (as fl::k_b2)
-template <int C>
+template <int C, bool BF>
 __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
     constexpr int CS = C / 8, NOB = nob_of(C), CSP = csp_of(C), GS = CSP + 4, WS = 68, W = 2 * C + CS + CS * C;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wv = threadIdx.x >> 6;
-    float *cst = lds, *wl = cst + 6 * C;                                   // Ww1[:, slab], row stride 68
+    float *cst = lds, *ucst = cst + 6 * C, *wl = ucst + 7 * CSP;           // wl: Ww1[:, slab], row stride 68
     float *gh_t = wl + CSP * WS + wv * 16 * GS, *v1_t = wl + CSP * WS + WPB * 16 * GS + wv * 16 * TS;
     const int slab = blockIdx.y, c0 = 64 * slab;
-    for (int e = threadIdx.x; e < CSP * 64; e += 64 * WPB) wl[(e / 64) * WS + e % 64] = e / 64 < CS ? gp(A.Ww1)[(size_t)(e / 64) * C + c0 + e % 64] : 0.f;
-    for (int e = threadIdx.x; e < WPB * 16 * GS; e += 64 * WPB) (wl + CSP * WS)[e] = 0.f;   // g_h tiles incl. padding columns
+    stage_rows<CSP, 64, WS>(wl, gp(A.Ww1) + c0, C, CS);
+    for (int e = threadIdx.x; e < WPB * 16 * GS; e += NT) (wl + CSP * WS)[e] = 0.f;   // g_h tiles incl. padding columns
     stage_consts<C>(cst, A, true);
+    stage_units<C, true>(ucst, A, gp(A.sums));
     __syncthreads();
     const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
-    const long wave_g = (long)blockIdx.x * WPB + wv, nwaves = (long)gridDim.x * WPB;
+    const GeoW G = geo_weights(A);
     f32x4 sg[4], sgr[4], sgh[NOB], accw[NOB][4], m1[4], r1[4];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
@@ -465,15 +636,29 @@ __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
     }
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob) sgh[ob] = zero4();
-    fl::PointWalk pw(A, threadIdx.x >> 6);
+    fl::PointWalk pw(A, wv);
     int nb_next = pw.valid() ? A.idx[pw.point() * 16 + row] : -1;
     for (; pw.valid(); pw.step()) {
         const long i = pw.point();
-        const int nb_cur = nb_next;
-        nb_next = pw.has_next() ? A.idx[pw.next_point() * 16 + row] : -1;   // next trip's index: in flight during this trip
-        const PRow R = load_prow(A, i, nb_cur);
+        const size_t ri = (size_t)i * 16 + row;
+        const int nb = nb_next;
+        const size_t nbc = (size_t)max(nb, 0);
+        nb_next = A.idx[(pw.has_next() ? pw.next_point() : i) * 16 + row];   // next trip's index: in flight during this trip
+        float pn[3], pi[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) { pn[b] = A.p[nbc * 3 + b]; pi[b] = A.p[(size_t)i * 3 + b]; }
+        f32x4 h[NOB], g2[NOB], xk[4], xq[4];
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) { h[ob] = ld_row4<BF>(A.H, ri * CS + unit_off<C>(ob, kq)); g2[ob] = ld_row4<BF>(A.G2, ri * CS + unit_off<C>(ob, kq)); }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int c4 = c0 + 16 * jj + 4 * kq;
+            xk[jj] = ld4(A.xk + nbc * C + c4); xq[jj] = ld4(A.xq + (size_t)i * C + c4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const Geo R = geo_of(G, nb, pn, pi);
         f32x4 gh[NOB];
-        hidden_grad<C>(A, gp(A.sums), i, row, kq, gh);
+        hidden_grad<C>(ucst, kq, h, g2, gh);
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) {
             sgh[ob] += gh[ob];
@@ -488,7 +673,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(16 * ob + 4 * kq + e) * WS + 16 * jj + row], gh[ob][e], acc, 0, 0, 0);
-            const f32x4 r = r4_of(A, cst, C, i, R, g);
+            const f32x4 r = (sel4(nb >= 0, xk[jj]) - xq[jj]) + pos4(cst, C, g, R.t1n);
             const f32x4 y1 = r * ld4(cst + 4 * C + 4 * g) + ld4(cst + 5 * C + 4 * g);
             f32x4 gy1;
 #pragma unroll
@@ -513,100 +698,133 @@ __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
         }
         wave_sync();
     }
-    float *o = A.partial + wave_g * W;
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float a = sg[jj][r], b = sgr[jj][r];
-#pragma unroll
-            for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
-            if (row == 0) { o[c0 + 16 * jj + 4 * kq + r] = a; o[C + c0 + 16 * jj + 4 * kq + r] = b; }
-        }
-#pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) {
-        if (slab == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float a = sgh[ob][r];
-#pragma unroll
-                for (int m = 1; m < 16; m <<= 1) a += __shfl_xor(a, m, 64);
-                if (row == 0 && 16 * ob + 4 * kq < CS) o[2 * C + 16 * ob + 4 * kq + r] = a;
-            }
-        }
+    // slab-local row in LDS: [sum g_y1 (64) | sum g_y1*rhat (64) | g_bw1 (CSP; slab 0 only) | g_Ww1[:, slab] (CS x 64)]
+    block_row(lds, 128 + CSP + CS * 64, [&](RowAcc o) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (16 * ob + 4 * kq < CS) o[2 * C + CS + (size_t)(16 * ob + 4 * kq + r) * C + c0 + 16 * jj + row] = accw[ob][jj][r];
-    }
+            for (int r = 0; r < 4; ++r) {
+                float a = sg[jj][r], b = sgr[jj][r];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+                if (row == 0) { o[16 * jj + 4 * kq + r] = a; o[64 + 16 * jj + 4 * kq + r] = b; }
+            }
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) {
+            if (slab == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float a = sgh[ob][r];
+#pragma unroll
+                    for (int m = 1; m < 16; m <<= 1) a += __shfl_xor(a, m, 64);
+                    if (row == 0 && 16 * ob + 4 * kq < CS) o[128 + 16 * ob + 4 * kq + r] = a;
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (16 * ob + 4 * kq < CS) o[128 + CSP + (16 * ob + 4 * kq + r) * 64 + 16 * jj + row] = accw[ob][jj][r];
+        }
+    });
+    float *dst = A.partial + (size_t)blockIdx.x * W;
+    if (threadIdx.x < 128) dst[(threadIdx.x >> 6) * C + c0 + (threadIdx.x & 63)] = lds[threadIdx.x];
+    if (slab == 0 && threadIdx.x < CS) dst[2 * C + threadIdx.x] = lds[128 + threadIdx.x];
+    for (int e = threadIdx.x; e < CS * 64; e += NT) dst[2 * C + CS + (size_t)(e >> 6) * C + c0 + (e & 63)] = lds[128 + CSP + e];
 }
 
 // ------------------------------------------------------------------------------------------------ B3
-// partial row per wave: [sum g_yp (3) | sum g_yp*that (3) | pad 2 | g_bp2 (C) | g_Wp2 (C*3)]   (as fl::k_b3)
-#ifndef PDF_B3_ROLLED
-#define PDF_B3_ROLLED 1   // rolled is 5-15 % faster at C <= 256 (measured), the unrolled form only wins at C = 512
-#endif
-template <int C>
+// partial row per block: [sum g_yp (3) | sum g_yp*that (3) | pad 2 | g_bp2 (C) | g_Wp2 (C*3)]   (as fl::k_b3)
+template <int C, bool BF>
 __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
     constexpr int CS = C / 8, NOB = nob_of(C), CSP = csp_of(C), NCHK = C / 64, WS = 68, W = 8 + 4 * C;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wv = threadIdx.x >> 6;
-    float *cst = lds, *w2 = cst + 6 * C, *wl = w2 + w2_floats(C);        // wl: Ww1[:, 64 q ..+64] of the current chunk
+    float *cst = lds;                        // Wp2 (3C, channel-major) | bp2 (C) | s1 (C) | t1 (C)
+    float *ccst = cst + 6 * C;               // this chunk's channels: mean1 | rstd1 | sum g_y1 / rows | sum g_y1*rhat / rows   (4 x 64)
+    float *ucst = ccst + 256;                // per-unit constants (stage_units), sums = B1's
+    float *wl = ucst + 7 * CSP;              // Ww1[:, 64 q ..+64] of the current chunk, row stride 68
     float *tile = wl + CSP * WS + wv * 32 * TS, *tile2 = tile + 16 * TS;   // g_r tile, g_pr tile
     float *t1nt = wl + CSP * WS + WPB * 32 * TS + wv * 64;
-    int *rowid = reinterpret_cast<int *>(wl + CSP * WS + WPB * 32 * TS + WPB * 64) + wv * 16;
+    float *crow = wl + CSP * WS + WPB * 32 * TS + WPB * 64;   // WPB x 256: the waves' columns of the current chunk
     stage_consts<C>(cst, A, true);
-    stage_w2<C>(w2, A);
+    const float *S2 = gp(A.sums);   // [sum g_y1 (C) | sum g_y1*rhat (C)]   (A.sums2 = B1's [sum g_y2 | sum g_y2*hhat])
+    stage_units<C, true>(ucst, A, gp(A.sums2));
     const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
-    const long wave_g = (long)blockIdx.x * WPB + wv, nwaves = (long)gridDim.x * WPB;
-    const float *S2 = gp(A.sums), *S1 = gp(A.sums2);   // [sum g_y1 (C) | sum g_y1*rhat (C)], [sum g_y2 | sum g_y2*hhat]
+    const GeoW G = geo_weights(A);
     float sgp[3] = {0.f, 0.f, 0.f}, sgpt[3] = {0.f, 0.f, 0.f};
-    float *o = A.partial + wave_g * W;
+    float *dst = A.partial + (size_t)blockIdx.x * W;   // the block's partial row
     // The 64-channel chunks are the OUTER loop (every chunk re-derives the cheap per-point quantities): the per-channel
     // accumulators then are four scalars, the Ww1 copy in LDS is one 64-column slab, and g_t1n (a sum over all channels)
     // is accumulated in G3 by the owning lane.
 #pragma unroll 1
     for (int q = 0; q < NCHK; ++q) {
         __syncthreads();   // previous slab fully consumed (and, first trip, constants staged)
-        for (int e = threadIdx.x; e < CSP * 64; e += 64 * WPB) wl[(e / 64) * WS + e % 64] = e / 64 < CS ? gp(A.Ww1)[(size_t)(e / 64) * C + 64 * q + e % 64] : 0.f;
+        stage_rows<CSP, 64, WS>(wl, gp(A.Ww1) + 64 * q, C, CS);
+        {
+            const int arr = threadIdx.x >> 6, c = 64 * q + (threadIdx.x & 63);
+            const float *src = arr == 0 ? gp(A.mean) + 3 : arr == 1 ? gp(A.rstd) + 3 : arr == 2 ? S2 : S2 + C;
+            ccst[threadIdx.x] = src[c] * (arr >= 2 ? A.inv_rows : 1.f);
+        }
         __syncthreads();
         float sbp2 = 0.f, awp2[3] = {0.f, 0.f, 0.f};
-        for (fl::PointWalk pw(A, wv); pw.valid(); pw.step()) {
+        fl::PointWalk pw(A, wv);
+        int nb_next = pw.valid() ? A.idx[pw.point() * 16 + row] : -1;
+        for (; pw.valid(); pw.step()) {
             const long i = pw.point();
-            const PRow R = load_prow(A, i, A.idx[i * 16 + row]);   // (index prefetch one trip ahead: slower here at C = 256, measured)
-            if (kq == 0) { t1nt[row * 4 + 0] = R.t1n[0]; t1nt[row * 4 + 1] = R.t1n[1]; t1nt[row * 4 + 2] = R.t1n[2]; }
-            f32x4 gh[NOB], h[NOB], u[NOB], w[NOB];
-            hidden_grad<C>(A, S1, i, row, kq, gh, h);
-            attn_weights<C>(A, w2, row, kq, h, u, w);
-            float gt1n[3] = {0.f, 0.f, 0.f};
-#if PDF_B3_ROLLED
-#pragma unroll 1
-#else
+            const size_t ri = (size_t)i * 16 + row;
+            const int nb = nb_next;
+            const size_t nbc = (size_t)max(nb, 0);
+            // ---------------- every global load of the trip
+            nb_next = A.idx[(pw.has_next() ? pw.next_point() : i) * 16 + row];
+            float pn[3], pi[3], g3old[3];
 #pragma unroll
-#endif
+            for (int b = 0; b < 3; ++b) { pn[b] = A.p[nbc * 3 + b]; pi[b] = A.p[(size_t)i * 3 + b]; g3old[b] = A.G3[ri * 3 + b]; }
+            f32x4 hh[NOB], g2[NOB], w[NOB], xk[4], xq[4], go[4];
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) {
+                const size_t o = ri * CS + unit_off<C>(ob, kq);
+                hh[ob] = ld_row4<BF>(A.H, o); g2[ob] = ld_row4<BF>(A.G2, o); w[ob] = ld_row4<BF>(A.Wsm, o);
+            }
+#pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                const int g = 4 * (4 * q + jj) + kq;
+                const int c4 = 4 * (4 * (4 * q + jj) + kq);
+                xk[jj] = ld4(A.xk + nbc * C + c4); xq[jj] = ld4(A.xq + (size_t)i * C + c4); go[jj] = ld4(A.gout + (size_t)i * C + c4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const Geo R = geo_of(G, nb, pn, pi);
+            if (kq == 0) { t1nt[row * 4 + 0] = R.t1n[0]; t1nt[row * 4 + 1] = R.t1n[1]; t1nt[row * 4 + 2] = R.t1n[2]; }
+            // g_h of the lane's hidden units (BN2 backward); softmax weights as B1 stored them (Wsm) -- read back instead of redoing
+            // BN2, the (C/8)^2 product and the softmax for every 64-channel chunk
+            f32x4 gh[NOB];
+            hidden_grad<C>(ucst, kq, hh, g2, gh);
+#pragma unroll
+            for (int ob = 0; ob < NOB; ++ob) w[ob] = sel4(16 * ob + 4 * kq < CS, w[ob]);
+            if (CS < 16) {   // channels of lanes kq = 2, 3 use the units of lanes kq - 2
+                const f32x4 x = xchg32(w[0]);
+                if (kq >= 2) w[0] = x;
+            }
+            float gt1n[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int g = 4 * (4 * q + jj) + kq, gl = 4 * (4 * jj + kq);   // channel group in the layer / in the chunk
                 f32x4 acc = zero4();
 #pragma unroll
                 for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(16 * ob + 4 * kq + e) * WS + 16 * jj + row], gh[ob][e], acc, 0, 0, 0);
-                const f32x4 r = r4_of(A, cst, C, i, R, g);
+                const f32x4 r = (sel4(nb >= 0, xk[jj]) - xq[jj]) + pos4(cst, C, g, R.t1n);
                 const f32x4 s1 = ld4(cst + 4 * C + 4 * g);
                 const f32x4 y1 = r * s1 + ld4(cst + 5 * C + 4 * g);
                 f32x4 gy1;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) gy1[e] = y1[e] > 0.f ? acc[e] : 0.f;
                 // BN1 backward: g_r = s1 * (g_y1 - mean(g_y1) - rhat * mean(g_y1 * rhat))
-                const f32x4 rhat = (r - ld4(gp(A.mean) + 3 + 4 * g)) * ld4(gp(A.rstd) + 3 + 4 * g);
-                const f32x4 gr = s1 * (gy1 - ld4(S2 + 4 * g) * A.inv_rows - rhat * (ld4(S2 + C + 4 * g) * A.inv_rows));
+                const f32x4 rhat = (r - ld4(ccst + gl)) * ld4(ccst + 64 + gl);
+                const f32x4 gr = s1 * (gy1 - ld4(ccst + 128 + gl) - rhat * ld4(ccst + 192 + gl));
                 st4(tile + row * TS + 16 * jj + 4 * kq, gr);
-                f32x4 wsel = w[0];   // w[jj % NOB] with a rolled jj
-#pragma unroll
-                for (int t = 1; t < NOB; ++t) if (jj % NOB == t) wsel = w[t];
-                const f32x4 gpr = gr + ld4(A.gout + (size_t)i * C + 4 * g) * wsel;   // + the aggregation's share of p_r
+                const f32x4 gpr = gr + go[jj] * w[jj % NOB];   // + the aggregation's share of p_r
                 st4(tile2 + row * TS + 16 * jj + 4 * kq, gpr);
                 const f32x4 w0 = ld4(cst + 12 * g), w1 = ld4(cst + 12 * g + 4), w2v = ld4(cst + 12 * g + 8);
                 const float wp[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2v[0], w2v[1], w2v[2], w2v[3]};
@@ -618,15 +836,17 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
             wave_sync();
             {   // lanes along channels: g_r rows out (256 B per row and chunk), g_xq[i] = - sum_rows g_r
                 float acc = 0.f;
-#pragma unroll 4
+#pragma unroll
                 for (int rr = 0; rr < 16; ++rr) {
                     const float v = tile[rr * TS + lane];
                     acc += v;
-                    fl::st_u1_stream(A.GR, ((size_t)i * 16 + rr) * C + 64 * q + lane, v, A.bf16);   // g_xk = segmented sum of these rows
+                    const size_t o = ((size_t)i * 16 + rr) * C + 64 * q + lane;   // g_xk = segmented sum of these rows
+                    if constexpr (BF) __builtin_nontemporal_store((unsigned short)fl::f2bf(v), reinterpret_cast<unsigned short *>(A.GR) + o);
+                    else __builtin_nontemporal_store(v, A.GR + o);
                 }
                 A.gxq[(size_t)i * C + 64 * q + lane] = -acc;
             }
-#pragma unroll 4
+#pragma unroll
             for (int rr = 0; rr < 16; ++rr) {   // g_bp2 / g_Wp2 of channel 64 q + lane
                 const float v = tile2[rr * TS + lane];
                 sbp2 += v;
@@ -639,68 +859,103 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
                 v += __shfl_xor(v, 16, 64);
                 v += __shfl_xor(v, 32, 64);
                 if (kq == 0) {
-                    float *g3 = A.G3 + ((size_t)i * 16 + row) * 3 + a;
-                    if (q > 0) v += *g3;
+                    if (q > 0) v += g3old[a];
                     if (q == NCHK - 1) {   // all channels seen: ReLU mask of BNp, BNp-backward sums
                         v = R.t1n[a] > 0.f ? v : 0.f;
                         sgp[a] += v;
                         sgpt[a] += v * ((R.t1[a] - A.mean[a]) * A.rstd[a]);
                     }
-                    *g3 = v;
+                    A.G3[ri * 3 + a] = v;
                 }
             }
         }
-        o[8 + 64 * q + lane] = sbp2;
+        // this chunk's columns of the block's row (g_bp2: 64, g_Wp2: 64 x 3): per wave into LDS, summed in wave order
+        crow[wv * 256 + lane] = sbp2;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) o[8 + C + (size_t)(64 * q + lane) * 3 + a] = awp2[a];
-    }
+        for (int a = 0; a < 3; ++a) crow[wv * 256 + 64 + lane * 3 + a] = awp2[a];
+        __syncthreads();
+        {
+            const int t = threadIdx.x;   // 256 threads, 256 columns
+            float v = crow[t];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float x = pdf_wave_sum_f32(sgp[a]), y = pdf_wave_sum_f32(sgpt[a]);
-        if (lane == 0) { o[a] = x; o[3 + a] = y; }
+            for (int w = 1; w < WPB; ++w) v += crow[w * 256 + t];
+            if (t < 64) dst[8 + 64 * q + t] = v; else dst[8 + C + (size_t)192 * q + (t - 64)] = v;
+        }
     }
-    if (lane == 0) { o[6] = 0.f; o[7] = 0.f; }
+    block_row(crow, 8, [&](RowAcc o) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float x = pdf_wave_sum_f32(sgp[a]), y = pdf_wave_sum_f32(sgpt[a]);
+            if (lane == 0) { o[a] = x; o[3 + a] = y; }
+        }
+        if (lane == 0) { o[6] = 0.f; o[7] = 0.f; }
+    });
+    store_row(crow, 8, dst);
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
+// (every allocation also holds the WPB partial rows of the epilogue, fl::block_row)
 template <typename KernelT>
 static void launch(KernelT kernel, dim3 grid, size_t lds_floats, const LayerArgs &A, hipStream_t s) {
     const size_t lds = lds_floats * sizeof(float);
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     kernel<<<grid, 64 * WPB, lds, s>>>(A);
 }
-#define PDF_FLM(KERNEL, GRID, LDS)                                                   \
-    do {                                                                              \
-        if (c == 64) launch(KERNEL<64>, GRID, LDS, A, s);                             \
-        else if (c == 128) launch(KERNEL<128>, GRID, LDS, A, s);                      \
-        else if (c == 256) launch(KERNEL<256>, GRID, LDS, A, s);                      \
-        else launch(KERNEL<512>, GRID, LDS, A, s);                                    \
+// KERNEL<C, ..., bf16 storage?> by the runtime channel count and storage flag
+#define PDF_FLM_C(KERNEL_OF, GRID, LDS)                                             \
+    do {                                                                             \
+        if (c == 64) { KERNEL_OF(64); } else if (c == 128) { KERNEL_OF(128); }       \
+        else if (c == 256) { KERNEL_OF(256); } else { KERNEL_OF(512); }              \
     } while (0)
 
-void launch_p2(const LayerArgs &A, int c, int grid, hipStream_t s) { PDF_FLM(k_p2, dim3(grid, c / 64), (size_t)4 * c); }
+void launch_p2(const LayerArgs &A, int c, int grid, hipStream_t s) {
+    const dim3 g(grid, c / 64);
+    const size_t lds = std::max<size_t>((size_t)4 * c, WPB * 128);
+#define K_(C_) launch(k_p2<C_>, g, lds, A, s)
+    PDF_FLM_C(K_, g, lds);
+#undef K_
+}
 void launch_p3(const LayerArgs &A, int c, bool stats, int grid, hipStream_t s) {
+    const dim3 g(grid);
     const size_t lds = (size_t)6 * c + (size_t)csp_of(c) * (c + 4);
-    if (stats) {
-        if (c == 64) launch(k_p3<64, true>, dim3(grid), lds, A, s); else if (c == 128) launch(k_p3<128, true>, dim3(grid), lds, A, s); else if (c == 256) launch(k_p3<256, true>, dim3(grid), lds, A, s); else launch(k_p3<512, true>, dim3(grid), lds, A, s);
-    } else {
-        if (c == 64) launch(k_p3<64, false>, dim3(grid), lds, A, s); else if (c == 128) launch(k_p3<128, false>, dim3(grid), lds, A, s); else if (c == 256) launch(k_p3<256, false>, dim3(grid), lds, A, s); else launch(k_p3<512, false>, dim3(grid), lds, A, s);
-    }
+#define K_(C_) do { if (stats) { if (A.bf16) launch(k_p3<C_, true, true>, g, lds, A, s); else launch(k_p3<C_, true, false>, g, lds, A, s); } \
+                    else { if (A.bf16) launch(k_p3<C_, false, true>, g, lds, A, s); else launch(k_p3<C_, false, false>, g, lds, A, s); } } while (0)
+    PDF_FLM_C(K_, g, lds);
+#undef K_
 }
 void launch_p4(const LayerArgs &A, int c, int grid, hipStream_t s) {
-    // no per-wave partial rows in this pass: size the grid for occupancy (one point per wave and trip, latency-bound)
-    long g = ((long)A.N + WPB - 1) / WPB;
-    g = g > 2048 ? 2048 : (g < grid ? grid : g);
-    PDF_FLM(k_p4, dim3((unsigned)g), (size_t)4 * c + w2_floats(c));
+    // no partial rows in this pass: size the grid for occupancy (one point per wave and trip)
+    long gl = ((long)A.N + WPB - 1) / WPB;
+    gl = gl > 2048 ? 2048 : (gl < grid ? grid : gl);
+    const dim3 g((unsigned)gl);
+    const size_t lds = (size_t)4 * c + 3 * csp_of(c) + w2_floats(c);
+#define K_(C_) do { if (A.bf16) launch(k_p4<C_, true>, g, lds, A, s); else launch(k_p4<C_, false>, g, lds, A, s); } while (0)
+    PDF_FLM_C(K_, g, lds);
+#undef K_
 }
 void launch_b1(const LayerArgs &A, int c, int grid, hipStream_t s) {
-    PDF_FLM(k_b1, dim3(grid), (size_t)4 * c + w2_floats(c) + WPB * 16 * TS + 2 * WPB * 16 * (csp_of(c) + 4) + WPB * 16);
+    const dim3 g(grid);
+    const size_t lds = std::max<size_t>((size_t)4 * c + 7 * csp_of(c) + w2_floats(c) + 2 * WPB * 16 * (csp_of(c) + 4),
+                                        (size_t)WPB * (3 * (c / 8) + (c / 8) * (c / 8)));
+#define K_(C_) do { if (A.bf16) launch(k_b1<C_, true>, g, lds, A, s); else launch(k_b1<C_, false>, g, lds, A, s); } while (0)
+    PDF_FLM_C(K_, g, lds);
+#undef K_
 }
 void launch_b2(const LayerArgs &A, int c, int grid, hipStream_t s) {
-    PDF_FLM(k_b2, dim3(grid, c / 64), (size_t)6 * c + (size_t)csp_of(c) * 68 + WPB * 16 * (csp_of(c) + 4) + WPB * 16 * TS);
+    const dim3 g(grid, c / 64);
+    const size_t lds = std::max<size_t>((size_t)6 * c + 7 * csp_of(c) + (size_t)csp_of(c) * 68 + WPB * 16 * (csp_of(c) + 4) + WPB * 16 * TS,
+                                        (size_t)WPB * (128 + csp_of(c) + c / 8 * 64));
+#define K_(C_) do { if (A.bf16) launch(k_b2<C_, true>, g, lds, A, s); else launch(k_b2<C_, false>, g, lds, A, s); } while (0)
+    PDF_FLM_C(K_, g, lds);
+#undef K_
 }
 void launch_b3(const LayerArgs &A, int c, int grid, hipStream_t s) {
-    PDF_FLM(k_b3, dim3(grid), (size_t)6 * c + w2_floats(c) + (size_t)csp_of(c) * 68 + WPB * 32 * TS + WPB * 64 + WPB * 16);
+    const dim3 g(grid);
+    const size_t lds = (size_t)6 * c + 256 + 7 * csp_of(c) + (size_t)csp_of(c) * 68 + WPB * 32 * TS + WPB * 64 + WPB * 256;
+#define K_(C_) do { if (A.bf16) launch(k_b3<C_, true>, g, lds, A, s); else launch(k_b3<C_, false>, g, lds, A, s); } while (0)
+    PDF_FLM_C(K_, g, lds);
+#undef K_
 }
-#undef PDF_FLM
+#undef PDF_FLM_C
 
 }  // namespace flm

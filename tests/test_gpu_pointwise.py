@@ -170,7 +170,9 @@ def test_bottleneck_matrix_core_path(C, K, train):
         if k == "y" or k.startswith("b_"):
             assert max_rel(a[k], b[k]) < 2e-5, (k, max_rel(a[k], b[k]))
         else:  # gradients: Frobenius norm (isolated ReLU-kink flips, see helpers.l2_rel)
-            assert l2_rel(a[k], b[k]) < 5e-3, (k, l2_rel(a[k], b[k]), max_rel(a[k], b[k]))  # 3-element tensors (BNp) get no averaging
+            # 3-element tensors (BNp) get no averaging: one ReLU-kink flip among 560 x 16 rows moves them by ~5e-3 in EITHER path
+            tol = 1e-2 if b[k].size <= 3 else 5e-3
+            assert l2_rel(a[k], b[k]) < tol, (k, l2_rel(a[k], b[k]), max_rel(a[k], b[k]))
 
 
 @pytest.mark.parametrize("n,c", [(200003, 13), (5000, 14), (77, 64), (3, 2)])
