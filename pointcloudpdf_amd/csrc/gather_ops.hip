@@ -332,23 +332,30 @@ __global__ __launch_bounds__(GB) void grouping_fwd_ord(unsigned total, FastDiv c
                                                        const int *__restrict__ idx, v4f *__restrict__ output) {
     const unsigned cv = cvd.d, blk = xcd_chunked_block(blockIdx.x, gridDim.x);
     const unsigned w0 = blk * (GB * U) + threadIdx.x;
+    // three phases, each with its U loads in flight together (visiting order -> neighbour index -> row piece): loads use clamped
+    // addresses and the masks are applied afterwards -- a load under a condition gets a branch and a wait of its own
     v4f v[U];
-    unsigned long dst[U];
+    unsigned long dst[U], row[U];
+    unsigned col[U], sq[U], jn[U];
+    int src[U];
     bool live[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const unsigned w = w0 + u * GB;
         live[u] = w < total;
-        const unsigned sq = live[u] ? fdiv(w, rowd) : 0;           // position in the visiting order
-        const unsigned rem = w - sq * rowd.d, j = fdiv(rem, cvd), col = rem - j * cv;
-        const unsigned long row = (unsigned long)(order ? (unsigned)order[sq] : sq) * nsample + j;
-        const int src = live[u] ? idx[row] : -1;
-        dst[u] = row * cv + col;
-        v[u] = src >= 0 ? input[(unsigned long)src * cv + col] : (v4f)(0.f);
+        sq[u] = fdiv(live[u] ? w : 0u, rowd);
+        const unsigned rem = (live[u] ? w : 0u) - sq[u] * rowd.d;
+        jn[u] = fdiv(rem, cvd); col[u] = rem - jn[u] * cv;
     }
 #pragma unroll
+    for (int u = 0; u < U; ++u) row[u] = (unsigned long)(order ? (unsigned)order[sq[u]] : sq[u]) * nsample + jn[u];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { src[u] = idx[row[u]]; dst[u] = row[u] * cv + col[u]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = input[(unsigned long)max(src[u], 0) * cv + col[u]];
+#pragma unroll
     for (int u = 0; u < U; ++u)
-        if (live[u]) st_stream(output + dst[u], v[u]);
+        if (live[u]) st_stream(output + dst[u], src[u] >= 0 ? v[u] : (v4f)(0.f));
 }
 
 // the same visiting scheme for the other forward gathers (order == nullptr: queries in storage order, still one contiguous
@@ -360,24 +367,27 @@ __global__ __launch_bounds__(GB) void sub_fwd_ord(unsigned total, FastDiv cvd, F
     const unsigned cv = cvd.d, blk = xcd_chunked_block(blockIdx.x, gridDim.x);
     const unsigned w0 = blk * (GB * U) + threadIdx.x;
     v4f a[U], b[U];
-    unsigned long dst[U];
+    unsigned long dst[U], row[U];
+    unsigned col[U], sq[U], jn[U], q[U];
+    int src[U];
     bool live[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const unsigned w = w0 + u * GB;
         live[u] = w < total;
-        const unsigned sq = live[u] ? fdiv(w, rowd) : 0;
-        const unsigned rem = w - sq * rowd.d, j = fdiv(rem, cvd), col = rem - j * cv;
-        const unsigned q = order ? (unsigned)order[sq] : sq;
-        const unsigned long row = (unsigned long)q * nsample + j;
-        const int src = live[u] ? idx[row] : -1;
-        dst[u] = row * cv + col;
-        a[u] = input1[(unsigned long)q * cv + col];
-        b[u] = src >= 0 ? input2[(unsigned long)src * cv + col] : (v4f)(0.f);
+        sq[u] = fdiv(live[u] ? w : 0u, rowd);
+        const unsigned rem = (live[u] ? w : 0u) - sq[u] * rowd.d;
+        jn[u] = fdiv(rem, cvd); col[u] = rem - jn[u] * cv;
     }
 #pragma unroll
+    for (int u = 0; u < U; ++u) { q[u] = order ? (unsigned)order[sq[u]] : sq[u]; row[u] = (unsigned long)q[u] * nsample + jn[u]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) { src[u] = idx[row[u]]; dst[u] = row[u] * cv + col[u]; a[u] = input1[(unsigned long)q[u] * cv + col[u]]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) b[u] = input2[(unsigned long)max(src[u], 0) * cv + col[u]];
+#pragma unroll
     for (int u = 0; u < U; ++u)
-        if (live[u]) st_stream(output + dst[u], a[u] - b[u]);
+        if (live[u]) st_stream(output + dst[u], a[u] - (src[u] >= 0 ? b[u] : (v4f)(0.f)));
 }
 
 // interpolation / aggregation: one lane = (query, 16-byte piece), the neighbours are a loop
@@ -392,10 +402,10 @@ __global__ __launch_bounds__(GB) void interp_fwd_ord(unsigned total, FastDiv cvd
 #pragma unroll
     for (int i = 0; i < K; ++i) { j[i] = idx[(unsigned long)r * K + i]; wt[i] = weight[(unsigned long)r * K + i]; }
 #pragma unroll
-    for (int i = 0; i < K; ++i) v[i] = j[i] >= 0 ? input[(unsigned long)j[i] * cv + col] : (v4f)(0.f);
+    for (int i = 0; i < K; ++i) v[i] = input[(unsigned long)max(j[i], 0) * cv + col];
     v4f acc = (v4f)(0.f);
 #pragma unroll
-    for (int i = 0; i < K; ++i) acc += v[i] * wt[i];   // same summation order as the reference (i ascending)
+    for (int i = 0; i < K; ++i) acc += (j[i] >= 0 ? v[i] : (v4f)(0.f)) * wt[i];   // same summation order as the reference (i ascending)
     st_stream(output + (unsigned long)r * cv + col, acc);
 }
 
@@ -408,11 +418,24 @@ __global__ __launch_bounds__(GB) void agg_fwd_ord(unsigned total, FastDiv cvd, i
     const unsigned sq = fdiv(w, cvd), col = w - sq * cv, wcol = col % wv, r = order ? (unsigned)order[sq] : sq;
     v4f acc = (v4f)(0.f);
     const unsigned long base = (unsigned long)r * nsample;
-#pragma unroll 4
-    for (int s = 0; s < nsample; ++s) {
+    int s = 0;
+    for (; s + 4 <= nsample; s += 4) {   // four neighbours at a time: indices, then rows / positions / weights, then the sum (s ascending)
+        int j[4]; v4f in[4], pos[4], wt[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) j[t] = idx[base + s + t];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            in[t] = input[(unsigned long)max(j[t], 0) * cv + col];
+            pos[t] = __builtin_nontemporal_load(position + (base + s + t) * cv + col);
+            wt[t] = weight[(base + s + t) * wv + wcol];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc += ((j[t] >= 0 ? in[t] : (v4f)(0.f)) + pos[t]) * wt[t];
+    }
+    for (; s < nsample; ++s) {
         const int j = idx[base + s];
-        const v4f in = j >= 0 ? input[(unsigned long)j * cv + col] : (v4f)(0.f);
-        acc += (in + __builtin_nontemporal_load(position + (base + s) * cv + col)) * weight[(base + s) * wv + wcol];
+        const v4f in = input[(unsigned long)max(j, 0) * cv + col];
+        acc += ((j >= 0 ? in : (v4f)(0.f)) + __builtin_nontemporal_load(position + (base + s) * cv + col)) * weight[(base + s) * wv + wcol];
     }
     output[(unsigned long)r * cv + col] = acc;
 }
@@ -429,29 +452,42 @@ __global__ __launch_bounds__(GB) void group_fwd_rows_ord(unsigned total, FastDiv
     const unsigned w0 = blk * (GB * U) + threadIdx.x;
     v4f v[U];
     float *o[U];
-    unsigned q[U], m[U];
+    unsigned q[U], m[U], sq[U], jn[U];
+    unsigned long r[U];
     int j[U];
+    float dx[U][3];
     bool live[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const unsigned w = w0 + u * GB;
         live[u] = w < total;
-        const unsigned sq = live[u] ? fdiv(w, qd) : 0, rem = w - sq * qd.d, jn = fdiv(rem, pd);
-        q[u] = rem - jn * pieces;
-        m[u] = order ? (unsigned)order[sq] : sq;
-        const unsigned long r = (unsigned long)m[u] * nsd.d + jn;
-        j[u] = live[u] ? idx[r] : -1;
-        o[u] = output + r * oc;
-        v[u] = (q[u] < cv && j[u] >= 0) ? reinterpret_cast<const v4f *>(feat)[(unsigned long)j[u] * cv + q[u]] : (v4f)(0.f);
+        sq[u] = fdiv(live[u] ? w : 0u, qd);
+        const unsigned rem = (live[u] ? w : 0u) - sq[u] * qd.d;
+        jn[u] = fdiv(rem, pd);
+        q[u] = rem - jn[u] * pieces;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) { m[u] = order ? (unsigned)order[sq[u]] : sq[u]; r[u] = (unsigned long)m[u] * nsd.d + jn[u]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) { j[u] = idx[r[u]]; o[u] = output + r[u] * oc; }
+    // (every lane issues the feature piece AND, clamped, nothing else under a branch: the coordinate lanes read xyz / new_xyz)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const unsigned long jc = (unsigned long)max(j[u], 0);
+        v[u] = reinterpret_cast<const v4f *>(feat)[jc * cv + min(q[u], cv - 1)];
+        if (with_xyz) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) dx[u][a] = xyz[jc * 3 + a] - new_xyz[(unsigned long)m[u] * 3 + a];
+        }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         if (!live[u]) continue;
         if (q[u] < cv) {
-            *reinterpret_cast<u4f *>(o[u] + sh + 4 * q[u]) = (u4f)v[u];
+            *reinterpret_cast<u4f *>(o[u] + sh + 4 * q[u]) = (u4f)(j[u] >= 0 ? v[u] : (v4f)(0.f));
         } else {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) o[u][a] = j[u] >= 0 ? xyz[(unsigned long)j[u] * 3 + a] - new_xyz[(unsigned long)m[u] * 3 + a] : 0.f;
+            for (int a = 0; a < 3; ++a) o[u][a] = j[u] >= 0 ? dx[u][a] : 0.f;
         }
     }
 }
