@@ -22,6 +22,7 @@
 namespace sg {
 
 constexpr int TB = 256;
+constexpr int SB = 8;   // entries of a segment in flight per trip
 
 struct FastDiv { unsigned d, m, s; };   // x / d for x < 2^31 by multiply-high (d >= 1)
 static inline FastDiv mk_fastdiv(unsigned d) {
@@ -72,13 +73,18 @@ __global__ __launch_bounds__(TB) void k_seg_rows(unsigned total, FastDiv cvd, un
     int t = inv_off[v];
     const int end = inv_off[v + 1];
     T a0 = zero<V>(), a1 = zero<V>();
-    for (; t + 4 <= end; t += 4) {
-        const int e0 = inv_entry[t] - entry_base, e1 = inv_entry[t + 1] - entry_base, e2 = inv_entry[t + 2] - entry_base, e3 = inv_entry[t + 3] - entry_base;
-        const T x0 = vld(src + (size_t)e0 * sv + p), x1 = vld(src + (size_t)e1 * sv + p);
-        const T x2 = vld(src + (size_t)e2 * sv + p), x3 = vld(src + (size_t)e3 * sv + p);
-        add_acc(a0, x0); add_acc(a1, x1); add_acc(a0, x2); add_acc(a1, x3);
+    // SB entries per trip, all entry ids in flight together, then all rows (a segment of <= SB entries costs two memory round trips;
+    // the tail is masked, not a serial loop: its ids are clamped to the segment's last entry -- a line the trip reads anyway)
+    for (; t < end; t += SB) {
+        int e[SB];
+        T x[SB];
+#pragma unroll
+        for (int k = 0; k < SB; ++k) e[k] = inv_entry[min(t + k, end - 1)] - entry_base;
+#pragma unroll
+        for (int k = 0; k < SB; ++k) x[k] = vld(src + (size_t)e[k] * sv + p);
+#pragma unroll
+        for (int k = 0; k < SB; ++k) add_acc((k & 1) ? a1 : a0, t + k < end ? x[k] : zero<V>());
     }
-    for (; t < end; ++t) add_acc(a0, vld(src + (size_t)(inv_entry[t] - entry_base) * sv + p));
     add_acc(a0, a1);
     out[(size_t)v * cv + p] = scaled(a0, scale);
 }
@@ -112,17 +118,15 @@ __global__ __launch_bounds__(TB) void k_seg_weighted(unsigned total, FastDiv cvd
             return w[(size_t)e * w_c + wo];
         }
     };
-    for (; t + 4 <= end; t += 4) {
-        const unsigned e0 = (unsigned)(inv_entry[t] - entry_base), e1 = (unsigned)(inv_entry[t + 1] - entry_base);
-        const unsigned e2 = (unsigned)(inv_entry[t + 2] - entry_base), e3 = (unsigned)(inv_entry[t + 3] - entry_base);
-        const T x0 = vld(src + (size_t)fdiv(e0, nsd) * cv + p), x1 = vld(src + (size_t)fdiv(e1, nsd) * cv + p);
-        const T x2 = vld(src + (size_t)fdiv(e2, nsd) * cv + p), x3 = vld(src + (size_t)fdiv(e3, nsd) * cv + p);
-        const T w0 = wload(e0), w1 = wload(e1), w2 = wload(e2), w3 = wload(e3);
-        fma_acc(a0, x0, w0); fma_acc(a1, x1, w1); fma_acc(a0, x2, w2); fma_acc(a1, x3, w3);
-    }
-    for (; t < end; ++t) {
-        const unsigned e0 = (unsigned)(inv_entry[t] - entry_base);
-        fma_acc(a0, vld(src + (size_t)fdiv(e0, nsd) * cv + p), wload(e0));
+    for (; t < end; t += SB) {   // (as k_seg_rows: ids, then rows + weights, masked tail)
+        unsigned e[SB];
+        T x[SB], ww[SB];
+#pragma unroll
+        for (int k = 0; k < SB; ++k) e[k] = (unsigned)(inv_entry[min(t + k, end - 1)] - entry_base);
+#pragma unroll
+        for (int k = 0; k < SB; ++k) { x[k] = vld(src + (size_t)fdiv(e[k], nsd) * cv + p); ww[k] = wload(e[k]); }
+#pragma unroll
+        for (int k = 0; k < SB; ++k) fma_acc((k & 1) ? a1 : a0, x[k], t + k < end ? ww[k] : zero<V>());
     }
     add_acc(a0, a1);
     out[(size_t)v * cv + p] = a0;
