@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--optimizer", choices=["fused", "torch"], default="fused",
+                    help="fused = SGD over all parameter tensors as one HIP launch (engine.FusedSGD); torch = torch.optim.SGD(fused=True)")
     ap.add_argument("--workload", choices=["s3dis", "scannet", "stratified"], default="s3dis",
                     help="s3dis = BASELINE config 2 / 3 (6 input channels, 13 classes, the headline); scannet = config 4 shape (coord + "
                          "colour + normal = 9 channels, 20 classes, unknown classes {4, 7, 14, 16}, 150k points per scene unless --points); "
@@ -312,7 +314,10 @@ def main():
     use_dp = world > 1 or force_dp
     module = engine.wrap_ddp(step, dev) if (use_dp and args.ddp == "torch") else step
     grad_sync = engine.FlatGradAllReduce(step) if (use_dp and args.ddp == "flat") else None
-    opt = torch.optim.SGD(step.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4, fused=True)
+    if args.optimizer == "fused":   # one launch over all 304 tensors (csrc/optim.hip); "torch" = torch.optim.SGD(fused=True), 13 launches
+        opt = engine.FusedSGD(step.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    else:
+        opt = torch.optim.SGD(step.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4, fused=True)
 
     def scene_sizes(i):
         if args.jitter <= 0:

@@ -290,6 +290,13 @@ int pdf_ce_forward(long n, int c, const float *logits, const long *target, long 
                    void *stream);
 int pdf_ce_backward(long n, int c, const float *dlogits, const float *acc, const float *gy, float *grad_out, void *stream);
 
+/* SGD with momentum and weight decay (torch.optim.SGD, dampening 0, no Nesterov -- the optimizer the reference's configs build,
+ * pointcept/utils/optimizer.py + configs/s3dis/openseg-pt-v1-0-*.py) over every parameter tensor in ONE launch.  tab: ntensors records
+ * {float *param; const float *grad; float *momentum; long length} in device memory; chunks: nchunks {tensor, chunk} int32 pairs, one
+ * per pdf_sgd_chunk() values of a tensor.  param / momentum are updated in place. */
+int pdf_sgd_chunk(void);
+int pdf_sgd_step(int nchunks, const void *tab, const int *chunks, float lr, float momentum, float weight_decay, void *stream);
+
 /* ---- libs/pointops2 window attention: the CSR-by-query v2 / v3 launchers of
  * libs/pointops2/src/attention_v2/attention_cuda_kernel_v2.h and libs/pointops2/src/rpe_v2/relative_pos_encoding_cuda_kernel_v2.h,
  * same parameter lists + stream.  N = number of queries (index0_offsets has N + 1 entries), M = edges, C = h * d,

@@ -493,6 +493,10 @@ class HipBackend(CBackend):
         lib.pdf_ce_forward.argtypes = [c_long, c_int, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p]
         lib.pdf_ce_backward.restype = c_int
         lib.pdf_ce_backward.argtypes = [c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        lib.pdf_sgd_chunk.restype = c_int
+        lib.pdf_sgd_chunk.argtypes = []
+        lib.pdf_sgd_step.restype = c_int
+        lib.pdf_sgd_step.argtypes = [c_int, c_void_p, c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_void_p]
         lib.pdf_linbn_forward.restype = c_int
         lib.pdf_linbn_forward.argtypes = [c_long, c_int, c_int, c_void_p, c_int, c_int, ctypes.c_float, ctypes.c_float, c_void_p]
         lib.pdf_linbn_backward.restype = c_int

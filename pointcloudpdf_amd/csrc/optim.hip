@@ -1,0 +1,61 @@
+// SGD with momentum and weight decay over ALL parameter tensors of the model in ONE launch (torch.optim.SGD semantics, dampening = 0,
+// no Nesterov: engines/defaults build the reference's optimizer from configs/_base_/default_runtime + the dataset config: SGD,
+// momentum 0.9, weight_decay 1e-4):   g' = g + wd * p;   buf = momentum * buf + g';   p -= lr * buf.
+// torch's fused multi-tensor SGD packs ~24 tensors per launch: 13 launches and 275 us per step for this model's 304 tensors (8.5 M
+// values, 170 MB of traffic = 21 us at the HBM peak).  Here the host hands over a table of (param, grad, momentum, length) and a
+// chunk list; one workgroup = one chunk of CH values of one tensor.  Bound: HBM.
+#include "pdfops_common.h"
+
+namespace {
+
+constexpr int OB = 256, CH = 4096;   // threads per workgroup, values per chunk
+
+struct SgdTensor { float *p; const float *g; float *m; long n; };
+
+__global__ __launch_bounds__(OB) void k_sgd(const SgdTensor *__restrict__ tab, const int2 *__restrict__ chunks, float lr, float momentum,
+                                            float wd) {
+    const int2 c = chunks[blockIdx.x];                 // (tensor, chunk inside the tensor)
+    const SgdTensor t = tab[c.x];
+    const long base = (long)c.y * CH;
+    const long left = t.n - base;
+    float *p = t.p + base, *m = t.m + base;
+    const float *g = t.g + base;
+    if (left >= CH && ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m)) & 15) == 0) {
+        float4 pv[CH / (4 * OB)], gv[CH / (4 * OB)], mv[CH / (4 * OB)];
+#pragma unroll
+        for (int k = 0; k < CH / (4 * OB); ++k) {
+            const int e = threadIdx.x + k * OB;
+            pv[k] = reinterpret_cast<const float4 *>(p)[e]; gv[k] = reinterpret_cast<const float4 *>(g)[e]; mv[k] = reinterpret_cast<const float4 *>(m)[e];
+        }
+#pragma unroll
+        for (int k = 0; k < CH / (4 * OB); ++k) {
+            const int e = threadIdx.x + k * OB;
+            float4 b;
+            b.x = momentum * mv[k].x + (gv[k].x + wd * pv[k].x); b.y = momentum * mv[k].y + (gv[k].y + wd * pv[k].y);
+            b.z = momentum * mv[k].z + (gv[k].z + wd * pv[k].z); b.w = momentum * mv[k].w + (gv[k].w + wd * pv[k].w);
+            reinterpret_cast<float4 *>(m)[e] = b;
+            reinterpret_cast<float4 *>(p)[e] = make_float4(pv[k].x - lr * b.x, pv[k].y - lr * b.y, pv[k].z - lr * b.z, pv[k].w - lr * b.w);
+        }
+    } else {
+        const long n = left < CH ? left : CH;
+        for (long e = threadIdx.x; e < n; e += OB) {
+            const float pe = p[e];
+            const float b = momentum * m[e] + (g[e] + wd * pe);
+            m[e] = b;
+            p[e] = pe - lr * b;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int pdf_sgd_chunk(void) { return CH; }
+
+// tab: ntensors x {param*, grad*, momentum*, length} (device, 32 bytes each); chunks: nchunks x {tensor, chunk} int32 pairs (device).
+extern "C" int pdf_sgd_step(int nchunks, const void *tab, const int *chunks, float lr, float momentum, float weight_decay, void *stream) {
+    if (nchunks == 0) return PDF_OK;
+    if (nchunks < 0 || !tab || !chunks) return PDF_ERR_BAD_ARG;
+    k_sgd<<<nchunks, OB, 0, static_cast<hipStream_t>(stream)>>>(static_cast<const SgdTensor *>(tab), reinterpret_cast<const int2 *>(chunks), lr, momentum,
+                                                              weight_decay);
+    return pdf_launch_status();
+}

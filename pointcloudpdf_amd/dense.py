@@ -62,6 +62,16 @@ class deferred_counters:
         return False
 
 
+_ONES_ROWS = {}
+
+
+def _ones_row(device, dtype):
+    key = (device, dtype)
+    if key not in _ONES_ROWS:
+        _ONES_ROWS[key] = torch.ones(1, 1, _CHUNK, device=device, dtype=dtype)
+    return _ONES_ROWS[key]
+
+
 class _LinearSplitK(torch.autograd.Function):
     @staticmethod
     @_amp_fwd
@@ -85,7 +95,16 @@ class _LinearSplitK(torch.autograd.Function):
             gw = torch.bmm(g[:body].view(s, _CHUNK, co).transpose(1, 2), x[:body].view(s, _CHUNK, ci)).sum(0)
             if body < n:
                 gw = gw + g[body:].t() @ x[body:]
-        gb = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        gb = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            # the bias gradient as a batched product with a row of ones (same split over the rows): torch's column reduction of a
+            # (200000, 13) tensor takes 250 us on MI355X, this 35
+            n, co = g.shape
+            s = n // _CHUNK
+            body = s * _CHUNK
+            gb = torch.bmm(_ones_row(g.device, g.dtype).expand(s, 1, _CHUNK), g[:body].view(s, _CHUNK, co)).sum(0).view(co) if s > 0 else g.new_zeros(co)
+            if body < n:
+                gb = gb + g[body:].sum(0)
         return gx, gw, gb
 
 

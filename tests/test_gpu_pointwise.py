@@ -271,3 +271,28 @@ def test_linear_bn_relu_node(n, k, o, train):
             assert max_rel(a[kk], b[kk]) < 2e-5, (kk, max_rel(a[kk], b[kk]))
         else:
             assert l2_rel(a[kk], b[kk]) < 2e-3, (kk, l2_rel(a[kk], b[kk]))
+
+
+def test_fused_sgd_matches_torch_sgd():
+    """engine.FusedSGD (one launch over all tensors, csrc/optim.hip) against torch.optim.SGD over five steps: odd lengths, a
+    tensor longer than several chunks, a misaligned view, a parameter that gets no gradient on some steps."""
+    from pointcloudpdf_amd import engine
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    shapes = [(3,), (13, 32), (70001,), (4096,), (512, 513), (9, 3, 3)]
+    base = [torch.randn(s, device="cuda", generator=g) for s in shapes]
+    flat = torch.randn(1001, device="cuda", generator=g)
+    pa = [torch.nn.Parameter(b.clone()) for b in base] + [torch.nn.Parameter(flat.clone()[1:])]   # (4-byte aligned only)
+    pb = [torch.nn.Parameter(b.clone()) for b in base] + [torch.nn.Parameter(flat.clone()[1:])]
+    oa = engine.FusedSGD(pa, lr=0.05, momentum=0.9, weight_decay=1e-2)
+    ob = torch.optim.SGD(pb, lr=0.05, momentum=0.9, weight_decay=1e-2)
+    for it in range(5):
+        oa.zero_grad(); ob.zero_grad()
+        for k, (x, y) in enumerate(zip(pa, pb)):
+            if k == 1 and it in (1, 3):
+                continue   # no gradient this step: skipped by both
+            gr = torch.randn(x.shape, device="cuda", generator=g)
+            x.grad, y.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+    for x, y in zip(pa, pb):
+        assert (x - y).abs().max() <= 1e-6 * (1 + y.abs().max()), (tuple(x.shape), float((x - y).abs().max()))
