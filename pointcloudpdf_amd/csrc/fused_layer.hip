@@ -832,7 +832,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b4(LayerArgs A) {
 // block = 16 columns x RED_RL row-lanes; every row-lane sums a strided subset of the rows.  These kernels are pure latency (a few
 // hundred KB read by 4 .. 64 workgroups, ~280 launches per step): every lane keeps RED_B independent loads in flight, so ~2,000 partial
 // rows cost two memory round trips instead of eight.
-constexpr int RED_RL = 64, RED_THREADS = 16 * RED_RL, RED_B = 16;
+constexpr int RED_RL = 16, RED_THREADS = 16 * RED_RL, RED_B = 16;
 __device__ __forceinline__ double strided_sum(const float *__restrict__ src, size_t stride, int rl, int rows) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     for (int r = rl; r < rows; r += RED_B * RED_RL) {
@@ -953,10 +953,13 @@ static inline int grid_for_points(long n, int cap) {
 // Per-pass grids of the matrix-core passes (one point per wave and trip).  The passes differ in what a resident block costs: P3 / B3 / B1
 // write short partial rows (2 C/8, 8 + 4 C, 3 C/8 + (C/8)^2 floats per wave) and gain from more waves per SIMD; B2's partial row holds a
 // (C/8) x C weight-gradient block per wave, so its grid stays small.  PDFOPS_PT_CAP_<pass> overrides the default cap.
-enum Pass { P3 = 0, B1 = 1, B2 = 2, B3 = 3 };
+// P2 / B2 run one workgroup per (point block, 64-channel slab): at C >= 256 the slab dimension already fills the chip and every extra
+// point block pays the slab staging and the partial-row epilogue again (B2 at 780 points x 512 channels: 90 us with 195 point blocks,
+// 45 us with 32).
+enum Pass { P3 = 0, B1 = 1, B2 = 2, B3 = 3, P2 = 4 };
 static inline int pass_grid(Pass pass, long n, int dflt_cap) {
-    static const int env_cap[4] = {env_blocks("PDFOPS_PT_CAP_P3", 0), env_blocks("PDFOPS_PT_CAP_B1", 0), env_blocks("PDFOPS_PT_CAP_B2", 0),
-                                   env_blocks("PDFOPS_PT_CAP_B3", 0)};   // (read once per process, like the other PDFOPS_PT_* caps)
+    static const int env_cap[5] = {env_blocks("PDFOPS_PT_CAP_P3", 0), env_blocks("PDFOPS_PT_CAP_B1", 0), env_blocks("PDFOPS_PT_CAP_B2", 0),
+                                   env_blocks("PDFOPS_PT_CAP_B3", 0), env_blocks("PDFOPS_PT_CAP_P2", 0)};   // (read once per process, like the other PDFOPS_PT_* caps)
     return grid_for_points(n, env_cap[pass] > 0 ? env_cap[pass] : dflt_cap);
 }
 
@@ -1016,8 +1019,10 @@ int forward_impl(LayerArgs A, int training, float eps, float momentum, const flo
     allow_lds(k_p4<C, K>, lds);
     k_p1<K><<<grid, 64 * WPB, 0, s>>>(A);
     k_bn_finalize<<<1, RED_THREADS, 0, s>>>(A.partial, grid, 3, (double)rows, bn_params[0], bn_params[1], eps, momentum, bn_buffers[0], bn_buffers[1], sp, tp, mp, rp);
-    if (flm::supported(K, C)) flm::launch_p2(A, C, grid, s); else k_p2<C, K><<<grid, 64 * WPB, lds, s>>>(A);
-    k_bn_finalize<<<pdf_divup(C, 16), RED_THREADS, 0, s>>>(A.partial, grid, C, (double)rows, bn_params[2], bn_params[3], eps, momentum, bn_buffers[2], bn_buffers[3], s1, t1, m1, r1);
+    int g2 = grid;
+    if (flm::supported(K, C)) { g2 = pass_grid(P2, A.N, C == 512 ? 64 : (C == 256 ? 128 : grid)); flm::launch_p2(A, C, g2, s); }
+    else k_p2<C, K><<<grid, 64 * WPB, lds, s>>>(A);
+    k_bn_finalize<<<pdf_divup(C, 16), RED_THREADS, 0, s>>>(A.partial, g2, C, (double)rows, bn_params[2], bn_params[3], eps, momentum, bn_buffers[2], bn_buffers[3], s1, t1, m1, r1);
     int nw3 = grid;   // (P3's partial rows are 2 C/8 floats: a larger grid than P2's fits the same scratch)
     if (flm::supported(K, C)) { const int g3 = pass_grid(P3, A.N, C <= 256 ? 2 * MAX_BLOCKS : MAX_BLOCKS); nw3 = g3; flm::launch_p3(A, C, true, g3, s); }
     else k_p3<C, K, true><<<grid, 64 * WPB, lds, s>>>(A);
@@ -1065,8 +1070,9 @@ int backward_impl(LayerArgs A, float *sums, const int *inv_off, const int *inv_e
     int rc = pdf_seg_sum_weighted_x(A.N, C, K, CS, A.gout, A.Wsm, A.bf16, inv_off, inv_entry, entry_base, gather_order, A.gxv, s);   // (destinations in Morton order: the g_out rows they share hit L2)
     if (rc != PDF_OK) return rc;
     A.sums = as_const(S1);
-    if (mfma) flm::launch_b2(A, C, grid, s); else k_b2<C, K><<<grid, 64 * WPB, lds, s>>>(A);
-    k_colsum<<<pdf_divup(b2_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, grid, b2_width<C>(), S2);
+    const int g2 = mfma ? std::min(grid, pass_grid(B2, A.N, C == 512 ? 32 : (C == 256 ? 128 : grid))) : grid;
+    if (mfma) flm::launch_b2(A, C, g2, s); else k_b2<C, K><<<grid, 64 * WPB, lds, s>>>(A);
+    k_colsum<<<pdf_divup(b2_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, g2, b2_width<C>(), S2);
     A.sums = as_const(S2);   // B3: BN1-backward terms from B2, BN2-backward terms from B1
     A.sums2 = as_const(S1);
     if (mfma) flm::launch_b3(A, C, g3, s); else k_b3<C, K><<<grid, 64 * WPB, lds, s>>>(A);
