@@ -65,6 +65,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--throttle", action="store_true",
+                    help="profiling aid: synchronise after every encoder / decoder block (forward and backward), so that at most ~100 "
+                         "dispatches are in flight -- rocprofv3 --pmc serialises kernels and its interception dies ('AQL packet is "
+                         "malformed' / SIGSEGV) when the host runs a whole step (1,100 dispatches) ahead of the device")
     ap.add_argument("--optimizer", choices=["fused", "torch"], default="fused",
                     help="fused = SGD over all parameter tensors as one HIP launch (engine.FusedSGD); torch = torch.optim.SGD(fused=True)")
     ap.add_argument("--workload", choices=["s3dis", "scannet", "stratified"], default="s3dis",
@@ -310,6 +314,13 @@ def main():
     step = engine.OpenSegStep(**step_kw).to(dev)
     synthetic.fill_parameters_deterministic(step, seed=1)  # identical "random-init" weights on every rank
     step.train()
+    if args.throttle:
+        from pointcloudpdf_amd import point_transformer as _pt
+        kinds = tuple(getattr(_pt, n) for n in ("Bottleneck", "TransitionDown", "TransitionUp") if hasattr(_pt, n))
+        for mod in step.modules():
+            if isinstance(mod, kinds):
+                mod.register_forward_hook(lambda *a: torch.cuda.synchronize())
+                mod.register_full_backward_hook(lambda *a: torch.cuda.synchronize())
     force_dp = bool(os.environ.get("PDFOPS_FORCE_DDP"))   # knob: exercise the N > 1 gradient exchange at world size 1
     use_dp = world > 1 or force_dp
     module = engine.wrap_ddp(step, dev) if (use_dp and args.ddp == "torch") else step
