@@ -13,7 +13,7 @@
  *   - all pointers are DEVICE pointers owned by the caller; the library never allocates,
  *     never synchronises and keeps no mutable global state (re-entrant, any thread, any stream).  The only process-wide inputs
  *     are a few read-only PDFOPS_* environment variables that select kernel variants / grid caps for experiments and tests
- *     (PDFOPS_FPS_MW, PDFOPS_KNN_*, PDFOPS_PT_BLOCKS_*; defaults are the measured best);
+ *     (PDFOPS_FPS_MW, PDFOPS_KNN_*, PDFOPS_PT_BLOCKS_*, PDFOPS_PT_CAP_<pass>; defaults are the measured best);
  *   - float data is fp32, indices/offsets are int32, `offset` arrays hold CUMULATIVE scene ends;
  *   - kNN placeholder for scenes with fewer than `nsample` points: idx = -1, dist2 = 1e10;
  *   - outputs written by plain stores need no initialisation (grouping/subtraction/

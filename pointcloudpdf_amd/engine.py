@@ -183,6 +183,9 @@ class FusedSGD:
         have = tuple(i for i, p in enumerate(self.params) if p.grad is not None)
         if not have:
             return
+        from . import _native
+
+        _native.require_current_device(self._tab)   # (launches go onto the current device's current stream)
         chunks, nchunks, static = self._plan(have)
         host, ev = self._ring[self._n % self.RING]
         self._n += 1
