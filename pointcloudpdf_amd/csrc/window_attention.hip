@@ -394,28 +394,53 @@ __global__ __launch_bounds__(WB) void k_dot3_bwd_m16(int N, int h, int L, const 
     for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) { aq[a][rb] = (f32x4)(0.f); ak[a][rb] = (f32x4)(0.f); }
-    for (long e = threadIdx.x; e < padded; e += WB) {
-        float xq = 0.f, xk = 0.f;
-        int r[3] = {-1, -1, -1};
-        if (e < total) {
-            const int m = e0 + (int)(e >> 4);
-            const int ql = find_query(offs, nq, m);
-            r[0] = rel_idx[(size_t)m * 3]; r[1] = rel_idx[(size_t)m * 3 + 1]; r[2] = rel_idx[(size_t)m * 3 + 2];
-            const float g = go[(size_t)m * h + hh];
-            const size_t kc = (size_t)index_k[m] * C + hh * d + i;
-            atomicAdd(&gqs[ql * d + i], lds_table_sum(tq, r[0], r[1], r[2], d, i) * g);
-            pdf_atomic_add(grad_k + kc, lds_table_sum(tk, r[0], r[1], r[2], d, i) * g);
-            xq = q[(size_t)(q0 + ql) * C + hh * d + i] * g;
-            xk = k[kc] * g;
+    // Two elements per lane and trip, every load of a trip issued before the first use (index / scalar loads, then the rows that depend
+    // on them), no load under `if (live)` -- clamped edge id, effects masked (a load under a branch is a wait of its own); the
+    // query of an edge is found by stepping on from the lane's previous query (edges are in CSR order: 0-1 steps instead of a 6-step
+    // binary search through LDS).
+    int ql_hint = 0;
+    const int m_last = e1 > e0 ? e1 - 1 : e0;
+    for (long e = threadIdx.x; e < padded; e += 2 * WB) {
+        bool live[2]; int m[2], ql[2], r[2][3], ik[2]; float g[2], xq[2], xk[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long eu = e + u * WB;
+            live[u] = eu < total;
+            m[u] = min(e0 + (int)(eu >> 4), m_last);
         }
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+        for (int u = 0; u < 2; ++u) {
+            r[u][0] = rel_idx[(size_t)m[u] * 3]; r[u][1] = rel_idx[(size_t)m[u] * 3 + 1]; r[u][2] = rel_idx[(size_t)m[u] * 3 + 2];
+            g[u] = go[(size_t)m[u] * h + hh];
+            ik[u] = index_k[m[u]];
+        }
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) {
-                const float hot = r[a] == 16 * rb + i ? 1.f : 0.f;
-                aq[a][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(hot, xq, aq[a][rb], 0, 0, 0);
-                ak[a][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(hot, xk, ak[a][rb], 0, 0, 0);
+        for (int u = 0; u < 2; ++u) {
+            while (ql_hint + 1 < nq && offs[ql_hint + 1] <= m[u]) ++ql_hint;
+            ql[u] = ql_hint;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            xq[u] = q[(size_t)(q0 + ql[u]) * C + hh * d + i];
+            xk[u] = k[(size_t)ik[u] * C + hh * d + i];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float gm = live[u] ? g[u] : 0.f;
+            if (live[u]) {
+                atomicAdd(&gqs[ql[u] * d + i], lds_table_sum(tq, r[u][0], r[u][1], r[u][2], d, i) * gm);
+                pdf_atomic_add(grad_k + (size_t)ik[u] * C + hh * d + i, lds_table_sum(tk, r[u][0], r[u][1], r[u][2], d, i) * gm);
             }
+            const float vq = xq[u] * gm, vk = xk[u] * gm;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    const float hot = (live[u] && r[u][a] == 16 * rb + i) ? 1.f : 0.f;
+                    aq[a][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(hot, vq, aq[a][rb], 0, 0, 0);
+                    ak[a][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(hot, vk, ak[a][rb], 0, 0, 0);
+                }
+        }
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -467,27 +492,45 @@ __global__ __launch_bounds__(WB) void k_step2rv_bwd_m16(int N, int h, int L, con
     for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) acc[a][rb] = (f32x4)(0.f);
-    for (long e = threadIdx.x; e < padded; e += WB) {
-        const bool live = e < total;
-        float part = 0.f, x = 0.f;
-        int m = 0, r[3] = {-1, -1, -1};
-        if (live) {
-            m = e0 + (int)(e >> 4);
-            const int ql = find_query(offs, nq, m);
-            r[0] = rel_idx[(size_t)m * 3]; r[1] = rel_idx[(size_t)m * 3 + 1]; r[2] = rel_idx[(size_t)m * 3 + 2];
-            const size_t vc = (size_t)index1[m] * C + hh * d + i;
-            const float gout = go[(size_t)(q0 + ql) * C + hh * d + i];
-            part = (lds_table_sum(tb, r[0], r[1], r[2], d, i) + v[vc]) * gout;
-            x = attn[(size_t)m * h + hh] * gout;
-            pdf_atomic_add(grad_v + vc, x);
+    int ql_hint = 0;   // (trip structure as k_dot3_bwd_m16)
+    const int m_last = e1 > e0 ? e1 - 1 : e0;
+    for (long e = threadIdx.x; e < padded; e += 2 * WB) {
+        bool live[2]; int m[2], ql[2], r[2][3], i1[2]; float at[2], gout[2], vv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long eu = e + u * WB;
+            live[u] = eu < total;
+            m[u] = min(e0 + (int)(eu >> 4), m_last);
         }
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+        for (int u = 0; u < 2; ++u) {
+            r[u][0] = rel_idx[(size_t)m[u] * 3]; r[u][1] = rel_idx[(size_t)m[u] * 3 + 1]; r[u][2] = rel_idx[(size_t)m[u] * 3 + 2];
+            at[u] = attn[(size_t)m[u] * h + hh];
+            i1[u] = index1[m[u]];
+        }
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-                acc[a][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(r[a] == 16 * rb + i ? 1.f : 0.f, x, acc[a][rb], 0, 0, 0);
-        for (int o = 8; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-        if (live && i == 0) grad_attn[(size_t)m * h + hh] = part;
+        for (int u = 0; u < 2; ++u) {
+            while (ql_hint + 1 < nq && offs[ql_hint + 1] <= m[u]) ++ql_hint;
+            ql[u] = ql_hint;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            gout[u] = go[(size_t)(q0 + ql[u]) * C + hh * d + i];
+            vv[u] = v[(size_t)i1[u] * C + hh * d + i];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float x = live[u] ? at[u] * gout[u] : 0.f;
+            float part = (lds_table_sum(tb, r[u][0], r[u][1], r[u][2], d, i) + vv[u]) * gout[u];
+            if (live[u]) pdf_atomic_add(grad_v + (size_t)i1[u] * C + hh * d + i, x);
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+                    acc[a][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32((live[u] && r[u][a] == 16 * rb + i) ? 1.f : 0.f, x, acc[a][rb], 0, 0, 0);
+            for (int o = 8; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+            if (live[u] && i == 0) grad_attn[(size_t)m[u] * h + hh] = part;
+        }
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a)
