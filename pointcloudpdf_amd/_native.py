@@ -906,11 +906,13 @@ class HipBackend(CBackend):
             raise PdfOpsError(f"pdf_bottleneck_forward failed with status {rc}")
 
     # optional second stream for the weight-gradient kernels of the Bottleneck backward (csrc/block.hip, Fork); PDFOPS_WGRAD_STREAM=1 turns it on
-    wgrad_stream = os.environ.get("PDFOPS_WGRAD_STREAM", "0") == "1"   # measured: 22.4 ms per step with it, 21.6 without (event traffic costs more than the overlap gains)
+    # "1": every block (measured: 22.4 ms per step with it, 21.6 without -- event traffic costs more than the overlap gains);
+    # "small": only blocks with at most 16,384 points (levels 3-5, where a weight-gradient kernel fills a fraction of the chip)
+    wgrad_stream = os.environ.get("PDFOPS_WGRAD_STREAM", "0")
 
-    def aux_handles(self, device):
+    def aux_handles(self, device, n=0):
         """[aux stream, fork event, join event] handles for ``device`` (created once per device), or three nulls."""
-        if not self.wgrad_stream:
+        if self.wgrad_stream not in ("1", "small") or (self.wgrad_stream == "small" and n > 16384):
             return [None, None, None]
         table = self.__dict__.setdefault("_aux", {})
         key = device.index if device.index is not None else torch.cuda.current_device()
