@@ -165,6 +165,13 @@ int pdf_pt_layer_forward(int n, int nsample, int c, const float *xq, const float
                          const float *const *bn_params, float *const *bn_buffers, int training, float eps,
                          float momentum, float *bn, float *saved, float *H, float *partial, float *out,
                          int storage_bf16, const int *order, void *stream);
+/* The same with the batch's relative-coordinate sums (pdf_knn_rel_moments, summed over the batch's scenes: 9 doubles in device
+ * memory) or NULL: in train mode the geometry branch's BatchNorm then comes from them (5 launches per layer instead of 7). */
+int pdf_pt_layer_forward_m(int n, int nsample, int c, const float *xq, const float *xk, const float *xv,
+                           const float *p, const int *idx, const float *const *weights,
+                           const float *const *bn_params, float *const *bn_buffers, int training, float eps,
+                           float momentum, float *bn, float *saved, float *H, float *partial, float *out,
+                           int storage_bf16, const int *order, const double *moments, void *stream);
 
 /* Backward of the fused PointTransformerLayer (train mode).  gxq / gxk / gxv are overwritten: the scatters of g_xk and g_xv run as
  * segmented gathers over the INVERSE of the kNN table (inv_off (n+1), inv_entry, entry_base -- see pdf_seg_sum_rows), so they are
@@ -289,6 +296,12 @@ int pdf_seg_sum_weighted(long n, int c, int nsample, int w_c, const float *src, 
 int pdf_ce_forward(long n, int c, const float *logits, const long *target, long ignore, float *grad, float *acc, float *loss,
                    void *stream);
 int pdf_ce_backward(long n, int c, const float *dlogits, const float *acc, const float *gy, float *grad_out, void *stream);
+
+/* Per-scene sums of the relative coordinates rel = xyz[idx[i, j]] - xyz[i] of a SELF neighbour table (rows with idx < 0: rel = 0):
+ * out (b, 9) double = [Sx Sy Sz | Mxx Mxy Mxz Myy Myz Mzz], pre-zeroed by the caller.  The train-mode BatchNorm after the layer's
+ * Linear(3, 3) (point_transformer_seg.py:27-29) is a closed form of these and the weights: pdf_pt_layer_forward_m takes the batch's sums
+ * and skips its first statistics pass (csrc/geom_moments.hip). */
+int pdf_knn_rel_moments(int b, long n, int nsample, const float *xyz, const int *offset, const int *idx, double *out, void *stream);
 
 /* SGD with momentum and weight decay (torch.optim.SGD, dampening 0, no Nesterov -- the optimizer the reference's configs build,
  * pointcept/utils/optimizer.py + configs/s3dis/openseg-pt-v1-0-*.py) over every parameter tensor in ONE launch.  tab: ntensors records

@@ -142,6 +142,23 @@ def order_of(idx):
     return None
 
 
+_MOM = "_pdf_moments"
+
+
+def attach_moments(idx, moments):
+    """Remember the batch's relative-coordinate sums of a SELF neighbour table (9 doubles on the device: csrc/geom_moments.hip) on
+    its idx tensor; the fused layer's forward then takes the geometry branch's BatchNorm statistics from them."""
+    setattr(idx, _MOM, (idx.data_ptr(), idx._version, moments))
+    return idx
+
+
+def moments_of(idx):
+    tag = getattr(idx, _MOM, None)
+    if tag is not None and tag[0] == idx.data_ptr() and tag[1] == idx._version:
+        return tag[2]
+    return None
+
+
 def _check(t, dtype, name):
     if t.dtype != dtype:
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
@@ -493,6 +510,8 @@ class HipBackend(CBackend):
         lib.pdf_ce_forward.argtypes = [c_long, c_int, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p]
         lib.pdf_ce_backward.restype = c_int
         lib.pdf_ce_backward.argtypes = [c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        lib.pdf_knn_rel_moments.restype = c_int
+        lib.pdf_knn_rel_moments.argtypes = [c_int, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         lib.pdf_sgd_chunk.restype = c_int
         lib.pdf_sgd_chunk.argtypes = []
         lib.pdf_sgd_step.restype = c_int
@@ -736,6 +755,23 @@ class HipBackend(CBackend):
     def layer_flags(self, bf16):
         """the `storage_bf16` argument of the layer entry points: bit 0 = bfloat16 row arrays, bit 1 = chunked point walk"""
         return int(bool(bf16)) | (2 if self.layer_chunked else 0) | (4 if self.layer_order else 0)
+
+    use_moments = os.environ.get("PDFOPS_BNP_MOMENTS", "1") != "0"   # 0: the layer's own first statistics pass (P1) instead
+
+    def _moments_ptr(self, idx):
+        m = moments_of(idx) if self.use_moments else None
+        return None if m is None else m.data_ptr()
+
+    def knn_rel_moments(self, nsample, xyz, offset, idx):
+        """Per-scene sums (b, 9) float64 of rel = xyz[idx] - xyz over the rows of a self kNN table (csrc/geom_moments.hip)."""
+        _check(xyz, torch.float32, "xyz"); _check(offset, torch.int32, "offset"); _check(idx, torch.int32, "idx")
+        out = torch.zeros((offset.shape[0], 9), dtype=torch.float64, device=xyz.device)
+        require_current_device(xyz, offset, idx)
+        rc = self.lib.pdf_knn_rel_moments(int(offset.shape[0]), int(xyz.shape[0]), int(nsample), xyz.data_ptr(), offset.data_ptr(), idx.data_ptr(),
+                                          out.data_ptr(), self._stream())
+        if rc != 0:
+            raise PdfOpsError(f"pdf_knn_rel_moments failed with status {rc}")
+        return out
 
     def _order_ptr(self, idx):
         o = order_of(idx)   # (always handed over: the g_xv gather visits its destinations in this order; the passes only with bit 2)

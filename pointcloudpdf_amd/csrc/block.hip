@@ -153,6 +153,7 @@ extern "C" int pdf_block_post_backward(long n, int c, void *const *p, int traini
 //   28-33 layer norm buffers (rm/rv x3) | 34 gamma2 35 beta2 36 rm2 37 rv2 | 38 W3 | 39 gamma3 40 beta3 41 rm3 42 rv3
 //   saved / outputs: 43 z1 44 coef1 45 xq 46 xk 47 xv 48 layer bn (2T) 49 layer saved (2T) 50 H 51 t 52 coef2 53 z3 54 coef3 55 y
 //   56 scratch (max of pdf_rowlin_partial_floats, pdf_bn_partial_floats, pdf_pt_layer_partial_floats) | 57 visiting order of the points (or null)
+//   58 the batch's relative-coordinate sums of the kNN table (9 doubles, pdf_knn_rel_moments) or null
 extern "C" int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p, int training, float eps, float momentum, int storage_bf16, void *stream) {
     if (n < 1 || !p) return PDF_ERR_BAD_ARG;
     Err e;
@@ -162,9 +163,9 @@ extern "C" int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p
     float *bn_buffers[6];
     for (int i = 0; i < 8; ++i) weights[i] = (const float *)p[14 + i];
     for (int i = 0; i < 6; ++i) { bn_params[i] = (const float *)p[22 + i]; bn_buffers[i] = (float *)p[28 + i]; }
-    e << pdf_pt_layer_forward((int)n, nsample, c, (const float *)p[45], (const float *)p[46], (const float *)p[47], (const float *)p[12],
-                              (const int *)p[13], weights, bn_params, bn_buffers, training, eps, momentum, (float *)p[48], (float *)p[49],
-                              (float *)p[50], (float *)p[56], (float *)p[51], storage_bf16, (const int *)p[57], stream);
+    e << pdf_pt_layer_forward_m((int)n, nsample, c, (const float *)p[45], (const float *)p[46], (const float *)p[47], (const float *)p[12],
+                                (const int *)p[13], weights, bn_params, bn_buffers, training, eps, momentum, (float *)p[48], (float *)p[49],
+                                (float *)p[50], (float *)p[56], (float *)p[51], storage_bf16, (const int *)p[57], (const double *)p[58], stream);
     void *post[16] = {p[51], p[0], p[34], p[35], p[36], p[37], p[38], p[39], p[40], p[41], p[42], p[52], p[53], p[54], p[55], p[56]};
     e << pdf_block_post_forward(n, c, post, training, eps, momentum, stream);
     return e.rc;

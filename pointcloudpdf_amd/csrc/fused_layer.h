@@ -35,6 +35,13 @@ struct LayerArgs {
     float inv_rows;                          // 1 / (N*K)
     int bf16;                                // H / G2 / Wsm / GR hold bfloat16 (half the bytes of the same buffers) instead of fp32
     int chunked;                             // point walk of the matrix-core passes: 1 = contiguous chunk per workgroup (XCD-major), 0 = grid-stride
+    // ---- forward, training: BatchNorm of the geometry branch from the relative-coordinate sums of the kNN table (geom_moments.hip)
+    const double *mom;                       // 9 sums [S (3) | M (6)] over all (point, neighbour) rows, or nullptr (P1 + finalizer compute the statistics)
+    cfloat_p gam_p, bet_p;                   // BNp gamma / beta (3 each)
+    float *bnp_coef, *bnp_saved;             // where block 0 of P2 leaves [sp (3) | tp (3)] and mean (3) / rstd (3, at bnp_saved + bnp_T)
+    float *bnp_rm, *bnp_rv;                  // running mean / var (nullable)
+    int bnp_T;
+    float bnp_eps, bnp_momentum;
     const int *order;                        // visiting order of the points (a permutation of 0 .. N-1, Morton order from the geometry
                                              // pre-pass) or nullptr: neighbouring points share neighbour rows -> per-XCD L2 hits
 };
@@ -92,6 +99,48 @@ __device__ __forceinline__ float4 ld_u4(const float *base, size_t idx, int bf16)
 __device__ __forceinline__ void st_u1_stream(float *base, size_t idx, float v, int bf16) {
     if (bf16) __builtin_nontemporal_store((unsigned short)f2bf(v), reinterpret_cast<unsigned short *>(base) + idx);
     else __builtin_nontemporal_store(v, base + idx);
+}
+
+// scale / shift of the geometry branch's BatchNorm: from the moments (every block computes its own copy; `writer` also stores the
+// coefficients, the saved statistics and the running-statistics update where the later passes and the backward read them), or as the
+// finalizer left them.  t1 = W rel + b  ->  mean = W S / rows + b,  E[t1^2] = (W M W^T + 2 b W S) / rows + b^2.
+struct BnP { float sp[3], tp[3]; };
+__device__ __forceinline__ BnP bnp_of(const LayerArgs &A, long rows, bool writer) {
+    BnP B;
+    if (A.mom == nullptr) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { B.sp[a] = A.sp[a]; B.tp[a] = A.tp[a]; }
+        return B;
+    }
+    const double S[3] = {A.mom[0], A.mom[1], A.mom[2]};
+    const double M[3][3] = {{A.mom[3], A.mom[4], A.mom[5]}, {A.mom[4], A.mom[6], A.mom[7]}, {A.mom[5], A.mom[7], A.mom[8]}};
+    const double inv = 1.0 / (double)rows;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double w[3] = {(double)A.Wp1[a * 3], (double)A.Wp1[a * 3 + 1], (double)A.Wp1[a * 3 + 2]}, b = (double)A.bp1[a];
+        const double ws = w[0] * S[0] + w[1] * S[1] + w[2] * S[2];
+        double wmw = 0.0;
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+#pragma unroll
+            for (int y = 0; y < 3; ++y) wmw += w[x] * M[x][y] * w[y];
+        const double mean = ws * inv + b;
+        double var = (wmw + 2.0 * b * ws) * inv + b * b - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)A.bnp_eps));
+        B.sp[a] = A.gam_p[a] * rstd;
+        B.tp[a] = A.bet_p[a] - (float)mean * B.sp[a];
+        if (writer) {
+            A.bnp_coef[a] = B.sp[a]; A.bnp_coef[3 + a] = B.tp[a];
+            A.bnp_saved[a] = (float)mean; A.bnp_saved[A.bnp_T + a] = rstd;
+            if (A.bnp_rm) {
+                const double unbiased = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
+                A.bnp_rm[a] = (1.f - A.bnp_momentum) * A.bnp_rm[a] + A.bnp_momentum * (float)mean;
+                A.bnp_rv[a] = (1.f - A.bnp_momentum) * A.bnp_rv[a] + A.bnp_momentum * (float)unbiased;
+            }
+        }
+    }
+    return B;
 }
 
 // ---- partial rows.  Every pass accumulates its BatchNorm sums / parameter gradients per wave in registers; the WPB waves of a block

@@ -197,10 +197,12 @@ __global__ __launch_bounds__(64 * WPB) void k_p2(LayerArgs A) {
     float s[NCH], ss[NCH];
 #pragma unroll
     for (int q = 0; q < NCH; ++q) { s[q] = 0.f; ss[q] = 0.f; }
+    const BnP B = bnp_of(A, (long)A.N * K, blockIdx.x == 0 && threadIdx.x == 0);   // (from the geometry moments when the caller has them)
     for (long tile = wave_g; tile < ntiles; tile += nwaves) {
         const Row R = load_row<K>(A, tile, lane);
         float t1n[3];
-        bn_relu3(A, R.t1, t1n);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) t1n[a] = fmaxf(R.t1[a] * B.sp[a] + B.tp[a], 0.f);
         L.rowid[lane] = R.nb;
         wave_sync();
 #pragma unroll
@@ -1017,11 +1019,18 @@ int forward_impl(LayerArgs A, int training, float eps, float momentum, const flo
     allow_lds(k_p2<C, K>, lds);
     allow_lds(k_p3<C, K, true>, lds);
     allow_lds(k_p4<C, K>, lds);
-    k_p1<K><<<grid, 64 * WPB, 0, s>>>(A);
-    k_bn_finalize<<<1, RED_THREADS, 0, s>>>(A.partial, grid, 3, (double)rows, bn_params[0], bn_params[1], eps, momentum, bn_buffers[0], bn_buffers[1], sp, tp, mp, rp);
+    if (A.mom) {   // BNp from the geometry moments: P2 computes the coefficients in its prologue, its block 0 stores them
+        A.gam_p = as_const(bn_params[0]); A.bet_p = as_const(bn_params[1]);
+        A.bnp_coef = sp; A.bnp_saved = mp; A.bnp_T = T; A.bnp_rm = bn_buffers[0]; A.bnp_rv = bn_buffers[1];
+        A.bnp_eps = eps; A.bnp_momentum = momentum;
+    } else {
+        k_p1<K><<<grid, 64 * WPB, 0, s>>>(A);
+        k_bn_finalize<<<1, RED_THREADS, 0, s>>>(A.partial, grid, 3, (double)rows, bn_params[0], bn_params[1], eps, momentum, bn_buffers[0], bn_buffers[1], sp, tp, mp, rp);
+    }
     int g2 = grid;
     if (flm::supported(K, C)) { g2 = pass_grid(P2, A.N, C == 512 ? 64 : (C == 256 ? 128 : grid)); flm::launch_p2(A, C, g2, s); }
     else k_p2<C, K><<<grid, 64 * WPB, lds, s>>>(A);
+    A.mom = nullptr;   // (P3 / P4 read the coefficients block 0 of P2 stored)
     k_bn_finalize<<<pdf_divup(C, 16), RED_THREADS, 0, s>>>(A.partial, g2, C, (double)rows, bn_params[2], bn_params[3], eps, momentum, bn_buffers[2], bn_buffers[3], s1, t1, m1, r1);
     int nw3 = grid;   // (P3's partial rows are 2 C/8 floats: a larger grid than P2's fits the same scratch)
     if (flm::supported(K, C)) { const int g3 = pass_grid(P3, A.N, C <= 256 ? 2 * MAX_BLOCKS : MAX_BLOCKS); nw3 = g3; flm::launch_p3(A, C, true, g3, s); }
@@ -1127,6 +1136,7 @@ extern "C" int pdf_pt_layer_backward(int n, int nsample, int c, const float *xq,
     A.sp = as_const(bn); A.tp = as_const(bn + 3); A.s1 = as_const(bn + 6); A.t1 = as_const(bn + 6 + c);
     A.s2 = as_const(bn + 6 + 2 * c); A.t2 = as_const(bn + 6 + 2 * c + cs);
     A.H = const_cast<float *>(H); A.out = nullptr; A.partial = partial;
+    A.mom = nullptr;
     A.gout = gout; A.G2 = G2; A.G3 = G3; A.gxq = gxq; A.gxk = gxk; A.gxv = gxv; A.Wsm = Wsm; A.GR = GR; A.bf16 = storage_bf16 & 1; A.chunked = (storage_bf16 >> 1) & 1; A.order = (storage_bf16 & 4) ? order : nullptr; A.sums = as_const(nullptr); A.sums2 = as_const(nullptr);
     hipStream_t s = static_cast<hipStream_t>(stream);
     A.mean = as_const(saved); A.rstd = as_const(saved + (3 + c + cs));   // forward's layout: [mean p|1|2][rstd p|1|2]
@@ -1147,11 +1157,24 @@ extern "C" int pdf_pt_layer_backward(int n, int nsample, int c, const float *xq,
 
 // Forward of one PointTransformerLayer.  weights: Wp1,bp1,Wp2,bp2,Ww1,bw1,Ww2,bw2 ; bn_params: gamma/beta of the three
 // norms ; bn_buffers: running mean/var of the three norms (updated in train mode; may hold nulls to skip the update).
+extern "C" int pdf_pt_layer_forward_m(int n, int nsample, int c, const float *xq, const float *xk, const float *xv,
+                                      const float *p, const int *idx, const float *const *weights,
+                                      const float *const *bn_params, float *const *bn_buffers, int training, float eps,
+                                      float momentum, float *bn, float *saved, float *H, float *partial, float *out,
+                                      int storage_bf16, const int *order, const double *moments, void *stream);
 extern "C" int pdf_pt_layer_forward(int n, int nsample, int c, const float *xq, const float *xk, const float *xv,
                                     const float *p, const int *idx, const float *const *weights,
                                     const float *const *bn_params, float *const *bn_buffers, int training, float eps,
                                     float momentum, float *bn, float *saved, float *H, float *partial, float *out,
                                     int storage_bf16, const int *order, void *stream) {
+    return pdf_pt_layer_forward_m(n, nsample, c, xq, xk, xv, p, idx, weights, bn_params, bn_buffers, training, eps, momentum, bn, saved, H,
+                                  partial, out, storage_bf16, order, nullptr, stream);
+}
+extern "C" int pdf_pt_layer_forward_m(int n, int nsample, int c, const float *xq, const float *xk, const float *xv,
+                                      const float *p, const int *idx, const float *const *weights,
+                                      const float *const *bn_params, float *const *bn_buffers, int training, float eps,
+                                      float momentum, float *bn, float *saved, float *H, float *partial, float *out,
+                                      int storage_bf16, const int *order, const double *moments, void *stream) {
     if (n < 1 || !xq || !xk || !xv || !p || !idx || !weights || !bn_params || !bn_buffers || !bn || !H || !partial || !out)
         return PDF_ERR_BAD_ARG;
     if (!pdf_pt_layer_supported(nsample, c)) return PDF_ERR_UNSUPPORTED;
@@ -1163,6 +1186,7 @@ extern "C" int pdf_pt_layer_forward(int n, int nsample, int c, const float *xq, 
     A.Wp1 = as_const(weights[0]); A.bp1 = as_const(weights[1]); A.Wp2 = as_const(weights[2]); A.bp2 = as_const(weights[3]);
     A.Ww1 = as_const(weights[4]); A.bw1 = as_const(weights[5]); A.Ww2 = as_const(weights[6]); A.bw2 = as_const(weights[7]);
     A.H = H; A.out = out; A.partial = partial; A.bf16 = storage_bf16 & 1; A.chunked = (storage_bf16 >> 1) & 1; A.order = (storage_bf16 & 4) ? order : nullptr;
+    A.mom = training ? moments : nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define PDF_FWD(C_, K_) return fl::forward_impl<C_, K_>(A, training, eps, momentum, bn_params, bn_buffers, bn, saved, s)
     if (nsample == 8) {

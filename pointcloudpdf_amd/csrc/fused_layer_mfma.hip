@@ -283,7 +283,12 @@ __global__ __launch_bounds__(64 * WPB) void k_p2(LayerArgs A) {
     __syncthreads();
     const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
     const int c0 = 64 * blockIdx.y;
-    const GeoW G = geo_weights(A);
+    GeoW G = geo_weights(A);
+    if (A.mom) {   // BNp from the geometry moments (fused_layer.h); block (0, 0) stores the coefficients for the later passes
+        const fl::BnP B = fl::bnp_of(A, (long)A.N * 16, blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { G.sp[a] = B.sp[a]; G.tp[a] = B.tp[a]; }
+    }
     f32x4 s[4], ss[4];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) { s[jj] = zero4(); ss[jj] = zero4(); }

@@ -1,0 +1,76 @@
+// Per-scene moments of the relative coordinates of a neighbour table -- the feature-independent half of a BatchNorm.
+//
+// The PointTransformerLayer's geometry branch starts with Linear(3, 3) on rel = p[idx[i, j]] - p[i] followed by a train-mode
+// BatchNorm over all (point, neighbour) rows (point_transformer_seg.py:27-29, 52-57).  Its batch statistics are a closed form of the
+// weights and of NINE sums that depend on the coordinates and the kNN table only:
+//     sum t1[a]   = W[a,:] . S + rows b[a]                      S = sum rel        (3)
+//     sum t1[a]^2 = W[a,:] M W[a,:]^T + 2 b[a] W[a,:] . S + rows b[a]^2       M = sum rel rel^T  (6 distinct)
+// so the geometry pre-pass computes S and M once per table (here, per scene, so that a pre-pass over several batches can hand every
+// batch the sums of its own scenes), and the layer's first statistics pass + its finalizer (2 of the 7 forward launches of a layer) are
+// replaced by ~60 flops in the prologue of the next pass (fused_layer.h, bnp_from_moments).
+// rel is formed in fp32 exactly as the layer kernels form it (0 for idx < 0 rows, which the reference keeps as rows); sums in fp64.
+// out (b, 9) double = [Sx Sy Sz | Mxx Mxy Mxz Myy Myz Mzz], pre-zeroed by the caller.  Bound: HBM (idx + gathered coordinates), ~10 us.
+#include "pdfops_common.h"
+
+namespace {
+
+constexpr int MB = 256;
+
+__device__ __forceinline__ int scene_of(const int *__restrict__ offset, int b, long i) {   // first s with offset[s] > i
+    int lo = 0, hi = b - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((long)offset[mid] > i) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(MB) void k_rel_moments(long n, int k, const float *__restrict__ p, const int *__restrict__ idx,
+                                                    const int *__restrict__ offset, int b, double *__restrict__ out) {
+    __shared__ double red[MB / 64][9];
+    const long i = (long)blockIdx.x * MB + threadIdx.x;
+    double acc[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) acc[e] = 0.0;
+    if (i < n) {
+        const float px = p[i * 3], py = p[i * 3 + 1], pz = p[i * 3 + 2];
+        for (int j = 0; j < k; ++j) {
+            const int nb = idx[i * k + j];
+            const long nc = nb >= 0 ? nb : 0;
+            const float qx = p[nc * 3], qy = p[nc * 3 + 1], qz = p[nc * 3 + 2];
+            const float rx = nb >= 0 ? qx - px : 0.f, ry = nb >= 0 ? qy - py : 0.f, rz = nb >= 0 ? qz - pz : 0.f;
+            const double x = rx, y = ry, z = rz;
+            acc[0] += x; acc[1] += y; acc[2] += z;
+            acc[3] += x * x; acc[4] += x * y; acc[5] += x * z; acc[6] += y * y; acc[7] += y * z; acc[8] += z * z;
+        }
+    }
+    const long first = (long)blockIdx.x * MB, last = min(first + MB, n) - 1;
+    const int s_first = scene_of(offset, b, first), s_last = scene_of(offset, b, last);
+    if (s_first == s_last) {   // the usual case: one scene per block -> block sum, 9 atomics
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+            double v = acc[e];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][e] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 9) {
+            double v = 0.0;
+            for (int w = 0; w < MB / 64; ++w) v += red[w][threadIdx.x];
+            atomicAdd(out + (size_t)s_first * 9 + threadIdx.x, v);
+        }
+    } else if (i < n) {        // a block that straddles a scene boundary: per-point atomics (at most b - 1 such blocks)
+        const int s = scene_of(offset, b, i);
+#pragma unroll
+        for (int e = 0; e < 9; ++e) atomicAdd(out + (size_t)s * 9 + e, acc[e]);
+    }
+}
+
+}  // namespace
+
+extern "C" int pdf_knn_rel_moments(int b, long n, int nsample, const float *xyz, const int *offset, const int *idx, double *out, void *stream) {
+    if (b < 1 || n < 0 || nsample < 1 || !offset || !out || (n > 0 && (!xyz || !idx))) return PDF_ERR_BAD_ARG;
+    if (n == 0) return PDF_OK;
+    k_rel_moments<<<(unsigned)((n + MB - 1) / MB), MB, 0, static_cast<hipStream_t>(stream)>>>(n, nsample, xyz, idx, offset, b, out);
+    return pdf_launch_status();
+}

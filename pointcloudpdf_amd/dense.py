@@ -429,7 +429,7 @@ class _BottleneckFn(torch.autograd.Function):
                 lw[3].running_mean.data_ptr(), lw[3].running_var.data_ptr(),
                 g2.data_ptr(), b2.data_ptr(), bn2.running_mean.data_ptr(), bn2.running_var.data_ptr(), W3.data_ptr(),
                 g3.data_ptr(), b3.data_ptr(), bn3.running_mean.data_ptr(), bn3.running_var.data_ptr(),
-                *ap, y.data_ptr(), scratch.data_ptr(), be._order_ptr(idx)]
+                *ap, y.data_ptr(), scratch.data_ptr(), be._order_ptr(idx), be._moments_ptr(idx) if training else None]
         bf16 = int(be.storage_bf16)
         be.bottleneck_forward(n, k, c, ptrs, training, bn1.eps, bn1.momentum, bf16)
         ctx.save_for_backward(x, p, idx, act, W1, Wq, Wk, Wv, W3, Wp1, bp1, Wp2, bp2, Ww1, bw1, Ww2, bw2)

@@ -133,6 +133,18 @@ class Geometry:
                 _native.attach_order(self._memo[key][0], self.order(query_level), self.order(src_level))
         return self._memo[key]
 
+    def rel_moments(self, nsample, level):
+        """Per-scene sums (scenes, 9) float64 of the relative coordinates of the self kNN table (nsample, level, level): the
+        feature-independent half of the BatchNorm behind the layer's Linear(3, 3) (csrc/geom_moments.hip).  The batch's sums (over its
+        scenes) are attached to the idx tensor, where the fused layer looks them up."""
+        key = ("mom", nsample, level, level)
+        if key not in self._memo:
+            L = self.levels[level]
+            idx, _ = self.knn(nsample, level, level)
+            self._memo[key] = _native.backend_for(L.p).knn_rel_moments(nsample, L.p, L.o, idx)
+            _native.attach_moments(idx, self._memo[key].sum(0))
+        return self._memo[key]
+
     def order(self, level):
         """Morton order of a level's points, scene by scene: a permutation (N_l,) int32 of the level's rows.  Used as the VISITING order
         of the queries in the forward gathers (csrc/gather_ops.hip); nothing is stored in this order."""
@@ -228,6 +240,9 @@ class Geometry:
         if self.levels[0].p.is_cuda:                     # tables of the fused TransitionDown (device path only)
             for i in range(1, len(strides)):
                 self.td(nsamples[i], i - 1, i)
+            if _native.hip_backend().use_moments:        # BatchNorm statistics of the layers' geometry branch from coordinate sums
+                for i in range(len(strides)):
+                    self.rel_moments(nsamples[i], i)
             if _native.hip_backend().use_inverse:        # inverse tables for the gather-form backward passes (device path only)
                 for i in range(len(strides)):
                     self.inverse(nsamples[i], i, i)      # PointTransformerLayer g_xk / g_xv
@@ -299,6 +314,8 @@ class Geometry:
                 elif kind == "td":   # rel4 by query rows, Z by source rows; the 12 sums are per batch
                     (rel4, Z, scene_sums, _), (q0, q1), (r0, r1) = val, rows[key[3]], rows[key[2]]
                     g._memo[key] = (rel4[q0:q1], Z[r0:r1], scene_sums[s0:s1], _td_consts(scene_sums[s0:s1]))
+                elif kind == "mom":   # per-scene sums: the batch's scenes
+                    g._memo[key] = val[s0:s1]
                 elif kind == "inv":   # absolute positions into the group's shared entry array; entry ids rebased by the batch's first entry
                     (off, ent, base), (q0, _), (r0, r1) = val, rows[key[3]], rows[key[2]]
                     tab = (off[r0:r1 + 1], ent, base + q0 * key[1])
@@ -306,9 +323,11 @@ class Geometry:
                     _native.attach_inverse(g._memo[("knn",) + key[1:]][0], r1 - r0, tab)
                 else:
                     raise RuntimeError(f"Geometry.split: unknown memo entry {key}")
-            for key, val in g._memo.items():   # visiting orders travel with the batch's index tensors
+            for key, val in g._memo.items():   # visiting orders and coordinate sums travel with the batch's index tensors
                 if key[0] == "knn" and ("order", key[3]) in g._memo:
                     _native.attach_order(val[0], g._memo[("order", key[3])], g._memo.get(("order", key[2])))
+                if key[0] == "mom":
+                    _native.attach_moments(g._memo[("knn",) + key[1:]][0], val.sum(0))
             out.append(g)
             s0 = s1
         return out

@@ -296,3 +296,52 @@ def test_fused_sgd_matches_torch_sgd():
         oa.step(); ob.step()
     for x, y in zip(pa, pb):
         assert (x - y).abs().max() <= 1e-6 * (1 + y.abs().max()), (tuple(x.shape), float((x - y).abs().max()))
+
+
+def test_geometry_branch_batchnorm_from_coordinate_sums():
+    """pdf_knn_rel_moments against a torch fp64 evaluation, and a Bottleneck whose geometry-branch BatchNorm comes from those sums
+    (Geometry.rel_moments, attached to the idx tensor) against the same block running its own statistics pass (P1): outputs, input /
+    parameter gradients and the running statistics agree to fp32 rounding."""
+    from pointcloudpdf_amd import _native, synthetic
+    from pointcloudpdf_amd.geometry import Geometry
+    from pointcloudpdf_amd.point_transformer import Bottleneck
+
+    be = _native.hip_backend()
+    batch = synthetic.make_batch([5000, 3000, 4100], first_scene_id=70, grid_size=0.1, device="cuda")
+    geom = Geometry(batch["coord"], batch["offset"], batch["offset_host"])
+    idx, _ = geom.knn(16, 0, 0)
+    mom = geom.rel_moments(16, 0)
+    p = geom.coord(0).double()
+    rel = torch.where((idx >= 0)[..., None], p[idx.clamp(min=0).long()] - p[:, None, :], torch.zeros((), dtype=torch.float64, device="cuda"))
+    scene = torch.bucketize(torch.arange(p.shape[0], device="cuda"), batch["offset"].long(), right=True)
+    for s in range(3):
+        r = rel[scene == s].reshape(-1, 3)
+        M = r.t() @ r
+        ref = torch.cat([r.sum(0), torch.stack([M[0, 0], M[0, 1], M[0, 2], M[1, 1], M[1, 2], M[2, 2]])])
+        assert (mom[s] - ref).abs().max() <= 1e-9 * ref.abs().max() + 1e-12, (s, mom[s], ref)
+    assert _native.moments_of(idx) is not None
+    res = []
+    for use in (True, False):
+        be.use_moments = use
+        try:
+            torch.manual_seed(0)
+            blk = Bottleneck(64, 64, 8, 16).cuda()
+            synthetic.fill_parameters_deterministic(blk, seed=9)
+            blk.train()
+            g = torch.Generator(device="cuda").manual_seed(2)
+            x = torch.randn(p.shape[0], 64, device="cuda", generator=g).requires_grad_(True)
+            y = blk([geom.coord(0), x, geom.offset(0)])[1]
+            y.backward(torch.randn(y.shape, device="cuda", generator=g))
+        finally:
+            be.use_moments = True
+        out = {"y": y.detach(), "gx": x.grad}
+        out.update({"g_" + n: q.grad for n, q in blk.named_parameters() if q.grad is not None})
+        out.update({"b_" + n: b.detach().float() for n, b in blk.named_buffers()})
+        res.append(out)
+    a, b = res
+    gscale = max(v.abs().max().item() for k, v in b.items() if k.startswith("g_"))
+    for k in b:
+        scale = b[k].abs().max().item() + 1e-12
+        if k.startswith("g_") and scale < 1e-4 * gscale:
+            continue   # analytically-zero gradients (biases in front of a train-mode BatchNorm): rounding noise in both runs
+        assert (a[k] - b[k]).abs().max().item() <= (2e-5 if (k == "y" or k.startswith("b_")) else 2e-3) * scale, (k, (a[k] - b[k]).abs().max().item(), scale)
