@@ -1,5 +1,8 @@
-# end-of-round check: full GPU suite, smoke, PMC passes + traffic file for the current kernel sources
+# end-of-round: default bench line, kernel trace tables, PMC passes + traffic file for the current kernel sources; usage: bash tools/final_check.sh <tag>
+TAG=${1:-r02_k}
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|rror" > gpurun_out/fin_tests.log
-timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/fin_smoke.log 2>&1
-timeout 1200 bash tools/pmc_only.sh r02_j
+timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+timeout 1200 bash tools/pmc_only.sh $TAG
+DB=$(find /tmp/p/kt -name "*.db" | head -1)
+python3 tools/rocpd_stats.py $DB 70 > gpurun_out/${TAG}_kernel_trace_stats.txt
+python3 tools/rocpd_categories.py $DB 18 > gpurun_out/${TAG}_kernel_categories.txt; python3 tools/rocpd_queues.py $DB 18 > gpurun_out/${TAG}_kernel_streams.txt
