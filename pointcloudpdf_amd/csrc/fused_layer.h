@@ -22,7 +22,7 @@ struct LayerArgs {
     cfloat_p sp, tp, s1, t1, s2, t2;         // BatchNorm scale/shift: y = x*s + t  (3,3,C,C,CS,CS)
     float *H;                                // (N,K,CS) pre-BN2 activations
     float *out;                              // (N,C)
-    float *partial;                          // per-wave partial sums for the statistics of the current pass
+    float *partial;                          // partial rows (one per workgroup) of the statistics / gradient sums of the current pass
     // ---- backward only
     const float *gout;                       // (N,C) gradient of the layer output
     cfloat_p mean, rstd;                     // saved batch statistics [p(3) | 1(C) | 2(CS)] (mean and rstd arrays)

@@ -406,7 +406,8 @@ __global__ __launch_bounds__(64 * WPB) void k_p4(LayerArgs A) {
 //   B3: BN1 backward -> g_r: scatter g_xk, g_xq, g_pr -> d Wp2, G3 = dL/d(BNp out, masked), BNp-sums
 //   B4: BNp backward -> d Wp1
 // Parameter gradients and BatchNorm sums are accumulated per wave in registers (lanes <-> output elements, operands
-// exchanged through LDS tiles), written as one partial row per wave and column-summed by k_colsum (deterministic).
+// exchanged through LDS tiles), combined per workgroup in LDS (fl::block_row: fixed order), written as one partial row per
+// workgroup and column-summed by k_colsum (deterministic).
 constexpr int MAX_BLOCKS_BWD = 256;
 
 // Store the 64x32 tile as channels [c0, c0+32) of rows row0 .. row0+63 of `table` (E x C): 2 rows x 32 consecutive channels per
@@ -953,8 +954,8 @@ static inline int grid_for_points(long n, int cap) {
 }
 
 // Per-pass grids of the matrix-core passes (one point per wave and trip).  The passes differ in what a resident block costs: P3 / B3 / B1
-// write short partial rows (2 C/8, 8 + 4 C, 3 C/8 + (C/8)^2 floats per wave) and gain from more waves per SIMD; B2's partial row holds a
-// (C/8) x C weight-gradient block per wave, so its grid stays small.  PDFOPS_PT_CAP_<pass> overrides the default cap.
+// write short partial rows (2 C/8, 8 + 4 C, 3 C/8 + (C/8)^2 floats per workgroup) and gain from more waves per SIMD; B2's partial row holds a
+// (C/8) x C weight-gradient block, so its grid stays small.  PDFOPS_PT_CAP_<pass> overrides the default cap.
 // P2 / B2 run one workgroup per (point block, 64-channel slab): at C >= 256 the slab dimension already fills the chip and every extra
 // point block pays the slab staging and the partial-row epilogue again (B2 at 780 points x 512 channels: 90 us with 195 point blocks,
 // 45 us with 32).
@@ -1045,7 +1046,7 @@ int forward_impl(LayerArgs A, int training, float eps, float momentum, const flo
 namespace fl {
 
 // two blocks per CU pay off where the passes are latency-bound on many small tiles (C <= 64: 1.0 -> 0.78 ms at level 1);
-// at C >= 128 the per-wave partial rows (weight-gradient blocks) cost more than the extra waves bring
+// at C >= 128 the partial rows (weight-gradient blocks) cost more than the extra waves bring
 static inline int grid_for_tiles_bwd(long ntiles, int c) {
     static const int env_cap = env_blocks("PDFOPS_PT_BLOCKS_BWD", 0);
     const int cap = env_cap > 0 ? env_cap : (c <= 64 ? 2 * MAX_BLOCKS_BWD : MAX_BLOCKS_BWD);

@@ -1,5 +1,5 @@
-// Fused PointTransformerLayer passes on the matrix cores, for nsample == 16 and C >= 128 (levels 3 and 4: 12.5k / 3.1k
-// points, 128 / 256 channels).  Same math and buffers as fused_layer.hip (which documents the pass structure and cites
+// Fused PointTransformerLayer passes on the matrix cores, for nsample == 16 and C = 64 / 128 / 256 / 512 (levels 2-5: 50k / 12.5k /
+// 3.1k / 780 points).  Same math and buffers as fused_layer.hip (which documents the pass structure and cites
 // point_transformer_seg.py:45-78); only the mapping differs.
 //
 // The row-per-lane kernels keep one (point, neighbour) row per lane and stream the weights through SGPRs; at C >= 128 that
@@ -73,15 +73,6 @@ __host__ __device__ constexpr int w2_floats(int c) { return csp_of(c) * (csp_of(
 // (3,124 / 780 points: one to three points per wave, the staging is not amortised).
 constexpr int NT = 64 * WPB;
 // (loads use a clamped index and the select happens afterwards: a load under a condition gets its own branch and wait)
-template <int N>
-__device__ __forceinline__ void stage_copy(float *dst, const float *src) {   // dst[e] = src[e], e < N
-    constexpr int PER = (N + NT - 1) / NT;
-    float v[PER];
-#pragma unroll
-    for (int t = 0; t < PER; ++t) v[t] = src[min((int)threadIdx.x + NT * t, N - 1)];
-#pragma unroll
-    for (int t = 0; t < PER; ++t) { const int e = threadIdx.x + NT * t; if (e < N) dst[e] = v[t]; }
-}
 // dst[r * WS + c] = r < rows_valid ? src[r * src_stride + c] : 0 for r < ROWS, c < COLS (float4 pieces; COLS, WS, src_stride % 4 == 0,
 // 16-byte aligned src -- checked at the C entry points)
 template <int ROWS, int COLS, int WS>
