@@ -19,6 +19,8 @@
 //
 // fp32 in / fp32 accumulate (bit-equal to an fmaf chain): the reference computes these layers in fp32.
 #include "pdfops_common.h"
+#include <algorithm>
+#include <cstdlib>
 #include <cstdlib>
 
 namespace rl2 {
@@ -257,8 +259,17 @@ static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t
 
 template <int K, int NOB, int NIN>
 static void launch_fwd(const FwdArgs &a, int nslabs, hipStream_t s) {
-    const dim3 grid((unsigned)fwd_row_blocks(a.N), (unsigned)nslabs);
     const bool pre = a.scale != nullptr, stats = a.partial != nullptr;
+    // Every workgroup first loads its waves' weight fragments (16 NOB columns x K: 8-32 KB per wave).  With many column slabs and few
+    // rows (levels 4-5: 3,124 / 780 rows, up to 96 slabs for the three-output q / k / v product) one row block per 64 rows means a wave
+    // loads its fragment for a single 16-row tile; fewer row blocks amortise it over several tiles.  (Not with STATS: the partial rows
+    // are indexed by row block and sized by pdf_rowlin_partial_rows.)
+    // Measured (PDFOPS_RL_BLOCKS = total workgroups aimed at): 512 -> q / k / v product at 3,124 x 256: 41 -> 31 us, three-input dgrad 36 -> 30 us,
+    // 780 x 512: 54 -> 46 us, single-slab shapes unchanged; 384 and below lose on the large levels, 1024 and above change nothing.
+    static const int total = [] { const char *v = getenv("PDFOPS_RL_BLOCKS"); const int x = v ? atoi(v) : 0; return x > 0 ? x : 512; }();
+    int gx = fwd_row_blocks(a.N);
+    if (!(NIN == 1 && stats)) gx = std::max(1, std::min(gx, std::max(8, total / std::max(nslabs, 1))));
+    const dim3 grid((unsigned)gx, (unsigned)nslabs);
     if (NIN == 1 && stats) {
         if (pre) k_fwd<K, NOB, 1, true, true><<<grid, 256, 0, s>>>(a);
         else k_fwd<K, NOB, 1, false, true><<<grid, 256, 0, s>>>(a);
