@@ -6,6 +6,7 @@
 // streaming float4 at HBM rate.  The ReLU mask and x_hat are recomputed from the saved pre-norm input, so no
 // activation-sized mask or normalised copy is stored.  Bound: HBM.  Algorithmic bytes: 4NC per tensor pass.
 #include "pdfops_common.h"
+#include <cstdlib>
 
 namespace pw {
 
@@ -15,7 +16,12 @@ constexpr int MAXB = 1024;
 static inline int grid_rows(long n, int c) {
     // one thread = one float4 of a row; a block covers PB*4/c rows per sweep
     const long rows_per_block = (long)PB * 4 / c > 0 ? (long)PB * 4 / c : 1;
-    long g = (n + rows_per_block * 8 - 1) / (rows_per_block * 8);
+    // rows per lane: 8 where the tensor is large enough to be a bandwidth problem, 4 on the short levels (a lane's rows are a chain of
+    // load -> accumulate round trips: at 3,124 x 256 eight of them ARE the kernel; measured 8 / 4 / 2 / 1 rows: 3.03 / 2.87 / 2.88 / 2.88 ms
+    // per step for these kernels + their reducers, which read one partial row per workgroup)
+    static const int short_rows = [] { const char *v = getenv("PDFOPS_BN_ROWS_SHORT"); const int x = v ? atoi(v) : 0; return x > 0 ? x : 4; }();
+    const long per = n * c >= (1L << 22) ? 8 : short_rows;
+    long g = (n + rows_per_block * per - 1) / (rows_per_block * per);
     if (g > MAXB) g = MAXB;
     if (g < 1) g = 1;
     return (int)g;
