@@ -438,6 +438,7 @@ def main():
         for i in range(steps):
             timer.sample = timer.every > 0 and i % timer.every == 0
             out = one_step(warmup + i, sched)
+        sched.enqueue_s = time.perf_counter() - t0   # host time to enqueue the K steps (the device may still be working)
         fence()
         dt = time.perf_counter() - t0
         timer.enabled = False
@@ -511,6 +512,7 @@ def main():
             "rank_ms_per_step": rank_ms,
             "loss": loss,
             "geometry_prefetch_group": (st_ahead if strat else D),
+            "host_enqueue_ms_per_step": sched.enqueue_s / args.steps * 1e3,   # < ms_per_step: the host runs ahead, the device is the bound
             "prepass_submit_host_ms": (1e3 * min(sched.submit_host_s)) if sched.submit_host_s else None,   # host time of one group submission (warm)
             "kernels": ks,
             "roofline": roof,

@@ -154,6 +154,7 @@ class PointTransformerLayer(nn.Module):
         return [lp[0].weight, lp[0].bias, lp[1].weight, lp[1].bias, lp[3].weight, lp[3].bias, lw[0].weight, lw[0].bias,
                 lw[2].weight, lw[2].bias, lw[3].weight, lw[3].bias, lw[5].weight, lw[5].bias]
 
+
     def forward(self, pxo):
         p, x, o = pxo  # (n, 3), (n, c), (b)
         x_q, x_k, x_v = _lin(self.linear_q, x), _lin(self.linear_k, x), _lin(self.linear_v, x)
@@ -279,6 +280,10 @@ class Bottleneck(nn.Module):
         self.linear3 = nn.Linear(planes, planes * self.expansion, bias=False)
         self.bn3 = nn.BatchNorm1d(planes * self.expansion)
         self.relu = nn.ReLU(inplace=True)
+
+    def _apply(self, fn, *a, **kw):   # (.to() / .cuda() / .float() may replace Parameter objects: drop dense._bottleneck_params' cache)
+        self.__dict__.pop("_pdf_params", None)
+        return super()._apply(fn, *a, **kw)
 
     matrix_core = os.environ.get("PDFOPS_MATRIX_CORE", "1") != "0"  # class-wide switch: Linear + BatchNorm chains through csrc/rowlin.hip
 
