@@ -346,7 +346,9 @@ def main():
 
     from pointcloudpdf_amd.geometry import GeometryPrefetcher
 
-    prefetcher = GeometryPrefetcher(depth=2)   # two side streams, alternating groups
+    # two side streams, alternating groups.  PDFOPS_PREPASS_THREAD=1 builds the pre-pass on a worker thread (measured: no gain -- the worker's
+    # Python / dispatch work competes with the training thread for the interpreter: 17.7-18.6 vs 18.2-18.4 ms per step)
+    prefetcher = GeometryPrefetcher(depth=2, threaded=bool(os.environ.get("PDFOPS_PREPASS_THREAD")))
 
     class Schedule:
         """Grouped geometry pre-pass for `warmup + steps` steps: the pre-pass of the next D batches runs as ONE launch sequence on a

@@ -98,7 +98,8 @@ def test_ddp_rccl_step_matches_plain_step():
 
 
 @pytest.mark.gpu
-def test_grouped_prepass_split_is_bit_identical_on_gpu():
+@pytest.mark.parametrize("threaded", [False, True])
+def test_grouped_prepass_split_is_bit_identical_on_gpu(threaded):
     """GeometryPrefetcher.submit_group: one FPS / kNN launch sequence over the scenes of three batches, split per batch,
     equals the pre-pass of every batch alone (HIP kernels, bit-exact tables)."""
     from pointcloudpdf_amd import synthetic
@@ -106,7 +107,7 @@ def test_grouped_prepass_split_is_bit_identical_on_gpu():
 
     dev = torch.device("cuda", 0)
     batches = [synthetic.make_batch(sz, first_scene_id=20 * i, device=dev) for i, sz in enumerate([[9000, 7000], [12000], [5000, 6500, 4000]])]
-    pf = GeometryPrefetcher(depth=2)
+    pf = GeometryPrefetcher(depth=2, threaded=threaded)   # (threaded: the pre-pass is built on a worker thread)
     tickets = pf.submit_group(batches)
     for b, t in zip(batches, tickets):
         part = pf.get(t)
