@@ -474,26 +474,35 @@ class _BottleneckFn(torch.autograd.Function):
                 S(0), S(1), S(2), S(6), S(7), S(3), S(4), S(5), S(8), S(9), inv_off.data_ptr(), inv_entry.data_ptr(), S(10),
                 *be.aux_handles(x.device, n), be._order_ptr(idx)]
         be.bottleneck_backward(n, k, c, ptrs, training, entry_base, bf16)
-        G = lambda o, sz, *shape: grads[o:o + sz].view(*shape) if shape else grads[o:o + sz]
-        # pre half: dW1 | dbeta1 | dgamma1 | {dW, db} x q, k, v
-        dW1, db1, dg1 = G(o_pre, cc, c, c), G(o_pre + cc, c), G(o_pre + cc + c, c)
-        q0 = o_pre + cc + 2 * c
-        qkv = []
-        for i in range(3):
-            qkv += [G(q0 + i * (cc + c), cc, c, c), G(q0 + i * (cc + c) + cc, c)]
-        # post half: dW3 | dbeta2 | dgamma2 | dbeta3 | dgamma3
-        dW3, db2, dg2, db3, dg3 = G(o_post, cc, c, c), G(o_post + cc, c), G(o_post + cc + c, c), G(o_post + cc + 2 * c, c), G(o_post + cc + 3 * c, c)
-        # layer sums (csrc/fused_layer.hip, pdf_pt_layer_backward): S1 | S2 | S3 | S4
-        o1 = o_sum
-        o2 = o1 + 3 * cs + cs * cs
-        o3 = o2 + 2 * c + cs + cs * c
-        o4 = o3 + 8 + 4 * c
-        beta2p, gamma2p, dbw2, dWw2 = G(o1, cs), G(o1 + cs, cs), G(o1 + 2 * cs, cs), G(o1 + 3 * cs, cs * cs, cs, cs)
-        beta1p, gamma1p, dbw1, dWw1 = G(o2, c), G(o2 + c, c), G(o2 + 2 * c, cs), G(o2 + 2 * c + cs, cs * c, cs, c)
-        betap, gammap, dbp2, dWp2 = G(o3, 3), G(o3 + 3, 3), G(o3 + 8, c), G(o3 + 8 + c, 3 * c, c, 3)
-        dbp1, dWp1 = G(o4, 3), G(o4 + 3, 9, 3, 3)
+        # the ~35 gradient views as ONE split of the buffer (a slice + view per gradient was ~100 us of host time per block)
+        sizes = _bottleneck_grad_sizes(c, o_post, o_sum, grads.shape[0])
+        (dW1, db1, dg1, dWq, dbq, dWk, dbk, dWv, dbv, _p0,
+         dW3, db2, dg2, db3, dg3, _p1,
+         beta2p, gamma2p, dbw2, dWw2, beta1p, gamma1p, dbw1, dWw1, betap, gammap, _p2, dbp2, dWp2, dbp1, dWp1, _rest) = grads.split_with_sizes(sizes)
+        dW1, dWq, dWk, dWv, dW3 = dW1.view(c, c), dWq.view(c, c), dWk.view(c, c), dWv.view(c, c), dW3.view(c, c)
+        dWw2, dWw1, dWp2, dWp1 = dWw2.view(cs, cs), dWw1.view(cs, c), dWp2.view(c, 3), dWp1.view(3, 3)
+        qkv = [dWq, dbq, dWk, dbk, dWv, dbv]
         layer = [dWp1, dbp1, gammap, betap, dWp2, dbp2, gamma1p, beta1p, dWw1, dbw1, gamma2p, beta2p, dWw2, dbw2]
         return (None, None, None, gx, dW1, dg1, db1, *qkv, *layer, dg2, db2, dW3, dg3, db3)
+
+
+_GRAD_SIZES = {}
+
+
+def _bottleneck_grad_sizes(c, o_post, o_sum, total):
+    """Piece sizes of _BottleneckFn.backward's gradient buffer, in buffer order (csrc/block.hip halves, then the layer's sums S1 | S2 | S3 |
+    S4 of csrc/fused_layer.hip; alignment pads and the trailing scratch are pieces too)."""
+    key = (c, o_post, o_sum, total)
+    if key not in _GRAD_SIZES:
+        cs, cc = c // 8, c * c
+        pre = [cc, c, c, cc, c, cc, c, cc, c]
+        post = [cc, c, c, c, c]
+        sums = [cs, cs, cs, cs * cs, c, c, cs, cs * c, 3, 3, 2, c, 3 * c, 3, 9]
+        sizes = pre + [o_post - sum(pre)] + post + [o_sum - o_post - sum(post)] + sums
+        sizes.append(total - sum(sizes))
+        assert min(sizes) >= 0
+        _GRAD_SIZES[key] = sizes
+    return _GRAD_SIZES[key]
 
 
 def _bottleneck_params(blk):
