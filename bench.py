@@ -522,6 +522,16 @@ def main():
         }
         if traffic and traffic.get("dominant_gpu_kernel"):
             line["dominant_gpu_kernel"] = traffic["dominant_gpu_kernel"]   # the single hottest GPU kernel of the kernel trace (tools/traffic_json.py)
+        if traffic and traffic.get("kernels"):
+            # the main-stream kernels that cost most per step, with the bandwidth their MEASURED traffic (PMC, profiles/r02_traffic.json)
+            # implies: how close each is to the 8 TB/s HBM peak on real bytes (algorithmic bytes: the `roofline` entries above)
+            rows = [(v["calls_per_step"] * v["avg_us"], k, v) for k, v in traffic["kernels"].items()
+                    if v.get("hbm_bytes_per_launch") and v.get("avg_us") and "k_fps" not in k and "k_grid" not in k and "k_td_tables" not in k]
+            line["kernel_traffic_roofline"] = [
+                dict(kernel=k.split("(")[0].replace("void ", ""), us_per_step=round(t, 1), launches_per_step=round(v["calls_per_step"], 1),
+                     avg_us=round(v["avg_us"], 1), hbm_MB_per_launch=round(v["hbm_bytes_per_launch"] / 1e6, 1),
+                     frac_of_hbm_peak=round(v["hbm_bytes_per_launch"] / (v["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 3))
+                for t, k, v in sorted(rows, key=lambda r: -r[0])[:12]]
 
     # ---- latency: how much look-ahead the number above depends on (FPS is a serial chain per scene).  serial = pre-pass inline on
     # the main stream, every step pays the whole FPS chain; then groups of 1 / 2 / 3 batches.
