@@ -275,6 +275,34 @@ class Geometry:
         pre-pass of the batch alone.  This is how FPS latency (a chain of ~25k dependent arg-max steps per scene, one
         workgroup per scene) is amortised: one launch carries the scenes of ``len(scene_counts)`` upcoming steps."""
         assert sum(scene_counts) == len(self.levels[0].o_host), "scene_counts must cover the group's scenes"
+        # Index tables are rebased for the WHOLE group first (one subtraction per table against a per-row vector of batch bases): the
+        # per-batch entries below are then plain row slices.  Rebasing per batch and table was 13 x D small kernels and ~4 ms of host time
+        # per group of 12 batches.
+        bounds, s0 = [], 0          # per batch: [(first row, end row) per level]
+        for nsc in scene_counts:
+            s1 = s0 + nsc
+            bounds.append([((lv.o_host[s0 - 1] if s0 > 0 else 0), lv.o_host[s1 - 1]) for lv in self.levels])
+            s0 = s1
+        dev = self.levels[0].p.device
+        base_rows = {}              # (source level, query level) -> per query row: first source row of its batch
+
+        def base_vector(src_level, query_level):
+            key = (src_level, query_level)
+            if key not in base_rows:
+                both = torch.tensor([[b[src_level][0] for b in bounds], [b[query_level][1] - b[query_level][0] for b in bounds]],
+                                    dtype=torch.int64).to(dev, non_blocking=True)   # (one small copy; expanded on the device)
+                base_rows[key] = torch.repeat_interleave(both[0].to(torch.int32), both[1], output_size=bounds[-1][query_level][1])
+            return base_rows[key]
+
+        rebased = {}
+        if len(scene_counts) > 1:
+            for key, val in self._memo.items():
+                if key[0] == "down":
+                    new_level, fps_idx = val
+                    rebased[key] = fps_idx - base_vector(key[1], new_level)
+                elif key[0] == "knn":
+                    idx = val[0]
+                    rebased[key] = torch.where(idx >= 0, idx - base_vector(key[2], key[3])[:, None], idx)
         out, s0 = [], 0
         for nsc in scene_counts:
             s1 = s0 + nsc
@@ -298,10 +326,10 @@ class Geometry:
                 elif kind == "down":
                     new_level, fps_idx = val
                     q0, q1 = rows[new_level]
-                    g._memo[key] = (new_level, rebase(fps_idx[q0:q1], rows[key[1]][0]))
+                    g._memo[key] = (new_level, rebased[key][q0:q1] if key in rebased else rebase(fps_idx[q0:q1], rows[key[1]][0]))
                 elif kind == "knn":
                     (idx, dist2), (q0, q1) = val, rows[key[3]]
-                    g._memo[key] = (rebase(idx[q0:q1], rows[key[2]][0]), dist2[q0:q1])
+                    g._memo[key] = (rebased[key][q0:q1] if key in rebased else rebase(idx[q0:q1], rows[key[2]][0]), dist2[q0:q1])
                 elif kind == "order":   # scene-major: the batch's rows occupy the same positions of the sorted list
                     r0, r1 = rows[key[1]]
                     g._memo[key] = val[r0:r1] - r0 if r0 else val[r0:r1]
