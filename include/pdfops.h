@@ -302,6 +302,9 @@ int pdf_ce_backward(long n, int c, const float *dlogits, const float *acc, const
  * Linear(3, 3) (point_transformer_seg.py:27-29) is a closed form of these and the weights: pdf_pt_layer_forward_m takes the batch's sums
  * and skips its first statistics pass (csrc/geom_moments.hip). */
 int pdf_knn_rel_moments(int b, long n, int nsample, const float *xyz, const int *offset, const int *idx, double *out, void *stream);
+/* the same for m queries new_xyz (scene ends new_offset) over other source points xyz: TransitionDown's grouping table */
+int pdf_knn_rel_moments_q(int b, long m, int nsample, const float *xyz, const float *new_xyz, const int *new_offset, const int *idx,
+                          double *out, void *stream);
 
 /* SGD with momentum and weight decay (torch.optim.SGD, dampening 0, no Nesterov -- the optimizer the reference's configs build,
  * pointcept/utils/optimizer.py + configs/s3dis/openseg-pt-v1-0-*.py) over every parameter tensor in ONE launch.  tab: ntensors records

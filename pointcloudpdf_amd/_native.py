@@ -512,6 +512,8 @@ class HipBackend(CBackend):
         lib.pdf_ce_backward.argtypes = [c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         lib.pdf_knn_rel_moments.restype = c_int
         lib.pdf_knn_rel_moments.argtypes = [c_int, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        lib.pdf_knn_rel_moments_q.restype = c_int
+        lib.pdf_knn_rel_moments_q.argtypes = [c_int, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         lib.pdf_sgd_chunk.restype = c_int
         lib.pdf_sgd_chunk.argtypes = []
         lib.pdf_sgd_step.restype = c_int
@@ -762,13 +764,15 @@ class HipBackend(CBackend):
         m = moments_of(idx) if self.use_moments else None
         return None if m is None else m.data_ptr()
 
-    def knn_rel_moments(self, nsample, xyz, offset, idx):
-        """Per-scene sums (b, 9) float64 of rel = xyz[idx] - xyz over the rows of a self kNN table (csrc/geom_moments.hip)."""
-        _check(xyz, torch.float32, "xyz"); _check(offset, torch.int32, "offset"); _check(idx, torch.int32, "idx")
+    def knn_rel_moments(self, nsample, xyz, offset, idx, new_xyz=None):
+        """Per-scene sums (b, 9) float64 of rel = xyz[idx] - new_xyz over the rows of a kNN table (csrc/geom_moments.hip); ``offset`` =
+        scene ends of the QUERIES; ``new_xyz`` None = a self table."""
+        q = xyz if new_xyz is None else new_xyz
+        _check(xyz, torch.float32, "xyz"); _check(q, torch.float32, "new_xyz"); _check(offset, torch.int32, "offset"); _check(idx, torch.int32, "idx")
         out = torch.zeros((offset.shape[0], 9), dtype=torch.float64, device=xyz.device)
-        require_current_device(xyz, offset, idx)
-        rc = self.lib.pdf_knn_rel_moments(int(offset.shape[0]), int(xyz.shape[0]), int(nsample), xyz.data_ptr(), offset.data_ptr(), idx.data_ptr(),
-                                          out.data_ptr(), self._stream())
+        require_current_device(xyz, q, offset, idx)
+        rc = self.lib.pdf_knn_rel_moments_q(int(offset.shape[0]), int(q.shape[0]), int(nsample), xyz.data_ptr(), q.data_ptr(), offset.data_ptr(),
+                                            idx.data_ptr(), out.data_ptr(), self._stream())
         if rc != 0:
             raise PdfOpsError(f"pdf_knn_rel_moments failed with status {rc}")
         return out

@@ -25,7 +25,8 @@ __device__ __forceinline__ int scene_of(const int *__restrict__ offset, int b, l
     return lo;
 }
 
-__global__ __launch_bounds__(MB) void k_rel_moments(long n, int k, const float *__restrict__ p, const int *__restrict__ idx,
+// p = source points (indexed by idx), q = query points (row i of idx belongs to q[i]; q == p for a self table)
+__global__ __launch_bounds__(MB) void k_rel_moments(long n, int k, const float *__restrict__ p, const float *__restrict__ q, const int *__restrict__ idx,
                                                     const int *__restrict__ offset, int b, double *__restrict__ out) {
     __shared__ double red[MB / 64][9];
     const long i = (long)blockIdx.x * MB + threadIdx.x;
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(MB) void k_rel_moments(long n, int k, const float *
 #pragma unroll
     for (int e = 0; e < 9; ++e) acc[e] = 0.0;
     if (i < n) {
-        const float px = p[i * 3], py = p[i * 3 + 1], pz = p[i * 3 + 2];
+        const float px = q[i * 3], py = q[i * 3 + 1], pz = q[i * 3 + 2];
         for (int j = 0; j < k; ++j) {
             const int nb = idx[i * k + j];
             const long nc = nb >= 0 ? nb : 0;
@@ -68,9 +69,15 @@ __global__ __launch_bounds__(MB) void k_rel_moments(long n, int k, const float *
 
 }  // namespace
 
-extern "C" int pdf_knn_rel_moments(int b, long n, int nsample, const float *xyz, const int *offset, const int *idx, double *out, void *stream) {
-    if (b < 1 || n < 0 || nsample < 1 || !offset || !out || (n > 0 && (!xyz || !idx))) return PDF_ERR_BAD_ARG;
-    if (n == 0) return PDF_OK;
-    k_rel_moments<<<(unsigned)((n + MB - 1) / MB), MB, 0, static_cast<hipStream_t>(stream)>>>(n, nsample, xyz, idx, offset, b, out);
+// The same for a table whose m queries (new_xyz, scene ends new_offset) differ from its source points (TransitionDown's grouping):
+// rel = xyz[idx[i, j]] - new_xyz[i].
+extern "C" int pdf_knn_rel_moments_q(int b, long m, int nsample, const float *xyz, const float *new_xyz, const int *new_offset, const int *idx,
+                                     double *out, void *stream) {
+    if (b < 1 || m < 0 || nsample < 1 || !new_offset || !out || (m > 0 && (!xyz || !new_xyz || !idx))) return PDF_ERR_BAD_ARG;
+    if (m == 0) return PDF_OK;
+    k_rel_moments<<<(unsigned)((m + MB - 1) / MB), MB, 0, static_cast<hipStream_t>(stream)>>>(m, nsample, xyz, new_xyz, idx, new_offset, b, out);
     return pdf_launch_status();
+}
+extern "C" int pdf_knn_rel_moments(int b, long n, int nsample, const float *xyz, const int *offset, const int *idx, double *out, void *stream) {
+    return pdf_knn_rel_moments_q(b, n, nsample, xyz, xyz, offset, idx, out, stream);
 }

@@ -17,6 +17,8 @@ libs/pointops/functions/sampling.py:15-18).
 """
 import weakref
 
+import os
+
 import torch
 
 from . import _native
@@ -195,17 +197,24 @@ class Geometry:
             S, Q = self.levels[src_level], self.levels[query_level]
             assert nsample == 16, "fused TransitionDown tables: nsample 16"
             rel4, Z, _ = _native.backend_for(S.p).td_tables(S.p, Q.p, idx, Q.o)
-            # per-scene [xx xy xz yy yz zz | sx sy sz] of the relative coordinates: per-point sums over the 16 rows, then one
-            # fp64 reduction per scene (scenes are contiguous point ranges known on the host; a column-wise cumsum took 57 ms)
-            r0, r1, r2 = rel4[..., 0], rel4[..., 1], rel4[..., 2]
-            mom = torch.stack([(r0 * r0).sum(1), (r0 * r1).sum(1), (r0 * r2).sum(1), (r1 * r1).sum(1), (r1 * r2).sum(1), (r2 * r2).sum(1),
-                               r0.sum(1), r1.sum(1), r2.sum(1)], -1).double()
+            # per-scene [xx xy xz yy yz zz | sx sy sz] of the relative coordinates: one kernel (csrc/geom_moments.hip, fp64 sums; a python
+            # loop over the scenes -- a slice + sum + store per scene and table -- was 15 ms of host time per group of 24 scenes)
             scene_sums = Z.new_zeros(len(Q.o_host), 16)
-            prev = 0
-            for si, e in enumerate(Q.o_host):
-                if e > prev:
-                    scene_sums[si, :9] = mom[prev:e].sum(0).float()
-                prev = e
+            be = _native.backend_for(S.p)
+            if hasattr(be, "knn_rel_moments") and os.environ.get("PDFOPS_TD_MOM_KERNEL", "1") != "0":
+                mom = be.knn_rel_moments(nsample, S.p, Q.o, idx, new_xyz=Q.p)          # (b, 9) = [S (3) | M (6)]
+                if S.p.device not in _MOM_TO_TD:
+                    _MOM_TO_TD[S.p.device] = torch.tensor([3, 4, 5, 6, 7, 8, 0, 1, 2], device=S.p.device)
+                scene_sums[:, :9] = mom[:, _MOM_TO_TD[S.p.device]].float()
+            else:
+                r0, r1, r2 = rel4[..., 0], rel4[..., 1], rel4[..., 2]
+                mom = torch.stack([(r0 * r0).sum(1), (r0 * r1).sum(1), (r0 * r2).sum(1), (r1 * r1).sum(1), (r1 * r2).sum(1), (r2 * r2).sum(1),
+                                   r0.sum(1), r1.sum(1), r2.sum(1)], -1).double()
+                prev = 0
+                for si, e in enumerate(Q.o_host):
+                    if e > prev:
+                        scene_sums[si, :9] = mom[prev:e].sum(0).float()
+                    prev = e
             self._memo[key] = (rel4, Z, scene_sums, _td_consts(scene_sums))
         return self._memo[key]
 
@@ -370,11 +379,18 @@ class Geometry:
 def _td_consts(scene_sums):
     """(b,16) per-scene [xx xy xz yy yz zz | sx sy sz] -> the batch's [sum rel^T rel (9) | sum rel (3) | 0 x4]."""
     t = scene_sums.double().sum(0)
+    # one gather through a per-device index tensor made ONCE (an H2D copy per call would block the host behind the whole pre-pass stream;
+    # torch.stack of nine 0-dim views, the previous form, cost 250 us of host time per call, 14 ms per group of 12 batches)
+    key = scene_sums.device
+    if key not in _TD_PERM:
+        _TD_PERM[key] = torch.tensor([0, 1, 2, 1, 3, 4, 2, 4, 5, 6, 7, 8], device=key)
     out = scene_sums.new_zeros(16)
-    out[:9] = torch.stack([t[0], t[1], t[2], t[1], t[3], t[4], t[2], t[4], t[5]]).float()   # (no index tensors: an H2D copy here would block the
-    #                                                                                         host behind the whole pre-pass stream)
-    out[9:12] = t[6:9].float()
+    out[:12] = t[_TD_PERM[key]].float()
     return out
+
+
+_TD_PERM = {}
+_MOM_TO_TD = {}
 
 
 class _LazyTicket:
