@@ -303,6 +303,21 @@ class Geometry:
                 base_rows[key] = torch.repeat_interleave(both[0].to(torch.int32), both[1], output_size=bounds[-1][query_level][1])
             return base_rows[key]
 
+        # per-batch sums of the per-scene tables (TransitionDown constants, coordinate sums of the self tables): one segmented sum per
+        # table for all batches (index_add over the scenes' batch ids), not a reduction per batch and table
+        batch_sums = {}
+        if len(scene_counts) > 1:
+            batch_of_scene = torch.repeat_interleave(torch.arange(len(scene_counts)), torch.tensor(scene_counts)).to(dev, non_blocking=True)
+            for key, val in self._memo.items():
+                if key[0] == "td":
+                    per = torch.zeros((len(scene_counts), 16), dtype=torch.float64, device=dev).index_add_(0, batch_of_scene, val[2].double())
+                    if dev not in _TD_PERM:
+                        _TD_PERM[dev] = torch.tensor([0, 1, 2, 1, 3, 4, 2, 4, 5, 6, 7, 8], device=dev)
+                    consts = val[2].new_zeros((len(scene_counts), 16))
+                    consts[:, :12] = per[:, _TD_PERM[dev]].float()
+                    batch_sums[key] = consts
+                elif key[0] == "mom":
+                    batch_sums[key] = torch.zeros((len(scene_counts), 9), dtype=torch.float64, device=dev).index_add_(0, batch_of_scene, val)
         rebased = {}
         if len(scene_counts) > 1:
             for key, val in self._memo.items():
@@ -313,7 +328,7 @@ class Geometry:
                     idx = val[0]
                     rebased[key] = torch.where(idx >= 0, idx - base_vector(key[2], key[3])[:, None], idx)
         out, s0 = [], 0
-        for nsc in scene_counts:
+        for bi, nsc in enumerate(scene_counts):
             s1 = s0 + nsc
             g = Geometry.__new__(Geometry)
             g.levels, g._memo = [], {}
@@ -350,7 +365,7 @@ class Geometry:
                     g._memo[key] = (g._memo[("knn",) + key[1:]][0], weight[q0:q1])
                 elif kind == "td":   # rel4 by query rows, Z by source rows; the 12 sums are per batch
                     (rel4, Z, scene_sums, _), (q0, q1), (r0, r1) = val, rows[key[3]], rows[key[2]]
-                    g._memo[key] = (rel4[q0:q1], Z[r0:r1], scene_sums[s0:s1], _td_consts(scene_sums[s0:s1]))
+                    g._memo[key] = (rel4[q0:q1], Z[r0:r1], scene_sums[s0:s1], batch_sums[key][bi] if key in batch_sums else _td_consts(scene_sums[s0:s1]))
                 elif kind == "mom":   # per-scene sums: the batch's scenes
                     g._memo[key] = val[s0:s1]
                 elif kind == "inv":   # absolute positions into the group's shared entry array; entry ids rebased by the batch's first entry
@@ -364,7 +379,7 @@ class Geometry:
                 if key[0] == "knn" and ("order", key[3]) in g._memo:
                     _native.attach_order(val[0], g._memo[("order", key[3])], g._memo.get(("order", key[2])))
                 if key[0] == "mom":
-                    _native.attach_moments(g._memo[("knn",) + key[1:]][0], val.sum(0))
+                    _native.attach_moments(g._memo[("knn",) + key[1:]][0], batch_sums[key][bi] if key in batch_sums else val.sum(0))
             out.append(g)
             s0 = s1
         return out
