@@ -232,6 +232,15 @@ int pdf_rowlin_multi(long n, int k, int o, int nin, int nout, const float *const
                      float *const *y, long ldy, int accumulate, void *stream);
 int pdf_rowlin_wgrad_multi(long n, int k, int o, int ng, const float *const *g, long ldg, const float *x, long ldx,
                            const float *scale, const float *shift, int relu, float *const *dw, float *const *db, void *stream);
+/* Input gradient y = sum_i x[i] W[i] (nin <= 3; W (k, o) = the layers' own (out, in) weights) of Linear layers reading a
+ * BatchNorm(+ReLU) output bx -> bn -> relu, with that BatchNorm's backward sums as the product's epilogue: partial
+ * (pdf_rowlin_partial_floats(n, o)) receives *partial_rows rows of [sum g' | sum g' xhat]; pdf_bn_act_backward_presummed then
+ * finishes the BatchNorm backward without re-reading y and bx for the reduction.  PDF_ERR_UNSUPPORTED outside the streaming
+ * shapes (callers then use pdf_rowlin_multi + pdf_bn_act_backward). */
+int pdf_rowlin_dgrad_bstats(long n, int k, int o, int nin, const float *const *x, long ldx, const float *const *w, float *y, long ldy,
+                            const float *bx, long ldb, const float *bcoef, int brelu, float *partial, int *partial_rows, void *stream);
+int pdf_bn_act_backward_presummed(long n, int c, const float *gy, const float *x, const float *coef, int training, int relu,
+                                  const float *partial, int partial_rows, float *sums, float *gx, void *stream);
 
 /* Dense halves of the Bottleneck (point_transformer_seg.py:184-192) as single host calls (csrc/block.hip documents the
  * pointer tables p[]): pre = linear1 + bn1 + ReLU + q/k/v projections, post = bn2 + ReLU + linear3 + bn3 + residual + ReLU. */

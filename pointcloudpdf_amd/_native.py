@@ -536,6 +536,12 @@ class HipBackend(CBackend):
         lib.pdf_rowlin_wgrad_multi.restype = c_int
         lib.pdf_rowlin_wgrad_multi.argtypes = [c_long, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int,
                                                c_void_p, c_void_p, c_void_p]
+        lib.pdf_rowlin_dgrad_bstats.restype = c_int
+        lib.pdf_rowlin_dgrad_bstats.argtypes = [c_long, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_long,
+                                                c_void_p, c_int, c_void_p, ctypes.POINTER(c_int), c_void_p]
+        lib.pdf_bn_act_backward_presummed.restype = c_int
+        lib.pdf_bn_act_backward_presummed.argtypes = [c_long, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
+                                                      c_void_p, c_void_p]
         lib.pdf_rowlin_partial_floats.restype = c_long
         lib.pdf_rowlin_partial_floats.argtypes = [c_long, c_int]
         lib.pdf_rowlin_partial_rows.restype = c_int
@@ -861,6 +867,30 @@ class HipBackend(CBackend):
         if rc != 0:
             raise PdfOpsError(f"pdf_rowlin_multi failed with status {rc}")
         return ys
+
+    def rowlin_dgrad_bn_backward(self, gs, ws, bx, coef, training=True, relu=True):
+        """Input gradient sum_i gs[i] @ ws[i] of Linear layers reading relu(bn(bx)), followed by that BatchNorm's backward with the
+        reduction pass folded into the product's epilogue (pdf_rowlin_dgrad_bstats + pdf_bn_act_backward_presummed).
+        -> (d bx, d gamma, d beta), or None when the streaming kernels do not cover the shape."""
+        n, k = gs[0].shape
+        o = ws[0].shape[1]
+        require_current_device(bx, *gs)
+        dy = self._new(bx, (n, o), torch.float32)
+        partial = self._new(bx, (int(self.lib.pdf_rowlin_partial_floats(n, o)),), torch.float32)
+        rows = c_int(0)
+        rc = self.lib.pdf_rowlin_dgrad_bstats(n, k, o, len(gs), self._ptrs(gs), gs[0].stride(0), self._ptrs(ws), dy.data_ptr(), o,
+                                              bx.data_ptr(), bx.stride(0), coef.data_ptr(), int(bool(relu)), partial.data_ptr(),
+                                              ctypes.byref(rows), self._stream())
+        if rc == -3:   # PDF_ERR_UNSUPPORTED
+            return None
+        if rc != 0:
+            raise PdfOpsError(f"pdf_rowlin_dgrad_bstats failed with status {rc}")
+        sums = self._new(bx, (2 * o,), torch.float32)
+        rc = self.lib.pdf_bn_act_backward_presummed(n, o, dy.data_ptr(), bx.data_ptr(), coef.data_ptr(), int(bool(training)), int(bool(relu)),
+                                                    partial.data_ptr(), rows.value, sums.data_ptr(), dy.data_ptr(), self._stream())
+        if rc != 0:
+            raise PdfOpsError(f"pdf_bn_act_backward_presummed failed with status {rc}")
+        return dy, sums[o:], sums[:o]
 
     def rowlin_wgrad_multi(self, gs, x, coef, relu):
         n, o = gs[0].shape

@@ -67,6 +67,11 @@ extern "C" int pdf_block_pre_forward(long n, int c, void *const *p, int training
 // p[]: x, z1, coef1, W1, Wq, Wk, Wv, gxq, gxk, gxv                                  (inputs)
 //      gx, grads [dW1 (c*c) | dbeta1 (c) | dgamma1 (c) | {dW (c*c), db (c)} x q,k,v]   (outputs; grads zeroed here)
 //      dy (n*c), partial (pdf_bn_partial_floats(n, c))                                    (scratch; p[14] unused)
+static bool dgrad_bstats() {   // PDFOPS_DGRAD_BSTATS=0: BatchNorm-backward sums from their own pass instead of the dgrad epilogue (A/B)
+    static const bool on = [] { const char *v = getenv("PDFOPS_DGRAD_BSTATS"); return !(v && v[0] == '0'); }();
+    return on;
+}
+
 static int block_pre_backward(long n, int c, void *const *p, int training, int accumulate_gx, int grads_zeroed, void *stream, const Fork *fk = nullptr) {
     if (n < 1 || !p) return PDF_ERR_BAD_ARG;
     const float *x = (const float *)p[0], *z1 = (const float *)p[1], *coef1 = (const float *)p[2], *W1 = (const float *)p[3];
@@ -85,9 +90,17 @@ static int block_pre_backward(long n, int c, void *const *p, int training, int a
     float *ys[1] = {dy};
     void *ws_stream = fk ? (void *)fk->begin(e) : stream;   // q/k/v weight gradients: g_xq / g_xk / g_xv are final here
     e << pdf_rowlin_wgrad_multi(n, c, c, 3, gs, c, z1, c, coef1, coef1 + c, 1, dws, dbs, ws_stream);
-    e << pdf_rowlin_multi(n, c, c, 3, 1, gs, c, ws, 1, nullptr, nullptr, nullptr, 0, ys, c, 0, stream);
-    // bn1 backward in place on dy (elementwise: same index read and written); its column sums ARE [d beta1 | d gamma1]
-    e << pdf_bn_act_backward(n, c, dy, z1, nullptr, coef1, training, 1, partial, db1, dy, nullptr, stream);   // (the atomic variant: 782 blocks on 64 addresses, +13 us)
+    // bn1 backward in place on dy (elementwise: same index read and written); its column sums ARE [d beta1 | d gamma1].  The sums come
+    // out of the input-gradient product's epilogue where the streaming kernel covers the shape, else from a pass over dy and z1.
+    int prow = 0;
+    const int rc1 = dgrad_bstats() ? pdf_rowlin_dgrad_bstats(n, c, c, 3, gs, c, ws, dy, c, z1, c, coef1, 1, partial, &prow, stream) : PDF_ERR_UNSUPPORTED;
+    if (rc1 == PDF_ERR_UNSUPPORTED) {
+        e << pdf_rowlin_multi(n, c, c, 3, 1, gs, c, ws, 1, nullptr, nullptr, nullptr, 0, ys, c, 0, stream);
+        e << pdf_bn_act_backward(n, c, dy, z1, nullptr, coef1, training, 1, partial, db1, dy, nullptr, stream);   // (the atomic variant: 782 blocks on 64 addresses, +13 us)
+    } else {
+        e << rc1;
+        e << pdf_bn_act_backward_presummed(n, c, dy, z1, coef1, training, 1, partial, prow, db1, dy, stream);
+    }
     ws_stream = fk ? (void *)fk->begin(e) : stream;         // dW1 needs the finished dy
     e << pdf_rowlin_wgrad(n, c, c, dy, c, x, c, nullptr, nullptr, 0, dW1, nullptr, ws_stream);
     e << pdf_rowlin_forward(n, c, c, dy, c, W1, 1, nullptr, nullptr, nullptr, 0, gx, c, accumulate_gx, nullptr, stream);
@@ -134,9 +147,17 @@ static int block_post_backward(long n, int c, void *const *p, int training, int 
     e << pdf_bn_act_backward(n, c, gy, z3, x, coef3, training, 1, partial, db3, da, gres, stream);
     void *ws_stream = fk ? (void *)fk->begin(e) : stream;
     e << pdf_rowlin_wgrad(n, c, c, da, c, t, c, coef2, coef2 + c, 1, dW3, nullptr, ws_stream);
-    e << pdf_rowlin_forward(n, c, c, da, c, W3, 1, nullptr, nullptr, nullptr, 0, gt, c, 0, nullptr, stream);
-    // bn2 backward in place on gt
-    e << pdf_bn_act_backward(n, c, gt, t, nullptr, coef2, training, 1, partial, db2, gt, nullptr, stream);
+    // bn2 backward in place on gt (sums from the product's epilogue, as in block_pre_backward)
+    int prow = 0;
+    const float *das[1] = {da}, *w3s[1] = {W3};
+    const int rc2 = dgrad_bstats() ? pdf_rowlin_dgrad_bstats(n, c, c, 1, das, c, w3s, gt, c, t, c, coef2, 1, partial, &prow, stream) : PDF_ERR_UNSUPPORTED;
+    if (rc2 == PDF_ERR_UNSUPPORTED) {
+        e << pdf_rowlin_forward(n, c, c, da, c, W3, 1, nullptr, nullptr, nullptr, 0, gt, c, 0, nullptr, stream);
+        e << pdf_bn_act_backward(n, c, gt, t, nullptr, coef2, training, 1, partial, db2, gt, nullptr, stream);
+    } else {
+        e << rc2;
+        e << pdf_bn_act_backward_presummed(n, c, gt, t, coef2, training, 1, partial, prow, db2, gt, stream);
+    }
     return e.rc;
 }
 

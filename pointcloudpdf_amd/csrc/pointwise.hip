@@ -207,17 +207,23 @@ extern "C" int pdf_bn_act_forward(long n, int c, const float *x, const float *re
 }
 
 // Backward.  sums (2c floats) receives [d beta | d gamma] = [sum g' | sum g' * xhat]; gres may be null.
+// presummed > 0: partial already holds that many rows of [sum g' | sum g' xhat] (epilogue of pdf_rowlin_dgrad_bstats); the reduction pass is skipped.
 static int bn_act_backward(long n, int c, const float *gy, const float *x, const float *res, const float *coef,
-                           int training, int relu, float *partial, float *sums, int sums_zeroed, float *gx, float *gres, void *stream) {
+                           int training, int relu, float *partial, float *sums, int sums_zeroed, float *gx, float *gres, void *stream,
+                           int presummed = 0) {
     if (n < 1 || !gy || !x || !coef || (!partial && !sums_zeroed) || !sums || !gx) return PDF_ERR_BAD_ARG;
     if (!pdf_bn_supported(c)) return PDF_ERR_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const float *scale = coef, *shift = coef + c, *mean = coef + 2 * c, *rstd = coef + 3 * c;
     const int g = pw::grid_rows(n, c);
     const long n4 = n * (c / 4);
-    pw::k_bn_bwd_reduce<<<g, pw::PB, pw::PB * 8 * sizeof(float), s>>>(n, c, gy, x, res, scale, shift, mean, rstd, relu, partial,
-                                                                      sums_zeroed ? sums : nullptr);
-    if (!sums_zeroed) fl::launch_colsum(partial, g, 2 * c, sums, s);
+    if (presummed > 0) {
+        fl::launch_colsum(partial, presummed, 2 * c, sums, s);
+    } else {
+        pw::k_bn_bwd_reduce<<<g, pw::PB, pw::PB * 8 * sizeof(float), s>>>(n, c, gy, x, res, scale, shift, mean, rstd, relu, partial,
+                                                                          sums_zeroed ? sums : nullptr);
+        if (!sums_zeroed) fl::launch_colsum(partial, g, 2 * c, sums, s);
+    }
 #define F4(p) reinterpret_cast<const float4 *>(p)
     if (training)
         pw::k_bn_bwd_apply<<<pw::grid_elems(n4), pw::PB, 0, s>>>(n4, c / 4, F4(gy), F4(x), F4(res), F4(scale), F4(shift), F4(mean), F4(rstd),
@@ -233,6 +239,12 @@ static int bn_act_backward(long n, int c, const float *gy, const float *x, const
 extern "C" int pdf_bn_act_backward(long n, int c, const float *gy, const float *x, const float *res, const float *coef,
                                    int training, int relu, float *partial, float *sums, float *gx, float *gres, void *stream) {
     return bn_act_backward(n, c, gy, x, res, coef, training, relu, partial, sums, 0, gx, gres, stream);
+}
+// same with the reduction pass already done by the producer of gy (pdf_rowlin_dgrad_bstats): partial holds partial_rows rows of 2c sums
+extern "C" int pdf_bn_act_backward_presummed(long n, int c, const float *gy, const float *x, const float *coef, int training, int relu,
+                                             const float *partial, int partial_rows, float *sums, float *gx, void *stream) {
+    if (partial_rows < 1 || !partial) return PDF_ERR_BAD_ARG;
+    return bn_act_backward(n, c, gy, x, nullptr, coef, training, relu, const_cast<float *>(partial), sums, 0, gx, nullptr, stream, partial_rows);
 }
 // same, `sums` (2c) zeroed by the caller: the block sums are added atomically, the column-sum launch disappears
 extern "C" int pdf_bn_act_backward_acc(long n, int c, const float *gy, const float *x, const float *res, const float *coef,

@@ -178,7 +178,8 @@ __global__ __launch_bounds__(256) void k_wgrad(WArgs a) {
 namespace rl2 {
 int try_forward(long n, int k, int o, int nin, int nout, const float *const *x, long ldx, const float *const *w, int transpose_w,
                 const float *const *bias, const float *scale, const float *shift, int relu, float *const *y, long ldy,
-                int accumulate, float *partial, hipStream_t s, const float *roww = nullptr, long rws = 0);
+                int accumulate, float *partial, hipStream_t s, const float *roww = nullptr, long rws = 0, const float *bx = nullptr,
+                long ldb = 0, const float *bcoef = nullptr, int brelu = 0, int *partial_rows = nullptr);
 int try_wgrad(long n, int k, int o, int ng, const float *const *g, long ldg, const float *x, long ldx, const float *scale,
               const float *shift, int relu, float *const *dw, float *const *db, hipStream_t s, const float *roww = nullptr, long rws = 0);
 int stats_rows(long n);
@@ -266,6 +267,23 @@ extern "C" int pdf_rowlin_multi(long n, int k, int o, int nin, int nout, const f
                                     accumulate || i > 0, nullptr, stream);
     }
     return rc;
+}
+
+// Input gradient y = sum_i x[i] W[i] (W (k, o) row-major, nin = 1..3) of Linear layers that read a BatchNorm(+ReLU) output, with that
+// BatchNorm's backward sums as an epilogue: partial receives *partial_rows rows of [sum g' | sum g' xhat] (2 o floats each; g' = y
+// masked by the ReLU of bx * scale + shift, xhat = (bx - mean) * rstd; bcoef = [scale | shift | mean | rstd]) - what
+// pdf_bn_act_backward's first pass would compute from a second read of y and bx.  partial must hold pdf_rowlin_partial_floats(n, o).
+// PDF_ERR_UNSUPPORTED for shapes outside the streaming kernels (the caller then runs the two separate passes).
+extern "C" int pdf_rowlin_dgrad_bstats(long n, int k, int o, int nin, const float *const *x, long ldx, const float *const *w, float *y, long ldy,
+                                       const float *bx, long ldb, const float *bcoef, int brelu, float *partial, int *partial_rows,
+                                       void *stream) {
+    if (n < 1 || k < 1 || o < 1 || !x || !w || !y || nin < 1 || nin > 3 || !bx || !bcoef || !partial || !partial_rows) return PDF_ERR_BAD_ARG;
+    if (!rowlin_streams(k, o)) return PDF_ERR_UNSUPPORTED;
+    float *ys[1] = {y};
+    if (!rl2::try_forward(n, k, o, nin, 1, x, ldx, w, 1, nullptr, nullptr, nullptr, 0, ys, ldy, 0, partial, static_cast<hipStream_t>(stream),
+                          nullptr, 0, bx, ldb, bcoef, brelu, partial_rows))
+        return PDF_ERR_UNSUPPORTED;
+    return pdf_launch_status();
 }
 
 // dW[i] += G[i]^T f(X), db[i] += column sums of G[i] for up to three gradients sharing the layer input X.

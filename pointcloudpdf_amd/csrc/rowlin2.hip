@@ -36,7 +36,10 @@ struct FwdArgs {
     const float *scale, *shift; int relu;
     float *Y[3]; long ldy;
     int accumulate;
-    float *partial;          // [gridDim.x][2 * O] (STATS; single output)
+    float *partial;          // [gridDim.x][2 * O] (ST != 0; single output)
+    // ST == 2: the output is the gradient of a BatchNorm(+ReLU) OUTPUT; the partial rows then carry that BatchNorm's backward sums
+    // [sum g' | sum g' xhat] (g' = output masked by the ReLU of bx * scale + shift, xhat = (bx - mean) * rstd) instead of [sum | sum of squares]
+    const float *bx; long ldb; const float *bcoef; int brelu;   // bx (N, O; row stride ldb), bcoef = [scale | shift | mean | rstd] (4 O)
     const float *roww; long rws;   // optional per-row factor of the product (y = roww[n] * (f(x) Wt) + bias), element stride rws
 };
 
@@ -46,8 +49,9 @@ static inline int fwd_row_blocks(long n) {
     return (int)(b < 1 ? 1 : (b > FWD_CAP ? FWD_CAP : b));
 }
 
-template <int K, int NOB, int NIN, bool PRE, bool STATS>
+template <int K, int NOB, int NIN, bool PRE, int ST>   // ST: 0 = no statistics, 1 = [sum | sum of squares] of the output, 2 = BatchNorm-backward sums (FwdArgs)
 __global__ __launch_bounds__(256) void k_fwd(FwdArgs a) {
+    constexpr bool STATS = ST != 0;
     constexpr int NJ = K / 16;
     constexpr bool COEF_REGS = K <= 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -94,6 +98,16 @@ __global__ __launch_bounds__(256) void k_fwd(FwdArgs a) {
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) { s4[ob] = f32x4{0.f, 0.f, 0.f, 0.f}; ss4[ob] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
+    // ST == 2: the BatchNorm coefficients of this workgroup's columns live in LDS (registers are full of weight fragments: 16 more per
+    // column block would halve the occupancy of the three-input K = 256 kernel); rstd is applied once, to the finished sums.
+    __shared__ float bco[ST == 2 ? 3 : 1][NOB * 16];   // scale | shift | mean
+    if (ST == 2) {
+        if (threadIdx.x < 3 * NOB * 16) {
+            const int v = threadIdx.x / (NOB * 16), t = threadIdx.x % (NOB * 16);
+            bco[ST == 2 ? v : 0][t] = a.bcoef[(long)v * a.O + gcol0 + t];
+        }
+        __syncthreads();
+    }
     const long ntiles = (a.N + 15) / 16;
     for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
         const long n = tile * 16 + li;
@@ -132,7 +146,19 @@ __global__ __launch_bounds__(256) void k_fwd(FwdArgs a) {
             float *dst = a.Y[outi[ob]] + (valid ? n : 0) * a.ldy + colb[ob] + 4 * kq;
             if (a.accumulate && valid) v += *reinterpret_cast<const f32x4 *>(dst);
             if (valid) *reinterpret_cast<f32x4 *>(dst) = v;
-            if (STATS && valid) { s4[ob] += v; ss4[ob] += v * v; }
+            if (ST == 1 && valid) { s4[ob] += v; ss4[ob] += v * v; }
+            if (ST == 2) {
+                const f32x4 x4 = *reinterpret_cast<const f32x4 *>(a.bx + (valid ? n : 0) * a.ldb + colb[ob] + 4 * kq);
+                const f32x4 sc = *reinterpret_cast<const f32x4 *>(&bco[0][ob * 16 + 4 * kq]);
+                const f32x4 sh = *reinterpret_cast<const f32x4 *>(&bco[ST == 2 ? 1 : 0][ob * 16 + 4 * kq]);
+                const f32x4 mu = *reinterpret_cast<const f32x4 *>(&bco[ST == 2 ? 2 : 0][ob * 16 + 4 * kq]);
+                const f32x4 pre = x4 * sc + sh;
+                f32x4 gm;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) gm[c] = (valid && (!a.brelu || pre[c] > 0.f)) ? v[c] : 0.f;
+                s4[ob] += gm;
+                ss4[ob] += gm * (x4 - mu);
+            }
         }
     }
     if (STATS) {
@@ -151,7 +177,8 @@ __global__ __launch_bounds__(256) void k_fwd(FwdArgs a) {
         if (t < NOB * 16) {
             float *row = a.partial + (size_t)blockIdx.x * 2 * a.O;
             row[gcol0 + t] = red[0][0][t] + red[1][0][t] + red[2][0][t] + red[3][0][t];      // STATS: single output, gcol0 == column
-            row[a.O + gcol0 + t] = red[0][1][t] + red[1][1][t] + red[2][1][t] + red[3][1][t];
+            const float ss = red[0][1][t] + red[1][1][t] + red[2][1][t] + red[3][1][t];
+            row[a.O + gcol0 + t] = ST == 2 ? ss * a.bcoef[3 * (long)a.O + gcol0 + t] : ss;
         }
     }
 }
@@ -258,33 +285,38 @@ __global__ __launch_bounds__(256) void k_wg(WArgs a) {
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 template <int K, int NOB, int NIN>
-static void launch_fwd(const FwdArgs &a, int nslabs, hipStream_t s) {
-    const bool pre = a.scale != nullptr, stats = a.partial != nullptr;
+static int launch_fwd(const FwdArgs &a, int nslabs, hipStream_t s) {   // returns the number of row blocks (= partial rows written)
+    const bool pre = a.scale != nullptr, stats = a.partial != nullptr, bst = stats && a.bx != nullptr;
     // Every workgroup first loads its waves' weight fragments (16 NOB columns x K: 8-32 KB per wave).  With many column slabs and few
     // rows (levels 4-5: 3,124 / 780 rows, up to 96 slabs for the three-output q / k / v product) one row block per 64 rows means a wave
-    // loads its fragment for a single 16-row tile; fewer row blocks amortise it over several tiles.  (Not with STATS: the partial rows
-    // are indexed by row block and sized by pdf_rowlin_partial_rows.)
+    // loads its fragment for a single 16-row tile; fewer row blocks amortise it over several tiles.  (Not with statistics: the partial
+    // rows are indexed by row block and sized by pdf_rowlin_partial_rows.)
     // Measured (PDFOPS_RL_BLOCKS = total workgroups aimed at): 512 -> q / k / v product at 3,124 x 256: 41 -> 31 us, three-input dgrad 36 -> 30 us,
     // 780 x 512: 54 -> 46 us, single-slab shapes unchanged; 384 and below lose on the large levels, 1024 and above change nothing.
     static const int total = [] { const char *v = getenv("PDFOPS_RL_BLOCKS"); const int x = v ? atoi(v) : 0; return x > 0 ? x : 512; }();
     int gx = fwd_row_blocks(a.N);
-    if (!(NIN == 1 && stats)) gx = std::max(1, std::min(gx, std::max(8, total / std::max(nslabs, 1))));
+    if (!stats || bst) gx = std::max(1, std::min(gx, std::max(8, total / std::max(nslabs, 1))));   // (bst: the caller is told the row count)
     const dim3 grid((unsigned)gx, (unsigned)nslabs);
-    if (NIN == 1 && stats) {
-        if (pre) k_fwd<K, NOB, 1, true, true><<<grid, 256, 0, s>>>(a);
-        else k_fwd<K, NOB, 1, false, true><<<grid, 256, 0, s>>>(a);
+    if (bst) {   // BatchNorm-backward sums of the output (dgrad kernels: no input prologue)
+        k_fwd<K, NOB, NIN, false, 2><<<grid, 256, 0, s>>>(a);
+    } else if (NIN == 1 && stats) {
+        if (pre) k_fwd<K, NOB, 1, true, 1><<<grid, 256, 0, s>>>(a);
+        else k_fwd<K, NOB, 1, false, 1><<<grid, 256, 0, s>>>(a);
     } else {
-        if (pre) k_fwd<K, NOB, NIN, true, false><<<grid, 256, 0, s>>>(a);
-        else k_fwd<K, NOB, NIN, false, false><<<grid, 256, 0, s>>>(a);
+        if (pre) k_fwd<K, NOB, NIN, true, 0><<<grid, 256, 0, s>>>(a);
+        else k_fwd<K, NOB, NIN, false, 0><<<grid, 256, 0, s>>>(a);
     }
+    return gx;
 }
 
 // returns 1 when a streaming kernel took the job, 0 when the shape is not covered (caller falls back to the tiled kernel)
 int try_forward(long n, int k, int o, int nin, int nout, const float *const *x, long ldx, const float *const *w, int transpose_w,
                 const float *const *bias, const float *scale, const float *shift, int relu, float *const *y, long ldy,
-                int accumulate, float *partial, hipStream_t s, const float *roww, long rws) {
+                int accumulate, float *partial, hipStream_t s, const float *roww, long rws, const float *bx, long ldb, const float *bcoef,
+                int brelu, int *partial_rows) {
     if (nin < 1 || nout < 1 || (nin > 1 && nout > 1) || nin > 3 || nout > 3) return 0;
-    if (partial && (nin != 1 || nout != 1)) return 0;
+    if (partial && !bx && (nin != 1 || nout != 1)) return 0;
+    if (bx && (!partial || nout != 1 || scale || !bcoef || (ldb & 3) || !aligned16(bx) || !aligned16(bcoef))) return 0;
     if ((ldx & 3) || (ldy & 3) || (o & 15)) return 0;
     for (int i = 0; i < (nin > 1 ? nin : nout); ++i) if (!aligned16(w[i])) return 0;
     if (scale && (!aligned16(scale) || !aligned16(shift))) return 0;
@@ -293,6 +325,7 @@ int try_forward(long n, int k, int o, int nin, int nout, const float *const *x, 
     FwdArgs a;
     a.N = n; a.O = o; a.ldx = ldx; a.ldy = ldy; a.scale = scale; a.shift = shift; a.relu = relu; a.accumulate = accumulate;
     a.partial = partial; a.roww = roww; a.rws = rws;
+    a.bx = bx; a.ldb = ldb; a.bcoef = bcoef; a.brelu = brelu;
     a.wso = transpose_w ? 1 : k; a.wsk = transpose_w ? o : 1;
     for (int i = 0; i < 3; ++i) {
         a.X[i] = i < nin ? x[i] : nullptr;
@@ -301,12 +334,12 @@ int try_forward(long n, int k, int o, int nin, int nout, const float *const *x, 
         a.Y[i] = i < nout ? y[i] : nullptr;
     }
     const int cols = o * nout;
-#define PDF_RL2(K_, NOB_, NIN_) do { if (cols % (NOB_ * 16) == 0) { launch_fwd<K_, NOB_, NIN_>(a, cols / (NOB_ * 16), s); return 1; } } while (0)
+#define PDF_RL2(K_, NOB_, NIN_) do { if (cols % (NOB_ * 16) == 0) { const int r_ = launch_fwd<K_, NOB_, NIN_>(a, cols / (NOB_ * 16), s); if (partial_rows) *partial_rows = r_; return 1; } } while (0)
     if (nin == 1) {
         switch (k) {
-        case 32: if (!partial) PDF_RL2(32, 6, 1); PDF_RL2(32, 2, 1); PDF_RL2(32, 1, 1); break;
+        case 32: if (!partial) PDF_RL2(32, 6, 1); PDF_RL2(32, 2, 1); PDF_RL2(32, 1, 1); break;   // (statistics: at most 2 column blocks per wave)
         case 64: PDF_RL2(64, 4, 1); PDF_RL2(64, 1, 1); break;
-        case 128: PDF_RL2(128, 4, 1); PDF_RL2(128, 1, 1); break;
+        case 128: if (!bx) PDF_RL2(128, 4, 1); else PDF_RL2(128, 2, 1); PDF_RL2(128, 1, 1); break;   // (ST == 2 with 4 column blocks: 305 registers, one wave per SIMD)
         case 256: PDF_RL2(256, 2, 1); PDF_RL2(256, 1, 1); break;
         case 512: PDF_RL2(512, 1, 1); break;
         default: break;

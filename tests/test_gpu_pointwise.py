@@ -133,6 +133,41 @@ def test_rowlin_multi(n, c, pre):
         assert max_rel(db.cpu().numpy(), gi.double().sum(0).cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("n,c,nin", [(30011, 32, 3), (30011, 32, 1), (9000, 64, 3), (9001, 64, 1), (4097, 128, 3), (4097, 128, 1),
+                                     (1500, 256, 3), (1501, 256, 1), (300, 512, 1), (7, 64, 3)])
+@pytest.mark.parametrize("train", [True, False])
+def test_dgrad_with_batchnorm_backward_sums(n, c, nin, train):
+    """Input gradient of Linear layers that read relu(bn(z)) with bn's backward sums as the product's epilogue
+    (pdf_rowlin_dgrad_bstats + pdf_bn_act_backward_presummed) against torch autograd in fp64."""
+    from pointcloudpdf_amd import _native
+
+    be = _native.hip_backend()
+    g = torch.Generator(device="cuda").manual_seed(n + c + nin)
+    z = torch.randn(n, c, device="cuda", generator=g) * 1.7 + 0.4
+    gamma = torch.rand(c, device="cuda", generator=g) + 0.5
+    gamma[::5] *= -1.0   # negative scales: the ReLU mask must follow the sign of the pre-activation, not of xhat
+    beta = torch.randn(c, device="cuda", generator=g) * 0.3
+    ws = [torch.randn(c, c, device="cuda", generator=g) / c ** 0.5 for _ in range(nin)]
+    gs = [torch.randn(n, c, device="cuda", generator=g) for _ in range(nin)]
+    zd = z.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    if train:
+        mean, var = zd.mean(0), zd.var(0, unbiased=False)
+    else:
+        mean, var = torch.full((c,), 0.3, device="cuda", dtype=torch.float64), torch.full((c,), 2.0, device="cuda", dtype=torch.float64)
+    rstd = (var + 1e-5).rsqrt()
+    y = torch.relu((zd - mean) * rstd * gd + bd)
+    sum((y @ w.double().t() * gi.double()).sum() for w, gi in zip(ws, gs)).backward()
+    scale = (gamma.double() * rstd.detach()).float()
+    coef = torch.cat([scale, (beta.double() - mean.detach() * gamma.double() * rstd.detach()).float(), mean.detach().float(), rstd.detach().float()])
+    out = be.rowlin_dgrad_bn_backward(gs, ws, z, coef, training=train, relu=True)
+    assert out is not None, "streaming kernels cover every Bottleneck width"
+    dz, dgamma, dbeta = out
+    assert l2_rel(dz.cpu().numpy(), zd.grad.cpu().numpy()) < 2e-6
+    assert l2_rel(dgamma.cpu().numpy(), gd.grad.cpu().numpy()) < 1e-5
+    assert l2_rel(dbeta.cpu().numpy(), bd.grad.cpu().numpy()) < 1e-5
+
+
 @pytest.mark.parametrize("C,K,train", [(32, 8, True), (64, 16, True), (256, 16, True), (512, 16, True), (32, 8, False)])
 def test_bottleneck_matrix_core_path(C, K, train):
     """Bottleneck through rowlin / folded norms vs the op-by-op path (same module, switch off)."""
