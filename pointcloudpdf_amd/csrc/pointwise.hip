@@ -56,20 +56,23 @@ __global__ __launch_bounds__(PB) void k_bn_stats(long n, int c, const float *__r
 }
 
 // y = [relu]( x * scale + shift [+ res] )
+// (RES as a template parameter: a load behind `if (res)` waits for the loads before it and is waited for on its own)
+template <bool RES>
 __global__ __launch_bounds__(PB) void k_bn_apply(long n4, int c4, const float4 *__restrict__ x, const float4 *__restrict__ scale,
                                                  const float4 *__restrict__ shift, const float4 *__restrict__ res, int relu,
                                                  float4 *__restrict__ y) {
     for (long e = (long)blockIdx.x * PB + threadIdx.x; e < n4; e += (long)gridDim.x * PB) {
         const int cc = (int)(e % c4);
         const float4 v = x[e], sc = scale[cc], sh = shift[cc];
-        float4 o = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
-        if (res) { const float4 r = res[e]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+        const float4 r = RES ? res[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 o = make_float4(v.x * sc.x + sh.x + r.x, v.y * sc.y + sh.y + r.y, v.z * sc.z + sh.z + r.z, v.w * sc.w + sh.w + r.w);
         if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         y[e] = o;
     }
 }
 
 // partial[block][2c] = sum g' | sum g' * xhat,   g' = gy masked by the ReLU (recomputed from x, res)
+template <bool RES>
 __global__ __launch_bounds__(PB) void k_bn_bwd_reduce(long n, int c, const float *__restrict__ gy, const float *__restrict__ x,
                                                       const float *__restrict__ res, const float *__restrict__ scale,
                                                       const float *__restrict__ shift, const float *__restrict__ mean,
@@ -86,8 +89,7 @@ __global__ __launch_bounds__(PB) void k_bn_bwd_reduce(long n, int c, const float
         for (long r = (long)blockIdx.x * rpb + tr; r < n; r += (long)gridDim.x * rpb) {
             const float4 g4 = *reinterpret_cast<const float4 *>(gy + r * c + tc * 4);
             const float4 x4 = *reinterpret_cast<const float4 *>(x + r * c + tc * 4);
-            float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (res) r4 = *reinterpret_cast<const float4 *>(res + r * c + tc * 4);
+            const float4 r4 = RES ? *reinterpret_cast<const float4 *>(res + r * c + tc * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             const float g[4] = {g4.x, g4.y, g4.z, g4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(PB) void k_bn_bwd_reduce(long n, int c, const float
 }
 
 // gx = scale * (g' - sums[ch]/n - xhat * sums[c+ch]/n) ; gres = g'
+template <bool RES>
 __global__ __launch_bounds__(PB) void k_bn_bwd_apply(long n4, int c4, const float4 *__restrict__ gy, const float4 *__restrict__ x,
                                                      const float4 *__restrict__ res, const float4 *__restrict__ scale,
                                                      const float4 *__restrict__ shift, const float4 *__restrict__ mean,
@@ -123,8 +126,7 @@ __global__ __launch_bounds__(PB) void k_bn_bwd_apply(long n4, int c4, const floa
         const int cc = (int)(e % c4);
         const float4 g4 = gy[e], x4 = x[e], sc = scale[cc], sh = shift[cc], mu = mean[cc], rs = rstd[cc];
         const float4 s1 = sums[cc], s2 = sums[c4 + cc];
-        float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (res) r4 = res[e];
+        const float4 r4 = RES ? res[e] : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 gm, o;
 #define PW_ONE(f)                                                                     \
         {                                                                             \
@@ -141,6 +143,7 @@ __global__ __launch_bounds__(PB) void k_bn_bwd_apply(long n4, int c4, const floa
 }
 
 // eval-mode backward: gx = scale * g' (running statistics are constants)
+template <bool RES>
 __global__ __launch_bounds__(PB) void k_bn_bwd_eval(long n4, int c4, const float4 *__restrict__ gy, const float4 *__restrict__ x,
                                                     const float4 *__restrict__ res, const float4 *__restrict__ scale,
                                                     const float4 *__restrict__ shift, int relu, float4 *__restrict__ gx,
@@ -148,8 +151,7 @@ __global__ __launch_bounds__(PB) void k_bn_bwd_eval(long n4, int c4, const float
     for (long e = (long)blockIdx.x * PB + threadIdx.x; e < n4; e += (long)gridDim.x * PB) {
         const int cc = (int)(e % c4);
         const float4 g4 = gy[e], x4 = x[e], sc = scale[cc], sh = shift[cc];
-        float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (res) r4 = res[e];
+        const float4 r4 = RES ? res[e] : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 gm;
         gm.x = (!relu || x4.x * sc.x + sh.x + r4.x > 0.f) ? g4.x : 0.f;
         gm.y = (!relu || x4.y * sc.y + sh.y + r4.y > 0.f) ? g4.y : 0.f;
@@ -200,7 +202,7 @@ extern "C" int pdf_bn_act_forward(long n, int c, const float *x, const float *re
         fl::launch_bn_eval(c, gamma, beta, eps, running_mean, running_var, scale, shift, mean, rstd, s);
     }
     const long n4 = n * (c / 4);
-    pw::k_bn_apply<<<pw::grid_elems(n4), pw::PB, 0, s>>>(n4, c / 4, reinterpret_cast<const float4 *>(x),
+    (res ? pw::k_bn_apply<true> : pw::k_bn_apply<false>)<<<pw::grid_elems(n4), pw::PB, 0, s>>>(n4, c / 4, reinterpret_cast<const float4 *>(x),
                                                         reinterpret_cast<const float4 *>(scale), reinterpret_cast<const float4 *>(shift),
                                                         reinterpret_cast<const float4 *>(res), relu, reinterpret_cast<float4 *>(y));
     return pdf_launch_status();
@@ -220,17 +222,17 @@ static int bn_act_backward(long n, int c, const float *gy, const float *x, const
     if (presummed > 0) {
         fl::launch_colsum(partial, presummed, 2 * c, sums, s);
     } else {
-        pw::k_bn_bwd_reduce<<<g, pw::PB, pw::PB * 8 * sizeof(float), s>>>(n, c, gy, x, res, scale, shift, mean, rstd, relu, partial,
+        (res ? pw::k_bn_bwd_reduce<true> : pw::k_bn_bwd_reduce<false>)<<<g, pw::PB, pw::PB * 8 * sizeof(float), s>>>(n, c, gy, x, res, scale, shift, mean, rstd, relu, partial,
                                                                           sums_zeroed ? sums : nullptr);
         if (!sums_zeroed) fl::launch_colsum(partial, g, 2 * c, sums, s);
     }
 #define F4(p) reinterpret_cast<const float4 *>(p)
     if (training)
-        pw::k_bn_bwd_apply<<<pw::grid_elems(n4), pw::PB, 0, s>>>(n4, c / 4, F4(gy), F4(x), F4(res), F4(scale), F4(shift), F4(mean), F4(rstd),
+        (res ? pw::k_bn_bwd_apply<true> : pw::k_bn_bwd_apply<false>)<<<pw::grid_elems(n4), pw::PB, 0, s>>>(n4, c / 4, F4(gy), F4(x), F4(res), F4(scale), F4(shift), F4(mean), F4(rstd),
                                                                 F4(sums), (float)(1.0 / (double)n), relu, reinterpret_cast<float4 *>(gx),
                                                                 reinterpret_cast<float4 *>(gres));
     else
-        pw::k_bn_bwd_eval<<<pw::grid_elems(n4), pw::PB, 0, s>>>(n4, c / 4, F4(gy), F4(x), F4(res), F4(scale), F4(shift), relu,
+        (res ? pw::k_bn_bwd_eval<true> : pw::k_bn_bwd_eval<false>)<<<pw::grid_elems(n4), pw::PB, 0, s>>>(n4, c / 4, F4(gy), F4(x), F4(res), F4(scale), F4(shift), relu,
                                                                reinterpret_cast<float4 *>(gx), reinterpret_cast<float4 *>(gres));
 #undef F4
     return pdf_launch_status();
@@ -267,7 +269,7 @@ extern "C" int pdf_bn_apply(long n, int c, const float *x, const float *res, con
     if (n < 1 || !x || !coef || !y) return PDF_ERR_BAD_ARG;
     if (!pdf_bn_supported(c)) return PDF_ERR_UNSUPPORTED;
     const long n4 = n * (c / 4);
-    pw::k_bn_apply<<<pw::grid_elems(n4), pw::PB, 0, static_cast<hipStream_t>(stream)>>>(
+    (res ? pw::k_bn_apply<true> : pw::k_bn_apply<false>)<<<pw::grid_elems(n4), pw::PB, 0, static_cast<hipStream_t>(stream)>>>(
         n4, c / 4, reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(coef), reinterpret_cast<const float4 *>(coef + c),
         reinterpret_cast<const float4 *>(res), relu, reinterpret_cast<float4 *>(y));
     return pdf_launch_status();
@@ -301,7 +303,7 @@ extern "C" int pdf_bn_bwd_sums(long n, int c, const float *gy, const float *x, c
     if (!pdf_bn_supported(c)) return PDF_ERR_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int g = pw::grid_rows(n, c);
-    pw::k_bn_bwd_reduce<<<g, pw::PB, pw::PB * 8 * sizeof(float), s>>>(n, c, gy, x, nullptr, coef, coef + c, coef + 2 * c, coef + 3 * c, relu, partial,
+    pw::k_bn_bwd_reduce<false><<<g, pw::PB, pw::PB * 8 * sizeof(float), s>>>(n, c, gy, x, nullptr, coef, coef + c, coef + 2 * c, coef + 3 * c, relu, partial,
                                                                       nullptr);
     fl::launch_colsum(partial, g, 2 * c, sums, s);
     return pdf_launch_status();

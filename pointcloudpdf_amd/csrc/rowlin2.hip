@@ -108,6 +108,20 @@ __global__ __launch_bounds__(256) void k_fwd(FwdArgs a) {
         }
         __syncthreads();
     }
+    // Prologue coefficients of the wide shapes (K > 64) in LDS: read next to the row loads without a trip to L2.
+    __shared__ float pco[PRE && !COEF_REGS ? 2 : 1][PRE && !COEF_REGS ? K : 1];
+    if (PRE && !COEF_REGS) {
+        for (int t = threadIdx.x; t < K; t += 256) { pco[0][t] = a.scale[t]; pco[PRE && !COEF_REGS ? 1 : 0][t] = a.shift[t]; }
+        __syncthreads();
+    }
+    const float relu_lo = a.relu ? 0.f : -INFINITY;   // max(x, lo): no branch between the loads of a trip
+    // Row loads of a tile are issued XB at a time ahead of the products that consume them.  Left to the compiler the K = 128 .. 512 shapes
+    // compile to load -> s_waitcnt -> 8 products per 16 reduction indices (the weight fragments fill the register file): 16-48 dependent
+    // trips to L2 per tile, which is what a level-4 / level-5 launch (one tile per wave) consists of.  XB is what the registers allow
+    // next to the weights: the three-input K = 256 kernel holds 192 of them (VGPRs + AGPRs <= 256 keeps two waves per SIMD).
+    // (with statistics and several column blocks per wave the accumulators of the sums take the room of half a batch)
+    constexpr int XB0 = NJ < 16 ? NJ : 16;
+    constexpr int XB = (K == 256 && NIN == 3) ? 4 : ((ST != 0 && NOB > 1 && NIN * NOB * NJ * 4 >= 128) ? ((PRE && K == 128) ? 2 : XB0 / 2) : XB0);
     const long ntiles = (a.N + 15) / 16;
     for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long)gridDim.x * 4) {
         const long n = tile * 16 + li;
@@ -117,25 +131,30 @@ __global__ __launch_bounds__(256) void k_fwd(FwdArgs a) {
         for (int ob = 0; ob < NOB; ++ob) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int in = 0; in < NIN; ++in) {
-            const float *xr = a.X[in] + (valid ? n : 0) * a.ldx + 4 * kq;
+            const float *xr = a.X[in] + (valid ? n : 0) * a.ldx + 4 * kq;   // (rows past the end read row 0: a column of the product depends on its own row only)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                f32x4 x4 = *reinterpret_cast<const f32x4 *>(xr + 16 * j);
-                if (PRE) {
-                    const f32x4 sc = COEF_REGS ? sc4[COEF_REGS ? j : 0] : *reinterpret_cast<const f32x4 *>(a.scale + 16 * j + 4 * kq);
-                    const f32x4 sh = COEF_REGS ? sh4[COEF_REGS ? j : 0] : *reinterpret_cast<const f32x4 *>(a.shift + 16 * j + 4 * kq);
-                    x4 = x4 * sc + sh;
-                    if (a.relu) {
+            for (int j0 = 0; j0 < NJ; j0 += XB) {
+                f32x4 xb[XB];
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) x4[c] = fmaxf(x4[c], 0.f);
+                for (int t = 0; t < XB; ++t) xb[t] = *reinterpret_cast<const f32x4 *>(xr + 16 * (j0 + t));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < XB; ++t) {
+                    const int j = j0 + t;
+                    f32x4 x4 = xb[t];
+                    if (PRE) {
+                        const f32x4 sc = COEF_REGS ? sc4[COEF_REGS ? j : 0] : *reinterpret_cast<const f32x4 *>(&pco[0][16 * j + 4 * kq]);
+                        const f32x4 sh = COEF_REGS ? sh4[COEF_REGS ? j : 0] : *reinterpret_cast<const f32x4 *>(&pco[PRE && !COEF_REGS ? 1 : 0][16 * j + 4 * kq]);
+                        x4 = x4 * sc + sh;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) x4[c] = fmaxf(x4[c], relu_lo);
                     }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int ob = 0; ob < NOB; ++ob)
+                            acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wr[in][ob][j][c], x4[c], acc[ob], 0, 0, 0);
                 }
-                if (!valid) x4 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int ob = 0; ob < NOB; ++ob)
-                        acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wr[in][ob][j][c], x4[c], acc[ob], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -198,7 +217,7 @@ template <int VW> struct Vec;
 template <> struct Vec<2> { typedef float type __attribute__((ext_vector_type(2))); };
 template <> struct Vec<4> { typedef float type __attribute__((ext_vector_type(4))); };
 
-template <int VW, bool PRE>
+template <int VW, bool PRE, bool RW>   // RW: per-row weight of G (a.roww)
 __global__ __launch_bounds__(256) void k_wg(WArgs a) {
     typedef typename Vec<VW>::type vec;
     constexpr int B = 16 * VW;   // block edge of dW
@@ -214,6 +233,7 @@ __global__ __launch_bounds__(256) void k_wg(WArgs a) {
         sc = *reinterpret_cast<const vec *>(a.scale + kb + VW * li);
         sh = *reinterpret_cast<const vec *>(a.shift + kb + VW * li);
     }
+    const float relu_lo = a.relu ? 0.f : -INFINITY;
     f32x4 acc[VW][VW];
     float gsum[VW];
 #pragma unroll
@@ -225,26 +245,33 @@ __global__ __launch_bounds__(256) void k_wg(WArgs a) {
     const long rb = (long)blockIdx.x * a.rows_per_block;
     const long re = rb + a.rows_per_block < a.N ? rb + a.rows_per_block : a.N;
     for (long r0 = rb + 16 * wave; r0 < re; r0 += 64) {
+        // the eight (twelve) loads of a trip first, nothing conditional between them: with the row weight behind `if (a.roww)` and the
+        // ReLU behind `if (a.relu)` the trip compiled to four dependent (g, x) round trips (k_wg<4, true>: 22.7 -> 17.7 us, <4, false>:
+        // 14.9 -> 12.2 us per launch over a step).  (Issuing the next trip's loads ahead of this trip's products: the compiler merges the
+        // two trips into one of 16 loads, 208 + 88 registers, one wave per SIMD.)
         vec gv[4], xv[4];
+        float rw[RW ? 4 : 1];
+        bool ok[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const long n = r0 + 4 * t + nq;
-            const bool ok = n < re;
-            const long nn = ok ? n : rb;
+            ok[t] = n < re;
+            const long nn = ok[t] ? n : rb;
             gv[t] = *reinterpret_cast<const vec *>(G + nn * a.ldg + ob + VW * li);
-            if (a.roww) gv[t] *= a.roww[nn * a.rws];
             xv[t] = *reinterpret_cast<const vec *>(a.X + nn * a.ldx + kb + VW * li);
+            if (RW) rw[RW ? t : 0] = a.roww[nn * a.rws];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (RW) gv[t] *= rw[RW ? t : 0];
             if (PRE) {
                 xv[t] = xv[t] * sc + sh;
-                if (a.relu) {
 #pragma unroll
-                    for (int c = 0; c < VW; ++c) xv[t][c] = fmaxf(xv[t][c], 0.f);
-                }
+                for (int c = 0; c < VW; ++c) xv[t][c] = fmaxf(xv[t][c], relu_lo);
             }
-            if (!ok) {
 #pragma unroll
-                for (int c = 0; c < VW; ++c) { gv[t][c] = 0.f; xv[t][c] = 0.f; }
-            }
+            for (int c = 0; c < VW; ++c) { gv[t][c] = ok[t] ? gv[t][c] : 0.f; xv[t][c] = ok[t] ? xv[t][c] : 0.f; }
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -376,8 +403,11 @@ int try_wgrad(long n, int k, int o, int ng, const float *const *g, long ldg, con
     if (split < 1) split = 1;
     a.rows_per_block = ((n + split - 1) / split + 63) / 64 * 64;
     const dim3 grid((unsigned)((n + a.rows_per_block - 1) / a.rows_per_block), (unsigned)((o / b) * (k / b)), (unsigned)ng);
-    if (vw == 4) { if (scale) k_wg<4, true><<<grid, 256, 0, s>>>(a); else k_wg<4, false><<<grid, 256, 0, s>>>(a); }
-    else         { if (scale) k_wg<2, true><<<grid, 256, 0, s>>>(a); else k_wg<2, false><<<grid, 256, 0, s>>>(a); }
+#define PDF_WG(VW_) do { \
+        if (roww) { if (scale) k_wg<VW_, true, true><<<grid, 256, 0, s>>>(a); else k_wg<VW_, false, true><<<grid, 256, 0, s>>>(a); } \
+        else      { if (scale) k_wg<VW_, true, false><<<grid, 256, 0, s>>>(a); else k_wg<VW_, false, false><<<grid, 256, 0, s>>>(a); } } while (0)
+    if (vw == 4) PDF_WG(4); else PDF_WG(2);
+#undef PDF_WG
     return 1;
 }
 
