@@ -515,6 +515,7 @@ def main():
             "loss": loss,
             "geometry_prefetch_group": (st_ahead if strat else D),
             "host_enqueue_ms_per_step": sched.enqueue_s / args.steps * 1e3,   # < ms_per_step: the host runs ahead, the device is the bound
+            "hbm_peak_gib": torch.cuda.max_memory_allocated(dev) / 2.0 ** 30,   # (caching-allocator peak of this rank over the whole run)
             "prepass_submit_host_ms": (1e3 * min(sched.submit_host_s)) if sched.submit_host_s else None,   # host time of one group submission (warm)
             "kernels": ks,
             "roofline": roof,
