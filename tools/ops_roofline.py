@@ -5,6 +5,7 @@ torch's current stream over `--iters` back-to-back calls.
 
     python tools/ops_roofline.py [--iters 20] [--json gpurun_out/ops_roofline.json]
 """
+import os
 import argparse, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -88,6 +89,10 @@ def run(iters=20, only="", verbose=False, level2=True, references=True):
         go = torch.randn(n, k, c, device=dev, generator=g)
         add(f"grouping2 bwd {tag}", gb, lambda: be.grouping_backward(go, idx, n))
         add(f"grouping(with_xyz) fwd {tag}", gb + 12 * n + 12 * n + 12 * n * k, lambda: be.group_forward(feat, L.p, L.p, idx, True))
+        if os.environ.get("PDFOPS_ROOFLINE_EXTRA"):   # the same op visiting the query points in index order (a plain copy of the table carries no order)
+            idx_plain = idx.clone()
+            add(f"grouping(with_xyz) fwd {tag} [index order]", gb + 12 * n + 12 * n + 12 * n * k, lambda: be.group_forward(feat, L.p, L.p, idx_plain, True))
+            add(f"grouping2 fwd {tag} [index order]", gb, lambda: be.grouping_forward(feat, idx_plain))
         gox = torch.randn(n, k, c + 3, device=dev, generator=g)
         add(f"grouping(with_xyz) bwd {tag}", 4 * n * k * (c + 3) + 4 * n * k + 4 * n * c, lambda: be.group_backward(gox, idx, n, c, True))
         # subtraction fwd: 8Nc + 4Nk + 4Nkc ; bwd: 4Nkc + 4Nk + 8Nc
