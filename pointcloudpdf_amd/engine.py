@@ -180,7 +180,8 @@ class FusedSGD:
 
     @torch.no_grad()
     def step(self):
-        have = tuple(i for i, p in enumerate(self.params) if p.grad is not None)
+        all_grads = [p.grad for p in self.params]   # (one attribute read per parameter and step: 304 of them)
+        have = tuple(i for i, g in enumerate(all_grads) if g is not None)
         if not have:
             return
         from . import _native
@@ -190,8 +191,9 @@ class FusedSGD:
         host, ev = self._ring[self._n % self.RING]
         self._n += 1
         ev.synchronize()   # (the copy that last used this slot has run)
-        grads = [self.params[i].grad for i in have]
-        grads = [g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous() for g in grads]   # (alive until queued)
+        grads = all_grads if len(have) == len(all_grads) else [all_grads[i] for i in have]
+        f32 = torch.float32
+        grads = [g if (g.dtype is f32 and g.is_contiguous()) else g.float().contiguous() for g in grads]   # (alive until queued)
         rows = host.numpy()[:len(have)]
         rows[:] = static
         rows[:, 1] = [g.data_ptr() for g in grads]
