@@ -200,7 +200,7 @@ class FusedSGD:
         self._tab[:len(have)].copy_(host[:len(have)], non_blocking=True)
         ev.record()
         rc = self.be.lib.pdf_sgd_step(nchunks, self._tab.data_ptr(), chunks.data_ptr(), self.lr, self.momentum, self.weight_decay,
-                                      self.ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                      self.ctypes.c_void_p(_native.raw_stream()))
         if rc != 0:
             raise RuntimeError(f"pdf_sgd_step failed with status {rc}")
 

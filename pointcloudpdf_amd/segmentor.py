@@ -44,7 +44,7 @@ class _FusedCE(torch.autograd.Function):
         grad = torch.empty_like(pred)
         acc = torch.empty((3,), dtype=torch.float32, device=pred.device)   # [sum, count, mean]
         _native.require_current_device(pred, target)
-        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        s = ctypes.c_void_p(_native.raw_stream())
         rc = be.lib.pdf_ce_forward(n, c, pred.data_ptr(), target.data_ptr(), ignore, grad.data_ptr(), acc.data_ptr(), acc.data_ptr() + 8, s)
         if rc != 0:
             raise RuntimeError(f"pdf_ce_forward failed with status {rc}")
@@ -62,7 +62,7 @@ class _FusedCE(torch.autograd.Function):
         gy = gy.contiguous().float()
         out = torch.empty_like(dlogits)   # the saved buffer stays untouched: the node may be differentiated again (retain_graph)
         _native.require_current_device(dlogits, gy)
-        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        s = ctypes.c_void_p(_native.raw_stream())
         rc = _native.hip_backend().lib.pdf_ce_backward(n, c, dlogits.data_ptr(), acc.data_ptr(), gy.data_ptr(), out.data_ptr(), s)
         if rc != 0:
             raise RuntimeError(f"pdf_ce_backward failed with status {rc}")
