@@ -77,7 +77,8 @@ class PdfOpsError(RuntimeError):
     pass
 
 
-_RAW_STREAM = None if os.environ.get("PDFOPS_RAW_STREAM", "1") == "0" else getattr(torch._C, "_cuda_getCurrentRawStream", None)
+# opt-in (PDFOPS_RAW_STREAM=1): see DESIGN section 6 -- one StratifiedTransformer gradient comparison failed once in a full-suite run with it on
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None) if os.environ.get("PDFOPS_RAW_STREAM", "0") == "1" else None
 
 
 def raw_stream():
