@@ -66,7 +66,7 @@ extern "C" int pdf_block_pre_forward(long n, int c, void *const *p, int training
 
 // p[]: x, z1, coef1, W1, Wq, Wk, Wv, gxq, gxk, gxv                                  (inputs)
 //      gx, grads [dW1 (c*c) | dbeta1 (c) | dgamma1 (c) | {dW (c*c), db (c)} x q,k,v]   (outputs; grads zeroed here)
-//      dy (n*c), partial (pdf_bn_partial_floats(n, c))                                    (scratch; p[14] unused)
+//      dy (n*c), partial (max(pdf_bn_partial_floats(n, c), pdf_rowlin_partial_floats(n, c)): the dgrad epilogue's rows)   (scratch; p[14] unused)
 static bool dgrad_bstats() {   // PDFOPS_DGRAD_BSTATS=0: BatchNorm-backward sums from their own pass instead of the dgrad epilogue (A/B)
     static const bool on = [] { const char *v = getenv("PDFOPS_DGRAD_BSTATS"); return !(v && v[0] == '0'); }();
     return on;
@@ -129,7 +129,7 @@ extern "C" int pdf_block_post_forward(long n, int c, void *const *p, int trainin
 
 // p[]: gy, t, x, z3, coef2, coef3, W3                                               (inputs)
 //      gt, gres, grads [dW3 (c*c) | dbeta2 | dgamma2 | dbeta3 | dgamma3]             (outputs; grads zeroed here)
-//      da (n*c), partial                                                              (scratch; p[12] unused)
+//      da (n*c), partial (max(pdf_bn_partial_floats(n, c), pdf_rowlin_partial_floats(n, c)))   (scratch; p[12] unused)
 static int block_post_backward(long n, int c, void *const *p, int training, int grads_zeroed, void *stream, const Fork *fk = nullptr) {
     if (n < 1 || !p) return PDF_ERR_BAD_ARG;
     const float *gy = (const float *)p[0], *t = (const float *)p[1], *x = (const float *)p[2], *z3 = (const float *)p[3];
@@ -199,7 +199,7 @@ extern "C" int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p
 //            [30 | 31 | 32 must be laid out contiguously in this order: 30 and 31 are zeroed with one memset]
 //            31 grads of the post half (pdf_block_post_backward layout) 32 layer sums (pdf_pt_layer_bwd_sums_floats(c))
 //   scratch: 33 gt 34 da / dy 35 gxq 36 gxk 37 gxv (n*c each) 38 G2 (n*nsample*c/8) 39 G3 (n*nsample*3)
-//            40 partial (max of pdf_bn_partial_floats, pdf_pt_layer_bwd_partial_floats)
+//            40 partial (max of pdf_bn_partial_floats, pdf_rowlin_partial_floats, pdf_pt_layer_bwd_partial_floats)
 //            41 Wsm (n*nsample*c/8) 42 GR (n*nsample*c) | inverse kNN table: 43 inv_off (n+1) 44 inv_entry, entry_base
 //            45 dy (n*c; separate from 34: the forked dW3 kernel may still be reading `da` when the pre half starts)
 //   optional: 46 aux stream, 47 fork event, 48 join event (all three or none: weight gradients on the second stream, see Fork)

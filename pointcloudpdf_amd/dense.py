@@ -338,7 +338,8 @@ class _BlockPre(torch.autograd.Function):
         cc = c * c
         e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=x.device)
         gx, grads, dy, sums = e(n, c), e(cc + 2 * c + 3 * (cc + c)), e(n, c), e(2 * c)
-        partial = e(int(be.lib.pdf_bn_partial_floats(n, c)))
+        # pdf_rowlin_dgrad_bstats writes pdf_rowlin_partial_rows rows of 2c floats here, the BatchNorm passes pdf_bn_partial_floats
+        partial = e(max(int(be.lib.pdf_bn_partial_floats(n, c)), int(be.lib.pdf_rowlin_partial_floats(n, c))))
         be.block_call("pre_backward", n, c, [x, z1, coef1, W1, Wq, Wk, Wv, gxq.contiguous(), gxk.contiguous(), gxv.contiguous(),
                                              gx, grads, dy, partial, sums], ctx.training)
         o = cc + 2 * c
@@ -376,7 +377,7 @@ class _BlockPost(torch.autograd.Function):
         cc = c * c
         e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=t.device)
         gt, gres, grads, da, sums = e(n, c), e(n, c), e(cc + 4 * c), e(n, c), e(2 * c)
-        partial = e(int(be.lib.pdf_bn_partial_floats(n, c)))
+        partial = e(max(int(be.lib.pdf_bn_partial_floats(n, c)), int(be.lib.pdf_rowlin_partial_floats(n, c))))
         be.block_call("post_backward", n, c, [gy.contiguous(), t, x, z3, coef2, coef3, W3, gt, gres, grads, da, partial, sums],
                       ctx.training)
         # buffer: dW3 | dbeta2 | dgamma2 | dbeta3 | dgamma3 ; forward args: t, x, g2, b2, W3, g3, b3
@@ -457,7 +458,7 @@ class _BottleneckFn(torch.autograd.Function):
         from . import _native
         inv_off, inv_entry, entry_base = _native.inverse_table(idx, n)   # cached on idx by the geometry pre-pass
         ssz = [nc, nc, nc, n * k * cs, n * k * 3,
-               max(int(lib.pdf_bn_partial_floats(n, c)), int(lib.pdf_pt_layer_bwd_partial_floats(n, k, c))),
+               max(int(lib.pdf_bn_partial_floats(n, c)), int(lib.pdf_rowlin_partial_floats(n, c)), int(lib.pdf_pt_layer_bwd_partial_floats(n, k, c))),
                nc, nc, n * k * cs, n * k * c, nc]   # gt da gxq G2 G3 partial | gxk gxv Wsm GR | dy
         soff, tot = [], 0
         for sz in ssz:

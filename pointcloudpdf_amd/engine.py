@@ -136,12 +136,17 @@ class FlatGradAllReduce:
         torch._foreach_copy_([g for _, g in have], [v for v, _ in have])
 
 
-class FusedSGD:
+class FusedSGD(torch.optim.Optimizer):
     """``torch.optim.SGD(params, lr, momentum, weight_decay)`` (dampening 0, no Nesterov: what the reference's configs build,
-    pointcept/utils/optimizer.py) as ONE HIP launch per step over all parameter tensors (csrc/optim.hip).  torch's fused multi-tensor
-    SGD needs 13 launches / 275 us for this model's 304 tensors; this is one launch / ~30 us.  Same arithmetic per element
-    (``g + wd p``, ``momentum buf + g'``, ``p - lr buf``; the first step's ``buf = g'`` is the zero-initialised buffer's update).
-    Parameters without a gradient are skipped, as torch does."""
+    pointcept/utils/optimizer.py) as ONE HIP launch per parameter group and step over all of the group's tensors (csrc/optim.hip).
+    torch's fused multi-tensor SGD needs 13 launches / 275 us for this model's 304 tensors; this is one launch / ~30 us.  Same
+    arithmetic per element (``g + wd p``, ``momentum buf + g'``, ``p - lr buf``; the first step's ``buf = g'`` is the zero-initialised
+    buffer's update).  Parameters without a gradient are skipped, as torch does.
+
+    A ``torch.optim.Optimizer``: ``param_groups`` (``lr`` / ``momentum`` / ``weight_decay`` are read from the group at every step, so
+    torch's LR schedulers attach to it -- the reference steps its scheduler every iteration, engines/train.py:366), ``state_dict`` /
+    ``load_state_dict`` with torch.optim.SGD's own layout (``state[p]["momentum_buffer"]``: checkpoints move both ways).  Parameter and
+    momentum pointers are read at every step (``model.to()``, ``load_state_dict`` may move them)."""
 
     RING = 8   # pinned pointer tables in flight (the host may run several steps ahead of the device)
 
@@ -151,58 +156,81 @@ class FusedSGD:
 
         self.be = _native.hip_backend()
         self.ctypes = ctypes
-        self.params = [p for p in params if p.requires_grad]
-        assert self.params and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in self.params)
-        self.lr, self.momentum, self.weight_decay = float(lr), float(momentum), float(weight_decay)
-        self.device = self.params[0].device
-        self.state = [torch.zeros_like(p) for p in self.params]   # momentum buffers
+        super().__init__(params, dict(lr=float(lr), momentum=float(momentum), weight_decay=float(weight_decay)))
+        for group in self.param_groups:
+            group["params"] = [p for p in group["params"] if p.requires_grad]
+        every = [p for group in self.param_groups for p in group["params"]]
+        assert every and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in every)
+        self.device = every[0].device
+        for p in every:
+            self.state[p]["momentum_buffer"] = torch.zeros_like(p)
         self.chunk = int(self.be.lib.pdf_sgd_chunk())
-        self._plans = {}      # tuple of parameter indices with a gradient -> (chunk list on the device, number of chunks)
-        self._ring = [(torch.empty((len(self.params), 4), dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(self.RING)]
-        self._tab = torch.empty((len(self.params), 4), dtype=torch.int64, device=self.device)
+        self._plans = {}      # (group, tuple of parameter indices with a gradient) -> (chunk list on the device, number of chunks, lengths)
+        rows = max(len(g["params"]) for g in self.param_groups)
+        self._ring = [(torch.empty((rows, 4), dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(self.RING)]
+        self._tabs = [torch.empty((rows, 4), dtype=torch.int64, device=self.device) for _ in range(self.RING)]
         self._n = 0
 
-    def zero_grad(self, set_to_none=True):
-        for p in self.params:
-            if set_to_none:
-                p.grad = None
-            elif p.grad is not None:
-                p.grad.zero_()
+    @property
+    def params(self):
+        return [p for group in self.param_groups for p in group["params"]]
 
-    def _plan(self, have):
-        if have not in self._plans:
+    def _plan(self, gi, have, params):
+        key = (gi, have)
+        if key not in self._plans:
             import numpy as np
 
-            pairs = [(row, c) for row, i in enumerate(have) for c in range((self.params[i].numel() + self.chunk - 1) // self.chunk)]
-            static = np.array([[self.params[i].data_ptr(), 0, self.state[i].data_ptr(), self.params[i].numel()] for i in have], dtype=np.int64)
-            self._plans[have] = (torch.tensor(pairs, dtype=torch.int32, device=self.device).contiguous(), len(pairs), static)
-        return self._plans[have]
+            pairs = [(row, c) for row, i in enumerate(have) for c in range((params[i].numel() + self.chunk - 1) // self.chunk)]
+            lengths = np.array([params[i].numel() for i in have], dtype=np.int64)
+            self._plans[key] = (torch.tensor(pairs, dtype=torch.int32, device=self.device).contiguous(), len(pairs), lengths)
+        return self._plans[key]
 
     @torch.no_grad()
-    def step(self):
-        all_grads = [p.grad for p in self.params]   # (one attribute read per parameter and step: 304 of them)
-        have = tuple(i for i, g in enumerate(all_grads) if g is not None)
-        if not have:
-            return
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
         from . import _native
 
-        _native.require_current_device(self._tab)   # (launches go onto the current device's current stream)
-        chunks, nchunks, static = self._plan(have)
-        host, ev = self._ring[self._n % self.RING]
-        self._n += 1
-        ev.synchronize()   # (the copy that last used this slot has run)
-        grads = all_grads if len(have) == len(all_grads) else [all_grads[i] for i in have]
         f32 = torch.float32
-        grads = [g if (g.dtype is f32 and g.is_contiguous()) else g.float().contiguous() for g in grads]   # (alive until queued)
-        rows = host.numpy()[:len(have)]
-        rows[:] = static
-        rows[:, 1] = [g.data_ptr() for g in grads]
-        self._tab[:len(have)].copy_(host[:len(have)], non_blocking=True)
-        ev.record()
-        rc = self.be.lib.pdf_sgd_step(nchunks, self._tab.data_ptr(), chunks.data_ptr(), self.lr, self.momentum, self.weight_decay,
-                                      self.ctypes.c_void_p(_native.raw_stream()))
-        if rc != 0:
-            raise RuntimeError(f"pdf_sgd_step failed with status {rc}")
+        for gi, group in enumerate(self.param_groups):
+            params = group["params"]
+            all_grads = [p.grad for p in params]   # (one attribute read per parameter and step: 304 of them)
+            have = tuple(i for i, g in enumerate(all_grads) if g is not None)
+            if not have:
+                continue
+            _native.require_current_device(self._tabs[0])   # (launches go onto the current device's current stream)
+            chunks, nchunks, lengths = self._plan(gi, have, params)
+            slot = self._n % self.RING
+            host, ev = self._ring[slot]
+            tab = self._tabs[slot]
+            self._n += 1
+            ev.synchronize()   # (the copy AND the launch that last used this slot have run)
+            full = len(have) == len(all_grads)
+            grads = all_grads if full else [all_grads[i] for i in have]
+            grads = [g if (g.dtype is f32 and g.is_contiguous()) else g.float().contiguous() for g in grads]   # (alive until queued)
+            ps = params if full else [params[i] for i in have]
+            state = self.state
+            bufs = []
+            for q in ps:
+                st = state[q]
+                buf = st.get("momentum_buffer")
+                if buf is None or buf.shape != q.shape or buf.device != q.device or buf.dtype is not f32 or not buf.is_contiguous():
+                    buf = st["momentum_buffer"] = torch.zeros_like(q) if buf is None else buf.to(q.device, f32).reshape(q.shape).contiguous()
+                bufs.append(buf)
+            rows = host.numpy()[:len(have)]
+            rows[:, 0] = [q.data_ptr() for q in ps]
+            rows[:, 1] = [g.data_ptr() for g in grads]
+            rows[:, 2] = [b.data_ptr() for b in bufs]
+            rows[:, 3] = lengths
+            tab[:len(have)].copy_(host[:len(have)], non_blocking=True)
+            rc = self.be.lib.pdf_sgd_step(nchunks, tab.data_ptr(), chunks.data_ptr(), float(group["lr"]), float(group["momentum"]),
+                                          float(group["weight_decay"]), self.ctypes.c_void_p(_native.raw_stream()))
+            ev.record()
+            if rc != 0:
+                raise RuntimeError(f"pdf_sgd_step failed with status {rc}")
+        return loss
 
 
 def shard_scene_ids(num_scenes, rank, world_size):

@@ -73,12 +73,18 @@ class OpenSegEvaluator:
         pred = seg_logits.max(1)[1]
         i, u, t = intersection_and_union(pred, segment_oracle, self.num_classes, self.ignore_index)
         h = torch.stack([i, u, t]).double()
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        if multi:
             torch.distributed.all_reduce(h)
         self.hist = h if self.hist is None else self.hist + h
-        a, r = aupr_and_auroc(score, segment_oracle, self.unknown_label, self.ignore_index)
-        if a is not None:
-            self.aupr.append(a); self.auroc.append(r)
+        pairs = [aupr_and_auroc(score, segment_oracle, self.unknown_label, self.ignore_index)]
+        if multi:   # every rank's pair of this batch, None included, as `recognition_metric` gathers them (hooks/evaluator.py:199-221)
+            gathered = [None] * torch.distributed.get_world_size()
+            torch.distributed.all_gather_object(gathered, pairs[0])
+            pairs = gathered
+        for a, r in pairs:
+            if a is not None:
+                self.aupr.append(a); self.auroc.append(r)
         if loss is not None:
             self.losses.append(float(loss))
 

@@ -388,6 +388,18 @@ class Geometry:
         out = [lv.p for lv in self.levels] + [lv.o for lv in self.levels]
         for v in self._memo.values():
             out += [t for t in (v if isinstance(v, tuple) else (v,)) if isinstance(t, torch.Tensor)]
+        # tensors that live ONLY as attachments of an index tensor (the batch's coordinate sums: `val.sum(0)` is a fresh allocation of
+        # the pre-pass stream; orders / inverse tables are normally memo entries too, listed again harmlessly): the consumer stream
+        # must record them as well, or the pre-pass stream's allocator may hand the block out while main-stream kernels still read it
+        for t in list(out):
+            for tag in (_native._MOM, _native._ORD, _native._INV):
+                att = getattr(t, tag, None)
+                if att is None:
+                    continue
+                for a in att[2:]:
+                    for u in (a if isinstance(a, tuple) else (a,)):
+                        if isinstance(u, torch.Tensor):
+                            out.append(u)
         return out
 
 

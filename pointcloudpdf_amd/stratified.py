@@ -332,9 +332,11 @@ class StratifiedPrefetcher:
         self.device = torch.cuda.current_device()
 
     def submit(self, batch):
+        # the geometry's constructor may enqueue conversions (coord.contiguous(), offset.int() for the int64 offsets of collate_fn) on
+        # the caller's stream: the event the side stream waits for is recorded AFTER them
+        geom = self.model.make_geometry(batch["coord"], batch["offset"], batch.get("offset_host"))
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream())   # the batch's tensors were produced on the caller's stream
-        geom = self.model.make_geometry(batch["coord"], batch["offset"], batch.get("offset_host"))
 
         def work():
             torch.cuda.set_device(self.device)

@@ -108,3 +108,46 @@ def test_bench_refuses_more_ranks_than_gpus():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and "--gpus 2 but only" in r.stderr and r.stdout.strip() == ""
+
+
+def _eval_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from pointcloudpdf_amd import evaluator
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ev = evaluator.OpenSegEvaluator(6, unknown_label=[4], ignore_index=-1)
+    for b in range(3):
+        g = torch.Generator().manual_seed(100 * b + rank)
+        logits = torch.randn(500, 6, generator=g)
+        score = torch.rand(500, generator=g)
+        seg = torch.randint(0, 6, (500,), generator=g)
+        if rank == 1 and b == 1:
+            seg[seg == 4] = 0   # this rank's batch holds no unknown point: its (None, None) pair is gathered and skipped
+        ev.update(logits, score, seg)
+    torch.save(ev.summary(), os.path.join(out_dir, f"eval_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_evaluator_gathers_every_ranks_recognition_metrics(tmp_path):
+    """engines/hooks/evaluator.py:199-221: every rank appends EVERY rank's (aupr, auroc) of a batch, so the summaries agree across
+    ranks and equal the one-process evaluation of all batches."""
+    from pointcloudpdf_amd import evaluator
+
+    world = 2
+    mp.spawn(_eval_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    s = [torch.load(tmp_path / f"eval_{r}.pt", weights_only=False) for r in range(world)]
+    one = evaluator.OpenSegEvaluator(6, unknown_label=[4], ignore_index=-1)
+    for b in range(3):
+        for rank in range(world):
+            g = torch.Generator().manual_seed(100 * b + rank)
+            logits, score, seg = torch.randn(500, 6, generator=g), torch.rand(500, generator=g), torch.randint(0, 6, (500,), generator=g)
+            if rank == 1 and b == 1:
+                seg[seg == 4] = 0
+            one.update(logits, score, seg)
+    ref = one.summary()
+    for key in ["mIoU", "mAcc", "allAcc", "aupr", "auroc"]:
+        assert s[0][key] == s[1][key], key
+        assert abs(s[0][key] - ref[key]) <= 1e-12, (key, s[0][key], ref[key])

@@ -331,6 +331,37 @@ def test_fused_sgd_matches_torch_sgd():
         oa.step(); ob.step()
     for x, y in zip(pa, pb):
         assert (x - y).abs().max() <= 1e-6 * (1 + y.abs().max()), (tuple(x.shape), float((x - y).abs().max()))
+    # a torch optimizer: LR schedulers attach (the reference steps its scheduler every iteration) and the state moves both ways
+    assert isinstance(oa, torch.optim.Optimizer) and oa.param_groups[0]["lr"] == 0.05
+    sa, sb = torch.optim.lr_scheduler.StepLR(oa, 1, 0.5), torch.optim.lr_scheduler.StepLR(ob, 1, 0.5)
+    pc = [torch.nn.Parameter(y.detach().clone()) for y in pb]
+    oc = engine.FusedSGD(pc, lr=123.0, momentum=0.0, weight_decay=0.0)
+    oc.load_state_dict(ob.state_dict())          # torch.optim.SGD's checkpoint: lr / momentum / weight decay and the momentum buffers
+    sc = torch.optim.lr_scheduler.StepLR(oc, 1, 0.5)
+    for it in range(3):
+        for x, y, z in zip(pa, pb, pc):
+            gr = torch.randn(x.shape, device="cuda", generator=g)
+            x.grad, y.grad, z.grad = gr.clone(), gr.clone(), gr.clone()
+        oa.step(); ob.step(); oc.step()
+        sa.step(); sb.step(); sc.step()
+    assert oa.param_groups[0]["lr"] == ob.param_groups[0]["lr"] == oc.param_groups[0]["lr"] == 0.05 / 8
+    for x, y, z in zip(pa, pb, pc):
+        assert (x - y).abs().max() <= 1e-6 * (1 + y.abs().max()), (tuple(x.shape), float((x - y).abs().max()))
+        assert (z - y).abs().max() <= 1e-6 * (1 + y.abs().max()), (tuple(x.shape), float((z - y).abs().max()))
+    ob2 = torch.optim.SGD(pb, lr=1.0, momentum=0.9)
+    ob2.load_state_dict(oa.state_dict())         # and back: FusedSGD's state in torch.optim.SGD
+    assert torch.equal(ob2.state[pb[2]]["momentum_buffer"], oa.state[pa[2]]["momentum_buffer"])
+    # moved parameters (model.to(), load_state_dict(assign=True)): pointers are read at every step
+    with torch.no_grad():
+        pa[2].data = pa[2].data.clone()
+    before = pa[2].detach().clone()
+    pa[2].grad = torch.ones_like(pa[2])
+    for k in range(len(pa)):
+        if k != 2:
+            pa[k].grad = None
+    oa.step()
+    torch.cuda.synchronize()
+    assert not torch.equal(pa[2].detach(), before)
 
 
 def test_geometry_branch_batchnorm_from_coordinate_sums():
@@ -380,3 +411,49 @@ def test_geometry_branch_batchnorm_from_coordinate_sums():
         if k.startswith("g_") and scale < 1e-4 * gscale:
             continue   # analytically-zero gradients (biases in front of a train-mode BatchNorm): rounding noise in both runs
         assert (a[k] - b[k]).abs().max().item() <= (2e-5 if (k == "y" or k.startswith("b_")) else 2e-3) * scale, (k, (a[k] - b[k]).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize("n,c", [(3648, 32), (8192, 32), (40000, 32), (9000, 64), (700, 256)])
+def test_block_halves_stay_inside_their_partial_buffer(n, c):
+    """The Bottleneck halves' own nodes (dense._BlockPre / _BlockPost: the path of a block whose attention layer is not fused) hand the
+    C calls a `partial` scratch sized max(pdf_bn_partial_floats, pdf_rowlin_partial_floats): the dgrad epilogue
+    (pdf_rowlin_dgrad_bstats) writes pdf_rowlin_partial_rows rows of 2c floats, more than the BatchNorm passes' rows at c = 32 and
+    n < 65536 (round-2 advisor finding: heap overrun).  Run both backward calls with a guard region behind `partial`."""
+    from pointcloudpdf_amd import _native
+
+    be = _native.hip_backend()
+    g = torch.Generator(device="cuda").manual_seed(n + c)
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    e = lambda *s: torch.empty(*s, device="cuda")
+    need = max(int(be.lib.pdf_bn_partial_floats(n, c)), int(be.lib.pdf_rowlin_partial_floats(n, c)))
+    GUARD, SENT = 1 << 16, 12345.0
+    cc = c * c
+    # pre half
+    x, W1, Wq, Wk, Wv = r(n, c), r(c, c) / c ** 0.5, r(c, c) / c ** 0.5, r(c, c) / c ** 0.5, r(c, c) / c ** 0.5
+    g1, b1, bq = torch.ones(c, device="cuda"), torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
+    rm, rv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+    z1, coef1, xq, xk, xv = e(n, c), e(4 * c), e(n, c), e(n, c), e(n, c)
+    part = torch.full((need + GUARD,), SENT, device="cuda")
+    be.block_call("pre_forward", n, c, [x, W1, g1, b1, rm, rv, Wq, bq, Wk, bq, Wv, bq, z1, coef1, xq, xk, xv, part], True, 1e-5, 0.1)
+    torch.cuda.synchronize()
+    assert bool((part[need:] == SENT).all()), "pre_forward wrote behind its partial buffer"
+    gx, grads, dy, sums = e(n, c), e(cc + 2 * c + 3 * (cc + c)), e(n, c), e(2 * c)
+    part.fill_(SENT)
+    be.block_call("pre_backward", n, c, [x, z1, coef1, W1, Wq, Wk, Wv, r(n, c), r(n, c), r(n, c), gx, grads, dy, part, sums], True)
+    torch.cuda.synchronize()
+    assert bool((part[need:] == SENT).all()), "pre_backward wrote behind its partial buffer"
+    assert bool(torch.isfinite(gx).all()) and bool(torch.isfinite(grads).all())
+    # post half
+    t, W3 = r(n, c), r(c, c) / c ** 0.5
+    rm2, rv2, rm3, rv3 = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda"), torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+    coef2, z3, coef3, y = e(4 * c), e(n, c), e(4 * c), e(n, c)
+    part.fill_(SENT)
+    be.block_call("post_forward", n, c, [t, x, g1, b1, rm2, rv2, W3, g1, b1, rm3, rv3, coef2, z3, coef3, y, part], True, 1e-5, 0.1)
+    torch.cuda.synchronize()
+    assert bool((part[need:] == SENT).all()), "post_forward wrote behind its partial buffer"
+    gt, gres, grads2, da = e(n, c), e(n, c), e(cc + 4 * c), e(n, c)
+    part.fill_(SENT)
+    be.block_call("post_backward", n, c, [r(n, c), t, x, z3, coef2, coef3, W3, gt, gres, grads2, da, part, sums], True)
+    torch.cuda.synchronize()
+    assert bool((part[need:] == SENT).all()), "post_backward wrote behind its partial buffer"
+    assert bool(torch.isfinite(gt).all()) and bool(torch.isfinite(grads2).all())
