@@ -37,6 +37,10 @@ extern "C" {
 /* version / build probe (no GPU needed) */
 int pdf_abi_version(void);
 const char *pdf_build_info(void);
+/* Arithmetic of the squared distance in this library's geometry kernels (kNN, ball query, FPS): 0 = the reference's expression as
+ * written in IEEE fp32 (libpdfops.so), 1 = fmaf(dz,dz,fmaf(dy,dy,dx*dx)), 2 = fmaf(dz,dz,fmaf(dx,dx,dy*dy)) (libpdfops_fma{1,2}.so:
+ * the contractions an `nvcc -O2` build of knn_query_cuda_kernel.cu:92 / sampling_cuda_kernel.cu:54 may compute; csrc/pdfops_common.h). */
+int pdf_dist_fma_mode(void);
 
 /* replaces knn_query_cuda_launcher, libs/pointops/src/knn_query/knn_query_cuda_kernel.h:13
  * (kernel knn_query_cuda_kernel.cu:60-104).  idx (m,nsample), dist2 (m,nsample) = SQUARED distances. */

@@ -35,6 +35,8 @@ class OracleBackend(CBackend):
         lib.oracle_opt_n_threads.argtypes = [ctypes.c_int]
         lib.oracle_num_threads.restype = ctypes.c_int
         lib.oracle_set_num_threads.argtypes = [ctypes.c_int]
+        lib.oracle_set_dist_mode.argtypes = [ctypes.c_int]
+        lib.oracle_get_dist_mode.restype = ctypes.c_int
 
     def opt_n_threads(self, n):
         return int(self.lib.oracle_opt_n_threads(int(n)))
@@ -44,6 +46,13 @@ class OracleBackend(CBackend):
 
     def set_num_threads(self, n):
         self.lib.oracle_set_num_threads(int(n))
+
+    def set_dist_mode(self, mode):
+        """0 = the distance expression as written (default), 1 / 2 = the two FMA contractions (pdfops_oracle.c: oracle_sqdist3).
+        Returns the previous mode."""
+        prev = int(self.lib.oracle_get_dist_mode())
+        self.lib.oracle_set_dist_mode(int(mode))
+        return prev
 
 
 _backend = None

@@ -17,7 +17,9 @@
  *     tests/golden/make_golden.py imports the reference's own Python files on top of this
  *     library and commits the outputs as fixtures.
  *
- * Arithmetic: IEEE fp32, as written, no FMA contraction (compile with -ffp-contract=off).
+ * Arithmetic: IEEE fp32, as written, no FMA contraction (compile with -ffp-contract=off); the squared distances of
+ * kNN / ball query / FPS additionally exist as two explicit FMA chains (oracle_set_dist_mode) that bound what an
+ * `nvcc -O2` build of the reference (fmad on) may compute instead.
  * Every function cites the reference file:line (paths relative to /root/reference/) it follows.
  */
 #include <math.h>
@@ -53,6 +55,26 @@ void oracle_set_num_threads(int n)
 #else
     (void)n;
 #endif
+}
+
+/* Squared distance of kNN / ball query / FPS from the coordinate differences (knn_query_cuda_kernel.cu:92,
+ * ball_query_cuda_kernel.cu:95, sampling_cuda_kernel.cu:54: `(a-x)*(a-x) + (b-y)*(b-y) + (c-z)*(c-z)`).
+ *   mode 0 (default): as written, every product and sum rounded (this file is compiled with -ffp-contract=off).
+ *   mode 1: fmaf(dz, dz, fmaf(dy, dy, dx*dx))  -- left-to-right contraction.
+ *   mode 2: fmaf(dz, dz, fmaf(dx, dx, dy*dy))  -- the contraction LLVM (clang 22) and GCC 11 emit for this expression under
+ *           -ffp-contract=fast; nvcc -O2 (fmad on by default, libs/pointops/setup.py:29) is LLVM-based and most likely emits it too.
+ * No NVIDIA toolchain exists here, so WHICH of the three an upstream build runs cannot be observed; tests/test_oracle_fma.py counts
+ * how many kNN rows / FPS picks differ between them and the HIP library has a matching build for each
+ * (PDFOPS_DIST_FMA). fmaf() is the correctly rounded fused operation whatever the host ISA. */
+static int g_dist_mode = 0;
+void oracle_set_dist_mode(int mode) { g_dist_mode = mode; }
+int oracle_get_dist_mode(void) { return g_dist_mode; }
+
+static inline float oracle_sqdist3(float dx, float dy, float dz)
+{
+    if (g_dist_mode == 1) return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    if (g_dist_mode == 2) return fmaf(dz, dz, fmaf(dx, dx, dy * dy));
+    return dx * dx + dy * dy + dz * dz;
 }
 
 /* ------------------------------------------------------------------ kNN */
@@ -113,7 +135,7 @@ int oracle_knn_query(int m, int nsample, const float *xyz, const float *new_xyz,
             float x = xyz[(size_t)i * 3 + 0];
             float y = xyz[(size_t)i * 3 + 1];
             float z = xyz[(size_t)i * 3 + 2];
-            float d2 = (new_x - x) * (new_x - x) + (new_y - y) * (new_y - y) + (new_z - z) * (new_z - z);
+            float d2 = oracle_sqdist3(new_x - x, new_y - y, new_z - z);
             if (d2 < best_dist[0]) {
                 best_dist[0] = d2;
                 best_idx[0] = i;
@@ -153,7 +175,7 @@ int oracle_ball_query(int m, int nsample, float min_radius, float max_radius, co
         int candi_num = 0;
         for (int i = start; i < end && candi_num < ORACLE_BQ_CAP; i++) {
             float x = xyz[i * 3 + 0], y = xyz[i * 3 + 1], z = xyz[i * 3 + 2];
-            float d2 = (new_x - x) * (new_x - x) + (new_y - y) * (new_y - y) + (new_z - z) * (new_z - z);
+            float d2 = oracle_sqdist3(new_x - x, new_y - y, new_z - z);
             if (d2 <= 1e-5 || (d2 >= min_radius2 && d2 < max_radius2)) { /* 1e-5 is a double literal upstream too */
                 candi_dist[candi_num] = d2;
                 candi_idx[candi_num] = i;
@@ -196,7 +218,7 @@ int oracle_random_ball_query(int m, int nsample, float min_radius, float max_rad
         int cnt = 0;
         for (int i = start; i < end; i++) {
             float x = xyz[order[i] * 3 + 0], y = xyz[order[i] * 3 + 1], z = xyz[order[i] * 3 + 2];
-            float d2 = (new_x - x) * (new_x - x) + (new_y - y) * (new_y - y) + (new_z - z) * (new_z - z);
+            float d2 = oracle_sqdist3(new_x - x, new_y - y, new_z - z);
             if (d2 <= 1e-5 || (d2 >= min_radius2 && d2 < max_radius2)) {
                 od[cnt] = d2;
                 oi[cnt] = order[i];
@@ -244,7 +266,7 @@ int oracle_farthest_point_sampling(int b, int n, const float *xyz, const int *of
                 float x2 = xyz[(size_t)k * 3 + 0];
                 float y2 = xyz[(size_t)k * 3 + 1];
                 float z2 = xyz[(size_t)k * 3 + 2];
-                float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+                float d = oracle_sqdist3(x2 - x1, y2 - y1, z2 - z1);
                 float d2 = d < tmp[k] ? d : tmp[k]; /* min(d, tmp[k]) */
                 tmp[k] = d2;
                 if (d2 > dists[tid]) { dists_i[tid] = k; dists[tid] = d2; }

@@ -13,7 +13,19 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpdfops.so")
+# PDFOPS_DIST_FMA=1|2: the library whose geometry kernels (kNN, ball query, FPS) evaluate the squared distance as an explicit FMA
+# chain -- the arithmetic an `nvcc -O2` build of libs/pointops most likely runs (csrc/pdfops_common.h: pdf_sqdist3).
+# Default: the as-written IEEE fp32 expression.
+DIST_FMA = int(os.environ.get("PDFOPS_DIST_FMA", "0") or 0)
+if DIST_FMA not in (0, 1, 2):
+    raise RuntimeError(f"PDFOPS_DIST_FMA={DIST_FMA}: expected 0 (as written), 1 or 2 (csrc/pdfops_common.h)")
+
+
+def library_path(dist_fma=0):
+    return os.path.join(_HERE, "lib", "libpdfops.so" if not dist_fma else f"libpdfops_fma{int(dist_fma)}.so")
+
+
+LIB_PATH = library_path(DIST_FMA)
 
 c_int = ctypes.c_int
 c_long = ctypes.c_long

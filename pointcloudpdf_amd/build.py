@@ -46,8 +46,18 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=False):
-    """Compile every csrc/*.hip for gfx950 and link libpdfops.so. Returns the library path."""
+# The geometry TUs again with the squared distance as an explicit FMA chain (csrc/pdfops_common.h: pdf_sqdist3): libpdfops_fma1.so /
+# libpdfops_fma2.so = the same library with those five objects swapped.  `PDFOPS_DIST_FMA=1|2` at import selects them (_native.py).
+GEOMETRY_TUS = ["knn_query.hip", "knn_grid.hip", "sampling.hip", "sampling_bucketed.hip", "ball_query.hip"]
+FMA_VARIANTS = (1, 2)
+
+
+def variant_path(variant):
+    return LIBPATH if not variant else os.path.join(LIBDIR, f"libpdfops_fma{int(variant)}.so")
+
+
+def build_library(force=False, verbose=False, variants=FMA_VARIANTS):
+    """Compile every csrc/*.hip for gfx950 and link libpdfops.so (+ the FMA-distance variants). Returns the default library's path."""
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
@@ -72,11 +82,25 @@ def build_library(force=False, verbose=False):
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
         return r
 
+    vobjs = {}
+    for v in variants:
+        vdir = os.path.join(OBJDIR, f"fma{v}")
+        os.makedirs(vdir, exist_ok=True)
+        vobjs[v] = list(objs)
+        for src in GEOMETRY_TUS:
+            sp = os.path.join(CSRC, src)
+            op = os.path.join(vdir, src.replace(".hip", ".o"))
+            vobjs[v][srcs.index(src)] = op
+            if force or _stale(op, [sp] + headers):
+                jobs.append([hipcc] + COMMON + EXTRA.get(src, []) + [f"-DPDF_DIST_FMA={v}", "-c", sp, "-o", op])
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if force or jobs or _stale(LIBPATH, objs):
         run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}"] + objs + ["-o", LIBPATH])
+    for v in variants:
+        if force or jobs or _stale(variant_path(v), vobjs[v]):
+            run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}"] + vobjs[v] + ["-o", variant_path(v)])
     return LIBPATH
 
 

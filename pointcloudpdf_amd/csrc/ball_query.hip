@@ -69,7 +69,7 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(int m, int ns
         float d2 = 0.f;
         if (i < end) {
             const float x = xyz[3 * (size_t)i + 0], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
-            d2 = (qx - x) * (qx - x) + (qy - y) * (qy - y) + (qz - z) * (qz - z);
+            d2 = pdf_sqdist3(qx - x, qy - y, qz - z);
             ok = in_shell(d2, min_r2, max_r2);
         }
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(ok);
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void random_ball_query_kernel(int m,
         if (i < end) {
             j = order[i];
             const float x = xyz[3 * (size_t)j + 0], y = xyz[3 * (size_t)j + 1], z = xyz[3 * (size_t)j + 2];
-            d2 = (qx - x) * (qx - x) + (qy - y) * (qy - y) + (qz - z) * (qz - z);
+            d2 = pdf_sqdist3(qx - x, qy - y, qz - z);
             ok = in_shell(d2, min_r2, max_r2);
         }
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(ok);

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(PB) void k_grid_query(int m, int b, const float *__
                         const unsigned p0 = cs[c], p1 = cs[c + 1];
                         for (unsigned p = p0; p < p1; ++p) {
                             const float4 v = sorted[p];
-                            const float d = (qx - v.x) * (qx - v.x) + (qy - v.y) * (qy - v.y) + (qz - v.z) * (qz - v.z);
+                            const float d = pdf_sqdist3(qx - v.x, qy - v.y, qz - v.z);
                             insert<KP1>(bd, bi, d, __float_as_int(v.w));
                         }
                     }
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64 * RQ_WAVES) void k_grid_radius_self(int n, int b
                 if (p < end) {
                     const float4 v = sorted[p];
                     id = __float_as_int(v.w);
-                    d2 = (qx - v.x) * (qx - v.x) + (qy - v.y) * (qy - v.y) + (qz - v.z) * (qz - v.z);
+                    d2 = pdf_sqdist3(qx - v.x, qy - v.y, qz - v.z);
                     ok = d2 <= 1e-5f || d2 < r2;
                 }
                 const unsigned long long mask = __builtin_amdgcn_ballot_w64(ok);
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(64 * RQ_WAVES) void k_grid_radius_self(int n, int b
             float d2 = 0.f;
             if (i < g.start + g.n) {
                 const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
-                d2 = (qx - x) * (qx - x) + (qy - y) * (qy - y) + (qz - z) * (qz - z);
+                d2 = pdf_sqdist3(qx - x, qy - y, qz - z);
                 ok = d2 <= 1e-5f || d2 < r2;
             }
             const unsigned long long mask = __builtin_amdgcn_ballot_w64(ok);

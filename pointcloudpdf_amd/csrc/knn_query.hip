@@ -88,7 +88,7 @@ __global__ __launch_bounds__(BLOCK) void knn_scan_kernel(int m, int k, const flo
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const float x = p[3 * u + 0], y = p[3 * u + 1], z = p[3 * u + 2];
-                d[u] = (qx - x) * (qx - x) + (qy - y) * (qy - y) + (qz - z) * (qz - z);
+                d[u] = pdf_sqdist3(qx - x, qy - y, qz - z);
             }
             const float m0 = fminf(fminf(d[0], d[1]), d[2]);
             const float m1 = fminf(fminf(d[3], d[4]), d[5]);
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(BLOCK) void knn_scan_kernel(int m, int k, const flo
         for (; i < end; ++i) {
             const float *__restrict__ p = xyz + 3 * (size_t)i;
             const float x = p[0], y = p[1], z = p[2];
-            const float d = (qx - x) * (qx - x) + (qy - y) * (qy - y) + (qz - z) * (qz - z);
+            const float d = pdf_sqdist3(qx - x, qy - y, qz - z);
             if (d < thr) {
                 heap_sift_root<BLOCK>(hd, hi, tid, k, d, i);
                 thr = hd[tid];
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(64) void knn_redo_wave_kernel(int m, int k, const f
             float d = 3.0e38f;
             if (i < end) {
                 const float x = xyz[3 * (size_t)i + 0], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
-                d = (qx - x) * (qx - x) + (qy - y) * (qy - y) + (qz - z) * (qz - z);
+                d = pdf_sqdist3(qx - x, qy - y, qz - z);
             }
             unsigned long long mask = __builtin_amdgcn_ballot_w64(i < end && d < thr);
             while (mask) {
@@ -232,3 +232,6 @@ extern "C" int pdf_knn_query(int m, int nsample, const float *xyz, const float *
                              const int *new_offset, int b, int *idx, float *dist2, void *stream) {
     return pdf_knn_query_list(m, nsample, xyz, new_xyz, offset, new_offset, b, idx, dist2, nullptr, nullptr, stream);
 }
+
+// which squared-distance arithmetic the geometry TUs of this library were compiled with (pdfops_common.h: pdf_sqdist3)
+extern "C" int pdf_dist_fma_mode(void) { return PDF_DIST_FMA; }

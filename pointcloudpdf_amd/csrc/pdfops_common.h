@@ -44,6 +44,30 @@ __device__ __forceinline__ float pdf_wave_sum_f32(float v) {
     return v;
 }
 
+// Squared distance of the geometry kernels (kNN, ball query, FPS) from the three coordinate differences.
+//   PDF_DIST_FMA undefined / 0 : the reference's expression as written in IEEE fp32 -- dx*dx + dy*dy + dz*dz, every product and sum rounded
+//                                (knn_query_cuda_kernel.cu:92, sampling_cuda_kernel.cu:54, ball_query_cuda_kernel.cu:95); the TUs that use it
+//                                are compiled with -ffp-contract=off.  The default: the one variant every toolchain reproduces.
+//   PDF_DIST_FMA == 1          : fmaf(dz, dz, fmaf(dy, dy, dx*dx))  -- left-to-right contraction of the same expression.
+//   PDF_DIST_FMA == 2          : fmaf(dz, dz, fmaf(dx, dx, dy*dy))  -- what LLVM's and GCC's contraction emit for it (first product of
+//                                `a*a + b*b` fused, second kept: clang 22 / gcc 11 -ffp-contract=fast here); nvcc -O2 (fmad on,
+//                                libs/pointops/setup.py:29) is LLVM-based and most likely emits this form.
+// The variants exist so that a user validating against an NVIDIA build of libs/pointops has a bit-matching mode (libpdfops_fma{1,2}.so,
+// selected with PDFOPS_DIST_FMA at import).  Every variant is monotone in |dx|, |dy|, |dz| (each rounding is), which
+// is all the pruning arguments of the grid kNN and the bucketed FPS need.
+#ifndef PDF_DIST_FMA
+#define PDF_DIST_FMA 0
+#endif
+__host__ __device__ __forceinline__ float pdf_sqdist3(float dx, float dy, float dz) {
+#if PDF_DIST_FMA == 1
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+#elif PDF_DIST_FMA == 2
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
+#else
+    return dx * dx + dy * dy + dz * dz;
+#endif
+}
+
 // Monotone map float -> uint32 (total order incl. negatives), used to pack (value, key) pairs.
 __device__ __forceinline__ unsigned pdf_f32_ordered(float f) {
     unsigned u = __float_as_uint(f);

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(FPS_BS) void fps_plain_kernel(const float *__restri
             const float x2 = xyz[3 * (size_t)k + 0];
             const float y2 = xyz[3 * (size_t)k + 1];
             const float z2 = xyz[3 * (size_t)k + 2];
-            const float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+            const float d = pdf_sqdist3(x2 - x1, y2 - y1, z2 - z1);
             const float t = first ? 1e10f : tmp[k];  // reference pre-fills tmp with 1e10 (sampling.py:19)
             const float d2 = fminf(d, t);
             tmp[k] = d2;

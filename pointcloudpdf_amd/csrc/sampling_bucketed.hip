@@ -89,7 +89,7 @@ __device__ inline unsigned keybits(int rel, int bs_ref_log2) {
 }
 
 __device__ inline float dist_as_written(float x2, float y2, float z2, float x1, float y1, float z1) {
-    return (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+    return pdf_sqdist3(x2 - x1, y2 - y1, z2 - z1);
 }
 
 // ---------------------------------------------------------------- preparation kernels
@@ -276,7 +276,7 @@ __device__ inline float box_dist(const Rec &r, int i, float cx, float cy, float 
     const float gx = fmaxf(fmaxf(r.lox[i] - cx, cx - r.hix[i]), 0.f);
     const float gy = fmaxf(fmaxf(r.loy[i] - cy, cy - r.hiy[i]), 0.f);
     const float gz = fmaxf(fmaxf(r.loz[i] - cz, cz - r.hiz[i]), 0.f);
-    return gx * gx + gy * gy + gz * gz;
+    return pdf_sqdist3(gx, gy, gz);
 }
 
 // wave64 unsigned max through DPP (no LDS round trips): row_shr 1/2/4/8 fold each 16-lane row into its last lane,
@@ -520,7 +520,7 @@ __device__ __forceinline__ float box_dist_v(float lox, float loy, float loz, flo
     const float gx = fmaxf(fmaxf(lox - cx, cx - hix), 0.f);
     const float gy = fmaxf(fmaxf(loy - cy, cy - hiy), 0.f);
     const float gz = fmaxf(fmaxf(loz - cz, cz - hiz), 0.f);
-    return gx * gx + gy * gy + gz * gz;
+    return pdf_sqdist3(gx, gy, gz);
 }
 __device__ __forceinline__ bool key_gt(unsigned ah, unsigned al, unsigned bh, unsigned bl) { return ah > bh || (ah == bh && al > bl); }
 

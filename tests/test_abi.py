@@ -71,3 +71,15 @@ def test_code_object_targets_gfx950():
 
     data = open(build.LIBPATH, "rb").read()
     assert b"gfx950" in data
+
+
+def test_fma_distance_variants_are_built_and_complete(lib):
+    """libpdfops_fma1.so / libpdfops_fma2.so (PDFOPS_DIST_FMA=1|2): same exports, geometry TUs compiled with the FMA chains."""
+    from pointcloudpdf_amd import _native, build
+
+    assert lib.pdf_dist_fma_mode() == 0
+    for v in build.FMA_VARIANTS:
+        assert _native.library_path(v) == build.variant_path(v)
+        vlib = ctypes.CDLL(build.variant_path(v))
+        assert vlib.pdf_dist_fma_mode() == v
+        assert not [s for s in declared_symbols() if not hasattr(vlib, s)]
