@@ -95,11 +95,18 @@ def parse():
     ap.add_argument("--prefetch", type=int, default=16,
                     help="geometry pre-pass group: the pre-pass of the NEXT `prefetch` batches runs as one launch sequence on a side "
                          "stream while the current group trains (0 = inline, serial)")
+    ap.add_argument("--graph", choices=["auto", "0", "1"], default="auto",
+                    help="1 = forward + backward of the step replayed as ONE captured hipGraph (engine.CapturedStep: batch tensors and the "
+                         "batch's geometry tables staged into fixed-address buffers by one copy launch per step); the optimizer, the "
+                         "gradient exchange and the geometry pre-pass stay eager.  Needs identical scene sizes in every batch (what "
+                         "SphereCrop(point_max) gives the reference's trainer): auto = on unless --jitter / --amp / --pseudo-label / "
+                         "--throttle / --ddp torch / the stratified workload ask for something the capture does not cover")
     ap.add_argument("--ddp", choices=["flat", "torch"], default="flat",
                     help="gradient exchange for N > 1: one flat-buffer all-reduce after the backward (engine.FlatGradAllReduce) or "
                          "torch DistributedDataParallel (per-parameter bucket copies: +3 ms per step, measured)")
     ap.add_argument("--no-latency-sweep", action="store_true",
                     help="skip the look-ahead sweep (serial step time with --prefetch 0 and groups of 1 / 2 / 3 batches; rank 0, N = 1)")
+    ap.add_argument("--no-affinity", action="store_true", help="N > 1: do not pin each rank to its own contiguous share of the host's cores")
     ap.add_argument("--no-n1-reference", action="store_true",
                     help="N > 1 started without torchrun: do not time the one-rank run that efficiency_vs_n1 is quoted against")
     return ap.parse_args()
@@ -232,23 +239,41 @@ def cpu_baseline(points):
     from pointcloudpdf_amd import _native, engine, synthetic
 
     be = oracle.backend()
-    # threads actually used: capped -- on a 256-core host, 256-way OpenMP/ATen threading of these small per-op loops
-    # is slower than 16 threads by two orders of magnitude (measured: 410 s vs seconds for the same sample)
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
-    be.set_num_threads(cores)
-    prev = _native._set_backend_for_testing(be)
-    try:
-        step = engine.OpenSegStep()
-        synthetic.fill_parameters_deterministic(step, seed=1)
-        step.train()
-        batch = synthetic.make_batch([points], first_scene_id=900)
-        t0 = time.perf_counter()
-        out = step(batch)
-        out["loss"].backward()
-        dt = time.perf_counter() - t0
-    finally:
-        _native._set_backend_for_testing(prev)
+    host = os.cpu_count() or 1
+
+    def run_once(sizes, oracle_threads, torch_threads):
+        """One training step (fwd + bwd) of the same host code on the CPU oracle -> seconds."""
+        torch.set_num_threads(torch_threads)
+        be.set_num_threads(oracle_threads)
+        prev = _native._set_backend_for_testing(be)
+        try:
+            step = engine.OpenSegStep()
+            synthetic.fill_parameters_deterministic(step, seed=1)
+            step.train()
+            batch = synthetic.make_batch(sizes, first_scene_id=900)
+            t0 = time.perf_counter()
+            out = step(batch)
+            out["loss"].backward()
+            return time.perf_counter() - t0, batch
+        finally:
+            _native._set_backend_for_testing(prev)
+
+    # (a) round 1 / 2's setting: 16 threads for both the oracle's OpenMP loops and ATen, one 100k-point scene;
+    # (b) the oracle's kNN / FPS / gather loops on ALL host cores (they scale: one query / one scene per iteration), ATen's intra-op
+    #     threads kept at 16 (256-way threading of its small per-op loops is slower by two orders of magnitude: 410 s measured), on the
+    #     headline batch itself (2 scenes).  `value` is the better of the two: the baseline must not be held back by a thread choice.
+    cores_a = min(host, 16)
+    dt_a, batch = run_once([points], cores_a, cores_a)
+    runs = [dict(points_per_s=points / dt_a, seconds=dt_a, scenes=1, oracle_threads=cores_a, torch_threads=cores_a)]
+    if host > cores_a:
+        try:
+            dt_b, _ = run_once([points, points], host, cores_a)
+            runs.append(dict(points_per_s=2 * points / dt_b, seconds=dt_b, scenes=2, oracle_threads=host, torch_threads=cores_a))
+        except Exception as e:   # noqa: BLE001
+            runs.append(dict(error=f"{type(e).__name__}: {e}"))
+    best = max((r for r in runs if "points_per_s" in r), key=lambda r: r["points_per_s"])
+    dt, cores = best["seconds"], max(best["oracle_threads"], best["torch_threads"])
+    be.set_num_threads(host)
     # op level (SURVEY 8d "CPU baseline" i / iii): the oracle's kNN (OpenMP over queries) and torch.cdist + topk -- the stand-in for
     # torch-cluster's knn, which is absent on both boxes -- on a bounded sample: the first 20,000 queries of the scene, k = 8
     ops = {}
@@ -271,9 +296,30 @@ def cpu_baseline(points):
             cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
     except OSError:
         pass
-    return dict(value=points / dt, unit="points/s", cores=cores, kind="port", cpu_model=cpu_model, host_cores=os.cpu_count(), ops=ops,
-                sample=f"1 step (fwd+bwd) on 1 synthetic scene of {points} points, CPU oracle ops (brute-force kNN, "
-                       f"iterative FPS; quadratic in scene size) + torch-CPU layers, {dt:.1f} s wall")
+    return dict(value=best["points_per_s"], unit="points/s", cores=cores, kind="port", cpu_model=cpu_model, host_cores=os.cpu_count(), ops=ops,
+                runs=runs,
+                sample=f"1 step (fwd+bwd) on {best['scenes']} synthetic scene(s) of {points} points, CPU oracle ops (brute-force kNN, "
+                       f"iterative FPS; quadratic in scene size; OpenMP over {best['oracle_threads']} threads) + torch-CPU layers "
+                       f"({best['torch_threads']} threads), {dt:.1f} s wall; `runs` lists every thread setting tried")
+
+
+def pin_rank_to_cores(args):
+    """One contiguous share of the host's cores per rank (LOCAL_RANK-th of LOCAL_WORLD_SIZE shares of this process's affinity mask): N
+    Python ranks that each issue ~1,000 launches per step otherwise migrate across the sockets of the host and share cores with each
+    other's pre-pass threads.  Contiguous logical ids keep a rank on one socket / NUMA node of a two-socket EPYC host (the launcher of
+    the reference leaves placement to the OS: pointcept/engines/launch.py:74-131).  Returns the description put into the JSON line."""
+    world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    if args.no_affinity or world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    lr = int(os.environ.get("LOCAL_RANK", "0"))
+    cpus = sorted(os.sched_getaffinity(0))
+    share = len(cpus) // world
+    if share < 2:
+        return None
+    mine = cpus[lr * share:(lr + 1) * share]
+    os.sched_setaffinity(0, mine)
+    torch.set_num_threads(max(1, min(share, 16)))
+    return f"rank {lr}: cpus {mine[0]}-{mine[-1]} ({len(mine)} of {len(cpus)})"
 
 
 def main():
@@ -288,6 +334,7 @@ def main():
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    affinity = pin_rank_to_cores(args)
     rank, local_rank, world = engine.init_distributed()
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (the HIP path has no CPU fallback)"
     if world != args.gpus:
@@ -349,6 +396,15 @@ def main():
     # two side streams, alternating groups.  PDFOPS_PREPASS_THREAD=1 builds the pre-pass on a worker thread (measured: no gain -- the worker's
     # Python / dispatch work competes with the training thread for the interpreter: 17.7-18.6 vs 18.2-18.4 ms per step)
     prefetcher = GeometryPrefetcher(depth=2, threaded=bool(os.environ.get("PDFOPS_PREPASS_THREAD")))
+
+    graph_ok = (args.jitter <= 0 and not args.amp and not args.pseudo_label and not args.throttle and not strat
+                and not (use_dp and args.ddp == "torch") and args.storage == "f32")
+    if args.graph == "1" and not graph_ok:
+        raise SystemExit("bench.py: --graph 1 needs fixed scene sizes and the plain f32 PointTransformer step (see --help)")
+    captured = None
+    if args.graph == "1" or (args.graph == "auto" and graph_ok):
+        captured = engine.CapturedStep(step, pool[0])       # set-up (like building the model): eager warm-up passes + one capture
+        torch.cuda.synchronize()
 
     class Schedule:
         """Grouped geometry pre-pass for `warmup + steps` steps: the pre-pass of the next D batches runs as ONE launch sequence on a
@@ -414,10 +470,17 @@ def main():
                 st_tickets[i] = st_prefetcher.submit(batch)
             st_tickets[i + 1] = st_prefetcher.submit(pool[(i + 1) % len(pool)])   # next batch's tables: during this step
             data["st_geometry"] = st_prefetcher.get(st_tickets.pop(i))
-        opt.zero_grad(set_to_none=True)
-        with torch.autocast("cuda", dtype=torch.float16, enabled=args.amp):
-            out = module(data)
-        out["loss"].backward()
+        replay = captured is not None and not (timer.enabled and timer.sample) and captured.matches(batch)
+        if replay:   # forward + backward as one hipGraph launch; steps that carry the per-kernel HIP events run eagerly
+            if geom is None:   # --prefetch 0: the pre-pass (and its packing) inline on this stream
+                from pointcloudpdf_amd.geometry import Geometry
+                geom = Geometry(batch["coord"], batch["offset"], batch["offset_host"]).precompute()
+            out = captured(batch, geom)
+        else:
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.float16, enabled=args.amp):
+                out = module(data)
+            out["loss"].backward()
         if grad_sync is not None:
             grad_sync.sync(force=force_dp)   # ONE all-reduce (RCCL) over the flat gradient buffer
         opt.step()
@@ -513,6 +576,10 @@ def main():
             "rccl_ranks": world if (world > 1 and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl") else 0,
             "rank_ms_per_step": rank_ms,
             "loss": loss,
+            "execution": ("forward + backward replayed as one captured hipGraph (engine.CapturedStep; fixed scene sizes), optimizer / gradient "
+                          "exchange / geometry pre-pass eager; the steps that carry per-kernel HIP events run eagerly" if captured is not None
+                          else "eager (one Python-issued launch sequence per step)"),
+            "cpu_affinity": affinity,
             "geometry_prefetch_group": (st_ahead if strat else D),
             "host_enqueue_ms_per_step": sched.enqueue_s / args.steps * 1e3,   # < ms_per_step: the host runs ahead, the device is the bound
             "hbm_peak_gib": torch.cuda.max_memory_allocated(dev) / 2.0 ** 30,   # (caching-allocator peak of this rank over the whole run)
@@ -541,6 +608,31 @@ def main():
         for Dl, st, wu in ((0, 4, 1), (1, 6, 2), (2, 6, 2), (3, 6, 3)):
             dtl, _, _ = timed(Dl, wu, st)
             sweep["serial" if Dl == 0 else f"group_{Dl}"] = dtl / st * 1e3
+        if captured is not None:   # the same schedule with the step issued from Python (no graph)
+            keep, captured = captured, None
+            dtl, _, sch = timed(args.prefetch, 3, args.steps)
+            sweep["eager"] = dtl / args.steps * 1e3
+            line["eager_ms_per_step"] = sweep["eager"]
+            line["eager_host_enqueue_ms_per_step"] = sch.enqueue_s / args.steps * 1e3
+            captured = keep
+        # what the data-parallel gradient exchange adds per step, measured at world size 1 over RCCL (pack 609 gradients into the flat
+        # buffer, all-reduce 34 MB with itself, scale, unpack): the part of an N-GPU step that is not the ring itself
+        try:
+            if not torch.distributed.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+                torch.distributed.init_process_group("nccl", rank=0, world_size=1)
+            gs_keep, fd_keep = grad_sync, force_dp
+            grad_sync, force_dp = engine.FlatGradAllReduce(step), True
+            dta, _, _ = timed(args.prefetch, 3, args.steps)
+            grad_sync, force_dp = gs_keep, fd_keep
+            dtb, _, _ = timed(args.prefetch, 3, args.steps)
+            line["ddp_overhead_ms"] = (dta - dtb) / args.steps * 1e3
+            line["ddp_overhead_note"] = (f"{dta / args.steps * 1e3:.2f} ms per step with the flat exchange forced at world size 1 vs "
+                                         f"{dtb / args.steps * 1e3:.2f} ms without, same schedule, back to back")
+        except Exception as e:   # noqa: BLE001  (a report, never a reason to lose the line)
+            line["ddp_overhead_ms"] = None
+            line["ddp_overhead_note"] = f"{type(e).__name__}: {e}"
         line["serial_ms_per_step"] = sweep["serial"]
         line["lookahead_sweep_ms_per_step"] = sweep
 

@@ -221,9 +221,12 @@ int pdf_rowlin_partial_rows(long n, int k, int o);
 int pdf_rowlin_forward(long n, int k, int o, const float *x, long ldx, const float *w, int transpose_w,
                        const float *bias, const float *scale, const float *shift, int relu, float *y, long ldy,
                        int accumulate, float *partial, void *stream);
-/* dW (o,k) += G^T f(X), db (o) += column sums of G (pre-zeroed; db may be NULL) */
+/* dW (o,k) = G^T f(X), db (o) = column sums of G (db may be NULL): both WRITTEN.  No float atomics: every workgroup stores its
+ * partial block into a slab of ws (pdf_rowlin_wgrad_ws_floats(n, k, o, ng) floats, ng = 1 here), a second launch sums the slabs in a
+ * fixed order -- bit-reproducible gradients (the reference's atomicAdd scatters are not: grouping_cuda_kernel.cu:16-25). */
+long pdf_rowlin_wgrad_ws_floats(long n, int k, int o, int ng);
 int pdf_rowlin_wgrad(long n, int k, int o, const float *g, long ldg, const float *x, long ldx,
-                     const float *scale, const float *shift, int relu, float *dw, float *db, void *stream);
+                     const float *scale, const float *shift, int relu, float *dw, float *db, float *ws, void *stream);
 /* BatchNorm coefficients from column partials [rows][2c] (sum | sum of squares): coef = scale|shift|mean|rstd */
 int pdf_bn_coef_from_partial(const float *partial, int rows, long n, int c, const float *gamma, const float *beta,
                              float *running_mean, float *running_var, float eps, float momentum, float *coef, void *stream);
@@ -235,7 +238,7 @@ int pdf_rowlin_multi(long n, int k, int o, int nin, int nout, const float *const
                      int transpose_w, const float *const *bias, const float *scale, const float *shift, int relu,
                      float *const *y, long ldy, int accumulate, void *stream);
 int pdf_rowlin_wgrad_multi(long n, int k, int o, int ng, const float *const *g, long ldg, const float *x, long ldx,
-                           const float *scale, const float *shift, int relu, float *const *dw, float *const *db, void *stream);
+                           const float *scale, const float *shift, int relu, float *const *dw, float *const *db, float *ws, void *stream);
 /* Input gradient y = sum_i x[i] W[i] (nin <= 3; W (k, o) = the layers' own (out, in) weights) of Linear layers reading a
  * BatchNorm(+ReLU) output bx -> bn -> relu, with that BatchNorm's backward sums as the product's epilogue: partial
  * (pdf_rowlin_partial_floats(n, o)) receives *partial_rows rows of [sum g' | sum g' xhat]; pdf_bn_act_backward_presummed then
@@ -266,7 +269,7 @@ int pdf_linbn_backward(long n, int k, int o, void *const *p, int training, int r
 int pdf_rowlin_forward_roww(long n, int k, int o, const float *x, long ldx, const float *w, int transpose_w, float *y, long ldy,
                             int accumulate, const float *roww, long rws, void *stream);
 int pdf_rowlin_wgrad_roww(long n, int k, int o, const float *g, long ldg, const float *x, long ldx, float *dw, const float *roww,
-                          long rws, void *stream);
+                          long rws, float *ws, void *stream);
 int pdf_bn_bwd_sums(long n, int c, const float *gy, const float *x, const float *coef, int relu, float *partial, float *sums,
                     void *stream);
 
@@ -277,11 +280,13 @@ int pdf_bn_bwd_sums(long n, int c, const float *gy, const float *x, const float 
  * Pointer tables: csrc/transition_down.hip. */
 int pdf_td_supported(int nsample, int cin, int cout);
 int pdf_td_tables(long m, int b, const float *p_src, const float *p_new, const int *idx, const int *new_offset, float *rel4, float *Z,
-                  float *scene_sums, void *stream);   /* Z (n,32) and scene_sums (b,16) zeroed by the caller */
+                  float *scene_sums, long n, const int *inv_off, const int *inv_entry, int entry_base,
+                  void *stream);   /* Z (n,32) and scene_sums (b,16) zeroed by the caller; inv_* = the inverse of idx (or NULL: float atomics) */
 long pdf_td_gram_floats(int cin);
+long pdf_td_fwd_scratch_floats(long n, int cin);
 long pdf_td_bwd_scratch_floats(long m, int cin, int cout);
 int pdf_td_forward(long n, long m, int cin, int cout, void *const *p, int training, float eps, float momentum, void *stream);
-int pdf_td_backward(long n, long m, int cin, int cout, void *const *p, void *stream);
+int pdf_td_backward(long n, long m, int cin, int cout, void *const *p, int entry_base, void *stream);
 
 /* ---- scatter-adds as segmented gathers over an inverse neighbour table (csrc/seg_gather.hip; no reference counterpart: the reference
  * scatters with atomicAdd -- grouping_cuda_kernel.cu:20-25, interpolation_cuda_kernel.cu:27-33, subtraction_cuda_kernel.cu:24-30,
@@ -303,21 +308,26 @@ int pdf_seg_sum_weighted(long n, int c, int nsample, int w_c, const float *src, 
                          int entry_base, float *out, void *stream);
 
 /* Cross-entropy with an ignore label, mean over the counted rows (pointcept/models/losses/misc.py:14-39 as configured on
- * this path).  Forward: loss[0], acc = [sum, count], grad (n*c) = softmax - onehot (0 on ignored rows); a target that is neither
+ * this path).  Forward: loss[0], acc (pdf_ce_workspace_floats() floats; the first two = [sum, count], the rest per-workgroup partial
+ * sums added in a fixed order: no atomics, nothing to zero), grad (n*c) = softmax - onehot (0 on ignored rows); a target that is neither
  * `ignore` nor in [0, c) makes the loss NaN (torch raises a device-side assert there).  Backward: grad_out = dlogits * gy[0] /
  * count; dlogits (the forward's `grad`) is only read, so the node can be differentiated more than once; grad_out may alias it. */
+long pdf_ce_workspace_floats(void);
 int pdf_ce_forward(long n, int c, const float *logits, const long *target, long ignore, float *grad, float *acc, float *loss,
                    void *stream);
 int pdf_ce_backward(long n, int c, const float *dlogits, const float *acc, const float *gy, float *grad_out, void *stream);
 
 /* Per-scene sums of the relative coordinates rel = xyz[idx[i, j]] - xyz[i] of a SELF neighbour table (rows with idx < 0: rel = 0):
- * out (b, 9) double = [Sx Sy Sz | Mxx Mxy Mxz Myy Myz Mzz], pre-zeroed by the caller.  The train-mode BatchNorm after the layer's
+ * out (b, 9) double = [Sx Sy Sz | Mxx Mxy Mxz Myy Myz Mzz], WRITTEN (every workgroup lies inside one scene and stores its nine sums
+ * into its own slot of ws -- pdf_knn_rel_moments_ws_doubles(b, n) doubles --, a second launch adds a scene's slots in order: no
+ * atomics, bit-reproducible statistics).  The train-mode BatchNorm after the layer's
  * Linear(3, 3) (point_transformer_seg.py:27-29) is a closed form of these and the weights: pdf_pt_layer_forward_m takes the batch's sums
  * and skips its first statistics pass (csrc/geom_moments.hip). */
-int pdf_knn_rel_moments(int b, long n, int nsample, const float *xyz, const int *offset, const int *idx, double *out, void *stream);
+long pdf_knn_rel_moments_ws_doubles(int b, long m);
+int pdf_knn_rel_moments(int b, long n, int nsample, const float *xyz, const int *offset, const int *idx, double *out, double *ws, void *stream);
 /* the same for m queries new_xyz (scene ends new_offset) over other source points xyz: TransitionDown's grouping table */
 int pdf_knn_rel_moments_q(int b, long m, int nsample, const float *xyz, const float *new_xyz, const int *new_offset, const int *idx,
-                          double *out, void *stream);
+                          double *out, double *ws, void *stream);
 
 /* SGD with momentum and weight decay (torch.optim.SGD, dampening 0, no Nesterov -- the optimizer the reference's configs build,
  * pointcept/utils/optimizer.py + configs/s3dis/openseg-pt-v1-0-*.py) over every parameter tensor in ONE launch.  tab: ntensors records
@@ -391,6 +401,21 @@ int pdf_radius_neighbors_self(int n, int nsample, float radius, const float *xyz
 int pdf_segment_softmax_forward(int N, int M, int h, const int *index0_offsets, const float *x, float *y, void *stream);
 int pdf_segment_softmax_backward(int N, int M, int h, const int *index0_offsets, const float *y, const float *grad_y, float *grad_x,
                                  void *stream);
+
+/* Staging copy for hipGraph replay (pointcloudpdf_amd/engine.py: CapturedStep; no reference counterpart -- the reference issues its
+ * step from Python): nseg (src -> dst, nbytes) segments in ONE launch.  src_offset (device int32, may be NULL): element offset (4-byte
+ * units) added to src, read on the device; every 4-byte element has sub_const + *sub (device int32, may be NULL) subtracted. */
+#define PDF_COPY_MAX_SEGS 72
+typedef struct PdfCopySeg {
+    const void *src;
+    void *dst;
+    long nbytes;            /* multiple of 4 */
+    const int *src_offset;
+    const int *sub;
+    int sub_const;
+    int src_elems;          /* > 0: number of 4-byte elements of the array src points into (reads of a device-offset window are clamped) */
+} PdfCopySeg;
+int pdf_stage_copy(int nseg, const PdfCopySeg *segs, void *stream);
 
 #ifdef __cplusplus
 }

@@ -519,25 +519,39 @@ class HipBackend(CBackend):
             f.restype = c_int
             f.argtypes = [c_long, c_int, c_void_p, c_int, ctypes.c_float, ctypes.c_float, c_void_p]
         lib.pdf_td_tables.restype = c_int
-        lib.pdf_td_tables.argtypes = [c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        lib.pdf_td_tables.argtypes = [c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p,
+                                      c_int, c_void_p]
         lib.pdf_td_supported.restype = c_int
         lib.pdf_td_supported.argtypes = [c_int, c_int, c_int]
         lib.pdf_td_gram_floats.restype = c_long
         lib.pdf_td_gram_floats.argtypes = [c_int]
+        lib.pdf_td_fwd_scratch_floats.restype = c_long
+        lib.pdf_td_fwd_scratch_floats.argtypes = [c_long, c_int]
         lib.pdf_td_bwd_scratch_floats.restype = c_long
         lib.pdf_td_bwd_scratch_floats.argtypes = [c_long, c_int, c_int]
         lib.pdf_td_forward.restype = c_int
         lib.pdf_td_forward.argtypes = [c_long, c_long, c_int, c_int, c_void_p, c_int, ctypes.c_float, ctypes.c_float, c_void_p]
         lib.pdf_td_backward.restype = c_int
-        lib.pdf_td_backward.argtypes = [c_long, c_long, c_int, c_int, c_void_p, c_void_p]
+        lib.pdf_td_backward.argtypes = [c_long, c_long, c_int, c_int, c_void_p, c_int, c_void_p]
+        lib.pdf_ce_workspace_floats.restype = c_long
+        lib.pdf_ce_workspace_floats.argtypes = []
         lib.pdf_ce_forward.restype = c_int
         lib.pdf_ce_forward.argtypes = [c_long, c_int, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p]
         lib.pdf_ce_backward.restype = c_int
         lib.pdf_ce_backward.argtypes = [c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         lib.pdf_knn_rel_moments.restype = c_int
-        lib.pdf_knn_rel_moments.argtypes = [c_int, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        lib.pdf_knn_rel_moments.argtypes = [c_int, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        lib.pdf_knn_rel_moments_ws_doubles.restype = c_long
+        lib.pdf_knn_rel_moments_ws_doubles.argtypes = [c_int, c_long]
         lib.pdf_knn_rel_moments_q.restype = c_int
-        lib.pdf_knn_rel_moments_q.argtypes = [c_int, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        lib.pdf_knn_rel_moments_q.argtypes = [c_int, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        class CopySeg(ctypes.Structure):   # include/pdfops.h: PdfCopySeg
+            _fields_ = [("src", c_void_p), ("dst", c_void_p), ("nbytes", c_long), ("src_offset", c_void_p), ("sub", c_void_p),
+                        ("sub_const", c_int), ("src_elems", c_int)]
+
+        self.CopySeg = CopySeg
+        lib.pdf_stage_copy.restype = c_int
+        lib.pdf_stage_copy.argtypes = [c_int, c_void_p, c_void_p]
         lib.pdf_sgd_chunk.restype = c_int
         lib.pdf_sgd_chunk.argtypes = []
         lib.pdf_sgd_step.restype = c_int
@@ -559,7 +573,9 @@ class HipBackend(CBackend):
                                          c_int, c_void_p, c_long, c_int, c_void_p]
         lib.pdf_rowlin_wgrad_multi.restype = c_int
         lib.pdf_rowlin_wgrad_multi.argtypes = [c_long, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int,
-                                               c_void_p, c_void_p, c_void_p]
+                                               c_void_p, c_void_p, c_void_p, c_void_p]
+        lib.pdf_rowlin_wgrad_ws_floats.restype = c_long
+        lib.pdf_rowlin_wgrad_ws_floats.argtypes = [c_long, c_int, c_int, c_int]
         lib.pdf_rowlin_dgrad_bstats.restype = c_int
         lib.pdf_rowlin_dgrad_bstats.argtypes = [c_long, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_long,
                                                 c_void_p, c_int, c_void_p, ctypes.POINTER(c_int), c_void_p]
@@ -575,7 +591,7 @@ class HipBackend(CBackend):
                                            c_int, c_void_p, c_long, c_int, c_void_p, c_void_p]
         lib.pdf_rowlin_wgrad.restype = c_int
         lib.pdf_rowlin_wgrad.argtypes = [c_long, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int,
-                                         c_void_p, c_void_p, c_void_p]
+                                         c_void_p, c_void_p, c_void_p, c_void_p]
         lib.pdf_bn_coef_from_partial.restype = c_int
         lib.pdf_bn_coef_from_partial.argtypes = [c_void_p, c_int, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                                  ctypes.c_float, ctypes.c_float, c_void_p, c_void_p]
@@ -799,10 +815,11 @@ class HipBackend(CBackend):
         scene ends of the QUERIES; ``new_xyz`` None = a self table."""
         q = xyz if new_xyz is None else new_xyz
         _check(xyz, torch.float32, "xyz"); _check(q, torch.float32, "new_xyz"); _check(offset, torch.int32, "offset"); _check(idx, torch.int32, "idx")
-        out = torch.zeros((offset.shape[0], 9), dtype=torch.float64, device=xyz.device)
+        out = torch.empty((offset.shape[0], 9), dtype=torch.float64, device=xyz.device)
+        ws = torch.empty((max(int(self.lib.pdf_knn_rel_moments_ws_doubles(int(offset.shape[0]), int(q.shape[0]))), 1),), dtype=torch.float64, device=xyz.device)
         require_current_device(xyz, q, offset, idx)
         rc = self.lib.pdf_knn_rel_moments_q(int(offset.shape[0]), int(q.shape[0]), int(nsample), xyz.data_ptr(), q.data_ptr(), offset.data_ptr(),
-                                            idx.data_ptr(), out.data_ptr(), self._stream())
+                                            idx.data_ptr(), out.data_ptr(), ws.data_ptr(), self._stream())
         if rc != 0:
             raise PdfOpsError(f"pdf_knn_rel_moments failed with status {rc}")
         return out
@@ -916,14 +933,19 @@ class HipBackend(CBackend):
             raise PdfOpsError(f"pdf_bn_act_backward_presummed failed with status {rc}")
         return dy, sums[o:], sums[:o]
 
+    def wgrad_workspace(self, n, k, o, ng, device):
+        """Slab workspace of the weight-gradient entry points (fixed-order reduction instead of float atomics)."""
+        return torch.empty((max(int(self.lib.pdf_rowlin_wgrad_ws_floats(int(n), int(k), int(o), int(ng))), 1),), dtype=torch.float32, device=device)
+
     def rowlin_wgrad_multi(self, gs, x, coef, relu):
         n, o = gs[0].shape
         k = x.shape[1]
-        dws = [torch.zeros((o, k), dtype=torch.float32, device=x.device) for _ in gs]
-        dbs = [torch.zeros((o,), dtype=torch.float32, device=x.device) for _ in gs]
+        dws = [torch.empty((o, k), dtype=torch.float32, device=x.device) for _ in gs]
+        dbs = [torch.empty((o,), dtype=torch.float32, device=x.device) for _ in gs]
+        ws = self.wgrad_workspace(n, k, o, len(gs), x.device)
         rc = self.lib.pdf_rowlin_wgrad_multi(n, k, o, len(gs), self._ptrs(gs), gs[0].stride(0), x.data_ptr(), x.stride(0),
                                              None if coef is None else coef.data_ptr(), None if coef is None else coef.data_ptr() + 4 * k,
-                                             int(relu), self._ptrs(dws), self._ptrs(dbs), self._stream())
+                                             int(relu), self._ptrs(dws), self._ptrs(dbs), ws.data_ptr(), self._stream())
         if rc != 0:
             raise PdfOpsError(f"pdf_rowlin_wgrad_multi failed with status {rc}")
         return dws, dbs
@@ -931,12 +953,13 @@ class HipBackend(CBackend):
     def rowlin_wgrad(self, g, x, coef, relu, need_bias):
         n, o = g.shape
         k = x.shape[1]
-        dw = torch.zeros((o, k), dtype=torch.float32, device=x.device)
-        db = torch.zeros((o,), dtype=torch.float32, device=x.device) if need_bias else None
+        dw = torch.empty((o, k), dtype=torch.float32, device=x.device)
+        db = torch.empty((o,), dtype=torch.float32, device=x.device) if need_bias else None
+        ws = self.wgrad_workspace(n, k, o, 1, x.device)
         rc = self.lib.pdf_rowlin_wgrad(n, k, o, g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0),
                                        None if coef is None else coef.data_ptr(),
                                        None if coef is None else coef.data_ptr() + 4 * k, int(relu), dw.data_ptr(),
-                                       None if db is None else db.data_ptr(), self._stream())
+                                       None if db is None else db.data_ptr(), ws.data_ptr(), self._stream())
         if rc != 0:
             raise PdfOpsError(f"pdf_rowlin_wgrad failed with status {rc}")
         return dw, db
@@ -980,14 +1003,17 @@ class HipBackend(CBackend):
             raise PdfOpsError(f"pdf_bn_apply failed with status {rc}")
         return y
 
-    def td_tables(self, p_src, p_new, idx, new_offset):
-        """Geometry-only tables of the fused TransitionDown: rel4 (m,16,4), Z (n,32), scene_sums (b,16) (csrc/transition_down.hip)."""
+    def td_tables(self, p_src, p_new, idx, new_offset, inverse=None):
+        """Geometry-only tables of the fused TransitionDown: rel4 (m,16,4), Z (n,32), scene_sums (b,16) (csrc/transition_down.hip).
+        ``inverse`` = (inv_off, inv_entry, entry_base) of idx: Z is then summed in destination order (bit-reproducible)."""
         m, n, b = p_new.shape[0], p_src.shape[0], new_offset.shape[0]
         rel4 = torch.empty((m, 16, 4), dtype=torch.float32, device=p_src.device)
         Z = torch.zeros((n, 32), dtype=torch.float32, device=p_src.device)
         sums = torch.zeros((b, 16), dtype=torch.float32, device=p_src.device)
+        off, ent, base = inverse if inverse is not None else (None, None, 0)
         rc = self.lib.pdf_td_tables(m, b, p_src.data_ptr(), p_new.data_ptr(), idx.data_ptr(), new_offset.data_ptr(), rel4.data_ptr(), Z.data_ptr(),
-                                    sums.data_ptr(), self._stream())
+                                    sums.data_ptr(), n, None if off is None else off.data_ptr(), None if ent is None else ent.data_ptr(), int(base),
+                                    self._stream())
         if rc != 0:
             raise PdfOpsError(f"pdf_td_tables failed with status {rc}")
         return rel4, Z, sums

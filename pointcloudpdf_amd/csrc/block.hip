@@ -65,31 +65,27 @@ extern "C" int pdf_block_pre_forward(long n, int c, void *const *p, int training
 }
 
 // p[]: x, z1, coef1, W1, Wq, Wk, Wv, gxq, gxk, gxv                                  (inputs)
-//      gx, grads [dW1 (c*c) | dbeta1 (c) | dgamma1 (c) | {dW (c*c), db (c)} x q,k,v]   (outputs; grads zeroed here)
-//      dy (n*c), partial (max(pdf_bn_partial_floats(n, c), pdf_rowlin_partial_floats(n, c)): the dgrad epilogue's rows)   (scratch; p[14] unused)
+//      gx, grads [dW1 (c*c) | dbeta1 (c) | dgamma1 (c) | {dW (c*c), db (c)} x q,k,v]   (outputs; every element is WRITTEN: no zeroing)
+//      dy (n*c), partial (max(pdf_bn_partial_floats(n, c), pdf_rowlin_partial_floats(n, c)): the dgrad epilogue's rows)   (scratch)
+//      p[14] = workspace of the weight-gradient slabs, pdf_rowlin_wgrad_ws_floats(n, c, c, 3) floats
 static bool dgrad_bstats() {   // PDFOPS_DGRAD_BSTATS=0: BatchNorm-backward sums from their own pass instead of the dgrad epilogue (A/B)
     static const bool on = [] { const char *v = getenv("PDFOPS_DGRAD_BSTATS"); return !(v && v[0] == '0'); }();
     return on;
 }
 
-static int block_pre_backward(long n, int c, void *const *p, int training, int accumulate_gx, int grads_zeroed, void *stream, const Fork *fk = nullptr) {
-    if (n < 1 || !p) return PDF_ERR_BAD_ARG;
+static int block_pre_backward(long n, int c, void *const *p, int training, int accumulate_gx, void *stream, const Fork *fk = nullptr) {
+    if (n < 1 || !p || !p[14]) return PDF_ERR_BAD_ARG;
     const float *x = (const float *)p[0], *z1 = (const float *)p[1], *coef1 = (const float *)p[2], *W1 = (const float *)p[3];
-    float *gx = (float *)p[10], *grads = (float *)p[11], *dy = (float *)p[12], *partial = (float *)p[13];
+    float *gx = (float *)p[10], *grads = (float *)p[11], *dy = (float *)p[12], *partial = (float *)p[13], *wslab = (float *)p[14];
     const long cc = (long)c * c;
     float *dW1 = grads, *db1 = grads + cc, *dqkv = db1 + 2 * c;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (!grads_zeroed) {
-        hipError_t he = hipMemsetAsync(grads, 0, sizeof(float) * (size_t)(cc + 2 * c + 3 * (cc + c)), s);
-        if (he != hipSuccess) return (int)he;
-    }
     Err e;
     const float *gs[3] = {(const float *)p[7], (const float *)p[8], (const float *)p[9]};
     const float *ws[3] = {(const float *)p[4], (const float *)p[5], (const float *)p[6]};
     float *dws[3] = {dqkv, dqkv + (cc + c), dqkv + 2 * (cc + c)}, *dbs[3] = {dqkv + cc, dqkv + (cc + c) + cc, dqkv + 2 * (cc + c) + cc};
     float *ys[1] = {dy};
     void *ws_stream = fk ? (void *)fk->begin(e) : stream;   // q/k/v weight gradients: g_xq / g_xk / g_xv are final here
-    e << pdf_rowlin_wgrad_multi(n, c, c, 3, gs, c, z1, c, coef1, coef1 + c, 1, dws, dbs, ws_stream);
+    e << pdf_rowlin_wgrad_multi(n, c, c, 3, gs, c, z1, c, coef1, coef1 + c, 1, dws, dbs, wslab, ws_stream);
     // bn1 backward in place on dy (elementwise: same index read and written); its column sums ARE [d beta1 | d gamma1].  The sums come
     // out of the input-gradient product's epilogue where the streaming kernel covers the shape, else from a pass over dy and z1.
     int prow = 0;
@@ -102,13 +98,13 @@ static int block_pre_backward(long n, int c, void *const *p, int training, int a
         e << pdf_bn_act_backward_presummed(n, c, dy, z1, coef1, training, 1, partial, prow, db1, dy, stream);
     }
     ws_stream = fk ? (void *)fk->begin(e) : stream;         // dW1 needs the finished dy
-    e << pdf_rowlin_wgrad(n, c, c, dy, c, x, c, nullptr, nullptr, 0, dW1, nullptr, ws_stream);
+    e << pdf_rowlin_wgrad(n, c, c, dy, c, x, c, nullptr, nullptr, 0, dW1, nullptr, wslab, ws_stream);   // (after the q/k/v reduction in stream order)
     e << pdf_rowlin_forward(n, c, c, dy, c, W1, 1, nullptr, nullptr, nullptr, 0, gx, c, accumulate_gx, nullptr, stream);
     return e.rc;
 }
 
 extern "C" int pdf_block_pre_backward(long n, int c, void *const *p, int training, void *stream) {
-    return block_pre_backward(n, c, p, training, 0, 0, stream, nullptr);
+    return block_pre_backward(n, c, p, training, 0, stream, nullptr);
 }
 
 // p[]: t, x (identity), gamma2, beta2, rm2, rv2, W3, gamma3, beta3, rm3, rv3        (inputs)
@@ -128,25 +124,21 @@ extern "C" int pdf_block_post_forward(long n, int c, void *const *p, int trainin
 }
 
 // p[]: gy, t, x, z3, coef2, coef3, W3                                               (inputs)
-//      gt, gres, grads [dW3 (c*c) | dbeta2 | dgamma2 | dbeta3 | dgamma3]             (outputs; grads zeroed here)
-//      da (n*c), partial (max(pdf_bn_partial_floats(n, c), pdf_rowlin_partial_floats(n, c)))   (scratch; p[12] unused)
-static int block_post_backward(long n, int c, void *const *p, int training, int grads_zeroed, void *stream, const Fork *fk = nullptr) {
-    if (n < 1 || !p) return PDF_ERR_BAD_ARG;
+//      gt, gres, grads [dW3 (c*c) | dbeta2 | dgamma2 | dbeta3 | dgamma3]             (outputs; every element is WRITTEN: no zeroing)
+//      da (n*c), partial (max(pdf_bn_partial_floats(n, c), pdf_rowlin_partial_floats(n, c)))   (scratch)
+//      p[12] = workspace of the weight-gradient slabs, pdf_rowlin_wgrad_ws_floats(n, c, c, 1) floats
+static int block_post_backward(long n, int c, void *const *p, int training, void *stream, const Fork *fk = nullptr) {
+    if (n < 1 || !p || !p[12]) return PDF_ERR_BAD_ARG;
     const float *gy = (const float *)p[0], *t = (const float *)p[1], *x = (const float *)p[2], *z3 = (const float *)p[3];
     const float *coef2 = (const float *)p[4], *coef3 = (const float *)p[5], *W3 = (const float *)p[6];
     float *gt = (float *)p[7], *gres = (float *)p[8], *grads = (float *)p[9], *da = (float *)p[10], *partial = (float *)p[11];
     const long cc = (long)c * c;
     float *dW3 = grads, *db2 = grads + cc, *db3 = db2 + 2 * c;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (!grads_zeroed) {
-        hipError_t he = hipMemsetAsync(grads, 0, sizeof(float) * (size_t)(cc + 4 * c), s);
-        if (he != hipSuccess) return (int)he;
-    }
     Err e;
     // bn3 backward: gz3 -> da (scratch), gres; column sums land in the gradient slots [d beta | d gamma]
     e << pdf_bn_act_backward(n, c, gy, z3, x, coef3, training, 1, partial, db3, da, gres, stream);
     void *ws_stream = fk ? (void *)fk->begin(e) : stream;
-    e << pdf_rowlin_wgrad(n, c, c, da, c, t, c, coef2, coef2 + c, 1, dW3, nullptr, ws_stream);
+    e << pdf_rowlin_wgrad(n, c, c, da, c, t, c, coef2, coef2 + c, 1, dW3, nullptr, (float *)p[12], ws_stream);
     // bn2 backward in place on gt (sums from the product's epilogue, as in block_pre_backward)
     int prow = 0;
     const float *das[1] = {da}, *w3s[1] = {W3};
@@ -162,7 +154,7 @@ static int block_post_backward(long n, int c, void *const *p, int training, int 
 }
 
 extern "C" int pdf_block_post_backward(long n, int c, void *const *p, int training, void *stream) {
-    return block_post_backward(n, c, p, training, 0, stream, nullptr);
+    return block_post_backward(n, c, p, training, stream, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -204,18 +196,19 @@ extern "C" int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p
 //            45 dy (n*c; separate from 34: the forked dW3 kernel may still be reading `da` when the pre half starts)
 //   optional: 46 aux stream, 47 fork event, 48 join event (all three or none: weight gradients on the second stream, see Fork)
 //             49 visiting order of the points (or null)
+//   50 workspace of the weight-gradient slabs: pdf_rowlin_wgrad_ws_floats(n, c, c, 3) + pdf_rowlin_wgrad_ws_floats(n, c, c, 1) floats (the post
+//      half's dW3 slabs first, the pre half's behind them: with the optional second stream the two halves' reductions may overlap)
+// No gradient slot is accumulated into any more (slab reductions and column sums WRITE): the memset of round 2 is gone.
 extern "C" int pdf_bottleneck_backward(long n, int nsample, int c, void *const *p, int training, int entry_base, int storage_bf16, void *stream) {
     if (n < 1 || !p) return PDF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     Err e;
     Fork fk{s, static_cast<hipStream_t>(p[46]), static_cast<hipEvent_t>(p[47]), static_cast<hipEvent_t>(p[48])};
     if (!p[46] || !p[47] || !p[48]) fk.aux = nullptr;
-    void *post[13] = {p[0], p[24], p[1], p[25], p[26], p[27], p[28], p[33], p[29], p[31], p[34], p[40], nullptr};
-    // ONE memset: the caller lays out [grads of the pre half | grads of the post half] contiguously (p[30] .. p[32]); g_xk / g_xv are
-    // written by the segmented gathers (no zeroing)
-    hipError_t he = hipMemsetAsync(p[30], 0, (size_t)((char *)p[32] - (char *)p[30]), s);
-    if (he != hipSuccess) return (int)he;
-    e << block_post_backward(n, c, post, training, 1, stream, &fk);
+    if (!p[50]) return PDF_ERR_BAD_ARG;
+    float *ws_post = (float *)p[50], *ws_pre = ws_post + pdf_rowlin_wgrad_ws_floats(n, c, c, 1);
+    void *post[13] = {p[0], p[24], p[1], p[25], p[26], p[27], p[28], p[33], p[29], p[31], p[34], p[40], ws_post};
+    e << block_post_backward(n, c, post, training, stream, &fk);
     const float *weights[8];
     for (int i = 0; i < 8; ++i) weights[i] = (const float *)p[10 + i];
     e << pdf_pt_layer_backward((int)n, nsample, c, (const float *)p[21], (const float *)p[22], (const float *)p[23], (const float *)p[8],
@@ -223,8 +216,8 @@ extern "C" int pdf_bottleneck_backward(long n, int nsample, int c, void *const *
                                (const float *)p[33], (float *)p[35], (float *)p[36], (float *)p[37], (float *)p[38], (float *)p[39],
                                (float *)p[41], (float *)p[42], (const int *)p[43], (const int *)p[44], entry_base,
                                (float *)p[40], (float *)p[32], storage_bf16, (const int *)p[49], stream);
-    void *pre[15] = {p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[35], p[36], p[37], p[29], p[30], p[45], p[40], nullptr};
-    e << block_pre_backward(n, c, pre, training, 1, 1, stream, &fk);   // gx += dy W1 on top of the identity branch
+    void *pre[15] = {p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[35], p[36], p[37], p[29], p[30], p[45], p[40], ws_pre};
+    e << block_pre_backward(n, c, pre, training, 1, stream, &fk);   // gx += dy W1 on top of the identity branch
     fk.finish(e);   // the gradients written on the second stream are complete before anything later on `stream`
     return e.rc;
 }
@@ -247,19 +240,16 @@ extern "C" int pdf_linbn_forward(long n, int k, int o, void *const *p, int train
     return e.rc;
 }
 
-// Backward p[]: 0 gy 1 x 2 z 3 coef 4 W | 5 gx (n,k) or null 6 grads [dW (o*k) | db (o) | dbeta (o) | dgamma (o)] (zeroed here)
-//               7 gz (n,o) scratch 8 partial (pdf_bn_partial_floats(n,o))
+// Backward p[]: 0 gy 1 x 2 z 3 coef 4 W | 5 gx (n,k) or null 6 grads [dW (o*k) | db (o) | dbeta (o) | dgamma (o)] (written)
+//               7 gz (n,o) scratch 8 partial (pdf_bn_partial_floats(n,o)) 9 weight-gradient slabs (pdf_rowlin_wgrad_ws_floats(n, k, o, 1))
 extern "C" int pdf_linbn_backward(long n, int k, int o, void *const *p, int training, int relu, void *stream) {
-    if (n < 1 || !p) return PDF_ERR_BAD_ARG;
-    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n < 1 || !p || !p[9]) return PDF_ERR_BAD_ARG;
     float *grads = (float *)p[6], *gz = (float *)p[7];
     const long ok = (long)o * k;
-    hipError_t he = hipMemsetAsync(grads, 0, sizeof(float) * (size_t)(ok + 3 * o), s);
-    if (he != hipSuccess) return (int)he;
     Err e;
     e << pdf_bn_act_backward(n, o, (const float *)p[0], (const float *)p[2], nullptr, (const float *)p[3], training, relu, (float *)p[8],
                              grads + ok + o, gz, nullptr, stream);                                                    // [dbeta | dgamma]
     if (p[5]) e << pdf_rowlin_forward(n, o, k, gz, o, (const float *)p[4], 1, nullptr, nullptr, nullptr, 0, (float *)p[5], k, 0, nullptr, stream);
-    e << pdf_rowlin_wgrad(n, k, o, gz, o, (const float *)p[1], k, nullptr, nullptr, 0, grads, grads + ok, stream);    // dW, db
+    e << pdf_rowlin_wgrad(n, k, o, gz, o, (const float *)p[1], k, nullptr, nullptr, 0, grads, grads + ok, (float *)p[9], stream);    // dW, db
     return e.rc;
 }

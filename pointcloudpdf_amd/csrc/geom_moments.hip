@@ -9,7 +9,7 @@
 // batch the sums of its own scenes), and the layer's first statistics pass + its finalizer (2 of the 7 forward launches of a layer) are
 // replaced by ~60 flops in the prologue of the next pass (fused_layer.h, bnp_from_moments).
 // rel is formed in fp32 exactly as the layer kernels form it (0 for idx < 0 rows, which the reference keeps as rows); sums in fp64.
-// out (b, 9) double = [Sx Sy Sz | Mxx Mxy Mxz Myy Myz Mzz], pre-zeroed by the caller.  Bound: HBM (idx + gathered coordinates), ~10 us.
+// out (b, 9) double = [Sx Sy Sz | Mxx Mxy Mxz Myy Myz Mzz], written.  Bound: HBM (idx + gathered coordinates), ~10 us.
 #include "pdfops_common.h"
 
 namespace {
@@ -25,15 +25,36 @@ __device__ __forceinline__ int scene_of(const int *__restrict__ offset, int b, l
     return lo;
 }
 
+// Workgroup g -> (scene, chunk of MB rows inside the scene): every workgroup lies inside ONE scene, so its nine sums go to its own slot
+// and the per-scene totals are formed in a fixed order by k_rel_moments_sum (round 3: no atomics -- the statistics are bit-reproducible).
+__device__ __forceinline__ bool block_rows(const int *__restrict__ offset, int b, int g, int *scene, long *first, long *last, int *g0, int *g1) {
+    int cum = 0;
+    long prev = 0;
+    for (int s = 0; s < b; ++s) {
+        const long end = offset[s];
+        const int nb = (int)((end - prev + MB - 1) / MB);
+        if (g < cum + nb) {
+            *scene = s; *first = prev + (long)(g - cum) * MB; *last = min(*first + MB, end); *g0 = cum; *g1 = cum + nb;
+            return true;
+        }
+        cum += nb;
+        prev = end;
+    }
+    return false;
+}
+
 // p = source points (indexed by idx), q = query points (row i of idx belongs to q[i]; q == p for a self table)
 __global__ __launch_bounds__(MB) void k_rel_moments(long n, int k, const float *__restrict__ p, const float *__restrict__ q, const int *__restrict__ idx,
-                                                    const int *__restrict__ offset, int b, double *__restrict__ out) {
+                                                    const int *__restrict__ offset, int b, double *__restrict__ part) {
     __shared__ double red[MB / 64][9];
-    const long i = (long)blockIdx.x * MB + threadIdx.x;
+    int scene, g0, g1;
+    long first, last;
+    const bool live = block_rows(offset, b, (int)blockIdx.x, &scene, &first, &last, &g0, &g1);
+    const long i = first + threadIdx.x;
     double acc[9];
 #pragma unroll
     for (int e = 0; e < 9; ++e) acc[e] = 0.0;
-    if (i < n) {
+    if (live && i < last) {
         const float px = q[i * 3], py = q[i * 3 + 1], pz = q[i * 3 + 2];
         for (int j = 0; j < k; ++j) {
             const int nb = idx[i * k + j];
@@ -45,39 +66,65 @@ __global__ __launch_bounds__(MB) void k_rel_moments(long n, int k, const float *
             acc[3] += x * x; acc[4] += x * y; acc[5] += x * z; acc[6] += y * y; acc[7] += y * z; acc[8] += z * z;
         }
     }
-    const long first = (long)blockIdx.x * MB, last = min(first + MB, n) - 1;
-    const int s_first = scene_of(offset, b, first), s_last = scene_of(offset, b, last);
-    if (s_first == s_last) {   // the usual case: one scene per block -> block sum, 9 atomics
 #pragma unroll
-        for (int e = 0; e < 9; ++e) {
-            double v = acc[e];
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][e] = v;
-        }
-        __syncthreads();
-        if (threadIdx.x < 9) {
-            double v = 0.0;
-            for (int w = 0; w < MB / 64; ++w) v += red[w][threadIdx.x];
-            atomicAdd(out + (size_t)s_first * 9 + threadIdx.x, v);
-        }
-    } else if (i < n) {        // a block that straddles a scene boundary: per-point atomics (at most b - 1 such blocks)
-        const int s = scene_of(offset, b, i);
+    for (int e = 0; e < 9; ++e) {
+        double v = acc[e];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][e] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        double v = 0.0;
+        for (int w = 0; w < MB / 64; ++w) v += red[w][threadIdx.x];
+        part[(size_t)blockIdx.x * 9 + threadIdx.x] = v;   // (workgroups beyond the last scene store zeros)
+    }
+}
+
+// out[s][e] = sum of the slots of scene s in workgroup order.  One workgroup per scene; lane l adds slots l, l + MB, ...
+__global__ __launch_bounds__(MB) void k_rel_moments_sum(const int *__restrict__ offset, int b, const double *__restrict__ part, double *__restrict__ out) {
+    __shared__ double red[MB][9];
+    const int s = blockIdx.x;
+    int g0 = 0;
+    long prev = 0;
+    for (int t = 0; t < s; ++t) { g0 += (int)((offset[t] - prev + MB - 1) / MB); prev = offset[t]; }
+    const int g1 = g0 + (int)((offset[s] - prev + MB - 1) / MB);
+    double acc[9];
 #pragma unroll
-        for (int e = 0; e < 9; ++e) atomicAdd(out + (size_t)s * 9 + e, acc[e]);
+    for (int e = 0; e < 9; ++e) acc[e] = 0.0;
+    for (int g = g0 + threadIdx.x; g < g1; g += MB)
+#pragma unroll
+        for (int e = 0; e < 9; ++e) acc[e] += part[(size_t)g * 9 + e];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) red[threadIdx.x][e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        double v = 0.0;
+        for (int t = 0; t < MB; ++t) v += red[t][threadIdx.x];
+        out[(size_t)s * 9 + threadIdx.x] = v;
     }
 }
 
 }  // namespace
 
+// workspace (doubles) of the two entry points below: one slot of nine sums per workgroup
+extern "C" long pdf_knn_rel_moments_ws_doubles(int b, long m) { return ((m + MB - 1) / MB + (b > 0 ? b : 0)) * 9; }
+
 // The same for a table whose m queries (new_xyz, scene ends new_offset) differ from its source points (TransitionDown's grouping):
-// rel = xyz[idx[i, j]] - new_xyz[i].
+// rel = xyz[idx[i, j]] - new_xyz[i].  out (b, 9) is WRITTEN (no zeroing); ws: pdf_knn_rel_moments_ws_doubles(b, m) doubles.
 extern "C" int pdf_knn_rel_moments_q(int b, long m, int nsample, const float *xyz, const float *new_xyz, const int *new_offset, const int *idx,
-                                     double *out, void *stream) {
-    if (b < 1 || m < 0 || nsample < 1 || !new_offset || !out || (m > 0 && (!xyz || !new_xyz || !idx))) return PDF_ERR_BAD_ARG;
-    if (m == 0) return PDF_OK;
-    k_rel_moments<<<(unsigned)((m + MB - 1) / MB), MB, 0, static_cast<hipStream_t>(stream)>>>(m, nsample, xyz, new_xyz, idx, new_offset, b, out);
+                                     double *out, double *ws, void *stream) {
+    if (b < 1 || m < 0 || nsample < 1 || !new_offset || !out || (m > 0 && (!xyz || !new_xyz || !idx || !ws))) return PDF_ERR_BAD_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (m == 0) {
+        hipError_t e = hipMemsetAsync(out, 0, sizeof(double) * 9 * (size_t)b, s);
+        return e == hipSuccess ? PDF_OK : (int)e;
+    }
+    const unsigned grid = (unsigned)((m + MB - 1) / MB + b);   // every scene rounds its rows up to whole workgroups
+    k_rel_moments<<<grid, MB, 0, s>>>(m, nsample, xyz, new_xyz, idx, new_offset, b, ws);
+    k_rel_moments_sum<<<(unsigned)b, MB, 0, s>>>(new_offset, b, ws, out);
     return pdf_launch_status();
 }
-extern "C" int pdf_knn_rel_moments(int b, long n, int nsample, const float *xyz, const int *offset, const int *idx, double *out, void *stream) {
-    return pdf_knn_rel_moments_q(b, n, nsample, xyz, xyz, offset, idx, out, stream);
+extern "C" int pdf_knn_rel_moments(int b, long n, int nsample, const float *xyz, const int *offset, const int *idx, double *out, double *ws,
+                                   void *stream) {
+    return pdf_knn_rel_moments_q(b, n, nsample, xyz, xyz, offset, idx, out, ws, stream);
 }

@@ -1,14 +1,15 @@
 // Cross-entropy over (N, C) logits with an ignore label, mean over the counted rows -- nn.CrossEntropyLoss as configured on
 // this path (losses/misc.py:14-39: weight=None, label_smoothing=0, reduction="mean", ignore_index=-1).
 // torch runs log_softmax + an nll reduction that is a single-block kernel (173 us forward + 147 us backward for 200k x 13);
-// here one lane owns one row (C <= 64 logits in registers): max / log-sum-exp / picked logit, a block reduction and two
-// atomics (sum of losses, number of counted rows).  The forward also leaves softmax - onehot (zero on ignored rows) in
+// here one lane owns one row (C <= 64 logits in registers): max / log-sum-exp / picked logit, a block reduction into the block's own
+// slot and a one-workgroup sum over the slots (sum of losses, number of counted rows; fixed order, no atomics).  The forward also leaves softmax - onehot (zero on ignored rows) in
 // `grad`, so the backward is one scaled copy.  Bound: HBM (8NC bytes forward).
 #include "pdfops_common.h"
 
 namespace {
 
 constexpr int LB = 256;
+constexpr int PDF_CE_HEAD = 4, PDF_CE_MAX_BLOCKS = 1024;   // acc = [sum, count, -, -] + one [sum | count] pair per workgroup
 
 __global__ __launch_bounds__(LB) void k_ce_fwd(long n, int c, const float *__restrict__ logits, const long *__restrict__ target,
                                                long ignore, float *__restrict__ grad, float *__restrict__ acc) {
@@ -35,16 +36,28 @@ __global__ __launch_bounds__(LB) void k_ce_fwd(long n, int c, const float *__res
     cnt = pdf_wave_sum_f32(cnt);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = loss; red[1][threadIdx.x >> 6] = cnt; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) {   // the block's [sum | count] goes to its own slot: k_ce_mean adds the slots in a fixed order (no float atomics)
         float a = 0.f, b = 0.f;
         for (int w = 0; w < LB / 64; ++w) { a += red[0][w]; b += red[1][w]; }
-        pdf_atomic_add(acc, a);
-        pdf_atomic_add(acc + 1, b);
+        acc[PDF_CE_HEAD + 2 * blockIdx.x] = a;
+        acc[PDF_CE_HEAD + 2 * blockIdx.x + 1] = b;
     }
 }
 
-// acc = [sum of losses, counted rows] -> out = mean loss (NaN when nothing is counted, as torch)
-__global__ void k_ce_mean(const float *__restrict__ acc, float *__restrict__ out) { out[0] = acc[0] / acc[1]; }
+// acc[PDF_CE_HEAD + 2 g] = the blocks' [sum of losses, counted rows] -> acc[0..1] = their totals, out = mean loss (NaN when nothing is
+// counted, as torch).  One workgroup; lane l adds blocks l, l + 256, ...; the 256 partial sums are combined in lane order.
+__global__ __launch_bounds__(LB) void k_ce_mean(float *__restrict__ acc, int blocks, float *__restrict__ out) {
+    __shared__ float red[2][LB];
+    float a = 0.f, b = 0.f;
+    for (int g = threadIdx.x; g < blocks; g += LB) { a += acc[PDF_CE_HEAD + 2 * g]; b += acc[PDF_CE_HEAD + 2 * g + 1]; }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    a = 0.f; b = 0.f;
+    for (int t = 0; t < LB; ++t) { a += red[0][t]; b += red[1][t]; }
+    acc[0] = a; acc[1] = b;
+    out[0] = a / b;
+}
 
 // grad_logits = (softmax - onehot) * gy / count.  The forward's buffer is only READ: a second backward over the same graph
 // (retain_graph, torch.autograd.grad followed by backward) must see the unscaled values again.
@@ -88,18 +101,19 @@ extern "C" int pdf_vote_accumulate(long n, int c, const float *logits, const flo
     return pdf_launch_status();
 }
 
+extern "C" long pdf_ce_workspace_floats(void) { return PDF_CE_HEAD + 2L * PDF_CE_MAX_BLOCKS; }
+
 // loss (1 float) = mean over rows with target != ignore of -log softmax(logits)[target]; grad (n*c) receives softmax - onehot;
-// acc (2 floats) receives [sum, count] (zeroed here).
+// acc (pdf_ce_workspace_floats() floats) receives [sum, count] in its first two floats (the rest: per-workgroup partial sums, added in a
+// fixed order: the loss is bit-reproducible).  Nothing needs zeroing.
 extern "C" int pdf_ce_forward(long n, int c, const float *logits, const long *target, long ignore, float *grad, float *acc,
                               float *loss, void *stream) {
     if (n < 1 || c < 1 || !logits || !target || !grad || !acc || !loss) return PDF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(acc, 0, 2 * sizeof(float), s);
-    if (e != hipSuccess) return (int)e;
     long g = (n + LB - 1) / LB;
-    if (g > 1024) g = 1024;
+    if (g > PDF_CE_MAX_BLOCKS) g = PDF_CE_MAX_BLOCKS;
     k_ce_fwd<<<(unsigned)g, LB, 0, s>>>(n, c, logits, target, ignore, grad, acc);
-    k_ce_mean<<<1, 1, 0, s>>>(acc, loss);
+    k_ce_mean<<<1, LB, 0, s>>>(acc, (int)g, loss);
     return pdf_launch_status();
 }
 

@@ -119,9 +119,11 @@ struct WArgs {
     const float *X; long ldx;        // (N, K) layer input (before the folded affine + ReLU)
     const float *scale, *shift;
     int relu;
-    float *dW;                       // (O, K) pre-zeroed
-    float *db;                       // (O) pre-zeroed or null
+    float *dW;                       // (O, K), written by the slab reduction
+    float *db;                       // (O) or null
     long rows_per_block;
+    float *slab;                     // [gridDim.y][4 gridDim.x][32 * 32]: one block of dW per WAVE (rl2::k_slab_reduce sums them in order)
+    float *bslab;                    // [ceil(O / 32)][4 gridDim.x][32]: column sums of G (k-block 0)
 };
 
 // One wave = one 32x32 block of dW over a row range: A operand = G^T (lanes along o), B operand = f(X) (lanes along k);
@@ -161,14 +163,16 @@ __global__ __launch_bounds__(256) void k_wgrad(WArgs a) {
             gsum += g[u];
         }
     }
+    const size_t sidx = (size_t)blockIdx.x * 4 + wave, nsl = (size_t)gridDim.x * 4;
+    float *slab = a.slab + ((size_t)blockIdx.y * nsl + sidx) * 1024;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // o index inside the block
-        if (o0 + i < a.O && cv) pdf_atomic_add(a.dW + (long)(o0 + i) * a.K + cc, acc[r]);
+        slab[i * 32 + ch] = acc[r];
     }
     if (a.db && c0 == 0) {
         gsum += __shfl_xor(gsum, 32, 64);
-        if (lane < 32 && ov) pdf_atomic_add(a.db + oc, gsum);
+        if (lane < 32) a.bslab[((size_t)(o0 / 32) * nsl + sidx) * 32 + ch] = gsum;
     }
 }
 
@@ -181,9 +185,27 @@ int try_forward(long n, int k, int o, int nin, int nout, const float *const *x, 
                 int accumulate, float *partial, hipStream_t s, const float *roww = nullptr, long rws = 0, const float *bx = nullptr,
                 long ldb = 0, const float *bcoef = nullptr, int brelu = 0, int *partial_rows = nullptr);
 int try_wgrad(long n, int k, int o, int ng, const float *const *g, long ldg, const float *x, long ldx, const float *scale,
-              const float *shift, int relu, float *const *dw, float *const *db, hipStream_t s, const float *roww = nullptr, long rws = 0);
+              const float *shift, int relu, float *const *dw, float *const *db, float *ws, hipStream_t s, const float *roww = nullptr, long rws = 0);
+long wgrad_ws_floats(long n, int k, int o, int ng);
+struct RArgs {
+    const float *slab, *bslab;
+    float *dW[3], *db[3];
+    int B, tiles_k, tiles, otiles, split, K, O;
+};
+void launch_slab_reduce(const RArgs &a, int ng, bool any_bias, hipStream_t s);
 int stats_rows(long n);
 }  // namespace rl2
+
+// split of the tiled weight-gradient kernel (shapes outside the streaming kernels)
+static inline void tiled_wg_plan(long n, int k, int o, int *blocks_oc, long *split, long *rows_per_block) {
+    *blocks_oc = ((o + 31) / 32) * ((k + 31) / 32);
+    long sp = (2048 + *blocks_oc - 1) / *blocks_oc;           // ~2048 workgroups in flight
+    const long max_split = (n + 255) / 256;                   // at least 256 rows per workgroup
+    if (sp > max_split) sp = max_split;
+    if (sp < 1) sp = 1;
+    *rows_per_block = ((n + sp - 1) / sp + 31) / 32 * 32;
+    *split = (n + *rows_per_block - 1) / *rows_per_block;
+}
 
 static inline bool rowlin_streams(int k, int o) {
     return (k == 32 || k == 64 || k == 128 || k == 256 || k == 512) && o % 16 == 0 && getenv("PDFOPS_ROWLIN_TILED") == nullptr;
@@ -224,25 +246,39 @@ extern "C" int pdf_rowlin_forward(long n, int k, int o, const float *x, long ldx
     return pdf_launch_status();
 }
 
-// dW (o, k) += G^T f(X), db (o) += column sums of G; both pre-zeroed by the caller (db may be null).
+// Workspace of the weight-gradient entry points, in floats: every workgroup stores its partial block of dW into its own slab, a second
+// launch sums the slabs in a fixed order -- no float atomics, bit-reproducible gradients (ng = number of gradients of a _multi call).
+extern "C" long pdf_rowlin_wgrad_ws_floats(long n, int k, int o, int ng) {
+    if (n < 1 || k < 1 || o < 1 || ng < 1) return 0;
+    int blocks_oc; long split, rpb;
+    tiled_wg_plan(n, k, o, &blocks_oc, &split, &rpb);
+    const long tiled = (long)blocks_oc * split * 4 * 1024 + (long)((o + 31) / 32) * split * 4 * 32;   // (_multi falls back to ng single calls)
+    const long streaming = rowlin_streams(k, o) ? rl2::wgrad_ws_floats(n, k, o, ng) : 0;
+    return tiled > streaming ? tiled : streaming;
+}
+
+// dW (o, k) = G^T f(X), db (o) = column sums of G (db may be null); both are WRITTEN.  ws: pdf_rowlin_wgrad_ws_floats(n, k, o, 1) floats.
 extern "C" int pdf_rowlin_wgrad(long n, int k, int o, const float *g, long ldg, const float *x, long ldx,
-                                const float *scale, const float *shift, int relu, float *dw, float *db, void *stream) {
-    if (n < 1 || k < 1 || o < 1 || !g || !x || !dw || ldg < o || ldx < k) return PDF_ERR_BAD_ARG;
-    if (rowlin_streams(k, o) && rl2::try_wgrad(n, k, o, 1, &g, ldg, x, ldx, scale, shift, relu, &dw, &db, static_cast<hipStream_t>(stream)))
+                                const float *scale, const float *shift, int relu, float *dw, float *db, float *ws, void *stream) {
+    if (n < 1 || k < 1 || o < 1 || !g || !x || !dw || !ws || ldg < o || ldx < k) return PDF_ERR_BAD_ARG;
+    if (rowlin_streams(k, o) && rl2::try_wgrad(n, k, o, 1, &g, ldg, x, ldx, scale, shift, relu, &dw, &db, ws, static_cast<hipStream_t>(stream)))
         return pdf_launch_status();
     rl::WArgs a;
     a.N = n; a.K = k; a.O = o; a.G = g; a.ldg = ldg; a.X = x; a.ldx = ldx; a.scale = scale; a.shift = shift; a.relu = relu;
     a.dW = dw; a.db = db;
-    const int blocks_oc = ((o + 31) / 32) * ((k + 31) / 32);
-    long split = (2048 + blocks_oc - 1) / blocks_oc;          // ~2048 workgroups in flight
-    const long max_split = (n + 255) / 256;                   // at least 256 rows per workgroup
-    if (split > max_split) split = max_split;
-    if (split < 1) split = 1;
-    a.rows_per_block = ((n + split - 1) / split + 31) / 32 * 32;
-    const dim3 grid((unsigned)((n + a.rows_per_block - 1) / a.rows_per_block), (unsigned)blocks_oc);
+    int blocks_oc; long split;
+    tiled_wg_plan(n, k, o, &blocks_oc, &split, &a.rows_per_block);
+    a.slab = ws;
+    a.bslab = ws + (size_t)blocks_oc * split * 4 * 1024;
+    const dim3 grid((unsigned)split, (unsigned)blocks_oc);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (scale) rl::k_wgrad<true><<<grid, 256, 0, s>>>(a);
     else rl::k_wgrad<false><<<grid, 256, 0, s>>>(a);
+    rl2::RArgs r;
+    r.slab = a.slab; r.bslab = a.bslab; r.B = 32; r.tiles_k = (k + 31) / 32; r.tiles = blocks_oc; r.otiles = (o + 31) / 32; r.split = (int)(split * 4);
+    r.K = k; r.O = o;
+    r.dW[0] = dw; r.db[0] = db; r.dW[1] = r.dW[2] = nullptr; r.db[1] = r.db[2] = nullptr;
+    rl2::launch_slab_reduce(r, 1, db != nullptr, s);
     return pdf_launch_status();
 }
 
@@ -286,15 +322,16 @@ extern "C" int pdf_rowlin_dgrad_bstats(long n, int k, int o, int nin, const floa
     return pdf_launch_status();
 }
 
-// dW[i] += G[i]^T f(X), db[i] += column sums of G[i] for up to three gradients sharing the layer input X.
+// dW[i] = G[i]^T f(X), db[i] = column sums of G[i] for up to three gradients sharing the layer input X (written).
+// ws: pdf_rowlin_wgrad_ws_floats(n, k, o, ng) floats.
 extern "C" int pdf_rowlin_wgrad_multi(long n, int k, int o, int ng, const float *const *g, long ldg, const float *x, long ldx,
                                       const float *scale, const float *shift, int relu, float *const *dw, float *const *db,
-                                      void *stream) {
-    if (n < 1 || k < 1 || o < 1 || ng < 1 || ng > 3 || !g || !x || !dw) return PDF_ERR_BAD_ARG;
-    if (rowlin_streams(k, o) && rl2::try_wgrad(n, k, o, ng, g, ldg, x, ldx, scale, shift, relu, dw, db, static_cast<hipStream_t>(stream)))
+                                      float *ws, void *stream) {
+    if (n < 1 || k < 1 || o < 1 || ng < 1 || ng > 3 || !g || !x || !dw || !ws) return PDF_ERR_BAD_ARG;
+    if (rowlin_streams(k, o) && rl2::try_wgrad(n, k, o, ng, g, ldg, x, ldx, scale, shift, relu, dw, db, ws, static_cast<hipStream_t>(stream)))
         return pdf_launch_status();
-    int rc = 0;
-    for (int i = 0; i < ng && rc == 0; ++i) rc = pdf_rowlin_wgrad(n, k, o, g[i], ldg, x, ldx, scale, shift, relu, dw[i], db ? db[i] : nullptr, stream);
+    int rc = 0;   // (stream order: the next call reuses the workspace after this call's reduction has read it)
+    for (int i = 0; i < ng && rc == 0; ++i) rc = pdf_rowlin_wgrad(n, k, o, g[i], ldg, x, ldx, scale, shift, relu, dw[i], db ? db[i] : nullptr, ws, stream);
     return rc;
 }
 
@@ -310,10 +347,10 @@ extern "C" int pdf_rowlin_forward_roww(long n, int k, int o, const float *x, lon
     return pdf_launch_status();
 }
 extern "C" int pdf_rowlin_wgrad_roww(long n, int k, int o, const float *g, long ldg, const float *x, long ldx, float *dw, const float *roww,
-                                     long rws, void *stream) {
-    if (n < 1 || !g || !x || !dw || !rowlin_streams(k, o)) return PDF_ERR_UNSUPPORTED;
+                                     long rws, float *ws, void *stream) {
+    if (n < 1 || !g || !x || !dw || !ws || !rowlin_streams(k, o)) return PDF_ERR_UNSUPPORTED;
     float *db = nullptr;
-    if (!rl2::try_wgrad(n, k, o, 1, &g, ldg, x, ldx, nullptr, nullptr, 0, &dw, &db, static_cast<hipStream_t>(stream), roww, rws))
+    if (!rl2::try_wgrad(n, k, o, 1, &g, ldg, x, ldx, nullptr, nullptr, 0, &dw, &db, ws, static_cast<hipStream_t>(stream), roww, rws))
         return PDF_ERR_UNSUPPORTED;
     return pdf_launch_status();
 }

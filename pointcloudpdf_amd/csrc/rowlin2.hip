@@ -15,7 +15,9 @@
 //   weight gradient (k_wg):  dW[o, k] += sum_n G[n, o] f(X[n, k]),  db[o] += sum_n G[n, o]
 //     reduction index = rows: lane (i = l & 15, nq = l >> 4) loads VW consecutive channels of row n0 + nq of G and of X;
 //     MFMA (c, c') accumulates the 16x16 sub-block {o = VW i + c} x {k = VW j + c'}: VW^2 MFMAs per 4 rows cover a
-//     (16 VW)^2 block of dW.  Waves reduce through LDS atomics, blocks through global atomics (dW pre-zeroed).
+//     (16 VW)^2 block of dW.  Waves reduce through LDS, every workgroup stores its block into its own SLAB of a caller-owned workspace,
+//     and k_slab_reduce sums the slabs of a block in a fixed order (round 3: no float atomics -- bit-reproducible gradients; dW is
+//     written, not accumulated).
 //
 // fp32 in / fp32 accumulate (bit-equal to an fmaf chain): the reference computes these layers in fp32.
 #include "pdfops_common.h"
@@ -211,6 +213,8 @@ struct WArgs {
     float *dW[3], *db[3];
     long rows_per_block;     // multiple of 64
     const float *roww; long rws;   // optional per-row weight of G (dW = sum_n roww[n] G[n]^T f(X[n]))
+    float *slab;             // [gridDim.z][gridDim.y][gridDim.x][(16 VW)^2]: one block of dW per workgroup
+    float *bslab;            // [gridDim.z][O / (16 VW)][gridDim.x][16 VW]: the workgroup's column sums of G (bias gradient), k-block 0 only
 };
 
 template <int VW> struct Vec;
@@ -302,11 +306,83 @@ __global__ __launch_bounds__(256) void k_wg(WArgs a) {
         }
     }
     __syncthreads();
-    float *dW = a.dW[blockIdx.z];
-    for (int e = threadIdx.x; e < B * B; e += 256)
-        pdf_atomic_add(dW + (long)(ob + e / B) * a.K + kb + e % B, (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]));
+    float *slab = a.slab + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (B * B);
+    for (int e = threadIdx.x; e < B * B; e += 256) slab[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
     if (want_db && threadIdx.x < B)
-        pdf_atomic_add(db + ob + threadIdx.x, (redb[0][threadIdx.x] + redb[1][threadIdx.x]) + (redb[2][threadIdx.x] + redb[3][threadIdx.x]));
+        a.bslab[(((size_t)blockIdx.z * (a.O / B) + ob / B) * gridDim.x + blockIdx.x) * B + threadIdx.x] =
+            (redb[0][threadIdx.x] + redb[1][threadIdx.x]) + (redb[2][threadIdx.x] + redb[3][threadIdx.x]);
+}
+
+// Sum of the `split` slabs of every dW block (and bias block) in a fixed order: lane l of an element adds slabs l, l + L, l + 2L, ...,
+// the L partial sums are combined in lane order.  grid = (ceil(B^2 / 64), tiles + bias tiles, ng), 64 L threads.  Works for the tiled
+// kernel of rowlin.hip as well (B = 32, edge blocks masked by O / K).
+struct RArgs {
+    const float *slab, *bslab;
+    float *dW[3], *db[3];
+    int B, tiles_k, tiles, otiles, split, K, O;
+};
+template <int L>
+__global__ __launch_bounds__(64 * L) void k_slab_reduce(RArgs a) {
+    __shared__ float red[L][64];
+    const int e = threadIdx.x & 63, l = threadIdx.x >> 6, z = blockIdx.z;
+    const int ei = blockIdx.x * 64 + e;
+    const bool bias = (int)blockIdx.y >= a.tiles;
+    const int t = bias ? (int)blockIdx.y - a.tiles : (int)blockIdx.y;
+    const int len = bias ? a.B : a.B * a.B;
+    if (bias && (int)blockIdx.x * 64 >= len) return;   // (uniform per block)
+    const float *src = bias ? a.bslab + ((size_t)z * a.otiles + t) * a.split * a.B : a.slab + ((size_t)z * a.tiles + t) * a.split * (size_t)(a.B * a.B);
+    float s = 0.f;
+    if (ei < len) {
+        int k = l;
+        for (; k + 3 * L < a.split; k += 4 * L) {   // four loads in flight per lane
+            const float v0 = src[(size_t)k * len + ei], v1 = src[(size_t)(k + L) * len + ei];
+            const float v2 = src[(size_t)(k + 2 * L) * len + ei], v3 = src[(size_t)(k + 3 * L) * len + ei];
+            s = (((s + v0) + v1) + v2) + v3;
+        }
+        for (; k < a.split; k += L) s += src[(size_t)k * len + ei];
+    }
+    red[l][e] = s;
+    __syncthreads();
+    if (l != 0 || ei >= len) return;
+#pragma unroll
+    for (int k = 1; k < L; ++k) s += red[k][e];
+    if (bias) {
+        const int o = t * a.B + ei;
+        if (a.db[z] && o < a.O) a.db[z][o] = s;
+    } else {
+        const int o = (t / a.tiles_k) * a.B + ei / a.B, kk = (t % a.tiles_k) * a.B + ei % a.B;
+        if (o < a.O && kk < a.K) a.dW[z][(size_t)o * a.K + kk] = s;
+    }
+}
+
+void launch_slab_reduce(const RArgs &a, int ng, bool any_bias, hipStream_t s) {
+    const dim3 grid((unsigned)((a.B * a.B + 63) / 64), (unsigned)(a.tiles + (any_bias ? a.otiles : 0)), (unsigned)ng);
+    if (a.split > 32) k_slab_reduce<16><<<grid, 64 * 16, 0, s>>>(a);
+    else if (a.split > 4) k_slab_reduce<4><<<grid, 64 * 4, 0, s>>>(a);
+    else k_slab_reduce<1><<<grid, 64, 0, s>>>(a);
+}
+
+// split of the row range for (n, k, o, ng): workgroups in flight vs rows per workgroup (shared by the launch and the workspace size)
+struct WgPlan { int vw, b, nblk; long split, rows_per_block; };
+static WgPlan wg_plan(long n, int k, int o, int ng) {
+    WgPlan p;
+    p.vw = (k % 64 == 0 && o % 64 == 0) ? 4 : ((k % 32 == 0 && o % 32 == 0) ? 2 : 0);
+    p.b = 16 * p.vw;
+    if (!p.vw) { p.nblk = 0; p.split = 0; p.rows_per_block = 0; return p; }
+    p.nblk = (o / p.b) * (k / p.b) * ng;
+    static const int target = [] { const char *v = getenv("PDFOPS_WG_BLOCKS"); const int x = v ? atoi(v) : 0; return x > 0 ? x : 512; }();
+    long split = (target + p.nblk - 1) / p.nblk;       // workgroups in flight
+    const long max_split = (n + 255) / 256;            // at least 256 rows (4 trips per wave) per workgroup
+    if (split > max_split) split = max_split;
+    if (split < 1) split = 1;
+    p.rows_per_block = ((n + split - 1) / split + 63) / 64 * 64;
+    p.split = (n + p.rows_per_block - 1) / p.rows_per_block;
+    return p;
+}
+long wgrad_ws_floats(long n, int k, int o, int ng) {
+    const WgPlan p = wg_plan(n, k, o, ng);
+    if (!p.vw) return 0;
+    return (long)p.nblk * p.split * p.b * p.b + (long)ng * (o / p.b) * p.split * p.b;
 }
 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -385,29 +461,35 @@ int try_forward(long n, int k, int o, int nin, int nout, const float *const *x, 
 }
 
 int try_wgrad(long n, int k, int o, int ng, const float *const *g, long ldg, const float *x, long ldx, const float *scale,
-              const float *shift, int relu, float *const *dw, float *const *db, hipStream_t s, const float *roww, long rws) {
-    if (ng < 1 || ng > 3) return 0;
-    const int vw = (k % 64 == 0 && o % 64 == 0) ? 4 : ((k % 32 == 0 && o % 32 == 0) ? 2 : 0);
+              const float *shift, int relu, float *const *dw, float *const *db, float *ws, hipStream_t s, const float *roww, long rws) {
+    if (ng < 1 || ng > 3 || !ws) return 0;
+    const WgPlan p = wg_plan(n, k, o, ng);
+    const int vw = p.vw;
     if (!vw) return 0;
     if ((ldg % vw) || (ldx % vw) || !aligned16(x)) return 0;
     if (scale && (!aligned16(scale) || !aligned16(shift))) return 0;
     for (int i = 0; i < ng; ++i) if (!aligned16(g[i])) return 0;
     WArgs a;
     a.N = n; a.K = k; a.O = o; a.ldg = ldg; a.X = x; a.ldx = ldx; a.scale = scale; a.shift = shift; a.relu = relu; a.roww = roww; a.rws = rws;
-    for (int i = 0; i < 3; ++i) { a.G[i] = i < ng ? g[i] : nullptr; a.dW[i] = i < ng ? dw[i] : nullptr; a.db[i] = (db && i < ng) ? db[i] : nullptr; }
-    const int b = 16 * vw, nblk = (o / b) * (k / b) * ng;
-    static const int target = [] { const char *v = getenv("PDFOPS_WG_BLOCKS"); const int x = v ? atoi(v) : 0; return x > 0 ? x : 512; }();
-    long split = (target + nblk - 1) / nblk;           // workgroups in flight (every one ends with (16 VW)^2 global atomics)
-    const long max_split = (n + 255) / 256;            // at least 256 rows (4 trips per wave) per workgroup
-    if (split > max_split) split = max_split;
-    if (split < 1) split = 1;
-    a.rows_per_block = ((n + split - 1) / split + 63) / 64 * 64;
-    const dim3 grid((unsigned)((n + a.rows_per_block - 1) / a.rows_per_block), (unsigned)((o / b) * (k / b)), (unsigned)ng);
+    bool any_bias = false;
+    for (int i = 0; i < 3; ++i) {
+        a.G[i] = i < ng ? g[i] : nullptr; a.dW[i] = i < ng ? dw[i] : nullptr; a.db[i] = (db && i < ng) ? db[i] : nullptr;
+        any_bias = any_bias || a.db[i] != nullptr;
+    }
+    const int b = p.b;
+    a.rows_per_block = p.rows_per_block;
+    a.slab = ws;
+    a.bslab = ws + (size_t)p.nblk * p.split * b * b;
+    const dim3 grid((unsigned)p.split, (unsigned)((o / b) * (k / b)), (unsigned)ng);
 #define PDF_WG(VW_) do { \
         if (roww) { if (scale) k_wg<VW_, true, true><<<grid, 256, 0, s>>>(a); else k_wg<VW_, false, true><<<grid, 256, 0, s>>>(a); } \
         else      { if (scale) k_wg<VW_, true, false><<<grid, 256, 0, s>>>(a); else k_wg<VW_, false, false><<<grid, 256, 0, s>>>(a); } } while (0)
     if (vw == 4) PDF_WG(4); else PDF_WG(2);
 #undef PDF_WG
+    RArgs r;
+    r.slab = a.slab; r.bslab = a.bslab; r.B = b; r.tiles_k = k / b; r.tiles = (o / b) * (k / b); r.otiles = o / b; r.split = (int)p.split; r.K = k; r.O = o;
+    for (int i = 0; i < 3; ++i) { r.dW[i] = a.dW[i]; r.db[i] = a.db[i]; }
+    launch_slab_reduce(r, ng, any_bias, s);
     return 1;
 }
 

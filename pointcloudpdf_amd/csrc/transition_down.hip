@@ -278,12 +278,63 @@ __global__ __launch_bounds__(64 * WPB) void k_td_din(int M, int cout, const floa
     }
 }
 
+// ---------------------------------------------------------------------------------------------------- backward: sparse input gradient, destination order
+// The same sum as k_td_din without atomics (round 3: bit-reproducible): gx[v, :] += sum over the entries (m, j) of the grouping table that
+// gather source point v -- ascending entry id, from the INVERSE table (csrc/seg_gather.hip layout) -- of
+//     sum_{c : arg[m, c] == j and out[m, c] > 0} s_c g[m, c] W[c, 3 + :].
+// The product is sparse (one arg-max neighbour per (m, c): ~cout / 16 channels hit per entry), so the dense MFMA form would spend
+// 15/16 of its work on zeros: one wave = one source point, lanes = the 64 channels of a chunk for the hit test (ballot), then lanes =
+// features for the few hit rows of W.  Every element of gx is owned by one lane: plain read-modify-write, fixed order.
+template <int CIN>
+__global__ __launch_bounds__(64 * WPB) void k_td_din_dst(int n, int cout, const float *__restrict__ gout, const float *__restrict__ out,
+                                                         const unsigned char *__restrict__ arg, const float *__restrict__ W,
+                                                         const float *__restrict__ coef, const int *__restrict__ inv_off,
+                                                         const int *__restrict__ inv_entry, int entry_base, float *__restrict__ gx) {
+    constexpr int NQ = (CIN + 63) / 64, D = 3 + CIN;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long wave_g = (long)blockIdx.x * WPB + wv, nwaves = (long)gridDim.x * WPB;
+    for (long v = wave_g; v < n; v += nwaves) {
+        const int beg = inv_off[v], end = inv_off[v + 1];
+        float acc[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = 0.f;
+        for (int p = beg; p < end; ++p) {
+            const int e = inv_entry[p] - entry_base;
+            const long m = e >> 4;
+            const int j = e & 15;
+            for (int cb = 0; cb < cout; cb += 64) {
+                const int c = cb + lane;
+                const size_t at = (size_t)m * cout + c;
+                const int a = arg[at];
+                const float o = out[at], g = gout[at], sc = coef[c];
+                const bool hit = a == j && o > 0.f;
+                const float val = sc * g;
+                unsigned long long mask = __ballot(hit);
+                while (mask) {
+                    const int b = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const float sv = __shfl(val, b, 64);
+                    const float *wrow = W + (size_t)(cb + b) * D + 3;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+                        if (lane + 64 * q < CIN) acc[q] += sv * wrow[lane + 64 * q];
+                }
+            }
+        }
+        if (end > beg) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (lane + 64 * q < CIN) gx[(size_t)v * CIN + lane + 64 * q] += acc[q];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------- backward: sparse weight gradient
 // dW[c][col] += sum_m sum_k [k == arg[m,c]] s_c g'[m,c] in[(m,k)][col]:  a weight-gradient product whose reduction index runs over the
 // m*16 rows without materialising them.  One block = a 64 x 64 block of dW (columns in feature-first order: [x (cin) | rel (3) | pad]).
 __global__ __launch_bounds__(256) void k_td_wg(int M, int cin, int cout, const float *__restrict__ gout, const float *__restrict__ out,
                                                const unsigned char *__restrict__ arg, const int *__restrict__ idx, const float *__restrict__ rel4,
-                                               const float *__restrict__ x, const float *__restrict__ coef, float *__restrict__ dW,
+                                               const float *__restrict__ x, const float *__restrict__ coef, float *__restrict__ slab,
                                                long points_per_block) {
     __shared__ float red[4][64 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -348,13 +399,31 @@ __global__ __launch_bounds__(256) void k_td_wg(int M, int cin, int cout, const f
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[wave][(4 * (4 * nq + r) + a) * 64 + 4 * li + b] = acc[a][b][r];
     __syncthreads();
-    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
-        const int o = ob + e / 64, cc = kb + e % 64;   // feature-first column -> W's column (rel first)
-        if (cc >= cin + 3) continue;
-        const int wc = cc < cin ? 3 + cc : cc - cin;
-        const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-        if (v != 0.f) pdf_atomic_add(dW + (size_t)o * d + wc, v);
-    }
+    // the workgroup's 64 x 64 block goes to its own slab [block of dW][row-range][64 * 64]; k_td_wg_reduce adds the slabs in order
+    float *dst = slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (64 * 64);
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) dst[e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    (void)d;
+}
+
+// dW[o][wc] += sum over the row-range slabs (fixed order) of the 64 x 64 blocks; feature-first column cc -> W's column wc (rel first).
+// dW already holds the dense part (k_td_small1).  grid = (64, blocks of dW), 256 threads = 64 elements x 4 slab-lanes.
+__global__ __launch_bounds__(256) void k_td_wg_reduce(int cin, int cout, const float *__restrict__ slab, int split, float *__restrict__ dW) {
+    __shared__ float red[4][64];
+    const int e64 = threadIdx.x & 63, l = threadIdx.x >> 6;
+    const int nkb = (cin + 4 + 63) / 64;
+    const int ob = (blockIdx.y / nkb) * 64, kb = (blockIdx.y % nkb) * 64;
+    const int e = blockIdx.x * 64 + e64;
+    const float *src = slab + (size_t)blockIdx.y * split * (64 * 64) + e;
+    float s = 0.f;
+    for (int k = l; k < split; k += 4) s += src[(size_t)k * (64 * 64)];
+    red[l][e64] = s;
+    __syncthreads();
+    if (l != 0) return;
+    s = ((red[0][e64] + red[1][e64]) + red[2][e64]) + red[3][e64];
+    const int o = ob + e / 64, cc = kb + e % 64;
+    if (cc >= cin + 3) return;
+    const int wc = cc < cin ? 3 + cc : cc - cin;
+    dW[(size_t)o * (3 + cin) + wc] += s;
 }
 
 template <typename KernelT>
@@ -377,13 +446,32 @@ extern "C" int pdf_td_supported(int nsample, int cin, int cout) {
 }
 // scratch floats of the forward (Gram blocks, kept for the backward): gxx (cin*cin) | gz (32*cin)
 extern "C" long pdf_td_gram_floats(int cin) { return (long)cin * cin + 32L * cin; }
+// split of the sparse weight-gradient kernel's point range (k_td_wg): workgroups in flight vs points per workgroup
+static inline void td_wg_plan(long m, int cin, int cout, int *nblk, long *split, long *ppb) {
+    *nblk = (cout / 64) * ((cin + 4 + 63) / 64);
+    long sp = (512 + *nblk - 1) / *nblk;
+    const long max_split = (m + 63) / 64;
+    if (sp > max_split) sp = max_split;
+    if (sp < 1) sp = 1;
+    *ppb = ((m + sp - 1) / sp + 15) / 16 * 16;
+    *split = (m + *ppb - 1) / *ppb;
+}
+// scratch floats of the forward: slabs of the two Gram products (pdf_rowlin_wgrad_ws_floats)
+extern "C" long pdf_td_fwd_scratch_floats(long n, int cin) {
+    const long a = pdf_rowlin_wgrad_ws_floats(n, cin, cin, 1), b = pdf_rowlin_wgrad_ws_floats(n, cin, 32, 1);
+    return a > b ? a : b;
+}
 // scratch floats of the backward: fake coef (4 cout) | AB (2 cout) | Qp (cin*cin) | QqT (cin*32) | partial (pdf_bn_partial_floats(m, cout))
+// | slabs of the sparse weight gradient (blocks x row ranges x 64 x 64)
 extern "C" long pdf_td_bwd_scratch_floats(long m, int cin, int cout) {
-    return 6L * cout + (long)cin * cin + 32L * cin + pdf_bn_partial_floats(m, cout);
+    int nblk; long split, ppb;
+    td_wg_plan(m, cin, cout, &nblk, &split, &ppb);
+    return 6L * cout + (long)cin * cin + 32L * cin + pdf_bn_partial_floats(m, cout) + (long)nblk * split * 64 * 64;
 }
 
 // Forward.  p[]: 0 x (n,cin) | 1 idx (m,16) | 2 rel4 (m,16,4) | 3 Z (n,32) = [R | cnt | 0] | 4 consts (16) = [S_rr | s_r] | 5 W (cout, 3+cin)
 //   6 gamma 7 beta 8 running_mean 9 running_var | outputs: 10 coef (4 cout) 11 out (m,cout) 12 arg (m,cout) u8 13 gram (pdf_td_gram_floats)
+//   14 scratch (pdf_td_fwd_scratch_floats(n, cin); training only)
 extern "C" int pdf_td_forward(long n, long m, int cin, int cout, void *const *p, int training, float eps, float momentum, void *stream) {
     if (n < 1 || m < 1 || !p) return PDF_ERR_BAD_ARG;
     if (!pdf_td_supported(16, cin, cout)) return PDF_ERR_UNSUPPORTED;
@@ -394,11 +482,10 @@ extern "C" int pdf_td_forward(long n, long m, int cin, int cout, void *const *p,
     float *coef = (float *)p[10], *out = (float *)p[11], *gxx = (float *)p[13], *gz = gxx + (size_t)cin * cin;
     int rc = 0;
     if (training) {
-        hipError_t e = hipMemsetAsync(gxx, 0, sizeof(float) * (size_t)pdf_td_gram_floats(cin), s);
-        if (e != hipSuccess) return (int)e;
-        rc = pdf_rowlin_wgrad_roww(n, cin, cin, x, cin, x, cin, gxx, Z + 3, 32, stream);       // x^T diag(cnt) x
+        if (!p[14]) return PDF_ERR_BAD_ARG;
+        rc = pdf_rowlin_wgrad_roww(n, cin, cin, x, cin, x, cin, gxx, Z + 3, 32, (float *)p[14], stream);       // x^T diag(cnt) x (written)
         if (rc) return rc;
-        rc = pdf_rowlin_wgrad_roww(n, cin, 32, Z, 32, x, cin, gz, nullptr, 0, stream);        // [R | cnt]^T x
+        rc = pdf_rowlin_wgrad_roww(n, cin, 32, Z, 32, x, cin, gz, nullptr, 0, (float *)p[14], stream);        // [R | cnt]^T x
         if (rc) return rc;
         td::k_td_coef<<<cout, 256, 0, s>>>(cin, cout, (double)m * 16.0, W, consts, gz, gxx, gamma, beta, eps, momentum, (float *)p[8],
                                            (float *)p[9], coef);
@@ -415,7 +502,10 @@ extern "C" int pdf_td_forward(long n, long m, int cin, int cout, void *const *p,
 
 // Backward (training mode).  p[]: 0 gout (m,cout) | 1 out | 2 arg | 3 x | 4 idx | 5 rel4 | 6 Z | 7 consts | 8 W | 9 gamma | 10 beta | 11 coef
 //   12 gram (from the forward) | outputs: 13 gx (n,cin) 14 dW (cout, 3+cin) 15 dgb (2 cout) = [d beta | d gamma] | 16 scratch
-extern "C" int pdf_td_backward(long n, long m, int cin, int cout, void *const *p, void *stream) {
+//   17 inv_off (n + 1), 18 inv_entry: the INVERSE of the grouping table idx (entries i * 16 + j grouped by source point, ascending inside a
+//   point; csrc/seg_gather.hip), entry ids offset by entry_base: the sparse input gradient then runs in destination order without
+//   atomics (bit-reproducible); both null: the scatter kernel with float atomics (not reproducible run to run)
+extern "C" int pdf_td_backward(long n, long m, int cin, int cout, void *const *p, int entry_base, void *stream) {
     if (n < 1 || m < 1 || !p) return PDF_ERR_BAD_ARG;
     if (!pdf_td_supported(16, cin, cout)) return PDF_ERR_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -436,18 +526,24 @@ extern "C" int pdf_td_backward(long n, long m, int cin, int cout, void *const *p
     if (rc) return rc;
     rc = pdf_rowlin_forward_roww(n, 32, cin, Z, 32, QqT, 0, gx, cin, 1, nullptr, 0, stream);     // gx += Z QqT^T
     if (rc) return rc;
-    const dim3 grid(td::grid_points(m, 1024), cout / 64);
+    if (p[17] && p[18]) {
+        const int *inv_off = (const int *)p[17], *inv_entry = (const int *)p[18];
+        const int g = td::grid_points(n, 2048);
+#define PDF_TD_DST(CIN_) td::k_td_din_dst<CIN_><<<g, 64 * td::WPB, 0, s>>>((int)n, cout, gout, out, arg, W, coef, inv_off, inv_entry, entry_base, gx)
+        if (cin == 32) PDF_TD_DST(32); else if (cin == 64) PDF_TD_DST(64); else if (cin == 128) PDF_TD_DST(128); else PDF_TD_DST(256);
+#undef PDF_TD_DST
+    } else {
+        const dim3 grid(td::grid_points(m, 1024), cout / 64);
 #define PDF_TD_DIN(CIN_) do { const size_t lds = sizeof(float) * (64 * (CIN_ + 4)) + sizeof(int) * 16 * td::WPB; td::set_lds(td::k_td_din<CIN_>, lds); \
         td::k_td_din<CIN_><<<grid, 64 * td::WPB, lds, s>>>((int)m, cout, gout, out, arg, idx, W, coef, gx); } while (0)
-    if (cin == 32) PDF_TD_DIN(32); else if (cin == 64) PDF_TD_DIN(64); else if (cin == 128) PDF_TD_DIN(128); else PDF_TD_DIN(256);
+        if (cin == 32) PDF_TD_DIN(32); else if (cin == 64) PDF_TD_DIN(64); else if (cin == 128) PDF_TD_DIN(128); else PDF_TD_DIN(256);
 #undef PDF_TD_DIN
-    const int nblk = (cout / 64) * ((cin + 4 + 63) / 64);
-    long split = (512 + nblk - 1) / nblk;
-    const long max_split = (m + 63) / 64;
-    if (split > max_split) split = max_split;
-    if (split < 1) split = 1;
-    const long ppb = ((m + split - 1) / split + 15) / 16 * 16;
-    td::k_td_wg<<<dim3((unsigned)((m + ppb - 1) / ppb), nblk), 256, 0, s>>>((int)m, cin, cout, gout, out, arg, idx, rel4, x, coef, dW, ppb);
+    }
+    int nblk; long split, ppb;
+    td_wg_plan(m, cin, cout, &nblk, &split, &ppb);
+    float *slab = partial + pdf_bn_partial_floats(m, cout);
+    td::k_td_wg<<<dim3((unsigned)split, nblk), 256, 0, s>>>((int)m, cin, cout, gout, out, arg, idx, rel4, x, coef, slab, ppb);
+    td::k_td_wg_reduce<<<dim3(64, nblk), 256, 0, s>>>(cin, cout, slab, (int)split, dW);
     return pdf_launch_status();
 }
 
@@ -456,6 +552,23 @@ extern "C" int pdf_td_backward(long n, long m, int cin, int cout, void *const *p
 // (The twelve per-scene moments of rel are formed by the host side from rel4 with a prefix sum: atomics onto a dozen
 // addresses from 75k waves cost 20 ms.)
 namespace td {
+// Z in destination order (no atomics): one lane per source point walks its entries of the inverse table in ascending entry id.
+__global__ __launch_bounds__(256) void k_td_z_dst(long n, const float *__restrict__ p_src, const float *__restrict__ p_new,
+                                                  const int *__restrict__ inv_off, const int *__restrict__ inv_entry, int entry_base,
+                                                  float *__restrict__ Z) {
+    const long v = (long)blockIdx.x * 256 + threadIdx.x;
+    if (v >= n) return;
+    const int beg = inv_off[v], end = inv_off[v + 1];
+    const float sx = p_src[v * 3], sy = p_src[v * 3 + 1], sz = p_src[v * 3 + 2];
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (int p = beg; p < end; ++p) {
+        const long mq = (inv_entry[p] - entry_base) >> 4;
+        ax += sx - p_new[mq * 3]; ay += sy - p_new[mq * 3 + 1]; az += sz - p_new[mq * 3 + 2];
+    }
+    *reinterpret_cast<f32x4 *>(Z + v * 32) = f32x4{ax, ay, az, (float)(end - beg)};
+}
+
+template <bool ZATOMIC>
 __global__ __launch_bounds__(256) void k_td_tables(long m, int b, const float *__restrict__ p_src, const float *__restrict__ p_new,
                                                    const int *__restrict__ idx, const int *__restrict__ new_offset, float *__restrict__ rel4,
                                                    float *__restrict__ Z, float *__restrict__ scene_sums) {
@@ -468,18 +581,28 @@ __global__ __launch_bounds__(256) void k_td_tables(long m, int b, const float *_
         if (nb >= 0) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) rel[a] = p_src[(size_t)nb * 3 + a] - p_new[(size_t)pt * 3 + a];
-            float *z = Z + (size_t)nb * 32;
-            pdf_atomic_add(z + 0, rel[0]); pdf_atomic_add(z + 1, rel[1]); pdf_atomic_add(z + 2, rel[2]); pdf_atomic_add(z + 3, 1.f);
+            if (ZATOMIC) {
+                float *z = Z + (size_t)nb * 32;
+                pdf_atomic_add(z + 0, rel[0]); pdf_atomic_add(z + 1, rel[1]); pdf_atomic_add(z + 2, rel[2]); pdf_atomic_add(z + 3, 1.f);
+            }
         }
         *reinterpret_cast<f32x4 *>(rel4 + r * 4) = f32x4{rel[0], rel[1], rel[2], 0.f};
     }
 }
 }  // namespace td
 
-// rel4 (m,16,4), Z (n,32) and scene_sums (b,16) -- the last two zeroed by the caller
+// rel4 (m,16,4), Z (n,32) and scene_sums (b,16) -- the last two zeroed by the caller.  With the inverse of idx (inv_off (n + 1), inv_entry,
+// entry_base; csrc/seg_gather.hip) Z is summed in destination order (fixed order, bit-reproducible); without it (both null) by float atomics.
 extern "C" int pdf_td_tables(long m, int b, const float *p_src, const float *p_new, const int *idx, const int *new_offset, float *rel4, float *Z,
-                             float *scene_sums, void *stream) {
+                             float *scene_sums, long n, const int *inv_off, const int *inv_entry, int entry_base, void *stream) {
     if (m < 1 || b < 1 || !p_src || !p_new || !idx || !new_offset || !rel4 || !Z || !scene_sums) return PDF_ERR_BAD_ARG;
-    td::k_td_tables<<<(unsigned)((m * 16 + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(m, b, p_src, p_new, idx, new_offset, rel4, Z, scene_sums);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (inv_off && inv_entry) {
+        if (n < 1) return PDF_ERR_BAD_ARG;
+        td::k_td_tables<false><<<(unsigned)((m * 16 + 255) / 256), 256, 0, s>>>(m, b, p_src, p_new, idx, new_offset, rel4, Z, scene_sums);
+        td::k_td_z_dst<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(n, p_src, p_new, inv_off, inv_entry, entry_base, Z);
+    } else {
+        td::k_td_tables<true><<<(unsigned)((m * 16 + 255) / 256), 256, 0, s>>>(m, b, p_src, p_new, idx, new_offset, rel4, Z, scene_sums);
+    }
     return pdf_launch_status();
 }

@@ -337,11 +337,12 @@ class _BlockPre(torch.autograd.Function):
         n, c = x.shape
         cc = c * c
         e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=x.device)
-        gx, grads, dy, sums = e(n, c), e(cc + 2 * c + 3 * (cc + c)), e(n, c), e(2 * c)
+        gx, grads, dy = e(n, c), e(cc + 2 * c + 3 * (cc + c)), e(n, c)
         # pdf_rowlin_dgrad_bstats writes pdf_rowlin_partial_rows rows of 2c floats here, the BatchNorm passes pdf_bn_partial_floats
         partial = e(max(int(be.lib.pdf_bn_partial_floats(n, c)), int(be.lib.pdf_rowlin_partial_floats(n, c))))
+        ws = be.wgrad_workspace(n, c, c, 3, x.device)
         be.block_call("pre_backward", n, c, [x, z1, coef1, W1, Wq, Wk, Wv, gxq.contiguous(), gxk.contiguous(), gxv.contiguous(),
-                                             gx, grads, dy, partial, sums], ctx.training)
+                                             gx, grads, dy, partial, ws], ctx.training)
         o = cc + 2 * c
         out = [gx, grads[:cc].view(c, c), grads[cc + c:cc + 2 * c], grads[cc:cc + c]]   # dW1, dgamma1, dbeta1 (buffer: dW1 | dbeta1 | dgamma1)
         for i in range(3):
@@ -376,9 +377,10 @@ class _BlockPost(torch.autograd.Function):
         n, c = t.shape
         cc = c * c
         e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=t.device)
-        gt, gres, grads, da, sums = e(n, c), e(n, c), e(cc + 4 * c), e(n, c), e(2 * c)
+        gt, gres, grads, da = e(n, c), e(n, c), e(cc + 4 * c), e(n, c)
         partial = e(max(int(be.lib.pdf_bn_partial_floats(n, c)), int(be.lib.pdf_rowlin_partial_floats(n, c))))
-        be.block_call("post_backward", n, c, [gy.contiguous(), t, x, z3, coef2, coef3, W3, gt, gres, grads, da, partial, sums],
+        ws = be.wgrad_workspace(n, c, c, 1, t.device)
+        be.block_call("post_backward", n, c, [gy.contiguous(), t, x, z3, coef2, coef3, W3, gt, gres, grads, da, partial, ws],
                       ctx.training)
         # buffer: dW3 | dbeta2 | dgamma2 | dbeta3 | dgamma3 ; forward args: t, x, g2, b2, W3, g3, b3
         return (gt, gres, grads[cc + c:cc + 2 * c], grads[cc:cc + c], grads[:cc].view(c, c), grads[cc + 3 * c:cc + 4 * c],
@@ -450,7 +452,7 @@ class _BottleneckFn(torch.autograd.Function):
         cs, cc, nc = c // 8, c * c, n * c
         gy = gy.contiguous()
         npre, npost, nsum = cc + 2 * c + 3 * (cc + c), cc + 4 * c, int(lib.pdf_pt_layer_bwd_sums_floats(c))
-        # one buffer: [grads pre | grads post] zeroed by ONE memset in C, then the layer's sums (overwritten)
+        # one buffer: [grads pre | grads post | the layer's sums]; every slot is WRITTEN by the slab reductions / column sums (no zeroing)
         o_pre, o_post = 0, _al(npre)
         o_sum = o_post + _al(npost)
         grads = torch.empty((o_sum + _al(nsum),), dtype=torch.float32, device=x.device)
@@ -459,7 +461,8 @@ class _BottleneckFn(torch.autograd.Function):
         inv_off, inv_entry, entry_base = _native.inverse_table(idx, n)   # cached on idx by the geometry pre-pass
         ssz = [nc, nc, nc, n * k * cs, n * k * 3,
                max(int(lib.pdf_bn_partial_floats(n, c)), int(lib.pdf_rowlin_partial_floats(n, c)), int(lib.pdf_pt_layer_bwd_partial_floats(n, k, c))),
-               nc, nc, n * k * cs, n * k * c, nc]   # gt da gxq G2 G3 partial | gxk gxv Wsm GR | dy
+               nc, nc, n * k * cs, n * k * c, nc,
+               int(lib.pdf_rowlin_wgrad_ws_floats(n, c, c, 3)) + int(lib.pdf_rowlin_wgrad_ws_floats(n, c, c, 1))]   # gt da gxq G2 G3 partial | gxk gxv Wsm GR | dy | wgrad slabs
         soff, tot = [], 0
         for sz in ssz:
             soff.append(tot)
@@ -473,7 +476,7 @@ class _BottleneckFn(torch.autograd.Function):
                 A(5), A(6), A(7), A(2), A(3), A(4), A(8), A(10), A(9), A(11), W3.data_ptr(),
                 gx.data_ptr(), gb + 4 * o_pre, gb + 4 * o_post, gb + 4 * o_sum,
                 S(0), S(1), S(2), S(6), S(7), S(3), S(4), S(5), S(8), S(9), inv_off.data_ptr(), inv_entry.data_ptr(), S(10),
-                *be.aux_handles(x.device, n), be._order_ptr(idx)]
+                *be.aux_handles(x.device, n), be._order_ptr(idx), S(11)]
         be.bottleneck_backward(n, k, c, ptrs, training, entry_base, bf16)
         # the ~35 gradient views as ONE split of the buffer (a slice + view per gradient was ~100 us of host time per block)
         sizes = _bottleneck_grad_sizes(c, o_post, o_sum, grads.shape[0])
@@ -563,8 +566,9 @@ class _TransitionDownFn(torch.autograd.Function):
         e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=x.device)
         coef, out, gram = e(4 * cout), e(m, cout), e(int(lib.pdf_td_gram_floats(cin)))
         arg = torch.empty((m, cout), dtype=torch.uint8, device=x.device)
+        ws = e(int(lib.pdf_td_fwd_scratch_floats(n, cin)))
         ptrs = [x.data_ptr(), idx.data_ptr(), rel4.data_ptr(), Z.data_ptr(), consts.data_ptr(), W.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                bn.running_mean.data_ptr(), bn.running_var.data_ptr(), coef.data_ptr(), out.data_ptr(), arg.data_ptr(), gram.data_ptr()]
+                bn.running_mean.data_ptr(), bn.running_var.data_ptr(), coef.data_ptr(), out.data_ptr(), arg.data_ptr(), gram.data_ptr(), ws.data_ptr()]
         rc = lib.pdf_td_forward(n, m, cin, cout, (c_void_p * len(ptrs))(*ptrs), int(training), ctypes.c_float(bn.eps),
                                 ctypes.c_float(bn.momentum), be._stream())
         if rc != 0:
@@ -587,10 +591,12 @@ class _TransitionDownFn(torch.autograd.Function):
         gx, dW, dgb = e(n, cin), e(cout, 3 + cin), e(2 * cout)
         scratch = e(int(lib.pdf_td_bwd_scratch_floats(m, cin, cout)))
         gout = gout.contiguous()
+        from . import _native
+        inv_off, inv_entry, entry_base = _native.inverse_table(idx, n)   # cached on idx by the geometry pre-pass: destination-order scatter
         ptrs = [gout.data_ptr(), out.data_ptr(), arg.data_ptr(), x.data_ptr(), idx.data_ptr(), rel4.data_ptr(), Z.data_ptr(), consts.data_ptr(),
                 W.data_ptr(), gamma.data_ptr(), beta.data_ptr(), coef.data_ptr(), gram.data_ptr(), gx.data_ptr(), dW.data_ptr(), dgb.data_ptr(),
-                scratch.data_ptr()]
-        rc = lib.pdf_td_backward(n, m, cin, cout, (c_void_p * len(ptrs))(*ptrs), be._stream())
+                scratch.data_ptr(), inv_off.data_ptr(), inv_entry.data_ptr()]
+        rc = lib.pdf_td_backward(n, m, cin, cout, (c_void_p * len(ptrs))(*ptrs), int(entry_base), be._stream())
         if rc != 0:
             raise RuntimeError(f"pdf_td_backward failed with status {rc}")
         return None, None, None, None, None, gx, dW, dgb[cout:], dgb[:cout]
@@ -656,8 +662,9 @@ class _LinBnFn(torch.autograd.Function):
         grads, gz = e(o * k + 3 * o), e(n, o)
         partial = e(int(lib.pdf_bn_partial_floats(n, o)))
         gy = gy.contiguous()
+        ws = be.wgrad_workspace(n, k, o, 1, x.device)
         ptrs = [gy.data_ptr(), x.data_ptr(), z.data_ptr(), coef.data_ptr(), W.data_ptr(), gx.data_ptr() if need_gx else None, grads.data_ptr(),
-                gz.data_ptr(), partial.data_ptr()]
+                gz.data_ptr(), partial.data_ptr(), ws.data_ptr()]
         rc = lib.pdf_linbn_backward(n, k, o, (c_void_p * len(ptrs))(*ptrs), int(training), int(relu), be._stream())
         if rc != 0:
             raise RuntimeError(f"pdf_linbn_backward failed with status {rc}")

@@ -80,6 +80,95 @@ class OpenSegStep(nn.Module):
                     score=rec["score"].detach())
 
 
+def release_autograd_state(step):
+    """Drop every reference an ``OpenSegStep`` keeps to the last step's autograd graph (the hook tap's captured tensors).  A live graph
+    keeps its AccumulateGrad nodes -- and the stream they were created on -- alive; needed before a step is captured into a hipGraph on
+    another stream (``CapturedStep``), harmless otherwise."""
+    for per_module in step.hooks.output.values():
+        for key in per_module:
+            per_module[key] = None
+
+
+class CapturedStep:
+    """Forward + backward of an ``OpenSegStep`` captured ONCE into a hipGraph and replayed per batch (the step is ~1,200 dependent
+    launches: issued from Python it is host-bound, replayed it costs the host one call).  Everything the captured kernels read lives
+    at fixed addresses: the batch tensors (``coord``, ``feat``, ``offset``, ``segment``: static copies) and the batch's coordinate-only
+    tables (``geometry.StaticGeometry``: one flat buffer), both filled by ONE staging launch per step that reads the pre-pass's tensors
+    where they lie (csrc/stage_copy.hip).
+    The graph is specific to the scene sizes it was captured with -- what ``SphereCrop(point_max)`` hands the reference's trainer for
+    every scene above the limit; batches of another shape run the eager path (``matches``).
+
+    The optimizer and the data-parallel gradient exchange stay outside the graph (one launch / one all-reduce): parameters' ``.grad``
+    are the graph's own static tensors (re-bound after every replay, so an eager step in between does no harm).  Python-side scalars
+    of the step (``PointPdfV1.alpha``, ``epoch`` gates, BatchNorm momenta) are baked in at capture: re-capture when they change."""
+
+    KEYS = ("coord", "feat", "offset", "segment")
+
+    def __init__(self, step, batch, geom=None, warmup=2):
+        from .geometry import Geometry, StaticGeometry
+
+        assert step.training, "CapturedStep captures a TRAINING step (forward + backward)"
+        self.step = step
+        dev = batch["coord"].device
+        self.sizes = [int(v) for v in batch["offset_host"]]
+        self.static = {k: batch[k].clone() for k in self.KEYS}
+        self.static["offset_host"] = list(self.sizes)
+        if geom is None:
+            geom = Geometry(batch["coord"], batch["offset"], batch["offset_host"]).precompute()
+        self.geometry = StaticGeometry(geom)
+        self.layout = self.geometry.layout
+        self.params = [p for p in step.parameters() if p.requires_grad]
+        # BatchNorm buffers / step counters move with every forward: the warm-up passes below must not count as training steps
+        buffers = [b for b in step.buffers()]
+        saved = [b.detach().clone() for b in buffers]
+        release_autograd_state(step)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(int(warmup), 1)):   # lazily created handles / caches must exist before the capture
+                for p in self.params:
+                    p.grad = None
+                self._eager()["loss"].backward()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        for p in self.params:
+            p.grad = None
+        release_autograd_state(step)
+        with torch.no_grad():
+            for b, v in zip(buffers, saved):
+                b.copy_(v)
+        # Capture on the SAME side stream the warm-up ran on: a parameter's AccumulateGrad node remembers the stream it was created on, and a
+        # node that survived the warm-up on another stream makes the engine fork the capture onto that stream -- work and allocations of
+        # the fork are then outside the graph's private pool (observed: replays that read recycled memory once eager work ran in between).
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side):
+            self.out = self._eager()
+            self.out["loss"].backward()
+        self.grads = [p.grad for p in self.params]
+        with torch.no_grad():   # (the capture itself does not execute anything, but keep the contract obvious)
+            for b, v in zip(buffers, saved):
+                b.copy_(v)
+        release_autograd_state(step)
+
+    def _eager(self):
+        return self.step(dict(self.static, pdf_geometry=self.geometry))
+
+    def matches(self, batch):
+        return [int(v) for v in batch["offset_host"]] == self.sizes and all(batch[k].shape == self.static[k].shape for k in self.KEYS)
+
+    @torch.no_grad()
+    def __call__(self, batch, geom):
+        """One training step's forward + backward on ``batch`` with the coordinate-only tables ``geom`` (any Geometry of the batch: its own
+        pre-pass or its share of a grouped one).  Two launches: the staging copy (batch tensors + ~70 tables into the fixed-address
+        buffers, csrc/stage_copy.hip) and the graph.  Returns the static output dict (``loss``, ``model_loss``, ``recognizer_loss``,
+        ``score``: overwritten by the next call); gradients are in ``p.grad``."""
+        self.geometry.stage(geom, extra=[(batch[k], self.static[k]) for k in self.KEYS])
+        self.graph.replay()
+        for p, g in zip(self.params, self.grads):
+            p.grad = g
+        return self.out
+
+
 def wrap_ddp(module, device):
     """DDP over RCCL: one flat bucket (34 MB of fp32 gradients), bucket views, per-rank BN buffers."""
     from torch.nn.parallel import DistributedDataParallel as DDP
@@ -170,6 +259,14 @@ class FusedSGD(torch.optim.Optimizer):
         self._ring = [(torch.empty((rows, 4), dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(self.RING)]
         self._tabs = [torch.empty((rows, 4), dtype=torch.int64, device=self.device) for _ in range(self.RING)]
         self._n = 0
+        self._captured = []   # pointer tables of captured steps (hipGraph replays read them)
+        self._spare = []
+        self.reserve_capture_tables(2 * len(self.param_groups))
+
+    def reserve_capture_tables(self, n):
+        """Pinned pointer tables for ``n`` more (group, captured step) pairs; must be called outside stream capture."""
+        rows = max(len(g["params"]) for g in self.param_groups)
+        self._spare += [torch.empty((rows, 4), dtype=torch.int64).pin_memory() for _ in range(n)]
 
     @property
     def params(self):
@@ -202,11 +299,20 @@ class FusedSGD(torch.optim.Optimizer):
                 continue
             _native.require_current_device(self._tabs[0])   # (launches go onto the current device's current stream)
             chunks, nchunks, lengths = self._plan(gi, have, params)
-            slot = self._n % self.RING
-            host, ev = self._ring[slot]
-            tab = self._tabs[slot]
-            self._n += 1
-            ev.synchronize()   # (the copy AND the launch that last used this slot have run)
+            capturing = torch.cuda.is_current_stream_capturing()
+            if capturing:   # a captured step replays this copy + launch: the tables must outlive the graph and never be rewritten
+                if not self._spare:
+                    raise RuntimeError("FusedSGD: more captured steps than pinned pointer tables (pinning host memory is not allowed "
+                                       "during stream capture); call reserve_capture_tables(n) before capturing")
+                host = self._spare.pop()
+                tab, ev = torch.empty((len(have), 4), dtype=torch.int64, device=self.device), None
+                self._captured.append((host, tab))
+            else:
+                slot = self._n % self.RING
+                host, ev = self._ring[slot]
+                tab = self._tabs[slot]
+                self._n += 1
+                ev.synchronize()   # (the copy AND the launch that last used this slot have run)
             full = len(have) == len(all_grads)
             grads = all_grads if full else [all_grads[i] for i in have]
             grads = [g if (g.dtype is f32 and g.is_contiguous()) else g.float().contiguous() for g in grads]   # (alive until queued)
@@ -227,7 +333,8 @@ class FusedSGD(torch.optim.Optimizer):
             tab[:len(have)].copy_(host[:len(have)], non_blocking=True)
             rc = self.be.lib.pdf_sgd_step(nchunks, tab.data_ptr(), chunks.data_ptr(), float(group["lr"]), float(group["momentum"]),
                                           float(group["weight_decay"]), self.ctypes.c_void_p(_native.raw_stream()))
-            ev.record()
+            if ev is not None:
+                ev.record()
             if rc != 0:
                 raise RuntimeError(f"pdf_sgd_step failed with status {rc}")
         return loss

@@ -196,7 +196,10 @@ class Geometry:
             idx, _ = self.knn(nsample, src_level, query_level)
             S, Q = self.levels[src_level], self.levels[query_level]
             assert nsample == 16, "fused TransitionDown tables: nsample 16"
-            rel4, Z, _ = _native.backend_for(S.p).td_tables(S.p, Q.p, idx, Q.o)
+            be0 = _native.backend_for(S.p)
+            # the inverse of the grouping table: Z in destination order here, the sparse input gradient of the backward likewise (no atomics)
+            inv = self.inverse(nsample, src_level, query_level) if (S.p.is_cuda and be0.use_inverse) else None
+            rel4, Z, _ = be0.td_tables(S.p, Q.p, idx, Q.o, inverse=inv) if inv is not None else be0.td_tables(S.p, Q.p, idx, Q.o)
             # per-scene [xx xy xz yy yz zz | sx sy sz] of the relative coordinates: one kernel (csrc/geom_moments.hip, fp64 sums; a python
             # loop over the scenes -- a slice + sum + store per scene and table -- was 15 ms of host time per group of 24 scenes)
             scene_sums = Z.new_zeros(len(Q.o_host), 16)
@@ -261,21 +264,74 @@ class Geometry:
                     self.inverse(interp_k, lvl, lvl)
         return self
 
-    def load(self, src):
-        """Overwrite this (static-address) Geometry with the tables of ``src`` (same level sizes): lets a captured
-        hipGraph of the training step replay against the pre-pass of a new batch."""
-        assert len(self.levels) == len(src.levels)
-        for a, b in zip(self.levels, src.levels):
-            assert a.p.shape == b.p.shape and a.o_host == b.o_host, "graph replay needs identical scene sizes"
-            a.p.copy_(b.p)
-            a.o.copy_(b.o)
-        assert set(self._memo) == set(src._memo), (set(self._memo) ^ set(src._memo))
-        for k, v in self._memo.items():
-            w = src._memo[k]
-            for t, u in zip(v if isinstance(v, tuple) else (v,), w if isinstance(w, tuple) else (w,)):
-                if isinstance(t, torch.Tensor):
-                    t.copy_(u)
-        return self
+    # ------------------------------------------------------------------ fixed-address form (hipGraph replay of a captured step)
+    def flat_tensors(self):
+        """Every device tensor a forward / backward over this Geometry reads, as an ordered list of (slot, tensor): level coordinates and
+        offsets, the memoised tables, the batch's coordinate sums (an attachment of the self-kNN index tensors) -- with the inverse
+        tables normalised to (offsets from 0, the batch's own entry list, entry base 0), so that a batch cut out of a grouped pre-pass
+        (``split``: views into the group's arrays + an integer base) and a batch with its own pre-pass give the same list of shapes.
+        The order is a function of the plan only (sorted keys)."""
+        out = []
+        for l, lv in enumerate(self.levels):
+            out += [(("p", l), lv.p), (("o", l), lv.o)]
+        for key in sorted(self._memo, key=repr):
+            v = self._memo[key]
+            kind = key[0]
+            if kind == "inv":
+                off, ent, base = v
+                nent = self._memo[("knn",) + key[1:]][0].numel()
+                off0 = off[:1]
+                pos = (_arange(nent, off.device) + off0).clamp_(max=max(ent.numel() - 1, 0)).long()
+                out += [((key, 0), off - off0), ((key, 1), ent.index_select(0, pos) - base if base else ent.index_select(0, pos))]
+            elif kind == "interp":     # (the index tensor is the kNN entry's own object)
+                out.append(((key, 1), v[1]))
+            else:
+                for j, t in enumerate(v if isinstance(v, tuple) else (v,)):
+                    if isinstance(t, torch.Tensor):
+                        out.append(((key, j), t))
+            if kind == "mom":
+                m = _native.moments_of(self._memo[("knn",) + key[1:]][0])
+                out.append(((("mom_batch",) + key[1:]), m if m is not None else v.sum(0)))
+        return out
+
+    def flat_sources(self):
+        """``flat_tensors()`` without materialising anything: (slot, source tensor, src_offset tensor | None, sub tensor | None, sub_const)
+        per slot, for the one-launch staging copy (csrc/stage_copy.hip).  The inverse tables' fix-ups happen inside that copy: the offset
+        array minus its own first element; the entry list as the window of the (group's) array that starts at that first offset, minus
+        the batch's entry base."""
+        out = []
+        for l, lv in enumerate(self.levels):
+            out += [(("p", l), lv.p, None, None, 0), (("o", l), lv.o, None, None, 0)]
+        for key in sorted(self._memo, key=repr):
+            v = self._memo[key]
+            kind = key[0]
+            if kind == "inv":
+                off, ent, base = v
+                out += [((key, 0), off, None, off, 0), ((key, 1), ent, off, None, int(base))]
+            elif kind == "interp":
+                out.append(((key, 1), v[1], None, None, 0))
+            else:
+                for j, t in enumerate(v if isinstance(v, tuple) else (v,)):
+                    if isinstance(t, torch.Tensor):
+                        out.append(((key, j), t, None, None, 0))
+            if kind == "mom":
+                m = _native.moments_of(self._memo[("knn",) + key[1:]][0])
+                out.append(((("mom_batch",) + key[1:]), m if m is not None else v.sum(0), None, None, 0))
+        return out
+
+    def pack(self, layout):
+        """This Geometry's tensors as ONE flat byte buffer in ``layout``'s order (``StaticGeometry.layout``): ~70 small copies, issued on
+        the current stream -- the pre-pass side stream, so the training stream needs a single copy per step."""
+        items = self.flat_tensors()
+        if len(items) != len(layout.items):
+            raise ValueError("Geometry.pack: this geometry does not have the layout's tables")
+        flat = torch.empty((layout.nbytes,), dtype=torch.uint8, device=self.device)
+        for (slot, t), (lslot, shape, dtype, o, nb) in zip(items, layout.items):
+            if slot != lslot or tuple(t.shape) != shape or t.dtype != dtype:
+                raise ValueError(f"Geometry.pack: {slot} {tuple(t.shape)} {t.dtype} does not match the captured layout {lslot} {shape} {dtype} "
+                                 "(hipGraph replay needs identical scene sizes)")
+            flat[o:o + nb].view(dtype).view(shape).copy_(t)
+        return flat
 
     def split(self, scene_counts):
         """Per-batch Geometry objects of a pre-pass that was run over several batches at once (scenes of batch 0, then
@@ -420,6 +476,107 @@ _TD_PERM = {}
 _MOM_TO_TD = {}
 
 
+_ARANGE = {}
+
+
+def _arange(n, device):
+    key = (int(n), device)
+    if key not in _ARANGE:
+        _ARANGE[key] = torch.arange(int(n), device=device, dtype=torch.int32)
+    return _ARANGE[key]
+
+
+class GeometryLayout:
+    """Slots, shapes, dtypes and byte offsets (256-byte aligned) of ``Geometry.flat_tensors()`` inside one flat buffer."""
+
+    def __init__(self, geom):
+        self.items, o = [], 0
+        for slot, t in geom.flat_tensors():
+            nb = t.numel() * t.element_size()
+            self.items.append((slot, tuple(t.shape), t.dtype, o, nb))
+            o += (nb + 255) & ~255
+        self.nbytes = o
+        self.levels = [list(lv.o_host) for lv in geom.levels]
+        self.memo = {key: (v if not isinstance(v, tuple) else tuple(None if isinstance(t, torch.Tensor) else t for t in v))
+                     for key, v in geom._memo.items()}   # non-tensor members (level numbers) of the memo entries
+
+
+class StaticGeometry(Geometry):
+    """A Geometry whose every tensor is a view of ONE flat device buffer at fixed addresses: a training step captured into a hipGraph
+    against it (engine.CapturedStep) replays on any batch with the same scene sizes after ``load(packed)`` -- one device copy of the
+    buffer another Geometry's ``pack(layout)`` produced."""
+
+    def __init__(self, template):
+        self.layout = GeometryLayout(template)
+        self.flat = template.pack(self.layout)
+        views = {slot: self.flat[o:o + nb].view(dtype).view(shape) for slot, shape, dtype, o, nb in self.layout.items}
+        self.levels, self._memo = [], {}
+        for l, o_host in enumerate(self.layout.levels):
+            self._add_level(views[("p", l)], views[("o", l)], o_host)
+        for key, proto in self.layout.memo.items():
+            kind = key[0]
+            if kind == "inv":
+                self._memo[key] = (views[(key, 0)], views[(key, 1)], 0)
+            elif kind == "interp":
+                continue
+            elif isinstance(proto, tuple):
+                self._memo[key] = tuple(views[(key, j)] if t is None else t for j, t in enumerate(proto))
+            else:
+                self._memo[key] = views[(key, 0)]
+        for key in self.layout.memo:
+            if key[0] == "interp":
+                self._memo[key] = (self._memo[("knn",) + key[1:]][0], views[(key, 1)])
+        for key, val in self._memo.items():   # the attachments the backend looks up on the index tensors
+            if key[0] == "knn" and ("order", key[3]) in self._memo:
+                _native.attach_order(val[0], self._memo[("order", key[3])], self._memo.get(("order", key[2])))
+            if key[0] == "mom":
+                _native.attach_moments(self._memo[("knn",) + key[1:]][0], views[("mom_batch",) + key[1:]])
+            if key[0] == "inv":
+                _native.attach_inverse(self._memo[("knn",) + key[1:]][0], self.levels[key[2]].p.shape[0], val)
+
+    def load(self, packed):
+        """Overwrite the tables with another batch's (``Geometry.pack(self.layout)``): one copy on the current stream."""
+        self.flat.data.copy_(packed)   # (.data: the views' version counters -- which the geometry tags and attachments check -- stay put)
+        return self
+
+    def stage(self, geom, extra=()):
+        """Overwrite the tables with those of ``geom`` (same scene sizes; any Geometry, e.g. a batch cut out of a grouped pre-pass) in ONE
+        launch on the current stream (csrc/stage_copy.hip), reading ``geom``'s tensors where they lie.  ``extra``: further
+        (source, destination) tensor pairs to move in the same launch (the batch's own tensors).  Nothing is allocated; the version
+        counters of the static views do not move."""
+        import ctypes
+
+        be = _native.hip_backend()
+        src = geom.flat_sources()
+        if len(src) != len(self.layout.items):
+            raise ValueError("StaticGeometry.stage: the geometry does not have the captured layout's tables")
+        n = len(src) + len(extra)
+        segs = (be.CopySeg * n)()
+        base = self.flat.data_ptr()
+        for i, ((slot, t, soff, sub, subc), (lslot, shape, dtype, o, nb)) in enumerate(zip(src, self.layout.items)):
+            windowed = soff is not None
+            if slot != lslot or t.dtype != dtype or not t.is_contiguous() or (not windowed and tuple(t.shape) != shape):
+                raise ValueError(f"StaticGeometry.stage: {slot} {tuple(t.shape)} {t.dtype} does not match the captured layout {lslot} {shape} "
+                                 f"{dtype} (hipGraph replay needs identical scene sizes)")
+            sg = segs[i]
+            sg.src, sg.dst, sg.nbytes = t.data_ptr(), base + o, nb
+            sg.src_offset = soff.data_ptr() if windowed else None
+            sg.sub = sub.data_ptr() if sub is not None else None
+            sg.sub_const = subc
+            sg.src_elems = t.numel() if windowed else 0
+        for i, (a, b) in enumerate(extra):
+            if a.shape != b.shape or a.dtype != b.dtype or not (a.is_contiguous() and b.is_contiguous()) or (a.numel() * a.element_size()) % 4:
+                raise ValueError("StaticGeometry.stage: extra pairs must be contiguous tensors of one shape and dtype (4-byte multiples)")
+            sg = segs[len(src) + i]
+            sg.src, sg.dst, sg.nbytes = a.data_ptr(), b.data_ptr(), a.numel() * a.element_size()
+            sg.src_offset, sg.sub, sg.sub_const, sg.src_elems = None, None, 0, 0
+        _native.require_current_device(self.flat)
+        rc = be.lib.pdf_stage_copy(n, segs, ctypes.c_void_p(_native.raw_stream()))
+        if rc != 0:
+            raise _native.PdfOpsError(f"pdf_stage_copy failed with status {rc}")
+        return self
+
+
 class _LazyTicket:
     """Ticket j of a group whose pre-pass is being built on the prefetcher's worker thread."""
 
@@ -447,6 +604,7 @@ class GeometryPrefetcher:
         self.streams = [torch.cuda.Stream() for _ in range(max(depth, 1))]   # (stream priorities: measured, no effect on this stack)
         self._n = 0
         self.pool = None
+        self.packer = None   # callable Geometry -> flat tensor, run on the pre-pass stream (set to engine.CapturedStep.pack)
         if threaded:
             from concurrent.futures import ThreadPoolExecutor
 
@@ -459,6 +617,8 @@ class GeometryPrefetcher:
         stream.wait_stream(torch.cuda.current_stream())  # inputs were produced on the caller's stream
         with torch.cuda.stream(stream):
             geom = Geometry(coord, offset, offset_host).precompute(**self.plan)
+            if self.packer is not None:
+                geom.packed = self.packer(geom)
             done = torch.cuda.Event()
             done.record(stream)
         return geom, done, stream
@@ -494,6 +654,9 @@ class GeometryPrefetcher:
             offset = torch.cat([b["offset"].to(torch.int32) + int(bs) for b, bs in zip(batches, bases)])
             group = Geometry(coord, offset, o_host).precompute(**self.plan)
             geoms = group.split(counts)
+            if self.packer is not None:   # fixed-address replay (engine.CapturedStep): the batch's tables as one flat buffer, made here
+                for g in geoms:
+                    g.packed = self.packer(g)
             done = torch.cuda.Event()
             done.record(stream)
         return [(g, done, stream) for g in geoms]
@@ -507,6 +670,9 @@ class GeometryPrefetcher:
         cur.wait_event(done)
         for t in geom.tensors():
             t.record_stream(cur)
+        packed = getattr(geom, "packed", None)
+        if packed is not None:
+            packed.record_stream(cur)
         return geom
 
 

@@ -101,8 +101,9 @@ class PointPdfV1(nn.Module):
             if self.epoch < self.start_epoch:
                 return dict(score=score)
             pseudo_mask = self.get_pseudo_mask(input_dict["coord"], seg_logits, input_dict["offset"])
-            segment_pseudo = input_dict["segment"].clone()
-            segment_pseudo[pseudo_mask] = self.num_classes
+            # segment_pseudo[pseudo_mask] = num_classes (pointpdf_v1m1_base.py:94-95) as a select: no index list, no host sync
+            segment = input_dict["segment"]
+            segment_pseudo = torch.where(pseudo_mask, segment.new_full((), self.num_classes), segment)
             full = torch.cat([seg_logits, score], -1)
             loss = self.criteria(full, segment_pseudo) * self.alpha
             if self.softmax_score:

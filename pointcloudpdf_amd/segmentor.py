@@ -42,7 +42,8 @@ class _FusedCE(torch.autograd.Function):
         be = _native.hip_backend()
         n, c = pred.shape
         grad = torch.empty_like(pred)
-        acc = torch.empty((3,), dtype=torch.float32, device=pred.device)   # [sum, count, mean]
+        # [sum, count, mean, -] + the per-workgroup partial sums (added in a fixed order: csrc/loss.hip)
+        acc = torch.empty((int(be.lib.pdf_ce_workspace_floats()),), dtype=torch.float32, device=pred.device)
         _native.require_current_device(pred, target)
         s = ctypes.c_void_p(_native.raw_stream())
         rc = be.lib.pdf_ce_forward(n, c, pred.data_ptr(), target.data_ptr(), ignore, grad.data_ptr(), acc.data_ptr(), acc.data_ptr() + 8, s)

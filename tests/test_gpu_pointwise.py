@@ -336,7 +336,10 @@ def test_fused_sgd_matches_torch_sgd():
     sa, sb = torch.optim.lr_scheduler.StepLR(oa, 1, 0.5), torch.optim.lr_scheduler.StepLR(ob, 1, 0.5)
     pc = [torch.nn.Parameter(y.detach().clone()) for y in pb]
     oc = engine.FusedSGD(pc, lr=123.0, momentum=0.0, weight_decay=0.0)
-    oc.load_state_dict(ob.state_dict())          # torch.optim.SGD's checkpoint: lr / momentum / weight decay and the momentum buffers
+    import copy
+    # torch.optim.SGD's checkpoint: lr / momentum / weight decay and the momentum buffers (deep copy = what torch.save / torch.load
+    # hand over; load_state_dict itself aliases same-device tensors)
+    oc.load_state_dict(copy.deepcopy(ob.state_dict()))
     sc = torch.optim.lr_scheduler.StepLR(oc, 1, 0.5)
     for it in range(3):
         for x, y, z in zip(pa, pb, pc):
@@ -349,7 +352,7 @@ def test_fused_sgd_matches_torch_sgd():
         assert (x - y).abs().max() <= 1e-6 * (1 + y.abs().max()), (tuple(x.shape), float((x - y).abs().max()))
         assert (z - y).abs().max() <= 1e-6 * (1 + y.abs().max()), (tuple(x.shape), float((z - y).abs().max()))
     ob2 = torch.optim.SGD(pb, lr=1.0, momentum=0.9)
-    ob2.load_state_dict(oa.state_dict())         # and back: FusedSGD's state in torch.optim.SGD
+    ob2.load_state_dict(copy.deepcopy(oa.state_dict()))         # and back: FusedSGD's state in torch.optim.SGD
     assert torch.equal(ob2.state[pb[2]]["momentum_buffer"], oa.state[pa[2]]["momentum_buffer"])
     # moved parameters (model.to(), load_state_dict(assign=True)): pointers are read at every step
     with torch.no_grad():
@@ -437,9 +440,10 @@ def test_block_halves_stay_inside_their_partial_buffer(n, c):
     be.block_call("pre_forward", n, c, [x, W1, g1, b1, rm, rv, Wq, bq, Wk, bq, Wv, bq, z1, coef1, xq, xk, xv, part], True, 1e-5, 0.1)
     torch.cuda.synchronize()
     assert bool((part[need:] == SENT).all()), "pre_forward wrote behind its partial buffer"
-    gx, grads, dy, sums = e(n, c), e(cc + 2 * c + 3 * (cc + c)), e(n, c), e(2 * c)
+    gx, grads, dy = e(n, c), e(cc + 2 * c + 3 * (cc + c)), e(n, c)
     part.fill_(SENT)
-    be.block_call("pre_backward", n, c, [x, z1, coef1, W1, Wq, Wk, Wv, r(n, c), r(n, c), r(n, c), gx, grads, dy, part, sums], True)
+    ws = be.wgrad_workspace(n, c, c, 3, x.device)
+    be.block_call("pre_backward", n, c, [x, z1, coef1, W1, Wq, Wk, Wv, r(n, c), r(n, c), r(n, c), gx, grads, dy, part, ws], True)
     torch.cuda.synchronize()
     assert bool((part[need:] == SENT).all()), "pre_backward wrote behind its partial buffer"
     assert bool(torch.isfinite(gx).all()) and bool(torch.isfinite(grads).all())
@@ -453,7 +457,7 @@ def test_block_halves_stay_inside_their_partial_buffer(n, c):
     assert bool((part[need:] == SENT).all()), "post_forward wrote behind its partial buffer"
     gt, gres, grads2, da = e(n, c), e(n, c), e(cc + 4 * c), e(n, c)
     part.fill_(SENT)
-    be.block_call("post_backward", n, c, [r(n, c), t, x, z3, coef2, coef3, W3, gt, gres, grads2, da, part, sums], True)
+    be.block_call("post_backward", n, c, [r(n, c), t, x, z3, coef2, coef3, W3, gt, gres, grads2, da, part, ws], True)
     torch.cuda.synchronize()
     assert bool((part[need:] == SENT).all()), "post_backward wrote behind its partial buffer"
     assert bool(torch.isfinite(gt).all()) and bool(torch.isfinite(grads2).all())

@@ -157,6 +157,38 @@ def test_geometry_split_matches_per_batch_prepass(use_oracle):
         assert torch.equal(idx, alone._memo[("knn", 8, 1, 1)][0])
 
 
+def test_static_geometry_pack_and_load(use_oracle):
+    """The fixed-address form behind hipGraph replay (engine.CapturedStep): two batches of identical scene sizes, one pre-passed alone
+    and one cut out of a grouped pre-pass, pack into the same layout; loading a pack into the StaticGeometry built from the other
+    batch reproduces that batch's tables at unchanged addresses, and the tags / attachments of the static tensors stay valid."""
+    from pointcloudpdf_amd import pointops
+    from pointcloudpdf_amd.geometry import Geometry, StaticGeometry, tag_of
+
+    sizes = [700, 500]
+    batches = [synthetic.make_batch(sizes, first_scene_id=10 * i, grid_size=0.3) for i in range(3)]
+    plan = dict(strides=(1, 4, 4), nsamples=(8, 8, 8), interp_k=3, recognizer=True)
+    alone = [Geometry(b["coord"], b["offset"], b["offset_host"]).precompute(**plan) for b in batches]
+    coord = torch.cat([b["coord"] for b in batches])
+    ends = [i * sum(sizes) + e for i in range(3) for e in batches[0]["offset_host"]]
+    parts = Geometry(coord, torch.tensor(ends, dtype=torch.int32), ends).precompute(**plan).split([2, 2, 2])
+    static = StaticGeometry(alone[0])
+    ptrs = [t.data_ptr() for _, t in static.flat_tensors()]
+    for g_alone, g_part in zip(alone, parts):
+        pa, pb = g_alone.pack(static.layout), g_part.pack(static.layout)
+        for slot, shape, dtype, o, nb in static.layout.items:   # (the alignment gaps between the slots are never read)
+            assert torch.equal(pa[o:o + nb], pb[o:o + nb]), slot
+        static.load(pb)
+        assert [t.data_ptr() for _, t in static.flat_tensors()] == ptrs
+        for (sa, ta), (sb, tb) in zip(static.flat_tensors(), g_alone.flat_tensors()):
+            assert sa == sb and torch.equal(ta, tb), sa
+        assert tag_of(static.coord(1)) == (static, 1)     # still a live geometry tag after the load
+        idx, _ = pointops.knn_query(8, static.coord(1), static.offset(1), static.coord(1), static.offset(1))
+        assert idx.data_ptr() == static._memo[("knn", 8, 1, 1)][0].data_ptr() and torch.equal(idx, g_alone._memo[("knn", 8, 1, 1)][0])
+    with pytest.raises(ValueError):
+        other = synthetic.make_batch([640, 560], first_scene_id=50, grid_size=0.3)
+        Geometry(other["coord"], other["offset"], other["offset_host"]).precompute(**plan).pack(static.layout)
+
+
 @pytest.mark.parametrize("mode", list(helpers.PDF_MODES))
 def test_pointpdf_forward_matches_reference_class(use_oracle, golden_dir, mode):
     """PointPdfV1.forward / trigger_operation (pointpdf_v1m1_base.py:72-116, 384-398) + DefaultSegmentor (default.py:39-62):
