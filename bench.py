@@ -642,7 +642,10 @@ def main():
             # the launching stream, against the 8 TB/s HBM peak with the SURVEY 8(d) byte counts (tools/ops_roofline.py)
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import ops_roofline
-            line["roofline_ops"] = [dict(op=r["op"], us=round(r["us"], 1), GBps=round(r["GBps"], 1), frac=round(r["frac"], 4))
+            line["roofline_ops"] = [dict(op=r["op"], us=round(r["us"], 1), GBps=round(r["GBps"], 1), frac=round(r["frac"], 4),
+                                         **({"pair_evals_per_s": float(f"{r['pair_evals_per_s']:.4g}"),
+                                             "valu_frac_bruteforce_equivalent": round(r["valu_frac_bruteforce_equivalent"], 4)}
+                                            if "pair_evals_per_s" in r else {}))
                                     for r in ops_roofline.run(iters=10, level2=False, references=False)]
         if world == 1 and not args.no_cpu_baseline and not scannet and not strat:   # (the CPU baseline is quoted on the headline workload)
             line["cpu_baseline"] = cpu_baseline(args.cpu_points)

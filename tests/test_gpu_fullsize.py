@@ -140,3 +140,117 @@ def test_full_size_step_matches_cpu_oracle_path(oracle_backend, kind, points):
     assert stats["median"][0] <= 4.0 * stats["median"][1] and stats["p90"][0] <= 4.0 * stats["p90"][1], stats
     # (3) the tail: the worst gradient no further from fp64 than 4x the reference composition's own worst, 0.15 at most
     assert stats["max"][0] <= min(4.0 * stats["max"][1], 0.15), stats
+
+
+def test_config4_full_size_step_with_the_pseudo_label_pass(oracle_backend):
+    """BASELINE config 4 as stated: ONE 150,000-point ScanNet-shaped scene, PT-v1 + PDF U-decoder WITH the pseudo-label pass inside the
+    step (recognizer settings of configs/scannet/openseg-pt-v1-0-pointpdf-v1m1-base.py:40-58; pointpdf_v1m1_base.py:118-382).
+      * the fixed-radius neighbour table of the whole scene (grid path, 27 cells per query) equals the in-order scan
+        (pdf_random_ball_query along the identity permutation) bit for bit, indices and squared distances, and -- on a sample of
+        3,000 queries -- the CPU oracle's table;
+      * the pseudo mask the pass returns is a non-trivial boolean mask of the scene (fraction bounds), identical when the pass is run
+        again with the same seeds (the pass itself is deterministic given its generators);
+      * one training step with the pass: finite losses, every parameter gets a finite gradient, the PDF loss is positive."""
+    from pointcloudpdf_amd import _native, engine, pseudo_label, synthetic
+
+    torch.backends.cuda.matmul.allow_tf32 = False
+    be = _native.hip_backend()
+    n = 150000
+    batch = synthetic.make_batch([n], first_scene_id=700, kind="scannet", device="cuda", unknown=(4, 7, 14, 16))
+    coord, off = batch["coord"], batch["offset"].int()
+    # -- radius table, whole scene
+    i_g, d_g = be.radius_neighbors_self(64, 0.1, coord, off)
+    order = torch.arange(n, dtype=torch.int32, device="cuda")
+    i_s, d_s = be.ball_query(64, 0.1, 0.0, coord, coord, off, off, order=order)
+    assert torch.equal(i_s, i_g), f"rows differing from the in-order scan: {(i_s != i_g).any(1).sum().item()}"
+    assert torch.equal(d_s, d_g)
+    q = torch.arange(0, n, 50)
+    oracle_backend.set_num_threads(min(os.cpu_count() or 1, 32))
+    i_o, _ = oracle_backend.ball_query(64, 0.1, 0.0, coord.cpu(), coord.cpu()[q].contiguous(), off.cpu(), torch.tensor([q.numel()], dtype=torch.int32),
+                                       order=torch.arange(n, dtype=torch.int32))
+    assert torch.equal(i_o, i_g.cpu()[q])
+    filled = (i_g >= 0).sum(1).float()
+    assert 4 <= float(filled.mean()) <= 64 and int((i_g[:, 0] == torch.arange(n, device="cuda")).sum()) > 0.99 * n   # every ball holds its own centre first
+    # -- the step with the pass
+    kw = dict(condition_from="msp", beta=1.5, seed_from="ml", seed_range=0.15, num_seed=100, slide_window=True)
+    fn = pseudo_label.make_pseudo_mask_fn(radius=0.02 * 5, max_neighbor=64, **kw)
+    step = engine.OpenSegStep(in_channels=9, num_classes=20, loss_weight=0.04, pseudo_mask_fn=fn).cuda()
+    synthetic.fill_parameters_deterministic(step, seed=4)
+    step.train()
+    np.random.seed(0)
+    torch.manual_seed(0)
+    out = step(batch)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out["loss"]).item() and float(out["recognizer_loss"]) > 0 and float(out["model_loss"]) > 0
+    missing = [name for name, p in step.named_parameters() if p.requires_grad and p.grad is None]
+    assert not missing, missing[:5]
+    assert all(torch.isfinite(p.grad).all() for p in step.parameters() if p.grad is not None)
+    # -- the mask itself (same logits, same generators -> same mask; a plausible share of the scene)
+    logits = step.hooks["backbone"]["forward_output"].detach()
+    masks = []
+    for _ in range(2):
+        np.random.seed(3)
+        masks.append(pseudo_label.get_pseudo_mask(coord, logits, off, radius=0.1, max_neighbor=64, generator=torch.Generator().manual_seed(3), **kw))
+    assert masks[0].dtype == torch.bool and masks[0].shape == (n,) and torch.equal(masks[0], masks[1])
+    share = float(masks[0].float().mean())
+    print(f"config 4 pseudo mask: {int(masks[0].sum())} of {n} points ({100 * share:.2f} %), mean ball occupancy {float(filled.mean()):.1f}")
+    assert 0.0 < share < 0.25, share
+
+
+def test_config5_full_size_stratified_step(oracle_backend):
+    """BASELINE config 5 at the reference's scene size: ONE 80,000-point scene (SphereCrop point_max of the ST configs) through ST-v1m1
+    + ST-v1m1-Recognizer (libs/pointops2 window attention; stratified_transformer_v1m1_origin.py:468-555) on the HIP path against the
+    SAME modules on the CPU oracle: the FPS subsets (window keys, TransitionDown samples) and the window edge tables of every level
+    bit-identical, logits / scores / loss within 1e-4 (eval mode: no DropPath, batch statistics do not enter), and one training step
+    with finite gradients for every parameter."""
+    from pointcloudpdf_amd import _native, engine, synthetic
+
+    torch.backends.cuda.matmul.allow_tf32 = False
+    n = 80000
+    oracle_backend.set_num_threads(min(os.cpu_count() or 1, 32))
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+
+    def build(device):
+        step = engine.OpenSegStep(backbone="ST-v1m1", loss_weight=0.008)
+        synthetic.fill_parameters_deterministic(step, seed=3)
+        return step.to(device)
+
+    batch = synthetic.make_batch([n], first_scene_id=700, device="cuda")
+    cpu_batch = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    dev = build("cuda").eval()
+    bb = dev.model.backbone
+    gd = bb.make_geometry(batch["coord"], batch["offset"], batch.get("offset_host")).precompute(bb.layers_by_level())
+    with torch.no_grad():
+        od = dev(dict(batch, st_geometry=gd))
+    logits_d = dev.hooks["backbone"]["forward_output"].detach().cpu()
+    prev = _native._set_backend_for_testing(oracle_backend)
+    try:
+        ref = build("cpu").eval()
+        rb = ref.model.backbone
+        gc = rb.make_geometry(cpu_batch["coord"], cpu_batch["offset"], cpu_batch.get("offset_host")).precompute(rb.layers_by_level())
+        with torch.no_grad():
+            oc = ref(dict(cpu_batch, st_geometry=gc))
+        logits_c = ref.hooks["backbone"]["forward_output"].detach()
+    finally:
+        _native._set_backend_for_testing(prev)
+    assert set(gd.samples) == set(gc.samples) and set(gd.windows) == set(gc.windows) == {0, 1, 2, 3}
+    for k in gc.samples:
+        assert torch.equal(gd.samples[k][0].cpu(), gc.samples[k][0]) and torch.equal(gd.samples[k][1].cpu(), gc.samples[k][1]), f"FPS subset {k}"
+    for lv in gc.windows:
+        for parity, tab in gc.windows[lv].items():
+            for x, y in zip(tab, gd.windows[lv][parity]):
+                assert (torch.equal(x, y.cpu()) if torch.is_tensor(x) else x == y), f"window tables of level {lv}, parity {parity}"
+    r_logits = helpers.max_rel(logits_d.numpy(), logits_c.numpy())
+    r_score = helpers.max_rel(od["score"].detach().cpu().numpy(), oc["score"].detach().numpy())
+    print(f"config 5 at {n} points: logits max-rel {r_logits:.1e}, score max-rel {r_score:.1e}")
+    assert r_logits <= 1e-4 and r_score <= 1e-4, (r_logits, r_score)
+    # one training step at this size
+    dev.train()
+    out = dev(dict(batch))
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out["loss"]).item()
+    missing = [name for name, p in dev.named_parameters() if p.requires_grad and p.grad is None]
+    assert not missing, missing[:5]
+    assert all(torch.isfinite(p.grad).all() for p in dev.parameters() if p.grad is not None)

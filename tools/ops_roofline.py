@@ -12,6 +12,7 @@ import torch
 from pointcloudpdf_amd import synthetic, _native
 from pointcloudpdf_amd.geometry import Geometry
 
+VALU_PEAK_FLOPS = 157.3e12   # fp32 vector peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK = 8000.0
 
 
@@ -55,12 +56,17 @@ def run(iters=20, only="", verbose=False, level2=True, references=True):
     g = torch.Generator(device=dev); g.manual_seed(7)
     rows = []
 
-    def add(name, nbytes, fn):
+    def add(name, nbytes, fn, pairs=None):
         if a.only and a.only not in name:
             return
         s = timeit(fn, a.iters)
         gbs = nbytes / s / 1e9
         rows.append(dict(op=name, us=s * 1e6, algorithmic_MB=nbytes / 1e6, GBps=gbs, frac=gbs / PEAK))
+        if pairs is not None:
+            # kNN is VALU / latency bound, not HBM bound: the brute-force definition evaluates m_b * n_b pairs per scene at
+            # 8 flop each (3 sub, 3 mul, 2 add); the grid search answers the same question, so "pair-evaluations answered per second"
+            # against the fp32 vector peak (157.3 TFLOP/s, MI355X_MICROARCH.md) is the honest VALU-side figure next to the GB/s
+            rows[-1].update(pair_evals_per_s=pairs / s, valu_frac_bruteforce_equivalent=8.0 * pairs / s / VALU_PEAK_FLOPS)
         if verbose:
             print(f"{name:58s} {s * 1e6:9.1f} us  {nbytes / 1e6:8.1f} MB  {gbs:8.1f} GB/s  {100 * gbs / PEAK:5.1f} % of HBM peak", flush=True)
 
@@ -68,10 +74,13 @@ def run(iters=20, only="", verbose=False, level2=True, references=True):
     def knn_bytes(n, m, k):
         return 12 * n + 12 * m + 8 * B + 8 * m * k
     n1, n2 = L1.p.shape[0], L2.p.shape[0]
-    add("knn_query L1 self k=8", knn_bytes(n1, n1, 8), lambda: be.knn_query(8, L1.p, L1.p, L1.o, L1.o))
-    add("knn_query L2 self k=16", knn_bytes(n2, n2, 16), lambda: be.knn_query(16, L2.p, L2.p, L2.o, L2.o))
-    add("knn_query L1->L2 down k=16", knn_bytes(n1, n2, 16), lambda: be.knn_query(16, L1.p, L2.p, L1.o, L2.o))
-    add("knn_query L2->L1 interp k=3", knn_bytes(n2, n1, 3), lambda: be.knn_query(3, L2.p, L1.p, L2.o, L1.o))
+    def pair_count(S, Q):   # sum over the scenes of (queries of the scene) x (source points of the scene)
+        so, qo = [0] + list(S.o_host), [0] + list(Q.o_host)
+        return float(sum((so[i + 1] - so[i]) * (qo[i + 1] - qo[i]) for i in range(len(S.o_host))))
+    add("knn_query L1 self k=8", knn_bytes(n1, n1, 8), lambda: be.knn_query(8, L1.p, L1.p, L1.o, L1.o), pair_count(L1, L1))
+    add("knn_query L2 self k=16", knn_bytes(n2, n2, 16), lambda: be.knn_query(16, L2.p, L2.p, L2.o, L2.o), pair_count(L2, L2))
+    add("knn_query L1->L2 down k=16", knn_bytes(n1, n2, 16), lambda: be.knn_query(16, L1.p, L2.p, L1.o, L2.o), pair_count(L1, L2))
+    add("knn_query L2->L1 interp k=3", knn_bytes(n2, n1, 3), lambda: be.knn_query(3, L2.p, L1.p, L2.o, L1.o), pair_count(L2, L1))
     # the tables as the model gets them: from the batch's Geometry (with the query level's Morton visiting order and, on first use
     # in a backward, the inverse table attached to the idx tensor)
     idx1, _ = geom.knn(8, 0, 0)
