@@ -41,6 +41,13 @@ const char *pdf_build_info(void);
  * written in IEEE fp32 (libpdfops.so), 1 = fmaf(dz,dz,fmaf(dy,dy,dx*dx)), 2 = fmaf(dz,dz,fmaf(dx,dx,dy*dy)) (libpdfops_fma{1,2}.so:
  * the contractions an `nvcc -O2` build of knn_query_cuda_kernel.cu:92 / sampling_cuda_kernel.cu:54 may compute; csrc/pdfops_common.h). */
 int pdf_dist_fma_mode(void);
+/* In-launch reductions (the BatchNorm statistics / column-sum tails of the producing kernels instead of separate reducer launches) need
+ * pdf_tickets_words() zero-initialised 32-bit words per stream, owned by the caller for as long as the stream launches through this
+ * library: bind them once with pdf_tickets_bind(stream, words).  The kernels leave every word zero again.  OPT-IN (PDFOPS_TAIL=1 in the
+ * environment): measured slower than the separate reducer launches on MI355X (csrc/api.hip), which stay the default -- the sums are the
+ * same up to the rounding of a different, equally fixed, order of additions. */
+int pdf_tickets_words(void);
+int pdf_tickets_bind(void *stream, void *words);
 
 /* replaces knn_query_cuda_launcher, libs/pointops/src/knn_query/knn_query_cuda_kernel.h:13
  * (kernel knn_query_cuda_kernel.cu:60-104).  idx (m,nsample), dist2 (m,nsample) = SQUARED distances. */
@@ -202,10 +209,6 @@ int pdf_bn_act_forward(long n, int c, const float *x, const float *res, const fl
                        float *coef, float *partial, float *y, void *stream);
 int pdf_bn_act_backward(long n, int c, const float *gy, const float *x, const float *res, const float *coef,
                         int training, int relu, float *partial, float *sums, float *gx, float *gres, void *stream);
-/* as pdf_bn_act_backward with sums zeroed by the caller (block sums added atomically, no column-sum pass) */
-int pdf_bn_act_backward_acc(long n, int c, const float *gy, const float *x, const float *res, const float *coef,
-                            int training, int relu, float *sums, float *gx, float *gres, void *stream);
-
 /* coefficients only (statistics pass + finalize, or running statistics) */
 int pdf_bn_coef(long n, int c, const float *x, const float *gamma, const float *beta, float *running_mean,
                 float *running_var, int training, float eps, float momentum, float *coef, float *partial, void *stream);
@@ -245,7 +248,13 @@ int pdf_rowlin_wgrad_multi(long n, int k, int o, int ng, const float *const *g, 
  * finishes the BatchNorm backward without re-reading y and bx for the reduction.  PDF_ERR_UNSUPPORTED outside the streaming
  * shapes (callers then use pdf_rowlin_multi + pdf_bn_act_backward). */
 int pdf_rowlin_dgrad_bstats(long n, int k, int o, int nin, const float *const *x, long ldx, const float *const *w, float *y, long ldy,
-                            const float *bx, long ldb, const float *bcoef, int brelu, float *partial, int *partial_rows, void *stream);
+                            const float *bx, long ldb, const float *bcoef, int brelu, float *partial, int *partial_rows, float *sums,
+                            void *stream);   /* sums (2 o, may be NULL) + ticket words bound: finished in the launch, *partial_rows = -1 */
+/* pdf_rowlin_forward + the coefficients (scale | shift | mean | rstd) of the train-mode BatchNorm behind it, finished inside the
+ * product's launch when ticket words are bound to the stream (pdf_tickets_bind), else by the finalizer launch. */
+int pdf_rowlin_forward_bn(long n, int k, int o, const float *x, long ldx, const float *w, const float *bias, const float *scale,
+                          const float *shift, int relu, float *y, long ldy, float *partial, const float *gamma, const float *beta,
+                          float *running_mean, float *running_var, float eps, float momentum, float *coef, void *stream);
 int pdf_bn_act_backward_presummed(long n, int c, const float *gy, const float *x, const float *coef, int training, int relu,
                                   const float *partial, int partial_rows, float *sums, float *gx, void *stream);
 

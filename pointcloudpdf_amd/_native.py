@@ -89,16 +89,32 @@ class PdfOpsError(RuntimeError):
     pass
 
 
-# opt-in (PDFOPS_RAW_STREAM=1) until the complete GPU suite has run with it on
-_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None) if os.environ.get("PDFOPS_RAW_STREAM", "0") == "1" else None
+# default since round 3: the complete GPU suite (315 tests, incl. the 10-evaluation bit-reproducibility test) passes with it on;
+# PDFOPS_RAW_STREAM=0 goes back through torch.cuda.current_stream()
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None) if os.environ.get("PDFOPS_RAW_STREAM", "1") != "0" else None
+
+
+_TICKETS = {}   # (device, stream handle) -> the stream's zero-initialised ticket words (in-launch reductions, include/pdfops.h: pdf_tickets_bind)
+
+
+def _bind_tickets(dev, handle):
+    be = hip_backend()
+    words = torch.zeros((int(be.lib.pdf_tickets_words()),), dtype=torch.int32, device=torch.device("cuda", dev))
+    rc = be.lib.pdf_tickets_bind(c_void_p(handle), c_void_p(words.data_ptr()))
+    if rc != 0:
+        raise PdfOpsError(f"pdf_tickets_bind failed with status {rc}")
+    _TICKETS[(dev, handle)] = words
 
 
 def raw_stream():
     """hipStream_t (as an integer) of torch's current stream on the current device.  ``torch.cuda.current_stream().cuda_stream`` builds a
-    Stream object per call (~12 us; ~60 calls per training step); the raw accessor torch's own code generators use takes < 1 us."""
-    if _RAW_STREAM is not None:
-        return _RAW_STREAM(torch.cuda.current_device())
-    return torch.cuda.current_stream().cuda_stream
+    Stream object per call (~12 us; ~60 calls per training step); the raw accessor torch's own code generators use takes < 1 us.
+    Every stream that launches through the library gets its ticket words bound on first use."""
+    dev = torch.cuda.current_device()
+    h = _RAW_STREAM(dev) if _RAW_STREAM is not None else torch.cuda.current_stream().cuda_stream
+    if (dev, h) not in _TICKETS:
+        _bind_tickets(dev, h)
+    return h
 
 
 def require_current_device(*tensors):
@@ -552,6 +568,10 @@ class HipBackend(CBackend):
         self.CopySeg = CopySeg
         lib.pdf_stage_copy.restype = c_int
         lib.pdf_stage_copy.argtypes = [c_int, c_void_p, c_void_p]
+        lib.pdf_tickets_words.restype = c_int
+        lib.pdf_tickets_words.argtypes = []
+        lib.pdf_tickets_bind.restype = c_int
+        lib.pdf_tickets_bind.argtypes = [c_void_p, c_void_p]
         lib.pdf_sgd_chunk.restype = c_int
         lib.pdf_sgd_chunk.argtypes = []
         lib.pdf_sgd_step.restype = c_int
@@ -578,7 +598,7 @@ class HipBackend(CBackend):
         lib.pdf_rowlin_wgrad_ws_floats.argtypes = [c_long, c_int, c_int, c_int]
         lib.pdf_rowlin_dgrad_bstats.restype = c_int
         lib.pdf_rowlin_dgrad_bstats.argtypes = [c_long, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_long,
-                                                c_void_p, c_int, c_void_p, ctypes.POINTER(c_int), c_void_p]
+                                                c_void_p, c_int, c_void_p, ctypes.POINTER(c_int), c_void_p, c_void_p]
         lib.pdf_bn_act_backward_presummed.restype = c_int
         lib.pdf_bn_act_backward_presummed.argtypes = [c_long, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
                                                       c_void_p, c_void_p]
@@ -919,14 +939,14 @@ class HipBackend(CBackend):
         dy = self._new(bx, (n, o), torch.float32)
         partial = self._new(bx, (int(self.lib.pdf_rowlin_partial_floats(n, o)),), torch.float32)
         rows = c_int(0)
+        sums = self._new(bx, (2 * o,), torch.float32)
         rc = self.lib.pdf_rowlin_dgrad_bstats(n, k, o, len(gs), self._ptrs(gs), gs[0].stride(0), self._ptrs(ws), dy.data_ptr(), o,
                                               bx.data_ptr(), bx.stride(0), coef.data_ptr(), int(bool(relu)), partial.data_ptr(),
-                                              ctypes.byref(rows), self._stream())
+                                              ctypes.byref(rows), sums.data_ptr(), self._stream())
         if rc == -3:   # PDF_ERR_UNSUPPORTED
             return None
         if rc != 0:
             raise PdfOpsError(f"pdf_rowlin_dgrad_bstats failed with status {rc}")
-        sums = self._new(bx, (2 * o,), torch.float32)
         rc = self.lib.pdf_bn_act_backward_presummed(n, o, dy.data_ptr(), bx.data_ptr(), coef.data_ptr(), int(bool(training)), int(bool(relu)),
                                                     partial.data_ptr(), rows.value, sums.data_ptr(), dy.data_ptr(), self._stream())
         if rc != 0:

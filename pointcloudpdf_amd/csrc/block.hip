@@ -55,8 +55,12 @@ extern "C" int pdf_block_pre_forward(long n, int c, void *const *p, int training
     float *rm1 = (float *)p[4], *rv1 = (float *)p[5];
     float *z1 = (float *)p[12], *coef1 = (float *)p[13], *partial = (float *)p[17];
     Err e;
-    e << pdf_rowlin_forward(n, c, c, x, c, W1, 0, nullptr, nullptr, nullptr, 0, z1, c, 0, training ? partial : nullptr, stream);
-    e << pdf_bn_coef_eval_or_partial(partial, pdf_rowlin_partial_rows(n, c, c), n, c, g1, b1, rm1, rv1, training, eps, momentum, coef1, stream);
+    if (training) {
+        e << pdf_rowlin_forward_bn(n, c, c, x, c, W1, nullptr, nullptr, nullptr, 0, z1, c, partial, g1, b1, rm1, rv1, eps, momentum, coef1, stream);
+    } else {
+        e << pdf_rowlin_forward(n, c, c, x, c, W1, 0, nullptr, nullptr, nullptr, 0, z1, c, 0, nullptr, stream);
+        e << pdf_bn_coef_eval_or_partial(partial, 0, n, c, g1, b1, rm1, rv1, 0, eps, momentum, coef1, stream);
+    }
     const float *xs[1] = {z1}, *ws[3] = {(const float *)p[6], (const float *)p[8], (const float *)p[10]};
     const float *bs[3] = {(const float *)p[7], (const float *)p[9], (const float *)p[11]};
     float *ys[3] = {(float *)p[14], (float *)p[15], (float *)p[16]};
@@ -89,7 +93,7 @@ static int block_pre_backward(long n, int c, void *const *p, int training, int a
     // bn1 backward in place on dy (elementwise: same index read and written); its column sums ARE [d beta1 | d gamma1].  The sums come
     // out of the input-gradient product's epilogue where the streaming kernel covers the shape, else from a pass over dy and z1.
     int prow = 0;
-    const int rc1 = dgrad_bstats() ? pdf_rowlin_dgrad_bstats(n, c, c, 3, gs, c, ws, dy, c, z1, c, coef1, 1, partial, &prow, stream) : PDF_ERR_UNSUPPORTED;
+    const int rc1 = dgrad_bstats() ? pdf_rowlin_dgrad_bstats(n, c, c, 3, gs, c, ws, dy, c, z1, c, coef1, 1, partial, &prow, db1, stream) : PDF_ERR_UNSUPPORTED;
     if (rc1 == PDF_ERR_UNSUPPORTED) {
         e << pdf_rowlin_multi(n, c, c, 3, 1, gs, c, ws, 1, nullptr, nullptr, nullptr, 0, ys, c, 0, stream);
         e << pdf_bn_act_backward(n, c, dy, z1, nullptr, coef1, training, 1, partial, db1, dy, nullptr, stream);   // (the atomic variant: 782 blocks on 64 addresses, +13 us)
@@ -116,9 +120,13 @@ extern "C" int pdf_block_post_forward(long n, int c, void *const *p, int trainin
     float *coef2 = (float *)p[11], *z3 = (float *)p[12], *coef3 = (float *)p[13], *y = (float *)p[14], *partial = (float *)p[15];
     Err e;
     e << pdf_bn_coef(n, c, t, (const float *)p[2], (const float *)p[3], (float *)p[4], (float *)p[5], training, eps, momentum, coef2, partial, stream);
-    e << pdf_rowlin_forward(n, c, c, t, c, (const float *)p[6], 0, nullptr, coef2, coef2 + c, 1, z3, c, 0, training ? partial : nullptr, stream);
-    e << pdf_bn_coef_eval_or_partial(partial, pdf_rowlin_partial_rows(n, c, c), n, c, (const float *)p[7], (const float *)p[8], (float *)p[9],
-                                     (float *)p[10], training, eps, momentum, coef3, stream);
+    if (training) {
+        e << pdf_rowlin_forward_bn(n, c, c, t, c, (const float *)p[6], nullptr, coef2, coef2 + c, 1, z3, c, partial, (const float *)p[7], (const float *)p[8],
+                                   (float *)p[9], (float *)p[10], eps, momentum, coef3, stream);
+    } else {
+        e << pdf_rowlin_forward(n, c, c, t, c, (const float *)p[6], 0, nullptr, coef2, coef2 + c, 1, z3, c, 0, nullptr, stream);
+        e << pdf_bn_coef_eval_or_partial(partial, 0, n, c, (const float *)p[7], (const float *)p[8], (float *)p[9], (float *)p[10], 0, eps, momentum, coef3, stream);
+    }
     e << pdf_bn_apply(n, c, z3, x, coef3, 1, y, stream);
     return e.rc;
 }
@@ -142,7 +150,7 @@ static int block_post_backward(long n, int c, void *const *p, int training, void
     // bn2 backward in place on gt (sums from the product's epilogue, as in block_pre_backward)
     int prow = 0;
     const float *das[1] = {da}, *w3s[1] = {W3};
-    const int rc2 = dgrad_bstats() ? pdf_rowlin_dgrad_bstats(n, c, c, 1, das, c, w3s, gt, c, t, c, coef2, 1, partial, &prow, stream) : PDF_ERR_UNSUPPORTED;
+    const int rc2 = dgrad_bstats() ? pdf_rowlin_dgrad_bstats(n, c, c, 1, das, c, w3s, gt, c, t, c, coef2, 1, partial, &prow, db2, stream) : PDF_ERR_UNSUPPORTED;
     if (rc2 == PDF_ERR_UNSUPPORTED) {
         e << pdf_rowlin_forward(n, c, c, da, c, W3, 1, nullptr, nullptr, nullptr, 0, gt, c, 0, nullptr, stream);
         e << pdf_bn_act_backward(n, c, gt, t, nullptr, coef2, training, 1, partial, db2, gt, nullptr, stream);
@@ -232,10 +240,13 @@ extern "C" int pdf_linbn_forward(long n, int k, int o, void *const *p, int train
     if (!pdf_bn_supported(o)) return PDF_ERR_UNSUPPORTED;
     Err e;
     float *z = (float *)p[7], *coef = (float *)p[8], *partial = (float *)p[10];
-    e << pdf_rowlin_forward(n, k, o, (const float *)p[0], k, (const float *)p[1], 0, (const float *)p[2], nullptr, nullptr, 0, z, o, 0,
-                            training ? partial : nullptr, stream);
-    e << pdf_bn_coef_eval_or_partial(partial, pdf_rowlin_partial_rows(n, k, o), n, o, (const float *)p[3], (const float *)p[4], (float *)p[5],
-                                     (float *)p[6], training, eps, momentum, coef, stream);
+    if (training) {
+        e << pdf_rowlin_forward_bn(n, k, o, (const float *)p[0], k, (const float *)p[1], (const float *)p[2], nullptr, nullptr, 0, z, o, partial,
+                                   (const float *)p[3], (const float *)p[4], (float *)p[5], (float *)p[6], eps, momentum, coef, stream);
+    } else {
+        e << pdf_rowlin_forward(n, k, o, (const float *)p[0], k, (const float *)p[1], 0, (const float *)p[2], nullptr, nullptr, 0, z, o, 0, nullptr, stream);
+        e << pdf_bn_coef_eval_or_partial(partial, 0, n, o, (const float *)p[3], (const float *)p[4], (float *)p[5], (float *)p[6], 0, eps, momentum, coef, stream);
+    }
     e << pdf_bn_apply(n, o, z, nullptr, coef, relu, (float *)p[9], stream);
     return e.rc;
 }

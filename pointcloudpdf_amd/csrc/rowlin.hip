@@ -183,7 +183,10 @@ namespace rl2 {
 int try_forward(long n, int k, int o, int nin, int nout, const float *const *x, long ldx, const float *const *w, int transpose_w,
                 const float *const *bias, const float *scale, const float *shift, int relu, float *const *y, long ldy,
                 int accumulate, float *partial, hipStream_t s, const float *roww = nullptr, long rws = 0, const float *bx = nullptr,
-                long ldb = 0, const float *bcoef = nullptr, int brelu = 0, int *partial_rows = nullptr);
+                long ldb = 0, const float *bcoef = nullptr, int brelu = 0, int *partial_rows = nullptr, const struct StatsBn *bn = nullptr);
+struct StatsBn { const float *gamma, *beta; float *running_mean, *running_var; float eps, momentum; float *out; };
+long stats_rows_floats(long n, int o);
+long stats_tail_floats(long n, int o);
 int try_wgrad(long n, int k, int o, int ng, const float *const *g, long ldg, const float *x, long ldx, const float *scale,
               const float *shift, int relu, float *const *dw, float *const *db, float *ws, hipStream_t s, const float *roww = nullptr, long rws = 0);
 long wgrad_ws_floats(long n, int k, int o, int ng);
@@ -214,9 +217,9 @@ static inline bool rowlin_streams(int k, int o) {
 extern "C" int pdf_rowlin_partial_rows(long n, int k, int o) {
     return rowlin_streams(k, o) ? rl2::stats_rows(n) : (int)((n + rl::BM - 1) / rl::BM);
 }
-extern "C" long pdf_rowlin_partial_floats(long n, int o) {
-    const long a = (n + rl::BM - 1) / rl::BM, b = rl2::stats_rows(n);
-    return (a > b ? a : b) * 2 * (long)o;
+extern "C" long pdf_rowlin_partial_floats(long n, int o) {   // rows of either kernel + the group rows of the in-launch tail
+    const long a = (n + rl::BM - 1) / rl::BM * 2 * (long)o, b = rl2::stats_rows_floats(n, o) + rl2::stats_tail_floats(n, o);
+    return a > b ? a : b;
 }
 
 // Y (n, o; row stride ldy) (+)= f(X (n, k; row stride ldx)) * Wt + bias.  transpose_w = 0: W is (o, k) row-major (forward);
@@ -255,6 +258,30 @@ extern "C" long pdf_rowlin_wgrad_ws_floats(long n, int k, int o, int ng) {
     const long tiled = (long)blocks_oc * split * 4 * 1024 + (long)((o + 31) / 32) * split * 4 * 32;   // (_multi falls back to ng single calls)
     const long streaming = rowlin_streams(k, o) ? rl2::wgrad_ws_floats(n, k, o, ng) : 0;
     return tiled > streaming ? tiled : streaming;
+}
+
+extern "C" int pdf_bn_coef_from_partial(const float *partial, int rows, long n, int c, const float *gamma, const float *beta,
+                                        float *running_mean, float *running_var, float eps, float momentum, float *coef, void *stream);
+
+// pdf_rowlin_forward with statistics + the coefficients of the train-mode BatchNorm that follows (coef = scale | shift | mean | rstd, 4 o
+// floats; running statistics updated): with ticket words bound to the stream the coefficients are finished INSIDE the product's launch
+// (in-launch tail of the statistics epilogue), otherwise by the finalizer launch -- the same coefficients either way.
+extern "C" int pdf_rowlin_forward_bn(long n, int k, int o, const float *x, long ldx, const float *w, const float *bias, const float *scale,
+                                     const float *shift, int relu, float *y, long ldy, float *partial, const float *gamma, const float *beta,
+                                     float *running_mean, float *running_var, float eps, float momentum, float *coef, void *stream) {
+    if (n < 1 || k < 1 || o < 1 || !x || !w || !y || !partial || !gamma || !beta || !coef || ldx < k || ldy < o) return PDF_ERR_BAD_ARG;
+    if (rowlin_streams(k, o)) {
+        const rl2::StatsBn bn{gamma, beta, running_mean, running_var, eps, momentum, coef};
+        int rows = 0;
+        if (rl2::try_forward(n, k, o, 1, 1, &x, ldx, &w, 0, &bias, scale, shift, relu, &y, ldy, 0, partial, static_cast<hipStream_t>(stream),
+                             nullptr, 0, nullptr, 0, nullptr, 0, &rows, &bn)) {
+            if (rows < 0) return pdf_launch_status();   // the tail wrote the coefficients
+            return pdf_bn_coef_from_partial(partial, rows, n, o, gamma, beta, running_mean, running_var, eps, momentum, coef, stream);
+        }
+    }
+    const int rc = pdf_rowlin_forward(n, k, o, x, ldx, w, 0, bias, scale, shift, relu, y, ldy, 0, partial, stream);
+    if (rc) return rc;
+    return pdf_bn_coef_from_partial(partial, pdf_rowlin_partial_rows(n, k, o), n, o, gamma, beta, running_mean, running_var, eps, momentum, coef, stream);
 }
 
 // dW (o, k) = G^T f(X), db (o) = column sums of G (db may be null); both are WRITTEN.  ws: pdf_rowlin_wgrad_ws_floats(n, k, o, 1) floats.
@@ -310,14 +337,17 @@ extern "C" int pdf_rowlin_multi(long n, int k, int o, int nin, int nout, const f
 // masked by the ReLU of bx * scale + shift, xhat = (bx - mean) * rstd; bcoef = [scale | shift | mean | rstd]) - what
 // pdf_bn_act_backward's first pass would compute from a second read of y and bx.  partial must hold pdf_rowlin_partial_floats(n, o).
 // PDF_ERR_UNSUPPORTED for shapes outside the streaming kernels (the caller then runs the two separate passes).
+// sums (2 o floats, may be null): with ticket words bound to the stream the finished sums are written there inside the launch and
+// *partial_rows is set to -1 (pdf_bn_act_backward_presummed then skips its column-sum launch).
 extern "C" int pdf_rowlin_dgrad_bstats(long n, int k, int o, int nin, const float *const *x, long ldx, const float *const *w, float *y, long ldy,
                                        const float *bx, long ldb, const float *bcoef, int brelu, float *partial, int *partial_rows,
-                                       void *stream) {
+                                       float *sums, void *stream) {
     if (n < 1 || k < 1 || o < 1 || !x || !w || !y || nin < 1 || nin > 3 || !bx || !bcoef || !partial || !partial_rows) return PDF_ERR_BAD_ARG;
     if (!rowlin_streams(k, o)) return PDF_ERR_UNSUPPORTED;
     float *ys[1] = {y};
+    const rl2::StatsBn bn{nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, sums};
     if (!rl2::try_forward(n, k, o, nin, 1, x, ldx, w, 1, nullptr, nullptr, nullptr, 0, ys, ldy, 0, partial, static_cast<hipStream_t>(stream),
-                          nullptr, 0, bx, ldb, bcoef, brelu, partial_rows))
+                          nullptr, 0, bx, ldb, bcoef, brelu, partial_rows, sums ? &bn : nullptr))
         return PDF_ERR_UNSUPPORTED;
     return pdf_launch_status();
 }

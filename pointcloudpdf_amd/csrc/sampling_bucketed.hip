@@ -11,11 +11,15 @@
 // d_fp32(k, s) >= d_bb_fp32 for every point k of the bucket, so a skipped bucket provably has min(d, tmp) == tmp for
 // all its points: pruning is EXACT, no epsilon.  16 buckets form a super-bucket with the same record, checked first.
 //
-// Execution: one single-wave workgroup per scene (a sample depends on the previous one; extra waves only add
-// barriers).  Per iteration: super check (<= 3 per lane) -> bucket check (lanes 0..15) -> 64-lane update of each
-// surviving bucket (one point per lane, coalesced 1 KiB loads from the L2-resident sorted copy) -> u64 wave
-// max-reductions.  Typical iteration touches 1-4 buckets instead of 1,563.  Roofline: latency-bound by design;
-// algorithmic HBM bytes 12N + 4M' (SURVEY.md 8d).
+// Execution (three kernels, chosen by the size of the largest scene; all give the same indices):
+//   k_fps<K>      one single-wave workgroup per scene, one sample per iteration (small scenes: extra waves only add barriers):
+//                 super check (<= 3 per lane) -> bucket check (lanes 0..15) -> 64-lane update of each surviving bucket (one point per
+//                 lane, coalesced 1 KiB loads from the L2-resident sorted copy) -> u64 wave max-reductions;
+//   k_fps_multi   several samples per ROUND, exactly (accepted prefix known before any update, see the kernel header);
+//   k_fps_mw<NW>  the same with one workgroup of NW = 8 / 16 waves per scene: wave 0 selects the round's centres, wave u owns centre u,
+//                 buckets claimed once through LDS and dealt round-robin to the waves (scenes >= 3k / 16k points).
+// A typical sample touches 1-4 buckets instead of 1,563.  Roofline: latency-bound by design; algorithmic HBM bytes 12N + 4M'
+// (SURVEY.md 8d).
 #include "pdfops_common.h"
 #include <stdlib.h>
 

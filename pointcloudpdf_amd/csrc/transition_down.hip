@@ -298,26 +298,44 @@ __global__ __launch_bounds__(64 * WPB) void k_td_din_dst(int n, int cout, const 
         float acc[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) acc[q] = 0.f;
-        for (int p = beg; p < end; ++p) {
-            const int e = inv_entry[p] - entry_base;
-            const long m = e >> 4;
-            const int j = e & 15;
+        // entries in batches of EB: the entry ids, then the EB x 3 row loads of a channel chunk go out together (the chain entry id ->
+        // rows -> ballot -> W rows is pure latency: one entry at a time it was 262 us at level 1, 4 entries per source on average)
+        constexpr int EB = 4;
+        for (int p0 = beg; p0 < end; p0 += EB) {
+            long m[EB];
+            int j[EB];
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
+                const int pp = p0 + u < end ? p0 + u : end - 1;
+                const int e = inv_entry[pp] - entry_base;
+                m[u] = e >> 4;
+                j[u] = p0 + u < end ? (e & 15) : -1;   // (-1: matches no arg byte)
+            }
             for (int cb = 0; cb < cout; cb += 64) {
                 const int c = cb + lane;
-                const size_t at = (size_t)m * cout + c;
-                const int a = arg[at];
-                const float o = out[at], g = gout[at], sc = coef[c];
-                const bool hit = a == j && o > 0.f;
-                const float val = sc * g;
-                unsigned long long mask = __ballot(hit);
-                while (mask) {
-                    const int b = __ffsll((long long)mask) - 1;
-                    mask &= mask - 1;
-                    const float sv = __shfl(val, b, 64);
-                    const float *wrow = W + (size_t)(cb + b) * D + 3;
+                const float sc = coef[c];
+                int a[EB];
+                float o[EB], g[EB];
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q)
-                        if (lane + 64 * q < CIN) acc[q] += sv * wrow[lane + 64 * q];
+                for (int u = 0; u < EB; ++u) {
+                    const size_t at = (size_t)m[u] * cout + c;
+                    a[u] = arg[at]; o[u] = out[at]; g[u] = gout[at];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < EB; ++u) {   // ascending entry id: the summation order is fixed
+                    const bool hit = a[u] == j[u] && o[u] > 0.f;
+                    const float val = sc * g[u];
+                    unsigned long long mask = __ballot(hit);
+                    while (mask) {
+                        const int b = __ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+                        const float sv = __shfl(val, b, 64);
+                        const float *wrow = W + (size_t)(cb + b) * D + 3;
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q)
+                            if (lane + 64 * q < CIN) acc[q] += sv * wrow[lane + 64 * q];
+                    }
                 }
             }
         }

@@ -61,10 +61,6 @@ class LayerNorm1d(nn.BatchNorm1d):
     are the same as BatchNorm over the (n*ns, c) view, which needs no copy."""
 
     def forward(self, input):
-        if not input.is_cuda:
-            # host-logic tests only: torch's CPU batch-norm is markedly less accurate on 2-D input, so take the
-            # upstream layout there; the device path below is the product
-            return super().forward(input.transpose(1, 2).contiguous()).transpose(1, 2).contiguous()
         shape = input.shape
         x2d = input.reshape(-1, shape[-1])
         if input.dtype == torch.float32 and _native.hip_backend().bn_supported(shape[-1]):
@@ -74,7 +70,10 @@ class LayerNorm1d(nn.BatchNorm1d):
 
 class _FusedPTLayer(torch.autograd.Function):
     """The whole PointTransformerLayer after the q/k/v projections as one autograd node over the fused HIP passes
-    (csrc/fused_layer.hip): no (n, ns, c) tensor is materialised in either direction."""
+    (csrc/fused_layer.hip).  Forward: no (n, ns, c) tensor is materialised (only ``H (n, ns, c/8)`` is saved).  Backward: the pass
+    that forms the gradient rows ``g_r (n, ns, c)`` streams them out once and a segmented gather over the inverse kNN table sums them
+    per source point (``g_xk``; no atomics, fixed order) -- one (n, ns, c) round trip through HBM per layer, which is most of the
+    Bottleneck backward's traffic."""
 
     @staticmethod
     @_amp_fwd
@@ -210,6 +209,12 @@ class TransitionDown(nn.Module):
         idx = pointops.farthest_point_sampling(p, o, n_o)
         return p[idx.long(), :].contiguous(), n_o
 
+    def _linear_bn_pool(self, x):
+        """(m, ns, 3 + c) grouped rows -> Linear -> BatchNorm -> ReLU -> max over the neighbours (point_transformer_seg.py:112-117)."""
+        m, ns = x.shape[0], x.shape[1]
+        y = _bn_act(self.bn, _lin(self.linear, x.view(m * ns, -1)), None, True)  # BN over all m*ns rows == BN1d on (m, c, ns)
+        return self.pool(y.view(m, ns, -1).transpose(1, 2)).squeeze(-1)  # (m, c)
+
     def forward(self, pxo):
         p, x, o = pxo  # (n, 3), (n, c), (b)
         if self.stride != 1:
@@ -218,16 +223,26 @@ class TransitionDown(nn.Module):
             if self.fused and tag is not None and ntag is not None and tag[0] is ntag[0] and dense.transition_down_ok(self, x):
                 return [n_p, dense.transition_down(self, tag[0], tag[1], ntag[1], x), n_o]
             x, _ = pointops.knn_query_and_group(x, p, offset=o, new_xyz=n_p, new_offset=n_o, nsample=self.nsample, with_xyz=True)
-            m, ns = x.shape[0], x.shape[1]
-            if x.is_cuda:
-                y = _bn_act(self.bn, _lin(self.linear, x.view(m * ns, -1)), None, True)  # BN over all m*ns rows == BN1d on (m, c, ns)
-                x = self.pool(y.view(m, ns, -1).transpose(1, 2)).squeeze(-1)  # (m, c)
-            else:  # host-logic tests only (see LayerNorm1d.forward)
-                x = self.pool(self.relu(self.bn(self.linear(x).transpose(1, 2).contiguous()))).squeeze(-1)
+            x = self._linear_bn_pool(x)
             p, o = n_p, n_o
         else:
             x = _bn_act(self.bn, _lin(self.linear, x), None, True)  # (n, c)
         return [p, x, o]
+
+
+class _RowsPerScene(torch.autograd.Function):
+    """``ctx (b, c)`` repeated over the points of its scene -> (N, c) (point_transformer_seg.py:155-158: ``x_b.repeat(cnt, 1)``).
+    torch.repeat_interleave's backward is an index_add_ with float atomics: the per-scene sum of the incoming rows then depends on the
+    arrival order (found by the bit-reproducibility check at 2 x 4,500 points).  Here the backward is a plain per-scene sum."""
+
+    @staticmethod
+    def forward(ctx, rows, sizes_dev, sizes_host, total):
+        ctx.sizes = [int(v) for v in sizes_host]
+        return torch.repeat_interleave(rows, sizes_dev, dim=0, output_size=total)
+
+    @staticmethod
+    def backward(ctx, g):
+        return torch.cat([ch.sum(0, keepdim=True) for ch in g.split(ctx.sizes, dim=0)], 0), None, None, None
 
 
 class TransitionUp(nn.Module):
@@ -257,7 +272,7 @@ class TransitionUp(nn.Module):
             ctx = _seq(self.linear2, means)
             tag = tag_of(p)
             sizes_dev = tag[0].sizes(tag[1]) if tag is not None else torch.diff(o.long(), prepend=o.new_zeros(1).long())
-            rep = torch.repeat_interleave(ctx, sizes_dev, dim=0, output_size=x.shape[0])
+            rep = _RowsPerScene.apply(ctx, sizes_dev, sizes, x.shape[0])
             x = _seq(self.linear1, torch.cat((x, rep), 1))
         else:
             p1, x1, o1 = pxo1
@@ -342,10 +357,13 @@ class PointTransformerSeg(nn.Module):
         self._last_geometry = geom
         return geom
 
+    @dense.fp32_path
     def forward(self, data_dict):
         geom = self.geometry_for(data_dict)
         p0, o0 = geom.coord(0), geom.offset(0)
         x0 = data_dict["feat"]
+        if x0.dtype in (torch.float16, torch.bfloat16):   # (an autocast producer upstream: the path itself is fp32)
+            x0 = x0.float()
         p1, x1, o1 = self.enc1([p0, x0, o0])
         p2, x2, o2 = self.enc2([p1, x1, o1])
         p3, x3, o3 = self.enc3([p2, x2, o2])

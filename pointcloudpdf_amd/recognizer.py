@@ -10,6 +10,7 @@
 import torch
 import torch.nn as nn
 
+from . import dense
 from .point_transformer import TransitionUp, _seq
 from .registry import MODELS, RECOGNIZER, build_model
 from .segmentor import build_criteria
@@ -29,6 +30,7 @@ class PTRecognizer(nn.Module):
             nn.Linear(planes[0], planes[0]), nn.BatchNorm1d(planes[0]), nn.ReLU(inplace=True), nn.Linear(planes[0], 1)
         )
 
+    @dense.fp32_path
     def forward(self, model_hooks):
         enc = [model_hooks[f"backbone.enc{i}"]["forward_output"] for i in range(1, 6)]
         dec = [model_hooks[f"backbone.dec{i}.1"]["forward_output"][1] for i in range(1, 6)]
@@ -93,6 +95,7 @@ class PointPdfV1(nn.Module):
             self.alpha = self.alpha * 0.1
             self.step_loss_weight = False
 
+    @dense.fp32_path
     def forward(self, input_dict):
         seg_logits = self.model_hooks["backbone"]["forward_output"]
         self.trigger_operation()

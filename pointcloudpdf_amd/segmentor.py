@@ -100,6 +100,9 @@ class DefaultSegmentor(nn.Module):
         self.criteria = build_criteria(criteria)
 
     def forward(self, input_dict):
+        if torch.is_autocast_enabled("cuda"):   # the path is fp32 (dense.fp32_path): the loss as well
+            with torch.autocast("cuda", enabled=False):
+                return self.forward(input_dict)
         if "condition" in input_dict.keys():
             input_dict["condition"] = input_dict["condition"][0]
         seg_logits = self.backbone(input_dict)

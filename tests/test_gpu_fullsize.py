@@ -170,7 +170,8 @@ def test_config4_full_size_step_with_the_pseudo_label_pass(oracle_backend):
                                        order=torch.arange(n, dtype=torch.int32))
     assert torch.equal(i_o, i_g.cpu()[q])
     filled = (i_g >= 0).sum(1).float()
-    assert 4 <= float(filled.mean()) <= 64 and int((i_g[:, 0] == torch.arange(n, device="cuda")).sum()) > 0.99 * n   # every ball holds its own centre first
+    assert 4 <= float(filled.mean()) <= 64
+    assert bool(((i_g == torch.arange(n, device="cuda", dtype=i_g.dtype)[:, None]).any(1) | (filled == 64)).all())   # a ball that is not full holds its own centre
     # -- the step with the pass
     kw = dict(condition_from="msp", beta=1.5, seed_from="ml", seed_range=0.15, num_seed=100, slide_window=True)
     fn = pseudo_label.make_pseudo_mask_fn(radius=0.02 * 5, max_neighbor=64, **kw)

@@ -313,3 +313,61 @@ def test_training_step_is_bit_reproducible(golden_dir):
         assert set(cur) == set(first)
         bad = [k for k in first if not torch.equal(first[k], cur[k])]
         assert not bad, f"evaluation {it} differs from evaluation 0 in {len(bad)} tensors, e.g. {bad[:5]}"
+
+
+@pytest.mark.parametrize("sizes", [[5000, 4000], [20000, 17000]])
+def test_engine_step_is_bit_reproducible(sizes):
+    """engine.OpenSegStep (segmentor + CE, hook tap, U-decoder + PDF loss, one backward) three times on one batch: loss, every tapped
+    feature and all 609 parameter gradients bit-identical -- at sizes where every level holds tens to thousands of points (the head's
+    per-scene context broadcast used to sum its gradient with index_add_ atomics: point_transformer._RowsPerScene)."""
+    from pointcloudpdf_amd import engine, synthetic
+
+    dev = torch.device("cuda", 0)
+    batch = synthetic.make_batch(sizes, first_scene_id=30, device=dev)
+    runs = []
+    for _ in range(3):
+        step = engine.OpenSegStep().to(dev)
+        synthetic.fill_parameters_deterministic(step, seed=5)
+        step.train()
+        out = step(dict(batch))
+        out["loss"].backward()
+        runs.append(dict(loss=out["loss"].detach().clone(), score=out["score"].detach().clone(),
+                         grads={n: p.grad.detach().clone() for n, p in step.named_parameters() if p.grad is not None}))
+        engine.release_autograd_state(step)
+    for k in (1, 2):
+        assert torch.equal(runs[0]["loss"], runs[k]["loss"]) and torch.equal(runs[0]["score"], runs[k]["score"])
+        bad = [n for n in runs[0]["grads"] if not torch.equal(runs[0]["grads"][n], runs[k]["grads"][n])]
+        assert not bad, f"evaluation {k}: {len(bad)} of {len(runs[0]['grads'])} gradients differ from evaluation 0, e.g. {bad[:4]}"
+
+
+def test_autocast_leaves_the_fp32_path_untouched():
+    """The reference trains this path under AMP (enable_amp = True, engines/train.py:340-363).  The modules opt out of autocast
+    (dense.fp32_path: every kernel is fp32): a step under torch.autocast(float16) gives the SAME kNN / FPS tables, bit-identical
+    logits, losses and gradients as the plain step, fp32 outputs -- enabling AMP in a trainer config costs nothing."""
+    from pointcloudpdf_amd import engine, synthetic
+
+    dev = torch.device("cuda", 0)
+    batch = synthetic.make_batch([5000, 4000], first_scene_id=30, device=dev)
+    res = []
+    for amp in (False, True, False):
+        step = engine.OpenSegStep().to(dev)
+        synthetic.fill_parameters_deterministic(step, seed=5)
+        step.train()
+        with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+            out = step(dict(batch))
+        out["loss"].backward()
+        geom = step.model.backbone._last_geometry
+        logits = step.hooks["backbone"]["forward_output"]
+        assert logits.dtype == torch.float32 and out["loss"].dtype == torch.float32
+        res.append(dict(loss=out["loss"].detach().clone(), logits=logits.detach().clone(), score=out["score"].detach().clone(),
+                        knn=geom.knn(16, 1, 1)[0].clone(), fps=geom.down(0, 4)[1].clone(),
+                        grads={n: p.grad.detach().clone() for n, p in step.named_parameters() if p.grad is not None}))
+        engine.release_autograd_state(step)
+    a, b, a2 = res
+    same = [n for n in a["grads"] if not torch.equal(a["grads"][n], a2["grads"][n])]
+    assert not same, ("two PLAIN steps differ", same[:6], max(float((a["grads"][n] - a2["grads"][n]).abs().max() / (a["grads"][n].abs().max() + 1e-30)) for n in same))
+    assert torch.equal(a["knn"], b["knn"]) and torch.equal(a["fps"], b["fps"])
+    assert torch.equal(a["logits"], b["logits"]) and torch.equal(a["loss"], b["loss"]) and torch.equal(a["score"], b["score"])
+    assert set(a["grads"]) == set(b["grads"]), sorted(set(a["grads"]) ^ set(b["grads"]))[:6]
+    bad = [n for n in a["grads"] if not torch.equal(a["grads"][n], b["grads"][n])]
+    assert not bad, (bad[:6], max(float((a["grads"][n] - b["grads"][n]).abs().max() / (a["grads"][n].abs().max() + 1e-30)) for n in bad))
