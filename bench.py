@@ -89,8 +89,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ops-roofline", action="store_true", help="skip the per-op HBM roofline micro-benchmark (rank 0, N = 1)")
     ap.add_argument("--cpu-points", type=int, default=100000, help="scene size of the bounded CPU-baseline sample")
-    ap.add_argument("--amp", action="store_true", help="fp16 autocast around the step (reference enable_amp=True)")
-    ap.add_argument("--storage", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--amp", nargs="?", const="bf16", default=None, choices=["bf16", "f16"],
+                    help="torch.autocast around the step (reference: enable_amp = True, engines/train.py:340-363): the streaming Linear products "
+                         "run with bfloat16 (default) / fp16 operands on the 16x16x16 matrix-core instructions, fp32 storage and accumulation "
+                         "(dense.fp32_path).  f16 adds a static loss scale of 4096 for the backward (the reference uses a GradScaler)")
+    ap.add_argument("--storage", choices=["f32", "bf16"], default=os.environ.get("PDFOPS_STORAGE", "f32"),
                     help="bf16: the reduced-precision variant -- the fused PointTransformerLayer keeps its saved / scratch row arrays (H, G2, "
                          "softmax weights, g_r rows) as bfloat16 with fp32 accumulation (the reference trains under AMP); the headline stays f32")
     ap.add_argument("--prefetch", type=int, default=16,
@@ -438,13 +441,15 @@ def main():
     # Python / dispatch work competes with the training thread for the interpreter: 17.7-18.6 vs 18.2-18.4 ms per step)
     prefetcher = GeometryPrefetcher(depth=2, threaded=bool(os.environ.get("PDFOPS_PREPASS_THREAD")))
 
-    graph_ok = (args.jitter <= 0 and not args.amp and not args.pseudo_label and not args.throttle and not strat
-                and not (use_dp and args.ddp == "torch") and args.storage == "f32")
+    amp_dtype = {None: None, "bf16": torch.bfloat16, "f16": torch.float16}[args.amp]
+    loss_scale = 4096.0 if args.amp == "f16" else 1.0
+    graph_ok = (args.jitter <= 0 and not args.pseudo_label and not args.throttle and not strat
+                and not (use_dp and args.ddp == "torch"))
     if args.graph == "1" and not graph_ok:
         raise SystemExit("bench.py: --graph 1 needs fixed scene sizes and the plain f32 PointTransformer step (see --help)")
     captured = None
     if args.graph == "1" or (args.graph == "auto" and graph_ok):
-        captured = engine.CapturedStep(step, pool[0])       # set-up (like building the model): eager warm-up passes + one capture
+        captured = engine.CapturedStep(step, pool[0], autocast=amp_dtype, loss_scale=loss_scale)       # set-up (like building the model): eager warm-up passes + one capture
         torch.cuda.synchronize()
 
     class Schedule:
@@ -519,9 +524,14 @@ def main():
             out = captured(batch, geom)
         else:
             opt.zero_grad(set_to_none=True)
-            with torch.autocast("cuda", dtype=torch.float16, enabled=args.amp):
+            with torch.autocast("cuda", dtype=amp_dtype or torch.float16, enabled=amp_dtype is not None):
                 out = module(data)
-            out["loss"].backward()
+            if loss_scale == 1.0:
+                out["loss"].backward()
+            else:
+                (out["loss"] * loss_scale).backward()
+                with torch.no_grad():
+                    torch._foreach_mul_([p.grad for p in step.parameters() if p.grad is not None], 1.0 / loss_scale)
         if grad_sync is not None:
             grad_sync.sync(force=force_dp)   # ONE all-reduce (RCCL) over the flat gradient buffer
         opt.step()
@@ -618,7 +628,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16-autocast" if args.amp else ("bf16-storage/f32-acc" if args.storage == "bf16" else "f32"),
+            "dtype": (f"{args.amp}-autocast (product operands {args.amp}, f32 storage / accumulation)") if args.amp else ("bf16-storage/f32-acc" if args.storage == "bf16" else "f32"),
             "data": "synthetic",
             "config": {"workload": f"{'ScanNet' if scannet else 'S3DIS'}-shaped synthetic voxelised scenes, {args.scenes} x {args.points} points per GPU, "
                                    + ("StratifiedTransformer ST-v1m1 + PointPdf-v1m1 / ST-v1m1-Recognizer, fwd+bwd+SGD, window partition recomputed every step" if strat else

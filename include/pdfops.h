@@ -48,6 +48,14 @@ int pdf_dist_fma_mode(void);
  * same up to the rounding of a different, equally fixed, order of additions. */
 int pdf_tickets_words(void);
 int pdf_tickets_bind(void *stream, void *words);
+/* Reduced-precision variant of the per-point Linear layers (the reference trains this path under torch.cuda.amp.autocast:
+ * configs/s3dis/openseg-pt-v1-0-msp.py:6, pointcept/engines/train.py:340-363).  mode 0 (default): fp32 operands, v_mfma_f32_16x16x4_f32 --
+ * the parity path; 1: the operands of the streaming pdf_rowlin_* products (forward, input gradient, weight gradient; channel widths
+ * 32..512) are rounded to fp16 in registers and multiplied with v_mfma_f32_16x16x16_f16; 2: the same with bfloat16.  Tensors stay fp32
+ * in memory and every accumulation is fp32 in all modes (what autocast does to nn.Linear, minus the rounding of the OUTPUT to half).
+ * Process-wide; read when a launch is issued.  Returns PDF_ERR_BAD_ARG for any other mode. */
+int pdf_set_mma_input(int mode);
+int pdf_get_mma_input(void);
 
 /* replaces knn_query_cuda_launcher, libs/pointops/src/knn_query/knn_query_cuda_kernel.h:13
  * (kernel knn_query_cuda_kernel.cu:60-104).  idx (m,nsample), dist2 (m,nsample) = SQUARED distances. */

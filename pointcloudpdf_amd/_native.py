@@ -572,6 +572,10 @@ class HipBackend(CBackend):
         lib.pdf_tickets_words.argtypes = []
         lib.pdf_tickets_bind.restype = c_int
         lib.pdf_tickets_bind.argtypes = [c_void_p, c_void_p]
+        lib.pdf_set_mma_input.restype = c_int
+        lib.pdf_set_mma_input.argtypes = [c_int]
+        lib.pdf_get_mma_input.restype = c_int
+        lib.pdf_get_mma_input.argtypes = []
         lib.pdf_sgd_chunk.restype = c_int
         lib.pdf_sgd_chunk.argtypes = []
         lib.pdf_sgd_step.restype = c_int
@@ -1209,6 +1213,44 @@ def hip_backend():
             if _hip is None:
                 _hip = HipBackend(load_library())
     return _hip
+
+
+# Input precision of the matrix-core products of the streaming Linear kernels (include/pdfops.h: pdf_set_mma_input): 0 fp32 operands (the
+# parity path), 1 fp16, 2 bfloat16 -- fp32 storage and accumulation in every mode.  ``dense.fp32_path`` selects 1 / 2 for a forward that
+# runs under torch.autocast(float16 / bfloat16); every autograd node remembers the mode of its forward and restores it for its backward.
+_MMA_INPUT = 0
+MMA_INPUT_OF_DTYPE = {torch.float16: 1, torch.bfloat16: 2}
+
+
+def current_mma_input():
+    return _MMA_INPUT
+
+
+def _apply_mma_input(mode):
+    global _MMA_INPUT
+    if _hip is not None or (_override is None and torch.cuda.is_available()):
+        rc = hip_backend().lib.pdf_set_mma_input(int(mode))
+        if rc != 0:
+            raise PdfOpsError(f"pdf_set_mma_input({mode}) failed with status {rc}")
+    _MMA_INPUT = int(mode)
+
+
+class mma_input:
+    """``with mma_input(mode):`` -- the library's product-input mode for the launches issued inside (no-op when it is already set)."""
+
+    def __init__(self, mode):
+        self.mode = int(mode)
+
+    def __enter__(self):
+        self.prev = _MMA_INPUT
+        if self.mode != self.prev:
+            _apply_mma_input(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        if self.mode != self.prev:
+            _apply_mma_input(self.prev)
+        return False
 
 
 def backend_for(t):

@@ -99,7 +99,8 @@ __device__ __forceinline__ unsigned pdf_xcd_chunked_block(unsigned b, unsigned g
 // bound to the stream (pdf_tickets_bind): launches of one stream do not overlap, launches of different streams use different arrays.
 #define PDF_TAIL_G 32
 #define PDF_TICKET_WORDS 4096
-unsigned *pdf_tickets_for(hipStream_t s);   // nullptr: none bound for this stream (callers then keep their separate reducer launch)
+unsigned *pdf_tickets_for(hipStream_t s, long n);
+int pdf_mma_input_mode();   // api.hip: 0 fp32 / 1 fp16 / 2 bfloat16 operands of the streaming Linear products (pdf_set_mma_input)   // nullptr: none bound for this stream (callers then keep their separate reducer launch)
 
 __device__ __forceinline__ bool pdf_arrive_last(unsigned *ticket, unsigned expected, volatile unsigned *lds_flag) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // every storing wave drains its stores

@@ -226,7 +226,7 @@ static inline size_t stats_lds(int c, bool tail) { const size_t a = PB * 8 * siz
 static inline StatsTail stats_tail(hipStream_t s, float *partial, long n, int c, const float *gamma, const float *beta, float eps, float momentum,
                                    float *running_mean, float *running_var, float *coef) {
     StatsTail t;
-    t.tickets = pdf_tickets_for(s);
+    t.tickets = pdf_tickets_for(s, n);
     t.grows = reinterpret_cast<double *>(partial + bn_rows_floats(n, c));
     t.count = (double)n; t.gamma = gamma; t.beta = beta; t.eps = eps; t.momentum = momentum;
     t.running_mean = running_mean; t.running_var = running_var;
@@ -278,7 +278,7 @@ static int bn_act_backward(long n, int c, const float *gy, const float *x, const
     } else if (presummed > 0) {
         fl::launch_colsum(partial, presummed, 2 * c, sums, s);
     } else {
-        unsigned *tk = pdf_tickets_for(s);
+        unsigned *tk = pdf_tickets_for(s, n);
         (res ? pw::k_bn_bwd_reduce<true> : pw::k_bn_bwd_reduce<false>)<<<g, pw::PB, pw::PB * 8 * sizeof(float), s>>>(
             n, c, gy, x, res, scale, shift, mean, rstd, relu, partial, tk, reinterpret_cast<double *>(partial + bn_rows_floats(n, c)), sums);
         if (!tk) fl::launch_colsum(partial, g, 2 * c, sums, s);
@@ -355,7 +355,7 @@ extern "C" int pdf_bn_bwd_sums(long n, int c, const float *gy, const float *x, c
     if (!pdf_bn_supported(c)) return PDF_ERR_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int g = pw::grid_rows(n, c);
-    unsigned *tk = pdf_tickets_for(s);
+    unsigned *tk = pdf_tickets_for(s, n);
     pw::k_bn_bwd_reduce<false><<<g, pw::PB, pw::PB * 8 * sizeof(float), s>>>(n, c, gy, x, nullptr, coef, coef + c, coef + 2 * c, coef + 3 * c, relu, partial,
                                                                       tk, reinterpret_cast<double *>(partial + bn_rows_floats(n, c)), sums);
     if (!tk) fl::launch_colsum(partial, g, 2 * c, sums, s);

@@ -7,32 +7,70 @@ keeps nn.Linear's parameters but routes that one product through a batched GEMM 
 as a batch: S = N / 2048 independent products, summed afterwards), which fills the chip.
 """
 import ctypes
+import os
 from ctypes import c_void_p
 
 import torch
 
-# custom autograd nodes run in fp32 under autocast (the kernels are fp32; upstream's python ops promote to fp32 the same way)
-_amp_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-_amp_bwd = torch.amp.custom_bwd(device_type="cuda")
+# Custom autograd nodes keep fp32 tensors under autocast (upstream's python ops promote to fp32 the same way); a node remembers the
+# product-input mode of its forward (fp32 / fp16 / bfloat16 operands of the streaming Linear kernels, _native.mma_input) and restores it
+# for its backward, which runs outside the autocast region.
+def _amp_fwd(fn):
+    import functools
+
+    from . import _native
+    inner = torch.amp.custom_fwd(fn, device_type="cuda", cast_inputs=torch.float32)
+
+    @functools.wraps(fn)
+    def wrapped(ctx, *args, **kwargs):
+        ctx._pdf_mma = _native.current_mma_input()
+        return inner(ctx, *args, **kwargs)
+
+    return wrapped
+
+
+def _amp_bwd(fn):
+    import functools
+
+    from . import _native
+    inner = torch.amp.custom_bwd(fn, device_type="cuda")
+
+    @functools.wraps(fn)
+    def wrapped(ctx, *grads):
+        with _native.mma_input(getattr(ctx, "_pdf_mma", 0)):
+            return inner(ctx, *grads)
+
+    return wrapped
+
+
 import torch.nn.functional as F
 
 _CHUNK = 2048
 _MIN_ROWS = 16384
 
 
+amp_mma = os.environ.get("PDFOPS_AMP_MMA", "1") != "0"   # 0: autocast leaves the products in fp32 as well (bit-identical to no autocast)
+
+
 def fp32_path(fn):
-    """Decorator of the model-level forwards: the path's kernels are fp32 (fp32 MFMA 16x16x4, fp32 BatchNorm statistics), so under
-    ``torch.autocast`` -- the reference's trainer runs with ``enable_amp = True`` (configs/s3dis/openseg-pt-v1-0-msp.py:6,
-    engines/train.py:340-363) -- the modules opt OUT instead of letting autocast wrap the remaining torch ops in half precision and
-    the custom nodes in casts (measured in round 2: 30.9 ms vs 17 ms per step).  Enabling AMP in a trainer config therefore costs
-    nothing and changes nothing: same kernels, same logits.  (The reduced-precision variant of this path is bf16 STORAGE of the
-    layer's row arrays, ``HipBackend.set_storage("bf16")``.)"""
+    """Decorator of the model-level forwards.  Every tensor of the path is fp32 (BatchNorm statistics, gathers, attention and all
+    accumulators included), so under ``torch.autocast`` -- the reference's trainer runs with ``enable_amp = True``
+    (configs/s3dis/openseg-pt-v1-0-msp.py:6, engines/train.py:340-363) -- the modules opt OUT of autocast's per-op casts (measured in
+    round 2: wrapping the remaining torch ops in half precision and the custom nodes in casts costs 30.9 ms vs 17 ms per step) and run
+    the reduced-precision variant of the path instead: the operands of the streaming Linear products (forward, input gradient, weight
+    gradient) are rounded to the autocast dtype (fp16 / bfloat16) in registers and multiplied on the 16x16x16 matrix-core instructions,
+    with fp32 accumulation (csrc/rowlin2_impl.h: Mma; ``_native.mma_input``).  Geometry (kNN / FPS tables) is unaffected; logits move by
+    the rounding of the operands (~1e-3).  ``PDFOPS_AMP_MMA=0`` / ``dense.amp_mma = False`` keeps fp32 operands: autocast then changes
+    nothing at all."""
     import functools
 
     @functools.wraps(fn)
     def wrapped(*args, **kwargs):
         if torch.is_autocast_enabled("cuda"):
-            with torch.autocast("cuda", enabled=False):
+            from . import _native
+
+            mode = _native.MMA_INPUT_OF_DTYPE.get(torch.get_autocast_dtype("cuda"), 0) if amp_mma else 0
+            with torch.autocast("cuda", enabled=False), _native.mma_input(mode):
                 return fn(*args, **kwargs)
         return fn(*args, **kwargs)
 

@@ -104,8 +104,13 @@ class CapturedStep:
 
     KEYS = ("coord", "feat", "offset", "segment")
 
-    def __init__(self, step, batch, geom=None, warmup=2):
+    def __init__(self, step, batch, geom=None, warmup=2, autocast=None, loss_scale=1.0):
+        """``autocast``: torch.float16 / torch.bfloat16 -> the forward is captured under torch.autocast (the path then runs its
+        reduced-precision products, dense.fp32_path); ``loss_scale``: static scale of the loss for the backward (fp16 operands: gradients of
+        ~1e-6 are below fp16's normal range), divided out of the gradients again inside the graph."""
         from .geometry import Geometry, StaticGeometry
+
+        self.autocast, self.loss_scale = autocast, float(loss_scale)
 
         assert step.training, "CapturedStep captures a TRAINING step (forward + backward)"
         self.step = step
@@ -128,7 +133,7 @@ class CapturedStep:
             for _ in range(max(int(warmup), 1)):   # lazily created handles / caches must exist before the capture
                 for p in self.params:
                     p.grad = None
-                self._eager()["loss"].backward()
+                self._backward(self._eager())
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         for p in self.params:
@@ -143,7 +148,7 @@ class CapturedStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=side):
             self.out = self._eager()
-            self.out["loss"].backward()
+            self._backward(self.out)
         self.grads = [p.grad for p in self.params]
         with torch.no_grad():   # (the capture itself does not execute anything, but keep the contract obvious)
             for b, v in zip(buffers, saved):
@@ -151,7 +156,16 @@ class CapturedStep:
         release_autograd_state(step)
 
     def _eager(self):
-        return self.step(dict(self.static, pdf_geometry=self.geometry))
+        with torch.autocast("cuda", dtype=self.autocast or torch.float16, enabled=self.autocast is not None):
+            return self.step(dict(self.static, pdf_geometry=self.geometry))
+
+    def _backward(self, out):
+        if self.loss_scale == 1.0:
+            out["loss"].backward()
+        else:
+            (out["loss"] * self.loss_scale).backward()
+            with torch.no_grad():
+                torch._foreach_mul_([p.grad for p in self.params if p.grad is not None], 1.0 / self.loss_scale)
 
     def matches(self, batch):
         return [int(v) for v in batch["offset_host"]] == self.sizes and all(batch[k].shape == self.static[k].shape for k in self.KEYS)

@@ -17,15 +17,12 @@ import os
 
 import torch
 
-# custom autograd nodes run in fp32 under autocast (the kernels are fp32; upstream's python ops promote to fp32 the same way)
-_amp_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-_amp_bwd = torch.amp.custom_bwd(device_type="cuda")
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _native, pointops
 from . import dense
-from .dense import bn_act as _bn_act, linear as _lin
+from .dense import _amp_bwd, _amp_fwd, bn_act as _bn_act, linear as _lin   # (custom nodes keep fp32 tensors under autocast: dense.py)
 from .geometry import Geometry, tag_of
 from .registry import MODELS
 

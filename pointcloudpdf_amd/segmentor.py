@@ -1,12 +1,10 @@
 """Segmentor wrapper and losses of the hot path -- pointcept/models/default.py:39-62,
 pointcept/models/losses/builder.py:13-27, pointcept/models/losses/misc.py:14-39 (contract only: dict in, dict out)."""
 import torch
-
-# custom autograd nodes run in fp32 under autocast (the kernels are fp32; upstream's python ops promote to fp32 the same way)
-_amp_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-_amp_bwd = torch.amp.custom_bwd(device_type="cuda")
 import torch.nn as nn
 
+from . import dense
+from .dense import _amp_bwd, _amp_fwd   # (custom nodes keep fp32 tensors under autocast: dense.py)
 from .registry import LOSSES, MODELS, build_model
 
 
@@ -99,10 +97,8 @@ class DefaultSegmentor(nn.Module):
         self.backbone = build_model(backbone)
         self.criteria = build_criteria(criteria)
 
+    @dense.fp32_path   # (the loss as well: fp32 tensors, reduced-precision product operands only -- dense.fp32_path)
     def forward(self, input_dict):
-        if torch.is_autocast_enabled("cuda"):   # the path is fp32 (dense.fp32_path): the loss as well
-            with torch.autocast("cuda", enabled=False):
-                return self.forward(input_dict)
         if "condition" in input_dict.keys():
             input_dict["condition"] = input_dict["condition"][0]
         seg_logits = self.backbone(input_dict)

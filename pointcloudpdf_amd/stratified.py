@@ -290,6 +290,30 @@ class StratifiedGeometry:
         self.samples[key] = (pointops.furthestsampling(xyz, off, n_off), n_off)
         return self.samples[key] + (n_ends,)
 
+    def _sample_pair(self, level, xyz, off, ends, fn_keys, fn_down):
+        """The window-key subset and the TransitionDown sample of one level from ONE farthest-point run.  Sample j of the reference's
+        kernel is the arg-max after j - 1 insertions whatever the requested count (sampling_cuda_kernel.cu:42-127: the loop bound is the
+        only use of m; the block size / tie rule depends on n alone), so the shorter subset is the per-scene PREFIX of the longer one:
+        one chain of max(keys, down) dependent steps per scene instead of two (bit-identical indices, tests/test_gpu_pointops2.py)."""
+        k_ends, d_ends = _strided_counts(ends, fn_keys), _strided_counts(ends, fn_down)
+        k_cnt = [e - (k_ends[i - 1] if i else 0) for i, e in enumerate(k_ends)]
+        d_cnt = [e - (d_ends[i - 1] if i else 0) for i, e in enumerate(d_ends)]
+        l_cnt = [max(a, b) for a, b in zip(k_cnt, d_cnt)]
+        l_ends = [sum(l_cnt[:i + 1]) for i in range(len(l_cnt))]
+        to_dev = lambda v: torch.tensor(v, dtype=torch.int32).to(xyz.device, non_blocking=True)
+        l_off = to_dev(l_ends)
+        long_idx = pointops.furthestsampling(xyz, off, l_off)
+
+        def prefix(cnt, c_ends):
+            if cnt == l_cnt:
+                return long_idx, l_off
+            parts = [long_idx[(l_ends[i] - l_cnt[i]):(l_ends[i] - l_cnt[i]) + c] for i, c in enumerate(cnt)]
+            return (parts[0] if len(parts) == 1 else torch.cat(parts)).contiguous(), to_dev(c_ends)
+
+        self.samples[("keys", level)] = prefix(k_cnt, k_ends)
+        self.samples[("down", level)] = prefix(d_cnt, d_ends)
+        return self.samples[("keys", level)][0], self.samples[("down", level)] + (d_ends,)
+
     def precompute(self, layers=None):
         """``layers``: the model's BasicLayers by level (``StratifiedTransformer.layers_by_level()``) -> also their window edge tables.
         Those have data-dependent shapes (host reads of counts), so that part belongs on a worker thread (StratifiedPrefetcher)."""
@@ -301,9 +325,10 @@ class StratifiedGeometry:
                 idx, off, ends = self._sample(("down", "stem"), xyz, off, ends, lambda n: int(n * ratio) + 1)
                 xyz, level = xyz[idx.long(), :].contiguous(), 1
             for l in range(level, num_layers):
-                keys = self._sample(("keys", l), xyz, off, ends, lambda n: n // scale + 1)[0]
-                if l < num_layers - 1:
-                    idx, n_off, n_ends = self._sample(("down", l), xyz, off, ends, lambda n: int(n * ratio) + 1)
+                if l < num_layers - 1:   # both subsets of the level from one farthest-point run
+                    keys, (idx, n_off, n_ends) = self._sample_pair(l, xyz, off, ends, lambda n: n // scale + 1, lambda n: int(n * ratio) + 1)
+                else:
+                    keys = self._sample(("keys", l), xyz, off, ends, lambda n: n // scale + 1)[0]
                 if layers is not None:
                     self.windows[l] = layers[l].window_tables(xyz, off, keys)
                 if l < num_layers - 1:

@@ -340,30 +340,41 @@ def test_engine_step_is_bit_reproducible(sizes):
         assert not bad, f"evaluation {k}: {len(bad)} of {len(runs[0]['grads'])} gradients differ from evaluation 0, e.g. {bad[:4]}"
 
 
-def test_autocast_leaves_the_fp32_path_untouched():
-    """The reference trains this path under AMP (enable_amp = True, engines/train.py:340-363).  The modules opt out of autocast
-    (dense.fp32_path: every kernel is fp32): a step under torch.autocast(float16) gives the SAME kNN / FPS tables, bit-identical
-    logits, losses and gradients as the plain step, fp32 outputs -- enabling AMP in a trainer config costs nothing."""
+def _autocast_runs(dtype, modes=(False, True, False), loss_scale=1.0):
     from pointcloudpdf_amd import engine, synthetic
 
     dev = torch.device("cuda", 0)
     batch = synthetic.make_batch([5000, 4000], first_scene_id=30, device=dev)
     res = []
-    for amp in (False, True, False):
+    for amp in modes:
         step = engine.OpenSegStep().to(dev)
         synthetic.fill_parameters_deterministic(step, seed=5)
         step.train()
-        with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+        with torch.autocast("cuda", dtype=dtype, enabled=amp):
             out = step(dict(batch))
-        out["loss"].backward()
+        (out["loss"] * loss_scale).backward()   # (a power of two: exact in fp32; what a GradScaler does for the fp16 operands of the backward)
+        for p in step.parameters():
+            if p.grad is not None:
+                p.grad.mul_(1.0 / loss_scale)
         geom = step.model.backbone._last_geometry
         logits = step.hooks["backbone"]["forward_output"]
         assert logits.dtype == torch.float32 and out["loss"].dtype == torch.float32
+        assert all(p.grad.dtype == torch.float32 for p in step.parameters() if p.grad is not None)
         res.append(dict(loss=out["loss"].detach().clone(), logits=logits.detach().clone(), score=out["score"].detach().clone(),
                         knn=geom.knn(16, 1, 1)[0].clone(), fps=geom.down(0, 4)[1].clone(),
                         grads={n: p.grad.detach().clone() for n, p in step.named_parameters() if p.grad is not None}))
         engine.release_autograd_state(step)
-    a, b, a2 = res
+    return res
+
+
+def test_autocast_with_fp32_operands_changes_nothing(monkeypatch):
+    """The reference trains this path under AMP (enable_amp = True, engines/train.py:340-363).  The modules opt out of autocast's per-op
+    casts (dense.fp32_path); with the reduced-precision products switched off (PDFOPS_AMP_MMA=0 / dense.amp_mma = False) a step under
+    torch.autocast(float16) gives the SAME kNN / FPS tables and bit-identical logits, losses and gradients as the plain step."""
+    from pointcloudpdf_amd import dense
+
+    monkeypatch.setattr(dense, "amp_mma", False)
+    a, b, a2 = _autocast_runs(torch.float16)
     same = [n for n in a["grads"] if not torch.equal(a["grads"][n], a2["grads"][n])]
     assert not same, ("two PLAIN steps differ", same[:6], max(float((a["grads"][n] - a2["grads"][n]).abs().max() / (a["grads"][n].abs().max() + 1e-30)) for n in same))
     assert torch.equal(a["knn"], b["knn"]) and torch.equal(a["fps"], b["fps"])
@@ -371,3 +382,30 @@ def test_autocast_leaves_the_fp32_path_untouched():
     assert set(a["grads"]) == set(b["grads"]), sorted(set(a["grads"]) ^ set(b["grads"]))[:6]
     bad = [n for n in a["grads"] if not torch.equal(a["grads"][n], b["grads"][n])]
     assert not bad, (bad[:6], max(float((a["grads"][n] - b["grads"][n]).abs().max() / (a["grads"][n].abs().max() + 1e-30)) for n in bad))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_autocast_runs_the_reduced_precision_products(dtype):
+    """Under torch.autocast the streaming Linear products (forward, input and weight gradients) run with fp16 / bfloat16 operands on
+    the 16x16x16 matrix-core instructions, fp32 accumulation, fp32 tensors (dense.fp32_path): kNN / FPS tables identical to the fp32
+    step, logits within 1e-2 (fp16; 4e-2 bfloat16) of the fp32 logits relative to their largest magnitude, loss within 1e-2, the parameter
+    gradients within 5e-2 (1.5e-1) in the relative L2 norm over all parameters -- and the backward, which runs OUTSIDE the autocast
+    region, uses the mode of its forward (a second plain step afterwards is bit-identical to the first).  fp16: the loss is scaled by
+    4096 for the backward, as the reference's GradScaler does (gradients of ~1e-6 are below fp16's normal range)."""
+    from pointcloudpdf_amd import _native
+
+    a, b, a2 = _autocast_runs(dtype, loss_scale=4096.0 if dtype == torch.float16 else 1.0)
+    assert _native.current_mma_input() == 0 and _native.hip_backend().lib.pdf_get_mma_input() == 0
+    assert torch.equal(a["knn"], b["knn"]) and torch.equal(a["fps"], b["fps"])
+    assert torch.equal(a["logits"], a2["logits"]) and all(torch.equal(a["grads"][n], a2["grads"][n]) for n in a["grads"])
+    assert not torch.equal(a["logits"], b["logits"]), "autocast did not engage the reduced-precision products"
+    tol = 1e-2 if dtype == torch.float16 else 4e-2
+    err = float((a["logits"] - b["logits"]).abs().max() / a["logits"].abs().max())
+    assert err <= tol, err
+    assert abs(float(a["loss"]) - float(b["loss"])) <= tol * abs(float(a["loss"]))
+    assert set(a["grads"]) == set(b["grads"])
+    num = sum(float((a["grads"][n].double() - b["grads"][n].double()).pow(2).sum()) for n in a["grads"])
+    den = sum(float(a["grads"][n].double().pow(2).sum()) for n in a["grads"])
+    assert (num / den) ** 0.5 <= (5e-2 if dtype == torch.float16 else 1.5e-1), (num / den) ** 0.5
+    moved = sum(1 for n in a["grads"] if not torch.equal(a["grads"][n], b["grads"][n]))
+    assert moved > len(a["grads"]) // 2, "the backward ran with fp32 operands"

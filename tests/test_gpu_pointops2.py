@@ -156,3 +156,30 @@ def test_stratified_prefetched_geometry_is_the_inline_geometry():
         assert abs(float(ref["loss"]) - float(out["loss"])) <= 1e-5 * abs(float(ref["loss"]))
         assert (ref["score"] - out["score"]).abs().max() <= 1e-4 * ref["score"].abs().max()
     pf.close()
+
+
+def test_stratified_geometry_shares_one_fps_run_per_level():
+    """StratifiedGeometry takes a level's window-key subset (n // 8 + 1 per scene) and its TransitionDown sample (n / 4 + 1) from ONE
+    farthest-point run -- the shorter one is the per-scene prefix of the longer (sampling_cuda_kernel.cu:42-127: the sample count only bounds
+    the loop).  Every subset must be bit-identical to its own separate call, as the module forwards issue them."""
+    from pointcloudpdf_amd import engine, stratified, synthetic
+    from pointcloudpdf_amd.pointops2 import pointops as p2ops   # noqa: F401  (registers nothing: same library)
+    from pointcloudpdf_amd import pointops
+
+    step = engine.OpenSegStep(backbone="ST-v1m1", loss_weight=0.008).cuda()
+    bb = step.model.backbone
+    for sizes in ([20000, 18000], [4097], [1500, 33000, 700]):
+        b = synthetic.make_batch(sizes, first_scene_id=71, device="cuda")
+        g = bb.make_geometry(b["coord"], b["offset"]).precompute()
+        xyz, off = g.coord, g.offset
+        for level in range(4):
+            k_idx, k_off = g.samples[("keys", level)]
+            want_off = stratified._strided_offsets(off, lambda n: n // 8 + 1)
+            assert torch.equal(k_off, want_off)
+            assert torch.equal(k_idx, pointops.furthestsampling(xyz, off, want_off)), ("keys", level, sizes)
+            if level < 3:
+                d_idx, d_off = g.samples[("down", level)]
+                want_off = stratified._strided_offsets(off, lambda n: int(n * 0.25) + 1)
+                assert torch.equal(d_off, want_off)
+                assert torch.equal(d_idx, pointops.furthestsampling(xyz, off, want_off)), ("down", level, sizes)
+                xyz, off = xyz[d_idx.long(), :].contiguous(), d_off

@@ -103,6 +103,57 @@ def test_rowlin_forward_dgrad_wgrad(n, k, o, pre):
     assert max_rel(y2.cpu().numpy(), (big[:, :k].double() @ w.double().t() + b.double()).cpu().numpy()) < 2e-6
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("n,k,o", [(5000, 32, 32), (777, 512, 512), (40000, 64, 192), (12517, 128, 128), (3125, 256, 256), (5, 32, 96)])
+@pytest.mark.parametrize("pre", [False, True])
+def test_rowlin_reduced_precision_operands(n, k, o, pre, dtype):
+    """pdf_set_mma_input(1 | 2): the streaming Linear products round their OPERANDS to fp16 / bfloat16 in registers (after the folded
+    BatchNorm + ReLU prologue, which stays fp32) and accumulate in fp32 -- so the result must equal, to fp32 accumulation error, the
+    float64 product of the operands rounded the same way; tensors in memory stay fp32 and mode 0 comes back afterwards."""
+    from pointcloudpdf_amd import _native
+
+    be = _native.hip_backend()
+    mode = _native.MMA_INPUT_OF_DTYPE[dtype]
+    rnd = lambda t: t.to(dtype).double()
+    g = torch.Generator(device="cuda").manual_seed(n + k + o + mode)
+    x = torch.randn(n, k, device="cuda", generator=g)
+    w = torch.randn(o, k, device="cuda", generator=g) / k ** 0.5
+    b = torch.randn(o, device="cuda", generator=g)
+    coef, fx = None, x
+    if pre:
+        sc = torch.rand(k, device="cuda", generator=g) + 0.5
+        sh = torch.randn(k, device="cuda", generator=g) * 0.3
+        coef = torch.cat([sc, sh, torch.zeros(2 * k, device="cuda")])
+        fx = torch.relu(x * sc + sh)
+    go = torch.randn(n, o, device="cuda", generator=g)
+    y32, _ = be.rowlin(x, w, b, coef=coef, relu=True)
+    with _native.mma_input(mode):
+        assert be.lib.pdf_get_mma_input() == mode
+        y, partial = be.rowlin(x, w, b, coef=coef, relu=True, stats=True)
+        gx, _ = be.rowlin(go, w, transpose_w=True)
+        dw, db = be.rowlin_wgrad(go, x, coef, True, True)
+    assert be.lib.pdf_get_mma_input() == 0 and _native.current_mma_input() == 0
+    assert y.dtype == torch.float32 and gx.dtype == torch.float32 and dw.dtype == torch.float32
+    ref = rnd(fx) @ rnd(w).t() + b.double()
+    assert max_rel(y.cpu().numpy(), ref.cpu().numpy()) < 5e-6
+    assert not torch.equal(y, y32), "the reduced-precision kernel was not the one that ran"
+    exact = fx.double() @ w.double().t() + b.double()
+    assert max_rel(y.cpu().numpy(), exact.cpu().numpy()) < (4e-3 if dtype == torch.float16 else 3e-2)   # the price of the rounding
+    rows = partial._pdf_rows
+    ps = partial[: rows * 2 * o].view(rows, 2 * o).double().sum(0)
+    assert max_rel(ps[:o].cpu().numpy(), ref.sum(0).cpu().numpy()) < 1e-4       # statistics of the values actually written
+    assert max_rel(gx.cpu().numpy(), (rnd(go) @ rnd(w)).cpu().numpy()) < 5e-6
+    assert max_rel(dw.cpu().numpy(), (rnd(go).t() @ rnd(fx)).cpu().numpy()) < 2e-5
+    assert max_rel(db.cpu().numpy(), go.double().sum(0).cpu().numpy()) < 1e-5   # the bias gradient is a plain fp32 column sum
+
+
+def test_mma_input_rejects_unknown_modes():
+    from pointcloudpdf_amd import _native
+
+    lib = _native.hip_backend().lib
+    assert lib.pdf_set_mma_input(3) == -1 and lib.pdf_set_mma_input(-1) == -1 and lib.pdf_get_mma_input() == 0
+
+
 @pytest.mark.parametrize("n,c", [(30011, 32), (9000, 64), (4097, 128), (1500, 256), (300, 512), (200, 48)])
 @pytest.mark.parametrize("pre", [False, True])
 def test_rowlin_multi(n, c, pre):
