@@ -89,9 +89,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ops-roofline", action="store_true", help="skip the per-op HBM roofline micro-benchmark (rank 0, N = 1)")
     ap.add_argument("--cpu-points", type=int, default=100000, help="scene size of the bounded CPU-baseline sample")
-    ap.add_argument("--amp", nargs="?", const="bf16", default=None, choices=["bf16", "f16"],
+    ap.add_argument("--amp", nargs="?", const="f16", default=None, choices=["bf16", "f16"],
                     help="torch.autocast around the step (reference: enable_amp = True, engines/train.py:340-363): the streaming Linear products "
-                         "run with bfloat16 (default) / fp16 operands on the 16x16x16 matrix-core instructions, fp32 storage and accumulation "
+                         "run with fp16 (default, as the reference's autocast) / bfloat16 operands on the 16x16x16 matrix-core instructions, fp32 storage and accumulation "
                          "(dense.fp32_path).  f16 adds a static loss scale of 4096 for the backward (the reference uses a GradScaler)")
     ap.add_argument("--storage", choices=["f32", "bf16"], default=os.environ.get("PDFOPS_STORAGE", "f32"),
                     help="bf16: the reduced-precision variant -- the fused PointTransformerLayer keeps its saved / scratch row arrays (H, G2, "

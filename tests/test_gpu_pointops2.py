@@ -163,8 +163,7 @@ def test_stratified_geometry_shares_one_fps_run_per_level():
     farthest-point run -- the shorter one is the per-scene prefix of the longer (sampling_cuda_kernel.cu:42-127: the sample count only bounds
     the loop).  Every subset must be bit-identical to its own separate call, as the module forwards issue them."""
     from pointcloudpdf_amd import engine, stratified, synthetic
-    from pointcloudpdf_amd.pointops2 import pointops as p2ops   # noqa: F401  (registers nothing: same library)
-    from pointcloudpdf_amd import pointops
+    from pointcloudpdf_amd.pointops2 import pointops
 
     step = engine.OpenSegStep(backbone="ST-v1m1", loss_weight=0.008).cuda()
     bb = step.model.backbone

@@ -135,15 +135,20 @@ def test_rowlin_reduced_precision_operands(n, k, o, pre, dtype):
     assert be.lib.pdf_get_mma_input() == 0 and _native.current_mma_input() == 0
     assert y.dtype == torch.float32 and gx.dtype == torch.float32 and dw.dtype == torch.float32
     ref = rnd(fx) @ rnd(w).t() + b.double()
-    assert max_rel(y.cpu().numpy(), ref.cpu().numpy()) < 5e-6
+    # (with the prologue the kernel forms x * scale + shift as one FMA, torch as a product and a sum: an operand one fp32 ulp apart now and
+    #  then rounds to the neighbouring half-precision value -- a few 2^-11 / 2^-8 flips per row instead of none)
+    assert max_rel(y.cpu().numpy(), ref.cpu().numpy()) < (1e-3 if pre else 5e-6)
     assert not torch.equal(y, y32), "the reduced-precision kernel was not the one that ran"
     exact = fx.double() @ w.double().t() + b.double()
     assert max_rel(y.cpu().numpy(), exact.cpu().numpy()) < (4e-3 if dtype == torch.float16 else 3e-2)   # the price of the rounding
     rows = partial._pdf_rows
     ps = partial[: rows * 2 * o].view(rows, 2 * o).double().sum(0)
-    assert max_rel(ps[:o].cpu().numpy(), ref.sum(0).cpu().numpy()) < 1e-4       # statistics of the values actually written
-    assert max_rel(gx.cpu().numpy(), (rnd(go) @ rnd(w)).cpu().numpy()) < 5e-6
-    assert max_rel(dw.cpu().numpy(), (rnd(go).t() @ rnd(fx)).cpu().numpy()) < 2e-5
+    assert max_rel(ps[:o].cpu().numpy(), y.double().sum(0).cpu().numpy()) < 1e-4       # statistics of the values actually written
+    if o in (32, 64, 128, 256, 512):   # the reduction width of the input gradient: streaming kernel (other widths: tiled kernel, fp32 operands)
+        assert max_rel(gx.cpu().numpy(), (rnd(go) @ rnd(w)).cpu().numpy()) < 5e-6
+    else:
+        assert max_rel(gx.cpu().numpy(), (go.double() @ w.double()).cpu().numpy()) < 2e-6
+    assert max_rel(dw.cpu().numpy(), (rnd(go).t() @ rnd(fx)).cpu().numpy()) < (1e-3 if pre else 2e-5)
     assert max_rel(db.cpu().numpy(), go.double().sum(0).cpu().numpy()) < 1e-5   # the bias gradient is a plain fp32 column sum
 
 
