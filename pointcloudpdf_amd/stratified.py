@@ -24,9 +24,25 @@ reference classes imported and run with these same stand-ins injected).
 import torch
 import torch.nn as nn
 
-from . import _native
+import torch.nn.functional as F
+
+from . import _native, dense
 from .pointops2 import pointops
 from .registry import MODELS
+
+
+class _Linear(nn.Linear):
+    """nn.Linear (same parameters, same ``state_dict`` keys) whose WEIGHT gradient over many rows runs as a batched split-K product
+    (dense._LinearSplitK): the library's dW = dY^T X with 10^5..10^6 rows is one 32x32 macro-tile on a single workgroup (0.5 ms per
+    call at 160k x 48 -> 144; 7.8 ms of the 93 ms ST-v1m1 step, profiles/r03_i_stratified_kernel_trace_stats.txt)."""
+
+    def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and x.is_contiguous() and x.dim() in (2, 3):
+            rows = x.shape[0] if x.dim() == 2 else x.shape[0] * x.shape[1]
+            if rows >= dense._MIN_ROWS:
+                y = dense._LinearSplitK.apply(x.view(rows, x.shape[-1]), self.weight, self.bias)
+                return y if x.dim() == 2 else y.view(x.shape[0], x.shape[1], -1)
+        return F.linear(x, self.weight, self.bias)
 
 
 class WindowAttention(nn.Module):
@@ -46,9 +62,9 @@ class WindowAttention(nn.Module):
                 nn.init.trunc_normal_(table, std=0.02)
                 setattr(self, name, table)
         self.quant_grid_length = quant_grid_length
-        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.qkv = _Linear(dim, dim * 3, bias=qkv_bias)
         self.attn_drop = nn.Dropout(attn_drop, inplace=True)
-        self.proj = nn.Linear(dim, dim)
+        self.proj = _Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop, inplace=True)
 
     def relative_position_index(self, xyz, index_0, index_1):
@@ -247,9 +263,9 @@ class Mlp(nn.Module):
         super().__init__()
         out_features = out_features or in_features
         hidden_features = hidden_features or in_features
-        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc1 = _Linear(in_features, hidden_features)
         self.act = act_layer()
-        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.fc2 = _Linear(hidden_features, out_features)
         self.drop = nn.Dropout(drop, inplace=True)
 
     def forward(self, x):
@@ -408,7 +424,7 @@ class TransitionDown(nn.Module):
         super().__init__()
         self.ratio, self.k = ratio, k
         self.norm = norm_layer(in_channels) if norm_layer else None
-        self.linear = nn.Linear(in_channels, out_channels, bias=False)
+        self.linear = _Linear(in_channels, out_channels, bias=False)
         self.pool = nn.MaxPool1d(k)
 
     def forward(self, feats, xyz, offset):
@@ -416,8 +432,10 @@ class TransitionDown(nn.Module):
         n_xyz = xyz[idx.long(), :].contiguous()
         feats = pointops.queryandgroup(self.k, xyz, n_xyz, feats.contiguous(), None, offset, n_offset, use_xyz=False)   # (m, k, c)
         m, k, c = feats.shape
-        feats = self.linear(self.norm(feats.view(m * k, c)).view(m, k, c)).transpose(1, 2).contiguous()
-        return self.pool(feats).squeeze(-1), n_xyz, n_offset
+        feats = self.linear(self.norm(feats.view(m * k, c)).view(m, k, c))
+        # MaxPool1d(k) over the k neighbours (:186-188) as a reduction over dim 1: same values, no (m, c, k) transpose copy, and the
+        # backward is an index scatter instead of max_pool_backward_nchw (1 ms per call at level 0: 3 ms of the step)
+        return feats.max(dim=1)[0], n_xyz, n_offset
 
 
 class SwinTransformerBlock(nn.Module):
@@ -503,8 +521,8 @@ class Upsample(nn.Module):
     def __init__(self, k, in_channels, out_channels, bn_momentum=0.02):
         super().__init__()
         self.k, self.in_channels, self.out_channels = k, in_channels, out_channels
-        self.linear1 = nn.Sequential(nn.LayerNorm(out_channels), nn.Linear(out_channels, out_channels))
-        self.linear2 = nn.Sequential(nn.LayerNorm(in_channels), nn.Linear(in_channels, out_channels))
+        self.linear1 = nn.Sequential(nn.LayerNorm(out_channels), _Linear(out_channels, out_channels))
+        self.linear2 = nn.Sequential(nn.LayerNorm(in_channels), _Linear(in_channels, out_channels))
 
     def forward(self, feats, xyz, support_xyz, offset, support_offset, support_feats=None):
         feats = self.linear1(support_feats) + pointops.interpolation(xyz.contiguous(), support_xyz.contiguous(), self.linear2(feats).contiguous(),
@@ -532,13 +550,13 @@ class KPConvResBlock(nn.Module):
         super().__init__()
         d_2 = out_channels // 4
         activation = nn.LeakyReLU(negative_slope=negative_slope)
-        self.unary_1 = nn.Sequential(nn.Linear(in_channels, d_2, bias=False), FastBatchNorm1d(d_2, momentum=bn_momentum), activation)
-        self.unary_2 = nn.Sequential(nn.Linear(d_2, out_channels, bias=False), FastBatchNorm1d(out_channels, momentum=bn_momentum), activation)
+        self.unary_1 = nn.Sequential(_Linear(in_channels, d_2, bias=False), FastBatchNorm1d(d_2, momentum=bn_momentum), activation)
+        self.unary_2 = nn.Sequential(_Linear(d_2, out_channels, bias=False), FastBatchNorm1d(out_channels, momentum=bn_momentum), activation)
         self.kpconv = KPConvLayer(d_2, d_2, point_influence=prev_grid_size * sigma, add_one=False)
         self.bn = FastBatchNorm1d(out_channels, momentum=bn_momentum)
         self.activation = activation
         if in_channels != out_channels:
-            self.shortcut_op = nn.Sequential(nn.Linear(in_channels, out_channels, bias=False), FastBatchNorm1d(out_channels, momentum=bn_momentum))
+            self.shortcut_op = nn.Sequential(_Linear(in_channels, out_channels, bias=False), FastBatchNorm1d(out_channels, momentum=bn_momentum))
         else:
             self.shortcut_op = nn.Identity()
 
@@ -581,8 +599,8 @@ class StratifiedTransformer(nn.Module):
             self.downsample.level = "stem"
         self.geometry_cfg = dict(downsample_scale=downsample_scale, ratio=ratio, num_layers=num_layers, stem_transformer=stem_transformer)
         self.upsamples = nn.ModuleList([Upsample(up_k, channels[i], channels[i - 1]) for i in range(num_layers - 1, 0, -1)])
-        self.classifier = nn.Sequential(nn.Linear(channels[0], channels[0]), nn.BatchNorm1d(channels[0]), nn.ReLU(inplace=True),
-                                        nn.Linear(channels[0], num_classes))
+        self.classifier = nn.Sequential(_Linear(channels[0], channels[0]), nn.BatchNorm1d(channels[0]), nn.ReLU(inplace=True),
+                                        _Linear(channels[0], num_classes))
         self.init_weights()
 
     def layers_by_level(self):
@@ -645,8 +663,8 @@ class STRecognizer(nn.Module):
     def __init__(self, up_k, channels, num_layers):
         super().__init__()
         self.upsamples = nn.ModuleList([Upsample(up_k, channels[i], channels[i - 1]) for i in range(num_layers - 1, 0, -1)])
-        self.confidence = nn.Sequential(nn.Linear(channels[0], channels[0]), nn.BatchNorm1d(channels[0]), nn.ReLU(inplace=True),
-                                        nn.Linear(channels[0], 1))
+        self.confidence = nn.Sequential(_Linear(channels[0], channels[0]), nn.BatchNorm1d(channels[0]), nn.ReLU(inplace=True),
+                                        _Linear(channels[0], 1))
 
     def forward(self, model_hooks):
         n = len(self.upsamples)
