@@ -365,6 +365,14 @@ __global__ __launch_bounds__(WB) void k_step2rv_bwd_h(int N, int h, int d, int L
 // the one-hot test of the lane's OWN edge against row 16*rb + lane%16.  So every wave-trip issues 3 axes x ceil(L/16) MFMAs per
 // table and keeps G in accumulators (D[m = 4*(lane/16) + j][n = lane%16]); LDS atomics are needed once per wave at the end.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Elements per lane and trip of the two kernels below (tuning knob, `PDFOPS_WA_UE=<n> python -m pointcloudpdf_amd.build`).  Measured on
+// the 2 x 80k-point ST-v1m1 step (tools/wa_ue_ab.sh, profiles/r03_wa_ue_ab.txt): 2 -> 1.81 / 1.01 ms per launch (dot_prod backward /
+// step2 backward), 4 -> 2.34 / 1.10, 8 -> 2.24 / 1.08: more loads in flight per trip do not pay, the kernels are not waiting for their
+// gathers.
+#ifndef PDF_WA_UE
+#define PDF_WA_UE 2
+#endif
+constexpr int UE = PDF_WA_UE;
 
 template <int RB>
 __global__ __launch_bounds__(WB) void k_dot3_bwd_m16(int N, int h, int L, const float *__restrict__ go, const float *__restrict__ q,
@@ -400,37 +408,46 @@ __global__ __launch_bounds__(WB) void k_dot3_bwd_m16(int N, int h, int L, const 
     // binary search through LDS).
     int ql_hint = 0;
     const int m_last = e1 > e0 ? e1 - 1 : e0;
-    for (long e = threadIdx.x; e < padded; e += 2 * WB) {
-        bool live[2]; int m[2], ql[2], r[2][3], ik[2]; float g[2], xq[2], xk[2];
+    for (long e = threadIdx.x; e < padded; e += UE * WB) {
+        bool live[UE]; int m[UE], ql[UE], r[UE][3], ik[UE]; float g[UE], xq[UE], xk[UE];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < UE; ++u) {
             const long eu = e + u * WB;
             live[u] = eu < total;
             m[u] = min(e0 + (int)(eu >> 4), m_last);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < UE; ++u) {
             r[u][0] = rel_idx[(size_t)m[u] * 3]; r[u][1] = rel_idx[(size_t)m[u] * 3 + 1]; r[u][2] = rel_idx[(size_t)m[u] * 3 + 2];
             g[u] = go[(size_t)m[u] * h + hh];
             ik[u] = index_k[m[u]];
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < UE; ++u) {
             while (ql_hint + 1 < nq && offs[ql_hint + 1] <= m[u]) ++ql_hint;
             ql[u] = ql_hint;
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < UE; ++u) {
             xq[u] = q[(size_t)(q0 + ql[u]) * C + hh * d + i];
             xk[u] = k[(size_t)ik[u] * C + hh * d + i];
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < UE; ++u) {
             const float gm = live[u] ? g[u] : 0.f;
-            if (live[u]) {
-                atomicAdd(&gqs[ql[u] * d + i], lds_table_sum(tq, r[u][0], r[u][1], r[u][2], d, i) * gm);
-                pdf_atomic_add(grad_k + (size_t)ik[u] * C + hh * d + i, lds_table_sum(tk, r[u][0], r[u][1], r[u][2], d, i) * gm);
+            // grad_q: the four edges a wave holds for channel i (lanes i, i + 16, i + 32, i + 48) are consecutive edges of the CSR list and
+            // mostly belong to ONE query: their contributions are added across the lanes first and one lane issues the LDS atomic (four
+            // same-address ds_add_f32 serialise); waves that straddle a query boundary take the per-lane path.
+            float cq = live[u] ? lds_table_sum(tq, r[u][0], r[u][1], r[u][2], d, i) * gm : 0.f;
+            const int ql0 = __shfl(ql[u], i, 64);
+            if (__ballot(ql[u] != ql0) == 0ull) {
+                cq += __shfl_xor(cq, 16, 64);
+                cq += __shfl_xor(cq, 32, 64);
+                if (lane < 16 && cq != 0.f) atomicAdd(&gqs[ql0 * d + i], cq);
+            } else if (live[u]) {
+                atomicAdd(&gqs[ql[u] * d + i], cq);
             }
+            if (live[u]) pdf_atomic_add(grad_k + (size_t)ik[u] * C + hh * d + i, lds_table_sum(tk, r[u][0], r[u][1], r[u][2], d, i) * gm);
             const float vq = xq[u] * gm, vk = xk[u] * gm;
 #pragma unroll
             for (int a = 0; a < 3; ++a)
@@ -494,32 +511,32 @@ __global__ __launch_bounds__(WB) void k_step2rv_bwd_m16(int N, int h, int L, con
         for (int rb = 0; rb < RB; ++rb) acc[a][rb] = (f32x4)(0.f);
     int ql_hint = 0;   // (trip structure as k_dot3_bwd_m16)
     const int m_last = e1 > e0 ? e1 - 1 : e0;
-    for (long e = threadIdx.x; e < padded; e += 2 * WB) {
-        bool live[2]; int m[2], ql[2], r[2][3], i1[2]; float at[2], gout[2], vv[2];
+    for (long e = threadIdx.x; e < padded; e += UE * WB) {
+        bool live[UE]; int m[UE], ql[UE], r[UE][3], i1[UE]; float at[UE], gout[UE], vv[UE];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < UE; ++u) {
             const long eu = e + u * WB;
             live[u] = eu < total;
             m[u] = min(e0 + (int)(eu >> 4), m_last);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < UE; ++u) {
             r[u][0] = rel_idx[(size_t)m[u] * 3]; r[u][1] = rel_idx[(size_t)m[u] * 3 + 1]; r[u][2] = rel_idx[(size_t)m[u] * 3 + 2];
             at[u] = attn[(size_t)m[u] * h + hh];
             i1[u] = index1[m[u]];
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < UE; ++u) {
             while (ql_hint + 1 < nq && offs[ql_hint + 1] <= m[u]) ++ql_hint;
             ql[u] = ql_hint;
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < UE; ++u) {
             gout[u] = go[(size_t)(q0 + ql[u]) * C + hh * d + i];
             vv[u] = v[(size_t)i1[u] * C + hh * d + i];
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < UE; ++u) {
             const float x = live[u] ? at[u] * gout[u] : 0.f;
             float part = (lds_table_sum(tb, r[u][0], r[u][1], r[u][2], d, i) + vv[u]) * gout[u];
             if (live[u]) pdf_atomic_add(grad_v + (size_t)i1[u] * C + hh * d + i, x);
