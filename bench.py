@@ -31,7 +31,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 FP32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 dense peak (same guide: fp32 matrix = fp32 vector rate)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_GLOB = os.path.join(ROOT, "profiles", "r*_traffic.json")   # tools/traffic_json.py output; the newest file measured on the current kernel sources is used
 
 
 def kernel_source_hash():
@@ -51,14 +51,19 @@ def load_traffic():
     FETCH_SIZE doubled for gfx950 and KB -> bytes as /opt/skills/guides/MI355X_MICROARCH.md prescribes), written by
     tools/traffic_json.py.  The file records the hash of the kernel sources it was measured on: numbers of other sources are not
     reported (traffic = null, note says why) rather than silently going stale."""
-    try:
-        with open(TRAFFIC_FILE) as f:
-            t = json.load(f)
-    except (OSError, ValueError):
-        return {}, "no profiles/r02_traffic.json"
-    if t.get("kernel_source_hash") != kernel_source_hash():
-        return {}, f"profiles/r02_traffic.json was measured on other kernel sources ({t.get('kernel_source_hash')})"
-    return t, None
+    import glob
+    want, seen = kernel_source_hash(), []
+    for path in sorted(glob.glob(TRAFFIC_GLOB), reverse=True):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if t.get("kernel_source_hash") == want:
+            t["file"] = os.path.relpath(path, ROOT)
+            return t, None
+        seen.append(f"{os.path.basename(path)} ({t.get('kernel_source_hash')})")
+    return {}, ("no profiles/r*_traffic.json" if not seen else "measured on other kernel sources: " + ", ".join(seen[:3]))
 
 
 def parse():

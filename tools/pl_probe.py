@@ -1,3 +1,4 @@
+"""Pseudo-label pass on the GPU against the reference fixtures: mask sizes and the number of differing points per scene (exact = 0)."""
 import sys, os
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np, torch
