@@ -452,10 +452,20 @@ def main():
                 and not (use_dp and args.ddp == "torch"))
     if args.graph == "1" and not graph_ok:
         raise SystemExit("bench.py: --graph 1 needs fixed scene sizes and the plain f32 PointTransformer step (see --help)")
-    captured = None
+    captured, capture_note = None, None
     if args.graph == "1" or (args.graph == "auto" and graph_ok):
-        captured = engine.CapturedStep(step, pool[0], autocast=amp_dtype, loss_scale=loss_scale)       # set-up (like building the model): eager warm-up passes + one capture
-        torch.cuda.synchronize()
+        try:   # set-up (like building the model): eager warm-up passes + one capture
+            captured = engine.CapturedStep(step, pool[0], autocast=amp_dtype, loss_scale=loss_scale)
+            torch.cuda.synchronize()
+        except Exception as e:   # noqa: BLE001  (auto: a stack that cannot capture the step still gets its line, on the eager path)
+            if args.graph == "1":
+                raise
+            captured, capture_note = None, f"graph capture failed ({type(e).__name__}: {e}); eager path"
+            print(f"bench.py: {capture_note}", file=sys.stderr)
+            torch.cuda.synchronize()
+            engine.release_autograd_state(step)
+            for p_ in step.parameters():
+                p_.grad = None
 
     class Schedule:
         """Grouped geometry pre-pass for `warmup + steps` steps: the pre-pass of the next D batches runs as ONE launch sequence on a
@@ -647,7 +657,7 @@ def main():
             "loss": loss,
             "execution": ("forward + backward replayed as one captured hipGraph (engine.CapturedStep; fixed scene sizes), optimizer / gradient "
                           "exchange / geometry pre-pass eager; the steps that carry per-kernel HIP events run eagerly" if captured is not None
-                          else "eager (one Python-issued launch sequence per step)"),
+                          else (capture_note or "eager (one Python-issued launch sequence per step)")),
             "cpu_affinity": affinity,
             "geometry_prefetch_group": (st_ahead if strat else D),
             "host_enqueue_ms_per_step": sched.enqueue_s / args.steps * 1e3,   # < ms_per_step: the host runs ahead, the device is the bound

@@ -165,8 +165,17 @@ class _LinearSplitK(torch.autograd.Function):
         return gx, gw, gb
 
 
+HIP_LINEAR = os.environ.get("PDFOPS_LINEAR", "hip") != "torch"   # torch: library GEMMs + split-K weight gradient (rounds 1-2; A/B runs)
+
+
 def linear(module, x):
-    """``module(x)`` for an nn.Linear, with the split-K weight gradient when the row count is large."""
+    """``module(x)`` for an nn.Linear outside the fused Linear -> BatchNorm nodes (first layer 6 -> 32, the 32 -> 13 / 32 -> 1 heads, the
+    1024 -> 512 TransitionUp head): forward, input gradient and weight gradient through the library's own matrix-core kernels
+    (csrc/rowlin.hip: the tiled kernel takes any (k, o); no library GEMM is left in the step).  ``PDFOPS_LINEAR=torch`` restores the
+    library GEMMs with the split-K weight gradient (``_LinearSplitK``)."""
+    if (HIP_LINEAR and x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and module.weight.dtype == torch.float32
+            and module.weight.is_contiguous()):
+        return _LinearStats.apply(x, module.weight, module.bias, False)[0]
     if x.dim() == 2 and x.is_cuda and x.shape[0] >= _MIN_ROWS and torch.is_grad_enabled() and x.is_contiguous():
         return _LinearSplitK.apply(x, module.weight, module.bias)
     return module(x)
