@@ -420,3 +420,50 @@ def test_autocast_runs_the_reduced_precision_products(dtype):
     assert l2(list(a["grads"])) <= (0.35 if f16 else 0.8), l2(list(a["grads"]))
     moved = sum(1 for n in a["grads"] if not torch.equal(a["grads"][n], b["grads"][n]))
     assert moved > len(a["grads"]) // 2, "the backward ran with fp32 operands"
+
+
+def test_training_loop_converges_in_every_precision_and_execution_mode():
+    """Thirty SGD steps on one fixed batch (2 scenes, 4,000 + 3,200 points; FusedSGD lr 0.05): the loss falls from 2.79 to ~0.16 in every
+    mode -- fp32, fp16 operands (static loss scale 4096), bfloat16 operands, each issued eagerly and replayed as a captured hipGraph.  A
+    replayed trajectory equals the eager one of the same precision step by step (same kernels, same order: bit-identical losses); the
+    reduced-precision trajectories stay within 10 % of the fp32 loss at every fifth step and within 5 % at the end
+    (`python tools/train_modes_probe.py`)."""
+    from pointcloudpdf_amd import engine, synthetic
+    from pointcloudpdf_amd.geometry import Geometry
+
+    dev = torch.device("cuda", 0)
+    batch = synthetic.make_batch([4000, 3200], first_scene_id=40, device=dev)
+    geom = Geometry(batch["coord"], batch["offset"], batch["offset_host"]).precompute()
+
+    def run(dtype, graph):
+        scale = 4096.0 if dtype == torch.float16 else 1.0
+        step = engine.OpenSegStep().to(dev)
+        synthetic.fill_parameters_deterministic(step, seed=2)
+        step.train()
+        opt = engine.FusedSGD(step.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+        cap = engine.CapturedStep(step, batch, geom=geom, autocast=dtype, loss_scale=scale) if graph else None
+        losses = []
+        for _ in range(30):
+            if cap is not None:
+                out = cap(batch, geom)
+            else:
+                opt.zero_grad(set_to_none=True)
+                with torch.autocast("cuda", dtype=dtype or torch.float16, enabled=dtype is not None):
+                    out = step(dict(batch, pdf_geometry=geom))
+                (out["loss"] * scale).backward()
+                if scale != 1.0:
+                    with torch.no_grad():
+                        torch._foreach_mul_([p.grad for p in step.parameters() if p.grad is not None], 1.0 / scale)
+            opt.step()
+            losses.append(float(out["loss"]))
+        engine.release_autograd_state(step)
+        return losses
+
+    ref = run(None, False)
+    assert ref[-1] < 0.1 * ref[0] and all(np.isfinite(ref)), ref
+    assert run(None, True) == ref, "graph replay left the eager fp32 trajectory"
+    for dtype in (torch.float16, torch.bfloat16):
+        eager, graph = run(dtype, False), run(dtype, True)
+        assert eager == graph, (dtype, "graph replay left the eager trajectory")
+        assert all(np.isfinite(eager)) and abs(eager[-1] - ref[-1]) <= 0.05 * ref[-1], (dtype, eager[-1], ref[-1])
+        assert all(abs(eager[i] - ref[i]) <= 0.10 * ref[i] for i in range(0, 30, 5)), (dtype, [round(eager[i] / ref[i], 3) for i in range(0, 30, 5)])
