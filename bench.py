@@ -721,11 +721,17 @@ def main():
             # the launching stream, against the 8 TB/s HBM peak with the SURVEY 8(d) byte counts (tools/ops_roofline.py)
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import ops_roofline
+            rows = ops_roofline.run(iters=10, level2=False, references=True)
+            # "also report against a measured stream-copy ceiling from the same run" -- a 256 MB device-to-device copy
+            # (read + write = 512 MB) timed the same way; `frac_of_stream_copy` = the op's algorithmic GB/s / that copy's GB/s
+            copy = next((r["GBps"] for r in rows if r["op"].startswith("copy 256 MB")), None)
+            line["stream_copy_GBps"] = None if copy is None else round(copy, 1)
             line["roofline_ops"] = [dict(op=r["op"], us=round(r["us"], 1), GBps=round(r["GBps"], 1), frac=round(r["frac"], 4),
+                                         **({"frac_of_stream_copy": round(r["GBps"] / copy, 3)} if copy and "pair_evals_per_s" not in r else {}),
                                          **({"pair_evals_per_s": float(f"{r['pair_evals_per_s']:.4g}"),
                                              "valu_frac_bruteforce_equivalent": round(r["valu_frac_bruteforce_equivalent"], 4)}
                                             if "pair_evals_per_s" in r else {}))
-                                    for r in ops_roofline.run(iters=10, level2=False, references=False)]
+                                    for r in rows]
         if world == 1 and not args.no_cpu_baseline and not scannet and not strat:   # (the CPU baseline is quoted on the headline workload)
             line["cpu_baseline"] = cpu_baseline(args.cpu_points)
     if torch.distributed.is_initialized():
