@@ -483,7 +483,7 @@ def main():
                     divs = [d for d in range(min(8, D), D + 1) if steps % d == 0]
                     D = max(divs) if divs else D
             self.D, self.phase = D, (warmup % D if D > 0 else 0)
-            self.tickets, self.submit_host_s = {}, []
+            self.tickets, self.submit_host_s, self.pending = {}, [], None
 
         def _submit_range(self, lo, hi):
             group = [pool[j % len(pool)] for j in range(lo, hi)]
@@ -505,8 +505,17 @@ def main():
                 return None
             geom = prefetcher.get(self.tickets.pop(i))
             if (i + self.D - self.phase) % self.D == 0:
-                self._submit_range(i + self.D, i + 2 * self.D)
+                self.pending = (i + self.D, i + 2 * self.D)   # submitted by after_step(): once this step's launches are queued
             return geom
+
+        def after_step(self):
+            """Queue the next group's pre-pass AFTER the current step has been enqueued: its submission is 9-15 ms of host work, and
+            issued in front of the step (rounds 1-3) it left the device idle for that long at every group boundary -- with replayed steps
+            the device queue is empty right after the opening fence of a timed region."""
+            if self.pending is not None:
+                lo, hi = self.pending
+                self.pending = None
+                self._submit_range(lo, hi)
 
         def drain(self):
             """Pre-passes queued beyond the last step (none when steps is a multiple of D): wait for them, drop them."""
@@ -550,6 +559,7 @@ def main():
         if grad_sync is not None:
             grad_sync.sync(force=force_dp)   # ONE all-reduce (RCCL) over the flat gradient buffer
         opt.step()
+        sched.after_step()
         return out
 
     def fence():
@@ -566,18 +576,21 @@ def main():
         fence()
         timer.enabled = with_timer
         # steps that carry the per-kernel HIP events run eagerly (events cannot time kernels inside a replayed graph): every 4th step of
-        # an eager run, ONE step (the first) of the timed region when the steps are graph replays
+        # an eager run, ONE step of the timed region when the steps are graph replays -- the LAST one: issuing a step from Python takes
+        # the host longer than the device needs to run it, which costs nothing behind the backlog of replays queued before it and
+        # 4-12 ms of idle device at the front of the region, right after the fence (where rounds 1-3 had it)
         every = timer.every if captured is None else max(steps, 1)
+        sample_at = 0 if captured is None else every - 1
         t0 = time.perf_counter()
         for i in range(steps):
-            timer.sample = every > 0 and i % every == 0
+            timer.sample = every > 0 and i % every == sample_at
             out = one_step(warmup + i, sched)
         sched.enqueue_s = time.perf_counter() - t0   # host time to enqueue the K steps (the device may still be working)
         fence()
         dt = time.perf_counter() - t0
         timer.enabled = False
         if with_timer:
-            timer.sampled_steps = len([i for i in range(steps) if every > 0 and i % every == 0])
+            timer.sampled_steps = len([i for i in range(steps) if every > 0 and i % every == sample_at])
             timer.every_used = every
         sched.drain()
         for t in st_tickets.values():
