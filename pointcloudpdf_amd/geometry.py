@@ -153,8 +153,10 @@ class Geometry:
         key = ("order", level)
         if key not in self._memo:
             p = self.levels[level].p
-            lo = p.min(0)[0]
-            cell = torch.clamp((p.max(0)[0] - lo).max() / 1023.0, min=1e-9)
+            # (bounding box from the TRANSPOSED coordinates: three contiguous rows reduce in ~10 us, the column reduction of an (N, 3)
+            #  tensor takes torch 0.2-1.4 ms at N = 0.2-2.4 M -- 0.4 ms of side-stream GPU time per step in round 3's trace)
+            lo, hi = torch.aminmax(p.t().contiguous(), dim=1)
+            cell = torch.clamp((hi - lo).max() / 1023.0, min=1e-9)
             q = ((p - lo) / cell).long().clamp_(0, 1023)
 
             def spread(v):   # 10 bits -> every third bit

@@ -117,14 +117,20 @@ class WindowAttention(nn.Module):
 # ------------------------------------------------------------------------------------------------------------------
 # stand-ins for the absent third-party pieces (see the module docstring)
 # ------------------------------------------------------------------------------------------------------------------
+def _colminmax(x):
+    """(min, max) over the rows of an (N, c) tensor with small c: from the transposed copy (c contiguous rows reduce in microseconds; the
+    column reduction of an (N, 3) tensor takes torch 0.2-1.4 ms at N = 0.2-2.4 M).  Same values: min / max are exact."""
+    return torch.aminmax(x.t().contiguous(), dim=1)
+
+
 def _voxel_grid(pos, batch, size, start=None):
     """torch_geometric.nn.pool.voxel_grid -> torch_cluster.grid_cluster: the batch index is appended as a 4th coordinate of cell size
     1; cell = floor((pos - start) / size) per axis; cluster id = sum_d cell_d * prod_{e<d} (floor((end_e - start_e) / size_e) + 1)
     (x fastest).  ``start`` None -> the per-axis minimum, ``end`` = the per-axis maximum."""
     pos4 = torch.cat([pos, batch.unsqueeze(-1).to(pos.dtype)], dim=-1)
     size4 = torch.cat([size.to(pos.dtype), size.new_ones(1).to(pos.dtype)])
-    start4 = pos4.min(0)[0] if start is None else torch.cat([start.to(pos.dtype), pos.new_zeros(1)])
-    end4 = pos4.max(0)[0]
+    lo4, end4 = _colminmax(pos4)
+    start4 = lo4 if start is None else torch.cat([start.to(pos.dtype), pos.new_zeros(1)])
     cell = torch.div(pos4 - start4, size4, rounding_mode="floor").long()
     num = (torch.div(end4 - start4, size4, rounding_mode="floor").long() + 1).clamp_(min=1)
     stride = torch.cumprod(torch.cat([num.new_ones(1), num[:-1]]), 0)
@@ -233,7 +239,7 @@ def get_indice_pairs(p2v_map, counts, new_p2v_map, new_counts, downsample_idx, b
     mask = torch.arange(k, device=dev).unsqueeze(0) < new_counts.unsqueeze(-1)
     downsample_mask = downsample_mask & mask
     mask_mat = mask.unsqueeze(-1) & downsample_mask.unsqueeze(-2)
-    xyz_min = xyz.min(0)[0]
+    xyz_min = _colminmax(xyz)[0]
     shift = 0.0 if i % 2 == 0 else 1 / 2 * window_size
     window_coord = torch.div(xyz[new_p2v_map] - xyz_min + shift, window_size, rounding_mode="trunc")
     mask_mat_prev = (window_coord.unsqueeze(2) != window_coord.unsqueeze(1)).any(-1)
@@ -482,7 +488,7 @@ class BasicLayer(nn.Module):
         (index_0 sorted, index_1, CSR offsets of index_0, longest row, relative-position table rows of the first block's attention)."""
         window_size = torch.tensor([self.window_size] * 3, dtype=xyz.dtype, device=xyz.device)
         batch = offset2batch(offset)
-        xyz_min = xyz.min(0)[0]
+        xyz_min = _colminmax(xyz)[0]
         new_window_size = 2 * window_size
         parts = {0: grid_sample(xyz, batch, window_size, start=None)[1:] + grid_sample(xyz, batch, new_window_size, start=None)[1:]}
         if self.depth > 1:
