@@ -83,3 +83,53 @@ def test_fma_distance_variants_are_built_and_complete(lib):
         vlib = ctypes.CDLL(build.variant_path(v))
         assert vlib.pdf_dist_fma_mode() == v
         assert not [s for s in declared_symbols() if not hasattr(vlib, s)]
+
+
+def test_mma_input_mode_entry_points(lib):
+    """pdf_set_mma_input / pdf_get_mma_input need no GPU: the mode is a process-wide switch read at launch time."""
+    lib.pdf_set_mma_input.restype = ctypes.c_int
+    lib.pdf_get_mma_input.restype = ctypes.c_int
+    assert lib.pdf_get_mma_input() == 0
+    for mode in (1, 2, 0):
+        assert lib.pdf_set_mma_input(mode) == 0 and lib.pdf_get_mma_input() == mode
+    assert lib.pdf_set_mma_input(3) == -1 and lib.pdf_set_mma_input(-1) == -1 and lib.pdf_get_mma_input() == 0
+
+
+def test_mma_input_context_restores_the_previous_mode(monkeypatch):
+    """_native.mma_input nests and restores (the autograd nodes use it to run their backward in the mode of their forward); without a
+    ROCm device the Python-side mode is tracked alone (the oracle backend has no reduced-precision products)."""
+    import torch
+
+    from pointcloudpdf_amd import _native, dense
+
+    if torch.cuda.is_available():
+        pytest.skip("CPU host-logic test")
+    assert _native.current_mma_input() == 0
+    with _native.mma_input(1):
+        assert _native.current_mma_input() == 1
+        with _native.mma_input(2):
+            assert _native.current_mma_input() == 2
+        with _native.mma_input(1):
+            assert _native.current_mma_input() == 1
+        assert _native.current_mma_input() == 1
+    assert _native.current_mma_input() == 0
+    seen = []
+
+    @dense.fp32_path
+    def forward():
+        seen.append(_native.current_mma_input())
+
+    forward()   # no autocast region: fp32 operands
+    # (a CPU-only torch build disables a "cuda" autocast region on entry, so the region's state is injected here)
+    state = {"dtype": torch.float16}
+    monkeypatch.setattr(torch, "is_autocast_enabled", lambda *a, **k: True)
+    monkeypatch.setattr(torch, "get_autocast_dtype", lambda *a, **k: state["dtype"])
+    forward()
+    state["dtype"] = torch.bfloat16
+    forward()
+    state["dtype"] = torch.float32
+    forward()
+    monkeypatch.setattr(dense, "amp_mma", False)
+    state["dtype"] = torch.float16
+    forward()
+    assert seen == [0, 1, 2, 0, 0] and _native.current_mma_input() == 0
