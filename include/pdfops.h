@@ -250,6 +250,14 @@ int pdf_rowlin_multi(long n, int k, int o, int nin, int nout, const float *const
                      float *const *y, long ldy, int accumulate, void *stream);
 int pdf_rowlin_wgrad_multi(long n, int k, int o, int ng, const float *const *g, long ldg, const float *x, long ldx,
                            const float *scale, const float *shift, int relu, float *const *dw, float *const *db, float *ws, void *stream);
+/* Up to five weight gradients of ONE shape (n, k, o) with their OWN inputs in one launch + one slab reduction -- the five c x c products
+ * of a Bottleneck backward (linear3, q / k / v, linear1; point_transformer_seg.py:184-192): dW_i = G_i^T f_i(X_i), f_i = relu_i?(x *
+ * scale_i + shift_i) where scale_i is non-null, else the identity; db_i (nullable, db itself may be null) = column sums of G_i.  Written,
+ * not accumulated.  Streaming shapes only (k, o multiples of 32 up to 512): PDF_ERR_UNSUPPORTED otherwise.
+ * ws: pdf_rowlin_wgrad_ws_floats(n, k, o, ng) floats. */
+int pdf_rowlin_wgrad_group(long n, int k, int o, int ng, const float *const *g, long ldg, const float *const *x, long ldx,
+                           const float *const *scale, const float *const *shift, const int *relu, float *const *dw,
+                           float *const *db, float *ws, void *stream);
 /* Input gradient y = sum_i x[i] W[i] (nin <= 3; W (k, o) = the layers' own (out, in) weights) of Linear layers reading a
  * BatchNorm(+ReLU) output bx -> bn -> relu, with that BatchNorm's backward sums as the product's epilogue: partial
  * (pdf_rowlin_partial_floats(n, o)) receives *partial_rows rows of [sum g' | sum g' xhat]; pdf_bn_act_backward_presummed then

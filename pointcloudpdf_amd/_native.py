@@ -595,6 +595,9 @@ class HipBackend(CBackend):
         lib.pdf_rowlin_multi.restype = c_int
         lib.pdf_rowlin_multi.argtypes = [c_long, c_int, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                          c_int, c_void_p, c_long, c_int, c_void_p]
+        lib.pdf_rowlin_wgrad_group.restype = c_int
+        lib.pdf_rowlin_wgrad_group.argtypes = [c_long, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_void_p]
         lib.pdf_rowlin_wgrad_multi.restype = c_int
         lib.pdf_rowlin_wgrad_multi.argtypes = [c_long, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int,
                                                c_void_p, c_void_p, c_void_p, c_void_p]
@@ -972,6 +975,27 @@ class HipBackend(CBackend):
                                              int(relu), self._ptrs(dws), self._ptrs(dbs), ws.data_ptr(), self._stream())
         if rc != 0:
             raise PdfOpsError(f"pdf_rowlin_wgrad_multi failed with status {rc}")
+        return dws, dbs
+
+    def rowlin_wgrad_group(self, gs, xs, coefs, relus, need_bias):
+        """Up to five weight gradients of one shape with their own inputs in one launch + one reduction (include/pdfops.h:
+        pdf_rowlin_wgrad_group): dW_i = G_i^T f_i(X_i), f_i = relu_i?(x * scale_i + shift_i) for a coef_i = [scale | shift | ...], else the
+        identity.  -> (list of dW, list of db | None); None when the shape is outside the streaming kernels."""
+        n, o = gs[0].shape
+        k = xs[0].shape[1]
+        dev = gs[0].device
+        dws = [torch.empty((o, k), dtype=torch.float32, device=dev) for _ in gs]
+        dbs = [torch.empty((o,), dtype=torch.float32, device=dev) if nb else None for nb in need_bias]
+        ws = self.wgrad_workspace(n, k, o, len(gs), dev)
+        P = lambda ts: (c_void_p * len(ts))(*[None if t is None else (t if isinstance(t, int) else t.data_ptr()) for t in ts])
+        sc = [None if cf is None else cf.data_ptr() for cf in coefs]
+        sh = [None if cf is None else cf.data_ptr() + 4 * k for cf in coefs]
+        rc = self.lib.pdf_rowlin_wgrad_group(n, k, o, len(gs), P(gs), gs[0].stride(0), P(xs), xs[0].stride(0), P(sc), P(sh),
+                                             (c_int * len(gs))(*[int(bool(r)) for r in relus]), P(dws), P(dbs), ws.data_ptr(), self._stream())
+        if rc == -2:   # PDF_ERR_UNSUPPORTED
+            return None
+        if rc != 0:
+            raise PdfOpsError(f"pdf_rowlin_wgrad_group failed with status {rc}")
         return dws, dbs
 
     def rowlin_wgrad(self, g, x, coef, relu, need_bias):

@@ -16,26 +16,6 @@ struct Err {
     Err &operator<<(int r) { if (rc == 0 && r != 0) rc = r; return *this; }
 };
 
-// Optional second stream for the weight-gradient kernels of a Bottleneck backward.  They are leaves of the backward graph (nothing
-// in the block consumes dW), while the input-gradient chain is a sequence of dependent, latency-bound launches at the deep levels
-// (3,124 / 780 points): forked onto `aux` behind an event, the wgrad kernels fill the CUs the chain leaves idle.  Caller-owned
-// handles (no global state); aux == nullptr runs everything on the main stream.
-struct Fork {
-    hipStream_t main, aux;
-    hipEvent_t fork, join;
-    bool on() const { return aux != nullptr; }
-    hipStream_t begin(Err &e) const {   // work issued on the returned stream starts after everything queued on `main` so far
-        if (!on()) return main;
-        e << (int)hipEventRecord(fork, main);
-        e << (int)hipStreamWaitEvent(aux, fork, 0);
-        return aux;
-    }
-    void finish(Err &e) const {         // `main` continues after everything queued on `aux`
-        if (!on()) return;
-        e << (int)hipEventRecord(join, aux);
-        e << (int)hipStreamWaitEvent(main, join, 0);
-    }
-};
 }  // namespace
 
 // coef from GEMM-epilogue partials (training) or running statistics (eval)
@@ -77,7 +57,9 @@ static bool dgrad_bstats() {   // PDFOPS_DGRAD_BSTATS=0: BatchNorm-backward sums
     return on;
 }
 
-static int block_pre_backward(long n, int c, void *const *p, int training, int accumulate_gx, void *stream, const Fork *fk = nullptr) {
+// defer_wgrad: the three weight-gradient products (q / k / v, linear1) are left to the caller (pdf_bottleneck_backward issues them together
+// with linear3's in ONE grouped launch); their inputs -- g_xq / g_xk / g_xv, z1 + coef1, dy, x -- stay untouched until then.
+static int block_pre_backward(long n, int c, void *const *p, int training, int accumulate_gx, void *stream, bool defer_wgrad = false) {
     if (n < 1 || !p || !p[14]) return PDF_ERR_BAD_ARG;
     const float *x = (const float *)p[0], *z1 = (const float *)p[1], *coef1 = (const float *)p[2], *W1 = (const float *)p[3];
     float *gx = (float *)p[10], *grads = (float *)p[11], *dy = (float *)p[12], *partial = (float *)p[13], *wslab = (float *)p[14];
@@ -88,8 +70,7 @@ static int block_pre_backward(long n, int c, void *const *p, int training, int a
     const float *ws[3] = {(const float *)p[4], (const float *)p[5], (const float *)p[6]};
     float *dws[3] = {dqkv, dqkv + (cc + c), dqkv + 2 * (cc + c)}, *dbs[3] = {dqkv + cc, dqkv + (cc + c) + cc, dqkv + 2 * (cc + c) + cc};
     float *ys[1] = {dy};
-    void *ws_stream = fk ? (void *)fk->begin(e) : stream;   // q/k/v weight gradients: g_xq / g_xk / g_xv are final here
-    e << pdf_rowlin_wgrad_multi(n, c, c, 3, gs, c, z1, c, coef1, coef1 + c, 1, dws, dbs, wslab, ws_stream);
+    if (!defer_wgrad) e << pdf_rowlin_wgrad_multi(n, c, c, 3, gs, c, z1, c, coef1, coef1 + c, 1, dws, dbs, wslab, stream);   // g_xq / g_xk / g_xv are final here
     // bn1 backward in place on dy (elementwise: same index read and written); its column sums ARE [d beta1 | d gamma1].  The sums come
     // out of the input-gradient product's epilogue where the streaming kernel covers the shape, else from a pass over dy and z1.
     int prow = 0;
@@ -101,14 +82,13 @@ static int block_pre_backward(long n, int c, void *const *p, int training, int a
         e << rc1;
         e << pdf_bn_act_backward_presummed(n, c, dy, z1, coef1, training, 1, partial, prow, db1, dy, stream);
     }
-    ws_stream = fk ? (void *)fk->begin(e) : stream;         // dW1 needs the finished dy
-    e << pdf_rowlin_wgrad(n, c, c, dy, c, x, c, nullptr, nullptr, 0, dW1, nullptr, wslab, ws_stream);   // (after the q/k/v reduction in stream order)
+    if (!defer_wgrad) e << pdf_rowlin_wgrad(n, c, c, dy, c, x, c, nullptr, nullptr, 0, dW1, nullptr, wslab, stream);   // dW1 needs the finished dy (after the q/k/v reduction in stream order)
     e << pdf_rowlin_forward(n, c, c, dy, c, W1, 1, nullptr, nullptr, nullptr, 0, gx, c, accumulate_gx, nullptr, stream);
     return e.rc;
 }
 
 extern "C" int pdf_block_pre_backward(long n, int c, void *const *p, int training, void *stream) {
-    return block_pre_backward(n, c, p, training, 0, stream, nullptr);
+    return block_pre_backward(n, c, p, training, 0, stream, false);
 }
 
 // p[]: t, x (identity), gamma2, beta2, rm2, rv2, W3, gamma3, beta3, rm3, rv3        (inputs)
@@ -135,7 +115,7 @@ extern "C" int pdf_block_post_forward(long n, int c, void *const *p, int trainin
 //      gt, gres, grads [dW3 (c*c) | dbeta2 | dgamma2 | dbeta3 | dgamma3]             (outputs; every element is WRITTEN: no zeroing)
 //      da (n*c), partial (max(pdf_bn_partial_floats(n, c), pdf_rowlin_partial_floats(n, c)))   (scratch)
 //      p[12] = workspace of the weight-gradient slabs, pdf_rowlin_wgrad_ws_floats(n, c, c, 1) floats
-static int block_post_backward(long n, int c, void *const *p, int training, void *stream, const Fork *fk = nullptr) {
+static int block_post_backward(long n, int c, void *const *p, int training, void *stream, bool defer_wgrad = false) {
     if (n < 1 || !p || !p[12]) return PDF_ERR_BAD_ARG;
     const float *gy = (const float *)p[0], *t = (const float *)p[1], *x = (const float *)p[2], *z3 = (const float *)p[3];
     const float *coef2 = (const float *)p[4], *coef3 = (const float *)p[5], *W3 = (const float *)p[6];
@@ -145,8 +125,7 @@ static int block_post_backward(long n, int c, void *const *p, int training, void
     Err e;
     // bn3 backward: gz3 -> da (scratch), gres; column sums land in the gradient slots [d beta | d gamma]
     e << pdf_bn_act_backward(n, c, gy, z3, x, coef3, training, 1, partial, db3, da, gres, stream);
-    void *ws_stream = fk ? (void *)fk->begin(e) : stream;
-    e << pdf_rowlin_wgrad(n, c, c, da, c, t, c, coef2, coef2 + c, 1, dW3, nullptr, (float *)p[12], ws_stream);
+    if (!defer_wgrad) e << pdf_rowlin_wgrad(n, c, c, da, c, t, c, coef2, coef2 + c, 1, dW3, nullptr, (float *)p[12], stream);
     // bn2 backward in place on gt (sums from the product's epilogue, as in block_pre_backward)
     int prow = 0;
     const float *das[1] = {da}, *w3s[1] = {W3};
@@ -162,7 +141,7 @@ static int block_post_backward(long n, int c, void *const *p, int training, void
 }
 
 extern "C" int pdf_block_post_backward(long n, int c, void *const *p, int training, void *stream) {
-    return block_post_backward(n, c, p, training, stream, nullptr);
+    return block_post_backward(n, c, p, training, stream, false);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -202,21 +181,23 @@ extern "C" int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p
 //            40 partial (max of pdf_bn_partial_floats, pdf_rowlin_partial_floats, pdf_pt_layer_bwd_partial_floats)
 //            41 Wsm (n*nsample*c/8) 42 GR (n*nsample*c) | inverse kNN table: 43 inv_off (n+1) 44 inv_entry, entry_base
 //            45 dy (n*c; separate from 34: the forked dW3 kernel may still be reading `da` when the pre half starts)
-//   optional: 46 aux stream, 47 fork event, 48 join event (all three or none: weight gradients on the second stream, see Fork)
+//   46-48: unused (rounds 2-3: handles of a second stream for the weight-gradient kernels -- measured slower, removed)
 //             49 visiting order of the points (or null)
-//   50 workspace of the weight-gradient slabs: pdf_rowlin_wgrad_ws_floats(n, c, c, 3) + pdf_rowlin_wgrad_ws_floats(n, c, c, 1) floats (the post
-//      half's dW3 slabs first, the pre half's behind them: with the optional second stream the two halves' reductions may overlap)
+//   50 workspace of the weight-gradient slabs: max(pdf_rowlin_wgrad_ws_floats(n, c, c, 5), pdf_rowlin_wgrad_ws_floats(n, c, c, 3) +
+//      pdf_rowlin_wgrad_ws_floats(n, c, c, 1)) floats (grouped launch / one product at a time)
 // No gradient slot is accumulated into any more (slab reductions and column sums WRITE): the memset of round 2 is gone.
 extern "C" int pdf_bottleneck_backward(long n, int nsample, int c, void *const *p, int training, int entry_base, int storage_bf16, void *stream) {
     if (n < 1 || !p) return PDF_ERR_BAD_ARG;
-    hipStream_t s = static_cast<hipStream_t>(stream);
     Err e;
-    Fork fk{s, static_cast<hipStream_t>(p[46]), static_cast<hipEvent_t>(p[47]), static_cast<hipEvent_t>(p[48])};
-    if (!p[46] || !p[47] || !p[48]) fk.aux = nullptr;
     if (!p[50]) return PDF_ERR_BAD_ARG;
+    // The five c x c weight gradients of the block (linear3, q / k / v, linear1) as ONE grouped launch + ONE slab reduction at the end
+    // (pdf_rowlin_wgrad_group; PDFOPS_WGRAD_GROUP=0: five launches + three reductions where each product's inputs become final, as in
+    // rounds 2-3).  Their inputs are scratch / saved tensors nothing else in the block overwrites: da (34), t (24), g_xq / g_xk / g_xv
+    // (35-37), z1 (2), dy (45), x (1).
+    static const bool group = [] { const char *v = getenv("PDFOPS_WGRAD_GROUP"); return !(v && v[0] == '0'); }();
     float *ws_post = (float *)p[50], *ws_pre = ws_post + pdf_rowlin_wgrad_ws_floats(n, c, c, 1);
     void *post[13] = {p[0], p[24], p[1], p[25], p[26], p[27], p[28], p[33], p[29], p[31], p[34], p[40], ws_post};
-    e << block_post_backward(n, c, post, training, stream, &fk);
+    e << block_post_backward(n, c, post, training, stream, group);
     const float *weights[8];
     for (int i = 0; i < 8; ++i) weights[i] = (const float *)p[10 + i];
     e << pdf_pt_layer_backward((int)n, nsample, c, (const float *)p[21], (const float *)p[22], (const float *)p[23], (const float *)p[8],
@@ -225,8 +206,27 @@ extern "C" int pdf_bottleneck_backward(long n, int nsample, int c, void *const *
                                (float *)p[41], (float *)p[42], (const int *)p[43], (const int *)p[44], entry_base,
                                (float *)p[40], (float *)p[32], storage_bf16, (const int *)p[49], stream);
     void *pre[15] = {p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[35], p[36], p[37], p[29], p[30], p[45], p[40], ws_pre};
-    e << block_pre_backward(n, c, pre, training, 1, stream, &fk);   // gx += dy W1 on top of the identity branch
-    fk.finish(e);   // the gradients written on the second stream are complete before anything later on `stream`
+    e << block_pre_backward(n, c, pre, training, 1, stream, group);   // gx += dy W1 on top of the identity branch
+    if (group && e.rc == 0) {
+        const long cc = (long)c * c;
+        float *gpre = (float *)p[30], *gpost = (float *)p[31];                  // block_pre_backward / block_post_backward gradient layouts
+        float *dW1 = gpre, *dqkv = gpre + cc + 2 * c, *dW3 = gpost;
+        const float *coef1 = (const float *)p[3], *coef2 = (const float *)p[26];
+        const float *g[5] = {(const float *)p[34], (const float *)p[35], (const float *)p[36], (const float *)p[37], (const float *)p[45]};
+        const float *x[5] = {(const float *)p[24], (const float *)p[2], (const float *)p[2], (const float *)p[2], (const float *)p[1]};
+        const float *sc[5] = {coef2, coef1, coef1, coef1, nullptr}, *sh[5] = {coef2 + c, coef1 + c, coef1 + c, coef1 + c, nullptr};
+        const int relu[5] = {1, 1, 1, 1, 0};
+        float *dw[5] = {dW3, dqkv, dqkv + (cc + c), dqkv + 2 * (cc + c), dW1};
+        float *db[5] = {nullptr, dqkv + cc, dqkv + (cc + c) + cc, dqkv + 2 * (cc + c) + cc, nullptr};
+        const int rc = pdf_rowlin_wgrad_group(n, c, c, 5, g, c, x, c, sc, sh, relu, dw, db, ws_post, stream);
+        if (rc == PDF_ERR_UNSUPPORTED) {   // widths outside the streaming kernels: one product at a time
+            e << pdf_rowlin_wgrad(n, c, c, g[0], c, x[0], c, sc[0], sh[0], 1, dw[0], nullptr, ws_post, stream);
+            e << pdf_rowlin_wgrad_multi(n, c, c, 3, g + 1, c, x[1], c, sc[1], sh[1], 1, dw + 1, db + 1, ws_pre, stream);
+            e << pdf_rowlin_wgrad(n, c, c, g[4], c, x[4], c, nullptr, nullptr, 0, dw[4], nullptr, ws_pre, stream);
+        } else {
+            e << rc;
+        }
+    }
     return e.rc;
 }
 

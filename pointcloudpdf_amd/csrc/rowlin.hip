@@ -190,11 +190,14 @@ long stats_tail_floats(long n, int o);
 int try_wgrad(long n, int k, int o, int ng, const float *const *g, long ldg, const float *x, long ldx, const float *scale,
               const float *shift, int relu, float *const *dw, float *const *db, float *ws, hipStream_t s, const float *roww = nullptr, long rws = 0);
 long wgrad_ws_floats(long n, int k, int o, int ng);
+constexpr int WG_MAXG = 5;   // (as in rowlin2_impl.h)
 struct RArgs {
     const float *slab, *bslab;
-    float *dW[3], *db[3];
+    float *dW[WG_MAXG], *db[WG_MAXG];
     int B, tiles_k, tiles, otiles, split, K, O;
 };
+int try_wgrad_group(long n, int k, int o, int ng, const float *const *g, long ldg, const float *const *x, long ldx, const float *const *scale,
+                    const float *const *shift, const int *relu, float *const *dw, float *const *db, float *ws, hipStream_t s);
 void launch_slab_reduce(const RArgs &a, int ng, bool any_bias, hipStream_t s);
 int stats_rows(long n);
 }  // namespace rl2
@@ -363,6 +366,20 @@ extern "C" int pdf_rowlin_wgrad_multi(long n, int k, int o, int ng, const float 
     int rc = 0;   // (stream order: the next call reuses the workspace after this call's reduction has read it)
     for (int i = 0; i < ng && rc == 0; ++i) rc = pdf_rowlin_wgrad(n, k, o, g[i], ldg, x, ldx, scale, shift, relu, dw[i], db ? db[i] : nullptr, ws, stream);
     return rc;
+}
+
+// Up to five weight gradients of ONE shape with their OWN inputs in one launch + one reduction (a Bottleneck's linear3, q / k / v and
+// linear1 products): dW_i (o, k) = G_i^T f_i(X_i), f_i = relu_i?(x * scale_i + shift_i) where scale_i is non-null, else the identity;
+// db_i = column sums of G_i where non-null.  Everything is WRITTEN.  Streaming shapes only (k, o in 32..512 by 32: PDF_ERR_UNSUPPORTED
+// otherwise -- the caller then issues pdf_rowlin_wgrad per matrix).  ws: pdf_rowlin_wgrad_ws_floats(n, k, o, ng) floats.
+extern "C" int pdf_rowlin_wgrad_group(long n, int k, int o, int ng, const float *const *g, long ldg, const float *const *x, long ldx,
+                                      const float *const *scale, const float *const *shift, const int *relu, float *const *dw,
+                                      float *const *db, float *ws, void *stream) {
+    if (n < 1 || k < 1 || o < 1 || ng < 1 || ng > rl2::WG_MAXG || !g || !x || !scale || !shift || !relu || !dw || !ws) return PDF_ERR_BAD_ARG;
+    for (int i = 0; i < ng; ++i) if (!g[i] || !x[i] || !dw[i] || (scale[i] && !shift[i])) return PDF_ERR_BAD_ARG;
+    if (!rowlin_streams(k, o) || !rl2::try_wgrad_group(n, k, o, ng, g, ldg, x, ldx, scale, shift, relu, dw, db, ws, static_cast<hipStream_t>(stream)))
+        return PDF_ERR_UNSUPPORTED;
+    return pdf_launch_status();
 }
 
 // Row-weighted variants for the streaming shapes (csrc/transition_down.hip: Gram matrices x^T diag(cnt) x and the dense part of

@@ -9,6 +9,12 @@ template int try_forward_mp<0>(long, int, int, int, int, const float *const *, l
                                const float *, int, int *, const StatsBn *);
 template int try_wgrad_mp<0>(long, int, int, int, const float *const *, long, const float *, long, const float *, const float *, int,
                              float *const *, float *const *, float *, hipStream_t, const float *, long);
+template int try_wgrad_group_mp<0>(long, int, int, int, const float *const *, long, const float *const *, long, const float *const *, const float *const *, const int *,
+                                   float *const *, float *const *, float *, hipStream_t);
+extern template int try_wgrad_group_mp<1>(long, int, int, int, const float *const *, long, const float *const *, long, const float *const *, const float *const *, const int *,
+                                   float *const *, float *const *, float *, hipStream_t);
+extern template int try_wgrad_group_mp<2>(long, int, int, int, const float *const *, long, const float *const *, long, const float *const *, const float *const *, const int *,
+                                   float *const *, float *const *, float *, hipStream_t);
 extern template int try_forward_mp<1>(long, int, int, int, int, const float *const *, long, const float *const *, int, const float *const *, const float *,
                                       const float *, int, float *const *, long, int, float *, hipStream_t, const float *, long, const float *, long,
                                       const float *, int, int *, const StatsBn *);
@@ -41,6 +47,15 @@ int try_wgrad(long n, int k, int o, int ng, const float *const *g, long ldg, con
     case 1: return try_wgrad_mp<1>(n, k, o, ng, g, ldg, x, ldx, scale, shift, relu, dw, db, ws, s, roww, rws);
     case 2: return try_wgrad_mp<2>(n, k, o, ng, g, ldg, x, ldx, scale, shift, relu, dw, db, ws, s, roww, rws);
     default: return try_wgrad_mp<0>(n, k, o, ng, g, ldg, x, ldx, scale, shift, relu, dw, db, ws, s, roww, rws);
+    }
+}
+
+int try_wgrad_group(long n, int k, int o, int ng, const float *const *g, long ldg, const float *const *x, long ldx, const float *const *scale,
+                    const float *const *shift, const int *relu, float *const *dw, float *const *db, float *ws, hipStream_t s) {
+    switch (pdf_mma_input_mode()) {
+    case 1: return try_wgrad_group_mp<1>(n, k, o, ng, g, ldg, x, ldx, scale, shift, relu, dw, db, ws, s);
+    case 2: return try_wgrad_group_mp<2>(n, k, o, ng, g, ldg, x, ldx, scale, shift, relu, dw, db, ws, s);
+    default: return try_wgrad_group_mp<0>(n, k, o, ng, g, ldg, x, ldx, scale, shift, relu, dw, db, ws, s);
     }
 }
 }  // namespace rl2

@@ -7,4 +7,6 @@ template int try_forward_mp<1>(long, int, int, int, int, const float *const *, l
                                const float *, int, int *, const StatsBn *);
 template int try_wgrad_mp<1>(long, int, int, int, const float *const *, long, const float *, long, const float *, const float *, int,
                              float *const *, float *const *, float *, hipStream_t, const float *, long);
+template int try_wgrad_group_mp<1>(long, int, int, int, const float *const *, long, const float *const *, long, const float *const *, const float *const *, const int *,
+                                   float *const *, float *const *, float *, hipStream_t);
 }  // namespace rl2

@@ -288,13 +288,17 @@ __global__ __launch_bounds__(256) void k_fwd(FwdArgs a) {
     }
 }
 
+constexpr int WG_MAXG = 5;   // weight gradients of one launch (blockIdx.z): q / k / v of one input, or the five c x c products of a Bottleneck
 struct WArgs {
     long N;
     int K, O;
-    const float *G[3]; long ldg;
+    const float *G[WG_MAXG]; long ldg;
     const float *X; long ldx;
     const float *scale, *shift; int relu;
-    float *dW[3], *db[3];
+    // per-matrix inputs (per_z != 0; kernels instantiated with PRE = true): its own X and, where scalez[z] is non-null, its own folded
+    // BatchNorm + ReLU prologue (a null scalez[z] runs the prologue with scale 1, shift 0, no ReLU: x * 1 + 0 is x)
+    int per_z; const float *Xz[WG_MAXG]; const float *scalez[WG_MAXG], *shiftz[WG_MAXG]; int reluz[WG_MAXG];
+    float *dW[WG_MAXG], *db[WG_MAXG];
     long rows_per_block;     // multiple of 64
     const float *roww; long rws;   // optional per-row weight of G (dW = sum_n roww[n] G[n]^T f(X[n]))
     float *slab;             // [gridDim.z][gridDim.y][gridDim.x][(16 VW)^2]: one block of dW per workgroup
@@ -316,12 +320,21 @@ __global__ __launch_bounds__(256) void k_wg(WArgs a) {
     const int nkb = a.K / B;
     const int ob = (blockIdx.y / nkb) * B, kb = (blockIdx.y % nkb) * B;
     const float *G = a.G[blockIdx.z];
+    const float *X = (PRE && a.per_z) ? a.Xz[blockIdx.z] : a.X;
     vec sc, sh;
+    bool relu = a.relu != 0;
     if (PRE) {
-        sc = *reinterpret_cast<const vec *>(a.scale + kb + VW * li);
-        sh = *reinterpret_cast<const vec *>(a.shift + kb + VW * li);
+        const float *scp = a.per_z ? a.scalez[blockIdx.z] : a.scale, *shp = a.per_z ? a.shiftz[blockIdx.z] : a.shift;
+        if (a.per_z) relu = scp != nullptr && a.reluz[blockIdx.z] != 0;
+        if (scp) {   // (uniform per workgroup)
+            sc = *reinterpret_cast<const vec *>(scp + kb + VW * li);
+            sh = *reinterpret_cast<const vec *>(shp + kb + VW * li);
+        } else {
+#pragma unroll
+            for (int c = 0; c < VW; ++c) { sc[c] = 1.f; sh[c] = 0.f; }
+        }
     }
-    const float relu_lo = a.relu ? 0.f : -INFINITY;
+    const float relu_lo = relu ? 0.f : -INFINITY;
     f32x4 acc[VW][VW];
     float gsum[VW];
 #pragma unroll
@@ -346,7 +359,7 @@ __global__ __launch_bounds__(256) void k_wg(WArgs a) {
             ok[t] = n < re;
             const long nn = ok[t] ? n : rb;
             gv[t] = *reinterpret_cast<const vec *>(G + nn * a.ldg + ob + VW * li);
-            xv[t] = *reinterpret_cast<const vec *>(a.X + nn * a.ldx + kb + VW * li);
+            xv[t] = *reinterpret_cast<const vec *>(X + nn * a.ldx + kb + VW * li);
             if (RW) rw[RW ? t : 0] = a.roww[nn * a.rws];
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -416,7 +429,7 @@ __global__ __launch_bounds__(256) void k_wg(WArgs a) {
 // kernel of rowlin.hip as well (B = 32, edge blocks masked by O / K).
 struct RArgs {
     const float *slab, *bslab;
-    float *dW[3], *db[3];
+    float *dW[WG_MAXG], *db[WG_MAXG];
     int B, tiles_k, tiles, otiles, split, K, O;
 };
 void launch_slab_reduce(const RArgs &a, int ng, bool any_bias, hipStream_t s);
@@ -596,9 +609,11 @@ int try_wgrad_mp(long n, int k, int o, int ng, const float *const *g, long ldg, 
     for (int i = 0; i < ng; ++i) if (!aligned16(g[i])) return 0;
     WArgs a;
     a.N = n; a.K = k; a.O = o; a.ldg = ldg; a.X = x; a.ldx = ldx; a.scale = scale; a.shift = shift; a.relu = relu; a.roww = roww; a.rws = rws;
+    a.per_z = 0;
     bool any_bias = false;
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < WG_MAXG; ++i) {
         a.G[i] = i < ng ? g[i] : nullptr; a.dW[i] = i < ng ? dw[i] : nullptr; a.db[i] = (db && i < ng) ? db[i] : nullptr;
+        a.Xz[i] = nullptr; a.scalez[i] = a.shiftz[i] = nullptr; a.reluz[i] = 0;
         any_bias = any_bias || a.db[i] != nullptr;
     }
     const int b = p.b;
@@ -613,7 +628,48 @@ int try_wgrad_mp(long n, int k, int o, int ng, const float *const *g, long ldg, 
 #undef PDF_WG
     RArgs r;
     r.slab = a.slab; r.bslab = a.bslab; r.B = b; r.tiles_k = k / b; r.tiles = (o / b) * (k / b); r.otiles = o / b; r.split = (int)p.split; r.K = k; r.O = o;
-    for (int i = 0; i < 3; ++i) { r.dW[i] = a.dW[i]; r.db[i] = a.db[i]; }
+    for (int i = 0; i < WG_MAXG; ++i) { r.dW[i] = a.dW[i]; r.db[i] = a.db[i]; }
+    launch_slab_reduce(r, ng, any_bias, s);
+    return 1;
+}
+
+// Up to WG_MAXG weight gradients of ONE shape (n, k, o) with their OWN inputs in one launch + one slab reduction: dW_i = G_i^T f_i(X_i),
+// f_i = relu?(x * scale_i + shift_i) where scale_i is non-null, the identity otherwise.  A Bottleneck's backward has five such products
+// (linear3, q / k / v, linear1: all c x c over the block's n rows); issued one by one at levels 3-5 each of them is a launch that fills a
+// fraction of the chip followed by its own reduction launch.  ws: wgrad_ws_floats(n, k, o, ng) floats.
+template <int MP>
+int try_wgrad_group_mp(long n, int k, int o, int ng, const float *const *g, long ldg, const float *const *x, long ldx,
+                       const float *const *scale, const float *const *shift, const int *relu, float *const *dw, float *const *db,
+                       float *ws, hipStream_t s) {
+    if (ng < 1 || ng > WG_MAXG || !ws) return 0;
+    const WgPlan p = wg_plan(n, k, o, ng);
+    const int vw = p.vw;
+    if (!vw) return 0;
+    if ((ldg % vw) || (ldx % vw)) return 0;
+    for (int i = 0; i < ng; ++i) {
+        if (!aligned16(g[i]) || !aligned16(x[i])) return 0;
+        if (scale[i] && (!aligned16(scale[i]) || !aligned16(shift[i]))) return 0;
+    }
+    WArgs a;
+    a.N = n; a.K = k; a.O = o; a.ldg = ldg; a.X = nullptr; a.ldx = ldx; a.scale = a.shift = nullptr; a.relu = 0; a.roww = nullptr; a.rws = 0;
+    a.per_z = 1;
+    bool any_bias = false;
+    for (int i = 0; i < WG_MAXG; ++i) {
+        const bool on = i < ng;
+        a.G[i] = on ? g[i] : nullptr; a.Xz[i] = on ? x[i] : nullptr;
+        a.scalez[i] = on ? scale[i] : nullptr; a.shiftz[i] = on ? shift[i] : nullptr; a.reluz[i] = on ? relu[i] : 0;
+        a.dW[i] = on ? dw[i] : nullptr; a.db[i] = (on && db) ? db[i] : nullptr;
+        any_bias = any_bias || a.db[i] != nullptr;
+    }
+    const int b = p.b;
+    a.rows_per_block = p.rows_per_block;
+    a.slab = ws;
+    a.bslab = ws + (size_t)p.nblk * p.split * b * b;
+    const dim3 grid((unsigned)p.split, (unsigned)((o / b) * (k / b)), (unsigned)ng);
+    if (vw == 4) k_wg<4, true, false, MP><<<grid, 256, 0, s>>>(a); else k_wg<2, true, false, MP><<<grid, 256, 0, s>>>(a);
+    RArgs r;
+    r.slab = a.slab; r.bslab = a.bslab; r.B = b; r.tiles_k = k / b; r.tiles = (o / b) * (k / b); r.otiles = o / b; r.split = (int)p.split; r.K = k; r.O = o;
+    for (int i = 0; i < WG_MAXG; ++i) { r.dW[i] = a.dW[i]; r.db[i] = a.db[i]; }
     launch_slab_reduce(r, ng, any_bias, s);
     return 1;
 }

@@ -531,7 +531,8 @@ class _BottleneckFn(torch.autograd.Function):
         ssz = [nc, nc, nc, n * k * cs, n * k * 3,
                max(int(lib.pdf_bn_partial_floats(n, c)), int(lib.pdf_rowlin_partial_floats(n, c)), int(lib.pdf_pt_layer_bwd_partial_floats(n, k, c))),
                nc, nc, n * k * cs, n * k * c, nc,
-               int(lib.pdf_rowlin_wgrad_ws_floats(n, c, c, 3)) + int(lib.pdf_rowlin_wgrad_ws_floats(n, c, c, 1))]   # gt da gxq G2 G3 partial | gxk gxv Wsm GR | dy | wgrad slabs
+               max(int(lib.pdf_rowlin_wgrad_ws_floats(n, c, c, 5)),       # the block's five weight gradients as one grouped launch
+                   int(lib.pdf_rowlin_wgrad_ws_floats(n, c, c, 3)) + int(lib.pdf_rowlin_wgrad_ws_floats(n, c, c, 1)))]   # gt da gxq G2 G3 partial | gxk gxv Wsm GR | dy | wgrad slabs
         soff, tot = [], 0
         for sz in ssz:
             soff.append(tot)

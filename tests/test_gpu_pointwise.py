@@ -152,6 +152,54 @@ def test_rowlin_reduced_precision_operands(n, k, o, pre, dtype):
     assert max_rel(db.cpu().numpy(), go.double().sum(0).cpu().numpy()) < 1e-5   # the bias gradient is a plain fp32 column sum
 
 
+@pytest.mark.parametrize("n,c", [(30011, 32), (9000, 64), (4097, 128), (3124, 256), (780, 512), (5, 64)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_rowlin_wgrad_group(n, c, mode):
+    """The five c x c weight gradients of a Bottleneck backward in one launch + one reduction: each with its own gradient rows, its own
+    input rows and its own folded BatchNorm + ReLU prologue (or none), biases where asked; against float64 and against the one-by-one
+    entry points; deterministic (two calls give identical bits).  mode 1: fp16 operands (the grouped kernel honours pdf_set_mma_input)."""
+    from pointcloudpdf_amd import _native
+
+    be = _native.hip_backend()
+    g = torch.Generator(device="cuda").manual_seed(n + c)
+    gs = [torch.randn(n, c, device="cuda", generator=g) for _ in range(5)]
+    xs = [torch.randn(n, c, device="cuda", generator=g) for _ in range(3)]
+    coefs = []
+    for _ in range(2):
+        sc = torch.rand(c, device="cuda", generator=g) + 0.5
+        sh = torch.randn(c, device="cuda", generator=g) * 0.3
+        coefs.append(torch.cat([sc, sh, torch.zeros(2 * c, device="cuda")]))
+    x_of, coef_of = [xs[0], xs[1], xs[1], xs[1], xs[2]], [coefs[0], coefs[1], coefs[1], coefs[1], None]
+    relus, need_bias = [True, True, True, True, False], [False, True, True, True, False]
+    with _native.mma_input(mode):
+        out = be.rowlin_wgrad_group(gs, x_of, coef_of, relus, need_bias)
+        again = be.rowlin_wgrad_group(gs, x_of, coef_of, relus, need_bias)
+        single = [be.rowlin_wgrad(gs[i], x_of[i], coef_of[i], relus[i], need_bias[i]) for i in range(5)]
+    assert out is not None
+    dws, dbs = out
+    rnd = (lambda t: t.half().double()) if mode == 1 else (lambda t: t.double())
+    for i in range(5):
+        fx = x_of[i] if coef_of[i] is None else torch.relu(x_of[i] * coef_of[i][:c] + coef_of[i][c:2 * c])
+        ref = rnd(gs[i]).t() @ rnd(fx)
+        tol = 1e-5 if mode == 0 else 1e-3   # (mode 1 with the prologue: FMA vs product + sum flips a few operand roundings, as in the single form)
+        assert max_rel(dws[i].cpu().numpy(), ref.cpu().numpy()) < tol, i
+        assert max_rel(dws[i].cpu().numpy(), single[i][0].cpu().numpy()) < (2e-6 if mode == 0 else 1e-3), i
+        assert torch.equal(dws[i], again[0][i])
+        if need_bias[i]:
+            assert max_rel(dbs[i].cpu().numpy(), gs[i].double().sum(0).cpu().numpy()) < 1e-5 and torch.equal(dbs[i], again[1][i])
+        else:
+            assert dbs[i] is None
+
+
+def test_rowlin_wgrad_group_outside_the_streaming_shapes():
+    from pointcloudpdf_amd import _native
+
+    be = _native.hip_backend()
+    g = [torch.randn(100, 48, device="cuda") for _ in range(2)]
+    x = [torch.randn(100, 48, device="cuda") for _ in range(2)]
+    assert be.rowlin_wgrad_group(g, x, [None, None], [False, False], [False, False]) is None   # PDF_ERR_UNSUPPORTED: one product at a time
+
+
 def test_mma_input_rejects_unknown_modes():
     from pointcloudpdf_amd import _native
 
