@@ -992,7 +992,7 @@ class HipBackend(CBackend):
         sh = [None if cf is None else cf.data_ptr() + 4 * k for cf in coefs]
         rc = self.lib.pdf_rowlin_wgrad_group(n, k, o, len(gs), P(gs), gs[0].stride(0), P(xs), xs[0].stride(0), P(sc), P(sh),
                                              (c_int * len(gs))(*[int(bool(r)) for r in relus]), P(dws), P(dbs), ws.data_ptr(), self._stream())
-        if rc == -2:   # PDF_ERR_UNSUPPORTED
+        if rc == -3:   # PDF_ERR_UNSUPPORTED
             return None
         if rc != 0:
             raise PdfOpsError(f"pdf_rowlin_wgrad_group failed with status {rc}")
