@@ -485,10 +485,10 @@ def main():
             self.D, self.phase = D, (warmup % D if D > 0 else 0)
             self.tickets, self.submit_host_s, self.pending = {}, [], None
 
-        def _submit_range(self, lo, hi):
+        def _submit_range(self, lo, hi, ready=None):
             group = [pool[j % len(pool)] for j in range(lo, hi)]
             t_sub = time.perf_counter()
-            for j, t in enumerate(prefetcher.submit_group(group)):
+            for j, t in enumerate(prefetcher.submit_group(group, ready=ready)):
                 self.tickets[lo + j] = t
             self.submit_host_s.append(time.perf_counter() - t_sub)
 
@@ -505,7 +505,9 @@ def main():
                 return None
             geom = prefetcher.get(self.tickets.pop(i))
             if (i + self.D - self.phase) % self.D == 0:
-                self.pending = (i + self.D, i + 2 * self.D)   # submitted by after_step(): once this step's launches are queued
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream())     # the pre-pass depends on what is queued up to HERE, not on this step
+                self.pending = (i + self.D, i + 2 * self.D, ready)   # submitted by after_step(): once this step's launches are queued
             return geom
 
         def after_step(self):
@@ -513,9 +515,9 @@ def main():
             issued in front of the step (rounds 1-3) it left the device idle for that long at every group boundary -- with replayed steps
             the device queue is empty right after the opening fence of a timed region."""
             if self.pending is not None:
-                lo, hi = self.pending
+                lo, hi, ready = self.pending
                 self.pending = None
-                self._submit_range(lo, hi)
+                self._submit_range(lo, hi, ready)
 
         def drain(self):
             """Pre-passes queued beyond the last step (none when steps is a multiple of D): wait for them, drop them."""

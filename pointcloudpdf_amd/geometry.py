@@ -625,14 +625,17 @@ class GeometryPrefetcher:
             done.record(stream)
         return geom, done, stream
 
-    def submit_group(self, batches):
+    def submit_group(self, batches, ready=None):
         """One pre-pass over the scenes of several upcoming batches (dicts with coord / offset / offset_host) -> one
-        ticket per batch.  See Geometry.split."""
+        ticket per batch.  See Geometry.split.  ``ready``: an event recorded on the caller's stream once the batches' tensors were
+        complete (default: the caller's stream as it stands NOW -- a caller that submits after queueing a training step passes the event
+        it recorded before that step, or the pre-pass would wait for the step)."""
         stream = self.streams[self._n % len(self.streams)]
         self._n += 1
         if self.pool is not None:
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream())   # the batches' tensors were produced on the caller's stream
+            if ready is None:
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream())   # the batches' tensors were produced on the caller's stream
 
             def work():
                 torch.cuda.set_device(self.device)
@@ -641,7 +644,10 @@ class GeometryPrefetcher:
 
             fut = self.pool.submit(work)
             return [_LazyTicket(fut, j) for j in range(len(batches))]
-        stream.wait_stream(torch.cuda.current_stream())
+        if ready is not None:
+            stream.wait_event(ready)
+        else:
+            stream.wait_stream(torch.cuda.current_stream())
         return self._group_on(stream, batches)
 
     def _group_on(self, stream, batches):
