@@ -183,7 +183,8 @@ namespace rl2 {
 int try_forward(long n, int k, int o, int nin, int nout, const float *const *x, long ldx, const float *const *w, int transpose_w,
                 const float *const *bias, const float *scale, const float *shift, int relu, float *const *y, long ldy,
                 int accumulate, float *partial, hipStream_t s, const float *roww = nullptr, long rws = 0, const float *bx = nullptr,
-                long ldb = 0, const float *bcoef = nullptr, int brelu = 0, int *partial_rows = nullptr, const struct StatsBn *bn = nullptr);
+                long ldb = 0, const float *bcoef = nullptr, int brelu = 0, int *partial_rows = nullptr, const struct StatsBn *bn = nullptr,
+                long ldw = 0);
 struct StatsBn { const float *gamma, *beta; float *running_mean, *running_var; float eps, momentum; float *out; };
 long stats_rows_floats(long n, int o);
 long stats_tail_floats(long n, int o);
@@ -236,6 +237,22 @@ extern "C" int pdf_rowlin_forward(long n, int k, int o, const float *x, long ldx
                              static_cast<hipStream_t>(stream)))
             return pdf_launch_status();
         if (partial) return PDF_ERR_BAD_ARG;  // statistics layout is tied to the streaming kernel for these shapes (needs 16-byte alignment)
+    }
+    // Wide inputs (k = 1024 ... 4096 in steps of 512: the TransitionUp head's Linear(2 * 512, 512), point_transformer_seg.py:131-136) as
+    // k / 512 passes of the streaming kernel over column windows of x and W, accumulating into y (not with the statistics epilogue: its row count
+    // is the tiled kernel's for these widths, pdf_rowlin_partial_rows).  The tiled kernel below walks such a k serially in a handful of
+    // workgroups: 274 us at 780 x 1024 -> 512 against 2 x 13 us.
+    if (!transpose_w && !partial && k > 512 && k % 512 == 0 && k <= 4096 && rowlin_streams(512, o) && !(ldx & 3) && !(ldy & 3)) {
+        const int chunks = k / 512;
+        bool ok = true;
+        for (int c = 0; c < chunks && ok; ++c) {
+            const float *xc = x + (long)c * 512, *wc = w + (long)c * 512, *bc = c == 0 ? bias : nullptr;
+            ok = rl2::try_forward(n, 512, o, 1, 1, &xc, ldx, &wc, 0, &bc, scale ? scale + (long)c * 512 : nullptr, shift ? shift + (long)c * 512 : nullptr,
+                                  relu, &y, ldy, (accumulate || c > 0) ? 1 : 0, nullptr, static_cast<hipStream_t>(stream),
+                                  nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, k) != 0;
+            if (!ok && c > 0) return PDF_ERR_UNSUPPORTED;   // (cannot happen: every window has the shape of the first)
+        }
+        if (ok) return pdf_launch_status();
     }
     rl::FwdArgs a;
     a.N = n; a.K = k; a.O = o; a.X = x; a.ldx = ldx; a.W = w;

@@ -541,7 +541,7 @@ template <int MP>
 int try_forward_mp(long n, int k, int o, int nin, int nout, const float *const *x, long ldx, const float *const *w, int transpose_w,
                    const float *const *bias, const float *scale, const float *shift, int relu, float *const *y, long ldy,
                    int accumulate, float *partial, hipStream_t s, const float *roww, long rws, const float *bx, long ldb, const float *bcoef,
-                   int brelu, int *partial_rows, const StatsBn *bn) {
+                   int brelu, int *partial_rows, const StatsBn *bn, long ldw) {
     if (nin < 1 || nout < 1 || (nin > 1 && nout > 1) || nin > 3 || nout > 3) return 0;
     if (partial && !bx && (nin != 1 || nout != 1)) return 0;
     if (bx && (!partial || nout != 1 || scale || !bcoef || (ldb & 3) || !aligned16(bx) || !aligned16(bcoef))) return 0;
@@ -562,7 +562,7 @@ int try_forward_mp(long n, int k, int o, int nin, int nout, const float *const *
         a.tail_out = bn->out; a.gamma = bn->gamma; a.beta = bn->beta; a.running_mean = bn->running_mean; a.running_var = bn->running_var;
         a.eps = bn->eps; a.momentum = bn->momentum;
     }
-    a.wso = transpose_w ? 1 : k; a.wsk = transpose_w ? o : 1;
+    a.wso = transpose_w ? 1 : (ldw ? ldw : k); a.wsk = transpose_w ? o : 1;   // ldw: row stride of an (o, k) window of a wider weight matrix
     for (int i = 0; i < 3; ++i) {
         a.X[i] = i < nin ? x[i] : nullptr;
         a.W[i] = i < (nin > 1 ? nin : nout) ? w[i] : nullptr;

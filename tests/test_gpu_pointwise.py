@@ -65,7 +65,8 @@ def test_split_k_linear_matches_torch():
 
 
 @pytest.mark.parametrize("n,k,o", [(5000, 32, 32), (3001, 6, 32), (777, 512, 512), (40000, 64, 192), (999, 35, 64), (2500, 32, 13), (130, 256, 1),
-                                   (100003, 32, 32), (50001, 64, 64), (12517, 128, 128), (3125, 256, 256), (5, 32, 96), (1000, 128, 48)])
+                                   (100003, 32, 32), (50001, 64, 64), (12517, 128, 128), (3125, 256, 256), (5, 32, 96), (1000, 128, 48),
+                                   (780, 1024, 512), (333, 1536, 64)])   # (k = 1024 / 1536: column windows of 512 through the streaming kernel)
 @pytest.mark.parametrize("pre", [False, True])
 def test_rowlin_forward_dgrad_wgrad(n, k, o, pre):
     from pointcloudpdf_amd import _native
@@ -101,6 +102,33 @@ def test_rowlin_forward_dgrad_wgrad(n, k, o, pre):
     big = torch.randn(n, k + 5, device="cuda", generator=g)
     y2, _ = be.rowlin(big[:, :k], w, b)
     assert max_rel(y2.cpu().numpy(), (big[:, :k].double() @ w.double().t() + b.double()).cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("n,k,o", [(780, 1024, 512), (333, 1536, 64), (3, 2048, 32)])
+@pytest.mark.parametrize("pre", [False, True])
+def test_rowlin_forward_wide_inputs(n, k, o, pre):
+    """k = 1024 .. 4096 (the TransitionUp head's Linear(2 * 512, 512)): column windows of 512 through the streaming kernel, accumulated
+    into y -- bias once, folded BatchNorm + ReLU prologue per window, on top of an existing y when asked."""
+    from pointcloudpdf_amd import _native
+
+    be = _native.hip_backend()
+    g = torch.Generator(device="cuda").manual_seed(n + k + o)
+    x = torch.randn(n, k, device="cuda", generator=g)
+    w = torch.randn(o, k, device="cuda", generator=g) / k ** 0.5
+    b = torch.randn(o, device="cuda", generator=g)
+    coef, fx = None, x
+    if pre:
+        sc = torch.rand(k, device="cuda", generator=g) + 0.5
+        sh = torch.randn(k, device="cuda", generator=g) * 0.3
+        coef = torch.cat([sc, sh, torch.zeros(2 * k, device="cuda")])
+        fx = torch.relu(x * sc + sh)
+    ref = fx.double() @ w.double().t() + b.double()
+    y, _ = be.rowlin(x, w, b, coef=coef, relu=True)
+    assert max_rel(y.cpu().numpy(), ref.cpu().numpy()) < 2e-6
+    y2, _ = be.rowlin(x, w, b, coef=coef, relu=True, out=y.clone(), accumulate=True)
+    assert max_rel(y2.cpu().numpy(), (2 * ref).cpu().numpy()) < 2e-6
+    y3, _ = be.rowlin(x, w, None, coef=coef, relu=True)
+    assert max_rel(y3.cpu().numpy(), (ref - b.double()).cpu().numpy()) < 2e-6
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
