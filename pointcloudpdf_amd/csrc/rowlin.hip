@@ -238,21 +238,15 @@ extern "C" int pdf_rowlin_forward(long n, int k, int o, const float *x, long ldx
             return pdf_launch_status();
         if (partial) return PDF_ERR_BAD_ARG;  // statistics layout is tied to the streaming kernel for these shapes (needs 16-byte alignment)
     }
-    // Wide inputs (k = 1024 ... 4096 in steps of 512: the TransitionUp head's Linear(2 * 512, 512), point_transformer_seg.py:131-136) as
-    // k / 512 passes of the streaming kernel over column windows of x and W, accumulating into y (not with the statistics epilogue: its row count
-    // is the tiled kernel's for these widths, pdf_rowlin_partial_rows).  The tiled kernel below walks such a k serially in a handful of
-    // workgroups: 274 us at 780 x 1024 -> 512 against 2 x 13 us.
-    if (!transpose_w && !partial && k > 512 && k % 512 == 0 && k <= 4096 && rowlin_streams(512, o) && !(ldx & 3) && !(ldy & 3)) {
-        const int chunks = k / 512;
-        bool ok = true;
-        for (int c = 0; c < chunks && ok; ++c) {
-            const float *xc = x + (long)c * 512, *wc = w + (long)c * 512, *bc = c == 0 ? bias : nullptr;
-            ok = rl2::try_forward(n, 512, o, 1, 1, &xc, ldx, &wc, 0, &bc, scale ? scale + (long)c * 512 : nullptr, shift ? shift + (long)c * 512 : nullptr,
-                                  relu, &y, ldy, (accumulate || c > 0) ? 1 : 0, nullptr, static_cast<hipStream_t>(stream),
-                                  nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, k) != 0;
-            if (!ok && c > 0) return PDF_ERR_UNSUPPORTED;   // (cannot happen: every window has the shape of the first)
-        }
-        if (ok) return pdf_launch_status();
+    // k = 1024 (the TransitionUp head's Linear(2 * 512, 512), point_transformer_seg.py:131-136) as ONE launch of the streaming kernel over
+    // the two 512-wide column windows of x and W (its multi-input form: one accumulation chain across both windows, bias at the end --
+    // the association of a single 1024-long dot product).  The tiled kernel below walks such a k serially in a handful of workgroups:
+    // 274 us at 780 x 1024 -> 512 against ~20 us.
+    if (!transpose_w && !partial && !scale && k == 1024 && rowlin_streams(512, o) && !(ldx & 3) && !(ldy & 3)) {
+        const float *xs[2] = {x, x + 512}, *ws[2] = {w, w + 512};
+        if (rl2::try_forward(n, 512, o, 2, 1, xs, ldx, ws, 0, &bias, nullptr, nullptr, 0, &y, ldy, accumulate, nullptr, static_cast<hipStream_t>(stream),
+                             nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, k))
+            return pdf_launch_status();
     }
     rl::FwdArgs a;
     a.N = n; a.K = k; a.O = o; a.X = x; a.ldx = ldx; a.W = w;

@@ -543,6 +543,7 @@ int try_forward_mp(long n, int k, int o, int nin, int nout, const float *const *
                    int accumulate, float *partial, hipStream_t s, const float *roww, long rws, const float *bx, long ldb, const float *bcoef,
                    int brelu, int *partial_rows, const StatsBn *bn, long ldw) {
     if (nin < 1 || nout < 1 || (nin > 1 && nout > 1) || nin > 3 || nout > 3) return 0;
+    if (nin == 2 && (scale || bx)) return 0;   // (the two-window form: plain product only)
     if (partial && !bx && (nin != 1 || nout != 1)) return 0;
     if (bx && (!partial || nout != 1 || scale || !bcoef || (ldb & 3) || !aligned16(bx) || !aligned16(bcoef))) return 0;
     if ((ldx & 3) || (ldy & 3) || (o & 15)) return 0;
@@ -584,6 +585,8 @@ int try_forward_mp(long n, int k, int o, int nin, int nout, const float *const *
         case 512: PDF_RL2(512, 1, 1); break;
         default: break;
         }
+    } else if (nin == 2) {   // two 512-wide column windows of one 1024-wide input (ldw): ONE accumulation chain over both, bias at the end
+        if (k == 512) PDF_RL2(512, 1, 2);
     } else if (nin == 3) {
         switch (k) {
         case 32: PDF_RL2(32, 2, 3); break;
