@@ -1073,27 +1073,6 @@ class HipBackend(CBackend):
         if rc != 0:
             raise PdfOpsError(f"pdf_bottleneck_forward failed with status {rc}")
 
-    # optional second stream for the weight-gradient kernels of the Bottleneck backward (csrc/block.hip, Fork); PDFOPS_WGRAD_STREAM=1 turns it on
-    # "1": every block (measured: 22.4 ms per step with it, 21.6 without -- event traffic costs more than the overlap gains);
-    # "small": only blocks with at most 16,384 points (levels 3-5, where a weight-gradient kernel fills a fraction of the chip)
-    wgrad_stream = os.environ.get("PDFOPS_WGRAD_STREAM", "0")
-
-    def aux_handles(self, device, n=0):
-        """[aux stream, fork event, join event] handles for ``device`` (created once per device), or three nulls."""
-        if self.wgrad_stream not in ("1", "small") or (self.wgrad_stream == "small" and n > 16384):
-            return [None, None, None]
-        table = self.__dict__.setdefault("_aux", {})
-        key = device.index if device.index is not None else torch.cuda.current_device()
-        if key not in table:
-            with torch.cuda.device(key):
-                st = torch.cuda.Stream()
-                evs = [torch.cuda.Event(), torch.cuda.Event()]
-                for ev in evs:
-                    ev.record(st)   # (torch creates the HIP event on its first record)
-            table[key] = (st, evs)
-        st, evs = table[key]
-        return [st.cuda_stream, evs[0].cuda_event, evs[1].cuda_event]
-
     def bottleneck_backward(self, n, k, c, ptrs, training, entry_base=0, storage_bf16=0):
         rc = self.lib.pdf_bottleneck_backward(n, k, c, (c_void_p * len(ptrs))(*ptrs), int(training), int(entry_base), self.layer_flags(storage_bf16), self._stream())
         if rc != 0:
