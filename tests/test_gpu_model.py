@@ -86,8 +86,8 @@ def test_ddp_rccl_step_matches_plain_step():
         (la, ga), (lb, gb) = grads
         assert abs(la - lb) < 1e-5 * max(1.0, abs(la))
         assert set(ga) == set(gb) and len(ga) > 100
-        # two runs of the step differ by the summation order of the scatter atomics; gradients formed behind the coarsest
-        # levels amplify that (helpers.WELL_CONDITIONED): tight bound on the well-conditioned groups, sanity bound on the rest
+        # (DDP's bucket views change where gradients are accumulated, not the kernels: tight bound on the well-conditioned groups,
+        #  helpers.WELL_CONDITIONED, sanity bound on the rest)
         tight = [k for k in ga if any(f".{w}" in k or k.startswith(w) for w in helpers.WELL_CONDITIONED) and np.abs(ga[k]).max() > 1e-6]
         assert len(tight) > 30
         worst = max(helpers.l2_rel(gb[k], ga[k]) for k in tight)
@@ -467,3 +467,32 @@ def test_training_loop_converges_in_every_precision_and_execution_mode():
         assert eager == graph, (dtype, "graph replay left the eager trajectory")
         assert all(np.isfinite(eager)) and abs(eager[-1] - ref[-1]) <= 0.05 * ref[-1], (dtype, eager[-1], ref[-1])
         assert all(abs(eager[i] - ref[i]) <= 0.10 * ref[i] for i in range(0, 30, 5)), (dtype, [round(eager[i] / ref[i], 3) for i in range(0, 30, 5)])
+
+
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_two_ranks_share_one_gpu_and_exchange_gradients(mode, tmp_path):
+    """BASELINE config 3 as far as a 1-GPU box allows: TWO data-parallel ranks (own process each, different whole scenes) run the HIP step
+    on cuda:0 and exchange gradients with engine.FlatGradAllReduce over gloo (RCCL refuses two ranks on one device; the collective is the
+    only thing that differs from the 8-GPU job).  Checked: rank 1 starts from rank 0's broadcast parameters; after the exchange both ranks
+    hold the SAME gradients, equal bit for bit to (g_rank0 + g_rank1) / 2 of their local gradients -- for the eagerly issued step and for
+    the captured / replayed one (whose gradient tensors are the graph's static buffers)."""
+    import socket
+    import subprocess
+    import sys
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "two_rank_worker.py")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank))
+        procs.append(subprocess.Popen([sys.executable, worker, mode, str(tmp_path / f"rank{rank}.pt")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\\n".join(o[-2000:] for o in outs)
+    r0, r1 = (torch.load(tmp_path / f"rank{rank}.pt", weights_only=False) for rank in range(2))
+    assert all(torch.equal(r0["weights"][n], r1["weights"][n]) for n in r0["weights"])          # the parameter broadcast
+    assert abs(r0["loss"] - r1["loss"]) > 1e-6                                                   # different scenes per rank
+    assert set(r0["synced"]) == set(r1["synced"]) == set(r0["local"]) and len(r0["synced"]) > 100
+    for n in r0["synced"]:
+        assert torch.equal(r0["synced"][n], r1["synced"][n]), n
+        assert torch.equal(r0["synced"][n], (r0["local"][n] + r1["local"][n]) * 0.5), n
