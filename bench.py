@@ -129,7 +129,9 @@ def launch_ranks(args):
     import socket
     import subprocess
 
-    if torch.cuda.device_count() < args.gpus:   # (device_count does not initialise the GPU on this image)
+    # PDFOPS_BENCH_SHARED_GPU=1 (functional check of the N-rank path on a box with fewer GPUs; tests/test_gpu_model.py): the ranks share
+    # the visible devices round-robin and rendezvous over gloo -- RCCL refuses two ranks on one device.  Never a performance number.
+    if torch.cuda.device_count() < args.gpus and not os.environ.get("PDFOPS_BENCH_SHARED_GPU"):   # (device_count does not initialise the GPU on this image)
         print(f"[bench] --gpus {args.gpus} but only {torch.cuda.device_count()} visible", file=sys.stderr)
         return 2
     argv = [a for a in sys.argv[1:]]
@@ -380,12 +382,17 @@ def main():
     os.dup2(2, 1)
 
     affinity = pin_rank_to_cores(args)
+    shared_gpu = bool(os.environ.get("PDFOPS_BENCH_SHARED_GPU")) and int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if shared_gpu:   # (see launch_ranks: the group exists before engine.init_distributed, which then only reads the environment)
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+        torch.distributed.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
     rank, local_rank, world = engine.init_distributed()
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (the HIP path has no CPU fallback)"
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count() if shared_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     torch.backends.cuda.matmul.allow_tf32 = False
     be = _native.hip_backend()
     be.set_storage(args.storage)
@@ -665,7 +672,9 @@ def main():
                                       "PointTransformer-Seg50 + PointPdf-v1m1 U-decoder, fwd+bwd+SGD, geometry recomputed every step")
                                    + (", PDF pseudo-label pass inside the step" if args.pseudo_label else ""),
                        "scenes_per_gpu": args.scenes, "points_per_scene": args.points, "size_jitter": args.jitter, "parallelism": f"dp{world}",
-                       "gradient_exchange": (args.ddp if use_dp else "none")},
+                       "gradient_exchange": (args.ddp if use_dp else "none"),
+                       **({"shared_gpu": "FUNCTIONAL CHECK ONLY: the ranks share the visible GPU(s) and rendezvous over gloo "
+                                         "(PDFOPS_BENCH_SHARED_GPU=1); not a scaling number"} if shared_gpu else {})},
             "per_gpu_points_per_s": pts_per_step * args.steps / dt / world,
             "rccl_ranks": world if (world > 1 and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl") else 0,
             "rank_ms_per_step": rank_ms,

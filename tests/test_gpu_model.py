@@ -238,6 +238,40 @@ def test_bench_launches_its_own_rccl_ranks():
     assert line["config"]["gradient_exchange"] == "flat" and 0.2 < line["efficiency_vs_n1"] < 1.5
 
 
+@pytest.mark.parametrize("launcher", ["own", "torchrun"])
+def test_bench_two_rank_path_on_a_shared_gpu(launcher):
+    """The N-rank code path of bench.py end to end on a 1-GPU box, started both ways: `python bench.py --gpus 2` (spawns its own ranks) and
+    the driver's `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 ... bench.py --gpus 2`.  With
+    PDFOPS_BENCH_SHARED_GPU=1 the two ranks share cuda:0 and rendezvous over gloo (RCCL refuses two ranks on one device; a functional
+    check, not a number): per-rank scene shards, graph replay + flat gradient exchange, barrier / synchronize fences, MAX over ranks, ONE
+    JSON line from rank 0 with the whole-job aggregate."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "4", "--points", "20000"]
+    if launcher == "own":
+        cmd = [sys.executable] + tail
+    else:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + tail
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, PDFOPS_BENCH_SHARED_GPU="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 4 and len(line["rank_ms_per_step"]) == 2
+    assert line["config"]["parallelism"] == "dp2" and line["config"]["gradient_exchange"] == "flat" and "shared_gpu" in line["config"]
+    assert line["scaling"] == "weak" and line["rccl_ranks"] == 0
+    # whole-job aggregate: both ranks' points over the slowest rank's time
+    assert abs(line["value"] - 2 * 2 * 20000 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+    assert abs(line["ms_per_step"] - max(line["rank_ms_per_step"])) <= 1e-9 and np.isfinite(line["loss"])
+    assert ("efficiency_vs_n1" in line) == (launcher == "own")   # (the one-rank reference run belongs to bench.py's own launcher)
+
+
 def test_captured_step_replays_the_eager_step():
     """engine.CapturedStep: forward + backward captured once into a hipGraph against static batch tensors + a StaticGeometry, replayed on
     OTHER batches of the same scene sizes (tables staged out of a grouped pre-pass's arrays by one copy launch): loss, score and every parameter
