@@ -68,6 +68,8 @@ def test_ddp_rccl_step_matches_plain_step():
     if dist.is_initialized():
         pytest.skip("a process group already exists in this process")
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    keys = ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE", "LOCAL_RANK")
+    saved = {k: os.environ.get(k) for k in keys}
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     dist.init_process_group(backend="nccl", rank=0, world_size=1)
     try:
@@ -95,6 +97,11 @@ def test_ddp_rccl_step_matches_plain_step():
         assert all(np.isfinite(v).all() for v in gb.values())
     finally:
         dist.destroy_process_group()
+        for k, v in saved.items():   # (later tests start launchers from this process's environment)
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 @pytest.mark.gpu
@@ -230,8 +237,9 @@ def test_bench_launches_its_own_rccl_ranks():
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (the round-end scaling run has them; the 1-GPU test box does not)")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "4", "--points", "30000"],
-                       capture_output=True, text=True, timeout=900)
+                       capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and len(line["rank_ms_per_step"]) == 2
@@ -258,7 +266,9 @@ def test_bench_two_rank_path_on_a_shared_gpu(launcher):
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", str(port)] + tail
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, PDFOPS_BENCH_SHARED_GPU="1"))
+    # (an earlier test of this process may have left a torchrun-style environment behind: the launchers must start from a clean one)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(env, PDFOPS_BENCH_SHARED_GPU="1"))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-1000:]
