@@ -258,6 +258,17 @@ int pdf_rowlin_wgrad_multi(long n, int k, int o, int ng, const float *const *g, 
 int pdf_rowlin_wgrad_group(long n, int k, int o, int ng, const float *const *g, long ldg, const float *const *x, long ldx,
                            const float *const *scale, const float *const *shift, const int *relu, float *const *dw,
                            float *const *db, float *ws, void *stream);
+
+/* Rigid KPConv of the StratifiedTransformer stem (stratified_transformer_v1m1_origin.py:582-662 over torch_points3d's KPConvLayer): the
+ * part that is not a matrix product.  weighted[n, k, c] = sum_m max(0, 1 - |support[nb[n, m]] - query[n] - k_points[k]| / extent) *
+ * x[nb[n, m], c] (overwritten; nb = -1: no neighbour); out = weighted (N, KP * C_in) times weight (KP * C_in, C_out) is a pdf_rowlin_forward.
+ * pdf_kpconv_scatter is its adjoint: grad_x[nb[n, m], c] += sum_k w grad_weighted[n, k, c] (grad_x zeroed by the caller; float atomics).
+ * KP <= 16, C_in <= 16 (pdf_kpconv_supported), else PDF_ERR_UNSUPPORTED. */
+int pdf_kpconv_supported(int kp, int cin);
+int pdf_kpconv_gather(int n, int m, int kp, int cin, const float *query, const float *support, const int *neighbors, const float *x,
+                      const float *k_points, float extent, float *weighted, void *stream);
+int pdf_kpconv_scatter(int n, int m, int kp, int cin, const float *query, const float *support, const int *neighbors,
+                       const float *grad_weighted, const float *k_points, float extent, float *grad_x, void *stream);
 /* Input gradient y = sum_i x[i] W[i] (nin <= 3; W (k, o) = the layers' own (out, in) weights) of Linear layers reading a
  * BatchNorm(+ReLU) output bx -> bn -> relu, with that BatchNorm's backward sums as the product's epilogue: partial
  * (pdf_rowlin_partial_floats(n, o)) receives *partial_rows rows of [sum g' | sum g' xhat]; pdf_bn_act_backward_presummed then

@@ -595,6 +595,12 @@ class HipBackend(CBackend):
         lib.pdf_rowlin_multi.restype = c_int
         lib.pdf_rowlin_multi.argtypes = [c_long, c_int, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                          c_int, c_void_p, c_long, c_int, c_void_p]
+        lib.pdf_kpconv_supported.restype = c_int
+        lib.pdf_kpconv_supported.argtypes = [c_int, c_int]
+        for nm in ("pdf_kpconv_gather", "pdf_kpconv_scatter"):
+            f = getattr(lib, nm)
+            f.restype = c_int
+            f.argtypes = [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p, c_void_p]
         lib.pdf_rowlin_wgrad_group.restype = c_int
         lib.pdf_rowlin_wgrad_group.argtypes = [c_long, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_void_p, c_void_p]
@@ -976,6 +982,31 @@ class HipBackend(CBackend):
         if rc != 0:
             raise PdfOpsError(f"pdf_rowlin_wgrad_multi failed with status {rc}")
         return dws, dbs
+
+    # -- rigid KPConv of the StratifiedTransformer stem (csrc/kpconv.hip): gather-accumulate and its adjoint
+    def kpconv_supported(self, kp, cin):
+        return bool(self.lib.pdf_kpconv_supported(int(kp), int(cin)))
+
+    def kpconv_gather(self, query, support, neighbors, x, k_points, extent):
+        """-> weighted (N, KP * C_in): per query and kernel point the influence-weighted sum of its neighbours' feature rows."""
+        n, m = neighbors.shape
+        kp, cin = k_points.shape[0], x.shape[1]
+        out = torch.empty((n, kp * cin), dtype=torch.float32, device=x.device)
+        rc = self.lib.pdf_kpconv_gather(n, m, kp, cin, query.data_ptr(), support.data_ptr(), neighbors.data_ptr(), x.data_ptr(),
+                                        k_points.data_ptr(), ctypes.c_float(extent), out.data_ptr(), self._stream())
+        if rc != 0:
+            raise PdfOpsError(f"pdf_kpconv_gather failed with status {rc}")
+        return out
+
+    def kpconv_scatter(self, query, support, neighbors, grad_weighted, k_points, extent, rows, cin):
+        """-> grad_x (rows, C_in): the adjoint of kpconv_gather."""
+        n, m = neighbors.shape
+        gx = torch.zeros((rows, cin), dtype=torch.float32, device=grad_weighted.device)
+        rc = self.lib.pdf_kpconv_scatter(n, m, k_points.shape[0], cin, query.data_ptr(), support.data_ptr(), neighbors.data_ptr(),
+                                         grad_weighted.data_ptr(), k_points.data_ptr(), ctypes.c_float(extent), gx.data_ptr(), self._stream())
+        if rc != 0:
+            raise PdfOpsError(f"pdf_kpconv_scatter failed with status {rc}")
+        return gx
 
     def rowlin_wgrad_group(self, gs, xs, coefs, relus, need_bias):
         """Up to five weight gradients of one shape with their own inputs in one launch + one reduction (include/pdfops.h:

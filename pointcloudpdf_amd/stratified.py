@@ -21,6 +21,8 @@ disposition of torch_points3d is the result of an offline optimisation shipped a
 Fibonacci sphere -- stands in).  The reference's OWN code around them is pinned by tests/golden/model_stratified_*.npz (the
 reference classes imported and run with these same stand-ins injected).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -198,10 +200,15 @@ class KPConvLayer(nn.Module):
         nn.init.xavier_normal_(weight)
         self.weight = nn.Parameter(weight)
 
+    FUSED = os.environ.get("PDFOPS_KPCONV", "hip") != "torch"   # torch: the composed form below on the device as well (A/B runs)
+
     def forward(self, query_points, support_points, neighbors, x):
         """neighbors (N, M) indices into support_points, -1 = no neighbour (a far "shadow" point with zero features)."""
         if self.add_one:
             x = torch.cat([x, x.new_ones(x.shape[0], 1)], 1)
+        if (self.FUSED and x.is_cuda and x.dtype == torch.float32 and _native.hip_backend().kpconv_supported(self.K_points.shape[0], x.shape[1])):
+            return _KPConvFn.apply(query_points.contiguous(), support_points.contiguous(), neighbors.to(torch.int32).contiguous(),
+                                   x.contiguous(), self.K_points, self.weight, float(self.KP_extent))
         n_s = support_points.shape[0]
         nb = torch.where(neighbors < 0, torch.full_like(neighbors, n_s), neighbors).long()
         sp = torch.cat([support_points, support_points.new_full((1, 3), 1e6)], 0)
@@ -211,6 +218,39 @@ class KPConvLayer(nn.Module):
         w = torch.clamp(1.0 - torch.sqrt(d2) / self.KP_extent, min=0.0).transpose(1, 2)   # (N, K, M)
         weighted = torch.matmul(w, xs[nb])                                                # (N, K, C_in)
         return torch.einsum("nkc,kco->no", weighted, self.weight)
+
+
+class _KPConvFn(torch.autograd.Function):
+    """KPConvLayer.forward on the device without the (N, M, K) intermediates: influence-weighted gather per (query, kernel point)
+    (csrc/kpconv.hip) + one plain product with the (K * C_in, C_out) weight; the backward is the two adjoint products + the scatter."""
+
+    @staticmethod
+    @dense._amp_fwd
+    def forward(ctx, query, support, neighbors, x, k_points, weight, extent):
+        be = _native.hip_backend()
+        kc, o = weight.shape[0] * weight.shape[1], weight.shape[2]
+        weighted = be.kpconv_gather(query, support, neighbors, x, k_points, extent)                 # (N, K * C_in)
+        out = be.rowlin(weighted, weight.detach().reshape(kc, o), transpose_w=True)[0]              # weighted @ W
+        ctx.save_for_backward(query, support, neighbors, k_points, weight, weighted)
+        ctx.cfg = (extent, x.shape[0], x.shape[1])
+        return out
+
+    @staticmethod
+    @dense._amp_bwd
+    def backward(ctx, g):
+        query, support, neighbors, k_points, weight, weighted = ctx.saved_tensors
+        extent, rows, cin = ctx.cfg
+        be = _native.hip_backend()
+        kc, o = weight.shape[0] * weight.shape[1], weight.shape[2]
+        g = g.contiguous()
+        wm = weight.detach().reshape(kc, o)
+        gx = gw = None
+        if ctx.needs_input_grad[3]:
+            g_weighted = be.rowlin(g, wm)[0]                                                         # g @ W^T  (N, K * C_in)
+            gx = be.kpconv_scatter(query, support, neighbors, g_weighted, k_points, extent, rows, cin)
+        if ctx.needs_input_grad[5]:
+            gw = be.rowlin_wgrad(weighted, g, None, False, False)[0].view_as(weight)                 # weighted^T @ g  (K * C_in, C_out)
+        return None, None, None, gx, None, gw, None
 
 
 def offset2batch(offset):

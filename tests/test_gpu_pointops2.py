@@ -182,3 +182,32 @@ def test_stratified_geometry_shares_one_fps_run_per_level():
                 assert torch.equal(d_off, want_off)
                 assert torch.equal(d_idx, pointops.furthestsampling(xyz, off, want_off)), ("down", level, sizes)
                 xyz, off = xyz[d_idx.long(), :].contiguous(), d_off
+
+
+@pytest.mark.parametrize("n,m,cin,cout", [(5000, 34, 6, 48), (3001, 34, 12, 12), (700, 20, 3, 16), (257, 7, 16, 32)])
+def test_kpconv_fused_matches_the_composed_form(n, m, cin, cout, monkeypatch):
+    """KPConvLayer on the device: the influence-weighted gather (csrc/kpconv.hip) + one product with the (K * C_in, C_out) weight against
+    the composed torch form (the (N, M, K) influence tensor and a batched product; stratified.KPConvLayer.forward) on the same neighbour
+    table with missing neighbours (-1): output, feature gradient (float atomics: 1e-5), weight gradient."""
+    from pointcloudpdf_amd import stratified
+
+    g = torch.Generator(device="cuda").manual_seed(n + m + cin)
+    pts = torch.rand(n, 3, device="cuda", generator=g)
+    nb = torch.randint(0, n, (n, m), device="cuda", generator=g)
+    nb[torch.rand(n, m, device="cuda", generator=g) < 0.2] = -1
+    x0 = torch.randn(n, cin, device="cuda", generator=g)
+    go = torch.randn(n, cout, device="cuda", generator=g)
+    layer = stratified.KPConvLayer(cin, cout, point_influence=0.08).cuda()
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(stratified.KPConvLayer, "FUSED", fused)
+        x = x0.clone().requires_grad_(True)
+        layer.weight.grad = None
+        y = layer(pts, pts, nb, x)
+        y.backward(go)
+        res.append((y.detach(), x.grad.clone(), layer.weight.grad.clone()))
+    (ya, gxa, gwa), (yb, gxb, gwb) = res
+    assert float(yb.abs().max()) > 0
+    assert_close(ya, yb, 2e-5, "kpconv out")
+    assert_close(gxa, gxb, 2e-5, "kpconv grad x")
+    assert_close(gwa, gwb, 2e-5, "kpconv grad weight")
