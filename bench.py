@@ -94,6 +94,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ops-roofline", action="store_true", help="skip the per-op HBM roofline micro-benchmark (rank 0, N = 1)")
     ap.add_argument("--cpu-points", type=int, default=100000, help="scene size of the bounded CPU-baseline sample")
+    ap.add_argument("--st-group", type=int, default=3, help="--workload stratified: batches per grouped coordinate pre-pass (1 = one batch ahead)")
     ap.add_argument("--amp", nargs="?", const="f16", default=None, choices=["bf16", "f16"],
                     help="torch.autocast around the step (reference: enable_amp = True, engines/train.py:340-363): the streaming Linear products "
                          "run with fp16 (default, as the reference's autocast) / bfloat16 operands on the 16x16x16 matrix-core instructions, fp32 storage and accumulation "
@@ -405,7 +406,9 @@ def main():
     if strat:
         # ST's coordinate-only work (FPS chain + window edge tables) runs one batch ahead on a worker thread + side stream
         # (stratified.StratifiedPrefetcher); --prefetch 0 keeps it inside the forward.  PointTransformer-V1's pre-pass does not apply.
-        st_ahead, args.prefetch = (1 if args.prefetch > 0 else 0), 0
+        # With a group of G > 1 batches (--st-group, default 3) the farthest-point chain of the G batches runs as ONE launch sequence
+        # (one workgroup per scene: G batches cost the latency of one), as PointTransformer-V1's grouped pre-pass does.
+        st_ahead, args.prefetch = (max(1, args.st_group) if args.prefetch > 0 else 0), 0
     if args.pseudo_label:
         from pointcloudpdf_amd import pseudo_label
         step_kw["pseudo_mask_fn"] = pseudo_label.make_pseudo_mask_fn(radius=0.02 * 5, max_neighbor=64, condition_from="msp", beta=1.5,
@@ -532,7 +535,7 @@ def main():
                 prefetcher.get(t)
             self.tickets.clear()
 
-    st_prefetcher, st_tickets = None, {}
+    st_prefetcher, st_tickets, st_state = None, {}, {"next": 0}
     if st_ahead:
         from pointcloudpdf_amd.stratified import StratifiedPrefetcher
         st_prefetcher = StratifiedPrefetcher(step.model.backbone, windows=not os.environ.get("PDFOPS_ST_FPS_ONLY"))
@@ -545,9 +548,17 @@ def main():
         if geom is not None:
             data["pdf_geometry"] = geom
         if st_prefetcher is not None:
-            if i not in st_tickets:
-                st_tickets[i] = st_prefetcher.submit(batch)
-            st_tickets[i + 1] = st_prefetcher.submit(pool[(i + 1) % len(pool)])   # next batch's tables: during this step
+            G = st_ahead
+
+            def st_submit(lo, hi):   # one group: batches lo .. hi - 1
+                for j, t in enumerate(st_prefetcher.submit_group([pool[x % len(pool)] for x in range(lo, hi)])):
+                    st_tickets[lo + j] = t
+            if i not in st_tickets:                      # the first step of a run
+                st_submit(i, i + G)
+                st_state["next"] = i + G
+            if i + G >= st_state["next"]:                # the group after the one in use: built while this one trains
+                st_submit(st_state["next"], st_state["next"] + G)
+                st_state["next"] += G
             data["st_geometry"] = st_prefetcher.get(st_tickets.pop(i))
         replay = captured is not None and not (timer.enabled and timer.sample) and captured.matches(batch)
         if replay:   # forward + backward as one hipGraph launch; steps that carry the per-kernel HIP events run eagerly

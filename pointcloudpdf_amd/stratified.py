@@ -282,7 +282,11 @@ def get_indice_pairs(p2v_map, counts, new_p2v_map, new_counts, downsample_idx, b
     xyz_min = _colminmax(xyz)[0]
     shift = 0.0 if i % 2 == 0 else 1 / 2 * window_size
     window_coord = torch.div(xyz[new_p2v_map] - xyz_min + shift, window_size, rounding_mode="trunc")
-    mask_mat_prev = (window_coord.unsqueeze(2) != window_coord.unsqueeze(1)).any(-1)
+    # (window_coord.unsqueeze(2) != window_coord.unsqueeze(1)).any(-1) upstream (:93-94): the window cells are small non-negative integers,
+    # so one packed key per point gives the same boolean with one comparison -- torch's reduction over a dim of 3 was 8 ms of the step
+    wc = window_coord.long()
+    key = (wc[..., 0] << 42) | (wc[..., 1] << 21) | wc[..., 2]
+    mask_mat_prev = key.unsqueeze(2) != key.unsqueeze(1)
     mask_mat = mask_mat & mask_mat_prev
     new_index_0 = new_p2v_map.unsqueeze(-1).expand(-1, -1, k)[mask_mat]
     new_index_1 = new_p2v_map.unsqueeze(1).expand(-1, k, -1)[mask_mat]
@@ -331,6 +335,28 @@ def _strided_offsets(offset, fn):
     return torch.tensor(_strided_counts([int(v) for v in offset.detach().cpu().tolist()], fn), dtype=torch.int32, device=offset.device)
 
 
+def _fps_pair(xyz, off, ends, fn_keys, fn_down):
+    """(key indices, their scene ends, down-sample indices, their scene ends) of one level from ONE farthest-point run.  Sample j of the
+    reference's kernel is the arg-max after j - 1 insertions whatever the requested count (sampling_cuda_kernel.cu:42-127: the loop bound
+    is the only use of m; the block size / tie rule depends on n alone), so the shorter subset is the per-scene PREFIX of the longer one:
+    one chain of max(keys, down) dependent steps per scene instead of two (bit-identical indices, tests/test_gpu_pointops2.py)."""
+    k_ends, d_ends = _strided_counts(ends, fn_keys), _strided_counts(ends, fn_down)
+    k_cnt = [e - (k_ends[i - 1] if i else 0) for i, e in enumerate(k_ends)]
+    d_cnt = [e - (d_ends[i - 1] if i else 0) for i, e in enumerate(d_ends)]
+    l_cnt = [max(a, b) for a, b in zip(k_cnt, d_cnt)]
+    l_ends = [sum(l_cnt[:i + 1]) for i in range(len(l_cnt))]
+    l_off = torch.tensor(l_ends, dtype=torch.int32).to(xyz.device, non_blocking=True)
+    long_idx = pointops.furthestsampling(xyz, off, l_off)
+
+    def prefix(cnt):
+        if cnt == l_cnt:
+            return long_idx
+        parts = [long_idx[(l_ends[i] - l_cnt[i]):(l_ends[i] - l_cnt[i]) + c] for i, c in enumerate(cnt)]
+        return (parts[0] if len(parts) == 1 else torch.cat(parts)).contiguous()
+
+    return prefix(k_cnt), k_ends, prefix(d_cnt), d_ends
+
+
 class StratifiedGeometry:
     """The coordinate-only chain of one StratifiedTransformer forward: per level the FPS subset that supplies the window keys
     (n // downsample_scale + 1 points per scene, BasicLayer :479-489) and the TransitionDown sample (int(n * ratio) + 1 points, :165-174),
@@ -353,28 +379,12 @@ class StratifiedGeometry:
         return self.samples[key] + (n_ends,)
 
     def _sample_pair(self, level, xyz, off, ends, fn_keys, fn_down):
-        """The window-key subset and the TransitionDown sample of one level from ONE farthest-point run.  Sample j of the reference's
-        kernel is the arg-max after j - 1 insertions whatever the requested count (sampling_cuda_kernel.cu:42-127: the loop bound is the
-        only use of m; the block size / tie rule depends on n alone), so the shorter subset is the per-scene PREFIX of the longer one:
-        one chain of max(keys, down) dependent steps per scene instead of two (bit-identical indices, tests/test_gpu_pointops2.py)."""
-        k_ends, d_ends = _strided_counts(ends, fn_keys), _strided_counts(ends, fn_down)
-        k_cnt = [e - (k_ends[i - 1] if i else 0) for i, e in enumerate(k_ends)]
-        d_cnt = [e - (d_ends[i - 1] if i else 0) for i, e in enumerate(d_ends)]
-        l_cnt = [max(a, b) for a, b in zip(k_cnt, d_cnt)]
-        l_ends = [sum(l_cnt[:i + 1]) for i in range(len(l_cnt))]
+        """The window-key subset and the TransitionDown sample of one level from ONE farthest-point run (``_fps_pair``)."""
+        keys, k_ends, down, d_ends = _fps_pair(xyz, off, ends, fn_keys, fn_down)
         to_dev = lambda v: torch.tensor(v, dtype=torch.int32).to(xyz.device, non_blocking=True)
-        l_off = to_dev(l_ends)
-        long_idx = pointops.furthestsampling(xyz, off, l_off)
-
-        def prefix(cnt, c_ends):
-            if cnt == l_cnt:
-                return long_idx, l_off
-            parts = [long_idx[(l_ends[i] - l_cnt[i]):(l_ends[i] - l_cnt[i]) + c] for i, c in enumerate(cnt)]
-            return (parts[0] if len(parts) == 1 else torch.cat(parts)).contiguous(), to_dev(c_ends)
-
-        self.samples[("keys", level)] = prefix(k_cnt, k_ends)
-        self.samples[("down", level)] = prefix(d_cnt, d_ends)
-        return self.samples[("keys", level)][0], self.samples[("down", level)] + (d_ends,)
+        self.samples[("keys", level)] = (keys, to_dev(k_ends))
+        self.samples[("down", level)] = (down, to_dev(d_ends))
+        return keys, self.samples[("down", level)] + (d_ends,)
 
     def precompute(self, layers=None):
         """``layers``: the model's BasicLayers by level (``StratifiedTransformer.layers_by_level()``) -> also their window edge tables.
@@ -396,6 +406,48 @@ class StratifiedGeometry:
                 if l < num_layers - 1:
                     xyz, off, ends = xyz[idx.long(), :].contiguous(), n_off, n_ends
         return self
+
+    @staticmethod
+    def precompute_group(geoms, layers=None):
+        """``precompute`` for several batches with ONE farthest-point chain: the scenes of all batches go through each level's sampling
+        launch together (one workgroup per scene: D batches cost the latency of one), every batch then gets its own row / index slices
+        (indices rebased to the batch's level arrays) and its own window tables.  Bit-identical to ``precompute`` per batch
+        (tests/test_gpu_pointops2.py::test_stratified_group_prepass_is_the_per_batch_prepass)."""
+        scale, ratio, num_layers, stem_transformer = geoms[0].cfg
+        assert stem_transformer and all(g.cfg == geoms[0].cfg for g in geoms)
+        dev = geoms[0].coord.device
+        to_dev = lambda v: torch.tensor(v, dtype=torch.int32).to(dev, non_blocking=True)
+        nsc = [len(g.offset_host) for g in geoms]                       # scenes per batch
+        s0 = [sum(nsc[:b]) for b in range(len(geoms))]
+        with torch.no_grad():
+            xyz = torch.cat([g.coord for g in geoms]) if len(geoms) > 1 else geoms[0].coord
+            ends, base = [], 0
+            for g in geoms:
+                ends += [base + e for e in g.offset_host]
+                base = ends[-1]
+            off = to_dev(ends)
+            for l in range(num_layers):
+                last = l == num_layers - 1
+                if not last:
+                    keys, k_ends, down, d_ends = _fps_pair(xyz, off, ends, lambda n: n // scale + 1, lambda n: int(n * ratio) + 1)
+                else:
+                    k_ends = _strided_counts(ends, lambda n: n // scale + 1)
+                    keys = pointops.furthestsampling(xyz, off, to_dev(k_ends))
+                for b, g in enumerate(geoms):
+                    a, z = s0[b], s0[b] + nsc[b]                         # the batch's scenes in the group
+                    p0 = ends[a - 1] if a else 0                          # first row of the batch in this level's arrays
+                    local_ends = [e - p0 for e in ends[a:z]]
+                    kb = k_ends[a - 1] if a else 0
+                    g.samples[("keys", l)] = ((keys[kb:k_ends[z - 1]] - p0).contiguous(), to_dev([e - kb for e in k_ends[a:z]]))
+                    if not last:
+                        db = d_ends[a - 1] if a else 0
+                        g.samples[("down", l)] = ((down[db:d_ends[z - 1]] - p0).contiguous(), to_dev([e - db for e in d_ends[a:z]]))
+                    if layers is not None:
+                        g.windows[l] = layers[l].window_tables(xyz[p0:ends[z - 1]], to_dev(local_ends), g.samples[("keys", l)][0])
+                if not last:
+                    xyz, ends = xyz[down.long(), :].contiguous(), d_ends
+                    off = to_dev(ends)
+        return geoms
 
     def tensors(self):
         out = [self.coord, self.offset] + [t for pair in self.samples.values() for t in pair]
@@ -435,6 +487,24 @@ class StratifiedPrefetcher:
             return done
 
         return geom, self.pool.submit(work)
+
+    def submit_group(self, batches):
+        """One ticket per batch; the farthest-point chain of all of them runs as one launch sequence (StratifiedGeometry.precompute_group)."""
+        geoms = [self.model.make_geometry(b["coord"], b["offset"], b.get("offset_host")) for b in batches]
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())
+
+        def work():
+            torch.cuda.set_device(self.device)
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ready)
+                StratifiedGeometry.precompute_group(geoms, self.model.layers_by_level() if self.windows else None)
+                done = torch.cuda.Event()
+                done.record(self.stream)
+            return done
+
+        future = self.pool.submit(work)
+        return [(g, future) for g in geoms]
 
     @staticmethod
     def get(ticket):

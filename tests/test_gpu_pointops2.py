@@ -211,3 +211,30 @@ def test_kpconv_fused_matches_the_composed_form(n, m, cin, cout, monkeypatch):
     assert_close(ya, yb, 2e-5, "kpconv out")
     assert_close(gxa, gxb, 2e-5, "kpconv grad x")
     assert_close(gwa, gwb, 2e-5, "kpconv grad weight")
+
+
+def test_stratified_group_prepass_is_the_per_batch_prepass():
+    """StratifiedGeometry.precompute_group: the farthest-point chain of three batches as ONE launch sequence per level, sliced and rebased
+    per batch, equals every batch's own precompute -- subsets, their scene ends and every window table bit-identical."""
+    from pointcloudpdf_amd import engine, stratified, synthetic
+
+    step = engine.OpenSegStep(backbone="ST-v1m1", loss_weight=0.008).cuda()
+    bb = step.model.backbone
+    batches = [synthetic.make_batch(sz, first_scene_id=80 + 7 * i, device="cuda") for i, sz in enumerate([[9000, 7000], [12000], [3000, 4100, 2500]])]
+    geoms = [bb.make_geometry(b["coord"], b["offset"], b["offset_host"]) for b in batches]
+    stratified.StratifiedGeometry.precompute_group(geoms, bb.layers_by_level())
+    pf = stratified.StratifiedPrefetcher(bb)
+    tickets = pf.submit_group(batches)
+    for b, g, t in zip(batches, geoms, tickets):
+        alone = bb.make_geometry(b["coord"], b["offset"], b["offset_host"]).precompute(bb.layers_by_level())
+        threaded = pf.get(t)
+        torch.cuda.synchronize()
+        for got in (g, threaded):
+            assert set(got.samples) == set(alone.samples) and set(got.windows) == set(alone.windows) == {0, 1, 2, 3}
+            for k in alone.samples:
+                assert torch.equal(got.samples[k][0], alone.samples[k][0]) and torch.equal(got.samples[k][1], alone.samples[k][1]), k
+            for lv in alone.windows:
+                for parity, tab in alone.windows[lv].items():
+                    for x, y in zip(tab, got.windows[lv][parity]):
+                        assert torch.equal(x, y) if torch.is_tensor(x) else x == y, (lv, parity)
+    pf.close()
