@@ -53,21 +53,42 @@ __global__ __launch_bounds__(WB) void k_step1_fwd(int h, int d, const float *__r
 
 // attention_cuda_kernel_v2.cu:50-93.  grad_q[q,:] = sum_m go[m,h] k[index1[m],:] (written, not accumulated);
 // grad_k[index1[m],:] += go[m,h] q[q,:] (pre-zeroed scatter target).
+// grad_q: S = WB / C edge slots walk the query's edges side by side (slot s takes edges start + s, start + s + S, ...: S dependent gather
+// chains in flight instead of one with C <= 128 of the 256 lanes idle -- the one-lane-per-channel walk took 466 us per launch of the ST-v1m1
+// step), the slots' partial rows are added in slot order by the first C lanes: a fixed order.  C > WB: channel chunks, one slot.
 __global__ __launch_bounds__(WB) void k_step1_bwd(int h, int d, const float *__restrict__ go, const int *__restrict__ offsets,
                                                   const int *__restrict__ index1, const float *__restrict__ q,
                                                   const float *__restrict__ k, float *__restrict__ grad_q,
                                                   float *__restrict__ grad_k) {
-    extern __shared__ float qv[];
+    extern __shared__ float qv[];          // [C] q row | [S * C] partial rows of grad_q
     const int qi = blockIdx.x, C = h * d;
     const int start = offsets[qi], end = offsets[qi + 1];
-    for (int c = threadIdx.x; c < C; c += WB) {
-        qv[c] = q[(size_t)qi * C + c];
-        const int hh = c / d;
-        float acc = 0.f;
-        for (int m = start; m < end; ++m) acc += go[(size_t)m * h + hh] * k[(size_t)index1[m] * C + c];
-        grad_q[(size_t)qi * C + c] = acc;
+    float *part = qv + C;
+    const int S = C <= WB ? WB / C : 1;
+    for (int c = threadIdx.x; c < C; c += WB) qv[c] = q[(size_t)qi * C + c];
+    if (C <= WB) {
+        const int s = threadIdx.x / C, c = threadIdx.x - s * C;
+        if (s < S) {
+            const int hh = c / d;
+            float acc = 0.f;
+            for (int m = start + s; m < end; m += S) acc += go[(size_t)m * h + hh] * k[(size_t)index1[m] * C + c];
+            part[s * C + c] = acc;
+        }
+        __syncthreads();
+        if (threadIdx.x < C) {
+            float acc = part[threadIdx.x];
+            for (int t = 1; t < S; ++t) acc += part[t * C + threadIdx.x];
+            grad_q[(size_t)qi * C + threadIdx.x] = acc;
+        }
+    } else {
+        for (int c = threadIdx.x; c < C; c += WB) {
+            const int hh = c / d;
+            float acc = 0.f;
+            for (int m = start; m < end; ++m) acc += go[(size_t)m * h + hh] * k[(size_t)index1[m] * C + c];
+            grad_q[(size_t)qi * C + c] = acc;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const long total = (long)(end - start) * C;
     for (long e = threadIdx.x; e < total; e += WB) {
         const int m = start + (int)(e / C), c = (int)(e % C);
@@ -632,7 +653,8 @@ extern "C" int pdf_attention_step1_backward_v2(int N, int M, int h, int C, unsig
     (void)n_max;
     if (bad_shape(N, M, h, C) || !grad_out || !q || !k || !index0_offsets || !index1 || !grad_q || !grad_k) return PDF_ERR_BAD_ARG;
     if (N == 0) return PDF_OK;
-    k_step1_bwd<<<N, WB, sizeof(float) * C, static_cast<hipStream_t>(stream)>>>(h, C / h, grad_out, index0_offsets, index1, q, k, grad_q, grad_k);
+    const size_t lds_b = sizeof(float) * ((size_t)C + (C <= WB ? (size_t)(WB / C) * C : 0));
+    k_step1_bwd<<<N, WB, lds_b, static_cast<hipStream_t>(stream)>>>(h, C / h, grad_out, index0_offsets, index1, q, k, grad_q, grad_k);
     return pdf_launch_status();
 }
 
