@@ -19,6 +19,7 @@
 // d is any positive size (the reference throws unless d is 16 or 32); n_max is accepted for signature parity and unused.
 // All kernels: HBM / atomic-rate bound; algorithmic bytes are listed at the entry points.
 #include "pdfops_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -589,6 +590,195 @@ __global__ __launch_bounds__(WB) void k_step2rv_bwd_m16(int N, int h, int L, con
 }
 
 
+// ---------------------------------------------------------------- table gradients factored by query (d = 16, L <= 64)
+// Wherever the value that multiplies the one-hot row selector is constant over the edges of a query -- q[query(m)] for table_q of
+// dot_prod_with_idx_v3, grad_out[query(m)] for the table of attention_step2_with_rel_pos_value_v2 -- the table gradient factors:
+//     G[r, :, a] = sum_m [rel[m, a] = r] s_m x[query(m), :]  =  sum_q x[q, :] (x) S_q[a, r],      S_q[a, r] = sum_{m in q, rel[m, a] = r} s_m
+// i.e. a per-query HISTOGRAM of the edge scalars (three LDS adds per edge and head) followed by one small dense product per workgroup
+// (3 L x QF queries x 16 channels) instead of 3 ceil(L / 16) one-hot matrix-core products per FOUR edges (15/16 of whose rows multiply
+// zeros).  The same histogram gives the query-indexed result: grad_q[q, :] = sum_{a, r} S_q[a, r] table_q[r, :, a]; and for the value
+// table the per-edge term <grad_out[q, :], T(m, :)> becomes three lookups in the projection P_q[a, r] = <table[r, :, a], grad_out[q, :]>.
+// Only table_k of dot_prod_with_idx_v3 (value = the gathered key row, different per edge) keeps the one-hot products (k_dot3_bwd_k).
+constexpr int QF = 32;   // queries per workgroup of the factored kernels (histogram: QF x 3 L floats of LDS)
+
+// dot_prod_with_idx_v3 backward, query side: grad_q (written) and grad_table_q.  lane = edge for the histogram.
+__global__ __launch_bounds__(WB) void k_dot3_bwd_fq(int N, int h, int L, const float *__restrict__ go, const float *__restrict__ q,
+                                                    const int *__restrict__ offsets, const float *__restrict__ table_q,
+                                                    const int *__restrict__ rel_idx, float *__restrict__ grad_q, float *__restrict__ grad_table_q) {
+    constexpr int d = 16;
+    extern __shared__ float sm[];
+    const int T = slab_floats(L, d), W = 3 * L;
+    float *tq = sm, *qr = tq + T, *S = qr + QF * d;
+    int *offs = reinterpret_cast<int *>(S + QF * W);
+    const int hh = blockIdx.y, C = h * d;
+    const int q0 = blockIdx.x * QF, nq = min(QF, N - q0);
+    for (int j = threadIdx.x; j <= nq; j += WB) offs[j] = offsets[q0 + j];
+    stage_table(tq, table_q, L, C, d, hh);
+    for (int e = threadIdx.x; e < QF * d; e += WB) qr[e] = e < nq * d ? q[(size_t)(q0 + e / d) * C + hh * d + e % d] : 0.f;
+    for (int e = threadIdx.x; e < QF * W; e += WB) S[e] = 0.f;
+    __syncthreads();
+    const int e0 = offs[0], e1 = offs[nq];
+    for (int m = e0 + threadIdx.x; m < e1; m += WB) {
+        const int ql = find_query(offs, nq, m);
+        const float g = go[(size_t)m * h + hh];
+        const int r1 = rel_idx[(size_t)m * 3], r2 = rel_idx[(size_t)m * 3 + 1], r3 = rel_idx[(size_t)m * 3 + 2];
+        atomicAdd(&S[ql * W + r1], g);
+        atomicAdd(&S[ql * W + L + r2], g);
+        atomicAdd(&S[ql * W + 2 * L + r3], g);
+    }
+    __syncthreads();
+    const int st = slab_stride(d);
+    for (int e = threadIdx.x; e < nq * d; e += WB) {          // grad_q[q, i] = sum_{a, r} S_q[a, r] table_q[r, i, a]
+        const int ql = e / d, i = e % d;
+        const float *Sq = S + ql * W;
+        float acc = 0.f;
+        for (int r = 0; r < L; ++r)
+            acc += Sq[r] * tq[r * st + 3 * i] + Sq[L + r] * tq[r * st + 3 * i + 1] + Sq[2 * L + r] * tq[r * st + 3 * i + 2];
+        grad_q[(size_t)(q0 + ql) * C + hh * d + i] = acc;
+    }
+    for (int e = threadIdx.x; e < W * d; e += WB) {            // grad_table_q[r, i, a] += sum_q S_q[a, r] q[q, i]
+        const int x = e / d, i = e % d, a = x / L, r = x - a * L;
+        float acc = 0.f;
+        for (int ql = 0; ql < nq; ++ql) acc += S[ql * W + x] * qr[ql * d + i];
+        if (acc != 0.f) pdf_atomic_add(grad_table_q + ((size_t)r * C + (size_t)hh * d + i) * 3 + a, acc);
+    }
+}
+
+// dot_prod_with_idx_v3 backward, key side: grad_k (scatter) and grad_table_k -- the value row differs per edge, so the table gradient
+// stays a one-hot matrix-core product (see k_dot3_bwd_m16); one table per workgroup: 12 RB accumulator registers, one LDS slab that is
+// the table while the edges stream and the gradient slab afterwards.
+template <int RB>
+__global__ __launch_bounds__(WB) void k_dot3_bwd_k(int N, int h, int L, const float *__restrict__ go, const int *__restrict__ offsets,
+                                                   const float *__restrict__ k, const int *__restrict__ index_k,
+                                                   const float *__restrict__ table_k, const int *__restrict__ rel_idx,
+                                                   float *__restrict__ grad_k, float *__restrict__ grad_table_k) {
+    constexpr int d = 16;
+    extern __shared__ float sm[];
+    const int T = slab_floats(L, d);
+    float *tb = sm;
+    const int hh = blockIdx.y, C = h * d;
+    const int q0 = blockIdx.x * QCH, nq = min(QCH, N - q0);
+    stage_table(tb, table_k, L, C, d, hh);
+    __syncthreads();
+    const int e0 = offsets[q0], e1 = offsets[q0 + nq];
+    const long total = (long)(e1 - e0) * d;
+    const long padded = (total + 63) & ~63L;
+    const int lane = threadIdx.x & 63, i = lane & 15;
+    f32x4 acc[3][RB];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[a][rb] = (f32x4)(0.f);
+    const int m_last = e1 > e0 ? e1 - 1 : e0;
+    for (long e = threadIdx.x; e < padded; e += UE * WB) {
+        bool live[UE]; int m[UE], r[UE][3], ik[UE]; float g[UE], x[UE];
+#pragma unroll
+        for (int u = 0; u < UE; ++u) {
+            const long eu = e + u * WB;
+            live[u] = eu < total;
+            m[u] = min(e0 + (int)(eu >> 4), m_last);
+        }
+#pragma unroll
+        for (int u = 0; u < UE; ++u) {
+            r[u][0] = rel_idx[(size_t)m[u] * 3]; r[u][1] = rel_idx[(size_t)m[u] * 3 + 1]; r[u][2] = rel_idx[(size_t)m[u] * 3 + 2];
+            g[u] = go[(size_t)m[u] * h + hh];
+            ik[u] = index_k[m[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < UE; ++u) x[u] = k[(size_t)ik[u] * C + hh * d + i];
+#pragma unroll
+        for (int u = 0; u < UE; ++u) {
+            const float gm = live[u] ? g[u] : 0.f;
+            if (live[u]) pdf_atomic_add(grad_k + (size_t)ik[u] * C + hh * d + i, lds_table_sum(tb, r[u][0], r[u][1], r[u][2], d, i) * gm);
+            const float v = x[u] * gm;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+                    acc[a][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32((live[u] && r[u][a] == 16 * rb + i) ? 1.f : 0.f, v, acc[a][rb], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                    // every wave is done reading the table: the slab becomes the gradient slab
+    for (int e = threadIdx.x; e < T; e += WB) tb[e] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = 16 * rb + 4 * (lane >> 4) + j;
+                if (row < L) atomicAdd(&tb[row * slab_stride(d) + 3 * i + a], acc[a][rb][j]);
+            }
+    __syncthreads();
+    const int per = d * 3;
+    for (int e = threadIdx.x; e < L * per; e += WB) {
+        const int rr = e / per, xx = e - rr * per;
+        const float a = tb[rr * (per + 1) + xx];
+        if (a != 0.f) pdf_atomic_add(grad_table_k + ((size_t)rr * C + (size_t)hh * d) * 3 + xx, a);
+    }
+}
+
+// attention_step2_with_rel_pos_value_v2 backward, factored: grad_attn (written), grad_v (scatter), grad_table.
+__global__ __launch_bounds__(WB) void k_step2rv_bwd_f(int N, int h, int L, const float *__restrict__ go, const int *__restrict__ offsets,
+                                                      const int *__restrict__ index1, const float *__restrict__ attn,
+                                                      const float *__restrict__ v, const float *__restrict__ table,
+                                                      const int *__restrict__ rel_idx, float *__restrict__ grad_attn,
+                                                      float *__restrict__ grad_v, float *__restrict__ grad_table) {
+    constexpr int d = 16;
+    extern __shared__ float sm[];
+    const int T = slab_floats(L, d), W = 3 * L;
+    float *tb = sm, *gr = tb + T, *P = gr + QF * d, *S = P + QF * W;
+    int *offs = reinterpret_cast<int *>(S + QF * W);
+    const int hh = blockIdx.y, C = h * d;
+    const int q0 = blockIdx.x * QF, nq = min(QF, N - q0);
+    for (int j = threadIdx.x; j <= nq; j += WB) offs[j] = offsets[q0 + j];
+    stage_table(tb, table, L, C, d, hh);
+    for (int e = threadIdx.x; e < QF * d; e += WB) gr[e] = e < nq * d ? go[(size_t)(q0 + e / d) * C + hh * d + e % d] : 0.f;
+    for (int e = threadIdx.x; e < QF * W; e += WB) S[e] = 0.f;
+    __syncthreads();
+    const int st = slab_stride(d);
+    for (int e = threadIdx.x; e < nq * W; e += WB) {           // P_q[a, r] = <table[r, :, a], grad_out[q, :]>
+        const int ql = e / W, x = e - ql * W, a = x / L, r = x - a * L;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < d; ++i) acc += tb[r * st + 3 * i + a] * gr[ql * d + i];
+        P[e] = acc;
+    }
+    __syncthreads();
+    const int e0 = offs[0], e1 = offs[nq];
+    for (int m = e0 + threadIdx.x; m < e1; m += WB) {          // lane = edge: grad_attn and the histogram of attn
+        const int ql = find_query(offs, nq, m);
+        const int r1 = rel_idx[(size_t)m * 3], r2 = rel_idx[(size_t)m * 3 + 1], r3 = rel_idx[(size_t)m * 3 + 2];
+        const float at = attn[(size_t)m * h + hh];
+        const float4 *vr = reinterpret_cast<const float4 *>(v + (size_t)index1[m] * C + hh * d);
+        const float *g = gr + ql * d;
+        float dot = 0.f;
+#pragma unroll
+        for (int c4 = 0; c4 < d / 4; ++c4) {
+            const float4 x = vr[c4];
+            dot += x.x * g[4 * c4] + x.y * g[4 * c4 + 1] + x.z * g[4 * c4 + 2] + x.w * g[4 * c4 + 3];
+        }
+        grad_attn[(size_t)m * h + hh] = dot + ((P[ql * W + r1] + P[ql * W + L + r2]) + P[ql * W + 2 * L + r3]);
+        atomicAdd(&S[ql * W + r1], at);
+        atomicAdd(&S[ql * W + L + r2], at);
+        atomicAdd(&S[ql * W + 2 * L + r3], at);
+    }
+    for (int ql = 0; ql < nq; ++ql) {                           // grad_v[index1[m], :] += attn[m] grad_out[q, :]: lane = (edge, channel)
+        const int i = threadIdx.x & 15;
+        const float gi = gr[ql * d + i];
+        for (int m = offs[ql] + (threadIdx.x >> 4); m < offs[ql + 1]; m += WB / 16)
+            pdf_atomic_add(grad_v + (size_t)index1[m] * C + hh * d + i, attn[(size_t)m * h + hh] * gi);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < W * d; e += WB) {            // grad_table[r, i, a] += sum_q S_q[a, r] grad_out[q, i]
+        const int x = e / d, i = e % d, a = x / L, r = x - a * L;
+        float acc = 0.f;
+        for (int ql = 0; ql < nq; ++ql) acc += S[ql * W + x] * gr[ql * d + i];
+        if (acc != 0.f) pdf_atomic_add(grad_table + ((size_t)r * C + (size_t)hh * d + i) * 3 + a, acc);
+    }
+}
+
 // ---------------------------------------------------------------- segment softmax over the edges of a query
 // StratifiedTransformer normalises the attention logits per query and head with torch_scatter.scatter_softmax(src, index_0, dim=0)
 // (stratified_transformer_v1m1_origin.py:322-324; torch_scatter is an unvendored dependency, absent here): y[m,h] =
@@ -715,8 +905,17 @@ extern "C" int pdf_dot_prod_with_idx_backward_v3_l(int N, int M, int h, int hdim
     const dim3 grid(pdf_divup(N, QCH), h);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (hdim == 16 && L <= 64) {   // table gradients as one-hot MFMA products
-#define PDF_DOT3_M16(RB_) k_dot3_bwd_m16<RB_><<<grid, WB, lds, st>>>(N, h, L, grad_out, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, \
-                                                                    grad_q, grad_k, grad_table_q, grad_table_k)
+        // PDFOPS_WA_FACTORED=0: both tables as one-hot matrix-core products in one kernel (k_dot3_bwd_m16, rounds 1-3); default: the query
+        // side factored by query (k_dot3_bwd_fq), the key side as one-hot products of one table (k_dot3_bwd_k)
+        static const bool factored = [] { const char *v = getenv("PDFOPS_WA_FACTORED"); return !(v && v[0] == '0'); }();
+        const size_t lds_fq = sizeof(float) * (size_t)(L * (hdim * 3 + 1) + QF * hdim + QF * 3 * L) + sizeof(int) * (QF + 1);
+        const size_t lds_k = sizeof(float) * (size_t)(L * (hdim * 3 + 1));
+        if (factored)
+            k_dot3_bwd_fq<<<dim3(pdf_divup(N, QF), h), WB, lds_fq, st>>>(N, h, L, grad_out, q, index_q_offsets, table_q, rel_idx, grad_q, grad_table_q);
+#define PDF_DOT3_M16(RB_) do { if (factored) k_dot3_bwd_k<RB_><<<grid, WB, lds_k, st>>>(N, h, L, grad_out, index_q_offsets, k, index_k, table_k, rel_idx, \
+                                                                                      grad_k, grad_table_k); \
+        else k_dot3_bwd_m16<RB_><<<grid, WB, lds, st>>>(N, h, L, grad_out, q, index_q_offsets, k, index_k, table_q, table_k, rel_idx, \
+                                                        grad_q, grad_k, grad_table_q, grad_table_k); } while (0)
         switch ((L + 15) / 16) {
             case 1: PDF_DOT3_M16(1); break;
             case 2: PDF_DOT3_M16(2); break;
@@ -771,6 +970,13 @@ extern "C" int pdf_attention_step2_with_rel_pos_value_backward_v2_l(int N, int M
     const dim3 grid(pdf_divup(N, QCH), h);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (hdim == 16 && L <= 64) {
+        static const bool factored = [] { const char *e = getenv("PDFOPS_WA_FACTORED"); return !(e && e[0] == '0'); }();
+        if (factored && !(((size_t)h * hdim) & 3) && !(reinterpret_cast<uintptr_t>(v) & 15)) {   // (float4 reads of the value rows)
+            const size_t lds_f = sizeof(float) * (size_t)(L * (hdim * 3 + 1) + QF * hdim + 2 * QF * 3 * L) + sizeof(int) * (QF + 1);
+            k_step2rv_bwd_f<<<dim3(pdf_divup(N, QF), h), WB, lds_f, st>>>(N, h, L, grad_out, index0_offsets, index1, attn, v, table, rel_idx,
+                                                                         grad_attn, grad_v, grad_table);
+            return pdf_launch_status();
+        }
 #define PDF_S2_M16(RB_) k_step2rv_bwd_m16<RB_><<<grid, WB, lds, st>>>(N, h, L, grad_out, index0_offsets, index1, attn, v, table, rel_idx, grad_attn, \
                                                                      grad_v, grad_table)
         switch ((L + 15) / 16) {
