@@ -764,11 +764,13 @@ __global__ __launch_bounds__(WB) void k_step2rv_bwd_f(int N, int h, int L, const
         atomicAdd(&S[ql * W + L + r2], at);
         atomicAdd(&S[ql * W + 2 * L + r3], at);
     }
-    for (int ql = 0; ql < nq; ++ql) {                           // grad_v[index1[m], :] += attn[m] grad_out[q, :]: lane = (edge, channel)
+    {                                                           // grad_v[index1[m], :] += attn[m] grad_out[q, :]: lane = (edge, channel)
         const int i = threadIdx.x & 15;
-        const float gi = gr[ql * d + i];
-        for (int m = offs[ql] + (threadIdx.x >> 4); m < offs[ql + 1]; m += WB / 16)
-            pdf_atomic_add(grad_v + (size_t)index1[m] * C + hh * d + i, attn[(size_t)m * h + hh] * gi);
+        int ql = 0;                                             // (a lane's edges ascend: the query is found by stepping on)
+        for (int m = e0 + (threadIdx.x >> 4); m < e1; m += WB / 16) {
+            while (offs[ql + 1] <= m) ++ql;
+            pdf_atomic_add(grad_v + (size_t)index1[m] * C + hh * d + i, attn[(size_t)m * h + hh] * gr[ql * d + i]);
+        }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < W * d; e += WB) {            // grad_table[r, i, a] += sum_q S_q[a, r] grad_out[q, i]
