@@ -493,7 +493,7 @@ def main():
                     divs = [d for d in range(min(8, D), D + 1) if steps % d == 0]
                     D = max(divs) if divs else D
             self.D, self.phase = D, (warmup % D if D > 0 else 0)
-            self.tickets, self.submit_host_s, self.pending = {}, [], None
+            self.tickets, self.submit_host_s, self.pending, self.step_index = {}, [], None, 0
 
         def _submit_range(self, lo, hi, ready=None):
             group = [pool[j % len(pool)] for j in range(lo, hi)]
@@ -517,20 +517,24 @@ def main():
             if (i + self.D - self.phase) % self.D == 0:
                 ready = torch.cuda.Event()
                 ready.record(torch.cuda.current_stream())     # the pre-pass depends on what is queued up to HERE, not on this step
-                self.pending = (i + self.D, i + 2 * self.D, ready)   # submitted by after_step(): once this step's launches are queued
+                # submitted by after_step() once a few steps are queued behind the boundary (the group has D steps of lead: its pre-pass
+                # is due D steps from here): on a slow host the submission takes longer than the one step queued so far
+                self.pending = (i + self.D, i + 2 * self.D, ready, i + min(2, self.D - 1))
+            self.step_index = i
             return geom
 
         def after_step(self):
             """Queue the next group's pre-pass AFTER the current step has been enqueued: its submission is 9-15 ms of host work, and
             issued in front of the step (rounds 1-3) it left the device idle for that long at every group boundary -- with replayed steps
             the device queue is empty right after the opening fence of a timed region."""
-            if self.pending is not None:
-                lo, hi, ready = self.pending
+            if self.pending is not None and self.step_index >= self.pending[3]:
+                lo, hi, ready, _ = self.pending
                 self.pending = None
                 self._submit_range(lo, hi, ready)
 
         def drain(self):
             """Pre-passes queued beyond the last step (none when steps is a multiple of D): wait for them, drop them."""
+            self.pending = None   # (a group that would only be needed after the last step)
             for t in self.tickets.values():
                 prefetcher.get(t)
             self.tickets.clear()
