@@ -462,20 +462,7 @@ def main():
                 and not (use_dp and args.ddp == "torch"))
     if args.graph == "1" and not graph_ok:
         raise SystemExit("bench.py: --graph 1 needs fixed scene sizes and the plain f32 PointTransformer step (see --help)")
-    captured, capture_note = None, None
-    if args.graph == "1" or (args.graph == "auto" and graph_ok):
-        try:   # set-up (like building the model): eager warm-up passes + one capture
-            captured = engine.CapturedStep(step, pool[0], autocast=amp_dtype, loss_scale=loss_scale)
-            torch.cuda.synchronize()
-        except Exception as e:   # noqa: BLE001  (auto: a stack that cannot capture the step still gets its line, on the eager path)
-            if args.graph == "1":
-                raise
-            captured, capture_note = None, f"graph capture failed ({type(e).__name__}: {e}); eager path"
-            print(f"bench.py: {capture_note}", file=sys.stderr)
-            torch.cuda.synchronize()
-            engine.release_autograd_state(step)
-            for p_ in step.parameters():
-                p_.grad = None
+    captured, capture_note, mode_calibration = None, None, None   # (the execution mode is settled below, once `timed` exists)
 
     class Schedule:
         """Grouped geometry pre-pass for `warmup + steps` steps: the pre-pass of the next D batches runs as ONE launch sequence on a
@@ -622,6 +609,37 @@ def main():
         st_tickets.clear()
         return dt, out, sched
 
+    # ---- execution mode of the step (set-up, like building the model): forward + backward replayed as one captured hipGraph, or every
+    # launch issued from Python.  Replay takes the host off the critical path (1.7 ms of host work per step instead of ~15-20) but costs
+    # the device ~0.6 ms per step (staging copy into the fixed-address buffers, graph-launch bookkeeping); where the host keeps ahead of
+    # the device anyway the eager step is the faster one (16.2 vs 16.9 ms on the fast hosts of the pool, 19.4 vs 17 on a slow one).
+    # --graph auto times six steps of each on THIS host before the warm-up and keeps the faster (eager first: an autograd graph that
+    # survives a capture binds the parameters' AccumulateGrad nodes to the capture stream and slows later eager steps).
+    if args.graph == "1" or (args.graph == "auto" and graph_ok):
+        # (one rank only: with N ranks the replayed step is kept -- N Python processes share the host, and every rank must pass the same
+        #  number of barriers)
+        dt_eager = timed(args.prefetch, 3, 6)[0] / 6 if (args.graph == "auto" and world == 1) else None
+        try:
+            captured = engine.CapturedStep(step, pool[0], autocast=amp_dtype, loss_scale=loss_scale)
+            torch.cuda.synchronize()
+        except Exception as e:   # noqa: BLE001  (auto: a stack that cannot capture the step still gets its line, on the eager path)
+            if args.graph == "1":
+                raise
+            captured, capture_note = None, f"graph capture failed ({type(e).__name__}: {e}); eager path"
+            print(f"bench.py: {capture_note}", file=sys.stderr)
+        if captured is not None and dt_eager is not None:
+            dt_graph = timed(args.prefetch, 3, 6)[0] / 6
+            mode_calibration = {"eager_ms_per_step": dt_eager * 1e3, "graph_ms_per_step": dt_graph * 1e3, "steps_each": 6}
+            if dt_eager < 0.97 * dt_graph:
+                captured = None
+        if captured is None:   # (dropped or failed: no autograd state of the capture may outlive it)
+            import gc
+            torch.cuda.synchronize()
+            engine.release_autograd_state(step)
+            for p_ in step.parameters():
+                p_.grad = None
+            gc.collect()
+            torch.cuda.empty_cache()
     dt_local, out, sched = timed(args.prefetch, args.warmup, args.steps, with_timer=True)
     D = sched.D
     dt, rank_ms = dt_local, [dt_local / args.steps * 1e3]
@@ -697,6 +715,7 @@ def main():
             "execution": ("forward + backward replayed as one captured hipGraph (engine.CapturedStep; fixed scene sizes), optimizer / gradient "
                           "exchange / geometry pre-pass eager; the steps that carry per-kernel HIP events run eagerly" if captured is not None
                           else (capture_note or "eager (one Python-issued launch sequence per step)")),
+            **({"execution_calibration": mode_calibration} if mode_calibration else {}),
             "cpu_affinity": affinity,
             "geometry_prefetch_group": (st_ahead if strat else D),
             "host_enqueue_ms_per_step": sched.enqueue_s / args.steps * 1e3,   # < ms_per_step: the host runs ahead, the device is the bound
