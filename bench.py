@@ -613,12 +613,13 @@ def main():
     # launch issued from Python.  Replay takes the host off the critical path (1.7 ms of host work per step instead of ~15-20) but costs
     # the device ~0.6 ms per step (staging copy into the fixed-address buffers, graph-launch bookkeeping); where the host keeps ahead of
     # the device anyway the eager step is the faster one (16.2 vs 16.9 ms on the fast hosts of the pool, 19.4 vs 17 on a slow one).
-    # --graph auto times six steps of each on THIS host before the warm-up and keeps the faster (eager first: an autograd graph that
+    # --graph auto times a region of the timed region's size of each on THIS host before the warm-up and keeps the faster (eager first: an autograd graph that
     # survives a capture binds the parameters' AccumulateGrad nodes to the capture stream and slows later eager steps).
     if args.graph == "1" or (args.graph == "auto" and graph_ok):
         # (one rank only: with N ranks the replayed step is kept -- N Python processes share the host, and every rank must pass the same
         #  number of barriers)
-        dt_eager = timed(args.prefetch, 3, 6)[0] / 6 if (args.graph == "auto" and world == 1) else None
+        cal = max(args.steps, 1)   # (a region of the size of the timed one: the same share of pre-pass submissions and event-carrying steps)
+        dt_eager = timed(args.prefetch, 3, cal, with_timer=True)[0] / cal if (args.graph == "auto" and world == 1) else None
         try:
             captured = engine.CapturedStep(step, pool[0], autocast=amp_dtype, loss_scale=loss_scale)
             torch.cuda.synchronize()
@@ -628,8 +629,8 @@ def main():
             captured, capture_note = None, f"graph capture failed ({type(e).__name__}: {e}); eager path"
             print(f"bench.py: {capture_note}", file=sys.stderr)
         if captured is not None and dt_eager is not None:
-            dt_graph = timed(args.prefetch, 3, 6)[0] / 6
-            mode_calibration = {"eager_ms_per_step": dt_eager * 1e3, "graph_ms_per_step": dt_graph * 1e3, "steps_each": 6}
+            dt_graph = timed(args.prefetch, 3, cal, with_timer=True)[0] / cal
+            mode_calibration = {"eager_ms_per_step": dt_eager * 1e3, "graph_ms_per_step": dt_graph * 1e3, "steps_each": cal}
             if dt_eager < 0.97 * dt_graph:
                 captured = None
         if captured is None:   # (dropped or failed: no autograd state of the capture may outlive it)
@@ -640,6 +641,8 @@ def main():
                 p_.grad = None
             gc.collect()
             torch.cuda.empty_cache()
+    for rec in timer.records.values():   # (the calibration regions carried kernel events like the timed one will: only the timed region's count)
+        rec.clear()
     dt_local, out, sched = timed(args.prefetch, args.warmup, args.steps, with_timer=True)
     D = sched.D
     dt, rank_ms = dt_local, [dt_local / args.steps * 1e3]
