@@ -506,7 +506,8 @@ def main():
                 ready.record(torch.cuda.current_stream())     # the pre-pass depends on what is queued up to HERE, not on this step
                 # submitted by after_step() once a few steps are queued behind the boundary (the group has D steps of lead: its pre-pass
                 # is due D steps from here): on a slow host the submission takes longer than the one step queued so far
-                self.pending = (i + self.D, i + 2 * self.D, ready, i + min(2, self.D - 1))
+                # (replayed steps only: issued from Python, two steps of host time are ~30 ms of the group's lead)
+                self.pending = (i + self.D, i + 2 * self.D, ready, i + (min(2, self.D - 1) if captured is not None else 0))
             self.step_index = i
             return geom
 
