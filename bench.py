@@ -559,15 +559,25 @@ def main():
                 geom = Geometry(batch["coord"], batch["offset"], batch["offset_host"]).precompute()
             out = captured(batch, geom)
         else:
-            opt.zero_grad(set_to_none=True)
-            with torch.autocast("cuda", dtype=amp_dtype or torch.float16, enabled=amp_dtype is not None):
-                out = module(data)
-            if loss_scale == 1.0:
-                out["loss"].backward()
-            else:
-                (out["loss"] * loss_scale).backward()
-                with torch.no_grad():
-                    torch._foreach_mul_([p.grad for p in step.parameters() if p.grad is not None], 1.0 / loss_scale)
+            # An eagerly issued step between replays (the one that carries the per-kernel HIP events) runs on the capture's stream: the
+            # parameters' AccumulateGrad nodes are bound to it while the captured autograd graph lives, and on any other stream the
+            # engine synchronises every one of the 609 of them (20-40 ms for the step instead of 16.5).
+            cur = torch.cuda.current_stream()
+            run_on = captured.stream if captured is not None else cur
+            if run_on is not cur:
+                run_on.wait_stream(cur)
+            with torch.cuda.stream(run_on):
+                opt.zero_grad(set_to_none=True)
+                with torch.autocast("cuda", dtype=amp_dtype or torch.float16, enabled=amp_dtype is not None):
+                    out = module(data)
+                if loss_scale == 1.0:
+                    out["loss"].backward()
+                else:
+                    (out["loss"] * loss_scale).backward()
+                    with torch.no_grad():
+                        torch._foreach_mul_([p.grad for p in step.parameters() if p.grad is not None], 1.0 / loss_scale)
+            if run_on is not cur:
+                cur.wait_stream(run_on)
         if grad_sync is not None:
             grad_sync.sync(force=force_dp)   # ONE all-reduce (RCCL) over the flat gradient buffer
         opt.step()

@@ -145,6 +145,8 @@ class CapturedStep:
         # Capture on the SAME side stream the warm-up ran on: a parameter's AccumulateGrad node remembers the stream it was created on, and a
         # node that survived the warm-up on another stream makes the engine fork the capture onto that stream -- work and allocations of
         # the fork are then outside the graph's private pool (observed: replays that read recycled memory once eager work ran in between).
+        self.stream = side   # an EAGER step of the same module between replays is fastest on this stream (see the comment above: the
+        #                      parameters' AccumulateGrad nodes stay bound to it for as long as the captured autograd graph lives)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=side):
             self.out = self._eager()
