@@ -66,6 +66,55 @@ def load_traffic():
     return {}, ("no profiles/r*_traffic.json" if not seen else "measured on other kernel sources: " + ", ".join(seen[:3]))
 
 
+SQ_GLOB = os.path.join(ROOT, "profiles", "r*_sq.json")   # tools/rocpd_sq.py --json output (SQ counter passes of tools/prof_sq.sh)
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 / fp16 matrix peak (same guide)
+
+
+def load_sq():
+    """Counter-based limiter / matrix-pipe figures per kernel (builder-side rocprofv3 --pmc passes: `bash tools/prof_sq.sh <tag>`), hash-locked
+    to the kernel sources like the traffic file."""
+    import glob
+    want = kernel_source_hash()
+    for path in sorted(glob.glob(SQ_GLOB), reverse=True):
+        try:
+            with open(path) as f:
+                t = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if t.get("kernel_source_hash") == want:
+            t["file"] = os.path.relpath(path, ROOT)
+            t["file_date"] = time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(path)))
+            return t
+    return None
+
+
+def dense_flops_forward(n1, in_channels=6, num_classes=13, enc_bottlenecks=(1, 2, 3, 5, 2)):
+    """Forward FLOPs of every nn.Linear of PointTransformer-Seg50 + the PDF U-decoder for ONE scene of n1 points: 2 * rows * in * out per
+    layer (SURVEY.md 8d; the probe there gives 0.365 + 0.018 MFLOP per point, which this reproduces).  Level sizes n_l = n_{l-1} // 4
+    (point_transformer_seg.py:96-99), planes 32..512, nsample 8 / 16; per Bottleneck (point_transformer_seg.py:171-192, 19-78): linear1,
+    linear3, q / k / v on n rows (10 n c^2), linear_p (3 -> 3 -> c) and linear_w (c -> c/8 -> c/8) on n k rows; TransitionDown
+    (:81-119): Linear(3 + c_in, c) on n k rows (level 1: Linear(in, 32) on n rows); TransitionUp (:122-168) and the recognizer's five
+    TransitionUp + confidence head (pt_v1.py:8-44); cls head (:229-234)."""
+    planes, ks = [32, 64, 128, 256, 512], [8, 16, 16, 16, 16]
+    n = [int(n1)]
+    for _ in range(4):
+        n.append(n[-1] // 4)
+    seg = rec = 0
+    for l in range(5):
+        N, c, k = n[l], planes[l], ks[l]
+        seg += 2 * N * in_channels * c if l == 0 else 2 * N * k * (3 + planes[l - 1]) * c
+        seg += (enc_bottlenecks[l] + 1) * (10 * N * c * c + 2 * N * k * (9 + 3 * c + c * c // 8 + (c // 8) ** 2))
+        if l == 4:
+            seg += 2 * N * (2 * c) * c
+            rec += 4 * N * c * c
+        else:
+            seg += 2 * N * c * c + 2 * n[l + 1] * planes[l + 1] * c
+            rec += 2 * N * c * c + 2 * n[l + 1] * planes[l + 1] * c
+    seg += 2 * n[0] * (32 * 32 + 32 * num_classes)
+    rec += 2 * n[0] * (32 * 32 + 32 * 1)
+    return float(seg + rec)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,7 +147,8 @@ def parse():
     ap.add_argument("--amp", nargs="?", const="f16", default=None, choices=["bf16", "f16"],
                     help="torch.autocast around the step (reference: enable_amp = True, engines/train.py:340-363): the streaming Linear products "
                          "run with fp16 (default, as the reference's autocast) / bfloat16 operands on the 16x16x16 matrix-core instructions, fp32 storage and accumulation "
-                         "(dense.fp32_path).  f16 adds a static loss scale of 4096 for the backward (the reference uses a GradScaler)")
+                         "(dense.fp32_path).  f16 scales the loss dynamically as the reference's GradScaler does (engine.DeviceGradScaler: scale, "
+                         "found-inf flag and growth tracker on the device, so the step still replays as a graph)")
     ap.add_argument("--storage", choices=["f32", "bf16"], default=os.environ.get("PDFOPS_STORAGE", "f32"),
                     help="bf16: the reduced-precision variant -- the fused PointTransformerLayer keeps its saved / scratch row arrays (H, G2, "
                          "softmax weights, g_r rows) as bfloat16 with fp32 accumulation (the reference trains under AMP); the headline stays f32")
@@ -109,7 +159,7 @@ def parse():
                     help="1 = forward + backward of the step replayed as ONE captured hipGraph (engine.CapturedStep: batch tensors and the "
                          "batch's geometry tables staged into fixed-address buffers by one copy launch per step); the optimizer, the "
                          "gradient exchange and the geometry pre-pass stay eager.  Needs identical scene sizes in every batch (what "
-                         "SphereCrop(point_max) gives the reference's trainer): auto = on unless --jitter / --amp / --pseudo-label / "
+                         "SphereCrop(point_max) gives the reference's trainer): auto = on unless --jitter / --pseudo-label / "
                          "--throttle / --ddp torch / the stratified workload ask for something the capture does not cover")
     ap.add_argument("--ddp", choices=["flat", "torch"], default="flat",
                     help="gradient exchange for N > 1: one flat-buffer all-reduce after the backward (engine.FlatGradAllReduce) or "
@@ -242,16 +292,18 @@ class KernelTimer:
 
     @staticmethod
     def mfma_flops(name, args):
-        """fp32 MFMA work of the window-attention table-gradient kernels (one-hot (L x edges) . (edges x d) products per head and axis,
-        csrc/window_attention.hip): 2 * 3 axes * L * M * C per table gradient (two tables in dot_prod_with_idx_v3's backward)."""
+        """ALGORITHMIC flops of the libs/pointops2 table ops (config 5), from their definitions -- not the flops of whatever formulation
+        the kernel uses (round 3 counted the one-hot matrix products of the round-1 kernels; the factored kernels of csrc/window_attention.hip
+        no longer run most of them).  dot_prod_with_idx_v3 (relative_pos_encoding_cuda_kernel_v2.cu:247-330): per edge m and head h,
+        out = sum over 3 axes and d channels of q * table_q[r] + k * table_k[r]: 6 d multiply-adds = 12 M C flops forward; every
+        multiply-add has two gradient multiply-adds: 24 M C backward.  attention_step2_with_rel_pos_value_v2 (:375-484): out[n] += attn *
+        (v + sum of 3 table rows): 5 M C forward; backward (grad_attn dot, grad_v, 3 table rows): 10 M C."""
         if name == "dot_prod_with_idx_v3_backward":
-            q, table = args[1], args[6]
-            m, c, L = args[5].shape[0], q.shape[1] * q.shape[2], table.shape[0]
-            return 2.0 * 2 * 3 * L * m * c
+            q = args[1]
+            return 24.0 * args[5].shape[0] * q.shape[1] * q.shape[2]
         if name == "attention_step2_with_rel_pos_value_v2_backward":
-            v, table = args[2], args[6]
-            m, c, L = args[1].shape[0], v.shape[1] * v.shape[2], table.shape[0]
-            return 2.0 * 3 * L * m * c
+            v = args[2]
+            return 10.0 * args[1].shape[0] * v.shape[1] * v.shape[2]
         return 0.0
 
     def summary(self):
@@ -450,212 +502,93 @@ def main():
     timer = KernelTimer(be, names)
     timer.install()
 
-    from pointcloudpdf_amd.geometry import GeometryPrefetcher
-
-    # two side streams, alternating groups.  PDFOPS_PREPASS_THREAD=1 builds the pre-pass on a worker thread (measured: no gain -- the worker's
-    # Python / dispatch work competes with the training thread for the interpreter: 17.7-18.6 vs 18.2-18.4 ms per step)
-    prefetcher = GeometryPrefetcher(depth=2, threaded=bool(os.environ.get("PDFOPS_PREPASS_THREAD")))
-
     amp_dtype = {None: None, "bf16": torch.bfloat16, "f16": torch.float16}[args.amp]
-    loss_scale = 4096.0 if args.amp == "f16" else 1.0
+    # fp16 operands: the reference's AMP loop scales the loss dynamically (torch GradScaler, engines/train.py:343-355); here the same
+    # policy with the scale / found-inf flag on the device (engine.DeviceGradScaler), so that the step still replays as a graph
+    scaler = engine.DeviceGradScaler(dev) if (args.amp == "f16" and args.optimizer == "fused") else None
+    static_scale = 4096.0 if (args.amp == "f16" and scaler is None) else 1.0
     graph_ok = (args.jitter <= 0 and not args.pseudo_label and not args.throttle and not strat
                 and not (use_dp and args.ddp == "torch"))
     if args.graph == "1" and not graph_ok:
-        raise SystemExit("bench.py: --graph 1 needs fixed scene sizes and the plain f32 PointTransformer step (see --help)")
-    captured, capture_note, mode_calibration = None, None, None   # (the execution mode is settled below, once `timed` exists)
-
-    class Schedule:
-        """Grouped geometry pre-pass for `warmup + steps` steps: the pre-pass of the next D batches runs as ONE launch sequence on a
-        side stream (FPS is a chain of dependent arg-max steps, one workgroup per scene: its latency is amortised over the group
-        instead of being paid per step).  Group boundaries sit at warmup + k * D, so the timed region queues exactly steps / D group
-        pre-passes -- every trained batch gets exactly one full pre-pass, nothing is cached -- and, D steps being a whole group's
-        lead time, drains them before the closing fence.  D = 0: the pre-pass runs inline on the main stream (serial step)."""
-
-        def __init__(self, D, warmup, steps):
-            if D > 0:
-                D = max(1, min(D, 64 // max(args.scenes, 1)))   # the grid kNN / radius workspaces hold <= 64 scenes per call
-                if steps <= D:
-                    D = max(steps, 1)
-                else:
-                    divs = [d for d in range(min(8, D), D + 1) if steps % d == 0]
-                    D = max(divs) if divs else D
-            self.D, self.phase = D, (warmup % D if D > 0 else 0)
-            self.tickets, self.submit_host_s, self.pending, self.step_index = {}, [], None, 0
-
-        def _submit_range(self, lo, hi, ready=None):
-            group = [pool[j % len(pool)] for j in range(lo, hi)]
-            t_sub = time.perf_counter()
-            for j, t in enumerate(prefetcher.submit_group(group, ready=ready)):
-                self.tickets[lo + j] = t
-            self.submit_host_s.append(time.perf_counter() - t_sub)
-
-        def start(self):
-            if self.D > 0:
-                b0 = self.phase if self.phase > 0 else self.D
-                self._submit_range(0, b0)
-                if self.phase > 0:
-                    self._submit_range(b0, b0 + self.D)
-
-        def geometry(self, i):
-            """Tables of step i's batch (queued with its group); queues the NEXT group when i crosses a boundary."""
-            if self.D == 0:
-                return None
-            geom = prefetcher.get(self.tickets.pop(i))
-            if (i + self.D - self.phase) % self.D == 0:
-                ready = torch.cuda.Event()
-                ready.record(torch.cuda.current_stream())     # the pre-pass depends on what is queued up to HERE, not on this step
-                # submitted by after_step() once a few steps are queued behind the boundary (the group has D steps of lead: its pre-pass
-                # is due D steps from here): on a slow host the submission takes longer than the one step queued so far
-                # (replayed steps only: issued from Python, two steps of host time are ~30 ms of the group's lead)
-                self.pending = (i + self.D, i + 2 * self.D, ready, i + (min(2, self.D - 1) if captured is not None else 0))
-            self.step_index = i
-            return geom
-
-        def after_step(self):
-            """Queue the next group's pre-pass AFTER the current step has been enqueued: its submission is 9-15 ms of host work, and
-            issued in front of the step (rounds 1-3) it left the device idle for that long at every group boundary -- with replayed steps
-            the device queue is empty right after the opening fence of a timed region."""
-            if self.pending is not None and self.step_index >= self.pending[3]:
-                lo, hi, ready, _ = self.pending
-                self.pending = None
-                self._submit_range(lo, hi, ready)
-
-        def drain(self):
-            """Pre-passes queued beyond the last step (none when steps is a multiple of D): wait for them, drop them."""
-            self.pending = None   # (a group that would only be needed after the last step)
-            for t in self.tickets.values():
-                prefetcher.get(t)
-            self.tickets.clear()
-
-    st_prefetcher, st_tickets, st_state = None, {}, {"next": 0}
+        raise SystemExit("bench.py: --graph 1 needs fixed scene sizes and the plain PointTransformer step (see --help)")
+    # The schedule of the run is PRODUCT code (pointcloudpdf_amd/engine.py): GroupedGeometryLoader owns the grouped look-ahead of the
+    # coordinate-only pre-pass (what to submit when, on which stream, waiting for what), TrainStep owns the step itself (graph replay
+    # when the batch has the captured shape, eager otherwise; gradient exchange; optimizer; loss scaling).  This file only feeds
+    # batches, times the region and reports.
+    trainer = engine.TrainStep(step, opt, exchange=grad_sync, scaler=scaler, autocast=amp_dtype, module=module, force_exchange=force_dp,
+                               graph=(args.graph == "1" or (args.graph == "auto" and graph_ok)), loss_scale=static_scale)
+    st_prefetcher = None
     if st_ahead:
         from pointcloudpdf_amd.stratified import StratifiedPrefetcher
         st_prefetcher = StratifiedPrefetcher(step.model.backbone, windows=not os.environ.get("PDFOPS_ST_FPS_ONLY"))
 
-    def one_step(i, sched):
-        batch = pool[i % len(pool)]
-        data = dict(coord=batch["coord"], feat=batch["feat"], offset=batch["offset"],
-                    offset_host=batch["offset_host"], segment=batch["segment"])
-        geom = sched.geometry(i)
-        if geom is not None:
-            data["pdf_geometry"] = geom
-        if st_prefetcher is not None:
-            G = st_ahead
+    def batch_stream(start=0):
+        i = start
+        while True:
+            b = pool[i % len(pool)]
+            yield dict(coord=b["coord"], feat=b["feat"], offset=b["offset"], offset_host=b["offset_host"], segment=b["segment"])
+            i += 1
 
-            def st_submit(lo, hi):   # one group: batches lo .. hi - 1
-                for j, t in enumerate(st_prefetcher.submit_group([pool[x % len(pool)] for x in range(lo, hi)])):
-                    st_tickets[lo + j] = t
-            if i not in st_tickets:                      # the first step of a run
-                st_submit(i, i + G)
-                st_state["next"] = i + G
-            if i + G >= st_state["next"]:                # the group after the one in use: built while this one trains
-                st_submit(st_state["next"], st_state["next"] + G)
-                st_state["next"] += G
-            data["st_geometry"] = st_prefetcher.get(st_tickets.pop(i))
-        replay = captured is not None and not (timer.enabled and timer.sample) and captured.matches(batch)
-        if replay:   # forward + backward as one hipGraph launch; steps that carry the per-kernel HIP events run eagerly
-            if geom is None:   # --prefetch 0: the pre-pass (and its packing) inline on this stream
-                from pointcloudpdf_amd.geometry import Geometry
-                geom = Geometry(batch["coord"], batch["offset"], batch["offset_host"]).precompute()
-            out = captured(batch, geom)
-        else:
-            # An eagerly issued step between replays (the one that carries the per-kernel HIP events) runs on the capture's stream: the
-            # parameters' AccumulateGrad nodes are bound to it while the captured autograd graph lives, and on any other stream the
-            # engine synchronises every one of the 609 of them (20-40 ms for the step instead of 16.5).
-            cur = torch.cuda.current_stream()
-            run_on = captured.stream if captured is not None else cur
-            if run_on is not cur:
-                run_on.wait_stream(cur)
-            with torch.cuda.stream(run_on):
-                opt.zero_grad(set_to_none=True)
-                with torch.autocast("cuda", dtype=amp_dtype or torch.float16, enabled=amp_dtype is not None):
-                    out = module(data)
-                if loss_scale == 1.0:
-                    out["loss"].backward()
-                else:
-                    (out["loss"] * loss_scale).backward()
-                    with torch.no_grad():
-                        torch._foreach_mul_([p.grad for p in step.parameters() if p.grad is not None], 1.0 / loss_scale)
-            if run_on is not cur:
-                cur.wait_stream(run_on)
-        if grad_sync is not None:
-            grad_sync.sync(force=force_dp)   # ONE all-reduce (RCCL) over the flat gradient buffer
-        opt.step()
-        sched.after_step()
-        return out
+    def make_loader(D, warmup, steps):
+        """The look-ahead group for `warmup + steps` steps: D batches per pre-pass (0 = inline, serial step), capped by the scene budget
+        of one grouped call, and a divisor of `steps` where one exists -- the timed region then queues exactly steps / D group
+        pre-passes (every trained batch gets exactly one full pre-pass, nothing is cached); the first group is sized so that a group
+        boundary coincides with the end of the warm-up."""
+        if st_prefetcher is not None:
+            return engine.GroupedGeometryLoader(batch_stream(), group=st_ahead, prefetcher=st_prefetcher, key="st_geometry", submit_delay=0), st_ahead
+        if D > 0:
+            D = max(1, min(D, engine.GroupedGeometryLoader.MAX_SCENES // max(args.scenes, 1)))
+            if steps <= D:
+                D = max(steps, 1)
+            else:
+                divs = [d for d in range(min(8, D), D + 1) if steps % d == 0]
+                D = max(divs) if divs else D
+        first = (warmup % D or D) if D > 0 else None
+        return engine.GroupedGeometryLoader(batch_stream(), group=D, first_group=first, threaded=bool(os.environ.get("PDFOPS_PREPASS_THREAD"))), D
 
     def fence():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    class Region:
+        pass
+
     def timed(D, warmup, steps, with_timer=False):
-        """W untimed steps, then EXACTLY K steps between barrier + synchronize pairs -> (seconds, last output, schedule)."""
-        sched = Schedule(D, warmup, steps)
-        sched.start()
-        for i in range(warmup):
-            one_step(i, sched)
+        """W untimed steps, then EXACTLY K steps between barrier + synchronize pairs -> (seconds, last output, region info)."""
+        loader, D = make_loader(D, warmup, steps)
+        it = iter(loader)
+        for _ in range(warmup):
+            out = trainer(next(it))
         fence()
         timer.enabled = with_timer
         # steps that carry the per-kernel HIP events run eagerly (events cannot time kernels inside a replayed graph): every 4th step of
-        # an eager run, ONE step of the timed region when the steps are graph replays -- the LAST one: issuing a step from Python takes
-        # the host longer than the device needs to run it, which costs nothing behind the backlog of replays queued before it and
-        # 4-12 ms of idle device at the front of the region, right after the fence (where rounds 1-3 had it)
-        every = timer.every if captured is None else max(steps, 1)
-        sample_at = 0 if captured is None else every - 1
+        # an eager run, ONE step of the timed region -- the last -- when the steps are graph replays
+        replaying = trainer.captured is not None
+        every = timer.every if not replaying else max(steps, 1)
+        sample_at = 0 if not replaying else every - 1
         t0 = time.perf_counter()
         for i in range(steps):
             timer.sample = every > 0 and i % every == sample_at
-            out = one_step(warmup + i, sched)
-        sched.enqueue_s = time.perf_counter() - t0   # host time to enqueue the K steps (the device may still be working)
+            out = trainer(next(it), eager=with_timer and timer.sample and replaying)
+        info = Region()
+        info.enqueue_s = time.perf_counter() - t0   # host time to enqueue the K steps (the device may still be working)
         fence()
         dt = time.perf_counter() - t0
         timer.enabled = False
         if with_timer:
             timer.sampled_steps = len([i for i in range(steps) if every > 0 and i % every == sample_at])
             timer.every_used = every
-        sched.drain()
-        for t in st_tickets.values():
-            st_prefetcher.get(t)
-        st_tickets.clear()
-        return dt, out, sched
+        it.close()
+        info.D, info.submit_host_s = D, list(loader.submit_host_s)
+        return dt, out, info
 
-    # ---- execution mode of the step (set-up, like building the model): forward + backward replayed as one captured hipGraph, or every
-    # launch issued from Python.  Replay takes the host off the critical path (1.7 ms of host work per step instead of ~15-20) but costs
-    # the device ~0.6 ms per step (staging copy into the fixed-address buffers, graph-launch bookkeeping); where the host keeps ahead of
-    # the device anyway the eager step is the faster one (16.2 vs 16.9 ms on the fast hosts of the pool, 19.4 vs 17 on a slow one).
-    # --graph auto times a region of the timed region's size of each on THIS host before the warm-up and keeps the faster (eager first: an autograd graph that
-    # survives a capture binds the parameters' AccumulateGrad nodes to the capture stream and slows later eager steps).
-    if args.graph == "1" or (args.graph == "auto" and graph_ok):
-        # (one rank only: with N ranks the replayed step is kept -- N Python processes share the host, and every rank must pass the same
-        #  number of barriers)
-        cal = max(args.steps, 1)   # (a region of the size of the timed one: the same share of pre-pass submissions and event-carrying steps)
-        dt_eager = timed(args.prefetch, 3, cal, with_timer=True)[0] / cal if (args.graph == "auto" and world == 1) else None
-        try:
-            captured = engine.CapturedStep(step, pool[0], autocast=amp_dtype, loss_scale=loss_scale)
-            torch.cuda.synchronize()
-        except Exception as e:   # noqa: BLE001  (auto: a stack that cannot capture the step still gets its line, on the eager path)
-            if args.graph == "1":
-                raise
-            captured, capture_note = None, f"graph capture failed ({type(e).__name__}: {e}); eager path"
-            print(f"bench.py: {capture_note}", file=sys.stderr)
-        if captured is not None and dt_eager is not None:
-            dt_graph = timed(args.prefetch, 3, cal, with_timer=True)[0] / cal
-            mode_calibration = {"eager_ms_per_step": dt_eager * 1e3, "graph_ms_per_step": dt_graph * 1e3, "steps_each": cal}
-            if dt_eager < 0.97 * dt_graph:
-                captured = None
-        if captured is None:   # (dropped or failed: no autograd state of the capture may outlive it)
-            import gc
-            torch.cuda.synchronize()
-            engine.release_autograd_state(step)
-            for p_ in step.parameters():
-                p_.grad = None
-            gc.collect()
-            torch.cuda.empty_cache()
-    for rec in timer.records.values():   # (the calibration regions carried kernel events like the timed one will: only the timed region's count)
+    for rec in timer.records.values():
         rec.clear()
     dt_local, out, sched = timed(args.prefetch, args.warmup, args.steps, with_timer=True)
     D = sched.D
+    if st_prefetcher is not None:
+        st_prefetcher.close()
     dt, rank_ms = dt_local, [dt_local / args.steps * 1e3]
     if world > 1:
         t = torch.tensor([dt_local], device=dev, dtype=torch.float64)
@@ -672,18 +605,13 @@ def main():
         pts_per_step = pts_total / args.steps
         ks = timer.summary()
         traffic, traffic_note = load_traffic()
+        if traffic and traffic.get("file"):
+            traffic["file_date"] = time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(os.path.join(ROOT, traffic["file"]))))
         steps_of = lambda name: args.steps if name in KernelTimer.ALWAYS else max(timer.sampled_steps, 1)
         cand = [n for n in ks if n.startswith(("attention_step", "dot_prod_with_idx"))] if strat else list(ks)   # config 5: the window-attention ops
         dom = max(cand or list(ks), key=lambda n: ks[n]["total_ms"] / steps_of(n)) if ks else None
 
         def roofline_of(name):
-            if ks[name].get("avg_mfma_flops"):   # MFMA-bound kernel: fp32 one-hot products against the dense fp32 matrix peak
-                ach = ks[name]["avg_mfma_flops"] / (ks[name]["avg_ms"] * 1e-3) / 1e12
-                return dict(bound="mfma", kernel=name, achieved=ach, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP32_MFMA_PEAK_TFLOPS,
-                            traffic=None, flops_per_launch=ks[name]["avg_mfma_flops"], algorithmic_bytes_per_launch=ks[name]["avg_bytes"],
-                            hbm_GBps_on_algorithmic_bytes=ks[name]["avg_bytes"] / (ks[name]["avg_ms"] * 1e-3) / 1e9,
-                            avg_launch_ms=ks[name]["avg_ms"], launches_per_step=ks[name]["calls"] / steps_of(name),
-                            gpu_time_share_of_step=ks[name]["total_ms"] / steps_of(name) / (dt / args.steps * 1e3))
             achieved = ks[name]["avg_bytes"] / (ks[name]["avg_ms"] * 1e-3) / 1e9
             r = dict(bound="hbm", kernel=name, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                      frac=achieved / HBM_PEAK_GBS, traffic=(traffic.get("host_calls", {}).get(name) if traffic else None),
@@ -691,9 +619,17 @@ def main():
                      launches_per_step=ks[name]["calls"] / steps_of(name),
                      gpu_time_share_of_step=ks[name]["total_ms"] / steps_of(name) / (dt / args.steps * 1e3),
                      timed_steps=f"{timer.sampled_steps} of {args.steps} (every {getattr(timer, 'every_used', timer.every)}th step of the timed region carries the HIP events"
-                                 + ("; those steps run eagerly, the others are graph replays)" if captured is not None else ")"))
+                                 + ("; those steps run eagerly, the others are graph replays)" if trainer.captured is not None else ")"))
+            if ks[name].get("avg_mfma_flops"):   # config 5's table ops: algorithmic flops of the definition next to the bytes
+                r["algorithmic_flops_per_launch"] = ks[name]["avg_mfma_flops"]
+                r["achieved_TFLOPs_on_algorithmic_flops"] = ks[name]["avg_mfma_flops"] / (ks[name]["avg_ms"] * 1e-3) / 1e12
+                r["frac_of_fp32_vector_peak"] = r["achieved_TFLOPs_on_algorithmic_flops"] / FP32_MFMA_PEAK_TFLOPS
             if traffic_note:
                 r["traffic_note"] = traffic_note
+            elif traffic and r["traffic"] is not None:   # NOT measured in this run: builder-side PMC passes, locked to the kernel sources by hash
+                r["traffic_source"] = (f"{traffic.get('file')} ({traffic.get('file_date')}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                       "tools/pmc_only.sh on the builder's gpurun box, 2 x FETCH_SIZE + WRITE_SIZE per launch; kernel-source hash "
+                                       f"{traffic.get('kernel_source_hash')} matches this tree")
             return r
 
         roof = roofline_of(dom) if dom else None
@@ -726,10 +662,12 @@ def main():
             "rccl_ranks": world if (world > 1 and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl") else 0,
             "rank_ms_per_step": rank_ms,
             "loss": loss,
-            "execution": ("forward + backward replayed as one captured hipGraph (engine.CapturedStep; fixed scene sizes), optimizer / gradient "
-                          "exchange / geometry pre-pass eager; the steps that carry per-kernel HIP events run eagerly" if captured is not None
-                          else (capture_note or "eager (one Python-issued launch sequence per step)")),
-            **({"execution_calibration": mode_calibration} if mode_calibration else {}),
+            "execution": ("engine.GroupedGeometryLoader + engine.TrainStep: forward + backward replayed as one captured hipGraph (fixed scene sizes), "
+                          "optimizer / gradient exchange / geometry pre-pass eager; the ONE step of the timed region that carries per-kernel HIP events runs eagerly"
+                          if trainer.captured is not None else
+                          ("engine.GroupedGeometryLoader + engine.TrainStep, eager (one Python-issued launch sequence per step)"
+                           + (f"; graph capture failed: {trainer.capture_error}" if trainer.capture_error else ""))),
+            **({"loss_scaling": "dynamic (engine.DeviceGradScaler: torch GradScaler's policy, decisions on the device)"} if scaler is not None else {}),
             "cpu_affinity": affinity,
             "geometry_prefetch_group": (st_ahead if strat else D),
             "host_enqueue_ms_per_step": sched.enqueue_s / args.steps * 1e3,   # < ms_per_step: the host runs ahead, the device is the bound
@@ -739,6 +677,29 @@ def main():
             "roofline": roof,
             "roofline_gather_family": roof2,
         }
+        if not strat:
+            # ---- matrix cores (north_star: "MFMA utilisation against peak"): the Linear layers' FLOPs of the step, 3 x forward (forward,
+            # input gradient, weight gradient), against the dense peak of the operand type -- over the whole step (live), over
+            # the time of the kernels that run them and as the matrix pipes' counter-measured busy share (builder-side SQ passes)
+            sizes = [pool[(args.warmup + i) % len(pool)]["offset_host"] for i in range(args.steps)]
+            fl = sum(3.0 * dense_flops_forward(b - a, 9 if scannet else 6, 20 if scannet else 13)
+                     for oh in sizes for a, b in zip([0] + list(oh[:-1]), oh)) / args.steps
+            peak = BF16_MFMA_PEAK_TFLOPS if args.amp else FP32_MFMA_PEAK_TFLOPS
+            ach = fl / (dt / args.steps) / 1e12
+            mf = dict(bound="mfma", flops_per_step=fl, flops_definition="3 x sum over every nn.Linear of 2 * rows * in * out (SURVEY.md 8d)",
+                      achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak,
+                      operands=("fp16/bf16 operands on v_mfma_f32_16x16x16, fp32 accumulate" if args.amp else "fp32 on v_mfma_f32_16x16x4_f32"),
+                      note="whole-step figure: the step is HBM / latency bound by design (0.38 MFLOP per point forward), see `roofline`")
+            sq = load_sq()
+            if sq is not None and not args.amp:
+                dk = sq["dense_kernel_ms_per_step"] * 1e-3
+                mf.update(dense_kernel_ms_per_step=sq["dense_kernel_ms_per_step"], dense_families_us_per_step=sq["dense_families_us_per_step"],
+                          achieved_in_dense_kernels=fl / dk / 1e12, frac_in_dense_kernels=fl / dk / 1e12 / peak,
+                          matrix_pipe_busy_share_of_dense_kernel_time=sq["matrix_pipe_busy_share_of_dense_kernel_time"],
+                          counters_source=(f"{sq['file']} ({sq['file_date']}): SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) per kernel, "
+                                           "rocprofv3 --pmc passes of tools/prof_sq.sh on the builder's gpurun box (not measured in this run; "
+                                           f"kernel-source hash {sq['kernel_source_hash']} matches this tree)"))
+            line["mfma"] = mf
         if traffic and traffic.get("dominant_gpu_kernel"):
             line["dominant_gpu_kernel"] = traffic["dominant_gpu_kernel"]   # the single hottest GPU kernel of the kernel trace (tools/traffic_json.py)
         if traffic and traffic.get("kernels"):
@@ -759,13 +720,14 @@ def main():
         for Dl, st, wu in ((0, 4, 1), (1, 6, 2), (2, 6, 2), (3, 6, 3)):
             dtl, _, _ = timed(Dl, wu, st)
             sweep["serial" if Dl == 0 else f"group_{Dl}"] = dtl / st * 1e3
-        if captured is not None:   # the same schedule with the step issued from Python (no graph)
-            keep, captured = captured, None
+        if trainer.captured is not None:   # the same schedule with the step issued from Python (no graph)
+            keep, trainer.captured = trainer.captured, None
+            trainer.graph = False
             dtl, _, sch = timed(args.prefetch, 3, args.steps)
             sweep["eager"] = dtl / args.steps * 1e3
             line["eager_ms_per_step"] = sweep["eager"]
             line["eager_host_enqueue_ms_per_step"] = sch.enqueue_s / args.steps * 1e3
-            captured = keep
+            trainer.captured, trainer.graph = keep, True
         # what the data-parallel gradient exchange adds per step, measured at world size 1 over RCCL (pack 609 gradients into the flat
         # buffer, all-reduce 34 MB with itself, scale, unpack): the part of an N-GPU step that is not the ring itself
         try:
@@ -773,10 +735,10 @@ def main():
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
                 os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
                 torch.distributed.init_process_group("nccl", rank=0, world_size=1)
-            gs_keep, fd_keep = grad_sync, force_dp
-            grad_sync, force_dp = engine.FlatGradAllReduce(step), True
+            gs_keep, fd_keep = trainer.exchange, trainer.force_exchange
+            trainer.exchange, trainer.force_exchange = engine.FlatGradAllReduce(step), True
             dta, _, _ = timed(args.prefetch, 3, args.steps)
-            grad_sync, force_dp = gs_keep, fd_keep
+            trainer.exchange, trainer.force_exchange = gs_keep, fd_keep
             dtb, _, _ = timed(args.prefetch, 3, args.steps)
             line["ddp_overhead_ms"] = (dta - dtb) / args.steps * 1e3
             line["ddp_overhead_note"] = (f"{dta / args.steps * 1e3:.2f} ms per step with the flat exchange forced at world size 1 vs "
@@ -799,9 +761,10 @@ def main():
             copy = next((r["GBps"] for r in rows if r["op"].startswith("copy 256 MB")), None)
             line["stream_copy_GBps"] = None if copy is None else round(copy, 1)
             line["roofline_ops"] = [dict(op=r["op"], us=round(r["us"], 1), GBps=round(r["GBps"], 1), frac=round(r["frac"], 4),
-                                         **({"frac_of_stream_copy": round(r["GBps"] / copy, 3)} if copy and "pair_evals_per_s" not in r else {}),
-                                         **({"pair_evals_per_s": float(f"{r['pair_evals_per_s']:.4g}"),
-                                             "valu_frac_bruteforce_equivalent": round(r["valu_frac_bruteforce_equivalent"], 4)}
+                                         **({"frac_of_stream_copy": round(r["GBps"] / copy, 3)} if copy and "bruteforce_pairs" not in r else {}),
+                                         **({"evaluated_pairs": r["evaluated_pairs"], "pair_evals_per_s": float(f"{r['pair_evals_per_s']:.4g}"),
+                                             "valu_frac_evaluated": round(r["valu_frac_evaluated"], 4),   # evaluated candidate distances x 8 flop / time / 157.3 TFLOP/s
+                                             "pruning_factor_vs_bruteforce": round(r["pruning_factor"], 1)}
                                             if "pair_evals_per_s" in r else {}))
                                     for r in rows]
         if world == 1 and not args.no_cpu_baseline and not scannet and not strat:   # (the CPU baseline is quoted on the headline workload)

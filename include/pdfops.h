@@ -11,9 +11,10 @@
  *
  * Contract (same as the reference unless noted):
  *   - all pointers are DEVICE pointers owned by the caller; the library never allocates,
- *     never synchronises and keeps no mutable global state (re-entrant, any thread, any stream).  The only process-wide inputs
+ *     never synchronises and keeps NO mutable state -- no globals, no per-stream tables (re-entrant, any thread, any stream; since
+ *     ABI 4 the reduced-precision mode of the Linear products is a per-call argument, `mma_input` below).  The only process-wide inputs
  *     are a few read-only PDFOPS_* environment variables that select kernel variants / grid caps for experiments and tests
- *     (PDFOPS_FPS_MW, PDFOPS_KNN_*, PDFOPS_PT_BLOCKS_*, PDFOPS_PT_CAP_<pass>; defaults are the measured best);
+ *     (PDFOPS_FPS_MW, PDFOPS_KNN_*, PDFOPS_PT_BLOCKS_*, PDFOPS_PT_CAP_<pass>; defaults are the measured best), read once per process;
  *   - float data is fp32, indices/offsets are int32, `offset` arrays hold CUMULATIVE scene ends;
  *   - kNN placeholder for scenes with fewer than `nsample` points: idx = -1, dist2 = 1e10;
  *   - outputs written by plain stores need no initialisation (grouping/subtraction/
@@ -34,28 +35,26 @@ extern "C" {
 #define PDF_ERR_NSAMPLE (-2)      /* nsample outside 1..128 (reference: best_dist[128], knn_query_cuda_kernel.cu:82) */
 #define PDF_ERR_UNSUPPORTED (-3)  /* shape outside what the kernels are built for */
 
-/* version / build probe (no GPU needed) */
+/* ABI version of THIS header.  pdf_abi_version() returns the version the loaded library was built with: a caller built against another
+ * version must refuse to call (parameter lists differ; pointcloudpdf_amd/_native.py does).  History: 1 = rounds 1-3 (signatures changed
+ * without a bump, see ADVICE of round 3); 4 = round 4: `mma_input` per call on the pdf_rowlin_ / pdf_block_ / pdf_bottleneck_ / pdf_linbn_ /
+ * pdf_td_ entries, pdf_set_mma_input / pdf_get_mma_input / pdf_tickets_* removed, pdf_sgd_step takes a found-inf flag. */
+#define PDF_ABI_VERSION 4
 int pdf_abi_version(void);
 const char *pdf_build_info(void);
 /* Arithmetic of the squared distance in this library's geometry kernels (kNN, ball query, FPS): 0 = the reference's expression as
  * written in IEEE fp32 (libpdfops.so), 1 = fmaf(dz,dz,fmaf(dy,dy,dx*dx)), 2 = fmaf(dz,dz,fmaf(dx,dx,dy*dy)) (libpdfops_fma{1,2}.so:
  * the contractions an `nvcc -O2` build of knn_query_cuda_kernel.cu:92 / sampling_cuda_kernel.cu:54 may compute; csrc/pdfops_common.h). */
 int pdf_dist_fma_mode(void);
-/* In-launch reductions (the BatchNorm statistics / column-sum tails of the producing kernels instead of separate reducer launches) need
- * pdf_tickets_words() zero-initialised 32-bit words per stream, owned by the caller for as long as the stream launches through this
- * library: bind them once with pdf_tickets_bind(stream, words).  The kernels leave every word zero again.  OPT-IN (PDFOPS_TAIL=1 in the
- * environment): measured slower than the separate reducer launches on MI355X (csrc/api.hip), which stay the default -- the sums are the
- * same up to the rounding of a different, equally fixed, order of additions. */
-int pdf_tickets_words(void);
-int pdf_tickets_bind(void *stream, void *words);
-/* Reduced-precision variant of the per-point Linear layers (the reference trains this path under torch.cuda.amp.autocast:
- * configs/s3dis/openseg-pt-v1-0-msp.py:6, pointcept/engines/train.py:340-363).  mode 0 (default): fp32 operands, v_mfma_f32_16x16x4_f32 --
- * the parity path; 1: the operands of the streaming pdf_rowlin_* products (forward, input gradient, weight gradient; channel widths
- * 32..512) are rounded to fp16 in registers and multiplied with v_mfma_f32_16x16x16_f16; 2: the same with bfloat16.  Tensors stay fp32
- * in memory and every accumulation is fp32 in all modes (what autocast does to nn.Linear, minus the rounding of the OUTPUT to half).
- * Process-wide; read when a launch is issued.  Returns PDF_ERR_BAD_ARG for any other mode. */
-int pdf_set_mma_input(int mode);
-int pdf_get_mma_input(void);
+/* `mma_input` (argument of every entry that runs the streaming per-point Linear products): the reduced-precision variant the reference
+ * trains this path with (torch.cuda.amp.autocast: configs/s3dis/openseg-pt-v1-0-msp.py:6, pointcept/engines/train.py:340-363).
+ * 0: fp32 operands, v_mfma_f32_16x16x4_f32 -- the parity path; 1: the operands of the products (forward, input gradient, weight gradient;
+ * channel widths 32..512) are rounded to fp16 in registers and multiplied with v_mfma_f32_16x16x16_f16; 2: the same with bfloat16.
+ * Tensors stay fp32 in memory and every accumulation is fp32 in all modes (what autocast does to nn.Linear, minus the rounding of the
+ * OUTPUT to half).  Shapes the streaming kernels do not cover run in fp32 whatever the mode.  Any other value: PDF_ERR_BAD_ARG. */
+#define PDF_MMA_F32 0
+#define PDF_MMA_F16 1
+#define PDF_MMA_BF16 2
 
 /* replaces knn_query_cuda_launcher, libs/pointops/src/knn_query/knn_query_cuda_kernel.h:13
  * (kernel knn_query_cuda_kernel.cu:60-104).  idx (m,nsample), dist2 (m,nsample) = SQUARED distances. */
@@ -70,6 +69,12 @@ int pdf_knn_grid_supported(int nsample);
 int pdf_knn_query_ws(int m, int nsample, int n, const float *xyz, const float *new_xyz, const int *offset,
                      const int *new_offset, int b, int *idx, float *dist2, void *workspace, long workspace_bytes,
                      void *stream);
+/* measurement aid: the same with the grid kernel counting the candidate distances it evaluates (*pairs, device counter zeroed by the
+ * caller, += count).  The grid prunes by design, so "pairs per second" of this path must be quoted on EVALUATED pairs, not on the
+ * m * n_scene pairs of the brute force it replaces. */
+int pdf_knn_query_ws_counted(int m, int nsample, int n, const float *xyz, const float *new_xyz, const int *offset,
+                             const int *new_offset, int b, int *idx, float *dist2, void *workspace, long workspace_bytes,
+                             unsigned long long *pairs, void *stream);
 /* the exact scan restricted to qlist[0 .. *qcount) (device pointers); qlist == NULL: all m queries */
 int pdf_knn_query_list(int m, int nsample, const float *xyz, const float *new_xyz, const int *offset,
                        const int *new_offset, int b, int *idx, float *dist2, const int *qlist, const int *qcount,
@@ -231,13 +236,13 @@ long pdf_rowlin_partial_floats(long n, int o);
 int pdf_rowlin_partial_rows(long n, int k, int o);
 int pdf_rowlin_forward(long n, int k, int o, const float *x, long ldx, const float *w, int transpose_w,
                        const float *bias, const float *scale, const float *shift, int relu, float *y, long ldy,
-                       int accumulate, float *partial, void *stream);
+                       int accumulate, float *partial, int mma_input, void *stream);
 /* dW (o,k) = G^T f(X), db (o) = column sums of G (db may be NULL): both WRITTEN.  No float atomics: every workgroup stores its
  * partial block into a slab of ws (pdf_rowlin_wgrad_ws_floats(n, k, o, ng) floats, ng = 1 here), a second launch sums the slabs in a
  * fixed order -- bit-reproducible gradients (the reference's atomicAdd scatters are not: grouping_cuda_kernel.cu:16-25). */
 long pdf_rowlin_wgrad_ws_floats(long n, int k, int o, int ng);
 int pdf_rowlin_wgrad(long n, int k, int o, const float *g, long ldg, const float *x, long ldx,
-                     const float *scale, const float *shift, int relu, float *dw, float *db, float *ws, void *stream);
+                     const float *scale, const float *shift, int relu, float *dw, float *db, float *ws, int mma_input, void *stream);
 /* BatchNorm coefficients from column partials [rows][2c] (sum | sum of squares): coef = scale|shift|mean|rstd */
 int pdf_bn_coef_from_partial(const float *partial, int rows, long n, int c, const float *gamma, const float *beta,
                              float *running_mean, float *running_var, float eps, float momentum, float *coef, void *stream);
@@ -247,9 +252,9 @@ int pdf_bn_coef_from_partial(const float *partial, int rows, long n, int c, cons
  * pdf_rowlin_wgrad_multi: weight / bias gradients of up to three layers sharing the input x. */
 int pdf_rowlin_multi(long n, int k, int o, int nin, int nout, const float *const *x, long ldx, const float *const *w,
                      int transpose_w, const float *const *bias, const float *scale, const float *shift, int relu,
-                     float *const *y, long ldy, int accumulate, void *stream);
+                     float *const *y, long ldy, int accumulate, int mma_input, void *stream);
 int pdf_rowlin_wgrad_multi(long n, int k, int o, int ng, const float *const *g, long ldg, const float *x, long ldx,
-                           const float *scale, const float *shift, int relu, float *const *dw, float *const *db, float *ws, void *stream);
+                           const float *scale, const float *shift, int relu, float *const *dw, float *const *db, float *ws, int mma_input, void *stream);
 /* Up to five weight gradients of ONE shape (n, k, o) with their OWN inputs in one launch + one slab reduction -- the five c x c products
  * of a Bottleneck backward (linear3, q / k / v, linear1; point_transformer_seg.py:184-192): dW_i = G_i^T f_i(X_i), f_i = relu_i?(x *
  * scale_i + shift_i) where scale_i is non-null, else the identity; db_i (nullable, db itself may be null) = column sums of G_i.  Written,
@@ -257,7 +262,7 @@ int pdf_rowlin_wgrad_multi(long n, int k, int o, int ng, const float *const *g, 
  * ws: pdf_rowlin_wgrad_ws_floats(n, k, o, ng) floats. */
 int pdf_rowlin_wgrad_group(long n, int k, int o, int ng, const float *const *g, long ldg, const float *const *x, long ldx,
                            const float *const *scale, const float *const *shift, const int *relu, float *const *dw,
-                           float *const *db, float *ws, void *stream);
+                           float *const *db, float *ws, int mma_input, void *stream);
 
 /* Rigid KPConv of the StratifiedTransformer stem (stratified_transformer_v1m1_origin.py:582-662 over torch_points3d's KPConvLayer): the
  * part that is not a matrix product.  weighted[n, k, c] = sum_m max(0, 1 - |support[nb[n, m]] - query[n] - k_points[k]| / extent) *
@@ -275,13 +280,13 @@ int pdf_kpconv_scatter(int n, int m, int kp, int cin, const float *query, const 
  * finishes the BatchNorm backward without re-reading y and bx for the reduction.  PDF_ERR_UNSUPPORTED outside the streaming
  * shapes (callers then use pdf_rowlin_multi + pdf_bn_act_backward). */
 int pdf_rowlin_dgrad_bstats(long n, int k, int o, int nin, const float *const *x, long ldx, const float *const *w, float *y, long ldy,
-                            const float *bx, long ldb, const float *bcoef, int brelu, float *partial, int *partial_rows, float *sums,
-                            void *stream);   /* sums (2 o, may be NULL) + ticket words bound: finished in the launch, *partial_rows = -1 */
-/* pdf_rowlin_forward + the coefficients (scale | shift | mean | rstd) of the train-mode BatchNorm behind it, finished inside the
- * product's launch when ticket words are bound to the stream (pdf_tickets_bind), else by the finalizer launch. */
+                            const float *bx, long ldb, const float *bcoef, int brelu, float *partial, int *partial_rows,
+                            int mma_input, void *stream);
+/* pdf_rowlin_forward + the coefficients (scale | shift | mean | rstd) of the train-mode BatchNorm behind it (column sums in the
+ * product's epilogue + one finalizer launch). */
 int pdf_rowlin_forward_bn(long n, int k, int o, const float *x, long ldx, const float *w, const float *bias, const float *scale,
                           const float *shift, int relu, float *y, long ldy, float *partial, const float *gamma, const float *beta,
-                          float *running_mean, float *running_var, float eps, float momentum, float *coef, void *stream);
+                          float *running_mean, float *running_var, float eps, float momentum, float *coef, int mma_input, void *stream);
 int pdf_bn_act_backward_presummed(long n, int c, const float *gy, const float *x, const float *coef, int training, int relu,
                                   const float *partial, int partial_rows, float *sums, float *gx, void *stream);
 
@@ -290,22 +295,22 @@ int pdf_bn_act_backward_presummed(long n, int c, const float *gy, const float *x
 int pdf_bn_coef_eval_or_partial(const float *partial, int rows, long n, int c, const float *gamma, const float *beta,
                                 float *running_mean, float *running_var, int training, float eps, float momentum,
                                 float *coef, void *stream);
-int pdf_block_pre_forward(long n, int c, void *const *p, int training, float eps, float momentum, void *stream);
-int pdf_block_pre_backward(long n, int c, void *const *p, int training, void *stream);
-int pdf_block_post_forward(long n, int c, void *const *p, int training, float eps, float momentum, void *stream);
-int pdf_block_post_backward(long n, int c, void *const *p, int training, void *stream);
+int pdf_block_pre_forward(long n, int c, void *const *p, int training, float eps, float momentum, int mma_input, void *stream);
+int pdf_block_pre_backward(long n, int c, void *const *p, int training, int mma_input, void *stream);
+int pdf_block_post_forward(long n, int c, void *const *p, int training, float eps, float momentum, int mma_input, void *stream);
+int pdf_block_post_backward(long n, int c, void *const *p, int training, int mma_input, void *stream);
 /* The whole Bottleneck (both halves + the fused attention layer) as one call per direction; tables in csrc/block.hip. */
-int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p, int training, float eps, float momentum, int storage_bf16, void *stream);
-int pdf_bottleneck_backward(long n, int nsample, int c, void *const *p, int training, int entry_base, int storage_bf16, void *stream);
+int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p, int training, float eps, float momentum, int storage_bf16, int mma_input, void *stream);
+int pdf_bottleneck_backward(long n, int nsample, int c, void *const *p, int training, int entry_base, int storage_bf16, int mma_input, void *stream);
 /* Linear (+ bias) -> BatchNorm1d -> (ReLU) as one call per direction (TransitionUp, heads); tables in csrc/block.hip. */
-int pdf_linbn_forward(long n, int k, int o, void *const *p, int training, int relu, float eps, float momentum, void *stream);
-int pdf_linbn_backward(long n, int k, int o, void *const *p, int training, int relu, void *stream);
+int pdf_linbn_forward(long n, int k, int o, void *const *p, int training, int relu, float eps, float momentum, int mma_input, void *stream);
+int pdf_linbn_backward(long n, int k, int o, void *const *p, int training, int relu, int mma_input, void *stream);
 
 /* Row-weighted variants of the streaming Linear kernels and the bare BatchNorm-backward sums (building blocks of pdf_td_*). */
 int pdf_rowlin_forward_roww(long n, int k, int o, const float *x, long ldx, const float *w, int transpose_w, float *y, long ldy,
-                            int accumulate, const float *roww, long rws, void *stream);
+                            int accumulate, const float *roww, long rws, int mma_input, void *stream);
 int pdf_rowlin_wgrad_roww(long n, int k, int o, const float *g, long ldg, const float *x, long ldx, float *dw, const float *roww,
-                          long rws, float *ws, void *stream);
+                          long rws, float *ws, int mma_input, void *stream);
 int pdf_bn_bwd_sums(long n, int c, const float *gy, const float *x, const float *coef, int relu, float *partial, float *sums,
                     void *stream);
 
@@ -321,8 +326,8 @@ int pdf_td_tables(long m, int b, const float *p_src, const float *p_new, const i
 long pdf_td_gram_floats(int cin);
 long pdf_td_fwd_scratch_floats(long n, int cin);
 long pdf_td_bwd_scratch_floats(long m, int cin, int cout);
-int pdf_td_forward(long n, long m, int cin, int cout, void *const *p, int training, float eps, float momentum, void *stream);
-int pdf_td_backward(long n, long m, int cin, int cout, void *const *p, int entry_base, void *stream);
+int pdf_td_forward(long n, long m, int cin, int cout, void *const *p, int training, float eps, float momentum, int mma_input, void *stream);
+int pdf_td_backward(long n, long m, int cin, int cout, void *const *p, int entry_base, int mma_input, void *stream);
 
 /* ---- scatter-adds as segmented gathers over an inverse neighbour table (csrc/seg_gather.hip; no reference counterpart: the reference
  * scatters with atomicAdd -- grouping_cuda_kernel.cu:20-25, interpolation_cuda_kernel.cu:27-33, subtraction_cuda_kernel.cu:24-30,
@@ -368,9 +373,19 @@ int pdf_knn_rel_moments_q(int b, long m, int nsample, const float *xyz, const fl
 /* SGD with momentum and weight decay (torch.optim.SGD, dampening 0, no Nesterov -- the optimizer the reference's configs build,
  * pointcept/utils/optimizer.py + configs/s3dis/openseg-pt-v1-0-*.py) over every parameter tensor in ONE launch.  tab: ntensors records
  * {float *param; const float *grad; float *momentum; long length} in device memory; chunks: nchunks {tensor, chunk} int32 pairs, one
- * per pdf_sgd_chunk() values of a tensor.  param / momentum are updated in place. */
+ * per pdf_sgd_chunk() values of a tensor.  param / momentum are updated in place.
+ * found_inf (device float, may be NULL): non-zero = the step is skipped as a whole (a GradScaler step that saw a non-finite gradient). */
 int pdf_sgd_chunk(void);
-int pdf_sgd_step(int nchunks, const void *tab, const int *chunks, float lr, float momentum, float weight_decay, void *stream);
+int pdf_sgd_step(int nchunks, const void *tab, const int *chunks, float lr, float momentum, float weight_decay, const float *found_inf,
+                 void *stream);
+/* Dynamic loss scaling of the reference's AMP training (torch.cuda.amp.GradScaler, pointcept/engines/train.py:340-363) with every decision
+ * on the device, so that a captured step replays: pdf_grad_unscale multiplies every gradient of the table (pdf_sgd_step's layout) by
+ * *inv_scale in place and sets *found_inf = 1 when any value is inf / nan (found_inf must be 0 on entry); pdf_scaler_update applies
+ * GradScaler.update(): found_inf -> scale *= backoff_factor, growth_tracker = 0; else growth_tracker += 1 and after growth_interval clean
+ * steps scale *= growth_factor; leaves inv_scale = 1 / scale and found_inf = 0.  All four words are caller-owned device scalars. */
+int pdf_grad_unscale(int nchunks, const void *tab, const int *chunks, const float *inv_scale, float *found_inf, void *stream);
+int pdf_scaler_update(float *scale, float *inv_scale, int *growth_tracker, float *found_inf, float growth_factor, float backoff_factor,
+                      int growth_interval, void *stream);
 
 /* ---- libs/pointops2 window attention: the CSR-by-query v2 / v3 launchers of
  * libs/pointops2/src/attention_v2/attention_cuda_kernel_v2.h and libs/pointops2/src/rpe_v2/relative_pos_encoding_cuda_kernel_v2.h,

@@ -26,6 +26,7 @@ def library_path(dist_fma=0):
 
 
 LIB_PATH = library_path(DIST_FMA)
+ABI_VERSION = 4   # include/pdfops.h: PDF_ABI_VERSION (the argtypes below are THIS version's parameter lists)
 
 c_int = ctypes.c_int
 c_long = ctypes.c_long
@@ -94,27 +95,11 @@ class PdfOpsError(RuntimeError):
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None) if os.environ.get("PDFOPS_RAW_STREAM", "1") != "0" else None
 
 
-_TICKETS = {}   # (device, stream handle) -> the stream's zero-initialised ticket words (in-launch reductions, include/pdfops.h: pdf_tickets_bind)
-
-
-def _bind_tickets(dev, handle):
-    be = hip_backend()
-    words = torch.zeros((int(be.lib.pdf_tickets_words()),), dtype=torch.int32, device=torch.device("cuda", dev))
-    rc = be.lib.pdf_tickets_bind(c_void_p(handle), c_void_p(words.data_ptr()))
-    if rc != 0:
-        raise PdfOpsError(f"pdf_tickets_bind failed with status {rc}")
-    _TICKETS[(dev, handle)] = words
-
-
 def raw_stream():
     """hipStream_t (as an integer) of torch's current stream on the current device.  ``torch.cuda.current_stream().cuda_stream`` builds a
-    Stream object per call (~12 us; ~60 calls per training step); the raw accessor torch's own code generators use takes < 1 us.
-    Every stream that launches through the library gets its ticket words bound on first use."""
+    Stream object per call (~12 us; ~60 calls per training step); the raw accessor torch's own code generators use takes < 1 us."""
     dev = torch.cuda.current_device()
-    h = _RAW_STREAM(dev) if _RAW_STREAM is not None else torch.cuda.current_stream().cuda_stream
-    if (dev, h) not in _TICKETS:
-        _bind_tickets(dev, h)
-    return h
+    return _RAW_STREAM(dev) if _RAW_STREAM is not None else torch.cuda.current_stream().cuda_stream
 
 
 def require_current_device(*tensors):
@@ -530,10 +515,14 @@ class HipBackend(CBackend):
         self.last_fps_stats = None
         lib.pdf_abi_version.restype = c_int
         lib.pdf_build_info.restype = ctypes.c_char_p
+        got = int(lib.pdf_abi_version())
+        if got != ABI_VERSION:   # parameter lists differ between versions: calling through would hand shifted arguments to the kernels
+            raise PdfOpsError(f"libpdfops ABI {got} != {ABI_VERSION} expected by pointcloudpdf_amd/_native.py (include/pdfops.h: PDF_ABI_VERSION): "
+                              "stale library -- rebuild with `python -m pointcloudpdf_amd.build --force`")
         for nm in ("pre_forward", "post_forward"):
             f = getattr(lib, "pdf_block_" + nm)
             f.restype = c_int
-            f.argtypes = [c_long, c_int, c_void_p, c_int, ctypes.c_float, ctypes.c_float, c_void_p]
+            f.argtypes = [c_long, c_int, c_void_p, c_int, ctypes.c_float, ctypes.c_float, c_int, c_void_p]
         lib.pdf_td_tables.restype = c_int
         lib.pdf_td_tables.argtypes = [c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p,
                                       c_int, c_void_p]
@@ -546,9 +535,9 @@ class HipBackend(CBackend):
         lib.pdf_td_bwd_scratch_floats.restype = c_long
         lib.pdf_td_bwd_scratch_floats.argtypes = [c_long, c_int, c_int]
         lib.pdf_td_forward.restype = c_int
-        lib.pdf_td_forward.argtypes = [c_long, c_long, c_int, c_int, c_void_p, c_int, ctypes.c_float, ctypes.c_float, c_void_p]
+        lib.pdf_td_forward.argtypes = [c_long, c_long, c_int, c_int, c_void_p, c_int, ctypes.c_float, ctypes.c_float, c_int, c_void_p]
         lib.pdf_td_backward.restype = c_int
-        lib.pdf_td_backward.argtypes = [c_long, c_long, c_int, c_int, c_void_p, c_int, c_void_p]
+        lib.pdf_td_backward.argtypes = [c_long, c_long, c_int, c_int, c_void_p, c_int, c_int, c_void_p]
         lib.pdf_ce_workspace_floats.restype = c_long
         lib.pdf_ce_workspace_floats.argtypes = []
         lib.pdf_ce_forward.restype = c_int
@@ -568,33 +557,29 @@ class HipBackend(CBackend):
         self.CopySeg = CopySeg
         lib.pdf_stage_copy.restype = c_int
         lib.pdf_stage_copy.argtypes = [c_int, c_void_p, c_void_p]
-        lib.pdf_tickets_words.restype = c_int
-        lib.pdf_tickets_words.argtypes = []
-        lib.pdf_tickets_bind.restype = c_int
-        lib.pdf_tickets_bind.argtypes = [c_void_p, c_void_p]
-        lib.pdf_set_mma_input.restype = c_int
-        lib.pdf_set_mma_input.argtypes = [c_int]
-        lib.pdf_get_mma_input.restype = c_int
-        lib.pdf_get_mma_input.argtypes = []
         lib.pdf_sgd_chunk.restype = c_int
         lib.pdf_sgd_chunk.argtypes = []
         lib.pdf_sgd_step.restype = c_int
-        lib.pdf_sgd_step.argtypes = [c_int, c_void_p, c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_void_p]
+        lib.pdf_sgd_step.argtypes = [c_int, c_void_p, c_void_p, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_void_p, c_void_p]
+        lib.pdf_grad_unscale.restype = c_int
+        lib.pdf_grad_unscale.argtypes = [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+        lib.pdf_scaler_update.restype = c_int
+        lib.pdf_scaler_update.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, ctypes.c_float, c_int, c_void_p]
         lib.pdf_linbn_forward.restype = c_int
-        lib.pdf_linbn_forward.argtypes = [c_long, c_int, c_int, c_void_p, c_int, c_int, ctypes.c_float, ctypes.c_float, c_void_p]
+        lib.pdf_linbn_forward.argtypes = [c_long, c_int, c_int, c_void_p, c_int, c_int, ctypes.c_float, ctypes.c_float, c_int, c_void_p]
         lib.pdf_linbn_backward.restype = c_int
-        lib.pdf_linbn_backward.argtypes = [c_long, c_int, c_int, c_void_p, c_int, c_int, c_void_p]
+        lib.pdf_linbn_backward.argtypes = [c_long, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]
         lib.pdf_bottleneck_forward.restype = c_int
-        lib.pdf_bottleneck_forward.argtypes = [c_long, c_int, c_int, c_void_p, c_int, ctypes.c_float, ctypes.c_float, c_int, c_void_p]
+        lib.pdf_bottleneck_forward.argtypes = [c_long, c_int, c_int, c_void_p, c_int, ctypes.c_float, ctypes.c_float, c_int, c_int, c_void_p]
         lib.pdf_bottleneck_backward.restype = c_int
-        lib.pdf_bottleneck_backward.argtypes = [c_long, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]
+        lib.pdf_bottleneck_backward.argtypes = [c_long, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
         for nm in ("pre_backward", "post_backward"):
             f = getattr(lib, "pdf_block_" + nm)
             f.restype = c_int
-            f.argtypes = [c_long, c_int, c_void_p, c_int, c_void_p]
+            f.argtypes = [c_long, c_int, c_void_p, c_int, c_int, c_void_p]
         lib.pdf_rowlin_multi.restype = c_int
         lib.pdf_rowlin_multi.argtypes = [c_long, c_int, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
-                                         c_int, c_void_p, c_long, c_int, c_void_p]
+                                         c_int, c_void_p, c_long, c_int, c_int, c_void_p]
         lib.pdf_kpconv_supported.restype = c_int
         lib.pdf_kpconv_supported.argtypes = [c_int, c_int]
         for nm in ("pdf_kpconv_gather", "pdf_kpconv_scatter"):
@@ -603,15 +588,15 @@ class HipBackend(CBackend):
             f.argtypes = [c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p, c_void_p]
         lib.pdf_rowlin_wgrad_group.restype = c_int
         lib.pdf_rowlin_wgrad_group.argtypes = [c_long, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p,
-                                               c_void_p, c_void_p, c_void_p, c_void_p]
+                                               c_void_p, c_void_p, c_void_p, c_int, c_void_p]
         lib.pdf_rowlin_wgrad_multi.restype = c_int
         lib.pdf_rowlin_wgrad_multi.argtypes = [c_long, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int,
-                                               c_void_p, c_void_p, c_void_p, c_void_p]
+                                               c_void_p, c_void_p, c_void_p, c_int, c_void_p]
         lib.pdf_rowlin_wgrad_ws_floats.restype = c_long
         lib.pdf_rowlin_wgrad_ws_floats.argtypes = [c_long, c_int, c_int, c_int]
         lib.pdf_rowlin_dgrad_bstats.restype = c_int
         lib.pdf_rowlin_dgrad_bstats.argtypes = [c_long, c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_long,
-                                                c_void_p, c_int, c_void_p, ctypes.POINTER(c_int), c_void_p, c_void_p]
+                                                c_void_p, c_int, c_void_p, ctypes.POINTER(c_int), c_int, c_void_p]
         lib.pdf_bn_act_backward_presummed.restype = c_int
         lib.pdf_bn_act_backward_presummed.argtypes = [c_long, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
                                                       c_void_p, c_void_p]
@@ -621,10 +606,10 @@ class HipBackend(CBackend):
         lib.pdf_rowlin_partial_rows.argtypes = [c_long, c_int, c_int]
         lib.pdf_rowlin_forward.restype = c_int
         lib.pdf_rowlin_forward.argtypes = [c_long, c_int, c_int, c_void_p, c_long, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
-                                           c_int, c_void_p, c_long, c_int, c_void_p, c_void_p]
+                                           c_int, c_void_p, c_long, c_int, c_void_p, c_int, c_void_p]
         lib.pdf_rowlin_wgrad.restype = c_int
         lib.pdf_rowlin_wgrad.argtypes = [c_long, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int,
-                                         c_void_p, c_void_p, c_void_p, c_void_p]
+                                         c_void_p, c_void_p, c_void_p, c_int, c_void_p]
         lib.pdf_bn_coef_from_partial.restype = c_int
         lib.pdf_bn_coef_from_partial.argtypes = [c_void_p, c_int, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                                  ctypes.c_float, ctypes.c_float, c_void_p, c_void_p]
@@ -660,6 +645,8 @@ class HipBackend(CBackend):
         lib.pdf_knn_grid_supported.argtypes = [c_int]
         lib.pdf_knn_query_ws.restype = c_int
         lib.pdf_knn_query_ws.argtypes = [c_int, c_int, c_int] + [c_void_p] * 4 + [c_int] + [c_void_p] * 3 + [c_long, c_void_p]
+        lib.pdf_knn_query_ws_counted.restype = c_int
+        lib.pdf_knn_query_ws_counted.argtypes = [c_int, c_int, c_int] + [c_void_p] * 4 + [c_int] + [c_void_p] * 3 + [c_long, c_void_p, c_void_p]
 
     KNN_GRID_MAX_SCENES = 64
     # scatter-adds of the gather family as segmented gathers over inverse tables (PDFOPS_INVERSE=0: the atomic kernels, for A/B runs)
@@ -782,6 +769,23 @@ class HipBackend(CBackend):
         if rc != 0:
             raise PdfOpsError(f"pdf_knn_query_ws failed with status {rc}")
         return idx, dist2
+
+    def knn_query_counted(self, nsample, xyz, new_xyz, offset, new_offset):
+        """Measurement aid: the grid kNN with its kernel counting the candidate distances it evaluates -> (idx, dist2, evaluated pairs)
+        (one host read-back).  tools/ops_roofline.py prices the kernel against the fp32 vector peak with this count."""
+        n, m, b = xyz.shape[0], new_xyz.shape[0], offset.shape[0]
+        require_current_device(xyz, new_xyz, offset, new_offset)
+        idx = self._new(xyz, (m, nsample), torch.int32)
+        dist2 = self._new(xyz, (m, nsample), torch.float32)
+        nbytes = int(self.lib.pdf_knn_workspace_bytes(b, n, m))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=xyz.device)
+        pairs = torch.zeros((1,), dtype=torch.int64, device=xyz.device)
+        rc = self.lib.pdf_knn_query_ws_counted(m, int(nsample), n, self._ptr(xyz), self._ptr(new_xyz), self._ptr(offset),
+                                               self._ptr(new_offset), b, self._ptr(idx), self._ptr(dist2), self._ptr(ws), nbytes,
+                                               self._ptr(pairs), c_void_p(raw_stream()))
+        if rc != 0:
+            raise PdfOpsError(f"pdf_knn_query_ws_counted failed with status {rc}")
+        return idx, dist2, int(pairs.item())
 
     def farthest_point_sampling(self, xyz, offset, new_offset, n_max, m_total):
         if self.fps_mode == "plain":
@@ -920,7 +924,7 @@ class HipBackend(CBackend):
                                          None if bias is None else bias.data_ptr(),
                                          None if coef is None else coef.data_ptr(),
                                          None if coef is None else coef.data_ptr() + 4 * k, int(relu), y.data_ptr(), y.stride(0),
-                                         int(accumulate), None if partial is None else partial.data_ptr(), self._stream())
+                                         int(accumulate), None if partial is None else partial.data_ptr(), current_mma_input(), self._stream())
         if rc != 0:
             raise PdfOpsError(f"pdf_rowlin_forward failed with status {rc}")
         return y, partial
@@ -937,7 +941,7 @@ class HipBackend(CBackend):
         rc = self.lib.pdf_rowlin_multi(n, k, o, len(xs), nout, self._ptrs(xs), xs[0].stride(0), self._ptrs(ws), int(transpose_w),
                                        None if biases is None else self._ptrs(biases),
                                        None if coef is None else coef.data_ptr(), None if coef is None else coef.data_ptr() + 4 * k,
-                                       int(relu), self._ptrs(ys), o, 0, self._stream())
+                                       int(relu), self._ptrs(ys), o, 0, current_mma_input(), self._stream())
         if rc != 0:
             raise PdfOpsError(f"pdf_rowlin_multi failed with status {rc}")
         return ys
@@ -955,7 +959,7 @@ class HipBackend(CBackend):
         sums = self._new(bx, (2 * o,), torch.float32)
         rc = self.lib.pdf_rowlin_dgrad_bstats(n, k, o, len(gs), self._ptrs(gs), gs[0].stride(0), self._ptrs(ws), dy.data_ptr(), o,
                                               bx.data_ptr(), bx.stride(0), coef.data_ptr(), int(bool(relu)), partial.data_ptr(),
-                                              ctypes.byref(rows), sums.data_ptr(), self._stream())
+                                              ctypes.byref(rows), current_mma_input(), self._stream())
         if rc == -3:   # PDF_ERR_UNSUPPORTED
             return None
         if rc != 0:
@@ -978,7 +982,7 @@ class HipBackend(CBackend):
         ws = self.wgrad_workspace(n, k, o, len(gs), x.device)
         rc = self.lib.pdf_rowlin_wgrad_multi(n, k, o, len(gs), self._ptrs(gs), gs[0].stride(0), x.data_ptr(), x.stride(0),
                                              None if coef is None else coef.data_ptr(), None if coef is None else coef.data_ptr() + 4 * k,
-                                             int(relu), self._ptrs(dws), self._ptrs(dbs), ws.data_ptr(), self._stream())
+                                             int(relu), self._ptrs(dws), self._ptrs(dbs), ws.data_ptr(), current_mma_input(), self._stream())
         if rc != 0:
             raise PdfOpsError(f"pdf_rowlin_wgrad_multi failed with status {rc}")
         return dws, dbs
@@ -1022,7 +1026,7 @@ class HipBackend(CBackend):
         sc = [None if cf is None else cf.data_ptr() for cf in coefs]
         sh = [None if cf is None else cf.data_ptr() + 4 * k for cf in coefs]
         rc = self.lib.pdf_rowlin_wgrad_group(n, k, o, len(gs), P(gs), gs[0].stride(0), P(xs), xs[0].stride(0), P(sc), P(sh),
-                                             (c_int * len(gs))(*[int(bool(r)) for r in relus]), P(dws), P(dbs), ws.data_ptr(), self._stream())
+                                             (c_int * len(gs))(*[int(bool(r)) for r in relus]), P(dws), P(dbs), ws.data_ptr(), current_mma_input(), self._stream())
         if rc == -3:   # PDF_ERR_UNSUPPORTED
             return None
         if rc != 0:
@@ -1038,7 +1042,7 @@ class HipBackend(CBackend):
         rc = self.lib.pdf_rowlin_wgrad(n, k, o, g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0),
                                        None if coef is None else coef.data_ptr(),
                                        None if coef is None else coef.data_ptr() + 4 * k, int(relu), dw.data_ptr(),
-                                       None if db is None else db.data_ptr(), ws.data_ptr(), self._stream())
+                                       None if db is None else db.data_ptr(), ws.data_ptr(), current_mma_input(), self._stream())
         if rc != 0:
             raise PdfOpsError(f"pdf_rowlin_wgrad failed with status {rc}")
         return dw, db
@@ -1100,12 +1104,12 @@ class HipBackend(CBackend):
     # -- whole Bottleneck as one host call per direction (csrc/block.hip); thin methods so that bench.py can time them
     def bottleneck_forward(self, n, k, c, ptrs, training, eps, momentum, storage_bf16=0):
         rc = self.lib.pdf_bottleneck_forward(n, k, c, (c_void_p * len(ptrs))(*ptrs), int(training), ctypes.c_float(eps),
-                                             ctypes.c_float(momentum), self.layer_flags(storage_bf16), self._stream())
+                                             ctypes.c_float(momentum), self.layer_flags(storage_bf16), current_mma_input(), self._stream())
         if rc != 0:
             raise PdfOpsError(f"pdf_bottleneck_forward failed with status {rc}")
 
     def bottleneck_backward(self, n, k, c, ptrs, training, entry_base=0, storage_bf16=0):
-        rc = self.lib.pdf_bottleneck_backward(n, k, c, (c_void_p * len(ptrs))(*ptrs), int(training), int(entry_base), self.layer_flags(storage_bf16), self._stream())
+        rc = self.lib.pdf_bottleneck_backward(n, k, c, (c_void_p * len(ptrs))(*ptrs), int(training), int(entry_base), self.layer_flags(storage_bf16), current_mma_input(), self._stream())
         if rc != 0:
             raise PdfOpsError(f"pdf_bottleneck_backward failed with status {rc}")
 
@@ -1116,9 +1120,9 @@ class HipBackend(CBackend):
     def block_call(self, name, n, c, tensors, training, eps=None, momentum=None):
         fn = getattr(self.lib, "pdf_block_" + name)
         if eps is None:
-            rc = fn(n, c, self._ptable(tensors), int(bool(training)), self._stream())
+            rc = fn(n, c, self._ptable(tensors), int(bool(training)), current_mma_input(), self._stream())
         else:
-            rc = fn(n, c, self._ptable(tensors), int(bool(training)), ctypes.c_float(eps), ctypes.c_float(momentum), self._stream())
+            rc = fn(n, c, self._ptable(tensors), int(bool(training)), ctypes.c_float(eps), ctypes.c_float(momentum), current_mma_input(), self._stream())
         if rc != 0:
             raise PdfOpsError(f"pdf_block_{name} failed with status {rc}")
 
@@ -1249,41 +1253,35 @@ def hip_backend():
     return _hip
 
 
-# Input precision of the matrix-core products of the streaming Linear kernels (include/pdfops.h: pdf_set_mma_input): 0 fp32 operands (the
-# parity path), 1 fp16, 2 bfloat16 -- fp32 storage and accumulation in every mode.  ``dense.fp32_path`` selects 1 / 2 for a forward that
-# runs under torch.autocast(float16 / bfloat16); every autograd node remembers the mode of its forward and restores it for its backward.
-_MMA_INPUT = 0
+# Input precision of the matrix-core products of the streaming Linear kernels (include/pdfops.h: `mma_input`): 0 fp32 operands (the
+# parity path), 1 fp16, 2 bfloat16 -- fp32 storage and accumulation in every mode.  The mode is an ARGUMENT of every C entry point that
+# runs those products; on the Python side it is state of the CALLING THREAD (a thread-local, so a forward on one thread and an autograd
+# backward on another never see each other's mode -- round 3 kept it in a process-wide word inside the library).  ``dense.fp32_path``
+# selects 1 / 2 for a forward that runs under torch.autocast(float16 / bfloat16); every autograd node remembers the mode of its forward
+# and runs its backward in it.
+_MMA = threading.local()
 MMA_INPUT_OF_DTYPE = {torch.float16: 1, torch.bfloat16: 2}
 
 
 def current_mma_input():
-    return _MMA_INPUT
-
-
-def _apply_mma_input(mode):
-    global _MMA_INPUT
-    if _hip is not None or (_override is None and torch.cuda.is_available()):
-        rc = hip_backend().lib.pdf_set_mma_input(int(mode))
-        if rc != 0:
-            raise PdfOpsError(f"pdf_set_mma_input({mode}) failed with status {rc}")
-    _MMA_INPUT = int(mode)
+    return getattr(_MMA, "mode", 0)
 
 
 class mma_input:
-    """``with mma_input(mode):`` -- the library's product-input mode for the launches issued inside (no-op when it is already set)."""
+    """``with mma_input(mode):`` -- product-input mode of the launches this THREAD issues inside the block."""
 
     def __init__(self, mode):
         self.mode = int(mode)
+        if self.mode not in (0, 1, 2):
+            raise PdfOpsError(f"mma_input({mode}): expected 0 (fp32), 1 (fp16) or 2 (bfloat16) operands")
 
     def __enter__(self):
-        self.prev = _MMA_INPUT
-        if self.mode != self.prev:
-            _apply_mma_input(self.mode)
+        self.prev = current_mma_input()
+        _MMA.mode = self.mode
         return self
 
     def __exit__(self, *exc):
-        if self.mode != self.prev:
-            _apply_mma_input(self.prev)
+        _MMA.mode = self.prev
         return False
 
 

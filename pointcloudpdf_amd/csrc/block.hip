@@ -28,7 +28,7 @@ extern "C" int pdf_bn_coef_eval_or_partial(const float *partial, int rows, long 
 
 // p[]: x, W1, gamma1, beta1, rm1, rv1, Wq, bq, Wk, bk, Wv, bv           (inputs)
 //      z1, coef1 (4c), xq, xk, xv, partial (pdf_rowlin_partial_floats(n, c))   (outputs / scratch)
-extern "C" int pdf_block_pre_forward(long n, int c, void *const *p, int training, float eps, float momentum, void *stream) {
+extern "C" int pdf_block_pre_forward(long n, int c, void *const *p, int training, float eps, float momentum, int mma_input, void *stream) {
     if (n < 1 || !p) return PDF_ERR_BAD_ARG;
     if (!pdf_bn_supported(c)) return PDF_ERR_UNSUPPORTED;
     const float *x = (const float *)p[0], *W1 = (const float *)p[1], *g1 = (const float *)p[2], *b1 = (const float *)p[3];
@@ -36,15 +36,15 @@ extern "C" int pdf_block_pre_forward(long n, int c, void *const *p, int training
     float *z1 = (float *)p[12], *coef1 = (float *)p[13], *partial = (float *)p[17];
     Err e;
     if (training) {
-        e << pdf_rowlin_forward_bn(n, c, c, x, c, W1, nullptr, nullptr, nullptr, 0, z1, c, partial, g1, b1, rm1, rv1, eps, momentum, coef1, stream);
+        e << pdf_rowlin_forward_bn(n, c, c, x, c, W1, nullptr, nullptr, nullptr, 0, z1, c, partial, g1, b1, rm1, rv1, eps, momentum, coef1, mma_input, stream);
     } else {
-        e << pdf_rowlin_forward(n, c, c, x, c, W1, 0, nullptr, nullptr, nullptr, 0, z1, c, 0, nullptr, stream);
+        e << pdf_rowlin_forward(n, c, c, x, c, W1, 0, nullptr, nullptr, nullptr, 0, z1, c, 0, nullptr, mma_input, stream);
         e << pdf_bn_coef_eval_or_partial(partial, 0, n, c, g1, b1, rm1, rv1, 0, eps, momentum, coef1, stream);
     }
     const float *xs[1] = {z1}, *ws[3] = {(const float *)p[6], (const float *)p[8], (const float *)p[10]};
     const float *bs[3] = {(const float *)p[7], (const float *)p[9], (const float *)p[11]};
     float *ys[3] = {(float *)p[14], (float *)p[15], (float *)p[16]};
-    e << pdf_rowlin_multi(n, c, c, 1, 3, xs, c, ws, 0, bs, coef1, coef1 + c, 1, ys, c, 0, stream);
+    e << pdf_rowlin_multi(n, c, c, 1, 3, xs, c, ws, 0, bs, coef1, coef1 + c, 1, ys, c, 0, mma_input, stream);
     return e.rc;
 }
 
@@ -59,7 +59,7 @@ static bool dgrad_bstats() {   // PDFOPS_DGRAD_BSTATS=0: BatchNorm-backward sums
 
 // defer_wgrad: the three weight-gradient products (q / k / v, linear1) are left to the caller (pdf_bottleneck_backward issues them together
 // with linear3's in ONE grouped launch); their inputs -- g_xq / g_xk / g_xv, z1 + coef1, dy, x -- stay untouched until then.
-static int block_pre_backward(long n, int c, void *const *p, int training, int accumulate_gx, void *stream, bool defer_wgrad = false) {
+static int block_pre_backward(long n, int c, void *const *p, int training, int accumulate_gx, int mma_input, void *stream, bool defer_wgrad = false) {
     if (n < 1 || !p || !p[14]) return PDF_ERR_BAD_ARG;
     const float *x = (const float *)p[0], *z1 = (const float *)p[1], *coef1 = (const float *)p[2], *W1 = (const float *)p[3];
     float *gx = (float *)p[10], *grads = (float *)p[11], *dy = (float *)p[12], *partial = (float *)p[13], *wslab = (float *)p[14];
@@ -70,30 +70,30 @@ static int block_pre_backward(long n, int c, void *const *p, int training, int a
     const float *ws[3] = {(const float *)p[4], (const float *)p[5], (const float *)p[6]};
     float *dws[3] = {dqkv, dqkv + (cc + c), dqkv + 2 * (cc + c)}, *dbs[3] = {dqkv + cc, dqkv + (cc + c) + cc, dqkv + 2 * (cc + c) + cc};
     float *ys[1] = {dy};
-    if (!defer_wgrad) e << pdf_rowlin_wgrad_multi(n, c, c, 3, gs, c, z1, c, coef1, coef1 + c, 1, dws, dbs, wslab, stream);   // g_xq / g_xk / g_xv are final here
+    if (!defer_wgrad) e << pdf_rowlin_wgrad_multi(n, c, c, 3, gs, c, z1, c, coef1, coef1 + c, 1, dws, dbs, wslab, mma_input, stream);   // g_xq / g_xk / g_xv are final here
     // bn1 backward in place on dy (elementwise: same index read and written); its column sums ARE [d beta1 | d gamma1].  The sums come
     // out of the input-gradient product's epilogue where the streaming kernel covers the shape, else from a pass over dy and z1.
     int prow = 0;
-    const int rc1 = dgrad_bstats() ? pdf_rowlin_dgrad_bstats(n, c, c, 3, gs, c, ws, dy, c, z1, c, coef1, 1, partial, &prow, db1, stream) : PDF_ERR_UNSUPPORTED;
+    const int rc1 = dgrad_bstats() ? pdf_rowlin_dgrad_bstats(n, c, c, 3, gs, c, ws, dy, c, z1, c, coef1, 1, partial, &prow, mma_input, stream) : PDF_ERR_UNSUPPORTED;
     if (rc1 == PDF_ERR_UNSUPPORTED) {
-        e << pdf_rowlin_multi(n, c, c, 3, 1, gs, c, ws, 1, nullptr, nullptr, nullptr, 0, ys, c, 0, stream);
+        e << pdf_rowlin_multi(n, c, c, 3, 1, gs, c, ws, 1, nullptr, nullptr, nullptr, 0, ys, c, 0, mma_input, stream);
         e << pdf_bn_act_backward(n, c, dy, z1, nullptr, coef1, training, 1, partial, db1, dy, nullptr, stream);   // (the atomic variant: 782 blocks on 64 addresses, +13 us)
     } else {
         e << rc1;
         e << pdf_bn_act_backward_presummed(n, c, dy, z1, coef1, training, 1, partial, prow, db1, dy, stream);
     }
-    if (!defer_wgrad) e << pdf_rowlin_wgrad(n, c, c, dy, c, x, c, nullptr, nullptr, 0, dW1, nullptr, wslab, stream);   // dW1 needs the finished dy (after the q/k/v reduction in stream order)
-    e << pdf_rowlin_forward(n, c, c, dy, c, W1, 1, nullptr, nullptr, nullptr, 0, gx, c, accumulate_gx, nullptr, stream);
+    if (!defer_wgrad) e << pdf_rowlin_wgrad(n, c, c, dy, c, x, c, nullptr, nullptr, 0, dW1, nullptr, wslab, mma_input, stream);   // dW1 needs the finished dy (after the q/k/v reduction in stream order)
+    e << pdf_rowlin_forward(n, c, c, dy, c, W1, 1, nullptr, nullptr, nullptr, 0, gx, c, accumulate_gx, nullptr, mma_input, stream);
     return e.rc;
 }
 
-extern "C" int pdf_block_pre_backward(long n, int c, void *const *p, int training, void *stream) {
-    return block_pre_backward(n, c, p, training, 0, stream, false);
+extern "C" int pdf_block_pre_backward(long n, int c, void *const *p, int training, int mma_input, void *stream) {
+    return block_pre_backward(n, c, p, training, 0, mma_input, stream, false);
 }
 
 // p[]: t, x (identity), gamma2, beta2, rm2, rv2, W3, gamma3, beta3, rm3, rv3        (inputs)
 //      coef2 (4c), z3, coef3 (4c), y, partial (max(pdf_bn_partial_floats, pdf_rowlin_partial_floats))   (outputs / scratch)
-extern "C" int pdf_block_post_forward(long n, int c, void *const *p, int training, float eps, float momentum, void *stream) {
+extern "C" int pdf_block_post_forward(long n, int c, void *const *p, int training, float eps, float momentum, int mma_input, void *stream) {
     if (n < 1 || !p) return PDF_ERR_BAD_ARG;
     if (!pdf_bn_supported(c)) return PDF_ERR_UNSUPPORTED;
     const float *t = (const float *)p[0], *x = (const float *)p[1];
@@ -102,9 +102,9 @@ extern "C" int pdf_block_post_forward(long n, int c, void *const *p, int trainin
     e << pdf_bn_coef(n, c, t, (const float *)p[2], (const float *)p[3], (float *)p[4], (float *)p[5], training, eps, momentum, coef2, partial, stream);
     if (training) {
         e << pdf_rowlin_forward_bn(n, c, c, t, c, (const float *)p[6], nullptr, coef2, coef2 + c, 1, z3, c, partial, (const float *)p[7], (const float *)p[8],
-                                   (float *)p[9], (float *)p[10], eps, momentum, coef3, stream);
+                                   (float *)p[9], (float *)p[10], eps, momentum, coef3, mma_input, stream);
     } else {
-        e << pdf_rowlin_forward(n, c, c, t, c, (const float *)p[6], 0, nullptr, coef2, coef2 + c, 1, z3, c, 0, nullptr, stream);
+        e << pdf_rowlin_forward(n, c, c, t, c, (const float *)p[6], 0, nullptr, coef2, coef2 + c, 1, z3, c, 0, nullptr, mma_input, stream);
         e << pdf_bn_coef_eval_or_partial(partial, 0, n, c, (const float *)p[7], (const float *)p[8], (float *)p[9], (float *)p[10], 0, eps, momentum, coef3, stream);
     }
     e << pdf_bn_apply(n, c, z3, x, coef3, 1, y, stream);
@@ -115,7 +115,7 @@ extern "C" int pdf_block_post_forward(long n, int c, void *const *p, int trainin
 //      gt, gres, grads [dW3 (c*c) | dbeta2 | dgamma2 | dbeta3 | dgamma3]             (outputs; every element is WRITTEN: no zeroing)
 //      da (n*c), partial (max(pdf_bn_partial_floats(n, c), pdf_rowlin_partial_floats(n, c)))   (scratch)
 //      p[12] = workspace of the weight-gradient slabs, pdf_rowlin_wgrad_ws_floats(n, c, c, 1) floats
-static int block_post_backward(long n, int c, void *const *p, int training, void *stream, bool defer_wgrad = false) {
+static int block_post_backward(long n, int c, void *const *p, int training, int mma_input, void *stream, bool defer_wgrad = false) {
     if (n < 1 || !p || !p[12]) return PDF_ERR_BAD_ARG;
     const float *gy = (const float *)p[0], *t = (const float *)p[1], *x = (const float *)p[2], *z3 = (const float *)p[3];
     const float *coef2 = (const float *)p[4], *coef3 = (const float *)p[5], *W3 = (const float *)p[6];
@@ -125,13 +125,13 @@ static int block_post_backward(long n, int c, void *const *p, int training, void
     Err e;
     // bn3 backward: gz3 -> da (scratch), gres; column sums land in the gradient slots [d beta | d gamma]
     e << pdf_bn_act_backward(n, c, gy, z3, x, coef3, training, 1, partial, db3, da, gres, stream);
-    if (!defer_wgrad) e << pdf_rowlin_wgrad(n, c, c, da, c, t, c, coef2, coef2 + c, 1, dW3, nullptr, (float *)p[12], stream);
+    if (!defer_wgrad) e << pdf_rowlin_wgrad(n, c, c, da, c, t, c, coef2, coef2 + c, 1, dW3, nullptr, (float *)p[12], mma_input, stream);
     // bn2 backward in place on gt (sums from the product's epilogue, as in block_pre_backward)
     int prow = 0;
     const float *das[1] = {da}, *w3s[1] = {W3};
-    const int rc2 = dgrad_bstats() ? pdf_rowlin_dgrad_bstats(n, c, c, 1, das, c, w3s, gt, c, t, c, coef2, 1, partial, &prow, db2, stream) : PDF_ERR_UNSUPPORTED;
+    const int rc2 = dgrad_bstats() ? pdf_rowlin_dgrad_bstats(n, c, c, 1, das, c, w3s, gt, c, t, c, coef2, 1, partial, &prow, mma_input, stream) : PDF_ERR_UNSUPPORTED;
     if (rc2 == PDF_ERR_UNSUPPORTED) {
-        e << pdf_rowlin_forward(n, c, c, da, c, W3, 1, nullptr, nullptr, nullptr, 0, gt, c, 0, nullptr, stream);
+        e << pdf_rowlin_forward(n, c, c, da, c, W3, 1, nullptr, nullptr, nullptr, 0, gt, c, 0, nullptr, mma_input, stream);
         e << pdf_bn_act_backward(n, c, gt, t, nullptr, coef2, training, 1, partial, db2, gt, nullptr, stream);
     } else {
         e << rc2;
@@ -140,8 +140,8 @@ static int block_post_backward(long n, int c, void *const *p, int training, void
     return e.rc;
 }
 
-extern "C" int pdf_block_post_backward(long n, int c, void *const *p, int training, void *stream) {
-    return block_post_backward(n, c, p, training, stream, false);
+extern "C" int pdf_block_post_backward(long n, int c, void *const *p, int training, int mma_input, void *stream) {
+    return block_post_backward(n, c, p, training, mma_input, stream, false);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -154,11 +154,11 @@ extern "C" int pdf_block_post_backward(long n, int c, void *const *p, int traini
 //   saved / outputs: 43 z1 44 coef1 45 xq 46 xk 47 xv 48 layer bn (2T) 49 layer saved (2T) 50 H 51 t 52 coef2 53 z3 54 coef3 55 y
 //   56 scratch (max of pdf_rowlin_partial_floats, pdf_bn_partial_floats, pdf_pt_layer_partial_floats) | 57 visiting order of the points (or null)
 //   58 the batch's relative-coordinate sums of the kNN table (9 doubles, pdf_knn_rel_moments) or null
-extern "C" int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p, int training, float eps, float momentum, int storage_bf16, void *stream) {
+extern "C" int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p, int training, float eps, float momentum, int storage_bf16, int mma_input, void *stream) {
     if (n < 1 || !p) return PDF_ERR_BAD_ARG;
     Err e;
     void *pre[18] = {p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], p[10], p[11], p[43], p[44], p[45], p[46], p[47], p[56]};
-    e << pdf_block_pre_forward(n, c, pre, training, eps, momentum, stream);
+    e << pdf_block_pre_forward(n, c, pre, training, eps, momentum, mma_input, stream);
     const float *weights[8], *bn_params[6];
     float *bn_buffers[6];
     for (int i = 0; i < 8; ++i) weights[i] = (const float *)p[14 + i];
@@ -167,7 +167,7 @@ extern "C" int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p
                                 (const int *)p[13], weights, bn_params, bn_buffers, training, eps, momentum, (float *)p[48], (float *)p[49],
                                 (float *)p[50], (float *)p[56], (float *)p[51], storage_bf16, (const int *)p[57], (const double *)p[58], stream);
     void *post[16] = {p[51], p[0], p[34], p[35], p[36], p[37], p[38], p[39], p[40], p[41], p[42], p[52], p[53], p[54], p[55], p[56]};
-    e << pdf_block_post_forward(n, c, post, training, eps, momentum, stream);
+    e << pdf_block_post_forward(n, c, post, training, eps, momentum, mma_input, stream);
     return e.rc;
 }
 
@@ -186,7 +186,7 @@ extern "C" int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p
 //   50 workspace of the weight-gradient slabs: max(pdf_rowlin_wgrad_ws_floats(n, c, c, 5), pdf_rowlin_wgrad_ws_floats(n, c, c, 3) +
 //      pdf_rowlin_wgrad_ws_floats(n, c, c, 1)) floats (grouped launch / one product at a time)
 // No gradient slot is accumulated into any more (slab reductions and column sums WRITE): the memset of round 2 is gone.
-extern "C" int pdf_bottleneck_backward(long n, int nsample, int c, void *const *p, int training, int entry_base, int storage_bf16, void *stream) {
+extern "C" int pdf_bottleneck_backward(long n, int nsample, int c, void *const *p, int training, int entry_base, int storage_bf16, int mma_input, void *stream) {
     if (n < 1 || !p) return PDF_ERR_BAD_ARG;
     Err e;
     if (!p[50]) return PDF_ERR_BAD_ARG;
@@ -197,7 +197,7 @@ extern "C" int pdf_bottleneck_backward(long n, int nsample, int c, void *const *
     static const bool group = [] { const char *v = getenv("PDFOPS_WGRAD_GROUP"); return !(v && v[0] == '0'); }();
     float *ws_post = (float *)p[50], *ws_pre = ws_post + pdf_rowlin_wgrad_ws_floats(n, c, c, 1);
     void *post[13] = {p[0], p[24], p[1], p[25], p[26], p[27], p[28], p[33], p[29], p[31], p[34], p[40], ws_post};
-    e << block_post_backward(n, c, post, training, stream, group);
+    e << block_post_backward(n, c, post, training, mma_input, stream, group);
     const float *weights[8];
     for (int i = 0; i < 8; ++i) weights[i] = (const float *)p[10 + i];
     e << pdf_pt_layer_backward((int)n, nsample, c, (const float *)p[21], (const float *)p[22], (const float *)p[23], (const float *)p[8],
@@ -206,7 +206,7 @@ extern "C" int pdf_bottleneck_backward(long n, int nsample, int c, void *const *
                                (float *)p[41], (float *)p[42], (const int *)p[43], (const int *)p[44], entry_base,
                                (float *)p[40], (float *)p[32], storage_bf16, (const int *)p[49], stream);
     void *pre[15] = {p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[35], p[36], p[37], p[29], p[30], p[45], p[40], ws_pre};
-    e << block_pre_backward(n, c, pre, training, 1, stream, group);   // gx += dy W1 on top of the identity branch
+    e << block_pre_backward(n, c, pre, training, 1, mma_input, stream, group);   // gx += dy W1 on top of the identity branch
     if (group && e.rc == 0) {
         const long cc = (long)c * c;
         float *gpre = (float *)p[30], *gpost = (float *)p[31];                  // block_pre_backward / block_post_backward gradient layouts
@@ -218,11 +218,11 @@ extern "C" int pdf_bottleneck_backward(long n, int nsample, int c, void *const *
         const int relu[5] = {1, 1, 1, 1, 0};
         float *dw[5] = {dW3, dqkv, dqkv + (cc + c), dqkv + 2 * (cc + c), dW1};
         float *db[5] = {nullptr, dqkv + cc, dqkv + (cc + c) + cc, dqkv + 2 * (cc + c) + cc, nullptr};
-        const int rc = pdf_rowlin_wgrad_group(n, c, c, 5, g, c, x, c, sc, sh, relu, dw, db, ws_post, stream);
+        const int rc = pdf_rowlin_wgrad_group(n, c, c, 5, g, c, x, c, sc, sh, relu, dw, db, ws_post, mma_input, stream);
         if (rc == PDF_ERR_UNSUPPORTED) {   // widths outside the streaming kernels: one product at a time
-            e << pdf_rowlin_wgrad(n, c, c, g[0], c, x[0], c, sc[0], sh[0], 1, dw[0], nullptr, ws_post, stream);
-            e << pdf_rowlin_wgrad_multi(n, c, c, 3, g + 1, c, x[1], c, sc[1], sh[1], 1, dw + 1, db + 1, ws_pre, stream);
-            e << pdf_rowlin_wgrad(n, c, c, g[4], c, x[4], c, nullptr, nullptr, 0, dw[4], nullptr, ws_pre, stream);
+            e << pdf_rowlin_wgrad(n, c, c, g[0], c, x[0], c, sc[0], sh[0], 1, dw[0], nullptr, ws_post, mma_input, stream);
+            e << pdf_rowlin_wgrad_multi(n, c, c, 3, g + 1, c, x[1], c, sc[1], sh[1], 1, dw + 1, db + 1, ws_pre, mma_input, stream);
+            e << pdf_rowlin_wgrad(n, c, c, g[4], c, x[4], c, nullptr, nullptr, 0, dw[4], nullptr, ws_pre, mma_input, stream);
         } else {
             e << rc;
         }
@@ -235,16 +235,16 @@ extern "C" int pdf_bottleneck_backward(long n, int nsample, int c, void *const *
 // and confidence heads: point_transformer_seg.py:131-147, 229-234; pt_v1.py:17-24).  Streaming shapes only (k in 32..512,
 // o % 16 == 0): the GEMM's epilogue emits the column statistics, so the norm costs one extra pass (apply) instead of three.
 // Forward p[]: 0 x 1 W (o,k) 2 bias 3 gamma 4 beta 5 rm 6 rv | 7 z (n,o) 8 coef (4o) 9 y (n,o) 10 partial (pdf_rowlin_partial_floats(n,o))
-extern "C" int pdf_linbn_forward(long n, int k, int o, void *const *p, int training, int relu, float eps, float momentum, void *stream) {
+extern "C" int pdf_linbn_forward(long n, int k, int o, void *const *p, int training, int relu, float eps, float momentum, int mma_input, void *stream) {
     if (n < 1 || !p) return PDF_ERR_BAD_ARG;
     if (!pdf_bn_supported(o)) return PDF_ERR_UNSUPPORTED;
     Err e;
     float *z = (float *)p[7], *coef = (float *)p[8], *partial = (float *)p[10];
     if (training) {
         e << pdf_rowlin_forward_bn(n, k, o, (const float *)p[0], k, (const float *)p[1], (const float *)p[2], nullptr, nullptr, 0, z, o, partial,
-                                   (const float *)p[3], (const float *)p[4], (float *)p[5], (float *)p[6], eps, momentum, coef, stream);
+                                   (const float *)p[3], (const float *)p[4], (float *)p[5], (float *)p[6], eps, momentum, coef, mma_input, stream);
     } else {
-        e << pdf_rowlin_forward(n, k, o, (const float *)p[0], k, (const float *)p[1], 0, (const float *)p[2], nullptr, nullptr, 0, z, o, 0, nullptr, stream);
+        e << pdf_rowlin_forward(n, k, o, (const float *)p[0], k, (const float *)p[1], 0, (const float *)p[2], nullptr, nullptr, 0, z, o, 0, nullptr, mma_input, stream);
         e << pdf_bn_coef_eval_or_partial(partial, 0, n, o, (const float *)p[3], (const float *)p[4], (float *)p[5], (float *)p[6], 0, eps, momentum, coef, stream);
     }
     e << pdf_bn_apply(n, o, z, nullptr, coef, relu, (float *)p[9], stream);
@@ -253,14 +253,14 @@ extern "C" int pdf_linbn_forward(long n, int k, int o, void *const *p, int train
 
 // Backward p[]: 0 gy 1 x 2 z 3 coef 4 W | 5 gx (n,k) or null 6 grads [dW (o*k) | db (o) | dbeta (o) | dgamma (o)] (written)
 //               7 gz (n,o) scratch 8 partial (pdf_bn_partial_floats(n,o)) 9 weight-gradient slabs (pdf_rowlin_wgrad_ws_floats(n, k, o, 1))
-extern "C" int pdf_linbn_backward(long n, int k, int o, void *const *p, int training, int relu, void *stream) {
+extern "C" int pdf_linbn_backward(long n, int k, int o, void *const *p, int training, int relu, int mma_input, void *stream) {
     if (n < 1 || !p || !p[9]) return PDF_ERR_BAD_ARG;
     float *grads = (float *)p[6], *gz = (float *)p[7];
     const long ok = (long)o * k;
     Err e;
     e << pdf_bn_act_backward(n, o, (const float *)p[0], (const float *)p[2], nullptr, (const float *)p[3], training, relu, (float *)p[8],
                              grads + ok + o, gz, nullptr, stream);                                                    // [dbeta | dgamma]
-    if (p[5]) e << pdf_rowlin_forward(n, o, k, gz, o, (const float *)p[4], 1, nullptr, nullptr, nullptr, 0, (float *)p[5], k, 0, nullptr, stream);
-    e << pdf_rowlin_wgrad(n, k, o, gz, o, (const float *)p[1], k, nullptr, nullptr, 0, grads, grads + ok, (float *)p[9], stream);    // dW, db
+    if (p[5]) e << pdf_rowlin_forward(n, o, k, gz, o, (const float *)p[4], 1, nullptr, nullptr, nullptr, 0, (float *)p[5], k, 0, nullptr, mma_input, stream);
+    e << pdf_rowlin_wgrad(n, k, o, gz, o, (const float *)p[1], k, nullptr, nullptr, 0, grads, grads + ok, (float *)p[9], mma_input, stream);    // dW, db
     return e.rc;
 }

@@ -196,13 +196,17 @@ __device__ __forceinline__ void insert(float (&bd)[KP1], int (&bi)[KP1], float d
 // SELF: the queries ARE the source points (self kNN of a level: 5 of the 13 tables, most of the query work).  Thread t then
 // takes the t-th point of the cell-sorted copy instead of the t-th point in memory order: the 64 lanes of a wave sit in the
 // same or adjacent cells, walk the same rings and read the same cell lists (coherent loads, little divergence).
-template <int KP1, bool SELF>
+// COUNT (measurement builds of the launch, pdf_knn_query_ws_counted): every lane counts the candidate distances it evaluates; the wave's
+// total goes to *pairs with one atomic per wave -- the work the kernel really does, as opposed to the m * n_scene pairs of the brute force
+// it replaces (bench.py / tools/ops_roofline.py price the kernel against the fp32 vector peak with THIS count).
+template <int KP1, bool SELF, bool COUNT>
 __global__ __launch_bounds__(PB) void k_grid_query(int m, int b, const float *__restrict__ new_xyz, const int *__restrict__ new_offset,
                                                    const SceneGrid *__restrict__ grids, const unsigned *__restrict__ cell_start,
                                                    const float4 *__restrict__ sorted, int *__restrict__ idx,
-                                                   float *__restrict__ dist2, int *__restrict__ redo) {
+                                                   float *__restrict__ dist2, int *__restrict__ redo, unsigned long long *pairs) {
     constexpr int K = KP1 - 1;
     const int t_ = blockIdx.x * PB + threadIdx.x;
+    unsigned evaluated = 0;
     if (t_ >= m) return;
     int q = t_;
     float qx, qy, qz;
@@ -238,6 +242,7 @@ __global__ __launch_bounds__(PB) void k_grid_query(int m, int b, const float *__
                         if (x < 0 || x >= g.nx) continue;
                         const int c = (z * g.ny + y) * g.nx + x;
                         const unsigned p0 = cs[c], p1 = cs[c + 1];
+                        if (COUNT) evaluated += p1 - p0;
                         for (unsigned p = p0; p < p1; ++p) {
                             const float4 v = sorted[p];
                             const float d = pdf_sqdist3(qx - v.x, qy - v.y, qz - v.z);
@@ -261,6 +266,9 @@ __global__ __launch_bounds__(PB) void k_grid_query(int m, int b, const float *__
         // ties among the K+1 best distances make the reference's answer depend on its heap history: exact scan instead
 #pragma unroll
         for (int t = 0; t < K; ++t) need_redo |= (bd[t] == bd[t + 1]);
+    }
+    if (COUNT) {   // a per-lane atomic: measurement launches only (wave-level reductions would need every lane to stay convergent here)
+        if (evaluated) atomicAdd(pairs, (unsigned long long)evaluated);
     }
     if (need_redo) {
         const int slot = atomicAdd(&redo[0], 1);
@@ -369,15 +377,15 @@ extern "C" long pdf_knn_workspace_bytes(int b, int n, int m) {
 // nsample values served by the grid path (others fall back to the scan inside pdf_knn_query_ws)
 extern "C" int pdf_knn_grid_supported(int nsample) { return nsample == 3 || nsample == 8 || nsample == 16; }
 
-extern "C" int pdf_knn_query_ws(int m, int nsample, int n, const float *xyz, const float *new_xyz, const int *offset,
-                                const int *new_offset, int b, int *idx, float *dist2, void *workspace,
-                                long workspace_bytes, void *stream) {
+static int knn_query_ws(int m, int nsample, int n, const float *xyz, const float *new_xyz, const int *offset,
+                        const int *new_offset, int b, int *idx, float *dist2, void *workspace,
+                        long workspace_bytes, unsigned long long *pairs, void *stream) {
     if (m == 0) return PDF_OK;   // (0-size tensors carry null pointers: not an argument error)
     if (m < 0 || n < 0 || b < 1 || !xyz || !new_xyz || !offset || !new_offset || !idx || !dist2) return PDF_ERR_BAD_ARG;
     if (nsample < 1 || nsample > 128) return PDF_ERR_NSAMPLE;
     if (m == 0) return PDF_OK;
     if (!pdf_knn_grid_supported(nsample) || b > 64)
-        return pdf_knn_query(m, nsample, xyz, new_xyz, offset, new_offset, b, idx, dist2, stream);
+        return pairs ? PDF_ERR_UNSUPPORTED : pdf_knn_query(m, nsample, xyz, new_xyz, offset, new_offset, b, idx, dist2, stream);
     const kg::Layout L = kg::make_layout(b, n, m);
     if (!workspace || workspace_bytes < (long)L.total) return PDF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -401,12 +409,14 @@ extern "C" int pdf_knn_query_ws(int m, int nsample, int n, const float *xyz, con
     kg::k_grid_scatter<<<pdf_divup(n, kg::PB), kg::PB, 0, s>>>(n, xyz, cell_of, cell_start, cursor, sorted);
     const int grid = pdf_divup(m, kg::PB);
     const bool self = new_xyz == xyz && new_offset == offset && m == n && getenv("PDFOPS_KNN_NO_SELF") == nullptr;
-#define PDF_KQ(KP1_) do { if (self) kg::k_grid_query<KP1_, true><<<grid, kg::PB, 0, s>>>(m, b, new_xyz, new_offset, grids, cell_start, sorted, idx, dist2, redo); \
-                          else kg::k_grid_query<KP1_, false><<<grid, kg::PB, 0, s>>>(m, b, new_xyz, new_offset, grids, cell_start, sorted, idx, dist2, redo); } while (0)
+#define PDF_KQ2(KP1_, SELF_, COUNT_) kg::k_grid_query<KP1_, SELF_, COUNT_><<<grid, kg::PB, 0, s>>>(m, b, new_xyz, new_offset, grids, cell_start, sorted, idx, dist2, redo, pairs)
+#define PDF_KQ(KP1_) do { if (pairs) { if (self) PDF_KQ2(KP1_, true, true); else PDF_KQ2(KP1_, false, true); } \
+                          else       { if (self) PDF_KQ2(KP1_, true, false); else PDF_KQ2(KP1_, false, false); } } while (0)
     if (nsample == 3) PDF_KQ(4);
     else if (nsample == 8) PDF_KQ(9);
     else PDF_KQ(17);
 #undef PDF_KQ
+#undef PDF_KQ2
     int rc = pdf_launch_status();
     if (rc != PDF_OK) return rc;
     if (getenv("PDFOPS_KNN_DEBUG")) {   // diagnostics: size of the exact-scan redo list (synchronises)
@@ -416,6 +426,21 @@ extern "C" int pdf_knn_query_ws(int m, int nsample, int n, const float *xyz, con
         fprintf(stderr, "[pdfops] knn grid: m=%d nsample=%d b=%d redo=%d\n", m, nsample, b, cnt);
     }
     return pdf_knn_query_list(m, nsample, xyz, new_xyz, offset, new_offset, b, idx, dist2, redo + 4, redo, stream);
+}
+
+
+extern "C" int pdf_knn_query_ws(int m, int nsample, int n, const float *xyz, const float *new_xyz, const int *offset,
+                                const int *new_offset, int b, int *idx, float *dist2, void *workspace,
+                                long workspace_bytes, void *stream) {
+    return knn_query_ws(m, nsample, n, xyz, new_xyz, offset, new_offset, b, idx, dist2, workspace, workspace_bytes, nullptr, stream);
+}
+// the same launch sequence with the grid kernel counting the candidate distances it evaluates: *pairs (device, zeroed by the caller)
+// += that count.  Measurement aid (the count costs a per-lane atomic); PDF_ERR_UNSUPPORTED where the grid path does not apply.
+extern "C" int pdf_knn_query_ws_counted(int m, int nsample, int n, const float *xyz, const float *new_xyz, const int *offset,
+                                        const int *new_offset, int b, int *idx, float *dist2, void *workspace,
+                                        long workspace_bytes, unsigned long long *pairs, void *stream) {
+    if (!pairs) return PDF_ERR_BAD_ARG;
+    return knn_query_ws(m, nsample, n, xyz, new_xyz, offset, new_offset, b, idx, dist2, workspace, workspace_bytes, pairs, stream);
 }
 
 

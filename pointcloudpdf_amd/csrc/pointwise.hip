@@ -27,17 +27,9 @@ static inline int grid_rows(long n, int c) {
     return (int)g;
 }
 
-// In-launch tail of the statistics pass (pdfops_common.h: pdf_tail_sum): the last workgroup turns the column sums into the BatchNorm
-// coefficients itself (what fl::k_bn_finalize does in its own launch).  tickets == nullptr: rows only, the caller launches the finalizer.
-struct StatsTail {
-    unsigned *tickets; double *grows;
-    double count; const float *gamma, *beta; float eps, momentum;
-    float *running_mean, *running_var, *scale, *shift, *mean_out, *rstd_out;
-};
-
 // partial[block][2c] = per-channel sum | sum of squares over the block's rows.   c % 4 == 0, c <= 1024
-__global__ __launch_bounds__(PB) void k_bn_stats(long n, int c, const float *__restrict__ x, float *partial, StatsTail tl) {
-    extern __shared__ float red[];  // [PB][8] (and, in the tail, 2c doubles + a flag word)
+__global__ __launch_bounds__(PB) void k_bn_stats(long n, int c, const float *__restrict__ x, float *partial) {
+    extern __shared__ float red[];  // [PB][8]
     const int tpr = c / 4;                    // threads per row
     const int rpb = PB / tpr;                 // rows per block sweep (c <= 1024 -> tpr <= 256)
     const int tr = threadIdx.x / tpr, tc = threadIdx.x % tpr;
@@ -59,30 +51,6 @@ __global__ __launch_bounds__(PB) void k_bn_stats(long n, int c, const float *__r
             for (int rr = 0; rr < rpb; ++rr) a += red[(rr * tpr + threadIdx.x) * 8 + k];
             const int ch = threadIdx.x * 4 + (k & 3);
             partial[(size_t)blockIdx.x * 2 * c + (k < 4 ? ch : c + ch)] = a;
-        }
-    }
-    if (!tl.tickets) return;
-    __syncthreads();                                   // (red is free again)
-    double *fin = reinterpret_cast<double *>(red);      // [2c]
-    volatile unsigned *flag = reinterpret_cast<volatile unsigned *>(fin + 2 * c);
-    if (!pdf_tail_sum(tl.tickets, tl.grows, partial, (size_t)2 * c, 2 * c, [](int j) { return (size_t)j; }, gridDim.x, blockIdx.x, flag,
-                      [&](int j, double v) { fin[j] = v; }))
-        return;
-    __syncthreads();
-    for (int ch = threadIdx.x; ch < c; ch += PB) {     // fl::k_bn_finalize's arithmetic
-        const double mean = fin[ch] / tl.count;
-        double var = fin[c + ch] / tl.count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)tl.eps));
-        const float sc = tl.gamma[ch] * rstd;
-        tl.scale[ch] = sc;
-        tl.shift[ch] = tl.beta[ch] - (float)mean * sc;
-        tl.mean_out[ch] = (float)mean;
-        tl.rstd_out[ch] = rstd;
-        if (tl.running_mean) {
-            const double unbiased = tl.count > 1.0 ? var * tl.count / (tl.count - 1.0) : var;
-            tl.running_mean[ch] = (1.f - tl.momentum) * tl.running_mean[ch] + tl.momentum * (float)mean;
-            tl.running_var[ch] = (1.f - tl.momentum) * tl.running_var[ch] + tl.momentum * (float)unbiased;
         }
     }
 }
@@ -108,8 +76,7 @@ template <bool RES>
 __global__ __launch_bounds__(PB) void k_bn_bwd_reduce(long n, int c, const float *__restrict__ gy, const float *__restrict__ x,
                                                       const float *__restrict__ res, const float *__restrict__ scale,
                                                       const float *__restrict__ shift, const float *__restrict__ mean,
-                                                      const float *__restrict__ rstd, int relu, float *partial,
-                                                      unsigned *tickets, double *grows, float *sums) {
+                                                      const float *__restrict__ rstd, int relu, float *partial) {
     extern __shared__ float red[];
     const int tpr = c / 4, rpb = PB / tpr;
     const int tr = threadIdx.x / tpr, tc = threadIdx.x % tpr;
@@ -144,10 +111,6 @@ __global__ __launch_bounds__(PB) void k_bn_bwd_reduce(long n, int c, const float
             partial[(size_t)blockIdx.x * 2 * c + (k < 4 ? ch : c + ch)] = a;
         }
     }
-    if (!tickets) return;   // (the caller launches the column sum)
-    __syncthreads();
-    pdf_tail_sum(tickets, grows, partial, (size_t)2 * c, 2 * c, [](int j) { return (size_t)j; }, gridDim.x, blockIdx.x,
-                 reinterpret_cast<volatile unsigned *>(red), [&](int j, double v) { sums[j] = (float)v; });
 }
 
 // gx = scale * (g' - sums[ch]/n - xhat * sums[c+ch]/n) ; gres = g'
@@ -216,24 +179,7 @@ void launch_colsum(const float *partial, int rows, int width, float *out, hipStr
 }  // namespace fl
 
 extern "C" int pdf_bn_supported(int c) { return c >= 4 && c % 4 == 0 && c <= 1024 && (1024 % c == 0); }
-// rows [grid][2c] floats + the tail's group rows [ceil(grid / PDF_TAIL_G)][2c] doubles
-static inline long bn_rows_floats(long n, int c) { return (((long)pw::grid_rows(n, c) * 2 * c + 1) / 2) * 2; }   // (even: the doubles behind are 8-byte aligned)
-extern "C" long pdf_bn_partial_floats(long n, int c) {
-    return bn_rows_floats(n, c) + 2L * ((pw::grid_rows(n, c) + PDF_TAIL_G - 1) / PDF_TAIL_G) * 2 * c;
-}
-namespace pw {
-static inline size_t stats_lds(int c, bool tail) { const size_t a = PB * 8 * sizeof(float), b = (size_t)2 * c * sizeof(double) + 16; return tail && b > a ? b : a; }
-static inline StatsTail stats_tail(hipStream_t s, float *partial, long n, int c, const float *gamma, const float *beta, float eps, float momentum,
-                                   float *running_mean, float *running_var, float *coef) {
-    StatsTail t;
-    t.tickets = pdf_tickets_for(s, n);
-    t.grows = reinterpret_cast<double *>(partial + bn_rows_floats(n, c));
-    t.count = (double)n; t.gamma = gamma; t.beta = beta; t.eps = eps; t.momentum = momentum;
-    t.running_mean = running_mean; t.running_var = running_var;
-    t.scale = coef; t.shift = coef + c; t.mean_out = coef + 2 * c; t.rstd_out = coef + 3 * c;
-    return t;
-}
-}  // namespace pw
+extern "C" long pdf_bn_partial_floats(long n, int c) { return (long)pw::grid_rows(n, c) * 2 * c; }   // rows [grid][2c]
 
 // Forward of BatchNorm1d (+residual)(+ReLU) over (n, c).  coef (4c floats) receives [scale | shift | mean | rstd].
 // training: batch statistics (running stats updated when non-null); else running statistics.
@@ -247,9 +193,8 @@ extern "C" int pdf_bn_act_forward(long n, int c, const float *x, const float *re
     if (training) {
         if (!partial) return PDF_ERR_BAD_ARG;
         const int g = pw::grid_rows(n, c);
-        const pw::StatsTail tl = pw::stats_tail(s, partial, n, c, gamma, beta, eps, momentum, running_mean, running_var, coef);
-        pw::k_bn_stats<<<g, pw::PB, pw::stats_lds(c, tl.tickets != nullptr), s>>>(n, c, x, partial, tl);
-        if (!tl.tickets) fl::launch_bn_finalize(partial, g, c, (double)n, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, rstd, s);
+        pw::k_bn_stats<<<g, pw::PB, pw::PB * 8 * sizeof(float), s>>>(n, c, x, partial);
+        fl::launch_bn_finalize(partial, g, c, (double)n, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, rstd, s);
     } else {
         if (!running_mean || !running_var) return PDF_ERR_BAD_ARG;
         fl::launch_bn_eval(c, gamma, beta, eps, running_mean, running_var, scale, shift, mean, rstd, s);
@@ -273,15 +218,12 @@ static int bn_act_backward(long n, int c, const float *gy, const float *x, const
     const float *scale = coef, *shift = coef + c, *mean = coef + 2 * c, *rstd = coef + 3 * c;
     const int g = pw::grid_rows(n, c);
     const long n4 = n * (c / 4);
-    if (presummed < 0) {
-        // (the producer's in-launch tail already wrote the finished sums)
-    } else if (presummed > 0) {
+    if (presummed > 0) {
         fl::launch_colsum(partial, presummed, 2 * c, sums, s);
     } else {
-        unsigned *tk = pdf_tickets_for(s, n);
         (res ? pw::k_bn_bwd_reduce<true> : pw::k_bn_bwd_reduce<false>)<<<g, pw::PB, pw::PB * 8 * sizeof(float), s>>>(
-            n, c, gy, x, res, scale, shift, mean, rstd, relu, partial, tk, reinterpret_cast<double *>(partial + bn_rows_floats(n, c)), sums);
-        if (!tk) fl::launch_colsum(partial, g, 2 * c, sums, s);
+            n, c, gy, x, res, scale, shift, mean, rstd, relu, partial);
+        fl::launch_colsum(partial, g, 2 * c, sums, s);
     }
 #define F4(p) reinterpret_cast<const float4 *>(p)
     if (training)
@@ -302,7 +244,7 @@ extern "C" int pdf_bn_act_backward(long n, int c, const float *gy, const float *
 // same with the reduction pass already done by the producer of gy (pdf_rowlin_dgrad_bstats): partial holds partial_rows rows of 2c sums
 extern "C" int pdf_bn_act_backward_presummed(long n, int c, const float *gy, const float *x, const float *coef, int training, int relu,
                                              const float *partial, int partial_rows, float *sums, float *gx, void *stream) {
-    if ((partial_rows < 1 && partial_rows != -1) || !partial) return PDF_ERR_BAD_ARG;   // -1: sums finished by pdf_rowlin_dgrad_bstats' tail
+    if (partial_rows < 1 || !partial) return PDF_ERR_BAD_ARG;
     return bn_act_backward(n, c, gy, x, nullptr, coef, training, relu, const_cast<float *>(partial), sums, 0, gx, nullptr, stream, partial_rows);
 }
 // Coefficients of a train-mode BatchNorm whose column statistics were produced by a GEMM epilogue (rowlin STATS).
@@ -336,10 +278,8 @@ extern "C" int pdf_bn_coef(long n, int c, const float *x, const float *gamma, co
     if (training) {
         if (!partial || !x) return PDF_ERR_BAD_ARG;
         const int g = pw::grid_rows(n, c);
-        const pw::StatsTail tl = pw::stats_tail(s, partial, n, c, gamma, beta, eps, momentum, running_mean, running_var, coef);
-        pw::k_bn_stats<<<g, pw::PB, pw::stats_lds(c, tl.tickets != nullptr), s>>>(n, c, x, partial, tl);
-        if (!tl.tickets) fl::launch_bn_finalize(partial, g, c, (double)n, gamma, beta, eps, momentum, running_mean, running_var, coef, coef + c,
-                                                coef + 2 * c, coef + 3 * c, s);
+        pw::k_bn_stats<<<g, pw::PB, pw::PB * 8 * sizeof(float), s>>>(n, c, x, partial);
+        fl::launch_bn_finalize(partial, g, c, (double)n, gamma, beta, eps, momentum, running_mean, running_var, coef, coef + c, coef + 2 * c, coef + 3 * c, s);
     } else {
         if (!running_mean || !running_var) return PDF_ERR_BAD_ARG;
         fl::launch_bn_eval(c, gamma, beta, eps, running_mean, running_var, coef, coef + c, coef + 2 * c, coef + 3 * c, s);
@@ -355,9 +295,7 @@ extern "C" int pdf_bn_bwd_sums(long n, int c, const float *gy, const float *x, c
     if (!pdf_bn_supported(c)) return PDF_ERR_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int g = pw::grid_rows(n, c);
-    unsigned *tk = pdf_tickets_for(s, n);
-    pw::k_bn_bwd_reduce<false><<<g, pw::PB, pw::PB * 8 * sizeof(float), s>>>(n, c, gy, x, nullptr, coef, coef + c, coef + 2 * c, coef + 3 * c, relu, partial,
-                                                                      tk, reinterpret_cast<double *>(partial + bn_rows_floats(n, c)), sums);
-    if (!tk) fl::launch_colsum(partial, g, 2 * c, sums, s);
+    pw::k_bn_bwd_reduce<false><<<g, pw::PB, pw::PB * 8 * sizeof(float), s>>>(n, c, gy, x, nullptr, coef, coef + c, coef + 2 * c, coef + 3 * c, relu, partial);
+    fl::launch_colsum(partial, g, 2 * c, sums, s);
     return pdf_launch_status();
 }

@@ -182,14 +182,11 @@ __global__ __launch_bounds__(256) void k_wgrad(WArgs a) {
 namespace rl2 {
 int try_forward(long n, int k, int o, int nin, int nout, const float *const *x, long ldx, const float *const *w, int transpose_w,
                 const float *const *bias, const float *scale, const float *shift, int relu, float *const *y, long ldy,
-                int accumulate, float *partial, hipStream_t s, const float *roww = nullptr, long rws = 0, const float *bx = nullptr,
-                long ldb = 0, const float *bcoef = nullptr, int brelu = 0, int *partial_rows = nullptr, const struct StatsBn *bn = nullptr,
-                long ldw = 0);
-struct StatsBn { const float *gamma, *beta; float *running_mean, *running_var; float eps, momentum; float *out; };
+                int accumulate, float *partial, int mma, hipStream_t s, const float *roww = nullptr, long rws = 0, const float *bx = nullptr,
+                long ldb = 0, const float *bcoef = nullptr, int brelu = 0, int *partial_rows = nullptr, long ldw = 0);
 long stats_rows_floats(long n, int o);
-long stats_tail_floats(long n, int o);
 int try_wgrad(long n, int k, int o, int ng, const float *const *g, long ldg, const float *x, long ldx, const float *scale,
-              const float *shift, int relu, float *const *dw, float *const *db, float *ws, hipStream_t s, const float *roww = nullptr, long rws = 0);
+              const float *shift, int relu, float *const *dw, float *const *db, float *ws, int mma, hipStream_t s, const float *roww = nullptr, long rws = 0);
 long wgrad_ws_floats(long n, int k, int o, int ng);
 constexpr int WG_MAXG = 5;   // (as in rowlin2_impl.h)
 struct RArgs {
@@ -198,7 +195,7 @@ struct RArgs {
     int B, tiles_k, tiles, otiles, split, K, O;
 };
 int try_wgrad_group(long n, int k, int o, int ng, const float *const *g, long ldg, const float *const *x, long ldx, const float *const *scale,
-                    const float *const *shift, const int *relu, float *const *dw, float *const *db, float *ws, hipStream_t s);
+                    const float *const *shift, const int *relu, float *const *dw, float *const *db, float *ws, int mma, hipStream_t s);
 void launch_slab_reduce(const RArgs &a, int ng, bool any_bias, hipStream_t s);
 int stats_rows(long n);
 }  // namespace rl2
@@ -221,8 +218,8 @@ static inline bool rowlin_streams(int k, int o) {
 extern "C" int pdf_rowlin_partial_rows(long n, int k, int o) {
     return rowlin_streams(k, o) ? rl2::stats_rows(n) : (int)((n + rl::BM - 1) / rl::BM);
 }
-extern "C" long pdf_rowlin_partial_floats(long n, int o) {   // rows of either kernel + the group rows of the in-launch tail
-    const long a = (n + rl::BM - 1) / rl::BM * 2 * (long)o, b = rl2::stats_rows_floats(n, o) + rl2::stats_tail_floats(n, o);
+extern "C" long pdf_rowlin_partial_floats(long n, int o) {   // rows of either kernel
+    const long a = (n + rl::BM - 1) / rl::BM * 2 * (long)o, b = rl2::stats_rows_floats(n, o);
     return a > b ? a : b;
 }
 
@@ -230,11 +227,12 @@ extern "C" long pdf_rowlin_partial_floats(long n, int o) {   // rows of either k
 // 1: W is (k, o) row-major, i.e. the layer's own (out, in) weight used for the input gradient dX = G W.
 extern "C" int pdf_rowlin_forward(long n, int k, int o, const float *x, long ldx, const float *w, int transpose_w,
                                   const float *bias, const float *scale, const float *shift, int relu, float *y, long ldy,
-                                  int accumulate, float *partial, void *stream) {
+                                  int accumulate, float *partial, int mma_input, void *stream) {
+    if (mma_input < 0 || mma_input > 2) return PDF_ERR_BAD_ARG;
     if (n < 1 || k < 1 || o < 1 || !x || !w || !y || ldx < k || ldy < o) return PDF_ERR_BAD_ARG;
     if (rowlin_streams(k, o)) {
         if (rl2::try_forward(n, k, o, 1, 1, &x, ldx, &w, transpose_w, &bias, scale, shift, relu, &y, ldy, accumulate, partial,
-                             static_cast<hipStream_t>(stream)))
+                             mma_input, static_cast<hipStream_t>(stream)))
             return pdf_launch_status();
         if (partial) return PDF_ERR_BAD_ARG;  // statistics layout is tied to the streaming kernel for these shapes (needs 16-byte alignment)
     }
@@ -244,8 +242,8 @@ extern "C" int pdf_rowlin_forward(long n, int k, int o, const float *x, long ldx
     // 274 us at 780 x 1024 -> 512 against ~20 us.
     if (!transpose_w && !partial && !scale && k == 1024 && rowlin_streams(512, o) && !(ldx & 3) && !(ldy & 3)) {
         const float *xs[2] = {x, x + 512}, *ws[2] = {w, w + 512};
-        if (rl2::try_forward(n, 512, o, 2, 1, xs, ldx, ws, 0, &bias, nullptr, nullptr, 0, &y, ldy, accumulate, nullptr, static_cast<hipStream_t>(stream),
-                             nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, k))
+        if (rl2::try_forward(n, 512, o, 2, 1, xs, ldx, ws, 0, &bias, nullptr, nullptr, 0, &y, ldy, accumulate, nullptr, mma_input, static_cast<hipStream_t>(stream),
+                             nullptr, 0, nullptr, 0, nullptr, 0, nullptr, k))
             return pdf_launch_status();
     }
     rl::FwdArgs a;
@@ -278,31 +276,31 @@ extern "C" int pdf_bn_coef_from_partial(const float *partial, int rows, long n, 
                                         float *running_mean, float *running_var, float eps, float momentum, float *coef, void *stream);
 
 // pdf_rowlin_forward with statistics + the coefficients of the train-mode BatchNorm that follows (coef = scale | shift | mean | rstd, 4 o
-// floats; running statistics updated): with ticket words bound to the stream the coefficients are finished INSIDE the product's launch
-// (in-launch tail of the statistics epilogue), otherwise by the finalizer launch -- the same coefficients either way.
+// floats; running statistics updated): the product's epilogue emits per-row-block column sums, the finalizer launch turns them into the
+// coefficients (fixed order: bit-reproducible).
 extern "C" int pdf_rowlin_forward_bn(long n, int k, int o, const float *x, long ldx, const float *w, const float *bias, const float *scale,
                                      const float *shift, int relu, float *y, long ldy, float *partial, const float *gamma, const float *beta,
-                                     float *running_mean, float *running_var, float eps, float momentum, float *coef, void *stream) {
+                                     float *running_mean, float *running_var, float eps, float momentum, float *coef, int mma_input, void *stream) {
+    if (mma_input < 0 || mma_input > 2) return PDF_ERR_BAD_ARG;
     if (n < 1 || k < 1 || o < 1 || !x || !w || !y || !partial || !gamma || !beta || !coef || ldx < k || ldy < o) return PDF_ERR_BAD_ARG;
     if (rowlin_streams(k, o)) {
-        const rl2::StatsBn bn{gamma, beta, running_mean, running_var, eps, momentum, coef};
         int rows = 0;
-        if (rl2::try_forward(n, k, o, 1, 1, &x, ldx, &w, 0, &bias, scale, shift, relu, &y, ldy, 0, partial, static_cast<hipStream_t>(stream),
-                             nullptr, 0, nullptr, 0, nullptr, 0, &rows, &bn)) {
-            if (rows < 0) return pdf_launch_status();   // the tail wrote the coefficients
+        if (rl2::try_forward(n, k, o, 1, 1, &x, ldx, &w, 0, &bias, scale, shift, relu, &y, ldy, 0, partial, mma_input, static_cast<hipStream_t>(stream),
+                             nullptr, 0, nullptr, 0, nullptr, 0, &rows)) {
             return pdf_bn_coef_from_partial(partial, rows, n, o, gamma, beta, running_mean, running_var, eps, momentum, coef, stream);
         }
     }
-    const int rc = pdf_rowlin_forward(n, k, o, x, ldx, w, 0, bias, scale, shift, relu, y, ldy, 0, partial, stream);
+    const int rc = pdf_rowlin_forward(n, k, o, x, ldx, w, 0, bias, scale, shift, relu, y, ldy, 0, partial, mma_input, stream);
     if (rc) return rc;
     return pdf_bn_coef_from_partial(partial, pdf_rowlin_partial_rows(n, k, o), n, o, gamma, beta, running_mean, running_var, eps, momentum, coef, stream);
 }
 
 // dW (o, k) = G^T f(X), db (o) = column sums of G (db may be null); both are WRITTEN.  ws: pdf_rowlin_wgrad_ws_floats(n, k, o, 1) floats.
 extern "C" int pdf_rowlin_wgrad(long n, int k, int o, const float *g, long ldg, const float *x, long ldx,
-                                const float *scale, const float *shift, int relu, float *dw, float *db, float *ws, void *stream) {
+                                const float *scale, const float *shift, int relu, float *dw, float *db, float *ws, int mma_input, void *stream) {
+    if (mma_input < 0 || mma_input > 2) return PDF_ERR_BAD_ARG;
     if (n < 1 || k < 1 || o < 1 || !g || !x || !dw || !ws || ldg < o || ldx < k) return PDF_ERR_BAD_ARG;
-    if (rowlin_streams(k, o) && rl2::try_wgrad(n, k, o, 1, &g, ldg, x, ldx, scale, shift, relu, &dw, &db, ws, static_cast<hipStream_t>(stream)))
+    if (rowlin_streams(k, o) && rl2::try_wgrad(n, k, o, 1, &g, ldg, x, ldx, scale, shift, relu, &dw, &db, ws, mma_input, static_cast<hipStream_t>(stream)))
         return pdf_launch_status();
     rl::WArgs a;
     a.N = n; a.K = k; a.O = o; a.G = g; a.ldg = ldg; a.X = x; a.ldx = ldx; a.scale = scale; a.shift = shift; a.relu = relu;
@@ -329,19 +327,20 @@ extern "C" int pdf_rowlin_wgrad(long n, int k, int o, const float *g, long ldg, 
 // Shapes the streaming kernels do not cover are issued as single-layer launches.
 extern "C" int pdf_rowlin_multi(long n, int k, int o, int nin, int nout, const float *const *x, long ldx, const float *const *w,
                                 int transpose_w, const float *const *bias, const float *scale, const float *shift, int relu,
-                                float *const *y, long ldy, int accumulate, void *stream) {
+                                float *const *y, long ldy, int accumulate, int mma_input, void *stream) {
+    if (mma_input < 0 || mma_input > 2) return PDF_ERR_BAD_ARG;
     if (n < 1 || k < 1 || o < 1 || !x || !w || !y || nin < 1 || nout < 1 || nin > 3 || nout > 3 || (nin > 1 && nout > 1)) return PDF_ERR_BAD_ARG;
     if (rowlin_streams(k, o) && rl2::try_forward(n, k, o, nin, nout, x, ldx, w, transpose_w, bias, scale, shift, relu, y, ldy, accumulate,
-                                                 nullptr, static_cast<hipStream_t>(stream)))
+                                                 nullptr, mma_input, static_cast<hipStream_t>(stream)))
         return pdf_launch_status();
     int rc = 0;
     if (nin == 1) {
         for (int i = 0; i < nout && rc == 0; ++i)
-            rc = pdf_rowlin_forward(n, k, o, x[0], ldx, w[i], transpose_w, bias ? bias[i] : nullptr, scale, shift, relu, y[i], ldy, accumulate, nullptr, stream);
+            rc = pdf_rowlin_forward(n, k, o, x[0], ldx, w[i], transpose_w, bias ? bias[i] : nullptr, scale, shift, relu, y[i], ldy, accumulate, nullptr, mma_input, stream);
     } else {
         for (int i = 0; i < nin && rc == 0; ++i)
             rc = pdf_rowlin_forward(n, k, o, x[i], ldx, w[i], transpose_w, (i == 0 && bias) ? bias[0] : nullptr, scale, shift, relu, y[0], ldy,
-                                    accumulate || i > 0, nullptr, stream);
+                                    accumulate || i > 0, nullptr, mma_input, stream);
     }
     return rc;
 }
@@ -351,17 +350,15 @@ extern "C" int pdf_rowlin_multi(long n, int k, int o, int nin, int nout, const f
 // masked by the ReLU of bx * scale + shift, xhat = (bx - mean) * rstd; bcoef = [scale | shift | mean | rstd]) - what
 // pdf_bn_act_backward's first pass would compute from a second read of y and bx.  partial must hold pdf_rowlin_partial_floats(n, o).
 // PDF_ERR_UNSUPPORTED for shapes outside the streaming kernels (the caller then runs the two separate passes).
-// sums (2 o floats, may be null): with ticket words bound to the stream the finished sums are written there inside the launch and
-// *partial_rows is set to -1 (pdf_bn_act_backward_presummed then skips its column-sum launch).
 extern "C" int pdf_rowlin_dgrad_bstats(long n, int k, int o, int nin, const float *const *x, long ldx, const float *const *w, float *y, long ldy,
                                        const float *bx, long ldb, const float *bcoef, int brelu, float *partial, int *partial_rows,
-                                       float *sums, void *stream) {
+                                       int mma_input, void *stream) {
+    if (mma_input < 0 || mma_input > 2) return PDF_ERR_BAD_ARG;
     if (n < 1 || k < 1 || o < 1 || !x || !w || !y || nin < 1 || nin > 3 || !bx || !bcoef || !partial || !partial_rows) return PDF_ERR_BAD_ARG;
     if (!rowlin_streams(k, o)) return PDF_ERR_UNSUPPORTED;
     float *ys[1] = {y};
-    const rl2::StatsBn bn{nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, sums};
-    if (!rl2::try_forward(n, k, o, nin, 1, x, ldx, w, 1, nullptr, nullptr, nullptr, 0, ys, ldy, 0, partial, static_cast<hipStream_t>(stream),
-                          nullptr, 0, bx, ldb, bcoef, brelu, partial_rows, sums ? &bn : nullptr))
+    if (!rl2::try_forward(n, k, o, nin, 1, x, ldx, w, 1, nullptr, nullptr, nullptr, 0, ys, ldy, 0, partial, mma_input, static_cast<hipStream_t>(stream),
+                          nullptr, 0, bx, ldb, bcoef, brelu, partial_rows))
         return PDF_ERR_UNSUPPORTED;
     return pdf_launch_status();
 }
@@ -370,12 +367,13 @@ extern "C" int pdf_rowlin_dgrad_bstats(long n, int k, int o, int nin, const floa
 // ws: pdf_rowlin_wgrad_ws_floats(n, k, o, ng) floats.
 extern "C" int pdf_rowlin_wgrad_multi(long n, int k, int o, int ng, const float *const *g, long ldg, const float *x, long ldx,
                                       const float *scale, const float *shift, int relu, float *const *dw, float *const *db,
-                                      float *ws, void *stream) {
+                                      float *ws, int mma_input, void *stream) {
+    if (mma_input < 0 || mma_input > 2) return PDF_ERR_BAD_ARG;
     if (n < 1 || k < 1 || o < 1 || ng < 1 || ng > 3 || !g || !x || !dw || !ws) return PDF_ERR_BAD_ARG;
-    if (rowlin_streams(k, o) && rl2::try_wgrad(n, k, o, ng, g, ldg, x, ldx, scale, shift, relu, dw, db, ws, static_cast<hipStream_t>(stream)))
+    if (rowlin_streams(k, o) && rl2::try_wgrad(n, k, o, ng, g, ldg, x, ldx, scale, shift, relu, dw, db, ws, mma_input, static_cast<hipStream_t>(stream)))
         return pdf_launch_status();
     int rc = 0;   // (stream order: the next call reuses the workspace after this call's reduction has read it)
-    for (int i = 0; i < ng && rc == 0; ++i) rc = pdf_rowlin_wgrad(n, k, o, g[i], ldg, x, ldx, scale, shift, relu, dw[i], db ? db[i] : nullptr, ws, stream);
+    for (int i = 0; i < ng && rc == 0; ++i) rc = pdf_rowlin_wgrad(n, k, o, g[i], ldg, x, ldx, scale, shift, relu, dw[i], db ? db[i] : nullptr, ws, mma_input, stream);
     return rc;
 }
 
@@ -385,10 +383,11 @@ extern "C" int pdf_rowlin_wgrad_multi(long n, int k, int o, int ng, const float 
 // otherwise -- the caller then issues pdf_rowlin_wgrad per matrix).  ws: pdf_rowlin_wgrad_ws_floats(n, k, o, ng) floats.
 extern "C" int pdf_rowlin_wgrad_group(long n, int k, int o, int ng, const float *const *g, long ldg, const float *const *x, long ldx,
                                       const float *const *scale, const float *const *shift, const int *relu, float *const *dw,
-                                      float *const *db, float *ws, void *stream) {
+                                      float *const *db, float *ws, int mma_input, void *stream) {
+    if (mma_input < 0 || mma_input > 2) return PDF_ERR_BAD_ARG;
     if (n < 1 || k < 1 || o < 1 || ng < 1 || ng > rl2::WG_MAXG || !g || !x || !scale || !shift || !relu || !dw || !ws) return PDF_ERR_BAD_ARG;
     for (int i = 0; i < ng; ++i) if (!g[i] || !x[i] || !dw[i] || (scale[i] && !shift[i])) return PDF_ERR_BAD_ARG;
-    if (!rowlin_streams(k, o) || !rl2::try_wgrad_group(n, k, o, ng, g, ldg, x, ldx, scale, shift, relu, dw, db, ws, static_cast<hipStream_t>(stream)))
+    if (!rowlin_streams(k, o) || !rl2::try_wgrad_group(n, k, o, ng, g, ldg, x, ldx, scale, shift, relu, dw, db, ws, mma_input, static_cast<hipStream_t>(stream)))
         return PDF_ERR_UNSUPPORTED;
     return pdf_launch_status();
 }
@@ -396,19 +395,21 @@ extern "C" int pdf_rowlin_wgrad_group(long n, int k, int o, int ng, const float 
 // Row-weighted variants for the streaming shapes (csrc/transition_down.hip: Gram matrices x^T diag(cnt) x and the dense part of
 // the input gradient cnt .* (x Q)): y = roww[n] * (x Wt) (+)= ..., dW += sum_n roww[n] g[n]^T x[n].  roww has element stride rws.
 extern "C" int pdf_rowlin_forward_roww(long n, int k, int o, const float *x, long ldx, const float *w, int transpose_w, float *y, long ldy,
-                                       int accumulate, const float *roww, long rws, void *stream) {
+                                       int accumulate, const float *roww, long rws, int mma_input, void *stream) {
+    if (mma_input < 0 || mma_input > 2) return PDF_ERR_BAD_ARG;
     if (n < 1 || !x || !w || !y || !rowlin_streams(k, o)) return PDF_ERR_UNSUPPORTED;
     const float *bias = nullptr;
     if (!rl2::try_forward(n, k, o, 1, 1, &x, ldx, &w, transpose_w, &bias, nullptr, nullptr, 0, &y, ldy, accumulate, nullptr,
-                          static_cast<hipStream_t>(stream), roww, rws))
+                          mma_input, static_cast<hipStream_t>(stream), roww, rws))
         return PDF_ERR_UNSUPPORTED;
     return pdf_launch_status();
 }
 extern "C" int pdf_rowlin_wgrad_roww(long n, int k, int o, const float *g, long ldg, const float *x, long ldx, float *dw, const float *roww,
-                                     long rws, float *ws, void *stream) {
+                                     long rws, float *ws, int mma_input, void *stream) {
+    if (mma_input < 0 || mma_input > 2) return PDF_ERR_BAD_ARG;
     if (n < 1 || !g || !x || !dw || !ws || !rowlin_streams(k, o)) return PDF_ERR_UNSUPPORTED;
     float *db = nullptr;
-    if (!rl2::try_wgrad(n, k, o, 1, &g, ldg, x, ldx, nullptr, nullptr, 0, &dw, &db, ws, static_cast<hipStream_t>(stream), roww, rws))
+    if (!rl2::try_wgrad(n, k, o, 1, &g, ldg, x, ldx, nullptr, nullptr, 0, &dw, &db, ws, mma_input, static_cast<hipStream_t>(stream), roww, rws))
         return PDF_ERR_UNSUPPORTED;
     return pdf_launch_status();
 }

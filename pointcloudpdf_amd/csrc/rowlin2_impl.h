@@ -33,7 +33,7 @@ namespace rl2 {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Input precision of the products (template parameter MP of the kernels; pdf_set_mma_input, include/pdfops.h):
+// Input precision of the products (template parameter MP of the kernels; `mma_input` of the C entry points, include/pdfops.h):
 //   0  fp32 operands, v_mfma_f32_16x16x4_f32 (bit-equal to an fmaf chain) -- the default and the parity path;
 //   1  operands rounded to fp16 in registers, v_mfma_f32_16x16x16_f16;   2  the same with bfloat16, v_mfma_f32_16x16x16_bf16.
 // Activations, weights and gradients stay fp32 in HBM and the accumulators are fp32: what torch.autocast does to an nn.Linear
@@ -59,11 +59,7 @@ template <> struct Mma<2> {
     static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 acc) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc, 0, 0, 0); }
 };
 
-// BatchNorm that follows (ST == 1: coefficients, out = coef (4 O)) or whose backward sums are wanted (ST == 2: out = sums (2 O)):
-// handed to try_forward when the statistics should be FINISHED in the launch (in-launch tail); out == nullptr: rows only.
-struct StatsBn { const float *gamma, *beta; float *running_mean, *running_var; float eps, momentum; float *out; };
 long stats_rows_floats(long n, int o);
-long stats_tail_floats(long n, int o);
 
 struct FwdArgs {
     long N;
@@ -79,11 +75,6 @@ struct FwdArgs {
     // [sum g' | sum g' xhat] (g' = output masked by the ReLU of bx * scale + shift, xhat = (bx - mean) * rstd) instead of [sum | sum of squares]
     const float *bx; long ldb; const float *bcoef; int brelu;   // bx (N, O; row stride ldb), bcoef = [scale | shift | mean | rstd] (4 O)
     const float *roww; long rws;   // optional per-row factor of the product (y = roww[n] * (f(x) Wt) + bias), element stride rws
-    // In-launch tail of the statistics epilogue (pdfops_common.h: pdf_tail_sum; tickets == nullptr: rows only).  ST == 1: the last
-    // workgroup of a column slab turns the slab's sums into the BatchNorm coefficients (coef = scale | shift | mean | rstd, 4 O floats)
-    // and updates the running statistics; ST == 2: it writes the finished backward sums [sum g' | sum g' xhat] (2 O floats) to `tail_out`.
-    unsigned *tickets; double *grows; float *tail_out;
-    const float *gamma, *beta; float *running_mean, *running_var; float eps, momentum; double count;
 };
 
 constexpr int FWD_CAP = 1024;   // row-blocks (4 waves each) of the persistent grid
@@ -250,40 +241,6 @@ __global__ __launch_bounds__(256) void k_fwd(FwdArgs a) {
             row[gcol0 + t] = red[0][0][t] + red[1][0][t] + red[2][0][t] + red[3][0][t];      // STATS: single output, gcol0 == column
             const float ss = red[0][1][t] + red[1][1][t] + red[2][1][t] + red[3][1][t];
             row[a.O + gcol0 + t] = ST == 2 ? ss * a.bcoef[3 * (long)a.O + gcol0 + t] : ss;
-        }
-        if (a.tickets) {   // the slab's tail: its own tickets / group rows, columns [gcol0, gcol0 + w) of both halves of the rows
-            constexpr int w = NOB * 16;
-            __shared__ double fin[2 * w + 1];
-            __syncthreads();
-            const unsigned ng = (gridDim.x + PDF_TAIL_G - 1) / PDF_TAIL_G;
-            const int O = a.O;
-            const bool last = pdf_tail_sum(a.tickets + (size_t)blockIdx.y * (1 + ng), a.grows + (size_t)blockIdx.y * ng * 2 * w, a.partial, (size_t)2 * O,
-                                           2 * w, [=](int j) { return (size_t)(j < w ? gcol0 + j : O + gcol0 + (j - w)); }, gridDim.x, blockIdx.x,
-                                           reinterpret_cast<volatile unsigned *>(&fin[2 * w]), [&](int j, double v) { fin[j] = v; });
-            if (!last) return;
-            __syncthreads();
-            if (t < w) {
-                const int ch = gcol0 + t;
-                if (ST == 2) {
-                    a.tail_out[ch] = (float)fin[t];
-                    a.tail_out[O + ch] = (float)fin[w + t];
-                } else {   // fl::k_bn_finalize's arithmetic
-                    const double mean = fin[t] / a.count;
-                    double var = fin[w + t] / a.count - mean * mean;
-                    if (var < 0.0) var = 0.0;
-                    const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
-                    const float sc = a.gamma[ch] * rstd;
-                    a.tail_out[ch] = sc;
-                    a.tail_out[O + ch] = a.beta[ch] - (float)mean * sc;
-                    a.tail_out[2 * O + ch] = (float)mean;
-                    a.tail_out[3 * O + ch] = rstd;
-                    if (a.running_mean) {
-                        const double unbiased = a.count > 1.0 ? var * a.count / (a.count - 1.0) : var;
-                        a.running_mean[ch] = (1.f - a.momentum) * a.running_mean[ch] + a.momentum * (float)mean;
-                        a.running_var[ch] = (1.f - a.momentum) * a.running_var[ch] + a.momentum * (float)unbiased;
-                    }
-                }
-            }
         }
     }
 }
@@ -528,12 +485,9 @@ static int launch_fwd(const FwdArgs &a, int nslabs, hipStream_t s) {   // return
     return gx;
 }
 
-// rows of the statistics epilogue [row blocks][2 O] floats (rounded to an even count: the tail's group rows -- doubles -- follow)
+// rows of the statistics epilogue [row blocks][2 O] floats
 #ifdef RL2_MAIN_TU
-long stats_rows_floats(long n, int o) { return (((long)fwd_row_blocks(n) * 2 * o + 1) / 2) * 2; }
-#endif
-#ifdef RL2_MAIN_TU
-long stats_tail_floats(long n, int o) { return 2L * ((fwd_row_blocks(n) + PDF_TAIL_G - 1) / PDF_TAIL_G) * 2 * o; }
+long stats_rows_floats(long n, int o) { return (long)fwd_row_blocks(n) * 2 * o; }
 #endif
 
 // returns 1 when a streaming kernel took the job, 0 when the shape is not covered (caller falls back to the tiled kernel)
@@ -541,7 +495,7 @@ template <int MP>
 int try_forward_mp(long n, int k, int o, int nin, int nout, const float *const *x, long ldx, const float *const *w, int transpose_w,
                    const float *const *bias, const float *scale, const float *shift, int relu, float *const *y, long ldy,
                    int accumulate, float *partial, hipStream_t s, const float *roww, long rws, const float *bx, long ldb, const float *bcoef,
-                   int brelu, int *partial_rows, const StatsBn *bn, long ldw) {
+                   int brelu, int *partial_rows, long ldw) {
     if (nin < 1 || nout < 1 || (nin > 1 && nout > 1) || nin > 3 || nout > 3) return 0;
     if (nin == 2 && (scale || bx)) return 0;   // (the two-window form: plain product only)
     if (partial && !bx && (nin != 1 || nout != 1)) return 0;
@@ -555,14 +509,6 @@ int try_forward_mp(long n, int k, int o, int nin, int nout, const float *const *
     a.N = n; a.O = o; a.ldx = ldx; a.ldy = ldy; a.scale = scale; a.shift = shift; a.relu = relu; a.accumulate = accumulate;
     a.partial = partial; a.roww = roww; a.rws = rws;
     a.bx = bx; a.ldb = ldb; a.bcoef = bcoef; a.brelu = brelu;
-    a.tickets = nullptr; a.grows = nullptr; a.tail_out = nullptr; a.gamma = a.beta = nullptr; a.running_mean = a.running_var = nullptr;
-    a.eps = a.momentum = 0.f; a.count = (double)n;
-    if (partial && bn && bn->out) {   // in-launch tail: needs the stream's ticket words and room for the group rows behind the rows
-        a.tickets = pdf_tickets_for(s, n);
-        a.grows = reinterpret_cast<double *>(partial + stats_rows_floats(n, o));
-        a.tail_out = bn->out; a.gamma = bn->gamma; a.beta = bn->beta; a.running_mean = bn->running_mean; a.running_var = bn->running_var;
-        a.eps = bn->eps; a.momentum = bn->momentum;
-    }
     a.wso = transpose_w ? 1 : (ldw ? ldw : k); a.wsk = transpose_w ? o : 1;   // ldw: row stride of an (o, k) window of a wider weight matrix
     for (int i = 0; i < 3; ++i) {
         a.X[i] = i < nin ? x[i] : nullptr;
@@ -572,9 +518,8 @@ int try_forward_mp(long n, int k, int o, int nin, int nout, const float *const *
     }
     const int cols = o * nout;
 #define PDF_RL2(K_, NOB_, NIN_) do { if (cols % (NOB_ * 16) == 0) { \
-        if (a.tickets && (1 + (fwd_row_blocks(n) + PDF_TAIL_G - 1) / PDF_TAIL_G) * (cols / (NOB_ * 16)) > PDF_TICKET_WORDS) a.tickets = nullptr; \
         const int r_ = launch_fwd<K_, NOB_, NIN_, MP>(a, cols / (NOB_ * 16), s); \
-        if (partial_rows) *partial_rows = a.tickets ? -1 : r_;   /* -1: the tail finished the sums / coefficients in the launch */ \
+        if (partial_rows) *partial_rows = r_; \
         return 1; } } while (0)
     if (nin == 1) {
         switch (k) {

@@ -40,11 +40,16 @@ __global__ __launch_bounds__(SB) void k_stage_copy(const Table t) {
     } else {   // 4-byte elements (every table is int32 / float32 / float64): tails, unaligned slices, the subtracting segments
         const long n4 = n >> 2;
         // a window that starts at a device-side offset must not leave its source array (src_elems; the tail of such a window is never
-        // read by the consumer: entries of placeholder rows)
-        const long last = s.src_elems > 0 ? (long)s.src_elems - 1 - (soff >> 2) - (base >> 2) : n4;
+        // read by the consumer: entries of placeholder rows).  The clamp is on the ABSOLUTE element index: a chunk that lies wholly past
+        // the array re-reads the array's last element (round 3 clamped relative to the chunk and read s.src[soff + base] itself then).
+        const int *arr = static_cast<const int *>(s.src);
+        const long first = (soff + base) >> 2;
+        const long avail_last = s.src_elems > 0 ? (long)s.src_elems - 1 : first + n4 - 1;
         for (long e = threadIdx.x; e < n4; e += SB) {
-            const long es = e <= last ? e : (last > 0 ? last : 0);
-            reinterpret_cast<int *>(dst)[e] = reinterpret_cast<const int *>(src)[es] - sub;
+            long a = first + e;
+            a = a <= avail_last ? a : avail_last;
+            a = a > 0 ? a : 0;
+            reinterpret_cast<int *>(dst)[e] = arr[a] - sub;
         }
     }
 }

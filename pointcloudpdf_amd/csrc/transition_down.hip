@@ -490,7 +490,7 @@ extern "C" long pdf_td_bwd_scratch_floats(long m, int cin, int cout) {
 // Forward.  p[]: 0 x (n,cin) | 1 idx (m,16) | 2 rel4 (m,16,4) | 3 Z (n,32) = [R | cnt | 0] | 4 consts (16) = [S_rr | s_r] | 5 W (cout, 3+cin)
 //   6 gamma 7 beta 8 running_mean 9 running_var | outputs: 10 coef (4 cout) 11 out (m,cout) 12 arg (m,cout) u8 13 gram (pdf_td_gram_floats)
 //   14 scratch (pdf_td_fwd_scratch_floats(n, cin); training only)
-extern "C" int pdf_td_forward(long n, long m, int cin, int cout, void *const *p, int training, float eps, float momentum, void *stream) {
+extern "C" int pdf_td_forward(long n, long m, int cin, int cout, void *const *p, int training, float eps, float momentum, int mma_input, void *stream) {
     if (n < 1 || m < 1 || !p) return PDF_ERR_BAD_ARG;
     if (!pdf_td_supported(16, cin, cout)) return PDF_ERR_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -501,9 +501,9 @@ extern "C" int pdf_td_forward(long n, long m, int cin, int cout, void *const *p,
     int rc = 0;
     if (training) {
         if (!p[14]) return PDF_ERR_BAD_ARG;
-        rc = pdf_rowlin_wgrad_roww(n, cin, cin, x, cin, x, cin, gxx, Z + 3, 32, (float *)p[14], stream);       // x^T diag(cnt) x (written)
+        rc = pdf_rowlin_wgrad_roww(n, cin, cin, x, cin, x, cin, gxx, Z + 3, 32, (float *)p[14], mma_input, stream);       // x^T diag(cnt) x (written)
         if (rc) return rc;
-        rc = pdf_rowlin_wgrad_roww(n, cin, 32, Z, 32, x, cin, gz, nullptr, 0, (float *)p[14], stream);        // [R | cnt]^T x
+        rc = pdf_rowlin_wgrad_roww(n, cin, 32, Z, 32, x, cin, gz, nullptr, 0, (float *)p[14], mma_input, stream);        // [R | cnt]^T x
         if (rc) return rc;
         td::k_td_coef<<<cout, 256, 0, s>>>(cin, cout, (double)m * 16.0, W, consts, gz, gxx, gamma, beta, eps, momentum, (float *)p[8],
                                            (float *)p[9], coef);
@@ -523,7 +523,7 @@ extern "C" int pdf_td_forward(long n, long m, int cin, int cout, void *const *p,
 //   17 inv_off (n + 1), 18 inv_entry: the INVERSE of the grouping table idx (entries i * 16 + j grouped by source point, ascending inside a
 //   point; csrc/seg_gather.hip), entry ids offset by entry_base: the sparse input gradient then runs in destination order without
 //   atomics (bit-reproducible); both null: the scatter kernel with float atomics (not reproducible run to run)
-extern "C" int pdf_td_backward(long n, long m, int cin, int cout, void *const *p, int entry_base, void *stream) {
+extern "C" int pdf_td_backward(long n, long m, int cin, int cout, void *const *p, int entry_base, int mma_input, void *stream) {
     if (n < 1 || m < 1 || !p) return PDF_ERR_BAD_ARG;
     if (!pdf_td_supported(16, cin, cout)) return PDF_ERR_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -540,9 +540,9 @@ extern "C" int pdf_td_backward(long n, long m, int cin, int cout, void *const *p
     if (rc) return rc;
     td::k_td_small1<<<cout, 256, 0, s>>>(cin, cout, rows, W, consts, gz, gxx, coef, dgb, AB, dW);
     td::k_td_small2<<<3 + cin + 1, 256, 0, s>>>(cin, cout, W, AB, Qp, QqT);
-    rc = pdf_rowlin_forward_roww(n, cin, cin, x, cin, Qp, 0, gx, cin, 0, Z + 3, 32, stream);     // gx = cnt .* (x Qp^T)
+    rc = pdf_rowlin_forward_roww(n, cin, cin, x, cin, Qp, 0, gx, cin, 0, Z + 3, 32, mma_input, stream);     // gx = cnt .* (x Qp^T)
     if (rc) return rc;
-    rc = pdf_rowlin_forward_roww(n, 32, cin, Z, 32, QqT, 0, gx, cin, 1, nullptr, 0, stream);     // gx += Z QqT^T
+    rc = pdf_rowlin_forward_roww(n, 32, cin, Z, 32, QqT, 0, gx, cin, 1, nullptr, 0, mma_input, stream);     // gx += Z QqT^T
     if (rc) return rc;
     if (p[17] && p[18]) {
         const int *inv_off = (const int *)p[17], *inv_entry = (const int *)p[18];

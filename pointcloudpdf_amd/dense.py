@@ -45,6 +45,13 @@ def _amp_bwd(fn):
 
 import torch.nn.functional as F
 
+
+def _mma():
+    """product-input mode of the calling thread (the `mma_input` argument of the C entry points, _native.mma_input)"""
+    from . import _native
+    return _native.current_mma_input()
+
+
 _CHUNK = 2048
 _MIN_ROWS = 16384
 
@@ -640,7 +647,7 @@ class _TransitionDownFn(torch.autograd.Function):
         ptrs = [x.data_ptr(), idx.data_ptr(), rel4.data_ptr(), Z.data_ptr(), consts.data_ptr(), W.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                 bn.running_mean.data_ptr(), bn.running_var.data_ptr(), coef.data_ptr(), out.data_ptr(), arg.data_ptr(), gram.data_ptr(), ws.data_ptr()]
         rc = lib.pdf_td_forward(n, m, cin, cout, (c_void_p * len(ptrs))(*ptrs), int(training), ctypes.c_float(bn.eps),
-                                ctypes.c_float(bn.momentum), be._stream())
+                                ctypes.c_float(bn.momentum), _mma(), be._stream())
         if rc != 0:
             raise RuntimeError(f"pdf_td_forward failed with status {rc}")
         ctx.save_for_backward(x, idx, rel4, Z, consts, W, gamma, beta, coef, out, arg, gram)
@@ -666,7 +673,7 @@ class _TransitionDownFn(torch.autograd.Function):
         ptrs = [gout.data_ptr(), out.data_ptr(), arg.data_ptr(), x.data_ptr(), idx.data_ptr(), rel4.data_ptr(), Z.data_ptr(), consts.data_ptr(),
                 W.data_ptr(), gamma.data_ptr(), beta.data_ptr(), coef.data_ptr(), gram.data_ptr(), gx.data_ptr(), dW.data_ptr(), dgb.data_ptr(),
                 scratch.data_ptr(), inv_off.data_ptr(), inv_entry.data_ptr()]
-        rc = lib.pdf_td_backward(n, m, cin, cout, (c_void_p * len(ptrs))(*ptrs), int(entry_base), be._stream())
+        rc = lib.pdf_td_backward(n, m, cin, cout, (c_void_p * len(ptrs))(*ptrs), int(entry_base), _mma(), be._stream())
         if rc != 0:
             raise RuntimeError(f"pdf_td_backward failed with status {rc}")
         return None, None, None, None, None, gx, dW, dgb[cout:], dgb[:cout]
@@ -710,7 +717,7 @@ class _LinBnFn(torch.autograd.Function):
         ptrs = [x.data_ptr(), W.data_ptr(), b.data_ptr() if b is not None else None, gamma.data_ptr(), beta.data_ptr(),
                 bn.running_mean.data_ptr(), bn.running_var.data_ptr(), z.data_ptr(), coef.data_ptr(), y.data_ptr(), partial.data_ptr()]
         rc = lib.pdf_linbn_forward(n, k, o, (c_void_p * len(ptrs))(*ptrs), int(training), int(relu), ctypes.c_float(bn.eps),
-                                   ctypes.c_float(bn.momentum), be._stream())
+                                   ctypes.c_float(bn.momentum), _mma(), be._stream())
         if rc != 0:
             raise RuntimeError(f"pdf_linbn_forward failed with status {rc}")
         ctx.save_for_backward(x, z, coef, W)
@@ -735,7 +742,7 @@ class _LinBnFn(torch.autograd.Function):
         ws = be.wgrad_workspace(n, k, o, 1, x.device)
         ptrs = [gy.data_ptr(), x.data_ptr(), z.data_ptr(), coef.data_ptr(), W.data_ptr(), gx.data_ptr() if need_gx else None, grads.data_ptr(),
                 gz.data_ptr(), partial.data_ptr(), ws.data_ptr()]
-        rc = lib.pdf_linbn_backward(n, k, o, (c_void_p * len(ptrs))(*ptrs), int(training), int(relu), be._stream())
+        rc = lib.pdf_linbn_backward(n, k, o, (c_void_p * len(ptrs))(*ptrs), int(training), int(relu), _mma(), be._stream())
         if rc != 0:
             raise RuntimeError(f"pdf_linbn_backward failed with status {rc}")
         ok = o * k

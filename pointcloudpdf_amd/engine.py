@@ -106,11 +106,16 @@ class CapturedStep:
 
     def __init__(self, step, batch, geom=None, warmup=2, autocast=None, loss_scale=1.0):
         """``autocast``: torch.float16 / torch.bfloat16 -> the forward is captured under torch.autocast (the path then runs its
-        reduced-precision products, dense.fp32_path); ``loss_scale``: static scale of the loss for the backward (fp16 operands: gradients of
-        ~1e-6 are below fp16's normal range), divided out of the gradients again inside the graph."""
+        reduced-precision products, dense.fp32_path).  ``loss_scale``: a ``DeviceGradScaler`` (the reference's AMP loop,
+        engines/train.py:343-355: the captured backward starts from ``loss * scale`` with the scale read from DEVICE memory at replay time,
+        and the gradients stay scaled until ``scaler.step(optimizer)`` / ``scaler.unscale_(optimizer)`` outside the graph -- after the
+        data-parallel exchange, as torch orders it), or a float: static scale, divided out of the gradients again inside the graph
+        (no overflow check: bench / A-B use only)."""
         from .geometry import Geometry, StaticGeometry
 
-        self.autocast, self.loss_scale = autocast, float(loss_scale)
+        self.autocast = autocast
+        self.scaler = loss_scale if isinstance(loss_scale, DeviceGradScaler) else None
+        self.loss_scale = 1.0 if self.scaler is not None else float(loss_scale)
 
         assert step.training, "CapturedStep captures a TRAINING step (forward + backward)"
         self.step = step
@@ -152,6 +157,7 @@ class CapturedStep:
             self.out = self._eager()
             self._backward(self.out)
         self.grads = [p.grad for p in self.params]
+        self.frozen = self._python_state()
         with torch.no_grad():   # (the capture itself does not execute anything, but keep the contract obvious)
             for b, v in zip(buffers, saved):
                 b.copy_(v)
@@ -162,15 +168,28 @@ class CapturedStep:
             return self.step(dict(self.static, pdf_geometry=self.geometry))
 
     def _backward(self, out):
-        if self.loss_scale == 1.0:
+        if self.scaler is not None:
+            self.scaler.scale(out["loss"]).backward()
+        elif self.loss_scale == 1.0:
             out["loss"].backward()
         else:
             (out["loss"] * self.loss_scale).backward()
             with torch.no_grad():
                 torch._foreach_mul_([p.grad for p in self.params if p.grad is not None], 1.0 / self.loss_scale)
 
+    def _python_state(self):
+        """Python-side scalars the capture bakes into the graph: the recognizer's loss weight ``alpha`` (decayed once at ``start_epoch``),
+        whether the PDF loss is active (epoch gate), ``step_loss_weight``, train / eval mode of every module, the autocast mode."""
+        rec = self.step.recognizer
+        return (float(getattr(rec, "alpha", 0.0)), int(getattr(rec, "epoch", 0)) >= int(getattr(rec, "start_epoch", 0)),
+                bool(getattr(rec, "step_loss_weight", False)), tuple(m.training for m in self.step.modules()), self.autocast)
+
     def matches(self, batch):
-        return [int(v) for v in batch["offset_host"]] == self.sizes and all(batch[k].shape == self.static[k].shape for k in self.KEYS)
+        """True when the captured graph IS this step: same scene sizes / shapes and the same Python-side schedule state as at capture.
+        (A graph replays what was recorded: after ``PointPdfV1.trigger_operation`` moved ``alpha`` or an epoch gate opened, or after
+        ``step.eval()``, the caller must run the eager step or capture again -- ``__call__`` refuses a stale graph.)"""
+        return ([int(v) for v in batch["offset_host"]] == self.sizes and all(batch[k].shape == self.static[k].shape for k in self.KEYS)
+                and self._python_state() == self.frozen)
 
     @torch.no_grad()
     def __call__(self, batch, geom):
@@ -178,11 +197,223 @@ class CapturedStep:
         pre-pass or its share of a grouped one).  Two launches: the staging copy (batch tensors + ~70 tables into the fixed-address
         buffers, csrc/stage_copy.hip) and the graph.  Returns the static output dict (``loss``, ``model_loss``, ``recognizer_loss``,
         ``score``: overwritten by the next call); gradients are in ``p.grad``."""
+        if self._python_state() != self.frozen:
+            raise RuntimeError("CapturedStep: the step's Python-side state (recognizer alpha / epoch gate / step_loss_weight / train mode / "
+                               f"autocast) changed since the capture: {self.frozen} -> {self._python_state()}; capture again "
+                               "(CapturedStep(step, batch, ...)) or run the eager step")
         self.geometry.stage(geom, extra=[(batch[k], self.static[k]) for k in self.KEYS])
         self.graph.replay()
         for p, g in zip(self.params, self.grads):
             p.grad = g
         return self.out
+
+
+class GroupedGeometryLoader:
+    """Wraps the training loader (any iterable of batch dicts: the reference's ``build_train_loader`` result,
+    pointcept/engines/train.py:426-465) and yields the same batches with the coordinate-only tables of the step attached
+    (``batch["pdf_geometry"]``: 4 FPS levels, 13 kNN tables, interpolation / inverse tables -- ``geometry.Geometry``), computed AHEAD of
+    the step on a side HIP stream:
+
+        loader = engine.GroupedGeometryLoader(build_train_loader(...), group=12)
+        for batch in loader:              # batch tensors on the device, batch["pdf_geometry"] ready (stream-ordered, no host sync)
+            out = train_step(batch)
+
+    Why a group: farthest-point sampling is a chain of dependent arg-max steps on ONE workgroup per scene (100k -> 25k points: ~33 ms)
+    that more CUs cannot shorten, so a per-batch pre-pass inline costs ~50 ms of latency per step.  The pre-pass of the NEXT ``group``
+    batches runs as one launch sequence (one FPS launch with 2 * group workgroups, kNN launches ``group`` times larger) while the
+    current group trains; ``Geometry.split`` hands out per-batch views that are bit-identical to a pre-pass of the batch alone
+    (tests: test_geometry_split_matches_per_batch_prepass, test_grouped_loader_steps_are_bit_identical_to_serial_steps).  Every batch
+    gets exactly one full pre-pass; nothing is cached across batches.  Two batches of look-ahead already clear 5 M points/s on
+    2 x 100k-point batches; the default (12) also amortises the kNN launches.
+
+    Timing owned here (none of it is the caller's business): the next group is pulled from the wrapped loader and its pre-pass
+    submitted right after the consumer came back for batch ``submit_delay`` of the current group -- i.e. AFTER that many training steps
+    of the group were enqueued, so the ~10 ms of host work of a submission never sits in front of a step -- and the pre-pass waits
+    only for the batch tensors (an event recorded when they were moved), not for the steps queued since.
+    ``first_group``: size of the first group only (default ``group``): a short first group gets the first batch out sooner.
+    The wrapped loader should have its batches ready when a group is pulled (``DataLoader(prefetch_factor >= group / num_workers)``).
+    """
+
+    MAX_SCENES = 64   # scenes per grouped kNN / FPS call (workspace layout of the grid kNN)
+
+    def __init__(self, loader, group=12, device=None, first_group=None, submit_delay=2, prefetcher=None, threaded=False, key="pdf_geometry",
+                 **plan):
+        """``prefetcher`` / ``key``: another coordinate-only pre-pass with the same ``submit_group(batches, ready=)`` / ``get(ticket)``
+        interface and the batch key its result goes under (``stratified.StratifiedPrefetcher`` -> "st_geometry": BASELINE config 5)."""
+        from .geometry import GeometryPrefetcher
+
+        self.key = key
+
+        self.loader, self.group = loader, max(int(group), 0)
+        self.first_group = self.group if first_group is None else max(int(first_group), 1)
+        self.device = torch.device(device) if device is not None else None
+        self.submit_delay = max(int(submit_delay), 0)
+        self.prefetcher = prefetcher if prefetcher is not None else (GeometryPrefetcher(depth=2, threaded=threaded, **plan) if self.group > 0 else None)
+        self.submit_host_s = []   # host time of every group submission (diagnostics)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _to_device(self, batch):
+        dev = self.device
+        if dev is None:
+            return batch
+        out = dict(batch)
+        for k, v in batch.items():   # engines/train.py:373-376: every tensor of the input dict moves to the device
+            if torch.is_tensor(v) and v.device != dev:
+                out[k] = v.to(dev, non_blocking=True)
+        return out
+
+    @staticmethod
+    def _with_host_offset(batch):
+        if "offset_host" not in batch:   # scene ends on the host: level sizes of the pre-pass without a device sync per level
+            batch = dict(batch)
+            batch["offset_host"] = [int(v) for v in batch["offset"].tolist()]
+        return batch
+
+    def _pull(self, it, n):
+        """Up to ``n`` batches (fewer at the end of the epoch, or when the scene budget of one grouped call is reached) -> list | None."""
+        got, scenes = [], 0
+        while len(got) < n:
+            held = getattr(self, "_held", None)
+            self._held = None
+            if held is None:
+                try:
+                    held = self._with_host_offset(next(it))
+                except StopIteration:
+                    break
+            k = len(held["offset_host"])
+            if got and scenes + k > self.MAX_SCENES:
+                self._held = held
+                break
+            got.append(self._to_device(held))
+            scenes += k
+        return got or None
+
+    def _submit(self, batches):
+        import time
+
+        t0 = time.perf_counter()
+        ready = None
+        if torch.cuda.is_available():
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream())   # the batch tensors are complete HERE; steps queued later do not delay the pre-pass
+        tickets = self.prefetcher.submit_group(batches, ready=ready)
+        self.submit_host_s.append(time.perf_counter() - t0)
+        return list(zip(batches, tickets))
+
+    def __iter__(self):
+        it = iter(self.loader)
+        self._held = None
+        if self.group == 0:   # no look-ahead: the model computes the tables inline (serial step)
+            for batch in it:
+                yield self._to_device(self._with_host_offset(batch))
+            return
+        first = self._pull(it, self.first_group)
+        if first is None:
+            return
+        current, upcoming, exhausted = self._submit(first), None, False
+        while current is not None:
+            delay = min(self.submit_delay, len(current) - 1)
+            for j, (batch, ticket) in enumerate(current):
+                if j == delay and upcoming is None and not exhausted:   # (we are back for batch j: j steps of this group are enqueued)
+                    nxt = self._pull(it, self.group)
+                    if nxt is None:
+                        exhausted = True
+                    else:
+                        upcoming = self._submit(nxt)
+                batch = dict(batch)
+                batch[self.key] = self.prefetcher.get(ticket)   # consumer stream waits for the pre-pass (stream-ordered)
+                yield batch
+            current, upcoming = upcoming, None
+
+
+class TrainStep:
+    """One optimisation step on one batch -- ``Trainer.run_step`` of the reference (pointcept/engines/train.py:334-371): forward under
+    autocast when AMP is on, (scaled) backward, gradient exchange, optimizer step, scaler update -- with forward + backward REPLAYED from
+    a ``CapturedStep`` whenever the batch has the captured scene sizes (``graph=True``; the capture happens on the first such batch), and
+    issued eagerly otherwise (other sizes, ``eager=True``, or a changed Python-side schedule state: see ``CapturedStep.matches``).
+
+        train_step = engine.TrainStep(step, optimizer, exchange=engine.FlatGradAllReduce(step), autocast=torch.float16,
+                                      scaler=engine.DeviceGradScaler(device))
+        for batch in engine.GroupedGeometryLoader(loader, group=12):
+            out = train_step(batch)       # dict(loss, model_loss, recognizer_loss, score)
+    """
+
+    def __init__(self, step, optimizer, exchange=None, scaler=None, autocast=None, graph=True, force_exchange=False, loss_scale=1.0, module=None):
+        """``module``: what the eager forward calls (a torch DistributedDataParallel wrapper of ``step``; default ``step`` itself);
+        ``loss_scale``: static loss scale when no ``scaler`` is given (A/B runs; no overflow check)."""
+        self.step, self.optimizer, self.exchange, self.scaler, self.autocast = step, optimizer, exchange, scaler, autocast
+        self.module = module if module is not None else step
+        self.graph, self.captured, self.capture_error = bool(graph), None, None
+        self.force_exchange, self.loss_scale = force_exchange, float(loss_scale)
+        self.params = [p for p in step.parameters() if p.requires_grad]
+
+    def capture(self, batch, geom=None):
+        self.captured = CapturedStep(self.step, batch, geom=geom, autocast=self.autocast,
+                                     loss_scale=self.scaler if self.scaler is not None else self.loss_scale)
+        return self.captured
+
+    def drop_capture(self):
+        """Release the captured graph and every autograd / gradient reference it pinned (eager steps run at full speed again)."""
+        import gc
+
+        self.captured, self.graph = None, False
+        torch.cuda.synchronize()
+        release_autograd_state(self.step)
+        for p in self.params:
+            p.grad = None
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    def _eager(self, batch):
+        # An eager step between replays runs on the capture's stream: the parameters' AccumulateGrad nodes are bound to it while the
+        # captured autograd graph lives, and on any other stream the engine synchronises every one of them (20-40 ms instead of 16).
+        cur = torch.cuda.current_stream()
+        run_on = self.captured.stream if self.captured is not None else cur
+        if run_on is not cur:
+            run_on.wait_stream(cur)
+        with torch.cuda.stream(run_on):
+            for p in self.params:
+                p.grad = None
+            with torch.autocast("cuda", dtype=self.autocast or torch.float16, enabled=self.autocast is not None):
+                out = self.module(batch)
+            if self.scaler is not None:
+                self.scaler.scale(out["loss"]).backward()
+            elif self.loss_scale == 1.0:
+                out["loss"].backward()
+            else:
+                (out["loss"] * self.loss_scale).backward()
+                with torch.no_grad():
+                    torch._foreach_mul_([p.grad for p in self.params if p.grad is not None], 1.0 / self.loss_scale)
+        if run_on is not cur:
+            cur.wait_stream(run_on)
+        return out
+
+    def __call__(self, batch, eager=False):
+        geom = batch.get("pdf_geometry")
+        if self.graph and self.captured is None and self.capture_error is None and not eager:
+            try:
+                self.capture(batch, geom)
+            except Exception as e:   # noqa: BLE001  (a stack that cannot capture the step trains on the eager path)
+                self.capture_error = f"{type(e).__name__}: {e}"
+                self.drop_capture()
+        cap = self.captured
+        if cap is not None and not eager and cap.matches(batch):
+            if geom is None:   # no look-ahead: the pre-pass inline on this stream
+                from .geometry import Geometry
+                geom = Geometry(batch["coord"], batch["offset"], batch["offset_host"]).precompute()
+            out = cap(batch, geom)
+        else:
+            out = self._eager(batch)
+        if self.exchange is not None:
+            self.exchange.sync(force=self.force_exchange)   # ONE all-reduce (RCCL) over the flat gradient buffer
+        if self.scaler is not None:
+            self.scaler.step(self.optimizer)
+            self.scaler.update()
+        else:
+            self.optimizer.step()
+        return out
 
 
 def wrap_ddp(module, device):
@@ -250,39 +481,62 @@ class FusedSGD(torch.optim.Optimizer):
 
     A ``torch.optim.Optimizer``: ``param_groups`` (``lr`` / ``momentum`` / ``weight_decay`` are read from the group at every step, so
     torch's LR schedulers attach to it -- the reference steps its scheduler every iteration, engines/train.py:366), ``state_dict`` /
-    ``load_state_dict`` with torch.optim.SGD's own layout (``state[p]["momentum_buffer"]``: checkpoints move both ways).  Parameter and
-    momentum pointers are read at every step (``model.to()``, ``load_state_dict`` may move them)."""
+    ``load_state_dict`` with torch.optim.SGD's own layout: ``state[p]["momentum_buffer"]`` and param groups that carry every key
+    torch.optim.SGD's do (``dampening`` 0, ``nesterov`` False, ``maximize`` False, ``foreach`` / ``fused`` None, ``differentiable``
+    False), so checkpoints move both ways (tests/test_ddp_gloo.py: test_fused_sgd_state_dict_round_trip).  ``dampening != 0``,
+    ``nesterov`` and ``maximize`` are refused at ``step()``.  Parameter and momentum pointers are read at every step (``model.to()``,
+    ``load_state_dict`` may move them)."""
 
     RING = 8   # pinned pointer tables in flight (the host may run several steps ahead of the device)
+    SGD_DEFAULTS = dict(dampening=0, nesterov=False, maximize=False, foreach=None, differentiable=False, fused=None)   # torch.optim.SGD's other keys
 
-    def __init__(self, params, lr, momentum=0.9, weight_decay=0.0):
+    def __init__(self, params, lr, momentum=0.9, weight_decay=0.0, backend=None):
         import ctypes
         from . import _native
 
-        self.be = _native.hip_backend()
+        self.be = backend if backend is not None else _native.hip_backend()   # (backend: tests of the host logic without a GPU)
         self.ctypes = ctypes
-        super().__init__(params, dict(lr=float(lr), momentum=float(momentum), weight_decay=float(weight_decay)))
-        for group in self.param_groups:
-            group["params"] = [p for p in group["params"] if p.requires_grad]
+        self._rows = 0
+        self._ring, self._tabs, self._spare, self._captured, self._plans, self._n = [], [], [], [], {}, 0
+        super().__init__(params, dict(lr=float(lr), momentum=float(momentum), weight_decay=float(weight_decay), **self.SGD_DEFAULTS))
         every = [p for group in self.param_groups for p in group["params"]]
-        assert every and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in every)
+        assert every and all(p.dtype == torch.float32 and p.is_contiguous() for p in every)
         self.device = every[0].device
         for p in every:
             self.state[p]["momentum_buffer"] = torch.zeros_like(p)
-        self.chunk = int(self.be.lib.pdf_sgd_chunk())
-        self._plans = {}      # (group, tuple of parameter indices with a gradient) -> (chunk list on the device, number of chunks, lengths)
-        rows = max(len(g["params"]) for g in self.param_groups)
-        self._ring = [(torch.empty((rows, 4), dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(self.RING)]
-        self._tabs = [torch.empty((rows, 4), dtype=torch.int64, device=self.device) for _ in range(self.RING)]
-        self._n = 0
-        self._captured = []   # pointer tables of captured steps (hipGraph replays read them)
-        self._spare = []
+        self.chunk = int(self.be.lib.pdf_sgd_chunk()) if self.be is not None else 4096
+        self._size_tables()
         self.reserve_capture_tables(2 * len(self.param_groups))
+
+    def add_param_group(self, param_group):
+        """torch.optim.Optimizer.add_param_group + the pointer tables re-sized for the largest group (they are pinned once, not per step)."""
+        super().add_param_group(param_group)
+        group = self.param_groups[-1]
+        group["params"] = [p for p in group["params"] if p.requires_grad]
+        if self._rows:   # (during __init__ the tables are sized once, after every group is in)
+            self._size_tables()
+
+    def _size_tables(self):
+        rows = max(len(g["params"]) for g in self.param_groups)
+        if rows <= self._rows:
+            return
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("FusedSGD.add_param_group: pinning host memory is not allowed during stream capture")
+        for _, ev in self._ring:   # tables of steps still in flight stay alive until their launch has run
+            if ev is not None:
+                ev.synchronize()
+        self._rows = rows
+        pin = (lambda t: t.pin_memory()) if self.device.type == "cuda" else (lambda t: t)
+        self._ring = [(pin(torch.empty((rows, 4), dtype=torch.int64)), torch.cuda.Event() if self.device.type == "cuda" else None)
+                      for _ in range(self.RING)]
+        self._tabs = [torch.empty((rows, 4), dtype=torch.int64, device=self.device) for _ in range(self.RING)]
+        self._spare = [pin(torch.empty((rows, 4), dtype=torch.int64)) for _ in self._spare]
+        self._plans = {}
 
     def reserve_capture_tables(self, n):
         """Pinned pointer tables for ``n`` more (group, captured step) pairs; must be called outside stream capture."""
-        rows = max(len(g["params"]) for g in self.param_groups)
-        self._spare += [torch.empty((rows, 4), dtype=torch.int64).pin_memory() for _ in range(n)]
+        pin = (lambda t: t.pin_memory()) if self.device.type == "cuda" else (lambda t: t)
+        self._spare += [pin(torch.empty((self._rows, 4), dtype=torch.int64)) for _ in range(n)]
 
     @property
     def params(self):
@@ -298,62 +552,176 @@ class FusedSGD(torch.optim.Optimizer):
             self._plans[key] = (torch.tensor(pairs, dtype=torch.int32, device=self.device).contiguous(), len(pairs), lengths)
         return self._plans[key]
 
+    def _tables(self, gi, group):
+        """Device table {param, grad, momentum, length} + chunk list of group ``gi`` for the parameters that have a gradient now.
+        -> (nchunks, tab, chunks, event | None) or None when no parameter of the group has a gradient."""
+        from . import _native
+
+        f32 = torch.float32
+        params = group["params"]
+        all_grads = [p.grad for p in params]   # (one attribute read per parameter and step: 304 of them)
+        have = tuple(i for i, g in enumerate(all_grads) if g is not None)
+        if not have:
+            return None
+        _native.require_current_device(self._tabs[0])   # (launches go onto the current device's current stream)
+        chunks, nchunks, lengths = self._plan(gi, have, params)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:   # a captured step replays this copy + launch: the tables must outlive the graph and never be rewritten
+            if not self._spare:
+                raise RuntimeError("FusedSGD: more captured steps than pinned pointer tables (pinning host memory is not allowed "
+                                   "during stream capture); call reserve_capture_tables(n) before capturing")
+            host = self._spare.pop()
+            tab, ev = torch.empty((len(have), 4), dtype=torch.int64, device=self.device), None
+            self._captured.append((host, tab))
+        else:
+            slot = self._n % self.RING
+            host, ev = self._ring[slot]
+            tab = self._tabs[slot]
+            self._n += 1
+            ev.synchronize()   # (the copy AND the launch that last used this slot have run)
+        full = len(have) == len(all_grads)
+        grads = all_grads if full else [all_grads[i] for i in have]
+        fixed = [g if (g.dtype is f32 and g.is_contiguous()) else g.float().contiguous() for g in grads]   # (alive until queued)
+        ps = params if full else [params[i] for i in have]
+        state = self.state
+        bufs = []
+        for q in ps:
+            st = state[q]
+            buf = st.get("momentum_buffer")
+            if buf is None or buf.shape != q.shape or buf.device != q.device or buf.dtype is not f32 or not buf.is_contiguous():
+                buf = st["momentum_buffer"] = torch.zeros_like(q) if buf is None else buf.to(q.device, f32).reshape(q.shape).contiguous()
+            bufs.append(buf)
+        rows = host.numpy()[:len(have)]
+        rows[:, 0] = [q.data_ptr() for q in ps]
+        rows[:, 1] = [g.data_ptr() for g in fixed]
+        rows[:, 2] = [b.data_ptr() for b in bufs]
+        rows[:, 3] = lengths
+        tab[:len(have)].copy_(host[:len(have)], non_blocking=True)
+        return nchunks, tab, chunks, ev, fixed
+
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, found_inf=None):
+        """``found_inf``: a device float (``DeviceGradScaler``): non-zero -> the kernel leaves parameters and momenta untouched."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
         from . import _native
 
-        f32 = torch.float32
+        prepared, self._prepared = getattr(self, "_prepared", None), None
         for gi, group in enumerate(self.param_groups):
-            params = group["params"]
-            all_grads = [p.grad for p in params]   # (one attribute read per parameter and step: 304 of them)
-            have = tuple(i for i, g in enumerate(all_grads) if g is not None)
-            if not have:
+            if group.get("dampening", 0) != 0 or group.get("nesterov", False) or group.get("maximize", False):
+                raise RuntimeError("FusedSGD: dampening / nesterov / maximize are not implemented (the reference's configs use none of them)")
+            t = prepared[gi] if prepared is not None else self._tables(gi, group)   # (unscale_ of the same iteration built them already)
+            if t is None:
                 continue
-            _native.require_current_device(self._tabs[0])   # (launches go onto the current device's current stream)
-            chunks, nchunks, lengths = self._plan(gi, have, params)
-            capturing = torch.cuda.is_current_stream_capturing()
-            if capturing:   # a captured step replays this copy + launch: the tables must outlive the graph and never be rewritten
-                if not self._spare:
-                    raise RuntimeError("FusedSGD: more captured steps than pinned pointer tables (pinning host memory is not allowed "
-                                       "during stream capture); call reserve_capture_tables(n) before capturing")
-                host = self._spare.pop()
-                tab, ev = torch.empty((len(have), 4), dtype=torch.int64, device=self.device), None
-                self._captured.append((host, tab))
-            else:
-                slot = self._n % self.RING
-                host, ev = self._ring[slot]
-                tab = self._tabs[slot]
-                self._n += 1
-                ev.synchronize()   # (the copy AND the launch that last used this slot have run)
-            full = len(have) == len(all_grads)
-            grads = all_grads if full else [all_grads[i] for i in have]
-            grads = [g if (g.dtype is f32 and g.is_contiguous()) else g.float().contiguous() for g in grads]   # (alive until queued)
-            ps = params if full else [params[i] for i in have]
-            state = self.state
-            bufs = []
-            for q in ps:
-                st = state[q]
-                buf = st.get("momentum_buffer")
-                if buf is None or buf.shape != q.shape or buf.device != q.device or buf.dtype is not f32 or not buf.is_contiguous():
-                    buf = st["momentum_buffer"] = torch.zeros_like(q) if buf is None else buf.to(q.device, f32).reshape(q.shape).contiguous()
-                bufs.append(buf)
-            rows = host.numpy()[:len(have)]
-            rows[:, 0] = [q.data_ptr() for q in ps]
-            rows[:, 1] = [g.data_ptr() for g in grads]
-            rows[:, 2] = [b.data_ptr() for b in bufs]
-            rows[:, 3] = lengths
-            tab[:len(have)].copy_(host[:len(have)], non_blocking=True)
+            nchunks, tab, chunks, ev, _alive = t
             rc = self.be.lib.pdf_sgd_step(nchunks, tab.data_ptr(), chunks.data_ptr(), float(group["lr"]), float(group["momentum"]),
-                                          float(group["weight_decay"]), self.ctypes.c_void_p(_native.raw_stream()))
+                                          float(group["weight_decay"]), None if found_inf is None else found_inf.data_ptr(),
+                                          self.ctypes.c_void_p(_native.raw_stream()))
             if ev is not None:
                 ev.record()
             if rc != 0:
                 raise RuntimeError(f"pdf_sgd_step failed with status {rc}")
         return loss
+
+
+class DeviceGradScaler:
+    """``torch.cuda.amp.GradScaler`` -- the dynamic loss scaling of the reference's AMP loop (pointcept/engines/train.py:343-355:
+    ``scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()``) -- with the scale, the growth tracker and the found-inf
+    flag as DEVICE scalars and every decision taken on the device: nothing is read back, so the step stays free of host syncs and a
+    ``CapturedStep`` replays with whatever the scale is at replay time.  Same policy and defaults as torch's (init 65536, growth 2,
+    backoff 0.5, interval 2000): a step that produced an inf / nan gradient leaves parameters AND momenta untouched and halves the scale.
+
+        scaler = DeviceGradScaler(device)
+        scaler.scale(loss).backward()          # or CapturedStep(..., loss_scale=scaler)
+        exchange.sync()                        # data-parallel mean of the (still scaled) gradients: an inf reaches every rank
+        scaler.step(optimizer)                 # FusedSGD: unscale_ (one launch: g *= 1 / scale, found_inf) + the guarded update
+        scaler.update()                        # one 1-thread launch
+
+    ``state_dict`` / ``load_state_dict`` use torch.amp.GradScaler's keys."""
+
+    def __init__(self, device, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, enabled=True):
+        self.device = torch.device(device)
+        self.enabled = bool(enabled)
+        self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
+        # [scale, inv_scale, found_inf] in one allocation (three fixed addresses for captured steps) + the int32 tracker
+        self._f = torch.tensor([float(init_scale), 1.0 / float(init_scale), 0.0], dtype=torch.float32, device=self.device)
+        self._tracker = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        self._unscaled = False
+
+    @property
+    def scale_tensor(self):
+        return self._f[0]
+
+    @property
+    def found_inf(self):
+        return self._f[2:3]
+
+    def scale(self, loss):
+        return loss * self._f[0] if self.enabled else loss
+
+    def get_scale(self):
+        return float(self._f[0]) if self.enabled else 1.0   # (a host sync: logging only)
+
+    @torch.no_grad()
+    def unscale_(self, optimizer):
+        """g *= 1 / scale for every gradient of ``optimizer`` (a FusedSGD) in one launch per group; sets found_inf."""
+        if not self.enabled or self._unscaled:
+            return
+        if not isinstance(optimizer, FusedSGD):
+            raise TypeError("DeviceGradScaler drives engine.FusedSGD (the guarded update is part of its kernel); use torch.amp.GradScaler "
+                            "with other optimizers")
+        from . import _native
+        import ctypes
+
+        prepared = []
+        for gi, group in enumerate(optimizer.param_groups):
+            t = optimizer._tables(gi, group)
+            prepared.append(t)
+            if t is None:
+                continue
+            nchunks, tab, chunks, _ev, _alive = t
+            rc = optimizer.be.lib.pdf_grad_unscale(nchunks, tab.data_ptr(), chunks.data_ptr(), self._f[1:2].data_ptr(), self._f[2:3].data_ptr(),
+                                                   ctypes.c_void_p(_native.raw_stream()))
+            if rc != 0:
+                raise RuntimeError(f"pdf_grad_unscale failed with status {rc}")
+        optimizer._prepared = prepared   # the step of this iteration reuses the tables (same gradients, same pointers)
+        self._unscaled = True
+
+    def step(self, optimizer):
+        if not self.enabled:
+            return optimizer.step()
+        self.unscale_(optimizer)
+        return optimizer.step(found_inf=self._f[2:3])
+
+    @torch.no_grad()
+    def update(self):
+        if not self.enabled:
+            return
+        from . import _native
+        import ctypes
+
+        lib = _native.hip_backend().lib
+        rc = lib.pdf_scaler_update(self._f[0:1].data_ptr(), self._f[1:2].data_ptr(), self._tracker.data_ptr(), self._f[2:3].data_ptr(),
+                                   ctypes.c_float(self.growth_factor), ctypes.c_float(self.backoff_factor), int(self.growth_interval),
+                                   ctypes.c_void_p(_native.raw_stream()))
+        if rc != 0:
+            raise RuntimeError(f"pdf_scaler_update failed with status {rc}")
+        self._unscaled = False
+
+    def state_dict(self):
+        return dict(scale=self.get_scale(), growth_factor=self.growth_factor, backoff_factor=self.backoff_factor,
+                    growth_interval=self.growth_interval, _growth_tracker=int(self._tracker[0])) if self.enabled else {}
+
+    def load_state_dict(self, state):
+        if not self.enabled or not state:
+            return
+        self.growth_factor, self.backoff_factor = float(state["growth_factor"]), float(state["backoff_factor"])
+        self.growth_interval = int(state["growth_interval"])
+        with torch.no_grad():   # (in place: captured steps hold these addresses)
+            self._f.copy_(torch.tensor([float(state["scale"]), 1.0 / float(state["scale"]), 0.0]))
+            self._tracker.fill_(int(state["_growth_tracker"]))
 
 
 def shard_scene_ids(num_scenes, rank, world_size):

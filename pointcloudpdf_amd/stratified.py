@@ -488,8 +488,10 @@ class StratifiedPrefetcher:
 
         return geom, self.pool.submit(work)
 
-    def submit_group(self, batches):
-        """One ticket per batch; the farthest-point chain of all of them runs as one launch sequence (StratifiedGeometry.precompute_group)."""
+    def submit_group(self, batches, ready=None):
+        """One ticket per batch; the farthest-point chain of all of them runs as one launch sequence (StratifiedGeometry.precompute_group).
+        (``ready`` is accepted for the interface of engine.GroupedGeometryLoader; the event is recorded here, after the conversions the
+        geometry constructors may enqueue on the caller's stream.)"""
         geoms = [self.model.make_geometry(b["coord"], b["offset"], b.get("offset_host")) for b in batches]
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream())

@@ -40,7 +40,12 @@ def test_every_declared_symbol_is_exported(lib):
 def test_probes_without_gpu(lib):
     lib.pdf_abi_version.restype = ctypes.c_int
     lib.pdf_build_info.restype = ctypes.c_char_p
-    assert lib.pdf_abi_version() >= 1
+    from pointcloudpdf_amd import _native
+
+    header = open(os.path.join(ROOT, "include", "pdfops.h")).read()
+    declared = int(re.search(r"#define\s+PDF_ABI_VERSION\s+(\d+)", header).group(1))
+    assert lib.pdf_abi_version() == declared == _native.ABI_VERSION   # library, header and binding agree (a mismatch refuses to load)
+    assert f"abi={declared}".encode() in lib.pdf_build_info()
     assert b"gfx950" in lib.pdf_build_info()
     lib.pdf_fps_reference_block_log2.restype = ctypes.c_int
     for n, want in [(1, 0), (3, 1), (1000, 9), (1024, 10), (100000, 10)]:
@@ -85,14 +90,51 @@ def test_fma_distance_variants_are_built_and_complete(lib):
         assert not [s for s in declared_symbols() if not hasattr(vlib, s)]
 
 
-def test_mma_input_mode_entry_points(lib):
-    """pdf_set_mma_input / pdf_get_mma_input need no GPU: the mode is a process-wide switch read at launch time."""
-    lib.pdf_set_mma_input.restype = ctypes.c_int
-    lib.pdf_get_mma_input.restype = ctypes.c_int
-    assert lib.pdf_get_mma_input() == 0
-    for mode in (1, 2, 0):
-        assert lib.pdf_set_mma_input(mode) == 0 and lib.pdf_get_mma_input() == mode
-    assert lib.pdf_set_mma_input(3) == -1 and lib.pdf_set_mma_input(-1) == -1 and lib.pdf_get_mma_input() == 0
+def test_mma_input_is_a_per_call_argument(lib):
+    """ABI 4: the product-input mode is an argument of every entry that runs the streaming Linear products; the library exports no
+    setter and keeps no state.  Argument validation needs no GPU: an unknown mode is PDF_ERR_BAD_ARG before anything is launched."""
+    assert not hasattr(lib, "pdf_set_mma_input") and not hasattr(lib, "pdf_get_mma_input") and not hasattr(lib, "pdf_tickets_bind")
+    f = lib.pdf_rowlin_forward
+    f.restype = ctypes.c_int
+    L, I, P = ctypes.c_long, ctypes.c_int, ctypes.c_void_p
+    f.argtypes = [L, I, I, P, L, P, I, P, P, P, I, P, L, I, P, I, P]
+    buf = (ctypes.c_float * 64)()
+    ptr = ctypes.cast(buf, P)
+    for bad in (3, -1):
+        assert f(4, 4, 4, ptr, 4, ptr, 0, None, None, None, 0, ptr, 4, 0, None, bad, None) == -1
+
+
+def test_stale_library_is_refused(lib, monkeypatch):
+    """A library built for another ABI version must not be called through (shifted parameter lists = silent device memory corruption)."""
+    from pointcloudpdf_amd import _native
+
+    monkeypatch.setattr(_native, "ABI_VERSION", _native.ABI_VERSION + 1)
+    with pytest.raises(_native.PdfOpsError, match="ABI"):
+        _native.HipBackend(lib)
+
+
+def test_mma_input_is_thread_local():
+    """The Python-side mode is state of the calling thread: a backward thread and a forward thread never see each other's mode."""
+    import threading
+
+    from pointcloudpdf_amd import _native
+
+    seen = {}
+    go = threading.Barrier(2)
+
+    def worker(name, mode):
+        with _native.mma_input(mode):
+            go.wait()
+            seen[name] = _native.current_mma_input()
+            go.wait()
+        seen[name + "_after"] = _native.current_mma_input()
+
+    ts = [threading.Thread(target=worker, args=("a", 1)), threading.Thread(target=worker, args=("b", 2))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert seen == {"a": 1, "b": 2, "a_after": 0, "b_after": 0} and _native.current_mma_input() == 0
+    with pytest.raises(_native.PdfOpsError):
+        _native.mma_input(3)
 
 
 def test_mma_input_context_restores_the_previous_mode(monkeypatch):

@@ -444,7 +444,7 @@ def test_autocast_runs_the_reduced_precision_products(dtype):
     from pointcloudpdf_amd import _native
 
     a, b, a2 = _autocast_runs(dtype, loss_scale=4096.0 if dtype == torch.float16 else 1.0)
-    assert _native.current_mma_input() == 0 and _native.hip_backend().lib.pdf_get_mma_input() == 0
+    assert _native.current_mma_input() == 0
     assert torch.equal(a["knn"], b["knn"]) and torch.equal(a["fps"], b["fps"])
     assert torch.equal(a["logits"], a2["logits"]) and all(torch.equal(a["grads"][n], a2["grads"][n]) for n in a["grads"])
     assert not torch.equal(a["logits"], b["logits"]), "autocast did not engage the reduced-precision products"
@@ -511,6 +511,153 @@ def test_training_loop_converges_in_every_precision_and_execution_mode():
         assert eager == graph, (dtype, "graph replay left the eager trajectory")
         assert all(np.isfinite(eager)) and abs(eager[-1] - ref[-1]) <= 0.05 * ref[-1], (dtype, eager[-1], ref[-1])
         assert all(abs(eager[i] - ref[i]) <= 0.10 * ref[i] for i in range(0, 30, 5)), (dtype, [round(eager[i] / ref[i], 3) for i in range(0, 30, 5)])
+
+
+def test_grouped_loader_steps_are_bit_identical_to_serial_steps():
+    """engine.GroupedGeometryLoader + engine.TrainStep (the product form of the look-ahead pipeline that bench.py runs): eight training
+    steps over batches of two shapes -- pre-pass of the next group on a side stream, per-batch views of a grouped pre-pass, graph replay for
+    the batches of the captured shape and the eager path for the others -- give bit-identical losses and parameters to eight serial
+    steps (pre-pass inline, every launch issued from Python)."""
+    from pointcloudpdf_amd import engine, synthetic
+
+    dev = torch.device("cuda", 0)
+    shapes = [[3000, 2600], [3000, 2600], [2200, 3100], [3000, 2600]]
+    pool = [synthetic.make_batch(sz, first_scene_id=60 + 3 * i, device=dev) for i, sz in enumerate(shapes)]
+
+    def stream(n):
+        for i in range(n):
+            b = pool[i % len(pool)]
+            yield {k: b[k] for k in ("coord", "feat", "offset", "offset_host", "segment")}
+
+    def run(group, graph):
+        step = engine.OpenSegStep().to(dev)
+        synthetic.fill_parameters_deterministic(step, seed=5)
+        step.train()
+        opt = engine.FusedSGD(step.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4)
+        train = engine.TrainStep(step, opt, graph=graph)
+        losses = [float(train(b)["loss"]) for b in engine.GroupedGeometryLoader(stream(8), group=group, first_group=2 if group else None)]
+        torch.cuda.synchronize()
+        params = [p.detach().clone() for p in step.parameters()]
+        replayed = train.captured is not None
+        engine.release_autograd_state(step)
+        return losses, params, replayed
+
+    serial, p_serial, _ = run(0, False)
+    assert all(np.isfinite(serial)) and serial[-1] < serial[0]
+    for group, graph in ((3, False), (3, True), (8, True)):
+        losses, params, replayed = run(group, graph)
+        assert replayed == graph
+        assert losses == serial, (group, graph, losses, serial)
+        assert all(torch.equal(a, b) for a, b in zip(params, p_serial)), (group, graph)
+
+
+def test_captured_step_refuses_a_stale_schedule_state():
+    """A graph replays what was recorded: once the recognizer's alpha changed (PointPdfV1.trigger_operation at start_epoch) the captured
+    step no longer `matches` and a direct call raises instead of silently training with the old loss weight."""
+    from pointcloudpdf_amd import engine, synthetic
+    from pointcloudpdf_amd.geometry import Geometry
+
+    dev = torch.device("cuda", 0)
+    batch = synthetic.make_batch([2500, 2100], first_scene_id=70, device=dev)
+    geom = Geometry(batch["coord"], batch["offset"], batch["offset_host"]).precompute()
+    step = engine.OpenSegStep().to(dev)
+    synthetic.fill_parameters_deterministic(step, seed=2)
+    step.train()
+    cap = engine.CapturedStep(step, batch, geom=geom)
+    assert cap.matches(batch)
+    cap(batch, geom)
+    step.recognizer.alpha = float(step.recognizer.alpha) * 0.5
+    assert not cap.matches(batch)
+    with pytest.raises(RuntimeError, match="changed since the capture"):
+        cap(batch, geom)
+    engine.release_autograd_state(step)
+
+
+def test_device_grad_scaler_follows_torch_grad_scaler():
+    """engine.DeviceGradScaler + FusedSGD against torch.amp.GradScaler + torch.optim.SGD on the same gradients: clean steps update
+    identically and grow the scale after `growth_interval` of them; a step with an inf / a nan gradient leaves parameters AND momentum
+    buffers untouched and halves the scale -- all without a host read-back (the found-inf flag, the scale and the tracker live on the
+    device; ADVICE round 3: a static scale wrote an overflow straight into the weights)."""
+    from pointcloudpdf_amd import engine
+
+    g = torch.Generator(device="cuda").manual_seed(11)
+    shapes = [(7,), (33, 64), (70001,), (4096,)]
+    pa = [torch.nn.Parameter(torch.randn(s, device="cuda", generator=g)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = engine.FusedSGD(pa, lr=0.05, momentum=0.9, weight_decay=1e-2)
+    ob = torch.optim.SGD(pb, lr=0.05, momentum=0.9, weight_decay=1e-2)
+    sa = engine.DeviceGradScaler("cuda", init_scale=1024.0, growth_interval=2)
+    sb = torch.amp.GradScaler("cuda", init_scale=1024.0, growth_interval=2)
+    plan = ["ok", "ok", "inf", "ok", "nan", "ok", "ok", "ok"]
+    for it, kind in enumerate(plan):
+        before = [p.detach().clone() for p in pa]
+        mom_before = [oa.state[p]["momentum_buffer"].clone() for p in pa]
+        scale = sb.get_scale()
+        assert sa.get_scale() == scale, (it, sa.get_scale(), scale)
+        for x, y in zip(pa, pb):
+            gr = torch.randn(x.shape, device="cuda", generator=g)
+            x.grad, y.grad = (gr * scale).clone(), (gr * scale).clone()      # what scale(loss).backward() leaves behind
+        if kind != "ok":
+            bad = float("inf") if kind == "inf" else float("nan")
+            pa[2].grad[12345] = bad
+            pb[2].grad[12345] = bad
+        sa.step(oa); sa.update()
+        sb.step(ob); sb.update()
+        if kind != "ok":
+            assert all(torch.equal(a, b) for a, b in zip(before, pa)), "a non-finite gradient reached the parameters"
+            assert all(torch.equal(m, oa.state[p]["momentum_buffer"]) for m, p in zip(mom_before, pa)), "... or the momentum buffers"
+        for x, y in zip(pa, pb):
+            assert (x - y).abs().max() <= 1e-6 * (1 + y.abs().max()), (it, kind, float((x - y).abs().max()))
+    assert sa.get_scale() == sb.get_scale()
+    st = sa.state_dict()
+    assert set(st) == set(sb.state_dict()) and st["scale"] == sb.get_scale()
+    sc = engine.DeviceGradScaler("cuda")
+    sc.load_state_dict(st)
+    assert sc.get_scale() == sa.get_scale() and int(sc._tracker[0]) == st["_growth_tracker"]
+
+
+def test_dynamic_loss_scale_inside_a_replayed_step():
+    """The captured backward starts from loss * scale with the scale read from device memory at REPLAY time: after the scaler changed
+    its scale the same graph produces gradients scaled by the new value (powers of two: exactly), and a training loop with fp16
+    operands + dynamic scaling gives the same trajectory replayed and issued eagerly."""
+    from pointcloudpdf_amd import engine, synthetic
+    from pointcloudpdf_amd.geometry import Geometry
+
+    dev = torch.device("cuda", 0)
+    batch = synthetic.make_batch([3000, 2400], first_scene_id=80, device=dev)
+    geom = Geometry(batch["coord"], batch["offset"], batch["offset_host"]).precompute()
+
+    def build():
+        step = engine.OpenSegStep().to(dev)
+        synthetic.fill_parameters_deterministic(step, seed=3)
+        step.train()
+        return step
+
+    step = build()
+    scaler = engine.DeviceGradScaler(dev, init_scale=256.0)
+    cap = engine.CapturedStep(step, batch, geom=geom, autocast=torch.float16, loss_scale=scaler)
+    cap(batch, geom)
+    g1 = [p.grad.clone() for p in cap.params]
+    scaler.load_state_dict(dict(scaler.state_dict(), scale=1024.0))
+    cap(batch, geom)
+    g2 = [p.grad.clone() for p in cap.params]
+    assert any(float(a.abs().max()) > 0 for a in g1)
+    assert all(torch.equal(a * 4.0, b) for a, b in zip(g1, g2))
+    engine.release_autograd_state(step)
+
+    def run(graph):
+        step = build()
+        opt = engine.FusedSGD(step.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+        sc = engine.DeviceGradScaler(dev, init_scale=65536.0, growth_interval=4)
+        train = engine.TrainStep(step, opt, scaler=sc, autocast=torch.float16, graph=graph)
+        losses = [float(train(dict(batch, pdf_geometry=geom))["loss"]) for _ in range(12)]
+        engine.release_autograd_state(step)
+        return losses, sc.get_scale()
+
+    (eager, s_eager), (graph, s_graph) = run(False), run(True)
+    assert eager == graph and s_eager == s_graph
+    assert all(np.isfinite(eager)) and eager[-1] < 0.5 * eager[0], eager
+    assert s_eager >= 1.0 and np.log2(s_eager) == int(np.log2(s_eager))
 
 
 @pytest.mark.parametrize("mode", ["eager", "graph"])

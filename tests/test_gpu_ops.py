@@ -128,6 +128,21 @@ def both_fps(hip, oracle_backend, xyz, sizes, msizes):
     return f_o, res
 
 
+def test_knn_counted_launch_returns_the_same_tables_and_the_evaluated_pairs():
+    """pdf_knn_query_ws_counted (measurement aid behind the `valu_frac_evaluated` figure of the bench line): identical idx / dist2 and a
+    count of evaluated candidate distances that is positive and far below the brute-force m * n pairs the reference kernel evaluates."""
+    from pointcloudpdf_amd import _native, synthetic
+
+    be = _native.hip_backend()
+    b = synthetic.make_batch([30000, 21000], first_scene_id=11, device="cuda")
+    for k in (3, 8, 16):
+        idx, d2 = be.knn_query(k, b["coord"], b["coord"], b["offset"], b["offset"])
+        idx2, d22, pairs = be.knn_query_counted(k, b["coord"], b["coord"], b["offset"], b["offset"])
+        assert torch.equal(idx, idx2) and torch.equal(d2, d22)
+        brute = 30000 * 30000 + 21000 * 21000
+        assert (k + 1) * 51000 <= pairs < brute / 20, (k, pairs, brute)
+
+
 @pytest.mark.parametrize("sizes", [[1000], [4096 + 7], [37], [300, 1500, 64], [2048, 1600], [25000], [6250, 6100]])
 @pytest.mark.parametrize("snap", [0, 6])
 def test_fps_bit_exact(hip, oracle_backend, sizes, snap):

@@ -135,7 +135,7 @@ def test_rowlin_forward_wide_inputs(n, k, o, pre):
 @pytest.mark.parametrize("n,k,o", [(5000, 32, 32), (777, 512, 512), (40000, 64, 192), (12517, 128, 128), (3125, 256, 256), (5, 32, 96)])
 @pytest.mark.parametrize("pre", [False, True])
 def test_rowlin_reduced_precision_operands(n, k, o, pre, dtype):
-    """pdf_set_mma_input(1 | 2): the streaming Linear products round their OPERANDS to fp16 / bfloat16 in registers (after the folded
+    """mma_input = 1 | 2 (per-call argument, include/pdfops.h): the streaming Linear products round their OPERANDS to fp16 / bfloat16 in registers (after the folded
     BatchNorm + ReLU prologue, which stays fp32) and accumulate in fp32 -- so the result must equal, to fp32 accumulation error, the
     float64 product of the operands rounded the same way; tensors in memory stay fp32 and mode 0 comes back afterwards."""
     from pointcloudpdf_amd import _native
@@ -156,11 +156,11 @@ def test_rowlin_reduced_precision_operands(n, k, o, pre, dtype):
     go = torch.randn(n, o, device="cuda", generator=g)
     y32, _ = be.rowlin(x, w, b, coef=coef, relu=True)
     with _native.mma_input(mode):
-        assert be.lib.pdf_get_mma_input() == mode
+        assert _native.current_mma_input() == mode
         y, partial = be.rowlin(x, w, b, coef=coef, relu=True, stats=True)
         gx, _ = be.rowlin(go, w, transpose_w=True)
         dw, db = be.rowlin_wgrad(go, x, coef, True, True)
-    assert be.lib.pdf_get_mma_input() == 0 and _native.current_mma_input() == 0
+    assert _native.current_mma_input() == 0
     assert y.dtype == torch.float32 and gx.dtype == torch.float32 and dw.dtype == torch.float32
     ref = rnd(fx) @ rnd(w).t() + b.double()
     # (with the prologue the kernel forms x * scale + shift as one FMA, torch as a product and a sum: an operand one fp32 ulp apart now and
@@ -185,7 +185,7 @@ def test_rowlin_reduced_precision_operands(n, k, o, pre, dtype):
 def test_rowlin_wgrad_group(n, c, mode):
     """The five c x c weight gradients of a Bottleneck backward in one launch + one reduction: each with its own gradient rows, its own
     input rows and its own folded BatchNorm + ReLU prologue (or none), biases where asked; against float64 and against the one-by-one
-    entry points; deterministic (two calls give identical bits).  mode 1: fp16 operands (the grouped kernel honours pdf_set_mma_input)."""
+    entry points; deterministic (two calls give identical bits).  mode 1: fp16 operands (the grouped kernel honours the call's mma_input)."""
     from pointcloudpdf_amd import _native
 
     be = _native.hip_backend()
@@ -231,8 +231,65 @@ def test_rowlin_wgrad_group_outside_the_streaming_shapes():
 def test_mma_input_rejects_unknown_modes():
     from pointcloudpdf_amd import _native
 
-    lib = _native.hip_backend().lib
-    assert lib.pdf_set_mma_input(3) == -1 and lib.pdf_set_mma_input(-1) == -1 and lib.pdf_get_mma_input() == 0
+    be = _native.hip_backend()
+    x = torch.randn(64, 32, device="cuda")
+    w = torch.randn(32, 32, device="cuda")
+    _native._MMA.mode = 3   # (bypassing the context manager's own check)
+    try:
+        with pytest.raises(_native.PdfOpsError, match="status -1"):
+            be.rowlin(x, w)
+    finally:
+        _native._MMA.mode = 0
+
+
+def test_two_threads_two_modes_run_concurrently():
+    """The product-input mode is a per-call argument (ABI 4; round 3 kept it in a process-wide word that dispatch read): two threads on
+    their own streams run forward + backward products in DIFFERENT modes at the same time, repeatedly, and every result is bit-identical
+    to the same thread's result when it runs alone."""
+    import threading
+
+    from pointcloudpdf_amd import _native
+
+    be = _native.hip_backend()
+    g = torch.Generator(device="cuda").manual_seed(7)
+    n, c = 30000, 64
+    x = torch.randn(n, c, device="cuda", generator=g)
+    w = torch.randn(c, c, device="cuda", generator=g) / 8
+    go = torch.randn(n, c, device="cuda", generator=g)
+
+    def work(mode, reps):
+        outs = []
+        with _native.mma_input(mode):
+            for _ in range(reps):
+                y, _ = be.rowlin(x, w)
+                gx, _ = be.rowlin(go, w, transpose_w=True)
+                dw, _ = be.rowlin_wgrad(go, x, None, False, False)
+                outs.append((y, gx, dw))
+        return outs
+
+    alone = {m: work(m, 1)[0] for m in (0, 1, 2)}
+    torch.cuda.synchronize()
+    assert not torch.equal(alone[0][0], alone[1][0]) and not torch.equal(alone[1][0], alone[2][0])
+    results, errors = {}, []
+    start = threading.Barrier(3)
+
+    def thread(mode):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                start.wait()
+                results[mode] = work(mode, 40)
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=thread, args=(m,)) for m in (0, 1, 2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+    for m in (0, 1, 2):
+        for y, gx, dw in results[m]:
+            assert torch.equal(y, alone[m][0]) and torch.equal(gx, alone[m][1]) and torch.equal(dw, alone[m][2]), m
+    assert _native.current_mma_input() == 0
 
 
 @pytest.mark.parametrize("n,c", [(30011, 32), (9000, 64), (4097, 128), (1500, 256), (300, 512), (200, 48)])
