@@ -190,12 +190,15 @@ int pdf_pt_layer_forward(int n, int nsample, int c, const float *xq, const float
                          float momentum, float *bn, float *saved, float *H, float *partial, float *out,
                          int storage_bf16, const int *order, void *stream);
 /* The same with the batch's relative-coordinate sums (pdf_knn_rel_moments, summed over the batch's scenes: 9 doubles in device
- * memory) or NULL: in train mode the geometry branch's BatchNorm then comes from them (5 launches per layer instead of 7). */
+ * memory) or NULL: in train mode the geometry branch's BatchNorm then comes from them (5 launches per layer instead of 7).
+ * out_stat_rows (host int, may be NULL): when given, the last pass also leaves *out_stat_rows partial rows [sum out (c) | sum out^2 (c)]
+ * in `partial` (train mode; 0 in eval mode) -- the statistics of a BatchNorm that reads `out` (the Bottleneck's bn2,
+ * point_transformer_seg.py:187) for pdf_bn_coef_from_partial, instead of a statistics pass over `out`. */
 int pdf_pt_layer_forward_m(int n, int nsample, int c, const float *xq, const float *xk, const float *xv,
                            const float *p, const int *idx, const float *const *weights,
                            const float *const *bn_params, float *const *bn_buffers, int training, float eps,
                            float momentum, float *bn, float *saved, float *H, float *partial, float *out,
-                           int storage_bf16, const int *order, const double *moments, void *stream);
+                           int storage_bf16, const int *order, const double *moments, int *out_stat_rows, void *stream);
 
 /* Backward of the fused PointTransformerLayer (train mode).  gxq / gxk / gxv are overwritten: the scatters of g_xk and g_xv run as
  * segmented gathers over the INVERSE of the kNN table (inv_off (n+1), inv_entry, entry_base -- see pdf_seg_sum_rows), so they are
@@ -369,6 +372,11 @@ int pdf_knn_rel_moments(int b, long n, int nsample, const float *xyz, const int 
 /* the same for m queries new_xyz (scene ends new_offset) over other source points xyz: TransitionDown's grouping table */
 int pdf_knn_rel_moments_q(int b, long m, int nsample, const float *xyz, const float *new_xyz, const int *new_offset, const int *idx,
                           double *out, double *ws, void *stream);
+
+/* Morton keys of the points of a batch, scene by scene (visiting order of the forward gathers and layer passes: a stable sort of these keys;
+ * pointcloudpdf_amd/geometry.py: Geometry.order -- no reference counterpart, nothing is stored in that order): keys[i] = scene(i) << 30 |
+ * 30-bit Morton code of point i on a 1024^3 grid over ITS scene's bounding box.  bounds: 4 b floats of scratch (written). */
+int pdf_scene_morton_keys(long n, int b, const float *xyz, const int *offset, float *bounds, long long *keys, void *stream);
 
 /* SGD with momentum and weight decay (torch.optim.SGD, dampening 0, no Nesterov -- the optimizer the reference's configs build,
  * pointcept/utils/optimizer.py + configs/s3dis/openseg-pt-v1-0-*.py) over every parameter tensor in ONE launch.  tab: ntensors records

@@ -557,6 +557,8 @@ class HipBackend(CBackend):
         self.CopySeg = CopySeg
         lib.pdf_stage_copy.restype = c_int
         lib.pdf_stage_copy.argtypes = [c_int, c_void_p, c_void_p]
+        lib.pdf_scene_morton_keys.restype = c_int
+        lib.pdf_scene_morton_keys.argtypes = [c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
         lib.pdf_sgd_chunk.restype = c_int
         lib.pdf_sgd_chunk.argtypes = []
         lib.pdf_sgd_step.restype = c_int
@@ -769,6 +771,18 @@ class HipBackend(CBackend):
         if rc != 0:
             raise PdfOpsError(f"pdf_knn_query_ws failed with status {rc}")
         return idx, dist2
+
+    def scene_morton_keys(self, xyz, offset):
+        """-> keys (n,) int64: scene << 30 | Morton code on the scene's own bounding box (include/pdfops.h: pdf_scene_morton_keys)."""
+        _check(xyz, torch.float32, "xyz"); _check(offset, torch.int32, "offset")
+        require_current_device(xyz, offset)
+        n, b = xyz.shape[0], offset.shape[0]
+        keys = torch.empty((n,), dtype=torch.int64, device=xyz.device)
+        bounds = torch.empty((4 * b,), dtype=torch.float32, device=xyz.device)
+        rc = self.lib.pdf_scene_morton_keys(n, b, self._ptr(xyz), self._ptr(offset), self._ptr(bounds), self._ptr(keys), c_void_p(raw_stream()))
+        if rc != 0:
+            raise PdfOpsError(f"pdf_scene_morton_keys failed with status {rc}")
+        return keys
 
     def knn_query_counted(self, nsample, xyz, new_xyz, offset, new_offset):
         """Measurement aid: the grid kNN with its kernel counting the candidate distances it evaluates -> (idx, dist2, evaluated pairs)

@@ -52,6 +52,10 @@ extern "C" int pdf_block_pre_forward(long n, int c, void *const *p, int training
 //      gx, grads [dW1 (c*c) | dbeta1 (c) | dgamma1 (c) | {dW (c*c), db (c)} x q,k,v]   (outputs; every element is WRITTEN: no zeroing)
 //      dy (n*c), partial (max(pdf_bn_partial_floats(n, c), pdf_rowlin_partial_floats(n, c)): the dgrad epilogue's rows)   (scratch)
 //      p[14] = workspace of the weight-gradient slabs, pdf_rowlin_wgrad_ws_floats(n, c, c, 3) floats
+static bool inkernel_bn() {   // PDFOPS_INKERNEL_BN=0: every BatchNorm finalize as its own reducer launch (rounds 1-3)
+    static const bool on = [] { const char *v = getenv("PDFOPS_INKERNEL_BN"); return !(v && v[0] == '0'); }();
+    return on;
+}
 static bool dgrad_bstats() {   // PDFOPS_DGRAD_BSTATS=0: BatchNorm-backward sums from their own pass instead of the dgrad epilogue (A/B)
     static const bool on = [] { const char *v = getenv("PDFOPS_DGRAD_BSTATS"); return !(v && v[0] == '0'); }();
     return on;
@@ -93,13 +97,32 @@ extern "C" int pdf_block_pre_backward(long n, int c, void *const *p, int trainin
 
 // p[]: t, x (identity), gamma2, beta2, rm2, rv2, W3, gamma3, beta3, rm3, rv3        (inputs)
 //      coef2 (4c), z3, coef3 (4c), y, partial (max(pdf_bn_partial_floats, pdf_rowlin_partial_floats))   (outputs / scratch)
-extern "C" int pdf_block_post_forward(long n, int c, void *const *p, int training, float eps, float momentum, int mma_input, void *stream) {
+// t_stat_rows > 0: `partial` already holds that many rows [sum t | sum t^2] (epilogue of the attention layer's last pass,
+// pdf_pt_layer_forward_m): bn2's coefficients come from them instead of a statistics pass over t.
+static int block_post_forward(long n, int c, void *const *p, int training, float eps, float momentum, int t_stat_rows, int mma_input, void *stream) {
     if (n < 1 || !p) return PDF_ERR_BAD_ARG;
     if (!pdf_bn_supported(c)) return PDF_ERR_UNSUPPORTED;
     const float *t = (const float *)p[0], *x = (const float *)p[1];
     float *coef2 = (float *)p[11], *z3 = (float *)p[12], *coef3 = (float *)p[13], *y = (float *)p[14], *partial = (float *)p[15];
     Err e;
-    e << pdf_bn_coef(n, c, t, (const float *)p[2], (const float *)p[3], (float *)p[4], (float *)p[5], training, eps, momentum, coef2, partial, stream);
+    if (training && t_stat_rows > 0)
+        e << pdf_bn_coef_from_partial(partial, t_stat_rows, n, c, (const float *)p[2], (const float *)p[3], (float *)p[4], (float *)p[5], eps, momentum, coef2, stream);
+    else
+        e << pdf_bn_coef(n, c, t, (const float *)p[2], (const float *)p[3], (float *)p[4], (float *)p[5], training, eps, momentum, coef2, partial, stream);
+    bool applied = false;
+    if (training && inkernel_bn()) {   // z3 product (+ statistics rows) -> ONE launch: bn3 finalize + affine + residual + ReLU
+        int rows = 0;
+        const int rc = pdf_rowlin_forward_stats_ho(n, c, c, t, c, (const float *)p[6], nullptr, coef2, coef2 + c, 1, z3, c, partial + PDF_HO_FLOATS, partial,
+                                                   &rows, mma_input, stream);
+        if (rc == PDF_OK) {
+            e << pdf_bn_apply_rows(n, c, z3, x, partial + PDF_HO_FLOATS, rows, (const float *)p[7], (const float *)p[8], (float *)p[9], (float *)p[10], eps,
+                                   momentum, coef3, partial, 1, y, stream);
+            applied = true;
+        } else if (rc != PDF_ERR_UNSUPPORTED) {
+            e << rc;
+        }
+    }
+    if (applied) return e.rc;
     if (training) {
         e << pdf_rowlin_forward_bn(n, c, c, t, c, (const float *)p[6], nullptr, coef2, coef2 + c, 1, z3, c, partial, (const float *)p[7], (const float *)p[8],
                                    (float *)p[9], (float *)p[10], eps, momentum, coef3, mma_input, stream);
@@ -109,6 +132,9 @@ extern "C" int pdf_block_post_forward(long n, int c, void *const *p, int trainin
     }
     e << pdf_bn_apply(n, c, z3, x, coef3, 1, y, stream);
     return e.rc;
+}
+extern "C" int pdf_block_post_forward(long n, int c, void *const *p, int training, float eps, float momentum, int mma_input, void *stream) {
+    return block_post_forward(n, c, p, training, eps, momentum, 0, mma_input, stream);
 }
 
 // p[]: gy, t, x, z3, coef2, coef3, W3                                               (inputs)
@@ -163,11 +189,15 @@ extern "C" int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p
     float *bn_buffers[6];
     for (int i = 0; i < 8; ++i) weights[i] = (const float *)p[14 + i];
     for (int i = 0; i < 6; ++i) { bn_params[i] = (const float *)p[22 + i]; bn_buffers[i] = (float *)p[28 + i]; }
+    // bn2's statistics as an epilogue of the attention layer's last pass (PDFOPS_P4_STATS=0: their own pass over t, as in rounds 1-3)
+    static const bool p4_stats = [] { const char *v = getenv("PDFOPS_P4_STATS"); return !(v && v[0] == '0'); }();
+    int t_rows = 0;
     e << pdf_pt_layer_forward_m((int)n, nsample, c, (const float *)p[45], (const float *)p[46], (const float *)p[47], (const float *)p[12],
                                 (const int *)p[13], weights, bn_params, bn_buffers, training, eps, momentum, (float *)p[48], (float *)p[49],
-                                (float *)p[50], (float *)p[56], (float *)p[51], storage_bf16, (const int *)p[57], (const double *)p[58], stream);
+                                (float *)p[50], (float *)p[56], (float *)p[51], storage_bf16, (const int *)p[57], (const double *)p[58],
+                                p4_stats ? &t_rows : nullptr, stream);
     void *post[16] = {p[51], p[0], p[34], p[35], p[36], p[37], p[38], p[39], p[40], p[41], p[42], p[52], p[53], p[54], p[55], p[56]};
-    e << pdf_block_post_forward(n, c, post, training, eps, momentum, mma_input, stream);
+    e << block_post_forward(n, c, post, training, eps, momentum, e.rc == 0 ? t_rows : 0, mma_input, stream);
     return e.rc;
 }
 

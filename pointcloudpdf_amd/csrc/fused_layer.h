@@ -192,7 +192,8 @@ namespace flm {
 bool supported(int nsample, int c);
 void launch_p2(const fl::LayerArgs &A, int c, int grid, hipStream_t s);
 void launch_p3(const fl::LayerArgs &A, int c, bool stats, int grid, hipStream_t s);
-void launch_p4(const fl::LayerArgs &A, int c, int grid, hipStream_t s);
+int p4_grid(long n, int grid);   // blocks (= partial rows with statistics) of launch_p4
+void launch_p4(const fl::LayerArgs &A, int c, int grid, bool stats, hipStream_t s);
 void launch_b1(const fl::LayerArgs &A, int c, int grid, hipStream_t s);
 void launch_b2(const fl::LayerArgs &A, int c, int grid, hipStream_t s);
 void launch_b3(const fl::LayerArgs &A, int c, int grid, hipStream_t s);

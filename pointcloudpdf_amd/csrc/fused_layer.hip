@@ -354,7 +354,9 @@ __device__ __forceinline__ void attn_weights(const LayerArgs &A, const Row &R, f
 }
 
 // ------------------------------------------------------------------------------------------------ P4: aggregation
-template <int C, int K>
+// STATS: the block also leaves one partial row [sum out (C) | sum out^2 (C)] in A.partial -- the statistics of the Bottleneck's bn2, which
+// reads this pass's output (point_transformer_seg.py:187): its own statistics pass over `out` (one launch per block) is not needed then.
+template <int C, int K, bool STATS>
 __global__ __launch_bounds__(64 * WPB) void k_p4(LayerArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NCH = C / 32, PPT = 64 / K, CS = C / 8;
@@ -362,6 +364,11 @@ __global__ __launch_bounds__(64 * WPB) void k_p4(LayerArgs A) {
     const WaveLds L = carve_lds<false, C>(lds, threadIdx.x >> 6);
     const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
     const long ntiles = ((long)A.N * K + 63) / 64;
+    float so[STATS ? NCH : 1], sso[STATS ? NCH : 1];   // lane (half, ch): channel q * 32 + ch of the points this lane finishes
+    if (STATS) {
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) { so[q] = 0.f; sso[q] = 0.f; }
+    }
     for (long tile = wave_g; tile < ntiles; tile += nwaves) {
         const Row R = load_row<K>(A, tile, lane);
         float t1n[3];
@@ -391,10 +398,23 @@ __global__ __launch_bounds__(64 * WPB) void k_p4(LayerArgs A) {
 #pragma unroll
                 for (int j = 0; j < K; ++j) acc += L.tile[(pt * K + j) * L.ts + ch];
                 const long i = tile * PPT + pt;
-                if (i < A.N) A.out[(size_t)i * C + q * 32 + ch] = acc;
+                if (i < A.N) {
+                    A.out[(size_t)i * C + q * 32 + ch] = acc;
+                    if (STATS) { so[STATS ? q : 0] += acc; sso[STATS ? q : 0] += acc * acc; }
+                }
             }
             wave_sync();
         }
+    }
+    if (STATS) {
+        block_row(lds, 2 * C, [&](RowAcc o) {
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) {
+                const float a = so[STATS ? q : 0] + __shfl_xor(so[STATS ? q : 0], 32, 64), b = sso[STATS ? q : 0] + __shfl_xor(sso[STATS ? q : 0], 32, 64);
+                if (lane < 32) { o[q * 32 + lane] = a; o[C + q * 32 + lane] = b; }
+            }
+        });
+        store_row(lds, 2 * C, A.partial + (size_t)blockIdx.x * 2 * C);
     }
 }
 
@@ -995,7 +1015,7 @@ namespace fl {
 
 template <int C, int K>
 int forward_impl(LayerArgs A, int training, float eps, float momentum, const float *const *bn_params, float *const *bn_buffers,
-                 float *bn, float *saved, hipStream_t s) {
+                 float *bn, float *saved, int *out_stat_rows, hipStream_t s) {
     constexpr int CS = C / 8;
     const long rows = (long)A.N * K;
     const long ntiles = (rows + 63) / 64;
@@ -1009,17 +1029,19 @@ int forward_impl(LayerArgs A, int training, float eps, float momentum, const flo
         k_bn_eval<<<pdf_divup(C, 64), 64, 0, s>>>(C, bn_params[2], bn_params[3], eps, bn_buffers[2], bn_buffers[3], s1, t1, nullptr, nullptr);
         k_bn_eval<<<1, 64, 0, s>>>(CS, bn_params[4], bn_params[5], eps, bn_buffers[4], bn_buffers[5], s2, t2, nullptr, nullptr);
         allow_lds(k_p3<C, K, false>, lds);
-        allow_lds(k_p4<C, K>, lds);
+        allow_lds(k_p4<C, K, false>, lds);
         if (flm::supported(K, C)) flm::launch_p3(A, C, false, grid, s);
         else k_p3<C, K, false><<<grid, 64 * WPB, lds, s>>>(A);
-        if (flm::supported(K, C)) flm::launch_p4(A, C, grid, s); else k_p4<C, K><<<grid, 64 * WPB, lds, s>>>(A);
+        if (flm::supported(K, C)) flm::launch_p4(A, C, grid, false, s); else k_p4<C, K, false><<<grid, 64 * WPB, lds, s>>>(A);
+        if (out_stat_rows) *out_stat_rows = 0;   // (eval: bn2 uses its running statistics)
         return pdf_launch_status();
     }
     constexpr int T = 3 + C + CS;   // saved = [mean: p(3) | 1(C) | 2(CS)] [rstd: same order]  (the layout the backward kernels index)
     float *mp = saved, *m1 = saved + 3, *m2 = saved + 3 + C, *rp = saved + T, *r1 = saved + T + 3, *r2 = saved + T + 3 + C;
     allow_lds(k_p2<C, K>, lds);
     allow_lds(k_p3<C, K, true>, lds);
-    allow_lds(k_p4<C, K>, lds);
+    allow_lds(k_p4<C, K, false>, lds);
+    allow_lds(k_p4<C, K, true>, lds);
     if (A.mom) {   // BNp from the geometry moments: P2 computes the coefficients in its prologue, its block 0 stores them
         A.gam_p = as_const(bn_params[0]); A.bet_p = as_const(bn_params[1]);
         A.bnp_coef = sp; A.bnp_saved = mp; A.bnp_T = T; A.bnp_rm = bn_buffers[0]; A.bnp_rv = bn_buffers[1];
@@ -1037,7 +1059,16 @@ int forward_impl(LayerArgs A, int training, float eps, float momentum, const flo
     if (flm::supported(K, C)) { const int g3 = pass_grid(P3, A.N, C <= 256 ? 2 * MAX_BLOCKS : MAX_BLOCKS); nw3 = g3; flm::launch_p3(A, C, true, g3, s); }
     else k_p3<C, K, true><<<grid, 64 * WPB, lds, s>>>(A);
     k_bn_finalize<<<pdf_divup(CS, 16), RED_THREADS, 0, s>>>(A.partial, nw3, CS, (double)rows, bn_params[4], bn_params[5], eps, momentum, bn_buffers[4], bn_buffers[5], s2, t2, m2, r2);
-    if (flm::supported(K, C)) flm::launch_p4(A, C, grid, s); else k_p4<C, K><<<grid, 64 * WPB, lds, s>>>(A);
+    // P4 (+ the statistics of its output for the Bottleneck's bn2 when the caller wants them: *out_stat_rows partial rows of 2 C floats in
+    // A.partial -- P3's rows there are consumed, the finalizer above ran in stream order)
+    const bool ostats = out_stat_rows != nullptr;
+    if (flm::supported(K, C)) {
+        flm::launch_p4(A, C, grid, ostats, s);
+        if (ostats) *out_stat_rows = flm::p4_grid(A.N, grid);
+    } else {
+        if (ostats) k_p4<C, K, true><<<grid, 64 * WPB, lds, s>>>(A); else k_p4<C, K, false><<<grid, 64 * WPB, lds, s>>>(A);
+        if (ostats) *out_stat_rows = grid;
+    }
     return pdf_launch_status();
 }
 
@@ -1162,20 +1193,20 @@ extern "C" int pdf_pt_layer_forward_m(int n, int nsample, int c, const float *xq
                                       const float *p, const int *idx, const float *const *weights,
                                       const float *const *bn_params, float *const *bn_buffers, int training, float eps,
                                       float momentum, float *bn, float *saved, float *H, float *partial, float *out,
-                                      int storage_bf16, const int *order, const double *moments, void *stream);
+                                      int storage_bf16, const int *order, const double *moments, int *out_stat_rows, void *stream);
 extern "C" int pdf_pt_layer_forward(int n, int nsample, int c, const float *xq, const float *xk, const float *xv,
                                     const float *p, const int *idx, const float *const *weights,
                                     const float *const *bn_params, float *const *bn_buffers, int training, float eps,
                                     float momentum, float *bn, float *saved, float *H, float *partial, float *out,
                                     int storage_bf16, const int *order, void *stream) {
     return pdf_pt_layer_forward_m(n, nsample, c, xq, xk, xv, p, idx, weights, bn_params, bn_buffers, training, eps, momentum, bn, saved, H,
-                                  partial, out, storage_bf16, order, nullptr, stream);
+                                  partial, out, storage_bf16, order, nullptr, nullptr, stream);
 }
 extern "C" int pdf_pt_layer_forward_m(int n, int nsample, int c, const float *xq, const float *xk, const float *xv,
                                       const float *p, const int *idx, const float *const *weights,
                                       const float *const *bn_params, float *const *bn_buffers, int training, float eps,
                                       float momentum, float *bn, float *saved, float *H, float *partial, float *out,
-                                      int storage_bf16, const int *order, const double *moments, void *stream) {
+                                      int storage_bf16, const int *order, const double *moments, int *out_stat_rows, void *stream) {
     if (n < 1 || !xq || !xk || !xv || !p || !idx || !weights || !bn_params || !bn_buffers || !bn || !H || !partial || !out)
         return PDF_ERR_BAD_ARG;
     if (!pdf_pt_layer_supported(nsample, c)) return PDF_ERR_UNSUPPORTED;
@@ -1189,7 +1220,7 @@ extern "C" int pdf_pt_layer_forward_m(int n, int nsample, int c, const float *xq
     A.H = H; A.out = out; A.partial = partial; A.bf16 = storage_bf16 & 1; A.chunked = (storage_bf16 >> 1) & 1; A.order = (storage_bf16 & 4) ? order : nullptr;
     A.mom = training ? moments : nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
-#define PDF_FWD(C_, K_) return fl::forward_impl<C_, K_>(A, training, eps, momentum, bn_params, bn_buffers, bn, saved, s)
+#define PDF_FWD(C_, K_) return fl::forward_impl<C_, K_>(A, training, eps, momentum, bn_params, bn_buffers, bn, saved, out_stat_rows, s)
     if (nsample == 8) {
         if (c == 32) PDF_FWD(32, 8);
         if (c == 64) PDF_FWD(64, 8);

@@ -420,9 +420,12 @@ __global__ __launch_bounds__(64 * WPB) void k_p3(LayerArgs A) {
 
 // ------------------------------------------------------------------------------------------------ P4: aggregation
 // out[i][c] = sum_rows (x_v[nb][c] + p_r[c]) * w[row][c mod CS]
-template <int C, bool BF>
+// STATS: + one partial row [sum out (C) | sum out^2 (C)] per block in A.partial (the statistics of the Bottleneck's bn2, fl::k_p4).  After
+// the sum over the 16 rows every row-lane holds the finished value of its channels; row-lane r accumulates the 16-channel blocks j with
+// j mod 16 == r.
+template <int C, bool BF, bool STATS>
 __global__ __launch_bounds__(64 * WPB) void k_p4(LayerArgs A) {
-    constexpr int CS = C / 8, NG = C / 64, NOB = nob_of(C), CSP = csp_of(C);
+    constexpr int CS = C / 8, NG = C / 64, NOB = nob_of(C), CSP = csp_of(C), NJ = C / 16, NA = (NJ + 15) / 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *cst = lds, *ucst = lds + 4 * C, *w2 = ucst + 3 * CSP;
     stage_consts<C>(cst, A, false);
@@ -431,6 +434,11 @@ __global__ __launch_bounds__(64 * WPB) void k_p4(LayerArgs A) {
     __syncthreads();
     const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
     const GeoW G = geo_weights(A);
+    f32x4 so[STATS ? NA : 1], sso[STATS ? NA : 1];
+    if (STATS) {
+#pragma unroll
+        for (int a = 0; a < NA; ++a) { so[a] = zero4(); sso[a] = zero4(); }
+    }
     fl::PointWalk pw(A, threadIdx.x >> 6);
     int nb_next = pw.valid() ? A.idx[pw.point() * 16 + row] : -1;
     for (; pw.valid(); pw.step()) {
@@ -466,8 +474,22 @@ __global__ __launch_bounds__(64 * WPB) void k_p4(LayerArgs A) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) t[e] = sum16(v[e]);
                 if (row == 0) st4(A.out + (size_t)i * C + 4 * g, t);
+                if (STATS && row == (j & 15)) { so[STATS ? j / 16 : 0] += t; sso[STATS ? j / 16 : 0] += t * t; }
             }
         }
+    }
+    if (STATS) {
+        block_row(lds, 2 * C, [&](RowAcc o) {
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                const int j = 16 * a + row;
+                if (j < NJ) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[16 * j + 4 * kq + e] = so[STATS ? a : 0][e]; o[C + 16 * j + 4 * kq + e] = sso[STATS ? a : 0][e]; }
+                }
+            }
+        });
+        store_row(lds, 2 * C, A.partial + (size_t)blockIdx.x * 2 * C);
     }
 }
 
@@ -731,18 +753,29 @@ __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
 
 // ------------------------------------------------------------------------------------------------ B3
 // partial row per block: [sum g_yp (3) | sum g_yp*that (3) | pad 2 | g_bp2 (C) | g_Wp2 (C*3)]   (as fl::k_b3)
+//
+// Round 4: the POINTS are the outer loop and the 64-channel chunks the inner one (rounds 1-3: chunks outermost, every chunk re-staged its
+// Ww1 slab behind two block barriers and re-read the point's H / G2 / Wsm / coordinates / G3 -- at levels 4-5, where a wave sees one or
+// two points, the launch was a chain of NCHK x (stage, barrier, trip, barrier): 47 us for 3,124 points).  Up to four chunks (256 channels)
+// of Ww1 and of the per-channel constants are staged at once; a point's row data is loaded once, its chunks run back to back (the next
+// chunk's rows are requested before the current chunk's column phase), g_t1n stays in registers and G3 is written once.  C = 512 takes two
+// such sweeps over the points (the second adds to the first one's G3), the other widths one.
+template <int C> constexpr int b3_ncp() { return C / 64 < 4 ? C / 64 : 4; }          // chunks per sweep
+template <int C> constexpr int b3_wls() { return 64 * b3_ncp<C>() + 4; }             // row stride of the Ww1 copy (floats)
 template <int C, bool BF>
 __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
-    constexpr int CS = C / 8, NOB = nob_of(C), CSP = csp_of(C), NCHK = C / 64, WS = 68, W = 8 + 4 * C;
+    constexpr int CS = C / 8, NOB = nob_of(C), CSP = csp_of(C), NCHK = C / 64, NCP = b3_ncp<C>(), NSW = NCHK / NCP, WS = b3_wls<C>(), W = 8 + 4 * C;
+    constexpr int CW = 64 * NCP;             // channels of a sweep
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wv = threadIdx.x >> 6;
     float *cst = lds;                        // Wp2 (3C, channel-major) | bp2 (C) | s1 (C) | t1 (C)
-    float *ccst = cst + 6 * C;               // this chunk's channels: mean1 | rstd1 | sum g_y1 / rows | sum g_y1*rhat / rows   (4 x 64)
-    float *ucst = ccst + 256;                // per-unit constants (stage_units), sums = B1's
-    float *wl = ucst + 7 * CSP;              // Ww1[:, 64 q ..+64] of the current chunk, row stride 68
-    float *tile = wl + CSP * WS + wv * 32 * TS, *tile2 = tile + 16 * TS;   // g_r tile, g_pr tile
-    float *t1nt = wl + CSP * WS + WPB * 32 * TS + wv * 64;
-    float *crow = wl + CSP * WS + WPB * 32 * TS + WPB * 64;   // WPB x 256: the waves' columns of the current chunk
+    float *ccst = cst + 6 * C;               // the sweep's channels: mean1 | rstd1 | sum g_y1 / rows | sum g_y1*rhat / rows   (4 x CW)
+    float *ucst = ccst + 4 * CW;             // per-unit constants (stage_units), sums = B1's
+    float *wl = ucst + 7 * CSP;              // Ww1[:, sweep's channels], row stride WS
+    float *tiles = wl + CSP * WS;
+    float *tile = tiles + wv * 32 * TS, *tile2 = tile + 16 * TS;   // g_r tile, g_pr tile (one 64-channel chunk)
+    float *t1nt = tiles + WPB * 32 * TS + wv * 64;
+    float *crow = tiles;                     // epilogue: WPB x 4 CW columns (the tiles are free then)
     stage_consts<C>(cst, A, true);
     const float *S2 = gp(A.sums);   // [sum g_y1 (C) | sum g_y1*rhat (C)]   (A.sums2 = B1's [sum g_y2 | sum g_y2*hhat])
     stage_units<C, true>(ucst, A, gp(A.sums2));
@@ -750,20 +783,20 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
     const GeoW G = geo_weights(A);
     float sgp[3] = {0.f, 0.f, 0.f}, sgpt[3] = {0.f, 0.f, 0.f};
     float *dst = A.partial + (size_t)blockIdx.x * W;   // the block's partial row
-    // The 64-channel chunks are the OUTER loop (every chunk re-derives the cheap per-point quantities): the per-channel
-    // accumulators then are four scalars, the Ww1 copy in LDS is one 64-column slab, and g_t1n (a sum over all channels)
-    // is accumulated in G3 by the owning lane.
 #pragma unroll 1
-    for (int q = 0; q < NCHK; ++q) {
-        __syncthreads();   // previous slab fully consumed (and, first trip, constants staged)
-        stage_rows<CSP, 64, WS>(wl, gp(A.Ww1) + 64 * q, C, CS);
-        {
-            const int arr = threadIdx.x >> 6, c = 64 * q + (threadIdx.x & 63);
+    for (int sw = 0; sw < NSW; ++sw) {
+        const int cb = CW * sw;              // first channel of the sweep
+        __syncthreads();                     // previous sweep fully consumed (and, first sweep, constants staged)
+        stage_rows<CSP, CW, WS>(wl, gp(A.Ww1) + cb, C, CS);
+        for (int e = threadIdx.x; e < 4 * CW; e += NT) {
+            const int arr = e / CW, c = cb + e % CW;
             const float *src = arr == 0 ? gp(A.mean) + 3 : arr == 1 ? gp(A.rstd) + 3 : arr == 2 ? S2 : S2 + C;
-            ccst[threadIdx.x] = src[c] * (arr >= 2 ? A.inv_rows : 1.f);
+            ccst[e] = src[c] * (arr >= 2 ? A.inv_rows : 1.f);
         }
         __syncthreads();
-        float sbp2 = 0.f, awp2[3] = {0.f, 0.f, 0.f};
+        float sbp2[NCP], awp2[NCP][3];
+#pragma unroll
+        for (int qc = 0; qc < NCP; ++qc) { sbp2[qc] = 0.f; awp2[qc][0] = 0.f; awp2[qc][1] = 0.f; awp2[qc][2] = 0.f; }
         fl::PointWalk pw(A, wv);
         int nb_next = pw.valid() ? A.idx[pw.point() * 16 + row] : -1;
         for (; pw.valid(); pw.step()) {
@@ -771,27 +804,24 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
             const size_t ri = (size_t)i * 16 + row;
             const int nb = nb_next;
             const size_t nbc = (size_t)max(nb, 0);
-            // ---------------- every global load of the trip
+            // ---------------- every global load of the point's row data + its first chunk
             nb_next = A.idx[(pw.has_next() ? pw.next_point() : i) * 16 + row];
             float pn[3], pi[3], g3old[3];
 #pragma unroll
-            for (int b = 0; b < 3; ++b) { pn[b] = A.p[nbc * 3 + b]; pi[b] = A.p[(size_t)i * 3 + b]; g3old[b] = A.G3[ri * 3 + b]; }
+            for (int b = 0; b < 3; ++b) { pn[b] = A.p[nbc * 3 + b]; pi[b] = A.p[(size_t)i * 3 + b]; g3old[b] = NSW > 1 ? A.G3[ri * 3 + b] : 0.f; }
             f32x4 hh[NOB], g2[NOB], w[NOB], xk[4], xq[4], go[4];
 #pragma unroll
             for (int ob = 0; ob < NOB; ++ob) {
                 const size_t o = ri * CS + unit_off<C>(ob, kq);
                 hh[ob] = ld_row4<BF>(A.H, o); g2[ob] = ld_row4<BF>(A.G2, o); w[ob] = ld_row4<BF>(A.Wsm, o);
             }
+            const float *xkr = A.xk + nbc * C + cb + 4 * kq, *xqr = A.xq + (size_t)i * C + cb + 4 * kq, *gor = A.gout + (size_t)i * C + cb + 4 * kq;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int c4 = 4 * (4 * (4 * q + jj) + kq);
-                xk[jj] = ld4(A.xk + nbc * C + c4); xq[jj] = ld4(A.xq + (size_t)i * C + c4); go[jj] = ld4(A.gout + (size_t)i * C + c4);
-            }
+            for (int jj = 0; jj < 4; ++jj) { xk[jj] = ld4(xkr + 16 * jj); xq[jj] = ld4(xqr + 16 * jj); go[jj] = ld4(gor + 16 * jj); }
             __builtin_amdgcn_sched_barrier(0);
             const Geo R = geo_of(G, nb, pn, pi);
             if (kq == 0) { t1nt[row * 4 + 0] = R.t1n[0]; t1nt[row * 4 + 1] = R.t1n[1]; t1nt[row * 4 + 2] = R.t1n[2]; }
-            // g_h of the lane's hidden units (BN2 backward); softmax weights as B1 stored them (Wsm) -- read back instead of redoing
-            // BN2, the (C/8)^2 product and the softmax for every 64-channel chunk
+            // g_h of the lane's hidden units (BN2 backward); softmax weights as B1 stored them (Wsm)
             f32x4 gh[NOB];
             hidden_grad<C>(ucst, kq, hh, g2, gh);
 #pragma unroll
@@ -801,62 +831,81 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
                 if (kq >= 2) w[0] = x;
             }
             float gt1n[3] = {0.f, 0.f, 0.f};
+            // (rolled on purpose: unrolled, the compiler keeps the operands of all four chunks live -- 512 registers and spills at C >= 128)
+#pragma unroll 1
+            for (int qc = 0; qc < NCP; ++qc) {
+                const int q = NCP * sw + qc;                                  // chunk in the layer
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int g = 4 * (4 * q + jj) + kq, gl = 4 * (4 * jj + kq);   // channel group in the layer / in the chunk
-                f32x4 acc = zero4();
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int g = 4 * (4 * q + jj) + kq, gl = 64 * qc + 4 * (4 * jj + kq);   // channel group in the layer / first channel in the sweep
+                    f32x4 acc = zero4();
 #pragma unroll
-                for (int ob = 0; ob < NOB; ++ob)
+                    for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(16 * ob + 4 * kq + e) * WS + 16 * jj + row], gh[ob][e], acc, 0, 0, 0);
-                const f32x4 r = (sel4(nb >= 0, xk[jj]) - xq[jj]) + pos4(cst, C, g, R.t1n);
-                const f32x4 s1 = ld4(cst + 4 * C + 4 * g);
-                const f32x4 y1 = r * s1 + ld4(cst + 5 * C + 4 * g);
-                f32x4 gy1;
+                        for (int e = 0; e < 4; ++e)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(16 * ob + 4 * kq + e) * WS + 64 * qc + 16 * jj + row], gh[ob][e], acc, 0, 0, 0);
+                    const f32x4 r = (sel4(nb >= 0, xk[jj]) - xq[jj]) + pos4(cst, C, g, R.t1n);
+                    const f32x4 s1 = ld4(cst + 4 * C + 4 * g);
+                    const f32x4 y1 = r * s1 + ld4(cst + 5 * C + 4 * g);
+                    f32x4 gy1;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) gy1[e] = y1[e] > 0.f ? acc[e] : 0.f;
-                // BN1 backward: g_r = s1 * (g_y1 - mean(g_y1) - rhat * mean(g_y1 * rhat))
-                const f32x4 rhat = (r - ld4(ccst + gl)) * ld4(ccst + 64 + gl);
-                const f32x4 gr = s1 * (gy1 - ld4(ccst + 128 + gl) - rhat * ld4(ccst + 192 + gl));
-                st4(tile + row * TS + 16 * jj + 4 * kq, gr);
-                const f32x4 gpr = gr + go[jj] * w[jj % NOB];   // + the aggregation's share of p_r
-                st4(tile2 + row * TS + 16 * jj + 4 * kq, gpr);
-                const f32x4 w0 = ld4(cst + 12 * g), w1 = ld4(cst + 12 * g + 4), w2v = ld4(cst + 12 * g + 8);
-                const float wp[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2v[0], w2v[1], w2v[2], w2v[3]};
+                    for (int e = 0; e < 4; ++e) gy1[e] = y1[e] > 0.f ? acc[e] : 0.f;
+                    // BN1 backward: g_r = s1 * (g_y1 - mean(g_y1) - rhat * mean(g_y1 * rhat))
+                    const f32x4 rhat = (r - ld4(ccst + gl)) * ld4(ccst + CW + gl);
+                    const f32x4 gr = s1 * (gy1 - ld4(ccst + 2 * CW + gl) - rhat * ld4(ccst + 3 * CW + gl));
+                    st4(tile + row * TS + 16 * jj + 4 * kq, gr);
+                    const f32x4 gpr = gr + go[jj] * w[jj % NOB];   // + the aggregation's share of p_r  ((4 q + jj) mod NOB = jj mod NOB: NOB divides 4)
+                    st4(tile2 + row * TS + 16 * jj + 4 * kq, gpr);
+                    const f32x4 w0 = ld4(cst + 12 * g), w1 = ld4(cst + 12 * g + 4), w2v = ld4(cst + 12 * g + 8);
+                    const float wp[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2v[0], w2v[1], w2v[2], w2v[3]};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    gt1n[0] += gpr[e] * wp[3 * e]; gt1n[1] += gpr[e] * wp[3 * e + 1]; gt1n[2] += gpr[e] * wp[3 * e + 2];
+                    for (int e = 0; e < 4; ++e) {
+                        gt1n[0] += gpr[e] * wp[3 * e]; gt1n[1] += gpr[e] * wp[3 * e + 1]; gt1n[2] += gpr[e] * wp[3 * e + 2];
+                    }
                 }
-            }
-            wave_sync();
-            {   // lanes along channels: g_r rows out (256 B per row and chunk), g_xq[i] = - sum_rows g_r
-                float acc = 0.f;
+                {   // the next chunk's rows: requested now, in flight during this chunk's column phase (last chunk: re-reads itself, unused)
+                    const int qn = qc + 1 < NCP ? qc + 1 : qc;
 #pragma unroll
-                for (int rr = 0; rr < 16; ++rr) {
-                    const float v = tile[rr * TS + lane];
-                    acc += v;
-                    const size_t o = ((size_t)i * 16 + rr) * C + 64 * q + lane;   // g_xk = segmented sum of these rows
-                    if constexpr (BF) __builtin_nontemporal_store((unsigned short)fl::f2bf(v), reinterpret_cast<unsigned short *>(A.GR) + o);
-                    else __builtin_nontemporal_store(v, A.GR + o);
+                    for (int jj = 0; jj < 4; ++jj) {
+                        xk[jj] = ld4(xkr + 64 * qn + 16 * jj); xq[jj] = ld4(xqr + 64 * qn + 16 * jj); go[jj] = ld4(gor + 64 * qn + 16 * jj);
+                    }
                 }
-                A.gxq[(size_t)i * C + 64 * q + lane] = -acc;
-            }
+                wave_sync();
+                {   // lanes along channels: g_r rows out (256 B per row and chunk), g_xq[i] = - sum_rows g_r
+                    float acc = 0.f;
 #pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {   // g_bp2 / g_Wp2 of channel 64 q + lane
-                const float v = tile2[rr * TS + lane];
-                sbp2 += v;
-                awp2[0] += v * t1nt[rr * 4 + 0]; awp2[1] += v * t1nt[rr * 4 + 1]; awp2[2] += v * t1nt[rr * 4 + 2];
+                    for (int rr = 0; rr < 16; ++rr) {
+                        const float v = tile[rr * TS + lane];
+                        acc += v;
+                        const size_t o = ((size_t)i * 16 + rr) * C + 64 * q + lane;   // g_xk = segmented sum of these rows
+                        if constexpr (BF) __builtin_nontemporal_store((unsigned short)fl::f2bf(v), reinterpret_cast<unsigned short *>(A.GR) + o);
+                        else __builtin_nontemporal_store(v, A.GR + o);
+                    }
+                    A.gxq[(size_t)i * C + 64 * q + lane] = -acc;
+                }
+                float cb2 = 0.f, cw2[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {   // g_bp2 / g_Wp2 of channel 64 q + lane
+                    const float v = tile2[rr * TS + lane];
+                    cb2 += v;
+                    cw2[0] += v * t1nt[rr * 4 + 0]; cw2[1] += v * t1nt[rr * 4 + 1]; cw2[2] += v * t1nt[rr * 4 + 2];
+                }
+#pragma unroll
+                for (int k = 0; k < NCP; ++k) {   // (static register indices: the chunk's sums go to accumulator set qc through selects)
+                    const bool on = k == qc;
+                    sbp2[k] += on ? cb2 : 0.f;
+                    awp2[k][0] += on ? cw2[0] : 0.f; awp2[k][1] += on ? cw2[1] : 0.f; awp2[k][2] += on ? cw2[2] : 0.f;
+                }
+                wave_sync();
             }
-            wave_sync();
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 float v = gt1n[a];
                 v += __shfl_xor(v, 16, 64);
                 v += __shfl_xor(v, 32, 64);
                 if (kq == 0) {
-                    if (q > 0) v += g3old[a];
-                    if (q == NCHK - 1) {   // all channels seen: ReLU mask of BNp, BNp-backward sums
+                    if (sw > 0) v += g3old[a];
+                    if (sw == NSW - 1) {   // all channels seen: ReLU mask of BNp, BNp-backward sums
                         v = R.t1n[a] > 0.f ? v : 0.f;
                         sgp[a] += v;
                         sgpt[a] += v * ((R.t1[a] - A.mean[a]) * A.rstd[a]);
@@ -865,19 +914,23 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
                 }
             }
         }
-        // this chunk's columns of the block's row (g_bp2: 64, g_Wp2: 64 x 3): per wave into LDS, summed in wave order
-        crow[wv * 256 + lane] = sbp2;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) crow[wv * 256 + 64 + lane * 3 + a] = awp2[a];
+        // the sweep's columns of the block's row (g_bp2: CW, g_Wp2: CW x 3): per wave into LDS (the tiles are free), summed in wave order
         __syncthreads();
-        {
-            const int t = threadIdx.x;   // 256 threads, 256 columns
+#pragma unroll
+        for (int qc = 0; qc < NCP; ++qc) {
+            crow[wv * 4 * CW + 64 * qc + lane] = sbp2[qc];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) crow[wv * 4 * CW + CW + (64 * qc + lane) * 3 + a] = awp2[qc][a];
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < 4 * CW; t += NT) {
             float v = crow[t];
 #pragma unroll
-            for (int w = 1; w < WPB; ++w) v += crow[w * 256 + t];
-            if (t < 64) dst[8 + 64 * q + t] = v; else dst[8 + C + (size_t)192 * q + (t - 64)] = v;
+            for (int w = 1; w < WPB; ++w) v += crow[w * 4 * CW + t];
+            if (t < CW) dst[8 + cb + t] = v; else dst[8 + C + (size_t)3 * cb + (t - CW)] = v;
         }
     }
+    __syncthreads();
     block_row(crow, 8, [&](RowAcc o) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -919,13 +972,17 @@ void launch_p3(const LayerArgs &A, int c, bool stats, int grid, hipStream_t s) {
     PDF_FLM_C(K_, g, lds);
 #undef K_
 }
-void launch_p4(const LayerArgs &A, int c, int grid, hipStream_t s) {
-    // no partial rows in this pass: size the grid for occupancy (one point per wave and trip)
-    long gl = ((long)A.N + WPB - 1) / WPB;
+int p4_grid(long n, int grid) {
+    // sized for occupancy (one point per wave and trip); with statistics one partial row of 2 C floats per block
+    long gl = (n + WPB - 1) / WPB;
     gl = gl > 2048 ? 2048 : (gl < grid ? grid : gl);
-    const dim3 g((unsigned)gl);
-    const size_t lds = (size_t)4 * c + 3 * csp_of(c) + w2_floats(c);
-#define K_(C_) do { if (A.bf16) launch(k_p4<C_, true>, g, lds, A, s); else launch(k_p4<C_, false>, g, lds, A, s); } while (0)
+    return (int)gl;
+}
+void launch_p4(const LayerArgs &A, int c, int grid, bool stats, hipStream_t s) {
+    const dim3 g((unsigned)p4_grid(A.N, grid));
+    const size_t lds = std::max<size_t>((size_t)4 * c + 3 * csp_of(c) + w2_floats(c), stats ? (size_t)WPB * 2 * c : 0);
+#define K_(C_) do { if (stats) { if (A.bf16) launch(k_p4<C_, true, true>, g, lds, A, s); else launch(k_p4<C_, false, true>, g, lds, A, s); } \
+                    else { if (A.bf16) launch(k_p4<C_, true, false>, g, lds, A, s); else launch(k_p4<C_, false, false>, g, lds, A, s); } } while (0)
     PDF_FLM_C(K_, g, lds);
 #undef K_
 }
@@ -947,7 +1004,8 @@ void launch_b2(const LayerArgs &A, int c, int grid, hipStream_t s) {
 }
 void launch_b3(const LayerArgs &A, int c, int grid, hipStream_t s) {
     const dim3 g(grid);
-    const size_t lds = (size_t)6 * c + 256 + 7 * csp_of(c) + (size_t)csp_of(c) * 68 + WPB * 32 * TS + WPB * 64 + WPB * 256;
+    const int ncp = c / 64 < 4 ? c / 64 : 4, cw = 64 * ncp;   // (b3_ncp / the sweep's channels)
+    const size_t lds = (size_t)6 * c + 4 * cw + 7 * csp_of(c) + (size_t)csp_of(c) * (cw + 4) + std::max<size_t>(WPB * 32 * TS + WPB * 64, (size_t)WPB * 4 * cw);
 #define K_(C_) do { if (A.bf16) launch(k_b3<C_, true>, g, lds, A, s); else launch(k_b3<C_, false>, g, lds, A, s); } while (0)
     PDF_FLM_C(K_, g, lds);
 #undef K_

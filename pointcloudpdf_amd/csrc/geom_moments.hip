@@ -128,3 +128,73 @@ extern "C" int pdf_knn_rel_moments(int b, long n, int nsample, const float *xyz,
                                    void *stream) {
     return pdf_knn_rel_moments_q(b, n, nsample, xyz, xyz, offset, idx, out, ws, stream);
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Morton keys of a batch's points, scene by scene: key = scene << 30 | 30-bit Morton code of the point on a 1024^3 grid over ITS SCENE's
+// bounding box.  A stable sort of the keys is the VISITING order of the forward gathers / layer passes (geometry.Geometry.order; nothing
+// is stored in that order).  Per-scene boxes make a scene's order a function of that scene alone: a batch gets the same order -- and with
+// it the same rounding of every per-workgroup partial sum -- whether its pre-pass ran alone or inside a group of batches.
+namespace {
+__global__ __launch_bounds__(MB) void k_scene_bounds(const float *__restrict__ xyz, const int *__restrict__ offset, float *__restrict__ bounds) {
+    __shared__ float red[6][MB / 64];
+    const int s = blockIdx.x;
+    const long start = s == 0 ? 0 : offset[s - 1], end = offset[s];
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (long i = start + threadIdx.x; i < end; i += MB)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = xyz[3 * i + a];
+            lo[a] = fminf(lo[a], v);
+            hi[a] = fmaxf(hi[a], v);
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o, 64)); }
+        if ((threadIdx.x & 63) == 0) { red[a][threadIdx.x >> 6] = lo[a]; red[3 + a][threadIdx.x >> 6] = hi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float l[3], ext = 0.f;
+        for (int a = 0; a < 3; ++a) {
+            float h = red[3 + a][0];
+            l[a] = red[a][0];
+            for (int w = 1; w < MB / 64; ++w) { l[a] = fminf(l[a], red[a][w]); h = fmaxf(h, red[3 + a][w]); }
+            ext = fmaxf(ext, end > start ? h - l[a] : 0.f);
+        }
+        bounds[4 * s + 0] = l[0]; bounds[4 * s + 1] = l[1]; bounds[4 * s + 2] = l[2];
+        bounds[4 * s + 3] = fmaxf(ext / 1023.0f, 1e-9f);   // cell edge
+    }
+}
+__device__ __forceinline__ unsigned spread10(unsigned v) {   // 10 bits -> every third bit
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    return (v | (v << 2)) & 0x09249249u;
+}
+__global__ __launch_bounds__(MB) void k_scene_morton(long n, int b, const float *__restrict__ xyz, const int *__restrict__ offset,
+                                                     const float *__restrict__ bounds, long long *__restrict__ keys) {
+    const long i = (long)blockIdx.x * MB + threadIdx.x;
+    if (i >= n) return;
+    const int s = scene_of(offset, b, i);
+    const float cell = bounds[4 * s + 3];
+    unsigned q[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int v = (int)((xyz[3 * i + a] - bounds[4 * s + a]) / cell);
+        q[a] = (unsigned)(v < 0 ? 0 : (v > 1023 ? 1023 : v));
+    }
+    keys[i] = ((long long)s << 30) | (long long)(spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2));
+}
+}  // namespace
+
+// keys (n) int64, bounds (4 b floats of scratch: per scene lo x / y / z and the cell edge), both written.
+extern "C" int pdf_scene_morton_keys(long n, int b, const float *xyz, const int *offset, float *bounds, long long *keys, void *stream) {
+    if (n < 0 || b < 1 || !offset || !bounds || (n > 0 && (!xyz || !keys))) return PDF_ERR_BAD_ARG;
+    if (n == 0) return PDF_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    k_scene_bounds<<<(unsigned)b, MB, 0, s>>>(xyz, offset, bounds);
+    k_scene_morton<<<(unsigned)((n + MB - 1) / MB), MB, 0, s>>>(n, b, xyz, offset, bounds, keys);
+    return pdf_launch_status();
+}

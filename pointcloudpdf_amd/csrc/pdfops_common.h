@@ -87,3 +87,113 @@ __device__ __forceinline__ unsigned pdf_xcd_chunked_block(unsigned b, unsigned g
     const unsigned q = g / PDF_XCDS, r = g % PDF_XCDS, x = b % PDF_XCDS;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / PDF_XCDS;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// In-kernel BatchNorm finalize in the CONSUMER ("consumer-side reduction", round 4).  A train-mode BatchNorm on this path is
+//     producer kernel (emits per-workgroup partial rows [sum | sum of squares])  ->  reducer launch (k_bn_finalize, ~5 us + a launch
+//     boundary, ~240 of them per step)  ->  consumer kernel (reads scale | shift).
+// Round 3 folded the reducer into the PRODUCER (last-arriver tails): slower -- every producing workgroup had to release its row across
+// the XCDs (an L2 write-back while the kernel still streams its output).  Here the rows cross a kernel boundary as before (free), and the
+// CONSUMER starts with the reduction: the first workgroups to arrive (role ticket) each reduce 16 channels of the rows and publish
+// scale | shift as 8-byte {tag, value} granules (one write-through store each: the data is the flag -- /opt/skills/guides/
+// cdna_hip_programming.md, Guideline 16, form R2); every workgroup then polls the granules of the channels it needs (relaxed agent-scope
+// loads: L2-served, no fence) while its own prologue work (weight staging, index loads) is in flight.  The granules and the ticket are
+// zeroed by workgroup 0 of the PRODUCER kernel (complete and visible at the boundary), so the scratch needs no host-side
+// initialisation and the tag is the constant 1.  Order of every sum: fixed by the row indices (bit-reproducible).
+struct PdfRowsBn {
+    const float *rows; int nrows; int c; double count;           // partial rows [nrows][2 c]
+    const float *gamma, *beta; float *running_mean, *running_var; float eps, momentum;
+    float *coef;                                                  // (4 c) scale | shift | mean | rstd: written for the later passes / the backward
+    unsigned long long *gran;                                     // (2 c) granules of scale | shift
+    unsigned *sync;                                               // [0] role ticket
+};
+#define PDF_HO_WORDS(c) (2 * (size_t)(c) * 2 + 4)                 /* 32-bit words of handoff scratch for a c-channel norm: granules + ticket */
+#define PDF_HO_FLOATS PDF_HO_WORDS(1024)                          /* what every `partial` scratch reserves in FRONT of its rows (c <= 1024) */
+int pdf_rowlin_forward_stats_ho(long n, int k, int o, const float *x, long ldx, const float *w, const float *bias, const float *scale,
+                                const float *shift, int relu, float *y, long ldy, float *rows_out, void *handoff, int *rows, int mma_input,
+                                void *stream);   // rowlin.hip
+int pdf_bn_apply_rows(long n, int c, const float *x, const float *res, const float *rows, int nrows, const float *gamma, const float *beta,
+                      float *running_mean, float *running_var, float eps, float momentum, float *coef, void *handoff, int relu, float *y,
+                      void *stream);             // pointwise.hip
+
+// producer side: any ONE workgroup of the kernel that writes the rows (before or after its own work; the kernel boundary orders it)
+__device__ __forceinline__ void pdf_handoff_zero(unsigned long long *gran, int c, unsigned *sync) {
+    for (int e = threadIdx.x; e < 2 * c; e += blockDim.x) gran[e] = 0ull;
+    if (threadIdx.x == 0) sync[0] = 0u;
+}
+
+// consumer side, called by ALL threads of EVERY workgroup (blockDim.x == NT, a multiple of 64) before the first use of the coefficients.
+// lds_coef: 2 c floats (scale | shift) filled for the whole block; lds_red: 2 * (NT / 16) * 17 doubles of scratch.
+// Roles are static -- workgroup i (linear id) reduces channel slice i -- and NO atomic is involved: a ticket word taken by all 2,048
+// workgroups of a bandwidth-bound consumer serialises at ~12 ns per arrival (measured: +5 us per launch instead of -5).  HIP promises no
+// dispatch order, so a poller that sees no progress for a long time reduces the missing slices itself (same rows, same order, same
+// values: idempotent); on this hardware workgroups start in id order and the path is never taken.
+template <int NT>
+__device__ __forceinline__ void pdf_bn_reduce_slice(const PdfRowsBn &b, int sl, double *lds_red) {
+    constexpr int RL = NT / 16;
+    const int c = b.c, cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int ch = sl * 16 + cl;
+    double s = 0.0, ss = 0.0;
+    if (ch < c) {
+        const float *p0 = b.rows + ch, *p1 = b.rows + c + ch;
+        const size_t stride = 2 * (size_t)c;
+        for (int r = rl; r < b.nrows; r += 8 * RL) {   // eight rows in flight per lane; clamped address + select (no load under a branch)
+            float v0[8], v1[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int rr = r + t * RL < b.nrows ? r + t * RL : b.nrows - 1;
+                v0[t] = p0[(size_t)rr * stride]; v1[t] = p1[(size_t)rr * stride];
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const bool ok = r + t * RL < b.nrows;
+                s += ok ? (double)v0[t] : 0.0; ss += ok ? (double)v1[t] : 0.0;
+            }
+        }
+    }
+    __syncthreads();   // (lds_red free again)
+    lds_red[(0 * RL + rl) * 17 + cl] = s;
+    lds_red[(1 * RL + rl) * 17 + cl] = ss;
+    __syncthreads();
+    if (rl == 0 && ch < c) {
+        double a = 0.0, q = 0.0;
+        for (int k = 0; k < RL; ++k) { a += lds_red[(0 * RL + k) * 17 + cl]; q += lds_red[(1 * RL + k) * 17 + cl]; }
+        const double mean = a / b.count;
+        double var = q / b.count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)b.eps));
+        const float sc = b.gamma[ch] * rstd, sh = b.beta[ch] - (float)mean * sc;
+        b.coef[ch] = sc; b.coef[c + ch] = sh; b.coef[2 * c + ch] = (float)mean; b.coef[3 * c + ch] = rstd;
+        if (b.running_mean && b.sync != nullptr) {   // (running statistics: by the slice's OWNER only -- sync == nullptr marks a take-over)
+            const double unbiased = b.count > 1.0 ? var * b.count / (b.count - 1.0) : var;
+            b.running_mean[ch] = (1.f - b.momentum) * b.running_mean[ch] + b.momentum * (float)mean;
+            b.running_var[ch] = (1.f - b.momentum) * b.running_var[ch] + b.momentum * (float)unbiased;
+        }
+        __hip_atomic_store(b.gran + ch, (1ull << 32) | (unsigned long long)__float_as_uint(sc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(b.gran + c + ch, (1ull << 32) | (unsigned long long)__float_as_uint(sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void pdf_bn_coef_inkernel(const PdfRowsBn &b, float *lds_coef, double *lds_red, unsigned *lds_word) {
+    (void)lds_word;
+    const int c = b.c, nsl = (c + 15) / 16;
+    const unsigned me = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nblk = gridDim.x * gridDim.y * gridDim.z;
+    for (unsigned sl = me; sl < (unsigned)nsl; sl += nblk) pdf_bn_reduce_slice<NT>(b, (int)sl, lds_red);   // (block-uniform trip count)
+    // every workgroup: sweep the granules until every tag is set
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+        for (int e = threadIdx.x; e < 2 * c; e += NT) {
+            const unsigned long long g = __hip_atomic_load(b.gran + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = ok && (g >> 32) == 1ull;
+            lds_coef[e] = __uint_as_float((unsigned)g);
+        }
+        if (__syncthreads_and(ok)) break;
+        if (spins == (1u << 14)) {   // ~50 ms without the owners: take the reduction over (never observed: workgroups start in id order)
+            PdfRowsBn mine = b;
+            mine.sync = nullptr;
+            for (int sl = 0; sl < nsl; ++sl) pdf_bn_reduce_slice<NT>(mine, sl, lds_red);
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+}

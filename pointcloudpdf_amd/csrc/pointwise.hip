@@ -71,6 +71,27 @@ __global__ __launch_bounds__(PB) void k_bn_apply(long n4, int c4, const float4 *
     }
 }
 
+// The same with the BatchNorm's finalize inside this kernel (pdfops_common.h: pdf_bn_coef_inkernel): the statistics arrive as the
+// producer's partial rows, the first workgroups reduce them, everyone picks the coefficients up through the granules.
+template <bool RES>
+__global__ __launch_bounds__(PB) void k_bn_apply_rows(long n4, int c4, const float4 *__restrict__ x, PdfRowsBn b, const float4 *__restrict__ res,
+                                                      int relu, float4 *__restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // scale | shift (2 c) | reducer scratch | ticket word
+    const int c = 4 * c4;
+    double *red = reinterpret_cast<double *>(lds + 2 * c);
+    unsigned *word = reinterpret_cast<unsigned *>(red + 2 * (PB / 16) * 17);
+    pdf_bn_coef_inkernel<PB>(b, lds, red, word);
+    const float4 *scale = reinterpret_cast<const float4 *>(lds), *shift = reinterpret_cast<const float4 *>(lds + c);
+    for (long e = (long)blockIdx.x * PB + threadIdx.x; e < n4; e += (long)gridDim.x * PB) {
+        const int cc = (int)(e % c4);
+        const float4 v = x[e], sc = scale[cc], sh = shift[cc];
+        const float4 r = RES ? res[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 o = make_float4(v.x * sc.x + sh.x + r.x, v.y * sc.y + sh.y + r.y, v.z * sc.z + sh.z + r.z, v.w * sc.w + sh.w + r.w);
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        y[e] = o;
+    }
+}
+
 // partial[block][2c] = sum g' | sum g' * xhat,   g' = gy masked by the ReLU (recomputed from x, res)
 template <bool RES>
 __global__ __launch_bounds__(PB) void k_bn_bwd_reduce(long n, int c, const float *__restrict__ gy, const float *__restrict__ x,
@@ -179,7 +200,7 @@ void launch_colsum(const float *partial, int rows, int width, float *out, hipStr
 }  // namespace fl
 
 extern "C" int pdf_bn_supported(int c) { return c >= 4 && c % 4 == 0 && c <= 1024 && (1024 % c == 0); }
-extern "C" long pdf_bn_partial_floats(long n, int c) { return (long)pw::grid_rows(n, c) * 2 * c; }   // rows [grid][2c]
+extern "C" long pdf_bn_partial_floats(long n, int c) { return (long)pw::grid_rows(n, c) * 2 * c + (long)PDF_HO_FLOATS; }   // rows [grid][2c] (+ handoff scratch)
 
 // Forward of BatchNorm1d (+residual)(+ReLU) over (n, c).  coef (4c floats) receives [scale | shift | mean | rstd].
 // training: batch statistics (running stats updated when non-null); else running statistics.
@@ -265,6 +286,24 @@ extern "C" int pdf_bn_apply(long n, int c, const float *x, const float *res, con
     (res ? pw::k_bn_apply<true> : pw::k_bn_apply<false>)<<<pw::grid_elems(n4), pw::PB, 0, static_cast<hipStream_t>(stream)>>>(
         n4, c / 4, reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(coef), reinterpret_cast<const float4 *>(coef + c),
         reinterpret_cast<const float4 *>(res), relu, reinterpret_cast<float4 *>(y));
+    return pdf_launch_status();
+}
+
+// y = relu?(bn(x) + res) for a train-mode BatchNorm whose statistics are `nrows` partial rows [sum | sum of squares] of a producer that
+// zeroed `handoff` (PDF_HO_WORDS(c) 32-bit words): finalize + apply in ONE launch; coef (4 c) is written for the backward.
+int pdf_bn_apply_rows(long n, int c, const float *x, const float *res, const float *rows, int nrows, const float *gamma, const float *beta,
+                      float *running_mean, float *running_var, float eps, float momentum, float *coef, void *handoff, int relu, float *y,
+                      void *stream) {
+    if (n < 1 || !x || !rows || nrows < 1 || !gamma || !beta || !coef || !handoff || !y) return PDF_ERR_BAD_ARG;
+    if (!pdf_bn_supported(c)) return PDF_ERR_UNSUPPORTED;
+    PdfRowsBn b;
+    b.rows = rows; b.nrows = nrows; b.c = c; b.count = (double)n; b.gamma = gamma; b.beta = beta; b.running_mean = running_mean;
+    b.running_var = running_var; b.eps = eps; b.momentum = momentum; b.coef = coef;
+    b.gran = static_cast<unsigned long long *>(handoff); b.sync = reinterpret_cast<unsigned *>(b.gran + 2 * (size_t)c);
+    const long n4 = n * (c / 4);
+    const size_t lds = sizeof(float) * 2 * c + sizeof(double) * 2 * (pw::PB / 16) * 17 + 16;
+    (res ? pw::k_bn_apply_rows<true> : pw::k_bn_apply_rows<false>)<<<pw::grid_elems(n4), pw::PB, lds, static_cast<hipStream_t>(stream)>>>(
+        n4, c / 4, reinterpret_cast<const float4 *>(x), b, reinterpret_cast<const float4 *>(res), relu, reinterpret_cast<float4 *>(y));
     return pdf_launch_status();
 }
 

@@ -183,7 +183,7 @@ namespace rl2 {
 int try_forward(long n, int k, int o, int nin, int nout, const float *const *x, long ldx, const float *const *w, int transpose_w,
                 const float *const *bias, const float *scale, const float *shift, int relu, float *const *y, long ldy,
                 int accumulate, float *partial, int mma, hipStream_t s, const float *roww = nullptr, long rws = 0, const float *bx = nullptr,
-                long ldb = 0, const float *bcoef = nullptr, int brelu = 0, int *partial_rows = nullptr, long ldw = 0);
+                long ldb = 0, const float *bcoef = nullptr, int brelu = 0, int *partial_rows = nullptr, long ldw = 0, void *handoff = nullptr);
 long stats_rows_floats(long n, int o);
 int try_wgrad(long n, int k, int o, int ng, const float *const *g, long ldg, const float *x, long ldx, const float *scale,
               const float *shift, int relu, float *const *dw, float *const *db, float *ws, int mma, hipStream_t s, const float *roww = nullptr, long rws = 0);
@@ -218,9 +218,9 @@ static inline bool rowlin_streams(int k, int o) {
 extern "C" int pdf_rowlin_partial_rows(long n, int k, int o) {
     return rowlin_streams(k, o) ? rl2::stats_rows(n) : (int)((n + rl::BM - 1) / rl::BM);
 }
-extern "C" long pdf_rowlin_partial_floats(long n, int o) {   // rows of either kernel
+extern "C" long pdf_rowlin_partial_floats(long n, int o) {   // rows of either kernel + the handoff scratch of an in-kernel finalize
     const long a = (n + rl::BM - 1) / rl::BM * 2 * (long)o, b = rl2::stats_rows_floats(n, o);
-    return a > b ? a : b;
+    return (a > b ? a : b) + (long)PDF_HO_FLOATS;
 }
 
 // Y (n, o; row stride ldy) (+)= f(X (n, k; row stride ldx)) * Wt + bias.  transpose_w = 0: W is (o, k) row-major (forward);
@@ -293,6 +293,19 @@ extern "C" int pdf_rowlin_forward_bn(long n, int k, int o, const float *x, long 
     const int rc = pdf_rowlin_forward(n, k, o, x, ldx, w, 0, bias, scale, shift, relu, y, ldy, 0, partial, mma_input, stream);
     if (rc) return rc;
     return pdf_bn_coef_from_partial(partial, pdf_rowlin_partial_rows(n, k, o), n, o, gamma, beta, running_mean, running_var, eps, momentum, coef, stream);
+}
+
+// Internal (csrc/block.hip): pdf_rowlin_forward with the statistics rows of its output and the handoff scratch of the CONSUMER's in-kernel
+// BatchNorm finalize zeroed by the product's launch (pdfops_common.h: PdfRowsBn).  Streaming shapes only: returns PDF_ERR_UNSUPPORTED
+// otherwise (the caller then takes the finalizer-launch path).  *rows = number of partial rows written.
+int pdf_rowlin_forward_stats_ho(long n, int k, int o, const float *x, long ldx, const float *w, const float *bias, const float *scale,
+                                const float *shift, int relu, float *y, long ldy, float *rows_out, void *handoff, int *rows, int mma_input,
+                                void *stream) {
+    if (!rowlin_streams(k, o)) return PDF_ERR_UNSUPPORTED;
+    if (!rl2::try_forward(n, k, o, 1, 1, &x, ldx, &w, 0, &bias, scale, shift, relu, &y, ldy, 0, rows_out, mma_input, static_cast<hipStream_t>(stream),
+                          nullptr, 0, nullptr, 0, nullptr, 0, rows, 0, handoff))
+        return PDF_ERR_UNSUPPORTED;
+    return pdf_launch_status();
 }
 
 // dW (o, k) = G^T f(X), db (o) = column sums of G (db may be null); both are WRITTEN.  ws: pdf_rowlin_wgrad_ws_floats(n, k, o, 1) floats.

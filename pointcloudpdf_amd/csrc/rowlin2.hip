@@ -6,7 +6,7 @@
 namespace rl2 {
 template int try_forward_mp<0>(long, int, int, int, int, const float *const *, long, const float *const *, int, const float *const *, const float *,
                                const float *, int, float *const *, long, int, float *, hipStream_t, const float *, long, const float *, long,
-                               const float *, int, int *, long);
+                               const float *, int, int *, long, void *);
 template int try_wgrad_mp<0>(long, int, int, int, const float *const *, long, const float *, long, const float *, const float *, int,
                              float *const *, float *const *, float *, hipStream_t, const float *, long);
 template int try_wgrad_group_mp<0>(long, int, int, int, const float *const *, long, const float *const *, long, const float *const *, const float *const *, const int *,
@@ -17,10 +17,10 @@ extern template int try_wgrad_group_mp<2>(long, int, int, int, const float *cons
                                    float *const *, float *const *, float *, hipStream_t);
 extern template int try_forward_mp<1>(long, int, int, int, int, const float *const *, long, const float *const *, int, const float *const *, const float *,
                                       const float *, int, float *const *, long, int, float *, hipStream_t, const float *, long, const float *, long,
-                                      const float *, int, int *, long);
+                                      const float *, int, int *, long, void *);
 extern template int try_forward_mp<2>(long, int, int, int, int, const float *const *, long, const float *const *, int, const float *const *, const float *,
                                       const float *, int, float *const *, long, int, float *, hipStream_t, const float *, long, const float *, long,
-                                      const float *, int, int *, long);
+                                      const float *, int, int *, long, void *);
 extern template int try_wgrad_mp<1>(long, int, int, int, const float *const *, long, const float *, long, const float *, const float *, int,
                                     float *const *, float *const *, float *, hipStream_t, const float *, long);
 extern template int try_wgrad_mp<2>(long, int, int, int, const float *const *, long, const float *, long, const float *, const float *, int,
@@ -30,9 +30,9 @@ extern template int try_wgrad_mp<2>(long, int, int, int, const float *const *, l
 int try_forward(long n, int k, int o, int nin, int nout, const float *const *x, long ldx, const float *const *w, int transpose_w,
                 const float *const *bias, const float *scale, const float *shift, int relu, float *const *y, long ldy,
                 int accumulate, float *partial, int mma, hipStream_t s, const float *roww, long rws, const float *bx, long ldb, const float *bcoef,
-                int brelu, int *partial_rows, long ldw) {
+                int brelu, int *partial_rows, long ldw, void *handoff) {
 #define RL2_FWD(MP_) try_forward_mp<MP_>(n, k, o, nin, nout, x, ldx, w, transpose_w, bias, scale, shift, relu, y, ldy, accumulate, partial, s, roww, rws, \
-                                         bx, ldb, bcoef, brelu, partial_rows, ldw)
+                                         bx, ldb, bcoef, brelu, partial_rows, ldw, handoff)
     switch (mma) {
     case 1: return RL2_FWD(1);
     case 2: return RL2_FWD(2);

@@ -4,7 +4,7 @@
 namespace rl2 {
 template int try_forward_mp<2>(long, int, int, int, int, const float *const *, long, const float *const *, int, const float *const *, const float *,
                                const float *, int, float *const *, long, int, float *, hipStream_t, const float *, long, const float *, long,
-                               const float *, int, int *, long);
+                               const float *, int, int *, long, void *);
 template int try_wgrad_mp<2>(long, int, int, int, const float *const *, long, const float *, long, const float *, const float *, int,
                              float *const *, float *const *, float *, hipStream_t, const float *, long);
 template int try_wgrad_group_mp<2>(long, int, int, int, const float *const *, long, const float *const *, long, const float *const *, const float *const *, const int *,

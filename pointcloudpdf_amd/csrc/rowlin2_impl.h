@@ -75,6 +75,8 @@ struct FwdArgs {
     // [sum g' | sum g' xhat] (g' = output masked by the ReLU of bx * scale + shift, xhat = (bx - mean) * rstd) instead of [sum | sum of squares]
     const float *bx; long ldb; const float *bcoef; int brelu;   // bx (N, O; row stride ldb), bcoef = [scale | shift | mean | rstd] (4 O)
     const float *roww; long rws;   // optional per-row factor of the product (y = roww[n] * (f(x) Wt) + bias), element stride rws
+    // ST == 1, optional: handoff scratch of the CONSUMER's in-kernel BatchNorm finalize (pdfops_common.h: PdfRowsBn) -- zeroed here
+    unsigned long long *ho_gran; unsigned *ho_sync;
 };
 
 constexpr int FWD_CAP = 1024;   // row-blocks (4 waves each) of the persistent grid
@@ -91,6 +93,7 @@ __global__ __launch_bounds__(256) void k_fwd(FwdArgs a) {
     constexpr bool COEF_REGS = K <= 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, kq = lane >> 4;
+    if (ST == 1 && a.ho_gran && blockIdx.x == 0 && blockIdx.y == 0) pdf_handoff_zero(a.ho_gran, a.O, a.ho_sync);
     const int gcol0 = blockIdx.y * NOB * 16;   // column over the concatenated outputs; a 16-column block never straddles two
     int outi[NOB], colb[NOB];
 #pragma unroll
@@ -495,7 +498,7 @@ template <int MP>
 int try_forward_mp(long n, int k, int o, int nin, int nout, const float *const *x, long ldx, const float *const *w, int transpose_w,
                    const float *const *bias, const float *scale, const float *shift, int relu, float *const *y, long ldy,
                    int accumulate, float *partial, hipStream_t s, const float *roww, long rws, const float *bx, long ldb, const float *bcoef,
-                   int brelu, int *partial_rows, long ldw) {
+                   int brelu, int *partial_rows, long ldw, void *handoff) {
     if (nin < 1 || nout < 1 || (nin > 1 && nout > 1) || nin > 3 || nout > 3) return 0;
     if (nin == 2 && (scale || bx)) return 0;   // (the two-window form: plain product only)
     if (partial && !bx && (nin != 1 || nout != 1)) return 0;
@@ -509,6 +512,8 @@ int try_forward_mp(long n, int k, int o, int nin, int nout, const float *const *
     a.N = n; a.O = o; a.ldx = ldx; a.ldy = ldy; a.scale = scale; a.shift = shift; a.relu = relu; a.accumulate = accumulate;
     a.partial = partial; a.roww = roww; a.rws = rws;
     a.bx = bx; a.ldb = ldb; a.bcoef = bcoef; a.brelu = brelu;
+    a.ho_gran = static_cast<unsigned long long *>(handoff);
+    a.ho_sync = handoff ? reinterpret_cast<unsigned *>(a.ho_gran + 2 * (size_t)o) : nullptr;
     a.wso = transpose_w ? 1 : (ldw ? ldw : k); a.wsk = transpose_w ? o : 1;   // ldw: row stride of an (o, k) window of a wider weight matrix
     for (int i = 0; i < 3; ++i) {
         a.X[i] = i < nin ? x[i] : nullptr;

@@ -285,12 +285,20 @@ __global__ __launch_bounds__(64 * WPB) void k_td_din(int M, int cout, const floa
 // The product is sparse (one arg-max neighbour per (m, c): ~cout / 16 channels hit per entry), so the dense MFMA form would spend
 // 15/16 of its work on zeros: one wave = one source point, lanes = the 64 channels of a chunk for the hit test (ballot), then lanes =
 // features for the few hit rows of W.  Every element of gx is owned by one lane: plain read-modify-write, fixed order.
-template <int CIN>
+// WLDS (cin <= 64: the feature part of W is <= 32 KB): the hit loop reads its W rows from an LDS copy -- every hit is a DEPENDENT load
+// (ballot -> row address), ~16 of them per source point at level 1; from L2 that chain was most of the kernel (SQ counters, round 4:
+// 83 % of the wave cycles parked in s_waitcnt, 201 us at 200k source points).
+template <int CIN, bool WLDS>
 __global__ __launch_bounds__(64 * WPB) void k_td_din_dst(int n, int cout, const float *__restrict__ gout, const float *__restrict__ out,
                                                          const unsigned char *__restrict__ arg, const float *__restrict__ W,
                                                          const float *__restrict__ coef, const int *__restrict__ inv_off,
                                                          const int *__restrict__ inv_entry, int entry_base, float *__restrict__ gx) {
     constexpr int NQ = (CIN + 63) / 64, D = 3 + CIN;
+    extern __shared__ __attribute__((aligned(16))) float wlds[];   // [cout][CIN] (WLDS)
+    if (WLDS) {
+        for (int e = threadIdx.x; e < cout * CIN; e += 64 * WPB) wlds[e] = W[(size_t)(e / CIN) * D + 3 + e % CIN];
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long wave_g = (long)blockIdx.x * WPB + wv, nwaves = (long)gridDim.x * WPB;
     for (long v = wave_g; v < n; v += nwaves) {
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(64 * WPB) void k_td_din_dst(int n, int cout, const 
                         const int b = __ffsll((long long)mask) - 1;
                         mask &= mask - 1;
                         const float sv = __shfl(val, b, 64);
-                        const float *wrow = W + (size_t)(cb + b) * D + 3;
+                        const float *wrow = WLDS ? wlds + (cb + b) * CIN : W + (size_t)(cb + b) * D + 3;
 #pragma unroll
                         for (int q = 0; q < NQ; ++q)
                             if (lane + 64 * q < CIN) acc[q] += sv * wrow[lane + 64 * q];
@@ -547,8 +555,12 @@ extern "C" int pdf_td_backward(long n, long m, int cin, int cout, void *const *p
     if (p[17] && p[18]) {
         const int *inv_off = (const int *)p[17], *inv_entry = (const int *)p[18];
         const int g = td::grid_points(n, 2048);
-#define PDF_TD_DST(CIN_) td::k_td_din_dst<CIN_><<<g, 64 * td::WPB, 0, s>>>((int)n, cout, gout, out, arg, W, coef, inv_off, inv_entry, entry_base, gx)
-        if (cin == 32) PDF_TD_DST(32); else if (cin == 64) PDF_TD_DST(64); else if (cin == 128) PDF_TD_DST(128); else PDF_TD_DST(256);
+#define PDF_TD_DST(CIN_, WLDS_) td::k_td_din_dst<CIN_, WLDS_><<<g, 64 * td::WPB, WLDS_ ? sizeof(float) * (size_t)cout * CIN_ : 0, s>>>( \
+            (int)n, cout, gout, out, arg, W, coef, inv_off, inv_entry, entry_base, gx)
+        const bool wlds = (size_t)cout * cin * sizeof(float) <= 48 * 1024;   // (the model's cout = 2 cin: 8 KB / 32 KB at cin = 32 / 64)
+        if (cin == 32) { if (wlds) PDF_TD_DST(32, true); else PDF_TD_DST(32, false); }
+        else if (cin == 64) { if (wlds) PDF_TD_DST(64, true); else PDF_TD_DST(64, false); }
+        else if (cin == 128) PDF_TD_DST(128, false); else PDF_TD_DST(256, false);
 #undef PDF_TD_DST
     } else {
         const dim3 grid(td::grid_points(m, 1024), cout / 64);

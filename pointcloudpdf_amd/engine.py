@@ -226,12 +226,14 @@ class GroupedGeometryLoader:
     gets exactly one full pre-pass; nothing is cached across batches.  Two batches of look-ahead already clear 5 M points/s on
     2 x 100k-point batches; the default (12) also amortises the kNN launches.
 
-    Timing owned here (none of it is the caller's business): the next group is pulled from the wrapped loader and its pre-pass
-    submitted right after the consumer came back for batch ``submit_delay`` of the current group -- i.e. AFTER that many training steps
-    of the group were enqueued, so the ~10 ms of host work of a submission never sits in front of a step -- and the pre-pass waits
-    only for the batch tensors (an event recorded when they were moved), not for the steps queued since.
+    Timing owned here (none of it is the caller's business): the next group's batches are pulled from the wrapped loader -- and their
+    host-to-device transfers started on a copy stream -- when the current group is entered; its pre-pass is submitted once the consumer
+    came back for batch ``submit_delay`` of the current group, i.e. AFTER that many training steps were enqueued (the ~10 ms of host
+    work of a submission never sits in front of a step), and waits only for the batch tensors (an event recorded when they were
+    pulled), not for the steps queued since.
     ``first_group``: size of the first group only (default ``group``): a short first group gets the first batch out sooner.
-    The wrapped loader should have its batches ready when a group is pulled (``DataLoader(prefetch_factor >= group / num_workers)``).
+    The wrapped loader should have a group's batches ready when it is pulled, one group ahead of use
+    (``DataLoader(num_workers=w, prefetch_factor >= 2 * group / w)``).
     """
 
     MAX_SCENES = 64   # scenes per grouped kNN / FPS call (workspace layout of the grid kNN)
@@ -249,20 +251,30 @@ class GroupedGeometryLoader:
         self.device = torch.device(device) if device is not None else None
         self.submit_delay = max(int(submit_delay), 0)
         self.prefetcher = prefetcher if prefetcher is not None else (GeometryPrefetcher(depth=2, threaded=threaded, **plan) if self.group > 0 else None)
+        self.inline = None
+        if self.group == 0 and prefetcher is None and key == "pdf_geometry" and torch.cuda.is_available():
+            from .geometry import Geometry
+            self.inline = lambda b: Geometry(b["coord"], b["offset"], b["offset_host"]).precompute(**plan)
         self.submit_host_s = []   # host time of every group submission (diagnostics)
+        self._held, self._copy_stream = None, None
 
     def __len__(self):
         return len(self.loader)
 
     def _to_device(self, batch):
+        """engines/train.py:373-376 (every tensor of the input dict moves to the device), on a copy stream of its own: the transfers of
+        an upcoming group must not queue behind -- or in front of -- the training steps on the consumer's stream."""
         dev = self.device
-        if dev is None:
-            return batch
+        if dev is None or not any(torch.is_tensor(v) and v.device != dev for v in batch.values()):
+            return batch, False
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=dev)
         out = dict(batch)
-        for k, v in batch.items():   # engines/train.py:373-376: every tensor of the input dict moves to the device
-            if torch.is_tensor(v) and v.device != dev:
-                out[k] = v.to(dev, non_blocking=True)
-        return out
+        with torch.cuda.stream(self._copy_stream):
+            for k, v in batch.items():
+                if torch.is_tensor(v) and v.device != dev:
+                    out[k] = v.to(dev, non_blocking=True)
+        return out, True
 
     @staticmethod
     def _with_host_offset(batch):
@@ -272,11 +284,12 @@ class GroupedGeometryLoader:
         return batch
 
     def _pull(self, it, n):
-        """Up to ``n`` batches (fewer at the end of the epoch, or when the scene budget of one grouped call is reached) -> list | None."""
-        got, scenes = [], 0
+        """Up to ``n`` batches (fewer at the end of the epoch, or when the scene budget of one grouped call is reached), moved to the
+        device -> (batches, ready event | None) or None.  ``ready`` is recorded NOW: on the copy stream when tensors were moved, else on
+        the consumer's stream as it stands -- a pre-pass submitted later waits for this point, not for the steps queued in between."""
+        got, scenes, moved = [], 0, False
         while len(got) < n:
-            held = getattr(self, "_held", None)
-            self._held = None
+            held, self._held = self._held, None
             if held is None:
                 try:
                     held = self._with_host_offset(next(it))
@@ -286,45 +299,61 @@ class GroupedGeometryLoader:
             if got and scenes + k > self.MAX_SCENES:
                 self._held = held
                 break
-            got.append(self._to_device(held))
-            scenes += k
-        return got or None
-
-    def _submit(self, batches):
-        import time
-
-        t0 = time.perf_counter()
+            b, m = self._to_device(held)
+            got.append(b)
+            moved, scenes = moved or m, scenes + k
+        if not got:
+            return None
         ready = None
         if torch.cuda.is_available():
             ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream())   # the batch tensors are complete HERE; steps queued later do not delay the pre-pass
+            ready.record(self._copy_stream if moved else torch.cuda.current_stream())
+        return got, ready, moved
+
+    def _submit(self, pulled):
+        import time
+
+        batches, ready, moved = pulled
+        t0 = time.perf_counter()
         tickets = self.prefetcher.submit_group(batches, ready=ready)
         self.submit_host_s.append(time.perf_counter() - t0)
-        return list(zip(batches, tickets))
+        return [(b, t, ready if moved else None) for b, t in zip(batches, tickets)]
 
     def __iter__(self):
         it = iter(self.loader)
-        self._held = None
-        if self.group == 0:   # no look-ahead: the model computes the tables inline (serial step)
+        self._held, self._copy_stream = None, None
+        if self.group == 0:   # no look-ahead: the same pre-pass, per batch, inline on the consumer's stream (the serial step)
             for batch in it:
-                yield self._to_device(self._with_host_offset(batch))
+                b, moved = self._to_device(self._with_host_offset(batch))
+                if moved:
+                    torch.cuda.current_stream().wait_stream(self._copy_stream)
+                if self.inline is not None:
+                    b = dict(b)
+                    b[self.key] = self.inline(b)
+                yield b
             return
         first = self._pull(it, self.first_group)
         if first is None:
             return
-        current, upcoming, exhausted = self._submit(first), None, False
+        current, pulled, upcoming, exhausted = self._submit(first), None, None, False
         while current is not None:
             delay = min(self.submit_delay, len(current) - 1)
-            for j, (batch, ticket) in enumerate(current):
-                if j == delay and upcoming is None and not exhausted:   # (we are back for batch j: j steps of this group are enqueued)
-                    nxt = self._pull(it, self.group)
-                    if nxt is None:
-                        exhausted = True
-                    else:
-                        upcoming = self._submit(nxt)
+            for j, (batch, ticket, copied) in enumerate(current):
+                # The NEXT group: its batches are pulled (and their transfers started) when this group is entered -- BEFORE any of its steps
+                # is enqueued, so that the pre-pass depends on nothing that trains -- and its pre-pass is submitted once we are back for
+                # batch `delay` of this group, i.e. after that many steps were enqueued (the submission's host work never sits in front of them).
+                if j == 0 and not exhausted:
+                    pulled = self._pull(it, self.group)
+                    exhausted = pulled is None
+                if j == delay and pulled is not None:
+                    upcoming, pulled = self._submit(pulled), None
+                if copied is not None:
+                    torch.cuda.current_stream().wait_event(copied)   # the batch's own tensors (moved on the copy stream)
                 batch = dict(batch)
                 batch[self.key] = self.prefetcher.get(ticket)   # consumer stream waits for the pre-pass (stream-ordered)
                 yield batch
+            if pulled is not None:   # (a group shorter than the delay)
+                upcoming, pulled = self._submit(pulled), None
             current, upcoming = upcoming, None
 
 

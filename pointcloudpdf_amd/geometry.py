@@ -152,12 +152,22 @@ class Geometry:
         of the queries in the forward gathers (csrc/gather_ops.hip); nothing is stored in this order."""
         key = ("order", level)
         if key not in self._memo:
-            p = self.levels[level].p
-            # (bounding box from the TRANSPOSED coordinates: three contiguous rows reduce in ~10 us, the column reduction of an (N, 3)
-            #  tensor takes torch 0.2-1.4 ms at N = 0.2-2.4 M -- 0.4 ms of side-stream GPU time per step in round 3's trace)
-            lo, hi = torch.aminmax(p.t().contiguous(), dim=1)
-            cell = torch.clamp((hi - lo).max() / 1023.0, min=1e-9)
-            q = ((p - lo) / cell).long().clamp_(0, 1023)
+            L = self.levels[level]
+            p = L.p
+            # Quantisation grid PER SCENE (its own bounding box): the order of a scene's points is then a function of that scene alone, so a
+            # batch gets the same visiting order -- and with it the same rounding of every per-workgroup partial sum -- whether its
+            # pre-pass ran alone or as part of a group (round 3 quantised over the bounding box of everything in the call).
+            be = _native.backend_for(p)
+            if hasattr(be, "scene_morton_keys"):   # two launches (csrc/geom_moments.hip) instead of ~20 elementwise torch ops
+                self._memo[key] = torch.argsort(be.scene_morton_keys(p, L.o), stable=True).to(torch.int32)
+                return self._memo[key]
+            b = len(L.o_host)
+            scene = torch.repeat_interleave(torch.arange(b, device=p.device), self.sizes(level), output_size=p.shape[0])
+            sidx = scene.unsqueeze(1).expand(-1, 3)
+            lo = torch.full((b, 3), float("inf"), dtype=p.dtype, device=p.device).scatter_reduce_(0, sidx, p, "amin", include_self=True)
+            hi = torch.full((b, 3), float("-inf"), dtype=p.dtype, device=p.device).scatter_reduce_(0, sidx, p, "amax", include_self=True)
+            cell = torch.clamp((hi - lo).amax(dim=1) / 1023.0, min=1e-9)
+            q = ((p - lo[scene]) / cell[scene].unsqueeze(1)).long().clamp_(0, 1023)
 
             def spread(v):   # 10 bits -> every third bit
                 v = (v | (v << 16)) & 0x030000FF
@@ -166,8 +176,6 @@ class Geometry:
                 return (v | (v << 2)) & 0x09249249
 
             code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
-            scene = torch.repeat_interleave(torch.arange(len(self.levels[level].o_host), device=p.device), self.sizes(level),
-                                            output_size=p.shape[0])
             self._memo[key] = torch.argsort(code + (scene << 30), stable=True).to(torch.int32)
         return self._memo[key]
 
