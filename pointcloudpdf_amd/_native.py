@@ -102,6 +102,32 @@ def raw_stream():
     return _RAW_STREAM(dev) if _RAW_STREAM is not None else torch.cuda.current_stream().cuda_stream
 
 
+def cu_masked_stream(first_cu, n_cus, device=None):
+    """A torch stream whose kernels run only on ``n_cus`` compute units starting at logical CU ``first_cu`` (hipExtStreamCreateWithCUMask).
+    MI355X numbering, measured with tools/probes/cu_mask_probe.hip: mask bit i = CU (i // 8) of XCD (i % 8) -- consecutive bits go round
+    the eight XCDs, so [first_cu, first_cu + n_cus) with both multiples of 8 takes the same CUs out of every XCD (a mask that leaves an XCD
+    without any CU is not honoured: that XCD then runs on all of its CUs).  The stream is a BLOCKING stream in HIP's sense (the call has no
+    flags): it synchronises implicitly with the legacy default stream, so nothing of a loop that uses it may run on that stream
+    (engine.TrainStep(stream=...) keeps the whole step on its own stream).  The handle lives as long as the process."""
+    if first_cu % 8 or n_cus % 8 or n_cus < 8:
+        raise PdfOpsError("cu_masked_stream: first_cu and n_cus must be multiples of 8 (one CU of every XCD per step of 8)")
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    total = torch.cuda.get_device_properties(dev).multi_processor_count
+    if first_cu + n_cus > total:
+        raise PdfOpsError(f"cu_masked_stream: CUs [{first_cu}, {first_cu + n_cus}) of {total}")
+    hip = ctypes.CDLL("libamdhip64.so")
+    words = (total + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    for cu in range(first_cu, first_cu + n_cus):
+        mask[cu // 32] |= 1 << (cu % 32)
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), ctypes.c_uint32(words), mask)
+    if rc != 0:
+        raise PdfOpsError(f"hipExtStreamCreateWithCUMask failed with status {rc}")
+    return torch.cuda.ExternalStream(handle.value, device=torch.device("cuda", dev))
+
+
 def require_current_device(*tensors):
     """Every launch goes onto torch's current stream of the CURRENT device (the reference relies on
     ``torch.cuda.set_device(local_rank)`` the same way, engines/launch.py:131).  A tensor that lives on another GPU would be

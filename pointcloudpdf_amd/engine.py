@@ -104,8 +104,9 @@ class CapturedStep:
 
     KEYS = ("coord", "feat", "offset", "segment")
 
-    def __init__(self, step, batch, geom=None, warmup=2, autocast=None, loss_scale=1.0):
-        """``autocast``: torch.float16 / torch.bfloat16 -> the forward is captured under torch.autocast (the path then runs its
+    def __init__(self, step, batch, geom=None, warmup=2, autocast=None, loss_scale=1.0, stream=None):
+        """``stream``: the stream to capture on (default: a new one) -- e.g. a CU-masked stream (``_native.cu_masked_stream``), see TrainStep.
+        ``autocast``: torch.float16 / torch.bfloat16 -> the forward is captured under torch.autocast (the path then runs its
         reduced-precision products, dense.fp32_path).  ``loss_scale``: a ``DeviceGradScaler`` (the reference's AMP loop,
         engines/train.py:343-355: the captured backward starts from ``loss * scale`` with the scale read from DEVICE memory at replay time,
         and the gradients stay scaled until ``scaler.step(optimizer)`` / ``scaler.unscale_(optimizer)`` outside the graph -- after the
@@ -132,7 +133,7 @@ class CapturedStep:
         buffers = [b for b in step.buffers()]
         saved = [b.detach().clone() for b in buffers]
         release_autograd_state(step)
-        side = torch.cuda.Stream(device=dev)
+        side = stream if stream is not None else torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(max(int(warmup), 1)):   # lazily created handles / caches must exist before the capture
@@ -369,9 +370,15 @@ class TrainStep:
             out = train_step(batch)       # dict(loss, model_loss, recognizer_loss, score)
     """
 
-    def __init__(self, step, optimizer, exchange=None, scaler=None, autocast=None, graph=True, force_exchange=False, loss_scale=1.0, module=None):
+    def __init__(self, step, optimizer, exchange=None, scaler=None, autocast=None, graph=True, force_exchange=False, loss_scale=1.0, module=None,
+                 stream=None):
         """``module``: what the eager forward calls (a torch DistributedDataParallel wrapper of ``step``; default ``step`` itself);
-        ``loss_scale``: static loss scale when no ``scaler`` is given (A/B runs; no overflow check)."""
+        ``loss_scale``: static loss scale when no ``scaler`` is given (A/B runs; no overflow check).
+        ``stream``: run EVERYTHING of the step (replay / eager issue, gradient exchange, optimizer) on this stream instead of the caller's
+        current one -- with ``_native.cu_masked_stream`` the training stream and the coordinate pre-pass get disjoint compute units
+        (``partition_compute_units``): the farthest-point chain (24 workgroups, ~20 ms per launch) next to the training kernels
+        cost every one of them a straggler tail (+2.3 ms per step beside it at full duty, tools/contention_probe.py)."""
+        self.stream = stream
         self.step, self.optimizer, self.exchange, self.scaler, self.autocast = step, optimizer, exchange, scaler, autocast
         self.module = module if module is not None else step
         self.graph, self.captured, self.capture_error = bool(graph), None, None
@@ -380,7 +387,7 @@ class TrainStep:
 
     def capture(self, batch, geom=None):
         self.captured = CapturedStep(self.step, batch, geom=geom, autocast=self.autocast,
-                                     loss_scale=self.scaler if self.scaler is not None else self.loss_scale)
+                                     loss_scale=self.scaler if self.scaler is not None else self.loss_scale, stream=self.stream)
         return self.captured
 
     def drop_capture(self):
@@ -420,6 +427,15 @@ class TrainStep:
         return out
 
     def __call__(self, batch, eager=False):
+        if self.stream is None:
+            return self._run(batch, eager)
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)             # (the batch's tensors / tables were handed over on the caller's stream)
+        with torch.cuda.stream(self.stream):
+            out = self._run(batch, eager)
+        return out                               # (the caller's stream does NOT wait: results are consumed on self.stream or after a sync)
+
+    def _run(self, batch, eager=False):
         geom = batch.get("pdf_geometry")
         if self.graph and self.captured is None and self.capture_error is None and not eager:
             try:
