@@ -213,7 +213,9 @@ int pdf_pt_layer_backward(int n, int nsample, int c, const float *xq, const floa
                           const float *p, const int *idx, const float *const *weights, const float *bn,
                           const float *saved, const float *H, const float *gout, float *gxq, float *gxk,
                           float *gxv, float *G2, float *G3, float *Wsm, float *GR, const int *inv_off, const int *inv_entry,
-                          int entry_base, float *partial, float *sums, int storage_bf16, const int *order, void *stream);
+                          int entry_base, float *partial, float *sums, int storage_bf16, const int *order, const double *moments,
+                          void *stream);   /* moments: the batch's relative-coordinate sums (pdf_knn_rel_moments) or NULL: with them d Wp1 / d bp1 come in
+                                              closed form from the sums of the third pass (no fourth pass over the rows) */
 
 /* BatchNorm1d over (n, c) rows fused with the residual add and ReLU that follow it in the Bottleneck
  * (point_transformer_seg.py:184-192).  c must be a power of two in 4..1024.  coef (4c floats) = scale|shift|mean|rstd,

@@ -664,7 +664,7 @@ class HipBackend(CBackend):
         lib.pdf_pt_layer_forward.restype = c_int
         lib.pdf_pt_layer_forward.argtypes = [c_int, c_int, c_int] + [c_void_p] * 8 + [c_int, ctypes.c_float, ctypes.c_float] + [c_void_p] * 5 + [c_int, c_void_p, c_void_p]
         lib.pdf_pt_layer_backward.restype = c_int
-        lib.pdf_pt_layer_backward.argtypes = [c_int, c_int, c_int] + [c_void_p] * 19 + [c_int] + [c_void_p] * 2 + [c_int, c_void_p, c_void_p]
+        lib.pdf_pt_layer_backward.argtypes = [c_int, c_int, c_int] + [c_void_p] * 19 + [c_int] + [c_void_p] * 2 + [c_int, c_void_p, c_void_p, c_void_p]
         self.fps_mode = os.environ.get("PDFOPS_FPS", "bucketed")  # "bucketed" | "plain"
         self.knn_mode = os.environ.get("PDFOPS_KNN", "grid")      # "grid" | "scan"
         lib.pdf_knn_workspace_bytes.restype = c_long
@@ -928,7 +928,7 @@ class HipBackend(CBackend):
             self._ptr(gxq), self._ptr(gxk), self._ptr(gxv), self._ptr(G2), self._ptr(G3), self._ptr(Wsm), self._ptr(GR),
             self._ptr(inv_off), self._ptr(inv_entry), int(entry_base), self._ptr(partial),
             self._ptr(sums), self.layer_flags(self.storage_bf16 if storage_bf16 is None else storage_bf16), self._order_ptr(idx),
-            c_void_p(raw_stream()))
+            self._moments_ptr(idx), c_void_p(raw_stream()))
         if rc != 0:
             raise PdfOpsError(f"pdf_pt_layer_backward failed with status {rc}")
         # unpack the parameter-gradient sections (layout: csrc/fused_layer.hip, pdf_pt_layer_backward)

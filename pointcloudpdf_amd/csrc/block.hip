@@ -211,7 +211,7 @@ extern "C" int pdf_bottleneck_forward(long n, int nsample, int c, void *const *p
 //            40 partial (max of pdf_bn_partial_floats, pdf_rowlin_partial_floats, pdf_pt_layer_bwd_partial_floats)
 //            41 Wsm (n*nsample*c/8) 42 GR (n*nsample*c) | inverse kNN table: 43 inv_off (n+1) 44 inv_entry, entry_base
 //            45 dy (n*c; separate from 34: the forked dW3 kernel may still be reading `da` when the pre half starts)
-//   46-48: unused (rounds 2-3: handles of a second stream for the weight-gradient kernels -- measured slower, removed)
+//   46: the batch's relative-coordinate sums of the kNN table (9 doubles, pdf_knn_rel_moments) or null | 47-48: unused
 //             49 visiting order of the points (or null)
 //   50 workspace of the weight-gradient slabs: max(pdf_rowlin_wgrad_ws_floats(n, c, c, 5), pdf_rowlin_wgrad_ws_floats(n, c, c, 3) +
 //      pdf_rowlin_wgrad_ws_floats(n, c, c, 1)) floats (grouped launch / one product at a time)
@@ -234,7 +234,7 @@ extern "C" int pdf_bottleneck_backward(long n, int nsample, int c, void *const *
                                (const int *)p[9], weights, (const float *)p[18], (const float *)p[19], (const float *)p[20],
                                (const float *)p[33], (float *)p[35], (float *)p[36], (float *)p[37], (float *)p[38], (float *)p[39],
                                (float *)p[41], (float *)p[42], (const int *)p[43], (const int *)p[44], entry_base,
-                               (float *)p[40], (float *)p[32], storage_bf16, (const int *)p[49], stream);
+                               (float *)p[40], (float *)p[32], storage_bf16, (const int *)p[49], (const double *)p[46], stream);
     void *pre[15] = {p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[35], p[36], p[37], p[29], p[30], p[45], p[40], ws_pre};
     e << block_pre_backward(n, c, pre, training, 1, mma_input, stream, group);   // gx += dy W1 on top of the identity branch
     if (group && e.rc == 0) {

@@ -461,8 +461,10 @@ __device__ __forceinline__ float dot_aux_tile(const WaveLds &L, int a, int b) {
 template <int C> constexpr int b1_width() { return 3 * (C / 8) + (C / 8) * (C / 8); }
 // ---- B2: [sum g_y1 (C) | sum g_y1*rhat (C) | g_bw1 (CS) | g_Ww1 (CS*C)]
 template <int C> constexpr int b2_width() { return 2 * C + C / 8 + (C / 8) * C; }
-// ---- B3: [sum g_yp (3) | sum g_yp*that (3) | pad 2 | g_bp2 (C) | g_Wp2 (C*3)]
+// ---- B3: [sum g_yp (3) | sum g_yp*that (3) | pad 2 | g_bp2 (C) | g_Wp2 (C*3)]; the PARTIAL rows carry 16 more columns
+//      [sum g_yp[a] * rel[b] (9) | pad 7] for the closed-form BNp backward (k_colsum_b3)
 template <int C> constexpr int b3_width() { return 8 + C + 3 * C; }
+template <int C> constexpr int b3_pwidth() { return b3_width<C>() + 16; }
 // ---- B4: [g_bp1 (3) | g_Wp1 (9) | pad 4]
 constexpr int b4_width() { return 16; }
 
@@ -690,14 +692,16 @@ __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
 template <int C, int K>
 __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int NCH = C / 32, PPT = 64 / K, CS = C / 8, W = b3_width<C>();
+    constexpr int NCH = C / 32, PPT = 64 / K, CS = C / 8, W = b3_pwidth<C>();
     const int lane = threadIdx.x & 63;
     const WaveLds L = carve_lds<true, C>(lds, threadIdx.x >> 6);
     const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
     const long ntiles = ((long)A.N * K + 63) / 64;
     cfloat_p m1 = A.mean + 3, r1 = A.rstd + 3, mp = A.mean, rp = A.rstd;
     cfloat_p sum_gy1 = A.sums, sum_gy1r = A.sums + C;  // column sums of B2 (A.sums points at B2's result here)
-    float sgp[3] = {0.f, 0.f, 0.f}, sgpt[3] = {0.f, 0.f, 0.f}, sbp2[NCH], awp2[NCH][2];
+    float sgp[3] = {0.f, 0.f, 0.f}, sgpt[3] = {0.f, 0.f, 0.f}, sbp2[NCH], awp2[NCH][2], sgr[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) sgr[e] = 0.f;
 #pragma unroll
     for (int q = 0; q < NCH; ++q) { sbp2[q] = 0.f; awp2[q][0] = 0.f; awp2[q][1] = 0.f; }
     for (long tile = wave_g; tile < ntiles; tile += nwaves) {
@@ -790,6 +794,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
             gyp[a] = (R.valid && t1n[a] > 0.f) ? gt1n[a] : 0.f;
             sgp[a] += gyp[a];
             sgpt[a] += gyp[a] * ((R.t1[a] - mp[a]) * rp[a]);
+            sgr[3 * a + 0] += gyp[a] * R.rel[0]; sgr[3 * a + 1] += gyp[a] * R.rel[1]; sgr[3 * a + 2] += gyp[a] * R.rel[2];
         }
         if (R.valid) {
             float *dst = A.G3 + (size_t)R.row * 3;
@@ -813,6 +818,12 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
                 if (e < 96) o[8 + C + (size_t)q * 96 + e] = awp2[q][m];  // == [(q*32 + c)*3 + a]
             }
         }
+#pragma unroll
+        for (int e = 0; e < 9; ++e) {
+            const float x = pdf_wave_sum_f32(sgr[e]);
+            if (lane == 0) o[b3_width<C>() + e] = x;
+        }
+        if (lane == 0) { for (int e = 9; e < 16; ++e) o[b3_width<C>() + e] = 0.f; }
     };
     if constexpr (W <= lds_floats_per_wave(C, true)) block_row(lds, W, emit); else block_row_seq(lds, emit);   // (WPB rows fit the tiles' LDS?)
     store_row(lds, W, A.partial + (size_t)blockIdx.x * W);
@@ -879,11 +890,62 @@ __device__ __forceinline__ double wave_rows_sum(double v) {
 }
 constexpr int RED_WAVES = RED_THREADS / 64;
 
-__global__ __launch_bounds__(RED_THREADS) void k_colsum(const float *__restrict__ partial, int rows, int width, float *__restrict__ out) {
+// Closed-form backward of the geometry branch's BatchNorm + Linear(3, 3) (point_transformer_seg.py:27-29 differentiated): the extra block
+// of k_colsum's launch over B3's rows.  With the row sums  s_a = sum g_yp[a],  u_a = sum g_yp[a] that[a],  G_ab = sum g_yp[a] rel[b]  (B3),
+// the coordinate sums S, M of the kNN table (geom_moments.hip; R = all (point, neighbour) rows) and the saved BNp statistics:
+//     g_t1[a] = sp_a (g_yp[a] - s_a / R - that[a] u_a / R)                      (BatchNorm backward per row)
+//     d Wp1[a][b] = sum g_t1[a] rel[b] = sp_a (G_ab - s_a S_b / R - u_a T_ab / R),   T_ab = sum that[a] rel[b] = rstd_a (sum_c Wp1[a][c] M_cb + (bp1_a - mean_a) S_b)
+//     d bp1[a]    = sum g_t1[a]        = sp_a (- u_a / R) sum that[a],               sum that[a] = rstd_a (sum_c Wp1[a][c] S_c + R (bp1_a - mean_a))
+// -- what fl::k_b4 + its column sum computed with one more pass over all rows (2 launches per layer; rounds 1-3).  out4: [d bp1 (3) | d Wp1 (9) | 0 x 4].
+struct BnpClosed {
+    const double *mom;            // [S (3) | Mxx Mxy Mxz Myy Myz Mzz]; nullptr: no closed form (the caller runs B4)
+    cfloat_p Wp1, bp1, sp, mean, rstd;
+    double rows;
+    int col_g;                    // first column of G in the partial rows
+    float *out4;
+};
+__global__ __launch_bounds__(RED_THREADS) void k_colsum(const float *__restrict__ partial, int rows, int width, int stride, float *__restrict__ out,
+                                                        BnpClosed bc) {
     __shared__ double red[RED_WAVES][17];
+    if (blockIdx.x * 16 >= (unsigned)width) {   // the closed-form block (one past the column blocks; only launched with bc.mom)
+        __shared__ double col[16];
+        // 15 columns: s (0..2), u (3..5), G (col_g .. col_g + 8): lane = (column, row-lane) as below, one pass
+        const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+        const int c = cl < 6 ? cl : bc.col_g + (cl - 6);
+        const double v = wave_rows_sum(cl < 15 ? strided_sum(partial + c, (size_t)stride, rl, rows) : 0.0);
+        if ((threadIdx.x & 63) < 16) red[threadIdx.x >> 6][cl] = v;
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < RED_WAVES; ++k) s += red[k][threadIdx.x];
+            col[threadIdx.x] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < 12) {
+            const double S[3] = {bc.mom[0], bc.mom[1], bc.mom[2]};
+            const double M[3][3] = {{bc.mom[3], bc.mom[4], bc.mom[5]}, {bc.mom[4], bc.mom[6], bc.mom[7]}, {bc.mom[5], bc.mom[7], bc.mom[8]}};
+            const int a = threadIdx.x < 3 ? (int)threadIdx.x : ((int)threadIdx.x - 3) / 3, b = threadIdx.x < 3 ? 0 : ((int)threadIdx.x - 3) % 3;
+            const double w[3] = {(double)bc.Wp1[a * 3], (double)bc.Wp1[a * 3 + 1], (double)bc.Wp1[a * 3 + 2]};
+            const double d = (double)bc.bp1[a] - (double)bc.mean[a], rs = (double)bc.rstd[a], sp = (double)bc.sp[a], R = bc.rows;
+            const double s_a = col[a], u_a = col[3 + a];
+            double r;
+            if (threadIdx.x < 3) {
+                const double sum_that = rs * (w[0] * S[0] + w[1] * S[1] + w[2] * S[2] + R * d);
+                r = sp * (-(u_a / R) * sum_that);
+            } else {
+                const double T = rs * (w[0] * M[0][b] + w[1] * M[1][b] + w[2] * M[2][b] + d * S[b]);
+                r = sp * (col[6 + 3 * a + b] - s_a * S[b] / R - u_a * T / R);
+            }
+            bc.out4[threadIdx.x] = (float)r;
+        } else if (threadIdx.x < 16) {
+            bc.out4[threadIdx.x] = 0.f;
+        }
+        return;
+    }
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int col = blockIdx.x * 16 + cl;
-    const double v = wave_rows_sum(col < width ? strided_sum(partial + col, (size_t)width, rl, rows) : 0.0);
+    const double v = wave_rows_sum(col < width ? strided_sum(partial + col, (size_t)stride, rl, rows) : 0.0);
     if ((threadIdx.x & 63) < 16) red[threadIdx.x >> 6][cl] = v;
     __syncthreads();
     if (rl != 0 || col >= width) return;
@@ -954,7 +1016,10 @@ void launch_bn_eval(int nch, const float *gamma, const float *beta, float eps, c
     k_bn_eval<<<pdf_divup(nch, 64), 64, 0, s>>>(nch, gamma, beta, eps, running_mean, running_var, scale, shift, mean_out, rstd_out);
 }
 void launch_colsum(const float *partial, int rows, int width, float *out, hipStream_t s) {
-    k_colsum<<<pdf_divup(width, 16), RED_THREADS, 0, s>>>(partial, rows, width, out);
+    BnpClosed none;
+    none.mom = nullptr; none.out4 = nullptr; none.rows = 0.0; none.col_g = 0;
+    none.Wp1 = none.bp1 = none.sp = none.mean = none.rstd = as_const(nullptr);
+    k_colsum<<<pdf_divup(width, 16), RED_THREADS, 0, s>>>(partial, rows, width, width, out, none);
 }
 
 template <typename KernelT>
@@ -1104,25 +1169,40 @@ int backward_impl(LayerArgs A, float *sums, const int *inv_off, const int *inv_e
     // (the scratch is sized for B2's rows at `grid`; B1 / B3 rows are shorter, so more waves fit)
     int g1 = mfma ? pass_grid(B1, A.N, grid) : grid, g3 = mfma ? pass_grid(B3, A.N, C == 256 ? 2 * grid : (C == 64 ? 4 * grid : grid)) : grid;
     g1 = (int)std::min<long>(g1, (long)grid * b2_width<C>() / b1_width<C>());
-    g3 = (int)std::min<long>(g3, (long)grid * b2_width<C>() / b3_width<C>());
+    g3 = (int)std::min<long>(g3, (long)grid * b2_width<C>() / b3_pwidth<C>());
+    BnpClosed none;
+    none.mom = nullptr; none.out4 = nullptr; none.rows = 0.0; none.col_g = 0;
+    none.Wp1 = none.bp1 = none.sp = none.mean = none.rstd = as_const(nullptr);
     if (mfma) flm::launch_b1(A, C, g1, s); else k_b1<C, K><<<grid, 64 * WPB, lds, s>>>(A);
-    k_colsum<<<pdf_divup(b1_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, g1, b1_width<C>(), S1);
+    k_colsum<<<pdf_divup(b1_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, g1, b1_width<C>(), b1_width<C>(), S1, none);
     // g_xv[nb, c] = sum over the entries (i, j) with idx[i, j] == nb of g_out[i, c] * w[i, j, c mod C/8]   (no atomics, fixed order)
     int rc = pdf_seg_sum_weighted_x(A.N, C, K, CS, A.gout, A.Wsm, A.bf16, inv_off, inv_entry, entry_base, gather_order, A.gxv, s);   // (destinations in Morton order: the g_out rows they share hit L2)
     if (rc != PDF_OK) return rc;
     A.sums = as_const(S1);
     const int g2 = mfma ? std::min(grid, pass_grid(B2, A.N, C == 512 ? 32 : (C == 256 ? 128 : grid))) : grid;
     if (mfma) flm::launch_b2(A, C, g2, s); else k_b2<C, K><<<grid, 64 * WPB, lds, s>>>(A);
-    k_colsum<<<pdf_divup(b2_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, g2, b2_width<C>(), S2);
+    k_colsum<<<pdf_divup(b2_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, g2, b2_width<C>(), b2_width<C>(), S2, none);
     A.sums = as_const(S2);   // B3: BN1-backward terms from B2, BN2-backward terms from B1
     A.sums2 = as_const(S1);
-    if (mfma) flm::launch_b3(A, C, g3, s); else k_b3<C, K><<<grid, 64 * WPB, lds, s>>>(A);
-    k_colsum<<<pdf_divup(b3_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, g3, b3_width<C>(), S3);
+    const int gb3 = mfma ? g3 : (int)std::min<long>(grid, (long)grid * b2_width<C>() / b3_pwidth<C>());   // (fl::k_b3's rows are 16 wider than S3)
+    if (mfma) flm::launch_b3(A, C, g3, s); else k_b3<C, K><<<gb3, 64 * WPB, lds, s>>>(A);
+    // column sums of B3's rows -> S3; with the kNN table's coordinate sums at hand one more block of the SAME launch finishes the geometry
+    // branch's BatchNorm + Linear(3, 3) backward in closed form (S4): no B4 pass, no second reducer (PDFOPS_BNP_CLOSED=0: B4, as before)
+    static const bool closed_on = [] { const char *v = getenv("PDFOPS_BNP_CLOSED"); return !(v && v[0] == '0'); }();
+    const bool closed = closed_on && A.mom != nullptr;
+    BnpClosed bc = none;
+    if (closed) {
+        bc.mom = A.mom; bc.Wp1 = A.Wp1; bc.bp1 = A.bp1; bc.sp = A.sp; bc.mean = A.mean; bc.rstd = A.rstd; bc.rows = (double)rows;
+        bc.col_g = b3_width<C>(); bc.out4 = S4;
+    }
+    k_colsum<<<pdf_divup(b3_width<C>(), 16) + (closed ? 1 : 0), RED_THREADS, 0, s>>>(A.partial, mfma ? g3 : gb3, b3_width<C>(), b3_pwidth<C>(), S3, bc);
     rc = pdf_seg_sum_rows_x(A.N, C, A.GR, C, A.bf16, inv_off, inv_entry, entry_base, 1.0f, A.gxk, s);   // g_xk[nb] = sum of the g_r rows that gathered nb
     if (rc != PDF_OK) return rc;
-    A.sums = as_const(S3);
-    k_b4<K><<<grid, 64 * WPB, 0, s>>>(A);
-    k_colsum<<<1, RED_THREADS, 0, s>>>(A.partial, grid, b4_width(), S4);
+    if (!closed) {
+        A.sums = as_const(S3);
+        k_b4<K><<<grid, 64 * WPB, 0, s>>>(A);
+        k_colsum<<<1, RED_THREADS, 0, s>>>(A.partial, grid, b4_width(), b4_width(), S4, none);
+    }
     return pdf_launch_status();
 }
 
@@ -1153,7 +1233,8 @@ extern "C" int pdf_pt_layer_backward(int n, int nsample, int c, const float *xq,
                                      const float *p, const int *idx, const float *const *weights, const float *bn,
                                      const float *saved, const float *H, const float *gout, float *gxq, float *gxk,
                                      float *gxv, float *G2, float *G3, float *Wsm, float *GR, const int *inv_off, const int *inv_entry,
-                                     int entry_base, float *partial, float *sums, int storage_bf16, const int *order, void *stream) {
+                                     int entry_base, float *partial, float *sums, int storage_bf16, const int *order, const double *moments,
+                                     void *stream) {
     if (n < 1 || !xq || !xk || !xv || !p || !idx || !weights || !bn || !saved || !H || !gout || !gxq || !gxk || !gxv ||
         !G2 || !G3 || !Wsm || !GR || !inv_off || !inv_entry || !partial || !sums)
         return PDF_ERR_BAD_ARG;
@@ -1168,7 +1249,7 @@ extern "C" int pdf_pt_layer_backward(int n, int nsample, int c, const float *xq,
     A.sp = as_const(bn); A.tp = as_const(bn + 3); A.s1 = as_const(bn + 6); A.t1 = as_const(bn + 6 + c);
     A.s2 = as_const(bn + 6 + 2 * c); A.t2 = as_const(bn + 6 + 2 * c + cs);
     A.H = const_cast<float *>(H); A.out = nullptr; A.partial = partial;
-    A.mom = nullptr;
+    A.mom = moments;   // the kNN table's coordinate sums (or null): closed-form backward of the geometry branch's first layers
     A.gout = gout; A.G2 = G2; A.G3 = G3; A.gxq = gxq; A.gxk = gxk; A.gxv = gxv; A.Wsm = Wsm; A.GR = GR; A.bf16 = storage_bf16 & 1; A.chunked = (storage_bf16 >> 1) & 1; A.order = (storage_bf16 & 4) ? order : nullptr; A.sums = as_const(nullptr); A.sums2 = as_const(nullptr);
     hipStream_t s = static_cast<hipStream_t>(stream);
     A.mean = as_const(saved); A.rstd = as_const(saved + (3 + c + cs));   // forward's layout: [mean p|1|2][rstd p|1|2]

@@ -166,7 +166,7 @@ __device__ __forceinline__ f32x4 sel4(bool c, f32x4 v) { return c ? v : zero4();
 
 // geometry branch of the lane's row (3 channels, replicated over the 4 kq lanes): weights in SGPRs, coordinates preloaded
 struct GeoW { float wp1[9], bp1[3], sp[3], tp[3]; };
-struct Geo { float t1[3], t1n[3]; };   // Linear(3,3) output (pre-BN), relu(BNp(t1))
+struct Geo { float t1[3], t1n[3], rel[3]; };   // Linear(3,3) output (pre-BN), relu(BNp(t1)), the masked relative coordinates
 __device__ __forceinline__ GeoW geo_weights(const LayerArgs &A) {
     GeoW G;
 #pragma unroll
@@ -177,7 +177,7 @@ __device__ __forceinline__ GeoW geo_weights(const LayerArgs &A) {
 }
 __device__ __forceinline__ Geo geo_of(const GeoW &G, int nb, const float *pn, const float *pi) {
     Geo R;
-    float rel[3];
+    float *rel = R.rel;
 #pragma unroll
     for (int b = 0; b < 3; ++b) rel[b] = nb >= 0 ? pn[b] - pi[b] : 0.f;
 #pragma unroll
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------ B3
-// partial row per block: [sum g_yp (3) | sum g_yp*that (3) | pad 2 | g_bp2 (C) | g_Wp2 (C*3)]   (as fl::k_b3)
+// partial row per block: [sum g_yp (3) | sum g_yp*that (3) | pad 2 | g_bp2 (C) | g_Wp2 (C*3) | sum g_yp (x) rel (9) | pad 7]   (as fl::k_b3)
 //
 // Round 4: the POINTS are the outer loop and the 64-channel chunks the inner one (rounds 1-3: chunks outermost, every chunk re-staged its
 // Ww1 slab behind two block barriers and re-read the point's H / G2 / Wsm / coordinates / G3 -- at levels 4-5, where a wave sees one or
@@ -764,7 +764,7 @@ template <int C> constexpr int b3_ncp() { return C / 64 < 4 ? C / 64 : 4; }     
 template <int C> constexpr int b3_wls() { return 64 * b3_ncp<C>() + 4; }             // row stride of the Ww1 copy (floats)
 template <int C, bool BF>
 __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
-    constexpr int CS = C / 8, NOB = nob_of(C), CSP = csp_of(C), NCHK = C / 64, NCP = b3_ncp<C>(), NSW = NCHK / NCP, WS = b3_wls<C>(), W = 8 + 4 * C;
+    constexpr int CS = C / 8, NOB = nob_of(C), CSP = csp_of(C), NCHK = C / 64, NCP = b3_ncp<C>(), NSW = NCHK / NCP, WS = b3_wls<C>(), W = 8 + 4 * C + 16;
     constexpr int CW = 64 * NCP;             // channels of a sweep
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wv = threadIdx.x >> 6;
@@ -781,7 +781,14 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
     stage_units<C, true>(ucst, A, gp(A.sums2));
     const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
     const GeoW G = geo_weights(A);
-    float sgp[3] = {0.f, 0.f, 0.f}, sgpt[3] = {0.f, 0.f, 0.f};
+    // the 15 sums of the geometry branch [sum g_yp (3) | sum g_yp*that (3) | sum g_yp[a] * rel[b] (9): closed-form BNp backward, fl::k_colsum]:
+    // one private LDS slot per row-owning lane (stride 15: conflict-free), not 15 registers carried through the point loop -- the kernel
+    // sits at the 256-register step of 2 waves per SIMD
+    float *gacc = tiles + WPB * 32 * TS + WPB * 64 + (wv * 16 + row) * 15;
+    if (kq == 0) {
+#pragma unroll
+        for (int e = 0; e < 15; ++e) gacc[e] = 0.f;
+    }
     float *dst = A.partial + (size_t)blockIdx.x * W;   // the block's partial row
 #pragma unroll 1
     for (int sw = 0; sw < NSW; ++sw) {
@@ -907,8 +914,9 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
                     if (sw > 0) v += g3old[a];
                     if (sw == NSW - 1) {   // all channels seen: ReLU mask of BNp, BNp-backward sums
                         v = R.t1n[a] > 0.f ? v : 0.f;
-                        sgp[a] += v;
-                        sgpt[a] += v * ((R.t1[a] - A.mean[a]) * A.rstd[a]);
+                        gacc[a] += v;
+                        gacc[3 + a] += v * ((R.t1[a] - A.mean[a]) * A.rstd[a]);
+                        gacc[6 + 3 * a + 0] += v * R.rel[0]; gacc[6 + 3 * a + 1] += v * R.rel[1]; gacc[6 + 3 * a + 2] += v * R.rel[2];
                     }
                     A.G3[ri * 3 + a] = v;
                 }
@@ -931,15 +939,16 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
         }
     }
     __syncthreads();
-    block_row(crow, 8, [&](RowAcc o) {
+    block_row(crow, 24, [&](RowAcc o) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float x = pdf_wave_sum_f32(sgp[a]), y = pdf_wave_sum_f32(sgpt[a]);
-            if (lane == 0) { o[a] = x; o[3 + a] = y; }
+        for (int e = 0; e < 15; ++e) {
+            const float x = pdf_wave_sum_f32(kq == 0 ? gacc[e] : 0.f);
+            if (lane == 0) o[e < 6 ? e : e + 2] = x;
         }
-        if (lane == 0) { o[6] = 0.f; o[7] = 0.f; }
+        if (lane == 0) { o[6] = 0.f; o[7] = 0.f; for (int e = 17; e < 24; ++e) o[e] = 0.f; }
     });
     store_row(crow, 8, dst);
+    if (threadIdx.x < 16) dst[8 + 4 * C + threadIdx.x] = crow[8 + threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -1005,7 +1014,7 @@ void launch_b2(const LayerArgs &A, int c, int grid, hipStream_t s) {
 void launch_b3(const LayerArgs &A, int c, int grid, hipStream_t s) {
     const dim3 g(grid);
     const int ncp = c / 64 < 4 ? c / 64 : 4, cw = 64 * ncp;   // (b3_ncp / the sweep's channels)
-    const size_t lds = (size_t)6 * c + 4 * cw + 7 * csp_of(c) + (size_t)csp_of(c) * (cw + 4) + std::max<size_t>(WPB * 32 * TS + WPB * 64, (size_t)WPB * 4 * cw);
+    const size_t lds = (size_t)6 * c + 4 * cw + 7 * csp_of(c) + (size_t)csp_of(c) * (cw + 4) + std::max<size_t>(WPB * 32 * TS + WPB * 64 + WPB * 240, (size_t)WPB * 4 * cw);   // (+ the geometry sums' slots)
 #define K_(C_) do { if (A.bf16) launch(k_b3<C_, true>, g, lds, A, s); else launch(k_b3<C_, false>, g, lds, A, s); } while (0)
     PDF_FLM_C(K_, g, lds);
 #undef K_

@@ -553,7 +553,7 @@ class _BottleneckFn(torch.autograd.Function):
                 A(5), A(6), A(7), A(2), A(3), A(4), A(8), A(10), A(9), A(11), W3.data_ptr(),
                 gx.data_ptr(), gb + 4 * o_pre, gb + 4 * o_post, gb + 4 * o_sum,
                 S(0), S(1), S(2), S(6), S(7), S(3), S(4), S(5), S(8), S(9), inv_off.data_ptr(), inv_entry.data_ptr(), S(10),
-                None, None, None, be._order_ptr(idx), S(11)]   # (46-48: unused slots of the table, csrc/block.hip)
+                be._moments_ptr(idx) if training else None, None, None, be._order_ptr(idx), S(11)]   # (46: the table's coordinate sums; 47-48: unused, csrc/block.hip)
         be.bottleneck_backward(n, k, c, ptrs, training, entry_base, bf16)
         # the ~35 gradient views as ONE split of the buffer (a slice + view per gradient was ~100 us of host time per block)
         sizes = _bottleneck_grad_sizes(c, o_post, o_sum, grads.shape[0])

@@ -10,7 +10,7 @@ from helpers import l2_rel, max_rel
 pytestmark = pytest.mark.gpu
 
 
-def run_layer(fused, C, K, N, train, seed=0):
+def run_layer(fused, C, K, N, train, seed=0, moments=False):
     from pointcloudpdf_amd import synthetic
     from pointcloudpdf_amd.geometry import Geometry
     from pointcloudpdf_amd.point_transformer import PointTransformerLayer
@@ -19,6 +19,10 @@ def run_layer(fused, C, K, N, train, seed=0):
     sizes = [N // 2 + 17, N - N // 2 - 17]
     batch = synthetic.make_batch(sizes, first_scene_id=50, grid_size=0.25, device="cuda")
     geom = Geometry(batch["coord"], batch["offset"], batch["offset_host"])
+    if moments:   # the table's coordinate sums, attached to idx: the backward's closed form for d Wp1 / d bp1 (no fourth pass)
+        from pointcloudpdf_amd import _native
+        geom.rel_moments(K, 0)
+        assert _native.moments_of(geom.knn(K, 0, 0)[0]) is not None
     layer = PointTransformerLayer(C, C, 8, K).cuda()
     synthetic.fill_parameters_deterministic(layer, seed=3)
     layer.train(train)
@@ -57,6 +61,26 @@ def test_fused_layer_train(C, K):
     bad = {k: v for k, v in report.items()
            if v[0] > (2e-5 if k.startswith("b_") else 1e-3) and (k.startswith("b_") or v[1] > 1e-4 * gscale)}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("C,K", [(32, 8), (64, 16), (128, 16), (32, 16), (64, 8), (256, 16), (512, 16)])
+def test_fused_layer_geometry_branch_gradients_in_closed_form(C, K):
+    """With the kNN table's coordinate sums at hand (Geometry.rel_moments) the backward takes d Wp1 / d bp1 -- linear_p's first Linear
+    under its train-mode BatchNorm -- from the sums of the third pass (fused_layer.hip, k_colsum's closed-form block) instead of a
+    fourth pass over the rows: every output as in the op-by-op composition, and the two geometry gradients also against the fused
+    layer's own fourth pass."""
+    n = 3000 if C <= 128 else 900
+    a = run_layer(True, C, K, n, True, moments=True)
+    b = run_layer(False, C, K, n, True)
+    c = run_layer(True, C, K, n, True)
+    assert max_rel(a["y"], b["y"]) < 2e-5
+    gscale = max(float(np.abs(b[k]).max()) for k in b if k.startswith("g_"))
+    for k in a:
+        if not k.startswith("g_") or float(np.abs(b[k]).max()) <= 1e-4 * gscale:
+            continue
+        assert l2_rel(a[k], b[k]) < 1e-3, (k, l2_rel(a[k], b[k]))
+    w = "g_linear_p.0.weight"
+    assert l2_rel(a[w], c[w]) < 2e-5, l2_rel(a[w], c[w])
 
 
 @pytest.mark.parametrize("C,K", [(32, 8), (64, 16), (128, 16), (256, 16), (512, 16)])

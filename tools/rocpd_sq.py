@@ -125,6 +125,9 @@ def to_json(out, kt_db, steps, files):
     for name, d in sqlite3.connect(kt_db).execute("select name, (end - start) from kernels"):
         a = dur.setdefault(short(name), [0, 0])
         a[0] += 1; a[1] += d
+    sgd = sum(v[0] for k, v in dur.items() if "k_sgd" in k)
+    if sgd:   # one optimizer launch per training step: the trace's own step count (warm-up and capture passes included in the kernel totals)
+        steps = float(sgd)
     kernels, fam = {}, {}
     for k, e in tab.items():
         c = e["c"]
