@@ -199,6 +199,48 @@ __device__ __forceinline__ void insert(float (&bd)[KP1], int (&bi)[KP1], float d
 // COUNT (measurement builds of the launch, pdf_knn_query_ws_counted): every lane counts the candidate distances it evaluates; the wave's
 // total goes to *pairs with one atomic per wave -- the work the kernel really does, as opposed to the m * n_scene pairs of the brute force
 // it replaces (bench.py / tools/ops_roofline.py price the kernel against the fp32 vector peak with THIS count).
+//
+// Round 4: the walk is organised for memory-level parallelism.  Rounds 1-3 visited the shell of radius R cell by cell -- two dependent
+// loads (the cell's range) and then one dependent load per point, ~27-125 cells per query, most of them empty on surface-like scenes: a
+// wave spent ~400 us in ~800 serialised L2 round trips (0.2 % of the vector peak on the pairs it evaluated).  Now
+//   * the shell is walked ROW by row (dz, dy in -R..R: wave-uniform trip counts, out-of-grid rows are empty ranges): the cells of a row
+//     on a z- or y-face are contiguous in the sorted copy -- ONE range [start(x0), start(x1 + 1)) for up to 2R+1 cells -- and an interior
+//     row contributes its two end cells;
+//   * the next row's ranges are requested before the current row's points are scanned;
+//   * points are loaded four at a time (clamped addresses, guarded inserts).
+// The candidates and the (distance, index)-ordered list are what they were: results unchanged bit for bit.
+struct RowRanges { unsigned a0, a1, b0, b1; };   // [a0, a1) and [b0, b1) of the sorted copy
+
+template <int KP1, bool COUNT>
+__device__ __forceinline__ void scan_range(unsigned p0, unsigned p1, const float4 *__restrict__ sorted, float qx, float qy, float qz,
+                                           float (&bd)[KP1], int (&bi)[KP1], unsigned &evaluated) {
+    if (COUNT) evaluated += p1 - p0;
+    for (unsigned p = p0; p < p1; p += 4) {
+        const unsigned last = p1 - 1;
+        const float4 v0 = sorted[p], v1 = sorted[min(p + 1, last)], v2 = sorted[min(p + 2, last)], v3 = sorted[min(p + 3, last)];
+        insert<KP1>(bd, bi, pdf_sqdist3(qx - v0.x, qy - v0.y, qz - v0.z), __float_as_int(v0.w));
+        if (p + 1 < p1) insert<KP1>(bd, bi, pdf_sqdist3(qx - v1.x, qy - v1.y, qz - v1.z), __float_as_int(v1.w));
+        if (p + 2 < p1) insert<KP1>(bd, bi, pdf_sqdist3(qx - v2.x, qy - v2.y, qz - v2.z), __float_as_int(v2.w));
+        if (p + 3 < p1) insert<KP1>(bd, bi, pdf_sqdist3(qx - v3.x, qy - v3.y, qz - v3.z), __float_as_int(v3.w));
+    }
+}
+
+// ranges of row (dz, dy) of the shell of radius R around cell (cx, cy, cz)
+__device__ __forceinline__ RowRanges row_ranges(const SceneGrid &g, const unsigned *__restrict__ cs, int cx, int cy, int cz, int R, int dz, int dy) {
+    RowRanges r = {0u, 0u, 0u, 0u};
+    const int z = cz + dz, y = cy + dy;
+    if (z < 0 || z >= g.nz || y < 0 || y >= g.ny) return r;
+    const unsigned *row = cs + (z * g.ny + y) * g.nx;
+    const bool face = dz == R || dz == -R || dy == R || dy == -R;   // (wave-uniform)
+    if (face) {
+        r.a0 = row[max(cx - R, 0)]; r.a1 = row[min(cx + R, g.nx - 1) + 1];
+    } else {   // R >= 1: the two x-faces
+        if (cx - R >= 0) { r.a0 = row[cx - R]; r.a1 = row[cx - R + 1]; }
+        if (cx + R < g.nx) { r.b0 = row[cx + R]; r.b1 = row[cx + R + 1]; }
+    }
+    return r;
+}
+
 template <int KP1, bool SELF, bool COUNT>
 __global__ __launch_bounds__(PB) void k_grid_query(int m, int b, const float *__restrict__ new_xyz, const int *__restrict__ new_offset,
                                                    const SceneGrid *__restrict__ grids, const unsigned *__restrict__ cell_start,
@@ -207,11 +249,11 @@ __global__ __launch_bounds__(PB) void k_grid_query(int m, int b, const float *__
     constexpr int K = KP1 - 1;
     const int t_ = blockIdx.x * PB + threadIdx.x;
     unsigned evaluated = 0;
-    if (t_ >= m) return;
-    int q = t_;
+    const bool live = t_ < m;                 // (no early return: the row walk below keeps the wave's trip counts uniform)
+    int q = live ? t_ : m - 1;
     float qx, qy, qz;
     if (SELF) {
-        const float4 me = sorted[t_];   // the sorted copy keeps the scenes in order: position t_ belongs to scene_of(t_)
+        const float4 me = sorted[q];   // the sorted copy keeps the scenes in order: position t_ belongs to scene_of(t_)
         q = __float_as_int(me.w);
         qx = me.x; qy = me.y; qz = me.z;
     } else {
@@ -224,32 +266,21 @@ __global__ __launch_bounds__(PB) void k_grid_query(int m, int b, const float *__
     int bi[KP1];
 #pragma unroll
     for (int t = 0; t < KP1; ++t) { bd[t] = 3.0e38f; bi[t] = 0x7fffffff; }
-    if (!need_redo) {
-        const int cx = cell_coord(qx, g.minx, g.inv_h, g.nx), cy = cell_coord(qy, g.miny, g.inv_h, g.ny), cz = cell_coord(qz, g.minz, g.inv_h, g.nz);
-        const unsigned *cs = cell_start + g.cell_base;
-        const int rmax = max(g.nx, max(g.ny, g.nz));
-        for (int R = 0; R <= rmax; ++R) {
-            const int x0 = max(cx - R, 0), x1 = min(cx + R, g.nx - 1);
-            const int y0 = max(cy - R, 0), y1 = min(cy + R, g.ny - 1);
-            const int z0 = max(cz - R, 0), z1 = min(cz + R, g.nz - 1);
-            for (int z = z0; z <= z1; ++z)
-                for (int y = y0; y <= y1; ++y) {
-                    // shell of the cube of radius R: on a z- or y-face every x, otherwise only the two x-faces
-                    const bool face = (z - cz == R) || (cz - z == R) || (y - cy == R) || (cy - y == R);
-                    const int xa = face ? x0 : cx - R, xb = face ? x1 : cx + R;
-                    const int xstep = face ? 1 : max(2 * R, 1);
-                    for (int x = xa; x <= xb; x += xstep) {
-                        if (x < 0 || x >= g.nx) continue;
-                        const int c = (z * g.ny + y) * g.nx + x;
-                        const unsigned p0 = cs[c], p1 = cs[c + 1];
-                        if (COUNT) evaluated += p1 - p0;
-                        for (unsigned p = p0; p < p1; ++p) {
-                            const float4 v = sorted[p];
-                            const float d = pdf_sqdist3(qx - v.x, qy - v.y, qz - v.z);
-                            insert<KP1>(bd, bi, d, __float_as_int(v.w));
-                        }
-                    }
-                }
+    const int cx = cell_coord(qx, g.minx, g.inv_h, g.nx), cy = cell_coord(qy, g.miny, g.inv_h, g.ny), cz = cell_coord(qz, g.minz, g.inv_h, g.nz);
+    const unsigned *cs = cell_start + g.cell_base;
+    const int rmax = max(g.nx, max(g.ny, g.nz));
+    bool done = need_redo || !live;
+    for (int R = 0; __builtin_amdgcn_ballot_w64(!done) != 0ull; ++R) {
+        if (!done) {
+            const int side = 2 * R + 1, rows = side * side;
+            RowRanges cur = row_ranges(g, cs, cx, cy, cz, R, -R, -R);
+            for (int e = 0; e < rows; ++e) {
+                RowRanges nxt = {0u, 0u, 0u, 0u};
+                if (e + 1 < rows) nxt = row_ranges(g, cs, cx, cy, cz, R, (e + 1) / side - R, (e + 1) % side - R);
+                scan_range<KP1, COUNT>(cur.a0, cur.a1, sorted, qx, qy, qz, bd, bi, evaluated);
+                scan_range<KP1, COUNT>(cur.b0, cur.b1, sorted, qx, qy, qz, bd, bi, evaluated);
+                cur = nxt;
+            }
             // certified radius: distance from the query to the nearest face of the searched cube that is not a grid wall
             float rc = 3.0e38f;
             if (cx - R > 0) rc = fminf(rc, qx - (g.minx + (float)(cx - R) * g.h));
@@ -258,16 +289,18 @@ __global__ __launch_bounds__(PB) void k_grid_query(int m, int b, const float *__
             if (cy + R < g.ny - 1) rc = fminf(rc, (g.miny + (float)(cy + R + 1) * g.h) - qy);
             if (cz - R > 0) rc = fminf(rc, qz - (g.minz + (float)(cz - R) * g.h));
             if (cz + R < g.nz - 1) rc = fminf(rc, (g.minz + (float)(cz + R + 1) * g.h) - qz);
-            if (rc >= 3.0e38f) break;                       // the cube is the whole grid
             // slack for the rounding of cell edges and distances (relative + a few ulps of the coordinate magnitude)
-            rc = fmaxf(rc * 0.999f - 2e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz) + g.h), 0.f);
-            if (bd[KP1 - 1] < rc * rc) break;               // the K+1 best are all inside the certified ball
+            const float rs = fmaxf(rc * 0.999f - 2e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz) + g.h), 0.f);
+            done = rc >= 3.0e38f                // the cube is the whole grid
+                   || bd[KP1 - 1] < rs * rs     // the K+1 best are all inside the certified ball
+                   || R >= rmax;
         }
-        // ties among the K+1 best distances make the reference's answer depend on its heap history: exact scan instead
-#pragma unroll
-        for (int t = 0; t < K; ++t) need_redo |= (bd[t] == bd[t + 1]);
     }
-    if (COUNT) {   // a per-lane atomic: measurement launches only (wave-level reductions would need every lane to stay convergent here)
+    if (!live) return;
+    // ties among the K+1 best distances make the reference's answer depend on its heap history: exact scan instead
+#pragma unroll
+    for (int t = 0; t < K; ++t) need_redo |= (bd[t] == bd[t + 1]);
+    if (COUNT) {   // a per-lane atomic: measurement launches only
         if (evaluated) atomicAdd(pairs, (unsigned long long)evaluated);
     }
     if (need_redo) {
