@@ -324,8 +324,8 @@ __device__ __forceinline__ unsigned row_umax_bcast(unsigned v, int row) {
 
 constexpr int FPS_UNROLL = 4;  // bucket loads in flight per wave
 #ifndef PDF_FPS_MW_UNROLL
-#define PDF_FPS_MW_UNROLL 4
-#endif
+#define PDF_FPS_MW_UNROLL 1   // k_fps_mw's update phase is bound by the CU's vector issue (16 waves, ~150 instructions per bucket), not by the
+#endif                        // loads: round 4, levels 100k / 25k / 6250: unroll 1 23.5 / 7.1 / 2.7 ms, 2 24.0 / 7.3 / 2.9, 4 26.6 / 8.6 / 3.1, 8 30.8 / 11.3 / 4.3
 
 // NW waves per scene.  Every wave derives the same sample / active-super / active-bucket lists from the shared LDS
 // records (redundantly, no communication); the surviving buckets are dealt round-robin to the waves; two barriers per
@@ -774,7 +774,7 @@ __global__ __launch_bounds__(64 * NW) void k_fps_multi(const int *__restrict__ o
 //            claim word (the owner clears the word).
 //   barrier B
 //   phase 4  the shared super list is dealt to the waves (4 supers per pass); barrier C.
-template <int NW>
+template <int NW, bool RANK>
 __global__ __launch_bounds__(64 * NW) void k_fps_mw(const int *__restrict__ offset, const int *__restrict__ new_offset,
                                                     float4 *__restrict__ pts, const unsigned *__restrict__ kbs,
                                                     const float *__restrict__ meta, int *__restrict__ idx, int nb_cap,
@@ -798,7 +798,10 @@ __global__ __launch_bounds__(64 * NW) void k_fps_mw(const int *__restrict__ offs
     unsigned *cnt = claimS + ns_cap;                                                             // [4]: n_bk[2], n_sup[2] by round parity
     float *cent = reinterpret_cast<float *>(cnt + 4);                                            // [3 * 16] the round's centres
     int *cent_n = reinterpret_cast<int *>(cent + 3 * 16);                                      // [4]
-    unsigned short *blist = reinterpret_cast<unsigned short *>(cent_n + 4);                      // [nb_cap + 64] shared
+    unsigned *rank = reinterpret_cast<unsigned *>(cent_n + 4);                                   // [ns_cap] supers with a greater key (RANK)
+    int *cand = reinterpret_cast<int *>(rank + ns_cap);                                          // [16] the round's candidate supers, best first
+    unsigned *c_s2h = reinterpret_cast<unsigned *>(cand + 16), *c_s2l = c_s2h + 16;              // [16] [16] their supers' second-best keys
+    unsigned short *blist = reinterpret_cast<unsigned short *>(c_s2l + 16);                      // [nb_cap + 64] shared
     unsigned short *slist = blist + nb_cap + 64;                                                 // [ns_cap + 64] shared
     const int psl_stride = ((ns_cap + 63) & ~63) + 64;
     unsigned short *pslist = slist + ns_cap + 64 + wave * psl_stride;                            // private per wave
@@ -820,6 +823,7 @@ __global__ __launch_bounds__(64 * NW) void k_fps_mw(const int *__restrict__ offs
         claimB[i] = 0u;
     }
     if (tid < 4) cnt[tid] = 0u;
+    if (tid < 16) cand[tid] = -1;
     __syncthreads();
     for (int s = tid; s < ns; s += 64 * NW) {
         float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
@@ -839,6 +843,7 @@ __global__ __launch_bounds__(64 * NW) void k_fps_mw(const int *__restrict__ offs
         S.k2hi[s] = (unsigned)(second >> 32); S.k2lo[s] = (unsigned)second;
         S.bx[s] = B.bx[bi]; S.by[s] = B.by[bi]; S.bz[s] = B.bz[bi];
         claimS[s] = 0u;
+        rank[s] = 0u;
     }
     __syncthreads();
 
@@ -846,9 +851,84 @@ __global__ __launch_bounds__(64 * NW) void k_fps_mw(const int *__restrict__ offs
     int j = 1;
     FPS_TICK(4);
     while (j < sc.m) {
-        // ---- 1. candidates: WAVE 0 ONLY (the other waves sleep at barrier D instead of competing for the SIMDs' issue
-        // slots with redundant copies) -- acceptance rule of k_fps_multi.  Each lane keeps the records of ITS supers
-        // (s = lane + 64 i) in registers for the round; lane u holds accepted centre u, so test (b) is one distance per lane.
+        // ---- 1. candidates.  The round's candidates are the KMAX supers with the largest best keys, best first (c_t = the best point
+        // outside the supers of c_1..c_{t-1}); tests (a) and (b) of k_fps_multi only use values from before the round, so the accepted
+        // prefix is the first t that fails either.  Rounds 2-3 found the candidates one wave arg-max after the other in wave 0 (~1,450
+        // cycles each, 16k of the 31k cycles of a level-1 round).  RANK: every wave counts, for every super, the supers of ITS slice with a
+        // greater key (broadcast LDS reads, LDS adds); after barrier R wave 0 places the supers of rank < KMAX, lane t takes candidate t
+        // and all tests run at once.
+        if (RANK) {
+            const int js = (ns + NW - 1) / NW, j0 = wave * js, j1 = min(ns, j0 + js);
+            unsigned long long mykey[NSL];
+            unsigned above[NSL];
+#pragma unroll
+            for (int i = 0; i < NSL; ++i) {
+                const int s = lane + 64 * i;
+                mykey[i] = s < ns ? (((unsigned long long)S.khi[s] << 32) | S.klo[s]) : ~0ull;
+                above[i] = 0u;
+            }
+            for (int jj = j0; jj < j1; ++jj) {
+                const unsigned long long kj = ((unsigned long long)S.khi[jj] << 32) | S.klo[jj];
+#pragma unroll
+                for (int i = 0; i < NSL; ++i) above[i] += kj > mykey[i] ? 1u : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < NSL; ++i)
+                if (above[i]) atomicAdd(&rank[lane + 64 * i], above[i]);   // (above != 0 only for s < ns)
+            __syncthreads();  // R: ranks complete
+            if (wave == 0) {
+                constexpr int G = 64 / KMAX;          // lane groups of test (b): lane = (g, t)
+                const int kmax = min(KMAX, sc.m - j);
+#pragma unroll
+                for (int i = 0; i < NSL; ++i) {
+                    const int s = lane + 64 * i;
+                    if (s < ns) {
+                        const unsigned rk = rank[s];
+                        rank[s] = 0u;
+                        if (rk < (unsigned)KMAX && (S.khi[s] | S.klo[s]) != 0u) cand[rk] = s;   // (keys are unique unless 0: ranks too)
+                    }
+                }
+                lds_fence();
+                const int t = lane % KMAX, g = lane / KMAX;
+                const int cs = cand[t];
+                const bool valid = cs >= 0 && t < kmax;
+                const int c0 = cs >= 0 ? cs : 0;
+                const unsigned kh = S.khi[c0], kl = S.klo[c0];
+                const float x = S.bx[c0], y = S.by[c0], z = S.bz[c0];
+                if (lane < KMAX) {
+                    cent[3 * t + 0] = x; cent[3 * t + 1] = y; cent[3 * t + 2] = z;
+                    c_s2h[t] = valid ? S.k2hi[c0] : 0u; c_s2l[t] = valid ? S.k2lo[c0] : 0u;
+                }
+                lds_fence();
+                bool fail = !valid;
+                {   // (a) the key beats the second-best key of every earlier candidate's super
+                    unsigned long long bound = 0ull;
+#pragma unroll
+                    for (int u = 0; u < KMAX - 1; ++u) {
+                        const unsigned long long k2 = ((unsigned long long)c_s2h[u] << 32) | c_s2l[u];
+                        if (u < t && k2 > bound) bound = k2;
+                    }
+                    const unsigned long long key = ((unsigned long long)kh << 32) | kl;
+                    fail = fail || (t > 0 && !(key > bound));
+                }
+#pragma unroll
+                for (int uu = 0; uu < KMAX / G; ++uu) {   // (b) no earlier candidate lowers tmp of this one
+                    const int u = g + G * uu;
+                    const bool near = pdf_f32_ordered(dist_as_written(x, y, z, cent[3 * u + 0], cent[3 * u + 1], cent[3 * u + 2])) < kh;
+                    fail = fail || (u < t && near);
+                }
+                unsigned long long fm = __ballot(fail);
+#pragma unroll
+                for (int sft = KMAX; sft < 64; sft <<= 1) fm |= fm >> sft;
+                const unsigned f = (unsigned)fm & ((1u << KMAX) - 1u) & ~1u;       // (candidate 0 is always accepted)
+                const int acc = f ? __ffs(f) - 1 : KMAX;
+                if (lane < acc) idx[sc.start_m + j + lane] = sc.start_n + (int)(~kl & REL_MASK);
+                if (lane == 0) cent_n[0] = acc;
+                if (lane < 16) cand[lane] = -1;
+            }
+        } else
+        // (rounds 2-3) WAVE 0 ONLY, one candidate after the other: each lane keeps the records of ITS supers (s = lane + 64 i) in
+        // registers for the round; lane u holds accepted centre u, so test (b) is one distance per lane.
         if (wave == 0) {
             unsigned skh[NSL], skl[NSL], sk2h[NSL], sk2l[NSL];
             float sbx[NSL], sby[NSL], sbz[NSL];
@@ -1099,18 +1179,20 @@ extern "C" int pdf_farthest_point_sampling_bucketed(int b, int n, int n_total, c
     // the one-sample kernel 91 / 20 / 4.9 / 1.2 ms -> by the size of the largest scene
     const int mw = env_mw ? atoi(env_mw) : (n >= 16384 ? 16 : n >= 3072 ? 8 : 0);
     const int mww = mw >= 16 ? 16 : 8;
-    const size_t lds3 = (size_t)(REC2 * nb_cap + REC2 * ns_cap + nb_cap + ns_cap + 4 + 3 * 16 + 4) * 4 +
+    const size_t lds3 = (size_t)(REC2 * nb_cap + REC2 * ns_cap + nb_cap + ns_cap + 4 + 3 * 16 + 4 + ns_cap + 3 * 16) * 4 +
                         (size_t)(nb_cap + 64 + ns_cap + 64 + mww * (((ns_cap + 63) & ~63) + 64)) * 2;
     if (kmulti > 1 && mw != 0 && lds3 <= 160 * 1024) {
-#define PDF_LAUNCH_FPS_MW(NW_)                                                                                            \
+#define PDF_LAUNCH_FPS_MW(NW_, RANK_)                                                                                     \
     do {                                                                                                                 \
         if (lds3 > 64 * 1024) {                                                                                          \
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fps_mw<NW_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3); \
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fps_mw<NW_, RANK_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3); \
             if (e != hipSuccess) return (int)e;                                                                          \
         }                                                                                                                \
-        k_fps_mw<NW_><<<b, 64 * NW_, lds3, s>>>(offset, new_offset, pts, kb, meta, idx, nb_cap, stats);                   \
+        k_fps_mw<NW_, RANK_><<<b, 64 * NW_, lds3, s>>>(offset, new_offset, pts, kb, meta, idx, nb_cap, stats);            \
     } while (0)
-        if (mww == 16) PDF_LAUNCH_FPS_MW(16); else PDF_LAUNCH_FPS_MW(8);
+        static const bool rank_sel = [] { const char *v = getenv("PDFOPS_FPS_RANK"); return !(v && v[0] == '0'); }();   // 0: rounds 2-3 candidate loop (A/B)
+        if (rank_sel) { if (mww == 16) PDF_LAUNCH_FPS_MW(16, true); else PDF_LAUNCH_FPS_MW(8, true); }
+        else { if (mww == 16) PDF_LAUNCH_FPS_MW(16, false); else PDF_LAUNCH_FPS_MW(8, false); }
 #undef PDF_LAUNCH_FPS_MW
         return pdf_launch_status();
     }
