@@ -1034,7 +1034,67 @@ __global__ __launch_bounds__(64 * NW) void k_fps_mw(const int *__restrict__ offs
         n_supers += n_sup;
         n_updates += n_bk;
 
-        // ---- 3. update the claimed buckets with every accepted centre
+        // ---- 3. update the claimed buckets with every accepted centre.  This phase is bound by the CU's vector issue (16 waves, one
+        // scene per CU), and most of a bucket's ~150 instructions were the four 64-lane reductions (best and second-best key) with their DPP
+        // wait states.  RANK (round 4): FOUR buckets per pass, one per 16-lane row, four consecutive points per lane -- a lane first
+        // reduces its own four points, the rows then need 4-step reductions, for four buckets at once.
+        if (RANK) {
+            for (int i0 = wave * 4; i0 < n_bk; i0 += NW * 4) {   // (two such sets in flight per wave: measured slower, 22.9 vs 21.7 ms at level 1)
+                const int bk = i0 + row < n_bk ? (int)blist[i0 + row] : -1;
+                const bool live = bk >= 0;
+                const size_t pos = (size_t)sc.pbase + (size_t)(live ? bk : 0) * BSZ + (size_t)col * 4;   // (idle rows read bucket 0, write nothing)
+                float4 p[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) p[e] = pts[pos + e];
+                const uint4 kb4 = *reinterpret_cast<const uint4 *>(kbs + pos);
+                const unsigned klo[4] = {live ? kb4.x : 0u, live ? kb4.y : 0u, live ? kb4.z : 0u, live ? kb4.w : 0u};
+                unsigned rem = live ? claimB[bk] : 0u;            // centres that reach the row's bucket
+                float w[4] = {p[0].w, p[1].w, p[2].w, p[3].w};
+                while (__ballot(rem != 0u) != 0ull) {             // every row takes ITS next centre (padding points carry w < 0: never lowered)
+                    const bool on = rem != 0u;
+                    const int v = on ? __ffs(rem) - 1 : 0;
+                    rem &= rem - 1u;
+                    const float ux = cent[3 * v + 0], uy = cent[3 * v + 1], uz = cent[3 * v + 2];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float d = dist_as_written(p[e].x, p[e].y, p[e].z, ux, uy, uz);
+                        if (on && d < w[e]) w[e] = d;
+                    }
+                }
+                unsigned long long key[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (live && w[e] < p[e].w) reinterpret_cast<float *>(pts + pos + e)[3] = w[e];
+                    key[e] = ((unsigned long long)(live && p[e].w >= 0.f ? pdf_f32_ordered(w[e]) : 0u) << 32) | klo[e];
+                }
+                // the lane's best and second-best point
+                unsigned long long best = key[0], second = 0ull;
+                float bx = p[0].x, by = p[0].y, bz = p[0].z;
+#pragma unroll
+                for (int e = 1; e < 4; ++e) {
+                    const bool gt = key[e] > best;
+                    const unsigned long long lower = gt ? best : key[e];
+                    second = lower > second ? lower : second;
+                    best = gt ? key[e] : best;
+                    bx = gt ? p[e].x : bx; by = gt ? p[e].y : by; bz = gt ? p[e].z : bz;
+                }
+                // the row's best point, and the best of the rest (the winning lane contributes its second-best)
+                const unsigned bh = (unsigned)(best >> 32), bl = (unsigned)best;
+                const unsigned mh = row_umax_bcast(bh, row);
+                const unsigned ml = row_umax_bcast(bh == mh ? bl : 0u, row);
+                const unsigned long long wm = __ballot(bh == mh && bl == ml);
+                const bool iam = col == __ffs((unsigned)(wm >> (16 * row)) & 0xffffu) - 1;
+                const unsigned ch = iam ? (unsigned)(second >> 32) : bh, cl = iam ? (unsigned)second : bl;
+                const unsigned m2h = row_umax_bcast(ch, row);
+                const unsigned m2l = row_umax_bcast(ch == m2h ? cl : 0u, row);
+                if (iam && live) {
+                    claimB[bk] = 0u;
+                    B.khi[bk] = mh; B.klo[bk] = ml;
+                    B.k2hi[bk] = m2h; B.k2lo[bk] = m2l;
+                    B.bx[bk] = bx; B.by[bk] = by; B.bz[bk] = bz;
+                }
+            }
+        } else
         for (int i0 = wave * UNR; i0 < n_bk; i0 += NW * UNR) {
             float4 p[UNR];
             unsigned kb[UNR];
