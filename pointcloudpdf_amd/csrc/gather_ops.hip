@@ -475,7 +475,7 @@ __global__ __launch_bounds__(GB) void group_fwd_rows_ord(unsigned total, FastDiv
     for (int u = 0; u < U; ++u) {
         const unsigned long jc = (unsigned long)max(j[u], 0);
         v[u] = reinterpret_cast<const v4f *>(feat)[jc * cv + min(q[u], cv - 1)];
-        if (with_xyz) {
+        if (with_xyz && q[u] >= cv) {   // (round 4: only the row's coordinate lane -- six scalar gathers in EVERY lane cost more than the branch)
 #pragma unroll
             for (int a = 0; a < 3; ++a) dx[u][a] = xyz[jc * 3 + a] - new_xyz[(unsigned long)m[u] * 3 + a];
         }
@@ -489,6 +489,62 @@ __global__ __launch_bounds__(GB) void group_fwd_rows_ord(unsigned total, FastDiv
 #pragma unroll
             for (int a = 0; a < 3; ++a) o[u][a] = j[u] >= 0 ? dx[u][a] : 0.f;
         }
+    }
+}
+
+// pointops.grouping(with_xyz) rows through LDS (round 4).  The rows of a query point are nsample * (3 + c) floats in a row, a multiple of 16
+// bytes when nsample % 4 == 0 -- but a single row (3 + c floats) is not: group_fwd_rows_ord stores its 16-byte feature pieces at
+// dword-aligned addresses (split by the hardware) and the three coordinates as scalars with a 4 * (3 + c)-byte stride, and ran at 0.39 of
+// the HBM peak where the same table without coordinates runs at 0.70.  Here a block assembles the rows of `ppb` query points in LDS
+// (same gathers) and writes every point's chunk out as whole aligned float4 lines.
+template <int TPR, int U>   // TPR lanes per row, U float4 feature pieces per lane and trip
+__global__ __launch_bounds__(GB) void group_fwd_lds(unsigned npts, unsigned ppb, FastDiv nsd, FastDiv c4d /* nsample * oc / 4 */, int c,
+                                                    const int *__restrict__ order, const float *__restrict__ feat,
+                                                    const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                    const int *__restrict__ idx, float *__restrict__ output) {
+    extern __shared__ __attribute__((aligned(16))) float g_stage[];   // [ppb * nsample * oc] | point ids [ppb]
+    const unsigned nsample = nsd.d, cv = c >> 2, oc = c + 3;
+    const unsigned chunk = nsample * oc;                      // floats per query point (% 4 == 0)
+    unsigned *pid = reinterpret_cast<unsigned *>(g_stage + ppb * chunk);
+    const unsigned blk = xcd_chunked_block(blockIdx.x, gridDim.x);
+    const unsigned s0 = blk * ppb, np = min(ppb, npts - s0), rows = np * nsample;   // rows <= GB / TPR
+    // TPR lanes per row: visiting order -> neighbour id -> (the row's feature pieces q = t, t + TPR, ... | coordinates t, t + TPR, ..): one
+    // dependent chain of three loads for everything the row needs
+    const unsigned rl = min(threadIdx.x / TPR, rows - 1), t = threadIdx.x % TPR;
+    const bool live = threadIdx.x / TPR < rows;
+    const unsigned pl = fdiv(rl, nsd), sq = s0 + pl;
+    const unsigned m = order ? (unsigned)order[sq] : sq;
+    const int j = idx[(unsigned long)m * nsample + (rl - pl * nsample)];
+    const unsigned long jc = (unsigned long)max(j, 0);
+    float dx[(3 + TPR - 1) / TPR];
+#pragma unroll
+    for (int i = 0; i < (3 + TPR - 1) / TPR; ++i) {
+        const unsigned a = min(t + i * TPR, 2u);
+        dx[i] = xyz[jc * 3 + a] - new_xyz[(unsigned long)m * 3 + a];
+    }
+    float *o = g_stage + rl * oc;
+    for (unsigned q0 = t; q0 < cv; q0 += TPR * U) {
+        v4f v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = reinterpret_cast<const v4f *>(feat)[jc * cv + min(q0 + TPR * u, cv - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned q = q0 + TPR * u;
+            if (live && q < cv) {
+                const v4f z = j >= 0 ? v[u] : (v4f)(0.f);
+                o[3 + 4 * q + 0] = z.x; o[3 + 4 * q + 1] = z.y; o[3 + 4 * q + 2] = z.z; o[3 + 4 * q + 3] = z.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < (3 + TPR - 1) / TPR; ++i)
+        if (live && t + i * TPR < 3) o[t + i * TPR] = j >= 0 ? dx[i] : 0.f;
+    if (live && t == 0 && rl == pl * nsample) pid[pl] = m;
+    __syncthreads();
+    const unsigned c4 = chunk >> 2, tot4 = np * c4;
+    for (unsigned e = threadIdx.x; e < tot4; e += GB) {
+        const unsigned p2 = fdiv(e, c4d), w = e - p2 * c4;
+        st_stream(reinterpret_cast<v4f *>(output) + (unsigned long)pid[p2] * c4 + w, reinterpret_cast<const v4f *>(g_stage)[e]);
     }
 }
 
@@ -744,6 +800,21 @@ extern "C" int pdf_group_forward_ordered(int m, int nsample, int c, int with_xyz
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long rows = (long)m * nsample;
     const int oc = c + (with_xyz ? 3 : 0);
+    // rows through LDS: narrow rows only (measured in one process, L1 c = 32 nsample 8: 65.5 us against 74.5 for the direct stores; L2
+    // c = 64 nsample 16: 45.7 against 44.5 -- there the 16-byte pieces already make whole lines)
+    if (c % 4 == 0 && c <= 32 && with_xyz && nsample % 4 == 0 && nsample <= 64 && rows * (c / 4 + 1) < (1L << 31) &&
+        getenv("PDFOPS_GROUP_LDS_OFF") == nullptr) {
+        // narrow rows: 2 lanes per row, 128 rows per block (a block's fixed latency -- three dependent loads, one barrier -- over 18 KB of
+        // output instead of 9); wide rows: 4 lanes per row, 64 rows
+        const bool narrow = c <= 32 && nsample <= 128;
+        const unsigned ppb = (unsigned)std::max(1, (narrow ? 128 : 64) / nsample);
+        const size_t lds = ((size_t)ppb * nsample * oc + ppb) * sizeof(float);
+        if (narrow) group_fwd_lds<2, 4><<<(m + ppb - 1) / ppb, GB, lds, s>>>((unsigned)m, ppb, mk_fastdiv((unsigned)nsample), mk_fastdiv((unsigned)(nsample * oc / 4)),
+                                                                            c, order, feat, xyz, new_xyz, idx, output);
+        else group_fwd_lds<4, 4><<<(m + ppb - 1) / ppb, GB, lds, s>>>((unsigned)m, ppb, mk_fastdiv((unsigned)nsample), mk_fastdiv((unsigned)(nsample * oc / 4)), c,
+                                                                    order, feat, xyz, new_xyz, idx, output);
+        return pdf_launch_status();
+    }
     if (c % 4 == 0 && rows * (c / 4 + 1) < (1L << 31)) {
         const unsigned pieces = (unsigned)(c / 4 + (with_xyz ? 1 : 0)), total = (unsigned)(rows * pieces);
         constexpr int U = 4;

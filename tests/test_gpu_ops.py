@@ -334,6 +334,36 @@ def test_group_fused_twin(hip, oracle_backend, table, c, with_xyz):
     assert_close(f_d.grad.cpu(), f_c.grad, 1e-5, "group bwd")
 
 
+@pytest.mark.parametrize("c,k,ordered", [(32, 8, False), (32, 8, True), (64, 16, True), (8, 4, False), (32, 12, True), (16, 64, False)])
+def test_group_with_xyz_rows_staged_through_lds(hip, oracle_backend, c, k, ordered):
+    """grouping(with_xyz) for c % 4 == 0, nsample % 4 == 0 assembles the rows of a few query points in LDS and writes them as whole
+    aligned lines (gather_ops.hip, group_fwd_lds): bit-identical to the oracle's rows, with and without a visiting order on the
+    table, -1 placeholders included, a last block with fewer points than the others."""
+    from pointcloudpdf_amd import _native
+
+    sizes = [611, 1302]
+    n = sum(sizes)
+    xyz = cloud(n, 21 + c)
+    off = offs(sizes)
+    idx, _ = oracle_backend.knn_query(k, xyz, xyz, off, off)
+    idx[::5, -2:] = -1
+    g = torch.Generator().manual_seed(c + k)
+    feat = torch.randn(n, c, generator=g)
+    new_xyz = xyz + 0.02
+    from pointcloudpdf_amd import pointops
+
+    prev = _native._set_backend_for_testing(oracle_backend)
+    try:
+        want = pointops.grouping(idx, feat, xyz, new_xyz, with_xyz=True)   # the reference's composition, on the CPU
+    finally:
+        _native._set_backend_for_testing(prev)
+    idx_d = idx.to(DEV)
+    if ordered:
+        _native.attach_order(idx_d, torch.randperm(n, generator=g).to(torch.int32).to(DEV))
+    got = hip.group_forward(feat.to(DEV), xyz.to(DEV), new_xyz.to(DEV), idx_d, True).cpu()
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("c,k", [(32, 3), (64, 3), (7, 5), (512, 3)])
 def test_interpolation2_fwd_bwd(hip, oracle_backend, c, k):
     xyz = cloud(3000, 4)
