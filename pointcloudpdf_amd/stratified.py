@@ -25,12 +25,17 @@ import os
 
 import torch
 import torch.nn as nn
-
 import torch.nn.functional as F
 
 from . import _native, dense
 from .pointops2 import pointops
 from .registry import MODELS
+
+
+# PDFOPS_ST_LINEAR=hip routes qkv / proj / fc1 / fc2 through csrc/rowlin.hip.  Measured in round 4 (2 x 80k points, one process): 73.6 ms per
+# step against 67.6 with the library GEMMs + split-K weight gradient -- the widths of this model (48 / 96 / 192 / 384, 3x and 4x expansions)
+# only have the generic tiled kernel there, not the rl2:: kernels of PT-v1's 32 .. 512 square layers.  Default: library GEMMs.
+ST_HIP_LINEAR = os.environ.get("PDFOPS_ST_LINEAR", "torch") == "hip"
 
 
 class _Linear(nn.Linear):
@@ -39,6 +44,11 @@ class _Linear(nn.Linear):
     call at 160k x 48 -> 144; 7.8 ms of the 93 ms ST-v1m1 step, profiles/r03_i_stratified_kernel_trace_stats.txt)."""
 
     def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() in (2, 3) and dense.HIP_LINEAR and ST_HIP_LINEAR:
+            # (round 4) forward, input gradient and weight gradient on the library's own matrix-core kernels (csrc/rowlin.hip): no rocBLAS
+            # GEMM left under qkv / proj / fc1 / fc2 and the heads
+            y = dense.linear(self, x.view(-1, x.shape[-1]))
+            return y if x.dim() == 2 else y.view(x.shape[0], x.shape[1], -1)
         if x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and x.is_contiguous() and x.dim() in (2, 3):
             rows = x.shape[0] if x.dim() == 2 else x.shape[0] * x.shape[1]
             if rows >= dense._MIN_ROWS:
