@@ -134,7 +134,7 @@ __global__ __launch_bounds__(BLOCK) void knn_scan_kernel(int m, int k, const flo
     }
 }
 
-constexpr int REDO_WAVE_MAX = 8192;
+constexpr int REDO_WAVE_MAX = 8192, REDO_UNR = 8;
 
 // The same exact process for a SHORT list of queries (the grid path's redo list: typically 0-10 of 10^5..10^6 queries),
 // one WAVE per query: 64 candidates are evaluated at a time in index order, a ballot marks the ones below the current heap
@@ -160,23 +160,31 @@ __global__ __launch_bounds__(64) void knn_redo_wave_kernel(int m, int k, const f
         __builtin_amdgcn_s_barrier();
         float thr = 1e10f;
         const int start = bt == 0 ? 0 : offset[bt - 1], end = offset[bt];
-        for (int i0 = start; i0 < end; i0 += 64) {
-            const int i = i0 + lane;
-            float d = 3.0e38f;
-            if (i < end) {
+        // REDO_UNR chunks of 64 candidates are loaded together (round 4: one chunk per trip was one L2 round trip per 64 points -- ~100 us
+        // per table at 100k-point scenes for a handful of queries, 1.5 ms per 12-batch pre-pass); they are then consumed in index order
+        for (int c0 = start; c0 < end; c0 += 64 * REDO_UNR) {
+            float dch[REDO_UNR];
+#pragma unroll
+            for (int u = 0; u < REDO_UNR; ++u) {
+                const int i = min(c0 + 64 * u + lane, end - 1);   // (clamped address; masked below)
                 const float x = xyz[3 * (size_t)i + 0], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
-                d = pdf_sqdist3(qx - x, qy - y, qz - z);
+                dch[u] = pdf_sqdist3(qx - x, qy - y, qz - z);
             }
-            unsigned long long mask = __builtin_amdgcn_ballot_w64(i < end && d < thr);
-            while (mask) {
-                const int j = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const float dj = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(d), j));
-                if (dj < thr) {                       // wave-uniform: every lane performs the same sift on the shared heap
-                    heap_sift_root<1>(hd, hi, 0, k, dj, i0 + j);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    __builtin_amdgcn_s_barrier();
-                    thr = hd[0];
+#pragma unroll
+            for (int u = 0; u < REDO_UNR; ++u) {
+                const int i0 = c0 + 64 * u;
+                const float d = dch[u];
+                unsigned long long mask = __builtin_amdgcn_ballot_w64(i0 + lane < end && d < thr);
+                while (mask) {
+                    const int j = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const float dj = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(d), j));
+                    if (dj < thr) {                       // wave-uniform: every lane performs the same sift on the shared heap
+                        heap_sift_root<1>(hd, hi, 0, k, dj, i0 + j);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_s_barrier();
+                        thr = hd[0];
+                    }
                 }
             }
         }
