@@ -36,6 +36,9 @@ constexpr int REL_BITS = 22;
 constexpr unsigned REL_MASK = (1u << REL_BITS) - 1u;
 constexpr int PB = 256;            // block size of the preparation kernels
 constexpr int MSTRIDE = 16;        // dwords of metadata per bucket (box 6, best key 2, best xyz 3, second-best key 2)
+constexpr int FPS_MULTI_MIN = 768;  // smallest largest-scene size for the several-samples-per-round kernels (3,072 before the rounds could take their
+                                    // candidates bucket by bucket: a 1,562-point scene has 2 super-buckets but 25 buckets)
+constexpr int BKC_MAX = 256;       // k_fps_mw: scenes with at most this many buckets take their round's candidates bucket by bucket
 
 struct Layout {  // byte offsets into the caller's workspace
     size_t stats, bbox, hist, cursor, cell, pts, kb, meta, total;
@@ -761,6 +764,41 @@ __global__ __launch_bounds__(64 * NW) void k_fps_multi(const int *__restrict__ o
 #undef FPS_TICK
 }
 
+// k_fps_mw, RANK: for every unit (super-bucket or bucket) the units of this wave's slice with a greater key, added to rank[] in LDS; then
+// (wave 0, after a barrier) the units of rank < KMAX placed best first into cand[].  N: units per lane.
+template <int N, int NW>
+__device__ __forceinline__ void rank_count(const Rec2 &U, int nu, unsigned *rank, int lane, int wave) {
+    const int js = (nu + NW - 1) / NW, j0 = wave * js, j1 = min(nu, j0 + js);
+    unsigned long long mykey[N];
+    unsigned above[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int s = lane + 64 * i;
+        mykey[i] = s < nu ? (((unsigned long long)U.khi[s] << 32) | U.klo[s]) : ~0ull;
+        above[i] = 0u;
+    }
+    for (int jj = j0; jj < j1; ++jj) {
+        const unsigned long long kj = ((unsigned long long)U.khi[jj] << 32) | U.klo[jj];
+#pragma unroll
+        for (int i = 0; i < N; ++i) above[i] += kj > mykey[i] ? 1u : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        if (above[i]) atomicAdd(&rank[lane + 64 * i], above[i]);   // (above != 0 only for s < nu)
+}
+template <int N, int KMAX>
+__device__ __forceinline__ void rank_place(const Rec2 &U, int nu, unsigned *rank, int *cand, int lane) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int s = lane + 64 * i;
+        if (s < nu) {
+            const unsigned rk = rank[s];
+            rank[s] = 0u;
+            if (rk < (unsigned)KMAX && (U.khi[s] | U.klo[s]) != 0u) cand[rk] = s;   // (keys are unique unless 0: ranks too)
+        }
+    }
+}
+
 // ---------------------------------------------------------------- one centre per wave
 // k_fps_multi still derives every list redundantly in every wave; measured (s_memtime, 100k-point scene, K = 8): candidate
 // selection 11.6k cycles per round, lists 13.7k, updates 24.7k, super refresh 8.8k -- instruction latency of ONE wave,
@@ -798,8 +836,9 @@ __global__ __launch_bounds__(64 * NW) void k_fps_mw(const int *__restrict__ offs
     unsigned *cnt = claimS + ns_cap;                                                             // [4]: n_bk[2], n_sup[2] by round parity
     float *cent = reinterpret_cast<float *>(cnt + 4);                                            // [3 * 16] the round's centres
     int *cent_n = reinterpret_cast<int *>(cent + 3 * 16);                                      // [4]
-    unsigned *rank = reinterpret_cast<unsigned *>(cent_n + 4);                                   // [ns_cap] supers with a greater key (RANK)
-    int *cand = reinterpret_cast<int *>(rank + ns_cap);                                          // [16] the round's candidate supers, best first
+    const int nr_cap = nb_cap <= BKC_MAX ? nb_cap : ns_cap;
+    unsigned *rank = reinterpret_cast<unsigned *>(cent_n + 4);                                   // [nr_cap] units with a greater key (RANK)
+    int *cand = reinterpret_cast<int *>(rank + nr_cap);                                          // [16] the round's candidate units, best first
     unsigned *c_s2h = reinterpret_cast<unsigned *>(cand + 16), *c_s2l = c_s2h + 16;              // [16] [16] their supers' second-best keys
     unsigned short *blist = reinterpret_cast<unsigned short *>(c_s2l + 16);                      // [nb_cap + 64] shared
     unsigned short *slist = blist + nb_cap + 64;                                                 // [ns_cap + 64] shared
@@ -843,8 +882,8 @@ __global__ __launch_bounds__(64 * NW) void k_fps_mw(const int *__restrict__ offs
         S.k2hi[s] = (unsigned)(second >> 32); S.k2lo[s] = (unsigned)second;
         S.bx[s] = B.bx[bi]; S.by[s] = B.by[bi]; S.bz[s] = B.bz[bi];
         claimS[s] = 0u;
-        rank[s] = 0u;
     }
+    for (int i = tid; i < nr_cap; i += 64 * NW) rank[i] = 0u;
     __syncthreads();
 
     if (tid == 0) idx[sc.start_m] = sc.start_n;
@@ -858,46 +897,29 @@ __global__ __launch_bounds__(64 * NW) void k_fps_mw(const int *__restrict__ offs
         // greater key (broadcast LDS reads, LDS adds); after barrier R wave 0 places the supers of rank < KMAX, lane t takes candidate t
         // and all tests run at once.
         if (RANK) {
-            const int js = (ns + NW - 1) / NW, j0 = wave * js, j1 = min(ns, j0 + js);
-            unsigned long long mykey[NSL];
-            unsigned above[NSL];
-#pragma unroll
-            for (int i = 0; i < NSL; ++i) {
-                const int s = lane + 64 * i;
-                mykey[i] = s < ns ? (((unsigned long long)S.khi[s] << 32) | S.klo[s]) : ~0ull;
-                above[i] = 0u;
-            }
-            for (int jj = j0; jj < j1; ++jj) {
-                const unsigned long long kj = ((unsigned long long)S.khi[jj] << 32) | S.klo[jj];
-#pragma unroll
-                for (int i = 0; i < NSL; ++i) above[i] += kj > mykey[i] ? 1u : 0u;
-            }
-#pragma unroll
-            for (int i = 0; i < NSL; ++i)
-                if (above[i]) atomicAdd(&rank[lane + 64 * i], above[i]);   // (above != 0 only for s < ns)
+            // The candidate UNITS: super-buckets (1,024 points) at level 1; the buckets themselves (64 points) when the scene has at most
+            // BKC_MAX of them (levels 2+) -- a scene of 25k points has 25 supers, one of 6,250 has 7, which capped a round at that many
+            // centres and let test (a) (second-best key of a 1,024-point unit) end it earlier still.  The proof of k_fps_multi holds for any
+            // partition into units that carry their best and second-best key.
+            const bool bkc = nb_cap <= BKC_MAX;   // (by the launch's largest scene: the rank array is sized for it; either way the same samples)
+            const Rec2 &U_ = bkc ? B : S;
+            const int nu = bkc ? nb : ns;
+            if (bkc) rank_count<BKC_MAX / 64, NW>(U_, nu, rank, lane, wave); else rank_count<NSL, NW>(U_, nu, rank, lane, wave);
             __syncthreads();  // R: ranks complete
             if (wave == 0) {
                 constexpr int G = 64 / KMAX;          // lane groups of test (b): lane = (g, t)
                 const int kmax = min(KMAX, sc.m - j);
-#pragma unroll
-                for (int i = 0; i < NSL; ++i) {
-                    const int s = lane + 64 * i;
-                    if (s < ns) {
-                        const unsigned rk = rank[s];
-                        rank[s] = 0u;
-                        if (rk < (unsigned)KMAX && (S.khi[s] | S.klo[s]) != 0u) cand[rk] = s;   // (keys are unique unless 0: ranks too)
-                    }
-                }
+                if (bkc) rank_place<BKC_MAX / 64, KMAX>(U_, nu, rank, cand, lane); else rank_place<NSL, KMAX>(U_, nu, rank, cand, lane);
                 lds_fence();
                 const int t = lane % KMAX, g = lane / KMAX;
                 const int cs = cand[t];
                 const bool valid = cs >= 0 && t < kmax;
                 const int c0 = cs >= 0 ? cs : 0;
-                const unsigned kh = S.khi[c0], kl = S.klo[c0];
-                const float x = S.bx[c0], y = S.by[c0], z = S.bz[c0];
+                const unsigned kh = U_.khi[c0], kl = U_.klo[c0];
+                const float x = U_.bx[c0], y = U_.by[c0], z = U_.bz[c0];
                 if (lane < KMAX) {
                     cent[3 * t + 0] = x; cent[3 * t + 1] = y; cent[3 * t + 2] = z;
-                    c_s2h[t] = valid ? S.k2hi[c0] : 0u; c_s2l[t] = valid ? S.k2lo[c0] : 0u;
+                    c_s2h[t] = valid ? U_.k2hi[c0] : 0u; c_s2l[t] = valid ? U_.k2lo[c0] : 0u;
                 }
                 lds_fence();
                 bool fail = !valid;
@@ -1232,14 +1254,14 @@ extern "C" int pdf_farthest_point_sampling_bucketed(int b, int n, int n_total, c
     // several samples per round (k_fps_multi) when its larger records fit the 160 KB of LDS (scenes up to ~180k points)
     const size_t lds2 = (size_t)(REC2 * nb_cap + REC2 * ns_cap) * 4 + (size_t)(2 * (((ns_cap + 63) & ~63) + 64) + nb_cap + 64) * 2;
     const char *env_k = getenv("PDFOPS_FPS_K");    // tuning knob (samples per round): 1 = the one-sample kernel, 4 or 8
-    const int kmulti = env_k ? atoi(env_k) : (n >= 3072 ? 8 : 1);
+    const int kmulti = env_k ? atoi(env_k) : (n >= FPS_MULTI_MIN ? 8 : 1);
     // one centre per wave (k_fps_mw<NW>): records + claim tags + shared / private lists
     const char *env_mw = getenv("PDFOPS_FPS_MW");   // tuning knob: 0 = k_fps_multi, 8 / 16 = waves (= centres per round) of k_fps_mw
     // measured (2 scenes, levels 100k / 25k / 6250 / 1562 points): 16 waves 33.0 / 10.0 / 3.9 / 1.7 ms, 8 waves 41.3 / 10.8 / 3.6 / 1.5 ms,
     // the one-sample kernel 91 / 20 / 4.9 / 1.2 ms -> by the size of the largest scene
-    const int mw = env_mw ? atoi(env_mw) : (n >= 16384 ? 16 : n >= 3072 ? 8 : 0);
+    const int mw = env_mw ? atoi(env_mw) : (n >= 16384 ? 16 : n >= FPS_MULTI_MIN ? 8 : 0);
     const int mww = mw >= 16 ? 16 : 8;
-    const size_t lds3 = (size_t)(REC2 * nb_cap + REC2 * ns_cap + nb_cap + ns_cap + 4 + 3 * 16 + 4 + ns_cap + 3 * 16) * 4 +
+    const size_t lds3 = (size_t)(REC2 * nb_cap + REC2 * ns_cap + nb_cap + ns_cap + 4 + 3 * 16 + 4 + (nb_cap <= BKC_MAX ? nb_cap : ns_cap) + 3 * 16) * 4 +
                         (size_t)(nb_cap + 64 + ns_cap + 64 + mww * (((ns_cap + 63) & ~63) + 64)) * 2;
     if (kmulti > 1 && mw != 0 && lds3 <= 160 * 1024) {
 #define PDF_LAUNCH_FPS_MW(NW_, RANK_)                                                                                     \

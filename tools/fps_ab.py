@@ -7,7 +7,7 @@ scenes = 2
 batch = synthetic.make_batch([100000] * scenes, device="cuda")
 xyz, off = batch["coord"], batch["offset"]
 sizes = [100000] * scenes
-for lvl in range(3):
+for lvl in range(4):
     msizes = [s // 4 for s in sizes]
     noff = torch.tensor(msizes, device="cuda").cumsum(0).int()
     idx = be.farthest_point_sampling(xyz, off, noff, max(sizes), sum(msizes))
