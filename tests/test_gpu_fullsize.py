@@ -26,7 +26,7 @@ pytestmark = pytest.mark.gpu
 FEATURE_TOL = 1e-4
 BUFFER_TOL = 1e-4
 GRAD_L2_TOL = 1e-3     # Frobenius-norm bar for every parameter gradient against the fp64 evaluation ...
-GRAD_REF_FACTOR = 3.0  # ... unless the reference-style fp32 evaluation itself is further from fp64: then at most this multiple of ITS error
+GRAD_REF_FACTOR = 2.0  # ... unless the reference-style fp32 evaluation itself is further from fp64: then at most this multiple of ITS error
 GRAD_SHARE = 0.75      # share of the parameters that must meet that per-parameter bar (the rest: distribution / tail bounds below)
 
 
@@ -122,19 +122,19 @@ def test_full_size_step_matches_cpu_oracle_path(oracle_backend, kind, points):
     order = sorted(e_dev, key=e_dev.get, reverse=True)
     print(f"gradients: {len(e_dev)} checked, {len(zeros)} analytically zero; median gradient scale {scale:.2e}")
     print("worst HIP-vs-fp64 (l2 rel; fp32 composition vs fp64 in brackets):", [(n, f"{e_dev[n]:.1e}", f"[{e_ref[n]:.1e}]") for n in order[:10]])
-    print("HIP worse than the fp32 composition by more than 3x:", [(n, f"{e_dev[n]:.1e}", f"[{e_ref[n]:.1e}]") for n in order if e_dev[n] > 3 * e_ref[n] and e_dev[n] > 1e-4][:10])
+    print("HIP worse than the fp32 composition by more than 2x:", [(n, f"{e_dev[n]:.1e}", f"[{e_ref[n]:.1e}]") for n in order if e_dev[n] > 2 * e_ref[n] and e_dev[n] > 1e-4][:10])
     print("share of gradients within 1e-3 of fp64: HIP", sum(v <= 1e-3 for v in e_dev.values()) / len(e_dev), "fp32 composition", sum(v <= 1e-3 for v in e_ref.values()) / len(e_ref))
     assert len(e_dev) > 400
     dv, rf = np.array([e_dev[n] for n in order]), np.array([e_ref[n] for n in order])
     stats = dict(median=(float(np.median(dv)), float(np.median(rf))), p90=(float(np.percentile(dv, 90)), float(np.percentile(rf, 90))),
-                 max=(float(dv.max()), float(rf.max())), share_within_3x_of_reference=float(np.mean(dv <= np.maximum(GRAD_L2_TOL, GRAD_REF_FACTOR * rf))))
+                 max=(float(dv.max()), float(rf.max())), share_within_2x_of_reference=float(np.mean(dv <= np.maximum(GRAD_L2_TOL, GRAD_REF_FACTOR * rf))))
     print("gradient error statistics (HIP, fp32 composition):", stats)
     # What the numbers say (MI355X, both configs): the reference-style fp32 composition is itself 2e-3 .. 1e-2 (median over the
     # parameters) and up to 5e-2 away from the fp64 evaluation of the same network at these sizes -- 50 layers of train-mode
     # BatchNorm backward (dy - mean(dy) - xhat * mean(dy * xhat)) amplify fp32 rounding --, so no fp32 implementation can be held to
     # 1e-3 here; the HIP path has to sit in the SAME error distribution:
-    # (1) the bulk: as close to fp64 as the reference-style fp32 evaluation (x3, or 1e-3), parameter by parameter
-    assert stats["share_within_3x_of_reference"] >= GRAD_SHARE, stats
+    # (1) the bulk: as close to fp64 as the reference-style fp32 evaluation (x2, or 1e-3), parameter by parameter
+    assert stats["share_within_2x_of_reference"] >= GRAD_SHARE, stats
     # (2) the distribution: median and 90th percentile within the same order as the reference composition's (they vary by ~2x from
     #     scene to scene on either side)
     assert stats["median"][0] <= 4.0 * stats["median"][1] and stats["p90"][0] <= 4.0 * stats["p90"][1], stats
