@@ -69,6 +69,11 @@ int pdf_knn_grid_supported(int nsample);
 int pdf_knn_query_ws(int m, int nsample, int n, const float *xyz, const float *new_xyz, const int *offset,
                      const int *new_offset, int b, int *idx, float *dist2, void *workspace, long workspace_bytes,
                      void *stream);
+/* The two halves of pdf_knn_query_ws on their own: one grid per set of SOURCE points (pdf_knn_grid_build), any number of query sets and
+ * nsample values (3 / 8 / 16) over it (pdf_knn_query_grid).  workspace_bytes >= pdf_knn_workspace_bytes(b, n, m) for the largest m. */
+int pdf_knn_grid_build(int n, const float *xyz, const int *offset, int b, void *workspace, long workspace_bytes, void *stream);
+int pdf_knn_query_grid(int m, int nsample, int n, const float *xyz, const float *new_xyz, const int *offset, const int *new_offset, int b,
+                       int *idx, float *dist2, void *workspace, long workspace_bytes, void *stream);
 /* measurement aid: the same with the grid kernel counting the candidate distances it evaluates (*pairs, device counter zeroed by the
  * caller, += count).  The grid prunes by design, so "pairs per second" of this path must be quoted on EVALUATED pairs, not on the
  * m * n_scene pairs of the brute force it replaces. */

@@ -663,6 +663,10 @@ class HipBackend(CBackend):
         lib.pdf_pt_layer_bwd_sums_floats.argtypes = [c_int]
         lib.pdf_pt_layer_forward.restype = c_int
         lib.pdf_pt_layer_forward.argtypes = [c_int, c_int, c_int] + [c_void_p] * 8 + [c_int, ctypes.c_float, ctypes.c_float] + [c_void_p] * 5 + [c_int, c_void_p, c_void_p]
+        lib.pdf_knn_grid_build.restype = c_int
+        lib.pdf_knn_grid_build.argtypes = [c_int, c_void_p, c_void_p, c_int, c_void_p, c_long, c_void_p]
+        lib.pdf_knn_query_grid.restype = c_int
+        lib.pdf_knn_query_grid.argtypes = [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_long, c_void_p]
         lib.pdf_pt_layer_backward.restype = c_int
         lib.pdf_pt_layer_backward.argtypes = [c_int, c_int, c_int] + [c_void_p] * 19 + [c_int] + [c_void_p] * 2 + [c_int, c_void_p, c_void_p, c_void_p]
         self.fps_mode = os.environ.get("PDFOPS_FPS", "bucketed")  # "bucketed" | "plain"
@@ -778,7 +782,35 @@ class HipBackend(CBackend):
         self._call("seg_sum_weighted_ordered", input.shape[0], c, ns, w_c, grad_output, weight, off, ent, base, src_order_of(idx, input.shape[0]), gi)
         return gi, gp, gw
 
-    def knn_query(self, nsample, xyz, new_xyz, offset, new_offset):
+    def knn_grid(self, xyz, offset, m_max):
+        """The uniform grid over the source points ``xyz`` (csrc/knn_grid.hip) as a workspace tensor that ``knn_query(..., grid=)`` takes for
+        any query set of up to ``m_max`` points and nsample 3 / 8 / 16; None where the grid path does not apply."""
+        n, b = xyz.shape[0], offset.shape[0]
+        if self.knn_mode == "scan" or b > self.KNN_GRID_MAX_SCENES or n < 1:
+            return None
+        _check(xyz, torch.float32, "xyz"); _check(offset, torch.int32, "offset")
+        require_current_device(xyz, offset)
+        nbytes = int(self.lib.pdf_knn_workspace_bytes(b, n, int(max(m_max, n))))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=xyz.device)
+        rc = self.lib.pdf_knn_grid_build(n, self._ptr(xyz), self._ptr(offset), b, self._ptr(ws), nbytes, c_void_p(raw_stream()))
+        if rc != 0:
+            raise PdfOpsError(f"pdf_knn_grid_build failed with status {rc}")
+        return ws
+
+    def knn_query(self, nsample, xyz, new_xyz, offset, new_offset, grid=None):
+        if grid is not None and self.lib.pdf_knn_grid_supported(int(nsample)) and new_xyz.shape[0] > 0:
+            _check(new_xyz, torch.float32, "new_xyz"); _check(new_offset, torch.int32, "new_offset")
+            require_current_device(xyz, new_xyz, offset, new_offset)
+            n, m, b = xyz.shape[0], new_xyz.shape[0], offset.shape[0]
+            if int(self.lib.pdf_knn_workspace_bytes(b, n, m)) > grid.numel():
+                raise PdfOpsError("knn_query: the grid workspace was built for fewer queries")
+            idx = self._new(xyz, (m, nsample), torch.int32)
+            dist2 = self._new(xyz, (m, nsample), torch.float32)
+            rc = self.lib.pdf_knn_query_grid(m, int(nsample), n, self._ptr(xyz), self._ptr(new_xyz), self._ptr(offset), self._ptr(new_offset), b,
+                                             self._ptr(idx), self._ptr(dist2), self._ptr(grid), grid.numel(), c_void_p(raw_stream()))
+            if rc != 0:
+                raise PdfOpsError(f"pdf_knn_query_grid failed with status {rc}")
+            return idx, dist2
         if self.knn_mode == "scan" or not self.lib.pdf_knn_grid_supported(int(nsample)):
             return super().knn_query(nsample, xyz, new_xyz, offset, new_offset)
         _check(xyz, torch.float32, "xyz"); _check(new_xyz, torch.float32, "new_xyz")

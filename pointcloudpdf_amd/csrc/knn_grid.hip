@@ -422,16 +422,9 @@ extern "C" long pdf_knn_workspace_bytes(int b, int n, int m) {
 // nsample values served by the grid path (others fall back to the scan inside pdf_knn_query_ws)
 extern "C" int pdf_knn_grid_supported(int nsample) { return nsample == 3 || nsample == 8 || nsample == 16; }
 
-static int knn_query_ws(int m, int nsample, int n, const float *xyz, const float *new_xyz, const int *offset,
-                        const int *new_offset, int b, int *idx, float *dist2, void *workspace,
-                        long workspace_bytes, unsigned long long *pairs, void *stream) {
-    if (m == 0) return PDF_OK;   // (0-size tensors carry null pointers: not an argument error)
-    if (m < 0 || n < 0 || b < 1 || !xyz || !new_xyz || !offset || !new_offset || !idx || !dist2) return PDF_ERR_BAD_ARG;
-    if (nsample < 1 || nsample > 128) return PDF_ERR_NSAMPLE;
-    if (m == 0) return PDF_OK;
-    if (!pdf_knn_grid_supported(nsample) || b > 64)
-        return pairs ? PDF_ERR_UNSUPPORTED : pdf_knn_query(m, nsample, xyz, new_xyz, offset, new_offset, b, idx, dist2, stream);
-    const kg::Layout L = kg::make_layout(b, n, m);
+// the grid of the SOURCE points (bounding boxes, cell size, counting sort of the points by cell) in `workspace`
+static int knn_grid_build(int n, const float *xyz, const int *offset, int b, void *workspace, long workspace_bytes, void *stream) {
+    const kg::Layout L = kg::make_layout(b, n, 0);
     if (!workspace || workspace_bytes < (long)L.total) return PDF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     char *ws = static_cast<char *>(workspace);
@@ -440,10 +433,7 @@ static int knn_query_ws(int m, int nsample, int n, const float *xyz, const float
     unsigned *cursor = reinterpret_cast<unsigned *>(ws + L.cursor);
     int *cell_of = reinterpret_cast<int *>(ws + L.cell_of);
     float4 *sorted = reinterpret_cast<float4 *>(ws + L.sorted);
-    int *redo = reinterpret_cast<int *>(ws + L.redo);
     hipError_t e = hipMemsetAsync(ws + L.cell_start, 0, L.cell_of - L.cell_start, s);  // counts + cursors
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(redo, 0, 16, s);
     if (e != hipSuccess) return (int)e;
     // cell size: `ppc` points per cell if the points filled the bounding box (they lie on surfaces, so occupied cells hold more)
     static const float ppc_env = [] { const char *v = getenv("PDFOPS_KNN_PPC"); return v ? (float)atof(v) : 0.f; }();
@@ -452,6 +442,22 @@ static int knn_query_ws(int m, int nsample, int n, const float *xyz, const float
     kg::k_grid_hist<<<pdf_divup(n, kg::PB), kg::PB, 0, s>>>(n, b, xyz, offset, grids, cell_start, cell_of);
     kg::k_grid_scan<<<b, 1024, 0, s>>>(grids, cell_start);
     kg::k_grid_scatter<<<pdf_divup(n, kg::PB), kg::PB, 0, s>>>(n, xyz, cell_of, cell_start, cursor, sorted);
+    return pdf_launch_status();
+}
+
+// the queries over a grid built by knn_grid_build in the same workspace (any number of query sets, any supported nsample)
+static int knn_query_grid(int m, int nsample, int n, const float *xyz, const float *new_xyz, const int *offset, const int *new_offset, int b,
+                          int *idx, float *dist2, void *workspace, long workspace_bytes, unsigned long long *pairs, void *stream) {
+    const kg::Layout L = kg::make_layout(b, n, m);
+    if (!workspace || workspace_bytes < (long)L.total) return PDF_ERR_BAD_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char *ws = static_cast<char *>(workspace);
+    kg::SceneGrid *grids = reinterpret_cast<kg::SceneGrid *>(ws + L.grid);
+    unsigned *cell_start = reinterpret_cast<unsigned *>(ws + L.cell_start);
+    float4 *sorted = reinterpret_cast<float4 *>(ws + L.sorted);
+    int *redo = reinterpret_cast<int *>(ws + L.redo);
+    hipError_t e = hipMemsetAsync(redo, 0, 16, s);
+    if (e != hipSuccess) return (int)e;
     const int grid = pdf_divup(m, kg::PB);
     const bool self = new_xyz == xyz && new_offset == offset && m == n && getenv("PDFOPS_KNN_NO_SELF") == nullptr;
 #define PDF_KQ2(KP1_, SELF_, COUNT_) kg::k_grid_query<KP1_, SELF_, COUNT_><<<grid, kg::PB, 0, s>>>(m, b, new_xyz, new_offset, grids, cell_start, sorted, idx, dist2, redo, pairs)
@@ -473,6 +479,34 @@ static int knn_query_ws(int m, int nsample, int n, const float *xyz, const float
     return pdf_knn_query_list(m, nsample, xyz, new_xyz, offset, new_offset, b, idx, dist2, redo + 4, redo, stream);
 }
 
+static int knn_query_ws(int m, int nsample, int n, const float *xyz, const float *new_xyz, const int *offset,
+                        const int *new_offset, int b, int *idx, float *dist2, void *workspace,
+                        long workspace_bytes, unsigned long long *pairs, void *stream) {
+    if (m == 0) return PDF_OK;   // (0-size tensors carry null pointers: not an argument error)
+    if (m < 0 || n < 0 || b < 1 || !xyz || !new_xyz || !offset || !new_offset || !idx || !dist2) return PDF_ERR_BAD_ARG;
+    if (nsample < 1 || nsample > 128) return PDF_ERR_NSAMPLE;
+    if (!pdf_knn_grid_supported(nsample) || b > 64)
+        return pairs ? PDF_ERR_UNSUPPORTED : pdf_knn_query(m, nsample, xyz, new_xyz, offset, new_offset, b, idx, dist2, stream);
+    if (!workspace || workspace_bytes < (long)kg::make_layout(b, n, m).total) return PDF_ERR_BAD_ARG;
+    const int rc = knn_grid_build(n, xyz, offset, b, workspace, workspace_bytes, stream);
+    if (rc != PDF_OK) return rc;
+    return knn_query_grid(m, nsample, n, xyz, new_xyz, offset, new_offset, b, idx, dist2, workspace, workspace_bytes, pairs, stream);
+}
+
+// The two halves on their own: ONE grid per set of source points, any number of query sets over it (the geometry pre-pass asks 2-3 tables of
+// every level: 14 grid builds per pre-pass were 2.0 + 0.6 of its 17 ms that are not farthest-point sampling).  The workspace of the build
+// must be at least pdf_knn_workspace_bytes(b, n, m) for the largest m queried over it.  nsample must be one pdf_knn_grid_supported accepts.
+extern "C" int pdf_knn_grid_build(int n, const float *xyz, const int *offset, int b, void *workspace, long workspace_bytes, void *stream) {
+    if (n < 1 || b < 1 || b > 64 || !xyz || !offset) return PDF_ERR_BAD_ARG;
+    return knn_grid_build(n, xyz, offset, b, workspace, workspace_bytes, stream);
+}
+extern "C" int pdf_knn_query_grid(int m, int nsample, int n, const float *xyz, const float *new_xyz, const int *offset, const int *new_offset, int b,
+                                  int *idx, float *dist2, void *workspace, long workspace_bytes, void *stream) {
+    if (m == 0) return PDF_OK;
+    if (m < 0 || n < 1 || b < 1 || b > 64 || !xyz || !new_xyz || !offset || !new_offset || !idx || !dist2) return PDF_ERR_BAD_ARG;
+    if (!pdf_knn_grid_supported(nsample)) return PDF_ERR_NSAMPLE;
+    return knn_query_grid(m, nsample, n, xyz, new_xyz, offset, new_offset, b, idx, dist2, workspace, workspace_bytes, nullptr, stream);
+}
 
 extern "C" int pdf_knn_query_ws(int m, int nsample, int n, const float *xyz, const float *new_xyz, const int *offset,
                                 const int *new_offset, int b, int *idx, float *dist2, void *workspace,

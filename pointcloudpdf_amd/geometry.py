@@ -47,6 +47,9 @@ def propagate_tag(src, dst):
     return dst
 
 
+_SHARE_GRIDS = os.environ.get("PDFOPS_KNN_SHARE_GRIDS", "1") != "0"   # 0: one grid build per table (rounds 1-3; A/B runs)
+
+
 class _Level:
     __slots__ = ("p", "o", "o_host", "n_max")
 
@@ -69,6 +72,8 @@ class Geometry:
         o_dev = offset.to(device=coord.device, dtype=torch.int32).contiguous()
         self.levels = []
         self._memo = {}
+        self._grids = {}          # level -> (kNN grid workspace of the level's points, largest query count it serves); pre-pass only
+        self._share_grids = False
         self._add_level(coord, o_dev, offset_host)
 
     # ------------------------------------------------------------------ levels
@@ -130,10 +135,27 @@ class Geometry:
         if key not in self._memo:
             S, Q = self.levels[src_level], self.levels[query_level]
             be = _native.backend_for(S.p)
-            self._memo[key] = be.knn_query(nsample, S.p, Q.p, S.o, Q.o)
+            grid = self._grid(be, src_level, Q.p.shape[0])
+            self._memo[key] = be.knn_query(nsample, S.p, Q.p, S.o, Q.o, grid=grid) if grid is not None else be.knn_query(nsample, S.p, Q.p, S.o, Q.o)
             if S.p.is_cuda:   # the forward gathers visit the queries in Morton order (neighbouring queries share rows: L2 hits)
                 _native.attach_order(self._memo[key][0], self.order(query_level), self.order(src_level))
         return self._memo[key]
+
+    def _grid(self, be, level, m):
+        """The kNN grid over a level's points, built once for all the tables that have the level as their SOURCE (self query, the down-sampling
+        query of the next level, the interpolation query of the previous one: 14 builds per pre-pass became 5).  Held only while the
+        pre-pass runs (``precompute`` drops the workspaces: ~8 MB per scene and level)."""
+        if not hasattr(be, "knn_grid") or not getattr(self, "_share_grids", False):   # (views of a grouped pre-pass / static copies never build)
+            return None
+        ws = self._grids.get(level)
+        if ws is None or ws[1] < m:
+            L = self.levels[level]
+            m_max = max(m, L.p.shape[0], self.levels[level - 1].p.shape[0] if level > 0 else 0)
+            t = be.knn_grid(L.p, L.o, m_max)
+            if t is None:
+                return None
+            ws = self._grids[level] = (t, m_max)
+        return ws[0]
 
     def rel_moments(self, nsample, level):
         """Per-scene sums (scenes, 9) float64 of the relative coordinates of the self kNN table (nsample, level, level): the
@@ -250,6 +272,7 @@ class Geometry:
         stream: 4 FPS, 5 self-kNN, 4 down-sampling kNN, 4 (+1 for the U-decoder's level-5 self query) interpolation
         tables -- the 13 distinct kNN tables behind the reference's 31 calls."""
         lvl = 0
+        self._share_grids = _SHARE_GRIDS
         self.knn_dist(nsamples[0], 0, 0)
         for i in range(1, len(strides)):
             new_level, _ = self.down(lvl, strides[i])
@@ -272,6 +295,8 @@ class Geometry:
                     self.inverse(interp_k, i, i - 1)     # interpolation backward (TransitionUp, U-decoder)
                 if recognizer:
                     self.inverse(interp_k, lvl, lvl)
+        self._grids.clear()
+        self._share_grids = False
         return self
 
     # ------------------------------------------------------------------ fixed-address form (hipGraph replay of a captured step)
