@@ -5,4 +5,4 @@ timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_
 timeout 1200 bash tools/pmc_only.sh $TAG
 DB=$(find /tmp/p/kt -name "*.db" | head -1)
 python3 tools/rocpd_stats.py $DB 70 > gpurun_out/${TAG}_kernel_trace_stats.txt
-python3 tools/rocpd_categories.py $DB 18 > gpurun_out/${TAG}_kernel_categories.txt; python3 tools/rocpd_queues.py $DB 12 16 > gpurun_out/${TAG}_kernel_streams.txt
+python3 tools/rocpd_categories.py $DB 12 > gpurun_out/${TAG}_kernel_categories.txt; python3 tools/rocpd_queues.py $DB 12 16 > gpurun_out/${TAG}_kernel_streams.txt

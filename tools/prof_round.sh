@@ -8,7 +8,7 @@ python3 $R/bench.py > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_be
 rocprofv3 --kernel-trace --stats -d /tmp/p/kt -o kt -- python3 $R/bench.py --steps 12 --warmup 6 --no-cpu-baseline --no-ops-roofline --no-latency-sweep > $R/gpurun_out/${TAG}_kt_bench.log 2>&1
 DB=$(find /tmp/p/kt -name "*.db" | head -1)
 python3 $R/tools/rocpd_stats.py $DB 70 > $R/gpurun_out/${TAG}_kernel_trace_stats.txt
-python3 $R/tools/rocpd_categories.py $DB 18 > $R/gpurun_out/${TAG}_kernel_categories.txt; python3 $R/tools/rocpd_queues.py $DB 12 16 > $R/gpurun_out/${TAG}_kernel_streams.txt
+python3 $R/tools/rocpd_categories.py $DB 12 > $R/gpurun_out/${TAG}_kernel_categories.txt; python3 $R/tools/rocpd_queues.py $DB 12 16 > $R/gpurun_out/${TAG}_kernel_streams.txt
 for c in FETCH_SIZE WRITE_SIZE; do
 # (rocprofv3 --pmc occasionally dies with SIGSEGV inside its dispatch interception on this many-kernel, three-thread process -- seen
 #  1 run in 3, never without --pmc -- or hangs after an 'AQL packet is malformed' abort: bounded by `timeout`, retried; the counters come

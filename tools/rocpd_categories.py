@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Group a rocprofv3 kernel trace (rocpd sqlite) into coarse categories: total ms, dispatch count, share.
-Usage: python tools/rocpd_categories.py results.db [steps]"""
+"""Group a rocprofv3 kernel trace (rocpd sqlite) into coarse categories: ms, dispatch count, share -- per STEADY-STATE training step: the
+window between the end of the (last - w)-th and the end of the last optimizer launch (`k_sgd`: one per step) holds exactly w steps; parameter
+initialisation, capture warm-ups and the first group's pre-pass lie outside it (rounds 1-3 divided the whole trace by a step count).
+Usage: python tools/rocpd_categories.py results.db [steps in the window = 12]"""
 import re
 import sqlite3
 import sys
@@ -24,10 +26,21 @@ CATS = [
 
 def main():
     db = sys.argv[1]
-    steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+    w = int(float(sys.argv[2])) if len(sys.argv) > 2 else 12
     c = sqlite3.connect(db)
+    rows = c.execute("select name, start, end from kernels order by end").fetchall()
+    sgd = [r[2] for r in rows if "k_sgd" in r[0]]
+    if len(sgd) > w:
+        t0, t1, steps = sgd[-w - 1], sgd[-1], float(w)
+        print(f"steady-state window: the last {w} of {len(sgd)} optimizer steps, all streams ({(t1 - t0) / 1e6 / w:.3f} ms per step wall on the device timeline)")
+    else:
+        t0, t1, steps = rows[0][1] - 1, rows[-1][2], float(max(len(sgd), 1))
+        print(f"no window of {w} optimizer steps ({len(sgd)} k_sgd launches): whole trace divided by {steps}")
     agg = {}
-    for name, dur in c.execute("select name, (end - start) from kernels"):
+    for name, start, end in rows:
+        if end <= t0 or end > t1:
+            continue
+        dur = end - start
         for cat, pat in CATS:
             if re.search(pat, name):
                 break
