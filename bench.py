@@ -118,8 +118,8 @@ def dense_flops_forward(n1, in_channels=6, num_classes=13, enc_bottlenecks=(1, 2
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--throttle", action="store_true",
                     help="profiling aid: synchronise after every encoder / decoder block (forward and backward), so that at most ~100 "
                          "dispatches are in flight -- rocprofv3 --pmc serialises kernels and its interception dies ('AQL packet is "
@@ -546,6 +546,8 @@ def main():
         first = (warmup % D or D) if D > 0 else None
         return engine.GroupedGeometryLoader(batch_stream(), group=D, first_group=first, threaded=bool(os.environ.get("PDFOPS_PREPASS_THREAD"))), D
 
+    sched_warm = [0]
+
     def fence():
         if world > 1:
             torch.distributed.barrier()
@@ -557,6 +559,8 @@ def main():
     def timed(D, warmup, steps, with_timer=False):
         """W untimed steps, then EXACTLY K steps between barrier + synchronize pairs -> (seconds, last output, region info)."""
         loader, D = make_loader(D, warmup, steps)
+        if D > 0 and st_prefetcher is None:   # allocator pools of the pre-pass streams at their steady state (GroupedGeometryLoader.warm)
+            sched_warm[0] = loader.warm([next(batch_stream()) for _ in range(D)])
         it = iter(loader)
         for _ in range(warmup):
             out = trainer(next(it))
@@ -673,6 +677,8 @@ def main():
             "host_enqueue_ms_per_step": sched.enqueue_s / args.steps * 1e3,   # < ms_per_step: the host runs ahead, the device is the bound
             "hbm_peak_gib": torch.cuda.max_memory_allocated(dev) / 2.0 ** 30,   # (caching-allocator peak of this rank over the whole run)
             "prepass_submit_host_ms": (1e3 * min(sched.submit_host_s)) if sched.submit_host_s else None,   # host time of one group submission (warm)
+            # untimed, before the W warm-up steps: one throw-away group pre-pass per pre-pass stream (allocator pools at their steady state)
+            "prepass_allocator_warmup_groups": sched_warm[0],
             "kernels": ks,
             "roofline": roof,
             "roofline_gather_family": roof2,
