@@ -14,3 +14,11 @@ try:
     d=json.load(open('gpurun_out/${TAG}_bench_$f.json')); print('$f', round(d['ms_per_step'],2), round(d['value']/1e6,2), 'M points/s')
 except Exception as e: print('$f FAILED', e)
 " >> gpurun_out/${TAG}_secondary.txt; done
+timeout 600 python bench.py $X --amp f16 > gpurun_out/${TAG}_bench_amp_f16.json 2> gpurun_out/sec_f16.err
+timeout 600 python bench.py $X --amp bf16 > gpurun_out/${TAG}_bench_amp_bf16.json 2> gpurun_out/sec_bf16.err
+for f in amp_f16 amp_bf16; do python -c "
+import json,sys
+try:
+    d=json.load(open('gpurun_out/${TAG}_bench_$f.json')); print('$f', round(d['ms_per_step'],2), round(d['value']/1e6,2), 'M points/s')
+except Exception as e: print('$f FAILED', e)
+" >> gpurun_out/${TAG}_secondary.txt; done
