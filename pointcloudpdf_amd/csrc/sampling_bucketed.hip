@@ -38,6 +38,7 @@ constexpr int PB = 256;            // block size of the preparation kernels
 constexpr int MSTRIDE = 16;        // dwords of metadata per bucket (box 6, best key 2, best xyz 3, second-best key 2)
 constexpr int FPS_MULTI_MIN = 768;  // smallest largest-scene size for the several-samples-per-round kernels (3,072 before the rounds could take their
                                     // candidates bucket by bucket: a 1,562-point scene has 2 super-buckets but 25 buckets)
+constexpr int TWO_MAX_SUPERS = 64;  // k_fps_mw: largest scene (in super-buckets) that takes its candidates in two levels
 constexpr int BKC_MAX = 256;       // k_fps_mw: scenes with at most this many buckets take their round's candidates bucket by bucket
 
 struct Layout {  // byte offsets into the caller's workspace
@@ -816,7 +817,7 @@ template <int NW, bool RANK>
 __global__ __launch_bounds__(64 * NW) void k_fps_mw(const int *__restrict__ offset, const int *__restrict__ new_offset,
                                                     float4 *__restrict__ pts, const unsigned *__restrict__ kbs,
                                                     const float *__restrict__ meta, int *__restrict__ idx, int nb_cap,
-                                                    unsigned *__restrict__ stats) {
+                                                    unsigned *__restrict__ stats, int two_level) {
     constexpr int KMAX = NW;
     constexpr int UNR = PDF_FPS_MW_UNROLL;   // bucket loads in flight per wave
     constexpr int NSL = (NS_MAX + 63) / 64;   // supers per lane
@@ -840,7 +841,8 @@ __global__ __launch_bounds__(64 * NW) void k_fps_mw(const int *__restrict__ offs
     unsigned *rank = reinterpret_cast<unsigned *>(cent_n + 4);                                   // [nr_cap] units with a greater key (RANK)
     int *cand = reinterpret_cast<int *>(rank + nr_cap);                                          // [16] the round's candidate units, best first
     unsigned *c_s2h = reinterpret_cast<unsigned *>(cand + 16), *c_s2l = c_s2h + 16;              // [16] [16] their supers' second-best keys
-    unsigned short *blist = reinterpret_cast<unsigned short *>(c_s2l + 16);                      // [nb_cap + 64] shared
+    unsigned *rank2 = c_s2l + 16;                                                                // [16 * SUP] buckets of the best supers with a greater key
+    unsigned short *blist = reinterpret_cast<unsigned short *>(rank2 + 16 * SUP);                // [nb_cap + 64] shared
     unsigned short *slist = blist + nb_cap + 64;                                                 // [ns_cap + 64] shared
     const int psl_stride = ((ns_cap + 63) & ~63) + 64;
     unsigned short *pslist = slist + ns_cap + 64 + wave * psl_stride;                            // private per wave
@@ -884,6 +886,7 @@ __global__ __launch_bounds__(64 * NW) void k_fps_mw(const int *__restrict__ offs
         claimS[s] = 0u;
     }
     for (int i = tid; i < nr_cap; i += 64 * NW) rank[i] = 0u;
+    for (int i = tid; i < 16 * SUP; i += 64 * NW) rank2[i] = 0u;
     __syncthreads();
 
     if (tid == 0) idx[sc.start_m] = sc.start_n;
@@ -902,14 +905,59 @@ __global__ __launch_bounds__(64 * NW) void k_fps_mw(const int *__restrict__ offs
             // centres and let test (a) (second-best key of a 1,024-point unit) end it earlier still.  The proof of k_fps_multi holds for any
             // partition into units that carry their best and second-best key.
             const bool bkc = nb_cap <= BKC_MAX;   // (by the launch's largest scene: the rank array is sized for it; either way the same samples)
-            const Rec2 &U_ = bkc ? B : S;
+            // Larger scenes, two levels: the KMAX best buckets lie inside the KMAX best super-buckets (a super whose best key is below the
+            // KMAX-th best bucket key holds none of them), so rank the supers, then the <= KMAX * SUP buckets of the KMAX best supers.
+            // (measured: 25k-point scenes 7.2 -> 5.5 ms; 100k-point scenes 22.5 -> 23.3 -- with 98 supers the two extra barriers cost more than
+            // the better yield returns: only up to TWO_MAX_SUPERS supers)
+            const bool two = !bkc && two_level && ns_cap <= TWO_MAX_SUPERS;
+            const Rec2 &U_ = (bkc || two) ? B : S;
             const int nu = bkc ? nb : ns;
-            if (bkc) rank_count<BKC_MAX / 64, NW>(U_, nu, rank, lane, wave); else rank_count<NSL, NW>(U_, nu, rank, lane, wave);
+            if (bkc) rank_count<BKC_MAX / 64, NW>(B, nu, rank, lane, wave); else rank_count<NSL, NW>(S, nu, rank, lane, wave);
             __syncthreads();  // R: ranks complete
+            if (two) {
+                if (wave == 0) rank_place<NSL, KMAX>(S, ns, rank, cand, lane);
+                __syncthreads();  // R2: the KMAX best supers are listed
+                constexpr int NSLOT = KMAX * SUP, NQ = NSLOT / 64, JS = NSLOT / NW;
+                unsigned long long mykey[NQ];
+                unsigned above[NQ];
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) {
+                    const int q = lane + 64 * i, sup = cand[q / SUP], bk = sup * SUP + q % SUP;
+                    mykey[i] = (sup >= 0 && bk < nb) ? (((unsigned long long)B.khi[bk] << 32) | B.klo[bk]) : 0ull;
+                    above[i] = 0u;
+                }
+                for (int q = wave * JS; q < wave * JS + JS; ++q) {
+                    const int sup = cand[q / SUP], bk = sup * SUP + q % SUP;
+                    const unsigned long long kj = (sup >= 0 && bk < nb) ? (((unsigned long long)B.khi[bk] << 32) | B.klo[bk]) : 0ull;
+#pragma unroll
+                    for (int i = 0; i < NQ; ++i) above[i] += kj > mykey[i] ? 1u : 0u;
+                }
+#pragma unroll
+                for (int i = 0; i < NQ; ++i)
+                    if (above[i]) atomicAdd(&rank2[lane + 64 * i], above[i]);
+                __syncthreads();  // R3: bucket ranks complete
+                if (wave == 0) {
+                    int mybk[NQ];
+#pragma unroll
+                    for (int i = 0; i < NQ; ++i) {
+                        const int q = lane + 64 * i, sup = cand[q / SUP];
+                        mybk[i] = sup >= 0 && sup * SUP + q % SUP < nb ? sup * SUP + q % SUP : -1;
+                    }
+                    lds_fence();
+                    if (lane < 16) cand[lane] = -1;
+                    lds_fence();
+#pragma unroll
+                    for (int i = 0; i < NQ; ++i) {
+                        const unsigned rk = rank2[lane + 64 * i];
+                        rank2[lane + 64 * i] = 0u;
+                        if (mybk[i] >= 0 && rk < (unsigned)KMAX && (B.khi[mybk[i]] | B.klo[mybk[i]]) != 0u) cand[rk] = mybk[i];
+                    }
+                }
+            }
             if (wave == 0) {
                 constexpr int G = 64 / KMAX;          // lane groups of test (b): lane = (g, t)
                 const int kmax = min(KMAX, sc.m - j);
-                if (bkc) rank_place<BKC_MAX / 64, KMAX>(U_, nu, rank, cand, lane); else rank_place<NSL, KMAX>(U_, nu, rank, cand, lane);
+                if (!two) { if (bkc) rank_place<BKC_MAX / 64, KMAX>(B, nu, rank, cand, lane); else rank_place<NSL, KMAX>(S, nu, rank, cand, lane); }
                 lds_fence();
                 const int t = lane % KMAX, g = lane / KMAX;
                 const int cs = cand[t];
@@ -1261,7 +1309,7 @@ extern "C" int pdf_farthest_point_sampling_bucketed(int b, int n, int n_total, c
     // the one-sample kernel 91 / 20 / 4.9 / 1.2 ms -> by the size of the largest scene
     const int mw = env_mw ? atoi(env_mw) : (n >= 16384 ? 16 : n >= FPS_MULTI_MIN ? 8 : 0);
     const int mww = mw >= 16 ? 16 : 8;
-    const size_t lds3 = (size_t)(REC2 * nb_cap + REC2 * ns_cap + nb_cap + ns_cap + 4 + 3 * 16 + 4 + (nb_cap <= BKC_MAX ? nb_cap : ns_cap) + 3 * 16) * 4 +
+    const size_t lds3 = (size_t)(REC2 * nb_cap + REC2 * ns_cap + nb_cap + ns_cap + 4 + 3 * 16 + 4 + (nb_cap <= BKC_MAX ? nb_cap : ns_cap) + 3 * 16 + 16 * SUP) * 4 +
                         (size_t)(nb_cap + 64 + ns_cap + 64 + mww * (((ns_cap + 63) & ~63) + 64)) * 2;
     if (kmulti > 1 && mw != 0 && lds3 <= 160 * 1024) {
 #define PDF_LAUNCH_FPS_MW(NW_, RANK_)                                                                                     \
@@ -1270,9 +1318,10 @@ extern "C" int pdf_farthest_point_sampling_bucketed(int b, int n, int n_total, c
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fps_mw<NW_, RANK_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3); \
             if (e != hipSuccess) return (int)e;                                                                          \
         }                                                                                                                \
-        k_fps_mw<NW_, RANK_><<<b, 64 * NW_, lds3, s>>>(offset, new_offset, pts, kb, meta, idx, nb_cap, stats);            \
+        k_fps_mw<NW_, RANK_><<<b, 64 * NW_, lds3, s>>>(offset, new_offset, pts, kb, meta, idx, nb_cap, stats, two_lvl);   \
     } while (0)
         static const bool rank_sel = [] { const char *v = getenv("PDFOPS_FPS_RANK"); return !(v && v[0] == '0'); }();   // 0: rounds 2-3 candidate loop (A/B)
+        static const int two_lvl = [] { const char *v = getenv("PDFOPS_FPS_TWO_LEVEL"); return (v && v[0] == '0') ? 0 : 1; }();   // 0: super-bucket candidates at level 1 (A/B)
         if (rank_sel) { if (mww == 16) PDF_LAUNCH_FPS_MW(16, true); else PDF_LAUNCH_FPS_MW(8, true); }
         else { if (mww == 16) PDF_LAUNCH_FPS_MW(16, false); else PDF_LAUNCH_FPS_MW(8, false); }
 #undef PDF_LAUNCH_FPS_MW
