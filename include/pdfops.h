@@ -347,6 +347,9 @@ int pdf_td_backward(long n, long m, int cin, int cout, void *const *p, int entry
  * accept a NULL scatter target (grad_input2 / grad_input) when the caller forms it with these. */
 int pdf_seg_sum_rows(long n, int c, const float *src, const int *inv_off, const int *inv_entry, int entry_base, float scale, float *out,
                      void *stream);
+/* self tables: inverse-segment sums (scaled) and every point's own-row sums of src (n * nsample, c) in one walk (subtraction backward) */
+int pdf_seg_sum_rows_own(long n, int c, int nsample, const float *src, const int *inv_off, const int *inv_entry, int entry_base, float scale,
+                         const int *order, float *out, float *out_own, void *stream);
 int pdf_seg_sum_rows_strided(long n, int c, const float *src, long src_stride, const int *inv_off, const int *inv_entry, int entry_base,
                              float scale, float *out, void *stream);
 int pdf_seg_sum_rows_x(long n, int c, const float *src, long src_stride, int src_bf16, const int *inv_off, const int *inv_entry, int entry_base,

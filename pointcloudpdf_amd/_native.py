@@ -80,6 +80,7 @@ _HIP_ONLY_PROTOS = {
     "aggregation_forward_ordered": "iiiipppppp",
     "seg_sum_rows": "lipppifp",
     "seg_sum_rows_strided": "liplppifp",
+    "seg_sum_rows_own": "liipppifppp",
     "seg_sum_weighted": "liiippppip",
     "seg_sum_weighted_ordered": "liiippppipp",
 }
@@ -760,11 +761,17 @@ class HipBackend(CBackend):
         if grad_output.numel() == 0 or n2 == 0:
             return super().subtraction_backward(idx, grad_output, n2)
         off, ent, base = inverse_table(idx, n2)
-        g1 = self._new(grad_output, (n, c), torch.float32, zero=True)
         g2 = self._new(grad_output, (n2, c), torch.float32)
+        if n == n2 and c % 4 == 0 and self.fuse_own_rows:   # self table: both sums in one walk over the gradient (csrc/seg_gather.hip)
+            g1 = self._new(grad_output, (n, c), torch.float32)
+            self._call("seg_sum_rows_own", n2, c, ns, grad_output, off, ent, base, -1.0, src_order_of(idx, n2), g2, g1)
+            return g1, g2
+        g1 = self._new(grad_output, (n, c), torch.float32, zero=True)
         self._call("subtraction_backward", n, ns, c, idx, grad_output, g1, None)       # row sums only
         self._call("seg_sum_rows", n2, c, grad_output, off, ent, base, -1.0, g2)
         return g1, g2
+
+    fuse_own_rows = os.environ.get("PDFOPS_FUSE_OWN_ROWS", "1") != "0"   # 0: two passes over the gradient (rounds 2-3; A/B runs)
 
     def aggregation_backward(self, input, position, weight, idx, grad_output):
         if not self.use_inverse:

@@ -89,6 +89,45 @@ __global__ __launch_bounds__(TB) void k_seg_rows(unsigned total, FastDiv cvd, un
     out[(size_t)v * cv + p] = scaled(a0, scale);
 }
 
+// Both sums of a SELF table's backward in one walk (round 4; subtraction: d input1 = own-row sums, d input2 = - inverse-segment sums):
+//     out_own[v, :] = sum_j src[v * nsample + j, :]        out[v, :] = scale * sum over v's segment of src[e, :]
+// The two passes of rounds 2-3 each ran at the copy rate but read the (m * nsample, c) gradient twice.  With the destinations visited in
+// Morton order (`order`) on XCD-chunked blocks, the rows a destination gathers are the own rows of points a few positions away in the
+// same order -- read by a neighbouring workgroup of the same XCD at about the same time: the second read is an L2 hit.
+__global__ __launch_bounds__(TB) void k_seg_rows_own(unsigned total, FastDiv cvd, int nsample, const float4 *__restrict__ src,
+                                                     const int *__restrict__ inv_off, const int *__restrict__ inv_entry, int entry_base,
+                                                     float scale, const int *__restrict__ order, float4 *__restrict__ out, float4 *__restrict__ out_own) {
+    const unsigned gid = pdf_xcd_chunked_block(blockIdx.x, gridDim.x) * TB + threadIdx.x;
+    if (gid >= total) return;
+    const unsigned sv = fdiv(gid, cvd), p = gid - sv * cvd.d, cv = cvd.d, v = order ? (unsigned)order[sv] : sv;
+    int t = inv_off[v];
+    const int end = inv_off[v + 1];
+    float4 o0 = zero<4>(), o1 = zero<4>();
+    const float4 *own = src + (size_t)v * nsample * cv + p;
+    for (int j = 0; j < nsample; j += SB) {   // own rows: contiguous, SB in flight
+        float4 x[SB];
+#pragma unroll
+        for (int k = 0; k < SB; ++k) x[k] = vld(own + (size_t)min(j + k, nsample - 1) * cv);
+#pragma unroll
+        for (int k = 0; k < SB; ++k) add_acc((k & 1) ? o1 : o0, j + k < nsample ? x[k] : zero<4>());
+    }
+    add_acc(o0, o1);
+    out_own[(size_t)v * cv + p] = o0;
+    float4 a0 = zero<4>(), a1 = zero<4>();
+    for (; t < end; t += SB) {
+        int e[SB];
+        float4 x[SB];
+#pragma unroll
+        for (int k = 0; k < SB; ++k) e[k] = inv_entry[min(t + k, end - 1)] - entry_base;
+#pragma unroll
+        for (int k = 0; k < SB; ++k) x[k] = vld(src + (size_t)e[k] * cv + p);
+#pragma unroll
+        for (int k = 0; k < SB; ++k) add_acc((k & 1) ? a1 : a0, t + k < end ? x[k] : zero<4>());
+    }
+    add_acc(a0, a1);
+    out[(size_t)v * cv + p] = scaled(a0, scale);
+}
+
 // out[v, ch] = sum over the segment of src[e / nsample, ch] * w[e, ch mod w_c]
 //   aggregation grad_input (w = attention weights), fused layer g_xv (src = g_out, w = softmax weights), interpolation (w_c = 1)
 // `order` (nullable): visiting order of the DESTINATION rows (their Morton order): neighbouring destinations are gathered by the same
@@ -201,6 +240,20 @@ extern "C" int pdf_seg_sum_rows_strided(long n, int c, const float *src, long sr
 extern "C" int pdf_seg_sum_rows(long n, int c, const float *src, const int *inv_off, const int *inv_entry, int entry_base, float scale,
                                 float *out, void *stream) {
     return pdf_seg_sum_rows_strided(n, c, src, c, inv_off, inv_entry, entry_base, scale, out, stream);
+}
+
+// SELF tables (n queries = n destinations): out (n, c) = scale * inverse-segment sums of src (n * nsample, c), out_own (n, c) = sums of every
+// point's own nsample rows, in ONE walk; `order` (nullable): visiting order of the points.  c % 4 == 0, 16-byte aligned pointers.
+extern "C" int pdf_seg_sum_rows_own(long n, int c, int nsample, const float *src, const int *inv_off, const int *inv_entry, int entry_base,
+                                    float scale, const int *order, float *out, float *out_own, void *stream) {
+    if (n == 0) return PDF_OK;
+    if (n < 0 || c < 1 || nsample < 1 || !src || !inv_off || !inv_entry || !out || !out_own) return PDF_ERR_BAD_ARG;
+    if (c % 4 != 0 || ((uintptr_t)src % 16) || ((uintptr_t)out % 16) || ((uintptr_t)out_own % 16) || n * (c / 4) >= (1L << 31)) return PDF_ERR_UNSUPPORTED;
+    const long total = n * (c / 4);
+    sg::k_seg_rows_own<<<(unsigned)((total + sg::TB - 1) / sg::TB), sg::TB, 0, static_cast<hipStream_t>(stream)>>>(
+        (unsigned)total, sg::mk_fastdiv(c / 4), nsample, reinterpret_cast<const float4 *>(src), inv_off, inv_entry, entry_base, scale, order,
+        reinterpret_cast<float4 *>(out), reinterpret_cast<float4 *>(out_own));
+    return pdf_launch_status();
 }
 
 // out (n, c)[v, ch] = segmented sum of src[e / nsample, ch] * w[e, ch mod w_c]; src (m, c), w (m * nsample, w_c).

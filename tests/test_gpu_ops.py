@@ -399,6 +399,21 @@ def test_subtraction_fwd_bwd(hip, oracle_backend, table, c):
     g1_h, g2_h = hip.subtraction_backward(idx.to(DEV), go.to(DEV))
     assert_close(g1_h.cpu(), g1_o, 1e-5, "sub g1")
     assert_close(g2_h.cpu(), g2_o, 1e-5, "sub g2")
+    # the one-walk form (self table, c % 4 == 0: own-row sums + inverse-segment sums together) visits the points in the table's order
+    # when one is attached: same sums, bit for bit; and it equals the two-pass form within rounding
+    from pointcloudpdf_amd import _native
+
+    idx_o = idx.to(DEV)
+    _native.attach_order(idx_o, torch.randperm(idx.shape[0], generator=g).to(torch.int32).to(DEV), torch.randperm(idx.shape[0], generator=g).to(torch.int32).to(DEV))
+    g1_p, g2_p = hip.subtraction_backward(idx_o, go.to(DEV))
+    assert torch.equal(g1_p, g1_h) and torch.equal(g2_p, g2_h)
+    hip.fuse_own_rows = False
+    try:
+        g1_t, g2_t = hip.subtraction_backward(idx.to(DEV), go.to(DEV))
+    finally:
+        hip.fuse_own_rows = True
+    assert_close(g1_t.cpu(), g1_h.cpu(), 1e-6, "sub g1 two-pass")
+    assert_close(g2_t.cpu(), g2_h.cpu(), 1e-6, "sub g2 two-pass")
 
 
 @pytest.mark.parametrize("c,w_c", [(32, 4), (64, 8), (24, 24), (128, 16), (16, 2), (40, 5)])
