@@ -29,6 +29,13 @@ EXTRA = {
 }
 
 
+# compiler-flag A/B runs: PDFOPS_EXTRA_FLAGS="fused_layer.hip,fused_layer_mfma.hip:-mllvm -some-flag" (files : flags; ';' between groups)
+for _grp in filter(None, os.environ.get("PDFOPS_EXTRA_FLAGS", "").split(";")):
+    _files, _, _flags = _grp.partition(":")
+    for _f in _files.split(","):
+        EXTRA[_f.strip()] = EXTRA.get(_f.strip(), []) + _flags.split()
+
+
 def _hipcc():
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
