@@ -762,6 +762,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
 // such sweeps over the points (the second adds to the first one's G3), the other widths one.
 template <int C> constexpr int b3_ncp() { return C / 64 < 4 ? C / 64 : 4; }          // chunks per sweep
 template <int C> constexpr int b3_wls() { return 64 * b3_ncp<C>() + 4; }             // row stride of the Ww1 copy (floats)
+template <int C> constexpr bool b3_gacc_lds() { return C == 128 || C == 512; }       // geometry-branch sums in LDS slots (else registers)
 template <int C, bool BF>
 __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
     constexpr int CS = C / 8, NOB = nob_of(C), CSP = csp_of(C), NCHK = C / 64, NCP = b3_ncp<C>(), NSW = NCHK / NCP, WS = b3_wls<C>(), W = 8 + 4 * C + 16;
@@ -781,11 +782,16 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
     stage_units<C, true>(ucst, A, gp(A.sums2));
     const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
     const GeoW G = geo_weights(A);
-    // the 15 sums of the geometry branch [sum g_yp (3) | sum g_yp*that (3) | sum g_yp[a] * rel[b] (9): closed-form BNp backward, fl::k_colsum]:
-    // one private LDS slot per row-owning lane (stride 15: conflict-free), not 15 registers carried through the point loop -- the kernel
-    // sits at the 256-register step of 2 waves per SIMD
+    // the 15 sums of the geometry branch [sum g_yp (3) | sum g_yp*that (3) | sum g_yp[a] * rel[b] (9): closed-form BNp backward, fl::k_colsum].
+    // C = 128 / 512 sit at the 256-register step of 2 waves per SIMD: one private LDS slot per row-owning lane (stride 15: conflict-free).
+    // C = 64 / 256 have the registers, and C = 256 does NOT have the LDS: the 3.8 KB of slots took its block from 80.3 to 84.1 KB, one block
+    // per CU instead of two (60 us instead of 41 per launch, found in the round-4 kernel trace) -- there the sums stay in registers.
+    constexpr bool GLDS = b3_gacc_lds<C>();
     float *gacc = tiles + WPB * 32 * TS + WPB * 64 + (wv * 16 + row) * 15;
-    if (kq == 0) {
+    float greg[15];
+#pragma unroll
+    for (int e = 0; e < 15; ++e) greg[e] = 0.f;
+    if (GLDS && kq == 0) {
 #pragma unroll
         for (int e = 0; e < 15; ++e) gacc[e] = 0.f;
     }
@@ -914,9 +920,16 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
                     if (sw > 0) v += g3old[a];
                     if (sw == NSW - 1) {   // all channels seen: ReLU mask of BNp, BNp-backward sums
                         v = R.t1n[a] > 0.f ? v : 0.f;
-                        gacc[a] += v;
-                        gacc[3 + a] += v * ((R.t1[a] - A.mean[a]) * A.rstd[a]);
-                        gacc[6 + 3 * a + 0] += v * R.rel[0]; gacc[6 + 3 * a + 1] += v * R.rel[1]; gacc[6 + 3 * a + 2] += v * R.rel[2];
+                        const float vt = v * ((R.t1[a] - A.mean[a]) * A.rstd[a]);
+                        if constexpr (GLDS) {
+                            gacc[a] += v;
+                            gacc[3 + a] += vt;
+                            gacc[6 + 3 * a + 0] += v * R.rel[0]; gacc[6 + 3 * a + 1] += v * R.rel[1]; gacc[6 + 3 * a + 2] += v * R.rel[2];
+                        } else {
+                            greg[a] += v;
+                            greg[3 + a] += vt;
+                            greg[6 + 3 * a + 0] += v * R.rel[0]; greg[6 + 3 * a + 1] += v * R.rel[1]; greg[6 + 3 * a + 2] += v * R.rel[2];
+                        }
                     }
                     A.G3[ri * 3 + a] = v;
                 }
@@ -942,7 +955,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
     block_row(crow, 24, [&](RowAcc o) {
 #pragma unroll
         for (int e = 0; e < 15; ++e) {
-            const float x = pdf_wave_sum_f32(kq == 0 ? gacc[e] : 0.f);
+            const float x = pdf_wave_sum_f32(kq == 0 ? (GLDS ? gacc[e] : greg[e]) : 0.f);
             if (lane == 0) o[e < 6 ? e : e + 2] = x;
         }
         if (lane == 0) { o[6] = 0.f; o[7] = 0.f; for (int e = 17; e < 24; ++e) o[e] = 0.f; }
@@ -1014,7 +1027,7 @@ void launch_b2(const LayerArgs &A, int c, int grid, hipStream_t s) {
 void launch_b3(const LayerArgs &A, int c, int grid, hipStream_t s) {
     const dim3 g(grid);
     const int ncp = c / 64 < 4 ? c / 64 : 4, cw = 64 * ncp;   // (b3_ncp / the sweep's channels)
-    const size_t lds = (size_t)6 * c + 4 * cw + 7 * csp_of(c) + (size_t)csp_of(c) * (cw + 4) + std::max<size_t>(WPB * 32 * TS + WPB * 64 + WPB * 240, (size_t)WPB * 4 * cw);   // (+ the geometry sums' slots)
+    const size_t lds = (size_t)6 * c + 4 * cw + 7 * csp_of(c) + (size_t)csp_of(c) * (cw + 4) + std::max<size_t>(WPB * 32 * TS + WPB * 64 + ((c == 128 || c == 512) ? WPB * 240 : 0), (size_t)WPB * 4 * cw);   // (+ the geometry sums' slots, b3_gacc_lds)
 #define K_(C_) do { if (A.bf16) launch(k_b3<C_, true>, g, lds, A, s); else launch(k_b3<C_, false>, g, lds, A, s); } while (0)
     PDF_FLM_C(K_, g, lds);
 #undef K_
