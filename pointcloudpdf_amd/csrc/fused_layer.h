@@ -46,6 +46,24 @@ struct LayerArgs {
                                              // pre-pass) or nullptr: neighbouring points share neighbour rows -> per-XCD L2 hits
 };
 
+// (round 4) The row-per-lane passes read ~500 per-channel constants (weights, BatchNorm coefficients, column sums) through the constant
+// address space.  They are loop-invariant, so the compiler hoisted all their scalar loads out of the tile loop -- and then had ~500 values
+// to keep in ~100 scalar registers: fl::k_b3<32,8> spilled 617 SGPRs into VGPR lanes and restored them with ~1,000 v_readlane per tile
+// (40 % of the pass's vector instructions; k_b2 494, k_p3 395 spills).  `fresh_consts` hands the tile loop's body pointers the optimiser
+// cannot see through: the loads stay at their uses (merged into wide scalar loads that hit the scalar cache), live for a few instructions.
+#ifdef PDF_NO_FRESH_CONSTS   // (A/B builds: the hoisted form of rounds 1-3)
+__device__ __forceinline__ cfloat_p fresh(cfloat_p p) { return p; }
+#else
+__device__ __forceinline__ cfloat_p fresh(cfloat_p p) { asm volatile("" : "+s"(p)); return p; }
+#endif
+__device__ __forceinline__ LayerArgs fresh_consts(LayerArgs A) {
+    A.Wp1 = fresh(A.Wp1); A.bp1 = fresh(A.bp1); A.Wp2 = fresh(A.Wp2); A.bp2 = fresh(A.bp2);
+    A.Ww1 = fresh(A.Ww1); A.bw1 = fresh(A.bw1); A.Ww2 = fresh(A.Ww2); A.bw2 = fresh(A.bw2);
+    A.sp = fresh(A.sp); A.tp = fresh(A.tp); A.s1 = fresh(A.s1); A.t1 = fresh(A.t1); A.s2 = fresh(A.s2); A.t2 = fresh(A.t2);
+    A.mean = fresh(A.mean); A.rstd = fresh(A.rstd); A.sums = fresh(A.sums); A.sums2 = fresh(A.sums2);
+    return A;
+}
+
 // The points one wave of the matrix-core passes visits: every workgroup owns one contiguous chunk of the visiting order (chunks dealt
 // XCD-major, pdf_xcd_chunked_block), its WPB waves interleave inside the chunk.
 struct PointWalk {

@@ -198,7 +198,9 @@ __global__ __launch_bounds__(64 * WPB) void k_p2(LayerArgs A) {
 #pragma unroll
     for (int q = 0; q < NCH; ++q) { s[q] = 0.f; ss[q] = 0.f; }
     const BnP B = bnp_of(A, (long)A.N * K, blockIdx.x == 0 && threadIdx.x == 0);   // (from the geometry moments when the caller has them)
+    const LayerArgs A0 = A;
     for (long tile = wave_g; tile < ntiles; tile += nwaves) {
+        const LayerArgs A = fresh_consts(A0);   // (constants re-read at their uses: fused_layer.h, fresh_consts)
         const Row R = load_row<K>(A, tile, lane);
         float t1n[3];
 #pragma unroll
@@ -245,7 +247,9 @@ __global__ __launch_bounds__(64 * WPB) void k_p3(LayerArgs A) {
     float s[NH], ss[NH];      // lane (ch = lane & 31, half) accumulates channel hh*32 + ch of h
 #pragma unroll
     for (int hh = 0; hh < NH; ++hh) { s[hh] = 0.f; ss[hh] = 0.f; }
+    const LayerArgs A0 = A;
     for (long tile = wave_g; tile < ntiles; tile += nwaves) {
+        const LayerArgs A = fresh_consts(A0);
         const Row R = load_row<K>(A, tile, lane);
         float t1n[3];
         bn_relu3(A, R.t1, t1n);
@@ -369,7 +373,9 @@ __global__ __launch_bounds__(64 * WPB) void k_p4(LayerArgs A) {
 #pragma unroll
         for (int q = 0; q < NCH; ++q) { so[q] = 0.f; sso[q] = 0.f; }
     }
+    const LayerArgs A0 = A;
     for (long tile = wave_g; tile < ntiles; tile += nwaves) {
+        const LayerArgs A = fresh_consts(A0);
         const Row R = load_row<K>(A, tile, lane);
         float t1n[3];
         bn_relu3(A, R.t1, t1n);
@@ -476,13 +482,15 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
     const WaveLds L = carve_lds<true, C>(lds, threadIdx.x >> 6);
     const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
     const long ntiles = ((long)A.N * K + 63) / 64;
-    cfloat_p m2 = A.mean + 3 + C, r2 = A.rstd + 3 + C;
     float sg[CS], sgh[CS], sgz[CS], aw2[NW2];
 #pragma unroll
     for (int o = 0; o < CS; ++o) { sg[o] = 0.f; sgh[o] = 0.f; sgz[o] = 0.f; }
 #pragma unroll
     for (int m = 0; m < NW2; ++m) aw2[m] = 0.f;
+    const LayerArgs A0 = A;
     for (long tile = wave_g; tile < ntiles; tile += nwaves) {
+        const LayerArgs A = fresh_consts(A0);
+        cfloat_p m2 = A.mean + 3 + C, r2 = A.rstd + 3 + C;
         const Row R = load_row<K>(A, tile, lane);
         float t1n[3];
         bn_relu3(A, R.t1, t1n);
@@ -613,7 +621,6 @@ __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
     const WaveLds L = carve_lds<true, C>(lds, threadIdx.x >> 6);
     const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
     const long ntiles = ((long)A.N * K + 63) / 64;
-    cfloat_p m1 = A.mean + 3, r1 = A.rstd + 3;
     constexpr int NH = (CS + 31) / 32;
     float sg[NCH], sgr[NCH], sgh[NH], aw1[NCH][CS / 2];
 #pragma unroll
@@ -624,7 +631,8 @@ __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
 #pragma unroll
         for (int m = 0; m < CS / 2; ++m) aw1[q][m] = 0.f;
     }
-    for (long tile = wave_g; tile < ntiles; tile += nwaves) {
+    cfloat_p m1 = A.mean + 3, r1 = A.rstd + 3;   // (this pass keeps its hoisted constants: with fresh_consts it needs 138 VGPRs -- 3 waves per SIMD instead
+    for (long tile = wave_g; tile < ntiles; tile += nwaves) {   // of 4, 133 -> 136 us; held to 128 it spills to scratch: 166 us)
         const Row R = load_row<K>(A, tile, lane);
         float t1n[3];
         bn_relu3(A, R.t1, t1n);
@@ -697,14 +705,16 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
     const WaveLds L = carve_lds<true, C>(lds, threadIdx.x >> 6);
     const long wave_g = (long)blockIdx.x * WPB + (threadIdx.x >> 6), nwaves = (long)gridDim.x * WPB;
     const long ntiles = ((long)A.N * K + 63) / 64;
-    cfloat_p m1 = A.mean + 3, r1 = A.rstd + 3, mp = A.mean, rp = A.rstd;
-    cfloat_p sum_gy1 = A.sums, sum_gy1r = A.sums + C;  // column sums of B2 (A.sums points at B2's result here)
     float sgp[3] = {0.f, 0.f, 0.f}, sgpt[3] = {0.f, 0.f, 0.f}, sbp2[NCH], awp2[NCH][2], sgr[9];
 #pragma unroll
     for (int e = 0; e < 9; ++e) sgr[e] = 0.f;
 #pragma unroll
     for (int q = 0; q < NCH; ++q) { sbp2[q] = 0.f; awp2[q][0] = 0.f; awp2[q][1] = 0.f; }
+    const LayerArgs A0 = A;
     for (long tile = wave_g; tile < ntiles; tile += nwaves) {
+        const LayerArgs A = fresh_consts(A0);   // (constants re-read at their uses: see fresh_consts)
+        cfloat_p m1 = A.mean + 3, r1 = A.rstd + 3, mp = A.mean, rp = A.rstd;
+        cfloat_p sum_gy1 = A.sums, sum_gy1r = A.sums + C;  // column sums of B2 (A.sums points at B2's result here)
         const Row R = load_row<K>(A, tile, lane);
         float t1n[3];
         bn_relu3(A, R.t1, t1n);
