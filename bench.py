@@ -152,7 +152,7 @@ def parse():
     ap.add_argument("--storage", choices=["f32", "bf16"], default=os.environ.get("PDFOPS_STORAGE", "f32"),
                     help="bf16: the reduced-precision variant -- the fused PointTransformerLayer keeps its saved / scratch row arrays (H, G2, "
                          "softmax weights, g_r rows) as bfloat16 with fp32 accumulation (the reference trains under AMP); the headline stays f32")
-    ap.add_argument("--prefetch", type=int, default=16,
+    ap.add_argument("--prefetch", type=int, default=32,
                     help="geometry pre-pass group: the pre-pass of the NEXT `prefetch` batches runs as one launch sequence on a side "
                          "stream while the current group trains (0 = inline, serial)")
     ap.add_argument("--graph", choices=["auto", "0", "1"], default="auto",
