@@ -1190,7 +1190,9 @@ int backward_impl(LayerArgs A, float *sums, const int *inv_off, const int *inv_e
     if (rc != PDF_OK) return rc;
     A.sums = as_const(S1);
     const int g2 = mfma ? std::min(grid, pass_grid(B2, A.N, C == 512 ? 32 : (C == 256 ? 128 : grid))) : grid;
-    if (mfma) flm::launch_b2(A, C, g2, s); else k_b2<C, K><<<grid, 64 * WPB, lds, s>>>(A);
+    if (mfma) flm::launch_b2(A, C, g2, s);
+    else if (flm::supported_l1(K, C)) flm::launch_b2_l1(A, grid, s);   // (same partial rows as fl::k_b2<32, 8>)
+    else k_b2<C, K><<<grid, 64 * WPB, lds, s>>>(A);
     k_colsum<<<pdf_divup(b2_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, g2, b2_width<C>(), b2_width<C>(), S2, none);
     A.sums = as_const(S2);   // B3: BN1-backward terms from B2, BN2-backward terms from B1
     A.sums2 = as_const(S1);

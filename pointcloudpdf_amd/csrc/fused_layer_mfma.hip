@@ -751,6 +751,121 @@ __global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
     for (int e = threadIdx.x; e < CS * 64; e += NT) dst[2 * C + CS + (size_t)(e >> 6) * C + c0 + (e & 63)] = lds[128 + CSP + e];
 }
 
+// ------------------------------------------------------------------------------------------------ B2 at level 1 (C = 32, nsample 8)
+// The same pass for the first level, where the row-per-lane form (fl::k_b2<32,8>) is bound by its vector issue and restores ~500 spilled
+// scalar registers per tile: one wave = TWO points = 2 x 8 neighbour rows (rows 0-7 / 8-15 of the 16-row tile; row r of pair pp is flat
+// row 16 pp + r of every (N, 8, .) array, i.e. the row-major layout as it is), ONE 32-channel slab (two 16-channel blocks), the 4 hidden
+// units in the kq = 0 lanes of a 16-unit block (12 rows of zero padding in the A operand).  Everything per row is as in k_b2; only the
+// centre point of a lane's row (x_q, coordinates) is 2 pp + (row >> 3), and an odd N leaves the upper half of the last tile empty.
+// partial row: [sum g_y1 (32) | sum g_y1*rhat (32) | g_bw1 (4) | g_Ww1 (4 x 32)]   (= fl::k_b2<32, 8>'s row)
+template <bool BF>
+__global__ __launch_bounds__(64 * WPB) void k_b2_l1(LayerArgs A) {
+    constexpr int C = 32, CS = 4, CSP = 16, GS = CSP + 4, CW = 32, NJ = 2, WS = CW + 4, W = 2 * C + CS + CS * C;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wv = threadIdx.x >> 6;
+    float *cst = lds, *ucst = cst + 6 * C, *wl = ucst + 7 * CSP;           // wl: Ww1 (zero rows 4 .. 15), row stride 36
+    float *gh_t = wl + CSP * WS + wv * 16 * GS, *v1_t = wl + CSP * WS + WPB * 16 * GS + wv * 16 * TS;
+    stage_rows<CSP, CW, WS>(wl, gp(A.Ww1), C, CS);
+    for (int e = threadIdx.x; e < WPB * 16 * GS; e += NT) (wl + CSP * WS)[e] = 0.f;   // g_h tiles incl. padding columns
+    stage_consts<C>(cst, A, true);
+    stage_units<C, true>(ucst, A, gp(A.sums));
+    __syncthreads();
+    const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
+    const GeoW G = geo_weights(A);
+    f32x4 sg[NJ], sgr[NJ], sgh = zero4(), accw[NJ], m1[NJ], r1[NJ];
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+        sg[jj] = zero4(); sgr[jj] = zero4(); accw[jj] = zero4();
+        m1[jj] = ld4(gp(A.mean) + 3 + 16 * jj + 4 * kq);
+        r1[jj] = ld4(gp(A.rstd) + 3 + 16 * jj + 4 * kq);
+    }
+    LayerArgs Ap = A;
+    Ap.N = (A.N + 1) / 2;          // the walk is over PAIRS of points
+    Ap.order = nullptr;
+    fl::PointWalk pw(Ap, wv);
+    const long last_row = (long)A.N * 8 - 1;
+    auto row_of = [&](long pp) { return min(pp * 16 + row, last_row); };   // (clamped: the upper half of an odd N's last tile)
+    int nb_next = pw.valid() ? A.idx[row_of(pw.point())] : -1;
+    for (; pw.valid(); pw.step()) {
+        const long pp = pw.point(), i = 2 * pp + (row >> 3);
+        const bool valid = i < A.N;
+        const size_t ri = (size_t)row_of(pp), ic = (size_t)min(i, (long)A.N - 1);
+        const int nb = valid ? nb_next : -1;
+        const size_t nbc = (size_t)max(nb, 0);
+        nb_next = A.idx[row_of(pw.has_next() ? pw.next_point() : pp)];   // next trip's index: in flight during this trip
+        float pn[3], pi[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) { pn[b] = A.p[nbc * 3 + b]; pi[b] = A.p[ic * 3 + b]; }
+        f32x4 h[1], g2[1], xk[NJ], xq[NJ];
+        h[0] = ld_row4<BF>(A.H, ri * CS); g2[0] = ld_row4<BF>(A.G2, ri * CS);
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const int c4 = 16 * jj + 4 * kq;
+            xk[jj] = ld4(A.xk + nbc * C + c4); xq[jj] = ld4(A.xq + ic * C + c4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const Geo R = geo_of(G, nb, pn, pi);
+        f32x4 gh[1];
+        hidden_grad<C>(ucst, kq, h, g2, gh);
+        gh[0] = sel4(valid, gh[0]);
+        sgh += gh[0];
+        if (kq == 0) st4(gh_t + row * GS, gh[0]);
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const int g = 4 * jj + kq;
+            f32x4 acc = zero4();   // (Ww1^T g_h)[channel 16 j + 4 kq + reg][row]
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(4 * kq + e) * WS + 16 * jj + row], gh[0][e], acc, 0, 0, 0);
+            const f32x4 r = (sel4(nb >= 0, xk[jj]) - xq[jj]) + pos4(cst, C, g, R.t1n);
+            const f32x4 y1 = r * ld4(cst + 4 * C + 4 * g) + ld4(cst + 5 * C + 4 * g);
+            f32x4 gy1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gy1[e] = y1[e] > 0.f ? acc[e] : 0.f;
+            sg[jj] += gy1;
+            sgr[jj] += gy1 * ((r - m1[jj]) * r1[jj]);
+            st4(v1_t + row * TS + 16 * jj + 4 * kq, relu4(y1));
+        }
+        wave_sync();
+        // g_Ww1[o][c] += sum_rows g_h[row][o] v1[row][c]
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float a_ = gh_t[(4 * t + kq) * GS + row];
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) accw[jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, v1_t[(4 * t + kq) * TS + 16 * jj + row], accw[jj], 0, 0, 0);
+        }
+        wave_sync();
+    }
+    // row in LDS: [sum g_y1 (32) | sum g_y1*rhat (32) | g_bw1 (16: 4 used) | g_Ww1 (4 x 32)]
+    block_row(lds, 2 * CW + CSP + CS * CW, [&](RowAcc o) {
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = sg[jj][r], b = sgr[jj][r];
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+                if (row == 0) { o[16 * jj + 4 * kq + r] = a; o[CW + 16 * jj + 4 * kq + r] = b; }
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a = sgh[r];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) a += __shfl_xor(a, m, 64);
+            if (row == 0 && kq == 0) o[2 * CW + r] = a;
+        }
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (kq == 0) o[2 * CW + CSP + r * CW + 16 * jj + row] = accw[jj][r];
+    });
+    float *dst = A.partial + (size_t)blockIdx.x * W;
+    if (threadIdx.x < 2 * C) dst[threadIdx.x] = lds[threadIdx.x];
+    if (threadIdx.x < CS) dst[2 * C + threadIdx.x] = lds[2 * CW + threadIdx.x];
+    if (threadIdx.x < CS * C) dst[2 * C + CS + threadIdx.x] = lds[2 * CW + CSP + threadIdx.x];
+}
+
 // ------------------------------------------------------------------------------------------------ B3
 // partial row per block: [sum g_yp (3) | sum g_yp*that (3) | pad 2 | g_bp2 (C) | g_Wp2 (C*3) | sum g_yp (x) rel (9) | pad 7]   (as fl::k_b3)
 //
@@ -1023,6 +1138,15 @@ void launch_b2(const LayerArgs &A, int c, int grid, hipStream_t s) {
 #define K_(C_) do { if (A.bf16) launch(k_b2<C_, true>, g, lds, A, s); else launch(k_b2<C_, false>, g, lds, A, s); } while (0)
     PDF_FLM_C(K_, g, lds);
 #undef K_
+}
+// level 1 (C = 32, nsample 8): PDFOPS_PT_L1_MFMA=0 keeps the row-per-lane passes
+bool supported_l1(int nsample, int c) {
+    static const bool on = [] { const char *v = getenv("PDFOPS_PT_L1_MFMA"); return !(v && v[0] == '0'); }();
+    return on && nsample == 8 && c == 32 && getenv("PDFOPS_PT_NO_MFMA") == nullptr;
+}
+void launch_b2_l1(const LayerArgs &A, int grid, hipStream_t s) {
+    const size_t lds = std::max<size_t>((size_t)6 * 32 + 7 * 16 + (size_t)16 * 36 + WPB * 16 * 20 + WPB * 16 * TS, (size_t)WPB * (2 * 32 + 16 + 4 * 32));
+    if (A.bf16) launch(k_b2_l1<true>, dim3(grid), lds, A, s); else launch(k_b2_l1<false>, dim3(grid), lds, A, s);
 }
 void launch_b3(const LayerArgs &A, int c, int grid, hipStream_t s) {
     const dim3 g(grid);
