@@ -217,4 +217,5 @@ void launch_b2(const fl::LayerArgs &A, int c, int grid, hipStream_t s);
 void launch_b3(const fl::LayerArgs &A, int c, int grid, hipStream_t s);
 bool supported_l1(int nsample, int c);   // level 1 (C = 32, nsample 8): two points per wave
 void launch_b2_l1(const fl::LayerArgs &A, int grid, hipStream_t s);
+void launch_b3_l1(const fl::LayerArgs &A, int grid, hipStream_t s);
 }  // namespace flm

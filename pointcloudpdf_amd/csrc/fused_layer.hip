@@ -1190,14 +1190,24 @@ int backward_impl(LayerArgs A, float *sums, const int *inv_off, const int *inv_e
     if (rc != PDF_OK) return rc;
     A.sums = as_const(S1);
     const int g2 = mfma ? std::min(grid, pass_grid(B2, A.N, C == 512 ? 32 : (C == 256 ? 128 : grid))) : grid;
+    // level 1 on the matrix-core form: 112 / 154 registers -> 4 / 3 waves per SIMD, so 4 / 3 workgroups per CU instead of the row-per-lane
+    // passes' 2 (the scratch holds grid * WPB rows of B2's width: room for them)
+    static const int l1_mul = [] { const char *v = getenv("PDFOPS_L1_GRID_MUL"); return v ? atoi(v) : 1; }();   // (measured 1 .. 4: 15.32 - 15.39 ms per step, no trend)
+    const long pair_blocks = ((long)(A.N + 1) / 2 + WPB - 1) / WPB;
+    const int g2l = (int)std::min<long>((long)l1_mul * grid, pair_blocks), g3l = (int)std::min<long>((long)(l1_mul * 3 / 2 > 0 ? l1_mul * 3 / 2 : 1) * grid, pair_blocks);
+    const bool l1 = !mfma && flm::supported_l1(K, C);
     if (mfma) flm::launch_b2(A, C, g2, s);
-    else if (flm::supported_l1(K, C)) flm::launch_b2_l1(A, grid, s);   // (same partial rows as fl::k_b2<32, 8>)
+    else if (l1) flm::launch_b2_l1(A, g2l, s);   // (the partial rows of fl::k_b2<32, 8>)
     else k_b2<C, K><<<grid, 64 * WPB, lds, s>>>(A);
-    k_colsum<<<pdf_divup(b2_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, g2, b2_width<C>(), b2_width<C>(), S2, none);
+    k_colsum<<<pdf_divup(b2_width<C>(), 16), RED_THREADS, 0, s>>>(A.partial, l1 ? g2l : g2, b2_width<C>(), b2_width<C>(), S2, none);
     A.sums = as_const(S2);   // B3: BN1-backward terms from B2, BN2-backward terms from B1
     A.sums2 = as_const(S1);
     const int gb3 = mfma ? g3 : (int)std::min<long>(grid, (long)grid * b2_width<C>() / b3_pwidth<C>());   // (fl::k_b3's rows are 16 wider than S3)
-    if (mfma) flm::launch_b3(A, C, g3, s); else k_b3<C, K><<<gb3, 64 * WPB, lds, s>>>(A);
+    static const bool l1_b3 = [] { const char *v = getenv("PDFOPS_PT_L1_B3"); return !(v && v[0] == '0'); }();   // (A/B: 0 = fl::k_b3 at level 1)
+    const bool l1b3 = l1 && l1_b3;
+    if (mfma) flm::launch_b3(A, C, g3, s);
+    else if (l1b3) flm::launch_b3_l1(A, g3l, s);   // (the partial rows of fl::k_b3<32, 8>)
+    else k_b3<C, K><<<gb3, 64 * WPB, lds, s>>>(A);
     // column sums of B3's rows -> S3; with the kNN table's coordinate sums at hand one more block of the SAME launch finishes the geometry
     // branch's BatchNorm + Linear(3, 3) backward in closed form (S4): no B4 pass, no second reducer (PDFOPS_BNP_CLOSED=0: B4, as before)
     static const bool closed_on = [] { const char *v = getenv("PDFOPS_BNP_CLOSED"); return !(v && v[0] == '0'); }();
@@ -1207,7 +1217,7 @@ int backward_impl(LayerArgs A, float *sums, const int *inv_off, const int *inv_e
         bc.mom = A.mom; bc.Wp1 = A.Wp1; bc.bp1 = A.bp1; bc.sp = A.sp; bc.mean = A.mean; bc.rstd = A.rstd; bc.rows = (double)rows;
         bc.col_g = b3_width<C>(); bc.out4 = S4;
     }
-    k_colsum<<<pdf_divup(b3_width<C>(), 16) + (closed ? 1 : 0), RED_THREADS, 0, s>>>(A.partial, mfma ? g3 : gb3, b3_width<C>(), b3_pwidth<C>(), S3, bc);
+    k_colsum<<<pdf_divup(b3_width<C>(), 16) + (closed ? 1 : 0), RED_THREADS, 0, s>>>(A.partial, mfma ? g3 : (l1b3 ? g3l : gb3), b3_width<C>(), b3_pwidth<C>(), S3, bc);
     rc = pdf_seg_sum_rows_x(A.N, C, A.GR, C, A.bf16, inv_off, inv_entry, entry_base, 1.0f, A.gxk, s);   // g_xk[nb] = sum of the g_r rows that gathered nb
     if (rc != PDF_OK) return rc;
     if (!closed) {

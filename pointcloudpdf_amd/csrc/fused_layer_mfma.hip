@@ -1079,6 +1079,164 @@ __global__ __launch_bounds__(64 * WPB) void k_b3(LayerArgs A) {
     if (threadIdx.x < 16) dst[8 + 4 * C + threadIdx.x] = crow[8 + threadIdx.x];
 }
 
+// ------------------------------------------------------------------------------------------------ B3 at level 1 (C = 32, nsample 8)
+// Two points per wave as in k_b2_l1, ONE 32-channel chunk (no sweeps, no chunk loop).  The four hidden units of a row are the four values
+// every lane loads (a lane's channels 16 j + 4 kq + e use unit e): no exchange between the kq groups.  The column phase runs lanes along
+// (point half, channel): lane l sums the 8 rows of point 2 pp + (l >> 5) for channel l & 31 -- the g_r rows leave as two 128-byte rows
+// per step, g_xq of both points in one store, g_bp2 / g_Wp2 as per-half partial sums that meet in the epilogue.
+// partial row: [sum g_yp (3) | sum g_yp*that (3) | pad 2 | g_bp2 (32) | g_Wp2 (32 x 3) | sum g_yp (x) rel (9) | pad 7]   (= fl::k_b3<32, 8>'s row)
+template <bool BF>
+__global__ __launch_bounds__(64 * WPB) void k_b3_l1(LayerArgs A) {
+    constexpr int C = 32, CS = 4, CSP = 16, CW = 32, NJ = 2, WS = CW + 4, W = 8 + 4 * C + 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wv = threadIdx.x >> 6;
+    float *cst = lds;                        // Wp2 (3C, channel-major) | bp2 (C) | s1 (C) | t1 (C)
+    float *ccst = cst + 6 * C;               // mean1 | rstd1 | sum g_y1 / rows | sum g_y1*rhat / rows   (4 x 32)
+    float *ucst = ccst + 4 * CW;             // per-unit constants (stage_units), sums = B1's
+    float *wl = ucst + 7 * CSP;              // Ww1 (zero rows 4 .. 15), row stride 36
+    float *tiles = wl + CSP * WS;
+    float *tile = tiles + wv * 32 * TS, *tile2 = tile + 16 * TS;   // g_r tile, g_pr tile (16 rows x 32 channels)
+    float *t1nt = tiles + WPB * 32 * TS + wv * 64;
+    float *crow = tiles;                     // epilogue: WPB x 2 x 4 CW columns (the tiles are free then)
+    stage_consts<C>(cst, A, true);
+    const float *S2 = gp(A.sums);            // [sum g_y1 (C) | sum g_y1*rhat (C)]   (A.sums2 = B1's)
+    stage_units<C, true>(ucst, A, gp(A.sums2));
+    stage_rows<CSP, CW, WS>(wl, gp(A.Ww1), C, CS);
+    for (int e = threadIdx.x; e < 4 * CW; e += NT) {
+        const int arr = e / CW, c = e % CW;
+        const float *src = arr == 0 ? gp(A.mean) + 3 : arr == 1 ? gp(A.rstd) + 3 : arr == 2 ? S2 : S2 + C;
+        ccst[e] = src[c] * (arr >= 2 ? A.inv_rows : 1.f);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4, half = lane >> 5, ch = lane & 31;
+    const GeoW G = geo_weights(A);
+    float greg[15];
+#pragma unroll
+    for (int e = 0; e < 15; ++e) greg[e] = 0.f;
+    float sbp2 = 0.f, awp2[3] = {0.f, 0.f, 0.f};
+    LayerArgs Ap = A;
+    Ap.N = (A.N + 1) / 2;          // the walk is over PAIRS of points
+    Ap.order = nullptr;
+    fl::PointWalk pw(Ap, wv);
+    const long last_row = (long)A.N * 8 - 1;
+    auto row_of = [&](long pp) { return min(pp * 16 + row, last_row); };
+    int nb_next = pw.valid() ? A.idx[row_of(pw.point())] : -1;
+    for (; pw.valid(); pw.step()) {
+        const long pp = pw.point(), i = 2 * pp + (row >> 3);
+        const bool valid = i < A.N;
+        const size_t ri = (size_t)row_of(pp), ic = (size_t)min(i, (long)A.N - 1);
+        const int nb = valid ? nb_next : -1;
+        const size_t nbc = (size_t)max(nb, 0);
+        nb_next = A.idx[row_of(pw.has_next() ? pw.next_point() : pp)];
+        float pn[3], pi[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) { pn[b] = A.p[nbc * 3 + b]; pi[b] = A.p[ic * 3 + b]; }
+        f32x4 hh[1], g2[1], xk[NJ], xq[NJ], go[NJ];
+        hh[0] = ld_row4<BF>(A.H, ri * CS); g2[0] = ld_row4<BF>(A.G2, ri * CS);
+        const f32x4 w = ld_row4<BF>(A.Wsm, ri * CS);     // softmax weights of the row's 4 units as B1 stored them
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const int c4 = 16 * jj + 4 * kq;
+            xk[jj] = ld4(A.xk + nbc * C + c4); xq[jj] = ld4(A.xq + ic * C + c4); go[jj] = ld4(A.gout + ic * C + c4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const Geo R = geo_of(G, nb, pn, pi);
+        if (kq == 0) { t1nt[row * 4 + 0] = valid ? R.t1n[0] : 0.f; t1nt[row * 4 + 1] = valid ? R.t1n[1] : 0.f; t1nt[row * 4 + 2] = valid ? R.t1n[2] : 0.f; }
+        f32x4 gh[1];
+        hidden_grad<C>(ucst, kq, hh, g2, gh);
+        float gt1n[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const int g = 4 * jj + kq, gl = 4 * g;   // channel group / first channel
+            f32x4 acc = zero4();
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(4 * kq + e) * WS + 16 * jj + row], gh[0][e], acc, 0, 0, 0);
+            const f32x4 r = (sel4(nb >= 0, xk[jj]) - xq[jj]) + pos4(cst, C, g, R.t1n);
+            const f32x4 s1 = ld4(cst + 4 * C + 4 * g);
+            const f32x4 y1 = r * s1 + ld4(cst + 5 * C + 4 * g);
+            f32x4 gy1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gy1[e] = y1[e] > 0.f ? acc[e] : 0.f;
+            // BN1 backward: g_r = s1 * (g_y1 - mean(g_y1) - rhat * mean(g_y1 * rhat))
+            const f32x4 rhat = (r - ld4(ccst + gl)) * ld4(ccst + CW + gl);
+            const f32x4 gr = sel4(valid, s1 * (gy1 - ld4(ccst + 2 * CW + gl) - rhat * ld4(ccst + 3 * CW + gl)));
+            st4(tile + row * TS + 16 * jj + 4 * kq, gr);
+            const f32x4 gpr = gr + sel4(valid, go[jj] * w);   // + the aggregation's share of p_r (channel 4 g + e uses unit e)
+            st4(tile2 + row * TS + 16 * jj + 4 * kq, gpr);
+            const f32x4 w0 = ld4(cst + 12 * g), w1 = ld4(cst + 12 * g + 4), w2v = ld4(cst + 12 * g + 8);
+            const float wp[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2v[0], w2v[1], w2v[2], w2v[3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                gt1n[0] += gpr[e] * wp[3 * e]; gt1n[1] += gpr[e] * wp[3 * e + 1]; gt1n[2] += gpr[e] * wp[3 * e + 2];
+            }
+        }
+        wave_sync();
+        {   // lanes along (point half, channel): g_r rows out, g_xq[i] = - sum of the point's 8 rows
+            const long ip = 2 * pp + half;
+            const bool pv = ip < A.N;
+            float acc = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const float v = tile[(8 * half + rr) * TS + ch];
+                acc += v;
+                if (pv) {
+                    const size_t o = ((size_t)ip * 8 + rr) * C + ch;   // g_xk = segmented sum of these rows
+                    if constexpr (BF) __builtin_nontemporal_store((unsigned short)fl::f2bf(v), reinterpret_cast<unsigned short *>(A.GR) + o);
+                    else __builtin_nontemporal_store(v, A.GR + o);
+                }
+            }
+            if (pv) A.gxq[(size_t)ip * C + ch] = -acc;
+            float cb2 = 0.f, cw2[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {   // g_bp2 / g_Wp2 of channel ch: this half's 8 rows
+                const float v = tile2[(8 * half + rr) * TS + ch];
+                cb2 += v;
+                cw2[0] += v * t1nt[(8 * half + rr) * 4 + 0]; cw2[1] += v * t1nt[(8 * half + rr) * 4 + 1]; cw2[2] += v * t1nt[(8 * half + rr) * 4 + 2];
+            }
+            sbp2 += cb2; awp2[0] += cw2[0]; awp2[1] += cw2[1]; awp2[2] += cw2[2];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float v = gt1n[a];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (kq == 0) {
+                v = (valid && R.t1n[a] > 0.f) ? v : 0.f;
+                greg[a] += v;
+                greg[3 + a] += v * ((R.t1[a] - A.mean[a]) * A.rstd[a]);
+                greg[6 + 3 * a + 0] += v * R.rel[0]; greg[6 + 3 * a + 1] += v * R.rel[1]; greg[6 + 3 * a + 2] += v * R.rel[2];
+                if (valid) A.G3[ri * 3 + a] = v;
+            }
+        }
+        wave_sync();
+    }
+    // columns of the block's row (g_bp2: 32, g_Wp2: 32 x 3): per wave and point half into LDS, summed in (wave, half) order
+    float *dst = A.partial + (size_t)blockIdx.x * W;
+    __syncthreads();
+    crow[(2 * wv + half) * 4 * CW + ch] = sbp2;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) crow[(2 * wv + half) * 4 * CW + CW + ch * 3 + a] = awp2[a];
+    __syncthreads();
+    for (int t = threadIdx.x; t < 4 * CW; t += NT) {
+        float v = crow[t];
+#pragma unroll
+        for (int w = 1; w < 2 * WPB; ++w) v += crow[w * 4 * CW + t];
+        if (t < CW) dst[8 + t] = v; else dst[8 + C + (t - CW)] = v;
+    }
+    __syncthreads();
+    block_row(crow, 24, [&](RowAcc o) {
+#pragma unroll
+        for (int e = 0; e < 15; ++e) {
+            const float x = pdf_wave_sum_f32(kq == 0 ? greg[e] : 0.f);
+            if (lane == 0) o[e < 6 ? e : e + 2] = x;
+        }
+        if (lane == 0) { o[6] = 0.f; o[7] = 0.f; for (int e = 17; e < 24; ++e) o[e] = 0.f; }
+    });
+    store_row(crow, 8, dst);
+    if (threadIdx.x < 16) dst[8 + 4 * C + threadIdx.x] = crow[8 + threadIdx.x];
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 // (every allocation also holds the WPB partial rows of the epilogue, fl::block_row)
 template <typename KernelT>
@@ -1147,6 +1305,10 @@ bool supported_l1(int nsample, int c) {
 void launch_b2_l1(const LayerArgs &A, int grid, hipStream_t s) {
     const size_t lds = std::max<size_t>((size_t)6 * 32 + 7 * 16 + (size_t)16 * 36 + WPB * 16 * 20 + WPB * 16 * TS, (size_t)WPB * (2 * 32 + 16 + 4 * 32));
     if (A.bf16) launch(k_b2_l1<true>, dim3(grid), lds, A, s); else launch(k_b2_l1<false>, dim3(grid), lds, A, s);
+}
+void launch_b3_l1(const LayerArgs &A, int grid, hipStream_t s) {
+    const size_t lds = (size_t)6 * 32 + 4 * 32 + 7 * 16 + (size_t)16 * 36 + std::max<size_t>(WPB * 32 * TS + WPB * 64, (size_t)2 * WPB * 4 * 32);
+    if (A.bf16) launch(k_b3_l1<true>, dim3(grid), lds, A, s); else launch(k_b3_l1<false>, dim3(grid), lds, A, s);
 }
 void launch_b3(const LayerArgs &A, int c, int grid, hipStream_t s) {
     const dim3 g(grid);
