@@ -63,6 +63,44 @@ def test_fused_layer_train(C, K):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("n", [2999, 17, 1])
+def test_fused_layer_level1_pairs_of_points_with_an_odd_count(n):
+    """The level-1 backward passes on the matrix cores walk PAIRS of points (flm::k_b2_l1 / k_b3_l1: 2 x 8 rows per wave): an odd number of
+    points leaves the upper half of the last tile empty -- outputs and every gradient as in the op-by-op composition, also for a handful of
+    points (placeholder neighbours) and a single one."""
+    sizes_total = n
+    from pointcloudpdf_amd import synthetic
+    from pointcloudpdf_amd.geometry import Geometry
+    from pointcloudpdf_amd.point_transformer import PointTransformerLayer
+
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(0)
+        batch = synthetic.make_batch([sizes_total], first_scene_id=77, grid_size=0.25, device="cuda")
+        geom = Geometry(batch["coord"], batch["offset"], batch["offset_host"])
+        layer = PointTransformerLayer(32, 32, 8, 8).cuda()
+        synthetic.fill_parameters_deterministic(layer, seed=3)
+        layer.train(True)
+        g = torch.Generator(device="cuda").manual_seed(1)
+        x = torch.randn(sizes_total, 32, device="cuda", generator=g).requires_grad_(True)
+        PointTransformerLayer.fused = fused
+        try:
+            y = layer([geom.coord(0), x, geom.offset(0)])
+            y.backward(torch.randn(y.shape, device="cuda", generator=g))
+        finally:
+            PointTransformerLayer.fused = True
+        out = {"y": y.detach().cpu().numpy(), "gx": x.grad.cpu().numpy()}
+        out.update({"g_" + k: p.grad.cpu().numpy() for k, p in layer.named_parameters()})
+        res.append(out)
+    a, b = res
+    assert a["y"].shape[0] == n and max_rel(a["y"], b["y"]) < 5e-5
+    gscale = max(float(np.abs(b[k]).max()) for k in b if k.startswith("g_"))
+    for k in b:
+        if k == "y" or float(np.abs(b[k]).max()) <= 1e-4 * max(gscale, 1e-30):
+            continue
+        assert l2_rel(a[k], b[k]) < 2e-3, (k, l2_rel(a[k], b[k]))
+
+
 @pytest.mark.parametrize("C,K", [(32, 8), (64, 16), (128, 16), (32, 16), (64, 8), (256, 16), (512, 16)])
 def test_fused_layer_geometry_branch_gradients_in_closed_form(C, K):
     """With the kNN table's coordinate sums at hand (Geometry.rel_moments) the backward takes d Wp1 / d bp1 -- linear_p's first Linear
