@@ -140,6 +140,10 @@ def parse():
     ap.add_argument("--jitter", type=float, default=0.0,
                     help="scene sizes drawn in points * (1 +- jitter), seeded per rank and scene (SURVEY 8d config 3, secondary "
                          "number: straggler imbalance across ranks); 0 = every scene exactly --points")
+    ap.add_argument("--size-classes", type=int, default=0,
+                    help="with --jitter: draw the scene sizes of a batch from this many fixed signatures (batch i has the sizes of class "
+                         "i %% K) and give each class a captured graph of its own (engine.TrainStep(max_captures=K)); 0 = every batch its "
+                         "own sizes (eager)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ops-roofline", action="store_true", help="skip the per-op HBM roofline micro-benchmark (rank 0, N = 1)")
     ap.add_argument("--cpu-points", type=int, default=100000, help="scene size of the bounded CPU-baseline sample")
@@ -488,7 +492,7 @@ def main():
         if args.jitter <= 0:
             return [args.points] * args.scenes
         import numpy as np
-        rng = np.random.default_rng(7919 * rank + i)
+        rng = np.random.default_rng(7919 * rank + (i % args.size_classes if args.size_classes > 0 else i))
         return [int(round(args.points * (1.0 + args.jitter * (2.0 * rng.random() - 1.0)))) for _ in range(args.scenes)]
 
     batch_kw = dict(kind="scannet", unknown=(4, 7, 14, 16)) if scannet else {}
@@ -507,7 +511,7 @@ def main():
     # policy with the scale / found-inf flag on the device (engine.DeviceGradScaler), so that the step still replays as a graph
     scaler = engine.DeviceGradScaler(dev) if (args.amp == "f16" and args.optimizer == "fused") else None
     static_scale = 4096.0 if (args.amp == "f16" and scaler is None) else 1.0
-    graph_ok = (args.jitter <= 0 and not args.pseudo_label and not args.throttle and not strat
+    graph_ok = ((args.jitter <= 0 or args.size_classes > 0) and not args.pseudo_label and not args.throttle and not strat
                 and not (use_dp and args.ddp == "torch"))
     if args.graph == "1" and not graph_ok:
         raise SystemExit("bench.py: --graph 1 needs fixed scene sizes and the plain PointTransformer step (see --help)")
@@ -516,7 +520,8 @@ def main():
     # when the batch has the captured shape, eager otherwise; gradient exchange; optimizer; loss scaling).  This file only feeds
     # batches, times the region and reports.
     trainer = engine.TrainStep(step, opt, exchange=grad_sync, scaler=scaler, autocast=amp_dtype, module=module, force_exchange=force_dp,
-                               graph=(args.graph == "1" or (args.graph == "auto" and graph_ok)), loss_scale=static_scale)
+                               graph=(args.graph == "1" or (args.graph == "auto" and graph_ok)), loss_scale=static_scale,
+                               max_captures=(args.size_classes if (args.jitter > 0 and args.size_classes > 0) else 1))
     st_prefetcher = None
     if st_ahead:
         from pointcloudpdf_amd.stratified import StratifiedPrefetcher
@@ -658,7 +663,8 @@ def main():
                                    + ("StratifiedTransformer ST-v1m1 + PointPdf-v1m1 / ST-v1m1-Recognizer, fwd+bwd+SGD, window partition recomputed every step" if strat else
                                       "PointTransformer-Seg50 + PointPdf-v1m1 U-decoder, fwd+bwd+SGD, geometry recomputed every step")
                                    + (", PDF pseudo-label pass inside the step" if args.pseudo_label else ""),
-                       "scenes_per_gpu": args.scenes, "points_per_scene": args.points, "size_jitter": args.jitter, "parallelism": f"dp{world}",
+                       "scenes_per_gpu": args.scenes, "points_per_scene": args.points, "size_jitter": args.jitter,
+                       **({"size_classes": args.size_classes, "captured_graphs": len(trainer.captures)} if args.size_classes > 0 else {}), "parallelism": f"dp{world}",
                        "gradient_exchange": (args.ddp if use_dp else "none"),
                        **({"shared_gpu": "FUNCTIONAL CHECK ONLY: the ranks share the visible GPU(s) and rendezvous over gloo "
                                          "(PDFOPS_BENCH_SHARED_GPU=1); not a scaling number"} if shared_gpu else {})},

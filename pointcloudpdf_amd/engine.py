@@ -391,36 +391,76 @@ class TrainStep:
     """
 
     def __init__(self, step, optimizer, exchange=None, scaler=None, autocast=None, graph=True, force_exchange=False, loss_scale=1.0, module=None,
-                 stream=None):
+                 stream=None, max_captures=1):
         """``module``: what the eager forward calls (a torch DistributedDataParallel wrapper of ``step``; default ``step`` itself);
         ``loss_scale``: static loss scale when no ``scaler`` is given (A/B runs; no overflow check).
         ``stream``: run EVERYTHING of the step (replay / eager issue, gradient exchange, optimizer) on this stream instead of the caller's
         current one -- with ``_native.cu_masked_stream`` the training stream and the coordinate pre-pass get disjoint compute units
         (``partition_compute_units``): the farthest-point chain (24 workgroups, ~20 ms per launch) next to the training kernels
-        cost every one of them a straggler tail (+2.3 ms per step beside it at full duty, tools/contention_probe.py)."""
+        cost every one of them a straggler tail (+2.3 ms per step beside it at full duty, tools/contention_probe.py).
+        ``max_captures``: how many scene-size classes get a graph of their own (default 1: the first batch's sizes -- what
+        ``SphereCrop(point_max)`` hands the trainer for every scene above the limit).  With more, the first ``max_captures`` distinct
+        size signatures are captured as they arrive (each capture costs ~3 eager steps once, and its private memory pool: the step's
+        activations, ~3 GB at 2 x 100k points); further sizes run eagerly.  A capture whose Python-side schedule state went stale
+        (``CapturedStep.matches``: the recognizer's alpha at ``start_epoch``) is released and its size class captured again."""
         self.stream = stream
         self.step, self.optimizer, self.exchange, self.scaler, self.autocast = step, optimizer, exchange, scaler, autocast
         self.module = module if module is not None else step
         self.graph, self.captured, self.capture_error = bool(graph), None, None
+        self.captures, self.max_captures, self._capture_stream = [], max(int(max_captures), 1), stream
         self.force_exchange, self.loss_scale = force_exchange, float(loss_scale)
         self.params = [p for p in step.parameters() if p.requires_grad]
 
     def capture(self, batch, geom=None):
-        self.captured = CapturedStep(self.step, batch, geom=geom, autocast=self.autocast,
-                                     loss_scale=self.scaler if self.scaler is not None else self.loss_scale, stream=self.stream)
-        return self.captured
+        """Capture forward + backward for ``batch``'s scene sizes.  Every capture of one TrainStep records on the SAME stream (the first
+        capture's): the parameters' AccumulateGrad nodes are bound to it for as long as any captured autograd graph lives."""
+        cap = CapturedStep(self.step, batch, geom=geom, autocast=self.autocast,
+                           loss_scale=self.scaler if self.scaler is not None else self.loss_scale, stream=self._capture_stream)
+        self._capture_stream = cap.stream
+        self.captures.append(cap)
+        self.captured = self.captures[0]   # (the capture whose stream eager steps run on; ``is not None`` == "this trainer replays")
+        return cap
 
     def drop_capture(self):
-        """Release the captured graph and every autograd / gradient reference it pinned (eager steps run at full speed again)."""
+        """Release the captured graphs and every autograd / gradient reference they pinned (eager steps run at full speed again)."""
         import gc
 
-        self.captured, self.graph = None, False
+        self.captured, self.graph, self.captures = None, False, []
+        self._capture_stream = self.stream
         torch.cuda.synchronize()
         release_autograd_state(self.step)
         for p in self.params:
             p.grad = None
         gc.collect()
         torch.cuda.empty_cache()
+
+    def _capture_for(self, batch, geom):
+        """The capture that IS this batch's step (same scene sizes, same schedule state), made now when a slot is free; else None."""
+        import gc
+
+        for cap in self.captures:
+            if cap.matches(batch):
+                return cap
+        if self.capture_error is not None:
+            return None
+        stale = [cap for cap in self.captures if cap._python_state() != cap.frozen]
+        if stale:   # the schedule moved on (alpha / epoch gate): those graphs can never match again
+            torch.cuda.synchronize()
+            self.captures = [cap for cap in self.captures if cap not in stale]
+            self.captured = self.captures[0] if self.captures else None
+            for p in self.params:   # (p.grad may be a released capture's static tensor)
+                p.grad = None
+            del stale, cap
+            gc.collect()
+            torch.cuda.empty_cache()
+        if len(self.captures) >= self.max_captures:
+            return None
+        try:
+            return self.capture(batch, geom)
+        except Exception as e:   # noqa: BLE001  (a stack that cannot capture the step trains on the eager path)
+            self.capture_error = f"{type(e).__name__}: {e}"
+            self.drop_capture()
+            return None
 
     def _eager(self, batch):
         # An eager step between replays runs on the capture's stream: the parameters' AccumulateGrad nodes are bound to it while the
@@ -457,14 +497,8 @@ class TrainStep:
 
     def _run(self, batch, eager=False):
         geom = batch.get("pdf_geometry")
-        if self.graph and self.captured is None and self.capture_error is None and not eager:
-            try:
-                self.capture(batch, geom)
-            except Exception as e:   # noqa: BLE001  (a stack that cannot capture the step trains on the eager path)
-                self.capture_error = f"{type(e).__name__}: {e}"
-                self.drop_capture()
-        cap = self.captured
-        if cap is not None and not eager and cap.matches(batch):
+        cap = self._capture_for(batch, geom) if self.graph and not eager else None
+        if cap is not None:
             if geom is None:   # no look-ahead: the pre-pass inline on this stream
                 from .geometry import Geometry
                 geom = Geometry(batch["coord"], batch["offset"], batch["offset_host"]).precompute()
