@@ -464,6 +464,24 @@ int pdf_vote_accumulate(long n, int c, const float *logits, const float *score, 
 int pdf_radius_neighbors_self(int n, int nsample, float radius, const float *xyz, const int *offset, int b, int *idx, float *dist2,
                               void *workspace, long workspace_bytes, void *stream);
 
+/* The graph stage of the PDF pseudo-label pass (pointpdf_v1m1_base.py:309-380: scipy.sparse.csgraph.minimum_spanning_tree over the
+ * region's neighbour similarities, :340; connected_components of the weak tree edges, :360) for ONE scene, one workgroup.
+ * u, v (E directed entries, node ids < n), w (E weights, or NULL: all equal), active (E flags, or NULL: all), nodes (n_nodes ids,
+ * repeats allowed, covering every endpoint of an active entry).  chosen (E bytes, or NULL) = 1 for the entries of the minimum
+ * spanning forest under the strict order (weight, entry index); comp (n ints, written at the listed nodes only) = the root of the
+ * node's connected component (one of its node ids).  workspace: pdf_graph_forest_workspace_bytes(n, E, n_nodes) bytes, 8-byte
+ * aligned.  Lists of up to 12,288 nodes keep the per-round state in LDS. */
+long pdf_graph_forest_workspace_bytes(long n, long E, long n_nodes);
+int pdf_graph_forest(long n, int E, const long long *u, const long long *v, const float *w, const unsigned char *active,
+                     const long long *nodes, int n_nodes, int *comp, unsigned char *chosen, void *workspace, long workspace_bytes,
+                     void *stream);
+
+/* Two-component 1-D Gaussian mixture by EM in double on m SORTED values: stands in for sklearn.mixture.GaussianMixture(n_components=2)
+ * .fit(tree weights) (pointpdf_v1m1_base.py:343-345; reg_covar 1e-6, tol on the mean log-likelihood, max_iter) with a deterministic
+ * start (quartiles, then 2-means) instead of sklearn's randomly seeded k-means.  resp: 2 m doubles of scratch; out (8 doubles): means,
+ * variances, weights of the two components, iterations run, final mean log-likelihood. */
+int pdf_gmm2_1d(int m, const float *sorted_x, double *resp, double *out, int iters, double tol, double reg, void *stream);
+
 /* Softmax over the edges of every query, per head (x, y: (M, h); index0_offsets: N + 1 entries; h <= 64): stands in for
  * torch_scatter.scatter_softmax(src, index_0, dim=0) in WindowAttention.forward (stratified_transformer_v1m1_origin.py:322-324;
  * torch_scatter is an unvendored dependency).  backward: grad_x = y * (grad_y - sum over the query of y * grad_y). */

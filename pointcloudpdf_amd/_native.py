@@ -66,6 +66,8 @@ _HIP_ONLY_PROTOS = {
     "grid_hash": "lippdddippp",
     "radius_neighbors_self": "iifppipppl",
     "vote_accumulate": "lipppppp",
+    "graph_forest": "lipppppipppl",
+    "gmm2_1d": "ipppidd",
     "dot_prod_with_idx_forward_v3_l": "iiiiipppppppp",
     "dot_prod_with_idx_backward_v3_l": "iiiiipppppppppppp",
     "attention_step2_with_rel_pos_value_backward_v2_l": "iiiiipppppppppp",
@@ -674,6 +676,8 @@ class HipBackend(CBackend):
         self.knn_mode = os.environ.get("PDFOPS_KNN", "grid")      # "grid" | "scan"
         lib.pdf_knn_workspace_bytes.restype = c_long
         lib.pdf_knn_workspace_bytes.argtypes = [c_int, c_int, c_int]
+        lib.pdf_graph_forest_workspace_bytes.restype = c_long
+        lib.pdf_graph_forest_workspace_bytes.argtypes = [c_long, c_long, c_long]
         lib.pdf_knn_grid_supported.restype = c_int
         lib.pdf_knn_grid_supported.argtypes = [c_int]
         lib.pdf_knn_query_ws.restype = c_int
@@ -1250,6 +1254,41 @@ class HipBackend(CBackend):
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=xyz.device)
         self._call("radius_neighbors_self", n, int(nsample), float(radius), xyz, offset, b, idx, dist2, ws, nbytes)
         return idx, dist2
+
+    def graph_forest(self, n, eu, ev, nodes, weight=None, active=None, want_chosen=True):
+        """One scene's region graph (pseudo-label pass, pointpdf_v1m1_base.py:309-380): directed entries (eu[e], ev[e]) with ``weight[e]``
+        (None: all equal) among the ``active`` ones (bool / uint8, None: all); ``nodes``: ids covering every endpoint (repeats allowed).
+        -> (chosen (E,) bool or None: the entries of the minimum spanning forest under the order (weight, entry index);
+            comp (n,) int32: the root of the component of every listed node, the node's own id elsewhere)."""
+        _check(eu, torch.int64, "eu"); _check(ev, torch.int64, "ev"); _check(nodes, torch.int64, "nodes")
+        E = int(eu.shape[0])
+        if int(ev.shape[0]) != E or (weight is not None and int(weight.shape[0]) != E) or (active is not None and int(active.shape[0]) != E):
+            raise ValueError("graph_forest: eu, ev, weight, active disagree on the number of entries")
+        if weight is not None:
+            _check(weight, torch.float32, "weight")
+        if active is not None:
+            active = active.view(torch.uint8) if active.dtype == torch.bool else active
+            _check(active, torch.uint8, "active")
+        comp = torch.arange(int(n), dtype=torch.int32, device=eu.device)
+        chosen = torch.empty((E,), dtype=torch.uint8, device=eu.device) if want_chosen else None
+        nbytes = int(self.lib.pdf_graph_forest_workspace_bytes(int(n), E, int(nodes.shape[0])))
+        ws = torch.empty((nbytes // 8 + 1,), dtype=torch.int64, device=eu.device)
+        nul = ctypes.c_void_p(None)
+        self._call("graph_forest", int(n), E, eu, ev, nul if weight is None else weight, nul if active is None else active, nodes,
+                   int(nodes.shape[0]), comp, nul if chosen is None else chosen, ws, ws.numel() * 8)
+        return (chosen.view(torch.bool) if chosen is not None else None), comp
+
+    def gmm2_1d(self, x, iters=200, tol=1e-6, reg=1e-6):
+        """Two-component 1-D Gaussian mixture of the float values ``x`` by EM in double, on the device (stands in for
+        sklearn.mixture.GaussianMixture(n_components=2).fit, pointpdf_v1m1_base.py:343-345).  -> (8,) float64 on the device: means (2),
+        variances (2), weights (2), iterations run, final mean log-likelihood."""
+        _check(x, torch.float32, "x")
+        xs = torch.sort(x.reshape(-1))[0]
+        m = int(xs.shape[0])
+        resp = torch.empty((max(2 * m, 1),), dtype=torch.float64, device=x.device)
+        out = torch.empty((8,), dtype=torch.float64, device=x.device)
+        self._call("gmm2_1d", m, xs, resp, out, int(iters), float(tol), float(reg))
+        return out
 
     def grid_hash(self, coord, offset, grid_size, min_grid, float32_division=False):
         """-> grid (n,3) int64 scene-relative voxel coordinates, key (n) int64 holding the uint64 FNV key bits.

@@ -1,0 +1,339 @@
+// The graph stage of the PDF pseudo-label pass (pointcept/recognizers/ours/pointpdf_v1m1_base.py:309-380) as two single-workgroup
+// kernels per scene.  Upstream moves the region's neighbour graph to the host and calls scipy.sparse.csgraph.minimum_spanning_tree,
+// sklearn.mixture.GaussianMixture(n_components=2) on the tree's weights and scipy.sparse.csgraph.connected_components on the weak
+// tree edges.  A region holds a few thousand points and <= 64 neighbours each: the work is tens of thousands of edges with a
+// round structure (Boruvka: <= log2(nodes) rounds; EM: <= 200 iterations), i.e. latency of dependent steps, not bandwidth -- one
+// workgroup per scene walks the edge list once per round out of L2 and synchronises with workgroup barriers instead of kernel
+// boundaries and host reads (the torch-op form of the same algorithms: 12 ms per scene, of which 6 ms a numpy EM on the host).
+//
+// k_forest: minimum spanning forest under the strict total order (weight, entry index) -- with a strict order the forest is unique, so
+// the chosen entries ARE scipy's tree whenever the weights are distinct -- and, as a by-product, the component label of every listed
+// node (the root it ended under).  With w == NULL every active edge is equal: the labels are plain connected components.
+// k_gmm2: two-component 1-D mixture by EM in double: quartile start, 2-means, EM until the mean log-likelihood moves < tol.
+#include "pdfops_common.h"
+
+namespace gp {
+
+using u64 = unsigned long long;
+constexpr int T = 1024;
+constexpr int U = 8;   // entries of the edge walk in flight per thread
+constexpr u64 NONE = ~0ull;
+
+__device__ inline unsigned order_bits(float f) {   // float -> unsigned with the same order (-0 == +0)
+    const unsigned b = __float_as_uint(f + 0.0f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// Atomics are performed in L2; a plain load of the same address may be served from this CU's vector cache: read what atomics wrote
+// with an agent-scope load.
+__device__ inline u64 load_l2(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+#ifdef GP_PROFILE   // tools/probes/forest_phase_probe.py: wall-clock ticks (100 MHz) at the phase boundaries of every round, thread 0
+__device__ long long gp_prof[64 * 8];
+#define GP_TICK(round, slot) do { if (threadIdx.x == 0) gp_prof[(round) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define GP_TICK(round, slot) do { } while (0)
+#endif
+
+// One workgroup.  u, v: E directed entries (node ids < n); w: E weights or NULL; active: E flags or NULL (all); nodes: n_nodes ids
+// (repeats allowed) covering every endpoint of an active entry.  Inside, a node is its SLOT in `nodes` (slot[x] = a position of x in
+// the list; a repeat's other positions stay isolated phantom slots): su / sv (E ints of scratch) hold the entries' endpoints as slots
+// (-1: inactive), and the two arrays every entry of every round touches -- the component of a slot and the running minimum of a
+// component -- live in LDS when the list fits (LDS_NODES): a round's walk is then coalesced reads of su / sv plus LDS traffic.
+// (With those two arrays in global memory one CU retires ~0.5 G atomics/s: 160 us for the 75k atomics of a 37k-entry first round.)
+// On return comp_out[x] = the ROOT of x's component for every listed x (the id of one of the component's nodes, the same for all of
+// them); chosen (E bytes, or NULL): 1 for the entries of the forest.
+constexpr int LDS_NODES = 12288;   // 12 B per slot: 144 KB of the CU's 160 KB
+
+template <bool LDS>
+__global__ __launch_bounds__(T) void k_forest(int E, const long long *__restrict__ u, const long long *__restrict__ v,
+                                              const float *__restrict__ w, const unsigned char *__restrict__ active,
+                                              const long long *__restrict__ nodes, int n_nodes, int *comp_out, int *slot, int *su, int *sv,
+                                              u64 *gbest, int *gcomp, int *parent, int *rootof, unsigned char *chosen) {
+    extern __shared__ u64 lds_dyn[];
+    __shared__ int live;
+    u64 *best;
+    int *comp;
+    if constexpr (LDS) {
+        best = lds_dyn;
+        comp = reinterpret_cast<int *>(lds_dyn + n_nodes);
+    } else {
+        best = gbest;
+        comp = gcomp;
+    }
+    auto best_now = [&](int c) -> u64 {
+        if constexpr (LDS) return best[c];
+        else return load_l2(&best[c]);
+    };
+    const int t = threadIdx.x;
+    for (int i = t; i < n_nodes; i += T) {
+        slot[(int)nodes[i]] = i;   // (a repeated id keeps one of its positions: whichever store lands last)
+        comp[i] = i;
+    }
+    if (t == 0) live = 0;
+    __syncthreads();
+    for (int e = t; e < E; e += T) {
+        const bool ok = !active || active[e];
+        su[e] = ok ? slot[(int)u[e]] : -1;
+        sv[e] = ok ? slot[(int)v[e]] : -1;
+        if (chosen) chosen[e] = 0;
+    }
+    __syncthreads();
+    for (int round = 0; round < 48; ++round) {   // (every round at least halves the number of components that still have an edge out)
+        GP_TICK(round, 0);
+        for (int i = t; i < n_nodes; i += T) best[i] = NONE;
+        __syncthreads();
+        GP_TICK(round, 1);
+        int any = 0;
+        // U entries per trip: their endpoint loads, then their component loads, are in flight together
+        for (int e0 = t; e0 < E; e0 += T * U) {
+            int a[U], b[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int e = e0 + j * T;
+                a[j] = e < E ? su[e] : -1;
+                b[j] = e < E ? sv[e] : -1;
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int x = a[j], y = b[j];
+                a[j] = x >= 0 ? comp[x] : 0;
+                b[j] = x >= 0 ? comp[y] : 0;
+            }
+            // An atomic only where the entry would lower the component's minimum as it stands: once components are large, thousands of
+            // entries aim at the same few words and same-address atomics serialise.  The minimum only falls within a round, so a value
+            // read earlier can only let a useless atomic through.
+            u64 ma[U], mb[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const bool lv = a[j] != b[j];
+                ma[j] = lv ? best_now(a[j]) : 0ull;
+                mb[j] = lv ? best_now(b[j]) : 0ull;
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                if (a[j] == b[j]) continue;
+                const int e = e0 + j * T;
+                const u64 key = ((u64)(w ? order_bits(w[e]) : 0u) << 32) | (unsigned)e;
+                if (key < ma[j]) atomicMin(&best[a[j]], key);
+                if (key < mb[j]) atomicMin(&best[b[j]], key);
+                any = 1;
+            }
+        }
+        if (any) live = 1;
+        __syncthreads();
+        GP_TICK(round, 2);
+        if (!live) break;
+        // every component hooks onto the component at the other end of its lightest outgoing entry
+        for (int c = t; c < n_nodes; c += T) {
+            if (comp[c] != c) continue;
+            const u64 bm = best_now(c);
+            int p = c;
+            if (bm != NONE) {
+                const int e = (int)(unsigned)(bm & 0xffffffffull);
+                if (chosen) chosen[e] = 1;
+                const int x = comp[su[e]], y = comp[sv[e]];
+                p = (x == c) ? y : x;
+            }
+            parent[c] = p;
+        }
+        __syncthreads();
+        if (t == 0) live = 0;
+        // two components that picked the same entry point at each other: the smaller slot stays a root
+        for (int c = t; c < n_nodes; c += T) {
+            if (comp[c] != c) continue;
+            const int p = parent[c];
+            if (p != c && c < p && parent[p] == c) parent[c] = c;
+        }
+        __syncthreads();
+        for (int c = t; c < n_nodes; c += T) {
+            if (comp[c] != c) continue;
+            int r = parent[c];
+            while (parent[r] != r) r = parent[r];
+            rootof[c] = r;
+        }
+        __syncthreads();
+        for (int i = t; i < n_nodes; i += T) comp[i] = rootof[comp[i]];   // (comp[i] is a root of the round before; a new root maps to itself)
+        __syncthreads();
+        GP_TICK(round, 3);
+    }
+    for (int i = t; i < n_nodes; i += T) {
+        const int x = (int)nodes[i];
+        comp_out[x] = (int)nodes[comp[slot[x]]];
+    }
+}
+
+// ---- two-component 1-D Gaussian mixture -----------------------------------------------------------------------------------------
+constexpr int TG = 256;
+
+template <int K>
+__device__ inline void block_sum(double (&val)[K], double *lds) {   // -> every thread holds the sums (fixed order: reproducible)
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double s = val[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if ((threadIdx.x & 63) == 0) lds[(threadIdx.x >> 6) * K + k] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double s = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < TG / 64; ++wv) s += lds[wv * K + k];
+        val[k] = s;
+    }
+}
+
+__device__ inline double quantile_sorted(const float *xs, int m, double q) {   // numpy.quantile(method="linear") on sorted data
+    const double pos = q * (double)(m - 1);
+    int lo = (int)floor(pos);
+    if (lo > m - 1) lo = m - 1;
+    const int hi = lo + 1 < m ? lo + 1 : m - 1;
+    const double g = pos - (double)lo, a = (double)xs[lo], b = (double)xs[hi];
+    return g >= 0.5 ? b - (b - a) * (1.0 - g) : a + (b - a) * g;
+}
+
+// xs: m values sorted ascending; resp: 2 m doubles of scratch; out: mu0, mu1, var0, var1, pi0, pi1, iterations, log-likelihood.
+__global__ __launch_bounds__(TG) void k_gmm2(int m, const float *__restrict__ xs, double *resp, double *out, int iters, double tol,
+                                             double reg) {
+    __shared__ double lds[(TG / 64) * 4];
+    const int t = threadIdx.x;
+    if (m < 2 || xs[m - 1] == xs[0]) {
+        double s[1] = {0.0};
+        for (int i = t; i < m; i += TG) s[0] += (double)xs[i];
+        block_sum<1>(s, lds);
+        if (t == 0) {
+            const double mean = m ? s[0] / (double)m : 0.0;
+            out[0] = out[1] = mean;
+            out[2] = out[3] = reg;
+            out[4] = out[5] = 0.5;
+            out[6] = 0.0;
+            out[7] = 0.0;
+        }
+        return;
+    }
+    const double q1 = quantile_sorted(xs, m, 0.25), q3 = quantile_sorted(xs, m, 0.75);
+    double mu0 = q3 > q1 ? q1 : (double)xs[0], mu1 = q3 > q1 ? q3 : (double)xs[m - 1];
+    for (int it = 0; it < 10; ++it) {   // 2-means from the quartiles
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int i = t; i < m; i += TG) {
+            const double x = (double)xs[i];
+            const int a = fabs(x - mu1) < fabs(x - mu0);   // (argmin: the first on a tie)
+            s[a] += 1.0;
+            s[2 + a] += x;
+        }
+        block_sum<4>(s, lds);
+        if (s[0] == 0.0 || s[1] == 0.0) break;
+        mu0 = s[2] / s[0];
+        mu1 = s[3] / s[1];
+    }
+    for (int i = t; i < m; i += TG) {
+        const double x = (double)xs[i];
+        const int a = fabs(x - mu1) < fabs(x - mu0);
+        resp[2 * i] = a ? 0.0 : 1.0;
+        resp[2 * i + 1] = a ? 1.0 : 0.0;
+    }
+    double var0 = reg, var1 = reg, pi0 = 0.5, pi1 = 0.5, prev = -INFINITY, ll = 0.0;
+    int it = 0;
+    for (; it < iters; ++it) {
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int i = t; i < m; i += TG) {
+            const double x = (double)xs[i], r0 = resp[2 * i], r1 = resp[2 * i + 1];
+            s[0] += r0;
+            s[1] += r1;
+            s[2] += r0 * x;
+            s[3] += r1 * x;
+        }
+        block_sum<4>(s, lds);
+        const double n0 = s[0] + 1e-300, n1 = s[1] + 1e-300;
+        pi0 = n0 / (double)m;
+        pi1 = n1 / (double)m;
+        mu0 = s[2] / n0;
+        mu1 = s[3] / n1;
+        double q[2] = {0.0, 0.0};
+        for (int i = t; i < m; i += TG) {
+            const double x = (double)xs[i];
+            q[0] += resp[2 * i] * (x - mu0) * (x - mu0);
+            q[1] += resp[2 * i + 1] * (x - mu1) * (x - mu1);
+        }
+        block_sum<2>(q, lds);
+        var0 = q[0] / n0 + reg;
+        var1 = q[1] / n1 + reg;
+        const double c0 = -0.5 * log(2.0 * M_PI * var0) + log(pi0), c1 = -0.5 * log(2.0 * M_PI * var1) + log(pi1);
+        double l[1] = {0.0};
+        for (int i = t; i < m; i += TG) {
+            const double x = (double)xs[i];
+            const double p0 = c0 - 0.5 * (x - mu0) * (x - mu0) / var0, p1 = c1 - 0.5 * (x - mu1) * (x - mu1) / var1;
+            const double mx = fmax(p0, p1);
+            const double lse = mx + log(exp(p0 - mx) + exp(p1 - mx));
+            resp[2 * i] = exp(p0 - lse);
+            resp[2 * i + 1] = exp(p1 - lse);
+            l[0] += lse;
+        }
+        block_sum<1>(l, lds);
+        ll = l[0] / (double)m;
+        if (fabs(ll - prev) < tol) {
+            ++it;
+            break;
+        }
+        prev = ll;
+    }
+    if (t == 0) {
+        out[0] = mu0;
+        out[1] = mu1;
+        out[2] = var0;
+        out[3] = var1;
+        out[4] = pi0;
+        out[5] = pi1;
+        out[6] = (double)it;
+        out[7] = ll;
+    }
+}
+
+}   // namespace gp
+
+extern "C" long pdf_graph_forest_workspace_bytes(long n, long E, long n_nodes) {
+    if (n < 0 || E < 0 || n_nodes < 0) return 0;
+    return n_nodes * (long)sizeof(gp::u64) + (n + 2 * E + 3 * n_nodes) * (long)sizeof(int);
+}
+
+// Minimum spanning forest / connected components of one scene's region graph: see k_forest.  comp: n ints (out, written at the listed
+// nodes only); chosen: E bytes or NULL; w, active: may be NULL; workspace: pdf_graph_forest_workspace_bytes(n, E, n_nodes), 8-byte aligned.
+extern "C" int pdf_graph_forest(long n, int E, const long long *u, const long long *v, const float *w, const unsigned char *active,
+                                const long long *nodes, int n_nodes, int *comp, unsigned char *chosen, void *workspace,
+                                long workspace_bytes, void *stream) {
+    if (n < 0 || E < 0 || n_nodes < 0 || n > 0x7fffffffL) return PDF_ERR_BAD_ARG;
+    if (n_nodes == 0) return PDF_OK;
+    if (!nodes || !comp || !workspace || (E > 0 && (!u || !v))) return PDF_ERR_BAD_ARG;
+    if (workspace_bytes < pdf_graph_forest_workspace_bytes(n, E, n_nodes) || (reinterpret_cast<uintptr_t>(workspace) & 7)) return PDF_ERR_BAD_ARG;
+    gp::u64 *best = static_cast<gp::u64 *>(workspace);
+    int *slot = reinterpret_cast<int *>(best + n_nodes);
+    int *su = slot + n, *sv = su + E, *gcomp = sv + E, *parent = gcomp + n_nodes, *rootof = parent + n_nodes;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n_nodes <= gp::LDS_NODES) {
+        const size_t lds = (size_t)n_nodes * (sizeof(gp::u64) + sizeof(int));
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gp::k_forest<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        gp::k_forest<true><<<1, gp::T, lds, s>>>(E, u, v, w, active, nodes, n_nodes, comp, slot, su, sv, best, gcomp, parent, rootof, chosen);
+    } else {
+        gp::k_forest<false><<<1, gp::T, 0, s>>>(E, u, v, w, active, nodes, n_nodes, comp, slot, su, sv, best, gcomp, parent, rootof, chosen);
+    }
+    return pdf_launch_status();
+}
+
+#ifdef GP_PROFILE
+extern "C" int pdf_graph_forest_profile(long long *host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(gp::gp_prof), sizeof(long long) * 64 * 8) == hipSuccess ? PDF_OK : PDF_ERR_BAD_ARG;
+}
+#endif
+
+// Two-component 1-D Gaussian mixture of m sorted float values by EM in double (sklearn.mixture.GaussianMixture(n_components=2,
+// reg_covar=reg, tol=tol, max_iter=iters) with a deterministic start: quartiles -> 2-means).  resp: 2 m doubles of scratch;
+// out (8 doubles): means, variances, weights of the two components, the iterations run, the final mean log-likelihood.
+extern "C" int pdf_gmm2_1d(int m, const float *sorted_x, double *resp, double *out, int iters, double tol, double reg, void *stream) {
+    if (m < 0 || !out || (m > 0 && (!sorted_x || !resp)) || iters < 1) return PDF_ERR_BAD_ARG;
+    gp::k_gmm2<<<1, gp::TG, 0, static_cast<hipStream_t>(stream)>>>(m, sorted_x, resp, out, iters, tol, reg);
+    return pdf_launch_status();
+}

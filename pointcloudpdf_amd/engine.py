@@ -153,16 +153,61 @@ class CapturedStep:
         # the fork are then outside the graph's private pool (observed: replays that read recycled memory once eager work ran in between).
         self.stream = side   # an EAGER step of the same module between replays is fastest on this stream (see the comment above: the
         #                      parameters' AccumulateGrad nodes stay bound to it for as long as the captured autograd graph lives)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=side):
-            self.out = self._eager()
-            self._backward(self.out)
+        self.graph, self.graph2, self.mask_fn = torch.cuda.CUDAGraph(), None, None
+        rec = getattr(step, "recognizer", None)
+        if getattr(rec, "pseudo_mask_fn", None) is None:
+            with torch.cuda.graph(self.graph, stream=side):
+                self.out = self._eager()
+                self._backward(self.out)
+        else:
+            self._capture_around_the_pseudo_label_pass(rec, side, dev)
         self.grads = [p.grad for p in self.params]
         self.frozen = self._python_state()
         with torch.no_grad():   # (the capture itself does not execute anything, but keep the contract obvious)
             for b, v in zip(buffers, saved):
                 b.copy_(v)
         release_autograd_state(step)
+
+    def _capture_around_the_pseudo_label_pass(self, rec, side, dev):
+        """A step whose recognizer runs the PDF pseudo-label pass (``PointPdfV1.pseudo_mask_fn``: region growing with data-dependent
+        shapes and host reads, pointpdf_v1m1_base.py:118-382) is captured as TWO graphs sharing one memory pool: everything up to the
+        pass (segmentor forward, U-decoder forward), and everything after it (the recognizer's loss, the whole backward).  A replay runs
+        graph 1, the pass eagerly on the static logits (its host reads are legal there: nothing is being captured), copies the mask into
+        the static mask tensor graph 2 was recorded with, and runs graph 2.  The capture switches graphs from INSIDE the forward: the
+        recognizer's ``pseudo_mask_fn`` is swapped for a function that ends the first capture, begins the second and hands back the
+        static mask."""
+        import gc
+
+        n = int(self.static["coord"].shape[0])
+        self.static_mask = torch.zeros(n, dtype=torch.bool, device=dev)
+        self.mask_fn, self.static_logits, g1, g2 = rec.pseudo_mask_fn, None, self.graph, torch.cuda.CUDAGraph()
+        state = {"split": False}
+
+        def switch_graphs(coord, seg_logits, offset):
+            g1.capture_end()
+            self.static_logits = seg_logits.detach()
+            g2.capture_begin(pool=g1.pool())
+            state["split"] = True
+            return self.static_mask
+
+        torch.cuda.synchronize(dev)
+        gc.collect()
+        torch.cuda.empty_cache()
+        rec.pseudo_mask_fn = switch_graphs
+        try:
+            with torch.cuda.stream(side):
+                g1.capture_begin()
+                try:
+                    self.out = self._eager()
+                    self._backward(self.out)
+                finally:
+                    (g2 if state["split"] else g1).capture_end()
+        finally:
+            rec.pseudo_mask_fn = self.mask_fn
+        if state["split"]:
+            self.graph2 = g2
+        else:   # (the pass is not part of this step: before start_epoch the recognizer returns ahead of it)
+            self.mask_fn = None
 
     def _eager(self):
         with torch.autocast("cuda", dtype=self.autocast or torch.float16, enabled=self.autocast is not None):
@@ -204,6 +249,9 @@ class CapturedStep:
                                "(CapturedStep(step, batch, ...)) or run the eager step")
         self.geometry.stage(geom, extra=[(batch[k], self.static[k]) for k in self.KEYS])
         self.graph.replay()
+        if self.graph2 is not None:   # the pseudo-label pass between the two halves (eager: it reads sizes back to the host)
+            self.static_mask.copy_(self.mask_fn(self.static["coord"], self.static_logits, self.static["offset"]).bool())
+            self.graph2.replay()
         for p, g in zip(self.params, self.grads):
             p.grad = g
         return self.out

@@ -9,8 +9,9 @@ outlier-LARGE connected components survive).  The result is the boolean ``pseudo
 extra "unknown" label.
 
 What runs where: the neighbour table comes from the HIP radius query (``radius_neighbors``); region growing is torch indexing on the
-device; MST / GMM / connected components stay on scipy / sklearn on the host exactly as upstream (it moves the tensors with .cpu()
-there too) -- they see a few thousand edges.  Upstream spreads scenes over joblib workers; here they run on worker threads.
+device; spanning tree / mixture fit / connected components are single-workgroup HIP kernels for device tensors
+(``_prune_by_spanning_tree_hip``, csrc/graph_prune.hip) and scipy / sklearn on the host exactly as upstream for CPU tensors (the
+reference-parity path).  Upstream spreads scenes over joblib workers; here they run on worker threads.
 
 Parity: ``pseudo_labeling`` is pinned against the reference's OWN static method (tests/golden/ops_pseudo_label_ref.npz, same
 neighbour table, same torch / numpy seeds).  The neighbour table itself replaces ``torch_points_kernels.ball_query(radius,
@@ -18,6 +19,8 @@ max_neighbor, x, x, mode="partial_dense")`` -- an unvendored, unversioned depend
 behaviour (the first ``max_neighbor`` points of the same scene, in index order, with d2 < radius^2, padded with -1) is what
 ``radius_neighbors`` implements; that part is "parity unpinned".
 """
+import os
+
 import numpy as np
 import torch
 
@@ -239,6 +242,42 @@ def _prune_by_spanning_tree_device(coord, msp, neighbors, node):
     return torch.isin(lab, labels[big])
 
 
+def _prune_by_spanning_tree_hip(coord, msp, neighbors, node):
+    """``_prune_by_spanning_tree_device`` with the three graph steps as single-workgroup HIP kernels (csrc/graph_prune.hip): the spanning
+    forest (``pdf_graph_forest``: the same forest as ``minimum_spanning_forest`` -- under the strict order (weight, entry) it is unique),
+    the mixture fit (``pdf_gmm2_1d``: ``gmm2_1d``'s EM in double, on the device -- the threshold never visits the host) and the
+    connected components of the weak tree edges (``pdf_graph_forest`` without weights).  One host read remains (the tree's size)."""
+    be = _native.backend_for(coord)
+    n = coord.shape[0]
+    node_nn = neighbors[node]
+    sim = _pair_similarity(node, node_nn, coord, msp)
+    member = torch.zeros(n + 1, dtype=torch.bool, device=coord.device)     # (slot n: the -1 padding)
+    member[node] = True
+    keep = member[node_nn] & (node_nn != -1) & (node_nn != node[:, None])
+    eu = node[:, None].expand_as(node_nn)[keep]
+    ev = node_nn[keep]
+    ew = sim[keep]
+    key, inv = torch.unique(eu * n + ev, return_inverse=True)              # (repeated entries are SUMMED, as scipy's csr_matrix does)
+    ew = torch.zeros(key.shape[0], dtype=ew.dtype, device=ew.device).scatter_add_(0, inv, ew)
+    eu, ev = torch.div(key, n, rounding_mode="floor"), key % n
+    if eu.numel() == 0:
+        return torch.zeros(n, dtype=torch.bool, device=coord.device)
+    chosen, _ = be.graph_forest(n, eu, ev, node, weight=ew)
+    tree = torch.nonzero(chosen).flatten()
+    w, tu, tv = ew[tree], eu[tree], ev[tree]
+    fit = be.gmm2_1d(w)                                                    # means (2), variances (2), ... on the device
+    top = (fit[1] > fit[0]).long()                                         # np.argmax(means)
+    lower = fit[top] - 2.0 * fit[2 + top]                                  # the "std" of upstream's z-score filter is the covariance, as there
+    weak = w.double() < lower
+    _, lab = be.graph_forest(n, tu, tv, node, active=weak, want_chosen=False)
+    lab = lab.long()
+    touched = torch.unique(torch.cat([node, node_nn.reshape(-1)]))[1:]     # ([1:]: upstream drops the first entry, the -1 padding)
+    labels, sizes = torch.unique(lab[touched], return_counts=True)
+    sz = sizes.double()
+    big = (sz - sz.mean()) / sz.std(unbiased=False) > 2.0
+    return torch.isin(lab, labels[big])
+
+
 @torch.no_grad()
 def pseudo_labeling(coord, logits, neighbors, condition_from="msp", beta=1.5, seed_from="ml", seed_range=0.15, num_seed=100,
                     slide_window=True, generator=None, prune="auto"):
@@ -254,15 +293,22 @@ def pseudo_labeling(coord, logits, neighbors, condition_from="msp", beta=1.5, se
     seeds = torch.sort(src, dim=-1)[1][dice.to(src.device)]
     region = _grow_region(coord, score, neighbors, seeds, stop, slide_window)
     # prune: "host" = scipy / sklearn exactly as upstream (CPU tensors: the reference-parity path); "device" = the same stage as
-    # device graph ops + a deterministic mixture fit; "auto" = device for device tensors
-    if prune == "device" or (prune == "auto" and coord.is_cuda):
+    # torch graph ops + a deterministic mixture fit (any device); "hip" = that stage as HIP kernels (csrc/graph_prune.hip);
+    # "auto" = hip for device tensors
+    if prune == "hip" or (prune == "auto" and coord.is_cuda):
+        return _prune_by_spanning_tree_hip(coord, msp, neighbors, region).cpu()
+    if prune == "device":
         return _prune_by_spanning_tree_device(coord, msp, neighbors, region).cpu()
     return _prune_by_spanning_tree(coord, msp, neighbors, region)
 
 
 @torch.no_grad()
-def get_pseudo_mask(coord, seg_logits, offset, radius=0.1, max_neighbor=64, neighbors=None, offset_host=None, generator=None, workers=4, **kw):
+def get_pseudo_mask(coord, seg_logits, offset, radius=0.1, max_neighbor=64, neighbors=None, offset_host=None, generator=None, workers=None, **kw):
     """pointpdf_v1m1_base.py:118-185 for a batch: neighbour table once, scenes one by one; -> bool (N,) on coord's device."""
+    if workers is None:
+        # device tensors: the scenes one after the other (the HIP pruning stage leaves ~3 ms of short launches per scene: worker threads
+        # only fight over the interpreter lock, 46.4 vs 42.7 ms per step with 4 vs 1); host tensors: upstream's 4 workers (scipy / sklearn)
+        workers = int(os.environ.get("PDFOPS_PL_WORKERS", "1" if coord.is_cuda else "4"))
     if neighbors is None:
         neighbors = radius_neighbors(coord, offset, radius, max_neighbor)
     ends = offset_host if offset_host is not None else [int(v) for v in offset.tolist()]
@@ -298,4 +344,26 @@ def make_pseudo_mask_fn(radius=0.1, max_neighbor=64, **kw):
     condition_from, beta, seed_from, seed_range, num_seed, slide_window)."""
     def fn(coord, seg_logits, offset):
         return get_pseudo_mask(coord, seg_logits.detach(), offset, radius=radius, max_neighbor=max_neighbor, **kw)
+
+    if os.environ.get("PDFOPS_PL_TRACE"):   # diagnostics: host wall time of the wait for the forward and of the pass, per call
+        import atexit
+        import time
+        log = []
+
+        def traced(coord, seg_logits, offset):
+            t0 = time.perf_counter()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            mask = fn(coord, seg_logits, offset)
+            torch.cuda.synchronize()
+            log.append((t1 - t0, time.perf_counter() - t1))
+            return mask
+
+        def report():
+            tail = log[len(log) // 2:]
+            if tail:
+                print(f"[PDFOPS_PL_TRACE] {len(log)} calls; second half: wait for the forward {1e3 * sum(a for a, _ in tail) / len(tail):.2f} ms, "
+                      f"pass {1e3 * sum(b for _, b in tail) / len(tail):.2f} ms per call", file=__import__("sys").stderr)
+        atexit.register(report)
+        return traced
     return fn

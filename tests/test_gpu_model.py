@@ -598,6 +598,47 @@ def test_train_step_recaptures_a_size_class_whose_schedule_state_went_stale():
     assert all(torch.equal(a, b) for a, b in zip(params, p_eager))
 
 
+def test_captured_step_splits_around_the_pseudo_label_pass():
+    """A step WITH the PDF pseudo-label pass (config 4) replays as two graphs with the pass run eagerly between them
+    (CapturedStep._capture_around_the_pseudo_label_pass): five steps over two ScanNet-shaped batches equal five eager steps bit for bit.
+    The mask function here reads a threshold back to the host -- what no single capture could contain."""
+    from pointcloudpdf_amd import engine, synthetic
+
+    dev = torch.device("cuda", 0)
+    pool = [synthetic.make_batch([2600, 2300], first_scene_id=90 + 3 * i, device=dev, kind="scannet", unknown=(4, 7, 14, 16)) for i in range(2)]
+    calls = []
+
+    def mask_fn(coord, seg_logits, offset):
+        top = seg_logits.max(-1)[0]
+        thr = float(top.median())                      # host read
+        calls.append(thr)
+        return top < thr
+
+    def run(graph):
+        step = engine.OpenSegStep(in_channels=9, num_classes=20, loss_weight=0.04, pseudo_mask_fn=mask_fn).to(dev)
+        synthetic.fill_parameters_deterministic(step, seed=6)
+        step.train()
+        opt = engine.FusedSGD(step.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4)
+        train = engine.TrainStep(step, opt, graph=graph)
+        batches = ({k: pool[i % 2][k] for k in ("coord", "feat", "offset", "offset_host", "segment")} for i in range(5))
+        del calls[:]
+        outs = [train(b) for b in engine.GroupedGeometryLoader(batches, group=0)]
+        losses = [(float(o["loss"]), float(o["recognizer_loss"])) for o in outs[-1:]]
+        torch.cuda.synchronize()
+        params = [p.detach().clone() for p in step.parameters()]
+        split = train.captured is not None and train.captured.graph2 is not None
+        assert train.capture_error is None, train.capture_error
+        engine.release_autograd_state(step)
+        return losses, params, split, list(calls)
+
+    eager, p_eager, _, thr_eager = run(False)
+    losses, params, split, thr = run(True)
+    assert split and eager[0][1] > 0
+    assert thr[-5:] == thr_eager, (thr, thr_eager)          # (the capture's warm-up passes call the function too: the last five are the steps)
+    assert losses == eager, (losses, eager)
+    assert all(torch.equal(a, b) for a, b in zip(params, p_eager))
+
+
 def test_captured_step_refuses_a_stale_schedule_state():
     """A graph replays what was recorded: once the recognizer's alpha changed (PointPdfV1.trigger_operation at start_epoch) the captured
     step no longer `matches` and a direct call raises instead of silently training with the old loss weight."""

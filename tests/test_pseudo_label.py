@@ -158,3 +158,88 @@ def test_device_pruning_matches_host_pruning(use_oracle, gp):
         dev = pl.pseudo_labeling(coord, logits, nn, generator=torch.Generator().manual_seed(seed), prune="device", **PSEUDO_KW)
         inter, union = int((host & dev).sum()), int((host | dev).sum())
         assert union > 0 and inter / union >= 0.9, (tag, inter, union)
+
+
+# ---------------------------------------------------------------- the pruning stage as HIP kernels (round 4, csrc/graph_prune.hip)
+@pytest.mark.gpu
+def test_hip_forest_kernel_matches_the_boruvka_restatement():
+    """pdf_graph_forest against pseudo_label.minimum_spanning_forest / connected_labels (the torch restatements pinned against scipy
+    above) on random directed neighbour graphs over a SUBSET of a scene's points (ids up to n, repeats in the node list, both directions
+    stored with different weights, negative weights, ties): the same entries chosen (the forest is unique under the order
+    (weight, entry)), the same partition; then components of a masked edge list without weights."""
+    from pointcloudpdf_amd import _native, pseudo_label as pl
+
+    be = _native.hip_backend()
+    g = torch.Generator().manual_seed(3)
+    for trial, (n, r, k) in enumerate([(5000, 1500, 8), (5000, 1500, 8), (5000, 1500, 8), (40000, 9000, 24), (300, 1, 4), (300, 2, 1), (20000, 5000, 2),
+                                       (60000, 14000, 6)]):   # (the last: more listed nodes than the LDS form holds)
+        nodes = torch.randperm(n, generator=g)[:r]
+        nn = nodes[torch.randint(0, r, (r, k), generator=g)]
+        if trial in (1, 6):   # many components: neighbours only inside blocks of the node list
+            blk = max(r // 12, 1)
+            nn = nodes[((torch.arange(r)[:, None] // blk) * blk + torch.randint(0, blk, (r, k), generator=g)).clamp(max=r - 1)]
+        w = torch.rand(r, k, generator=g) - 0.3
+        if trial == 2:
+            w = torch.round(w * 8) / 8          # ties: broken by entry index
+        eu, ev, ew = nodes[:, None].expand(r, k).reshape(-1), nn.reshape(-1), w.reshape(-1)
+        keep = eu != ev
+        key, first = np.unique((eu[keep] * n + ev[keep]).numpy(), return_index=True)
+        eu, ev, ew = eu[keep][first].cuda(), ev[keep][first].cuda(), ew[keep][first].cuda()
+        listed = torch.cat([nodes, nodes[: r // 3]]).cuda()     # repeats, as a seed list drawn with replacement has them
+        if eu.numel() == 0:
+            continue
+        chosen, comp = be.graph_forest(n, eu, ev, listed, weight=ew)
+        ref = pl.minimum_spanning_forest(n, eu, ev, ew)
+        assert torch.equal(torch.nonzero(chosen).flatten(), ref), trial
+        lab_ref = pl.connected_labels(n, eu, ev)
+        pairs = torch.unique(torch.stack([lab_ref, comp.long()], 1), dim=0)
+        assert pairs.shape[0] == torch.unique(lab_ref).numel() == torch.unique(comp).numel(), trial
+        # components of a subset of the tree's edges, no weights
+        tu, tv = eu[ref], ev[ref]
+        active = torch.rand(tu.shape[0], generator=g).cuda() < 0.7
+        _, comp2 = be.graph_forest(n, tu, tv, listed, active=active, want_chosen=False)
+        lab2 = pl.connected_labels(n, tu[active], tv[active])
+        pairs = torch.unique(torch.stack([lab2, comp2.long()], 1), dim=0)
+        assert pairs.shape[0] == torch.unique(lab2).numel() == torch.unique(comp2).numel(), trial
+
+
+@pytest.mark.gpu
+def test_hip_mixture_kernel_matches_the_numpy_em():
+    """pdf_gmm2_1d against pseudo_label.gmm2_1d (pinned against sklearn above): same start, same EM in double, same stopping rule --
+    means / variances / weights to 1e-9, the same number of iterations; degenerate inputs (0, 1, 2 values, all equal)."""
+    from pointcloudpdf_amd import _native, pseudo_label as pl
+
+    be = _native.hip_backend()
+    cases = [(0.2, 0.05, 3000, 0.7, 0.1, 1500), (-0.5, 0.2, 800, 0.6, 0.05, 4000), (0.55, 0.02, 2200, 0.3, 0.1, 120), (0.0, 1.0, 3, 5.0, 1.0, 2),
+             (0.4, 0.05, 30000, 0.6, 0.05, 30000)]
+    for seed, (m0, s0, n0, m1, s1, n1) in enumerate(cases):
+        rs = np.random.RandomState(seed)
+        x = np.concatenate([rs.normal(m0, s0, n0), rs.normal(m1, s1, n1)]).astype(np.float32)
+        rs.shuffle(x)
+        mu, var, pi = pl.gmm2_1d(x)
+        out = be.gmm2_1d(torch.from_numpy(x).cuda()).cpu().numpy()
+        assert np.allclose(out[0:2], mu, rtol=1e-9, atol=1e-12) and np.allclose(out[2:4], var, rtol=1e-8, atol=1e-14), (seed, out, mu, var)
+        assert np.allclose(out[4:6], pi, rtol=1e-9, atol=1e-12), (seed, out, pi)
+    for x in (np.zeros(0, np.float32), np.array([0.25], np.float32), np.array([0.25, 0.25, 0.25], np.float32), np.array([0.1, 0.9], np.float32)):
+        mu, var, pi = pl.gmm2_1d(x)
+        out = be.gmm2_1d(torch.from_numpy(x).cuda()).cpu().numpy()
+        assert np.allclose(out[0:2], mu, atol=1e-12) and np.allclose(out[2:4], var, rtol=1e-9) and np.allclose(out[4:6], pi, atol=1e-12), (x, out, mu, var, pi)
+
+
+@pytest.mark.gpu
+def test_hip_pruning_equals_the_torch_op_pruning():
+    """pseudo_labeling(prune="hip") (the default for device tensors) and prune="device" (the same stage as torch ops + numpy EM) give the
+    same mask on the fixture scenes and on a random-logit scene (one growth round, ~2k-point region: what a fresh model hands the pass)."""
+    from pointcloudpdf_amd import pseudo_label as pl, synthetic
+
+    scenes = [pseudo_label_scene(*PSEUDO_CASES[t]) for t in sorted(PSEUDO_CASES)]
+    g = torch.Generator().manual_seed(5)
+    sc = synthetic.make_scene(60000, scene_id=9, kind="scannet")
+    scenes.append((torch.from_numpy(sc["coord"]), 0.3 * torch.randn(60000, 20, generator=g)))
+    for i, (coord, logits) in enumerate(scenes):
+        coord, logits = coord.cuda(), logits.cuda()
+        n = coord.shape[0]
+        nn = pl.radius_neighbors(coord, torch.tensor([n], dtype=torch.int32, device="cuda"), 0.1, 64)
+        a = pl.pseudo_labeling(coord, logits, nn, generator=torch.Generator().manual_seed(i), prune="hip", **PSEUDO_KW)
+        b = pl.pseudo_labeling(coord, logits, nn, generator=torch.Generator().manual_seed(i), prune="device", **PSEUDO_KW)
+        assert int(a.sum()) > 0 and torch.equal(a, b), (i, int(a.sum()), int(b.sum()), int((a ^ b).sum()))
