@@ -50,10 +50,11 @@ def _pair_similarity(node, node_nn, coord, score):
     return 0.4 * dist_sim + 0.6 * conf_sim
 
 
-def _grow_region(coord, score, neighbors, seeds, stop, slide_window):
-    """pointpdf_v1m1_base.py:233-305"""
+def _grow_region(coord, score, neighbors, seeds, stop, slide_window, with_flag=False):
+    """pointpdf_v1m1_base.py:233-305.  ``with_flag``: also return whether the region grew (it is then a sorted ``unique``)."""
     graph = seeds
     n = coord.shape[0]
+    grew = False
     while True:
         g_coord, g_score = coord[graph], score[graph]
         if g_score.mean(0) > stop and len(graph) > 0.01 * n and len(graph) > 50:
@@ -74,8 +75,8 @@ def _grow_region(coord, score, neighbors, seeds, stop, slide_window):
         grown = grown[grown != -1]
         if grown.shape[0] == graph.shape[0]:
             break
-        graph = grown
-    return graph
+        graph, grew = grown, True
+    return (graph, grew) if with_flag else graph
 
 
 def _prune_by_spanning_tree(coord, msp, neighbors, node):
@@ -242,11 +243,12 @@ def _prune_by_spanning_tree_device(coord, msp, neighbors, node):
     return torch.isin(lab, labels[big])
 
 
-def _prune_by_spanning_tree_hip(coord, msp, neighbors, node):
+def _prune_by_spanning_tree_hip(coord, msp, neighbors, node, distinct=False):
     """``_prune_by_spanning_tree_device`` with the three graph steps as single-workgroup HIP kernels (csrc/graph_prune.hip): the spanning
     forest (``pdf_graph_forest``: the same forest as ``minimum_spanning_forest`` -- under the strict order (weight, entry) it is unique),
     the mixture fit (``pdf_gmm2_1d``: ``gmm2_1d``'s EM in double, on the device -- the threshold never visits the host) and the
-    connected components of the weak tree edges (``pdf_graph_forest`` without weights).  One host read remains (the tree's size)."""
+    connected components of the weak tree edges (``pdf_graph_forest`` without weights).  One host read remains (the tree's size).
+    ``distinct``: ``node`` is sorted and free of repeats (a region that grew at least once)."""
     be = _native.backend_for(coord)
     n = coord.shape[0]
     node_nn = neighbors[node]
@@ -257,9 +259,13 @@ def _prune_by_spanning_tree_hip(coord, msp, neighbors, node):
     eu = node[:, None].expand_as(node_nn)[keep]
     ev = node_nn[keep]
     ew = sim[keep]
-    key, inv = torch.unique(eu * n + ev, return_inverse=True)              # (repeated entries are SUMMED, as scipy's csr_matrix does)
-    ew = torch.zeros(key.shape[0], dtype=ew.dtype, device=ew.device).scatter_add_(0, inv, ew)
-    eu, ev = torch.div(key, n, rounding_mode="floor"), key % n
+    if not distinct:
+        # repeated (row, col) entries are SUMMED, as scipy's csr_matrix does -- `node` holds repeats only while the region is still the
+        # seed list (seeds are drawn with replacement, :206).  A grown region is a sorted `unique` and a neighbour row lists ids in
+        # ascending order: its entries are distinct and already in this (row, col) order
+        key, inv = torch.unique(eu * n + ev, return_inverse=True)
+        ew = torch.zeros(key.shape[0], dtype=ew.dtype, device=ew.device).scatter_add_(0, inv, ew)
+        eu, ev = torch.div(key, n, rounding_mode="floor"), key % n
     if eu.numel() == 0:
         return torch.zeros(n, dtype=torch.bool, device=coord.device)
     chosen, _ = be.graph_forest(n, eu, ev, node, weight=ew)
@@ -291,12 +297,12 @@ def pseudo_labeling(coord, logits, neighbors, condition_from="msp", beta=1.5, se
     src = msp if seed_from == "msp" else ml
     dice = torch.randint(0, int(seed_range * len(src)), [num_seed], generator=generator)
     seeds = torch.sort(src, dim=-1)[1][dice.to(src.device)]
-    region = _grow_region(coord, score, neighbors, seeds, stop, slide_window)
+    region, grew = _grow_region(coord, score, neighbors, seeds, stop, slide_window, with_flag=True)
     # prune: "host" = scipy / sklearn exactly as upstream (CPU tensors: the reference-parity path); "device" = the same stage as
     # torch graph ops + a deterministic mixture fit (any device); "hip" = that stage as HIP kernels (csrc/graph_prune.hip);
     # "auto" = hip for device tensors
     if prune == "hip" or (prune == "auto" and coord.is_cuda):
-        return _prune_by_spanning_tree_hip(coord, msp, neighbors, region).cpu()
+        return _prune_by_spanning_tree_hip(coord, msp, neighbors, region, distinct=grew).cpu()
     if prune == "device":
         return _prune_by_spanning_tree_device(coord, msp, neighbors, region).cpu()
     return _prune_by_spanning_tree(coord, msp, neighbors, region)
