@@ -467,7 +467,7 @@ int pdf_radius_neighbors_self(int n, int nsample, float radius, const float *xyz
 /* The graph stage of the PDF pseudo-label pass (pointpdf_v1m1_base.py:309-380: scipy.sparse.csgraph.minimum_spanning_tree over the
  * region's neighbour similarities, :340; connected_components of the weak tree edges, :360) for ONE scene, one workgroup.
  * u, v (E directed entries, node ids < n), w (E weights, or NULL: all equal), active (E flags, or NULL: all), nodes (n_nodes ids,
- * repeats allowed, covering every endpoint of an active entry).  chosen (E bytes, or NULL) = 1 for the entries of the minimum
+ * repeats allowed, covering every endpoint of an active entry; an entry with an endpoint outside the list or outside [0, n) is ignored).  chosen (E bytes, or NULL) = 1 for the entries of the minimum
  * spanning forest under the strict order (weight, entry index); comp (n ints, written at the listed nodes only) = the root of the
  * node's connected component (one of its node ids).  workspace: pdf_graph_forest_workspace_bytes(n, E, n_nodes) bytes, 8-byte
  * aligned.  Lists of up to 12,288 nodes keep the per-round state in LDS. */

@@ -46,7 +46,7 @@ __device__ long long gp_prof[64 * 8];
 constexpr int LDS_NODES = 12288;   // 12 B per slot: 144 KB of the CU's 160 KB
 
 template <bool LDS>
-__global__ __launch_bounds__(T) void k_forest(int E, const long long *__restrict__ u, const long long *__restrict__ v,
+__global__ __launch_bounds__(T) void k_forest(long long n, int E, const long long *__restrict__ u, const long long *__restrict__ v,
                                               const float *__restrict__ w, const unsigned char *__restrict__ active,
                                               const long long *__restrict__ nodes, int n_nodes, int *comp_out, int *slot, int *su, int *sv,
                                               u64 *gbest, int *gcomp, int *parent, int *rootof, unsigned char *chosen) {
@@ -67,15 +67,28 @@ __global__ __launch_bounds__(T) void k_forest(int E, const long long *__restrict
     };
     const int t = threadIdx.x;
     for (int i = t; i < n_nodes; i += T) {
-        slot[(int)nodes[i]] = i;   // (a repeated id keeps one of its positions: whichever store lands last)
+        const long long x = nodes[i];
+        if (x >= 0 && x < n) slot[x] = i;   // (a repeated id keeps one of its positions: whichever store lands last)
         comp[i] = i;
     }
     if (t == 0) live = 0;
     __syncthreads();
+    // `slot` is scratch that only the listed ids initialised: an endpoint outside [0, n) or missing from the list (a caller's mistake)
+    // reads garbage there -- such an entry is dropped (its slot would not point back at the id), it must not index LDS
+    auto slot_of = [&](long long x) -> int {
+        if (x < 0 || x >= n) return -1;
+        const int k = slot[x];
+        return ((unsigned)k < (unsigned)n_nodes && nodes[k] == x) ? k : -1;
+    };
     for (int e = t; e < E; e += T) {
-        const bool ok = !active || active[e];
-        su[e] = ok ? slot[(int)u[e]] : -1;
-        sv[e] = ok ? slot[(int)v[e]] : -1;
+        int a = -1, b = -1;
+        if (!active || active[e]) {
+            a = slot_of(u[e]);
+            b = slot_of(v[e]);
+        }
+        const bool ok = a >= 0 && b >= 0;
+        su[e] = ok ? a : -1;
+        sv[e] = ok ? b : -1;
         if (chosen) chosen[e] = 0;
     }
     __syncthreads();
@@ -158,8 +171,8 @@ __global__ __launch_bounds__(T) void k_forest(int E, const long long *__restrict
         GP_TICK(round, 3);
     }
     for (int i = t; i < n_nodes; i += T) {
-        const int x = (int)nodes[i];
-        comp_out[x] = (int)nodes[comp[slot[x]]];
+        const long long x = nodes[i];
+        if (x >= 0 && x < n) comp_out[x] = (int)nodes[comp[slot[x]]];
     }
 }
 
@@ -316,9 +329,9 @@ extern "C" int pdf_graph_forest(long n, int E, const long long *u, const long lo
         const size_t lds = (size_t)n_nodes * (sizeof(gp::u64) + sizeof(int));
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gp::k_forest<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        gp::k_forest<true><<<1, gp::T, lds, s>>>(E, u, v, w, active, nodes, n_nodes, comp, slot, su, sv, best, gcomp, parent, rootof, chosen);
+        gp::k_forest<true><<<1, gp::T, lds, s>>>(n, E, u, v, w, active, nodes, n_nodes, comp, slot, su, sv, best, gcomp, parent, rootof, chosen);
     } else {
-        gp::k_forest<false><<<1, gp::T, 0, s>>>(E, u, v, w, active, nodes, n_nodes, comp, slot, su, sv, best, gcomp, parent, rootof, chosen);
+        gp::k_forest<false><<<1, gp::T, 0, s>>>(n, E, u, v, w, active, nodes, n_nodes, comp, slot, su, sv, best, gcomp, parent, rootof, chosen);
     }
     return pdf_launch_status();
 }

@@ -51,7 +51,45 @@ def _pair_similarity(node, node_nn, coord, score):
 
 
 def _grow_region(coord, score, neighbors, seeds, stop, slide_window, with_flag=False):
-    """pointpdf_v1m1_base.py:233-305.  ``with_flag``: also return whether the region grew (it is then a sorted ``unique``)."""
+    """pointpdf_v1m1_base.py:233-305.  ``with_flag``: also return whether the region grew (it is then sorted and free of repeats).
+
+    Upstream forms the candidate set as ``unique(neighbors[graph])`` minus ``-1`` minus ``isin(., graph)`` and the grown region as
+    ``unique(cat(graph, chosen))``: three sorts of up to |graph| x 64 ids per round.  The same SETS, in the same ascending order, come
+    out of a membership mask over the scene's points (scatter the ids, clear the members, ``nonzero``): one host read per set instead
+    of a sort + a read, every other line as upstream (``_grow_region_reference`` is the line-by-line form; the tests compare them)."""
+    graph = seeds
+    n = coord.shape[0]
+    grew = False
+    while True:
+        g_coord, g_score = coord[graph], score[graph]
+        if g_score.mean(0) > stop and len(graph) > 0.01 * n and len(graph) > 50:
+            break
+        seen = torch.zeros(n + 1, dtype=torch.bool, device=coord.device)   # (slot n: the -1 padding)
+        seen[neighbors[graph].reshape(-1)] = True
+        seen[graph] = False
+        cand = torch.nonzero(seen[:n]).flatten()
+        dist = torch.norm(coord[cand] - g_coord.mean(0), dim=-1)
+        dist_sim = 1 - (dist - dist.min()) / (dist.max() - dist.min() + 1e-3)
+        if slide_window:
+            lo = torch.kthvalue(g_score, int(len(g_score) * 0.1)).values
+            hi = torch.kthvalue(g_score, int(len(g_score) * 0.6)).values
+        else:
+            lo, hi = g_score.min(), g_score.max()
+        conf_sim = torch.exp(-torch.abs(score[cand] - g_score[(g_score >= lo) & (g_score <= hi)].mean(0)))
+        sim = 0.4 * dist_sim + 0.6 * conf_sim
+        take = torch.topk(sim.view(-1), k=int(sim.numel() * 0.4))[1]
+        seen.zero_()
+        seen[graph] = True
+        seen[cand[take]] = True
+        grown = torch.nonzero(seen[:n]).flatten()
+        if grown.shape[0] == graph.shape[0]:
+            break
+        graph, grew = grown, True
+    return (graph, grew) if with_flag else graph
+
+
+def _grow_region_reference(coord, score, neighbors, seeds, stop, slide_window, with_flag=False):
+    """pointpdf_v1m1_base.py:233-305 line by line (``unique`` / ``isin`` per round): what ``_grow_region`` is tested against."""
     graph = seeds
     n = coord.shape[0]
     grew = False
@@ -297,7 +335,8 @@ def pseudo_labeling(coord, logits, neighbors, condition_from="msp", beta=1.5, se
     src = msp if seed_from == "msp" else ml
     dice = torch.randint(0, int(seed_range * len(src)), [num_seed], generator=generator)
     seeds = torch.sort(src, dim=-1)[1][dice.to(src.device)]
-    region, grew = _grow_region(coord, score, neighbors, seeds, stop, slide_window, with_flag=True)
+    grow = _grow_region_reference if os.environ.get("PDFOPS_PL_GROW") == "reference" else _grow_region   # (A/B knob)
+    region, grew = grow(coord, score, neighbors, seeds, stop, slide_window, with_flag=True)
     # prune: "host" = scipy / sklearn exactly as upstream (CPU tensors: the reference-parity path); "device" = the same stage as
     # torch graph ops + a deterministic mixture fit (any device); "hip" = that stage as HIP kernels (csrc/graph_prune.hip);
     # "auto" = hip for device tensors
@@ -323,8 +362,8 @@ def get_pseudo_mask(coord, seg_logits, offset, radius=0.1, max_neighbor=64, neig
 
     def one(se):
         s0, e = se
-        nn = neighbors[s0:e].clone()
-        nn[nn != -1] -= s0
+        nn = neighbors[s0:e]
+        nn = torch.where(nn != -1, nn - s0, nn)
         return pseudo_labeling(coord[s0:e], seg_logits[s0:e], nn, generator=generator, **kw)
 
     def one_on_stream(se):   # worker threads start on the default stream: keep them on the caller's

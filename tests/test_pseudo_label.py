@@ -98,6 +98,25 @@ def test_training_step_with_the_pseudo_label_pass():
     assert all(p.grad is None or torch.isfinite(p.grad).all() for p in step.parameters())
 
 
+def test_mask_based_region_growing_equals_the_line_by_line_form(use_oracle):
+    """_grow_region (candidate / grown sets out of a membership mask) against _grow_region_reference (upstream's unique / isin per
+    round) on the fixture scenes: the same region, element for element; with and without the sliding window."""
+    from pointcloudpdf_amd import pseudo_label as pl
+
+    for tag, (seed, n) in PSEUDO_CASES.items():
+        coord, logits = pseudo_label_scene(seed, n)
+        nn = pl.radius_neighbors(coord, torch.tensor([n], dtype=torch.int32), 0.1, 64)
+        msp = torch.softmax(logits, dim=-1).max(dim=-1)[0]
+        ml = logits.max(dim=-1)[0]
+        stop = torch.mean(msp) - 1.5 * torch.std(msp)
+        dice = torch.randint(0, int(0.15 * n), [100], generator=torch.Generator().manual_seed(seed))
+        seeds = torch.sort(ml, dim=-1)[1][dice]
+        for window in (True, False):
+            a, grew = pl._grow_region(coord, msp, nn, seeds, stop, window, with_flag=True)
+            b = pl._grow_region_reference(coord, msp, nn, seeds, stop, window)
+            assert torch.equal(a, b) and grew == (not torch.equal(a, seeds)), (tag, window, grew, a.numel(), b.numel())
+
+
 # ---------------------------------------------------------------- the pruning stage as device graph ops (round 2)
 def test_device_spanning_forest_and_components_match_scipy():
     """Boruvka (minimum_spanning_forest) picks a forest of the same size and total weight as scipy's minimum_spanning_tree on random
@@ -201,6 +220,36 @@ def test_hip_forest_kernel_matches_the_boruvka_restatement():
         lab2 = pl.connected_labels(n, tu[active], tv[active])
         pairs = torch.unique(torch.stack([lab2, comp2.long()], 1), dim=0)
         assert pairs.shape[0] == torch.unique(lab2).numel() == torch.unique(comp2).numel(), trial
+
+
+@pytest.mark.gpu
+def test_hip_forest_kernel_ignores_entries_outside_the_node_list():
+    """The kernel's scratch is only initialised at the listed ids: an entry whose endpoint is not listed, or not in [0, n), must be
+    dropped (not followed into LDS) -- the forest is then the one of the entries among listed nodes."""
+    from pointcloudpdf_amd import _native, pseudo_label as pl
+
+    be = _native.hip_backend()
+    g = torch.Generator().manual_seed(8)
+    n, r, k = 6000, 2000, 6
+    nodes = torch.randperm(n, generator=g)[:r]
+    eu = nodes[:, None].expand(r, k).reshape(-1)
+    ev = nodes[torch.randint(0, r, (r * k,), generator=g)]
+    keep = eu != ev
+    key, first = np.unique((eu[keep] * n + ev[keep]).numpy(), return_index=True)
+    eu, ev = eu[keep][first], ev[keep][first]
+    ew = torch.rand(eu.shape[0], generator=g)
+    bad_u = torch.tensor([n + 5, -3, int(nodes[0]), 2 ** 40])
+    bad_v = torch.tensor([int(nodes[1]), int(nodes[2]), n + 77, int(nodes[3])])
+    eu2, ev2, ew2 = torch.cat([eu, bad_u]).cuda(), torch.cat([ev, bad_v]).cuda(), torch.cat([ew, torch.zeros(4) - 5.0]).cuda()
+    listed = nodes[: r // 2].cuda()                                      # half of the endpoints are NOT listed
+    chosen, comp = be.graph_forest(n, eu2, ev2, listed, weight=ew2)
+    inside = torch.isin(eu2, listed) & torch.isin(ev2, listed)
+    idx = torch.nonzero(inside).flatten()
+    ref = idx[pl.minimum_spanning_forest(n, eu2[idx], ev2[idx], ew2[idx])]
+    assert torch.equal(torch.nonzero(chosen).flatten(), ref)
+    unlisted = torch.ones(n, dtype=torch.bool, device="cuda")
+    unlisted[listed] = False
+    assert torch.equal(comp[unlisted].long(), torch.arange(n, device="cuda")[unlisted])
 
 
 @pytest.mark.gpu

@@ -53,14 +53,14 @@ for rep in range(2):
         return msp, stop, torch.sort(ml, dim=-1)[1][dice.to(ml.device)]
     (msp, stop, seeds), t_seed = timed(seeds_fn)
     rounds = [0]
-    orig_unique = torch.unique
+    orig_unique = torch.nonzero
 
     def counting_unique(*a, **k):
         rounds[0] += 1
         return orig_unique(*a, **k)
-    torch.unique = counting_unique
+    torch.nonzero = counting_unique
     region, t_grow = timed(pseudo_label._grow_region, c, msp, local, seeds, stop, True)
-    torch.unique = orig_unique
+    torch.nonzero = orig_unique
     mask, t_prune = timed(pseudo_label._prune_by_spanning_tree_device, c, msp, local, region)
     print(f"scene 0 rep {rep}: seeds {t_seed:.2f} ms, growing {t_grow:.2f} ms ({rounds[0] // 2} rounds, region {region.numel()}), "
           f"pruning {t_prune:.2f} ms (mask {int(mask.sum())})")
