@@ -144,3 +144,53 @@ def test_captured_step_state_guard_is_host_logic():
     step.eval()
     c = cap._python_state()
     assert a != b and b != c and a[0] == 2 * b[0]
+
+
+def test_train_step_keeps_one_graph_per_size_class_host_logic(monkeypatch):
+    """TrainStep._capture_for (which capture IS this batch's step): one per scene-size signature up to ``max_captures``, every capture on
+    the first one's stream, further signatures eager, stale captures (schedule state moved) released and their size class captured
+    again.  The captures are stand-ins here (the replays themselves: tests/test_gpu_model.py)."""
+    from pointcloudpdf_amd import engine
+
+    made = []
+    state = {"alpha": 1.0}
+
+    class FakeCapture:
+        def __init__(self, step, batch, geom=None, autocast=None, loss_scale=1.0, stream=None):
+            self.sizes, self.stream_arg = list(batch["offset_host"]), stream
+            self.stream = stream if stream is not None else object()
+            self.frozen = state["alpha"]
+            made.append(self)
+
+        def _python_state(self):
+            return state["alpha"]
+
+        def matches(self, batch):
+            return list(batch["offset_host"]) == self.sizes and self._python_state() == self.frozen
+
+    monkeypatch.setattr(engine, "CapturedStep", FakeCapture)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(torch.cuda, "empty_cache", lambda *a, **k: None)
+    lin = torch.nn.Linear(2, 2)
+    train = engine.TrainStep(lin, optimizer=None, graph=True, max_captures=2)
+    A, B, C = ({"offset_host": s} for s in ([10, 20], [11, 20], [12, 20]))
+    a = train._capture_for(A, None)
+    assert a is made[0] and train.captured is a and a.stream_arg is None
+    assert train._capture_for(A, None) is a and len(made) == 1          # same sizes: the same capture
+    b = train._capture_for(B, None)
+    assert b is made[1] and b.stream_arg is a.stream                     # recorded on the first capture's stream
+    assert train._capture_for(C, None) is None and len(made) == 2       # both slots taken: eager
+    assert train._capture_for(A, None) is a and train._capture_for(B, None) is b
+    state["alpha"] = 0.1                                                 # the schedule moved: both graphs are stale
+    c = train._capture_for(C, None)
+    assert c is made[2] and train.captures == [c] and train.captured is c and c.stream_arg is a.stream
+    a2 = train._capture_for(A, None)
+    assert a2 is made[3] and train.captures == [c, a2]
+    assert train._capture_for(B, None) is None
+
+    def boom(*a, **k):
+        raise RuntimeError("capture failed")
+    monkeypatch.setattr(engine, "CapturedStep", boom)
+    monkeypatch.setattr(engine, "release_autograd_state", lambda step: None)
+    one = engine.TrainStep(lin, optimizer=None, graph=True)
+    assert one._capture_for(A, None) is None and "capture failed" in one.capture_error and one.graph is False and one.captures == []
