@@ -401,14 +401,18 @@ def make_pseudo_mask_fn(radius=0.1, max_neighbor=64, **kw):
             t1 = time.perf_counter()
             mask = fn(coord, seg_logits, offset)
             torch.cuda.synchronize()
-            log.append((t1 - t0, time.perf_counter() - t1))
+            st = torch.cuda.memory_stats()
+            log.append((t1 - t0, time.perf_counter() - t1, st.get("num_device_alloc", 0), st.get("num_alloc_retries", 0)))
             return mask
 
         def report():
             tail = log[len(log) // 2:]
             if tail:
-                print(f"[PDFOPS_PL_TRACE] {len(log)} calls; second half: wait for the forward {1e3 * sum(a for a, _ in tail) / len(tail):.2f} ms, "
-                      f"pass {1e3 * sum(b for _, b in tail) / len(tail):.2f} ms per call", file=__import__("sys").stderr)
+                passes = sorted(x[1] for x in tail)
+                print(f"[PDFOPS_PL_TRACE] {len(log)} calls; second half: wait for the forward {1e3 * sum(x[0] for x in tail) / len(tail):.2f} ms, "
+                      f"pass {1e3 * sum(passes) / len(tail):.2f} ms per call (min {1e3 * passes[0]:.2f}, median {1e3 * passes[len(passes) // 2]:.2f}, "
+                      f"max {1e3 * passes[-1]:.2f}); device allocations in that half: {tail[-1][2] - tail[0][2]}, allocator retries: "
+                      f"{tail[-1][3] - tail[0][3]}", file=__import__("sys").stderr)
         atexit.register(report)
         return traced
     return fn
