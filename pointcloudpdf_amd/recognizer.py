@@ -7,6 +7,8 @@
   a "next" row of the scope table: a ``pseudo_mask_fn(coord, seg_logits, offset) -> bool mask`` can be plugged in.
 * ``MaxProbability`` -- MSP / max-logit baselines, pointcept/recognizers/max_probability/max_probability_v1m1_base.py:7-32.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -66,6 +68,10 @@ class PointPdfV1(nn.Module):
         self.slide_window, self.adaptive_radius = slide_window, adaptive_radius
         self.softmax_score = softmax_score
         self.pseudo_mask_fn = pseudo_mask_fn
+        # (off by default: measured inconclusive on a loaded pod -- 38.7 vs 42.1 ms per step averaged over three traced runs each, 43.6 vs
+        # 42.1 over four untraced ones, profiles/r04_pl_side_stream_ab.txt; PDFOPS_PL_SIDE_STREAM=1 turns it on)
+        self.pass_on_side_stream = os.environ.get("PDFOPS_PL_SIDE_STREAM", "0") == "1"
+        self._logits_ready, self._pass_stream = None, None
         self.model_hooks = None
         self.epoch = 0
 
@@ -79,7 +85,22 @@ class PointPdfV1(nn.Module):
                 "pass pseudo_mask_fn=... to supply the mask"
             )
         with torch.no_grad():
-            return self.pseudo_mask_fn(coord, seg_logits, offset).bool()
+            ready = getattr(self, "_logits_ready", None)
+            self._logits_ready = None
+            if ready is None or not self.pass_on_side_stream:
+                return self.pseudo_mask_fn(coord, seg_logits, offset).bool()
+            # The pass only needs the segmentor's logits, but it is issued after the U-decoder's forward (upstream's order, :84-93): on
+            # the same stream its first host read would wait for the decoder too.  On a side stream that waits for the logits alone the
+            # decoder's forward runs on the device while the host walks through the pass.
+            cur = torch.cuda.current_stream()
+            if self._pass_stream is None:
+                self._pass_stream = torch.cuda.Stream(device=coord.device)
+            self._pass_stream.wait_event(ready)
+            with torch.cuda.stream(self._pass_stream):
+                mask = self.pseudo_mask_fn(coord, seg_logits, offset).bool()
+            cur.wait_stream(self._pass_stream)
+            mask.record_stream(cur)
+            return mask
 
     def trigger_operation(self):
         """pointpdf_v1m1_base.py:384-398: freeze the U-decoder until start_epoch, then release; decay alpha once."""
@@ -99,6 +120,10 @@ class PointPdfV1(nn.Module):
     def forward(self, input_dict):
         seg_logits = self.model_hooks["backbone"]["forward_output"]
         self.trigger_operation()
+        if (self.training and self.pseudo_mask_fn is not None and self.pass_on_side_stream and seg_logits.is_cuda
+                and self.epoch >= self.start_epoch and not torch.cuda.is_current_stream_capturing()):
+            self._logits_ready = torch.cuda.Event()
+            self._logits_ready.record()          # (before the U-decoder's forward is issued: see get_pseudo_mask)
         score = self.recognizer(self.model_hooks)
         if self.training:
             if self.epoch < self.start_epoch:
