@@ -8,7 +8,9 @@ timeout 600 python bench.py $X --jitter 0.1 > gpurun_out/${TAG}_bench_jitter.jso
 timeout 600 python bench.py $X --scenes 4 > gpurun_out/${TAG}_bench_bs4.json 2> gpurun_out/sec_bs4.err
 timeout 900 python bench.py --workload stratified > gpurun_out/${TAG}_bench_stratified.json 2> gpurun_out/sec_st.err
 timeout 600 python bench.py $X --optimizer torch > gpurun_out/${TAG}_bench_torch_sgd.json 2> gpurun_out/sec_tsgd.err
-for f in scannet scannet_pseudo_label jitter bs4 stratified torch_sgd; do python -c "
+timeout 600 python bench.py $X --jitter 0.1 --size-classes 4 --pool 8 > gpurun_out/${TAG}_bench_jitter_4classes.json 2> gpurun_out/sec_j4.err
+rm -f gpurun_out/${TAG}_secondary.txt
+for f in scannet scannet_pseudo_label jitter jitter_4classes bs4 stratified torch_sgd; do python -c "
 import json,sys
 try:
     d=json.load(open('gpurun_out/${TAG}_bench_$f.json')); print('$f', round(d['ms_per_step'],2), round(d['value']/1e6,2), 'M points/s')
