@@ -175,3 +175,30 @@ def test_mma_input_context_restores_the_previous_mode(monkeypatch):
     state["dtype"] = torch.float16
     forward()
     assert seen == [0, 1, 2, 0, 0] and _native.current_mma_input() == 0
+
+
+def test_graph_stage_entries_validate_before_any_launch(lib):
+    """pdf_graph_forest / pdf_gmm2_1d (the pseudo-label pass's graph stage): negative sizes, null pointers, a short or misaligned workspace
+    are PDF_ERR_BAD_ARG before anything is launched; an empty node list is a no-op."""
+    c_long, c_int, c_void_p, c_double = ctypes.c_long, ctypes.c_int, ctypes.c_void_p, ctypes.c_double
+    lib.pdf_graph_forest_workspace_bytes.restype = c_long
+    lib.pdf_graph_forest_workspace_bytes.argtypes = [c_long, c_long, c_long]
+    lib.pdf_graph_forest.restype = c_int
+    lib.pdf_graph_forest.argtypes = [c_long, c_int] + [c_void_p] * 5 + [c_int] + [c_void_p] * 3 + [c_long, c_void_p]
+    lib.pdf_gmm2_1d.restype = c_int
+    lib.pdf_gmm2_1d.argtypes = [c_int, c_void_p, c_void_p, c_void_p, c_int, c_double, c_double, c_void_p]
+    n, E, k = 100, 40, 10
+    need = lib.pdf_graph_forest_workspace_bytes(n, E, k)
+    assert need == k * 8 + (n + 2 * E + 3 * k) * 4 and lib.pdf_graph_forest_workspace_bytes(-1, 0, 0) == 0
+    buf = (ctypes.c_longlong * 1024)()
+    p = ctypes.cast(buf, c_void_p)
+    assert lib.pdf_graph_forest(n, E, p, p, None, None, p, 0, p, None, p, need, None) == 0            # no nodes: nothing to do
+    assert lib.pdf_graph_forest(-1, E, p, p, None, None, p, k, p, None, p, need, None) == -1
+    assert lib.pdf_graph_forest(n, E, None, p, None, None, p, k, p, None, p, need, None) == -1         # entries without endpoints
+    assert lib.pdf_graph_forest(n, E, p, p, None, None, None, k, p, None, p, need, None) == -1         # no node list
+    assert lib.pdf_graph_forest(n, E, p, p, None, None, p, k, p, None, p, need - 1, None) == -1        # short workspace
+    assert lib.pdf_graph_forest(n, E, p, p, None, None, p, k, p, None, c_void_p(p.value + 4), need, None) == -1   # misaligned workspace
+    assert lib.pdf_gmm2_1d(-1, p, p, p, 200, 1e-6, 1e-6, None) == -1
+    assert lib.pdf_gmm2_1d(5, None, p, p, 200, 1e-6, 1e-6, None) == -1
+    assert lib.pdf_gmm2_1d(5, p, p, None, 200, 1e-6, 1e-6, None) == -1
+    assert lib.pdf_gmm2_1d(5, p, p, p, 0, 1e-6, 1e-6, None) == -1
