@@ -321,6 +321,8 @@ class GroupedGeometryLoader:
         batches = [self._to_device(self._with_host_offset(b))[0] for b in batches]
         if self._copy_stream is not None:
             torch.cuda.current_stream().wait_stream(self._copy_stream)
+            for b in batches:
+                self._used_on(b, torch.cuda.current_stream())
         n = len(self.prefetcher.streams)
         for _ in range(n):
             tickets = self.prefetcher.submit_group(batches)
@@ -344,6 +346,15 @@ class GroupedGeometryLoader:
                 if torch.is_tensor(v) and v.device != dev:
                     out[k] = v.to(dev, non_blocking=True)
         return out, True
+
+    @staticmethod
+    def _used_on(batch, stream):
+        """The batch's tensors were allocated on the copy stream's pool: tell the caching allocator that ``stream`` reads them too, or
+        their blocks go back to the copy stream's pool when the group is dropped and the NEXT group's transfers may overwrite them
+        while steps that read them are still queued (the host runs several steps ahead of the device)."""
+        for v in batch.values():
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(stream)
 
     @staticmethod
     def _with_host_offset(batch):
@@ -396,6 +407,7 @@ class GroupedGeometryLoader:
                 b, moved = self._to_device(self._with_host_offset(batch))
                 if moved:
                     torch.cuda.current_stream().wait_stream(self._copy_stream)
+                    self._used_on(b, torch.cuda.current_stream())
                 if self.inline is not None:
                     b = dict(b)
                     b[self.key] = self.inline(b)
@@ -417,7 +429,9 @@ class GroupedGeometryLoader:
                 if j == delay and pulled is not None:
                     upcoming, pulled = self._submit(pulled), None
                 if copied is not None:
-                    torch.cuda.current_stream().wait_event(copied)   # the batch's own tensors (moved on the copy stream)
+                    cur = torch.cuda.current_stream()
+                    cur.wait_event(copied)   # the batch's own tensors (moved on the copy stream)
+                    self._used_on(batch, cur)
                 batch = dict(batch)
                 batch[self.key] = self.prefetcher.get(ticket)   # consumer stream waits for the pre-pass (stream-ordered)
                 yield batch
@@ -539,6 +553,19 @@ class TrainStep:
             return self._run(batch, eager)
         cur = torch.cuda.current_stream()
         self.stream.wait_stream(cur)             # (the batch's tensors / tables were handed over on the caller's stream)
+        # ... and were allocated on other streams' pools (the caller's, the copy stream's, the pre-pass's): the allocator must know that
+        # self.stream reads them, or a block freed by the caller can be handed out again before the staging copy / the step ran here
+        for v in batch.values():
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(self.stream)
+        geom = batch.get("pdf_geometry")
+        if geom is not None:
+            if hasattr(geom, "tensors"):
+                for t in geom.tensors():
+                    t.record_stream(self.stream)
+            packed = getattr(geom, "packed", None)
+            if packed is not None:
+                packed.record_stream(self.stream)
         with torch.cuda.stream(self.stream):
             out = self._run(batch, eager)
         return out                               # (the caller's stream does NOT wait: results are consumed on self.stream or after a sync)

@@ -685,6 +685,10 @@ class GeometryPrefetcher:
 
     def _group_on(self, stream, batches):
         with torch.cuda.stream(stream):
+            for b in batches:   # (allocated on the caller's / the loader's copy stream, read here)
+                for k in ("coord", "offset"):
+                    if torch.is_tensor(b[k]) and b[k].is_cuda:
+                        b[k].record_stream(stream)
             coord = torch.cat([b["coord"] for b in batches])
             counts, o_host, base = [], [], 0
             for b in batches:

@@ -500,15 +500,19 @@ class StratifiedPrefetcher:
 
     def submit_group(self, batches, ready=None):
         """One ticket per batch; the farthest-point chain of all of them runs as one launch sequence (StratifiedGeometry.precompute_group).
-        (``ready`` is accepted for the interface of engine.GroupedGeometryLoader; the event is recorded here, after the conversions the
-        geometry constructors may enqueue on the caller's stream.)"""
+        ``ready``: the event engine.GroupedGeometryLoader recorded when the batches' tensors were handed over (on its copy stream when
+        it moved them): the pre-pass waits for it AND for an event recorded here, after the conversions the geometry constructors may
+        enqueue on the caller's stream."""
         geoms = [self.model.make_geometry(b["coord"], b["offset"], b.get("offset_host")) for b in batches]
+        handed_over = ready
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream())
 
         def work():
             torch.cuda.set_device(self.device)
             with torch.cuda.stream(self.stream):
+                if handed_over is not None:
+                    self.stream.wait_event(handed_over)
                 self.stream.wait_event(ready)
                 StratifiedGeometry.precompute_group(geoms, self.model.layers_by_level() if self.windows else None)
                 done = torch.cuda.Event()

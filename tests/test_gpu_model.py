@@ -563,6 +563,54 @@ def test_grouped_loader_steps_are_bit_identical_to_serial_steps():
         assert all(torch.equal(a, b) for a, b in zip(params, p_serial)), (group, graph, max_captures)
 
 
+def test_loader_moved_batches_and_a_private_training_stream_equal_the_serial_steps():
+    """Stream safety of the two hand-over paths nothing else exercises (round-4 advisor): (a) the loader receives HOST batches and moves
+    them on its copy stream (``device=``), long look-ahead, with allocator churn between the steps so that a block wrongly returned to the
+    copy stream's pool would be overwritten; (b) ``TrainStep(stream=...)`` runs every step on a stream of its own while the caller's
+    stream keeps allocating.  Both give the losses and parameters of the serial steps."""
+    from pointcloudpdf_amd import engine, synthetic
+
+    dev = torch.device("cuda", 0)
+    shapes = [[3000, 2600], [2200, 3100], [3000, 2600], [2500, 2500]]
+    pool_dev = [synthetic.make_batch(sz, first_scene_id=140 + 3 * i, device=dev) for i, sz in enumerate(shapes)]
+    keys = ("coord", "feat", "offset", "offset_host", "segment")
+    pool_cpu = [{k: (b[k].cpu().pin_memory() if torch.is_tensor(b[k]) else b[k]) for k in keys} for b in pool_dev]
+
+    def stream_of(pool, n):
+        for i in range(n):
+            yield {k: pool[i % len(pool)][k] for k in keys}
+
+    def run(pool, group, device=None, private_stream=False, churn=False):
+        step = engine.OpenSegStep().to(dev)
+        synthetic.fill_parameters_deterministic(step, seed=7)
+        step.train()
+        opt = engine.FusedSGD(step.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4)
+        side = torch.cuda.Stream(device=dev) if private_stream else None
+        train = engine.TrainStep(step, opt, graph=False, stream=side)
+        outs = []
+        for b in engine.GroupedGeometryLoader(stream_of(pool, 8), group=group, device=device, first_group=2 if group else None):
+            outs.append(train(b)["loss"])
+            del b
+            if churn:   # same-sized allocations on the caller's stream right after the hand-over: they reuse any block freed too early
+                junk = [torch.full((n,), float("nan"), device=dev) for n in (9000, 16800, 33600, 5600)]
+                del junk
+        torch.cuda.synchronize()
+        losses = [float(v) for v in outs]
+        params = [p.detach().clone() for p in step.parameters()]
+        engine.release_autograd_state(step)
+        return losses, params
+
+    serial, p_serial = run(pool_dev, 0)
+    assert all(np.isfinite(serial))
+    for name, kw in (("moved", dict(pool=pool_cpu, group=4, device=dev, churn=True)),
+                     ("moved inline", dict(pool=pool_cpu, group=0, device=dev, churn=True)),
+                     ("private stream", dict(pool=pool_dev, group=4, private_stream=True, churn=True)),
+                     ("moved + private stream", dict(pool=pool_cpu, group=4, device=dev, private_stream=True, churn=True))):
+        losses, params = run(**kw)
+        assert losses == serial, (name, losses, serial)
+        assert all(torch.equal(a, b) for a, b in zip(params, p_serial)), name
+
+
 def test_train_step_recaptures_a_size_class_whose_schedule_state_went_stale():
     """engine.TrainStep: once the recognizer's alpha moved (PointPdfV1.trigger_operation at start_epoch) the captured graphs are stale;
     the trainer releases them and captures the size class again -- the six steps equal six eager steps with the same alpha change."""
