@@ -192,6 +192,8 @@ def launch_ranks(args):
         print(f"[bench] --gpus {args.gpus} but only {torch.cuda.device_count()} visible", file=sys.stderr)
         return 2
     argv = [a for a in sys.argv[1:]]
+    points = args.points if args.points is not None else (150000 if args.workload == "scannet" else (80000 if args.workload == "stratified" else 100000))
+    preflight_host(args.gpus, args.scenes, points, max(args.prefetch, 0))   # (exits 3 with the reason when the node cannot hold the ranks)
 
     def run(world, extra):
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -428,6 +430,80 @@ def pin_rank_to_cores(args):
     return f"rank {lr}: cpus {mine[0]}-{mine[-1]} ({len(mine)} of {len(cpus)})"
 
 
+def _mem_available_gib():
+    try:
+        with open("/proc/meminfo") as f:
+            for ln in f:
+                if ln.startswith("MemAvailable:"):
+                    return int(ln.split()[1]) / 2.0 ** 20
+    except OSError:
+        pass
+    return None
+
+
+def preflight_host(world, scenes, points, group, out=sys.stderr):
+    """Before any rank touches a GPU: will `world` ranks fit this HOST?  One rank holds its pool of synthetic batches on the device, but
+    its process (torch + the HIP runtime + RCCL + pinned staging) is ~3.5 GiB of resident host memory, and the look-ahead keeps `group`
+    batches of index tables in flight per rank.  A node that cannot hold all ranks kills one of them without a message (the container
+    has no swap): fail here, loudly, instead.  Returns a dict for the JSON line; raises SystemExit(3) when the job cannot fit."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    avail = _mem_available_gib()
+    per_rank_host = 3.5 + 1e-9 * 64.0 * scenes * points   # process image + the pool's host-side copies (offsets, a few staging buffers)
+    need = world * per_rank_host
+    info = {"ranks": world, "host_cores": cores, "host_mem_available_gib": avail, "host_mem_needed_gib": round(need, 1),
+            "lookahead_batches_per_rank": group}
+    problems = []
+    if cores < world:
+        problems.append(f"{world} ranks on {cores} visible cores: every rank needs a core of its own for its enqueue thread")
+    if avail is not None and avail < need:
+        problems.append(f"{world} ranks need ~{need:.0f} GiB of host memory, {avail:.0f} GiB available")
+    if problems:
+        print("[bench] pre-flight FAILED: " + "; ".join(problems), file=out, flush=True)
+        raise SystemExit(3)
+    if cores < 4 * world:
+        print(f"[bench] pre-flight: {cores} cores for {world} ranks (< 4 per rank): the host side of a step may become the bound", file=out, flush=True)
+    return info
+
+
+def preflight_device(dev, world, scenes, points, group, strat=False, out=sys.stderr):
+    """In every rank, after torch.cuda.set_device and before the first allocation: does this rank's GPU have room for the step's
+    activations (measured: 4.8 GiB at 2 x 100k points -- `hbm_peak_gib` of the N = 1 line -- scaled by the point count) plus `group`
+    batches of look-ahead tables (~0.11 GB per 2 x 100k-point batch, twice: the group in flight and the one being consumed)?  On a node
+    whose GPUs are shared with other jobs (or a rank mapped onto a busy device) the run would otherwise die minutes in, inside hipMalloc."""
+    free, total = torch.cuda.mem_get_info(dev)
+    pts = scenes * points
+    need = (4.8 * pts / 2e5 * (1.6 if strat else 1.0) + 2 * group * 0.11 * pts / 2e5 + 2.0) * 2.0 ** 30   # + 2 GiB: graph pool slack, RCCL buffers
+    info = {"device_free_gib": round(free / 2.0 ** 30, 1), "device_total_gib": round(total / 2.0 ** 30, 1), "device_needed_gib": round(need / 2.0 ** 30, 1)}
+    if free < need:
+        print(f"[bench] pre-flight FAILED on {dev}: {free / 2.0 ** 30:.1f} GiB free of {total / 2.0 ** 30:.1f}, this rank needs ~{need / 2.0 ** 30:.1f} GiB "
+              f"({scenes} x {points} points, look-ahead of {group} batches)", file=out, flush=True)
+        raise SystemExit(3)
+    return info
+
+
+class TimedExchange:
+    """The gradient exchange with a pair of HIP events around every call (N > 1 only): `exposed_allreduce_ms` of the line is the time the
+    training stream spends inside pack + all-reduce + scale + unpack, i.e. what data parallelism adds to a step that overlaps nothing."""
+
+    def __init__(self, inner):
+        self.inner, self.events, self.on = inner, [], False
+
+    def __getattr__(self, name):
+        return getattr(self.inner, name)
+
+    def sync(self, force=False):
+        if not self.on:
+            return self.inner.sync(force=force)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.inner.sync(force=force)
+        e1.record()
+        self.events.append((e0, e1))
+
+    def mean_ms(self):
+        return (sum(a.elapsed_time(b) for a, b in self.events) / len(self.events)) if self.events else None
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -460,6 +536,13 @@ def main():
     if args.points is None:
         args.points = 150000 if scannet else (80000 if strat else 100000)
     step_kw = dict(in_channels=9, num_classes=20, loss_weight=0.04) if scannet else (dict(backbone="ST-v1m1", loss_weight=0.008) if strat else {})
+    pre = {}
+    if world > 1 and rank == 0 and not os.environ.get("PDFOPS_BENCH_CHILD"):   # (started by torchrun: nobody ran the host check yet)
+        pre.update(preflight_host(world, args.scenes, args.points, max(args.prefetch, 0)))
+    if not shared_gpu:
+        pre.update(preflight_device(dev, world, args.scenes, args.points, max(args.prefetch, 0), strat=strat))
+    if world > 1 and not shared_gpu and torch.distributed.get_backend() != "nccl":
+        raise SystemExit(f"bench.py: {world} ranks on their own GPUs must exchange gradients over RCCL, the process group is '{torch.distributed.get_backend()}'")
     st_ahead = 0
     if strat:
         # ST's coordinate-only work (FPS chain + window edge tables) runs one batch ahead on a worker thread + side stream
@@ -485,6 +568,8 @@ def main():
     use_dp = world > 1 or force_dp
     module = engine.wrap_ddp(step, dev) if (use_dp and args.ddp == "torch") else step
     grad_sync = engine.FlatGradAllReduce(step) if (use_dp and args.ddp == "flat") else None
+    if grad_sync is not None and world > 1:
+        grad_sync = TimedExchange(grad_sync)
     if args.optimizer == "fused":   # one launch over all 304 tensors (csrc/optim.hip); "torch" = torch.optim.SGD(fused=True), 13 launches
         opt = engine.FusedSGD(step.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
     else:
@@ -573,6 +658,8 @@ def main():
             out = trainer(next(it))
         fence()
         timer.enabled = with_timer
+        if isinstance(trainer.exchange, TimedExchange):
+            trainer.exchange.on, trainer.exchange.events = with_timer, []
         # steps that carry the per-kernel HIP events run eagerly (events cannot time kernels inside a replayed graph): every 4th step of
         # an eager run, ONE step of the timed region -- the last -- when the steps are graph replays
         replaying = trainer.captured is not None
@@ -587,6 +674,8 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         timer.enabled = False
+        if isinstance(trainer.exchange, TimedExchange):
+            trainer.exchange.on = False
         if with_timer:
             timer.sampled_steps = len([i for i in range(steps) if every > 0 and i % every == sample_at])
             timer.every_used = every
@@ -673,6 +762,14 @@ def main():
             "per_gpu_points_per_s": pts_per_step * args.steps / dt / world,
             "rccl_ranks": world if (world > 1 and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl") else 0,
             "rank_ms_per_step": rank_ms,
+            # what a scaling-efficiency figure computed from `value` is made of: the slowest rank sets the step (barrier + max), the
+            # spread says how much of the loss is rank imbalance (host side, clocks), the exchange how much is the all-reduce itself
+            "efficiency_breakdown": {"rank_ms_per_step_min": min(rank_ms), "rank_ms_per_step_max": max(rank_ms),
+                                     "rank_spread_ms": max(rank_ms) - min(rank_ms),
+                                     "exposed_allreduce_ms": (trainer.exchange.mean_ms() if isinstance(trainer.exchange, TimedExchange) else None),
+                                     "note": ("exposed_allreduce_ms: HIP events around pack + all-reduce + scale + unpack on the training stream of rank 0, "
+                                              "mean over the timed steps; at world size 1 see ddp_overhead_ms") },
+            "preflight": pre,
             "loss": loss,
             "execution": ("engine.GroupedGeometryLoader + engine.TrainStep: forward + backward replayed as one captured hipGraph (fixed scene sizes), "
                           "optimizer / gradient exchange / geometry pre-pass eager; the ONE step of the timed region that carries per-kernel HIP events runs eagerly"

@@ -325,10 +325,15 @@ extern "C" int pdf_graph_forest(long n, int E, const long long *u, const long lo
     int *slot = reinterpret_cast<int *>(best + n_nodes);
     int *su = slot + n, *sv = su + E, *gcomp = sv + E, *parent = gcomp + n_nodes, *rootof = parent + n_nodes;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (n_nodes <= gp::LDS_NODES) {
+    // The LDS form needs up to LDS_NODES * 12 bytes of dynamic LDS (> the 64 KB default limit): raised ONCE per process to the maximum any
+    // call can ask for (a per-call value would race between host threads: one lowers the limit another is about to launch with), result
+    // checked -- where the runtime refuses, every call takes the global-memory form.
+    static const bool lds_form = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(&gp::k_forest<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(gp::LDS_NODES * (sizeof(gp::u64) + sizeof(int)))) == hipSuccess;
+    }();
+    if (n_nodes <= gp::LDS_NODES && (lds_form || (size_t)n_nodes * (sizeof(gp::u64) + sizeof(int)) <= 64 * 1024)) {
         const size_t lds = (size_t)n_nodes * (sizeof(gp::u64) + sizeof(int));
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gp::k_forest<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         gp::k_forest<true><<<1, gp::T, lds, s>>>(n, E, u, v, w, active, nodes, n_nodes, comp, slot, su, sv, best, gcomp, parent, rootof, chosen);
     } else {
         gp::k_forest<false><<<1, gp::T, 0, s>>>(n, E, u, v, w, active, nodes, n_nodes, comp, slot, su, sv, best, gcomp, parent, rootof, chosen);

@@ -226,9 +226,12 @@ class CapturedStep:
     def _python_state(self):
         """Python-side scalars the capture bakes into the graph: the recognizer's loss weight ``alpha`` (decayed once at ``start_epoch``),
         whether the PDF loss is active (epoch gate), ``step_loss_weight``, train / eval mode of every module, the autocast mode."""
-        rec = self.step.recognizer
+        rec = getattr(self.step, "recognizer", None)   # (a step module without a recognizer captures like any other)
+        mods = self.__dict__.get("_modules_at_capture")
+        if mods is None:   # the module list is walked once per capture, not on every replay
+            mods = self.__dict__["_modules_at_capture"] = list(self.step.modules())
         return (float(getattr(rec, "alpha", 0.0)), int(getattr(rec, "epoch", 0)) >= int(getattr(rec, "start_epoch", 0)),
-                bool(getattr(rec, "step_loss_weight", False)), tuple(m.training for m in self.step.modules()), self.autocast)
+                bool(getattr(rec, "step_loss_weight", False)), tuple(m.training for m in mods), self.autocast)
 
     def matches(self, batch):
         """True when the captured graph IS this step: same scene sizes / shapes and the same Python-side schedule state as at capture.
@@ -491,7 +494,7 @@ class TrainStep:
         self._capture_stream = self.stream
         torch.cuda.synchronize()
         release_autograd_state(self.step)
-        for p in self.params:
+        for p in self.step.parameters():
             p.grad = None
         gc.collect()
         torch.cuda.empty_cache()
@@ -510,7 +513,7 @@ class TrainStep:
             torch.cuda.synchronize()
             self.captures = [cap for cap in self.captures if cap not in stale]
             self.captured = self.captures[0] if self.captures else None
-            for p in self.params:   # (p.grad may be a released capture's static tensor)
+            for p in self.step.parameters():   # (p.grad may be a released capture's static tensor)
                 p.grad = None
             del stale, cap
             gc.collect()
@@ -532,7 +535,9 @@ class TrainStep:
         if run_on is not cur:
             run_on.wait_stream(cur)
         with torch.cuda.stream(run_on):
-            for p in self.params:
+            # every parameter of the step, not the requires_grad list of construction time: PointPdfV1.trigger_operation releases the
+            # U-decoder's parameters INSIDE the forward at start_epoch, and their gradients must not accumulate across eager steps
+            for p in self.step.parameters():
                 p.grad = None
             with torch.autocast("cuda", dtype=self.autocast or torch.float16, enabled=self.autocast is not None):
                 out = self.module(batch)
@@ -773,6 +778,9 @@ class FusedSGD(torch.optim.Optimizer):
         tab[:len(have)].copy_(host[:len(have)], non_blocking=True)
         return nchunks, tab, chunks, ev, fixed
 
+    def _grad_key(self):
+        return tuple(p.grad.data_ptr() if p.grad is not None else 0 for group in self.param_groups for p in group["params"])
+
     @torch.no_grad()
     def step(self, closure=None, found_inf=None):
         """``found_inf``: a device float (``DeviceGradScaler``): non-zero -> the kernel leaves parameters and momenta untouched."""
@@ -783,6 +791,10 @@ class FusedSGD(torch.optim.Optimizer):
         from . import _native
 
         prepared, self._prepared = getattr(self, "_prepared", None), None
+        if prepared is not None:   # tables of an unscale_: valid only for the gradients they were built from (an iteration that aborted
+            key, prepared = prepared   # between unscale_ and step, or re-assigned gradients, must not reuse stale pointer tables)
+            if key != self._grad_key():
+                prepared = None
         for gi, group in enumerate(self.param_groups):
             if group.get("dampening", 0) != 0 or group.get("nesterov", False) or group.get("maximize", False):
                 raise RuntimeError("FusedSGD: dampening / nesterov / maximize are not implemented (the reference's configs use none of them)")
@@ -860,8 +872,8 @@ class DeviceGradScaler:
                                                    ctypes.c_void_p(_native.raw_stream()))
             if rc != 0:
                 raise RuntimeError(f"pdf_grad_unscale failed with status {rc}")
-        optimizer._prepared = prepared   # the step of this iteration reuses the tables (same gradients, same pointers)
-        self._unscaled = True
+        optimizer._prepared = (optimizer._grad_key(), prepared)   # the step of this iteration reuses the tables (same gradients, same pointers)
+        self._unscaled, self._prepared_for = True, optimizer
 
     def step(self, optimizer):
         if not self.enabled:
@@ -883,6 +895,9 @@ class DeviceGradScaler:
         if rc != 0:
             raise RuntimeError(f"pdf_scaler_update failed with status {rc}")
         self._unscaled = False
+        opt, self._prepared_for = getattr(self, "_prepared_for", None), None
+        if opt is not None:   # (an iteration that skipped optimizer.step(): its tables die with it)
+            opt._prepared = None
 
     def state_dict(self):
         return dict(scale=self.get_scale(), growth_factor=self.growth_factor, backoff_factor=self.backoff_factor,

@@ -18,6 +18,11 @@ neighbour table, same torch / numpy seeds).  The neighbour table itself replaces
 max_neighbor, x, x, mode="partial_dense")`` -- an unvendored, unversioned dependency (README.md:105), absent here: its documented
 behaviour (the first ``max_neighbor`` points of the same scene, in index order, with d2 < radius^2, padded with -1) is what
 ``radius_neighbors`` implements; that part is "parity unpinned".
+The device pruning path's mixture fit (``pdf_gmm2_1d``: EM in double from a deterministic quartile / 2-means start, tol 1e-6, at most 200
+iterations) is "parity unpinned vs sklearn": upstream calls ``GaussianMixture(n_components=2)`` (k-means++ start from numpy's global
+state, tol 1e-3, 100 iterations).  Both converge to the same two components on well separated similarity histograms -- the masks of the
+fixture scenes are identical (tests/test_pseudo_label.py::test_pseudo_mask_on_gpu_batch, exact against the reference fixture) -- but the
+cut ``mean - 2 * covariance`` can move near sklearn's looser convergence boundary; the host path (CPU tensors) is the upstream-exact one.
 """
 import os
 

@@ -110,6 +110,24 @@ def test_bench_refuses_more_ranks_than_gpus():
     assert r.returncode == 2 and "--gpus 2 but only" in r.stderr and r.stdout.strip() == ""
 
 
+def test_bench_preflight_fails_loudly_when_the_node_cannot_hold_the_ranks():
+    """bench.preflight_host: the check `--gpus N` runs before any rank is started (and rank 0 runs under torchrun) -- N ranks need a
+    core each and ~3.5 GiB of host memory each; a node that cannot hold them exits 3 with the reason instead of losing a rank to the
+    OOM killer minutes into the run."""
+    import io
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    ok = bench.preflight_host(1, 2, 100000, 20, out=io.StringIO())
+    assert ok["ranks"] == 1 and ok["host_cores"] >= 1 and ok["lookahead_batches_per_rank"] == 20
+    msg = io.StringIO()
+    with pytest.raises(SystemExit) as e:
+        bench.preflight_host(100000, 2, 100000, 20, out=msg)
+    assert e.value.code == 3 and "pre-flight FAILED" in msg.getvalue() and "100000 ranks" in msg.getvalue()
+
+
 def _eval_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))

@@ -68,17 +68,20 @@ def _capture(device, sizes, kind, backend=None, dtype=torch.float32):
             _native._set_backend_for_testing(prev)
 
 
-@pytest.mark.parametrize("kind,points", [("s3dis", 100000), ("scannet", 150000)])
-def test_full_size_step_matches_cpu_oracle_path(oracle_backend, kind, points):
+# (the third case is BASELINE's headline batch itself -- config 2: TWO 100,000-point scenes in one batch, so that the cross-scene batch
+#  statistics of every train-mode BatchNorm, the per-scene FPS / kNN segments and the scene-mean context of dec5 are pinned at full size)
+@pytest.mark.parametrize("kind,scenes", [("s3dis", [100000]), ("scannet", [150000]), ("s3dis", [100000, 100000])],
+                         ids=["s3dis-100000", "scannet-150000", "s3dis-2x100000"])
+def test_full_size_step_matches_cpu_oracle_path(oracle_backend, kind, scenes):
     oracle_backend.set_num_threads(min(os.cpu_count() or 1, 32))
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     torch.backends.cuda.matmul.allow_tf32 = False
-    ref = _capture("cpu", [points], kind, backend=oracle_backend)                         # the reference's composition, fp32
-    ref64 = _capture("cpu", [points], kind, backend=oracle_backend, dtype=torch.float64)   # the same network evaluated in fp64
-    dev = _capture("cuda", [points], kind)
+    ref = _capture("cpu", scenes, kind, backend=oracle_backend)                         # the reference's composition, fp32
+    ref64 = _capture("cpu", scenes, kind, backend=oracle_backend, dtype=torch.float64)   # the same network evaluated in fp64
+    dev = _capture("cuda", scenes, kind)
 
     # ---- geometry: bit-exact
-    sizes = [points // 4 ** i for i in range(5)]
+    sizes = [sum(n // 4 ** i for n in scenes) for i in range(5)]
     assert [p.shape[0] for p, _ in dev["levels"]] == sizes
     for lvl in range(4):
         assert torch.equal(dev["fps"][lvl], ref["fps"][lvl]), f"FPS indices differ at level {lvl + 1} ({sizes[lvl]} -> {sizes[lvl + 1]})"
