@@ -38,8 +38,9 @@ extern "C" {
 /* ABI version of THIS header.  pdf_abi_version() returns the version the loaded library was built with: a caller built against another
  * version must refuse to call (parameter lists differ; pointcloudpdf_amd/_native.py does).  History: 1 = rounds 1-3 (signatures changed
  * without a bump, see ADVICE of round 3); 4 = round 4: `mma_input` per call on the pdf_rowlin_ / pdf_block_ / pdf_bottleneck_ / pdf_linbn_ /
- * pdf_td_ entries, pdf_set_mma_input / pdf_get_mma_input / pdf_tickets_* removed, pdf_sgd_step takes a found-inf flag. */
-#define PDF_ABI_VERSION 4
+ * pdf_td_ entries, pdf_set_mma_input / pdf_get_mma_input / pdf_tickets_* removed, pdf_sgd_step takes a found-inf flag;
+ * 5 = round 5: pdf_wa_* (atomic-free window-attention backward) added. */
+#define PDF_ABI_VERSION 5
 int pdf_abi_version(void);
 const char *pdf_build_info(void);
 /* Arithmetic of the squared distance in this library's geometry kernels (kNN, ball query, FPS): 0 = the reference's expression as
@@ -488,6 +489,25 @@ int pdf_gmm2_1d(int m, const float *sorted_x, double *resp, double *out, int ite
 int pdf_segment_softmax_forward(int N, int M, int h, const int *index0_offsets, const float *x, float *y, void *stream);
 int pdf_segment_softmax_backward(int N, int M, int h, const int *index0_offsets, const float *y, const float *grad_y, float *grad_x,
                                  void *stream);
+
+/* Atomic-free building blocks of the three backward launchers above (csrc/window_attention_bwd.hip), for head dim 16, L <= 64.  The
+ * reference scatters with one atomicAdd per (edge, channel) (attention_cuda_kernel_v2.cu:50-93, relative_pos_encoding_cuda_kernel_v2.cu:
+ * 287-340, 441-484); here every such sum is a segmented sum over the edge list grouped by query (the CSR arrays of the forward) or by key
+ * (the transposed list the caller builds once per edge table: key offsets, edge ids grouped by key, and the query / rel_idx of those
+ * edges -- pointcloudpdf_amd/_native.py: window_csc), in ascending edge order: bit-reproducible, outputs written (not accumulated).
+ *   pdf_wa_segment_rows: out[n, c] = sum_{e in [seg_off[n], seg_off[n+1])} w[eid(e), c / 16] * (X[other[e], c] + T(rel[e])[c]),
+ *       eid(e) = seg_edge ? seg_edge[e] : e;  X (rows, with `other`) and table (with `rel`, (M, 3) in SEGMENT order) are each optional.
+ *   pdf_wa_table_grad:   grad_table[r, c, a] = sum_n x[n, c] * sum_{e in seg(n), rel[e][a] == r} w[eid(e), c / 16]   (x = the segment
+ *       owner's row: q or grad_out over the CSR list, k over the CSC list); ws: pdf_wa_table_grad_ws_floats(N, h, L) floats.
+ *   pdf_wa_grad_attn:    grad_attn[m, hh] = <grad_out[q(m), hh, :], v[index1[m], hh, :] + T(m, hh, :)>.
+ * PDF_ERR_UNSUPPORTED for other head dims / longer tables: the caller keeps the atomic launchers above. */
+int pdf_wa_segment_rows(int N, int h, int d, int L, const int *seg_off, const int *seg_edge, const int *other, const int *rel,
+                        const float *w, const float *X, const float *table, float *out, void *stream);
+long pdf_wa_table_grad_ws_floats(int N, int h, int L);
+int pdf_wa_table_grad(int N, int h, int d, int L, const int *seg_off, const int *seg_edge, const int *rel, const float *w,
+                      const float *x, float *ws, float *grad_table, void *stream);
+int pdf_wa_grad_attn(int N, int M, int h, int d, int L, const float *grad_out, const int *offsets, const int *index1, const float *v,
+                     const float *table, const int *rel, float *grad_attn, void *stream);
 
 /* Staging copy for hipGraph replay (pointcloudpdf_amd/engine.py: CapturedStep; no reference counterpart -- the reference issues its
  * step from Python): nseg (src -> dst, nbytes) segments in ONE launch.  src_offset (device int32, may be NULL): element offset (4-byte

@@ -26,7 +26,7 @@ def library_path(dist_fma=0):
 
 
 LIB_PATH = library_path(DIST_FMA)
-ABI_VERSION = 4   # include/pdfops.h: PDF_ABI_VERSION (the argtypes below are THIS version's parameter lists)
+ABI_VERSION = 5   # include/pdfops.h: PDF_ABI_VERSION (the argtypes below are THIS version's parameter lists)
 
 c_int = ctypes.c_int
 c_long = ctypes.c_long
@@ -71,6 +71,9 @@ _HIP_ONLY_PROTOS = {
     "dot_prod_with_idx_forward_v3_l": "iiiiipppppppp",
     "dot_prod_with_idx_backward_v3_l": "iiiiipppppppppppp",
     "attention_step2_with_rel_pos_value_backward_v2_l": "iiiiipppppppppp",
+    "wa_segment_rows": "iiiipppppppp",
+    "wa_table_grad": "iiiippppppp",
+    "wa_grad_attn": "iiiiippppppp",
     "group_forward": "iiiippppp",
     "group_backward": "iiiippp",
     "interpolation_weights": "iipp",
@@ -169,6 +172,33 @@ def inverse_table(idx, n):
     vals, perm = torch.sort(flat, stable=True)        # ascending destination, ascending entry id inside a destination; -1 first
     off = torch.searchsorted(vals, torch.arange(int(n) + 1, device=idx.device, dtype=vals.dtype), out_int32=True)
     return attach_inverse(idx, n, (off, perm.to(torch.int32), 0))
+
+
+_CSC = "_pdf_window_csc"
+
+
+def window_csc(index1, offsets, rel_idx=None, n_keys=None):
+    """The window-attention edge list grouped by KEY (csrc/window_attention_bwd.hip): for index1 (M) int32 = key of every edge and the
+    CSR offsets (N + 1) of the queries -> (key_off (N + 1) int32, key_edge (M) int32: edge ids grouped by key in ascending order,
+    key_q (M) int32: the query of those edges[, key_rel (M, 3) int32: their rel_idx rows]).  Coordinate-only, so the pre-pass of a
+    window partition builds it once (stratified.BasicLayer.window_tables) and every block / step reuses it: cached on ``index1``."""
+    cache = getattr(index1, _CSC, None)
+    if cache is None or cache["key"] != (index1.data_ptr(), index1._version, offsets.data_ptr(), offsets._version):
+        n, m = offsets.shape[0] - 1, index1.shape[0]
+        nk = n if n_keys is None else int(n_keys)
+        vals, perm = torch.sort(index1, stable=True)
+        key_off = torch.searchsorted(vals, torch.arange(nk + 1, device=index1.device, dtype=vals.dtype), out_int32=True)
+        counts = (offsets[1:] - offsets[:-1]).long()
+        index0 = torch.repeat_interleave(torch.arange(n, device=index1.device, dtype=torch.int32), counts, output_size=m)
+        cache = {"key": (index1.data_ptr(), index1._version, offsets.data_ptr(), offsets._version),
+                 "base": (key_off, perm.to(torch.int32), index0[perm].contiguous()), "perm": perm, "rel": {}}
+        setattr(index1, _CSC, cache)
+    if rel_idx is None:
+        return cache["base"]
+    rk = (rel_idx.data_ptr(), rel_idx._version)
+    if rk not in cache["rel"]:
+        cache["rel"] = {rk: rel_idx[cache["perm"]].contiguous()}   # (one table per edge list in practice; a new one replaces the old)
+    return cache["base"] + (cache["rel"][rk],)
 
 
 _ORD = "_pdf_order"
@@ -538,6 +568,8 @@ class HipBackend(CBackend):
         super().__init__(lib, "pdf_", "cuda", True, extra_protos=tuple(_HIP_ONLY_PROTOS))
         lib.pdf_fps_workspace_bytes.restype = c_long
         lib.pdf_fps_workspace_bytes.argtypes = [c_int, c_int]
+        lib.pdf_wa_table_grad_ws_floats.restype = c_long
+        lib.pdf_wa_table_grad_ws_floats.argtypes = [c_int, c_int, c_int]
         lib.pdf_fps_stats_offset.restype = c_long
         lib.pdf_fps_stats_offset.argtypes = [c_int, c_int]
         self.collect_fps_stats = False  # debug: keep the work counters of the last bucketed FPS call (forces a sync)
@@ -991,6 +1023,60 @@ class HipBackend(CBackend):
         return gxq, gxk, gxv, g
 
     # -- dense per-point Linear on the matrix cores (csrc/rowlin.hip) ---------------------------------------
+    # -- libs/pointops2 window attention, backward: atomic-free segmented sums (csrc/window_attention_bwd.hip) ---------------------
+    # PDFOPS_WA_ATOMICS=1: the fp32-atomic launchers of rounds 1-4 (csrc/window_attention.hip) -- A/B and fallback for other shapes
+    wa_atomic_free = os.environ.get("PDFOPS_WA_ATOMICS", "0") != "1"
+
+    def _wa_ok(self, d, L, *tensors):
+        return self.wa_atomic_free and d == 16 and L <= 64 and all(t.data_ptr() % 16 == 0 for t in tensors)
+
+    def _wa_table_grad(self, n, h, d, L, seg_off, seg_edge, rel, w, x, like):
+        g = torch.empty((L, h, d, 3), dtype=torch.float32, device=like.device)
+        ws = torch.empty((max(int(self.lib.pdf_wa_table_grad_ws_floats(n, h, L)), 1),), dtype=torch.float32, device=like.device)
+        self._call("wa_table_grad", n, h, d, L, seg_off, seg_edge, rel, w, x, ws, g)
+        return g
+
+    def attention_step1_v2_backward(self, grad_out, q, k, index1, offsets, n_max):
+        n, h, d = q.shape
+        if index1.shape[0] == 0 or not self._wa_ok(d, 1, q, k):
+            return super().attention_step1_v2_backward(grad_out, q, k, index1, offsets, n_max)
+        _check(grad_out, torch.float32, "grad_output")
+        key_off, key_edge, key_q = window_csc(index1, offsets, n_keys=k.shape[0])
+        gq, gk = torch.empty_like(q), torch.empty_like(k)
+        self._call("wa_segment_rows", n, h, d, 0, offsets, None, index1, None, grad_out, k, None, gq)            # grad_q = sum g k[index1]
+        self._call("wa_segment_rows", k.shape[0], h, d, 0, key_off, key_edge, key_q, None, grad_out, q, None, gk)   # grad_k = sum g q[query]
+        return gq, gk
+
+    def dot_prod_with_idx_v3_backward(self, grad_out, q, offsets, n_max, k, index_k, table_q, table_k, rel_idx):
+        n, h, d = q.shape
+        L = int(table_q.shape[0])
+        if index_k.shape[0] == 0 or not self._wa_ok(d, L, q, k):
+            return super().dot_prod_with_idx_v3_backward(grad_out, q, offsets, n_max, k, index_k, table_q, table_k, rel_idx)
+        _check(grad_out, torch.float32, "grad_output")
+        nk = k.shape[0]
+        key_off, key_edge, _key_q, key_rel = window_csc(index_k, offsets, rel_idx, n_keys=nk)
+        gq, gk = torch.empty_like(q), torch.empty_like(k)
+        self._call("wa_segment_rows", n, h, d, L, offsets, None, None, rel_idx, grad_out, None, table_q, gq)         # grad_q = sum g T_q
+        self._call("wa_segment_rows", nk, h, d, L, key_off, key_edge, None, key_rel, grad_out, None, table_k, gk)    # grad_k = sum g T_k
+        gtq = self._wa_table_grad(n, h, d, L, offsets, None, rel_idx, grad_out, q, q)
+        gtk = self._wa_table_grad(nk, h, d, L, key_off, key_edge, key_rel, grad_out, k, q)
+        return gq, gk, gtq, gtk
+
+    def attention_step2_with_rel_pos_value_v2_backward(self, grad_out, attn, v, offsets, n_max, index1, table, rel_idx):
+        m, h = attn.shape
+        n, _, d = v.shape
+        L = int(table.shape[0])
+        if m == 0 or offsets.shape[0] != n + 1 or not self._wa_ok(d, L, v, grad_out):
+            return super().attention_step2_with_rel_pos_value_v2_backward(grad_out, attn, v, offsets, n_max, index1, table, rel_idx)
+        _check(grad_out, torch.float32, "grad_output")
+        key_off, key_edge, key_q = window_csc(index1, offsets, n_keys=n)
+        ga = torch.empty((m, h), dtype=torch.float32, device=v.device)
+        gv = torch.empty_like(v)
+        self._call("wa_grad_attn", n, m, h, d, L, grad_out, offsets, index1, v, table, rel_idx, ga)
+        self._call("wa_segment_rows", n, h, d, 0, key_off, key_edge, key_q, None, attn, grad_out, None, gv)          # grad_v = sum attn grad_out[query]
+        gt = self._wa_table_grad(n, h, d, L, offsets, None, rel_idx, attn, grad_out, v)
+        return ga, gv, gt
+
     def _stream(self):
         return c_void_p(raw_stream())
 

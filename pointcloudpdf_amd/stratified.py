@@ -462,7 +462,11 @@ class StratifiedGeometry:
     def tensors(self):
         out = [self.coord, self.offset] + [t for pair in self.samples.values() for t in pair]
         for tables in self.windows.values():
-            out += [t for tab in tables.values() for t in tab if torch.is_tensor(t)]
+            for tab in tables.values():
+                out += [t for t in tab if torch.is_tensor(t)]
+                csc = getattr(tab[1], _native._CSC, None)   # the key-grouped edge list cached on index_1 (_native.window_csc)
+                if csc is not None:
+                    out += list(csc["base"]) + [csc["perm"]] + list(csc["rel"].values())
         return out
 
 
@@ -629,6 +633,11 @@ class BasicLayer(nn.Module):
             n_max = int(index_0_counts.max())
             index_0_offsets = torch.cat([index_0_counts.new_zeros(1), index_0_counts.cumsum(dim=-1)], 0)
             rel_idx = self.blocks[parity].attn.checked_relative_position_index(xyz, index_0, index_1)
+            # int32 copies made ONCE (WindowAttention.forward's `.int()` then hands the same tensors to every block: the backward's
+            # key-grouped edge list is cached on them), and that list itself -- coordinate-only like everything else here
+            index_1, index_0_offsets = index_1.int().contiguous(), index_0_offsets.int().contiguous()
+            if xyz.is_cuda:
+                _native.window_csc(index_1, index_0_offsets, rel_idx, n_keys=xyz.shape[0])
             tables[parity] = (index_0, index_1, index_0_offsets, n_max, rel_idx)
         return tables
 

@@ -49,6 +49,30 @@ def test_hip_vs_oracle_bigger_graphs(p2, oracle_backend, cfg):
         assert_close(hip[key], ora[key], 5e-5, f"{cfg} {key}")
 
 
+@pytest.mark.parametrize("cfg", [(31, 5000, 3, 16, 64, 90), (32, 1200, 24, 16, 64, 85), (33, 700, 2, 16, 33, 120), (34, 900, 6, 16, 1, 40),
+                                 (35, 2600, 12, 16, 64, 70)])
+def test_atomic_free_backward_is_bit_reproducible_and_matches_the_atomic_kernels(p2, cfg):
+    """csrc/window_attention_bwd.hip (round 5): grad_k / grad_v / the three table gradients as segmented sums over the edge list grouped
+    by key / by query instead of fp32 atomics.  Two evaluations are BIT-identical (fixed summation order), and every gradient equals the
+    atomic launchers of rounds 1-4 (PDFOPS_WA_ATOMICS=1) to rounding; 3 / 6 / 12 / 24 heads (groups of three heads per workgroup), 2
+    heads (single-head groups), one-row tables, queries without edges, keys nobody attends to."""
+    from pointcloudpdf_amd import _native
+
+    be = _native.hip_backend()
+    assert be.wa_atomic_free
+    G = window_graph(*cfg)
+    a, b = chain(p2, G, dev="cuda"), chain(p2, G, dev="cuda")
+    for key in a:
+        assert torch.equal(a[key], b[key]), f"{cfg} {key}: two evaluations differ"
+    be.wa_atomic_free = False
+    try:
+        c = chain(p2, G, dev="cuda")
+    finally:
+        be.wa_atomic_free = True
+    for key in a:
+        assert_close(a[key], c[key], 2e-5, f"{cfg} {key}")
+
+
 def test_reference_test_script_shape_properties(p2):
     """The reference's own test scripts use N = 35000, M = 800000, C = 96, h = 6 (libs/pointops2/functions/
     test_attention_op_step1_v2.py:13-18): v2 / v3 against the dense edge-list formulas at that size."""
