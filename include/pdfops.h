@@ -39,7 +39,7 @@ extern "C" {
  * version must refuse to call (parameter lists differ; pointcloudpdf_amd/_native.py does).  History: 1 = rounds 1-3 (signatures changed
  * without a bump, see ADVICE of round 3); 4 = round 4: `mma_input` per call on the pdf_rowlin_ / pdf_block_ / pdf_bottleneck_ / pdf_linbn_ /
  * pdf_td_ entries, pdf_set_mma_input / pdf_get_mma_input / pdf_tickets_* removed, pdf_sgd_step takes a found-inf flag;
- * 5 = round 5: pdf_wa_* (atomic-free window-attention backward) added. */
+ * 5 = round 5: pdf_wa_* (atomic-free window-attention backward, fused logits) and pdf_layernorm_* added. */
 #define PDF_ABI_VERSION 5
 int pdf_abi_version(void);
 const char *pdf_build_info(void);
@@ -508,6 +508,21 @@ int pdf_wa_table_grad(int N, int h, int d, int L, const int *seg_off, const int 
                       const float *x, float *ws, float *grad_table, void *stream);
 int pdf_wa_grad_attn(int N, int M, int h, int d, int L, const float *grad_out, const int *offsets, const int *index1, const float *v,
                      const float *table, const int *rel, float *grad_attn, void *stream);
+/* attention_step1_forward_cuda_launcher_v2 + dot_prod_with_idx_forward_cuda_launcher_v3 in one pass over the key rows (their sum is what
+ * WindowAttention.forward feeds the softmax, stratified_transformer_v1m1_origin.py:300-321):
+ * logits[m, hh] = <q[q(m), hh], k[index1[m], hh] + T_q(m, hh)> + <k[index1[m], hh], T_k(m, hh)>. */
+int pdf_wa_logits_forward(int N, int M, int h, int d, int L, const float *q, const float *k, const int *offsets, const int *index1,
+                          const float *table_q, const float *table_k, const int *rel, float *out, void *stream);
+
+/* torch.nn.LayerNorm over the channel dim of (n, c) rows (StratifiedTransformer's norms: stratified_transformer_v1m1_origin.py:123-139,
+ * 366-368, 566-569) as one pass per direction (csrc/layernorm.hip): forward saves mean / rstd (n each); backward writes gx, dgamma, dbeta
+ * (partial: pdf_layernorm_partial_floats(n, c) floats; fixed summation order).  c % 4 == 0, c <= 512, 16-byte aligned pointers. */
+int pdf_layernorm_supported(int c);
+long pdf_layernorm_partial_floats(long n, int c);
+int pdf_layernorm_forward(long n, int c, const float *x, const float *gamma, const float *beta, float eps, float *y, float *mean,
+                          float *rstd, void *stream);
+int pdf_layernorm_backward(long n, int c, const float *gy, const float *x, const float *mean, const float *rstd, const float *gamma,
+                           float *gx, float *partial, float *dgamma, float *dbeta, void *stream);
 
 /* Staging copy for hipGraph replay (pointcloudpdf_amd/engine.py: CapturedStep; no reference counterpart -- the reference issues its
  * step from Python): nseg (src -> dst, nbytes) segments in ONE launch.  src_offset (device int32, may be NULL): element offset (4-byte

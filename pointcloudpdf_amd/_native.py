@@ -74,6 +74,7 @@ _HIP_ONLY_PROTOS = {
     "wa_segment_rows": "iiiipppppppp",
     "wa_table_grad": "iiiippppppp",
     "wa_grad_attn": "iiiiippppppp",
+    "wa_logits_forward": "iiiiipppppppp",
     "group_forward": "iiiippppp",
     "group_backward": "iiiippp",
     "interpolation_weights": "iipp",
@@ -570,6 +571,14 @@ class HipBackend(CBackend):
         lib.pdf_fps_workspace_bytes.argtypes = [c_int, c_int]
         lib.pdf_wa_table_grad_ws_floats.restype = c_long
         lib.pdf_wa_table_grad_ws_floats.argtypes = [c_int, c_int, c_int]
+        lib.pdf_layernorm_supported.restype = c_int
+        lib.pdf_layernorm_supported.argtypes = [c_int]
+        lib.pdf_layernorm_partial_floats.restype = c_long
+        lib.pdf_layernorm_partial_floats.argtypes = [c_long, c_int]
+        lib.pdf_layernorm_forward.restype = c_int
+        lib.pdf_layernorm_forward.argtypes = [c_long, c_int, c_void_p, c_void_p, c_void_p, ctypes.c_float, c_void_p, c_void_p, c_void_p, c_void_p]
+        lib.pdf_layernorm_backward.restype = c_int
+        lib.pdf_layernorm_backward.argtypes = [c_long, c_int] + [c_void_p] * 10
         lib.pdf_fps_stats_offset.restype = c_long
         lib.pdf_fps_stats_offset.argtypes = [c_int, c_int]
         self.collect_fps_stats = False  # debug: keep the work counters of the last bucketed FPS call (forces a sync)
@@ -1055,11 +1064,37 @@ class HipBackend(CBackend):
         _check(grad_out, torch.float32, "grad_output")
         nk = k.shape[0]
         key_off, key_edge, _key_q, key_rel = window_csc(index_k, offsets, rel_idx, n_keys=nk)
+        g_key = grad_out.index_select(0, key_edge)   # (the edge scalars in key order, once: two kernels read them sequentially)
         gq, gk = torch.empty_like(q), torch.empty_like(k)
         self._call("wa_segment_rows", n, h, d, L, offsets, None, None, rel_idx, grad_out, None, table_q, gq)         # grad_q = sum g T_q
-        self._call("wa_segment_rows", nk, h, d, L, key_off, key_edge, None, key_rel, grad_out, None, table_k, gk)    # grad_k = sum g T_k
+        self._call("wa_segment_rows", nk, h, d, L, key_off, None, None, key_rel, g_key, None, table_k, gk)           # grad_k = sum g T_k
         gtq = self._wa_table_grad(n, h, d, L, offsets, None, rel_idx, grad_out, q, q)
-        gtk = self._wa_table_grad(nk, h, d, L, key_off, key_edge, key_rel, grad_out, k, q)
+        gtk = self._wa_table_grad(nk, h, d, L, key_off, None, key_rel, g_key, k, q)
+        return gq, gk, gtq, gtk
+
+    def window_logits_supported(self, q, k, table_q):
+        return self.wa_atomic_free and q.shape[0] == k.shape[0] and self._wa_ok(q.shape[2], int(table_q.shape[0]), q, k)
+
+    def window_logits(self, q, k, index1, offsets, table_q, table_k, rel_idx):
+        """attention_step1_v2(q, k) + dot_prod_with_idx_v3(q, k, table_q, table_k) as ONE pass over the key rows -> (M, h)."""
+        n, h, d = q.shape
+        m = index1.shape[0]
+        out = torch.empty((m, h), dtype=torch.float32, device=q.device)
+        self._call("wa_logits_forward", n, m, h, d, int(table_q.shape[0]), q, k, offsets, index1, table_q, table_k, rel_idx, out)
+        return out
+
+    def window_logits_backward(self, g, q, k, index1, offsets, table_q, table_k, rel_idx):
+        """-> (grad_q, grad_k, grad_table_q, grad_table_k): the sums of the two ops' gradients, each as ONE segmented pass (rows + table term
+        together); the edge scalars are brought into key order once for the two key-side kernels."""
+        n, h, d = q.shape
+        L = int(table_q.shape[0])
+        key_off, key_edge, key_q, key_rel = window_csc(index1, offsets, rel_idx, n_keys=n)
+        g_key = g.index_select(0, key_edge)
+        gq, gk = torch.empty_like(q), torch.empty_like(k)
+        self._call("wa_segment_rows", n, h, d, L, offsets, None, index1, rel_idx, g, k, table_q, gq)          # sum g (k[index1] + T_q)
+        self._call("wa_segment_rows", n, h, d, L, key_off, None, key_q, key_rel, g_key, q, table_k, gk)       # sum g (q[query] + T_k)
+        gtq = self._wa_table_grad(n, h, d, L, offsets, None, rel_idx, g, q, q)
+        gtk = self._wa_table_grad(n, h, d, L, key_off, None, key_rel, g_key, k, q)
         return gq, gk, gtq, gtk
 
     def attention_step2_with_rel_pos_value_v2_backward(self, grad_out, attn, v, offsets, n_max, index1, table, rel_idx):

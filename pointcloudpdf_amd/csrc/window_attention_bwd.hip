@@ -241,6 +241,51 @@ __global__ __launch_bounds__(TB) void k_grad_attn(int N, int h, int L, const flo
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- fused logits
+// attention_step1_v2 + dot_prod_with_idx_v3 in one pass (WindowAttention.forward adds the two, stratified_transformer_v1m1_origin.py:
+// 300-321): logit[m, hh] = sum_i q[q(m), hh, i] * (k[j, hh, i] + T_q(m, hh, i)) + k[j, hh, i] * T_k(m, hh, i),  j = index1[m].
+// One gather of the key row instead of two and no (M, h) addition.  grid = (ceil(N / QL), h); lane = edge; the head's two table slabs
+// and the chunk's query rows sit in LDS.
+constexpr int QL = 64;
+__global__ __launch_bounds__(TB) void k_logits_fwd(int N, int h, int L, const float *__restrict__ q, const float *__restrict__ k,
+                                                   const int *__restrict__ offsets, const int *__restrict__ index1,
+                                                   const float *__restrict__ table_q, const float *__restrict__ table_k,
+                                                   const int *__restrict__ rel, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *tq = sm, *tk = tq + 3 * L * D, *qs = tk + 3 * L * D;     // [3][L][16] x 2 | qs [QL][16]
+    int *offs = reinterpret_cast<int *>(qs + QL * D);
+    const int hh = blockIdx.y, q0 = blockIdx.x * QL, nq = min(QL, N - q0);
+    const size_t C = (size_t)h * D;
+    for (int jj = threadIdx.x; jj <= nq; jj += TB) offs[jj] = offsets[q0 + jj];
+    stage_table<1>(tq, table_q, L, h, hh);
+    stage_table<1>(tk, table_k, L, h, hh);
+    for (int e = threadIdx.x; e < QL * D; e += TB) qs[e] = e < nq * D ? q[(size_t)(q0 + e / D) * C + (size_t)hh * D + e % D] : 0.f;
+    __syncthreads();
+    const int e0 = offs[0], e1 = offs[nq];
+    int ql = 0;
+    for (int m = e0 + threadIdx.x; m < e1; m += TB) {
+        while (offs[ql + 1] <= m) ++ql;
+        const int r1 = rel[(size_t)m * 3], r2 = rel[(size_t)m * 3 + 1], r3 = rel[(size_t)m * 3 + 2];
+        const float4 *kr = reinterpret_cast<const float4 *>(k + (size_t)index1[m] * C + (size_t)hh * D);
+        const float4 *q4 = reinterpret_cast<const float4 *>(qs + ql * D);
+        const float4 *a0 = reinterpret_cast<const float4 *>(tq + (0 * L + r1) * D), *a1 = reinterpret_cast<const float4 *>(tq + (1 * L + r2) * D);
+        const float4 *a2 = reinterpret_cast<const float4 *>(tq + (2 * L + r3) * D);
+        const float4 *b0 = reinterpret_cast<const float4 *>(tk + (0 * L + r1) * D), *b1 = reinterpret_cast<const float4 *>(tk + (1 * L + r2) * D);
+        const float4 *b2 = reinterpret_cast<const float4 *>(tk + (2 * L + r3) * D);
+        float sum = 0.f;
+#pragma unroll
+        for (int c4 = 0; c4 < D / 4; ++c4) {
+            const float4 kv = kr[c4], qv = q4[c4];
+            const float4 tqv = add4(add4(a0[c4], a1[c4]), a2[c4]), tkv = add4(add4(b0[c4], b1[c4]), b2[c4]);
+            sum += qv.x * (kv.x + tqv.x) + kv.x * tkv.x;
+            sum += qv.y * (kv.y + tqv.y) + kv.y * tkv.y;
+            sum += qv.z * (kv.z + tqv.z) + kv.z * tkv.z;
+            sum += qv.w * (kv.w + tqv.w) + kv.w * tkv.w;
+        }
+        out[(size_t)m * h + hh] = sum;
+    }
+}
+
 static inline int head_group(int h) { return h % 3 == 0 ? 3 : 1; }
 static inline int table_grid(int N, int h) {
     const int nchunks = (N + OC - 1) / OC, hgn = h / head_group(h);
@@ -287,6 +332,18 @@ extern "C" int pdf_wa_grad_attn(int N, int M, int h, int d, int L, const float *
     const size_t lds = sizeof(float) * (size_t)(3 * L * wb::D + wb::QF * wb::D + wb::QF * 3 * L) + sizeof(int) * (wb::QF + 1);
     wb::k_grad_attn<<<dim3((unsigned)((N + wb::QF - 1) / wb::QF), (unsigned)h), wb::TB, lds, static_cast<hipStream_t>(stream)>>>(
         N, h, L, grad_out, offsets, index1, v, table, rel, grad_attn);
+    return pdf_launch_status();
+}
+
+// logits (M, h) = attention_step1_v2(q, k) + dot_prod_with_idx_v3(q, k, table_q, table_k), every element written
+extern "C" int pdf_wa_logits_forward(int N, int M, int h, int d, int L, const float *q, const float *k, const int *offsets, const int *index1,
+                                     const float *table_q, const float *table_k, const int *rel, float *out, void *stream) {
+    if (N < 0 || M < 0 || h < 1 || d < 1 || L < 1 || !q || !k || !offsets || !index1 || !table_q || !table_k || !rel || !out) return PDF_ERR_BAD_ARG;
+    if (N == 0 || M == 0) return PDF_OK;
+    if (d != wb::D || L > wb::LMAX || (reinterpret_cast<uintptr_t>(k) & 15)) return PDF_ERR_UNSUPPORTED;
+    const size_t lds = sizeof(float) * (size_t)(6 * L * wb::D + wb::QL * wb::D) + sizeof(int) * (wb::QL + 1);
+    wb::k_logits_fwd<<<dim3((unsigned)((N + wb::QL - 1) / wb::QL), (unsigned)h), wb::TB, lds, static_cast<hipStream_t>(stream)>>>(
+        N, h, L, q, k, offsets, index1, table_q, table_k, rel, out);
     return pdf_launch_status();
 }
 

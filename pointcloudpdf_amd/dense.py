@@ -43,6 +43,7 @@ def _amp_bwd(fn):
     return wrapped
 
 
+import torch.nn as nn
 import torch.nn.functional as F
 
 
@@ -378,6 +379,55 @@ def bn_relu_linear(bn, z, partial, lins, relu=True, want_stats=False):
 
 def bn_act_partial(bn, z, partial, residual=None, relu=True):
     return _BnActPartial.apply(z, partial, residual, bn.weight, bn.bias, bn, relu)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# torch.nn.LayerNorm on (n, c) rows as one pass per direction (csrc/layernorm.hip) -- StratifiedTransformer's norms.
+# ------------------------------------------------------------------------------------------------------------------
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, x, weight, bias, eps):
+        be = _be()
+        n, c = x.shape
+        y = torch.empty_like(x)
+        stat = torch.empty((2, n), dtype=torch.float32, device=x.device)
+        rc = be.lib.pdf_layernorm_forward(n, c, x.data_ptr(), weight.data_ptr(), bias.data_ptr(), ctypes.c_float(eps), y.data_ptr(),
+                                          stat[0].data_ptr(), stat[1].data_ptr(), be._stream())
+        if rc != 0:
+            raise RuntimeError(f"pdf_layernorm_forward failed with status {rc}")
+        ctx.save_for_backward(x, stat, weight)
+        return y
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, gy):
+        x, stat, weight = ctx.saved_tensors
+        be = _be()
+        n, c = x.shape
+        gy = gy.contiguous()
+        gx = torch.empty_like(x)
+        gwb = torch.empty((2, c), dtype=torch.float32, device=x.device)
+        partial = torch.empty((max(int(be.lib.pdf_layernorm_partial_floats(n, c)), 1),), dtype=torch.float32, device=x.device)
+        rc = be.lib.pdf_layernorm_backward(n, c, gy.data_ptr(), x.data_ptr(), stat[0].data_ptr(), stat[1].data_ptr(), weight.data_ptr(),
+                                           gx.data_ptr(), partial.data_ptr(), gwb[0].data_ptr(), gwb[1].data_ptr(), be._stream())
+        if rc != 0:
+            raise RuntimeError(f"pdf_layernorm_backward failed with status {rc}")
+        return gx, gwb[0], gwb[1], None
+
+
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm (same parameters and ``state_dict`` keys) whose forward / backward on fp32 device rows run as ONE HIP pass each
+    (csrc/layernorm.hip) instead of torch's three kernels; anything else (CPU, other dtypes, no affine parameters) is torch's."""
+
+    hip = os.environ.get("PDFOPS_LAYERNORM", "hip") == "hip"
+
+    def forward(self, x):
+        c = x.shape[-1]
+        if (self.hip and x.is_cuda and x.dtype == torch.float32 and self.weight is not None and self.bias is not None and len(self.normalized_shape) == 1
+                and x.numel() > 0 and x.is_contiguous() and x.data_ptr() % 16 == 0 and _be().lib.pdf_layernorm_supported(c)):
+            return _LayerNormFn.apply(x.view(-1, c), self.weight, self.bias, float(self.eps)).view(x.shape)
+        return super().forward(x)
 
 
 # ------------------------------------------------------------------------------------------------------------------

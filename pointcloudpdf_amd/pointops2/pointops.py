@@ -91,6 +91,37 @@ class AttentionStep2WithRelPosValue_v2(Function):
         return ga, gv, None, None, None, gt, None
 
 
+class WindowLogits(Function):
+    """attention_step1_v2(q, k, ...) + dot_prod_with_idx_v3(q, ..., k, ..., table_q, table_k, rel_idx) -- the sum WindowAttention.forward
+    feeds the softmax (stratified_transformer_v1m1_origin.py:300-321) -- as one op: one pass over the key rows forward, and the two ops'
+    gradients as single segmented passes backward (csrc/window_attention_bwd.hip).  HIP only (d = 16, L <= 64); ``window_logits`` falls back
+    to the two reference ops elsewhere."""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, q, k, index1, index0_offsets, table_q, table_k, rel_idx):
+        for t in (q, k, index1, index0_offsets, table_q, table_k, rel_idx):
+            assert t.is_contiguous()
+        out = _be(q).window_logits(q, k, index1, index0_offsets, table_q, table_k, rel_idx)
+        ctx.save_for_backward(q, k, index1, index0_offsets, table_q, table_k, rel_idx)
+        return out
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, g):
+        q, k, index1, index0_offsets, table_q, table_k, rel_idx = ctx.saved_tensors
+        gq, gk, gtq, gtk = _be(q).window_logits_backward(g.contiguous(), q, k, index1, index0_offsets, table_q, table_k, rel_idx)
+        return gq, gk, None, None, gtq, gtk, None
+
+
+def window_logits(q, k, index1, index0_offsets, n_max, table_q, table_k, rel_idx):
+    be = _be(q)
+    if getattr(be, "window_logits_supported", None) is not None and index1.shape[0] > 0 and be.window_logits_supported(q, k, table_q):
+        return WindowLogits.apply(q, k, index1, index0_offsets, table_q, table_k, rel_idx)
+    return (AttentionStep1_v2.apply(q, k, index1, index0_offsets, n_max)
+            + DotProdWithIdx_v3.apply(q, index0_offsets, n_max, k, index1, table_q, table_k, rel_idx))
+
+
 attention_step1_v2 = AttentionStep1_v2.apply
 dot_prod_with_idx_v3 = DotProdWithIdx_v3.apply
 attention_step2_with_rel_pos_value_v2 = AttentionStep2WithRelPosValue_v2.apply

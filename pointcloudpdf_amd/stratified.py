@@ -103,19 +103,18 @@ class WindowAttention(nn.Module):
         query, key, value = qkv[0], qkv[1], qkv[2]
         query = query * self.scale
         i1, off = index_1.int().contiguous(), index_0_offsets.int().contiguous()
-        attn = pointops.attention_step1_v2(query.float(), key.float(), i1, off, n_max)
         if rel_idx is None:
             rel_idx = self.checked_relative_position_index(xyz, index_0, index_1)
-        if self.rel_query and self.rel_key:
-            bias = pointops.dot_prod_with_idx_v3(query.float(), off, n_max, key.float(), i1, self.relative_pos_query_table.float(),
-                                                 self.relative_pos_key_table.float(), rel_idx)
-        elif self.rel_query:
-            bias = pointops.dot_prod_with_idx(query.float(), index_0.int(), self.relative_pos_query_table.float(), rel_idx)
-        elif self.rel_key:
-            bias = pointops.dot_prod_with_idx(key.float(), index_1.int(), self.relative_pos_key_table.float(), rel_idx)
+        if self.rel_query and self.rel_key:   # attention_step1_v2 + dot_prod_with_idx_v3 (:300-321) as one op where the backend has it
+            logits = pointops.window_logits(query.float(), key.float(), i1, off, n_max, self.relative_pos_query_table.float(),
+                                            self.relative_pos_key_table.float(), rel_idx)
         else:
-            bias = 0.0
-        attn = pointops.segment_softmax(attn + bias, off)                                  # scatter_softmax(src, index_0, dim=0), :322-324
+            logits = pointops.attention_step1_v2(query.float(), key.float(), i1, off, n_max)
+            if self.rel_query:
+                logits = logits + pointops.dot_prod_with_idx(query.float(), index_0.int(), self.relative_pos_query_table.float(), rel_idx)
+            elif self.rel_key:
+                logits = logits + pointops.dot_prod_with_idx(key.float(), index_1.int(), self.relative_pos_key_table.float(), rel_idx)
+        attn = pointops.segment_softmax(logits, off)                                       # scatter_softmax(src, index_0, dim=0), :322-324
         # (upstream constructs ``attn_drop`` but never applies it -- :246 vs :322-341 -- so neither does this forward)
         if self.rel_value:
             x = pointops.attention_step2_with_rel_pos_value_v2(attn.float(), value.float(), off, n_max, i1,
@@ -556,7 +555,7 @@ class TransitionDown(nn.Module):
 
     level = None   # set by StratifiedTransformer: key of this module's FPS call in a StratifiedGeometry
 
-    def __init__(self, in_channels, out_channels, ratio, k, norm_layer=nn.LayerNorm):
+    def __init__(self, in_channels, out_channels, ratio, k, norm_layer=dense.LayerNorm):
         super().__init__()
         self.ratio, self.k = ratio, k
         self.norm = norm_layer(in_channels) if norm_layer else None
@@ -578,7 +577,7 @@ class SwinTransformerBlock(nn.Module):
     """:353-410"""
 
     def __init__(self, dim, num_heads, window_size, quant_size, rel_query=True, rel_key=False, rel_value=False, drop_path=0.0,
-                 mlp_ratio=4.0, qkv_bias=True, qk_scale=None, act_layer=nn.GELU, norm_layer=nn.LayerNorm, mode=4):
+                 mlp_ratio=4.0, qkv_bias=True, qk_scale=None, act_layer=nn.GELU, norm_layer=dense.LayerNorm, mode=4):
         super().__init__()
         self.mode = mode
         self.norm1 = norm_layer(dim)
@@ -599,7 +598,7 @@ class BasicLayer(nn.Module):
     """:413-555 -- window partition (fine + shifted, coarse + shifted), FPS key subset, ``depth`` Swin blocks, optional TransitionDown."""
 
     def __init__(self, downsample_scale, depth, channel, num_heads, window_size, grid_size, quant_size, rel_query=True, rel_key=False,
-                 rel_value=False, drop_path=0.0, mlp_ratio=4.0, qkv_bias=True, qk_scale=None, norm_layer=nn.LayerNorm, downsample=None,
+                 rel_value=False, drop_path=0.0, mlp_ratio=4.0, qkv_bias=True, qk_scale=None, norm_layer=dense.LayerNorm, downsample=None,
                  ratio=0.25, k=16, out_channels=None):
         super().__init__()
         self.level = None   # set by StratifiedTransformer (key of this layer's FPS calls in a StratifiedGeometry)
@@ -662,8 +661,8 @@ class Upsample(nn.Module):
     def __init__(self, k, in_channels, out_channels, bn_momentum=0.02):
         super().__init__()
         self.k, self.in_channels, self.out_channels = k, in_channels, out_channels
-        self.linear1 = nn.Sequential(nn.LayerNorm(out_channels), _Linear(out_channels, out_channels))
-        self.linear2 = nn.Sequential(nn.LayerNorm(in_channels), _Linear(in_channels, out_channels))
+        self.linear1 = nn.Sequential(dense.LayerNorm(out_channels), _Linear(out_channels, out_channels))
+        self.linear2 = nn.Sequential(dense.LayerNorm(in_channels), _Linear(in_channels, out_channels))
 
     def forward(self, feats, xyz, support_xyz, offset, support_offset, support_feats=None):
         feats = self.linear1(support_feats) + pointops.interpolation(xyz.contiguous(), support_xyz.contiguous(), self.linear2(feats).contiguous(),
