@@ -286,7 +286,7 @@ class KernelTimer:
             xq, idx = args[0], args[4]
             n, c = xq.shape
             return 4 * n * c * 3 + 12 * n + 4 * idx.numel() + 4 * n * c
-        if name.startswith(("attention_step", "dot_prod_with_idx", "window_logits")):
+        if name.startswith(("attention_step", "dot_prod_with_idx", "window_")):
             # libs/pointops2 CSR-by-query ops: every operand once (q / k / v rows (N, C), per-edge scalars (M, h), the edge index and the
             # 3 quantised offsets per edge, the relative-position tables (L, h, d, 3)); the backward passes read the same plus the
             # incoming gradient and write the operands' gradients
@@ -312,6 +312,8 @@ class KernelTimer:
         if name == "window_logits_backward":   # (g, q, k, index1, ...): dot_prod_with_idx_v3's 24 M C + attention_step1's 4 M C
             q = args[1]
             return 28.0 * args[3].shape[0] * q.shape[1] * q.shape[2]
+        if name == "window_attention_core_backward":   # (go, qkv, attn, index1, ...): the three ops' 4 + 24 + 10 M C
+            return 38.0 * args[3].shape[0] * args[0].shape[1]
         if name == "attention_step2_with_rel_pos_value_v2_backward":
             v = args[2]
             return 10.0 * args[1].shape[0] * v.shape[1] * v.shape[2]
@@ -592,7 +594,8 @@ def main():
              "pt_layer_forward", "pt_layer_backward", "bottleneck_forward", "bottleneck_backward"]
     if strat:   # config 5: the libs/pointops2 window-attention ops (csrc/window_attention.hip)
         names += ["attention_step1_v2", "attention_step1_v2_backward", "dot_prod_with_idx_v3", "dot_prod_with_idx_v3_backward",
-                  "window_logits", "window_logits_backward",   # (the two ops above as one, csrc/window_attention_bwd.hip: what the model calls)
+                  "window_logits", "window_logits_backward",   # (the two ops above as one, csrc/window_attention_bwd.hip)
+                  "window_attention_core", "window_attention_core_backward",   # (all of them + the softmax as one node: what the model calls)
                   "attention_step2_with_rel_pos_value_v2", "attention_step2_with_rel_pos_value_v2_backward"]
     timer = KernelTimer(be, names)
     timer.install()
@@ -712,7 +715,7 @@ def main():
         if traffic and traffic.get("file"):
             traffic["file_date"] = time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(os.path.join(ROOT, traffic["file"]))))
         steps_of = lambda name: args.steps if name in KernelTimer.ALWAYS else max(timer.sampled_steps, 1)
-        cand = [n for n in ks if n.startswith(("attention_step", "dot_prod_with_idx", "window_logits"))] if strat else list(ks)   # config 5: the window-attention ops
+        cand = [n for n in ks if n.startswith(("attention_step", "dot_prod_with_idx", "window_"))] if strat else list(ks)   # config 5: the window-attention ops
         dom = max(cand or list(ks), key=lambda n: ks[n]["total_ms"] / steps_of(n)) if ks else None
 
         def roofline_of(name):

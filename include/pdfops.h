@@ -500,19 +500,22 @@ int pdf_segment_softmax_backward(int N, int M, int h, const int *index0_offsets,
  *   pdf_wa_table_grad:   grad_table[r, c, a] = sum_n x[n, c] * sum_{e in seg(n), rel[e][a] == r} w[eid(e), c / 16]   (x = the segment
  *       owner's row: q or grad_out over the CSR list, k over the CSC list); ws: pdf_wa_table_grad_ws_floats(N, h, L) floats.
  *   pdf_wa_grad_attn:    grad_attn[m, hh] = <grad_out[q(m), hh, :], v[index1[m], hh, :] + T(m, hh, :)>.
+ * Row operands carry a row stride in floats (ldx / ldo / ldg / ldv / ld >= h * 16: q, k, v may be slices of the (N, 3 C) rows the qkv Linear
+ * writes, gradients may be written into slices of one (N, 3 C) buffer) and the scales that WindowAttention applies to the query
+ * (xscale on gathered / owner rows, oscale on the result, qscale on the query rows of the logits).
  * PDF_ERR_UNSUPPORTED for other head dims / longer tables: the caller keeps the atomic launchers above. */
 int pdf_wa_segment_rows(int N, int h, int d, int L, const int *seg_off, const int *seg_edge, const int *other, const int *rel,
-                        const float *w, const float *X, const float *table, float *out, void *stream);
+                        const float *w, const float *X, long ldx, float xscale, const float *table, float *out, long ldo, float oscale, void *stream);
 long pdf_wa_table_grad_ws_floats(int N, int h, int L);
 int pdf_wa_table_grad(int N, int h, int d, int L, const int *seg_off, const int *seg_edge, const int *rel, const float *w,
-                      const float *x, float *ws, float *grad_table, void *stream);
-int pdf_wa_grad_attn(int N, int M, int h, int d, int L, const float *grad_out, const int *offsets, const int *index1, const float *v,
-                     const float *table, const int *rel, float *grad_attn, void *stream);
+                      const float *x, long ldx, float xscale, float *ws, float *grad_table, void *stream);
+int pdf_wa_grad_attn(int N, int M, int h, int d, int L, const float *grad_out, long ldg, const int *offsets, const int *index1, const float *v,
+                     long ldv, const float *table, const int *rel, float *grad_attn, void *stream);
 /* attention_step1_forward_cuda_launcher_v2 + dot_prod_with_idx_forward_cuda_launcher_v3 in one pass over the key rows (their sum is what
  * WindowAttention.forward feeds the softmax, stratified_transformer_v1m1_origin.py:300-321):
  * logits[m, hh] = <q[q(m), hh], k[index1[m], hh] + T_q(m, hh)> + <k[index1[m], hh], T_k(m, hh)>. */
-int pdf_wa_logits_forward(int N, int M, int h, int d, int L, const float *q, const float *k, const int *offsets, const int *index1,
-                          const float *table_q, const float *table_k, const int *rel, float *out, void *stream);
+int pdf_wa_logits_forward(int N, int M, int h, int d, int L, const float *q, const float *k, long ld, float qscale, const int *offsets,
+                          const int *index1, const float *table_q, const float *table_k, const int *rel, float *out, void *stream);
 
 /* torch.nn.LayerNorm over the channel dim of (n, c) rows (StratifiedTransformer's norms: stratified_transformer_v1m1_origin.py:123-139,
  * 366-368, 566-569) as one pass per direction (csrc/layernorm.hip): forward saves mean / rstd (n each); backward writes gx, dgamma, dbeta

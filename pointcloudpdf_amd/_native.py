@@ -71,10 +71,10 @@ _HIP_ONLY_PROTOS = {
     "dot_prod_with_idx_forward_v3_l": "iiiiipppppppp",
     "dot_prod_with_idx_backward_v3_l": "iiiiipppppppppppp",
     "attention_step2_with_rel_pos_value_backward_v2_l": "iiiiipppppppppp",
-    "wa_segment_rows": "iiiipppppppp",
-    "wa_table_grad": "iiiippppppp",
-    "wa_grad_attn": "iiiiippppppp",
-    "wa_logits_forward": "iiiiipppppppp",
+    "wa_segment_rows": "iiiipppppplfpplf",
+    "wa_table_grad": "iiiippppplfpp",
+    "wa_grad_attn": "iiiiiplppplppp",
+    "wa_logits_forward": "iiiiipplfpppppp",
     "group_forward": "iiiippppp",
     "group_backward": "iiiippp",
     "interpolation_weights": "iipp",
@@ -1039,10 +1039,16 @@ class HipBackend(CBackend):
     def _wa_ok(self, d, L, *tensors):
         return self.wa_atomic_free and d == 16 and L <= 64 and all(t.data_ptr() % 16 == 0 for t in tensors)
 
-    def _wa_table_grad(self, n, h, d, L, seg_off, seg_edge, rel, w, x, like):
+    def _wa_rows(self, n, h, d, L, seg_off, seg_edge, other, rel, w, X, table, out, ldx=None, xscale=1.0, ldo=None, oscale=1.0):
+        """pdf_wa_segment_rows; X / out may be column slices of wider rows (ldx / ldo = their row strides in floats)."""
+        c = h * d
+        self._call("wa_segment_rows", n, h, d, L, seg_off, seg_edge, other, rel, w, X, c if ldx is None else int(ldx), float(xscale), table, out,
+                   c if ldo is None else int(ldo), float(oscale))
+
+    def _wa_table_grad(self, n, h, d, L, seg_off, seg_edge, rel, w, x, like, ldx=None, xscale=1.0):
         g = torch.empty((L, h, d, 3), dtype=torch.float32, device=like.device)
         ws = torch.empty((max(int(self.lib.pdf_wa_table_grad_ws_floats(n, h, L)), 1),), dtype=torch.float32, device=like.device)
-        self._call("wa_table_grad", n, h, d, L, seg_off, seg_edge, rel, w, x, ws, g)
+        self._call("wa_table_grad", n, h, d, L, seg_off, seg_edge, rel, w, x, h * d if ldx is None else int(ldx), float(xscale), ws, g)
         return g
 
     def attention_step1_v2_backward(self, grad_out, q, k, index1, offsets, n_max):
@@ -1052,8 +1058,8 @@ class HipBackend(CBackend):
         _check(grad_out, torch.float32, "grad_output")
         key_off, key_edge, key_q = window_csc(index1, offsets, n_keys=k.shape[0])
         gq, gk = torch.empty_like(q), torch.empty_like(k)
-        self._call("wa_segment_rows", n, h, d, 0, offsets, None, index1, None, grad_out, k, None, gq)            # grad_q = sum g k[index1]
-        self._call("wa_segment_rows", k.shape[0], h, d, 0, key_off, key_edge, key_q, None, grad_out, q, None, gk)   # grad_k = sum g q[query]
+        self._wa_rows(n, h, d, 0, offsets, None, index1, None, grad_out, k, None, gq)                      # grad_q = sum g k[index1]
+        self._wa_rows(k.shape[0], h, d, 0, key_off, key_edge, key_q, None, grad_out, q, None, gk)          # grad_k = sum g q[query]
         return gq, gk
 
     def dot_prod_with_idx_v3_backward(self, grad_out, q, offsets, n_max, k, index_k, table_q, table_k, rel_idx):
@@ -1066,8 +1072,8 @@ class HipBackend(CBackend):
         key_off, key_edge, _key_q, key_rel = window_csc(index_k, offsets, rel_idx, n_keys=nk)
         g_key = grad_out.index_select(0, key_edge)   # (the edge scalars in key order, once: two kernels read them sequentially)
         gq, gk = torch.empty_like(q), torch.empty_like(k)
-        self._call("wa_segment_rows", n, h, d, L, offsets, None, None, rel_idx, grad_out, None, table_q, gq)         # grad_q = sum g T_q
-        self._call("wa_segment_rows", nk, h, d, L, key_off, None, None, key_rel, g_key, None, table_k, gk)           # grad_k = sum g T_k
+        self._wa_rows(n, h, d, L, offsets, None, None, rel_idx, grad_out, None, table_q, gq)               # grad_q = sum g T_q
+        self._wa_rows(nk, h, d, L, key_off, None, None, key_rel, g_key, None, table_k, gk)                 # grad_k = sum g T_k
         gtq = self._wa_table_grad(n, h, d, L, offsets, None, rel_idx, grad_out, q, q)
         gtk = self._wa_table_grad(nk, h, d, L, key_off, None, key_rel, g_key, k, q)
         return gq, gk, gtq, gtk
@@ -1087,7 +1093,7 @@ class HipBackend(CBackend):
         if tuple(table.shape[1:]) != (h, d, 3):
             raise ValueError("attention_step2_with_rel_pos_value_v2: inconsistent shapes")
         out = torch.empty((n, h, d), dtype=torch.float32, device=v.device)
-        self._call("wa_segment_rows", n, h, d, L, offsets, None, index1, rel_idx, attn, v, table, out)
+        self._wa_rows(n, h, d, L, offsets, None, index1, rel_idx, attn, v, table, out)
         return out
 
     def window_logits_supported(self, q, k, table_q):
@@ -1098,7 +1104,7 @@ class HipBackend(CBackend):
         n, h, d = q.shape
         m = index1.shape[0]
         out = torch.empty((m, h), dtype=torch.float32, device=q.device)
-        self._call("wa_logits_forward", n, m, h, d, int(table_q.shape[0]), q, k, offsets, index1, table_q, table_k, rel_idx, out)
+        self._call("wa_logits_forward", n, m, h, d, int(table_q.shape[0]), q, k, h * d, 1.0, offsets, index1, table_q, table_k, rel_idx, out)
         return out
 
     def window_logits_backward(self, g, q, k, index1, offsets, table_q, table_k, rel_idx):
@@ -1109,8 +1115,8 @@ class HipBackend(CBackend):
         key_off, key_edge, key_q, key_rel = window_csc(index1, offsets, rel_idx, n_keys=n)
         g_key = g.index_select(0, key_edge)
         gq, gk = torch.empty_like(q), torch.empty_like(k)
-        self._call("wa_segment_rows", n, h, d, L, offsets, None, index1, rel_idx, g, k, table_q, gq)          # sum g (k[index1] + T_q)
-        self._call("wa_segment_rows", n, h, d, L, key_off, None, key_q, key_rel, g_key, q, table_k, gk)       # sum g (q[query] + T_k)
+        self._wa_rows(n, h, d, L, offsets, None, index1, rel_idx, g, k, table_q, gq)          # sum g (k[index1] + T_q)
+        self._wa_rows(n, h, d, L, key_off, None, key_q, key_rel, g_key, q, table_k, gk)       # sum g (q[query] + T_k)
         gtq = self._wa_table_grad(n, h, d, L, offsets, None, rel_idx, g, q, q)
         gtk = self._wa_table_grad(n, h, d, L, key_off, None, key_rel, g_key, k, q)
         return gq, gk, gtq, gtk
@@ -1122,13 +1128,58 @@ class HipBackend(CBackend):
         if m == 0 or offsets.shape[0] != n + 1 or not self._wa_ok(d, L, v, grad_out):
             return super().attention_step2_with_rel_pos_value_v2_backward(grad_out, attn, v, offsets, n_max, index1, table, rel_idx)
         _check(grad_out, torch.float32, "grad_output")
+        c = h * d
         key_off, key_edge, key_q = window_csc(index1, offsets, n_keys=n)
         ga = torch.empty((m, h), dtype=torch.float32, device=v.device)
         gv = torch.empty_like(v)
-        self._call("wa_grad_attn", n, m, h, d, L, grad_out, offsets, index1, v, table, rel_idx, ga)
-        self._call("wa_segment_rows", n, h, d, 0, key_off, key_edge, key_q, None, attn, grad_out, None, gv)          # grad_v = sum attn grad_out[query]
+        self._call("wa_grad_attn", n, m, h, d, L, grad_out, c, offsets, index1, v, c, table, rel_idx, ga)
+        self._wa_rows(n, h, d, 0, key_off, key_edge, key_q, None, attn, grad_out, None, gv)                # grad_v = sum attn grad_out[query]
         gt = self._wa_table_grad(n, h, d, L, offsets, None, rel_idx, attn, grad_out, v)
         return ga, gv, gt
+
+    # The whole attention core of WindowAttention.forward (stratified_transformer_v1m1_origin.py:296-341) on the (N, 3 C) output of the
+    # qkv Linear: q / k / v are read as column slices (no permute copy), the query scale rides on the kernels, and the backward writes
+    # the three gradients into the slices of one (N, 3 C) buffer.
+    wa_core = os.environ.get("PDFOPS_WA_CORE", "1") != "0"   # (A/B: 0 = the model composes window_logits / softmax / step2 itself)
+
+    def window_attention_core_supported(self, qkv, table_q, table_k, table_v):
+        L, h, d, _ = table_q.shape
+        return (self.wa_core and self.wa_atomic_free and qkv.dim() == 2 and qkv.shape[1] == 3 * h * d and table_k.shape == table_q.shape == table_v.shape
+                and qkv.dtype == torch.float32 and qkv.is_contiguous() and self._wa_ok(d, L, qkv) and (h * d) % 4 == 0)
+
+    def window_attention_core(self, qkv, index1, offsets, table_q, table_k, table_v, rel_idx, scale):
+        """-> (out (N, C), attn (M, h) after the softmax)."""
+        n = qkv.shape[0]
+        L, h, d, _ = table_q.shape
+        c, m = h * d, index1.shape[0]
+        q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
+        logits = torch.empty((m, h), dtype=torch.float32, device=qkv.device)
+        self._call("wa_logits_forward", n, m, h, d, L, q, k, 3 * c, float(scale), offsets, index1, table_q, table_k, rel_idx, logits)
+        attn = self.segment_softmax(logits, offsets)
+        out = torch.empty((n, c), dtype=torch.float32, device=qkv.device)
+        self._wa_rows(n, h, d, L, offsets, None, index1, rel_idx, attn, v, table_v, out, ldx=3 * c)
+        return out, attn
+
+    def window_attention_core_backward(self, go, qkv, attn, index1, offsets, table_q, table_k, table_v, rel_idx, scale):
+        """-> (grad_qkv (N, 3 C), grad_table_q, grad_table_k, grad_table_v)"""
+        n = qkv.shape[0]
+        L, h, d, _ = table_q.shape
+        c, m = h * d, index1.shape[0]
+        q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
+        key_off, key_edge, key_q, key_rel = window_csc(index1, offsets, rel_idx, n_keys=n)
+        gqkv = torch.empty_like(qkv)
+        ga = torch.empty((m, h), dtype=torch.float32, device=qkv.device)
+        self._call("wa_grad_attn", n, m, h, d, L, go, c, offsets, index1, v, 3 * c, table_v, rel_idx, ga)
+        attn_key = attn.index_select(0, key_edge)
+        self._wa_rows(n, h, d, 0, key_off, None, key_q, None, attn_key, go, None, gqkv[:, 2 * c:], ldo=3 * c)          # grad_v
+        gtv = self._wa_table_grad(n, h, d, L, offsets, None, rel_idx, attn, go, qkv)
+        g = self.segment_softmax_backward(attn, ga, offsets)
+        g_key = g.index_select(0, key_edge)
+        self._wa_rows(n, h, d, L, offsets, None, index1, rel_idx, g, k, table_q, gqkv[:, :c], ldx=3 * c, ldo=3 * c, oscale=scale)      # grad_q
+        self._wa_rows(n, h, d, L, key_off, None, key_q, key_rel, g_key, q, table_k, gqkv[:, c:2 * c], ldx=3 * c, xscale=scale, ldo=3 * c)   # grad_k
+        gtq = self._wa_table_grad(n, h, d, L, offsets, None, rel_idx, g, q, qkv, ldx=3 * c, xscale=scale)
+        gtk = self._wa_table_grad(n, h, d, L, key_off, None, key_rel, g_key, k, qkv, ldx=3 * c)
+        return gqkv, gtq, gtk, gtv
 
     def _stream(self):
         return c_void_p(raw_stream())

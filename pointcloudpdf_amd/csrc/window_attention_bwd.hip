@@ -57,7 +57,8 @@ __device__ __forceinline__ void stage_table(float *dst, const float *__restrict_
 template <int HG, bool CSC, bool ROWS, bool TABLE>
 __global__ __launch_bounds__(TB) void k_rows(int N, int h, int L, const int *__restrict__ seg_off, const int *__restrict__ seg_edge,
                                              const int *__restrict__ other, const int *__restrict__ rel, const float *__restrict__ w,
-                                             const float *__restrict__ X, const float *__restrict__ table, float *__restrict__ out) {
+                                             const float *__restrict__ X, long ldx, float xscale, const float *__restrict__ table,
+                                             float *__restrict__ out, long ldo, float oscale) {
     constexpr int CG = HG * D, PQ = CG / 4, RPB = TB / PQ;
     extern __shared__ __attribute__((aligned(16))) float tl[];   // [3][L][CG]
     const int h0 = blockIdx.y * HG;
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(TB) void k_rows(int N, int h, int L, const int *__r
     const long n = (long)blockIdx.x * RPB + slot;
     if (slot >= RPB || n >= N) return;
     const int hh = h0 + p / 4;                       // this lane's head
-    const size_t C = (size_t)h * D, col = (size_t)h0 * D + 4 * p;
+    const size_t col = (size_t)h0 * D + 4 * p;
     int t = seg_off[n];
     const int end = seg_off[n + 1];
     float4 a0 = f4(0.f), a1 = f4(0.f);
@@ -87,11 +88,11 @@ __global__ __launch_bounds__(TB) void k_rows(int N, int h, int L, const int *__r
 #pragma unroll
         for (int k = 0; k < SB; ++k) {
             ww[k] = w[(size_t)eid[k] * h + hh];
-            if (ROWS) x[k] = *reinterpret_cast<const float4 *>(X + (size_t)oth[k] * C + col);
+            if (ROWS) x[k] = *reinterpret_cast<const float4 *>(X + (size_t)oth[k] * ldx + col);
         }
 #pragma unroll
         for (int k = 0; k < SB; ++k) {
-            float4 v = ROWS ? x[k] : f4(0.f);
+            float4 v = ROWS ? make_float4(x[k].x * xscale, x[k].y * xscale, x[k].z * xscale, x[k].w * xscale) : f4(0.f);
             if (TABLE) {
                 const float4 t0 = *reinterpret_cast<const float4 *>(tl + (0 * L + r[k][0]) * CG + 4 * p);
                 const float4 t1 = *reinterpret_cast<const float4 *>(tl + (1 * L + r[k][1]) * CG + 4 * p);
@@ -102,7 +103,8 @@ __global__ __launch_bounds__(TB) void k_rows(int N, int h, int L, const int *__r
             if (k & 1) a1 = fma4(v, s, a1); else a0 = fma4(v, s, a0);
         }
     }
-    *reinterpret_cast<float4 *>(out + (size_t)n * C + col) = add4(a0, a1);
+    const float4 r4 = add4(a0, a1);
+    *reinterpret_cast<float4 *>(out + (size_t)n * ldo + col) = make_float4(r4.x * oscale, r4.y * oscale, r4.z * oscale, r4.w * oscale);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- table gradients
@@ -113,12 +115,11 @@ constexpr int HS = LMAX + 1;        // histogram row stride (odd: lanes of diffe
 template <int HG, bool CSC>
 __global__ __launch_bounds__(TB) void k_table(int N, int h, int L, const int *__restrict__ seg_off, const int *__restrict__ seg_edge,
                                               const int *__restrict__ rel, const float *__restrict__ w, const float *__restrict__ x,
-                                              float *__restrict__ partial) {
+                                              long ldx, float xscale, float *__restrict__ partial) {
     constexpr int CG = HG * D, NP = HG * 3;            // NP histogram rows per owner
     __shared__ __attribute__((aligned(16))) float S[OC * NP * HS];
     __shared__ __attribute__((aligned(16))) float xs[OC * CG];
     const int h0 = blockIdx.y * HG;
-    const size_t C = (size_t)h * D;
     // phase-2 role: thread ar < 3 L owns (axis, row) = (ar / L, ar % L) and the CG channels of the head group
     const int ar = threadIdx.x, pa = ar / L, pr = ar - pa * L;
     const bool owner2 = ar < 3 * L;
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(TB) void k_table(int N, int h, int L, const int *__
         for (int e = threadIdx.x; e < OC * NP * HS; e += TB) S[e] = 0.f;
         for (int e = threadIdx.x; e < OC * CG; e += TB) {
             const int s = e / CG, c = e - s * CG;
-            xs[e] = s < cnt ? x[(size_t)(n0 + s) * C + (size_t)h0 * D + c] : 0.f;
+            xs[e] = s < cnt ? x[(size_t)(n0 + s) * ldx + (size_t)h0 * D + c] * xscale : 0.f;
         }
         __syncthreads();
         if (owner1 && slot < cnt) {
@@ -206,17 +207,16 @@ __global__ __launch_bounds__(TB) void k_table_reduce(int G, int HGN, int HGsz, i
 // The table term factors through the projection P_q[a][r] = < table[r, hh, :, a], grad_out[q, hh, :] > (3 L dot products per query instead
 // of 3 x 16 multiply-adds per edge).  grid = (ceil(N / QF), h); lane = edge (value row: 4 x 16 bytes contiguous).
 constexpr int QF = 32;
-__global__ __launch_bounds__(TB) void k_grad_attn(int N, int h, int L, const float *__restrict__ go, const int *__restrict__ offsets,
-                                                  const int *__restrict__ index1, const float *__restrict__ v, const float *__restrict__ table,
+__global__ __launch_bounds__(TB) void k_grad_attn(int N, int h, int L, const float *__restrict__ go, long ldg, const int *__restrict__ offsets,
+                                                  const int *__restrict__ index1, const float *__restrict__ v, long ldv, const float *__restrict__ table,
                                                   const int *__restrict__ rel, float *__restrict__ grad_attn) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float *tb = sm, *gr = tb + 3 * L * D, *P = gr + QF * D;     // tb [3][L][16] | gr [QF][16] | P [QF][3 L]
     int *offs = reinterpret_cast<int *>(P + QF * 3 * L);
     const int hh = blockIdx.y, q0 = blockIdx.x * QF, nq = min(QF, N - q0), W = 3 * L;
-    const size_t C = (size_t)h * D;
     for (int jj = threadIdx.x; jj <= nq; jj += TB) offs[jj] = offsets[q0 + jj];
     stage_table<1>(tb, table, L, h, hh);
-    for (int e = threadIdx.x; e < QF * D; e += TB) gr[e] = e < nq * D ? go[(size_t)(q0 + e / D) * C + (size_t)hh * D + e % D] : 0.f;
+    for (int e = threadIdx.x; e < QF * D; e += TB) gr[e] = e < nq * D ? go[(size_t)(q0 + e / D) * ldg + (size_t)hh * D + e % D] : 0.f;
     __syncthreads();
     for (int e = threadIdx.x; e < nq * W; e += TB) {
         const int ql = e / W, x = e - ql * W;   // x = a * L + r
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(TB) void k_grad_attn(int N, int h, int L, const flo
     for (int m = e0 + threadIdx.x; m < e1; m += TB) {           // (a lane's edges ascend: the query is found by stepping on)
         while (offs[ql + 1] <= m) ++ql;
         const int r1 = rel[(size_t)m * 3], r2 = rel[(size_t)m * 3 + 1], r3 = rel[(size_t)m * 3 + 2];
-        const float4 *vr = reinterpret_cast<const float4 *>(v + (size_t)index1[m] * C + (size_t)hh * D);
+        const float4 *vr = reinterpret_cast<const float4 *>(v + (size_t)index1[m] * ldv + (size_t)hh * D);
         const float4 *g4 = reinterpret_cast<const float4 *>(gr + ql * D);
         float dot = 0.f;
 #pragma unroll
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(TB) void k_grad_attn(int N, int h, int L, const flo
 // One gather of the key row instead of two and no (M, h) addition.  grid = (ceil(N / QL), h); lane = edge; the head's two table slabs
 // and the chunk's query rows sit in LDS.
 constexpr int QL = 64;
-__global__ __launch_bounds__(TB) void k_logits_fwd(int N, int h, int L, const float *__restrict__ q, const float *__restrict__ k,
+__global__ __launch_bounds__(TB) void k_logits_fwd(int N, int h, int L, const float *__restrict__ q, const float *__restrict__ k, long ld, float qscale,
                                                    const int *__restrict__ offsets, const int *__restrict__ index1,
                                                    const float *__restrict__ table_q, const float *__restrict__ table_k,
                                                    const int *__restrict__ rel, float *__restrict__ out) {
@@ -255,18 +255,17 @@ __global__ __launch_bounds__(TB) void k_logits_fwd(int N, int h, int L, const fl
     float *tq = sm, *tk = tq + 3 * L * D, *qs = tk + 3 * L * D;     // [3][L][16] x 2 | qs [QL][16]
     int *offs = reinterpret_cast<int *>(qs + QL * D);
     const int hh = blockIdx.y, q0 = blockIdx.x * QL, nq = min(QL, N - q0);
-    const size_t C = (size_t)h * D;
     for (int jj = threadIdx.x; jj <= nq; jj += TB) offs[jj] = offsets[q0 + jj];
     stage_table<1>(tq, table_q, L, h, hh);
     stage_table<1>(tk, table_k, L, h, hh);
-    for (int e = threadIdx.x; e < QL * D; e += TB) qs[e] = e < nq * D ? q[(size_t)(q0 + e / D) * C + (size_t)hh * D + e % D] : 0.f;
+    for (int e = threadIdx.x; e < QL * D; e += TB) qs[e] = e < nq * D ? q[(size_t)(q0 + e / D) * ld + (size_t)hh * D + e % D] * qscale : 0.f;
     __syncthreads();
     const int e0 = offs[0], e1 = offs[nq];
     int ql = 0;
     for (int m = e0 + threadIdx.x; m < e1; m += TB) {
         while (offs[ql + 1] <= m) ++ql;
         const int r1 = rel[(size_t)m * 3], r2 = rel[(size_t)m * 3 + 1], r3 = rel[(size_t)m * 3 + 2];
-        const float4 *kr = reinterpret_cast<const float4 *>(k + (size_t)index1[m] * C + (size_t)hh * D);
+        const float4 *kr = reinterpret_cast<const float4 *>(k + (size_t)index1[m] * ld + (size_t)hh * D);
         const float4 *q4 = reinterpret_cast<const float4 *>(qs + ql * D);
         const float4 *a0 = reinterpret_cast<const float4 *>(tq + (0 * L + r1) * D), *a1 = reinterpret_cast<const float4 *>(tq + (1 * L + r2) * D);
         const float4 *a2 = reinterpret_cast<const float4 *>(tq + (2 * L + r3) * D);
@@ -298,22 +297,25 @@ static inline int table_grid(int N, int h) {
 }  // namespace wb
 
 // out (N, h, 16) = segmented sums over the entries [seg_off[n], seg_off[n + 1]) of owner n:
-//     out[n, c] = sum_e w[eid(e), c / 16] * ( (X ? X[other[e], c] : 0) + (table ? T(rel[e])[c] : 0) ),   eid(e) = seg_edge ? seg_edge[e] : e
+//     out[n, c] = oscale * sum_e w[eid(e), c / 16] * ( (X ? xscale * X[other[e], c] : 0) + (table ? T(rel[e])[c] : 0) ),   eid(e) = seg_edge ? seg_edge[e] : e
+// ldx / ldo: row strides (floats) of X and out -- rows may be slices of wider rows (q / k / v inside the (N, 3 C) output of the qkv Linear).
 // other / rel are given IN SEGMENT ORDER (the CSR arrays themselves, or the permuted copies of the CSC list).  Bytes: 4 M C per gathered
 // row table + (8 + 12 + 4 h) M of integers / scalars + 4 N C written.
 extern "C" int pdf_wa_segment_rows(int N, int h, int d, int L, const int *seg_off, const int *seg_edge, const int *other, const int *rel,
-                                   const float *w, const float *X, const float *table, float *out, void *stream) {
+                                   const float *w, const float *X, long ldx, float xscale, const float *table, float *out, long ldo, float oscale,
+                                   void *stream) {
     if (N < 0 || h < 1 || d < 1 || !seg_off || !w || !out || (X && !other) || (table && (!rel || L < 1))) return PDF_ERR_BAD_ARG;
     if (N == 0) return PDF_OK;
     if (d != wb::D || (table && L > wb::LMAX) || (!X && !table)) return PDF_ERR_UNSUPPORTED;
-    if ((X && (reinterpret_cast<uintptr_t>(X) & 15)) || (reinterpret_cast<uintptr_t>(out) & 15)) return PDF_ERR_UNSUPPORTED;
+    if ((X && ((reinterpret_cast<uintptr_t>(X) & 15) || (ldx & 3) || ldx < (long)h * d)) || (reinterpret_cast<uintptr_t>(out) & 15) || (ldo & 3) || ldo < (long)h * d)
+        return PDF_ERR_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int hg = wb::head_group(h);
 #define PDF_WB_ROWS(HG_, CSC_, ROWS_, TABLE_) do { \
         constexpr int rpb = wb::TB / (HG_ * 4); \
         const size_t lds = TABLE_ ? sizeof(float) * 3 * (size_t)L * HG_ * wb::D : 0; \
         wb::k_rows<HG_, CSC_, ROWS_, TABLE_><<<dim3((unsigned)((N + rpb - 1) / rpb), (unsigned)(h / HG_)), wb::TB, lds, s>>>( \
-            N, h, L, seg_off, seg_edge, other, rel, w, X, table, out); } while (0)
+            N, h, L, seg_off, seg_edge, other, rel, w, X, ldx, xscale, table, out, ldo, oscale); } while (0)
 #define PDF_WB_ROWS2(HG_, CSC_) do { \
         if (X && table) PDF_WB_ROWS(HG_, CSC_, true, true); else if (X) PDF_WB_ROWS(HG_, CSC_, true, false); else PDF_WB_ROWS(HG_, CSC_, false, true); } while (0)
     if (hg == 3) { if (seg_edge) PDF_WB_ROWS2(3, true); else PDF_WB_ROWS2(3, false); }
@@ -324,26 +326,26 @@ extern "C" int pdf_wa_segment_rows(int N, int h, int d, int L, const int *seg_of
 }
 
 // grad_attn (M, h), every element written:  < grad_out[q(m), hh, :], v[index1[m], hh, :] + T(m, hh, :) >
-extern "C" int pdf_wa_grad_attn(int N, int M, int h, int d, int L, const float *grad_out, const int *offsets, const int *index1, const float *v,
-                                const float *table, const int *rel, float *grad_attn, void *stream) {
+extern "C" int pdf_wa_grad_attn(int N, int M, int h, int d, int L, const float *grad_out, long ldg, const int *offsets, const int *index1,
+                                const float *v, long ldv, const float *table, const int *rel, float *grad_attn, void *stream) {
     if (N < 0 || M < 0 || h < 1 || d < 1 || L < 1 || !grad_out || !offsets || !index1 || !v || !table || !rel || !grad_attn) return PDF_ERR_BAD_ARG;
     if (N == 0 || M == 0) return PDF_OK;
-    if (d != wb::D || L > wb::LMAX || (reinterpret_cast<uintptr_t>(v) & 15)) return PDF_ERR_UNSUPPORTED;
+    if (d != wb::D || L > wb::LMAX || (reinterpret_cast<uintptr_t>(v) & 15) || (ldv & 3) || ldv < (long)h * d || ldg < (long)h * d) return PDF_ERR_UNSUPPORTED;
     const size_t lds = sizeof(float) * (size_t)(3 * L * wb::D + wb::QF * wb::D + wb::QF * 3 * L) + sizeof(int) * (wb::QF + 1);
     wb::k_grad_attn<<<dim3((unsigned)((N + wb::QF - 1) / wb::QF), (unsigned)h), wb::TB, lds, static_cast<hipStream_t>(stream)>>>(
-        N, h, L, grad_out, offsets, index1, v, table, rel, grad_attn);
+        N, h, L, grad_out, ldg, offsets, index1, v, ldv, table, rel, grad_attn);
     return pdf_launch_status();
 }
 
 // logits (M, h) = attention_step1_v2(q, k) + dot_prod_with_idx_v3(q, k, table_q, table_k), every element written
-extern "C" int pdf_wa_logits_forward(int N, int M, int h, int d, int L, const float *q, const float *k, const int *offsets, const int *index1,
-                                     const float *table_q, const float *table_k, const int *rel, float *out, void *stream) {
+extern "C" int pdf_wa_logits_forward(int N, int M, int h, int d, int L, const float *q, const float *k, long ld, float qscale, const int *offsets,
+                                     const int *index1, const float *table_q, const float *table_k, const int *rel, float *out, void *stream) {
     if (N < 0 || M < 0 || h < 1 || d < 1 || L < 1 || !q || !k || !offsets || !index1 || !table_q || !table_k || !rel || !out) return PDF_ERR_BAD_ARG;
     if (N == 0 || M == 0) return PDF_OK;
-    if (d != wb::D || L > wb::LMAX || (reinterpret_cast<uintptr_t>(k) & 15)) return PDF_ERR_UNSUPPORTED;
+    if (d != wb::D || L > wb::LMAX || (reinterpret_cast<uintptr_t>(k) & 15) || (ld & 3) || ld < (long)h * d) return PDF_ERR_UNSUPPORTED;
     const size_t lds = sizeof(float) * (size_t)(6 * L * wb::D + wb::QL * wb::D) + sizeof(int) * (wb::QL + 1);
     wb::k_logits_fwd<<<dim3((unsigned)((N + wb::QL - 1) / wb::QL), (unsigned)h), wb::TB, lds, static_cast<hipStream_t>(stream)>>>(
-        N, h, L, q, k, offsets, index1, table_q, table_k, rel, out);
+        N, h, L, q, k, ld, qscale, offsets, index1, table_q, table_k, rel, out);
     return pdf_launch_status();
 }
 
@@ -355,19 +357,19 @@ extern "C" long pdf_wa_table_grad_ws_floats(int N, int h, int L) {
 // grad_table (L, h, 16, 3), WRITTEN:  G[r, c, a] = sum_n x[n, c] * sum_{e in seg(n), rel[e][a] == r} w[eid(e), c / 16]
 // x (N, h, 16): the row of the segment OWNER (q / grad_out over the CSR list, k over the CSC list); ws: pdf_wa_table_grad_ws_floats floats.
 extern "C" int pdf_wa_table_grad(int N, int h, int d, int L, const int *seg_off, const int *seg_edge, const int *rel, const float *w,
-                                 const float *x, float *ws, float *grad_table, void *stream) {
+                                 const float *x, long ldx, float xscale, float *ws, float *grad_table, void *stream) {
     if (N < 0 || h < 1 || d < 1 || L < 1 || !seg_off || !rel || !w || !x || !ws || !grad_table) return PDF_ERR_BAD_ARG;
-    if (d != wb::D || L > wb::LMAX) return PDF_ERR_UNSUPPORTED;
+    if (d != wb::D || L > wb::LMAX || ldx < (long)h * d) return PDF_ERR_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (N == 0) return hipMemsetAsync(grad_table, 0, sizeof(float) * (size_t)L * h * d * 3, s) == hipSuccess ? PDF_OK : PDF_ERR_BAD_ARG;
     const int hg = wb::head_group(h), hgn = h / hg, G = wb::table_grid(N, h);
     const dim3 grid((unsigned)G, (unsigned)hgn);
     if (hg == 3) {
-        if (seg_edge) wb::k_table<3, true><<<grid, wb::TB, 0, s>>>(N, h, L, seg_off, seg_edge, rel, w, x, ws);
-        else wb::k_table<3, false><<<grid, wb::TB, 0, s>>>(N, h, L, seg_off, seg_edge, rel, w, x, ws);
+        if (seg_edge) wb::k_table<3, true><<<grid, wb::TB, 0, s>>>(N, h, L, seg_off, seg_edge, rel, w, x, ldx, xscale, ws);
+        else wb::k_table<3, false><<<grid, wb::TB, 0, s>>>(N, h, L, seg_off, seg_edge, rel, w, x, ldx, xscale, ws);
     } else {
-        if (seg_edge) wb::k_table<1, true><<<grid, wb::TB, 0, s>>>(N, h, L, seg_off, seg_edge, rel, w, x, ws);
-        else wb::k_table<1, false><<<grid, wb::TB, 0, s>>>(N, h, L, seg_off, seg_edge, rel, w, x, ws);
+        if (seg_edge) wb::k_table<1, true><<<grid, wb::TB, 0, s>>>(N, h, L, seg_off, seg_edge, rel, w, x, ldx, xscale, ws);
+        else wb::k_table<1, false><<<grid, wb::TB, 0, s>>>(N, h, L, seg_off, seg_edge, rel, w, x, ldx, xscale, ws);
     }
     const long total = (long)hgn * 3 * L * hg * wb::D;
     wb::k_table_reduce<<<(unsigned)((total + wb::TB - 1) / wb::TB), wb::TB, 0, s>>>(G, hgn, hg, L, h, ws, grad_table);

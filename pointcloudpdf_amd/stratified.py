@@ -99,12 +99,16 @@ class WindowAttention(nn.Module):
         BasicLayer computes them once per window partition instead of once per block)."""
         n, c = feats.shape
         assert index_0.shape[0] == index_1.shape[0]
-        qkv = self.qkv(feats).reshape(n, 3, self.num_heads, c // self.num_heads).permute(1, 0, 2, 3).contiguous()
-        query, key, value = qkv[0], qkv[1], qkv[2]
-        query = query * self.scale
         i1, off = index_1.int().contiguous(), index_0_offsets.int().contiguous()
         if rel_idx is None:
             rel_idx = self.checked_relative_position_index(xyz, index_0, index_1)
+        if self.rel_query and self.rel_key and self.rel_value:   # the configured model: everything up to the projection as one node
+            x = pointops.window_attention_core(self.qkv(feats).float(), i1, off, n_max, self.relative_pos_query_table.float(),
+                                               self.relative_pos_key_table.float(), self.relative_pos_value_table.float(), rel_idx, self.scale)
+            return self.proj_drop(self.proj(x))
+        qkv = self.qkv(feats).reshape(n, 3, self.num_heads, c // self.num_heads).permute(1, 0, 2, 3).contiguous()
+        query, key, value = qkv[0], qkv[1], qkv[2]
+        query = query * self.scale
         if self.rel_query and self.rel_key:   # attention_step1_v2 + dot_prod_with_idx_v3 (:300-321) as one op where the backend has it
             logits = pointops.window_logits(query.float(), key.float(), i1, off, n_max, self.relative_pos_query_table.float(),
                                             self.relative_pos_key_table.float(), rel_idx)

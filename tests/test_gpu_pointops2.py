@@ -94,6 +94,34 @@ def test_fused_window_logits_equals_the_two_reference_ops(p2, cfg):
         assert_close(res[0][key], res[1][key], 2e-5, f"{cfg} {key}")
 
 
+@pytest.mark.parametrize("cfg", [(51, 3000, 3, 16, 64, 80), (52, 700, 12, 16, 40, 60), (53, 500, 2, 16, 16, 50)])
+def test_window_attention_core_equals_the_composed_reference_ops(p2, cfg):
+    """pointops.window_attention_core on the (N, 3 C) rows of the qkv Linear (slices, query scale on the kernels, one gradient buffer)
+    against the composition WindowAttention.forward spells out: permute copy, scale, step1 + dot_prod, segment softmax, step2."""
+    seed, n, h, d, L, _ = cfg
+    G = window_graph(*cfg)
+    T = lambda t: t.cuda()
+    off, i1, rel = T(G["offsets"]), T(G["index1"]), T(G["rel_idx"])
+    qkv0 = torch.cat([G["q"].reshape(n, -1), G["k"].reshape(n, -1), G["v"].reshape(n, -1)], 1)
+    go = torch.randn(n, h * d, generator=torch.Generator().manual_seed(7)).cuda()
+    scale = d ** -0.5
+    res = []
+    for fused in (True, False):
+        qkv = T(qkv0).clone().requires_grad_(True)
+        tq, tk, tv = (T(G[nm]).clone().requires_grad_(True) for nm in ("tq", "tk", "tv"))
+        if fused:
+            out = p2.window_attention_core(qkv, i1, off, G["n_max"], tq, tk, tv, rel, scale)
+            assert type(out.grad_fn).__name__.startswith("WindowAttentionCore")
+        else:
+            q, k, v = (t.contiguous() for t in qkv.reshape(n, 3, h, d).unbind(1))
+            logits = p2.attention_step1_v2(q * scale, k, i1, off, G["n_max"]) + p2.dot_prod_with_idx_v3(q * scale, off, G["n_max"], k, i1, tq, tk, rel)
+            out = p2.attention_step2_with_rel_pos_value_v2(p2.segment_softmax(logits, off), v, off, G["n_max"], i1, tv, rel).reshape(n, h * d)
+        out.backward(go)
+        res.append(dict(out=out.detach().cpu(), gqkv=qkv.grad.cpu(), gtq=tq.grad.cpu(), gtk=tk.grad.cpu(), gtv=tv.grad.cpu()))
+    for key in res[0]:
+        assert_close(res[0][key], res[1][key], 2e-5, f"{cfg} {key}")
+
+
 @pytest.mark.parametrize("n,c", [(1, 48), (37, 48), (100000, 48), (40002, 96), (10002, 192), (2502, 384), (777, 32), (513, 512), (64, 20)])
 def test_layernorm_kernel_matches_torch(n, c):
     """dense.LayerNorm (csrc/layernorm.hip) against torch.nn.LayerNorm: output, input gradient, d gamma, d beta; two evaluations of the
