@@ -39,7 +39,7 @@ extern "C" {
  * version must refuse to call (parameter lists differ; pointcloudpdf_amd/_native.py does).  History: 1 = rounds 1-3 (signatures changed
  * without a bump, see ADVICE of round 3); 4 = round 4: `mma_input` per call on the pdf_rowlin_ / pdf_block_ / pdf_bottleneck_ / pdf_linbn_ /
  * pdf_td_ entries, pdf_set_mma_input / pdf_get_mma_input / pdf_tickets_* removed, pdf_sgd_step takes a found-inf flag;
- * 5 = round 5: pdf_wa_* (atomic-free window-attention backward, fused logits) and pdf_layernorm_* added. */
+ * 5 = round 5: pdf_wa_* (atomic-free window-attention backward, fused logits), pdf_layernorm_*, pdf_region_* / *_dev (sync-free pseudo-label pass) added. */
 #define PDF_ABI_VERSION 5
 int pdf_abi_version(void);
 const char *pdf_build_info(void);
@@ -516,6 +516,28 @@ int pdf_wa_grad_attn(int N, int M, int h, int d, int L, const float *grad_out, l
  * logits[m, hh] = <q[q(m), hh], k[index1[m], hh] + T_q(m, hh)> + <k[index1[m], hh], T_k(m, hh)>. */
 int pdf_wa_logits_forward(int N, int M, int h, int d, int L, const float *q, const float *k, long ld, float qscale, const int *offsets,
                           const int *index1, const float *table_q, const float *table_k, const int *rel, float *out, void *stream);
+
+/* The PDF pseudo-label pass without a host in the loop (pointcept/recognizers/ours/pointpdf_v1m1_base.py:233-380; csrc/region_grow.hip,
+ * csrc/graph_prune.hip).  All scenes of a batch per call (one workgroup per scene); starts / sizes (scenes) int32 = the scenes' point ranges;
+ * neighbors (N, nsample) int64 ids LOCAL to the scene, -1 padded; every size the next stage needs stays in device memory:
+ *   pdf_region_grow : all growth rounds of :233-305 on mult (N) int32 (in: multiplicities of the seed list, out: the region);
+ *                     info (scenes, 4) = [rounds, grew, list length, distinct points]
+ *   pdf_region_edges: the region's ascending node list and the (row, col, weight) entries of its neighbour graph (:309-335, ours/utils.py:7-43)
+ *                     at capacity sizes[s] / sizes[s] * nsample per scene; counts (scenes, 4) = [nodes, entries, any -1 padding, smallest id touched]
+ *   pdf_graph_forest_dev / pdf_gmm2_1d_dev: pdf_graph_forest / pdf_gmm2_1d with the sizes read from device memory ([nodes, entries] / [m])
+ *   pdf_region_tree : the forest's chosen entries compacted in entry order (+inf-padded weights), tdev (scenes, 2) = [nodes, tree edges] */
+int pdf_region_grow(int scenes, const int *starts, const int *sizes, const float *coord, const float *score, const long long *neighbors,
+                    int nsample, const float *stop, int slide_window, int max_rounds, int *mult, unsigned char *cand, float *sim, int *info,
+                    void *stream);
+int pdf_region_edges(int scenes, const int *starts, const int *sizes, const float *coord, const float *msp, const long long *neighbors,
+                     int nsample, const int *mult, long long *nodes_out, long long *eu, long long *ev, float *ew, unsigned char *touched,
+                     int *counts, void *stream);
+int pdf_region_tree(int scenes, const int *starts, const int *sizes, int nsample, const int *counts, const unsigned char *chosen,
+                    const long long *eu, const long long *ev, const float *ew, long long *tu, long long *tv, float *tw, int *tdev, void *stream);
+int pdf_graph_forest_dev(long n, int E, const long long *u, const long long *v, const float *w, const unsigned char *active,
+                         const long long *nodes, int n_nodes, const int *dev, int *comp, unsigned char *chosen, void *workspace,
+                         long workspace_bytes, void *stream);
+int pdf_gmm2_1d_dev(int m_cap, const float *sorted_x, const int *m_dev, double *resp, double *out, int iters, double tol, double reg, void *stream);
 
 /* torch.nn.LayerNorm over the channel dim of (n, c) rows (StratifiedTransformer's norms: stratified_transformer_v1m1_origin.py:123-139,
  * 366-368, 566-569) as one pass per direction (csrc/layernorm.hip): forward saves mean / rstd (n each); backward writes gx, dgamma, dbeta

@@ -71,6 +71,11 @@ _HIP_ONLY_PROTOS = {
     "dot_prod_with_idx_forward_v3_l": "iiiiipppppppp",
     "dot_prod_with_idx_backward_v3_l": "iiiiipppppppppppp",
     "attention_step2_with_rel_pos_value_backward_v2_l": "iiiiipppppppppp",
+    "region_grow": "ipppppipiipppp",
+    "region_edges": "ipppppippppppp",
+    "region_tree": "ippipppppppp",
+    "graph_forest_dev": "lipppppippppl",
+    "gmm2_1d_dev": "ippppidd",
     "wa_segment_rows": "iiiipppppplfpplf",
     "wa_table_grad": "iiiippppplfpp",
     "wa_grad_attn": "iiiiiplppplppp",

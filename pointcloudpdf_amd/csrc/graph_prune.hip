@@ -11,6 +11,7 @@
 // node (the root it ended under).  With w == NULL every active edge is equal: the labels are plain connected components.
 // k_gmm2: two-component 1-D mixture by EM in double: quartile start, 2-means, EM until the mean log-likelihood moves < tol.
 #include "pdfops_common.h"
+#include <algorithm>
 
 namespace gp {
 
@@ -45,13 +46,22 @@ __device__ long long gp_prof[64 * 8];
 // them); chosen (E bytes, or NULL): 1 for the entries of the forest.
 constexpr int LDS_NODES = 12288;   // 12 B per slot: 144 KB of the CU's 160 KB
 
+// (round 5) dev: [n_nodes, E] in device memory (the region's sizes, left there by pdf_region_edges) or NULL; the by-value E / n_nodes are then
+// the CAPACITIES of the arrays.  `when`: 0 = always, 1 = only when the list fits the LDS form, 2 = only when it does not (the host cannot
+// know, so it launches both forms and one of them returns at once).
 template <bool LDS>
 __global__ __launch_bounds__(T) void k_forest(long long n, int E, const long long *__restrict__ u, const long long *__restrict__ v,
                                               const float *__restrict__ w, const unsigned char *__restrict__ active,
                                               const long long *__restrict__ nodes, int n_nodes, int *comp_out, int *slot, int *su, int *sv,
-                                              u64 *gbest, int *gcomp, int *parent, int *rootof, unsigned char *chosen) {
+                                              u64 *gbest, int *gcomp, int *parent, int *rootof, unsigned char *chosen,
+                                              const int *__restrict__ dev = nullptr, int when = 0) {
     extern __shared__ u64 lds_dyn[];
     __shared__ int live;
+    if (dev) {
+        n_nodes = min(n_nodes, dev[0]);
+        E = min(E, dev[1]);
+        if ((when == 1 && n_nodes > LDS_NODES) || (when == 2 && n_nodes <= LDS_NODES) || n_nodes <= 0) return;
+    }
     u64 *best;
     int *comp;
     if constexpr (LDS) {
@@ -210,9 +220,10 @@ __device__ inline double quantile_sorted(const float *xs, int m, double q) {   /
 
 // xs: m values sorted ascending; resp: 2 m doubles of scratch; out: mu0, mu1, var0, var1, pi0, pi1, iterations, log-likelihood.
 __global__ __launch_bounds__(TG) void k_gmm2(int m, const float *__restrict__ xs, double *resp, double *out, int iters, double tol,
-                                             double reg) {
+                                             double reg, const int *__restrict__ m_dev = nullptr) {
     __shared__ double lds[(TG / 64) * 4];
     const int t = threadIdx.x;
+    if (m_dev) m = min(m, *m_dev);   // (m by value = the capacity of xs / resp)
     if (m < 2 || xs[m - 1] == xs[0]) {
         double s[1] = {0.0};
         for (int i = t; i < m; i += TG) s[0] += (double)xs[i];
@@ -350,6 +361,42 @@ extern "C" int pdf_graph_forest_profile(long long *host_out) {
 // Two-component 1-D Gaussian mixture of m sorted float values by EM in double (sklearn.mixture.GaussianMixture(n_components=2,
 // reg_covar=reg, tol=tol, max_iter=iters) with a deterministic start: quartiles -> 2-means).  resp: 2 m doubles of scratch;
 // out (8 doubles): means, variances, weights of the two components, the iterations run, the final mean log-likelihood.
+// The same graph with its sizes in DEVICE memory (dev = [n_nodes, E]; the by-value E / n_nodes are capacities): nothing is read back, so the
+// pseudo-label pass stays free of host syncs (and capturable).  Both forms of the kernel are launched; the one the actual size does not
+// call for returns at once.  workspace: pdf_graph_forest_workspace_bytes(n, E capacity, n_nodes capacity).
+extern "C" int pdf_graph_forest_dev(long n, int E, const long long *u, const long long *v, const float *w, const unsigned char *active,
+                                    const long long *nodes, int n_nodes, const int *dev, int *comp, unsigned char *chosen, void *workspace,
+                                    long workspace_bytes, void *stream) {
+    if (n < 0 || E < 0 || n_nodes < 0 || n > 0x7fffffffL || !dev) return PDF_ERR_BAD_ARG;
+    if (n_nodes == 0) return PDF_OK;
+    if (!nodes || !comp || !workspace || (E > 0 && (!u || !v))) return PDF_ERR_BAD_ARG;
+    if (workspace_bytes < pdf_graph_forest_workspace_bytes(n, E, n_nodes) || (reinterpret_cast<uintptr_t>(workspace) & 7)) return PDF_ERR_BAD_ARG;
+    gp::u64 *best = static_cast<gp::u64 *>(workspace);
+    int *slot = reinterpret_cast<int *>(best + n_nodes);
+    int *su = slot + n, *sv = su + E, *gcomp = sv + E, *parent = gcomp + n_nodes, *rootof = parent + n_nodes;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    static const bool lds_form = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(&gp::k_forest<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(gp::LDS_NODES * (sizeof(gp::u64) + sizeof(int)))) == hipSuccess;
+    }();
+    if (lds_form) {
+        const size_t lds = (size_t)std::min(n_nodes, gp::LDS_NODES) * (sizeof(gp::u64) + sizeof(int));
+        gp::k_forest<true><<<1, gp::T, lds, s>>>(n, E, u, v, w, active, nodes, n_nodes, comp, slot, su, sv, best, gcomp, parent, rootof, chosen, dev, 1);
+        if (n_nodes > gp::LDS_NODES)
+            gp::k_forest<false><<<1, gp::T, 0, s>>>(n, E, u, v, w, active, nodes, n_nodes, comp, slot, su, sv, best, gcomp, parent, rootof, chosen, dev, 2);
+    } else {
+        gp::k_forest<false><<<1, gp::T, 0, s>>>(n, E, u, v, w, active, nodes, n_nodes, comp, slot, su, sv, best, gcomp, parent, rootof, chosen, dev, 0);
+    }
+    return pdf_launch_status();
+}
+
+extern "C" int pdf_gmm2_1d_dev(int m_cap, const float *sorted_x, const int *m_dev, double *resp, double *out, int iters, double tol, double reg,
+                               void *stream) {
+    if (m_cap < 0 || !out || !m_dev || (m_cap > 0 && (!sorted_x || !resp)) || iters < 1) return PDF_ERR_BAD_ARG;
+    gp::k_gmm2<<<1, gp::TG, 0, static_cast<hipStream_t>(stream)>>>(m_cap, sorted_x, resp, out, iters, tol, reg, m_dev);
+    return pdf_launch_status();
+}
+
 extern "C" int pdf_gmm2_1d(int m, const float *sorted_x, double *resp, double *out, int iters, double tol, double reg, void *stream) {
     if (m < 0 || !out || (m > 0 && (!sorted_x || !resp)) || iters < 1) return PDF_ERR_BAD_ARG;
     gp::k_gmm2<<<1, gp::TG, 0, static_cast<hipStream_t>(stream)>>>(m, sorted_x, resp, out, iters, tol, reg);

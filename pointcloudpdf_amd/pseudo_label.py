@@ -332,6 +332,10 @@ def pseudo_labeling(coord, logits, neighbors, condition_from="msp", beta=1.5, se
                     slide_window=True, generator=None, prune="auto"):
     """One scene (local neighbour ids) -> bool mask (n,) on the host, like upstream's static method (:187-382).  The seed draw uses
     a CPU generator (upstream: the global one), the GMM numpy's global state."""
+    if coord.is_cuda and prune in ("auto", "hip") and os.environ.get("PDFOPS_PL_STATIC", "1") != "0":
+        # device tensors: the sync-free form (all growth rounds in one kernel, sizes kept on the device); PDFOPS_PL_STATIC=0: rounds 1-4's
+        return get_pseudo_mask_static(coord, logits, [coord.shape[0]], neighbors, condition_from=condition_from, beta=beta, seed_from=seed_from,
+                                      seed_range=seed_range, num_seed=num_seed, slide_window=slide_window, generator=generator).cpu()
     msp = torch.softmax(logits, dim=-1).max(dim=-1)[0]
     ml = logits.max(dim=-1)[0]
     ml = (ml - ml.min()) / (ml.max() - ml.min() + 1e-6)
@@ -352,6 +356,127 @@ def pseudo_labeling(coord, logits, neighbors, condition_from="msp", beta=1.5, se
     return _prune_by_spanning_tree(coord, msp, neighbors, region)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# The whole pass without a host read (round 5): region growing as ONE kernel per batch (csrc/region_grow.hip: all rounds on the device),
+# the region's graph entries by a second kernel, spanning forest / mixture fit / components with their sizes read from device memory
+# (pdf_graph_forest_dev / pdf_gmm2_1d_dev), everything else as fixed-shape torch ops.  Nothing waits for the device, so the step around
+# it keeps running ahead (rounds 1-4: ~10 host reads per scene, the device idle for the ~7 ms the host needed per 150k-point scene) and
+# the pass can be captured into the step's graph.
+# ------------------------------------------------------------------------------------------------------------------
+class _SeedBuffer:
+    """Pinned host buffers for the seed draws (a pageable host -> device copy would wait for the stream; a captured step re-reads the
+    pinned buffer at every replay: the draw of the replayed step is whatever the host wrote last)."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, key, n):
+        b = self.buf.get(key)
+        if b is None or b.shape[0] != n:
+            b = self.buf[key] = torch.empty((n,), dtype=torch.int64).pin_memory()
+        return b
+
+
+_SEEDS = _SeedBuffer()
+
+
+@torch.no_grad()
+def get_pseudo_mask_static(coord, seg_logits, offset_host, neighbors, condition_from="msp", beta=1.5, seed_from="ml", seed_range=0.15,
+                           num_seed=100, slide_window=True, generator=None, max_rounds=4096, info=None):
+    """pointpdf_v1m1_base.py:118-382 for a batch on the device, free of host reads.  ``neighbors``: (N, k) int64 GLOBAL ids, -1 padded
+    (``radius_neighbors``); ``offset_host``: the scenes' end positions as Python ints.  -> bool (N,) on the device.
+    ``info`` (dict, optional): receives the device tensors with the per-scene round counts / region sizes (diagnostics: reading them syncs)."""
+    be = _native.backend_for(coord)
+    dev = coord.device
+    N, ns = neighbors.shape
+    ends = [int(v) for v in offset_host]
+    starts = [0] + ends[:-1]
+    sizes = [e - s for s, e in zip(starts, ends)]
+    B = len(ends)
+    i32 = dict(dtype=torch.int32, device=dev)
+    starts_d = torch.tensor(starts, dtype=torch.int32).to(dev, non_blocking=True) if B > 1 else torch.zeros(1, **i32)
+    sizes_d = torch.tensor(sizes, dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
+    base = torch.repeat_interleave(starts_d.long(), sizes_d.long(), output_size=N) if B > 1 else None
+    nn_local = neighbors if base is None else torch.where(neighbors != -1, neighbors - base[:, None], neighbors)
+    nn_local = nn_local.contiguous()
+    logits = seg_logits.float()
+    msp = torch.softmax(logits, dim=-1).max(dim=-1)[0].contiguous()
+    ml_raw = logits.max(dim=-1)[0]
+    score_parts, stop_parts, mult = [], [], torch.zeros(N, **i32)
+    for b, (s0, e) in enumerate(zip(starts, ends)):
+        ml_b = ml_raw[s0:e]
+        ml_b = (ml_b - ml_b.min()) / (ml_b.max() - ml_b.min() + 1e-6)
+        msp_b = msp[s0:e]
+        score_b = msp_b if condition_from == "msp" else ml_b
+        src_b = msp_b if seed_from == "msp" else ml_b
+        score_parts.append(score_b)
+        stop_parts.append((torch.mean(score_b) - beta * torch.std(score_b)).reshape(1))
+        dice = _SEEDS.get((b, num_seed), num_seed)
+        dice.copy_(torch.randint(0, int(seed_range * (e - s0)), [num_seed], generator=generator))
+        seeds = torch.sort(src_b, dim=-1)[1][dice.to(dev, non_blocking=True)]
+        mult[s0:e].index_add_(0, seeds, torch.ones(num_seed, **i32))
+    score = (torch.cat(score_parts) if B > 1 else score_parts[0]).contiguous()
+    stop = torch.cat(stop_parts).float().contiguous()
+    cand = torch.empty(N, dtype=torch.uint8, device=dev)
+    simbuf = torch.empty(N, dtype=torch.float32, device=dev)
+    ginfo = torch.empty((B, 4), **i32)
+    be._call("region_grow", B, starts_d, sizes_d, coord, score, nn_local, ns, stop, int(bool(slide_window)), int(max_rounds), mult, cand, simbuf, ginfo)
+    nodes = torch.empty(N, dtype=torch.int64, device=dev)
+    eu = torch.empty(N * ns, dtype=torch.int64, device=dev)
+    ev = torch.empty(N * ns, dtype=torch.int64, device=dev)
+    ew = torch.empty(N * ns, dtype=torch.float32, device=dev)
+    touched = torch.empty(N, dtype=torch.uint8, device=dev)
+    counts = torch.empty((B, 4), **i32)
+    be._call("region_edges", B, starts_d, sizes_d, coord, msp, nn_local, ns, mult, nodes, eu, ev, ew, touched, counts)
+    chosen = torch.empty(N * ns, dtype=torch.uint8, device=dev)
+    comp = torch.empty(N, **i32)
+    lab = torch.empty(N, **i32)
+    for b, (s0, e) in enumerate(zip(starts, ends)):      # the spanning forest of every scene (one workgroup each)
+        n = e - s0
+        comp[s0:e] = torch.arange(n, **i32)
+        lab[s0:e] = comp[s0:e]
+        nbytes = int(be.lib.pdf_graph_forest_workspace_bytes(n, n * ns, n))
+        ws = torch.empty((nbytes // 8 + 1,), dtype=torch.int64, device=dev)
+        be._call("graph_forest_dev", n, n * ns, eu[s0 * ns:e * ns], ev[s0 * ns:e * ns], ew[s0 * ns:e * ns], None, nodes[s0:e], n, counts[b, 0:2],
+                 comp[s0:e], chosen[s0 * ns:e * ns], ws, ws.numel() * 8)
+    tu = torch.empty(N, dtype=torch.int64, device=dev)
+    tv = torch.empty(N, dtype=torch.int64, device=dev)
+    tw = torch.empty(N, dtype=torch.float32, device=dev)
+    tdev = torch.empty((B, 2), **i32)
+    be._call("region_tree", B, starts_d, sizes_d, ns, counts, chosen, eu, ev, ew, tu, tv, tw, tdev)
+    mask = torch.empty(N, dtype=torch.bool, device=dev)
+    for b, (s0, e) in enumerate(zip(starts, ends)):
+        n = e - s0
+        xs = torch.sort(tw[s0:e])[0]
+        resp = torch.empty((2 * n,), dtype=torch.float64, device=dev)
+        fit = torch.empty((8,), dtype=torch.float64, device=dev)
+        be._call("gmm2_1d_dev", n, xs, tdev[b, 1:2], resp, fit, 200, 1e-6, 1e-6)
+        top = (fit[1] > fit[0]).long()                                     # np.argmax(means)
+        lower = fit[top] - 2.0 * fit[2 + top]                              # the "std" of upstream's z-score filter is the covariance, as there
+        weak = (tw[s0:e].double() < lower).to(torch.uint8)
+        nbytes = int(be.lib.pdf_graph_forest_workspace_bytes(n, n, n))
+        ws = torch.empty((nbytes // 8 + 1,), dtype=torch.int64, device=dev)
+        be._call("graph_forest_dev", n, n, tu[s0:e], tv[s0:e], None, weak, nodes[s0:e], n, tdev[b], lab[s0:e], None, ws, ws.numel() * 8)
+        lab_b = lab[s0:e].long()
+        # touched = unique(cat([node, node_nn]))[1:]: the first entry is the -1 padding -- or, when no row of the region is padded, the
+        # smallest id touched (dropped all the same upstream)
+        t_b = touched[s0:e].clone()
+        first = counts[b, 3].clamp(max=n - 1).long().reshape(1)
+        t_b.index_put_((first,), t_b[first] * (counts[b, 2] != 0).to(torch.uint8))
+        cnt = torch.zeros(n, dtype=torch.int64, device=dev).index_add_(0, lab_b, t_b.long())
+        present = cnt > 0
+        k = present.sum().double()
+        c = cnt.double()
+        mean = c.sum() / k
+        std = torch.sqrt((torch.where(present, (c - mean) ** 2, torch.zeros((), dtype=torch.float64, device=dev))).sum() / k)
+        big = present & ((c - mean) / std > 2.0)                           # z_score_mask_np(area="right", score=2.0), population std
+        mask[s0:e] = big[lab_b]
+    if info is not None:
+        info.update(grow=ginfo, counts=counts, tree=tdev)
+    return mask
+
+
+
 @torch.no_grad()
 def get_pseudo_mask(coord, seg_logits, offset, radius=0.1, max_neighbor=64, neighbors=None, offset_host=None, generator=None, workers=None, **kw):
     """pointpdf_v1m1_base.py:118-185 for a batch: neighbour table once, scenes one by one; -> bool (N,) on coord's device."""
@@ -361,6 +486,12 @@ def get_pseudo_mask(coord, seg_logits, offset, radius=0.1, max_neighbor=64, neig
         workers = int(os.environ.get("PDFOPS_PL_WORKERS", "1" if coord.is_cuda else "4"))
     if neighbors is None:
         neighbors = radius_neighbors(coord, offset, radius, max_neighbor)
+    static = coord.is_cuda and os.environ.get("PDFOPS_PL_STATIC", "1") != "0" and kw.get("prune", "auto") in ("auto", "hip")
+    if static and (offset_host is not None or torch.cuda.is_current_stream_capturing() is False):
+        # the sync-free form (get_pseudo_mask_static): scene ends from the host copy when the caller has one (one read of `offset` else)
+        ends = offset_host if offset_host is not None else [int(v) for v in offset.tolist()]
+        kw2 = {k: v for k, v in kw.items() if k != "prune"}
+        return get_pseudo_mask_static(coord, seg_logits, ends, neighbors, generator=generator, **kw2)
     ends = offset_host if offset_host is not None else [int(v) for v in offset.tolist()]
     starts = [0] + ends[:-1]
     stream = torch.cuda.current_stream() if coord.is_cuda else None
@@ -392,19 +523,21 @@ def make_pseudo_mask_fn(radius=0.1, max_neighbor=64, **kw):
     """A ``pseudo_mask_fn(coord, seg_logits, offset)`` for ``recognizer.PointPdfV1`` / ``engine.OpenSegStep`` built from the
     recognizer section of configs/scannet/openseg-pt-v1-0-pointpdf-v1m1-base.py:40-58 (kp_ball_radius, kp_max_neighbor,
     condition_from, beta, seed_from, seed_range, num_seed, slide_window)."""
-    def fn(coord, seg_logits, offset):
-        return get_pseudo_mask(coord, seg_logits.detach(), offset, radius=radius, max_neighbor=max_neighbor, **kw)
+    def fn(coord, seg_logits, offset, offset_host=None):
+        return get_pseudo_mask(coord, seg_logits.detach(), offset, radius=radius, max_neighbor=max_neighbor, offset_host=offset_host, **kw)
+
+    fn.accepts_offset_host = True   # (PointPdfV1 hands the host copy of the scene ends over when the batch carries one: no read of `offset`)
 
     if os.environ.get("PDFOPS_PL_TRACE"):   # diagnostics: host wall time of the wait for the forward and of the pass, per call
         import atexit
         import time
         log = []
 
-        def traced(coord, seg_logits, offset):
+        def traced(coord, seg_logits, offset, offset_host=None):
             t0 = time.perf_counter()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            mask = fn(coord, seg_logits, offset)
+            mask = fn(coord, seg_logits, offset, offset_host=offset_host)
             torch.cuda.synchronize()
             st = torch.cuda.memory_stats()
             log.append((t1 - t0, time.perf_counter() - t1, st.get("num_device_alloc", 0), st.get("num_alloc_retries", 0)))
@@ -419,5 +552,6 @@ def make_pseudo_mask_fn(radius=0.1, max_neighbor=64, **kw):
                       f"max {1e3 * passes[-1]:.2f}); device allocations in that half: {tail[-1][2] - tail[0][2]}, allocator retries: "
                       f"{tail[-1][3] - tail[0][3]}", file=__import__("sys").stderr)
         atexit.register(report)
+        traced.accepts_offset_host = True
         return traced
     return fn

@@ -292,3 +292,52 @@ def test_hip_pruning_equals_the_torch_op_pruning():
         a = pl.pseudo_labeling(coord, logits, nn, generator=torch.Generator().manual_seed(i), prune="hip", **PSEUDO_KW)
         b = pl.pseudo_labeling(coord, logits, nn, generator=torch.Generator().manual_seed(i), prune="device", **PSEUDO_KW)
         assert int(a.sum()) > 0 and torch.equal(a, b), (i, int(a.sum()), int(b.sum()), int((a ^ b).sum()))
+
+
+# ---------------------------------------------------------------- the sync-free pass (round 5, csrc/region_grow.hip)
+@pytest.mark.gpu
+def test_static_pass_equals_the_host_driven_pass(gp, monkeypatch):
+    """get_pseudo_mask_static (all growth rounds in one kernel, region graph / forest / mixture / components with device-side sizes, no host
+    read) against the host-driven form of rounds 1-4 (PDFOPS_PL_STATIC=0) and the reference's fixtures: the fixture scenes (1 growth
+    round), a structured confidence map (many rounds), a random-logit scene, and a two-scene batch in ONE call."""
+    from pointcloudpdf_amd import pseudo_label as pl, synthetic
+
+    scenes = [pseudo_label_scene(*PSEUDO_CASES[t]) for t in sorted(PSEUDO_CASES)]
+    g = torch.Generator().manual_seed(5)
+    sc = synthetic.make_scene(60000, scene_id=9, kind="scannet")
+    scenes.append((torch.from_numpy(sc["coord"]), 0.3 * torch.randn(60000, 20, generator=g)))
+    c2, l2 = pseudo_label_scene(21, 40000)
+    scenes.append((c2, l2 * 0.35))                       # flatter confidence: the region needs several rounds
+    masks_static, rounds = [], []
+    for i, (coord, logits) in enumerate(scenes):
+        coord, logits = coord.cuda(), logits.cuda()
+        n = coord.shape[0]
+        nn = pl.radius_neighbors(coord, torch.tensor([n], dtype=torch.int32, device="cuda"), 0.1, 64)
+        info = {}
+        a = pl.get_pseudo_mask_static(coord, logits, [n], nn, generator=torch.Generator().manual_seed(i), info=info, **PSEUDO_KW)
+        monkeypatch.setenv("PDFOPS_PL_STATIC", "0")
+        b = pl.pseudo_labeling(coord, logits, nn, generator=torch.Generator().manual_seed(i), **PSEUDO_KW)
+        monkeypatch.delenv("PDFOPS_PL_STATIC")
+        assert int(a.sum()) > 0 and torch.equal(a.cpu(), b), (i, int(a.sum()), int(b.sum()), int((a.cpu() ^ b).sum()), info["grow"].tolist())
+        masks_static.append(a)
+        rounds.append(int(info["grow"][0, 0]))
+    assert max(rounds) >= 3, rounds
+    for t, (seed, n) in PSEUDO_CASES.items():            # the reference's own masks
+        coord, logits = pseudo_label_scene(seed, n)
+        nn = pl.radius_neighbors(coord.cuda(), torch.tensor([n], dtype=torch.int32, device="cuda"), 0.1, 64)
+        m = pl.get_pseudo_mask_static(coord.cuda(), logits.cuda(), [n], nn, generator=torch.Generator().manual_seed(seed), **PSEUDO_KW)
+        assert np.array_equal(m.cpu().numpy(), gp[f"{t}_mask"]), t
+    # two scenes in one call = the scenes one by one (same generator order)
+    (ca, la), (cb, lb) = scenes[0], scenes[1]
+    coord, logits = torch.cat([ca, cb]).cuda(), torch.cat([la, lb]).cuda()
+    ends = [ca.shape[0], ca.shape[0] + cb.shape[0]]
+    nn = pl.radius_neighbors(coord, torch.tensor(ends, dtype=torch.int32, device="cuda"), 0.1, 64)
+    gen = torch.Generator().manual_seed(3)
+    both = pl.get_pseudo_mask_static(coord, logits, ends, nn, generator=gen, **PSEUDO_KW)
+    gen = torch.Generator().manual_seed(3)
+    one = []
+    for (c, l) in ((ca, la), (cb, lb)):
+        n = c.shape[0]
+        nn1 = pl.radius_neighbors(c.cuda(), torch.tensor([n], dtype=torch.int32, device="cuda"), 0.1, 64)
+        one.append(pl.get_pseudo_mask_static(c.cuda(), l.cuda(), [n], nn1, generator=gen, **PSEUDO_KW))
+    assert torch.equal(both, torch.cat(one))
