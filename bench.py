@@ -164,9 +164,9 @@ def parse():
                          "batch's geometry tables staged into fixed-address buffers by one copy launch per step); the optimizer, the "
                          "gradient exchange and the geometry pre-pass stay eager.  Needs identical scene sizes in every batch (what "
                          "SphereCrop(point_max) gives the reference's trainer): auto = on unless --jitter (without --size-classes) / "
-                         "--throttle / --ddp torch / the stratified workload ask for something the capture does not cover, or "
-                         "--pseudo-label is set (the step then replays as TWO graphs around the eager pass with --graph 1: measured "
-                         "equal to the eager step on this pool's hosts, 37.8 vs 36.4-37.7 ms)")
+                         "--throttle / --ddp torch / the stratified workload ask for something the capture does not cover.  With --pseudo-label "
+                         "the sync-free pass (csrc/region_grow.hip) is recorded into the same graph (PDFOPS_PL_STATIC=0: the host-driven pass "
+                         "of rounds 1-4, eager step, or TWO graphs around it with --graph 1)")
     ap.add_argument("--ddp", choices=["flat", "torch"], default="flat",
                     help="gradient exchange for N > 1: one flat-buffer all-reduce after the backward (engine.FlatGradAllReduce) or "
                          "torch DistributedDataParallel (per-parameter bucket copies: +3 ms per step, measured)")
@@ -614,7 +614,7 @@ def main():
     # when the batch has the captured shape, eager otherwise; gradient exchange; optimizer; loss scaling).  This file only feeds
     # batches, times the region and reports.
     trainer = engine.TrainStep(step, opt, exchange=grad_sync, scaler=scaler, autocast=amp_dtype, module=module, force_exchange=force_dp,
-                               graph=(args.graph == "1" or (args.graph == "auto" and graph_ok and not args.pseudo_label)), loss_scale=static_scale,
+                               graph=(args.graph == "1" or (args.graph == "auto" and graph_ok and (not args.pseudo_label or getattr(step_kw.get("pseudo_mask_fn"), "capturable", False)))), loss_scale=static_scale,
                                max_captures=(args.size_classes if (args.jitter > 0 and args.size_classes > 0) else 1))
     st_prefetcher = None
     if st_ahead:

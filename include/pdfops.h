@@ -517,27 +517,50 @@ int pdf_wa_grad_attn(int N, int M, int h, int d, int L, const float *grad_out, l
 int pdf_wa_logits_forward(int N, int M, int h, int d, int L, const float *q, const float *k, long ld, float qscale, const int *offsets,
                           const int *index1, const float *table_q, const float *table_k, const int *rel, float *out, void *stream);
 
-/* The PDF pseudo-label pass without a host in the loop (pointcept/recognizers/ours/pointpdf_v1m1_base.py:233-380; csrc/region_grow.hip,
- * csrc/graph_prune.hip).  All scenes of a batch per call (one workgroup per scene); starts / sizes (scenes) int32 = the scenes' point ranges;
- * neighbors (N, nsample) int64 ids LOCAL to the scene, -1 padded; every size the next stage needs stays in device memory:
- *   pdf_region_grow : all growth rounds of :233-305 on mult (N) int32 (in: multiplicities of the seed list, out: the region);
- *                     info (scenes, 4) = [rounds, grew, list length, distinct points]
- *   pdf_region_edges: the region's ascending node list and the (row, col, weight) entries of its neighbour graph (:309-335, ours/utils.py:7-43)
- *                     at capacity sizes[s] / sizes[s] * nsample per scene; counts (scenes, 4) = [nodes, entries, any -1 padding, smallest id touched]
+/* The PDF pseudo-label pass without a host in the loop (pointcept/recognizers/ours/pointpdf_v1m1_base.py:190-380; csrc/region_grow.hip,
+ * csrc/graph_prune.hip).  All scenes of a batch per call; starts / sizes (scenes) int32 = the scenes' point ranges; neighbors (N, nsample)
+ * int32 GLOBAL row ids, -1 padded (the table pdf_radius_neighbors_self writes); every size the next stage needs stays in device memory, and
+ * every reduction is done here (torch's multi-block reductions are not replay-safe on this stack: docs/NOTEBOOK.md, round 5):
+ *   pdf_region_stats : :190-205 -- ml_norm = (ml - min) / (max - min + 1e-6), stop = mean(score) - beta * std(score) per scene; clears mult
+ *   pdf_region_seeds : :206-207 -- mult[p] += 1 for the point whose src value has rank dice[s, j] (radix select; stands in for sort + gather)
+ *   pdf_region_grow  : all growth rounds of :233-305 on mult (N) int32 (in: multiplicities of the seed list, out: the region);
+ *                      info (scenes, 4) = [rounds, grew, list length, distinct points]
+ *   pdf_region_edges : the region's ascending node list and the (row, col, weight) entries of its neighbour graph (:309-335, ours/utils.py:7-43)
+ *                      at capacity sizes[s] / sizes[s] * nsample per scene; counts (scenes, 4) = [nodes, entries, any -1 padding, smallest id
+ *                      touched]; comp / lab (N) = every point's own local id; rows_ws: 3 * n_total words
  *   pdf_graph_forest_dev / pdf_gmm2_1d_dev: pdf_graph_forest / pdf_gmm2_1d with the sizes read from device memory ([nodes, entries] / [m])
- *   pdf_region_tree : the forest's chosen entries compacted in entry order (+inf-padded weights), tdev (scenes, 2) = [nodes, tree edges] */
-int pdf_region_grow(int scenes, const int *starts, const int *sizes, const float *coord, const float *score, const long long *neighbors,
+ *   pdf_region_tree  : the forest's chosen entries compacted in entry order (+inf-padded weights), tdev (scenes, 2) = [nodes, tree edges]
+ *   pdf_sort_floats_dev: the first tdev[s, 1] weights of every scene ascending (what the mixture fit takes); tmp: N words
+ *   pdf_gmm2_weak_dev: :343-358 for every scene -- the two-component fit of the sorted weights (fit (scenes, 8) doubles as pdf_gmm2_1d) and
+ *                      weak[e] = tw[e] < mean - 2 * covariance of the component with the larger mean (N bytes); resp: 2 N doubles
+ *   pdf_region_mask  : :360-380 -- component sizes over the touched points, z-score > 2 -> mask (N bytes); cnt: N ints of workspace */
+int pdf_region_stats(int scenes, const int *starts, const int *sizes, const float *msp, const float *ml, int score_is_ml, float beta,
+                     float *ml_norm, float *stop, int *mult, void *stream);
+int pdf_region_seeds(int scenes, const int *starts, const int *sizes, const float *src, const long long *dice, int num_seed, int *mult,
+                     void *stream);
+int pdf_region_grow(int scenes, const int *starts, const int *sizes, const float *coord, const float *score, const int *neighbors,
                     int nsample, const float *stop, int slide_window, int max_rounds, int *mult, unsigned char *cand, float *sim, int *info,
                     void *stream);
-int pdf_region_edges(int scenes, const int *starts, const int *sizes, const float *coord, const float *msp, const long long *neighbors,
+int pdf_region_edges(int scenes, const int *starts, const int *sizes, const float *coord, const float *msp, const int *neighbors,
                      int nsample, const int *mult, long long *nodes_out, long long *eu, long long *ev, float *ew, unsigned char *touched,
-                     int *counts, void *stream);
+                     int *comp, int *lab, int *counts, void *rows_ws, long n_total, void *stream);
 int pdf_region_tree(int scenes, const int *starts, const int *sizes, int nsample, const int *counts, const unsigned char *chosen,
                     const long long *eu, const long long *ev, const float *ew, long long *tu, long long *tv, float *tw, int *tdev, void *stream);
 int pdf_graph_forest_dev(long n, int E, const long long *u, const long long *v, const float *w, const unsigned char *active,
                          const long long *nodes, int n_nodes, const int *dev, int *comp, unsigned char *chosen, void *workspace,
                          long workspace_bytes, void *stream);
 int pdf_gmm2_1d_dev(int m_cap, const float *sorted_x, const int *m_dev, double *resp, double *out, int iters, double tol, double reg, void *stream);
+int pdf_sort_floats_dev(int scenes, const int *starts, const int *sizes, const int *tdev, const float *x, float *out, void *tmp, void *stream);
+int pdf_gmm2_weak_dev(int scenes, const int *starts, const int *sizes, const int *tdev, const float *sorted_x, const float *tw, double *resp,
+                      double *fit, unsigned char *weak, int iters, double tol, double reg, void *stream);
+int pdf_region_mask(int scenes, const int *starts, const int *sizes, const int *lab, const unsigned char *touched, const int *counts, int *cnt,
+                    unsigned char *mask, void *stream);
+
+/* The TransitionUp head's per-scene context (point_transformer_seg.py:148-161: ``x_b.sum(0, True) / cnt`` and ``.repeat(cnt, 1)``) as one
+ * launch each with a fixed summation order (csrc/scene_rows.hip; torch's multi-workgroup reduction is not replay-safe on this stack).
+ * offset (scenes) int32 = the scenes' end rows; mean != 0: divide by the scene's row count (sum: the forward's mean / repeat: its backward). */
+int pdf_scene_sum_rows(int scenes, const int *offset, int c, const float *x, long ldx, int mean, float *out, void *stream);
+int pdf_scene_repeat_rows(int scenes, const int *offset, long n, int c, const float *rows, int mean, float *out, void *stream);
 
 /* torch.nn.LayerNorm over the channel dim of (n, c) rows (StratifiedTransformer's norms: stratified_transformer_v1m1_origin.py:123-139,
  * 366-368, 566-569) as one pass per direction (csrc/layernorm.hip): forward saves mean / rstd (n each); backward writes gx, dgamma, dbeta

@@ -71,8 +71,15 @@ _HIP_ONLY_PROTOS = {
     "dot_prod_with_idx_forward_v3_l": "iiiiipppppppp",
     "dot_prod_with_idx_backward_v3_l": "iiiiipppppppppppp",
     "attention_step2_with_rel_pos_value_backward_v2_l": "iiiiipppppppppp",
+    "scene_sum_rows": "ipiplip",
+    "scene_repeat_rows": "iplipip",
+    "region_stats": "ippppifppp",
+    "region_seeds": "ippppip",
     "region_grow": "ipppppipiipppp",
-    "region_edges": "ipppppippppppp",
+    "region_edges": "ipppppippppppppppl",
+    "sort_floats_dev": "ipppppp",
+    "gmm2_weak_dev": "ippppppppidd",
+    "region_mask": "ippppppp",
     "region_tree": "ippipppppppp",
     "graph_forest_dev": "lipppppippppl",
     "gmm2_1d_dev": "ippppidd",

@@ -219,24 +219,24 @@ __device__ inline double quantile_sorted(const float *xs, int m, double q) {   /
 }
 
 // xs: m values sorted ascending; resp: 2 m doubles of scratch; out: mu0, mu1, var0, var1, pi0, pi1, iterations, log-likelihood.
-__global__ __launch_bounds__(TG) void k_gmm2(int m, const float *__restrict__ xs, double *resp, double *out, int iters, double tol,
-                                             double reg, const int *__restrict__ m_dev = nullptr) {
-    __shared__ double lds[(TG / 64) * 4];
+struct Fit { double mu0, mu1, var0, var1; };   // (what every thread of the workgroup holds when the fit returns)
+
+__device__ __forceinline__ Fit gmm2_fit(int m, const float *__restrict__ xs, double *resp, double *out, int iters, double tol, double reg,
+                                        double *lds /* [(TG / 64) * 4] */) {
     const int t = threadIdx.x;
-    if (m_dev) m = min(m, *m_dev);   // (m by value = the capacity of xs / resp)
     if (m < 2 || xs[m - 1] == xs[0]) {
         double s[1] = {0.0};
         for (int i = t; i < m; i += TG) s[0] += (double)xs[i];
         block_sum<1>(s, lds);
+        const double mean = m ? s[0] / (double)m : 0.0;
         if (t == 0) {
-            const double mean = m ? s[0] / (double)m : 0.0;
             out[0] = out[1] = mean;
             out[2] = out[3] = reg;
             out[4] = out[5] = 0.5;
             out[6] = 0.0;
             out[7] = 0.0;
         }
-        return;
+        return Fit{mean, mean, reg, reg};
     }
     const double q1 = quantile_sorted(xs, m, 0.25), q3 = quantile_sorted(xs, m, 0.75);
     double mu0 = q3 > q1 ? q1 : (double)xs[0], mu1 = q3 > q1 ? q3 : (double)xs[m - 1];
@@ -314,6 +314,29 @@ __global__ __launch_bounds__(TG) void k_gmm2(int m, const float *__restrict__ xs
         out[6] = (double)it;
         out[7] = ll;
     }
+    return Fit{mu0, mu1, var0, var1};
+}
+
+__global__ __launch_bounds__(TG) void k_gmm2(int m, const float *__restrict__ xs, double *resp, double *out, int iters, double tol,
+                                             double reg, const int *__restrict__ m_dev = nullptr) {
+    __shared__ double lds[(TG / 64) * 4];
+    if (m_dev) m = min(m, *m_dev);   // (m by value = the capacity of xs / resp)
+    gmm2_fit(m, xs, resp, out, iters, tol, reg, lds);
+}
+
+// Every scene of a batch (grid = scenes): the fit of the scene's first tdev[2 s + 1] sorted weights, then upstream's cut of the tree
+// (pointpdf_v1m1_base.py:346-358): the component with the larger mean, "std" = its covariance as upstream, weak[e] = tw[e] < mean - 2 * "std"
+// for the scene's tree entries in entry order (tw is +inf beyond the tree).
+__global__ __launch_bounds__(TG) void k_gmm2_weak(const int *__restrict__ starts, const int *__restrict__ sizes, const int *__restrict__ tdev,
+                                                  const float *__restrict__ xs, const float *__restrict__ tw, double *resp, double *fit,
+                                                  unsigned char *__restrict__ weak, int iters, double tol, double reg) {
+    __shared__ double lds[(TG / 64) * 4];
+    const int s = blockIdx.x;
+    const long s0 = starts[s];
+    const int n = sizes[s], m = min(tdev[2 * s + 1], n);
+    const Fit f = gmm2_fit(m, xs + s0, resp + 2 * s0, fit + 8 * s, iters, tol, reg, lds);
+    const double lower = f.mu1 > f.mu0 ? f.mu1 - 2.0 * f.var1 : f.mu0 - 2.0 * f.var0;   // (np.argmax(means): the first on a tie)
+    for (int i = threadIdx.x; i < n; i += TG) weak[s0 + i] = (double)tw[s0 + i] < lower ? 1 : 0;
 }
 
 }   // namespace gp
@@ -400,5 +423,16 @@ extern "C" int pdf_gmm2_1d_dev(int m_cap, const float *sorted_x, const int *m_de
 extern "C" int pdf_gmm2_1d(int m, const float *sorted_x, double *resp, double *out, int iters, double tol, double reg, void *stream) {
     if (m < 0 || !out || (m > 0 && (!sorted_x || !resp)) || iters < 1) return PDF_ERR_BAD_ARG;
     gp::k_gmm2<<<1, gp::TG, 0, static_cast<hipStream_t>(stream)>>>(m, sorted_x, resp, out, iters, tol, reg);
+    return pdf_launch_status();
+}
+
+// pdf_gmm2_1d_dev for every scene of a batch + the cut of the spanning tree it decides (see k_gmm2_weak).  sorted_x, tw (N) floats; resp 2 N
+// doubles of scratch; fit (scenes, 8) doubles out; weak (N) bytes out.
+extern "C" int pdf_gmm2_weak_dev(int scenes, const int *starts, const int *sizes, const int *tdev, const float *sorted_x, const float *tw,
+                                 double *resp, double *fit, unsigned char *weak, int iters, double tol, double reg, void *stream) {
+    if (scenes < 0 || iters < 1) return PDF_ERR_BAD_ARG;
+    if (scenes == 0) return PDF_OK;
+    if (!starts || !sizes || !tdev || !sorted_x || !tw || !resp || !fit || !weak) return PDF_ERR_BAD_ARG;
+    gp::k_gmm2_weak<<<scenes, gp::TG, 0, static_cast<hipStream_t>(stream)>>>(starts, sizes, tdev, sorted_x, tw, resp, fit, weak, iters, tol, reg);
     return pdf_launch_status();
 }

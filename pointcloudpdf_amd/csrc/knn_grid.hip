@@ -523,6 +523,12 @@ extern "C" int pdf_knn_query_ws_counted(int m, int nsample, int n, const float *
 }
 
 
+namespace kg {
+__global__ __launch_bounds__(256) void k_zero_words(unsigned *__restrict__ p, size_t words) {
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < words && i < ((size_t)blockIdx.x + 1) * 1024; i += 256) p[i] = 0u;
+}
+}  // namespace kg
+
 // Fixed-radius neighbour table of a batch with itself: idx (n, nsample) = the first nsample points of the query's scene, in index
 // order, within `radius` (the query included), -1 padded; dist2 = squared distances (1e10 padded).  Same results as
 // pdf_random_ball_query with order = identity and min_radius = 0.  Workspace: pdf_knn_workspace_bytes(b, n, 0).
@@ -540,8 +546,13 @@ extern "C" int pdf_radius_neighbors_self(int n, int nsample, float radius, const
     unsigned *cursor = reinterpret_cast<unsigned *>(ws + L.cursor);
     int *cell_of = reinterpret_cast<int *>(ws + L.cell_of);
     float4 *sorted = reinterpret_cast<float4 *>(ws + L.sorted);
-    hipError_t e = hipMemsetAsync(ws + L.cell_start, 0, L.cell_of - L.cell_start, s);
-    if (e != hipSuccess) return (int)e;
+    // (a zero-fill KERNEL, not hipMemsetAsync: this table is part of the pseudo-label pass, which a captured step records into its graph;
+    //  a graph holding a memset node faulted at replay -- "write access to a read-only page" -- once any device-to-device copy ran
+    //  between capture and replay on ROCm 7.2: tools/scratch reproduction in docs/NOTEBOOK.md, round 5)
+    {
+        const size_t words = (size_t)(L.cell_of - L.cell_start) / 4;
+        kg::k_zero_words<<<pdf_divup((long)words, 1024), 256, 0, s>>>(reinterpret_cast<unsigned *>(ws + L.cell_start), words);
+    }
     kg::k_grid_setup<<<b, kg::PB, 0, s>>>(xyz, offset, grids, 1.0f, radius * 1.0001f);   // cell >= radius
     kg::k_grid_hist<<<pdf_divup(n, kg::PB), kg::PB, 0, s>>>(n, b, xyz, offset, grids, cell_start, cell_of);
     kg::k_grid_scan<<<b, 1024, 0, s>>>(grids, cell_start);

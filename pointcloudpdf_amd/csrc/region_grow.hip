@@ -44,7 +44,8 @@ __device__ __forceinline__ void block_sum(double (&v)[K], double *lds) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         double s = 0.0;
-        for (int w = 0; w < NW; ++w) s += lds[w * K + k];
+#pragma unroll 4
+        for (int w = 0; w < NW; ++w) s += lds[w * K + k];   // (fully unrolled, the 16 * K loads in flight cost 2 * 16 * K registers)
         v[k] = s;
     }
 }
@@ -79,7 +80,8 @@ __device__ __forceinline__ long long block_sum_ll(long long v, long long *lds) {
 // The k-th smallest (k >= 1, 1-indexed) key of the weighted multiset {key[i] with weight wt(i)}: 4 passes of 8 bits, most significant
 // first.  `wt(i)` returns 0 for elements outside the multiset.  Exact (integer histogram).
 template <typename W, typename Kf>
-__device__ __forceinline__ unsigned radix_select(int n, long long k, W wt, Kf keyf, int *hist /* [256] */, unsigned *bcast /* [2] */) {
+__device__ __forceinline__ unsigned radix_select(int n, long long k, W wt, Kf keyf, int *hist /* [256] */, unsigned *bcast /* [2] */,
+                                                 long long *rank_among_equal = nullptr) {
     unsigned prefix = 0;
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
@@ -108,6 +110,7 @@ __device__ __forceinline__ unsigned radix_select(int n, long long k, W wt, Kf ke
         k = (long long)bcast[1];
         __syncthreads();
     }
+    if (rank_among_equal) *rank_among_equal = k;   // the wanted element is the k-th (1-indexed) of those equal to the returned key
     return prefix;
 }
 
@@ -117,13 +120,14 @@ __device__ __forceinline__ float fmul(float a, float b) { return __fmul_rn(a, b)
 __device__ __forceinline__ float fdivr(float a, float b) { return __fdiv_rn(a, b); }
 __device__ __forceinline__ float norm3(float dx, float dy, float dz) { return __fsqrt_rn(fadd(fadd(fmul(dx, dx), fmul(dy, dy)), fmul(dz, dz))); }
 
-// grid = scenes.  Per scene s: points [start[s], start[s] + n), neighbour ids LOCAL to the scene (-1 padded).
+// grid = scenes.  Per scene s: points [start[s], start[s] + n); neighbour table: GLOBAL row ids (int32, -1 padded: what
+// pdf_radius_neighbors_self writes), made local here.
 //   mult   (N) int32  in: multiplicity of every point in the seed list; out: 1 on the region's points (or the seed multiplicities when the
 //                     region never grew)
 //   cand   (N) uint8  scratch;  sim (N) float scratch
 //   info   (scenes, 4) int32 out: [rounds run, grew (0 / 1), length of the region list, distinct points]
 __global__ __launch_bounds__(T) void k_grow(const int *__restrict__ starts, const int *__restrict__ sizes, const float *__restrict__ coord,
-                                            const float *__restrict__ score, const long long *__restrict__ neighbors, int nsample,
+                                            const float *__restrict__ score, const int *__restrict__ neighbors, int nsample,
                                             const float *__restrict__ stop, int slide_window, int max_rounds, int *__restrict__ mult,
                                             unsigned char *__restrict__ cand, float *__restrict__ sim, int *__restrict__ info) {
     __shared__ double dl[NW * 5];
@@ -164,9 +168,9 @@ __global__ __launch_bounds__(T) void k_grow(const int *__restrict__ starts, cons
         __syncthreads();
         for (int i = t; i < n; i += T) {
             if (mult[i] > 0) {
-                const long long *row = neighbors + (size_t)i * nsample;
+                const int *row = neighbors + (size_t)i * nsample;
                 for (int k = 0; k < nsample; ++k) {
-                    const long long nb = row[k];
+                    const int nb = row[k] < 0 ? -1 : row[k] - (int)s0;
                     if (nb >= 0 && nb < n) cand[nb] = 1;
                 }
             }
@@ -267,101 +271,232 @@ __global__ __launch_bounds__(T) void k_grow(const int *__restrict__ starts, cons
     if (t == 0) { info[4 * s] = rounds; info[4 * s + 1] = grew; info[4 * s + 2] = (int)L; info[4 * s + 3] = (int)distinct; }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- before the growth
+// Per scene (grid = scenes): what upstream computes on the logits before it grows a region (pointpdf_v1m1_base.py:190-207):
+//   ml_norm = (ml - min) / (max - min + 1e-6)   (ml = the row maximum of the logits)
+//   stop    = mean(score) - beta * std(score)   (unbiased std; score = msp or ml_norm)
+// and the seed multiplicities are cleared (k_seed_select adds to them).  The reductions run in double in a fixed order.  (They are NOT
+// left to torch: its multi-block reductions clear their semaphores with a memset node, and replays of a captured step that are queued
+// back to back read garbage from them on this stack -- docs/NOTEBOOK.md, round 5.)
+__global__ __launch_bounds__(T) void k_scene_stats(const int *__restrict__ starts, const int *__restrict__ sizes, const float *__restrict__ msp,
+                                                   const float *__restrict__ ml, int score_is_ml, float beta, float *__restrict__ ml_norm,
+                                                   float *__restrict__ stop, int *__restrict__ mult) {
+    __shared__ double dl[NW];
+    __shared__ float fl[NW];
+    const int s = blockIdx.x, t = threadIdx.x;
+    const long s0 = starts[s];
+    const int n = sizes[s];
+    msp += s0; ml += s0; ml_norm += s0; mult += s0;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int i = t; i < n; i += T) { mn = fminf(mn, ml[i]); mx = fmaxf(mx, ml[i]); }
+    mn = block_min(mn, fl);
+    mx = block_max(mx, fl);
+    const float den = fadd(fsub(mx, mn), 1e-6f);
+    double a[1] = {0.0};
+    for (int i = t; i < n; i += T) {
+        const float v = fdivr(fsub(ml[i], mn), den);
+        ml_norm[i] = v;
+        mult[i] = 0;
+        a[0] += (double)(score_is_ml ? v : msp[i]);
+    }
+    block_sum<1>(a, dl);
+    const double mean = n > 0 ? a[0] / (double)n : 0.0;
+    double q[1] = {0.0};
+    for (int i = t; i < n; i += T) {
+        const double d = (double)(score_is_ml ? fdivr(fsub(ml[i], mn), den) : msp[i]) - mean;
+        q[0] += d * d;
+    }
+    block_sum<1>(q, dl);
+    if (t == 0) stop[s] = fsub((float)mean, fmul(beta, (float)sqrt(q[0] / (double)(n - 1))));
+}
+
+// The seed list (:206-207: ``torch.sort(src)[1][dice]``) without the sort: workgroup (scene, j) finds the point whose src value has rank
+// dice[scene, j] (0-indexed; among equal values the lower id first) by an exact radix select and adds 1 to its multiplicity.
+__global__ __launch_bounds__(T) void k_seed_select(const int *__restrict__ starts, const int *__restrict__ sizes, const float *__restrict__ src,
+                                                   const long long *__restrict__ dice, int num_seed, int *__restrict__ mult) {
+    __shared__ int hist[256];
+    __shared__ unsigned bc[2];
+    __shared__ int found;
+    __shared__ int wcount[NW];
+    const int s = blockIdx.x / num_seed, t = threadIdx.x;
+    const long s0 = starts[s];
+    const int n = sizes[s];
+    if (n <= 0) return;
+    src += s0; mult += s0;
+    long long r = dice[blockIdx.x];
+    r = r < 0 ? 0 : (r > n - 1 ? n - 1 : r);
+    long long need = 1;
+    auto wt = [&](int) { return 1; };
+    auto kf = [&](int i) { return okey(src[i]); };
+    const unsigned cut = radix_select(n, r + 1, wt, kf, hist, bc, &need);
+    if (t == 0) { found = 0x7fffffff; bc[0] = 0u; }
+    __syncthreads();
+    if (need <= 1) {   // the lowest id among the equal values
+        int best = 0x7fffffff;
+        for (int i = t; i < n; i += T)
+            if (okey(src[i]) == cut) { best = i; break; }
+        if (best != 0x7fffffff) atomicMin(&found, best);
+        __syncthreads();
+    } else {           // the need-th of them in id order: ordered walk in chunks of T
+        for (int base = 0; base < n; base += T) {
+            const int i = base + t;
+            const bool eq = i < n && okey(src[i]) == cut;
+            const unsigned long long bal = __ballot(eq);
+            if ((t & 63) == 0) wcount[t >> 6] = __popcll(bal);
+            __syncthreads();
+            int before = (int)bc[0];
+            for (int w = 0; w < (t >> 6); ++w) before += wcount[w];
+            before += __popcll(bal & ((1ull << (t & 63)) - 1ull));
+            if (eq && before + 1 == need) found = i;
+            __syncthreads();
+            if (t == 0) { int tot = 0; for (int w = 0; w < NW; ++w) tot += wcount[w]; bc[0] += (unsigned)tot; }
+            __syncthreads();
+            if ((long long)bc[0] >= need) break;
+        }
+    }
+    if (t == 0 && found != 0x7fffffff) atomicAdd(&mult[found], 1);
+}
+
 // ---------------------------------------------------------------------------------------------------------------- the region's graph
-// Per scene (grid = scenes): node list = the region's points in ascending order (LOCAL ids, int64: what pdf_graph_forest takes) and the
-// entries (u, v, w) of its neighbour graph in (row, col) order: v among u's neighbours with v != -1, v != u, v in the region;
+// Node list = the region's points in ascending order (LOCAL ids, int64: what pdf_graph_forest takes) and the entries (u, v, w) of its
+// neighbour graph in (row, col) order: v among u's neighbours with v != -1, v != u, v in the region;
 // w = mult[u] * (0.4 * dist_sim + 0.6 * conf_sim) (ours/utils.py:7-43; repeated rows of a seed list are SUMMED by upstream's csr_matrix).
 // Row minima / maxima of the distance run over ALL of u's neighbour slots with invalid ones (padding, u itself) counted as 0, as upstream's
 // masked tensor does.  counts (scenes, 4) int32: [nodes, entries, any -1 padding among the region's rows, smallest id touched].
 // Capacities: nodes_out / the entry arrays hold sizes[s] resp. sizes[s] * nsample elements per scene at offset starts[s] (* nsample).
-__global__ __launch_bounds__(T) void k_region_edges(const int *__restrict__ starts, const int *__restrict__ sizes, const float *__restrict__ coord,
-                                                    const float *__restrict__ msp, const long long *__restrict__ neighbors, int nsample,
-                                                    const int *__restrict__ mult, long long *__restrict__ nodes_out, long long *__restrict__ eu,
-                                                    long long *__restrict__ ev, float *__restrict__ ew, unsigned char *__restrict__ touched,
-                                                    int *__restrict__ counts) {
-    __shared__ int wsum[NW], wm[NW], wc[NW];
-    __shared__ int carry[2];
-    __shared__ int flags[2];
+// Four short kernels (round 5's first form walked the scene in chunks of 1024 points inside ONE workgroup and did the rows' 64-slot loops on
+// the few member lanes of a chunk: 12 ms per 150k-point scene):
+//   k_region_nodes   (scenes)          the ascending node list (ballot prefix per chunk), comp / lab = own id, touched = 0
+//   k_region_rows    (scenes x RW)     one WAVE per region row, lanes over the neighbour slots: entry count, distance range, touched marks
+//   k_region_scan    (scenes)          exclusive prefix of the rows' entry counts
+//   k_region_entries (scenes x RW)     the rows again: entries written at their prefix
+constexpr int RW = 64;   // workgroups per scene of the row kernels
+
+__global__ __launch_bounds__(T) void k_region_nodes(const int *__restrict__ starts, const int *__restrict__ sizes, const int *__restrict__ mult,
+                                                    long long *__restrict__ nodes_out, unsigned char *__restrict__ touched, int *__restrict__ comp,
+                                                    int *__restrict__ lab, int *__restrict__ counts) {
+    __shared__ int wm[NW];
+    __shared__ int carry;
     const int s = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const long s0 = starts[s];
     const int n = sizes[s];
-    coord += s0 * 3; msp += s0; neighbors += s0 * nsample; mult += s0; nodes_out += s0; touched += s0;
-    eu += s0 * nsample; ev += s0 * nsample; ew += s0 * nsample;
-    if (t == 0) { carry[0] = 0; carry[1] = 0; flags[0] = 0; flags[1] = 0x7fffffff; }
-    for (int i = t; i < n; i += T) touched[i] = 0;
+    mult += s0; nodes_out += s0; touched += s0; comp += s0; lab += s0;
+    if (t == 0) carry = 0;
     __syncthreads();
-    // chunks of T points in ascending order: exclusive prefix of (is member, valid entries of the row) inside the workgroup
     for (int base = 0; base < n; base += T) {
         const int i = base + t;
-        const int m = i < n ? mult[i] : 0;
-        int cnt = 0;
-        bool pad = false;
-        if (m > 0) {
-            const long long *row = neighbors + (size_t)i * nsample;
-            for (int k = 0; k < nsample; ++k) {
-                const long long nb = row[k];
-                if (nb < 0) pad = true;
-                else {
-                    touched[nb] = 1;
-                    if (nb != i && nb < n && mult[nb] > 0) ++cnt;
+        const bool on = i < n && mult[i] > 0;
+        if (i < n) { touched[i] = 0; comp[i] = i; lab[i] = i; }
+        const unsigned long long bal = __ballot(on);
+        if (lane == 0) wm[wv] = __popcll(bal);
+        __syncthreads();
+        int pos = carry;
+        for (int w = 0; w < wv; ++w) pos += wm[w];
+        pos += __popcll(bal & ((1ull << lane) - 1ull));
+        if (on) nodes_out[pos] = i;
+        __syncthreads();
+        if (t == 0) { int tot = 0; for (int w = 0; w < NW; ++w) tot += wm[w]; carry += tot; }
+        __syncthreads();
+    }
+    if (t == 0) { counts[4 * s] = carry; counts[4 * s + 1] = 0; counts[4 * s + 2] = 0; counts[4 * s + 3] = 0x7fffffff; }
+}
+
+// WRITE = false: rowcnt[r] = entries of row r, rowrange[2 r] = (dmin, dmax), touched marks, counts[2] |= padding seen, counts[3] = min id touched
+// WRITE = true : the entries of row r at rowcnt[r] (by then the exclusive prefix)
+template <bool WRITE>
+__global__ __launch_bounds__(T) void k_region_rows(const int *__restrict__ starts, const int *__restrict__ sizes, const float *__restrict__ coord,
+                                                   const float *__restrict__ msp, const int *__restrict__ neighbors, int nsample,
+                                                   const int *__restrict__ mult, const long long *__restrict__ nodes, int *__restrict__ rowcnt,
+                                                   float *__restrict__ rowrange, long long *__restrict__ eu, long long *__restrict__ ev,
+                                                   float *__restrict__ ew, unsigned char *__restrict__ touched, int *__restrict__ counts) {
+    const int s = blockIdx.x / RW, t = threadIdx.x, lane = t & 63;
+    const long s0 = starts[s];
+    const int n = sizes[s], M = counts[4 * s];
+    coord += s0 * 3; msp += s0; neighbors += s0 * nsample; mult += s0; nodes += s0; rowcnt += s0; rowrange += 2 * s0; touched += s0;
+    eu += s0 * nsample; ev += s0 * nsample; ew += s0 * nsample;
+    bool pad = false;
+    int first = 0x7fffffff;
+    for (int r = (blockIdx.x % RW) * NW + (t >> 6); r < M; r += RW * NW) {
+        const int i = (int)nodes[r];
+        const int *row = neighbors + (size_t)i * nsample;
+        const float px = coord[3 * i], py = coord[3 * i + 1], pz = coord[3 * i + 2];
+        if (!WRITE) {
+            float dmin = INFINITY, dmax = -INFINITY;
+            int cnt = 0;
+            for (int k0 = 0; k0 < nsample; k0 += 64) {
+                const int k = k0 + lane;
+                if (k < nsample) {
+                    const int nb = row[k] < 0 ? -1 : row[k] - (int)s0;
+                    const bool valid = nb >= 0 && nb != i;
+                    const int j = nb >= 0 ? nb : n - 1;   // (upstream indexes coord[-1]: the last point; its distance is masked to 0 anyway)
+                    const float d = valid ? norm3(fsub(coord[3 * j], px), fsub(coord[3 * j + 1], py), fsub(coord[3 * j + 2], pz)) : 0.f;
+                    dmin = fminf(dmin, d); dmax = fmaxf(dmax, d);
+                    if (nb < 0) pad = true;
+                    else {
+                        touched[nb] = 1;
+                        first = min(first, nb);
+                        if (valid && nb < n && mult[nb] > 0) ++cnt;
+                    }
                 }
             }
-            touched[i] = 1;
-        }
-        if (pad) flags[0] = 1;
-        // wave-level inclusive scans of (member, cnt)
-        int pm = m > 0 ? 1 : 0, pc = cnt;
-        for (int o = 1; o < 64; o <<= 1) {
-            const int a = __shfl_up(pm, o, 64), b = __shfl_up(pc, o, 64);
-            if (lane >= o) { pm += a; pc += b; }
-        }
-        if (lane == 63) { wm[wv] = pm; wc[wv] = pc; }
-        __syncthreads();
-        int om = carry[0], oc = carry[1];
-        for (int w = 0; w < wv; ++w) { om += wm[w]; oc += wc[w]; }
-        const int my_node = om + pm - (m > 0 ? 1 : 0), my_entry = oc + pc - cnt;
-        if (m > 0) {
-            nodes_out[my_node] = i;
-            const long long *row = neighbors + (size_t)i * nsample;
-            const float px = coord[3 * i], py = coord[3 * i + 1], pz = coord[3 * i + 2], si = msp[i];
-            float dmin = INFINITY, dmax = -INFINITY;
-            for (int k = 0; k < nsample; ++k) {
-                const long long nb = row[k];
-                const bool valid = nb >= 0 && nb != i;
-                const long long j = nb >= 0 ? nb : n - 1;   // (upstream indexes coord[-1]: the last point; its distance is masked to 0 anyway)
-                const float d = valid ? norm3(fsub(coord[3 * j], px), fsub(coord[3 * j + 1], py), fsub(coord[3 * j + 2], pz)) : 0.f;
-                dmin = fminf(dmin, d); dmax = fmaxf(dmax, d);
+            for (int o = 32; o > 0; o >>= 1) {
+                dmin = fminf(dmin, __shfl_xor(dmin, o, 64)); dmax = fmaxf(dmax, __shfl_xor(dmax, o, 64)); cnt += __shfl_xor(cnt, o, 64);
             }
-            const float den = fadd(fsub(dmax, dmin), 1e-3f);
-            int e = my_entry;
-            for (int k = 0; k < nsample; ++k) {
-                const long long nb = row[k];
-                if (nb >= 0 && nb != i && nb < n && mult[nb] > 0) {
+            if (lane == 0) { rowcnt[r] = cnt; rowrange[2 * r] = dmin; rowrange[2 * r + 1] = dmax; touched[i] = 1; first = min(first, i); }
+        } else {
+            const float dmin = rowrange[2 * r], den = fadd(fsub(rowrange[2 * r + 1], dmin), 1e-3f), si = msp[i];
+            const int m = mult[i];
+            int e = rowcnt[r];
+            for (int k0 = 0; k0 < nsample; k0 += 64) {
+                const int k = k0 + lane;
+                const int nb = k < nsample ? (row[k] < 0 ? -1 : row[k] - (int)s0) : -1;
+                const bool in = nb >= 0 && nb != i && nb < n && mult[nb] > 0;
+                const unsigned long long bal = __ballot(in);
+                if (in) {
                     const float d = norm3(fsub(coord[3 * nb], px), fsub(coord[3 * nb + 1], py), fsub(coord[3 * nb + 2], pz));
                     const float ds = fsub(1.0f, fdivr(fsub(d, dmin), den));
                     const float cs = expf(-fabsf(fsub(msp[nb], si)));
                     const float w = fadd(fmul(0.4f, ds), fmul(0.6f, cs));
-                    eu[e] = i; ev[e] = nb; ew[e] = m == 1 ? w : fmul((float)m, w);
-                    ++e;
+                    const int at = e + __popcll(bal & ((1ull << lane) - 1ull));
+                    eu[at] = i; ev[at] = nb; ew[at] = m == 1 ? w : fmul((float)m, w);
                 }
+                e += __popcll(bal);
             }
         }
-        __syncthreads();
-        if (t == T - 1) { carry[0] = om + pm; carry[1] = oc + pc; }
-        __syncthreads();
     }
-    // smallest touched id (upstream's `unique(...)[1:]` drops it when the rows hold no -1 padding)
-    int first = 0x7fffffff;
-    for (int i = t; i < n; i += T)
-        if (touched[i]) { first = i; break; }
-    for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_down(first, o, 64));
-    if (lane == 0) wsum[wv] = first;
+    if (!WRITE) {
+        if (__ballot(pad)) { if (lane == 0) atomicOr(&counts[4 * s + 2], 1); }
+        for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, 64));
+        if (lane == 0 && first != 0x7fffffff) atomicMin(&counts[4 * s + 3], first);
+    }
+}
+
+__global__ __launch_bounds__(T) void k_region_scan(const int *__restrict__ starts, int *__restrict__ rowcnt, int *__restrict__ counts) {
+    __shared__ int wsum[NW];
+    __shared__ int carry;
+    const int s = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int M = counts[4 * s];
+    rowcnt += (long)starts[s];
+    if (t == 0) carry = 0;
     __syncthreads();
-    if (t == 0) {
-        int f = wsum[0];
-        for (int w = 1; w < NW; ++w) f = min(f, wsum[w]);
-        counts[4 * s] = carry[0]; counts[4 * s + 1] = carry[1]; counts[4 * s + 2] = flags[0]; counts[4 * s + 3] = f;
+    for (int base = 0; base < M; base += T) {
+        const int r = base + t;
+        const int c = r < M ? rowcnt[r] : 0;
+        int p = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int a = __shfl_up(p, o, 64);
+            if (lane >= o) p += a;
+        }
+        if (lane == 63) wsum[wv] = p;
+        __syncthreads();
+        int off = carry;
+        for (int w = 0; w < wv; ++w) off += wsum[w];
+        if (r < M) rowcnt[r] = off + p - c;
+        __syncthreads();
+        if (t == T - 1) carry = off + p;
+        __syncthreads();
     }
+    if (t == 0) counts[4 * s + 1] = carry;
 }
 
 // The chosen entries of the spanning forest, in entry order: tu, tv (ids), tw (weights; +inf beyond the tree so that a plain sort of the
@@ -398,12 +533,133 @@ __global__ __launch_bounds__(T) void k_tree_edges(const int *__restrict__ starts
     if (t == 0) { tdev[2 * s] = counts[4 * s]; tdev[2 * s + 1] = m; }
 }
 
+// Ascending sort of the first m = tdev[2 s + 1] floats of every scene's slice (the spanning tree's weights: the mixture fit below takes
+// its quartiles from sorted data and sums in sorted order, as the host form does after torch.sort).  One workgroup per scene, LSD radix
+// sort of the order-preserving keys, 8 passes of 4 bits; the rank of a key inside a chunk of T comes from 16 ballots.  out / tmp: N words.
+__global__ __launch_bounds__(T) void k_sort_floats(const int *__restrict__ starts, const int *__restrict__ sizes, const int *__restrict__ tdev,
+                                                   const float *__restrict__ x, float *__restrict__ out, unsigned *__restrict__ tmp) {
+    __shared__ int hist[16];
+    __shared__ int base[16];
+    __shared__ int wtot[NW * 16];
+    const int s = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const long s0 = starts[s];
+    const int m = min(tdev[2 * s + 1], sizes[s]);
+    x += s0; tmp += s0;
+    unsigned *a = reinterpret_cast<unsigned *>(out + s0);
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 4 * pass;
+        const unsigned *src = (pass & 1) ? tmp : a;          // pass 0 reads x itself
+        unsigned *dst = (pass & 1) ? a : tmp;
+        if (t < 16) hist[t] = 0;
+        __syncthreads();
+        for (int i = t; i < m; i += T) {
+            const unsigned key = pass == 0 ? okey(x[i]) : src[i];
+            atomicAdd(&hist[(key >> shift) & 15u], 1);
+        }
+        __syncthreads();
+        if (t == 0) {
+            int acc = 0;
+            for (int b = 0; b < 16; ++b) { base[b] = acc; acc += hist[b]; }
+        }
+        __syncthreads();
+        for (int c0 = 0; c0 < m; c0 += T) {
+            const int i = c0 + t;
+            const bool on = i < m;
+            const unsigned key = on ? (pass == 0 ? okey(x[i]) : src[i]) : 0u;
+            const int d = on ? (int)((key >> shift) & 15u) : 16;
+            unsigned long long mine = 0ull;
+            int tot = 0;
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                const unsigned long long bal = __ballot(d == b);
+                if (d == b) mine = bal;
+                if (lane == b) tot = __popcll(bal);
+            }
+            if (lane < 16) wtot[wv * 16 + lane] = tot;
+            __syncthreads();
+            if (on) {
+                int pos = base[d];
+                for (int w = 0; w < wv; ++w) pos += wtot[w * 16 + d];
+                pos += __popcll(mine & ((1ull << lane) - 1ull));
+                dst[pos] = key;
+            }
+            __syncthreads();
+            if (t < 16) { int add = 0; for (int w = 0; w < NW; ++w) add += wtot[w * 16 + t]; base[t] += add; }
+            __syncthreads();
+        }
+    }
+    for (int i = t; i < m; i += T) out[s0 + i] = unkey(a[i]);   // (8 passes: the last one wrote `a`)
+}
+
+// The pseudo mask of every scene from its second component labelling (pointpdf_v1m1_base.py:360-380): size of every component counted
+// over the TOUCHED points (region rows and their neighbours, minus the first entry upstream's unique(...)[1:] drops), components whose
+// size lies more than 2 population standard deviations above the mean -> mask.  cnt: N ints of workspace.
+__global__ __launch_bounds__(T) void k_region_mask(const int *__restrict__ starts, const int *__restrict__ sizes, const int *__restrict__ lab,
+                                                   const unsigned char *__restrict__ touched, const int *__restrict__ counts, int *__restrict__ cnt,
+                                                   unsigned char *__restrict__ mask) {
+    __shared__ double dl[NW * 2];
+    const int s = blockIdx.x, t = threadIdx.x;
+    const long s0 = starts[s];
+    const int n = sizes[s];
+    lab += s0; touched += s0; cnt += s0; mask += s0;
+    const int has_pad = counts[4 * s + 2];
+    const int first = min(counts[4 * s + 3], n - 1);
+    for (int i = t; i < n; i += T) cnt[i] = 0;
+    __syncthreads();
+    for (int i = t; i < n; i += T) {
+        // touched = unique(cat([node, node_nn]))[1:]: the first entry is the -1 padding -- or, when no row of the region is padded, the
+        // smallest id touched (dropped all the same upstream)
+        if (touched[i] && !(i == first && !has_pad)) atomicAdd(&cnt[lab[i]], 1);
+    }
+    __threadfence();
+    __syncthreads();
+    double a[2] = {0.0, 0.0};
+    for (int i = t; i < n; i += T) {
+        const int c = __hip_atomic_load(&cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c > 0) { a[0] += 1.0; a[1] += (double)c; }
+    }
+    block_sum<2>(a, dl);
+    const double k = a[0], mean = a[1] / k;
+    double q[1] = {0.0};
+    for (int i = t; i < n; i += T) {
+        const int c = __hip_atomic_load(&cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c > 0) q[0] += ((double)c - mean) * ((double)c - mean);
+    }
+    block_sum<1>(q, dl);
+    const double sd = sqrt(q[0] / k);
+    for (int i = t; i < n; i += T) {
+        const int c = __hip_atomic_load(&cnt[lab[i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mask[i] = (c > 0 && ((double)c - mean) / sd > 2.0) ? 1 : 0;   // z_score_mask_np(area="right", score=2.0)
+    }
+}
+
 }  // namespace rg
 
+// Before the growth (see k_scene_stats): ml_norm (N) out, stop (scenes) out, mult (N) cleared.  msp / ml (N): the row maxima of the softmax /
+// of the logits; score_is_ml: the growth condition runs on ml_norm instead of msp.
+extern "C" int pdf_region_stats(int scenes, const int *starts, const int *sizes, const float *msp, const float *ml, int score_is_ml, float beta,
+                                float *ml_norm, float *stop, int *mult, void *stream) {
+    if (scenes < 0) return PDF_ERR_BAD_ARG;
+    if (scenes == 0) return PDF_OK;
+    if (!starts || !sizes || !msp || !ml || !ml_norm || !stop || !mult) return PDF_ERR_BAD_ARG;
+    rg::k_scene_stats<<<scenes, rg::T, 0, static_cast<hipStream_t>(stream)>>>(starts, sizes, msp, ml, score_is_ml, beta, ml_norm, stop, mult);
+    return pdf_launch_status();
+}
+
+// The seed list: mult[p] += 1 for the point p of scene s whose src value has rank dice[s * num_seed + j] (see k_seed_select).
+extern "C" int pdf_region_seeds(int scenes, const int *starts, const int *sizes, const float *src, const long long *dice, int num_seed, int *mult,
+                                void *stream) {
+    if (scenes < 0 || num_seed < 0) return PDF_ERR_BAD_ARG;
+    if (scenes == 0 || num_seed == 0) return PDF_OK;
+    if (!starts || !sizes || !src || !dice || !mult) return PDF_ERR_BAD_ARG;
+    rg::k_seed_select<<<scenes * num_seed, rg::T, 0, static_cast<hipStream_t>(stream)>>>(starts, sizes, src, dice, num_seed, mult);
+    return pdf_launch_status();
+}
+
 // Region growing of every scene of a batch, all rounds on the device.  starts / sizes (scenes) int32: the scenes' point ranges; neighbors
-// (N, nsample) int64 LOCAL ids (-1 padded); stop (scenes) float; mult (N) int32 in / out; cand (N) bytes, sim (N) floats: scratch;
-// info (scenes, 4) int32 out [rounds, grew, list length, distinct points].
-extern "C" int pdf_region_grow(int scenes, const int *starts, const int *sizes, const float *coord, const float *score, const long long *neighbors,
+// (N, nsample) int32 GLOBAL row ids (-1 padded: pdf_radius_neighbors_self's table); stop (scenes) float; mult (N) int32 in / out; cand (N)
+// bytes, sim (N) floats: scratch; info (scenes, 4) int32 out [rounds, grew, list length, distinct points].
+extern "C" int pdf_region_grow(int scenes, const int *starts, const int *sizes, const float *coord, const float *score, const int *neighbors,
                                int nsample, const float *stop, int slide_window, int max_rounds, int *mult, unsigned char *cand, float *sim,
                                int *info, void *stream) {
     if (scenes < 0 || nsample < 1 || max_rounds < 0) return PDF_ERR_BAD_ARG;
@@ -414,16 +670,25 @@ extern "C" int pdf_region_grow(int scenes, const int *starts, const int *sizes, 
     return pdf_launch_status();
 }
 
-// The region's node list and neighbour-graph entries (see k_region_edges).  nodes_out (N) int64; eu, ev (N * nsample) int64, ew (N * nsample)
-// float: scene s writes at starts[s] (* nsample); touched (N) bytes out; counts (scenes, 4) int32 out.
-extern "C" int pdf_region_edges(int scenes, const int *starts, const int *sizes, const float *coord, const float *msp, const long long *neighbors,
+// The region's node list and neighbour-graph entries (see k_region_rows).  nodes_out (N) int64; eu, ev (N * nsample) int64, ew (N * nsample)
+// float: scene s writes at starts[s] (* nsample); touched (N) bytes out; comp, lab (N) int32 out: every point's own LOCAL id (what the two
+// pdf_graph_forest_dev calls start from); counts (scenes, 4) int32 out; rows_ws: 3 N words of workspace.
+extern "C" int pdf_region_edges(int scenes, const int *starts, const int *sizes, const float *coord, const float *msp, const int *neighbors,
                                 int nsample, const int *mult, long long *nodes_out, long long *eu, long long *ev, float *ew, unsigned char *touched,
-                                int *counts, void *stream) {
-    if (scenes < 0 || nsample < 1) return PDF_ERR_BAD_ARG;
+                                int *comp, int *lab, int *counts, void *rows_ws, long n_total, void *stream) {
+    if (scenes < 0 || nsample < 1 || n_total < 0) return PDF_ERR_BAD_ARG;
     if (scenes == 0) return PDF_OK;
-    if (!starts || !sizes || !coord || !msp || !neighbors || !mult || !nodes_out || !eu || !ev || !ew || !touched || !counts) return PDF_ERR_BAD_ARG;
-    rg::k_region_edges<<<scenes, rg::T, 0, static_cast<hipStream_t>(stream)>>>(starts, sizes, coord, msp, neighbors, nsample, mult, nodes_out, eu, ev, ew,
-                                                                             touched, counts);
+    if (!starts || !sizes || !coord || !msp || !neighbors || !mult || !nodes_out || !eu || !ev || !ew || !touched || !comp || !lab || !counts || !rows_ws)
+        return PDF_ERR_BAD_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int *rowcnt = static_cast<int *>(rows_ws);
+    float *rowrange = reinterpret_cast<float *>(rowcnt + n_total);
+    rg::k_region_nodes<<<scenes, rg::T, 0, st>>>(starts, sizes, mult, nodes_out, touched, comp, lab, counts);
+    rg::k_region_rows<false><<<scenes * rg::RW, rg::T, 0, st>>>(starts, sizes, coord, msp, neighbors, nsample, mult, nodes_out, rowcnt, rowrange, eu, ev, ew,
+                                                               touched, counts);
+    rg::k_region_scan<<<scenes, rg::T, 0, st>>>(starts, rowcnt, counts);
+    rg::k_region_rows<true><<<scenes * rg::RW, rg::T, 0, st>>>(starts, sizes, coord, msp, neighbors, nsample, mult, nodes_out, rowcnt, rowrange, eu, ev, ew,
+                                                              touched, counts);
     return pdf_launch_status();
 }
 
@@ -435,5 +700,25 @@ extern "C" int pdf_region_tree(int scenes, const int *starts, const int *sizes, 
     if (scenes == 0) return PDF_OK;
     if (!starts || !sizes || !counts || !chosen || !eu || !ev || !ew || !tu || !tv || !tw || !tdev) return PDF_ERR_BAD_ARG;
     rg::k_tree_edges<<<scenes, rg::T, 0, static_cast<hipStream_t>(stream)>>>(starts, sizes, nsample, counts, chosen, eu, ev, ew, tu, tv, tw, tdev);
+    return pdf_launch_status();
+}
+
+// The first tdev[2 s + 1] floats of every scene's slice of x, ascending, into the same slice of out (see k_sort_floats); tmp: N words.
+extern "C" int pdf_sort_floats_dev(int scenes, const int *starts, const int *sizes, const int *tdev, const float *x, float *out, void *tmp,
+                                   void *stream) {
+    if (scenes < 0) return PDF_ERR_BAD_ARG;
+    if (scenes == 0) return PDF_OK;
+    if (!starts || !sizes || !tdev || !x || !out || !tmp) return PDF_ERR_BAD_ARG;
+    rg::k_sort_floats<<<scenes, rg::T, 0, static_cast<hipStream_t>(stream)>>>(starts, sizes, tdev, x, out, static_cast<unsigned *>(tmp));
+    return pdf_launch_status();
+}
+
+// The pseudo mask (N bytes, 0 / 1) from the second labelling (see k_region_mask); cnt: N ints of workspace.
+extern "C" int pdf_region_mask(int scenes, const int *starts, const int *sizes, const int *lab, const unsigned char *touched, const int *counts,
+                               int *cnt, unsigned char *mask, void *stream) {
+    if (scenes < 0) return PDF_ERR_BAD_ARG;
+    if (scenes == 0) return PDF_OK;
+    if (!starts || !sizes || !lab || !touched || !counts || !cnt || !mask) return PDF_ERR_BAD_ARG;
+    rg::k_region_mask<<<scenes, rg::T, 0, static_cast<hipStream_t>(stream)>>>(starts, sizes, lab, touched, counts, cnt, mask);
     return pdf_launch_status();
 }

@@ -155,7 +155,8 @@ class CapturedStep:
         #                      parameters' AccumulateGrad nodes stay bound to it for as long as the captured autograd graph lives)
         self.graph, self.graph2, self.mask_fn = torch.cuda.CUDAGraph(), None, None
         rec = getattr(step, "recognizer", None)
-        if getattr(rec, "pseudo_mask_fn", None) is None:
+        fn = getattr(rec, "pseudo_mask_fn", None)
+        if fn is None or getattr(fn, "capturable", False):   # (the sync-free pseudo-label pass is recorded like any other stage)
             with torch.cuda.graph(self.graph, stream=side):
                 self.out = self._eager()
                 self._backward(self.out)

@@ -227,19 +227,73 @@ class TransitionDown(nn.Module):
         return [p, x, o]
 
 
+def _scene_rows_kernels(x):
+    """The backend's per-scene row kernels (csrc/scene_rows.hip) for float32 device rows, else None (host tensors: the torch composition)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0):
+        return None
+    be = _native.backend_for(x)
+    return be if "scene_sum_rows" in getattr(be, "_fn", {}) else None
+
+
+class _SceneMean(torch.autograd.Function):
+    """``x (N, c)`` -> the mean row of every scene (b, c) (point_transformer_seg.py:152-154: ``x_b.sum(0, True) / cnt``).  One launch with
+    a fixed summation order each way; NOT torch's ``sum(0)``: from 512 rows on that is a multi-workgroup reduction whose semaphore is cleared
+    by a memset node when the step is captured, and replays then return garbage on this stack (csrc/scene_rows.hip)."""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, x, offset, sizes_host):
+        be = _scene_rows_kernels(x)
+        ctx.sizes, ctx.n = [int(v) for v in sizes_host], x.shape[0]
+        if be is None:
+            ctx.offset = None
+            return torch.cat([ch.sum(0, True) / ch.shape[0] for ch in x.split(ctx.sizes, dim=0)], 0)
+        x = x.contiguous()
+        ctx.offset = offset = offset.int().contiguous()
+        out = torch.empty((len(ctx.sizes), x.shape[1]), dtype=x.dtype, device=x.device)
+        be._call("scene_sum_rows", len(ctx.sizes), offset, x.shape[1], x, x.shape[1], 1, out)
+        return out
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, g):
+        if ctx.offset is None:
+            return torch.cat([(g[i:i + 1] / n).expand(n, -1) for i, n in enumerate(ctx.sizes)], 0), None, None
+        g = g.contiguous()
+        out = torch.empty((ctx.n, g.shape[1]), dtype=g.dtype, device=g.device)
+        _native.backend_for(g)._call("scene_repeat_rows", len(ctx.sizes), ctx.offset, ctx.n, g.shape[1], g, 1, out)
+        return out, None, None
+
+
 class _RowsPerScene(torch.autograd.Function):
     """``ctx (b, c)`` repeated over the points of its scene -> (N, c) (point_transformer_seg.py:155-158: ``x_b.repeat(cnt, 1)``).
     torch.repeat_interleave's backward is an index_add_ with float atomics: the per-scene sum of the incoming rows then depends on the
-    arrival order (found by the bit-reproducibility check at 2 x 4,500 points).  Here the backward is a plain per-scene sum."""
+    arrival order (found by the bit-reproducibility check at 2 x 4,500 points).  Here the backward is a plain per-scene sum in a fixed
+    order (csrc/scene_rows.hip; see _SceneMean for why it is not torch's ``sum(0)``)."""
 
     @staticmethod
-    def forward(ctx, rows, sizes_dev, sizes_host, total):
+    @_amp_fwd
+    def forward(ctx, rows, offset, sizes_dev, sizes_host, total):
         ctx.sizes = [int(v) for v in sizes_host]
-        return torch.repeat_interleave(rows, sizes_dev, dim=0, output_size=total)
+        be = _scene_rows_kernels(rows)
+        if be is None:
+            ctx.offset = None
+            return torch.repeat_interleave(rows, sizes_dev, dim=0, output_size=total)
+        rows = rows.contiguous()
+        ctx.offset = offset = offset.int().contiguous()
+        out = torch.empty((total, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+        be._call("scene_repeat_rows", len(ctx.sizes), offset, total, rows.shape[1], rows, 0, out)
+        return out
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g):
-        return torch.cat([ch.sum(0, keepdim=True) for ch in g.split(ctx.sizes, dim=0)], 0), None, None, None
+        if ctx.offset is None:
+            return torch.cat([ch.sum(0, keepdim=True) for ch in g.split(ctx.sizes, dim=0)], 0), None, None, None, None
+        g = g.contiguous()
+        out = torch.empty((len(ctx.sizes), g.shape[1]), dtype=g.dtype, device=g.device)
+        _native.backend_for(g)._call("scene_sum_rows", len(ctx.sizes), ctx.offset, g.shape[1], g, g.shape[1], 0, out)
+        return out, None, None, None, None
 
 
 class TransitionUp(nn.Module):
@@ -264,12 +318,11 @@ class TransitionUp(nn.Module):
         if pxo2 is None:
             p, x, o = pxo1  # head: append the scene-mean context to every point (:148-161)
             sizes = self._scene_sizes(p, o)
-            chunks = x.split(sizes, dim=0)
-            means = torch.cat([ch.sum(0, True) / ch.shape[0] for ch in chunks], 0)  # (b, c)
+            means = _SceneMean.apply(x, o, sizes)  # (b, c)
             ctx = _seq(self.linear2, means)
             tag = tag_of(p)
             sizes_dev = tag[0].sizes(tag[1]) if tag is not None else torch.diff(o.long(), prepend=o.new_zeros(1).long())
-            rep = _RowsPerScene.apply(ctx, sizes_dev, sizes, x.shape[0])
+            rep = _RowsPerScene.apply(ctx, o, sizes_dev, sizes, x.shape[0])
             x = _seq(self.linear1, torch.cat((x, rep), 1))
         else:
             p1, x1, o1 = pxo1

@@ -32,8 +32,9 @@ import torch
 from . import _native
 
 
-def radius_neighbors(coord, offset, radius, max_neighbor):
-    """-> (N, max_neighbor) int64 neighbour ids (global rows, the point itself included), -1 padded."""
+def radius_neighbors(coord, offset, radius, max_neighbor, raw=False):
+    """-> (N, max_neighbor) int64 neighbour ids (global rows, the point itself included), -1 padded.  ``raw``: the backend's int32 table
+    as it is (what ``get_pseudo_mask_static`` reads; saves two passes over 8 N max_neighbor bytes)."""
     be = _native.backend_for(coord)
     off = offset.int().contiguous()
     if hasattr(be, "radius_neighbors_self"):       # HIP: 27 grid cells around every point instead of the whole scene (same results)
@@ -41,7 +42,7 @@ def radius_neighbors(coord, offset, radius, max_neighbor):
     else:
         order = torch.arange(coord.shape[0], dtype=torch.int32, device=coord.device)   # identity permutation: index order
         idx, _ = be.ball_query(int(max_neighbor), float(radius), 0.0, coord.contiguous(), coord.contiguous(), off, off, order=order)
-    return idx.long()
+    return idx if raw else idx.long()
 
 
 def _pair_similarity(node, node_nn, coord, score):
@@ -363,28 +364,43 @@ def pseudo_labeling(coord, logits, neighbors, condition_from="msp", beta=1.5, se
 # it keeps running ahead (rounds 1-4: ~10 host reads per scene, the device idle for the ~7 ms the host needed per 150k-point scene) and
 # the pass can be captured into the step's graph.
 # ------------------------------------------------------------------------------------------------------------------
-class _SeedBuffer:
-    """Pinned host buffers for the seed draws (a pageable host -> device copy would wait for the stream; a captured step re-reads the
-    pinned buffer at every replay: the draw of the replayed step is whatever the host wrote last)."""
-
-    def __init__(self):
-        self.buf = {}
-
-    def get(self, key, n):
-        b = self.buf.get(key)
-        if b is None or b.shape[0] != n:
-            b = self.buf[key] = torch.empty((n,), dtype=torch.int64).pin_memory()
-        return b
+_RANGES = {}   # (device, scene sizes) -> (starts, sizes) int32 device tensors: made once, outside any graph capture
 
 
-_SEEDS = _SeedBuffer()
+def _scene_ranges(dev, starts, sizes):
+    key = (str(dev), tuple(sizes))
+    r = _RANGES.get(key)
+    if r is None:
+        if len(_RANGES) > 64:
+            _RANGES.clear()
+        r = _RANGES[key] = (torch.tensor(starts, dtype=torch.int32, device=dev), torch.tensor(sizes, dtype=torch.int32, device=dev))
+    return r
+
+
+def _draw_seeds(num_seed, hi, generator, dev):
+    """``torch.randint(0, hi, [num_seed])`` of upstream's seed draw (:206) on the device without waiting for it.  Eager: the CPU draw of
+    upstream (global or explicit generator) through a FRESH pinned buffer per call (a pageable host -> device copy would wait for the
+    stream; the pinned allocator recycles a buffer only after its copy ran, so the host may run steps ahead).  While a step is being
+    CAPTURED the draw moves to the device generator (graph-safe Philox offsets): a replayed graph cannot re-read a host buffer the host
+    has meanwhile refilled for a later step."""
+    if torch.cuda.is_current_stream_capturing():
+        if generator is not None:
+            raise RuntimeError("pseudo-label pass: a captured step draws its seeds with the device generator (no explicit CPU generator)")
+        return torch.randint(0, hi, [num_seed], device=dev)
+    dice = torch.empty((num_seed,), dtype=torch.int64, pin_memory=True)
+    dice.copy_(torch.randint(0, hi, [num_seed], generator=generator))
+    return dice.to(dev, non_blocking=True)
 
 
 @torch.no_grad()
 def get_pseudo_mask_static(coord, seg_logits, offset_host, neighbors, condition_from="msp", beta=1.5, seed_from="ml", seed_range=0.15,
                            num_seed=100, slide_window=True, generator=None, max_rounds=4096, info=None):
-    """pointpdf_v1m1_base.py:118-382 for a batch on the device, free of host reads.  ``neighbors``: (N, k) int64 GLOBAL ids, -1 padded
-    (``radius_neighbors``); ``offset_host``: the scenes' end positions as Python ints.  -> bool (N,) on the device.
+    """pointpdf_v1m1_base.py:118-382 for a batch on the device, free of host reads.  ``neighbors``: (N, k) GLOBAL ids, -1 padded: the int32
+    table of ``radius_neighbors(..., raw=True)`` as it is, or the int64 one (converted); ``offset_host``: the scenes' end positions as
+    Python ints.  -> bool (N,) on the device.
+    Torch does the row-wise work on the logits (softmax, row maxima) and draws the seed ranks; every reduction over a scene, the seed
+    lookup, the growth, the region's graph, both labellings, the mixture fit and the component statistics are kernels of
+    csrc/region_grow.hip / csrc/graph_prune.hip, one launch for all scenes wherever the stage allows.
     ``info`` (dict, optional): receives the device tensors with the per-scene round counts / region sizes (diagnostics: reading them syncs)."""
     be = _native.backend_for(coord)
     dev = coord.device
@@ -394,87 +410,62 @@ def get_pseudo_mask_static(coord, seg_logits, offset_host, neighbors, condition_
     sizes = [e - s for s, e in zip(starts, ends)]
     B = len(ends)
     i32 = dict(dtype=torch.int32, device=dev)
-    starts_d = torch.tensor(starts, dtype=torch.int32).to(dev, non_blocking=True) if B > 1 else torch.zeros(1, **i32)
-    sizes_d = torch.tensor(sizes, dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
-    base = torch.repeat_interleave(starts_d.long(), sizes_d.long(), output_size=N) if B > 1 else None
-    nn_local = neighbors if base is None else torch.where(neighbors != -1, neighbors - base[:, None], neighbors)
-    nn_local = nn_local.contiguous()
+    f32 = dict(dtype=torch.float32, device=dev)
+    u8 = dict(dtype=torch.uint8, device=dev)
+    starts_d, sizes_d = _scene_ranges(dev, starts, sizes)
+    nn = neighbors if neighbors.dtype == torch.int32 else neighbors.int()
+    nn = nn.contiguous()
+    coord = coord.contiguous()
     logits = seg_logits.float()
     msp = torch.softmax(logits, dim=-1).max(dim=-1)[0].contiguous()
-    ml_raw = logits.max(dim=-1)[0]
-    score_parts, stop_parts, mult = [], [], torch.zeros(N, **i32)
-    for b, (s0, e) in enumerate(zip(starts, ends)):
-        ml_b = ml_raw[s0:e]
-        ml_b = (ml_b - ml_b.min()) / (ml_b.max() - ml_b.min() + 1e-6)
-        msp_b = msp[s0:e]
-        score_b = msp_b if condition_from == "msp" else ml_b
-        src_b = msp_b if seed_from == "msp" else ml_b
-        score_parts.append(score_b)
-        stop_parts.append((torch.mean(score_b) - beta * torch.std(score_b)).reshape(1))
-        dice = _SEEDS.get((b, num_seed), num_seed)
-        dice.copy_(torch.randint(0, int(seed_range * (e - s0)), [num_seed], generator=generator))
-        seeds = torch.sort(src_b, dim=-1)[1][dice.to(dev, non_blocking=True)]
-        mult[s0:e].index_add_(0, seeds, torch.ones(num_seed, **i32))
-    score = (torch.cat(score_parts) if B > 1 else score_parts[0]).contiguous()
-    stop = torch.cat(stop_parts).float().contiguous()
-    cand = torch.empty(N, dtype=torch.uint8, device=dev)
-    simbuf = torch.empty(N, dtype=torch.float32, device=dev)
+    ml_raw = logits.max(dim=-1)[0].contiguous()
+    ml = torch.empty(N, **f32)
+    stop = torch.empty(B, **f32)
+    mult = torch.empty(N, **i32)
+    be._call("region_stats", B, starts_d, sizes_d, msp, ml_raw, int(condition_from != "msp"), float(beta), ml, stop, mult)
+    score = msp if condition_from == "msp" else ml
+    dice = torch.stack([_draw_seeds(num_seed, int(seed_range * n), generator, dev) for n in sizes]).contiguous()
+    be._call("region_seeds", B, starts_d, sizes_d, msp if seed_from == "msp" else ml, dice, int(num_seed), mult)
+    cand = torch.empty(N, **u8)
+    simbuf = torch.empty(N, **f32)
     ginfo = torch.empty((B, 4), **i32)
-    be._call("region_grow", B, starts_d, sizes_d, coord, score, nn_local, ns, stop, int(bool(slide_window)), int(max_rounds), mult, cand, simbuf, ginfo)
+    be._call("region_grow", B, starts_d, sizes_d, coord, score, nn, ns, stop, int(bool(slide_window)), int(max_rounds), mult, cand, simbuf, ginfo)
     nodes = torch.empty(N, dtype=torch.int64, device=dev)
     eu = torch.empty(N * ns, dtype=torch.int64, device=dev)
     ev = torch.empty(N * ns, dtype=torch.int64, device=dev)
-    ew = torch.empty(N * ns, dtype=torch.float32, device=dev)
-    touched = torch.empty(N, dtype=torch.uint8, device=dev)
-    counts = torch.empty((B, 4), **i32)
-    be._call("region_edges", B, starts_d, sizes_d, coord, msp, nn_local, ns, mult, nodes, eu, ev, ew, touched, counts)
-    chosen = torch.empty(N * ns, dtype=torch.uint8, device=dev)
+    ew = torch.empty(N * ns, **f32)
+    touched = torch.empty(N, **u8)
     comp = torch.empty(N, **i32)
     lab = torch.empty(N, **i32)
+    counts = torch.empty((B, 4), **i32)
+    rows_ws = torch.empty(3 * N, **i32)
+    be._call("region_edges", B, starts_d, sizes_d, coord, msp, nn, ns, mult, nodes, eu, ev, ew, touched, comp, lab, counts, rows_ws, N)
+    chosen = torch.empty(N * ns, **u8)
+    ws_bytes = max(int(be.lib.pdf_graph_forest_workspace_bytes(n, n * ns, n)) for n in sizes)
+    ws = torch.empty((ws_bytes // 8 + 1,), dtype=torch.int64, device=dev)   # (the scenes' forests run one after the other: one workspace)
     for b, (s0, e) in enumerate(zip(starts, ends)):      # the spanning forest of every scene (one workgroup each)
         n = e - s0
-        comp[s0:e] = torch.arange(n, **i32)
-        lab[s0:e] = comp[s0:e]
-        nbytes = int(be.lib.pdf_graph_forest_workspace_bytes(n, n * ns, n))
-        ws = torch.empty((nbytes // 8 + 1,), dtype=torch.int64, device=dev)
         be._call("graph_forest_dev", n, n * ns, eu[s0 * ns:e * ns], ev[s0 * ns:e * ns], ew[s0 * ns:e * ns], None, nodes[s0:e], n, counts[b, 0:2],
                  comp[s0:e], chosen[s0 * ns:e * ns], ws, ws.numel() * 8)
     tu = torch.empty(N, dtype=torch.int64, device=dev)
     tv = torch.empty(N, dtype=torch.int64, device=dev)
-    tw = torch.empty(N, dtype=torch.float32, device=dev)
+    tw = torch.empty(N, **f32)
     tdev = torch.empty((B, 2), **i32)
     be._call("region_tree", B, starts_d, sizes_d, ns, counts, chosen, eu, ev, ew, tu, tv, tw, tdev)
-    mask = torch.empty(N, dtype=torch.bool, device=dev)
-    for b, (s0, e) in enumerate(zip(starts, ends)):
+    xs = torch.empty(N, **f32)
+    be._call("sort_floats_dev", B, starts_d, sizes_d, tdev, tw, xs, simbuf.view(torch.int32))
+    resp = torch.empty((2 * N,), dtype=torch.float64, device=dev)
+    fit = torch.empty((B, 8), dtype=torch.float64, device=dev)
+    weak = torch.empty(N, **u8)
+    be._call("gmm2_weak_dev", B, starts_d, sizes_d, tdev, xs, tw, resp, fit, weak, 200, 1e-6, 1e-6)
+    for b, (s0, e) in enumerate(zip(starts, ends)):      # the components the tree falls into without its weak edges
         n = e - s0
-        xs = torch.sort(tw[s0:e])[0]
-        resp = torch.empty((2 * n,), dtype=torch.float64, device=dev)
-        fit = torch.empty((8,), dtype=torch.float64, device=dev)
-        be._call("gmm2_1d_dev", n, xs, tdev[b, 1:2], resp, fit, 200, 1e-6, 1e-6)
-        top = (fit[1] > fit[0]).long()                                     # np.argmax(means)
-        lower = fit[top] - 2.0 * fit[2 + top]                              # the "std" of upstream's z-score filter is the covariance, as there
-        weak = (tw[s0:e].double() < lower).to(torch.uint8)
-        nbytes = int(be.lib.pdf_graph_forest_workspace_bytes(n, n, n))
-        ws = torch.empty((nbytes // 8 + 1,), dtype=torch.int64, device=dev)
-        be._call("graph_forest_dev", n, n, tu[s0:e], tv[s0:e], None, weak, nodes[s0:e], n, tdev[b], lab[s0:e], None, ws, ws.numel() * 8)
-        lab_b = lab[s0:e].long()
-        # touched = unique(cat([node, node_nn]))[1:]: the first entry is the -1 padding -- or, when no row of the region is padded, the
-        # smallest id touched (dropped all the same upstream)
-        t_b = touched[s0:e].clone()
-        first = counts[b, 3].clamp(max=n - 1).long().reshape(1)
-        t_b.index_put_((first,), t_b[first] * (counts[b, 2] != 0).to(torch.uint8))
-        cnt = torch.zeros(n, dtype=torch.int64, device=dev).index_add_(0, lab_b, t_b.long())
-        present = cnt > 0
-        k = present.sum().double()
-        c = cnt.double()
-        mean = c.sum() / k
-        std = torch.sqrt((torch.where(present, (c - mean) ** 2, torch.zeros((), dtype=torch.float64, device=dev))).sum() / k)
-        big = present & ((c - mean) / std > 2.0)                           # z_score_mask_np(area="right", score=2.0), population std
-        mask[s0:e] = big[lab_b]
+        be._call("graph_forest_dev", n, n, tu[s0:e], tv[s0:e], None, weak[s0:e], nodes[s0:e], n, tdev[b], lab[s0:e], None, ws, ws.numel() * 8)
+    mask = torch.empty(N, **u8)
+    be._call("region_mask", B, starts_d, sizes_d, lab, touched, counts, comp, mask)   # (comp: free again -- the counts' workspace)
     if info is not None:
-        info.update(grow=ginfo, counts=counts, tree=tdev)
-    return mask
-
+        info.update(grow=ginfo, counts=counts, tree=tdev, stop=stop, fit=fit)
+    return mask.view(torch.bool)
 
 
 @torch.no_grad()
@@ -484,10 +475,11 @@ def get_pseudo_mask(coord, seg_logits, offset, radius=0.1, max_neighbor=64, neig
         # device tensors: the scenes one after the other (the HIP pruning stage leaves ~3 ms of short launches per scene: worker threads
         # only fight over the interpreter lock, 46.4 vs 42.7 ms per step with 4 vs 1); host tensors: upstream's 4 workers (scipy / sklearn)
         workers = int(os.environ.get("PDFOPS_PL_WORKERS", "1" if coord.is_cuda else "4"))
-    if neighbors is None:
-        neighbors = radius_neighbors(coord, offset, radius, max_neighbor)
     static = coord.is_cuda and os.environ.get("PDFOPS_PL_STATIC", "1") != "0" and kw.get("prune", "auto") in ("auto", "hip")
-    if static and (offset_host is not None or torch.cuda.is_current_stream_capturing() is False):
+    static = static and (offset_host is not None or torch.cuda.is_current_stream_capturing() is False)
+    if neighbors is None:
+        neighbors = radius_neighbors(coord, offset, radius, max_neighbor, raw=static)
+    if static:
         # the sync-free form (get_pseudo_mask_static): scene ends from the host copy when the caller has one (one read of `offset` else)
         ends = offset_host if offset_host is not None else [int(v) for v in offset.tolist()]
         kw2 = {k: v for k, v in kw.items() if k != "prune"}
@@ -527,6 +519,8 @@ def make_pseudo_mask_fn(radius=0.1, max_neighbor=64, **kw):
         return get_pseudo_mask(coord, seg_logits.detach(), offset, radius=radius, max_neighbor=max_neighbor, offset_host=offset_host, **kw)
 
     fn.accepts_offset_host = True   # (PointPdfV1 hands the host copy of the scene ends over when the batch carries one: no read of `offset`)
+    # device tensors take the sync-free form: the pass can be recorded into the step's graph (engine.CapturedStep captures ONE graph then)
+    fn.capturable = os.environ.get("PDFOPS_PL_STATIC", "1") != "0" and kw.get("prune", "auto") in ("auto", "hip") and kw.get("generator") is None
 
     if os.environ.get("PDFOPS_PL_TRACE"):   # diagnostics: host wall time of the wait for the forward and of the pass, per call
         import atexit

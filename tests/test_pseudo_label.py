@@ -341,3 +341,81 @@ def test_static_pass_equals_the_host_driven_pass(gp, monkeypatch):
         nn1 = pl.radius_neighbors(c.cuda(), torch.tensor([n], dtype=torch.int32, device="cuda"), 0.1, 64)
         one.append(pl.get_pseudo_mask_static(c.cuda(), l.cuda(), [n], nn1, generator=gen, **PSEUDO_KW))
     assert torch.equal(both, torch.cat(one))
+
+
+@pytest.mark.gpu
+def test_region_kernels_equal_their_torch_forms():
+    """The stages of get_pseudo_mask_static that used to be torch ops, kernel by kernel (csrc/region_grow.hip): scene statistics, seed
+    lookup by rank, the ascending sort of the tree weights, the component statistics behind the mask."""
+    from pointcloudpdf_amd import _native
+
+    be = _native.hip_backend()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(11)
+    sizes = [7001, 1, 12345]
+    ends = np.cumsum(sizes).tolist()
+    starts = [0] + ends[:-1]
+    N, B = ends[-1], len(sizes)
+    i32 = dict(dtype=torch.int32, device=dev)
+    starts_d, sizes_d = torch.tensor(starts, **i32), torch.tensor(sizes, **i32)
+    msp = torch.rand(N, generator=g).to(dev)
+    ml_raw = (3 * torch.randn(N, generator=g)).to(dev)
+    for score_is_ml in (0, 1):
+        ml, stop, mult = torch.empty(N, device=dev), torch.empty(B, device=dev), torch.full((N,), 7, **i32)
+        be._call("region_stats", B, starts_d, sizes_d, msp, ml_raw, score_is_ml, 1.5, ml, stop, mult)
+        assert int(mult.abs().sum()) == 0
+        for s0, e, b in zip(starts, ends, range(B)):
+            x = ml_raw[s0:e]
+            ref = (x - x.min()) / (x.max() - x.min() + 1e-6)
+            assert torch.allclose(ml[s0:e], ref, rtol=0, atol=2e-7)
+            sc = ref if score_is_ml else msp[s0:e]
+            if e - s0 > 1:
+                want = float(sc.double().mean() - 1.5 * sc.double().std())
+                assert abs(float(stop[b]) - want) <= 1e-6, (b, float(stop[b]), want)
+    # seeds: rank -> point (distinct values: the stable order is the only order), repeats add up
+    src = torch.rand(N, generator=g).to(dev)
+    S = 50
+    dice = torch.stack([torch.randint(0, max(int(0.15 * n), 1), (S,), generator=g) for n in sizes]).to(dev)
+    dice[0, :5] = dice[0, 5]                                   # repeats
+    mult = torch.zeros(N, **i32)
+    be._call("region_seeds", B, starts_d, sizes_d, src, dice.contiguous(), S, mult)
+    want = torch.zeros(N, dtype=torch.int64, device=dev)
+    for b, (s0, e) in enumerate(zip(starts, ends)):
+        order = torch.sort(src[s0:e])[1]
+        want[s0:e].index_add_(0, order[dice[b]], torch.ones(S, dtype=torch.int64, device=dev))
+    assert torch.equal(mult.long(), want) and int(mult.sum()) == B * S
+    # ties: equal values are taken in id order
+    tie = torch.zeros(64, device=dev)
+    mult = torch.zeros(64, **i32)
+    be._call("region_seeds", 1, torch.zeros(1, **i32), torch.tensor([64], **i32), tie, torch.tensor([[0, 5, 5, 63]], device=dev), 4, mult)
+    assert mult.nonzero().flatten().tolist() == [0, 5, 63] and int(mult[5]) == 2
+    # sort of the first m values of every scene's slice
+    x = torch.randn(N, generator=g).to(dev)
+    x[3] = float("inf"); x[10] = -0.0; x[11] = 0.0; x[12] = -1e30
+    m = [5000, 1, 0]
+    tdev = torch.tensor([[0, m[0]], [0, m[1]], [0, m[2]]], **i32)
+    out, tmp = torch.full((N,), -7.0, device=dev), torch.empty(N, **i32)
+    be._call("sort_floats_dev", B, starts_d, sizes_d, tdev, x, out, tmp)
+    for s0, k in zip(starts, m):
+        assert torch.equal(out[s0:s0 + k], torch.sort(x[s0:s0 + k])[0])
+    # component statistics -> mask
+    lab = torch.empty(N, **i32)
+    touched = (torch.rand(N, generator=g) < 0.4).to(torch.uint8).to(dev)
+    counts = torch.zeros((B, 4), **i32)
+    for b, (s0, n) in enumerate(zip(starts, sizes)):
+        lab[s0:s0 + n] = torch.randint(0, max(n // 300, 1), (n,), generator=g).int().to(dev) ** 2 % n   # uneven component sizes
+        first = int(touched[s0:s0 + n].nonzero()[0]) if int(touched[s0:s0 + n].sum()) else 0x7fffffff
+        counts[b, 2], counts[b, 3] = b % 2, first
+    cnt, mask = torch.empty(N, **i32), torch.empty(N, dtype=torch.uint8, device=dev)
+    be._call("region_mask", B, starts_d, sizes_d, lab, touched, counts, cnt, mask)
+    for b, (s0, n) in enumerate(zip(starts, sizes)):
+        t_b = touched[s0:s0 + n].clone().long()
+        if not b % 2 and int(counts[b, 3]) < n:
+            t_b[int(counts[b, 3])] = 0
+        c = torch.zeros(n, dtype=torch.int64, device=dev).index_add_(0, lab[s0:s0 + n].long(), t_b).double()
+        present = c > 0
+        k = present.sum().double()
+        mean = c.sum() / k
+        std = torch.sqrt(torch.where(present, (c - mean) ** 2, torch.zeros((), dtype=torch.float64, device=dev)).sum() / k)
+        big = present & ((c - mean) / std > 2.0)
+        assert torch.equal(mask[s0:s0 + n].bool(), big[lab[s0:s0 + n].long()]), b
