@@ -550,6 +550,12 @@ int pdf_graph_forest_dev(long n, int E, const long long *u, const long long *v, 
                          const long long *nodes, int n_nodes, const int *dev, int *comp, unsigned char *chosen, void *workspace,
                          long workspace_bytes, void *stream);
 int pdf_gmm2_1d_dev(int m_cap, const float *sorted_x, const int *m_dev, double *resp, double *out, int iters, double tol, double reg, void *stream);
+/* pdf_graph_forest_dev for the scenes of a batch in ONE launch (grid = scenes).  starts / sizes: HOST arrays; u, v, w, active, chosen
+ * (N * stride) / nodes, comp (N): the batch's arrays, scene s at starts[s] (* stride); dev + s * dev_stride = the scene's [nodes, entries];
+ * workspace: the scenes' pdf_graph_forest_workspace_bytes(size, size * stride, size), each rounded up to 8 bytes, back to back. */
+int pdf_graph_forest_batch_dev(int scenes, const int *starts, const int *sizes, int stride, const long long *u, const long long *v,
+                               const float *w, const unsigned char *active, const long long *nodes, const int *dev, int dev_stride,
+                               int *comp, unsigned char *chosen, void *workspace, long workspace_bytes, void *stream);
 int pdf_sort_floats_dev(int scenes, const int *starts, const int *sizes, const int *tdev, const float *x, float *out, void *tmp, void *stream);
 int pdf_gmm2_weak_dev(int scenes, const int *starts, const int *sizes, const int *tdev, const float *sorted_x, const float *tw, double *resp,
                       double *fit, unsigned char *weak, int iters, double tol, double reg, void *stream);

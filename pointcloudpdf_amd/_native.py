@@ -83,6 +83,7 @@ _HIP_ONLY_PROTOS = {
     "region_tree": "ippipppppppp",
     "graph_forest_dev": "lipppppippppl",
     "gmm2_1d_dev": "ippppidd",
+    "graph_forest_batch_dev": "ippippppppipppl",
     "wa_segment_rows": "iiiipppppplfpplf",
     "wa_table_grad": "iiiippppplfpp",
     "wa_grad_attn": "iiiiiplppplppp",

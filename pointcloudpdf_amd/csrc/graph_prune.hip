@@ -50,11 +50,11 @@ constexpr int LDS_NODES = 12288;   // 12 B per slot: 144 KB of the CU's 160 KB
 // the CAPACITIES of the arrays.  `when`: 0 = always, 1 = only when the list fits the LDS form, 2 = only when it does not (the host cannot
 // know, so it launches both forms and one of them returns at once).
 template <bool LDS>
-__global__ __launch_bounds__(T) void k_forest(long long n, int E, const long long *__restrict__ u, const long long *__restrict__ v,
-                                              const float *__restrict__ w, const unsigned char *__restrict__ active,
-                                              const long long *__restrict__ nodes, int n_nodes, int *comp_out, int *slot, int *su, int *sv,
-                                              u64 *gbest, int *gcomp, int *parent, int *rootof, unsigned char *chosen,
-                                              const int *__restrict__ dev = nullptr, int when = 0) {
+__device__ __forceinline__ void forest_body(long long n, int E, const long long *__restrict__ u, const long long *__restrict__ v,
+                                            const float *__restrict__ w, const unsigned char *__restrict__ active,
+                                            const long long *__restrict__ nodes, int n_nodes, int *comp_out, int *slot, int *su, int *sv,
+                                            u64 *gbest, int *gcomp, int *parent, int *rootof, unsigned char *chosen,
+                                            const int *__restrict__ dev, int when) {
     extern __shared__ u64 lds_dyn[];
     __shared__ int live;
     if (dev) {
@@ -186,8 +186,45 @@ __global__ __launch_bounds__(T) void k_forest(long long n, int E, const long lon
     }
 }
 
+template <bool LDS>
+__global__ __launch_bounds__(T) void k_forest(long long n, int E, const long long *__restrict__ u, const long long *__restrict__ v,
+                                              const float *__restrict__ w, const unsigned char *__restrict__ active,
+                                              const long long *__restrict__ nodes, int n_nodes, int *comp_out, int *slot, int *su, int *sv,
+                                              u64 *gbest, int *gcomp, int *parent, int *rootof, unsigned char *chosen,
+                                              const int *__restrict__ dev = nullptr, int when = 0) {
+    forest_body<LDS>(n, E, u, v, w, active, nodes, n_nodes, comp_out, slot, su, sv, gbest, gcomp, parent, rootof, chosen, dev, when);
+}
+
+// The forests of several scenes in ONE launch (grid = scenes; round 5: one launch per scene ran the scenes one after the other, 0.2 ms each).
+// Scene s: points [start[s], start[s] + size[s]); its entry arrays hold size * stride entries at start * stride; its sizes are
+// dev[s * dev_stride + 0 / 1]; workspace: the scenes' pdf_graph_forest_workspace_bytes(size, size * stride, size), 8-byte aligned, back to back.
+constexpr int FOREST_BATCH = 16;
+struct ForestBatch {
+    int start[FOREST_BATCH], size[FOREST_BATCH];
+    long ws_off[FOREST_BATCH];   // bytes
+    int stride, dev_stride;
+    const long long *u, *v, *nodes;
+    const float *w;
+    const unsigned char *active;
+    const int *dev;
+    int *comp;
+    unsigned char *chosen, *ws;
+};
+template <bool LDS>
+__global__ __launch_bounds__(T) void k_forest_batch(const ForestBatch b, int when) {
+    const int s = blockIdx.x;
+    const long s0 = b.start[s], e0 = s0 * b.stride;
+    const int n = b.size[s], E = n * b.stride;
+    u64 *best = reinterpret_cast<u64 *>(b.ws + b.ws_off[s]);
+    int *slot = reinterpret_cast<int *>(best + n);
+    int *su = slot + n, *sv = su + E, *gcomp = sv + E, *parent = gcomp + n, *rootof = parent + n;
+    forest_body<LDS>(n, E, b.u + e0, b.v + e0, b.w ? b.w + e0 : nullptr, b.active ? b.active + e0 : nullptr, b.nodes + s0, n, b.comp + s0, slot, su,
+                     sv, best, gcomp, parent, rootof, b.chosen ? b.chosen + e0 : nullptr, b.dev + (long)s * b.dev_stride, when);
+}
+
 // ---- two-component 1-D Gaussian mixture -----------------------------------------------------------------------------------------
 constexpr int TG = 256;
+constexpr int GMM_R = 16;   // values per thread the mixture fit keeps in registers (m <= GMM_R * TG: the register form)
 
 template <int K>
 __device__ inline void block_sum(double (&val)[K], double *lds) {   // -> every thread holds the sums (fixed order: reproducible)
@@ -240,69 +277,150 @@ __device__ __forceinline__ Fit gmm2_fit(int m, const float *__restrict__ xs, dou
     }
     const double q1 = quantile_sorted(xs, m, 0.25), q3 = quantile_sorted(xs, m, 0.75);
     double mu0 = q3 > q1 ? q1 : (double)xs[0], mu1 = q3 > q1 ? q3 : (double)xs[m - 1];
-    for (int it = 0; it < 10; ++it) {   // 2-means from the quartiles
-        double s[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int i = t; i < m; i += TG) {
-            const double x = (double)xs[i];
-            const int a = fabs(x - mu1) < fabs(x - mu0);   // (argmin: the first on a tie)
-            s[a] += 1.0;
-            s[2 + a] += x;
-        }
-        block_sum<4>(s, lds);
-        if (s[0] == 0.0 || s[1] == 0.0) break;
-        mu0 = s[2] / s[0];
-        mu1 = s[3] / s[1];
-    }
-    for (int i = t; i < m; i += TG) {
-        const double x = (double)xs[i];
-        const int a = fabs(x - mu1) < fabs(x - mu0);
-        resp[2 * i] = a ? 0.0 : 1.0;
-        resp[2 * i + 1] = a ? 1.0 : 0.0;
-    }
     double var0 = reg, var1 = reg, pi0 = 0.5, pi1 = 0.5, prev = -INFINITY, ll = 0.0;
     int it = 0;
-    for (; it < iters; ++it) {
-        double s[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int i = t; i < m; i += TG) {
-            const double x = (double)xs[i], r0 = resp[2 * i], r1 = resp[2 * i + 1];
-            s[0] += r0;
-            s[1] += r1;
-            s[2] += r0 * x;
-            s[3] += r1 * x;
+    if (m <= GMM_R * TG) {
+        // (round 5) up to GMM_R values per thread: the values and their responsibilities stay in registers for all iterations (the pass's
+        // trees have ~2,400 edges).  Thread t owns i = t, t + TG, ... as the loops of the general form below do: same sums, same order,
+        // same bits -- without the two L2 round trips per iteration (523 -> ~200 us per call on the pass's trees).
+        float xr[GMM_R];
+        double r0[GMM_R], r1[GMM_R];
+#pragma unroll
+        for (int k = 0; k < GMM_R; ++k) xr[k] = t + k * TG < m ? xs[t + k * TG] : 0.f;
+        for (int it2 = 0; it2 < 10; ++it2) {   // 2-means from the quartiles
+            double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < GMM_R; ++k)
+                if (t + k * TG < m) {
+                    const double x = (double)xr[k];
+                    const int a = fabs(x - mu1) < fabs(x - mu0);
+                    s[a] += 1.0;
+                    s[2 + a] += x;
+                }
+            block_sum<4>(s, lds);
+            if (s[0] == 0.0 || s[1] == 0.0) break;
+            mu0 = s[2] / s[0];
+            mu1 = s[3] / s[1];
         }
-        block_sum<4>(s, lds);
-        const double n0 = s[0] + 1e-300, n1 = s[1] + 1e-300;
-        pi0 = n0 / (double)m;
-        pi1 = n1 / (double)m;
-        mu0 = s[2] / n0;
-        mu1 = s[3] / n1;
-        double q[2] = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < GMM_R; ++k) {
+            const double x = (double)xr[k];
+            const int a = fabs(x - mu1) < fabs(x - mu0);
+            r0[k] = a ? 0.0 : 1.0;
+            r1[k] = a ? 1.0 : 0.0;
+        }
+        for (; it < iters; ++it) {
+            double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < GMM_R; ++k)
+                if (t + k * TG < m) {
+                    const double x = (double)xr[k];
+                    s[0] += r0[k];
+                    s[1] += r1[k];
+                    s[2] += r0[k] * x;
+                    s[3] += r1[k] * x;
+                }
+            block_sum<4>(s, lds);
+            const double n0 = s[0] + 1e-300, n1 = s[1] + 1e-300;
+            pi0 = n0 / (double)m;
+            pi1 = n1 / (double)m;
+            mu0 = s[2] / n0;
+            mu1 = s[3] / n1;
+            double q[2] = {0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < GMM_R; ++k)
+                if (t + k * TG < m) {
+                    const double x = (double)xr[k];
+                    q[0] += r0[k] * (x - mu0) * (x - mu0);
+                    q[1] += r1[k] * (x - mu1) * (x - mu1);
+                }
+            block_sum<2>(q, lds);
+            var0 = q[0] / n0 + reg;
+            var1 = q[1] / n1 + reg;
+            const double c0 = -0.5 * log(2.0 * M_PI * var0) + log(pi0), c1 = -0.5 * log(2.0 * M_PI * var1) + log(pi1);
+            double l[1] = {0.0};
+#pragma unroll
+            for (int k = 0; k < GMM_R; ++k)
+                if (t + k * TG < m) {
+                    const double x = (double)xr[k];
+                    const double p0 = c0 - 0.5 * (x - mu0) * (x - mu0) / var0, p1 = c1 - 0.5 * (x - mu1) * (x - mu1) / var1;
+                    const double mx = fmax(p0, p1);
+                    const double lse = mx + log(exp(p0 - mx) + exp(p1 - mx));
+                    r0[k] = exp(p0 - lse);
+                    r1[k] = exp(p1 - lse);
+                    l[0] += lse;
+                }
+            block_sum<1>(l, lds);
+            ll = l[0] / (double)m;
+            if (fabs(ll - prev) < tol) {
+                ++it;
+                break;
+            }
+            prev = ll;
+        }
+    } else {
+        for (int it2 = 0; it2 < 10; ++it2) {   // 2-means from the quartiles
+            double s[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int i = t; i < m; i += TG) {
+                const double x = (double)xs[i];
+                const int a = fabs(x - mu1) < fabs(x - mu0);   // (argmin: the first on a tie)
+                s[a] += 1.0;
+                s[2 + a] += x;
+            }
+            block_sum<4>(s, lds);
+            if (s[0] == 0.0 || s[1] == 0.0) break;
+            mu0 = s[2] / s[0];
+            mu1 = s[3] / s[1];
+        }
         for (int i = t; i < m; i += TG) {
             const double x = (double)xs[i];
-            q[0] += resp[2 * i] * (x - mu0) * (x - mu0);
-            q[1] += resp[2 * i + 1] * (x - mu1) * (x - mu1);
+            const int a = fabs(x - mu1) < fabs(x - mu0);
+            resp[2 * i] = a ? 0.0 : 1.0;
+            resp[2 * i + 1] = a ? 1.0 : 0.0;
         }
-        block_sum<2>(q, lds);
-        var0 = q[0] / n0 + reg;
-        var1 = q[1] / n1 + reg;
-        const double c0 = -0.5 * log(2.0 * M_PI * var0) + log(pi0), c1 = -0.5 * log(2.0 * M_PI * var1) + log(pi1);
-        double l[1] = {0.0};
-        for (int i = t; i < m; i += TG) {
-            const double x = (double)xs[i];
-            const double p0 = c0 - 0.5 * (x - mu0) * (x - mu0) / var0, p1 = c1 - 0.5 * (x - mu1) * (x - mu1) / var1;
-            const double mx = fmax(p0, p1);
-            const double lse = mx + log(exp(p0 - mx) + exp(p1 - mx));
-            resp[2 * i] = exp(p0 - lse);
-            resp[2 * i + 1] = exp(p1 - lse);
-            l[0] += lse;
+        for (; it < iters; ++it) {
+            double s[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int i = t; i < m; i += TG) {
+                const double x = (double)xs[i], r0 = resp[2 * i], r1 = resp[2 * i + 1];
+                s[0] += r0;
+                s[1] += r1;
+                s[2] += r0 * x;
+                s[3] += r1 * x;
+            }
+            block_sum<4>(s, lds);
+            const double n0 = s[0] + 1e-300, n1 = s[1] + 1e-300;
+            pi0 = n0 / (double)m;
+            pi1 = n1 / (double)m;
+            mu0 = s[2] / n0;
+            mu1 = s[3] / n1;
+            double q[2] = {0.0, 0.0};
+            for (int i = t; i < m; i += TG) {
+                const double x = (double)xs[i];
+                q[0] += resp[2 * i] * (x - mu0) * (x - mu0);
+                q[1] += resp[2 * i + 1] * (x - mu1) * (x - mu1);
+            }
+            block_sum<2>(q, lds);
+            var0 = q[0] / n0 + reg;
+            var1 = q[1] / n1 + reg;
+            const double c0 = -0.5 * log(2.0 * M_PI * var0) + log(pi0), c1 = -0.5 * log(2.0 * M_PI * var1) + log(pi1);
+            double l[1] = {0.0};
+            for (int i = t; i < m; i += TG) {
+                const double x = (double)xs[i];
+                const double p0 = c0 - 0.5 * (x - mu0) * (x - mu0) / var0, p1 = c1 - 0.5 * (x - mu1) * (x - mu1) / var1;
+                const double mx = fmax(p0, p1);
+                const double lse = mx + log(exp(p0 - mx) + exp(p1 - mx));
+                resp[2 * i] = exp(p0 - lse);
+                resp[2 * i + 1] = exp(p1 - lse);
+                l[0] += lse;
+            }
+            block_sum<1>(l, lds);
+            ll = l[0] / (double)m;
+            if (fabs(ll - prev) < tol) {
+                ++it;
+                break;
+            }
+            prev = ll;
         }
-        block_sum<1>(l, lds);
-        ll = l[0] / (double)m;
-        if (fabs(ll - prev) < tol) {
-            ++it;
-            break;
-        }
-        prev = ll;
     }
     if (t == 0) {
         out[0] = mu0;
@@ -434,5 +552,45 @@ extern "C" int pdf_gmm2_weak_dev(int scenes, const int *starts, const int *sizes
     if (scenes == 0) return PDF_OK;
     if (!starts || !sizes || !tdev || !sorted_x || !tw || !resp || !fit || !weak) return PDF_ERR_BAD_ARG;
     gp::k_gmm2_weak<<<scenes, gp::TG, 0, static_cast<hipStream_t>(stream)>>>(starts, sizes, tdev, sorted_x, tw, resp, fit, weak, iters, tol, reg);
+    return pdf_launch_status();
+}
+
+// pdf_graph_forest_dev for the scenes of a batch in one launch per form (see k_forest_batch).  starts / sizes: HOST arrays (scenes ints);
+// entry arrays u, v, w, active, chosen (N * stride) and nodes, comp (N) are the batch's, scene s at starts[s] (* stride); dev: the scenes'
+// [nodes, entries] pairs dev_stride ints apart; workspace: sum over the scenes of pdf_graph_forest_workspace_bytes(size, size * stride, size)
+// rounded up to 8 bytes each.
+extern "C" int pdf_graph_forest_batch_dev(int scenes, const int *starts, const int *sizes, int stride, const long long *u, const long long *v,
+                                          const float *w, const unsigned char *active, const long long *nodes, const int *dev, int dev_stride,
+                                          int *comp, unsigned char *chosen, void *workspace, long workspace_bytes, void *stream) {
+    if (scenes < 0 || stride < 1 || dev_stride < 2) return PDF_ERR_BAD_ARG;
+    if (scenes == 0) return PDF_OK;
+    if (!starts || !sizes || !u || !v || !nodes || !dev || !comp || !workspace || (reinterpret_cast<uintptr_t>(workspace) & 7)) return PDF_ERR_BAD_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    static const bool lds_form = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(&gp::k_forest_batch<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(gp::LDS_NODES * (sizeof(gp::u64) + sizeof(int)))) == hipSuccess;
+    }();
+    long off = 0;
+    for (int at = 0; at < scenes; at += gp::FOREST_BATCH) {
+        gp::ForestBatch b;
+        const int nb = std::min(scenes - at, gp::FOREST_BATCH);
+        int nmax = 0;
+        for (int i = 0; i < nb; ++i) {
+            if (sizes[at + i] < 0 || starts[at + i] < 0) return PDF_ERR_BAD_ARG;
+            b.start[i] = starts[at + i]; b.size[i] = sizes[at + i]; b.ws_off[i] = off;
+            off += (pdf_graph_forest_workspace_bytes(sizes[at + i], (long)sizes[at + i] * stride, sizes[at + i]) + 7) & ~7L;
+            nmax = std::max(nmax, sizes[at + i]);
+        }
+        if (off > workspace_bytes) return PDF_ERR_BAD_ARG;
+        b.stride = stride; b.dev_stride = dev_stride; b.u = u; b.v = v; b.nodes = nodes; b.w = w; b.active = active;
+        b.dev = dev + (long)at * dev_stride; b.comp = comp; b.chosen = chosen; b.ws = static_cast<unsigned char *>(workspace);
+        if (lds_form) {
+            const size_t lds = (size_t)std::min(nmax, gp::LDS_NODES) * (sizeof(gp::u64) + sizeof(int));
+            gp::k_forest_batch<true><<<nb, gp::T, lds, s>>>(b, 1);
+            if (nmax > gp::LDS_NODES) gp::k_forest_batch<false><<<nb, gp::T, 0, s>>>(b, 2);
+        } else {
+            gp::k_forest_batch<false><<<nb, gp::T, 0, s>>>(b, 0);
+        }
+    }
     return pdf_launch_status();
 }

@@ -87,6 +87,7 @@ __device__ __forceinline__ unsigned radix_select(int n, long long k, W wt, Kf ke
         const int shift = 24 - 8 * pass;
         for (int b = threadIdx.x; b < 256; b += T) hist[b] = 0;
         __syncthreads();
+#pragma unroll 4
         for (int i = threadIdx.x; i < n; i += T) {
             const int w = wt(i);
             if (w > 0) {
@@ -147,6 +148,7 @@ __global__ __launch_bounds__(T) void k_grow(const int *__restrict__ starts, cons
         // ---- the region list: length (with repeats), mean score, centroid
         double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
         long long dcount = 0;
+#pragma unroll 4
         for (int i = t; i < n; i += T) {
             const int m = mult[i];
             if (m > 0) {
@@ -164,8 +166,10 @@ __global__ __launch_bounds__(T) void k_grow(const int *__restrict__ starts, cons
         if (g_mean > stop_s && (double)L > 0.01 * (double)n && L > 50) break;
         const float cx = (float)(a[2] / a[0]), cy = (float)(a[3] / a[0]), cz = (float)(a[4] / a[0]);
         // ---- candidates: neighbours of the members that are not members
+#pragma unroll 4
         for (int i = t; i < n; i += T) cand[i] = 0;
         __syncthreads();
+#pragma unroll 4
         for (int i = t; i < n; i += T) {
             if (mult[i] > 0) {
                 const int *row = neighbors + (size_t)i * nsample;
@@ -177,6 +181,7 @@ __global__ __launch_bounds__(T) void k_grow(const int *__restrict__ starts, cons
         }
         __syncthreads();
         long long nc_l = 0;
+#pragma unroll 4
         for (int i = t; i < n; i += T) {
             if (mult[i] > 0) cand[i] = 0;
             nc_l += cand[i];
@@ -192,12 +197,14 @@ __global__ __launch_bounds__(T) void k_grow(const int *__restrict__ starts, cons
             hi = unkey(radix_select(n, k2 < 1 ? 1 : k2, wt, kf, hist, bc));
         } else {
             float mn = INFINITY, mx = -INFINITY;
+#pragma unroll 4
             for (int i = t; i < n; i += T)
                 if (mult[i] > 0) { mn = fminf(mn, score[i]); mx = fmaxf(mx, score[i]); }
             lo = block_min(mn, fl);
             hi = block_max(mx, fl);
         }
         double r2[2] = {0.0, 0.0};
+#pragma unroll 4
         for (int i = t; i < n; i += T) {
             const int m = mult[i];
             if (m > 0 && score[i] >= lo && score[i] <= hi) { r2[0] += (double)m; r2[1] += (double)m * (double)score[i]; }
@@ -206,6 +213,7 @@ __global__ __launch_bounds__(T) void k_grow(const int *__restrict__ starts, cons
         const float ref = (float)(r2[1] / r2[0]);
         // ---- similarity of every candidate: 0.4 * (1 - (dist - min) / (max - min + 1e-3)) + 0.6 * exp(-|score - ref|)
         float dmn = INFINITY, dmx = -INFINITY;
+#pragma unroll 4
         for (int i = t; i < n; i += T) {
             if (cand[i]) {
                 const float d = norm3(fsub(coord[3 * i], cx), fsub(coord[3 * i + 1], cy), fsub(coord[3 * i + 2], cz));
@@ -215,6 +223,7 @@ __global__ __launch_bounds__(T) void k_grow(const int *__restrict__ starts, cons
         }
         const float dmin = block_min(dmn, fl), dmax = block_max(dmx, fl);
         const float den = fadd(fsub(dmax, dmin), 1e-3f);
+#pragma unroll 4
         for (int i = t; i < n; i += T) {
             if (cand[i]) {
                 const float ds = fsub(1.0f, fdivr(fsub(sim[i], dmin), den));
@@ -231,13 +240,16 @@ __global__ __launch_bounds__(T) void k_grow(const int *__restrict__ starts, cons
             auto kf = [&](int i) { return okey(sim[i]); };
             const unsigned cut = radix_select(n, nc - k + 1, wt, kf, hist, bc);
             long long above_l = 0;
+#pragma unroll 4
             for (int i = t; i < n; i += T) above_l += (cand[i] && okey(sim[i]) > cut) ? 1 : 0;
             const long long above = block_sum_ll(above_l, ll);
             const long long need = k - above;   // >= 1 entries at the cut value join
             long long ties_l = 0;
+#pragma unroll 4
             for (int i = t; i < n; i += T) ties_l += (cand[i] && okey(sim[i]) == cut) ? 1 : 0;
             const long long ties = block_sum_ll(ties_l, ll);
             if (ties == need) {   // (always, but for exact float ties across the cut)
+#pragma unroll 4
                 for (int i = t; i < n; i += T) cand[i] = (cand[i] && okey(sim[i]) >= cut) ? 2 : 0;   // 2 = joins
             } else {              // of the entries AT the cut, the lowest ids until k are reached: ordered walk in chunks of T
                 if (t == 0) bc[0] = 0u;
@@ -264,6 +276,7 @@ __global__ __launch_bounds__(T) void k_grow(const int *__restrict__ starts, cons
         ++rounds;
         // ---- upstream: grown = unique(cat(graph, chosen)); `if grown.shape[0] == graph.shape[0]: break` compares the new SET with the old LIST
         if (distinct + added == L) break;
+#pragma unroll 4
         for (int i = t; i < n; i += T) mult[i] = (mult[i] > 0 || (k > 0 && cand[i] == 2)) ? 1 : 0;
         grew = 1;
         __syncthreads();
@@ -288,11 +301,13 @@ __global__ __launch_bounds__(T) void k_scene_stats(const int *__restrict__ start
     const int n = sizes[s];
     msp += s0; ml += s0; ml_norm += s0; mult += s0;
     float mn = INFINITY, mx = -INFINITY;
+#pragma unroll 4
     for (int i = t; i < n; i += T) { mn = fminf(mn, ml[i]); mx = fmaxf(mx, ml[i]); }
     mn = block_min(mn, fl);
     mx = block_max(mx, fl);
     const float den = fadd(fsub(mx, mn), 1e-6f);
     double a[1] = {0.0};
+#pragma unroll 4
     for (int i = t; i < n; i += T) {
         const float v = fdivr(fsub(ml[i], mn), den);
         ml_norm[i] = v;
@@ -302,6 +317,7 @@ __global__ __launch_bounds__(T) void k_scene_stats(const int *__restrict__ start
     block_sum<1>(a, dl);
     const double mean = n > 0 ? a[0] / (double)n : 0.0;
     double q[1] = {0.0};
+#pragma unroll 4
     for (int i = t; i < n; i += T) {
         const double d = (double)(score_is_ml ? fdivr(fsub(ml[i], mn), den) : msp[i]) - mean;
         q[0] += d * d;
@@ -333,6 +349,7 @@ __global__ __launch_bounds__(T) void k_seed_select(const int *__restrict__ start
     __syncthreads();
     if (need <= 1) {   // the lowest id among the equal values
         int best = 0x7fffffff;
+#pragma unroll 4
         for (int i = t; i < n; i += T)
             if (okey(src[i]) == cut) { best = i; break; }
         if (best != 0x7fffffff) atomicMin(&found, best);
@@ -604,8 +621,10 @@ __global__ __launch_bounds__(T) void k_region_mask(const int *__restrict__ start
     lab += s0; touched += s0; cnt += s0; mask += s0;
     const int has_pad = counts[4 * s + 2];
     const int first = min(counts[4 * s + 3], n - 1);
+#pragma unroll 4
     for (int i = t; i < n; i += T) cnt[i] = 0;
     __syncthreads();
+#pragma unroll 4
     for (int i = t; i < n; i += T) {
         // touched = unique(cat([node, node_nn]))[1:]: the first entry is the -1 padding -- or, when no row of the region is padded, the
         // smallest id touched (dropped all the same upstream)
@@ -614,6 +633,7 @@ __global__ __launch_bounds__(T) void k_region_mask(const int *__restrict__ start
     __threadfence();
     __syncthreads();
     double a[2] = {0.0, 0.0};
+#pragma unroll 4
     for (int i = t; i < n; i += T) {
         const int c = __hip_atomic_load(&cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (c > 0) { a[0] += 1.0; a[1] += (double)c; }
@@ -621,12 +641,14 @@ __global__ __launch_bounds__(T) void k_region_mask(const int *__restrict__ start
     block_sum<2>(a, dl);
     const double k = a[0], mean = a[1] / k;
     double q[1] = {0.0};
+#pragma unroll 4
     for (int i = t; i < n; i += T) {
         const int c = __hip_atomic_load(&cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (c > 0) q[0] += ((double)c - mean) * ((double)c - mean);
     }
     block_sum<1>(q, dl);
     const double sd = sqrt(q[0] / k);
+#pragma unroll 4
     for (int i = t; i < n; i += T) {
         const int c = __hip_atomic_load(&cnt[lab[i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         mask[i] = (c > 0 && ((double)c - mean) / sd > 2.0) ? 1 : 0;   // z_score_mask_np(area="right", score=2.0)

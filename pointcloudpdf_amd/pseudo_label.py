@@ -441,12 +441,12 @@ def get_pseudo_mask_static(coord, seg_logits, offset_host, neighbors, condition_
     rows_ws = torch.empty(3 * N, **i32)
     be._call("region_edges", B, starts_d, sizes_d, coord, msp, nn, ns, mult, nodes, eu, ev, ew, touched, comp, lab, counts, rows_ws, N)
     chosen = torch.empty(N * ns, **u8)
-    ws_bytes = max(int(be.lib.pdf_graph_forest_workspace_bytes(n, n * ns, n)) for n in sizes)
-    ws = torch.empty((ws_bytes // 8 + 1,), dtype=torch.int64, device=dev)   # (the scenes' forests run one after the other: one workspace)
-    for b, (s0, e) in enumerate(zip(starts, ends)):      # the spanning forest of every scene (one workgroup each)
-        n = e - s0
-        be._call("graph_forest_dev", n, n * ns, eu[s0 * ns:e * ns], ev[s0 * ns:e * ns], ew[s0 * ns:e * ns], None, nodes[s0:e], n, counts[b, 0:2],
-                 comp[s0:e], chosen[s0 * ns:e * ns], ws, ws.numel() * 8)
+    import ctypes
+    starts_h, sizes_h = (ctypes.c_int * B)(*starts), (ctypes.c_int * B)(*sizes)
+    ws1_bytes = sum((int(be.lib.pdf_graph_forest_workspace_bytes(n, n * ns, n)) + 7) & ~7 for n in sizes)
+    ws = torch.empty((ws1_bytes // 8 + 1,), dtype=torch.int64, device=dev)
+    # the spanning forest of every scene (one workgroup each, all scenes in one launch)
+    be._call("graph_forest_batch_dev", B, starts_h, sizes_h, ns, eu, ev, ew, None, nodes, counts, 4, comp, chosen, ws, ws.numel() * 8)
     tu = torch.empty(N, dtype=torch.int64, device=dev)
     tv = torch.empty(N, dtype=torch.int64, device=dev)
     tw = torch.empty(N, **f32)
@@ -458,9 +458,8 @@ def get_pseudo_mask_static(coord, seg_logits, offset_host, neighbors, condition_
     fit = torch.empty((B, 8), dtype=torch.float64, device=dev)
     weak = torch.empty(N, **u8)
     be._call("gmm2_weak_dev", B, starts_d, sizes_d, tdev, xs, tw, resp, fit, weak, 200, 1e-6, 1e-6)
-    for b, (s0, e) in enumerate(zip(starts, ends)):      # the components the tree falls into without its weak edges
-        n = e - s0
-        be._call("graph_forest_dev", n, n, tu[s0:e], tv[s0:e], None, weak[s0:e], nodes[s0:e], n, tdev[b], lab[s0:e], None, ws, ws.numel() * 8)
+    # the components the tree falls into without its weak edges
+    be._call("graph_forest_batch_dev", B, starts_h, sizes_h, 1, tu, tv, None, weak, nodes, tdev, 2, lab, None, ws, ws.numel() * 8)
     mask = torch.empty(N, **u8)
     be._call("region_mask", B, starts_d, sizes_d, lab, touched, counts, comp, mask)   # (comp: free again -- the counts' workspace)
     if info is not None:
