@@ -478,7 +478,7 @@ def test_training_loop_converges_in_every_precision_and_execution_mode():
     mode -- fp32, fp16 operands (static loss scale 4096), bfloat16 operands, each issued eagerly and replayed as a captured hipGraph.  A
     replayed trajectory equals the eager one of the same precision step by step (same kernels, same order: bit-identical losses); the
     reduced-precision trajectories stay within 10 % (fp16) / 15 % (bfloat16) of the fp32 loss at every fifth step and within 5 % at the end
-    (`python tools/train_modes_probe.py`)."""
+    (a one-off probe of round 4: `docs/NOTEBOOK.md`)."""
     from pointcloudpdf_amd import engine, synthetic
     from pointcloudpdf_amd.geometry import Geometry
 

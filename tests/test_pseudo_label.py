@@ -73,7 +73,7 @@ def test_pseudo_mask_on_gpu_batch(gp):
                                             generator=torch.Generator().manual_seed(seed), **PSEUDO_KW).numpy()
         ref = gp[f"{t}_mask"]
         # exact on these fixtures (no seed / top-k boundary sits at a float tie between the device's and the host's softmax: checked with
-        # tools/pl_probe.py -- 86 / 57 points, 0 differing); round 2 only bounded the overlap
+        # a one-off probe of round 4 -- 86 / 57 points, 0 differing); round 2 only bounded the overlap
         assert np.array_equal(mask, ref), (t, int(mask.sum()), int(ref.sum()), int((mask ^ ref).sum()))
         start += n
     full = pseudo_label.get_pseudo_mask(coord, logits, off, radius=0.1, max_neighbor=64, generator=torch.Generator().manual_seed(1), **PSEUDO_KW)
