@@ -68,9 +68,13 @@ class LayerNorm1d(nn.BatchNorm1d):
 class _FusedPTLayer(torch.autograd.Function):
     """The whole PointTransformerLayer after the q/k/v projections as one autograd node over the fused HIP passes
     (csrc/fused_layer.hip).  Forward: no (n, ns, c) tensor is materialised (only ``H (n, ns, c/8)`` is saved).  Backward: the pass
-    that forms the gradient rows ``g_r (n, ns, c)`` streams them out once and a segmented gather over the inverse kNN table sums them
-    per source point (``g_xk``; no atomics, fixed order) -- one (n, ns, c) round trip through HBM per layer, which is most of the
-    Bottleneck backward's traffic."""
+    that forms the gradient rows ``g_r (n, ns, c)`` (B3) streams them out once and a segmented gather over the inverse kNN table
+    (``sg::k_seg_rows``) sums them per source point (``g_xk``; no atomics, fixed order).  That write + re-read of ``GR`` is the one
+    (n, ns, c) tensor the layer's backward still moves through HBM: 0.46 ms of the 15.2 ms step over the 18 layers (205 MB each way at
+    level 1), NOT the bulk of the Bottleneck backward's traffic -- that is the passes' re-gathering of rows (DESIGN.md sections 5a, 6).
+    Forming ``g_xk`` inside the segmented walk instead means redoing B3's per-entry chain (relative-position MLP, BatchNorm + ReLU masks,
+    the (c/8 x c) product) in destination order with a gathered ``x_q`` row per entry: the same row volume as the ``GR`` read it would
+    save, plus the arithmetic a second time (priced, not built)."""
 
     @staticmethod
     @_amp_fwd
