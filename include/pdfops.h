@@ -524,12 +524,14 @@ int pdf_wa_logits_forward(int N, int M, int h, int d, int L, const float *q, con
  *   pdf_region_stats : :190-205 -- ml_norm = (ml - min) / (max - min + 1e-6), stop = mean(score) - beta * std(score) per scene; clears mult
  *   pdf_region_seeds : :206-207 -- mult[p] += 1 for the point whose src value has rank dice[s, j] (radix select; stands in for sort + gather)
  *   pdf_region_grow  : all growth rounds of :233-305 on mult (N) int32 (in: multiplicities of the seed list, out: the region);
+ *                      lists: 2 N ints of scratch; max_points: the largest scene (host value: sizes the LDS bitmaps);
  *                      info (scenes, 4) = [rounds, grew, list length, distinct points]
  *   pdf_region_edges : the region's ascending node list and the (row, col, weight) entries of its neighbour graph (:309-335, ours/utils.py:7-43)
  *                      at capacity sizes[s] / sizes[s] * nsample per scene; counts (scenes, 4) = [nodes, entries, any -1 padding, smallest id
- *                      touched]; comp / lab (N) = every point's own local id; rows_ws: 3 * n_total words
+ *                      touched]; comp / lab (N) = every point's own local id; rows_ws: 3 * n_total words; lists / grow_info:
+ *                      pdf_region_grow's `lists` / `info` when its largest scene <= pdf_region_grow_list_points(), else NULL, NULL
  *   pdf_graph_forest_dev / pdf_gmm2_1d_dev: pdf_graph_forest / pdf_gmm2_1d with the sizes read from device memory ([nodes, entries] / [m])
- *   pdf_region_tree  : the forest's chosen entries compacted in entry order (+inf-padded weights), tdev (scenes, 2) = [nodes, tree edges]
+ *   pdf_region_tree  : the forest's chosen entries compacted in entry order (tdev[s, 1] of them per scene), tdev (scenes, 2) = [nodes, tree edges]
  *   pdf_sort_floats_dev: the first tdev[s, 1] weights of every scene ascending (what the mixture fit takes); tmp: N words
  *   pdf_gmm2_weak_dev: :343-358 for every scene -- the two-component fit of the sorted weights (fit (scenes, 8) doubles as pdf_gmm2_1d) and
  *                      weak[e] = tw[e] < mean - 2 * covariance of the component with the larger mean (N bytes); resp: 2 N doubles
@@ -538,12 +540,13 @@ int pdf_region_stats(int scenes, const int *starts, const int *sizes, const floa
                      float *ml_norm, float *stop, int *mult, void *stream);
 int pdf_region_seeds(int scenes, const int *starts, const int *sizes, const float *src, const long long *dice, int num_seed, int *mult,
                      void *stream);
-int pdf_region_grow(int scenes, const int *starts, const int *sizes, const float *coord, const float *score, const int *neighbors,
-                    int nsample, const float *stop, int slide_window, int max_rounds, int *mult, unsigned char *cand, float *sim, int *info,
-                    void *stream);
+int pdf_region_grow(int scenes, const int *starts, const int *sizes, int max_points, const float *coord, const float *score,
+                    const int *neighbors, int nsample, const float *stop, int slide_window, int max_rounds, int *mult, int *lists, float *sim,
+                    int *info, void *stream);
 int pdf_region_edges(int scenes, const int *starts, const int *sizes, const float *coord, const float *msp, const int *neighbors,
-                     int nsample, const int *mult, long long *nodes_out, long long *eu, long long *ev, float *ew, unsigned char *touched,
-                     int *comp, int *lab, int *counts, void *rows_ws, long n_total, void *stream);
+                     int nsample, const int *mult, const int *lists, const int *grow_info, long long *nodes_out, long long *eu, long long *ev,
+                     float *ew, unsigned char *touched, int *comp, int *lab, int *counts, void *rows_ws, long n_total, void *stream);
+long pdf_region_grow_list_points(void);   /* largest scene for which pdf_region_grow leaves the ascending member list in `lists` */
 int pdf_region_tree(int scenes, const int *starts, const int *sizes, int nsample, const int *counts, const unsigned char *chosen,
                     const long long *eu, const long long *ev, const float *ew, long long *tu, long long *tv, float *tw, int *tdev, void *stream);
 int pdf_graph_forest_dev(long n, int E, const long long *u, const long long *v, const float *w, const unsigned char *active,

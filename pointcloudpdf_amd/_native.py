@@ -75,8 +75,8 @@ _HIP_ONLY_PROTOS = {
     "scene_repeat_rows": "iplipip",
     "region_stats": "ippppifppp",
     "region_seeds": "ippppip",
-    "region_grow": "ipppppipiipppp",
-    "region_edges": "ipppppippppppppppl",
+    "region_grow": "ippipppipiipppp",
+    "region_edges": "ipppppippppppppppppl",
     "sort_floats_dev": "ipppppp",
     "gmm2_weak_dev": "ippppppppidd",
     "region_mask": "ippppppp",
@@ -731,6 +731,8 @@ class HipBackend(CBackend):
         lib.pdf_knn_workspace_bytes.restype = c_long
         lib.pdf_knn_workspace_bytes.argtypes = [c_int, c_int, c_int]
         lib.pdf_graph_forest_workspace_bytes.restype = c_long
+        lib.pdf_region_grow_list_points.restype = c_long
+        lib.pdf_region_grow_list_points.argtypes = []
         lib.pdf_graph_forest_workspace_bytes.argtypes = [c_long, c_long, c_long]
         lib.pdf_knn_grid_supported.restype = c_int
         lib.pdf_knn_grid_supported.argtypes = [c_int]

@@ -444,7 +444,7 @@ __global__ __launch_bounds__(TG) void k_gmm2(int m, const float *__restrict__ xs
 
 // Every scene of a batch (grid = scenes): the fit of the scene's first tdev[2 s + 1] sorted weights, then upstream's cut of the tree
 // (pointpdf_v1m1_base.py:346-358): the component with the larger mean, "std" = its covariance as upstream, weak[e] = tw[e] < mean - 2 * "std"
-// for the scene's tree entries in entry order (tw is +inf beyond the tree).
+// for the scene's tdev[2 s + 1] tree entries in entry order.
 __global__ __launch_bounds__(TG) void k_gmm2_weak(const int *__restrict__ starts, const int *__restrict__ sizes, const int *__restrict__ tdev,
                                                   const float *__restrict__ xs, const float *__restrict__ tw, double *resp, double *fit,
                                                   unsigned char *__restrict__ weak, int iters, double tol, double reg) {
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(TG) void k_gmm2_weak(const int *__restrict__ starts
     const int n = sizes[s], m = min(tdev[2 * s + 1], n);
     const Fit f = gmm2_fit(m, xs + s0, resp + 2 * s0, fit + 8 * s, iters, tol, reg, lds);
     const double lower = f.mu1 > f.mu0 ? f.mu1 - 2.0 * f.var1 : f.mu0 - 2.0 * f.var0;   // (np.argmax(means): the first on a tie)
-    for (int i = threadIdx.x; i < n; i += TG) weak[s0 + i] = (double)tw[s0 + i] < lower ? 1 : 0;
+    for (int i = threadIdx.x; i < m; i += TG) weak[s0 + i] = (double)tw[s0 + i] < lower ? 1 : 0;   // (the second labelling reads tdev[2 s + 1] entries)
 }
 
 }   // namespace gp

@@ -125,9 +125,168 @@ __device__ __forceinline__ float norm3(float dx, float dy, float dz) { return __
 // pdf_radius_neighbors_self writes), made local here.
 //   mult   (N) int32  in: multiplicity of every point in the seed list; out: 1 on the region's points (or the seed multiplicities when the
 //                     region never grew)
+//   lists  (2 N) int32 scratch: the scene's member list | candidate list;  sim (N) float scratch (one value per candidate)
+//   info   (scenes, 4) int32 out: [rounds run, grew (0 / 1), length of the region list, distinct points]
+// A round touches all n points ONCE (the ascending member list + the member bitmap, by ballots); everything else walks the member list
+// (a few thousand entries), the members' neighbour rows, or the candidate list they produce (round 5's first form made ~25 passes over all
+// points per round, each 146 dependent iterations per lane at 150k points: 1.05 ms per round).  Membership and candidate marks are two
+// bitmaps in LDS (n / 8 bytes each: test-and-set by an LDS atomicOr); the candidate list is appended in arrival order -- nothing that is
+// computed from it depends on its order (minima, maxima, counts, radix selects, the tie rule by id) -- while the member list is ascending,
+// so the double sums over it run in a fixed order.
+__global__ __launch_bounds__(T) void k_grow(const int *__restrict__ starts, const int *__restrict__ sizes, const float *__restrict__ coord,
+                                            const float *__restrict__ score, const int *__restrict__ neighbors, int nsample,
+                                            const float *__restrict__ stop, int slide_window, int max_rounds, int *__restrict__ mult,
+                                            int *__restrict__ lists, float *__restrict__ sim, int *__restrict__ info, int max_points) {
+    extern __shared__ unsigned bits[];   // member bitmap [words] | candidate bitmap [words]
+    __shared__ double dl[NW * 5];
+    __shared__ float fl[NW];
+    __shared__ long long ll[NW];
+    __shared__ int hist[256];
+    __shared__ unsigned bc[2];
+    __shared__ int wcount[2][NW];
+    __shared__ int ccount;
+    const int s = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const long s0 = starts[s];
+    const int n = sizes[s];
+    if (n > max_points) {   // (the launch sized the bitmaps for max_points)
+        if (threadIdx.x == 0) { info[4 * s] = -1; info[4 * s + 1] = 0; info[4 * s + 2] = 0; info[4 * s + 3] = 0; }
+        return;
+    }
+    const int words = (n + 63) / 64 * 2;   // (whole 64-point chunks: a wave's ballot is two words)
+    unsigned *mbits = bits, *cbits = bits + words;
+    coord += s0 * 3; score += s0; neighbors += s0 * nsample; mult += s0; sim += s0;
+    int *mlist = lists + 2 * s0, *clist = mlist + n;
+    const float stop_s = stop[s];
+    int rounds = 0, grew = 0;
+    long long L = 0, distinct = 0;
+    for (int w = t; w < words; w += T) cbits[w] = 0u;
+    for (;;) {
+        // ---- the ONE pass over the scene's points: ascending member list + member bitmap
+        int M = 0;
+        for (int base = 0, it = 0; base < n; base += T, ++it) {
+            const int i = base + t;
+            const bool on = i < n && mult[i] > 0;
+            const unsigned long long bal = __ballot(on);
+            if (lane == 0) {
+                wcount[it & 1][wv] = __popcll(bal);
+                if (base + 64 * wv < n) { mbits[(base >> 5) + 2 * wv] = (unsigned)bal; mbits[(base >> 5) + 2 * wv + 1] = (unsigned)(bal >> 32); }
+            }
+            __syncthreads();
+            int pos = M, tot = 0;
+            for (int w = 0; w < NW; ++w) { const int c = wcount[it & 1][w]; if (w < wv) pos += c; tot += c; }
+            if (on) mlist[pos + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+            M += tot;
+        }
+        if (t == 0) ccount = 0;
+        __syncthreads();
+        // ---- the region list: length (with repeats), mean score, centroid
+        double a[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int j = t; j < M; j += T) {
+            const int i = mlist[j];
+            const double dm = (double)mult[i];
+            a[0] += dm; a[1] += dm * (double)score[i];
+            a[2] += dm * (double)coord[3 * i]; a[3] += dm * (double)coord[3 * i + 1]; a[4] += dm * (double)coord[3 * i + 2];
+        }
+        block_sum<5>(a, dl);
+        distinct = M;
+        L = (long long)a[0];
+        if (L == 0 || rounds >= max_rounds) break;
+        const float g_mean = (float)(a[1] / a[0]);
+        if (g_mean > stop_s && (double)L > 0.01 * (double)n && L > 50) break;
+        const float cx = (float)(a[2] / a[0]), cy = (float)(a[3] / a[0]), cz = (float)(a[4] / a[0]);
+        // ---- candidates: neighbours of the members that are not members (one wave per member row, lanes over the slots)
+        for (int j = wv; j < M; j += NW) {
+            const int *row = neighbors + (size_t)mlist[j] * nsample;
+            for (int k = lane; k < nsample; k += 64) {
+                const int nb = row[k] < 0 ? -1 : row[k] - (int)s0;
+                if (nb >= 0 && nb < n && !((mbits[nb >> 5] >> (nb & 31)) & 1u)) {
+                    const unsigned bit = 1u << (nb & 31);
+                    if (!(atomicOr(&cbits[nb >> 5], bit) & bit)) clist[atomicAdd(&ccount, 1)] = nb;
+                }
+            }
+        }
+        __syncthreads();
+        const int nc = ccount;
+        // ---- the score the candidates are compared with: mean of the region's scores between its 10 % and 60 % quantiles
+        float lo, hi;
+        if (slide_window) {
+            const long long k1 = (long long)((double)L * 0.1), k2 = (long long)((double)L * 0.6);   // int(len * 0.1), int(len * 0.6)
+            auto wt = [&](int j) { return mult[mlist[j]]; };
+            auto kf = [&](int j) { return okey(score[mlist[j]]); };
+            lo = unkey(radix_select(M, k1 < 1 ? 1 : k1, wt, kf, hist, bc));
+            hi = unkey(radix_select(M, k2 < 1 ? 1 : k2, wt, kf, hist, bc));
+        } else {
+            float mn = INFINITY, mx = -INFINITY;
+            for (int j = t; j < M; j += T) { const float v = score[mlist[j]]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+            lo = block_min(mn, fl);
+            hi = block_max(mx, fl);
+        }
+        double r2[2] = {0.0, 0.0};
+        for (int j = t; j < M; j += T) {
+            const int i = mlist[j];
+            const float v = score[i];
+            if (v >= lo && v <= hi) { const double dm = (double)mult[i]; r2[0] += dm; r2[1] += dm * (double)v; }
+        }
+        block_sum<2>(r2, dl);
+        const float ref = (float)(r2[1] / r2[0]);
+        // ---- similarity of every candidate: 0.4 * (1 - (dist - min) / (max - min + 1e-3)) + 0.6 * exp(-|score - ref|)
+        float dmn = INFINITY, dmx = -INFINITY;
+        for (int j = t; j < nc; j += T) {
+            const int i = clist[j];
+            const float d = norm3(fsub(coord[3 * i], cx), fsub(coord[3 * i + 1], cy), fsub(coord[3 * i + 2], cz));
+            sim[j] = d;
+            dmn = fminf(dmn, d); dmx = fmaxf(dmx, d);
+        }
+        const float dmin = block_min(dmn, fl), dmax = block_max(dmx, fl);
+        const float den = fadd(fsub(dmax, dmin), 1e-3f);
+        for (int j = t; j < nc; j += T) {
+            const float ds = fsub(1.0f, fdivr(fsub(sim[j], dmin), den));
+            const float cs = expf(-fabsf(fsub(score[clist[j]], ref)));
+            sim[j] = fadd(fmul(0.4f, ds), fmul(0.6f, cs));
+        }
+        __syncthreads();
+        // ---- the best 40 % join: k-th largest similarity = (nc - k + 1)-th smallest
+        const long long k = (long long)((double)nc * 0.4);   // int(sim.numel() * 0.4)
+        ++rounds;
+        // ---- upstream: grown = unique(cat(graph, chosen)); `if grown.shape[0] == graph.shape[0]: break` compares the new SET with the old LIST
+        if (distinct + k == L) break;
+        if (k > 0) {
+            auto one = [&](int) { return 1; };
+            auto kf = [&](int j) { return okey(sim[j]); };
+            long long need = 0;   // how many of the entries AT the cut value join (>= 1)
+            const unsigned cut = radix_select(nc, (long long)nc - k + 1, one, kf, hist, bc, &need);
+            // (rank_among_equal counts from the smallest: `need_low` of the ties lie below the wanted element; the ties that join are the
+            //  others -- ties - need_low + 1; upstream's topk keeps, of equal values, the lowest ids: the tie rule below)
+            long long ties_l = 0;
+            for (int j = t; j < nc; j += T) ties_l += okey(sim[j]) == cut ? 1 : 0;
+            const long long ties = block_sum_ll(ties_l, ll);
+            const long long join_ties = ties - need + 1;
+            int id_cut = 0x7fffffff;
+            if (join_ties < ties) {   // (only with exact float ties across the cut) the join_ties lowest ids among the ties
+                auto wtie = [&](int j) { return okey(sim[j]) == cut ? 1 : 0; };
+                auto kid = [&](int j) { return (unsigned)clist[j]; };
+                id_cut = (int)radix_select(nc, join_ties, wtie, kid, hist, bc);
+            }
+            for (int j = t; j < nc; j += T) {
+                const unsigned key = okey(sim[j]);
+                if (key > cut || (key == cut && clist[j] <= id_cut)) mult[clist[j]] = 1;
+            }
+        }
+        for (int j = t; j < M; j += T) mult[mlist[j]] = 1;        // (a grown region is a set)
+        for (int w = t; w < words; w += T) cbits[w] = 0u;
+        grew = 1;
+        __syncthreads();
+    }
+    if (t == 0) { info[4 * s] = rounds; info[4 * s + 1] = grew; info[4 * s + 2] = (int)L; info[4 * s + 3] = (int)distinct; }
+}
+
+// The first form of the growth kernel (round 5): every stage of a round as a pass over ALL points of the scene -- kept for scenes whose two
+// bitmaps (n / 4 bytes) do not fit the LDS (more than ~600k points).  Same results as k_grow up to the summation order of the region's sums.
+//   mult   (N) int32  in: multiplicity of every point in the seed list; out: 1 on the region's points (or the seed multiplicities when the
+//                     region never grew)
 //   cand   (N) uint8  scratch;  sim (N) float scratch
 //   info   (scenes, 4) int32 out: [rounds run, grew (0 / 1), length of the region list, distinct points]
-__global__ __launch_bounds__(T) void k_grow(const int *__restrict__ starts, const int *__restrict__ sizes, const float *__restrict__ coord,
+__global__ __launch_bounds__(T) void k_grow_scan(const int *__restrict__ starts, const int *__restrict__ sizes, const float *__restrict__ coord,
                                             const float *__restrict__ score, const int *__restrict__ neighbors, int nsample,
                                             const float *__restrict__ stop, int slide_window, int max_rounds, int *__restrict__ mult,
                                             unsigned char *__restrict__ cand, float *__restrict__ sim, int *__restrict__ info) {
@@ -392,30 +551,42 @@ constexpr int RW = 64;   // workgroups per scene of the row kernels
 __global__ __launch_bounds__(T) void k_region_nodes(const int *__restrict__ starts, const int *__restrict__ sizes, const int *__restrict__ mult,
                                                     long long *__restrict__ nodes_out, unsigned char *__restrict__ touched, int *__restrict__ comp,
                                                     int *__restrict__ lab, int *__restrict__ counts) {
-    __shared__ int wm[NW];
-    __shared__ int carry;
+    __shared__ int wm[2][NW];
     const int s = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const long s0 = starts[s];
     const int n = sizes[s];
     mult += s0; nodes_out += s0; touched += s0; comp += s0; lab += s0;
-    if (t == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += T) {
+    int carry = 0;   // (the same value in every thread: one barrier per chunk, wave counts double-buffered)
+    for (int base = 0, it = 0; base < n; base += T, ++it) {
         const int i = base + t;
         const bool on = i < n && mult[i] > 0;
         if (i < n) { touched[i] = 0; comp[i] = i; lab[i] = i; }
         const unsigned long long bal = __ballot(on);
-        if (lane == 0) wm[wv] = __popcll(bal);
+        if (lane == 0) wm[it & 1][wv] = __popcll(bal);
         __syncthreads();
-        int pos = carry;
-        for (int w = 0; w < wv; ++w) pos += wm[w];
-        pos += __popcll(bal & ((1ull << lane) - 1ull));
-        if (on) nodes_out[pos] = i;
-        __syncthreads();
-        if (t == 0) { int tot = 0; for (int w = 0; w < NW; ++w) tot += wm[w]; carry += tot; }
-        __syncthreads();
+        int pos = carry, tot = 0;
+        for (int w = 0; w < NW; ++w) { const int c = wm[it & 1][w]; if (w < wv) pos += c; tot += c; }
+        if (on) nodes_out[pos + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        carry += tot;
     }
     if (t == 0) { counts[4 * s] = carry; counts[4 * s + 1] = 0; counts[4 * s + 2] = 0; counts[4 * s + 3] = 0x7fffffff; }
+}
+
+// The same from the ascending member list pdf_region_grow left behind (lists: 2 N ints, scene s at 2 * start[s]; info[4 s + 3] = its
+// length): a plain copy, RW workgroups per scene instead of a one-workgroup compaction (137 -> ~10 us per 150k-point scene).
+__global__ __launch_bounds__(T) void k_region_nodes_from_list(const int *__restrict__ starts, const int *__restrict__ sizes,
+                                                              const int *__restrict__ lists, const int *__restrict__ info,
+                                                              long long *__restrict__ nodes_out, unsigned char *__restrict__ touched,
+                                                              int *__restrict__ comp, int *__restrict__ lab, int *__restrict__ counts) {
+    const int s = blockIdx.x / RW, part = blockIdx.x % RW;
+    const long s0 = starts[s];
+    const int n = sizes[s], M = min(max(info[4 * s + 3], 0), n);
+    const int *mlist = lists + 2 * s0;
+    for (int i = part * T + threadIdx.x; i < n; i += RW * T) {
+        touched[s0 + i] = 0; comp[s0 + i] = i; lab[s0 + i] = i;
+        if (i < M) nodes_out[s0 + i] = mlist[i];
+    }
+    if (part == 0 && threadIdx.x == 0) { counts[4 * s] = M; counts[4 * s + 1] = 0; counts[4 * s + 2] = 0; counts[4 * s + 3] = 0x7fffffff; }
 }
 
 // WRITE = false: rowcnt[r] = entries of row r, rowrange[2 r] = (dmin, dmax), touched marks, counts[2] |= padding seen, counts[3] = min id touched
@@ -516,37 +687,55 @@ __global__ __launch_bounds__(T) void k_region_scan(const int *__restrict__ start
     if (t == 0) counts[4 * s + 1] = carry;
 }
 
-// The chosen entries of the spanning forest, in entry order: tu, tv (ids), tw (weights; +inf beyond the tree so that a plain sort of the
-// scene's slice brings the tree's weights to the front), tdev (scenes, 2) = [nodes, tree edges] for the second graph kernel.
+// The chosen entries of the spanning forest, in entry order: tu, tv (ids), tw (weights), tdev (scenes, 2) = [nodes, tree edges] for the sort,
+// the mixture fit and the second graph kernel (nothing is written beyond the tree: a one-workgroup fill of the scene's slices was half of
+// this kernel's time).
 __global__ __launch_bounds__(T) void k_tree_edges(const int *__restrict__ starts, const int *__restrict__ sizes, int nsample,
                                                   const int *__restrict__ counts, const unsigned char *__restrict__ chosen,
                                                   const long long *__restrict__ eu, const long long *__restrict__ ev, const float *__restrict__ ew,
                                                   long long *__restrict__ tu, long long *__restrict__ tv, float *__restrict__ tw, int *__restrict__ tdev) {
-    __shared__ int wcnt[NW];
-    __shared__ int carry;
+    __shared__ int wcnt[2][NW];
     const int s = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const long s0 = starts[s];
     const int n = sizes[s], E = counts[4 * s + 1];
     chosen += s0 * nsample; eu += s0 * nsample; ev += s0 * nsample; ew += s0 * nsample;
     tu += s0; tv += s0; tw += s0;
-    if (t == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < E; base += T) {
-        const int e = base + t;
-        const bool on = e < E && chosen[e] != 0;
-        const unsigned long long bal = __ballot(on);
-        if (lane == 0) wcnt[wv] = __popcll(bal);
+    int carry = 0;   // (the same value in every thread: one barrier per chunk, wave counts double-buffered)
+    // four consecutive entries per lane and trip (the flags of a scene start at a multiple of nsample: 4-byte loads when nsample % 4 == 0):
+    // the walk is a chain of dependent flag loads, one per chunk -- 85 chunks of 1,024 entries at 87k entries, 22 of 4,096
+    const bool vec = (nsample & 3) == 0;
+    const int step = vec ? 4 * T : T;
+    for (int base = 0, it = 0; base < E; base += step, ++it) {
+        const int e0 = vec ? base + 4 * t : base + t;
+        unsigned f = 0;   // flags of the lane's entries, one bit each
+        if (vec) {
+            if (e0 < E) {
+                const unsigned v = *reinterpret_cast<const unsigned *>(chosen + e0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) f |= (e0 + q < E && ((v >> (8 * q)) & 0xffu)) ? 1u << q : 0u;
+            }
+        } else {
+            f = (e0 < E && chosen[e0] != 0) ? 1u : 0u;
+        }
+        const int c = __popc(f);
+        int p = c;   // inclusive prefix of the lane counts inside the wave
+        for (int o = 1; o < 64; o <<= 1) {
+            const int a = __shfl_up(p, o, 64);
+            if (lane >= o) p += a;
+        }
+        if (lane == 63) wcnt[it & 1][wv] = p;
         __syncthreads();
-        int pos = carry;
-        for (int w = 0; w < wv; ++w) pos += wcnt[w];
-        pos += __popcll(bal & ((1ull << lane) - 1ull));
-        if (on && pos < n) { tu[pos] = eu[e]; tv[pos] = ev[e]; tw[pos] = ew[e]; }
-        __syncthreads();
-        if (t == 0) { int tot = 0; for (int w = 0; w < NW; ++w) tot += wcnt[w]; carry += tot; }
-        __syncthreads();
+        int pos = carry + p - c, tot = 0;
+        for (int w = 0; w < NW; ++w) { const int cw = wcnt[it & 1][w]; if (w < wv) pos += cw; tot += cw; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if ((f >> q) & 1u) {
+                if (pos < n) { tu[pos] = eu[e0 + q]; tv[pos] = ev[e0 + q]; tw[pos] = ew[e0 + q]; }
+                ++pos;
+            }
+        carry += tot;
     }
-    const int m = min(carry, n);
-    for (int i = m + t; i < n; i += T) { tu[i] = 0; tv[i] = 0; tw[i] = INFINITY; }
+    const int m = min(carry, n);   // (entries beyond m are left as they are: every consumer reads tdev[2 s + 1])
     if (t == 0) { tdev[2 * s] = counts[4 * s]; tdev[2 * s + 1] = m; }
 }
 
@@ -678,34 +867,59 @@ extern "C" int pdf_region_seeds(int scenes, const int *starts, const int *sizes,
     return pdf_launch_status();
 }
 
+// Dynamic LDS the growth kernel may ask for: 150 KB (+ ~2 KB static; the CU has 160 KB) once the runtime accepted the raised limit, else the
+// 64 KB default minus the static part.
+static size_t grow_lds_limit() {
+    static const size_t limit = [] {
+        constexpr size_t LDS_MAX = 150 * 1024;
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(&rg::k_grow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) == hipSuccess
+                   ? LDS_MAX : (size_t)60 * 1024;
+    }();
+    return limit;
+}
+
 // Region growing of every scene of a batch, all rounds on the device.  starts / sizes (scenes) int32: the scenes' point ranges; neighbors
-// (N, nsample) int32 GLOBAL row ids (-1 padded: pdf_radius_neighbors_self's table); stop (scenes) float; mult (N) int32 in / out; cand (N)
-// bytes, sim (N) floats: scratch; info (scenes, 4) int32 out [rounds, grew, list length, distinct points].
-extern "C" int pdf_region_grow(int scenes, const int *starts, const int *sizes, const float *coord, const float *score, const int *neighbors,
-                               int nsample, const float *stop, int slide_window, int max_rounds, int *mult, unsigned char *cand, float *sim,
-                               int *info, void *stream) {
-    if (scenes < 0 || nsample < 1 || max_rounds < 0) return PDF_ERR_BAD_ARG;
+// (N, nsample) int32 GLOBAL row ids (-1 padded: pdf_radius_neighbors_self's table); stop (scenes) float; mult (N) int32 in / out; lists
+// (2 N) ints, sim (N) floats: scratch; info (scenes, 4) int32 out [rounds, grew, list length, distinct points].  max_points: the largest
+// scene of the batch (host value: sizes the LDS bitmaps; larger scenes than it would corrupt the workgroup's LDS -- checked on the device:
+// such a scene reports rounds = -1 and keeps its seeds).
+extern "C" int pdf_region_grow(int scenes, const int *starts, const int *sizes, int max_points, const float *coord, const float *score,
+                               const int *neighbors, int nsample, const float *stop, int slide_window, int max_rounds, int *mult, int *lists,
+                               float *sim, int *info, void *stream) {
+    if (scenes < 0 || nsample < 1 || max_rounds < 0 || max_points < 0) return PDF_ERR_BAD_ARG;
     if (scenes == 0) return PDF_OK;
-    if (!starts || !sizes || !coord || !score || !neighbors || !stop || !mult || !cand || !sim || !info) return PDF_ERR_BAD_ARG;
-    rg::k_grow<<<scenes, rg::T, 0, static_cast<hipStream_t>(stream)>>>(starts, sizes, coord, score, neighbors, nsample, stop, slide_window, max_rounds,
-                                                                     mult, cand, sim, info);
+    if (!starts || !sizes || !coord || !score || !neighbors || !stop || !mult || !lists || !sim || !info) return PDF_ERR_BAD_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t lds = (size_t)((max_points + 63) / 64 * 2) * 2 * sizeof(unsigned);
+    if (lds <= grow_lds_limit())
+        rg::k_grow<<<scenes, rg::T, lds, st>>>(starts, sizes, coord, score, neighbors, nsample, stop, slide_window, max_rounds, mult, lists, sim, info,
+                                              max_points);
+    else
+        rg::k_grow_scan<<<scenes, rg::T, 0, st>>>(starts, sizes, coord, score, neighbors, nsample, stop, slide_window, max_rounds, mult,
+                                                 reinterpret_cast<unsigned char *>(lists), sim, info);
     return pdf_launch_status();
 }
 
 // The region's node list and neighbour-graph entries (see k_region_rows).  nodes_out (N) int64; eu, ev (N * nsample) int64, ew (N * nsample)
 // float: scene s writes at starts[s] (* nsample); touched (N) bytes out; comp, lab (N) int32 out: every point's own LOCAL id (what the two
-// pdf_graph_forest_dev calls start from); counts (scenes, 4) int32 out; rows_ws: 3 N words of workspace.
+// pdf_graph_forest_dev calls start from); counts (scenes, 4) int32 out; rows_ws: 3 N words of workspace.  lists / grow_info: pdf_region_grow's
+// `lists` and `info` of the SAME batch when it ran its LDS form (largest scene <= pdf_region_grow_list_points()), else both NULL.
 extern "C" int pdf_region_edges(int scenes, const int *starts, const int *sizes, const float *coord, const float *msp, const int *neighbors,
-                                int nsample, const int *mult, long long *nodes_out, long long *eu, long long *ev, float *ew, unsigned char *touched,
-                                int *comp, int *lab, int *counts, void *rows_ws, long n_total, void *stream) {
+                                int nsample, const int *mult, const int *lists, const int *grow_info, long long *nodes_out, long long *eu,
+                                long long *ev, float *ew, unsigned char *touched, int *comp, int *lab, int *counts, void *rows_ws, long n_total,
+                                void *stream) {
     if (scenes < 0 || nsample < 1 || n_total < 0) return PDF_ERR_BAD_ARG;
     if (scenes == 0) return PDF_OK;
     if (!starts || !sizes || !coord || !msp || !neighbors || !mult || !nodes_out || !eu || !ev || !ew || !touched || !comp || !lab || !counts || !rows_ws)
         return PDF_ERR_BAD_ARG;
+    if ((lists == nullptr) != (grow_info == nullptr)) return PDF_ERR_BAD_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
     int *rowcnt = static_cast<int *>(rows_ws);
     float *rowrange = reinterpret_cast<float *>(rowcnt + n_total);
-    rg::k_region_nodes<<<scenes, rg::T, 0, st>>>(starts, sizes, mult, nodes_out, touched, comp, lab, counts);
+    if (lists)   // (the member list pdf_region_grow's LDS form left behind; its scan form leaves none: the caller passes NULL then)
+        rg::k_region_nodes_from_list<<<scenes * rg::RW, rg::T, 0, st>>>(starts, sizes, lists, grow_info, nodes_out, touched, comp, lab, counts);
+    else
+        rg::k_region_nodes<<<scenes, rg::T, 0, st>>>(starts, sizes, mult, nodes_out, touched, comp, lab, counts);
     rg::k_region_rows<false><<<scenes * rg::RW, rg::T, 0, st>>>(starts, sizes, coord, msp, neighbors, nsample, mult, nodes_out, rowcnt, rowrange, eu, ev, ew,
                                                                touched, counts);
     rg::k_region_scan<<<scenes, rg::T, 0, st>>>(starts, rowcnt, counts);
@@ -744,3 +958,6 @@ extern "C" int pdf_region_mask(int scenes, const int *starts, const int *sizes, 
     rg::k_region_mask<<<scenes, rg::T, 0, static_cast<hipStream_t>(stream)>>>(starts, sizes, lab, touched, counts, cnt, mask);
     return pdf_launch_status();
 }
+
+// The largest scene (points) for which pdf_region_grow runs its LDS form -- the form that leaves the ascending member list in `lists`.
+extern "C" long pdf_region_grow_list_points(void) { return (long)(grow_lds_limit() / (2 * 2 * sizeof(unsigned))) * 64 - 64; }

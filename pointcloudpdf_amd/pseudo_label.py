@@ -426,10 +426,11 @@ def get_pseudo_mask_static(coord, seg_logits, offset_host, neighbors, condition_
     score = msp if condition_from == "msp" else ml
     dice = torch.stack([_draw_seeds(num_seed, int(seed_range * n), generator, dev) for n in sizes]).contiguous()
     be._call("region_seeds", B, starts_d, sizes_d, msp if seed_from == "msp" else ml, dice, int(num_seed), mult)
-    cand = torch.empty(N, **u8)
+    lists = torch.empty(2 * N, **i32)
     simbuf = torch.empty(N, **f32)
     ginfo = torch.empty((B, 4), **i32)
-    be._call("region_grow", B, starts_d, sizes_d, coord, score, nn, ns, stop, int(bool(slide_window)), int(max_rounds), mult, cand, simbuf, ginfo)
+    be._call("region_grow", B, starts_d, sizes_d, max(sizes), coord, score, nn, ns, stop, int(bool(slide_window)), int(max_rounds), mult, lists,
+             simbuf, ginfo)
     nodes = torch.empty(N, dtype=torch.int64, device=dev)
     eu = torch.empty(N * ns, dtype=torch.int64, device=dev)
     ev = torch.empty(N * ns, dtype=torch.int64, device=dev)
@@ -439,7 +440,9 @@ def get_pseudo_mask_static(coord, seg_logits, offset_host, neighbors, condition_
     lab = torch.empty(N, **i32)
     counts = torch.empty((B, 4), **i32)
     rows_ws = torch.empty(3 * N, **i32)
-    be._call("region_edges", B, starts_d, sizes_d, coord, msp, nn, ns, mult, nodes, eu, ev, ew, touched, comp, lab, counts, rows_ws, N)
+    listed = max(sizes) <= int(be.lib.pdf_region_grow_list_points())   # (the growth left the ascending member list behind)
+    be._call("region_edges", B, starts_d, sizes_d, coord, msp, nn, ns, mult, lists if listed else None, ginfo if listed else None, nodes, eu, ev, ew,
+             touched, comp, lab, counts, rows_ws, N)
     chosen = torch.empty(N * ns, **u8)
     import ctypes
     starts_h, sizes_h = (ctypes.c_int * B)(*starts), (ctypes.c_int * B)(*sizes)
