@@ -202,3 +202,63 @@ def test_graph_stage_entries_validate_before_any_launch(lib):
     assert lib.pdf_gmm2_1d(5, None, p, p, 200, 1e-6, 1e-6, None) == -1
     assert lib.pdf_gmm2_1d(5, p, p, None, 200, 1e-6, 1e-6, None) == -1
     assert lib.pdf_gmm2_1d(5, p, p, p, 0, 1e-6, 1e-6, None) == -1
+
+
+def test_pseudo_label_pass_entries_validate_before_any_launch(lib):
+    """The device-side pseudo-label pass (pdf_region_*, pdf_graph_forest_batch_dev, pdf_sort_floats_dev, pdf_gmm2_weak_dev) and the TransitionUp
+    head's per-scene row kernels: negative sizes, null pointers, half-given optional pairs and unsupported widths are PDF_ERR_BAD_ARG before
+    anything is launched; zero scenes / zero rows are no-ops."""
+    c_long, c_int, c_void_p, c_double, c_float = ctypes.c_long, ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_float
+    P = c_void_p
+    sig = {
+        "pdf_region_stats": [c_int, P, P, P, P, c_int, c_float, P, P, P, P],
+        "pdf_region_seeds": [c_int, P, P, P, P, c_int, P, P],
+        "pdf_region_grow": [c_int, P, P, c_int, P, P, P, c_int, P, c_int, c_int, P, P, P, P, P],
+        "pdf_region_edges": [c_int, P, P, P, P, P, c_int] + [P] * 12 + [c_long, P],
+        "pdf_region_tree": [c_int, P, P, c_int] + [P] * 9 + [P],
+        "pdf_graph_forest_batch_dev": [c_int, P, P, c_int, P, P, P, P, P, P, c_int, P, P, P, c_long, P],
+        "pdf_sort_floats_dev": [c_int, P, P, P, P, P, P, P],
+        "pdf_gmm2_weak_dev": [c_int] + [P] * 8 + [c_int, c_double, c_double, P],
+        "pdf_region_mask": [c_int] + [P] * 7 + [P],
+        "pdf_scene_sum_rows": [c_int, P, c_int, P, c_long, c_int, P, P],
+        "pdf_scene_repeat_rows": [c_int, P, c_long, c_int, P, c_int, P, P],
+    }
+    for name, argtypes in sig.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = c_int, argtypes
+    buf = (ctypes.c_longlong * 1024)()
+    p = ctypes.cast(buf, c_void_p)
+    hs = (c_int * 2)(0, 50)
+    hn = (c_int * 2)(50, 50)
+    BAD = -1
+    assert lib.pdf_region_stats(0, p, p, p, p, 0, 1.5, p, p, p, None) == 0
+    assert lib.pdf_region_stats(-1, p, p, p, p, 0, 1.5, p, p, p, None) == BAD
+    assert lib.pdf_region_stats(2, p, p, None, p, 0, 1.5, p, p, p, None) == BAD
+    assert lib.pdf_region_seeds(2, p, p, p, p, 0, p, None) == 0                       # no seeds: nothing to do
+    assert lib.pdf_region_seeds(2, p, p, p, p, -1, p, None) == BAD
+    assert lib.pdf_region_seeds(2, p, p, p, None, 10, p, None) == BAD
+    assert lib.pdf_region_grow(0, p, p, 100, p, p, p, 64, p, 1, 100, p, p, p, p, None) == 0
+    assert lib.pdf_region_grow(2, p, p, 100, p, p, p, 0, p, 1, 100, p, p, p, p, None) == BAD       # nsample < 1
+    assert lib.pdf_region_grow(2, p, p, -5, p, p, p, 64, p, 1, 100, p, p, p, p, None) == BAD       # negative largest scene
+    assert lib.pdf_region_grow(2, p, p, 100, p, p, p, 64, p, 1, 100, p, None, p, p, None) == BAD   # no list workspace
+    edges = lambda lists, info: lib.pdf_region_edges(2, p, p, p, p, p, 64, p, lists, info, p, p, p, p, p, p, p, p, p, 100, None)
+    assert edges(p, None) == BAD and edges(None, p) == BAD                            # the growth's list and its info come together
+    assert lib.pdf_region_edges(0, p, p, p, p, p, 64, p, None, None, p, p, p, p, p, p, p, p, p, 100, None) == 0
+    assert lib.pdf_region_edges(2, p, p, p, p, p, 64, p, None, None, p, p, p, p, p, p, p, p, None, 100, None) == BAD   # no row workspace
+    assert lib.pdf_region_tree(2, p, p, 0, p, p, p, p, p, p, p, p, p, None) == BAD
+    assert lib.pdf_graph_forest_batch_dev(0, hs, hn, 64, p, p, p, None, p, p, 4, p, p, p, 1 << 20, None) == 0
+    assert lib.pdf_graph_forest_batch_dev(2, hs, hn, 0, p, p, p, None, p, p, 4, p, p, p, 1 << 20, None) == BAD          # stride < 1
+    assert lib.pdf_graph_forest_batch_dev(2, hs, hn, 64, p, p, p, None, p, p, 1, p, p, p, 1 << 20, None) == BAD         # [nodes, entries] need 2 ints
+    assert lib.pdf_graph_forest_batch_dev(2, hs, hn, 64, p, p, p, None, p, p, 4, p, p, p, 64, None) == BAD              # short workspace
+    assert lib.pdf_graph_forest_batch_dev(2, hs, hn, 64, p, p, p, None, p, p, 4, p, p, c_void_p(p.value + 4), 1 << 20, None) == BAD
+    assert lib.pdf_sort_floats_dev(2, p, p, p, p, p, None, None) == BAD
+    assert lib.pdf_gmm2_weak_dev(2, p, p, p, p, p, p, p, p, 0, 1e-6, 1e-6, None) == BAD            # iters < 1
+    assert lib.pdf_gmm2_weak_dev(2, p, p, p, p, p, p, p, None, 200, 1e-6, 1e-6, None) == BAD
+    assert lib.pdf_region_mask(2, p, p, p, p, p, None, p, None) == BAD
+    assert lib.pdf_region_mask(0, p, p, p, p, p, p, p, None) == 0
+    assert lib.pdf_scene_sum_rows(0, p, 32, p, 32, 1, p, None) == 0
+    assert lib.pdf_scene_sum_rows(2, p, 32, p, 16, 1, p, None) == BAD                 # row stride < c
+    assert lib.pdf_scene_sum_rows(2, None, 32, p, 32, 1, p, None) == BAD
+    assert lib.pdf_scene_repeat_rows(2, p, 0, 32, p, 0, p, None) == 0                 # no rows
+    assert lib.pdf_scene_repeat_rows(2, p, 10, 30, p, 0, p, None) == BAD              # c % 4
+    assert lib.pdf_scene_repeat_rows(0, p, 10, 32, p, 0, p, None) == BAD              # rows but no scene
