@@ -171,7 +171,7 @@ def parse():
                     help="gradient exchange for N > 1: one flat-buffer all-reduce after the backward (engine.FlatGradAllReduce) or "
                          "torch DistributedDataParallel (per-parameter bucket copies: +3 ms per step, measured)")
     ap.add_argument("--no-latency-sweep", action="store_true",
-                    help="skip the look-ahead sweep (serial step time with --prefetch 0 and groups of 1 / 2 / 3 / 4 batches; rank 0, N = 1)")
+                    help="skip the look-ahead sweep (serial step time with --prefetch 0 and groups of 1 / 2 / 3 batches; rank 0, N = 1)")
     ap.add_argument("--no-affinity", action="store_true", help="N > 1: do not pin each rank to its own contiguous share of the host's cores")
     ap.add_argument("--no-n1-reference", action="store_true",
                     help="N > 1 started without torchrun: do not time the one-rank run that efficiency_vs_n1 is quoted against")
@@ -832,10 +832,10 @@ def main():
                 for t, k, v in sorted(rows, key=lambda r: -r[0])[:12]]
 
     # ---- latency: how much look-ahead the number above depends on (FPS is a serial chain per scene).  serial = pre-pass inline on
-    # the main stream, every step pays the whole FPS chain; then groups of 1 / 2 / 3 / 4 batches.
+    # the main stream, every step pays the whole FPS chain; then groups of 1 / 2 / 3 batches.
     if world == 1 and not args.no_latency_sweep and not args.pseudo_label and not strat:
         sweep = {}
-        for Dl, st, wu in ((0, 4, 1), (1, 6, 2), (2, 6, 2), (3, 6, 3), (4, 8, 4)):
+        for Dl, st, wu in ((0, 4, 1), (1, 6, 2), (2, 6, 2), (3, 6, 3)):
             dtl, _, _ = timed(Dl, wu, st)
             sweep["serial" if Dl == 0 else f"group_{Dl}"] = dtl / st * 1e3
         if trainer.captured is not None:   # the same schedule with the step issued from Python (no graph)

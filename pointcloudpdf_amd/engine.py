@@ -302,7 +302,7 @@ class GroupedGeometryLoader:
         self.loader, self.group = loader, max(int(group), 0)
         self.first_group = self.group if first_group is None else max(int(first_group), 1)
         self.device = torch.device(device) if device is not None else None
-        self.submit_delay = max(int(submit_delay), 0)
+        self.submit_delay = max(int(os.environ.get("PDFOPS_SUBMIT_DELAY", submit_delay)), 0)   # (env: A/B knob)
         self.prefetcher = prefetcher if prefetcher is not None else (GeometryPrefetcher(depth=2, threaded=threaded, **plan) if self.group > 0 else None)
         self.inline = None
         if self.group == 0 and prefetcher is None and key == "pdf_geometry" and torch.cuda.is_available():
