@@ -429,8 +429,11 @@ def get_pseudo_mask_static(coord, seg_logits, offset_host, neighbors, condition_
     lists = torch.empty(2 * N, **i32)
     simbuf = torch.empty(N, **f32)
     ginfo = torch.empty((B, 4), **i32)
-    be._call("region_grow", B, starts_d, sizes_d, max(sizes), coord, score, nn, ns, stop, int(bool(slide_window)), int(max_rounds), mult, lists,
-             simbuf, ginfo)
+    # (PDFOPS_GROW_SCAN=1: the growth kernel's first form -- every stage a pass over all points -- which scenes beyond ~600k points fall
+    #  back to; the size handed down only has to exceed what the LDS form can hold.  A/B and test knob.)
+    scan = os.environ.get("PDFOPS_GROW_SCAN") == "1"
+    be._call("region_grow", B, starts_d, sizes_d, (1 << 30) if scan else max(sizes), coord, score, nn, ns, stop, int(bool(slide_window)),
+             int(max_rounds), mult, lists, simbuf, ginfo)
     nodes = torch.empty(N, dtype=torch.int64, device=dev)
     eu = torch.empty(N * ns, dtype=torch.int64, device=dev)
     ev = torch.empty(N * ns, dtype=torch.int64, device=dev)
@@ -440,7 +443,7 @@ def get_pseudo_mask_static(coord, seg_logits, offset_host, neighbors, condition_
     lab = torch.empty(N, **i32)
     counts = torch.empty((B, 4), **i32)
     rows_ws = torch.empty(3 * N, **i32)
-    listed = max(sizes) <= int(be.lib.pdf_region_grow_list_points())   # (the growth left the ascending member list behind)
+    listed = not scan and max(sizes) <= int(be.lib.pdf_region_grow_list_points())   # (the growth left the ascending member list behind)
     be._call("region_edges", B, starts_d, sizes_d, coord, msp, nn, ns, mult, lists if listed else None, ginfo if listed else None, nodes, eu, ev, ew,
              touched, comp, lab, counts, rows_ws, N)
     chosen = torch.empty(N * ns, **u8)

@@ -419,3 +419,46 @@ def test_region_kernels_equal_their_torch_forms():
         std = torch.sqrt(torch.where(present, (c - mean) ** 2, torch.zeros((), dtype=torch.float64, device=dev)).sum() / k)
         big = present & ((c - mean) / std > 2.0)
         assert torch.equal(mask[s0:s0 + n].bool(), big[lab[s0:s0 + n].long()]), b
+
+
+@pytest.mark.gpu
+def test_both_forms_of_the_growth_kernel_give_the_same_regions(monkeypatch):
+    """rg::k_grow (member / candidate lists, LDS bitmaps) against rg::k_grow_scan (every stage a pass over all points: what scenes beyond the
+    LDS form's ~600k points fall back to; PDFOPS_GROW_SCAN=1 forces it): the same masks and round counts on a many-round scene, a
+    random-logit scene, small scenes, and two scenes in one call -- incl. seed lists with repeats (num_seed > the seed range)."""
+    from pointcloudpdf_amd import pseudo_label as pl, synthetic
+
+    g = torch.Generator().manual_seed(17)
+    cases = []
+    c2, l2 = pseudo_label_scene(21, 40000)
+    cases.append((c2, l2 * 0.35, dict(PSEUDO_KW)))                                           # several rounds
+    sc = synthetic.make_scene(30000, scene_id=4, kind="scannet")
+    cases.append((torch.from_numpy(sc["coord"]), 0.3 * torch.randn(30000, 20, generator=g), dict(PSEUDO_KW)))
+    small = synthetic.make_scene(700, scene_id=5, kind="scannet")
+    kw = dict(PSEUDO_KW); kw["num_seed"] = 300                                               # 105 distinct ranks: repeats in the seed list
+    cases.append((torch.from_numpy(small["coord"]), torch.randn(700, 20, generator=g), kw))
+    rounds = []
+    for i, (coord, logits, kw) in enumerate(cases):
+        coord, logits = coord.cuda(), logits.cuda()
+        n = coord.shape[0]
+        nn = pl.radius_neighbors(coord, torch.tensor([n], dtype=torch.int32, device="cuda"), 0.1, 64, raw=True)
+        out = []
+        for scan in ("0", "1"):
+            monkeypatch.setenv("PDFOPS_GROW_SCAN", scan)
+            info = {}
+            m = pl.get_pseudo_mask_static(coord, logits, [n], nn, generator=torch.Generator().manual_seed(i), info=info, **kw)
+            out.append((m.clone(), info["grow"].clone(), info["counts"].clone()))
+        assert torch.equal(out[0][0], out[1][0]), (i, int(out[0][0].sum()), int(out[1][0].sum()))
+        assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2][:, :3], out[1][2][:, :3]), (i, out[0][1].tolist(), out[1][1].tolist())
+        rounds.append(int(out[0][1][0, 0]))
+    assert max(rounds) >= 3, rounds
+    # two scenes of different sizes in one call
+    (ca, la, _), (cb, lb, _) = cases[0], cases[1]
+    coord, logits = torch.cat([ca, cb]).cuda(), torch.cat([la, lb]).cuda()
+    ends = [ca.shape[0], ca.shape[0] + cb.shape[0]]
+    nn = pl.radius_neighbors(coord, torch.tensor(ends, dtype=torch.int32, device="cuda"), 0.1, 64, raw=True)
+    res = []
+    for scan in ("0", "1"):
+        monkeypatch.setenv("PDFOPS_GROW_SCAN", scan)
+        res.append(pl.get_pseudo_mask_static(coord, logits, ends, nn, generator=torch.Generator().manual_seed(9), **PSEUDO_KW))
+    assert torch.equal(res[0], res[1]) and int(res[0].sum()) > 0
