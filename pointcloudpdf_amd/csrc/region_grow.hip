@@ -1,21 +1,28 @@
-// Region growing of the PDF pseudo-label pass (pointcept/recognizers/ours/pointpdf_v1m1_base.py:233-305) and the region's edge list
-// (:309-335, ours/utils.py:7-43) without a host in the loop: one workgroup per scene runs ALL growth rounds.
+// The PDF pseudo-label pass (pointcept/recognizers/ours/pointpdf_v1m1_base.py:188-382, helpers ours/utils.py:7-43) without a host in the
+// loop.  Stage by stage, every scene of the batch per launch:
+//   k_scene_stats (:190-205)   ml_norm, stop = mean - beta * std of the growth score
+//   k_seed_select (:206-207)   the point of a given rank (radix select: stands in for sort + gather), seed multiplicities
+//   k_grow        (:233-305)   ALL growth rounds in one workgroup per scene (k_grow_scan: its first form, fallback for huge scenes)
+//   k_region_nodes[_from_list] / k_region_rows / k_region_scan (:309-335)   the region's node list and the (row, col, weight) entries of
+//                              its neighbour graph -- what scipy's csr_matrix holds upstream
+//   k_tree_edges, k_sort_floats   the spanning forest's entries compacted, their weights sorted (csrc/graph_prune.hip picks the forest,
+//                              fits the mixture and labels the components: pdf_graph_forest_batch_dev, pdf_gmm2_weak_dev)
+//   k_region_mask (:360-380)   component sizes over the touched points, z-score > 2 -> the pseudo mask
+// Every size the next stage needs stays in device memory, and every reduction is done here in a fixed order (see k_scene_stats for why
+// none is left to torch), so the pass can be recorded into the training step's hipGraph.
 //
 // Upstream grows the seed list round by round with host-side control flow: candidates = unique(neighbors[graph]) minus the members,
 // ranked by 0.4 * closeness to the region's centroid + 0.6 * similarity of their score to the region's (mean of the scores between the
 // region's 10 % and 60 % quantiles), the best 40 % join, until the region's mean score passes `stop` or nothing changes -- three host
 // reads per round, ~35 short launches, and the device idles while the host walks through them (rounds 1-4 of this repo kept that
-// shape: 6.9 ms of host-paced work per 150k-point scene).  Everything a round needs is a reduction, a k-th order statistic or a
-// mask update over the scene's points, so one 1024-thread workgroup keeps the whole loop on the device:
+// shape: 6.9 ms of host-paced work per 150k-point scene).  Everything a round needs is a reduction, a k-th order statistic or a set
+// update, so one 1024-thread workgroup keeps the whole loop on the device:
 //   state      mult[i] = multiplicity of point i in the region list (the seed list may hold repeats -- drawn with replacement, :206 --
 //              and upstream's statistics of the first round count them; a grown region is a set: mult in {0, 1})
-//   per round  block reductions in double in a fixed order (length, mean score, centroid), candidate marks (plain stores), the two
-//              quantiles and the 40 % cut by an exact 4-pass radix select over order-preserving keys (LDS histograms, integer adds),
-//              similarity in upstream's operation order with contraction off, mask update
+//   per round  block reductions in double in a fixed order (length, mean score, centroid), candidate marks, the two quantiles and the
+//              40 % cut by an exact 4-pass radix select over order-preserving keys (LDS histograms, integer adds), similarity in
+//              upstream's operation order with contraction off, set update
 // The result is the same SET as upstream's loop whenever no decision sits at a float tie (summation order differs from torch's).
-// k_region_edges then lists the region's nodes in ascending order and the (row, col, weight) entries of its neighbour graph in
-// (row, col) order -- what scipy's csr_matrix holds upstream -- with the counts left in device memory for the graph kernels
-// (csrc/graph_prune.hip: pdf_graph_forest_dev / pdf_gmm2_1d_dev).
 #include "pdfops_common.h"
 
 namespace rg {

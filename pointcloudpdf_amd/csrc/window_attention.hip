@@ -388,7 +388,7 @@ __global__ __launch_bounds__(WB) void k_step2rv_bwd_h(int N, int h, int d, int L
 // table and keeps G in accumulators (D[m = 4*(lane/16) + j][n = lane%16]); LDS atomics are needed once per wave at the end.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Elements per lane and trip of the two kernels below (tuning knob, `PDFOPS_WA_UE=<n> python -m pointcloudpdf_amd.build`).  Measured on
-// the 2 x 80k-point ST-v1m1 step (tools/wa_ue_ab.sh, profiles/r03_wa_ue_ab.txt): 2 -> 1.81 / 1.01 ms per launch (dot_prod backward /
+// the 2 x 80k-point ST-v1m1 step (A/B of round 3, profiles/r03_wa_ue_ab.txt): 2 -> 1.81 / 1.01 ms per launch (dot_prod backward /
 // step2 backward), 4 -> 2.34 / 1.10, 8 -> 2.24 / 1.08: more loads in flight per trip do not pay, the kernels are not waiting for their
 // gathers.
 #ifndef PDF_WA_UE

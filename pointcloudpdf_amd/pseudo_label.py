@@ -24,6 +24,7 @@ state, tol 1e-3, 100 iterations).  Both converge to the same two components on w
 fixture scenes are identical (tests/test_pseudo_label.py::test_pseudo_mask_on_gpu_batch, exact against the reference fixture) -- but the
 cut ``mean - 2 * covariance`` can move near sklearn's looser convergence boundary; the host path (CPU tensors) is the upstream-exact one.
 """
+import ctypes
 import os
 
 import numpy as np
@@ -409,6 +410,8 @@ def get_pseudo_mask_static(coord, seg_logits, offset_host, neighbors, condition_
     starts = [0] + ends[:-1]
     sizes = [e - s for s, e in zip(starts, ends)]
     B = len(ends)
+    if B == 0 or N == 0:
+        return torch.zeros(N, dtype=torch.bool, device=dev)
     i32 = dict(dtype=torch.int32, device=dev)
     f32 = dict(dtype=torch.float32, device=dev)
     u8 = dict(dtype=torch.uint8, device=dev)
@@ -447,7 +450,6 @@ def get_pseudo_mask_static(coord, seg_logits, offset_host, neighbors, condition_
     be._call("region_edges", B, starts_d, sizes_d, coord, msp, nn, ns, mult, lists if listed else None, ginfo if listed else None, nodes, eu, ev, ew,
              touched, comp, lab, counts, rows_ws, N)
     chosen = torch.empty(N * ns, **u8)
-    import ctypes
     starts_h, sizes_h = (ctypes.c_int * B)(*starts), (ctypes.c_int * B)(*sizes)
     ws1_bytes = sum((int(be.lib.pdf_graph_forest_workspace_bytes(n, n * ns, n)) + 7) & ~7 for n in sizes)
     ws = torch.empty((ws1_bytes // 8 + 1,), dtype=torch.int64, device=dev)
