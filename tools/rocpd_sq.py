@@ -20,7 +20,7 @@ import sqlite3
 import sys
 
 HOT = re.compile(r"fl::k_[bp]\d|flm::k_[bp]\d|rl2::k_|rl::k_|td::k_|sg::k_seg|pw::k_bn|fl::k_colsum|fl::k_bn_finalize|kg::k_grid_query|k_fps_mw|"
-                 r"k_dot3|k_step|gather|grouping|interp|agg_|sub_")
+                 r"k_dot3|k_step|gather|grouping|interp|agg_|sub_|wb::k_|ln::k_|k_seg_softmax|rg::k_|gp::k_|k_grid_radius")
 
 
 def short(name):
