@@ -462,3 +462,31 @@ def test_both_forms_of_the_growth_kernel_give_the_same_regions(monkeypatch):
         monkeypatch.setenv("PDFOPS_GROW_SCAN", scan)
         res.append(pl.get_pseudo_mask_static(coord, logits, ends, nn, generator=torch.Generator().manual_seed(9), **PSEUDO_KW))
     assert torch.equal(res[0], res[1]) and int(res[0].sum()) > 0
+
+
+@pytest.mark.gpu
+def test_static_pass_on_a_batch_of_many_small_scenes():
+    """20 scenes in one call (more than one launch of the batched labelling kernel holds: 16) give the masks of the scenes one by one --
+    ragged sizes, the same generator order."""
+    from pointcloudpdf_amd import pseudo_label as pl, synthetic
+
+    g = torch.Generator().manual_seed(23)
+    sizes = [1500 + 137 * (i % 7) for i in range(20)]
+    scenes = []
+    for i, n in enumerate(sizes):
+        sc = synthetic.make_scene(n, scene_id=40 + i, kind="scannet")
+        scenes.append((torch.from_numpy(sc["coord"]), 0.5 * torch.randn(n, 20, generator=g)))
+    coord = torch.cat([c for c, _ in scenes]).cuda()
+    logits = torch.cat([l for _, l in scenes]).cuda()
+    ends = np.cumsum(sizes).tolist()
+    nn = pl.radius_neighbors(coord, torch.tensor(ends, dtype=torch.int32, device="cuda"), 0.1, 64, raw=True)
+    info = {}
+    both = pl.get_pseudo_mask_static(coord, logits, ends, nn, generator=torch.Generator().manual_seed(3), info=info, **PSEUDO_KW)
+    assert info["grow"].shape[0] == 20 and int(info["grow"][:, 0].min()) >= 0
+    gen = torch.Generator().manual_seed(3)
+    one = []
+    for (c, l) in scenes:
+        n = c.shape[0]
+        nn1 = pl.radius_neighbors(c.cuda(), torch.tensor([n], dtype=torch.int32, device="cuda"), 0.1, 64)
+        one.append(pl.get_pseudo_mask_static(c.cuda(), l.cuda(), [n], nn1, generator=gen, **PSEUDO_KW))
+    assert torch.equal(both, torch.cat(one)) and int(both.sum()) > 0
