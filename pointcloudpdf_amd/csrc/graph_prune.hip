@@ -224,7 +224,7 @@ __global__ __launch_bounds__(T) void k_forest_batch(const ForestBatch b, int whe
 
 // ---- two-component 1-D Gaussian mixture -----------------------------------------------------------------------------------------
 constexpr int TG = 256;
-constexpr int GMM_R = 16;   // values per thread the mixture fit keeps in registers (m <= GMM_R * TG: the register form)
+constexpr int GMM_R = 32;   // values per thread the mixture fit keeps in registers (m <= GMM_R * TG = 8,192; more: re-read from memory)
 
 template <int K>
 __device__ inline void block_sum(double (&val)[K], double *lds) {   // -> every thread holds the sums (fixed order: reproducible)
@@ -259,7 +259,7 @@ __device__ inline double quantile_sorted(const float *xs, int m, double q) {   /
 struct Fit { double mu0, mu1, var0, var1; };   // (what every thread of the workgroup holds when the fit returns)
 
 __device__ __forceinline__ Fit gmm2_fit(int m, const float *__restrict__ xs, double *resp, double *out, int iters, double tol, double reg,
-                                        double *lds /* [(TG / 64) * 4] */) {
+                                        double *lds /* [(TG / 64) * 7] */) {
     const int t = threadIdx.x;
     if (m < 2 || xs[m - 1] == xs[0]) {
         double s[1] = {0.0};
@@ -279,149 +279,79 @@ __device__ __forceinline__ Fit gmm2_fit(int m, const float *__restrict__ xs, dou
     double mu0 = q3 > q1 ? q1 : (double)xs[0], mu1 = q3 > q1 ? q3 : (double)xs[m - 1];
     double var0 = reg, var1 = reg, pi0 = 0.5, pi1 = 0.5, prev = -INFINITY, ll = 0.0;
     int it = 0;
-    if (m <= GMM_R * TG) {
-        // (round 5) up to GMM_R values per thread: the values and their responsibilities stay in registers for all iterations (the pass's
-        // trees have ~2,400 edges).  Thread t owns i = t, t + TG, ... as the loops of the general form below do: same sums, same order,
-        // same bits -- without the two L2 round trips per iteration (523 -> ~200 us per call on the pass's trees).
-        float xr[GMM_R];
-        double r0[GMM_R], r1[GMM_R];
+    // One pass over the values and ONE block reduction per EM iteration (round 5; rounds 4-5 made three of each: the M-step's sums, the
+    // variances around the new means, the E-step's log-likelihood -- and kept the responsibilities in a scratch array between them): the
+    // E-step accumulates, with the responsibilities it has just computed, what the NEXT M-step needs -- sum r, sum r (x - c), sum r (x - c)^2
+    // around the CURRENT means c -- so  mu' = c + sum r (x - c) / n  and  var' = sum r (x - c)^2 / n - (mu' - c)^2  (= sum r (x - mu')^2 / n:
+    // the shift keeps the subtraction harmless, c and mu' differ by the step of one iteration).  Same iteration sequence and stopping rule.
+    // Values: up to GMM_R per thread in registers (the pass's trees have ~2,400 edges), else re-read from xs (L2-resident).
+    const bool inreg = m <= GMM_R * TG;
+    float xr[GMM_R];
 #pragma unroll
-        for (int k = 0; k < GMM_R; ++k) xr[k] = t + k * TG < m ? xs[t + k * TG] : 0.f;
-        for (int it2 = 0; it2 < 10; ++it2) {   // 2-means from the quartiles
-            double s[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int k = 0; k < GMM_R; ++k)
-                if (t + k * TG < m) {
-                    const double x = (double)xr[k];
-                    const int a = fabs(x - mu1) < fabs(x - mu0);
-                    s[a] += 1.0;
-                    s[2 + a] += x;
-                }
-            block_sum<4>(s, lds);
-            if (s[0] == 0.0 || s[1] == 0.0) break;
-            mu0 = s[2] / s[0];
-            mu1 = s[3] / s[1];
-        }
-#pragma unroll
-        for (int k = 0; k < GMM_R; ++k) {
-            const double x = (double)xr[k];
-            const int a = fabs(x - mu1) < fabs(x - mu0);
-            r0[k] = a ? 0.0 : 1.0;
-            r1[k] = a ? 1.0 : 0.0;
-        }
-        for (; it < iters; ++it) {
-            double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < GMM_R; ++k) xr[k] = (inreg && t + k * TG < m) ? xs[t + k * TG] : 0.f;
+    auto for_each = [&](auto &&f) {   // thread t owns i = t, t + TG, ... in this order (fixed summation order)
+        if (inreg) {
 #pragma unroll
             for (int k = 0; k < GMM_R; ++k)
-                if (t + k * TG < m) {
-                    const double x = (double)xr[k];
-                    s[0] += r0[k];
-                    s[1] += r1[k];
-                    s[2] += r0[k] * x;
-                    s[3] += r1[k] * x;
-                }
-            block_sum<4>(s, lds);
-            const double n0 = s[0] + 1e-300, n1 = s[1] + 1e-300;
-            pi0 = n0 / (double)m;
-            pi1 = n1 / (double)m;
-            mu0 = s[2] / n0;
-            mu1 = s[3] / n1;
-            double q[2] = {0.0, 0.0};
-#pragma unroll
-            for (int k = 0; k < GMM_R; ++k)
-                if (t + k * TG < m) {
-                    const double x = (double)xr[k];
-                    q[0] += r0[k] * (x - mu0) * (x - mu0);
-                    q[1] += r1[k] * (x - mu1) * (x - mu1);
-                }
-            block_sum<2>(q, lds);
-            var0 = q[0] / n0 + reg;
-            var1 = q[1] / n1 + reg;
-            const double c0 = -0.5 * log(2.0 * M_PI * var0) + log(pi0), c1 = -0.5 * log(2.0 * M_PI * var1) + log(pi1);
-            double l[1] = {0.0};
-#pragma unroll
-            for (int k = 0; k < GMM_R; ++k)
-                if (t + k * TG < m) {
-                    const double x = (double)xr[k];
-                    const double p0 = c0 - 0.5 * (x - mu0) * (x - mu0) / var0, p1 = c1 - 0.5 * (x - mu1) * (x - mu1) / var1;
-                    const double mx = fmax(p0, p1);
-                    const double lse = mx + log(exp(p0 - mx) + exp(p1 - mx));
-                    r0[k] = exp(p0 - lse);
-                    r1[k] = exp(p1 - lse);
-                    l[0] += lse;
-                }
-            block_sum<1>(l, lds);
-            ll = l[0] / (double)m;
-            if (fabs(ll - prev) < tol) {
-                ++it;
-                break;
-            }
-            prev = ll;
+                if (t + k * TG < m) f((double)xr[k]);
+        } else {
+            for (int i = t; i < m; i += TG) f((double)xs[i]);
         }
-    } else {
-        for (int it2 = 0; it2 < 10; ++it2) {   // 2-means from the quartiles
-            double s[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int i = t; i < m; i += TG) {
-                const double x = (double)xs[i];
-                const int a = fabs(x - mu1) < fabs(x - mu0);   // (argmin: the first on a tie)
-                s[a] += 1.0;
-                s[2 + a] += x;
-            }
-            block_sum<4>(s, lds);
-            if (s[0] == 0.0 || s[1] == 0.0) break;
-            mu0 = s[2] / s[0];
-            mu1 = s[3] / s[1];
-        }
-        for (int i = t; i < m; i += TG) {
-            const double x = (double)xs[i];
-            const int a = fabs(x - mu1) < fabs(x - mu0);
-            resp[2 * i] = a ? 0.0 : 1.0;
-            resp[2 * i + 1] = a ? 1.0 : 0.0;
-        }
-        for (; it < iters; ++it) {
-            double s[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int i = t; i < m; i += TG) {
-                const double x = (double)xs[i], r0 = resp[2 * i], r1 = resp[2 * i + 1];
-                s[0] += r0;
-                s[1] += r1;
-                s[2] += r0 * x;
-                s[3] += r1 * x;
-            }
-            block_sum<4>(s, lds);
-            const double n0 = s[0] + 1e-300, n1 = s[1] + 1e-300;
-            pi0 = n0 / (double)m;
-            pi1 = n1 / (double)m;
-            mu0 = s[2] / n0;
-            mu1 = s[3] / n1;
-            double q[2] = {0.0, 0.0};
-            for (int i = t; i < m; i += TG) {
-                const double x = (double)xs[i];
-                q[0] += resp[2 * i] * (x - mu0) * (x - mu0);
-                q[1] += resp[2 * i + 1] * (x - mu1) * (x - mu1);
-            }
-            block_sum<2>(q, lds);
-            var0 = q[0] / n0 + reg;
-            var1 = q[1] / n1 + reg;
-            const double c0 = -0.5 * log(2.0 * M_PI * var0) + log(pi0), c1 = -0.5 * log(2.0 * M_PI * var1) + log(pi1);
-            double l[1] = {0.0};
-            for (int i = t; i < m; i += TG) {
-                const double x = (double)xs[i];
-                const double p0 = c0 - 0.5 * (x - mu0) * (x - mu0) / var0, p1 = c1 - 0.5 * (x - mu1) * (x - mu1) / var1;
-                const double mx = fmax(p0, p1);
-                const double lse = mx + log(exp(p0 - mx) + exp(p1 - mx));
-                resp[2 * i] = exp(p0 - lse);
-                resp[2 * i + 1] = exp(p1 - lse);
-                l[0] += lse;
-            }
-            block_sum<1>(l, lds);
-            ll = l[0] / (double)m;
-            if (fabs(ll - prev) < tol) {
-                ++it;
-                break;
-            }
-            prev = ll;
-        }
+    };
+    for (int it2 = 0; it2 < 10; ++it2) {   // 2-means from the quartiles
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        for_each([&](double x) {
+            const int a = fabs(x - mu1) < fabs(x - mu0);   // (argmin: the first on a tie)
+            s[a] += 1.0;
+            s[2 + a] += x;
+        });
+        block_sum<4>(s, lds);
+        if (s[0] == 0.0 || s[1] == 0.0) break;
+        mu0 = s[2] / s[0];
+        mu1 = s[3] / s[1];
     }
+    double c0 = mu0, c1 = mu1;   // the shifts of the running sums
+    double S[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for_each([&](double x) {     // hard assignment = the responsibilities the first M-step starts from
+        const int a = fabs(x - mu1) < fabs(x - mu0);
+        const double r0 = a ? 0.0 : 1.0, r1 = a ? 1.0 : 0.0, d0 = x - c0, d1 = x - c1;
+        S[0] += r0; S[1] += r1; S[2] += r0 * d0; S[3] += r1 * d1; S[4] += r0 * d0 * d0; S[5] += r1 * d1 * d1;
+    });
+    block_sum<7>(S, lds);
+    for (; it < iters; ++it) {
+        const double n0 = S[0] + 1e-300, n1 = S[1] + 1e-300;
+        pi0 = n0 / (double)m;
+        pi1 = n1 / (double)m;
+        mu0 = c0 + S[2] / n0;
+        mu1 = c1 + S[3] / n1;
+        var0 = S[4] / n0 - (mu0 - c0) * (mu0 - c0) + reg;
+        var1 = S[5] / n1 - (mu1 - c1) * (mu1 - c1) + reg;
+        const double k0 = -0.5 * log(2.0 * M_PI * var0) + log(pi0), k1 = -0.5 * log(2.0 * M_PI * var1) + log(pi1);
+        double T[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for_each([&](double x) {
+            const double d0 = x - mu0, d1 = x - mu1;
+            const double p0 = k0 - 0.5 * d0 * d0 / var0, p1 = k1 - 0.5 * d1 * d1 / var1;
+            // log-sum-exp and the two responsibilities from ONE exponential: with e = exp(-|p0 - p1|), lse = max + log(1 + e), the larger
+            // responsibility is 1 / (1 + e) and the smaller e / (1 + e) (rounds 4-5 evaluated four exponentials and a logarithm per value:
+            // the fit is issue-bound on one CU's double-precision pipes, 8 us per iteration at 2,400 values)
+            const double mx = fmax(p0, p1), e = exp(-fabs(p0 - p1)), inv = 1.0 / (1.0 + e);
+            const double lse = mx + log1p(e);
+            const double rb = inv, rs = e * inv;
+            const double r0 = p0 >= p1 ? rb : rs, r1 = p0 >= p1 ? rs : rb;
+            T[0] += r0; T[1] += r1; T[2] += r0 * d0; T[3] += r1 * d1; T[4] += r0 * d0 * d0; T[5] += r1 * d1 * d1; T[6] += lse;
+        });
+        block_sum<7>(T, lds);
+        ll = T[6] / (double)m;
+        if (fabs(ll - prev) < tol) {
+            ++it;
+            break;
+        }
+        prev = ll;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) S[k] = T[k];
+        c0 = mu0; c1 = mu1;
+    }
+    (void)resp;   // (scratch of the earlier forms: kept in the signature)
     if (t == 0) {
         out[0] = mu0;
         out[1] = mu1;
@@ -437,7 +367,7 @@ __device__ __forceinline__ Fit gmm2_fit(int m, const float *__restrict__ xs, dou
 
 __global__ __launch_bounds__(TG) void k_gmm2(int m, const float *__restrict__ xs, double *resp, double *out, int iters, double tol,
                                              double reg, const int *__restrict__ m_dev = nullptr) {
-    __shared__ double lds[(TG / 64) * 4];
+    __shared__ double lds[(TG / 64) * 7];
     if (m_dev) m = min(m, *m_dev);   // (m by value = the capacity of xs / resp)
     gmm2_fit(m, xs, resp, out, iters, tol, reg, lds);
 }
@@ -448,7 +378,7 @@ __global__ __launch_bounds__(TG) void k_gmm2(int m, const float *__restrict__ xs
 __global__ __launch_bounds__(TG) void k_gmm2_weak(const int *__restrict__ starts, const int *__restrict__ sizes, const int *__restrict__ tdev,
                                                   const float *__restrict__ xs, const float *__restrict__ tw, double *resp, double *fit,
                                                   unsigned char *__restrict__ weak, int iters, double tol, double reg) {
-    __shared__ double lds[(TG / 64) * 4];
+    __shared__ double lds[(TG / 64) * 7];
     const int s = blockIdx.x;
     const long s0 = starts[s];
     const int n = sizes[s], m = min(tdev[2 * s + 1], n);
