@@ -235,6 +235,8 @@ def _scene_rows_kernels(x):
     """The backend's per-scene row kernels (csrc/scene_rows.hip) for float32 device rows, else None (host tensors: the torch composition)."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 4 == 0):
         return None
+    if os.environ.get("PDFOPS_HEAD_TORCH_SUMS") == "1":   # rounds 1-4: torch's sum(0) per scene (tools/probes/replay_reduction_probe.py shows what
+        return None                                        # that does to replays of a captured step from 512 rows per scene on)
     be = _native.backend_for(x)
     return be if "scene_sum_rows" in getattr(be, "_fn", {}) else None
 
