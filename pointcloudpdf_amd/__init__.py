@@ -3,3 +3,16 @@
 Python host code on PyTorch-ROCm over a C-ABI HIP library (include/pdfops.h, csrc/*.hip, gfx950 only).
 """
 __version__ = "0.1.0"
+
+import os as _os
+
+# ROCm's "graph packet capture" (hipGraph launches from pre-recorded AQL packets, on by default in ROCm 7.x) is switched OFF for processes
+# that use this package, unless the environment says otherwise:
+#  * correctness: with it on, a memset node inside a captured graph is replayed with stale arguments once other device work ran in
+#    between -- torch's multi-workgroup reductions (semaphore cleared by hipMemsetAsync) then return garbage inside a captured training
+#    step (tools/probes/replay_reduction_probe.py: 11 of 12 replays wrong with it on, 0 of 12 with it off; docs/NOTEBOOK.md, round 5).
+#    The captured step of this package no longer contains such nodes either way.
+#  * speed: the captured step replays 2-3 % faster with it off (15.59 -> 15.10 ms per 2 x 100k-point step on the driver's command): the
+#    pre-recorded packets cost the device more per dependent node than the runtime's ordinary dispatch, and the host has the time.
+# The runtime reads the variable when HIP initialises (the first device call), so importing this package before any device work is enough.
+_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
