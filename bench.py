@@ -786,6 +786,7 @@ def main():
                            + (f"; graph capture failed: {trainer.capture_error}" if trainer.capture_error else ""))),
             **({"loss_scaling": "dynamic (engine.DeviceGradScaler: torch GradScaler's policy, decisions on the device)"} if scaler is not None else {}),
             "cpu_affinity": affinity,
+            "runtime_knobs": __import__("pointcloudpdf_amd").RUNTIME_KNOBS,   # (the ROCm graph-replay switch the package sets at import, and whether it could still take effect)
             "geometry_prefetch_group": (st_ahead if strat else D),
             "host_enqueue_ms_per_step": sched.enqueue_s / args.steps * 1e3,   # < ms_per_step: the host runs ahead, the device is the bound
             "hbm_peak_gib": torch.cuda.max_memory_allocated(dev) / 2.0 ** 30,   # (caching-allocator peak of this rank over the whole run)

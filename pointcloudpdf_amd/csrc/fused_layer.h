@@ -219,3 +219,10 @@ bool supported_l1(int nsample, int c);   // level 1 (C = 32, nsample 8): two poi
 void launch_b2_l1(const fl::LayerArgs &A, int grid, hipStream_t s);
 void launch_b3_l1(const fl::LayerArgs &A, int grid, hipStream_t s);
 }  // namespace flm
+
+namespace fls {
+// slab form (fused_layer_slab.hip): one wave = one 64-channel slab of one point; workgroups of max(4, C / 64) waves, partial rows = grid
+bool enabled(int c);                                  // PDFOPS_PT_SLAB (default: C = 256, 512)
+int b3_grid(long n, int c, int max_rows);
+void launch_b3(const fl::LayerArgs &A, int c, int grid, hipStream_t s);   // closed-form geometry backward only (G3 is not written)
+}  // namespace fls

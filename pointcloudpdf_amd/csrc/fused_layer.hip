@@ -1205,13 +1205,16 @@ int backward_impl(LayerArgs A, float *sums, const int *inv_off, const int *inv_e
     const int gb3 = mfma ? g3 : (int)std::min<long>(grid, (long)grid * b2_width<C>() / b3_pwidth<C>());   // (fl::k_b3's rows are 16 wider than S3)
     static const bool l1_b3 = [] { const char *v = getenv("PDFOPS_PT_L1_B3"); return !(v && v[0] == '0'); }();   // (A/B: 0 = fl::k_b3 at level 1)
     const bool l1b3 = l1 && l1_b3;
-    if (mfma) flm::launch_b3(A, C, g3, s);
+    static const bool closed_on = [] { const char *v = getenv("PDFOPS_BNP_CLOSED"); return !(v && v[0] == '0'); }();
+    const bool closed = closed_on && A.mom != nullptr;
+    // slab form (fused_layer_slab.hip: wave = 64-channel slab): needs the closed-form geometry backward (it does not write G3)
+    const bool slab3 = mfma && closed && fls::enabled(C);
+    if (slab3) { g3 = fls::b3_grid(A.N, C, (int)std::min<long>(1 << 20, (long)grid * b2_width<C>() / b3_pwidth<C>())); fls::launch_b3(A, C, g3, s); }
+    else if (mfma) flm::launch_b3(A, C, g3, s);
     else if (l1b3) flm::launch_b3_l1(A, g3l, s);   // (the partial rows of fl::k_b3<32, 8>)
     else k_b3<C, K><<<gb3, 64 * WPB, lds, s>>>(A);
     // column sums of B3's rows -> S3; with the kNN table's coordinate sums at hand one more block of the SAME launch finishes the geometry
     // branch's BatchNorm + Linear(3, 3) backward in closed form (S4): no B4 pass, no second reducer (PDFOPS_BNP_CLOSED=0: B4, as before)
-    static const bool closed_on = [] { const char *v = getenv("PDFOPS_BNP_CLOSED"); return !(v && v[0] == '0'); }();
-    const bool closed = closed_on && A.mom != nullptr;
     BnpClosed bc = none;
     if (closed) {
         bc.mom = A.mom; bc.Wp1 = A.Wp1; bc.bp1 = A.bp1; bc.sp = A.sp; bc.mean = A.mean; bc.rstd = A.rstd; bc.rows = (double)rows;

@@ -407,13 +407,12 @@ extern "C" int pdf_graph_forest(long n, int E, const long long *u, const long lo
     int *slot = reinterpret_cast<int *>(best + n_nodes);
     int *su = slot + n, *sv = su + E, *gcomp = sv + E, *parent = gcomp + n_nodes, *rootof = parent + n_nodes;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // The LDS form needs up to LDS_NODES * 12 bytes of dynamic LDS (> the 64 KB default limit): raised ONCE per process to the maximum any
+    // The LDS form needs up to LDS_NODES * 12 bytes of dynamic LDS (> the 64 KB default limit): raised ONCE per device to the maximum any
     // call can ask for (a per-call value would race between host threads: one lowers the limit another is about to launch with), result
     // checked -- where the runtime refuses, every call takes the global-memory form.
-    static const bool lds_form = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(&gp::k_forest<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)(gp::LDS_NODES * (sizeof(gp::u64) + sizeof(int)))) == hipSuccess;
-    }();
+    static PdfLdsLimit lds_site;
+    const bool lds_form = pdf_lds_limit_raised(lds_site, reinterpret_cast<const void *>(&gp::k_forest<true>),
+                                               (int)(gp::LDS_NODES * (sizeof(gp::u64) + sizeof(int))));
     if (n_nodes <= gp::LDS_NODES && (lds_form || (size_t)n_nodes * (sizeof(gp::u64) + sizeof(int)) <= 64 * 1024)) {
         const size_t lds = (size_t)n_nodes * (sizeof(gp::u64) + sizeof(int));
         gp::k_forest<true><<<1, gp::T, lds, s>>>(n, E, u, v, w, active, nodes, n_nodes, comp, slot, su, sv, best, gcomp, parent, rootof, chosen);
@@ -446,10 +445,9 @@ extern "C" int pdf_graph_forest_dev(long n, int E, const long long *u, const lon
     int *slot = reinterpret_cast<int *>(best + n_nodes);
     int *su = slot + n, *sv = su + E, *gcomp = sv + E, *parent = gcomp + n_nodes, *rootof = parent + n_nodes;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static const bool lds_form = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(&gp::k_forest<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)(gp::LDS_NODES * (sizeof(gp::u64) + sizeof(int)))) == hipSuccess;
-    }();
+    static PdfLdsLimit lds_site;
+    const bool lds_form = pdf_lds_limit_raised(lds_site, reinterpret_cast<const void *>(&gp::k_forest<true>),
+                                               (int)(gp::LDS_NODES * (sizeof(gp::u64) + sizeof(int))));
     if (lds_form) {
         const size_t lds = (size_t)std::min(n_nodes, gp::LDS_NODES) * (sizeof(gp::u64) + sizeof(int));
         gp::k_forest<true><<<1, gp::T, lds, s>>>(n, E, u, v, w, active, nodes, n_nodes, comp, slot, su, sv, best, gcomp, parent, rootof, chosen, dev, 1);
@@ -496,10 +494,9 @@ extern "C" int pdf_graph_forest_batch_dev(int scenes, const int *starts, const i
     if (scenes == 0) return PDF_OK;
     if (!starts || !sizes || !u || !v || !nodes || !dev || !comp || !workspace || (reinterpret_cast<uintptr_t>(workspace) & 7)) return PDF_ERR_BAD_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static const bool lds_form = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(&gp::k_forest_batch<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)(gp::LDS_NODES * (sizeof(gp::u64) + sizeof(int)))) == hipSuccess;
-    }();
+    static PdfLdsLimit lds_site;
+    const bool lds_form = pdf_lds_limit_raised(lds_site, reinterpret_cast<const void *>(&gp::k_forest_batch<true>),
+                                               (int)(gp::LDS_NODES * (sizeof(gp::u64) + sizeof(int))));
     long off = 0;
     for (int at = 0; at < scenes; at += gp::FOREST_BATCH) {
         gp::ForestBatch b;

@@ -2,14 +2,32 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/pdfops.h"
 
 #define PDF_WAVE 64
+#define PDF_MAX_DEVICES_LDS 64
 
 // Launch-status helper: report a launch-configuration error as the entry point's return value.
 static inline int pdf_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PDF_OK : (int)e;
+}
+
+// Raised dynamic-LDS limit of one kernel, remembered PER DEVICE (the attribute belongs to the device's code object: a process that drives
+// several GPUs must set it on each; rounds 1-5 set it once per process).  `state` = the call site's own table (zero-initialised static):
+// 0 = not asked yet on this device, 1 = accepted, 2 = refused.  Racing first calls on one device both set the same value: harmless.
+struct PdfLdsLimit { std::atomic<int> state[PDF_MAX_DEVICES_LDS]; };
+static inline bool pdf_lds_limit_raised(PdfLdsLimit &site, const void *kernel, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PDF_MAX_DEVICES_LDS) return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+    int st = site.state[dev].load(std::memory_order_acquire);
+    if (st == 0) {
+        st = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 1 : 2;
+        if (st == 2) (void)hipGetLastError();
+        site.state[dev].store(st, std::memory_order_release);
+    }
+    return st == 1;
 }
 
 static inline int pdf_divup(long a, long b) { return (int)((a + b - 1) / b); }

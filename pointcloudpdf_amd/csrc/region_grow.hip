@@ -877,12 +877,9 @@ extern "C" int pdf_region_seeds(int scenes, const int *starts, const int *sizes,
 // Dynamic LDS the growth kernel may ask for: 150 KB (+ ~2 KB static; the CU has 160 KB) once the runtime accepted the raised limit, else the
 // 64 KB default minus the static part.
 static size_t grow_lds_limit() {
-    static const size_t limit = [] {
-        constexpr size_t LDS_MAX = 150 * 1024;
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(&rg::k_grow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) == hipSuccess
-                   ? LDS_MAX : (size_t)60 * 1024;
-    }();
-    return limit;
+    constexpr size_t LDS_MAX = 150 * 1024;
+    static PdfLdsLimit site;   // per device (pdfops_common.h)
+    return pdf_lds_limit_raised(site, reinterpret_cast<const void *>(&rg::k_grow), (int)LDS_MAX) ? LDS_MAX : (size_t)60 * 1024;
 }
 
 // Region growing of every scene of a batch, all rounds on the device.  starts / sizes (scenes) int32: the scenes' point ranges; neighbors

@@ -89,6 +89,16 @@ def release_autograd_state(step):
             per_module[key] = None
 
 
+def graph_dot_census(text):
+    """Node kinds in a hipGraphDebugDotPrint dump: every node statement carries a label; memset / memcpy nodes name themselves in it,
+    the rest are kernels (their label is the kernel's name) or empty / event nodes."""
+    import re
+    labels = re.findall(r'\[[^\]]*label="([^"]*)"', text)
+    memset = sum(1 for l in labels if re.search(r"memset", l, re.I))
+    memcpy = sum(1 for l in labels if re.search(r"memcpy", l, re.I))
+    return {"nodes": len(labels), "memset": memset, "memcpy": memcpy, "kernel": len(labels) - memset - memcpy}
+
+
 class CapturedStep:
     """Forward + backward of an ``OpenSegStep`` captured ONCE into a hipGraph and replayed per batch (the step is ~1,200 dependent
     launches: issued from Python it is host-bound, replayed it costs the host one call).  Everything the captured kernels read lives
@@ -104,8 +114,10 @@ class CapturedStep:
 
     KEYS = ("coord", "feat", "offset", "segment")
 
-    def __init__(self, step, batch, geom=None, warmup=2, autocast=None, loss_scale=1.0, stream=None):
-        """``stream``: the stream to capture on (default: a new one) -- e.g. a CU-masked stream (``_native.cu_masked_stream``), see TrainStep.
+    def __init__(self, step, batch, geom=None, warmup=2, autocast=None, loss_scale=1.0, stream=None, debug_graph=False):
+        """``debug_graph``: keep the captured hipGraph inspectable (``node_census``: the rule "no memset node inside a captured step" is
+        checked by walking the graph, tests/test_gpu_model.py).
+        ``stream``: the stream to capture on (default: a new one) -- e.g. a CU-masked stream (``_native.cu_masked_stream``), see TrainStep.
         ``autocast``: torch.float16 / torch.bfloat16 -> the forward is captured under torch.autocast (the path then runs its
         reduced-precision products, dense.fp32_path).  ``loss_scale``: a ``DeviceGradScaler`` (the reference's AMP loop,
         engines/train.py:343-355: the captured backward starts from ``loss * scale`` with the scale read from DEVICE memory at replay time,
@@ -154,6 +166,9 @@ class CapturedStep:
         self.stream = side   # an EAGER step of the same module between replays is fastest on this stream (see the comment above: the
         #                      parameters' AccumulateGrad nodes stay bound to it for as long as the captured autograd graph lives)
         self.graph, self.graph2, self.mask_fn = torch.cuda.CUDAGraph(), None, None
+        self._census = None
+        if debug_graph:
+            self.graph.enable_debug_mode()
         rec = getattr(step, "recognizer", None)
         fn = getattr(rec, "pseudo_mask_fn", None)
         if fn is None or getattr(fn, "capturable", False):   # (the sync-free pseudo-label pass is recorded like any other stage)
@@ -168,6 +183,22 @@ class CapturedStep:
             for b, v in zip(buffers, saved):
                 b.copy_(v)
         release_autograd_state(step)
+
+    def node_census(self):
+        """Kinds of the nodes of the captured graph, read from the runtime's own dump of it (hipGraphDebugDotPrint through
+        ``CUDAGraph.debug_dump``; needs ``debug_graph=True``): {"nodes", "memset", "memcpy", "kernel"}.
+        A memset node inside a captured step is what replayed with stale arguments on ROCm 7.2 (docs/NOTEBOOK.md, round 5): the step must
+        hold none, whatever the runtime's packet-capture switch says."""
+        if self._census is None:
+            import re
+            import tempfile
+            with tempfile.TemporaryDirectory() as d:
+                path = os.path.join(d, "step.dot")
+                self.graph.debug_dump(path)
+                with open(path) as f:
+                    text = f.read()
+            self._census = graph_dot_census(text)
+        return self._census
 
     def _capture_around_the_pseudo_label_pass(self, rec, side, dev):
         """A step whose recognizer runs the PDF pseudo-label pass (``PointPdfV1.pseudo_mask_fn``: region growing with data-dependent

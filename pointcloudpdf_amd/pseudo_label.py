@@ -365,40 +365,53 @@ def pseudo_labeling(coord, logits, neighbors, condition_from="msp", beta=1.5, se
 # it keeps running ahead (rounds 1-4: ~10 host reads per scene, the device idle for the ~7 ms the host needed per 150k-point scene) and
 # the pass can be captured into the step's graph.
 # ------------------------------------------------------------------------------------------------------------------
-_RANGES = {}   # (device, scene sizes) -> (starts, sizes) int32 device tensors: made once, outside any graph capture
-
-
-def _scene_ranges(dev, starts, sizes):
-    key = (str(dev), tuple(sizes))
-    r = _RANGES.get(key)
-    if r is None:
-        if len(_RANGES) > 64:
-            _RANGES.clear()
-        r = _RANGES[key] = (torch.tensor(starts, dtype=torch.int32, device=dev), torch.tensor(sizes, dtype=torch.int32, device=dev))
-    return r
+def _scene_ranges(dev, starts, sizes, offset=None):
+    """(starts, sizes) of the scenes as int32 device tensors, owned by the CALLER's step (round 6; rounds 1-5 kept them in a
+    process-wide cache whose eviction freed tensors that captured graphs still pointed at).
+    With the batch's device ``offset`` (scene ends) they are derived from it by two elementwise kernels: graph-safe, allocated from the
+    capturing graph's own pool, hence alive exactly as long as the graph.  Without it (eager callers that only hold host sizes) they
+    travel through a fresh pinned buffer and a non-blocking copy, as ``_draw_seeds`` does: nothing waits for the device.  A capture
+    without ``offset`` is refused: a host buffer cannot be read by a replay."""
+    if offset is not None and offset.device == dev and offset.numel() == len(sizes):
+        ends = offset.detach().to(torch.int32)
+        sizes_d = ends.clone()
+        sizes_d[1:] -= ends[:-1]
+        return ends - sizes_d, sizes_d
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("pseudo-label pass: a captured step needs the batch's device `offset` tensor for its scene ranges")
+    host = torch.empty((2, len(sizes)), dtype=torch.int32, pin_memory=dev.type == "cuda")
+    host[0] = torch.tensor(starts, dtype=torch.int32)
+    host[1] = torch.tensor(sizes, dtype=torch.int32)
+    r = host.to(dev, non_blocking=True)
+    return r[0], r[1]
 
 
 def _draw_seeds(num_seed, hi, generator, dev):
-    """``torch.randint(0, hi, [num_seed])`` of upstream's seed draw (:206) on the device without waiting for it.  Eager: the CPU draw of
-    upstream (global or explicit generator) through a FRESH pinned buffer per call (a pageable host -> device copy would wait for the
-    stream; the pinned allocator recycles a buffer only after its copy ran, so the host may run steps ahead).  While a step is being
-    CAPTURED the draw moves to the device generator (graph-safe Philox offsets): a replayed graph cannot re-read a host buffer the host
-    has meanwhile refilled for a later step."""
-    if torch.cuda.is_current_stream_capturing():
-        if generator is not None:
-            raise RuntimeError("pseudo-label pass: a captured step draws its seeds with the device generator (no explicit CPU generator)")
+    """``torch.randint(0, hi, [num_seed])`` of upstream's seed draw (:206) on the device without waiting for it.
+    ONE source per configuration, the same whether the step runs eagerly or is replayed (round 6; rounds 1-5 drew eager steps from the
+    CPU generator and captured ones from the device generator, so a trainer that mixes replayed and eager batches used two unrelated
+    streams and a capture's warm-up advanced the CPU generator):
+    * no explicit generator, device tensors -> the DEVICE generator (graph-safe Philox offsets; `torch.cuda.manual_seed` seeds it).
+      Deviation from upstream, which draws from the global CPU generator: same distribution, different stream.
+    * an explicit (CPU) generator -> upstream's CPU draw through a FRESH pinned buffer per call (a pageable host -> device copy would
+      wait for the stream; the pinned allocator recycles a buffer only after its copy ran).  Not capturable: a replayed graph cannot
+      re-read a host buffer the host has refilled for a later step."""
+    if generator is None and dev.type == "cuda":
         return torch.randint(0, hi, [num_seed], device=dev)
-    dice = torch.empty((num_seed,), dtype=torch.int64, pin_memory=True)
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("pseudo-label pass: a captured step draws its seeds with the device generator (no explicit CPU generator)")
+    dice = torch.empty((num_seed,), dtype=torch.int64, pin_memory=dev.type == "cuda")
     dice.copy_(torch.randint(0, hi, [num_seed], generator=generator))
     return dice.to(dev, non_blocking=True)
 
 
 @torch.no_grad()
 def get_pseudo_mask_static(coord, seg_logits, offset_host, neighbors, condition_from="msp", beta=1.5, seed_from="ml", seed_range=0.15,
-                           num_seed=100, slide_window=True, generator=None, max_rounds=4096, info=None):
+                           num_seed=100, slide_window=True, generator=None, max_rounds=4096, info=None, offset=None):
     """pointpdf_v1m1_base.py:118-382 for a batch on the device, free of host reads.  ``neighbors``: (N, k) GLOBAL ids, -1 padded: the int32
     table of ``radius_neighbors(..., raw=True)`` as it is, or the int64 one (converted); ``offset_host``: the scenes' end positions as
-    Python ints.  -> bool (N,) on the device.
+    Python ints; ``offset``: the same ends as the batch's device tensor (required while a step is being captured: the scene ranges
+    the kernels read are derived from it inside the graph, ``_scene_ranges``).  -> bool (N,) on the device.
     Torch does the row-wise work on the logits (softmax, row maxima) and draws the seed ranks; every reduction over a scene, the seed
     lookup, the growth, the region's graph, both labellings, the mixture fit and the component statistics are kernels of
     csrc/region_grow.hip / csrc/graph_prune.hip, one launch for all scenes wherever the stage allows.
@@ -415,7 +428,7 @@ def get_pseudo_mask_static(coord, seg_logits, offset_host, neighbors, condition_
     i32 = dict(dtype=torch.int32, device=dev)
     f32 = dict(dtype=torch.float32, device=dev)
     u8 = dict(dtype=torch.uint8, device=dev)
-    starts_d, sizes_d = _scene_ranges(dev, starts, sizes)
+    starts_d, sizes_d = _scene_ranges(dev, starts, sizes, offset)
     nn = neighbors if neighbors.dtype == torch.int32 else neighbors.int()
     nn = nn.contiguous()
     coord = coord.contiguous()
@@ -490,7 +503,7 @@ def get_pseudo_mask(coord, seg_logits, offset, radius=0.1, max_neighbor=64, neig
         # the sync-free form (get_pseudo_mask_static): scene ends from the host copy when the caller has one (one read of `offset` else)
         ends = offset_host if offset_host is not None else [int(v) for v in offset.tolist()]
         kw2 = {k: v for k, v in kw.items() if k != "prune"}
-        return get_pseudo_mask_static(coord, seg_logits, ends, neighbors, generator=generator, **kw2)
+        return get_pseudo_mask_static(coord, seg_logits, ends, neighbors, generator=generator, offset=offset, **kw2)
     ends = offset_host if offset_host is not None else [int(v) for v in offset.tolist()]
     starts = [0] + ends[:-1]
     stream = torch.cuda.current_stream() if coord.is_cuda else None

@@ -827,6 +827,58 @@ def test_captured_step_refuses_a_stale_schedule_state():
     engine.release_autograd_state(step)
 
 
+def test_captured_step_holds_no_memset_node():
+    """The rule behind the round-5 replay fault, enforced on the graph itself: a captured training step (with and without the
+    pseudo-label pass) holds no memset node -- every zero-fill and every reduction inside it is a kernel of this library or an
+    elementwise torch kernel.  The walker (hipGraphDebugDotPrint through CUDAGraph.debug_dump) is validated first on a graph that is
+    KNOWN to hold one: a torch reduction of a long dimension clears its semaphore with hipMemsetAsync."""
+    from pointcloudpdf_amd import engine, pseudo_label, synthetic
+    from pointcloudpdf_amd.geometry import Geometry
+
+    dev = torch.device("cuda", 0)
+    x = torch.randn(1 << 16, 8, device=dev)
+    buf = torch.empty(64, device=dev)
+    s = torch.cuda.Stream(device=dev)
+    s.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(s):
+        x.sum(0)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    g.enable_debug_mode()
+    with torch.cuda.graph(g, stream=s):
+        y = x.sum(0)                                           # multi-workgroup reduction: semaphore memset
+        buf.zero_()                                            # elementwise fill kernel (no memset node)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        g.debug_dump(os.path.join(d, "control.dot"))
+        control = engine.graph_dot_census(open(os.path.join(d, "control.dot")).read())
+    assert control["nodes"] >= 2, control
+    if control["memset"] == 0:
+        pytest.skip(f"this torch build reduces without a memset node ({control}): the walker has no positive control here")
+    del y
+
+    for kind in ("s3dis", "scannet+pass"):
+        if kind == "s3dis":
+            batch = synthetic.make_batch([2500, 2100], first_scene_id=70, device=dev)
+            step = engine.OpenSegStep().to(dev)
+        else:
+            batch = synthetic.make_batch([9000, 8000], first_scene_id=50, device=dev, kind="scannet", unknown=(4, 7, 14, 16))
+            fn = pseudo_label.make_pseudo_mask_fn(radius=0.1, max_neighbor=64, condition_from="msp", beta=1.5, seed_from="ml", seed_range=0.15,
+                                                  num_seed=100, slide_window=True)
+            step = engine.OpenSegStep(in_channels=9, num_classes=20, loss_weight=0.04, pseudo_mask_fn=fn).to(dev)
+        synthetic.fill_parameters_deterministic(step, seed=2)
+        step.train()
+        geom = Geometry(batch["coord"], batch["offset"], batch["offset_host"]).precompute()
+        cap = engine.CapturedStep(step, batch, geom=geom, debug_graph=True)
+        assert cap.graph2 is None
+        census = cap.node_census()
+        assert census["kernel"] > 300 and census["memset"] == 0, (kind, census)
+        cap(batch, geom)   # (the dump leaves the executable graph intact)
+        torch.cuda.synchronize()
+        assert np.isfinite(float(cap.out["loss"]))
+        engine.release_autograd_state(step)
+
+
 def test_device_grad_scaler_follows_torch_grad_scaler():
     """engine.DeviceGradScaler + FusedSGD against torch.amp.GradScaler + torch.optim.SGD on the same gradients: clean steps update
     identically and grow the scale after `growth_interval` of them; a step with an inf / a nan gradient leaves parameters AND momentum
