@@ -28,7 +28,7 @@ struct SlabWalk {
     __device__ __forceinline__ SlabWalk(const LayerArgs &A, int plane, int ppb) {
         const unsigned g = gridDim.x;
         order = A.order;
-        if (A.chunked) {
+        if (A.chunked & 1) {
             const unsigned blk = pdf_xcd_chunked_block(blockIdx.x, g);
             const long per = ((long)A.N + g - 1) / g;
             t = (long)blk * per + plane;
@@ -48,17 +48,13 @@ struct SlabWalk {
 };
 
 // ---- the wave's private LDS strip (floats): its 64 channels' constants
-//   [Wp2 (64 x 3, channel-major) | bp2 | s1 | t1 | backward: mean1 | rstd1 | sum g_y1 / rows | sum g_y1*rhat / rows]
-constexpr int SC_W = 0, SC_B = 192, SC_S1 = 256, SC_T1 = 320, SC_M1 = 384, SC_R1 = 448, SC_SA = 512, SC_SB = 576, SC_N = 640;
+//   [Wp2[:, 0] | Wp2[:, 1] | Wp2[:, 2] (a-major: packed fp32 math over channel pairs) | bp2 | s1 | t1 | backward: mean1 | rstd1 |
+//    s1 * sum g_y1 / rows | s1 * sum g_y1*rhat / rows | the trip's x_q | g_out]
+constexpr int SC_W = 0, SC_B = 192, SC_S1 = 256, SC_T1 = 320, SC_M1 = 384, SC_R1 = 448, SC_SA = 512, SC_SB = 576, SC_XQ = 640, SC_GO = 704, SC_N = 768;   // SC_W: three 64-float rows Wp2[:, a]
 
-// p_r of the lane's four channels of LOCAL group gl = 4 jj + kq (channels 4 gl .. 4 gl + 3 of the slab)
+// p_r of the lane's four channels of LOCAL group gl = 4 jj + kq (channels 4 gl .. 4 gl + 3 of the slab): three vector FMAs (v_pk_fma_f32)
 __device__ __forceinline__ f32x4 pos4s(const float *sc, int gl, const float *t1n) {
-    const f32x4 w0 = ld4(sc + SC_W + 12 * gl), w1 = ld4(sc + SC_W + 12 * gl + 4), w2 = ld4(sc + SC_W + 12 * gl + 8), b = ld4(sc + SC_B + 4 * gl);
-    const float w[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0], w2[1], w2[2], w2[3]};
-    f32x4 pr;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) pr[e] = t1n[0] * w[3 * e] + t1n[1] * w[3 * e + 1] + t1n[2] * w[3 * e + 2] + b[e];
-    return pr;
+    return t1n[0] * ld4(sc + SC_W + 4 * gl) + (t1n[1] * ld4(sc + SC_W + 64 + 4 * gl) + (t1n[2] * ld4(sc + SC_W + 128 + 4 * gl) + ld4(sc + SC_B + 4 * gl)));
 }
 
 // Every lane loads the constants of channel c0 + lane and stores them into the wave's strip (all loads first; no block barrier: the
@@ -69,31 +65,65 @@ __device__ __forceinline__ void stage_slab_consts(float *sc, const LayerArgs &A,
     const float w0 = gp(A.Wp2)[3 * ch], w1 = gp(A.Wp2)[3 * ch + 1], w2 = gp(A.Wp2)[3 * ch + 2], b = gp(A.bp2)[ch], s1 = gp(A.s1)[ch], t1 = gp(A.t1)[ch];
     float m1 = 0.f, r1 = 0.f, sa = 0.f, sb = 0.f;
     if constexpr (BWD) { m1 = gp(A.mean)[3 + ch]; r1 = gp(A.rstd)[3 + ch]; sa = S[ch] * A.inv_rows; sb = S[C + ch] * A.inv_rows; }
-    sc[SC_W + 3 * lane] = w0; sc[SC_W + 3 * lane + 1] = w1; sc[SC_W + 3 * lane + 2] = w2;
+    sc[SC_W + lane] = w0; sc[SC_W + 64 + lane] = w1; sc[SC_W + 128 + lane] = w2;
     sc[SC_B + lane] = b; sc[SC_S1 + lane] = s1; sc[SC_T1 + lane] = t1;
-    if constexpr (BWD) { sc[SC_M1 + lane] = m1; sc[SC_R1 + lane] = r1; sc[SC_SA + lane] = sa; sc[SC_SB + lane] = sb; }
+    if constexpr (BWD) { sc[SC_M1 + lane] = m1; sc[SC_R1 + lane] = r1; sc[SC_SA + lane] = s1 * sa; sc[SC_SB + lane] = s1 * sb; }
 }
 
 // The strip's constants are invariant over the point loop: left alone, the compiler hoists all ~40 float4 reads per 16-channel block out
 // of it (160 registers, one wave per SIMD less).  An opaque copy of the strip pointer per trip keeps the reads at their uses.
-__device__ __forceinline__ const float *per_trip(const float *p) { asm volatile("" : "+v"(p)); return p; }
+// (the OFFSET is made opaque, not the pointer: an opaque pointer loses its address space and every read becomes a flat load)
+__device__ __forceinline__ int per_trip_zero() { int z = 0; asm volatile("" : "+v"(z)); return z; }
 
 // ================================================================================================ B3
 // partial row per workgroup: [sum g_yp (3) | sum g_yp*that (3) | pad 2 | g_bp2 (C) | g_Wp2 (C*3) | sum g_yp (x) rel (9) | pad 7]   (as flm::k_b3)
 // Only with the closed-form geometry backward (A.mom != nullptr, fl::k_colsum's extra block): G3 is not written -- a wave holds its
 // slab's share of g_t1n only, which is all the 15 sums need.
-constexpr int B3_WAVE_FLOATS = SC_N + 32 * TS + 64;   // constants | g_r tile | g_pr tile | t1n of the 16 rows
+constexpr int B3_WAVE_FLOATS = SC_N + 32 * TS + 64 + 240;   // constants | g_r tile | g_pr tile | t1n of the 16 rows | the 15 geometry sums per row lane
 template <int C> constexpr size_t b3_lds_floats() { return (size_t)7 * csp_of(C) + (size_t)waves_of<C>() * B3_WAVE_FLOATS; }
 
+// The row data of one trip (one point, the wave's slab), as it comes out of global memory
+template <int NOB>
+struct B3Rows {
+    float pn[3], pi[3];
+    f32x4 hh[NOB], g2[NOB], w[NOB], xk[4];
+    float xq, go;   // x_q / g_out of channel c0 + lane (row-invariant: one value per lane, handed to the row lanes through the strip)
+};
 template <int C, bool BF>
-__global__ __launch_bounds__(64 * waves_of<C>()) void k_b3(LayerArgs A) {
+__device__ __forceinline__ void b3_load(B3Rows<nob_of(C)> &D, const LayerArgs &A, long i, int nb, int row, int kq, int c0) {
+    constexpr int CS = C / 8, NOB = nob_of(C);
+    const size_t nbc = (size_t)max(nb, 0), ri = (size_t)i * 16 + row;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) { D.pn[b] = A.p[nbc * 3 + b]; D.pi[b] = A.p[(size_t)i * 3 + b]; }
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+        const size_t o = ri * CS + unit_off<C>(ob, kq);
+        D.hh[ob] = ld_row4<BF>(A.H, o); D.g2[ob] = ld_row4<BF>(A.G2, o); D.w[ob] = ld_row4<BF>(A.Wsm, o);
+    }
+    const float *xkr = A.xk + nbc * C + c0 + 4 * kq;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) D.xk[jj] = ld4(xkr + 16 * jj);
+    const int lane = 16 * kq + row;
+    D.xq = A.xq[(size_t)i * C + c0 + lane]; D.go = A.gout[(size_t)i * C + c0 + lane];
+}
+
+// VAR (A/B builds, PDFOPS_FLS_VAR): 0 = loads of the NEXT trip issued behind the channel loop of the current one (the registers of the
+// consumed rows are free there: the round trip hides behind the column phases), 1 = the same with one scheduling barrier per 16-channel
+// block, 2 = every trip loads its own rows at its top.
+template <int C, bool BF, int VAR>
+__global__ __launch_bounds__(64 * waves_of<C>()) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_b3(LayerArgs A) {
     constexpr int CS = C / 8, NOB = nob_of(C), CSP = csp_of(C), NSLAB = C / 64, WV = waves_of<C>(), PPB = WV / NSLAB, W = 8 + 4 * C + 16;
+    constexpr bool PIPE = VAR != 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, row = lane & 15, kq = lane >> 4;
     const int q = wv % NSLAB, plane = wv / NSLAB, c0 = 64 * q;
     float *ucst = lds;                                   // per-unit constants (stage_units), block-shared; sums = B1's
     float *scw = lds + 7 * CSP + wv * B3_WAVE_FLOATS;    // the wave's strip
     float *tile = scw + SC_N, *tile2 = tile + 16 * TS, *t1nt = tile2 + 16 * TS;
+    float *gacc = t1nt + 64 + row * 15;   // the row lane's share of the 15 sums of the geometry branch (lanes kq == 0; stride 15: conflict-free)
+    SlabWalk pw(A, plane, PPB);
+    // the first trip's neighbour index goes out before anything else: its round trip overlaps the staging below
+    int nb_cur = pw.valid() ? A.idx[pw.point() * 16 + row] : -1;
     stage_units<C, true>(ucst, A, gp(A.sums2));
     stage_slab_consts<C, true>(scw, A, c0, lane, gp(A.sums));
     // the slab of Ww1 as the A operand of (Ww1^T g_h): wf[ob][e][jj] = Ww1[16 ob + 4 kq + e][c0 + 16 jj + row]   (padding units: 0)
@@ -110,45 +140,41 @@ __global__ __launch_bounds__(64 * waves_of<C>()) void k_b3(LayerArgs A) {
             }
         }
     const GeoW G = geo_weights(A);
-    float greg[15];
+    if (kq == 0) {
 #pragma unroll
-    for (int e = 0; e < 15; ++e) greg[e] = 0.f;
+        for (int e = 0; e < 15; ++e) gacc[e] = 0.f;
+    }
     float sbp2 = 0.f, awp2[3] = {0.f, 0.f, 0.f};
+    B3Rows<NOB> D;
+    int nb_next = -1;
+    if (PIPE && pw.valid()) {
+        b3_load<C, BF>(D, A, pw.point(), nb_cur, row, kq, c0);
+        nb_next = A.idx[(pw.has_next() ? pw.next_point() : pw.point()) * 16 + row];
+    }
     __syncthreads();
-    SlabWalk pw(A, plane, PPB);
-    int nb_next = pw.valid() ? A.idx[pw.point() * 16 + row] : -1;
     for (; pw.valid(); pw.step()) {
         const long i = pw.point();
-        const size_t ri = (size_t)i * 16 + row;
-        const int nb = nb_next;
-        const size_t nbc = (size_t)max(nb, 0);
-        const float *sc = per_trip(scw);
-        // ---------------- every global load of the trip
-        nb_next = A.idx[(pw.has_next() ? pw.next_point() : i) * 16 + row];
-        float pn[3], pi[3];
-#pragma unroll
-        for (int b = 0; b < 3; ++b) { pn[b] = A.p[nbc * 3 + b]; pi[b] = A.p[(size_t)i * 3 + b]; }
-        f32x4 hh[NOB], g2[NOB], w[NOB], xk[4], xq[4], go[4];
-#pragma unroll
-        for (int ob = 0; ob < NOB; ++ob) {
-            const size_t o = ri * CS + unit_off<C>(ob, kq);
-            hh[ob] = ld_row4<BF>(A.H, o); g2[ob] = ld_row4<BF>(A.G2, o); w[ob] = ld_row4<BF>(A.Wsm, o);
+        const int nb = nb_cur;
+        const float *sc = scw + per_trip_zero();
+        if (!PIPE) {   // ---------------- every global load of the trip
+            b3_load<C, BF>(D, A, i, nb, row, kq, c0);
+            nb_next = A.idx[(pw.has_next() ? pw.next_point() : i) * 16 + row];
+            __builtin_amdgcn_sched_barrier(0);
         }
-        const float *xkr = A.xk + nbc * C + c0 + 4 * kq, *xqr = A.xq + (size_t)i * C + c0 + 4 * kq, *gor = A.gout + (size_t)i * C + c0 + 4 * kq;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) { xk[jj] = ld4(xkr + 16 * jj); xq[jj] = ld4(xqr + 16 * jj); go[jj] = ld4(gor + 16 * jj); }
-        __builtin_amdgcn_sched_barrier(0);
-        const Geo R = geo_of(G, nb, pn, pi);
+        scw[SC_XQ + lane] = D.xq; scw[SC_GO + lane] = D.go;
+        const Geo R = geo_of(G, nb, D.pn, D.pi);
         if (kq == 0) { t1nt[row * 4 + 0] = R.t1n[0]; t1nt[row * 4 + 1] = R.t1n[1]; t1nt[row * 4 + 2] = R.t1n[2]; }
-        f32x4 gh[NOB];
-        hidden_grad<C>(ucst, kq, hh, g2, gh);
+        f32x4 gh[NOB], w[NOB];
+        hidden_grad<C>(ucst, kq, D.hh, D.g2, gh);
 #pragma unroll
-        for (int ob = 0; ob < NOB; ++ob) w[ob] = sel4(16 * ob + 4 * kq < CS, w[ob]);
+        for (int ob = 0; ob < NOB; ++ob) w[ob] = sel4(16 * ob + 4 * kq < CS, D.w[ob]);
         if (CS < 16) {   // channels of lanes kq = 2, 3 use the units of lanes kq - 2
             const f32x4 x = xchg32(w[0]);
             if (kq >= 2) w[0] = x;
         }
-        float gt1n[3] = {0.f, 0.f, 0.f};
+        f32x4 gt[3] = {zero4(), zero4(), zero4()};   // g_t1n: per-lane partial sums over the lane's channels (vector accumulators)
+        const float live = nb >= 0 ? 1.f : 0.f;
+        wave_sync();   // (x_q / g_out of the trip are in the strip)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int gl = 4 * jj + kq;   // local channel group: channels c0 + 4 gl ..+4
@@ -157,24 +183,35 @@ __global__ __launch_bounds__(64 * waves_of<C>()) void k_b3(LayerArgs A) {
             for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ob][e][jj], gh[ob][e], acc, 0, 0, 0);
-            const f32x4 r = (sel4(nb >= 0, xk[jj]) - xq[jj]) + pos4s(sc, gl, R.t1n);
+            const f32x4 wa0 = ld4(sc + SC_W + 4 * gl), wa1 = ld4(sc + SC_W + 64 + 4 * gl), wa2 = ld4(sc + SC_W + 128 + 4 * gl);
+            const f32x4 pr = R.t1n[0] * wa0 + (R.t1n[1] * wa1 + (R.t1n[2] * wa2 + ld4(sc + SC_B + 4 * gl)));
+            const f32x4 r = (D.xk[jj] * live - ld4(sc + SC_XQ + 4 * gl)) + pr;
             const f32x4 s1 = ld4(sc + SC_S1 + 4 * gl);
             const f32x4 y1 = r * s1 + ld4(sc + SC_T1 + 4 * gl);
             f32x4 gy1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) gy1[e] = y1[e] > 0.f ? acc[e] : 0.f;
-            // BN1 backward: g_r = s1 * (g_y1 - mean(g_y1) - rhat * mean(g_y1 * rhat))
+            // BN1 backward: g_r = s1 * (g_y1 - mean(g_y1) - rhat * mean(g_y1 * rhat)), the two means pre-multiplied by s1 in the strip
             const f32x4 rhat = (r - ld4(sc + SC_M1 + 4 * gl)) * ld4(sc + SC_R1 + 4 * gl);
-            const f32x4 gr = s1 * (gy1 - ld4(sc + SC_SA + 4 * gl) - rhat * ld4(sc + SC_SB + 4 * gl));
+            const f32x4 gr = (s1 * gy1 - ld4(sc + SC_SA + 4 * gl)) - rhat * ld4(sc + SC_SB + 4 * gl);
             st4(tile + row * TS + 16 * jj + 4 * kq, gr);
-            const f32x4 gpr = gr + go[jj] * w[jj % NOB];   // + the aggregation's share of p_r  ((4 q + jj) mod NOB = jj mod NOB: NOB divides 4)
+            const f32x4 gpr = gr + ld4(sc + SC_GO + 4 * gl) * w[jj % NOB];   // + the aggregation's share of p_r  ((4 q + jj) mod NOB = jj mod NOB: NOB divides 4)
             st4(tile2 + row * TS + 16 * jj + 4 * kq, gpr);
-            const f32x4 w0 = ld4(sc + SC_W + 12 * gl), w1 = ld4(sc + SC_W + 12 * gl + 4), w2v = ld4(sc + SC_W + 12 * gl + 8);
-            const float wp[12] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2v[0], w2v[1], w2v[2], w2v[3]};
+            gt[0] += gpr * wa0; gt[1] += gpr * wa1; gt[2] += gpr * wa2;
+        }
+        float gt1n[3];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                gt1n[0] += gpr[e] * wp[3 * e]; gt1n[1] += gpr[e] * wp[3 * e + 1]; gt1n[2] += gpr[e] * wp[3 * e + 2];
+        for (int a = 0; a < 3; ++a) gt1n[a] = (gt[a][0] + gt[a][1]) + (gt[a][2] + gt[a][3]);
+        // the row data is consumed: the NEXT trip's rows are requested now and arrive behind the column phases
+        const int nb_after = nb_next;
+        if (PIPE) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (pw.has_next()) {
+                b3_load<C, BF>(D, A, pw.next_point(), nb_after, row, kq, c0);
+                const long t2 = pw.t + 2 * pw.stride;
+                nb_next = A.idx[(t2 < pw.end ? (pw.order ? (long)pw.order[t2] : t2) : pw.next_point()) * 16 + row];
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         wave_sync();
         {   // lanes along channels: g_r rows out (256 B per row), g_xq[i] = - sum_rows g_r
@@ -207,24 +244,21 @@ __global__ __launch_bounds__(64 * waves_of<C>()) void k_b3(LayerArgs A) {
             v += __shfl_xor(v, 32, 64);
             if (kq == 0) {
                 v = R.t1n[a] > 0.f ? v : 0.f;
-                greg[a] += v;
-                greg[3 + a] += v * ((R.t1[a] - A.mean[a]) * A.rstd[a]);
-                greg[6 + 3 * a + 0] += v * R.rel[0]; greg[6 + 3 * a + 1] += v * R.rel[1]; greg[6 + 3 * a + 2] += v * R.rel[2];
+                gacc[a] += v;
+                gacc[3 + a] += v * ((R.t1[a] - A.mean[a]) * A.rstd[a]);
+                gacc[6 + 3 * a + 0] += v * R.rel[0]; gacc[6 + 3 * a + 1] += v * R.rel[1]; gacc[6 + 3 * a + 2] += v * R.rel[2];
             }
         }
         wave_sync();
+        nb_cur = nb_after;
     }
-    // ---- the workgroup's partial row.  Columns of a slab: summed over the point lanes in lane order; the 15 geometry sums: over all waves.
+    // ---- the workgroup's partial row.  Columns of a slab: summed over the point lanes in lane order; the 15 geometry sums: over all
+    // waves and their 16 row lanes, in that order.
     float *dst = A.partial + (size_t)blockIdx.x * W;
-    float *crow = tile;   // 4 x 64 + 16 floats of the wave's own strip
+    float *crow = tile;   // 4 x 64 floats of the wave's own strip
     crow[lane] = sbp2;
 #pragma unroll
     for (int a = 0; a < 3; ++a) crow[64 + lane * 3 + a] = awp2[a];
-#pragma unroll
-    for (int e = 0; e < 15; ++e) {
-        const float x = pdf_wave_sum_f32(kq == 0 ? greg[e] : 0.f);
-        if (lane == 0) crow[256 + e] = x;
-    }
     __syncthreads();
     if (plane == 0) {
         float b = 0.f, wsum[3] = {0.f, 0.f, 0.f};
@@ -242,8 +276,12 @@ __global__ __launch_bounds__(64 * waves_of<C>()) void k_b3(LayerArgs A) {
         const int src = e < 6 ? e : (e >= 8 && e < 17 ? e - 2 : -1);
         float v = 0.f;
         if (src >= 0) {
+#pragma unroll 1
+            for (int w = 0; w < WV; ++w) {
+                const float *ga = lds + 7 * CSP + w * B3_WAVE_FLOATS + SC_N + 32 * TS + 64;
 #pragma unroll
-            for (int w = 0; w < WV; ++w) v += (lds + 7 * CSP + w * B3_WAVE_FLOATS + SC_N)[256 + src];
+                for (int r = 0; r < 16; ++r) v += ga[r * 15 + src];
+            }
         }
         dst[e < 8 ? e : 4 * C + e] = v;
     }
@@ -257,11 +295,11 @@ static void launch(KernelT kernel, dim3 grid, int threads, size_t lds_floats, co
     kernel<<<grid, threads, lds, s>>>(A);
 }
 
-// which widths take the slab form (PDFOPS_PT_SLAB: comma list of widths, "0" = none; default: 256,512)
+// which widths take the slab form (PDFOPS_PT_SLAB: comma list of widths, "0" = none; default: all four)
 bool enabled(int c) {
     static const unsigned mask = [] {
         const char *v = getenv("PDFOPS_PT_SLAB");
-        if (!v) return (1u << 2) | (1u << 3);
+        if (!v) return 15u;
         unsigned m = 0;
         for (const char *p = v; *p;) {
             const int w = atoi(p);
@@ -276,20 +314,25 @@ bool enabled(int c) {
 
 static inline int waves_of_rt(int c) { return c / 64 > 4 ? c / 64 : 4; }
 
-// rows of the partial matrix = workgroups: every wave should see ~2 points (one to prefetch behind), bounded by the scratch (`max_rows`)
+// rows of the partial matrix = workgroups.  One resident round of workgroups (two per CU) with 6 - 50 trips per wave beats more, shorter
+// ones at every level: 512 -> 35.8 us, 1,042 -> 55 us at 3,124 points x 256 channels; 99.6 vs 116 us at 50,000 x 64
+// (profiles/r06_slab_b3_ab.txt) -- the prologue (constants, the slab of Ww1) and the partial row are paid per workgroup.
 int b3_grid(long n, int c, int max_rows) {
     static const int env = [] { const char *v = getenv("PDFOPS_PT_SLAB_B3_GRID"); return v ? atoi(v) : 0; }();
     const int ppb = waves_of_rt(c) / (c / 64);
-    long g = env > 0 ? env : (n + 2L * ppb - 1) / (2L * ppb);
-    if (g > 2048) g = 2048;
+    long g = env > 0 ? env : 512;
+    if (g > (n + ppb - 1) / ppb) g = (n + ppb - 1) / ppb;
     if (g > max_rows) g = max_rows;
     if (g < 1) g = 1;
     return (int)g;
 }
 
-void launch_b3(const LayerArgs &A, int c, int grid, hipStream_t s) {
-#define K_(C_) do { if (A.bf16) launch(k_b3<C_, true>, dim3(grid), 64 * waves_of<C_>(), b3_lds_floats<C_>(), A, s); \
-                    else launch(k_b3<C_, false>, dim3(grid), 64 * waves_of<C_>(), b3_lds_floats<C_>(), A, s); } while (0)
+void launch_b3(const LayerArgs &A0, int c, int grid, hipStream_t s) {
+    static const int var = [] { const char *v = getenv("PDFOPS_FLS_VAR"); return v ? atoi(v) : 2; }();   // code variants (A/B builds)
+    const LayerArgs &A = A0;
+#define K_(C_) do { if (A.bf16) launch(k_b3<C_, true, 2>, dim3(grid), 64 * waves_of<C_>(), b3_lds_floats<C_>(), A, s); \
+                    else if (var == 0) launch(k_b3<C_, false, 0>, dim3(grid), 64 * waves_of<C_>(), b3_lds_floats<C_>(), A, s); \
+                    else launch(k_b3<C_, false, 2>, dim3(grid), 64 * waves_of<C_>(), b3_lds_floats<C_>(), A, s); } while (0)
     if (c == 64) K_(64); else if (c == 128) K_(128); else if (c == 256) K_(256); else K_(512);
 #undef K_
 }
