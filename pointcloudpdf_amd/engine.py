@@ -89,14 +89,29 @@ def release_autograd_state(step):
             per_module[key] = None
 
 
-def graph_dot_census(text):
-    """Node kinds in a hipGraphDebugDotPrint dump: every node statement carries a label; memset / memcpy nodes name themselves in it,
-    the rest are kernels (their label is the kernel's name) or empty / event nodes."""
-    import re
-    labels = re.findall(r'\[[^\]]*label="([^"]*)"', text)
-    memset = sum(1 for l in labels if re.search(r"memset", l, re.I))
-    memcpy = sum(1 for l in labels if re.search(r"memcpy", l, re.I))
-    return {"nodes": len(labels), "memset": memset, "memcpy": memcpy, "kernel": len(labels) - memset - memcpy}
+def graph_node_census(raw_graph):
+    """Kinds of the nodes of a captured hipGraph (``torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph()``), read through the
+    runtime's own hipGraphGetNodes / hipGraphNodeGetType: {"nodes", "kernel", "memcpy", "memset", "other"}."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    g = ctypes.c_void_p(int(raw_graph))
+    n = ctypes.c_size_t(0)
+    rc = hip.hipGraphGetNodes(g, None, ctypes.byref(n))
+    if rc != 0:
+        raise RuntimeError(f"hipGraphGetNodes failed: {rc}")
+    nodes = (ctypes.c_void_p * max(n.value, 1))()
+    rc = hip.hipGraphGetNodes(g, nodes, ctypes.byref(n))
+    if rc != 0:
+        raise RuntimeError(f"hipGraphGetNodes failed: {rc}")
+    kinds = {"nodes": int(n.value), "kernel": 0, "memcpy": 0, "memset": 0, "other": 0}
+    names = {0: "kernel", 1: "memcpy", 2: "memset"}   # hipGraphNodeTypeKernel / Memcpy / Memset (hip_runtime_api.h)
+    for i in range(n.value):
+        t = ctypes.c_int(-1)
+        rc = hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(t))
+        if rc != 0:
+            raise RuntimeError(f"hipGraphNodeGetType failed: {rc}")
+        kinds[names.get(t.value, "other")] += 1
+    return kinds
 
 
 class CapturedStep:
@@ -165,10 +180,8 @@ class CapturedStep:
         # the fork are then outside the graph's private pool (observed: replays that read recycled memory once eager work ran in between).
         self.stream = side   # an EAGER step of the same module between replays is fastest on this stream (see the comment above: the
         #                      parameters' AccumulateGrad nodes stay bound to it for as long as the captured autograd graph lives)
-        self.graph, self.graph2, self.mask_fn = torch.cuda.CUDAGraph(), None, None
+        self.graph, self.graph2, self.mask_fn = torch.cuda.CUDAGraph(keep_graph=bool(debug_graph)), None, None
         self._census = None
-        if debug_graph:
-            self.graph.enable_debug_mode()
         rec = getattr(step, "recognizer", None)
         fn = getattr(rec, "pseudo_mask_fn", None)
         if fn is None or getattr(fn, "capturable", False):   # (the sync-free pseudo-label pass is recorded like any other stage)
@@ -185,19 +198,12 @@ class CapturedStep:
         release_autograd_state(step)
 
     def node_census(self):
-        """Kinds of the nodes of the captured graph, read from the runtime's own dump of it (hipGraphDebugDotPrint through
-        ``CUDAGraph.debug_dump``; needs ``debug_graph=True``): {"nodes", "memset", "memcpy", "kernel"}.
+        """Kinds of the nodes of the captured graph, read from the runtime (hipGraphGetNodes; needs ``debug_graph=True``, which keeps
+        the hipGraph next to its executable form): {"nodes", "kernel", "memcpy", "memset", "other"}.
         A memset node inside a captured step is what replayed with stale arguments on ROCm 7.2 (docs/NOTEBOOK.md, round 5): the step must
         hold none, whatever the runtime's packet-capture switch says."""
         if self._census is None:
-            import re
-            import tempfile
-            with tempfile.TemporaryDirectory() as d:
-                path = os.path.join(d, "step.dot")
-                self.graph.debug_dump(path)
-                with open(path) as f:
-                    text = f.read()
-            self._census = graph_dot_census(text)
+            self._census = graph_node_census(self.graph.raw_cuda_graph())
         return self._census
 
     def _capture_around_the_pseudo_label_pass(self, rec, side, dev):

@@ -830,7 +830,7 @@ def test_captured_step_refuses_a_stale_schedule_state():
 def test_captured_step_holds_no_memset_node():
     """The rule behind the round-5 replay fault, enforced on the graph itself: a captured training step (with and without the
     pseudo-label pass) holds no memset node -- every zero-fill and every reduction inside it is a kernel of this library or an
-    elementwise torch kernel.  The walker (hipGraphDebugDotPrint through CUDAGraph.debug_dump) is validated first on a graph that is
+    elementwise torch kernel.  The walker (hipGraphGetNodes / hipGraphNodeGetType on the kept hipGraph) is validated first on a graph that is
     KNOWN to hold one: a torch reduction of a long dimension clears its semaphore with hipMemsetAsync."""
     from pointcloudpdf_amd import engine, pseudo_label, synthetic
     from pointcloudpdf_amd.geometry import Geometry
@@ -843,16 +843,12 @@ def test_captured_step_holds_no_memset_node():
     with torch.cuda.stream(s):
         x.sum(0)
     torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    g.enable_debug_mode()
+    g = torch.cuda.CUDAGraph(keep_graph=True)
     with torch.cuda.graph(g, stream=s):
         y = x.sum(0)                                           # multi-workgroup reduction: semaphore memset
         buf.zero_()                                            # elementwise fill kernel (no memset node)
-    import tempfile
-    with tempfile.TemporaryDirectory() as d:
-        g.debug_dump(os.path.join(d, "control.dot"))
-        control = engine.graph_dot_census(open(os.path.join(d, "control.dot")).read())
-    assert control["nodes"] >= 2, control
+    control = engine.graph_node_census(g.raw_cuda_graph())
+    assert control["nodes"] >= 2 and control["kernel"] >= 2, control
     if control["memset"] == 0:
         pytest.skip(f"this torch build reduces without a memset node ({control}): the walker has no positive control here")
     del y
