@@ -40,7 +40,7 @@ extern "C" {
  * without a bump, see ADVICE of round 3); 4 = round 4: `mma_input` per call on the pdf_rowlin_ / pdf_block_ / pdf_bottleneck_ / pdf_linbn_ /
  * pdf_td_ entries, pdf_set_mma_input / pdf_get_mma_input / pdf_tickets_* removed, pdf_sgd_step takes a found-inf flag;
  * 5 = round 5: pdf_wa_* (atomic-free window-attention backward, fused logits), pdf_layernorm_*, pdf_region_* / *_dev (sync-free pseudo-label pass) added. */
-#define PDF_ABI_VERSION 5
+#define PDF_ABI_VERSION 6
 int pdf_abi_version(void);
 const char *pdf_build_info(void);
 /* Arithmetic of the squared distance in this library's geometry kernels (kNN, ball query, FPS): 0 = the reference's expression as
@@ -516,6 +516,20 @@ int pdf_wa_grad_attn(int N, int M, int h, int d, int L, const float *grad_out, l
  * logits[m, hh] = <q[q(m), hh], k[index1[m], hh] + T_q(m, hh)> + <k[index1[m], hh], T_k(m, hh)>. */
 int pdf_wa_logits_forward(int N, int M, int h, int d, int L, const float *q, const float *k, long ld, float qscale, const int *offsets,
                           const int *index1, const float *table_q, const float *table_k, const int *rel, float *out, void *stream);
+
+/* Edge tables of the StratifiedTransformer's window partitions (stratified_transformer_v1m1_origin.py:45-127 get_indice_pairs / grid_sample +
+ * the stable sort by query of :468-536, and WindowAttention's quantised relative positions :282-292), built per QUERY instead of by pair
+ * expansion + an edge-sized sort (csrc/window_edges.hip).  Inputs: int64 keys per point (fine-window key kf, coarse-window key kc, packed
+ * fine-window cell wk), kf in ascending order (kf_sorted) with the point ids in that order (order_f, ties ascending), and the same for the
+ * m FPS-downsampled points by coarse key (kcd_sorted, order_cd, wkd = wk[order_cd]).
+ *   pdf_window_edges_count : count (n) int32 = row length of every query, seg (n, 4) int32 (16-byte aligned) = its two segments
+ *   pdf_window_edges_fill  : offsets (n + 1) = exclusive scan of count -> index0 (E) int64 ascending, index1 (E) int32, rel (E, 3) int32 or
+ *                            null; *flag |= 1 if a quantised offset leaves [0, vmax] (the reference asserts that range) */
+int pdf_window_edges_count(int n, const long long *kf_sorted, const long long *kf, int m, const long long *kcd_sorted, const long long *kc,
+                           const long long *wk, const long long *wkd, int *count, int *seg, void *stream);
+int pdf_window_edges_fill(int n, const int *offsets, const int *seg, const int *order_f, const int *order_cd, const long long *wk,
+                          const long long *wkd, const float *xyz, float c2w, float qs, int vmax, long long *index0, int *index1, int *rel,
+                          int *flag, void *stream);
 
 /* The PDF pseudo-label pass without a host in the loop (pointcept/recognizers/ours/pointpdf_v1m1_base.py:190-380; csrc/region_grow.hip,
  * csrc/graph_prune.hip).  All scenes of a batch per call; starts / sizes (scenes) int32 = the scenes' point ranges; neighbors (N, nsample)

@@ -47,6 +47,12 @@ class OracleBackend(CBackend):
     def set_num_threads(self, n):
         self.lib.oracle_set_num_threads(int(n))
 
+    def window_edges(self, xyz, kf, kc, wk, downsample_idx, c2w, qs, vmax):
+        """The reference's window-partition edge tables (oracle/window_tables.py) behind the backend interface."""
+        from . import window_tables
+
+        return window_tables.window_edges(xyz, kf, kc, wk, downsample_idx, c2w, qs, vmax)
+
     def set_dist_mode(self, mode):
         """0 = the distance expression as written (default), 1 / 2 = the two FMA contractions (pdfops_oracle.c: oracle_sqdist3).
         Returns the previous mode."""

@@ -26,7 +26,7 @@ def library_path(dist_fma=0):
 
 
 LIB_PATH = library_path(DIST_FMA)
-ABI_VERSION = 5   # include/pdfops.h: PDF_ABI_VERSION (the argtypes below are THIS version's parameter lists)
+ABI_VERSION = 6   # include/pdfops.h: PDF_ABI_VERSION (the argtypes below are THIS version's parameter lists)
 
 c_int = ctypes.c_int
 c_long = ctypes.c_long
@@ -88,6 +88,8 @@ _HIP_ONLY_PROTOS = {
     "wa_table_grad": "iiiippppplfpp",
     "wa_grad_attn": "iiiiiplppplppp",
     "wa_logits_forward": "iiiiipplfpppppp",
+    "window_edges_count": "ippipppppp",
+    "window_edges_fill": "ipppppppffipppp",
     "group_forward": "iiiippppp",
     "group_backward": "iiiippp",
     "interpolation_weights": "iipp",
@@ -1110,6 +1112,35 @@ class HipBackend(CBackend):
         out = torch.empty((n, h, d), dtype=torch.float32, device=v.device)
         self._wa_rows(n, h, d, L, offsets, None, index1, rel_idx, attn, v, table, out)
         return out
+
+    def window_edges(self, xyz, kf, kc, wk, downsample_idx, c2w, qs, vmax):
+        """The CSR-by-query edge table of one window partition (csrc/window_edges.hip; stratified_transformer_v1m1_origin.py:45-127 + the
+        sort by query of :468-536 + :282-292).  kf / kc / wk (N) int64: fine-window key, coarse-window key, packed fine-window cell of every
+        point; downsample_idx: the FPS key subset.  -> index_0 (E) int64 ascending, index_1 (E) int32, offsets (N + 1) int32, n_max (int),
+        rel_idx (E, 3) int32, flag (1) int32 device tensor (non-zero: a quantised offset left [0, vmax] -- the caller asserts).
+        Two point-sized stable sorts (torch / rocPRIM), two launches, ONE host read (edge count + longest row)."""
+        n, dev = int(xyz.shape[0]), xyz.device
+        i32 = dict(dtype=torch.int32, device=dev)
+        kf, kc, wk = kf.contiguous(), kc.contiguous(), wk.contiguous()
+        kf_sorted, order_f = torch.sort(kf, stable=True)
+        ds = torch.sort(downsample_idx.long())[0]
+        kcd_sorted, perm = torch.sort(kc[ds], stable=True)
+        order_cd = ds[perm]
+        wkd = wk[order_cd].contiguous()
+        m = int(ds.shape[0])
+        count = torch.empty(n, **i32)
+        seg = torch.empty((n, 4), **i32)
+        self._call("window_edges_count", n, kf_sorted, kf, m, kcd_sorted, kc, wk, wkd, count, seg)
+        offsets = torch.zeros(n + 1, **i32)
+        torch.cumsum(count, 0, dtype=torch.int32, out=offsets[1:])
+        e, n_max = (int(v) for v in torch.stack([offsets[-1], count.max() if n else offsets[-1]]).tolist())   # the one host read
+        index0 = torch.empty(e, dtype=torch.int64, device=dev)
+        index1 = torch.empty(e, **i32)
+        rel = torch.empty((e, 3), **i32)
+        flag = torch.zeros(1, **i32)
+        self._call("window_edges_fill", n, offsets, seg, order_f.int(), order_cd.int(), wk, wkd, xyz.contiguous(), float(c2w), float(qs), int(vmax),
+                   index0, index1, rel, flag)
+        return index0, index1, offsets, n_max, rel, flag
 
     def window_logits_supported(self, q, k, table_q):
         return self.wa_atomic_free and q.shape[0] == k.shape[0] and self._wa_ok(q.shape[2], int(table_q.shape[0]), q, k)

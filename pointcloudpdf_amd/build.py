@@ -25,6 +25,7 @@ EXTRA = {
     "sampling_bucketed.hip": ["-ffp-contract=off"] + (["-DFPS_PROFILE"] if os.environ.get("PDFOPS_FPS_PROFILE") else []) + ([f"-DPDF_FPS_MW_UNROLL={os.environ['PDFOPS_FPS_MW_UNROLL']}"] if os.environ.get("PDFOPS_FPS_MW_UNROLL") else []),
     "knn_grid.hip": ["-ffp-contract=off"],
     "ball_query.hip": ["-ffp-contract=off"],
+    "window_edges.hip": ["-ffp-contract=off"],   # the quantised relative positions must round like the torch expression they replace
     "window_attention.hip": ([f"-DPDF_WA_UE={os.environ['PDFOPS_WA_UE']}"] if os.environ.get("PDFOPS_WA_UE") else []),   # tuning knob (A/B builds)
 }
 

@@ -9,8 +9,9 @@ reference checkpoints load and the reference's hook configuration resolves.
 
 What runs where: window attention = ``pointops2`` HIP kernels (attention_step1_v2, dot_prod_with_idx_v3, CSR segment softmax,
 attention_step2_with_rel_pos_value_v2); FPS / kNN / grouping / interpolation = the ``pointops`` HIP kernels; the window partition
-(``grid_sample`` / ``get_indice_pairs``: unique / argsort / boolean-mask expansion) is torch device code exactly as upstream, with
-upstream's host syncs (``counts.max().item()``).
+(upstream ``grid_sample`` / ``get_indice_pairs`` + the sort of the edges by query: unique / argsort / dense boolean-mask expansion) is
+built per QUERY by csrc/window_edges.hip from per-point window keys (``window_keys``), with one host read per partition (edge count and
+longest row); the reference construction itself lives in oracle/window_tables.py, where the tests compare the two bit for bit.
 
 Third-party pieces the reference imports and this image lacks -- all unvendored, unversioned, hence **parity unpinned** -- are restated
 from their documented behaviour in this file: ``torch_scatter.scatter_softmax`` (-> the CSR segment-softmax kernel),
@@ -273,50 +274,24 @@ def offset2batch(offset):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# the reference's own code, restated (stratified_transformer_v1m1_origin.py)
+# window partitions: keys per point here (elementwise), the edge tables by the backend (csrc/window_edges.hip)
 # ------------------------------------------------------------------------------------------------------------------
-def get_indice_pairs(p2v_map, counts, new_p2v_map, new_counts, downsample_idx, batch, xyz, window_size, i):
-    """:45-100 -- edge list (index_0 = query, index_1 = key): all pairs inside a window of the fine partition, plus, from the
-    coarse (2 x window) partition, the pairs whose key is an FPS-downsampled point lying in a DIFFERENT fine window."""
-    dev = p2v_map.device
-    n, k = p2v_map.shape
-    mask = torch.arange(k, device=dev).unsqueeze(0) < counts.unsqueeze(-1)
-    mask_mat = mask.unsqueeze(-1) & mask.unsqueeze(-2)
-    index_0 = p2v_map.unsqueeze(-1).expand(-1, -1, k)[mask_mat]
-    index_1 = p2v_map.unsqueeze(1).expand(-1, k, -1)[mask_mat]
-
-    downsample_mask = torch.zeros_like(batch).bool()
-    downsample_mask[downsample_idx.long()] = True
-    downsample_mask = downsample_mask[new_p2v_map]
-    n, k = new_p2v_map.shape
-    mask = torch.arange(k, device=dev).unsqueeze(0) < new_counts.unsqueeze(-1)
-    downsample_mask = downsample_mask & mask
-    mask_mat = mask.unsqueeze(-1) & downsample_mask.unsqueeze(-2)
-    xyz_min = _colminmax(xyz)[0]
-    shift = 0.0 if i % 2 == 0 else 1 / 2 * window_size
-    window_coord = torch.div(xyz[new_p2v_map] - xyz_min + shift, window_size, rounding_mode="trunc")
-    # (window_coord.unsqueeze(2) != window_coord.unsqueeze(1)).any(-1) upstream (:93-94): the window cells are small non-negative integers,
-    # so one packed key per point gives the same boolean with one comparison -- torch's reduction over a dim of 3 was 8 ms of the step
-    wc = window_coord.long()
-    key = (wc[..., 0] << 42) | (wc[..., 1] << 21) | wc[..., 2]
-    mask_mat_prev = key.unsqueeze(2) != key.unsqueeze(1)
-    mask_mat = mask_mat & mask_mat_prev
-    new_index_0 = new_p2v_map.unsqueeze(-1).expand(-1, -1, k)[mask_mat]
-    new_index_1 = new_p2v_map.unsqueeze(1).expand(-1, k, -1)[mask_mat]
-    return torch.cat([index_0, new_index_0], 0), torch.cat([index_1, new_index_1], 0)
-
-
-def grid_sample(pos, batch, size, start, return_p2v=True):
-    """:103-127 -- voxel id per point, (voxel -> member points) table padded to the largest voxel, member counts."""
-    cluster = _voxel_grid(pos, batch, size, start=start)
-    if not return_p2v:
-        return torch.unique(cluster, sorted=True, return_inverse=True)[1]
-    unique, cluster, counts = torch.unique(cluster, sorted=True, return_inverse=True, return_counts=True)
-    n, k = unique.shape[0], int(counts.max().item())
-    p2v_map = cluster.new_zeros(n, k)
-    mask = torch.arange(k, device=pos.device).unsqueeze(0) < counts.unsqueeze(-1)
-    p2v_map[mask] = torch.argsort(cluster, stable=True)
-    return cluster, p2v_map, counts
+def window_keys(xyz, batch, window_size, xyz_min, parity):
+    """What one Swin block's partition is made of, per POINT (stratified_transformer_v1m1_origin.py:468-499 + :91-94): the voxel id of
+    the fine window partition, of the coarse (2 x window) one -- torch_geometric's ``voxel_grid`` on the plain coordinates for even blocks,
+    on the coordinates shifted by half a window from ``xyz_min`` for odd ones -- and the fine-window CELL of :91-94 (the predicate "lies
+    in another fine window" compares those cells), packed into one integer.  -> (kf, kc, wk), int64 each."""
+    new_window_size = 2 * window_size
+    if parity % 2 == 0:
+        kf, kc = _voxel_grid(xyz, batch, window_size, start=None), _voxel_grid(xyz, batch, new_window_size, start=None)
+        shift = 0.0
+    else:
+        kf = _voxel_grid(xyz + 1 / 2 * window_size, batch, window_size, start=xyz_min)
+        kc = _voxel_grid(xyz + 1 / 2 * new_window_size, batch, new_window_size, start=xyz_min)
+        shift = 1 / 2 * window_size
+    wc = torch.div(xyz - xyz_min + shift, window_size, rounding_mode="trunc").long()
+    # (the cells are small non-negative integers: one packed key per point gives `(a != b).any(-1)` of :93-94 with one comparison)
+    return kf, kc, (wc[:, 0] << 42) | (wc[:, 1] << 21) | wc[:, 2]
 
 
 class Mlp(nn.Module):
@@ -622,26 +597,21 @@ class BasicLayer(nn.Module):
         window_size = torch.tensor([self.window_size] * 3, dtype=xyz.dtype, device=xyz.device)
         batch = offset2batch(offset)
         xyz_min = _colminmax(xyz)[0]
-        new_window_size = 2 * window_size
-        parts = {0: grid_sample(xyz, batch, window_size, start=None)[1:] + grid_sample(xyz, batch, new_window_size, start=None)[1:]}
-        if self.depth > 1:
-            parts[1] = (grid_sample(xyz + 1 / 2 * window_size, batch, window_size, start=xyz_min)[1:]
-                        + grid_sample(xyz + 1 / 2 * new_window_size, batch, new_window_size, start=xyz_min)[1:])
-        tables = {}
-        for parity, (p2v, cnt, new_p2v, new_cnt) in parts.items():
-            index_0, index_1 = get_indice_pairs(p2v, cnt, new_p2v, new_cnt, downsample_idx, batch, xyz, window_size, parity)
-            index_0, indices = torch.sort(index_0, stable=True)   # CSR by query
-            index_1 = index_1[indices]
-            index_0_counts = torch.bincount(index_0, minlength=xyz.shape[0])
-            n_max = int(index_0_counts.max())
-            index_0_offsets = torch.cat([index_0_counts.new_zeros(1), index_0_counts.cumsum(dim=-1)], 0)
-            rel_idx = self.blocks[parity].attn.checked_relative_position_index(xyz, index_0, index_1)
-            # int32 copies made ONCE (WindowAttention.forward's `.int()` then hands the same tensors to every block: the backward's
-            # key-grouped edge list is cached on them), and that list itself -- coordinate-only like everything else here
-            index_1, index_0_offsets = index_1.int().contiguous(), index_0_offsets.int().contiguous()
-            if xyz.is_cuda:
+        be = _native.backend_for(xyz)
+        tables, flags = {}, []
+        for parity in range(2 if self.depth > 1 else 1):
+            kf, kc, wk = window_keys(xyz, batch, window_size, xyz_min, parity)
+            attn = self.blocks[parity].attn
+            # every query's row = [its fine window, ascending] ++ [the downsampled points of its coarse window in another fine window,
+            # ascending] -- what :45-100 + the stable sort by query of :507 produce -- with the quantised relative positions of :282-292
+            index_0, index_1, index_0_offsets, n_max, rel_idx, flag = be.window_edges(
+                xyz, kf, kc, wk, downsample_idx, 2 * attn.window_size, attn.quant_size, 2 * attn.quant_grid_length - 1)
+            flags.append(flag)
+            if xyz.is_cuda:   # the backward's key-grouped edge list: coordinate-only like everything else here, cached on index_1
                 _native.window_csc(index_1, index_0_offsets, rel_idx, n_keys=xyz.shape[0])
             tables[parity] = (index_0, index_1, index_0_offsets, n_max, rel_idx)
+        # WindowAttention asserts 0 <= rel_idx < 2 * quant_grid_length upstream (:291): one host read for the layer's partitions
+        assert not bool(torch.stack(flags).any()), "window edge tables: a quantised relative position left the table (coordinates outside the window?)"
         return tables
 
     def forward(self, feats, xyz, offset):

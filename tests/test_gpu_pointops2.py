@@ -366,3 +366,45 @@ def test_stratified_group_prepass_is_the_per_batch_prepass():
                     for x, y in zip(tab, got.windows[lv][parity]):
                         assert torch.equal(x, y) if torch.is_tensor(x) else x == y, (lv, parity)
     pf.close()
+
+
+@pytest.mark.parametrize("case", ["two-scenes", "one-window", "own-window", "no-keys", "s3dis-20k"])
+@pytest.mark.parametrize("parity", [0, 1])
+def test_window_edge_builder_equals_the_reference_construction(oracle_backend, case, parity):
+    """csrc/window_edges.hip (rows per query from two point-sized sorts) against oracle/window_tables.py (the reference's pair expansion +
+    stable sort by query + quantised offsets, stratified_transformer_v1m1_origin.py:45-127, 282-292, 507): index_0 / index_1 / offsets /
+    longest row / rel_idx bit-identical -- two scenes, every point in one window, every point alone in its window, an empty key subset,
+    and an S3DIS-shaped scene at the model's first-level window size."""
+    from pointcloudpdf_amd import _native, stratified, synthetic
+
+    g = torch.Generator().manual_seed(5)
+    ws, quant = 0.3, 0.02
+    if case == "s3dis-20k":
+        b = synthetic.make_batch([12000, 8000], first_scene_id=900, device="cpu")
+        xyz, n = b["coord"].float(), 20000
+        batch = (torch.arange(n) >= 12000).long()
+        ws, quant = 0.16, 0.01
+    else:
+        n = 700
+        xyz = torch.rand(n, 3, generator=g) * torch.tensor([1.5, 1.2, 0.4])
+        batch = (torch.arange(n) >= 400).long() if case == "two-scenes" else torch.zeros(n, dtype=torch.long)
+        if case == "one-window":
+            xyz = xyz * 0.1
+        if case == "own-window":
+            n = 64
+            xyz = (torch.stack(torch.meshgrid(torch.arange(4.), torch.arange(4.), torch.arange(4.), indexing="ij"), -1).reshape(-1, 3) + 0.5) * 1.0
+            batch = torch.zeros(n, dtype=torch.long)
+    ds = torch.zeros(0, dtype=torch.int32) if case == "no-keys" else torch.randperm(n, generator=g)[: n // 6 + 1].int()
+    wsz = torch.tensor([ws] * 3)
+    qgl = int((2 * ws + 1e-4) // quant)
+    kf, kc, wk = stratified.window_keys(xyz, batch, wsz, xyz.min(0).values, parity)
+    want = oracle_backend.window_edges(xyz, kf, kc, wk, ds, 2 * ws, quant, 2 * qgl - 1)
+    be = _native.hip_backend()
+    got = be.window_edges(xyz.cuda(), kf.cuda(), kc.cuda(), wk.cuda(), ds.cuda(), 2 * ws, quant, 2 * qgl - 1)
+    names = ["index_0", "index_1", "offsets", "n_max", "rel_idx", "flag"]
+    for name, a, b in zip(names, got, want):
+        if torch.is_tensor(a):
+            assert a.dtype == b.dtype and torch.equal(a.cpu(), b), (case, parity, name)
+        else:
+            assert a == b, (case, parity, name, a, b)
+    assert int(got[5]) == 0 and got[0].shape[0] > 0

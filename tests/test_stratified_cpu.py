@@ -53,23 +53,58 @@ def test_stratified_state_dict_layout_and_registry():
     assert "stem_layer.1.unary_1.0.weight" in m2.state_dict() and "downsample.linear.weight" in m2.state_dict() and len(m2.layers) == 3
 
 
-def test_window_partition_properties():
-    """grid_sample / get_indice_pairs: every point is listed once in its window; the edge list contains every ordered pair of points
-    that share a fine window, and every extra edge ends in an FPS-selected key of the same coarse window but another fine window."""
-    g = torch.Generator().manual_seed(0)
-    xyz = torch.rand(600, 3, generator=g) * torch.tensor([1.5, 1.2, 0.4])
-    batch = (torch.arange(600) >= 350).long()
+def _partition_case(n=600, seed=0, parity=0):
+    g = torch.Generator().manual_seed(seed)
+    xyz = torch.rand(n, 3, generator=g) * torch.tensor([1.5, 1.2, 0.4])
+    batch = (torch.arange(n) >= (7 * n) // 12).long()
     ws = torch.tensor([0.3] * 3)
-    v2p, p2v, counts = stratified.grid_sample(xyz, batch, ws, start=None)
+    kf, kc, wk = stratified.window_keys(xyz, batch, ws, xyz.min(0).values, parity)
+    ds = torch.arange(0, n, 8)
+    return xyz, batch, kf, kc, wk, ds
+
+
+@pytest.mark.parametrize("parity", [0, 1])
+def test_window_partition_properties(parity):
+    """The oracle's restatement of grid_sample / get_indice_pairs (oracle/window_tables.py) on the product's per-point keys: every point is
+    listed once in its window; the edge list contains every ordered pair of points that share a fine window, and every extra edge ends in
+    an FPS-selected key of the same coarse window but another fine window."""
+    from oracle import window_tables
+
+    xyz, batch, kf, kc, wk, ds = _partition_case(parity=parity)
+    p2v, counts = window_tables.p2v_from_keys(kf)
     listed = torch.cat([p2v[i, :counts[i]] for i in range(p2v.shape[0])])
     assert sorted(listed.tolist()) == list(range(600)) and int(counts.sum()) == 600
     for i in range(0, p2v.shape[0], 7):
         members = p2v[i, :counts[i]]
-        assert (v2p[members] == i).all() and len(set(batch[members].tolist())) == 1
-    _, p2v2, counts2 = stratified.grid_sample(xyz, batch, 2 * ws, start=None)
-    ds = torch.arange(0, 600, 8)
-    i0, i1 = stratified.get_indice_pairs(p2v, counts, p2v2, counts2, ds, batch, xyz, ws, 0)
-    same_fine = v2p[i0] == v2p[i1]
+        assert len(set(kf[members].tolist())) == 1 and len(set(batch[members].tolist())) == 1
+    p2v2, counts2 = window_tables.p2v_from_keys(kc)
+    i0, i1 = window_tables.get_indice_pairs(p2v, counts, p2v2, counts2, ds, 600, wk)
+    same_fine = kf[i0] == kf[i1]
     assert int(same_fine.sum()) == int((counts * counts).sum())
     extra = ~same_fine
     assert extra.any() and torch.isin(i1[extra], ds).all() and (batch[i0[extra]] == batch[i1[extra]]).all()
+    assert (kc[i0[extra]] == kc[i1[extra]]).all() and (wk[i0[extra]] != wk[i1[extra]]).all()
+
+
+@pytest.mark.parametrize("parity", [0, 1])
+def test_window_rows_are_what_the_reference_construction_sorts_into(parity):
+    """The per-query statement the device builder implements (csrc/window_edges.hip): after the reference's pair expansion and its
+    stable sort by query, a query's row is [its fine window, ascending] ++ [the downsampled points of its coarse window that lie in
+    another fine window, ascending] -- checked here against the oracle's tables by brute force."""
+    from oracle import window_tables
+
+    xyz, batch, kf, kc, wk, ds = _partition_case(n=500, seed=3, parity=parity)
+    i0, i1, off, n_max, rel, flag = window_tables.window_edges(xyz, kf, kc, wk, ds, 0.6, 0.02, 59)
+    isds = torch.zeros(500, dtype=torch.bool)
+    isds[ds] = True
+    ids = torch.arange(500)
+    rows = 0
+    for q in range(500):
+        fine = ids[kf == kf[q]]
+        coarse = ids[(kc == kc[q]) & isds & (wk != wk[q])]
+        want = torch.cat([fine, coarse]).int()
+        got = i1[off[q]:off[q + 1]]
+        assert torch.equal(got, want), q
+        assert (i0[off[q]:off[q + 1]] == q).all()
+        rows = max(rows, want.shape[0])
+    assert n_max == rows and int(off[-1]) == i0.shape[0] and int(flag) == 0
