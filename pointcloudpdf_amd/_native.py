@@ -1514,7 +1514,7 @@ class HipBackend(CBackend):
                    int(nodes.shape[0]), comp, nul if chosen is None else chosen, ws, ws.numel() * 8)
         return (chosen.view(torch.bool) if chosen is not None else None), comp
 
-    def gmm2_1d(self, x, iters=200, tol=1e-6, reg=1e-6):
+    def gmm2_1d(self, x, iters=100, tol=1e-3, reg=1e-6):
         """Two-component 1-D Gaussian mixture of the float values ``x`` by EM in double, on the device (stands in for
         sklearn.mixture.GaussianMixture(n_components=2).fit, pointpdf_v1m1_base.py:343-345).  -> (8,) float64 on the device: means (2),
         variances (2), weights (2), iterations run, final mean log-likelihood."""

@@ -9,7 +9,9 @@
 // k_forest: minimum spanning forest under the strict total order (weight, entry index) -- with a strict order the forest is unique, so
 // the chosen entries ARE scipy's tree whenever the weights are distinct -- and, as a by-product, the component label of every listed
 // node (the root it ended under).  With w == NULL every active edge is equal: the labels are plain connected components.
-// k_gmm2: two-component 1-D mixture by EM in double: quartile start, 2-means, EM until the mean log-likelihood moves < tol.
+// k_gmm2: two-component 1-D mixture by EM in double: quartile start, 2-means to its fixed point, then sklearn's loop (E-step, M-step, stop
+// when the mean log-likelihood moved < tol) -- with sklearn's defaults (tol 1e-3, 100 iterations) the fit lands where GaussianMixture(2)
+// does (its loose tolerance stops ~5 steps after the k-means start; a fully converged EM ends at another cut: tests/test_pseudo_label.py).
 #include "pdfops_common.h"
 #include <algorithm>
 
@@ -298,7 +300,7 @@ __device__ __forceinline__ Fit gmm2_fit(int m, const float *__restrict__ xs, dou
             for (int i = t; i < m; i += TG) f((double)xs[i]);
         }
     };
-    for (int it2 = 0; it2 < 10; ++it2) {   // 2-means from the quartiles
+    for (int it2 = 0; it2 < 300; ++it2) {   // 2-means from the quartiles, run to its fixed point (sklearn's k-means start: max_iter 300)
         double s[4] = {0.0, 0.0, 0.0, 0.0};
         for_each([&](double x) {
             const int a = fabs(x - mu1) < fabs(x - mu0);   // (argmin: the first on a tie)
@@ -307,8 +309,11 @@ __device__ __forceinline__ Fit gmm2_fit(int m, const float *__restrict__ xs, dou
         });
         block_sum<4>(s, lds);
         if (s[0] == 0.0 || s[1] == 0.0) break;
-        mu0 = s[2] / s[0];
-        mu1 = s[3] / s[1];
+        const double n0 = s[2] / s[0], n1 = s[3] / s[1];
+        const bool fixed = n0 == mu0 && n1 == mu1;   // (every thread holds the same sums: a uniform branch)
+        mu0 = n0;
+        mu1 = n1;
+        if (fixed) break;
     }
     double c0 = mu0, c1 = mu1;   // the shifts of the running sums
     double S[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -342,14 +347,23 @@ __device__ __forceinline__ Fit gmm2_fit(int m, const float *__restrict__ xs, dou
         });
         block_sum<7>(T, lds);
         ll = T[6] / (double)m;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) S[k] = T[k];
+        c0 = mu0; c1 = mu1;
         if (fabs(ll - prev) < tol) {
             ++it;
             break;
         }
         prev = ll;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) S[k] = T[k];
-        c0 = mu0; c1 = mu1;
+    }
+    {   // sklearn's loop is (E-step, M-step, test): the parameters it returns include the M-step of the LAST responsibilities
+        const double n0 = S[0] + 1e-300, n1 = S[1] + 1e-300;
+        pi0 = n0 / (double)m;
+        pi1 = n1 / (double)m;
+        mu0 = c0 + S[2] / n0;
+        mu1 = c1 + S[3] / n1;
+        var0 = S[4] / n0 - (mu0 - c0) * (mu0 - c0) + reg;
+        var1 = S[5] / n1 - (mu1 - c1) * (mu1 - c1) + reg;
     }
     (void)resp;   // (scratch of the earlier forms: kept in the signature)
     if (t == 0) {

@@ -29,6 +29,9 @@ def default_pseudo_mask(coord, seg_logits, offset):
     return (torch.arange(coord.shape[0], device=coord.device) % 7) == 3
 
 
+default_pseudo_mask.capturable = True   # (three elementwise kernels, no host read: recorded into the step's ONE graph like the real pass)
+
+
 ST_V1M1_HOOKS = {  # configs/s3dis/openseg-st-v1m1-0-origin-pointpdf-v1m1-base.py:41-51 (the non-existent "backbone.upsamples.3" left out)
     **{f"backbone.upsamples.{i}": ["forward_input", "forward_output"] for i in range(3)},
     "backbone": ["forward_output"],
@@ -180,7 +183,8 @@ class CapturedStep:
         # the fork are then outside the graph's private pool (observed: replays that read recycled memory once eager work ran in between).
         self.stream = side   # an EAGER step of the same module between replays is fastest on this stream (see the comment above: the
         #                      parameters' AccumulateGrad nodes stay bound to it for as long as the captured autograd graph lives)
-        self.graph, self.graph2, self.mask_fn = torch.cuda.CUDAGraph(keep_graph=bool(debug_graph)), None, None
+        self._keep_graph = bool(debug_graph)
+        self.graph, self.graph2, self.mask_fn = torch.cuda.CUDAGraph(keep_graph=self._keep_graph), None, None
         self._census = None
         rec = getattr(step, "recognizer", None)
         fn = getattr(rec, "pseudo_mask_fn", None)
@@ -204,6 +208,9 @@ class CapturedStep:
         hold none, whatever the runtime's packet-capture switch says."""
         if self._census is None:
             self._census = graph_node_census(self.graph.raw_cuda_graph())
+            if self.graph2 is not None:   # (a step split around a host-driven pseudo-label pass: both halves)
+                second = graph_node_census(self.graph2.raw_cuda_graph())
+                self._census = {k: v + second[k] for k, v in self._census.items()}
         return self._census
 
     def _capture_around_the_pseudo_label_pass(self, rec, side, dev):
@@ -218,7 +225,7 @@ class CapturedStep:
 
         n = int(self.static["coord"].shape[0])
         self.static_mask = torch.zeros(n, dtype=torch.bool, device=dev)
-        self.mask_fn, self.static_logits, g1, g2 = rec.pseudo_mask_fn, None, self.graph, torch.cuda.CUDAGraph()
+        self.mask_fn, self.static_logits, g1, g2 = rec.pseudo_mask_fn, None, self.graph, torch.cuda.CUDAGraph(keep_graph=self._keep_graph)
         state = {"split": False}
 
         def switch_graphs(coord, seg_logits, offset):

@@ -529,22 +529,26 @@ def run_gridsample_cases():
     return out
 
 
-def pseudo_label_scene(seed, n):
+def pseudo_label_scene(seed, n, radius=0.8, slope=4.0):
     """A scene with a smooth low-confidence blob: coordinates from the synthetic generator, 20-class logits that are confident
-    everywhere except around one furniture-sized region."""
+    everywhere except around one region (``radius`` m, ``slope`` of its rim per m)."""
     sc = synthetic.make_scene(n, scene_id=seed, kind="scannet")
     coord = torch.from_numpy(sc["coord"])
     g = torch.Generator().manual_seed(seed)
     centre = coord[torch.randint(0, n, (1,), generator=g)]
     d = torch.norm(coord - centre, dim=-1)
-    conf = 6.0 * torch.sigmoid((d - 0.8) * 4.0) + 0.3 * torch.randn(n, generator=g)       # low near the centre
+    conf = 6.0 * torch.sigmoid((d - radius) * slope) + 0.3 * torch.randn(n, generator=g)       # low near the centre
     logits = 0.2 * torch.randn(n, 20, generator=g)
     cls = (coord[:, 0] * 3).long() % 20
     logits[torch.arange(n), cls] += conf
     return coord, logits
 
 
-PSEUDO_CASES = {"s1": (5, 6000), "s2": (9, 9000)}
+# tag: (seed, points, blob radius, rim slope).  s1 / s2 (rounds 1-5) leave the reference's `while True` (pointpdf_v1m1_base.py:233-305) at its
+# first check: the 100 seeds already satisfy the stop rule, NO growth round runs.  Round 6: s3 / s4 -- a blob of ~17 % of the scene with a
+# steep rim -- take 8 / 11 growth rounds (`<tag>_rounds`: counted through the loop's one torch.topk call per round); s5 is a small scene
+# whose 100 seed draws repeat (89 distinct, `<tag>_distinct_seeds`) and grows for 5 rounds.
+PSEUDO_CASES = {"s1": (5, 6000, 0.8, 4.0), "s2": (9, 9000, 0.8, 4.0), "s3": (11, 12000, 0.45, 8.0), "s4": (13, 20000, 0.6, 8.0), "s5": (31, 3000, 0.5, 8.0)}
 PSEUDO_KW = dict(condition_from="msp", beta=1.5, seed_from="ml", seed_range=0.15, num_seed=100, slide_window=True)
 
 
@@ -566,17 +570,32 @@ def run_pseudo_label_cases():
     spec.loader.exec_module(mod)
     be = oracle.backend()
     out = {}
-    for tag, (seed, n) in PSEUDO_CASES.items():
-        coord, logits = pseudo_label_scene(seed, n)
+    real_topk = torch.topk
+    for tag, (seed, n, radius, slope) in PSEUDO_CASES.items():
+        coord, logits = pseudo_label_scene(seed, n, radius, slope)
         off = torch.tensor([n], dtype=torch.int32)
         nn, _ = be.ball_query(64, 0.1, 0.0, coord.contiguous(), coord.contiguous(), off, off, order=torch.arange(n, dtype=torch.int32))
+        rounds = [0]
+
+        def counting_topk(*a, **k):   # (the growth loop calls torch.topk exactly once per round, :291-293)
+            rounds[0] += 1
+            return real_topk(*a, **k)
+
         torch.manual_seed(seed)
         np.random.seed(seed)
-        mask = mod.PointPdfV1.pseudo_labeling(coord, logits, nn.long(), PSEUDO_KW["condition_from"], PSEUDO_KW["beta"], PSEUDO_KW["seed_from"],
-                                              PSEUDO_KW["seed_range"], PSEUDO_KW["num_seed"], PSEUDO_KW["slide_window"])
+        torch.topk = counting_topk
+        try:
+            mask = mod.PointPdfV1.pseudo_labeling(coord, logits, nn.long(), PSEUDO_KW["condition_from"], PSEUDO_KW["beta"], PSEUDO_KW["seed_from"],
+                                                  PSEUDO_KW["seed_range"], PSEUDO_KW["num_seed"], PSEUDO_KW["slide_window"])
+        finally:
+            torch.topk = real_topk
+        torch.manual_seed(seed)
+        dice = torch.randint(0, int(PSEUDO_KW["seed_range"] * n), [PSEUDO_KW["num_seed"]])   # the draw the method makes first (:206)
         out[f"{tag}_mask"] = mask.numpy()
         out[f"{tag}_nn_rows"] = nn[:50].numpy()
-        print("pseudo", tag, int(mask.sum()), "of", n)
+        out[f"{tag}_rounds"] = np.array(rounds[0])
+        out[f"{tag}_distinct_seeds"] = np.array(len(set(dice.tolist())))
+        print("pseudo", tag, int(mask.sum()), "of", n, "growth rounds", rounds[0], "distinct seed draws", len(set(dice.tolist())))
     return out
 
 

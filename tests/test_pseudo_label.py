@@ -10,11 +10,14 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
 
-PSEUDO_CASES = {"s1": (5, 6000), "s2": (9, 9000)}
+# tag: (seed, points, blob radius, rim slope) -- tests/golden/make_golden.py::PSEUDO_CASES.  s1 / s2 leave the reference's growth loop at its
+# first check (0 rounds); s3 / s4 take 8 / 11 growth rounds, s5 has repeated seed draws (89 distinct of 100) and 5 rounds (round 6)
+PSEUDO_CASES = {"s1": (5, 6000, 0.8, 4.0), "s2": (9, 9000, 0.8, 4.0), "s3": (11, 12000, 0.45, 8.0), "s4": (13, 20000, 0.6, 8.0), "s5": (31, 3000, 0.5, 8.0)}
+EXACT_ON_DEVICE = ("s1", "s2")   # no growth round: nothing a device exp / softmax rounding could move
 PSEUDO_KW = dict(condition_from="msp", beta=1.5, seed_from="ml", seed_range=0.15, num_seed=100, slide_window=True)
 
 
-def pseudo_label_scene(seed, n):
+def pseudo_label_scene(seed, n, radius=0.8, slope=4.0):
     """Same generator as tests/golden/make_golden.py::pseudo_label_scene."""
     from pointcloudpdf_amd import synthetic
 
@@ -23,7 +26,7 @@ def pseudo_label_scene(seed, n):
     g = torch.Generator().manual_seed(seed)
     centre = coord[torch.randint(0, n, (1,), generator=g)]
     d = torch.norm(coord - centre, dim=-1)
-    conf = 6.0 * torch.sigmoid((d - 0.8) * 4.0) + 0.3 * torch.randn(n, generator=g)
+    conf = 6.0 * torch.sigmoid((d - radius) * slope) + 0.3 * torch.randn(n, generator=g)
     logits = 0.2 * torch.randn(n, 20, generator=g)
     cls = (coord[:, 0] * 3).long() % 20
     logits[torch.arange(n), cls] += conf
@@ -39,8 +42,8 @@ def gp(golden_dir):
 def test_pseudo_labeling_matches_reference_method(use_oracle, gp, tag):
     from pointcloudpdf_amd import pseudo_label
 
-    seed, n = PSEUDO_CASES[tag]
-    coord, logits = pseudo_label_scene(seed, n)
+    seed, n = PSEUDO_CASES[tag][:2]
+    coord, logits = pseudo_label_scene(*PSEUDO_CASES[tag])
     off = torch.tensor([n], dtype=torch.int32)
     nn = pseudo_label.radius_neighbors(coord, off, 0.1, 64)          # oracle-backed here: first 64 in index order within 0.1 m
     assert np.array_equal(nn[:50].numpy(), gp[f"{tag}_nn_rows"])
@@ -48,6 +51,9 @@ def test_pseudo_labeling_matches_reference_method(use_oracle, gp, tag):
     np.random.seed(seed)
     mask = pseudo_label.pseudo_labeling(coord, logits, nn, generator=torch.Generator().manual_seed(seed), **PSEUDO_KW)
     assert mask.dtype == torch.bool and np.array_equal(mask.numpy(), gp[f"{tag}_mask"])
+    # the multi-round cases really are multi-round in the reference's own run, and the repeated-seed case really repeats
+    assert int(gp[f"{tag}_rounds"]) == {"s1": 0, "s2": 0, "s3": 8, "s4": 11, "s5": 5}[tag]
+    assert int(gp["s5_distinct_seeds"]) == 89
 
 
 @pytest.mark.gpu
@@ -72,9 +78,15 @@ def test_pseudo_mask_on_gpu_batch(gp):
         mask = pseudo_label.pseudo_labeling(coord[start:start + n], logits[start:start + n], local,
                                             generator=torch.Generator().manual_seed(seed), **PSEUDO_KW).numpy()
         ref = gp[f"{t}_mask"]
-        # exact on these fixtures (no seed / top-k boundary sits at a float tie between the device's and the host's softmax: checked with
-        # a one-off probe of round 4 -- 86 / 57 points, 0 differing); round 2 only bounded the overlap
-        assert np.array_equal(mask, ref), (t, int(mask.sum()), int(ref.sum()), int((mask ^ ref).sum()))
+        # exact where no growth round runs (s1 / s2: no seed / top-k boundary sits at a float tie between the device's and the host's
+        # softmax); the multi-round cases rank exp(-|score - ref|) of the device against the host's: a last-bit difference may move a
+        # 40 % boundary, bounded here by the overlap
+        if t in EXACT_ON_DEVICE:
+            assert np.array_equal(mask, ref), (t, int(mask.sum()), int(ref.sum()), int((mask ^ ref).sum()))
+        else:
+            iou = (mask & ref).sum() / max((mask | ref).sum(), 1)
+            print(f"pseudo-label case {t}: {int(mask.sum())} vs {int(ref.sum())} points, {int((mask ^ ref).sum())} differ, IoU {iou:.4f}")
+            assert iou >= 0.97, (t, iou)
         start += n
     full = pseudo_label.get_pseudo_mask(coord, logits, off, radius=0.1, max_neighbor=64, generator=torch.Generator().manual_seed(1), **PSEUDO_KW)
     assert full.shape == (sum(sizes),) and full.dtype == torch.bool and full.is_cuda and 0 < int(full.sum()) < sum(sizes) // 4
@@ -103,8 +115,9 @@ def test_mask_based_region_growing_equals_the_line_by_line_form(use_oracle):
     round) on the fixture scenes: the same region, element for element; with and without the sliding window."""
     from pointcloudpdf_amd import pseudo_label as pl
 
-    for tag, (seed, n) in PSEUDO_CASES.items():
-        coord, logits = pseudo_label_scene(seed, n)
+    for tag, case in PSEUDO_CASES.items():
+        seed, n = case[:2]
+        coord, logits = pseudo_label_scene(*case)
         nn = pl.radius_neighbors(coord, torch.tensor([n], dtype=torch.int32), 0.1, 64)
         msp = torch.softmax(logits, dim=-1).max(dim=-1)[0]
         ml = logits.max(dim=-1)[0]
@@ -168,8 +181,9 @@ def test_device_pruning_matches_host_pruning(use_oracle, gp):
     can differ only through the mixture fit (deterministic EM vs sklearn's k-means-seeded one)."""
     from pointcloudpdf_amd import pseudo_label as pl
 
-    for tag, (seed, n) in PSEUDO_CASES.items():
-        coord, logits = pseudo_label_scene(seed, n)
+    for tag, case in PSEUDO_CASES.items():
+        seed, n = case[:2]
+        coord, logits = pseudo_label_scene(*case)
         nn = pl.radius_neighbors(coord, torch.tensor([n], dtype=torch.int32), 0.1, 64)
         np.random.seed(seed)
         host = pl.pseudo_labeling(coord, logits, nn, generator=torch.Generator().manual_seed(seed), prune="host", **PSEUDO_KW)
@@ -299,7 +313,8 @@ def test_hip_pruning_equals_the_torch_op_pruning():
 def test_static_pass_equals_the_host_driven_pass(gp, monkeypatch):
     """get_pseudo_mask_static (all growth rounds in one kernel, region graph / forest / mixture / components with device-side sizes, no host
     read) against the host-driven form of rounds 1-4 (PDFOPS_PL_STATIC=0) and the reference's fixtures: the fixture scenes (1 growth
-    round), a structured confidence map (many rounds), a random-logit scene, and a two-scene batch in ONE call."""
+    round; round 6: three cases of 5 - 11 growth rounds in the reference's own run, one with repeated seeds), a structured confidence map
+    (many rounds), a random-logit scene, and a two-scene batch in ONE call."""
     from pointcloudpdf_amd import pseudo_label as pl, synthetic
 
     scenes = [pseudo_label_scene(*PSEUDO_CASES[t]) for t in sorted(PSEUDO_CASES)]
@@ -322,11 +337,19 @@ def test_static_pass_equals_the_host_driven_pass(gp, monkeypatch):
         masks_static.append(a)
         rounds.append(int(info["grow"][0, 0]))
     assert max(rounds) >= 3, rounds
-    for t, (seed, n) in PSEUDO_CASES.items():            # the reference's own masks
-        coord, logits = pseudo_label_scene(seed, n)
+    for t, case in PSEUDO_CASES.items():                 # the reference's own masks -- and its own number of growth rounds (s3 - s5: 8 / 11 / 5)
+        seed, n = case[:2]
+        coord, logits = pseudo_label_scene(*case)
         nn = pl.radius_neighbors(coord.cuda(), torch.tensor([n], dtype=torch.int32, device="cuda"), 0.1, 64)
-        m = pl.get_pseudo_mask_static(coord.cuda(), logits.cuda(), [n], nn, generator=torch.Generator().manual_seed(seed), **PSEUDO_KW)
-        assert np.array_equal(m.cpu().numpy(), gp[f"{t}_mask"]), t
+        info = {}
+        m = pl.get_pseudo_mask_static(coord.cuda(), logits.cuda(), [n], nn, generator=torch.Generator().manual_seed(seed), info=info, **PSEUDO_KW)
+        got, ref = m.cpu().numpy(), gp[f"{t}_mask"]
+        if t in EXACT_ON_DEVICE:
+            assert np.array_equal(got, ref), t
+        else:
+            iou = (got & ref).sum() / max((got | ref).sum(), 1)
+            print(f"static pass, case {t}: rounds {int(info['grow'][0, 0])} (reference {int(gp[f'{t}_rounds'])}), {int((got ^ ref).sum())} of {int(ref.sum())} points differ, IoU {iou:.4f}")
+            assert abs(int(info["grow"][0, 0]) - int(gp[f"{t}_rounds"])) <= 1 and iou >= 0.97, (t, info["grow"].tolist(), iou)
     # two scenes in one call = the scenes one by one (same generator order)
     (ca, la), (cb, lb) = scenes[0], scenes[1]
     coord, logits = torch.cat([ca, cb]).cuda(), torch.cat([la, lb]).cuda()
@@ -490,3 +513,34 @@ def test_static_pass_on_a_batch_of_many_small_scenes():
         nn1 = pl.radius_neighbors(c.cuda(), torch.tensor([n], dtype=torch.int32, device="cuda"), 0.1, 64)
         one.append(pl.get_pseudo_mask_static(c.cuda(), l.cuda(), [n], nn1, generator=gen, **PSEUDO_KW))
     assert torch.equal(both, torch.cat(one)) and int(both.sum()) > 0
+
+
+@pytest.mark.gpu
+def test_device_mixture_cut_lands_where_sklearn_does():
+    """csrc/graph_prune.hip's mixture fit (pdf_gmm2_1d: deterministic start, sklearn's loop and defaults) against
+    sklearn.mixture.GaussianMixture(2) on the spanning-tree weights of the reference fixtures' regions (2,317 / 3,797 / 827 edges; the same
+    numpy seed as the fixture run): the cut ``mean - 2 * covariance`` of the larger component within 2e-3 (sklearn's own spread over its
+    random starts is 2e-4 there), and the same edges below it up to 1 %."""
+    from sklearn.mixture import GaussianMixture
+    from pointcloudpdf_amd import pseudo_label as pl
+
+    for tag in ("s3", "s4", "s5"):
+        seed, n = PSEUDO_CASES[tag][:2]
+        coord, logits = pseudo_label_scene(*PSEUDO_CASES[tag])
+        coord, logits = coord.cuda(), logits.cuda()
+        nn = pl.radius_neighbors(coord, torch.tensor([n], dtype=torch.int32, device="cuda"), 0.1, 64)
+        info = {}
+        pl.get_pseudo_mask_static(coord, logits, [n], nn, generator=torch.Generator().manual_seed(seed), info=info, **PSEUDO_KW)
+        m = int(info["tree"][0, 1])                                     # edges of the scene's spanning tree
+        w = info["tree_weights"][:m].double().cpu().numpy()
+        fit = info["fit"][0].double().cpu().numpy()                     # means (2), variances (2), weights (2), iterations, log-likelihood
+        mu, var = fit[0:2], fit[2:4]
+        top = int(np.argmax(mu))
+        cut = mu[top] - 2.0 * var[top]
+        np.random.seed(seed)
+        gm = GaussianMixture(2).fit(w.reshape(-1, 1))
+        j = int(np.argmax(gm.means_.flatten()))
+        ref = gm.means_.flatten()[j] - 2.0 * gm.covariances_.flatten()[j]
+        moved = int(((w < cut) != (w < ref)).sum())
+        print(f"mixture cut, case {tag}: {len(w)} tree edges, device {cut:.5f} vs sklearn {ref:.5f} ({gm.n_iter_} iterations), {moved} edges change side")
+        assert abs(cut - ref) <= 2e-3 and moved <= max(1, len(w) // 100), (tag, cut, ref, moved)
