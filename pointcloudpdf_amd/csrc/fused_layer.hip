@@ -1177,7 +1177,7 @@ int backward_impl(LayerArgs A, float *sums, const int *inv_off, const int *inv_e
     allow_lds(k_b3<C, K>, lds);
     const bool mfma = flm::supported(K, C);
     // (the scratch is sized for B2's rows at `grid`; B1 / B3 rows are shorter, so more waves fit)
-    int g1 = mfma ? pass_grid(B1, A.N, grid) : grid, g3 = mfma ? pass_grid(B3, A.N, C == 256 ? 2 * grid : (C == 64 ? 4 * grid : grid)) : grid;
+    int g1 = mfma ? pass_grid(B1, A.N, C == 64 ? 768 : grid) : grid, g3 = mfma ? pass_grid(B3, A.N, C == 256 ? 2 * grid : (C == 64 ? 4 * grid : grid)) : grid;
     g1 = (int)std::min<long>(g1, (long)grid * b2_width<C>() / b1_width<C>());
     g3 = (int)std::min<long>(g3, (long)grid * b2_width<C>() / b3_pwidth<C>());
     BnpClosed none;
@@ -1189,7 +1189,7 @@ int backward_impl(LayerArgs A, float *sums, const int *inv_off, const int *inv_e
     int rc = pdf_seg_sum_weighted_x(A.N, C, K, CS, A.gout, A.Wsm, A.bf16, inv_off, inv_entry, entry_base, gather_order, A.gxv, s);   // (destinations in Morton order: the g_out rows they share hit L2)
     if (rc != PDF_OK) return rc;
     A.sums = as_const(S1);
-    const int g2 = mfma ? std::min(grid, pass_grid(B2, A.N, C == 512 ? 32 : (C == 256 ? 128 : grid))) : grid;
+    const int g2 = mfma ? std::min(C == 64 ? 2 * grid : grid, pass_grid(B2, A.N, C == 512 ? 32 : (C == 256 ? 128 : (C == 64 ? 768 : grid)))) : grid;   // (C = 64: one slab, three workgroups per CU since round 6 -- the scratch holds grid * WPB rows)
     // level 1 on the matrix-core form: 112 / 154 registers -> 4 / 3 waves per SIMD, so 4 / 3 workgroups per CU instead of the row-per-lane
     // passes' 2 (the scratch holds grid * WPB rows of B2's width: room for them)
     static const int l1_mul = [] { const char *v = getenv("PDFOPS_L1_GRID_MUL"); return v ? atoi(v) : 1; }();   // (measured 1 .. 4: 15.32 - 15.39 ms per step, no trend)

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64 * WPB) void k_p4(LayerArgs A) {
 // ------------------------------------------------------------------------------------------------ B1
 // partial row per block: [sum g_y2 (CS) | sum g_y2*hhat (CS) | g_bw2 (CS) | g_Ww2 (CS*CS)]   (as fl::k_b1)
 template <int C, bool BF>
-__global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(C == 64 ? 3 : 1, 8))) void k_b1(LayerArgs A) {   // (C = 64: 176 -> 168 registers: 79 -> 73 us with 768 workgroups)
     constexpr int CS = C / 8, NOB = nob_of(C), CSP = csp_of(C), NCHK = C / 64, GS = CSP + 4, WS2 = CSP + 4, W = 3 * CS + CS * CS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *cst = lds, *ucst = cst + 4 * C, *w2 = ucst + 7 * CSP;           // Wp2 (3C) | bp2 (C); per-unit constants; padded Ww2
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(64 * WPB) void k_b1(LayerArgs A) {
 // partial row per block (all slabs of one blockIdx.x write disjoint columns of the same row):
 //   [sum g_y1 (C) | sum g_y1*rhat (C) | g_bw1 (CS) | g_Ww1 (CS*C)]   (as fl::k_b2)
 template <int C, bool BF>
-__global__ __launch_bounds__(64 * WPB) void k_b2(LayerArgs A) {
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(C == 64 ? 3 : 1, 8))) void k_b2(LayerArgs A) {   // (C = 64: 180 -> 168 registers, 9 spilled: a third wave per SIMD, 80 -> 77 us with 768 workgroups; the same hint costs C = 128 +25 %)
     constexpr int CS = C / 8, NOB = nob_of(C), CSP = csp_of(C), GS = CSP + 4, WS = 68, W = 2 * C + CS + CS * C;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wv = threadIdx.x >> 6;

@@ -10,8 +10,8 @@ import sys
 CATS = [
     ("fps", r"k_fps|k_bbox|k_hist|k_scan\b|k_scatter|k_pad|k_meta|fps_"),
     ("knn grid/scan", r"kg::|knn_"),
-    ("pt-layer fwd (k_p*)", r"flm?::k_p\d"),
-    ("pt-layer bwd (k_b*)", r"flm?::k_b\d"),
+    ("pt-layer fwd (k_p*)", r"fl[ms]?::k_p\d"),
+    ("pt-layer bwd (k_b*)", r"fl[ms]?::k_b\d"),
     ("bn finalize/colsum/eval", r"fl::k_bn_finalize|fl::k_colsum|fl::k_bn_eval"),
     ("pointwise bn (pw::)", r"pw::"),
     ("rowlin (rl:: / rl2::)", r"rl2?::"),

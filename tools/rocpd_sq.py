@@ -19,7 +19,7 @@ import re
 import sqlite3
 import sys
 
-HOT = re.compile(r"fl::k_[bp]\d|flm::k_[bp]\d|rl2::k_|rl::k_|td::k_|sg::k_seg|pw::k_bn|fl::k_colsum|fl::k_bn_finalize|kg::k_grid_query|k_fps_mw|"
+HOT = re.compile(r"fl::k_[bp]\d|fl[ms]::k_[bp]\d|rl2::k_|rl::k_|td::k_|sg::k_seg|pw::k_bn|fl::k_colsum|fl::k_bn_finalize|kg::k_grid_query|k_fps_mw|"
                  r"k_dot3|k_step|gather|grouping|interp|agg_|sub_|wb::k_|ln::k_|k_seg_softmax|rg::k_|gp::k_|k_grid_radius")
 
 
@@ -143,7 +143,7 @@ def to_json(out, kt_db, steps, files):
                    lds_bank_conflict=round(c.get("SQ_LDS_BANK_CONFLICT", 0) / max(c.get("SQ_LDS_IDX_ACTIVE", 0), 1.0), 3),
                    mfma_busy=round(mfma_busy(c), 4), mfma_insts_per_launch=int(c.get("SQ_INSTS_MFMA", 0)))
         kernels[k] = row
-        f = re.match(r"(?:void )?(rl2|rl|flm|fl|td)::", k)
+        f = re.match(r"(?:void )?(rl2|rl|flm|fls|fl|td)::", k)
         if f:
             a = fam.setdefault(f.group(1), dict(us_per_step=0.0, mfma_busy_us_per_step=0.0))
             a["us_per_step"] += avg_us * per_step

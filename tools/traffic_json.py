@@ -21,8 +21,8 @@ sys.path.insert(0, ROOT)
 
 # composite host calls -> the kernels they launch (regular expressions on demangled names) and calls per step
 HOST_CALLS = {
-    "bottleneck_backward": (r"flm?::k_b\d|sg::k_seg_rows|sg::k_seg_weighted<4, true>|rl2::k_wg|pw::k_bn_bwd|fl::k_colsum", 18),   # (seg_weighted<4, false> = interpolation backward, outside the blocks)
-    "bottleneck_forward": (r"flm?::k_p\d|rl2::k_fwd|fl::k_bn_finalize|pw::k_bn_apply|pw::k_bn_stats", 18),
+    "bottleneck_backward": (r"fl[ms]?::k_b\d|sg::k_seg_rows|sg::k_seg_weighted<4, true>|rl2::k_wg|pw::k_bn_bwd|fl::k_colsum", 18),   # (seg_weighted<4, false> = interpolation backward, outside the blocks)
+    "bottleneck_forward": (r"fl[ms]?::k_p\d|rl2::k_fwd|fl::k_bn_finalize|pw::k_bn_apply|pw::k_bn_stats", 18),
     "farthest_point_sampling": (r"k_fps|fps_plain", None),   # per launch (the grouped pre-pass launches it once per level)
 }
 
