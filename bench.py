@@ -260,6 +260,23 @@ class KernelTimer:
 
             setattr(self.backend, n, wrapped)
 
+    # ---- replayed measuring steps (engine.CapturedStep(split_calls=): the step as a sequence of graphs cut around the named calls)
+    STEP_CALLS = ("group_forward", "group_backward", "pt_layer_forward", "pt_layer_backward", "bottleneck_forward", "bottleneck_backward")
+
+    def describe(self, name, args, out):
+        """What a segmented capture remembers about a named call: its algorithmic bytes / flops (the tensors are gone at replay time)."""
+        return (self._bytes(name, args, out), self.mfma_flops(name, args))
+
+    def on_call(self, name, info, replay):
+        """The named call of a replayed measuring step: its graph between two HIP events on the replay's stream."""
+        if not self.enabled:
+            return replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        replay()
+        e1.record()
+        self.records[name].append((e0, e1) + tuple(info))
+
     @staticmethod
     def _bytes(name, args, out):
         """Algorithmic HBM bytes of one call."""
@@ -662,8 +679,16 @@ def main():
         if D > 0 and st_prefetcher is None:   # allocator pools of the pre-pass streams at their steady state (GroupedGeometryLoader.warm)
             sched_warm[0] = loader.warm([next(batch_stream()) for _ in range(D)])
         it = iter(loader)
-        for _ in range(warmup):
-            out = trainer(next(it))
+        segmented = False
+        for w in range(warmup):
+            b = next(it)
+            # the LAST warm-up step makes (and runs once) the segmented capture the measuring step of the timed region replays: the
+            # step as a sequence of graphs cut around the timed calls (engine.CapturedStep(split_calls=)); without it -- eager schedules,
+            # a stack that cannot capture, PDFOPS_BENCH_EAGER_SAMPLE=1 -- the measuring step runs eagerly as in rounds 1-5
+            if (with_timer and w == warmup - 1 and w >= 1 and trainer.captured is not None and not strat
+                    and not os.environ.get("PDFOPS_BENCH_EAGER_SAMPLE") and b.get("pdf_geometry") is not None):
+                segmented = trainer.instrument(b, b["pdf_geometry"], KernelTimer.STEP_CALLS, timer.describe)
+            out = trainer(b, on_call=(lambda name, info, replay: replay()) if segmented else None)
         fence()
         timer.enabled = with_timer
         if isinstance(trainer.exchange, TimedExchange):
@@ -676,8 +701,11 @@ def main():
         t0 = time.perf_counter()
         for i in range(steps):
             timer.sample = every > 0 and i % every == sample_at
-            out = trainer(next(it), eager=with_timer and timer.sample and replaying)
+            measuring = with_timer and timer.sample and replaying
+            out = trainer(next(it), eager=measuring, on_call=timer.on_call if (measuring and segmented) else None)
         info = Region()
+        info.segmented = segmented and trainer.instrumented is not None
+        info.instrument_error = trainer.instrument_error
         info.enqueue_s = time.perf_counter() - t0   # host time to enqueue the K steps (the device may still be working)
         fence()
         dt = time.perf_counter() - t0
@@ -727,7 +755,9 @@ def main():
                      launches_per_step=ks[name]["calls"] / steps_of(name),
                      gpu_time_share_of_step=ks[name]["total_ms"] / steps_of(name) / (dt / args.steps * 1e3),
                      timed_steps=f"{timer.sampled_steps} of {args.steps} (every {getattr(timer, 'every_used', timer.every)}th step of the timed region carries the HIP events"
-                                 + ("; those steps run eagerly, the others are graph replays)" if trainer.captured is not None else ")"))
+                                 + (("; those steps replay the SEGMENTED capture -- the same step as a sequence of graphs cut around the timed calls, "
+                                     "events between the segments -- the others the one-graph capture)" if getattr(sched, "segmented", False)
+                                     else "; those steps run eagerly, the others are graph replays)") if trainer.captured is not None else ")"))
             if ks[name].get("avg_mfma_flops"):   # config 5's table ops: algorithmic flops of the definition next to the bytes
                 r["algorithmic_flops_per_launch"] = ks[name]["avg_mfma_flops"]
                 r["achieved_TFLOPs_on_algorithmic_flops"] = ks[name]["avg_mfma_flops"] / (ks[name]["avg_ms"] * 1e-3) / 1e12
@@ -780,7 +810,9 @@ def main():
             "preflight": pre,
             "loss": loss,
             "execution": ("engine.GroupedGeometryLoader + engine.TrainStep: forward + backward replayed as one captured hipGraph (fixed scene sizes), "
-                          "optimizer / gradient exchange / geometry pre-pass eager; the ONE step of the timed region that carries per-kernel HIP events runs eagerly"
+                          "optimizer / gradient exchange / geometry pre-pass eager; the ONE step of the timed region that carries per-kernel HIP events "
+                          + ("replays the segmented capture (engine.CapturedStep(split_calls=): graphs cut around the timed calls)" if getattr(sched, "segmented", False)
+                             else "runs eagerly" + (f" (segmented capture unavailable: {sched.instrument_error})" if getattr(sched, "instrument_error", None) else ""))
                           if trainer.captured is not None else
                           ("engine.GroupedGeometryLoader + engine.TrainStep, eager (one Python-issued launch sequence per step)"
                            + (f"; graph capture failed: {trainer.capture_error}" if trainer.capture_error else ""))),

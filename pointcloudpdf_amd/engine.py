@@ -132,8 +132,14 @@ class CapturedStep:
 
     KEYS = ("coord", "feat", "offset", "segment")
 
-    def __init__(self, step, batch, geom=None, warmup=2, autocast=None, loss_scale=1.0, stream=None, debug_graph=False):
-        """``debug_graph``: keep the captured hipGraph inspectable (``node_census``: the rule "no memset node inside a captured step" is
+    def __init__(self, step, batch, geom=None, warmup=2, autocast=None, loss_scale=1.0, stream=None, debug_graph=False, split_calls=None,
+                 describe=None):
+        """``split_calls``: names of backend entry points (``_native.HipBackend`` methods, e.g. ``("bottleneck_backward",)``): the step is
+        captured as a SEQUENCE of graphs sharing one memory pool, cut before and after every call of one of them, so that a replayed step
+        can carry HIP events around exactly those calls (``__call__(..., on_call=)``; events cannot be recorded inside a graph on this
+        stack: tools/probes/event_in_graph_probe.py).  ``describe(name, args, out)``: what to remember about such a call (handed back to
+        ``on_call``).  A training loop replays the ONE-graph capture; the segmented one is for the steps that measure.
+        ``debug_graph``: keep the captured hipGraph inspectable (``node_census``: the rule "no memset node inside a captured step" is
         checked by walking the graph, tests/test_gpu_model.py).
         ``stream``: the stream to capture on (default: a new one) -- e.g. a CU-masked stream (``_native.cu_masked_stream``), see TrainStep.
         ``autocast``: torch.float16 / torch.bfloat16 -> the forward is captured under torch.autocast (the path then runs its
@@ -188,7 +194,12 @@ class CapturedStep:
         self._census = None
         rec = getattr(step, "recognizer", None)
         fn = getattr(rec, "pseudo_mask_fn", None)
-        if fn is None or getattr(fn, "capturable", False):   # (the sync-free pseudo-label pass is recorded like any other stage)
+        self.segments = None
+        if split_calls:
+            if not (fn is None or getattr(fn, "capturable", False)):
+                raise RuntimeError("CapturedStep(split_calls=): a step with a host-driven pseudo-label pass cannot be segmented")
+            self._capture_segmented(side, dev, tuple(split_calls), describe)
+        elif fn is None or getattr(fn, "capturable", False):   # (the sync-free pseudo-label pass is recorded like any other stage)
             with torch.cuda.graph(self.graph, stream=side):
                 self.out = self._eager()
                 self._backward(self.out)
@@ -206,12 +217,84 @@ class CapturedStep:
         the hipGraph next to its executable form): {"nodes", "kernel", "memcpy", "memset", "other"}.
         A memset node inside a captured step is what replayed with stale arguments on ROCm 7.2 (docs/NOTEBOOK.md, round 5): the step must
         hold none, whatever the runtime's packet-capture switch says."""
+        if self._census is None and self.segments is not None:
+            self._census = {}
+            for g, _, _ in self.segments:
+                for k, v in graph_node_census(g.raw_cuda_graph()).items():
+                    self._census[k] = self._census.get(k, 0) + v
+            self._census["segments"] = len(self.segments)
         if self._census is None:
             self._census = graph_node_census(self.graph.raw_cuda_graph())
             if self.graph2 is not None:   # (a step split around a host-driven pseudo-label pass: both halves)
                 second = graph_node_census(self.graph2.raw_cuda_graph())
                 self._census = {k: v + second[k] for k, v in self._census.items()}
         return self._census
+
+    def _capture_segmented(self, side, dev, split_calls, describe):
+        """The step as a sequence of graphs (one pool): [... up to a named call][the call][... up to the next][the call] ... -- the
+        capture switches graphs from INSIDE the forward / backward, in a wrapper around the named backend methods.  The backward runs on
+        the capturing thread (autograd's per-device worker thread could not end a capture this thread began)."""
+        import gc
+        from . import _native
+
+        be = _native.hip_backend()
+        segs, cur, pool, graveyard = [], {"g": None}, torch.cuda.graph_pool_handle(), []
+
+        def begin():
+            g = torch.cuda.CUDAGraph(keep_graph=self._keep_graph)
+            g.capture_begin(pool=pool)
+            cur["g"] = g
+
+        def end(label, info=None):
+            import warnings
+            with warnings.catch_warnings(record=True) as caught:   # (two named calls back to back leave an EMPTY graph between them)
+                warnings.simplefilter("always")
+                cur["g"].capture_end()
+            empty = any("Graph is empty" in str(w.message) for w in caught)
+            if not empty or label is not None:
+                segs.append((cur["g"], label, info))
+            else:   # dropped from the replay list, but kept alive until the whole capture is over: a graph destroyed while the NEXT
+                graveyard.append(cur["g"])   # one captures makes a runtime call the capture forbids (the process aborts)
+
+        originals = {}
+        for name in split_calls:
+            orig = getattr(be, name)
+            originals[name] = (name in be.__dict__, orig)
+
+            def wrapped(*a, _orig=orig, _n=name, **k):
+                end(None)
+                begin()
+                out = _orig(*a, **k)
+                end(_n, describe(_n, a, out) if describe is not None else None)
+                begin()
+                return out
+
+            setattr(be, name, wrapped)
+        torch.cuda.synchronize(dev)
+        gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            with torch.cuda.stream(side), torch.autograd.set_multithreading_enabled(False):
+                try:
+                    begin()
+                    self.out = self._eager()
+                    self._backward(self.out)
+                    end(None)
+                except BaseException:
+                    try:   # leave no capture open behind the error (a graph destroyed while its stream captures aborts the process)
+                        cur["g"].capture_end()
+                    except Exception:   # noqa: BLE001
+                        pass
+                    raise
+        finally:
+            for name, (own, orig) in originals.items():
+                if own:
+                    setattr(be, name, orig)
+                else:
+                    delattr(be, name)
+        self.segments, self.graph = segs, None
+        cur["g"] = None
+        del graveyard[:]
 
     def _capture_around_the_pseudo_label_pass(self, rec, side, dev):
         """A step whose recognizer runs the PDF pseudo-label pass (``PointPdfV1.pseudo_mask_fn``: region growing with data-dependent
@@ -286,8 +369,10 @@ class CapturedStep:
                 and self._python_state() == self.frozen)
 
     @torch.no_grad()
-    def __call__(self, batch, geom):
-        """One training step's forward + backward on ``batch`` with the coordinate-only tables ``geom`` (any Geometry of the batch: its own
+    def __call__(self, batch, geom, on_call=None):
+        """``on_call(name, info, replay)`` (segmented captures only): called for every named backend call of the step instead of replaying
+        its graph directly -- it must call ``replay()`` once (e.g. between two HIP events).
+        One training step's forward + backward on ``batch`` with the coordinate-only tables ``geom`` (any Geometry of the batch: its own
         pre-pass or its share of a grouped one).  Two launches: the staging copy (batch tensors + ~70 tables into the fixed-address
         buffers, csrc/stage_copy.hip) and the graph.  Returns the static output dict (``loss``, ``model_loss``, ``recognizer_loss``,
         ``score``: overwritten by the next call); gradients are in ``p.grad``."""
@@ -296,6 +381,15 @@ class CapturedStep:
                                f"autocast) changed since the capture: {self.frozen} -> {self._python_state()}; capture again "
                                "(CapturedStep(step, batch, ...)) or run the eager step")
         self.geometry.stage(geom, extra=[(batch[k], self.static[k]) for k in self.KEYS])
+        if self.segments is not None:
+            for g, label, info in self.segments:
+                if label is not None and on_call is not None:
+                    on_call(label, info, g.replay)
+                else:
+                    g.replay()
+            for p, g in zip(self.params, self.grads):
+                p.grad = g
+            return self.out
         self.graph.replay()
         if self.graph2 is not None:   # the pseudo-label pass between the two halves (eager: it reads sizes back to the host)
             self.static_mask.copy_(self.mask_fn(self.static["coord"], self.static_logits, self.static["offset"]).bool())
@@ -518,6 +612,7 @@ class TrainStep:
         self.module = module if module is not None else step
         self.graph, self.captured, self.capture_error = bool(graph), None, None
         self.captures, self.max_captures, self._capture_stream = [], max(int(max_captures), 1), stream
+        self.instrumented, self.instrument_error = None, None   # the segmented capture of measuring steps (``__call__(..., on_call=)``)
         self.force_exchange, self.loss_scale = force_exchange, float(loss_scale)
         self.params = [p for p in step.parameters() if p.requires_grad]
 
@@ -598,7 +693,38 @@ class TrainStep:
             cur.wait_stream(run_on)
         return out
 
-    def __call__(self, batch, eager=False):
+    def instrument(self, batch, geom, split_calls, describe=None):
+        """Capture the step a second time as a sequence of graphs cut around ``split_calls`` (``CapturedStep(split_calls=)``), for steps
+        that carry HIP events around those calls while everything else replays (``__call__(..., on_call=)``).  Costs one more pool of
+        activations; made by whoever measures (bench.py, during its warm-up), never by a training loop.  Returns True when available."""
+        if self.instrumented is not None and self.instrumented.matches(batch):
+            return True
+        if self.captured is None or self.instrument_error is not None:
+            return False
+        try:
+            self.instrumented = CapturedStep(self.step, batch, geom=geom, autocast=self.autocast,
+                                             loss_scale=self.scaler if self.scaler is not None else self.loss_scale, stream=self._capture_stream,
+                                             split_calls=split_calls, describe=describe)
+            return True
+        except Exception as e:   # noqa: BLE001  (the measuring step then runs eagerly, as before round 6)
+            if os.environ.get("PDFOPS_DEBUG_INSTRUMENT"):
+                import traceback
+                traceback.print_exc()
+            self.instrument_error = f"{type(e).__name__}: {e}"
+            self.instrumented = None
+            release_autograd_state(self.step)
+            return False
+
+    def __call__(self, batch, eager=False, on_call=None):
+        """``on_call``: run this step on the segmented capture (``instrument``) with ``on_call(name, info, replay)`` around the named calls;
+        without a matching segmented capture the step runs eagerly when ``eager`` says so, else as usual."""
+        self._on_call = on_call
+        try:
+            return self._call(batch, eager)
+        finally:
+            self._on_call = None
+
+    def _call(self, batch, eager=False):
         if self.stream is None:
             return self._run(batch, eager)
         cur = torch.cuda.current_stream()
@@ -622,8 +748,12 @@ class TrainStep:
 
     def _run(self, batch, eager=False):
         geom = batch.get("pdf_geometry")
-        cap = self._capture_for(batch, geom) if self.graph and not eager else None
-        if cap is not None:
+        on_call = getattr(self, "_on_call", None)
+        measuring = on_call is not None and self.instrumented is not None and self.instrumented.matches(batch) and geom is not None
+        cap = self.instrumented if measuring else (self._capture_for(batch, geom) if self.graph and not eager else None)
+        if measuring:
+            out = cap(batch, geom, on_call=on_call)
+        elif cap is not None:
             if geom is None:   # no look-ahead: the pre-pass inline on this stream
                 from .geometry import Geometry
                 geom = Geometry(batch["coord"], batch["offset"], batch["offset_host"]).precompute()

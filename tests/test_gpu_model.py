@@ -875,6 +875,67 @@ def test_captured_step_holds_no_memset_node():
         engine.release_autograd_state(step)
 
 
+def test_segmented_capture_replays_the_same_step_with_events_around_the_named_calls():
+    """engine.CapturedStep(split_calls=...): the training step captured as a sequence of graphs cut around every Bottleneck call (what
+    bench.py's measuring step replays instead of running eagerly).  Losses, scores and every parameter gradient are BIT-identical to the
+    one-graph capture's on the same batches; ``on_call`` sees the 18 + 18 calls with what ``describe`` remembered; HIP events recorded
+    around the segments give positive times; the graphs hold no memset node."""
+    from pointcloudpdf_amd import engine, synthetic
+    from pointcloudpdf_amd.geometry import Geometry
+
+    dev = torch.device("cuda", 0)
+    batches = [synthetic.make_batch([3000, 2600], first_scene_id=80 + 10 * i, device=dev) for i in range(2)]
+    geoms = [Geometry(b["coord"], b["offset"], b["offset_host"]).precompute() for b in batches]
+    step = engine.OpenSegStep().to(dev)
+    synthetic.fill_parameters_deterministic(step, seed=2)
+    step.train()
+    opt = engine.FusedSGD(step.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    train = engine.TrainStep(step, opt, graph=True)
+    keys = ("coord", "feat", "offset", "offset_host", "segment")
+    batch = lambda j: dict({k: batches[j][k] for k in keys}, pdf_geometry=geoms[j])
+    train(batch(0))
+    assert train.captured is not None, train.capture_error
+    seen = []
+    described = lambda name, args, out: (name, int(args[0]))
+    assert train.instrument(batch(0), geoms[0], ("bottleneck_forward", "bottleneck_backward"), described), train.instrument_error
+    cap = train.instrumented
+    assert cap.segments is not None and sum(1 for _, label, _ in cap.segments if label) == 36
+    state = {k: v.detach().clone() for k, v in step.state_dict().items()}
+    momenta = [opt.state[p]["momentum_buffer"].detach().clone() if "momentum_buffer" in opt.state.get(p, {}) else None for p in step.parameters()]
+
+    def run(on_call):
+        step.load_state_dict(state)
+        for p, m in zip(step.parameters(), momenta):
+            if m is not None:
+                opt.state[p]["momentum_buffer"].copy_(m)
+        outs = []
+        for j in (1, 0):
+            out = train(batch(j), on_call=on_call)
+            outs.append((out["loss"].detach().clone(), out["score"].detach().clone(), [p.grad.detach().clone() for p in step.parameters()]))
+        torch.cuda.synchronize()
+        return outs, [p.detach().clone() for p in step.parameters()]
+
+    events = []
+
+    def on_call(name, info, replay):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        replay()
+        e1.record()
+        seen.append((name, info))
+        events.append((e0, e1))
+
+    plain, p_plain = run(None)
+    timed, p_timed = run(on_call)
+    assert len(seen) == 72 and [n for n, _ in seen[:36]] == ["bottleneck_forward"] * 18 + ["bottleneck_backward"] * 18
+    assert all(info[0] == name and info[1] > 0 for name, info in seen)
+    assert all(e0.elapsed_time(e1) > 0 for e0, e1 in events)
+    for (la, sa, ga), (lb, sb, gb) in zip(plain, timed):
+        assert torch.equal(la, lb) and torch.equal(sa, sb) and all(torch.equal(x, y) for x, y in zip(ga, gb))
+    assert all(torch.equal(x, y) for x, y in zip(p_plain, p_timed))
+    engine.release_autograd_state(step)
+
+
 def test_device_grad_scaler_follows_torch_grad_scaler():
     """engine.DeviceGradScaler + FusedSGD against torch.amp.GradScaler + torch.optim.SGD on the same gradients: clean steps update
     identically and grow the scale after `growth_interval` of them; a step with an inf / a nan gradient leaves parameters AND momentum
