@@ -612,6 +612,9 @@ class StaticGeometry(Geometry):
         return self
 
 
+_WAIT_ALWAYS = os.environ.get("PDFOPS_WAIT_QUERY") == "0"
+
+
 class _LazyTicket:
     """Ticket j of a group whose pre-pass is being built on the prefetcher's worker thread."""
 
@@ -712,7 +715,11 @@ class GeometryPrefetcher:
             ticket = ticket.resolve()
         geom, done, stream = ticket
         cur = torch.cuda.current_stream()
-        cur.wait_event(done)
+        # The pre-pass runs a group ahead, so its event has usually fired long ago: asked on the HOST first (round 6).  A device-side wait
+        # is a barrier packet in the training queue, and with the pre-pass queues busy beside it that packet cost ~0.45 ms of idle time at
+        # the start of every step (profiles/r06_z_timeline.txt: the gap in front of the staging launch; PDFOPS_WAIT_QUERY=0: always wait).
+        if _WAIT_ALWAYS or not done.query():
+            cur.wait_event(done)
         for t in geom.tensors():
             t.record_stream(cur)
         packed = getattr(geom, "packed", None)
