@@ -525,6 +525,12 @@ int pdf_wa_logits_forward(int N, int M, int h, int d, int L, const float *q, con
  *   pdf_window_edges_count : count (n) int32 = row length of every query, seg (n, 4) int32 (16-byte aligned) = its two segments
  *   pdf_window_edges_fill  : offsets (n + 1) = exclusive scan of count -> index0 (E) int64 ascending, index1 (E) int32, rel (E, 3) int32 or
  *                            null; *flag |= 1 if a quantised offset leaves [0, vmax] (the reference asserts that range) */
+/* The keys themselves (the elementwise part of :468-499 -- torch_geometric's voxel_grid on the plain coordinates for even blocks, on the
+ * coordinates shifted by half a window from the batch minimum for odd ones -- and the fine-window cell of :91-94), one launch per partition:
+ * xyz (n, 3), ends (scenes) int32 scene ends, lo / hi (3) float32 DEVICE = per-axis minimum / maximum of xyz -> kf, kc, wk (n) int64.
+ * Same floating-point steps as torch.div(.., rounding_mode="floor" / "trunc") on float32 tensors: bit-identical keys. */
+int pdf_window_keys(int n, const float *xyz, const int *ends, int scenes, const float *lo, const float *hi, float window_size, int parity,
+                    long long *kf, long long *kc, long long *wk, void *stream);
 int pdf_window_edges_count(int n, const long long *kf_sorted, const long long *kf, int m, const long long *kcd_sorted, const long long *kc,
                            const long long *wk, const long long *wkd, int *count, int *seg, void *stream);
 int pdf_window_edges_fill(int n, const int *offsets, const int *seg, const int *order_f, const int *order_cd, const long long *wk,

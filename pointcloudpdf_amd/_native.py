@@ -88,6 +88,7 @@ _HIP_ONLY_PROTOS = {
     "wa_table_grad": "iiiippppplfpp",
     "wa_grad_attn": "iiiiiplppplppp",
     "wa_logits_forward": "iiiiipplfpppppp",
+    "window_keys": "ippippfippp",
     "window_edges_count": "ippipppppp",
     "window_edges_fill": "ipppppppffipppp",
     "group_forward": "iiiippppp",
@@ -1112,6 +1113,15 @@ class HipBackend(CBackend):
         out = torch.empty((n, h, d), dtype=torch.float32, device=v.device)
         self._wa_rows(n, h, d, L, offsets, None, index1, rel_idx, attn, v, table, out)
         return out
+
+    def window_keys(self, xyz, ends, lo, hi, window_size, parity):
+        """(kf, kc, wk) int64 per point of one window partition (csrc/window_edges.hip we::k_keys; what stratified.window_keys composes from
+        ~45 torch ops): xyz (N, 3), ends (scenes) int32 scene ends, lo / hi (3) float32 = per-axis minimum / maximum of xyz."""
+        n = int(xyz.shape[0])
+        out = torch.empty((3, n), dtype=torch.int64, device=xyz.device)
+        self._call("window_keys", n, xyz.contiguous(), ends.int().contiguous(), int(ends.shape[0]), lo.float().contiguous(), hi.float().contiguous(),
+                   float(window_size), int(parity), out[0], out[1], out[2])
+        return out[0], out[1], out[2]
 
     def window_edges(self, xyz, kf, kc, wk, downsample_idx, c2w, qs, vmax):
         """The CSR-by-query edge table of one window partition (csrc/window_edges.hip; stratified_transformer_v1m1_origin.py:45-127 + the

@@ -108,77 +108,175 @@ __global__ __launch_bounds__(TB) void k_rows(int N, int h, int L, const int *__r
 }
 
 // ---------------------------------------------------------------------------------------------------------------- table gradients
-constexpr int OC = 24;              // owners per chunk (histogram rows in LDS: OC x 9 x (L + 1) floats)
-constexpr int HS = LMAX + 1;        // histogram row stride (odd: lanes of different owners spread over the banks)
+constexpr int HS = LMAX + 1;        // histogram row stride (odd: the MFMA A-operand reads of 4 owners x 16 rows spread over the banks)
+constexpr int PR = 3;               // rounds of 64 entries a wave loads ahead per owner quad (= one LDS window of entries)
+constexpr int WIN = 64 * PR;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// grid = (G, h / HG): workgroup (g, hg) walks the owner chunks g, g + G, ...; partial[(g * HGN + hg)][a][r][c] (3 x L x CG floats)
+// grid = (G, h / HG): workgroup (g, hg); partial[(g * HGN + hg)][a][r][c] (3 x L x CG floats).  Every WAVE works alone on a sequence of
+// owner QUADS (4 consecutive owners: their entries are one contiguous range of the segment-ordered arrays); no block barrier in the loop.
+//   loads    lane = ENTRY: coalesced loads of rel (3 ints) and w (HG floats) of the NEXT quad, issued at the top of a quad together with
+//            that quad's owner rows and the bounds of the one after it, so no global round trip is waited for inside a quad; the entries
+//            go through a window of the wave's LDS slice (WIN entries; longer quads take further windows, loaded in place).
+//   phase 1  lane = (owner of the quad, head, axis) adds its owner's entries into its PRIVATE histogram row, in entry order, four at a
+//            time: the four bins are read together and written back in order, an entry's value carrying the earlier ones of the same
+//            bin in its group -- one LDS round trip per four entries instead of one per entry, no atomics (ds_add_f32 turned out ~15x
+//            slower than a read-modify-write here: profiles/r06_wa_table_ab.txt), a fixed summation order.
+//            (Round 5: the same private rows fed by two dependent global loads per 8 entries: 258 us per call at 160k owners / 5 M entries.)
+//   phase 2  G[(a, r), c] += sum_s S[s][hh(c)][a][r] * x[s][c] on the matrix cores: per (head, axis) a 64 x 16 block = four 16x16x4 tiles
+//            with K = the quad's four owners; the HG x 3 x 4 accumulator tiles stay in registers across all quads of the wave; the four
+//            waves of a workgroup add theirs through LDS in wave order at the end.
 template <int HG, bool CSC>
-__global__ __launch_bounds__(TB) void k_table(int N, int h, int L, const int *__restrict__ seg_off, const int *__restrict__ seg_edge,
-                                              const int *__restrict__ rel, const float *__restrict__ w, const float *__restrict__ x,
-                                              long ldx, float xscale, float *__restrict__ partial) {
-    constexpr int CG = HG * D, NP = HG * 3;            // NP histogram rows per owner
-    __shared__ __attribute__((aligned(16))) float S[OC * NP * HS];
-    __shared__ __attribute__((aligned(16))) float xs[OC * CG];
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_table(
+    int N, int h, int L, const int *__restrict__ seg_off, const int *__restrict__ seg_edge, const int *__restrict__ rel,
+    const float *__restrict__ w, const float *__restrict__ x, long ldx, float xscale, float *__restrict__ partial) {
+    constexpr int CG = HG * D, NP = HG * 3, NT = NP * 4;   // NP histogram rows per owner; NT 16 x 16 output tiles (head, axis, row block)
+    constexpr int QS = 4 * NP * HS;                        // floats of one wave's histogram rows
+    constexpr int XL = 4 * CG / 64;                        // owner-row values per lane (4 owners x CG channels over 64 lanes)
+    constexpr int WS = QS + WIN * (3 + HG) + 4 * CG;       // a wave's LDS slice: histograms | entry window (rel, w) | owner rows
+    static_assert(NT * 256 <= 4 * WS, "the accumulators of one wave must fit the LDS area for the final sum");
+    static_assert(QS % 4 == 0 && WS % 4 == 0, "16-byte stores clear the histograms");
+    __shared__ __attribute__((aligned(16))) float lds[4 * WS];
     const int h0 = blockIdx.y * HG;
-    // phase-2 role: thread ar < 3 L owns (axis, row) = (ar / L, ar % L) and the CG channels of the head group
-    const int ar = threadIdx.x, pa = ar / L, pr = ar - pa * L;
-    const bool owner2 = ar < 3 * L;
-    float acc[CG];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    float *Sw = lds + wv * WS, *xw = Sw + QS + WIN * (3 + HG);
+    int *rel_s = reinterpret_cast<int *>(Sw + QS);
+    float *w_s = Sw + QS + WIN * 3;
+    f32x4 acc[NT];
 #pragma unroll
-    for (int c = 0; c < CG; ++c) acc[c] = 0.f;
-    // phase-1 role: lane (slot, hh, axis) walks the segment of owner chunk0 + slot
-    const int slot = threadIdx.x / NP, j = threadIdx.x - slot * NP, hh = j / 3, ax = j - 3 * hh;
-    const bool owner1 = slot < OC;
-    const int nchunks = (N + OC - 1) / OC;
-    for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-        const int n0 = ch * OC, cnt = min(OC, N - n0);
-        for (int e = threadIdx.x; e < OC * NP * HS; e += TB) S[e] = 0.f;
-        for (int e = threadIdx.x; e < OC * CG; e += TB) {
-            const int s = e / CG, c = e - s * CG;
-            xs[e] = s < cnt ? x[(size_t)(n0 + s) * ldx + (size_t)h0 * D + c] * xscale : 0.f;
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nquads = (N + 3) >> 2, nw = gridDim.x * 4;
+    auto load_off = [&](int qd) { return seg_off[min(4 * qd + min(lane, 4), N)]; };              // lanes 0 .. 4: the quad's five bounds
+    auto load_x = [&](int qd, float (&xr)[XL]) {
+#pragma unroll
+        for (int i = 0; i < XL; ++i) {
+            const int e = lane + 64 * i, sl = e / CG, c = e - sl * CG;
+            xr[i] = x[(size_t)min(4 * qd + sl, N - 1) * ldx + (size_t)h0 * D + c];
         }
-        __syncthreads();
-        if (owner1 && slot < cnt) {
-            float *row = S + (slot * NP + j) * HS;
-            int t = seg_off[n0 + slot];
-            const int end = seg_off[n0 + slot + 1];
-            for (; t < end; t += SB) {
-                int eid[SB], rr[SB];
-                float ww[SB];
+    };
+    int rr[PR][3];
+    float ww[PR][HG];
+    auto load_entries = [&](int e0, int e1) {      // entries e0 + lane + 64 k < e1 of a window
 #pragma unroll
-                for (int k = 0; k < SB; ++k) {
-                    const int e = min(t + k, end - 1);
-                    eid[k] = CSC ? seg_edge[e] : e;
-                    rr[k] = rel[(size_t)e * 3 + ax];
-                }
+        for (int k = 0; k < PR; ++k) {
+            const int e = e0 + lane + 64 * k;
+            if (e < e1) {
+                rr[k][0] = rel[(size_t)e * 3]; rr[k][1] = rel[(size_t)e * 3 + 1]; rr[k][2] = rel[(size_t)e * 3 + 2];
+                const size_t wi = (size_t)(CSC ? seg_edge[e] : e) * h + h0;
 #pragma unroll
-                for (int k = 0; k < SB; ++k) ww[k] = w[(size_t)eid[k] * h + h0 + hh];
-#pragma unroll
-                for (int k = 0; k < SB; ++k)
-                    if (t + k < end) row[rr[k]] += ww[k];       // private row, program order: a fixed summation order without atomics
+                for (int g = 0; g < HG; ++g) ww[k][g] = w[wi + g];
             }
         }
-        __syncthreads();
-        if (owner2) {
-            for (int s = 0; s < cnt; ++s) {
-                float sv[HG];
+    };
+    auto store_entries = [&]() {                   // the window: rel_s[local][3], w_s[local][HG]  (lanes past the end write stale values: never read)
 #pragma unroll
-                for (int g = 0; g < HG; ++g) sv[g] = S[(s * NP + g * 3 + pa) * HS + pr];
-                const float4 *xr = reinterpret_cast<const float4 *>(xs + s * CG);   // (same address in every lane: broadcast reads)
+        for (int k = 0; k < PR; ++k) {
+            const int l = lane + 64 * k;
+            rel_s[l * 3] = rr[k][0]; rel_s[l * 3 + 1] = rr[k][1]; rel_s[l * 3 + 2] = rr[k][2];
 #pragma unroll
-                for (int q = 0; q < CG / 4; ++q) {
-                    const float4 v = xr[q];
-                    const float f = sv[q / 4];
-                    acc[4 * q] += v.x * f; acc[4 * q + 1] += v.y * f; acc[4 * q + 2] += v.z * f; acc[4 * q + 3] += v.w * f;
+            for (int g = 0; g < HG; ++g) w_s[l * HG + g] = ww[k][g];
+        }
+    };
+    // phase-1 role of the lane: (owner ps of the quad, histogram row pj = head * 3 + axis)
+    const int ps = lane / NP, pj = lane - ps * NP, pg = pj / 3, pa = pj - 3 * pg;
+    const bool p1 = ps < 4;
+    float *prow = Sw + (ps * NP + pj) * HS;
+    int qd = blockIdx.x * 4 + wv;
+    int off0 = 0, off1 = 0;       // bounds (lanes 0 .. 4) of this quad and of the next
+    float xr[XL];
+    if (qd < nquads) {
+        off0 = load_off(qd);
+        load_x(qd, xr);
+        if (qd + nw < nquads) off1 = load_off(qd + nw);
+        load_entries(__shfl(off0, 0, 64), min(__shfl(off0, 4, 64), __shfl(off0, 0, 64) + WIN));
+    }
+    for (; qd < nquads; qd += nw) {
+        const int o0 = __shfl(off0, 0, 64), o4 = __shfl(off0, 4, 64);
+        const int pb = __shfl(off0, min(ps, 3), 64), pe = __shfl(off0, min(ps, 3) + 1, 64);     // the lane's owner row [pb, pe)
+        for (int e = lane; e < QS / 4; e += 64) reinterpret_cast<float4 *>(Sw)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < XL; ++i) {
+            const int e = lane + 64 * i;
+            xw[e] = 4 * qd + e / CG < N ? xr[i] * xscale : 0.f;
+        }
+        store_entries();
+        // everything the NEXT quad needs from global memory: in flight from here on
+        const int qn = qd + nw, qnn = qn + nw;
+        int off2 = 0;
+        if (qn < nquads) {
+            load_x(qn, xr);
+            const int n0 = __shfl(off1, 0, 64);
+            load_entries(n0, min(__shfl(off1, 4, 64), n0 + WIN));
+            if (qnn < nquads) off2 = load_off(qnn);
+        }
+        for (int wb = o0; wb < o4; wb += WIN) {
+            if (wb != o0) {                       // a further window of a long quad: loaded in place (rare; the next quad's registers are in use,
+                const int we = min(o4, wb + WIN);  // so this one goes straight to LDS)
+                for (int l = lane; l < we - wb; l += 64) {
+                    const int e = wb + l;
+                    rel_s[l * 3] = rel[(size_t)e * 3]; rel_s[l * 3 + 1] = rel[(size_t)e * 3 + 1]; rel_s[l * 3 + 2] = rel[(size_t)e * 3 + 2];
+                    const size_t wi = (size_t)(CSC ? seg_edge[e] : e) * h + h0;
+#pragma unroll
+                    for (int g = 0; g < HG; ++g) w_s[l * HG + g] = w[wi + g];
                 }
             }
+            if (p1) {
+                const int t1 = min(pe, wb + WIN);
+                int t = max(pb, wb);
+                // four entries at a time: their bins are read together and written back in order; the NEXT four entries' (bin, value)
+                // are read from the window before the write-back (the compiler keeps LDS accesses in program order)
+                int b[4];
+                float v[4];
+                auto fetch = [&](int tt) {
+                    const int l = tt - wb;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { b[i] = rel_s[(l + i) * 3 + pa]; v[i] = w_s[(l + i) * HG + pg]; }
+                };
+                if (t + 3 < t1) fetch(t);
+                for (; t + 3 < t1; t += 4) {
+                    const int b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+                    const float w0 = v[0], w1 = v[1], w2 = v[2], w3 = v[3];
+                    const float s0 = prow[b0], s1 = prow[b1], s2 = prow[b2], s3 = prow[b3];
+                    if (t + 7 < t1) fetch(t + 4);
+                    const float c1 = b1 == b0 ? w0 + w1 : w1;
+                    const float c2 = b2 == b1 ? c1 + w2 : (b2 == b0 ? w0 + w2 : w2);
+                    const float c3 = b3 == b2 ? c2 + w3 : (b3 == b1 ? c1 + w3 : (b3 == b0 ? w0 + w3 : w3));
+                    prow[b0] = s0 + w0; prow[b1] = s1 + c1; prow[b2] = s2 + c2; prow[b3] = s3 + c3;
+                }
+                for (; t < t1; ++t) prow[rel_s[(t - wb) * 3 + pa]] += w_s[(t - wb) * HG + pg];
+            }
+        }
+        // phase 2: A[i = row][k = owner lk] from the histograms, B[k = owner lk][j = channel] from the owner rows
+        float bv[HG];
+#pragma unroll
+        for (int g = 0; g < HG; ++g) bv[g] = xw[lk * CG + g * D + li];
+#pragma unroll
+        for (int t = 0; t < NP; ++t)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+                acc[t * 4 + rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Sw[(lk * NP + t) * HS + rb * 16 + li], bv[t / 3], acc[t * 4 + rb], 0, 0, 0);
+        off0 = off1; off1 = off2;
+    }
+    // the workgroup's slab: the four waves' accumulators added in wave order through LDS (element (tile, v, lane) at (4 tile + v) 64 + lane)
+    __syncthreads();
+    for (int k = 0; k < 4; ++k) {
+        if (wv == k) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    float *p = lds + (4 * t + v) * 64 + lane;
+                    *p = k == 0 ? acc[t][v] : *p + acc[t][v];
+                }
         }
         __syncthreads();
     }
-    if (owner2) {
-        float4 *dst = reinterpret_cast<float4 *>(partial + (((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 3 * L + ar) * CG);
-#pragma unroll
-        for (int q = 0; q < CG / 4; ++q) dst[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    float *dst = partial + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 3 * L * CG;
+    for (int e = threadIdx.x; e < NT * 256; e += TB) {
+        const int ln = e & 63, v = (e >> 6) & 3, t = e >> 8, rb = t & 3, tt = t >> 2;      // D[i = 4 (lane / 16) + v][j = lane % 16]
+        const int r = rb * 16 + 4 * (ln >> 4) + v;
+        if (r < L) dst[((size_t)(tt % 3) * L + r) * CG + (tt / 3) * D + (ln & 15)] = lds[e];
     }
 }
 
@@ -286,9 +384,11 @@ __global__ __launch_bounds__(TB) void k_logits_fwd(int N, int h, int L, const fl
 }
 
 static inline int head_group(int h) { return h % 3 == 0 ? 3 : 1; }
+static inline int table_head_group(int h) { return head_group(h); }
 static inline int table_grid(int N, int h) {
-    const int nchunks = (N + OC - 1) / OC, hgn = h / head_group(h);
-    int g = 512 / (hgn < 1 ? 1 : hgn);          // ~512 workgroups in flight over all head groups
+    const int nchunks = (N + 15) / 16, hgn = h / table_head_group(h);      // (a workgroup = four waves = four owner quads at a time)
+    static const int target = [] { const char *e = getenv("PDFOPS_WA_TABLE_GRID"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+    int g = target / (hgn < 1 ? 1 : hgn);       // ~512 workgroups in flight over all head groups
     if (g < 8) g = 8;
     if (g > nchunks) g = nchunks;
     return g < 1 ? 1 : g;
@@ -362,7 +462,7 @@ extern "C" int pdf_wa_table_grad(int N, int h, int d, int L, const int *seg_off,
     if (d != wb::D || L > wb::LMAX || ldx < (long)h * d) return PDF_ERR_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (N == 0) return hipMemsetAsync(grad_table, 0, sizeof(float) * (size_t)L * h * d * 3, s) == hipSuccess ? PDF_OK : PDF_ERR_BAD_ARG;
-    const int hg = wb::head_group(h), hgn = h / hg, G = wb::table_grid(N, h);
+    const int hg = wb::table_head_group(h), hgn = h / hg, G = wb::table_grid(N, h);
     const dim3 grid((unsigned)G, (unsigned)hgn);
     if (hg == 3) {
         if (seg_edge) wb::k_table<3, true><<<grid, wb::TB, 0, s>>>(N, h, L, seg_off, seg_edge, rel, w, x, ldx, xscale, ws);

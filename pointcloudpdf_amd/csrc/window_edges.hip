@@ -98,7 +98,75 @@ __global__ __launch_bounds__(256) void k_fill(int n, const int *__restrict__ off
     if (bad) atomicOr(flag, 1);
 }
 
+// ---- window keys per point (the elementwise part of :468-499: torch_geometric's voxel_grid on the plain / half-window-shifted coordinates)
+// Floor division as torch.div(a, b, rounding_mode="floor") defines it for floats: the quotient of (a - fmod(a, b)) by b, moved down by one
+// when the remainder and the divisor differ in sign, rounded to the nearest integer below -- NOT floorf(a / b) (they differ when a / b
+// rounds up to an integer).  IEEE division (hipcc's default), no contraction (-ffp-contract=off).
+__device__ __forceinline__ float floor_div(float a, float b) {
+    if (b == 0.f) return a / b;
+    const float mod = fmodf(a, b);
+    float div = (a - mod) / b;
+    if (mod != 0.f && ((b < 0.f) != (mod < 0.f))) div -= 1.f;
+    if (div == 0.f) return copysignf(0.f, a / b);
+    float fl = floorf(div);
+    if (div - fl > 0.5f) fl += 1.f;
+    return fl;
+}
+
+struct KeyArgs { float ws; int parity, scenes; };
+
+// one thread per point.  lo / hi (3): per-axis minimum / maximum of xyz over the whole batch; ends (scenes): scene ends.
+// kf / kc: cluster id of the fine (ws) / coarse (2 ws) grid = sum_d cell_d * prod_{e < d} num_e with the scene index as 4th coordinate of
+// cell size 1; even parity: grid origin = the minimum, odd parity: coordinates shifted by half a cell, origin = the minimum of the
+// UNSHIFTED coordinates.  wk: the fine-window cell of :91-94 (trunc((xyz - min + shift) / ws) per axis) packed 21 bits per axis.
+__global__ void k_keys(int n, const float *__restrict__ xyz, const int *__restrict__ ends, const float *__restrict__ lo,
+                       const float *__restrict__ hi, KeyArgs A, i64 *__restrict__ kf, i64 *__restrict__ kc, i64 *__restrict__ wk) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int b = 0;
+    while (b < A.scenes - 1 && i >= ends[b]) ++b;
+    i64 key[2], wc[3];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const float size = g == 0 ? A.ws : 2.f * A.ws;
+        const float shift = A.parity ? 0.5f * size : 0.f;
+        i64 k = 0, stride = 1;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float p = A.parity ? xyz[3 * (size_t)i + d] + shift : xyz[3 * (size_t)i + d];
+            const float e = A.parity ? hi[d] + shift : hi[d];
+            const i64 cell = (i64)floor_div(p - lo[d], size);
+            i64 num = (i64)floor_div(e - lo[d], size) + 1;
+            if (num < 1) num = 1;
+            k += cell * stride;
+            stride *= num;
+        }
+        key[g] = k + stride * (i64)b;
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float r = xyz[3 * (size_t)i + d] - lo[d];
+        const float t = A.parity ? r + 0.5f * A.ws : r + 0.f;
+        wc[d] = (i64)truncf(t / A.ws);
+    }
+    kf[i] = key[0];
+    kc[i] = key[1];
+    wk[i] = (wc[0] << 42) | (wc[1] << 21) | wc[2];
+}
+
 }  // namespace we
+
+// Window keys of one Swin block's partition (parity 0: plain, 1: shifted by half a window).  xyz (n, 3); ends (scenes) int32 scene ends;
+// lo / hi (3) float32: per-axis minimum / maximum of xyz (device).  -> kf, kc, wk (n) int64 (see we::k_keys).
+extern "C" int pdf_window_keys(int n, const float *xyz, const int *ends, int scenes, const float *lo, const float *hi, float window_size,
+                               int parity, long long *kf, long long *kc, long long *wk, void *stream) {
+    if (n < 0 || scenes < 0 || !(window_size > 0.f)) return PDF_ERR_BAD_ARG;
+    if (n == 0) return PDF_OK;
+    if (!xyz || !ends || scenes < 1 || !lo || !hi || !kf || !kc || !wk) return PDF_ERR_BAD_ARG;
+    we::KeyArgs A{window_size, parity & 1, scenes};
+    we::k_keys<<<pdf_divup(n, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(n, xyz, ends, lo, hi, A, kf, kc, wk);
+    return pdf_launch_status();
+}
 
 // Row lengths of the CSR-by-query edge table.  kf / kc / wk (n) int64: fine-window key, coarse-window key and packed fine-window cell of
 // every point; kf_sorted (n): kf in ascending order; kcd_sorted (m), wkd (m): kc / wk of the m downsampled points in ascending kc order

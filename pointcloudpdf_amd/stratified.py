@@ -29,6 +29,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _native, dense
+from .pointops import _ops as _p1_ops
 from .pointops2 import pointops
 from .registry import MODELS
 
@@ -267,10 +268,12 @@ class _KPConvFn(torch.autograd.Function):
         return None, None, None, gx, None, gw, None
 
 
-def offset2batch(offset):
-    """:27-42 (without the per-scene python lists)"""
+def offset2batch(offset, n=None):
+    """:27-42 (without the per-scene python lists).  ``n``: the number of points when the caller knows it (``coord.shape[0]``): without it
+    ``repeat_interleave`` reads the total from the device -- the host waits for everything queued before it (6.7 ms per step at
+    2 x 80k points, tools/st_host_profile.py)."""
     sizes = torch.diff(offset.long(), prepend=offset.new_zeros(1).long())
-    return torch.repeat_interleave(torch.arange(offset.shape[0], device=offset.device), sizes)
+    return torch.repeat_interleave(torch.arange(offset.shape[0], device=offset.device), sizes, output_size=n)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -353,12 +356,34 @@ class StratifiedGeometry:
     points when it runs inline).  Results are bit-identical to the inline calls (same kernel, same inputs).  With ``offset_host`` (the
     scene ends as Python ints, as the collate function has them) no call of the chain waits for the device."""
 
-    def __init__(self, coord, offset, offset_host=None, downsample_scale=8, ratio=0.25, num_layers=4, stem_transformer=True):
+    def __init__(self, coord, offset, offset_host=None, downsample_scale=8, ratio=0.25, num_layers=4, stem_transformer=True, k=16, up_k=3,
+                 ball=None):
         self.coord, self.offset = coord.contiguous(), offset.int()
         self.offset_host = [int(v) for v in (offset_host if offset_host is not None else offset.detach().cpu().tolist())]
         self.cfg = (downsample_scale, ratio, num_layers, stem_transformer)
+        self.nn_cfg = (k, up_k, ball)   # TransitionDown's k, Upsample's interpolation k, (radius, max_neighbor) of the KPConv stem
         self.samples = {}        # ("keys" | "down", level) -> (int32 indices into that level's points, int32 scene ends of the subset)
         self.windows = {}        # level -> BasicLayer.window_tables (filled by precompute(layers=...) only: data-dependent shapes)
+        # The neighbour searches of the forward (filled together with the windows): ("ball",) -> the KPConv stem's radius table;
+        # ("td", level) -> (coordinates of the level's TransitionDown sample = the next level's points, their k nearest points of the
+        # level); ("up", level) -> (idx, weight) of the interpolation from level + 1 back onto level (Upsample :558-579 -- the backbone's
+        # stack and the recognizer's walk the same pairs).  Coordinates only, static shapes.
+        self.neighbors = {}
+
+    def _level_neighbors(self, key, xyz, off, n_xyz, n_off):
+        k, up_k, _ = self.nn_cfg
+        self.neighbors[("td", key)] = (n_xyz, _native.backend_for(xyz).knn_query(k, xyz, n_xyz, off.int().contiguous(), n_off.int().contiguous())[0])
+        self.neighbors[("up", key)] = _p1_ops._interp_tables(n_xyz, xyz, n_off, off, up_k)
+        if xyz.is_cuda:   # the entries of both tables grouped by source row: what the backward's segmented sums walk (one stable sort
+            # per table, cached on the idx tensor -- csrc/seg_gather.hip; built lazily inside the backward otherwise)
+            _native.inverse_table(self.neighbors[("td", key)][1], xyz.shape[0])
+            _native.inverse_table(self.neighbors[("up", key)][0], n_xyz.shape[0])
+
+    def _ball(self):
+        from .pseudo_label import radius_neighbors
+
+        if self.nn_cfg[2] is not None:
+            self.neighbors[("ball",)] = radius_neighbors(self.coord, self.offset, *self.nn_cfg[2])
 
     def _sample(self, key, xyz, off, ends, fn):
         n_ends = _strided_counts(ends, fn)
@@ -381,9 +406,14 @@ class StratifiedGeometry:
         xyz, off, ends = self.coord, self.offset, self.offset_host
         level = 0
         with torch.no_grad():
+            if layers is not None:
+                self._ball()
             if not stem_transformer:   # a TransitionDown follows the KPConv stem (:737-741)
-                idx, off, ends = self._sample(("down", "stem"), xyz, off, ends, lambda n: int(n * ratio) + 1)
-                xyz, level = xyz[idx.long(), :].contiguous(), 1
+                idx, n_off, ends = self._sample(("down", "stem"), xyz, off, ends, lambda n: int(n * ratio) + 1)
+                n_xyz, level = xyz[idx.long(), :].contiguous(), 1
+                if layers is not None:
+                    self._level_neighbors("stem", xyz, off, n_xyz, n_off)
+                xyz, off = n_xyz, n_off
             for l in range(level, num_layers):
                 if l < num_layers - 1:   # both subsets of the level from one farthest-point run
                     keys, (idx, n_off, n_ends) = self._sample_pair(l, xyz, off, ends, lambda n: n // scale + 1, lambda n: int(n * ratio) + 1)
@@ -392,7 +422,10 @@ class StratifiedGeometry:
                 if layers is not None:
                     self.windows[l] = layers[l].window_tables(xyz, off, keys)
                 if l < num_layers - 1:
-                    xyz, off, ends = xyz[idx.long(), :].contiguous(), n_off, n_ends
+                    n_xyz = xyz[idx.long(), :].contiguous()
+                    if layers is not None:
+                        self._level_neighbors(l, xyz, off, n_xyz, n_off)
+                    xyz, off, ends = n_xyz, n_off, n_ends
         return self
 
     @staticmethod
@@ -431,7 +464,13 @@ class StratifiedGeometry:
                         db = d_ends[a - 1] if a else 0
                         g.samples[("down", l)] = ((down[db:d_ends[z - 1]] - p0).contiguous(), to_dev([e - db for e in d_ends[a:z]]))
                     if layers is not None:
-                        g.windows[l] = layers[l].window_tables(xyz[p0:ends[z - 1]], to_dev(local_ends), g.samples[("keys", l)][0])
+                        xb, ob = (g.coord if l == 0 else xyz[p0:ends[z - 1]]), (g.offset if l == 0 else to_dev(local_ends))
+                        g.windows[l] = layers[l].window_tables(xb, ob, g.samples[("keys", l)][0])
+                        if l == 0:
+                            g._ball()
+                        if not last:
+                            d_idx, d_off = g.samples[("down", l)]
+                            g._level_neighbors(l, xb, ob, xb[d_idx.long(), :].contiguous(), d_off)
                 if not last:
                     xyz, ends = xyz[down.long(), :].contiguous(), d_ends
                     off = to_dev(ends)
@@ -445,6 +484,13 @@ class StratifiedGeometry:
                 csc = getattr(tab[1], _native._CSC, None)   # the key-grouped edge list cached on index_1 (_native.window_csc)
                 if csc is not None:
                     out += list(csc["base"]) + [csc["perm"]] + list(csc["rel"].values())
+        for v in self.neighbors.values():
+            for t in (v if isinstance(v, tuple) else (v,)):
+                if torch.is_tensor(t):
+                    out.append(t)
+                    inv = getattr(t, _native._INV, None)   # (data_ptr, version, n, (offsets, entries, base))
+                    if inv is not None:
+                        out += [x for x in inv[3] if torch.is_tensor(x)]
         return out
 
 
@@ -543,8 +589,11 @@ class TransitionDown(nn.Module):
 
     def forward(self, feats, xyz, offset):
         idx, n_offset = _fps(("down", self.level), xyz, offset, lambda n: int(n * self.ratio) + 1)
-        n_xyz = xyz[idx.long(), :].contiguous()
-        feats = pointops.queryandgroup(self.k, xyz, n_xyz, feats.contiguous(), None, offset, n_offset, use_xyz=False)   # (m, k, c)
+        g = _ACTIVE_GEOMETRY
+        n_xyz, knn_idx = g.neighbors.get(("td", self.level), (None, None)) if g is not None else (None, None)
+        if n_xyz is None:
+            n_xyz = xyz[idx.long(), :].contiguous()
+        feats = pointops.queryandgroup(self.k, xyz, n_xyz, feats.contiguous(), knn_idx, offset, n_offset, use_xyz=False)   # (m, k, c)
         m, k, c = feats.shape
         feats = self.linear(self.norm(feats.view(m * k, c)).view(m, k, c))
         # MaxPool1d(k) over the k neighbours (:186-188) as a reduction over dim 1: same values, no (m, c, k) transpose copy, and the
@@ -594,13 +643,18 @@ class BasicLayer(nn.Module):
         """The edge tables of this layer's two window partitions (even blocks: plain, odd blocks: shifted by half a window) -- :468-536,
         which rebuilds them for every block although they depend on the coordinates and the block's parity only.  Per parity:
         (index_0 sorted, index_1, CSR offsets of index_0, longest row, relative-position table rows of the first block's attention)."""
-        window_size = torch.tensor([self.window_size] * 3, dtype=xyz.dtype, device=xyz.device)
-        batch = offset2batch(offset)
-        xyz_min = _colminmax(xyz)[0]
+        xyz_min, xyz_max = _colminmax(xyz)
         be = _native.backend_for(xyz)
+        on_device = hasattr(be, "window_keys") and xyz.dtype == torch.float32
+        if not on_device:
+            window_size = torch.tensor([self.window_size] * 3, dtype=xyz.dtype, device=xyz.device)
+            batch = offset2batch(offset, xyz.shape[0])
         tables, flags = {}, []
         for parity in range(2 if self.depth > 1 else 1):
-            kf, kc, wk = window_keys(xyz, batch, window_size, xyz_min, parity)
+            if on_device:   # one launch (csrc/window_edges.hip we::k_keys): the same float32 steps as the torch composition below
+                kf, kc, wk = be.window_keys(xyz, offset, xyz_min, xyz_max, self.window_size, parity)
+            else:
+                kf, kc, wk = window_keys(xyz, batch, window_size, xyz_min, parity)
             attn = self.blocks[parity].attn
             # every query's row = [its fine window, ascending] ++ [the downsampled points of its coarse window in another fine window,
             # ascending] -- what :45-100 + the stable sort by query of :507 produce -- with the quantised relative positions of :282-292
@@ -638,10 +692,17 @@ class Upsample(nn.Module):
         self.linear1 = nn.Sequential(dense.LayerNorm(out_channels), _Linear(out_channels, out_channels))
         self.linear2 = nn.Sequential(dense.LayerNorm(in_channels), _Linear(in_channels, out_channels))
 
+    level = None   # set by the owner: the level this module interpolates ONTO (key of its tables in a StratifiedGeometry)
+
     def forward(self, feats, xyz, support_xyz, offset, support_offset, support_feats=None):
-        feats = self.linear1(support_feats) + pointops.interpolation(xyz.contiguous(), support_xyz.contiguous(), self.linear2(feats).contiguous(),
-                                                                     offset, support_offset)
-        return feats, support_xyz, support_offset
+        g = _ACTIVE_GEOMETRY
+        tab = g.neighbors.get(("up", self.level)) if g is not None and self.level is not None else None
+        coarse = self.linear2(feats).contiguous()
+        if tab is not None and tab[0].shape[0] == support_xyz.shape[0] and coarse.dtype == torch.float32:
+            up = _p1_ops._InterpolateIdx.apply(coarse, tab[0], tab[1])
+        else:
+            up = pointops.interpolation(xyz.contiguous(), support_xyz.contiguous(), coarse, offset, support_offset)
+        return self.linear1(support_feats) + up, support_xyz, support_offset
 
 
 class KPConvSimpleBlock(nn.Module):
@@ -680,6 +741,14 @@ class KPConvResBlock(nn.Module):
         return feats + self.shortcut_op(shortcut)
 
 
+def _set_upsample_levels(upsamples, num_layers, stem_transformer=True):
+    """Upsample i of the stack interpolates from level num_layers - 1 - i onto the level below it ("stem": the full-resolution points in
+    front of the first TransitionDown of the stem_transformer=False variant)."""
+    for i, up in enumerate(upsamples):
+        target = num_layers - 2 - i
+        up.level = target if (stem_transformer or target > 0) else "stem"
+
+
 @MODELS.register_module("ST-v1m1")
 class StratifiedTransformer(nn.Module):
     """:665-845"""
@@ -711,8 +780,10 @@ class StratifiedTransformer(nn.Module):
                 layer.downsample.level = self.layer_start + j
         if not stem_transformer:
             self.downsample.level = "stem"
-        self.geometry_cfg = dict(downsample_scale=downsample_scale, ratio=ratio, num_layers=num_layers, stem_transformer=stem_transformer)
+        self.geometry_cfg = dict(downsample_scale=downsample_scale, ratio=ratio, num_layers=num_layers, stem_transformer=stem_transformer, k=k,
+                                 ball=(kp_ball_radius, kp_max_neighbor))
         self.upsamples = nn.ModuleList([Upsample(up_k, channels[i], channels[i - 1]) for i in range(num_layers - 1, 0, -1)])
+        _set_upsample_levels(self.upsamples, num_layers, stem_transformer)
         self.classifier = nn.Sequential(_Linear(channels[0], channels[0]), nn.BatchNorm1d(channels[0]), nn.ReLU(inplace=True),
                                         _Linear(channels[0], num_classes))
         self.init_weights()
@@ -737,9 +808,12 @@ class StratifiedTransformer(nn.Module):
         from .pseudo_label import radius_neighbors
 
         feats, xyz, offset = data_dict["feat"], data_dict["coord"].contiguous(), data_dict["offset"].int()
-        batch = offset2batch(offset)
+        batch = offset2batch(offset, xyz.shape[0])
         # tp.ball_query(radius, max_neighbor, xyz, xyz, mode="partial_dense", batch_x, batch_y)[0]  (:766-774)
-        neighbor_idx = radius_neighbors(xyz, offset, self.kp_ball_radius, self.kp_max_neighbor)
+        g = _ACTIVE_GEOMETRY
+        neighbor_idx = g.neighbors.get(("ball",)) if g is not None and g.nn_cfg[2] == (self.kp_ball_radius, self.kp_max_neighbor) else None
+        if neighbor_idx is None:
+            neighbor_idx = radius_neighbors(xyz, offset, self.kp_ball_radius, self.kp_max_neighbor)
         feats_stack, xyz_stack, offset_stack = [], [], []
         for layer in self.stem_layer:
             feats = layer(feats, xyz, batch, neighbor_idx)
@@ -777,6 +851,7 @@ class STRecognizer(nn.Module):
     def __init__(self, up_k, channels, num_layers):
         super().__init__()
         self.upsamples = nn.ModuleList([Upsample(up_k, channels[i], channels[i - 1]) for i in range(num_layers - 1, 0, -1)])
+        _set_upsample_levels(self.upsamples, num_layers)
         self.confidence = nn.Sequential(_Linear(channels[0], channels[0]), nn.BatchNorm1d(channels[0]), nn.ReLU(inplace=True),
                                         _Linear(channels[0], 1))
 

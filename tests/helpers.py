@@ -308,7 +308,7 @@ def run_stratified_case(mode, device="cpu", geometry=None):
     with mh:
         logits = model(data)
         conf = recog(mh)
-    out = dict(logits=logits, conf=conf, hooks=mh, model=model, recog=recog)
+    out = dict(logits=logits, conf=conf, hooks=mh, model=model, recog=recog, geometry=data.get("st_geometry"))
     if train:
         ce = torch.nn.CrossEntropyLoss(ignore_index=-1)
         loss = ce(logits, batch["segment"]) + 0.1 * ce(torch.cat([logits, conf], -1), batch["segment"].clamp(min=0))

@@ -305,6 +305,7 @@ def test_stratified_prefetched_geometry_is_the_inline_geometry():
             for parity, tab in inline.windows[lv].items():
                 for x, y in zip(tab, geom.windows[lv][parity]):
                     assert torch.equal(x, y) if torch.is_tensor(x) else x == y, (lv, parity)
+        assert set(geom.neighbors) == set(inline.neighbors) and ("ball",) in geom.neighbors
         with torch.random.fork_rng(devices=["cuda"]):
             torch.manual_seed(5)
             out = step(dict(b, st_geometry=geom))
@@ -392,6 +393,10 @@ def test_stratified_group_prepass_is_the_per_batch_prepass():
                 for parity, tab in alone.windows[lv].items():
                     for x, y in zip(tab, got.windows[lv][parity]):
                         assert torch.equal(x, y) if torch.is_tensor(x) else x == y, (lv, parity)
+            assert set(got.neighbors) == set(alone.neighbors) == {("ball",)} | {(kind, l) for kind in ("td", "up") for l in range(3)}
+            for k, v in alone.neighbors.items():
+                for x, y in zip(v if isinstance(v, tuple) else (v,), got.neighbors[k] if isinstance(v, tuple) else (got.neighbors[k],)):
+                    assert torch.equal(x, y), k
     pf.close()
 
 
@@ -435,3 +440,41 @@ def test_window_edge_builder_equals_the_reference_construction(oracle_backend, c
         else:
             assert a == b, (case, parity, name, a, b)
     assert int(got[5]) == 0 and got[0].shape[0] > 0
+
+
+@pytest.mark.parametrize("case", ["unit-box", "negative-coordinates", "on-the-cell-faces", "three-scenes", "s3dis-2x40k"])
+@pytest.mark.parametrize("parity", [0, 1])
+def test_window_key_kernel_equals_the_torch_composition(case, parity):
+    """csrc/window_edges.hip we::k_keys against stratified.window_keys (torch_geometric's voxel_grid restated with torch ops,
+    stratified_transformer_v1m1_origin.py:468-499, 91-94) evaluated on the CPU and on the device: fine key, coarse key and packed fine cell
+    bit-identical -- random clouds, negative coordinates, points exactly on cell faces (where floorf(a / b) and torch's floor division
+    part), three scenes, and two S3DIS-shaped scenes at the model's four window sizes."""
+    from pointcloudpdf_amd import _native, stratified, synthetic
+
+    g = torch.Generator().manual_seed(11 + parity)
+    sizes, windows = [700], [0.3]
+    if case == "s3dis-2x40k":
+        b = synthetic.make_batch([40000, 37000], first_scene_id=910, device="cpu")
+        xyz, sizes, windows = b["coord"].float(), [40000, 37000], [0.16, 0.32, 0.64, 1.28]
+    else:
+        if case == "three-scenes":
+            sizes = [300, 1, 420]
+        n = sum(sizes)
+        xyz = torch.rand(n, 3, generator=g) * torch.tensor([1.5, 1.2, 0.4])
+        if case == "negative-coordinates":
+            xyz = xyz * 7.0 - torch.tensor([5.0, 3.3, 1.9])
+        if case == "on-the-cell-faces":   # multiples of the window size (and of half of it), from an origin that is itself a multiple
+            xyz = torch.randint(0, 12, (n, 3), generator=g).float() * 0.15 + torch.tensor([0.3, -0.6, 0.0])
+            windows = [0.3, 0.15, 0.1]
+    ends = torch.tensor(sizes).cumsum(0).int()
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    be = _native.hip_backend()
+    lo, hi = xyz.min(0).values, xyz.max(0).values
+    for ws in windows:
+        wsz = torch.tensor([ws] * 3)
+        want = stratified.window_keys(xyz, batch, wsz, lo, parity)
+        on_dev = stratified.window_keys(xyz.cuda(), batch.cuda(), wsz.cuda(), lo.cuda(), parity)
+        got = be.window_keys(xyz.cuda(), ends.cuda(), lo.cuda(), hi.cuda(), ws, parity)
+        for name, a, b, c in zip(("kf", "kc", "wk"), got, want, on_dev):
+            assert a.dtype == torch.int64 and torch.equal(a.cpu(), b), (case, parity, ws, name, int((a.cpu() != b).sum()))
+            assert torch.equal(a, c), (case, parity, ws, name, "device composition")

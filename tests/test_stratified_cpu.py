@@ -32,6 +32,9 @@ def test_stratified_geometry_ahead_of_the_forward_changes_nothing(use_oracle, ge
         if ga[k].grad is not None:
             assert (ga[k].grad - gb[k].grad).abs().max() <= 1e-5 * (ga[k].grad.abs().max() + 1e-30), k
     assert len(b["model"].backbone.layers_by_level()) == 4
+    # the full pre-pass also holds the forward's neighbour searches (KPConv radius table, TransitionDown kNN, Upsample interpolation tables)
+    want = {("ball",)} | {(kind, l) for kind in ("td", "up") for l in range(3)} if geometry == "windows" else set()
+    assert set(b["geometry"].neighbors) == want
 
 
 def test_stratified_state_dict_layout_and_registry():

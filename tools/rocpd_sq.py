@@ -126,8 +126,10 @@ def to_json(out, kt_db, steps, files):
         a = dur.setdefault(short(name), [0, 0])
         a[0] += 1; a[1] += d
     sgd = sum(v[0] for k, v in dur.items() if "k_sgd" in k)
-    if sgd:   # one optimizer launch per training step: the trace's own step count (warm-up and capture passes included in the kernel totals)
+    if steps <= 0:   # 0: count the optimizer launches (one per TRAINING step -- bench.py's look-ahead sweep steps run none: trace with --no-latency-sweep)
         steps = float(sgd)
+    elif sgd and sgd != steps:
+        print(f"note: {sgd} optimizer launches in the trace, {steps:g} steps given: using the given count", file=sys.stderr)
     kernels, fam = {}, {}
     for k, e in tab.items():
         c = e["c"]
