@@ -516,6 +516,8 @@ int pdf_wa_grad_attn(int N, int M, int h, int d, int L, const float *grad_out, l
  * logits[m, hh] = <q[q(m), hh], k[index1[m], hh] + T_q(m, hh)> + <k[index1[m], hh], T_k(m, hh)>. */
 int pdf_wa_logits_forward(int N, int M, int h, int d, int L, const float *q, const float *k, long ld, float qscale, const int *offsets,
                           const int *index1, const float *table_q, const float *table_k, const int *rel, float *out, void *stream);
+/* dst (M, h) = src[edge[m], :]: edge scalars (attention weights / logit gradients) brought into the order of the key-grouped edge list. */
+int pdf_wa_permute_edges(int M, int h, const float *src, const int *edge, float *dst, void *stream);
 
 /* Edge tables of the StratifiedTransformer's window partitions (stratified_transformer_v1m1_origin.py:45-127 get_indice_pairs / grid_sample +
  * the stable sort by query of :468-536, and WindowAttention's quantised relative positions :282-292), built per QUERY instead of by pair

@@ -88,6 +88,7 @@ _HIP_ONLY_PROTOS = {
     "wa_table_grad": "iiiippppplfpp",
     "wa_grad_attn": "iiiiiplppplppp",
     "wa_logits_forward": "iiiiipplfpppppp",
+    "wa_permute_edges": "iippp",
     "window_keys": "ippippfippp",
     "window_edges_count": "ippipppppp",
     "window_edges_fill": "ipppppppffipppp",
@@ -1063,6 +1064,14 @@ class HipBackend(CBackend):
         self._call("wa_segment_rows", n, h, d, L, seg_off, seg_edge, other, rel, w, X, c if ldx is None else int(ldx), float(xscale), table, out,
                    c if ldo is None else int(ldo), float(oscale))
 
+    def _wa_permute(self, w, edge):
+        """w (M, h) float32 -> w[edge] (torch's index_select takes 25-95 us for these 12-96-byte rows; this is one pass at copy speed)"""
+        w = w.contiguous()
+        _check(w, torch.float32, "edge scalars"); _check(edge, torch.int32, "edge ids")
+        out = torch.empty((edge.shape[0], w.shape[1]), dtype=torch.float32, device=w.device)
+        self._call("wa_permute_edges", int(edge.shape[0]), int(w.shape[1]), w, edge, out)
+        return out
+
     def _wa_table_grad(self, n, h, d, L, seg_off, seg_edge, rel, w, x, like, ldx=None, xscale=1.0):
         g = torch.empty((L, h, d, 3), dtype=torch.float32, device=like.device)
         ws = torch.empty((max(int(self.lib.pdf_wa_table_grad_ws_floats(n, h, L)), 1),), dtype=torch.float32, device=like.device)
@@ -1088,7 +1097,7 @@ class HipBackend(CBackend):
         _check(grad_out, torch.float32, "grad_output")
         nk = k.shape[0]
         key_off, key_edge, _key_q, key_rel = window_csc(index_k, offsets, rel_idx, n_keys=nk)
-        g_key = grad_out.index_select(0, key_edge)   # (the edge scalars in key order, once: two kernels read them sequentially)
+        g_key = self._wa_permute(grad_out, key_edge)   # (the edge scalars in key order, once: two kernels read them sequentially)
         gq, gk = torch.empty_like(q), torch.empty_like(k)
         self._wa_rows(n, h, d, L, offsets, None, None, rel_idx, grad_out, None, table_q, gq)               # grad_q = sum g T_q
         self._wa_rows(nk, h, d, L, key_off, None, None, key_rel, g_key, None, table_k, gk)                 # grad_k = sum g T_k
@@ -1169,7 +1178,7 @@ class HipBackend(CBackend):
         n, h, d = q.shape
         L = int(table_q.shape[0])
         key_off, key_edge, key_q, key_rel = window_csc(index1, offsets, rel_idx, n_keys=n)
-        g_key = g.index_select(0, key_edge)
+        g_key = self._wa_permute(g, key_edge)
         gq, gk = torch.empty_like(q), torch.empty_like(k)
         self._wa_rows(n, h, d, L, offsets, None, index1, rel_idx, g, k, table_q, gq)          # sum g (k[index1] + T_q)
         self._wa_rows(n, h, d, L, key_off, None, key_q, key_rel, g_key, q, table_k, gk)       # sum g (q[query] + T_k)
@@ -1226,11 +1235,11 @@ class HipBackend(CBackend):
         gqkv = torch.empty_like(qkv)
         ga = torch.empty((m, h), dtype=torch.float32, device=qkv.device)
         self._call("wa_grad_attn", n, m, h, d, L, go, c, offsets, index1, v, 3 * c, table_v, rel_idx, ga)
-        attn_key = attn.index_select(0, key_edge)
+        attn_key = self._wa_permute(attn, key_edge)
         self._wa_rows(n, h, d, 0, key_off, None, key_q, None, attn_key, go, None, gqkv[:, 2 * c:], ldo=3 * c)          # grad_v
         gtv = self._wa_table_grad(n, h, d, L, offsets, None, rel_idx, attn, go, qkv)
         g = self.segment_softmax_backward(attn, ga, offsets)
-        g_key = g.index_select(0, key_edge)
+        g_key = self._wa_permute(g, key_edge)
         self._wa_rows(n, h, d, L, offsets, None, index1, rel_idx, g, k, table_q, gqkv[:, :c], ldx=3 * c, ldo=3 * c, oscale=scale)      # grad_q
         self._wa_rows(n, h, d, L, key_off, None, key_q, key_rel, g_key, q, table_k, gqkv[:, c:2 * c], ldx=3 * c, xscale=scale, ldo=3 * c)   # grad_k
         gtq = self._wa_table_grad(n, h, d, L, offsets, None, rel_idx, g, q, qkv, ldx=3 * c, xscale=scale)

@@ -383,6 +383,14 @@ __global__ __launch_bounds__(TB) void k_logits_fwd(int N, int h, int L, const fl
     }
 }
 
+// dst[m, :] = src[edge[m], :] for (M, h) edge scalars (the key-ordered copy the CSC passes read sequentially): one thread per element
+__global__ __launch_bounds__(TB) void k_permute_edges(long total, int h, const float *__restrict__ src, const int *__restrict__ edge, float *__restrict__ dst) {
+    const long t = (long)blockIdx.x * TB + threadIdx.x;
+    if (t >= total) return;
+    const long m = t / h;
+    dst[t] = src[(size_t)edge[m] * h + (int)(t - m * h)];
+}
+
 static inline int head_group(int h) { return h % 3 == 0 ? 3 : 1; }
 static inline int table_head_group(int h) { return head_group(h); }
 static inline int table_grid(int N, int h) {
@@ -446,6 +454,15 @@ extern "C" int pdf_wa_logits_forward(int N, int M, int h, int d, int L, const fl
     const size_t lds = sizeof(float) * (size_t)(6 * L * wb::D + wb::QL * wb::D) + sizeof(int) * (wb::QL + 1);
     wb::k_logits_fwd<<<dim3((unsigned)((N + wb::QL - 1) / wb::QL), (unsigned)h), wb::TB, lds, static_cast<hipStream_t>(stream)>>>(
         N, h, L, q, k, ld, qscale, offsets, index1, table_q, table_k, rel, out);
+    return pdf_launch_status();
+}
+
+// dst (M, h) = src[edge[m], :]: the edge scalars of a pass in the order of another edge list (edge: ids into src's rows)
+extern "C" int pdf_wa_permute_edges(int M, int h, const float *src, const int *edge, float *dst, void *stream) {
+    if (M < 0 || h < 1 || (M > 0 && (!src || !edge || !dst))) return PDF_ERR_BAD_ARG;
+    if (M == 0) return PDF_OK;
+    const long total = (long)M * h;
+    wb::k_permute_edges<<<(unsigned)((total + wb::TB - 1) / wb::TB), wb::TB, 0, static_cast<hipStream_t>(stream)>>>(total, h, src, edge, dst);
     return pdf_launch_status();
 }
 

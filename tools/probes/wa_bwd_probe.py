@@ -45,8 +45,11 @@ for level, layer in bb.layers_by_level().items():
         ("logits_fwd", lambda: be._call("wa_logits_forward", n, m, h, d, L, q, k, 3 * c, 1.0, offsets, index1, tq, tk, rel, ga)),
         ("rows fwd out (CSR, rows+table)", lambda: be._wa_rows(n, h, d, L, offsets, None, index1, rel, attn, v, tv, out, ldx=3 * c)),
         ("grad_attn", lambda: be._call("wa_grad_attn", n, m, h, d, L, go, c, offsets, index1, v, 3 * c, tv, rel, ga)),
-        ("index_select (M, h)", lambda: attn.index_select(0, key_edge)),
+        ("edge scalars in key order (M, h)", lambda: be._wa_permute(attn, key_edge)),
         ("rows grad_v (CSC, rows)", lambda: be._wa_rows(n, h, d, 0, key_off, None, key_q, None, attn_key, go, None, gqkv[:, 2 * c:], ldo=3 * c)),
+        ("rows grad_v (CSC, edge ids)", lambda: be._wa_rows(n, h, d, 0, key_off, key_edge, key_q, None, attn, go, None, gqkv[:, 2 * c:], ldo=3 * c)),
+        ("rows grad_k (CSC, edge ids)", lambda: be._wa_rows(n, h, d, L, key_off, key_edge, key_q, key_rel, gsm, q, tk, gqkv[:, c:2 * c], ldx=3 * c, xscale=0.25, ldo=3 * c)),
+        ("table gtk (key order, edge ids)", lambda: be._wa_table_grad(n, h, d, L, key_off, key_edge, key_rel, gsm, k, qkv, ldx=3 * c)),
         ("table gtv (CSR)", lambda: be._wa_table_grad(n, h, d, L, offsets, None, rel, attn, go, qkv)),
         ("softmax_bwd", lambda: be.segment_softmax_backward(attn, ga, offsets)),
         ("rows grad_q (CSR, rows+table)", lambda: be._wa_rows(n, h, d, L, offsets, None, index1, rel, gsm, k, tq, gqkv[:, :c], ldx=3 * c, ldo=3 * c, oscale=0.25)),
@@ -57,7 +60,7 @@ for level, layer in bb.layers_by_level().items():
     print(f"level {level}: N={n} M={m} C={c} h={h} L={L} n_max={n_max} mean row {m / n:.1f}  blocks={layer.depth}")
     for name, fn in rows:
         us = t(fn)
-        if name not in ("logits_fwd", "rows fwd out (CSR, rows+table)"):
+        if name not in ("logits_fwd", "rows fwd out (CSR, rows+table)") and "edge ids" not in name:
             total += us * layer.depth
         print(f"    {name:34s} {us:9.1f} us", flush=True)
 print(f"backward pieces x blocks per level: {total / 1e3:.2f} ms per step")
