@@ -151,6 +151,15 @@ class _LinearSplitK(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         g = g.contiguous()
         gx = g @ weight if ctx.needs_input_grad[0] else None
+        if (_OWN_WGRAD and ctx.needs_input_grad[1] and g.is_cuda and g.dtype == torch.float32 and x.dtype == torch.float32 and x.dim() == 2
+                and x.stride(1) == 1):
+            # weight AND bias gradient as one split-K launch + one reduction of the package's own matrix-core kernel (csrc/rowlin*.hip):
+            # 26-90 us per call at the StratifiedTransformer's shapes against 96-108 us of the five-launch library composition below
+            # (tools/probes/st_linear_probe.py; forward and input gradient stay on the library GEMMs, which win there)
+            from . import _native
+
+            gw, gb = _native.backend_for(g).rowlin_wgrad(g, x, None, False, ctx.has_bias and ctx.needs_input_grad[2])
+            return gx, gw, gb
         gw = None
         if ctx.needs_input_grad[1]:
             n, ci = x.shape
@@ -173,6 +182,7 @@ class _LinearSplitK(torch.autograd.Function):
         return gx, gw, gb
 
 
+_OWN_WGRAD = os.environ.get("PDFOPS_SPLITK_WGRAD", "own") != "torch"   # torch: the library composition (A/B runs)
 HIP_LINEAR = os.environ.get("PDFOPS_LINEAR", "hip") != "torch"   # torch: library GEMMs + split-K weight gradient (rounds 1-2; A/B runs)
 
 

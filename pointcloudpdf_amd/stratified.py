@@ -53,7 +53,7 @@ class _Linear(nn.Linear):
             return y if x.dim() == 2 else y.view(x.shape[0], x.shape[1], -1)
         if x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and x.is_contiguous() and x.dim() in (2, 3):
             rows = x.shape[0] if x.dim() == 2 else x.shape[0] * x.shape[1]
-            if rows >= dense._MIN_ROWS:
+            if rows >= (1024 if dense._OWN_WGRAD else dense._MIN_ROWS):   # (the own weight-gradient kernel pays from ~1k rows on)
                 y = dense._LinearSplitK.apply(x.view(rows, x.shape[-1]), self.weight, self.bias)
                 return y if x.dim() == 2 else y.view(x.shape[0], x.shape[1], -1)
         return F.linear(x, self.weight, self.bias)
