@@ -661,7 +661,9 @@ def main():
                 divs = [d for d in range(min(8, D), D + 1) if steps % d == 0]
                 D = max(divs) if divs else D
         first = (warmup % D or D) if D > 0 else None
-        return engine.GroupedGeometryLoader(batch_stream(), group=D, first_group=first, threaded=bool(os.environ.get("PDFOPS_PREPASS_THREAD"))), D
+        # (a pseudo-label pass names the coordinate-only table it wants from the pre-pass: its radius table)
+        plan = {} if os.environ.get("PDFOPS_PL_INLINE_RADIUS") else dict(getattr(step_kw.get("pseudo_mask_fn"), "prepass_plan", {}))
+        return engine.GroupedGeometryLoader(batch_stream(), group=D, first_group=first, threaded=bool(os.environ.get("PDFOPS_PREPASS_THREAD")), **plan), D
 
     sched_warm = [0]
 

@@ -262,17 +262,34 @@ class Geometry:
             self._memo[key] = _native.inverse_table(idx, self.levels[src_level].p.shape[0])
         return self._memo[key]
 
+    def radius(self, radius, max_neighbor):
+        """Radius table of the level-0 points with themselves: (N, max_neighbor) int32 GLOBAL rows, -1 padded, the point itself included
+        (``pseudo_label.radius_neighbors(raw=True)``) -- the neighbour table of the PDF pseudo-label pass (pointpdf_v1m1_base.py:131-137).
+        It reads coordinates only, so it belongs to the pre-pass like the kNN tables (0.66 ms of the step at 2 x 150k points otherwise)."""
+        key = ("radius", float(radius), int(max_neighbor))
+        if key not in self._memo:
+            from .pseudo_label import radius_neighbors
+
+            self._memo[key] = radius_neighbors(self.levels[0].p, self.levels[0].o, radius, max_neighbor, raw=True).int()
+        return self._memo[key]
+
+    def radius_cached(self, radius, max_neighbor):
+        """The table ``radius()`` made ahead of the step, or None (the caller then runs the query itself)."""
+        return self._memo.get(("radius", float(radius), int(max_neighbor)))
+
     def memo_size(self):
         """Number of memoised geometry ops (FPS + kNN + interpolation tables)."""
         return sum(1 for k in self._memo if k[0] in ("down", "knn", "interp"))  # ("td" tables are derived data)
 
     # ------------------------------------------------------------------ pre-pass
-    def precompute(self, strides=(1, 4, 4, 4, 4), nsamples=(8, 16, 16, 16, 16), interp_k=3, recognizer=True):
+    def precompute(self, strides=(1, 4, 4, 4, 4), nsamples=(8, 16, 16, 16, 16), interp_k=3, recognizer=True, radius=None):
         """Run every coordinate-only op of one PointTransformer-Seg (+ PDF U-decoder) forward now, on the current
         stream: 4 FPS, 5 self-kNN, 4 down-sampling kNN, 4 (+1 for the U-decoder's level-5 self query) interpolation
         tables -- the 13 distinct kNN tables behind the reference's 31 calls."""
         lvl = 0
         self._share_grids = _SHARE_GRIDS
+        if radius is not None:   # (radius, max_neighbor) of the pseudo-label pass: pseudo_label.make_pseudo_mask_fn(...).prepass_plan
+            self.radius(*radius)
         self.knn_dist(nsamples[0], 0, 0)
         for i in range(1, len(strides)):
             new_level, _ = self.down(lvl, strides[i])
@@ -418,6 +435,8 @@ class Geometry:
                 elif key[0] == "knn":
                     idx = val[0]
                     rebased[key] = torch.where(idx >= 0, idx - base_vector(key[2], key[3])[:, None], idx)
+                elif key[0] == "radius":
+                    rebased[key] = torch.where(val >= 0, val - base_vector(0, 0)[:, None], val)
         out, s0 = [], 0
         for bi, nsc in enumerate(scene_counts):
             s1 = s0 + nsc
@@ -451,6 +470,9 @@ class Geometry:
                 elif kind == "knn_dist":
                     q0, q1 = rows[key[3]]
                     g._memo[key] = val[q0:q1]
+                elif kind == "radius":   # global rows of the group -> rows of the batch
+                    r0, r1 = rows[0]
+                    g._memo[key] = rebased[key][r0:r1] if key in rebased else rebase(val[r0:r1], r0)
                 elif kind == "interp":   # (the index tensor OBJECT of the kNN entry: the inverse table is cached on it)
                     (idx, weight), (q0, q1) = val, rows[key[3]]
                     g._memo[key] = (g._memo[("knn",) + key[1:]][0], weight[q0:q1])

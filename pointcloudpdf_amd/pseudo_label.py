@@ -513,6 +513,8 @@ def get_pseudo_mask(coord, seg_logits, offset, radius=0.1, max_neighbor=64, neig
     static = static and (offset_host is not None or torch.cuda.is_current_stream_capturing() is False)
     if neighbors is None:
         neighbors = radius_neighbors(coord, offset, radius, max_neighbor, raw=static)
+    elif not static and neighbors.dtype != torch.int64:
+        neighbors = neighbors.long()
     if static:
         # the sync-free form (get_pseudo_mask_static): scene ends from the host copy when the caller has one (one read of `offset` else)
         ends = offset_host if offset_host is not None else [int(v) for v in offset.tolist()]
@@ -549,9 +551,16 @@ def make_pseudo_mask_fn(radius=0.1, max_neighbor=64, **kw):
     """A ``pseudo_mask_fn(coord, seg_logits, offset)`` for ``recognizer.PointPdfV1`` / ``engine.OpenSegStep`` built from the
     recognizer section of configs/scannet/openseg-pt-v1-0-pointpdf-v1m1-base.py:40-58 (kp_ball_radius, kp_max_neighbor,
     condition_from, beta, seed_from, seed_range, num_seed, slide_window)."""
-    def fn(coord, seg_logits, offset, offset_host=None):
-        return get_pseudo_mask(coord, seg_logits.detach(), offset, radius=radius, max_neighbor=max_neighbor, offset_host=offset_host, **kw)
+    def fn(coord, seg_logits, offset, offset_host=None, geometry=None):
+        # the neighbour table from the batch's coordinate pre-pass when it made one (geometry.Geometry.radius: `prepass_plan` below)
+        table = geometry.radius_cached(radius, max_neighbor) if geometry is not None and hasattr(geometry, "radius_cached") else None
+        if table is not None and table.shape[0] != coord.shape[0]:
+            table = None
+        return get_pseudo_mask(coord, seg_logits.detach(), offset, radius=radius, max_neighbor=max_neighbor, neighbors=table,
+                               offset_host=offset_host, **kw)
 
+    fn.accepts_geometry = True      # (PointPdfV1 hands over input_dict["pdf_geometry"])
+    fn.prepass_plan = dict(radius=(float(radius), int(max_neighbor)))   # -> engine.GroupedGeometryLoader(..., **fn.prepass_plan) / Geometry.precompute
     fn.accepts_offset_host = True   # (PointPdfV1 hands the host copy of the scene ends over when the batch carries one: no read of `offset`)
     # device tensors take the sync-free form: the pass can be recorded into the step's graph (engine.CapturedStep captures ONE graph then)
     fn.capturable = os.environ.get("PDFOPS_PL_STATIC", "1") != "0" and kw.get("prune", "auto") in ("auto", "hip") and kw.get("generator") is None
@@ -561,11 +570,11 @@ def make_pseudo_mask_fn(radius=0.1, max_neighbor=64, **kw):
         import time
         log = []
 
-        def traced(coord, seg_logits, offset, offset_host=None):
+        def traced(coord, seg_logits, offset, offset_host=None, geometry=None):
             t0 = time.perf_counter()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            mask = fn(coord, seg_logits, offset, offset_host=offset_host)
+            mask = fn(coord, seg_logits, offset, offset_host=offset_host, geometry=geometry)
             torch.cuda.synchronize()
             st = torch.cuda.memory_stats()
             log.append((t1 - t0, time.perf_counter() - t1, st.get("num_device_alloc", 0), st.get("num_alloc_retries", 0)))

@@ -78,7 +78,7 @@ class PointPdfV1(nn.Module):
     def set_epoch(self, epoch):
         self.epoch = epoch
 
-    def get_pseudo_mask(self, coord, seg_logits, offset, offset_host=None):
+    def get_pseudo_mask(self, coord, seg_logits, offset, offset_host=None, geometry=None):
         if self.pseudo_mask_fn is None:
             raise NotImplementedError(
                 "PDF pseudo-label pass (pointpdf_v1m1_base.py:118-382) is row f-2 of the scope table; "
@@ -87,10 +87,13 @@ class PointPdfV1(nn.Module):
         with torch.no_grad():
             ready = getattr(self, "_logits_ready", None)
             self._logits_ready = None
+            extra = {}
+            if geometry is not None and getattr(self.pseudo_mask_fn, "accepts_geometry", False):
+                extra["geometry"] = geometry      # (its radius table, when the coordinate pre-pass made one)
             if ready is None or not self.pass_on_side_stream:
                 if offset_host is not None and getattr(self.pseudo_mask_fn, "accepts_offset_host", False):
-                    return self.pseudo_mask_fn(coord, seg_logits, offset, offset_host=offset_host).bool()
-                return self.pseudo_mask_fn(coord, seg_logits, offset).bool()
+                    return self.pseudo_mask_fn(coord, seg_logits, offset, offset_host=offset_host, **extra).bool()
+                return self.pseudo_mask_fn(coord, seg_logits, offset, **extra).bool()
             # The pass only needs the segmentor's logits, but it is issued after the U-decoder's forward (upstream's order, :84-93): on
             # the same stream its first host read would wait for the decoder too.  On a side stream that waits for the logits alone the
             # decoder's forward runs on the device while the host walks through the pass.
@@ -99,7 +102,7 @@ class PointPdfV1(nn.Module):
                 self._pass_stream = torch.cuda.Stream(device=coord.device)
             self._pass_stream.wait_event(ready)
             with torch.cuda.stream(self._pass_stream):
-                mask = self.pseudo_mask_fn(coord, seg_logits, offset).bool()
+                mask = self.pseudo_mask_fn(coord, seg_logits, offset, **extra).bool()
             cur.wait_stream(self._pass_stream)
             mask.record_stream(cur)
             return mask
@@ -130,7 +133,8 @@ class PointPdfV1(nn.Module):
         if self.training:
             if self.epoch < self.start_epoch:
                 return dict(score=score)
-            pseudo_mask = self.get_pseudo_mask(input_dict["coord"], seg_logits, input_dict["offset"], input_dict.get("offset_host"))
+            pseudo_mask = self.get_pseudo_mask(input_dict["coord"], seg_logits, input_dict["offset"], input_dict.get("offset_host"),
+                                               input_dict.get("pdf_geometry"))
             # segment_pseudo[pseudo_mask] = num_classes (pointpdf_v1m1_base.py:94-95) as a select: no index list, no host sync
             segment = input_dict["segment"]
             segment_pseudo = torch.where(pseudo_mask, segment.new_full((), self.num_classes), segment)

@@ -130,7 +130,7 @@ def test_geometry_split_matches_per_batch_prepass(use_oracle):
     from pointcloudpdf_amd.geometry import Geometry
 
     batches = [synthetic.make_batch(sz, first_scene_id=10 * i, grid_size=0.3) for i, sz in enumerate([[700, 500], [640], [300, 900, 420]])]
-    plan = dict(strides=(1, 4, 4), nsamples=(8, 8, 8), interp_k=3, recognizer=True)
+    plan = dict(strides=(1, 4, 4), nsamples=(8, 8, 8), interp_k=3, recognizer=True, radius=(0.9, 12))   # (+ the pseudo-label pass's radius table)
     coord = torch.cat([b["coord"] for b in batches])
     ends, base = [], 0
     for b in batches:
@@ -155,6 +155,9 @@ def test_geometry_split_matches_per_batch_prepass(use_oracle):
         from pointcloudpdf_amd import pointops
         idx, _ = pointops.knn_query(8, part.coord(1), part.offset(1), part.coord(1), part.offset(1))
         assert torch.equal(idx, alone._memo[("knn", 8, 1, 1)][0])
+        tab = part.radius_cached(0.9, 12)
+        assert tab is not None and tab.dtype == torch.int32 and tab.shape == (b["coord"].shape[0], 12) and int(tab.max()) < b["coord"].shape[0]
+        assert (tab >= 0).sum(1).min() >= 1 and part.radius_cached(0.5, 12) is None
 
 
 def test_static_geometry_pack_and_load(use_oracle):
@@ -166,7 +169,7 @@ def test_static_geometry_pack_and_load(use_oracle):
 
     sizes = [700, 500]
     batches = [synthetic.make_batch(sizes, first_scene_id=10 * i, grid_size=0.3) for i in range(3)]
-    plan = dict(strides=(1, 4, 4), nsamples=(8, 8, 8), interp_k=3, recognizer=True)
+    plan = dict(strides=(1, 4, 4), nsamples=(8, 8, 8), interp_k=3, recognizer=True, radius=(0.9, 12))
     alone = [Geometry(b["coord"], b["offset"], b["offset_host"]).precompute(**plan) for b in batches]
     coord = torch.cat([b["coord"] for b in batches])
     ends = [i * sum(sizes) + e for i in range(3) for e in batches[0]["offset_host"]]

@@ -544,3 +544,40 @@ def test_device_mixture_cut_lands_where_sklearn_does():
         moved = int(((w < cut) != (w < ref)).sum())
         print(f"mixture cut, case {tag}: {len(w)} tree edges, device {cut:.5f} vs sklearn {ref:.5f} ({gm.n_iter_} iterations), {moved} edges change side")
         assert abs(cut - ref) <= 2e-3 and moved <= max(1, len(w) // 100), (tag, cut, ref, moved)
+
+
+@pytest.mark.gpu
+def test_pass_reads_the_radius_table_of_the_coordinate_prepass(monkeypatch):
+    """The pass's neighbour table is coordinate-only: with ``make_pseudo_mask_fn(...).prepass_plan`` in the pre-pass plan
+    (geometry.Geometry.precompute(radius=), engine.GroupedGeometryLoader(**plan)) the table comes from the batch's Geometry -- alone or
+    cut out of a grouped pre-pass of three batches -- and the pass runs no radius query of its own; same mask as the inline query."""
+    from pointcloudpdf_amd import pseudo_label as pl, synthetic
+    from pointcloudpdf_amd.geometry import Geometry, GeometryPrefetcher
+
+    fn = pl.make_pseudo_mask_fn(radius=0.02 * 5, max_neighbor=64, **PSEUDO_KW)
+    assert fn.prepass_plan == dict(radius=(0.1, 64)) and fn.accepts_geometry
+    batches = [synthetic.make_batch(sz, first_scene_id=40 + 3 * i, kind="scannet", device="cuda") for i, sz in enumerate([[9000, 7000], [12000], [5000, 6100, 4000]])]
+    g = torch.Generator(device="cuda").manual_seed(2)
+    logits = [0.4 * torch.randn(b["coord"].shape[0], 20, device="cuda", generator=g) for b in batches]
+
+    def mask(b, lg, **kw):
+        torch.manual_seed(11)   # (the seed draw of the pass: the device generator)
+        return fn(b["coord"], lg, b["offset"], offset_host=b["offset_host"], **kw)
+
+    want = [mask(b, lg) for b, lg in zip(batches, logits)]
+    alone = [Geometry(b["coord"], b["offset"], b["offset_host"]).precompute(**fn.prepass_plan) for b in batches]
+    pf = GeometryPrefetcher(depth=1, **fn.prepass_plan)
+    grouped = [pf.get(t) for t in pf.submit_group(batches)]
+    torch.cuda.synchronize()
+    for b, ga, gg in zip(batches, alone, grouped):
+        ta, tg = ga.radius_cached(0.1, 64), gg.radius_cached(0.1, 64)
+        assert ta is not None and ta.dtype == torch.int32 and ta.shape == (b["coord"].shape[0], 64) and torch.equal(ta, tg)
+        assert torch.equal(ta, pl.radius_neighbors(b["coord"], b["offset"], 0.1, 64, raw=True))
+
+    def no_query(*a, **k):
+        raise AssertionError("the pass ran its own radius query")
+
+    monkeypatch.setattr(pl, "radius_neighbors", no_query)
+    for b, lg, w, ga, gg in zip(batches, logits, want, alone, grouped):
+        assert torch.equal(mask(b, lg, geometry=ga), w) and torch.equal(mask(b, lg, geometry=gg), w)
+        assert 0 < int(w.sum()) < w.numel()
