@@ -785,16 +785,41 @@ __global__ __launch_bounds__(WB) void k_step2rv_bwd_f(int N, int h, int L, const
 // StratifiedTransformer normalises the attention logits per query and head with torch_scatter.scatter_softmax(src, index_0, dim=0)
 // (stratified_transformer_v1m1_origin.py:322-324; torch_scatter is an unvendored dependency, absent here): y[m,h] =
 // exp(x[m,h] - max_q) / sum_q over the edges m of query q.  With the CSR offsets the op is one pass per query: lane = (query slot,
-// head) with HP = next power of two >= h heads per slot, so a wave carries 64 / HP queries and walks their edge lists in lockstep
-// (rows of h consecutive floats: coalesced); max, sum and the write are three sweeps over <= n_max edges.
+// head) with HP = next power of two >= h heads per slot, so a wave carries 64 / HP queries and walks their edge lists in lockstep;
+// max, sum and the write are three sweeps over <= n_max edges.  The rows of a wave's queries are ONE contiguous range of x: when it
+// fits the wave's slice of LDS (SM_CAP floats) it is brought in with coalesced loads, swept there and written back coalesced (the
+// lockstep walk reads 64 / HP separate rows per instruction, h consecutive floats each: 171 -> see profiles/r06_wa_softmax_ab.txt);
+// longer ranges take the sweeps over global memory.  Same operations in the same order on both paths: identical results.
+constexpr int SM_CAP = 2048;
 __global__ __launch_bounds__(WB) void k_seg_softmax_fwd(int N, int h, int HP, const int *__restrict__ offsets, const float *__restrict__ x,
                                                         float *__restrict__ y) {
+    __shared__ float buf[(WB / 64) * SM_CAP];
     const int per_wave = 64 / HP;
     const int lane = threadIdx.x & 63, slot = lane / HP, hh = lane - slot * HP;
     const long wave = ((long)blockIdx.x * WB + threadIdx.x) >> 6;
-    const long q = wave * per_wave + slot;
-    if (q >= N || hh >= h) return;
-    const int start = offsets[q], end = offsets[q + 1];
+    const long q0 = wave * per_wave, q = q0 + slot;
+    if (q0 >= N) return;
+    const int s = offsets[q0], e = offsets[min(q0 + per_wave, (long)N)];
+    const bool mine = q < N && hh < h;
+    const int start = mine ? offsets[q] : 0, end = mine ? offsets[q + 1] : 0;
+    const long cnt = (long)(e - s) * h;
+    if (cnt <= SM_CAP) {
+        float *b = buf + (threadIdx.x >> 6) * SM_CAP;
+        const float *src = x + (size_t)s * h;
+        for (int i = lane; i < cnt; i += 64) b[i] = src[i];
+        float *row = mine ? b + (size_t)(start - s) * h + hh : b;
+        const int len = end - start;
+        float mx = -3.0e38f;
+        for (int m = 0; m < len; ++m) mx = fmaxf(mx, row[m * h]);
+        float sum = 0.f;
+        for (int m = 0; m < len; ++m) sum += __expf(row[m * h] - mx);
+        const float inv = 1.f / sum;
+        for (int m = 0; m < len; ++m) row[m * h] = __expf(row[m * h] - mx) * inv;
+        float *dst = y + (size_t)s * h;
+        for (int i = lane; i < cnt; i += 64) dst[i] = b[i];
+        return;
+    }
+    if (!mine) return;
     float mx = -3.0e38f;
     for (int m = start; m < end; ++m) mx = fmaxf(mx, x[(size_t)m * h + hh]);
     float sum = 0.f;
@@ -803,15 +828,33 @@ __global__ __launch_bounds__(WB) void k_seg_softmax_fwd(int N, int h, int HP, co
     for (int m = start; m < end; ++m) y[(size_t)m * h + hh] = __expf(x[(size_t)m * h + hh] - mx) * inv;
 }
 
-// gx = y * (gy - sum_q y * gy)
+// gx = y * (gy - sum_q y * gy); staged through LDS like the forward (y and gy: 2 x SM_CAP floats per wave)
 __global__ __launch_bounds__(WB) void k_seg_softmax_bwd(int N, int h, int HP, const int *__restrict__ offsets, const float *__restrict__ y,
                                                         const float *__restrict__ gy, float *__restrict__ gx) {
+    __shared__ float buf[(WB / 64) * 2 * SM_CAP];
     const int per_wave = 64 / HP;
     const int lane = threadIdx.x & 63, slot = lane / HP, hh = lane - slot * HP;
     const long wave = ((long)blockIdx.x * WB + threadIdx.x) >> 6;
-    const long q = wave * per_wave + slot;
-    if (q >= N || hh >= h) return;
-    const int start = offsets[q], end = offsets[q + 1];
+    const long q0 = wave * per_wave, q = q0 + slot;
+    if (q0 >= N) return;
+    const int s = offsets[q0], e = offsets[min(q0 + per_wave, (long)N)];
+    const bool mine = q < N && hh < h;
+    const int start = mine ? offsets[q] : 0, end = mine ? offsets[q + 1] : 0;
+    const long cnt = (long)(e - s) * h;
+    if (cnt <= SM_CAP) {
+        float *by = buf + (threadIdx.x >> 6) * 2 * SM_CAP, *bg = by + SM_CAP;
+        const float *sy = y + (size_t)s * h, *sg = gy + (size_t)s * h;
+        for (int i = lane; i < cnt; i += 64) { by[i] = sy[i]; bg[i] = sg[i]; }
+        float *ry = mine ? by + (size_t)(start - s) * h + hh : by, *rg = mine ? bg + (size_t)(start - s) * h + hh : bg;
+        const int len = end - start;
+        float dot = 0.f;
+        for (int m = 0; m < len; ++m) dot += ry[m * h] * rg[m * h];
+        for (int m = 0; m < len; ++m) rg[m * h] = ry[m * h] * (rg[m * h] - dot);
+        float *dst = gx + (size_t)s * h;
+        for (int i = lane; i < cnt; i += 64) dst[i] = bg[i];
+        return;
+    }
+    if (!mine) return;
     float dot = 0.f;
     for (int m = start; m < end; ++m) dot += y[(size_t)m * h + hh] * gy[(size_t)m * h + hh];
     for (int m = start; m < end; ++m) gx[(size_t)m * h + hh] = y[(size_t)m * h + hh] * (gy[(size_t)m * h + hh] - dot);

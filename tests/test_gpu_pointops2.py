@@ -478,3 +478,27 @@ def test_window_key_kernel_equals_the_torch_composition(case, parity):
         for name, a, b, c in zip(("kf", "kc", "wk"), got, want, on_dev):
             assert a.dtype == torch.int64 and torch.equal(a.cpu(), b), (case, parity, ws, name, int((a.cpu() != b).sum()))
             assert torch.equal(a, c), (case, parity, ws, name, "device composition")
+
+
+@pytest.mark.parametrize("h", [1, 3, 6, 12, 24])
+def test_segment_softmax_rows_through_lds_and_through_global_memory(p2, h):
+    """pdf_segment_softmax_forward / _backward (scatter_softmax over the CSR rows, stratified_transformer_v1m1_origin.py:322-324): ragged
+    rows -- empty ones, rows of one entry, window-sized rows (a wave's rows fit its LDS slice: staged path) and rows of thousands of
+    entries (they do not: global-memory path) in one call -- against the dense formula in float64; forward rows sum to one."""
+    g = torch.Generator().manual_seed(40 + h)
+    lens = torch.cat([torch.randint(20, 60, (300,), generator=g), torch.tensor([0, 1, 0, 2, 5000, 1, 3000, 0]),
+                      torch.randint(1, 90, (200,), generator=g), torch.tensor([900, 0, 0])])
+    off = torch.cat([torch.zeros(1, dtype=torch.long), lens.cumsum(0)]).int()
+    m = int(off[-1])
+    x = (3.0 * torch.randn(m, h, generator=g)).cuda().requires_grad_(True)
+    gy = torch.randn(m, h, generator=g).cuda()
+    y = p2.segment_softmax(x, off.cuda())
+    y.backward(gy)
+    xr = x.detach().double().cpu().requires_grad_(True)
+    rows = [xr[a:b].softmax(0) for a, b in zip(off[:-1].tolist(), off[1:].tolist()) if b > a]
+    yr = torch.cat(rows)
+    yr.backward(gy.double().cpu())
+    assert (y.detach().cpu().double() - yr.detach()).abs().max() < 5e-6   # (__expf)
+    assert (x.grad.cpu().double() - xr.grad).abs().max() < 2e-5 * gy.abs().max()
+    sums = torch.zeros(lens.shape[0], h, dtype=torch.float64).index_add_(0, torch.repeat_interleave(torch.arange(lens.shape[0]), lens), y.detach().cpu().double())
+    assert ((sums - 1.0).abs()[lens > 0] < 1e-5).all()
