@@ -122,8 +122,8 @@ struct WArgs {
     float *dW;                       // (O, K), written by the slab reduction
     float *db;                       // (O) or null
     long rows_per_block;
-    float *slab;                     // [gridDim.y][4 gridDim.x][32 * 32]: one block of dW per WAVE (rl2::k_slab_reduce sums them in order)
-    float *bslab;                    // [ceil(O / 32)][4 gridDim.x][32]: column sums of G (k-block 0)
+    float *slab;                     // [gridDim.y][gridDim.x][32 * 32]: one block of dW per WORKGROUP (rl2::k_slab_reduce sums them in order)
+    float *bslab;                    // [ceil(O / 32)][gridDim.x][32]: column sums of G (k-block 0)
 };
 
 // One wave = one 32x32 block of dW over a row range: A operand = G^T (lanes along o), B operand = f(X) (lanes along k);
@@ -163,17 +163,26 @@ __global__ __launch_bounds__(256) void k_wgrad(WArgs a) {
             gsum += g[u];
         }
     }
-    const size_t sidx = (size_t)blockIdx.x * 4 + wave, nsl = (size_t)gridDim.x * 4;
-    float *slab = a.slab + ((size_t)blockIdx.y * nsl + sidx) * 1024;
+    // the four waves' blocks added in wave order through LDS: ONE slab per workgroup (round 6: a slab per wave was 4x the workspace
+    // traffic and 4x the reducer's reads -- the fixed cost of this kernel at a few thousand rows; 46 -> 36 us at 160k x 48 -> 48,
+    // 27 -> 23 us at 10k x 192 -> 192.  Measured and dropped: 8 / 16 loads in flight per lane instead of 4 (+-0 / slower); every wave its
+    // own 32 x 32 block of a 64 x 64 region over all rows of the range, sharing operand rows through L1 (wide layers -12 %, the rest +20 %))
+    __shared__ float comb[4][1024 + 32];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // o index inside the block
-        slab[i * 32 + ch] = acc[r];
+        comb[wave][i * 32 + ch] = acc[r];
     }
-    if (a.db && c0 == 0) {
-        gsum += __shfl_xor(gsum, 32, 64);
-        if (lane < 32) a.bslab[((size_t)(o0 / 32) * nsl + sidx) * 32 + ch] = gsum;
-    }
+    gsum += __shfl_xor(gsum, 32, 64);
+    if (lane < 32) comb[wave][1024 + ch] = gsum;
+    __syncthreads();
+    const size_t sidx = blockIdx.x, nsl = gridDim.x;
+    float *slab = a.slab + ((size_t)blockIdx.y * nsl + sidx) * 1024;
+#pragma unroll
+    for (int e = threadIdx.x; e < 1024; e += 256) slab[e] = ((comb[0][e] + comb[1][e]) + comb[2][e]) + comb[3][e];
+    if (a.db && c0 == 0 && threadIdx.x < 32)
+        a.bslab[((size_t)(o0 / 32) * nsl + sidx) * 32 + threadIdx.x] =
+            ((comb[0][1024 + threadIdx.x] + comb[1][1024 + threadIdx.x]) + comb[2][1024 + threadIdx.x]) + comb[3][1024 + threadIdx.x];
 }
 
 }  // namespace rl
@@ -321,13 +330,13 @@ extern "C" int pdf_rowlin_wgrad(long n, int k, int o, const float *g, long ldg, 
     int blocks_oc; long split;
     tiled_wg_plan(n, k, o, &blocks_oc, &split, &a.rows_per_block);
     a.slab = ws;
-    a.bslab = ws + (size_t)blocks_oc * split * 4 * 1024;
+    a.bslab = ws + (size_t)blocks_oc * split * 1024;
     const dim3 grid((unsigned)split, (unsigned)blocks_oc);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (scale) rl::k_wgrad<true><<<grid, 256, 0, s>>>(a);
     else rl::k_wgrad<false><<<grid, 256, 0, s>>>(a);
     rl2::RArgs r;
-    r.slab = a.slab; r.bslab = a.bslab; r.B = 32; r.tiles_k = (k + 31) / 32; r.tiles = blocks_oc; r.otiles = (o + 31) / 32; r.split = (int)(split * 4);
+    r.slab = a.slab; r.bslab = a.bslab; r.B = 32; r.tiles_k = (k + 31) / 32; r.tiles = blocks_oc; r.otiles = (o + 31) / 32; r.split = (int)split;
     r.K = k; r.O = o;
     r.dW[0] = dw; r.db[0] = db; r.dW[1] = r.dW[2] = nullptr; r.db[1] = r.db[2] = nullptr;
     rl2::launch_slab_reduce(r, 1, db != nullptr, s);
