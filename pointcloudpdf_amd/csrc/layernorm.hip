@@ -18,7 +18,14 @@
 namespace ln {
 
 constexpr int TB = 256;
-constexpr int MAX_BLOCKS = 512;   // (= partial rows of the backward: two workgroups per CU)
+// Workgroups in flight.  A wave's trip is one 16-byte load per lane and a butterfly: the walk is bound by the load's round trip, so the
+// forward spreads the rows over as many waves as the device holds (640k x 48 rows: 91 us with 512 workgroups, 46 us with 2,048); the
+// backward keeps 512 (= its partial rows: the scratch stays under the caching allocator's 1-2 MB classes for every width; 2,048 measured
+// -0.2 ms per config-5 step on one box and +2 ms on another).  PDFOPS_LN_BLOCKS: both, for A/B runs.
+static inline int max_blocks(bool backward) {
+    static const int v = [] { const char *e = getenv("PDFOPS_LN_BLOCKS"); return e ? atoi(e) : 0; }();
+    return v > 0 ? v : (backward ? 512 : 2048);
+}
 
 __device__ __forceinline__ float group_sum(float v, int G) {
     for (int m = 1; m < G; m <<= 1) v += __shfl_xor(v, m, 64);
@@ -177,9 +184,9 @@ __global__ __launch_bounds__(TB) void k_colsum(const float *__restrict__ partial
     }
 }
 
-static inline int grid_for(long n, const Geo &g) {
+static inline int grid_for(long n, const Geo &g, bool backward) {
     const long waves = (n + g.rpw - 1) / g.rpw, blocks = (waves + 3) / 4;
-    return (int)(blocks < 1 ? 1 : (blocks > MAX_BLOCKS ? MAX_BLOCKS : blocks));
+    return (int)(blocks < 1 ? 1 : (blocks > max_blocks(backward) ? max_blocks(backward) : blocks));
 }
 
 }  // namespace ln
@@ -188,7 +195,7 @@ extern "C" int pdf_layernorm_supported(int c) { return c >= 4 && c % 4 == 0 && c
 
 extern "C" long pdf_layernorm_partial_floats(long n, int c) {
     if (n < 1 || !pdf_layernorm_supported(c)) return 0;
-    return (long)ln::grid_for(n, ln::geo_of(c)) * 2 * c;
+    return (long)ln::grid_for(n, ln::geo_of(c), true) * 2 * c;
 }
 
 // torch.nn.functional.layer_norm(x, (c,), gamma, beta, eps) on (n, c) rows; mean / rstd (n) are saved for the backward.
@@ -200,8 +207,8 @@ extern "C" int pdf_layernorm_forward(long n, int c, const float *x, const float 
                                          reinterpret_cast<uintptr_t>(beta)) & 15)) return PDF_ERR_UNSUPPORTED;
     const ln::Geo g = ln::geo_of(c);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (g.V == 1) ln::k_fwd<1><<<ln::grid_for(n, g), ln::TB, 0, s>>>(n, c, g.G, x, gamma, beta, eps, y, mean, rstd);
-    else ln::k_fwd<2><<<ln::grid_for(n, g), ln::TB, 0, s>>>(n, c, g.G, x, gamma, beta, eps, y, mean, rstd);
+    if (g.V == 1) ln::k_fwd<1><<<ln::grid_for(n, g, false), ln::TB, 0, s>>>(n, c, g.G, x, gamma, beta, eps, y, mean, rstd);
+    else ln::k_fwd<2><<<ln::grid_for(n, g, false), ln::TB, 0, s>>>(n, c, g.G, x, gamma, beta, eps, y, mean, rstd);
     return pdf_launch_status();
 }
 
@@ -217,7 +224,7 @@ extern "C" int pdf_layernorm_backward(long n, int c, const float *gy, const floa
         return PDF_OK;
     }
     const ln::Geo g = ln::geo_of(c);
-    const int grid = ln::grid_for(n, g);
+    const int grid = ln::grid_for(n, g, true);
     const size_t lds = sizeof(float) * 8 * (size_t)c;
     if (g.V == 1) ln::k_bwd<1><<<grid, ln::TB, lds, s>>>(n, c, g.G, gy, x, mean, rstd, gamma, gx, partial);
     else ln::k_bwd<2><<<grid, ln::TB, lds, s>>>(n, c, g.G, gy, x, mean, rstd, gamma, gx, partial);
