@@ -506,6 +506,11 @@ int pdf_segment_softmax_backward(int N, int M, int h, const int *index0_offsets,
  * PDF_ERR_UNSUPPORTED for other head dims / longer tables: the caller keeps the atomic launchers above. */
 int pdf_wa_segment_rows(int N, int h, int d, int L, const int *seg_off, const int *seg_edge, const int *other, const int *rel,
                         const float *w, const float *X, long ldx, float xscale, const float *table, float *out, long ldo, float oscale, void *stream);
+/* pdf_wa_segment_rows with a visiting order of the owners (a permutation of 0 .. N - 1, or null = storage order): same sums, same results;
+ * owners of one window side by side gather the same rows (stratified.BasicLayer.window_tables hands the window-sorted order over). */
+int pdf_wa_segment_rows_ordered(int N, int h, int d, int L, const int *seg_off, const int *seg_edge, const int *other, const int *rel,
+                                const float *w, const float *X, long ldx, float xscale, const float *table, float *out, long ldo, float oscale,
+                                const int *order, void *stream);
 long pdf_wa_table_grad_ws_floats(int N, int h, int L);
 int pdf_wa_table_grad(int N, int h, int d, int L, const int *seg_off, const int *seg_edge, const int *rel, const float *w,
                       const float *x, long ldx, float xscale, float *ws, float *grad_table, void *stream);

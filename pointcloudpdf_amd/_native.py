@@ -85,6 +85,7 @@ _HIP_ONLY_PROTOS = {
     "gmm2_1d_dev": "ippppidd",
     "graph_forest_batch_dev": "ippippppppipppl",
     "wa_segment_rows": "iiiipppppplfpplf",
+    "wa_segment_rows_ordered": "iiiipppppplfpplfp",
     "wa_table_grad": "iiiippppplfpp",
     "wa_grad_attn": "iiiiiplppplppp",
     "wa_logits_forward": "iiiiipplfpppppp",
@@ -193,6 +194,15 @@ def inverse_table(idx, n):
 
 
 _CSC = "_pdf_window_csc"
+_WORDER = "_pdf_window_order"   # on the CSR offsets of a window edge table: the queries sorted by fine-window key (int32 permutation)
+
+
+def window_order_of(offsets):
+    """The visiting order ``HipBackend.window_edges`` left on a table's CSR offsets (queries window by window), or None."""
+    tag = getattr(offsets, _WORDER, None)
+    if tag is not None and tag[0] == offsets.data_ptr() and tag[1] == offsets._version and tag[2].shape[0] == offsets.shape[0] - 1:
+        return tag[2]
+    return None
 
 
 def window_csc(index1, offsets, rel_idx=None, n_keys=None):
@@ -1058,11 +1068,19 @@ class HipBackend(CBackend):
     def _wa_ok(self, d, L, *tensors):
         return self.wa_atomic_free and d == 16 and L <= 64 and all(t.data_ptr() % 16 == 0 for t in tensors)
 
-    def _wa_rows(self, n, h, d, L, seg_off, seg_edge, other, rel, w, X, table, out, ldx=None, xscale=1.0, ldo=None, oscale=1.0):
-        """pdf_wa_segment_rows; X / out may be column slices of wider rows (ldx / ldo = their row strides in floats)."""
+    def _wa_rows(self, n, h, d, L, seg_off, seg_edge, other, rel, w, X, table, out, ldx=None, xscale=1.0, ldo=None, oscale=1.0, order=None):
+        """pdf_wa_segment_rows[_ordered]; X / out may be column slices of wider rows (ldx / ldo = their row strides in floats); ``order``:
+        visiting order of the owners (int32 permutation) or None."""
         c = h * d
-        self._call("wa_segment_rows", n, h, d, L, seg_off, seg_edge, other, rel, w, X, c if ldx is None else int(ldx), float(xscale), table, out,
-                   c if ldo is None else int(ldo), float(oscale))
+        if order is not None and (order.shape[0] != n or order.dtype != torch.int32):
+            order = None
+        self._call("wa_segment_rows_ordered", n, h, d, L, seg_off, seg_edge, other, rel, w, X, c if ldx is None else int(ldx), float(xscale), table, out,
+                   c if ldo is None else int(ldo), float(oscale), order)
+
+    wa_window_order = os.environ.get("PDFOPS_WA_WINDOW_ORDER", "1") != "0"   # (A/B: 0 = owners in storage order)
+
+    def _wa_order(self, offsets):
+        return window_order_of(offsets) if self.wa_window_order else None
 
     def _wa_permute(self, w, edge):
         """w (M, h) float32 -> w[edge] (torch's index_select takes 25-95 us for these 12-96-byte rows; this is one pass at copy speed)"""
@@ -1157,8 +1175,12 @@ class HipBackend(CBackend):
         index1 = torch.empty(e, **i32)
         rel = torch.empty((e, 3), **i32)
         flag = torch.zeros(1, **i32)
-        self._call("window_edges_fill", n, offsets, seg, order_f.int(), order_cd.int(), wk, wkd, xyz.contiguous(), float(c2w), float(qs), int(vmax),
+        order32 = order_f.int()
+        self._call("window_edges_fill", n, offsets, seg, order32, order_cd.int(), wk, wkd, xyz.contiguous(), float(c2w), float(qs), int(vmax),
                    index0, index1, rel, flag)
+        # the queries window by window: the visiting order of the attention's segmented row passes (queries / keys of one window gather
+        # the same rows: pdf_wa_segment_rows_ordered)
+        setattr(offsets, _WORDER, (offsets.data_ptr(), offsets._version, order32))
         return index0, index1, offsets, n_max, rel, flag
 
     def window_logits_supported(self, q, k, table_q):
@@ -1222,7 +1244,7 @@ class HipBackend(CBackend):
         self._call("wa_logits_forward", n, m, h, d, L, q, k, 3 * c, float(scale), offsets, index1, table_q, table_k, rel_idx, logits)
         attn = self.segment_softmax(logits, offsets)
         out = torch.empty((n, c), dtype=torch.float32, device=qkv.device)
-        self._wa_rows(n, h, d, L, offsets, None, index1, rel_idx, attn, v, table_v, out, ldx=3 * c)
+        self._wa_rows(n, h, d, L, offsets, None, index1, rel_idx, attn, v, table_v, out, ldx=3 * c, order=self._wa_order(offsets))
         return out, attn
 
     def window_attention_core_backward(self, go, qkv, attn, index1, offsets, table_q, table_k, table_v, rel_idx, scale):
@@ -1236,11 +1258,12 @@ class HipBackend(CBackend):
         ga = torch.empty((m, h), dtype=torch.float32, device=qkv.device)
         self._call("wa_grad_attn", n, m, h, d, L, go, c, offsets, index1, v, 3 * c, table_v, rel_idx, ga)
         attn_key = self._wa_permute(attn, key_edge)
-        self._wa_rows(n, h, d, 0, key_off, None, key_q, None, attn_key, go, None, gqkv[:, 2 * c:], ldo=3 * c)          # grad_v
+        order = self._wa_order(offsets)   # (window by window: measured on the query-side passes and the table-free key-side pass, not on grad_k)
+        self._wa_rows(n, h, d, 0, key_off, None, key_q, None, attn_key, go, None, gqkv[:, 2 * c:], ldo=3 * c, order=order)          # grad_v
         gtv = self._wa_table_grad(n, h, d, L, offsets, None, rel_idx, attn, go, qkv)
         g = self.segment_softmax_backward(attn, ga, offsets)
         g_key = self._wa_permute(g, key_edge)
-        self._wa_rows(n, h, d, L, offsets, None, index1, rel_idx, g, k, table_q, gqkv[:, :c], ldx=3 * c, ldo=3 * c, oscale=scale)      # grad_q
+        self._wa_rows(n, h, d, L, offsets, None, index1, rel_idx, g, k, table_q, gqkv[:, :c], ldx=3 * c, ldo=3 * c, oscale=scale, order=order)      # grad_q
         self._wa_rows(n, h, d, L, key_off, None, key_q, key_rel, g_key, q, table_k, gqkv[:, c:2 * c], ldx=3 * c, xscale=scale, ldo=3 * c)   # grad_k
         gtq = self._wa_table_grad(n, h, d, L, offsets, None, rel_idx, g, q, qkv, ldx=3 * c, xscale=scale)
         gtk = self._wa_table_grad(n, h, d, L, key_off, None, key_rel, g_key, k, qkv, ldx=3 * c)

@@ -58,7 +58,7 @@ template <int HG, bool CSC, bool ROWS, bool TABLE>
 __global__ __launch_bounds__(TB) void k_rows(int N, int h, int L, const int *__restrict__ seg_off, const int *__restrict__ seg_edge,
                                              const int *__restrict__ other, const int *__restrict__ rel, const float *__restrict__ w,
                                              const float *__restrict__ X, long ldx, float xscale, const float *__restrict__ table,
-                                             float *__restrict__ out, long ldo, float oscale) {
+                                             float *__restrict__ out, long ldo, float oscale, const int *__restrict__ order) {
     constexpr int CG = HG * D, PQ = CG / 4, RPB = TB / PQ;
     extern __shared__ __attribute__((aligned(16))) float tl[];   // [3][L][CG]
     const int h0 = blockIdx.y * HG;
@@ -67,8 +67,9 @@ __global__ __launch_bounds__(TB) void k_rows(int N, int h, int L, const int *__r
         __syncthreads();
     }
     const int slot = threadIdx.x / PQ, p = threadIdx.x - slot * PQ;
-    const long n = (long)blockIdx.x * RPB + slot;
-    if (slot >= RPB || n >= N) return;
+    const long pos = (long)blockIdx.x * RPB + slot;
+    if (slot >= RPB || pos >= N) return;
+    const long n = order ? order[pos] : pos;     // visiting order of the owners (window by window: their gathered rows coincide)
     const int hh = h0 + p / 4;                       // this lane's head
     const size_t col = (size_t)h0 * D + 4 * p;
     int t = seg_off[n];
@@ -409,9 +410,21 @@ static inline int table_grid(int N, int h) {
 // ldx / ldo: row strides (floats) of X and out -- rows may be slices of wider rows (q / k / v inside the (N, 3 C) output of the qkv Linear).
 // other / rel are given IN SEGMENT ORDER (the CSR arrays themselves, or the permuted copies of the CSC list).  Bytes: 4 M C per gathered
 // row table + (8 + 12 + 4 h) M of integers / scalars + 4 N C written.
+extern "C" int pdf_wa_segment_rows_ordered(int N, int h, int d, int L, const int *seg_off, const int *seg_edge, const int *other, const int *rel,
+                                           const float *w, const float *X, long ldx, float xscale, const float *table, float *out, long ldo,
+                                           float oscale, const int *order, void *stream);
 extern "C" int pdf_wa_segment_rows(int N, int h, int d, int L, const int *seg_off, const int *seg_edge, const int *other, const int *rel,
                                    const float *w, const float *X, long ldx, float xscale, const float *table, float *out, long ldo, float oscale,
                                    void *stream) {
+    return pdf_wa_segment_rows_ordered(N, h, d, L, seg_off, seg_edge, other, rel, w, X, ldx, xscale, table, out, ldo, oscale, nullptr, stream);
+}
+
+// The same with a visiting order of the owners (order: a permutation of 0 .. N - 1, or null): workgroups that run side by side then work
+// on owners of one window, whose segments gather the same rows (the window's members) -- L2 hits instead of Infinity-Cache traffic.
+// Every owner's sum is formed as before: results are identical.
+extern "C" int pdf_wa_segment_rows_ordered(int N, int h, int d, int L, const int *seg_off, const int *seg_edge, const int *other, const int *rel,
+                                           const float *w, const float *X, long ldx, float xscale, const float *table, float *out, long ldo,
+                                           float oscale, const int *order, void *stream) {
     if (N < 0 || h < 1 || d < 1 || !seg_off || !w || !out || (X && !other) || (table && (!rel || L < 1))) return PDF_ERR_BAD_ARG;
     if (N == 0) return PDF_OK;
     if (d != wb::D || (table && L > wb::LMAX) || (!X && !table)) return PDF_ERR_UNSUPPORTED;
@@ -423,7 +436,7 @@ extern "C" int pdf_wa_segment_rows(int N, int h, int d, int L, const int *seg_of
         constexpr int rpb = wb::TB / (HG_ * 4); \
         const size_t lds = TABLE_ ? sizeof(float) * 3 * (size_t)L * HG_ * wb::D : 0; \
         wb::k_rows<HG_, CSC_, ROWS_, TABLE_><<<dim3((unsigned)((N + rpb - 1) / rpb), (unsigned)(h / HG_)), wb::TB, lds, s>>>( \
-            N, h, L, seg_off, seg_edge, other, rel, w, X, ldx, xscale, table, out, ldo, oscale); } while (0)
+            N, h, L, seg_off, seg_edge, other, rel, w, X, ldx, xscale, table, out, ldo, oscale, order); } while (0)
 #define PDF_WB_ROWS2(HG_, CSC_) do { \
         if (X && table) PDF_WB_ROWS(HG_, CSC_, true, true); else if (X) PDF_WB_ROWS(HG_, CSC_, true, false); else PDF_WB_ROWS(HG_, CSC_, false, true); } while (0)
     if (hg == 3) { if (seg_edge) PDF_WB_ROWS2(3, true); else PDF_WB_ROWS2(3, false); }

@@ -481,6 +481,9 @@ class StratifiedGeometry:
         for tables in self.windows.values():
             for tab in tables.values():
                 out += [t for t in tab if torch.is_tensor(t)]
+                order = _native.window_order_of(tab[2])   # the queries window by window, left on the CSR offsets by the edge builder
+                if order is not None:
+                    out.append(order)
                 csc = getattr(tab[1], _native._CSC, None)   # the key-grouped edge list cached on index_1 (_native.window_csc)
                 if csc is not None:
                     out += list(csc["base"]) + [csc["perm"]] + list(csc["rel"].values())

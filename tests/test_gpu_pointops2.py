@@ -502,3 +502,38 @@ def test_segment_softmax_rows_through_lds_and_through_global_memory(p2, h):
     assert (x.grad.cpu().double() - xr.grad).abs().max() < 2e-5 * gy.abs().max()
     sums = torch.zeros(lens.shape[0], h, dtype=torch.float64).index_add_(0, torch.repeat_interleave(torch.arange(lens.shape[0]), lens), y.detach().cpu().double())
     assert ((sums - 1.0).abs()[lens > 0] < 1e-5).all()
+
+
+def test_segment_rows_in_any_owner_order_are_the_same_rows(p2):
+    """pdf_wa_segment_rows_ordered: the visiting order of the owners (the queries window by window: what the edge builder leaves on a
+    table's CSR offsets) changes which workgroup forms a row, not the row -- bit-identical outputs for the query-side pass with rows +
+    table, and for the key-side pass over the transposed list; the window edge builder's order is a permutation sorted by window key."""
+    from pointcloudpdf_amd import _native, stratified, synthetic
+
+    be = _native.hip_backend()
+    b = synthetic.make_batch([9000, 7000], first_scene_id=77, device="cuda")
+    xyz, off = b["coord"], b["offset"]
+    lo, hi = xyz.min(0).values, xyz.max(0).values
+    kf, kc, wk = be.window_keys(xyz, off, lo, hi, 0.16, 0)
+    ds = torch.arange(0, xyz.shape[0], 8, device="cuda", dtype=torch.int32)
+    i0, i1, offsets, n_max, rel, flag = be.window_edges(xyz, kf, kc, wk, ds, 0.32, 0.01, 63)
+    order = _native.window_order_of(offsets)
+    n, m, h, d, L = xyz.shape[0], i1.shape[0], 3, 16, 64
+    assert order is not None and order.dtype == torch.int32 and torch.equal(order.long().sort().values, torch.arange(n, device="cuda"))
+    assert bool((kf[order.long()][1:] >= kf[order.long()][:-1]).all())
+    g = torch.Generator(device="cuda").manual_seed(9)
+    w = torch.rand(m, h, device="cuda", generator=g)
+    X = torch.randn(n, h * d, device="cuda", generator=g)
+    T = torch.randn(L, h, d, 3, device="cuda", generator=g)
+    outs = []
+    for o in (None, order, torch.randperm(n, device="cuda", generator=g).int()):
+        out = torch.empty(n, h * d, device="cuda")
+        be._wa_rows(n, h, d, L, offsets, None, i1, rel, w, X, T, out, order=o)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and float(outs[0].abs().max()) > 0
+    key_off, key_edge, key_q, key_rel = _native.window_csc(i1, offsets, rel, n_keys=n)
+    wk_ = be._wa_permute(w, key_edge)
+    a, c = torch.empty(n, h * d, device="cuda"), torch.empty(n, h * d, device="cuda")
+    be._wa_rows(n, h, d, 0, key_off, None, key_q, None, wk_, X, None, a)
+    be._wa_rows(n, h, d, 0, key_off, None, key_q, None, wk_, X, None, c, order=order)
+    assert torch.equal(a, c)

@@ -25,8 +25,14 @@ def t(fn):
     return e0.elapsed_time(e1) / iters * 1e3
 
 total = 0.0
+xyzs, offs = {0: b["coord"]}, {0: b["offset"]}
+for l in range(3):
+    xyzs[l + 1], offs[l + 1] = geom.neighbors[("td", l)][0], geom.samples[("down", l)][1]
 for level, layer in bb.layers_by_level().items():
     index0, index1, offsets, n_max, rel = geom.windows[level][0]
+    lo, hi = xyzs[level].min(0).values, xyzs[level].max(0).values
+    kf = be.window_keys(xyzs[level], offs[level], lo, hi, layer.window_size, 0)[0]
+    worder = torch.sort(kf, stable=True)[1].int()      # the owners window by window
     attn_mod = layer.blocks[0].attn
     tq, tk, tv = attn_mod.relative_pos_query_table.detach(), attn_mod.relative_pos_key_table.detach(), attn_mod.relative_pos_value_table.detach()
     L, h, d, _ = tq.shape
@@ -50,6 +56,9 @@ for level, layer in bb.layers_by_level().items():
         ("rows grad_v (CSC, edge ids)", lambda: be._wa_rows(n, h, d, 0, key_off, key_edge, key_q, None, attn, go, None, gqkv[:, 2 * c:], ldo=3 * c)),
         ("rows grad_k (CSC, edge ids)", lambda: be._wa_rows(n, h, d, L, key_off, key_edge, key_q, key_rel, gsm, q, tk, gqkv[:, c:2 * c], ldx=3 * c, xscale=0.25, ldo=3 * c)),
         ("table gtk (key order, edge ids)", lambda: be._wa_table_grad(n, h, d, L, key_off, key_edge, key_rel, gsm, k, qkv, ldx=3 * c)),
+        ("rows fwd out, window order", lambda: be._wa_rows(n, h, d, L, offsets, None, index1, rel, attn, v, tv, out, ldx=3 * c, order=worder)),
+        ("rows grad_v (CSC), window order", lambda: be._wa_rows(n, h, d, 0, key_off, None, key_q, None, attn_key, go, None, gqkv[:, 2 * c:], ldo=3 * c, order=worder)),
+        ("rows grad_k (CSC), window order", lambda: be._wa_rows(n, h, d, L, key_off, None, key_q, key_rel, g_key, q, tk, gqkv[:, c:2 * c], ldx=3 * c, xscale=0.25, ldo=3 * c, order=worder)),
         ("table gtv (CSR)", lambda: be._wa_table_grad(n, h, d, L, offsets, None, rel, attn, go, qkv)),
         ("softmax_bwd", lambda: be.segment_softmax_backward(attn, ga, offsets)),
         ("rows grad_q (CSR, rows+table)", lambda: be._wa_rows(n, h, d, L, offsets, None, index1, rel, gsm, k, tq, gqkv[:, :c], ldx=3 * c, ldo=3 * c, oscale=0.25)),
@@ -60,7 +69,7 @@ for level, layer in bb.layers_by_level().items():
     print(f"level {level}: N={n} M={m} C={c} h={h} L={L} n_max={n_max} mean row {m / n:.1f}  blocks={layer.depth}")
     for name, fn in rows:
         us = t(fn)
-        if name not in ("logits_fwd", "rows fwd out (CSR, rows+table)") and "edge ids" not in name:
+        if name not in ("logits_fwd", "rows fwd out (CSR, rows+table)") and "edge ids" not in name and "window order" not in name:
             total += us * layer.depth
         print(f"    {name:34s} {us:9.1f} us", flush=True)
 print(f"backward pieces x blocks per level: {total / 1e3:.2f} ms per step")
