@@ -523,6 +523,13 @@ int pdf_wa_logits_forward(int N, int M, int h, int d, int L, const float *q, con
                           const int *index1, const float *table_q, const float *table_k, const int *rel, float *out, void *stream);
 /* dst (M, h) = src[edge[m], :]: edge scalars (attention weights / logit gradients) brought into the order of the key-grouped edge list. */
 int pdf_wa_permute_edges(int M, int h, const float *src, const int *edge, float *dst, void *stream);
+/* pdf_wa_logits_forward / pdf_wa_grad_attn with the queries a workgroup takes given by a visiting order (see pdf_wa_segment_rows_ordered);
+ * every output element is the same expression: identical results. */
+int pdf_wa_logits_forward_ordered(int N, int M, int h, int d, int L, const float *q, const float *k, long ld, float qscale, const int *offsets,
+                                  const int *index1, const float *table_q, const float *table_k, const int *rel, float *out, const int *order,
+                                  void *stream);
+int pdf_wa_grad_attn_ordered(int N, int M, int h, int d, int L, const float *grad_out, long ldg, const int *offsets, const int *index1,
+                             const float *v, long ldv, const float *table, const int *rel, float *grad_attn, const int *order, void *stream);
 
 /* Edge tables of the StratifiedTransformer's window partitions (stratified_transformer_v1m1_origin.py:45-127 get_indice_pairs / grid_sample +
  * the stable sort by query of :468-536, and WindowAttention's quantised relative positions :282-292), built per QUERY instead of by pair

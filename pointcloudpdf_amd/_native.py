@@ -90,6 +90,8 @@ _HIP_ONLY_PROTOS = {
     "wa_grad_attn": "iiiiiplppplppp",
     "wa_logits_forward": "iiiiipplfpppppp",
     "wa_permute_edges": "iippp",
+    "wa_logits_forward_ordered": "iiiiipplfppppppp",
+    "wa_grad_attn_ordered": "iiiiiplppplpppp",
     "window_keys": "ippippfippp",
     "window_edges_count": "ippipppppp",
     "window_edges_fill": "ipppppppffipppp",
@@ -1241,7 +1243,8 @@ class HipBackend(CBackend):
         c, m = h * d, index1.shape[0]
         q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
         logits = torch.empty((m, h), dtype=torch.float32, device=qkv.device)
-        self._call("wa_logits_forward", n, m, h, d, L, q, k, 3 * c, float(scale), offsets, index1, table_q, table_k, rel_idx, logits)
+        self._call("wa_logits_forward_ordered", n, m, h, d, L, q, k, 3 * c, float(scale), offsets, index1, table_q, table_k, rel_idx, logits,
+                   self._wa_order(offsets))
         attn = self.segment_softmax(logits, offsets)
         out = torch.empty((n, c), dtype=torch.float32, device=qkv.device)
         self._wa_rows(n, h, d, L, offsets, None, index1, rel_idx, attn, v, table_v, out, ldx=3 * c, order=self._wa_order(offsets))
@@ -1256,9 +1259,9 @@ class HipBackend(CBackend):
         key_off, key_edge, key_q, key_rel = window_csc(index1, offsets, rel_idx, n_keys=n)
         gqkv = torch.empty_like(qkv)
         ga = torch.empty((m, h), dtype=torch.float32, device=qkv.device)
-        self._call("wa_grad_attn", n, m, h, d, L, go, c, offsets, index1, v, 3 * c, table_v, rel_idx, ga)
-        attn_key = self._wa_permute(attn, key_edge)
         order = self._wa_order(offsets)   # (window by window: measured on the query-side passes and the table-free key-side pass, not on grad_k)
+        self._call("wa_grad_attn_ordered", n, m, h, d, L, go, c, offsets, index1, v, 3 * c, table_v, rel_idx, ga, order)
+        attn_key = self._wa_permute(attn, key_edge)
         self._wa_rows(n, h, d, 0, key_off, None, key_q, None, attn_key, go, None, gqkv[:, 2 * c:], ldo=3 * c, order=order)          # grad_v
         gtv = self._wa_table_grad(n, h, d, L, offsets, None, rel_idx, attn, go, qkv)
         g = self.segment_softmax_backward(attn, ga, offsets)

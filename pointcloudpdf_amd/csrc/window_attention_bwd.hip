@@ -306,16 +306,37 @@ __global__ __launch_bounds__(TB) void k_table_reduce(int G, int HGN, int HGsz, i
 // The table term factors through the projection P_q[a][r] = < table[r, hh, :, a], grad_out[q, hh, :] > (3 L dot products per query instead
 // of 3 x 16 multiply-adds per edge).  grid = (ceil(N / QF), h); lane = edge (value row: 4 x 16 bytes contiguous).
 constexpr int QF = 32;
+// The chunk's queries are positions q0 .. q0 + nq - 1 of `order` (null: the queries themselves): their edge ranges need not be adjacent,
+// so the lanes walk a VIRTUAL edge index over the chunk (pref: exclusive prefix of the row lengths, qst: first edge of every row).
+template <int QN>
+__device__ __forceinline__ void chunk_rows(int *pref, int *qst, int *qid, const int *__restrict__ offsets, const int *__restrict__ order, int q0, int nq) {
+    static_assert(QN <= 64, "one wave scans the chunk's row lengths");
+    if (threadIdx.x < 64) {
+        const int jj = threadIdx.x;
+        const int q = jj < nq ? (order ? order[q0 + jj] : q0 + jj) : 0;
+        const int st = jj < nq ? offsets[q] : 0;
+        int len = jj < nq ? offsets[q + 1] - st : 0, sum = len;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(sum, o, 64);
+            if (jj >= o) sum += u;
+        }
+        if (jj < QN) { qid[jj] = q; qst[jj] = st; pref[jj + 1] = sum; }
+        if (jj == 0) pref[0] = 0;
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(TB) void k_grad_attn(int N, int h, int L, const float *__restrict__ go, long ldg, const int *__restrict__ offsets,
                                                   const int *__restrict__ index1, const float *__restrict__ v, long ldv, const float *__restrict__ table,
-                                                  const int *__restrict__ rel, float *__restrict__ grad_attn) {
+                                                  const int *__restrict__ rel, float *__restrict__ grad_attn, const int *__restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float *tb = sm, *gr = tb + 3 * L * D, *P = gr + QF * D;     // tb [3][L][16] | gr [QF][16] | P [QF][3 L]
-    int *offs = reinterpret_cast<int *>(P + QF * 3 * L);
+    int *offs = reinterpret_cast<int *>(P + QF * 3 * L), *qst = offs + QF + 1, *qid = qst + QF;
     const int hh = blockIdx.y, q0 = blockIdx.x * QF, nq = min(QF, N - q0), W = 3 * L;
-    for (int jj = threadIdx.x; jj <= nq; jj += TB) offs[jj] = offsets[q0 + jj];
+    chunk_rows<QF>(offs, qst, qid, offsets, order, q0, nq);
     stage_table<1>(tb, table, L, h, hh);
-    for (int e = threadIdx.x; e < QF * D; e += TB) gr[e] = e < nq * D ? go[(size_t)(q0 + e / D) * ldg + (size_t)hh * D + e % D] : 0.f;
+    for (int e = threadIdx.x; e < QF * D; e += TB) gr[e] = e < nq * D ? go[(size_t)qid[e / D] * ldg + (size_t)hh * D + e % D] : 0.f;
     __syncthreads();
     for (int e = threadIdx.x; e < nq * W; e += TB) {
         const int ql = e / W, x = e - ql * W;   // x = a * L + r
@@ -326,10 +347,11 @@ __global__ __launch_bounds__(TB) void k_grad_attn(int N, int h, int L, const flo
         P[e] = acc;
     }
     __syncthreads();
-    const int e0 = offs[0], e1 = offs[nq];
+    const int total = offs[nq];
     int ql = 0;
-    for (int m = e0 + threadIdx.x; m < e1; m += TB) {           // (a lane's edges ascend: the query is found by stepping on)
-        while (offs[ql + 1] <= m) ++ql;
+    for (int t = threadIdx.x; t < total; t += TB) {             // (a lane's virtual edges ascend: the query is found by stepping on)
+        while (offs[ql + 1] <= t) ++ql;
+        const int m = qst[ql] + (t - offs[ql]);
         const int r1 = rel[(size_t)m * 3], r2 = rel[(size_t)m * 3 + 1], r3 = rel[(size_t)m * 3 + 2];
         const float4 *vr = reinterpret_cast<const float4 *>(v + (size_t)index1[m] * ldv + (size_t)hh * D);
         const float4 *g4 = reinterpret_cast<const float4 *>(gr + ql * D);
@@ -349,20 +371,21 @@ constexpr int QL = 64;
 __global__ __launch_bounds__(TB) void k_logits_fwd(int N, int h, int L, const float *__restrict__ q, const float *__restrict__ k, long ld, float qscale,
                                                    const int *__restrict__ offsets, const int *__restrict__ index1,
                                                    const float *__restrict__ table_q, const float *__restrict__ table_k,
-                                                   const int *__restrict__ rel, float *__restrict__ out) {
+                                                   const int *__restrict__ rel, float *__restrict__ out, const int *__restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float *tq = sm, *tk = tq + 3 * L * D, *qs = tk + 3 * L * D;     // [3][L][16] x 2 | qs [QL][16]
-    int *offs = reinterpret_cast<int *>(qs + QL * D);
+    int *offs = reinterpret_cast<int *>(qs + QL * D), *qst = offs + QL + 1, *qid = qst + QL;
     const int hh = blockIdx.y, q0 = blockIdx.x * QL, nq = min(QL, N - q0);
-    for (int jj = threadIdx.x; jj <= nq; jj += TB) offs[jj] = offsets[q0 + jj];
+    chunk_rows<QL>(offs, qst, qid, offsets, order, q0, nq);
     stage_table<1>(tq, table_q, L, h, hh);
     stage_table<1>(tk, table_k, L, h, hh);
-    for (int e = threadIdx.x; e < QL * D; e += TB) qs[e] = e < nq * D ? q[(size_t)(q0 + e / D) * ld + (size_t)hh * D + e % D] * qscale : 0.f;
+    for (int e = threadIdx.x; e < QL * D; e += TB) qs[e] = e < nq * D ? q[(size_t)qid[e / D] * ld + (size_t)hh * D + e % D] * qscale : 0.f;
     __syncthreads();
-    const int e0 = offs[0], e1 = offs[nq];
+    const int total = offs[nq];
     int ql = 0;
-    for (int m = e0 + threadIdx.x; m < e1; m += TB) {
-        while (offs[ql + 1] <= m) ++ql;
+    for (int t = threadIdx.x; t < total; t += TB) {
+        while (offs[ql + 1] <= t) ++ql;
+        const int m = qst[ql] + (t - offs[ql]);
         const int r1 = rel[(size_t)m * 3], r2 = rel[(size_t)m * 3 + 1], r3 = rel[(size_t)m * 3 + 2];
         const float4 *kr = reinterpret_cast<const float4 *>(k + (size_t)index1[m] * ld + (size_t)hh * D);
         const float4 *q4 = reinterpret_cast<const float4 *>(qs + ql * D);
@@ -447,26 +470,41 @@ extern "C" int pdf_wa_segment_rows_ordered(int N, int h, int d, int L, const int
 }
 
 // grad_attn (M, h), every element written:  < grad_out[q(m), hh, :], v[index1[m], hh, :] + T(m, hh, :) >
+extern "C" int pdf_wa_grad_attn_ordered(int N, int M, int h, int d, int L, const float *grad_out, long ldg, const int *offsets, const int *index1,
+                                        const float *v, long ldv, const float *table, const int *rel, float *grad_attn, const int *order, void *stream);
 extern "C" int pdf_wa_grad_attn(int N, int M, int h, int d, int L, const float *grad_out, long ldg, const int *offsets, const int *index1,
                                 const float *v, long ldv, const float *table, const int *rel, float *grad_attn, void *stream) {
+    return pdf_wa_grad_attn_ordered(N, M, h, d, L, grad_out, ldg, offsets, index1, v, ldv, table, rel, grad_attn, nullptr, stream);
+}
+// (order: the queries a workgroup takes, as for pdf_wa_segment_rows_ordered; every element of grad_attn is the same dot product)
+extern "C" int pdf_wa_grad_attn_ordered(int N, int M, int h, int d, int L, const float *grad_out, long ldg, const int *offsets, const int *index1,
+                                        const float *v, long ldv, const float *table, const int *rel, float *grad_attn, const int *order, void *stream) {
     if (N < 0 || M < 0 || h < 1 || d < 1 || L < 1 || !grad_out || !offsets || !index1 || !v || !table || !rel || !grad_attn) return PDF_ERR_BAD_ARG;
     if (N == 0 || M == 0) return PDF_OK;
     if (d != wb::D || L > wb::LMAX || (reinterpret_cast<uintptr_t>(v) & 15) || (ldv & 3) || ldv < (long)h * d || ldg < (long)h * d) return PDF_ERR_UNSUPPORTED;
-    const size_t lds = sizeof(float) * (size_t)(3 * L * wb::D + wb::QF * wb::D + wb::QF * 3 * L) + sizeof(int) * (wb::QF + 1);
+    const size_t lds = sizeof(float) * (size_t)(3 * L * wb::D + wb::QF * wb::D + wb::QF * 3 * L) + sizeof(int) * (3 * wb::QF + 1);
     wb::k_grad_attn<<<dim3((unsigned)((N + wb::QF - 1) / wb::QF), (unsigned)h), wb::TB, lds, static_cast<hipStream_t>(stream)>>>(
-        N, h, L, grad_out, ldg, offsets, index1, v, ldv, table, rel, grad_attn);
+        N, h, L, grad_out, ldg, offsets, index1, v, ldv, table, rel, grad_attn, order);
     return pdf_launch_status();
 }
 
 // logits (M, h) = attention_step1_v2(q, k) + dot_prod_with_idx_v3(q, k, table_q, table_k), every element written
+extern "C" int pdf_wa_logits_forward_ordered(int N, int M, int h, int d, int L, const float *q, const float *k, long ld, float qscale, const int *offsets,
+                                             const int *index1, const float *table_q, const float *table_k, const int *rel, float *out,
+                                             const int *order, void *stream);
 extern "C" int pdf_wa_logits_forward(int N, int M, int h, int d, int L, const float *q, const float *k, long ld, float qscale, const int *offsets,
                                      const int *index1, const float *table_q, const float *table_k, const int *rel, float *out, void *stream) {
+    return pdf_wa_logits_forward_ordered(N, M, h, d, L, q, k, ld, qscale, offsets, index1, table_q, table_k, rel, out, nullptr, stream);
+}
+extern "C" int pdf_wa_logits_forward_ordered(int N, int M, int h, int d, int L, const float *q, const float *k, long ld, float qscale, const int *offsets,
+                                             const int *index1, const float *table_q, const float *table_k, const int *rel, float *out,
+                                             const int *order, void *stream) {
     if (N < 0 || M < 0 || h < 1 || d < 1 || L < 1 || !q || !k || !offsets || !index1 || !table_q || !table_k || !rel || !out) return PDF_ERR_BAD_ARG;
     if (N == 0 || M == 0) return PDF_OK;
     if (d != wb::D || L > wb::LMAX || (reinterpret_cast<uintptr_t>(k) & 15) || (ld & 3) || ld < (long)h * d) return PDF_ERR_UNSUPPORTED;
-    const size_t lds = sizeof(float) * (size_t)(6 * L * wb::D + wb::QL * wb::D) + sizeof(int) * (wb::QL + 1);
+    const size_t lds = sizeof(float) * (size_t)(6 * L * wb::D + wb::QL * wb::D) + sizeof(int) * (3 * wb::QL + 1);
     wb::k_logits_fwd<<<dim3((unsigned)((N + wb::QL - 1) / wb::QL), (unsigned)h), wb::TB, lds, static_cast<hipStream_t>(stream)>>>(
-        N, h, L, q, k, ld, qscale, offsets, index1, table_q, table_k, rel, out);
+        N, h, L, q, k, ld, qscale, offsets, index1, table_q, table_k, rel, out, order);
     return pdf_launch_status();
 }
 

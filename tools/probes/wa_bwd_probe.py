@@ -56,6 +56,8 @@ for level, layer in bb.layers_by_level().items():
         ("rows grad_v (CSC, edge ids)", lambda: be._wa_rows(n, h, d, 0, key_off, key_edge, key_q, None, attn, go, None, gqkv[:, 2 * c:], ldo=3 * c)),
         ("rows grad_k (CSC, edge ids)", lambda: be._wa_rows(n, h, d, L, key_off, key_edge, key_q, key_rel, gsm, q, tk, gqkv[:, c:2 * c], ldx=3 * c, xscale=0.25, ldo=3 * c)),
         ("table gtk (key order, edge ids)", lambda: be._wa_table_grad(n, h, d, L, key_off, key_edge, key_rel, gsm, k, qkv, ldx=3 * c)),
+        ("logits_fwd, window order", lambda: be._call("wa_logits_forward_ordered", n, m, h, d, L, q, k, 3 * c, 1.0, offsets, index1, tq, tk, rel, ga, worder)),
+        ("grad_attn, window order", lambda: be._call("wa_grad_attn_ordered", n, m, h, d, L, go, c, offsets, index1, v, 3 * c, tv, rel, ga, worder)),
         ("rows fwd out, window order", lambda: be._wa_rows(n, h, d, L, offsets, None, index1, rel, attn, v, tv, out, ldx=3 * c, order=worder)),
         ("rows grad_v (CSC), window order", lambda: be._wa_rows(n, h, d, 0, key_off, None, key_q, None, attn_key, go, None, gqkv[:, 2 * c:], ldo=3 * c, order=worder)),
         ("rows grad_k (CSC), window order", lambda: be._wa_rows(n, h, d, L, key_off, None, key_q, key_rel, g_key, q, tk, gqkv[:, c:2 * c], ldx=3 * c, xscale=0.25, ldo=3 * c, order=worder)),
