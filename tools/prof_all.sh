@@ -7,4 +7,4 @@ cd $R
 bash tools/final_check.sh $TAG
 bash tools/prof_sq.sh $TAG
 DB=$(find /tmp/p/kt -name "*.db" | head -1)
-python3 tools/rocpd_sq.py --json gpurun_out/${TAG}_sq.json $DB 18 gpurun_out/${TAG}_sq1.txt gpurun_out/${TAG}_sq2.txt gpurun_out/${TAG}_sq3.txt gpurun_out/${TAG}_sq4.txt > gpurun_out/${TAG}_sq_json.log 2>&1
+python3 tools/rocpd_sq.py --json gpurun_out/${TAG}_sq.json $DB 12 gpurun_out/${TAG}_sq1.txt gpurun_out/${TAG}_sq2.txt gpurun_out/${TAG}_sq3.txt gpurun_out/${TAG}_sq4.txt > gpurun_out/${TAG}_sq_json.log 2>&1

@@ -4,7 +4,7 @@
     python tools/rocpd_sq.py results.db             -> one line per (kernel, counter): calls, average per launch, average duration
     python tools/rocpd_sq.py --merge a.txt b.txt .. -> one block per kernel with all counters and the derived fractions
     python tools/rocpd_sq.py --json out.json kt.db steps a.txt b.txt ..  -> profiles/<tag>_sq.json for bench.py's `mfma` entry: per kernel
-        the un-profiled average duration (kernel trace kt.db over `steps` steps), launches per step, the limiter fractions and the
+        the un-profiled average duration and launches per step over the last `steps` optimizer steps of the kernel trace kt.db, the limiter fractions and the
         matrix-pipe busy share, + the per-step totals of the dense-product kernel families (rl2:: rl:: flm:: td::)
 
 Derived (guide: WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES, all in quad-cycles; MFMA_BUSY in cycles):
@@ -121,15 +121,23 @@ def to_json(out, kt_db, steps, files):
     import bench
 
     tab = load(files)
+    rows = sorted(sqlite3.connect(kt_db).execute("select name, start, end from kernels").fetchall(), key=lambda r: r[1])
+    # per-step figures over a steady-state window delimited by the optimizer kernel (k_sgd: one launch per training step, its last
+    # kernel), as tools/rocpd_queues.py does: the last `steps` optimizer steps of the trace (steps <= 0: 12).  Counting launches over the
+    # whole trace and dividing by the optimizer launches over-counts (warm-up, capture and measuring passes run no optimizer).
+    ends = [r[2] for r in rows if "k_sgd" in str(r[0])]
+    w = int(steps) if steps > 0 else 12
+    if len(ends) > w:
+        t0, t1, steps = ends[-w - 1], ends[-1], float(w)
+    else:
+        t0, t1, steps = rows[0][1], rows[-1][2], float(max(len(ends), 1))
+        print(f"note: {len(ends)} optimizer launches in the trace: whole trace divided by {steps:g}", file=sys.stderr)
     dur = {}
-    for name, d in sqlite3.connect(kt_db).execute("select name, (end - start) from kernels"):
+    for name, st, en in rows:
+        if st < t0 or en > t1:
+            continue
         a = dur.setdefault(short(name), [0, 0])
-        a[0] += 1; a[1] += d
-    sgd = sum(v[0] for k, v in dur.items() if "k_sgd" in k)
-    if steps <= 0:   # 0: count the optimizer launches (one per TRAINING step -- bench.py's look-ahead sweep steps run none: trace with --no-latency-sweep)
-        steps = float(sgd)
-    elif sgd and sgd != steps:
-        print(f"note: {sgd} optimizer launches in the trace, {steps:g} steps given: using the given count", file=sys.stderr)
+        a[0] += 1; a[1] += en - st
     kernels, fam = {}, {}
     for k, e in tab.items():
         c = e["c"]
