@@ -367,19 +367,24 @@ __global__ __launch_bounds__(TB) void k_grad_attn(int N, int h, int L, const flo
 // 300-321): logit[m, hh] = sum_i q[q(m), hh, i] * (k[j, hh, i] + T_q(m, hh, i)) + k[j, hh, i] * T_k(m, hh, i),  j = index1[m].
 // One gather of the key row instead of two and no (M, h) addition.  grid = (ceil(N / QL), h); lane = edge; the head's two table slabs
 // and the chunk's query rows sit in LDS.
+// TK = false: the same pass without the key-side table term -- grad_attn[m, hh] = <grad_out[q(m), hh, :], v[j, hh, :] + T_v(m, hh, :)>
+// (attention_step2_with_rel_pos_value_v2 backward, relative_pos_encoding_cuda_kernel_v2.cu:441-470) is this expression with q := grad_out,
+// k := v, table_q := table_v.  (Rounds 5-6 factored the table term through per-query projections P_q[a][r]: 3 L x 16 multiply-adds per
+// query against 3 x 16 per edge -- more work below 64 edges per row, and rows hold ~31: 298 -> see profiles/r06_wa_table_ab.txt.)
 constexpr int QL = 64;
-__global__ __launch_bounds__(TB) void k_logits_fwd(int N, int h, int L, const float *__restrict__ q, const float *__restrict__ k, long ld, float qscale,
+template <bool TK>
+__global__ __launch_bounds__(TB) void k_logits_fwd(int N, int h, int L, const float *__restrict__ q, long ldq, const float *__restrict__ k, long ld, float qscale,
                                                    const int *__restrict__ offsets, const int *__restrict__ index1,
                                                    const float *__restrict__ table_q, const float *__restrict__ table_k,
                                                    const int *__restrict__ rel, float *__restrict__ out, const int *__restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float *tq = sm, *tk = tq + 3 * L * D, *qs = tk + 3 * L * D;     // [3][L][16] x 2 | qs [QL][16]
+    float *tq = sm, *tk = tq + 3 * L * D, *qs = tk + (TK ? 3 * L * D : 0);     // [3][L][16] (x 2 with the key-side table) | qs [QL][16]
     int *offs = reinterpret_cast<int *>(qs + QL * D), *qst = offs + QL + 1, *qid = qst + QL;
     const int hh = blockIdx.y, q0 = blockIdx.x * QL, nq = min(QL, N - q0);
     chunk_rows<QL>(offs, qst, qid, offsets, order, q0, nq);
     stage_table<1>(tq, table_q, L, h, hh);
-    stage_table<1>(tk, table_k, L, h, hh);
-    for (int e = threadIdx.x; e < QL * D; e += TB) qs[e] = e < nq * D ? q[(size_t)qid[e / D] * ld + (size_t)hh * D + e % D] * qscale : 0.f;
+    if (TK) stage_table<1>(tk, table_k, L, h, hh);
+    for (int e = threadIdx.x; e < QL * D; e += TB) qs[e] = e < nq * D ? q[(size_t)qid[e / D] * ldq + (size_t)hh * D + e % D] * qscale : 0.f;
     __syncthreads();
     const int total = offs[nq];
     int ql = 0;
@@ -397,11 +402,19 @@ __global__ __launch_bounds__(TB) void k_logits_fwd(int N, int h, int L, const fl
 #pragma unroll
         for (int c4 = 0; c4 < D / 4; ++c4) {
             const float4 kv = kr[c4], qv = q4[c4];
-            const float4 tqv = add4(add4(a0[c4], a1[c4]), a2[c4]), tkv = add4(add4(b0[c4], b1[c4]), b2[c4]);
-            sum += qv.x * (kv.x + tqv.x) + kv.x * tkv.x;
-            sum += qv.y * (kv.y + tqv.y) + kv.y * tkv.y;
-            sum += qv.z * (kv.z + tqv.z) + kv.z * tkv.z;
-            sum += qv.w * (kv.w + tqv.w) + kv.w * tkv.w;
+            const float4 tqv = add4(add4(a0[c4], a1[c4]), a2[c4]);
+            if (TK) {
+                const float4 tkv = add4(add4(b0[c4], b1[c4]), b2[c4]);
+                sum += qv.x * (kv.x + tqv.x) + kv.x * tkv.x;
+                sum += qv.y * (kv.y + tqv.y) + kv.y * tkv.y;
+                sum += qv.z * (kv.z + tqv.z) + kv.z * tkv.z;
+                sum += qv.w * (kv.w + tqv.w) + kv.w * tkv.w;
+            } else {
+                sum += qv.x * (kv.x + tqv.x);
+                sum += qv.y * (kv.y + tqv.y);
+                sum += qv.z * (kv.z + tqv.z);
+                sum += qv.w * (kv.w + tqv.w);
+            }
         }
         out[(size_t)m * h + hh] = sum;
     }
@@ -482,6 +495,14 @@ extern "C" int pdf_wa_grad_attn_ordered(int N, int M, int h, int d, int L, const
     if (N < 0 || M < 0 || h < 1 || d < 1 || L < 1 || !grad_out || !offsets || !index1 || !v || !table || !rel || !grad_attn) return PDF_ERR_BAD_ARG;
     if (N == 0 || M == 0) return PDF_OK;
     if (d != wb::D || L > wb::LMAX || (reinterpret_cast<uintptr_t>(v) & 15) || (ldv & 3) || ldv < (long)h * d || ldg < (long)h * d) return PDF_ERR_UNSUPPORTED;
+    static const bool factored = [] { const char *e = getenv("PDFOPS_WA_GRAD_ATTN"); return e && e[0] == 'f'; }();   // (A/B: the round-5 form)
+    if (!factored) {
+        if (reinterpret_cast<uintptr_t>(v) & 15) return PDF_ERR_UNSUPPORTED;
+        const size_t lds1 = sizeof(float) * (size_t)(3 * L * wb::D + wb::QL * wb::D) + sizeof(int) * (3 * wb::QL + 1);
+        wb::k_logits_fwd<false><<<dim3((unsigned)((N + wb::QL - 1) / wb::QL), (unsigned)h), wb::TB, lds1, static_cast<hipStream_t>(stream)>>>(
+            N, h, L, grad_out, ldg, v, ldv, 1.f, offsets, index1, table, nullptr, rel, grad_attn, order);
+        return pdf_launch_status();
+    }
     const size_t lds = sizeof(float) * (size_t)(3 * L * wb::D + wb::QF * wb::D + wb::QF * 3 * L) + sizeof(int) * (3 * wb::QF + 1);
     wb::k_grad_attn<<<dim3((unsigned)((N + wb::QF - 1) / wb::QF), (unsigned)h), wb::TB, lds, static_cast<hipStream_t>(stream)>>>(
         N, h, L, grad_out, ldg, offsets, index1, v, ldv, table, rel, grad_attn, order);
@@ -503,8 +524,8 @@ extern "C" int pdf_wa_logits_forward_ordered(int N, int M, int h, int d, int L, 
     if (N == 0 || M == 0) return PDF_OK;
     if (d != wb::D || L > wb::LMAX || (reinterpret_cast<uintptr_t>(k) & 15) || (ld & 3) || ld < (long)h * d) return PDF_ERR_UNSUPPORTED;
     const size_t lds = sizeof(float) * (size_t)(6 * L * wb::D + wb::QL * wb::D) + sizeof(int) * (3 * wb::QL + 1);
-    wb::k_logits_fwd<<<dim3((unsigned)((N + wb::QL - 1) / wb::QL), (unsigned)h), wb::TB, lds, static_cast<hipStream_t>(stream)>>>(
-        N, h, L, q, k, ld, qscale, offsets, index1, table_q, table_k, rel, out, order);
+    wb::k_logits_fwd<true><<<dim3((unsigned)((N + wb::QL - 1) / wb::QL), (unsigned)h), wb::TB, lds, static_cast<hipStream_t>(stream)>>>(
+        N, h, L, q, ld, k, ld, qscale, offsets, index1, table_q, table_k, rel, out, order);
     return pdf_launch_status();
 }
 
