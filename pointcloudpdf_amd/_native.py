@@ -222,6 +222,15 @@ def window_csc(index1, offsets, rel_idx=None, n_keys=None):
         index0 = torch.repeat_interleave(torch.arange(n, device=index1.device, dtype=torch.int32), counts, output_size=m)
         cache = {"key": (index1.data_ptr(), index1._version, offsets.data_ptr(), offsets._version),
                  "base": (key_off, perm.to(torch.int32), index0[perm].contiguous()), "perm": perm, "rel": {}}
+        # Visiting order of the KEY-side row passes: the rows by key are long (a down-sampled point is a key of every query of its coarse
+        # window: ~10x the entries) or short; owners that share a workgroup walk their rows in lockstep, so equal lengths belong together:
+        # longest first, window by window inside a length (the window order of the table when the edge builder left one).  Level 0 of
+        # config 5: grad_k 305 -> 152 us, grad_v 106 -> 59 us per call (tools/probes/wa_bwd_probe.py).
+        if nk == n:
+            wo = window_order_of(offsets)
+            base = wo.long() if wo is not None else torch.arange(nk, device=index1.device)
+            klen = (key_off[1:] - key_off[:-1]).index_select(0, base)
+            cache["order"] = base.index_select(0, torch.sort(klen, descending=True, stable=True)[1]).to(torch.int32)
         setattr(index1, _CSC, cache)
     if rel_idx is None:
         return cache["base"]
@@ -229,6 +238,12 @@ def window_csc(index1, offsets, rel_idx=None, n_keys=None):
     if rk not in cache["rel"]:
         cache["rel"] = {rk: rel_idx[cache["perm"]].contiguous()}   # (one table per edge list in practice; a new one replaces the old)
     return cache["base"] + (cache["rel"][rk],)
+
+
+def window_key_order(index1):
+    """The key-side visiting order ``window_csc`` cached on ``index1`` (longest rows first, window by window), or None."""
+    cache = getattr(index1, _CSC, None)
+    return cache.get("order") if cache is not None and cache["key"][:2] == (index1.data_ptr(), index1._version) else None
 
 
 _ORD = "_pdf_order"
@@ -1259,15 +1274,16 @@ class HipBackend(CBackend):
         key_off, key_edge, key_q, key_rel = window_csc(index1, offsets, rel_idx, n_keys=n)
         gqkv = torch.empty_like(qkv)
         ga = torch.empty((m, h), dtype=torch.float32, device=qkv.device)
-        order = self._wa_order(offsets)   # (window by window: measured on the query-side passes and the table-free key-side pass, not on grad_k)
+        order = self._wa_order(offsets)   # (query side: window by window)
         self._call("wa_grad_attn_ordered", n, m, h, d, L, go, c, offsets, index1, v, 3 * c, table_v, rel_idx, ga, order)
         attn_key = self._wa_permute(attn, key_edge)
-        self._wa_rows(n, h, d, 0, key_off, None, key_q, None, attn_key, go, None, gqkv[:, 2 * c:], ldo=3 * c, order=order)          # grad_v
+        korder = window_key_order(index1) if self.wa_window_order else None   # (key side: longest rows first, window by window)
+        self._wa_rows(n, h, d, 0, key_off, None, key_q, None, attn_key, go, None, gqkv[:, 2 * c:], ldo=3 * c, order=korder)          # grad_v
         gtv = self._wa_table_grad(n, h, d, L, offsets, None, rel_idx, attn, go, qkv)
         g = self.segment_softmax_backward(attn, ga, offsets)
         g_key = self._wa_permute(g, key_edge)
         self._wa_rows(n, h, d, L, offsets, None, index1, rel_idx, g, k, table_q, gqkv[:, :c], ldx=3 * c, ldo=3 * c, oscale=scale, order=order)      # grad_q
-        self._wa_rows(n, h, d, L, key_off, None, key_q, key_rel, g_key, q, table_k, gqkv[:, c:2 * c], ldx=3 * c, xscale=scale, ldo=3 * c)   # grad_k
+        self._wa_rows(n, h, d, L, key_off, None, key_q, key_rel, g_key, q, table_k, gqkv[:, c:2 * c], ldx=3 * c, xscale=scale, ldo=3 * c, order=korder)   # grad_k
         gtq = self._wa_table_grad(n, h, d, L, offsets, None, rel_idx, g, q, qkv, ldx=3 * c, xscale=scale)
         gtk = self._wa_table_grad(n, h, d, L, key_off, None, key_rel, g_key, k, qkv, ldx=3 * c)
         return gqkv, gtq, gtk, gtv

@@ -486,7 +486,7 @@ class StratifiedGeometry:
                     out.append(order)
                 csc = getattr(tab[1], _native._CSC, None)   # the key-grouped edge list cached on index_1 (_native.window_csc)
                 if csc is not None:
-                    out += list(csc["base"]) + [csc["perm"]] + list(csc["rel"].values())
+                    out += list(csc["base"]) + [csc["perm"]] + list(csc["rel"].values()) + ([csc["order"]] if "order" in csc else [])
         for v in self.neighbors.values():
             for t in (v if isinstance(v, tuple) else (v,)):
                 if torch.is_tensor(t):

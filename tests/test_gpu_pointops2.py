@@ -537,3 +537,9 @@ def test_segment_rows_in_any_owner_order_are_the_same_rows(p2):
     be._wa_rows(n, h, d, 0, key_off, None, key_q, None, wk_, X, None, a)
     be._wa_rows(n, h, d, 0, key_off, None, key_q, None, wk_, X, None, c, order=order)
     assert torch.equal(a, c)
+    # the key side's own order (window_csc): a permutation, longest rows first -- and the same rows again
+    korder = _native.window_key_order(i1)
+    klen = (key_off[1:] - key_off[:-1])[korder.long()]
+    assert korder.dtype == torch.int32 and torch.equal(korder.long().sort().values, torch.arange(n, device="cuda")) and bool((klen[1:] <= klen[:-1]).all())
+    be._wa_rows(n, h, d, 0, key_off, None, key_q, None, wk_, X, None, c, order=korder)
+    assert torch.equal(a, c)

@@ -47,7 +47,12 @@ for level, layer in bb.layers_by_level().items():
     attn_key = attn.index_select(0, key_edge)
     gsm = be.segment_softmax_backward(attn, torch.randn(m, h, device=dev, generator=g), offsets)
     g_key = gsm.index_select(0, key_edge)
+    klen = (key_off[1:] - key_off[:-1])[worder.long()]                      # rows of the key side: long (FPS keys: a whole coarse window refers to them) and short
+    lorder = worder[torch.sort(-klen, stable=True)[1]].contiguous()         # longest first, window order inside equal lengths
+    qlen = (offsets[1:] - offsets[:-1])[worder.long()]
+    qorder = worder[torch.sort(-qlen, stable=True)[1]].contiguous()
     rows = [
+        ("rows fwd out, length then window order", lambda: be._wa_rows(n, h, d, L, offsets, None, index1, rel, attn, v, tv, out, ldx=3 * c, order=qorder)),
         ("logits_fwd", lambda: be._call("wa_logits_forward", n, m, h, d, L, q, k, 3 * c, 1.0, offsets, index1, tq, tk, rel, ga)),
         ("rows fwd out (CSR, rows+table)", lambda: be._wa_rows(n, h, d, L, offsets, None, index1, rel, attn, v, tv, out, ldx=3 * c)),
         ("grad_attn", lambda: be._call("wa_grad_attn", n, m, h, d, L, go, c, offsets, index1, v, 3 * c, tv, rel, ga)),
@@ -61,6 +66,8 @@ for level, layer in bb.layers_by_level().items():
         ("rows fwd out, window order", lambda: be._wa_rows(n, h, d, L, offsets, None, index1, rel, attn, v, tv, out, ldx=3 * c, order=worder)),
         ("rows grad_v (CSC), window order", lambda: be._wa_rows(n, h, d, 0, key_off, None, key_q, None, attn_key, go, None, gqkv[:, 2 * c:], ldo=3 * c, order=worder)),
         ("rows grad_k (CSC), window order", lambda: be._wa_rows(n, h, d, L, key_off, None, key_q, key_rel, g_key, q, tk, gqkv[:, c:2 * c], ldx=3 * c, xscale=0.25, ldo=3 * c, order=worder)),
+        ("rows grad_k (CSC), length then window order", lambda: be._wa_rows(n, h, d, L, key_off, None, key_q, key_rel, g_key, q, tk, gqkv[:, c:2 * c], ldx=3 * c, xscale=0.25, ldo=3 * c, order=lorder)),
+        ("rows grad_v (CSC), length then window order", lambda: be._wa_rows(n, h, d, 0, key_off, None, key_q, None, attn_key, go, None, gqkv[:, 2 * c:], ldo=3 * c, order=lorder)),
         ("table gtv (CSR)", lambda: be._wa_table_grad(n, h, d, L, offsets, None, rel, attn, go, qkv)),
         ("softmax_bwd", lambda: be.segment_softmax_backward(attn, ga, offsets)),
         ("rows grad_q (CSR, rows+table)", lambda: be._wa_rows(n, h, d, L, offsets, None, index1, rel, gsm, k, tq, gqkv[:, :c], ldx=3 * c, ldo=3 * c, oscale=0.25)),
@@ -71,7 +78,7 @@ for level, layer in bb.layers_by_level().items():
     print(f"level {level}: N={n} M={m} C={c} h={h} L={L} n_max={n_max} mean row {m / n:.1f}  blocks={layer.depth}")
     for name, fn in rows:
         us = t(fn)
-        if name not in ("logits_fwd", "rows fwd out (CSR, rows+table)") and "edge ids" not in name and "window order" not in name:
+        if name not in ("logits_fwd", "rows fwd out (CSR, rows+table)") and "edge ids" not in name and "window order" not in name and "length" not in name:
             total += us * layer.depth
         print(f"    {name:34s} {us:9.1f} us", flush=True)
 print(f"backward pieces x blocks per level: {total / 1e3:.2f} ms per step")
